@@ -1,0 +1,171 @@
+/*
+ * biokanga_amd.h - C ABI of the MI355X-native `biokanga align` hot path (libbiokanga_amd.so).
+ *
+ * Drop-in boundary.  The reference (csiro-crop-informatics/biokanga v4.4.2) has no FFI of its own;
+ * the seam is the pair of call sites SURVEY.md §8(b) names:
+ *   - per read : CSfxArrayV3::AlignReads            libbiokanga/SfxArrayV2.h:585-606, called from
+ *                CAligner::ProcCoredApprox          biokanga/Aligner.cpp:9220-9237
+ *   - per batch: CAligner::LocateCoredApprox        biokanga/Aligner.h:930-931 (Aligner.cpp:8651)
+ * bk_align_batch() is the batch form of the first placed where the second is: it consumes the
+ * reads exactly as CAligner holds them (1 byte/base: bits 0-2 base, bit 3 soft-mask, bits 4-7
+ * quality, biokanga/Aligner.cpp:9038-9055) and fills, per read, the fields ProcCoredApprox writes
+ * into tsReadHit (NAR, NumHits, LowHitInstances, LowMMCnt, NxtLowMMCnt, HitLoci.Hit.Seg[0]).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns 0 (eBSFSuccess) or a
+ * negative teBSFrsltCodes value (libbiokanga/ErrorCodes.h:15-95); HIP/RCCL failures map to
+ * BK_ERR_INTERNAL.  The library never calls exit().  There is NO CPU fallback: without a usable
+ * HIP device every compute entry point fails with BK_ERR_NODEVICE.
+ */
+#ifndef BIOKANGA_AMD_H
+#define BIOKANGA_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* teBSFrsltCodes subset (libbiokanga/ErrorCodes.h) */
+#define BK_OK               0
+#define BK_ERR_INTERNAL    (-1)    /* eBSFerrInternal  */
+#define BK_ERR_PARAMS      (-100)  /* eBSFerrParams    */
+#define BK_ERR_MEM         (-95)   /* eBSFerrMem       */
+#define BK_ERR_NOTBIOSEQ   (-94)   /* eBSFerrNotBioseq */
+#define BK_ERR_OPNFILE     (-90)   /* eBSFerrOpnFile   */
+#define BK_ERR_CREATEFILE  (-89)   /* eBSFerrCreateFile*/
+#define BK_ERR_FILEVER     (-86)   /* eBSFerrFileVer   */
+#define BK_ERR_FILEACCESS  (-85)   /* eBSFerrFileAccess*/
+#define BK_ERR_NODEVICE    (-2)    /* ours: no HIP device / kernels unavailable */
+
+/* tHRslt, libbiokanga/SfxArrayV2.h:68-74 */
+enum { BK_HR_NONE = 0, BK_HR_HITS = 1, BK_HR_MMDELTA = 2, BK_HR_HITINSTS = 3, BK_HR_RMMDELTA = 4 };
+/* teNAR, biokanga/Aligner.h:106-128 (values produced by the hot path) */
+enum { BK_NAR_UNALIGNED = 0, BK_NAR_ACCEPTED = 1, BK_NAR_NS = 2, BK_NAR_NOHIT = 3, BK_NAR_MMDELTA = 4,
+       BK_NAR_MULTIALIGN = 5 };
+
+/* alignment parameters = the `biokanga align` options that reach the hot path
+ * (biokanga/kanga.cpp:194-294) */
+typedef struct bk_align_params {
+    int32_t max_subs;       /* -s  max substitutions per 100 bp (reference default 10)         */
+    int32_t min_edit_dist;  /* -e  minimum Hamming delta to the next best hit, 1 or 2           */
+    int32_t align_strand;   /* -Q  0 both strands, 1 sense only, 2 antisense only               */
+    int32_t pmode;          /* -m  0 default, 1 more sensitive, 2 ultra sensitive, 3 less sens. */
+    int32_t max_ns;         /* -n  max indeterminate bases per 100 bp (default 1)               */
+    int32_t max_ml;         /* MaxMLmatches; 1 (the default -r0 mode) is the supported value    */
+    int32_t reserved[2];
+} bk_align_params;
+
+/* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and
+ * tsHitLoci.Seg[0] (SfxArrayV2.h:219-240).  20 bytes, little endian. */
+typedef struct bk_hit {
+    uint32_t chrom_id;           /* Seg[0].ChromID = tsSfxEntry.EntryID (1..n), 0 if none        */
+    uint32_t match_loci;         /* Seg[0].MatchLoci, 0-based within the entry                   */
+    uint16_t match_len;          /* Seg[0].MatchLen                                              */
+    int16_t  low_hit_instances;  /* tsReadHit.LowHitInstances                                    */
+    uint8_t  rslt;               /* tHRslt returned by AlignReads                                */
+    uint8_t  nar;                /* teNAR                                                        */
+    uint8_t  strand;             /* '+', '-' or '?'                                              */
+    int8_t   low_mm;             /* tsReadHit.LowMMCnt                                           */
+    int8_t   nxt_low_mm;         /* tsReadHit.NxtLowMMCnt                                        */
+    uint8_t  num_hits;           /* tsReadHit.NumHits                                            */
+    uint8_t  mismatches;         /* Seg[0].Mismatches (Hamming score of the accepted hit)        */
+    uint8_t  flags;              /* reserved                                                     */
+} bk_hit;
+
+/* counters behind the "algorithmic bytes" figure of SURVEY.md §8(d); all are counts of what the
+ * REFERENCE algorithm does for the same reads (independent of our data layout) */
+typedef struct bk_counters {
+    uint64_t n_reads;
+    uint64_t n_search;      /* LocateFirstExact calls                                  */
+    uint64_t n_cand;        /* candidates Hamming-extended (new, in-bounds targets)    */
+    uint64_t n_lcm_calls;   /* LocateCoreMultiples invocations                         */
+    uint64_t n_heavy;       /* (ours) LocateCoreMultiples calls routed to the wave-per-read kernel */
+    uint64_t reserved[3];
+} bk_counters;
+
+/* timing of the device work of the last bk_align_batch*() call, measured with HIP events on the
+ * stream the kernels were launched on */
+typedef struct bk_timing {
+    float    ms_total;          /* first kernel start -> last kernel end                       */
+    float    ms_search;         /* sum over launches of the SA-interval search kernel          */
+    float    ms_extend;         /* sum over launches of the candidate walk / Hamming kernel    */
+    float    ms_heavy;          /* sum over launches of the wave-per-read kernel               */
+    float    ms_other;          /* pack / finalize                                             */
+    uint32_t n_search_launches;
+    uint32_t n_extend_launches;
+    uint32_t n_heavy_launches;
+    uint32_t reserved;
+} bk_timing;
+
+typedef struct bk_entry_info {
+    uint32_t entry_id;
+    uint32_t seq_len;
+    uint64_t start_ofs;
+    uint64_t end_ofs;
+    char     name[81];
+} bk_entry_info;
+
+typedef struct bk_ctx bk_ctx;
+
+const char *bk_version(void);
+const char *bk_strerror(int rc);
+/* number of usable HIP devices (0 if none); never fails */
+int  bk_device_count(void);
+
+/* Replaces CSfxArrayV3::Open + SetTargBlock (libbiokanga/SfxArrayV2.cpp:891-1103,1836-1890) and the
+ * MinCoreLen/MaxIter set-up of CAligner::Align / LocateCoredApprox (Aligner.cpp:341-356,8725-8761):
+ * reads the .sfx file, uploads target + suffix array to HBM, builds the k-mer interval table. */
+int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p);
+
+/* Same, from an index image already resident in HBM (synthetic benchmarks, GPU-built indexes):
+ * d_seq  = concat_len bytes, 1 byte/base, eBaseEOS(7) after every entry (tsSfxBlock.SeqSuffix)
+ * d_sa   = concat_len suffix array elements of sfx_el_size (4 or 5) bytes, little endian
+ * entries (host) describe the sequences as tsSfxEntry does.  The buffers are copied/re-packed;
+ * the caller keeps ownership and may free them after the call returns. */
+int  bk_ctx_create_from_device(bk_ctx **out, const void *d_seq, uint64_t concat_len, const void *d_sa,
+                               int sfx_el_size, const bk_entry_info *entries, uint32_t n_entries,
+                               int device_id, const bk_align_params *p);
+
+void bk_ctx_destroy(bk_ctx *ctx);
+
+/* change alignment parameters (re-derives MinCoreLen, MaxIter, slides) */
+int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
+/* tuning knobs: name = "kmer_bits" | "heavy_thresh" | "chunk_reads" | "use_ktab"; returns old value or <0 */
+int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
+
+uint32_t bk_num_entries(const bk_ctx *ctx);
+int  bk_get_entry(const bk_ctx *ctx, uint32_t idx, bk_entry_info *out);
+const char *bk_dataset_name(const bk_ctx *ctx);
+uint64_t bk_concat_len(const bk_ctx *ctx);
+int  bk_sfx_el_size(const bk_ctx *ctx);
+int  bk_min_core_len(const bk_ctx *ctx);
+
+/* Batch form of CSfxArrayV3::AlignReads over host buffers (blocking).
+ * bases: all reads concatenated, 1 byte/base as CAligner holds them; offs[i] = start of read i in
+ * bases; lens[i] = read length (<= 2000); out[nreads]. */
+int  bk_align_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
+                    uint32_t nreads, bk_hit *out);
+
+/* Same over buffers already resident in HBM on the context's device.  Asynchronous on `stream`
+ * (a hipStream_t, NULL = the context's own stream) unless `sync` is non-zero. */
+int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
+                           uint32_t nreads, void *d_out, void *stream, int sync);
+
+/* counters/timing accumulated since the last reset */
+int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);
+int  bk_get_timing(bk_ctx *ctx, bk_timing *out, int reset);
+
+/* per-sequence count of accepted reads since the last reset (CAligner::ReportTargHitCnts,
+ * Aligner.cpp:5475-5537) - the vector the multi-GPU run sum-reduces over RCCL.  n = bk_num_entries */
+int  bk_seq_counts(bk_ctx *ctx, uint64_t *per_entry_hits, uint32_t n, int reset);
+
+/* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
+/* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into
+ * d_sa_out (sfx_el_size bytes/element) on the device: order = nibble-lexicographic exactly as
+ * QSortSeqCmp32/40 (SfxArrayV2.cpp:9491-9542). */
+int  bk_build_sa_device(const void *d_seq, uint64_t concat_len, void *d_sa_out, int sfx_el_size,
+                        int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ by RUNNING THE REAL REFERENCE executable
+(oracle/_ref/biokanga, built by oracle/build_ref.sh from /root/reference) on small seeded synthetic
+inputs.  Run in the build container only (the GPU box has no /root/reference and just consumes the
+committed files).  Everything written here is data: inputs (FASTA), the reference-built .sfx and
+the reference's outputs (SAM / CSV / log summaries), gzip-compressed.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+
+Fixtures
+  basic/   2 x 100 kbp random sequences (+ a 100-mer shared by both, + an N run of 120 in chrB)
+           reads: 0..4 substitutions, both strands, N-containing, lower case, entry-boundary
+           spanning, exact duplicates, whitespace in names, lengths 50..150
+  repeat/  unique background + four families of an exact 25-mer repeated K = 2000/3000/4000/6000
+           times; reads whose only clean core is the repeat (pins the 100-candidate copy-count
+           cut-off and MaxIter truncation, SfxArrayV2.cpp:5857-5875)
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "biokanga")
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+
+
+def revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+def mutate(rng, s, nsubs, positions=None):
+    r = list(s)
+    if positions is None:
+        positions = rng.choice(len(r), nsubs, replace=False)
+    for k in positions:
+        r[k] = "ACGT"[("ACGT".index(r[k].upper()) + int(rng.integers(1, 4))) % 4]
+    return "".join(r)
+
+
+def write_fasta(path, recs, width=70):
+    with open(path, "w") as f:
+        for name, seq in recs:
+            f.write(">" + name + "\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+def write_reads(path, reads):
+    with open(path, "w") as f:
+        for name, seq in reads:
+            f.write(">" + name + "\n" + seq + "\n")
+
+
+def run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout[-4000:])
+        raise SystemExit("reference run failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def gz_copy(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
+
+
+def nar_summary(log):
+    out = []
+    keep = False
+    for line in log.splitlines():
+        msg = line.split("](biokanga) ", 1)[-1]
+        if "Read nonalignment reason summary" in msg:
+            keep = True
+            continue
+        if keep:
+            if msg.strip().split(" ")[0].isdigit():
+                out.append(msg.strip())
+            else:
+                keep = False
+    return "\n".join(out) + "\n"
+
+
+def align_runs(tmp, outdir, sfx, reads, runs):
+    for tag, flags in runs:
+        for fmt, ext in (("-M6", "m6.sam"), ("-M5", "m5.sam"), ("-M0", "m0.csv")):
+            if fmt != "-M6" and not tag.endswith("*"):
+                continue
+            t = tag.rstrip("*")
+            out = os.path.join(tmp, f"{t}.{ext}")
+            log = run([REF, "align", "-i", reads, "-I", sfx, "-o", out, fmt, "-T4"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{t}.{ext}.gz"))
+            if fmt == "-M6":
+                with open(os.path.join(outdir, f"{t}.nar.txt"), "w") as f:
+                    f.write(nar_summary(log))
+            print("  ran", t, fmt, flags)
+
+
+def make_basic(tmp):
+    rng = np.random.default_rng(20261002)
+    outdir = os.path.join(HERE, "basic")
+    os.makedirs(outdir, exist_ok=True)
+    a = rand_seq(rng, 100000)
+    b = rand_seq(rng, 100000)
+    shared = rand_seq(rng, 100)
+    a = a[:40000] + shared + a[40100:]
+    b = b[:70000] + shared + b[70100:]
+    b = b[:20000] + "N" * 120 + b[20120:]          # N run > 25 -> every 13th N mutated at index time
+    a = a[:5000] + a[5000:5400].lower() + a[5400:]  # soft-masked stretch
+    # near-duplicate segments (exercise NxtLowMMCnt / -e MMDelta): 1 sub per 100, 2 subs per 100,
+    # and an exact 150-mer present three times
+    def near(seg, every):
+        seg = list(seg)
+        for q in every:
+            seg[q] = "ACGT"[("ACGT".index(seg[q]) + 1) % 4]
+        return "".join(seg)
+    b = b[:50000] + near(a[30000:30400], range(50, 400, 100)) + b[50400:]
+    b = b[:52000] + near(a[32000:32400], [q for k in range(4) for q in (k * 100 + 30, k * 100 + 70)]) + b[52400:]
+    b = b[:54000] + a[34000:34150] + b[54150:56000] + a[34000:34150] + b[56150:]
+    genome = [("chrA basic test sequence", a), ("chrB", b)]
+    fa = os.path.join(tmp, "basic.fa")
+    write_fasta(fa, genome)
+    seqs = {"chrA": a.upper(), "chrB": b.upper()}
+
+    reads = []
+    idx = 0
+
+    def add(name, seq):
+        nonlocal idx
+        reads.append((name, seq))
+        idx += 1
+
+    for e in range(5):                      # substitution strata, 100 bp
+        for _ in range(400):
+            c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
+            p = int(rng.integers(0, 100000 - 100))
+            s = seqs[c][p:p + 100]
+            if "N" in s:
+                continue
+            r = mutate(rng, s, e)
+            strand = "+"
+            if rng.integers(0, 2):
+                r = revcomp(r)
+                strand = "-"
+            add(f"s{idx}|{c}|{p}|{strand}|{e}", r)
+    for L in (50, 60, 75, 90, 125, 150):     # other lengths, 0..3 subs
+        for _ in range(60):
+            c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
+            p = int(rng.integers(0, 100000 - L))
+            s = seqs[c][p:p + L]
+            if "N" in s:
+                continue
+            e = int(rng.integers(0, 4))
+            r = mutate(rng, s, e)
+            strand = "+"
+            if rng.integers(0, 2):
+                r = revcomp(r)
+                strand = "-"
+            add(f"l{idx}|{c}|{p}|{strand}|{e}|{L}", r)
+    for base, L in ((30000, 400), (32000, 400), (34000, 150)):   # near-duplicate / triplicate segments
+        for k in range(30):
+            c = "chrA" if k % 3 else "chrB"
+            start = base + (20000 if c == "chrB" else 0) + int(rng.integers(0, L - 100 + 1))
+            e = k % 4 if k < 24 else 0
+            r = mutate(rng, seqs[c][start:start + 100], e)
+            if k % 2:
+                r = revcomp(r)
+            add(f"nd{idx}|{c}|{start}|{e}", r)
+    for k in range(40):                      # reads with 1 N (costs a mismatch) and 2 Ns (EN)
+        p = int(rng.integers(0, 19000))
+        s = list(seqs["chrA"][p:p + 100])
+        s[int(rng.integers(0, 100))] = "N"
+        if k % 2:
+            q = int(rng.integers(0, 100))
+            s[q] = "N" if s[q] != "N" else s[q]
+            s[(q + 7) % 100] = "N"
+        r = "".join(s)
+        if k % 3 == 0:
+            r = mutate(rng, r.replace("N", "A"), 0)
+            r = "".join("R" if i == 10 else ch for i, ch in enumerate(r))   # IUPAC -> N
+        add(f"n{idx}|chrA|{p}", r)
+    for k in range(10):                      # lower case reads
+        p = int(rng.integers(0, 99000))
+        add(f"lc{idx}|chrB|{p}", mutate(rng, seqs["chrB"][p:p + 100], k % 3).lower() if "N" not in seqs["chrB"][p:p + 100] else rand_seq(rng, 100))
+    for k in range(6):                       # spanning the chrA/chrB boundary (EOS between entries)
+        n_a = 30 + 8 * k
+        add(f"span{idx}|{n_a}", seqs["chrA"][100000 - n_a:] + seqs["chrB"][:100 - n_a])
+    add(f"shared{idx}", shared)               # occurs in both sequences -> ML
+    add(f"sharedrc{idx}", revcomp(shared))
+    add(f"shared1{idx}", mutate(rng, shared, 1))
+    dup = seqs["chrA"][61234:61334]
+    for k in range(4):                       # exact duplicates, consecutive and not
+        add(f"dup{idx} extra words here", dup)
+    add(f"dupx{idx}", seqs["chrB"][1234:1334])
+    add(f"dup{idx}\ttabbed", dup)
+    for k in range(5):                       # reads near N run of chrB (target Ns were mutated)
+        p = 20000 - 60 + 10 * k
+        add(f"nrun{idx}|{p}", seqs["chrB"][p:p + 100])
+    for k in range(20):                      # random (unalignable) reads
+        add(f"rnd{idx}", rand_seq(rng, 100))
+    add("lcl|usimreads|00000001|chrA|300|399|100|+|0|0|0 kept whole", seqs["chrA"][300:400])
+    # ends of sequences
+    add(f"endA{idx}", seqs["chrA"][-100:])
+    add(f"startA{idx}", seqs["chrA"][:100])
+    add(f"endB{idx}", revcomp(seqs["chrB"][-100:]))
+    add(f"startB{idx}", seqs["chrB"][:100])
+
+    rd = os.path.join(tmp, "basic_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "basic.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "basic", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    align_runs(tmp, outdir, sfx, rd, [
+        ("s3*", ["-s3"]),
+        ("s0", ["-s0"]),
+        ("s5", ["-s5"]),
+        ("dflt", []),
+        ("s3e2", ["-s3", "-e2"]),
+        ("s3Q1", ["-s3", "-Q1"]),
+        ("s3Q2", ["-s3", "-Q2"]),
+        ("s3m1", ["-s3", "-m1"]),
+        ("s3m2", ["-s3", "-m2"]),
+        ("s3m3", ["-s3", "-m3"]),
+        ("s3n0", ["-s3", "-n0"]),
+        ("s3n3", ["-s3", "-n3"]),
+        ("s2l30", ["-s2", "-l30"]),
+    ])
+
+
+def make_repeat(tmp):
+    rng = np.random.default_rng(77)
+    outdir = os.path.join(HERE, "repeat")
+    os.makedirs(outdir, exist_ok=True)
+    fams = [(2000, rand_seq(rng, 25)), (3000, rand_seq(rng, 25)), (4000, rand_seq(rng, 25)), (6000, rand_seq(rng, 25))]
+    # chrU: unique background with one copy of each family's 25-mer embedded at known places
+    u = list(rand_seq(rng, 60000))
+    sites = []
+    for fi, (K, R) in enumerate(fams):
+        for j in range(12):
+            p = 1000 + fi * 14000 + j * 1100
+            u[p + 25:p + 50] = list(R)          # read [p, p+100) has core 1 == R
+            sites.append((fi, p))
+    u = "".join(u)
+    # chrR: the repeat copies separated by short random spacers
+    parts = []
+    for K, R in fams:
+        for _ in range(K):
+            parts.append(R)
+            parts.append(rand_seq(rng, int(rng.integers(4, 12))))
+    r = "".join(parts)
+    fa = os.path.join(tmp, "repeat.fa")
+    write_fasta(fa, [("chrU", u), ("chrR", r)])
+    reads = []
+    for fi, p in sites:
+        s = u[p:p + 100]
+        # subs in cores 0, 2 and 3 only (final phase CoreLen 25 at offsets 0,25,50,75)
+        for variant in range(3):
+            pos = [int(rng.integers(0, 25)), int(rng.integers(50, 75)), int(rng.integers(75, 100))]
+            rr = mutate(rng, s, 3, positions=pos)
+            strand = "+"
+            if variant == 2:
+                rr = revcomp(rr)
+                strand = "-"
+            reads.append((f"rep|K{fams[fi][0]}|{p}|{strand}|v{variant}", rr))
+        reads.append((f"rep0|K{fams[fi][0]}|{p}", s))
+    # reads made only of repeat material (multi-loci / many instances)
+    for fi, (K, R) in enumerate(fams):
+        off = r.find(R)
+        reads.append((f"inrep|K{K}", r[off:off + 100]))
+        reads.append((f"inrep1|K{K}", mutate(rng, r[off + 7:off + 107], 1)))
+    rd = os.path.join(tmp, "repeat_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "repeat.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "repeat", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    align_runs(tmp, outdir, sfx, rd, [
+        ("s3*", ["-s3"]),
+        ("s3m1", ["-s3", "-m1"]),
+        ("s3m3", ["-s3", "-m3"]),
+        ("s5", ["-s5"]),
+    ])
+
+
+def main():
+    if not os.path.exists(REF):
+        raise SystemExit("build the reference first: oracle/build_ref.sh")
+    with tempfile.TemporaryDirectory() as tmp:
+        make_basic(tmp)
+        make_repeat(tmp)
+    print("done")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,207 @@
+"""Shared test helpers: golden-fixture access, a ctypes binding of the CPU oracle (oracle/ is test
+infrastructure - only tests/, smoke() and bench.py's cpu_baseline leg may use it), a small FASTA
+reader that follows the reference's read-ingest rules, and SAM/CSV parsers."""
+import ctypes
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+NAR_TAGS = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"]
+
+
+# ------------------------------------------------------------------------------------------------
+class OraParams(ctypes.Structure):
+    _fields_ = [("max_subs", ctypes.c_int32), ("min_edit_dist", ctypes.c_int32),
+                ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
+                ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
+
+
+HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
+                      ("low_hit_instances", "<i2"), ("rslt", "u1"), ("nar", "u1"), ("strand", "u1"),
+                      ("low_mm", "i1"), ("nxt_low_mm", "i1"), ("num_hits", "u1"),
+                      ("mismatches", "u1"), ("flags", "u1")])
+assert HIT_DTYPE.itemsize == 20
+
+
+class OraCounters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("n_reads", "n_search", "n_probe", "n_last_search", "n_cand", "n_cand_seen", "n_lcm_calls")]
+
+
+def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, cls=OraParams):
+    p = cls()
+    p.max_subs, p.min_edit_dist, p.align_strand, p.pmode, p.max_ns, p.max_ml = \
+        max_subs, min_edit_dist, align_strand, pmode, max_ns, max_ml
+    return p
+
+
+_oracle = None
+
+
+def oracle_lib():
+    """Builds (if needed) and loads oracle/libbk_oracle.so."""
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    so = os.path.join(ORACLE_DIR, "libbk_oracle.so")
+    src = os.path.join(ORACLE_DIR, "bk_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libbk_oracle.so"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    lib.ora_sfx_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ora_sfx_load.restype = ctypes.c_int
+    lib.ora_sfx_free.argtypes = [ctypes.c_void_p]
+    lib.ora_align_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                    ctypes.POINTER(OraCounters), ctypes.c_int]
+    lib.ora_align_batch.restype = ctypes.c_int
+    lib.ora_min_core_len.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.ora_min_core_len.restype = ctypes.c_int
+    lib.ora_locate_first_exact.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_void_p]
+    lib.ora_locate_first_exact.restype = ctypes.c_int64
+    lib.ora_locate_last_exact.argtypes = lib.ora_locate_first_exact.argtypes
+    lib.ora_locate_last_exact.restype = ctypes.c_int64
+    _oracle = lib
+    return lib
+
+
+class OracleSfx:
+    def __init__(self, path):
+        self.lib = oracle_lib()
+        h = ctypes.c_void_p()
+        rc = self.lib.ora_sfx_load(path.encode(), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ora_sfx_load({path}) failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.ora_sfx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def align(self, bases, offs, lens, params, nthreads=4):
+        """bases: uint8 array (1 B/base), offs uint64, lens uint32 -> (hits structured array, counters)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        ctr = OraCounters()
+        rc = self.lib.ora_align_batch(self.h, ctypes.byref(params), bases.ctypes.data, offs.ctypes.data,
+                                      lens.ctypes.data, n, out.ctypes.data, ctypes.byref(ctr), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"ora_align_batch failed: {rc}")
+        return out, ctr
+
+
+# ------------------------------------------------------------------------------------------------
+_A2S = np.full(256, 4, dtype=np.uint8)          # CFasta::Ascii2Sense (Fasta.cpp:1518): anything else -> N
+for ch, v in (("a", 0), ("c", 1), ("g", 2), ("t", 3), ("u", 3)):
+    _A2S[ord(ch)] = v | 0x08                    # lower case carries cRptMskFlg
+    _A2S[ord(ch.upper())] = v
+_A2S[ord("-")] = 6
+
+
+def read_name(descr, sim=False):
+    """Descriptor rule of CAligner::LoadRawReads (Aligner.cpp:10967-10974,11296-11307): if the FIRST
+    descriptor of the file starts lcl|usimreads| / lcr|usimreads| every descriptor is kept whole,
+    otherwise each is cut at the first whitespace (and at cMaxDescrIDLen-1 = 79 chars)."""
+    if sim:
+        return descr
+    for i, c in enumerate(descr[:79]):
+        if c.isspace():
+            return descr[:i]
+    return descr[:79]
+
+
+def read_fasta_reads(path):
+    """-> (names, bases uint8 (1 B/base), offs uint64, lens uint32); non-alpha (except '-') sloughed."""
+    op = gzip.open if path.endswith(".gz") else open
+    names, seqs = [], []
+    cur = None
+    sim = None
+    with op(path, "rt") as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if cur is not None:
+                    seqs.append("".join(cur))
+                if sim is None:
+                    sim = line[1:].startswith("lcl|usimreads|") or line[1:].startswith("lcr|usimreads|")
+                names.append(read_name(line[1:], sim))
+                cur = []
+            elif cur is not None:
+                cur.append("".join(c for c in line if c.isalpha() or c == "-"))
+    if cur is not None:
+        seqs.append("".join(cur))
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    offs = np.zeros(len(seqs), dtype=np.uint64)
+    if len(seqs):
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    raw = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    bases = _A2S[raw]
+    return names, bases, offs, lens
+
+
+def filter_reads_by_len(names, bases, offs, lens, min_len=50, max_len=500):
+    """default -l50 -L500 read-length acceptance (Aligner.h:92-93); under-length reads are never loaded."""
+    keep = [i for i in range(len(lens)) if min_len <= lens[i] <= max_len]
+    return keep
+
+
+# ------------------------------------------------------------------------------------------------
+def gunzip_to(src_gz, dst):
+    with gzip.open(src_gz, "rb") as f, open(dst, "wb") as g:
+        shutil.copyfileobj(f, g)
+    return dst
+
+
+def parse_sam(path):
+    """-> (header lines, list of dict records)"""
+    op = gzip.open if path.endswith(".gz") else open
+    hdr, recs = [], []
+    with op(path, "rt") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith("@"):
+                hdr.append(line)
+                continue
+            t = line.split("\t")
+            rec = dict(qname=t[0], flag=int(t[1]), rname=t[2], pos=int(t[3]), mapq=int(t[4]), cigar=t[5],
+                       rnext=t[6], pnext=int(t[7]), tlen=int(t[8]), seq=t[9], qual=t[10], tags=t[11:], raw=line)
+            nar = "AA"
+            for tg in t[11:]:
+                if tg.startswith("YU:Z:"):
+                    nar = tg[5:]
+            rec["nar"] = nar
+            recs.append(rec)
+    return hdr, recs
+
+
+def parse_m0_csv(path):
+    """-M0 CSV (Aligner.cpp:6380-6620): ReadID,"ar",dataset,chrom,start,end,len,strand,?,?,NumReads,mismatches,bsmap,name"""
+    op = gzip.open if path.endswith(".gz") else open
+    out = {}
+    with op(path, "rt") as f:
+        for line in f:
+            t = line.rstrip("\n").split(",")
+            if len(t) < 14:
+                continue
+            out[t[13].strip('"')] = dict(read_id=int(t[0]), chrom=t[3].strip('"'), start=int(t[4]), end=int(t[5]),
+                                         length=int(t[6]), strand=t[7].strip('"'), mismatches=int(t[11]))
+    return out
