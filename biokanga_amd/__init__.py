@@ -1,0 +1,13 @@
+"""biokanga_amd - MI355X-native implementation of the `biokanga align` hot path.
+
+The product is the C-ABI shared library `biokanga_amd/lib/libbiokanga_amd.so` (hand-written HIP
+kernels for gfx950 + C++ host code, see include/biokanga_amd.h) and the C++ command line front end
+`biokanga_amd/bin/biokanga` (`index` / `align`).  This Python package is only plumbing for tests and
+bench.py: a ctypes binding of the C ABI.  There is no CPU fallback anywhere - if the library is
+missing, or no HIP device is present, calls fail loudly.
+"""
+from .binding import (Aligner, AlignParams, HIT_DTYPE, ENTRY_DTYPE, BkError, lib_path, load_library,
+                      device_count, build_sa_device, NAR_TAGS)
+
+__all__ = ["Aligner", "AlignParams", "HIT_DTYPE", "ENTRY_DTYPE", "BkError", "lib_path", "load_library",
+           "device_count", "build_sa_device", "NAR_TAGS"]

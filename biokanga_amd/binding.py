@@ -1,0 +1,249 @@
+"""ctypes binding of include/biokanga_amd.h (libbiokanga_amd.so).  Plumbing only."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NAR_TAGS = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP",
+            "IS", "IT", "NP", "LC"]          # CAligner::m_NARdesc, biokanga/Aligner.cpp:32-51
+
+# every symbol include/biokanga_amd.h declares
+EXPORTED_SYMBOLS = [
+    "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
+    "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
+    "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
+    "bk_align_batch_device", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+]
+
+
+class BkError(RuntimeError):
+    def __init__(self, rc, what):
+        self.rc = rc
+        super().__init__(f"{what} failed: rc={rc} ({_strerror(rc)})")
+
+
+class AlignParams(ctypes.Structure):
+    """bk_align_params: the `biokanga align` options that reach the hot path (kanga.cpp:194-294)."""
+    _fields_ = [("max_subs", ctypes.c_int32), ("min_edit_dist", ctypes.c_int32),
+                ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
+                ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
+
+    def __init__(self, max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1):
+        super().__init__()
+        self.max_subs, self.min_edit_dist, self.align_strand = max_subs, min_edit_dist, align_strand
+        self.pmode, self.max_ns, self.max_ml = pmode, max_ns, max_ml
+
+
+HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
+                      ("low_hit_instances", "<i2"), ("rslt", "u1"), ("nar", "u1"), ("strand", "u1"),
+                      ("low_mm", "i1"), ("nxt_low_mm", "i1"), ("num_hits", "u1"),
+                      ("mismatches", "u1"), ("flags", "u1")])
+assert HIT_DTYPE.itemsize == 20
+
+ENTRY_DTYPE = np.dtype([("entry_id", "<u4"), ("seq_len", "<u4"), ("start_ofs", "<u8"), ("end_ofs", "<u8"),
+                        ("name", "S81"), ("_pad", "S7")])
+assert ENTRY_DTYPE.itemsize == 112
+
+
+class _Counters(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64), ("n_search", ctypes.c_uint64), ("n_cand", ctypes.c_uint64),
+                ("n_lcm_calls", ctypes.c_uint64), ("n_heavy", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 3)]
+
+
+class _Timing(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_search", ctypes.c_float), ("ms_extend", ctypes.c_float),
+                ("ms_heavy", ctypes.c_float), ("ms_other", ctypes.c_float),
+                ("n_search_launches", ctypes.c_uint32), ("n_extend_launches", ctypes.c_uint32),
+                ("n_heavy_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libbiokanga_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libbiokanga_amd.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError(f"{p} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C biokanga_amd/csrc). There is no CPU fallback.")
+    lib = ctypes.CDLL(p)
+    vp, i32, u32, u64, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64
+    lib.bk_version.restype = ctypes.c_char_p
+    lib.bk_strerror.restype = ctypes.c_char_p
+    lib.bk_strerror.argtypes = [i32]
+    lib.bk_device_count.restype = i32
+    lib.bk_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, i32, ctypes.POINTER(AlignParams)]
+    lib.bk_ctx_create.restype = i32
+    lib.bk_ctx_create_from_device.argtypes = [ctypes.POINTER(vp), vp, u64, vp, i32, vp, u32, i32,
+                                              ctypes.POINTER(AlignParams)]
+    lib.bk_ctx_create_from_device.restype = i32
+    lib.bk_ctx_destroy.argtypes = [vp]
+    lib.bk_ctx_destroy.restype = None
+    lib.bk_ctx_set_params.argtypes = [vp, ctypes.POINTER(AlignParams)]
+    lib.bk_ctx_set_params.restype = i32
+    lib.bk_ctx_tune.argtypes = [vp, ctypes.c_char_p, i64]
+    lib.bk_ctx_tune.restype = i64
+    lib.bk_num_entries.argtypes = [vp]
+    lib.bk_num_entries.restype = u32
+    lib.bk_get_entry.argtypes = [vp, u32, vp]
+    lib.bk_get_entry.restype = i32
+    lib.bk_dataset_name.argtypes = [vp]
+    lib.bk_dataset_name.restype = ctypes.c_char_p
+    lib.bk_concat_len.argtypes = [vp]
+    lib.bk_concat_len.restype = u64
+    lib.bk_sfx_el_size.argtypes = [vp]
+    lib.bk_sfx_el_size.restype = i32
+    lib.bk_min_core_len.argtypes = [vp]
+    lib.bk_min_core_len.restype = i32
+    lib.bk_align_batch.argtypes = [vp, vp, vp, vp, u32, vp]
+    lib.bk_align_batch.restype = i32
+    lib.bk_align_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
+    lib.bk_align_batch_device.restype = i32
+    lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
+    lib.bk_get_counters.restype = i32
+    lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
+    lib.bk_get_timing.restype = i32
+    lib.bk_seq_counts.argtypes = [vp, vp, u32, i32]
+    lib.bk_seq_counts.restype = i32
+    lib.bk_build_sa_device.argtypes = [vp, u64, vp, i32, i32]
+    lib.bk_build_sa_device.restype = i32
+    _lib = lib
+    return lib
+
+
+def _strerror(rc):
+    try:
+        return load_library().bk_strerror(rc).decode()
+    except Exception:
+        return "?"
+
+
+def device_count():
+    return load_library().bk_device_count()
+
+
+def build_sa_device(d_seq_ptr, concat_len, d_sa_ptr, el_size=4, device=0):
+    rc = load_library().bk_build_sa_device(d_seq_ptr, concat_len, d_sa_ptr, el_size, device)
+    if rc:
+        raise BkError(rc, "bk_build_sa_device")
+
+
+class Aligner:
+    """One context per GPU (mirror of CSfxArrayV3 opened for alignment + the CAligner parameters)."""
+
+    def __init__(self, sfx_path=None, params=None, device=0, *, d_seq=None, concat_len=0, d_sa=None,
+                 el_size=4, entries=None):
+        self.lib = load_library()
+        self.params = params or AlignParams()
+        self.h = ctypes.c_void_p()
+        if sfx_path is not None:
+            rc = self.lib.bk_ctx_create(ctypes.byref(self.h), os.fsencode(sfx_path), device, ctypes.byref(self.params))
+            what = f"bk_ctx_create({sfx_path})"
+        else:
+            ent = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+            rc = self.lib.bk_ctx_create_from_device(ctypes.byref(self.h), d_seq, concat_len, d_sa, el_size,
+                                                    ent.ctypes.data, len(ent), device, ctypes.byref(self.params))
+            what = "bk_ctx_create_from_device"
+        if rc:
+            self.h = None
+            raise BkError(rc, what)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- metadata
+    @property
+    def num_entries(self):
+        return self.lib.bk_num_entries(self.h)
+
+    def entries(self):
+        out = np.zeros(self.num_entries, dtype=ENTRY_DTYPE)
+        for i in range(len(out)):
+            rc = self.lib.bk_get_entry(self.h, i, out[i:i + 1].ctypes.data)
+            if rc:
+                raise BkError(rc, "bk_get_entry")
+        return out
+
+    @property
+    def min_core_len(self):
+        return self.lib.bk_min_core_len(self.h)
+
+    @property
+    def concat_len(self):
+        return self.lib.bk_concat_len(self.h)
+
+    def set_params(self, params):
+        rc = self.lib.bk_ctx_set_params(self.h, ctypes.byref(params))
+        if rc:
+            raise BkError(rc, "bk_ctx_set_params")
+        self.params = params
+
+    def tune(self, name, value):
+        r = self.lib.bk_ctx_tune(self.h, name.encode(), int(value))
+        if r < 0:
+            raise BkError(int(r), f"bk_ctx_tune({name})")
+        return r
+
+    # -- alignment
+    def align(self, bases, offs, lens):
+        """Host buffers: bases uint8 (1 B/base as CAligner holds them), offs uint64, lens uint32."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        out = np.zeros(len(lens), dtype=HIT_DTYPE)
+        rc = self.lib.bk_align_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(lens),
+                                     out.ctypes.data)
+        if rc:
+            raise BkError(rc, "bk_align_batch")
+        return out
+
+    def align_device(self, d_bases, d_offs, d_lens, nreads, d_out, stream=None, sync=True):
+        """Device pointers (ints) of buffers resident in HBM on this context's GPU."""
+        rc = self.lib.bk_align_batch_device(self.h, d_bases, d_offs, d_lens, nreads, d_out, stream, 1 if sync else 0)
+        if rc:
+            raise BkError(rc, "bk_align_batch_device")
+
+    def counters(self, reset=False):
+        c = _Counters()
+        rc = self.lib.bk_get_counters(self.h, ctypes.byref(c), 1 if reset else 0)
+        if rc:
+            raise BkError(rc, "bk_get_counters")
+        return {k: getattr(c, k) for k in ("n_search", "n_cand", "n_lcm_calls", "n_heavy")}
+
+    def timing(self, reset=False):
+        t = _Timing()
+        rc = self.lib.bk_get_timing(self.h, ctypes.byref(t), 1 if reset else 0)
+        if rc:
+            raise BkError(rc, "bk_get_timing")
+        return {k: getattr(t, k) for k, _ in _Timing._fields_ if k != "reserved"}
+
+    def seq_counts(self, reset=False):
+        out = np.zeros(self.num_entries, dtype=np.uint64)
+        rc = self.lib.bk_seq_counts(self.h, out.ctypes.data, len(out), 1 if reset else 0)
+        if rc:
+            raise BkError(rc, "bk_seq_counts")
+        return out

@@ -1,0 +1,131 @@
+// bk_device.h - device-side data layout and helpers shared by the HIP kernels (gfx950 only).
+//
+// HBM layout of the index image
+//   tgt4   : target bases packed 4 bit/base, 16 bases per uint64, FIRST base in the MOST significant
+//            nibble, so that an unsigned compare of two words is the reference's low-nibble
+//            lexicographic compare (A0 C1 G2 T3 N4 < EOS7; SfxArrayV2.cpp:7791-7812).  Padded with
+//            EOS nibbles past concat_len so windows never read out of bounds.
+//   sa_lo  : uint32[N] low 32 bits of each suffix array element; sa_hi: uint8[N] bits 32..39 when
+//            the .sfx uses 5-byte elements (SfxOfsToLoci, SfxArrayV2.cpp:33-44)
+//   ktab   : uint32/uint64[4^k + 1]; ktab[c] = number of suffixes sorting before k-mer code c, i.e.
+//            the LocateFirstExact lower bound of c; a core whose first k bases have code c can only
+//            match inside [ktab[c], ktab[c+1])
+//   ent_*  : tsSfxEntry StartOfs/EndOfs/EntryID (MapChunkHit2Entry, SfxArrayV2.cpp:2530-2575)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/biokanga_amd.h"
+
+namespace bk {
+
+constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
+constexpr int kWave = 64;
+constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)
+constexpr uint32_t kNodeCap = 1024000; // cMaxNumIdentNodes, SfxArrayV2.h:15
+constexpr uint64_t kEosWord = 0x7777777777777777ULL;
+
+struct DevIndex {
+    const uint64_t *tgt4;
+    const uint32_t *sa_lo;
+    const uint8_t *sa_hi;       // null unless 5-byte elements
+    const uint64_t *ent_start;
+    const uint64_t *ent_end;
+    const uint32_t *ent_id;
+    const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
+    const uint64_t *ktab64;
+    uint64_t n;                 // concat_len
+    uint32_t n_ent;
+    int k;                      // k-mer table order (0 = none)
+};
+
+struct DevAlignCfg {            // derived once per context (CAligner::LocateCoredApprox, Align)
+    int max_subs, mm_delta, align_strand, max_ns, max_hits;
+    int min_core_len, slides_per100, max_iter;
+    int heavy_thresh;           // intervals longer than this go to the wave-per-read kernel
+};
+
+struct DevBatch {
+    const uint8_t *bases;       // 1 B/base as CAligner holds them
+    const uint64_t *offs;
+    const uint32_t *lens;
+    uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp)
+    uint64_t *iv_first;         // [read][strand][kMaxCoresFast]
+    uint32_t *iv_n;
+    bk_hit *out;
+    unsigned long long *seq_counts;   // per entry accepted reads
+    unsigned long long *ctr;          // [0] n_search [1] n_cand [2] n_lcm [3] n_heavy
+    uint32_t wpr;
+    uint32_t n_reads;
+};
+
+struct HeavyScratch {
+    unsigned long long *htab;   // slots * tab_size entries of (epoch<<32 | key)
+    uint32_t *slot_epoch;
+    uint32_t tab_size;          // power of two
+    uint32_t n_slots;
+};
+
+// ------------------------------------------------------------------------------------------------
+struct ReadPlan {
+    int len, max_tot_mm, core_len, core_delta, max_slides, n_loop, n_phases;
+};
+
+// CAligner::ProcCoredApprox parameter derivation (Aligner.cpp:9085-9095) + the phase schedule of
+// CSfxArrayV3::AlignReads (SfxArrayV2.cpp:7695-7719)
+__host__ __device__ inline ReadPlan make_plan(int len, const DevAlignCfg &c)
+{
+    ReadPlan p;
+    p.len = len;
+    int m = c.max_subs == 0 ? 0 : (int)(0.5 + (double)(len * c.max_subs) / 100.0);
+    if (c.max_subs != 0 && m < 1) m = 1;
+    if (m > 63) m = 63;
+    p.max_tot_mm = m;
+    int cl = len / (c.mm_delta == 1 ? m + 1 : m + 2);
+    p.core_len = cl > c.min_core_len ? cl : c.min_core_len;
+    int ms = (c.slides_per100 * len + 99) / 100;
+    p.max_slides = ms > 1 ? ms : 1;
+    int cd = len / p.max_slides - 1;
+    p.core_delta = cd > p.core_len ? cd : p.core_len;
+    p.n_loop = 0;
+    int has_final = 1;
+    if (m > 0) {
+        int a;
+        for (a = 0; a <= m; a++) {
+            if (len / (a + c.mm_delta) <= p.core_len) break;
+            p.n_loop++;
+        }
+        has_final = a <= m;
+    }
+    p.n_phases = p.n_loop + has_final;
+    return p;
+}
+
+__host__ __device__ inline void phase_params(const ReadPlan &p, const DevAlignCfg &c, int phase, int &mm, int &cl, int &cd)
+{
+    if (phase < p.n_loop) {
+        mm = phase;
+        cl = p.len / (phase + c.mm_delta);
+        cd = cl;
+    } else {
+        mm = p.max_tot_mm;
+        cl = p.core_len;
+        cd = p.core_delta;
+    }
+}
+
+// core sliding rule of LocateCoreMultiples (SfxArrayV2.cpp:5836-5847); returns the number of cores,
+// writes the first `maxn` offsets
+__host__ __device__ inline int core_offsets(int plen, int cl, int cd, int max_slides, int *ofs, int maxn)
+{
+    int cur = cd, o = 0, n = 0;
+    while (n < max_slides && o <= plen - cl && cur > cl / 3) {
+        if (o + cl + cur > plen) cur = plen - (o + cl);
+        if (n < maxn) ofs[n] = o;
+        n++;
+        o += cur;
+    }
+    return n;
+}
+
+}  // namespace bk

@@ -1,0 +1,668 @@
+// bk_engine.cpp - implementation of the C ABI in include/biokanga_amd.h: context (index image in
+// HBM), batch driver (phase loop of CSfxArrayV3::AlignReads over whole batches), counters, timing.
+// Compiled with hipcc; device code lives in bk_kernels.hip.  No CPU fallback exists: every compute
+// entry point needs a HIP device and fails with BK_ERR_NODEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bk_device.h"
+#include "sfx_file.h"
+
+namespace bk {
+// launchers defined in bk_kernels.hip
+void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
+void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
+void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
+void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                   int phase, int cmax, int nstr, hipStream_t s);
+void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                   int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
+                   uint32_t *cmax_next, hipStream_t s);
+void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                  uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
+                  hipStream_t s);
+int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_size, hipStream_t s);
+}  // namespace bk
+
+using namespace bk;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            fprintf(stderr, "biokanga_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return e__ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL;                      \
+        }                                                                                          \
+    } while (0)
+
+struct bk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bk_align_params params{};
+    DevAlignCfg cfg{};
+    DevIndex ix{};
+    // owned device allocations of the index image
+    uint64_t *d_tgt4 = nullptr;
+    uint32_t *d_sa_lo = nullptr;
+    uint8_t *d_sa_hi = nullptr;
+    uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
+    uint32_t *d_ent_id = nullptr;
+    void *d_ktab = nullptr;
+    bool ktab64 = false;
+    int k_req = -1;          // requested k (-1 auto)
+    int use_ktab = 1;
+    uint32_t el_size = 4;
+    uint64_t tot_seq_len = 0;
+    std::string dataset;
+    std::vector<bk_entry_info> entries;
+
+    // batch scratch (grown on demand)
+    uint32_t cap_reads = 0, cap_wpr = 0;
+    uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
+    uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr;
+    uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen
+    uint32_t *h_small = nullptr;          // pinned mirror
+    unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
+    // heavy path scratch
+    HeavyScratch hs{};
+    int max_read_len = 500;
+    uint32_t chunk_reads = 4u << 20;
+    // staging for host-buffer batches
+    uint8_t *d_in_bases = nullptr;
+    uint64_t *d_in_offs = nullptr;
+    uint32_t *d_in_lens = nullptr;
+    bk_hit *d_in_out = nullptr;
+    uint64_t cap_in_bases = 0;
+    uint32_t cap_in_reads = 0;
+
+    bk_timing timing{};
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int derive_cfg(bk_ctx *c)
+{
+    const bk_align_params &p = c->params;
+    if (p.max_subs < 0 || p.max_subs > 25 || p.min_edit_dist < 1 || p.min_edit_dist > 2 || p.align_strand < 0 ||
+        p.align_strand > 2 || p.pmode < 0 || p.pmode > 3 || p.max_ns < 0 || p.max_ns > 5)
+        return BK_ERR_PARAMS;
+    if (p.max_ml != 0 && p.max_ml != 1) return BK_ERR_PARAMS;   // multi-loci modes: not built yet
+    DevAlignCfg &g = c->cfg;
+    g.max_subs = p.max_subs;
+    g.mm_delta = p.min_edit_dist;
+    g.align_strand = p.align_strand;
+    g.max_ns = p.max_ns;
+    g.max_hits = 1;
+    // CAligner::LocateCoredApprox, Aligner.cpp:8725-8761
+    uint64_t t = c->tot_seq_len;
+    int m;
+    if (t <= 500000ULL) m = 4;
+    else if (t <= 20000000ULL) m = 7;
+    else if (t <= 250000000ULL) m = 11;
+    else if (t <= 3500000000ULL) m = 12;
+    else m = 15;
+    switch (p.pmode) {
+    case 2: g.slides_per100 = 9; break;
+    case 1: m += 1; g.slides_per100 = 8; break;
+    case 0: m += 2; g.slides_per100 = 8; break;
+    default: m += 4; g.slides_per100 = 6; break;
+    }
+    g.min_core_len = m;
+    // CAligner::Align, Aligner.cpp:341-356
+    switch (p.pmode) {
+    case 0: g.max_iter = 5000; break;
+    case 1: g.max_iter = 10000; break;
+    case 2: g.max_iter = 20000; break;
+    default: g.max_iter = 2500; break;
+    }
+    if (g.heavy_thresh < 0 || g.heavy_thresh > 100) g.heavy_thresh = 100;
+    return BK_OK;
+}
+
+void free_dev(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
+int pick_k(uint64_t n)
+{
+    int k = 1;
+    while (k < 16 && (1ULL << (2 * k)) < n) k++;
+    return k < 8 ? 8 : k;
+}
+
+int build_ktab(bk_ctx *c)
+{
+    free_dev(c->d_ktab);
+    c->d_ktab = nullptr;
+    c->ix.ktab32 = nullptr;
+    c->ix.ktab64 = nullptr;
+    c->ix.k = 0;
+    if (!c->use_ktab) return BK_OK;
+    int k = c->k_req > 0 ? c->k_req : pick_k(c->ix.n);
+    if (k > 16) k = 16;
+    if (k < 2) k = 2;
+    uint64_t ncodes = 1ULL << (2 * k);
+    c->ktab64 = c->ix.n >= (1ULL << 32);
+    size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
+    HIP_TRY(hipMalloc(&c->d_ktab, bytes));
+    DevIndex ix = c->ix;
+    launch_build_ktab(ix, c->d_ktab, k, c->ktab64, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+    else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
+    c->ix.k = k;
+    return BK_OK;
+}
+
+int size_heavy_scratch(bk_ctx *c)
+{
+    // worst-case inserts per strand pass = min(node cap, cores(max_read_len) * MaxIter)
+    int slides = std::max(1, (c->cfg.slides_per100 * c->max_read_len + 99) / 100);
+    uint64_t worst = c->cfg.max_iter ? (uint64_t)slides * (uint64_t)c->cfg.max_iter : kNodeCap;
+    if (worst > kNodeCap) worst = kNodeCap;
+    uint32_t ts = 1024;
+    while (ts < 2 * worst) ts <<= 1;
+    uint32_t slots = 1024;
+    while ((uint64_t)slots * ts * 8 > (8ULL << 30) && slots > 64) slots >>= 1;
+    if (c->hs.htab && c->hs.tab_size == ts && c->hs.n_slots == slots) return BK_OK;
+    free_dev(c->hs.htab);
+    free_dev(c->hs.slot_epoch);
+    c->hs = HeavyScratch{};
+    HIP_TRY(hipMalloc(&c->hs.htab, (size_t)slots * ts * 8));
+    HIP_TRY(hipMalloc(&c->hs.slot_epoch, (size_t)slots * 4));
+    HIP_TRY(hipMemsetAsync(c->hs.htab, 0, (size_t)slots * ts * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->hs.slot_epoch, 0, (size_t)slots * 4, c->stream));
+    c->hs.tab_size = ts;
+    c->hs.n_slots = slots;
+    return BK_OK;
+}
+
+int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
+{
+    // entries
+    c->entries.assign(entries, entries + n_entries);
+    c->tot_seq_len = 0;
+    std::vector<uint64_t> es(n_entries), ee(n_entries);
+    std::vector<uint32_t> ei(n_entries);
+    for (uint32_t i = 0; i < n_entries; i++) {
+        es[i] = entries[i].start_ofs;
+        ee[i] = entries[i].end_ofs;
+        ei[i] = entries[i].entry_id;
+        c->tot_seq_len += entries[i].seq_len;
+        if (i && es[i] <= ee[i - 1]) return BK_ERR_PARAMS;
+    }
+    HIP_TRY(hipMalloc(&c->d_ent_start, n_entries * 8));
+    HIP_TRY(hipMalloc(&c->d_ent_end, n_entries * 8));
+    HIP_TRY(hipMalloc(&c->d_ent_id, n_entries * 4));
+    HIP_TRY(hipMemcpy(c->d_ent_start, es.data(), n_entries * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ent_end, ee.data(), n_entries * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ent_id, ei.data(), n_entries * 4, hipMemcpyHostToDevice));
+    c->ix.ent_start = c->d_ent_start;
+    c->ix.ent_end = c->d_ent_end;
+    c->ix.ent_id = c->d_ent_id;
+    c->ix.n_ent = n_entries;
+    HIP_TRY(hipMalloc(&c->d_seq_counts, n_entries * 8));
+    HIP_TRY(hipMemset(c->d_seq_counts, 0, n_entries * 8));
+    HIP_TRY(hipMalloc(&c->d_ctr, 8 * 8));
+    HIP_TRY(hipMemset(c->d_ctr, 0, 8 * 8));
+    HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
+    HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
+    int rc = derive_cfg(c);
+    if (rc) return rc;
+    rc = build_ktab(c);
+    if (rc) return rc;
+    return size_heavy_scratch(c);
+}
+
+int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
+{
+    if (!out || !p) return BK_ERR_PARAMS;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BK_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(device_id));
+    bk_ctx *c = new bk_ctx();
+    c->device = device_id;
+    c->params = *p;
+    c->cfg.heavy_thresh = 100;
+    if (c->params.max_ml == 0) c->params.max_ml = 1;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BK_ERR_INTERNAL; }
+    *pc = c;
+    return BK_OK;
+}
+
+// uploads the 1 B/base sequence + suffix array that already sit in device memory
+int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_t *d_sa, int el)
+{
+    c->el_size = (uint32_t)el;
+    c->ix.n = n;
+    uint64_t nwords = (n + 15) / 16 + (kMaxReadLenAbs / 16) + 4;
+    HIP_TRY(hipMalloc(&c->d_tgt4, nwords * 8));
+    launch_pack_target(d_seq, n, c->d_tgt4, nwords, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
+    if (el == 5) {
+        HIP_TRY(hipMalloc(&c->d_sa_hi, n));
+        launch_split_sa5(d_sa, n, c->d_sa_lo, c->d_sa_hi, c->stream);
+        HIP_TRY(hipGetLastError());
+    } else
+        HIP_TRY(hipMemcpyAsync(c->d_sa_lo, d_sa, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ix.tgt4 = c->d_tgt4;
+    c->ix.sa_lo = c->d_sa_lo;
+    c->ix.sa_hi = c->d_sa_hi;
+    return BK_OK;
+}
+
+int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr)
+{
+    if (n_reads <= c->cap_reads && wpr <= c->cap_wpr) return BK_OK;
+    uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy);
+    c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr;
+    c->d_act[0] = c->d_act[1] = c->d_heavy = nullptr;
+    c->cap_reads = 0;
+    HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
+    HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
+    HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * kMaxCoresFast * 4));
+    HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
+    c->cap_reads = nr;
+    c->cap_wpr = w;
+    return BK_OK;
+}
+
+struct EvTimer {
+    bk_ctx *c;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;   // kind, (start, stop)
+    size_t next_ev = 0;
+    hipEvent_t get()
+    {
+        if (next_ev == c->ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            c->ev_pool.push_back(e);
+        }
+        return c->ev_pool[next_ev++];
+    }
+    hipEvent_t begin(hipStream_t s)
+    {
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, s);
+        return e;
+    }
+    void end(int kind, hipEvent_t b, hipStream_t s)
+    {
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, s);
+        spans.push_back({kind, {b, e}});
+    }
+};
+
+// one chunk of reads, all phases.  Blocking (host reads back the active counts between phases).
+int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+                bk_hit *d_out, hipStream_t s, EvTimer &tm)
+{
+    uint32_t *sm = c->d_small, *hm = c->h_small;
+    HIP_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
+    launch_max_len(d_lens, n, sm + 5, s);
+    HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t maxlen = hm[5];
+    if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+    if ((int)maxlen > c->max_read_len) {
+        c->max_read_len = (int)maxlen;
+        int rc = size_heavy_scratch(c);
+        if (rc) return rc;
+    }
+    uint32_t wpr = (maxlen + 15) / 16 + 1;
+    int rc = ensure_batch_scratch(c, n, wpr);
+    if (rc) return rc;
+
+    DevBatch b{};
+    b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
+    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
+    b.wpr = wpr; b.n_reads = n;
+    const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
+
+    hipEvent_t e0 = tm.begin(s);
+    launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
+    HIP_TRY(hipGetLastError());
+    tm.end(3, e0, s);
+    HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t n_act = hm[0];
+    int cmax = (int)hm[3];
+    int cur = 0;
+    for (int phase = 0; n_act > 0; phase++) {
+        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor
+        HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
+        if (cmax > 0) {
+            hipEvent_t e1 = tm.begin(s);
+            launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, s);
+            HIP_TRY(hipGetLastError());
+            tm.end(0, e1, s);
+        }
+        hipEvent_t e2 = tm.begin(s);
+        launch_extend(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
+        HIP_TRY(hipGetLastError());
+        tm.end(1, e2, s);
+        HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint32_t n_heavy = hm[2];
+        if (n_heavy) {
+            hipEvent_t e3 = tm.begin(s);
+            launch_heavy(c->ix, c->cfg, b, c->hs, c->d_heavy, n_heavy, phase, sm + 4, c->d_act[cur ^ 1], sm + 1, sm + 3, s);
+            HIP_TRY(hipGetLastError());
+            tm.end(2, e3, s);
+            HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        n_act = hm[1];
+        cmax = (int)hm[3];
+        cur ^= 1;
+        if (phase > 70) return BK_ERR_INTERNAL;
+    }
+    return BK_OK;
+}
+
+int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads,
+                 bk_hit *d_out, hipStream_t s)
+{
+    EvTimer tm{c};
+    hipEvent_t t0 = tm.begin(s);
+    for (uint32_t done = 0; done < nreads;) {
+        uint32_t n = std::min(c->chunk_reads, nreads - done);
+        int rc = align_chunk(c, d_bases, d_offs + done, d_lens + done, n, d_out + done, s, tm);
+        if (rc) return rc;
+        done += n;
+    }
+    hipEvent_t t1 = tm.begin(s);
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    c->timing.ms_total += ms;
+    for (auto &sp : tm.spans) {
+        float m = 0;
+        (void)hipEventElapsedTime(&m, sp.second.first, sp.second.second);
+        switch (sp.first) {
+        case 0: c->timing.ms_search += m; c->timing.n_search_launches++; break;
+        case 1: c->timing.ms_extend += m; c->timing.n_extend_launches++; break;
+        case 2: c->timing.ms_heavy += m; c->timing.n_heavy_launches++; break;
+        default: c->timing.ms_other += m; break;
+        }
+    }
+    return BK_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *bk_version(void) { return "biokanga_amd 0.1 (gfx950; reference biokanga 4.4.2)"; }
+
+const char *bk_strerror(int rc)
+{
+    switch (rc) {
+    case BK_OK: return "success";
+    case BK_ERR_INTERNAL: return "internal processing error (HIP failure or inconsistency)";
+    case BK_ERR_NODEVICE: return "no usable HIP device - this library has no CPU fallback";
+    case BK_ERR_PARAMS: return "parameter error";
+    case BK_ERR_MEM: return "unable to allocate memory";
+    case BK_ERR_NOTBIOSEQ: return "file exists but is not a biokanga suffix array file";
+    case BK_ERR_OPNFILE: return "unable to open file";
+    case BK_ERR_CREATEFILE: return "unable to create file";
+    case BK_ERR_FILEVER: return "file version error";
+    case BK_ERR_FILEACCESS: return "file access (seek/read/write) failed";
+    default: return "error";
+    }
+}
+
+int bk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p)
+{
+    if (!sfx_path) return BK_ERR_PARAMS;
+    bk_ctx *c = nullptr;
+    int rc = new_ctx(out, device_id, p, &c);
+    if (rc) return rc;
+    SfxFile f;
+    std::string err;
+    rc = sfx_open(sfx_path, f, &err);
+    if (rc) {
+        fprintf(stderr, "biokanga_amd: %s\n", err.c_str());
+        bk_ctx_destroy(c);
+        return rc;
+    }
+    c->dataset = f.dataset;
+    // stage the file image through HBM: bases and suffix array as they are on disk
+    uint8_t *d_seq = nullptr, *d_sa = nullptr;
+    auto cleanup = [&]() { free_dev(d_seq); free_dev(d_sa); };
+    if (hipMalloc(&d_seq, f.concat_len + 16) != hipSuccess || hipMalloc(&d_sa, f.concat_len * f.el_size) != hipSuccess) {
+        cleanup(); bk_ctx_destroy(c); return BK_ERR_MEM;
+    }
+    if (hipMemcpy(d_seq, f.seq, f.concat_len, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_sa, f.sa, f.concat_len * f.el_size, hipMemcpyHostToDevice) != hipSuccess) {
+        cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL;
+    }
+    rc = adopt_device_image(c, d_seq, f.concat_len, d_sa, (int)f.el_size);
+    cleanup();
+    if (rc) { bk_ctx_destroy(c); return rc; }
+    std::vector<bk_entry_info> ents(f.entries.size());
+    for (size_t i = 0; i < ents.size(); i++) {
+        ents[i].entry_id = f.entries[i].entry_id;
+        ents[i].seq_len = f.entries[i].seq_len;
+        ents[i].start_ofs = f.entries[i].start_ofs;
+        ents[i].end_ofs = f.entries[i].end_ofs;
+        memcpy(ents[i].name, f.entries[i].name, 81);
+    }
+    rc = finish_ctx(c, ents.data(), (uint32_t)ents.size());
+    if (rc) { bk_ctx_destroy(c); return rc; }
+    *out = c;
+    return BK_OK;
+}
+
+int bk_ctx_create_from_device(bk_ctx **out, const void *d_seq, uint64_t concat_len, const void *d_sa, int sfx_el_size,
+                              const bk_entry_info *entries, uint32_t n_entries, int device_id, const bk_align_params *p)
+{
+    if (!d_seq || !d_sa || !entries || !n_entries || !concat_len || (sfx_el_size != 4 && sfx_el_size != 5)) return BK_ERR_PARAMS;
+    bk_ctx *c = nullptr;
+    int rc = new_ctx(out, device_id, p, &c);
+    if (rc) return rc;
+    c->dataset = "device";
+    rc = adopt_device_image(c, (const uint8_t *)d_seq, concat_len, (const uint8_t *)d_sa, sfx_el_size);
+    if (!rc) rc = finish_ctx(c, entries, n_entries);
+    if (rc) { bk_ctx_destroy(c); return rc; }
+    *out = c;
+    return BK_OK;
+}
+
+void bk_ctx_destroy(bk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_ktab);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_small);
+    free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
+    free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bk_ctx_set_params(bk_ctx *c, const bk_align_params *p)
+{
+    if (!c || !p) return BK_ERR_PARAMS;
+    bk_align_params old = c->params;
+    c->params = *p;
+    if (c->params.max_ml == 0) c->params.max_ml = 1;
+    int rc = derive_cfg(c);
+    if (rc) { c->params = old; derive_cfg(c); return rc; }
+    (void)hipSetDevice(c->device);
+    return size_heavy_scratch(c);
+}
+
+int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return BK_ERR_PARAMS;
+    (void)hipSetDevice(c->device);
+    std::string n(name);
+    if (n == "heavy_thresh") {
+        int64_t old = c->cfg.heavy_thresh;
+        if (value < 0 || value > 100) return BK_ERR_PARAMS;
+        c->cfg.heavy_thresh = (int)value;     // 0 routes every call with a non-empty interval to k_heavy
+        return old;
+    }
+    if (n == "chunk_reads") {
+        int64_t old = c->chunk_reads;
+        if (value < 1 || value > (1LL << 30)) return BK_ERR_PARAMS;
+        c->chunk_reads = (uint32_t)value;
+        return old;
+    }
+    if (n == "kmer_bits" || n == "use_ktab") {
+        int64_t old = n == "use_ktab" ? c->use_ktab : c->ix.k;
+        if (n == "use_ktab") c->use_ktab = value ? 1 : 0;
+        else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
+        int rc = build_ktab(c);
+        return rc ? rc : old;
+    }
+    if (n == "max_read_len") {
+        int64_t old = c->max_read_len;
+        if (value < 16 || value > kMaxReadLenAbs) return BK_ERR_PARAMS;
+        c->max_read_len = (int)value;
+        int rc = size_heavy_scratch(c);
+        return rc ? rc : old;
+    }
+    return BK_ERR_PARAMS;
+}
+
+uint32_t bk_num_entries(const bk_ctx *c) { return c ? (uint32_t)c->entries.size() : 0; }
+int bk_get_entry(const bk_ctx *c, uint32_t idx, bk_entry_info *out)
+{
+    if (!c || !out || idx >= c->entries.size()) return BK_ERR_PARAMS;
+    *out = c->entries[idx];
+    return BK_OK;
+}
+const char *bk_dataset_name(const bk_ctx *c) { return c ? c->dataset.c_str() : ""; }
+uint64_t bk_concat_len(const bk_ctx *c) { return c ? c->ix.n : 0; }
+int bk_sfx_el_size(const bk_ctx *c) { return c ? (int)c->el_size : 0; }
+int bk_min_core_len(const bk_ctx *c) { return c ? c->cfg.min_core_len : 0; }
+
+int bk_align_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t nreads,
+                          void *d_out, void *stream, int sync)
+{
+    (void)sync;   // the phase loop reads active counts back, so the call always completes before returning
+    if (!c || (nreads && (!d_bases || !d_offs || !d_lens || !d_out))) return BK_ERR_PARAMS;
+    if (!nreads) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return align_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, nreads,
+                        (bk_hit *)d_out, s);
+}
+
+int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, bk_hit *out)
+{
+    if (!c || (nreads && (!bases || !offs || !lens || !out))) return BK_ERR_PARAMS;
+    if (!nreads) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // the reads need not be contiguous in `bases`: find the extent referenced
+    uint64_t lo = ~0ULL, hi = 0;
+    for (uint32_t i = 0; i < nreads; i++) {
+        if (lens[i] > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+        lo = std::min(lo, offs[i]);
+        hi = std::max(hi, offs[i] + lens[i]);
+    }
+    uint64_t nbytes = hi - lo;
+    if (nbytes + 16 > c->cap_in_bases) {
+        free_dev(c->d_in_bases);
+        c->d_in_bases = nullptr;
+        c->cap_in_bases = 0;
+        HIP_TRY(hipMalloc(&c->d_in_bases, nbytes + 16));
+        c->cap_in_bases = nbytes + 16;
+    }
+    if (nreads > c->cap_in_reads) {
+        free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
+        c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr;
+        c->cap_in_reads = 0;
+        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        c->cap_in_reads = nreads;
+    }
+    std::vector<uint64_t> rel(nreads);
+    for (uint32_t i = 0; i < nreads; i++) rel[i] = offs[i] - lo;
+    HIP_TRY(hipMemcpyAsync(c->d_in_bases, bases + lo, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_in_offs, rel.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = align_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, nreads, c->d_in_out, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
+    return BK_OK;
+}
+
+int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
+{
+    if (!c || !out) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3];
+    if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(h)));
+    return BK_OK;
+}
+
+int bk_get_timing(bk_ctx *c, bk_timing *out, int reset)
+{
+    if (!c || !out) return BK_ERR_PARAMS;
+    *out = c->timing;
+    if (reset) c->timing = bk_timing{};
+    return BK_OK;
+}
+
+int bk_seq_counts(bk_ctx *c, uint64_t *per_entry_hits, uint32_t n, int reset)
+{
+    if (!c || !per_entry_hits || n != c->entries.size()) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(per_entry_hits, c->d_seq_counts, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_seq_counts, 0, (size_t)n * 8));
+    return BK_OK;
+}
+
+int bk_build_sa_device(const void *d_seq, uint64_t concat_len, void *d_sa_out, int sfx_el_size, int device_id)
+{
+    if (!d_seq || !d_sa_out || !concat_len || (sfx_el_size != 4 && sfx_el_size != 5)) return BK_ERR_PARAMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BK_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(device_id));
+    return build_sa_device((const uint8_t *)d_seq, concat_len, d_sa_out, sfx_el_size, nullptr);
+}
+
+}  // extern "C"

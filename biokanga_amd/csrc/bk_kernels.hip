@@ -1,0 +1,756 @@
+// bk_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the `biokanga align` hot path.
+//
+//   k_pack_target   1 B/base target -> 4-bit packed words (index upload)
+//   k_split_sa5     5-byte suffix elements -> lo32 + hi8 arrays
+//   k_build_ktab    k-mer -> SA lower-bound table from the sorted suffix array
+//   k_prep_reads    N policy (Aligner.cpp:9041-9063), pack read + reverse complement (SeqTrans.cpp:458-512)
+//   k_search        K1: one lane per (read, strand, core): SA interval of the core
+//                   = LocateFirstExact (SfxArrayV2.cpp:7765) + the extent of the matching run
+//   k_extend        K2/K3: one lane per read: candidate walk in SA order, bounds + dedupe, Hamming
+//                   extension, best / next-best / instances state machine and classification of
+//                   LocateCoreMultiples (SfxArrayV2.cpp:5830-6261) for reads whose core intervals
+//                   are all short (no truncation possible)
+//   k_heavy         general wave-per-read form of the same call for everything else (repeat cores:
+//                   100-candidate copy-count cut-off, MaxIter, node cap), 64 candidates per step with
+//                   ballot prefix sums reproducing the reference's sequential order
+//
+// Integer / bit-compare work, HBM + latency bound: no MFMA anywhere.
+#include "bk_device.h"
+
+namespace bk {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ uint64_t nib16(const uint64_t *__restrict__ w, uint64_t pos)
+{
+    uint64_t i = pos >> 4;
+    unsigned s = (unsigned)(pos & 15) << 2;
+    uint64_t a = w[i];
+    if (s == 0) return a;
+    uint64_t b = w[i + 1];
+    return (a << s) | (b >> (64 - s));
+}
+
+__device__ __forceinline__ uint64_t top_mask(int nibs)   // mask keeping the first `nibs` (1..16) nibbles
+{
+    return nibs >= 16 ? ~0ULL : (~0ULL << (64 - 4 * nibs));
+}
+
+template <bool WIDE>
+__device__ __forceinline__ uint64_t sa_get(const DevIndex &ix, uint64_t i)
+{
+    uint64_t v = ix.sa_lo[i];
+    if (WIDE) v |= (uint64_t)ix.sa_hi[i] << 32;
+    return v;
+}
+
+// probe core (cl bases at read offset ofs; p0 = its first 16 nibbles, masked) vs the suffix at pos.
+// <0 / 0 / >0 exactly as the reference's compare loops (EOS in target makes the probe lower).
+__device__ __forceinline__ int cmp_core(const uint64_t *__restrict__ rdw, int ofs, int cl, uint64_t p0,
+                                        const uint64_t *__restrict__ tgt, uint64_t pos)
+{
+    uint64_t t0 = nib16(tgt, pos) & top_mask(cl);
+    if (p0 != t0) return p0 < t0 ? -1 : 1;
+    for (int i = 16; i < cl; i += 16) {
+        uint64_t m = top_mask(cl - i);
+        uint64_t p = nib16(rdw, ofs + i) & m;
+        uint64_t t = nib16(tgt, pos + i) & m;
+        if (p != t) return p < t ? -1 : 1;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ int find_entry(const DevIndex &ix, uint64_t t)
+{
+    int lo = 0, hi = (int)ix.n_ent - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        if (t < ix.ent_start[mid]) hi = mid - 1;
+        else if (t > ix.ent_end[mid]) lo = mid + 1;
+        else return mid;
+    }
+    return -1;
+}
+
+// Hamming distance of the whole read against the target window at t; stops once > limit
+__device__ __forceinline__ int hamming(const uint64_t *__restrict__ rdw, int len, const uint64_t *__restrict__ tgt,
+                                       uint64_t t, int limit)
+{
+    int mm = 0;
+    for (int i = 0; i < len; i += 16) {
+        uint64_t x = (nib16(rdw, i) ^ nib16(tgt, t + i)) & top_mask(len - i);
+        x = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+        mm += __popcll(x);
+        if (mm > limit) break;
+    }
+    return mm;
+}
+
+// 2-bit code of the first 16 nibbles (first base in the top 2 bits)
+__device__ __forceinline__ uint32_t squeeze2(uint64_t x)
+{
+    x &= 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+    return (uint32_t)x;
+}
+
+__device__ __forceinline__ uint64_t ktab_get(const DevIndex &ix, uint64_t c)
+{
+    return ix.ktab32 ? (uint64_t)ix.ktab32[c] : ix.ktab64[c];
+}
+
+// SA index range [lo, hi) that can contain suffixes starting with the core
+__device__ __forceinline__ void core_range(const DevIndex &ix, uint64_t p0, int cl, uint64_t &lo, uint64_t &hi)
+{
+    lo = 0;
+    hi = ix.n;
+    int k = ix.k;
+    if (k <= 0) return;
+    int kk = cl < k ? cl : k;
+    if (p0 & 0x4444444444444444ULL & top_mask(kk)) return;   // an N inside the indexed prefix
+    uint32_t code = squeeze2(p0);
+    uint64_t c_lo = (uint64_t)(code >> (32 - 2 * kk)) << (2 * (k - kk));
+    uint64_t c_hi = c_lo | ((1ULL << (2 * (k - kk))) - 1);
+    lo = ktab_get(ix, c_lo);
+    hi = ktab_get(ix, c_hi + 1);
+}
+
+// lower bound (LocateFirstExact) + length of the matching run, capped at `cap`
+template <bool WIDE>
+__device__ __forceinline__ void search_core(const DevIndex &ix, const uint64_t *__restrict__ rdw, int ofs, int cl,
+                                            uint64_t cap, uint64_t &first, uint64_t &count)
+{
+    uint64_t p0 = nib16(rdw, ofs) & top_mask(cl);
+    uint64_t lo, hi;
+    core_range(ix, p0, cl, lo, hi);
+    uint64_t end = hi;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        int c = cmp_core(rdw, ofs, cl, p0, ix.tgt4, sa_get<WIDE>(ix, mid));
+        if (c > 0) lo = mid + 1;
+        else hi = mid;
+    }
+    first = lo;
+    count = 0;
+    if (lo >= end) return;
+    if (cmp_core(rdw, ofs, cl, p0, ix.tgt4, sa_get<WIDE>(ix, lo)) != 0) return;
+    // gallop over the run of matches, then bisect its end
+    uint64_t limit = end - lo < cap ? end : lo + cap;    // exclusive
+    uint64_t cur = lo, step = 1;
+    while (cur + step < limit && cmp_core(rdw, ofs, cl, p0, ix.tgt4, sa_get<WIDE>(ix, cur + step)) == 0) {
+        cur += step;
+        step <<= 1;
+    }
+    uint64_t l2 = cur + 1, h2 = cur + step < limit ? cur + step : limit;
+    while (l2 < h2) {
+        uint64_t mid = l2 + ((h2 - l2) >> 1);
+        if (cmp_core(rdw, ofs, cl, p0, ix.tgt4, sa_get<WIDE>(ix, mid)) == 0) l2 = mid + 1;
+        else h2 = mid;
+    }
+    count = l2 - lo;
+}
+
+// classification at the end of LocateCoreMultiples for a call that started from the fresh state
+// (SfxArrayV2.cpp:6238-6261); init = MaxTotMM + MMDelta + 1
+__device__ __forceinline__ int classify(int low_inst, int low_mm, int nxt, int init, int mm_delta, int max_hits)
+{
+    if (low_inst == 0 && low_mm == init) return BK_HR_NONE;
+    if (low_inst >= 1 && (nxt - low_mm) < mm_delta) return BK_HR_MMDELTA;
+    if (low_inst > max_hits) return BK_HR_HITINSTS;
+    return BK_HR_HITS;
+}
+
+// HitRslt -> tsReadHit fields, default MLMode (Aligner.cpp:9241,9311-9479)
+__device__ __forceinline__ void write_result(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t r,
+                                             int len, int rslt, int low_inst, int low_mm, int nxt, uint64_t hit_left,
+                                             int hit_ent, int hit_strand)
+{
+    bk_hit h;
+    h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0;
+    h.rslt = (uint8_t)rslt; h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0;
+    h.num_hits = 0; h.mismatches = 0; h.flags = 0;
+    if (low_inst > cfg.max_hits) low_inst = cfg.max_hits + 1;
+    switch (rslt) {
+    case BK_HR_HITS:
+        if (low_inst == 1) {
+            h.nar = BK_NAR_ACCEPTED;
+            h.num_hits = 1;
+            h.strand = (uint8_t)hit_strand;
+            h.chrom_id = ix.ent_id[hit_ent];
+            h.match_loci = (uint32_t)(hit_left - ix.ent_start[hit_ent]);
+            h.match_len = (uint16_t)len;
+            h.mismatches = (uint8_t)low_mm;
+            atomicAdd(&b.seq_counts[hit_ent], 1ULL);
+        } else
+            h.nar = BK_NAR_MULTIALIGN;
+        break;
+    case BK_HR_MMDELTA:
+        h.nar = BK_NAR_MMDELTA;
+        h.match_len = (uint16_t)len;
+        break;
+    case BK_HR_HITINSTS:
+        h.nar = BK_NAR_MULTIALIGN;
+        h.match_len = (uint16_t)len;
+        break;
+    default:
+        break;
+    }
+    h.low_hit_instances = (int16_t)low_inst;
+    h.low_mm = (int8_t)low_mm;
+    h.nxt_low_mm = (int8_t)nxt;
+    b.out[r] = h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index upload kernels
+
+__global__ void k_pack_target(const uint8_t *__restrict__ seq, uint64_t n, uint64_t *__restrict__ tgt4, uint64_t nwords)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; w < nwords; w += stride) {
+        uint64_t base = w << 4;
+        uint64_t v = 0;
+        if (base + 16 <= n) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(seq + base);
+            uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) v = (v << 4) | ((d[j] >> (8 * k)) & 0x0f);
+        } else {
+            for (int k = 0; k < 16; k++) {
+                uint64_t p = base + k;
+                uint64_t nb = p < n ? (uint64_t)(seq[p] & 0x0f) : 7ULL;
+                v = (v << 4) | nb;
+            }
+        }
+        tgt4[w] = v;
+    }
+}
+
+__global__ void k_split_sa5(const uint8_t *__restrict__ sa5, uint64_t n, uint32_t *__restrict__ lo, uint8_t *__restrict__ hi)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint8_t *p = sa5 + i * 5;
+        lo[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        hi[i] = p[4];
+    }
+}
+
+// bucket of a suffix = 2-bit code of its first k bases; a suffix that meets N/EOS after j < k bases
+// sorts after every real k-mer sharing those j bases, i.e. in the bucket "prefix padded with T"
+__device__ __forceinline__ uint64_t suffix_bucket(const uint64_t *__restrict__ tgt, uint64_t pos, int k)
+{
+    uint64_t w = nib16(tgt, pos);
+    uint64_t bad = w & 0x4444444444444444ULL;           // N(4) and EOS(7) have bit 2 set
+    if (bad) {
+        int j = __clzll(bad) >> 2;                       // first offending nibble
+        if (j < 16) w |= (~0ULL >> (4 * j)) & 0x3333333333333333ULL;   // pad with T from there on
+    }
+    return (uint64_t)(squeeze2(w) >> (32 - 2 * k));
+}
+
+template <bool WIDE, typename TabT>
+__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k)
+{
+    uint64_t n = ix.n;
+    uint64_t ncodes = 1ULL << (2 * k);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i <= n; i += stride) {
+        // entries (prev, cur] receive i; prev = bucket(i-1) (or -1), cur = bucket(i) (or ncodes at i == n)
+        uint64_t cur = i < n ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), k) : ncodes;
+        uint64_t from = i > 0 ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i - 1), k) + 1 : 0;
+        for (uint64_t c = from; c <= cur; c++) tab[c] = (TabT)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prep_reads: one lane per read
+
+__global__ void k_prep_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act, uint32_t *__restrict__ act_cnt,
+                             uint32_t *__restrict__ cmax)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_reads) return;
+    int len = (int)b.lens[r];
+    const uint8_t *s = b.bases + b.offs[r];
+    bk_hit h;
+    h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
+    h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
+    // N policy, Aligner.cpp:9041-9063
+    int max_ns_seq = 0, num_ns = 0, i;
+    if (cfg.max_ns) {
+        max_ns_seq = (len * cfg.max_ns) / 100;
+        if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
+    }
+    uint64_t *fw = b.rd4 + (uint64_t)r * 2 * b.wpr;
+    uint64_t *rc = fw + b.wpr;
+    uint64_t acc = 0;
+    for (i = 0; i < len; i++) {
+        uint8_t v = s[i] & 0x07;
+        if (v > 4) break;
+        if (v == 4 && ++num_ns > max_ns_seq) break;
+        acc = (acc << 4) | v;
+        if ((i & 15) == 15) { fw[i >> 4] = acc; acc = 0; }
+    }
+    if (i != len) {
+        h.nar = BK_NAR_NS;
+        b.out[r] = h;
+        return;
+    }
+    b.out[r] = h;
+    int nw = (len + 15) >> 4;
+    if (len & 15) fw[len >> 4] = acc << (4 * (16 - (len & 15)));
+    for (int w = nw; w < (int)b.wpr; w++) fw[w] = 0;
+    // reverse complement: A<->T, C<->G, N stays (SeqTrans.cpp:458-512)
+    acc = 0;
+    for (i = 0; i < len; i++) {
+        uint8_t v = s[len - 1 - i] & 0x07;
+        v = v < 4 ? (uint8_t)(3 - v) : v;
+        acc = (acc << 4) | v;
+        if ((i & 15) == 15) { rc[i >> 4] = acc; acc = 0; }
+    }
+    if (len & 15) rc[len >> 4] = acc << (4 * (16 - (len & 15)));
+    for (int w = nw; w < (int)b.wpr; w++) rc[w] = 0;
+
+    ReadPlan p = make_plan(len, cfg);
+    if (p.n_phases > 0) {
+        int mm, cl, cd, ofs[1];
+        phase_params(p, cfg, 0, mm, cl, cd);
+        int nc = core_offsets(len, cl, cd, p.max_slides, ofs, 0);
+        if (nc <= kMaxCoresFast) atomicMax(cmax, (uint32_t)nc);
+        act[atomicAdd(act_cnt, 1u)] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: SA interval search, one lane per (active read, strand, core)
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                uint32_t n_act, int phase, int cmax, int nstr)
+{
+    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t per_read = (uint32_t)(nstr * cmax);
+    uint64_t a = tid / per_read;
+    if (a >= n_act) return;
+    uint32_t rem = (uint32_t)(tid - a * per_read);
+    int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
+    uint32_t r = act[a];
+    int len = (int)b.lens[r];
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd;
+    phase_params(p, cfg, phase, mm, cl, cd);
+    // offset of core c by the sliding rule
+    int cur = cd, o = 0, n = 0, my_ofs = -1;
+    while (n < p.max_slides && o <= len - cl && cur > cl / 3) {
+        if (o + cl + cur > len) cur = len - (o + cl);
+        if (n == c) my_ofs = o;
+        n++;
+        o += cur;
+    }
+    if (my_ofs < 0 || n > kMaxCoresFast) return;
+    int strand = cfg.align_strand == 2 ? 1 : si;
+    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+    uint64_t first, count;
+    search_core<WIDE>(ix, rdw, my_ofs, cl, (uint64_t)cfg.heavy_thresh + 1, first, count);
+    uint64_t slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
+    b.iv_first[slot] = first;
+    b.iv_n[slot] = (uint32_t)count;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2/K3: candidate walk + Hamming extension + classification, one lane per active read
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                uint32_t n_act, int phase, uint32_t *__restrict__ next_act,
+                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
+                                                uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ cmax_next)
+{
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    if (a < n_act) {
+        uint32_t r = act[a];
+        int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd, ofs[kMaxCoresFast];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        int nc = core_offsets(len, cl, cd, p.max_slides, ofs, kMaxCoresFast);
+        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        bool is_heavy = nc > kMaxCoresFast;
+        if (!is_heavy)
+            for (int st = s0; st <= s1; st++)
+                for (int c = 0; c < nc; c++)
+                    if (b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+        if (is_heavy) {
+            heavy[atomicAdd(heavy_cnt, 1u)] = r;
+        } else {
+            n_lcm = 1;
+            const int init = mm + cfg.mm_delta + 1;
+            int low_inst = 0, low_mm = init, nxt = init;
+            uint64_t hit_left = 0;
+            int hit_ent = -1, hit_strand = '?';
+            bool done = false;
+            for (int st = s0; st <= s1 && !done; st++) {
+                const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
+                for (int c = 0; c < nc && !done; c++) {
+                    n_search++;
+                    uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + c;
+                    uint32_t n = b.iv_n[slot];
+                    uint64_t first = b.iv_first[slot];
+                    for (uint32_t j = 0; j < n; j++) {
+                        uint64_t loci = sa_get<WIDE>(ix, first + j);
+                        if (loci < (uint64_t)ofs[c]) continue;
+                        uint64_t t = loci - (uint64_t)ofs[c];
+                        int e = find_entry(ix, t);
+                        if (e < 0 || t + (uint64_t)len - 1 > ix.ent_end[e]) continue;
+                        // already processed through an earlier core of this strand pass?  (no core
+                        // interval is truncated here, so "processed" == "that core matches at t")
+                        bool dup = false;
+                        for (int c2 = 0; c2 < c && !dup; c2++) {
+                            uint64_t q0 = nib16(rdw, ofs[c2]) & top_mask(cl);
+                            dup = cmp_core(rdw, ofs[c2], cl, q0, ix.tgt4, t + (uint64_t)ofs[c2]) == 0;
+                        }
+                        if (dup) continue;
+                        n_cand++;
+                        int lim = mm < nxt - 1 ? mm : nxt - 1;
+                        int cm = hamming(rdw, len, ix.tgt4, t, lim);
+                        if (cm > lim) continue;
+                        if (cm < low_mm) {
+                            low_inst = 1; nxt = low_mm; low_mm = cm;
+                            hit_left = t; hit_ent = e; hit_strand = st ? '-' : '+';
+                        } else if (cm == low_mm)
+                            low_inst++;
+                        else
+                            nxt = cm;
+                        if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
+                    }
+                }
+            }
+            int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+            if (rslt != BK_HR_NONE)
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand);
+            else if (phase + 1 < p.n_phases) {
+                int mm2, cl2, cd2, dummy[1];
+                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
+                next_act[atomicAdd(next_cnt, 1u)] = r;
+            }
+        }
+    }
+    // counters: wave reduce, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_search += __shfl_down(n_search, off);
+        n_cand += __shfl_down(n_cand, off);
+        n_lcm += __shfl_down(n_lcm, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// general wave-per-read form of one LocateCoreMultiples call
+
+__device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask)
+{
+    return (key * 2654435761u) & mask;      // table size is a power of two
+}
+
+__device__ __forceinline__ bool htab_contains(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) return false;
+        if (v == mine) return true;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) {
+            unsigned long long old = atomicCAS(&tab[h], v, mine);
+            if (old == v) return;
+            continue;                       // somebody else took the slot: look at it again
+        }
+        if (v == mine) return;
+        h = (h + 1) & mask;
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
+                                               const uint32_t *__restrict__ list, uint32_t n_list, int phase,
+                                               uint32_t *__restrict__ cursor, uint32_t *__restrict__ next_act,
+                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave_slot >= hs.n_slots) return;
+    unsigned long long *tab = hs.htab + (uint64_t)wave_slot * hs.tab_size;
+    const uint32_t tmask = hs.tab_size - 1;
+    uint32_t epoch = hs.slot_epoch[wave_slot];
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(cursor, 1u);
+        item = __shfl(item, 0);
+        if (item >= n_list) break;
+        uint32_t r = list[item];
+        int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd;
+        phase_params(p, cfg, phase, mm, cl, cd);
+        n_lcm++;
+        const int init = mm + cfg.mm_delta + 1;
+        int low_inst = 0, low_mm = init, nxt = init;
+        uint64_t hit_left = 0;
+        int hit_ent = -1, hit_strand = '?';
+        bool done = false;
+        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        for (int st = s0; st <= s1 && !done; st++) {
+            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
+            // new dedupe set for this strand pass (memset of the hash heads, SfxArrayV2.cpp:5834)
+            epoch++;
+            if (epoch == 0) {               // wrapped: really clear the table
+                for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
+                epoch = 1;
+            }
+            uint32_t nodes = 0;
+            // walk the cores in order; every 64 cores the lanes search one core each
+            int cur = cd, o = 0, ci = 0;
+            uint64_t my_first = 0, my_n = 0;
+            int my_ofs = 0;
+            while (ci < p.max_slides && o <= len - cl && cur > cl / 3 && nodes < kNodeCap && !done) {
+                if ((ci & 63) == 0) {
+                    // replay the sliding rule from here for the next 64 cores; lane l takes core ci + l
+                    int cur2 = cur, o2 = o, c2 = ci;
+                    bool have = false;
+                    while (c2 < ci + 64 && c2 < p.max_slides && o2 <= len - cl && cur2 > cl / 3) {
+                        if (o2 + cl + cur2 > len) cur2 = len - (o2 + cl);
+                        if (c2 - ci == lane) { my_ofs = o2; have = true; }
+                        c2++;
+                        o2 += cur2;
+                    }
+                    my_first = 0; my_n = 0;
+                    if (have) search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, my_first, my_n);
+                }
+                if (o + cl + cur > len) cur = len - (o + cl);
+                const int ofs = o;
+                const uint64_t first = __shfl(my_first, ci & 63);
+                const uint64_t n = __shfl(my_n, ci & 63);
+                n_search++;
+                // candidate walk of this core, 64 SA elements per step
+                uint32_t iter = 0;
+                bool copies_checked = false;
+                for (uint64_t j0 = 0; j0 < n && !done; j0 += 64) {
+                    uint64_t j = j0 + lane;
+                    bool active = j < n;
+                    uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
+                    uint64_t t = loci - (uint64_t)ofs;
+                    int e = -1;
+                    bool valid = active && loci >= (uint64_t)ofs;
+                    if (valid) {
+                        e = find_entry(ix, t);
+                        valid = e >= 0 && t + (uint64_t)len - 1 <= ix.ent_end[e];
+                    }
+                    uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
+                    bool isnew = valid && !htab_contains(tab, tmask, epoch, key);
+                    uint64_t newmask = __ballot(isnew);
+                    uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
+                    uint32_t iter_before = iter + pre;
+                    uint32_t nodes_before = nodes + pre;
+                    // loop-top conditions of the reference's while() for candidate j (:5857-5875)
+                    bool stop = active && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
+                    uint64_t cutoff = n;                               // first candidate index NOT processed
+                    uint64_t stopmask = __ballot(stop);
+                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                    if (!copies_checked) {
+                        bool chk = active && j > 0 && iter_before == 100;
+                        uint64_t chkmask = __ballot(chk);
+                        if (chkmask) {
+                            uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                            if (jc < cutoff) {
+                                copies_checked = true;
+                                uint64_t num_copies = n - jc + 2;      // 1 + LastTargIdx - TargIdx, :5871-5872
+                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                            }
+                        }
+                    }
+                    bool proc = active && j < cutoff && isnew;
+                    if (proc) htab_insert(tab, tmask, epoch, key);
+                    int cm = 127;
+                    if (proc) {
+                        int lim = mm < nxt - 1 ? mm : nxt - 1;
+                        cm = hamming(rdw, len, ix.tgt4, t, lim);
+                        if (cm > lim) cm = 127;
+                    }
+                    bool acc = cm != 127;
+                    // early exit once MaxHits+1 exact instances have been seen, in order (:6206)
+                    uint64_t keep = ~0ULL;
+                    uint64_t zmask = __ballot(acc && cm == 0);
+                    int zc0 = low_mm == 0 ? low_inst : 0;
+                    if (zmask && zc0 + __popcll(zmask) > cfg.max_hits) {
+                        int need = cfg.max_hits + 1 - zc0;
+                        uint64_t z = zmask;
+                        for (int q = 1; q < need; q++) z &= z - 1;
+                        int cut_lane = __ffsll((unsigned long long)z) - 1;
+                        keep = cut_lane >= 63 ? ~0ULL : ((2ULL << cut_lane) - 1);
+                        done = true;
+                    }
+                    uint64_t procmask = __ballot(proc) & keep;
+                    uint32_t nproc = (uint32_t)__popcll(procmask);
+                    iter += nproc;
+                    nodes += nproc;
+                    n_cand += (lane == 0) ? nproc : 0;
+                    acc = acc && ((keep >> lane) & 1);
+                    uint64_t accmask = __ballot(acc);
+                    if (accmask) {
+                        int v = acc ? cm : 127;
+                        int bmin = v;
+                        for (int off = 32; off > 0; off >>= 1) { int w = __shfl_xor(bmin, off); bmin = w < bmin ? w : bmin; }
+                        int v2 = (acc && cm > bmin) ? cm : 127;
+                        int bsec = v2;
+                        for (int off = 32; off > 0; off >>= 1) { int w = __shfl_xor(bsec, off); bsec = w < bsec ? w : bsec; }
+                        uint64_t minmask = __ballot(acc && cm == bmin);
+                        int cnt = __popcll(minmask);
+                        int fl = __ffsll((unsigned long long)minmask) - 1;
+                        if (bmin < low_mm) {
+                            nxt = low_mm < bsec ? low_mm : bsec;
+                            low_mm = bmin;
+                            low_inst = cnt;
+                            hit_left = __shfl(t, fl);
+                            hit_ent = __shfl(e, fl);
+                            hit_strand = st ? '-' : '+';
+                        } else if (bmin == low_mm) {
+                            low_inst += cnt;
+                            if (bsec < nxt) nxt = bsec;
+                        } else if (bmin < nxt)
+                            nxt = bmin;
+                    }
+                    if (cutoff < j0 + 64) break;                    // core abandoned / iteration limit
+                }
+                ci++;
+                o += cur;
+            }
+        }
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+        if (lane == 0) {
+            if (rslt != BK_HR_NONE)
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand);
+            else if (phase + 1 < p.n_phases) {
+                int mm2, cl2, cd2, dummy[1];
+                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
+                next_act[atomicAdd(next_cnt, 1u)] = r;
+            }
+        }
+    }
+    if (lane == 0) {
+        hs.slot_epoch[wave_slot] = epoch;
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+    }
+}
+
+__global__ void k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_t *__restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = i < n ? lens[i] : 0;
+    for (int off = 32; off > 0; off >>= 1) { uint32_t w = __shfl_down(v, off); v = w > v ? w : v; }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from bk_engine.cpp through plain function pointers-free C++ interface)
+
+void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s)
+{
+    uint64_t blocks = (nwords + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_pack_target, dim3((unsigned)blocks), dim3(256), 0, s, seq, n, tgt4, nwords);
+}
+
+void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s)
+{
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_split_sa5, dim3((unsigned)blocks), dim3(256), 0, s, sa5, n, lo, hi);
+}
+
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s)
+{
+    uint64_t blocks = (ix.n + 1 + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    bool wide = ix.sa_hi != nullptr;
+    if (wide) {
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k);
+        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k);
+    } else {
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k);
+        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k);
+    }
+}
+
+void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_max_len, dim3((n + 255) / 256), dim3(256), 0, s, lens, n, out);
+}
+
+void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prep_reads, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
+}
+
+void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                   int phase, int cmax, int nstr, hipStream_t s)
+{
+    uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
+    else hipLaunchKernelGGL(k_search<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
+}
+
+void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                   int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
+                   uint32_t *cmax_next, hipStream_t s)
+{
+    unsigned blocks = (n_act + 255) / 256;
+    if (ix.sa_hi) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
+}
+
+void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                  uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
+                  hipStream_t s)
+{
+    uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
+    unsigned blocks = (waves + 3) / 4;
+    if (ix.sa_hi) hipLaunchKernelGGL(k_heavy<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
+    else hipLaunchKernelGGL(k_heavy<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
+}
+
+}  // namespace bk

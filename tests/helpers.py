@@ -205,3 +205,53 @@ def parse_m0_csv(path):
             out[t[13].strip('"')] = dict(read_id=int(t[0]), chrom=t[3].strip('"'), start=int(t[4]), end=int(t[5]),
                                          length=int(t[6]), strand=t[7].strip('"'), mismatches=int(t[11]))
     return out
+
+
+def gen_hash16(name):
+    """CUtility::GenHash16 (libbiokanga/Utility.cpp:17-37)"""
+    if not name:
+        return 0
+    h = 19937
+    for ch in name:
+        h = ((h ^ ord(ch.lower())) * 3119) & 0xFFFFFFFF
+        if h & 0x80000000:
+            h -= 1 << 32
+        h ^= (h >> 13)
+        h &= 0xFFFF
+    return h or 19937
+
+
+def write_sfx(path, dataset, entries, seq, sa, el_size=4):
+    """Test-side writer of the reference .sfx layout (header 1224 B pack(4), block 20 B + bases + SA,
+    entries 8 B + 111 B each; SfxArrayV2.h:79-104,174-187).  entries: [(name, seq_len)], seq already
+    concatenated with EOS terminators, sa uint32 (el_size 4) or uint64 values (el_size 5)."""
+    import struct
+    n = len(seq)
+    hdr = bytearray(1224)
+    hdr[0:4] = b"sfx5"
+    struct.pack_into("<iI", hdr, 4, 5, 0)
+    blk_size = 20 + n + n * el_size
+    ent_size = 8 + 111 * len(entries)
+    file_len = 1224 + blk_size + ent_size
+    struct.pack_into("<QQIIQQ", hdr, 12, file_len, 1224 + blk_size, ent_size, 1, blk_size, 1224)
+    ds = dataset.encode()[:80]
+    hdr[52:52 + len(ds)] = ds
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(struct.pack("<IIQI", 1, len(entries), n, el_size))
+        f.write(np.ascontiguousarray(seq, dtype=np.uint8).tobytes())
+        if el_size == 4:
+            f.write(np.ascontiguousarray(sa, dtype="<u4").tobytes())
+        else:
+            v = np.ascontiguousarray(sa, dtype="<u8")
+            b = v.view(np.uint8).reshape(-1, 8)[:, :5]
+            f.write(np.ascontiguousarray(b).tobytes())
+        f.write(struct.pack("<II", len(entries), len(entries)))
+        ofs = 0
+        for i, (name, slen) in enumerate(entries):
+            nm = name.encode()[:80]
+            rec = struct.pack("<II", i + 1, 1) + nm + b"\0" * (81 - len(nm)) + \
+                struct.pack("<HIQQ", gen_hash16(name), slen, ofs, ofs + slen - 1)
+            assert len(rec) == 111
+            f.write(rec)
+            ofs += slen + 1

@@ -1,0 +1,188 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(a) the golden outputs of the real reference and (b) the CPU oracle, bit-exact on every bk_hit field."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import helpers
+from test_oracle_golden import RUNS, MIN_LEN, check_hits_against_sam, chrom_names_from_hdr, expected_from_sam
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm",
+          "nxt_low_mm", "num_hits", "mismatches"]
+
+
+def _bk():
+    import biokanga_amd
+    return biokanga_amd
+
+
+def assert_hits_equal(got, exp, names=None):
+    for f in FIELDS:
+        if not np.array_equal(got[f], exp[f]):
+            bad = np.nonzero(got[f] != exp[f])[0]
+            i = int(bad[0])
+            raise AssertionError(f"field {f}: {len(bad)} reads differ; first idx {i} "
+                                 f"({names[i] if names else ''}): got {got[i]} exp {exp[i]}")
+
+
+def load_fixture(golden_tmp, fixture, tag="s3"):
+    d = golden_tmp[fixture]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    keep = helpers.filter_reads_by_len(names, bases, offs, lens, MIN_LEN.get(tag, 50), 500)
+    return d, names, bases, offs, lens, keep
+
+
+@pytest.mark.parametrize("fixture,tag", [(f, t) for f in RUNS for t in RUNS[f]])
+def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, tag)
+    kw = RUNS[fixture][tag]
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+        hits = al.align(bases, offs[keep], lens[keep])
+        ctr = al.counters()
+    hdr, recs = expected_from_sam(fixture, tag)
+    check_hits_against_sam(names, lens, hits, recs, chrom_names_from_hdr(hdr), keep)
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, octr = sfx.align(bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    assert_hits_equal(hits, exp, [names[i] for i in keep])
+    # the counters behind the algorithmic-bytes figure are the reference algorithm's own counts
+    assert ctr["n_search"] == octr.n_search
+    assert ctr["n_cand"] == octr.n_cand
+    assert ctr["n_lcm_calls"] == octr.n_lcm_calls
+    sfx.close()
+
+
+@pytest.mark.parametrize("fixture", ["basic", "repeat"])
+@pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("use_ktab", 0), ("kmer_bits", 4),
+                                  ("kmer_bits", 12), ("chunk_reads", 333)])
+def test_paths_agree(golden_tmp, fixture, knob):
+    """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
+    chunking does not matter."""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture)
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align(bases, offs[keep], lens[keep])
+        c0 = al.counters(reset=True)
+        al.tune(*knob)
+        got = al.align(bases, offs[keep], lens[keep])
+        c1 = al.counters()
+    assert_hits_equal(got, ref, [names[i] for i in keep])
+    for k in ("n_search", "n_cand", "n_lcm_calls"):
+        assert c0[k] == c1[k], (k, c0, c1)
+    if knob == ("heavy_thresh", 0):
+        # every call with at least one non-empty core interval went through the wave-per-read kernel
+        assert c1["n_heavy"] > c0["n_heavy"] and c1["n_heavy"] >= np.count_nonzero(ref["rslt"] != 0)
+
+
+def test_seq_counts_and_empty(golden_tmp):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic")
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        hits = al.align(bases, offs[keep], lens[keep])
+        counts = al.seq_counts(reset=True)
+        ents = al.entries()
+        assert [e["name"].decode() for e in ents] == ["chrA", "chrB"]
+        for k, e in enumerate(ents):
+            assert counts[k] == np.count_nonzero((hits["nar"] == 1) & (hits["chrom_id"] == e["entry_id"]))
+        assert al.seq_counts().sum() == 0
+        # empty batch is a no-op
+        out = al.align(np.zeros(0, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+        assert len(out) == 0
+        # reads longer than the 2000 bp limit are refused, not truncated
+        with pytest.raises(bk.BkError):
+            al.align(np.zeros(2100, np.uint8), np.zeros(1, np.uint64), np.array([2100], np.uint32))
+
+
+def test_device_resident_batch_and_sa_builder(golden_tmp):
+    """bk_align_batch_device over torch-owned HBM buffers; bk_build_sa_device reproduces the suffix
+    array the reference's qsort wrote into the golden .sfx."""
+    import torch
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic")
+    raw = open(os.path.join(d, "genome.sfx"), "rb").read()
+    blk_ofs = struct.unpack_from("<Q", raw, 44)[0]
+    n = struct.unpack_from("<Q", raw, blk_ofs + 8)[0]
+    seq = np.frombuffer(raw, dtype=np.uint8, count=n, offset=blk_ofs + 20)
+    sa = np.frombuffer(raw, dtype="<u4", count=n, offset=blk_ofs + 20 + n)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq.copy()).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    torch.cuda.synchronize()
+    got_sa = d_sa.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_sa, sa)
+
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align(bases, offs[keep], lens[keep])
+        ents = al.entries()
+    # context from the device-resident image + device-resident reads
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=d_seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(),
+                    el_size=4, entries=ents) as al2:
+        t_bases = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+        t_offs = torch.from_numpy(offs[keep].astype(np.int64)).to(dev)
+        t_lens = torch.from_numpy(lens[keep].astype(np.int32)).to(dev)
+        t_out = torch.zeros(len(keep) * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        al2.align_device(t_bases.data_ptr(), t_offs.data_ptr(), t_lens.data_ptr(), len(keep), t_out.data_ptr())
+        got = t_out.cpu().numpy().view(bk.HIT_DTYPE)
+    assert_hits_equal(got, ref)
+
+
+def _synth_case(seed, n_genome, n_reads, read_len, max_e):
+    rng = np.random.default_rng(seed)
+    # two sequences with a planted repeat family so multi-loci / truncation paths trigger
+    g = rng.integers(0, 4, n_genome, dtype=np.uint8)
+    fam = rng.integers(0, 4, 60, dtype=np.uint8)
+    for p in rng.integers(0, n_genome - 100, 300):
+        g[p:p + 60] = fam
+    cut = n_genome // 2
+    seq = np.concatenate([g[:cut], [7], g[cut:], [7]]).astype(np.uint8)
+    ents = np.zeros(2, dtype=_bk().ENTRY_DTYPE)
+    ents[0] = (1, cut, 0, cut - 1, b"s1", b"")
+    ents[1] = (2, n_genome - cut, cut + 1, n_genome, b"s2", b"")
+    starts = rng.integers(0, n_genome - read_len, n_reads)
+    reads = np.zeros((n_reads, read_len), dtype=np.uint8)
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    for i, st in enumerate(starts):
+        r = g[st:st + read_len].copy()
+        e = int(rng.integers(0, max_e + 1))
+        for q in rng.choice(read_len, e, replace=False):
+            r[q] = (r[q] + rng.integers(1, 4)) % 4
+        if rng.integers(0, 2):
+            r = comp[r[::-1]]
+        if rng.integers(0, 40) == 0:
+            r[int(rng.integers(0, read_len))] = 4
+        reads[i] = r
+    return seq, ents, reads
+
+
+@pytest.mark.parametrize("read_len,max_subs", [(100, 3), (150, 5), (64, 10)])
+def test_synthetic_parity_vs_oracle(tmp_path, read_len, max_subs):
+    """index built on the GPU -> .sfx written in the reference's format -> oracle and HIP path agree"""
+    import torch
+    bk = _bk()
+    seq, ents, reads = _synth_case(11 + read_len, 300000, 20000, read_len, 6)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    path = str(tmp_path / "synth.sfx")
+    helpers.write_sfx(path, "synth", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = (np.arange(nreads, dtype=np.uint64) * read_len)
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    with bk.Aligner(path, bk.AlignParams(max_subs=max_subs)) as al:
+        got = al.align(bases, offs, lens)
+        ctr = al.counters()
+    o = helpers.OracleSfx(path)
+    exp, octr = o.align(bases, offs, lens, helpers.make_params(max_subs=max_subs), nthreads=8)
+    assert_hits_equal(got, exp)
+    assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
+    assert np.count_nonzero(got["nar"] == 1) > nreads // 3
+    o.close()
