@@ -76,6 +76,13 @@ def load_library():
     if not os.path.exists(p):
         raise ImportError(f"{p} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C biokanga_amd/csrc). There is no CPU fallback.")
+    # PyTorch bundles its own HIP runtime under the same SONAME (libamdhip64.so.7).  Two copies of
+    # the runtime in one process do not work ("No HIP GPUs are available" in whichever initialises
+    # second), so when torch is installed it is imported FIRST and our library binds to its copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(p)
     vp, i32, u32, u64, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64
     lib.bk_version.restype = ctypes.c_char_p

@@ -20,6 +20,7 @@ void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                    int phase, int cmax, int nstr, hipStream_t s);
@@ -181,8 +182,10 @@ int size_heavy_scratch(bk_ctx *c)
     c->hs = HeavyScratch{};
     HIP_TRY(hipMalloc(&c->hs.htab, (size_t)slots * ts * 8));
     HIP_TRY(hipMalloc(&c->hs.slot_epoch, (size_t)slots * 4));
-    HIP_TRY(hipMemsetAsync(c->hs.htab, 0, (size_t)slots * ts * 8, c->stream));
+    launch_fill_u64(c->hs.htab, (uint64_t)slots * ts, 0ULL, c->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(c->hs.slot_epoch, 0, (size_t)slots * 4, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->hs.tab_size = ts;
     c->hs.n_slots = slots;
     return BK_OK;
@@ -373,6 +376,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
+        if (getenv("BK_DEBUG"))
+            fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, hm[1], hm[3]);
         n_act = hm[1];
         cmax = (int)hm[3];
         cur ^= 1;

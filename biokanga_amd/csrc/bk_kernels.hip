@@ -24,12 +24,13 @@ namespace bk {
 
 __device__ __forceinline__ uint64_t nib16(const uint64_t *__restrict__ w, uint64_t pos)
 {
+    // 16 nibbles starting at base position pos.  Both words are always loaded (every array is
+    // padded by at least one word) - straight-line code, no exec-masked second load.
     uint64_t i = pos >> 4;
     unsigned s = (unsigned)(pos & 15) << 2;
     uint64_t a = w[i];
-    if (s == 0) return a;
     uint64_t b = w[i + 1];
-    return (a << s) | (b >> (64 - s));
+    return (a << s) | ((b >> 1) >> (63 - s));
 }
 
 __device__ __forceinline__ uint64_t top_mask(int nibs)   // mask keeping the first `nibs` (1..16) nibbles
@@ -167,12 +168,13 @@ __device__ __forceinline__ int classify(int low_inst, int low_mm, int nxt, int i
 // HitRslt -> tsReadHit fields, default MLMode (Aligner.cpp:9241,9311-9479)
 __device__ __forceinline__ void write_result(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t r,
                                              int len, int rslt, int low_inst, int low_mm, int nxt, uint64_t hit_left,
-                                             int hit_ent, int hit_strand)
+                                             int hit_ent, int hit_strand, int diag)
 {
     bk_hit h;
     h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0;
     h.rslt = (uint8_t)rslt; h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0;
-    h.num_hits = 0; h.mismatches = 0; h.flags = 0;
+    h.num_hits = 0; h.mismatches = 0;
+    h.flags = (uint8_t)diag;      // diagnostics only: (AlignReads phase << 1) | resolved by k_heavy
     if (low_inst > cfg.max_hits) low_inst = cfg.max_hits + 1;
     switch (rslt) {
     case BK_HR_HITS:
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
             }
             int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
             if (rslt != BK_HR_NONE)
-                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand);
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand, phase << 1);
             else if (phase + 1 < p.n_phases) {
                 int mm2, cl2, cd2, dummy[1];
                 phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
@@ -658,7 +660,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
         if (lane == 0) {
             if (rslt != BK_HR_NONE)
-                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand);
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand, (phase << 1) | 1);
             else if (phase + 1 < p.n_phases) {
                 int mm2, cl2, cd2, dummy[1];
                 phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
@@ -674,6 +676,13 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         if (n_cand) atomicAdd(&b.ctr[1], n_cand);
         if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
     }
+}
+
+__global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
 }
 
 __global__ void k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_t *__restrict__ out)
@@ -713,6 +722,15 @@ void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStre
         if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k);
         else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k);
     }
+}
+
+// hipMemsetAsync is not trusted with >= 4 GiB spans: clear with our own grid-stride kernel
+void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s)
+{
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
 }
 
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s)

@@ -4,9 +4,11 @@
 // Order produced = the reference comparator's order (QSortSeqCmp32/40): lexicographic on the low
 // nibble of each base (A0 C1 G2 T3 N4 < EOS7), comparison NOT stopped at EOS, bounded at
 // 5*cMaxReadLen = 983 040 bases (ties beyond that are unordered in the reference; here: stable).
-// Positions past the end of the concatenation compare as EOS (the reference reads whatever memory
-// follows; only suffixes already equal up to and including an EOS are affected, and the search
-// comparator never looks past an EOS, so any tie-break is search-equivalent).
+// Positions past the end of the concatenation compare as a sentinel below every base (the reference
+// reads whatever memory follows - the suffix array being sorted; only suffixes already equal up to
+// and including an EOS are affected, and the search comparator never looks past an EOS, so any
+// tie-break is search-equivalent.  The sentinel reproduces what the reference wrote for the
+// golden fixtures: the final EOS suffix sorts before the other EOS suffixes).
 //
 // Method: prefix doubling.  Round 0 sorts suffixes by their first 16 bases (one 64-bit nibble
 // word); round r sorts by (rank[i], rank[i+h]), h = 16*2^(r-1), with rocPRIM's LSD radix sort
@@ -37,7 +39,7 @@ __global__ void k_sa_init(const uint8_t *__restrict__ seq, uint64_t n, uint64_t 
         uint64_t v = 0;
         for (int k = 0; k < 16; k++) {
             uint64_t p = i + k;
-            uint64_t nb = p < n ? (uint64_t)(seq[p] & 0x0f) : 7ULL;
+            uint64_t nb = p < n ? (uint64_t)(seq[p] & 0x0f) + 1 : 0ULL;   // 0 = end sentinel, below every base
             v = (v << 4) | nb;
         }
         key[i] = v;
@@ -77,7 +79,7 @@ __global__ void k_sa_make_keys(const uint32_t *__restrict__ rank, const uint32_t
     for (; j < n; j += stride) {
         uint64_t i = val[j];
         uint64_t r1 = rank[i];
-        uint64_t r2 = i + h < n ? (uint64_t)rank[i + h] : 0xFFFFFFFFULL;   // past the end sorts last (as EOS padding)
+        uint64_t r2 = i + h < n ? (uint64_t)rank[i + h] + 1 : 0ULL;         // past the end sorts first (sentinel)
         key[j] = (r1 << 32) | r2;
     }
 }

@@ -114,7 +114,16 @@ def test_device_resident_batch_and_sa_builder(golden_tmp):
     bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
     torch.cuda.synchronize()
     got_sa = d_sa.cpu().numpy().view(np.uint32)
-    assert np.array_equal(got_sa, sa)
+    # identical except among suffixes that are equal up to and including an EOS: the reference's
+    # comparator then runs off the end of the sequence into the array being sorted, so their order is
+    # arbitrary there (and irrelevant: no search ever compares past an EOS)
+    for j in np.nonzero(got_sa != sa)[0]:
+        a, b = int(got_sa[j]), int(sa[j])
+        l = 0
+        while a + l < n and b + l < n and seq[a + l] == seq[b + l]:
+            l += 1
+        assert 7 in seq[a:a + l], (j, a, b, l)
+    assert np.array_equal(np.sort(got_sa), np.arange(n, dtype=np.uint32))
 
     with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
         ref = al.align(bases, offs[keep], lens[keep])
@@ -186,3 +195,27 @@ def test_synthetic_parity_vs_oracle(tmp_path, read_len, max_subs):
     assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
     assert np.count_nonzero(got["nar"] == 1) > nreads // 3
     o.close()
+
+
+def test_repeatable(tmp_path):
+    """the same batch aligned repeatedly gives bit-identical results (guards against races between
+    the search / extend / wave-per-read kernels; an earlier build showed ~1e-4 flaky interval counts)"""
+    import torch
+    bk = _bk()
+    seq, ents, reads = _synth_case(75, 300000, 20000, 64, 6)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = (np.arange(nreads, dtype=np.uint64) * 64)
+    lens = np.full(nreads, 64, dtype=np.uint32)
+    with bk.Aligner(None, bk.AlignParams(max_subs=10), d_seq=d_seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(),
+                    el_size=4, entries=ents) as al:
+        ref = al.align(bases, offs, lens)
+        for thresh in (100, 99, 10, 100, 0, 100):
+            al.tune("heavy_thresh", thresh)
+            for _ in range(4):
+                assert_hits_equal(al.align(bases, offs, lens), ref)
