@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the `biokanga align` hot path on MI355X.
+
+Metric (BASELINE.json): aligned reads/s, results identical to the reference, 100 bp SE reads vs a
+GRCh38-scale index.  One "step" = one pass of the hot path (bk_align_batch_device: pack, SA-interval
+search, candidate walk + Hamming extension, classification - every AlignReads phase) over one batch
+of synthetic reads that is already resident in HBM, followed by the path's only exchange step, the
+sum-reduction of the per-sequence hit counts (RCCL all-reduce when N > 1).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload at N = 1: BASELINE.json configs[1] restated over a synthetic genome (SURVEY.md §8d "C2"):
+50 M x 100 bp SE reads, 0-3 substitutions, vs a 24-sequence 3.1 Gbp GRCh38-like genome, `-s3`.
+Reads are sharded over ranks with the index replicated per GPU (weak scaling: per-GPU batch fixed).
+The genome, its suffix array (built on the GPU by bk_build_sa_device) and the reads are generated
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, budget_s):
+    """Times the CPU oracle (restatement of the reference path, pthreads on every host core) on a
+    bounded sample of the same workload; also checks the GPU results of that sample against it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import helpers
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    seq = seq_t.cpu().numpy()
+    sa = sa_t.cpu().numpy()
+    log(f"cpu_baseline: index image copied to host in {time.time() - t0:.1f}s ({(seq.nbytes + sa.nbytes) / 1e9:.1f} GB)")
+    ora = helpers.OracleSfx(seq=seq, sa=sa, el_size=4, entries=entries)
+    p = helpers.make_params(**params_kw)
+    n_avail = reads_t.numel() // read_len
+    # probe run to size the sample for ~budget_s seconds of CPU work
+    n0 = min(n_avail, 20000 * max(1, cores // 8))
+    bases = reads_t[: n0 * read_len].cpu().numpy()
+    offs = (np.arange(n0, dtype=np.uint64) * read_len)
+    lens = np.full(n0, read_len, dtype=np.uint32)
+    t0 = time.time()
+    ora.align(bases, offs, lens, p, nthreads=cores)
+    rate0 = n0 / max(1e-6, time.time() - t0)
+    n1 = int(min(n_avail, max(n0, rate0 * budget_s)))
+    bases = reads_t[: n1 * read_len].cpu().numpy()
+    offs = (np.arange(n1, dtype=np.uint64) * read_len)
+    lens = np.full(n1, read_len, dtype=np.uint32)
+    t0 = time.time()
+    exp, octr = ora.align(bases, offs, lens, p, nthreads=cores)
+    dt = time.time() - t0
+    got = gpu_hits[:n1]
+    nbad = 0
+    for f in ("chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm",
+              "nxt_low_mm", "num_hits", "mismatches"):
+        nbad += int((got[f] != exp[f]).sum())
+    ora.close()
+    return {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {n1} reads of the rank-0 batch, oracle/bk_oracle.c ora_align_batch with {cores} pthreads, "
+                      f"{dt:.1f} s wall; index already in host RAM",
+            "parity_mismatching_fields_vs_gpu": nbad,
+            "n_search_per_read": octr.n_search / n1, "n_cand_per_read": octr.n_cand / n1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (Mbp); 3100 = GRCh38 scale")
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--max-subs", type=int, default=3, help="`-s` of biokanga align")
+    ap.add_argument("--cpu-baseline-secs", type=float, default=15.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import biokanga_amd as bk
+    from biokanga_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- workload (untimed set-up)
+    t0 = time.time()
+    total_bp = int(args.genome_mbp * 1e6)
+    seq, seq_lens = synth.make_genome(total_bp, dev, seed=38)
+    n = seq.numel()
+    torch.cuda.synchronize()
+    log(f"genome: {n} concatenated bases, {len(seq_lens)} sequences, generated in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), 4, local_rank)
+    torch.cuda.synchronize()
+    log(f"suffix array built on the GPU in {time.time() - t0:.1f}s")
+    entries = synth.entry_table(seq_lens)
+    ent = np.zeros(len(entries), dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"chr{eid}".encode(), b"")
+    params_kw = dict(max_subs=args.max_subs)
+    t0 = time.time()
+    al = bk.Aligner(None, bk.AlignParams(**params_kw), device=local_rank, d_seq=seq.data_ptr(), concat_len=n,
+                    d_sa=sa.data_ptr(), el_size=4, entries=ent)
+    if args.kmer_bits:
+        al.tune("kmer_bits", args.kmer_bits)
+    log(f"context (packed target + k-mer table) ready in {time.time() - t0:.1f}s; MinCoreLen {al.min_core_len}")
+    t0 = time.time()
+    rd_bases, rd_offs, rd_lens, truth = synth.make_reads(seq, seq_lens, args.reads, args.read_len, dev,
+                                                         seed=1000 + rank, max_subs=args.max_subs)
+    out = torch.zeros(args.reads * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    counts_dev = torch.zeros(len(entries), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    log(f"reads: {args.reads} x {args.read_len} bp generated in {time.time() - t0:.1f}s")
+    if args.cpu_baseline_secs <= 0 or rank != 0 or world != 1:
+        del seq, sa            # the context holds its own packed copy
+        seq = sa = None
+        torch.cuda.empty_cache()
+
+    def step():
+        al.align_device(rd_bases.data_ptr(), rd_offs.data_ptr(), rd_lens.data_ptr(), args.reads, out.data_ptr())
+        # the path's one exchange step: per-sequence hit counts summed over ranks
+        c = al.seq_counts(reset=True)
+        counts_dev.copy_(torch.from_numpy(c.astype(np.int64)))
+        if dist is not None:
+            dist.all_reduce(counts_dev)
+
+    for _ in range(args.warmup):
+        step()
+    al.counters(reset=True)
+    al.timing(reset=True)
+    barrier()
+    t_start = time.time()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.time() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ctr = al.counters()
+    tim = al.timing()
+    hits = out.cpu().numpy().view(bk.HIT_DTYPE)
+    accepted = int((hits["nar"] == 1).sum())
+    total_reads = args.reads * world * args.steps
+    value = total_reads / elapsed
+
+    # roofline of the dominant kernel (k_search): algorithmic bytes = n_search * ceil(log2 N) * (E + 8)
+    #  over the kernel's summed launch time, measured with HIP events on its stream
+    E = 4
+    log2n = math.ceil(math.log2(n))
+    search_bytes = ctr["n_search"] * log2n * (E + 8)
+    cand_bytes = ctr["n_cand"] * (E + (args.read_len + 1) // 2)
+    io_bytes = args.reads * args.steps * ((args.read_len + 3) // 4 + 16)
+    kernels = {"k_search": (search_bytes, tim["ms_search"], tim["n_search_launches"]),
+               "k_extend": (cand_bytes, tim["ms_extend"] + tim["ms_heavy"], tim["n_extend_launches"] + tim["n_heavy_launches"])}
+    dom = max(kernels, key=lambda k: kernels[k][1])
+    ach = kernels["k_search"][0] / max(1e-9, tim["ms_search"] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": search_bytes / max(1, tim["n_search_launches"]),
+                "avg_launch_ms": tim["ms_search"] / max(1, tim["n_search_launches"]),
+                "whole_step_algorithmic_GBs": (search_bytes + cand_bytes + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9,
+                "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other")},
+                "slowest_kernel": dom}
+
+    result = {
+        "metric": "aligned reads/s (SAM-identical) on 100 bp SE vs GRCh38, 1->8 MI355X",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"C2: {args.reads} x {args.read_len} bp SE reads per GPU per step (0-{args.max_subs} subs, "
+                               f"simreads-like) vs synthetic GRCh38-like genome of {total_bp} bp in {len(seq_lens)} "
+                               f"sequences (45% repeat-derived, N gaps), biokanga align -s{args.max_subs}",
+                   "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
+                   "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
+                   "parallelism": f"reads sharded over {world} GPU(s)", "accepted_frac_rank0": accepted / args.reads,
+                   "n_search_per_read": ctr["n_search"] / (args.reads * args.steps),
+                   "n_cand_per_read": ctr["n_cand"] / (args.reads * args.steps),
+                   "heavy_calls_frac": ctr["n_heavy"] / max(1, ctr["n_lcm_calls"])},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and args.cpu_baseline_secs > 0:
+        try:
+            result["cpu_baseline"] = cpu_baseline(seq, sa, entries, rd_bases, args.read_len, params_kw, hits,
+                                                  args.cpu_baseline_secs)
+        except Exception as e:      # the baseline is reporting only - never lose the measured line
+            result["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {e!r}"}
+    al.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

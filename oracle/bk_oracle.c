@@ -96,6 +96,34 @@ int ora_sfx_load(const char *path, ora_sfx **out)
     return 0;
 }
 
+/* index image already in host memory (bench.py: copied back from the GPU-built synthetic index).
+ * seq / sa are borrowed, not copied; entries: n_entries x {entry_id, seq_len, start_ofs, end_ofs}. */
+int ora_sfx_from_memory(const uint8_t *seq, const uint8_t *sa, uint64_t concat_len, uint32_t el_size,
+                        const uint64_t *entries4, uint32_t n_entries, ora_sfx **out)
+{
+    if (!seq || !sa || !entries4 || !n_entries || (el_size != 4 && el_size != 5)) return -1;
+    ora_sfx *s = (ora_sfx *)calloc(1, sizeof(ora_sfx));
+    s->seq = (uint8_t *)seq;
+    s->sa = (uint8_t *)sa;
+    s->concat_len = concat_len;
+    s->el_size = el_size;
+    s->block_id = 1;
+    s->num_entries = n_entries;
+    s->entries = (ora_entry *)calloc(n_entries, sizeof(ora_entry));
+    for (uint32_t i = 0; i < n_entries; i++) {
+        ora_entry *d = &s->entries[i];
+        d->entry_id = (uint32_t)entries4[4 * i];
+        d->fblock_id = 1;
+        d->seq_len = (uint32_t)entries4[4 * i + 1];
+        d->start_ofs = entries4[4 * i + 2];
+        d->end_ofs = entries4[4 * i + 3];
+        snprintf(d->name, sizeof(d->name), "seq%u", d->entry_id);
+        s->tot_seq_len += d->seq_len;
+    }
+    *out = s;
+    return 0;
+}
+
 void ora_sfx_free(ora_sfx *s)
 {
     if (!s) return;

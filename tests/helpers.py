@@ -59,6 +59,9 @@ def oracle_lib():
     lib.ora_sfx_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.ora_sfx_load.restype = ctypes.c_int
     lib.ora_sfx_free.argtypes = [ctypes.c_void_p]
+    lib.ora_sfx_from_memory.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                        ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ora_sfx_from_memory.restype = ctypes.c_int
     lib.ora_align_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                     ctypes.POINTER(OraCounters), ctypes.c_int]
@@ -75,12 +78,23 @@ def oracle_lib():
 
 
 class OracleSfx:
-    def __init__(self, path):
+    def __init__(self, path=None, *, seq=None, sa=None, el_size=4, entries=None):
+        """path: a .sfx file; or seq (uint8, 1 B/base incl. EOS) + sa (raw little-endian element bytes or
+        uint32 array) + entries [(entry_id, seq_len, start_ofs, end_ofs)] held in host memory."""
         self.lib = oracle_lib()
         h = ctypes.c_void_p()
-        rc = self.lib.ora_sfx_load(path.encode(), ctypes.byref(h))
-        if rc != 0:
-            raise RuntimeError(f"ora_sfx_load({path}) failed: {rc}")
+        if path is not None:
+            rc = self.lib.ora_sfx_load(path.encode(), ctypes.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"ora_sfx_load({path}) failed: {rc}")
+        else:
+            self._seq = np.ascontiguousarray(seq, dtype=np.uint8)
+            self._sa = np.ascontiguousarray(sa)
+            self._ent = np.ascontiguousarray(np.array(entries, dtype=np.uint64).reshape(-1, 4))
+            rc = self.lib.ora_sfx_from_memory(self._seq.ctypes.data, self._sa.ctypes.data, len(self._seq), el_size,
+                                              self._ent.ctypes.data, len(self._ent), ctypes.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"ora_sfx_from_memory failed: {rc}")
         self.h = h
 
     def close(self):
