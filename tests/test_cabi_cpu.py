@@ -1,0 +1,75 @@
+"""CPU-side checks of the C-ABI library: it builds (cross-compiles for gfx950 without a GPU), loads,
+exports every symbol include/biokanga_amd.h declares, and FAILS LOUDLY (no CPU fallback) when no
+HIP device is present.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import helpers
+
+ROOT = helpers.ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(ROOT, "biokanga_amd", "lib", "libbiokanga_amd.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "biokanga_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+    import biokanga_amd
+    return biokanga_amd.load_library()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "biokanga_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(bk_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_exports_every_declared_symbol(lib):
+    from biokanga_amd.binding import EXPORTED_SYMBOLS
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    assert sorted(EXPORTED_SYMBOLS) == decl
+    for s in decl:
+        assert getattr(lib, s) is not None
+    assert b"biokanga_amd" in lib.bk_version()
+
+
+def test_struct_layouts_match_header():
+    import biokanga_amd as bk
+    from biokanga_amd import binding
+    assert bk.HIT_DTYPE.itemsize == 20                      # bk_hit
+    assert ctypes.sizeof(bk.AlignParams) == 32              # bk_align_params
+    assert bk.ENTRY_DTYPE.itemsize == 112                   # bk_entry_info (8-byte aligned)
+    assert ctypes.sizeof(binding._Counters) == 64
+    assert ctypes.sizeof(binding._Timing) == 36
+    assert helpers.HIT_DTYPE == bk.HIT_DTYPE                # oracle ora_hit has the same layout
+
+
+def test_no_cpu_fallback(lib, golden_tmp):
+    """Without a HIP device the library refuses to work instead of computing on the CPU."""
+    import biokanga_amd as bk
+    if bk.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(bk.BkError) as e:
+        bk.Aligner(os.path.join(golden_tmp["basic"], "genome.sfx"), bk.AlignParams(max_subs=3))
+    assert e.value.rc == -2                                  # BK_ERR_NODEVICE
+    assert b"no CPU fallback" in lib.bk_strerror(-2)
+    with pytest.raises(bk.BkError):
+        bk.build_sa_device(1, 10, 1, 4, 0)
+
+
+def test_product_never_touches_oracle():
+    """oracle/ is test infrastructure: nothing under biokanga_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("biokanga_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if "oracle" in txt.lower() and "bk_oracle" in txt or "ora_align" in txt or "libbk_oracle" in txt:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
