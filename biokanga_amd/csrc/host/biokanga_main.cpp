@@ -1,0 +1,509 @@
+// biokanga_main.cpp - host front end: `biokanga index` and `biokanga align` (C++ above the C ABI).
+//
+// Keeps the reference's option letters and defaults for the subset that reaches the hot path
+// (biokanga/kanga.cpp:194-294, biokanga/kangax.cpp:95-116), the .sfx index format and the SAM text
+// the reference writes (libbiokanga/SAMfile.cpp:1521,1573-1575,1766,2110-2283).  The alignment
+// itself is ONLY available through libbiokanga_amd (HIP kernels); there is no host fallback.
+//
+//   biokanga index -i genome.fa [-i more.fa] -o genome.sfx -r name [-l minseqlen] [-d descr] [-t title]
+//   biokanga align -i reads.fa[.gz] -I genome.sfx -o out.sam [-s subs] [-e 1|2] [-Q 0|1|2] [-m 0..3]
+//                  [-n maxNs] [-l minlen] [-L maxlen] [-y trim5] [-Y trim3] [-M 0|5|6] [-O stats.csv]
+//                  [-T threads(ignored)] [-F logfile] [--device n]
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/biokanga_amd.h"
+#include "../sfx_file.h"
+#include "fasta.h"
+#include "mtqsort.h"
+
+namespace {
+
+const char *kProgVer = "4.4.2";          // cpszProgVer of the release whose formats are kept (biokanga.cpp:33)
+std::string g_proc = "biokanga";          // gszProcName = basename(argv[0]) (used for @PG ID:)
+FILE *g_logfile = nullptr;
+
+// CDiagnostics::DiagOut style line: [Www Mmm dd hh:mm:ss.mmm yyyy](proc) text
+void diag(const char *fmt, ...)
+{
+    char msg[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof(msg), fmt, ap);
+    va_end(ap);
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    struct tm tmv;
+    localtime_r(&tv.tv_sec, &tmv);
+    char ts[64], line[4300];
+    strftime(ts, sizeof(ts), "%b %e %H:%M:%S", &tmv);
+    snprintf(line, sizeof(line), "[%s.%03d %d](%s) %s\n", ts, (int)(tv.tv_usec / 1000), tmv.tm_year + 1900, g_proc.c_str(), msg);
+    fputs(line, stdout);
+    fflush(stdout);
+    if (g_logfile) { fputs(line, g_logfile); fflush(g_logfile); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiny option parser: -x val, -xval, --long=val, --long val; repeated options accumulate
+struct Args {
+    std::map<std::string, std::vector<std::string>> v;
+    bool has(const std::string &k) const { return v.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d = "") const { return has(k) ? v.at(k).back() : d; }
+    int num(const std::string &k, int d) const { return has(k) ? atoi(v.at(k).back().c_str()) : d; }
+};
+
+bool parse_args(int argc, char **argv, int first, const std::map<std::string, std::string> &longnames,
+                const std::string &flags_with_val, const std::string &flags_no_val, Args &out, std::string &err)
+{
+    for (int i = first; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() >= 2 && a[0] == '-' && a[1] == '-') {
+            std::string name = a.substr(2), val;
+            bool hasval = false;
+            size_t eq = name.find('=');
+            if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); hasval = true; }
+            auto it = longnames.find(name);
+            if (it == longnames.end()) { err = "unknown option --" + name; return false; }
+            std::string key = it->second;
+            bool wants = flags_with_val.find(key) != std::string::npos || key.size() > 1;
+            if (flags_no_val.find(key) != std::string::npos && key.size() == 1) wants = false;
+            if (wants && !hasval) {
+                if (i + 1 >= argc) { err = "option --" + name + " needs a value"; return false; }
+                val = argv[++i];
+            }
+            out.v[key].push_back(wants ? val : "1");
+        } else if (a.size() >= 2 && a[0] == '-') {
+            std::string key(1, a[1]);
+            if (flags_no_val.find(key) != std::string::npos) { out.v[key].push_back("1"); continue; }
+            if (flags_with_val.find(key) == std::string::npos) { err = "unknown option " + a; return false; }
+            std::string val = a.substr(2);
+            if (val.empty()) {
+                if (i + 1 >= argc) { err = "option " + a + " needs a value"; return false; }
+                val = argv[++i];
+            }
+            out.v[key].push_back(val);
+        } else {
+            err = "unexpected argument '" + a + "'";
+            return false;
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index
+
+int cmd_index(int argc, char **argv, int first)
+{
+    Args a;
+    std::string err;
+    std::map<std::string, std::string> ln = {{"mode", "m"}, {"minseqlen", "l"}, {"descr", "d"}, {"title", "t"}, {"ref", "r"},
+                                             {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"device", "device"}};
+    if (!parse_args(argc, argv, first, ln, "mlidtroTFf", "", a, err)) {
+        fprintf(stderr, "%s index: %s\n", g_proc.c_str(), err.c_str());
+        return 1;
+    }
+    if (!a.has("i") || !a.has("o") || !a.has("r")) {
+        fprintf(stderr, "usage: %s index -i <fasta> [-i <fasta>..] -o <out.sfx> -r <refspecies> [-l minseqlen] [-d descr] [-t title]\n", g_proc.c_str());
+        return 1;
+    }
+    if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
+    if (a.num("m", 0) != 0) { diag("Error: only standard indexing mode '-m0' is supported"); return 1; }
+    int min_seq_len = a.has("l") ? a.num("l", 50) : 50;                  // kangax.cpp:275-280
+    min_seq_len = std::max(1, std::min(1000000, min_seq_len));
+    std::string ref = a.str("r").substr(0, 80);
+    std::string title = a.has("t") ? a.str("t").substr(0, 63) : ref.substr(0, 63);
+    std::string descr = a.has("d") ? a.str("d").substr(0, 1023) : ref;
+    diag("Subprocess index Version %s starting", kProgVer);
+
+    // CreateBioseqSuffixFile / ProcessFastaFile (kangax.cpp:545-690,774-926)
+    std::vector<uint8_t> seq;
+    std::vector<bk::SfxEntry> entries;
+    const size_t kChunk = 0x00ffffff;                                    // cMaxAllocBuffChunk, kangax.cpp:37
+    uint32_t n_under = 0;
+    std::vector<std::string> files = a.v["i"];
+    std::sort(files.begin(), files.end());                               // SG_GLOB_FULLSORT
+    for (const std::string &fn : files) {
+        bk::SeqReader rd;
+        int rc = rd.open(fn, &err);
+        if (rc) { diag("ProcessFastaFile: Unable to open '%s' %s", fn.c_str(), err.c_str()); return 1; }
+        diag("ProcessFastaFile:- Adding %s..", fn.c_str());
+        // the reference's read buffer bookkeeping decides where its 16 M-base chunks fall, and the
+        // N-run mutation state is reset at every chunk boundary (kangax.cpp:572,589,626-660)
+        size_t allocd = kChunk * 16, avail = allocd;
+        std::string d;
+        std::vector<uint8_t> bases;
+        int seq_id = 0;
+        while ((rc = rd.next(d, bases)) > 0) {
+            seq_id++;
+            char name[256];
+            if (sscanf(d.c_str(), " %255s", name) != 1) snprintf(name, sizeof(name), "%s.%d", fn.c_str(), ++seq_id);
+            size_t buff_ofs = 0, len = bases.size();
+            while (buff_ofs < len) {
+                size_t chunk = std::min(std::min(avail, kChunk), len - buff_ofs);
+                uint8_t *p = bases.data() + buff_ofs;
+                int seq_ns = 0;
+                for (size_t k = 0; k < chunk; k++) {
+                    p[k] &= ~0x08;
+                    if (p[k] == bk::kBaseN && (k + 5) < chunk) {
+                        if (++seq_ns > 25 && p[k + 1] == bk::kBaseN && p[k + 2] == bk::kBaseN && p[k + 3] == bk::kBaseN &&
+                            p[k + 4] == bk::kBaseN) {
+                            if (!(seq_ns % 13)) p[k] = (uint8_t)(rand() % 4);      // unseeded libc rand(), as the reference
+                        }
+                    } else
+                        seq_ns = 0;
+                }
+                buff_ofs += chunk;
+                avail -= chunk;
+                if (avail < kChunk / 8) {
+                    allocd += kChunk;
+                    avail = allocd - buff_ofs;
+                }
+            }
+            if (len < (size_t)min_seq_len) { n_under++; continue; }
+            if (len > 0xfff00000ULL) { diag("AddEntry: SeqLen %zu not in range 1..%u", len, 0xfff00000u); return 1; }
+            bk::SfxEntry e;
+            e.entry_id = (uint32_t)entries.size() + 1;
+            e.fblock_id = 1;
+            strncpy(e.name, name, 80);
+            e.name_hash = bk::gen_hash16(name);
+            e.seq_len = (uint32_t)len;
+            e.start_ofs = seq.size();
+            e.end_ofs = seq.size() + len - 1;
+            for (const bk::SfxEntry &o : entries)
+                if (!strcasecmp(o.name, e.name)) { diag("CreateBioseqSuffixFile, duplicate sequence entry name '%s' in file '%s'", e.name, fn.c_str()); return 1; }
+            entries.push_back(e);
+            seq.insert(seq.end(), bases.begin(), bases.end());
+            seq.push_back(bk::kBaseEOS);
+        }
+        if (rc < 0) { diag("ProcessFastaFile: errors whilst reading '%s'", fn.c_str()); return 1; }
+    }
+    if (n_under) diag("ProcessFastaFile - %u sequences not accepted for indexing as length under %dbp ", n_under, min_seq_len);
+    if (entries.empty()) { diag("Nothing to index"); return 1; }
+
+    diag("CreateBioseqSuffixFile: sorting suffix array...");
+    uint64_t n = seq.size();
+    uint32_t el = n < bk::kThres5ByteEls ? 4 : 5;
+    int dev = a.num("device", 0);
+    if (bk_device_count() < 1) { diag("Fatal: no HIP device - the suffix sort runs on the GPU only"); return 1; }
+    if (hipSetDevice(dev) != hipSuccess) { diag("Fatal: unable to select HIP device %d", dev); return 1; }
+    uint8_t *d_seq = nullptr, *d_sa = nullptr;
+    if (hipMalloc(&d_seq, n) != hipSuccess || hipMalloc(&d_sa, n * el) != hipSuccess) { diag("Fatal: unable to allocate device memory"); return 1; }
+    if (hipMemcpy(d_seq, seq.data(), n, hipMemcpyHostToDevice) != hipSuccess) { diag("Fatal: upload failed"); return 1; }
+    int rc = bk_build_sa_device(d_seq, n, d_sa, (int)el, dev);
+    if (rc) { diag("Fatal: suffix sort failed: %s", bk_strerror(rc)); return 1; }
+    std::vector<uint8_t> sa(n * el);
+    if (hipMemcpy(sa.data(), d_sa, n * el, hipMemcpyDeviceToHost) != hipSuccess) { diag("Fatal: download failed"); return 1; }
+    (void)hipFree(d_seq);
+    (void)hipFree(d_sa);
+    rc = bk::sfx_write(a.str("o").c_str(), ref, descr, title, entries, seq.data(), n, sa.data(), el, &err);
+    if (rc) { diag("Fatal: %s", err.c_str()); return 1; }
+    diag("CreateBioseqSuffixFile: completed...");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// align
+
+const char *kNarTag[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
+const char *kNarDescr[20] = {"Not processed for alignment", "Alignment accepted", "Excessive indeterminate (Ns) bases",
+                             "No potential alignment loci", "Mismatch delta (minimum Hamming) criteria not met",
+                             "Aligned to multiloci", "Excessively end trimmed", "Aligned as orphaned splice junction",
+                             "Aligned as orphaned microInDel", "Duplicate PCR", "Duplicate read sequence",
+                             "Aligned to filtered target sequence", "Aligned to a priority region", "PE under minimum insert size",
+                             "PE over maximum insert size", "PE partner not aligned", "PE partner aligned to inconsistent strand",
+                             "PE partner aligned to different target sequence", "PE alignment not accepted",
+                             "Alignment violated loci base constraints"};
+
+struct ReadStore {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> lens;
+    std::vector<char> names;               // '\0' separated
+    std::vector<uint64_t> name_ofs;
+    size_t size() const { return lens.size(); }
+    const char *name(size_t i) const { return names.data() + name_ofs[i]; }
+};
+
+// CAligner::LoadRawReads (Aligner.cpp:10724-11427): descriptor rule, -y/-Y trims, -l/-L acceptance
+int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, ReadStore &rs)
+{
+    for (const std::string &fn : files) {
+        bk::SeqReader rd;
+        std::string err;
+        int rc = rd.open(fn, &err);
+        if (rc) { diag("Load: %s", err.c_str()); return rc; }
+        diag("Loading reads from '%s'", fn.c_str());
+        std::string d;
+        std::vector<uint8_t> b;
+        bool sim = false;
+        uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
+        while ((rc = rd.next(d, b)) > 0) {
+            n_descr++;
+            if (d.size() > 127) d.resize(127);                            // cMaxDescrLen-1
+            if (n_descr == 1) sim = !strncmp(d.c_str(), "lcl|usimreads|", 14) || !strncmp(d.c_str(), "lcr|usimreads|", 14);
+            int len = (int)b.size();
+            if (len < 1 || len > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
+            if (trim5 + trim3 + min_len > len) {
+                if (++n_under <= 10) diag("Load: under length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str());
+                continue;
+            }
+            if (trim5 + trim3 + max_len < len) {
+                if (++n_over <= 10) diag("Load: over length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str());
+                continue;
+            }
+            if (!sim) {                                                   // cut at first whitespace, < cMaxDescrIDLen
+                size_t k = 0;
+                while (k < 79 && k < d.size() && !isspace((unsigned char)d[k])) k++;
+                d.resize(k);
+            }
+            int keep = len - trim5 - trim3;
+            rs.offs.push_back(rs.bases.size());
+            rs.lens.push_back((uint32_t)keep);
+            rs.bases.insert(rs.bases.end(), b.begin() + trim5, b.begin() + trim5 + keep);
+            rs.name_ofs.push_back(rs.names.size());
+            rs.names.insert(rs.names.end(), d.begin(), d.end());
+            rs.names.push_back('\0');
+            n_acc++;
+        }
+        if (rc < 0) { diag("Load: errors whilst parsing '%s'", fn.c_str()); return rc; }
+        diag("Load: %u reads parsed, %u accepted, %u under length, %u over length from '%s'", n_descr, n_acc, n_under, n_over, fn.c_str());
+    }
+    return 0;
+}
+
+struct OutBuf {
+    int fd = -1;
+    std::vector<char> b;
+    void open(const char *path) { fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644); b.reserve(8 << 20); }
+    void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
+    void put(const std::string &s) { put(s.data(), s.size()); }
+    void flush()
+    {
+        size_t o = 0;
+        while (o < b.size()) { ssize_t w = ::write(fd, b.data() + o, b.size() - o); if (w <= 0) break; o += (size_t)w; }
+        b.clear();
+    }
+    void close() { flush(); if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
+};
+
+int cmd_align(int argc, char **argv, int first)
+{
+    Args a;
+    std::string err;
+    std::map<std::string, std::string> ln = {
+        {"mode", "m"}, {"alignstrand", "Q"}, {"editdelta", "e"}, {"substitutions", "s"}, {"maxns", "n"}, {"trim5", "y"},
+        {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
+        {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
+        {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4", "", a, err)) {
+        fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
+        return 1;
+    }
+    if (!a.has("i") || !a.has("I") || !a.has("o")) {
+        fprintf(stderr, "usage: %s align -i <reads> -I <genome.sfx> -o <out.sam> [-s subs] [-e delta] [-Q strand] [-m mode] [-n maxNs] "
+                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats]\n", g_proc.c_str());
+        return 1;
+    }
+    if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
+    diag("Subprocess align Version %s starting", kProgVer);
+    if (a.num("U", 0) != 0) { diag("Error: paired end processing '-U' is not available in this build"); return 1; }
+    if (a.num("r", 0) != 0) { diag("Error: multiloci modes '-r1..5' are not available in this build"); return 1; }
+    bk_align_params P = {};
+    P.pmode = a.num("m", 0);
+    P.align_strand = a.num("Q", 0);
+    P.min_edit_dist = a.num("e", 1);
+    P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
+    P.max_ns = a.num("n", 1);
+    P.max_ml = 1;
+    int fmt = a.num("M", 5);
+    int min_len = a.num("l", 50), max_len = a.num("L", 500);
+    int trim5 = a.num("y", 0), trim3 = a.num("Y", 0);
+    int max_rpt_sam_seqs = a.num("4", 10000);
+    if (P.pmode < 0 || P.pmode > 3 || P.align_strand < 0 || P.align_strand > 2 || P.min_edit_dist < 1 || P.min_edit_dist > 2 ||
+        P.max_subs < 0 || P.max_subs > 25 || P.max_ns < 0 || P.max_ns > 5 || min_len < 15 || min_len > 2000 || max_len < min_len ||
+        max_len > 2000 || (fmt != 0 && fmt != 5 && fmt != 6)) {
+        diag("Error: an option value is outside its accepted range");
+        return 1;
+    }
+
+    diag("Loading suffix array file '%s'", a.str("I").c_str());
+    bk_ctx *ctx = nullptr;
+    int rc = bk_ctx_create(&ctx, a.str("I").c_str(), a.num("device", 0), &P);
+    if (rc) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(rc)); return 1; }
+    std::string species = bk_dataset_name(ctx);
+    uint32_t n_ent = bk_num_entries(ctx);
+    std::vector<bk_entry_info> ents(n_ent);
+    for (uint32_t i = 0; i < n_ent; i++) bk_get_entry(ctx, i, &ents[i]);
+    diag("Genome Assembly Name: '%s'", species.c_str());
+    diag("Genome assembly suffix array loaded");
+
+    ReadStore rs;
+    rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, rs);
+    if (rc) { bk_ctx_destroy(ctx); return 1; }
+    size_t nr = rs.size();
+    diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
+    std::vector<bk_hit> hits(nr);
+    const size_t kBatch = 16u << 20;
+    for (size_t lo = 0; lo < nr; lo += kBatch) {
+        size_t n = std::min(kBatch, nr - lo);
+        rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
+        if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+    }
+    diag("Alignment of %zu from %zu loaded completed", nr, nr);
+
+    // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): NAR histogram
+    uint64_t nar[20] = {0};
+    for (const bk_hit &h : hits) nar[h.nar < 20 ? h.nar : 0]++;
+    diag("Unable to align %llu source reads of which %llu were not aligned as they contained excessive number of indeterminate 'N' bases",
+         (unsigned long long)(nr - nar[1]), (unsigned long long)nar[2]);
+    diag("Read nonalignment reason summary:");
+    for (int k = 0; k < 20; k++) diag("   %llu (%s) %s", (unsigned long long)nar[k], kNarTag[k], kNarDescr[k]);
+
+    // SortReadHits(eRSMHitMatch): index in load (ReadID) order -> reference order
+    diag("Reporting of aligned result set started...");
+    diag("Sorting alignments by ascending chrom.loci");
+    std::vector<uint32_t> order(nr);
+    for (size_t i = 0; i < nr; i++) order[i] = (uint32_t)i;
+    const bk_hit *H = hits.data();
+    auto cmp = [H](uint32_t x, uint32_t y) -> int {                      // CAligner::SortHitMatch, Aligner.cpp:10069-10114
+        const bk_hit &p = H[x], &q = H[y];
+        if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
+        if (p.num_hits == 1 && q.num_hits != 1) return -1;
+        if (p.num_hits != 1 && q.num_hits == 1) return 1;
+        if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
+        if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
+        if (p.match_loci != q.match_loci) return p.match_loci < q.match_loci ? -1 : 1;
+        if (p.match_len != q.match_len) return p.match_len < q.match_len ? -1 : 1;
+        if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
+        if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
+        return 0;
+    };
+    bk::ref_order_sort(order.data(), (int64_t)nr, cmp);
+
+    OutBuf out;
+    out.open(a.str("o").c_str());
+    if (out.fd < 0) { diag("Fatal: unable to create '%s'", a.str("o").c_str()); bk_ctx_destroy(ctx); return 1; }
+    char line[8192];
+    uint64_t n_reported = 0;
+    if (fmt >= 5) {
+        // header: CSAMfile::Create/AddRefSeq/StartAlignments
+        std::vector<uint8_t> has_hit(n_ent + 1, 0);
+        for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) has_hit[h.chrom_id] = 1;
+        bool all = (uint32_t)max_rpt_sam_seqs >= n_ent;
+        out.put("@HD\tVN:1.4\tSO:coordinate");
+        int n_hdr = 0, n_with = 0;
+        for (uint32_t c = 1; c <= n_ent; c++) {
+            if (!has_hit[c] && !all) continue;
+            int n = snprintf(line, sizeof(line), "\n@SQ\tAS:%s\tSN:%s\tLN:%u", species.empty() ? "NA" : species.c_str(), ents[c - 1].name, ents[c - 1].seq_len);
+            out.put(line, (size_t)n);
+            n_hdr++;
+            n_with += has_hit[c];
+        }
+        int n = snprintf(line, sizeof(line), "\n@PG\tID:%s\tVN:%s\n", g_proc.c_str(), kProgVer);
+        out.put(line, (size_t)n);
+        diag("Header written with references to %d sequences of which %d have at least 1 alignments", n_hdr, n_with);
+        static const char comp[8] = {'T', 'G', 'C', 'A', 'N', 'N', 'N', 'N'};
+        static const char fwd[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
+        std::string rec;
+        for (size_t k = 0; k < nr; k++) {
+            uint32_t i = order[k];
+            const bk_hit &h = hits[i];
+            bool acc = h.nar == BK_NAR_ACCEPTED;
+            if (!acc && fmt != 6) continue;
+            const uint8_t *s = rs.bases.data() + rs.offs[i];
+            uint32_t len = rs.lens[i];
+            rec.clear();
+            rec += rs.name(i);
+            if (acc) {
+                int flag = h.strand == '+' ? 0 : 16;
+                int m = snprintf(line, sizeof(line), "\t%d\t%s\t%u\t255\t%uM\t*\t0\t0\t", flag, ents[h.chrom_id - 1].name, h.match_loci + 1, (unsigned)h.match_len);
+                rec.append(line, (size_t)m);
+                if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
+                else for (uint32_t q = 0; q < len; q++) rec.push_back(comp[s[len - 1 - q] & 7]);
+                rec += "\t*\n";
+            } else {
+                int m = snprintf(line, sizeof(line), "\t4\t*\t0\t255\t%uM\t*\t0\t0\t", len);
+                rec.append(line, (size_t)m);
+                for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
+                rec += "\t*\t\tYU:Z:";                                   // the doubled TAB is what the reference writes
+                rec += kNarTag[h.nar < 20 ? h.nar : 0];
+                rec.push_back('\n');
+            }
+            out.put(rec);
+            n_reported++;
+        }
+        diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
+    } else {
+        // -M0 CSV loci only (Aligner.cpp:6380-6620)
+        for (size_t k = 0; k < nr; k++) {
+            uint32_t i = order[k];
+            const bk_hit &h = hits[i];
+            if (h.nar != BK_NAR_ACCEPTED) continue;
+            int m = snprintf(line, sizeof(line), "%u,\"ar\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"\n", i + 1, species.c_str(),
+                             ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len - 1, (unsigned)h.match_len, (char)h.strand,
+                             (unsigned)h.mismatches, rs.name(i));
+            out.put(line, (size_t)m);
+            n_reported++;
+        }
+    }
+    out.close();
+    diag("Reporting of aligned result set completed");
+
+    if (a.has("O")) {                                                    // CAligner::ReportTargHitCnts, Aligner.cpp:5475-5537
+        std::vector<uint64_t> cnt(n_ent);
+        bk_seq_counts(ctx, cnt.data(), n_ent, 0);
+        FILE *f = fopen(a.str("O").c_str(), "w");
+        if (f) {
+            fprintf(f, "\"TargSeq\",\"TargLen\",\"NumHits\"\n");
+            for (uint32_t c = 0; c < n_ent; c++)
+                if (cnt[c]) fprintf(f, "\"%s\",%u,%llu\n", ents[c].name, ents[c].seq_len, (unsigned long long)cnt[c]);
+            fclose(f);
+        }
+    }
+    bk_ctx_destroy(ctx);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    // gszProcName: basename of argv[0] without extension (biokanga.cpp:236-246)
+    std::string p = argv[0];
+    size_t sl = p.find_last_of('/');
+    if (sl != std::string::npos) p = p.substr(sl + 1);
+    size_t dot = p.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) p = p.substr(0, dot);
+    if (!p.empty()) g_proc = p;
+    if (argc < 2) {
+        fprintf(stderr, "%s: MI355X build of the BioKanga `index` and `align` sub-processes (%s)\nusage: %s index|align <options>\n",
+                g_proc.c_str(), bk_version(), g_proc.c_str());
+        return 1;
+    }
+    time_t t0 = time(nullptr);
+    int rc;
+    std::string sub = argv[1];
+    if (sub == "index" || sub == "kangax") rc = cmd_index(argc, argv, 2);
+    else if (sub == "align" || sub == "kanga") rc = cmd_align(argc, argv, 2);
+    else {
+        fprintf(stderr, "%s: sub-process '%s' is outside the supported hot path (index, align)\n", g_proc.c_str(), sub.c_str());
+        return 1;
+    }
+    diag("Exit code: %d Total processing time: %ld seconds", rc, (long)(time(nullptr) - t0));
+    return rc;
+}

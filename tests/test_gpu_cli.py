@@ -1,0 +1,87 @@
+"""GPU tests of the C++ front end (`biokanga_amd/bin/biokanga index|align`): files byte-identical to
+what the real reference wrote for the same inputs (tests/golden/*)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(helpers.ROOT, "biokanga_amd", "bin", "biokanga")
+
+
+def run(args, cwd):
+    r = subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return r.stdout
+
+
+def golden_bytes(fixture, name):
+    return gzip.open(os.path.join(helpers.GOLDEN, fixture, name), "rb").read()
+
+
+@pytest.mark.parametrize("fixture", ["basic", "repeat"])
+def test_index_writes_the_reference_sfx(golden_tmp, tmp_path, fixture):
+    """header, sequence bytes (incl. the rand()-mutated N run), entries identical; suffix array
+    identical except among suffixes tied through an EOS (arbitrary in the reference)."""
+    d = golden_tmp[fixture]
+    out = str(tmp_path / "g.sfx")
+    run(["index", "-i", os.path.join(d, "genome.fa"), "-o", out, "-r", fixture], str(tmp_path))
+    got = open(out, "rb").read()
+    exp = open(os.path.join(d, "genome.sfx"), "rb").read()
+    assert len(got) == len(exp)
+    assert got[:1224] == exp[:1224]
+    blk = struct.unpack_from("<Q", exp, 44)[0]
+    n = struct.unpack_from("<Q", exp, blk + 8)[0]
+    assert got[blk:blk + 20 + n] == exp[blk:blk + 20 + n]              # block header + bases
+    ent = struct.unpack_from("<Q", exp, 20)[0]
+    assert got[ent:] == exp[ent:]                                        # entries block
+    seq = np.frombuffer(exp, dtype=np.uint8, count=n, offset=blk + 20)
+    sa_g = np.frombuffer(got, dtype="<u4", count=n, offset=blk + 20 + n)
+    sa_e = np.frombuffer(exp, dtype="<u4", count=n, offset=blk + 20 + n)
+    for j in np.nonzero(sa_g != sa_e)[0]:
+        a, b = int(sa_g[j]), int(sa_e[j])
+        l = 0
+        while a + l < n and b + l < n and seq[a + l] == seq[b + l]:
+            l += 1
+        assert 7 in seq[a:a + l], (j, a, b)
+
+
+@pytest.mark.parametrize("fixture,tag,flags", [
+    ("basic", "s3", ["-s3"]), ("repeat", "s3", ["-s3"]), ("basic", "dflt", []), ("basic", "s3m2", ["-s3", "-m2"]),
+    ("basic", "s3Q2", ["-s3", "-Q2"]), ("basic", "s2l30", ["-s2", "-l30"]), ("repeat", "s3m3", ["-s3", "-m3"])])
+def test_align_sam_byte_identical(golden_tmp, tmp_path, fixture, tag, flags):
+    d = golden_tmp[fixture]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    out6 = str(tmp_path / "o6.sam")
+    run(["align", "-i", reads, "-I", sfx, "-o", out6, "-M6"] + flags, str(tmp_path))
+    assert open(out6, "rb").read() == golden_bytes(fixture, f"{tag}.m6.sam.gz")
+    if tag == "s3":
+        out5 = str(tmp_path / "o5.sam")
+        log = run(["align", "-i", reads, "-I", sfx, "-o", out5] + flags, str(tmp_path))
+        assert open(out5, "rb").read() == golden_bytes(fixture, "s3.m5.sam.gz")
+        out0 = str(tmp_path / "o0.csv")
+        run(["align", "-i", reads, "-I", sfx, "-o", out0, "-M0", "-O", str(tmp_path / "st.csv")] + flags, str(tmp_path))
+        assert open(out0, "rb").read() == golden_bytes(fixture, "s3.m0.csv.gz")
+        # the NAR histogram lines the reference logged
+        exp = open(os.path.join(helpers.GOLDEN, fixture, "s3.nar.txt")).read().split("\n")
+        for line in exp:
+            if line.strip():
+                assert line.strip() in log
+        st = open(tmp_path / "st.csv").read().split("\n")
+        assert st[0] == '"TargSeq","TargLen","NumHits"' and len(st) >= 3
+
+
+def test_gz_reads_and_own_index_roundtrip(golden_tmp, tmp_path):
+    """reads from a .gz file, index written by our own `index` -> same SAM"""
+    d = golden_tmp["basic"]
+    sfx = str(tmp_path / "own.sfx")
+    run(["index", "-i", os.path.join(d, "genome.fa"), "-o", sfx, "-r", "basic"], str(tmp_path))
+    gzr = os.path.join(helpers.GOLDEN, "basic", "reads.fa.gz")
+    out = str(tmp_path / "o.sam")
+    run(["align", "-i", gzr, "-I", sfx, "-o", out, "-M6", "-s3"], str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
