@@ -1,0 +1,40 @@
+// test harness: applies the host's reference-order sort (biokanga_amd/csrc/host/mtqsort.h) with the
+// SortHitMatch comparator to a binary array of bk_hit records (20 B each) and writes the order.
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../biokanga_amd/csrc/host/mtqsort.h"
+#include "../../include/biokanga_amd.h"
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 3;
+    std::vector<bk_hit> hits;
+    bk_hit h;
+    while (fread(&h, sizeof(h), 1, f) == 1) hits.push_back(h);
+    fclose(f);
+    std::vector<uint32_t> order(hits.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    const bk_hit *H = hits.data();
+    auto cmp = [H](uint32_t x, uint32_t y) -> int {
+        const bk_hit &p = H[x], &q = H[y];
+        if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
+        if (p.num_hits == 1 && q.num_hits != 1) return -1;
+        if (p.num_hits != 1 && q.num_hits == 1) return 1;
+        if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
+        if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
+        if (p.match_loci != q.match_loci) return p.match_loci < q.match_loci ? -1 : 1;
+        if (p.match_len != q.match_len) return p.match_len < q.match_len ? -1 : 1;
+        if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
+        if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
+        return 0;
+    };
+    bk::ref_order_sort(order.data(), (int64_t)order.size(), cmp);
+    FILE *g = fopen(argv[2], "wb");
+    fwrite(order.data(), 4, order.size(), g);
+    fclose(g);
+    return 0;
+}

@@ -294,12 +294,64 @@ def make_repeat(tmp):
     ])
 
 
+def make_sortorder(tmp):
+    """30 000 reads (>= cMinUseLibQsort 25 000, so the reference's own quicksort - not glibc's stable
+    merge sort - orders the output) drawn from 2 500 loci, i.e. with many exact ties: pins the tie
+    order the sort replica has to reproduce (MTqsort.cpp:313-479)."""
+    rng = np.random.default_rng(4242)
+    outdir = os.path.join(HERE, "sortorder")
+    os.makedirs(outdir, exist_ok=True)
+    basic = os.path.join(HERE, "basic")
+    fa = os.path.join(tmp, "so.fa")
+    with gzip.open(os.path.join(basic, "genome.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    seqs = {}
+    name = None
+    for line in open(fa):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = []
+        else:
+            seqs[name].append(line.upper())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    loci = [("chrA" if rng.integers(0, 2) == 0 else "chrB", int(rng.integers(0, 99900))) for _ in range(2500)]
+    reads = []
+    for i in range(30000):
+        c, p = loci[int(rng.integers(0, len(loci)))]
+        s = seqs[c][p:p + 60]
+        if "N" in s:
+            s = seqs["chrA"][100:160]
+        e = int(rng.integers(0, 3))
+        r = mutate(rng, s, e)
+        if rng.integers(0, 2):
+            r = revcomp(r)
+        reads.append((f"q{i}", r))
+    rd = os.path.join(tmp, "so_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "so.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "basic", "-T4"], tmp)
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for threads in ("-T1", "-T8"):
+        out = os.path.join(tmp, f"so{threads}.sam")
+        run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M5", "-s3", threads], tmp)
+    a = open(os.path.join(tmp, "so-T1.sam"), "rb").read()
+    b = open(os.path.join(tmp, "so-T8.sam"), "rb").read()
+    assert a == b, "reference output order depends on the thread count"
+    gz_copy(os.path.join(tmp, "so-T8.sam"), os.path.join(outdir, "s3.m5.sam.gz"))
+    print("  sortorder fixture written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
+        if "--only-sortorder" in sys.argv:
+            make_sortorder(tmp)
+            return
         make_basic(tmp)
         make_repeat(tmp)
+        make_sortorder(tmp)
     print("done")
 
 

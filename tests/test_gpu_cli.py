@@ -85,3 +85,12 @@ def test_gz_reads_and_own_index_roundtrip(golden_tmp, tmp_path):
     out = str(tmp_path / "o.sam")
     run(["align", "-i", gzr, "-I", sfx, "-o", out, "-M6", "-s3"], str(tmp_path))
     assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
+
+
+def test_align_30000_reads_order_byte_identical(golden_tmp, tmp_path):
+    """>= 25 000 reads: the reference orders its output with its own quicksort (tie order!)"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "o.sam")
+    run(["align", "-i", os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
+         "-o", out, "-s3"], str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("sortorder", "s3.m5.sam.gz")
