@@ -27,6 +27,12 @@ void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
 void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
+void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
+void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+                  uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
+                  uint32_t *cmax_next, int nw, hipStream_t s);
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
+                 uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
@@ -57,6 +63,8 @@ struct bk_ctx {
     uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
     uint32_t *d_ent_id = nullptr;
     void *d_ktab = nullptr;
+    uint32_t *d_isa = nullptr;
+    int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     bool ktab64 = false;
     int k_req = -1;          // requested k (-1 auto)
     int use_ktab = 1;
@@ -68,8 +76,8 @@ struct bk_ctx {
     // batch scratch (grown on demand)
     uint32_t cap_reads = 0, cap_wpr = 0;
     uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
-    uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr;
-    uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen
+    uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
+    uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror
     unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
     // heavy path scratch
@@ -125,7 +133,7 @@ int derive_cfg(bk_ctx *c)
     case 2: g.max_iter = 20000; break;
     default: g.max_iter = 2500; break;
     }
-    if (g.heavy_thresh < 0 || g.heavy_thresh > 100) g.heavy_thresh = 100;
+    if (g.heavy_thresh < 0 || g.heavy_thresh > 100) g.heavy_thresh = 8;
     return BK_OK;
 }
 
@@ -163,6 +171,20 @@ int build_ktab(bk_ctx *c)
     if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
     else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
     c->ix.k = k;
+    return BK_OK;
+}
+
+int build_isa(bk_ctx *c)
+{
+    free_dev(c->d_isa);
+    c->d_isa = nullptr;
+    c->ix.isa = nullptr;
+    if (!c->use_wave || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
+    HIP_TRY(hipMalloc(&c->d_isa, c->ix.n * 4));
+    launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ix.isa = c->d_isa;
     return BK_OK;
 }
 
@@ -225,6 +247,8 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     if (rc) return rc;
     rc = build_ktab(c);
     if (rc) return rc;
+    rc = build_isa(c);
+    if (rc) return rc;
     return size_heavy_scratch(c);
 }
 
@@ -239,7 +263,7 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     bk_ctx *c = new bk_ctx();
     c->device = device_id;
     c->params = *p;
-    c->cfg.heavy_thresh = 100;
+    c->cfg.heavy_thresh = 8;
     if (c->params.max_ml == 0) c->params.max_ml = 1;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BK_ERR_INTERNAL; }
     *pc = c;
@@ -274,9 +298,9 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr)
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave);
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr;
-    c->d_act[0] = c->d_act[1] = c->d_heavy = nullptr;
+    c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
     HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
@@ -284,6 +308,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr)
     HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
     c->cap_reads = nr;
     c->cap_wpr = w;
     return BK_OK;
@@ -342,6 +367,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
+    // register-resident window kernels handle reads of <= 128 / <= 256 bases
+    const bool reg_path = c->use_wave && maxlen <= 256;
+    const int nw16 = maxlen <= 128 ? 8 : 16;
 
     hipEvent_t e0 = tm.begin(s);
     launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
@@ -353,8 +381,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     int cmax = (int)hm[3];
     int cur = 0;
     for (int phase = 0; n_act > 0; phase++) {
-        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor
+        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
+        HIP_TRY(hipMemsetAsync(sm + 6, 0, 2 * 4, s));
         if (cmax > 0) {
             hipEvent_t e1 = tm.begin(s);
             launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, s);
@@ -362,22 +391,34 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             tm.end(0, e1, s);
         }
         hipEvent_t e2 = tm.begin(s);
-        launch_extend(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
+        if (reg_path)
+            launch_light(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
+                         sm + 3, nw16, s);
+        else
+            launch_extend(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
         HIP_TRY(hipGetLastError());
         tm.end(1, e2, s);
         HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        uint32_t n_heavy = hm[2];
+        uint32_t n_heavy = hm[2], n_wave = hm[6];
+        if (n_wave) {
+            hipEvent_t e3 = tm.begin(s);
+            launch_wave(c->ix, c->cfg, b, c->d_wave, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
+            HIP_TRY(hipGetLastError());
+            tm.end(2, e3, s);
+        }
         if (n_heavy) {
             hipEvent_t e3 = tm.begin(s);
             launch_heavy(c->ix, c->cfg, b, c->hs, c->d_heavy, n_heavy, phase, sm + 4, c->d_act[cur ^ 1], sm + 1, sm + 3, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
+        }
+        if (n_wave || n_heavy) {
             HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         if (getenv("BK_DEBUG"))
-            fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, hm[1], hm[3]);
+            fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u n_wave %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, n_wave, hm[1], hm[3]);
         n_act = hm[1];
         cmax = (int)hm[3];
         cur ^= 1;
@@ -511,7 +552,8 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_ktab);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_small);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
+    free_dev(c->d_isa);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -554,6 +596,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         if (n == "use_ktab") c->use_ktab = value ? 1 : 0;
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
         int rc = build_ktab(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_wave") {
+        int64_t old = c->use_wave;
+        c->use_wave = value ? 1 : 0;
+        int rc = build_isa(c);
         return rc ? rc : old;
     }
     if (n == "max_read_len") {

@@ -363,10 +363,10 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     int strand = cfg.align_strand == 2 ? 1 : si;
     const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
     uint64_t first, count;
-    search_core<WIDE>(ix, rdw, my_ofs, cl, (uint64_t)cfg.heavy_thresh + 1, first, count);
+    search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, count);     // exact run length
     uint64_t slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
     b.iv_first[slot] = first;
-    b.iv_n[slot] = (uint32_t)count;
+    b.iv_n[slot] = count > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)count;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -461,6 +461,392 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         if (n_cand) atomicAdd(&b.ctr[1], n_cand);
         if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Register-resident candidate evaluation for reads of <= 16*NW bases (NW = 8 or 16 sixteen-base words).
+// One pass over the target window gives everything the reference's loop derives per candidate:
+//   * EOS inside the window  <=> the read would cross an entry boundary (MapChunkHit2Entry bounds test)
+//   * a bit-per-base mismatch map: Hamming distance = popcount, "core c' matches exactly here" = its
+//     bit range is clear (which is what the reference's dedupe set encodes, see k_wave)
+// The nw+1 window words are independent loads, all in flight together.
+
+template <int NW>
+struct Window {
+    uint64_t bm[NW / 4];        // mismatch bit map, bit b of bm[b/64] = base b differs
+    int mm;
+    bool eos;
+};
+
+__device__ __forceinline__ uint32_t flags_to_bits16(uint64_t f)   // f: flags at bit 0 of each nibble, base 0 in the top nibble
+{
+    uint64_t g = __brevll(f) >> 3;                                 // flag of base k now at bit 4k
+    g = (g | (g >> 3)) & 0x0303030303030303ULL;
+    g = (g | (g >> 6)) & 0x000F000F000F000FULL;
+    g = (g | (g >> 12)) & 0x000000FF000000FFULL;
+    g = (g | (g >> 24)) & 0xFFFFULL;
+    return (uint32_t)g;                                            // bit k = base k
+}
+
+template <int NW>
+__device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, const uint64_t *__restrict__ tgt, uint64_t t,
+                                            Window<NW> &w)
+{
+    const uint64_t i0 = t >> 4;
+    const unsigned s = (unsigned)(t & 15) << 2;
+    uint64_t raw[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; k++) raw[k] = (16 * (k - 1) < len || k == 0) ? tgt[i0 + k] : 0;   // word k is needed iff base 16(k-1) exists
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) w.bm[k] = 0;
+    uint64_t eosacc = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        if (16 * k < len) {
+            uint64_t win = (raw[k] << s) | ((raw[k + 1] >> 1) >> (63 - s));
+            uint64_t m = top_mask(len - 16 * k);
+            uint64_t x = (rw[k] ^ win) & m;
+            uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+            eosacc |= win & (win >> 1) & (win >> 2) & m & 0x1111111111111111ULL;      // nibble 7 = EOS
+            w.bm[k >> 2] |= (uint64_t)flags_to_bits16(f) << (16 * (k & 3));
+        }
+    }
+    int mm = 0;
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) mm += __popcll(w.bm[k]);
+    w.mm = mm;
+    w.eos = eosacc != 0;
+}
+
+// true when bases [o, o+cl) of the read all match the window (cl >= 1)
+template <int NW>
+__device__ __forceinline__ bool core_clean(const Window<NW> &w, int o, int cl)
+{
+    const int hi = o + cl;
+    bool dirty = false;
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) {
+        int a = o > 64 * k ? o - 64 * k : 0;
+        int b = hi < 64 * k + 64 ? hi - 64 * k : 64;
+        if (a < b) {
+            uint64_t m = (b >= 64 ? ~0ULL : ((1ULL << b) - 1)) & ~((1ULL << a) - 1);
+            dirty |= (w.bm[k] & m) != 0;
+        }
+    }
+    return !dirty;
+}
+
+template <int NW>
+__device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw, int len, uint64_t (&rw)[NW])
+{
+#pragma unroll
+    for (int k = 0; k < NW; k++) rw[k] = 16 * k < len ? rdw[k] : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_light: one lane per read, reads of <= 16*NW bases whose core intervals are all <= heavy_thresh
+// long.  Same contract as k_extend (which stays for longer reads); differences: the window is
+// evaluated once in registers, bounds come from the EOS test instead of the entry table, and calls
+// it cannot take go to the wave kernel (`wave`) or to the general kernel (`heavy`).
+
+template <bool WIDE, int NW>
+__global__ void __launch_bounds__(256) k_light(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                               uint32_t n_act, int phase, uint32_t *__restrict__ next_act,
+                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
+                                               uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
+                                               uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
+{
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    if (a < n_act) {
+        uint32_t r = act[a];
+        int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd, ofs[kMaxCoresFast];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        int nc = core_offsets(len, cl, cd, p.max_slides, ofs, kMaxCoresFast);
+        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        bool fits = nc <= kMaxCoresFast && len <= 16 * NW;
+        bool is_heavy = !fits;
+        if (fits)
+            for (int st = s0; st <= s1; st++)
+                for (int c = 0; c < nc; c++)
+                    if (b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+        if (is_heavy) {
+            if (fits && !WIDE && ix.isa != nullptr && wave != nullptr) wave[atomicAdd(wave_cnt, 1u)] = r;
+            else heavy[atomicAdd(heavy_cnt, 1u)] = r;
+        } else {
+            n_lcm = 1;
+            const int init = mm + cfg.mm_delta + 1;
+            int low_inst = 0, low_mm = init, nxt = init;
+            uint64_t hit_left = 0;
+            int hit_strand = '?';
+            bool done = false;
+            for (int st = s0; st <= s1 && !done; st++) {
+                uint64_t rw[NW];
+                load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
+                for (int c = 0; c < nc && !done; c++) {
+                    n_search++;
+                    uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + c;
+                    uint32_t n = b.iv_n[slot];
+                    uint64_t first = b.iv_first[slot];
+                    for (uint32_t j = 0; j < n; j++) {
+                        uint64_t loci = sa_get<WIDE>(ix, first + j);
+                        if (loci < (uint64_t)ofs[c]) continue;
+                        uint64_t t = loci - (uint64_t)ofs[c];
+                        Window<NW> w;
+                        eval_window<NW>(rw, len, ix.tgt4, t, w);
+                        if (w.eos) continue;                                    // crosses an entry boundary
+                        bool dup = false;                                       // reached through an earlier core already?
+                        for (int c2 = 0; c2 < c; c2++) dup |= core_clean<NW>(w, ofs[c2], cl);
+                        if (dup) continue;
+                        n_cand++;
+                        int cm = w.mm;
+                        if (cm > mm || cm >= nxt) continue;
+                        if (cm < low_mm) {
+                            low_inst = 1; nxt = low_mm; low_mm = cm;
+                            hit_left = t; hit_strand = st ? '-' : '+';
+                        } else if (cm == low_mm)
+                            low_inst++;
+                        else
+                            nxt = cm;
+                        if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
+                    }
+                }
+            }
+            int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+            if (rslt != BK_HR_NONE) {
+                int e = low_inst >= 1 ? find_entry(ix, hit_left) : -1;
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
+            } else if (phase + 1 < p.n_phases) {
+                int mm2, cl2, cd2, dummy[1];
+                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
+                next_act[atomicAdd(next_cnt, 1u)] = r;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_search += __shfl_down(n_search, off);
+        n_cand += __shfl_down(n_cand, off);
+        n_lcm += __shfl_down(n_lcm, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_wave: one wave per LocateCoreMultiples call for reads of <= 16*NW bases and <= 16 cores per
+// strand (4-byte suffix arrays).  64 candidates of a core interval per step; the reference's
+// SEQUENTIAL semantics are reproduced exactly with ballot prefix sums, as in k_heavy:
+//   IterCnt counts only new, in-bounds targets; at the first loop top with IterCnt == 100 the
+//   remaining copy count (n - j + 2) abandons the core when > MaxIter; MaxIter and the 1 024 000
+//   node cap stop it; after MaxHits+1 exact instances everything stops (SfxArrayV2.cpp:5857-5875,6206).
+// The reference's hash set of already-seen target starts is replaced by an equivalent test: target
+// start T reached through core c was already processed in this strand pass  <=>  for some earlier
+// core c2 the read's core c2 matches the target at T (so T+ofs[c2] lies in c2's suffix interval) AND
+// that suffix lay inside the prefix of c2's interval that was actually walked (rank from the inverse
+// suffix array; only looked up when c2's walk was cut short).
+
+struct WaveCoreInfo {
+    unsigned long long first;
+    uint32_t n;
+    uint32_t walked;        // number of leading SA entries of the interval whose loop body was reached
+    int ofs;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list,
+                                              uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
+                                              uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
+                                              uint32_t *__restrict__ cmax_next)
+{
+    __shared__ WaveCoreInfo s_core[4][kMaxCoresFast];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    WaveCoreInfo *core = s_core[wib];
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(cursor, 1u);
+        item = __shfl(item, 0);
+        if (item >= n_list) break;
+        const uint32_t r = list[item];
+        const int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd;
+        phase_params(p, cfg, phase, mm, cl, cd);
+        n_lcm++;
+        const int init = mm + cfg.mm_delta + 1;
+        int low_inst = 0, low_mm = init, nxt = init;
+        uint64_t hit_left = 0;
+        int hit_strand = '?';
+        bool done = false;
+        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        // core geometry (same for both strands)
+        int nc;
+        {
+            int ofs_tmp[kMaxCoresFast];
+            nc = core_offsets(len, cl, cd, p.max_slides, ofs_tmp, kMaxCoresFast);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nc && lane < kMaxCoresFast) {
+                int o = 0;
+#pragma unroll
+                for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
+                core[lane].ofs = o;
+            }
+        }
+        for (int st = s0; st <= s1 && !done; st++) {
+            uint64_t rw[NW];
+            load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
+            if (lane < nc) {
+                uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + lane;
+                core[lane].first = b.iv_first[slot];
+                core[lane].n = b.iv_n[slot];
+                core[lane].walked = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t nodes = 0;
+            for (int c = 0; c < nc && !done && nodes < kNodeCap; c++) {
+                n_search++;
+                const uint64_t first = core[c].first;
+                const uint64_t n = core[c].n;
+                const int ofs = core[c].ofs;
+                uint32_t iter = 0;
+                bool copies_checked = false;
+                uint64_t walked = n;
+                for (uint64_t j0 = 0; j0 < n && !done; j0 += 64) {
+                    const uint64_t j = j0 + lane;
+                    const bool active = j < n;
+                    const uint64_t loci = active ? sa_get<false>(ix, first + j) : 0;
+                    const uint64_t t = loci - (uint64_t)ofs;
+                    bool valid = active && loci >= (uint64_t)ofs;
+                    Window<NW> w;
+                    w.mm = 127; w.eos = true;
+#pragma unroll
+                    for (int k = 0; k < NW / 4; k++) w.bm[k] = ~0ULL;
+                    if (valid) {
+                        eval_window<NW>(rw, len, ix.tgt4, t, w);
+                        valid = !w.eos;
+                    }
+                    bool dup = false;
+                    for (int c2 = 0; c2 < c; c2++) {
+                        bool m = valid && !dup && core_clean<NW>(w, core[c2].ofs, cl);
+                        if (__ballot(m)) {
+                            if (m) {
+                                if (core[c2].walked >= core[c2].n) dup = true;
+                                else {
+                                    uint64_t rank = (uint64_t)ix.isa[t + (uint64_t)core[c2].ofs] - core[c2].first;
+                                    dup = rank < (uint64_t)core[c2].walked;
+                                }
+                            }
+                        }
+                    }
+                    const bool isnew = valid && !dup;
+                    const uint64_t newmask = __ballot(isnew);
+                    const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
+                    const uint32_t iter_before = iter + pre;
+                    const uint32_t nodes_before = nodes + pre;
+                    bool stop = active && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
+                    uint64_t cutoff = n;
+                    uint64_t stopmask = __ballot(stop);
+                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                    if (!copies_checked) {
+                        bool chk = active && j > 0 && iter_before == 100;
+                        uint64_t chkmask = __ballot(chk);
+                        if (chkmask) {
+                            uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                            if (jc < cutoff) {
+                                copies_checked = true;
+                                uint64_t num_copies = n - jc + 2;
+                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                            }
+                        }
+                    }
+                    const bool proc = active && j < cutoff && isnew;
+                    int cm = (proc && w.mm <= mm && w.mm < nxt) ? w.mm : 127;
+                    bool acc = cm != 127;
+                    uint64_t keep = ~0ULL;
+                    uint64_t zmask = __ballot(acc && cm == 0);
+                    int zc0 = low_mm == 0 ? low_inst : 0;
+                    bool exit_now = false;
+                    if (zmask && zc0 + __popcll(zmask) > cfg.max_hits) {
+                        int need = cfg.max_hits + 1 - zc0;
+                        uint64_t z = zmask;
+                        for (int q = 1; q < need; q++) z &= z - 1;
+                        int cut_lane = __ffsll((unsigned long long)z) - 1;
+                        keep = cut_lane >= 63 ? ~0ULL : ((2ULL << cut_lane) - 1);
+                        exit_now = true;
+                    }
+                    uint64_t procmask = __ballot(proc) & keep;
+                    uint32_t nproc = (uint32_t)__popcll(procmask);
+                    iter += nproc;
+                    nodes += nproc;
+                    n_cand += (lane == 0) ? nproc : 0;
+                    acc = acc && ((keep >> lane) & 1);
+                    uint64_t accmask = __ballot(acc);
+                    if (accmask) {
+                        int v = acc ? cm : 127;
+                        int bmin = v;
+                        for (int off = 32; off > 0; off >>= 1) { int q = __shfl_xor(bmin, off); bmin = q < bmin ? q : bmin; }
+                        int v2 = (acc && cm > bmin) ? cm : 127;
+                        int bsec = v2;
+                        for (int off = 32; off > 0; off >>= 1) { int q = __shfl_xor(bsec, off); bsec = q < bsec ? q : bsec; }
+                        uint64_t minmask = __ballot(acc && cm == bmin);
+                        int cnt = __popcll(minmask);
+                        int fl = __ffsll((unsigned long long)minmask) - 1;
+                        if (bmin < low_mm) {
+                            nxt = low_mm < bsec ? low_mm : bsec;
+                            low_mm = bmin;
+                            low_inst = cnt;
+                            hit_left = __shfl(t, fl);
+                            hit_strand = st ? '-' : '+';
+                        } else if (bmin == low_mm) {
+                            low_inst += cnt;
+                            if (bsec < nxt) nxt = bsec;
+                        } else if (bmin < nxt)
+                            nxt = bmin;
+                    }
+                    if (exit_now) done = true;
+                    if (cutoff < j0 + 64) { walked = cutoff; break; }
+                }
+                if (lane == 0) core[c].walked = walked > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)walked;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+        if (lane == 0) {
+            if (rslt != BK_HR_NONE) {
+                int e = low_inst >= 1 ? find_entry(ix, hit_left) : -1;
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, (phase << 1) | 1);
+            } else if (phase + 1 < p.n_phases) {
+                int mm2, cl2, cd2, dummy[1];
+                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
+                next_act[atomicAdd(next_cnt, 1u)] = r;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+    }
+}
+
+__global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_t *__restrict__ isa)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) isa[sa[i]] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,6 +1145,34 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
     unsigned blocks = (n_act + 255) / 256;
     if (ix.sa_hi) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
     else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
+}
+
+void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s)
+{
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(k_build_isa, dim3((unsigned)blocks), dim3(256), 0, s, sa, n, isa);
+}
+
+void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+                  uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
+                  uint32_t *cmax_next, int nw, hipStream_t s)
+{
+    unsigned blocks = (n_act + 255) / 256;
+    bool wide = ix.sa_hi != nullptr;
+#define BK_LIGHT(W, N) hipLaunchKernelGGL((k_light<W, N>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
+    if (nw <= 8) { if (wide) BK_LIGHT(true, 8); else BK_LIGHT(false, 8); }
+    else { if (wide) BK_LIGHT(true, 16); else BK_LIGHT(false, 16); }
+#undef BK_LIGHT
+}
+
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
+                 uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s)
+{
+    uint32_t waves = n_list < max_waves ? n_list : max_waves;
+    unsigned blocks = (waves + 3) / 4;
+    if (nw <= 8) hipLaunchKernelGGL((k_wave<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
+    else hipLaunchKernelGGL((k_wave<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
 }
 
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,

@@ -129,7 +129,8 @@ void bk_ctx_destroy(bk_ctx *ctx);
 
 /* change alignment parameters (re-derives MinCoreLen, MaxIter, slides) */
 int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
-/* tuning knobs: name = "kmer_bits" | "heavy_thresh" | "chunk_reads" | "use_ktab"; returns old value or <0 */
+/* tuning knobs: name = "kmer_bits" | "heavy_thresh" | "chunk_reads" | "use_ktab" | "use_wave" | "max_read_len";
+ * returns the old value or <0 */
 int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
 
 uint32_t bk_num_entries(const bk_ctx *ctx);

@@ -57,8 +57,8 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat"])
-@pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("use_ktab", 0), ("kmer_bits", 4),
-                                  ("kmer_bits", 12), ("chunk_reads", 333)])
+@pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
+                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0)])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""
@@ -215,7 +215,9 @@ def test_repeatable(tmp_path):
     with bk.Aligner(None, bk.AlignParams(max_subs=10), d_seq=d_seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(),
                     el_size=4, entries=ents) as al:
         ref = al.align(bases, offs, lens)
-        for thresh in (100, 99, 10, 100, 0, 100):
-            al.tune("heavy_thresh", thresh)
-            for _ in range(4):
-                assert_hits_equal(al.align(bases, offs, lens), ref)
+        for wave in (1, 0):
+            al.tune("use_wave", wave)
+            for thresh in (100, 8, 99, 10, 0):
+                al.tune("heavy_thresh", thresh)
+                for _ in range(3):
+                    assert_hits_equal(al.align(bases, offs, lens), ref)
