@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--max-subs", type=int, default=3, help="`-s` of biokanga align")
     ap.add_argument("--cpu-baseline-secs", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
+    ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
+    ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
     args = ap.parse_args()
 
     import numpy as np
@@ -133,6 +135,9 @@ def main():
                     d_sa=sa.data_ptr(), el_size=4, entries=ent)
     if args.kmer_bits:
         al.tune("kmer_bits", args.kmer_bits)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        al.tune(k, int(v))
     log(f"context (packed target + k-mer table) ready in {time.time() - t0:.1f}s; MinCoreLen {al.min_core_len}")
     t0 = time.time()
     rd_bases, rd_offs, rd_lens, truth = synth.make_reads(seq, seq_lens, args.reads, args.read_len, dev,
@@ -156,6 +161,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.sweep:
+        name, vals = args.sweep.split("=")
+        for v in vals.split(","):
+            al.tune(name, int(v))
+            step()
+            al.timing(reset=True)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            step()
+            torch.cuda.synchronize()
+            log(f"sweep {name}={v}: {1e3 * (time.time() - t1):.1f} ms/step wall; device {al.timing(reset=True)}")
     al.counters(reset=True)
     al.timing(reset=True)
     barrier()

@@ -3,7 +3,7 @@
 //   k_pack_target   1 B/base target -> 4-bit packed words (index upload)
 //   k_split_sa5     5-byte suffix elements -> lo32 + hi8 arrays
 //   k_build_ktab    k-mer -> SA lower-bound table from the sorted suffix array
-//   k_prep_reads    N policy (Aligner.cpp:9041-9063), pack read + reverse complement (SeqTrans.cpp:458-512)
+//   k_pack_reads / k_init_reads   pack read + reverse complement (SeqTrans.cpp:458-512), N policy (Aligner.cpp:9041-9063)
 //   k_search        K1: one lane per (read, strand, core): SA interval of the core
 //                   = LocateFirstExact (SfxArrayV2.cpp:7765) + the extent of the matching run
 //   k_extend        K2/K3: one lane per read: candidate walk in SA order, bounds + dedupe, Hamming
@@ -139,6 +139,7 @@ __device__ __forceinline__ void search_core(const DevIndex &ix, const uint64_t *
     count = 0;
     if (lo >= end) return;
     if (cmp_core(rdw, ofs, cl, p0, ix.tgt4, sa_get<WIDE>(ix, lo)) != 0) return;
+    if (end - lo == 1) { count = 1; return; }            // bucket of one suffix: nothing else can match
     // gallop over the run of matches, then bisect its end
     uint64_t limit = end - lo < cap ? end : lo + cap;    // exclusive
     uint64_t cur = lo, step = 1;
@@ -275,54 +276,71 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_prep_reads: one lane per read
+// read preparation: k_pack_reads (one lane per packed 16-base word of the read or of its reverse
+// complement: 16 byte loads, one 8-byte store) then k_init_reads (one lane per read: N policy of
+// Aligner.cpp:9041-9063 from the packed words, default result record, first active list).
+// Nibble written for a base byte v: v & 7 (quality / mask bits dropped); values 5..7 mark a byte
+// the reference would refuse ((*pSeq = (*pSeqVal & 0x07)) > eBaseN).
 
-__global__ void k_prep_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act, uint32_t *__restrict__ act_cnt,
-                             uint32_t *__restrict__ cmax)
+__global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
+{
+    const uint32_t wpr = b.wpr;
+    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t per_read = 2ULL * wpr;
+    uint64_t r = tid / per_read;
+    if (r >= b.n_reads) return;
+    uint32_t rem = (uint32_t)(tid - r * per_read);
+    uint32_t st = rem / wpr, w = rem - st * wpr;
+    int len = (int)b.lens[r];
+    const uint8_t *s = b.bases + b.offs[r];
+    uint64_t v = 0;
+    int base0 = 16 * (int)w;
+    if (base0 < len) {
+        int cnt = len - base0 < 16 ? len - base0 : 16;
+        if (st == 0) {
+            for (int k = 0; k < cnt; k++) v |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
+        } else {
+            // reverse complement: A<->T, C<->G, others unchanged (SeqTrans.cpp:458-512)
+            for (int k = 0; k < cnt; k++) {
+                uint8_t x = s[len - 1 - base0 - k] & 7;
+                x = x < 4 ? (uint8_t)(3 - x) : x;
+                v |= (uint64_t)x << (60 - 4 * k);
+            }
+        }
+    }
+    b.rd4[r * per_read + rem] = v;
+}
+
+__global__ void __launch_bounds__(256) k_init_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
+                                                     uint32_t *__restrict__ act_cnt, uint32_t *__restrict__ cmax)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= b.n_reads) return;
     int len = (int)b.lens[r];
-    const uint8_t *s = b.bases + b.offs[r];
     bk_hit h;
     h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
     h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
-    // N policy, Aligner.cpp:9041-9063
-    int max_ns_seq = 0, num_ns = 0, i;
+    int max_ns_seq = 0;
     if (cfg.max_ns) {
         max_ns_seq = (len * cfg.max_ns) / 100;
         if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
     }
-    uint64_t *fw = b.rd4 + (uint64_t)r * 2 * b.wpr;
-    uint64_t *rc = fw + b.wpr;
-    uint64_t acc = 0;
-    for (i = 0; i < len; i++) {
-        uint8_t v = s[i] & 0x07;
-        if (v > 4) break;
-        if (v == 4 && ++num_ns > max_ns_seq) break;
-        acc = (acc << 4) | v;
-        if ((i & 15) == 15) { fw[i >> 4] = acc; acc = 0; }
+    const uint64_t *fw = b.rd4 + (uint64_t)r * 2 * b.wpr;
+    int num_ns = 0;
+    bool bad = false;
+    for (int w = 0; 16 * w < len; w++) {
+        uint64_t x = fw[w] & top_mask(len - 16 * w);
+        uint64_t hi = x & 0x4444444444444444ULL;                    // values 4..7
+        uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;       // low two bits non-zero
+        bad |= ((hi >> 2) & lo) != 0;                               // 5,6,7: not a base the reference accepts
+        num_ns += __popcll(hi);
     }
-    if (i != len) {
+    if (bad || num_ns > max_ns_seq) {
         h.nar = BK_NAR_NS;
         b.out[r] = h;
         return;
     }
     b.out[r] = h;
-    int nw = (len + 15) >> 4;
-    if (len & 15) fw[len >> 4] = acc << (4 * (16 - (len & 15)));
-    for (int w = nw; w < (int)b.wpr; w++) fw[w] = 0;
-    // reverse complement: A<->T, C<->G, N stays (SeqTrans.cpp:458-512)
-    acc = 0;
-    for (i = 0; i < len; i++) {
-        uint8_t v = s[len - 1 - i] & 0x07;
-        v = v < 4 ? (uint8_t)(3 - v) : v;
-        acc = (acc << 4) | v;
-        if ((i & 15) == 15) { rc[i >> 4] = acc; acc = 0; }
-    }
-    if (len & 15) rc[len >> 4] = acc << (4 * (16 - (len & 15)));
-    for (int w = nw; w < (int)b.wpr; w++) rc[w] = 0;
-
     ReadPlan p = make_plan(len, cfg);
     if (p.n_phases > 0) {
         int mm, cl, cd, ofs[1];
@@ -536,6 +554,12 @@ __device__ __forceinline__ bool core_clean(const Window<NW> &w, int o, int cl)
     return !dirty;
 }
 
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)      // value known to be wave-uniform -> scalar registers
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int NW>
 __device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw, int len, uint64_t (&rw)[NW])
 {
@@ -550,7 +574,7 @@ __device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw
 // it cannot take go to the wave kernel (`wave`) or to the general kernel (`heavy`).
 
 template <bool WIDE, int NW>
-__global__ void __launch_bounds__(256) k_light(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                uint32_t n_act, int phase, uint32_t *__restrict__ next_act,
                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
                                                uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
@@ -660,7 +684,7 @@ struct WaveCoreInfo {
 };
 
 template <int NW>
-__global__ void __launch_bounds__(256) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list,
+__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list,
                                               uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
                                               uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
                                               uint32_t *__restrict__ cmax_next)
@@ -705,6 +729,8 @@ __global__ void __launch_bounds__(256) k_wave(DevIndex ix, DevAlignCfg cfg, DevB
         for (int st = s0; st <= s1 && !done; st++) {
             uint64_t rw[NW];
             load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
+#pragma unroll
+            for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);      // same read for the whole wave
             if (lane < nc) {
                 uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + lane;
                 core[lane].first = b.iv_first[slot];
@@ -1126,7 +1152,9 @@ void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t
 
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prep_reads, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
+    uint64_t words = (uint64_t)b.n_reads * 2 * b.wpr;
+    hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_init_reads, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
 }
 
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
