@@ -133,7 +133,7 @@ int derive_cfg(bk_ctx *c)
     case 2: g.max_iter = 20000; break;
     default: g.max_iter = 2500; break;
     }
-    if (g.heavy_thresh < 0 || g.heavy_thresh > 100) g.heavy_thresh = 8;
+    if (g.heavy_thresh < 0 || g.heavy_thresh > 100) g.heavy_thresh = 64;
     return BK_OK;
 }
 
@@ -263,7 +263,7 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     bk_ctx *c = new bk_ctx();
     c->device = device_id;
     c->params = *p;
-    c->cfg.heavy_thresh = 8;
+    c->cfg.heavy_thresh = 64;
     if (c->params.max_ml == 0) c->params.max_ml = 1;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BK_ERR_INTERNAL; }
     *pc = c;

@@ -645,3 +645,265 @@ int ora_align_batch(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
     free(w); free(th);
     return rslt;
 }
+
+/* =========================================================================================== */
+/* Paired-end association: restatement of CAligner::ProcessPairedEnds (biokanga/Aligner.cpp:
+ * 3055-3489), AcceptProvPE / PEInsertSize (:2726-2850), CSfxArrayV3::AlignPairedRead
+ * (libbiokanga/SfxArrayV2.cpp:8247-8433), AdaptiveTrim (:5482-5682), IterateExactsRange (:3382-3474).
+ * Chromosome filters, circularised PE and chimeric trimming are off (their defaults). */
+
+enum { NAR_CHROMFILT = 11, NAR_PEINSERTMIN = 13, NAR_PEINSERTMAX = 14, NAR_PENOHIT = 15, NAR_PESTRAND = 16,
+       NAR_PECHROM = 17, NAR_PEUNALIGN = 18 };
+enum { PE_ORPHAN = 1, PE_UNIQUE = 2, PE_ORPHAN_SE = 3, PE_UNIQUE_SE = 4 };
+
+/* PEInsertSize, Aligner.cpp:2802-2850 */
+static int pe_insert_size(int min_len, int max_len, int pair_strand, uint8_t s1, uint32_t st1, uint32_t en1,
+                          uint8_t s2, uint32_t st2, uint32_t en2)
+{
+    int frag;
+    if ((pair_strand && s1 != s2) || (!pair_strand && s1 == s2)) return -1;
+    if (s1 == '+') frag = 1 + (int)en2 - (int)st1;
+    else frag = 1 + (int)en1 - (int)st2;
+    if (frag < 0) return -1;
+    if (frag < min_len) return -6;
+    if (frag > max_len) return -7;
+    return frag;
+}
+
+typedef struct at_region { uint16_t ofs, len; uint8_t mm, trim5, trim3; } at_region;
+
+/* AdaptiveTrim, SfxArrayV2.cpp:5482-5682 */
+static int adaptive_trim(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
+                         uint32_t min_flank, uint32_t *p_trim_mms)
+{
+    static __thread at_region regs[2048];
+    *p_trim_mms = 0;
+    if (seq_len < 25 || seq_len > 2048 || min_trim_len < 15 || min_trim_len > seq_len || max_mm > 15 || min_flank > 10)
+        return -100;
+    if (min_flank == 0) min_flank = 1;
+    uint32_t n_regs = 0, n_min_exact = 0;
+    at_region *cur = NULL;
+    for (uint32_t o = 0; o < seq_len; o++) {
+        int mm = (probe[o] & 0x0f) != (targ[o] & 0x0f);
+        if (cur == NULL || mm != cur->mm) {
+            cur = &regs[n_regs++];
+            cur->mm = (uint8_t)mm; cur->len = 1; cur->ofs = (uint16_t)o;
+        } else {
+            cur->len++;
+            if (cur->len == 8 && !mm) n_min_exact++;
+        }
+    }
+    if (!n_min_exact) return 0;
+    uint32_t first_start = 0, last_start = 0, first_end = 0, last_end = 0;
+    for (uint32_t i = 0; i < n_regs; i++) {
+        at_region *r = &regs[i];
+        r->trim5 = r->trim3 = 0;
+        if (r->mm == 0 && r->len >= min_flank) {
+            if (r->ofs <= seq_len - min_trim_len) { r->trim5 = 1; last_start = i + 1; if (!first_start) first_start = last_start; }
+            if ((uint32_t)r->ofs + r->len >= (uint16_t)min_trim_len) { r->trim3 = 1; last_end = i + 1; if (!first_end) first_end = last_end; }
+        }
+    }
+    if (!first_start || !first_end) return 0;
+    uint32_t best_len = 0, best_mm = 0;
+    for (uint32_t si = first_start - 1; si < last_start; si++) {
+        at_region *sr = &regs[si];
+        if (!sr->trim5) continue;
+        uint32_t cur_len = 0, cur_mm = 0, idx = si;
+        at_region *r = sr;
+        while (idx++ < last_end) {
+            cur_len += r->len;
+            if (r->mm) {
+                if (max_mm == 0) break;
+                cur_mm += r->len;
+                if ((max_mm + 1.0) / 100.0 <= (double)cur_mm / (seq_len - sr->ofs)) break;
+            } else if (best_len == 0) {
+                best_len = cur_len; best_mm = 0;
+                r++;
+                continue;
+            }
+            if (cur_len < min_trim_len || !r->trim3) { r++; continue; }
+            r++;
+            if ((max_mm + 1.0) / 100.0 <= (double)cur_mm / cur_len) continue;
+            if (best_len < cur_len || (best_len == cur_len && (best_mm == 0 || cur_mm < best_mm))) { best_len = cur_len; best_mm = cur_mm; }
+        }
+    }
+    if (best_len >= min_trim_len) { *p_trim_mms = best_mm; return (int)best_len; }
+    return 0;
+}
+
+/* AlignPairedRead, SfxArrayV2.cpp:8247-8433 (MinChimericLen = 0) */
+static int align_paired_read(const ora_sfx *s, int b3prime, int antisense, uint32_t chrom_id, uint32_t start_loci, uint32_t end_loci,
+                             int min_dist, int max_dist, int max_allowed_mm, int read_len, int core_len, int core_delta,
+                             const uint8_t *read, hit_rec *out)
+{
+    if (min_dist < read_len || min_dist > max_dist) return 0;
+    if (chrom_id < 1 || chrom_id > s->num_entries) return 0;
+    const ora_entry *ent = &s->entries[chrom_id - 1];
+    uint32_t targ_len = ent->seq_len;
+    if (!targ_len) return 0;
+    int targ_loci;
+    if (b3prime) { targ_loci = (int)start_loci; if ((uint32_t)(targ_loci + min_dist) > targ_len) return 0; }
+    else { targ_loci = (int)end_loci; if (targ_loci < min_dist || (uint32_t)targ_loci >= targ_len) return 0; }
+    const uint8_t *chrom = s->seq + ent->start_ofs;
+    uint8_t rs[2100];
+    memcpy(rs, read, (size_t)read_len);
+    rs[read_len] = B_EOS;
+    if (antisense) revcomp(rs, read_len);
+    uint32_t min_put_len = (uint32_t)read_len, start_put, end_put;
+    if (b3prime) {
+        start_put = (uint32_t)(targ_loci + min_dist);
+        if (start_put + min_put_len >= targ_len) return 0;
+        end_put = (uint32_t)(targ_loci + max_dist);
+    } else {
+        start_put = end_loci < (uint32_t)max_dist ? 0 : end_loci - (uint32_t)max_dist;
+        end_put = end_loci - (uint32_t)min_dist;
+    }
+    uint32_t prev_best = (uint32_t)max_allowed_mm + 1, mms;
+    memset(out, 0, sizeof(*out));
+    if (end_put - start_put >= 1000) {
+        for (uint32_t core_ofs = 0; (int)core_ofs + core_len <= read_len; core_ofs += (uint32_t)core_delta) {
+            /* IterateExactsRange: every suffix matching the core, in SA order, restricted to the window */
+            int64_t idx = ora_locate_first_exact(s, rs + core_ofs, core_len, 0, (int64_t)s->concat_len - 1, NULL);
+            if (idx == 0) continue;
+            for (idx -= 1; idx < (int64_t)s->concat_len; idx++) {
+                int64_t pos = sa_at(s, idx);
+                if (cmp_probe(rs + core_ofs, s->seq + pos, core_len) != 0) break;
+                const ora_entry *e = map_entry(s, (uint64_t)pos);
+                if (e == NULL || e->entry_id != chrom_id) continue;
+                uint32_t hit = (uint32_t)((uint64_t)pos - e->start_ofs);
+                if (hit < start_put || hit > end_put) continue;
+                if (core_ofs > hit || (hit + (uint32_t)read_len - core_ofs) >= targ_len) continue;
+                int r = adaptive_trim((uint32_t)read_len, rs, chrom + (hit - core_ofs), min_put_len, (uint32_t)max_allowed_mm, 3, &mms);
+                if (r > (int)min_put_len || (r == (int)min_put_len && mms < prev_best)) {
+                    prev_best = mms; min_put_len = (uint32_t)r;
+                    out->strand = antisense ? '-' : '+'; out->chrom_id = chrom_id; out->match_loci = hit - core_ofs;
+                    out->match_len = (uint16_t)read_len; out->mismatches = (uint8_t)mms;
+                }
+            }
+        }
+    } else {
+        for (uint32_t hit = start_put; hit <= end_put; hit++) {
+            const uint8_t *win = chrom + hit;
+            uint8_t tmpw[2100];
+            if (ent->start_ofs + hit + (uint64_t)read_len > s->concat_len) {      /* window runs off the concatenation: */
+                for (int k = 0; k < read_len; k++) {                              /* (the reference reads whatever follows) */
+                    uint64_t q = ent->start_ofs + hit + (uint64_t)k;
+                    tmpw[k] = q < s->concat_len ? s->seq[q] : B_EOS;
+                }
+                win = tmpw;
+            }
+            int r = adaptive_trim((uint32_t)read_len, rs, win, min_put_len, (uint32_t)max_allowed_mm, 3, &mms);
+            if (r > (int)min_put_len || (r == (int)min_put_len && mms < prev_best)) {
+                prev_best = mms; min_put_len = (uint32_t)r;
+                out->strand = antisense ? '-' : '+'; out->chrom_id = chrom_id; out->match_loci = hit;
+                out->match_len = (uint16_t)read_len; out->mismatches = (uint8_t)mms;
+            }
+        }
+    }
+    return prev_best <= (uint32_t)max_allowed_mm ? 1 : 0;
+}
+
+static void pe_clear(ora_hit *h) { h->num_hits = 0; h->low_hit_instances = 0; }
+
+/* hits[2i] = PE1, hits[2i+1] = PE2 as left by the SE alignment; updated in place.  ora_hit.flags
+ * bit 7 = FlgPEAligned.  Returns 0. */
+int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, int pair_min_len, int pair_max_len,
+                            int pair_strand, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
+                            uint32_t n_pairs, ora_hit *hits)
+{
+    int min_core = ora_min_core_len(s, p->pmode);
+    int slides = ora_max_num_slides(p->pmode);
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        ora_hit *f = &hits[2 * i], *r = &hits[2 * i + 1];
+        f->flags &= 0x7f; r->flags &= 0x7f;
+        int f_un = (f->nar == NAR_NS || f->nar == NAR_NOHIT || f->nar == NAR_UNALIGNED);
+        int r_un = (r->nar == NAR_NS || r->nar == NAR_NOHIT || r->nar == NAR_UNALIGNED);
+        if (!(f->nar == NAR_ACCEPTED || r->nar == NAR_ACCEPTED)) continue;
+        if (pe_mode == PE_UNIQUE && (f_un || r_un)) {
+            pe_clear(f); pe_clear(r);
+            if (f->nar == NAR_ACCEPTED) f->nar = NAR_PENOHIT;
+            if (r->nar == NAR_ACCEPTED) r->nar = NAR_PENOHIT;
+            continue;
+        }
+        if (f->nar == NAR_ACCEPTED && r->nar == NAR_ACCEPTED) {
+            int frag = 0;
+            if (f->num_hits == 1 && r->num_hits == 1) {                 /* AcceptProvPE */
+                if (f->chrom_id != r->chrom_id) frag = -2;
+                else frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, f->strand, f->match_loci,
+                                           f->match_loci + f->match_len - 1, r->strand, r->match_loci, r->match_loci + r->match_len - 1);
+            }
+            if (frag > 0) { f->flags |= 0x80; r->flags |= 0x80; continue; }
+            switch (frag) {
+            case -1: f->nar = r->nar = NAR_PESTRAND; break;
+            case -2: f->nar = r->nar = NAR_PECHROM; break;
+            case -6: f->nar = r->nar = NAR_PEINSERTMIN; break;
+            case -7: f->nar = r->nar = NAR_PEINSERTMAX; break;
+            }
+            if (pe_mode == PE_UNIQUE) {
+                pe_clear(f); pe_clear(r);
+                if (f->nar == NAR_ACCEPTED) f->nar = NAR_PENOHIT;
+                if (r->nar == NAR_ACCEPTED) r->nar = NAR_PENOHIT;
+                continue;
+            }
+        }
+        if (pe_mode == PE_ORPHAN || pe_mode == PE_ORPHAN_SE) {
+            int done = 0;
+            for (int anchor = 0; anchor < 2 && !done; anchor++) {
+                ora_hit *a = anchor == 0 ? f : r, *o = anchor == 0 ? r : f;
+                int o_un = anchor == 0 ? r_un : f_un;
+                if (!(a->num_hits == 1 && !o_un)) continue;
+                uint32_t oi = 2 * i + (anchor == 0 ? 1 : 0);
+                int b3, anti;
+                if (anchor == 0) {
+                    b3 = a->strand == '+';
+                    anti = pair_strand ? (a->strand != '+') : (a->strand == '+');
+                } else {
+                    b3 = a->strand == '+'; anti = a->strand == '+';
+                    if (pair_strand) { b3 = !b3; anti = !anti; }
+                }
+                uint32_t a_start = a->match_loci, a_end = a->match_loci + a->match_len - 1;
+                int probe_len = (int)lens[oi], match_len = probe_len - 1;
+                int max_tot_mm = p->max_subs == 0 ? 0 : imax(1, (int)(0.5 + (match_len * p->max_subs) / 100.0));
+                if (max_tot_mm > MAX_TOT_SUBS) max_tot_mm = MAX_TOT_SUBS;
+                int core_len = imax(min_core, probe_len / (p->min_edit_dist == 1 ? max_tot_mm + 1 : max_tot_mm + 2));
+                int core_delta = imax(probe_len / slides - 1, core_len);
+                uint8_t rs[2100];
+                for (int k = 0; k < probe_len; k++) rs[k] = bases[offs[oi] + k] & 0x07;
+                hit_rec h;
+                int rc = align_paired_read(s, b3, anti, a->chrom_id, a_start, a_end, pair_min_len, pair_max_len, p->max_subs,
+                                           probe_len, core_len, core_delta, rs, &h);
+                if (rc == 1) {
+                    int frag;
+                    uint32_t h_end = h.match_loci + h.match_len - 1;
+                    if (anchor == 0) frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, a->strand, a_start, a_end, h.strand, h.match_loci, h_end);
+                    else frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, h.strand, h.match_loci, h_end, a->strand, a_start, a_end);
+                    if (frag <= 0) rc = 0;
+                }
+                if (rc == 1) {
+                    o->chrom_id = h.chrom_id; o->match_loci = h.match_loci; o->match_len = h.match_len; o->strand = h.strand;
+                    o->mismatches = h.mismatches; o->num_hits = 1; o->low_mm = (int8_t)h.mismatches; o->low_hit_instances = 1;
+                    f->flags |= 0x80; r->flags |= 0x80;
+                    f->nar = r->nar = NAR_ACCEPTED;
+                    done = 1;
+                }
+            }
+            if (done) continue;
+        }
+        if (!(pe_mode == PE_ORPHAN_SE || pe_mode == PE_UNIQUE_SE)) {
+            pe_clear(f); pe_clear(r);
+            if (f->nar == NAR_ACCEPTED) f->nar = NAR_PENOHIT;
+            if (r->nar == NAR_ACCEPTED) r->nar = NAR_PENOHIT;
+            continue;
+        }
+        for (int k = 0; k < 2; k++) {                    /* accept as SE what aligned uniquely */
+            ora_hit *h = k == 0 ? f : r;
+            int chrom_ok = h->num_hits == 1;             /* AcceptThisChromID() is always true without filters */
+            if (h->num_hits != 1 || !chrom_ok) {
+                pe_clear(h);
+                if (h->nar == NAR_ACCEPTED) h->nar = chrom_ok ? NAR_CHROMFILT : NAR_PEUNALIGN;
+            } else
+                h->nar = NAR_ACCEPTED;
+        }
+    }
+    return 0;
+}

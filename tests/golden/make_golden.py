@@ -294,6 +294,100 @@ def make_repeat(tmp):
     ])
 
 
+def make_pe(tmp):
+    """paired-end fixture on the basic genome: FR pairs with inserts in and out of the accepted range,
+    same-strand pairs, different-chromosome pairs, one mate unalignable, one mate in a duplicated /
+    triplicated segment (orphan recovery by the anchored window scan), mates with substitutions."""
+    rng = np.random.default_rng(909)
+    outdir = os.path.join(HERE, "pe")
+    os.makedirs(outdir, exist_ok=True)
+    basic = os.path.join(HERE, "basic")
+    fa = os.path.join(tmp, "pe.fa")
+    with gzip.open(os.path.join(basic, "genome.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    seqs = {}
+    name = None
+    for line in open(fa):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = []
+        else:
+            seqs[name].append(line.upper())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    L = 100
+    r1, r2 = [], []
+
+    def pair(tag, c1, p1, c2, p2, flip1=False, flip2=True, e1=0, e2=0, rand2=False):
+        a = seqs[c1][p1:p1 + L]
+        b = seqs[c2][p2:p2 + L]
+        if "N" in a or "N" in b or len(a) < L or len(b) < L:
+            return
+        a = mutate(rng, a, e1)
+        b = mutate(rng, b, e2) if not rand2 else rand_seq(rng, L)
+        if flip1:
+            a = revcomp(a)
+        if flip2:
+            b = revcomp(b)
+        i = len(r1)
+        r1.append((f"p{i}_{tag}/1", a))
+        r2.append((f"p{i}_{tag}/2", b))
+
+    for k in range(900):                                   # proper FR pairs, inserts 150..650
+        c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
+        ins = int(np.clip(rng.normal(300, 90), 150, 650))
+        p = int(rng.integers(0, 100000 - ins))
+        e1, e2 = int(rng.integers(0, 3)), int(rng.integers(0, 4))
+        if rng.integers(0, 2):
+            pair(f"fr{ins}", c, p, c, p + ins - L, False, True, e1, e2)
+        else:                                               # the pair read from the other strand
+            pair(f"rf{ins}", c, p + ins - L, c, p, True, False, e1, e2)
+    for k in range(60):                                    # both mates on the same strand
+        c = "chrA"
+        p = int(rng.integers(0, 99000))
+        pair("same", c, p, c, p + 200, False, False)
+    for k in range(60):                                    # mates on different sequences
+        pair("xchr", "chrA", int(rng.integers(0, 99000)), "chrB", int(rng.integers(0, 99000)), False, True)
+    for k in range(60):                                    # mate 2 unalignable
+        pair("r2rnd", "chrB", int(rng.integers(0, 99000)), "chrB", 0, False, True, 0, 0, True)
+    # mate 2 inside the exact triplicate (chrA 34000.., chrB 54000.., chrB 56000..) / shared 100-mer, mate 1 unique nearby
+    for k in range(40):
+        ins = int(rng.integers(220, 390))
+        q = 34000 + int(rng.integers(0, 50))
+        pair("tripA", "chrA", q - (ins - L), "chrA", q, False, True, int(rng.integers(0, 2)), int(rng.integers(0, 3)))
+        q = 54000 + int(rng.integers(0, 50))
+        pair("tripB", "chrB", q - (ins - L), "chrB", q, False, True, 0, int(rng.integers(0, 2)))
+        q = 56000 + int(rng.integers(0, 50))
+        pair("tripC", "chrB", q + (ins - L), "chrB", q, True, False, 0, 0)     # anchor downstream, mate upstream
+    for k in range(20):                                    # mate 1 in the near-duplicate (1 sub / 100) segment pair
+        q = 30000 + int(rng.integers(0, 300))
+        pair("nd", "chrA", q, "chrA", q + 250, False, True, 0, 1)
+    for k in range(30):                                    # pairs near sequence ends
+        pair("endA", "chrA", 100000 - 330 + k, "chrA", 100000 - L - int(rng.integers(0, 3)), False, True)
+        pair("startB", "chrB", int(rng.integers(0, 5)), "chrB", 230 + k, False, True)
+    f1 = os.path.join(tmp, "pe_1.fa")
+    f2 = os.path.join(tmp, "pe_2.fa")
+    write_reads(f1, r1)
+    write_reads(f2, r2)
+    sfx = os.path.join(tmp, "pe.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "basic", "-T4"], tmp)
+    gz_copy(f1, os.path.join(outdir, "reads_1.fa.gz"))
+    gz_copy(f2, os.path.join(outdir, "reads_2.fa.gz"))
+    runs = [("U3", ["-U3", "-d200", "-D400", "-s5"]), ("U1", ["-U1", "-d200", "-D400", "-s5"]),
+            ("U2", ["-U2", "-d200", "-D400", "-s5"]), ("U4", ["-U4", "-d200", "-D400", "-s5"]),
+            ("U3dflt", ["-U3", "-s3"]), ("U3wide", ["-U3", "-d150", "-D1500", "-s5"]), ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"])]
+    for tag, flags in runs:
+        out = os.path.join(tmp, f"pe_{tag}.sam")
+        log = run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M6", "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.m6.sam.gz"))
+        with open(os.path.join(outdir, f"{tag}.nar.txt"), "w") as f:
+            f.write(nar_summary(log))
+        print("  ran PE", tag, flags)
+    out = os.path.join(tmp, "pe_U3.m5.sam")
+    run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M5", "-T4", "-U3", "-d200", "-D400", "-s5"], tmp)
+    gz_copy(out, os.path.join(outdir, "U3.m5.sam.gz"))
+
+
 def make_sortorder(tmp):
     """30 000 reads (>= cMinUseLibQsort 25 000, so the reference's own quicksort - not glibc's stable
     merge sort - orders the output) drawn from 2 500 loci, i.e. with many exact ties: pins the tie
@@ -346,12 +440,16 @@ def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
+        if "--only-pe" in sys.argv:
+            make_pe(tmp)
+            return
         if "--only-sortorder" in sys.argv:
             make_sortorder(tmp)
             return
         make_basic(tmp)
         make_repeat(tmp)
         make_sortorder(tmp)
+        make_pe(tmp)
     print("done")
 
 

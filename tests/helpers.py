@@ -66,6 +66,10 @@ def oracle_lib():
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                     ctypes.POINTER(OraCounters), ctypes.c_int]
     lib.ora_align_batch.restype = ctypes.c_int
+    lib.ora_process_paired_ends.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                            ctypes.c_void_p]
+    lib.ora_process_paired_ends.restype = ctypes.c_int
     lib.ora_min_core_len.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ora_min_core_len.restype = ctypes.c_int
     lib.ora_locate_first_exact.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
@@ -121,6 +125,64 @@ class OracleSfx:
         if rc != 0:
             raise RuntimeError(f"ora_align_batch failed: {rc}")
         return out, ctr
+
+
+def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits):
+    """in-place PE association on `hits` (PE1/PE2 interleaved); flags bit 7 = FlgPEAligned"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    assert len(hits) % 2 == 0 and hits.flags["C_CONTIGUOUS"]
+    rc = osfx.lib.ora_process_paired_ends(osfx.h, ctypes.byref(params), pe_mode, min_len, max_len, 1 if pair_strand else 0,
+                                          bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2, hits.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ora_process_paired_ends failed: {rc}")
+    return hits
+
+
+def interleave_pe(path1, path2, min_len=50, max_len=500):
+    """reads PE1/PE2 files and interleaves accepted pairs (both mates must pass the length filter,
+    CAligner::LoadRawReads Aligner.cpp:11080-11130) -> names, bases, offs, lens"""
+    n1, b1, o1, l1 = read_fasta_reads(path1)
+    n2, b2, o2, l2 = read_fasta_reads(path2)
+    assert len(n1) == len(n2)
+    names, chunks, lens = [], [], []
+    for i in range(len(n1)):
+        if not (min_len <= l1[i] <= max_len and min_len <= l2[i] <= max_len):
+            continue
+        names += [n1[i], n2[i]]
+        chunks += [b1[int(o1[i]):int(o1[i]) + int(l1[i])], b2[int(o2[i]):int(o2[i]) + int(l2[i])]]
+        lens += [int(l1[i]), int(l2[i])]
+    lens = np.array(lens, dtype=np.uint32)
+    offs = np.zeros(len(lens), dtype=np.uint64)
+    offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    return names, np.concatenate(chunks), offs, lens
+
+
+def expected_pe_sam_fields(hits, i):
+    """(flag, pos1, rnext, pnext, tlen) of read i per CAligner::ReportBAMread (Aligner.cpp:5864-5924,6036-6054)"""
+    h = hits[i]
+    first = i % 2 == 0
+    m = hits[i + 1] if first else hits[i - 1]
+    flag = 0x1 | 0x2 | (0x40 if first else 0x80)
+    acc = h["nar"] == 1
+    if acc:
+        flag |= 0x10 if h["strand"] != ord("+") else 0
+    else:
+        flag |= 0x4
+    pe = bool(h["flags"] & 0x80) and bool(m["flags"] & 0x80) and m["nar"] == 1
+    rnext, pnext, tlen = "*", 0, 0
+    if pe:
+        flag |= 0x20 if m["strand"] != ord("+") else 0
+        if acc:
+            rnext = "="
+            pnext = int(m["match_loci"]) + 1
+            s, e = int(h["match_loci"]), int(m["match_loci"])
+            tlen = (e - s) + int(m["match_len"]) if s <= e else (s - e) + int(h["match_len"])
+    else:
+        flag |= 0x8
+    pos = int(h["match_loci"]) + 1 if acc else 0
+    return flag, pos, rnext, pnext, tlen
 
 
 # ------------------------------------------------------------------------------------------------

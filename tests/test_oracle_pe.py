@@ -1,0 +1,58 @@
+"""Pins the oracle's paired-end restatement (ProcessPairedEnds, AlignPairedRead, AdaptiveTrim,
+IterateExactsRange) against the real reference's PE outputs (tests/golden/pe/*, -U1..4, -E, default
+and >= 1000 bp windows)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+PE_RUNS = {
+    "U3": dict(pe=3, d=200, D=400, s=5), "U1": dict(pe=1, d=200, D=400, s=5), "U2": dict(pe=2, d=200, D=400, s=5),
+    "U4": dict(pe=4, d=200, D=400, s=5), "U3dflt": dict(pe=3, d=100, D=1000, s=3), "U3wide": dict(pe=3, d=150, D=1500, s=5),
+    "U3E": dict(pe=3, d=200, D=400, s=5, E=True),
+}
+
+
+def pe_inputs(tmp_path):
+    r1, r2 = str(tmp_path / "r1.fa"), str(tmp_path / "r2.fa")
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_1.fa.gz"), r1)
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_2.fa.gz"), r2)
+    return helpers.interleave_pe(r1, r2)
+
+
+def check_pe_hits_against_sam(names, hits, tag, chrom_names):
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "pe", f"{tag}.m6.sam.gz"))
+    by = {r["qname"]: r for r in recs}
+    assert len(by) == len(recs) == len(names)
+    bad = []
+    for i, nm in enumerate(names):
+        r = by[nm]
+        flag, pos, rnext, pnext, tlen = helpers.expected_pe_sam_fields(hits, i)
+        nar = helpers.NAR_TAGS[hits[i]["nar"]]
+        got = (flag, pos, rnext, pnext, tlen, nar, chrom_names[hits[i]["chrom_id"] - 1] if nar == "AA" else "*")
+        exp = (r["flag"], r["pos"], r["rnext"], r["pnext"], r["tlen"], r["nar"], r["rname"])
+        if got != exp:
+            bad.append((nm, got, exp))
+    assert not bad, (len(bad), bad[:8])
+
+
+@pytest.mark.parametrize("tag", list(PE_RUNS))
+def test_oracle_pe_matches_reference(golden_tmp, tmp_path, tag):
+    cfg = PE_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path)
+    o = helpers.OracleSfx(os.path.join(golden_tmp["basic"], "genome.sfx"))
+    p = helpers.make_params(max_subs=cfg["s"])
+    hits, _ = o.align(bases, offs, lens, p, nthreads=8)
+    helpers.oracle_process_pe(o, p, cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False), bases, offs, lens, hits)
+    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"])
+    exp = {}
+    with open(os.path.join(helpers.GOLDEN, "pe", f"{tag}.nar.txt")) as f:
+        for line in f:
+            t = line.split()
+            exp[t[1].strip("()")] = int(t[0])
+    got = np.bincount(hits["nar"], minlength=20)
+    for k, tg in enumerate(helpers.NAR_TAGS):
+        assert got[k] == exp[tg], (tg, got[k], exp[tg])
+    o.close()
