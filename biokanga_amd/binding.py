@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -46,6 +46,16 @@ assert HIT_DTYPE.itemsize == 20
 ENTRY_DTYPE = np.dtype([("entry_id", "<u4"), ("seq_len", "<u4"), ("start_ofs", "<u8"), ("end_ofs", "<u8"),
                         ("name", "S81"), ("_pad", "S7")])
 assert ENTRY_DTYPE.itemsize == 112
+
+
+class PEParams(ctypes.Structure):
+    """bk_pe_params: -U / -d / -D / -E of `biokanga align`"""
+    _fields_ = [("pe_mode", ctypes.c_int32), ("pair_min_len", ctypes.c_int32), ("pair_max_len", ctypes.c_int32),
+                ("pair_strand", ctypes.c_int32)]
+
+    def __init__(self, pe_mode=3, pair_min_len=100, pair_max_len=1000, pair_strand=0):
+        super().__init__()
+        self.pe_mode, self.pair_min_len, self.pair_max_len, self.pair_strand = pe_mode, pair_min_len, pair_max_len, int(pair_strand)
 
 
 class _Counters(ctypes.Structure):
@@ -116,6 +126,8 @@ def load_library():
     lib.bk_align_batch.restype = i32
     lib.bk_align_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
     lib.bk_align_batch_device.restype = i32
+    lib.bk_pair_batch.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(PEParams)]
+    lib.bk_pair_batch.restype = i32
     lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
     lib.bk_get_counters.restype = i32
     lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
@@ -227,6 +239,19 @@ class Aligner:
         if rc:
             raise BkError(rc, "bk_align_batch")
         return out
+
+    def pair(self, bases, offs, lens, hits, pe):
+        """PE association in place on `hits` (PE1/PE2 interleaved; the output of align() for the same reads)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        assert hits.dtype == HIT_DTYPE and len(hits) == len(lens) and len(hits) % 2 == 0
+        hits = np.ascontiguousarray(hits)
+        rc = self.lib.bk_pair_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2,
+                                    hits.ctypes.data, ctypes.byref(pe))
+        if rc:
+            raise BkError(rc, "bk_pair_batch")
+        return hits
 
     def align_device(self, d_bases, d_offs, d_lens, nreads, d_out, stream=None, sync=True):
         """Device pointers (ints) of buffers resident in HBM on this context's GPU."""

@@ -28,6 +28,8 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
+void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
+               bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, hipStream_t s);
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                   uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
                   uint32_t *cmax_next, int nw, hipStream_t s);
@@ -676,6 +678,65 @@ int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const 
     int rc = align_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, nreads, c->d_in_out, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
+    return BK_OK;
+}
+
+int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs, bk_hit *hits,
+                  const bk_pe_params *pe)
+{
+    if (!c || !pe || (n_pairs && (!bases || !offs || !lens || !hits))) return BK_ERR_PARAMS;
+    if (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len) return BK_ERR_PARAMS;
+    if (!n_pairs) return BK_OK;
+    if (n_pairs > 0x7fffffffu) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nreads = 2 * n_pairs;
+    uint64_t lo = ~0ULL, hi = 0;
+    uint32_t maxlen = 0;
+    for (uint32_t i = 0; i < nreads; i++) {
+        if (lens[i] > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+        lo = std::min(lo, offs[i]);
+        hi = std::max(hi, offs[i] + lens[i]);
+        maxlen = std::max(maxlen, lens[i]);
+    }
+    uint64_t nbytes = hi - lo;
+    if (nbytes + 16 > c->cap_in_bases) {
+        free_dev(c->d_in_bases);
+        c->d_in_bases = nullptr;
+        c->cap_in_bases = 0;
+        HIP_TRY(hipMalloc(&c->d_in_bases, nbytes + 16));
+        c->cap_in_bases = nbytes + 16;
+    }
+    if (nreads > c->cap_in_reads) {
+        free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
+        c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr;
+        c->cap_in_reads = 0;
+        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        c->cap_in_reads = nreads;
+    }
+    std::vector<uint64_t> rel(nreads);
+    for (uint32_t i = 0; i < nreads; i++) rel[i] = offs[i] - lo;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_in_bases, bases + lo, nbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_in_offs, rel.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_in_out, hits, (size_t)nreads * sizeof(bk_hit), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t wpr = (maxlen + 15) / 16 + 1;
+    int rc = ensure_batch_scratch(c, nreads, wpr);
+    if (rc) return rc;
+    DevBatch b{};
+    b.bases = c->d_in_bases; b.offs = c->d_in_offs; b.lens = c->d_in_lens;
+    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.out = c->d_in_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
+    b.wpr = wpr; b.n_reads = nreads;
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+    launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, c->d_in_out, n_pairs,
+              c->d_heavy, c->d_small, c->h_small, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(hits, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
 }
 

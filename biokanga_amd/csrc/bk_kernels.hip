@@ -1106,6 +1106,266 @@ __global__ void k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4: paired-end association after the SE pass - CAligner::ProcessPairedEnds (biokanga/Aligner.cpp:
+// 3055-3489), AcceptProvPE / PEInsertSize (:2726-2850) and the orphan recovery of
+// CSfxArrayV3::AlignPairedRead (libbiokanga/SfxArrayV2.cpp:8247-8433) whose AdaptiveTrim (:5482-5682)
+// is called with MinTrimLen == read length, i.e. it accepts a window iff: the first and the last 3
+// bases match, some run of >= 8 bases matches, and (MaxMM+1.0)/100.0 > mismatches/length (double
+// compare, MaxMM = the -s value, <= 15); the FIRST window with the fewest mismatches wins.
+// hits[2i] / hits[2i+1] = PE1 / PE2; bk_hit.flags bit 7 = FlgPEAligned.
+
+struct DevPE { int pe_mode, min_len, max_len, pair_strand; };
+
+enum { NAR_CHROMFILT = 11, NAR_PEINSERTMIN = 13, NAR_PEINSERTMAX = 14, NAR_PENOHIT = 15, NAR_PESTRAND = 16, NAR_PECHROM = 17,
+       NAR_PEUNALIGN = 18 };
+
+__device__ __forceinline__ int pe_insert_size(const DevPE &pe, uint8_t s1, uint32_t st1, uint32_t en1, uint8_t s2, uint32_t st2, uint32_t en2)
+{
+    int frag;
+    if ((pe.pair_strand && s1 != s2) || (!pe.pair_strand && s1 == s2)) return -1;
+    if (s1 == '+') frag = 1 + (int)en2 - (int)st1;
+    else frag = 1 + (int)en1 - (int)st2;
+    if (frag < 0) return -1;
+    if (frag < pe.min_len) return -6;
+    if (frag > pe.max_len) return -7;
+    return frag;
+}
+
+__device__ __forceinline__ bool pe_unaligned(const bk_hit &h) { return h.nar == BK_NAR_NS || h.nar == BK_NAR_NOHIT || h.nar == BK_NAR_UNALIGNED; }
+
+// the tail of ProcessPairedEnds once no PE could be formed (:3440-3480)
+__device__ __forceinline__ void pe_finish(const DevPE &pe, bk_hit &f, bk_hit &r)
+{
+    if (!(pe.pe_mode == 3 || pe.pe_mode == 4)) {
+        f.num_hits = 0; f.low_hit_instances = 0; r.num_hits = 0; r.low_hit_instances = 0;
+        if (f.nar == BK_NAR_ACCEPTED) f.nar = NAR_PENOHIT;
+        if (r.nar == BK_NAR_ACCEPTED) r.nar = NAR_PENOHIT;
+        return;
+    }
+    bk_hit *hh[2] = {&f, &r};
+    for (int k = 0; k < 2; k++) {
+        bk_hit &h = *hh[k];
+        if (h.num_hits != 1) {
+            h.num_hits = 0; h.low_hit_instances = 0;
+            if (h.nar == BK_NAR_ACCEPTED) h.nar = NAR_PEUNALIGN;
+        } else
+            h.nar = BK_NAR_ACCEPTED;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pe_classify(DevPE pe, bk_hit *__restrict__ hits, uint32_t n_pairs,
+                                                      uint32_t *__restrict__ orphans, uint32_t *__restrict__ orphan_cnt)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    bk_hit f = hits[2 * i], r = hits[2 * i + 1];
+    f.flags &= 0x7f; r.flags &= 0x7f;
+    bool f_un = pe_unaligned(f), r_un = pe_unaligned(r);
+    bool store = true;
+    if (!(f.nar == BK_NAR_ACCEPTED || r.nar == BK_NAR_ACCEPTED)) {
+        // neither end accepted: nothing to pair
+    } else if (pe.pe_mode == 2 && (f_un || r_un)) {
+        f.num_hits = 0; f.low_hit_instances = 0; r.num_hits = 0; r.low_hit_instances = 0;
+        if (f.nar == BK_NAR_ACCEPTED) f.nar = NAR_PENOHIT;
+        if (r.nar == BK_NAR_ACCEPTED) r.nar = NAR_PENOHIT;
+    } else {
+        bool paired = false, stop = false;
+        if (f.nar == BK_NAR_ACCEPTED && r.nar == BK_NAR_ACCEPTED) {
+            int frag = 0;
+            if (f.num_hits == 1 && r.num_hits == 1) {
+                if (f.chrom_id != r.chrom_id) frag = -2;
+                else frag = pe_insert_size(pe, f.strand, f.match_loci, f.match_loci + f.match_len - 1, r.strand, r.match_loci,
+                                           r.match_loci + r.match_len - 1);
+            }
+            if (frag > 0) { f.flags |= 0x80; r.flags |= 0x80; paired = true; }
+            else {
+                switch (frag) {
+                case -1: f.nar = r.nar = NAR_PESTRAND; break;
+                case -2: f.nar = r.nar = NAR_PECHROM; break;
+                case -6: f.nar = r.nar = NAR_PEINSERTMIN; break;
+                case -7: f.nar = r.nar = NAR_PEINSERTMAX; break;
+                }
+                if (pe.pe_mode == 2) {
+                    f.num_hits = 0; f.low_hit_instances = 0; r.num_hits = 0; r.low_hit_instances = 0;
+                    if (f.nar == BK_NAR_ACCEPTED) f.nar = NAR_PENOHIT;
+                    if (r.nar == BK_NAR_ACCEPTED) r.nar = NAR_PENOHIT;
+                    stop = true;
+                }
+            }
+        }
+        if (!paired && !stop) {
+            bool try_orphan = (pe.pe_mode == 1 || pe.pe_mode == 3) && ((f.num_hits == 1 && !r_un) || (r.num_hits == 1 && !f_un));
+            if (try_orphan) orphans[atomicAdd(orphan_cnt, 1u)] = i;      // finished by k_pe_orphan
+            else pe_finish(pe, f, r);
+        }
+    }
+    if (store) { hits[2 * i] = f; hits[2 * i + 1] = r; }
+}
+
+// AdaptiveTrim(full length) acceptance of the read (packed words rdw) against the target at t
+__device__ __forceinline__ bool pe_window_ok(const uint64_t *__restrict__ rdw, int len, const uint64_t *__restrict__ tgt, uint64_t t,
+                                             int max_mm, int &mm_out)
+{
+    int mm = 0, run = 0;
+    bool have8 = false, first3 = false;
+    for (int i = 0; i < len; i += 16) {
+        int nv = len - i < 16 ? len - i : 16;
+        uint64_t x = (nib16(rdw, i) ^ nib16(tgt, t + i)) & top_mask(nv);
+        uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+        uint32_t bits = flags_to_bits16(f);                         // bit k = base i+k mismatches
+        uint32_t valid = nv >= 16 ? 0xFFFFu : ((1u << nv) - 1);
+        uint32_t g = ~bits & valid;                                 // bit k = base matches
+        mm += __popc(bits);
+        if (i == 0) first3 = (g & 7u) == 7u;
+        // runs of >= 8 matches: inside the word, or continuing the run carried from previous words
+        uint32_t y = g & (g >> 1);
+        y &= y >> 2;
+        y &= y >> 4;
+        int lead = __ffs((int)(~g & 0x1FFFFu)) - 1;                 // matches at the start of this word (0..16)
+        if (lead > nv) lead = nv;
+        if (y != 0 || run + lead >= 8) have8 = true;
+        if (g == valid) run += nv;
+        else run = nv - (32 - __clz((int)(~g & valid)));            // matches after the last mismatch of this word
+    }
+    mm_out = mm;
+    if (len < 25 || len > 2048 || max_mm > 15) return false;         // AdaptiveTrim parameter validation -> eBSFerrParams
+    if (!have8 || !first3 || run < 3) return false;
+    if (mm > 0 && max_mm == 0) return false;
+    if ((max_mm + 1.0) / 100.0 <= (double)mm / (double)len) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg, DevPE pe, DevBatch b, bk_hit *__restrict__ hits,
+                                                    const uint32_t *__restrict__ list, uint32_t n_list, uint32_t *__restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(cursor, 1u);
+        item = __shfl(item, 0);
+        if (item >= n_list) break;
+        const uint32_t i = list[item];
+        bk_hit f = hits[2 * i], r = hits[2 * i + 1];
+        const bool f_un = pe_unaligned(f), r_un = pe_unaligned(r);
+        bool done = false;
+        for (int anchor = 0; anchor < 2 && !done; anchor++) {
+            bk_hit &a = anchor == 0 ? f : r;
+            bk_hit &o = anchor == 0 ? r : f;
+            const bool o_un = anchor == 0 ? r_un : f_un;
+            if (!(a.num_hits == 1 && !o_un)) continue;
+            const uint32_t oi = 2 * i + (anchor == 0 ? 1 : 0);
+            bool b3, anti;
+            if (anchor == 0) {
+                b3 = a.strand == '+';
+                anti = pe.pair_strand ? (a.strand != '+') : (a.strand == '+');
+            } else {
+                b3 = a.strand == '+'; anti = a.strand == '+';
+                if (pe.pair_strand) { b3 = !b3; anti = !anti; }
+            }
+            const uint32_t a_start = a.match_loci, a_end = a.match_loci + a.match_len - 1;
+            const int read_len = (int)b.lens[oi];
+            const int max_allowed = cfg.max_subs;
+            // AlignPairedRead set-up (:8270-8330)
+            if (pe.min_len < read_len || pe.min_len > pe.max_len) continue;
+            if (a.chrom_id < 1 || a.chrom_id > ix.n_ent) continue;
+            const uint64_t c_start = ix.ent_start[a.chrom_id - 1];
+            const uint32_t targ_len = (uint32_t)(ix.ent_end[a.chrom_id - 1] - c_start + 1);
+            int targ_loci;
+            if (b3) { targ_loci = (int)a_start; if ((uint32_t)(targ_loci + pe.min_len) > targ_len) continue; }
+            else { targ_loci = (int)a_end; if (targ_loci < pe.min_len || (uint32_t)targ_loci >= targ_len) continue; }
+            uint32_t start_put, end_put;
+            if (b3) {
+                start_put = (uint32_t)(targ_loci + pe.min_len);
+                if (start_put + (uint32_t)read_len >= targ_len) continue;
+                end_put = (uint32_t)(targ_loci + pe.max_len);
+            } else {
+                start_put = a_end < (uint32_t)pe.max_len ? 0 : a_end - (uint32_t)pe.max_len;
+                end_put = a_end - (uint32_t)pe.min_len;
+            }
+            const uint64_t *rdw = b.rd4 + ((uint64_t)oi * 2 + (anti ? 1 : 0)) * b.wpr;
+            // best = fewest mismatches, first in scan order; key = mm << 40 | order
+            unsigned long long best = ~0ULL;
+            uint32_t best_loci = 0;
+            if (end_put - start_put >= 1000) {
+                // cores of the read located through the suffix array (IterateExactsRange, :3382-3474)
+                int match_len = read_len - 1;
+                int m = cfg.max_subs == 0 ? 0 : (int)(0.5 + (double)(match_len * cfg.max_subs) / 100.0);
+                if (cfg.max_subs != 0 && m < 1) m = 1;
+                if (m > 63) m = 63;
+                int core_len = read_len / (cfg.mm_delta == 1 ? m + 1 : m + 2);
+                if (core_len < cfg.min_core_len) core_len = cfg.min_core_len;
+                int core_delta = read_len / cfg.slides_per100 - 1;
+                if (core_delta < core_len) core_delta = core_len;
+                unsigned long long order = 0;
+                for (int core_ofs = 0; core_ofs + core_len <= read_len; core_ofs += core_delta) {
+                    uint64_t first, n;
+                    if (ix.sa_hi) search_core<true>(ix, rdw, core_ofs, core_len, ~0ULL >> 1, first, n);
+                    else search_core<false>(ix, rdw, core_ofs, core_len, ~0ULL >> 1, first, n);
+                    first = uniform64(first); n = uniform64(n);
+                    for (uint64_t j0 = 0; j0 < n; j0 += 64) {
+                        uint64_t j = j0 + lane;
+                        unsigned long long key = ~0ULL;
+                        uint32_t loci = 0;
+                        if (j < n) {
+                            uint64_t pos = ix.sa_hi ? sa_get<true>(ix, first + j) : sa_get<false>(ix, first + j);
+                            if (pos >= c_start && pos <= ix.ent_end[a.chrom_id - 1]) {
+                                uint32_t hit = (uint32_t)(pos - c_start);
+                                if (hit >= start_put && hit <= end_put && (uint32_t)core_ofs <= hit &&
+                                    (hit + (uint32_t)read_len - (uint32_t)core_ofs) < targ_len) {
+                                    int mm;
+                                    if (pe_window_ok(rdw, read_len, ix.tgt4, c_start + hit - (uint32_t)core_ofs, max_allowed, mm) && mm <= max_allowed) {
+                                        key = ((unsigned long long)mm << 40) | (order + j);
+                                        loci = hit - (uint32_t)core_ofs;
+                                    }
+                                }
+                            }
+                        }
+                        unsigned long long k2 = key;
+                        for (int off = 32; off > 0; off >>= 1) { unsigned long long q = __shfl_xor(k2, off); k2 = q < k2 ? q : k2; }
+                        if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) {      // strictly fewer mismatches than the best so far
+                            int src = __ffsll((unsigned long long)__ballot(key == k2)) - 1;
+                            best = k2;
+                            best_loci = __shfl(loci, src);
+                        }
+                    }
+                    order += n;
+                }
+            } else {
+                for (uint32_t h0 = start_put; h0 <= end_put; h0 += 64) {
+                    uint32_t hit = h0 + (uint32_t)lane;
+                    unsigned long long key = ~0ULL;
+                    if (hit <= end_put && hit >= h0) {
+                        int mm;
+                        if (pe_window_ok(rdw, read_len, ix.tgt4, c_start + hit, max_allowed, mm) && mm <= max_allowed)
+                            key = ((unsigned long long)mm << 40) | hit;
+                    }
+                    unsigned long long k2 = key;
+                    for (int off = 32; off > 0; off >>= 1) { unsigned long long q = __shfl_xor(k2, off); k2 = q < k2 ? q : k2; }
+                    if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) { best = k2; best_loci = (uint32_t)(k2 & 0xFFFFFFFFFFULL); }
+                    if (h0 + 64 < h0) break;
+                }
+            }
+            if (best == ~0ULL) continue;
+            const int mm = (int)(best >> 40);
+            const uint8_t h_strand = anti ? '-' : '+';
+            const uint32_t h_end = best_loci + (uint32_t)read_len - 1;
+            int frag;
+            if (anchor == 0) frag = pe_insert_size(pe, a.strand, a_start, a_end, h_strand, best_loci, h_end);
+            else frag = pe_insert_size(pe, h_strand, best_loci, h_end, a.strand, a_start, a_end);
+            if (frag <= 0) continue;
+            o.chrom_id = a.chrom_id; o.match_loci = best_loci; o.match_len = (uint16_t)read_len; o.strand = h_strand;
+            o.mismatches = (uint8_t)mm; o.num_hits = 1; o.low_mm = (int8_t)mm; o.low_hit_instances = 1;
+            f.flags |= 0x80; r.flags |= 0x80;
+            f.nar = BK_NAR_ACCEPTED; r.nar = BK_NAR_ACCEPTED;
+            done = true;
+        }
+        if (!done) pe_finish(pe, f, r);
+        if (lane == 0) { hits[2 * i] = f; hits[2 * i + 1] = r; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (called from bk_engine.cpp through plain function pointers-free C++ interface)
 
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s)
@@ -1173,6 +1433,23 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
     unsigned blocks = (n_act + 255) / 256;
     if (ix.sa_hi) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
     else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
+}
+
+void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
+               bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters /*[0] count [1] cursor, zeroed*/,
+               uint32_t *h_count, hipStream_t s)
+{
+    DevPE pe{pe_mode, min_len, max_len, pair_strand};
+    uint64_t words = (uint64_t)b.n_reads * 2 * b.wpr;
+    hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters);
+    (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    uint32_t n = *h_count;
+    if (n) {
+        uint32_t waves = n < 8192 ? n : 8192;
+        hipLaunchKernelGGL(k_pe_orphan, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1);
+    }
 }
 
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s)

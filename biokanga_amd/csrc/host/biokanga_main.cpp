@@ -8,7 +8,7 @@
 //   biokanga index -i genome.fa [-i more.fa] -o genome.sfx -r name [-l minseqlen] [-d descr] [-t title]
 //   biokanga align -i reads.fa[.gz] -I genome.sfx -o out.sam [-s subs] [-e 1|2] [-Q 0|1|2] [-m 0..3]
 //                  [-n maxNs] [-l minlen] [-L maxlen] [-y trim5] [-Y trim3] [-M 0|5|6] [-O stats.csv]
-//                  [-T threads(ignored)] [-F logfile] [--device n]
+//                  [-U 1..4 -u mates.fa -d minins -D maxins [-E]] [-T threads(ignored)] [-F logfile] [--device n]
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
@@ -286,6 +286,64 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
     return 0;
 }
 
+// paired end loading: PE1/PE2 records in lockstep, both ends must pass the length acceptance
+// (Aligner.cpp:11080-11130); stored interleaved PE1, PE2
+int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::string> &f2, int trim5, int trim3, int min_len, int max_len,
+                  ReadStore &rs)
+{
+    for (size_t k = 0; k < f1.size(); k++) {
+        bk::SeqReader r1, r2;
+        std::string err;
+        int rc = r1.open(f1[k], &err);
+        if (rc) { diag("Load: %s", err.c_str()); return rc; }
+        rc = r2.open(f2[k], &err);
+        if (rc) { diag("Load: %s", err.c_str()); return rc; }
+        diag("Loading paired end reads from '%s' and '%s'", f1[k].c_str(), f2[k].c_str());
+        std::string d[2];
+        std::vector<uint8_t> b[2];
+        bool sim[2] = {false, false};
+        uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
+        for (;;) {
+            int rc1 = r1.next(d[0], b[0]);
+            if (rc1 < 0) { diag("Load: errors whilst parsing '%s'", f1[k].c_str()); return rc1; }
+            if (rc1 == 0) break;
+            int rc2 = r2.next(d[1], b[1]);
+            if (rc2 <= 0) { diag("Load: '%s' has fewer reads than '%s'", f2[k].c_str(), f1[k].c_str()); return -63; }
+            n_descr++;
+            bool skip = false;
+            for (int e = 0; e < 2; e++) {
+                if (d[e].size() > 127) d[e].resize(127);
+                if (n_descr == 1) sim[e] = !strncmp(d[e].c_str(), "lcl|usimreads|", 14) || !strncmp(d[e].c_str(), "lcr|usimreads|", 14);
+                int len = (int)b[e].size();
+                if (len < 1 || len > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
+            }
+            for (int e = 0; e < 2 && !skip; e++) {
+                int len = (int)b[e].size();
+                if (trim5 + trim3 + min_len > len) { n_under++; skip = true; }
+                else if (trim5 + trim3 + max_len < len) { n_over++; skip = true; }
+            }
+            if (skip) continue;
+            for (int e = 0; e < 2; e++) {
+                if (!sim[e]) {
+                    size_t q = 0;
+                    while (q < 79 && q < d[e].size() && !isspace((unsigned char)d[e][q])) q++;
+                    d[e].resize(q);
+                }
+                int keep = (int)b[e].size() - trim5 - trim3;
+                rs.offs.push_back(rs.bases.size());
+                rs.lens.push_back((uint32_t)keep);
+                rs.bases.insert(rs.bases.end(), b[e].begin() + trim5, b[e].begin() + trim5 + keep);
+                rs.name_ofs.push_back(rs.names.size());
+                rs.names.insert(rs.names.end(), d[e].begin(), d[e].end());
+                rs.names.push_back('\0');
+            }
+            n_acc++;
+        }
+        diag("Load: %u pairs parsed, %u accepted, %u under length, %u over length", n_descr, n_acc, n_under, n_over);
+    }
+    return 0;
+}
+
 struct OutBuf {
     int fd = -1;
     std::vector<char> b;
@@ -309,8 +367,9 @@ int cmd_align(int argc, char **argv, int first)
         {"mode", "m"}, {"alignstrand", "Q"}, {"editdelta", "e"}, {"substitutions", "s"}, {"maxns", "n"}, {"trim5", "y"},
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
-        {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4", "", a, err)) {
+        {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
+        {"pairstrand", "E"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udD", "E", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -321,7 +380,21 @@ int cmd_align(int argc, char **argv, int first)
     }
     if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
     diag("Subprocess align Version %s starting", kProgVer);
-    if (a.num("U", 0) != 0) { diag("Error: paired end processing '-U' is not available in this build"); return 1; }
+    const int pe_mode = a.num("U", 0);
+    if (pe_mode < 0 || pe_mode > 4) { diag("Error: paired end processing mode '-U%d' must be in range 0..4", pe_mode); return 1; }
+    if (pe_mode && (!a.has("u") || a.v["u"].size() != a.v["i"].size())) {
+        diag("Error: paired end processing '-U%d' needs as many '-u' PE2 files as '-i' PE1 files", pe_mode);
+        return 1;
+    }
+    bk_pe_params PE = {};
+    PE.pe_mode = pe_mode;
+    PE.pair_min_len = a.num("d", 100);            // cDfltPairMinLen
+    PE.pair_max_len = a.num("D", 1000);           // cDfltPairMaxLen
+    PE.pair_strand = a.has("E") ? 1 : 0;
+    if (pe_mode && (PE.pair_min_len < 25 || PE.pair_max_len < PE.pair_min_len || PE.pair_max_len > 100000)) {
+        diag("Error: paired end insert size range '-d%d -D%d' not accepted", PE.pair_min_len, PE.pair_max_len);
+        return 1;
+    }
     if (a.num("r", 0) != 0) { diag("Error: multiloci modes '-r1..5' are not available in this build"); return 1; }
     bk_align_params P = {};
     P.pmode = a.num("m", 0);
@@ -353,7 +426,8 @@ int cmd_align(int argc, char **argv, int first)
     diag("Genome assembly suffix array loaded");
 
     ReadStore rs;
-    rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, rs);
+    if (pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], trim5, trim3, min_len, max_len, rs);
+    else rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, rs);
     if (rc) { bk_ctx_destroy(ctx); return 1; }
     size_t nr = rs.size();
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
@@ -365,6 +439,19 @@ int cmd_align(int argc, char **argv, int first)
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
     }
     diag("Alignment of %zu from %zu loaded completed", nr, nr);
+    if (pe_mode) {
+        // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355)
+        diag("Paired end association and partner alignment processing started..");
+        const size_t kPairs = 8u << 20;
+        for (size_t lo = 0; lo < nr / 2; lo += kPairs) {
+            size_t n = std::min(kPairs, nr / 2 - lo);
+            rc = bk_pair_batch(ctx, rs.bases.data(), rs.offs.data() + 2 * lo, rs.lens.data() + 2 * lo, (uint32_t)n, hits.data() + 2 * lo, &PE);
+            if (rc) { diag("Fatal: paired end processing failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+        }
+        size_t n_pe = 0;
+        for (size_t i = 0; i < nr; i += 2) n_pe += (hits[i].flags & 0x80) && (hits[i + 1].flags & 0x80);
+        diag("From %zu paired reads there were %zu accepted as paired", nr / 2, n_pe);
+    }
 
     // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): NAR histogram
     uint64_t nar[20] = {0};
@@ -429,15 +516,34 @@ int cmd_align(int argc, char **argv, int first)
             uint32_t len = rs.lens[i];
             rec.clear();
             rec += rs.name(i);
+            // FLAG / RNEXT / PNEXT / TLEN: CAligner::ReportBAMread, Aligner.cpp:5850-5924,6036-6054
+            int flag = 0, tlen = 0;
+            long pnext = -1;
+            if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
+            else {
+                const bool first_of_pair = (i & 1) == 0;
+                const bk_hit &m = hits[first_of_pair ? i + 1 : i - 1];
+                flag = 0x1 | 0x2 | (first_of_pair ? 0x40 : 0x80);
+                flag |= acc ? (h.strand == '+' ? 0 : 0x10) : 0x4;
+                if ((h.flags & 0x80) && (m.flags & 0x80) && m.nar == BK_NAR_ACCEPTED) {
+                    flag |= m.strand == '+' ? 0 : 0x20;
+                    if (acc) {
+                        pnext = (long)m.match_loci;
+                        long s0 = (long)h.match_loci, s1 = (long)m.match_loci;
+                        tlen = (int)(s0 <= s1 ? (s1 - s0) + m.match_len : (s0 - s1) + h.match_len);
+                    }
+                } else
+                    flag |= 0x8;
+            }
             if (acc) {
-                int flag = h.strand == '+' ? 0 : 16;
-                int m = snprintf(line, sizeof(line), "\t%d\t%s\t%u\t255\t%uM\t*\t0\t0\t", flag, ents[h.chrom_id - 1].name, h.match_loci + 1, (unsigned)h.match_len);
+                int m = snprintf(line, sizeof(line), "\t%d\t%s\t%u\t255\t%uM\t%c\t%ld\t%d\t", flag, ents[h.chrom_id - 1].name, h.match_loci + 1,
+                                 (unsigned)h.match_len, pnext < 0 ? '*' : '=', pnext < 0 ? 0L : pnext + 1, tlen);
                 rec.append(line, (size_t)m);
                 if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
                 else for (uint32_t q = 0; q < len; q++) rec.push_back(comp[s[len - 1 - q] & 7]);
                 rec += "\t*\n";
             } else {
-                int m = snprintf(line, sizeof(line), "\t4\t*\t0\t255\t%uM\t*\t0\t0\t", len);
+                int m = snprintf(line, sizeof(line), "\t%d\t*\t0\t255\t%uM\t*\t0\t0\t", flag, len);
                 rec.append(line, (size_t)m);
                 for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
                 rec += "\t*\t\tYU:Z:";                                   // the doubled TAB is what the reference writes

@@ -151,6 +151,20 @@ int  bk_align_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, con
 int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
                            uint32_t nreads, void *d_out, void *stream, int sync);
 
+/* Paired-end association after the SE pass = CAligner::ProcessPairedEnds (biokanga/Aligner.cpp:
+ * 2876-3489) incl. orphan recovery by CSfxArrayV3::AlignPairedRead (libbiokanga/SfxArrayV2.cpp:8247).
+ * Reads and hits are interleaved PE1, PE2, PE1, PE2 ... (2 * n_pairs of each); hits must be the
+ * results bk_align_batch() returned for exactly these reads and are updated in place
+ * (NAR, NumHits, LowHitInstances, LowMMCnt, Seg[0]); bk_hit.flags bit 7 = FlgPEAligned. */
+typedef struct bk_pe_params {
+    int32_t pe_mode;        /* -U  1 orphan recovery, 2 unique only, 3 = 1 + leftover ends as SE, 4 = 2 + SE */
+    int32_t pair_min_len;   /* -d  minimum insert (default 100)  */
+    int32_t pair_max_len;   /* -D  maximum insert (default 1000) */
+    int32_t pair_strand;    /* -E  both ends on the same strand  */
+} bk_pe_params;
+int  bk_pair_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs,
+                   bk_hit *hits, const bk_pe_params *pe);
+
 /* counters/timing accumulated since the last reset */
 int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);
 int  bk_get_timing(bk_ctx *ctx, bk_timing *out, int reset);

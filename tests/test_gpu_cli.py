@@ -94,3 +94,20 @@ def test_align_30000_reads_order_byte_identical(golden_tmp, tmp_path):
     run(["align", "-i", os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
          "-o", out, "-s3"], str(tmp_path))
     assert open(out, "rb").read() == golden_bytes("sortorder", "s3.m5.sam.gz")
+
+
+@pytest.mark.parametrize("tag,flags", [("U3", ["-U3", "-d200", "-D400", "-s5"]), ("U1", ["-U1", "-d200", "-D400", "-s5"]),
+                                       ("U2", ["-U2", "-d200", "-D400", "-s5"]), ("U4", ["-U4", "-d200", "-D400", "-s5"]),
+                                       ("U3dflt", ["-U3", "-s3"]), ("U3wide", ["-U3", "-d150", "-D1500", "-s5"]),
+                                       ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"])])
+def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags):
+    d = golden_tmp["basic"]
+    pe = os.path.join(helpers.GOLDEN, "pe")
+    out = str(tmp_path / "pe.sam")
+    run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
+         "-o", out, "-M6"] + flags, str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("pe", f"{tag}.m6.sam.gz")
+    if tag == "U3":
+        run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
+             "-o", out] + flags, str(tmp_path))
+        assert open(out, "rb").read() == golden_bytes("pe", "U3.m5.sam.gz")

@@ -221,3 +221,26 @@ def test_repeatable(tmp_path):
                 al.tune("heavy_thresh", thresh)
                 for _ in range(3):
                     assert_hits_equal(al.align(bases, offs, lens), ref)
+
+
+from test_oracle_pe import PE_RUNS, pe_inputs, check_pe_hits_against_sam
+
+
+@pytest.mark.parametrize("tag", list(PE_RUNS))
+def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, tag):
+    """K4: paired-end association + orphan recovery on the GPU vs the reference's PE SAM and the oracle"""
+    bk = _bk()
+    cfg = PE_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path)
+    sfx_path = os.path.join(golden_tmp["basic"], "genome.sfx")
+    with bk.Aligner(sfx_path, bk.AlignParams(max_subs=cfg["s"])) as al:
+        hits = al.align(bases, offs, lens)
+        hits = al.pair(bases, offs, lens, hits, bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False)))
+    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"])
+    o = helpers.OracleSfx(sfx_path)
+    p = helpers.make_params(max_subs=cfg["s"])
+    exp, _ = o.align(bases, offs, lens, p, nthreads=8)
+    helpers.oracle_process_pe(o, p, cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False), bases, offs, lens, exp)
+    o.close()
+    assert_hits_equal(hits, exp, names)
+    assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
