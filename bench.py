@@ -192,24 +192,32 @@ def main():
     total_reads = args.reads * world * args.steps
     value = total_reads / elapsed
 
-    # roofline of the dominant kernel (k_search): algorithmic bytes = n_search * ceil(log2 N) * (E + 8)
-    #  over the kernel's summed launch time, measured with HIP events on its stream
+    # roofline: algorithmic bytes over the kernel's summed launch time, measured with HIP
+    # events on the stream the kernels run on.  Per search: ceil(log2 N) * (E + 8); per candidate
+    # Hamming-extended: E + ceil(L/2).  The dominant kernel (largest share of device time) is quoted.
     E = 4
     log2n = math.ceil(math.log2(n))
-    search_bytes = ctr["n_search"] * log2n * (E + 8)
-    cand_bytes = ctr["n_cand"] * (E + (args.read_len + 1) // 2)
+    per_search = log2n * (E + 8)
+    per_cand = E + (args.read_len + 1) // 2
     io_bytes = args.reads * args.steps * ((args.read_len + 3) // 4 + 16)
-    kernels = {"k_search": (search_bytes, tim["ms_search"], tim["n_search_launches"]),
-               "k_extend": (cand_bytes, tim["ms_extend"] + tim["ms_heavy"], tim["n_extend_launches"] + tim["n_heavy_launches"])}
-    dom = max(kernels, key=lambda k: kernels[k][1])
-    ach = kernels["k_search"][0] / max(1e-9, tim["ms_search"] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    kern = {
+        "k_search": dict(bytes=ctr["n_search"] * per_search, ms=tim["ms_search"], launches=tim["n_search_launches"]),
+        "k_wave": dict(bytes=ctr["n_cand_heavy"] * per_cand, ms=tim["ms_heavy"], launches=tim["n_heavy_launches"]),
+        "k_light": dict(bytes=(ctr["n_cand"] - ctr["n_cand_heavy"]) * per_cand, ms=tim["ms_extend"], launches=tim["n_extend_launches"]),
+    }
+    for k in kern.values():
+        k["GBs"] = k["bytes"] / max(1e-9, k["ms"] * 1e-3) / 1e9
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    ach = kern[dom]["GBs"]
+    whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": search_bytes / max(1, tim["n_search_launches"]),
-                "avg_launch_ms": tim["ms_search"] / max(1, tim["n_search_launches"]),
-                "whole_step_algorithmic_GBs": (search_bytes + cand_bytes + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9,
-                "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other")},
-                "slowest_kernel": dom}
+                "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, kern[dom]["launches"]),
+                "avg_launch_ms": kern[dom]["ms"] / max(1, kern[dom]["launches"]),
+                "per_kernel": {k: {"algorithmic_GBs": round(v["GBs"], 1), "ms": round(v["ms"], 2), "launches": v["launches"]}
+                               for k, v in kern.items()},
+                "whole_step_algorithmic_GBs": whole, "whole_step_frac": whole / HBM_PEAK_GBS,
+                "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other")}}
 
     result = {
         "metric": "aligned reads/s (SAM-identical) on 100 bp SE vs GRCh38, 1->8 MI355X",

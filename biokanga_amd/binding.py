@@ -60,7 +60,8 @@ class PEParams(ctypes.Structure):
 
 class _Counters(ctypes.Structure):
     _fields_ = [("n_reads", ctypes.c_uint64), ("n_search", ctypes.c_uint64), ("n_cand", ctypes.c_uint64),
-                ("n_lcm_calls", ctypes.c_uint64), ("n_heavy", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 3)]
+                ("n_lcm_calls", ctypes.c_uint64), ("n_heavy", ctypes.c_uint64), ("n_cand_heavy", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64 * 2)]
 
 
 class _Timing(ctypes.Structure):
@@ -264,7 +265,7 @@ class Aligner:
         rc = self.lib.bk_get_counters(self.h, ctypes.byref(c), 1 if reset else 0)
         if rc:
             raise BkError(rc, "bk_get_counters")
-        return {k: getattr(c, k) for k in ("n_search", "n_cand", "n_lcm_calls", "n_heavy")}
+        return {k: getattr(c, k) for k in ("n_search", "n_cand", "n_lcm_calls", "n_heavy", "n_cand_heavy")}
 
     def timing(self, reset=False):
         t = _Timing()

@@ -23,7 +23,7 @@ void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t
 void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
-                   int phase, int cmax, int nstr, hipStream_t s);
+                   int phase, int cmax, int nstr, int lazy, hipStream_t s);
 void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
@@ -67,6 +67,7 @@ struct bk_ctx {
     void *d_ktab = nullptr;
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
+    int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;
     int k_req = -1;          // requested k (-1 auto)
     int use_ktab = 1;
@@ -388,7 +389,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         HIP_TRY(hipMemsetAsync(sm + 6, 0, 2 * 4, s));
         if (cmax > 0) {
             hipEvent_t e1 = tm.begin(s);
-            launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, s);
+            launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, (reg_path && c->lazy_search) ? 1 : 0, s);
             HIP_TRY(hipGetLastError());
             tm.end(0, e1, s);
         }
@@ -600,6 +601,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_ktab(c);
         return rc ? rc : old;
     }
+    if (n == "lazy_search") {
+        int64_t old = c->lazy_search;
+        c->lazy_search = value ? 1 : 0;
+        return old;
+    }
     if (n == "use_wave") {
         int64_t old = c->use_wave;
         c->use_wave = value ? 1 : 0;
@@ -747,7 +753,7 @@ int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
-    out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3];
+    out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3]; out->n_cand_heavy = h[4];
     if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(h)));
     return BK_OK;
 }

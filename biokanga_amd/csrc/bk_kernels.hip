@@ -354,9 +354,16 @@ __global__ void __launch_bounds__(256) k_init_reads(DevAlignCfg cfg, DevBatch b,
 // ------------------------------------------------------------------------------------------------
 // K1: SA interval search, one lane per (active read, strand, core)
 
+// With `lazy` set (register-window path), a core whose k-mer table bucket holds <= kLazyBucket suffixes
+// is NOT bisected/verified here: the bucket is handed on as is (bit 31 of iv_n set) and the extend
+// kernels keep only the members whose core bases are clean in the window they evaluate anyway -
+// same candidates in the same SA order, two dependent HBM round trips fewer per probe.
+constexpr uint32_t kLazyBucket = 4;
+constexpr uint32_t kLazyFlag = 0x80000000u;
+
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                                uint32_t n_act, int phase, int cmax, int nstr)
+                                                uint32_t n_act, int phase, int cmax, int nstr, int lazy)
 {
     uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t per_read = (uint32_t)(nstr * cmax);
@@ -381,10 +388,20 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     int strand = cfg.align_strand == 2 ? 1 : si;
     const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
     uint64_t first, count;
-    search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, count);     // exact run length
     uint64_t slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
+    if (lazy && ix.k > 0 && cl >= ix.k) {
+        uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
+        uint64_t lo, hi;
+        core_range(ix, p0, cl, lo, hi);
+        if (hi - lo <= kLazyBucket && !(lo == 0 && hi == ix.n)) {
+            b.iv_first[slot] = lo;
+            b.iv_n[slot] = (uint32_t)(hi - lo) | (hi > lo ? kLazyFlag : 0u);
+            return;
+        }
+    }
+    search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, count);     // exact run length
     b.iv_first[slot] = first;
-    b.iv_n[slot] = count > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)count;
+    b.iv_n[slot] = count > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)count;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -595,7 +612,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
         if (fits)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if (b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if ((b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             if (fits && !WIDE && ix.isa != nullptr && wave != nullptr) wave[atomicAdd(wave_cnt, 1u)] = r;
             else heavy[atomicAdd(heavy_cnt, 1u)] = r;
@@ -612,7 +629,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
                     uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + c;
-                    uint32_t n = b.iv_n[slot];
+                    const uint32_t nraw = b.iv_n[slot];
+                    const uint32_t n = nraw & ~kLazyFlag;
+                    const bool lazy = (nraw & kLazyFlag) != 0;
                     uint64_t first = b.iv_first[slot];
                     for (uint32_t j = 0; j < n; j++) {
                         uint64_t loci = sa_get<WIDE>(ix, first + j);
@@ -620,6 +639,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                         uint64_t t = loci - (uint64_t)ofs[c];
                         Window<NW> w;
                         eval_window<NW>(rw, len, ix.tgt4, t, w);
+                        if (lazy && !core_clean<NW>(w, ofs[c], cl)) continue;    // bucket member that is not a match of this core
                         if (w.eos) continue;                                    // crosses an entry boundary
                         bool dup = false;                                       // reached through an earlier core already?
                         for (int c2 = 0; c2 < c; c2++) dup |= core_clean<NW>(w, ofs[c2], cl);
@@ -734,7 +754,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             if (lane < nc) {
                 uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + lane;
                 core[lane].first = b.iv_first[slot];
-                core[lane].n = b.iv_n[slot];
+                core[lane].n = b.iv_n[slot];          // bit 31: unverified bucket (<= kLazyBucket members)
                 core[lane].walked = 0;
             }
             __builtin_amdgcn_wave_barrier();
@@ -742,7 +762,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             for (int c = 0; c < nc && !done && nodes < kNodeCap; c++) {
                 n_search++;
                 const uint64_t first = core[c].first;
-                const uint64_t n = core[c].n;
+                const bool lazy = (core[c].n & kLazyFlag) != 0;
+                const uint64_t n = core[c].n & ~kLazyFlag;
                 const int ofs = core[c].ofs;
                 uint32_t iter = 0;
                 bool copies_checked = false;
@@ -759,14 +780,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     for (int k = 0; k < NW / 4; k++) w.bm[k] = ~0ULL;
                     if (valid) {
                         eval_window<NW>(rw, len, ix.tgt4, t, w);
-                        valid = !w.eos;
+                        valid = !w.eos && (!lazy || core_clean<NW>(w, ofs, cl));
                     }
                     bool dup = false;
                     for (int c2 = 0; c2 < c; c2++) {
                         bool m = valid && !dup && core_clean<NW>(w, core[c2].ofs, cl);
                         if (__ballot(m)) {
                             if (m) {
-                                if (core[c2].walked >= core[c2].n) dup = true;
+                                if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
                                 else {
                                     uint64_t rank = (uint64_t)ix.isa[t + (uint64_t)core[c2].ofs] - core[c2].first;
                                     dup = rank < (uint64_t)core[c2].walked;
@@ -842,7 +863,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     if (exit_now) done = true;
                     if (cutoff < j0 + 64) { walked = cutoff; break; }
                 }
-                if (lane == 0) core[c].walked = walked > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)walked;
+                if (lane == 0) core[c].walked = walked > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)walked;
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -865,6 +886,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (n_search) atomicAdd(&b.ctr[0], n_search);
         if (n_cand) atomicAdd(&b.ctr[1], n_cand);
         if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
@@ -1087,6 +1109,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         if (n_search) atomicAdd(&b.ctr[0], n_search);
         if (n_cand) atomicAdd(&b.ctr[1], n_cand);
         if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
@@ -1418,12 +1441,12 @@ void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint3
 }
 
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
-                   int phase, int cmax, int nstr, hipStream_t s)
+                   int phase, int cmax, int nstr, int lazy, hipStream_t s)
 {
     uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
     unsigned blocks = (unsigned)((threads + 255) / 256);
-    if (ix.sa_hi) hipLaunchKernelGGL(k_search<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
-    else hipLaunchKernelGGL(k_search<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy);
+    else hipLaunchKernelGGL(k_search<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy);
 }
 
 void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,

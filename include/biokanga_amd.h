@@ -78,8 +78,9 @@ typedef struct bk_counters {
     uint64_t n_search;      /* LocateFirstExact calls                                  */
     uint64_t n_cand;        /* candidates Hamming-extended (new, in-bounds targets)    */
     uint64_t n_lcm_calls;   /* LocateCoreMultiples invocations                         */
-    uint64_t n_heavy;       /* (ours) LocateCoreMultiples calls routed to the wave-per-read kernel */
-    uint64_t reserved[3];
+    uint64_t n_heavy;       /* (ours) LocateCoreMultiples calls routed to the wave-per-read kernels */
+    uint64_t n_cand_heavy;  /* (ours) the part of n_cand processed by the wave-per-read kernels    */
+    uint64_t reserved[2];
 } bk_counters;
 
 /* timing of the device work of the last bk_align_batch*() call, measured with HIP events on the
