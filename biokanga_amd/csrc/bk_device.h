@@ -119,15 +119,23 @@ __host__ __device__ inline void phase_params(const ReadPlan &p, const DevAlignCf
 }
 
 // core sliding rule of LocateCoreMultiples (SfxArrayV2.cpp:5836-5847); returns the number of cores,
-// writes the first `maxn` offsets
+// writes the first `maxn` offsets.  The rule advances by `cd` until a core would overrun the read,
+// then places one last core flush with the read's end, so offset i is min(i*cd, plen-cl).  The
+// offsets are written with compile-time indexes after the counting loop: a data-dependent
+// `if (n < maxn) ofs[n] = o` inside the loop was miscompiled for gfx950 (hipcc 7.2) when the count
+// exceeded maxn - the 17th offset landed in a neighbouring register.
 __host__ __device__ inline int core_offsets(int plen, int cl, int cd, int max_slides, int *ofs, int maxn)
 {
     int cur = cd, o = 0, n = 0;
     while (n < max_slides && o <= plen - cl && cur > cl / 3) {
         if (o + cl + cur > plen) cur = plen - (o + cl);
-        if (n < maxn) ofs[n] = o;
         n++;
         o += cur;
+    }
+    const int last = plen - cl;
+    for (int i = 0; i < maxn; i++) {
+        int v = i * cd;
+        ofs[i] = v < last ? v : last;
     }
     return n;
 }

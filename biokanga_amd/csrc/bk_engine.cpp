@@ -360,7 +360,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         int rc = size_heavy_scratch(c);
         if (rc) return rc;
     }
-    uint32_t wpr = (maxlen + 15) / 16 + 1;
+    uint32_t wpr = ((maxlen + 15) / 16 + 2) & ~1u;      // even: every packed row starts 16-byte aligned
     int rc = ensure_batch_scratch(c, n, wpr);
     if (rc) return rc;
 
@@ -729,7 +729,7 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_in_out, hits, (size_t)nreads * sizeof(bk_hit), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    uint32_t wpr = (maxlen + 15) / 16 + 1;
+    uint32_t wpr = ((maxlen + 15) / 16 + 2) & ~1u;
     int rc = ensure_batch_scratch(c, nreads, wpr);
     if (rc) return rc;
     DevBatch b{};

@@ -527,18 +527,36 @@ template <int NW>
 __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, const uint64_t *__restrict__ tgt, uint64_t t,
                                             Window<NW> &w)
 {
+    // The chip retires only ~49 G divergent lane-loads/s whatever their width (tools/rand_access_bench),
+    // so the window is fetched with 16-byte loads: ceil((len/16 + 2) / 2) instructions instead of len/16 + 1.
     const uint64_t i0 = t >> 4;
     const unsigned s = (unsigned)(t & 15) << 2;
-    uint64_t raw[NW + 1];
+    const bool odd = (i0 & 1) != 0;
+    const uint4 *__restrict__ blk = reinterpret_cast<const uint4 *>(tgt) + (i0 >> 1);
+    constexpr int NB = NW / 2 + 1;
+    uint64_t r2[2 * NB];
 #pragma unroll
-    for (int k = 0; k <= NW; k++) raw[k] = (16 * (k - 1) < len || k == 0) ? tgt[i0 + k] : 0;   // word k is needed iff base 16(k-1) exists
+    for (int q = 0; q < NB; q++) {
+        // block q holds words 2q, 2q+1 counted from the even word at or below i0; the last window word
+        // k = (len-1)/16 reads words k+odd and k+1+odd
+        if (32 * (q - 1) < len) {
+            uint4 v = blk[q];
+            r2[2 * q] = ((uint64_t)v.y << 32) | v.x;
+            r2[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+        } else {
+            r2[2 * q] = 0;
+            r2[2 * q + 1] = 0;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NW / 4; k++) w.bm[k] = 0;
     uint64_t eosacc = 0;
 #pragma unroll
     for (int k = 0; k < NW; k++) {
         if (16 * k < len) {
-            uint64_t win = (raw[k] << s) | ((raw[k + 1] >> 1) >> (63 - s));
+            uint64_t a = odd ? r2[k + 1] : r2[k];
+            uint64_t b = odd ? r2[k + 2] : r2[k + 1];
+            uint64_t win = (a << s) | ((b >> 1) >> (63 - s));
             uint64_t m = top_mask(len - 16 * k);
             uint64_t x = (rw[k] ^ win) & m;
             uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
@@ -580,8 +598,19 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)      // value known to
 template <int NW>
 __device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw, int len, uint64_t (&rw)[NW])
 {
+    // rd4 rows are 16-byte aligned (wpr is even): 16-byte loads
+    const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(rdw);
 #pragma unroll
-    for (int k = 0; k < NW; k++) rw[k] = 16 * k < len ? rdw[k] : 0;
+    for (int q = 0; q < NW / 2; q++) {
+        if (32 * q < len) {
+            uint4 v = p[q];
+            rw[2 * q] = ((uint64_t)v.y << 32) | v.x;
+            rw[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+        } else {
+            rw[2 * q] = 0;
+            rw[2 * q + 1] = 0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

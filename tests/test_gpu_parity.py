@@ -244,3 +244,37 @@ def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, tag):
     o.close()
     assert_hits_equal(hits, exp, names)
     assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
+
+
+@pytest.mark.parametrize("read_len", [100, 300])
+def test_five_byte_suffix_elements(tmp_path, read_len):
+    """.sfx with 5-byte suffix elements (what the reference writes above 4 Gbp), forced onto a small
+    genome: the WIDE kernels (sa_lo + sa_hi) agree with the oracle; 300 bp reads also exercise the
+    long-read path (k_extend / k_heavy, no register window)."""
+    import torch
+    bk = _bk()
+    seq, ents, reads = _synth_case(500 + read_len, 300000, 6000, read_len, 6)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    path = str(tmp_path / "wide.sfx")
+    helpers.write_sfx(path, "wide", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa.astype(np.uint64), el_size=5)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = (np.arange(nreads, dtype=np.uint64) * read_len)
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    o = helpers.OracleSfx(path)
+    exp, octr = o.align(bases, offs, lens, helpers.make_params(max_subs=5), nthreads=8)
+    o.close()
+    with bk.Aligner(path, bk.AlignParams(max_subs=5)) as al:
+        assert al.lib.bk_sfx_el_size(al.h) == 5
+        for thresh in (64, 0):
+            al.tune("heavy_thresh", thresh)
+            al.counters(reset=True)
+            got = al.align(bases, offs, lens)
+            ctr = al.counters()
+            assert_hits_equal(got, exp)
+            assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
