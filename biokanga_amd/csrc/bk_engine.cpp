@@ -20,6 +20,7 @@ void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
@@ -63,7 +64,7 @@ struct bk_ctx {
     uint32_t *d_sa_lo = nullptr;
     uint8_t *d_sa_hi = nullptr;
     uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
-    uint32_t *d_ent_id = nullptr;
+    uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
     void *d_ktab = nullptr;
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
@@ -239,6 +240,15 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     c->ix.ent_start = c->d_ent_start;
     c->ix.ent_end = c->d_ent_end;
     c->ix.ent_id = c->d_ent_id;
+    {   // EntryID -> entry index, for the per-sequence hit counts
+        uint32_t max_id = 0;
+        for (uint32_t i = 0; i < n_entries; i++) max_id = std::max(max_id, ei[i]);
+        if ((uint64_t)max_id > 16ULL * n_entries + (1u << 20)) return BK_ERR_PARAMS;
+        std::vector<uint32_t> map((size_t)max_id + 1, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < n_entries; i++) map[ei[i]] = i;
+        HIP_TRY(hipMalloc(&c->d_id2idx, map.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_id2idx, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+    }
     c->ix.n_ent = n_entries;
     HIP_TRY(hipMalloc(&c->d_seq_counts, n_entries * 8));
     HIP_TRY(hipMemset(c->d_seq_counts, 0, n_entries * 8));
@@ -427,6 +437,10 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         cur ^= 1;
         if (phase > 70) return BK_ERR_INTERNAL;
     }
+    hipEvent_t e4 = tm.begin(s);
+    launch_count_seqs(d_out, n, c->d_id2idx, c->ix.n_ent, c->d_seq_counts, s);
+    HIP_TRY(hipGetLastError());
+    tm.end(3, e4, s);
     return BK_OK;
 }
 
@@ -553,7 +567,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_ktab);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -586,6 +600,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->cfg.heavy_thresh;
         if (value < 0 || value > 100) return BK_ERR_PARAMS;
         c->cfg.heavy_thresh = (int)value;     // 0 routes every call with a non-empty interval to k_heavy
+        return old;
+    }
+    if (n == "exp") {
+        int64_t old = c->cfg.exp;
+        c->cfg.exp = (int)value;
         return old;
     }
     if (n == "chunk_reads") {

@@ -187,7 +187,6 @@ __device__ __forceinline__ void write_result(const DevIndex &ix, const DevAlignC
             h.match_loci = (uint32_t)(hit_left - ix.ent_start[hit_ent]);
             h.match_len = (uint16_t)len;
             h.mismatches = (uint8_t)low_mm;
-            atomicAdd(&b.seq_counts[hit_ent], 1ULL);
         } else
             h.nar = BK_NAR_MULTIALIGN;
         break;
@@ -492,9 +491,9 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         n_lcm += __shfl_down(n_lcm, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
+        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm && !(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm);
     }
 }
 
@@ -626,10 +625,21 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                                                uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
                                                uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
 {
+    // list appends, the next phase's core maximum and the counters are combined per block in LDS:
+    // one global atomic per block and list instead of one per wave (same-address returning atomics
+    // retire at only ~170 M/s on this part)
+    __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
+    __shared__ unsigned long long s_ctr[3];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 4) s_cmax = 0;
+    if (threadIdx.x >= 8 && threadIdx.x < 11) s_ctr[threadIdx.x - 8] = 0;
+    __syncthreads();
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel
+    uint32_t r = 0, my_cmax = 0;
     if (a < n_act) {
-        uint32_t r = act[a];
+        r = act[a];
         int len = (int)b.lens[r];
         ReadPlan p = make_plan(len, cfg);
         int mm, cl, cd, ofs[kMaxCoresFast];
@@ -643,8 +653,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 for (int c = 0; c < nc; c++)
                     if ((b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
-            if (fits && !WIDE && ix.isa != nullptr && wave != nullptr) wave[atomicAdd(wave_cnt, 1u)] = r;
-            else heavy[atomicAdd(heavy_cnt, 1u)] = r;
+            dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
         } else {
             n_lcm = 1;
             const int init = mm + cfg.mm_delta + 1;
@@ -695,21 +704,50 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 int mm2, cl2, cd2, dummy[1];
                 phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
                 int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
-                next_act[atomicAdd(next_cnt, 1u)] = r;
+                if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
+                dest = 1;
             }
         }
     }
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ULL << lane) - 1;
     for (int off = 32; off > 0; off >>= 1) {
         n_search += __shfl_down(n_search, off);
         n_cand += __shfl_down(n_cand, off);
         n_lcm += __shfl_down(n_lcm, off);
+        uint32_t m = __shfl_down(my_cmax, off);
+        my_cmax = m > my_cmax ? m : my_cmax;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
+    uint32_t my_off = 0;
+#pragma unroll
+    for (int d = 1; d <= 3; d++) {
+        uint64_t m = __ballot(dest == d);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
+        }
     }
+    if (lane == 0) {
+        if (my_cmax) atomicMax(&s_cmax, my_cmax);
+        if (n_search) atomicAdd(&s_ctr[0], n_search);
+        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
+    }
+    __syncthreads();
+    {
+        const uint32_t t = threadIdx.x;
+        if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
+        if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
+        if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
+        if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
+        if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    }
+    __syncthreads();
+    if (dest == 1) next_act[s_base[1] + my_off] = r;
+    else if (dest == 2) wave[s_base[2] + my_off] = r;
+    else if (dest == 3) heavy[s_base[3] + my_off] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -724,6 +762,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 // core c2 the read's core c2 matches the target at T (so T+ofs[c2] lies in c2's suffix interval) AND
 // that suffix lay inside the prefix of c2's interval that was actually walked (rank from the inverse
 // suffix array; only looked up when c2's walk was cut short).
+
+constexpr int kWaveGrab = 8;
 
 struct WaveCoreInfo {
     unsigned long long first;
@@ -745,10 +785,28 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     const uint64_t lt_mask = (1ULL << lane) - 1;
     unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
 
+    // work items are claimed kWaveGrab at a time: one device-scope atomic on the shared cursor per
+    // item serialises 8192 resident waves on a single address
+    uint32_t grab_next = 0, grab_left = 0;
+    const int grab = kWaveGrab;
+    // reads that go on to the next phase are parked one per lane and appended 64 at a time
+    uint32_t pend_r = 0, pend_n = 0, cmax_loc = 0;
+    auto flush_pending = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_cnt, pend_n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((uint32_t)lane < pend_n) next_act[base + lane] = pend_r;
+        pend_n = 0;
+    };
     for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(cursor, 1u);
-        item = __shfl(item, 0);
+        if (grab_left == 0) {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(cursor, (uint32_t)grab);
+            grab_next = __builtin_amdgcn_readfirstlane(g);
+            grab_left = (uint32_t)grab;
+        }
+        const uint32_t item = grab_next++;
+        grab_left--;
         if (item >= n_list) break;
         const uint32_t r = list[item];
         const int len = (int)b.lens[r];
@@ -896,26 +954,29 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-        if (lane == 0) {
-            if (rslt != BK_HR_NONE) {
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
+        if (rslt != BK_HR_NONE) {
+            if (lane == 0) {
                 int e = low_inst >= 1 ? find_entry(ix, hit_left) : -1;
                 write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, (phase << 1) | 1);
-            } else if (phase + 1 < p.n_phases) {
-                int mm2, cl2, cd2, dummy[1];
-                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
-                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
-                next_act[atomicAdd(next_cnt, 1u)] = r;
             }
+        } else if (phase + 1 < p.n_phases) {
+            int mm2, cl2, cd2, dummy[1];
+            phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+            int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+            if (nc2 <= kMaxCoresFast && (uint32_t)nc2 > cmax_loc) cmax_loc = (uint32_t)nc2;
+            if ((uint32_t)lane == pend_n) pend_r = r;
+            if (++pend_n == 64) flush_pending();
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (pend_n) flush_pending();
+    if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { if (!(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm); if (!(cfg.exp & 2)) atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
@@ -1135,10 +1196,10 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     }
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { if (!(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm); if (!(cfg.exp & 2)) atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
@@ -1155,6 +1216,29 @@ __global__ void k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_
     uint32_t v = i < n ? lens[i] : 0;
     for (int off = 32; off > 0; off >>= 1) { uint32_t w = __shfl_down(v, off); v = w > v ? w : v; }
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
+// per-sequence counts of accepted reads (feeds the -O CSV and the cross-rank reduction): one pass over
+// a finished chunk's hit records with a block-private LDS histogram, so that the alignment kernels
+// carry no same-address global atomics (47 M of them per 50 M reads cost ~30 ms inside k_light)
+constexpr uint32_t kHistLds = 4096;
+
+__global__ void __launch_bounds__(256) k_count_seqs(const bk_hit *__restrict__ out, uint32_t n, const uint32_t *__restrict__ id2idx,
+                                                    uint32_t n_ent, unsigned long long *__restrict__ counts)
+{
+    __shared__ uint32_t s_hist[kHistLds];
+    const uint32_t nl = n_ent < kHistLds ? n_ent : kHistLds;
+    for (uint32_t i = threadIdx.x; i < nl; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (out[i].nar != BK_NAR_ACCEPTED) continue;
+        uint32_t e = id2idx[out[i].chrom_id];
+        if (e < nl) atomicAdd(&s_hist[e], 1u);
+        else atomicAdd(&counts[e], 1ULL);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nl; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&counts[i], (unsigned long long)s_hist[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1455,6 +1539,14 @@ void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hi
     if (blocks > 65536) blocks = 65536;
     if (!blocks) return;
     hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+}
+
+void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s)
+{
+    if (!n) return;
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_count_seqs, dim3(blocks), dim3(256), 0, s, out, n, id2idx, n_ent, counts);
 }
 
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s)
