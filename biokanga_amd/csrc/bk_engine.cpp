@@ -29,6 +29,11 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
+void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s);
+void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
+                     uint32_t n_list, hipStream_t s);
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, hipStream_t s);
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
@@ -66,6 +71,10 @@ struct bk_ctx {
     uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
     uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
     void *d_ktab = nullptr;
+    uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
+    uint32_t *d_slist = nullptr;          // work list of the two-pass search
+    uint64_t cap_slist = 0;
+    int use_k2 = 1;
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
@@ -87,7 +96,7 @@ struct bk_ctx {
     // heavy path scratch
     HeavyScratch hs{};
     int max_read_len = 500;
-    uint32_t chunk_reads = 4u << 20;
+    uint32_t chunk_reads = 64u << 20;
     // staging for host-buffer batches
     uint8_t *d_in_bases = nullptr;
     uint64_t *d_in_offs = nullptr;
@@ -178,6 +187,37 @@ int build_ktab(bk_ctx *c)
     return BK_OK;
 }
 
+// second-level key array; needs the k-mer table.  Skipped (search falls back to the one-pass kernel)
+// when it would not leave a quarter of the HBM free, or if the suffix array is not ordered the way
+// the bisection needs (never seen; checked because .sfx files come from outside).
+int build_k2(bk_ctx *c)
+{
+    free_dev(c->d_k2);
+    c->d_k2 = nullptr;
+    c->ix.k2 = nullptr;
+    if (!c->use_k2 || c->ix.k <= 0) return BK_OK;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t need = c->ix.n * 8;
+    if (need > free_b || free_b - need < total_b / 4) return BK_OK;
+    HIP_TRY(hipMalloc(&c->d_k2, need));
+    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
+    launch_build_k2(c->ix, c->d_k2, c->d_ctr + 7, c->stream);
+    HIP_TRY(hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, c->d_ctr + 7, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
+    if (bad) {
+        fprintf(stderr, "biokanga_amd: suffix array not in nibble order inside %llu k-mer bucket(s); second-level keys disabled\n", bad);
+        free_dev(c->d_k2);
+        c->d_k2 = nullptr;
+        return BK_OK;
+    }
+    c->ix.k2 = c->d_k2;
+    return BK_OK;
+}
+
 int build_isa(bk_ctx *c)
 {
     free_dev(c->d_isa);
@@ -259,6 +299,7 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     int rc = derive_cfg(c);
     if (rc) return rc;
     rc = build_ktab(c);
+    if (!rc) rc = build_k2(c);
     if (rc) return rc;
     rc = build_isa(c);
     if (rc) return rc;
@@ -355,22 +396,23 @@ struct EvTimer {
 };
 
 // one chunk of reads, all phases.  Blocking (host reads back the active counts between phases).
-int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+static inline uint32_t words_per_read(uint32_t maxlen)
+{
+    return ((maxlen + 15) / 16 + 2) & ~1u;      // even: every packed row starts 16-byte aligned
+}
+
+// per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
+static inline uint64_t scratch_bytes_per_read(uint32_t wpr)
+{
+    return 2ULL * wpr * 8 + 2ULL * kMaxCoresFast * 12 + 4 * 4;
+}
+
+int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n, uint32_t maxlen,
                 bk_hit *d_out, hipStream_t s, EvTimer &tm)
 {
     uint32_t *sm = c->d_small, *hm = c->h_small;
     HIP_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
-    launch_max_len(d_lens, n, sm + 5, s);
-    HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint32_t maxlen = hm[5];
-    if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
-    if ((int)maxlen > c->max_read_len) {
-        c->max_read_len = (int)maxlen;
-        int rc = size_heavy_scratch(c);
-        if (rc) return rc;
-    }
-    uint32_t wpr = ((maxlen + 15) / 16 + 2) & ~1u;      // even: every packed row starts 16-byte aligned
+    const uint32_t wpr = words_per_read(maxlen);
     int rc = ensure_batch_scratch(c, n, wpr);
     if (rc) return rc;
 
@@ -398,8 +440,26 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
         HIP_TRY(hipMemsetAsync(sm + 6, 0, 2 * 4, s));
         if (cmax > 0) {
+            const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
             hipEvent_t e1 = tm.begin(s);
-            launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, (reg_path && c->lazy_search) ? 1 : 0, s);
+            if (c->ix.k2) {
+                const uint64_t lanes = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+                if (lanes > c->cap_slist) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    free_dev(c->d_slist);
+                    c->d_slist = nullptr;
+                    c->cap_slist = 0;
+                    HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
+                    c->cap_slist = lanes;
+                }
+                HIP_TRY(hipMemsetAsync(sm + 8, 0, 4, s));
+                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                launch_search_b(c->ix, c->cfg, b, phase, lazy, c->d_slist, hm[8], s);
+            } else
+                launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, s);
             HIP_TRY(hipGetLastError());
             tm.end(0, e1, s);
         }
@@ -449,9 +509,33 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
 {
     EvTimer tm{c};
     hipEvent_t t0 = tm.begin(s);
+    // longest read of the call -> row width of the packed reads and the kernel family used
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+    launch_max_len(d_lens, nreads, c->d_small + 5, s);
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 16 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t maxlen = c->h_small[5];
+    if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+    if ((int)maxlen > c->max_read_len) {
+        c->max_read_len = (int)maxlen;
+        int rc = size_heavy_scratch(c);
+        if (rc) return rc;
+    }
+    // chunk size: as many reads as the knob allows and as fit in about half of the HBM still free
+    // (the phase kernels run better the more reads they see: fewer launches, shorter tails)
+    uint32_t chunk = c->chunk_reads;
+    {
+        const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen));
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr);
+        uint64_t fit = ((uint64_t)free_b + have) / 2 / per_read;
+        if (fit < 65536) fit = 65536;
+        if (fit < chunk) chunk = (uint32_t)fit;
+    }
     for (uint32_t done = 0; done < nreads;) {
-        uint32_t n = std::min(c->chunk_reads, nreads - done);
-        int rc = align_chunk(c, d_bases, d_offs + done, d_lens + done, n, d_out + done, s, tm);
+        uint32_t n = std::min(chunk, nreads - done);
+        int rc = align_chunk(c, d_bases, d_offs + done, d_lens + done, n, maxlen, d_out + done, s, tm);
         if (rc) return rc;
         done += n;
     }
@@ -567,7 +651,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -618,6 +702,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         if (n == "use_ktab") c->use_ktab = value ? 1 : 0;
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
         int rc = build_ktab(c);
+        if (!rc) rc = build_k2(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_k2") {
+        int64_t old = c->use_k2;
+        c->use_k2 = value ? 1 : 0;
+        int rc = build_k2(c);
         return rc ? rc : old;
     }
     if (n == "lazy_search") {

@@ -281,6 +281,24 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k)
 // Nibble written for a base byte v: v & 7 (quality / mask bits dropped); values 5..7 mark a byte
 // the reference would refuse ((*pSeq = (*pSeqVal & 0x07)) > eBaseN).
 
+struct __attribute__((packed)) Bytes16 { uint64_t lo, hi; };      // unaligned 16-byte load (one global_load_dwordx4)
+
+// 8 base bytes, first base in the MOST significant byte -> 8 nibbles (bits 0..2 of each byte kept)
+__device__ __forceinline__ uint64_t pack8_msb(uint64_t y)
+{
+    y &= 0x0707070707070707ULL;
+    y = (y | (y >> 4)) & 0x00FF00FF00FF00FFULL;
+    y = (y | (y >> 8)) & 0x0000FFFF0000FFFFULL;
+    y = (y | (y >> 16)) & 0x00000000FFFFFFFFULL;
+    return y;
+}
+
+__device__ __forceinline__ uint64_t complement8(uint64_t x)       // A<->T, C<->G on 3-bit codes, others unchanged
+{
+    x &= 0x0707070707070707ULL;
+    return x ^ (((~x >> 2) & 0x0101010101010101ULL) * 3);
+}
+
 __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
 {
     const uint32_t wpr = b.wpr;
@@ -294,12 +312,21 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
     const uint8_t *s = b.bases + b.offs[r];
     uint64_t v = 0;
     int base0 = 16 * (int)w;
-    if (base0 < len) {
-        int cnt = len - base0 < 16 ? len - base0 : 16;
+    if (base0 + 16 <= len) {
+        // a full word: the 16 source bytes lie inside the read, fetch them with one load
+        if (st == 0) {
+            Bytes16 q = *reinterpret_cast<const Bytes16 *>(s + base0);
+            v = (pack8_msb(__builtin_bswap64(q.lo)) << 32) | pack8_msb(__builtin_bswap64(q.hi));
+        } else {
+            // reverse complement (SeqTrans.cpp:458-512): output base k = complement of s[len-1-base0-k]
+            Bytes16 q = *reinterpret_cast<const Bytes16 *>(s + (len - 16 - base0));
+            v = (pack8_msb(complement8(q.hi)) << 32) | pack8_msb(complement8(q.lo));
+        }
+    } else if (base0 < len) {
+        int cnt = len - base0;
         if (st == 0) {
             for (int k = 0; k < cnt; k++) v |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
         } else {
-            // reverse complement: A<->T, C<->G, others unchanged (SeqTrans.cpp:458-512)
             for (int k = 0; k < cnt; k++) {
                 uint8_t x = s[len - 1 - base0 - k] & 7;
                 x = x < 4 ? (uint8_t)(3 - x) : x;
@@ -310,44 +337,64 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
     b.rd4[r * per_read + rem] = v;
 }
 
-__global__ void __launch_bounds__(256) k_init_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
-                                                     uint32_t *__restrict__ act_cnt, uint32_t *__restrict__ cmax)
+__global__ void __launch_bounds__(1024) k_init_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
+                                                      uint32_t *__restrict__ act_cnt, uint32_t *__restrict__ cmax)
 {
+    __shared__ uint32_t s_cnt, s_base, s_cmax;
+    if (threadIdx.x == 0) { s_cnt = 0; s_cmax = 0; }
+    __syncthreads();
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= b.n_reads) return;
-    int len = (int)b.lens[r];
-    bk_hit h;
-    h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
-    h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
-    int max_ns_seq = 0;
-    if (cfg.max_ns) {
-        max_ns_seq = (len * cfg.max_ns) / 100;
-        if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
-    }
-    const uint64_t *fw = b.rd4 + (uint64_t)r * 2 * b.wpr;
-    int num_ns = 0;
-    bool bad = false;
-    for (int w = 0; 16 * w < len; w++) {
-        uint64_t x = fw[w] & top_mask(len - 16 * w);
-        uint64_t hi = x & 0x4444444444444444ULL;                    // values 4..7
-        uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;       // low two bits non-zero
-        bad |= ((hi >> 2) & lo) != 0;                               // 5,6,7: not a base the reference accepts
-        num_ns += __popcll(hi);
-    }
-    if (bad || num_ns > max_ns_seq) {
-        h.nar = BK_NAR_NS;
+    bool go = false;
+    uint32_t my_cmax = 0;
+    if (r < b.n_reads) {
+        int len = (int)b.lens[r];
+        bk_hit h;
+        h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
+        h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
+        int max_ns_seq = 0;
+        if (cfg.max_ns) {
+            max_ns_seq = (len * cfg.max_ns) / 100;
+            if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
+        }
+        const uint64_t *fw = b.rd4 + (uint64_t)r * 2 * b.wpr;
+        int num_ns = 0;
+        bool bad = false;
+        for (int w = 0; 16 * w < len; w++) {
+            uint64_t x = fw[w] & top_mask(len - 16 * w);
+            uint64_t hi = x & 0x4444444444444444ULL;                    // values 4..7
+            uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;       // low two bits non-zero
+            bad |= ((hi >> 2) & lo) != 0;                               // 5,6,7: not a base the reference accepts
+            num_ns += __popcll(hi);
+        }
+        if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
         b.out[r] = h;
-        return;
+        if (h.nar != BK_NAR_NS) {
+            ReadPlan p = make_plan(len, cfg);
+            if (p.n_phases > 0) {
+                int mm, cl, cd, ofs[1];
+                phase_params(p, cfg, 0, mm, cl, cd);
+                int nc = core_offsets(len, cl, cd, p.max_slides, ofs, 0);
+                if (nc <= kMaxCoresFast) my_cmax = (uint32_t)nc;
+                go = true;
+            }
+        }
     }
-    b.out[r] = h;
-    ReadPlan p = make_plan(len, cfg);
-    if (p.n_phases > 0) {
-        int mm, cl, cd, ofs[1];
-        phase_params(p, cfg, 0, mm, cl, cd);
-        int nc = core_offsets(len, cl, cd, p.max_slides, ofs, 0);
-        if (nc <= kMaxCoresFast) atomicMax(cmax, (uint32_t)nc);
-        act[atomicAdd(act_cnt, 1u)] = r;
+    // one global append per block (see k_light)
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(go);
+    uint32_t my_off = 0;
+    for (int off = 32; off > 0; off >>= 1) { uint32_t q = __shfl_down(my_cmax, off); my_cmax = q > my_cmax ? q : my_cmax; }
+    if (m) {
+        uint32_t w = 0;
+        if (lane == 0) { w = atomicAdd(&s_cnt, (uint32_t)__popcll(m)); if (my_cmax) atomicMax(&s_cmax, my_cmax); }
+        w = __builtin_amdgcn_readfirstlane(w);
+        my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(act_cnt, s_cnt);
+    if (threadIdx.x == 64 && s_cmax) atomicMax(cmax, s_cmax);
+    __syncthreads();
+    if (go) act[s_base + my_off] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +452,222 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
 
 // ------------------------------------------------------------------------------------------------
 // K2/K3: candidate walk + Hamming extension + classification, one lane per active read
+
+// ------------------------------------------------------------------------------------------------
+// Two-pass search over the second-level key array (DevIndex::k2).
+//   k2[i] = the 16 nibbles that FOLLOW the first k bases of suffix sa[i]  (all-ones when one of those
+//           first k nibbles is N/EOS: such suffixes sit at the end of their k-mer bucket and compare
+//           above every N-free probe).  Inside one k-mer bucket k2 is non-decreasing, so bases
+//           k .. k+15 of a core are resolved by a bisection over CONTIGUOUS 8-byte keys - one load per
+//           step instead of the dependent suffix-array-then-target pair, and a bucket of <= 8
+//           suffixes is settled from one or two cache lines.
+//   pass A (lane per read/strand/core): k-mer table lookup; empty buckets and buckets of <= 8 keys are
+//           finished here, everything else is appended to a work list.
+//   pass B (lane per work item): bisection over k2, then - for cores longer than k+16 bases whose
+//           sub-bucket is not handed on unverified - over suffix array + target from base k+16 on.
+// The split keeps the lanes of pass B uniformly busy: in one combined kernel ~70 % of the lanes
+// finished after the table lookup and idled while their wave's longest bisection ran.
+// Work items: the slot index; its iv_first/iv_n entry carries (range start, size | kind << 30).
+
+constexpr uint32_t kKindShift = 30;
+constexpr uint32_t kKindK2 = 1;        // bisect k2 over [first, first+size)
+constexpr uint32_t kKindDeep = 2;      // [first, first+size) shares k+16 bases with the core: resolve the rest
+constexpr uint32_t kKindFull = 3;      // no usable k-mer bucket: full search
+constexpr uint32_t kInlineBucket = 8;
+
+// -1 / 0 / +1: key (masked to the core's nibbles) vs probe; the all-ones key sorts above everything
+__device__ __forceinline__ int k2_cmp(uint64_t key, uint64_t m, uint64_t q2)
+{
+    if (key == ~0ULL) return 1;
+    key &= m;
+    return key < q2 ? -1 : (key > q2 ? 1 : 0);
+}
+
+// as cmp_core, but only bases [start, cl) of the core are compared
+__device__ __forceinline__ int cmp_core_from(const uint64_t *__restrict__ rdw, int ofs, int cl, int start,
+                                             const uint64_t *__restrict__ tgt, uint64_t pos)
+{
+    for (int i = start; i < cl; i += 16) {
+        uint64_t m = top_mask(cl - i);
+        uint64_t p = nib16(rdw, ofs + i) & m;
+        uint64_t t = nib16(tgt, pos + i) & m;
+        if (p != t) return p < t ? -1 : 1;
+    }
+    return 0;
+}
+
+template <bool WIDE>
+__global__ void k_build_k2(DevIndex ix, uint64_t *__restrict__ k2)
+{
+    const uint64_t km = top_mask(ix.k) & 0x4444444444444444ULL;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t pos = sa_get<WIDE>(ix, i);
+        uint64_t w0 = nib16(ix.tgt4, pos);
+        k2[i] = (w0 & km) ? ~0ULL : nib16(ix.tgt4, pos + (uint64_t)ix.k);
+    }
+}
+
+// the bisection needs k2 non-decreasing inside every k-mer bucket; count the places where it is not
+template <bool WIDE>
+__global__ void k_check_k2(DevIndex ix, const uint64_t *__restrict__ k2, unsigned long long *__restrict__ bad)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (k2[i] <= k2[i + 1]) continue;
+        if (suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), ix.k) == suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i + 1), ix.k))
+            atomicAdd(bad, 1ULL);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                  uint32_t n_act, int phase, int cmax, int nstr, int lazy,
+                                                  uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+{
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t per_read = (uint32_t)(nstr * cmax);
+    uint64_t a = tid / per_read;
+    bool push = false;
+    uint64_t slot = 0;
+    if (a < n_act) {
+        uint32_t rem = (uint32_t)(tid - a * per_read);
+        int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
+        uint32_t r = act[a];
+        int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd, dummy[1];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+        if (c < nc && nc <= kMaxCoresFast) {
+            int my_ofs = c * cd < len - cl ? c * cd : len - cl;
+            int strand = cfg.align_strand == 2 ? 1 : si;
+            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+            slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
+            const int k = ix.k;
+            uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
+            uint64_t first = 0;
+            uint32_t nval = kKindFull << kKindShift;
+            push = true;
+            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
+                uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
+                uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
+                uint64_t size = hi - lo;
+                if (size == 0) {
+                    first = lo; nval = 0; push = false;
+                } else if (size <= kInlineBucket) {
+                    const int rem2 = cl - k;
+                    const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
+                    const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
+                    uint64_t key[kInlineBucket];
+#pragma unroll
+                    for (uint32_t j = 0; j < kInlineBucket; j++) key[j] = j < size ? ix.k2[lo + j] : ~0ULL;
+                    uint32_t lb = 0, ub = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kInlineBucket; j++) {
+                        int cm = k2_cmp(key[j], m, q2);
+                        lb += cm < 0;
+                        ub += cm <= 0;
+                    }
+                    first = lo + lb;
+                    uint32_t cnt = ub - lb;
+                    if (cnt == 0 || cl <= k + 16) { nval = cnt; push = false; }
+                    else if (lazy && cnt <= kLazyBucket) { nval = cnt | kLazyFlag; push = false; }
+                    else nval = cnt | (kKindDeep << kKindShift);
+                } else if (size < (1ULL << kKindShift)) {
+                    first = lo;
+                    nval = (uint32_t)size | (kKindK2 << kKindShift);
+                }
+            }
+            b.iv_first[slot] = first;
+            b.iv_n[slot] = nval;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(push);
+    uint32_t my_off = 0;
+    if (m) {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+        w = __builtin_amdgcn_readfirstlane(w);
+        my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(list_cnt, s_cnt);
+    __syncthreads();
+    if (push) list[s_base + my_off] = (uint32_t)slot;
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, DevBatch b, int phase, int lazy,
+                                                  const uint32_t *__restrict__ list, uint32_t n_list)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint64_t slot = list[i];
+    const uint32_t r = (uint32_t)(slot / (2 * kMaxCoresFast));
+    const int strand = (int)((slot / kMaxCoresFast) & 1), c = (int)(slot % kMaxCoresFast);
+    const int len = (int)b.lens[r];
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd;
+    phase_params(p, cfg, phase, mm, cl, cd);
+    const int my_ofs = c * cd < len - cl ? c * cd : len - cl;
+    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+    const uint32_t raw = b.iv_n[slot];
+    const uint32_t kind = raw >> kKindShift;
+    uint64_t first = b.iv_first[slot], cnt = raw & ((1u << kKindShift) - 1);
+    const int k = ix.k;
+    if (kind == kKindFull) {
+        search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, cnt);
+        b.iv_first[slot] = first;
+        b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+        return;
+    }
+    if (kind == kKindK2) {
+        const int rem2 = cl - k;
+        const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
+        const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
+        // lower and upper bound in lock step: two independent loads per round
+        uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
+        while (l1 < h1 || l2 < h2) {
+            const bool a1 = l1 < h1, a2 = l2 < h2;
+            const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+            const uint64_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
+            if (a1) { if (k2_cmp(v1, m, q2) < 0) l1 = m1 + 1; else h1 = m1; }
+            if (a2) { if (k2_cmp(v2, m, q2) <= 0) l2 = m2 + 1; else h2 = m2; }
+        }
+        first = l1;
+        cnt = l2 - l1;
+        if (cnt == 0 || cl <= k + 16) {
+            b.iv_first[slot] = first;
+            b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+            return;
+        }
+    }
+    // [first, first+cnt) agrees with the core on its first k+16 bases
+    if (lazy && cnt <= kLazyBucket) {
+        b.iv_first[slot] = first;
+        b.iv_n[slot] = (uint32_t)cnt | kLazyFlag;
+        return;
+    }
+    {
+        const int start = k + 16;
+        uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
+        while (l1 < h1 || l2 < h2) {
+            const bool a1 = l1 < h1, a2 = l2 < h2;
+            const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+            const uint64_t s1 = a1 ? sa_get<WIDE>(ix, m1) : 0, s2 = a2 ? sa_get<WIDE>(ix, m2) : 0;
+            const int c1 = a1 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s1) : 0;
+            const int c2 = a2 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s2) : 0;
+            if (a1) { if (c1 > 0) l1 = m1 + 1; else h1 = m1; }
+            if (a2) { if (c2 >= 0) l2 = m2 + 1; else h2 = m2; }
+        }
+        first = l1;
+        cnt = l2 - l1;
+    }
+    b.iv_first[slot] = first;
+    b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+}
 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
@@ -1210,12 +1473,20 @@ __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsig
     for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_t *__restrict__ out)
+__global__ void __launch_bounds__(256) k_max_len(const uint32_t *__restrict__ lens, uint32_t n, uint32_t *__restrict__ out)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t v = i < n ? lens[i] : 0;
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    uint32_t v = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = lens[i];
+        v = w > v ? w : v;
+    }
     for (int off = 32; off > 0; off >>= 1) { uint32_t w = __shfl_down(v, off); v = w > v ? w : v; }
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(&s_max, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(out, s_max);
 }
 
 // per-sequence counts of accepted reads (feeds the -O CSV and the cross-rank reduction): one pass over
@@ -1551,14 +1822,16 @@ void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, ui
 
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_max_len, dim3((n + 255) / 256), dim3(256), 0, s, lens, n, out);
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (n) hipLaunchKernelGGL(k_max_len, dim3(blocks), dim3(256), 0, s, lens, n, out);
 }
 
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
 {
     uint64_t words = (uint64_t)b.n_reads * 2 * b.wpr;
     hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_init_reads, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
+    hipLaunchKernelGGL(k_init_reads, dim3((b.n_reads + 1023) / 1024), dim3(1024), 0, s, cfg, b, act, act_cnt, cmax);
 }
 
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
@@ -1594,6 +1867,38 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
         uint32_t waves = n < 8192 ? n : 8192;
         hipLaunchKernelGGL(k_pe_orphan, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1);
     }
+}
+
+void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s)
+{
+    uint64_t blocks = (ix.n + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    DevIndex t = ix;
+    t.k2 = k2;
+    if (ix.sa_hi) {
+        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2);
+        hipLaunchKernelGGL(k_check_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad);
+    } else {
+        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2);
+        hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad);
+    }
+}
+
+void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s)
+{
+    uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(k_search_a, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
+}
+
+void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
+                     uint32_t n_list, hipStream_t s)
+{
+    if (!n_list) return;
+    unsigned blocks = (n_list + 255) / 256;
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search_b<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
+    else hipLaunchKernelGGL(k_search_b<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
 }
 
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s)

@@ -58,7 +58,9 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat"])
 @pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
-                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0)])
+                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0),
+                                  (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
+                                  (("use_k2", 0), ("lazy_search", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""
@@ -67,7 +69,8 @@ def test_paths_agree(golden_tmp, fixture, knob):
     with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
         ref = al.align(bases, offs[keep], lens[keep])
         c0 = al.counters(reset=True)
-        al.tune(*knob)
+        for kv in (knob if isinstance(knob[0], tuple) else (knob,)):
+            al.tune(*kv)
         got = al.align(bases, offs[keep], lens[keep])
         c1 = al.counters()
     assert_hits_equal(got, ref, [names[i] for i in keep])
