@@ -532,6 +532,7 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
         uint64_t fit = ((uint64_t)free_b + have) / 2 / per_read;
         if (fit < 65536) fit = 65536;
         if (fit < chunk) chunk = (uint32_t)fit;
+        if (chunk > (1u << 27)) chunk = 1u << 27;       // 32 interval slots per read are indexed with 32 bits
     }
     for (uint32_t done = 0; done < nreads;) {
         uint32_t n = std::min(chunk, nreads - done);

@@ -38,6 +38,13 @@ __device__ __forceinline__ uint64_t top_mask(int nibs)   // mask keeping the fir
     return nibs >= 16 ? ~0ULL : (~0ULL << (64 - 4 * nibs));
 }
 
+// core interval slot of (read, strand, core): [strand][core][read], so that lanes working on
+// neighbouring reads touch neighbouring words
+__device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t r, int st, int c)
+{
+    return (uint64_t)(st * kMaxCoresFast + c) * b.n_reads + r;
+}
+
 template <bool WIDE>
 __device__ __forceinline__ uint64_t sa_get(const DevIndex &ix, uint64_t i)
 {
@@ -434,7 +441,7 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     int strand = cfg.align_strand == 2 ? 1 : si;
     const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
     uint64_t first, count;
-    uint64_t slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
+    uint64_t slot = iv_slot(b, r, strand, c);
     if (lazy && ix.k > 0 && cl >= ix.k) {
         uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
         uint64_t lo, hi;
@@ -543,7 +550,7 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
             int my_ofs = c * cd < len - cl ? c * cd : len - cl;
             int strand = cfg.align_strand == 2 ? 1 : si;
             const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
-            slot = ((uint64_t)r * 2 + strand) * kMaxCoresFast + c;
+            slot = iv_slot(b, r, strand, c);
             const int k = ix.k;
             uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
             uint64_t first = 0;
@@ -605,8 +612,8 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_list) return;
     const uint64_t slot = list[i];
-    const uint32_t r = (uint32_t)(slot / (2 * kMaxCoresFast));
-    const int strand = (int)((slot / kMaxCoresFast) & 1), c = (int)(slot % kMaxCoresFast);
+    const uint32_t r = (uint32_t)(slot % b.n_reads), sc = (uint32_t)(slot / b.n_reads);
+    const int strand = (int)(sc / kMaxCoresFast), c = (int)(sc % kMaxCoresFast);
     const int len = (int)b.lens[r];
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd;
@@ -689,7 +696,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         if (!is_heavy)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if (b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if (b.iv_n[iv_slot(b, r, st, c)] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             heavy[atomicAdd(heavy_cnt, 1u)] = r;
         } else {
@@ -703,7 +710,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
                 const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
-                    uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + c;
+                    uint64_t slot = iv_slot(b, r, st, c);
                     uint32_t n = b.iv_n[slot];
                     uint64_t first = b.iv_first[slot];
                     for (uint32_t j = 0; j < n; j++) {
@@ -914,7 +921,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
         if (fits)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if ((b.iv_n[((uint64_t)r * 2 + st) * kMaxCoresFast + c] & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if ((b.iv_n[iv_slot(b, r, st, c)] & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
         } else {
@@ -929,7 +936,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
-                    uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + c;
+                    uint64_t slot = iv_slot(b, r, st, c);
                     const uint32_t nraw = b.iv_n[slot];
                     const uint32_t n = nraw & ~kLazyFlag;
                     const bool lazy = (nraw & kLazyFlag) != 0;
@@ -1102,7 +1109,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 #pragma unroll
             for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);      // same read for the whole wave
             if (lane < nc) {
-                uint64_t slot = ((uint64_t)r * 2 + st) * kMaxCoresFast + lane;
+                uint64_t slot = iv_slot(b, r, st, lane);
                 core[lane].first = b.iv_first[slot];
                 core[lane].n = b.iv_n[slot];          // bit 31: unverified bucket (<= kLazyBucket members)
                 core[lane].walked = 0;
