@@ -39,6 +39,9 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                   uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
                   uint32_t *cmax_next, int nw, hipStream_t s);
+void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+                 int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
+                 uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
                  uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
@@ -75,6 +78,7 @@ struct bk_ctx {
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
@@ -464,7 +468,10 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             tm.end(0, e1, s);
         }
         hipEvent_t e2 = tm.begin(s);
-        if (reg_path)
+        if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
+            launch_flat(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
+                        c->d_wave, sm + 6, sm + 3, nw16, s);
+        else if (reg_path)
             launch_light(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
                          sm + 3, nw16, s);
         else
@@ -705,6 +712,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
         return rc ? rc : old;
+    }
+    if (n == "use_flat") {
+        int64_t old = c->use_flat;
+        c->use_flat = value ? 1 : 0;
+        return old;
     }
     if (n == "use_k2") {
         int64_t old = c->use_k2;

@@ -1021,6 +1021,232 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_flat: the same contract as k_light, organised so that every lane does the same amount of work.
+// A block owns 256 consecutive active reads.  Their candidates (every suffix of every core interval,
+// in the reference's walk order strand -> core -> suffix) are numbered consecutively and EVALUATED
+// one per lane - suffix array load, window compare, one result byte in LDS (mismatch count, or
+// "skip": off the read's start / unverified bucket member that does not match / crosses an entry
+// boundary / already reached through an earlier core).  Then each read's lane replays its own bytes
+// sequentially through the Low/NxtLow/instances state machine, which needs no memory access.
+// In k_light a lane walked all candidates of its read itself, so a wave ran as long as its read with
+// the most candidates (up to 4 x 64) while the typical read has one or two.
+// Valid while no interval is longer than 100: then the reference's IterCnt==100 copy-count check and
+// MaxIter cannot trigger, every interval is walked to its end, and "already reached through an
+// earlier core" is exactly "that earlier core matches here" (see k_wave for the general case).
+
+constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
+constexpr uint8_t kRecSkip = 255;
+
+template <bool WIDE, int NW>
+__global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                              uint32_t n_act, int phase, int slots_max, uint32_t *__restrict__ next_act,
+                                              uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
+                                              uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
+                                              uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
+{
+    extern __shared__ uint16_t s_sp[];                  // [256][slots_max] running candidate count after each slot
+    __shared__ uint32_t s_off[257];                     // first candidate number of each read of the block
+    __shared__ uint32_t s_r[256];
+    __shared__ uint16_t s_len[256], s_cl[256], s_cd[256];
+    __shared__ uint8_t s_nc[256];
+    __shared__ uint8_t s_rec[kFlatCap];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
+    __shared__ unsigned long long s_ctr[3];
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    if (t < 4) s_cnt[t] = 0;
+    if (t == 4) s_cmax = 0;
+    if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
+
+    const uint32_t a = blockIdx.x * blockDim.x + t;
+    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel
+    uint32_t r = 0, my_cmax = 0, my_total = 0;
+    int len = 0, mm = 0, cl = 1, cd = 1, nc = 0, n_phases = 0;
+    bool mine = false;              // this lane's read is resolved here
+    if (a < n_act) {
+        r = act[a];
+        len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        n_phases = p.n_phases;
+        int dummy[1];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+        const bool fits = nc <= kMaxCoresFast && len <= 16 * NW && (s1 - s0 + 1) * nc <= slots_max;
+        bool is_heavy = !fits;
+        if (fits) {
+            uint32_t run = 0;
+            int q = 0;
+            for (int st = s0; st <= s1; st++)
+                for (int c = 0; c < nc; c++) {
+                    uint32_t cnt = b.iv_n[iv_slot(b, r, st, c)] & ~kLazyFlag;
+                    if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    run += is_heavy ? 0 : cnt;
+                    s_sp[t * slots_max + q++] = (uint16_t)run;
+                }
+            for (; q < slots_max; q++) s_sp[t * slots_max + q] = (uint16_t)run;
+            my_total = is_heavy ? 0 : run;
+        }
+        if (is_heavy) dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
+        else { mine = true; n_lcm = 1; }
+    }
+    s_r[t] = r; s_len[t] = (uint16_t)len; s_cl[t] = (uint16_t)cl; s_cd[t] = (uint16_t)cd; s_nc[t] = (uint8_t)nc;
+    // block-wide exclusive prefix sum of the candidate counts
+    {
+        uint32_t v = my_total;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t u = __shfl_up(v, off); if (lane >= off) v += u; }
+        if (lane == 63) s_wsum[wid] = v;
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < wid; w++) add += s_wsum[w];
+        s_off[t] = add + v - my_total;
+        if (t == 255) s_off[256] = add + v;
+    }
+    __syncthreads();
+
+    // replay state of this lane's read
+    const int init = mm + cfg.mm_delta + 1;
+    int low_inst = 0, low_mm = init, nxt = init;
+    int best_q = -1;
+    uint32_t best_j = 0;
+
+    for (uint32_t start = 0; start < 256;) {
+        // reads [start, end): as many as fit the result buffer (a single read never exceeds it)
+        const uint32_t base = s_off[start];
+        uint32_t lo = start + 1, hi = 256;
+        while (lo < hi) {                                   // largest end with s_off[end] - base <= kFlatCap
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] - base <= kFlatCap) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t end = lo;
+        const uint32_t total = s_off[end] - base;
+        for (uint32_t f = t; f < total; f += 256) {
+            const uint32_t g = base + f;
+            uint32_t l2 = start, h2 = end - 1;              // read ri: last one with s_off[ri] <= g
+            while (l2 < h2) {
+                uint32_t mid = (l2 + h2 + 1) >> 1;
+                if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
+            }
+            const uint32_t ri = l2;
+            const uint32_t local = g - s_off[ri];
+            const uint16_t *sp = s_sp + ri * slots_max;
+            int q = 0;
+            while (sp[q] <= local) q++;                      // slot holding candidate `local`
+            const uint32_t j = local - (q ? sp[q - 1] : 0);
+            const int c_nc = s_nc[ri], c_len = s_len[ri], c_cl = s_cl[ri], c_cd = s_cd[ri];
+            const int st = s0 + q / c_nc, c = q % c_nc;
+            const uint32_t cr = s_r[ri];
+            const uint64_t slot = iv_slot(b, cr, st, c);
+            const bool lazy = (b.iv_n[slot] & kLazyFlag) != 0;
+            const uint64_t loci = sa_get<WIDE>(ix, b.iv_first[slot] + j);
+            const int last = c_len - c_cl;
+            const int ofs = c * c_cd < last ? c * c_cd : last;
+            uint8_t rec = kRecSkip;
+            if (loci >= (uint64_t)ofs) {
+                uint64_t rw[NW];
+                load_read_words<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, rw);
+                Window<NW> w;
+                eval_window<NW>(rw, c_len, ix.tgt4, loci - (uint64_t)ofs, w);
+                bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
+                for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
+                if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
+            }
+            s_rec[f] = rec;
+        }
+        __syncthreads();
+        if (mine && t >= start && t < end) {
+            const uint16_t *sp = s_sp + t * slots_max;
+            const uint32_t rb = s_off[t] - base;
+            const int nslots = (s1 - s0 + 1) * nc;
+            bool done = false;
+            uint32_t prev = 0;
+            for (int q = 0; q < nslots && !done; q++) {
+                n_search++;
+                const uint32_t upto = sp[q];
+                for (uint32_t x = prev; x < upto; x++) {
+                    const int cm = s_rec[rb + x];
+                    if (cm == kRecSkip) continue;
+                    n_cand++;
+                    if (cm > mm || cm >= nxt) continue;
+                    if (cm < low_mm) {
+                        low_inst = 1; nxt = low_mm; low_mm = cm;
+                        best_q = q; best_j = x - prev;
+                    } else if (cm == low_mm)
+                        low_inst++;
+                    else
+                        nxt = cm;
+                    if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
+                }
+                prev = upto;
+            }
+        }
+        __syncthreads();
+        start = end;
+    }
+
+    if (mine) {
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+        if (rslt != BK_HR_NONE) {
+            uint64_t hit_left = 0;
+            int hit_strand = '?', e = -1;
+            if (low_inst >= 1) {
+                const int st = s0 + best_q / nc, c = best_q % nc;
+                const int last = len - cl;
+                const int ofs = c * cd < last ? c * cd : last;
+                hit_left = sa_get<WIDE>(ix, b.iv_first[iv_slot(b, r, st, c)] + best_j) - (uint64_t)ofs;
+                hit_strand = st ? '-' : '+';
+                e = find_entry(ix, hit_left);
+            }
+            write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
+        } else if (phase + 1 < n_phases) {
+            ReadPlan p = make_plan(len, cfg);
+            int mm2, cl2, cd2, dummy[1];
+            phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+            int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+            if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
+            dest = 1;
+        }
+    }
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_search += __shfl_down(n_search, off);
+        n_cand += __shfl_down(n_cand, off);
+        n_lcm += __shfl_down(n_lcm, off);
+        uint32_t m = __shfl_down(my_cmax, off);
+        my_cmax = m > my_cmax ? m : my_cmax;
+    }
+    uint32_t my_off = 0;
+#pragma unroll
+    for (int d = 1; d <= 3; d++) {
+        uint64_t m = __ballot(dest == d);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
+        }
+    }
+    if (lane == 0) {
+        if (my_cmax) atomicMax(&s_cmax, my_cmax);
+        if (n_search) atomicAdd(&s_ctr[0], n_search);
+        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
+    }
+    __syncthreads();
+    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
+    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
+    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
+    if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
+    if (t >= 8 && t < 11 && s_ctr[t - 8] && !(cfg.exp & 2)) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    __syncthreads();
+    if (dest == 1) next_act[s_base[1] + my_off] = r;
+    else if (dest == 2) wave[s_base[2] + my_off] = r;
+    else if (dest == 3) heavy[s_base[3] + my_off] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_wave: one wave per LocateCoreMultiples call for reads of <= 16*NW bases and <= 16 cores per
 // strand (4-byte suffix arrays).  64 candidates of a core interval per step; the reference's
 // SEQUENTIAL semantics are reproduced exactly with ballot prefix sums, as in k_heavy:
@@ -1925,6 +2151,20 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     if (nw <= 8) { if (wide) BK_LIGHT(true, 8); else BK_LIGHT(false, 8); }
     else { if (wide) BK_LIGHT(true, 16); else BK_LIGHT(false, 16); }
 #undef BK_LIGHT
+}
+
+void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+                 int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
+                 uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s)
+{
+    unsigned blocks = (n_act + 255) / 256;
+    bool wide = ix.sa_hi != nullptr;
+    if (slots_max < 1) slots_max = 1;
+    size_t lds = (size_t)256 * slots_max * sizeof(uint16_t);
+#define BK_FLAT(W, N) hipLaunchKernelGGL((k_flat<W, N>), dim3(blocks), dim3(256), lds, s, ix, cfg, b, act, n_act, phase, slots_max, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
+    if (nw <= 8) { if (wide) BK_FLAT(true, 8); else BK_FLAT(false, 8); }
+    else { if (wide) BK_FLAT(true, 16); else BK_FLAT(false, 16); }
+#undef BK_FLAT
 }
 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
