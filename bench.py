@@ -76,6 +76,28 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
             "n_search_per_read": octr.n_search / n1, "n_cand_per_read": octr.n_cand / n1}
 
 
+def profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB units,
+    calibrated in this path's access patterns - see profiles/README.md).  bench.py cannot collect
+    counters itself, so this is the last profiled value for the default workload, or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    members = {"k_search": ("k_search_a", "k_search_b"), "k_wave": ("k_wave",), "k_flat": ("k_flat",)}[kernel]
+    tot = 0.0
+    seen = set()
+    for r in csv.DictReader(open(files[-1])):
+        if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and r["kernel"].split("<")[0] in members:
+            tot += float(r["mean_per_dispatch"]) * 1024.0
+            seen.add((r["kernel"].split("<")[0], r["counter"]))
+    if len(seen) != 2 * len(members):
+        return None, None
+    return tot, os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,18 +222,22 @@ def main():
     per_search = log2n * (E + 8)
     per_cand = E + (args.read_len + 1) // 2
     io_bytes = args.reads * args.steps * ((args.read_len + 3) // 4 + 16)
+    # (k_search = passes k_search_a + k_search_b of one phase, timed together; k_flat = the block-cooperative
+    # extend kernel; k_wave = the wave-per-call kernel for repeat reads)
     kern = {
         "k_search": dict(bytes=ctr["n_search"] * per_search, ms=tim["ms_search"], launches=tim["n_search_launches"]),
         "k_wave": dict(bytes=ctr["n_cand_heavy"] * per_cand, ms=tim["ms_heavy"], launches=tim["n_heavy_launches"]),
-        "k_light": dict(bytes=(ctr["n_cand"] - ctr["n_cand_heavy"]) * per_cand, ms=tim["ms_extend"], launches=tim["n_extend_launches"]),
+        "k_flat": dict(bytes=(ctr["n_cand"] - ctr["n_cand_heavy"]) * per_cand, ms=tim["ms_extend"], launches=tim["n_extend_launches"]),
     }
     for k in kern.values():
         k["GBs"] = k["bytes"] / max(1e-9, k["ms"] * 1e-3) / 1e9
     dom = max(kern, key=lambda k: kern[k]["ms"])
     ach = kern[dom]["GBs"]
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
+    default_workload = (args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
+    traffic, traffic_src = profiled_traffic(dom) if default_workload else (None, None)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, kern[dom]["launches"]),
                 "avg_launch_ms": kern[dom]["ms"] / max(1, kern[dom]["launches"]),
                 "per_kernel": {k: {"algorithmic_GBs": round(v["GBs"], 1), "ms": round(v["ms"], 2), "launches": v["launches"]}

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <string>
 template <int ILP>
 __global__ void k_rand(const uint64_t *__restrict__ tab, uint64_t mask, uint64_t *out, int iters, int dependent)
 {
@@ -23,8 +24,47 @@ __global__ void k_rand(const uint64_t *__restrict__ tab, uint64_t mask, uint64_t
     }
     if (acc == 0x1234567) out[0] = acc;
 }
-int main()
+// calibration kernels for the FETCH_SIZE counter in OUR access patterns (MI355X_MICROARCH.md: the counter is
+// only calibrated for wide streaming reads): a known number of random 8-byte loads, and of random
+// 80-byte windows read as five 16-byte loads at a 16-byte aligned offset (eval_window's pattern for a
+// 100-base read).  Run under `rocprofv3 --pmc FETCH_SIZE` with the argument `calib`.
+__global__ void k_calib8(const uint64_t *__restrict__ tab, uint64_t mask, uint64_t *out, int iters)
 {
+    uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ULL, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        acc += tab[(x >> 20) & mask];
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void k_calib80(const uint4 *__restrict__ tab, uint64_t mask16, uint64_t *out, int iters)
+{
+    uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ULL, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        uint64_t i = (x >> 20) & mask16;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { uint4 v = tab[i + q]; acc += v.x + v.w; }
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+static int calib()
+{
+    uint64_t bytes = 16ULL << 30;
+    uint64_t *tab, *out;
+    hipMalloc(&tab, bytes + 256);
+    hipMalloc(&out, 8);
+    hipMemset(tab, 1, bytes + 256);
+    const int blocks = 8192, iters = 64;
+    hipLaunchKernelGGL(k_calib8, dim3(blocks), dim3(256), 0, 0, tab, bytes / 8 - 1, out, iters);
+    hipLaunchKernelGGL(k_calib80, dim3(blocks), dim3(256), 0, 0, (const uint4 *)tab, bytes / 16 - 1, out, iters);
+    hipDeviceSynchronize();
+    printf("calib: %llu accesses per kernel (k_calib8: 8 B each, k_calib80: 80 B each)\n", (unsigned long long)blocks * 256 * iters);
+    return 0;
+}
+int main(int argc, char **argv)
+{
+    if (argc > 1 && std::string(argv[1]) == "calib") return calib();
     uint64_t maxn = (16ULL << 30) / 8;
     uint64_t *tab, *out;
     hipMalloc(&tab, maxn * 8);
