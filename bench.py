@@ -34,7 +34,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, budget_s):
+def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, budget_s, ref_reads=0, cli_device=0):
     """Times the CPU oracle (restatement of the reference path, pthreads on every host core) on a
     bounded sample of the same workload; also checks the GPU results of that sample against it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -69,11 +69,166 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
               "nxt_low_mm", "num_hits", "mismatches"):
         nbad += int((got[f] != exp[f]).sum())
     ora.close()
-    return {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+    port = {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": f"first {n1} reads of the rank-0 batch, oracle/bk_oracle.c ora_align_batch with {cores} pthreads, "
                       f"{dt:.1f} s wall; index already in host RAM",
             "parity_mismatching_fields_vs_gpu": nbad,
             "n_search_per_read": octr.n_search / n1, "n_cand_per_read": octr.n_cand / n1}
+    if ref_reads <= 0:
+        return port
+    # the real reference on the same box, when its binary travelled with the repo
+    ref = None
+    named = [(f"chr{eid}", slen) for (eid, slen, _so, _eo) in entries]
+    for n_ref in dict.fromkeys((int(min(n_avail, ref_reads)), int(min(n_avail, ref_reads, 1_000_000)))):
+        try:
+            ref = reference_baseline(seq, sa, named, reads_t[: n_ref * read_len].cpu().numpy(), read_len,
+                                     params_kw.get("max_subs", 3), gpu_hits, n_ref, cli_device)
+        except Exception as e:
+            log(f"cpu_baseline(reference) failed: {e!r}")
+            ref = None
+        if ref and "exited with" not in str(ref.get("sample")):
+            break
+    if not ref or ref.get("value") is None:
+        port["reference_leg"] = ref
+        return port
+    ref["port"] = port
+    return ref
+
+
+REF_LADDER = (0, 32, 8)        # -T values tried in turn by the reference leg
+
+
+def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits, n_sample, cli_device):
+    """Times the REAL reference (oracle/_ref/biokanga, built from /root/reference by oracle/build_ref.sh and
+    shipped as a binary) on the box's host cores on the first `n_sample` reads of the rank-0 batch against
+    the same index, written out as a `.sfx`; checks its SAM records against the GPU results of the timed
+    steps; then runs our own command line on the same two files and compares the SAM files byte for byte.
+    Returns None when the reference binary is not present."""
+    import datetime
+    import re
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import numpy as np
+    import helpers
+    import biokanga_amd as bk
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "biokanga")
+    our_bin = os.path.join(ROOT, "biokanga_amd", "bin", "biokanga")
+    if not os.path.exists(ref_bin):
+        return None
+    n = len(seq)
+    need = 5 * n + 200 * n_sample + (1 << 28)
+    base = "/dev/shm" if shutil.disk_usage("/dev/shm").free > 2 * need else None
+    tmp = tempfile.mkdtemp(prefix="bk_ref_", dir=base)
+    try:
+        t0 = time.time()
+        sfx, fa = os.path.join(tmp, "genome.sfx"), os.path.join(tmp, "reads.fa")
+        # .sfx: header 1224 B pack(4), block header 20 B + bases + 4-byte suffix array, entries 8 + 111 B each
+        hdr = bytearray(1224)
+        hdr[0:4] = b"sfx5"
+        struct.pack_into("<iI", hdr, 4, 5, 0)
+        blk_size = 20 + n + n * 4
+        ent_size = 8 + 111 * len(entries)
+        struct.pack_into("<QQIIQQ", hdr, 12, 1224 + blk_size + ent_size, 1224 + blk_size, ent_size, 1, blk_size, 1224)
+        hdr[52:57] = b"synth"
+        with open(sfx, "wb") as f:
+            f.write(hdr)
+            f.write(struct.pack("<IIQI", 1, len(entries), n, 4))
+            f.write(memoryview(np.ascontiguousarray(seq, dtype=np.uint8)))
+            f.write(memoryview(np.ascontiguousarray(sa, dtype="<u4")))
+            f.write(struct.pack("<II", len(entries), len(entries)))
+            ofs = 0
+            for i, (name, slen) in enumerate(entries):
+                nm = name.encode()[:80]
+                f.write(struct.pack("<II", i + 1, 1) + nm + b"\0" * (81 - len(nm)) +
+                        struct.pack("<HIQQ", helpers.gen_hash16(name), slen, ofs, ofs + slen - 1))
+                ofs += slen + 1
+        # FASTA of the sample: >r000000001\n<bases>\n
+        rec = np.empty((n_sample, 12 + read_len + 1), dtype=np.uint8)
+        rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 11] = 10; rec[:, -1] = 10
+        idx = np.arange(1, n_sample + 1, dtype=np.int64)
+        for d in range(9):
+            rec[:, 10 - d] = 48 + (idx // 10 ** d) % 10
+        lut = np.frombuffer(b"ACGTNNNN", dtype=np.uint8)
+        rec[:, 12:12 + read_len] = lut[reads_np[: n_sample * read_len].reshape(n_sample, read_len) & 7]
+        with open(fa, "wb") as f:
+            f.write(memoryview(rec))
+        del rec
+        t_files = time.time() - t0
+
+        def run(binary, out, logf, extra):
+            t = time.time()
+            r = subprocess.run([binary, "align", "-i", fa, "-I", sfx, "-o", out, f"-s{max_subs}", "-M6", "-F", logf] + extra,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, timeout=1500)
+            return r.returncode, time.time() - t
+
+        ref_sam, ref_log = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "ref.log")
+
+        def t_align_of(logf):
+            # "Now aligning with minimum core size" -> "Alignment of N from N loaded completed".  The worker
+            # threads start right after the first line and the main thread then sleeps a fixed 5 s
+            # (Aligner.cpp:8794-8799) before joining them, so the span is the alignment time only when it
+            # exceeds that sleep.
+            stamp = {}
+            for line in open(logf, errors="replace"):
+                m = re.match(r"\[(\w+\s+\d+ \d+:\d+:\d+\.\d+ \d+)\]", line)
+                if not m:
+                    continue
+                ts = datetime.datetime.strptime(re.sub(r"\s+", " ", m.group(1)), "%b %d %H:%M:%S.%f %Y").timestamp()
+                if "Now aligning with minimum core size" in line:
+                    stamp["start"] = ts
+                elif "Alignment of" in line and "completed" in line:
+                    stamp["end"] = ts
+            return stamp["end"] - stamp["start"]
+
+        # -T0 = every core up to cMaxWorkerThreads 128 (Aligner.h:15).  The sample cannot grow beyond ~1 M reads
+        # (the reference's loader hand-off breaks when loading takes > 3 s, Aligner.cpp:4822), so when all
+        # cores finish it inside the 5 s sleep the run is repeated with fewer threads until it is measurable.
+        tried = []
+        t_align = ref_wall = None
+        threads = None
+        for T in REF_LADDER:
+            rc, wall = run(ref_bin, ref_sam, ref_log, [f"-T{T}"])
+            if rc != 0:
+                return {"value": None, "unit": "reads/s", "kind": "reference", "sample": f"reference exited with {rc} at -T{T}"}
+            ta = t_align_of(ref_log)
+            nthr = min(os.cpu_count() or 1, 128) if T == 0 else T
+            tried.append(f"-T{T} ({nthr} threads): {ta:.2f} s")
+            t_align, ref_wall, threads = ta, wall, nthr
+            if ta > 6.0:
+                break
+        # reference SAM records vs the GPU hits of the same reads
+        names = {i + 1: nm for i, (nm, _) in enumerate(entries)}
+        got = gpu_hits[:n_sample]
+        bad = seen = 0
+        for line in open(ref_sam):
+            if line[0] == "@":
+                continue
+            fld = line.rstrip("\n").split("\t")
+            i = int(fld[0][1:]) - 1
+            h = got[i]
+            seen += 1
+            if h["nar"] == 1:
+                exp = (16 if h["strand"] == ord("-") else 0, names[int(h["chrom_id"])], int(h["match_loci"]) + 1)
+                bad += (int(fld[1]), fld[2], int(fld[3])) != exp
+            else:
+                bad += not (fld[1] == "4" and fld[2] == "*" and fld[-1] == "YU:Z:" + bk.NAR_TAGS[int(h["nar"])])
+        bad += abs(seen - n_sample)
+        res = {"value": n_sample / t_align if t_align > 6.0 else None, "unit": "reads/s", "cores": threads, "kind": "reference",
+               "sample": f"oracle/_ref/biokanga align -s{max_subs} -M6 on the first {n_sample} reads of the rank-0 batch vs the same "
+                         f"{n / 1e9:.2f} Gbp index written as .sfx; T_align = log 'Now aligning' -> 'Alignment of .. completed' "
+                         f"(valid above the reference's fixed 5 s start-up sleep); runs: {'; '.join(tried)}; whole process {ref_wall:.1f} s",
+               "t_align_s": t_align, "t_e2e_s": ref_wall, "sam_records_differing_from_gpu": int(bad)}
+        if os.path.exists(our_bin) and cli_device is not None:
+            our_sam, our_log = os.path.join(tmp, "our.sam"), os.path.join(tmp, "our.log")
+            rc, our_wall = run(our_bin, our_sam, our_log, ["--device", str(cli_device)])
+            same = rc == 0 and subprocess.run(["cmp", "-s", ref_sam, our_sam]).returncode == 0
+            res["our_cli"] = {"t_e2e_s": our_wall, "rc": rc, "sam_byte_identical_to_reference": bool(same)}
+        log(f"cpu_baseline(reference): files {t_files:.1f}s, reference {ref_wall:.1f}s (T_align {t_align:.2f}s)")
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def profiled_traffic(kernel):
@@ -108,6 +263,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--max-subs", type=int, default=3, help="`-s` of biokanga align")
     ap.add_argument("--cpu-baseline-secs", type=float, default=15.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--reference-reads", type=int, default=2_000_000,
+                    help="reads given to the real reference binary (oracle/_ref/biokanga) in the cpu_baseline leg; 0 = port only. "
+                         "Kept at 2 M: the reference's loader hand-off breaks when loading takes > 3 s (Aligner.cpp:4822) - "
+                         "3 M reads crash it on the MI355X host about every other run (tools/ref_scaling.py)")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
     ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
@@ -264,7 +423,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_baseline_secs > 0:
         try:
             result["cpu_baseline"] = cpu_baseline(seq, sa, entries, rd_bases, args.read_len, params_kw, hits,
-                                                  args.cpu_baseline_secs)
+                                                  args.cpu_baseline_secs, args.reference_reads, local_rank)
         except Exception as e:      # the baseline is reporting only - never lose the measured line
             result["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "port",
                                       "sample": f"failed: {e!r}"}
