@@ -95,6 +95,51 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
     return ref
 
 
+def write_sfx_file(path, seq, sa, entries):
+    """`.sfx` as the reference writes it: header 1224 B pack(4), block header 20 B + bases + 4-byte suffix
+    array, entries 8 + 111 B each (SfxArrayV2.h:79-104,174-187).  entries: [(name, seq_len)]."""
+    import struct
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    n = len(seq)
+    hdr = bytearray(1224)
+    hdr[0:4] = b"sfx5"
+    struct.pack_into("<iI", hdr, 4, 5, 0)
+    blk_size = 20 + n + n * 4
+    ent_size = 8 + 111 * len(entries)
+    struct.pack_into("<QQIIQQ", hdr, 12, 1224 + blk_size + ent_size, 1224 + blk_size, ent_size, 1, blk_size, 1224)
+    hdr[52:57] = b"synth"
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(struct.pack("<IIQI", 1, len(entries), n, 4))
+        f.write(memoryview(np.ascontiguousarray(seq, dtype=np.uint8)))
+        f.write(memoryview(np.ascontiguousarray(sa, dtype="<u4")))
+        f.write(struct.pack("<II", len(entries), len(entries)))
+        ofs = 0
+        for i, (name, slen) in enumerate(entries):
+            nm = name.encode()[:80]
+            f.write(struct.pack("<II", i + 1, 1) + nm + b"\0" * (81 - len(nm)) +
+                    struct.pack("<HIQQ", helpers.gen_hash16(name), slen, ofs, ofs + slen - 1))
+            ofs += slen + 1
+
+
+def write_fasta_file(path, reads_np, n_reads, read_len, chunk=4_000_000):
+    """>r000000001\n<bases>\n per read (fixed-width names so the whole file is one array)."""
+    import numpy as np
+    lut = np.frombuffer(b"ACGTNNNN", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for lo in range(0, n_reads, chunk):
+            m = min(chunk, n_reads - lo)
+            rec = np.empty((m, 12 + read_len + 1), dtype=np.uint8)
+            rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 11] = 10; rec[:, -1] = 10
+            idx = np.arange(lo + 1, lo + m + 1, dtype=np.int64)
+            for d in range(9):
+                rec[:, 10 - d] = 48 + (idx // 10 ** d) % 10
+            rec[:, 12:12 + read_len] = lut[reads_np[lo * read_len: (lo + m) * read_len].reshape(m, read_len) & 7]
+            f.write(memoryview(rec))
+
+
 REF_LADDER = (0, 32, 8)        # -T values tried in turn by the reference leg
 
 
@@ -124,37 +169,8 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
     try:
         t0 = time.time()
         sfx, fa = os.path.join(tmp, "genome.sfx"), os.path.join(tmp, "reads.fa")
-        # .sfx: header 1224 B pack(4), block header 20 B + bases + 4-byte suffix array, entries 8 + 111 B each
-        hdr = bytearray(1224)
-        hdr[0:4] = b"sfx5"
-        struct.pack_into("<iI", hdr, 4, 5, 0)
-        blk_size = 20 + n + n * 4
-        ent_size = 8 + 111 * len(entries)
-        struct.pack_into("<QQIIQQ", hdr, 12, 1224 + blk_size + ent_size, 1224 + blk_size, ent_size, 1, blk_size, 1224)
-        hdr[52:57] = b"synth"
-        with open(sfx, "wb") as f:
-            f.write(hdr)
-            f.write(struct.pack("<IIQI", 1, len(entries), n, 4))
-            f.write(memoryview(np.ascontiguousarray(seq, dtype=np.uint8)))
-            f.write(memoryview(np.ascontiguousarray(sa, dtype="<u4")))
-            f.write(struct.pack("<II", len(entries), len(entries)))
-            ofs = 0
-            for i, (name, slen) in enumerate(entries):
-                nm = name.encode()[:80]
-                f.write(struct.pack("<II", i + 1, 1) + nm + b"\0" * (81 - len(nm)) +
-                        struct.pack("<HIQQ", helpers.gen_hash16(name), slen, ofs, ofs + slen - 1))
-                ofs += slen + 1
-        # FASTA of the sample: >r000000001\n<bases>\n
-        rec = np.empty((n_sample, 12 + read_len + 1), dtype=np.uint8)
-        rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 11] = 10; rec[:, -1] = 10
-        idx = np.arange(1, n_sample + 1, dtype=np.int64)
-        for d in range(9):
-            rec[:, 10 - d] = 48 + (idx // 10 ** d) % 10
-        lut = np.frombuffer(b"ACGTNNNN", dtype=np.uint8)
-        rec[:, 12:12 + read_len] = lut[reads_np[: n_sample * read_len].reshape(n_sample, read_len) & 7]
-        with open(fa, "wb") as f:
-            f.write(memoryview(rec))
-        del rec
+        write_sfx_file(sfx, seq, sa, entries)
+        write_fasta_file(fa, reads_np, n_sample, read_len)
         t_files = time.time() - t0
 
         def run(binary, out, logf, extra):

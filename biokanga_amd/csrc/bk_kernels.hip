@@ -308,13 +308,16 @@ __device__ __forceinline__ uint64_t complement8(uint64_t x)       // A<->T, C<->
 
 __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
 {
+    // a block packs 256 / (2 * wpr) whole reads: 32-bit index arithmetic only
     const uint32_t wpr = b.wpr;
-    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t per_read = 2ULL * wpr;
-    uint64_t r = tid / per_read;
+    const uint32_t per_read = 2 * wpr;                      // <= 256 (kMaxReadLenAbs)
+    const uint32_t rpb = 256 / per_read;
+    const uint32_t lr = threadIdx.x / per_read;
+    if (lr >= rpb) return;
+    const uint64_t r = (uint64_t)blockIdx.x * rpb + lr;
     if (r >= b.n_reads) return;
-    uint32_t rem = (uint32_t)(tid - r * per_read);
-    uint32_t st = rem / wpr, w = rem - st * wpr;
+    const uint32_t rem = threadIdx.x - lr * per_read;
+    const uint32_t st = rem >= wpr ? 1 : 0, w = rem - st * wpr;
     int len = (int)b.lens[r];
     const uint8_t *s = b.bases + b.offs[r];
     uint64_t v = 0;
@@ -2062,8 +2065,8 @@ void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t
 
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
 {
-    uint64_t words = (uint64_t)b.n_reads * 2 * b.wpr;
-    hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, b);
+    const uint32_t rpb = 256 / (2 * b.wpr);
+    hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_init_reads, dim3((b.n_reads + 1023) / 1024), dim3(1024), 0, s, cfg, b, act, act_cnt, cmax);
 }
 
@@ -2090,8 +2093,8 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
                uint32_t *h_count, hipStream_t s)
 {
     DevPE pe{pe_mode, min_len, max_len, pair_strand};
-    uint64_t words = (uint64_t)b.n_reads * 2 * b.wpr;
-    hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, b);
+    const uint32_t rpb = 256 / (2 * b.wpr);
+    hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters);
     (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);

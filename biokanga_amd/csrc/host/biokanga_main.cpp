@@ -24,6 +24,7 @@
 #include <ctime>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/biokanga_amd.h"
@@ -240,24 +241,25 @@ struct ReadStore {
 };
 
 // CAligner::LoadRawReads (Aligner.cpp:10724-11427): descriptor rule, -y/-Y trims, -l/-L acceptance
-int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, ReadStore &rs)
+int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, int nthreads, ReadStore &rs)
 {
     for (const std::string &fn : files) {
-        bk::SeqReader rd;
+        bk::RecordStream rd;
         std::string err;
-        int rc = rd.open(fn, &err);
+        int rc = rd.open(fn, nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading reads from '%s'", fn.c_str());
-        std::string d;
-        std::vector<uint8_t> b;
+        const char *d;
+        const uint8_t *b;
+        size_t dl, bl;
         bool sim = false;
         uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
-        while ((rc = rd.next(d, b)) > 0) {
+        while ((rc = rd.next(d, dl, b, bl)) > 0) {
             n_descr++;
-            if (d.size() > 127) d.resize(127);                            // cMaxDescrLen-1
-            if (n_descr == 1) sim = !strncmp(d.c_str(), "lcl|usimreads|", 14) || !strncmp(d.c_str(), "lcr|usimreads|", 14);
-            int len = (int)b.size();
-            if (len < 1 || len > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
+            if (dl > 127) dl = 127;                                       // cMaxDescrLen-1
+            if (n_descr == 1) sim = dl >= 14 && (!strncmp(d, "lcl|usimreads|", 14) || !strncmp(d, "lcr|usimreads|", 14));
+            int len = (int)bl;
+            if (bl < 1 || bl > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
             if (trim5 + trim3 + min_len > len) {
                 if (++n_under <= 10) diag("Load: under length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str());
                 continue;
@@ -268,15 +270,15 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
             }
             if (!sim) {                                                   // cut at first whitespace, < cMaxDescrIDLen
                 size_t k = 0;
-                while (k < 79 && k < d.size() && !isspace((unsigned char)d[k])) k++;
-                d.resize(k);
+                while (k < 79 && k < dl && !isspace((unsigned char)d[k])) k++;
+                dl = k;
             }
             int keep = len - trim5 - trim3;
             rs.offs.push_back(rs.bases.size());
             rs.lens.push_back((uint32_t)keep);
-            rs.bases.insert(rs.bases.end(), b.begin() + trim5, b.begin() + trim5 + keep);
+            rs.bases.insert(rs.bases.end(), b + trim5, b + trim5 + keep);
             rs.name_ofs.push_back(rs.names.size());
-            rs.names.insert(rs.names.end(), d.begin(), d.end());
+            rs.names.insert(rs.names.end(), d, d + dl);
             rs.names.push_back('\0');
             n_acc++;
         }
@@ -289,36 +291,36 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
 // paired end loading: PE1/PE2 records in lockstep, both ends must pass the length acceptance
 // (Aligner.cpp:11080-11130); stored interleaved PE1, PE2
 int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::string> &f2, int trim5, int trim3, int min_len, int max_len,
-                  ReadStore &rs)
+                  int nthreads, ReadStore &rs)
 {
     for (size_t k = 0; k < f1.size(); k++) {
-        bk::SeqReader r1, r2;
+        bk::RecordStream rd[2];
         std::string err;
-        int rc = r1.open(f1[k], &err);
+        int rc = rd[0].open(f1[k], nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
-        rc = r2.open(f2[k], &err);
+        rc = rd[1].open(f2[k], nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading paired end reads from '%s' and '%s'", f1[k].c_str(), f2[k].c_str());
-        std::string d[2];
-        std::vector<uint8_t> b[2];
+        const char *d[2];
+        const uint8_t *b[2];
+        size_t dl[2], bl[2];
         bool sim[2] = {false, false};
         uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
         for (;;) {
-            int rc1 = r1.next(d[0], b[0]);
+            int rc1 = rd[0].next(d[0], dl[0], b[0], bl[0]);
             if (rc1 < 0) { diag("Load: errors whilst parsing '%s'", f1[k].c_str()); return rc1; }
             if (rc1 == 0) break;
-            int rc2 = r2.next(d[1], b[1]);
+            int rc2 = rd[1].next(d[1], dl[1], b[1], bl[1]);
             if (rc2 <= 0) { diag("Load: '%s' has fewer reads than '%s'", f2[k].c_str(), f1[k].c_str()); return -63; }
             n_descr++;
             bool skip = false;
             for (int e = 0; e < 2; e++) {
-                if (d[e].size() > 127) d[e].resize(127);
-                if (n_descr == 1) sim[e] = !strncmp(d[e].c_str(), "lcl|usimreads|", 14) || !strncmp(d[e].c_str(), "lcr|usimreads|", 14);
-                int len = (int)b[e].size();
-                if (len < 1 || len > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
+                if (dl[e] > 127) dl[e] = 127;
+                if (n_descr == 1) sim[e] = dl[e] >= 14 && (!strncmp(d[e], "lcl|usimreads|", 14) || !strncmp(d[e], "lcr|usimreads|", 14));
+                if (bl[e] < 1 || bl[e] > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
             }
             for (int e = 0; e < 2 && !skip; e++) {
-                int len = (int)b[e].size();
+                int len = (int)bl[e];
                 if (trim5 + trim3 + min_len > len) { n_under++; skip = true; }
                 else if (trim5 + trim3 + max_len < len) { n_over++; skip = true; }
             }
@@ -326,15 +328,15 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
             for (int e = 0; e < 2; e++) {
                 if (!sim[e]) {
                     size_t q = 0;
-                    while (q < 79 && q < d[e].size() && !isspace((unsigned char)d[e][q])) q++;
-                    d[e].resize(q);
+                    while (q < 79 && q < dl[e] && !isspace((unsigned char)d[e][q])) q++;
+                    dl[e] = q;
                 }
-                int keep = (int)b[e].size() - trim5 - trim3;
+                int keep = (int)bl[e] - trim5 - trim3;
                 rs.offs.push_back(rs.bases.size());
                 rs.lens.push_back((uint32_t)keep);
-                rs.bases.insert(rs.bases.end(), b[e].begin() + trim5, b[e].begin() + trim5 + keep);
+                rs.bases.insert(rs.bases.end(), b[e] + trim5, b[e] + trim5 + keep);
                 rs.name_ofs.push_back(rs.names.size());
-                rs.names.insert(rs.names.end(), d[e].begin(), d[e].end());
+                rs.names.insert(rs.names.end(), d[e], d[e] + dl[e]);
                 rs.names.push_back('\0');
             }
             n_acc++;
@@ -407,6 +409,11 @@ int cmd_align(int argc, char **argv, int first)
     int min_len = a.num("l", 50), max_len = a.num("L", 500);
     int trim5 = a.num("y", 0), trim3 = a.num("Y", 0);
     int max_rpt_sam_seqs = a.num("4", 10000);
+    // -T: host threads for parsing, sorting and formatting (0 = all cores, capped like the reference's cMaxWorkerThreads)
+    int nthreads = a.num("T", 0);
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 128) nthreads = 128;
     if (P.pmode < 0 || P.pmode > 3 || P.align_strand < 0 || P.align_strand > 2 || P.min_edit_dist < 1 || P.min_edit_dist > 2 ||
         P.max_subs < 0 || P.max_subs > 25 || P.max_ns < 0 || P.max_ns > 5 || min_len < 15 || min_len > 2000 || max_len < min_len ||
         max_len > 2000 || (fmt != 0 && fmt != 5 && fmt != 6)) {
@@ -426,8 +433,8 @@ int cmd_align(int argc, char **argv, int first)
     diag("Genome assembly suffix array loaded");
 
     ReadStore rs;
-    if (pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], trim5, trim3, min_len, max_len, rs);
-    else rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, rs);
+    if (pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], trim5, trim3, min_len, max_len, nthreads, rs);
+    else rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, nthreads, rs);
     if (rc) { bk_ctx_destroy(ctx); return 1; }
     size_t nr = rs.size();
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
@@ -480,7 +487,7 @@ int cmd_align(int argc, char **argv, int first)
         if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
         return 0;
     };
-    bk::ref_order_sort(order.data(), (int64_t)nr, cmp);
+    bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
 
     OutBuf out;
     out.open(a.str("o").c_str());
@@ -506,17 +513,24 @@ int cmd_align(int argc, char **argv, int first)
         diag("Header written with references to %d sequences of which %d have at least 1 alignments", n_hdr, n_with);
         static const char comp[8] = {'T', 'G', 'C', 'A', 'N', 'N', 'N', 'N'};
         static const char fwd[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
-        std::string rec;
-        for (size_t k = 0; k < nr; k++) {
+        auto put_num = [](std::string &r, long v) {
+            char t[24];
+            int n = 0;
+            bool neg = v < 0;
+            unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
+            do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+            if (neg) r.push_back('-');
+            while (n) r.push_back(t[--n]);
+        };
+        // one record (CAligner::ReportBAMread, Aligner.cpp:5850-5924,6036-6054); false when the read is not reported
+        auto format_rec = [&](size_t k, std::string &rec) -> bool {
             uint32_t i = order[k];
             const bk_hit &h = hits[i];
             bool acc = h.nar == BK_NAR_ACCEPTED;
-            if (!acc && fmt != 6) continue;
+            if (!acc && fmt != 6) return false;
             const uint8_t *s = rs.bases.data() + rs.offs[i];
             uint32_t len = rs.lens[i];
-            rec.clear();
             rec += rs.name(i);
-            // FLAG / RNEXT / PNEXT / TLEN: CAligner::ReportBAMread, Aligner.cpp:5850-5924,6036-6054
             int flag = 0, tlen = 0;
             long pnext = -1;
             if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
@@ -535,23 +549,60 @@ int cmd_align(int argc, char **argv, int first)
                 } else
                     flag |= 0x8;
             }
+            rec.push_back('\t');
+            put_num(rec, flag);
             if (acc) {
-                int m = snprintf(line, sizeof(line), "\t%d\t%s\t%u\t255\t%uM\t%c\t%ld\t%d\t", flag, ents[h.chrom_id - 1].name, h.match_loci + 1,
-                                 (unsigned)h.match_len, pnext < 0 ? '*' : '=', pnext < 0 ? 0L : pnext + 1, tlen);
-                rec.append(line, (size_t)m);
-                if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
-                else for (uint32_t q = 0; q < len; q++) rec.push_back(comp[s[len - 1 - q] & 7]);
+                rec.push_back('\t');
+                rec += ents[h.chrom_id - 1].name;
+                rec.push_back('\t');
+                put_num(rec, (long)h.match_loci + 1);
+                rec += "\t255\t";
+                put_num(rec, h.match_len);
+                rec += "M\t";
+                rec.push_back(pnext < 0 ? '*' : '=');
+                rec.push_back('\t');
+                put_num(rec, pnext < 0 ? 0L : pnext + 1);
+                rec.push_back('\t');
+                put_num(rec, tlen);
+                rec.push_back('\t');
+                size_t o = rec.size();
+                rec.resize(o + len);
+                if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
+                else for (uint32_t q = 0; q < len; q++) rec[o + q] = comp[s[len - 1 - q] & 7];
                 rec += "\t*\n";
             } else {
-                int m = snprintf(line, sizeof(line), "\t%d\t*\t0\t255\t%uM\t*\t0\t0\t", flag, len);
-                rec.append(line, (size_t)m);
-                for (uint32_t q = 0; q < len; q++) rec.push_back(fwd[s[q] & 7]);
-                rec += "\t*\t\tYU:Z:";                                   // the doubled TAB is what the reference writes
+                rec += "\t*\t0\t255\t";
+                put_num(rec, len);
+                rec += "M\t*\t0\t0\t";
+                size_t o = rec.size();
+                rec.resize(o + len);
+                for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
+                rec += "\t*\t\tYU:Z:";                                 // the doubled TAB is what the reference writes
                 rec += kNarTag[h.nar < 20 ? h.nar : 0];
                 rec.push_back('\n');
             }
-            out.put(rec);
-            n_reported++;
+            return true;
+        };
+        // records are formatted by all host threads into per-thread buffers, one stripe of the sorted order
+        // each, and written out in order (the reference formats serially, ~4.5 us per read)
+        const size_t per_thread = 32768;
+        const int nt = (int)std::min<size_t>((size_t)nthreads, (nr + per_thread - 1) / per_thread ? (nr + per_thread - 1) / per_thread : 1);
+        std::vector<std::string> bufs((size_t)nt);
+        std::vector<uint64_t> cnts((size_t)nt);
+        for (size_t k0 = 0; k0 < nr; k0 += per_thread * (size_t)nt) {
+            auto work = [&](int t) {
+                size_t lo = k0 + (size_t)t * per_thread, hi = std::min(nr, lo + per_thread);
+                std::string &buf = bufs[(size_t)t];
+                buf.clear();
+                uint64_t c = 0;
+                for (size_t k = lo; k < hi; k++) c += format_rec(k, buf) ? 1 : 0;
+                cnts[(size_t)t] = c;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &t : th) t.join();
+            for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t]); n_reported += cnts[(size_t)t]; }
         }
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {

@@ -1,8 +1,14 @@
 // fasta.cpp - see fasta.h
 #include "fasta.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cctype>
 #include <cstring>
+#include <thread>
 
 namespace bk {
 
@@ -111,6 +117,121 @@ int SeqReader::next(std::string &descr, std::vector<uint8_t> &bases)
         if (c == '>') { ungetc_(); break; }
         if (isalpha(c) || c == '-') bases.push_back(a2s((uint8_t)c));
     }
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// same state machine as SeqReader::next (FASTA branch) over [p, e); e is a record start or the file end
+void parse_range(const uint8_t *p, const uint8_t *e, ParsedChunk &out)
+{
+    size_t approx = (size_t)(e - p);
+    out.bases.reserve(approx);
+    out.descr.reserve(approx / 8 + 64);
+    while (p < e) {
+        while (p < e && *p != '>') p++;               // skip to the next descriptor
+        if (p >= e) break;
+        p++;
+        size_t d0 = out.descr.size();
+        while (p < e && *p != '\n' && *p != '\r') {
+            uint8_t c = *p++;
+            out.descr.push_back(c > 0x7f ? '?' : (char)c);
+        }
+        out.descr_lens.push_back((uint32_t)(out.descr.size() - d0));
+        size_t b0 = out.bases.size();
+        while (p < e && *p != '>') {
+            uint8_t c = *p++;
+            if (isalpha(c) || c == '-') out.bases.push_back(a2s(c));
+        }
+        out.lens.push_back((uint32_t)(out.bases.size() - b0));
+    }
+}
+
+// first record start at or after q: a '>' with no other '>' between it and the preceding line break
+// (a '>' inside a descriptor line is part of the descriptor)
+const uint8_t *next_record_start(const uint8_t *base, const uint8_t *q, const uint8_t *end)
+{
+    while (q < end) {
+        while (q < end && *q != '>') q++;
+        if (q >= end) return end;
+        const uint8_t *r = q;
+        bool inside = false;
+        while (r > base) {
+            --r;
+            if (*r == '\n' || *r == '\r') break;
+            if (*r == '>') { inside = true; break; }
+        }
+        if (!inside) return q;
+        q++;
+    }
+    return end;
+}
+
+}  // namespace
+
+int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<ParsedChunk> &out, std::string *err)
+{
+    out.clear();
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) {
+        if (err) *err = "unable to open '" + path + "'";
+        return -90;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < (1 << 20)) { ::close(fd); return 0; }
+    size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return 0;
+    const uint8_t *base = (const uint8_t *)m, *end = base + size;
+    const uint8_t *p = base;
+    while (p < end && isspace(*p)) p++;
+    if ((base[0] == 0x1f && base[1] == 0x8b) || p >= end || *p != '>') { munmap(m, size); return 0; }
+    if (nthreads < 1) nthreads = 1;
+    size_t pieces = (size_t)nthreads * 4;                 // a few pieces per thread evens out the tail
+    if (pieces > size / (256 << 10) + 1) pieces = size / (256 << 10) + 1;
+    std::vector<const uint8_t *> cut(pieces + 1);
+    cut[0] = p;
+    cut[pieces] = end;
+    for (size_t t = 1; t < pieces; t++) cut[t] = next_record_start(base, base + size / pieces * t, end);
+    for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    out.resize(pieces);
+    std::vector<std::thread> th;
+    for (int w = 0; w < nthreads; w++)
+        th.emplace_back([&, w]() { for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads) parse_range(cut[t], cut[t + 1], out[t]); });
+    for (auto &t : th) t.join();
+    munmap(m, size);
+    return 1;
+}
+
+int RecordStream::open(const std::string &path, int nthreads, std::string *err)
+{
+    int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, chunks_, err) : 0;
+    if (rc < 0) return rc;
+    parsed_ = rc == 1;
+    ci_ = ri_ = bo_ = dofs_ = 0;
+    return parsed_ ? 0 : rd_.open(path, err);
+}
+
+int RecordStream::next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl)
+{
+    if (!parsed_) {
+        int rc = rd_.next(d_, b_);
+        if (rc <= 0) return rc;
+        d = d_.data(); dl = d_.size(); b = b_.data(); bl = b_.size();
+        return 1;
+    }
+    while (ci_ < chunks_.size() && ri_ >= chunks_[ci_].lens.size()) {
+        ParsedChunk().bases.swap(chunks_[ci_].bases);      // release a finished chunk
+        ParsedChunk().descr.swap(chunks_[ci_].descr);
+        ci_++; ri_ = 0; bo_ = 0; dofs_ = 0;
+    }
+    if (ci_ >= chunks_.size()) return 0;
+    const ParsedChunk &c = chunks_[ci_];
+    d = c.descr.data() + dofs_; dl = c.descr_lens[ri_];
+    b = c.bases.data() + bo_; bl = c.lens[ri_];
+    dofs_ += dl; bo_ += bl; ri_++;
     return 1;
 }
 

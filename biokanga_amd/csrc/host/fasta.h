@@ -37,4 +37,34 @@ private:
     std::string path_;
 };
 
+// A run of parsed records held in memory (file order inside a chunk, chunks in file order).
+struct ParsedChunk {
+    std::vector<uint8_t> bases;         // all records' bases back to back, Ascii2Sense-mapped
+    std::vector<uint32_t> lens;
+    std::vector<char> descr;            // descriptors back to back (as SeqReader::next returns them)
+    std::vector<uint32_t> descr_lens;
+};
+
+// Parses a whole plain-text (not gzip'd) FASTA file with `nthreads` threads: the file is mapped, cut at
+// record starts (the first '>' of a line) and every piece goes through the same state machine as
+// SeqReader::next.  Returns 1 and fills `out` when it handled the file, 0 when the file is not eligible
+// (gzip, FASTQ, tiny: use SeqReader), < 0 on error.
+int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<ParsedChunk> &out, std::string *err);
+
+// One stream of records, from either source.
+class RecordStream {
+public:
+    int open(const std::string &path, int nthreads, std::string *err);
+    // 1 = record, 0 = end, < 0 = error; pointers stay valid until the next call
+    int next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl);
+
+private:
+    SeqReader rd_;
+    bool parsed_ = false;
+    std::vector<ParsedChunk> chunks_;
+    size_t ci_ = 0, ri_ = 0, bo_ = 0, dofs_ = 0;
+    std::string d_;
+    std::vector<uint8_t> b_;
+};
+
 }  // namespace bk

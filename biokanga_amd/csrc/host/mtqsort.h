@@ -10,6 +10,9 @@
 //                         <= 16 elements finished by a max-selection sort
 #pragma once
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstddef>
 #include <cstdint>
 #include <utility>
@@ -29,18 +32,19 @@ void selection_finish(T *left, T *right, Cmp cmp)
     }
 }
 
-template <typename T, typename Cmp>
-void ref_order_sort(T *a, int64_t n, Cmp cmp)
+// One span and everything below it; sub-spans of more than `share_above` elements are handed to
+// `share` (another thread's work) instead of the local stack.  Partitions never overlap, so the
+// result does not depend on who sorts which span or in what order.
+template <typename T, typename Cmp, typename Share>
+void ref_order_span(T *lo, T *hi, Cmp cmp, size_t share_above, Share share)
 {
-    if (n < 2) return;
-    if (n < 25000) {            // cMinUseLibQsort
-        std::stable_sort(a, a + n, [&](const T &x, const T &y) { return cmp(x, y) < 0; });
-        return;
-    }
     struct Span { T *l, *r; };
     std::vector<Span> stack;
     stack.reserve(128);
-    T *lo = a, *hi = a + (n - 1);
+    auto defer = [&](T *l, T *r) {
+        if (share_above && (size_t)(r - l) + 1 > share_above) share(l, r);
+        else stack.push_back({l, r});
+    };
     for (;;) {
         size_t cnt = (size_t)(hi - lo) + 1;
         bool descend = false;
@@ -67,12 +71,12 @@ void ref_order_sort(T *a, int64_t n, Cmp cmp)
                 do { --ph; } while (ph > mid && cmp(*ph, *mid) == 0);
             if (mid >= ph)
                 do { --ph; } while (ph > lo && cmp(*ph, *mid) == 0);
-            // larger side is stacked, smaller side is continued with
+            // larger side is deferred, smaller side is continued with
             if (ph - lo >= hi - pl) {
-                if (lo < ph) stack.push_back({lo, ph});
+                if (lo < ph) defer(lo, ph);
                 if (pl < hi) { lo = pl; descend = true; }
             } else {
-                if (pl < hi) stack.push_back({pl, hi});
+                if (pl < hi) defer(pl, hi);
                 if (lo < ph) { hi = ph; descend = true; }
             }
         }
@@ -82,6 +86,54 @@ void ref_order_sort(T *a, int64_t n, Cmp cmp)
         hi = stack.back().r;
         stack.pop_back();
     }
+}
+
+template <typename T, typename Cmp>
+void ref_order_sort(T *a, int64_t n, Cmp cmp, int nthreads = 1)
+{
+    if (n < 2) return;
+    if (n < 25000) {            // cMinUseLibQsort
+        std::stable_sort(a, a + n, [&](const T &x, const T &y) { return cmp(x, y) < 0; });
+        return;
+    }
+    if (nthreads <= 1 || n < 200000) {
+        ref_order_span(a, a + (n - 1), cmp, 0, [](T *, T *) {});
+        return;
+    }
+    // the reference's own threads also take whole sub-partitions (MTqsort.cpp:313-479)
+    struct Span { T *l, *r; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Span> queue;
+    int active = 0;
+    queue.push_back({a, a + (n - 1)});
+    auto share = [&](T *l, T *r) {
+        { std::lock_guard<std::mutex> g(mu); queue.push_back({l, r}); }
+        cv.notify_one();
+    };
+    auto worker = [&]() {
+        for (;;) {
+            Span sp;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return !queue.empty() || active == 0; });
+                if (queue.empty()) { cv.notify_all(); return; }
+                sp = queue.back();
+                queue.pop_back();
+                active++;
+            }
+            ref_order_span(sp.l, sp.r, cmp, (size_t)65536, share);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                active--;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
 }
 
 }  // namespace bk

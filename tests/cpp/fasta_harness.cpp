@@ -1,0 +1,38 @@
+// test harness: parses a FASTA file with the serial SeqReader and with parse_fasta_parallel
+// (biokanga_amd/csrc/host/fasta.cpp) and reports whether both give the same records.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../biokanga_amd/csrc/host/fasta.h"
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) return 2;
+    const int nthreads = atoi(argv[2]);
+    std::string err;
+    bk::SeqReader rd;
+    if (rd.open(argv[1], &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
+    bk::RecordStream rs;
+    if (rs.open(argv[1], nthreads, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
+    std::vector<bk::ParsedChunk> probe;
+    int handled = bk::parse_fasta_parallel(argv[1], nthreads, probe, &err);
+    std::string d;
+    std::vector<uint8_t> b;
+    unsigned long n = 0, nbases = 0;
+    for (;;) {
+        int r1 = rd.next(d, b);
+        const char *pd; const uint8_t *pb; size_t dl, bl;
+        int r2 = rs.next(pd, dl, pb, bl);
+        if (r1 != r2) { printf("MISMATCH rc %d %d at record %lu\n", r1, r2, n); return 1; }
+        if (r1 <= 0) break;
+        if (d.size() != dl || memcmp(d.data(), pd, dl) || b.size() != bl || memcmp(b.data(), pb, bl)) {
+            printf("MISMATCH at record %lu (descr %zu/%zu bases %zu/%zu)\n", n, d.size(), dl, b.size(), bl);
+            return 1;
+        }
+        n++;
+        nbases += bl;
+    }
+    printf("OK records %lu bases %lu parallel %d pieces %zu\n", n, nbases, handled, probe.size());
+    return 0;
+}

@@ -2,6 +2,7 @@
 // SortHitMatch comparator to a binary array of bk_hit records (20 B each) and writes the order.
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../biokanga_amd/csrc/host/mtqsort.h"
@@ -9,7 +10,8 @@
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) return 2;
+    if (argc != 3 && argc != 4) return 2;
+    const int nthreads = argc == 4 ? atoi(argv[3]) : 1;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 3;
     std::vector<bk_hit> hits;
@@ -32,7 +34,7 @@ int main(int argc, char **argv)
         if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
         return 0;
     };
-    bk::ref_order_sort(order.data(), (int64_t)order.size(), cmp);
+    bk::ref_order_sort(order.data(), (int64_t)order.size(), cmp, nthreads);
     FILE *g = fopen(argv[2], "wb");
     fwrite(order.data(), 4, order.size(), g);
     fclose(g);

@@ -1,0 +1,75 @@
+"""Host ingest: the multi-threaded whole-file FASTA parse must give exactly the records of the serial
+reader (CFasta semantics, libbiokanga/Fasta.cpp:907-1137) - CPU only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("f") / "fasta_harness")
+    src = [os.path.join(helpers.ROOT, "tests", "cpp", "fasta_harness.cpp"),
+           os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "fasta.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe] + src + ["-lz"])
+    return exe
+
+
+def nasty_fasta(path, n_records, seed):
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGTacgtNnRY-", dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"\n\n")
+        for i in range(n_records):
+            kind = i % 11
+            name = f"read{i} extra words".encode()
+            if kind == 3:
+                name += b" with > inside the descriptor >twice"
+            if kind == 5:
+                name += b" caf\xc3\xa9"
+            eol = b"\r\n" if kind == 7 else b"\n"
+            f.write(b">" + name + eol)
+            L = int(rng.integers(1, 400))
+            seq = alphabet[rng.integers(0, len(alphabet), L)].tobytes()
+            if kind == 2:
+                seq = seq[: L // 2] + b" 12 \t" + seq[L // 2:]           # sloughed characters
+            width = int(rng.integers(20, 90))
+            for o in range(0, len(seq), width):
+                f.write(seq[o:o + width] + eol)
+            if kind == 9:
+                f.write(eol)                                            # blank line between records
+            if kind == 10:
+                f.write(b"ACGT>midline descriptor" + eol + b"TTGA" + eol)   # '>' after bases starts a new record
+
+
+@pytest.mark.parametrize("threads", [2, 7, 16])
+def test_parallel_parse_equals_serial(harness, tmp_path, threads):
+    p = str(tmp_path / "nasty.fa")
+    nasty_fasta(p, 12000, seed=threads)
+    assert os.path.getsize(p) > (1 << 20)
+    out = subprocess.check_output([harness, p, str(threads)]).decode()
+    assert out.startswith("OK"), out
+    assert "parallel 1" in out and int(out.split("pieces")[1]) > 1, out
+
+
+def test_small_gzip_and_fastq_take_the_serial_reader(harness, tmp_path):
+    import gzip
+    p = str(tmp_path / "small.fa")
+    nasty_fasta(p, 50, seed=1)
+    assert "parallel 0" in subprocess.check_output([harness, p, "4"]).decode()
+    big = str(tmp_path / "big.fa")
+    nasty_fasta(big, 12000, seed=2)
+    gz = str(tmp_path / "big.fa.gz")
+    with open(big, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    out = subprocess.check_output([harness, gz, "4"]).decode()
+    assert out.startswith("OK") and "parallel 0" in out, out
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "wb") as f:
+        for i in range(30000):
+            f.write(b"@q%d\nACGTNACGTTGCA\n+\nIIIIIIIIIIIII\n" % i)
+    out = subprocess.check_output([harness, fq, "4"]).decode()
+    assert out.startswith("OK records 30000") and "parallel 0" in out, out

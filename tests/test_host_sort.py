@@ -13,7 +13,7 @@ import helpers
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("h") / "sort_harness")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "sort_harness.cpp")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "sort_harness.cpp")])
     return exe
 
 
@@ -52,3 +52,29 @@ def test_sort_replica_small(harness, golden_tmp, tmp_path, fixture):
     got = sorted_names(harness, tmp_path, hits, [names[i] for i in keep])
     _, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, fixture, "s3.m5.sam.gz"))
     assert got == [r["qname"] for r in recs]
+
+
+def test_sort_threads_do_not_change_the_order(harness, tmp_path):
+    """the multi-threaded form hands whole sub-partitions to other threads, like the reference's CMTqsort:
+    the order of tied records must be the single-threaded one"""
+    import biokanga_amd.binding as b
+    rng = np.random.default_rng(11)
+    n = 700_000
+    hits = np.zeros(n, dtype=b.HIT_DTYPE)
+    hits["nar"] = rng.choice([1, 1, 1, 4, 6], n)
+    hits["num_hits"] = (hits["nar"] == 1).astype(np.uint8)
+    hits["chrom_id"] = rng.integers(1, 4, n)
+    hits["match_loci"] = rng.integers(0, 20000, n)          # many exact ties
+    hits["match_len"] = 100
+    hits["strand"] = rng.choice([ord("+"), ord("-")], n)
+    hits["low_mm"] = rng.integers(0, 3, n)
+    hp = str(tmp_path / "hits.bin")
+    hits.tofile(hp)
+    orders = []
+    for t in (1, 8):
+        op = str(tmp_path / f"order{t}.bin")
+        subprocess.check_call([harness, hp, op, str(t)])
+        orders.append(np.fromfile(op, dtype=np.uint32))
+    assert np.array_equal(orders[0], orders[1])
+    srt = hits[orders[0]]
+    assert np.all(np.diff(srt["nar"].astype(int)) >= 0)
