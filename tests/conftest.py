@@ -25,4 +25,12 @@ def golden_tmp(tmp_path_factory):
         helpers.gunzip_to(os.path.join(src, "genome.fa.gz"), str(dst / "genome.fa"))
         helpers.gunzip_to(os.path.join(src, "reads.fa.gz"), str(dst / "reads.fa"))
         out[name] = str(dst)
+    # fixtures that reuse the basic genome with their own reads
+    for name in ("lengths",):
+        dst = d / name
+        dst.mkdir()
+        os.symlink(os.path.join(out["basic"], "genome.sfx"), str(dst / "genome.sfx"))
+        os.symlink(os.path.join(out["basic"], "genome.fa"), str(dst / "genome.fa"))
+        helpers.gunzip_to(os.path.join(helpers.GOLDEN, name, "reads.fa.gz"), str(dst / "reads.fa"))
+        out[name] = str(dst)
     return out

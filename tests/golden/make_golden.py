@@ -436,12 +436,64 @@ def make_sortorder(tmp):
     print("  sortorder fixture written")
 
 
+def make_lengths(tmp):
+    """reads of 15..49 and 151..2000 bases on the basic genome (-l15 -L2000): pins the short-read core
+    geometry and the many-cores-per-strand paths (a 2000-base read at -s3 has MaxTotMM 60 and far more
+    than 16 cores per strand) that the 50..150-base fixtures never reach."""
+    rng = np.random.default_rng(777)
+    outdir = os.path.join(HERE, "lengths")
+    os.makedirs(outdir, exist_ok=True)
+    basic = os.path.join(HERE, "basic")
+    fa = os.path.join(tmp, "len.fa")
+    with gzip.open(os.path.join(basic, "genome.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    seqs = {}
+    name = None
+    for line in open(fa):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = []
+        else:
+            seqs[name].append(line.upper())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    reads = []
+    k = 0
+    for L in (15, 16, 17, 20, 24, 25, 26, 30, 33, 40, 49, 151, 200, 256, 257, 300, 400, 500, 501, 640, 800, 1000, 1500, 2000):
+        for rep in range(20):
+            c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
+            while True:
+                p0 = int(rng.integers(0, len(seqs[c]) - L))
+                s = seqs[c][p0:p0 + L]
+                if "N" not in s:
+                    break
+            allowed = max(1, int(0.5 + L * 3 / 100.0))
+            e = [0, 1, allowed - 1, allowed, allowed + 1, 2 * allowed + 3][rep % 6] if L >= 25 else rep % 3
+            e = max(0, min(e, L // 2))
+            r = mutate(rng, s, e)
+            if rng.integers(0, 2):
+                r = revcomp(r)
+            reads.append((f"L{L}_{k}_e{e}", r))
+            k += 1
+    rd = os.path.join(tmp, "len_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "len.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "basic", "-T4"], tmp)
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    align_runs(tmp, outdir, sfx, rd, [("s3L", ["-s3", "-l15", "-L2000"]), ("s5L", ["-s5", "-l15", "-L2000"]),
+                                      ("dfltL", ["-l15", "-L2000"]), ("s0L", ["-s0", "-l15", "-L2000"])])
+    print("  lengths fixture written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-lengths" in sys.argv:
+            make_lengths(tmp)
             return
         if "--only-sortorder" in sys.argv:
             make_sortorder(tmp)
@@ -450,6 +502,7 @@ def main():
         make_repeat(tmp)
         make_sortorder(tmp)
         make_pe(tmp)
+        make_lengths(tmp)
     print("done")
 
 

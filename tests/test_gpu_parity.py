@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import helpers
-from test_oracle_golden import RUNS, MIN_LEN, check_hits_against_sam, chrom_names_from_hdr, expected_from_sam
+from test_oracle_golden import RUNS, MIN_LEN, MAX_LEN, check_hits_against_sam, chrom_names_from_hdr, expected_from_sam
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def assert_hits_equal(got, exp, names=None):
 def load_fixture(golden_tmp, fixture, tag="s3"):
     d = golden_tmp[fixture]
     names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
-    keep = helpers.filter_reads_by_len(names, bases, offs, lens, MIN_LEN.get(tag, 50), 500)
+    keep = helpers.filter_reads_by_len(names, bases, offs, lens, MIN_LEN.get(tag, 50), MAX_LEN.get(tag, 500))
     return d, names, bases, offs, lens, keep
 
 
@@ -56,7 +56,7 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
     sfx.close()
 
 
-@pytest.mark.parametrize("fixture", ["basic", "repeat"])
+@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
 @pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
                                   ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
@@ -65,7 +65,7 @@ def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""
     bk = _bk()
-    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture)
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
     with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
         ref = al.align(bases, offs[keep], lens[keep])
         c0 = al.counters(reset=True)

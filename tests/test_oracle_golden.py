@@ -22,8 +22,13 @@ RUNS = {
         "s3": dict(max_subs=3), "s3m1": dict(max_subs=3, pmode=1), "s3m3": dict(max_subs=3, pmode=3),
         "s5": dict(max_subs=5),
     },
+    # reads of 15..49 and 151..2000 bases on the basic genome, -l15 -L2000 (make_golden.make_lengths)
+    "lengths": {
+        "s3L": dict(max_subs=3), "s5L": dict(max_subs=5), "dfltL": dict(), "s0L": dict(max_subs=0),
+    },
 }
-MIN_LEN = {"s2l30": 30}
+MIN_LEN = {"s2l30": 30, "s3L": 15, "s5L": 15, "dfltL": 15, "s0L": 15}
+MAX_LEN = {"s3L": 2000, "s5L": 2000, "dfltL": 2000, "s0L": 2000}
 
 
 def expected_from_sam(fixture, tag):
@@ -66,7 +71,7 @@ def chrom_names_from_hdr(hdr):
 def test_oracle_matches_reference(golden_tmp, fixture, tag):
     d = golden_tmp[fixture]
     names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
-    keep = helpers.filter_reads_by_len(names, bases, offs, lens, MIN_LEN.get(tag, 50), 500)
+    keep = helpers.filter_reads_by_len(names, bases, offs, lens, MIN_LEN.get(tag, 50), MAX_LEN.get(tag, 500))
     sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
     p = helpers.make_params(**RUNS[fixture][tag])
     hits, ctr = sfx.align(bases, offs[keep], lens[keep], p)
