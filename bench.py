@@ -358,6 +358,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    first_out = out.clone() if args.warmup > 0 else None       # results of an untimed step, to check repeatability
     if args.sweep:
         name, vals = args.sweep.split("=")
         for v in vals.split(","):
@@ -384,6 +385,8 @@ def main():
 
     ctr = al.counters()
     tim = al.timing()
+    repeatable = bool(torch.equal(first_out, out)) if first_out is not None else None
+    del first_out
     hits = out.cpu().numpy().view(bk.HIT_DTYPE)
     accepted = int((hits["nar"] == 1).sum())
     total_reads = args.reads * world * args.steps
@@ -433,7 +436,8 @@ def main():
                    "parallelism": f"reads sharded over {world} GPU(s)", "accepted_frac_rank0": accepted / args.reads,
                    "n_search_per_read": ctr["n_search"] / (args.reads * args.steps),
                    "n_cand_per_read": ctr["n_cand"] / (args.reads * args.steps),
-                   "heavy_calls_frac": ctr["n_heavy"] / max(1, ctr["n_lcm_calls"])},
+                   "heavy_calls_frac": ctr["n_heavy"] / max(1, ctr["n_lcm_calls"]),
+                   "results_bitwise_equal_across_steps": repeatable},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.cpu_baseline_secs > 0:

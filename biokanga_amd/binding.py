@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -129,6 +129,8 @@ def load_library():
     lib.bk_align_batch_device.restype = i32
     lib.bk_pair_batch.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(PEParams)]
     lib.bk_pair_batch.restype = i32
+    lib.bk_pair_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(PEParams)]
+    lib.bk_pair_batch_device.restype = i32
     lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
     lib.bk_get_counters.restype = i32
     lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
@@ -253,6 +255,12 @@ class Aligner:
         if rc:
             raise BkError(rc, "bk_pair_batch")
         return hits
+
+    def pair_device(self, d_bases, d_offs, d_lens, n_pairs, d_hits, pe):
+        """PE association on device-resident buffers (ints = device pointers); hits updated in place."""
+        rc = self.lib.bk_pair_batch_device(self.h, d_bases, d_offs, d_lens, n_pairs, d_hits, ctypes.byref(pe))
+        if rc:
+            raise BkError(rc, "bk_pair_batch_device")
 
     def align_device(self, d_bases, d_offs, d_lens, nreads, d_out, stream=None, sync=True):
         """Device pointers (ints) of buffers resident in HBM on this context's GPU."""

@@ -568,6 +568,28 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// K4 on buffers resident in HBM (shared by bk_pair_batch and bk_pair_batch_device)
+static int pair_on_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs,
+                          bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe)
+{
+    const uint32_t nreads = 2 * n_pairs;
+    hipStream_t s = c->stream;
+    const uint32_t wpr = words_per_read(maxlen);
+    int rc = ensure_batch_scratch(c, nreads, wpr);
+    if (rc) return rc;
+    DevBatch b{};
+    b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
+    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.out = d_hits; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
+    b.wpr = wpr; b.n_reads = nreads;
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+    launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, d_hits, n_pairs,
+              c->d_heavy, c->d_small, c->h_small, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return BK_OK;
+}
+
 extern "C" {
 
 const char *bk_version(void) { return "biokanga_amd 0.1 (gfx950; reference biokanga 4.4.2)"; }
@@ -852,21 +874,32 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_in_out, hits, (size_t)nreads * sizeof(bk_hit), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    uint32_t wpr = ((maxlen + 15) / 16 + 2) & ~1u;
-    int rc = ensure_batch_scratch(c, nreads, wpr);
+    int rc = pair_on_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, n_pairs, c->d_in_out, maxlen, pe);
     if (rc) return rc;
-    DevBatch b{};
-    b.bases = c->d_in_bases; b.offs = c->d_in_offs; b.lens = c->d_in_lens;
-    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
-    b.out = c->d_in_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
-    b.wpr = wpr; b.n_reads = nreads;
-    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
-    launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, c->d_in_out, n_pairs,
-              c->d_heavy, c->d_small, c->h_small, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(hits, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
+}
+
+// device-resident form: reads and their bk_hit records (the output of bk_align_batch_device for exactly these
+// reads, interleaved PE1, PE2) already in HBM; hits are updated in place
+int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs, void *d_hits,
+                         const bk_pe_params *pe)
+{
+    if (!c || !pe || (n_pairs && (!d_bases || !d_offs || !d_lens || !d_hits))) return BK_ERR_PARAMS;
+    if (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len) return BK_ERR_PARAMS;
+    if (!n_pairs) return BK_OK;
+    if (n_pairs > 0x7fffffffu) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nreads = 2 * n_pairs;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+    launch_max_len((const uint32_t *)d_lens, nreads, c->d_small + 5, s);
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 16 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t maxlen = c->h_small[5];
+    if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+    return pair_on_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, n_pairs, (bk_hit *)d_hits,
+                          maxlen, pe);
 }
 
 int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)

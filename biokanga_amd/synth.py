@@ -54,14 +54,22 @@ def make_genome(total_bp, device, seed=38, n_seqs=24, repeat_frac=0.45, n_gap_fr
         while done < copies:
             c = min(copies - done, max(1, (1 << 27) // L))        # <= 128 M elements per chunk
             pos = torch.randint(0, n_bases - L, (c,), dtype=torch.int64, device=device, generator=g)
-            idx = (pos[:, None] + torch.arange(L, device=device)[None, :]).reshape(-1)
+            # copies of one chunk may overlap; an indexed store with duplicate indices is not deterministic on
+            # the GPU, so the copies are laid down in position order and every base is written only by the
+            # LAST copy covering it (= the part of a copy before the next copy's start)
+            pos = torch.sort(pos).values
+            nxt = torch.cat([pos[1:], torch.full((1,), n_bases, dtype=torch.int64, device=device)])
+            ar = torch.arange(L, device=device)
+            idx = (pos[:, None] + ar[None, :])
+            keep = (idx < nxt[:, None]).reshape(-1)
+            idx = idx.reshape(-1)
             mut = torch.rand((c * L,), device=device, generator=g) < div
             delta = torch.randint(1, 4, (c * L,), dtype=torch.uint8, device=device, generator=g)
             val = cons.repeat(c)
             val = torch.where(mut, (val + delta) & 3, val)
-            bases[idx] = val
+            bases[idx[keep]] = val[keep]
             done += c
-            del pos, idx, mut, delta, val
+            del pos, nxt, idx, keep, mut, delta, val
         placed += copies * L
 
     # N gaps: runs of 10 k .. 3 M (scaled down for small genomes)
@@ -125,3 +133,48 @@ def make_reads(seq, seq_lens, n_reads, read_len, device, seed=2, max_subs=3):
     lens = torch.full((n_reads,), read_len, dtype=torch.int32, device=device)
     truth = {"chrom": chrom, "local": local, "strand": strand, "nsubs": nsubs}
     return out.reshape(-1), offs, lens, truth
+
+
+def make_pairs(seq, seq_lens, n_pairs, read_len, device, seed=3, max_subs=5, ins_mean=300.0, ins_sd=50.0, ins_lo=200, ins_hi=400):
+    """FR paired ends (C3 of SURVEY.md §8d): insert ~ N(ins_mean, ins_sd) clipped to [ins_lo, ins_hi], substitutions
+    per read uniform on 0..max_subs; half of the fragments come from the '-' strand.
+    -> (bases uint8 [2*n_pairs*read_len] interleaved PE1,PE2, offs int64, lens int32)"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ent = entry_table(seq_lens)
+    lens_t = torch.tensor([e[1] for e in ent], dtype=torch.float64, device=device)
+    starts_t = torch.tensor([e[2] for e in ent], dtype=torch.int64, device=device)
+    chrom = torch.multinomial(lens_t / lens_t.sum(), n_pairs, replacement=True, generator=g)
+    ins = (torch.randn(n_pairs, device=device, generator=g) * ins_sd + ins_mean).round().clamp(ins_lo, ins_hi).to(torch.int64)
+    ins = torch.maximum(ins, torch.full_like(ins, read_len))
+    span = (lens_t[chrom] - ins.double() + 1).clamp(min=1)
+    local = (torch.rand(n_pairs, dtype=torch.float64, device=device, generator=g) * span).to(torch.int64)
+    start = starts_t[chrom] + local
+    flip = torch.randint(0, 2, (n_pairs,), device=device, generator=g).bool()
+    comp = torch.tensor([3, 2, 1, 0, 4, 5, 6, 7], dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, device=device)
+    out = torch.empty((n_pairs, 2, read_len), dtype=torch.uint8, device=device)
+    chunk = max(1, (1 << 25) // read_len)
+    for lo in range(0, n_pairs, chunk):
+        hi = min(n_pairs, lo + chunk)
+        left = seq[(start[lo:hi, None] + ar[None, :])]
+        right = seq[(start[lo:hi, None] + ins[lo:hi, None] - read_len + ar[None, :])]
+        mates = []
+        for r in (left, right):
+            nsubs = torch.randint(0, max_subs + 1, (hi - lo,), device=device, generator=g)
+            key = torch.rand((hi - lo, read_len), device=device, generator=g)
+            rank = key.argsort(dim=1).argsort(dim=1)
+            mut = (rank < nsubs[:, None]) & (r < 4)
+            delta = torch.randint(1, 4, (hi - lo, read_len), dtype=torch.uint8, device=device, generator=g)
+            mates.append(torch.where(mut, (r + delta) & 3, r))
+        l, r = mates
+        rc_r = comp[r.long()].flip(1)
+        rc_l = comp[l.long()].flip(1)
+        f = flip[lo:hi, None]
+        out[lo:hi, 0] = torch.where(f, rc_r, l)        # '+' fragment: PE1 = left fwd, PE2 = right revcomp
+        out[lo:hi, 1] = torch.where(f, l, rc_r)        # '-' fragment: PE1 = right revcomp ... seen from the other strand
+        del left, right, l, r, rc_r, rc_l
+    n = 2 * n_pairs
+    offs = torch.arange(n, dtype=torch.int64, device=device) * read_len
+    lens = torch.full((n,), read_len, dtype=torch.int32, device=device)
+    return out.reshape(-1), offs, lens

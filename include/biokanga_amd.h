@@ -165,6 +165,10 @@ typedef struct bk_pe_params {
 } bk_pe_params;
 int  bk_pair_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs,
                    bk_hit *hits, const bk_pe_params *pe);
+/* the same on buffers already resident in HBM on the context's GPU (d_hits = what bk_align_batch_device wrote
+ * for exactly these reads); nothing crosses PCIe */
+int  bk_pair_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs,
+                          void *d_hits, const bk_pe_params *pe);
 
 /* counters/timing accumulated since the last reset */
 int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);

@@ -281,3 +281,25 @@ def test_five_byte_suffix_elements(tmp_path, read_len):
             ctr = al.counters()
             assert_hits_equal(got, exp)
             assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
+
+
+def test_pe_device_resident_entry_point(golden_tmp, tmp_path):
+    """bk_pair_batch_device on buffers in HBM == bk_pair_batch on host buffers"""
+    import torch
+    bk = _bk()
+    cfg = PE_RUNS["U3"]
+    names, bases, offs, lens = pe_inputs(tmp_path)
+    sfx_path = os.path.join(golden_tmp["basic"], "genome.sfx")
+    pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False))
+    with bk.Aligner(sfx_path, bk.AlignParams(max_subs=cfg["s"])) as al:
+        hits = al.align(bases, offs, lens)
+        exp = al.pair(bases, offs, lens, hits.copy(), pe)
+        dev = torch.device("cuda", 0)
+        d_b = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+        d_o = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_l = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        d_h = torch.zeros(len(lens) * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        al.align_device(d_b.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), len(lens), d_h.data_ptr())
+        al.pair_device(d_b.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), len(lens) // 2, d_h.data_ptr(), pe)
+        got = d_h.cpu().numpy().view(bk.HIT_DTYPE)
+    assert np.array_equal(got, exp)
