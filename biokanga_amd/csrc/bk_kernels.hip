@@ -807,11 +807,15 @@ __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, c
     const uint4 *__restrict__ blk = reinterpret_cast<const uint4 *>(tgt) + (i0 >> 1);
     constexpr int NB = NW / 2 + 1;
     uint64_t r2[2 * NB];
+    // words touched from i0 on: the window's bases plus the shift spill; 16-byte blocks from the even word
+    // at or below i0.  Only what is needed is fetched (a 100-base window needs the 5th block in 3 of 32
+    // alignments) - these kernels are bound by 32-byte sectors moved, see DESIGN.md
+    const int nwords = ((int)(t & 15) + len + 15) >> 4;
+    const int nblk = ((odd ? 1 : 0) + nwords + 1) >> 1;
 #pragma unroll
     for (int q = 0; q < NB; q++) {
-        // block q holds words 2q, 2q+1 counted from the even word at or below i0; the last window word
-        // k = (len-1)/16 reads words k+odd and k+1+odd
-        if (32 * (q - 1) < len) {
+        // block q holds words 2q, 2q+1 counted from the even word at or below i0
+        if (q < nblk) {
             uint4 v = blk[q];
             r2[2 * q] = ((uint64_t)v.y << 32) | v.x;
             r2[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
