@@ -5,6 +5,11 @@
 //            nibble, so that an unsigned compare of two words is the reference's low-nibble
 //            lexicographic compare (A0 C1 G2 T3 N4 < EOS7; SfxArrayV2.cpp:7791-7812).  Padded with
 //            EOS nibbles past concat_len so windows never read out of bounds.
+//   tgt2   : the same bases at 2 bit/base (32 per uint64, first base in the top bits) for the window compare of
+//            the extend kernels: a 100-base window is 25 bytes = 1.8 32-byte sectors instead of 2.6.  N/EOS
+//            cannot be held; nflag (1 bit per 2^flag_shift bases, sized to stay <= 16 KB so that it lives in the L1 -
+//            a bigger bitmap costs one more cache miss per candidate, which is what bounds these kernels) says where the
+//            4-bit copy has to be used instead
 //   sa_lo  : uint32[N] low 32 bits of each suffix array element; sa_hi: uint8[N] bits 32..39 when
 //            the .sfx uses 5-byte elements (SfxOfsToLoci, SfxArrayV2.cpp:33-44)
 //   ktab   : uint32/uint64[4^k + 1]; ktab[c] = number of suffixes sorting before k-mer code c, i.e.
@@ -33,6 +38,9 @@ constexpr uint64_t kEosWord = 0x7777777777777777ULL;
 
 struct DevIndex {
     const uint64_t *tgt4;
+    const uint64_t *tgt2;       // 2 bit/base copy of the target (32 bases per word), may be null
+    const uint8_t *nflag;       // bit per 2^flag_shift bases: region holds N/EOS (tgt2 unusable there); <= 16 KB, L1 resident
+    int flag_shift;
     const uint32_t *sa_lo;
     const uint8_t *sa_hi;       // null unless 5-byte elements
     const uint64_t *ent_start;
@@ -60,6 +68,7 @@ struct DevBatch {
     const uint64_t *offs;
     const uint32_t *lens;
     uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp)
+    uint64_t *rd2;              // [read][strand][3*NW/4]: NW/2 words at 2 bit/base + NW/4 words of N mask; may be null
     uint64_t *iv_first;         // [read][strand][kMaxCoresFast]
     uint32_t *iv_n;
     bk_hit *out;

@@ -17,6 +17,8 @@
 namespace bk {
 // launchers defined in bk_kernels.hip
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
+void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
+void launch_pack_reads2(const DevBatch &b, int nw, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
@@ -74,6 +76,12 @@ struct bk_ctx {
     uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
     uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
     void *d_ktab = nullptr;
+    uint64_t *d_tgt2 = nullptr;           // 2 bit/base target copy (DevIndex::tgt2)
+    uint8_t *d_nflag = nullptr;
+    uint64_t *d_rd2 = nullptr;            // 2-bit read rows
+    uint64_t n_tgt4_words = 0;
+    uint32_t cap_rd2w = 0;
+    int use_tgt2 = 1;
     uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint64_t cap_slist = 0;
@@ -236,6 +244,32 @@ int build_isa(bk_ctx *c)
     return BK_OK;
 }
 
+// 2 bit/base target copy + N/EOS block bitmap for the window compare of the extend kernels
+int build_tgt2(bk_ctx *c)
+{
+    free_dev(c->d_tgt2); free_dev(c->d_nflag);
+    c->d_tgt2 = nullptr; c->d_nflag = nullptr;
+    c->ix.tgt2 = nullptr; c->ix.nflag = nullptr;
+    if (!c->use_tgt2) return BK_OK;
+    const uint64_t nblocks = c->n_tgt4_words / 4;
+    // flag granule: the smallest power of two that keeps the bitmap within 16 KB; at least 256 bases so that a
+    // window of the register kernels (<= 256 bases) spans at most two regions
+    int shift = 8;
+    while ((((nblocks * 64) >> shift) + 7) / 8 > 16384) shift++;
+    const uint64_t flag_bytes = (((((nblocks * 64) >> shift) + 1) + 31) / 32) * 4 + 16;
+    HIP_TRY(hipMalloc(&c->d_tgt2, nblocks * 16 + 64));
+    HIP_TRY(hipMalloc(&c->d_nflag, flag_bytes));
+    HIP_TRY(hipMemsetAsync(c->d_nflag, 0, flag_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_tgt2 + nblocks * 2, 0, 64, c->stream));
+    launch_pack_target2(c->d_tgt4, c->n_tgt4_words, c->d_tgt2, (unsigned int *)c->d_nflag, shift, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ix.tgt2 = c->d_tgt2;
+    c->ix.nflag = c->d_nflag;
+    c->ix.flag_shift = shift;
+    return BK_OK;
+}
+
 int size_heavy_scratch(bk_ctx *c)
 {
     // worst-case inserts per strand pass = min(node cap, cores(max_read_len) * MaxIter)
@@ -307,6 +341,8 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     if (rc) return rc;
     rc = build_isa(c);
     if (rc) return rc;
+    rc = build_tgt2(c);
+    if (rc) return rc;
     return size_heavy_scratch(c);
 }
 
@@ -333,10 +369,11 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
 {
     c->el_size = (uint32_t)el;
     c->ix.n = n;
-    uint64_t nwords = (n + 15) / 16 + (kMaxReadLenAbs / 16) + 4;
+    uint64_t nwords = ((n + 15) / 16 + (kMaxReadLenAbs / 16) + 4 + 3) & ~3ULL;      // whole 64-base blocks
     HIP_TRY(hipMalloc(&c->d_tgt4, nwords * 8));
     launch_pack_target(d_seq, n, c->d_tgt4, nwords, c->stream);
     HIP_TRY(hipGetLastError());
+    c->n_tgt4_words = nwords;
     HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
     if (el == 5) {
         HIP_TRY(hipMalloc(&c->d_sa_hi, n));
@@ -351,16 +388,17 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
     return BK_OK;
 }
 
-int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr)
+int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2w = 0)
 {
-    if (n_reads <= c->cap_reads && wpr <= c->cap_wpr) return BK_OK;
-    uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr);
-    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
+    if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
+    uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave);
-    c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr;
+    c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
+    if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8));
     HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
     HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * kMaxCoresFast * 4));
     HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
@@ -369,6 +407,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr)
     HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
     c->cap_reads = nr;
     c->cap_wpr = w;
+    c->cap_rd2w = w2;
     return BK_OK;
 }
 
@@ -406,9 +445,9 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 }
 
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
-static inline uint64_t scratch_bytes_per_read(uint32_t wpr)
+static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
 {
-    return 2ULL * wpr * 8 + 2ULL * kMaxCoresFast * 12 + 4 * 4;
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 12 + 4 * 4;
 }
 
 int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n, uint32_t maxlen,
@@ -417,21 +456,24 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     uint32_t *sm = c->d_small, *hm = c->h_small;
     HIP_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
     const uint32_t wpr = words_per_read(maxlen);
-    int rc = ensure_batch_scratch(c, n, wpr);
+    // register-resident window kernels handle reads of <= 128 / <= 256 bases
+    const bool reg_path = c->use_wave && maxlen <= 256;
+    const int nw16 = maxlen <= 128 ? 8 : 16;
+    const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
+    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(3 * nw16 / 4) : 0u);
     if (rc) return rc;
 
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.rd2 = two_bit ? c->d_rd2 : nullptr;
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
-    // register-resident window kernels handle reads of <= 128 / <= 256 bases
-    const bool reg_path = c->use_wave && maxlen <= 256;
-    const int nw16 = maxlen <= 128 ? 8 : 16;
 
     hipEvent_t e0 = tm.begin(s);
     launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
+    if (two_bit) launch_pack_reads2(b, nw16, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e0, s);
     HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
@@ -681,7 +723,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -733,6 +775,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_tgt2") {
+        int64_t old = c->use_tgt2;
+        c->use_tgt2 = value ? 1 : 0;
+        int rc = build_tgt2(c);
         return rc ? rc : old;
     }
     if (n == "use_flat") {

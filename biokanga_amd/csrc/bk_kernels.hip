@@ -242,6 +242,23 @@ __global__ void k_pack_target(const uint8_t *__restrict__ seq, uint64_t n, uint6
     }
 }
 
+// 2 bit/base copy + "block holds N/EOS" bitmap, derived from the packed 4-bit target (padding included)
+__global__ void k_pack_target2(const uint64_t *__restrict__ tgt4, uint64_t nwords4, uint64_t *__restrict__ tgt2,
+                               unsigned int *__restrict__ nflag32, int flag_shift)
+{
+    // one thread per 64-base block = 4 nibble words -> 2 words of tgt2; flags per 2^flag_shift bases
+    uint64_t nblocks = nwords4 / 4;
+    for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < nblocks; blk += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t a = tgt4[4 * blk], b = tgt4[4 * blk + 1], c = tgt4[4 * blk + 2], d = tgt4[4 * blk + 3];
+        tgt2[2 * blk] = ((uint64_t)squeeze2(a) << 32) | squeeze2(b);
+        tgt2[2 * blk + 1] = ((uint64_t)squeeze2(c) << 32) | squeeze2(d);
+        if ((a | b | c | d) & 0x4444444444444444ULL) {
+            uint64_t g = blk >> (flag_shift - 6);
+            atomicOr(&nflag32[g >> 5], 1u << (g & 31));
+        }
+    }
+}
+
 __global__ void k_split_sa5(const uint8_t *__restrict__ sa5, uint64_t n, uint32_t *__restrict__ lo, uint8_t *__restrict__ hi)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -890,6 +907,118 @@ __device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2-bit window compare.  Read side: per read and strand NW/2 words at 2 bit/base (N held as A) plus NW/4
+// words of "this read base is N" in the mismatch-map format; target side: DevIndex::tgt2.  Only for
+// windows whose 64-base blocks hold no N/EOS (window_flagged), where a read N always is a mismatch and
+// nothing else can differ from the 4-bit compare.
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_pack_reads2(DevBatch b)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (read, strand)
+    if (i >= 2ULL * b.n_reads) return;
+    const uint64_t *src = b.rd4 + i * b.wpr;
+    uint64_t *dst = b.rd2 + i * (3 * NW / 4);
+    uint64_t r4[NW];
+    const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int q = 0; q < NW / 2; q++) {
+        if (2 * q < (int)b.wpr) {
+            uint4 v = p[q];
+            r4[2 * q] = ((uint64_t)v.y << 32) | v.x;
+            r4[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+        } else {
+            r4[2 * q] = 0;
+            r4[2 * q + 1] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) dst[k] = ((uint64_t)squeeze2(r4[2 * k]) << 32) | squeeze2(r4[2 * k + 1]);
+#pragma unroll
+    for (int q = 0; q < NW / 4; q++) {
+        uint64_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) m |= (uint64_t)flags_to_bits16((r4[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
+        dst[NW / 2 + q] = m;
+    }
+}
+
+__device__ __forceinline__ bool window_flagged(const DevIndex &ix, uint64_t t, int len)
+{
+    const uint64_t g0 = t >> ix.flag_shift, g1 = (t + (uint64_t)len - 1) >> ix.flag_shift;     // a window spans <= 2 regions
+    return (((ix.nflag[g0 >> 3] >> (g0 & 7)) | (ix.nflag[g1 >> 3] >> (g1 & 7))) & 1) != 0;
+}
+
+template <int NW>
+__device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], const uint64_t (&rnm)[NW / 4], int len,
+                                             const uint64_t *__restrict__ tgt2, uint64_t t, Window<NW> &w)
+{
+    const uint64_t i0 = t >> 5;
+    const unsigned s = (unsigned)(t & 31) << 1;
+    const bool odd = (i0 & 1) != 0;
+    const uint4 *__restrict__ blk = reinterpret_cast<const uint4 *>(tgt2) + (i0 >> 1);
+    constexpr int NB = NW / 4 + 1;
+    uint64_t r[2 * NB];
+    const int nwords = ((int)(t & 31) + len + 31) >> 5;
+    const int nblk = ((odd ? 1 : 0) + nwords + 1) >> 1;
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        if (q < nblk) {
+            uint4 v = blk[q];
+            r[2 * q] = ((uint64_t)v.y << 32) | v.x;
+            r[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+        } else {
+            r[2 * q] = 0;
+            r[2 * q + 1] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) w.bm[k] = rnm[k];
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+        if (32 * k < len) {
+            uint64_t a = odd ? r[k + 1] : r[k];
+            uint64_t b = odd ? r[k + 2] : r[k + 1];
+            uint64_t win = (a << s) | ((b >> 1) >> (63 - s));
+            uint64_t x = r2w[k] ^ win;
+            uint64_t y = (x | (x >> 1)) & 0x5555555555555555ULL;        // base j of the word: bit 62 - 2j
+            const int rem = len - 32 * k;
+            if (rem < 32) y &= ~0ULL << (64 - 2 * rem);
+            uint64_t g = __brevll(y) >> 1;                               // base j: bit 2j
+            g = (g | (g >> 1)) & 0x3333333333333333ULL;
+            g = (g | (g >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+            g = (g | (g >> 4)) & 0x00FF00FF00FF00FFULL;
+            g = (g | (g >> 8)) & 0x0000FFFF0000FFFFULL;
+            g = (g | (g >> 16)) & 0x00000000FFFFFFFFULL;
+            w.bm[k >> 1] |= g << (32 * (k & 1));
+        }
+    }
+    int mm = 0;
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) mm += __popcll(w.bm[k]);
+    w.mm = mm;
+    w.eos = false;
+}
+
+template <int NW>
+__device__ __forceinline__ void load_read_words2(const uint64_t *__restrict__ row, uint64_t (&r2w)[NW / 2], uint64_t (&rnm)[NW / 4])
+{
+    // rows are 3*NW/4 words = a multiple of 16 bytes
+    const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(row);
+    uint64_t v[3 * NW / 4];
+#pragma unroll
+    for (int q = 0; q < 3 * NW / 8; q++) {
+        uint4 u = p[q];
+        v[2 * q] = ((uint64_t)u.y << 32) | u.x;
+        v[2 * q + 1] = ((uint64_t)u.w << 32) | u.z;
+    }
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) r2w[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) rnm[k] = v[NW / 2 + k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_light: one lane per read, reads of <= 16*NW bases whose core intervals are all <= heavy_thresh
 // long.  Same contract as k_extend (which stays for longer reads); differences: the window is
 // evaluated once in registers, bounds come from the EOS test instead of the entry table, and calls
@@ -1152,10 +1281,20 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             const int ofs = c * c_cd < last ? c * c_cd : last;
             uint8_t rec = kRecSkip;
             if (loci >= (uint64_t)ofs) {
-                uint64_t rw[NW];
-                load_read_words<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, rw);
+                const uint64_t t0 = loci - (uint64_t)ofs;
                 Window<NW> w;
-                eval_window<NW>(rw, c_len, ix.tgt4, loci - (uint64_t)ofs, w);
+                bool flg = true;
+                if (b.rd2 != nullptr) {
+                    flg = window_flagged(ix, t0, c_len);                 // issued together with the loads below
+                    uint64_t r2w[NW / 2], rnm[NW / 4];
+                    load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
+                    eval_window2<NW>(r2w, rnm, c_len, ix.tgt2, t0, w);
+                }
+                if (flg) {                                               // N/EOS nearby (rare): the 4-bit copy decides
+                    uint64_t rw[NW];
+                    load_read_words<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, rw);
+                    eval_window<NW>(rw, c_len, ix.tgt4, t0, w);
+                }
                 bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
                 for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
                 if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
@@ -1341,6 +1480,20 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
 #pragma unroll
             for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);      // same read for the whole wave
+            uint64_t r2w[NW / 2], rnm[NW / 4];
+            const bool two_bit = b.rd2 != nullptr;
+            if (two_bit) {
+                load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (3 * NW / 4), r2w, rnm);
+#pragma unroll
+                for (int k = 0; k < NW / 2; k++) r2w[k] = uniform64(r2w[k]);
+#pragma unroll
+                for (int k = 0; k < NW / 4; k++) rnm[k] = uniform64(rnm[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW / 2; k++) r2w[k] = 0;
+#pragma unroll
+                for (int k = 0; k < NW / 4; k++) rnm[k] = 0;
+            }
             if (lane < nc) {
                 uint64_t slot = iv_slot(b, r, st, lane);
                 core[lane].first = b.iv_first[slot];
@@ -1369,7 +1522,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 #pragma unroll
                     for (int k = 0; k < NW / 4; k++) w.bm[k] = ~0ULL;
                     if (valid) {
-                        eval_window<NW>(rw, len, ix.tgt4, t, w);
+                        // the block-flag load and the 2-bit window loads are issued together; only the rare
+                        // flagged window is then fetched again from the 4-bit copy
+                        if (two_bit) {
+                            const bool flg = window_flagged(ix, t, len);
+                            eval_window2<NW>(r2w, rnm, len, ix.tgt2, t, w);
+                            if (flg) eval_window<NW>(rw, len, ix.tgt4, t, w);
+                        } else
+                            eval_window<NW>(rw, len, ix.tgt4, t, w);
                         valid = !w.eos && (!lazy || core_clean<NW>(w, ofs, cl));
                     }
                     bool dup = false;
@@ -2065,6 +2225,20 @@ void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t
     uint32_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (n) hipLaunchKernelGGL(k_max_len, dim3(blocks), dim3(256), 0, s, lens, n, out);
+}
+
+void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s)
+{
+    uint64_t blocks = (nwords4 / 4 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_pack_target2, dim3((unsigned)blocks), dim3(256), 0, s, tgt4, nwords4, tgt2, nflag32, flag_shift);
+}
+
+void launch_pack_reads2(const DevBatch &b, int nw, hipStream_t s)
+{
+    unsigned blocks = (unsigned)((2ULL * b.n_reads + 255) / 256);
+    if (nw <= 8) hipLaunchKernelGGL(k_pack_reads2<8>, dim3(blocks), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(k_pack_reads2<16>, dim3(blocks), dim3(256), 0, s, b);
 }
 
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
