@@ -76,6 +76,7 @@ struct DevBatch {
     unsigned long long *ctr;          // [0] n_search [1] n_cand [2] n_lcm [3] n_heavy
     uint32_t wpr;
     uint32_t n_reads;
+    uint32_t nw;                // 4-bit words covered by an rd2 row (8 or 16), 0 without rd2
 };
 
 struct HeavyScratch {

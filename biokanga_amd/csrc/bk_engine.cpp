@@ -18,7 +18,6 @@ namespace bk {
 // launchers defined in bk_kernels.hip
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
-void launch_pack_reads2(const DevBatch &b, int nw, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
@@ -467,13 +466,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
+    b.nw = two_bit ? (uint32_t)nw16 : 0u;
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
 
     hipEvent_t e0 = tm.begin(s);
+    // the pack kernel has one thread per 4-bit word of a row (wpr of them); an rd2 row covers nw words
+    if (two_bit && (uint32_t)nw16 > wpr) HIP_TRY(hipMemsetAsync(c->d_rd2, 0, (size_t)n * 2 * (3 * nw16 / 4) * 8, s));
     launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
-    if (two_bit) launch_pack_reads2(b, nw16, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e0, s);
     HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));

@@ -106,6 +106,16 @@ __device__ __forceinline__ uint32_t squeeze2(uint64_t x)
     return (uint32_t)x;
 }
 
+__device__ __forceinline__ uint32_t flags_to_bits16(uint64_t f)   // f: flags at bit 0 of each nibble, base 0 in the top nibble
+{
+    uint64_t g = __brevll(f) >> 3;                                 // flag of base k now at bit 4k
+    g = (g | (g >> 3)) & 0x0303030303030303ULL;
+    g = (g | (g >> 6)) & 0x000F000F000F000FULL;
+    g = (g | (g >> 12)) & 0x000000FF000000FFULL;
+    g = (g | (g >> 24)) & 0xFFFFULL;
+    return (uint32_t)g;                                            // bit k = base k
+}
+
 __device__ __forceinline__ uint64_t ktab_get(const DevIndex &ix, uint64_t c)
 {
     return ix.ktab32 ? (uint64_t)ix.ktab32[c] : ix.ktab64[c];
@@ -362,6 +372,13 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
         }
     }
     b.rd4[r * per_read + rem] = v;
+    if (b.rd2 != nullptr && w < b.nw) {
+        // the same 16 bases for the 2-bit window compare: half a word at 2 bit/base (N held as A) and 16 bits of
+        // "read base is N" in the mismatch-map format (see eval_window2); each thread stores its own piece
+        uint64_t *row = b.rd2 + (r * 2 + st) * (uint64_t)(3 * b.nw / 4);
+        reinterpret_cast<uint32_t *>(row)[2 * (w >> 1) + ((w & 1) ? 0 : 1)] = squeeze2(v);
+        reinterpret_cast<uint16_t *>(row + b.nw / 2)[w] = (uint16_t)flags_to_bits16((v >> 2) & 0x1111111111111111ULL);
+    }
 }
 
 __global__ void __launch_bounds__(1024) k_init_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
@@ -802,15 +819,6 @@ struct Window {
     bool eos;
 };
 
-__device__ __forceinline__ uint32_t flags_to_bits16(uint64_t f)   // f: flags at bit 0 of each nibble, base 0 in the top nibble
-{
-    uint64_t g = __brevll(f) >> 3;                                 // flag of base k now at bit 4k
-    g = (g | (g >> 3)) & 0x0303030303030303ULL;
-    g = (g | (g >> 6)) & 0x000F000F000F000FULL;
-    g = (g | (g >> 12)) & 0x000000FF000000FFULL;
-    g = (g | (g >> 24)) & 0xFFFFULL;
-    return (uint32_t)g;                                            // bit k = base k
-}
 
 template <int NW>
 __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, const uint64_t *__restrict__ tgt, uint64_t t,
@@ -911,37 +919,6 @@ __device__ __forceinline__ void load_read_words(const uint64_t *__restrict__ rdw
 // words of "this read base is N" in the mismatch-map format; target side: DevIndex::tgt2.  Only for
 // windows whose 64-base blocks hold no N/EOS (window_flagged), where a read N always is a mismatch and
 // nothing else can differ from the 4-bit compare.
-
-template <int NW>
-__global__ void __launch_bounds__(256) k_pack_reads2(DevBatch b)
-{
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (read, strand)
-    if (i >= 2ULL * b.n_reads) return;
-    const uint64_t *src = b.rd4 + i * b.wpr;
-    uint64_t *dst = b.rd2 + i * (3 * NW / 4);
-    uint64_t r4[NW];
-    const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(src);
-#pragma unroll
-    for (int q = 0; q < NW / 2; q++) {
-        if (2 * q < (int)b.wpr) {
-            uint4 v = p[q];
-            r4[2 * q] = ((uint64_t)v.y << 32) | v.x;
-            r4[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
-        } else {
-            r4[2 * q] = 0;
-            r4[2 * q + 1] = 0;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NW / 2; k++) dst[k] = ((uint64_t)squeeze2(r4[2 * k]) << 32) | squeeze2(r4[2 * k + 1]);
-#pragma unroll
-    for (int q = 0; q < NW / 4; q++) {
-        uint64_t m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) m |= (uint64_t)flags_to_bits16((r4[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
-        dst[NW / 2 + q] = m;
-    }
-}
 
 __device__ __forceinline__ bool window_flagged(const DevIndex &ix, uint64_t t, int len)
 {
@@ -1170,6 +1147,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 // MaxIter cannot trigger, every interval is walked to its end, and "already reached through an
 // earlier core" is exactly "that earlier core matches here" (see k_wave for the general case).
 
+constexpr uint32_t kLdsEntries = 128;     // entry tables up to this size are searched in LDS
 constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
 constexpr uint8_t kRecSkip = 255;
 
@@ -1189,11 +1167,14 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
+    __shared__ uint64_t s_es[kLdsEntries], s_ee[kLdsEntries];          // entry table, when it is small enough
     const uint32_t t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     if (t < 4) s_cnt[t] = 0;
     if (t == 4) s_cmax = 0;
     if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
+    const bool ent_lds = ix.n_ent <= kLdsEntries;
+    if (ent_lds && t < ix.n_ent) { s_es[t] = ix.ent_start[t]; s_ee[t] = ix.ent_end[t]; }
 
     const uint32_t a = blockIdx.x * blockDim.x + t;
     const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
@@ -1343,7 +1324,16 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
                 const int ofs = c * cd < last ? c * cd : last;
                 hit_left = sa_get<WIDE>(ix, b.iv_first[iv_slot(b, r, st, c)] + best_j) - (uint64_t)ofs;
                 hit_strand = st ? '-' : '+';
-                e = find_entry(ix, hit_left);
+                if (ent_lds) {
+                    int lo = 0, hi = (int)ix.n_ent - 1;
+                    while (lo <= hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (hit_left < s_es[mid]) hi = mid - 1;
+                        else if (hit_left > s_ee[mid]) lo = mid + 1;
+                        else { e = mid; break; }
+                    }
+                } else
+                    e = find_entry(ix, hit_left);
             }
             write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
         } else if (phase + 1 < n_phases) {
@@ -1619,10 +1609,16 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
         if (rslt != BK_HR_NONE) {
-            if (lane == 0) {
-                int e = low_inst >= 1 ? find_entry(ix, hit_left) : -1;
-                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, (phase << 1) | 1);
+            int e = -1;
+            if (low_inst >= 1) {
+                if (ix.n_ent <= 64) {       // one entry per lane, one round trip
+                    bool in = (uint32_t)lane < ix.n_ent && hit_left >= ix.ent_start[lane] && hit_left <= ix.ent_end[lane];
+                    uint64_t m = __ballot(in);
+                    e = m ? __ffsll((unsigned long long)m) - 1 : -1;
+                } else if (lane == 0)
+                    e = find_entry(ix, hit_left);
             }
+            if (lane == 0) write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, (phase << 1) | 1);
         } else if (phase + 1 < p.n_phases) {
             int mm2, cl2, cd2, dummy[1];
             phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
@@ -2232,13 +2228,6 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
     uint64_t blocks = (nwords4 / 4 + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_pack_target2, dim3((unsigned)blocks), dim3(256), 0, s, tgt4, nwords4, tgt2, nflag32, flag_shift);
-}
-
-void launch_pack_reads2(const DevBatch &b, int nw, hipStream_t s)
-{
-    unsigned blocks = (unsigned)((2ULL * b.n_reads + 255) / 256);
-    if (nw <= 8) hipLaunchKernelGGL(k_pack_reads2<8>, dim3(blocks), dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(k_pack_reads2<16>, dim3(blocks), dim3(256), 0, s, b);
 }
 
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)

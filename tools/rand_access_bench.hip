@@ -72,10 +72,10 @@ int main(int argc, char **argv)
     hipMemset(tab, 1, maxn * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (uint64_t bytes : {64ULL << 20, 1ULL << 30, 16ULL << 30}) {
+    for (uint64_t bytes : {16ULL << 10, 2ULL << 20, 24ULL << 20, 128ULL << 20, 16ULL << 30}) {
         uint64_t mask = bytes / 8 - 1;
         for (int dep = 0; dep < 2; dep++)
-        for (int occ : {1024, 2048, 4096, 8192}) {          // blocks of 256 threads
+        for (int occ : {2048, 8192}) {          // blocks of 256 threads
             auto run = [&](int ilp, auto kern) {
                 int iters = 64;
                 hipLaunchKernelGGL(kern, dim3(occ), dim3(256), 0, 0, tab, mask, out, 4, dep);
