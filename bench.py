@@ -283,6 +283,8 @@ def main():
                     help="reads given to the real reference binary (oracle/_ref/biokanga) in the cpu_baseline leg; 0 = port only. "
                          "Kept at 2 M: the reference's loader hand-off breaks when loading takes > 3 s (Aligner.cpp:4822) - "
                          "3 M reads crash it on the MI355X host about every other run (tools/ref_scaling.py)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
+    ap.add_argument("--force-device", type=int, default=-1, help="dry runs: put every rank on this GPU instead of LOCAL_RANK")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
     ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
@@ -296,6 +298,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.force_device >= 0:
+        local_rank = args.force_device
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     torch.cuda.set_device(local_rank)
@@ -303,7 +307,20 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
+
+    def all_reduce(t, op=None):
+        """in place; through host memory when the backend is not RCCL"""
+        kw = {} if op is None else {"op": op}
+        if args.dist_backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
 
     def barrier():
         if dist is not None:
@@ -354,7 +371,7 @@ def main():
         c = al.seq_counts(reset=True)
         counts_dev.copy_(torch.from_numpy(c.astype(np.int64)))
         if dist is not None:
-            dist.all_reduce(counts_dev)
+            all_reduce(counts_dev)
 
     for _ in range(args.warmup):
         step()
@@ -380,7 +397,7 @@ def main():
     elapsed = time.time() - t_start
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ctr = al.counters()

@@ -49,6 +49,11 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
 int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_size, hipStream_t s);
+int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
+                     void *tmp, size_t *tmp_bytes, hipStream_t s);
+void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s);
+void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
+                      hipStream_t s);
 }  // namespace bk
 
 using namespace bk;
@@ -83,6 +88,12 @@ struct bk_ctx {
     int use_tgt2 = 1;
     uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
+    uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
+    void *d_sort_tmp = nullptr;
+    uint64_t cap_sort = 0;
+    size_t sort_tmp_bytes = 0;
+    int sort_lists = 1;      // bit 0: search work list, bit 1: wave list (no gain measured) are grouped by index position
+    int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
@@ -373,6 +384,8 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
     launch_pack_target(d_seq, n, c->d_tgt4, nwords, c->stream);
     HIP_TRY(hipGetLastError());
     c->n_tgt4_words = nwords;
+    c->sort_shift = 0;
+    while ((n >> c->sort_shift) >= (1ULL << 32)) c->sort_shift++;
     HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
     if (el == 5) {
         HIP_TRY(hipMalloc(&c->d_sa_hi, n));
@@ -438,6 +451,37 @@ struct EvTimer {
 };
 
 // one chunk of reads, all phases.  Blocking (host reads back the active counts between phases).
+// Work-list grouping.  A list is reordered so that items touching the same part of the index (same k-mer
+// bucket / same core interval: reads from one repeat family) sit next to each other: neighbouring lanes then
+// walk the same bisection path (their loads coalesce) and neighbouring waves fetch the same target windows
+// (L2 hits instead of HBM misses).  Results do not depend on the order.
+static int ensure_sort_scratch(bk_ctx *c, uint32_t n, hipStream_t s)
+{
+    if (n <= c->cap_sort) return BK_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (auto &p : c->d_sort) { free_dev(p); p = nullptr; }
+    free_dev(c->d_sort_tmp);
+    c->d_sort_tmp = nullptr;
+    c->cap_sort = 0;
+    const uint64_t cap = (uint64_t)n + n / 4;
+    for (auto &p : c->d_sort) HIP_TRY(hipMalloc(&p, cap * 4));
+    size_t tb = 0;
+    if (sort_list_by_key(nullptr, nullptr, nullptr, nullptr, (uint32_t)cap, nullptr, &tb, s)) return BK_ERR_INTERNAL;
+    HIP_TRY(hipMalloc(&c->d_sort_tmp, tb));
+    c->sort_tmp_bytes = tb;
+    c->cap_sort = cap;
+    return BK_OK;
+}
+
+// keys are expected in d_sort[0]; returns the reordered list (d_sort[2])
+static int sort_work(bk_ctx *c, const uint32_t *list, uint32_t n, hipStream_t s, const uint32_t **out)
+{
+    size_t tb = c->sort_tmp_bytes;
+    if (sort_list_by_key(c->d_sort[0], c->d_sort[1], list, c->d_sort[2], n, c->d_sort_tmp, &tb, s)) return BK_ERR_INTERNAL;
+    *out = c->d_sort[2];
+    return BK_OK;
+}
+
 static inline uint32_t words_per_read(uint32_t maxlen)
 {
     return ((maxlen + 15) / 16 + 2) & ~1u;      // even: every packed row starts 16-byte aligned
@@ -504,7 +548,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                launch_search_b(c->ix, c->cfg, b, phase, lazy, c->d_slist, hm[8], s);
+                const uint32_t *slist = c->d_slist;
+                if ((c->sort_lists & 1) && hm[8] >= 4096) {
+                    int rs = ensure_sort_scratch(c, hm[8], s);
+                    if (rs) return rs;
+                    launch_keys_search(b, c->d_slist, hm[8], c->sort_shift, c->d_sort[0], s);
+                    rs = sort_work(c, c->d_slist, hm[8], s, &slist);
+                    if (rs) return rs;
+                }
+                launch_search_b(c->ix, c->cfg, b, phase, lazy, slist, hm[8], s);
             } else
                 launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, s);
             HIP_TRY(hipGetLastError());
@@ -526,7 +578,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         uint32_t n_heavy = hm[2], n_wave = hm[6];
         if (n_wave) {
             hipEvent_t e3 = tm.begin(s);
-            launch_wave(c->ix, c->cfg, b, c->d_wave, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
+            const uint32_t *wlist = c->d_wave;
+            if ((c->sort_lists & 2) && n_wave >= 4096) {
+                int rs = ensure_sort_scratch(c, n_wave, s);
+                if (rs) return rs;
+                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, c->sort_shift, c->d_sort[0], s);
+                rs = sort_work(c, c->d_wave, n_wave, s, &wlist);
+                if (rs) return rs;
+            }
+            launch_wave(c->ix, c->cfg, b, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
@@ -724,7 +784,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -777,6 +837,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
         return rc ? rc : old;
+    }
+    if (n == "sort_lists") {
+        int64_t old = c->sort_lists;
+        c->sort_lists = (int)value & 3;
+        return old;
     }
     if (n == "use_tgt2") {
         int64_t old = c->use_tgt2;

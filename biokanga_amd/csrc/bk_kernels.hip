@@ -2287,6 +2287,50 @@ void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, 
     }
 }
 
+// keys for grouping work items that touch the same part of the index (see bk_engine.cpp, sort_work):
+// search items by the start of their k-mer bucket, wave items by the start of their longest core interval
+__global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t *__restrict__ list, uint32_t n, int shift,
+                                                     uint32_t *__restrict__ keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (uint32_t)(b.iv_first[list[i]] >> shift);
+}
+
+__global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, int phase, const uint32_t *__restrict__ list,
+                                                   uint32_t n, int shift, uint32_t *__restrict__ keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i];
+    const int len = (int)b.lens[r];
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd, dummy[1];
+    phase_params(p, cfg, phase, mm, cl, cd);
+    int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+    if (nc > kMaxCoresFast) nc = kMaxCoresFast;
+    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+    uint32_t best_n = 0;
+    uint64_t best_first = 0;
+    for (int st = s0; st <= s1; st++)
+        for (int c = 0; c < nc; c++) {
+            uint64_t slot = iv_slot(b, r, st, c);
+            uint32_t cnt = b.iv_n[slot] & ~kLazyFlag;
+            if (cnt > best_n) { best_n = cnt; best_first = b.iv_first[slot]; }
+        }
+    keys[i] = (uint32_t)(best_first >> shift);
+}
+
+void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_keys_search, dim3((n + 255) / 256), dim3(256), 0, s, b, list, n, shift, keys);
+}
+
+void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
+                      hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys);
+}
+
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s)
 {

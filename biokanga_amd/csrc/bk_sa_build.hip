@@ -160,4 +160,16 @@ done:
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Work-list sort used by the aligner: reorders a list of 32-bit items by 32-bit keys (rocPRIM radix sort).
+// Called with tmp == nullptr it only reports the temporary storage needed.
+int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
+                     void *tmp, size_t *tmp_bytes, hipStream_t s)
+{
+    size_t tb = *tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 32, s);
+    if (tmp == nullptr) *tmp_bytes = tb;
+    return e == hipSuccess ? 0 : -100;
+}
+
 }  // namespace bk
