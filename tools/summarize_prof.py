@@ -17,7 +17,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(?:bk::)?(k_\w+(?:<[^>]*>)?)", name)
+    m = re.search(r"bk::(k_\w+(?:<[^>]*>)?)", name) or re.match(r"(k_calib\w+)", name)
     return m.group(1) if m else None
 
 
