@@ -59,8 +59,6 @@ struct DevAlignCfg {            // derived once per context (CAligner::LocateCor
     int max_subs, mm_delta, align_strand, max_ns, max_hits;
     int min_core_len, slides_per100, max_iter;
     int heavy_thresh;           // intervals longer than this go to the wave-per-read kernel
-    int exp;                    // experiment bits for timing studies only (0 in production): 1 = no seq_counts
-                                // atomics, 2 = no counter atomics
 };
 
 struct DevBatch {

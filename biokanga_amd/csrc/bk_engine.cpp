@@ -819,11 +819,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->cfg.heavy_thresh = (int)value;     // 0 routes every call with a non-empty interval to k_heavy
         return old;
     }
-    if (n == "exp") {
-        int64_t old = c->cfg.exp;
-        c->cfg.exp = (int)value;
-        return old;
-    }
     if (n == "chunk_reads") {
         int64_t old = c->chunk_reads;
         if (value < 1 || value > (1LL << 30)) return BK_ERR_PARAMS;

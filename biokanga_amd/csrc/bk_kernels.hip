@@ -798,9 +798,9 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         n_lcm += __shfl_down(n_lcm, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm && !(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm);
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
     }
 }
 
@@ -1375,7 +1375,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
     if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
     if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
     if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8] && !(cfg.exp & 2)) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
     __syncthreads();
     if (dest == 1) next_act[s_base[1] + my_off] = r;
     else if (dest == 2) wave[s_base[2] + my_off] = r;
@@ -1632,10 +1632,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     if (pend_n) flush_pending();
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
-        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { if (!(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm); if (!(cfg.exp & 2)) atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[4], n_cand);
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
@@ -1855,10 +1855,10 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     }
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
-        if (n_search && !(cfg.exp & 2)) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { if (!(cfg.exp & 2)) atomicAdd(&b.ctr[2], n_lcm); if (!(cfg.exp & 2)) atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand && !(cfg.exp & 2)) atomicAdd(&b.ctr[4], n_cand);
+        if (n_search) atomicAdd(&b.ctr[0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
     }
 }
 
