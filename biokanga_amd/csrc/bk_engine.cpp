@@ -544,6 +544,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                     c->cap_slist = lanes;
                 }
                 HIP_TRY(hipMemsetAsync(sm + 8, 0, 4, s));
+                // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
+                for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
+                    HIP_TRY(hipMemsetAsync(c->d_iv_n + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 4, s));
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
