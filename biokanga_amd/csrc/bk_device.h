@@ -67,8 +67,9 @@ struct DevBatch {
     const uint32_t *lens;
     uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp)
     uint64_t *rd2;              // [read][strand][3*NW/4]: NW/2 words at 2 bit/base + NW/4 words of N mask; may be null
-    uint64_t *iv_first;         // [read][strand][kMaxCoresFast]
-    uint32_t *iv_n;
+    uint64_t *iv_first;         // core intervals [strand][core][read]: start (suffix array index) ...
+    uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
+    uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null
     bk_hit *out;
     unsigned long long *seq_counts;   // per entry accepted reads
     unsigned long long *ctr;          // [0] n_search [1] n_cand [2] n_lcm [3] n_heavy

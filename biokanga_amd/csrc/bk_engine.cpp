@@ -111,6 +111,7 @@ struct bk_ctx {
     // batch scratch (grown on demand)
     uint32_t cap_reads = 0, cap_wpr = 0;
     uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
+    uint2 *d_iv2 = nullptr;
     uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror
@@ -404,15 +405,19 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
 {
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
-    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave);
-    c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr;
+    c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
     if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8));
-    HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
-    HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * kMaxCoresFast * 4));
+    if (c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32))
+        HIP_TRY(hipMalloc(&c->d_iv2, (size_t)nr * 2 * kMaxCoresFast * 8));
+    else {
+        HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
+        HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * kMaxCoresFast * 4));
+    }
     HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
@@ -508,7 +513,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
 
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
-    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
     b.nw = two_bit ? (uint32_t)nw16 : 0u;
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
@@ -546,7 +551,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 HIP_TRY(hipMemsetAsync(sm + 8, 0, 4, s));
                 // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
                 for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    HIP_TRY(hipMemsetAsync(c->d_iv_n + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 4, s));
+                    if (c->d_iv2) HIP_TRY(hipMemsetAsync(c->d_iv2 + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 8, s));
+                    else HIP_TRY(hipMemsetAsync(c->d_iv_n + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 4, s));
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
@@ -685,7 +691,7 @@ static int pair_on_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
     if (rc) return rc;
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
-    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n;
+    b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.out = d_hits; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = nreads;
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
@@ -788,7 +794,7 @@ void bk_ctx_destroy(bk_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_rd2);
-    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);

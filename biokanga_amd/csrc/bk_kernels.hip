@@ -45,6 +45,27 @@ __device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t r, int s
     return (uint64_t)(st * kMaxCoresFast + c) * b.n_reads + r;
 }
 
+// core interval records.  4-byte indexes keep {start, count} of a slot in ONE 8-byte word (b.iv2), so every
+// access is one line; 5-byte indexes (starts beyond 2^32) keep the two arrays
+__device__ __forceinline__ uint32_t iv_count(const DevBatch &b, uint64_t slot)
+{
+    return b.iv2 ? b.iv2[slot].y : b.iv_n[slot];
+}
+__device__ __forceinline__ uint64_t iv_start(const DevBatch &b, uint64_t slot)
+{
+    return b.iv2 ? (uint64_t)b.iv2[slot].x : b.iv_first[slot];
+}
+__device__ __forceinline__ void iv_get(const DevBatch &b, uint64_t slot, uint64_t &first, uint32_t &n)
+{
+    if (b.iv2) { const uint2 v = b.iv2[slot]; first = v.x; n = v.y; }
+    else { first = b.iv_first[slot]; n = b.iv_n[slot]; }
+}
+__device__ __forceinline__ void iv_put(const DevBatch &b, uint64_t slot, uint64_t first, uint32_t n)
+{
+    if (b.iv2) b.iv2[slot] = make_uint2((uint32_t)first, n);
+    else { b.iv_first[slot] = first; b.iv_n[slot] = n; }
+}
+
 template <bool WIDE>
 __device__ __forceinline__ uint64_t sa_get(const DevIndex &ix, uint64_t i)
 {
@@ -484,14 +505,12 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
         uint64_t lo, hi;
         core_range(ix, p0, cl, lo, hi);
         if (hi - lo <= kLazyBucket && !(lo == 0 && hi == ix.n)) {
-            b.iv_first[slot] = lo;
-            b.iv_n[slot] = (uint32_t)(hi - lo) | (hi > lo ? kLazyFlag : 0u);
+            iv_put(b, slot, lo, (uint32_t)(hi - lo) | (hi > lo ? kLazyFlag : 0u));
             return;
         }
     }
     search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, count);     // exact run length
-    b.iv_first[slot] = first;
-    b.iv_n[slot] = count > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)count;
+    iv_put(b, slot, first, count > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,8 +645,7 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
             // iv_n of the phase's slots is zeroed before the launch: empty results (about 40 % of the lanes)
             // store nothing - two partial-line writes less
             if (nval != 0) {
-                b.iv_first[slot] = first;
-                b.iv_n[slot] = nval;
+                iv_put(b, slot, first, nval);
             }
         }
     }
@@ -661,14 +679,15 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     phase_params(p, cfg, phase, mm, cl, cd);
     const int my_ofs = c * cd < len - cl ? c * cd : len - cl;
     const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
-    const uint32_t raw = b.iv_n[slot];
+    uint64_t first;
+    uint32_t raw;
+    iv_get(b, slot, first, raw);
     const uint32_t kind = raw >> kKindShift;
-    uint64_t first = b.iv_first[slot], cnt = raw & ((1u << kKindShift) - 1);
+    uint64_t cnt = raw & ((1u << kKindShift) - 1);
     const int k = ix.k;
     if (kind == kKindFull) {
         search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, cnt);
-        b.iv_first[slot] = first;
-        b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+        iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
         return;
     }
     if (kind == kKindK2) {
@@ -687,15 +706,13 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         first = l1;
         cnt = l2 - l1;
         if (cnt == 0 || cl <= k + 16) {
-            b.iv_first[slot] = first;
-            b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+            iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
             return;
         }
     }
     // [first, first+cnt) agrees with the core on its first k+16 bases
     if (lazy && cnt <= kLazyBucket) {
-        b.iv_first[slot] = first;
-        b.iv_n[slot] = (uint32_t)cnt | kLazyFlag;
+        iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
         return;
     }
     {
@@ -713,8 +730,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         first = l1;
         cnt = l2 - l1;
     }
-    b.iv_first[slot] = first;
-    b.iv_n[slot] = cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt;
+    iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
 }
 
 template <bool WIDE>
@@ -737,7 +753,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         if (!is_heavy)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if (b.iv_n[iv_slot(b, r, st, c)] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if (iv_count(b, iv_slot(b, r, st, c)) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             heavy[atomicAdd(heavy_cnt, 1u)] = r;
         } else {
@@ -752,8 +768,9 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
                     uint64_t slot = iv_slot(b, r, st, c);
-                    uint32_t n = b.iv_n[slot];
-                    uint64_t first = b.iv_first[slot];
+                    uint32_t n;
+                    uint64_t first;
+                    iv_get(b, slot, first, n);
                     for (uint32_t j = 0; j < n; j++) {
                         uint64_t loci = sa_get<WIDE>(ix, first + j);
                         if (loci < (uint64_t)ofs[c]) continue;
@@ -1038,7 +1055,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
         if (fits)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if ((b.iv_n[iv_slot(b, r, st, c)] & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if ((iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
         } else {
@@ -1054,10 +1071,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
                     uint64_t slot = iv_slot(b, r, st, c);
-                    const uint32_t nraw = b.iv_n[slot];
+                    uint32_t nraw;
+                    uint64_t first;
+                    iv_get(b, slot, first, nraw);
                     const uint32_t n = nraw & ~kLazyFlag;
                     const bool lazy = (nraw & kLazyFlag) != 0;
-                    uint64_t first = b.iv_first[slot];
                     for (uint32_t j = 0; j < n; j++) {
                         uint64_t loci = sa_get<WIDE>(ix, first + j);
                         if (loci < (uint64_t)ofs[c]) continue;
@@ -1202,7 +1220,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             int q = 0;
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++) {
-                    uint32_t cnt = b.iv_n[iv_slot(b, r, st, c)] & ~kLazyFlag;
+                    uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
                     if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                     run += is_heavy ? 0 : cnt;
                     s_sp[t * slots_max + q++] = (uint16_t)run;
@@ -1260,8 +1278,11 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             const int st = s0 + q / c_nc, c = q % c_nc;
             const uint32_t cr = s_r[ri];
             const uint64_t slot = iv_slot(b, cr, st, c);
-            const bool lazy = (b.iv_n[slot] & kLazyFlag) != 0;
-            const uint64_t loci = sa_get<WIDE>(ix, b.iv_first[slot] + j);
+            uint64_t iv_f;
+            uint32_t iv_c;
+            iv_get(b, slot, iv_f, iv_c);
+            const bool lazy = (iv_c & kLazyFlag) != 0;
+            const uint64_t loci = sa_get<WIDE>(ix, iv_f + j);
             const int last = c_len - c_cl;
             const int ofs = c * c_cd < last ? c * c_cd : last;
             uint8_t rec = kRecSkip;
@@ -1326,7 +1347,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
                 const int st = s0 + best_q / nc, c = best_q % nc;
                 const int last = len - cl;
                 const int ofs = c * cd < last ? c * cd : last;
-                hit_left = sa_get<WIDE>(ix, b.iv_first[iv_slot(b, r, st, c)] + best_j) - (uint64_t)ofs;
+                hit_left = sa_get<WIDE>(ix, iv_start(b, iv_slot(b, r, st, c)) + best_j) - (uint64_t)ofs;
                 hit_strand = st ? '-' : '+';
                 if (ent_lds) {
                     int lo = 0, hi = (int)ix.n_ent - 1;
@@ -1490,8 +1511,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             }
             if (lane < nc) {
                 uint64_t slot = iv_slot(b, r, st, lane);
-                core[lane].first = b.iv_first[slot];
-                core[lane].n = b.iv_n[slot];          // bit 31: unverified bucket (<= kLazyBucket members)
+                uint64_t f;
+                uint32_t cn;
+                iv_get(b, slot, f, cn);
+                core[lane].first = f;
+                core[lane].n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
                 core[lane].walked = 0;
             }
             __builtin_amdgcn_wave_barrier();
@@ -2297,7 +2321,7 @@ __global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t 
                                                      uint32_t *__restrict__ keys)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = (uint32_t)(b.iv_first[list[i]] >> shift);
+    if (i < n) keys[i] = (uint32_t)(iv_start(b, list[i]) >> shift);
 }
 
 __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, int phase, const uint32_t *__restrict__ list,
@@ -2318,8 +2342,11 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
     for (int st = s0; st <= s1; st++)
         for (int c = 0; c < nc; c++) {
             uint64_t slot = iv_slot(b, r, st, c);
-            uint32_t cnt = b.iv_n[slot] & ~kLazyFlag;
-            if (cnt > best_n) { best_n = cnt; best_first = b.iv_first[slot]; }
+            uint64_t f;
+            uint32_t raw;
+            iv_get(b, slot, f, raw);
+            uint32_t cnt = raw & ~kLazyFlag;
+            if (cnt > best_n) { best_n = cnt; best_first = f; }
         }
     keys[i] = (uint32_t)(best_first >> shift);
 }
