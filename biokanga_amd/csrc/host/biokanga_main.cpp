@@ -240,6 +240,113 @@ struct ReadStore {
     const char *name(size_t i) const { return names.data() + name_ofs[i]; }
 };
 
+// The acceptance rules of load_reads() applied to a file that was parsed whole (fasta.h, ParsedChunk): every
+// chunk is filtered and measured by its own thread, a prefix sum gives each chunk its place in the read
+// store, and the threads copy their accepted records there.  Same records, same order, same log lines.
+int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, int trim5, int trim3, int min_len, int max_len,
+                  int nthreads, ReadStore &rs)
+{
+    const size_t nc = chunks.size();
+    bool sim = false;
+    for (const auto &c : chunks)
+        if (!c.lens.empty()) {
+            size_t dl = std::min<size_t>(c.descr_lens[0], 127);
+            sim = dl >= 14 && (!strncmp(c.descr.data(), "lcl|usimreads|", 14) || !strncmp(c.descr.data(), "lcr|usimreads|", 14));
+            break;
+        }
+    struct Tot { uint64_t n_acc = 0, n_bases = 0, n_names = 0, n_under = 0, n_over = 0, n_rec = 0; long bad_at = -1; };
+    std::vector<Tot> tot(nc);
+    std::vector<std::vector<uint32_t>> keep_name_len(nc);       // per record: accepted name length + 1, or 0 when sloughed
+    auto name_len = [&](const char *d, size_t dl) {
+        if (dl > 127) dl = 127;
+        if (sim) return dl;
+        size_t k = 0;
+        while (k < 79 && k < dl && !isspace((unsigned char)d[k])) k++;
+        return k;
+    };
+    auto run = [&](auto fn_) {
+        std::vector<std::thread> th;
+        for (int w = 1; w < nthreads; w++) th.emplace_back([&, w]() { for (size_t c = (size_t)w; c < nc; c += (size_t)nthreads) fn_(c); });
+        for (size_t c = 0; c < nc; c += (size_t)nthreads) fn_(c);
+        for (auto &t : th) t.join();
+    };
+    run([&](size_t ci) {
+        const bk::ParsedChunk &c = chunks[ci];
+        Tot &t = tot[ci];
+        auto &kn = keep_name_len[ci];
+        kn.assign(c.lens.size(), 0);
+        size_t dofs = 0;
+        for (size_t i = 0; i < c.lens.size(); i++) {
+            const int len = (int)c.lens[i];
+            const size_t dl = c.descr_lens[i];
+            t.n_rec++;
+            if (len < 1 || len > 0x30000) { if (t.bad_at < 0) t.bad_at = (long)i; }
+            else if (trim5 + trim3 + min_len > len) t.n_under++;
+            else if (trim5 + trim3 + max_len < len) t.n_over++;
+            else {
+                size_t nl = name_len(c.descr.data() + dofs, dl);
+                kn[i] = (uint32_t)nl + 1;
+                t.n_acc++;
+                t.n_bases += (uint64_t)(len - trim5 - trim3);
+                t.n_names += nl + 1;
+            }
+            dofs += dl;
+        }
+    });
+    // log lines in file order, as the serial loader prints them
+    uint64_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
+    for (size_t ci = 0; ci < nc; ci++) {
+        const bk::ParsedChunk &c = chunks[ci];
+        if (tot[ci].bad_at >= 0) { diag("Problem parsing sequence after %llu reads parsed", (unsigned long long)(n_descr + tot[ci].bad_at + 1)); return -63; }
+        if ((n_under < 10 && tot[ci].n_under) || (n_over < 10 && tot[ci].n_over))
+            for (size_t i = 0; i < c.lens.size(); i++) {
+                const int len = (int)c.lens[i];
+                if (trim5 + trim3 + min_len > len) { if (++n_under <= 10) diag("Load: under length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str()); }
+                else if (trim5 + trim3 + max_len < len) { if (++n_over <= 10) diag("Load: over length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str()); }
+            }
+        else { n_under += tot[ci].n_under; n_over += tot[ci].n_over; }
+        n_descr += tot[ci].n_rec;
+        n_acc += tot[ci].n_acc;
+    }
+    // placement
+    std::vector<uint64_t> r0(nc + 1), b0(nc + 1), m0(nc + 1);
+    r0[0] = rs.lens.size(); b0[0] = rs.bases.size(); m0[0] = rs.names.size();
+    for (size_t ci = 0; ci < nc; ci++) {
+        r0[ci + 1] = r0[ci] + tot[ci].n_acc;
+        b0[ci + 1] = b0[ci] + tot[ci].n_bases;
+        m0[ci + 1] = m0[ci] + tot[ci].n_names;
+    }
+    rs.lens.resize(r0[nc]); rs.offs.resize(r0[nc]); rs.name_ofs.resize(r0[nc]);
+    rs.bases.resize(b0[nc]);
+    rs.names.resize(m0[nc]);
+    run([&](size_t ci) {
+        bk::ParsedChunk &c = chunks[ci];
+        const auto &kn = keep_name_len[ci];
+        uint64_t r = r0[ci], bo = b0[ci], mo = m0[ci];
+        size_t dofs = 0, sofs = 0;
+        for (size_t i = 0; i < c.lens.size(); i++) {
+            const uint32_t len = c.lens[i];
+            if (kn[i]) {
+                const uint32_t keep = len - (uint32_t)trim5 - (uint32_t)trim3, nl = kn[i] - 1;
+                rs.offs[r] = bo;
+                rs.lens[r] = keep;
+                memcpy(rs.bases.data() + bo, c.bases.data() + sofs + trim5, keep);
+                rs.name_ofs[r] = mo;
+                memcpy(rs.names.data() + mo, c.descr.data() + dofs, nl);
+                rs.names[mo + nl] = '\0';
+                r++; bo += keep; mo += nl + 1;
+            }
+            dofs += c.descr_lens[i];
+            sofs += len;
+        }
+        bk::ParsedChunk().bases.swap(c.bases);
+        bk::ParsedChunk().descr.swap(c.descr);
+    });
+    diag("Load: %llu reads parsed, %llu accepted, %llu under length, %llu over length from '%s'", (unsigned long long)n_descr,
+         (unsigned long long)n_acc, (unsigned long long)n_under, (unsigned long long)n_over, fn.c_str());
+    return 0;
+}
+
 // CAligner::LoadRawReads (Aligner.cpp:10724-11427): descriptor rule, -y/-Y trims, -l/-L acceptance
 int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, int nthreads, ReadStore &rs)
 {
@@ -249,6 +356,11 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
         int rc = rd.open(fn, nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading reads from '%s'", fn.c_str());
+        if (rd.parsed()) {
+            rc = accept_chunks(rd.chunks(), fn, trim5, trim3, min_len, max_len, nthreads, rs);
+            if (rc) return rc;
+            continue;
+        }
         const char *d;
         const uint8_t *b;
         size_t dl, bl;
@@ -348,14 +460,16 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
 
 struct OutBuf {
     int fd = -1;
+    off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
     std::vector<char> b;
-    void open(const char *path) { fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644); b.reserve(8 << 20); }
+    void open(const char *path) { fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644); b.reserve(8 << 20); pos = 0; }
     void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
     void put(const std::string &s) { put(s.data(), s.size()); }
     void flush()
     {
         size_t o = 0;
-        while (o < b.size()) { ssize_t w = ::write(fd, b.data() + o, b.size() - o); if (w <= 0) break; o += (size_t)w; }
+        while (o < b.size()) { ssize_t w = ::pwrite(fd, b.data() + o, b.size() - o, pos + (off_t)o); if (w <= 0) break; o += (size_t)w; }
+        pos += (off_t)o;
         b.clear();
     }
     void close() { flush(); if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
@@ -602,7 +716,25 @@ int cmd_align(int argc, char **argv, int first)
             for (int t = 1; t < nt; t++) th.emplace_back(work, t);
             work(0);
             for (auto &t : th) t.join();
-            for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t]); n_reported += cnts[(size_t)t]; }
+            // the stripes go to their places in the file in parallel as well
+            out.flush();
+            std::vector<off_t> at((size_t)nt + 1);
+            at[0] = out.pos;
+            for (int t = 0; t < nt; t++) { at[(size_t)t + 1] = at[(size_t)t] + (off_t)bufs[(size_t)t].size(); n_reported += cnts[(size_t)t]; }
+            auto put = [&](int t) {
+                const std::string &bf = bufs[(size_t)t];
+                size_t o = 0;
+                while (o < bf.size()) {
+                    ssize_t w = ::pwrite(out.fd, bf.data() + o, bf.size() - o, at[(size_t)t] + (off_t)o);
+                    if (w <= 0) break;
+                    o += (size_t)w;
+                }
+            };
+            th.clear();
+            for (int t = 1; t < nt; t++) th.emplace_back(put, t);
+            put(0);
+            for (auto &t : th) t.join();
+            out.pos = at[(size_t)nt];
         }
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {

@@ -57,6 +57,9 @@ public:
     int open(const std::string &path, int nthreads, std::string *err);
     // 1 = record, 0 = end, < 0 = error; pointers stay valid until the next call
     int next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl);
+    // whole-file parse available: the chunks in file order (then next() need not be used)
+    bool parsed() const { return parsed_; }
+    std::vector<ParsedChunk> &chunks() { return chunks_; }
 
 private:
     SeqReader rd_;
