@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cctype>
@@ -29,6 +30,7 @@
 
 #include "../../../include/biokanga_amd.h"
 #include "../sfx_file.h"
+#include "bam_writer.h"
 #include "fasta.h"
 #include "mtqsort.h"
 
@@ -460,19 +462,28 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
 
 struct OutBuf {
     int fd = -1;
+    gzFile gz = nullptr;                    // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337)
     off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
     std::vector<char> b;
-    void open(const char *path) { fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644); b.reserve(8 << 20); pos = 0; }
+    void open(const char *path)
+    {
+        size_t n = strlen(path);
+        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz")) gz = gzdopen(fd, "wb");
+        b.reserve(8 << 20);
+        pos = 0;
+    }
     void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
     void put(const std::string &s) { put(s.data(), s.size()); }
     void flush()
     {
         size_t o = 0;
+        if (gz) { if (!b.empty()) gzwrite(gz, b.data(), (unsigned)b.size()); b.clear(); return; }
         while (o < b.size()) { ssize_t w = ::pwrite(fd, b.data() + o, b.size() - o, pos + (off_t)o); if (w <= 0) break; o += (size_t)w; }
         pos += (off_t)o;
         b.clear();
     }
-    void close() { flush(); if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
+    void close() { flush(); if (gz) { gzclose(gz); gz = nullptr; fd = -1; } if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
 };
 
 int cmd_align(int argc, char **argv, int first)
@@ -603,6 +614,151 @@ int cmd_align(int argc, char **argv, int first)
     };
     bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
 
+    auto write_stats = [&]() {
+        if (a.has("O")) {                                                    // CAligner::ReportTargHitCnts, Aligner.cpp:5475-5537
+            std::vector<uint64_t> cnt(n_ent);
+            bk_seq_counts(ctx, cnt.data(), n_ent, 0);
+            FILE *f = fopen(a.str("O").c_str(), "w");
+            if (f) {
+                fprintf(f, "\"TargSeq\",\"TargLen\",\"NumHits\"\n");
+                for (uint32_t c = 0; c < n_ent; c++)
+                    if (cnt[c]) fprintf(f, "\"%s\",%u,%llu\n", ents[c].name, ents[c].seq_len, (unsigned long long)cnt[c]);
+                fclose(f);
+            }
+        }
+    };
+
+    // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index
+    const std::string opath = a.str("o");
+    if (fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) {
+        std::vector<uint8_t> has_hit(n_ent + 1, 0);
+        for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) has_hit[h.chrom_id] = 1;
+        const bool all = (uint32_t)max_rpt_sam_seqs >= n_ent;
+        std::string text = "@HD\tVN:1.4\tSO:coordinate";
+        std::vector<int32_t> ref_of(n_ent + 1, -1);
+        std::vector<uint32_t> refs;
+        int n_with = 0;
+        char tmp[512];
+        for (uint32_t c = 1; c <= n_ent; c++) {
+            if (!has_hit[c] && !all) continue;
+            int n = snprintf(tmp, sizeof(tmp), "\n@SQ\tAS:%s\tSN:%s\tLN:%u", species.empty() ? "NA" : species.c_str(), ents[c - 1].name, ents[c - 1].seq_len);
+            text.append(tmp, (size_t)n);
+            ref_of[c] = (int32_t)refs.size();
+            refs.push_back(c);
+            n_with += has_hit[c];
+        }
+        int n = snprintf(tmp, sizeof(tmp), "\n@PG\tID:%s\tVN:%s\n", g_proc.c_str(), kProgVer);
+        text.append(tmp, (size_t)n);
+        diag("Header written with references to %d sequences of which %d have at least 1 alignments", (int)refs.size(), n_with);
+        std::vector<uint8_t> stream;
+        auto p32 = [](std::vector<uint8_t> &v, uint32_t x) { v.insert(v.end(), (uint8_t *)&x, (uint8_t *)&x + 4); };
+        stream.insert(stream.end(), {'B', 'A', 'M', 1});
+        p32(stream, (uint32_t)text.size());
+        stream.insert(stream.end(), text.begin(), text.end());
+        p32(stream, (uint32_t)refs.size());
+        for (uint32_t c : refs) {
+            uint32_t ln = (uint32_t)strlen(ents[c - 1].name) + 1;
+            p32(stream, ln);
+            stream.insert(stream.end(), ents[c - 1].name, ents[c - 1].name + ln);
+            p32(stream, ents[c - 1].seq_len);
+        }
+        // records (CAligner::ReportBAMread, Aligner.cpp:5768-6126; CSAMfile::AddAlignment, SAMfile.cpp:2283-2540),
+        // formatted in stripes of the sorted order by all host threads
+        static const uint8_t code4[8] = {1, 2, 4, 8, 15, 15, 15, 15}, comp4[8] = {8, 4, 2, 1, 15, 15, 15, 15};
+        struct Stripe { std::vector<uint8_t> bytes; std::vector<bk::BamAligned> al; uint64_t n = 0; };
+        const size_t per_thread = 32768;
+        const size_t n_stripes = (nr + per_thread - 1) / per_thread;
+        std::vector<Stripe> stripes(n_stripes);
+        auto format_stripe = [&](size_t si) {
+            Stripe &S = stripes[si];
+            const size_t lo = si * per_thread, hi = std::min(nr, lo + per_thread);
+            std::vector<uint8_t> &v = S.bytes;
+            for (size_t k = lo; k < hi; k++) {
+                const uint32_t i = order[k];
+                const bk_hit &h = hits[i];
+                const bool acc = h.nar == BK_NAR_ACCEPTED;
+                if (!acc && fmt != 6) continue;
+                const uint8_t *sq = rs.bases.data() + rs.offs[i];
+                const uint32_t len = rs.lens[i];
+                int flag = 0, tlen = 0;
+                long pnext = -1;
+                if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
+                else {
+                    const bool first_of_pair = (i & 1) == 0;
+                    const bk_hit &m = hits[first_of_pair ? i + 1 : i - 1];
+                    flag = 0x1 | 0x2 | (first_of_pair ? 0x40 : 0x80);
+                    flag |= acc ? (h.strand == '+' ? 0 : 0x10) : 0x4;
+                    if ((h.flags & 0x80) && (m.flags & 0x80) && m.nar == BK_NAR_ACCEPTED) {
+                        flag |= m.strand == '+' ? 0 : 0x20;
+                        if (acc) {
+                            pnext = (long)m.match_loci;
+                            long s0 = (long)h.match_loci, s1 = (long)m.match_loci;
+                            tlen = (int)(s0 <= s1 ? (s1 - s0) + m.match_len : (s0 - s1) + h.match_len);
+                        }
+                    } else
+                        flag |= 0x8;
+                }
+                const char *qn = rs.name(i);
+                const uint32_t l_qn = (uint32_t)strlen(qn) + 1;
+                const char *tag = acc ? nullptr : kNarTag[h.nar < 20 ? h.nar : 0];
+                const uint32_t aux = tag ? 3 + (uint32_t)strlen(tag) + 1 : 0;
+                const uint32_t block = 32 + l_qn + 4 + (len + 1) / 2 + len + aux;
+                const size_t at = v.size();
+                v.resize(at + 4 + block);
+                uint8_t *q = v.data() + at;
+                auto w32 = [&](uint32_t x) { memcpy(q, &x, 4); q += 4; };
+                w32(block);
+                const int32_t ref = acc ? ref_of[h.chrom_id] : -1;
+                w32((uint32_t)ref);
+                w32(acc ? h.match_loci : 0xFFFFFFFFu);
+                const uint32_t bin = acc ? (uint32_t)bk::bam_reg2bin((int)h.match_loci, (int)(h.match_loci + h.match_len)) : 0u;
+                w32(bin << 16 | 255u << 8 | l_qn);
+                w32((uint32_t)flag << 16 | 1u);
+                w32(len);
+                w32(acc && pnext >= 0 ? (uint32_t)ref : 0xFFFFFFFFu);
+                w32(acc ? (uint32_t)pnext : 0xFFFFFFFFu);
+                w32((uint32_t)tlen);
+                memcpy(q, qn, l_qn); q += l_qn;
+                w32((acc ? (uint32_t)h.match_len : len) << 4);
+                uint8_t byte = 0;
+                for (uint32_t o = 0; o < len; o++) {
+                    uint8_t c4 = (acc && h.strand != '+') ? comp4[sq[len - 1 - o] & 7] : code4[sq[o] & 7];
+                    if (!(o & 1)) byte = (uint8_t)(c4 << 4);
+                    else byte |= c4;
+                    if ((o & 1) || o == len - 1) *q++ = byte;
+                }
+                memset(q, 0xff, len); q += len;
+                if (tag) { *q++ = 'Y'; *q++ = 'U'; *q++ = 'Z'; size_t tl = strlen(tag) + 1; memcpy(q, tag, tl); q += tl; }
+                if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)h.match_loci, (int32_t)(h.match_loci + h.match_len - 1)});
+                S.n++;
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            auto work = [&](int w) { for (size_t si = (size_t)w; si < n_stripes; si += (size_t)nthreads) format_stripe(si); };
+            for (int w = 1; w < nthreads; w++) th.emplace_back(work, w);
+            work(0);
+            for (auto &t : th) t.join();
+        }
+        std::vector<bk::BamAligned> aligned;
+        uint64_t flush_at = 0, n_rep = 0;
+        for (Stripe &S : stripes) {
+            const uint64_t base = stream.size();
+            for (bk::BamAligned al : S.al) { al.u_beg += base; al.u_end += base; aligned.push_back(al); flush_at = al.u_end; }
+            stream.insert(stream.end(), S.bytes.begin(), S.bytes.end());
+            n_rep += S.n;
+            std::vector<uint8_t>().swap(S.bytes);
+        }
+        std::string berr;
+        rc = bk::write_bam_and_bai(opath, stream, aligned, flush_at, (uint32_t)refs.size(), nthreads, &berr);
+        if (rc) { diag("Fatal: %s", berr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        diag("Completed reporting BAM %llu read alignments", (unsigned long long)n_rep);
+        diag("Reporting of aligned result set completed");
+        write_stats();
+        bk_ctx_destroy(ctx);
+        return 0;
+    }
+
     OutBuf out;
     out.open(a.str("o").c_str());
     if (out.fd < 0) { diag("Fatal: unable to create '%s'", a.str("o").c_str()); bk_ctx_destroy(ctx); return 1; }
@@ -716,6 +872,10 @@ int cmd_align(int argc, char **argv, int first)
             for (int t = 1; t < nt; t++) th.emplace_back(work, t);
             work(0);
             for (auto &t : th) t.join();
+            if (out.gz) {                    // compressed SAM: one deflate stream, in order
+                for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t]); n_reported += cnts[(size_t)t]; }
+                continue;
+            }
             // the stripes go to their places in the file in parallel as well
             out.flush();
             std::vector<off_t> at((size_t)nt + 1);
@@ -753,17 +913,7 @@ int cmd_align(int argc, char **argv, int first)
     out.close();
     diag("Reporting of aligned result set completed");
 
-    if (a.has("O")) {                                                    // CAligner::ReportTargHitCnts, Aligner.cpp:5475-5537
-        std::vector<uint64_t> cnt(n_ent);
-        bk_seq_counts(ctx, cnt.data(), n_ent, 0);
-        FILE *f = fopen(a.str("O").c_str(), "w");
-        if (f) {
-            fprintf(f, "\"TargSeq\",\"TargLen\",\"NumHits\"\n");
-            for (uint32_t c = 0; c < n_ent; c++)
-                if (cnt[c]) fprintf(f, "\"%s\",%u,%llu\n", ents[c].name, ents[c].seq_len, (unsigned long long)cnt[c]);
-            fclose(f);
-        }
-    }
+    write_stats();
     bk_ctx_destroy(ctx);
     return 0;
 }

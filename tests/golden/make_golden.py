@@ -485,12 +485,46 @@ def make_lengths(tmp):
     print("  lengths fixture written")
 
 
+def make_bam(tmp):
+    """BAM + BAI as the reference writes them (output name ending in ".bam"): SE -M6 -s3 on the basic fixture and
+    PE -U3.  Stored as they are (BGZF is already compressed)."""
+    basic = os.path.join(HERE, "basic")
+    pe = os.path.join(HERE, "pe")
+    sfx = os.path.join(tmp, "bam.sfx")
+    with gzip.open(os.path.join(basic, "genome.sfx.gz"), "rb") as f, open(sfx, "wb") as g:
+        shutil.copyfileobj(f, g)
+    def gunz(src, dst):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    rd = os.path.join(tmp, "bam_reads.fa")
+    gunz(os.path.join(basic, "reads.fa.gz"), rd)
+    out = os.path.join(tmp, "out_s3m6.bam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"], tmp)
+    shutil.copy(out, os.path.join(basic, "s3.m6.bam"))
+    shutil.copy(out + ".bai", os.path.join(basic, "s3.m6.bam.bai"))
+    out = os.path.join(tmp, "out_s3m5.bam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M5", "-s3", "-T4"], tmp)
+    shutil.copy(out, os.path.join(basic, "s3.m5.bam"))
+    shutil.copy(out + ".bai", os.path.join(basic, "s3.m5.bam.bai"))
+    r1, r2 = os.path.join(tmp, "bam_r1.fa"), os.path.join(tmp, "bam_r2.fa")
+    gunz(os.path.join(pe, "reads_1.fa.gz"), r1)
+    gunz(os.path.join(pe, "reads_2.fa.gz"), r2)
+    out = os.path.join(tmp, "out_U3m6.bam")
+    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", out, "-M6", "-s5", "-U3", "-d200", "-D400", "-T4"], tmp)
+    shutil.copy(out, os.path.join(pe, "U3.m6.bam"))
+    shutil.copy(out + ".bai", os.path.join(pe, "U3.m6.bam.bai"))
+    print("  bam fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-bam" in sys.argv:
+            make_bam(tmp)
             return
         if "--only-lengths" in sys.argv:
             make_lengths(tmp)
@@ -503,6 +537,7 @@ def main():
         make_sortorder(tmp)
         make_pe(tmp)
         make_lengths(tmp)
+        make_bam(tmp)
     print("done")
 
 

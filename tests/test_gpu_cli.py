@@ -111,3 +111,31 @@ def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags):
         run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
              "-o", out] + flags, str(tmp_path))
         assert open(out, "rb").read() == golden_bytes("pe", "U3.m5.sam.gz")
+
+
+@pytest.mark.parametrize("fixture,name,flags", [
+    ("basic", "s3.m6.bam", ["-M6", "-s3"]), ("basic", "s3.m5.bam", ["-M5", "-s3"]),
+    ("pe", "U3.m6.bam", ["-M6", "-s5", "-U3", "-d200", "-D400"])])
+def test_align_bam_and_bai_byte_identical(golden_tmp, tmp_path, fixture, name, flags):
+    """output name ending in '.bam': BGZF blocks, BAM records and the BAI index are the reference's, byte for byte"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "out_align.bam")
+    if fixture == "pe":
+        pe = os.path.join(helpers.GOLDEN, "pe")
+        inputs = ["-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz")]
+    else:
+        inputs = ["-i", os.path.join(d, "reads.fa")]
+    run(["align"] + inputs + ["-I", os.path.join(d, "genome.sfx"), "-o", out] + flags, str(tmp_path))
+    exp = open(os.path.join(helpers.GOLDEN, fixture, name), "rb").read()
+    got = open(out, "rb").read()
+    assert gzip.decompress(got) == gzip.decompress(exp)           # records first: easier to read when it fails
+    assert got == exp
+    assert open(out + ".bai", "rb").read() == open(os.path.join(helpers.GOLDEN, fixture, name + ".bai"), "rb").read()
+
+
+def test_align_gz_sam(golden_tmp, tmp_path):
+    """output name ending in '.gz': the SAM text through zlib"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "out.sam.gz")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"], str(tmp_path))
+    assert gzip.open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")

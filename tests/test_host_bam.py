@@ -1,0 +1,32 @@
+"""Host BAM/BAI writer (CPU only): feeding it the uncompressed record stream of a BAM the reference wrote must
+reproduce that file and its .bai byte for byte - the BGZF block cuts (0xff00 bytes, plus the flush after the
+last aligned record), zlib level 6 raw deflate, virtual offsets, chunk merging and the sparse linear index."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import helpers
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("b") / "bam_harness")
+    src = [os.path.join(helpers.ROOT, "tests", "cpp", "bam_harness.cpp"),
+           os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "bam_writer.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe] + src + ["-lz"])
+    return exe
+
+
+@pytest.mark.parametrize("fixture,name", [("basic", "s3.m6.bam"), ("basic", "s3.m5.bam"), ("pe", "U3.m6.bam")])
+@pytest.mark.parametrize("threads", [1, 5])
+def test_bam_writer_reproduces_reference_files(harness, tmp_path, fixture, name, threads):
+    ref = os.path.join(helpers.GOLDEN, fixture, name)
+    raw = str(tmp_path / "stream.bin")
+    with open(raw, "wb") as f:
+        f.write(gzip.open(ref, "rb").read())
+    out = str(tmp_path / "out.bam")
+    subprocess.check_call([harness, raw, out, str(threads)])
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    assert open(out + ".bai", "rb").read() == open(ref + ".bai", "rb").read()
