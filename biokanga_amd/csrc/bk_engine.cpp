@@ -515,14 +515,12 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
-    b.nw = two_bit ? (uint32_t)nw16 : 0u;
+    b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
 
     hipEvent_t e0 = tm.begin(s);
-    // the pack kernel has one thread per 4-bit word of a row (wpr of them); an rd2 row covers nw words
-    if (two_bit && (uint32_t)nw16 > wpr) HIP_TRY(hipMemsetAsync(c->d_rd2, 0, (size_t)n * 2 * (3 * nw16 / 4) * 8, s));
     launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e0, s);
