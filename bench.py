@@ -240,7 +240,11 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
             our_sam, our_log = os.path.join(tmp, "our.sam"), os.path.join(tmp, "our.log")
             rc, our_wall = run(our_bin, our_sam, our_log, ["--device", str(cli_device)])
             same = rc == 0 and subprocess.run(["cmp", "-s", ref_sam, our_sam]).returncode == 0
-            res["our_cli"] = {"t_e2e_s": our_wall, "rc": rc, "sam_byte_identical_to_reference": bool(same)}
+            try:
+                our_t_align = t_align_of(our_log)      # same two log lines; no start-up sleep on our side
+            except Exception:
+                our_t_align = None
+            res["our_cli"] = {"t_e2e_s": our_wall, "t_align_s": our_t_align, "rc": rc, "sam_byte_identical_to_reference": bool(same)}
         log(f"cpu_baseline(reference): files {t_files:.1f}s, reference {ref_wall:.1f}s (T_align {t_align:.2f}s)")
         return res
     finally:
