@@ -39,6 +39,7 @@ constexpr uint64_t kEosWord = 0x7777777777777777ULL;
 struct DevIndex {
     const uint64_t *tgt4;
     const uint64_t *tgt2;       // 2 bit/base copy of the target (32 bases per word), may be null
+    const uint64_t *tgt2s;      // tgt2 again, physically shifted by 32 bytes (windows never straddle a 64-byte line); may be null
     const uint8_t *nflag;       // bit per 2^flag_shift bases: region holds N/EOS (tgt2 unusable there); <= 16 KB, L1 resident
     int flag_shift;
     const uint32_t *sa_lo;

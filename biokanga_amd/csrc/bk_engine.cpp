@@ -81,11 +81,12 @@ struct bk_ctx {
     uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
     void *d_ktab = nullptr;
     uint64_t *d_tgt2 = nullptr;           // 2 bit/base target copy (DevIndex::tgt2)
+    uint64_t *d_tgt2s = nullptr;          // the same, stored 32 bytes later (DevIndex::tgt2s)
     uint8_t *d_nflag = nullptr;
     uint64_t *d_rd2 = nullptr;            // 2-bit read rows
     uint64_t n_tgt4_words = 0;
     uint32_t cap_rd2w = 0;
-    int use_tgt2 = 1;
+    int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
     uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
@@ -258,7 +259,7 @@ int build_isa(bk_ctx *c)
 // 2 bit/base target copy + N/EOS block bitmap for the window compare of the extend kernels
 int build_tgt2(bk_ctx *c)
 {
-    free_dev(c->d_tgt2); free_dev(c->d_nflag);
+    free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_tgt2s); c->d_tgt2s = nullptr; c->ix.tgt2s = nullptr;
     c->d_tgt2 = nullptr; c->d_nflag = nullptr;
     c->ix.tgt2 = nullptr; c->ix.nflag = nullptr;
     if (!c->use_tgt2) return BK_OK;
@@ -277,6 +278,17 @@ int build_tgt2(bk_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->ix.tgt2 = c->d_tgt2;
     c->ix.nflag = c->d_nflag;
+    free_dev(c->d_tgt2s);
+    c->d_tgt2s = nullptr;
+    c->ix.tgt2s = nullptr;
+    if (c->use_tgt2 >= 2) {
+        // second copy: element j holds tgt2[j + 4], i.e. logical byte p sits at physical byte p - 32
+        HIP_TRY(hipMalloc(&c->d_tgt2s, nblocks * 16 + 64));
+        HIP_TRY(hipMemsetAsync(c->d_tgt2s, 0, nblocks * 16 + 64, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_tgt2s, c->d_tgt2 + 4, (nblocks * 2 - 4) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->ix.tgt2s = c->d_tgt2s;
+    }
     c->ix.flag_shift = shift;
     return BK_OK;
 }
@@ -791,7 +803,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -847,7 +859,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     }
     if (n == "use_tgt2") {
         int64_t old = c->use_tgt2;
-        c->use_tgt2 = value ? 1 : 0;
+        c->use_tgt2 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         int rc = build_tgt2(c);
         return rc ? rc : old;
     }

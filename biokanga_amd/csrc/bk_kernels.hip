@@ -1078,12 +1078,17 @@ __device__ __forceinline__ bool window_flagged(const DevIndex &ix, uint64_t t, i
 
 template <int NW>
 __device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], const uint64_t (&rnm)[NW / 4], int len,
-                                             const uint64_t *__restrict__ tgt2, uint64_t t, Window<NW> &w)
+                                             const uint64_t *__restrict__ tgt2, const uint64_t *__restrict__ tgt2s, uint64_t t,
+                                             Window<NW> &w)
 {
     const uint64_t i0 = t >> 5;
     const unsigned s = (unsigned)(t & 31) << 1;
     const bool odd = (i0 & 1) != 0;
-    const uint4 *__restrict__ blk = reinterpret_cast<const uint4 *>(tgt2) + (i0 >> 1);
+    // tgt2s (optional) is the same data stored again 32 bytes later: a window that would straddle a 64-byte
+    // line in one copy lies inside a line of the other (16-byte block index 2 or 3 within the line -> 0 or 1)
+    const uint64_t blk0 = i0 >> 1;
+    const uint4 *__restrict__ blk = (tgt2s != nullptr && (blk0 & 2)) ? reinterpret_cast<const uint4 *>(tgt2s) + (blk0 - 2)
+                                                                      : reinterpret_cast<const uint4 *>(tgt2) + blk0;
     constexpr int NB = NW / 4 + 1;
     uint64_t r[2 * NB];
     const int nwords = ((int)(t & 31) + len + 31) >> 5;
@@ -1423,7 +1428,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
                     flg = window_flagged(ix, t0, c_len);                 // issued together with the loads below
                     uint64_t r2w[NW / 2], rnm[NW / 4];
                     load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
-                    eval_window2<NW>(r2w, rnm, c_len, ix.tgt2, t0, w);
+                    eval_window2<NW>(r2w, rnm, c_len, ix.tgt2, ix.tgt2s, t0, w);
                 }
                 if (flg) {                                               // N/EOS nearby (rare): the 4-bit copy decides
                     uint64_t rw[NW];
@@ -1673,7 +1678,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         // flagged window is then fetched again from the 4-bit copy
                         if (two_bit) {
                             const bool flg = window_flagged(ix, t, len);
-                            eval_window2<NW>(r2w, rnm, len, ix.tgt2, t, w);
+                            eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t, w);
                             if (flg) eval_window<NW>(rw, len, ix.tgt4, t, w);
                         } else
                             eval_window<NW>(rw, len, ix.tgt4, t, w);
