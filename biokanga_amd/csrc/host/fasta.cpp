@@ -89,19 +89,42 @@ int SeqReader::next(std::string &descr, std::vector<uint8_t> &bases)
     bases.clear();
     int c;
     if (fastq_) {
-        // @descr \n seq \n + \n qual
-        while ((c = getc_()) >= 0 && (c == '\n' || c == '\r')) {}
+        // CFasta::ParseFastQblockQ (libbiokanga/Fasta.cpp:1206-1440): @id / sequence / +[id] / qualities, one line
+        // each, blank lines between elements sloughed; the sequence may only hold acgtn (either case) - IUPAC codes
+        // and SOLiD colour calls end the run, as they do in the reference (colour space is out of scope here);
+        // sequence and quality lengths must agree; characters outside 0x20..0x7f are errors
+        auto bad_chr = [](int ch) { return !isspace(ch) && (ch < 0x20 || ch > 0x7f); };
+        while ((c = getc_()) >= 0 && isspace(c)) {}
         if (c < 0) return 0;
-        if (c != '@') return -77;                    // eBSFerrFastqSeqID-ish: malformed record
-        while ((c = getc_()) >= 0 && c != '\n') if (c != '\r') descr.push_back((char)c);
-        while ((c = getc_()) >= 0 && c != '\n') {
-            if (c == '\r') continue;
-            if (isalpha(c) || c == '-') bases.push_back(a2s((uint8_t)c));
+        if (c != '@') return -77;                    // eBSFerrFastqSeqID
+        while ((c = getc_()) >= 0 && c != '\n' && c != '\r') {
+            if (bad_chr(c)) return -76;              // eBSFerrFastqChr
+            if (descr.size() < 8192) descr.push_back((char)c);              // cMaxFastaDescrLen
         }
-        while ((c = getc_()) >= 0 && c != '\n') {}   // '+' line
+        for (;;) {                                   // sequence line (leading blank lines sloughed)
+            c = getc_();
+            if (c < 0) break;
+            if (c == '\n' || c == '\r') { if (bases.empty()) continue; break; }
+            switch (c) {
+            case 'a': case 'A': case 'c': case 'C': case 'g': case 'G': case 't': case 'T': case 'n': case 'N':
+                if (bases.size() < 0x30000) bases.push_back(a2s((uint8_t)c));   // cMaxFastQSeqLen (commdefs.h:161): silently truncated
+                break;
+            default:
+                return -78;                          // eBSFerrFastqSeq
+            }
+        }
+        while ((c = getc_()) >= 0 && (c == '\n' || c == '\r')) {}
+        if (c != '+') return -79;                    // eBSFerrFastqDescr
+        while ((c = getc_()) >= 0 && c != '\n' && c != '\r') if (bad_chr(c)) return -76;
         size_t nq = 0;
-        while ((c = getc_()) >= 0 && c != '\n') if (c != '\r') nq++;
-        (void)nq;
+        for (;;) {                                   // quality line
+            c = getc_();
+            if (c < 0) break;
+            if (c == '\n' || c == '\r') { if (nq == 0) continue; break; }
+            if (bad_chr(c)) return -76;
+            if (nq < 0x30000) nq++;
+        }
+        if (descr.empty() || bases.empty() || nq != bases.size()) return -85;   // eBSFerrFileAccess: empty or unequal elements
         return 1;
     }
     // FASTA

@@ -516,12 +516,59 @@ def make_bam(tmp):
     print("  bam fixtures written")
 
 
+def make_fastq(tmp):
+    """the basic reads as FASTQ (IUPAC codes replaced by N - the reference refuses them in FASTQ sequences;
+    quality lines that start with '@' or '>', '+' lines with and without the repeated id, a blank line now and
+    then): the reference's SAM for it, plus the proof that a FASTQ read with an IUPAC code ends the run."""
+    import random
+    import re
+    rnd = random.Random(3)
+    basic = os.path.join(HERE, "basic")
+    sfx = os.path.join(tmp, "fq.sfx")
+    with gzip.open(os.path.join(basic, "genome.sfx.gz"), "rb") as f, open(sfx, "wb") as g:
+        shutil.copyfileobj(f, g)
+    recs = []
+    name = None
+    for line in gzip.open(os.path.join(basic, "reads.fa.gz"), "rt"):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line[1:]
+        else:
+            recs.append((name, re.sub(r"[^ACGTNacgtn]", "N", line)))
+    qchars = "!\"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHIJ"
+    fq = os.path.join(tmp, "reads.fq")
+    with open(fq, "w") as f:
+        for i, (n, s) in enumerate(recs):
+            q = "".join(rnd.choice(qchars) for _ in s)
+            if i % 7 == 0:
+                q = "@" + q[1:]
+            if i % 11 == 0:
+                q = ">" + q[1:]
+            f.write(f"@{n}\n{s}\n+{n if i % 3 == 0 else ''}\n{q}\n")
+            if i % 13 == 0:
+                f.write("\n")
+    out = os.path.join(tmp, "fq.sam")
+    run([REF, "align", "-i", fq, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"], tmp)
+    gz_copy(fq, os.path.join(basic, "reads.fq.gz"))
+    gz_copy(out, os.path.join(basic, "s3fq.m6.sam.gz"))
+    bad = os.path.join(tmp, "bad.fq")
+    with open(bad, "w") as f:
+        f.write("@ok\n" + "ACGT" * 15 + "\n+\n" + "I" * 60 + "\n@iupac\n" + "ACGR" * 15 + "\n+\n" + "I" * 60 + "\n")
+    r = subprocess.run([REF, "align", "-i", bad, "-I", sfx, "-o", os.path.join(tmp, "bad.sam"), "-M6", "-s3", "-T4"], cwd=tmp,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0, "the reference was expected to refuse an IUPAC code inside a FASTQ sequence"
+    print("  fastq fixture written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-fastq" in sys.argv:
+            make_fastq(tmp)
             return
         if "--only-bam" in sys.argv:
             make_bam(tmp)
@@ -538,6 +585,7 @@ def main():
         make_pe(tmp)
         make_lengths(tmp)
         make_bam(tmp)
+        make_fastq(tmp)
     print("done")
 
 

@@ -139,3 +139,20 @@ def test_align_gz_sam(golden_tmp, tmp_path):
     out = str(tmp_path / "out.sam.gz")
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"], str(tmp_path))
     assert gzip.open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
+
+
+def test_align_fastq_input(golden_tmp, tmp_path):
+    """FASTQ ingest (CFasta::ParseFastQblockQ): quality lines starting with '@' / '>', optional repeated id, blank
+    lines; SAM byte-identical to the reference's.  An IUPAC code inside a FASTQ sequence ends the run, as it does
+    in the reference."""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "fq.sam")
+    run(["align", "-i", os.path.join(helpers.GOLDEN, "basic", "reads.fq.gz"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"],
+        str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("basic", "s3fq.m6.sam.gz")
+    bad = str(tmp_path / "bad.fq")
+    with open(bad, "w") as f:
+        f.write("@ok\n" + "ACGT" * 15 + "\n+\n" + "I" * 60 + "\n@iupac\n" + "ACGR" * 15 + "\n+\n" + "I" * 60 + "\n")
+    r = subprocess.run([BIN, "align", "-i", bad, "-I", os.path.join(d, "genome.sfx"), "-o", str(tmp_path / "bad.sam"), "-M6", "-s3"],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0
