@@ -531,6 +531,10 @@ int cmd_align(int argc, char **argv, int first)
     P.max_ns = a.num("n", 1);
     P.max_ml = 1;
     int fmt = a.num("M", 5);
+    if (a.has("O") && fmt == 6) {                 // kanga.cpp:1015-1021
+        diag("Error: Output induced substitution mode '-O<file>' not available in '-M6' output mode\n");
+        return 1;
+    }
     int min_len = a.num("l", 50), max_len = a.num("L", 500);
     int trim5 = a.num("y", 0), trim3 = a.num("Y", 0);
     int max_rpt_sam_seqs = a.num("4", 10000);
@@ -614,18 +618,87 @@ int cmd_align(int argc, char **argv, int first)
     };
     bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
 
+    // -O: CAligner::ProcessPairedEnds' insert length table (PE only, Aligner.cpp:3024-3040), WriteBasicCountStats
+    // (:4186-4330, fed by WriteSubDist :6275-6336 for every accepted read) and ReportTargHitCnts (:5475-5537)
     auto write_stats = [&]() {
-        if (a.has("O")) {                                                    // CAligner::ReportTargHitCnts, Aligner.cpp:5475-5537
-            std::vector<uint64_t> cnt(n_ent);
-            bk_seq_counts(ctx, cnt.data(), n_ent, 0);
-            FILE *f = fopen(a.str("O").c_str(), "w");
-            if (f) {
-                fprintf(f, "\"TargSeq\",\"TargLen\",\"NumHits\"\n");
-                for (uint32_t c = 0; c < n_ent; c++)
-                    if (cnt[c]) fprintf(f, "\"%s\",%u,%llu\n", ents[c].name, ents[c].seq_len, (unsigned long long)cnt[c]);
-                fclose(f);
+        if (!a.has("O")) return;
+        FILE *f = fopen(a.str("O").c_str(), "w");
+        if (!f) { diag("Unable to create '%s'", a.str("O").c_str()); return; }
+        if (pe_mode) {
+            std::vector<int> len_dist(100001, 0);                    // cPairMaxLen + 1
+            for (size_t i = 0; i + 1 < nr; i += 2) {
+                const bk_hit &p1 = hits[i], &p2 = hits[i + 1];
+                if (!((p1.flags & 0x80) && (p2.flags & 0x80))) continue;
+                long s1 = p1.match_loci, e1 = s1 + p1.match_len - 1, s2 = p2.match_loci, e2 = s2 + p2.match_len - 1;
+                long frag = p1.strand == '+' ? 1 + e2 - s1 : 1 + e1 - s2;
+                if (frag >= 0 && frag <= 100000) len_dist[(size_t)frag]++;
             }
+            for (int i = 0; i <= 100000; i++) fprintf(f, "%d,%d\n", i, len_dist[(size_t)i]);
         }
+        size_t n_acc = 0;
+        uint32_t max_len = 0;
+        for (size_t i = 0; i < nr; i++) if (hits[i].nar == BK_NAR_ACCEPTED) { n_acc++; max_len = std::max(max_len, rs.lens[i]); }
+        if (n_acc && max_len) {
+            bk::SfxFile sf;
+            std::string serr;
+            if (bk::sfx_open(a.str("I").c_str(), sf, &serr) == 0) {
+                // per read position: accepted reads covering it, and those whose base differs from the target there
+                // (read orientation; the target is reverse complemented for '-' alignments); no qualities are
+                // loaded, so everything falls into the lowest Phred band
+                std::vector<std::vector<uint64_t>> qi((size_t)nthreads, std::vector<uint64_t>(max_len, 0)), sb(qi), ms(qi);
+                auto work = [&](int w) {
+                    auto &Q = qi[(size_t)w], &S = sb[(size_t)w], &M = ms[(size_t)w];
+                    for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
+                        const bk_hit &h = hits[i];
+                        if (h.nar != BK_NAR_ACCEPTED || h.chrom_id < 1 || h.chrom_id > n_ent) continue;
+                        const uint8_t *rd = rs.bases.data() + rs.offs[i];
+                        const uint32_t len = rs.lens[i];
+                        const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
+                        uint32_t nsub = 0;
+                        for (uint32_t k = 0; k < len; k++) {
+                            uint8_t t = h.strand == '-' ? tg[len - 1 - k] & 7 : tg[k] & 7;
+                            if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
+                            Q[k]++;
+                            if ((rd[k] & 7) != t) { S[k]++; nsub++; }
+                        }
+                        M[nsub < max_len ? nsub : max_len - 1]++;
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int w = 1; w < nthreads; w++) th.emplace_back(work, w);
+                work(0);
+                for (auto &t : th) t.join();
+                for (int w = 1; w < nthreads; w++)
+                    for (uint32_t k = 0; k < max_len; k++) { qi[0][k] += qi[(size_t)w][k]; sb[0][k] += sb[(size_t)w][k]; ms[0][k] += ms[(size_t)w][k]; }
+                static const char *band_a[4] = {"Phred 0..9", "Phred 10..19", "Phred 20..29", "Phred 30+"};
+                static const char *band_b[4] = {"Phred 0..8", "Phred 9..19", "Phred 20..29", "Phred 30+"};
+                fprintf(f, "\"Phred Score Instances\",");
+                for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k + 1);
+                for (int bnd = 0; bnd < 4; bnd++) {
+                    fprintf(f, "\n,\"%s\"", band_a[bnd]);
+                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", bnd ? 0ULL : (unsigned long long)qi[0][k]);
+                }
+                fprintf(f, "\n\n\"Aligner Induced Subs\",");
+                for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k + 1);
+                for (int bnd = 0; bnd < 4; bnd++) {
+                    fprintf(f, "\n,\"%s\"", band_b[bnd]);
+                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", bnd ? 0ULL : (unsigned long long)sb[0][k]);
+                }
+                fprintf(f, "\n\n\"Multiple substitutions\",");
+                for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k);
+                fprintf(f, "\n,\"Instances\"");
+                for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", (unsigned long long)ms[0][k]);
+                fprintf(f, "\n");
+            } else
+                diag("Unable to reopen '%s' for the substitution statistics: %s", a.str("I").c_str(), serr.c_str());
+            std::vector<uint64_t> cnt(n_ent, 0);                  // final NAR (after any PE processing), in entry order
+            for (size_t i = 0; i < nr; i++)
+                if (hits[i].nar == BK_NAR_ACCEPTED && hits[i].chrom_id >= 1 && hits[i].chrom_id <= n_ent) cnt[hits[i].chrom_id - 1]++;
+            fprintf(f, "\"TargSeq\",\"TargLen\",\"NumHits\"\n");
+            for (uint32_t c = 0; c < n_ent; c++)
+                if (cnt[c]) fprintf(f, "\"%s\",%u,%llu\n", ents[c].name, ents[c].seq_len, (unsigned long long)cnt[c]);
+        }
+        fclose(f);
     };
 
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index

@@ -560,12 +560,36 @@ def make_fastq(tmp):
     print("  fastq fixture written")
 
 
+def make_stats(tmp):
+    """the -O statistics file: SE (-M5; the reference refuses -O with -M6) and PE (insert length table first)"""
+    basic = os.path.join(HERE, "basic")
+    pe = os.path.join(HERE, "pe")
+    def gunz(src, dst):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    sfx, rd, r1, r2 = (os.path.join(tmp, x) for x in ("st.sfx", "st_reads.fa", "st_r1.fa", "st_r2.fa"))
+    gunz(os.path.join(basic, "genome.sfx.gz"), sfx)
+    gunz(os.path.join(basic, "reads.fa.gz"), rd)
+    gunz(os.path.join(pe, "reads_1.fa.gz"), r1)
+    gunz(os.path.join(pe, "reads_2.fa.gz"), r2)
+    st = os.path.join(tmp, "se_stats.csv")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", os.path.join(tmp, "st.sam"), "-s3", "-M5", "-T4", "-O", st], tmp)
+    gz_copy(st, os.path.join(basic, "s3.m5.stats.csv.gz"))
+    st = os.path.join(tmp, "pe_stats.csv")
+    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", os.path.join(tmp, "stpe.sam"), "-s5", "-U3", "-d200", "-D400", "-M5", "-T4", "-O", st], tmp)
+    gz_copy(st, os.path.join(pe, "U3.m5.stats.csv.gz"))
+    print("  stats fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-stats" in sys.argv:
+            make_stats(tmp)
             return
         if "--only-fastq" in sys.argv:
             make_fastq(tmp)
@@ -586,6 +610,7 @@ def main():
         make_lengths(tmp)
         make_bam(tmp)
         make_fastq(tmp)
+        make_stats(tmp)
     print("done")
 
 

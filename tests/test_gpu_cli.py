@@ -72,8 +72,10 @@ def test_align_sam_byte_identical(golden_tmp, tmp_path, fixture, tag, flags):
         for line in exp:
             if line.strip():
                 assert line.strip() in log
-        st = open(tmp_path / "st.csv").read().split("\n")
-        assert st[0] == '"TargSeq","TargLen","NumHits"' and len(st) >= 3
+        if fixture == "basic":
+            assert open(tmp_path / "st.csv", "rb").read() == golden_bytes("basic", "s3.m5.stats.csv.gz")
+        else:
+            assert '"TargSeq","TargLen","NumHits"' in open(tmp_path / "st.csv").read()
 
 
 def test_gz_reads_and_own_index_roundtrip(golden_tmp, tmp_path):
@@ -154,5 +156,23 @@ def test_align_fastq_input(golden_tmp, tmp_path):
     with open(bad, "w") as f:
         f.write("@ok\n" + "ACGT" * 15 + "\n+\n" + "I" * 60 + "\n@iupac\n" + "ACGR" * 15 + "\n+\n" + "I" * 60 + "\n")
     r = subprocess.run([BIN, "align", "-i", bad, "-I", os.path.join(d, "genome.sfx"), "-o", str(tmp_path / "bad.sam"), "-M6", "-s3"],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0
+
+
+def test_stats_file(golden_tmp, tmp_path):
+    """-O: substitution profile along the read + per-sequence counts (SE), preceded by the insert length table (PE);
+    refused together with -M6 as in the reference"""
+    d = golden_tmp["basic"]
+    sfx = os.path.join(d, "genome.sfx")
+    st = str(tmp_path / "se.csv")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "o.sam"), "-s3", "-M5", "-O", st], str(tmp_path))
+    assert open(st, "rb").read() == golden_bytes("basic", "s3.m5.stats.csv.gz")
+    pe = os.path.join(helpers.GOLDEN, "pe")
+    st = str(tmp_path / "pe.csv")
+    run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", sfx, "-o", str(tmp_path / "p.sam"),
+         "-s5", "-U3", "-d200", "-D400", "-M5", "-O", st], str(tmp_path))
+    assert open(st, "rb").read() == golden_bytes("pe", "U3.m5.stats.csv.gz")
+    r = subprocess.run([BIN, "align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "x.sam"), "-s3", "-M6", "-O", st],
                        cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0
