@@ -495,8 +495,8 @@ int cmd_align(int argc, char **argv, int first)
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
-        {"pairstrand", "E"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udD", "E", a, err)) {
+        {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJ", "E", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -617,6 +617,32 @@ int cmd_align(int argc, char **argv, int first)
         return 0;
     };
     bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
+
+    // -j / -J: reads that found no alignment at all (NAR EN, NL) / multi-loci reads (NAR ML) as FASTA, in the sorted
+    // order, 70 columns (CAligner::ReportNoneAligned / ReportMultiAlign, Aligner.cpp:3826-4010)
+    auto write_read_subset = [&](const char *opt, const char *tag, auto want) {
+        if (!a.has(opt)) return;
+        OutBuf o;
+        o.open(a.str(opt).c_str());
+        if (o.fd < 0) { diag("Unable to create '%s'", a.str(opt).c_str()); return; }
+        static const char up[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
+        std::string rec;
+        for (size_t k = 0; k < nr; k++) {
+            const uint32_t i = order[k];
+            if (!want(hits[i].nar)) continue;
+            const uint32_t len = rs.lens[i];
+            const uint8_t *sq = rs.bases.data() + rs.offs[i];
+            char hd[400];
+            int n = snprintf(hd, sizeof(hd), ">lcl|%s|%u %s %u|1|%u\n", tag, i + 1, rs.name(i), i + 1, len);
+            rec.assign(hd, (size_t)n);
+            for (uint32_t q = 0; q < len; q++) {
+                rec.push_back(up[sq[q] & 7]);
+                if ((q + 1) % 70 == 0 || q + 1 == len) rec.push_back('\n');
+            }
+            o.put(rec);
+        }
+        o.close();
+    };
 
     // -O: CAligner::ProcessPairedEnds' insert length table (PE only, Aligner.cpp:3024-3040), WriteBasicCountStats
     // (:4186-4330, fed by WriteSubDist :6275-6336 for every accepted read) and ReportTargHitCnts (:5475-5537)
@@ -827,6 +853,8 @@ int cmd_align(int argc, char **argv, int first)
         if (rc) { diag("Fatal: %s", berr.c_str()); bk_ctx_destroy(ctx); return 1; }
         diag("Completed reporting BAM %llu read alignments", (unsigned long long)n_rep);
         diag("Reporting of aligned result set completed");
+        write_read_subset("j", "na", [](uint8_t nar) { return nar == BK_NAR_NS || nar == BK_NAR_NOHIT; });
+        write_read_subset("J", "ml", [](uint8_t nar) { return nar == BK_NAR_MULTIALIGN; });
         write_stats();
         bk_ctx_destroy(ctx);
         return 0;
@@ -986,6 +1014,8 @@ int cmd_align(int argc, char **argv, int first)
     out.close();
     diag("Reporting of aligned result set completed");
 
+    write_read_subset("j", "na", [](uint8_t nar) { return nar == BK_NAR_NS || nar == BK_NAR_NOHIT; });
+    write_read_subset("J", "ml", [](uint8_t nar) { return nar == BK_NAR_MULTIALIGN; });
     write_stats();
     bk_ctx_destroy(ctx);
     return 0;

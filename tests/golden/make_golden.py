@@ -573,11 +573,18 @@ def make_stats(tmp):
     gunz(os.path.join(pe, "reads_1.fa.gz"), r1)
     gunz(os.path.join(pe, "reads_2.fa.gz"), r2)
     st = os.path.join(tmp, "se_stats.csv")
-    run([REF, "align", "-i", rd, "-I", sfx, "-o", os.path.join(tmp, "st.sam"), "-s3", "-M5", "-T4", "-O", st], tmp)
+    nj, mj = os.path.join(tmp, "se_none.fa"), os.path.join(tmp, "se_multi.fa")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", os.path.join(tmp, "st.sam"), "-s3", "-M5", "-T4", "-O", st, "-j", nj, "-J", mj], tmp)
     gz_copy(st, os.path.join(basic, "s3.m5.stats.csv.gz"))
+    gz_copy(nj, os.path.join(basic, "s3.none.fa.gz"))
+    gz_copy(mj, os.path.join(basic, "s3.multi.fa.gz"))
     st = os.path.join(tmp, "pe_stats.csv")
-    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", os.path.join(tmp, "stpe.sam"), "-s5", "-U3", "-d200", "-D400", "-M5", "-T4", "-O", st], tmp)
+    nj, mj = os.path.join(tmp, "pe_none.fa"), os.path.join(tmp, "pe_multi.fa")
+    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", os.path.join(tmp, "stpe.sam"), "-s5", "-U3", "-d200", "-D400", "-M5", "-T4", "-O", st,
+         "-j", nj, "-J", mj], tmp)
     gz_copy(st, os.path.join(pe, "U3.m5.stats.csv.gz"))
+    gz_copy(nj, os.path.join(pe, "U3.none.fa.gz"))
+    gz_copy(mj, os.path.join(pe, "U3.multi.fa.gz"))
     print("  stats fixtures written")
 
 

@@ -166,13 +166,19 @@ def test_stats_file(golden_tmp, tmp_path):
     d = golden_tmp["basic"]
     sfx = os.path.join(d, "genome.sfx")
     st = str(tmp_path / "se.csv")
-    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "o.sam"), "-s3", "-M5", "-O", st], str(tmp_path))
+    nj, mj = str(tmp_path / "none.fa"), str(tmp_path / "multi.fa")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "o.sam"), "-s3", "-M5", "-O", st, "-j", nj, "-J", mj],
+        str(tmp_path))
     assert open(st, "rb").read() == golden_bytes("basic", "s3.m5.stats.csv.gz")
+    assert open(nj, "rb").read() == golden_bytes("basic", "s3.none.fa.gz")          # -j: reads without any alignment
+    assert open(mj, "rb").read() == golden_bytes("basic", "s3.multi.fa.gz")         # -J: multi-loci reads
     pe = os.path.join(helpers.GOLDEN, "pe")
     st = str(tmp_path / "pe.csv")
     run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", sfx, "-o", str(tmp_path / "p.sam"),
-         "-s5", "-U3", "-d200", "-D400", "-M5", "-O", st], str(tmp_path))
+         "-s5", "-U3", "-d200", "-D400", "-M5", "-O", st, "-j", nj, "-J", mj], str(tmp_path))
     assert open(st, "rb").read() == golden_bytes("pe", "U3.m5.stats.csv.gz")
+    assert open(nj, "rb").read() == golden_bytes("pe", "U3.none.fa.gz")
+    assert open(mj, "rb").read() == golden_bytes("pe", "U3.multi.fa.gz")
     r = subprocess.run([BIN, "align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "x.sam"), "-s3", "-M6", "-O", st],
                        cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0
