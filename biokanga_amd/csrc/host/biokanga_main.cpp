@@ -495,8 +495,8 @@ int cmd_align(int argc, char **argv, int first)
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
-        {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJ", "E", a, err)) {
+        {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJt", "E", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -545,7 +545,7 @@ int cmd_align(int argc, char **argv, int first)
     if (nthreads > 128) nthreads = 128;
     if (P.pmode < 0 || P.pmode > 3 || P.align_strand < 0 || P.align_strand > 2 || P.min_edit_dist < 1 || P.min_edit_dist > 2 ||
         P.max_subs < 0 || P.max_subs > 25 || P.max_ns < 0 || P.max_ns > 5 || min_len < 15 || min_len > 2000 || max_len < min_len ||
-        max_len > 2000 || (fmt != 0 && fmt != 5 && fmt != 6)) {
+        max_len > 2000 || fmt < 0 || fmt > 6) {
         diag("Error: an option value is outside its accepted range");
         return 1;
     }
@@ -999,15 +999,55 @@ int cmd_align(int argc, char **argv, int first)
         }
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {
-        // -M0 CSV loci only (Aligner.cpp:6380-6620)
+        // -M0..3 CSV (loci; 1: + match sequence, 2: + read sequence, 3: + both) and -M4 UCSC BED
+        // (CAligner::WriteReadHits, Aligner.cpp:6336-6660); the site-preference score column is 0 as in the
+        // reference when no -8 preferences are computed
+        static const char up[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
+        bk::SfxFile sf;
+        if (fmt == 1 || fmt == 3) {
+            std::string serr;
+            if (bk::sfx_open(a.str("I").c_str(), sf, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        }
+        if (fmt == 4) {
+            std::string title = a.str("t", "kanga");
+            int m = snprintf(line, sizeof(line), "track type=bed name=\"%s\" description=\"%s\"\n", title.c_str(), title.c_str());
+            out.put(line, (size_t)m);
+        }
+        std::string rec;
         for (size_t k = 0; k < nr; k++) {
             uint32_t i = order[k];
             const bk_hit &h = hits[i];
             if (h.nar != BK_NAR_ACCEPTED) continue;
-            int m = snprintf(line, sizeof(line), "%u,\"ar\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"\n", i + 1, species.c_str(),
+            if (fmt == 4) {
+                int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len,
+                                 (char)h.strand);
+                out.put(line, (size_t)m);
+                n_reported++;
+                continue;
+            }
+            int m = snprintf(line, sizeof(line), "%u,\"ar\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, species.c_str(),
                              ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len - 1, (unsigned)h.match_len, (char)h.strand,
                              (unsigned)h.mismatches, rs.name(i));
-            out.put(line, (size_t)m);
+            rec.assign(line, (size_t)m);
+            const uint32_t len = rs.lens[i];
+            if (fmt >= 2) {                                              // the read as loaded
+                const uint8_t *sq = rs.bases.data() + rs.offs[i];
+                rec += ",\"";
+                for (uint32_t q = 0; q < len; q++) rec.push_back(up[sq[q] & 7]);
+                rec.push_back('"');
+            }
+            if (fmt == 1 || fmt == 3) {                                  // the target it matched, in read orientation
+                const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
+                rec += ",\"";
+                for (uint32_t q = 0; q < len; q++) {
+                    uint8_t t = h.strand == '-' ? tg[len - 1 - q] & 7 : tg[q] & 7;
+                    if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
+                    rec.push_back(up[t]);
+                }
+                rec.push_back('"');
+            }
+            rec.push_back('\n');
+            out.put(rec);
             n_reported++;
         }
     }

@@ -588,12 +588,29 @@ def make_stats(tmp):
     print("  stats fixtures written")
 
 
+def make_formats(tmp):
+    """-M1..3 (CSV with match / read / both sequences) and -M4 (UCSC BED, default and -t title) on the basic fixture"""
+    basic = os.path.join(HERE, "basic")
+    sfx, rd = os.path.join(tmp, "fm.sfx"), os.path.join(tmp, "fm_reads.fa")
+    for src, dst in ((os.path.join(basic, "genome.sfx.gz"), sfx), (os.path.join(basic, "reads.fa.gz"), rd)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    for m, name, extra in ((1, "s3.m1.csv", []), (2, "s3.m2.csv", []), (3, "s3.m3.csv", []), (4, "s3.m4.bed", []), (4, "s3.m4t.bed", ["-t", "my track"])):
+        out = os.path.join(tmp, name)
+        run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-s3", f"-M{m}", "-T4"] + extra, tmp)
+        gz_copy(out, os.path.join(basic, name + ".gz"))
+    print("  format fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-formats" in sys.argv:
+            make_formats(tmp)
             return
         if "--only-stats" in sys.argv:
             make_stats(tmp)
@@ -618,6 +635,7 @@ def main():
         make_bam(tmp)
         make_fastq(tmp)
         make_stats(tmp)
+        make_formats(tmp)
     print("done")
 
 

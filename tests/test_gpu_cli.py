@@ -182,3 +182,13 @@ def test_stats_file(golden_tmp, tmp_path):
     r = subprocess.run([BIN, "align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", str(tmp_path / "x.sam"), "-s3", "-M6", "-O", st],
                        cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("m,name,extra", [(1, "s3.m1.csv", []), (2, "s3.m2.csv", []), (3, "s3.m3.csv", []), (4, "s3.m4.bed", []),
+                                          (4, "s3.m4t.bed", ["-t", "my track"])])
+def test_align_other_formats_byte_identical(golden_tmp, tmp_path, m, name, extra):
+    """-M1..3: CSV with the matched target / the read / both; -M4: UCSC BED"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / name)
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-s3", f"-M{m}"] + extra, str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("basic", name + ".gz")
