@@ -599,6 +599,9 @@ def make_formats(tmp):
         out = os.path.join(tmp, name)
         run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-s3", f"-M{m}", "-T4"] + extra, tmp)
         gz_copy(out, os.path.join(basic, name + ".gz"))
+    out = os.path.join(tmp, "s3y5Y3.sam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-s3", "-M6", "-y5", "-Y3", "-l60", "-T4"], tmp)      # end trims + length acceptance
+    gz_copy(out, os.path.join(basic, "s3y5Y3l60.m6.sam.gz"))
     print("  format fixtures written")
 
 

@@ -192,3 +192,11 @@ def test_align_other_formats_byte_identical(golden_tmp, tmp_path, m, name, extra
     out = str(tmp_path / name)
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-s3", f"-M{m}"] + extra, str(tmp_path))
     assert open(out, "rb").read() == golden_bytes("basic", name + ".gz")
+
+
+def test_align_end_trims(golden_tmp, tmp_path):
+    """-y / -Y end trims with -l: the trimmed reads are what is aligned and reported"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "trim.sam")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-s3", "-M6", "-y5", "-Y3", "-l60"], str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("basic", "s3y5Y3l60.m6.sam.gz")
