@@ -303,3 +303,46 @@ def test_pe_device_resident_entry_point(golden_tmp, tmp_path):
         al.pair_device(d_b.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), len(lens) // 2, d_h.data_ptr(), pe)
         got = d_h.cpu().numpy().view(bk.HIT_DTYPE)
     assert np.array_equal(got, exp)
+
+
+def test_edge_case_reads_match_oracle(golden_tmp):
+    """degenerate reads through the C ABI: length 1..14 (shorter than any core), all-N, all one base, non-ACGT codes,
+    overlapping / out-of-order offsets, a single read - every field as the oracle (= the reference algorithm) has it"""
+    bk = _bk()
+    d = golden_tmp["basic"]
+    rng = np.random.default_rng(123)
+    genome = helpers.read_fasta_reads(os.path.join(d, "genome.fa"))           # (names, bases, offs, lens) of the two sequences
+    gbases, goffs, glens = genome[1], genome[2], genome[3]
+    chunks, lens = [], []
+    for L in list(range(1, 20)) + [24, 25, 26, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 255, 256, 257]:
+        for rep in range(4):
+            p0 = int(rng.integers(0, int(glens[0]) - L))
+            r = gbases[int(goffs[0]) + p0: int(goffs[0]) + p0 + L].copy() & 7
+            if rep == 1 and L > 2:
+                r[L // 2] = (r[L // 2] + 1) & 3
+            if rep == 2:
+                r[:] = 4                                                        # all N
+            if rep == 3:
+                r[:] = rng.integers(0, 4)                                       # homopolymer
+            chunks.append(r); lens.append(L)
+    chunks.append(np.array([5, 6, 7, 0, 1, 2, 3] * 10, dtype=np.uint8)); lens.append(70)      # codes the loader never produces
+    bases = np.concatenate(chunks)
+    lens = np.array(lens, dtype=np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.uint64)
+    # same reads again through overlapping windows of one buffer, in reverse order
+    offs2 = np.concatenate([offs, offs[::-1]]); lens2 = np.concatenate([lens, lens[::-1]])
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    for kw in (dict(max_subs=3), dict(max_subs=10), dict(max_subs=0)):
+        exp, _ = sfx.align(bases, offs2, lens2, helpers.make_params(**kw))
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            # the longest read of a call picks the kernel family: <= 128, <= 256 bases (register kernels), longer
+            for cap in (128, 256, 100000):
+                sel = np.nonzero(lens2 <= cap)[0]
+                got = al.align(bases, offs2[sel], lens2[sel])
+                for f in FIELDS:
+                    bad = np.nonzero(got[f] != exp[f][sel])[0]
+                    assert len(bad) == 0, (kw, cap, f, bad[:10], lens2[sel][bad[:10]])
+            one = al.align(bases, offs2[40:41], lens2[40:41])
+            for f in FIELDS:
+                assert one[f][0] == exp[f][40]
+    sfx.close()
