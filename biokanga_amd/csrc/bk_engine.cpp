@@ -43,8 +43,9 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s);
-void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
-                 uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s);
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+                 int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
+                 hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
@@ -97,6 +98,7 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
@@ -247,7 +249,7 @@ int build_isa(bk_ctx *c)
     free_dev(c->d_isa);
     c->d_isa = nullptr;
     c->ix.isa = nullptr;
-    if (!c->use_wave || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
+    if (!c->use_wave || !c->use_isa || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
     HIP_TRY(hipMalloc(&c->d_isa, c->ix.n * 4));
     launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream);
     HIP_TRY(hipGetLastError());
@@ -301,8 +303,8 @@ int size_heavy_scratch(bk_ctx *c)
     if (worst > kNodeCap) worst = kNodeCap;
     uint32_t ts = 1024;
     while (ts < 2 * worst) ts <<= 1;
-    uint32_t slots = 1024;
-    while ((uint64_t)slots * ts * 8 > (8ULL << 30) && slots > 64) slots >>= 1;
+    uint32_t slots = 8192;                  // one per resident wave of the wave kernels when they fit in 16 GB
+    while ((uint64_t)slots * ts * 8 > (16ULL << 30) && slots > 64) slots >>= 1;
     if (c->hs.htab && c->hs.tab_size == ts && c->hs.n_slots == slots) return BK_OK;
     free_dev(c->hs.htab);
     free_dev(c->hs.slot_epoch);
@@ -364,9 +366,7 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     if (rc) return rc;
     rc = build_isa(c);
     if (rc) return rc;
-    rc = build_tgt2(c);
-    if (rc) return rc;
-    return size_heavy_scratch(c);
+    return build_tgt2(c);        // the hash scratch of the general kernels is sized when they first run
 }
 
 int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
@@ -605,12 +605,14 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 rs = sort_work(c, c->d_wave, n_wave, s, &wlist);
                 if (rs) return rs;
             }
-            launch_wave(c->ix, c->cfg, b, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
+            if (c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
+            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
         if (n_heavy) {
             hipEvent_t e3 = tm.begin(s);
+            { int rh = size_heavy_scratch(c); if (rh) return rh; }
             launch_heavy(c->ix, c->cfg, b, c->hs, c->d_heavy, n_heavy, phase, sm + 4, c->d_act[cur ^ 1], sm + 1, sm + 3, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
@@ -647,8 +649,6 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
     if ((int)maxlen > c->max_read_len) {
         c->max_read_len = (int)maxlen;
-        int rc = size_heavy_scratch(c);
-        if (rc) return rc;
     }
     // chunk size: as many reads as the knob allows and as fit in about half of the HBM still free
     // (the phase kernels run better the more reads they see: fewer launches, shorter tails)
@@ -824,7 +824,7 @@ int bk_ctx_set_params(bk_ctx *c, const bk_align_params *p)
     int rc = derive_cfg(c);
     if (rc) { c->params = old; derive_cfg(c); return rc; }
     (void)hipSetDevice(c->device);
-    return size_heavy_scratch(c);
+    return BK_OK;
 }
 
 int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
@@ -863,6 +863,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_tgt2(c);
         return rc ? rc : old;
     }
+    if (n == "use_isa") {
+        int64_t old = c->use_isa;
+        c->use_isa = value ? 1 : 0;
+        int rc = build_isa(c);
+        return rc ? rc : old;
+    }
     if (n == "use_flat") {
         int64_t old = c->use_flat;
         c->use_flat = value ? 1 : 0;
@@ -889,8 +895,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->max_read_len;
         if (value < 16 || value > kMaxReadLenAbs) return BK_ERR_PARAMS;
         c->max_read_len = (int)value;
-        int rc = size_heavy_scratch(c);
-        return rc ? rc : old;
+        return old;
     }
     return BK_ERR_PARAMS;
 }

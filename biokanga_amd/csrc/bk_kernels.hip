@@ -1191,7 +1191,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 for (int c = 0; c < nc; c++)
                     if ((iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
-            dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
+            dest = (fits && wave != nullptr) ? 2 : 3;
         } else {
             n_lcm = 1;
             const int init = mm + cfg.mm_delta + 1;
@@ -1362,7 +1362,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             for (; q < slots_max; q++) s_sp[t * slots_max + q] = (uint16_t)run;
             my_total = is_heavy ? 0 : run;
         }
-        if (is_heavy) dest = (fits && !WIDE && ix.isa != nullptr && wave != nullptr) ? 2 : 3;
+        if (is_heavy) dest = (fits && wave != nullptr) ? 2 : 3;
         else { mine = true; n_lcm = 1; }
     }
     s_r[t] = r; s_len[t] = (uint16_t)len; s_cl[t] = (uint16_t)cl; s_cd[t] = (uint16_t)cd; s_nc[t] = (uint8_t)nc;
@@ -1554,6 +1554,39 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
 // that suffix lay inside the prefix of c2's interval that was actually walked (rank from the inverse
 // suffix array; only looked up when c2's walk was cut short).
 
+__device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask)
+{
+    return (key * 2654435761u) & mask;      // table size is a power of two
+}
+
+__device__ __forceinline__ bool htab_contains(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) return false;
+        if (v == mine) return true;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) {
+            unsigned long long old = atomicCAS(&tab[h], v, mine);
+            if (old == v) return;
+            continue;                       // somebody else took the slot: look at it again
+        }
+        if (v == mine) return;
+        h = (h + 1) & mask;
+    }
+}
+
 constexpr int kWaveGrab = 8;
 
 struct WaveCoreInfo {
@@ -1563,8 +1596,13 @@ struct WaveCoreInfo {
     int ofs;
 };
 
-template <int NW>
-__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list,
+// HASH: the reference's own dedupe instead - a per-wave set of the 32-bit truncated target-start keys
+// (SfxArrayV2.cpp:5932), kept in HBM with epoch tags as in k_heavy.  This is the form for 5-byte indexes (no
+// inverse suffix array; and only the truncated keys reproduce the reference there, where two starts 2^32 apart
+// count as one) and for 4-byte indexes whose inverse suffix array was not built.
+template <int NW, bool WIDE, bool HASH>
+__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
+                                              const uint32_t *__restrict__ list,
                                               uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
                                               uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
                                               uint32_t *__restrict__ cmax_next)
@@ -1573,6 +1611,15 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned long long *tab = nullptr;
+    uint32_t tmask = 0, epoch = 0;
+    if (HASH) {
+        if (wave_slot >= hs.n_slots) return;
+        tab = hs.htab + (uint64_t)wave_slot * hs.tab_size;
+        tmask = hs.tab_size - 1;
+        epoch = hs.slot_epoch[wave_slot];
+    }
     const uint64_t lt_mask = (1ULL << lane) - 1;
     unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
 
@@ -1625,6 +1672,13 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             }
         }
         for (int st = s0; st <= s1 && !done; st++) {
+            if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
+                epoch++;
+                if (epoch == 0) {            // wrapped: really clear the table
+                    for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
+                    epoch = 1;
+                }
+            }
             uint64_t rw[NW];
             load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
 #pragma unroll
@@ -1666,7 +1720,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 for (uint64_t j0 = 0; j0 < n && !done; j0 += 64) {
                     const uint64_t j = j0 + lane;
                     const bool active = j < n;
-                    const uint64_t loci = active ? sa_get<false>(ix, first + j) : 0;
+                    const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
                     const uint64_t t = loci - (uint64_t)ofs;
                     bool valid = active && loci >= (uint64_t)ofs;
                     Window<NW> w;
@@ -1685,7 +1739,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         valid = !w.eos && (!lazy || core_clean<NW>(w, ofs, cl));
                     }
                     bool dup = false;
-                    for (int c2 = 0; c2 < c; c2++) {
+                    const uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
+                    if (HASH) dup = valid && htab_contains(tab, tmask, epoch, key);
+                    else for (int c2 = 0; c2 < c; c2++) {
                         bool m = valid && !dup && core_clean<NW>(w, core[c2].ofs, cl);
                         if (__ballot(m)) {
                             if (m) {
@@ -1719,6 +1775,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         }
                     }
                     const bool proc = active && j < cutoff && isnew;
+                    if (HASH && proc) htab_insert(tab, tmask, epoch, key);
                     int cm = (proc && w.mm <= mm && w.mm < nxt) ? w.mm : 127;
                     bool acc = cm != 127;
                     uint64_t keep = ~0ULL;
@@ -1791,6 +1848,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (HASH && lane == 0) hs.slot_epoch[wave_slot] = epoch;
     if (pend_n) flush_pending();
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
@@ -1810,39 +1868,6 @@ __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_
 
 // ------------------------------------------------------------------------------------------------
 // general wave-per-read form of one LocateCoreMultiples call
-
-__device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask)
-{
-    return (key * 2654435761u) & mask;      // table size is a power of two
-}
-
-__device__ __forceinline__ bool htab_contains(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
-{
-    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
-    uint32_t h = hash_key(key, mask);
-    for (;;) {
-        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 32) != epoch) return false;
-        if (v == mine) return true;
-        h = (h + 1) & mask;
-    }
-}
-
-__device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
-{
-    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
-    uint32_t h = hash_key(key, mask);
-    for (;;) {
-        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 32) != epoch) {
-            unsigned long long old = atomicCAS(&tab[h], v, mine);
-            if (old == v) return;
-            continue;                       // somebody else took the slot: look at it again
-        }
-        if (v == mine) return;
-        h = (h + 1) & mask;
-    }
-}
 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
@@ -2552,13 +2577,18 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 #undef BK_FLAT
 }
 
-void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *list, uint32_t n_list, int phase,
-                 uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s)
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+                 int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
+                 hipStream_t s)
 {
+    const bool wide = ix.sa_hi != nullptr, hash = ix.isa == nullptr;
     uint32_t waves = n_list < max_waves ? n_list : max_waves;
+    if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-    if (nw <= 8) hipLaunchKernelGGL((k_wave<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
-    else hipLaunchKernelGGL((k_wave<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
+#define BK_WAVE(N, W, H) hipLaunchKernelGGL((k_wave<N, W, H>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
+    if (nw <= 8) { if (wide) BK_WAVE(8, true, true); else if (hash) BK_WAVE(8, false, true); else BK_WAVE(8, false, false); }
+    else { if (wide) BK_WAVE(16, true, true); else if (hash) BK_WAVE(16, false, true); else BK_WAVE(16, false, false); }
+#undef BK_WAVE
 }
 
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
