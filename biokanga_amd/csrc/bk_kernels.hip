@@ -1,20 +1,25 @@
 // bk_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the `biokanga align` hot path.
 //
-//   k_pack_target   1 B/base target -> 4-bit packed words (index upload)
-//   k_split_sa5     5-byte suffix elements -> lo32 + hi8 arrays
-//   k_build_ktab    k-mer -> SA lower-bound table from the sorted suffix array
-//   k_pack_reads / k_init_reads   pack read + reverse complement (SeqTrans.cpp:458-512), N policy (Aligner.cpp:9041-9063)
-//   k_search        K1: one lane per (read, strand, core): SA interval of the core
-//                   = LocateFirstExact (SfxArrayV2.cpp:7765) + the extent of the matching run
-//   k_extend        K2/K3: one lane per read: candidate walk in SA order, bounds + dedupe, Hamming
-//                   extension, best / next-best / instances state machine and classification of
-//                   LocateCoreMultiples (SfxArrayV2.cpp:5830-6261) for reads whose core intervals
-//                   are all short (no truncation possible)
-//   k_heavy         general wave-per-read form of the same call for everything else (repeat cores:
-//                   100-candidate copy-count cut-off, MaxIter, node cap), 64 candidates per step with
-//                   ballot prefix sums reproducing the reference's sequential order
+// index set-up
+//   k_pack_target / k_pack_target2   1 B/base target -> 4 bit/base words; 2 bit/base copy + N/EOS region bitmap
+//   k_split_sa5                      5-byte suffix elements -> lo32 + hi8 arrays
+//   k_build_ktab / k_build_k2 / k_check_k2 / k_build_isa   k-mer table, second-level keys, inverse suffix array
+// per batch (register-kernel path: reads of <= 256 bases, <= 16 cores per strand)
+//   k_prep_fused    pack read + reverse complement (SeqTrans.cpp:458-512) as 4-bit and 2-bit rows, N policy
+//                   (Aligner.cpp:9041-9063), result record, first active list
+//   k_search_a/_b   LocateFirstExact (SfxArrayV2.cpp:7765) + extent of the matching run for every core of the phase:
+//                   k-mer table + contiguous second-level keys, work list grouped by bucket for the bisection pass
+//   k_flat          LocateCoreMultiples (SfxArrayV2.cpp:5830-6261) for reads whose core intervals are all short:
+//                   one candidate per lane, per-read replay of the best / next-best / instances state machine
+//   k_wave          the same call for repeat reads: one wave per call, 64 candidates per round, ballot prefix sums
+//                   reproduce the reference's sequential order (100-candidate copy-count cut-off, MaxIter, node
+//                   cap, early exit); dedupe by inverse suffix array, or by the reference's hash set (5-byte indexes)
+//   k_count_seqs    per-sequence accepted-read histogram
+//   k_pe_classify / k_pe_orphan      paired-end association and orphan recovery (Aligner.cpp:2726-3489)
+// general path (longer reads, more cores; also selectable for cross-checks)
+//   k_pack_reads / k_init_reads, k_search, k_light / k_extend, k_heavy
 //
-// Integer / bit-compare work, HBM + latency bound: no MFMA anywhere.
+// Integer / bit-compare work bound by random cache-line misses: no MFMA anywhere.
 #include "bk_device.h"
 
 namespace bk {
@@ -974,8 +979,7 @@ template <int NW>
 __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, const uint64_t *__restrict__ tgt, uint64_t t,
                                             Window<NW> &w)
 {
-    // The chip retires only ~49 G divergent lane-loads/s whatever their width (tools/rand_access_bench),
-    // so the window is fetched with 16-byte loads: ceil((len/16 + 2) / 2) instructions instead of len/16 + 1.
+    // window fetched with 16-byte loads: ceil((len/16 + 2) / 2) instructions instead of len/16 + 1
     const uint64_t i0 = t >> 4;
     const unsigned s = (unsigned)(t & 15) << 2;
     const bool odd = (i0 & 1) != 0;
