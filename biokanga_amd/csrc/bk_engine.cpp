@@ -98,6 +98,7 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
@@ -606,7 +607,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 if (rs) return rs;
             }
             if (c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
-            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, 256u * 8u * 4u, s);
+            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, c->wave_waves, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
@@ -862,6 +863,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->use_tgt2 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         int rc = build_tgt2(c);
         return rc ? rc : old;
+    }
+    if (n == "wave_waves") {
+        int64_t old = c->wave_waves;
+        if (value < 64 || value > 65536) return BK_ERR_PARAMS;
+        c->wave_waves = (uint32_t)value;
+        return old;
     }
     if (n == "use_isa") {
         int64_t old = c->use_isa;
