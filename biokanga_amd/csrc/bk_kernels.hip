@@ -1888,10 +1888,24 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     const uint64_t lt_mask = (1ULL << lane) - 1;
     unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
 
+    // items are claimed kWaveGrab at a time and next-phase reads parked one per lane (see k_wave)
+    uint32_t grab_next = 0, grab_left = 0, pend_r = 0, pend_n = 0, cmax_loc = 0;
+    auto flush_pending = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_cnt, pend_n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((uint32_t)lane < pend_n) next_act[base + lane] = pend_r;
+        pend_n = 0;
+    };
     for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(cursor, 1u);
-        item = __shfl(item, 0);
+        if (grab_left == 0) {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(cursor, (uint32_t)kWaveGrab);
+            grab_next = __builtin_amdgcn_readfirstlane(g);
+            grab_left = kWaveGrab;
+        }
+        const uint32_t item = grab_next++;
+        grab_left--;
         if (item >= n_list) break;
         uint32_t r = list[item];
         int len = (int)b.lens[r];
@@ -2031,19 +2045,21 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                 o += cur;
             }
         }
-        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-        if (lane == 0) {
-            if (rslt != BK_HR_NONE)
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
+        if (rslt != BK_HR_NONE) {
+            if (lane == 0)
                 write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand, (phase << 1) | 1);
-            else if (phase + 1 < p.n_phases) {
-                int mm2, cl2, cd2, dummy[1];
-                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
-                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                if (nc2 <= kMaxCoresFast) atomicMax(cmax_next, (uint32_t)nc2);
-                next_act[atomicAdd(next_cnt, 1u)] = r;
-            }
+        } else if (phase + 1 < p.n_phases) {
+            int mm2, cl2, cd2, dummy[1];
+            phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+            int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+            if (nc2 <= kMaxCoresFast && (uint32_t)nc2 > cmax_loc) cmax_loc = (uint32_t)nc2;
+            if ((uint32_t)lane == pend_n) pend_r = r;
+            if (++pend_n == 64) flush_pending();
         }
     }
+    if (pend_n) flush_pending();
+    if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
         if (n_search) atomicAdd(&b.ctr[0], n_search);
