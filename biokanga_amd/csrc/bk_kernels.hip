@@ -95,6 +95,20 @@ __device__ __forceinline__ int cmp_core(const uint64_t *__restrict__ rdw, int of
     return 0;
 }
 
+// entry table in LDS for kernels that look an entry up per candidate (the table is a few dozen sequences for
+// assembled genomes; bigger tables stay in global memory)
+struct LdsEntries {
+    uint64_t start[128], end[128];
+    bool on;
+};
+__device__ __forceinline__ void lds_entries_load(LdsEntries &le, const DevIndex &ix)
+{
+    le.on = ix.n_ent <= 128;
+    if (le.on)
+        for (uint32_t i = threadIdx.x; i < ix.n_ent; i += blockDim.x) { le.start[i] = ix.ent_start[i]; le.end[i] = ix.ent_end[i]; }
+    __syncthreads();
+}
+
 __device__ __forceinline__ int find_entry(const DevIndex &ix, uint64_t t)
 {
     int lo = 0, hi = (int)ix.n_ent - 1;
@@ -102,6 +116,19 @@ __device__ __forceinline__ int find_entry(const DevIndex &ix, uint64_t t)
         int mid = (lo + hi) >> 1;
         if (t < ix.ent_start[mid]) hi = mid - 1;
         else if (t > ix.ent_end[mid]) lo = mid + 1;
+        else return mid;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int find_entry_lds(const LdsEntries &le, const DevIndex &ix, uint64_t t)
+{
+    if (!le.on) return find_entry(ix, t);
+    int lo = 0, hi = (int)ix.n_ent - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        if (t < le.start[mid]) hi = mid - 1;
+        else if (t > le.end[mid]) lo = mid + 1;
         else return mid;
     }
     return -1;
@@ -873,6 +900,8 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
                                                 uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
                                                 uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ cmax_next)
 {
+    __shared__ LdsEntries s_le;
+    lds_entries_load(s_le, ix);
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
     if (a < n_act) {
@@ -909,7 +938,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
                         uint64_t loci = sa_get<WIDE>(ix, first + j);
                         if (loci < (uint64_t)ofs[c]) continue;
                         uint64_t t = loci - (uint64_t)ofs[c];
-                        int e = find_entry(ix, t);
+                        int e = find_entry_lds(s_le, ix, t);
                         if (e < 0 || t + (uint64_t)len - 1 > ix.ent_end[e]) continue;
                         // already processed through an earlier core of this strand pass?  (no core
                         // interval is truncated here, so "processed" == "that core matches at t")
@@ -1879,6 +1908,8 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ next_act,
                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next)
 {
+    __shared__ LdsEntries s_le;
+    lds_entries_load(s_le, ix);
     const int lane = threadIdx.x & 63;
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wave_slot >= hs.n_slots) return;
@@ -1962,7 +1993,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     int e = -1;
                     bool valid = active && loci >= (uint64_t)ofs;
                     if (valid) {
-                        e = find_entry(ix, t);
+                        e = find_entry_lds(s_le, ix, t);
                         valid = e >= 0 && t + (uint64_t)len - 1 <= ix.ent_end[e];
                     }
                     uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
