@@ -346,3 +346,55 @@ def test_edge_case_reads_match_oracle(golden_tmp):
             for f in FIELDS:
                 assert one[f][0] == exp[f][40]
     sfx.close()
+
+
+def test_many_sequences(golden_tmp):
+    """300 short sequences (> 128: entry table outside LDS; > 64: no lane-per-entry lookup), some of them copies of
+    each other, reads that hang over sequence ends: every field as the oracle has it, counts per sequence included"""
+    import torch
+    bk = _bk()
+    rng = np.random.default_rng(314)
+    n_seq, L = 300, 1000
+    seqs = [rng.integers(0, 4, L).astype(np.uint8) for _ in range(n_seq)]
+    for k in range(0, n_seq, 10):                                        # every tenth sequence repeats its neighbour
+        seqs[k] = seqs[k + 1].copy()
+        seqs[k][rng.integers(0, L, 5)] ^= 1
+    concat = np.concatenate([np.concatenate([s, [7]]) for s in seqs]).astype(np.uint8)
+    n = len(concat)
+    entries = [(i + 1, L, i * (L + 1), i * (L + 1) + L - 1) for i in range(n_seq)]
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(concat).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    reads, lens = [], []
+    for i in range(6000):
+        p = int(rng.integers(0, n - 120))                                # may span an EOS
+        ln = int(rng.integers(50, 121))
+        r = concat[p:p + ln].copy()
+        r[r == 7] = rng.integers(0, 4)
+        for _ in range(i % 4):
+            q = int(rng.integers(0, ln)); r[q] = (r[q] + 1) & 3
+        if i % 2:
+            r = (3 - r)[::-1]
+        reads.append(r); lens.append(ln)
+    bases = np.concatenate(reads).astype(np.uint8)
+    lens = np.array(lens, dtype=np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.uint64)
+    ora = helpers.OracleSfx(seq=concat, sa=sa, el_size=4, entries=entries)
+    exp, octr = ora.align(bases, offs, lens, helpers.make_params(max_subs=3))
+    ora.close()
+    ent = np.zeros(n_seq, dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"s{eid}".encode(), b"")
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=d_seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(), el_size=4, entries=ent) as al:
+        got = al.align(bases, offs, lens)
+        counts = al.seq_counts()
+        al.tune("use_wave", 0)                                           # general-path kernels too
+        got2 = al.align(bases, offs, lens)
+    for f in FIELDS:
+        assert np.array_equal(got[f], exp[f]), f
+        assert np.array_equal(got2[f], exp[f]), f
+    assert (exp["nar"] == 1).sum() > 3000 and (exp["nar"] == 5).sum() > 100      # accepted and multi-loci (ML) both occur
+    for k in range(n_seq):
+        assert counts[k] == np.count_nonzero((exp["nar"] == 1) & (exp["chrom_id"] == k + 1))
