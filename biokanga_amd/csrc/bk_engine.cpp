@@ -50,6 +50,12 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
 int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_size, hipStream_t s);
+int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, void *tmp, size_t *tmp_bytes, hipStream_t s);
+void launch_loci_count(const bk_hit *out, uint32_t n, unsigned long long *cnt, hipStream_t s);
+void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
+                        hipStream_t s);
+void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, hipStream_t s);
 int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
                      void *tmp, size_t *tmp_bytes, hipStream_t s);
 void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s);
@@ -134,6 +140,9 @@ struct bk_ctx {
 
     bk_timing timing{};
     std::vector<hipEvent_t> ev_pool;
+    // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)
+    std::vector<uint64_t> loci_offs;
+    std::vector<bk_loci> loci;
 };
 
 namespace {
@@ -144,13 +153,13 @@ int derive_cfg(bk_ctx *c)
     if (p.max_subs < 0 || p.max_subs > 25 || p.min_edit_dist < 1 || p.min_edit_dist > 2 || p.align_strand < 0 ||
         p.align_strand > 2 || p.pmode < 0 || p.pmode > 3 || p.max_ns < 0 || p.max_ns > 5)
         return BK_ERR_PARAMS;
-    if (p.max_ml != 0 && p.max_ml != 1) return BK_ERR_PARAMS;   // multi-loci modes: not built yet
+    if (p.max_ml < 0 || p.max_ml > BK_MAX_ML) return BK_ERR_PARAMS;
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
     g.mm_delta = p.min_edit_dist;
     g.align_strand = p.align_strand;
     g.max_ns = p.max_ns;
-    g.max_hits = 1;
+    g.max_hits = p.max_ml > 1 ? p.max_ml : 1;
     // CAligner::LocateCoredApprox, Aligner.cpp:8725-8761
     uint64_t t = c->tot_seq_len;
     int m;
@@ -511,6 +520,64 @@ static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
     return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 12 + 4 * 4;
 }
 
+// Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
+// entries each).  Counts -> offsets (scan) -> single loci copied from the result records, the others replayed
+// by the ENUM form of the wave-per-read kernel; appended to the context's host vectors.
+int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, hipStream_t s)
+{
+    unsigned long long *d_cnt = nullptr, *d_offs = nullptr;
+    void *d_tmp = nullptr;
+    bk_loci *d_loci = nullptr;
+    int rc = BK_OK;
+    auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_loci); };
+#define LOCI_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
+    LOCI_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
+    LOCI_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
+    LOCI_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 8, s));
+    launch_loci_count(b.out, n, d_cnt, s);
+    size_t tb = 0;
+    if (scan_counts_u64(nullptr, nullptr, n + 1, nullptr, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
+    LOCI_TRY(hipMalloc(&d_tmp, tb ? tb : 16));
+    if (scan_counts_u64(d_cnt, d_offs, n + 1, d_tmp, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
+    const size_t base = c->loci_offs.empty() ? 0 : c->loci_offs.size() - 1;      // reads of earlier chunks
+    const uint64_t loci_base = c->loci.size();
+    if (c->loci_offs.empty()) c->loci_offs.push_back(0);
+    c->loci_offs.resize(base + n + 1);
+    LOCI_TRY(hipMemcpyAsync(c->loci_offs.data() + base, d_offs, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+    LOCI_TRY(hipStreamSynchronize(s));
+    const uint64_t total = c->loci_offs[base + n];
+    if (total) {
+        uint32_t *sm = c->d_small;
+        LOCI_TRY(hipMalloc(&d_loci, (size_t)total * sizeof(bk_loci)));
+        LOCI_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
+        uint32_t *list = c->d_act[0];                  // the phase work lists are free by now
+        launch_loci_single(b.out, n, d_offs, d_loci, list, sm + 0, s);
+        LOCI_TRY(hipMemcpyAsync(c->h_small, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+        LOCI_TRY(hipStreamSynchronize(s));
+        const uint32_t n_multi = c->h_small[0];
+        if (n_multi) {
+            rc = size_heavy_scratch(c);
+            if (rc) { cleanup(); return rc; }
+            launch_loci_enum(c->ix, c->cfg, b, c->hs, list, n_multi, sm + 1, d_offs, d_loci, sm + 2, s);
+            LOCI_TRY(hipGetLastError());
+            LOCI_TRY(hipMemcpyAsync(c->h_small, sm, 16 * 4, hipMemcpyDeviceToHost, s));
+        }
+        c->loci.resize(loci_base + total);
+        LOCI_TRY(hipMemcpyAsync(c->loci.data() + loci_base, d_loci, (size_t)total * sizeof(bk_loci), hipMemcpyDeviceToHost, s));
+        LOCI_TRY(hipStreamSynchronize(s));
+        if (n_multi && c->h_small[2] != 0) {           // a replay that did not reproduce LowHitInstances: never ignore
+            fprintf(stderr, "bk: loci replay disagreed with LowHitInstances for %u reads\n", c->h_small[2]);
+            cleanup();
+            return BK_ERR_INTERNAL;
+        }
+    }
+    if (loci_base)
+        for (size_t i = 0; i <= n; i++) c->loci_offs[base + i] += loci_base;
+#undef LOCI_TRY
+    cleanup();
+    return BK_OK;
+}
+
 int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n, uint32_t maxlen,
                 bk_hit *d_out, hipStream_t s, EvTimer &tm)
 {
@@ -633,6 +700,10 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     launch_count_seqs(d_out, n, c->d_id2idx, c->ix.n_ent, c->d_seq_counts, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e4, s);
+    if (c->cfg.max_hits > 1) {
+        int rl = collect_loci(c, b, n, s);
+        if (rl) return rl;
+    }
     return BK_OK;
 }
 
@@ -641,6 +712,8 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
 {
     EvTimer tm{c};
     hipEvent_t t0 = tm.begin(s);
+    c->loci_offs.clear();
+    c->loci.clear();
     // longest read of the call -> row width of the packed reads and the kernel family used
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
     launch_max_len(d_lens, nreads, c->d_small + 5, s);
@@ -714,6 +787,16 @@ static int pair_on_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
 }
 
 extern "C" {
+
+int bk_batch_loci(bk_ctx *c, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci)
+{
+    if (!c || !offs || !loci || !n_loci) return BK_ERR_PARAMS;
+    if (c->loci_offs.empty()) { *offs = nullptr; *loci = nullptr; *n_loci = 0; return BK_OK; }
+    *offs = c->loci_offs.data();
+    *loci = c->loci.data();
+    *n_loci = c->loci.size();
+    return BK_OK;
+}
 
 const char *bk_version(void) { return "biokanga_amd 0.1 (gfx950; reference biokanga 4.4.2)"; }
 

@@ -1902,11 +1902,20 @@ __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_
 // ------------------------------------------------------------------------------------------------
 // general wave-per-read form of one LocateCoreMultiples call
 
-template <bool WIDE>
+//
+// ENUM form (multi-loci modes, MaxHits > 1): the read's result is already known; the call that produced it (its
+// AlignReads phase is kept in bk_hit.flags) is replayed with the same cut-off rules and every candidate whose
+// Hamming distance equals the final LowMMCnt is written out in discovery order - the contents of the
+// reference's pHits[] when LocateCoreMultiples returns (SfxArrayV2.cpp:6157-6205: '+' strand first, cores in
+// order, suffix array order within a core).  `enum_err` counts reads whose replay did not reproduce
+// LowHitInstances (must stay 0).
+template <bool WIDE, bool ENUM>
 __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
-                                               const uint32_t *__restrict__ list, uint32_t n_list, int phase,
+                                               const uint32_t *__restrict__ list, uint32_t n_list, int phase_arg,
                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ next_act,
-                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next)
+                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next,
+                                               const unsigned long long *__restrict__ loci_offs, bk_loci *__restrict__ loci_out,
+                                               uint32_t *__restrict__ enum_err)
 {
     __shared__ LdsEntries s_le;
     lds_entries_load(s_le, ix);
@@ -1942,6 +1951,16 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         int len = (int)b.lens[r];
         ReadPlan p = make_plan(len, cfg);
         int mm, cl, cd;
+        int phase = phase_arg, want_mm = 0;
+        uint32_t want_n = 0, emitted = 0;
+        unsigned long long emit_base = 0;
+        if (ENUM) {
+            const bk_hit h = b.out[r];
+            phase = h.flags >> 1;
+            want_mm = h.low_mm;
+            want_n = (uint32_t)h.low_hit_instances;
+            emit_base = loci_offs[r];
+        }
         phase_params(p, cfg, phase, mm, cl, cd);
         n_lcm++;
         const int init = mm + cfg.mm_delta + 1;
@@ -2023,9 +2042,31 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     if (proc) htab_insert(tab, tmask, epoch, key);
                     int cm = 127;
                     if (proc) {
-                        int lim = mm < nxt - 1 ? mm : nxt - 1;
+                        int lim = ENUM ? want_mm : (mm < nxt - 1 ? mm : nxt - 1);
                         cm = hamming(rdw, len, ix.tgt4, t, lim);
                         if (cm > lim) cm = 127;
+                    }
+                    if (ENUM) {
+                        const bool hit = proc && cm == want_mm;
+                        const uint64_t hmask = __ballot(hit);
+                        if (hit) {
+                            const uint32_t k = emitted + (uint32_t)__popcll(hmask & lt_mask);
+                            if (k < want_n) {
+                                bk_loci L;
+                                L.chrom_id = ix.ent_id[e];
+                                L.match_loci = (uint32_t)(t - ix.ent_start[e]);
+                                L.match_len = (uint16_t)len;
+                                L.strand = (uint8_t)(st ? '-' : '+');
+                                L.mismatches = (uint8_t)cm;
+                                loci_out[emit_base + k] = L;
+                            }
+                        }
+                        emitted += (uint32_t)__popcll(hmask);
+                        const uint32_t np = (uint32_t)__popcll(__ballot(proc));
+                        iter += np;
+                        nodes += np;
+                        if (cutoff < j0 + 64) break;
+                        continue;
                     }
                     bool acc = cm != 127;
                     // early exit once MaxHits+1 exact instances have been seen, in order (:6206)
@@ -2076,6 +2117,10 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                 o += cur;
             }
         }
+        if (ENUM) {
+            if (lane == 0 && emitted != want_n) atomicAdd(enum_err, 1u);
+            continue;
+        }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
         if (rslt != BK_HR_NONE) {
             if (lane == 0)
@@ -2093,11 +2138,39 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+        if (!ENUM) {                                   // the replay is ours, not work the reference does
+            if (n_search) atomicAdd(&b.ctr[0], n_search);
+            if (n_cand) atomicAdd(&b.ctr[1], n_cand);
+            if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
+            if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+        }
     }
+}
+
+// multi-loci bookkeeping: per read the number of loci to report (LowHitInstances of a read whose AlignReads
+// returned eHRhits, else 0); after the scan, reads with one locus copy it from their result record and reads
+// with several are queued for the replay above
+__global__ void __launch_bounds__(256) k_loci_count(const bk_hit *__restrict__ out, uint32_t n, unsigned long long *__restrict__ cnt)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const bk_hit h = out[r];
+    cnt[r] = (h.rslt == BK_HR_HITS && h.low_hit_instances > 0) ? (unsigned long long)h.low_hit_instances : 0ULL;
+}
+
+__global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ out, uint32_t n, const unsigned long long *__restrict__ offs,
+                                                     bk_loci *__restrict__ loci, uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const bk_hit h = out[r];
+    if (h.rslt != BK_HR_HITS || h.low_hit_instances <= 0) return;
+    if (h.low_hit_instances == 1) {
+        bk_loci L;
+        L.chrom_id = h.chrom_id; L.match_loci = h.match_loci; L.match_len = h.match_len; L.strand = h.strand; L.mismatches = h.mismatches;
+        loci[offs[r]] = L;
+    } else
+        list[atomicAdd(list_cnt, 1u)] = r;
 }
 
 __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)
@@ -2648,8 +2721,29 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 {
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-    if (ix.sa_hi) hipLaunchKernelGGL(k_heavy<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
-    else hipLaunchKernelGGL(k_heavy<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((k_heavy<false, false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+}
+
+void launch_loci_count(const bk_hit *out, uint32_t n, unsigned long long *cnt, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_loci_count, dim3((n + 255) / 256), dim3(256), 0, s, out, n, cnt);
+}
+
+void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
+                        hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_loci_single, dim3((n + 255) / 256), dim3(256), 0, s, out, n, offs, loci, list, list_cnt);
+}
+
+void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, hipStream_t s)
+{
+    if (!n_list) return;
+    uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
+    unsigned blocks = (waves + 3) / 4;
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
+    else hipLaunchKernelGGL((k_heavy<false, true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
 }
 
 }  // namespace bk

@@ -172,4 +172,13 @@ int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t
     return e == hipSuccess ? 0 : -100;
 }
 
+// exclusive prefix sum over 64-bit counts (loci list offsets of the multi-loci modes); same tmp protocol
+int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, void *tmp, size_t *tmp_bytes, hipStream_t s)
+{
+    size_t tb = *tmp_bytes;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, in, out, (size_t)n, s);
+    if (tmp == nullptr) *tmp_bytes = tb;
+    return e == hipSuccess ? 0 : -100;
+}
+
 }  // namespace bk

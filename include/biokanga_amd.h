@@ -50,7 +50,8 @@ typedef struct bk_align_params {
     int32_t align_strand;   /* -Q  0 both strands, 1 sense only, 2 antisense only               */
     int32_t pmode;          /* -m  0 default, 1 more sensitive, 2 ultra sensitive, 3 less sens. */
     int32_t max_ns;         /* -n  max indeterminate bases per 100 bp (default 1)               */
-    int32_t max_ml;         /* MaxMLmatches; 1 (the default -r0 mode) is the supported value    */
+    int32_t max_ml;         /* -R  MaxMLmatches (MaxHits of AlignReads): 1 in the default -r0 mode, 2..BK_MAX_ML in the
+                             *     multi-loci modes -r1..-r5, whose loci lists bk_batch_loci() then returns         */
     int32_t reserved[2];
 } bk_align_params;
 
@@ -175,6 +176,27 @@ int  bk_pair_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, cons
  * for exactly these reads); nothing crosses PCIe */
 int  bk_pair_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs,
                           void *d_hits, const bk_pe_params *pe);
+
+/* ---- multi-loci modes (-r1..-r5: AlignReads called with MaxHits = -R > 1) ---------------------- */
+/* One locus of a read that aligned to 1..MaxHits places with the same, lowest, number of mismatches: the
+ * Seg[0] fields of the tsHitLoci entries LocateCoreMultiples leaves in pHits[] (SfxArrayV2.cpp:6157-6205),
+ * in the reference's discovery order ('+' strand first, cores in order, suffix-array order within a core) -
+ * the order `-r5` reports them in and `-r2` indexes with rand() (Aligner.cpp:9337-9366).  12 bytes. */
+#define BK_MAX_ML 32766
+typedef struct bk_loci {
+    uint32_t chrom_id;           /* Seg[0].ChromID                  */
+    uint32_t match_loci;         /* Seg[0].MatchLoci                */
+    uint16_t match_len;          /* Seg[0].MatchLen                 */
+    uint8_t  strand;             /* '+' or '-'                      */
+    uint8_t  mismatches;         /* Seg[0].Mismatches               */
+} bk_loci;
+/* Loci lists of the reads of the LAST bk_align_batch()/bk_align_batch_device() call on a context created
+ * with max_ml > 1: read r owns loci[offs[r] .. offs[r+1]), that is LowHitInstances entries when its
+ * bk_hit.rslt is eHRhits (1 for a unique read, whose record it repeats) and none otherwise.  The pointers
+ * are host memory owned by the context, valid until its next align call.  With max_ml == 1 there are no
+ * lists (*n_loci = 0, NULL pointers).  What to do with them (-r1 statistics, -r2 random pick, -r3/-r4
+ * clustering, -r5 report all; Aligner.cpp:9328-9424,5105-5272) is host policy above this boundary. */
+int  bk_batch_loci(bk_ctx *ctx, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
 
 /* counters/timing accumulated since the last reset */
 int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);

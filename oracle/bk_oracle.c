@@ -485,8 +485,10 @@ int ora_max_iter(int pmode)
 
 static int imax(int a, int b) { return a > b ? a : b; }
 
+/* loci_out (optional): room for p->max_ml entries - the pHits[] contents of a read whose AlignReads returned
+ * eHRhits, in the order LocateCoreMultiples left them (the multi-loci modes -r1..-r5 consume these) */
 static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *bases, int len,
-                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf)
+                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf, ora_loci *loci_out)
 {
     memset(out, 0, sizeof(*out));
     out->nar = NAR_NOHIT;                                      /* Aligner.cpp:9030 */
@@ -516,15 +518,22 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
 
     int low_inst = 0, low_mm = 0, nxt = 0;
     int max_ml = p->max_ml > 0 ? p->max_ml : 1;
-    hit_rec hits[8];
-    memset(hits, 0, sizeof(hits));
-    if (max_ml > 7) max_ml = 7;
+    hit_rec hits_small[8];
+    hit_rec *hits = hits_small;
+    if (max_ml > 7) hits = (hit_rec *)malloc(sizeof(hit_rec) * ((size_t)max_ml + 1));
+    memset(hits, 0, sizeof(hit_rec) * ((size_t)max_ml + 1));
     int rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
                            &low_inst, &low_mm, &nxt, seqbuf, match_len, max_ml, hits,
                            ora_max_iter(p->pmode), sc, ctr);
-    if (rslt < 0) return rslt;
+    if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }
     if (low_inst > max_ml) low_inst = max_ml + 1;                                       /* :9241 */
     out->rslt = (uint8_t)rslt;
+    if (loci_out && rslt == HR_HITS)
+        for (int k = 0; k < low_inst && k < max_ml; k++) {
+            loci_out[k].chrom_id = hits[k].chrom_id; loci_out[k].match_loci = hits[k].match_loci;
+            loci_out[k].match_len = hits[k].match_len; loci_out[k].strand = hits[k].strand;
+            loci_out[k].mismatches = hits[k].mismatches;
+        }
 
     switch (rslt) {                                                                     /* :9311-9479 */
     case HR_NONE:
@@ -569,6 +578,7 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
         out->nxt_low_mm = (int8_t)nxt;
         break;
     }
+    if (hits != hits_small) free(hits);
     return 0;
 }
 
@@ -585,7 +595,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 {
     scratch *sc = scratch_new();
     uint8_t *buf = (uint8_t *)malloc((size_t)len + 16);
-    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf);
+    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf, NULL);
     free(buf);
     scratch_free(sc);
     return r;
@@ -593,7 +603,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 
 typedef struct worker {
     const ora_sfx *s; const ora_params *p; const uint8_t *bases; const uint64_t *offs;
-    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt;
+    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt; ora_loci *loci;
 } worker;
 
 static void *worker_main(void *arg)
@@ -604,7 +614,8 @@ static void *worker_main(void *arg)
     for (uint32_t i = w->lo; i < w->hi; i++) if (w->lens[i] > maxlen) maxlen = w->lens[i];
     uint8_t *buf = (uint8_t *)malloc((size_t)maxlen + 16);
     for (uint32_t i = w->lo; i < w->hi; i++) {
-        int r = align_read_sc(w->s, w->p, w->bases + w->offs[i], (int)w->lens[i], &w->out[i], &w->ctr, sc, buf);
+        ora_loci *lo = w->loci ? w->loci + (size_t)i * (size_t)(w->p->max_ml > 0 ? w->p->max_ml : 1) : NULL;
+        int r = align_read_sc(w->s, w->p, w->bases + w->offs[i], (int)w->lens[i], &w->out[i], &w->ctr, sc, buf, lo);
         if (r < 0) { w->rslt = r; break; }
     }
     free(buf);
@@ -616,6 +627,13 @@ int ora_align_batch(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
                     const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                     ora_hit *out, ora_counters *ctr, int nthreads)
 {
+    return ora_align_batch_multi(s, p, bases, offs, lens, nreads, out, NULL, ctr, nthreads);
+}
+
+int ora_align_batch_multi(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
+                          const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                          ora_hit *out, ora_loci *loci, ora_counters *ctr, int nthreads)
+{
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > nreads) nthreads = nreads ? (int)nreads : 1;
     worker *w = (worker *)calloc((size_t)nthreads, sizeof(worker));
@@ -624,7 +642,7 @@ int ora_align_batch(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
      * reads are independent so a static split gives the same answers */
     uint64_t per = ((uint64_t)nreads + nthreads - 1) / nthreads;
     for (int t = 0; t < nthreads; t++) {
-        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out;
+        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out; w[t].loci = loci;
         uint64_t lo = per * t, hi = lo + per;
         if (lo > nreads) lo = nreads;
         if (hi > nreads) hi = nreads;

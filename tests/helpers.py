@@ -66,6 +66,10 @@ def oracle_lib():
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                     ctypes.POINTER(OraCounters), ctypes.c_int]
     lib.ora_align_batch.restype = ctypes.c_int
+    lib.ora_align_batch_multi.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.POINTER(OraCounters), ctypes.c_int]
+    lib.ora_align_batch_multi.restype = ctypes.c_int
     lib.ora_process_paired_ends.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                             ctypes.c_void_p]
@@ -125,6 +129,30 @@ class OracleSfx:
         if rc != 0:
             raise RuntimeError(f"ora_align_batch failed: {rc}")
         return out, ctr
+
+
+LOCI_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("strand", "u1"), ("mismatches", "u1")])
+
+
+def oracle_align_multi(osfx, bases, offs, lens, params, nthreads=4):
+    """Multi-loci form (params.max_ml > 1) -> (hits, offs[n+1], loci) in the layout bk_batch_loci() returns."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = len(lens)
+    ml = max(1, params.max_ml)
+    out = np.zeros(n, dtype=HIT_DTYPE)
+    dense = np.zeros((n, ml), dtype=LOCI_DTYPE)
+    ctr = OraCounters()
+    rc = osfx.lib.ora_align_batch_multi(osfx.h, ctypes.byref(params), bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, n,
+                                        out.ctypes.data, dense.ctypes.data, ctypes.byref(ctr), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"ora_align_batch_multi failed: {rc}")
+    cnt = np.where(out["rslt"] == 1, out["low_hit_instances"].astype(np.int64), 0)
+    lo = np.zeros(n + 1, dtype=np.uint64)
+    lo[1:] = np.cumsum(cnt)
+    mask = np.arange(ml)[None, :] < cnt[:, None]
+    return out, lo, dense[mask]
 
 
 def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits):

@@ -143,13 +143,26 @@ def test_device_resident_batch_and_sa_builder(golden_tmp):
     assert_hits_equal(got, ref)
 
 
-def _synth_case(seed, n_genome, n_reads, read_len, max_e):
+def _synth_case(seed, n_genome, n_reads, read_len, max_e, dup_len=0):
     rng = np.random.default_rng(seed)
     # two sequences with a planted repeat family so multi-loci / truncation paths trigger
     g = rng.integers(0, 4, n_genome, dtype=np.uint8)
     fam = rng.integers(0, 4, 60, dtype=np.uint8)
     for p in rng.integers(0, n_genome - 100, 300):
         g[p:p + 60] = fam
+    if dup_len:
+        # segments longer than a read present in 2..9 places, half of the copies with one substitution:
+        # reads from them align to several loci with the same (or a next-best) number of mismatches
+        for _ in range(120):
+            src = int(rng.integers(0, n_genome - dup_len))
+            seg = g[src:src + dup_len].copy()
+            for _c in range(int(rng.integers(1, 9))):
+                dst = int(rng.integers(0, n_genome - dup_len))
+                cp = seg.copy()
+                if rng.integers(0, 2):
+                    q = int(rng.integers(0, dup_len))
+                    cp[q] = (cp[q] + 1) % 4
+                g[dst:dst + dup_len] = cp
     cut = n_genome // 2
     seq = np.concatenate([g[:cut], [7], g[cut:], [7]]).astype(np.uint8)
     ents = np.zeros(2, dtype=_bk().ENTRY_DTYPE)
@@ -398,3 +411,61 @@ def test_many_sequences(golden_tmp):
     assert (exp["nar"] == 1).sum() > 3000 and (exp["nar"] == 5).sum() > 100      # accepted and multi-loci (ML) both occur
     for k in range(n_seq):
         assert counts[k] == np.count_nonzero((exp["nar"] == 1) & (exp["chrom_id"] == k + 1))
+
+
+def _assert_loci_equal(bk, al, nreads, got_hits, exp_hits, exp_offs, exp_loci):
+    assert_hits_equal(got_hits, exp_hits)
+    offs, loci = al.batch_loci(nreads)
+    assert np.array_equal(offs, exp_offs)
+    assert len(loci) == len(exp_loci)
+    for f in ("chrom_id", "match_loci", "match_len", "strand", "mismatches"):
+        if not np.array_equal(loci[f], exp_loci[f]):
+            i = int(np.nonzero(loci[f] != exp_loci[f])[0][0])
+            r = int(np.searchsorted(offs, i, side="right") - 1)
+            raise AssertionError(f"loci field {f} differs at entry {i} (read {r}): got {loci[i]} exp {exp_loci[i]}")
+
+
+@pytest.mark.parametrize("max_ml", [2, 5, 64, 500])
+@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
+def test_multi_loci_lists_match_oracle(golden_tmp, fixture, max_ml):
+    """MaxHits > 1 (the -R of the multi-loci modes): result records AND the pHits[] lists, in the reference's
+    discovery order, against the oracle"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
+    kw = dict(max_subs=3, max_ml=max_ml)
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, eo, el = helpers.oracle_align_multi(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    sfx.close()
+    for knobs in ([], [("use_wave", 0)], [("use_isa", 0)], [("heavy_thresh", 0)], [("chunk_reads", 257)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs[keep], lens[keep])
+            _assert_loci_equal(bk, al, len(keep), got, exp, eo, el)
+
+
+@pytest.mark.parametrize("read_len,max_subs,max_ml", [(100, 3, 5), (150, 5, 20), (64, 10, 3), (300, 3, 8)])
+def test_multi_loci_synthetic(tmp_path, read_len, max_subs, max_ml):
+    import torch
+    bk = _bk()
+    seq, ents, reads = _synth_case(23 + read_len, 300000, 12000, read_len, 4, dup_len=2 * read_len + 50)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    path = str(tmp_path / "synth.sfx")
+    helpers.write_sfx(path, "synth", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = (np.arange(nreads, dtype=np.uint64) * read_len)
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    kw = dict(max_subs=max_subs, max_ml=max_ml)
+    o = helpers.OracleSfx(path)
+    exp, eo, el = helpers.oracle_align_multi(o, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    o.close()
+    with bk.Aligner(path, bk.AlignParams(**kw)) as al:
+        got = al.align(bases, offs, lens)
+        _assert_loci_equal(bk, al, nreads, got, exp, eo, el)
+    assert np.count_nonzero(np.diff(eo.astype(np.int64)) > 1) > 20
