@@ -51,7 +51,7 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
                   hipStream_t s);
 int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_size, hipStream_t s);
 int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, void *tmp, size_t *tmp_bytes, hipStream_t s);
-void launch_loci_count(const bk_hit *out, uint32_t n, unsigned long long *cnt, hipStream_t s);
+void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
                         hipStream_t s);
 void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
@@ -534,7 +534,7 @@ int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, hipStream_t s)
     LOCI_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
     LOCI_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
     LOCI_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 8, s));
-    launch_loci_count(b.out, n, d_cnt, s);
+    launch_loci_count(b.out, n, c->params.clamp_ml ? c->cfg.max_hits : 0, d_cnt, s);
     size_t tb = 0;
     if (scan_counts_u64(nullptr, nullptr, n + 1, nullptr, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
     LOCI_TRY(hipMalloc(&d_tmp, tb ? tb : 16));

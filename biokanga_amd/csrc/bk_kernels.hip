@@ -1954,12 +1954,14 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         int phase = phase_arg, want_mm = 0;
         uint32_t want_n = 0, emitted = 0;
         unsigned long long emit_base = 0;
+        bool clamped = false;
         if (ENUM) {
             const bk_hit h = b.out[r];
             phase = h.flags >> 1;
             want_mm = h.low_mm;
-            want_n = (uint32_t)h.low_hit_instances;
             emit_base = loci_offs[r];
+            want_n = (uint32_t)(loci_offs[r + 1] - emit_base);
+            clamped = h.rslt == BK_HR_HITINSTS;      // -X: only the first MaxHits loci of a read with more
         }
         phase_params(p, cfg, phase, mm, cl, cd);
         n_lcm++;
@@ -2062,6 +2064,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                             }
                         }
                         emitted += (uint32_t)__popcll(hmask);
+                        if (clamped && emitted >= want_n) done = true;
                         const uint32_t np = (uint32_t)__popcll(__ballot(proc));
                         iter += np;
                         nodes += np;
@@ -2118,7 +2121,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
             }
         }
         if (ENUM) {
-            if (lane == 0 && emitted != want_n) atomicAdd(enum_err, 1u);
+            if (lane == 0 && (clamped ? emitted < want_n : emitted != want_n)) atomicAdd(enum_err, 1u);
             continue;
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
@@ -2150,12 +2153,16 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
 // multi-loci bookkeeping: per read the number of loci to report (LowHitInstances of a read whose AlignReads
 // returned eHRhits, else 0); after the scan, reads with one locus copy it from their result record and reads
 // with several are queued for the replay above
-__global__ void __launch_bounds__(256) k_loci_count(const bk_hit *__restrict__ out, uint32_t n, unsigned long long *__restrict__ cnt)
+__global__ void __launch_bounds__(256) k_loci_count(const bk_hit *__restrict__ out, uint32_t n, int clamp_to,
+                                                    unsigned long long *__restrict__ cnt)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const bk_hit h = out[r];
-    cnt[r] = (h.rslt == BK_HR_HITS && h.low_hit_instances > 0) ? (unsigned long long)h.low_hit_instances : 0ULL;
+    unsigned long long c = 0;
+    if (h.rslt == BK_HR_HITS && h.low_hit_instances > 0) c = (unsigned long long)h.low_hit_instances;
+    else if (h.rslt == BK_HR_HITINSTS && clamp_to > 0) c = (unsigned long long)clamp_to;
+    cnt[r] = c;
 }
 
 __global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ out, uint32_t n, const unsigned long long *__restrict__ offs,
@@ -2164,8 +2171,8 @@ __global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ 
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const bk_hit h = out[r];
-    if (h.rslt != BK_HR_HITS || h.low_hit_instances <= 0) return;
-    if (h.low_hit_instances == 1) {
+    if (offs[r + 1] == offs[r]) return;
+    if (h.rslt == BK_HR_HITS && h.low_hit_instances == 1) {
         bk_loci L;
         L.chrom_id = h.chrom_id; L.match_loci = h.match_loci; L.match_len = h.match_len; L.strand = h.strand; L.mismatches = h.mismatches;
         loci[offs[r]] = L;
@@ -2725,9 +2732,9 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     else hipLaunchKernelGGL((k_heavy<false, false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
 }
 
-void launch_loci_count(const bk_hit *out, uint32_t n, unsigned long long *cnt, hipStream_t s)
+void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_loci_count, dim3((n + 255) / 256), dim3(256), 0, s, out, n, cnt);
+    if (n) hipLaunchKernelGGL(k_loci_count, dim3((n + 255) / 256), dim3(256), 0, s, out, n, clamp_to, cnt);
 }
 
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,

@@ -32,7 +32,9 @@
 #include "../sfx_file.h"
 #include "bam_writer.h"
 #include "fasta.h"
+#include "glibc_rand.h"
 #include "mtqsort.h"
+#include "multi_assign.h"
 
 namespace {
 
@@ -138,6 +140,7 @@ int cmd_index(int argc, char **argv, int first)
     std::vector<bk::SfxEntry> entries;
     const size_t kChunk = 0x00ffffff;                                    // cMaxAllocBuffChunk, kangax.cpp:37
     uint32_t n_under = 0;
+    bk::GlibcRand nrun_rand;                                             // one sequence over all files, as the process-wide rand()
     std::vector<std::string> files = a.v["i"];
     std::sort(files.begin(), files.end());                               // SG_GLOB_FULLSORT
     for (const std::string &fn : files) {
@@ -165,7 +168,7 @@ int cmd_index(int argc, char **argv, int first)
                     if (p[k] == bk::kBaseN && (k + 5) < chunk) {
                         if (++seq_ns > 25 && p[k + 1] == bk::kBaseN && p[k + 2] == bk::kBaseN && p[k + 3] == bk::kBaseN &&
                             p[k + 4] == bk::kBaseN) {
-                            if (!(seq_ns % 13)) p[k] = (uint8_t)(rand() % 4);      // unseeded libc rand(), as the reference
+                            if (!(seq_ns % 13)) p[k] = (uint8_t)(nrun_rand.next() % 4);      // the reference's unseeded rand()
                         }
                     } else
                         seq_ns = 0;
@@ -495,8 +498,9 @@ int cmd_align(int argc, char **argv, int first)
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
-        {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJt", "E", a, err)) {
+        {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
+        {"bestmatches", "N"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtR", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -522,15 +526,34 @@ int cmd_align(int argc, char **argv, int first)
         diag("Error: paired end insert size range '-d%d -D%d' not accepted", PE.pair_min_len, PE.pair_max_len);
         return 1;
     }
-    if (a.num("r", 0) != 0) { diag("Error: multiloci modes '-r1..5' are not available in this build"); return 1; }
+    // -r multi-loci modes (kanga.cpp:482-486,535-539,666-694): 0 slough, 1 stats only, 2 random pick, 3 cluster with
+    // uniques, 4 cluster with uniques + other multi-loci reads, 5 report all loci; -R loci limit, -X clamp
+    const int ml_mode = a.num("r", 0);
+    if (ml_mode < 0 || ml_mode > 5) { diag("Error: multiple aligned reads processing mode '-r%d' specified outside of range 0..5", ml_mode); return 1; }
+    if (pe_mode && ml_mode) { diag("Error: Sorry, currently multiloci processing '-r%d' not supported in paired end '-U%d' processing", ml_mode, pe_mode); return 1; }
+    int max_ml = 1;
+    bool clamp_ml = false;
+    if (ml_mode) {
+        max_ml = a.num("R", 5);                                         // cDfltMaxMultiHits
+        const int lim = ml_mode == 5 ? 100000 : 500;                    // cMaxAllHits / cMaxMultiHits
+        if (max_ml < 2 || max_ml > lim) { diag("Error: multiple aligned reads '-R%d' specified outside of range 2..%d", max_ml, lim); return 1; }
+        if (max_ml > BK_MAX_ML) { diag("Error: '-R%d' is above the %d loci per read this build keeps", max_ml, BK_MAX_ML); return 1; }
+        if (a.has("N")) { diag("Error: '-N' (best matches, CSfxArrayV3::LocateBestMatches) is not available in this build"); return 1; }
+        clamp_ml = a.has("X");
+    }
     bk_align_params P = {};
     P.pmode = a.num("m", 0);
     P.align_strand = a.num("Q", 0);
     P.min_edit_dist = a.num("e", 1);
     P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
     P.max_ns = a.num("n", 1);
-    P.max_ml = 1;
+    P.max_ml = max_ml;
+    P.clamp_ml = clamp_ml ? 1 : 0;
     int fmt = a.num("M", 5);
+    if (ml_mode == 5 && !(fmt == 0 || fmt == 4 || fmt == 5 || fmt == 6)) {      // kanga.cpp:830-834
+        diag("Error: reporting all multiloci alignments '-r5' is only available with output formats '-M0', '-M4', '-M5' and '-M6'");
+        return 1;
+    }
     if (a.has("O") && fmt == 6) {                 // kanga.cpp:1015-1021
         diag("Error: Output induced substitution mode '-O<file>' not available in '-M6' output mode\n");
         return 1;
@@ -568,13 +591,105 @@ int cmd_align(int argc, char **argv, int first)
     size_t nr = rs.size();
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
     std::vector<bk_hit> hits(nr);
+    std::vector<uint64_t> l_offs;                  // multi-loci modes: read i owns loci [l_offs[i], l_offs[i+1])
+    std::vector<bk_loci> loci;
+    if (ml_mode) l_offs.assign(1, 0);
     const size_t kBatch = 16u << 20;
     for (size_t lo = 0; lo < nr; lo += kBatch) {
         size_t n = std::min(kBatch, nr - lo);
         rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+        if (ml_mode) {
+            const uint64_t *bo = nullptr;
+            const bk_loci *bl = nullptr;
+            uint64_t nl = 0;
+            rc = bk_batch_loci(ctx, &bo, &bl, &nl);
+            if (rc || !bo) { diag("Fatal: loci lists unavailable: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+            const uint64_t base = loci.size();
+            for (size_t i = 1; i <= n; i++) l_offs.push_back(base + bo[i]);
+            loci.insert(loci.end(), bl, bl + nl);
+        }
     }
     diag("Alignment of %zu from %zu loaded completed", nr, nr);
+
+    std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
+    std::vector<int> multi_dist((size_t)max_ml, 0);
+    if (ml_mode) {
+        // CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424); reads in load order, as -T1 runs them
+        auto eff_count = [&](size_t i) -> uint32_t {            // LowHitInstances of a read that counts as eHRhits (after -X)
+            const bk_hit &h = hits[i];
+            if (h.rslt == BK_HR_HITS || (clamp_ml && h.rslt == BK_HR_HITINSTS)) return (uint32_t)(l_offs[i + 1] - l_offs[i]);
+            return 0;
+        };
+        auto take = [&](bk_hit &h, const bk_loci &L) {
+            h.chrom_id = L.chrom_id; h.match_loci = L.match_loci; h.match_len = L.match_len; h.strand = L.strand;
+            h.mismatches = L.mismatches; h.nar = BK_NAR_ACCEPTED; h.num_hits = 1; h.low_hit_instances = 1;
+        };
+        uint64_t n_uniq = 0, n_multi = 0, n_loci = 0;
+        for (size_t i = 0; i < nr; i++) {
+            const uint32_t c = eff_count(i);
+            if (!c) continue;
+            n_loci += c;
+            (c == 1 ? n_uniq : n_multi)++;
+            if (ml_mode != 5) multi_dist[c - 1]++;
+            if (clamp_ml && hits[i].rslt == BK_HR_HITINSTS) hits[i].low_hit_instances = (int16_t)c;
+        }
+        diag("Provisionally accepted %llu aligned reads (%llu uniquely, %llu aligning to multiloci) aligning to a total of %llu loci",
+             (unsigned long long)(n_uniq + n_multi), (unsigned long long)n_uniq, (unsigned long long)n_multi, (unsigned long long)n_loci);
+        if (ml_mode == 2) {
+            // eMLrand: rand() % LowHitInstances for every eHRhits read, unique ones included (:9365-9366); the sequence is
+            // glibc's unseeded one (glibc_rand.h), which is what a single-threaded reference run consumes in the same order
+            bk::GlibcRand pick;
+            for (size_t i = 0; i < nr; i++) {
+                const uint32_t c = eff_count(i);
+                if (!c) continue;
+                const uint32_t k = (uint32_t)pick.next() % c;
+                take(hits[i], loci[l_offs[i] + k]);
+            }
+        } else if (ml_mode == 3 || ml_mode == 4) {
+            uint32_t max_reads_len = 0;
+            for (size_t i = 0; i < nr; i++) max_reads_len = std::max(max_reads_len, rs.lens[i]);
+            bk::MultiAssign ma;
+            for (size_t i = 0; i < nr; i++) {
+                const uint32_t c = eff_count(i);
+                for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[l_offs[i] + k], c > 1);
+            }
+            diag("Assigning %llu reads which aligned to multiple loci to a single loci", (unsigned long long)n_multi);
+            bk::MultiAssignStats st = ma.assign(ml_mode == 3, nthreads, max_reads_len);
+            for (const bk::MultiHitRec &m : ma.recs)
+                if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
+            diag("Clustering completed, removed %d unclustered orphans from %d putative resulting in %d (%d clustered near unique, %d clustered near other multiloci reads) multihit reads accepted as assigned",
+                 st.putative - st.assigned, st.putative, st.assigned, st.near_unique, st.near_multi);
+        } else if (ml_mode == 5) {
+            // eMLall: every locus becomes a record of its own, ReadID = order of creation (CAligner::WriteHitLoci / AddMultiHit,
+            // Aligner.cpp:6666-6800); with -M6 reads without alignment (eHRnone, eHRHitInsts) are kept as one unaligned
+            // record, everything else (EN, MMDelta) drops out (:9311-9352,9441-9449)
+            std::vector<bk_hit> recs;
+            for (size_t i = 0; i < nr; i++) {
+                const bk_hit &h = hits[i];
+                const uint32_t c = eff_count(i);
+                if (c) {
+                    for (uint32_t k = 0; k < c; k++) {
+                        bk_hit r = h;
+                        take(r, loci[l_offs[i] + k]);
+                        recs.push_back(r);
+                        src.push_back((uint32_t)i);
+                    }
+                } else if (fmt == 6 && h.nar != BK_NAR_NS && (h.rslt == BK_HR_NONE || h.rslt == BK_HR_HITINSTS)) {
+                    bk_hit r = h;
+                    r.num_hits = 0;
+                    r.low_mm = 0;
+                    recs.push_back(r);
+                    src.push_back((uint32_t)i);
+                }
+            }
+            diag("Treating accepted %llu multialigned reads as uniquely aligned %llu source reads in subsequent processing",
+                 (unsigned long long)n_multi, (unsigned long long)(n_loci - n_uniq));
+            hits.swap(recs);
+            nr = hits.size();
+        }
+    }
+    auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     if (pe_mode) {
         // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355)
         diag("Paired end association and partner alignment processing started..");
@@ -621,7 +736,7 @@ int cmd_align(int argc, char **argv, int first)
     // -j / -J: reads that found no alignment at all (NAR EN, NL) / multi-loci reads (NAR ML) as FASTA, in the sorted
     // order, 70 columns (CAligner::ReportNoneAligned / ReportMultiAlign, Aligner.cpp:3826-4010)
     auto write_read_subset = [&](const char *opt, const char *tag, auto want) {
-        if (!a.has(opt)) return;
+        if (!a.has(opt) || ml_mode == 5) return;                         // kanga.cpp:1045-1066
         OutBuf o;
         o.open(a.str(opt).c_str());
         if (o.fd < 0) { diag("Unable to create '%s'", a.str(opt).c_str()); return; }
@@ -630,10 +745,10 @@ int cmd_align(int argc, char **argv, int first)
         for (size_t k = 0; k < nr; k++) {
             const uint32_t i = order[k];
             if (!want(hits[i].nar)) continue;
-            const uint32_t len = rs.lens[i];
-            const uint8_t *sq = rs.bases.data() + rs.offs[i];
+            const uint32_t len = rs.lens[RD(i)];
+            const uint8_t *sq = rs.bases.data() + rs.offs[RD(i)];
             char hd[400];
-            int n = snprintf(hd, sizeof(hd), ">lcl|%s|%u %s %u|1|%u\n", tag, i + 1, rs.name(i), i + 1, len);
+            int n = snprintf(hd, sizeof(hd), ">lcl|%s|%u %s %u|1|%u\n", tag, i + 1, rs.name(RD(i)), i + 1, len);
             rec.assign(hd, (size_t)n);
             for (uint32_t q = 0; q < len; q++) {
                 rec.push_back(up[sq[q] & 7]);
@@ -663,7 +778,7 @@ int cmd_align(int argc, char **argv, int first)
         }
         size_t n_acc = 0;
         uint32_t max_len = 0;
-        for (size_t i = 0; i < nr; i++) if (hits[i].nar == BK_NAR_ACCEPTED) { n_acc++; max_len = std::max(max_len, rs.lens[i]); }
+        for (size_t i = 0; i < nr; i++) if (hits[i].nar == BK_NAR_ACCEPTED) { n_acc++; max_len = std::max(max_len, rs.lens[RD(i)]); }
         if (n_acc && max_len) {
             bk::SfxFile sf;
             std::string serr;
@@ -677,8 +792,8 @@ int cmd_align(int argc, char **argv, int first)
                     for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
                         const bk_hit &h = hits[i];
                         if (h.nar != BK_NAR_ACCEPTED || h.chrom_id < 1 || h.chrom_id > n_ent) continue;
-                        const uint8_t *rd = rs.bases.data() + rs.offs[i];
-                        const uint32_t len = rs.lens[i];
+                        const uint8_t *rd = rs.bases.data() + rs.offs[RD(i)];
+                        const uint32_t len = rs.lens[RD(i)];
                         const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
                         uint32_t nsub = 0;
                         for (uint32_t k = 0; k < len; k++) {
@@ -698,6 +813,13 @@ int cmd_align(int argc, char **argv, int first)
                     for (uint32_t k = 0; k < max_len; k++) { qi[0][k] += qi[(size_t)w][k]; sb[0][k] += sb[(size_t)w][k]; ms[0][k] += ms[(size_t)w][k]; }
                 static const char *band_a[4] = {"Phred 0..9", "Phred 10..19", "Phred 20..29", "Phred 30+"};
                 static const char *band_b[4] = {"Phred 0..8", "Phred 9..19", "Phred 20..29", "Phred 30+"};
+                if (ml_mode) {                                           // WriteBasicCountStats, Aligner.cpp:4203-4227
+                    fprintf(f, "\"Multihit distribution\",");
+                    for (int k = 0; k < max_ml; k++) fprintf(f, ",%d", k + 1);
+                    fprintf(f, "\n,\"Instances\"");
+                    for (int k = 0; k < max_ml; k++) fprintf(f, ",%d", multi_dist[(size_t)k]);
+                    fprintf(f, "\n");
+                }
                 fprintf(f, "\"Phred Score Instances\",");
                 for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k + 1);
                 for (int bnd = 0; bnd < 4; bnd++) {
@@ -777,8 +899,8 @@ int cmd_align(int argc, char **argv, int first)
                 const bk_hit &h = hits[i];
                 const bool acc = h.nar == BK_NAR_ACCEPTED;
                 if (!acc && fmt != 6) continue;
-                const uint8_t *sq = rs.bases.data() + rs.offs[i];
-                const uint32_t len = rs.lens[i];
+                const uint8_t *sq = rs.bases.data() + rs.offs[RD(i)];
+                const uint32_t len = rs.lens[RD(i)];
                 int flag = 0, tlen = 0;
                 long pnext = -1;
                 if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
@@ -797,7 +919,7 @@ int cmd_align(int argc, char **argv, int first)
                     } else
                         flag |= 0x8;
                 }
-                const char *qn = rs.name(i);
+                const char *qn = rs.name(RD(i));
                 const uint32_t l_qn = (uint32_t)strlen(qn) + 1;
                 const char *tag = acc ? nullptr : kNarTag[h.nar < 20 ? h.nar : 0];
                 const uint32_t aux = tag ? 3 + (uint32_t)strlen(tag) + 1 : 0;
@@ -899,9 +1021,9 @@ int cmd_align(int argc, char **argv, int first)
             const bk_hit &h = hits[i];
             bool acc = h.nar == BK_NAR_ACCEPTED;
             if (!acc && fmt != 6) return false;
-            const uint8_t *s = rs.bases.data() + rs.offs[i];
-            uint32_t len = rs.lens[i];
-            rec += rs.name(i);
+            const uint8_t *s = rs.bases.data() + rs.offs[RD(i)];
+            uint32_t len = rs.lens[RD(i)];
+            rec += rs.name(RD(i));
             int flag = 0, tlen = 0;
             long pnext = -1;
             if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
@@ -1012,6 +1134,7 @@ int cmd_align(int argc, char **argv, int first)
             std::string title = a.str("t", "kanga");
             int m = snprintf(line, sizeof(line), "track type=bed name=\"%s\" description=\"%s\"\n", title.c_str(), title.c_str());
             out.put(line, (size_t)m);
+            if (ml_mode == 5) out.put(line, (size_t)m);      // written at file creation AND by WriteReadHits (Aligner.cpp:4405-4413,6356-6362)
         }
         std::string rec;
         for (size_t k = 0; k < nr; k++) {
@@ -1027,11 +1150,11 @@ int cmd_align(int argc, char **argv, int first)
             }
             int m = snprintf(line, sizeof(line), "%u,\"ar\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, species.c_str(),
                              ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len - 1, (unsigned)h.match_len, (char)h.strand,
-                             (unsigned)h.mismatches, rs.name(i));
+                             (unsigned)h.mismatches, rs.name(RD(i)));
             rec.assign(line, (size_t)m);
-            const uint32_t len = rs.lens[i];
+            const uint32_t len = rs.lens[RD(i)];
             if (fmt >= 2) {                                              // the read as loaded
-                const uint8_t *sq = rs.bases.data() + rs.offs[i];
+                const uint8_t *sq = rs.bases.data() + rs.offs[RD(i)];
                 rec += ",\"";
                 for (uint32_t q = 0; q < len; q++) rec.push_back(up[sq[q] & 7]);
                 rec.push_back('"');

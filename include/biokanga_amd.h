@@ -52,7 +52,9 @@ typedef struct bk_align_params {
     int32_t max_ns;         /* -n  max indeterminate bases per 100 bp (default 1)               */
     int32_t max_ml;         /* -R  MaxMLmatches (MaxHits of AlignReads): 1 in the default -r0 mode, 2..BK_MAX_ML in the
                              *     multi-loci modes -r1..-r5, whose loci lists bk_batch_loci() then returns         */
-    int32_t reserved[2];
+    int32_t clamp_ml;       /* -X  with max_ml > 1: reads with more than max_ml loci (rslt eHRHitInsts) also get a loci
+                             *     list, of their first max_ml loci (bClampMaxMLmatches, Aligner.cpp:9243-9248)        */
+    int32_t reserved;
 } bk_align_params;
 
 /* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and
@@ -192,7 +194,8 @@ typedef struct bk_loci {
 } bk_loci;
 /* Loci lists of the reads of the LAST bk_align_batch()/bk_align_batch_device() call on a context created
  * with max_ml > 1: read r owns loci[offs[r] .. offs[r+1]), that is LowHitInstances entries when its
- * bk_hit.rslt is eHRhits (1 for a unique read, whose record it repeats) and none otherwise.  The pointers
+ * bk_hit.rslt is eHRhits (1 for a unique read, whose record it repeats), max_ml entries when it is eHRHitInsts
+ * and clamp_ml is set, and none otherwise.  The pointers
  * are host memory owned by the context, valid until its next align call.  With max_ml == 1 there are no
  * lists (*n_loci = 0, NULL pointers).  What to do with them (-r1 statistics, -r2 random pick, -r3/-r4
  * clustering, -r5 report all; Aligner.cpp:9328-9424,5105-5272) is host policy above this boundary. */

@@ -528,7 +528,7 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }
     if (low_inst > max_ml) low_inst = max_ml + 1;                                       /* :9241 */
     out->rslt = (uint8_t)rslt;
-    if (loci_out && rslt == HR_HITS)
+    if (loci_out && (rslt == HR_HITS || (rslt == HR_HITINSTS && p->clamp_ml)))
         for (int k = 0; k < low_inst && k < max_ml; k++) {
             loci_out[k].chrom_id = hits[k].chrom_id; loci_out[k].match_loci = hits[k].match_loci;
             loci_out[k].match_len = hits[k].match_len; loci_out[k].strand = hits[k].strand;

@@ -1,0 +1,63 @@
+// drives host/multi_assign.h and host/glibc_rand.h the way the command line does for -r2 / -r3 / -r4:
+//   multi_harness <mode 2|3|4> <threads> <max_reads_len> <clamp 0|1> hits.bin offs.bin loci.bin out_hits.bin
+// hits.bin: bk_hit records (as bk_align_batch returns them with max_ml > 1), offs.bin: uint64[n+1], loci.bin: bk_loci
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../biokanga_amd/csrc/host/glibc_rand.h"
+#include "../../biokanga_amd/csrc/host/multi_assign.h"
+
+template <typename T>
+static std::vector<T> slurp(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<T> v((size_t)n / sizeof(T));
+    if (n && fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 9) return 2;
+    const int mode = atoi(argv[1]), threads = atoi(argv[2]);
+    const uint32_t max_reads_len = (uint32_t)atoi(argv[3]);
+    const bool clamp = atoi(argv[4]) != 0;
+    std::vector<bk_hit> hits = slurp<bk_hit>(argv[5]);
+    std::vector<uint64_t> offs = slurp<uint64_t>(argv[6]);
+    std::vector<bk_loci> loci = slurp<bk_loci>(argv[7]);
+    const size_t nr = hits.size();
+    auto count = [&](size_t i) -> uint32_t {
+        const bk_hit &h = hits[i];
+        if (h.rslt == BK_HR_HITS || (clamp && h.rslt == BK_HR_HITINSTS)) return (uint32_t)(offs[i + 1] - offs[i]);
+        return 0;
+    };
+    auto take = [&](bk_hit &h, const bk_loci &L) {
+        h.chrom_id = L.chrom_id; h.match_loci = L.match_loci; h.match_len = L.match_len; h.strand = L.strand;
+        h.mismatches = L.mismatches; h.nar = BK_NAR_ACCEPTED; h.num_hits = 1; h.low_hit_instances = 1;
+    };
+    if (mode == 2) {
+        bk::GlibcRand pick;
+        for (size_t i = 0; i < nr; i++) {
+            const uint32_t c = count(i);
+            if (c) take(hits[i], loci[offs[i] + (uint32_t)pick.next() % c]);
+        }
+    } else {
+        bk::MultiAssign ma;
+        for (size_t i = 0; i < nr; i++) {
+            const uint32_t c = count(i);
+            for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[offs[i] + k], c > 1);
+        }
+        ma.assign(mode == 3, threads, max_reads_len);
+        for (const bk::MultiHitRec &m : ma.recs)
+            if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
+    }
+    FILE *f = fopen(argv[8], "wb");
+    fwrite(hits.data(), sizeof(bk_hit), nr, f);
+    fclose(f);
+    return 0;
+}

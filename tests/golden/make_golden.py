@@ -605,12 +605,98 @@ def make_formats(tmp):
     print("  format fixtures written")
 
 
+MULTI_RUNS = [("r1R5", ["-r1", "-R5", "-T4"]), ("r2R5", ["-r2", "-R5", "-T1"]), ("r3R5", ["-r3", "-R5", "-T4"]),
+              ("r4R5", ["-r4", "-R5", "-T4"]), ("r4R3X", ["-r4", "-R3", "-X", "-T4"]), ("r3R8T1", ["-r3", "-R8", "-T1"]),
+              ("r5R5", ["-r5", "-R5", "-T1"]), ("r5R3X", ["-r5", "-R3", "-X", "-T1"])]
+
+
+def make_multi(tmp):
+    """multi-loci modes (-r1..-r5 with -R / -X): a genome with 300-base segments present in 2..9 places (some
+    copies one substitution away), reads from them and from their unique surroundings so that the clustering
+    modes have unique neighbours (-r3) and other multi-loci reads (-r4) to cluster with.  -r2 and -r5 runs use -T1:
+    with more threads the reference's rand() sequence / record order depends on thread timing."""
+    rng = np.random.default_rng(555)
+    outdir = os.path.join(HERE, "multi")
+    os.makedirs(outdir, exist_ok=True)
+    g = [list(rand_seq(rng, 90000)), list(rand_seq(rng, 60000))]
+    dups = []
+    for _ in range(60):
+        c = int(rng.integers(0, 2))
+        src = int(rng.integers(0, len(g[c]) - 300))
+        seg = g[c][src:src + 300]
+        places = [(c, src)]
+        for _k in range(int(rng.integers(1, 9))):
+            c2 = int(rng.integers(0, 2))
+            dst = int(rng.integers(0, len(g[c2]) - 300))
+            cp = list(seg)
+            if rng.integers(0, 3) == 0:
+                q = int(rng.integers(0, 300))
+                cp[q] = "ACGT"[("ACGT".index(cp[q]) + 1) % 4]
+            g[c2][dst:dst + 300] = cp
+            places.append((c2, dst))
+        dups.append(places)
+    seqs = ["".join(x) for x in g]
+    fa = os.path.join(tmp, "multi.fa")
+    write_fasta(fa, [("mA", seqs[0]), ("mB", seqs[1])])
+    reads = []
+
+    def add(c, p, tag):
+        s = seqs[c][p:p + 100]
+        s = mutate(rng, s, int(rng.integers(0, 3)))
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"{tag}{len(reads)}", s))
+
+    for places in dups:
+        for (c, p) in places[:3]:
+            for _r in range(int(rng.integers(2, 7))):            # inside the repeated segment: multi-loci
+                add(c, p + int(rng.integers(0, 200)), "m")
+            for _r in range(int(rng.integers(0, 6))):            # straddling its edge / next to it: unique neighbours
+                q = p + int(rng.integers(-90, 290))
+                add(c, max(0, min(q, len(seqs[c]) - 100)), "u")
+    for _ in range(3000):
+        c = int(rng.integers(0, 2))
+        add(c, int(rng.integers(0, len(seqs[c]) - 100)), "b")
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "multi_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "multi.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "multi", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags in MULTI_RUNS:
+        for fmt, ext in (("-M6", "m6.sam"), ("-M5", "m5.sam"), ("-M0", "m0.csv"), ("-M4", "m4.bed")):
+            if fmt in ("-M0", "-M4") and not tag.startswith("r5R5"):
+                continue
+            if fmt == "-M5" and tag not in ("r5R5", "r3R5"):
+                continue
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-s3"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            print("  ran", tag, fmt, flags)
+    # thread-count independence of the clustering modes (their block hand-out depends on -T only through
+    # the shortcut for identical neighbours, Aligner.cpp:4978-4986)
+    for mode in ("-r3", "-r4"):
+        outs = []
+        for th in ("-T1", "-T4", "-T8"):
+            out = os.path.join(tmp, f"chk{mode}{th}.sam")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M6", "-s3", mode, "-R5", th], tmp)
+            outs.append(open(out, "rb").read())
+        print("  ", mode, "identical across -T1/-T4/-T8:", outs[0] == outs[1] == outs[2])
+    print("  multi fixture written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-multi" in sys.argv:
+            make_multi(tmp)
             return
         if "--only-formats" in sys.argv:
             make_formats(tmp)
@@ -639,6 +725,7 @@ def main():
         make_fastq(tmp)
         make_stats(tmp)
         make_formats(tmp)
+        make_multi(tmp)
     print("done")
 
 

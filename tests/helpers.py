@@ -21,7 +21,7 @@ class OraParams(ctypes.Structure):
     _fields_ = [("max_subs", ctypes.c_int32), ("min_edit_dist", ctypes.c_int32),
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("clamp_ml", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
@@ -36,8 +36,9 @@ class OraCounters(ctypes.Structure):
                 ("n_reads", "n_search", "n_probe", "n_last_search", "n_cand", "n_cand_seen", "n_lcm_calls")]
 
 
-def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, cls=OraParams):
+def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, cls=OraParams):
     p = cls()
+    p.clamp_ml = clamp_ml
     p.max_subs, p.min_edit_dist, p.align_strand, p.pmode, p.max_ns, p.max_ml = \
         max_subs, min_edit_dist, align_strand, pmode, max_ns, max_ml
     return p
@@ -149,6 +150,8 @@ def oracle_align_multi(osfx, bases, offs, lens, params, nthreads=4):
     if rc != 0:
         raise RuntimeError(f"ora_align_batch_multi failed: {rc}")
     cnt = np.where(out["rslt"] == 1, out["low_hit_instances"].astype(np.int64), 0)
+    if params.clamp_ml:
+        cnt = np.where(out["rslt"] == 3, ml, cnt)
     lo = np.zeros(n + 1, dtype=np.uint64)
     lo[1:] = np.cumsum(cnt)
     mask = np.arange(ml)[None, :] < cnt[:, None]

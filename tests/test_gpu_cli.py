@@ -200,3 +200,35 @@ def test_align_end_trims(golden_tmp, tmp_path):
     out = str(tmp_path / "trim.sam")
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-s3", "-M6", "-y5", "-Y3", "-l60"], str(tmp_path))
     assert open(out, "rb").read() == golden_bytes("basic", "s3y5Y3l60.m6.sam.gz")
+
+
+# multi-loci modes (-r1..-r5, -R, -X): files the reference wrote for tests/golden/multi (make_golden.py:make_multi);
+# its -r2 / -r5 runs are single-threaded because their rand() sequence / record numbering follow thread timing
+MULTI_CASES = [("r1R5", ["-r1", "-R5"], ["m6.sam"]), ("r2R5", ["-r2", "-R5"], ["m6.sam"]), ("r3R5", ["-r3", "-R5", "-T4"], ["m6.sam", "m5.sam"]),
+               ("r4R5", ["-r4", "-R5", "-T4"], ["m6.sam"]), ("r4R3X", ["-r4", "-R3", "-X", "-T4"], ["m6.sam"]),
+               ("r3R8T1", ["-r3", "-R8", "-T1"], ["m6.sam"]), ("r5R5", ["-r5", "-R5"], ["m6.sam", "m5.sam", "m0.csv", "m4.bed"]),
+               ("r5R3X", ["-r5", "-R3", "-X"], ["m6.sam"])]
+FMT_FLAG = {"m6.sam": "-M6", "m5.sam": "-M5", "m0.csv": "-M0", "m4.bed": "-M4"}
+
+
+@pytest.mark.parametrize("tag,flags,exts", MULTI_CASES)
+def test_multi_loci_modes_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
+    d = golden_tmp["multi"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    for ext in exts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext], "-s3"] + flags, str(tmp_path))
+        got, exp = open(out, "rb").read(), golden_bytes("multi", f"{tag}.{ext}.gz")
+        if got != exp:
+            g, e = got.split(b"\n"), exp.split(b"\n")
+            k = next((i for i in range(min(len(g), len(e))) if g[i] != e[i]), min(len(g), len(e)))
+            raise AssertionError(f"{tag}.{ext}: {len(g)} vs {len(e)} lines, first difference at line {k}:\n{g[k:k+1]}\n{e[k:k+1]}")
+
+
+def test_multi_loci_option_checks(golden_tmp, tmp_path):
+    d = golden_tmp["multi"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    for bad in (["-r6"], ["-r3", "-R1"], ["-r3", "-R501"], ["-r5", "-M2"], ["-r2", "-N"]):
+        r = subprocess.run([BIN, "align", "-i", reads, "-I", sfx, "-o", str(tmp_path / "x.sam")] + bad, cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0, bad

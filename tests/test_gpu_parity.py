@@ -425,14 +425,14 @@ def _assert_loci_equal(bk, al, nreads, got_hits, exp_hits, exp_offs, exp_loci):
             raise AssertionError(f"loci field {f} differs at entry {i} (read {r}): got {loci[i]} exp {exp_loci[i]}")
 
 
-@pytest.mark.parametrize("max_ml", [2, 5, 64, 500])
-@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
-def test_multi_loci_lists_match_oracle(golden_tmp, fixture, max_ml):
+@pytest.mark.parametrize("max_ml,clamp", [(2, 0), (2, 1), (5, 0), (5, 1), (64, 1), (500, 0)])
+@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths", "multi"])
+def test_multi_loci_lists_match_oracle(golden_tmp, fixture, max_ml, clamp):
     """MaxHits > 1 (the -R of the multi-loci modes): result records AND the pHits[] lists, in the reference's
     discovery order, against the oracle"""
     bk = _bk()
     d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
-    kw = dict(max_subs=3, max_ml=max_ml)
+    kw = dict(max_subs=3, max_ml=max_ml, clamp_ml=clamp)
     sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
     exp, eo, el = helpers.oracle_align_multi(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
     sfx.close()
@@ -444,8 +444,8 @@ def test_multi_loci_lists_match_oracle(golden_tmp, fixture, max_ml):
             _assert_loci_equal(bk, al, len(keep), got, exp, eo, el)
 
 
-@pytest.mark.parametrize("read_len,max_subs,max_ml", [(100, 3, 5), (150, 5, 20), (64, 10, 3), (300, 3, 8)])
-def test_multi_loci_synthetic(tmp_path, read_len, max_subs, max_ml):
+@pytest.mark.parametrize("read_len,max_subs,max_ml,clamp", [(100, 3, 5, 0), (100, 3, 3, 1), (150, 5, 20, 0), (64, 10, 3, 1), (300, 3, 8, 0)])
+def test_multi_loci_synthetic(tmp_path, read_len, max_subs, max_ml, clamp):
     import torch
     bk = _bk()
     seq, ents, reads = _synth_case(23 + read_len, 300000, 12000, read_len, 4, dup_len=2 * read_len + 50)
@@ -461,7 +461,7 @@ def test_multi_loci_synthetic(tmp_path, read_len, max_subs, max_ml):
     bases = reads.reshape(-1)
     offs = (np.arange(nreads, dtype=np.uint64) * read_len)
     lens = np.full(nreads, read_len, dtype=np.uint32)
-    kw = dict(max_subs=max_subs, max_ml=max_ml)
+    kw = dict(max_subs=max_subs, max_ml=max_ml, clamp_ml=clamp)
     o = helpers.OracleSfx(path)
     exp, eo, el = helpers.oracle_align_multi(o, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
     o.close()

@@ -1,0 +1,75 @@
+"""Multi-loci modes on CPU: (a) the oracle's pHits[] lists against what the real reference reported with -r5
+(the first CSV column is the record's creation order, so the discovery ORDER of the loci is pinned, not just the
+set); (b) the host-side policies above the C ABI - glibc rand() picks (-r2) and the clustering assignment
+(-r3/-r4, multi_assign.h) - fed with the oracle's lists, against the reference's SAM files."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from test_oracle_golden import check_hits_against_sam, chrom_names_from_hdr
+
+
+@pytest.fixture(scope="module")
+def multi_case(golden_tmp):
+    d = golden_tmp["multi"]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    return d, names, bases, offs, lens
+
+
+def _oracle(d, bases, offs, lens, max_ml, clamp=0):
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    out = helpers.oracle_align_multi(sfx, bases, offs, lens, helpers.make_params(max_subs=3, max_ml=max_ml, clamp_ml=clamp), nthreads=8)
+    sfx.close()
+    return out
+
+
+def test_oracle_loci_order_matches_reference_r5(multi_case):
+    d, names, bases, offs, lens = multi_case
+    hits, lo, loci = _oracle(d, bases, offs, lens, 5)
+    rows = []
+    for line in gzip.open(os.path.join(helpers.GOLDEN, "multi", "r5R5.m0.csv.gz"), "rt"):
+        f = line.rstrip("\n").split(",")
+        rows.append((int(f[0]), f[3].strip('"'), int(f[4]), f[7].strip('"'), int(f[11]), f[13].strip('"')))
+    rows.sort()
+    assert [r[0] for r in rows] == list(range(1, len(rows) + 1)) and len(rows) == len(loci) > 5000
+    chrom = {1: "mA", 2: "mB"}
+    k = 0
+    for i, nm in enumerate(names):
+        for j in range(int(lo[i]), int(lo[i + 1])):
+            L = loci[j]
+            assert rows[k][1:] == (chrom[int(L["chrom_id"])], int(L["match_loci"]), chr(L["strand"]), int(L["mismatches"]), nm), (k, nm)
+            k += 1
+    assert np.count_nonzero(np.diff(lo.astype(np.int64)) > 1) > 500
+
+
+@pytest.fixture(scope="module")
+def multi_harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("mh") / "multi_harness")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "multi_harness.cpp")])
+    return exe
+
+
+@pytest.mark.parametrize("tag,mode,max_ml,clamp,threads", [("r2R5", 2, 5, 0, 1), ("r3R5", 3, 5, 0, 4), ("r4R5", 4, 5, 0, 4), ("r4R3X", 4, 3, 1, 4),
+                                                            ("r3R8T1", 3, 8, 0, 1), ("r3R5", 3, 5, 0, 64)])
+def test_host_policies_match_reference(multi_case, multi_harness, tmp_path, tag, mode, max_ml, clamp, threads):
+    d, names, bases, offs, lens = multi_case
+    hits, lo, loci = _oracle(d, bases, offs, lens, max_ml, clamp)
+    hp, op, lp, rp = (str(tmp_path / n) for n in ("hits.bin", "offs.bin", "loci.bin", "out.bin"))
+    hits.tofile(hp); lo.tofile(op); loci.tofile(lp)
+    subprocess.check_call([multi_harness, str(mode), str(threads), str(int(lens.max())), str(clamp), hp, op, lp, rp])
+    got = np.fromfile(rp, dtype=helpers.HIT_DTYPE)
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "multi", f"{tag}.m6.sam.gz"))
+    check_hits_against_sam(names, lens, got, recs, chrom_names_from_hdr(hdr), list(range(len(names))))
+    assert np.count_nonzero(got["nar"] == 1) > np.count_nonzero(hits["nar"] == 1)        # some multi-loci reads were placed
+
+
+def test_r1_is_the_plain_result(multi_case):
+    """-r1 only gathers statistics: the records are what AlignReads returned with MaxHits = -R"""
+    d, names, bases, offs, lens = multi_case
+    hits, lo, loci = _oracle(d, bases, offs, lens, 5)
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "multi", "r1R5.m6.sam.gz"))
+    check_hits_against_sam(names, lens, hits, recs, chrom_names_from_hdr(hdr), list(range(len(names))))

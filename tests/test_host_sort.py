@@ -78,3 +78,10 @@ def test_sort_threads_do_not_change_the_order(harness, tmp_path):
     assert np.array_equal(orders[0], orders[1])
     srt = hits[orders[0]]
     assert np.all(np.diff(srt["nar"].astype(int)) >= 0)
+
+
+def test_glibc_rand_replica(tmp_path):
+    """glibc_rand.h yields the C library's unseeded rand() sequence (the reference's N-run mutations and -r2 picks)"""
+    exe = str(tmp_path / "rand_harness")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "rand_harness.cpp")])
+    assert subprocess.check_output([exe, "200000"]).strip() == b"0"
