@@ -52,6 +52,9 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_size, hipStream_t s);
 int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, void *tmp, size_t *tmp_bytes, hipStream_t s);
 void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s);
+void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                 uint32_t n_list, uint32_t *cursor, unsigned long long *cnt, bk_loci *dense, hipStream_t s);
+void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
                         hipStream_t s);
 void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
@@ -154,6 +157,7 @@ int derive_cfg(bk_ctx *c)
         p.align_strand > 2 || p.pmode < 0 || p.pmode > 3 || p.max_ns < 0 || p.max_ns > 5)
         return BK_ERR_PARAMS;
     if (p.max_ml < 0 || p.max_ml > BK_MAX_ML) return BK_ERR_PARAMS;
+    if (p.best_matches && p.max_ml < 2) return BK_ERR_PARAMS;
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
     g.mm_delta = p.min_edit_dist;
@@ -578,6 +582,52 @@ int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, hipStream_t s)
     return BK_OK;
 }
 
+// -N (LocateBestMatches): one wave-per-read pass over the reads the N policy let through, dense rows of MaxHits
+// loci per read compacted into the same host-side lists the other multi-loci modes return
+int best_matches_chunk(bk_ctx *c, const DevBatch &b, uint32_t n, const uint32_t *d_list, uint32_t n_list, hipStream_t s)
+{
+    unsigned long long *d_cnt = nullptr, *d_offs = nullptr;
+    void *d_tmp = nullptr;
+    bk_loci *d_dense = nullptr, *d_loci = nullptr;
+    const uint32_t width = (uint32_t)c->cfg.max_hits;
+    auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_dense); free_dev(d_loci); };
+#define BEST_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
+    BEST_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
+    BEST_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
+    BEST_TRY(hipMalloc(&d_dense, (size_t)n * width * sizeof(bk_loci)));
+    BEST_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 8, s));
+    int rc = size_heavy_scratch(c);
+    if (rc) { cleanup(); return rc; }
+    uint32_t *sm = c->d_small;
+    BEST_TRY(hipMemsetAsync(sm + 4, 0, 4, s));
+    launch_best(c->ix, c->cfg, b, c->hs, d_list, n_list, sm + 4, d_cnt, d_dense, s);
+    BEST_TRY(hipGetLastError());
+    size_t tb = 0;
+    if (scan_counts_u64(nullptr, nullptr, n + 1, nullptr, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
+    BEST_TRY(hipMalloc(&d_tmp, tb ? tb : 16));
+    if (scan_counts_u64(d_cnt, d_offs, n + 1, d_tmp, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
+    const size_t base = c->loci_offs.empty() ? 0 : c->loci_offs.size() - 1;
+    const uint64_t loci_base = c->loci.size();
+    if (c->loci_offs.empty()) c->loci_offs.push_back(0);
+    c->loci_offs.resize(base + n + 1);
+    BEST_TRY(hipMemcpyAsync(c->loci_offs.data() + base, d_offs, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+    BEST_TRY(hipStreamSynchronize(s));
+    const uint64_t total = c->loci_offs[base + n];
+    if (total) {
+        BEST_TRY(hipMalloc(&d_loci, (size_t)total * sizeof(bk_loci)));
+        launch_loci_compact(d_dense, width, d_offs, n, d_loci, s);
+        BEST_TRY(hipGetLastError());
+        c->loci.resize(loci_base + total);
+        BEST_TRY(hipMemcpyAsync(c->loci.data() + loci_base, d_loci, (size_t)total * sizeof(bk_loci), hipMemcpyDeviceToHost, s));
+        BEST_TRY(hipStreamSynchronize(s));
+    }
+    if (loci_base)
+        for (size_t i = 0; i <= n; i++) c->loci_offs[base + i] += loci_base;
+#undef BEST_TRY
+    cleanup();
+    return BK_OK;
+}
+
 int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n, uint32_t maxlen,
                 bk_hit *d_out, hipStream_t s, EvTimer &tm)
 {
@@ -609,6 +659,13 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     uint32_t n_act = hm[0];
     int cmax = (int)hm[3];
     int cur = 0;
+    if (c->params.best_matches) {
+        hipEvent_t eb = tm.begin(s);
+        int rb = best_matches_chunk(c, b, n, c->d_act[0], n_act, s);
+        if (rb) return rb;
+        tm.end(2, eb, s);
+        n_act = 0;
+    }
     for (int phase = 0; n_act > 0; phase++) {
         // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
@@ -700,7 +757,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     launch_count_seqs(d_out, n, c->d_id2idx, c->ix.n_ent, c->d_seq_counts, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e4, s);
-    if (c->cfg.max_hits > 1) {
+    if (c->cfg.max_hits > 1 && !c->params.best_matches) {
         int rl = collect_loci(c, b, n, s);
         if (rl) return rl;
     }
@@ -736,6 +793,10 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
         if (fit < 65536) fit = 65536;
         if (fit < chunk) chunk = (uint32_t)fit;
         if (chunk > (1u << 27)) chunk = 1u << 27;       // 32 interval slots per read are indexed with 32 bits
+        if (c->params.best_matches) {                   // dense rows of MaxHits loci per read: keep them within 4 GB
+            const uint64_t lim = std::max<uint64_t>(1024, (4ULL << 30) / (sizeof(bk_loci) * (uint64_t)c->cfg.max_hits));
+            if (lim < chunk) chunk = (uint32_t)lim;
+        }
     }
     for (uint32_t done = 0; done < nreads;) {
         uint32_t n = std::min(chunk, nreads - done);

@@ -148,6 +148,23 @@ __device__ __forceinline__ int hamming(const uint64_t *__restrict__ rdw, int len
     return mm;
 }
 
+// the same for a window that has not been checked against the entry table: 127 when it holds an EOS (code 7, only
+// ever found in the target) - LocateBestMatches' Hamming loop is what keeps its hits inside one entry (:6826-6833)
+__device__ __forceinline__ int hamming_eos(const uint64_t *__restrict__ rdw, int len, const uint64_t *__restrict__ tgt,
+                                           uint64_t t, int limit)
+{
+    int mm = 0;
+    uint64_t eos = 0;
+    for (int i = 0; i < len; i += 16) {
+        const uint64_t w = nib16(tgt, t + i), m = top_mask(len - i);
+        eos |= w & (w >> 1) & (w >> 2) & m & 0x1111111111111111ULL;
+        uint64_t x = (nib16(rdw, i) ^ w) & m;
+        x = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+        mm += __popcll(x);
+    }
+    return (eos || mm > limit) ? 127 : mm;
+}
+
 // 2-bit code of the first 16 nibbles (first base in the top 2 bits)
 __device__ __forceinline__ uint32_t squeeze2(uint64_t x)
 {
@@ -1909,7 +1926,18 @@ __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_
 // reference's pHits[] when LocateCoreMultiples returns (SfxArrayV2.cpp:6157-6205: '+' strand first, cores in
 // order, suffix array order within a core).  `enum_err` counts reads whose replay did not reproduce
 // LowHitInstances (must stay 0).
-template <bool WIDE, bool ENUM>
+//
+// BEST form (`-N`, CSfxArrayV3::LocateBestMatches, SfxArrayV2.cpp:6654-7019): one call with the caller's MaxTotMM /
+// CoreLen / CoreDelta (no phase schedule, no Hamming-delta rule); the answer is the first MaxHits candidates in
+// (mismatches, discovery order) - what the reference's insertion list holds at the end (a new hit goes in front
+// of the first one with more mismatches; once full, the worst entry falls off and the mismatch limit tightens to
+// the new worst, :6917-6961).  Two replays per read: the first histograms the candidates by mismatches, the second
+// writes each kept candidate straight to its final place (class offset + rank within the class).  Candidates are
+// hashed before the entry table is consulted (only the concatenation end is checked, :6816), entry boundaries are
+// caught by the EOS test of the Hamming loop - both as in the reference, they change which candidates count
+// towards the iteration limits.  Output: dense rows of MaxHits loci per read + the count; the result record is
+// written here (eHRhits / eHRnone, LowMMCnt and NxtLowMMCnt stay 0 as ProcCoredApprox leaves them, Aligner.cpp:9197-9218).
+template <bool WIDE, int MODE>
 __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                                const uint32_t *__restrict__ list, uint32_t n_list, int phase_arg,
                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ next_act,
@@ -1917,9 +1945,13 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                                                const unsigned long long *__restrict__ loci_offs, bk_loci *__restrict__ loci_out,
                                                uint32_t *__restrict__ enum_err)
 {
+    constexpr bool ENUM = MODE == 1, BEST = MODE == 2;
     __shared__ LdsEntries s_le;
+    __shared__ uint32_t s_hist[BEST ? 4 : 1][64], s_pre[BEST ? 4 : 1][64], s_run[BEST ? 4 : 1][64];
+    __shared__ bk_loci s_first[BEST ? 4 : 1];
     lds_entries_load(s_le, ix);
     const int lane = threadIdx.x & 63;
+    const int wib = BEST ? (int)(threadIdx.x >> 6) : 0;
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wave_slot >= hs.n_slots) return;
     unsigned long long *tab = hs.htab + (uint64_t)wave_slot * hs.tab_size;
@@ -1963,6 +1995,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
             want_n = (uint32_t)(loci_offs[r + 1] - emit_base);
             clamped = h.rslt == BK_HR_HITINSTS;      // -X: only the first MaxHits loci of a read with more
         }
+        if (BEST) phase = p.n_phases - 1;                 // the caller's own MaxTotMM / CoreLen / CoreDelta
         phase_params(p, cfg, phase, mm, cl, cd);
         n_lcm++;
         const int init = mm + cfg.mm_delta + 1;
@@ -1971,6 +2004,24 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         int hit_ent = -1, hit_strand = '?';
         bool done = false;
         int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        int best_t = 0;                                    // BEST: last mismatch class kept, how many of it, total kept
+        uint32_t best_need = 0, best_count = 0;
+        if (BEST) { s_hist[wib][lane] = 0; s_run[wib][lane] = 0; __builtin_amdgcn_wave_barrier(); }
+      for (int pass = 0; pass < (BEST ? 2 : 1); pass++) {
+        if (BEST && pass == 1) {
+            // classes 0..mm: inclusive scan of the histogram over the lanes
+            const uint32_t hcnt = s_hist[wib][lane];
+            uint32_t cum = hcnt;
+            for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(cum, d); if (lane >= d) cum += v; }
+            const uint32_t total = __shfl(cum, 63);
+            best_count = total < (uint32_t)cfg.max_hits ? total : (uint32_t)cfg.max_hits;
+            if (best_count == 0) break;
+            const uint64_t reach = __ballot(cum >= best_count);
+            best_t = __ffsll((unsigned long long)reach) - 1;
+            s_pre[wib][lane] = cum - hcnt;
+            __builtin_amdgcn_wave_barrier();
+            best_need = best_count - s_pre[wib][best_t];
+        }
         for (int st = s0; st <= s1 && !done; st++) {
             const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
             // new dedupe set for this strand pass (memset of the hash heads, SfxArrayV2.cpp:5834)
@@ -2002,7 +2053,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                 const int ofs = o;
                 const uint64_t first = __shfl(my_first, ci & 63);
                 const uint64_t n = __shfl(my_n, ci & 63);
-                n_search++;
+                if (!BEST || pass == 0) n_search++;
                 // candidate walk of this core, 64 SA elements per step
                 uint32_t iter = 0;
                 bool copies_checked = false;
@@ -2013,7 +2064,8 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     uint64_t t = loci - (uint64_t)ofs;
                     int e = -1;
                     bool valid = active && loci >= (uint64_t)ofs;
-                    if (valid) {
+                    if (BEST) valid = valid && t + (uint64_t)len <= ix.n;
+                    else if (valid) {
                         e = find_entry_lds(s_le, ix, t);
                         valid = e >= 0 && t + (uint64_t)len - 1 <= ix.ent_end[e];
                     }
@@ -2043,6 +2095,44 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     bool proc = active && j < cutoff && isnew;
                     if (proc) htab_insert(tab, tmask, epoch, key);
                     int cm = 127;
+                    if (BEST) {
+                        if (proc) cm = hamming_eos(rdw, len, ix.tgt4, t, pass ? best_t : mm);
+                        const bool hit = cm != 127;
+                        if (pass == 0) {
+                            if (hit) atomicAdd(&s_hist[wib][cm], 1u);
+                        } else if (__ballot(hit)) {
+                            uint32_t my_pos = 0xffffffffu;
+                            for (int m = 0; m <= best_t; m++) {
+                                const uint64_t bm = __ballot(hit && cm == m);
+                                if (!bm) continue;
+                                const uint32_t run = s_run[wib][m];
+                                if (hit && cm == m) {
+                                    const uint32_t k = run + (uint32_t)__popcll(bm & lt_mask);
+                                    if (m < best_t || k < best_need) my_pos = s_pre[wib][m] + k;
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                if (lane == 0) s_run[wib][m] = run + (uint32_t)__popcll(bm);
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                            if (my_pos != 0xffffffffu) {
+                                e = find_entry_lds(s_le, ix, t);
+                                bk_loci L;
+                                L.chrom_id = ix.ent_id[e];
+                                L.match_loci = (uint32_t)(t - ix.ent_start[e]);
+                                L.match_len = (uint16_t)len;
+                                L.strand = (uint8_t)(st ? '-' : '+');
+                                L.mismatches = (uint8_t)cm;
+                                loci_out[(unsigned long long)r * (unsigned)cfg.max_hits + my_pos] = L;
+                                if (my_pos == 0) s_first[wib] = L;
+                            }
+                        }
+                        const uint32_t np = (uint32_t)__popcll(__ballot(proc));
+                        iter += np;
+                        nodes += np;
+                        if (pass == 0) n_cand += (lane == 0) ? np : 0;
+                        if (cutoff < j0 + 64) break;
+                        continue;
+                    }
                     if (proc) {
                         int lim = ENUM ? want_mm : (mm < nxt - 1 ? mm : nxt - 1);
                         cm = hamming(rdw, len, ix.tgt4, t, lim);
@@ -2120,8 +2210,27 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                 o += cur;
             }
         }
+      }   // pass
         if (ENUM) {
             if (lane == 0 && (clamped ? emitted < want_n : emitted != want_n)) atomicAdd(enum_err, 1u);
+            continue;
+        }
+        if (BEST) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                bk_hit h;
+                h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = (int16_t)best_count;
+                h.rslt = best_count ? BK_HR_HITS : BK_HR_NONE; h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0;
+                h.num_hits = 0; h.mismatches = 0; h.flags = (uint8_t)((phase << 1) | 1);
+                if (best_count == 1) {
+                    const bk_loci L = s_first[wib];
+                    h.nar = BK_NAR_ACCEPTED; h.num_hits = 1; h.strand = L.strand; h.chrom_id = L.chrom_id; h.match_loci = L.match_loci;
+                    h.match_len = L.match_len; h.mismatches = L.mismatches;
+                } else if (best_count > 1)
+                    h.nar = BK_NAR_MULTIALIGN;
+                b.out[r] = h;
+                ((unsigned long long *)loci_offs)[r] = best_count;          // here: the per-read count array
+            }
             continue;
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
@@ -2141,7 +2250,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
-        if (!ENUM) {                                   // the replay is ours, not work the reference does
+        if (!ENUM) {                                   // the ENUM replay is ours, not work the reference does
             if (n_search) atomicAdd(&b.ctr[0], n_search);
             if (n_cand) atomicAdd(&b.ctr[1], n_cand);
             if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
@@ -2728,8 +2837,37 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 {
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL((k_heavy<false, false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((k_heavy<false, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+}
+
+// -N: LocateBestMatches for every read of `list`; cnt[r] = loci kept, dense[r * MaxHits ..] = the loci
+void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
+                 uint32_t n_list, uint32_t *cursor, unsigned long long *cnt, bk_loci *dense, hipStream_t s)
+{
+    if (!n_list) return;
+    uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
+    unsigned blocks = (waves + 3) / 4;
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 2>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, cnt, dense, nullptr);
+    else hipLaunchKernelGGL((k_heavy<false, 2>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, cnt, dense, nullptr);
+}
+
+// dense rows of `width` loci -> packed lists at offs[]
+__global__ void __launch_bounds__(256) k_loci_compact(const bk_loci *__restrict__ dense, uint32_t width, const unsigned long long *__restrict__ offs,
+                                                      uint32_t n, bk_loci *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = i / width;
+    const uint32_t k = (uint32_t)(i % width);
+    if (r >= n) return;
+    const unsigned long long o = offs[r];
+    if (k < offs[r + 1] - o) out[o + k] = dense[i];
+}
+
+void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s)
+{
+    const uint64_t tot = (uint64_t)n * width;
+    if (tot) hipLaunchKernelGGL(k_loci_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dense, width, offs, n, out);
 }
 
 void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s)
@@ -2749,8 +2887,8 @@ void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
-    else hipLaunchKernelGGL((k_heavy<false, true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
+    else hipLaunchKernelGGL((k_heavy<false, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
 }
 
 }  // namespace bk

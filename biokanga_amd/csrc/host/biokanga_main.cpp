@@ -532,14 +532,14 @@ int cmd_align(int argc, char **argv, int first)
     if (ml_mode < 0 || ml_mode > 5) { diag("Error: multiple aligned reads processing mode '-r%d' specified outside of range 0..5", ml_mode); return 1; }
     if (pe_mode && ml_mode) { diag("Error: Sorry, currently multiloci processing '-r%d' not supported in paired end '-U%d' processing", ml_mode, pe_mode); return 1; }
     int max_ml = 1;
-    bool clamp_ml = false;
+    bool clamp_ml = false, best_matches = false;
     if (ml_mode) {
         max_ml = a.num("R", 5);                                         // cDfltMaxMultiHits
         const int lim = ml_mode == 5 ? 100000 : 500;                    // cMaxAllHits / cMaxMultiHits
         if (max_ml < 2 || max_ml > lim) { diag("Error: multiple aligned reads '-R%d' specified outside of range 2..%d", max_ml, lim); return 1; }
         if (max_ml > BK_MAX_ML) { diag("Error: '-R%d' is above the %d loci per read this build keeps", max_ml, BK_MAX_ML); return 1; }
-        if (a.has("N")) { diag("Error: '-N' (best matches, CSfxArrayV3::LocateBestMatches) is not available in this build"); return 1; }
-        clamp_ml = a.has("X");
+        best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
+        clamp_ml = a.has("X") || best_matches;
     }
     bk_align_params P = {};
     P.pmode = a.num("m", 0);
@@ -549,6 +549,7 @@ int cmd_align(int argc, char **argv, int first)
     P.max_ns = a.num("n", 1);
     P.max_ml = max_ml;
     P.clamp_ml = clamp_ml ? 1 : 0;
+    P.best_matches = best_matches ? 1 : 0;
     int fmt = a.num("M", 5);
     if (ml_mode == 5 && !(fmt == 0 || fmt == 4 || fmt == 5 || fmt == 6)) {      // kanga.cpp:830-834
         diag("Error: reporting all multiloci alignments '-r5' is only available with output formats '-M0', '-M4', '-M5' and '-M6'");

@@ -54,7 +54,9 @@ typedef struct bk_align_params {
                              *     multi-loci modes -r1..-r5, whose loci lists bk_batch_loci() then returns         */
     int32_t clamp_ml;       /* -X  with max_ml > 1: reads with more than max_ml loci (rslt eHRHitInsts) also get a loci
                              *     list, of their first max_ml loci (bClampMaxMLmatches, Aligner.cpp:9243-9248)        */
-    int32_t reserved;
+    int32_t best_matches;   /* -N  with max_ml > 1: CSfxArrayV3::LocateBestMatches instead of AlignReads - per read the (up to)
+                             *     max_ml loci with the fewest mismatches, none above the -s limit, ordered by mismatches
+                             *     then discovery; bk_hit.rslt is eHRhits / eHRnone, LowMMCnt and NxtLowMMCnt stay 0          */
 } bk_align_params;
 
 /* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and

@@ -428,6 +428,115 @@ static int locate_core_multiples(const ora_sfx *s, int max_tot_mm, int core_len,
     return HR_HITS;
 }
 
+/* LocateBestMatches, SfxArrayV2.cpp:6654-7019 (`-N`: at most max_hits alignments with the fewest mismatches, none
+ * above max_tot_mm; no phase schedule, no Hamming-delta rule).  Differences from LocateCoreMultiples that matter:
+ * a candidate is hashed (and counted towards the iteration limits) before anything is known about the entry it
+ * lies in - only the concatenation end is checked (:6816) - and entry boundaries are caught by the EOS test of
+ * the Hamming loop; hits[] is kept ordered by mismatches, a new hit going in front of the first one with MORE
+ * mismatches (:6917-6935), and once full the mismatch limit drops to that of its last element (:6957-6961).
+ * hits[] must have room for max_hits + 1 entries (the reference's memmove moves one past the limit when full). */
+static int locate_best_matches(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta, int max_slides,
+                               int align2strand, uint8_t *probe, int plen, int max_hits, hit_rec *hits,
+                               int max_iter, scratch *sc, ora_counters *ctr)
+{
+    int64_t sfx_len = (int64_t)s->concat_len;
+    int low_inst = 0, sloughed = 0;
+    char cur_strand;
+    if (ctr) ctr->n_lcm_calls++;
+    if (s->concat_len == 0) return -1;
+    if (align2strand == ALS_CRICK) { revcomp(probe, plen); cur_strand = '-'; }
+    else cur_strand = '+';
+    do {
+        int cur_delta = core_delta, n_slides = 0, n_nodes = 0;
+        memset(sc->heads, 0xff, sizeof(sc->heads));
+        for (int core_ofs = 0;
+             n_slides < max_slides && core_ofs <= (plen - core_len) && cur_delta > core_len / 3 && n_nodes < MAX_IDENT_NODES;
+             n_slides++, core_ofs += cur_delta) {
+            if ((core_ofs + core_len + cur_delta) > plen) cur_delta = plen - (core_ofs + core_len);
+            int64_t targ_idx = ora_locate_first_exact(s, probe + core_ofs, core_len, 0, sfx_len - 1, ctr);
+            if (targ_idx == 0) continue;
+            targ_idx -= 1;
+            int iter_cnt = 0, first_iter = 1;
+            uint32_t num_copies = 0;
+            while (!max_iter || iter_cnt < max_iter) {
+                if (n_nodes >= MAX_IDENT_NODES) break;
+                if (!first_iter) {
+                    if ((targ_idx + 1) >= sfx_len || (sa_at(s, targ_idx + 1) + core_len) > sfx_len) break;
+                    if (iter_cnt == 100 && !num_copies) {
+                        int64_t last = ora_locate_last_exact(s, probe + core_ofs, core_len, targ_idx - 1, sfx_len - 1, ctr);
+                        num_copies = last > 0 ? (uint32_t)(1 + last - targ_idx) : 0;
+                        if (max_iter && num_copies > (uint32_t)max_iter) break;
+                    }
+                    if (cmp_probe(probe + core_ofs, s->seq + sa_at(s, targ_idx + 1), core_len) != 0) break;
+                    targ_idx += 1;
+                }
+                first_iter = 0;
+                if (ctr) ctr->n_cand_seen++;
+                int64_t loci = sa_at(s, targ_idx);
+                if (loci < (int64_t)(uint32_t)core_ofs) continue;                      /* :6809 */
+                int64_t left = loci - core_ofs;
+                if (!plen || ((uint64_t)left + (uint32_t)plen) > s->concat_len) continue;  /* :6816 */
+                uint32_t targ_id = (uint32_t)(1 + loci - (uint32_t)core_ofs);
+                int h = (int)(targ_id & HASH_MASK);
+                int32_t n = sc->heads[h];
+                int dup = 0;
+                while (n >= 0) {
+                    if (sc->nodes[n].id == targ_id) { dup = 1; break; }
+                    n = sc->nodes[n].next;
+                }
+                if (dup) continue;
+                sc->nodes[n_nodes].id = targ_id;
+                sc->nodes[n_nodes].next = sc->heads[h];
+                sc->heads[h] = n_nodes++;
+                iter_cnt++;
+                if (ctr) ctr->n_cand++;
+                const uint8_t *t = s->seq + left;
+                int mm = 0, i;
+                for (i = 0; i < plen; i++) {
+                    uint8_t tb = t[i] & 0x0f, pb = probe[i] & 0x0f;
+                    if (tb == B_EOS) break;
+                    if (pb == tb) continue;
+                    if (++mm > max_tot_mm) break;
+                }
+                if (i != plen) continue;
+                int at = -1;
+                if (low_inst) {
+                    if (low_inst == max_hits) sloughed = 1;
+                    int k;
+                    for (k = 0; k < low_inst; k++)
+                        if (hits[k].mismatches > mm) {
+                            at = k;
+                            if (k + 1 < max_hits) memmove(&hits[k + 1], &hits[k], sizeof(hit_rec) * (size_t)(low_inst - k));
+                            break;
+                        }
+                    if (k == low_inst && low_inst < max_hits) at = k;
+                } else
+                    at = 0;
+                if (at >= 0) {
+                    const ora_entry *ent = map_entry(s, (uint64_t)left);
+                    if (ent == NULL) return -1;
+                    hits[at].strand = (uint8_t)cur_strand;
+                    hits[at].chrom_id = ent->entry_id;
+                    hits[at].match_loci = (uint32_t)((uint64_t)left - ent->start_ofs);
+                    hits[at].match_len = (uint16_t)plen;
+                    hits[at].mismatches = (uint8_t)mm;
+                    if (low_inst < max_hits) low_inst++;
+                    else max_tot_mm = hits[low_inst - 1].mismatches;
+                }
+            }
+            if (low_inst == max_hits && max_tot_mm == 0 && !sloughed) { align2strand = ALS_NONE; break; }
+        }
+        if (cur_strand == '+' && align2strand == ALS_BOTH) {
+            revcomp(probe, plen);
+            cur_strand = '-';
+            align2strand = ALS_CRICK;
+        } else
+            align2strand = ALS_NONE;
+    } while (!(low_inst == max_hits && max_tot_mm == 0 && !sloughed) && align2strand != ALS_NONE);
+    if (cur_strand == '-') revcomp(probe, plen);
+    return low_inst;
+}
+
 /* AlignReads, SfxArrayV2.cpp:7666-7760 with microInDelLen = MaxSpliceJunctLen = MinChimericLen = 0 */
 static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta, int max_slides,
                        int mm_delta, int align2strand, int *p_low_inst, int *p_low_mm, int *p_nxt,
@@ -522,7 +631,13 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     hit_rec *hits = hits_small;
     if (max_ml > 7) hits = (hit_rec *)malloc(sizeof(hit_rec) * ((size_t)max_ml + 1));
     memset(hits, 0, sizeof(hit_rec) * ((size_t)max_ml + 1));
-    int rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
+    int rslt;
+    if (p->best_matches) {                                                             /* Aligner.cpp:9197-9218 */
+        rslt = locate_best_matches(s, max_tot_mm, core_len, core_delta, max_slides, align2strand, seqbuf, match_len, max_ml, hits,
+                                   ora_max_iter(p->pmode), sc, ctr);
+        if (rslt >= 0) { low_inst = rslt; rslt = rslt ? HR_HITS : HR_NONE; }           /* LowMMCnt / NxtLowMMCnt stay 0 */
+    } else
+        rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
                            &low_inst, &low_mm, &nxt, seqbuf, match_len, max_ml, hits,
                            ora_max_iter(p->pmode), sc, ctr);
     if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }

@@ -688,12 +688,36 @@ def make_multi(tmp):
     print("  multi fixture written")
 
 
+MULTI_BEST_RUNS = [("r5R5N", ["-r5", "-R5", "-N", "-T1"], ["-M6", "-M0"]), ("r5R2Ns1", ["-r5", "-R2", "-N", "-T1", "-s1"], ["-M0"]),
+                   ("r3R4N", ["-r3", "-R4", "-N", "-T4"], ["-M6"]), ("r2R3N", ["-r2", "-R3", "-N", "-T1"], ["-M6"]),
+                   ("r1R5N", ["-r1", "-R5", "-N", "-T4"], ["-M6"])]
+
+
+def make_multi_best(tmp):
+    """-N (CSfxArrayV3::LocateBestMatches: the best -R loci by mismatches instead of the AlignReads schedule) on the multi fixture"""
+    outdir = os.path.join(HERE, "multi")
+    sfx, rd = os.path.join(tmp, "mb.sfx"), os.path.join(tmp, "mb_reads.fa")
+    for src, dst in ((os.path.join(outdir, "genome.sfx.gz"), sfx), (os.path.join(outdir, "reads.fa.gz"), rd)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    ext = {"-M6": "m6.sam", "-M0": "m0.csv"}
+    for tag, flags, fmts in MULTI_BEST_RUNS:
+        for fmt in fmts:
+            out = os.path.join(tmp, f"{tag}.{ext[fmt]}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt] + (["-s3"] if "-s1" not in flags else []) + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext[fmt]}.gz"))
+            print("  ran", tag, fmt, flags)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-multi-best" in sys.argv:
+            make_multi_best(tmp)
             return
         if "--only-multi" in sys.argv:
             make_multi(tmp)
@@ -726,6 +750,7 @@ def main():
         make_stats(tmp)
         make_formats(tmp)
         make_multi(tmp)
+        make_multi_best(tmp)
     print("done")
 
 

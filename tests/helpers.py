@@ -21,7 +21,7 @@ class OraParams(ctypes.Structure):
     _fields_ = [("max_subs", ctypes.c_int32), ("min_edit_dist", ctypes.c_int32),
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
-                ("clamp_ml", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
@@ -36,9 +36,10 @@ class OraCounters(ctypes.Structure):
                 ("n_reads", "n_search", "n_probe", "n_last_search", "n_cand", "n_cand_seen", "n_lcm_calls")]
 
 
-def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, cls=OraParams):
+def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0, cls=OraParams):
     p = cls()
     p.clamp_ml = clamp_ml
+    p.best_matches = best_matches
     p.max_subs, p.min_edit_dist, p.align_strand, p.pmode, p.max_ns, p.max_ml = \
         max_subs, min_edit_dist, align_strand, pmode, max_ns, max_ml
     return p

@@ -207,7 +207,10 @@ def test_align_end_trims(golden_tmp, tmp_path):
 MULTI_CASES = [("r1R5", ["-r1", "-R5"], ["m6.sam"]), ("r2R5", ["-r2", "-R5"], ["m6.sam"]), ("r3R5", ["-r3", "-R5", "-T4"], ["m6.sam", "m5.sam"]),
                ("r4R5", ["-r4", "-R5", "-T4"], ["m6.sam"]), ("r4R3X", ["-r4", "-R3", "-X", "-T4"], ["m6.sam"]),
                ("r3R8T1", ["-r3", "-R8", "-T1"], ["m6.sam"]), ("r5R5", ["-r5", "-R5"], ["m6.sam", "m5.sam", "m0.csv", "m4.bed"]),
-               ("r5R3X", ["-r5", "-R3", "-X"], ["m6.sam"])]
+               ("r5R3X", ["-r5", "-R3", "-X"], ["m6.sam"]),
+               # -N: LocateBestMatches instead of the AlignReads schedule
+               ("r5R5N", ["-r5", "-R5", "-N"], ["m6.sam", "m0.csv"]), ("r5R2Ns1", ["-r5", "-R2", "-N", "-s1"], ["m0.csv"]),
+               ("r3R4N", ["-r3", "-R4", "-N", "-T4"], ["m6.sam"]), ("r2R3N", ["-r2", "-R3", "-N"], ["m6.sam"]), ("r1R5N", ["-r1", "-R5", "-N"], ["m6.sam"])]
 FMT_FLAG = {"m6.sam": "-M6", "m5.sam": "-M5", "m0.csv": "-M0", "m4.bed": "-M4"}
 
 
@@ -217,7 +220,7 @@ def test_multi_loci_modes_byte_identical(golden_tmp, tmp_path, tag, flags, exts)
     sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
     for ext in exts:
         out = str(tmp_path / f"o.{ext}")
-        run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext], "-s3"] + flags, str(tmp_path))
+        run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext]] + ([] if "-s1" in flags else ["-s3"]) + flags, str(tmp_path))
         got, exp = open(out, "rb").read(), golden_bytes("multi", f"{tag}.{ext}.gz")
         if got != exp:
             g, e = got.split(b"\n"), exp.split(b"\n")
@@ -228,7 +231,7 @@ def test_multi_loci_modes_byte_identical(golden_tmp, tmp_path, tag, flags, exts)
 def test_multi_loci_option_checks(golden_tmp, tmp_path):
     d = golden_tmp["multi"]
     sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
-    for bad in (["-r6"], ["-r3", "-R1"], ["-r3", "-R501"], ["-r5", "-M2"], ["-r2", "-N"]):
+    for bad in (["-r6"], ["-r3", "-R1"], ["-r3", "-R501"], ["-r5", "-M2"]):
         r = subprocess.run([BIN, "align", "-i", reads, "-I", sfx, "-o", str(tmp_path / "x.sam")] + bad, cwd=str(tmp_path),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode != 0, bad

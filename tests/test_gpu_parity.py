@@ -469,3 +469,53 @@ def test_multi_loci_synthetic(tmp_path, read_len, max_subs, max_ml, clamp):
         got = al.align(bases, offs, lens)
         _assert_loci_equal(bk, al, nreads, got, exp, eo, el)
     assert np.count_nonzero(np.diff(eo.astype(np.int64)) > 1) > 20
+
+
+@pytest.mark.parametrize("max_ml,max_subs", [(2, 3), (5, 3), (5, 1), (64, 5), (500, 3)])
+@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths", "multi"])
+def test_best_matches_match_oracle(golden_tmp, fixture, max_ml, max_subs):
+    """-N (LocateBestMatches): result records and the loci kept, ordered by mismatches then discovery, against the oracle's
+    literal restatement of the reference's insertion list"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
+    kw = dict(max_subs=max_subs, max_ml=max_ml, best_matches=1)
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, eo, el = helpers.oracle_align_multi(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    sfx.close()
+    for knobs in ([], [("chunk_reads", 300)], [("kmer_bits", 8)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs[keep], lens[keep])
+            ctr = al.counters()
+            _assert_loci_equal(bk, al, len(keep), got, exp, eo, el)
+
+
+def test_best_matches_synthetic(tmp_path):
+    import torch
+    bk = _bk()
+    read_len = 100
+    seq, ents, reads = _synth_case(77, 300000, 12000, read_len, 4, dup_len=250)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    path = str(tmp_path / "synth.sfx")
+    helpers.write_sfx(path, "synth", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = (np.arange(nreads, dtype=np.uint64) * read_len)
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    kw = dict(max_subs=4, max_ml=6, best_matches=1)
+    o = helpers.OracleSfx(path)
+    exp, eo, el = helpers.oracle_align_multi(o, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    octr = o.align(bases, offs, lens, helpers.make_params(**kw), nthreads=8)[1]
+    o.close()
+    with bk.Aligner(path, bk.AlignParams(**kw)) as al:
+        got = al.align(bases, offs, lens)
+        ctr = al.counters()
+        _assert_loci_equal(bk, al, nreads, got, exp, eo, el)
+    assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
+    assert np.count_nonzero(np.diff(eo.astype(np.int64)) > 1) > 20
