@@ -57,6 +57,9 @@ typedef struct bk_align_params {
     int32_t best_matches;   /* -N  with max_ml > 1: CSfxArrayV3::LocateBestMatches instead of AlignReads - per read the (up to)
                              *     max_ml loci with the fewest mismatches, none above the -s limit, ordered by mismatches
                              *     then discovery; bk_hit.rslt is eHRhits / eHRnone, LowMMCnt and NxtLowMMCnt stay 0          */
+    int32_t micro_indel_len;/* -a  0, or the longest microInDel (1..20) looked for in reads the AlignReads phases leave unaligned
+                             *     (CSfxArrayV3::LocateInDels); second segments come back through bk_batch_seg2()             */
+    int32_t reserved2[3];
 } bk_align_params;
 
 /* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and

@@ -537,13 +537,284 @@ static int locate_best_matches(const ora_sfx *s, int max_tot_mm, int core_len, i
     return low_inst;
 }
 
+/* ---- microInDels (`-a`): LocateInDels SfxArrayV2.cpp:7348-7660, ExploreInDelMatchRight :8943-9168,
+ * ExploreInDelMatchLeft :9172-9405 ------------------------------------------------------------- */
+enum { MAX_MM_EXPLORE_INDEL = 7, MIN_INDEL_SEQ_LEN = 7, MAX_MICRO_INDEL_MM = 2, MAX_PUT_INDEL_OFSS = 80,
+       BASE_SCORE = 500, MAX_SCORE = 1000, SCORE_MATCH = 3, SCORE_MISMATCH = 5, SCORE_INDEL_OPN = 20, SCORE_INDEL_EXTN = 1 };
+
+typedef struct indel_hit {
+    int score, is_indel, is_insert;
+    uint64_t s0_loci, s1_loci;          /* suffix offsets until locate_indels makes them entry relative */
+    int s0_len, s0_mm, s1_len, s1_mm, s1_read_ofs;
+    uint32_t s0_chrom, s1_chrom;
+    char strand;
+} indel_hit;
+
+static int base_mismatch(uint8_t pb, uint8_t tb) { return !(pb == tb && pb <= B_T); }
+
+/* anchored at the 5' end of the probe: everything left of a mismatch position matches as is, the rest after
+ * skipping 1..max_len probe bases (insertion in the read) or target bases (deletion from the read) */
+static int explore_indel_right(char strand, int max_len, int max_mm, int plen, const uint8_t *probe, const ora_entry *ent,
+                               int64_t targ_ofs, const uint8_t *targ, indel_hit *hit)
+{
+    int mm_ofs[MAX_PUT_INDEL_OFSS + 8];
+    indel_hit ins, del;
+    memset(hit, 0, sizeof(*hit));
+    if (targ_ofs < (int64_t)ent->start_ofs || (targ_ofs + plen - 1) > (int64_t)ent->end_ofs) return 0;
+    uint32_t targ_seq_len = (uint32_t)(ent->seq_len - (targ_ofs - (int64_t)ent->start_ofs));
+    memset(&ins, 0, sizeof(ins));
+    memset(&del, 0, sizeof(del));
+    if (max_mm > MAX_PUT_INDEL_OFSS) max_mm = MAX_PUT_INDEL_OFSS;
+    int n_mm = 0;
+    int lim = max_mm > MAX_MM_EXPLORE_INDEL ? max_mm : MAX_MM_EXPLORE_INDEL;
+    for (int i = 0; i < plen && n_mm <= lim; i++) {
+        uint8_t pb = probe[i] & 7, tb = targ[i] & 7;
+        if (tb > B_N || pb > B_N) return 0;
+        if (!base_mismatch(pb, tb)) continue;
+        mm_ofs[n_mm++] = i;
+    }
+    if (n_mm < MAX_MM_EXPLORE_INDEL || MIN_INDEL_SEQ_LEN > (plen - mm_ofs[0])) {
+        if (n_mm > max_mm) return 0;
+        hit->s0_len = plen; hit->s0_loci = (uint64_t)targ_ofs; hit->s0_mm = n_mm; hit->strand = strand;
+        hit->score = BASE_SCORE + plen * SCORE_MATCH - n_mm * SCORE_MISMATCH;
+        return 1;
+    }
+    int tot = max_mm < n_mm ? max_mm : n_mm;
+    for (int k = 0; k <= tot && MIN_INDEL_SEQ_LEN < (plen - mm_ofs[k]); k++)
+        for (int l = 1; l <= max_len; l++) {
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((l - 1) * SCORE_INDEL_EXTN + SCORE_INDEL_OPN);
+            const uint8_t *pp = probe + mm_ofs[k] + l, *pt = targ + mm_ofs[k];
+            uint32_t rest = (uint32_t)(plen - (mm_ofs[k] + l));
+            if (rest < MIN_INDEL_SEQ_LEN) break;
+            uint32_t trest = targ_seq_len - (uint32_t)mm_ofs[k];
+            if (trest < rest) break;
+            int imm = 0;
+            uint32_t i;
+            for (i = 0; i < rest && (k + imm) <= max_mm; i++, pt++, pp++) {
+                uint8_t pb = *pp & 7, tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                imm++;
+                score -= SCORE_MISMATCH;
+                if (rest < (uint32_t)(MIN_INDEL_SEQ_LEN * imm)) break;
+            }
+            if (i != rest) continue;
+            if (score > ins.score) {
+                memset(&ins, 0, sizeof(ins));
+                ins.s0_len = mm_ofs[k]; ins.s0_loci = (uint64_t)targ_ofs; ins.s0_mm = k; ins.strand = strand;
+                ins.s1_len = (int)rest; ins.s1_loci = ins.s0_loci + (uint64_t)ins.s0_len; ins.s1_mm = imm;
+                ins.s1_read_ofs = ins.s0_len + l;
+                ins.score = score; ins.is_indel = 1; ins.is_insert = 1;
+            }
+        }
+    for (int k = 0; k <= tot && MIN_INDEL_SEQ_LEN < (plen - mm_ofs[k]); k++)
+        for (int l = 1; l <= max_len; l++) {
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((l - 1) * SCORE_INDEL_EXTN + SCORE_INDEL_OPN);
+            const uint8_t *pp = probe + mm_ofs[k], *pt = targ + mm_ofs[k] + l;
+            uint32_t rest = (uint32_t)(plen - mm_ofs[k]);
+            if (rest < MIN_INDEL_SEQ_LEN) break;
+            uint32_t trest = targ_seq_len - (uint32_t)(mm_ofs[k] + l);
+            if (trest < rest) break;
+            int imm = 0;
+            uint32_t i;
+            for (i = 0; i < rest && (k + imm) <= max_mm; i++, pt++, pp++) {
+                uint8_t pb = *pp & 7, tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                imm++;
+                score -= SCORE_MISMATCH;
+                if (rest < (uint32_t)(MIN_INDEL_SEQ_LEN * imm)) break;
+            }
+            if (i != rest) continue;
+            if (score > del.score) {
+                memset(&del, 0, sizeof(del));
+                del.s0_len = mm_ofs[k]; del.s0_loci = (uint64_t)targ_ofs; del.s0_mm = k; del.strand = strand;
+                del.s1_len = (int)rest; del.s1_loci = (uint64_t)targ_ofs + (uint64_t)del.s0_len + (uint64_t)l; del.s1_mm = imm;
+                del.s1_read_ofs = del.s0_len;
+                del.score = score; del.is_indel = 1; del.is_insert = 0;
+            }
+        }
+    if (del.score == 0 && ins.score == 0) return 0;
+    if (del.score > ins.score) { *hit = del; return 3; }
+    *hit = ins;
+    return 2;
+}
+
+/* anchored at the 3' end of the probe, scanning right to left */
+static int explore_indel_left(char strand, int max_len, int max_mm, int plen, const uint8_t *probe, const ora_entry *ent,
+                              int64_t targ_ofs, const uint8_t *targ, indel_hit *hit)
+{
+    int mm_ofs[MAX_PUT_INDEL_OFSS + 8];
+    indel_hit ins, del;
+    memset(hit, 0, sizeof(*hit));
+    if (targ_ofs < (int64_t)ent->start_ofs || (targ_ofs + plen - 1) > (int64_t)ent->end_ofs) return 0;
+    memset(&ins, 0, sizeof(ins));
+    memset(&del, 0, sizeof(del));
+    if (max_mm > MAX_PUT_INDEL_OFSS) max_mm = MAX_PUT_INDEL_OFSS;
+    int n_mm = 0;
+    int lim = max_mm > MAX_MM_EXPLORE_INDEL ? max_mm : MAX_MM_EXPLORE_INDEL;
+    for (int i = plen - 1; i >= 0 && n_mm <= lim; i--) {
+        uint8_t pb = probe[i] & 7, tb = targ[i] & 7;
+        if (tb > B_N || pb > B_N) return 0;
+        if (!base_mismatch(pb, tb)) continue;
+        mm_ofs[n_mm++] = i;
+    }
+    if (n_mm < MAX_MM_EXPLORE_INDEL || MIN_INDEL_SEQ_LEN > mm_ofs[0]) {
+        if (n_mm > max_mm) return 0;
+        hit->s0_len = plen; hit->s0_loci = (uint64_t)targ_ofs; hit->s0_mm = n_mm; hit->strand = strand;
+        hit->score = BASE_SCORE + plen * SCORE_MATCH - n_mm * SCORE_MISMATCH;
+        return 1;
+    }
+    int tot = max_mm < n_mm ? max_mm : n_mm;
+    for (int k = 0; k <= tot && MIN_INDEL_SEQ_LEN < mm_ofs[k]; k++)
+        for (int l = 1; l <= max_len; l++) {
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((l - 1) * SCORE_INDEL_EXTN + SCORE_INDEL_OPN);
+            score -= k * SCORE_MISMATCH;
+            if (score < ins.score) break;
+            const uint8_t *pp = probe + mm_ofs[k] - l, *pt = targ + mm_ofs[k];
+            uint32_t rest = (uint32_t)(mm_ofs[k] - (l - 1));
+            if (rest < MIN_INDEL_SEQ_LEN) break;
+            int imm = 0, i;
+            for (i = 0; i < (int)rest && (k + imm) <= max_mm; i++, pt--, pp--) {
+                uint8_t pb = *pp & 7, tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                imm++;
+                score -= SCORE_MISMATCH;
+                if (rest < (uint32_t)(MIN_INDEL_SEQ_LEN * imm)) break;
+            }
+            if (i != (int)rest) continue;
+            if (score > ins.score) {
+                memset(&ins, 0, sizeof(ins));
+                ins.s0_len = (int)rest; ins.s0_loci = (uint64_t)(uint32_t)(targ_ofs + l); ins.s0_mm = imm; ins.strand = strand;
+                ins.s1_len = plen - ((int)rest + l); ins.s1_loci = ins.s0_loci + (uint64_t)ins.s0_len; ins.s1_mm = k;
+                ins.s1_read_ofs = ins.s0_len + l;
+                ins.score = score; ins.is_indel = 1; ins.is_insert = 1;
+            }
+        }
+    for (int k = 0; k <= tot && MIN_INDEL_SEQ_LEN < mm_ofs[k]; k++)
+        for (int l = 1; l <= max_len; l++) {
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((l - 1) * SCORE_INDEL_EXTN + SCORE_INDEL_OPN);
+            score -= k * SCORE_MISMATCH;
+            if (score < del.score) break;
+            const uint8_t *pp = probe + mm_ofs[k], *pt = targ + mm_ofs[k] - l;
+            uint32_t rest = (uint32_t)(mm_ofs[k] + 1);
+            if (rest < MIN_INDEL_SEQ_LEN) break;
+            if ((uint64_t)(uint32_t)l > (uint64_t)targ_ofs) break;
+            int imm = 0, i;
+            for (i = 0; i < (int)rest && (k + imm) <= max_mm; i++, pt--, pp--) {
+                uint8_t pb = *pp & 7, tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                imm++;
+                score -= SCORE_MISMATCH;
+                if (rest < (uint32_t)(MIN_INDEL_SEQ_LEN * imm)) break;
+            }
+            if (i != (int)rest) continue;
+            if (score > del.score) {
+                memset(&del, 0, sizeof(del));
+                del.s0_len = (int)rest; del.s0_loci = (uint64_t)(uint32_t)(targ_ofs - l); del.s0_mm = imm; del.strand = strand;
+                del.s1_len = plen - (int)rest; del.s1_loci = del.s0_loci + (uint64_t)rest + (uint64_t)l; del.s1_mm = k;
+                del.s1_read_ofs = (int)rest;
+                del.score = score; del.is_indel = 1; del.is_insert = 0;
+            }
+        }
+    if (del.score == 0 && ins.score == 0) return 0;
+    if (del.score > ins.score) { *hit = del; return 3; }
+    *hit = ins;
+    return 2;
+}
+
+/* LocateInDels with MaxHits = 1 (the only value AlignReads passes, :7731): two anchor cores per strand, the 5' one explored
+ * rightwards and the 3' one leftwards; the best scoring placement wins, further placements with the same score at a
+ * different Seg[0] start make the read ambiguous (returns eHRnone) */
+static int locate_indels(const ora_sfx *s, int max_len, int max_tot_mm, int core_len, int align2strand,
+                         int *p_low_inst, int *p_low_mm, int *p_nxt, uint8_t *probe, int plen, indel_hit *best,
+                         int max_iter, ora_counters *ctr)
+{
+    int64_t sfx_len = (int64_t)s->concat_len;
+    char cur_strand;
+    int best_instances = 0;
+    const int max_hits = 1;
+    if (s->concat_len == 0) return -1;
+    *p_low_inst = 0; *p_low_mm = 0; *p_nxt = 0;
+    memset(best, 0, sizeof(*best));
+    if (align2strand == ALS_CRICK) { revcomp(probe, plen); cur_strand = '-'; }
+    else cur_strand = '+';
+    do {
+        for (int phase = 0; phase < 2; phase++) {
+            int core_ofs = phase == 0 ? 0 : plen - core_len;
+            int64_t targ_idx = ora_locate_first_exact(s, probe + core_ofs, core_len, 0, sfx_len - 1, ctr);
+            if (targ_idx == 0) continue;
+            targ_idx -= 1;
+            int iter_cnt = 0, first_iter = 1;
+            uint32_t num_copies = 0;
+            while (!max_iter || iter_cnt < max_iter) {
+                if (!first_iter) {
+                    if ((targ_idx + 1) >= sfx_len || (sa_at(s, targ_idx + 1) + core_len) > sfx_len) break;
+                    if (iter_cnt == 100 && !num_copies) {
+                        int64_t last = ora_locate_last_exact(s, probe + core_ofs, core_len, targ_idx - 1, sfx_len - 1, ctr);
+                        num_copies = last > 0 ? (uint32_t)(1 + last - targ_idx) : 0;
+                        if (max_iter && num_copies > (uint32_t)max_iter) break;
+                    }
+                    if (cmp_probe(probe + core_ofs, s->seq + sa_at(s, targ_idx + 1), core_len) != 0) break;
+                    targ_idx += 1;
+                }
+                first_iter = 0;
+                int64_t loci = sa_at(s, targ_idx);
+                if (loci < (int64_t)(uint32_t)core_ofs) continue;
+                int64_t left = loci - core_ofs;
+                const ora_entry *ent = map_entry(s, (uint64_t)loci);
+                if (ent == NULL) continue;
+                if (left < (int64_t)ent->start_ofs || (left + plen - 1) > (int64_t)ent->end_ofs) continue;
+                if ((left + plen) > sfx_len) continue;
+                iter_cnt++;
+                indel_hit h;
+                int r = phase == 0 ? explore_indel_right(cur_strand, max_len, max_tot_mm, plen, probe, ent, left, s->seq + left, &h)
+                                   : explore_indel_left(cur_strand, max_len, max_tot_mm, plen, probe, ent, left, s->seq + left, &h);
+                if (r > 0 && h.score >= best->score) {
+                    if (h.score == best->score) {
+                        if (best->s0_loci == h.s0_loci) continue;
+                        if (++best_instances > max_hits) continue;
+                    } else
+                        best_instances = 0;
+                    *best = h;                       /* pHits[BestScoreInstances++] with MaxHits 1: always slot 0 */
+                    best_instances++;
+                }
+            }
+            if (best_instances >= 1 && best->score >= MAX_SCORE) { align2strand = ALS_NONE; break; }
+        }
+        if (cur_strand == '+' && align2strand == ALS_BOTH) {
+            revcomp(probe, plen);
+            cur_strand = '-';
+            align2strand = ALS_CRICK;
+        } else
+            align2strand = ALS_NONE;
+    } while (!(best_instances >= 1 && best->score >= MAX_SCORE) && align2strand != ALS_NONE);
+    if (cur_strand == '-') revcomp(probe, plen);
+    if (best_instances == 0) return HR_NONE;
+    if (best->score > MAX_SCORE) best->score = MAX_SCORE;
+    {
+        const ora_entry *e0 = map_entry(s, best->s0_loci), *e1 = map_entry(s, best->s1_loci);
+        if (e0 == NULL || e1 == NULL) return HR_NONE;
+        if (e0->entry_id != e1->entry_id) return HR_NONE;      /* also drops placements without a second segment outside the first entry */
+        best->s0_chrom = e0->entry_id;
+        best->s0_loci -= e0->start_ofs;
+        if (best->s1_loci > 0) { best->s1_chrom = e1->entry_id; best->s1_loci -= e1->start_ofs; }
+    }
+    *p_low_inst = best_instances < max_hits ? best_instances : max_hits;
+    *p_low_mm = best->s0_mm + best->s1_mm;
+    *p_nxt = *p_low_mm + 2;
+    return best_instances <= max_hits ? HR_HITS : HR_NONE;
+}
+
 /* AlignReads, SfxArrayV2.cpp:7666-7760 with microInDelLen = MaxSpliceJunctLen = MinChimericLen = 0 */
 static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta, int max_slides,
                        int mm_delta, int align2strand, int *p_low_inst, int *p_low_mm, int *p_nxt,
                        uint8_t *probe, int plen, int max_hits, hit_rec *hits, int max_iter,
-                       scratch *sc, ora_counters *ctr)
+                       scratch *sc, ora_counters *ctr, int micro_indel_len, indel_hit *ih, int *got_indel)
 {
-    int rslt, allow_mm;
+    int rslt = 0, allow_mm;
     if (max_tot_mm > 0) {
         for (allow_mm = 0; allow_mm <= max_tot_mm; allow_mm++) {
             int cl = plen / (allow_mm + mm_delta);
@@ -560,6 +831,12 @@ static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_
                                      align2strand, p_low_inst, p_low_mm, p_nxt, probe, plen,
                                      max_hits, hits, max_iter, sc, ctr);
         if (rslt != 0) return rslt;
+    }
+    if (rslt == 0 && micro_indel_len > 0) {                                            /* :7722-7734 */
+        int splice_core = core_len * 2 < (plen - 1) / 2 ? core_len * 2 : (plen - 1) / 2;
+        rslt = locate_indels(s, micro_indel_len, max_tot_mm > MAX_MICRO_INDEL_MM ? MAX_MICRO_INDEL_MM : max_tot_mm, splice_core,
+                             align2strand, p_low_inst, p_low_mm, p_nxt, probe, plen, ih, max_iter, ctr);
+        if (rslt != 0) { *got_indel = 1; return rslt; }
     }
     return 0;
 }
@@ -597,8 +874,9 @@ static int imax(int a, int b) { return a > b ? a : b; }
 /* loci_out (optional): room for p->max_ml entries - the pHits[] contents of a read whose AlignReads returned
  * eHRhits, in the order LocateCoreMultiples left them (the multi-loci modes -r1..-r5 consume these) */
 static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *bases, int len,
-                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf, ora_loci *loci_out)
+                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf, ora_loci *loci_out, ora_seg2 *seg2_out)
 {
+    if (seg2_out) memset(seg2_out, 0, sizeof(*seg2_out));
     memset(out, 0, sizeof(*out));
     out->nar = NAR_NOHIT;                                      /* Aligner.cpp:9030 */
     out->strand = '?';                                         /* CAligner::AddEntry :10652 */
@@ -631,7 +909,9 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     hit_rec *hits = hits_small;
     if (max_ml > 7) hits = (hit_rec *)malloc(sizeof(hit_rec) * ((size_t)max_ml + 1));
     memset(hits, 0, sizeof(hit_rec) * ((size_t)max_ml + 1));
-    int rslt;
+    int rslt, got_indel = 0;
+    indel_hit ih;
+    memset(&ih, 0, sizeof(ih));
     if (p->best_matches) {                                                             /* Aligner.cpp:9197-9218 */
         rslt = locate_best_matches(s, max_tot_mm, core_len, core_delta, max_slides, align2strand, seqbuf, match_len, max_ml, hits,
                                    ora_max_iter(p->pmode), sc, ctr);
@@ -639,7 +919,17 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     } else
         rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
                            &low_inst, &low_mm, &nxt, seqbuf, match_len, max_ml, hits,
-                           ora_max_iter(p->pmode), sc, ctr);
+                           ora_max_iter(p->pmode), sc, ctr, p->micro_indel_len, &ih, &got_indel);
+    if (got_indel && rslt == HR_HITS) {            /* the one tsHitLoci LocateInDels returned -> pMultiHits[0] */
+        hits[0].strand = (uint8_t)ih.strand; hits[0].chrom_id = ih.s0_chrom; hits[0].match_loci = (uint32_t)ih.s0_loci;
+        hits[0].match_len = (uint16_t)ih.s0_len; hits[0].mismatches = (uint8_t)ih.s0_mm;
+        if (seg2_out) {
+            seg2_out->match_loci = (uint32_t)ih.s1_loci; seg2_out->match_len = (uint16_t)ih.s1_len;
+            seg2_out->read_ofs = (uint16_t)ih.s1_read_ofs; seg2_out->mismatches = (uint8_t)ih.s1_mm;
+            seg2_out->flags = (uint8_t)((ih.is_indel ? 1 : 0) | (ih.is_insert ? 2 : 0));
+            seg2_out->score = (uint16_t)ih.score;
+        }
+    }
     if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }
     if (low_inst > max_ml) low_inst = max_ml + 1;                                       /* :9241 */
     out->rslt = (uint8_t)rslt;
@@ -710,7 +1000,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 {
     scratch *sc = scratch_new();
     uint8_t *buf = (uint8_t *)malloc((size_t)len + 16);
-    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf, NULL);
+    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf, NULL, NULL);
     free(buf);
     scratch_free(sc);
     return r;
@@ -718,7 +1008,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 
 typedef struct worker {
     const ora_sfx *s; const ora_params *p; const uint8_t *bases; const uint64_t *offs;
-    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt; ora_loci *loci;
+    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt; ora_loci *loci; ora_seg2 *seg2;
 } worker;
 
 static void *worker_main(void *arg)
@@ -730,7 +1020,8 @@ static void *worker_main(void *arg)
     uint8_t *buf = (uint8_t *)malloc((size_t)maxlen + 16);
     for (uint32_t i = w->lo; i < w->hi; i++) {
         ora_loci *lo = w->loci ? w->loci + (size_t)i * (size_t)(w->p->max_ml > 0 ? w->p->max_ml : 1) : NULL;
-        int r = align_read_sc(w->s, w->p, w->bases + w->offs[i], (int)w->lens[i], &w->out[i], &w->ctr, sc, buf, lo);
+        int r = align_read_sc(w->s, w->p, w->bases + w->offs[i], (int)w->lens[i], &w->out[i], &w->ctr, sc, buf, lo,
+                              w->seg2 ? w->seg2 + i : NULL);
         if (r < 0) { w->rslt = r; break; }
     }
     free(buf);
@@ -742,12 +1033,19 @@ int ora_align_batch(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
                     const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                     ora_hit *out, ora_counters *ctr, int nthreads)
 {
-    return ora_align_batch_multi(s, p, bases, offs, lens, nreads, out, NULL, ctr, nthreads);
+    return ora_align_batch_ex(s, p, bases, offs, lens, nreads, out, NULL, NULL, ctr, nthreads);
 }
 
 int ora_align_batch_multi(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
                           const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                           ora_hit *out, ora_loci *loci, ora_counters *ctr, int nthreads)
+{
+    return ora_align_batch_ex(s, p, bases, offs, lens, nreads, out, loci, NULL, ctr, nthreads);
+}
+
+int ora_align_batch_ex(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
+                       const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                       ora_hit *out, ora_loci *loci, ora_seg2 *seg2, ora_counters *ctr, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > nreads) nthreads = nreads ? (int)nreads : 1;
@@ -757,7 +1055,7 @@ int ora_align_batch_multi(const ora_sfx *s, const ora_params *p, const uint8_t *
      * reads are independent so a static split gives the same answers */
     uint64_t per = ((uint64_t)nreads + nthreads - 1) / nthreads;
     for (int t = 0; t < nthreads; t++) {
-        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out; w[t].loci = loci;
+        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out; w[t].loci = loci; w[t].seg2 = seg2;
         uint64_t lo = per * t, hi = lo + per;
         if (lo > nreads) lo = nreads;
         if (hi > nreads) hi = nreads;

@@ -709,12 +709,64 @@ def make_multi_best(tmp):
             print("  ran", tag, fmt, flags)
 
 
+def make_indel(tmp):
+    """microInDels (-a): reads carrying an insertion or a deletion of 1..8 bases (plus 0-1 substitutions), one to three reads
+    per site so that both supported and orphan placements occur, among ordinary reads; -a10 and -a3 in SAM / CSV / BED."""
+    rng = np.random.default_rng(99)
+    outdir = os.path.join(HERE, "indel")
+    os.makedirs(outdir, exist_ok=True)
+    g = [rand_seq(rng, 40000), rand_seq(rng, 30000)]
+    fa = os.path.join(tmp, "indel.fa")
+    write_fasta(fa, [("iA", g[0]), ("iB", g[1])])
+    reads = []
+    for i in range(150):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(200, len(g[c]) - 400)); L = int(rng.integers(1, 9)); kind = int(rng.integers(0, 2))
+        for r in range(int(rng.integers(1, 4))):
+            st = p - int(rng.integers(12, 90))
+            if kind == 0:
+                s = g[c][st:p] + rand_seq(rng, L) + g[c][p:st + 100 - L]
+            else:
+                s = g[c][st:p] + g[c][p + L:st + 100 + L]
+            s = mutate(rng, s[:100], int(rng.integers(0, 2)))
+            if rng.integers(0, 2):
+                s = revcomp(s)
+            reads.append((f"{'ins' if kind == 0 else 'del'}{i}_{r}_L{L}", s))
+    for i in range(400):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 100))
+        s = mutate(rng, g[c][p:p + 100], int(rng.integers(0, 5)))
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"n{i}", s))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "indel_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "indel.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "indel", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags in (("a10", ["-a10", "-s3"]), ("a3s5", ["-a3", "-s5"]), ("a20Q1", ["-a20", "-s3", "-Q1"])):
+        for fmt, ext in (("-M6", "m6.sam"), ("-M5", "m5.sam"), ("-M0", "m0.csv"), ("-M3", "m3.csv"), ("-M4", "m4.bed")):
+            if tag != "a10" and fmt not in ("-M6", "-M0"):
+                continue
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-T4"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            if fmt == "-M4":
+                gz_copy(out + ".ind", os.path.join(outdir, f"{tag}.{ext}.ind.gz"))
+            print("  ran", tag, fmt, flags)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-indel" in sys.argv:
+            make_indel(tmp)
             return
         if "--only-multi-best" in sys.argv:
             make_multi_best(tmp)
@@ -751,6 +803,7 @@ def main():
         make_formats(tmp)
         make_multi(tmp)
         make_multi_best(tmp)
+        make_indel(tmp)
     print("done")
 
 

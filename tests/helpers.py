@@ -21,7 +21,8 @@ class OraParams(ctypes.Structure):
     _fields_ = [("max_subs", ctypes.c_int32), ("min_edit_dist", ctypes.c_int32),
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
-                ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32)]
+                ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32),
+                ("micro_indel_len", ctypes.c_int32), ("reserved2", ctypes.c_int32 * 3)]
 
 
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
@@ -36,8 +37,10 @@ class OraCounters(ctypes.Structure):
                 ("n_reads", "n_search", "n_probe", "n_last_search", "n_cand", "n_cand_seen", "n_lcm_calls")]
 
 
-def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0, cls=OraParams):
+def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0, micro_indel_len=0,
+                cls=OraParams):
     p = cls()
+    p.micro_indel_len = micro_indel_len
     p.clamp_ml = clamp_ml
     p.best_matches = best_matches
     p.max_subs, p.min_edit_dist, p.align_strand, p.pmode, p.max_ns, p.max_ml = \
@@ -72,6 +75,9 @@ def oracle_lib():
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(OraCounters), ctypes.c_int]
     lib.ora_align_batch_multi.restype = ctypes.c_int
+    lib.ora_align_batch_ex.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(OraCounters), ctypes.c_int]
+    lib.ora_align_batch_ex.restype = ctypes.c_int
     lib.ora_process_paired_ends.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                             ctypes.c_void_p]
@@ -157,6 +163,43 @@ def oracle_align_multi(osfx, bases, offs, lens, params, nthreads=4):
     lo[1:] = np.cumsum(cnt)
     mask = np.arange(ml)[None, :] < cnt[:, None]
     return out, lo, dense[mask]
+
+
+SEG2_DTYPE = np.dtype([("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"), ("flags", "u1"), ("score", "<u2")])
+
+
+def oracle_align_indel(osfx, bases, offs, lens, params, nthreads=4):
+    """params.micro_indel_len > 0 -> (hits, seg2): seg2[i].flags != 0 marks a read aligned with a microInDel"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = len(lens)
+    out = np.zeros(n, dtype=HIT_DTYPE)
+    seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+    ctr = OraCounters()
+    rc = osfx.lib.ora_align_batch_ex(osfx.h, ctypes.byref(params), bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, n,
+                                     out.ctypes.data, None, seg2.ctypes.data, ctypes.byref(ctr), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"ora_align_batch_ex failed: {rc}")
+    return out, seg2
+
+
+def remove_orphan_indels(hits, seg2):
+    """CAligner::RemoveOrphanMicroInDels (Aligner.cpp:2382-2470): a microInDel placement stands only if another read has its
+    junction within 3 bases on both sides; the others become NAR 8 (OM).  In place."""
+    idx = [i for i in range(len(hits)) if hits["nar"][i] == 1 and (seg2["flags"][i] & 1)]
+    j = sorted((int(hits["chrom_id"][i]), int(hits["match_loci"][i]) + int(hits["match_len"][i]) - 1, int(seg2["match_loci"][i]), i) for i in idx)
+    keep = set()
+    if len(j) > 1:
+        for a, b in zip(j, j[1:]):
+            if a[0] == b[0] and abs(a[1] - b[1]) <= 3 and abs(a[2] - b[2]) <= 3:
+                keep.add(a[3]); keep.add(b[3])
+    for i in idx:
+        if i not in keep:
+            hits["nar"][i] = 8
+            hits["num_hits"][i] = 0
+            hits["low_hit_instances"][i] = 0
+    return hits
 
 
 def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits):
