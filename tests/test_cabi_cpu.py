@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     import biokanga_amd as bk
     from biokanga_amd import binding
     assert bk.HIT_DTYPE.itemsize == 20                      # bk_hit
-    assert ctypes.sizeof(bk.AlignParams) == 32              # bk_align_params
+    assert ctypes.sizeof(bk.AlignParams) == 48              # bk_align_params
     assert bk.ENTRY_DTYPE.itemsize == 112                   # bk_entry_info (8-byte aligned)
     assert ctypes.sizeof(binding._Counters) == 64
     assert ctypes.sizeof(binding._Timing) == 36
