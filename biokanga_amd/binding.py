@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -49,6 +49,8 @@ HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", 
 assert HIT_DTYPE.itemsize == 20
 LOCI_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("strand", "u1"), ("mismatches", "u1")])
 assert LOCI_DTYPE.itemsize == 12
+SEG2_DTYPE = np.dtype([("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"), ("flags", "u1"), ("score", "<u2")])
+assert SEG2_DTYPE.itemsize == 12
 
 ENTRY_DTYPE = np.dtype([("entry_id", "<u4"), ("seq_len", "<u4"), ("start_ofs", "<u8"), ("end_ofs", "<u8"),
                         ("name", "S81"), ("_pad", "S7")])
@@ -139,6 +141,7 @@ def load_library():
     lib.bk_pair_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(PEParams)]
     lib.bk_pair_batch_device.restype = i32
     lib.bk_batch_loci.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_batch_seg2.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
     lib.bk_get_counters.restype = i32
     lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
@@ -264,6 +267,17 @@ class Aligner:
             return offs, np.zeros(0, dtype=LOCI_DTYPE)
         raw = np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_DTYPE.itemsize,))
         return offs, raw.view(LOCI_DTYPE).copy()
+
+    def batch_seg2(self):
+        """Second segments of the last align call (contexts with micro_indel_len > 0): SEG2_DTYPE array, one per read (a copy)."""
+        ps, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self.lib.bk_batch_seg2(self.h, ctypes.byref(ps), ctypes.byref(n))
+        if rc:
+            raise BkError(rc, "bk_batch_seg2")
+        if not ps.value or n.value == 0:
+            return np.zeros(0, dtype=SEG2_DTYPE)
+        raw = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * SEG2_DTYPE.itemsize,))
+        return raw.view(SEG2_DTYPE).copy()
 
     def pair(self, bases, offs, lens, hits, pe):
         """PE association in place on `hits` (PE1/PE2 interleaved; the output of align() for the same reads)"""

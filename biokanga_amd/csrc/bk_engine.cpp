@@ -54,6 +54,8 @@ int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint3
 void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s);
 void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                  uint32_t n_list, uint32_t *cursor, unsigned long long *cnt, bk_loci *dense, hipStream_t s);
+void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, uint32_t *list, uint32_t *list_cnt_dev,
+                  uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
                         hipStream_t s);
@@ -146,6 +148,7 @@ struct bk_ctx {
     // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)
     std::vector<uint64_t> loci_offs;
     std::vector<bk_loci> loci;
+    std::vector<bk_seg2> seg2;           // -a: second segments of the last align call, one per read
 };
 
 namespace {
@@ -158,6 +161,8 @@ int derive_cfg(bk_ctx *c)
         return BK_ERR_PARAMS;
     if (p.max_ml < 0 || p.max_ml > BK_MAX_ML) return BK_ERR_PARAMS;
     if (p.best_matches && p.max_ml < 2) return BK_ERR_PARAMS;
+    if (p.micro_indel_len < 0 || p.micro_indel_len > 20) return BK_ERR_PARAMS;           // cMaxMicroInDelLen
+    if (p.micro_indel_len && p.max_ml > 1) return BK_ERR_PARAMS;                         // kanga.cpp:706-710 (and MaxHits is 1 in LocateInDels)
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
     g.mm_delta = p.min_edit_dist;
@@ -753,6 +758,25 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         cur ^= 1;
         if (phase > 70) return BK_ERR_INTERNAL;
     }
+    if (c->params.micro_indel_len > 0) {
+        // AlignReads' microInDel branch for what is still unaligned (SfxArrayV2.cpp:7722-7734)
+        hipEvent_t ei = tm.begin(s);
+        bk_seg2 *d_seg2 = nullptr;
+        HIP_TRY(hipMalloc(&d_seg2, (size_t)n * sizeof(bk_seg2)));
+        hipError_t eh = hipMemsetAsync(d_seg2, 0, (size_t)n * sizeof(bk_seg2), s);
+        if (eh == hipSuccess) eh = hipMemsetAsync(sm, 0, 16 * 4, s);
+        if (eh == hipSuccess) {
+            launch_indel(c->ix, c->cfg, b, n, c->params.micro_indel_len, c->d_act[0], sm + 0, hm + 0, sm + 1, d_seg2, s);
+            eh = hipGetLastError();
+        }
+        const size_t at = c->seg2.size();
+        c->seg2.resize(at + n);
+        if (eh == hipSuccess) eh = hipMemcpyAsync(c->seg2.data() + at, d_seg2, (size_t)n * sizeof(bk_seg2), hipMemcpyDeviceToHost, s);
+        if (eh == hipSuccess) eh = hipStreamSynchronize(s);
+        free_dev(d_seg2);
+        if (eh != hipSuccess) return BK_ERR_INTERNAL;
+        tm.end(2, ei, s);
+    }
     hipEvent_t e4 = tm.begin(s);
     launch_count_seqs(d_out, n, c->d_id2idx, c->ix.n_ent, c->d_seq_counts, s);
     HIP_TRY(hipGetLastError());
@@ -771,6 +795,7 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
     hipEvent_t t0 = tm.begin(s);
     c->loci_offs.clear();
     c->loci.clear();
+    c->seg2.clear();
     // longest read of the call -> row width of the packed reads and the kernel family used
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
     launch_max_len(d_lens, nreads, c->d_small + 5, s);
@@ -848,6 +873,14 @@ static int pair_on_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
 }
 
 extern "C" {
+
+int bk_batch_seg2(bk_ctx *c, const bk_seg2 **seg2, uint64_t *n)
+{
+    if (!c || !seg2 || !n) return BK_ERR_PARAMS;
+    *seg2 = c->seg2.empty() ? nullptr : c->seg2.data();
+    *n = c->seg2.size();
+    return BK_OK;
+}
 
 int bk_batch_loci(bk_ctx *c, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci)
 {

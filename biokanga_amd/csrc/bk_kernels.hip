@@ -2289,6 +2289,260 @@ __global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ 
         list[atomicAdd(list_cnt, 1u)] = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// microInDels (`-a`): CSfxArrayV3::LocateInDels (SfxArrayV2.cpp:7348-7660) for the reads the AlignReads phases left
+// unaligned, called as AlignReads does (:7722-7734): core = min(2 CoreLen, (len-1)/2), at most cMaxMicroInDelMM (2)
+// mismatches, MaxHits 1.  One wave per read; per strand two anchor cores (5' end explored rightwards, 3' end
+// leftwards); a lane takes one suffix-array member of the anchor's interval and runs ExploreInDelMatchRight / -Left
+// (:8943-9405) on it: mismatch positions of the ungapped compare (only placements with >= 7 of them are explored),
+// then for each of the first MaxTotMM+1 positions every gap length 1..microInDelLen as insertion and as deletion,
+// keeping the best score.  The lanes' results are then folded in suffix-array order with the reference's rule:
+// a higher score replaces, an equal score at another Seg[0] start makes the read ambiguous.
+
+struct IndelPlacement {
+    int r, score, is_insert;
+    uint64_t s0_loci, s1_loci;
+    int s0_len, s0_mm, s1_len, s1_mm, s1_ofs;
+};
+
+__device__ __forceinline__ int rd_base4(const uint64_t *__restrict__ rdw, int i)
+{
+    return (int)((rdw[i >> 4] >> (60 - 4 * (i & 15))) & 7);
+}
+__device__ __forceinline__ int tg_base4(const uint64_t *__restrict__ tgt, uint64_t pos)
+{
+    return (int)((tgt[pos >> 4] >> (60 - 4 * (int)(pos & 15))) & 7);
+}
+
+constexpr int kIndelMMExplore = 7, kIndelMinSeq = 7, kIndelMaxMM = 2, kIndelBase = 500, kIndelMaxScore = 1000, kIndelMatch = 3,
+              kIndelMismatch = 5, kIndelOpen = 20, kIndelExt = 1;
+
+// right == true: ExploreInDelMatchRight, else ExploreInDelMatchLeft.  t = target offset of the read's first base,
+// ent_left = bases of the entry from t to its end (right) - only used for the two "enough target left" tests.
+template <bool RIGHT>
+__device__ void explore_indel(const uint64_t *__restrict__ rdw, const uint64_t *__restrict__ tgt, int plen, uint64_t t, uint32_t targ_seq_len,
+                              int max_len, int max_mm, IndelPlacement &out)
+{
+    out.r = 0; out.score = 0; out.is_insert = 0; out.s0_loci = 0; out.s1_loci = 0; out.s0_len = 0; out.s0_mm = 0; out.s1_len = 0; out.s1_mm = 0; out.s1_ofs = 0;
+    int mm_ofs[kIndelMMExplore + 2];
+    int n_mm = 0;
+    const int lim = max_mm > kIndelMMExplore ? max_mm : kIndelMMExplore;      // max_mm <= 2 here
+    for (int q = 0; q < plen && n_mm <= lim; q++) {
+        const int i = RIGHT ? q : plen - 1 - q;
+        const int pb = rd_base4(rdw, i), tb = tg_base4(tgt, t + (uint64_t)i);
+        if (tb > 4 || pb > 4) return;
+        if (pb == tb && pb <= 3) continue;
+        if (n_mm < kIndelMMExplore + 2) mm_ofs[n_mm] = i;
+        n_mm++;
+    }
+    if (n_mm < kIndelMMExplore || (RIGHT ? kIndelMinSeq > plen - mm_ofs[0] : kIndelMinSeq > mm_ofs[0])) {
+        if (n_mm > max_mm) return;
+        out.r = 1; out.s0_len = plen; out.s0_loci = t; out.s0_mm = n_mm;
+        out.score = kIndelBase + plen * kIndelMatch - n_mm * kIndelMismatch;
+        return;
+    }
+    const int tot = max_mm < n_mm ? max_mm : n_mm;
+    IndelPlacement ins = out, del = out;
+    for (int pass = 0; pass < 2; pass++) {                 // 0: insertion into the read, 1: deletion from it
+        IndelPlacement &best = pass ? del : ins;
+        for (int k = 0; k <= tot; k++) {
+            const int mo = mm_ofs[k];
+            if (RIGHT ? !(kIndelMinSeq < plen - mo) : !(kIndelMinSeq < mo)) break;
+            for (int l = 1; l <= max_len; l++) {
+                int score = kIndelBase + plen * kIndelMatch - ((l - 1) * kIndelExt + kIndelOpen);
+                int rest, p0;                              // bases compared, first probe index
+                long long t0;                              // first target offset relative to t
+                if (RIGHT) {
+                    if (pass == 0) { rest = plen - (mo + l); p0 = mo + l; t0 = mo; }
+                    else { rest = plen - mo; p0 = mo; t0 = mo + l; }
+                    if (rest < kIndelMinSeq) break;
+                    const uint32_t trest = targ_seq_len - (uint32_t)(pass == 0 ? mo : mo + l);
+                    if (trest < (uint32_t)rest) break;
+                } else {
+                    score -= k * kIndelMismatch;
+                    if (score < best.score) break;
+                    if (pass == 0) { rest = mo - (l - 1); p0 = mo - l; t0 = mo; }
+                    else { rest = mo + 1; p0 = mo; t0 = (long long)mo - l; }
+                    if (rest < kIndelMinSeq) break;
+                    if (pass == 1 && (uint64_t)l > t) break;
+                }
+                int imm = 0, i;
+                for (i = 0; i < rest && (k + imm) <= max_mm; i++) {
+                    const int pi = RIGHT ? p0 + i : p0 - i;
+                    const long long ti = RIGHT ? t0 + i : t0 - i;
+                    const int pb = rd_base4(rdw, pi), tb = tg_base4(tgt, (uint64_t)((long long)t + ti));
+                    if (pb > 4 || tb > 4) break;
+                    if (pb == tb && pb <= 3) continue;
+                    imm++;
+                    score -= kIndelMismatch;
+                    if ((uint32_t)rest < (uint32_t)(kIndelMinSeq * imm)) break;
+                }
+                if (i != rest) continue;
+                if (score > best.score) {
+                    best.score = score; best.is_insert = pass == 0 ? 1 : 0;
+                    if (RIGHT) {
+                        best.s0_len = mo; best.s0_loci = t; best.s0_mm = k;
+                        best.s1_len = rest; best.s1_mm = imm;
+                        best.s1_loci = pass == 0 ? t + (uint64_t)mo : t + (uint64_t)mo + (uint64_t)l;
+                        best.s1_ofs = pass == 0 ? mo + l : mo;
+                    } else {
+                        best.s0_len = rest; best.s0_mm = imm; best.s1_mm = k;
+                        if (pass == 0) {
+                            best.s0_loci = (uint64_t)(uint32_t)(t + (uint64_t)l);
+                            best.s1_len = plen - (rest + l); best.s1_loci = best.s0_loci + (uint64_t)rest; best.s1_ofs = rest + l;
+                        } else {
+                            best.s0_loci = (uint64_t)(uint32_t)(t - (uint64_t)l);
+                            best.s1_len = plen - rest; best.s1_loci = best.s0_loci + (uint64_t)rest + (uint64_t)l; best.s1_ofs = rest;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (del.score == 0 && ins.score == 0) return;
+    if (del.score > ins.score) { out = del; out.r = 3; }
+    else { out = ins; out.r = 2; }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list, uint32_t n_list,
+                                               int max_indel, uint32_t *__restrict__ cursor, bk_seg2 *__restrict__ seg2)
+{
+    __shared__ LdsEntries s_le;
+    lds_entries_load(s_le, ix);
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(cursor, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_list) break;
+        const uint32_t r = list[item];
+        const int len = (int)b.lens[r];
+        const ReadPlan p = make_plan(len, cfg);
+        const int core = p.core_len * 2 < (len - 1) / 2 ? p.core_len * 2 : (len - 1) / 2;
+        const int max_mm = p.max_tot_mm > kIndelMaxMM ? kIndelMaxMM : p.max_tot_mm;
+        if (core < 1) continue;
+        // best placement so far (wave-uniform)
+        int best_score = 0, best_inst = 0, b_insert = 0, b_indel = 0, b_s0_len = 0, b_s0_mm = 0, b_s1_len = 0, b_s1_mm = 0, b_s1_ofs = 0, b_strand = '+';
+        uint64_t b_s0 = 0, b_s1 = 0;
+        bool done = false;
+        const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        for (int st = s0; st <= s1 && !done; st++) {
+            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
+            for (int phase = 0; phase < 2; phase++) {
+                const int ofs = phase == 0 ? 0 : len - core;
+                uint64_t first = 0, n = 0;
+                search_core<WIDE>(ix, rdw, ofs, core, ~0ULL >> 1, first, n);       // every lane the same search
+                uint32_t iter = 0;
+                bool copies_checked = false;
+                for (uint64_t j0 = 0; j0 < n; j0 += 64) {
+                    const uint64_t j = j0 + lane;
+                    const bool active = j < n;
+                    const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
+                    const uint64_t t = loci - (uint64_t)ofs;
+                    bool valid = active && loci >= (uint64_t)ofs;
+                    int e = -1;
+                    if (valid) {
+                        e = find_entry_lds(s_le, ix, loci);                   // MapChunkHit2Entry of the ANCHOR position (:7497)
+                        valid = e >= 0 && t >= ix.ent_start[e] && t + (uint64_t)len - 1 <= ix.ent_end[e] && t + (uint64_t)len <= ix.n;
+                    }
+                    const uint64_t newmask = __ballot(valid);
+                    const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
+                    const uint32_t iter_before = iter + pre;
+                    const bool stop = active && cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter;
+                    uint64_t cutoff = n;
+                    const uint64_t stopmask = __ballot(stop);
+                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                    if (!copies_checked) {
+                        const bool chk = active && j > 0 && iter_before == 100;
+                        const uint64_t chkmask = __ballot(chk);
+                        if (chkmask) {
+                            const uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                            if (jc < cutoff) {
+                                copies_checked = true;
+                                const uint64_t num_copies = n - jc + 2;
+                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                            }
+                        }
+                    }
+                    const bool proc = valid && j < cutoff;
+                    iter += (uint32_t)__popcll(__ballot(proc));
+                    IndelPlacement pl;
+                    pl.r = 0; pl.score = 0;
+                    if (proc) {
+                        const uint32_t seq_left = (uint32_t)(ix.ent_end[e] + 1 - t);      // SeqLen - (TargOfs - StartOfs)
+                        if (phase == 0) explore_indel<true>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
+                        else explore_indel<false>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
+                    }
+                    // fold this round's placements in suffix-array order (:7517-7561)
+                    uint64_t hm = __ballot(proc && pl.r > 0);
+                    while (hm) {
+                        const int src = __ffsll((unsigned long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int sc = __shfl(pl.score, src);
+                        if (sc < best_score) continue;
+                        const uint64_t c_s0 = __shfl(pl.s0_loci, src);
+                        if (sc == best_score) {
+                            if (b_s0 == c_s0) continue;
+                            if (++best_inst > 1) continue;
+                        } else
+                            best_inst = 0;
+                        best_score = sc; b_s0 = c_s0; b_s1 = __shfl(pl.s1_loci, src);
+                        b_s0_len = __shfl(pl.s0_len, src); b_s0_mm = __shfl(pl.s0_mm, src); b_s1_len = __shfl(pl.s1_len, src);
+                        b_s1_mm = __shfl(pl.s1_mm, src); b_s1_ofs = __shfl(pl.s1_ofs, src); b_insert = __shfl(pl.is_insert, src);
+                        b_indel = __shfl(pl.r, src) > 1 ? 1 : 0;
+                        b_strand = st ? '-' : '+';
+                        best_inst++;
+                    }
+                    if (cutoff < j0 + 64) break;
+                }
+                if (best_inst >= 1 && best_score >= kIndelMaxScore) { done = true; break; }
+            }
+        }
+        if (best_inst != 1) continue;                       // none, or ambiguous
+        if (lane == 0) {
+            if (best_score > kIndelMaxScore) best_score = kIndelMaxScore;
+            const int e0 = find_entry(ix, b_s0), e1 = find_entry(ix, b_s1);
+            if (e0 >= 0 && e1 >= 0 && ix.ent_id[e0] == ix.ent_id[e1]) {
+                bk_hit h;
+                h.chrom_id = ix.ent_id[e0]; h.match_loci = (uint32_t)(b_s0 - ix.ent_start[e0]); h.match_len = (uint16_t)b_s0_len;
+                h.low_hit_instances = 1; h.rslt = BK_HR_HITS; h.nar = BK_NAR_ACCEPTED; h.strand = (uint8_t)b_strand;
+                h.low_mm = (int8_t)(b_s0_mm + b_s1_mm); h.nxt_low_mm = (int8_t)(b_s0_mm + b_s1_mm + 2); h.num_hits = 1;
+                h.mismatches = (uint8_t)b_s0_mm; h.flags = (uint8_t)(((p.n_phases) << 1) | 1);
+                b.out[r] = h;
+                bk_seg2 g;
+                g.match_loci = b_s1 > 0 ? (uint32_t)(b_s1 - ix.ent_start[e1]) : 0u; g.match_len = (uint16_t)b_s1_len; g.read_ofs = (uint16_t)b_s1_ofs;
+                g.mismatches = (uint8_t)b_s1_mm; g.flags = (uint8_t)((b_indel ? 1 : 0) | (b_insert ? 2 : 0)); g.score = (uint16_t)best_score;
+                seg2[r] = g;
+            }
+        }
+    }
+}
+
+// reads AlignReads' phases left without any result (candidates for the -a pass)
+__global__ void __launch_bounds__(256) k_unaligned_list(const bk_hit *__restrict__ out, uint32_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ cnt)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const bk_hit h = out[r];
+    if (h.nar == BK_NAR_NOHIT && h.rslt == BK_HR_NONE) list[atomicAdd(cnt, 1u)] = r;
+}
+
+void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, uint32_t *list, uint32_t *list_cnt_dev,
+                  uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_unaligned_list, dim3((n + 255) / 256), dim3(256), 0, s, b.out, n, list, list_cnt_dev);
+    (void)hipMemcpyAsync(list_cnt_host, list_cnt_dev, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    const uint32_t n_list = *list_cnt_host;
+    if (!n_list) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n_list + 3) / 4, 8192);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, cursor, seg2);
+    else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, cursor, seg2);
+}
+
 __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -206,6 +206,23 @@ typedef struct bk_loci {
  * clustering, -r5 report all; Aligner.cpp:9328-9424,5105-5272) is host policy above this boundary. */
 int  bk_batch_loci(bk_ctx *ctx, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
 
+/* ---- microInDels (-a) ---------------------------------------------------------------------- */
+/* Second segment of a read aligned with a microInDel (tsHitLoci.Seg[1] and flags, SfxArrayV2.h:219-240): the read's bk_hit holds
+ * the first segment (match_loci / match_len / mismatches of Seg[0]; low_mm = mismatches of both, nxt_low_mm = low_mm + 2 as
+ * LocateInDels returns them, SfxArrayV2.cpp:7655-7657).  12 bytes. */
+typedef struct bk_seg2 {
+    uint32_t match_loci;         /* Seg[1].MatchLoci, 0-based within the entry of Seg[0]          */
+    uint16_t match_len;          /* Seg[1].MatchLen                                               */
+    uint16_t read_ofs;           /* Seg[1].ReadOfs: first read base of the second segment        */
+    uint8_t  mismatches;         /* Seg[1].Mismatches                                             */
+    uint8_t  flags;              /* bit 0 FlgInDel, bit 1 FlgInsert (gap is in the read); 0 = the read has no second segment */
+    uint16_t score;              /* tsHitLoci.Score                                               */
+} bk_seg2;
+/* One entry per read of the LAST align call on a context created with micro_indel_len > 0 (host memory owned by the context,
+ * valid until its next align call; NULL / 0 otherwise).  Orphan removal (CAligner::RemoveOrphanMicroInDels, Aligner.cpp:2382-2470)
+ * is host policy above this boundary. */
+int  bk_batch_seg2(bk_ctx *ctx, const bk_seg2 **seg2, uint64_t *n);
+
 /* counters/timing accumulated since the last reset */
 int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);
 int  bk_get_timing(bk_ctx *ctx, bk_timing *out, int reset);

@@ -519,3 +519,29 @@ def test_best_matches_synthetic(tmp_path):
         _assert_loci_equal(bk, al, nreads, got, exp, eo, el)
     assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand)
     assert np.count_nonzero(np.diff(eo.astype(np.int64)) > 1) > 20
+
+
+@pytest.mark.parametrize("kw", [dict(max_subs=3, micro_indel_len=10), dict(max_subs=5, micro_indel_len=3), dict(max_subs=3, micro_indel_len=20, align_strand=1),
+                                dict(max_subs=3, micro_indel_len=20, align_strand=2), dict(max_subs=1, micro_indel_len=5), dict(max_subs=0, micro_indel_len=8)])
+@pytest.mark.parametrize("fixture", ["indel", "basic", "lengths"])
+def test_micro_indels_match_oracle(golden_tmp, fixture, kw):
+    """-a: result records and second segments (LocateInDels) against the oracle, which is pinned on the reference's -a output"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, eseg = helpers.oracle_align_indel(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    sfx.close()
+    for knobs in ([], [("chunk_reads", 200)], [("use_wave", 0)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs[keep], lens[keep])
+            seg = al.batch_seg2()
+        assert_hits_equal(got, exp, [names[i] for i in keep])
+        assert len(seg) == len(eseg)
+        for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score"):
+            if not np.array_equal(seg[f], eseg[f]):
+                i = int(np.nonzero(seg[f] != eseg[f])[0][0])
+                raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
+    if fixture == "indel":
+        assert np.count_nonzero(eseg["flags"] & 1) > 50 or kw["max_subs"] == 0
