@@ -499,8 +499,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtR", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRa", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -541,7 +541,13 @@ int cmd_align(int argc, char **argv, int first)
         best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
         clamp_ml = a.has("X") || best_matches;
     }
+    // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned
+    const int micro_indel = a.num("a", 0);
+    if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
+    if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
+    if (micro_indel && (ml_mode || pe_mode)) { diag("Error: microInDels '-a%d' together with '-r%d' / '-U%d' are not available in this build", micro_indel, ml_mode, pe_mode); return 1; }
     bk_align_params P = {};
+    P.micro_indel_len = micro_indel;
     P.pmode = a.num("m", 0);
     P.align_strand = a.num("Q", 0);
     P.min_edit_dist = a.num("e", 1);
@@ -594,12 +600,20 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<bk_hit> hits(nr);
     std::vector<uint64_t> l_offs;                  // multi-loci modes: read i owns loci [l_offs[i], l_offs[i+1])
     std::vector<bk_loci> loci;
+    std::vector<bk_seg2> seg2;                     // -a: second segment of each read (flags 0 = none)
     if (ml_mode) l_offs.assign(1, 0);
     const size_t kBatch = 16u << 20;
     for (size_t lo = 0; lo < nr; lo += kBatch) {
         size_t n = std::min(kBatch, nr - lo);
         rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+        if (micro_indel) {
+            const bk_seg2 *bs = nullptr;
+            uint64_t ns = 0;
+            rc = bk_batch_seg2(ctx, &bs, &ns);
+            if (rc || !bs || ns != n) { diag("Fatal: microInDel segments unavailable: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
+            seg2.insert(seg2.end(), bs, bs + ns);
+        }
         if (ml_mode) {
             const uint64_t *bo = nullptr;
             const bk_loci *bl = nullptr;
@@ -691,6 +705,40 @@ int cmd_align(int argc, char **argv, int first)
         }
     }
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
+    auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 1); };
+    if (micro_indel) {
+        // CAligner::RemoveOrphanMicroInDels (Aligner.cpp:2382-2470): a placement stands only if another read's junction lies
+        // within 3 bases of it on both sides; the others become eNARmicroInDel
+        diag("Removal of orphan microInDels processing started..");
+        struct Junct { uint32_t chrom; uint32_t starts, ends; size_t read; };
+        std::vector<Junct> jn;
+        for (size_t i = 0; i < nr; i++)
+            if (hits[i].nar == BK_NAR_ACCEPTED && (seg2[i].flags & 1))
+                jn.push_back({hits[i].chrom_id, hits[i].match_loci + hits[i].match_len - 1u, seg2[i].match_loci, i});
+        std::sort(jn.begin(), jn.end(), [](const Junct &x, const Junct &y) {
+            if (x.chrom != y.chrom) return x.chrom < y.chrom;
+            if (x.starts != y.starts) return x.starts < y.starts;
+            return x.ends < y.ends;
+        });
+        std::vector<uint8_t> supported(jn.size(), 0);
+        for (size_t k = 0; k + 1 < jn.size(); k++) {
+            const Junct &x = jn[k], &y = jn[k + 1];
+            if (x.chrom == y.chrom && x.starts <= y.starts + 3u && x.starts >= y.starts - 3u && x.ends <= y.ends + 3u &&
+                x.ends >= y.ends - 3u)                      // UINT32 arithmetic as in tsSegJuncts
+                supported[k] = supported[k + 1] = 1;
+        }
+        size_t n_orphan = 0;
+        for (size_t k = 0; k < jn.size(); k++)
+            if (!supported[k]) {
+                bk_hit &h = hits[jn[k].read];
+                h.nar = 8;                                  // eNARmicroInDel
+                h.num_hits = 0;
+                h.low_hit_instances = 0;
+                n_orphan++;
+            }
+        diag("From %zu reads with putative microIndels %zu orphans were removed", jn.size(), n_orphan);
+        diag("Removal of orphan microInDels processing completed");
+    }
     if (pe_mode) {
         // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355)
         diag("Paired end association and partner alignment processing started..");
@@ -792,7 +840,7 @@ int cmd_align(int argc, char **argv, int first)
                     auto &Q = qi[(size_t)w], &S = sb[(size_t)w], &M = ms[(size_t)w];
                     for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
                         const bk_hit &h = hits[i];
-                        if (h.nar != BK_NAR_ACCEPTED || h.chrom_id < 1 || h.chrom_id > n_ent) continue;
+                        if (h.nar != BK_NAR_ACCEPTED || h.chrom_id < 1 || h.chrom_id > n_ent || has_seg2(i)) continue;     // FlagSegs reads are sloughed (:6286)
                         const uint8_t *rd = rs.bases.data() + rs.offs[RD(i)];
                         const uint32_t len = rs.lens[RD(i)];
                         const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
@@ -924,7 +972,10 @@ int cmd_align(int argc, char **argv, int first)
                 const uint32_t l_qn = (uint32_t)strlen(qn) + 1;
                 const char *tag = acc ? nullptr : kNarTag[h.nar < 20 ? h.nar : 0];
                 const uint32_t aux = tag ? 3 + (uint32_t)strlen(tag) + 1 : 0;
-                const uint32_t block = 32 + l_qn + 4 + (len + 1) / 2 + len + aux;
+                const bool two = acc && has_seg2(i);
+                const uint32_t n_cig = two ? 3u : 1u;
+                const uint32_t hit_len = acc ? (uint32_t)h.match_len + (two ? seg2[RD(i)].match_len : 0u) : 0u;      // AdjAlignHitLen
+                const uint32_t block = 32 + l_qn + 4 * n_cig + (len + 1) / 2 + len + aux;
                 const size_t at = v.size();
                 v.resize(at + 4 + block);
                 uint8_t *q = v.data() + at;
@@ -933,15 +984,21 @@ int cmd_align(int argc, char **argv, int first)
                 const int32_t ref = acc ? ref_of[h.chrom_id] : -1;
                 w32((uint32_t)ref);
                 w32(acc ? h.match_loci : 0xFFFFFFFFu);
-                const uint32_t bin = acc ? (uint32_t)bk::bam_reg2bin((int)h.match_loci, (int)(h.match_loci + h.match_len)) : 0u;
+                const uint32_t bin = acc ? (uint32_t)bk::bam_reg2bin((int)h.match_loci, (int)(h.match_loci + hit_len)) : 0u;
                 w32(bin << 16 | 255u << 8 | l_qn);
-                w32((uint32_t)flag << 16 | 1u);
+                w32((uint32_t)flag << 16 | n_cig);
                 w32(len);
                 w32(acc && pnext >= 0 ? (uint32_t)ref : 0xFFFFFFFFu);
                 w32(acc ? (uint32_t)pnext : 0xFFFFFFFFu);
                 w32((uint32_t)tlen);
                 memcpy(q, qn, l_qn); q += l_qn;
                 w32((acc ? (uint32_t)h.match_len : len) << 4);
+                if (two) {
+                    const bk_seg2 &g = seg2[RD(i)];
+                    if (g.flags & 2) w32((uint32_t)((long)len - ((long)h.match_len + g.match_len)) << 4 | 1u);
+                    else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); w32((uint32_t)(gap < 0 ? -gap : gap) << 4 | 2u); }
+                    w32((uint32_t)g.match_len << 4);
+                }
                 uint8_t byte = 0;
                 for (uint32_t o = 0; o < len; o++) {
                     uint8_t c4 = (acc && h.strand != '+') ? comp4[sq[len - 1 - o] & 7] : code4[sq[o] & 7];
@@ -951,7 +1008,7 @@ int cmd_align(int argc, char **argv, int first)
                 }
                 memset(q, 0xff, len); q += len;
                 if (tag) { *q++ = 'Y'; *q++ = 'U'; *q++ = 'Z'; size_t tl = strlen(tag) + 1; memcpy(q, tag, tl); q += tl; }
-                if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)h.match_loci, (int32_t)(h.match_loci + h.match_len - 1)});
+                if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)h.match_loci, (int32_t)(h.match_loci + hit_len - 1)});
                 S.n++;
             }
         };
@@ -1052,7 +1109,15 @@ int cmd_align(int argc, char **argv, int first)
                 put_num(rec, (long)h.match_loci + 1);
                 rec += "\t255\t";
                 put_num(rec, h.match_len);
-                rec += "M\t";
+                rec += "M";
+                if (has_seg2(i)) {                                       // CAligner::ReportBAMread, Aligner.cpp:5986-6033
+                    const bk_seg2 &g = seg2[RD(i)];
+                    if (g.flags & 2) { put_num(rec, (long)len - ((long)h.match_len + g.match_len)); rec.push_back('I'); }
+                    else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); put_num(rec, gap < 0 ? -gap : gap); rec.push_back('D'); }
+                    put_num(rec, g.match_len);
+                    rec.push_back('M');
+                }
+                rec.push_back('\t');
                 rec.push_back(pnext < 0 ? '*' : '=');
                 rec.push_back('\t');
                 put_num(rec, pnext < 0 ? 0L : pnext + 1);
@@ -1137,43 +1202,66 @@ int cmd_align(int argc, char **argv, int first)
             out.put(line, (size_t)m);
             if (ml_mode == 5) out.put(line, (size_t)m);      // written at file creation AND by WriteReadHits (Aligner.cpp:4405-4413,6356-6362)
         }
+        // -a with -M4: reads aligned with a microInDel go to "<out>.ind" as 12-column BED lines (Aligner.cpp:4417-4438,6372-6376,6519-6526)
+        OutBuf ind;
+        if (fmt == 4 && micro_indel) {
+            ind.open((a.str("o") + ".ind").c_str());
+            if (ind.fd < 0) { diag("Fatal: unable to create '%s.ind'", a.str("o").c_str()); bk_ctx_destroy(ctx); return 1; }
+            std::string title = a.str("t", "kanga");
+            int m = snprintf(line, sizeof(line), "track type=bed name=\"IND_%s\" description=\"%s\"\n", title.c_str(), title.c_str());
+            ind.put(line, (size_t)m);
+        }
         std::string rec;
         for (size_t k = 0; k < nr; k++) {
             uint32_t i = order[k];
             const bk_hit &h = hits[i];
             if (h.nar != BK_NAR_ACCEPTED) continue;
+            const bool two = has_seg2(i);
             if (fmt == 4) {
-                int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len,
-                                 (char)h.strand);
-                out.put(line, (size_t)m);
+                if (two) {
+                    const bk_seg2 &g = seg2[RD(i)];
+                    const uint32_t end1 = g.match_loci + g.match_len;          // AdjAlignEndLoci + 1
+                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tari\t0\t%c\t%u\t%u\t0\t2\t%u,%u\t0,%u\n", ents[h.chrom_id - 1].name, h.match_loci, end1,
+                                     (char)h.strand, h.match_loci, end1, (unsigned)h.match_len, (unsigned)g.match_len, g.match_loci - h.match_loci);
+                    ind.put(line, (size_t)m);
+                } else {
+                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len,
+                                     (char)h.strand);
+                    out.put(line, (size_t)m);
+                }
                 n_reported++;
                 continue;
             }
-            int m = snprintf(line, sizeof(line), "%u,\"ar\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, species.c_str(),
-                             ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len - 1, (unsigned)h.match_len, (char)h.strand,
-                             (unsigned)h.mismatches, rs.name(RD(i)));
-            rec.assign(line, (size_t)m);
+            // one line per segment (WriteReadHits, Aligner.cpp:6566-6627)
             const uint32_t len = rs.lens[RD(i)];
-            if (fmt >= 2) {                                              // the read as loaded
-                const uint8_t *sq = rs.bases.data() + rs.offs[RD(i)];
-                rec += ",\"";
-                for (uint32_t q = 0; q < len; q++) rec.push_back(up[sq[q] & 7]);
-                rec.push_back('"');
-            }
-            if (fmt == 1 || fmt == 3) {                                  // the target it matched, in read orientation
-                const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
-                rec += ",\"";
-                for (uint32_t q = 0; q < len; q++) {
-                    uint8_t t = h.strand == '-' ? tg[len - 1 - q] & 7 : tg[q] & 7;
-                    if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
-                    rec.push_back(up[t]);
+            for (int sg = 0; sg < (two ? 2 : 1); sg++) {
+                const uint32_t s_loci = sg ? seg2[RD(i)].match_loci : h.match_loci, s_len = sg ? seg2[RD(i)].match_len : h.match_len;
+                const uint32_t s_mm = sg ? seg2[RD(i)].mismatches : h.mismatches, s_rofs = sg ? seg2[RD(i)].read_ofs : 0u;
+                int m = snprintf(line, sizeof(line), "%u,\"%s\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, two ? "ari" : "ar", species.c_str(),
+                                 ents[h.chrom_id - 1].name, s_loci, s_loci + s_len - 1, (unsigned)s_len, (char)h.strand, (unsigned)s_mm, rs.name(RD(i)));
+                rec.assign(line, (size_t)m);
+                if (fmt >= 2) {                                          // the read as loaded, from the segment's read offset
+                    const uint8_t *sq = rs.bases.data() + rs.offs[RD(i)];
+                    rec += ",\"";
+                    for (uint32_t q = 0; q < s_len && s_rofs + q < len; q++) rec.push_back(up[sq[s_rofs + q] & 7]);
+                    rec.push_back('"');
                 }
-                rec.push_back('"');
+                if (fmt == 1 || fmt == 3) {                              // the target it matched, in read orientation
+                    const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + s_loci;
+                    rec += ",\"";
+                    for (uint32_t q = 0; q < s_len; q++) {
+                        uint8_t t = h.strand == '-' ? tg[s_len - 1 - q] & 7 : tg[q] & 7;
+                        if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
+                        rec.push_back(up[t]);
+                    }
+                    rec.push_back('"');
+                }
+                rec.push_back('\n');
+                out.put(rec);
             }
-            rec.push_back('\n');
-            out.put(rec);
             n_reported++;
         }
+        if (ind.fd >= 0) ind.close();
     }
     out.close();
     diag("Reporting of aligned result set completed");

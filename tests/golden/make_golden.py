@@ -756,6 +756,10 @@ def make_indel(tmp):
             if fmt == "-M4":
                 gz_copy(out + ".ind", os.path.join(outdir, f"{tag}.{ext}.ind.gz"))
             print("  ran", tag, fmt, flags)
+    bam = os.path.join(tmp, "a10.m6.bam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", bam, "-M6", "-T4", "-a10", "-s3"], tmp)
+    shutil.copyfile(bam, os.path.join(outdir, "a10.m6.bam"))
+    shutil.copyfile(bam + ".bai", os.path.join(outdir, "a10.m6.bam.bai"))
 
 
 def main():

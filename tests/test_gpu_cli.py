@@ -235,3 +235,34 @@ def test_multi_loci_option_checks(golden_tmp, tmp_path):
         r = subprocess.run([BIN, "align", "-i", reads, "-I", sfx, "-o", str(tmp_path / "x.sam")] + bad, cwd=str(tmp_path),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode != 0, bad
+
+
+# microInDels (-a): files of tests/golden/indel (make_golden.py:make_indel)
+INDEL_CASES = [("a10", ["-a10", "-s3"], ["m6.sam", "m5.sam", "m0.csv", "m3.csv", "m4.bed"]), ("a3s5", ["-a3", "-s5"], ["m6.sam", "m0.csv"]),
+               ("a20Q1", ["-a20", "-s3", "-Q1"], ["m6.sam", "m0.csv"])]
+
+
+@pytest.mark.parametrize("tag,flags,exts", INDEL_CASES)
+def test_micro_indel_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
+    d = golden_tmp["indel"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    fmt = dict(FMT_FLAG, **{"m3.csv": "-M3"})
+    for ext in exts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, fmt[ext]] + flags, str(tmp_path))
+        pairs = [(out, f"{tag}.{ext}.gz")] + ([(out + ".ind", f"{tag}.{ext}.ind.gz")] if ext == "m4.bed" else [])
+        for path, gold in pairs:
+            got, exp = open(path, "rb").read(), golden_bytes("indel", gold)
+            if got != exp:
+                g, e = got.split(b"\n"), exp.split(b"\n")
+                k = next((i for i in range(min(len(g), len(e))) if g[i] != e[i]), min(len(g), len(e)))
+                raise AssertionError(f"{gold}: {len(g)} vs {len(e)} lines, first difference at line {k}:\n{g[k:k+1]}\n{e[k:k+1]}")
+
+
+def test_micro_indel_bam_byte_identical(golden_tmp, tmp_path):
+    d = golden_tmp["indel"]
+    out = str(tmp_path / "o.bam")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-a10", "-s3"], str(tmp_path))
+    gold = os.path.join(helpers.GOLDEN, "indel", "a10.m6.bam")
+    assert open(out, "rb").read() == open(gold, "rb").read()
+    assert open(out + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
