@@ -499,8 +499,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRa", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRax", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -546,6 +546,10 @@ int cmd_align(int argc, char **argv, int first)
     if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
     if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
     if (micro_indel && (ml_mode || pe_mode)) { diag("Error: microInDels '-a%d' together with '-r%d' / '-U%d' are not available in this build", micro_indel, ml_mode, pe_mode); return 1; }
+    // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
+    const int min_flank = a.num("x", 0);
+    if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
+    if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
     bk_align_params P = {};
     P.micro_indel_len = micro_indel;
     P.pmode = a.num("m", 0);
@@ -706,6 +710,74 @@ int cmd_align(int argc, char **argv, int first)
     }
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 1); };
+    // per-record flank trims in READ orientation (tsSegLoci.TrimLeft / TrimRight / TrimMismatches of Seg[0])
+    std::vector<uint16_t> trim_l, trim_r;
+    std::vector<uint8_t> trim_mm;
+    auto TL = [&](size_t i) -> uint32_t { return trim_l.empty() ? 0u : trim_l[i]; };
+    auto TR = [&](size_t i) -> uint32_t { return trim_r.empty() ? 0u : trim_r[i]; };
+    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
+    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
+    auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return trim_mm.empty() ? h.mismatches : trim_mm[i]; };               // TrimMismatches
+    if (min_flank > 0) {
+        // CAligner::AutoTrimFlanks (Aligner.cpp:1608-1800): from each end of the read walk inwards until min_flank consecutive
+        // bases match the target; what lies outside is trimmed.  SE: a read that cannot keep half its length (>= 15) between two
+        // such runs becomes eNARTrim; PE: the walks stop after a third of the read and nothing is eliminated.
+        diag("Starting 5' and 3' flank sequence autotrim processing...");
+        bk::SfxFile sft;
+        std::string serr;
+        if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        trim_l.assign(nr, 0); trim_r.assign(nr, 0); trim_mm.resize(nr);
+        for (size_t i = 0; i < nr; i++) trim_mm[i] = hits[i].mismatches;
+        std::vector<size_t> plus((size_t)nthreads, 0), minus((size_t)nthreads, 0);
+        auto work = [&](int w) {
+            std::vector<uint8_t> tg;
+            for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
+                bk_hit &h = hits[i];
+                if (h.nar != BK_NAR_ACCEPTED || has_seg2(i) || h.chrom_id < 1 || h.chrom_id > n_ent) continue;
+                const uint32_t mlen = h.match_len;
+                int min_trimmed = (int)(mlen + 1) / 2;
+                if (min_trimmed < 15) min_trimmed = 15;
+                const uint8_t *rd = rs.bases.data() + rs.offs[RD(i)];
+                const uint8_t *t0 = sft.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
+                tg.resize(mlen);
+                for (uint32_t k = 0; k < mlen; k++) {                          // target in read orientation
+                    uint8_t t = h.strand == '-' ? t0[mlen - 1 - k] & 7 : t0[k] & 7;
+                    if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
+                    tg[k] = t;
+                }
+                int exact = 0, tmm = 0;
+                const int core_l = pe_mode ? (int)mlen / 3 : (int)mlen;
+                uint32_t idx;
+                for (idx = 0; idx <= mlen - (uint32_t)min_trimmed && idx < (uint32_t)core_l; idx++) {
+                    if ((rd[idx] & 7) != tg[idx]) { exact = 0; tmm++; continue; }
+                    if (++exact == min_flank) break;
+                }
+                auto eliminate = [&]() { h.num_hits = 0; h.nar = 6; (h.strand == '+' ? plus : minus)[(size_t)w]++; };      // eNARTrim
+                if (!pe_mode && ((idx + (uint32_t)min_trimmed) > mlen || exact < min_flank)) { eliminate(); continue; }
+                const int left = (int)idx - (min_flank - 1);
+                exact = 0;
+                const int core_r = pe_mode ? (int)(mlen * 2) / 3 : 0;
+                for (idx = mlen - 1; idx >= (uint32_t)(left + min_trimmed) && idx > (uint32_t)core_r; idx--) {
+                    if ((rd[idx] & 7) != tg[idx]) { exact = 0; tmm++; continue; }
+                    if (++exact == min_flank) break;
+                }
+                if (!pe_mode && (exact != min_flank || idx < (uint32_t)(left + min_trimmed))) { eliminate(); continue; }
+                const int right = (int)idx + min_flank;
+                trim_l[i] = (uint16_t)left;
+                trim_r[i] = (uint16_t)(mlen - (uint32_t)right);
+                if (left || (mlen - (uint32_t)right)) trim_mm[i] = (uint8_t)(h.mismatches - tmm);
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int w = 1; w < nthreads; w++) th.emplace_back(work, w);
+            work(0);
+            for (auto &t : th) t.join();
+        }
+        size_t np = 0, nm = 0;
+        for (int w = 0; w < nthreads; w++) { np += plus[(size_t)w]; nm += minus[(size_t)w]; }
+        diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", np, nm);
+    }
     if (micro_indel) {
         // CAligner::RemoveOrphanMicroInDels (Aligner.cpp:2382-2470): a placement stands only if another read's junction lies
         // within 3 bases of it on both sides; the others become eNARmicroInDel
@@ -767,15 +839,16 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<uint32_t> order(nr);
     for (size_t i = 0; i < nr; i++) order[i] = (uint32_t)i;
     const bk_hit *H = hits.data();
-    auto cmp = [H](uint32_t x, uint32_t y) -> int {                      // CAligner::SortHitMatch, Aligner.cpp:10069-10114
+    auto cmp = [&, H](uint32_t x, uint32_t y) -> int {                   // CAligner::SortHitMatch, Aligner.cpp:10069-10114
         const bk_hit &p = H[x], &q = H[y];
         if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
         if (p.num_hits == 1 && q.num_hits != 1) return -1;
         if (p.num_hits != 1 && q.num_hits == 1) return 1;
         if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
         if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
-        if (p.match_loci != q.match_loci) return p.match_loci < q.match_loci ? -1 : 1;
-        if (p.match_len != q.match_len) return p.match_len < q.match_len ? -1 : 1;
+        const uint32_t ps = a_start(p, x), qs = a_start(q, y), pl = a_len(p, x), ql = a_len(q, y);
+        if (ps != qs) return ps < qs ? -1 : 1;
+        if (pl != ql) return pl < ql ? -1 : 1;
         if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
         if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
         return 0;
@@ -843,13 +916,14 @@ int cmd_align(int argc, char **argv, int first)
                         if (h.nar != BK_NAR_ACCEPTED || h.chrom_id < 1 || h.chrom_id > n_ent || has_seg2(i)) continue;     // FlagSegs reads are sloughed (:6286)
                         const uint8_t *rd = rs.bases.data() + rs.offs[RD(i)];
                         const uint32_t len = rs.lens[RD(i)];
-                        const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
+                        const uint8_t *tg = sf.seq + ents[h.chrom_id - 1].start_ofs + a_start(h, i);
+                        const uint32_t alen = a_len(h, i), tl0 = TL(i);
                         uint32_t nsub = 0;
-                        for (uint32_t k = 0; k < len; k++) {
-                            uint8_t t = h.strand == '-' ? tg[len - 1 - k] & 7 : tg[k] & 7;
+                        for (uint32_t k = 0; k < alen && tl0 + k < len; k++) {      // read positions TrimLeft .. ReadLen - TrimRight (:6303-6306)
+                            uint8_t t = h.strand == '-' ? tg[alen - 1 - k] & 7 : tg[k] & 7;
                             if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
-                            Q[k]++;
-                            if ((rd[k] & 7) != t) { S[k]++; nsub++; }
+                            Q[tl0 + k]++;
+                            if ((rd[tl0 + k] & 7) != t) { S[tl0 + k]++; nsub++; }
                         }
                         M[nsub < max_len ? nsub : max_len - 1]++;
                     }
@@ -961,9 +1035,10 @@ int cmd_align(int argc, char **argv, int first)
                     if ((h.flags & 0x80) && (m.flags & 0x80) && m.nar == BK_NAR_ACCEPTED) {
                         flag |= m.strand == '+' ? 0 : 0x20;
                         if (acc) {
-                            pnext = (long)m.match_loci;
-                            long s0 = (long)h.match_loci, s1 = (long)m.match_loci;
-                            tlen = (int)(s0 <= s1 ? (s1 - s0) + m.match_len : (s0 - s1) + h.match_len);
+                            const size_t mi = first_of_pair ? i + 1 : i - 1;
+                            pnext = (long)a_start(m, mi);
+                            long s0 = (long)a_start(h, i), s1 = (long)a_start(m, mi);
+                            tlen = (int)(s0 <= s1 ? (s1 - s0) + (long)a_len(m, mi) : (s0 - s1) + (long)a_len(h, i));
                         }
                     } else
                         flag |= 0x8;
@@ -973,8 +1048,11 @@ int cmd_align(int argc, char **argv, int first)
                 const char *tag = acc ? nullptr : kNarTag[h.nar < 20 ? h.nar : 0];
                 const uint32_t aux = tag ? 3 + (uint32_t)strlen(tag) + 1 : 0;
                 const bool two = acc && has_seg2(i);
-                const uint32_t n_cig = two ? 3u : 1u;
-                const uint32_t hit_len = acc ? (uint32_t)h.match_len + (two ? seg2[RD(i)].match_len : 0u) : 0u;      // AdjAlignHitLen
+                // soft clips in target order: read orientation for '+', swapped for '-' (Aligner.cpp:5961-5984)
+                const uint32_t clip5 = acc ? (h.strand == '+' ? TL(i) : TR(i)) : 0u, clip3 = acc ? (h.strand == '+' ? TR(i) : TL(i)) : 0u;
+                const uint32_t n_cig = (two ? 3u : 1u) + (clip5 ? 1u : 0u) + (clip3 ? 1u : 0u);
+                const uint32_t pos0 = acc ? a_start(h, i) : 0u;
+                const uint32_t hit_len = acc ? a_len(h, i) + (two ? seg2[RD(i)].match_len : 0u) : 0u;      // AdjAlignHitLen
                 const uint32_t block = 32 + l_qn + 4 * n_cig + (len + 1) / 2 + len + aux;
                 const size_t at = v.size();
                 v.resize(at + 4 + block);
@@ -983,8 +1061,8 @@ int cmd_align(int argc, char **argv, int first)
                 w32(block);
                 const int32_t ref = acc ? ref_of[h.chrom_id] : -1;
                 w32((uint32_t)ref);
-                w32(acc ? h.match_loci : 0xFFFFFFFFu);
-                const uint32_t bin = acc ? (uint32_t)bk::bam_reg2bin((int)h.match_loci, (int)(h.match_loci + hit_len)) : 0u;
+                w32(acc ? pos0 : 0xFFFFFFFFu);
+                const uint32_t bin = acc ? (uint32_t)bk::bam_reg2bin((int)pos0, (int)(pos0 + hit_len)) : 0u;
                 w32(bin << 16 | 255u << 8 | l_qn);
                 w32((uint32_t)flag << 16 | n_cig);
                 w32(len);
@@ -992,7 +1070,9 @@ int cmd_align(int argc, char **argv, int first)
                 w32(acc ? (uint32_t)pnext : 0xFFFFFFFFu);
                 w32((uint32_t)tlen);
                 memcpy(q, qn, l_qn); q += l_qn;
-                w32((acc ? (uint32_t)h.match_len : len) << 4);
+                if (clip5) w32(clip5 << 4 | 4u);
+                w32((acc ? a_len(h, i) : len) << 4);
+                if (clip3) w32(clip3 << 4 | 4u);
                 if (two) {
                     const bk_seg2 &g = seg2[RD(i)];
                     if (g.flags & 2) w32((uint32_t)((long)len - ((long)h.match_len + g.match_len)) << 4 | 1u);
@@ -1008,7 +1088,7 @@ int cmd_align(int argc, char **argv, int first)
                 }
                 memset(q, 0xff, len); q += len;
                 if (tag) { *q++ = 'Y'; *q++ = 'U'; *q++ = 'Z'; size_t tl = strlen(tag) + 1; memcpy(q, tag, tl); q += tl; }
-                if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)h.match_loci, (int32_t)(h.match_loci + hit_len - 1)});
+                if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)pos0, (int32_t)(pos0 + hit_len - 1)});
                 S.n++;
             }
         };
@@ -1093,9 +1173,10 @@ int cmd_align(int argc, char **argv, int first)
                 if ((h.flags & 0x80) && (m.flags & 0x80) && m.nar == BK_NAR_ACCEPTED) {
                     flag |= m.strand == '+' ? 0 : 0x20;
                     if (acc) {
-                        pnext = (long)m.match_loci;
-                        long s0 = (long)h.match_loci, s1 = (long)m.match_loci;
-                        tlen = (int)(s0 <= s1 ? (s1 - s0) + m.match_len : (s0 - s1) + h.match_len);
+                        const size_t mi = first_of_pair ? i + 1 : i - 1;
+                        pnext = (long)a_start(m, mi);
+                        long s0 = (long)a_start(h, i), s1 = (long)a_start(m, mi);
+                        tlen = (int)(s0 <= s1 ? (s1 - s0) + (long)a_len(m, mi) : (s0 - s1) + (long)a_len(h, i));
                     }
                 } else
                     flag |= 0x8;
@@ -1106,10 +1187,13 @@ int cmd_align(int argc, char **argv, int first)
                 rec.push_back('\t');
                 rec += ents[h.chrom_id - 1].name;
                 rec.push_back('\t');
-                put_num(rec, (long)h.match_loci + 1);
+                put_num(rec, (long)a_start(h, i) + 1);
                 rec += "\t255\t";
-                put_num(rec, h.match_len);
+                const uint32_t clip5 = h.strand == '+' ? TL(i) : TR(i), clip3 = h.strand == '+' ? TR(i) : TL(i);
+                if (clip5) { put_num(rec, clip5); rec.push_back('S'); }
+                put_num(rec, a_len(h, i));
                 rec += "M";
+                if (clip3) { put_num(rec, clip3); rec.push_back('S'); }
                 if (has_seg2(i)) {                                       // CAligner::ReportBAMread, Aligner.cpp:5986-6033
                     const bk_seg2 &g = seg2[RD(i)];
                     if (g.flags & 2) { put_num(rec, (long)len - ((long)h.match_len + g.match_len)); rec.push_back('I'); }
@@ -1225,7 +1309,7 @@ int cmd_align(int argc, char **argv, int first)
                                      (char)h.strand, h.match_loci, end1, (unsigned)h.match_len, (unsigned)g.match_len, g.match_loci - h.match_loci);
                     ind.put(line, (size_t)m);
                 } else {
-                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, h.match_loci, h.match_loci + h.match_len,
+                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, a_start(h, i), a_start(h, i) + a_len(h, i),
                                      (char)h.strand);
                     out.put(line, (size_t)m);
                 }
@@ -1235,8 +1319,8 @@ int cmd_align(int argc, char **argv, int first)
             // one line per segment (WriteReadHits, Aligner.cpp:6566-6627)
             const uint32_t len = rs.lens[RD(i)];
             for (int sg = 0; sg < (two ? 2 : 1); sg++) {
-                const uint32_t s_loci = sg ? seg2[RD(i)].match_loci : h.match_loci, s_len = sg ? seg2[RD(i)].match_len : h.match_len;
-                const uint32_t s_mm = sg ? seg2[RD(i)].mismatches : h.mismatches, s_rofs = sg ? seg2[RD(i)].read_ofs : 0u;
+                const uint32_t s_loci = sg ? seg2[RD(i)].match_loci : a_start(h, i), s_len = sg ? seg2[RD(i)].match_len : a_len(h, i);
+                const uint32_t s_mm = sg ? seg2[RD(i)].mismatches : a_mm(h, i), s_rofs = sg ? seg2[RD(i)].read_ofs : TL(i);       // ReadOfs + TrimLeft
                 int m = snprintf(line, sizeof(line), "%u,\"%s\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, two ? "ari" : "ar", species.c_str(),
                                  ents[h.chrom_id - 1].name, s_loci, s_loci + s_len - 1, (unsigned)s_len, (char)h.strand, (unsigned)s_mm, rs.name(RD(i)));
                 rec.assign(line, (size_t)m);

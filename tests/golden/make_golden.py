@@ -762,12 +762,54 @@ def make_indel(tmp):
     shutil.copyfile(bam + ".bai", os.path.join(outdir, "a10.m6.bam.bai"))
 
 
+def make_trim(tmp):
+    """-x (AutoTrimFlanks): the basic reads with -x5 -s3 and -x6 -s10 in every output kind, the pe fixture with -U3 -x4,
+    the indel fixture with -a10 -x4 (segmented reads are left alone by the trimmer)"""
+    basic, pe, indel = os.path.join(HERE, "basic"), os.path.join(HERE, "pe"), os.path.join(HERE, "indel")
+    def unz(src, dst):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    sfx, rd = os.path.join(tmp, "tr.sfx"), os.path.join(tmp, "tr_reads.fa")
+    unz(os.path.join(basic, "genome.sfx.gz"), sfx)
+    unz(os.path.join(basic, "reads.fa.gz"), rd)
+    for tag, flags, fmts in (("s3x5", ["-s3", "-x5"], ["-M6", "-M5", "-M0", "-M3", "-M4"]), ("s10x6", ["-s10", "-x6"], ["-M6", "-M0"])):
+        for fmt in fmts:
+            ext = {"-M6": "m6.sam", "-M5": "m5.sam", "-M0": "m0.csv", "-M3": "m3.csv", "-M4": "m4.bed"}[fmt]
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            extra = ["-O", os.path.join(tmp, "st.csv")] if (tag == "s3x5" and fmt == "-M5") else []
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-T4"] + flags + extra, tmp)
+            gz_copy(out, os.path.join(basic, f"{tag}.{ext}.gz"))
+            if extra:
+                gz_copy(extra[1], os.path.join(basic, f"{tag}.m5.stats.csv.gz"))
+    bam = os.path.join(tmp, "s3x5.m6.bam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", bam, "-M6", "-T4", "-s3", "-x5"], tmp)
+    shutil.copyfile(bam, os.path.join(basic, "s3x5.m6.bam"))
+    shutil.copyfile(bam + ".bai", os.path.join(basic, "s3x5.m6.bam.bai"))
+    r1, r2 = os.path.join(tmp, "tr_r1.fa"), os.path.join(tmp, "tr_r2.fa")
+    unz(os.path.join(pe, "reads_1.fa.gz"), r1)
+    unz(os.path.join(pe, "reads_2.fa.gz"), r2)
+    out = os.path.join(tmp, "U3x4.sam")
+    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", out, "-M6", "-T4", "-U3", "-d200", "-D400", "-s5", "-x4"], tmp)
+    gz_copy(out, os.path.join(pe, "U3x4.m6.sam.gz"))
+    isfx, ird = os.path.join(tmp, "tri.sfx"), os.path.join(tmp, "tri_reads.fa")
+    unz(os.path.join(indel, "genome.sfx.gz"), isfx)
+    unz(os.path.join(indel, "reads.fa.gz"), ird)
+    for fmt, ext in (("-M6", "m6.sam"), ("-M0", "m0.csv")):
+        out = os.path.join(tmp, f"a10x4.{ext}")
+        run([REF, "align", "-i", ird, "-I", isfx, "-o", out, fmt, "-T4", "-a10", "-s3", "-x4"], tmp)
+        gz_copy(out, os.path.join(indel, f"a10x4.{ext}.gz"))
+    print("  trim fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-trim" in sys.argv:
+            make_trim(tmp)
             return
         if "--only-indel" in sys.argv:
             make_indel(tmp)
@@ -808,6 +850,7 @@ def main():
         make_multi(tmp)
         make_multi_best(tmp)
         make_indel(tmp)
+        make_trim(tmp)
     print("done")
 
 

@@ -266,3 +266,47 @@ def test_micro_indel_bam_byte_identical(golden_tmp, tmp_path):
     gold = os.path.join(helpers.GOLDEN, "indel", "a10.m6.bam")
     assert open(out, "rb").read() == open(gold, "rb").read()
     assert open(out + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
+
+
+# -x (AutoTrimFlanks): soft clips in SAM / BAM, trimmed loci in CSV / BED, -O statistics over the kept part
+def _cmp_bytes(path, fixture, gold):
+    got, exp = open(path, "rb").read(), golden_bytes(fixture, gold)
+    if got != exp:
+        g, e = got.split(b"\n"), exp.split(b"\n")
+        k = next((i for i in range(min(len(g), len(e))) if g[i] != e[i]), min(len(g), len(e)))
+        raise AssertionError(f"{gold}: {len(g)} vs {len(e)} lines, first difference at line {k}:\n{g[k:k+1]}\n{e[k:k+1]}")
+
+
+@pytest.mark.parametrize("tag,flags,exts", [("s3x5", ["-s3", "-x5"], ["m6.sam", "m5.sam", "m0.csv", "m3.csv", "m4.bed"]), ("s10x6", ["-s10", "-x6"], ["m6.sam", "m0.csv"])])
+def test_flank_trim_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
+    d = golden_tmp["basic"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    fmt = dict(FMT_FLAG, **{"m3.csv": "-M3"})
+    for ext in exts:
+        out = str(tmp_path / f"o.{ext}")
+        extra = ["-O", str(tmp_path / "st.csv")] if (tag == "s3x5" and ext == "m5.sam") else []
+        run(["align", "-i", reads, "-I", sfx, "-o", out, fmt[ext]] + flags + extra, str(tmp_path))
+        _cmp_bytes(out, "basic", f"{tag}.{ext}.gz")
+        if extra:
+            _cmp_bytes(extra[1], "basic", f"{tag}.m5.stats.csv.gz")
+    if tag == "s3x5":
+        out = str(tmp_path / "o.bam")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, "-M6"] + flags, str(tmp_path))
+        gold = os.path.join(helpers.GOLDEN, "basic", "s3x5.m6.bam")
+        assert open(out, "rb").read() == open(gold, "rb").read()
+        assert open(out + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
+
+
+def test_flank_trim_pe_and_indel(golden_tmp, tmp_path):
+    d = golden_tmp["basic"]
+    r1, r2 = str(tmp_path / "r1.fa"), str(tmp_path / "r2.fa")
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_1.fa.gz"), r1)
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_2.fa.gz"), r2)
+    out = str(tmp_path / "pe.sam")
+    run(["align", "-i", r1, "-u", r2, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-U3", "-d200", "-D400", "-s5", "-x4"], str(tmp_path))
+    _cmp_bytes(out, "pe", "U3x4.m6.sam.gz")
+    di = golden_tmp["indel"]
+    for ext, m in (("m6.sam", "-M6"), ("m0.csv", "-M0")):
+        out = str(tmp_path / f"i.{ext}")
+        run(["align", "-i", os.path.join(di, "reads.fa"), "-I", os.path.join(di, "genome.sfx"), "-o", out, m, "-a10", "-s3", "-x4"], str(tmp_path))
+        _cmp_bytes(out, "indel", f"a10x4.{ext}.gz")
