@@ -59,7 +59,9 @@ typedef struct bk_align_params {
                              *     then discovery; bk_hit.rslt is eHRhits / eHRnone, LowMMCnt and NxtLowMMCnt stay 0          */
     int32_t micro_indel_len;/* -a  0, or the longest microInDel (1..20) looked for in reads the AlignReads phases leave unaligned
                              *     (CSfxArrayV3::LocateInDels); second segments come back through bk_batch_seg2()             */
-    int32_t reserved2[3];
+    int32_t splice_junct_len;/* -A  0, or the longest splice junction (25..100000) looked for in reads still unaligned after that
+                             *     (CSfxArrayV3::LocateSpliceJuncts); second segments through bk_batch_seg2(), flags bit 2      */
+    int32_t reserved2[2];
 } bk_align_params;
 
 /* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and
@@ -215,7 +217,7 @@ typedef struct bk_seg2 {
     uint16_t match_len;          /* Seg[1].MatchLen                                               */
     uint16_t read_ofs;           /* Seg[1].ReadOfs: first read base of the second segment        */
     uint8_t  mismatches;         /* Seg[1].Mismatches                                             */
-    uint8_t  flags;              /* bit 0 FlgInDel, bit 1 FlgInsert (gap is in the read); 0 = the read has no second segment */
+    uint8_t  flags;              /* bit 0 FlgInDel, bit 1 FlgInsert (gap is in the read), bit 2 FlgSplice; 0 = no second segment */
     uint16_t score;              /* tsHitLoci.Score                                               */
 } bk_seg2;
 /* One entry per read of the LAST align call on a context created with micro_indel_len > 0 (host memory owned by the context,

@@ -808,11 +808,288 @@ static int locate_indels(const ora_sfx *s, int max_len, int max_tot_mm, int core
     return best_instances <= max_hits ? HR_HITS : HR_NONE;
 }
 
+/* ---- splice junctions (`-A`): LocateSpliceJuncts SfxArrayV2.cpp:7022-7345, ExploreSpliceRight :8437-8685,
+ * ExploreSpliceLeft :8688-8940.  Restated as written, quirks included: the mismatch budget test of the segment compare is
+ * strict (`<`), the rolling base-sum filter, the 35 bases probed for an EOS first.  One deliberate difference: with a
+ * mismatch budget of 0 (-s0) the reference indexes its offset table at -1 (ExploreSpliceRight :8521); here such a call
+ * reports nothing. */
+enum { MIN_JUNCT_ALIGN_SEP = 25, MAX_JUNCT_ALIGN_MM = 2, MIN_JUNCT_SEG_LEN = 10, SPLICE_DONOR_ACCEPT = 50, SPLICE_LEN = 10 };
+
+static int splice_bonus(char strand, uint8_t d0, uint8_t d1, uint8_t a0, uint8_t a1)
+{
+    int gt_ag = d0 == B_G && d1 == B_T && a0 == B_G && a1 == B_A, ct_ac = d0 == B_C && d1 == B_T && a0 == B_C && a1 == B_A;
+    if (strand == '+') return gt_ag ? SPLICE_DONOR_ACCEPT : (ct_ac ? SPLICE_DONOR_ACCEPT / 2 : 0);
+    return ct_ac ? SPLICE_DONOR_ACCEPT : (gt_ag ? SPLICE_DONOR_ACCEPT / 2 : 0);
+}
+
+static int explore_splice_right(char strand, int max_junct, int max_mm, int core_len, int plen, const uint8_t *probe, int64_t targ_ofs,
+                                int64_t targ_len, const uint8_t *targ, indel_hit *hit)
+{
+    int mm_ofs[MAX_PUT_INDEL_OFSS + 8];
+    indel_hit cur;
+    uint8_t pb = 0, tb = 0;
+    memset(hit, 0, sizeof(*hit));
+    if ((targ_ofs + plen + MIN_JUNCT_ALIGN_SEP) > targ_len) return 0;
+    memset(&cur, 0, sizeof(cur));
+    if (max_mm > MAX_JUNCT_ALIGN_MM) max_mm = MAX_JUNCT_ALIGN_MM;
+    int n_mm = 0;
+    const int lim = max_mm > MAX_JUNCT_ALIGN_MM * 5 ? max_mm : MAX_JUNCT_ALIGN_MM * 5;
+    for (int i = core_len; i < plen && n_mm <= lim; i++) {
+        pb = probe[i] & 7; tb = targ[i] & 7;
+        if (tb > B_N || pb > B_N) return 0;
+        if (!base_mismatch(pb, tb)) continue;
+        mm_ofs[n_mm++] = i;
+    }
+    if (n_mm < MAX_JUNCT_ALIGN_MM * 4 || MIN_JUNCT_SEG_LEN > (plen - mm_ofs[0])) {
+        if (n_mm > max_mm) return 0;
+        hit->s0_len = plen; hit->s0_loci = (uint64_t)targ_ofs; hit->s0_mm = n_mm; hit->strand = strand;
+        hit->score = BASE_SCORE + plen * SCORE_MATCH - n_mm * SCORE_MISMATCH;
+        return 1;
+    }
+    const int tot = n_mm < max_mm ? n_mm : max_mm;
+    if (tot < 1) return 0;
+    {
+        const uint8_t *pt = targ + mm_ofs[tot - 1];
+        for (int i = 0; i < MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN; i++, pt++)
+            if ((*pt & 7) > B_N) return 0;
+    }
+    for (int k = 0; k <= tot && MIN_JUNCT_SEG_LEN < (plen - mm_ofs[k]); k++) {
+        if (cur.score >= MAX_SCORE) break;
+        const uint32_t seg_len = (uint32_t)(plen - mm_ofs[k]);
+        const uint8_t *cur_p = probe + mm_ofs[k], *donor = targ + mm_ofs[k];
+        const uint8_t *t_start = donor + MIN_JUNCT_ALIGN_SEP;
+        const int hash_diff = 4 * (max_mm - k);
+        int probe_hash = 100000;
+        for (uint32_t i = 0; i < seg_len; i++) probe_hash += cur_p[i] & 7;
+        const int min_hash = probe_hash - hash_diff, max_hash = probe_hash + hash_diff;
+        int targ_hash = 100000;
+        const uint8_t *t_end = t_start;
+        uint32_t i;
+        for (i = 0; i < seg_len - 1; i++) {
+            if ((*t_end & 7) > B_N) break;
+            targ_hash += *t_end++ & 7;
+        }
+        if (i < seg_len - 1) break;
+        for (int gap = MIN_JUNCT_ALIGN_SEP; gap < max_junct - (int)seg_len; gap++, t_start++, t_end++) {
+            if ((tb = *t_end & 7) > B_N) break;
+            targ_hash += tb;
+            if (targ_hash < min_hash || targ_hash > max_hash) { targ_hash -= (*t_start & 7); continue; }
+            targ_hash -= (*t_start & 7);
+            const uint8_t *pt = t_start, *pp = cur_p;
+            const uint32_t tmp_len = (uint32_t)(targ_len - (targ_ofs + mm_ofs[k] + gap + 1));
+            if (tmp_len < seg_len) break;
+            int cmm = 0;
+            for (i = 0; i < seg_len && (k + cmm) < max_mm; i++, pt++, pp++) {
+                pb = *pp & 7; tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                cmm++;
+            }
+            if (i != seg_len) {
+                if (pb > B_N || tb > B_N) break;
+                continue;
+            }
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((k + cmm) * SCORE_MISMATCH + (gap / 1000) * SPLICE_LEN);
+            score += splice_bonus(strand, donor[0] & 7, donor[1] & 7, t_start[-1] & 7, t_start[-2] & 7);
+            if (score > cur.score) {
+                memset(&cur, 0, sizeof(cur));
+                cur.s0_len = mm_ofs[k]; cur.s0_loci = (uint64_t)targ_ofs; cur.s0_mm = k; cur.strand = strand;
+                cur.s1_len = plen - mm_ofs[k]; cur.s1_loci = (uint64_t)(targ_ofs + mm_ofs[k] + gap); cur.s1_mm = cmm;
+                cur.s1_read_ofs = mm_ofs[k]; cur.score = score; cur.is_indel = 2;      /* here: 2 = FlgSplice */
+            }
+        }
+    }
+    if (cur.score == 0) return 0;
+    *hit = cur;
+    return 3;
+}
+
+static int explore_splice_left(char strand, int max_junct, int max_mm, int core_len, int plen, const uint8_t *probe0, int64_t targ_ofs,
+                               int64_t targ_len, const uint8_t *targ0, indel_hit *hit)
+{
+    int mm_ofs[MAX_PUT_INDEL_OFSS + 8];
+    indel_hit cur;
+    uint8_t pb = 0, tb = 0;
+    (void)targ_len;
+    memset(hit, 0, sizeof(*hit));
+    if (targ_ofs < (int64_t)(MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN)) return 0;
+    memset(&cur, 0, sizeof(cur));
+    if (max_mm > MAX_JUNCT_ALIGN_MM) max_mm = MAX_JUNCT_ALIGN_MM;
+    const uint8_t *probe = probe0 + plen - 1, *targ = targ0 + plen - 1;          /* last base; offsets below count leftwards */
+    int n_mm = 0;
+    const int lim = max_mm > MAX_JUNCT_ALIGN_MM * 5 ? max_mm : MAX_JUNCT_ALIGN_MM * 5;
+    for (int i = core_len; i < plen && n_mm <= lim; i++) {
+        pb = probe[-i] & 7; tb = targ[-i] & 7;
+        if (tb > B_N || pb > B_N) return 0;
+        if (!base_mismatch(pb, tb)) continue;
+        mm_ofs[n_mm++] = i;
+    }
+    if (n_mm < MAX_JUNCT_ALIGN_MM * 4 || MIN_JUNCT_SEG_LEN > (plen - mm_ofs[0])) {
+        if (n_mm > max_mm) return 0;
+        hit->s0_len = plen; hit->s0_loci = (uint64_t)targ_ofs; hit->s0_mm = n_mm; hit->strand = strand;
+        hit->score = BASE_SCORE + plen * SCORE_MATCH - n_mm * SCORE_MISMATCH;
+        return 1;
+    }
+    const int tot = n_mm < max_mm ? n_mm : max_mm;
+    {
+        const uint8_t *pt = targ - mm_ofs[tot];
+        for (int i = 0; i < MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN; i++, pt--)
+            if ((*pt & 7) > B_N) return 0;
+    }
+    for (int k = 0; k <= tot && MIN_JUNCT_SEG_LEN < (plen - mm_ofs[k]); k++) {
+        if (cur.score >= MAX_SCORE) break;
+        const uint32_t seg_len = (uint32_t)(plen - mm_ofs[k]);
+        const uint8_t *cur_p = probe - mm_ofs[k], *donor = targ - mm_ofs[k];
+        const uint8_t *t_start = donor - MIN_JUNCT_ALIGN_SEP;
+        const int hash_diff = 4 * (max_mm - k);
+        int probe_hash = 100000;
+        for (uint32_t i = 0; i < seg_len; i++) probe_hash += *(cur_p - i) & 7;
+        const int min_hash = probe_hash - hash_diff, max_hash = probe_hash + hash_diff;
+        int targ_hash = 100000;
+        const uint8_t *t_end = t_start;
+        uint32_t i;
+        for (i = 0; i < seg_len - 1; i++) {
+            if ((*t_end & 7) > B_N) break;
+            targ_hash += *t_end-- & 7;
+        }
+        if (i < seg_len - 1) break;
+        for (int gap = MIN_JUNCT_ALIGN_SEP; gap < max_junct - (int)seg_len; gap++, t_start--, t_end--) {
+            if ((tb = *t_end & 7) > B_N) break;
+            targ_hash += tb;
+            if (targ_hash < min_hash || targ_hash > max_hash) { targ_hash -= (*t_start & 7); continue; }
+            targ_hash -= (*t_start & 7);
+            const uint8_t *pt = t_start, *pp = cur_p;
+            const uint32_t tmp_len = (uint32_t)(targ_ofs - gap);
+            if (tmp_len < 1) break;
+            int cmm = 0;
+            for (i = 0; i < seg_len && (k + cmm) < max_mm; i++, pt--, pp--) {
+                pb = *pp & 7; tb = *pt & 7;
+                if (pb > B_N || tb > B_N) break;
+                if (!base_mismatch(pb, tb)) continue;
+                cmm++;
+            }
+            if (i != seg_len) {
+                if (pb > B_N || tb > B_N) break;
+                continue;
+            }
+            int score = BASE_SCORE + plen * SCORE_MATCH - ((k + cmm) * SCORE_MISMATCH + (gap / 1000) * SPLICE_LEN);
+            score += splice_bonus(strand, t_start[1] & 7, t_start[2] & 7, donor[0] & 7, donor[-1] & 7);
+            if (score > cur.score) {
+                memset(&cur, 0, sizeof(cur));
+                cur.s0_len = plen - mm_ofs[k]; cur.s0_loci = (uint64_t)(targ_ofs - gap); cur.s0_mm = cmm; cur.strand = strand;
+                cur.s1_len = mm_ofs[k]; cur.s1_loci = cur.s0_loci + (uint64_t)cur.s0_len + (uint64_t)gap; cur.s1_mm = k;
+                cur.s1_read_ofs = cur.s0_len; cur.score = score; cur.is_indel = 2;
+            }
+        }
+    }
+    if (cur.score == 0) return 0;
+    *hit = cur;
+    return 3;
+}
+
+static int locate_splice_juncts(const ora_sfx *s, int max_junct, int max_tot_mm, int core_len, int align2strand,
+                                int *p_low_inst, int *p_low_mm, int *p_nxt, uint8_t *probe, int plen, indel_hit *best,
+                                int max_iter, ora_counters *ctr)
+{
+    int64_t sfx_len = (int64_t)s->concat_len;
+    char cur_strand;
+    int best_instances = 0;
+    const int max_hits = 1;
+    if (s->concat_len == 0) return -1;
+    if (max_tot_mm > MAX_JUNCT_ALIGN_MM) max_tot_mm = MAX_JUNCT_ALIGN_MM;
+    *p_low_inst = 0; *p_low_mm = 0; *p_nxt = 0;
+    memset(best, 0, sizeof(*best));
+    if (align2strand == ALS_CRICK) { revcomp(probe, plen); cur_strand = '-'; }
+    else cur_strand = '+';
+    do {
+        for (int phase = 0; phase < 2; phase++) {
+            int core_ofs = phase == 0 ? 0 : plen - core_len;
+            int64_t targ_idx = ora_locate_first_exact(s, probe + core_ofs, core_len, 0, sfx_len - 1, ctr);
+            if (targ_idx == 0) continue;
+            targ_idx -= 1;
+            int iter_cnt = 0, first_iter = 1;
+            uint32_t num_copies = 0;
+            while (!max_iter || iter_cnt < max_iter) {
+                if (!first_iter) {
+                    if ((targ_idx + 1) >= sfx_len || (sa_at(s, targ_idx + 1) + (phase == 0 ? plen : core_len)) >= sfx_len) break;
+                    if (iter_cnt == 100 && !num_copies) {
+                        int64_t last = ora_locate_last_exact(s, probe + core_ofs, core_len, targ_idx - 1, sfx_len - 1, ctr);
+                        num_copies = last > 0 ? (uint32_t)(1 + last - targ_idx) : 0;
+                        if (max_iter && num_copies > (uint32_t)max_iter) break;
+                    }
+                    if (cmp_probe(probe + core_ofs, s->seq + sa_at(s, targ_idx + 1), core_len) != 0) break;
+                    targ_idx += 1;
+                }
+                first_iter = 0;
+                int64_t loci = sa_at(s, targ_idx);
+                if (loci < (int64_t)(uint32_t)core_ofs) continue;
+                int64_t left = loci - core_ofs;
+                if ((left + plen) >= sfx_len) continue;
+                const ora_entry *ent = map_entry(s, (uint64_t)loci);
+                if (ent == NULL) continue;
+                if (left < (int64_t)ent->start_ofs || (left + plen) > (int64_t)ent->end_ofs) continue;
+                iter_cnt++;
+                indel_hit h;
+                int r = 0;
+                if (phase == 0) {
+                    int limit = (int)(sfx_len - left);
+                    if (limit > (MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN)) {
+                        limit -= (MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN);
+                        if (limit > max_junct) limit = max_junct;
+                        r = explore_splice_right(cur_strand, limit, max_tot_mm, core_len, plen, probe, left, sfx_len, s->seq + left, &h);
+                    }
+                } else if ((uint64_t)left >= (uint64_t)(uint32_t)(core_ofs + MIN_JUNCT_SEG_LEN)) {
+                    int limit = (int)((uint64_t)left < (uint64_t)(uint32_t)max_junct ? (uint64_t)left : (uint64_t)(uint32_t)max_junct);
+                    if (limit >= (MIN_JUNCT_ALIGN_SEP + MIN_JUNCT_SEG_LEN)) {
+                        limit -= MIN_JUNCT_SEG_LEN;
+                        r = explore_splice_left(cur_strand, limit, max_tot_mm, core_len, plen, probe, left, sfx_len, s->seq + left, &h);
+                    }
+                }
+                if (r > 0 && h.score >= best->score) {
+                    if (h.score == best->score) {
+                        if (best->s0_loci == h.s0_loci) continue;
+                        if (++best_instances > max_hits) continue;
+                    } else
+                        best_instances = 0;
+                    *best = h;
+                    best_instances++;
+                }
+            }
+            if (best_instances >= 1 && best->score >= MAX_SCORE) { align2strand = ALS_NONE; break; }
+        }
+        if (cur_strand == '+' && align2strand == ALS_BOTH) {
+            revcomp(probe, plen);
+            cur_strand = '-';
+            align2strand = ALS_CRICK;
+        } else
+            align2strand = ALS_NONE;
+    } while (!(best_instances >= 1 && best->score >= MAX_SCORE) && align2strand != ALS_NONE);
+    if (cur_strand == '-') revcomp(probe, plen);
+    if (best_instances == 0) return HR_NONE;
+    if (best->score > MAX_SCORE) best->score = MAX_SCORE;
+    {
+        const ora_entry *e0 = map_entry(s, best->s0_loci);
+        if (e0 == NULL) return HR_NONE;
+        best->s0_chrom = e0->entry_id;
+        best->s0_loci -= e0->start_ofs;
+        if (best->s1_loci > 0) {
+            const ora_entry *e1 = map_entry(s, best->s1_loci);
+            if (e1 == NULL) return HR_NONE;
+            best->s1_chrom = e1->entry_id;
+            best->s1_loci -= e1->start_ofs;
+        }
+    }
+    *p_low_inst = best_instances;
+    *p_low_mm = best->s0_mm + best->s1_mm;
+    *p_nxt = *p_low_mm + 2;
+    return best_instances <= max_hits ? HR_HITS : HR_NONE;
+}
+
 /* AlignReads, SfxArrayV2.cpp:7666-7760 with microInDelLen = MaxSpliceJunctLen = MinChimericLen = 0 */
 static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta, int max_slides,
                        int mm_delta, int align2strand, int *p_low_inst, int *p_low_mm, int *p_nxt,
                        uint8_t *probe, int plen, int max_hits, hit_rec *hits, int max_iter,
-                       scratch *sc, ora_counters *ctr, int micro_indel_len, indel_hit *ih, int *got_indel)
+                       scratch *sc, ora_counters *ctr, int micro_indel_len, int splice_junct_len, indel_hit *ih, int *got_indel)
 {
     int rslt = 0, allow_mm;
     if (max_tot_mm > 0) {
@@ -836,6 +1113,12 @@ static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_
         int splice_core = core_len * 2 < (plen - 1) / 2 ? core_len * 2 : (plen - 1) / 2;
         rslt = locate_indels(s, micro_indel_len, max_tot_mm > MAX_MICRO_INDEL_MM ? MAX_MICRO_INDEL_MM : max_tot_mm, splice_core,
                              align2strand, p_low_inst, p_low_mm, p_nxt, probe, plen, ih, max_iter, ctr);
+        if (rslt != 0) { *got_indel = 1; return rslt; }
+    }
+    if (rslt == 0 && splice_junct_len > 0) {                                           /* :7736-7748 */
+        int splice_core = core_len * 2 < (plen - 1) / 2 ? core_len * 2 : (plen - 1) / 2;
+        rslt = locate_splice_juncts(s, splice_junct_len, max_tot_mm > MAX_JUNCT_ALIGN_MM ? MAX_JUNCT_ALIGN_MM : max_tot_mm, splice_core,
+                                    align2strand, p_low_inst, p_low_mm, p_nxt, probe, plen, ih, max_iter, ctr);
         if (rslt != 0) { *got_indel = 1; return rslt; }
     }
     return 0;
@@ -919,14 +1202,14 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     } else
         rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
                            &low_inst, &low_mm, &nxt, seqbuf, match_len, max_ml, hits,
-                           ora_max_iter(p->pmode), sc, ctr, p->micro_indel_len, &ih, &got_indel);
+                           ora_max_iter(p->pmode), sc, ctr, p->micro_indel_len, p->splice_junct_len, &ih, &got_indel);
     if (got_indel && rslt == HR_HITS) {            /* the one tsHitLoci LocateInDels returned -> pMultiHits[0] */
         hits[0].strand = (uint8_t)ih.strand; hits[0].chrom_id = ih.s0_chrom; hits[0].match_loci = (uint32_t)ih.s0_loci;
         hits[0].match_len = (uint16_t)ih.s0_len; hits[0].mismatches = (uint8_t)ih.s0_mm;
         if (seg2_out) {
             seg2_out->match_loci = (uint32_t)ih.s1_loci; seg2_out->match_len = (uint16_t)ih.s1_len;
             seg2_out->read_ofs = (uint16_t)ih.s1_read_ofs; seg2_out->mismatches = (uint8_t)ih.s1_mm;
-            seg2_out->flags = (uint8_t)((ih.is_indel ? 1 : 0) | (ih.is_insert ? 2 : 0));
+            seg2_out->flags = (uint8_t)((ih.is_indel == 1 ? 1 : 0) | (ih.is_insert ? 2 : 0) | (ih.is_indel == 2 ? 4 : 0));
             seg2_out->score = (uint16_t)ih.score;
         }
     }

@@ -801,12 +801,71 @@ def make_trim(tmp):
     print("  trim fixtures written")
 
 
+def make_splice(tmp):
+    """splice junctions (-A, which also switches flank trimming on: MinFlankExacts = -s): reads spanning an intron of 30..4000 bases
+    (most with GT..AG or CT..AC ends, some without), one to three reads per junction so that supported and orphan junctions occur,
+    plus ordinary reads; -A5000 and -A500 in SAM / CSV / BED (+ .jct)"""
+    rng = np.random.default_rng(4711)
+    outdir = os.path.join(HERE, "splice")
+    os.makedirs(outdir, exist_ok=True)
+    g = [list(rand_seq(rng, 60000)), list(rand_seq(rng, 40000))]
+    juncs = []
+    for i in range(140):
+        c = int(rng.integers(0, 2)); a = int(rng.integers(300, len(g[c]) - 5000)); gap = int(rng.choice([30, 60, 120, 400, 900, 2500, 4000]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            g[c][a:a + 2] = "GT"; g[c][a + gap - 2:a + gap] = "AG"
+        elif kind == 1:
+            g[c][a:a + 2] = "CT"; g[c][a + gap - 2:a + gap] = "AC"
+        juncs.append((c, a, gap))
+    seqs = ["".join(x) for x in g]
+    fa = os.path.join(tmp, "splice.fa")
+    write_fasta(fa, [("sA", seqs[0]), ("sB", seqs[1])])
+    reads = []
+    for i, (c, a, gap) in enumerate(juncs):
+        for r in range(int(rng.integers(1, 4))):
+            left = int(rng.integers(15, 86))
+            s = seqs[c][a - left:a] + seqs[c][a + gap:a + gap + 100 - left]
+            s = mutate(rng, s, int(rng.integers(0, 2)))
+            if rng.integers(0, 2):
+                s = revcomp(s)
+            reads.append((f"j{i}_{r}_g{gap}", s))
+    for i in range(400):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(seqs[c]) - 100))
+        s = mutate(rng, seqs[c][p:p + 100], int(rng.integers(0, 5)))
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"n{i}", s))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "splice_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "splice.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "splice", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags in (("A5000", ["-A5000", "-s3"]), ("A500s5", ["-A500", "-s5"]), ("A5000a5", ["-A5000", "-a5", "-s3"])):
+        for fmt, ext in (("-M6", "m6.sam"), ("-M5", "m5.sam"), ("-M0", "m0.csv"), ("-M4", "m4.bed")):
+            if tag != "A5000" and fmt not in ("-M6", "-M0"):
+                continue
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-T4"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            if fmt in ("-M4", "-M6", "-M5"):
+                gz_copy(out + ".jct", os.path.join(outdir, f"{tag}.{ext}.jct.gz"))
+            print("  ran", tag, fmt, flags)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-splice" in sys.argv:
+            make_splice(tmp)
             return
         if "--only-trim" in sys.argv:
             make_trim(tmp)
@@ -851,6 +910,7 @@ def main():
         make_multi_best(tmp)
         make_indel(tmp)
         make_trim(tmp)
+        make_splice(tmp)
     print("done")
 
 

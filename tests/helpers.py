@@ -22,7 +22,7 @@ class OraParams(ctypes.Structure):
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
                 ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32),
-                ("micro_indel_len", ctypes.c_int32), ("reserved2", ctypes.c_int32 * 3)]
+                ("micro_indel_len", ctypes.c_int32), ("splice_junct_len", ctypes.c_int32), ("reserved2", ctypes.c_int32 * 2)]
 
 
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
@@ -38,8 +38,9 @@ class OraCounters(ctypes.Structure):
 
 
 def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0, micro_indel_len=0,
-                cls=OraParams):
+                splice_junct_len=0, cls=OraParams):
     p = cls()
+    p.splice_junct_len = splice_junct_len
     p.micro_indel_len = micro_indel_len
     p.clamp_ml = clamp_ml
     p.best_matches = best_matches
@@ -184,10 +185,19 @@ def oracle_align_indel(osfx, bases, offs, lens, params, nthreads=4):
     return out, seg2
 
 
+def remove_orphan_splices(hits, seg2):
+    """CAligner::RemoveOrphanSpliceJuncts (Aligner.cpp:2287-2380): same rule as for microInDels, NAR 7 (OJ).  In place."""
+    return _remove_orphans(hits, seg2, 4, 7)
+
+
 def remove_orphan_indels(hits, seg2):
+    return _remove_orphans(hits, seg2, 1, 8)
+
+
+def _remove_orphans(hits, seg2, flag, nar):
     """CAligner::RemoveOrphanMicroInDels (Aligner.cpp:2382-2470): a microInDel placement stands only if another read has its
     junction within 3 bases on both sides; the others become NAR 8 (OM).  In place."""
-    idx = [i for i in range(len(hits)) if hits["nar"][i] == 1 and (seg2["flags"][i] & 1)]
+    idx = [i for i in range(len(hits)) if hits["nar"][i] == 1 and (seg2["flags"][i] & flag)]
     j = sorted((int(hits["chrom_id"][i]), int(hits["match_loci"][i]) + int(hits["match_len"][i]) - 1, int(seg2["match_loci"][i]), i) for i in idx)
     keep = set()
     if len(j) > 1:
@@ -196,7 +206,7 @@ def remove_orphan_indels(hits, seg2):
                 keep.add(a[3]); keep.add(b[3])
     for i in idx:
         if i not in keep:
-            hits["nar"][i] = 8
+            hits["nar"][i] = nar
             hits["num_hits"][i] = 0
             hits["low_hit_instances"][i] = 0
     return hits
