@@ -2404,9 +2404,111 @@ __device__ void explore_indel(const uint64_t *__restrict__ rdw, const uint64_t *
     else { out = ins; out.r = 2; }
 }
 
+// ExploreSpliceRight / ExploreSpliceLeft (SfxArrayV2.cpp:8437-8940) for one placement of the read at target offset t: beyond the
+// anchor core collect the mismatch positions; with >= 8 of them try, for each of the first MaxTotMM+1, to move the rest of the read
+// 25 .. max_junct bases further along the target - candidates are pre-filtered by a rolling sum of base codes, compared with the
+// reference's strict mismatch budget, scored (GT..AG / CT..AC ends earn a bonus, every 1000 bases of intron cost 10).
+constexpr int kJunctSep = 25, kJunctMM = 2, kJunctSeg = 10, kSpliceBonus = 50, kSpliceLenCost = 10;
+
+__device__ __forceinline__ int splice_bonus(bool plus, int d0, int d1, int a0, int a1)
+{
+    const bool gt_ag = d0 == 2 && d1 == 3 && a0 == 2 && a1 == 0, ct_ac = d0 == 1 && d1 == 3 && a0 == 1 && a1 == 0;
+    if (plus) return gt_ag ? kSpliceBonus : (ct_ac ? kSpliceBonus / 2 : 0);
+    return ct_ac ? kSpliceBonus : (gt_ag ? kSpliceBonus / 2 : 0);
+}
+
+template <bool RIGHT>
+__device__ void explore_splice(const uint64_t *__restrict__ rdw, const uint64_t *__restrict__ tgt, int plen, uint64_t t, uint64_t targ_len,
+                               int max_junct, int max_mm, int core_len, bool plus, IndelPlacement &out)
+{
+    out.r = 0; out.score = 0; out.is_insert = 0; out.s0_loci = 0; out.s1_loci = 0; out.s0_len = 0; out.s0_mm = 0; out.s1_len = 0; out.s1_mm = 0; out.s1_ofs = 0;
+    if (RIGHT) { if (t + (uint64_t)plen + kJunctSep > targ_len) return; }
+    else if (t < (uint64_t)(kJunctSep + kJunctSeg)) return;
+    if (max_mm > kJunctMM) max_mm = kJunctMM;
+    const int pe = plen - 1;
+    // probe / target base i positions away from the scan origin (5' end going right, or 3' end going left)
+    auto P = [&](int i) -> int { return rd_base4(rdw, RIGHT ? i : pe - i); };
+    auto T = [&](long long i) -> int { return tg_base4(tgt, RIGHT ? t + (uint64_t)i : (uint64_t)((long long)t + pe - i)); };
+    int mm_ofs[kJunctMM * 5 + 2];
+    int n_mm = 0, pb = 0, tb = 0;
+    const int lim = kJunctMM * 5;
+    for (int i = core_len; i < plen && n_mm <= lim; i++) {
+        pb = P(i); tb = T(i);
+        if (tb > 4 || pb > 4) return;
+        if (pb == tb && pb <= 3) continue;
+        mm_ofs[n_mm++] = i;
+    }
+    if (n_mm < kJunctMM * 4 || kJunctSeg > plen - mm_ofs[0]) {
+        if (n_mm > max_mm) return;
+        out.r = 1; out.s0_len = plen; out.s0_loci = t; out.s0_mm = n_mm;
+        out.score = kIndelBase + plen * kIndelMatch - n_mm * kIndelMismatch;
+        return;
+    }
+    const int tot = n_mm < max_mm ? n_mm : max_mm;
+    if (RIGHT && tot < 1) return;
+    {
+        const int from = RIGHT ? mm_ofs[tot - 1] : mm_ofs[tot];
+        for (int i = 0; i < kJunctSep + kJunctSeg; i++)
+            if (T((long long)from + i) > 4) return;
+    }
+    IndelPlacement cur = out;
+    for (int k = 0; k <= tot && kJunctSeg < plen - mm_ofs[k]; k++) {
+        if (cur.score >= kIndelMaxScore) break;
+        const int seg_len = plen - mm_ofs[k], mo = mm_ofs[k];
+        const int hash_diff = 4 * (max_mm - k);
+        int probe_hash = 100000;
+        for (int i = 0; i < seg_len; i++) probe_hash += P(mo + i);
+        const int min_hash = probe_hash - hash_diff, max_hash = probe_hash + hash_diff;
+        int targ_hash = 100000, i;
+        for (i = 0; i < seg_len - 1; i++) {
+            const int b = T((long long)mo + kJunctSep + i);
+            if (b > 4) break;
+            targ_hash += b;
+        }
+        if (i < seg_len - 1) break;
+        for (int gap = kJunctSep; gap < max_junct - seg_len; gap++) {
+            const long long ts = (long long)mo + gap, te = ts + seg_len - 1;        // start / end of the moved segment, scan coordinates
+            if ((tb = T(te)) > 4) break;
+            targ_hash += tb;
+            const bool in_range = !(targ_hash < min_hash || targ_hash > max_hash);
+            targ_hash -= T(ts);
+            if (!in_range) continue;
+            if (RIGHT) { if ((uint32_t)(targ_len - (t + (uint64_t)mo + (uint64_t)gap + 1)) < (uint32_t)seg_len) break; }
+            else if ((uint32_t)(t - (uint64_t)gap) < 1u) break;
+            int cmm = 0;
+            for (i = 0; i < seg_len && (k + cmm) < max_mm; i++) {
+                pb = P(mo + i); tb = T(ts + i);
+                if (pb > 4 || tb > 4) break;
+                if (pb == tb && pb <= 3) continue;
+                cmm++;
+            }
+            if (i != seg_len) {
+                if (pb > 4 || tb > 4) break;
+                continue;
+            }
+            int score = kIndelBase + plen * kIndelMatch - ((k + cmm) * kIndelMismatch + (gap / 1000) * kSpliceLenCost);
+            // donor = first two intron bases after the kept part, acceptor = last two before the moved part (target order)
+            if (RIGHT) score += splice_bonus(plus, T(mo), T(mo + 1), T(ts - 1), T(ts - 2));
+            else score += splice_bonus(plus, T(ts - 1), T(ts - 2), T(mo), T(mo + 1));
+            if (score > cur.score) {
+                cur.score = score; cur.r = 3;
+                if (RIGHT) {
+                    cur.s0_len = mo; cur.s0_loci = t; cur.s0_mm = k;
+                    cur.s1_len = seg_len; cur.s1_loci = t + (uint64_t)mo + (uint64_t)gap; cur.s1_mm = cmm; cur.s1_ofs = mo;
+                } else {
+                    cur.s0_len = seg_len; cur.s0_loci = t - (uint64_t)gap; cur.s0_mm = cmm;
+                    cur.s1_len = mo; cur.s1_loci = cur.s0_loci + (uint64_t)seg_len + (uint64_t)gap; cur.s1_mm = k; cur.s1_ofs = seg_len;
+                }
+            }
+        }
+    }
+    if (cur.score == 0) return;
+    out = cur;
+}
+
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list, uint32_t n_list,
-                                               int max_indel, uint32_t *__restrict__ cursor, bk_seg2 *__restrict__ seg2)
+                                               int max_indel, int max_junct, uint32_t *__restrict__ cursor, bk_seg2 *__restrict__ seg2)
 {
     __shared__ LdsEntries s_le;
     lds_entries_load(s_le, ix);
@@ -2421,90 +2523,122 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
         const int len = (int)b.lens[r];
         const ReadPlan p = make_plan(len, cfg);
         const int core = p.core_len * 2 < (len - 1) / 2 ? p.core_len * 2 : (len - 1) / 2;
-        const int max_mm = p.max_tot_mm > kIndelMaxMM ? kIndelMaxMM : p.max_tot_mm;
+        const int max_mm = p.max_tot_mm > kIndelMaxMM ? kIndelMaxMM : p.max_tot_mm;       // cMaxMicroInDelMM == cMaxJunctAlignMM == 2
         if (core < 1) continue;
-        // best placement so far (wave-uniform)
-        int best_score = 0, best_inst = 0, b_insert = 0, b_indel = 0, b_s0_len = 0, b_s0_mm = 0, b_s1_len = 0, b_s1_mm = 0, b_s1_ofs = 0, b_strand = '+';
-        uint64_t b_s0 = 0, b_s1 = 0;
-        bool done = false;
-        const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-        for (int st = s0; st <= s1 && !done; st++) {
-            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
-            for (int phase = 0; phase < 2; phase++) {
-                const int ofs = phase == 0 ? 0 : len - core;
-                uint64_t first = 0, n = 0;
-                search_core<WIDE>(ix, rdw, ofs, core, ~0ULL >> 1, first, n);       // every lane the same search
-                uint32_t iter = 0;
-                bool copies_checked = false;
-                for (uint64_t j0 = 0; j0 < n; j0 += 64) {
-                    const uint64_t j = j0 + lane;
-                    const bool active = j < n;
-                    const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
-                    const uint64_t t = loci - (uint64_t)ofs;
-                    bool valid = active && loci >= (uint64_t)ofs;
-                    int e = -1;
-                    if (valid) {
-                        e = find_entry_lds(s_le, ix, loci);                   // MapChunkHit2Entry of the ANCHOR position (:7497)
-                        valid = e >= 0 && t >= ix.ent_start[e] && t + (uint64_t)len - 1 <= ix.ent_end[e] && t + (uint64_t)len <= ix.n;
-                    }
-                    const uint64_t newmask = __ballot(valid);
-                    const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
-                    const uint32_t iter_before = iter + pre;
-                    const bool stop = active && cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter;
-                    uint64_t cutoff = n;
-                    const uint64_t stopmask = __ballot(stop);
-                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
-                    if (!copies_checked) {
-                        const bool chk = active && j > 0 && iter_before == 100;
-                        const uint64_t chkmask = __ballot(chk);
-                        if (chkmask) {
-                            const uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
-                            if (jc < cutoff) {
-                                copies_checked = true;
-                                const uint64_t num_copies = n - jc + 2;
-                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+        // AlignReads: LocateInDels first, LocateSpliceJuncts only if that returned nothing (SfxArrayV2.cpp:7722-7748)
+        for (int mode = max_indel > 0 ? 0 : 1; mode < 2; mode++) {
+            if (mode == 1 && max_junct <= 0) break;
+            const bool splice = mode == 1;
+            // best placement so far (wave-uniform)
+            int best_score = 0, best_inst = 0, b_insert = 0, b_kind = 0, b_s0_len = 0, b_s0_mm = 0, b_s1_len = 0, b_s1_mm = 0, b_s1_ofs = 0, b_strand = '+';
+            uint64_t b_s0 = 0, b_s1 = 0;
+            bool done = false;
+            const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+            for (int st = s0; st <= s1 && !done; st++) {
+                const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
+                for (int phase = 0; phase < 2; phase++) {
+                    const int ofs = phase == 0 ? 0 : len - core;
+                    uint64_t first = 0, n = 0;
+                    search_core<WIDE>(ix, rdw, ofs, core, ~0ULL >> 1, first, n);       // every lane the same search
+                    uint32_t iter = 0;
+                    bool copies_checked = false;
+                    for (uint64_t j0 = 0; j0 < n; j0 += 64) {
+                        const uint64_t j = j0 + lane;
+                        const bool active = j < n;
+                        const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
+                        const uint64_t t = loci - (uint64_t)ofs;
+                        bool valid = active && loci >= (uint64_t)ofs;
+                        int e = -1;
+                        if (valid && splice) valid = t + (uint64_t)len < ix.n;                                   // :7132
+                        if (valid) {
+                            e = find_entry_lds(s_le, ix, loci);                   // MapChunkHit2Entry of the ANCHOR position (:7497 / :7135)
+                            if (splice) valid = e >= 0 && t >= ix.ent_start[e] && t + (uint64_t)len <= ix.ent_end[e];
+                            else valid = e >= 0 && t >= ix.ent_start[e] && t + (uint64_t)len - 1 <= ix.ent_end[e] && t + (uint64_t)len <= ix.n;
+                        }
+                        const uint64_t newmask = __ballot(valid);
+                        const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
+                        const uint32_t iter_before = iter + pre;
+                        bool stop = active && cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter;
+                        // the splice walk also ends at a suffix too close to the end of the concatenation (:7087)
+                        if (splice && active && j > 0 && loci + (uint64_t)(phase == 0 ? len : core) >= ix.n) stop = true;
+                        uint64_t cutoff = n;
+                        const uint64_t stopmask = __ballot(stop);
+                        if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                        if (!copies_checked) {
+                            const bool chk = active && j > 0 && iter_before == 100;
+                            const uint64_t chkmask = __ballot(chk);
+                            if (chkmask) {
+                                const uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                                if (jc < cutoff) {
+                                    copies_checked = true;
+                                    const uint64_t num_copies = n - jc + 2;
+                                    if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                                }
                             }
                         }
+                        const bool proc = valid && j < cutoff;
+                        iter += (uint32_t)__popcll(__ballot(proc));
+                        IndelPlacement pl;
+                        pl.r = 0; pl.score = 0;
+                        if (proc && !splice) {
+                            const uint32_t seq_left = (uint32_t)(ix.ent_end[e] + 1 - t);      // SeqLen - (TargOfs - StartOfs)
+                            if (phase == 0) explore_indel<true>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
+                            else explore_indel<false>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
+                        } else if (proc) {
+                            if (phase == 0) {
+                                int limit = (int)(ix.n - t);
+                                if (limit > kJunctSep + kJunctSeg) {
+                                    limit -= kJunctSep + kJunctSeg;
+                                    if (limit > max_junct) limit = max_junct;
+                                    explore_splice<true>(rdw, ix.tgt4, len, t, ix.n, limit, max_mm, core, st == 0, pl);
+                                }
+                            } else if (t >= (uint64_t)(uint32_t)(ofs + kJunctSeg)) {
+                                int limit = (int)(t < (uint64_t)(uint32_t)max_junct ? t : (uint64_t)(uint32_t)max_junct);
+                                if (limit >= kJunctSep + kJunctSeg) {
+                                    limit -= kJunctSeg;
+                                    explore_splice<false>(rdw, ix.tgt4, len, t, ix.n, limit, max_mm, core, st == 0, pl);
+                                }
+                            }
+                        }
+                        // fold this round's placements in suffix-array order (:7517-7561 / :7160-7200)
+                        uint64_t hm = __ballot(proc && pl.r > 0);
+                        while (hm) {
+                            const int src = __ffsll((unsigned long long)hm) - 1;
+                            hm &= hm - 1;
+                            const int sc = __shfl(pl.score, src);
+                            if (sc < best_score) continue;
+                            const uint64_t c_s0 = __shfl(pl.s0_loci, src);
+                            if (sc == best_score) {
+                                if (b_s0 == c_s0) continue;
+                                if (++best_inst > 1) continue;
+                            } else
+                                best_inst = 0;
+                            best_score = sc; b_s0 = c_s0; b_s1 = __shfl(pl.s1_loci, src);
+                            b_s0_len = __shfl(pl.s0_len, src); b_s0_mm = __shfl(pl.s0_mm, src); b_s1_len = __shfl(pl.s1_len, src);
+                            b_s1_mm = __shfl(pl.s1_mm, src); b_s1_ofs = __shfl(pl.s1_ofs, src); b_insert = __shfl(pl.is_insert, src);
+                            b_kind = __shfl(pl.r, src) > 1 ? (splice ? 4 : 1) : 0;
+                            b_strand = st ? '-' : '+';
+                            best_inst++;
+                        }
+                        if (cutoff < j0 + 64) break;
                     }
-                    const bool proc = valid && j < cutoff;
-                    iter += (uint32_t)__popcll(__ballot(proc));
-                    IndelPlacement pl;
-                    pl.r = 0; pl.score = 0;
-                    if (proc) {
-                        const uint32_t seq_left = (uint32_t)(ix.ent_end[e] + 1 - t);      // SeqLen - (TargOfs - StartOfs)
-                        if (phase == 0) explore_indel<true>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
-                        else explore_indel<false>(rdw, ix.tgt4, len, t, seq_left, max_indel, max_mm, pl);
-                    }
-                    // fold this round's placements in suffix-array order (:7517-7561)
-                    uint64_t hm = __ballot(proc && pl.r > 0);
-                    while (hm) {
-                        const int src = __ffsll((unsigned long long)hm) - 1;
-                        hm &= hm - 1;
-                        const int sc = __shfl(pl.score, src);
-                        if (sc < best_score) continue;
-                        const uint64_t c_s0 = __shfl(pl.s0_loci, src);
-                        if (sc == best_score) {
-                            if (b_s0 == c_s0) continue;
-                            if (++best_inst > 1) continue;
-                        } else
-                            best_inst = 0;
-                        best_score = sc; b_s0 = c_s0; b_s1 = __shfl(pl.s1_loci, src);
-                        b_s0_len = __shfl(pl.s0_len, src); b_s0_mm = __shfl(pl.s0_mm, src); b_s1_len = __shfl(pl.s1_len, src);
-                        b_s1_mm = __shfl(pl.s1_mm, src); b_s1_ofs = __shfl(pl.s1_ofs, src); b_insert = __shfl(pl.is_insert, src);
-                        b_indel = __shfl(pl.r, src) > 1 ? 1 : 0;
-                        b_strand = st ? '-' : '+';
-                        best_inst++;
-                    }
-                    if (cutoff < j0 + 64) break;
+                    if (best_inst >= 1 && best_score >= kIndelMaxScore) { done = true; break; }
                 }
-                if (best_inst >= 1 && best_score >= kIndelMaxScore) { done = true; break; }
             }
-        }
-        if (best_inst != 1) continue;                       // none, or ambiguous
-        if (lane == 0) {
+            if (best_inst != 1) continue;                   // none, or ambiguous: on to the next mode
             if (best_score > kIndelMaxScore) best_score = kIndelMaxScore;
-            const int e0 = find_entry(ix, b_s0), e1 = find_entry(ix, b_s1);
-            if (e0 >= 0 && e1 >= 0 && ix.ent_id[e0] == ix.ent_id[e1]) {
+            // offsets -> entry + position; LocateInDels insists on one entry for both segments (a placement without a second
+            // segment looks up offset 0 there), LocateSpliceJuncts only looks the second one up when there is one
+            int e0 = -1, e1 = -1;
+            if (lane == 0) {
+                e0 = find_entry(ix, b_s0);
+                e1 = (splice && b_s1 == 0) ? e0 : find_entry(ix, b_s1);
+            }
+            e0 = __shfl(e0, 0); e1 = __shfl(e1, 0);
+            bool ok = e0 >= 0 && e1 >= 0;
+            if (ok && !splice) ok = ix.ent_id[e0] == ix.ent_id[e1];
+            if (!ok) continue;
+            if (lane == 0) {
                 bk_hit h;
                 h.chrom_id = ix.ent_id[e0]; h.match_loci = (uint32_t)(b_s0 - ix.ent_start[e0]); h.match_len = (uint16_t)b_s0_len;
                 h.low_hit_instances = 1; h.rslt = BK_HR_HITS; h.nar = BK_NAR_ACCEPTED; h.strand = (uint8_t)b_strand;
@@ -2513,9 +2647,10 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
                 b.out[r] = h;
                 bk_seg2 g;
                 g.match_loci = b_s1 > 0 ? (uint32_t)(b_s1 - ix.ent_start[e1]) : 0u; g.match_len = (uint16_t)b_s1_len; g.read_ofs = (uint16_t)b_s1_ofs;
-                g.mismatches = (uint8_t)b_s1_mm; g.flags = (uint8_t)((b_indel ? 1 : 0) | (b_insert ? 2 : 0)); g.score = (uint16_t)best_score;
+                g.mismatches = (uint8_t)b_s1_mm; g.flags = (uint8_t)(b_kind | (b_insert ? 2 : 0)); g.score = (uint16_t)best_score;
                 seg2[r] = g;
             }
+            break;                                          // aligned: no further mode
         }
     }
 }
@@ -2529,8 +2664,8 @@ __global__ void __launch_bounds__(256) k_unaligned_list(const bk_hit *__restrict
     if (h.nar == BK_NAR_NOHIT && h.rslt == BK_HR_NONE) list[atomicAdd(cnt, 1u)] = r;
 }
 
-void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, uint32_t *list, uint32_t *list_cnt_dev,
-                  uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
+void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, uint32_t *list,
+                  uint32_t *list_cnt_dev, uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
 {
     if (!n) return;
     hipLaunchKernelGGL(k_unaligned_list, dim3((n + 255) / 256), dim3(256), 0, s, b.out, n, list, list_cnt_dev);
@@ -2539,8 +2674,8 @@ void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     const uint32_t n_list = *list_cnt_host;
     if (!n_list) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n_list + 3) / 4, 8192);
-    if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, cursor, seg2);
-    else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, cursor, seg2);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, cursor, seg2);
+    else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, cursor, seg2);
 }
 
 __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)

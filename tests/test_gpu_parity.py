@@ -522,8 +522,10 @@ def test_best_matches_synthetic(tmp_path):
 
 
 @pytest.mark.parametrize("kw", [dict(max_subs=3, micro_indel_len=10), dict(max_subs=5, micro_indel_len=3), dict(max_subs=3, micro_indel_len=20, align_strand=1),
-                                dict(max_subs=3, micro_indel_len=20, align_strand=2), dict(max_subs=1, micro_indel_len=5), dict(max_subs=0, micro_indel_len=8)])
-@pytest.mark.parametrize("fixture", ["indel", "basic", "lengths"])
+                                dict(max_subs=3, micro_indel_len=20, align_strand=2), dict(max_subs=1, micro_indel_len=5), dict(max_subs=0, micro_indel_len=8),
+                                dict(max_subs=3, splice_junct_len=5000), dict(max_subs=5, splice_junct_len=500), dict(max_subs=3, splice_junct_len=5000, micro_indel_len=5),
+                                dict(max_subs=1, splice_junct_len=100000, align_strand=1), dict(max_subs=3, splice_junct_len=25, align_strand=2)])
+@pytest.mark.parametrize("fixture", ["indel", "splice", "basic", "lengths"])
 def test_micro_indels_match_oracle(golden_tmp, fixture, kw):
     """-a: result records and second segments (LocateInDels) against the oracle, which is pinned on the reference's -a output"""
     bk = _bk()
@@ -543,5 +545,7 @@ def test_micro_indels_match_oracle(golden_tmp, fixture, kw):
             if not np.array_equal(seg[f], eseg[f]):
                 i = int(np.nonzero(seg[f] != eseg[f])[0][0])
                 raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
-    if fixture == "indel":
+    if fixture == "indel" and kw.get("micro_indel_len"):
         assert np.count_nonzero(eseg["flags"] & 1) > 50 or kw["max_subs"] == 0
+    if fixture == "splice" and kw.get("splice_junct_len", 0) >= 500 and kw["max_subs"] >= 3:
+        assert np.count_nonzero(eseg["flags"] & 4) > 50
