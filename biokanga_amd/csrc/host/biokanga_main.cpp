@@ -499,8 +499,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRax", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxA", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -547,15 +547,23 @@ int cmd_align(int argc, char **argv, int first)
     if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
     if (micro_indel && (ml_mode || pe_mode)) { diag("Error: microInDels '-a%d' together with '-r%d' / '-U%d' are not available in this build", micro_indel, ml_mode, pe_mode); return 1; }
     // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
-    const int min_flank = a.num("x", 0);
+    // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
+    const int splice_len = a.num("A", 0);
+    if (splice_len != 0 && (splice_len < 25 || splice_len > 100000)) { diag("Error: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000", splice_len); return 1; }
+    if (splice_len && ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
+    if (splice_len && pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", splice_len, pe_mode); return 1; }
+    if (splice_len && ml_mode) { diag("Error: splice junctions '-A%d' together with '-r%d' are not available in this build", splice_len, ml_mode); return 1; }
+    int min_flank = a.num("x", 0);
     if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
     if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
     bk_align_params P = {};
     P.micro_indel_len = micro_indel;
+    P.splice_junct_len = splice_len;
     P.pmode = a.num("m", 0);
     P.align_strand = a.num("Q", 0);
     P.min_edit_dist = a.num("e", 1);
     P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
+    if (splice_len > 0 && min_flank == 0) min_flank = P.max_subs;      // MinFlankExacts = MaxSubs (kanga.cpp:810-811)
     P.max_ns = a.num("n", 1);
     P.max_ml = max_ml;
     P.clamp_ml = clamp_ml ? 1 : 0;
@@ -611,7 +619,7 @@ int cmd_align(int argc, char **argv, int first)
         size_t n = std::min(kBatch, nr - lo);
         rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-        if (micro_indel) {
+        if (micro_indel || splice_len) {
             const bk_seg2 *bs = nullptr;
             uint64_t ns = 0;
             rc = bk_batch_seg2(ctx, &bs, &ns);
@@ -709,7 +717,7 @@ int cmd_align(int argc, char **argv, int first)
         }
     }
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
-    auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 1); };
+    auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 5); };       // FlgInDel or FlgSplice
     // per-record flank trims in READ orientation (tsSegLoci.TrimLeft / TrimRight / TrimMismatches of Seg[0])
     std::vector<uint16_t> trim_l, trim_r;
     std::vector<uint8_t> trim_mm;
@@ -778,14 +786,16 @@ int cmd_align(int argc, char **argv, int first)
         for (int w = 0; w < nthreads; w++) { np += plus[(size_t)w]; nm += minus[(size_t)w]; }
         diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", np, nm);
     }
-    if (micro_indel) {
-        // CAligner::RemoveOrphanMicroInDels (Aligner.cpp:2382-2470): a placement stands only if another read's junction lies
-        // within 3 bases of it on both sides; the others become eNARmicroInDel
-        diag("Removal of orphan microInDels processing started..");
+    // CAligner::RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (Aligner.cpp:2287-2470), in that order: a placement stands only if
+    // another read's junction lies within 3 bases of it on both sides; the others become eNARSpliceJctn / eNARmicroInDel
+    for (int pass = 0; pass < 2; pass++) {
+        const uint8_t want = pass == 0 ? 4 : 1, orphan_nar = pass == 0 ? 7 : 8;
+        if (pass == 0 ? splice_len == 0 : micro_indel == 0) continue;
+        diag(pass == 0 ? "Removal of orphan splice junction processing started.." : "Removal of orphan microInDels processing started..");
         struct Junct { uint32_t chrom; uint32_t starts, ends; size_t read; };
         std::vector<Junct> jn;
         for (size_t i = 0; i < nr; i++)
-            if (hits[i].nar == BK_NAR_ACCEPTED && (seg2[i].flags & 1))
+            if (hits[i].nar == BK_NAR_ACCEPTED && (seg2[i].flags & want))
                 jn.push_back({hits[i].chrom_id, hits[i].match_loci + hits[i].match_len - 1u, seg2[i].match_loci, i});
         std::sort(jn.begin(), jn.end(), [](const Junct &x, const Junct &y) {
             if (x.chrom != y.chrom) return x.chrom < y.chrom;
@@ -803,13 +813,12 @@ int cmd_align(int argc, char **argv, int first)
         for (size_t k = 0; k < jn.size(); k++)
             if (!supported[k]) {
                 bk_hit &h = hits[jn[k].read];
-                h.nar = 8;                                  // eNARmicroInDel
+                h.nar = orphan_nar;
                 h.num_hits = 0;
                 h.low_hit_instances = 0;
                 n_orphan++;
             }
-        diag("From %zu reads with putative microIndels %zu orphans were removed", jn.size(), n_orphan);
-        diag("Removal of orphan microInDels processing completed");
+        diag("From %zu reads with putative %s %zu orphans were removed", jn.size(), pass == 0 ? "splice junctions" : "microIndels", n_orphan);
     }
     if (pe_mode) {
         // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355)
@@ -972,6 +981,31 @@ int cmd_align(int argc, char **argv, int first)
         fclose(f);
     };
 
+    // -A with SAM / BAM output: the junctions are still reported as BED lines in "<out>.jct" (Aligner.cpp:713-721,4440-4462); the track
+    // title is empty in these modes
+    auto write_jct_for_sam = [&]() {
+        if (!splice_len || fmt < 5) return;
+        std::string jp = a.str("o");
+        if (jp.size() > 3 && !strcasecmp(jp.c_str() + jp.size() - 3, ".gz")) jp.resize(jp.size() - 3);
+        OutBuf j;
+        j.open((jp + ".jct").c_str());
+        if (j.fd < 0) { diag("Unable to create '%s.jct'", jp.c_str()); return; }
+        char ln[1024];
+        int m = snprintf(ln, sizeof(ln), "track type=bed name=\"JCT_\" description=\"\"\n");
+        j.put(ln, (size_t)m);
+        for (size_t k = 0; k < nr; k++) {
+            const uint32_t i = order[k];
+            const bk_hit &h = hits[i];
+            if (h.nar != BK_NAR_ACCEPTED || !has_seg2(i) || !(seg2[RD(i)].flags & 4)) continue;
+            const bk_seg2 &g = seg2[RD(i)];
+            const uint32_t end1 = g.match_loci + g.match_len;
+            m = snprintf(ln, sizeof(ln), "%s\t%u\t%u\tarj\t0\t%c\t%u\t%u\t0\t2\t%u,%u\t0,%u\n", ents[h.chrom_id - 1].name, h.match_loci, end1, (char)h.strand,
+                         h.match_loci, end1, (unsigned)h.match_len, (unsigned)g.match_len, g.match_loci - h.match_loci);
+            j.put(ln, (size_t)m);
+        }
+        j.close();
+    };
+
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index
     const std::string opath = a.str("o");
     if (fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) {
@@ -1075,7 +1109,8 @@ int cmd_align(int argc, char **argv, int first)
                 if (clip3) w32(clip3 << 4 | 4u);
                 if (two) {
                     const bk_seg2 &g = seg2[RD(i)];
-                    if (g.flags & 2) w32((uint32_t)((long)len - ((long)h.match_len + g.match_len)) << 4 | 1u);
+                    if (g.flags & 4) w32((uint32_t)((long)g.match_loci - ((long)h.match_loci + h.match_len)) << 4 | 3u);
+                    else if (g.flags & 2) w32((uint32_t)((long)len - ((long)h.match_len + g.match_len)) << 4 | 1u);
                     else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); w32((uint32_t)(gap < 0 ? -gap : gap) << 4 | 2u); }
                     w32((uint32_t)g.match_len << 4);
                 }
@@ -1111,6 +1146,7 @@ int cmd_align(int argc, char **argv, int first)
         std::string berr;
         rc = bk::write_bam_and_bai(opath, stream, aligned, flush_at, (uint32_t)refs.size(), nthreads, &berr);
         if (rc) { diag("Fatal: %s", berr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        write_jct_for_sam();
         diag("Completed reporting BAM %llu read alignments", (unsigned long long)n_rep);
         diag("Reporting of aligned result set completed");
         write_read_subset("j", "na", [](uint8_t nar) { return nar == BK_NAR_NS || nar == BK_NAR_NOHIT; });
@@ -1196,7 +1232,8 @@ int cmd_align(int argc, char **argv, int first)
                 if (clip3) { put_num(rec, clip3); rec.push_back('S'); }
                 if (has_seg2(i)) {                                       // CAligner::ReportBAMread, Aligner.cpp:5986-6033
                     const bk_seg2 &g = seg2[RD(i)];
-                    if (g.flags & 2) { put_num(rec, (long)len - ((long)h.match_len + g.match_len)); rec.push_back('I'); }
+                    if (g.flags & 4) { put_num(rec, (long)g.match_loci - ((long)h.match_loci + h.match_len)); rec.push_back('N'); }
+                    else if (g.flags & 2) { put_num(rec, (long)len - ((long)h.match_len + g.match_len)); rec.push_back('I'); }
                     else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); put_num(rec, gap < 0 ? -gap : gap); rec.push_back('D'); }
                     put_num(rec, g.match_len);
                     rec.push_back('M');
@@ -1269,6 +1306,7 @@ int cmd_align(int argc, char **argv, int first)
             for (auto &t : th) t.join();
             out.pos = at[(size_t)nt];
         }
+        write_jct_for_sam();
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {
         // -M0..3 CSV (loci; 1: + match sequence, 2: + read sequence, 3: + both) and -M4 UCSC BED
@@ -1295,6 +1333,14 @@ int cmd_align(int argc, char **argv, int first)
             int m = snprintf(line, sizeof(line), "track type=bed name=\"IND_%s\" description=\"%s\"\n", title.c_str(), title.c_str());
             ind.put(line, (size_t)m);
         }
+        OutBuf jct;
+        if (fmt == 4 && splice_len) {
+            jct.open((a.str("o") + ".jct").c_str());
+            if (jct.fd < 0) { diag("Fatal: unable to create '%s.jct'", a.str("o").c_str()); bk_ctx_destroy(ctx); return 1; }
+            std::string title = a.str("t", "kanga");
+            int m = snprintf(line, sizeof(line), "track type=bed name=\"JCT_%s\" description=\"%s\"\n", title.c_str(), title.c_str());
+            jct.put(line, (size_t)m);
+        }
         std::string rec;
         for (size_t k = 0; k < nr; k++) {
             uint32_t i = order[k];
@@ -1304,10 +1350,11 @@ int cmd_align(int argc, char **argv, int first)
             if (fmt == 4) {
                 if (two) {
                     const bk_seg2 &g = seg2[RD(i)];
+                    const bool sj = (g.flags & 4) != 0;
                     const uint32_t end1 = g.match_loci + g.match_len;          // AdjAlignEndLoci + 1
-                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tari\t0\t%c\t%u\t%u\t0\t2\t%u,%u\t0,%u\n", ents[h.chrom_id - 1].name, h.match_loci, end1,
-                                     (char)h.strand, h.match_loci, end1, (unsigned)h.match_len, (unsigned)g.match_len, g.match_loci - h.match_loci);
-                    ind.put(line, (size_t)m);
+                    int m = snprintf(line, sizeof(line), "%s\t%u\t%u\t%s\t0\t%c\t%u\t%u\t0\t2\t%u,%u\t0,%u\n", ents[h.chrom_id - 1].name, h.match_loci, end1,
+                                     sj ? "arj" : "ari", (char)h.strand, h.match_loci, end1, (unsigned)h.match_len, (unsigned)g.match_len, g.match_loci - h.match_loci);
+                    (sj ? jct : ind).put(line, (size_t)m);
                 } else {
                     int m = snprintf(line, sizeof(line), "%s\t%u\t%u\tar\t0\t%c\n", ents[h.chrom_id - 1].name, a_start(h, i), a_start(h, i) + a_len(h, i),
                                      (char)h.strand);
@@ -1321,7 +1368,8 @@ int cmd_align(int argc, char **argv, int first)
             for (int sg = 0; sg < (two ? 2 : 1); sg++) {
                 const uint32_t s_loci = sg ? seg2[RD(i)].match_loci : a_start(h, i), s_len = sg ? seg2[RD(i)].match_len : a_len(h, i);
                 const uint32_t s_mm = sg ? seg2[RD(i)].mismatches : a_mm(h, i), s_rofs = sg ? seg2[RD(i)].read_ofs : TL(i);       // ReadOfs + TrimLeft
-                int m = snprintf(line, sizeof(line), "%u,\"%s\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1, two ? "ari" : "ar", species.c_str(),
+                int m = snprintf(line, sizeof(line), "%u,\"%s\",\"%s\",\"%s\",%u,%u,%u,\"%c\",0,0,1,%u,\"N/A\",\"%s\"", i + 1,
+                                 two ? ((seg2[RD(i)].flags & 4) ? "arj" : "ari") : "ar", species.c_str(),
                                  ents[h.chrom_id - 1].name, s_loci, s_loci + s_len - 1, (unsigned)s_len, (char)h.strand, (unsigned)s_mm, rs.name(RD(i)));
                 rec.assign(line, (size_t)m);
                 if (fmt >= 2) {                                          // the read as loaded, from the segment's read offset
@@ -1346,6 +1394,7 @@ int cmd_align(int argc, char **argv, int first)
             n_reported++;
         }
         if (ind.fd >= 0) ind.close();
+        if (jct.fd >= 0) jct.close();
     }
     out.close();
     diag("Reporting of aligned result set completed");

@@ -310,3 +310,17 @@ def test_flank_trim_pe_and_indel(golden_tmp, tmp_path):
         out = str(tmp_path / f"i.{ext}")
         run(["align", "-i", os.path.join(di, "reads.fa"), "-I", os.path.join(di, "genome.sfx"), "-o", out, m, "-a10", "-s3", "-x4"], str(tmp_path))
         _cmp_bytes(out, "indel", f"a10x4.{ext}.gz")
+
+
+# splice junctions (-A; switches -x on): files of tests/golden/splice (make_golden.py:make_splice)
+@pytest.mark.parametrize("tag,flags,exts", [("A5000", ["-A5000", "-s3"], ["m6.sam", "m5.sam", "m0.csv", "m4.bed"]), ("A500s5", ["-A500", "-s5"], ["m6.sam", "m0.csv"]),
+                                            ("A5000a5", ["-A5000", "-a5", "-s3"], ["m6.sam", "m0.csv"])])
+def test_splice_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
+    d = golden_tmp["splice"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    for ext in exts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext]] + flags, str(tmp_path))
+        _cmp_bytes(out, "splice", f"{tag}.{ext}.gz")
+        if ext != "m0.csv":
+            _cmp_bytes(out + ".jct", "splice", f"{tag}.{ext}.jct.gz")
