@@ -541,6 +541,8 @@ int cmd_align(int argc, char **argv, int first)
         best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
         clamp_ml = a.has("X") || best_matches;
     }
+    // -g FASTQ quality scores: only the reference's default (3 = ignore, QUAL printed as '*') is built
+    if (a.has("g") && a.num("g", 3) != 3) { diag("Error: FASTQ quality modes '-g0..2' are not available in this build (qualities are ignored as with the default '-g3')"); return 1; }
     // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned
     const int micro_indel = a.num("a", 0);
     if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
