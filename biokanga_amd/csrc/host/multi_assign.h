@@ -29,6 +29,37 @@ struct MultiHitRec {
 
 struct MultiAssignStats { int putative = 0, assigned = 0, near_unique = 0, near_multi = 0; };
 
+// sort with a strict total order on all host threads: chunks sorted independently, then merged pairwise, round by round
+template <typename T, typename Less>
+inline void par_sort(std::vector<T> &v, Less less, int nthreads)
+{
+    const size_t n = v.size();
+    size_t parts = 1;
+    while (parts * 2 <= (size_t)(nthreads < 1 ? 1 : nthreads) && n / (parts * 2) >= 65536) parts *= 2;
+    if (parts == 1) { std::sort(v.begin(), v.end(), less); return; }
+    std::vector<size_t> cut(parts + 1);
+    for (size_t i = 0; i <= parts; i++) cut[i] = n * i / parts;
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < parts; i++) th.emplace_back([&, i]() { std::sort(v.begin() + (ptrdiff_t)cut[i], v.begin() + (ptrdiff_t)cut[i + 1], less); });
+        std::sort(v.begin(), v.begin() + (ptrdiff_t)cut[1], less);
+        for (auto &t : th) t.join();
+    }
+    std::vector<T> tmp(n);
+    std::vector<T> *src = &v, *dst = &tmp;
+    for (size_t width = 1; width < parts; width *= 2) {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < parts; i += 2 * width) {
+            const size_t a = cut[i], m = cut[std::min(i + width, parts)], b = cut[std::min(i + 2 * width, parts)];
+            th.emplace_back([=, &less]() { std::merge(src->begin() + (ptrdiff_t)a, src->begin() + (ptrdiff_t)m, src->begin() + (ptrdiff_t)m, src->begin() + (ptrdiff_t)b,
+                                                       dst->begin() + (ptrdiff_t)a, less); });
+        }
+        for (auto &t : th) t.join();
+        std::swap(src, dst);
+    }
+    if (src != &v) v.swap(tmp);
+}
+
 class MultiAssign {
 public:
     std::vector<MultiHitRec> recs;
@@ -41,6 +72,7 @@ public:
         MultiAssignStats st;
         if (recs.empty()) return st;
         if (nthreads < 1) nthreads = 1;
+        threads_ = nthreads;
         sort_by_loci();
         // blocks as the clustering threads would claim them (GetClusterStartEnd :4929-4957)
         std::vector<std::pair<size_t, size_t>> blocks;
@@ -64,7 +96,7 @@ public:
             for (auto &t : th) t.join();
         }
         // best scoring locus per read first (:5134-5181)
-        std::sort(recs.begin(), recs.end(), [](const MultiHitRec &a, const MultiHitRec &b) {
+        par_sort(recs, [](const MultiHitRec &a, const MultiHitRec &b) {
             if (a.read_id != b.read_id) return a.read_id < b.read_id;
             if (a.score != b.score) return a.score > b.score;
             if (a.loci.chrom_id != b.loci.chrom_id) return a.loci.chrom_id < b.loci.chrom_id;
@@ -72,7 +104,7 @@ public:
             if (a.loci.mismatches != b.loci.mismatches) return a.loci.mismatches < b.loci.mismatches;
             if (a.loci.match_loci != b.loci.match_loci) return a.loci.match_loci < b.loci.match_loci;
             return a.loci.strand < b.loci.strand;
-        });
+        }, threads_);
         uint32_t cur_read = 0;
         for (size_t i = 0; i < n; i++) {
             MultiHitRec &c = recs[i];
@@ -130,16 +162,18 @@ private:
     static uint32_t start_of(const MultiHitRec &r) { return r.loci.match_loci; }                                   // AdjStartLoci, no trims
     static uint32_t end_of(const MultiHitRec &r) { return r.loci.match_loci + (uint32_t)r.loci.match_len - 1u; }   // AdjEndLoci
 
+    int threads_ = 1;
+
     void sort_by_loci()
     {
-        std::sort(recs.begin(), recs.end(), [](const MultiHitRec &a, const MultiHitRec &b) {
+        par_sort(recs, [](const MultiHitRec &a, const MultiHitRec &b) {
             if (a.loci.chrom_id != b.loci.chrom_id) return a.loci.chrom_id < b.loci.chrom_id;
             if (a.loci.match_loci != b.loci.match_loci) return a.loci.match_loci < b.loci.match_loci;
             if (a.loci.match_len != b.loci.match_len) return a.loci.match_len < b.loci.match_len;
             if (a.loci.mismatches != b.loci.mismatches) return a.loci.mismatches < b.loci.mismatches;
             if (a.loci.strand != b.loci.strand) return a.loci.strand < b.loci.strand;
             return a.read_id < b.read_id;
-        });
+        }, threads_);
     }
 
     // one pass of the neighbour scoring; `cap` = 0x1fff upstream, 0x3fff downstream.  Returns true when the scan can stop.

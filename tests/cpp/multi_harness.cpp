@@ -3,6 +3,8 @@
 // hits.bin: bk_hit records (as bk_align_batch returns them with max_ml > 1), offs.bin: uint64[n+1], loci.bin: bk_loci
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <utility>
 #include <vector>
 #include "../../biokanga_amd/csrc/host/glibc_rand.h"
 #include "../../biokanga_amd/csrc/host/multi_assign.h"
@@ -23,6 +25,18 @@ static std::vector<T> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "sorttest") {          // par_sort against std::sort on pseudo-random keys with many ties
+        const size_t n = (size_t)atol(argv[2]);
+        std::vector<std::pair<uint32_t, uint32_t>> a(n);
+        uint64_t x = 88172645463325252ULL;
+        for (size_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; a[i] = {(uint32_t)(x % 5000), (uint32_t)i}; }
+        auto b = a;
+        auto less = [](const std::pair<uint32_t, uint32_t> &p, const std::pair<uint32_t, uint32_t> &q) { return p < q; };
+        std::sort(b.begin(), b.end(), less);
+        for (int t : {1, 3, 8, 64}) { auto c = a; bk::par_sort(c, less, t); if (c != b) { printf("mismatch at %d threads\n", t); return 1; } }
+        printf("ok\n");
+        return 0;
+    }
     if (argc != 9) return 2;
     const int mode = atoi(argv[1]), threads = atoi(argv[2]);
     const uint32_t max_reads_len = (uint32_t)atoi(argv[3]);

@@ -75,3 +75,8 @@ def test_r1_is_the_plain_result(multi_case):
     hits, lo, loci = _oracle(d, bases, offs, lens, 5)
     hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "multi", "r1R5.m6.sam.gz"))
     check_hits_against_sam(names, lens, hits, recs, chrom_names_from_hdr(hdr), list(range(len(names))))
+
+
+def test_parallel_sort_of_the_clustering(multi_harness):
+    """par_sort (chunks sorted on all threads, merged pairwise) equals std::sort; sized so that the parallel path really runs"""
+    assert subprocess.check_output([multi_harness, "sorttest", "3000000"]).strip() == b"ok"
