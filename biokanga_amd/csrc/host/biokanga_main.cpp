@@ -35,6 +35,7 @@
 #include "glibc_rand.h"
 #include "mtqsort.h"
 #include "multi_assign.h"
+#include "post_filters.h"
 
 namespace {
 
@@ -720,110 +721,9 @@ int cmd_align(int argc, char **argv, int first)
     }
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 5); };       // FlgInDel or FlgSplice
-    // per-record flank trims in READ orientation (tsSegLoci.TrimLeft / TrimRight / TrimMismatches of Seg[0])
-    std::vector<uint16_t> trim_l, trim_r;
-    std::vector<uint8_t> trim_mm;
-    auto TL = [&](size_t i) -> uint32_t { return trim_l.empty() ? 0u : trim_l[i]; };
-    auto TR = [&](size_t i) -> uint32_t { return trim_r.empty() ? 0u : trim_r[i]; };
-    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
-    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
-    auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return trim_mm.empty() ? h.mismatches : trim_mm[i]; };               // TrimMismatches
-    if (min_flank > 0) {
-        // CAligner::AutoTrimFlanks (Aligner.cpp:1608-1800): from each end of the read walk inwards until min_flank consecutive
-        // bases match the target; what lies outside is trimmed.  SE: a read that cannot keep half its length (>= 15) between two
-        // such runs becomes eNARTrim; PE: the walks stop after a third of the read and nothing is eliminated.
-        diag("Starting 5' and 3' flank sequence autotrim processing...");
-        bk::SfxFile sft;
-        std::string serr;
-        if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
-        trim_l.assign(nr, 0); trim_r.assign(nr, 0); trim_mm.resize(nr);
-        for (size_t i = 0; i < nr; i++) trim_mm[i] = hits[i].mismatches;
-        std::vector<size_t> plus((size_t)nthreads, 0), minus((size_t)nthreads, 0);
-        auto work = [&](int w) {
-            std::vector<uint8_t> tg;
-            for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
-                bk_hit &h = hits[i];
-                if (h.nar != BK_NAR_ACCEPTED || has_seg2(i) || h.chrom_id < 1 || h.chrom_id > n_ent) continue;
-                const uint32_t mlen = h.match_len;
-                int min_trimmed = (int)(mlen + 1) / 2;
-                if (min_trimmed < 15) min_trimmed = 15;
-                const uint8_t *rd = rs.bases.data() + rs.offs[RD(i)];
-                const uint8_t *t0 = sft.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci;
-                tg.resize(mlen);
-                for (uint32_t k = 0; k < mlen; k++) {                          // target in read orientation
-                    uint8_t t = h.strand == '-' ? t0[mlen - 1 - k] & 7 : t0[k] & 7;
-                    if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
-                    tg[k] = t;
-                }
-                int exact = 0, tmm = 0;
-                const int core_l = pe_mode ? (int)mlen / 3 : (int)mlen;
-                uint32_t idx;
-                for (idx = 0; idx <= mlen - (uint32_t)min_trimmed && idx < (uint32_t)core_l; idx++) {
-                    if ((rd[idx] & 7) != tg[idx]) { exact = 0; tmm++; continue; }
-                    if (++exact == min_flank) break;
-                }
-                auto eliminate = [&]() { h.num_hits = 0; h.nar = 6; (h.strand == '+' ? plus : minus)[(size_t)w]++; };      // eNARTrim
-                if (!pe_mode && ((idx + (uint32_t)min_trimmed) > mlen || exact < min_flank)) { eliminate(); continue; }
-                const int left = (int)idx - (min_flank - 1);
-                exact = 0;
-                const int core_r = pe_mode ? (int)(mlen * 2) / 3 : 0;
-                for (idx = mlen - 1; idx >= (uint32_t)(left + min_trimmed) && idx > (uint32_t)core_r; idx--) {
-                    if ((rd[idx] & 7) != tg[idx]) { exact = 0; tmm++; continue; }
-                    if (++exact == min_flank) break;
-                }
-                if (!pe_mode && (exact != min_flank || idx < (uint32_t)(left + min_trimmed))) { eliminate(); continue; }
-                const int right = (int)idx + min_flank;
-                trim_l[i] = (uint16_t)left;
-                trim_r[i] = (uint16_t)(mlen - (uint32_t)right);
-                if (left || (mlen - (uint32_t)right)) trim_mm[i] = (uint8_t)(h.mismatches - tmm);
-            }
-        };
-        {
-            std::vector<std::thread> th;
-            for (int w = 1; w < nthreads; w++) th.emplace_back(work, w);
-            work(0);
-            for (auto &t : th) t.join();
-        }
-        size_t np = 0, nm = 0;
-        for (int w = 0; w < nthreads; w++) { np += plus[(size_t)w]; nm += minus[(size_t)w]; }
-        diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", np, nm);
-    }
-    // CAligner::RemoveOrphanSpliceJuncts / RemoveOrphanMicroInDels (Aligner.cpp:2287-2470), in that order: a placement stands only if
-    // another read's junction lies within 3 bases of it on both sides; the others become eNARSpliceJctn / eNARmicroInDel
-    for (int pass = 0; pass < 2; pass++) {
-        const uint8_t want = pass == 0 ? 4 : 1, orphan_nar = pass == 0 ? 7 : 8;
-        if (pass == 0 ? splice_len == 0 : micro_indel == 0) continue;
-        diag(pass == 0 ? "Removal of orphan splice junction processing started.." : "Removal of orphan microInDels processing started..");
-        struct Junct { uint32_t chrom; uint32_t starts, ends; size_t read; };
-        std::vector<Junct> jn;
-        for (size_t i = 0; i < nr; i++)
-            if (hits[i].nar == BK_NAR_ACCEPTED && (seg2[i].flags & want))
-                jn.push_back({hits[i].chrom_id, hits[i].match_loci + hits[i].match_len - 1u, seg2[i].match_loci, i});
-        std::sort(jn.begin(), jn.end(), [](const Junct &x, const Junct &y) {
-            if (x.chrom != y.chrom) return x.chrom < y.chrom;
-            if (x.starts != y.starts) return x.starts < y.starts;
-            return x.ends < y.ends;
-        });
-        std::vector<uint8_t> supported(jn.size(), 0);
-        for (size_t k = 0; k + 1 < jn.size(); k++) {
-            const Junct &x = jn[k], &y = jn[k + 1];
-            if (x.chrom == y.chrom && x.starts <= y.starts + 3u && x.starts >= y.starts - 3u && x.ends <= y.ends + 3u &&
-                x.ends >= y.ends - 3u)                      // UINT32 arithmetic as in tsSegJuncts
-                supported[k] = supported[k + 1] = 1;
-        }
-        size_t n_orphan = 0;
-        for (size_t k = 0; k < jn.size(); k++)
-            if (!supported[k]) {
-                bk_hit &h = hits[jn[k].read];
-                h.nar = orphan_nar;
-                h.num_hits = 0;
-                h.low_hit_instances = 0;
-                n_orphan++;
-            }
-        diag("From %zu reads with putative %s %zu orphans were removed", jn.size(), pass == 0 ? "splice junctions" : "microIndels", n_orphan);
-    }
     if (pe_mode) {
-        // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355)
+        // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355); before the flank trimmer, as in
+        // CAligner::Align (:573-622)
         diag("Paired end association and partner alignment processing started..");
         const size_t kPairs = 8u << 20;
         for (size_t lo = 0; lo < nr / 2; lo += kPairs) {
@@ -834,6 +734,39 @@ int cmd_align(int argc, char **argv, int first)
         size_t n_pe = 0;
         for (size_t i = 0; i < nr; i += 2) n_pe += (hits[i].flags & 0x80) && (hits[i + 1].flags & 0x80);
         diag("From %zu paired reads there were %zu accepted as paired", nr / 2, n_pe);
+    }
+
+    // per-record flank trims in READ orientation (tsSegLoci.TrimLeft / TrimRight / TrimMismatches of Seg[0]), host/post_filters.h
+    bk::FlankTrims trims;
+    auto TL = [&](size_t i) -> uint32_t { return trims.empty() ? 0u : trims.left[i]; };
+    auto TR = [&](size_t i) -> uint32_t { return trims.empty() ? 0u : trims.right[i]; };
+    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
+    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
+    auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return trims.empty() ? h.mismatches : trims.mismatches[i]; };        // TrimMismatches
+    if (min_flank > 0) {
+        diag("Starting 5' and 3' flank sequence autotrim processing...");
+        bk::SfxFile sft;
+        std::string serr;
+        if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        bk::auto_trim_flanks(hits, [&](size_t i) { return has_seg2(i); }, [&](size_t i) { return rs.bases.data() + rs.offs[RD(i)]; },
+                             [&](size_t i) -> const uint8_t * {
+                                 const bk_hit &h = hits[i];
+                                 return (h.chrom_id >= 1 && h.chrom_id <= n_ent) ? sft.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci : nullptr;
+                             },
+                             min_flank, pe_mode != 0, nthreads, trims);
+        diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", trims.removed_plus,
+             trims.removed_minus);
+    }
+    // orphan junction filters, splice junctions first (Aligner.cpp:630-650)
+    if (splice_len) {
+        diag("Removal of orphan splice junction processing started..");
+        auto r = bk::remove_orphan_segs(hits, seg2, 4, 7);
+        diag("From %zu reads with putative splice junctions %zu orphans were removed", r.first, r.second);
+    }
+    if (micro_indel) {
+        diag("Removal of orphan microInDels processing started..");
+        auto r = bk::remove_orphan_segs(hits, seg2, 1, 8);
+        diag("From %zu reads with putative microIndels %zu orphans were removed", r.first, r.second);
     }
 
     // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): NAR histogram
