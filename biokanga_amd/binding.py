@@ -30,11 +30,12 @@ class AlignParams(ctypes.Structure):
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
                 ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32),
-                ("micro_indel_len", ctypes.c_int32), ("splice_junct_len", ctypes.c_int32), ("reserved2", ctypes.c_int32 * 2)]
+                ("micro_indel_len", ctypes.c_int32), ("splice_junct_len", ctypes.c_int32), ("min_chimeric_len", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
     def __init__(self, max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0,
-                 micro_indel_len=0, splice_junct_len=0):
+                 micro_indel_len=0, splice_junct_len=0, min_chimeric_len=0):
         super().__init__()
+        self.min_chimeric_len = min_chimeric_len
         self.splice_junct_len = splice_junct_len
         self.micro_indel_len = micro_indel_len
         self.clamp_ml = clamp_ml

@@ -61,7 +61,9 @@ typedef struct bk_align_params {
                              *     (CSfxArrayV3::LocateInDels); second segments come back through bk_batch_seg2()             */
     int32_t splice_junct_len;/* -A  0, or the longest splice junction (25..100000) looked for in reads still unaligned after that
                              *     (CSfxArrayV3::LocateSpliceJuncts); second segments through bk_batch_seg2(), flags bit 2      */
-    int32_t reserved2[2];
+    int32_t min_chimeric_len;/* -c  0, or 50..99: reads nothing else aligned may be placed end-trimmed, keeping at least this percentage of
+                             *     their length (chimeric form of LocateCoreMultiples); trims through bk_batch_seg2(), flags bit 3 */
+    int32_t reserved2;
 } bk_align_params;
 
 /* per-read result: the tsReadHit fields written by ProcCoredApprox (Aligner.cpp:9311-9479) and
@@ -217,7 +219,8 @@ typedef struct bk_seg2 {
     uint16_t match_len;          /* Seg[1].MatchLen                                               */
     uint16_t read_ofs;           /* Seg[1].ReadOfs: first read base of the second segment        */
     uint8_t  mismatches;         /* Seg[1].Mismatches                                             */
-    uint8_t  flags;              /* bit 0 FlgInDel, bit 1 FlgInsert (gap is in the read), bit 2 FlgSplice; 0 = no second segment */
+    uint8_t  flags;              /* bit 0 FlgInDel, bit 1 FlgInsert (gap is in the read), bit 2 FlgSplice; bit 3 FlgChimeric: no second segment,
+                                  * match_len = Seg[0].TrimLeft, read_ofs = Seg[0].TrimRight (read orientation); 0 = plain hit */
     uint16_t score;              /* tsHitLoci.Score                                               */
 } bk_seg2;
 /* One entry per read of the LAST align call on a context created with micro_indel_len > 0 (host memory owned by the context,

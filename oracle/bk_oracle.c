@@ -272,16 +272,38 @@ typedef struct hit_rec {
     uint32_t match_loci;
     uint16_t match_len;
     uint8_t  mismatches;
+    uint8_t  chimeric;          /* FlgChimeric */
+    uint16_t trim_left, trim_right;   /* Seg[0].TrimLeft / TrimRight (read orientation) */
 } hit_rec;
 
-/* LocateCoreMultiples, SfxArrayV2.cpp:5693-6262 - standard (non chimeric, basespace, non
- * bisulfite) path.  probe is modified in place while the '-' strand is processed and restored. */
+static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
+                            uint32_t min_flank, uint32_t *p_trim_mms, uint32_t *p_trim_start, uint32_t *p_trim_end);
+
+/* LocateCoreMultiples, SfxArrayV2.cpp:5693-6262 - basespace, non bisulfite.  min_chimeric_pct 50..99 selects the chimeric
+ * form (:5959-6080): every candidate is end-trimmed adaptively and the longest (then cleanest) trimmed placement wins.
+ * probe is modified in place while the '-' strand is processed and restored. */
+static int locate_core_multiples_c(const ora_sfx *s, int min_chimeric_pct, int max_tot_mm, int core_len, int core_delta,
+                                   int max_slides, int mm_delta, int align2strand,
+                                   int *p_low_inst, int *p_low_mm, int *p_nxt_low_mm,
+                                   uint8_t *probe, int plen, int max_hits, hit_rec *hits,
+                                   int max_iter, scratch *sc, ora_counters *ctr);
 static int locate_core_multiples(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta,
                                  int max_slides, int mm_delta, int align2strand,
                                  int *p_low_inst, int *p_low_mm, int *p_nxt_low_mm,
                                  uint8_t *probe, int plen, int max_hits, hit_rec *hits,
                                  int max_iter, scratch *sc, ora_counters *ctr)
 {
+    return locate_core_multiples_c(s, 0, max_tot_mm, core_len, core_delta, max_slides, mm_delta, align2strand, p_low_inst, p_low_mm,
+                                   p_nxt_low_mm, probe, plen, max_hits, hits, max_iter, sc, ctr);
+}
+static int locate_core_multiples_c(const ora_sfx *s, int min_chimeric_pct, int max_tot_mm, int core_len, int core_delta,
+                                   int max_slides, int mm_delta, int align2strand,
+                                   int *p_low_inst, int *p_low_mm, int *p_nxt_low_mm,
+                                   uint8_t *probe, int plen, int max_hits, hit_rec *hits,
+                                   int max_iter, scratch *sc, ora_counters *ctr)
+{
+    const uint32_t min_probe_chimeric = (min_chimeric_pct >= 50 && min_chimeric_pct <= 99) ? (uint32_t)((min_chimeric_pct * plen) / 100) : 0;
+    int best_chim_len = 0, best_chim_mm = 0;
     int low_inst, low_mm, nxt_low_mm;
     char cur_strand;
     int64_t sfx_len = (int64_t)s->concat_len;
@@ -363,6 +385,39 @@ static int locate_core_multiples(const ora_sfx *s, int max_tot_mm, int core_len,
                 iter_cnt++;
                 if (ctr) ctr->n_cand++;
 
+                if (min_probe_chimeric > 0) {                                          /* :5959-6080 */
+                    uint32_t tmm = 0, t5 = 0, t3 = 0;
+                    int clen = adaptive_trim_ex((uint32_t)plen, probe, s->seq + left, min_probe_chimeric, (uint32_t)max_tot_mm, 3, &tmm, &t5, &t3);
+                    if (clen < 0) clen = 0;
+                    if (clen < (int)min_probe_chimeric) continue;
+                    const int cmm = (int)tmm;
+                    hit_rec nh;
+                    memset(&nh, 0, sizeof(nh));
+                    if (clen > best_chim_len || (clen == best_chim_len && cmm < best_chim_mm) ||
+                        (clen == best_chim_len && cmm == best_chim_mm)) {
+                        const ora_entry *e2 = map_entry(s, (uint64_t)left + t5);
+                        if (e2 == NULL) e2 = ent;
+                        nh.chimeric = 1; nh.strand = (uint8_t)cur_strand;
+                        nh.trim_left = (uint16_t)(cur_strand == '+' ? t5 : t3); nh.trim_right = (uint16_t)(cur_strand == '+' ? t3 : t5);
+                        nh.chrom_id = e2->entry_id; nh.match_loci = (uint32_t)((uint64_t)left - e2->start_ofs);
+                        nh.match_len = (uint16_t)plen; nh.mismatches = (uint8_t)cmm;
+                    }
+                    if (clen > best_chim_len || (clen == best_chim_len && cmm < best_chim_mm)) {
+                        if (best_chim_len > 0 && clen > best_chim_len) low_mm = cmm + mm_delta + 1;
+                        best_chim_len = clen; best_chim_mm = cmm;
+                        cur_hit = 0;
+                        low_inst = 1;
+                        nxt_low_mm = low_mm;
+                        low_mm = cmm;
+                        hits[0] = nh;
+                    } else if (clen == best_chim_len && cmm == best_chim_mm) {
+                        low_inst += 1;
+                        if (cur_hit >= 0 && low_inst <= max_hits) hits[++cur_hit] = nh;
+                    } else if (clen == best_chim_len && cmm < nxt_low_mm)
+                        nxt_low_mm = cmm;
+                    if (clen == plen && low_inst > max_hits && low_mm == 0) break;
+                    continue;
+                }
                 /* Hamming extension over the whole read with the reference's early exits,
                  * :6085-6154 */
                 const uint8_t *t = s->seq + left;
@@ -1089,7 +1144,8 @@ static int locate_splice_juncts(const ora_sfx *s, int max_junct, int max_tot_mm,
 static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_delta, int max_slides,
                        int mm_delta, int align2strand, int *p_low_inst, int *p_low_mm, int *p_nxt,
                        uint8_t *probe, int plen, int max_hits, hit_rec *hits, int max_iter,
-                       scratch *sc, ora_counters *ctr, int micro_indel_len, int splice_junct_len, indel_hit *ih, int *got_indel)
+                       scratch *sc, ora_counters *ctr, int micro_indel_len, int splice_junct_len, indel_hit *ih, int *got_indel,
+                       int min_chimeric_pct, int min_core_len)
 {
     int rslt = 0, allow_mm;
     if (max_tot_mm > 0) {
@@ -1120,6 +1176,13 @@ static int align_reads(const ora_sfx *s, int max_tot_mm, int core_len, int core_
         rslt = locate_splice_juncts(s, splice_junct_len, max_tot_mm > MAX_JUNCT_ALIGN_MM ? MAX_JUNCT_ALIGN_MM : max_tot_mm, splice_core,
                                     align2strand, p_low_inst, p_low_mm, p_nxt, probe, plen, ih, max_iter, ctr);
         if (rslt != 0) { *got_indel = 1; return rslt; }
+    }
+    if (min_chimeric_pct > 0) {                                                        /* :7750-7757 */
+        int cl = min_core_len > plen / (max_tot_mm + 4) ? min_core_len : plen / (max_tot_mm + 4);
+        int cd = max_slides > 1 ? plen / (max_slides - 1) : plen;
+        if (cd < cl) cd = cl;
+        return locate_core_multiples_c(s, min_chimeric_pct, max_tot_mm, cl, cd, max_slides, mm_delta, align2strand, p_low_inst, p_low_mm, p_nxt,
+                                       probe, plen, max_hits, hits, max_iter, sc, ctr);
     }
     return 0;
 }
@@ -1202,7 +1265,8 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
     } else
         rslt = align_reads(s, max_tot_mm, core_len, core_delta, max_slides, p->min_edit_dist, align2strand,
                            &low_inst, &low_mm, &nxt, seqbuf, match_len, max_ml, hits,
-                           ora_max_iter(p->pmode), sc, ctr, p->micro_indel_len, p->splice_junct_len, &ih, &got_indel);
+                           ora_max_iter(p->pmode), sc, ctr, p->micro_indel_len, p->splice_junct_len, &ih, &got_indel,
+                           p->min_chimeric_len, min_core);
     if (got_indel && rslt == HR_HITS) {            /* the one tsHitLoci LocateInDels returned -> pMultiHits[0] */
         hits[0].strand = (uint8_t)ih.strand; hits[0].chrom_id = ih.s0_chrom; hits[0].match_loci = (uint32_t)ih.s0_loci;
         hits[0].match_len = (uint16_t)ih.s0_len; hits[0].mismatches = (uint8_t)ih.s0_mm;
@@ -1214,6 +1278,9 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
         }
     }
     if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }
+    if (!got_indel && rslt == HR_HITS && hits[0].chimeric && seg2_out) {                /* trims of a chimeric placement travel in the seg2 record */
+        seg2_out->flags = 8; seg2_out->match_len = hits[0].trim_left; seg2_out->read_ofs = hits[0].trim_right;
+    }
     if (low_inst > max_ml) low_inst = max_ml + 1;                                       /* :9241 */
     out->rslt = (uint8_t)rslt;
     if (loci_out && (rslt == HR_HITS || (rslt == HR_HITINSTS && p->clamp_ml)))
@@ -1387,11 +1454,20 @@ static int pe_insert_size(int min_len, int max_len, int pair_strand, uint8_t s1,
 typedef struct at_region { uint16_t ofs, len; uint8_t mm, trim5, trim3; } at_region;
 
 /* AdaptiveTrim, SfxArrayV2.cpp:5482-5682 */
+static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
+                            uint32_t min_flank, uint32_t *p_trim_mms, uint32_t *p_trim_start, uint32_t *p_trim_end);
 static int adaptive_trim(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
                          uint32_t min_flank, uint32_t *p_trim_mms)
 {
+    uint32_t a, b;
+    return adaptive_trim_ex(seq_len, probe, targ, min_trim_len, max_mm, min_flank, p_trim_mms, &a, &b);
+}
+static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
+                            uint32_t min_flank, uint32_t *p_trim_mms, uint32_t *p_trim_start, uint32_t *p_trim_end)
+{
     static __thread at_region regs[2048];
-    *p_trim_mms = 0;
+    uint32_t best_start = 0, best_end = 0;
+    *p_trim_mms = 0; *p_trim_start = 0; *p_trim_end = 0;
     if (seq_len < 25 || seq_len > 2048 || min_trim_len < 15 || min_trim_len > seq_len || max_mm > 15 || min_flank > 10)
         return -100;
     if (min_flank == 0) min_flank = 1;
@@ -1431,6 +1507,7 @@ static int adaptive_trim(uint32_t seq_len, const uint8_t *probe, const uint8_t *
                 cur_mm += r->len;
                 if ((max_mm + 1.0) / 100.0 <= (double)cur_mm / (seq_len - sr->ofs)) break;
             } else if (best_len == 0) {
+                best_start = sr->ofs; best_end = seq_len - (best_start + cur_len);
                 best_len = cur_len; best_mm = 0;
                 r++;
                 continue;
@@ -1438,10 +1515,13 @@ static int adaptive_trim(uint32_t seq_len, const uint8_t *probe, const uint8_t *
             if (cur_len < min_trim_len || !r->trim3) { r++; continue; }
             r++;
             if ((max_mm + 1.0) / 100.0 <= (double)cur_mm / cur_len) continue;
-            if (best_len < cur_len || (best_len == cur_len && (best_mm == 0 || cur_mm < best_mm))) { best_len = cur_len; best_mm = cur_mm; }
+            if (best_len < cur_len || (best_len == cur_len && (best_mm == 0 || cur_mm < best_mm))) {
+                best_start = sr->ofs; best_end = seq_len - (best_start + cur_len);
+                best_len = cur_len; best_mm = cur_mm;
+            }
         }
     }
-    if (best_len >= min_trim_len) { *p_trim_mms = best_mm; return (int)best_len; }
+    if (best_len >= min_trim_len) { *p_trim_mms = best_mm; *p_trim_start = best_start; *p_trim_end = best_end; return (int)best_len; }
     return 0;
 }
 

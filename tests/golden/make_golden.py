@@ -857,12 +857,74 @@ def make_splice(tmp):
             print("  ran", tag, fmt, flags)
 
 
+def make_chimeric(tmp):
+    """chimeric trimming (-c): reads whose 5' and / or 3' end (10..45 bases) comes from elsewhere (random bases or another place of
+    the genome), with 0-2 substitutions in the genuine part, among ordinary reads; -c50, -c70 in SAM / BAM / CSV / BED"""
+    rng = np.random.default_rng(2718)
+    outdir = os.path.join(HERE, "chimeric")
+    os.makedirs(outdir, exist_ok=True)
+    g = [rand_seq(rng, 50000), rand_seq(rng, 30000)]
+    # a duplicated region so that some chimeric placements are ambiguous
+    g[1] = g[1][:5000] + g[0][7000:7400] + g[1][5400:]
+    fa = os.path.join(tmp, "chim.fa")
+    write_fasta(fa, [("cA", g[0]), ("cB", g[1])])
+    reads = []
+    for i in range(500):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 100))
+        if i < 40:
+            c, p = 0, 7000 + int(rng.integers(0, 300))
+        core = mutate(rng, g[c][p:p + 100], int(rng.integers(0, 3)))
+        k5 = int(rng.integers(10, 46)) if rng.integers(0, 3) else 0
+        k3 = int(rng.integers(10, 46)) if (rng.integers(0, 3) == 0 or k5 == 0) else 0
+        if k5 + k3 > 55:
+            k3 = 0
+        def foreign(k):
+            if rng.integers(0, 2):
+                return rand_seq(rng, k)
+            c2 = int(rng.integers(0, 2)); q = int(rng.integers(0, len(g[c2]) - k))
+            return g[c2][q:q + k]
+        s = foreign(k5) + core[k5:100 - k3] + foreign(k3)
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"c{i}_{k5}_{k3}", s))
+    for i in range(300):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 100))
+        s = mutate(rng, g[c][p:p + 100], int(rng.integers(0, 5)))
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"n{i}", s))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "chim_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "chim.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "chim", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags in (("c50", ["-c50", "-s3"]), ("c70s5", ["-c70", "-s5"]), ("c60e2", ["-c60", "-s3", "-e2"])):
+        for fmt, ext in (("-M6", "m6.sam"), ("-M5", "m5.sam"), ("-M0", "m0.csv"), ("-M3", "m3.csv"), ("-M4", "m4.bed")):
+            if tag != "c50" and fmt not in ("-M6", "-M0"):
+                continue
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-T4"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            print("  ran", tag, fmt, flags)
+    bam = os.path.join(tmp, "c50.m6.bam")
+    run([REF, "align", "-i", rd, "-I", sfx, "-o", bam, "-M6", "-T4", "-c50", "-s3"], tmp)
+    shutil.copyfile(bam, os.path.join(outdir, "c50.m6.bam"))
+    shutil.copyfile(bam + ".bai", os.path.join(outdir, "c50.m6.bam.bai"))
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-chimeric" in sys.argv:
+            make_chimeric(tmp)
             return
         if "--only-splice" in sys.argv:
             make_splice(tmp)
@@ -911,6 +973,7 @@ def main():
         make_indel(tmp)
         make_trim(tmp)
         make_splice(tmp)
+        make_chimeric(tmp)
     print("done")
 
 

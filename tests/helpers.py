@@ -22,7 +22,7 @@ class OraParams(ctypes.Structure):
                 ("align_strand", ctypes.c_int32), ("pmode", ctypes.c_int32),
                 ("max_ns", ctypes.c_int32), ("max_ml", ctypes.c_int32),
                 ("clamp_ml", ctypes.c_int32), ("best_matches", ctypes.c_int32),
-                ("micro_indel_len", ctypes.c_int32), ("splice_junct_len", ctypes.c_int32), ("reserved2", ctypes.c_int32 * 2)]
+                ("micro_indel_len", ctypes.c_int32), ("splice_junct_len", ctypes.c_int32), ("min_chimeric_len", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
@@ -38,8 +38,9 @@ class OraCounters(ctypes.Structure):
 
 
 def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1, max_ml=1, clamp_ml=0, best_matches=0, micro_indel_len=0,
-                splice_junct_len=0, cls=OraParams):
+                splice_junct_len=0, min_chimeric_len=0, cls=OraParams):
     p = cls()
+    p.min_chimeric_len = min_chimeric_len
     p.splice_junct_len = splice_junct_len
     p.micro_indel_len = micro_indel_len
     p.clamp_ml = clamp_ml
