@@ -56,6 +56,9 @@ void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
                  uint32_t n_list, uint32_t *cursor, unsigned long long *cnt, bk_loci *dense, hipStream_t s);
 void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, uint32_t *list,
                   uint32_t *list_cnt_dev, uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
+void launch_unaligned_list(const bk_hit *out, uint32_t n, uint32_t *list, uint32_t *cnt, hipStream_t s);
+void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+                     int min_pct, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
                         hipStream_t s);
@@ -163,6 +166,7 @@ int derive_cfg(bk_ctx *c)
     if (p.best_matches && p.max_ml < 2) return BK_ERR_PARAMS;
     if (p.micro_indel_len < 0 || p.micro_indel_len > 20) return BK_ERR_PARAMS;           // cMaxMicroInDelLen
     if (p.micro_indel_len && p.max_ml > 1) return BK_ERR_PARAMS;                         // kanga.cpp:706-710 (and MaxHits is 1 in LocateInDels)
+    if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99 || p.max_ml > 1)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
     if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000 || p.max_ml > 1)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
@@ -759,22 +763,43 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         cur ^= 1;
         if (phase > 70) return BK_ERR_INTERNAL;
     }
-    if (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0) {
-        // AlignReads' microInDel branch for what is still unaligned (SfxArrayV2.cpp:7722-7734)
+    if (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0 || c->params.min_chimeric_len > 0) {
+        // AlignReads' branches for what is still unaligned (SfxArrayV2.cpp:7722-7757): microInDels, then splice junctions, then the
+        // chimeric (end-trimmed) placement
         hipEvent_t ei = tm.begin(s);
         bk_seg2 *d_seg2 = nullptr;
         HIP_TRY(hipMalloc(&d_seg2, (size_t)n * sizeof(bk_seg2)));
         hipError_t eh = hipMemsetAsync(d_seg2, 0, (size_t)n * sizeof(bk_seg2), s);
-        if (eh == hipSuccess) eh = hipMemsetAsync(sm, 0, 16 * 4, s);
-        if (eh == hipSuccess) {
-            launch_indel(c->ix, c->cfg, b, n, c->params.micro_indel_len, c->params.splice_junct_len, c->d_act[0], sm + 0, hm + 0, sm + 1, d_seg2, s);
-            eh = hipGetLastError();
+        int rc2 = BK_OK;
+        if (eh == hipSuccess && (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0)) {
+            eh = hipMemsetAsync(sm, 0, 16 * 4, s);
+            if (eh == hipSuccess) {
+                launch_indel(c->ix, c->cfg, b, n, c->params.micro_indel_len, c->params.splice_junct_len, c->d_act[0], sm + 0, hm + 0, sm + 1, d_seg2, s);
+                eh = hipGetLastError();
+            }
+        }
+        if (eh == hipSuccess && c->params.min_chimeric_len > 0) {
+            if (maxlen > 512) rc2 = BK_ERR_PARAMS;                 // the device AdaptiveTrim keeps a 512-base mismatch map per lane
+            else rc2 = size_heavy_scratch(c);
+            if (rc2 == BK_OK) {
+                eh = hipMemsetAsync(sm, 0, 16 * 4, s);
+                if (eh == hipSuccess) {
+                    launch_unaligned_list(b.out, n, c->d_act[0], sm + 0, s);
+                    eh = hipMemcpyAsync(hm, sm, 4, hipMemcpyDeviceToHost, s);
+                }
+                if (eh == hipSuccess) eh = hipStreamSynchronize(s);
+                if (eh == hipSuccess && hm[0]) {
+                    launch_chimeric(c->ix, c->cfg, b, c->hs, c->d_act[0], hm[0], c->params.min_chimeric_len, sm + 1, d_seg2, s);
+                    eh = hipGetLastError();
+                }
+            }
         }
         const size_t at = c->seg2.size();
         c->seg2.resize(at + n);
-        if (eh == hipSuccess) eh = hipMemcpyAsync(c->seg2.data() + at, d_seg2, (size_t)n * sizeof(bk_seg2), hipMemcpyDeviceToHost, s);
+        if (eh == hipSuccess && rc2 == BK_OK) eh = hipMemcpyAsync(c->seg2.data() + at, d_seg2, (size_t)n * sizeof(bk_seg2), hipMemcpyDeviceToHost, s);
         if (eh == hipSuccess) eh = hipStreamSynchronize(s);
         free_dev(d_seg2);
+        if (rc2 != BK_OK) return rc2;
         if (eh != hipSuccess) return BK_ERR_INTERNAL;
         tm.end(2, ei, s);
     }

@@ -1916,6 +1916,94 @@ __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_
     for (; i < n; i += stride) isa[sa[i]] = (uint32_t)i;
 }
 
+// CSfxArrayV3::AdaptiveTrim (SfxArrayV2.cpp:5482-5682) for one candidate: the longest stretch of the read that starts and ends in a
+// run of >= min_flank matching bases, is at least min_trim long and stays under (max_mm + 1) % mismatches - counting, as the
+// reference does, every base of a mismatching run against the length from the stretch's start (first test) and against the
+// stretch itself (second test), in double precision.  The reference keeps a table of match / mismatch runs; here the runs are
+// read off a bitmap of the mismatching positions (bit i of word i / 64), so a lane needs 8 words for reads of up to 512 bases.
+constexpr int kATWords = 8;
+
+__device__ __forceinline__ int at_run_end(const uint64_t (&bm)[kATWords], int p, int n)    // first q > p with bit(q) != bit(p), or n
+{
+    const int bit = (int)((bm[p >> 6] >> (p & 63)) & 1);
+    int w = p >> 6;
+    uint64_t x = (bit ? ~bm[w] : bm[w]) >> (p & 63);
+    if (x) { const int q = p + (__ffsll((unsigned long long)x) - 1); return q < n ? q : n; }
+    for (w++; w < kATWords && (w << 6) < n; w++) {
+        x = bit ? ~bm[w] : bm[w];
+        if (x) { const int q = (w << 6) + (__ffsll((unsigned long long)x) - 1); return q < n ? q : n; }
+    }
+    return n;
+}
+
+// returns the trimmed length (0 = nothing acceptable); trim5 / trim3 = bases cut from the start / end of the read as given
+__device__ int adaptive_trim_dev(const uint64_t *__restrict__ rdw, const uint64_t *__restrict__ tgt, uint64_t t, int len, int min_trim, int max_mm,
+                                 int min_flank, int &trim_mm, int &trim5, int &trim3)
+{
+    trim_mm = 0; trim5 = 0; trim3 = 0;
+    if (len < 25 || len > 64 * kATWords || min_trim < 15 || min_trim > len || max_mm > 15 || min_flank > 10) return 0;
+    if (min_flank == 0) min_flank = 1;
+    uint64_t bm[kATWords];
+#pragma unroll
+    for (int w = 0; w < kATWords; w++) bm[w] = 0;
+    for (int i = 0; i < len; i += 16) {
+        const int nv = len - i < 16 ? len - i : 16;
+        const uint64_t x = (nib16(rdw, i) ^ nib16(tgt, t + i)) & top_mask(nv);
+        const uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+        bm[i >> 6] |= (uint64_t)flags_to_bits16(f) << (i & 63);            // bit k of the 16 = base i + k mismatches
+    }
+    // pass 1: is there an exact run of >= 8; first / last run that may start a stretch, last run that may end one
+    bool have8 = false;
+    int first_start = -1, last_start = -1, last_end = -1, first_end = -1;
+    for (int p = 0; p < len;) {
+        const int q = at_run_end(bm, p, len), rl = q - p;
+        const bool mm = ((bm[p >> 6] >> (p & 63)) & 1) != 0;
+        if (!mm) {
+            if (rl >= 8) have8 = true;
+            if (rl >= min_flank) {
+                if (p <= len - min_trim) { last_start = p; if (first_start < 0) first_start = p; }
+                if (p + rl >= min_trim) { last_end = p; if (first_end < 0) first_end = p; }
+            }
+        }
+        p = q;
+    }
+    if (!have8 || first_start < 0 || first_end < 0) return 0;
+    const double lim = (max_mm + 1.0) / 100.0;
+    int best_len = 0, best_mm = 0, best_start = 0, best_end = 0;
+    for (int sp = first_start; sp <= last_start;) {
+        const int sq = at_run_end(bm, sp, len);
+        const bool smm = ((bm[sp >> 6] >> (sp & 63)) & 1) != 0;
+        const bool can_start = !smm && (sq - sp) >= min_flank && sp <= len - min_trim;
+        if (can_start) {
+            int cur_len = 0, cur_mm = 0;
+            for (int p = sp; p < len && p <= last_end;) {
+                const int q = at_run_end(bm, p, len), rl = q - p;
+                const bool mm = ((bm[p >> 6] >> (p & 63)) & 1) != 0;
+                const bool can_end = !mm && rl >= min_flank && p + rl >= min_trim;
+                cur_len += rl;
+                p = q;
+                if (mm) {
+                    if (max_mm == 0) break;
+                    cur_mm += rl;
+                    if (lim <= (double)cur_mm / (double)(len - sp)) break;
+                } else if (best_len == 0) {
+                    best_start = sp; best_end = len - (sp + cur_len); best_len = cur_len; best_mm = 0;
+                    continue;
+                }
+                if (cur_len < min_trim || !can_end) continue;
+                if (lim <= (double)cur_mm / (double)cur_len) continue;
+                if (best_len < cur_len || (best_len == cur_len && (best_mm == 0 || cur_mm < best_mm))) {
+                    best_start = sp; best_end = len - (sp + cur_len); best_len = cur_len; best_mm = cur_mm;
+                }
+            }
+        }
+        sp = sq;
+    }
+    if (best_len < min_trim) return 0;
+    trim_mm = best_mm; trim5 = best_start; trim3 = best_end;
+    return best_len;
+}
+
 // ------------------------------------------------------------------------------------------------
 // general wave-per-read form of one LocateCoreMultiples call
 
@@ -1945,7 +2033,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                                                const unsigned long long *__restrict__ loci_offs, bk_loci *__restrict__ loci_out,
                                                uint32_t *__restrict__ enum_err)
 {
-    constexpr bool ENUM = MODE == 1, BEST = MODE == 2;
+    constexpr bool ENUM = MODE == 1, BEST = MODE == 2, CHIM = MODE == 3;
     __shared__ LdsEntries s_le;
     __shared__ uint32_t s_hist[BEST ? 4 : 1][64], s_pre[BEST ? 4 : 1][64], s_run[BEST ? 4 : 1][64];
     __shared__ bk_loci s_first[BEST ? 4 : 1];
@@ -1997,6 +2085,17 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         }
         if (BEST) phase = p.n_phases - 1;                 // the caller's own MaxTotMM / CoreLen / CoreDelta
         phase_params(p, cfg, phase, mm, cl, cd);
+        // CHIM (`-c`, AlignReads :7750-7757): the last call, with shorter cores; a placement is a candidate trimmed at its ends by
+        // AdaptiveTrim to at least min_chimeric_len % of the read; longest first, then fewest mismatches (:5959-6080)
+        int chim_min = 0, chim_best_len = 0, chim_best_mm = 0, chim_t5 = 0, chim_t3 = 0;
+        if (CHIM) {
+            phase = p.n_phases;
+            mm = p.max_tot_mm;
+            cl = len / (mm + 4) > cfg.min_core_len ? len / (mm + 4) : cfg.min_core_len;
+            cd = p.max_slides > 1 ? len / (p.max_slides - 1) : len;
+            if (cd < cl) cd = cl;
+            chim_min = (phase_arg * len) / 100;            // phase_arg carries the percentage
+        }
         n_lcm++;
         const int init = mm + cfg.mm_delta + 1;
         int low_inst = 0, low_mm = init, nxt = init;
@@ -2095,6 +2194,39 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     bool proc = active && j < cutoff && isnew;
                     if (proc) htab_insert(tab, tmask, epoch, key);
                     int cm = 127;
+                    if (CHIM) {
+                        int c_len = 0, c_mm = 0, c_t5 = 0, c_t3 = 0, e2 = -1;
+                        if (proc) {
+                            c_len = adaptive_trim_dev(rdw, ix.tgt4, t, len, chim_min, mm, 3, c_mm, c_t5, c_t3);
+                            if (c_len < chim_min) c_len = 0;
+                            if (c_len) { e2 = find_entry_lds(s_le, ix, t + (uint64_t)c_t5); if (e2 < 0) e2 = e; }
+                        }
+                        const uint32_t np = (uint32_t)__popcll(__ballot(proc));
+                        iter += np;
+                        nodes += np;
+                        n_cand += (lane == 0) ? np : 0;
+                        uint64_t hm = __ballot(c_len > 0);
+                        while (hm && !done) {                       // in suffix-array order, as the reference meets them
+                            const int src = __ffsll((unsigned long long)hm) - 1;
+                            hm &= hm - 1;
+                            const int l2 = __shfl(c_len, src), m2 = __shfl(c_mm, src);
+                            if (l2 > chim_best_len || (l2 == chim_best_len && m2 < chim_best_mm)) {
+                                if (chim_best_len > 0 && l2 > chim_best_len) low_mm = m2 + cfg.mm_delta + 1;
+                                chim_best_len = l2; chim_best_mm = m2;
+                                low_inst = 1;
+                                nxt = low_mm;
+                                low_mm = m2;
+                                hit_left = __shfl(t, src); hit_ent = __shfl(e2, src); hit_strand = st ? '-' : '+';
+                                chim_t5 = __shfl(c_t5, src); chim_t3 = __shfl(c_t3, src);
+                            } else if (l2 == chim_best_len && m2 == chim_best_mm)
+                                low_inst++;
+                            else if (l2 == chim_best_len && m2 < nxt)
+                                nxt = m2;
+                            if (l2 == len && low_inst > cfg.max_hits && low_mm == 0) done = true;
+                        }
+                        if (cutoff < j0 + 64) break;
+                        continue;
+                    }
                     if (BEST) {
                         if (proc) cm = hamming_eos(rdw, len, ix.tgt4, t, pass ? best_t : mm);
                         const bool hit = cm != 127;
@@ -2206,6 +2338,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     }
                     if (cutoff < j0 + 64) break;                    // core abandoned / iteration limit
                 }
+                if (CHIM && low_inst > cfg.max_hits && low_mm == 0) done = true;        // :6206-6213
                 ci++;
                 o += cur;
             }
@@ -2235,8 +2368,16 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
         if (rslt != BK_HR_NONE) {
-            if (lane == 0)
+            if (lane == 0) {
                 write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand, (phase << 1) | 1);
+                if (CHIM && rslt == BK_HR_HITS && low_inst == 1) {          // Seg[0].TrimLeft / TrimRight in read orientation (:6027-6036)
+                    bk_seg2 g;
+                    g.match_loci = 0; g.mismatches = 0; g.score = 0; g.flags = 8;
+                    g.match_len = (uint16_t)(hit_strand == '+' ? chim_t5 : chim_t3);
+                    g.read_ofs = (uint16_t)(hit_strand == '+' ? chim_t3 : chim_t5);
+                    reinterpret_cast<bk_seg2 *>(loci_out)[r] = g;
+                }
+            }
         } else if (phase + 1 < p.n_phases) {
             int mm2, cl2, cd2, dummy[1];
             phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
@@ -2662,6 +2803,11 @@ __global__ void __launch_bounds__(256) k_unaligned_list(const bk_hit *__restrict
     if (r >= n) return;
     const bk_hit h = out[r];
     if (h.nar == BK_NAR_NOHIT && h.rslt == BK_HR_NONE) list[atomicAdd(cnt, 1u)] = r;
+}
+
+void launch_unaligned_list(const bk_hit *out, uint32_t n, uint32_t *list, uint32_t *cnt, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_unaligned_list, dim3((n + 255) / 256), dim3(256), 0, s, out, n, list, cnt);
 }
 
 void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, uint32_t *list,
@@ -3228,6 +3374,17 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     unsigned blocks = (waves + 3) / 4;
     if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((k_heavy<false, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
+}
+
+// -c: the chimeric LocateCoreMultiples call for every read of `list` (reads nothing else aligned); trims into seg2[]
+void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+                     int min_pct, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
+{
+    if (!n_list) return;
+    uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
+    unsigned blocks = (waves + 3) / 4;
+    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 3>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr);
+    else hipLaunchKernelGGL((k_heavy<false, 3>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr);
 }
 
 // -N: LocateBestMatches for every read of `list`; cnt[r] = loci kept, dense[r * MaxHits ..] = the loci

@@ -549,3 +549,30 @@ def test_micro_indels_match_oracle(golden_tmp, fixture, kw):
         assert np.count_nonzero(eseg["flags"] & 1) > 50 or kw["max_subs"] == 0
     if fixture == "splice" and kw.get("splice_junct_len", 0) >= 500 and kw["max_subs"] >= 3:
         assert np.count_nonzero(eseg["flags"] & 4) > 50
+
+
+@pytest.mark.parametrize("kw", [dict(max_subs=3, min_chimeric_len=50), dict(max_subs=5, min_chimeric_len=70), dict(max_subs=3, min_chimeric_len=60, min_edit_dist=2),
+                                dict(max_subs=3, min_chimeric_len=99, align_strand=1), dict(max_subs=1, min_chimeric_len=50, align_strand=2),
+                                dict(max_subs=3, min_chimeric_len=55, micro_indel_len=6, splice_junct_len=3000)])
+@pytest.mark.parametrize("fixture", ["chimeric", "basic", "indel", "splice"])
+def test_chimeric_placements_match_oracle(golden_tmp, fixture, kw):
+    """-c: the chimeric LocateCoreMultiples call (AdaptiveTrim per candidate) - result records and the trims carried in bk_seg2 -
+    against the oracle, which is pinned on the reference's -c output"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3")
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, eseg = helpers.oracle_align_indel(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    sfx.close()
+    for knobs in ([], [("chunk_reads", 150)], [("use_wave", 0)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs[keep], lens[keep])
+            seg = al.batch_seg2()
+        assert_hits_equal(got, exp, [names[i] for i in keep])
+        for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score"):
+            if not np.array_equal(seg[f], eseg[f]):
+                i = int(np.nonzero(seg[f] != eseg[f])[0][0])
+                raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
+    if fixture == "chimeric" and kw["min_chimeric_len"] <= 70 and kw["max_subs"] >= 3:
+        assert np.count_nonzero(eseg["flags"] & 8) > 100
