@@ -500,8 +500,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxA", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAc", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -556,6 +556,10 @@ int cmd_align(int argc, char **argv, int first)
     if (splice_len && ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
     if (splice_len && pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", splice_len, pe_mode); return 1; }
     if (splice_len && ml_mode) { diag("Error: splice junctions '-A%d' together with '-r%d' are not available in this build", splice_len, ml_mode); return 1; }
+    // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
+    const int min_chim = a.num("c", 0);
+    if (min_chim != 0 && (min_chim < 50 || min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", min_chim < 0 ? -min_chim : min_chim); return 1; }
+    if (min_chim && (ml_mode || pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", min_chim, ml_mode, pe_mode); return 1; }
     int min_flank = a.num("x", 0);
     if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
     if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
@@ -566,7 +570,8 @@ int cmd_align(int argc, char **argv, int first)
     P.align_strand = a.num("Q", 0);
     P.min_edit_dist = a.num("e", 1);
     P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
-    if (splice_len > 0 && min_flank == 0) min_flank = P.max_subs;      // MinFlankExacts = MaxSubs (kanga.cpp:810-811)
+    if (splice_len > 0 && min_chim == 0 && min_flank == 0) min_flank = P.max_subs;      // MinFlankExacts = MaxSubs (kanga.cpp:810-811)
+    P.min_chimeric_len = min_chim;
     P.max_ns = a.num("n", 1);
     P.max_ml = max_ml;
     P.clamp_ml = clamp_ml ? 1 : 0;
@@ -622,7 +627,7 @@ int cmd_align(int argc, char **argv, int first)
         size_t n = std::min(kBatch, nr - lo);
         rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-        if (micro_indel || splice_len) {
+        if (micro_indel || splice_len || min_chim) {
             const bk_seg2 *bs = nullptr;
             uint64_t ns = 0;
             rc = bk_batch_seg2(ctx, &bs, &ns);
@@ -743,12 +748,13 @@ int cmd_align(int argc, char **argv, int first)
     auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
     auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
     auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return trims.empty() ? h.mismatches : trims.mismatches[i]; };        // TrimMismatches
+    auto is_chimeric = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 8); };     // FlgChimeric: trims come with the hit
     if (min_flank > 0) {
         diag("Starting 5' and 3' flank sequence autotrim processing...");
         bk::SfxFile sft;
         std::string serr;
         if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
-        bk::auto_trim_flanks(hits, [&](size_t i) { return has_seg2(i); }, [&](size_t i) { return rs.bases.data() + rs.offs[RD(i)]; },
+        bk::auto_trim_flanks(hits, [&](size_t i) { return has_seg2(i) || is_chimeric(i); }, [&](size_t i) { return rs.bases.data() + rs.offs[RD(i)]; },
                              [&](size_t i) -> const uint8_t * {
                                  const bk_hit &h = hits[i];
                                  return (h.chrom_id >= 1 && h.chrom_id <= n_ent) ? sft.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci : nullptr;
@@ -756,6 +762,17 @@ int cmd_align(int argc, char **argv, int first)
                              min_flank, pe_mode != 0, nthreads, trims);
         diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", trims.removed_plus,
              trims.removed_minus);
+    }
+    if (min_chim) {
+        // chimeric placements keep the trims AdaptiveTrim found (ProcCoredApprox :9292-9299); the flank trimmer leaves them alone (:1641)
+        if (trims.empty()) {
+            trims.left.assign(nr, 0); trims.right.assign(nr, 0); trims.mismatches.resize(nr);
+            for (size_t i = 0; i < nr; i++) trims.mismatches[i] = hits[i].mismatches;
+        }
+        size_t n_ch = 0;
+        for (size_t i = 0; i < nr; i++)
+            if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) { trims.left[i] = seg2[RD(i)].match_len; trims.right[i] = seg2[RD(i)].read_ofs; n_ch++; }
+        diag("Of the accepted aligned reads, %zu were chimeric", n_ch);
     }
     // orphan junction filters, splice junctions first (Aligner.cpp:630-650)
     if (splice_len) {

@@ -324,3 +324,22 @@ def test_splice_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
         _cmp_bytes(out, "splice", f"{tag}.{ext}.gz")
         if ext != "m0.csv":
             _cmp_bytes(out + ".jct", "splice", f"{tag}.{ext}.jct.gz")
+
+
+# chimeric trimming (-c): files of tests/golden/chimeric (make_golden.py:make_chimeric)
+@pytest.mark.parametrize("tag,flags,exts", [("c50", ["-c50", "-s3"], ["m6.sam", "m5.sam", "m0.csv", "m3.csv", "m4.bed"]), ("c70s5", ["-c70", "-s5"], ["m6.sam", "m0.csv"]),
+                                            ("c60e2", ["-c60", "-s3", "-e2"], ["m6.sam", "m0.csv"])])
+def test_chimeric_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts):
+    d = golden_tmp["chimeric"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    fmt = dict(FMT_FLAG, **{"m3.csv": "-M3"})
+    for ext in exts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, fmt[ext]] + flags, str(tmp_path))
+        _cmp_bytes(out, "chimeric", f"{tag}.{ext}.gz")
+    if tag == "c50":
+        out = str(tmp_path / "o.bam")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, "-M6"] + flags, str(tmp_path))
+        gold = os.path.join(helpers.GOLDEN, "chimeric", "c50.m6.bam")
+        assert open(out, "rb").read() == open(gold, "rb").read()
+        assert open(out + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
