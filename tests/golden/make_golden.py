@@ -916,12 +916,72 @@ def make_chimeric(tmp):
     shutil.copyfile(bam + ".bai", os.path.join(outdir, "c50.m6.bam.bai"))
 
 
+def make_combined(tmp):
+    """-a / -A / -c together (AlignReads tries them in that order and hands each one's leftover state to the next, :7722-7757):
+    the indel, splice and chimeric reads in ONE run against a genome holding all three fixtures' sequences"""
+    outdir = os.path.join(HERE, "combined")
+    os.makedirs(outdir, exist_ok=True)
+    recs, reads = [], []
+    for fx in ("indel", "splice", "chimeric"):
+        name, seq = None, []
+        for line in gzip.open(os.path.join(HERE, fx, "genome.fa.gz"), "rt"):
+            line = line.strip()
+            if line.startswith(">"):
+                if name:
+                    recs.append((name, "".join(seq)))
+                name, seq = line[1:].split()[0], []
+            else:
+                seq.append(line)
+        recs.append((name, "".join(seq)))
+        nm = None
+        for line in gzip.open(os.path.join(HERE, fx, "reads.fa.gz"), "rt"):
+            line = line.strip()
+            if line.startswith(">"):
+                nm = line[1:]
+            else:
+                reads.append((fx[0] + "_" + nm, line))
+    # reads built to be ambiguous for the microInDel search: the same deletion read placed in two copies of a segment
+    rng = np.random.default_rng(31337)
+    seg = rand_seq(rng, 600)
+    extra = rand_seq(rng, 3000) + seg + rand_seq(rng, 2000) + seg + rand_seq(rng, 3000)
+    recs.append(("xD", extra))
+    for i in range(60):
+        p = 3000 + int(rng.integers(60, 400)); L = int(rng.integers(1, 7))
+        s = extra[p - 50:p] + extra[p + L:p + L + 50]
+        s = mutate(rng, s, int(rng.integers(0, 2)))
+        k = int(rng.integers(0, 30))
+        if k >= 12:
+            s = rand_seq(rng, k) + s[k:]
+        if rng.integers(0, 2):
+            s = revcomp(s)
+        reads.append((f"x_amb{i}_L{L}_{k}", s))
+    fa, rd = os.path.join(tmp, "comb.fa"), os.path.join(tmp, "comb_reads.fa")
+    write_fasta(fa, recs)
+    order = rng.permutation(len(reads))
+    write_reads(rd, [reads[i] for i in order])
+    sfx = os.path.join(tmp, "comb.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "comb", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags in (("a10c50", ["-a10", "-c50", "-s3"]), ("a10A5000c50", ["-a10", "-A5000", "-c50", "-s3"]), ("A5000c60", ["-A5000", "-c60", "-s3"]),
+                       ("a10A5000", ["-a10", "-A5000", "-s3"])):
+        for fmt, ext in (("-M6", "m6.sam"), ("-M0", "m0.csv")):
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt, "-T4"] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            print("  ran", tag, fmt, flags)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-combined" in sys.argv:
+            make_combined(tmp)
             return
         if "--only-chimeric" in sys.argv:
             make_chimeric(tmp)
@@ -974,6 +1034,7 @@ def main():
         make_trim(tmp)
         make_splice(tmp)
         make_chimeric(tmp)
+        make_combined(tmp)
     print("done")
 
 

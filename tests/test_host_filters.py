@@ -49,7 +49,12 @@ def expected_cigar(h, s2, tl, tr, read_len):
 
 CASES = [("basic", "s3x5", dict(max_subs=3), 5), ("basic", "s10x6", dict(max_subs=10), 6), ("indel", "a10x4", dict(max_subs=3, micro_indel_len=10), 4),
          ("indel", "a10", dict(max_subs=3, micro_indel_len=10), 0), ("splice", "A5000", dict(max_subs=3, splice_junct_len=5000), 3),
-         ("splice", "A5000a5", dict(max_subs=3, splice_junct_len=5000, micro_indel_len=5), 3), ("splice", "A500s5", dict(max_subs=5, splice_junct_len=500), 5)]
+         ("splice", "A5000a5", dict(max_subs=3, splice_junct_len=5000, micro_indel_len=5), 3), ("splice", "A500s5", dict(max_subs=5, splice_junct_len=500), 5),
+         # -a / -A / -c in one run: each search hands its leftover LowHitInstances / LowMMCnt on to the next (with -c there is no forced trimming)
+         ("combined", "a10c50", dict(max_subs=3, micro_indel_len=10, min_chimeric_len=50), 0),
+         ("combined", "a10A5000c50", dict(max_subs=3, micro_indel_len=10, splice_junct_len=5000, min_chimeric_len=50), 0),
+         ("combined", "A5000c60", dict(max_subs=3, splice_junct_len=5000, min_chimeric_len=60), 0),
+         ("combined", "a10A5000", dict(max_subs=3, micro_indel_len=10, splice_junct_len=5000), 3)]
 
 
 @pytest.mark.parametrize("fixture,tag,kw,min_flank", CASES)
@@ -78,6 +83,8 @@ def test_trims_and_orphan_filters_match_reference(golden_tmp, filters_harness, t
         if h["nar"] != 1:
             continue
         tl, tr = int(trims[j][0]), int(trims[j][1])
+        if seg2["flags"][j] & 8:                                    # chimeric placement: its own trims
+            tl, tr = int(seg2["match_len"][j]), int(seg2["read_ofs"][j])
         start = int(h["match_loci"]) + (tl if chr(h["strand"]) == "+" else tr)
         assert (chrom[h["chrom_id"] - 1], start + 1) == (r["rname"], r["pos"]), (names[i], h, trims[j], r)
         assert expected_cigar(h, seg2[j], tl, tr, int(lens[i])) == r["cigar"], (names[i], h, seg2[j], trims[j], r)

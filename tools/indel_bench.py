@@ -15,6 +15,10 @@ def main():
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
     mbp = float(sys.argv[2]) if len(sys.argv) > 2 else 3100.0
     frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+    # 4th argument: extra alignment parameters of the second run, e.g. "micro_indel_len=10" (default), "splice_junct_len=5000",
+    # "min_chimeric_len=50", or several separated by commas
+    extra = dict(kv.split("=") for kv in (sys.argv[4] if len(sys.argv) > 4 else "micro_indel_len=10").split(","))
+    extra = {k: int(v) for k, v in extra.items()}
     dev = torch.device("cuda", 0)
     seq, seq_lens = synth.make_genome(int(mbp * 1e6), dev, seed=38)
     n = seq.numel()
@@ -49,7 +53,7 @@ def main():
     out = torch.zeros(n_reads * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     res = {}
     for a in (0, 10):
-        al = bk.Aligner(None, bk.AlignParams(max_subs=3, micro_indel_len=a), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(), el_size=4, entries=ent)
+        al = bk.Aligner(None, bk.AlignParams(max_subs=3, **(extra if a else {})), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(), el_size=4, entries=ent)
         for it in range(2):
             al.timing(reset=True)
             torch.cuda.synchronize(); t = time.time()
@@ -59,19 +63,27 @@ def main():
         seg = al.batch_seg2() if a else None
         res[a] = (hits, seg)
         nar, cnt = np.unique(hits["nar"], return_counts=True)
-        print(f"-a{a}: {n_reads} reads in {dt * 1e3:.1f} ms = {n_reads / dt / 1e6:.1f} M reads/s; NAR {({bk.NAR_TAGS[int(k)]: int(v) for k, v in zip(nar, cnt)})}"
-              + (f"; reads placed with a microInDel {int((seg['flags'] & 1).sum())} (insertions {int(((seg['flags'] & 3) == 3).sum())})" if a else ""))
+        print(f"{extra if a else 'plain'}: {n_reads} reads in {dt * 1e3:.1f} ms = {n_reads / dt / 1e6:.1f} M reads/s; NAR {({bk.NAR_TAGS[int(k)]: int(v) for k, v in zip(nar, cnt)})}"
+              + (f"; placed with a microInDel {int((seg['flags'] & 1).sum())} (insertions {int(((seg['flags'] & 3) == 3).sum())}), with a splice junction "
+                 f"{int(((seg['flags'] & 4) != 0).sum())}, end-trimmed {int(((seg['flags'] & 8) != 0).sum())}" if a else ""))
         al.close()
     hits, seg = res[10]
     ns = min(n_reads, 200_000)
     b_h, o_h, l_h = bases[: ns * 100].cpu().numpy(), offs[:ns].cpu().numpy().astype(np.uint64), lens[:ns].cpu().numpy().astype(np.uint32)
     ora = helpers.OracleSfx(seq=seq.cpu().numpy(), sa=sa.cpu().numpy(), el_size=4, entries=entries)
-    exp, eseg = helpers.oracle_align_indel(ora, b_h, o_h, l_h, helpers.make_params(max_subs=3, micro_indel_len=10), nthreads=os.cpu_count())
+    exp, eseg = helpers.oracle_align_indel(ora, b_h, o_h, l_h, helpers.make_params(max_subs=3, **extra), nthreads=os.cpu_count())
     fields = ["chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm", "nxt_low_mm", "num_hits", "mismatches"]
     bad = sum(int((hits[:ns][f] != exp[f]).sum()) for f in fields)
     bad2 = sum(int((seg[:ns][f] != eseg[f]).sum()) for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score"))
+    shown = 0
+    for i in range(ns):
+        if any(hits[i][f] != exp[i][f] for f in fields) or any(seg[i][f] != eseg[i][f] for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score")):
+            print("  read", i, "gpu", hits[i], seg[i], "oracle", exp[i], eseg[i])
+            shown += 1
+            if shown >= 6:
+                break
     print(f"oracle check on the first {ns} reads: mismatching result fields {bad}, mismatching second-segment fields {bad2}; "
-          f"microInDel placements in the sample {int((eseg['flags'] & 1).sum())}")
+          f"two-segment / trimmed placements in the sample {int((eseg['flags'] != 0).sum())}")
 
 if __name__ == "__main__":
     main()
