@@ -54,7 +54,7 @@ int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint3
 void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned long long *cnt, hipStream_t s);
 void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                  uint32_t n_list, uint32_t *cursor, unsigned long long *cnt, bk_loci *dense, hipStream_t s);
-void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, uint32_t *list,
+void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, int keep_state, uint32_t *list,
                   uint32_t *list_cnt_dev, uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_unaligned_list(const bk_hit *out, uint32_t n, uint32_t *list, uint32_t *cnt, hipStream_t s);
 void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
@@ -774,7 +774,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         if (eh == hipSuccess && (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0)) {
             eh = hipMemsetAsync(sm, 0, 16 * 4, s);
             if (eh == hipSuccess) {
-                launch_indel(c->ix, c->cfg, b, n, c->params.micro_indel_len, c->params.splice_junct_len, c->d_act[0], sm + 0, hm + 0, sm + 1, d_seg2, s);
+                launch_indel(c->ix, c->cfg, b, n, c->params.micro_indel_len, c->params.splice_junct_len, c->params.min_chimeric_len > 0 ? 1 : 0, c->d_act[0], sm + 0,
+                             hm + 0, sm + 1, d_seg2, s);
                 eh = hipGetLastError();
             }
         }

@@ -2096,9 +2096,27 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
             if (cd < cl) cd = cl;
             chim_min = (phase_arg * len) / 100;            // phase_arg carries the percentage
         }
+        // state an ambiguous microInDel / splice search left behind (k_indel); LocateCoreMultiples starts from it (:5775-5800)
+        int in_inst = 0, in_mm = 0, in_nxt = 0;
+        bool inherited = false;
+        if (CHIM) {
+            bk_seg2 *sg = reinterpret_cast<bk_seg2 *>(loci_out);
+            const bk_seg2 st0 = sg[r];
+            if (st0.flags == 0x80) {
+                inherited = true;
+                in_inst = st0.match_len; in_mm = st0.mismatches; in_nxt = in_mm + 2;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { bk_seg2 z; z.match_loci = 0; z.match_len = 0; z.read_ofs = 0; z.mismatches = 0; z.flags = 0; z.score = 0; sg[r] = z; }
+                if (in_inst > cfg.max_hits && in_mm == 0) {                     // :5775 - nothing is searched
+                    if (lane == 0) write_result(ix, cfg, b, r, len, BK_HR_HITINSTS, in_inst, in_mm, in_nxt, 0, -1, '?', (phase << 1) | 1);
+                    continue;
+                }
+            }
+        }
         n_lcm++;
         const int init = mm + cfg.mm_delta + 1;
         int low_inst = 0, low_mm = init, nxt = init;
+        if (CHIM && inherited) { low_inst = in_inst; low_mm = in_mm; nxt = in_nxt; }
         uint64_t hit_left = 0;
         int hit_ent = -1, hit_strand = '?';
         bool done = false;
@@ -2367,6 +2385,18 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
             continue;
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
+        if (CHIM && inherited) {                            // the general tail of LocateCoreMultiples (:6238-6261)
+            if (low_mm == in_mm && low_inst == in_inst) {
+                if (in_nxt > nxt) rslt = (nxt - in_mm) < cfg.mm_delta ? BK_HR_MMDELTA : BK_HR_RMMDELTA;
+                else rslt = BK_HR_NONE;
+            } else if (low_inst >= 1 && (nxt - low_mm) < cfg.mm_delta) rslt = BK_HR_MMDELTA;
+            else if (low_inst > cfg.max_hits) rslt = BK_HR_HITINSTS;
+            else rslt = BK_HR_HITS;
+            if (rslt == BK_HR_RMMDELTA) {                   // ProcCoredApprox only takes the new NxtLowMMCnt (Aligner.cpp:9470-9473)
+                if (lane == 0) { bk_hit h = b.out[r]; h.rslt = BK_HR_RMMDELTA; h.nxt_low_mm = (int8_t)nxt; h.flags = (uint8_t)((phase << 1) | 1); b.out[r] = h; }
+                continue;
+            }
+        }
         if (rslt != BK_HR_NONE) {
             if (lane == 0) {
                 write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, hit_ent, hit_strand, (phase << 1) | 1);
@@ -2649,7 +2679,7 @@ __device__ void explore_splice(const uint64_t *__restrict__ rdw, const uint64_t 
 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ list, uint32_t n_list,
-                                               int max_indel, int max_junct, uint32_t *__restrict__ cursor, bk_seg2 *__restrict__ seg2)
+                                               int max_indel, int max_junct, int keep_state, uint32_t *__restrict__ cursor, bk_seg2 *__restrict__ seg2)
 {
     __shared__ LdsEntries s_le;
     lds_entries_load(s_le, ix);
@@ -2666,10 +2696,15 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
         const int core = p.core_len * 2 < (len - 1) / 2 ? p.core_len * 2 : (len - 1) / 2;
         const int max_mm = p.max_tot_mm > kIndelMaxMM ? kIndelMaxMM : p.max_tot_mm;       // cMaxMicroInDelMM == cMaxJunctAlignMM == 2
         if (core < 1) continue;
-        // AlignReads: LocateInDels first, LocateSpliceJuncts only if that returned nothing (SfxArrayV2.cpp:7722-7748)
+        // AlignReads: LocateInDels first, LocateSpliceJuncts only if that returned nothing (SfxArrayV2.cpp:7722-7748).  Both write
+        // their caller's LowHitInstances / LowMMCnt / NxtLowMMCnt even when they then return "nothing" because the best placement
+        // is ambiguous (:7655-7659, :7340-7344); the chimeric call that may follow starts from those values (left_*).
+        int left_inst = 0, left_mm = 0;
+        bool aligned = false;
         for (int mode = max_indel > 0 ? 0 : 1; mode < 2; mode++) {
             if (mode == 1 && max_junct <= 0) break;
             const bool splice = mode == 1;
+            left_inst = 0; left_mm = 0;
             // best placement so far (wave-uniform)
             int best_score = 0, best_inst = 0, b_insert = 0, b_kind = 0, b_s0_len = 0, b_s0_mm = 0, b_s1_len = 0, b_s1_mm = 0, b_s1_ofs = 0, b_strand = '+';
             uint64_t b_s0 = 0, b_s1 = 0;
@@ -2766,7 +2801,7 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
                     if (best_inst >= 1 && best_score >= kIndelMaxScore) { done = true; break; }
                 }
             }
-            if (best_inst != 1) continue;                   // none, or ambiguous: on to the next mode
+            if (best_inst == 0) continue;                   // nothing: on to the next mode
             if (best_score > kIndelMaxScore) best_score = kIndelMaxScore;
             // offsets -> entry + position; LocateInDels insists on one entry for both segments (a placement without a second
             // segment looks up offset 0 there), LocateSpliceJuncts only looks the second one up when there is one
@@ -2779,6 +2814,12 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
             bool ok = e0 >= 0 && e1 >= 0;
             if (ok && !splice) ok = ix.ent_id[e0] == ix.ent_id[e1];
             if (!ok) continue;
+            if (best_inst > 1) {                            // ambiguous: reported as nothing, but the counts stay behind
+                left_inst = splice ? best_inst : 1;
+                left_mm = b_s0_mm + b_s1_mm;
+                continue;
+            }
+            aligned = true;
             if (lane == 0) {
                 bk_hit h;
                 h.chrom_id = ix.ent_id[e0]; h.match_loci = (uint32_t)(b_s0 - ix.ent_start[e0]); h.match_len = (uint16_t)b_s0_len;
@@ -2792,6 +2833,12 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
                 seg2[r] = g;
             }
             break;                                          // aligned: no further mode
+        }
+        if (!aligned && keep_state && left_inst > 0 && lane == 0) {
+            bk_seg2 g;
+            g.match_loci = 0; g.read_ofs = 0; g.score = 0; g.flags = 0x80;          // not a placement: state for the chimeric call
+            g.match_len = (uint16_t)(left_inst > 65535 ? 65535 : left_inst); g.mismatches = (uint8_t)left_mm;
+            seg2[r] = g;
         }
     }
 }
@@ -2810,7 +2857,7 @@ void launch_unaligned_list(const bk_hit *out, uint32_t n, uint32_t *list, uint32
     if (n) hipLaunchKernelGGL(k_unaligned_list, dim3((n + 255) / 256), dim3(256), 0, s, out, n, list, cnt);
 }
 
-void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, uint32_t *list,
+void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, uint32_t n, int max_indel, int max_junct, int keep_state, uint32_t *list,
                   uint32_t *list_cnt_dev, uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
 {
     if (!n) return;
@@ -2820,8 +2867,8 @@ void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     const uint32_t n_list = *list_cnt_host;
     if (!n_list) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n_list + 3) / 4, 8192);
-    if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, cursor, seg2);
-    else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, cursor, seg2);
+    if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, keep_state, cursor, seg2);
+    else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, keep_state, cursor, seg2);
 }
 
 __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)

@@ -343,3 +343,15 @@ def test_chimeric_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, exts)
         gold = os.path.join(helpers.GOLDEN, "chimeric", "c50.m6.bam")
         assert open(out, "rb").read() == open(gold, "rb").read()
         assert open(out + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
+
+
+# -a / -A / -c in one run (tests/golden/combined): each search of AlignReads hands its leftover state to the next one
+@pytest.mark.parametrize("tag,flags", [("a10c50", ["-a10", "-c50", "-s3"]), ("a10A5000c50", ["-a10", "-A5000", "-c50", "-s3"]), ("A5000c60", ["-A5000", "-c60", "-s3"]),
+                                       ("a10A5000", ["-a10", "-A5000", "-s3"])])
+def test_combined_rescue_modes_byte_identical(golden_tmp, tmp_path, tag, flags):
+    d = golden_tmp["combined"]
+    sfx, reads = os.path.join(d, "genome.sfx"), os.path.join(d, "reads.fa")
+    for ext in ("m6.sam", "m0.csv"):
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext]] + flags, str(tmp_path))
+        _cmp_bytes(out, "combined", f"{tag}.{ext}.gz")

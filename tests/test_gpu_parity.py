@@ -553,8 +553,10 @@ def test_micro_indels_match_oracle(golden_tmp, fixture, kw):
 
 @pytest.mark.parametrize("kw", [dict(max_subs=3, min_chimeric_len=50), dict(max_subs=5, min_chimeric_len=70), dict(max_subs=3, min_chimeric_len=60, min_edit_dist=2),
                                 dict(max_subs=3, min_chimeric_len=99, align_strand=1), dict(max_subs=1, min_chimeric_len=50, align_strand=2),
-                                dict(max_subs=3, min_chimeric_len=55, micro_indel_len=6, splice_junct_len=3000)])
-@pytest.mark.parametrize("fixture", ["chimeric", "basic", "indel", "splice"])
+                                dict(max_subs=3, min_chimeric_len=55, micro_indel_len=6, splice_junct_len=3000),
+                                dict(max_subs=3, min_chimeric_len=50, micro_indel_len=10), dict(max_subs=3, min_chimeric_len=60, splice_junct_len=5000),
+                                dict(max_subs=5, min_chimeric_len=50, micro_indel_len=20, splice_junct_len=100000, min_edit_dist=2)])
+@pytest.mark.parametrize("fixture", ["chimeric", "basic", "indel", "splice", "combined"])
 def test_chimeric_placements_match_oracle(golden_tmp, fixture, kw):
     """-c: the chimeric LocateCoreMultiples call (AdaptiveTrim per candidate) - result records and the trims carried in bk_seg2 -
     against the oracle, which is pinned on the reference's -c output"""
