@@ -2,7 +2,7 @@
 """Multi-loci modes at C2 scale: the bench workload (100 bp SE reads, 0-3 subs, -s3, synthetic GRCh38-like genome) aligned
 with MaxHits = -R (default 5): time of the align call with and without the loci lists, share of reads with several loci,
 and a sample checked against the CPU oracle (result records and the pHits[] lists, in order).
-  python tools/multi_bench.py [n_reads] [genome_mbp] [max_ml] [clamp]"""
+  python tools/multi_bench.py [n_reads] [genome_mbp] [max_ml] [clamp] [best_matches]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +16,7 @@ def main():
     mbp = float(sys.argv[2]) if len(sys.argv) > 2 else 3100.0
     max_ml = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     clamp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    best = int(sys.argv[5]) if len(sys.argv) > 5 else 0            # 1: -N (LocateBestMatches)
     dev = torch.device("cuda", 0)
     seq, seq_lens = synth.make_genome(int(mbp * 1e6), dev, seed=38)
     n = seq.numel()
@@ -29,7 +30,7 @@ def main():
     out = torch.zeros(n_reads * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     res = {}
     for ml, cl in ((1, 0), (max_ml, clamp)):
-        al = bk.Aligner(None, bk.AlignParams(max_subs=3, max_ml=ml, clamp_ml=cl), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(),
+        al = bk.Aligner(None, bk.AlignParams(max_subs=3, max_ml=ml, clamp_ml=cl, best_matches=(best if ml > 1 else 0)), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(),
                         el_size=4, entries=ent)
         for it in range(2):
             al.timing(reset=True)
@@ -51,7 +52,7 @@ def main():
     ns = min(n_reads, 200_000)
     b_h, o_h, l_h = bases[: ns * 100].cpu().numpy(), offs[:ns].cpu().numpy().astype(np.uint64), lens[:ns].cpu().numpy().astype(np.uint32)
     ora = helpers.OracleSfx(seq=seq.cpu().numpy(), sa=sa.cpu().numpy(), el_size=4, entries=entries)
-    exp, eo, el = helpers.oracle_align_multi(ora, b_h, o_h, l_h, helpers.make_params(max_subs=3, max_ml=max_ml, clamp_ml=clamp), nthreads=os.cpu_count())
+    exp, eo, el = helpers.oracle_align_multi(ora, b_h, o_h, l_h, helpers.make_params(max_subs=3, max_ml=max_ml, clamp_ml=clamp, best_matches=best), nthreads=os.cpu_count())
     fields = ["chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm", "nxt_low_mm", "num_hits", "mismatches"]
     bad = sum(int((hits[:ns][f] != exp[f]).sum()) for f in fields)
     ok_offs = bool(np.array_equal(lo[: ns + 1], eo))
