@@ -2588,6 +2588,22 @@ __device__ __forceinline__ int splice_bonus(bool plus, int d0, int d1, int a0, i
     return ct_ac ? kSpliceBonus : (gt_ag ? kSpliceBonus / 2 : 0);
 }
 
+// one base per call from consecutive target positions (ascending when FWD, else descending): the 16-base word is reloaded only
+// when the position crosses into the next one - the junction scan below walks up to 100 000 positions per candidate
+template <bool FWD>
+struct NibStream {
+    const uint64_t *__restrict__ tgt;
+    uint64_t pos, word;
+    __device__ __forceinline__ void start(const uint64_t *__restrict__ t4, uint64_t p) { tgt = t4; pos = p; word = t4[p >> 4]; }
+    __device__ __forceinline__ int next()
+    {
+        const int v = (int)((word >> (60 - 4 * (int)(pos & 15))) & 7);
+        if (FWD) { pos++; if ((pos & 15) == 0) word = tgt[pos >> 4]; }
+        else { if ((pos & 15) == 0) word = tgt[(pos - 1) >> 4]; pos--; }
+        return v;
+    }
+};
+
 template <bool RIGHT>
 __device__ void explore_splice(const uint64_t *__restrict__ rdw, const uint64_t *__restrict__ tgt, int plen, uint64_t t, uint64_t targ_len,
                                int max_junct, int max_mm, int core_len, bool plus, IndelPlacement &out)
@@ -2637,12 +2653,19 @@ __device__ void explore_splice(const uint64_t *__restrict__ rdw, const uint64_t 
             targ_hash += b;
         }
         if (i < seg_len - 1) break;
+        // the two ends of the sliding window as streams (scan coordinate i is target t + i for RIGHT, t + pe - i for LEFT)
+        NibStream<RIGHT> s_te, s_ts;
+        {
+            const long long te0 = (long long)mo + kJunctSep + seg_len - 1, ts0 = (long long)mo + kJunctSep;
+            s_te.start(tgt, RIGHT ? t + (uint64_t)te0 : (uint64_t)((long long)t + pe - te0));
+            s_ts.start(tgt, RIGHT ? t + (uint64_t)ts0 : (uint64_t)((long long)t + pe - ts0));
+        }
         for (int gap = kJunctSep; gap < max_junct - seg_len; gap++) {
-            const long long ts = (long long)mo + gap, te = ts + seg_len - 1;        // start / end of the moved segment, scan coordinates
-            if ((tb = T(te)) > 4) break;
+            const long long ts = (long long)mo + gap;                                // start of the moved segment, scan coordinates
+            if ((tb = s_te.next()) > 4) break;
             targ_hash += tb;
             const bool in_range = !(targ_hash < min_hash || targ_hash > max_hash);
-            targ_hash -= T(ts);
+            targ_hash -= s_ts.next();
             if (!in_range) continue;
             if (RIGHT) { if ((uint32_t)(targ_len - (t + (uint64_t)mo + (uint64_t)gap + 1)) < (uint32_t)seg_len) break; }
             else if ((uint32_t)(t - (uint64_t)gap) < 1u) break;
