@@ -354,11 +354,14 @@ int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, i
 }
 
 // CAligner::LoadRawReads (Aligner.cpp:10724-11427): descriptor rule, -y/-Y trims, -l/-L acceptance
+int g_qual_mode = 3;
+
 int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, int nthreads, ReadStore &rs)
 {
     for (const std::string &fn : files) {
         bk::RecordStream rd;
         std::string err;
+        rd.set_quality_mode(g_qual_mode);
         int rc = rd.open(fn, nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading reads from '%s'", fn.c_str());
@@ -414,6 +417,8 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
     for (size_t k = 0; k < f1.size(); k++) {
         bk::RecordStream rd[2];
         std::string err;
+        rd[0].set_quality_mode(g_qual_mode);
+        rd[1].set_quality_mode(g_qual_mode);
         int rc = rd[0].open(f1[k], nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         rc = rd[1].open(f2[k], nthreads, &err);
@@ -542,8 +547,9 @@ int cmd_align(int argc, char **argv, int first)
         best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
         clamp_ml = a.has("X") || best_matches;
     }
-    // -g FASTQ quality scores: only the reference's default (3 = ignore, QUAL printed as '*') is built
-    if (a.has("g") && a.num("g", 3) != 3) { diag("Error: FASTQ quality modes '-g0..2' are not available in this build (qualities are ignored as with the default '-g3')"); return 1; }
+    // -g FASTQ quality scores: 0 Sanger / Illumina 1.8+, 1 Illumina 1.3+, 2 Solexa, 3 ignore (default; QUAL is then '*')
+    g_qual_mode = a.num("g", 3);
+    if (g_qual_mode < 0 || g_qual_mode > 3) { diag("Error: fastq quality '-g%d' specified outside of range 0..3", g_qual_mode); return 1; }
     // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned
     const int micro_indel = a.num("a", 0);
     if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
@@ -869,7 +875,9 @@ int cmd_align(int argc, char **argv, int first)
                 // per read position: accepted reads covering it, and those whose base differs from the target there
                 // (read orientation; the target is reverse complemented for '-' alignments); no qualities are
                 // loaded, so everything falls into the lowest Phred band
-                std::vector<std::vector<uint64_t>> qi((size_t)nthreads, std::vector<uint64_t>(max_len, 0)), sb(qi), ms(qi);
+                // qi / sb hold the four Phred bands back to back (band * max_len + position)
+                std::vector<std::vector<uint64_t>> qi((size_t)nthreads, std::vector<uint64_t>((size_t)max_len * 4, 0)), sb(qi),
+                    ms((size_t)nthreads, std::vector<uint64_t>(max_len, 0));
                 auto work = [&](int w) {
                     auto &Q = qi[(size_t)w], &S = sb[(size_t)w], &M = ms[(size_t)w];
                     for (size_t i = (size_t)w; i < nr; i += (size_t)nthreads) {
@@ -883,8 +891,10 @@ int cmd_align(int argc, char **argv, int first)
                         for (uint32_t k = 0; k < alen && tl0 + k < len; k++) {      // read positions TrimLeft .. ReadLen - TrimRight (:6303-6306)
                             uint8_t t = h.strand == '-' ? tg[alen - 1 - k] & 7 : tg[k] & 7;
                             if (h.strand == '-' && t < 4) t = (uint8_t)(3 - t);
-                            Q[tl0 + k]++;
-                            if ((rd[tl0 + k] & 7) != t) { S[tl0 + k]++; nsub++; }
+                            const uint32_t q4 = (rd[tl0 + k] >> 4) & 15;           // 4-bit score -> band (WriteSubDist :6309-6320)
+                            const size_t at = (size_t)(q4 <= 3 ? 0 : q4 <= 7 ? 1 : q4 <= 11 ? 2 : 3) * max_len + tl0 + k;
+                            Q[at]++;
+                            if ((rd[tl0 + k] & 7) != t) { S[at]++; nsub++; }
                         }
                         M[nsub < max_len ? nsub : max_len - 1]++;
                     }
@@ -894,7 +904,7 @@ int cmd_align(int argc, char **argv, int first)
                 work(0);
                 for (auto &t : th) t.join();
                 for (int w = 1; w < nthreads; w++)
-                    for (uint32_t k = 0; k < max_len; k++) { qi[0][k] += qi[(size_t)w][k]; sb[0][k] += sb[(size_t)w][k]; ms[0][k] += ms[(size_t)w][k]; }
+                    for (size_t k = 0; k < (size_t)max_len * 4; k++) { qi[0][k] += qi[(size_t)w][k]; sb[0][k] += sb[(size_t)w][k]; if (k < max_len) ms[0][k] += ms[(size_t)w][k]; }
                 static const char *band_a[4] = {"Phred 0..9", "Phred 10..19", "Phred 20..29", "Phred 30+"};
                 static const char *band_b[4] = {"Phred 0..8", "Phred 9..19", "Phred 20..29", "Phred 30+"};
                 if (ml_mode) {                                           // WriteBasicCountStats, Aligner.cpp:4203-4227
@@ -908,13 +918,13 @@ int cmd_align(int argc, char **argv, int first)
                 for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k + 1);
                 for (int bnd = 0; bnd < 4; bnd++) {
                     fprintf(f, "\n,\"%s\"", band_a[bnd]);
-                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", bnd ? 0ULL : (unsigned long long)qi[0][k]);
+                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", (unsigned long long)qi[0][(size_t)bnd * max_len + k]);
                 }
                 fprintf(f, "\n\n\"Aligner Induced Subs\",");
                 for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k + 1);
                 for (int bnd = 0; bnd < 4; bnd++) {
                     fprintf(f, "\n,\"%s\"", band_b[bnd]);
-                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", bnd ? 0ULL : (unsigned long long)sb[0][k]);
+                    for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%llu", (unsigned long long)sb[0][(size_t)bnd * max_len + k]);
                 }
                 fprintf(f, "\n\n\"Multiple substitutions\",");
                 for (uint32_t k = 0; k < max_len; k++) fprintf(f, ",%u", k);
@@ -1073,7 +1083,16 @@ int cmd_align(int argc, char **argv, int first)
                     else byte |= c4;
                     if ((o & 1) || o == len - 1) *q++ = byte;
                 }
-                memset(q, 0xff, len); q += len;
+                {
+                    uint32_t sum = 0;
+                    for (uint32_t o = 0; o < len; o++) sum += (sq[o] >> 4) & 15;
+                    if (!sum) memset(q, 0xff, len);
+                    else {                                       // the reference stores the ASCII form here as well (SAMfile.cpp:2374)
+                        const bool rev = acc && h.strand != '+';
+                        for (uint32_t o = 0; o < len; o++) q[o] = (uint8_t)(33 + ((((rev ? sq[len - 1 - o] : sq[o]) >> 4) & 15) * 40) / 15);
+                    }
+                    q += len;
+                }
                 if (tag) { *q++ = 'Y'; *q++ = 'U'; *q++ = 'Z'; size_t tl = strlen(tag) + 1; memcpy(q, tag, tl); q += tl; }
                 if (acc) S.al.push_back({(uint64_t)at, (uint64_t)(at + 4 + block), ref, (int32_t)pos0, (int32_t)(pos0 + hit_len - 1)});
                 S.n++;
@@ -1141,6 +1160,15 @@ int cmd_align(int argc, char **argv, int first)
             if (neg) r.push_back('-');
             while (n) r.push_back(t[--n]);
         };
+        // QUAL (ReportBAMread :5928-5955): '*' when no base carries a score, else 33 + q4 * 40 / 15 per base, reversed with the read
+        auto put_qual = [](std::string &r, const uint8_t *sq, uint32_t n, bool reversed) {
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < n; q++) sum += (sq[q] >> 4) & 15;
+            if (!sum) { r.push_back('*'); return; }
+            const size_t o = r.size();
+            r.resize(o + n);
+            for (uint32_t q = 0; q < n; q++) r[o + q] = (char)(33 + ((((reversed ? sq[n - 1 - q] : sq[q]) >> 4) & 15) * 40) / 15);
+        };
         // one record (CAligner::ReportBAMread, Aligner.cpp:5850-5924,6036-6054); false when the read is not reported
         auto format_rec = [&](size_t k, std::string &rec) -> bool {
             uint32_t i = order[k];
@@ -1201,7 +1229,9 @@ int cmd_align(int argc, char **argv, int first)
                 rec.resize(o + len);
                 if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
                 else for (uint32_t q = 0; q < len; q++) rec[o + q] = comp[s[len - 1 - q] & 7];
-                rec += "\t*\n";
+                rec.push_back('\t');
+                put_qual(rec, s, len, h.strand != '+');
+                rec.push_back('\n');
             } else {
                 rec += "\t*\t0\t255\t";
                 put_num(rec, len);
@@ -1209,7 +1239,9 @@ int cmd_align(int argc, char **argv, int first)
                 size_t o = rec.size();
                 rec.resize(o + len);
                 for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
-                rec += "\t*\t\tYU:Z:";                                 // the doubled TAB is what the reference writes
+                rec.push_back('\t');
+                put_qual(rec, s, len, false);
+                rec += "\t\tYU:Z:";                                    // the doubled TAB is what the reference writes
                 rec += kNarTag[h.nar < 20 ? h.nar : 0];
                 rec.push_back('\n');
             }

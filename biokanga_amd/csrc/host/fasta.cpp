@@ -1,6 +1,8 @@
 // fasta.cpp - see fasta.h
 #include "fasta.h"
 
+#include <cmath>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -117,14 +119,32 @@ int SeqReader::next(std::string &descr, std::vector<uint8_t> &bases)
         if (c != '+') return -79;                    // eBSFerrFastqDescr
         while ((c = getc_()) >= 0 && c != '\n' && c != '\r') if (bad_chr(c)) return -76;
         size_t nq = 0;
+        qual_.clear();
         for (;;) {                                   // quality line
             c = getc_();
             if (c < 0) break;
             if (c == '\n' || c == '\r') { if (nq == 0) continue; break; }
             if (bad_chr(c)) return -76;
-            if (nq < 0x30000) nq++;
+            if (nq < 0x30000) { nq++; if (qmode_ != 3) qual_.push_back((uint8_t)c); }
         }
         if (descr.empty() || bases.empty() || nq != bases.size()) return -85;   // eBSFerrFileAccess: empty or unequal elements
+        if (qmode_ != 3) {
+            // Aligner.cpp:11133-11194: clamp to the encoding's range, Phred capped at 40, 4 bits per base
+            for (size_t i = 0; i < nq; i++) {
+                int q = qual_[i], ph;
+                switch (qmode_) {
+                case 0: if (q < 33) q = 33; else if (q >= 126) q = 125; ph = q - 33; break;
+                case 1: if (q < 64) q = 64; else if (q >= 126) q = 125; ph = q - 64; break;
+                default:
+                    if (q < 59 || q >= 126) q = q < 64 ? 64 : 125;
+                    ph = q - 59;
+                    ph = (int)(uint8_t)(10 * log(1 + pow(10.0, ((double)ph / 10.0) / log(10.0))));
+                    break;
+                }
+                if (ph > 40) ph = 40;
+                bases[i] |= (uint8_t)((((uint32_t)ph + 2) * 15) / 40) << 4;
+            }
+        }
         return 1;
     }
     // FASTA

@@ -4,7 +4,7 @@
 //   * sequence characters: every non-alphabetic character except '-' is sloughed
 //   * CFasta::Ascii2Sense: a/c/g/t/u -> 0..3 | cRptMskFlg(0x08), A/C/G/T/U -> 0..3, '-' -> eBaseInDel(6),
 //     everything else -> eBaseN(4)
-//   * FASTQ: 4-line records (@id, sequence, +, qualities); qualities are not retained (-g3 default)
+//   * FASTQ: 4-line records (@id, sequence, +, qualities); qualities are dropped (-g3 default) or packed 4 bits per base
 #pragma once
 #include <zlib.h>
 
@@ -25,6 +25,10 @@ public:
     // returns 1 = record, 0 = end of file, <0 = error
     int next(std::string &descr, std::vector<uint8_t> &bases);
     bool is_fastq() const { return fastq_; }
+    // FASTQ quality scores (`-g`, CAligner::LoadReads biokanga/Aligner.cpp:11121-11200): 0 Sanger / Illumina 1.8+, 1 Illumina 1.3+,
+    // 2 Solexa, 3 ignore (default).  Unless ignored, the score of every base is reduced to 4 bits, ((Qphred + 2) * 15) / 40, and
+    // travels in bits 4..7 of the base's byte - where the reference keeps it.
+    void set_quality_mode(int m) { qmode_ = m; }
 
 private:
     int fill();
@@ -34,6 +38,8 @@ private:
     std::vector<uint8_t> buf_;
     size_t pos_ = 0, len_ = 0;
     bool eof_ = false, fastq_ = false, started_ = false;
+    int qmode_ = 3;
+    std::vector<uint8_t> qual_;
     std::string path_;
 };
 
@@ -55,6 +61,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<Pars
 class RecordStream {
 public:
     int open(const std::string &path, int nthreads, std::string *err);
+    void set_quality_mode(int m) { rd_.set_quality_mode(m); }       // before open()
     // 1 = record, 0 = end, < 0 = error; pointers stay valid until the next call
     int next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl);
     // whole-file parse available: the chunks in file order (then next() need not be used)

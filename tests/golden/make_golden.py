@@ -973,12 +973,39 @@ def make_combined(tmp):
             print("  ran", tag, fmt, flags)
 
 
+def make_quality(tmp):
+    """FASTQ quality modes (-g0 Sanger, -g1 Illumina 1.3+, -g2 Solexa) on the basic FASTQ reads: QUAL columns of SAM, BAM and the
+    Phred bands of the -O statistics"""
+    basic = os.path.join(HERE, "basic")
+    sfx, fq = os.path.join(tmp, "q.sfx"), os.path.join(tmp, "q_reads.fq")
+    for src, dst in ((os.path.join(basic, "genome.sfx.gz"), sfx), (os.path.join(basic, "reads.fq.gz"), fq)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    for g_ in (0, 1, 2):
+        out = os.path.join(tmp, f"g{g_}.sam")
+        run([REF, "align", "-i", fq, "-I", sfx, "-o", out, "-M6", "-s3", f"-g{g_}", "-T4"], tmp)
+        gz_copy(out, os.path.join(basic, f"s3fqg{g_}.m6.sam.gz"))
+    out = os.path.join(tmp, "g0.m5.sam")
+    st = os.path.join(tmp, "g0.stats.csv")
+    run([REF, "align", "-i", fq, "-I", sfx, "-o", out, "-M5", "-s3", "-g0", "-y3", "-Y5", "-T4", "-O", st], tmp)
+    gz_copy(out, os.path.join(basic, "s3fqg0y3Y5.m5.sam.gz"))
+    gz_copy(st, os.path.join(basic, "s3fqg0y3Y5.m5.stats.csv.gz"))
+    bam = os.path.join(tmp, "g0.m6.bam")
+    run([REF, "align", "-i", fq, "-I", sfx, "-o", bam, "-M6", "-s3", "-g0", "-T4"], tmp)
+    shutil.copyfile(bam, os.path.join(basic, "s3fqg0.m6.bam"))
+    shutil.copyfile(bam + ".bai", os.path.join(basic, "s3fqg0.m6.bam.bai"))
+    print("  quality fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-quality" in sys.argv:
+            make_quality(tmp)
             return
         if "--only-combined" in sys.argv:
             make_combined(tmp)
@@ -1035,6 +1062,7 @@ def main():
         make_splice(tmp)
         make_chimeric(tmp)
         make_combined(tmp)
+        make_quality(tmp)
     print("done")
 
 

@@ -355,3 +355,24 @@ def test_combined_rescue_modes_byte_identical(golden_tmp, tmp_path, tag, flags):
         out = str(tmp_path / f"o.{ext}")
         run(["align", "-i", reads, "-I", sfx, "-o", out, FMT_FLAG[ext]] + flags, str(tmp_path))
         _cmp_bytes(out, "combined", f"{tag}.{ext}.gz")
+
+
+# FASTQ quality modes (-g0..2): QUAL columns (SAM text, BAM), end trims applied to bases and scores alike, Phred bands of -O
+@pytest.mark.parametrize("g", [0, 1, 2])
+def test_fastq_quality_modes_byte_identical(golden_tmp, tmp_path, g):
+    d = golden_tmp["basic"]
+    sfx = os.path.join(d, "genome.sfx")
+    fq = os.path.join(helpers.GOLDEN, "basic", "reads.fq.gz")
+    out = str(tmp_path / "o.sam")
+    run(["align", "-i", fq, "-I", sfx, "-o", out, "-M6", "-s3", f"-g{g}"], str(tmp_path))
+    _cmp_bytes(out, "basic", f"s3fqg{g}.m6.sam.gz")
+    if g == 0:
+        out5, st = str(tmp_path / "o5.sam"), str(tmp_path / "st.csv")
+        run(["align", "-i", fq, "-I", sfx, "-o", out5, "-M5", "-s3", "-g0", "-y3", "-Y5", "-O", st], str(tmp_path))
+        _cmp_bytes(out5, "basic", "s3fqg0y3Y5.m5.sam.gz")
+        _cmp_bytes(st, "basic", "s3fqg0y3Y5.m5.stats.csv.gz")
+        bam = str(tmp_path / "o.bam")
+        run(["align", "-i", fq, "-I", sfx, "-o", bam, "-M6", "-s3", "-g0"], str(tmp_path))
+        gold = os.path.join(helpers.GOLDEN, "basic", "s3fqg0.m6.bam")
+        assert open(bam, "rb").read() == open(gold, "rb").read()
+        assert open(bam + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
