@@ -505,8 +505,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAc", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -566,6 +566,10 @@ int cmd_align(int argc, char **argv, int first)
     const int min_chim = a.num("c", 0);
     if (min_chim != 0 && (min_chim < 50 || min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", min_chim < 0 ? -min_chim : min_chim); return 1; }
     if (min_chim && (ml_mode || pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", min_chim, ml_mode, pe_mode); return 1; }
+    // -k PCR differential amplification artefact reduction (kanga.cpp:718-724): window 0..250, off by default
+    const int pcr_win = a.has("k") ? a.num("k", -1) : -1;
+    if (a.has("k") && (pcr_win < 0 || pcr_win > 250)) { diag("Error: PCR differential amplification artefacts window length '-k%d' specified outside of range 0..250", pcr_win); return 1; }
+    if (pcr_win >= 0 && ml_mode == 5) { diag("Error: '-k%d' together with '-r5' is not available in this build", pcr_win); return 1; }
     int min_flank = a.num("x", 0);
     if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
     if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
@@ -755,6 +759,41 @@ int cmd_align(int argc, char **argv, int first)
     auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
     auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return trims.empty() ? h.mismatches : trims.mismatches[i]; };        // TrimMismatches
     auto is_chimeric = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 8); };     // FlgChimeric: trims come with the hit
+    if (min_chim) {
+        // chimeric placements keep the trims AdaptiveTrim found (ProcCoredApprox :9292-9299); the flank trimmer leaves them alone (:1641)
+        if (trims.empty()) {
+            trims.left.assign(nr, 0); trims.right.assign(nr, 0); trims.mismatches.resize(nr);
+            for (size_t i = 0; i < nr; i++) trims.mismatches[i] = hits[i].mismatches;
+        }
+        size_t n_ch = 0;
+        for (size_t i = 0; i < nr; i++)
+            if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) { trims.left[i] = seg2[RD(i)].match_len; trims.right[i] = seg2[RD(i)].read_ofs; n_ch++; }
+        diag("Of the accepted aligned reads, %zu were chimeric", n_ch);
+    }
+    // CAligner::SortHitMatch (Aligner.cpp:10069-10114) over record indexes, ties left to the replica of the reference's sort
+    auto cmp = [&](uint32_t x, uint32_t y) -> int {
+        const bk_hit &p = hits[x], &q = hits[y];
+        if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
+        if (p.num_hits == 1 && q.num_hits != 1) return -1;
+        if (p.num_hits != 1 && q.num_hits == 1) return 1;
+        if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
+        if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
+        const uint32_t ps = a_start(p, x), qs = a_start(q, y), pl = a_len(p, x), ql = a_len(q, y);
+        if (ps != qs) return ps < qs ? -1 : 1;
+        if (pl != ql) return pl < ql ? -1 : 1;
+        if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
+        if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
+        return 0;
+    };
+    if (pcr_win >= 0 && !pe_mode) {
+        // CAligner::ReducePCRduplicates runs on the sorted set, before the flank trimmer (Aligner.cpp:598-610)
+        diag("Processing to reduce PCR differential amplification artefacts processing started..");
+        std::vector<uint32_t> ord(nr);
+        for (size_t i = 0; i < nr; i++) ord[i] = (uint32_t)i;
+        bk::ref_order_sort(ord.data(), (int64_t)nr, cmp, nthreads);
+        const size_t n_dup = bk::reduce_pcr_duplicates(hits, ord, [&](size_t i) { return a_start(hits[i], i); }, [&](size_t i) { return a_len(hits[i], i); }, pcr_win);
+        diag("Removed %zu potential PCR artefact reads", n_dup);
+    }
     if (min_flank > 0) {
         diag("Starting 5' and 3' flank sequence autotrim processing...");
         bk::SfxFile sft;
@@ -768,17 +807,6 @@ int cmd_align(int argc, char **argv, int first)
                              min_flank, pe_mode != 0, nthreads, trims);
         diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", trims.removed_plus,
              trims.removed_minus);
-    }
-    if (min_chim) {
-        // chimeric placements keep the trims AdaptiveTrim found (ProcCoredApprox :9292-9299); the flank trimmer leaves them alone (:1641)
-        if (trims.empty()) {
-            trims.left.assign(nr, 0); trims.right.assign(nr, 0); trims.mismatches.resize(nr);
-            for (size_t i = 0; i < nr; i++) trims.mismatches[i] = hits[i].mismatches;
-        }
-        size_t n_ch = 0;
-        for (size_t i = 0; i < nr; i++)
-            if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) { trims.left[i] = seg2[RD(i)].match_len; trims.right[i] = seg2[RD(i)].read_ofs; n_ch++; }
-        diag("Of the accepted aligned reads, %zu were chimeric", n_ch);
     }
     // orphan junction filters, splice junctions first (Aligner.cpp:630-650)
     if (splice_len) {
@@ -805,21 +833,6 @@ int cmd_align(int argc, char **argv, int first)
     diag("Sorting alignments by ascending chrom.loci");
     std::vector<uint32_t> order(nr);
     for (size_t i = 0; i < nr; i++) order[i] = (uint32_t)i;
-    const bk_hit *H = hits.data();
-    auto cmp = [&, H](uint32_t x, uint32_t y) -> int {                   // CAligner::SortHitMatch, Aligner.cpp:10069-10114
-        const bk_hit &p = H[x], &q = H[y];
-        if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
-        if (p.num_hits == 1 && q.num_hits != 1) return -1;
-        if (p.num_hits != 1 && q.num_hits == 1) return 1;
-        if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
-        if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
-        const uint32_t ps = a_start(p, x), qs = a_start(q, y), pl = a_len(p, x), ql = a_len(q, y);
-        if (ps != qs) return ps < qs ? -1 : 1;
-        if (pl != ql) return pl < ql ? -1 : 1;
-        if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
-        if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
-        return 0;
-    };
     bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
 
     // -j / -J: reads that found no alignment at all (NAR EN, NL) / multi-loci reads (NAR ML) as FASTA, in the sorted

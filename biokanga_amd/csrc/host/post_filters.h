@@ -29,10 +29,12 @@ inline void auto_trim_flanks(std::vector<bk_hit> &hits, const std::function<bool
                              const std::function<const uint8_t *(size_t)> &target, int min_flank, bool paired, int nthreads, FlankTrims &out)
 {
     const size_t nr = hits.size();
-    out.left.assign(nr, 0);
-    out.right.assign(nr, 0);
-    out.mismatches.resize(nr);
-    for (size_t i = 0; i < nr; i++) out.mismatches[i] = hits[i].mismatches;
+    if (out.left.size() != nr) {                        // may already hold the trims of chimeric placements, which are skipped below
+        out.left.assign(nr, 0);
+        out.right.assign(nr, 0);
+        out.mismatches.resize(nr);
+        for (size_t i = 0; i < nr; i++) out.mismatches[i] = hits[i].mismatches;
+    }
     if (nthreads < 1) nthreads = 1;
     std::vector<size_t> plus((size_t)nthreads, 0), minus((size_t)nthreads, 0);
     auto work = [&](int w) {
@@ -114,6 +116,75 @@ inline std::pair<size_t, size_t> remove_orphan_segs(std::vector<bk_hit> &hits, c
             n_orphan++;
         }
     return {jn.size(), n_orphan};
+}
+
+// CAligner::ReducePCRduplicates (Aligner.cpp:2184-2285), `-k`: among accepted reads with the same sequence, start, strand and
+// length only the first few of the sorted order are kept - none beyond the first when win_len is 0, else a number that grows with the
+// density of distinct read starts within win_len bases (NumUpUniques / NumDnUniques, :9817-9920, quirks included: the upstream
+// count looks at the read itself first and gives up at the first non-aligned read of another "sequence").  `order` = the
+// reads in the reference's sorted order (SortHitMatch).  Returns the number of reads turned into eNARPCRdup (9).
+inline size_t reduce_pcr_duplicates(std::vector<bk_hit> &hits, const std::vector<uint32_t> &order, const std::function<uint32_t(size_t)> &adj_start,
+                                    const std::function<uint32_t(size_t)> &adj_len, int win_len)
+{
+    const size_t n = order.size();
+    auto acc = [&](size_t p) { return hits[order[p]].nar == BK_NAR_ACCEPTED; };
+    auto uniques = [&](size_t p, bool up) -> int {
+        const bk_hit &c = hits[order[p]];
+        const int cur_start = (int)adj_start(order[p]);
+        int prv = cur_start, cnt = 0;
+        if (up) {
+            if (p == 0) return 0;                                   // ReadHitIdx == 1
+            for (size_t q = p + 1; q-- > 0;) {                      // starts with the read itself (m_ppReadHitsIdx[ReadHitIdx - 1])
+                const bk_hit &h = hits[order[q]];
+                if (c.chrom_id != h.chrom_id) return cnt;
+                if (h.nar != BK_NAR_ACCEPTED) continue;
+                const int st = (int)adj_start(order[q]);
+                if (cur_start > win_len && (cur_start - win_len) > st) return cnt;
+                if (c.strand != h.strand) continue;
+                if (st != prv) { cnt++; prv = st; }
+            }
+            return cnt;
+        }
+        if (p + 1 == n) return 0;
+        for (size_t q = p + 1; q < n; q++) {
+            const bk_hit &h = hits[order[q]];
+            if (c.chrom_id != h.chrom_id) return cnt;
+            if (h.nar != BK_NAR_ACCEPTED) continue;
+            const int st = (int)adj_start(order[q]);
+            if ((cur_start + win_len) < st) return cnt;
+            if (c.strand != h.strand) continue;
+            if (st != prv) { cnt++; prv = st; }
+        }
+        return cnt;
+    };
+    size_t removed = 0;
+    for (size_t p = 0; p < n; p++) {
+        if (!acc(p)) continue;
+        int limit = 0;
+        if (win_len > 0) {
+            const int up = uniques(p, true), dn = uniques(p, false);
+            limit = up > dn ? up : dn;
+            const int prop = (int)(((double)limit / win_len) * 100.0);
+            limit = prop < 5 ? 1 : prop <= 10 ? 2 : prop <= 20 ? 3 : prop <= 40 ? 4 : prop <= 60 ? 5 : prop <= 80 ? 10 : 50;
+        }
+        const bk_hit c = hits[order[p]];
+        const uint32_t c_start = adj_start(order[p]), c_len = adj_len(order[p]);
+        size_t mark = p;
+        for (size_t q = p + 1; q < n; q++) {
+            bk_hit &h = hits[order[q]];
+            if (h.nar != BK_NAR_ACCEPTED) continue;
+            if (c.chrom_id == h.chrom_id && c_start == adj_start(order[q]) && c.strand == h.strand) {
+                if (c_len != adj_len(order[q])) continue;
+                if (limit > 0) { limit--; continue; }
+                h.num_hits = 0; h.low_hit_instances = 0; h.nar = 9;          // eNARPCRdup
+                mark = q;
+                removed++;
+            } else
+                break;
+        }
+        p = mark;
+    }
+    return removed;
 }
 
 }  // namespace bk

@@ -997,12 +997,29 @@ def make_quality(tmp):
     print("  quality fixtures written")
 
 
+def make_pcr(tmp):
+    """-k (ReducePCRduplicates) on the sortorder reads (30 000 reads stacked on 2 500 loci): window 0, 20 and 200, and with -c"""
+    basic, so = os.path.join(HERE, "basic"), os.path.join(HERE, "sortorder")
+    sfx, rd = os.path.join(tmp, "k.sfx"), os.path.join(tmp, "k_reads.fa")
+    for src, dst in ((os.path.join(basic, "genome.sfx.gz"), sfx), (os.path.join(so, "reads.fa.gz"), rd)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    for tag, flags in (("k0", ["-k0"]), ("k20", ["-k20"]), ("k200", ["-k200"]), ("k50x4", ["-k50", "-x4"])):
+        out = os.path.join(tmp, f"{tag}.sam")
+        run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(so, f"s3{tag}.m6.sam.gz"))
+    print("  pcr fixtures written")
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-pcr" in sys.argv:
+            make_pcr(tmp)
             return
         if "--only-quality" in sys.argv:
             make_quality(tmp)
@@ -1063,6 +1080,7 @@ def main():
         make_chimeric(tmp)
         make_combined(tmp)
         make_quality(tmp)
+        make_pcr(tmp)
     print("done")
 
 

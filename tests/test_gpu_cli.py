@@ -376,3 +376,13 @@ def test_fastq_quality_modes_byte_identical(golden_tmp, tmp_path, g):
         gold = os.path.join(helpers.GOLDEN, "basic", "s3fqg0.m6.bam")
         assert open(bam, "rb").read() == open(gold, "rb").read()
         assert open(bam + ".bai", "rb").read() == open(gold + ".bai", "rb").read()
+
+
+# -k (ReducePCRduplicates) on the 30 000 stacked reads of the sortorder fixture
+@pytest.mark.parametrize("tag,flags", [("k0", ["-k0"]), ("k20", ["-k20"]), ("k200", ["-k200"]), ("k50x4", ["-k50", "-x4"])])
+def test_pcr_artefact_reduction_byte_identical(golden_tmp, tmp_path, tag, flags):
+    d = golden_tmp["basic"]
+    rd = os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz")
+    out = str(tmp_path / "o.sam")
+    run(["align", "-i", rd, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"] + flags, str(tmp_path))
+    _cmp_bytes(out, "sortorder", f"s3{tag}.m6.sam.gz")
