@@ -355,6 +355,7 @@ int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, i
 
 // CAligner::LoadRawReads (Aligner.cpp:10724-11427): descriptor rule, -y/-Y trims, -l/-L acceptance
 int g_qual_mode = 3;
+int g_sample_nth = 1;      // -#: every Nth raw read (or pair) of each file is processed, starting with the first (Aligner.cpp:10943,11027-11033)
 
 int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int min_len, int max_len, int nthreads, ReadStore &rs)
 {
@@ -365,7 +366,7 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
         int rc = rd.open(fn, nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading reads from '%s'", fn.c_str());
-        if (rd.parsed()) {
+        if (rd.parsed() && g_sample_nth <= 1) {
             rc = accept_chunks(rd.chunks(), fn, trim5, trim3, min_len, max_len, nthreads, rs);
             if (rc) return rc;
             continue;
@@ -375,10 +376,16 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
         size_t dl, bl;
         bool sim = false;
         uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
+        int nxt_sample = g_sample_nth;
         while ((rc = rd.next(d, dl, b, bl)) > 0) {
             n_descr++;
             if (dl > 127) dl = 127;                                       // cMaxDescrLen-1
             if (n_descr == 1) sim = dl >= 14 && (!strncmp(d, "lcl|usimreads|", 14) || !strncmp(d, "lcr|usimreads|", 14));
+            if (g_sample_nth > 1) {
+                nxt_sample++;
+                if (g_sample_nth > nxt_sample) continue;
+                nxt_sample = 0;
+            }
             int len = (int)bl;
             if (bl < 1 || bl > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
             if (trim5 + trim3 + min_len > len) {
@@ -429,6 +436,7 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
         size_t dl[2], bl[2];
         bool sim[2] = {false, false};
         uint32_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
+        int nxt_sample = g_sample_nth;
         for (;;) {
             int rc1 = rd[0].next(d[0], dl[0], b[0], bl[0]);
             if (rc1 < 0) { diag("Load: errors whilst parsing '%s'", f1[k].c_str()); return rc1; }
@@ -441,6 +449,11 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
                 if (dl[e] > 127) dl[e] = 127;
                 if (n_descr == 1) sim[e] = dl[e] >= 14 && (!strncmp(d[e], "lcl|usimreads|", 14) || !strncmp(d[e], "lcr|usimreads|", 14));
                 if (bl[e] < 1 || bl[e] > 0x30000) { diag("Problem parsing sequence after %u reads parsed", n_descr); return -63; }
+            }
+            if (g_sample_nth > 1) {
+                nxt_sample++;
+                if (g_sample_nth > nxt_sample) continue;
+                nxt_sample = 0;
             }
             for (int e = 0; e < 2 && !skip; e++) {
                 int len = (int)bl[e];
@@ -505,8 +518,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -548,6 +561,8 @@ int cmd_align(int argc, char **argv, int first)
         clamp_ml = a.has("X") || best_matches;
     }
     // -g FASTQ quality scores: 0 Sanger / Illumina 1.8+, 1 Illumina 1.3+, 2 Solexa, 3 ignore (default; QUAL is then '*')
+    g_sample_nth = a.num("#", 1);
+    if (g_sample_nth < 1 || g_sample_nth > 10000) { diag("Error: sample every Nth raw read '-#%d' specified outside of range 1..10000", g_sample_nth); return 1; }
     g_qual_mode = a.num("g", 3);
     if (g_qual_mode < 0 || g_qual_mode > 3) { diag("Error: fastq quality '-g%d' specified outside of range 0..3", g_qual_mode); return 1; }
     // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned

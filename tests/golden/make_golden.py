@@ -1008,6 +1008,21 @@ def make_pcr(tmp):
         out = os.path.join(tmp, f"{tag}.sam")
         run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"] + flags, tmp)
         gz_copy(out, os.path.join(so, f"s3{tag}.m6.sam.gz"))
+    # -# (sample every Nth raw read / pair): SE CSV (shows the read numbering) and PE SAM
+    rd2 = os.path.join(tmp, "k_basic.fa")
+    with gzip.open(os.path.join(basic, "reads.fa.gz"), "rb") as f, open(rd2, "wb") as g:
+        shutil.copyfileobj(f, g)
+    out = os.path.join(tmp, "n3.csv")
+    run([REF, "align", "-i", rd2, "-I", sfx, "-o", out, "-M0", "-s3", "-T4", "-#3"], tmp)
+    gz_copy(out, os.path.join(basic, "s3n3.m0.csv.gz"))
+    pe = os.path.join(HERE, "pe")
+    r1, r2 = os.path.join(tmp, "k_r1.fa"), os.path.join(tmp, "k_r2.fa")
+    for src, dst in ((os.path.join(pe, "reads_1.fa.gz"), r1), (os.path.join(pe, "reads_2.fa.gz"), r2)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    out = os.path.join(tmp, "U3n4.sam")
+    run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", out, "-M6", "-T4", "-U3", "-d200", "-D400", "-s5", "-#4"], tmp)
+    gz_copy(out, os.path.join(pe, "U3n4.m6.sam.gz"))
     print("  pcr fixtures written")
 
 

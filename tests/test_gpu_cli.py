@@ -386,3 +386,16 @@ def test_pcr_artefact_reduction_byte_identical(golden_tmp, tmp_path, tag, flags)
     out = str(tmp_path / "o.sam")
     run(["align", "-i", rd, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"] + flags, str(tmp_path))
     _cmp_bytes(out, "sortorder", f"s3{tag}.m6.sam.gz")
+
+
+def test_sample_nth_read_byte_identical(golden_tmp, tmp_path):
+    d = golden_tmp["basic"]
+    sfx = os.path.join(d, "genome.sfx")
+    out = str(tmp_path / "o.csv")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", sfx, "-o", out, "-M0", "-s3", "-#3"], str(tmp_path))
+    _cmp_bytes(out, "basic", "s3n3.m0.csv.gz")
+    pe = os.path.join(helpers.GOLDEN, "pe")
+    out = str(tmp_path / "pe.sam")
+    run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", sfx, "-o", out, "-M6", "-U3", "-d200", "-D400", "-s5", "-#4"],
+        str(tmp_path))
+    _cmp_bytes(out, "pe", "U3n4.m6.sam.gz")
