@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <regex.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -518,8 +519,8 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#Zz", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -585,6 +586,16 @@ int cmd_align(int argc, char **argv, int first)
     const int pcr_win = a.has("k") ? a.num("k", -1) : -1;
     if (a.has("k") && (pcr_win < 0 || pcr_win > 250)) { diag("Error: PCR differential amplification artefacts window length '-k%d' specified outside of range 0..250", pcr_win); return 1; }
     if (pcr_win >= 0 && ml_mode == 5) { diag("Error: '-k%d' together with '-r5' is not available in this build", pcr_win); return 1; }
+    // -Z / -z chromosome exclude / include filters: POSIX extended regular expressions, case-insensitive (Aligner.cpp:4770-4795)
+    std::vector<regex_t> re_excl, re_incl;
+    for (const char *opt : {"Z", "z"})
+        if (a.has(opt))
+            for (const std::string &pat : a.v[opt]) {
+                regex_t re;
+                if (regcomp(&re, pat.c_str(), REG_EXTENDED | REG_ICASE)) { diag("Error: ProcessAlign: %s chrom RE '%s' error", opt[0] == 'Z' ? "exclude" : "include", pat.c_str()); return 1; }
+                (opt[0] == 'Z' ? re_excl : re_incl).push_back(re);
+            }
+    if ((!re_excl.empty() || !re_incl.empty()) && (pe_mode || ml_mode == 5)) { diag("Error: chromosome filters '-Z/-z' together with '-U%d' / '-r5' are not available in this build", pe_mode); return 1; }
     int min_flank = a.num("x", 0);
     if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
     if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
@@ -833,6 +844,29 @@ int cmd_align(int argc, char **argv, int first)
         diag("Removal of orphan microInDels processing started..");
         auto r = bk::remove_orphan_segs(hits, seg2, 1, 8);
         diag("From %zu reads with putative microIndels %zu orphans were removed", r.first, r.second);
+    }
+
+    if (!re_excl.empty() || !re_incl.empty()) {
+        // CAligner::FiltByChroms (Aligner.cpp:4019-4120): a sequence stays if an include expression matches its name, or - with no
+        // include expressions at all - if no exclude expression does; accepted reads on the others become eNARChromFilt
+        diag("Now filtering matches by chromosome");
+        std::vector<uint8_t> keep(n_ent + 1, 1);
+        for (uint32_t c = 1; c <= n_ent; c++) {
+            regmatch_t mc;
+            bool ok = false;
+            for (regex_t &re : re_incl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = true; break; }
+            if (!ok && re_incl.empty()) {
+                ok = true;
+                for (regex_t &re : re_excl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = false; break; }
+            }
+            keep[c] = ok ? 1 : 0;
+        }
+        size_t n_filt = 0;
+        for (size_t i = 0; i < nr; i++) {
+            bk_hit &h = hits[i];
+            if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent && !keep[h.chrom_id]) { h.nar = 11; h.num_hits = 0; h.low_hit_instances = 0; n_filt++; }
+        }
+        diag("Filtering by chromosome completed - removed %zu  matches", n_filt);
     }
 
     // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): NAR histogram

@@ -1023,6 +1023,11 @@ def make_pcr(tmp):
     out = os.path.join(tmp, "U3n4.sam")
     run([REF, "align", "-i", r1, "-u", r2, "-I", sfx, "-o", out, "-M6", "-T4", "-U3", "-d200", "-D400", "-s5", "-#4"], tmp)
     gz_copy(out, os.path.join(pe, "U3n4.m6.sam.gz"))
+    # -Z / -z chromosome filters
+    for tag, flags in (("ZchrB", ["-Z", "chrB"]), ("zchra", ["-z", "^chra$"]), ("zAZB", ["-z", "chr[AB]", "-Z", "chrA"])):
+        out = os.path.join(tmp, f"{tag}.sam")
+        run([REF, "align", "-i", rd2, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(basic, f"s3{tag}.m6.sam.gz"))
     print("  pcr fixtures written")
 
 

@@ -399,3 +399,11 @@ def test_sample_nth_read_byte_identical(golden_tmp, tmp_path):
     run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", sfx, "-o", out, "-M6", "-U3", "-d200", "-D400", "-s5", "-#4"],
         str(tmp_path))
     _cmp_bytes(out, "pe", "U3n4.m6.sam.gz")
+
+
+@pytest.mark.parametrize("tag,flags", [("ZchrB", ["-Z", "chrB"]), ("zchra", ["-z", "^chra$"]), ("zAZB", ["-z", "chr[AB]", "-Z", "chrA"])])
+def test_chromosome_filters_byte_identical(golden_tmp, tmp_path, tag, flags):
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "o.sam")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"] + flags, str(tmp_path))
+    _cmp_bytes(out, "basic", f"s3{tag}.m6.sam.gz")
