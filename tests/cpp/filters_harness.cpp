@@ -4,7 +4,9 @@
 // out_trims.bin: per record uint16 left, uint16 right, uint16 trimmed mismatches
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
+#include "../../biokanga_amd/csrc/host/mtqsort.h"
 #include "../../biokanga_amd/csrc/host/post_filters.h"
 
 template <typename T>
@@ -23,6 +25,32 @@ static std::vector<T> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
+    if (argc == 5 && std::string(argv[1]) == "pcr") {
+        // filters_harness pcr <win_len> hits.bin out_hits.bin : CAligner::ReducePCRduplicates over the reference's sorted order
+        const int win = atoi(argv[2]);
+        std::vector<bk_hit> hits = slurp<bk_hit>(argv[3]);
+        std::vector<uint32_t> ord(hits.size());
+        for (size_t i = 0; i < ord.size(); i++) ord[i] = (uint32_t)i;
+        auto cmp = [&](uint32_t x, uint32_t y) -> int {          // CAligner::SortHitMatch
+            const bk_hit &p = hits[x], &q = hits[y];
+            if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
+            if (p.num_hits == 1 && q.num_hits != 1) return -1;
+            if (p.num_hits != 1 && q.num_hits == 1) return 1;
+            if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
+            if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
+            if (p.match_loci != q.match_loci) return p.match_loci < q.match_loci ? -1 : 1;
+            if (p.match_len != q.match_len) return p.match_len < q.match_len ? -1 : 1;
+            if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
+            if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
+            return 0;
+        };
+        bk::ref_order_sort(ord.data(), (int64_t)ord.size(), cmp, 4);
+        bk::reduce_pcr_duplicates(hits, ord, [&](size_t i) { return hits[i].match_loci; }, [&](size_t i) { return (uint32_t)hits[i].match_len; }, win);
+        FILE *f = fopen(argv[4], "wb");
+        fwrite(hits.data(), sizeof(bk_hit), hits.size(), f);
+        fclose(f);
+        return 0;
+    }
     if (argc != 13) return 2;
     const int min_flank = atoi(argv[1]);
     const bool paired = atoi(argv[2]) != 0, splice = atoi(argv[3]) != 0, indel = atoi(argv[4]) != 0;

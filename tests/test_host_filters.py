@@ -91,3 +91,25 @@ def test_trims_and_orphan_filters_match_reference(golden_tmp, filters_harness, t
         n_clip += (tl + tr) > 0
     if min_flank:
         assert n_clip > 20
+
+
+@pytest.mark.parametrize("tag,win", [("k0", 0), ("k20", 20), ("k200", 200)])
+def test_pcr_artefact_reduction_matches_reference(golden_tmp, filters_harness, tmp_path, tag, win):
+    """-k: the oracle's records of the 30 000 stacked sortorder reads -> reference-order sort replica -> ReducePCRduplicates restatement;
+    every read's NAR class (AA / DP / ...) against the reference's SAM"""
+    d = golden_tmp["basic"]
+    rd = str(tmp_path / "reads.fa")
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz"), rd)
+    names, bases, offs, lens = helpers.read_fasta_reads(rd)
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    hits, _ = sfx.align(bases, offs, lens, helpers.make_params(max_subs=3), nthreads=8)
+    sfx.close()
+    hp, op = str(tmp_path / "h.bin"), str(tmp_path / "o.bin")
+    hits.tofile(hp)
+    subprocess.check_call([filters_harness, "pcr", str(win), hp, op])
+    got = np.fromfile(op, dtype=helpers.HIT_DTYPE)
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "sortorder", f"s3{tag}.m6.sam.gz"))
+    tags = {r["qname"]: r["nar"] for r in recs}
+    bad = [(nm, helpers.NAR_TAGS[got["nar"][i]], tags[nm]) for i, nm in enumerate(names) if helpers.NAR_TAGS[got["nar"][i]] != tags[nm]]
+    assert not bad, (len(bad), bad[:5])
+    assert np.count_nonzero(got["nar"] == 9) > 15000
