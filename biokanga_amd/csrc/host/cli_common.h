@@ -1,0 +1,101 @@
+// cli_common.h - what the pieces of the command-line front end share: log lines in the reference's format, the option map, the
+// read store, buffered (optionally gzip'd) file output, the NAR tags.
+#pragma once
+#include <fcntl.h>
+#include <sys/time.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace bkcli {
+
+
+inline const char *kProgVer = "4.4.2";          // cpszProgVer of the release whose formats are kept (biokanga.cpp:33)
+inline std::string g_proc = "biokanga";          // gszProcName = basename(argv[0]) (used for @PG ID:)
+inline FILE *g_logfile = nullptr;
+
+// CDiagnostics::DiagOut style line: [Www Mmm dd hh:mm:ss.mmm yyyy](proc) text
+inline void diag(const char *fmt, ...)
+{
+    char msg[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof(msg), fmt, ap);
+    va_end(ap);
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    struct tm tmv;
+    localtime_r(&tv.tv_sec, &tmv);
+    char ts[64], line[4300];
+    strftime(ts, sizeof(ts), "%b %e %H:%M:%S", &tmv);
+    snprintf(line, sizeof(line), "[%s.%03d %d](%s) %s\n", ts, (int)(tv.tv_usec / 1000), tmv.tm_year + 1900, g_proc.c_str(), msg);
+    fputs(line, stdout);
+    fflush(stdout);
+    if (g_logfile) { fputs(line, g_logfile); fflush(g_logfile); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiny option parser: -x val, -xval, --long=val, --long val; repeated options accumulate
+struct Args {
+    std::map<std::string, std::vector<std::string>> v;
+    bool has(const std::string &k) const { return v.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d = "") const { return has(k) ? v.at(k).back() : d; }
+    int num(const std::string &k, int d) const { return has(k) ? atoi(v.at(k).back().c_str()) : d; }
+};
+
+inline const char *kNarTag[20] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
+inline const char *kNarDescr[20] = {"Not processed for alignment", "Alignment accepted", "Excessive indeterminate (Ns) bases",
+                             "No potential alignment loci", "Mismatch delta (minimum Hamming) criteria not met",
+                             "Aligned to multiloci", "Excessively end trimmed", "Aligned as orphaned splice junction",
+                             "Aligned as orphaned microInDel", "Duplicate PCR", "Duplicate read sequence",
+                             "Aligned to filtered target sequence", "Aligned to a priority region", "PE under minimum insert size",
+                             "PE over maximum insert size", "PE partner not aligned", "PE partner aligned to inconsistent strand",
+                             "PE partner aligned to different target sequence", "PE alignment not accepted",
+                             "Alignment violated loci base constraints"};
+
+struct ReadStore {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> lens;
+    std::vector<char> names;               // '\0' separated
+    std::vector<uint64_t> name_ofs;
+    size_t size() const { return lens.size(); }
+    const char *name(size_t i) const { return names.data() + name_ofs[i]; }
+};
+
+struct OutBuf {
+    int fd = -1;
+    gzFile gz = nullptr;                    // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337)
+    off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
+    std::vector<char> b;
+    void open(const char *path)
+    {
+        size_t n = strlen(path);
+        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz")) gz = gzdopen(fd, "wb");
+        b.reserve(8 << 20);
+        pos = 0;
+    }
+    void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
+    void put(const std::string &s) { put(s.data(), s.size()); }
+    void flush()
+    {
+        size_t o = 0;
+        if (gz) { if (!b.empty()) gzwrite(gz, b.data(), (unsigned)b.size()); b.clear(); return; }
+        while (o < b.size()) { ssize_t w = ::pwrite(fd, b.data() + o, b.size() - o, pos + (off_t)o); if (w <= 0) break; o += (size_t)w; }
+        pos += (off_t)o;
+        b.clear();
+    }
+    void close() { flush(); if (gz) { gzclose(gz); gz = nullptr; fd = -1; } if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
+};
+
+}  // namespace bkcli
