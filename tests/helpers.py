@@ -53,6 +53,13 @@ def make_params(max_subs=10, min_edit_dist=1, align_strand=0, pmode=0, max_ns=1,
 _oracle = None
 
 
+def cxx():
+    """compiler command for the C++ harnesses under tests/cpp; BK_TEST_CXXFLAGS replaces -O2, e.g.
+    BK_TEST_CXXFLAGS="-O1 -g -fsanitize=address,undefined" ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m "not gpu" -k host"""
+    flags = os.environ.get("BK_TEST_CXXFLAGS", "-O2").split()
+    return ["g++"] + flags + ["-std=c++17"]
+
+
 def oracle_lib():
     """Builds (if needed) and loads oracle/libbk_oracle.so."""
     global _oracle

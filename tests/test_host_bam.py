@@ -15,7 +15,7 @@ def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("b") / "bam_harness")
     src = [os.path.join(helpers.ROOT, "tests", "cpp", "bam_harness.cpp"),
            os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "bam_writer.cpp")]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe] + src + ["-lz"])
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe] + src + ["-lz"])
     return exe
 
 

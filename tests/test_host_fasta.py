@@ -14,7 +14,7 @@ def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("f") / "fasta_harness")
     src = [os.path.join(helpers.ROOT, "tests", "cpp", "fasta_harness.cpp"),
            os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "fasta.cpp")]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe] + src + ["-lz"])
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe] + src + ["-lz"])
     return exe
 
 

@@ -15,7 +15,7 @@ from test_oracle_golden import MIN_LEN, MAX_LEN
 @pytest.fixture(scope="module")
 def filters_harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("fh") / "filters_harness")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "filters_harness.cpp")])
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "filters_harness.cpp")])
     return exe
 
 

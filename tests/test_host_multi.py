@@ -51,7 +51,7 @@ def test_oracle_loci_order_matches_reference_r5(multi_case, tag, max_ml, best, m
 @pytest.fixture(scope="module")
 def multi_harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("mh") / "multi_harness")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "multi_harness.cpp")])
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "multi_harness.cpp")])
     return exe
 
 

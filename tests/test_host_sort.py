@@ -13,7 +13,7 @@ import helpers
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("h") / "sort_harness")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "sort_harness.cpp")])
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "sort_harness.cpp")])
     return exe
 
 
@@ -83,5 +83,5 @@ def test_sort_threads_do_not_change_the_order(harness, tmp_path):
 def test_glibc_rand_replica(tmp_path):
     """glibc_rand.h yields the C library's unseeded rand() sequence (the reference's N-run mutations and -r2 picks)"""
     exe = str(tmp_path / "rand_harness")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "rand_harness.cpp")])
+    subprocess.check_call(helpers.cxx() + ["-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "rand_harness.cpp")])
     assert subprocess.check_output([exe, "200000"]).strip() == b"0"
