@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the device path against the CPU oracle over EVERY mode of the boundary: random option sets
-(substitutions, Hamming delta, strand, sensitivity, N policy; multi-loci with / without clamp; best matches; microInDels, splice
+(substitutions, Hamming delta, strand, sensitivity, N policy; paired-end association in every -U mode; multi-loci with / without clamp;
+best matches; microInDels, splice
 junctions, chimeric trimming and their combinations) on reads built to exercise them (substitutions, insertions / deletions,
 introns, foreign ends, Ns, repeats, ragged lengths) against a repeat-rich synthetic genome.  Compares every bk_hit field, the loci
 lists and the second-segment records; stops at the first disagreement and prints the case.
@@ -59,6 +60,32 @@ def make_reads(rng, g, n, max_len):
     return np.concatenate(out), offs, lens
 
 
+def make_pairs(rng, g, n_pairs, L):
+    """FR pairs (insert 120..900, some far apart / same strand / one mate mutated beyond recognition), interleaved PE1, PE2"""
+    comp = np.array([3, 2, 1, 0, 4, 5, 6, 7], dtype=np.uint8)
+    N = len(g)
+    out = []
+    for _ in range(n_pairs):
+        ins = int(rng.integers(120, 900)) if rng.integers(0, 8) else int(rng.integers(2000, 20000))
+        st = int(rng.integers(0, N - ins - 2 * L - 100))
+        a = g[st:st + L].copy()
+        b = comp[g[st + max(ins, L) - L:st + max(ins, L)][::-1]].copy()
+        if rng.integers(0, 12) == 0:
+            b = comp[b[::-1]].copy()                     # same strand
+        for r in (a, b):
+            if (r > 4).any():
+                r[:] = g[1000:1000 + L]
+            k = int(rng.integers(0, 5)) if rng.integers(0, 10) else int(rng.integers(10, 25))
+            for q in rng.choice(L, k, replace=False):
+                r[q] = (r[q] + rng.integers(1, 4)) % 4 if r[q] < 4 else r[q]
+        if rng.integers(0, 2):
+            a, b = b, a
+        out += [a, b]
+    lens = np.full(2 * n_pairs, L, dtype=np.uint32)
+    offs = (np.arange(2 * n_pairs, dtype=np.uint64) * L)
+    return np.concatenate(out), offs, lens
+
+
 def random_params(rng):
     kw = dict(max_subs=int(rng.choice([0, 1, 2, 3, 5, 8, 10])), min_edit_dist=int(rng.integers(1, 3)), align_strand=int(rng.choice([0, 0, 1, 2])),
               pmode=int(rng.integers(0, 4)), max_ns=int(rng.choice([0, 1, 1, 3])))
@@ -106,6 +133,35 @@ def main():
     al = bk.Aligner(None, bk.AlignParams(max_subs=3), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa_ptr, el_size=el, entries=ent)
     t0 = time.time()
     for it in range(rounds):
+        if rng.integers(0, 5) == 0:                      # a paired-end round: SE pass, then the association on both sides
+            kw = dict(max_subs=int(rng.choice([1, 3, 5, 8])), min_edit_dist=int(rng.integers(1, 3)), pmode=int(rng.integers(0, 4)))
+            L = int(rng.choice([50, 100, 150, 250]))
+            bases, offs, lens = make_pairs(rng, seq_h, nreads // 2, L)
+            pe = dict(pe_mode=int(rng.integers(1, 5)), pair_min_len=int(rng.choice([100, 200])), pair_max_len=int(rng.choice([400, 1000, 5000])),
+                      pair_strand=int(rng.integers(0, 6) == 0))
+            al.set_params(bk.AlignParams(**kw))
+            al.tune("chunk_reads", 64 << 20); al.tune("use_wave", 1); al.tune("use_flat", 1)
+            got = al.align(bases, offs, lens)
+            p = helpers.make_params(**kw)
+            exp, _ = ora.align(bases, offs, lens, p, nthreads=os.cpu_count())
+            bad = None
+            for f in FIELDS:
+                if not np.array_equal(got[f], exp[f]):
+                    bad = "SE pass " + f
+            gp = al.pair(bases, offs, lens, got.copy(), bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"])))
+            ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy())
+            for f in [x for x in FIELDS if x != "rslt"]:
+                if not np.array_equal(gp[f], ep[f]):
+                    i = int(np.nonzero(gp[f] != ep[f])[0][0])
+                    bad = f"PE {f} at read {i}: gpu {gp[i]} oracle {ep[i]}"
+                    break
+            if not bad and not np.array_equal(gp["flags"] & 0x80, ep["flags"] & 0x80):
+                bad = "PE paired flag"
+            nar, cnt = np.unique(gp["nar"], return_counts=True)
+            print(f"round {it}: PE {kw} {pe} L {L}: {'OK' if not bad else 'MISMATCH ' + bad}; NAR {({bk.NAR_TAGS[int(k)]: int(v) for k, v in zip(nar, cnt)})}", flush=True)
+            if bad:
+                sys.exit(1)
+            continue
         kw = random_params(rng)
         max_len = 500 if kw.get("min_chimeric_len") else int(rng.choice([100, 150, 256, 400]))
         bases, offs, lens = make_reads(rng, seq_h, nreads, max_len)
