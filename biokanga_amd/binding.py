@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_sites", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -53,6 +53,10 @@ LOCI_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len",
 assert LOCI_DTYPE.itemsize == 12
 SEG2_DTYPE = np.dtype([("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"), ("flags", "u1"), ("score", "<u2")])
 assert SEG2_DTYPE.itemsize == 12
+SNP_ALN_DTYPE = np.dtype([("read_idx", "<u4"), ("chrom_id", "<u4"), ("loci", "<u4"), ("len", "<u2"), ("read_ofs", "<u2"), ("strand", "u1"), ("_r", "u1", (3,))])
+assert SNP_ALN_DTYPE.itemsize == 20
+SNP_SITE_DTYPE = np.dtype([("loci", "<u4"), ("num_ref", "<u4"), ("non_ref", "<u4", (5,)), ("win_mismatches", "<u4"), ("win_matches", "<u4"), ("ref_base", "<u4")])
+assert SNP_SITE_DTYPE.itemsize == 40
 
 ENTRY_DTYPE = np.dtype([("entry_id", "<u4"), ("seq_len", "<u4"), ("start_ofs", "<u8"), ("end_ofs", "<u8"),
                         ("name", "S81"), ("_pad", "S7")])
@@ -148,6 +152,12 @@ def load_library():
     lib.bk_get_counters.restype = i32
     lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
     lib.bk_get_timing.restype = i32
+    lib.bk_snp_reset.argtypes = [vp]
+    lib.bk_snp_reset.restype = i32
+    lib.bk_snp_pileup.argtypes = [vp, vp, vp, vp, u32, vp, u64]
+    lib.bk_snp_pileup.restype = i32
+    lib.bk_snp_sites.argtypes = [vp, u32, i32, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), vp]
+    lib.bk_snp_sites.restype = i32
     lib.bk_seq_counts.argtypes = [vp, vp, u32, i32]
     lib.bk_seq_counts.restype = i32
     lib.bk_build_sa_device.argtypes = [vp, u64, vp, i32, i32]
@@ -280,6 +290,33 @@ class Aligner:
             return np.zeros(0, dtype=SEG2_DTYPE)
         raw = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * SEG2_DTYPE.itemsize,))
         return raw.view(SEG2_DTYPE).copy()
+
+    def snp_reset(self):
+        rc = self.lib.bk_snp_reset(self.h)
+        if rc:
+            raise BkError(rc, "bk_snp_reset")
+
+    def snp_pileup(self, bases, offs, lens, alns):
+        """piles SNP_ALN_DTYPE alignments of the given reads up on the per-locus counts in HBM (CAligner::ProcessSNPs)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        alns = np.ascontiguousarray(alns, dtype=SNP_ALN_DTYPE)
+        rc = self.lib.bk_snp_pileup(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(lens), alns.ctypes.data, len(alns))
+        if rc:
+            raise BkError(rc, "bk_snp_pileup")
+
+    def snp_sites(self, chrom_id, min_reads, min_nonref_prop):
+        """putative SNP loci of one sequence (SNP_SITE_DTYPE, ascending loci) and its (tot_match, tot_mismatch, loci_covered, bases_coverage)"""
+        ps, n = ctypes.c_void_p(), ctypes.c_uint64()
+        tot = np.zeros(4, dtype=np.uint64)
+        rc = self.lib.bk_snp_sites(self.h, chrom_id, min_reads, float(min_nonref_prop), ctypes.byref(ps), ctypes.byref(n), tot.ctypes.data)
+        if rc:
+            raise BkError(rc, "bk_snp_sites")
+        if not ps.value or n.value == 0:
+            return np.zeros(0, dtype=SNP_SITE_DTYPE), tot
+        raw = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * SNP_SITE_DTYPE.itemsize,))
+        return raw.view(SNP_SITE_DTYPE).copy(), tot
 
     def pair(self, bases, offs, lens, hits, pe):
         """PE association in place on `hits` (PE1/PE2 interleaved; the output of align() for the same reads)"""

@@ -21,6 +21,10 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
+                       uint32_t *planes, hipStream_t s);
+void launch_snp_sites(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads, double min_prop,
+                      bk_snp_site *sites, uint32_t cap, uint32_t *n_sites, unsigned long long *totals, hipStream_t s);
 void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
@@ -125,6 +129,12 @@ struct bk_ctx {
     uint64_t tot_seq_len = 0;
     std::string dataset;
     std::vector<bk_entry_info> entries;
+    // SNP pile-up: 6 count planes over the concatenated target, site list of the last bk_snp_sites call
+    uint32_t *d_snp_planes = nullptr;
+    unsigned long long *d_snp_tot = nullptr;
+    bk_snp_site *d_snp_sites = nullptr;
+    uint32_t cap_snp_sites = 0;
+    std::vector<bk_snp_site> snp_sites;
 
     // batch scratch (grown on demand)
     uint32_t cap_reads = 0, cap_wpr = 0;
@@ -1008,7 +1018,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
     free_dev(c->d_isa);
@@ -1244,6 +1254,98 @@ int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, con
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
     return pair_on_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, n_pairs, (bk_hit *)d_hits,
                           maxlen, pe);
+}
+
+// ---- SNP pile-up and screening (see include/biokanga_amd.h) -------------------------------------
+int bk_snp_reset(bk_ctx *c)
+{
+    if (!c) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->ix.n * 6 * sizeof(uint32_t);
+    if (!c->d_snp_planes) HIP_TRY(hipMalloc(&c->d_snp_planes, bytes));
+    if (!c->d_snp_tot) HIP_TRY(hipMalloc(&c->d_snp_tot, 4 * 8));
+    HIP_TRY(hipMemsetAsync(c->d_snp_planes, 0, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BK_OK;
+}
+
+int bk_snp_pileup(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, const bk_snp_aln *alns,
+                  uint64_t n_alns)
+{
+    if (!c || (n_alns && (!bases || !offs || !lens || !alns || !nreads))) return BK_ERR_PARAMS;
+    if (!c->d_snp_planes) return BK_ERR_PARAMS;                      // bk_snp_reset() first
+    if (!n_alns) return BK_OK;
+    uint64_t lo = ~0ULL, hi = 0;
+    for (uint32_t i = 0; i < nreads; i++) { lo = std::min(lo, offs[i]); hi = std::max(hi, offs[i] + lens[i]); }
+    uint32_t max_id = 0;
+    for (const auto &e : c->entries) max_id = std::max(max_id, e.entry_id);
+    for (uint64_t i = 0; i < n_alns; i++) {
+        const bk_snp_aln &a = alns[i];
+        if (a.read_idx >= nreads || (uint32_t)a.read_ofs + a.len > lens[a.read_idx] || (a.strand != '+' && a.strand != '-')) return BK_ERR_PARAMS;
+        if (a.chrom_id == 0 || a.chrom_id > max_id) return BK_ERR_PARAMS;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    uint8_t *d_bases = nullptr;
+    uint64_t *d_offs = nullptr;
+    bk_snp_aln *d_alns = nullptr;
+    std::vector<uint64_t> rel(nreads);
+    for (uint32_t i = 0; i < nreads; i++) rel[i] = offs[i] - lo;
+    int rc = BK_OK;
+    auto try_ = [&](hipError_t e) { if (e != hipSuccess && rc == BK_OK) rc = e == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; return e == hipSuccess; };
+    if (try_(hipMalloc(&d_bases, hi - lo + 16)) && try_(hipMalloc(&d_offs, (size_t)nreads * 8)) && try_(hipMalloc(&d_alns, (size_t)n_alns * sizeof(bk_snp_aln)))) {
+        try_(hipMemcpyAsync(d_bases, bases + lo, hi - lo, hipMemcpyHostToDevice, s));
+        try_(hipMemcpyAsync(d_offs, rel.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
+        try_(hipMemcpyAsync(d_alns, alns, (size_t)n_alns * sizeof(bk_snp_aln), hipMemcpyHostToDevice, s));
+        if (rc == BK_OK) {
+            launch_snp_pileup(c->ix, d_bases, d_offs, c->d_id2idx, d_alns, n_alns, c->d_snp_planes, s);
+            try_(hipGetLastError());
+        }
+        try_(hipStreamSynchronize(s));
+    }
+    free_dev(d_bases); free_dev(d_offs); free_dev(d_alns);
+    return rc;
+}
+
+int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop, const bk_snp_site **sites, uint64_t *n_sites,
+                 bk_snp_chrom *totals)
+{
+    if (!c || !sites || !n_sites || !totals || min_reads < 1 || !(min_nonref_prop >= 0.0)) return BK_ERR_PARAMS;
+    if (!c->d_snp_planes) return BK_ERR_PARAMS;
+    const bk_entry_info *ent = nullptr;
+    for (const auto &e : c->entries) if (e.entry_id == chrom_id) { ent = &e; break; }
+    if (!ent) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!c->cap_snp_sites) {
+        HIP_TRY(hipMalloc(&c->d_snp_sites, (size_t)(1u << 20) * sizeof(bk_snp_site)));
+        c->cap_snp_sites = 1u << 20;
+    }
+    unsigned long long h_tot[4] = {0, 0, 0, 0};
+    uint32_t n = 0;
+    for (;;) {                                                        // second pass only when the list outgrew its buffer
+        HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+        HIP_TRY(hipMemsetAsync(c->d_snp_tot, 0, 4 * 8, s));
+        launch_snp_sites(c->ix, c->d_snp_planes, ent->start_ofs, (uint32_t)ent->seq_len, (uint32_t)min_reads, min_nonref_prop, c->d_snp_sites,
+                         c->cap_snp_sites, c->d_small, c->d_snp_tot, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n, c->d_small, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_tot, c->d_snp_tot, sizeof(h_tot), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n <= c->cap_snp_sites) break;
+        free_dev(c->d_snp_sites);
+        c->d_snp_sites = nullptr;
+        c->cap_snp_sites = 0;
+        HIP_TRY(hipMalloc(&c->d_snp_sites, (size_t)n * sizeof(bk_snp_site)));
+        c->cap_snp_sites = n;
+    }
+    c->snp_sites.resize(n);
+    if (n) HIP_TRY(hipMemcpy(c->snp_sites.data(), c->d_snp_sites, (size_t)n * sizeof(bk_snp_site), hipMemcpyDeviceToHost));
+    std::sort(c->snp_sites.begin(), c->snp_sites.end(), [](const bk_snp_site &a, const bk_snp_site &b) { return a.loci < b.loci; });
+    *sites = n ? c->snp_sites.data() : nullptr;
+    *n_sites = n;
+    totals->tot_match = h_tot[0]; totals->tot_mismatch = h_tot[1]; totals->loci_covered = h_tot[2]; totals->bases_coverage = h_tot[3];
+    return BK_OK;
 }
 
 int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)

@@ -37,6 +37,7 @@
 #include "mtqsort.h"
 #include "multi_assign.h"
 #include "post_filters.h"
+#include "snp.h"
 #include "report.h"
 
 namespace {
@@ -442,8 +443,9 @@ int cmd_align(int argc, char **argv, int first)
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
-        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#Zz", "EXN", a, err)) {
+        {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
+        {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#ZzpP1S", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -505,6 +507,19 @@ int cmd_align(int argc, char **argv, int first)
     const int min_chim = a.num("c", 0);
     if (min_chim != 0 && (min_chim < 50 || min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", min_chim < 0 ? -min_chim : min_chim); return 1; }
     if (min_chim && (ml_mode || pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", min_chim, ml_mode, pe_mode); return 1; }
+    // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
+    SnpOpts snp;
+    snp.min_reads = a.num("p", 0);
+    if (snp.min_reads != 0 && (snp.min_reads < 1 || snp.min_reads > 100)) { diag("Error: Minimum read coverage at any loci '-p%d' must be in range 1..100", snp.min_reads); return 1; }
+    if (snp.min_reads > 0) {
+        snp.qvalue = a.has("P") ? atof(a.str("P").c_str()) : 0.0;
+        if (snp.qvalue < 0.0 || snp.qvalue > 0.40) { diag("Error: QValue '-P%1.5f' for controlling SNP FDR (Benjamini-Hochberg) must be in range 0.0 to 0.4", snp.qvalue); return 1; }
+        if (snp.qvalue == 0.0) snp.qvalue = 0.05;
+        const double pcnt = a.has("1") ? atof(a.str("1").c_str()) : 25.0;
+        if (pcnt < 0.1 || pcnt > 35.0) { diag("Error: SNP minimum non-ref '-1%f' for controlling SNP FDR must be in range 0.1 to 35.0", pcnt); return 1; }
+        snp.nonref_prop = pcnt / 100.0;
+        if (ml_mode == 5) { diag("Error: SNP processing not currently supported if reporting multiloci alignments"); return 1; }
+    }
     // -k PCR differential amplification artefact reduction (kanga.cpp:718-724): window 0..250, off by default
     const int pcr_win = a.has("k") ? a.num("k", -1) : -1;
     if (a.has("k") && (pcr_win < 0 || pcr_win > 250)) { diag("Error: PCR differential amplification artefacts window length '-k%d' specified outside of range 0..250", pcr_win); return 1; }
@@ -809,7 +824,19 @@ int cmd_align(int argc, char **argv, int first)
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, pe_mode, ml_mode, max_ml, fmt, nthreads, micro_indel, splice_len, max_rpt_sam_seqs};
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");
-    const int rr = (fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);
+    int rr = (fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);
+    // SNPs: the file is only opened for '-M0' .. '-M5' (Aligner.cpp:4488), and only processed when reads were accepted (:746)
+    if (rr == 0 && snp.min_reads > 0 && fmt <= 5) {
+        snp.path = a.has("S") ? a.str("S") : opath + ".snp";
+        snp.bed = fmt == 4;
+        snp.vcf = !snp.bed && snp.path.size() >= 4 && !strcasecmp(snp.path.c_str() + snp.path.size() - 4, ".vcf");     // Aligner.cpp:157-165
+        snp.title = a.str("t", "kanga");
+        snp.sfx_path = a.str("I");
+        bool any = false;
+        for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED) { any = true; break; }
+        if (any) rr = process_snps(ctx, R, snp);
+        else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv"}) { OutBuf e; e.open((snp.path + ext).c_str()); e.close(); }
+    }
     bk_ctx_destroy(ctx);
     return rr;
 }

@@ -236,6 +236,43 @@ int  bk_get_timing(bk_ctx *ctx, bk_timing *out, int reset);
  * Aligner.cpp:5475-5537) - the vector the multi-GPU run sum-reduces over RCCL.  n = bk_num_entries */
 int  bk_seq_counts(bk_ctx *ctx, uint64_t *per_entry_hits, uint32_t n, int reset);
 
+/* ---- SNP calling (-p / -P / -1 / -S) --------------------------------------------------------- */
+/* The pile-up and the per-locus screening of CAligner::ProcessSNPs (biokanga/Aligner.cpp:7737-7960) and of the first
+ * loop of CAligner::OutputSNPs (:6880-7110) on the GPU: per-locus counts of reference / non-reference read bases live
+ * in HBM (6 x uint32 per target base), reads are piled up with atomic adds, and only the loci that qualify as putative
+ * SNPs travel back.  P-values (CStats::Binomial), the Benjamini-Hochberg cut and the CSV/BED/VCF writers are host
+ * policy above this boundary (biokanga_amd/csrc/host/snp.cpp). */
+typedef struct bk_snp_aln {      /* one accepted alignment without InDel/splice, after every host filter */
+    uint32_t read_idx;           /* read of this call the alignment belongs to                              */
+    uint32_t chrom_id;           /* Seg[0].ChromID                                                          */
+    uint32_t loci;               /* AdjStartLoci(Seg[0])  (Aligner.cpp:1528)                                */
+    uint16_t len;                /* AdjHitLen(Seg[0])     (Aligner.cpp:1546)                                */
+    uint16_t read_ofs;           /* Seg[0].ReadOfs + TrimLeft: first read base of the aligned part          */
+    uint8_t  strand;             /* '+' | '-' : '-' piles up the reverse complement of those read bases     */
+    uint8_t  reserved[3];
+} bk_snp_aln;                    /* 20 bytes */
+typedef struct bk_snp_site {     /* a locus passing the coverage / non-reference proportion screen (:6932-6960) */
+    uint32_t loci;
+    uint32_t num_ref;            /* tsSNPcnts.NumRefBases                                                   */
+    uint32_t non_ref[5];         /* tsSNPcnts.NonRefBaseCnts a,c,g,t,n (their sum = NumNonRefBases)         */
+    uint32_t win_mismatches;     /* LocalTotMismatches of the 51 base background window at this locus       */
+    uint32_t win_matches;        /* LocalTotMatches                                                         */
+    uint32_t ref_base;           /* tsSNPcnts.RefBase 0..3                                                  */
+} bk_snp_site;                   /* 40 bytes */
+typedef struct bk_snp_chrom {    /* whole-sequence totals OutputSNPs needs (:6881, :6927-6931) */
+    uint64_t tot_match, tot_mismatch;        /* tsChromSNPs.TotMatch / TotMismatch                          */
+    uint64_t loci_covered, bases_coverage;   /* contribution to m_LociBasesCovered / m_LociBasesCoverage    */
+} bk_snp_chrom;
+/* allocate (first call) and zero the per-locus counts */
+int  bk_snp_reset(bk_ctx *ctx);
+/* pile up `n_alns` alignments of the `nreads` host-resident reads; may be called any number of times */
+int  bk_snp_pileup(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                   const bk_snp_aln *alns, uint64_t n_alns);
+/* screen sequence `chrom_id`: loci covered by >= min_reads bases of which >= 1 and a proportion >= min_nonref_prop differ
+ * from the target, in ascending loci order (host memory owned by the context, valid until its next call) */
+int  bk_snp_sites(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop,
+                  const bk_snp_site **sites, uint64_t *n_sites, bk_snp_chrom *totals);
+
 /* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
 /* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into
  * d_sa_out (sfx_el_size bytes/element) on the device: order = nibble-lexicographic exactly as

@@ -1701,3 +1701,76 @@ int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SNP pile-up and screening.  CAligner::ProcessSNPs walks the sorted accepted reads of one sequence and counts, per
+ * locus, read bases equal to / different from the target (Aligner.cpp:7737-7960, basespace branch :7937-7957);
+ * CAligner::OutputSNPs then slides a 51 base window over the counts for the local background rate and screens every
+ * locus (:6880-7110).  P-values and everything after them are host code of the product, pinned on reference output. */
+typedef struct snp_cnts { uint8_t ref_base; uint32_t num_ref, num_nonref, nonref[5]; } snp_cnts;   /* tsSNPcnts, Aligner.h:280 */
+
+int64_t ora_snp_chrom_sites(const ora_sfx *s, const uint8_t *bases, const uint64_t *offs, const ora_snp_aln *alns, uint64_t n_alns,
+                            uint32_t chrom_id, int min_reads, double min_nonref_prop, ora_snp_site *sites_out, uint64_t max_sites,
+                            ora_snp_chrom *totals)
+{
+    if (!s || !totals || chrom_id < 1 || chrom_id > s->num_entries) return -1;
+    const ora_entry *ent = &s->entries[chrom_id - 1];
+    const uint32_t chrom_len = ent->seq_len;
+    snp_cnts *cnts = (snp_cnts *)calloc((size_t)chrom_len + 16, sizeof(snp_cnts));
+    if (!cnts) return -2;
+    uint64_t tot_match = 0, tot_mismatch = 0;
+    for (uint64_t a = 0; a < n_alns; a++) {
+        const ora_snp_aln *al = &alns[a];
+        if (al->chrom_id != chrom_id) continue;
+        uint32_t match_len = al->len, hit_loci = al->loci;
+        uint8_t rd[4096], tg[4096];
+        if (match_len > sizeof(rd)) { free(cnts); return -1; }
+        for (uint32_t i = 0; i < match_len; i++) tg[i] = s->seq[ent->start_ofs + hit_loci + i] & 0x07;
+        for (uint32_t i = 0; i < match_len; i++) rd[i] = bases[offs[al->read_idx] + al->read_ofs + i] & 0x07;
+        if (al->strand == '-') {                                              /* CSeqTrans::ReverseComplement */
+            for (uint32_t i = 0, j = match_len - 1; i < j; i++, j--) { uint8_t t = rd[i]; rd[i] = rd[j]; rd[j] = t; }
+            for (uint32_t i = 0; i < match_len; i++) if (rd[i] < 4) rd[i] = (uint8_t)(3 - rd[i]);
+        }
+        if ((uint64_t)hit_loci + match_len > chrom_len) {                     /* :7826-7830 */
+            if ((int)chrom_len - (int)hit_loci < 10) continue;
+            match_len = chrom_len - hit_loci;
+        }
+        snp_cnts *p = &cnts[hit_loci];
+        for (uint32_t i = 0; i < match_len; i++, p++) {
+            if (tg[i] >= 4 || rd[i] > 4) continue;                            /* :7877 */
+            p->ref_base = tg[i];
+            if (tg[i] == rd[i]) { p->num_ref++; tot_match++; }
+            else { p->nonref[rd[i]]++; p->num_nonref++; tot_mismatch++; }
+        }
+    }
+    /* OutputSNPs: window of cSNPBkgndRateWindow = 51 loci */
+    const uint32_t flank = 51 / 2, window = flank * 2 + 1;
+    uint32_t local_mm = 0, local_m = 0;
+    const snp_cnts *win_r = cnts, *win_l = cnts, *p = cnts;
+    for (uint32_t l = 0; l < (window < chrom_len ? window : chrom_len); l++, win_r++) { local_mm += win_r->num_nonref; local_m += win_r->num_ref; }
+    uint64_t n_sites = 0, covered = 0, coverage = 0;
+    for (uint32_t l = 0; l < chrom_len; l++, p++) {
+        if (l > flank && (l + flank) < chrom_len) {
+            local_mm = local_mm >= win_l->num_nonref ? local_mm - win_l->num_nonref : 0;
+            local_m = local_m >= win_l->num_ref ? local_m - win_l->num_ref : 0;
+            local_mm += win_r->num_nonref;
+            local_m += win_r->num_ref;
+            win_l++; win_r++;
+        }
+        int tot = (int)(p->num_nonref + p->num_ref);
+        if (tot > 0) { covered++; coverage += (uint64_t)tot; }
+        if (tot < min_reads) continue;
+        if (p->num_nonref < 1) continue;                                      /* cMinSNPreads */
+        if ((double)p->num_nonref / tot < min_nonref_prop) continue;
+        if (n_sites < max_sites && sites_out) {
+            ora_snp_site *o = &sites_out[n_sites];
+            o->loci = l; o->num_ref = p->num_ref;
+            for (int k = 0; k < 5; k++) o->non_ref[k] = p->nonref[k];
+            o->win_mismatches = local_mm; o->win_matches = local_m; o->ref_base = p->ref_base;
+        }
+        n_sites++;
+    }
+    totals->tot_match = tot_match; totals->tot_mismatch = tot_mismatch; totals->loci_covered = covered; totals->bases_coverage = coverage;
+    free(cnts);
+    return (int64_t)n_sites;
+}

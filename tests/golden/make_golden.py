@@ -1031,10 +1031,81 @@ def make_pcr(tmp):
     print("  pcr fixtures written")
 
 
+def make_snp(tmp):
+    """SNP calling (-p / -P / -1 / -S): reads drawn from a donor that differs from the indexed genome at a few hundred loci
+    (homozygous, and heterozygous with about half of the reads carrying the other allele; some adjacent so that DiSNPs and
+    TriSNPs occur), 13x coverage with 0.4% substitution errors, a few N bases; CSV, VCF and BED output, also with -x / -c."""
+    rng = np.random.default_rng(4242)
+    outdir = os.path.join(HERE, "snp")
+    os.makedirs(outdir, exist_ok=True)
+    g = [rand_seq(rng, 50000), rand_seq(rng, 25000), rand_seq(rng, 6000)]
+    g[1] = g[1][:9000] + "N" * 40 + g[1][9040:]
+    fa = os.path.join(tmp, "snp.fa")
+    write_fasta(fa, [("sA", g[0]), ("sB", g[1]), ("sC", g[2])])
+    donors = []
+    for c, seq in enumerate(g):
+        hom, het = list(seq), list(seq)
+        pos = 150
+        while pos < len(seq) - 150:
+            if seq[pos] != "N":
+                alt = "ACGT"[("ACGT".index(seq[pos]) + int(rng.integers(1, 4))) % 4]
+                hom[pos] = alt
+                if rng.integers(0, 3) != 0:
+                    het[pos] = alt
+            pos += int(rng.choice([1, 2, 7, 40, 180, 420, 700]))
+        donors.append(("".join(hom), "".join(het)))
+    reads = []
+    for c, seq in enumerate(g):
+        n = len(seq) * 13 // 100
+        for i in range(n):
+            p0 = int(rng.integers(0, len(seq) - 100))
+            src = donors[c][int(rng.integers(0, 2))]
+            s = src[p0:p0 + 100]
+            if "N" in s:
+                continue
+            s = mutate(rng, s, int(rng.binomial(100, 0.004)))
+            if rng.integers(0, 40) == 0:
+                k = int(rng.integers(0, 100)); s = s[:k] + "N" + s[k + 1:]
+            if rng.integers(0, 2):
+                s = revcomp(s)
+            reads.append((f"r{c}_{i}", s))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "snp_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "snp.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "snpsp", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    runs = (("p5", ["-M5", "-p5"], "sam", None), ("p3P10n10", ["-M5", "-p3", "-P0.1", "-1", "10"], "sam", "vcf"),
+            ("p5bed", ["-M4", "-p5"], "bed", None), ("p8x5", ["-M0", "-p8", "-x5"], "csv", None), ("p5c60", ["-M5", "-p5", "-c60"], "sam", None),
+            ("p1P40n1", ["-M0", "-p1", "-P0.4", "-1", "0.1"], "csv", None))
+    for tag, flags, ext, snpext in runs:
+        out = os.path.join(tmp, f"{tag}.{ext}")
+        cmd = [REF, "align", "-i", rd, "-I", sfx, "-o", out, "-T4", "-s5"] + flags
+        snp = out + ".snp"
+        if snpext:
+            snp = os.path.join(tmp, f"{tag}.{snpext}")
+            cmd += ["-S", snp]
+        log = run(cmd, tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+        gz_copy(snp, os.path.join(outdir, f"{tag}.snp.gz" if not snpext else f"{tag}.{snpext}.gz"))
+        for extra in (".disnp.csv", ".trisnp.csv"):
+            if os.path.exists(snp + extra):
+                gz_copy(snp + extra, os.path.join(outdir, f"{tag}{extra}.gz"))
+        with open(os.path.join(outdir, f"{tag}.log.txt"), "w") as f:
+            f.write("".join(l.split(") ", 1)[-1] for l in log.splitlines(True) if "putative SNPs" in l or "aligned loci bases" in l))
+        print("  ran", tag, flags)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
+        if "--only-snp" in sys.argv:
+            make_snp(tmp)
+            return
         if "--only-pe" in sys.argv:
             make_pe(tmp)
             return

@@ -91,6 +91,9 @@ def oracle_lib():
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                             ctypes.c_void_p]
     lib.ora_process_paired_ends.restype = ctypes.c_int
+    lib.ora_snp_chrom_sites.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.ora_snp_chrom_sites.restype = ctypes.c_int64
     lib.ora_min_core_len.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ora_min_core_len.restype = ctypes.c_int
     lib.ora_locate_first_exact.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
@@ -424,3 +427,18 @@ def write_sfx(path, dataset, entries, seq, sa, el_size=4):
             assert len(rec) == 111
             f.write(rec)
             ofs += slen + 1
+
+
+def oracle_snp_sites(sfx, bases, offs, alns, chrom_id, min_reads, min_nonref_prop, max_sites=1 << 20):
+    """ora_snp_chrom_sites: (sites as SNP_SITE_DTYPE, totals[4]) of one sequence"""
+    from biokanga_amd.binding import SNP_ALN_DTYPE, SNP_SITE_DTYPE
+    lib = oracle_lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    alns = np.ascontiguousarray(alns, dtype=SNP_ALN_DTYPE)
+    sites = np.zeros(max_sites, dtype=SNP_SITE_DTYPE)
+    tot = np.zeros(4, dtype=np.uint64)
+    n = lib.ora_snp_chrom_sites(sfx, bases.ctypes.data, offs.ctypes.data, alns.ctypes.data, len(alns), chrom_id, min_reads, float(min_nonref_prop),
+                                sites.ctypes.data, max_sites, tot.ctypes.data)
+    assert 0 <= n <= max_sites, n
+    return sites[:n].copy(), tot

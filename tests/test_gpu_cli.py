@@ -407,3 +407,53 @@ def test_chromosome_filters_byte_identical(golden_tmp, tmp_path, tag, flags):
     out = str(tmp_path / "o.sam")
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"] + flags, str(tmp_path))
     _cmp_bytes(out, "basic", f"s3{tag}.m6.sam.gz")
+
+
+SNP_RUNS = [("p5", ["-M5", "-p5"], "sam", None), ("p3P10n10", ["-M5", "-p3", "-P0.1", "-1", "10"], "sam", "vcf"), ("p5bed", ["-M4", "-p5"], "bed", None),
+            ("p8x5", ["-M0", "-p8", "-x5"], "csv", None), ("p5c60", ["-M5", "-p5", "-c60"], "sam", None), ("p1P40n1", ["-M0", "-p1", "-P0.4", "-1", "0.1"], "csv", None)]
+
+
+@pytest.mark.parametrize("tag,flags,ext,snpext", SNP_RUNS)
+def test_snp_outputs_byte_identical(golden_tmp, tmp_path, tag, flags, ext, snpext):
+    """-p / -P / -1 / -S: the SNP file (CSV, VCF or BED) and the DiSNP / TriSNP tables the reference wrote beside it.  In the VCF the
+    reference prints stale stack contents as ALT / AF when every differing base of a locus is an N (nothing qualifies as ALT); those
+    rows are compared without these two fields."""
+    d = golden_tmp["snp"]
+    out = str(tmp_path / f"{tag}.{ext}")
+    cmd = ["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-s5"] + flags
+    snp = out + ".snp"
+    if snpext:
+        snp = str(tmp_path / f"{tag}.{snpext}")
+        cmd += ["-S", snp]
+    log = run(cmd, str(tmp_path))
+    _cmp_bytes(out, "snp", f"{tag}.{ext}.gz")
+    for extra in (".disnp.csv", ".trisnp.csv"):
+        _cmp_bytes(snp + extra, "snp", f"{tag}{extra}.gz")
+    if not snpext:
+        _cmp_bytes(snp, "snp", f"{tag}.snp.gz")
+    else:
+        got, exp = open(snp, "rb").read().split(b"\n"), golden_bytes("snp", f"{tag}.{snpext}.gz").split(b"\n")
+        assert len(got) == len(exp)
+        stale = 0
+        for g, e in zip(got, exp):
+            if g.startswith(b"##reference="):
+                continue
+            if g != e:
+                gf, ef = g.split(b"\t"), e.split(b"\t")
+                assert gf[:4] == ef[:4] and gf[5:7] == ef[5:7] and gf[7].split(b";")[1] == ef[7].split(b";")[1], (g, e)
+                stale += 1
+        assert stale < len(exp) // 20
+    want = [l for l in open(os.path.join(helpers.GOLDEN, "snp", f"{tag}.log.txt")).read().splitlines() if "putative SNPs" in l or "aligned loci bases" in l]
+    for l in want:
+        assert l.split(") ", 1)[-1] in log, l
+
+
+def test_snp_option_checks(golden_tmp, tmp_path):
+    d = golden_tmp["snp"]
+    base = ["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", str(tmp_path / "o.sam")]
+    for bad in (["-p101"], ["-p5", "-P0.5"], ["-p5", "-1", "40"], ["-p5", "-r5"]):
+        r = subprocess.run([BIN] + base + bad, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0 and "Error" in r.stdout, bad
+    # -M6 never opens a SNP file (Aligner.cpp:4488)
+    run(base + ["-M6", "-p5", "-s5"], str(tmp_path))
+    assert not os.path.exists(str(tmp_path / "o.sam.snp"))

@@ -578,3 +578,107 @@ def test_chimeric_placements_match_oracle(golden_tmp, fixture, kw):
                 raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
     if fixture == "chimeric" and kw["min_chimeric_len"] <= 70 and kw["max_subs"] >= 3:
         assert np.count_nonzero(eseg["flags"] & 8) > 100
+
+
+def _assert_sites_equal(got, gtot, exp, etot, what):
+    assert np.array_equal(gtot, etot), (what, gtot, etot)
+    assert len(got) == len(exp), (what, len(got), len(exp))
+    for f in ("loci", "num_ref", "non_ref", "win_mismatches", "win_matches", "ref_base"):
+        if not np.array_equal(got[f], exp[f]):
+            i = int(np.nonzero(np.atleast_2d((got[f] != exp[f]).T).any(axis=0))[0][0])
+            raise AssertionError(f"{what}: site field {f} differs at {i}: got {got[i]} exp {exp[i]}")
+
+
+def test_snp_pileup_and_sites_match_oracle_on_fixture(golden_tmp):
+    """-p: reads of the snp fixture aligned on the device, piled up (in two calls) and screened per sequence: the site lists and the
+    totals the oracle computes from the same alignments (oracle pinned on the reference's SNP rows in test_oracle_snp.py)"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "snp", "s3")
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=5)) as al:
+        hits = al.align(bases, offs, lens)
+        acc = np.nonzero(hits["nar"] == 1)[0]
+        alns = np.zeros(len(acc), dtype=bk.SNP_ALN_DTYPE)
+        alns["read_idx"] = acc; alns["chrom_id"] = hits["chrom_id"][acc]; alns["loci"] = hits["match_loci"][acc]
+        alns["len"] = hits["match_len"][acc]; alns["strand"] = hits["strand"][acc]
+        assert len(acc) > 9000
+        al.snp_reset()
+        h = len(alns) // 2
+        al.snp_pileup(bases, offs, lens, alns[:h])
+        al.snp_pileup(bases, offs, lens, alns[h:])
+        sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+        n_sites = 0
+        for min_reads, prop in ((1, 0.001), (5, 0.25), (12, 0.1)):
+            for chrom in (1, 2, 3):
+                got, gtot = al.snp_sites(chrom, min_reads, prop)
+                exp, etot = helpers.oracle_snp_sites(sfx.h, bases, offs, alns, chrom, min_reads, prop)
+                _assert_sites_equal(got, gtot, exp, etot, (min_reads, prop, chrom))
+                n_sites += len(exp)
+        assert n_sites > 3000
+        al.snp_reset()                                                   # counts really are cleared
+        got, gtot = al.snp_sites(1, 1, 0.001)
+        assert len(got) == 0 and not gtot.any()
+        sfx.close()
+
+
+def test_snp_pileup_synthetic_edges(tmp_path):
+    """sequences shorter than, equal to and just longer than the 51 base background window, alignments on both strands with read
+    offsets, N and other non-ACGT read codes, N in the target, alignments that run past the end of their sequence"""
+    import torch
+    bk = _bk()
+    rng = np.random.default_rng(77)
+    seq_lens = [30, 50, 51, 52, 53, 76, 77, 78, 100, 101, 102, 103, 400, 1000, 2500]
+    seqs = [rng.integers(0, 4, L).astype(np.uint8) for L in seq_lens]
+    seqs[12][100:110] = 4
+    concat = np.concatenate([np.concatenate([s, [7]]) for s in seqs]).astype(np.uint8)
+    n = len(concat)
+    starts = np.concatenate([[0], np.cumsum(np.array(seq_lens) + 1)[:-1]])
+    entries = [(i + 1, seq_lens[i], int(starts[i]), int(starts[i]) + seq_lens[i] - 1) for i in range(len(seqs))]
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(concat).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    n_reads = 4000
+    lens = rng.integers(25, 130, n_reads).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.uint64)
+    bases = rng.integers(0, 4, int(lens.sum())).astype(np.uint8)
+    bases[rng.integers(0, len(bases), 600)] = 4
+    bases[rng.integers(0, len(bases), 60)] = 5
+    bases |= (rng.integers(0, 16, len(bases)).astype(np.uint8) << 4)      # quality nibbles must be ignored
+    alns = np.zeros(9000, dtype=bk.SNP_ALN_DTYPE)
+    for k in range(len(alns)):
+        r = int(rng.integers(0, n_reads)); c = int(rng.integers(0, len(seqs))); L = seq_lens[c]
+        ofs = int(rng.integers(0, 10)) if k % 3 == 0 else 0
+        ln = max(int(min(int(lens[r]) - ofs, L)), 1)
+        loci = int(rng.integers(0, L - ln + 1))
+        if k % 50 == 0 and L >= 60:
+            loci = L - ln + int(rng.integers(1, min(20, ln)))             # hangs over the end
+        alns[k] = (r, c + 1, loci, ln, ofs, ord("+-"[k & 1]), 0)
+    # and agreement with the target where a read really comes from it, so that matches dominate somewhere
+    for k in range(0, len(alns), 2):
+        a = alns[k]
+        c, L = int(a["chrom_id"]) - 1, seq_lens[int(a["chrom_id"]) - 1]
+        if a["loci"] + a["len"] > L or k % 50 == 0:
+            continue
+        lo, ln = int(a["loci"]), int(a["len"])
+        seg = seqs[c][lo:lo + ln].copy()
+        if chr(a["strand"]) == "-":
+            seg = np.where(seg < 4, 3 - seg, seg)[::-1]
+        o = int(offs[a["read_idx"]]) + int(a["read_ofs"])
+        bases[o:o + ln] = seg
+    ent = np.zeros(len(seqs), dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"s{eid}".encode(), b"")
+    ora = helpers.OracleSfx(seq=concat, sa=sa, el_size=4, entries=entries)
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=d_seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(), el_size=4, entries=ent) as al:
+        al.snp_reset()
+        al.snp_pileup(bases, offs, lens, alns)
+        tot_sites = 0
+        for min_reads, prop in ((1, 0.0), (2, 0.2), (4, 0.5)):
+            for c in range(len(seqs)):
+                got, gtot = al.snp_sites(c + 1, min_reads, prop)
+                exp, etot = helpers.oracle_snp_sites(ora.h, bases, offs, alns, c + 1, min_reads, prop)
+                _assert_sites_equal(got, gtot, exp, etot, (min_reads, prop, c + 1))
+                tot_sites += len(exp)
+        assert tot_sites > 5000
+    ora.close()
