@@ -1097,6 +1097,26 @@ def make_snp(tmp):
         with open(os.path.join(outdir, f"{tag}.log.txt"), "w") as f:
             f.write("".join(l.split(") ", 1)[-1] for l in log.splitlines(True) if "putative SNPs" in l or "aligned loci bases" in l))
         print("  ran", tag, flags)
+    # SNPs over reads other options placed: paired ends, microInDel / spliced reads (left out of the pile-up), multi-loci reads assigned by -r3,
+    # chimeric trims
+    def unz(fix, name, dst):
+        with gzip.open(os.path.join(HERE, fix, name), "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+        return dst
+    bsfx = unz("basic", "genome.sfx.gz", os.path.join(tmp, "x_basic.sfx"))
+    r1, r2 = unz("pe", "reads_1.fa.gz", os.path.join(tmp, "x_r1.fa")), unz("pe", "reads_2.fa.gz", os.path.join(tmp, "x_r2.fa"))
+    combos = [("x_pe", ["-i", r1, "-u", r2, "-I", bsfx, "-U3", "-d200", "-D400", "-s5", "-M5", "-p1", "-P0.4", "-1", "5"], "sam")]
+    for fix, tag, flags in (("indel", "x_indel", ["-a10", "-s3", "-M0", "-p1", "-P0.4", "-1", "2"]), ("multi", "x_multi", ["-r3", "-R5", "-s3", "-M0", "-p2", "-P0.4", "-1", "5"]),
+                            ("combined", "x_comb", ["-a8", "-A3000", "-c55", "-s3", "-M5", "-p1", "-P0.4", "-1", "2"]), ("splice", "x_splice", ["-A5000", "-s3", "-M4", "-p1", "-P0.4", "-1", "2"])):
+        fs, fr = unz(fix, "genome.sfx.gz", os.path.join(tmp, f"{tag}.sfx")), unz(fix, "reads.fa.gz", os.path.join(tmp, f"{tag}.fa"))
+        combos.append((tag, ["-i", fr, "-I", fs] + flags, {"-M0": "csv", "-M5": "sam", "-M4": "bed"}[[f for f in flags if f.startswith("-M")][0]]))
+    for tag, flags, ext in combos:
+        out = os.path.join(tmp, f"{tag}.{ext}")
+        run([REF, "align", "-o", out, "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+        for extra in (".snp", ".snp.disnp.csv", ".snp.trisnp.csv"):
+            gz_copy(out + extra, os.path.join(outdir, f"{tag}{extra}.gz"))
+        print("  ran", tag)
 
 
 def main():

@@ -457,3 +457,27 @@ def test_snp_option_checks(golden_tmp, tmp_path):
     # -M6 never opens a SNP file (Aligner.cpp:4488)
     run(base + ["-M6", "-p5", "-s5"], str(tmp_path))
     assert not os.path.exists(str(tmp_path / "o.sam.snp"))
+
+
+SNP_COMBOS = [("x_pe", "pe", ["-U3", "-d200", "-D400", "-s5", "-M5", "-p1", "-P0.4", "-1", "5"], "sam"), ("x_indel", "indel", ["-a10", "-s3", "-M0", "-p1", "-P0.4", "-1", "2"], "csv"),
+              ("x_multi", "multi", ["-r3", "-R5", "-s3", "-M0", "-p2", "-P0.4", "-1", "5"], "csv"),
+              ("x_comb", "combined", ["-a8", "-A3000", "-c55", "-s3", "-M5", "-p1", "-P0.4", "-1", "2"], "sam"), ("x_splice", "splice", ["-A5000", "-s3", "-M4", "-p1", "-P0.4", "-1", "2"], "bed")]
+
+
+@pytest.mark.parametrize("tag,fixture,flags,ext", SNP_COMBOS)
+def test_snp_with_other_modes_byte_identical(golden_tmp, tmp_path, tag, fixture, flags, ext):
+    """SNPs over what the other modes placed: paired ends, microInDel / spliced reads (left out of the pile-up), reads -r3 assigned,
+    chimeric trims"""
+    out = str(tmp_path / f"{tag}.{ext}")
+    if fixture == "pe":
+        r1, r2 = str(tmp_path / "r1.fa"), str(tmp_path / "r2.fa")
+        helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_1.fa.gz"), r1)
+        helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_2.fa.gz"), r2)
+        src = ["-i", r1, "-u", r2, "-I", os.path.join(golden_tmp["basic"], "genome.sfx")]
+    else:
+        d = golden_tmp[fixture]
+        src = ["-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx")]
+    run(["align", "-o", out, "-T4"] + src + flags, str(tmp_path))
+    _cmp_bytes(out, "snp", f"{tag}.{ext}.gz")
+    for extra in (".snp", ".snp.disnp.csv", ".snp.trisnp.csv"):
+        _cmp_bytes(out + extra, "snp", f"{tag}{extra}.gz")
