@@ -495,7 +495,8 @@ int cmd_align(int argc, char **argv, int first)
     const int micro_indel = a.num("a", 0);
     if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
     if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
-    if (micro_indel && (ml_mode || pe_mode)) { diag("Error: microInDels '-a%d' together with '-r%d' / '-U%d' are not available in this build", micro_indel, ml_mode, pe_mode); return 1; }
+    if (micro_indel && pe_mode) { diag("Error: Sorry, currently microInDel processing '-a%d' not supported in paired end '-U%d' processing", micro_indel, pe_mode); return 1; }   // kanga.cpp:541-545
+    if (micro_indel && ml_mode) { diag("Error: microInDels '-a%d' together with '-r%d' are not available in this build", micro_indel, ml_mode); return 1; }
     // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
     // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
     const int splice_len = a.num("A", 0);
