@@ -1307,6 +1307,18 @@ int bk_snp_pileup(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     return rc;
 }
 
+int bk_snp_pileup_device(bk_ctx *c, const void *d_bases, const void *d_offs, uint32_t nreads, const void *d_alns, uint64_t n_alns, int sync)
+{
+    if (!c || (n_alns && (!d_bases || !d_offs || !d_alns || !nreads))) return BK_ERR_PARAMS;
+    if (!c->d_snp_planes) return BK_ERR_PARAMS;
+    if (!n_alns) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_snp_pileup(c->ix, (const uint8_t *)d_bases, (const uint64_t *)d_offs, c->d_id2idx, (const bk_snp_aln *)d_alns, n_alns, c->d_snp_planes, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return BK_OK;
+}
+
 int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop, const bk_snp_site **sites, uint64_t *n_sites,
                  bk_snp_chrom *totals)
 {

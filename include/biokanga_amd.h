@@ -268,6 +268,10 @@ int  bk_snp_reset(bk_ctx *ctx);
 /* pile up `n_alns` alignments of the `nreads` host-resident reads; may be called any number of times */
 int  bk_snp_pileup(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                    const bk_snp_aln *alns, uint64_t n_alns);
+/* the same on reads already resident in HBM on the context's GPU (e.g. the buffers bk_align_batch_device was given) and a device
+ * array of alignments; asynchronous on the context's stream unless `sync`.  The caller guarantees what bk_snp_pileup checks:
+ * read_idx < nreads, read_ofs + len within the read, chrom_id a sequence of the index */
+int  bk_snp_pileup_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, uint32_t nreads, const void *d_alns, uint64_t n_alns, int sync);
 /* screen sequence `chrom_id`: loci covered by >= min_reads bases of which >= 1 and a proportion >= min_nonref_prop differ
  * from the target, in ascending loci order (host memory owned by the context, valid until its next call) */
 int  bk_snp_sites(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop,

@@ -617,6 +617,15 @@ def test_snp_pileup_and_sites_match_oracle_on_fixture(golden_tmp):
         al.snp_reset()                                                   # counts really are cleared
         got, gtot = al.snp_sites(1, 1, 0.001)
         assert len(got) == 0 and not gtot.any()
+        import torch                                                     # device-resident entry point: same counts
+        dev = torch.device("cuda:0")
+        d_b, d_o = torch.from_numpy(bases).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_a = torch.from_numpy(alns.view(np.uint8)).to(dev)
+        al.snp_pileup_device(d_b.data_ptr(), d_o.data_ptr(), len(lens), d_a.data_ptr(), len(alns))
+        for chrom in (1, 2, 3):
+            got, gtot = al.snp_sites(chrom, 5, 0.25)
+            exp, etot = helpers.oracle_snp_sites(sfx.h, bases, offs, alns, chrom, 5, 0.25)
+            _assert_sites_equal(got, gtot, exp, etot, ("device", chrom))
         sfx.close()
 
 

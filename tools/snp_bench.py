@@ -46,6 +46,16 @@ def main():
         print(f"pass {it}: reset of {6 * 4 * n / 1e9:.1f} GB of counts {(t1 - t0) * 1e3:.1f} ms; pile-up of {len(alns)} alignments ({len(alns) * 100 / 1e9:.2f} G bases, reads over PCIe) "
               f"{(t2 - t1) * 1e3:.1f} ms; screening of {len(entries)} sequences ({n / 1e9:.2f} G loci) {(t3 - t2) * 1e3:.1f} ms -> {n_sites} putative loci at -p5 -1 25; "
               f"covered loci {int(tot[2])}, coverage {int(tot[3])} bases")
+    d_alns = torch.from_numpy(alns.view(np.uint8)).to(dev)
+    for it in range(2):
+        al.snp_reset()
+        torch.cuda.synchronize(); t0 = time.time()
+        al.snp_pileup_device(bases.data_ptr(), offs.data_ptr(), n_reads, d_alns.data_ptr(), len(alns))
+        t1 = time.time()
+    s, t = al.snp_sites(entries[0][0], 5, 0.25)
+    same = np.array_equal(t, per[entries[0][0]][1]) and all(np.array_equal(s[f], per[entries[0][0]][0][f]) for f in s.dtype.names)
+    print(f"pile-up with reads and alignments resident in HBM: {(t1 - t0) * 1e3:.1f} ms = {len(alns) * 100 / (t1 - t0) / 1e9:.0f} G bases/s; sequence {entries[0][0]} "
+          f"{'identical to' if same else 'DIFFERENT from'} the host-buffer run")
     small = sorted(entries, key=lambda e: e[1])[:2]
     ora = helpers.OracleSfx(seq=seq.cpu().numpy(), sa=np.zeros(1, dtype=np.uint32), el_size=4, entries=entries)
     bad = 0
