@@ -175,9 +175,9 @@ int derive_cfg(bk_ctx *c)
     if (p.max_ml < 0 || p.max_ml > BK_MAX_ML) return BK_ERR_PARAMS;
     if (p.best_matches && p.max_ml < 2) return BK_ERR_PARAMS;
     if (p.micro_indel_len < 0 || p.micro_indel_len > 20) return BK_ERR_PARAMS;           // cMaxMicroInDelLen
-    if (p.micro_indel_len && p.max_ml > 1) return BK_ERR_PARAMS;                         // kanga.cpp:706-710 (and MaxHits is 1 in LocateInDels)
+    if ((p.micro_indel_len || p.splice_junct_len) && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;   // LocateBestMatches has no such branches
     if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99 || p.max_ml > 1)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
-    if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000 || p.max_ml > 1)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
+    if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
     g.mm_delta = p.min_edit_dist;

@@ -496,14 +496,14 @@ int cmd_align(int argc, char **argv, int first)
     if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
     if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
     if (micro_indel && pe_mode) { diag("Error: Sorry, currently microInDel processing '-a%d' not supported in paired end '-U%d' processing", micro_indel, pe_mode); return 1; }   // kanga.cpp:541-545
-    if (micro_indel && ml_mode) { diag("Error: microInDels '-a%d' together with '-r%d' are not available in this build", micro_indel, ml_mode); return 1; }
+    if (micro_indel && best_matches) { diag("Error: microInDels '-a%d' together with '-N' are not available in this build", micro_indel); return 1; }
     // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
     // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
     const int splice_len = a.num("A", 0);
     if (splice_len != 0 && (splice_len < 25 || splice_len > 100000)) { diag("Error: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000", splice_len); return 1; }
     if (splice_len && ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
     if (splice_len && pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", splice_len, pe_mode); return 1; }
-    if (splice_len && ml_mode) { diag("Error: splice junctions '-A%d' together with '-r%d' are not available in this build", splice_len, ml_mode); return 1; }
+    if (splice_len && best_matches) { diag("Error: splice junctions '-A%d' together with '-N' are not available in this build", splice_len); return 1; }
     // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
     const int min_chim = a.num("c", 0);
     if (min_chim != 0 && (min_chim < 50 || min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", min_chim < 0 ? -min_chim : min_chim); return 1; }

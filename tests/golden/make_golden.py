@@ -1119,10 +1119,32 @@ def make_snp(tmp):
         print("  ran", tag)
 
 
+def make_multi_rescue(tmp):
+    """-r1..-r4 together with -a / -A (the reference takes them; AlignReads with MaxHits > 1 runs its microInDel / splice branches): on
+    the indel, splice and combined fixtures"""
+    outdir = os.path.join(HERE, "multi")
+    def unz(fix, name, dst):
+        with gzip.open(os.path.join(HERE, fix, name), "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+        return dst
+    for fix, tag, flags, fmt, ext in (("indel", "xi_r1R5a10", ["-r1", "-R5", "-a10", "-s3"], "-M6", "sam"), ("indel", "xi_r3R5a10", ["-r3", "-R5", "-a10", "-s3"], "-M6", "sam"),
+                                     ("indel", "xi_r2R5a10", ["-r2", "-R5", "-a10", "-s3"], "-M0", "csv"), ("splice", "xs_r4R5A5000", ["-r4", "-R5", "-A5000", "-s3"], "-M6", "sam"),
+                                     ("splice", "xs_r3R3XA5000", ["-r3", "-R3", "-X", "-A5000", "-s3"], "-M5", "sam"), ("combined", "xc_r3R3a8A3000", ["-r3", "-R3", "-a8", "-A3000", "-s3"], "-M0", "csv"),
+                                     ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3"], "-M4", "bed")):
+        fs, fr = unz(fix, "genome.sfx.gz", os.path.join(tmp, f"{tag}.sfx")), unz(fix, "reads.fa.gz", os.path.join(tmp, f"{tag}.fa"))
+        out = os.path.join(tmp, f"{tag}.{ext}")
+        run([REF, "align", "-i", fr, "-I", fs, "-o", out, fmt, "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+        print("  ran", tag)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("build the reference first: oracle/build_ref.sh")
     with tempfile.TemporaryDirectory() as tmp:
+        if "--only-multi-rescue" in sys.argv:
+            make_multi_rescue(tmp)
+            return
         if "--only-snp" in sys.argv:
             make_snp(tmp)
             return

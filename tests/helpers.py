@@ -196,6 +196,30 @@ def oracle_align_indel(osfx, bases, offs, lens, params, nthreads=4):
     return out, seg2
 
 
+def oracle_align_multi_indel(osfx, bases, offs, lens, params, nthreads=4):
+    """-r modes together with -a / -A: (hits, offs[n+1], loci, seg2) - AlignReads with MaxHits > 1 and its microInDel / splice branches"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = len(lens)
+    ml = max(1, params.max_ml)
+    out = np.zeros(n, dtype=HIT_DTYPE)
+    dense = np.zeros((n, ml), dtype=LOCI_DTYPE)
+    seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+    ctr = OraCounters()
+    rc = osfx.lib.ora_align_batch_ex(osfx.h, ctypes.byref(params), bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, n,
+                                     out.ctypes.data, dense.ctypes.data, seg2.ctypes.data, ctypes.byref(ctr), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"ora_align_batch_ex failed: {rc}")
+    cnt = np.where(out["rslt"] == 1, out["low_hit_instances"].astype(np.int64), 0)
+    if params.clamp_ml:
+        cnt = np.where(out["rslt"] == 3, ml, cnt)
+    lo = np.zeros(n + 1, dtype=np.uint64)
+    lo[1:] = np.cumsum(cnt)
+    mask = np.arange(ml)[None, :] < cnt[:, None]
+    return out, lo, dense[mask], seg2
+
+
 def remove_orphan_splices(hits, seg2):
     """CAligner::RemoveOrphanSpliceJuncts (Aligner.cpp:2287-2380): same rule as for microInDels, NAR 7 (OJ).  In place."""
     return _remove_orphans(hits, seg2, 4, 7)

@@ -481,3 +481,18 @@ def test_snp_with_other_modes_byte_identical(golden_tmp, tmp_path, tag, fixture,
     _cmp_bytes(out, "snp", f"{tag}.{ext}.gz")
     for extra in (".snp", ".snp.disnp.csv", ".snp.trisnp.csv"):
         _cmp_bytes(out + extra, "snp", f"{tag}{extra}.gz")
+
+
+MULTI_RESCUE = [("indel", "xi_r1R5a10", ["-r1", "-R5", "-a10", "-s3", "-M6"], "sam"), ("indel", "xi_r3R5a10", ["-r3", "-R5", "-a10", "-s3", "-M6"], "sam"),
+                ("indel", "xi_r2R5a10", ["-r2", "-R5", "-a10", "-s3", "-M0"], "csv"), ("splice", "xs_r4R5A5000", ["-r4", "-R5", "-A5000", "-s3", "-M6"], "sam"),
+                ("splice", "xs_r3R3XA5000", ["-r3", "-R3", "-X", "-A5000", "-s3", "-M5"], "sam"), ("combined", "xc_r3R3a8A3000", ["-r3", "-R3", "-a8", "-A3000", "-s3", "-M0"], "csv"),
+                ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3", "-M4"], "bed")]
+
+
+@pytest.mark.parametrize("fixture,tag,flags,ext", MULTI_RESCUE)
+def test_multi_loci_modes_with_indel_and_splice_byte_identical(golden_tmp, tmp_path, fixture, tag, flags, ext):
+    """-r1..-r4 together with -a / -A: microInDel and spliced placements among reads handled by the multi-loci modes"""
+    d = golden_tmp[fixture]
+    out = str(tmp_path / f"{tag}.{ext}")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-T4"] + flags, str(tmp_path))
+    _cmp_bytes(out, "multi", f"{tag}.{ext}.gz")

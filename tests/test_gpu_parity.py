@@ -691,3 +691,29 @@ def test_snp_pileup_synthetic_edges(tmp_path):
                 tot_sites += len(exp)
         assert tot_sites > 5000
     ora.close()
+
+
+@pytest.mark.parametrize("kw", [dict(max_subs=3, max_ml=5, micro_indel_len=10), dict(max_subs=3, max_ml=5, clamp_ml=1, micro_indel_len=10, splice_junct_len=5000),
+                                dict(max_subs=5, max_ml=2, splice_junct_len=3000), dict(max_subs=3, max_ml=20, micro_indel_len=20, min_edit_dist=2)])
+@pytest.mark.parametrize("fixture", ["indel", "splice", "multi", "combined", "repeat"])
+def test_multi_loci_with_indel_and_splice_match_oracle(golden_tmp, fixture, kw):
+    """-r1..-r4 together with -a / -A: AlignReads with MaxHits > 1 runs the same microInDel / splice branches for what its phases left
+    unaligned; result records, loci lists and second segments against the oracle"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3")
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, eo, el, eseg = helpers.oracle_align_multi_indel(sfx, bases, offs[keep], lens[keep], helpers.make_params(**kw))
+    sfx.close()
+    for knobs in ([], [("chunk_reads", 211)], [("use_wave", 0)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs[keep], lens[keep])
+            seg = al.batch_seg2()
+            _assert_loci_equal(bk, al, len(keep), got, exp, eo, el)
+        for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score"):
+            if not np.array_equal(seg[f], eseg[f]):
+                i = int(np.nonzero(seg[f] != eseg[f])[0][0])
+                raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
+    if (fixture in ("indel", "combined") and kw.get("micro_indel_len")) or (fixture in ("splice", "combined") and kw.get("splice_junct_len")):
+        assert np.count_nonzero(eseg["flags"] & 5) > 20
