@@ -92,6 +92,11 @@ def random_params(rng):
     mode = int(rng.integers(0, 4))
     if mode == 1:
         kw.update(max_ml=int(rng.choice([2, 3, 5, 20, 500])), clamp_ml=int(rng.integers(0, 2)))
+        if rng.integers(0, 3) == 0:                      # -r1..-r4 take -a / -A too
+            if rng.integers(0, 2):
+                kw["micro_indel_len"] = int(rng.integers(1, 21))
+            else:
+                kw["splice_junct_len"] = int(rng.choice([25, 100, 2000, 6000]))
     elif mode == 2:
         kw.update(max_ml=int(rng.choice([2, 5, 50])), best_matches=1)
     elif mode == 3:
@@ -172,10 +177,15 @@ def main():
         got = al.align(bases, offs, lens)
         bad = None
         if kw.get("max_ml", 1) > 1:
-            exp, eo, el = helpers.oracle_align_multi(ora, bases, offs, lens, p, nthreads=os.cpu_count())
+            exp, eo, el, eseg = helpers.oracle_align_multi_indel(ora, bases, offs, lens, p, nthreads=os.cpu_count())
             lo, loci = al.batch_loci(len(lens))
             if not np.array_equal(lo, eo) or any(not np.array_equal(loci[f], el[f]) for f in LOCI):
                 bad = "loci lists"
+            if kw.get("micro_indel_len") or kw.get("splice_junct_len"):
+                seg = al.batch_seg2()
+                for f in SEG:
+                    if not np.array_equal(seg[f], eseg[f]):
+                        bad = f"seg2.{f} (multi-loci run)"
         else:
             exp, eseg = helpers.oracle_align_indel(ora, bases, offs, lens, p, nthreads=os.cpu_count())
             if any(kw.get(k) for k in ("micro_indel_len", "splice_junct_len", "min_chimeric_len")):
@@ -190,6 +200,21 @@ def main():
                 i = int(np.nonzero(got[f] != exp[f])[0][0])
                 bad = f"{f} at read {i} (len {lens[i]}): gpu {got[i]} oracle {exp[i]}"
                 break
+        if not bad and it % 3 == 0:                      # SNP pile-up of what was accepted, one random sequence screened against the oracle
+            acc = np.nonzero((got["nar"] == 1) & (got["strand"] != ord("?")))[0]
+            if kw.get("micro_indel_len") or kw.get("splice_junct_len") or kw.get("min_chimeric_len"):
+                acc = acc[(al.batch_seg2()["flags"][acc] & 13) == 0]
+            alns = np.zeros(len(acc), dtype=bk.SNP_ALN_DTYPE)
+            alns["read_idx"] = acc; alns["chrom_id"] = got["chrom_id"][acc]; alns["loci"] = got["match_loci"][acc]
+            alns["len"] = got["match_len"][acc]; alns["strand"] = got["strand"][acc]
+            if len(alns):
+                al.snp_reset(); al.snp_pileup(bases, offs, lens, alns)
+                chrom = int(rng.choice(np.unique(alns["chrom_id"])))
+                mr, pr = int(rng.choice([1, 2, 5])), float(rng.choice([0.001, 0.1, 0.25]))
+                gs, gt = al.snp_sites(chrom, mr, pr)
+                es, et = helpers.oracle_snp_sites(ora.h, bases, offs, alns, chrom, mr, pr, max_sites=1 << 22)
+                if len(gs) != len(es) or not np.array_equal(gt, et) or any(not np.array_equal(gs[f], es[f]) for f in es.dtype.names):
+                    bad = f"SNP sites of sequence {chrom} (-p{mr} -1 {pr * 100}): gpu {len(gs)} {gt.tolist()} oracle {len(es)} {et.tolist()}"
         nar, cnt = np.unique(got["nar"], return_counts=True)
         print(f"round {it}: {kw} max_len {max_len}: {'OK' if not bad else 'MISMATCH ' + bad}; NAR {({bk.NAR_TAGS[int(k)]: int(v) for k, v in zip(nar, cnt)})}", flush=True)
         if bad:
