@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the device path against the CPU oracle over EVERY mode of the boundary: random option sets
-(substitutions, Hamming delta, strand, sensitivity, N policy; paired-end association in every -U mode; multi-loci with / without clamp;
+(substitutions, Hamming delta, strand, sensitivity, N policy; paired-end association in every -U mode; multi-loci with / without clamp, with -a / -A; SNP pile-up and screening of the accepted reads;
 best matches; microInDels, splice
 junctions, chimeric trimming and their combinations) on reads built to exercise them (substitutions, insertions / deletions,
 introns, foreign ends, Ns, repeats, ragged lengths) against a repeat-rich synthetic genome.  Compares every bk_hit field, the loci
