@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -158,6 +158,8 @@ def load_library():
     lib.bk_snp_pileup.restype = i32
     lib.bk_snp_pileup_device.argtypes = [vp, vp, vp, u32, vp, u64, i32]
     lib.bk_snp_pileup_device.restype = i32
+    lib.bk_snp_counts.argtypes = [vp, u32, u32, u32, vp]
+    lib.bk_snp_counts.restype = i32
     lib.bk_snp_sites.argtypes = [vp, u32, i32, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), vp]
     lib.bk_snp_sites.restype = i32
     lib.bk_seq_counts.argtypes = [vp, vp, u32, i32]
@@ -313,6 +315,14 @@ class Aligner:
         rc = self.lib.bk_snp_pileup_device(self.h, d_bases_ptr, d_offs_ptr, nreads, d_alns_ptr, n_alns, 1 if sync else 0)
         if rc:
             raise BkError(rc, "bk_snp_pileup_device")
+
+    def snp_counts(self, chrom_id, loci, n):
+        """[n, 7] uint32: NumRefBases, NonRefBaseCnts a,c,g,t,n, target base of n consecutive loci"""
+        out = np.zeros((n, 7), dtype=np.uint32)
+        rc = self.lib.bk_snp_counts(self.h, chrom_id, loci, n, out.ctypes.data)
+        if rc:
+            raise BkError(rc, "bk_snp_counts")
+        return out
 
     def snp_sites(self, chrom_id, min_reads, min_nonref_prop):
         """putative SNP loci of one sequence (SNP_SITE_DTYPE, ascending loci) and its (tot_match, tot_mismatch, loci_covered, bases_coverage)"""

@@ -23,6 +23,7 @@ void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStre
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
                        uint32_t *planes, hipStream_t s);
+void launch_snp_gather(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_snp_sites(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads, double min_prop,
                       bk_snp_site *sites, uint32_t cap, uint32_t *n_sites, unsigned long long *totals, hipStream_t s);
 void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s);
@@ -1317,6 +1318,24 @@ int bk_snp_pileup_device(bk_ctx *c, const void *d_bases, const void *d_offs, uin
     HIP_TRY(hipGetLastError());
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return BK_OK;
+}
+
+int bk_snp_counts(bk_ctx *c, uint32_t chrom_id, uint32_t loci, uint32_t n, uint32_t *out)
+{
+    if (!c || !out || !c->d_snp_planes) return BK_ERR_PARAMS;
+    const bk_entry_info *ent = nullptr;
+    for (const auto &e : c->entries) if (e.entry_id == chrom_id) { ent = &e; break; }
+    if (!ent || (uint64_t)loci + n > ent->seq_len) return BK_ERR_PARAMS;
+    if (!n) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)n * 7 * 4));
+    launch_snp_gather(c->ix, c->d_snp_planes, ent->start_ofs + loci, n, d_out, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 7 * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free_dev(d_out);
+    return e == hipSuccess ? BK_OK : BK_ERR_INTERNAL;
 }
 
 int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop, const bk_snp_site **sites, uint64_t *n_sites,

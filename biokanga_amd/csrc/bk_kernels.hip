@@ -3592,6 +3592,21 @@ __global__ void __launch_bounds__(256) k_snp_sites(DevIndex ix, const uint32_t *
     if (threadIdx.x < 4 && s_tot[threadIdx.x]) atomicAdd(&totals[threadIdx.x], s_tot[threadIdx.x]);
 }
 
+__global__ void __launch_bounds__(256) k_snp_gather(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t g0, uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t g = g0 + i;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[(uint64_t)i * 7 + k] = planes[(uint64_t)k * ix.n + g];
+    out[(uint64_t)i * 7 + 6] = (uint32_t)(ix.tgt4[g >> 4] >> (60 - 4 * (unsigned)(g & 15))) & 7u;
+}
+
+void launch_snp_gather(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t n, uint32_t *out, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_snp_gather, dim3((n + 255) / 256), dim3(256), 0, s, ix, planes, g0, n, out);
+}
+
 void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
                        uint32_t *planes, hipStream_t s)
 {

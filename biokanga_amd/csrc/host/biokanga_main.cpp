@@ -444,8 +444,8 @@ int cmd_align(int argc, char **argv, int first)
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
         {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
-        {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#ZzpP1S", "EXN", a, err)) {
+        {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#ZzpP1SKG", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -520,6 +520,12 @@ int cmd_align(int argc, char **argv, int first)
         if (pcnt < 0.1 || pcnt > 35.0) { diag("Error: SNP minimum non-ref '-1%f' for controlling SNP FDR must be in range 0.1 to 35.0", pcnt); return 1; }
         snp.nonref_prop = pcnt / 100.0;
         if (ml_mode == 5) { diag("Error: SNP processing not currently supported if reporting multiloci alignments"); return 1; }
+        snp.marker_len = a.num("K", 0);                    // kanga.cpp:928-952
+        if (snp.marker_len != 0 && (snp.marker_len < 25 || snp.marker_len > 500)) { diag("Error: Marker length specified with '-K%d' must be in range 25 to 500", snp.marker_len); return 1; }
+        if (snp.marker_len) {
+            snp.marker_poly_thres = a.has("G") ? atof(a.str("G").c_str()) : (1.0 / 3.0);
+            if (snp.marker_poly_thres < 0.0 || snp.marker_poly_thres > 0.50) { diag("Error: Max marker sequence base poymorphism specified with '-G%1.3f' must be in range 0.0 to 0.5", snp.marker_poly_thres); return 1; }
+        }
     }
     // -k PCR differential amplification artefact reduction (kanga.cpp:718-724): window 0..250, off by default
     const int pcr_win = a.has("k") ? a.num("k", -1) : -1;
@@ -836,7 +842,7 @@ int cmd_align(int argc, char **argv, int first)
         bool any = false;
         for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED) { any = true; break; }
         if (any) rr = process_snps(ctx, R, snp);
-        else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv"}) { OutBuf e; e.open((snp.path + ext).c_str()); e.close(); }
+        else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv", ".markers"}) { if (ext[1] == 'm' && !snp.marker_len) continue; OutBuf e; e.open((snp.path + ext).c_str()); e.close(); }
     }
     bk_ctx_destroy(ctx);
     return rr;

@@ -3,7 +3,8 @@
 // screen run on the GPU (bk_snp_pileup / bk_snp_sites); here: the binomial P-values (CStats::Binomial,
 // libbiokanga/Stats.cpp:475-551), the Benjamini-Hochberg cut, the CSV / VCF / BED writers and the DiSNP / TriSNP
 // haplotype tables the reference writes beside the SNP file (`<snpfile>.disnp.csv`, `.trisnp.csv`).
-// Marker sequences (-K) and SNP centroids (-7) are not built.
+// Marker sequences (-K / -G, `<snpfile>.markers`) are assembled from the device counts around each putative SNP (bk_snp_counts).
+// SNP centroids (-7) are not built.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -26,6 +27,8 @@ struct SnpOpts {
     bool vcf = false, bed = false;
     std::string title;            // BED track title
     std::string sfx_path;         // ##reference= of the VCF header
+    int marker_len = 0;           // -K  0 or 25..500
+    double marker_poly_thres = 0; // -G  m_MarkerPolyThres
 };
 
 namespace snp_detail {
@@ -65,6 +68,7 @@ struct LociP {                    // tsLociPValues
     uint32_t loci, rank;
     double pvalue, bkgnd_rate;
     uint32_t local_reads, local_subs, num_reads, num_subs, ref_base, non_ref[5];
+    uint32_t marker_id, n_polymorphic;
 };
 
 inline char base_uc(uint32_t b) { return b < 4 ? "ACGT"[b] : 'N'; }          // CSeqTrans::MapBase2Ascii
@@ -85,6 +89,16 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
     tri_out.open(tri_path.c_str());
     if (di_out.fd < 0 || tri_out.fd < 0) { diag("Fatal: Unable to create/truncate DiSNP/TriSNP files beside '%s'", o.path.c_str()); return 1; }
     diag("Processing for SNPs and writing out SNPs to file '%s", o.path.c_str());
+    OutBuf marker_out;
+    const std::string marker_path = o.path + ".markers";
+    const int marker5 = o.marker_len / 2, marker3 = o.marker_len - 1 - marker5;       // Aligner.cpp:224-225
+    uint32_t marker_id = 0;
+    if (o.marker_len) {
+        marker_out.open(marker_path.c_str());
+        if (marker_out.fd < 0) { diag("Fatal: Unable to create/truncate markers file '%s'", marker_path.c_str()); return 1; }
+        diag("Processing for Markers and writing out marker sequences to file '%s", marker_path.c_str());
+    }
+    std::vector<uint32_t> mcnt;
     char line[4096];
     // headers (ProcessSNPs :7633-7718)
     if (o.bed) snp_out.put(line, (size_t)snprintf(line, sizeof(line), "track type=bed name=\"%s_SNPs\" description=\"%s SNPs\"\n", o.title.c_str(), o.title.c_str()));
@@ -185,6 +199,44 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
             }
             if (rate > 0.20) continue;                     // cMaxBkgdNoiseThres
             LociP e{};
+            if (o.marker_len) {                            // :7006-7086: only SNPs a marker sequence can be built around are reported
+                if (s.loci < (uint32_t)marker5 || s.loci + (uint32_t)marker3 >= (uint32_t)R.ents[chrom - 1].seq_len) continue;
+                if ((double)nonref / tot_bases < 0.5) continue;
+                const int mlen = 1 + marker5 + marker3, mstart = (int)s.loci - marker5;
+                mcnt.resize((size_t)mlen * 7);
+                rc = bk_snp_counts(ctx, chrom, (uint32_t)mstart, (uint32_t)mlen, mcnt.data());
+                if (rc) { diag("Fatal: SNP marker counts could not be fetched: %s", bk_strerror(rc)); return 1; }
+                std::string mseq((size_t)mlen, 'N');
+                int n_poly = 0, q = 0;
+                for (; q < mlen; q++) {
+                    const uint32_t *c7 = &mcnt[(size_t)q * 7];
+                    const uint32_t nr = c7[1] + c7[2] + c7[3] + c7[4] + c7[5];
+                    const int tb = (int)(nr + c7[0]);
+                    if (tb < o.min_reads) break;
+                    double prop = (double)nr / tb;
+                    if (prop <= o.marker_poly_thres) {
+                        if (prop > 0.1) n_poly++;
+                        mseq[(size_t)q] = base_uc(c7[6]);
+                        continue;
+                    }
+                    int al = 0;
+                    for (; al < 5; al++)
+                        if (c7[1 + al] > 0 && (prop = (double)c7[1 + al] / tb) >= (1.0 - o.marker_poly_thres)) {
+                            if (prop < 0.9) n_poly++;
+                            mseq[(size_t)q] = base_uc((uint32_t)al);
+                            break;
+                        }
+                    if (al == 5) break;
+                }
+                if (q != mlen) continue;
+                const char ref_c = base_uc(s.ref_base), snp_c = mseq[(size_t)marker5];
+                if (ref_c == snp_c) continue;
+                marker_id++;
+                e.marker_id = marker_id; e.n_polymorphic = (uint32_t)n_poly;
+                marker_out.put(line, (size_t)snprintf(line, sizeof(line), ">Marker%d %s %d|%d|%d|%d|%c|%c|%d\n", (int)marker_id, chrom_name, mstart, mlen, (int)s.loci, marker5, snp_c, ref_c, n_poly));
+                marker_out.put(mseq);
+                marker_out.put("\n", 1);
+            }
             e.loci = s.loci; e.rank = 0;
             e.pvalue = 1.0 - binomial(tot_bases, (int)nonref, rate);
             e.bkgnd_rate = rate; e.local_reads = loc_tmm + loc_tm; e.local_subs = loc_tmm;
@@ -282,7 +334,7 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
                 c5[e.ref_base] = e.num_reads - e.num_subs;
                 snp_out.put(line, (size_t)snprintf(line, sizeof(line), "%d,\"SNP\",\"%s\",\"%s\",%d,%d,1,\"+\",%d,%f,%d,%d,\"%c\",%d,%d,%d,%d,%d,%f,%d,%d,%d,%d\n", (int)tot_snps, R.species.c_str(),
                                                    chrom_name, (int)e.loci, (int)e.loci, rel_rank, e.pvalue, (int)e.num_reads, (int)e.num_subs, base_uc(e.ref_base), (int)c5[0], (int)c5[1],
-                                                   (int)c5[2], (int)c5[3], (int)c5[4], e.bkgnd_rate, (int)e.local_reads, (int)e.local_subs, 0, 0));
+                                                   (int)c5[2], (int)c5[3], (int)c5[4], e.bkgnd_rate, (int)e.local_reads, (int)e.local_subs, (int)e.marker_id, (int)e.n_polymorphic));
             }
             // ---- DiSNPs / TriSNPs (:7246-7560)
             const int cur_di = (int)e.loci;
@@ -359,6 +411,10 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
         }
     }
     snp_out.close(); di_out.close(); tri_out.close();
+    if (o.marker_len) {
+        marker_out.close();
+        diag("Marker processing completed with %d marker sequences writtten to file '%s", (int)marker_id, marker_path.c_str());
+    }
     diag("SNP processing completed with %d putative SNPs discovered", (int)tot_snps);
     diag("There are %lld aligned loci bases which are covered by %lld read bases with mean coverage of %1.2f", (long long)loci_covered, (long long)bases_coverage,
          (double)bases_coverage / (double)loci_covered);

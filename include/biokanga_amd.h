@@ -276,6 +276,9 @@ int  bk_snp_pileup_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, 
  * from the target, in ascending loci order (host memory owned by the context, valid until its next call) */
 int  bk_snp_sites(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop,
                   const bk_snp_site **sites, uint64_t *n_sites, bk_snp_chrom *totals);
+/* the counts of `n` consecutive loci of sequence `chrom_id` from `loci` on, 7 uint32 per locus: NumRefBases, NonRefBaseCnts a,c,g,t,n and
+ * the target base - what the marker sequences of `-K` are assembled from (OutputSNPs, Aligner.cpp:7006-7086) */
+int  bk_snp_counts(bk_ctx *ctx, uint32_t chrom_id, uint32_t loci, uint32_t n, uint32_t *out);
 
 /* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
 /* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into

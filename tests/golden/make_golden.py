@@ -1097,6 +1097,15 @@ def make_snp(tmp):
         with open(os.path.join(outdir, f"{tag}.log.txt"), "w") as f:
             f.write("".join(l.split(") ", 1)[-1] for l in log.splitlines(True) if "putative SNPs" in l or "aligned loci bases" in l))
         print("  ran", tag, flags)
+    # marker sequences around the SNPs (-K / -G)
+    for tag, flags in (("k51", ["-M5", "-p5", "-K51"]), ("k25G10", ["-M0", "-p3", "-K25", "-G0.1", "-P0.2", "-1", "10"]), ("k120G45", ["-M5", "-p2", "-K120", "-G0.45"])):
+        out = os.path.join(tmp, f"{tag}.sam")
+        log = run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-T4", "-s5"] + flags, tmp)
+        for extra in (".snp", ".snp.markers", ".snp.disnp.csv", ".snp.trisnp.csv"):
+            gz_copy(out + extra, os.path.join(outdir, f"{tag}{extra}.gz"))
+        with open(os.path.join(outdir, f"{tag}.log.txt"), "w") as f:
+            f.write("".join(l.split(") ", 1)[-1] for l in log.splitlines(True) if "putative SNPs" in l or "aligned loci bases" in l or "marker sequences writtten" in l))
+        print("  ran", tag, flags)
     # SNPs over reads other options placed: paired ends, microInDel / spliced reads (left out of the pile-up), multi-loci reads assigned by -r3,
     # chimeric trims
     def unz(fix, name, dst):

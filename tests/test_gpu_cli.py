@@ -496,3 +496,16 @@ def test_multi_loci_modes_with_indel_and_splice_byte_identical(golden_tmp, tmp_p
     out = str(tmp_path / f"{tag}.{ext}")
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-T4"] + flags, str(tmp_path))
     _cmp_bytes(out, "multi", f"{tag}.{ext}.gz")
+
+
+@pytest.mark.parametrize("tag,flags", [("k51", ["-M5", "-p5", "-K51"]), ("k25G10", ["-M0", "-p3", "-K25", "-G0.1", "-P0.2", "-1", "10"]), ("k120G45", ["-M5", "-p2", "-K120", "-G0.45"])])
+def test_snp_marker_sequences_byte_identical(golden_tmp, tmp_path, tag, flags):
+    """-K / -G: marker sequences assembled around the SNPs (`<snpfile>.markers`), and the SNP file restricted to the SNPs a marker could
+    be built for, with their MarkerID / NumPolymorphicSites columns"""
+    d = golden_tmp["snp"]
+    out = str(tmp_path / f"{tag}.sam")
+    log = run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-T4", "-s5"] + flags, str(tmp_path))
+    for extra in (".snp", ".snp.markers", ".snp.disnp.csv", ".snp.trisnp.csv"):
+        _cmp_bytes(out + extra, "snp", f"{tag}{extra}.gz")
+    for l in open(os.path.join(helpers.GOLDEN, "snp", f"{tag}.log.txt")).read().splitlines():
+        assert l.split(" to file")[0] in log, l
