@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
 ]
 
 
@@ -158,6 +158,8 @@ def load_library():
     lib.bk_snp_pileup.restype = i32
     lib.bk_snp_pileup_device.argtypes = [vp, vp, vp, u32, vp, u64, i32]
     lib.bk_snp_pileup_device.restype = i32
+    lib.bk_snp_centroid_insts.argtypes = [vp, u32, i32, vp]
+    lib.bk_snp_centroid_insts.restype = i32
     lib.bk_snp_counts.argtypes = [vp, u32, u32, u32, vp]
     lib.bk_snp_counts.restype = i32
     lib.bk_snp_sites.argtypes = [vp, u32, i32, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), vp]
@@ -315,6 +317,15 @@ class Aligner:
         rc = self.lib.bk_snp_pileup_device(self.h, d_bases_ptr, d_offs_ptr, nreads, d_alns_ptr, n_alns, 1 if sync else 0)
         if rc:
             raise BkError(rc, "bk_snp_pileup_device")
+
+    def snp_centroid_insts(self, chrom_id, min_reads, acc=None):
+        """adds the sequence's NumInsts per 7-mer centroid to acc (uint32[16384], created when None) and returns it"""
+        if acc is None:
+            acc = np.zeros(16384, dtype=np.uint32)
+        rc = self.lib.bk_snp_centroid_insts(self.h, chrom_id, min_reads, acc.ctypes.data)
+        if rc:
+            raise BkError(rc, "bk_snp_centroid_insts")
+        return acc
 
     def snp_counts(self, chrom_id, loci, n):
         """[n, 7] uint32: NumRefBases, NonRefBaseCnts a,c,g,t,n, target base of n consecutive loci"""

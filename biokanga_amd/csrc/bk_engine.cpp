@@ -24,6 +24,7 @@ void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t
 void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
                        uint32_t *planes, hipStream_t s);
 void launch_snp_gather(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_snp_centroids(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads, uint32_t *hist, hipStream_t s);
 void launch_snp_sites(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads, double min_prop,
                       bk_snp_site *sites, uint32_t cap, uint32_t *n_sites, unsigned long long *totals, hipStream_t s);
 void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s);
@@ -1336,6 +1337,26 @@ int bk_snp_counts(bk_ctx *c, uint32_t chrom_id, uint32_t loci, uint32_t n, uint3
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     free_dev(d_out);
     return e == hipSuccess ? BK_OK : BK_ERR_INTERNAL;
+}
+
+int bk_snp_centroid_insts(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, uint32_t *num_insts)
+{
+    if (!c || !num_insts || min_reads < 1 || !c->d_snp_planes) return BK_ERR_PARAMS;
+    const bk_entry_info *ent = nullptr;
+    for (const auto &e : c->entries) if (e.entry_id == chrom_id) { ent = &e; break; }
+    if (!ent) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d_hist = nullptr;
+    HIP_TRY(hipMalloc(&d_hist, BK_SNP_CENTROIDS * 4));
+    std::vector<uint32_t> h(BK_SNP_CENTROIDS);
+    hipError_t e = hipMemsetAsync(d_hist, 0, BK_SNP_CENTROIDS * 4, c->stream);
+    if (e == hipSuccess) { launch_snp_centroids(c->ix, c->d_snp_planes, ent->start_ofs, (uint32_t)ent->seq_len, (uint32_t)min_reads, d_hist, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_hist, BK_SNP_CENTROIDS * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free_dev(d_hist);
+    if (e != hipSuccess) return BK_ERR_INTERNAL;
+    for (int i = 0; i < BK_SNP_CENTROIDS; i++) num_insts[i] += h[i];
+    return BK_OK;
 }
 
 int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_nonref_prop, const bk_snp_site **sites, uint64_t *n_sites,

@@ -3607,6 +3607,42 @@ void launch_snp_gather(const DevIndex &ix, const uint32_t *planes, uint64_t g0, 
     if (n) hipLaunchKernelGGL(k_snp_gather, dim3((n + 255) / 256), dim3(256), 0, s, ix, planes, g0, n, out);
 }
 
+__global__ void __launch_bounds__(256) k_snp_centroids(DevIndex ix, const uint32_t *__restrict__ planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads,
+                                                       uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[BK_SNP_CENTROIDS];                          // 64 KB of the CU's 160 KB LDS
+    for (uint32_t i = threadIdx.x; i < BK_SNP_CENTROIDS; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    for (uint64_t l64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 3; l64 + 3 < chrom_len; l64 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g = g0 + l64;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) tot += planes[(uint64_t)k * ix.n + g];
+        if (tot < min_reads) continue;
+        const uint64_t w = nib16(ix.tgt4, g - 3);                         // 7 target bases from the top nibble down
+        uint32_t idx = 0;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint32_t b = (uint32_t)(w >> (60 - 4 * j)) & 7u;
+            ok = ok && b < 4;
+            idx = (idx << 2) | (b & 3u);
+        }
+        if (ok) atomicAdd(&s_hist[idx], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < BK_SNP_CENTROIDS; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+void launch_snp_centroids(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t chrom_len, uint32_t min_reads, uint32_t *hist, hipStream_t s)
+{
+    if (chrom_len < 7) return;
+    uint64_t blocks = ((uint64_t)chrom_len + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_snp_centroids, dim3((unsigned)blocks), dim3(256), 0, s, ix, planes, g0, chrom_len, min_reads, hist);
+}
+
 void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
                        uint32_t *planes, hipStream_t s)
 {

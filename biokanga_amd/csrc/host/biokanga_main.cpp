@@ -444,8 +444,8 @@ int cmd_align(int argc, char **argv, int first)
         {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
         {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
-        {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}};
-    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#ZzpP1SKG", "EXN", a, err)) {
+        {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}, {"snpcentroid", "7"}};
+    if (!parse_args(argc, argv, first, ln, "mQesnyYlLMiIoOTFfUrg4udDjJtRaxAck#ZzpP1SKG7", "EXN", a, err)) {
         fprintf(stderr, "%s align: %s\n", g_proc.c_str(), err.c_str());
         return 1;
     }
@@ -521,6 +521,7 @@ int cmd_align(int argc, char **argv, int first)
         snp.nonref_prop = pcnt / 100.0;
         if (ml_mode == 5) { diag("Error: SNP processing not currently supported if reporting multiloci alignments"); return 1; }
         snp.marker_len = a.num("K", 0);                    // kanga.cpp:928-952
+        snp.centroid_path = a.str("7", "");                // kanga.cpp:954-960
         if (snp.marker_len != 0 && (snp.marker_len < 25 || snp.marker_len > 500)) { diag("Error: Marker length specified with '-K%d' must be in range 25 to 500", snp.marker_len); return 1; }
         if (snp.marker_len) {
             snp.marker_poly_thres = a.has("G") ? atof(a.str("G").c_str()) : (1.0 / 3.0);

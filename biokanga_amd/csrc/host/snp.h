@@ -4,7 +4,7 @@
 // libbiokanga/Stats.cpp:475-551), the Benjamini-Hochberg cut, the CSV / VCF / BED writers and the DiSNP / TriSNP
 // haplotype tables the reference writes beside the SNP file (`<snpfile>.disnp.csv`, `.trisnp.csv`).
 // Marker sequences (-K / -G, `<snpfile>.markers`) are assembled from the device counts around each putative SNP (bk_snp_counts).
-// SNP centroids (-7) are not built.
+// SNP centroids (-7 <file>): NumInsts per 7-mer from the device (bk_snp_centroid_insts), the per-SNP sums on the host.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -28,6 +28,7 @@ struct SnpOpts {
     std::string title;            // BED track title
     std::string sfx_path;         // ##reference= of the VCF header
     int marker_len = 0;           // -K  0 or 25..500
+    std::string centroid_path;    // -7
     double marker_poly_thres = 0; // -G  m_MarkerPolyThres
 };
 
@@ -73,6 +74,7 @@ struct LociP {                    // tsLociPValues
 
 inline char base_uc(uint32_t b) { return b < 4 ? "ACGT"[b] : 'N'; }          // CSeqTrans::MapBase2Ascii
 inline char base_lc(uint32_t b) { return b < 4 ? "acgt"[b] : 'n'; }
+inline const char *kCentroidCase = "ACGT";     // CSeqTrans::MapSeq2Ascii
 
 }  // namespace snp_detail
 
@@ -99,6 +101,16 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
         diag("Processing for Markers and writing out marker sequences to file '%s", marker_path.c_str());
     }
     std::vector<uint32_t> mcnt;
+    struct Centroid { uint32_t num_snps = 0, ref_cnt = 0, non_ref[5] = {0, 0, 0, 0, 0}; };
+    std::vector<Centroid> cents;
+    std::vector<uint32_t> cent_insts;
+    OutBuf cent_out;
+    if (!o.centroid_path.empty()) {
+        cent_out.open(o.centroid_path.c_str());
+        if (cent_out.fd < 0) { diag("Fatal: Unable to create/truncate SNP centroids file '%s'", o.centroid_path.c_str()); return 1; }
+        cents.resize(BK_SNP_CENTROIDS);
+        cent_insts.assign(BK_SNP_CENTROIDS, 0);
+    }
     char line[4096];
     // headers (ProcessSNPs :7633-7718)
     if (o.bed) snp_out.put(line, (size_t)snprintf(line, sizeof(line), "track type=bed name=\"%s_SNPs\" description=\"%s SNPs\"\n", o.title.c_str(), o.title.c_str()));
@@ -179,6 +191,10 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
         rc = bk_snp_sites(ctx, chrom, o.min_reads, o.nonref_prop, &sites, &n_sites, &tot);
         if (rc) { diag("Fatal: SNP screening failed: %s", bk_strerror(rc)); return 1; }
         loci_covered += tot.loci_covered; bases_coverage += tot.bases_coverage;
+        if (!cents.empty()) {
+            rc = bk_snp_centroid_insts(ctx, chrom, o.min_reads, cent_insts.data());
+            if (rc) { diag("Fatal: SNP centroid counting failed: %s", bk_strerror(rc)); return 1; }
+        }
         const char *chrom_name = R.ents[chrom - 1].name;
         const ChromAcc &ca = acc[chrom];
         const int max_disnp_sep = (int)(uint32_t)((ca.tot_len + ca.n_reads - 1) / ca.n_reads);      // MeanReadLen (:7750)
@@ -408,9 +424,35 @@ inline int process_snps(bk_ctx *ctx, Report &R, const SnpOpts &o)
             prev_di = cur_di;
             first_tri = prev_tri;
             prev_tri = cur_tri;
+            if (!cents.empty() && e.loci >= 3 && e.loci < (uint32_t)R.ents[chrom - 1].seq_len - 3) {          // :7563-7590
+                uint32_t c7[7 * 7];
+                rc = bk_snp_counts(ctx, chrom, e.loci - 3, 7, c7);
+                if (rc) { diag("Fatal: SNP centroid counts could not be fetched: %s", bk_strerror(rc)); return 1; }
+                uint32_t idx = 0;
+                bool ok = true;
+                for (int q = 0; q < 7; q++) { ok = ok && c7[q * 7 + 6] < 4; idx = (idx << 2) | (c7[q * 7 + 6] & 3u); }
+                if (ok) {
+                    Centroid &c = cents[idx];
+                    c.ref_cnt += c7[3 * 7 + 0];
+                    for (int b = 0; b < 5; b++) c.non_ref[b] += c7[3 * 7 + 1 + b];
+                    c.num_snps++;
+                }
+            }
         }
     }
     snp_out.close(); di_out.close(); tri_out.close();
+    if (!cents.empty()) {                                  // ProcessSNPs :8001-8032
+        cent_out.put(std::string("\"CentroidID\",\"Seq\",\"NumInsts\",\"NumSNPs\",\"RefBase\",\"RefBaseCnt\",\"BaseA\",\"BaseC\",\"BaseG\",\"BaseT\",\"BaseN\"\n"));
+        for (uint32_t k = 0; k < BK_SNP_CENTROIDS; k++) {
+            char seq7[8];
+            for (int q = 0; q < 7; q++) seq7[q] = kCentroidCase[(k >> (2 * (6 - q))) & 3u];
+            seq7[7] = '\0';
+            const Centroid &c = cents[k];
+            cent_out.put(line, (size_t)snprintf(line, sizeof(line), "%d,\"%s\",%d,%d,\"%c\",%d,%d,%d,%d,%d,%d\n", (int)k + 1, seq7, (int)cent_insts[k], (int)c.num_snps, base_uc((k >> 6) & 3u),
+                                                (int)c.ref_cnt, (int)c.non_ref[0], (int)c.non_ref[1], (int)c.non_ref[2], (int)c.non_ref[3], (int)c.non_ref[4]));
+        }
+        cent_out.close();
+    }
     if (o.marker_len) {
         marker_out.close();
         diag("Marker processing completed with %d marker sequences writtten to file '%s", (int)marker_id, marker_path.c_str());

@@ -279,6 +279,11 @@ int  bk_snp_sites(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, double min_
 /* the counts of `n` consecutive loci of sequence `chrom_id` from `loci` on, 7 uint32 per locus: NumRefBases, NonRefBaseCnts a,c,g,t,n and
  * the target base - what the marker sequences of `-K` are assembled from (OutputSNPs, Aligner.cpp:7006-7086) */
 int  bk_snp_counts(bk_ctx *ctx, uint32_t chrom_id, uint32_t loci, uint32_t n, uint32_t *out);
+/* SNP centroids (`-7 <file>`): adds, for every locus of sequence `chrom_id` covered by >= min_reads bases and at least 3 bases away from
+ * both ends, one to num_insts[k], k = the 7 target bases centred on the locus as a base-4 number (first base most significant; loci with a
+ * non-ACGT base in the window are skipped) - tsSNPCentroid.NumInsts of OutputSNPs (Aligner.cpp:6934-6953).  num_insts: 16384 uint32. */
+#define BK_SNP_CENTROIDS 16384
+int  bk_snp_centroid_insts(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, uint32_t *num_insts);
 
 /* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
 /* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into

@@ -1106,6 +1106,13 @@ def make_snp(tmp):
         with open(os.path.join(outdir, f"{tag}.log.txt"), "w") as f:
             f.write("".join(l.split(") ", 1)[-1] for l in log.splitlines(True) if "putative SNPs" in l or "aligned loci bases" in l or "marker sequences writtten" in l))
         print("  ran", tag, flags)
+    # SNP centroids (-7): per 7-mer context, how many well covered loci and how many SNPs
+    for tag, flags in (("cent5", ["-M5", "-p5"]), ("cent2P40", ["-M0", "-p2", "-P0.4", "-1", "1"])):
+        out, cent = os.path.join(tmp, f"{tag}.sam"), os.path.join(tmp, f"{tag}.centroids.csv")
+        run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-T4", "-s5", "-7", cent] + flags, tmp)
+        gz_copy(out + ".snp", os.path.join(outdir, f"{tag}.snp.gz"))
+        gz_copy(cent, os.path.join(outdir, f"{tag}.centroids.csv.gz"))
+        print("  ran", tag, flags)
     # SNPs over reads other options placed: paired ends, microInDel / spliced reads (left out of the pile-up), multi-loci reads assigned by -r3,
     # chimeric trims
     def unz(fix, name, dst):

@@ -509,3 +509,13 @@ def test_snp_marker_sequences_byte_identical(golden_tmp, tmp_path, tag, flags):
         _cmp_bytes(out + extra, "snp", f"{tag}{extra}.gz")
     for l in open(os.path.join(helpers.GOLDEN, "snp", f"{tag}.log.txt")).read().splitlines():
         assert l.split(" to file")[0] in log, l
+
+
+@pytest.mark.parametrize("tag,flags", [("cent5", ["-M5", "-p5"]), ("cent2P40", ["-M0", "-p2", "-P0.4", "-1", "1"])])
+def test_snp_centroids_byte_identical(golden_tmp, tmp_path, tag, flags):
+    """-7: the SNP centroid table (per 7-mer context: covered loci counted on the device, SNPs and their base counts)"""
+    d = golden_tmp["snp"]
+    out, cent = str(tmp_path / f"{tag}.sam"), str(tmp_path / f"{tag}.centroids.csv")
+    run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-T4", "-s5", "-7", cent] + flags, str(tmp_path))
+    _cmp_bytes(out + ".snp", "snp", f"{tag}.snp.gz")
+    _cmp_bytes(cent, "snp", f"{tag}.centroids.csv.gz")

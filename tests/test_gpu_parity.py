@@ -690,6 +690,22 @@ def test_snp_pileup_synthetic_edges(tmp_path):
                 _assert_sites_equal(got, gtot, exp, etot, (min_reads, prop, c + 1))
                 tot_sites += len(exp)
         assert tot_sites > 5000
+        # bk_snp_counts (per-locus counts + target base) and the 7-mer centroid histogram built from them
+        acc, exp_hist = None, np.zeros(16384, dtype=np.uint32)
+        for c, L in enumerate(seq_lens):
+            cnt = al.snp_counts(c + 1, 0, L)
+            assert np.array_equal(cnt[:, 6], seqs[c] & 7)
+            sites, _ = helpers.oracle_snp_sites(ora.h, bases, offs, alns, c + 1, 1, 0.0)
+            for st in sites[:: max(1, len(sites) // 50)]:
+                row = cnt[int(st["loci"])]
+                assert row[0] == st["num_ref"] and np.array_equal(row[1:6], st["non_ref"])
+            acc = al.snp_centroid_insts(c + 1, 2, acc)
+            tot = cnt[:, :6].sum(axis=1)
+            for l in range(3, L - 3):
+                w = seqs[c][l - 3:l + 4]
+                if tot[l] >= 2 and (w < 4).all():
+                    exp_hist[int(sum(int(b) << (2 * (6 - j)) for j, b in enumerate(w)))] += 1
+        assert np.array_equal(acc, exp_hist) and exp_hist.sum() > 3000
     ora.close()
 
 
