@@ -15,6 +15,8 @@ EXPORTED_SYMBOLS = [
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
+    "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
 ]
 
 
@@ -84,6 +86,11 @@ class _Timing(ctypes.Structure):
                 ("ms_heavy", ctypes.c_float), ("ms_other", ctypes.c_float),
                 ("n_search_launches", ctypes.c_uint32), ("n_extend_launches", ctypes.c_uint32),
                 ("n_heavy_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class _StreamStats(ctypes.Structure):
+    _fields_ = [("batches", ctypes.c_uint64), ("reads", ctypes.c_uint64), ("bytes_h2d", ctypes.c_uint64),
+                ("bytes_d2h", ctypes.c_uint64), ("seconds_first_submit_to_last_result", ctypes.c_double)]
 
 
 def lib_path():
@@ -168,6 +175,28 @@ def load_library():
     lib.bk_seq_counts.restype = i32
     lib.bk_build_sa_device.argtypes = [vp, u64, vp, i32, i32]
     lib.bk_build_sa_device.restype = i32
+    lib.bk_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.bk_host_alloc.restype = vp
+    lib.bk_host_free.argtypes = [vp]
+    lib.bk_host_free.restype = None
+    lib.bk_stream_create.argtypes = [ctypes.POINTER(vp), vp, u32, u64, i32, ctypes.POINTER(PEParams)]
+    lib.bk_stream_create.restype = i32
+    lib.bk_stream_submit.argtypes = [vp, vp, u64, vp, vp, u32, vp, ctypes.POINTER(u64)]
+    lib.bk_stream_submit.restype = i32
+    lib.bk_stream_wait.argtypes = [vp, u64]
+    lib.bk_stream_wait.restype = i32
+    lib.bk_stream_batch_loci.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_stream_batch_loci.restype = i32
+    lib.bk_stream_batch_seg2.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_stream_batch_seg2.restype = i32
+    lib.bk_stream_release.argtypes = [vp, u64]
+    lib.bk_stream_release.restype = i32
+    lib.bk_stream_drain.argtypes = [vp]
+    lib.bk_stream_drain.restype = i32
+    lib.bk_stream_get_stats.argtypes = [vp, ctypes.POINTER(_StreamStats), i32]
+    lib.bk_stream_get_stats.restype = i32
+    lib.bk_stream_destroy.argtypes = [vp]
+    lib.bk_stream_destroy.restype = None
     _lib = lib
     return lib
 
@@ -392,3 +421,116 @@ class Aligner:
         if rc:
             raise BkError(rc, "bk_seq_counts")
         return out
+
+
+def host_array(n, dtype):
+    """numpy array of n elements over page-locked host memory (bk_host_alloc) - what bk_stream_* DMAs from / to directly.
+    The memory is released when the array (and every view of it) is gone."""
+    lib = load_library()
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n) * dt.itemsize)
+    p = lib.bk_host_alloc(nbytes)
+    if not p:
+        raise MemoryError(f"bk_host_alloc({nbytes})")
+
+    class _Owner:
+        def __del__(self, p=p, lib=lib):
+            lib.bk_host_free(p)
+    buf = (ctypes.c_uint8 * nbytes).from_address(p)
+    buf._owner = _Owner()
+    return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
+class Stream:
+    """bk_stream_*: overlapped upload / align / download of consecutive batches on one context."""
+
+    def __init__(self, aligner, max_batch_reads, max_batch_bases, depth=3, pe=None):
+        self.lib = aligner.lib
+        self.al = aligner
+        self.h = ctypes.c_void_p()
+        rc = self.lib.bk_stream_create(ctypes.byref(self.h), aligner.h, int(max_batch_reads), int(max_batch_bases), int(depth),
+                                       ctypes.byref(pe) if pe is not None else None)
+        if rc:
+            self.h = None
+            raise BkError(rc, "bk_stream_create")
+        self._keep = {}
+
+    def submit(self, bases, offs, lens, out):
+        """arrays must stay alive and untouched until wait(ticket) (they are kept referenced here); offs may be None for
+        reads lying back to back"""
+        assert bases.dtype == np.uint8 and lens.dtype == np.uint32 and out.dtype == HIT_DTYPE and len(out) >= len(lens)
+        assert offs is None or (offs.dtype == np.uint64 and len(offs) == len(lens))
+        for a in (bases, lens, out) + (() if offs is None else (offs,)):
+            assert a.flags["C_CONTIGUOUS"]
+        t = ctypes.c_uint64()
+        rc = self.lib.bk_stream_submit(self.h, bases.ctypes.data, bases.size, None if offs is None else offs.ctypes.data,
+                                       lens.ctypes.data, len(lens), out.ctypes.data, ctypes.byref(t))
+        if rc:
+            raise BkError(rc, "bk_stream_submit")
+        self._keep[t.value] = (bases, offs, lens, out)
+        return t.value
+
+    def wait(self, ticket):
+        rc = self.lib.bk_stream_wait(self.h, ticket)
+        self._keep.pop(ticket, None)
+        if rc:
+            raise BkError(rc, "bk_stream_wait")
+
+    def batch_loci(self, ticket, nreads):
+        po, pl, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self.lib.bk_stream_batch_loci(self.h, ticket, ctypes.byref(po), ctypes.byref(pl), ctypes.byref(n))
+        if rc:
+            raise BkError(rc, "bk_stream_batch_loci")
+        if not po.value:
+            return np.zeros(nreads + 1, dtype=np.uint64), np.zeros(0, dtype=LOCI_DTYPE)
+        offs = np.ctypeslib.as_array(ctypes.cast(po, ctypes.POINTER(ctypes.c_uint64)), shape=(nreads + 1,)).copy()
+        if n.value == 0:
+            return offs, np.zeros(0, dtype=LOCI_DTYPE)
+        raw = np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_DTYPE.itemsize,))
+        return offs, raw.view(LOCI_DTYPE).copy()
+
+    def batch_seg2(self, ticket):
+        ps, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self.lib.bk_stream_batch_seg2(self.h, ticket, ctypes.byref(ps), ctypes.byref(n))
+        if rc:
+            raise BkError(rc, "bk_stream_batch_seg2")
+        if not ps.value or n.value == 0:
+            return np.zeros(0, dtype=SEG2_DTYPE)
+        raw = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * SEG2_DTYPE.itemsize,))
+        return raw.view(SEG2_DTYPE).copy()
+
+    def release(self, ticket):
+        rc = self.lib.bk_stream_release(self.h, ticket)
+        if rc:
+            raise BkError(rc, "bk_stream_release")
+
+    def drain(self):
+        rc = self.lib.bk_stream_drain(self.h)
+        self._keep.clear()
+        if rc:
+            raise BkError(rc, "bk_stream_drain")
+
+    def stats(self, reset=False):
+        st = _StreamStats()
+        rc = self.lib.bk_stream_get_stats(self.h, ctypes.byref(st), 1 if reset else 0)
+        if rc:
+            raise BkError(rc, "bk_stream_get_stats")
+        return {k: getattr(st, k) for k, _ in _StreamStats._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bk_stream_destroy(self.h)
+            self.h = None
+            self._keep.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,109 @@
+// bk_ctx_int.h - internal: the context behind the C ABI (include/biokanga_amd.h), shared by bk_engine.cpp (batch driver)
+// and bk_stream.cpp (overlapped host <-> device pipeline).  Not part of the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "bk_device.h"
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            fprintf(stderr, "biokanga_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return e__ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL;                      \
+        }                                                                                          \
+    } while (0)
+
+struct bk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bk_align_params params{};
+    bk::DevAlignCfg cfg{};
+    bk::DevIndex ix{};
+    // owned device allocations of the index image
+    uint64_t *d_tgt4 = nullptr;
+    uint32_t *d_sa_lo = nullptr;
+    uint8_t *d_sa_hi = nullptr;
+    uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
+    uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
+    void *d_ktab = nullptr;
+    uint64_t *d_tgt2 = nullptr;           // 2 bit/base target copy (DevIndex::tgt2)
+    uint64_t *d_tgt2s = nullptr;          // the same, stored 32 bytes later (DevIndex::tgt2s)
+    uint8_t *d_nflag = nullptr;
+    uint64_t *d_rd2 = nullptr;            // 2-bit read rows
+    uint64_t n_tgt4_words = 0;
+    uint32_t cap_rd2w = 0;
+    int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
+    uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
+    uint32_t *d_slist = nullptr;          // work list of the two-pass search
+    uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
+    void *d_sort_tmp = nullptr;
+    uint64_t cap_sort = 0;
+    size_t sort_tmp_bytes = 0;
+    int sort_lists = 1;      // bit 0: search work list, bit 1: wave list (no gain measured) are grouped by index position
+    int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
+    uint64_t cap_slist = 0;
+    int use_k2 = 1;
+    uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
+    int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
+    int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
+    uint32_t *d_isa = nullptr;
+    int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
+    int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
+    bool ktab64 = false;
+    int k_req = -1;          // requested k (-1 auto)
+    int use_ktab = 1;
+    uint32_t el_size = 4;
+    uint64_t tot_seq_len = 0;
+    std::string dataset;
+    std::vector<bk_entry_info> entries;
+    // SNP pile-up: 6 count planes over the concatenated target, site list of the last bk_snp_sites call
+    uint32_t *d_snp_planes = nullptr;
+    unsigned long long *d_snp_tot = nullptr;
+    bk_snp_site *d_snp_sites = nullptr;
+    uint32_t cap_snp_sites = 0;
+    std::vector<bk_snp_site> snp_sites;
+
+    // batch scratch (grown on demand)
+    uint32_t cap_reads = 0, cap_wpr = 0;
+    uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
+    uint2 *d_iv2 = nullptr;
+    uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
+    uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
+    uint32_t *h_small = nullptr;          // pinned mirror
+    unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
+    // heavy path scratch
+    bk::HeavyScratch hs{};
+    int max_read_len = 500;
+    uint32_t chunk_reads = 64u << 20;
+    // staging for host-buffer batches
+    uint8_t *d_in_bases = nullptr;
+    uint64_t *d_in_offs = nullptr;
+    uint32_t *d_in_lens = nullptr;
+    bk_hit *d_in_out = nullptr;
+    bk_seg2 *d_seg2 = nullptr;            // -a / -A / -c: second segments of a chunk (kept with the batch scratch)
+    uint32_t cap_seg2 = 0;
+    uint64_t cap_in_bases = 0;
+    uint32_t cap_in_reads = 0;
+
+    bk_timing timing{};
+    std::vector<hipEvent_t> ev_pool;
+    // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)
+    std::vector<uint64_t> loci_offs;
+    std::vector<bk_loci> loci;
+    std::vector<bk_seg2> seg2;           // -a: second segments of the last align call, one per read
+};
+
+
+namespace bk {
+// batch driver entry points of bk_engine.cpp used by the stream pipeline (all blocking on `s`: the phase loop reads the
+// active counts back between phases)
+int engine_align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads, bk_hit *d_out,
+                        hipStream_t s);
+int engine_pair_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs, bk_hit *d_hits,
+                       uint32_t maxlen, const bk_pe_params *pe, hipStream_t s);
+}  // namespace bk

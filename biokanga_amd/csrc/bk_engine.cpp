@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "bk_device.h"
+#include "bk_ctx_int.h"
 #include "sfx_file.h"
 
 namespace bk {
@@ -79,93 +79,6 @@ void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, cons
 
 using namespace bk;
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess) {                                                                   \
-            fprintf(stderr, "biokanga_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-            return e__ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL;                      \
-        }                                                                                          \
-    } while (0)
-
-struct bk_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bk_align_params params{};
-    DevAlignCfg cfg{};
-    DevIndex ix{};
-    // owned device allocations of the index image
-    uint64_t *d_tgt4 = nullptr;
-    uint32_t *d_sa_lo = nullptr;
-    uint8_t *d_sa_hi = nullptr;
-    uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
-    uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
-    void *d_ktab = nullptr;
-    uint64_t *d_tgt2 = nullptr;           // 2 bit/base target copy (DevIndex::tgt2)
-    uint64_t *d_tgt2s = nullptr;          // the same, stored 32 bytes later (DevIndex::tgt2s)
-    uint8_t *d_nflag = nullptr;
-    uint64_t *d_rd2 = nullptr;            // 2-bit read rows
-    uint64_t n_tgt4_words = 0;
-    uint32_t cap_rd2w = 0;
-    int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
-    uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
-    uint32_t *d_slist = nullptr;          // work list of the two-pass search
-    uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
-    void *d_sort_tmp = nullptr;
-    uint64_t cap_sort = 0;
-    size_t sort_tmp_bytes = 0;
-    int sort_lists = 1;      // bit 0: search work list, bit 1: wave list (no gain measured) are grouped by index position
-    int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
-    uint64_t cap_slist = 0;
-    int use_k2 = 1;
-    uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
-    int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
-    int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
-    uint32_t *d_isa = nullptr;
-    int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
-    int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
-    bool ktab64 = false;
-    int k_req = -1;          // requested k (-1 auto)
-    int use_ktab = 1;
-    uint32_t el_size = 4;
-    uint64_t tot_seq_len = 0;
-    std::string dataset;
-    std::vector<bk_entry_info> entries;
-    // SNP pile-up: 6 count planes over the concatenated target, site list of the last bk_snp_sites call
-    uint32_t *d_snp_planes = nullptr;
-    unsigned long long *d_snp_tot = nullptr;
-    bk_snp_site *d_snp_sites = nullptr;
-    uint32_t cap_snp_sites = 0;
-    std::vector<bk_snp_site> snp_sites;
-
-    // batch scratch (grown on demand)
-    uint32_t cap_reads = 0, cap_wpr = 0;
-    uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
-    uint2 *d_iv2 = nullptr;
-    uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
-    uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
-    uint32_t *h_small = nullptr;          // pinned mirror
-    unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
-    // heavy path scratch
-    HeavyScratch hs{};
-    int max_read_len = 500;
-    uint32_t chunk_reads = 64u << 20;
-    // staging for host-buffer batches
-    uint8_t *d_in_bases = nullptr;
-    uint64_t *d_in_offs = nullptr;
-    uint32_t *d_in_lens = nullptr;
-    bk_hit *d_in_out = nullptr;
-    uint64_t cap_in_bases = 0;
-    uint32_t cap_in_reads = 0;
-
-    bk_timing timing{};
-    std::vector<hipEvent_t> ev_pool;
-    // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)
-    std::vector<uint64_t> loci_offs;
-    std::vector<bk_loci> loci;
-    std::vector<bk_seg2> seg2;           // -a: second segments of the last align call, one per read
-};
-
 namespace {
 
 int derive_cfg(bk_ctx *c)
@@ -215,6 +128,24 @@ int derive_cfg(bk_ctx *c)
 void free_dev(void *p)
 {
     if (p) (void)hipFree(p);
+}
+
+// zero-fill that stays correct for spans of 4 GiB and more: hipMemsetAsync is not trusted with those (bk_kernels.hip,
+// k_fill_u64), so large clears go through the fill kernel (8-byte words, plus a byte tail through hipMemsetAsync)
+hipError_t clear_dev(void *p, size_t bytes, hipStream_t s)
+{
+    if (bytes < (1ULL << 30) || ((uintptr_t)p & 7)) {
+        for (size_t at = 0; at < bytes; at += (1ULL << 30)) {
+            hipError_t e = hipMemsetAsync((uint8_t *)p + at, 0, std::min<size_t>(1ULL << 30, bytes - at), s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    const size_t words = bytes / 8;
+    launch_fill_u64((unsigned long long *)p, words, 0ULL, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && (bytes & 7)) e = hipMemsetAsync((uint8_t *)p + words * 8, 0, bytes & 7, s);
+    return e;
 }
 
 int pick_k(uint64_t n)
@@ -322,7 +253,7 @@ int build_tgt2(bk_ctx *c)
     if (c->use_tgt2 >= 2) {
         // second copy: element j holds tgt2[j + 4], i.e. logical byte p sits at physical byte p - 32
         HIP_TRY(hipMalloc(&c->d_tgt2s, nblocks * 16 + 64));
-        HIP_TRY(hipMemsetAsync(c->d_tgt2s, 0, nblocks * 16 + 64, c->stream));
+        HIP_TRY(clear_dev(c->d_tgt2s, nblocks * 16 + 64, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_tgt2s, c->d_tgt2 + 4, (nblocks * 2 - 4) * 8, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->ix.tgt2s = c->d_tgt2s;
@@ -708,8 +639,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 HIP_TRY(hipMemsetAsync(sm + 8, 0, 4, s));
                 // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
                 for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    if (c->d_iv2) HIP_TRY(hipMemsetAsync(c->d_iv2 + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 8, s));
-                    else HIP_TRY(hipMemsetAsync(c->d_iv_n + (size_t)st * kMaxCoresFast * n, 0, (size_t)cmax * n * 4, s));
+                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
+                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
@@ -779,9 +710,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         // AlignReads' branches for what is still unaligned (SfxArrayV2.cpp:7722-7757): microInDels, then splice junctions, then the
         // chimeric (end-trimmed) placement
         hipEvent_t ei = tm.begin(s);
-        bk_seg2 *d_seg2 = nullptr;
-        HIP_TRY(hipMalloc(&d_seg2, (size_t)n * sizeof(bk_seg2)));
-        hipError_t eh = hipMemsetAsync(d_seg2, 0, (size_t)n * sizeof(bk_seg2), s);
+        if (n > c->cap_seg2) {                                     // kept with the batch scratch, grown on demand
+            free_dev(c->d_seg2);
+            c->d_seg2 = nullptr;
+            c->cap_seg2 = 0;
+            HIP_TRY(hipMalloc(&c->d_seg2, (size_t)n * sizeof(bk_seg2)));
+            c->cap_seg2 = n;
+        }
+        bk_seg2 *d_seg2 = c->d_seg2;
+        hipError_t eh = clear_dev(d_seg2, (size_t)n * sizeof(bk_seg2), s);
         int rc2 = BK_OK;
         if (eh == hipSuccess && (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0)) {
             eh = hipMemsetAsync(sm, 0, 16 * 4, s);
@@ -811,7 +748,6 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         c->seg2.resize(at + n);
         if (eh == hipSuccess && rc2 == BK_OK) eh = hipMemcpyAsync(c->seg2.data() + at, d_seg2, (size_t)n * sizeof(bk_seg2), hipMemcpyDeviceToHost, s);
         if (eh == hipSuccess) eh = hipStreamSynchronize(s);
-        free_dev(d_seg2);
         if (rc2 != BK_OK) return rc2;
         if (eh != hipSuccess) return BK_ERR_INTERNAL;
         tm.end(2, ei, s);
@@ -888,13 +824,18 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
 
 }  // namespace
 
+int bk::engine_align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads, bk_hit *d_out,
+                            hipStream_t s)
+{
+    return align_device(c, d_bases, d_offs, d_lens, nreads, d_out, s);
+}
+
 // ------------------------------------------------------------------------------------------------
-// K4 on buffers resident in HBM (shared by bk_pair_batch and bk_pair_batch_device)
-static int pair_on_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs,
-                          bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe)
+// K4 on buffers resident in HBM (shared by bk_pair_batch, bk_pair_batch_device and the stream pipeline)
+int bk::engine_pair_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs,
+                           bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s)
 {
     const uint32_t nreads = 2 * n_pairs;
-    hipStream_t s = c->stream;
     const uint32_t wpr = words_per_read(maxlen);
     int rc = ensure_batch_scratch(c, nreads, wpr);
     if (rc) return rc;
@@ -1023,7 +964,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
-    free_dev(c->d_isa);
+    free_dev(c->d_isa); free_dev(c->d_seg2);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1230,7 +1171,7 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_in_out, hits, (size_t)nreads * sizeof(bk_hit), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    int rc = pair_on_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, n_pairs, c->d_in_out, maxlen, pe);
+    int rc = engine_pair_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, n_pairs, c->d_in_out, maxlen, pe, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(hits, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
@@ -1254,8 +1195,8 @@ int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, con
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t maxlen = c->h_small[5];
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
-    return pair_on_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, n_pairs, (bk_hit *)d_hits,
-                          maxlen, pe);
+    return engine_pair_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, n_pairs, (bk_hit *)d_hits,
+                              maxlen, pe, s);
 }
 
 // ---- SNP pile-up and screening (see include/biokanga_amd.h) -------------------------------------
@@ -1266,7 +1207,7 @@ int bk_snp_reset(bk_ctx *c)
     const size_t bytes = (size_t)c->ix.n * 6 * sizeof(uint32_t);
     if (!c->d_snp_planes) HIP_TRY(hipMalloc(&c->d_snp_planes, bytes));
     if (!c->d_snp_tot) HIP_TRY(hipMalloc(&c->d_snp_tot, 4 * 8));
-    HIP_TRY(hipMemsetAsync(c->d_snp_planes, 0, bytes, c->stream));
+    HIP_TRY(clear_dev(c->d_snp_planes, bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BK_OK;
 }

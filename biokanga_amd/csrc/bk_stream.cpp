@@ -1,0 +1,398 @@
+// bk_stream.cpp - overlapped host <-> device pipeline over the batch driver (bk_stream_* of include/biokanga_amd.h).
+//
+// The reference overlaps its loader thread with the aligner threads: reads are handed out in blocks while the
+// file is still being parsed (CAligner::LoadReads / ThreadedIterReads, biokanga/Aligner.cpp:4820-4860,9636-9704),
+// and T_align of SURVEY.md §8(d) runs from the first block handed out to the last result stored.  Here the same
+// overlap is between PCIe and the kernels: three host threads, three HIP streams, `depth` sets of device buffers.
+//
+//   submit() -> [uploader: H2D of batch k+1 on s_up] -> [aligner: every AlignReads phase of batch k on s_al,
+//                (+ paired-end association on the resident buffers)] -> [downloader: D2H of batch k-1 on s_dn] -> wait()
+//
+// The batch scratch (packed reads, core intervals, work lists) belongs to the context and is used by one batch at a
+// time - the phase kernels fill the whole chip - so only the 1 B/base reads, their offsets/lengths and the 20-byte
+// result records are multi-buffered.  Host buffers obtained from bk_host_alloc() (pinned) are DMA'd directly;
+// pageable ones go through the HIP runtime's staging copies (slower, still overlapped with the kernels).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "bk_ctx_int.h"
+
+namespace {
+
+struct CastU64 {
+    __host__ __device__ unsigned long long operator()(const uint32_t &v) const { return (unsigned long long)v; }
+};
+
+// max over reads of offs[i] + lens[i] (reads must lie inside the uploaded bases) and of lens[i]
+__global__ void __launch_bounds__(256) k_extent(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens, uint32_t n,
+                                                unsigned long long *__restrict__ out)
+{
+    unsigned long long e = 0, l = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long len = lens[i], end = offs[i] + len;
+        e = end > e ? end : e;
+        l = len > l ? len : l;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long e2 = __shfl_down(e, off), l2 = __shfl_down(l, off);
+        e = e2 > e ? e2 : e;
+        l = l2 > l ? l2 : l;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (e) atomicMax(out + 0, e);
+        if (l) atomicMax(out + 1, l);
+    }
+}
+
+struct Job {
+    uint64_t ticket = 0;
+    const uint8_t *bases = nullptr;
+    uint64_t nbases = 0;
+    const uint64_t *offs = nullptr;
+    const uint32_t *lens = nullptr;
+    uint32_t n = 0;
+    bk_hit *out = nullptr;
+    int slot = 0;
+    int rc = BK_OK;
+    bool done = false;
+    double t_submit = 0, t_done = 0;
+    // list modes: what the context held after this batch's align call
+    std::vector<uint64_t> loci_offs;
+    std::vector<bk_loci> loci;
+    std::vector<bk_seg2> seg2;
+};
+
+struct Slot {
+    uint8_t *d_bases = nullptr;
+    uint64_t *d_offs = nullptr;
+    uint32_t *d_lens = nullptr;
+    bk_hit *d_out = nullptr;
+    hipEvent_t ev_up = nullptr, ev_al = nullptr;
+};
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+}  // namespace
+
+struct bk_stream {
+    bk_ctx *ctx = nullptr;
+    int depth = 0;
+    uint32_t max_reads = 0;
+    uint64_t max_bases = 0;
+    std::vector<Slot> slots;
+    hipStream_t s_up = nullptr, s_al = nullptr, s_dn = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    unsigned long long *d_ext = nullptr, *h_ext = nullptr;     // [0] max read end [1] max read length
+    std::thread t_up, t_al, t_dn;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job *> q_up, q_al, q_dn;
+    std::map<uint64_t, Job *> jobs;
+    uint64_t next_ticket = 1, n_done = 0;
+    bool stop = false, list_modes = false, has_pe = false, span_open = false;
+    bk_pe_params pe{};
+    bk_stream_stats stats{};
+    double t_first_submit = 0, t_last_done = 0;
+
+    void fail(Job *j, int rc) { if (j->rc == BK_OK) j->rc = rc; }
+    static int rc_of(hipError_t e) { return e == hipSuccess ? BK_OK : (e == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL); }
+
+    Job *pop(std::deque<Job *> &q)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return nullptr;
+        Job *j = q.front();
+        q.pop_front();
+        return j;
+    }
+    void push(std::deque<Job *> &q, Job *j)
+    {
+        { std::lock_guard<std::mutex> lk(mu); q.push_back(j); }
+        cv.notify_all();
+    }
+
+    void run_upload()
+    {
+        (void)hipSetDevice(ctx->device);
+        while (Job *j = pop(q_up)) {
+            Slot &sl = slots[j->slot];
+            hipError_t e = hipSuccess;
+            if (j->n) {
+                e = hipMemcpyAsync(sl.d_bases, j->bases, j->nbases, hipMemcpyHostToDevice, s_up);
+                if (e == hipSuccess && j->offs) e = hipMemcpyAsync(sl.d_offs, j->offs, (size_t)j->n * 8, hipMemcpyHostToDevice, s_up);
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.d_lens, j->lens, (size_t)j->n * 4, hipMemcpyHostToDevice, s_up);
+            }
+            if (e == hipSuccess) e = hipEventRecord(sl.ev_up, s_up);
+            if (e != hipSuccess) fail(j, rc_of(e));
+            push(q_al, j);
+        }
+    }
+
+    void run_align()
+    {
+        (void)hipSetDevice(ctx->device);
+        while (Job *j = pop(q_al)) {
+            Slot &sl = slots[j->slot];
+            if (j->rc == BK_OK && j->n) {
+                hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
+                if (e == hipSuccess && !j->offs) {          // contiguous reads: offsets = exclusive prefix sum of the lengths
+                    size_t tb = scan_tmp_bytes;
+                    hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t *> in(sl.d_lens, CastU64());
+                    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, in, (unsigned long long *)sl.d_offs, (size_t)j->n, s_al);
+                }
+                if (e == hipSuccess) e = hipMemsetAsync(d_ext, 0, 16, s_al);
+                if (e == hipSuccess) {
+                    unsigned blocks = (j->n + 255) / 256;
+                    if (blocks > 2048) blocks = 2048;
+                    hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s_al, sl.d_offs, sl.d_lens, j->n, d_ext);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(h_ext, d_ext, 16, hipMemcpyDeviceToHost, s_al);
+                if (e == hipSuccess) e = hipStreamSynchronize(s_al);
+                if (e != hipSuccess) fail(j, rc_of(e));
+                else if (h_ext[0] > j->nbases || h_ext[1] > (unsigned long long)bk::kMaxReadLenAbs) fail(j, BK_ERR_PARAMS);
+                const uint32_t maxlen = (uint32_t)h_ext[1];
+                if (j->rc == BK_OK) {
+                    int rc = bk::engine_align_device(ctx, sl.d_bases, sl.d_offs, sl.d_lens, j->n, sl.d_out, s_al);
+                    if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, sl.d_bases, sl.d_offs, sl.d_lens, j->n / 2, sl.d_out, maxlen, &pe, s_al);
+                    if (rc) fail(j, rc);
+                    else if (list_modes) {
+                        j->loci_offs.swap(ctx->loci_offs);
+                        j->loci.swap(ctx->loci);
+                        j->seg2.swap(ctx->seg2);
+                    }
+                }
+                if (j->rc == BK_OK) {
+                    e = hipEventRecord(sl.ev_al, s_al);
+                    if (e != hipSuccess) fail(j, rc_of(e));
+                }
+            }
+            push(q_dn, j);
+        }
+    }
+
+    void run_download()
+    {
+        (void)hipSetDevice(ctx->device);
+        while (Job *j = pop(q_dn)) {
+            Slot &sl = slots[j->slot];
+            if (j->rc == BK_OK && j->n) {
+                hipError_t e = hipStreamWaitEvent(s_dn, sl.ev_al, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(j->out, sl.d_out, (size_t)j->n * sizeof(bk_hit), hipMemcpyDeviceToHost, s_dn);
+                if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
+                if (e != hipSuccess) fail(j, rc_of(e));
+            } else if (j->rc != BK_OK)
+                (void)hipStreamSynchronize(s_up);           // nothing of a failed batch may still be in flight when its slot is reused
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j->done = true;
+                j->t_done = now_s();
+                t_last_done = j->t_done;
+                n_done++;
+                stats.batches++;
+                stats.reads += j->n;
+                stats.bytes_h2d += j->nbases + (uint64_t)j->n * (j->offs ? 12 : 4);
+                stats.bytes_d2h += (uint64_t)j->n * sizeof(bk_hit);
+                stats.seconds_first_submit_to_last_result = t_last_done - t_first_submit;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+void *bk_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void bk_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+void bk_stream_destroy(bk_stream *s)
+{
+    if (!s) return;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->n_done + 1 == s->next_ticket; });      // let what was submitted finish
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    if (s->t_up.joinable()) s->t_up.join();
+    if (s->t_al.joinable()) s->t_al.join();
+    if (s->t_dn.joinable()) s->t_dn.join();
+    (void)hipSetDevice(s->ctx->device);
+    for (Slot &sl : s->slots) {
+        if (sl.d_bases) (void)hipFree(sl.d_bases);
+        if (sl.d_offs) (void)hipFree(sl.d_offs);
+        if (sl.d_lens) (void)hipFree(sl.d_lens);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+        if (sl.ev_al) (void)hipEventDestroy(sl.ev_al);
+    }
+    if (s->d_scan_tmp) (void)hipFree(s->d_scan_tmp);
+    if (s->d_ext) (void)hipFree(s->d_ext);
+    if (s->h_ext) (void)hipHostFree(s->h_ext);
+    if (s->s_up) (void)hipStreamDestroy(s->s_up);
+    if (s->s_al) (void)hipStreamDestroy(s->s_al);
+    if (s->s_dn) (void)hipStreamDestroy(s->s_dn);
+    for (auto &kv : s->jobs) delete kv.second;
+    delete s;
+}
+
+int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, int depth, const bk_pe_params *pe)
+{
+    if (!out || !ctx || !max_batch_reads || !max_batch_bases || depth < 1 || depth > 8) return BK_ERR_PARAMS;
+    if (pe && (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len)) return BK_ERR_PARAMS;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    bk_stream *s = new bk_stream();
+    s->ctx = ctx;
+    s->depth = depth;
+    s->max_reads = max_batch_reads;
+    s->max_bases = max_batch_bases;
+    s->list_modes = ctx->params.max_ml > 1 || ctx->params.micro_indel_len > 0 || ctx->params.splice_junct_len > 0 || ctx->params.min_chimeric_len > 0;
+    if (pe) { s->has_pe = true; s->pe = *pe; }
+    s->slots.resize((size_t)depth);
+    hipError_t e = hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_al, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_dn, hipStreamNonBlocking);
+    for (Slot &sl : s->slots) {
+        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, max_batch_bases + 16);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_al, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t *> in(nullptr, CastU64());
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, s->scan_tmp_bytes, in, (unsigned long long *)nullptr, (size_t)max_batch_reads, s->s_al);
+    }
+    if (e == hipSuccess) e = hipMalloc(&s->d_scan_tmp, s->scan_tmp_bytes ? s->scan_tmp_bytes : 16);
+    if (e == hipSuccess) e = hipMalloc(&s->d_ext, 16);
+    if (e == hipSuccess) e = hipHostMalloc(&s->h_ext, 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fprintf(stderr, "biokanga_amd: bk_stream_create: %s\n", hipGetErrorString(e));
+        s->next_ticket = 1;
+        bk_stream_destroy(s);
+        return e == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL;
+    }
+    s->t_up = std::thread([s] { s->run_upload(); });
+    s->t_al = std::thread([s] { s->run_align(); });
+    s->t_dn = std::thread([s] { s->run_download(); });
+    *out = s;
+    return BK_OK;
+}
+
+int bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                     bk_hit *out, uint64_t *ticket)
+{
+    if (!s || !ticket || (nreads && (!bases || !lens || !out))) return BK_ERR_PARAMS;
+    if (nreads > s->max_reads || nbases > s->max_bases || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
+    Job *j = new Job();
+    j->bases = bases; j->nbases = nbases; j->offs = offs; j->lens = lens; j->n = nreads; j->out = out;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->next_ticket - 1 - s->n_done < (uint64_t)s->depth; });     // a free set of device buffers
+        j->ticket = s->next_ticket++;
+        j->slot = (int)((j->ticket - 1) % (uint64_t)s->depth);
+        j->t_submit = now_s();
+        if (!s->span_open) { s->t_first_submit = j->t_submit; s->span_open = true; }      // T_align: first batch submitted -> last result back
+        s->jobs[j->ticket] = j;
+        s->q_up.push_back(j);
+    }
+    s->cv.notify_all();
+    *ticket = j->ticket;
+    return BK_OK;
+}
+
+int bk_stream_wait(bk_stream *s, uint64_t ticket)
+{
+    if (!s) return BK_ERR_PARAMS;
+    std::unique_lock<std::mutex> lk(s->mu);
+    auto it = s->jobs.find(ticket);
+    if (it == s->jobs.end()) return BK_ERR_PARAMS;
+    Job *j = it->second;
+    s->cv.wait(lk, [&] { return j->done; });
+    const int rc = j->rc;
+    if (!s->list_modes || rc != BK_OK) { s->jobs.erase(it); delete j; }       // nothing more to fetch for this batch
+    return rc;
+}
+
+int bk_stream_batch_loci(bk_stream *s, uint64_t ticket, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci)
+{
+    if (!s || !offs || !loci || !n_loci) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->jobs.find(ticket);
+    if (it == s->jobs.end() || !it->second->done) return BK_ERR_PARAMS;
+    Job *j = it->second;
+    if (j->loci_offs.empty()) { *offs = nullptr; *loci = nullptr; *n_loci = 0; return BK_OK; }
+    *offs = j->loci_offs.data();
+    *loci = j->loci.data();
+    *n_loci = j->loci.size();
+    return BK_OK;
+}
+
+int bk_stream_batch_seg2(bk_stream *s, uint64_t ticket, const bk_seg2 **seg2, uint64_t *n)
+{
+    if (!s || !seg2 || !n) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->jobs.find(ticket);
+    if (it == s->jobs.end() || !it->second->done) return BK_ERR_PARAMS;
+    Job *j = it->second;
+    *seg2 = j->seg2.empty() ? nullptr : j->seg2.data();
+    *n = j->seg2.size();
+    return BK_OK;
+}
+
+int bk_stream_release(bk_stream *s, uint64_t ticket)
+{
+    if (!s) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->jobs.find(ticket);
+    if (it == s->jobs.end() || !it->second->done) return BK_ERR_PARAMS;
+    delete it->second;
+    s->jobs.erase(it);
+    return BK_OK;
+}
+
+int bk_stream_drain(bk_stream *s)
+{
+    if (!s) return BK_ERR_PARAMS;
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return s->n_done + 1 == s->next_ticket; });
+    int rc = BK_OK;
+    for (auto &kv : s->jobs)
+        if (kv.second->rc != BK_OK && rc == BK_OK) rc = kv.second->rc;
+    return rc;
+}
+
+int bk_stream_get_stats(bk_stream *s, bk_stream_stats *out, int reset)
+{
+    if (!s || !out) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    *out = s->stats;
+    if (reset) { s->stats = bk_stream_stats{}; s->span_open = false; }
+    return BK_OK;
+}
+
+}  // extern "C"

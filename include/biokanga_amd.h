@@ -165,8 +165,11 @@ int  bk_min_core_len(const bk_ctx *ctx);
 int  bk_align_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
                     uint32_t nreads, bk_hit *out);
 
-/* Same over buffers already resident in HBM on the context's device.  Asynchronous on `stream`
- * (a hipStream_t, NULL = the context's own stream) unless `sync` is non-zero. */
+/* Same over buffers already resident in HBM on the context's device.  The kernels are launched on `stream` (a
+ * hipStream_t, NULL = the context's own stream), after whatever that stream already holds.  The call is
+ * HOST-SYNCHRONOUS: the phase loop of AlignReads reads the number of still-unaligned reads back between phases to size
+ * the next launches, so it returns when the results are in d_out; `sync` is accepted and has no effect.  The
+ * overlapped form (uploads, kernels and downloads of consecutive batches running concurrently) is bk_stream_*. */
 int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
                            uint32_t nreads, void *d_out, void *stream, int sync);
 
@@ -227,6 +230,43 @@ typedef struct bk_seg2 {
  * valid until its next align call; NULL / 0 otherwise).  Orphan removal (CAligner::RemoveOrphanMicroInDels, Aligner.cpp:2382-2470)
  * is host policy above this boundary. */
 int  bk_batch_seg2(bk_ctx *ctx, const bk_seg2 **seg2, uint64_t *n);
+
+/* ---- overlapped pipeline: host buffers in -> host results out ---------------------------------------------------
+ * Batch form of the reference's loader-thread / aligner-threads overlap (CAligner::LoadReads + ThreadedIterReads,
+ * biokanga/Aligner.cpp:4820-4860,9636-9704): batch k+1 crosses PCIe while batch k runs through the AlignReads phases
+ * and the results of batch k-1 travel back, on three HIP streams driven by three host threads owned by the stream
+ * object.  T_align of the metric (first batch submitted -> last result back) is what bk_stream_get_stats() reports.
+ * While a stream exists the context's own align / pair / loci / seg2 calls must not be used from other threads. */
+typedef struct bk_stream bk_stream;
+typedef struct bk_stream_stats {
+    uint64_t batches, reads;
+    uint64_t bytes_h2d, bytes_d2h;                      /* what crossed PCIe */
+    double   seconds_first_submit_to_last_result;       /* T_align of the batches since the last reset */
+} bk_stream_stats;
+/* page-locked host memory (hipHostMalloc): buffers the stream DMAs from / to directly.  Pageable buffers are accepted
+ * too and are staged by the HIP runtime (slower). */
+void *bk_host_alloc(size_t bytes);
+void  bk_host_free(void *p);
+/* depth = sets of device buffers (2..4 is useful: one uploading, one aligning, one downloading); every batch may hold up to
+ * max_batch_reads reads in max_batch_bases bytes.  pe != NULL: batches hold whole pairs interleaved PE1, PE2 and the
+ * paired-end association (bk_pair_batch_device) runs on the resident buffers right after the SE pass. */
+int  bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, int depth, const bk_pe_params *pe);
+/* bases[0 .. nbases) holds the reads of this batch, 1 byte/base as CAligner holds them; offs[i] = start of read i within
+ * bases, or offs == NULL when the reads lie back to back in lens order (the offsets are then computed on the device and
+ * 8 bytes per read stay off PCIe); out[nreads].  Returns once the batch is queued (it blocks only while all `depth`
+ * buffer sets are busy); every buffer must stay valid and untouched until bk_stream_wait(ticket) has returned. */
+int  bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                      bk_hit *out, uint64_t *ticket);
+/* blocks until the results of that batch are in its `out`; returns the batch's result code (each ticket once, unless the
+ * context runs a list mode - then bk_stream_batch_loci / _seg2 stay available until bk_stream_release) */
+int  bk_stream_wait(bk_stream *s, uint64_t ticket);
+int  bk_stream_batch_loci(bk_stream *s, uint64_t ticket, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
+int  bk_stream_batch_seg2(bk_stream *s, uint64_t ticket, const bk_seg2 **seg2, uint64_t *n);
+int  bk_stream_release(bk_stream *s, uint64_t ticket);
+/* waits for everything submitted; first failing batch's code or BK_OK */
+int  bk_stream_drain(bk_stream *s);
+int  bk_stream_get_stats(bk_stream *s, bk_stream_stats *out, int reset);
+void bk_stream_destroy(bk_stream *s);
 
 /* counters/timing accumulated since the last reset */
 int  bk_get_counters(bk_ctx *ctx, bk_counters *out, int reset);

@@ -1,0 +1,137 @@
+"""GPU tests of the overlapped pipeline (bk_stream_*): batches submitted from host buffers must give exactly the
+records the blocking batch call and the CPU oracle give, whatever the batch size, buffer kind (pinned / pageable),
+offset form (explicit / back-to-back) or pipeline depth; list modes and paired ends travel with their batch."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from test_gpu_parity import FIELDS, assert_hits_equal, load_fixture, _bk
+
+pytestmark = pytest.mark.gpu
+
+
+def _contiguous(bases, offs, lens):
+    """reads copied back to back (what offs=None means)"""
+    out = np.concatenate([bases[int(o):int(o) + int(l)] for o, l in zip(offs, lens)]) if len(lens) else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(out, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("fixture,tag", [("basic", "s3"), ("repeat", "s3"), ("lengths", "s3L")])
+@pytest.mark.parametrize("batch,depth,pinned,explicit_offs", [(257, 3, True, True), (1000, 2, False, False), (64, 4, True, False),
+                                                               (100000, 1, False, True)])
+def test_stream_equals_blocking_call_and_oracle(golden_tmp, fixture, tag, batch, depth, pinned, explicit_offs):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, tag)
+    offs, lens = offs[keep], lens[keep]
+    n = len(lens)
+    cb = _contiguous(bases, offs, lens)
+    coffs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    mk = (lambda m, dt: bk.host_array(m, dt)) if pinned else (lambda m, dt: np.zeros(m, dtype=dt))
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align(bases, offs, lens)
+        out = mk(n, bk.HIT_DTYPE)
+        out[:] = np.zeros(1, bk.HIT_DTYPE)[0]
+        with bk.Stream(al, max_batch_reads=min(batch, n), max_batch_bases=int(lens.astype(np.int64).max()) * min(batch, n), depth=depth) as st:
+            tickets = []
+            for lo in range(0, n, batch):
+                hi = min(n, lo + batch)
+                b0, b1 = int(coffs[lo]), int(coffs[hi - 1]) + int(lens[hi - 1])
+                hb = mk(b1 - b0, np.uint8); hb[:] = cb[b0:b1]
+                hl = mk(hi - lo, np.uint32); hl[:] = lens[lo:hi]
+                ho = None
+                if explicit_offs:
+                    ho = mk(hi - lo, np.uint64); ho[:] = coffs[lo:hi] - np.uint64(b0)
+                tickets.append(st.submit(hb, ho, hl, out[lo:hi]))
+            for t in tickets:
+                st.wait(t)
+            stats = st.stats()
+        assert stats["reads"] == n and stats["batches"] == len(tickets)
+        assert stats["bytes_d2h"] == 20 * n
+        assert stats["seconds_first_submit_to_last_result"] > 0
+    assert_hits_equal(out, ref, [names[i] for i in keep])
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, _ = sfx.align(bases, offs, lens, helpers.make_params(max_subs=3))
+    sfx.close()
+    assert_hits_equal(out, exp, [names[i] for i in keep])
+
+
+def test_stream_rejects_reads_outside_the_batch(golden_tmp):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        with bk.Stream(al, 16, 4096, depth=2) as st:
+            hb = np.zeros(1000, np.uint8)
+            hl = np.full(4, 100, np.uint32)
+            ho = np.array([0, 100, 950, 300], dtype=np.uint64)          # read 2 runs past the 1000 bases handed over
+            out = np.zeros(4, bk.HIT_DTYPE)
+            t = st.submit(hb, ho, hl, out)
+            with pytest.raises(bk.BkError) as e:
+                st.wait(t)
+            assert e.value.rc == -100
+            # the stream stays usable
+            ho2 = np.array([0, 100, 900, 300], dtype=np.uint64)
+            t = st.submit(hb, ho2, hl, out)
+            st.wait(t)
+            with pytest.raises(bk.BkError):                             # more reads than the stream was sized for
+                st.submit(np.zeros(1700, np.uint8), None, np.full(17, 100, np.uint32), np.zeros(17, bk.HIT_DTYPE))
+
+
+def test_stream_multi_loci_lists_travel_with_their_batch(golden_tmp):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "repeat", "s3")
+    offs, lens = offs[keep], lens[keep]
+    n = len(lens)
+    p = bk.AlignParams(max_subs=3, max_ml=5)
+    with bk.Aligner(os.path.join(d, "genome.sfx"), p) as al:
+        ref = al.align(bases, offs, lens)
+        ro, rl = al.batch_loci(n)
+        cb = _contiguous(bases, offs, lens)
+        coffs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+        out = np.zeros(n, bk.HIT_DTYPE)
+        B = 301
+        got_offs, got_loci = [np.zeros(1, np.uint64)], []
+        with bk.Stream(al, B, int(lens.max()) * B, depth=3) as st:
+            tk = []
+            for lo in range(0, n, B):
+                hi = min(n, lo + B)
+                b0, b1 = int(coffs[lo]), int(coffs[hi - 1]) + int(lens[hi - 1])
+                tk.append((st.submit(cb[b0:b1].copy(), None, lens[lo:hi].copy(), out[lo:hi]), hi - lo))
+            for t, m in tk:
+                st.wait(t)
+                o, l = st.batch_loci(t, m)
+                got_offs.append(o[1:] + got_offs[-1][-1])
+                got_loci.append(l)
+                st.release(t)
+    assert_hits_equal(out, ref)
+    assert np.array_equal(np.concatenate(got_offs), ro)
+    assert np.array_equal(np.concatenate(got_loci), rl)
+
+
+def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path):
+    from test_oracle_pe import PE_RUNS, pe_inputs, check_pe_hits_against_sam
+    bk = _bk()
+    cfg = PE_RUNS["U3"]
+    names, bases, offs, lens = pe_inputs(tmp_path)
+    cb = _contiguous(bases, offs, lens)
+    coffs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    n = len(lens)
+    pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False))
+    with bk.Aligner(os.path.join(golden_tmp["basic"], "genome.sfx"), bk.AlignParams(max_subs=cfg["s"])) as al:
+        ref = al.pair(bases, offs, lens, al.align(bases, offs, lens), pe)
+        out = np.zeros(n, bk.HIT_DTYPE)
+        B = 2 * 77
+        with bk.Stream(al, B, int(lens.max()) * B, depth=2, pe=pe) as st:
+            tk = []
+            for lo in range(0, n, B):
+                hi = min(n, lo + B)
+                b0, b1 = int(coffs[lo]), int(coffs[hi - 1]) + int(lens[hi - 1])
+                tk.append(st.submit(cb[b0:b1].copy(), None, lens[lo:hi].copy(), out[lo:hi]))
+            for t in tk:
+                st.wait(t)
+            with pytest.raises(bk.BkError):                 # half a pair
+                st.submit(cb[:int(lens[0])].copy(), None, lens[:1].copy(), out[:1])
+    for f in FIELDS + ["flags"]:
+        assert np.array_equal(out[f], ref[f]), f
+    check_pe_hits_against_sam(names, out, "U3", ["chrA", "chrB"])
