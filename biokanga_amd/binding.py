@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
 ]
@@ -173,6 +173,8 @@ def load_library():
     lib.bk_snp_sites.restype = i32
     lib.bk_seq_counts.argtypes = [vp, vp, u32, i32]
     lib.bk_seq_counts.restype = i32
+    lib.bk_seq_counts_allreduce.argtypes = [ctypes.POINTER(vp), i32, vp, u32, i32]
+    lib.bk_seq_counts_allreduce.restype = i32
     lib.bk_build_sa_device.argtypes = [vp, u64, vp, i32, i32]
     lib.bk_build_sa_device.restype = i32
     lib.bk_host_alloc.argtypes = [ctypes.c_size_t]
@@ -210,6 +212,17 @@ def _strerror(rc):
 
 def device_count():
     return load_library().bk_device_count()
+
+
+def seq_counts_allreduce(aligners, reset=False):
+    """sum of the per-sequence accepted-read counts over several contexts (RCCL between distinct devices)"""
+    lib = load_library()
+    arr = (ctypes.c_void_p * len(aligners))(*[a.h for a in aligners])
+    out = np.zeros(aligners[0].num_entries, dtype=np.uint64)
+    rc = lib.bk_seq_counts_allreduce(arr, len(aligners), out.ctypes.data, len(out), 1 if reset else 0)
+    if rc:
+        raise BkError(rc, "bk_seq_counts_allreduce")
+    return out
 
 
 def build_sa_device(d_seq_ptr, concat_len, d_sa_ptr, el_size=4, device=0):

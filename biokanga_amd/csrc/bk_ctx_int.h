@@ -76,6 +76,7 @@ struct bk_ctx {
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror
     unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
+    unsigned long long *d_seq_global = nullptr;   // bk_seq_counts_allreduce: the counts summed over every context of the run
     // heavy path scratch
     bk::HeavyScratch hs{};
     int max_read_len = 500;

@@ -433,6 +433,333 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
     return 0;
 }
 
+// Everything `biokanga align` was asked for, validated the way kanga.cpp:298-1066 validates it
+struct AlignOpts {
+    int pe_mode = 0, ml_mode = 0, max_ml = 1, micro_indel = 0, splice_len = 0, min_chim = 0, pcr_win = -1, min_flank = 0, fmt = 5;
+    int min_len = 50, max_len = 500, trim5 = 0, trim3 = 0, max_rpt_sam_seqs = 10000, nthreads = 1;
+    bool clamp_ml = false, best_matches = false;
+    bk_pe_params PE{};
+    bk_align_params P{};
+    SnpOpts snp;
+    std::vector<regex_t> re_excl, re_incl;
+    std::vector<int> devices;              // --device n | --devices a,b,c | a-b: one context (+ upload / align / download pipeline) per entry
+};
+
+// 0, or 1 after the error message has been logged
+int read_align_opts(Args &a, AlignOpts &o)
+{
+    o.pe_mode = a.num("U", 0);
+    if (o.pe_mode < 0 || o.pe_mode > 4) { diag("Error: paired end processing mode '-U%d' must be in range 0..4", o.pe_mode); return 1; }
+    if (o.pe_mode && (!a.has("u") || a.v["u"].size() != a.v["i"].size())) {
+        diag("Error: paired end processing '-U%d' needs as many '-u' PE2 files as '-i' PE1 files", o.pe_mode);
+        return 1;
+    }
+    o.PE = bk_pe_params{};
+    o.PE.pe_mode = o.pe_mode;
+    o.PE.pair_min_len = a.num("d", 100);            // cDfltPairMinLen
+    o.PE.pair_max_len = a.num("D", 1000);           // cDfltPairMaxLen
+    o.PE.pair_strand = a.has("E") ? 1 : 0;
+    if (o.pe_mode && (o.PE.pair_min_len < 25 || o.PE.pair_max_len < o.PE.pair_min_len || o.PE.pair_max_len > 100000)) {
+        diag("Error: paired end insert size range '-d%d -D%d' not accepted", o.PE.pair_min_len, o.PE.pair_max_len);
+        return 1;
+    }
+    // -r multi-loci modes (kanga.cpp:482-486,535-539,666-694): 0 slough, 1 stats only, 2 random pick, 3 cluster with
+    // uniques, 4 cluster with uniques + other multi-loci reads, 5 report all loci; -R loci limit, -X clamp
+    o.ml_mode = a.num("r", 0);
+    if (o.ml_mode < 0 || o.ml_mode > 5) { diag("Error: multiple aligned reads processing mode '-r%d' specified outside of range 0..5", o.ml_mode); return 1; }
+    if (o.pe_mode && o.ml_mode) { diag("Error: Sorry, currently multiloci processing '-r%d' not supported in paired end '-U%d' processing", o.ml_mode, o.pe_mode); return 1; }
+    o.max_ml = 1;
+
+    if (o.ml_mode) {
+        o.max_ml = a.num("R", 5);                                         // cDfltMaxMultiHits
+        const int lim = o.ml_mode == 5 ? 100000 : 500;                    // cMaxAllHits / cMaxMultiHits
+        if (o.max_ml < 2 || o.max_ml > lim) { diag("Error: multiple aligned reads '-R%d' specified outside of range 2..%d", o.max_ml, lim); return 1; }
+        if (o.max_ml > BK_MAX_ML) { diag("Error: '-R%d' is above the %d loci per read this build keeps", o.max_ml, BK_MAX_ML); return 1; }
+        o.best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
+        o.clamp_ml = a.has("X") || o.best_matches;
+    }
+    // -g FASTQ quality scores: 0 Sanger / Illumina 1.8+, 1 Illumina 1.3+, 2 Solexa, 3 ignore (default; QUAL is then '*')
+    g_sample_nth = a.num("#", 1);
+    if (g_sample_nth < 1 || g_sample_nth > 10000) { diag("Error: sample every Nth raw read '-#%d' specified outside of range 1..10000", g_sample_nth); return 1; }
+    g_qual_mode = a.num("g", 3);
+    if (g_qual_mode < 0 || g_qual_mode > 3) { diag("Error: fastq quality '-g%d' specified outside of range 0..3", g_qual_mode); return 1; }
+    // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned
+    o.micro_indel = a.num("a", 0);
+    if (o.micro_indel < 0 || o.micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", o.micro_indel); return 1; }
+    if (o.micro_indel && o.ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
+    if (o.micro_indel && o.pe_mode) { diag("Error: Sorry, currently microInDel processing '-a%d' not supported in paired end '-U%d' processing", o.micro_indel, o.pe_mode); return 1; }   // kanga.cpp:541-545
+    if (o.micro_indel && o.best_matches) { diag("Error: microInDels '-a%d' together with '-N' are not available in this build", o.micro_indel); return 1; }
+    // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
+    // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
+    o.splice_len = a.num("A", 0);
+    if (o.splice_len != 0 && (o.splice_len < 25 || o.splice_len > 100000)) { diag("Error: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000", o.splice_len); return 1; }
+    if (o.splice_len && o.ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
+    if (o.splice_len && o.pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", o.splice_len, o.pe_mode); return 1; }
+    if (o.splice_len && o.best_matches) { diag("Error: splice junctions '-A%d' together with '-N' are not available in this build", o.splice_len); return 1; }
+    // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
+    o.min_chim = a.num("c", 0);
+    if (o.min_chim != 0 && (o.min_chim < 50 || o.min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", o.min_chim < 0 ? -o.min_chim : o.min_chim); return 1; }
+    if (o.min_chim && (o.ml_mode || o.pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", o.min_chim, o.ml_mode, o.pe_mode); return 1; }
+    // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
+
+    o.snp.min_reads = a.num("p", 0);
+    if (o.snp.min_reads != 0 && (o.snp.min_reads < 1 || o.snp.min_reads > 100)) { diag("Error: Minimum read coverage at any loci '-p%d' must be in range 1..100", o.snp.min_reads); return 1; }
+    if (o.snp.min_reads > 0) {
+        o.snp.qvalue = a.has("P") ? atof(a.str("P").c_str()) : 0.0;
+        if (o.snp.qvalue < 0.0 || o.snp.qvalue > 0.40) { diag("Error: QValue '-P%1.5f' for controlling SNP FDR (Benjamini-Hochberg) must be in range 0.0 to 0.4", o.snp.qvalue); return 1; }
+        if (o.snp.qvalue == 0.0) o.snp.qvalue = 0.05;
+        const double pcnt = a.has("1") ? atof(a.str("1").c_str()) : 25.0;
+        if (pcnt < 0.1 || pcnt > 35.0) { diag("Error: SNP minimum non-ref '-1%f' for controlling SNP FDR must be in range 0.1 to 35.0", pcnt); return 1; }
+        o.snp.nonref_prop = pcnt / 100.0;
+        if (o.ml_mode == 5) { diag("Error: SNP processing not currently supported if reporting multiloci alignments"); return 1; }
+        o.snp.marker_len = a.num("K", 0);                    // kanga.cpp:928-952
+        o.snp.centroid_path = a.str("7", "");                // kanga.cpp:954-960
+        if (o.snp.marker_len != 0 && (o.snp.marker_len < 25 || o.snp.marker_len > 500)) { diag("Error: Marker length specified with '-K%d' must be in range 25 to 500", o.snp.marker_len); return 1; }
+        if (o.snp.marker_len) {
+            o.snp.marker_poly_thres = a.has("G") ? atof(a.str("G").c_str()) : (1.0 / 3.0);
+            if (o.snp.marker_poly_thres < 0.0 || o.snp.marker_poly_thres > 0.50) { diag("Error: Max marker sequence base poymorphism specified with '-G%1.3f' must be in range 0.0 to 0.5", o.snp.marker_poly_thres); return 1; }
+        }
+    }
+    // -k PCR differential amplification artefact reduction (kanga.cpp:718-724): window 0..250, off by default
+    o.pcr_win = a.has("k") ? a.num("k", -1) : -1;
+    if (a.has("k") && (o.pcr_win < 0 || o.pcr_win > 250)) { diag("Error: PCR differential amplification artefacts window length '-k%d' specified outside of range 0..250", o.pcr_win); return 1; }
+    if (o.pcr_win >= 0 && o.ml_mode == 5) { diag("Error: '-k%d' together with '-r5' is not available in this build", o.pcr_win); return 1; }
+    // -Z / -z chromosome exclude / include filters: POSIX extended regular expressions, case-insensitive (Aligner.cpp:4770-4795)
+
+    for (const char *opt : {"Z", "z"})
+        if (a.has(opt))
+            for (const std::string &pat : a.v[opt]) {
+                regex_t re;
+                if (regcomp(&re, pat.c_str(), REG_EXTENDED | REG_ICASE)) { diag("Error: ProcessAlign: %s chrom RE '%s' error", opt[0] == 'Z' ? "exclude" : "include", pat.c_str()); return 1; }
+                (opt[0] == 'Z' ? o.re_excl : o.re_incl).push_back(re);
+            }
+    if ((!o.re_excl.empty() || !o.re_incl.empty()) && (o.pe_mode || o.ml_mode == 5)) { diag("Error: chromosome filters '-Z/-z' together with '-U%d' / '-r5' are not available in this build", o.pe_mode); return 1; }
+    o.min_flank = a.num("x", 0);
+    if (o.min_flank < 0 || o.min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", o.min_flank); return 1; }      // cMaxAllowedSubs / 2
+    if (o.min_flank && o.ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", o.min_flank); return 1; }
+    o.P = bk_align_params{};
+    o.P.micro_indel_len = o.micro_indel;
+    o.P.splice_junct_len = o.splice_len;
+    o.P.pmode = a.num("m", 0);
+    o.P.align_strand = a.num("Q", 0);
+    o.P.min_edit_dist = a.num("e", 1);
+    o.P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
+    if (o.splice_len > 0 && o.min_chim == 0 && o.min_flank == 0) o.min_flank = o.P.max_subs;      // MinFlankExacts = MaxSubs (kanga.cpp:810-811)
+    o.P.min_chimeric_len = o.min_chim;
+    o.P.max_ns = a.num("n", 1);
+    o.P.max_ml = o.max_ml;
+    o.P.clamp_ml = o.clamp_ml ? 1 : 0;
+    o.P.best_matches = o.best_matches ? 1 : 0;
+    o.fmt = a.num("M", 5);
+    if (o.ml_mode == 5 && !(o.fmt == 0 || o.fmt == 4 || o.fmt == 5 || o.fmt == 6)) {      // kanga.cpp:830-834
+        diag("Error: reporting all multiloci alignments '-r5' is only available with output formats '-M0', '-M4', '-M5' and '-M6'");
+        return 1;
+    }
+    if (a.has("O") && o.fmt == 6) {                 // kanga.cpp:1015-1021
+        diag("Error: Output induced substitution mode '-O<file>' not available in '-M6' output mode\n");
+        return 1;
+    }
+    o.min_len = a.num("l", 50), o.max_len = a.num("L", 500);
+    o.trim5 = a.num("y", 0), o.trim3 = a.num("Y", 0);
+    o.max_rpt_sam_seqs = a.num("4", 10000);
+    // -T: host threads for parsing, sorting and formatting (0 = all cores, capped like the reference's cMaxWorkerThreads)
+    o.nthreads = a.num("T", 0);
+    if (o.nthreads <= 0) o.nthreads = (int)std::thread::hardware_concurrency();
+    if (o.nthreads < 1) o.nthreads = 1;
+    if (o.nthreads > 128) o.nthreads = 128;
+    if (o.P.pmode < 0 || o.P.pmode > 3 || o.P.align_strand < 0 || o.P.align_strand > 2 || o.P.min_edit_dist < 1 || o.P.min_edit_dist > 2 ||
+        o.P.max_subs < 0 || o.P.max_subs > 25 || o.P.max_ns < 0 || o.P.max_ns > 5 || o.min_len < 15 || o.min_len > 2000 || o.max_len < o.min_len ||
+        o.max_len > 2000 || o.fmt < 0 || o.fmt > 6) {
+        diag("Error: an option value is outside its accepted range");
+        return 1;
+    }
+    // --device n (one GPU) or --devices 0-7 / 0,1,2: the read batches are dealt round-robin over one context per entry
+    if (a.has("devices")) {
+        const std::string spec = a.str("devices");
+        size_t at = 0;
+        while (at < spec.size()) {
+            size_t end = spec.find(',', at);
+            if (end == std::string::npos) end = spec.size();
+            const std::string part = spec.substr(at, end - at);
+            const size_t dash = part.find('-');
+            const int lo = atoi(part.c_str()), hi = dash == std::string::npos ? lo : atoi(part.c_str() + dash + 1);
+            if (part.empty() || lo < 0 || hi < lo || hi > 1023) { diag("Error: '--devices %s' is not a list of device numbers / ranges", spec.c_str()); return 1; }
+            for (int d = lo; d <= hi; d++) o.devices.push_back(d);
+            at = end + 1;
+        }
+    } else
+        o.devices.push_back(a.num("device", 0));
+    if (o.devices.empty() || o.devices.size() > 64) { diag("Error: between 1 and 64 devices can be used"); return 1; }
+    return 0;
+}
+
+// what the alignment pass leaves for the policies above the boundary
+struct AlignedSet {
+    std::vector<bk_hit> hits;                      // one per read, load order
+    std::vector<uint64_t> l_offs;                  // multi-loci modes: read i owns loci [l_offs[i], l_offs[i+1])
+    std::vector<bk_loci> loci;
+    std::vector<bk_seg2> seg2;                     // -a / -A / -c: second segment of each read (flags 0 = none)
+    std::vector<uint64_t> seq_counts;              // per sequence: reads the SE pass accepted, summed over the devices (RCCL when > 1)
+};
+
+// CAligner::LocateCoredApprox over every loaded read: the reads leave the read store in batches through one upload / align /
+// download pipeline per device (bk_stream_*), batch b on device b mod N; with -U the paired-end association runs on the
+// device-resident batch right after its SE pass (batches hold whole pairs).  Results land in load order whatever the
+// number of devices, so everything downstream - the reference's sort order included - is the same as on one GPU.
+int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const ReadStore &rs, AlignedSet &A)
+{
+    const size_t nr = rs.size(), ndev = ctxs.size();
+    A.hits.resize(nr);
+    const bool lists = o.ml_mode != 0, segs = o.micro_indel || o.splice_len || o.min_chim;
+    if (lists) A.l_offs.assign(1, 0);
+    size_t per = 8u << 20;                                                          // reads per batch
+    if (nr / ndev / 2 + 1 < per) per = std::max<size_t>(65536, nr / ndev / 2 + 1);   // at least two batches per device: overlap
+    per += per & 1;
+    struct Batch { size_t lo, hi; uint64_t b0, b1, ticket; };
+    std::vector<Batch> batches;
+    uint64_t max_bases = 1;
+    for (size_t lo = 0; lo < nr; lo += per) {
+        Batch b{lo, std::min(nr, lo + per), rs.offs[lo], 0, 0};
+        b.b1 = rs.offs[b.hi - 1] + rs.lens[b.hi - 1];
+        max_bases = std::max(max_bases, b.b1 - b.b0);
+        batches.push_back(b);
+    }
+    std::vector<bk_stream *> st(ndev, nullptr);
+    auto close = [&]() { for (bk_stream *s : st) bk_stream_destroy(s); };
+    for (size_t d = 0; d < ndev; d++) {
+        int rc = bk_stream_create(&st[d], ctxs[d], (uint32_t)std::min(per, std::max<size_t>(nr, 1)), max_bases, 3, o.pe_mode ? &o.PE : nullptr);
+        if (rc) { diag("Fatal: unable to set up the device pipeline: %s", bk_strerror(rc)); close(); return rc; }
+    }
+    // the read store keeps reads back to back in load order, so a batch is one span of bases and the offsets are rebuilt on the device
+    auto collect = [&](size_t k) -> int {
+        Batch &b = batches[k];
+        bk_stream *s = st[k % ndev];
+        int rc = bk_stream_wait(s, b.ticket);
+        if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); return rc; }
+        const size_t n = b.hi - b.lo;
+        if (segs) {
+            const bk_seg2 *bs = nullptr;
+            uint64_t ns = 0;
+            rc = bk_stream_batch_seg2(s, b.ticket, &bs, &ns);
+            if (rc || !bs || ns != n) { diag("Fatal: microInDel segments unavailable: %s", bk_strerror(rc)); return rc ? rc : BK_ERR_INTERNAL; }
+            A.seg2.insert(A.seg2.end(), bs, bs + ns);
+        }
+        if (lists) {
+            const uint64_t *bo = nullptr;
+            const bk_loci *bl = nullptr;
+            uint64_t nl = 0;
+            rc = bk_stream_batch_loci(s, b.ticket, &bo, &bl, &nl);
+            if (rc || !bo) { diag("Fatal: loci lists unavailable: %s", bk_strerror(rc)); return rc ? rc : BK_ERR_INTERNAL; }
+            const uint64_t base = A.loci.size();
+            for (size_t i = 1; i <= n; i++) A.l_offs.push_back(base + bo[i]);
+            A.loci.insert(A.loci.end(), bl, bl + nl);
+        }
+        if (segs || lists) bk_stream_release(s, b.ticket);
+        return BK_OK;
+    };
+    // submit() blocks while a device's three buffer sets are busy, and a batch completes without being waited for, so the
+    // loop below keeps every pipeline full; results are collected in load order, 3 * ndev batches behind the submissions
+    size_t next_collect = 0;
+    const size_t lag = 3 * ndev;
+    for (size_t k = 0; k < batches.size(); k++) {
+        Batch &b = batches[k];
+        int rc = bk_stream_submit(st[k % ndev], rs.bases.data() + b.b0, b.b1 - b.b0, nullptr, rs.lens.data() + b.lo, (uint32_t)(b.hi - b.lo),
+                                  A.hits.data() + b.lo, &b.ticket);
+        if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); close(); return rc; }
+        while (next_collect + lag <= k) { rc = collect(next_collect++); if (rc) { close(); return rc; } }
+    }
+    while (next_collect < batches.size()) { int rc = collect(next_collect++); if (rc) { close(); return rc; } }
+    close();
+    // the path's one exchange step: per-sequence accepted-read counts summed over the devices
+    A.seq_counts.assign(bk_num_entries(ctxs[0]), 0);
+    int rc = bk_seq_counts_allreduce((bk_ctx *const *)ctxs.data(), (int)ndev, A.seq_counts.data(), (uint32_t)A.seq_counts.size(), 1);
+    if (rc) { diag("Fatal: unable to reduce the per sequence hit counts over the devices: %s", bk_strerror(rc)); return rc; }
+    return BK_OK;
+}
+
+// CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424): what becomes of the reads that aligned to more than one
+// locus (-r1 statistics, -r2 random pick, -r3 / -r4 clustering, -r5 every locus its own record).  `src` maps the records of -r5 back
+// to their reads; `nr` is the record count afterwards.
+void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, std::vector<uint32_t> &src, std::vector<int> &multi_dist, size_t &nr)
+{
+    std::vector<bk_hit> &hits = A.hits;
+    const std::vector<uint64_t> &l_offs = A.l_offs;
+    const std::vector<bk_loci> &loci = A.loci;
+    // CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424); reads in load order, as -T1 runs them
+    auto eff_count = [&](size_t i) -> uint32_t {            // LowHitInstances of a read that counts as eHRhits (after -X)
+        const bk_hit &h = hits[i];
+        if (h.rslt == BK_HR_HITS || (o.clamp_ml && h.rslt == BK_HR_HITINSTS)) return (uint32_t)(l_offs[i + 1] - l_offs[i]);
+        return 0;
+    };
+    auto take = [&](bk_hit &h, const bk_loci &L) {
+        h.chrom_id = L.chrom_id; h.match_loci = L.match_loci; h.match_len = L.match_len; h.strand = L.strand;
+        h.mismatches = L.mismatches; h.nar = BK_NAR_ACCEPTED; h.num_hits = 1; h.low_hit_instances = 1;
+    };
+    uint64_t n_uniq = 0, n_multi = 0, n_loci = 0;
+    for (size_t i = 0; i < nr; i++) {
+        const uint32_t c = eff_count(i);
+        if (!c) continue;
+        n_loci += c;
+        (c == 1 ? n_uniq : n_multi)++;
+        if (o.ml_mode != 5) multi_dist[c - 1]++;
+        if (o.clamp_ml && hits[i].rslt == BK_HR_HITINSTS) hits[i].low_hit_instances = (int16_t)c;
+    }
+    diag("Provisionally accepted %llu aligned reads (%llu uniquely, %llu aligning to multiloci) aligning to a total of %llu loci",
+         (unsigned long long)(n_uniq + n_multi), (unsigned long long)n_uniq, (unsigned long long)n_multi, (unsigned long long)n_loci);
+    if (o.ml_mode == 2) {
+        // eMLrand: rand() % LowHitInstances for every eHRhits read, unique ones included (:9365-9366); the sequence is
+        // glibc's unseeded one (glibc_rand.h), which is what a single-threaded reference run consumes in the same order
+        bk::GlibcRand pick;
+        for (size_t i = 0; i < nr; i++) {
+            const uint32_t c = eff_count(i);
+            if (!c) continue;
+            const uint32_t k = (uint32_t)pick.next() % c;
+            take(hits[i], loci[l_offs[i] + k]);
+        }
+    } else if (o.ml_mode == 3 || o.ml_mode == 4) {
+        uint32_t max_reads_len = 0;
+        for (size_t i = 0; i < nr; i++) max_reads_len = std::max(max_reads_len, rs.lens[i]);
+        bk::MultiAssign ma;
+        for (size_t i = 0; i < nr; i++) {
+            const uint32_t c = eff_count(i);
+            for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[l_offs[i] + k], c > 1);
+        }
+        diag("Assigning %llu reads which aligned to multiple loci to a single loci", (unsigned long long)n_multi);
+        bk::MultiAssignStats st = ma.assign(o.ml_mode == 3, o.nthreads, max_reads_len);
+        for (const bk::MultiHitRec &m : ma.recs)
+            if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
+        diag("Clustering completed, removed %d unclustered orphans from %d putative resulting in %d (%d clustered near unique, %d clustered near other multiloci reads) multihit reads accepted as assigned",
+             st.putative - st.assigned, st.putative, st.assigned, st.near_unique, st.near_multi);
+    } else if (o.ml_mode == 5) {
+        // eMLall: every locus becomes a record of its own, ReadID = order of creation (CAligner::WriteHitLoci / AddMultiHit,
+        // Aligner.cpp:6666-6800); with -M6 reads without alignment (eHRnone, eHRHitInsts) are kept as one unaligned
+        // record, everything else (EN, MMDelta) drops out (:9311-9352,9441-9449)
+        std::vector<bk_hit> recs;
+        for (size_t i = 0; i < nr; i++) {
+            const bk_hit &h = hits[i];
+            const uint32_t c = eff_count(i);
+            if (c) {
+                for (uint32_t k = 0; k < c; k++) {
+                    bk_hit r = h;
+                    take(r, loci[l_offs[i] + k]);
+                    recs.push_back(r);
+                    src.push_back((uint32_t)i);
+                }
+            } else if (o.fmt == 6 && h.nar != BK_NAR_NS && (h.rslt == BK_HR_NONE || h.rslt == BK_HR_HITINSTS)) {
+                bk_hit r = h;
+                r.num_hits = 0;
+                r.low_mm = 0;
+                recs.push_back(r);
+                src.push_back((uint32_t)i);
+            }
+        }
+        diag("Treating accepted %llu multialigned reads as uniquely aligned %llu source reads in subsequent processing",
+             (unsigned long long)n_multi, (unsigned long long)(n_loci - n_uniq));
+        hits.swap(recs);
+        nr = hits.size();
+    }
+}
+
 int cmd_align(int argc, char **argv, int first)
 {
     Args a;
@@ -441,7 +768,7 @@ int cmd_align(int argc, char **argv, int first)
         {"mode", "m"}, {"alignstrand", "Q"}, {"editdelta", "e"}, {"substitutions", "s"}, {"maxns", "n"}, {"trim5", "y"},
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
-        {"quality", "g"}, {"device", "device"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
+        {"quality", "g"}, {"device", "device"}, {"devices", "devices"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
         {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
         {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}, {"snpcentroid", "7"}};
@@ -451,141 +778,33 @@ int cmd_align(int argc, char **argv, int first)
     }
     if (!a.has("i") || !a.has("I") || !a.has("o")) {
         fprintf(stderr, "usage: %s align -i <reads> -I <genome.sfx> -o <out.sam> [-s subs] [-e delta] [-Q strand] [-m mode] [-n maxNs] "
-                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats]\n", g_proc.c_str());
+                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats] [--device n | --devices a-b]\n", g_proc.c_str());
         return 1;
     }
     if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
     diag("Subprocess align Version %s starting", kProgVer);
-    const int pe_mode = a.num("U", 0);
-    if (pe_mode < 0 || pe_mode > 4) { diag("Error: paired end processing mode '-U%d' must be in range 0..4", pe_mode); return 1; }
-    if (pe_mode && (!a.has("u") || a.v["u"].size() != a.v["i"].size())) {
-        diag("Error: paired end processing '-U%d' needs as many '-u' PE2 files as '-i' PE1 files", pe_mode);
-        return 1;
-    }
-    bk_pe_params PE = {};
-    PE.pe_mode = pe_mode;
-    PE.pair_min_len = a.num("d", 100);            // cDfltPairMinLen
-    PE.pair_max_len = a.num("D", 1000);           // cDfltPairMaxLen
-    PE.pair_strand = a.has("E") ? 1 : 0;
-    if (pe_mode && (PE.pair_min_len < 25 || PE.pair_max_len < PE.pair_min_len || PE.pair_max_len > 100000)) {
-        diag("Error: paired end insert size range '-d%d -D%d' not accepted", PE.pair_min_len, PE.pair_max_len);
-        return 1;
-    }
-    // -r multi-loci modes (kanga.cpp:482-486,535-539,666-694): 0 slough, 1 stats only, 2 random pick, 3 cluster with
-    // uniques, 4 cluster with uniques + other multi-loci reads, 5 report all loci; -R loci limit, -X clamp
-    const int ml_mode = a.num("r", 0);
-    if (ml_mode < 0 || ml_mode > 5) { diag("Error: multiple aligned reads processing mode '-r%d' specified outside of range 0..5", ml_mode); return 1; }
-    if (pe_mode && ml_mode) { diag("Error: Sorry, currently multiloci processing '-r%d' not supported in paired end '-U%d' processing", ml_mode, pe_mode); return 1; }
-    int max_ml = 1;
-    bool clamp_ml = false, best_matches = false;
-    if (ml_mode) {
-        max_ml = a.num("R", 5);                                         // cDfltMaxMultiHits
-        const int lim = ml_mode == 5 ? 100000 : 500;                    // cMaxAllHits / cMaxMultiHits
-        if (max_ml < 2 || max_ml > lim) { diag("Error: multiple aligned reads '-R%d' specified outside of range 2..%d", max_ml, lim); return 1; }
-        if (max_ml > BK_MAX_ML) { diag("Error: '-R%d' is above the %d loci per read this build keeps", max_ml, BK_MAX_ML); return 1; }
-        best_matches = a.has("N");                                      // bLocateBestMatches (implies the clamp, kanga.cpp:686-694)
-        clamp_ml = a.has("X") || best_matches;
-    }
-    // -g FASTQ quality scores: 0 Sanger / Illumina 1.8+, 1 Illumina 1.3+, 2 Solexa, 3 ignore (default; QUAL is then '*')
-    g_sample_nth = a.num("#", 1);
-    if (g_sample_nth < 1 || g_sample_nth > 10000) { diag("Error: sample every Nth raw read '-#%d' specified outside of range 1..10000", g_sample_nth); return 1; }
-    g_qual_mode = a.num("g", 3);
-    if (g_qual_mode < 0 || g_qual_mode > 3) { diag("Error: fastq quality '-g%d' specified outside of range 0..3", g_qual_mode); return 1; }
-    // -a microInDels (kanga.cpp:696-710): looked for in reads the substitution-only phases leave unaligned
-    const int micro_indel = a.num("a", 0);
-    if (micro_indel < 0 || micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", micro_indel); return 1; }
-    if (micro_indel && ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
-    if (micro_indel && pe_mode) { diag("Error: Sorry, currently microInDel processing '-a%d' not supported in paired end '-U%d' processing", micro_indel, pe_mode); return 1; }   // kanga.cpp:541-545
-    if (micro_indel && best_matches) { diag("Error: microInDels '-a%d' together with '-N' are not available in this build", micro_indel); return 1; }
-    // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
-    // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
-    const int splice_len = a.num("A", 0);
-    if (splice_len != 0 && (splice_len < 25 || splice_len > 100000)) { diag("Error: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000", splice_len); return 1; }
-    if (splice_len && ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
-    if (splice_len && pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", splice_len, pe_mode); return 1; }
-    if (splice_len && best_matches) { diag("Error: splice junctions '-A%d' together with '-N' are not available in this build", splice_len); return 1; }
-    // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
-    const int min_chim = a.num("c", 0);
-    if (min_chim != 0 && (min_chim < 50 || min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", min_chim < 0 ? -min_chim : min_chim); return 1; }
-    if (min_chim && (ml_mode || pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", min_chim, ml_mode, pe_mode); return 1; }
-    // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
-    SnpOpts snp;
-    snp.min_reads = a.num("p", 0);
-    if (snp.min_reads != 0 && (snp.min_reads < 1 || snp.min_reads > 100)) { diag("Error: Minimum read coverage at any loci '-p%d' must be in range 1..100", snp.min_reads); return 1; }
-    if (snp.min_reads > 0) {
-        snp.qvalue = a.has("P") ? atof(a.str("P").c_str()) : 0.0;
-        if (snp.qvalue < 0.0 || snp.qvalue > 0.40) { diag("Error: QValue '-P%1.5f' for controlling SNP FDR (Benjamini-Hochberg) must be in range 0.0 to 0.4", snp.qvalue); return 1; }
-        if (snp.qvalue == 0.0) snp.qvalue = 0.05;
-        const double pcnt = a.has("1") ? atof(a.str("1").c_str()) : 25.0;
-        if (pcnt < 0.1 || pcnt > 35.0) { diag("Error: SNP minimum non-ref '-1%f' for controlling SNP FDR must be in range 0.1 to 35.0", pcnt); return 1; }
-        snp.nonref_prop = pcnt / 100.0;
-        if (ml_mode == 5) { diag("Error: SNP processing not currently supported if reporting multiloci alignments"); return 1; }
-        snp.marker_len = a.num("K", 0);                    // kanga.cpp:928-952
-        snp.centroid_path = a.str("7", "");                // kanga.cpp:954-960
-        if (snp.marker_len != 0 && (snp.marker_len < 25 || snp.marker_len > 500)) { diag("Error: Marker length specified with '-K%d' must be in range 25 to 500", snp.marker_len); return 1; }
-        if (snp.marker_len) {
-            snp.marker_poly_thres = a.has("G") ? atof(a.str("G").c_str()) : (1.0 / 3.0);
-            if (snp.marker_poly_thres < 0.0 || snp.marker_poly_thres > 0.50) { diag("Error: Max marker sequence base poymorphism specified with '-G%1.3f' must be in range 0.0 to 0.5", snp.marker_poly_thres); return 1; }
-        }
-    }
-    // -k PCR differential amplification artefact reduction (kanga.cpp:718-724): window 0..250, off by default
-    const int pcr_win = a.has("k") ? a.num("k", -1) : -1;
-    if (a.has("k") && (pcr_win < 0 || pcr_win > 250)) { diag("Error: PCR differential amplification artefacts window length '-k%d' specified outside of range 0..250", pcr_win); return 1; }
-    if (pcr_win >= 0 && ml_mode == 5) { diag("Error: '-k%d' together with '-r5' is not available in this build", pcr_win); return 1; }
-    // -Z / -z chromosome exclude / include filters: POSIX extended regular expressions, case-insensitive (Aligner.cpp:4770-4795)
-    std::vector<regex_t> re_excl, re_incl;
-    for (const char *opt : {"Z", "z"})
-        if (a.has(opt))
-            for (const std::string &pat : a.v[opt]) {
-                regex_t re;
-                if (regcomp(&re, pat.c_str(), REG_EXTENDED | REG_ICASE)) { diag("Error: ProcessAlign: %s chrom RE '%s' error", opt[0] == 'Z' ? "exclude" : "include", pat.c_str()); return 1; }
-                (opt[0] == 'Z' ? re_excl : re_incl).push_back(re);
-            }
-    if ((!re_excl.empty() || !re_incl.empty()) && (pe_mode || ml_mode == 5)) { diag("Error: chromosome filters '-Z/-z' together with '-U%d' / '-r5' are not available in this build", pe_mode); return 1; }
-    int min_flank = a.num("x", 0);
-    if (min_flank < 0 || min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", min_flank); return 1; }      // cMaxAllowedSubs / 2
-    if (min_flank && ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", min_flank); return 1; }
-    bk_align_params P = {};
-    P.micro_indel_len = micro_indel;
-    P.splice_junct_len = splice_len;
-    P.pmode = a.num("m", 0);
-    P.align_strand = a.num("Q", 0);
-    P.min_edit_dist = a.num("e", 1);
-    P.max_subs = a.num("s", 10);                  // cDfltAllowedSubs per 100bp
-    if (splice_len > 0 && min_chim == 0 && min_flank == 0) min_flank = P.max_subs;      // MinFlankExacts = MaxSubs (kanga.cpp:810-811)
-    P.min_chimeric_len = min_chim;
-    P.max_ns = a.num("n", 1);
-    P.max_ml = max_ml;
-    P.clamp_ml = clamp_ml ? 1 : 0;
-    P.best_matches = best_matches ? 1 : 0;
-    int fmt = a.num("M", 5);
-    if (ml_mode == 5 && !(fmt == 0 || fmt == 4 || fmt == 5 || fmt == 6)) {      // kanga.cpp:830-834
-        diag("Error: reporting all multiloci alignments '-r5' is only available with output formats '-M0', '-M4', '-M5' and '-M6'");
-        return 1;
-    }
-    if (a.has("O") && fmt == 6) {                 // kanga.cpp:1015-1021
-        diag("Error: Output induced substitution mode '-O<file>' not available in '-M6' output mode\n");
-        return 1;
-    }
-    int min_len = a.num("l", 50), max_len = a.num("L", 500);
-    int trim5 = a.num("y", 0), trim3 = a.num("Y", 0);
-    int max_rpt_sam_seqs = a.num("4", 10000);
-    // -T: host threads for parsing, sorting and formatting (0 = all cores, capped like the reference's cMaxWorkerThreads)
-    int nthreads = a.num("T", 0);
-    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 128) nthreads = 128;
-    if (P.pmode < 0 || P.pmode > 3 || P.align_strand < 0 || P.align_strand > 2 || P.min_edit_dist < 1 || P.min_edit_dist > 2 ||
-        P.max_subs < 0 || P.max_subs > 25 || P.max_ns < 0 || P.max_ns > 5 || min_len < 15 || min_len > 2000 || max_len < min_len ||
-        max_len > 2000 || fmt < 0 || fmt > 6) {
-        diag("Error: an option value is outside its accepted range");
-        return 1;
-    }
+    AlignOpts o;
+    if (read_align_opts(a, o)) return 1;
 
+    // index images travel to the devices (one loader thread each) while this thread parses the reads: the two longest serial steps
+    // of a run overlap (the reference loads its reads in the background of the alignment instead, Aligner.cpp:4820-4860)
     diag("Loading suffix array file '%s'", a.str("I").c_str());
-    bk_ctx *ctx = nullptr;
-    int rc = bk_ctx_create(&ctx, a.str("I").c_str(), a.num("device", 0), &P);
-    if (rc) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(rc)); return 1; }
+    const size_t ndev = o.devices.size();
+    std::vector<bk_ctx *> ctxs(ndev, nullptr);
+    std::vector<int> ctx_rc(ndev, 0);
+    std::vector<std::thread> loaders;
+    for (size_t d = 0; d < ndev; d++)
+        loaders.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_create(&ctxs[d], a.str("I").c_str(), o.devices[d], &o.P); });
+    auto destroy_ctxs = [&]() { for (bk_ctx *c : ctxs) bk_ctx_destroy(c); };
+    ReadStore rs;
+    int rc;
+    if (o.pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
+    else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
+    for (auto &t : loaders) t.join();
+    for (size_t d = 0; d < ndev; d++)
+        if (ctx_rc[d]) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(ctx_rc[d])); destroy_ctxs(); return 1; }
+    if (rc) { destroy_ctxs(); return 1; }
+    bk_ctx *ctx = ctxs[0];
     std::string species = bk_dataset_name(ctx);
     uint32_t n_ent = bk_num_entries(ctx);
     std::vector<bk_entry_info> ents(n_ent);
@@ -593,131 +812,23 @@ int cmd_align(int argc, char **argv, int first)
     diag("Genome Assembly Name: '%s'", species.c_str());
     diag("Genome assembly suffix array loaded");
 
-    ReadStore rs;
-    if (pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], trim5, trim3, min_len, max_len, nthreads, rs);
-    else rc = load_reads(a.v["i"], trim5, trim3, min_len, max_len, nthreads, rs);
-    if (rc) { bk_ctx_destroy(ctx); return 1; }
     size_t nr = rs.size();
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
-    std::vector<bk_hit> hits(nr);
-    std::vector<uint64_t> l_offs;                  // multi-loci modes: read i owns loci [l_offs[i], l_offs[i+1])
-    std::vector<bk_loci> loci;
-    std::vector<bk_seg2> seg2;                     // -a: second segment of each read (flags 0 = none)
-    if (ml_mode) l_offs.assign(1, 0);
-    const size_t kBatch = 16u << 20;
-    for (size_t lo = 0; lo < nr; lo += kBatch) {
-        size_t n = std::min(kBatch, nr - lo);
-        rc = bk_align_batch(ctx, rs.bases.data(), rs.offs.data() + lo, rs.lens.data() + lo, (uint32_t)n, hits.data() + lo);
-        if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-        if (micro_indel || splice_len || min_chim) {
-            const bk_seg2 *bs = nullptr;
-            uint64_t ns = 0;
-            rc = bk_batch_seg2(ctx, &bs, &ns);
-            if (rc || !bs || ns != n) { diag("Fatal: microInDel segments unavailable: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-            seg2.insert(seg2.end(), bs, bs + ns);
-        }
-        if (ml_mode) {
-            const uint64_t *bo = nullptr;
-            const bk_loci *bl = nullptr;
-            uint64_t nl = 0;
-            rc = bk_batch_loci(ctx, &bo, &bl, &nl);
-            if (rc || !bo) { diag("Fatal: loci lists unavailable: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-            const uint64_t base = loci.size();
-            for (size_t i = 1; i <= n; i++) l_offs.push_back(base + bo[i]);
-            loci.insert(loci.end(), bl, bl + nl);
-        }
-    }
+    AlignedSet A;
+    if (o.pe_mode) diag("Paired end association and partner alignment processing runs with the alignment of each batch");
+    rc = align_reads(ctxs, o, rs, A);
+    if (rc) { destroy_ctxs(); return 1; }
+    std::vector<bk_hit> &hits = A.hits;
+    std::vector<bk_seg2> &seg2 = A.seg2;
     diag("Alignment of %zu from %zu loaded completed", nr, nr);
 
     std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
-    std::vector<int> multi_dist((size_t)max_ml, 0);
-    if (ml_mode) {
-        // CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424); reads in load order, as -T1 runs them
-        auto eff_count = [&](size_t i) -> uint32_t {            // LowHitInstances of a read that counts as eHRhits (after -X)
-            const bk_hit &h = hits[i];
-            if (h.rslt == BK_HR_HITS || (clamp_ml && h.rslt == BK_HR_HITINSTS)) return (uint32_t)(l_offs[i + 1] - l_offs[i]);
-            return 0;
-        };
-        auto take = [&](bk_hit &h, const bk_loci &L) {
-            h.chrom_id = L.chrom_id; h.match_loci = L.match_loci; h.match_len = L.match_len; h.strand = L.strand;
-            h.mismatches = L.mismatches; h.nar = BK_NAR_ACCEPTED; h.num_hits = 1; h.low_hit_instances = 1;
-        };
-        uint64_t n_uniq = 0, n_multi = 0, n_loci = 0;
-        for (size_t i = 0; i < nr; i++) {
-            const uint32_t c = eff_count(i);
-            if (!c) continue;
-            n_loci += c;
-            (c == 1 ? n_uniq : n_multi)++;
-            if (ml_mode != 5) multi_dist[c - 1]++;
-            if (clamp_ml && hits[i].rslt == BK_HR_HITINSTS) hits[i].low_hit_instances = (int16_t)c;
-        }
-        diag("Provisionally accepted %llu aligned reads (%llu uniquely, %llu aligning to multiloci) aligning to a total of %llu loci",
-             (unsigned long long)(n_uniq + n_multi), (unsigned long long)n_uniq, (unsigned long long)n_multi, (unsigned long long)n_loci);
-        if (ml_mode == 2) {
-            // eMLrand: rand() % LowHitInstances for every eHRhits read, unique ones included (:9365-9366); the sequence is
-            // glibc's unseeded one (glibc_rand.h), which is what a single-threaded reference run consumes in the same order
-            bk::GlibcRand pick;
-            for (size_t i = 0; i < nr; i++) {
-                const uint32_t c = eff_count(i);
-                if (!c) continue;
-                const uint32_t k = (uint32_t)pick.next() % c;
-                take(hits[i], loci[l_offs[i] + k]);
-            }
-        } else if (ml_mode == 3 || ml_mode == 4) {
-            uint32_t max_reads_len = 0;
-            for (size_t i = 0; i < nr; i++) max_reads_len = std::max(max_reads_len, rs.lens[i]);
-            bk::MultiAssign ma;
-            for (size_t i = 0; i < nr; i++) {
-                const uint32_t c = eff_count(i);
-                for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[l_offs[i] + k], c > 1);
-            }
-            diag("Assigning %llu reads which aligned to multiple loci to a single loci", (unsigned long long)n_multi);
-            bk::MultiAssignStats st = ma.assign(ml_mode == 3, nthreads, max_reads_len);
-            for (const bk::MultiHitRec &m : ma.recs)
-                if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
-            diag("Clustering completed, removed %d unclustered orphans from %d putative resulting in %d (%d clustered near unique, %d clustered near other multiloci reads) multihit reads accepted as assigned",
-                 st.putative - st.assigned, st.putative, st.assigned, st.near_unique, st.near_multi);
-        } else if (ml_mode == 5) {
-            // eMLall: every locus becomes a record of its own, ReadID = order of creation (CAligner::WriteHitLoci / AddMultiHit,
-            // Aligner.cpp:6666-6800); with -M6 reads without alignment (eHRnone, eHRHitInsts) are kept as one unaligned
-            // record, everything else (EN, MMDelta) drops out (:9311-9352,9441-9449)
-            std::vector<bk_hit> recs;
-            for (size_t i = 0; i < nr; i++) {
-                const bk_hit &h = hits[i];
-                const uint32_t c = eff_count(i);
-                if (c) {
-                    for (uint32_t k = 0; k < c; k++) {
-                        bk_hit r = h;
-                        take(r, loci[l_offs[i] + k]);
-                        recs.push_back(r);
-                        src.push_back((uint32_t)i);
-                    }
-                } else if (fmt == 6 && h.nar != BK_NAR_NS && (h.rslt == BK_HR_NONE || h.rslt == BK_HR_HITINSTS)) {
-                    bk_hit r = h;
-                    r.num_hits = 0;
-                    r.low_mm = 0;
-                    recs.push_back(r);
-                    src.push_back((uint32_t)i);
-                }
-            }
-            diag("Treating accepted %llu multialigned reads as uniquely aligned %llu source reads in subsequent processing",
-                 (unsigned long long)n_multi, (unsigned long long)(n_loci - n_uniq));
-            hits.swap(recs);
-            nr = hits.size();
-        }
-    }
+    std::vector<int> multi_dist((size_t)o.max_ml, 0);
+    if (o.ml_mode) resolve_multi_loci(o, rs, A, src, multi_dist, nr);
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 5); };       // FlgInDel or FlgSplice
-    if (pe_mode) {
-        // CAligner::ProcessPairedEnds: reads are held interleaved PE1,PE2 (Aligner.cpp:11349-11355); before the flank trimmer, as in
-        // CAligner::Align (:573-622)
-        diag("Paired end association and partner alignment processing started..");
-        const size_t kPairs = 8u << 20;
-        for (size_t lo = 0; lo < nr / 2; lo += kPairs) {
-            size_t n = std::min(kPairs, nr / 2 - lo);
-            rc = bk_pair_batch(ctx, rs.bases.data(), rs.offs.data() + 2 * lo, rs.lens.data() + 2 * lo, (uint32_t)n, hits.data() + 2 * lo, &PE);
-            if (rc) { diag("Fatal: paired end processing failed: %s", bk_strerror(rc)); bk_ctx_destroy(ctx); return 1; }
-        }
+    if (o.pe_mode) {
+        // CAligner::ProcessPairedEnds ran on the device with each batch (reads are held interleaved PE1,PE2, Aligner.cpp:11349-11355)
         size_t n_pe = 0;
         for (size_t i = 0; i < nr; i += 2) n_pe += (hits[i].flags & 0x80) && (hits[i + 1].flags & 0x80);
         diag("From %zu paired reads there were %zu accepted as paired", nr / 2, n_pe);
@@ -730,7 +841,7 @@ int cmd_align(int argc, char **argv, int first)
     auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
     auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
     auto is_chimeric = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 8); };     // FlgChimeric: trims come with the hit
-    if (min_chim) {
+    if (o.min_chim) {
         // chimeric placements keep the trims AdaptiveTrim found (ProcCoredApprox :9292-9299); the flank trimmer leaves them alone (:1641)
         if (trims.empty()) {
             trims.left.assign(nr, 0); trims.right.assign(nr, 0); trims.mismatches.resize(nr);
@@ -756,42 +867,42 @@ int cmd_align(int argc, char **argv, int first)
         if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
         return 0;
     };
-    if (pcr_win >= 0 && !pe_mode) {
+    if (o.pcr_win >= 0 && !o.pe_mode) {
         // CAligner::ReducePCRduplicates runs on the sorted set, before the flank trimmer (Aligner.cpp:598-610)
         diag("Processing to reduce PCR differential amplification artefacts processing started..");
         std::vector<uint32_t> ord(nr);
         for (size_t i = 0; i < nr; i++) ord[i] = (uint32_t)i;
-        bk::ref_order_sort(ord.data(), (int64_t)nr, cmp, nthreads);
-        const size_t n_dup = bk::reduce_pcr_duplicates(hits, ord, [&](size_t i) { return a_start(hits[i], i); }, [&](size_t i) { return a_len(hits[i], i); }, pcr_win);
+        bk::ref_order_sort(ord.data(), (int64_t)nr, cmp, o.nthreads);
+        const size_t n_dup = bk::reduce_pcr_duplicates(hits, ord, [&](size_t i) { return a_start(hits[i], i); }, [&](size_t i) { return a_len(hits[i], i); }, o.pcr_win);
         diag("Removed %zu potential PCR artefact reads", n_dup);
     }
-    if (min_flank > 0) {
+    if (o.min_flank > 0) {
         diag("Starting 5' and 3' flank sequence autotrim processing...");
         bk::SfxFile sft;
         std::string serr;
-        if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); bk_ctx_destroy(ctx); return 1; }
+        if (bk::sfx_open(a.str("I").c_str(), sft, &serr) != 0) { diag("Fatal: %s", serr.c_str()); destroy_ctxs(); return 1; }
         bk::auto_trim_flanks(hits, [&](size_t i) { return has_seg2(i) || is_chimeric(i); }, [&](size_t i) { return rs.bases.data() + rs.offs[RD(i)]; },
                              [&](size_t i) -> const uint8_t * {
                                  const bk_hit &h = hits[i];
                                  return (h.chrom_id >= 1 && h.chrom_id <= n_ent) ? sft.seq + ents[h.chrom_id - 1].start_ofs + h.match_loci : nullptr;
                              },
-                             min_flank, pe_mode != 0, nthreads, trims);
+                             o.min_flank, o.pe_mode != 0, o.nthreads, trims);
         diag("Finished 5' and 3' flank sequence autotriming, %zu plus strand and %zu minus strand aligned reads removed", trims.removed_plus,
              trims.removed_minus);
     }
     // orphan junction filters, splice junctions first (Aligner.cpp:630-650)
-    if (splice_len) {
+    if (o.splice_len) {
         diag("Removal of orphan splice junction processing started..");
         auto r = bk::remove_orphan_segs(hits, seg2, 4, 7);
         diag("From %zu reads with putative splice junctions %zu orphans were removed", r.first, r.second);
     }
-    if (micro_indel) {
+    if (o.micro_indel) {
         diag("Removal of orphan microInDels processing started..");
         auto r = bk::remove_orphan_segs(hits, seg2, 1, 8);
         diag("From %zu reads with putative microIndels %zu orphans were removed", r.first, r.second);
     }
 
-    if (!re_excl.empty() || !re_incl.empty()) {
+    if (!o.re_excl.empty() || !o.re_incl.empty()) {
         // CAligner::FiltByChroms (Aligner.cpp:4019-4120): a sequence stays if an include expression matches its name, or - with no
         // include expressions at all - if no exclude expression does; accepted reads on the others become eNARChromFilt
         diag("Now filtering matches by chromosome");
@@ -799,10 +910,10 @@ int cmd_align(int argc, char **argv, int first)
         for (uint32_t c = 1; c <= n_ent; c++) {
             regmatch_t mc;
             bool ok = false;
-            for (regex_t &re : re_incl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = true; break; }
-            if (!ok && re_incl.empty()) {
+            for (regex_t &re : o.re_incl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = true; break; }
+            if (!ok && o.re_incl.empty()) {
                 ok = true;
-                for (regex_t &re : re_excl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = false; break; }
+                for (regex_t &re : o.re_excl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = false; break; }
             }
             keep[c] = ok ? 1 : 0;
         }
@@ -821,31 +932,39 @@ int cmd_align(int argc, char **argv, int first)
          (unsigned long long)(nr - nar[1]), (unsigned long long)nar[2]);
     diag("Read nonalignment reason summary:");
     for (int k = 0; k < 20; k++) diag("   %llu (%s) %s", (unsigned long long)nar[k], kNarTag[k], kNarDescr[k]);
+    if (!o.pe_mode && !o.ml_mode && !o.micro_indel && !o.splice_len && !o.min_chim && o.pcr_win < 0 && !o.min_flank && o.re_excl.empty() && o.re_incl.empty()) {
+        // nothing above changed an acceptance: the per-sequence counts the devices kept (summed over them by the exchange step)
+        // must add up to the accepted reads counted here
+        uint64_t tot = 0;
+        for (uint64_t c : A.seq_counts) tot += c;
+        if (tot != nar[1]) { diag("Fatal: the devices counted %llu accepted reads, the result records hold %llu", (unsigned long long)tot, (unsigned long long)nar[1]); destroy_ctxs(); return 1; }
+        if (ndev > 1) diag("Accepted read counts per sequence reduced over %zu devices: %llu reads", ndev, (unsigned long long)tot);
+    }
 
     // SortReadHits(eRSMHitMatch): index in load (ReadID) order -> reference order
     diag("Reporting of aligned result set started...");
     diag("Sorting alignments by ascending chrom.loci");
     std::vector<uint32_t> order(nr);
     for (size_t i = 0; i < nr; i++) order[i] = (uint32_t)i;
-    bk::ref_order_sort(order.data(), (int64_t)nr, cmp, nthreads);
+    bk::ref_order_sort(order.data(), (int64_t)nr, cmp, o.nthreads);
 
-    Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, pe_mode, ml_mode, max_ml, fmt, nthreads, micro_indel, splice_len, max_rpt_sam_seqs};
+    Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");
-    int rr = (fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);
+    int rr = (o.fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);
     // SNPs: the file is only opened for '-M0' .. '-M5' (Aligner.cpp:4488), and only processed when reads were accepted (:746)
-    if (rr == 0 && snp.min_reads > 0 && fmt <= 5) {
-        snp.path = a.has("S") ? a.str("S") : opath + ".snp";
-        snp.bed = fmt == 4;
-        snp.vcf = !snp.bed && snp.path.size() >= 4 && !strcasecmp(snp.path.c_str() + snp.path.size() - 4, ".vcf");     // Aligner.cpp:157-165
-        snp.title = a.str("t", "kanga");
-        snp.sfx_path = a.str("I");
+    if (rr == 0 && o.snp.min_reads > 0 && o.fmt <= 5) {
+        o.snp.path = a.has("S") ? a.str("S") : opath + ".snp";
+        o.snp.bed = o.fmt == 4;
+        o.snp.vcf = !o.snp.bed && o.snp.path.size() >= 4 && !strcasecmp(o.snp.path.c_str() + o.snp.path.size() - 4, ".vcf");     // Aligner.cpp:157-165
+        o.snp.title = a.str("t", "kanga");
+        o.snp.sfx_path = a.str("I");
         bool any = false;
         for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED) { any = true; break; }
-        if (any) rr = process_snps(ctx, R, snp);
-        else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv", ".markers"}) { if (ext[1] == 'm' && !snp.marker_len) continue; OutBuf e; e.open((snp.path + ext).c_str()); e.close(); }
+        if (any) rr = process_snps(ctx, R, o.snp);
+        else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv", ".markers"}) { if (ext[1] == 'm' && !o.snp.marker_len) continue; OutBuf e; e.open((o.snp.path + ext).c_str()); e.close(); }
     }
-    bk_ctx_destroy(ctx);
+    destroy_ctxs();
     return rr;
 }
 

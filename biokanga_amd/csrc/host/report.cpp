@@ -16,25 +16,13 @@ namespace bkcli {
     // order, 70 columns (CAligner::ReportNoneAligned / ReportMultiAlign, Aligner.cpp:3826-4010)
 void report_read_subset(Report &R, const char *opt, const char *tag, bool (*want)(uint8_t))
 {
-    [[maybe_unused]] const Args &a = R.a;
-    [[maybe_unused]] auto &hits = R.hits;
-    [[maybe_unused]] auto &rs = R.rs;
-    [[maybe_unused]] auto &ents = R.ents;
-    [[maybe_unused]] const std::string &species = R.species;
-    [[maybe_unused]] const uint32_t n_ent = R.n_ent;
-    [[maybe_unused]] const size_t nr = R.hits.size();
-    [[maybe_unused]] const auto &order = R.order;
-    [[maybe_unused]] const auto &seg2 = R.seg2;
-    [[maybe_unused]] const auto &multi_dist = R.multi_dist;
-    [[maybe_unused]] const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel,
-                               splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
-    [[maybe_unused]] auto RD = [&](size_t i) -> size_t { return R.RD(i); };
-    [[maybe_unused]] auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
-    [[maybe_unused]] auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
-    [[maybe_unused]] auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
-    [[maybe_unused]] auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
-    [[maybe_unused]] auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
-    [[maybe_unused]] auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    const Args &a = R.a;
+    auto &hits = R.hits;
+    auto &rs = R.rs;
+    const size_t nr = R.hits.size();
+    const auto &order = R.order;
+    auto RD = [&](size_t i) -> size_t { return R.RD(i); };
+    const int ml_mode = R.ml_mode;
     if (!a.has(opt) || ml_mode == 5) return;                         // kanga.cpp:1045-1066
     OutBuf o;
     o.open(a.str(opt).c_str());
@@ -62,25 +50,19 @@ void report_read_subset(Report &R, const char *opt, const char *tag, bool (*want
     // (:4186-4330, fed by WriteSubDist :6275-6336 for every accepted read) and ReportTargHitCnts (:5475-5537)
 void report_stats(Report &R)
 {
-    [[maybe_unused]] const Args &a = R.a;
-    [[maybe_unused]] auto &hits = R.hits;
-    [[maybe_unused]] auto &rs = R.rs;
-    [[maybe_unused]] auto &ents = R.ents;
-    [[maybe_unused]] const std::string &species = R.species;
-    [[maybe_unused]] const uint32_t n_ent = R.n_ent;
-    [[maybe_unused]] const size_t nr = R.hits.size();
-    [[maybe_unused]] const auto &order = R.order;
-    [[maybe_unused]] const auto &seg2 = R.seg2;
-    [[maybe_unused]] const auto &multi_dist = R.multi_dist;
-    [[maybe_unused]] const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel,
-                               splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
-    [[maybe_unused]] auto RD = [&](size_t i) -> size_t { return R.RD(i); };
-    [[maybe_unused]] auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
-    [[maybe_unused]] auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
-    [[maybe_unused]] auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
-    [[maybe_unused]] auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
-    [[maybe_unused]] auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
-    [[maybe_unused]] auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    const Args &a = R.a;
+    auto &hits = R.hits;
+    auto &rs = R.rs;
+    auto &ents = R.ents;
+    const uint32_t n_ent = R.n_ent;
+    const size_t nr = R.hits.size();
+    const auto &multi_dist = R.multi_dist;
+    auto RD = [&](size_t i) -> size_t { return R.RD(i); };
+    auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
+    auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
+    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
+    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
+    const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, nthreads = R.nthreads;
     if (!a.has("O")) return;
     FILE *f = fopen(a.str("O").c_str(), "w");
     if (!f) { diag("Unable to create '%s'", a.str("O").c_str()); return; }
@@ -177,25 +159,15 @@ void report_stats(Report &R)
     // title is empty in these modes
 void report_jct_for_sam(Report &R)
 {
-    [[maybe_unused]] const Args &a = R.a;
-    [[maybe_unused]] auto &hits = R.hits;
-    [[maybe_unused]] auto &rs = R.rs;
-    [[maybe_unused]] auto &ents = R.ents;
-    [[maybe_unused]] const std::string &species = R.species;
-    [[maybe_unused]] const uint32_t n_ent = R.n_ent;
-    [[maybe_unused]] const size_t nr = R.hits.size();
-    [[maybe_unused]] const auto &order = R.order;
-    [[maybe_unused]] const auto &seg2 = R.seg2;
-    [[maybe_unused]] const auto &multi_dist = R.multi_dist;
-    [[maybe_unused]] const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel,
-                               splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
-    [[maybe_unused]] auto RD = [&](size_t i) -> size_t { return R.RD(i); };
-    [[maybe_unused]] auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
-    [[maybe_unused]] auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
-    [[maybe_unused]] auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
-    [[maybe_unused]] auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
-    [[maybe_unused]] auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
-    [[maybe_unused]] auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    const Args &a = R.a;
+    auto &hits = R.hits;
+    auto &ents = R.ents;
+    const size_t nr = R.hits.size();
+    const auto &order = R.order;
+    const auto &seg2 = R.seg2;
+    auto RD = [&](size_t i) -> size_t { return R.RD(i); };
+    auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
+    const int fmt = R.fmt, splice_len = R.splice_len;
     if (!splice_len || fmt < 5) return;
     std::string jp = a.str("o");
     if (jp.size() > 3 && !strcasecmp(jp.c_str() + jp.size() - 3, ".gz")) jp.resize(jp.size() - 3);
@@ -221,25 +193,21 @@ void report_jct_for_sam(Report &R)
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index
 int report_bam(Report &R, const std::string &opath)
 {
-    [[maybe_unused]] const Args &a = R.a;
-    [[maybe_unused]] auto &hits = R.hits;
-    [[maybe_unused]] auto &rs = R.rs;
-    [[maybe_unused]] auto &ents = R.ents;
-    [[maybe_unused]] const std::string &species = R.species;
-    [[maybe_unused]] const uint32_t n_ent = R.n_ent;
-    [[maybe_unused]] const size_t nr = R.hits.size();
-    [[maybe_unused]] const auto &order = R.order;
-    [[maybe_unused]] const auto &seg2 = R.seg2;
-    [[maybe_unused]] const auto &multi_dist = R.multi_dist;
-    [[maybe_unused]] const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel,
-                               splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
-    [[maybe_unused]] auto RD = [&](size_t i) -> size_t { return R.RD(i); };
-    [[maybe_unused]] auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
-    [[maybe_unused]] auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
-    [[maybe_unused]] auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
-    [[maybe_unused]] auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
-    [[maybe_unused]] auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
-    [[maybe_unused]] auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    auto &hits = R.hits;
+    auto &rs = R.rs;
+    auto &ents = R.ents;
+    const std::string &species = R.species;
+    const uint32_t n_ent = R.n_ent;
+    const size_t nr = R.hits.size();
+    const auto &order = R.order;
+    const auto &seg2 = R.seg2;
+    auto RD = [&](size_t i) -> size_t { return R.RD(i); };
+    auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
+    auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
+    auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
+    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
+    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
+    const int pe_mode = R.pe_mode, fmt = R.fmt, nthreads = R.nthreads, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
     int rc = 0;
     std::vector<uint8_t> has_hit(n_ent + 1, 0);
     for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) has_hit[h.chrom_id] = 1;
@@ -399,25 +367,23 @@ int report_bam(Report &R, const std::string &opath)
 // SAM text (-M5 / -M6, optionally gzip'd), CSV (-M0..3) and BED (-M4) output
 int report_text(Report &R)
 {
-    [[maybe_unused]] const Args &a = R.a;
-    [[maybe_unused]] auto &hits = R.hits;
-    [[maybe_unused]] auto &rs = R.rs;
-    [[maybe_unused]] auto &ents = R.ents;
-    [[maybe_unused]] const std::string &species = R.species;
-    [[maybe_unused]] const uint32_t n_ent = R.n_ent;
-    [[maybe_unused]] const size_t nr = R.hits.size();
-    [[maybe_unused]] const auto &order = R.order;
-    [[maybe_unused]] const auto &seg2 = R.seg2;
-    [[maybe_unused]] const auto &multi_dist = R.multi_dist;
-    [[maybe_unused]] const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, max_ml = R.max_ml, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel,
-                               splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
-    [[maybe_unused]] auto RD = [&](size_t i) -> size_t { return R.RD(i); };
-    [[maybe_unused]] auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
-    [[maybe_unused]] auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
-    [[maybe_unused]] auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
-    [[maybe_unused]] auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
-    [[maybe_unused]] auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
-    [[maybe_unused]] auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    const Args &a = R.a;
+    auto &hits = R.hits;
+    auto &rs = R.rs;
+    auto &ents = R.ents;
+    const std::string &species = R.species;
+    const uint32_t n_ent = R.n_ent;
+    const size_t nr = R.hits.size();
+    const auto &order = R.order;
+    const auto &seg2 = R.seg2;
+    auto RD = [&](size_t i) -> size_t { return R.RD(i); };
+    auto has_seg2 = [&](size_t i) -> bool { return R.has_seg2(i); };
+    auto TL = [&](size_t i) -> uint32_t { return R.TL(i); };
+    auto TR = [&](size_t i) -> uint32_t { return R.TR(i); };
+    auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_start(h, i); };
+    auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
+    auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
+    const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel, splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
     OutBuf out;
     out.open(a.str("o").c_str());
     if (out.fd < 0) { diag("Fatal: unable to create '%s'", a.str("o").c_str()); return 1; }

@@ -275,6 +275,13 @@ int  bk_get_timing(bk_ctx *ctx, bk_timing *out, int reset);
 /* per-sequence count of accepted reads since the last reset (CAligner::ReportTargHitCnts,
  * Aligner.cpp:5475-5537) - the vector the multi-GPU run sum-reduces over RCCL.  n = bk_num_entries */
 int  bk_seq_counts(bk_ctx *ctx, uint64_t *per_entry_hits, uint32_t n, int reset);
+/* The path's one exchange step (what CAligner::ReportTargHitCnts and the "@SQ has hits" decision of
+ * Aligner.cpp:5475-5537,5606-5637 see on a single host): the count vectors of the `n` contexts of one process - one context per
+ * GPU, each fed its own shard of the reads - are sum-reduced where they lie in HBM, with RCCL (ncclAllReduce over xGMI) between
+ * distinct devices; contexts sharing a device are added up there first.  `out` (n_entries values, may be NULL) receives the
+ * total; reset != 0 then clears the per-context counts.  Multi-process runs reduce bk_seq_counts() through their own
+ * communicator instead (bench.py: torch.distributed / RCCL). */
+int  bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t n_entries, int reset);
 
 /* ---- SNP calling (-p / -P / -1 / -S) --------------------------------------------------------- */
 /* The pile-up and the per-locus screening of CAligner::ProcessSNPs (biokanga/Aligner.cpp:7737-7960) and of the first

@@ -519,3 +519,27 @@ def test_snp_centroids_byte_identical(golden_tmp, tmp_path, tag, flags):
     run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-T4", "-s5", "-7", cent] + flags, str(tmp_path))
     _cmp_bytes(out + ".snp", "snp", f"{tag}.snp.gz")
     _cmp_bytes(cent, "snp", f"{tag}.centroids.csv.gz")
+
+
+@pytest.mark.parametrize("fixture,tag,flags,pe", [("basic", "s3", ["-s3"], False), ("sortorder", "s3", ["-s3"], False),
+                                                  ("pe", "U3", ["-U3", "-d200", "-D400", "-s5"], True)])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_align_over_several_contexts_sam_byte_identical(golden_tmp, tmp_path, fixture, tag, flags, pe, devices):
+    """`--devices a,b,..`: one context + pipeline per entry, batches dealt round-robin, per-sequence counts summed over the
+    contexts by the exchange step - the files are those of the single-context run (= the reference's), byte for byte.  With
+    one GPU visible the contexts share it; on a multi-GPU node the same code path reduces with RCCL."""
+    d = golden_tmp["basic"]
+    if pe:
+        p = os.path.join(helpers.GOLDEN, "pe")
+        inputs = ["-i", os.path.join(p, "reads_1.fa.gz"), "-u", os.path.join(p, "reads_2.fa.gz")]
+    elif fixture == "sortorder":
+        inputs = ["-i", os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz")]
+    else:
+        inputs = ["-i", os.path.join(d, "reads.fa")]
+    name = {"basic": "s3.m6.sam.gz", "sortorder": "s3.m5.sam.gz", "pe": "U3.m6.sam.gz"}[fixture]
+    fmt = [] if fixture == "sortorder" else ["-M6"]
+    out = str(tmp_path / "o.sam")
+    log = run(["align"] + inputs + ["-I", os.path.join(d, "genome.sfx"), "-o", out, "--devices", devices] + fmt + flags, str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes(fixture, name)
+    if not pe:
+        assert f"reduced over {devices.count(',') + 1} devices" in log

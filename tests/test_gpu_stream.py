@@ -135,3 +135,21 @@ def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path)
     for f in FIELDS + ["flags"]:
         assert np.array_equal(out[f], ref[f]), f
     check_pe_hits_against_sam(names, out, "U3", ["chrA", "chrB"])
+
+
+def test_seq_counts_allreduce_over_contexts(golden_tmp):
+    """the exchange step: two contexts, each fed half of the reads, reduce to the counts of one context fed all of them"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    offs, lens = offs[keep], lens[keep]
+    sfx = os.path.join(d, "genome.sfx")
+    with bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as a0, bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as a1, \
+            bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as whole:
+        hits = whole.align(bases, offs, lens)
+        exp = whole.seq_counts()
+        a0.align(bases, offs[0::2], lens[0::2])
+        a1.align(bases, offs[1::2], lens[1::2])
+        got = bk.seq_counts_allreduce([a0, a1], reset=True)
+        assert np.array_equal(got, exp)
+        assert got.sum() == int((hits["nar"] == 1).sum())
+        assert a0.seq_counts().sum() == 0 and a1.seq_counts().sum() == 0          # reset
