@@ -108,3 +108,12 @@ int engine_align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
 int engine_pair_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs, bk_hit *d_hits,
                        uint32_t maxlen, const bk_pe_params *pe, hipStream_t s);
 }  // namespace bk
+
+namespace bk {
+// Host -> device copy that runs near PCIe rate whatever the kind of host memory: pinned sources are DMA'd directly; pageable
+// ones (file mappings, std::vector) are copied by a few host threads into a pool of pinned staging buffers, each thread feeding
+// its own HIP stream, so that the DRAM / page-cache reads and the DMAs of different slices overlap (a plain hipMemcpy stages
+// through one thread: 6-8 GB/s).  Returns when the bytes are on the device.  bk_upload.cpp
+int upload_host(void *d_dst, const void *h_src, size_t bytes, int device);
+bool host_is_pinned(const void *p);
+}  // namespace bk

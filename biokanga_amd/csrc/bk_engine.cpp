@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,14 @@ void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, cons
 using namespace bk;
 
 namespace {
+
+// BK_TIMING=1: wall-clock of the set-up stages on stderr
+struct StageClock {
+    bool on = getenv("BK_TIMING") != nullptr;
+    double t0 = now();
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: %-28s %7.1f ms\n", what, 1e3 * (t - t0)); t0 = t; }
+};
 
 int derive_cfg(bk_ctx *c)
 {
@@ -292,6 +301,7 @@ int size_heavy_scratch(bk_ctx *c)
 
 int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
 {
+    StageClock clk0;
     // entries
     c->entries.assign(entries, entries + n_entries);
     c->tot_seq_len = 0;
@@ -331,12 +341,19 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
     int rc = derive_cfg(c);
     if (rc) return rc;
+    clk0.lap("entry table, small buffers");
+    StageClock clk;
     rc = build_ktab(c);
+    clk.lap("k-mer table");
     if (!rc) rc = build_k2(c);
+    clk.lap("second-level keys");
     if (rc) return rc;
     rc = build_isa(c);
+    clk.lap("inverse suffix array");
     if (rc) return rc;
-    return build_tgt2(c);        // the hash scratch of the general kernels is sized when they first run
+    rc = build_tgt2(c);          // the hash scratch of the general kernels is sized when they first run
+    clk.lap("2-bit target");
+    return rc;
 }
 
 int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
@@ -905,11 +922,14 @@ int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_al
 {
     if (!sfx_path) return BK_ERR_PARAMS;
     bk_ctx *c = nullptr;
+    StageClock clk;
     int rc = new_ctx(out, device_id, p, &c);
     if (rc) return rc;
+    clk.lap("HIP runtime + device + stream");
     SfxFile f;
     std::string err;
     rc = sfx_open(sfx_path, f, &err);
+    clk.lap("sfx_open");
     if (rc) {
         fprintf(stderr, "biokanga_amd: %s\n", err.c_str());
         bk_ctx_destroy(c);
@@ -922,12 +942,15 @@ int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_al
     if (hipMalloc(&d_seq, f.concat_len + 16) != hipSuccess || hipMalloc(&d_sa, f.concat_len * f.el_size) != hipSuccess) {
         cleanup(); bk_ctx_destroy(c); return BK_ERR_MEM;
     }
-    if (hipMemcpy(d_seq, f.seq, f.concat_len, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_sa, f.sa, f.concat_len * f.el_size, hipMemcpyHostToDevice) != hipSuccess) {
+    clk.lap("device allocations");
+    if (upload_host(d_seq, f.seq, f.concat_len, device_id) != BK_OK || upload_host(d_sa, f.sa, f.concat_len * f.el_size, device_id) != BK_OK) {
         cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL;
     }
+    clk.lap("upload bases + suffix array");
     rc = adopt_device_image(c, d_seq, f.concat_len, d_sa, (int)f.el_size);
+    clk.lap("pack target, adopt");
     cleanup();
+    clk.lap("free staging");
     if (rc) { bk_ctx_destroy(c); return rc; }
     std::vector<bk_entry_info> ents(f.entries.size());
     for (size_t i = 0; i < ents.size(); i++) {
@@ -940,6 +963,7 @@ int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_al
     rc = finish_ctx(c, ents.data(), (uint32_t)ents.size());
     if (rc) { bk_ctx_destroy(c); return rc; }
     *out = c;
+    clk.lap("(rest of bk_ctx_create)");
     return BK_OK;
 }
 

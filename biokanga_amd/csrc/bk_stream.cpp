@@ -131,7 +131,9 @@ struct bk_stream {
             Slot &sl = slots[j->slot];
             hipError_t e = hipSuccess;
             if (j->n) {
-                e = hipMemcpyAsync(sl.d_bases, j->bases, j->nbases, hipMemcpyHostToDevice, s_up);
+                // the bases are the bulk: pageable buffers are staged by several threads (bk::upload_host), pinned ones DMA'd as they are
+                if (bk::host_is_pinned(j->bases)) e = hipMemcpyAsync(sl.d_bases, j->bases, j->nbases, hipMemcpyHostToDevice, s_up);
+                else if (bk::upload_host(sl.d_bases, j->bases, j->nbases, ctx->device) != BK_OK) e = hipErrorUnknown;
                 if (e == hipSuccess && j->offs) e = hipMemcpyAsync(sl.d_offs, j->offs, (size_t)j->n * 8, hipMemcpyHostToDevice, s_up);
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.d_lens, j->lens, (size_t)j->n * 4, hipMemcpyHostToDevice, s_up);
             }

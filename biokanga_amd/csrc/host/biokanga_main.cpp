@@ -564,7 +564,7 @@ int read_align_opts(Args &a, AlignOpts &o)
     o.max_rpt_sam_seqs = a.num("4", 10000);
     // -T: host threads for parsing, sorting and formatting (0 = all cores, capped like the reference's cMaxWorkerThreads)
     o.nthreads = a.num("T", 0);
-    if (o.nthreads <= 0) o.nthreads = (int)std::thread::hardware_concurrency();
+    if (o.nthreads <= 0) o.nthreads = effective_cpus();                  // the cores the process may really use (cgroup quota included)
     if (o.nthreads < 1) o.nthreads = 1;
     if (o.nthreads > 128) o.nthreads = 128;
     if (o.P.pmode < 0 || o.P.pmode > 3 || o.P.align_strand < 0 || o.P.align_strand > 2 || o.P.min_edit_dist < 1 || o.P.min_edit_dist > 2 ||
@@ -852,27 +852,50 @@ int cmd_align(int argc, char **argv, int first)
             if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) { trims.left[i] = seg2[RD(i)].match_len; trims.right[i] = seg2[RD(i)].read_ofs; n_ch++; }
         diag("Of the accepted aligned reads, %zu were chimeric", n_ch);
     }
-    // CAligner::SortHitMatch (Aligner.cpp:10069-10114) over record indexes, ties left to the replica of the reference's sort
-    auto cmp = [&](uint32_t x, uint32_t y) -> int {
-        const bk_hit &p = hits[x], &q = hits[y];
-        if (p.nar != q.nar) return p.nar < q.nar ? -1 : 1;
-        if (p.num_hits == 1 && q.num_hits != 1) return -1;
-        if (p.num_hits != 1 && q.num_hits == 1) return 1;
-        if (p.num_hits != 1 && q.num_hits != 1) return p.num_hits < q.num_hits ? -1 : (p.num_hits > q.num_hits ? 1 : 0);
-        if (p.chrom_id != q.chrom_id) return p.chrom_id < q.chrom_id ? -1 : 1;
-        const uint32_t ps = a_start(p, x), qs = a_start(q, y), pl = a_len(p, x), ql = a_len(q, y);
-        if (ps != qs) return ps < qs ? -1 : 1;
-        if (pl != ql) return pl < ql ? -1 : 1;
-        if (p.strand != q.strand) return p.strand < q.strand ? -1 : 1;
-        if (p.low_mm != q.low_mm) return p.low_mm < q.low_mm ? -1 : 1;
+    // CAligner::SortHitMatch (Aligner.cpp:10069-10114), ties left to the replica of the reference's sort.  The comparator's fields are
+    // packed into three words per record first (NAR | NumHits class: 1 before the others | NumHits | ChromID, then AdjStartLoci |
+    // AdjHitLen, then Strand | LowMMCnt; records whose NumHits is not 1 compare equal beyond NumHits, so their other fields stay 0): the
+    // quicksort then walks keys lying next to each other instead of chasing record indexes through the result array - same
+    // comparisons, same outcome, same order
+    struct SortRec { uint64_t hi, lo; uint32_t tail, idx; };
+    auto sort_cmp = [](const SortRec &x, const SortRec &y) -> int {
+        if (x.hi != y.hi) return x.hi < y.hi ? -1 : 1;
+        if (x.lo != y.lo) return x.lo < y.lo ? -1 : 1;
+        if (x.tail != y.tail) return x.tail < y.tail ? -1 : 1;
         return 0;
+    };
+    auto sorted_order = [&](std::vector<uint32_t> &ord) {
+        bk::RawVec<SortRec> recs(nr);
+        auto fill = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                const bk_hit &p = hits[i];
+                SortRec &r = recs[i];
+                r.idx = (uint32_t)i;
+                if (p.num_hits == 1) {
+                    r.hi = ((uint64_t)p.nar << 41) | (uint64_t)p.chrom_id;
+                    r.lo = ((uint64_t)a_start(p, i) << 32) | (uint64_t)a_len(p, i);
+                    r.tail = ((uint32_t)p.strand << 8) | (uint32_t)(uint8_t)(p.low_mm + 128);
+                } else {
+                    r.hi = ((uint64_t)p.nar << 41) | (1ULL << 40) | ((uint64_t)p.num_hits << 32);
+                    r.lo = 0;
+                    r.tail = 0;
+                }
+            }
+        };
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)o.nthreads, nr / 65536));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(fill, nr * (size_t)t / (size_t)nt, nr * (size_t)(t + 1) / (size_t)nt);
+        fill(0, nr / (size_t)nt);
+        for (auto &t : th) t.join();
+        bk::ref_order_sort(recs.data(), (int64_t)nr, sort_cmp, o.nthreads);
+        ord.resize(nr);
+        for (size_t i = 0; i < nr; i++) ord[i] = recs[i].idx;
     };
     if (o.pcr_win >= 0 && !o.pe_mode) {
         // CAligner::ReducePCRduplicates runs on the sorted set, before the flank trimmer (Aligner.cpp:598-610)
         diag("Processing to reduce PCR differential amplification artefacts processing started..");
-        std::vector<uint32_t> ord(nr);
-        for (size_t i = 0; i < nr; i++) ord[i] = (uint32_t)i;
-        bk::ref_order_sort(ord.data(), (int64_t)nr, cmp, o.nthreads);
+        std::vector<uint32_t> ord;
+        sorted_order(ord);
         const size_t n_dup = bk::reduce_pcr_duplicates(hits, ord, [&](size_t i) { return a_start(hits[i], i); }, [&](size_t i) { return a_len(hits[i], i); }, o.pcr_win);
         diag("Removed %zu potential PCR artefact reads", n_dup);
     }
@@ -944,9 +967,8 @@ int cmd_align(int argc, char **argv, int first)
     // SortReadHits(eRSMHitMatch): index in load (ReadID) order -> reference order
     diag("Reporting of aligned result set started...");
     diag("Sorting alignments by ascending chrom.loci");
-    std::vector<uint32_t> order(nr);
-    for (size_t i = 0; i < nr; i++) order[i] = (uint32_t)i;
-    bk::ref_order_sort(order.data(), (int64_t)nr, cmp, o.nthreads);
+    std::vector<uint32_t> order;
+    sorted_order(order);
 
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include "noinit.h"
+
 namespace bkcli {
 
 
@@ -62,12 +64,35 @@ inline const char *kNarDescr[20] = {"Not processed for alignment", "Alignment ac
                              "PE partner aligned to different target sequence", "PE alignment not accepted",
                              "Alignment violated loci base constraints"};
 
+// CPUs this process can actually keep busy: the hardware threads it may run on, cut down to the cgroup's CPU quota when there is
+// one (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1).  More runnable threads than that only buy throttling.
+inline int effective_cpus()
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64];
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota > 0 && period > 0) {
+        const long lim = (long)((quota + period - 1) / period);
+        if (lim >= 1 && lim < n) n = lim;
+    }
+    return (int)n;
+}
+
 struct ReadStore {
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offs;
-    std::vector<uint32_t> lens;
-    std::vector<char> names;               // '\0' separated
-    std::vector<uint64_t> name_ofs;
+    bk::RawVec<uint8_t> bases;             // (RawVec: sized once, filled by all threads - see noinit.h)
+    bk::RawVec<uint64_t> offs;
+    bk::RawVec<uint32_t> lens;
+    bk::RawVec<char> names;                // '\0' separated
+    bk::RawVec<uint64_t> name_ofs;
     size_t size() const { return lens.size(); }
     const char *name(size_t i) const { return names.data() + name_ofs[i]; }
 };

@@ -166,29 +166,47 @@ int SeqReader::next(std::string &descr, std::vector<uint8_t> &bases)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// same state machine as SeqReader::next (FASTA branch) over [p, e); e is a record start or the file end
+// same state machine as SeqReader::next (FASTA branch) over [p, e); e is a record start or the file end.  One table look-up per
+// sequence character (0xff = not a sequence character: everything but letters and '-'), output through raw pointers into
+// buffers sized for the worst case up front.
+struct SeqLut {
+    uint8_t t[256];
+    SeqLut() { for (int i = 0; i < 256; i++) t[i] = (isalpha(i) || i == '-') ? a2s((uint8_t)i) : 0xff; t[(uint8_t)'>'] = 0xfe; }
+};
+const SeqLut g_seq_lut;
+
 void parse_range(const uint8_t *p, const uint8_t *e, ParsedChunk &out)
 {
-    size_t approx = (size_t)(e - p);
-    out.bases.reserve(approx);
-    out.descr.reserve(approx / 8 + 64);
+    const size_t approx = (size_t)(e - p);
+    out.bases.resize(approx);
+    out.descr.resize(approx);
+    out.lens.reserve(approx / 64 + 16);
+    out.descr_lens.reserve(approx / 64 + 16);
+    uint8_t *bw = out.bases.data();
+    char *dw = out.descr.data();
+    const uint8_t *lut = g_seq_lut.t;
     while (p < e) {
-        while (p < e && *p != '>') p++;               // skip to the next descriptor
-        if (p >= e) break;
+        p = (const uint8_t *)memchr(p, '>', (size_t)(e - p));          // skip to the next descriptor
+        if (!p) break;
         p++;
-        size_t d0 = out.descr.size();
+        char *d0 = dw;
         while (p < e && *p != '\n' && *p != '\r') {
-            uint8_t c = *p++;
-            out.descr.push_back(c > 0x7f ? '?' : (char)c);
+            const uint8_t c = *p++;
+            *dw++ = c > 0x7f ? '?' : (char)c;
         }
-        out.descr_lens.push_back((uint32_t)(out.descr.size() - d0));
-        size_t b0 = out.bases.size();
-        while (p < e && *p != '>') {
-            uint8_t c = *p++;
-            if (isalpha(c) || c == '-') out.bases.push_back(a2s(c));
+        out.descr_lens.push_back((uint32_t)(dw - d0));
+        uint8_t *b0 = bw;
+        while (p < e) {
+            const uint8_t v = lut[*p];
+            if (v == 0xfe) break;                                      // '>': the next record
+            p++;
+            *bw = v;
+            bw += v != 0xff;
         }
-        out.lens.push_back((uint32_t)(out.bases.size() - b0));
+        out.lens.push_back((uint32_t)(bw - b0));
     }
+    out.bases.resize((size_t)(bw - out.bases.data()));
+    out.descr.resize((size_t)(dw - out.descr.data()));
 }
 
 // first record start at or after q: a '>' with no other '>' between it and the preceding line break

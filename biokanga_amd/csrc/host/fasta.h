@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include "noinit.h"
+
 namespace bk {
 
 class SeqReader {
@@ -45,9 +47,9 @@ private:
 
 // A run of parsed records held in memory (file order inside a chunk, chunks in file order).
 struct ParsedChunk {
-    std::vector<uint8_t> bases;         // all records' bases back to back, Ascii2Sense-mapped
+    RawVec<uint8_t> bases;              // all records' bases back to back, Ascii2Sense-mapped
     std::vector<uint32_t> lens;
-    std::vector<char> descr;            // descriptors back to back (as SeqReader::next returns them)
+    RawVec<char> descr;                 // descriptors back to back (as SeqReader::next returns them)
     std::vector<uint32_t> descr_lens;
 };
 

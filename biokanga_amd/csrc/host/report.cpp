@@ -2,6 +2,8 @@
 #include "report.h"
 
 #include <strings.h>
+#include <time.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <thread>
@@ -408,33 +410,50 @@ int report_text(Report &R)
         diag("Header written with references to %d sequences of which %d have at least 1 alignments", n_hdr, n_with);
         static const char comp[8] = {'T', 'G', 'C', 'A', 'N', 'N', 'N', 'N'};
         static const char fwd[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};
-        auto put_num = [](std::string &r, long v) {
+        // Records are written through a raw pointer into a stripe buffer that is grown to the record's worst case first (the
+        // reference formats with sprintf, ~4.5 us per read; the host's core-seconds are what bounds T_e2e here).
+        struct Stripe {
+            char *d = nullptr;
+            size_t n = 0, cap = 0;
+            ~Stripe() { free(d); }
+            char *room(size_t k)
+            {
+                if (n + k > cap) { cap = std::max(cap * 2, n + k + (1u << 20)); d = (char *)realloc(d, cap); }
+                return d + n;
+            }
+        };
+        auto put_num = [](char *w, long v) -> char * {
             char t[24];
             int n = 0;
             bool neg = v < 0;
             unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
             do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-            if (neg) r.push_back('-');
-            while (n) r.push_back(t[--n]);
+            if (neg) *w++ = '-';
+            while (n) *w++ = t[--n];
+            return w;
         };
+        auto put_str = [](char *w, const char *z) -> char * { const size_t k = strlen(z); memcpy(w, z, k); return w + k; };
         // QUAL (ReportBAMread :5928-5955): '*' when no base carries a score, else 33 + q4 * 40 / 15 per base, reversed with the read
-        auto put_qual = [](std::string &r, const uint8_t *sq, uint32_t n, bool reversed) {
+        auto put_qual = [](char *w, const uint8_t *sq, uint32_t n, bool reversed) -> char * {
             uint32_t sum = 0;
-            for (uint32_t q = 0; q < n; q++) sum += (sq[q] >> 4) & 15;
-            if (!sum) { r.push_back('*'); return; }
-            const size_t o = r.size();
-            r.resize(o + n);
-            for (uint32_t q = 0; q < n; q++) r[o + q] = (char)(33 + ((((reversed ? sq[n - 1 - q] : sq[q]) >> 4) & 15) * 40) / 15);
+            for (uint32_t q = 0; q < n; q++) sum |= sq[q] & 0xf0u;
+            if (!sum) { *w++ = '*'; return w; }
+            for (uint32_t q = 0; q < n; q++) w[q] = (char)(33 + ((((reversed ? sq[n - 1 - q] : sq[q]) >> 4) & 15) * 40) / 15);
+            return w + n;
         };
         // one record (CAligner::ReportBAMread, Aligner.cpp:5850-5924,6036-6054); false when the read is not reported
-        auto format_rec = [&](size_t k, std::string &rec) -> bool {
+        auto format_rec = [&](size_t k, Stripe &st) -> bool {
             uint32_t i = order[k];
             const bk_hit &h = hits[i];
             bool acc = h.nar == BK_NAR_ACCEPTED;
             if (!acc && fmt != 6) return false;
             const uint8_t *s = rs.bases.data() + rs.offs[RD(i)];
             uint32_t len = rs.lens[RD(i)];
-            rec += rs.name(RD(i));
+            const char *nm = rs.name(RD(i));
+            const size_t nml = strlen(nm);
+            char *w = st.room(nml + 2 * (size_t)len + 400);
+            memcpy(w, nm, nml);
+            w += nml;
             int flag = 0, tlen = 0;
             long pnext = -1;
             if (!pe_mode) flag = acc ? (h.strand == '+' ? 0 : 16) : 4;
@@ -454,89 +473,124 @@ int report_text(Report &R)
                 } else
                     flag |= 0x8;
             }
-            rec.push_back('\t');
-            put_num(rec, flag);
+            *w++ = '\t';
+            w = put_num(w, flag);
             if (acc) {
-                rec.push_back('\t');
-                rec += ents[h.chrom_id - 1].name;
-                rec.push_back('\t');
-                put_num(rec, (long)a_start(h, i) + 1);
-                rec += "\t255\t";
+                *w++ = '\t';
+                w = put_str(w, ents[h.chrom_id - 1].name);
+                *w++ = '\t';
+                w = put_num(w, (long)a_start(h, i) + 1);
+                w = put_str(w, "\t255\t");
                 const uint32_t clip5 = h.strand == '+' ? TL(i) : TR(i), clip3 = h.strand == '+' ? TR(i) : TL(i);
-                if (clip5) { put_num(rec, clip5); rec.push_back('S'); }
-                put_num(rec, a_len(h, i));
-                rec += "M";
-                if (clip3) { put_num(rec, clip3); rec.push_back('S'); }
+                if (clip5) { w = put_num(w, clip5); *w++ = 'S'; }
+                w = put_num(w, a_len(h, i));
+                *w++ = 'M';
+                if (clip3) { w = put_num(w, clip3); *w++ = 'S'; }
                 if (has_seg2(i)) {                                       // CAligner::ReportBAMread, Aligner.cpp:5986-6033
                     const bk_seg2 &g = seg2[RD(i)];
-                    if (g.flags & 4) { put_num(rec, (long)g.match_loci - ((long)h.match_loci + h.match_len)); rec.push_back('N'); }
-                    else if (g.flags & 2) { put_num(rec, (long)len - ((long)h.match_len + g.match_len)); rec.push_back('I'); }
-                    else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); put_num(rec, gap < 0 ? -gap : gap); rec.push_back('D'); }
-                    put_num(rec, g.match_len);
-                    rec.push_back('M');
+                    if (g.flags & 4) { w = put_num(w, (long)g.match_loci - ((long)h.match_loci + h.match_len)); *w++ = 'N'; }
+                    else if (g.flags & 2) { w = put_num(w, (long)len - ((long)h.match_len + g.match_len)); *w++ = 'I'; }
+                    else { long gap = (long)g.match_loci - ((long)h.match_loci + h.match_len); w = put_num(w, gap < 0 ? -gap : gap); *w++ = 'D'; }
+                    w = put_num(w, g.match_len);
+                    *w++ = 'M';
                 }
-                rec.push_back('\t');
-                rec.push_back(pnext < 0 ? '*' : '=');
-                rec.push_back('\t');
-                put_num(rec, pnext < 0 ? 0L : pnext + 1);
-                rec.push_back('\t');
-                put_num(rec, tlen);
-                rec.push_back('\t');
-                size_t o = rec.size();
-                rec.resize(o + len);
-                if (h.strand == '+') for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
-                else for (uint32_t q = 0; q < len; q++) rec[o + q] = comp[s[len - 1 - q] & 7];
-                rec.push_back('\t');
-                put_qual(rec, s, len, h.strand != '+');
-                rec.push_back('\n');
+                *w++ = '\t';
+                *w++ = pnext < 0 ? '*' : '=';
+                *w++ = '\t';
+                w = put_num(w, pnext < 0 ? 0L : pnext + 1);
+                *w++ = '\t';
+                w = put_num(w, tlen);
+                *w++ = '\t';
+                if (h.strand == '+') for (uint32_t q = 0; q < len; q++) w[q] = fwd[s[q] & 7];
+                else for (uint32_t q = 0; q < len; q++) w[q] = comp[s[len - 1 - q] & 7];
+                w += len;
+                *w++ = '\t';
+                w = put_qual(w, s, len, h.strand != '+');
+                *w++ = '\n';
             } else {
-                rec += "\t*\t0\t255\t";
-                put_num(rec, len);
-                rec += "M\t*\t0\t0\t";
-                size_t o = rec.size();
-                rec.resize(o + len);
-                for (uint32_t q = 0; q < len; q++) rec[o + q] = fwd[s[q] & 7];
-                rec.push_back('\t');
-                put_qual(rec, s, len, false);
-                rec += "\t\tYU:Z:";                                    // the doubled TAB is what the reference writes
-                rec += kNarTag[h.nar < 20 ? h.nar : 0];
-                rec.push_back('\n');
+                w = put_str(w, "\t*\t0\t255\t");
+                w = put_num(w, len);
+                w = put_str(w, "M\t*\t0\t0\t");
+                for (uint32_t q = 0; q < len; q++) w[q] = fwd[s[q] & 7];
+                w += len;
+                *w++ = '\t';
+                w = put_qual(w, s, len, false);
+                w = put_str(w, "\t\tYU:Z:");                           // the doubled TAB is what the reference writes
+                w = put_str(w, kNarTag[h.nar < 20 ? h.nar : 0]);
+                *w++ = '\n';
             }
+            st.n = (size_t)(w - st.d);
             return true;
         };
         // records are formatted by all host threads into per-thread buffers, one stripe of the sorted order
         // each, and written out in order (the reference formats serially, ~4.5 us per read)
-        const size_t per_thread = 32768;
+        const size_t per_thread = 131072;
         const int nt = (int)std::min<size_t>((size_t)nthreads, (nr + per_thread - 1) / per_thread ? (nr + per_thread - 1) / per_thread : 1);
-        std::vector<std::string> bufs((size_t)nt);
+        std::vector<Stripe> bufs((size_t)nt);
         std::vector<uint64_t> cnts((size_t)nt);
+        const bool timing = getenv("BK_TIMING") != nullptr;
+        auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+        double t_fmt = 0, t_grow = 0, t_put = 0;
         for (size_t k0 = 0; k0 < nr; k0 += per_thread * (size_t)nt) {
+            const double tA = now();
             auto work = [&](int t) {
                 size_t lo = k0 + (size_t)t * per_thread, hi = std::min(nr, lo + per_thread);
-                std::string &buf = bufs[(size_t)t];
-                buf.clear();
+                Stripe &buf = bufs[(size_t)t];
+                buf.n = 0;
                 uint64_t c = 0;
-                for (size_t k = lo; k < hi; k++) c += format_rec(k, buf) ? 1 : 0;
+                // the sorted order walks the read store at random: the records' lines are requested a few records ahead
+                for (size_t k = lo; k < hi; k++) {
+                    if (k + 16 < hi) {
+                        const uint32_t j = order[k + 16];
+                        __builtin_prefetch(&hits[j]);
+                        const size_t r = RD(j);
+                        __builtin_prefetch(&rs.offs[r]);
+                        __builtin_prefetch(&rs.lens[r]);
+                        __builtin_prefetch(&rs.name_ofs[r]);
+                    }
+                    if (k + 8 < hi) {
+                        const size_t r = RD(order[k + 8]);
+                        const uint8_t *b = rs.bases.data() + rs.offs[r];
+                        __builtin_prefetch(b);
+                        __builtin_prefetch(b + 64);
+                        __builtin_prefetch(rs.names.data() + rs.name_ofs[r]);
+                    }
+                    c += format_rec(k, buf) ? 1 : 0;
+                }
                 cnts[(size_t)t] = c;
             };
             std::vector<std::thread> th;
             for (int t = 1; t < nt; t++) th.emplace_back(work, t);
             work(0);
             for (auto &t : th) t.join();
+            const double tB = now();
+            t_fmt += tB - tA;
             if (out.gz) {                    // compressed SAM: one deflate stream, in order
-                for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t]); n_reported += cnts[(size_t)t]; }
+                for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t].d, bufs[(size_t)t].n); n_reported += cnts[(size_t)t]; }
                 continue;
             }
-            // the stripes go to their places in the file in parallel as well
+            // the stripes go to their places in the file in parallel as well: the file is grown by the round's bytes and the threads
+            // copy into a shared mapping of that range (concurrent pwrite()s to one file queue up behind the inode lock - 1.3 GB/s
+            // on tmpfs - while page faults on a mapping do not); pwrite() remains for outputs that cannot be mapped
             out.flush();
             std::vector<off_t> at((size_t)nt + 1);
             at[0] = out.pos;
-            for (int t = 0; t < nt; t++) { at[(size_t)t + 1] = at[(size_t)t] + (off_t)bufs[(size_t)t].size(); n_reported += cnts[(size_t)t]; }
+            for (int t = 0; t < nt; t++) { at[(size_t)t + 1] = at[(size_t)t] + (off_t)bufs[(size_t)t].n; n_reported += cnts[(size_t)t]; }
+            const off_t map_lo = at[0] & ~(off_t)4095;
+            const size_t map_len = (size_t)(at[(size_t)nt] - map_lo);
+            char *map = nullptr;
+            if (at[(size_t)nt] > at[0] && ftruncate(out.fd, at[(size_t)nt]) == 0) {
+                void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, out.fd, map_lo);
+                if (m != MAP_FAILED) map = (char *)m;
+            }
+            const double tC = now();
+            t_grow += tC - tB;
             auto put = [&](int t) {
-                const std::string &bf = bufs[(size_t)t];
+                const Stripe &bf = bufs[(size_t)t];
+                if (map) { memcpy(map + (at[(size_t)t] - map_lo), bf.d, bf.n); return; }
                 size_t o = 0;
-                while (o < bf.size()) {
-                    ssize_t w = ::pwrite(out.fd, bf.data() + o, bf.size() - o, at[(size_t)t] + (off_t)o);
+                while (o < bf.n) {
+                    ssize_t w = ::pwrite(out.fd, bf.d + o, bf.n - o, at[(size_t)t] + (off_t)o);
                     if (w <= 0) break;
                     o += (size_t)w;
                 }
@@ -545,8 +599,11 @@ int report_text(Report &R)
             for (int t = 1; t < nt; t++) th.emplace_back(put, t);
             put(0);
             for (auto &t : th) t.join();
+            if (map) munmap(map, map_len);
+            t_put += now() - tC;
             out.pos = at[(size_t)nt];
         }
+        if (timing) fprintf(stderr, "bk timing: SAM format %.0f ms, grow + map %.0f ms, copy out %.0f ms (%d threads)\n", 1e3 * t_fmt, 1e3 * t_grow, 1e3 * t_put, nt);
         report_jct_for_sam(R);
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {

@@ -108,7 +108,8 @@ int sfx_open(const char *path, SfxFile &out, std::string *err)
     out.title = zstr(oTitle, 64);
     if (nblocks != 1 || ent_ofs == 0 || ent_size < 8)
         return fail(err, -1, std::string(path) + ": no suffix block / entries");
-    if (blk_ofs + kBlkHdrSize > out.map_len || ent_ofs + ent_size > out.map_len)
+    // every header field comes from outside: compare against what is left of the mapping, never add first (sums can wrap)
+    if (blk_ofs > out.map_len || out.map_len - blk_ofs < kBlkHdrSize || ent_ofs > out.map_len || out.map_len - ent_ofs < ent_size)
         return fail(err, -85, std::string(path) + ": truncated file");
 
     const uint8_t *blk = img + blk_ofs;
@@ -116,8 +117,11 @@ int sfx_open(const char *path, SfxFile &out, std::string *err)
     out.concat_len = rd<uint64_t>(blk + 8);
     out.el_size = rd<uint32_t>(blk + 16);
     if (out.el_size != 4 && out.el_size != 5) return fail(err, -1, "unsupported suffix element size");
+    const uint64_t room = out.map_len - blk_ofs - kBlkHdrSize;
+    if (out.concat_len == 0 || out.concat_len > room / (1 + (uint64_t)out.el_size))
+        return fail(err, -85, std::string(path) + ": suffix block size mismatch");
     uint64_t need = kBlkHdrSize + out.concat_len + out.concat_len * out.el_size;
-    if (blk_ofs + need > out.map_len || (blk_size && blk_size != need))
+    if (blk_size && blk_size != need)
         return fail(err, -85, std::string(path) + ": suffix block size mismatch");
     out.seq = blk + kBlkHdrSize;
     out.sa = out.seq + out.concat_len;
@@ -140,6 +144,10 @@ int sfx_open(const char *path, SfxFile &out, std::string *err)
         d.start_ofs = rd<uint64_t>(e + 95);
         d.end_ofs = rd<uint64_t>(e + 103);
         out.tot_seq_len += d.seq_len;
+        // an entry is a span of the concatenated bases (the EOS after it included in concat_len)
+        if (d.seq_len == 0 || d.start_ofs >= out.concat_len || d.end_ofs >= out.concat_len || d.end_ofs < d.start_ofs ||
+            d.end_ofs - d.start_ofs + 1 != d.seq_len)
+            return fail(err, -85, std::string(path) + ": sequence entry outside the suffix block");
     }
     return 0;
 }

@@ -30,11 +30,12 @@ def main():
         del seq_h, sa_h, reads_h
         t = time.time()
         rc = subprocess.run([os.path.join(ROOT, "biokanga_amd", "bin", "biokanga"), "align", "-i", fa, "-I", sfx, "-o", sam,
-                             "-s3", "-M6", "-F", logf] + sys.argv[2:], stdout=subprocess.DEVNULL).returncode
+                             "-s3", "-M6", "-F", logf] + sys.argv[2:], stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1")).returncode
         wall = time.time() - t
         print(f"rc {rc}; T_e2e {wall:.2f} s for {n_reads} reads = {n_reads / wall / 1e6:.2f} M reads/s; SAM {os.path.getsize(sam) / 1e9:.2f} GB")
         keys = ("Loading suffix", "suffix array loaded", "Loading reads", "Load:", "Now aligning", "Alignment of", "Sorting",
                 "Header written", "Completed reporting", "Reporting of aligned result set completed", "phase:")
+        print(open(logf + ".err").read())
         for line in open(logf, errors="replace"):
             if any(k in line for k in keys):
                 print(line.rstrip())
