@@ -9,6 +9,8 @@ sum-reduction of the per-sequence hit counts (RCCL all-reduce when N > 1).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N            (no WORLD_SIZE in the environment: starts the N ranks itself, same launcher)
+    python bench.py --config C3         (2 x 150 bp paired ends, -s5 -U3 -d200 -D400: SE pass + PE association per step)
 
 Workload at N = 1: BASELINE.json configs[1] restated over a synthetic genome (SURVEY.md §8d "C2"):
 50 M x 100 bp SE reads, 0-3 substitutions, vs a 24-sequence 3.1 Gbp GRCh38-like genome, `-s3`.
@@ -29,18 +31,55 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def effective_cpus():
+    """CPUs this process can keep busy: hardware threads it may run on, cut down to the cgroup CPU quota (the GPU boxes of
+    this pool expose 256 hardware threads under a 16-CPU quota - more runnable threads than that only buy throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    touched a GPU yet) through the same torch.distributed.run command line the driver uses, and hand their exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no WORLD_SIZE in the environment: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, budget_s, ref_reads=0, cli_device=0):
+def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, budget_s, ref_reads=0, cli_device=0, pe=None,
+                 full_cli=True):
     """Times the CPU oracle (restatement of the reference path, pthreads on every host core) on a
     bounded sample of the same workload; also checks the GPU results of that sample against it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import helpers
-    cores = os.cpu_count() or 1
+    hw_threads = os.cpu_count() or 1
+    cores = effective_cpus()
     t0 = time.time()
     seq = seq_t.cpu().numpy()
     sa = sa_t.cpu().numpy()
@@ -54,24 +93,29 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
     offs = (np.arange(n0, dtype=np.uint64) * read_len)
     lens = np.full(n0, read_len, dtype=np.uint32)
     t0 = time.time()
-    ora.align(bases, offs, lens, p, nthreads=cores)
+    ora.align(bases, offs, lens, p, nthreads=hw_threads)
     rate0 = n0 / max(1e-6, time.time() - t0)
     n1 = int(min(n_avail, max(n0, rate0 * budget_s)))
+    n1 -= n1 & 1
     bases = reads_t[: n1 * read_len].cpu().numpy()
     offs = (np.arange(n1, dtype=np.uint64) * read_len)
     lens = np.full(n1, read_len, dtype=np.uint32)
     t0 = time.time()
-    exp, octr = ora.align(bases, offs, lens, p, nthreads=cores)
+    exp, octr = ora.align(bases, offs, lens, p, nthreads=hw_threads)
+    if pe:          # CAligner::ProcessPairedEnds of the restatement (single-threaded there, as in the reference)
+        helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], False, bases, offs, lens, exp)
     dt = time.time() - t0
     got = gpu_hits[:n1]
     nbad = 0
-    for f in ("chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm",
-              "nxt_low_mm", "num_hits", "mismatches"):
+    for f in ("chrom_id", "match_loci", "match_len", "low_hit_instances", "nar", "strand", "low_mm",
+              "nxt_low_mm", "num_hits", "mismatches") + (() if pe else ("rslt",)):
         nbad += int((got[f] != exp[f]).sum())
+    if pe:
+        nbad += int(((got["flags"] & 0x80) != (exp["flags"] & 0x80)).sum())
     ora.close()
-    port = {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n1} reads of the rank-0 batch, oracle/bk_oracle.c ora_align_batch with {cores} pthreads, "
-                      f"{dt:.1f} s wall; index already in host RAM",
+    port = {"value": n1 / dt, "unit": "reads/s", "cores": cores, "hardware_threads": hw_threads, "kind": "port",
+            "sample": f"first {n1} reads of the rank-0 batch, oracle/bk_oracle.c ora_align_batch with {hw_threads} pthreads under a "
+                      f"cgroup quota of {cores} CPUs, {dt:.1f} s wall; index already in host RAM",
             "parity_mismatching_fields_vs_gpu": nbad,
             "n_search_per_read": octr.n_search / n1, "n_cand_per_read": octr.n_cand / n1}
     if ref_reads <= 0:
@@ -79,10 +123,12 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
     # the real reference on the same box, when its binary travelled with the repo
     ref = None
     named = [(f"chr{eid}", slen) for (eid, slen, _so, _eo) in entries]
+    all_np = reads_t.cpu().numpy() if full_cli else None
     for n_ref in dict.fromkeys((int(min(n_avail, ref_reads)), int(min(n_avail, ref_reads, 1_000_000)))):
         try:
             ref = reference_baseline(seq, sa, named, reads_t[: n_ref * read_len].cpu().numpy(), read_len,
-                                     params_kw.get("max_subs", 3), gpu_hits, n_ref, cli_device)
+                                     params_kw.get("max_subs", 3), gpu_hits, n_ref, cli_device, pe=pe,
+                                     full_reads=n_avail if full_cli else 0, all_reads_np=all_np)
         except Exception as e:
             log(f"cpu_baseline(reference) failed: {e!r}")
             ref = None
@@ -124,26 +170,30 @@ def write_sfx_file(path, seq, sa, entries):
             ofs += slen + 1
 
 
-def write_fasta_file(path, reads_np, n_reads, read_len, chunk=4_000_000):
-    """>r000000001\n<bases>\n per read (fixed-width names so the whole file is one array)."""
+def write_fasta_file(path, reads_np, n_reads, read_len, chunk=4_000_000, start=0, step=1):
+    """>r000000001\n<bases>\n per read (fixed-width names = 1 + the read's index in `reads_np`, so the whole file is one array);
+    start / step pick every step-th read from `start` on (the two files of a paired-end set)."""
     import numpy as np
     lut = np.frombuffer(b"ACGTNNNN", dtype=np.uint8)
+    rows = reads_np[: n_reads * read_len].reshape(n_reads, read_len)[start::step]
+    total = len(rows)
     with open(path, "wb") as f:
-        for lo in range(0, n_reads, chunk):
-            m = min(chunk, n_reads - lo)
+        for lo in range(0, total, chunk):
+            m = min(chunk, total - lo)
             rec = np.empty((m, 12 + read_len + 1), dtype=np.uint8)
             rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 11] = 10; rec[:, -1] = 10
-            idx = np.arange(lo + 1, lo + m + 1, dtype=np.int64)
+            idx = (np.arange(lo, lo + m, dtype=np.int64) * step) + start + 1
             for d in range(9):
                 rec[:, 10 - d] = 48 + (idx // 10 ** d) % 10
-            rec[:, 12:12 + read_len] = lut[reads_np[lo * read_len: (lo + m) * read_len].reshape(m, read_len) & 7]
+            rec[:, 12:12 + read_len] = lut[rows[lo:lo + m] & 7]
             f.write(memoryview(rec))
 
 
 REF_LADDER = (0, 32, 8)        # -T values tried in turn by the reference leg
 
 
-def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits, n_sample, cli_device):
+def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits, n_sample, cli_device, pe=None, full_reads=0,
+                       all_reads_np=None):
     """Times the REAL reference (oracle/_ref/biokanga, built from /root/reference by oracle/build_ref.sh and
     shipped as a binary) on the box's host cores on the first `n_sample` reads of the rank-0 batch against
     the same index, written out as a `.sfx`; checks its SAM records against the GPU results of the timed
@@ -168,14 +218,20 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
     tmp = tempfile.mkdtemp(prefix="bk_ref_", dir=base)
     try:
         t0 = time.time()
-        sfx, fa = os.path.join(tmp, "genome.sfx"), os.path.join(tmp, "reads.fa")
+        sfx, fa, fa2 = os.path.join(tmp, "genome.sfx"), os.path.join(tmp, "reads.fa"), os.path.join(tmp, "reads_2.fa")
         write_sfx_file(sfx, seq, sa, entries)
-        write_fasta_file(fa, reads_np, n_sample, read_len)
+        if pe:          # interleaved PE1, PE2 -> two files; names stay 1 + the read's index
+            write_fasta_file(fa, reads_np, n_sample, read_len, start=0, step=2)
+            write_fasta_file(fa2, reads_np, n_sample, read_len, start=1, step=2)
+            inputs = ["-i", fa, "-u", fa2, f"-U{pe['pe_mode']}", f"-d{pe['pair_min_len']}", f"-D{pe['pair_max_len']}"]
+        else:
+            write_fasta_file(fa, reads_np, n_sample, read_len)
+            inputs = ["-i", fa]
         t_files = time.time() - t0
 
-        def run(binary, out, logf, extra):
+        def run(binary, out, logf, extra, inp=None):
             t = time.time()
-            r = subprocess.run([binary, "align", "-i", fa, "-I", sfx, "-o", out, f"-s{max_subs}", "-M6", "-F", logf] + extra,
+            r = subprocess.run([binary, "align"] + (inp or inputs) + ["-I", sfx, "-o", out, f"-s{max_subs}", "-M6", "-F", logf] + extra,
                                stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, timeout=1500)
             return r.returncode, time.time() - t
 
@@ -209,7 +265,7 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
             if rc != 0:
                 return {"value": None, "unit": "reads/s", "kind": "reference", "sample": f"reference exited with {rc} at -T{T}"}
             ta = t_align_of(ref_log)
-            nthr = min(os.cpu_count() or 1, 128) if T == 0 else T
+            nthr = min(os.cpu_count() or 1, 128) if T == 0 else T          # its worker threads; the box's CPU quota is stated beside them
             tried.append(f"-T{T} ({nthr} threads): {ta:.2f} s")
             t_align, ref_wall, threads = ta, wall, nthr
             if ta > 6.0:
@@ -225,14 +281,22 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
             i = int(fld[0][1:]) - 1
             h = got[i]
             seen += 1
-            if h["nar"] == 1:
+            if pe:
+                flag, pos, rnext, pnext, tlen = helpers.expected_pe_sam_fields(got, i)
+                rname = names[int(h["chrom_id"])] if h["nar"] == 1 else "*"
+                bad += (int(fld[1]), fld[2], int(fld[3]), fld[6], int(fld[7]), int(fld[8])) != (flag, rname, pos, rnext, pnext, tlen)
+                bad += h["nar"] != 1 and fld[-1] != "YU:Z:" + bk.NAR_TAGS[int(h["nar"])]
+            elif h["nar"] == 1:
                 exp = (16 if h["strand"] == ord("-") else 0, names[int(h["chrom_id"])], int(h["match_loci"]) + 1)
                 bad += (int(fld[1]), fld[2], int(fld[3])) != exp
             else:
                 bad += not (fld[1] == "4" and fld[2] == "*" and fld[-1] == "YU:Z:" + bk.NAR_TAGS[int(h["nar"])])
         bad += abs(seen - n_sample)
-        res = {"value": n_sample / t_align if t_align > 6.0 else None, "unit": "reads/s", "cores": threads, "kind": "reference",
-               "sample": f"oracle/_ref/biokanga align -s{max_subs} -M6 on the first {n_sample} reads of the rank-0 batch vs the same "
+        res = {"value": n_sample / t_align if t_align > 6.0 else None, "unit": "reads/s", "cores": min(threads, effective_cpus()),
+               "threads": threads, "kind": "reference", "value_is_a_lower_bound": True,
+               "lower_bound_because": "T_align is read off the reference's log and sits only a few seconds above its fixed 5 s start-up "
+                                      "sleep; the sample cannot grow (its loader hand-off breaks beyond ~3 s of loading, Aligner.cpp:4822)",
+               "sample": f"oracle/_ref/biokanga align {' '.join(inputs[2:]) + ' ' if pe else ''}-s{max_subs} -M6 on the first {n_sample} reads of the rank-0 batch vs the same "
                          f"{n / 1e9:.2f} Gbp index written as .sfx; T_align = log 'Now aligning' -> 'Alignment of .. completed' "
                          f"(valid above the reference's fixed 5 s start-up sleep); runs: {'; '.join(tried)}; whole process {ref_wall:.1f} s",
                "t_align_s": t_align, "t_e2e_s": ref_wall, "sam_records_differing_from_gpu": int(bad)}
@@ -245,6 +309,28 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
             except Exception:
                 our_t_align = None
             res["our_cli"] = {"t_e2e_s": our_wall, "t_align_s": our_t_align, "rc": rc, "sam_byte_identical_to_reference": bool(same)}
+            if full_reads > n_sample and all_reads_np is not None:
+                # T_e2e of our command line on the WHOLE step's reads (process start -> exit, files in the same tmp dir)
+                t0 = time.time()
+                fa_full, fa_full2 = os.path.join(tmp, "all.fa"), os.path.join(tmp, "all_2.fa")
+                if pe:
+                    write_fasta_file(fa_full, all_reads_np, full_reads, read_len, start=0, step=2)
+                    write_fasta_file(fa_full2, all_reads_np, full_reads, read_len, start=1, step=2)
+                    inp = ["-i", fa_full, "-u", fa_full2] + inputs[4:]
+                else:
+                    write_fasta_file(fa_full, all_reads_np, full_reads, read_len)
+                    inp = ["-i", fa_full]
+                t_w = time.time() - t0
+                full_sam, full_log = os.path.join(tmp, "full.sam"), os.path.join(tmp, "full.log")
+                rc, wall = run(our_bin, full_sam, full_log, ["--device", str(cli_device)], inp)
+                try:
+                    ta = t_align_of(full_log)
+                except Exception:
+                    ta = None
+                res["our_cli_full"] = {"reads": full_reads, "t_e2e_s": wall, "reads_per_s_e2e": full_reads / wall if rc == 0 else None,
+                                       "t_align_s": ta, "rc": rc, "sam_bytes": os.path.getsize(full_sam) if rc == 0 else None,
+                                       "note": f"biokanga align -M6 on every read of one step, reads + index + SAM in {os.path.dirname(tmp) or '/tmp'}; "
+                                               f"FASTA written in {t_w:.0f} s (untimed)"}
         log(f"cpu_baseline(reference): files {t_files:.1f}s, reference {ref_wall:.1f}s (T_align {t_align:.2f}s)")
         return res
     finally:
@@ -273,7 +359,7 @@ def profiled_traffic(kernel):
     return tot, os.path.basename(files[-1])
 
 
-def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, dev):
+def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, dev, pe_params=None):
     """The metric's real T_align (first batch submitted -> last result back) with reads and results in HOST
     memory: the same reads leave pinned host buffers in batches through bk_stream_submit, cross PCIe while the previous
     batch runs through the AlignReads phases, and every bk_hit record is back in host memory when the clock stops.
@@ -289,11 +375,12 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
     torch.from_numpy(h_lens.view(np.int32)).copy_(rd_lens[:n])
     h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(2)]
     expect = d_out.cpu().numpy().view(bk.HIT_DTYPE)
-    B = max(1, min(args.stream_batch, n))
+    B = max(2, min(args.stream_batch, n))
+    B -= B & 1
     cuts = list(range(0, n, B)) + [n]
     log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step")
     result = {}
-    with bk.Stream(al, B, B * L, depth=3) as st:
+    with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
         def one_step(k):
             out = h_out[k & 1]
             return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])]
@@ -333,29 +420,54 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
     return result
 
 
+CONFIGS = {
+    # the synthetic restatements of BASELINE.json's configs that fit one GPU
+    "C2": dict(read_len=100, max_subs=3, reads=50_000_000, pe=None,
+               text="{reads} x {read_len} bp SE reads per GPU per step (0-{max_subs} subs, simreads-like)", cli="biokanga align -s{max_subs}"),
+    "C3": dict(read_len=150, max_subs=5, reads=40_000_000, pe=dict(pe_mode=3, pair_min_len=200, pair_max_len=400),
+               text="{pairs} x 2x{read_len} bp FR pairs per GPU per step = {reads} reads (insert ~N(300,50) in [200,400], 0-5 subs per read)",
+               cli="biokanga align -s{max_subs} -U3 -d200 -D400"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="C2 = BASELINE.json's headline workload (default); C3 = 2x150 bp paired ends")
     ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (Mbp); 3100 = GRCh38 scale")
-    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per step per GPU")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--max-subs", type=int, default=3, help="`-s` of biokanga align")
+    ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (0 = the config's own: 50 M for C2, 40 M = 20 M pairs for C3)")
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--max-subs", type=int, default=-1, help="`-s` of biokanga align")
     ap.add_argument("--cpu-baseline-secs", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--reference-reads", type=int, default=2_000_000,
                     help="reads given to the real reference binary (oracle/_ref/biokanga) in the cpu_baseline leg; 0 = port only. "
                          "Kept at 2 M: the reference's loader hand-off breaks when loading takes > 3 s (Aligner.cpp:4822) - "
                          "3 M reads crash it on the MI355X host about every other run (tools/ref_scaling.py)")
+    ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
     ap.add_argument("--stream-steps", type=int, default=5, help="steps of the host-resident leg (bk_stream_*: host buffers in -> host "
                                                                 "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
     ap.add_argument("--stream-batch", type=int, default=12_500_000, help="reads per submitted batch of the host-resident leg")
+    ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
+                                                                              "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
     ap.add_argument("--force-device", type=int, default=-1, help="dry runs: put every rank on this GPU instead of LOCAL_RANK")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
     ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))          # before anything here touches a GPU
+    cfg = CONFIGS[args.config]
+    args.reads = args.reads or cfg["reads"]
+    args.read_len = args.read_len or cfg["read_len"]
+    args.max_subs = cfg["max_subs"] if args.max_subs < 0 else args.max_subs
+    pe = cfg["pe"]
+    if pe:
+        args.reads -= args.reads & 1
 
     import numpy as np
     import torch
@@ -368,7 +480,8 @@ def main():
     if args.force_device >= 0:
         local_rank = args.force_device
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s) - refusing to report a "
+                         f"{args.gpus}-GPU line measured on {world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -411,6 +524,7 @@ def main():
     for i, (eid, slen, so, eo) in enumerate(entries):
         ent[i] = (eid, slen, so, eo, f"chr{eid}".encode(), b"")
     params_kw = dict(max_subs=args.max_subs)
+    pe_params = bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], False) if pe else None
     t0 = time.time()
     al = bk.Aligner(None, bk.AlignParams(**params_kw), device=local_rank, d_seq=seq.data_ptr(), concat_len=n,
                     d_sa=sa.data_ptr(), el_size=4, entries=ent)
@@ -420,25 +534,36 @@ def main():
         k, v = kv.split("=")
         al.tune(k, int(v))
     log(f"context (packed target + k-mer table) ready in {time.time() - t0:.1f}s; MinCoreLen {al.min_core_len}")
+
+    def make_set(n_reads, seed):
+        """one synthetic read set of this config: (bases, offs, lens) in HBM"""
+        if pe:
+            return synth.make_pairs(seq, seq_lens, n_reads // 2, args.read_len, dev, seed=seed, max_subs=args.max_subs)
+        b, o, l, _ = synth.make_reads(seq, seq_lens, n_reads, args.read_len, dev, seed=seed, max_subs=args.max_subs)
+        return b, o, l
+
     t0 = time.time()
-    rd_bases, rd_offs, rd_lens, truth = synth.make_reads(seq, seq_lens, args.reads, args.read_len, dev,
-                                                         seed=1000 + rank, max_subs=args.max_subs)
+    # weak scaling: every rank owns a batch of its own.  Read g of the job's global set = read g // N of rank g % N's batch,
+    # i.e. the global set is dealt i mod N (SURVEY.md §8e); the strong-scaling and shard-check legs below deal ONE common set
+    rd_bases, rd_offs, rd_lens = make_set(args.reads, 1000 + rank)
     out = torch.zeros(args.reads * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     counts_dev = torch.zeros(len(entries), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     log(f"reads: {args.reads} x {args.read_len} bp generated in {time.time() - t0:.1f}s")
-    if args.cpu_baseline_secs <= 0 or rank != 0 or world != 1:
-        del seq, sa            # the context holds its own packed copy
-        seq = sa = None
-        torch.cuda.empty_cache()
+    keep_index_for_baseline = args.cpu_baseline_secs > 0 and rank == 0 and world == 1
 
-    def step():
-        al.align_device(rd_bases.data_ptr(), rd_offs.data_ptr(), rd_lens.data_ptr(), args.reads, out.data_ptr())
+    def run_step(bases, offs, lens, nreads, dst):
+        al.align_device(bases.data_ptr(), offs.data_ptr(), lens.data_ptr(), nreads, dst.data_ptr())
+        if pe:
+            al.pair_device(bases.data_ptr(), offs.data_ptr(), lens.data_ptr(), nreads // 2, dst.data_ptr(), pe_params)
         # the path's one exchange step: per-sequence hit counts summed over ranks
         c = al.seq_counts(reset=True)
         counts_dev.copy_(torch.from_numpy(c.astype(np.int64)))
         if dist is not None:
             all_reduce(counts_dev)
+
+    def step():
+        run_step(rd_bases, rd_offs, rd_lens, args.reads, out)
 
     for _ in range(args.warmup):
         step()
@@ -472,7 +597,7 @@ def main():
     host_leg = None
     if args.stream_steps > 0:
         try:
-            host_leg = host_resident_leg(al, rd_bases, rd_lens, out, args, barrier, all_reduce if dist is not None else None, dev)
+            host_leg = host_resident_leg(al, rd_bases, rd_lens, out, args, barrier, all_reduce if dist is not None else None, dev, pe_params)
         except Exception as e:       # reporting only - never lose the measured line
             host_leg = {"value": None, "error": repr(e)}
     repeatable = bool(torch.equal(first_out, out)) if first_out is not None else None
@@ -481,6 +606,10 @@ def main():
     accepted = int((hits["nar"] == 1).sum())
     total_reads = args.reads * world * args.steps
     value = total_reads / elapsed
+
+    multi = None
+    if world > 1:
+        multi = multi_gpu_legs(al, make_set, run_step, counts_dev, args, rank, world, dev, barrier, all_reduce, dist)
 
     # roofline: algorithmic bytes over the kernel's summed launch time, measured with HIP
     # events on the stream the kernels run on.  Per search: ceil(log2 N) * (E + 8); per candidate
@@ -502,7 +631,7 @@ def main():
     dom = max(kern, key=lambda k: kern[k]["ms"])
     ach = kern[dom]["GBs"]
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
-    default_workload = (args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
+    default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
     traffic, traffic_src = profiled_traffic(dom) if default_workload else (None, None)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -513,17 +642,18 @@ def main():
                 "whole_step_algorithmic_GBs": whole, "whole_step_frac": whole / HBM_PEAK_GBS,
                 "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other")}}
 
+    fmt = dict(reads=args.reads, pairs=args.reads // 2, read_len=args.read_len, max_subs=args.max_subs)
     result = {
         "metric": "aligned reads/s (SAM-identical) on 100 bp SE vs GRCh38, 1->8 MI355X",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"C2: {args.reads} x {args.read_len} bp SE reads per GPU per step (0-{args.max_subs} subs, "
-                               f"simreads-like) vs synthetic GRCh38-like genome of {total_bp} bp in {len(seq_lens)} "
-                               f"sequences (45% repeat-derived, N gaps), biokanga align -s{args.max_subs}",
+        "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic GRCh38-like genome of {total_bp} bp in {len(seq_lens)} "
+                               f"sequences (45% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
-                   "parallelism": f"reads sharded over {world} GPU(s)", "accepted_frac_rank0": accepted / args.reads,
+                   "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",
+                   "accepted_frac_rank0": accepted / args.reads,
                    "n_search_per_read": ctr["n_search"] / (args.reads * args.steps),
                    "n_cand_per_read": ctr["n_cand"] / (args.reads * args.steps),
                    "heavy_calls_frac": ctr["n_heavy"] / max(1, ctr["n_lcm_calls"]),
@@ -531,12 +661,15 @@ def main():
         "roofline": roofline,
         "t_align_host_resident": host_leg,
     }
-    if rank == 0 and world == 1 and args.cpu_baseline_secs > 0:
+    if multi is not None:
+        result.update(multi)
+    if keep_index_for_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(seq, sa, entries, rd_bases, args.read_len, params_kw, hits,
-                                                  args.cpu_baseline_secs, args.reference_reads, local_rank)
+                                                  args.cpu_baseline_secs, args.reference_reads, local_rank, pe=pe,
+                                                  full_cli=not args.no_full_cli)
         except Exception as e:      # the baseline is reporting only - never lose the measured line
-            result["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "port",
+            result["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": effective_cpus(), "kind": "port",
                                       "sample": f"failed: {e!r}"}
     al.close()
     if dist is not None:
@@ -544,6 +677,72 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def multi_gpu_legs(al, make_set, run_step, counts_dev, args, rank, world, dev, barrier, all_reduce, dist):
+    """N > 1 only.  (1) shard check: ONE read set, the same on every rank, is dealt i mod N; the all-reduced per-sequence counts
+    and NAR histogram must equal those of rank 0 aligning the whole set alone.  (2) strong scaling: ONE set of the config's
+    per-step size dealt i mod N, timed like the weak-scaling steps."""
+    import numpy as np
+    import torch
+    import biokanga_amd as bk
+    res = {}
+    L = args.read_len
+    unit = 2 if CONFIGS[args.config]["pe"] else 1            # pairs stay together
+
+    def shard_of(bases, lens, n_total):
+        """rows r, r + N, .. (whole pairs) of a set -> contiguous (bases, offs, lens, n)"""
+        rows = bases.view(n_total // unit, unit * L)[rank::world].contiguous()
+        m = rows.shape[0] * unit
+        return rows.view(-1), torch.arange(m, dtype=torch.int64, device=dev) * L, lens[:m].contiguous(), m
+
+    # ---- (1) shard check
+    G = max(unit * world, args.shard_check_reads - args.shard_check_reads % (unit * world))
+    gb, go, gl = make_set(G, 777)
+    sb, so, sl, m = shard_of(gb, gl, G)
+    d_hits = torch.zeros(m * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    al.seq_counts(reset=True)
+    run_step(sb, so, sl, m, d_hits)                      # leaves the all-reduced counts in counts_dev
+    reduced_counts = counts_dev.cpu().numpy().copy()
+    nar = torch.from_numpy(np.bincount(d_hits.cpu().numpy().view(bk.HIT_DTYPE)["nar"], minlength=20).astype(np.int64)).to(dev)
+    all_reduce(nar)
+    check = None
+    if rank == 0:
+        whole = torch.zeros(G * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        al.align_device(gb.data_ptr(), go.data_ptr(), gl.data_ptr(), G, whole.data_ptr())
+        if CONFIGS[args.config]["pe"]:
+            pp = CONFIGS[args.config]["pe"]
+            al.pair_device(gb.data_ptr(), go.data_ptr(), gl.data_ptr(), G // 2, whole.data_ptr(),
+                           bk.PEParams(pp["pe_mode"], pp["pair_min_len"], pp["pair_max_len"], False))
+        one_counts = al.seq_counts(reset=True).astype(np.int64)
+        one_nar = np.bincount(whole.cpu().numpy().view(bk.HIT_DTYPE)["nar"], minlength=20).astype(np.int64)
+        check = {"reads": G, "dealt": f"read i -> rank i mod {world}" + (" (pairs kept together)" if unit == 2 else ""),
+                 "per_sequence_counts_equal_1gpu_run": bool(np.array_equal(reduced_counts, one_counts)),
+                 "nar_histogram_equal_1gpu_run": bool(np.array_equal(nar.cpu().numpy(), one_nar)),
+                 "accepted": int(one_counts.sum())}
+        del whole
+    al.seq_counts(reset=True)
+    res["shard_check"] = check
+    del gb, go, gl, sb, so, sl, d_hits
+    # ---- (2) strong scaling: the config's per-step read count in total
+    T = args.reads - args.reads % (unit * world)
+    gb, go, gl = make_set(T, 2000)
+    sb, so, sl, m = shard_of(gb, gl, T)
+    del gb, go
+    d_hits = torch.zeros(m * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    run_step(sb, so, sl, m, d_hits)                      # warm-up
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        run_step(sb, so, sl, m, d_hits)
+    barrier()
+    el = time.time() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    res["strong_scaling"] = {"reads_total_per_step": T, "reads_per_gpu_per_step": m, "value": T * args.steps / el, "unit": "reads/s",
+                             "ms_per_step": el / args.steps * 1e3, "steps": args.steps}
+    return res
 
 
 if __name__ == "__main__":
