@@ -51,6 +51,11 @@ struct bk_ctx {
     uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
+    int use_direct = 0;      // 1: k_direct (pass A of the search + in-place evaluation of the reads it settles), 0: k_search_a then k_flat for all.
+                             //    Off: measured on C2 it is SLOWER (search 95 ms/step instead of 46, k_flat 9 instead of 21: the fused lanes
+                             //    carry the window registers through the search - 160 VGPRs, 3 waves/SIMD against k_search_a's 31 / 8 - and
+                             //    run four dependent random loads back to back)
+    uint32_t *d_gen = nullptr;            // reads k_direct hands on to pass B + k_flat / k_wave
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified

@@ -47,6 +47,8 @@ struct DevIndex {
     const uint64_t *ent_start;
     const uint64_t *ent_end;
     const uint32_t *ent_id;
+    const uint32_t *id2idx;     // EntryID -> entry index (0xffffffff = no such id), max_id + 1 elements: ids need not be 1..n in file order
+    uint32_t max_id;
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
     const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null

@@ -56,6 +56,9 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
                  int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
                  hipStream_t s);
+void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
+                   int lazy, uint32_t *slist, uint32_t *slist_cnt, uint32_t *general, uint32_t *general_cnt, uint32_t *next_act, uint32_t *next_cnt,
+                   uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
@@ -331,6 +334,8 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
         for (uint32_t i = 0; i < n_entries; i++) map[ei[i]] = i;
         HIP_TRY(hipMalloc(&c->d_id2idx, map.size() * 4));
         HIP_TRY(hipMemcpy(c->d_id2idx, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+        c->ix.id2idx = c->d_id2idx;
+        c->ix.max_id = max_id;
     }
     c->ix.n_ent = n_entries;
     HIP_TRY(hipMalloc(&c->d_seq_counts, n_entries * 8));
@@ -405,7 +410,8 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen);
+    c->d_gen = nullptr;
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     c->cap_reads = 0;
@@ -421,6 +427,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_gen, (size_t)nr * 4));
     c->cap_reads = nr;
     c->cap_wpr = w;
     c->cap_rd2w = w2;
@@ -494,7 +501,7 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
 static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
 {
-    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 12 + 4 * 4;
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 12 + 5 * 4;
 }
 
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
@@ -640,11 +647,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         n_act = 0;
     }
     for (int phase = 0; n_act > 0; phase++) {
-        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor
+        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list, [9] general list
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
-        HIP_TRY(hipMemsetAsync(sm + 6, 0, 2 * 4, s));
+        HIP_TRY(hipMemsetAsync(sm + 6, 0, 4 * 4, s));
+        // the reads the extend kernels see: all active ones, or - after k_direct - those it did not finish itself
+        const uint32_t *ext_list = c->d_act[cur];
+        uint32_t n_ext = n_act;
         if (cmax > 0) {
             const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
+            const bool direct = c->use_direct && c->ix.k2 && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100;
             hipEvent_t e1 = tm.begin(s);
             if (c->ix.k2) {
                 const uint64_t lanes = (uint64_t)n_act * (uint64_t)(cmax * nstr);
@@ -656,15 +667,25 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                     HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
                     c->cap_slist = lanes;
                 }
-                HIP_TRY(hipMemsetAsync(sm + 8, 0, 4, s));
-                // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
-                for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
-                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
-                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                if (direct) {
+                    // pass A + the whole call for the reads it settles (k_direct); interval records only for the others, every slot written
+                    launch_direct(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, c->d_gen, sm + 9,
+                                  c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, s);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 8, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    ext_list = c->d_gen;
+                    n_ext = hm[9];
+                } else {
+                    // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
+                    for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
+                        if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
+                        else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
+                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                }
                 const uint32_t *slist = c->d_slist;
                 if ((c->sort_lists & 1) && hm[8] >= 4096) {
                     int rs = ensure_sort_scratch(c, hm[8], s);
@@ -680,14 +701,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             tm.end(0, e1, s);
         }
         hipEvent_t e2 = tm.begin(s);
-        if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
-            launch_flat(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
+        if (n_ext == 0) {}
+        else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
+            launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
                         c->d_wave, sm + 6, sm + 3, nw16, s);
         else if (reg_path)
-            launch_light(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
+            launch_light(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
                          sm + 3, nw16, s);
         else
-            launch_extend(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
+            launch_extend(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
         HIP_TRY(hipGetLastError());
         tm.end(1, e2, s);
         HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
@@ -990,7 +1012,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_small);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_small);
     free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
@@ -1059,6 +1081,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->use_isa = value ? 1 : 0;
         int rc = build_isa(c);
         return rc ? rc : old;
+    }
+    if (n == "use_direct") {
+        int64_t old = c->use_direct;
+        c->use_direct = value ? 1 : 0;
+        return old;
     }
     if (n == "use_flat") {
         int64_t old = c->use_flat;

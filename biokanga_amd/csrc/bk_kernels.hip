@@ -1592,6 +1592,253 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_direct: pass A of the two-pass search (exactly k_search_a: one lane per active read, strand and core) and, for the reads
+// whose EVERY core it settles with a handful of candidates, the rest of the LocateCoreMultiples call in the same launch: the
+// lane that located a core's few suffixes evaluates them itself (suffix array element, window compare, one result byte in LDS
+// - k_flat's evaluation), then one lane per read replays the bytes in the reference's walk order (strand, core, suffix)
+// through the Low / NxtLow / instances state machine and writes the result or hands the read to the next phase.  For these
+// reads - most reads of every phase - no interval record is ever written to or read back from HBM, no work-list item is
+// produced, and k_flat does not see them.  The other reads (a core that needs pass B, or an interval above the in-place
+// limit) get their interval records written as k_search_a writes them - every slot, empty ones included, so the phase's
+// slots need no clearing - and go on the `general` list that pass B + k_flat / k_wave continue from.
+constexpr uint32_t kDirectMax = kInlineBucket;     // candidates per core evaluated in place
+
+template <bool WIDE, int NW>
+__global__ void __launch_bounds__(256) k_direct(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act,
+                                                int phase, int cmax, int nstr, int lazy, uint32_t *__restrict__ slist,
+                                                uint32_t *__restrict__ slist_cnt, uint32_t *__restrict__ general,
+                                                uint32_t *__restrict__ general_cnt, uint32_t *__restrict__ next_act,
+                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next)
+{
+    __shared__ uint8_t s_gen[256];                      // per read of the block: 1 = continues on the general path, 2 = does not fit these kernels
+    __shared__ uint8_t s_rec[256 * kDirectMax];         // [lane][candidate]: mismatches, or kRecSkip
+    __shared__ uint8_t s_n[256];                        // candidates of the lane's slot
+    __shared__ unsigned long long s_first[256];         // suffix array index of the slot's first candidate
+    __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
+    __shared__ unsigned long long s_ctr[3];
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63;
+    if (t < 4) s_cnt[t] = 0;
+    if (t == 4) s_cmax = 0;
+    if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
+    s_gen[t] = 0;
+    s_n[t] = 0;
+    __syncthreads();
+
+    const uint32_t per_read = (uint32_t)(nstr * cmax);
+    const uint32_t rpb = 256u / per_read;               // reads per block
+    const uint32_t ri = t / per_read, q = t - ri * per_read;
+    const uint64_t a = (uint64_t)blockIdx.x * rpb + ri;
+    const bool have = ri < rpb && a < n_act;
+    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+
+    uint32_t r = 0;
+    int len = 0, mm = 0, cl = 1, cd = 1, nc = 0, n_phases = 0, c = 0, strand = 0, my_ofs = 0;
+    bool slot_lane = false, push = false, lazy_slot = false;
+    uint64_t slot = 0, first = 0;
+    uint32_t nval = 0, cnt = 0;
+    if (have) {
+        r = act[a];
+        len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        n_phases = p.n_phases;
+        int dummy[1];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+        const bool fits = nc <= kMaxCoresFast && nc <= cmax && len <= 16 * NW;
+        const int si = (int)(q / (uint32_t)cmax);
+        c = (int)(q % (uint32_t)cmax);
+        strand = cfg.align_strand == 2 ? 1 : si;
+        if (!fits) {
+            if (q == 0) s_gen[ri] = 2;
+        } else if (c < nc) {
+            // ---- k_search_a, verbatim
+            slot_lane = true;
+            my_ofs = c * cd < len - cl ? c * cd : len - cl;
+            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+            slot = iv_slot(b, r, strand, c);
+            const int k = ix.k;
+            const uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
+            nval = kKindFull << kKindShift;
+            push = true;
+            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
+                const uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
+                const uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
+                const uint64_t size = hi - lo;
+                if (size == 0) {
+                    first = lo; nval = 0; push = false;
+                } else if (size <= kInlineBucket) {
+                    const int rem2 = cl - k;
+                    const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
+                    const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
+                    uint64_t key[kInlineBucket];
+#pragma unroll
+                    for (uint32_t j = 0; j < kInlineBucket; j++) key[j] = j < size ? ix.k2[lo + j] : ~0ULL;
+                    uint32_t lb = 0, ub = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kInlineBucket; j++) {
+                        int cm = k2_cmp(key[j], m, q2);
+                        lb += cm < 0;
+                        ub += cm <= 0;
+                    }
+                    first = lo + lb;
+                    const uint32_t n2 = ub - lb;
+                    if (n2 == 0 || cl <= k + 16) { nval = n2; push = false; }
+                    else if (lazy && n2 <= kLazyBucket) { nval = n2 | kLazyFlag; push = false; }
+                    else nval = n2 | (kKindDeep << kKindShift);
+                } else if (size < (1ULL << kKindShift)) {
+                    first = lo;
+                    nval = (uint32_t)size | (kKindK2 << kKindShift);
+                }
+            }
+            cnt = nval & ~kLazyFlag;
+            lazy_slot = (nval & kLazyFlag) != 0;
+            const uint32_t lim = kDirectMax < (uint32_t)cfg.heavy_thresh ? kDirectMax : (uint32_t)cfg.heavy_thresh;
+            if (push || cnt > lim) s_gen[ri] = 1;
+        }
+    }
+    __syncthreads();
+    const int gen = have ? (int)s_gen[ri] : 0;
+    if (gen != 1) push = false;
+    if (gen == 1 && slot_lane) iv_put(b, slot, first, nval);           // every slot of the read, empty ones too
+
+    // ---- in-place evaluation (k_flat's candidate step)
+    if (have && gen == 0 && slot_lane && cnt > 0) {
+        s_n[t] = (uint8_t)cnt;
+        s_first[t] = first;
+        uint64_t r2w[NW / 2], rnm[NW / 4], rw[NW];
+        const bool two_bit = b.rd2 != nullptr;
+        if (two_bit) load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + strand) * (3 * NW / 4), r2w, rnm);
+        bool have_rw = false;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint64_t loci = sa_get<WIDE>(ix, first + j);
+            uint8_t rec = kRecSkip;
+            if (loci >= (uint64_t)my_ofs) {
+                const uint64_t t0 = loci - (uint64_t)my_ofs;
+                Window<NW> w;
+                bool flg = true;
+                if (two_bit) {
+                    flg = window_flagged(ix, t0, len);
+                    eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t0, w);
+                }
+                if (flg) {                                               // N/EOS nearby (rare): the 4-bit copy decides
+                    if (!have_rw) { load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr, len, rw); have_rw = true; }
+                    eval_window<NW>(rw, len, ix.tgt4, t0, w);
+                }
+                bool skip = w.eos || (lazy_slot && !core_clean<NW>(w, my_ofs, cl));
+                for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * cd, cl);      // earlier cores never sit at the clipped offset
+                if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
+            }
+            s_rec[t * kDirectMax + j] = rec;
+        }
+    }
+    __syncthreads();
+
+    // ---- replay, one lane per read
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    int dest = 0;                   // 1 = next phase, 2 = general path
+    uint32_t my_cmax = 0;
+    if (have && q == 0) {
+        if (gen != 0) dest = 2;
+        else {
+            n_lcm = 1;
+            const int init = mm + cfg.mm_delta + 1;
+            int low_inst = 0, low_mm = init, nxt = init;
+            int best_lane = -1, best_c = 0, best_st = 0;
+            uint32_t best_j = 0;
+            bool done = false;
+            for (int st = s0; st <= s1 && !done; st++) {
+                const int si = cfg.align_strand == 2 ? 0 : st;
+                for (int cc = 0; cc < nc && !done; cc++) {
+                    n_search++;
+                    const uint32_t tl = ri * per_read + (uint32_t)(si * cmax + cc);
+                    const uint32_t n = s_n[tl];
+                    for (uint32_t x = 0; x < n; x++) {
+                        const int cm = s_rec[tl * kDirectMax + x];
+                        if (cm == kRecSkip) continue;
+                        n_cand++;
+                        if (cm > mm || cm >= nxt) continue;
+                        if (cm < low_mm) {
+                            low_inst = 1; nxt = low_mm; low_mm = cm;
+                            best_lane = (int)tl; best_j = x; best_c = cc; best_st = st;
+                        } else if (cm == low_mm)
+                            low_inst++;
+                        else
+                            nxt = cm;
+                        if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
+                    }
+                }
+            }
+            const int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+            if (rslt != BK_HR_NONE) {
+                uint64_t hit_left = 0;
+                int hit_strand = '?', e = -1;
+                if (low_inst >= 1) {
+                    const int last = len - cl;
+                    const int ofs = best_c * cd < last ? best_c * cd : last;
+                    hit_left = sa_get<WIDE>(ix, s_first[best_lane] + best_j) - (uint64_t)ofs;
+                    hit_strand = best_st ? '-' : '+';
+                    e = find_entry(ix, hit_left);
+                }
+                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
+            } else if (phase + 1 < n_phases) {
+                ReadPlan p = make_plan(len, cfg);
+                int mm2, cl2, cd2, dummy[1];
+                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                const int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
+                dest = 1;
+            }
+        }
+    }
+    // ---- appends (one global atomic per block and list) and counters
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_search += __shfl_down(n_search, off);
+        n_cand += __shfl_down(n_cand, off);
+        n_lcm += __shfl_down(n_lcm, off);
+        uint32_t m = __shfl_down(my_cmax, off);
+        my_cmax = m > my_cmax ? m : my_cmax;
+    }
+    uint32_t my_off = 0, my_soff = 0;
+#pragma unroll
+    for (int d = 1; d <= 2; d++) {
+        uint64_t m = __ballot(dest == d);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
+        }
+    }
+    {
+        uint64_t m = __ballot(push);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt[3], (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (push) my_soff = w + (uint32_t)__popcll(m & lt_mask);
+        }
+    }
+    if (lane == 0) {
+        if (my_cmax) atomicMax(&s_cmax, my_cmax);
+        if (n_search) atomicAdd(&s_ctr[0], n_search);
+        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
+    }
+    __syncthreads();
+    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
+    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(general_cnt, s_cnt[2]);
+    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(slist_cnt, s_cnt[3]);
+    if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    __syncthreads();
+    if (dest == 1) next_act[s_base[1] + my_off] = r;
+    else if (dest == 2) general[s_base[2] + my_off] = r;
+    if (push) slist[s_base[3] + my_soff] = (uint32_t)slot;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_wave: one wave per LocateCoreMultiples call for reads of <= 16*NW bases and <= 16 cores per
 // strand (4-byte suffix arrays).  64 candidates of a core interval per step; the reference's
 // SEQUENTIAL semantics are reproduced exactly with ballot prefix sums, as in k_heavy:
@@ -3102,9 +3349,11 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
             const int max_allowed = cfg.max_subs;
             // AlignPairedRead set-up (:8270-8330)
             if (pe.min_len < read_len || pe.min_len > pe.max_len) continue;
-            if (a.chrom_id < 1 || a.chrom_id > ix.n_ent) continue;
-            const uint64_t c_start = ix.ent_start[a.chrom_id - 1];
-            const uint32_t targ_len = (uint32_t)(ix.ent_end[a.chrom_id - 1] - c_start + 1);
+            if (a.chrom_id < 1 || a.chrom_id > ix.max_id) continue;
+            const uint32_t a_ent = ix.id2idx[a.chrom_id];                  // EntryIDs need not be 1..n in file order
+            if (a_ent >= ix.n_ent) continue;
+            const uint64_t c_start = ix.ent_start[a_ent];
+            const uint32_t targ_len = (uint32_t)(ix.ent_end[a_ent] - c_start + 1);
             int targ_loci;
             if (b3) { targ_loci = (int)a_start; if ((uint32_t)(targ_loci + pe.min_len) > targ_len) continue; }
             else { targ_loci = (int)a_end; if (targ_loci < pe.min_len || (uint32_t)targ_loci >= targ_len) continue; }
@@ -3143,7 +3392,7 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
                         uint32_t loci = 0;
                         if (j < n) {
                             uint64_t pos = ix.sa_hi ? sa_get<true>(ix, first + j) : sa_get<false>(ix, first + j);
-                            if (pos >= c_start && pos <= ix.ent_end[a.chrom_id - 1]) {
+                            if (pos >= c_start && pos <= ix.ent_end[a_ent]) {
                                 uint32_t hit = (uint32_t)(pos - c_start);
                                 if (hit >= start_put && hit <= end_put && (uint32_t)core_ofs <= hit &&
                                     (hit + (uint32_t)read_len - (uint32_t)core_ofs) < targ_len) {
@@ -3420,6 +3669,19 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (nw <= 8) { if (wide) BK_FLAT(true, 8); else BK_FLAT(false, 8); }
     else { if (wide) BK_FLAT(true, 16); else BK_FLAT(false, 16); }
 #undef BK_FLAT
+}
+
+void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
+                   int lazy, uint32_t *slist, uint32_t *slist_cnt, uint32_t *general, uint32_t *general_cnt, uint32_t *next_act, uint32_t *next_cnt,
+                   uint32_t *cmax_next, int nw, hipStream_t s)
+{
+    const uint32_t rpb = 256u / (uint32_t)(nstr * cmax);
+    const unsigned blocks = (unsigned)(((uint64_t)n_act + rpb - 1) / rpb);
+    const bool wide = ix.sa_hi != nullptr;
+#define BK_DIRECT(W, N) hipLaunchKernelGGL((k_direct<W, N>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, slist, slist_cnt, general, general_cnt, next_act, next_cnt, cmax_next)
+    if (nw <= 8) { if (wide) BK_DIRECT(true, 8); else BK_DIRECT(false, 8); }
+    else { if (wide) BK_DIRECT(true, 16); else BK_DIRECT(false, 16); }
+#undef BK_DIRECT
 }
 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <thread>
 
 namespace bk {
@@ -66,9 +67,34 @@ int bam_reg2bin(int beg, int end)
     return 0;
 }
 
-int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &stream, const std::vector<BamAligned> &aligned,
-                      uint64_t flush_at, uint32_t n_refs, int nthreads, std::string *err)
+// CSIreg2bin of the CSI specification as the reference has it (SAMfile.cpp:2059-2070); end exclusive
+static int csi_reg2bin(int64_t beg, int64_t end, int min_shift, int depth)
 {
+    int l, s = min_shift, t = ((1 << depth * 3) - 1) / 7;
+    for (--end, l = depth; l > 0; --l, s += 3, t -= 1 << l * 3)
+        if (beg >> s == end >> s) return t + (int)(beg >> s);
+    return 0;
+}
+
+int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &stream, const std::vector<BamAligned> &aligned,
+                      uint64_t flush_at, uint32_t n_refs, uint64_t max_ref_len, int nthreads, std::string *err)
+{
+    // the reference switches from BAI to CSI when a header sequence reaches the 512 Mbp a BAI can address (CSAMfile::StartAlignments,
+    // SAMfile.cpp:1602-1607); R-tree depth from the longest sequence, never below the BAI's 5 (CSIDepth :2089, :1666-1668)
+    const bool csi = max_ref_len >= 0x20000000ULL;
+    const int min_shift = 14;
+    int depth = 5;
+    if (csi) {
+        int lv = 0;
+        for (int64_t sz = (int64_t)1 << min_shift; (int64_t)max_ref_len > sz; ++lv, sz <<= 3) {}
+        depth = lv < 5 ? 5 : lv;
+    }
+    const uint64_t max_idx_len = csi ? 0x7fffffffULL : 0x20000000ULL;          // cMaxCSIRefSeqLen / cMaxSAIRefSeqLen
+    for (const BamAligned &a : aligned)
+        if ((uint64_t)(uint32_t)a.end >= max_idx_len) {
+            if (err) *err = "alignment ending at " + std::to_string((uint32_t)a.end) + " is beyond what a " + (csi ? "CSI" : "BAI") + " index of this build covers";
+            return -100;
+        }
     const uint64_t total = stream.size();
     // block table: [0, flush_at) and [flush_at, total) are each cut every kBlock bytes
     std::vector<uint64_t> beg;
@@ -113,13 +139,19 @@ int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &strea
         return (caddr[u / kBlock] << 16) | (u % kBlock);
     };
 
-    // ---- BAI (CSAMfile::AddAlignment / AddChunk / UpdateSAIIndex) ----
+    // ---- BAI / CSI (CSAMfile::AddAlignment / AddChunk / UpdateSAIIndex) ----
     std::vector<uint8_t> bai;
     auto put32 = [&](uint32_t v) { bai.insert(bai.end(), (uint8_t *)&v, (uint8_t *)&v + 4); };
     auto put64 = [&](uint64_t v) { bai.insert(bai.end(), (uint8_t *)&v, (uint8_t *)&v + 8); };
-    bai.insert(bai.end(), {'B', 'A', 'I', 1});
+    if (csi) {
+        bai.insert(bai.end(), {'C', 'S', 'I', 1});
+        put32((uint32_t)min_shift);
+        put32((uint32_t)depth);
+        put32(0);                            // l_aux
+    } else
+        bai.insert(bai.end(), {'B', 'A', 'I', 1});
     put32(n_refs);
-    std::vector<std::vector<Chunk>> bins(kNumBins);
+    std::vector<std::vector<Chunk>> bins(csi ? (size_t)(((1ULL << (depth + 1) * 3) - 1) / 7) : (size_t)kNumBins);
     std::vector<int> used;                   // bins owning chunks for the current reference
     std::vector<uint64_t> lin;
     uint32_t n_lin = 0;
@@ -130,14 +162,21 @@ int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &strea
             std::sort(order.begin(), order.end());
             for (int b : order) {
                 put32((uint32_t)b);
+                if (csi) {                   // loffset: the lowest virtual address any chunk of the bin starts at (tsBAIbin.StartVA)
+                    uint64_t lo = bins[b][0].start_va;
+                    for (const Chunk &c : bins[b]) lo = std::min(lo, c.start_va);
+                    put64(lo);
+                }
                 put32((uint32_t)bins[b].size());
                 for (const Chunk &c : bins[b]) { put64(c.start_va); put64(c.end_va); }
                 bins[b].clear();
             }
-            put32(n_lin);
-            for (uint32_t k = 0; k < n_lin; k++) put64(lin[k]);
+            if (!csi) {                      // the 16 kb linear index exists in the BAI only
+                put32(n_lin);
+                for (uint32_t k = 0; k < n_lin; k++) put64(lin[k]);
+            }
         } else
-            put32(0);
+            put32(0);                        // the reference writes this second zero ("n_intv") in both formats
         used.clear();
         std::fill(lin.begin(), lin.end(), 0);
         n_lin = 0;
@@ -152,7 +191,9 @@ int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &strea
         const uint32_t k = start / 0x4000;
         if (lin.size() <= k) lin.resize((size_t)k + 1024, 0);
         if (lin[k] == 0) { n_lin = k + 1; lin[k] = sva; }
-        const int bin = bam_reg2bin((int)start, (int)end);               // inclusive end, as AddChunk passes it
+        const int bin = csi ? csi_reg2bin((int64_t)start, (int64_t)end, min_shift, depth)
+                            : bam_reg2bin((int)start, (int)end);         // inclusive end, as AddChunk passes it
+        if ((size_t)bin >= bins.size()) { if (err) *err = "index bin out of range"; return -1; }
         std::vector<Chunk> &cl = bins[bin];
         if (cl.empty()) {
             used.push_back(bin);
@@ -169,10 +210,19 @@ int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &strea
     }
     (void)any;
     flush_ref();                             // Close(): the reference being indexed when the records ended
-    const std::string bpath = path + ".bai";
+    const std::string bpath = path + (csi ? ".csi" : ".bai");
     fd = ::open(bpath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
     if (fd < 0) { if (err) *err = "unable to create '" + bpath + "'"; return -91; }
-    bool good = write_all(fd, bai.data(), bai.size());
+    bool good = true;
+    if (csi) {
+        // the CSI goes through bgzf_write (SAMfile.cpp:1688, WriteIdxToDisk :1826): 0xff00-byte blocks at the BAM's compression
+        // level, then bgzf_close's empty block
+        std::vector<uint8_t> blk;
+        for (uint64_t u = 0; u < bai.size() && good; u += kBlock)
+            good = bgzf_block(bai.data() + u, (size_t)std::min<uint64_t>(kBlock, bai.size() - u), 6, blk) && write_all(fd, blk.data(), blk.size());
+        if (good) good = bgzf_block(nullptr, 0, Z_DEFAULT_COMPRESSION, blk) && write_all(fd, blk.data(), blk.size());
+    } else
+        good = write_all(fd, bai.data(), bai.size());
     fsync(fd);
     ::close(fd);
     if (!good) { if (err) *err = "write failed"; return -96; }

@@ -24,10 +24,12 @@ struct BamAligned {         // one aligned record, in stream order
 // bin of [beg, end) - the formula of the SAM specification as the reference uses it
 int bam_reg2bin(int beg, int end);
 
+// max_ref_len: the longest sequence of the header; from 512 Mbp on the index is a BGZF-compressed CSI (<file>.csi; min_shift 14,
+// depth from that length) instead of a BAI, as in the reference (SAMfile.cpp:1602-1607,1664-1695,1751-1762,1870-1875).
 // stream: whole uncompressed BAM (magic, header text, references, records).  aligned: the aligned records in
 // stream order.  flush_at: stream offset right after the last aligned record (0 when there is none).
 // Returns 0 or a negative teBSFrsltCodes value.
 int write_bam_and_bai(const std::string &path, const std::vector<uint8_t> &stream, const std::vector<BamAligned> &aligned,
-                      uint64_t flush_at, uint32_t n_refs, int nthreads, std::string *err);
+                      uint64_t flush_at, uint32_t n_refs, uint64_t max_ref_len, int nthreads, std::string *err);
 
 }  // namespace bk

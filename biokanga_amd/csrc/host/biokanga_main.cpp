@@ -488,14 +488,12 @@ int read_align_opts(Args &a, AlignOpts &o)
     if (o.micro_indel < 0 || o.micro_indel > 20) { diag("Error: microInDel length maximum '-a%d' specified outside of range 0..20", o.micro_indel); return 1; }
     if (o.micro_indel && o.ml_mode == 5) { diag("Error: microInDels not supported when reporting multiloci alignments"); return 1; }
     if (o.micro_indel && o.pe_mode) { diag("Error: Sorry, currently microInDel processing '-a%d' not supported in paired end '-U%d' processing", o.micro_indel, o.pe_mode); return 1; }   // kanga.cpp:541-545
-    if (o.micro_indel && o.best_matches) { diag("Error: microInDels '-a%d' together with '-N' are not available in this build", o.micro_indel); return 1; }
     // -x: trim aligned reads back from both ends until that many consecutive bases match (CAligner::AutoTrimFlanks)
     // -A RNA-seq splice junctions (kanga.cpp:726-742,810-811): looked for after the microInDel pass; switches flank trimming on
     o.splice_len = a.num("A", 0);
     if (o.splice_len != 0 && (o.splice_len < 25 || o.splice_len > 100000)) { diag("Error: RNAseq maximum splice junction separation '-A%d' must be either 0 or in the range 25..100000", o.splice_len); return 1; }
     if (o.splice_len && o.ml_mode == 5) { diag("Error: in report all multiloci mode '-r5', there is no splice junction processing.."); return 1; }
     if (o.splice_len && o.pe_mode) { diag("Error: Sorry, currently RNA-seq splice junction processing '-A%d' not supported in paired end '-U%d' processing", o.splice_len, o.pe_mode); return 1; }
-    if (o.splice_len && o.best_matches) { diag("Error: splice junctions '-A%d' together with '-N' are not available in this build", o.splice_len); return 1; }
     // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
     o.min_chim = a.num("c", 0);
     if (o.min_chim != 0 && (o.min_chim < 50 || o.min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", o.min_chim < 0 ? -o.min_chim : o.min_chim); return 1; }
@@ -538,8 +536,10 @@ int read_align_opts(Args &a, AlignOpts &o)
     if (o.min_flank < 0 || o.min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", o.min_flank); return 1; }      // cMaxAllowedSubs / 2
     if (o.min_flank && o.ml_mode == 5) { diag("Error: flank trimming '-x%d' together with '-r5' is not available in this build", o.min_flank); return 1; }
     o.P = bk_align_params{};
-    o.P.micro_indel_len = o.micro_indel;
-    o.P.splice_junct_len = o.splice_len;
+    // with -N the reads go through LocateBestMatches, which has no microInDel / splice junction branches (Aligner.cpp:9197-9218): the
+    // options are accepted as the reference accepts them and only their host-side consequences remain (-A still switches flank trimming on)
+    o.P.micro_indel_len = o.best_matches ? 0 : o.micro_indel;
+    o.P.splice_junct_len = o.best_matches ? 0 : o.splice_len;
     o.P.pmode = a.num("m", 0);
     o.P.align_strand = a.num("Q", 0);
     o.P.min_edit_dist = a.num("e", 1);
@@ -610,7 +610,7 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Rea
 {
     const size_t nr = rs.size(), ndev = ctxs.size();
     A.hits.resize(nr);
-    const bool lists = o.ml_mode != 0, segs = o.micro_indel || o.splice_len || o.min_chim;
+    const bool lists = o.ml_mode != 0, segs = o.P.micro_indel_len || o.P.splice_junct_len || o.P.min_chimeric_len;
     if (lists) A.l_offs.assign(1, 0);
     size_t per = 8u << 20;                                                          // reads per batch
     if (nr / ndev / 2 + 1 < per) per = std::max<size_t>(65536, nr / ndev / 2 + 1);   // at least two batches per device: overlap
@@ -948,9 +948,47 @@ int cmd_align(int argc, char **argv, int first)
         diag("Filtering by chromosome completed - removed %zu  matches", n_filt);
     }
 
-    // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): NAR histogram
+    // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): strand counts, the simulated-reads truth check, NAR histogram
     uint64_t nar[20] = {0};
     for (const bk_hit &h : hits) nar[h.nar < 20 ? h.nar : 0]++;
+    {
+        // Reads named by `biokanga simreads` carry where they came from (lcl|usimreads|id|chrom|start|end|len|strand|..): an accepted
+        // alignment on the named sequence counts as high confidence when one or both of its ends are the named ones, anything
+        // else as misaligned.  Reads are visited in load order; the first accepted read decides whether the set is simulated, and
+        // a later accepted read that does not parse ends the check - and drops the line - exactly as the reference's loop does
+        // (:3560-3650).  The descriptors are parsed with the reference's own sscanf formats.
+        uint64_t n_plus = 0, n_acc = 0, n2 = 0, n1 = 0, n_mis = 0;
+        bool sim = false;
+        for (size_t i = 0; i < nr; i++) {
+            const bk_hit &h = hits[i];
+            if (h.nar != BK_NAR_ACCEPTED) continue;
+            n_acc++;
+            n_plus += h.strand == '+';
+            if (!(sim || n_acc == 1)) continue;
+            char typ[100], xchrom[300], x1c[100], x2c[100], xstrand;
+            int id, xs, xe, xl, xerrs;
+            const char *nm = rs.name(RD(i));
+            if (strlen(nm) > 127) continue;
+            int its = sscanf(nm, "%99[^|]|usimreads|%d|%99[^|]|%d|%d|%d|%c|%d", typ, &id, xchrom, &xs, &xe, &xl, &xstrand, &xerrs);
+            if (its >= 6) sim = true;
+            else {
+                its = sscanf(nm, "%99[^|]|usimreads|%d|%99[^|]|%99[^|]|%99[^|]|%d|%d|%d|%c|%d", typ, &id, xchrom, x1c, x2c, &xs, &xe, &xl, &xstrand, &xerrs);
+                if (its < 8) sim = false;
+                else { strcat(xchrom, "|"); strcat(xchrom, x1c); strcat(xchrom, "|"); strcat(xchrom, x2c); sim = true; }
+            }
+            if (!sim) continue;
+            if (h.chrom_id < 1 || h.chrom_id > n_ent || strcasecmp(ents[h.chrom_id - 1].name, xchrom)) { n_mis++; continue; }
+            const long left = (long)h.match_loci;
+            const long right = has_seg2(i) ? (long)seg2[RD(i)].match_loci + seg2[RD(i)].match_len - 1 : left + h.match_len - 1;
+            if (left == xs || right == xe) (left != xs || right != xe ? n1 : n2)++;
+            else n_mis++;
+        }
+        diag("From %zu source reads there are %llu accepted alignments, %llu on '+' strand, %llu on '-' strand", rs.size(), (unsigned long long)n_acc,
+             (unsigned long long)n_plus, (unsigned long long)(n_acc - n_plus));
+        if (sim)
+            diag("There are %llu (%llu 2 edge, %llu 1 edge) high confidence aligned simulated reads with %llu misaligned", (unsigned long long)(n2 + n1),
+                 (unsigned long long)n2, (unsigned long long)n1, (unsigned long long)n_mis);
+    }
     diag("Unable to align %llu source reads of which %llu were not aligned as they contained excessive number of indeterminate 'N' bases",
          (unsigned long long)(nr - nar[1]), (unsigned long long)nar[2]);
     diag("Read nonalignment reason summary:");

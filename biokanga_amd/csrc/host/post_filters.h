@@ -91,6 +91,7 @@ inline std::pair<size_t, size_t> remove_orphan_segs(std::vector<bk_hit> &hits, c
 {
     struct Junct { uint32_t chrom, starts, ends; size_t read; };
     std::vector<Junct> jn;
+    if (seg2.empty()) return {0, 0};                 // no segmented alignments were looked for (-N)
     for (size_t i = 0; i < hits.size(); i++)
         if (hits[i].nar == BK_NAR_ACCEPTED && (seg2[i].flags & want))
             jn.push_back({hits[i].chrom_id, hits[i].match_loci + hits[i].match_len - 1u, seg2[i].match_loci, i});

@@ -355,7 +355,9 @@ int report_bam(Report &R, const std::string &opath)
         std::vector<uint8_t>().swap(S.bytes);
     }
     std::string berr;
-    rc = bk::write_bam_and_bai(opath, stream, aligned, flush_at, (uint32_t)refs.size(), nthreads, &berr);
+    uint64_t max_ref_len = 0;
+    for (uint32_t c : refs) max_ref_len = std::max<uint64_t>(max_ref_len, ents[c - 1].seq_len);
+    rc = bk::write_bam_and_bai(opath, stream, aligned, flush_at, (uint32_t)refs.size(), max_ref_len, nthreads, &berr);
     if (rc) { diag("Fatal: %s", berr.c_str()); return 1; }
     report_jct_for_sam(R);
     diag("Completed reporting BAM %llu read alignments", (unsigned long long)n_rep);

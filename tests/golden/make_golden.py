@@ -294,12 +294,12 @@ def make_repeat(tmp):
     ])
 
 
-def make_pe(tmp):
+def make_pe(tmp, L=100, name="pe"):
     """paired-end fixture on the basic genome: FR pairs with inserts in and out of the accepted range,
     same-strand pairs, different-chromosome pairs, one mate unalignable, one mate in a duplicated /
     triplicated segment (orphan recovery by the anchored window scan), mates with substitutions."""
     rng = np.random.default_rng(909)
-    outdir = os.path.join(HERE, "pe")
+    outdir = os.path.join(HERE, name)
     os.makedirs(outdir, exist_ok=True)
     basic = os.path.join(HERE, "basic")
     fa = os.path.join(tmp, "pe.fa")
@@ -315,8 +315,8 @@ def make_pe(tmp):
         else:
             seqs[name].append(line.upper())
     seqs = {k: "".join(v) for k, v in seqs.items()}
-    L = 100
     r1, r2 = [], []
+    emax1, emax2 = (3, 4) if L == 100 else (7, 10)          # -s5 on 150 bp allows 8 substitutions: 0..6 / 0..9 per mate
 
     def pair(tag, c1, p1, c2, p2, flip1=False, flip2=True, e1=0, e2=0, rand2=False):
         a = seqs[c1][p1:p1 + L]
@@ -337,7 +337,7 @@ def make_pe(tmp):
         c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
         ins = int(np.clip(rng.normal(300, 90), 150, 650))
         p = int(rng.integers(0, 100000 - ins))
-        e1, e2 = int(rng.integers(0, 3)), int(rng.integers(0, 4))
+        e1, e2 = int(rng.integers(0, emax1)), int(rng.integers(0, emax2))
         if rng.integers(0, 2):
             pair(f"fr{ins}", c, p, c, p + ins - L, False, True, e1, e2)
         else:                                               # the pair read from the other strand
@@ -365,8 +365,8 @@ def make_pe(tmp):
     for k in range(30):                                    # pairs near sequence ends
         pair("endA", "chrA", 100000 - 330 + k, "chrA", 100000 - L - int(rng.integers(0, 3)), False, True)
         pair("startB", "chrB", int(rng.integers(0, 5)), "chrB", 230 + k, False, True)
-    f1 = os.path.join(tmp, "pe_1.fa")
-    f2 = os.path.join(tmp, "pe_2.fa")
+    f1 = os.path.join(tmp, f"{name}_1.fa")
+    f2 = os.path.join(tmp, f"{name}_2.fa")
     write_reads(f1, r1)
     write_reads(f2, r2)
     sfx = os.path.join(tmp, "pe.sfx")
@@ -376,14 +376,16 @@ def make_pe(tmp):
     runs = [("U3", ["-U3", "-d200", "-D400", "-s5"]), ("U1", ["-U1", "-d200", "-D400", "-s5"]),
             ("U2", ["-U2", "-d200", "-D400", "-s5"]), ("U4", ["-U4", "-d200", "-D400", "-s5"]),
             ("U3dflt", ["-U3", "-s3"]), ("U3wide", ["-U3", "-d150", "-D1500", "-s5"]), ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"])]
+    if L != 100:         # C3 of SURVEY.md 8(d): 2 x 150 bp, -U3 -d200 -D400 -s5 (+ the other -U modes)
+        runs = runs[:4]
     for tag, flags in runs:
-        out = os.path.join(tmp, f"pe_{tag}.sam")
+        out = os.path.join(tmp, f"{name}_{tag}.sam")
         log = run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M6", "-T4"] + flags, tmp)
         gz_copy(out, os.path.join(outdir, f"{tag}.m6.sam.gz"))
         with open(os.path.join(outdir, f"{tag}.nar.txt"), "w") as f:
             f.write(nar_summary(log))
         print("  ran PE", tag, flags)
-    out = os.path.join(tmp, "pe_U3.m5.sam")
+    out = os.path.join(tmp, f"{name}_U3.m5.sam")
     run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M5", "-T4", "-U3", "-d200", "-D400", "-s5"], tmp)
     gz_copy(out, os.path.join(outdir, "U3.m5.sam.gz"))
 
@@ -1135,7 +1137,7 @@ def make_snp(tmp):
         print("  ran", tag)
 
 
-def make_multi_rescue(tmp):
+def make_multi_rescue(tmp, only=None):
     """-r1..-r4 together with -a / -A (the reference takes them; AlignReads with MaxHits > 1 runs its microInDel / splice branches): on
     the indel, splice and combined fixtures"""
     outdir = os.path.join(HERE, "multi")
@@ -1146,12 +1148,130 @@ def make_multi_rescue(tmp):
     for fix, tag, flags, fmt, ext in (("indel", "xi_r1R5a10", ["-r1", "-R5", "-a10", "-s3"], "-M6", "sam"), ("indel", "xi_r3R5a10", ["-r3", "-R5", "-a10", "-s3"], "-M6", "sam"),
                                      ("indel", "xi_r2R5a10", ["-r2", "-R5", "-a10", "-s3"], "-M0", "csv"), ("splice", "xs_r4R5A5000", ["-r4", "-R5", "-A5000", "-s3"], "-M6", "sam"),
                                      ("splice", "xs_r3R3XA5000", ["-r3", "-R3", "-X", "-A5000", "-s3"], "-M5", "sam"), ("combined", "xc_r3R3a8A3000", ["-r3", "-R3", "-a8", "-A3000", "-s3"], "-M0", "csv"),
-                                     ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3"], "-M4", "bed")):
+                                     ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3"], "-M4", "bed"),
+                                     # -N (LocateBestMatches) has no microInDel / splice branches: the options are accepted and only -A's flank trimming acts
+                                     ("indel", "xn_r2R5Na10", ["-r2", "-R5", "-N", "-a10", "-s3"], "-M6", "sam"), ("splice", "xn_r3R4NA5000", ["-r3", "-R4", "-N", "-A5000", "-s3"], "-M6", "sam"),
+                                     ("combined", "xn_r1R5Na8A3000", ["-r1", "-R5", "-N", "-a8", "-A3000", "-s3"], "-M0", "csv")):
+        if only and not tag.startswith(only):
+            continue
         fs, fr = unz(fix, "genome.sfx.gz", os.path.join(tmp, f"{tag}.sfx")), unz(fix, "reads.fa.gz", os.path.join(tmp, f"{tag}.fa"))
         out = os.path.join(tmp, f"{tag}.{ext}")
         run([REF, "align", "-i", fr, "-I", fs, "-o", out, fmt, "-T4"] + flags, tmp)
         gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
         print("  ran", tag)
+
+
+def make_simreads(tmp):
+    """Reads named the way `biokanga simreads` names them (lcl|usimreads|id|chrom|start|end|len|strand|...): the reference's only
+    built-in correctness signal is the truth-check line of CAligner::ReportAlignStats (Aligner.cpp:3581-3728) - "There are N (a 2
+    edge, b 1 edge) high confidence aligned simulated reads with m misaligned".  Claims: correct, end off (1 edge), both off,
+    wrong sequence, the three-part sequence-name form.  `mixed`: one plainly named read among them (the check stops there and the
+    line is not printed)."""
+    rng = np.random.default_rng(4242)
+    outdir = os.path.join(HERE, "simreads")
+    os.makedirs(outdir, exist_ok=True)
+    basic = os.path.join(HERE, "basic")
+    fa = os.path.join(tmp, "sim.fa")
+    with gzip.open(os.path.join(basic, "genome.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    seqs, name = {}, None
+    for line in open(fa):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = []
+        else:
+            seqs[name].append(line.upper())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    L = 100
+    reads = []
+    for k in range(600):
+        c = "chrA" if rng.integers(0, 2) == 0 else "chrB"
+        p = int(rng.integers(0, 100000 - L))
+        s = seqs[c][p:p + L]
+        if "N" in s:
+            continue
+        e = int(rng.integers(0, 5))                        # 4 substitutions: not aligned at -s3
+        s = mutate(rng, s, e)
+        strand = "+" if rng.integers(0, 2) == 0 else "-"
+        if strand == "-":
+            s = revcomp(s)
+        kind = k % 10
+        cc, st, en = c, p, p + L - 1
+        if kind == 6:
+            en += 5                                         # one edge agrees
+        elif kind == 7:
+            st += 3; en += 3                                # neither edge
+        elif kind == 8:
+            cc = "chrB" if c == "chrA" else "chrA"          # wrong sequence
+        elif kind == 9:
+            cc = "gnl|UG|" + c                              # three-part name form (never equals the target's name here)
+        reads.append((f"lcl|usimreads|{len(reads) + 1:08d}|{cc}|{st}|{en}|{L}|{strand}|{e}|0|0", s))
+    sfx = os.path.join(tmp, "sim.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "basic", "-T4"], tmp)
+    for tag in ("sim", "mixed"):
+        rd = list(reads)
+        if tag == "mixed":                                  # an accepted read (0 substitutions) in the middle loses its simreads name
+            j = next(i for i in range(300, len(rd)) if rd[i][0].split("|")[8] == "0")
+            rd[j] = ("plainname extra words", rd[j][1])
+        f = os.path.join(tmp, f"{tag}.fa")
+        write_reads(f, rd)
+        gz_copy(f, os.path.join(outdir, f"{tag}.reads.fa.gz"))
+        out = os.path.join(tmp, f"{tag}.sam")
+        log = run([REF, "align", "-i", f, "-I", sfx, "-o", out, "-M6", "-s3", "-T4"], tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.s3.m6.sam.gz"))
+        keep = [line.split("](biokanga) ", 1)[-1].rstrip() for line in log.splitlines()
+                if "accepted alignments" in line or "high confidence aligned simulated reads" in line]
+        with open(os.path.join(outdir, f"{tag}.truthcheck.txt"), "w") as g:
+            g.write("\n".join(keep) + "\n")
+        print("  simreads", tag, keep)
+
+
+def make_csi(tmp):
+    """One sequence of 537 Mbp (> the 512 Mbp a BAI addresses): the reference writes a BGZF-compressed CSI index instead
+    (SAMfile.cpp:1602-1607).  The genome is regenerated from its seed by the test (tests/helpers.py write_big_genome); committed
+    are the reads and the reference's .bam + .bam.csi.  The reference's index build of 538 M suffixes takes a few minutes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    outdir = os.path.join(HERE, "csi")
+    os.makedirs(outdir, exist_ok=True)
+    big = "/dev/shm/bk_csi_golden"
+    os.makedirs(big, exist_ok=True)
+    try:
+        fa = os.path.join(big, "big.fa")
+        seqs = helpers.write_big_genome(fa)
+        rng = np.random.default_rng(99)
+        reads = []
+        comp = np.zeros(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        for k in range(3000):
+            name = "big" if k % 10 else "small"
+            n = len(seqs[name])
+            if name == "big" and k % 3:
+                p = int(rng.integers(536_870_912 - 50, n - 100))          # around and beyond the BAI limit
+            else:
+                p = int(rng.integers(0, n - 100))
+            s = seqs[name][p:p + 100].copy()
+            for q in rng.choice(100, size=int(rng.integers(0, 3)), replace=False):
+                s[q] = b"ACGT"[(b"ACGT".index(s[q]) + 1 + int(rng.integers(0, 3))) % 4]
+            if rng.integers(0, 2):
+                s = comp[s[::-1]]
+            reads.append((f"r{k}_{name}_{p}", s.tobytes().decode()))
+        rd = os.path.join(big, "reads.fa")
+        write_reads(rd, reads)
+        gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+        sfx = os.path.join(big, "big.sfx")
+        run([REF, "index", "-i", fa, "-o", sfx, "-r", "bigcsi", "-T8"], big)
+        out = os.path.join(big, "out_align.bam")
+        log = run([REF, "align", "-i", rd, "-I", sfx, "-o", out, "-M6", "-s3", "-T8"], big)
+        shutil.copyfile(out, os.path.join(outdir, "s3.m6.bam"))
+        shutil.copyfile(out + ".csi", os.path.join(outdir, "s3.m6.bam.csi"))
+        with open(os.path.join(outdir, "s3.nar.txt"), "w") as f:
+            f.write(nar_summary(log))
+        print("  csi fixture written;", [l for l in log.splitlines() if "CSI" in l])
+    finally:
+        shutil.rmtree(big, ignore_errors=True)
 
 
 def main():
@@ -1161,11 +1281,23 @@ def main():
         if "--only-multi-rescue" in sys.argv:
             make_multi_rescue(tmp)
             return
+        if "--only-multi-rescue-n" in sys.argv:
+            make_multi_rescue(tmp, only="xn_")
+            return
         if "--only-snp" in sys.argv:
             make_snp(tmp)
             return
         if "--only-pe" in sys.argv:
             make_pe(tmp)
+            return
+        if "--only-csi" in sys.argv:
+            make_csi(tmp)
+            return
+        if "--only-simreads" in sys.argv:
+            make_simreads(tmp)
+            return
+        if "--only-pe150" in sys.argv:
+            make_pe(tmp, L=150, name="pe150")
             return
         if "--only-pcr" in sys.argv:
             make_pcr(tmp)
@@ -1216,6 +1348,7 @@ def main():
         make_repeat(tmp)
         make_sortorder(tmp)
         make_pe(tmp)
+        make_pe(tmp, L=150, name="pe150")
         make_lengths(tmp)
         make_bam(tmp)
         make_fastq(tmp)
@@ -1230,6 +1363,7 @@ def main():
         make_combined(tmp)
         make_quality(tmp)
         make_pcr(tmp)
+        make_simreads(tmp)
     print("done")
 
 

@@ -466,3 +466,25 @@ def oracle_snp_sites(sfx, bases, offs, alns, chrom_id, min_reads, min_nonref_pro
                                 sites.ctypes.data, max_sites, tot.ctypes.data)
     assert 0 <= n <= max_sites, n
     return sites[:n].copy(), tot
+
+
+# ------------------------------------------------------------------------------------------------
+def write_big_genome(path, big_len=537_000_000, small_len=1_000_000, seed=5377):
+    """FASTA with one sequence beyond the 512 Mbp a BAI index can address ("big") and a small one: i.i.d. bases from a seeded
+    numpy generator, 70 columns.  Used by tests/golden/make_golden.py (reference run, here) and by the GPU test of the CSI
+    index (regenerated there: the file is far too large to commit).  Returns {name: uint8 array of ASCII bases}."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    with open(path, "wb") as f:
+        for name, n in (("big", big_len), ("small", small_len)):
+            seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n, dtype=np.uint8)]
+            out[name] = seq
+            f.write(f">{name}\n".encode())
+            full = n // 70
+            rows = np.empty((full, 71), dtype=np.uint8)
+            rows[:, :70] = seq[: full * 70].reshape(full, 70)
+            rows[:, 70] = 10
+            f.write(memoryview(rows))
+            if n % 70:
+                f.write(seq[full * 70:].tobytes() + b"\n")
+    return out

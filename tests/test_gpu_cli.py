@@ -102,17 +102,20 @@ def test_align_30000_reads_order_byte_identical(golden_tmp, tmp_path):
                                        ("U2", ["-U2", "-d200", "-D400", "-s5"]), ("U4", ["-U4", "-d200", "-D400", "-s5"]),
                                        ("U3dflt", ["-U3", "-s3"]), ("U3wide", ["-U3", "-d150", "-D1500", "-s5"]),
                                        ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"])])
-def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags):
+@pytest.mark.parametrize("fixture", ["pe", "pe150"])
+def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags, fixture):
+    if fixture == "pe150" and tag not in ("U1", "U2", "U3", "U4"):
+        pytest.skip("the 2 x 150 bp fixture holds the four -U modes")
     d = golden_tmp["basic"]
-    pe = os.path.join(helpers.GOLDEN, "pe")
+    pe = os.path.join(helpers.GOLDEN, fixture)
     out = str(tmp_path / "pe.sam")
     run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
          "-o", out, "-M6"] + flags, str(tmp_path))
-    assert open(out, "rb").read() == golden_bytes("pe", f"{tag}.m6.sam.gz")
+    assert open(out, "rb").read() == golden_bytes(fixture, f"{tag}.m6.sam.gz")
     if tag == "U3":
         run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
              "-o", out] + flags, str(tmp_path))
-        assert open(out, "rb").read() == golden_bytes("pe", "U3.m5.sam.gz")
+        assert open(out, "rb").read() == golden_bytes(fixture, "U3.m5.sam.gz")
 
 
 @pytest.mark.parametrize("fixture,name,flags", [
@@ -486,7 +489,10 @@ def test_snp_with_other_modes_byte_identical(golden_tmp, tmp_path, tag, fixture,
 MULTI_RESCUE = [("indel", "xi_r1R5a10", ["-r1", "-R5", "-a10", "-s3", "-M6"], "sam"), ("indel", "xi_r3R5a10", ["-r3", "-R5", "-a10", "-s3", "-M6"], "sam"),
                 ("indel", "xi_r2R5a10", ["-r2", "-R5", "-a10", "-s3", "-M0"], "csv"), ("splice", "xs_r4R5A5000", ["-r4", "-R5", "-A5000", "-s3", "-M6"], "sam"),
                 ("splice", "xs_r3R3XA5000", ["-r3", "-R3", "-X", "-A5000", "-s3", "-M5"], "sam"), ("combined", "xc_r3R3a8A3000", ["-r3", "-R3", "-a8", "-A3000", "-s3", "-M0"], "csv"),
-                ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3", "-M4"], "bed")]
+                ("combined", "xc_r4R8a8A3000", ["-r4", "-R8", "-a8", "-A3000", "-s3", "-M4"], "bed"),
+                # -a / -A together with -N: accepted, LocateBestMatches has no such branches, -A still trims flanks
+                ("indel", "xn_r2R5Na10", ["-r2", "-R5", "-N", "-a10", "-s3", "-M6"], "sam"), ("splice", "xn_r3R4NA5000", ["-r3", "-R4", "-N", "-A5000", "-s3", "-M6"], "sam"),
+                ("combined", "xn_r1R5Na8A3000", ["-r1", "-R5", "-N", "-a8", "-A3000", "-s3", "-M0"], "csv")]
 
 
 @pytest.mark.parametrize("fixture,tag,flags,ext", MULTI_RESCUE)
@@ -543,3 +549,45 @@ def test_align_over_several_contexts_sam_byte_identical(golden_tmp, tmp_path, fi
     assert open(out, "rb").read() == golden_bytes(fixture, name)
     if not pe:
         assert f"reduced over {devices.count(',') + 1} devices" in log
+
+
+@pytest.mark.parametrize("tag", ["sim", "mixed"])
+def test_simreads_truth_check_line(golden_tmp, tmp_path, tag):
+    """the reference's built-in correctness signal (CAligner::ReportAlignStats, Aligner.cpp:3581-3728): reads named by
+    `biokanga simreads` are checked against the loci in their names; the two log lines must be the reference's, and a plainly
+    named accepted read in the set drops the second one, as it does there"""
+    d = golden_tmp["basic"]
+    sim = os.path.join(helpers.GOLDEN, "simreads")
+    out = str(tmp_path / "o.sam")
+    log = run(["align", "-i", os.path.join(sim, f"{tag}.reads.fa.gz"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3"], str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("simreads", f"{tag}.s3.m6.sam.gz")
+    exp = [l for l in open(os.path.join(sim, f"{tag}.truthcheck.txt")).read().split("\n") if l.strip()]
+    got = [l.split("](biokanga) ", 1)[-1].rstrip() for l in log.splitlines()
+           if "accepted alignments" in l or "high confidence aligned simulated reads" in l]
+    assert got == exp
+
+
+def test_bam_gets_a_csi_index_when_a_sequence_reaches_512_mbp(tmp_path):
+    """A BAI cannot address loci beyond 512 Mbp: the reference then writes a BGZF-compressed CSI (CSAMfile::StartAlignments,
+    SAMfile.cpp:1602-1607).  The 537 Mbp genome is regenerated from its seed (tests/helpers.py write_big_genome), indexed by our
+    own `index`, and `align -o x.bam` must give the reference's .bam and .bam.csi byte for byte (fixture: tests/golden/csi, made by
+    the reference from the same genome)."""
+    import shutil
+    import tempfile
+    gold = os.path.join(helpers.GOLDEN, "csi")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (8 << 30) else str(tmp_path)
+    work = tempfile.mkdtemp(prefix="bk_csi_", dir=base)
+    try:
+        fa, sfx, out = os.path.join(work, "big.fa"), os.path.join(work, "big.sfx"), os.path.join(work, "out_align.bam")
+        helpers.write_big_genome(fa)
+        run(["index", "-i", fa, "-o", sfx, "-r", "bigcsi"], work)
+        os.remove(fa)
+        log = run(["align", "-i", os.path.join(gold, "reads.fa.gz"), "-I", sfx, "-o", out, "-M6", "-s3"], work)
+        assert not os.path.exists(out + ".bai")
+        assert open(out, "rb").read() == open(os.path.join(gold, "s3.m6.bam"), "rb").read()
+        assert open(out + ".csi", "rb").read() == open(os.path.join(gold, "s3.m6.bam.csi"), "rb").read()
+        for line in open(os.path.join(gold, "s3.nar.txt")).read().split("\n"):
+            if line.strip():
+                assert line.strip() in log
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

@@ -57,7 +57,7 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
-@pytest.mark.parametrize("knob", [("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
+@pytest.mark.parametrize("knob", [("use_direct", 1), (("use_direct", 1), ("heavy_thresh", 7)), (("use_direct", 1), ("lazy_search", 0)), (("use_direct", 1), ("heavy_thresh", 3)), (("use_direct", 1), ("kmer_bits", 9)), ("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
                                   ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)), ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
                                   (("use_k2", 0), ("lazy_search", 0))])
@@ -239,20 +239,21 @@ def test_repeatable(tmp_path):
                     assert_hits_equal(al.align(bases, offs, lens), ref)
 
 
-from test_oracle_pe import PE_RUNS, pe_inputs, check_pe_hits_against_sam
+from test_oracle_pe import PE_RUNS, ALL_PE_RUNS, pe_cfg, pe_inputs, check_pe_hits_against_sam
 
 
-@pytest.mark.parametrize("tag", list(PE_RUNS))
-def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, tag):
-    """K4: paired-end association + orphan recovery on the GPU vs the reference's PE SAM and the oracle"""
+@pytest.mark.parametrize("fixture,tag", ALL_PE_RUNS)
+def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, fixture, tag):
+    """K4: paired-end association + orphan recovery on the GPU vs the reference's PE SAM and the oracle (2 x 100 bp, and the
+    2 x 150 bp geometry of C3: MaxTotMM 8, 16-mer cores, 9 cores per strand)"""
     bk = _bk()
-    cfg = PE_RUNS[tag]
-    names, bases, offs, lens = pe_inputs(tmp_path)
+    cfg = pe_cfg(fixture, tag)
+    names, bases, offs, lens = pe_inputs(tmp_path, fixture)
     sfx_path = os.path.join(golden_tmp["basic"], "genome.sfx")
     with bk.Aligner(sfx_path, bk.AlignParams(max_subs=cfg["s"])) as al:
         hits = al.align(bases, offs, lens)
         hits = al.pair(bases, offs, lens, hits, bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False)))
-    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"])
+    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"], fixture)
     o = helpers.OracleSfx(sfx_path)
     p = helpers.make_params(max_subs=cfg["s"])
     exp, _ = o.align(bases, offs, lens, p, nthreads=8)
@@ -733,3 +734,99 @@ def test_multi_loci_with_indel_and_splice_match_oracle(golden_tmp, fixture, kw):
                 raise AssertionError(f"seg2 field {f} differs at read {i} ({names[keep[i]]}): got {seg[i]} exp {eseg[i]} hit {got[i]}")
     if (fixture in ("indel", "combined") and kw.get("micro_indel_len")) or (fixture in ("splice", "combined") and kw.get("splice_junct_len")):
         assert np.count_nonzero(eseg["flags"] & 5) > 20
+
+
+def test_pe_with_sparse_entry_ids(golden_tmp, tmp_path):
+    """bk_ctx_create_from_device accepts any EntryID values: with ids (7, 3) instead of (1, 2) every kernel that turns a
+    ChromID back into a sequence - the orphan recovery of the PE pass included - must go through the id map.  Same placements
+    as the file-built context, ChromIDs renamed."""
+    import torch
+    bk = _bk()
+    cfg = PE_RUNS["U3"]
+    names, bases, offs, lens = pe_inputs(tmp_path)
+    sfx_path = os.path.join(golden_tmp["basic"], "genome.sfx")
+    img = np.fromfile(sfx_path, dtype=np.uint8)
+    blk = struct.unpack_from("<Q", img, 44)[0]
+    n = struct.unpack_from("<Q", img, blk + 8)[0]
+    seq = img[blk + 20: blk + 20 + n].copy()
+    sa = img[blk + 20 + n: blk + 20 + 5 * n].view("<u4").copy()
+    pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], False)
+    with bk.Aligner(sfx_path, bk.AlignParams(max_subs=cfg["s"])) as al:
+        ents = al.entries()
+        exp = al.pair(bases, offs, lens, al.align(bases, offs, lens), pe)
+    assert list(ents["entry_id"]) == [1, 2]
+    ren = np.array([0, 7, 3], dtype=np.uint32)
+    ents2 = ents.copy()
+    ents2["entry_id"] = ren[ents["entry_id"]]
+    dev = torch.device("cuda", 0)
+    d_seq, d_sa = torch.from_numpy(seq).to(dev), torch.from_numpy(sa.view(np.int32)).to(dev)
+    with bk.Aligner(None, bk.AlignParams(max_subs=cfg["s"]), d_seq=d_seq.data_ptr(), concat_len=int(n), d_sa=d_sa.data_ptr(), el_size=4,
+                    entries=ents2) as al2:
+        got = al2.pair(bases, offs, lens, al2.align(bases, offs, lens), pe)
+        cnt = al2.seq_counts()
+    want = exp.copy()
+    want["chrom_id"] = ren[exp["chrom_id"]]
+    assert_hits_equal(got, want, names)
+    assert np.array_equal(got["flags"] & 0x80, want["flags"] & 0x80)
+    assert cnt.sum() > 0
+
+
+def _sfx_bytes(golden_tmp):
+    return bytearray(open(os.path.join(golden_tmp["basic"], "genome.sfx"), "rb").read())
+
+
+@pytest.mark.parametrize("what,rc", [("truncated", -85), ("version", -86), ("magic", -94), ("entry_outside", -85), ("concat_wraps", -85),
+                                     ("blk_ofs_wraps", -85), ("missing", -90)])
+def test_corrupt_sfx_files_are_refused_with_the_reference_codes(golden_tmp, tmp_path, what, rc):
+    """.sfx files come from outside: every header field is checked against the mapping before it is used, and the failure comes
+    back as the teBSFrsltCodes value the reference's loader would return (eBSFerrFileAccess -85, eBSFerrFileVer -86,
+    eBSFerrNotBioseq -94, eBSFerrOpnFile -90) - never as a crash or a wild device copy"""
+    bk = _bk()
+    img = _sfx_bytes(golden_tmp)
+    blk = struct.unpack_from("<Q", img, 44)[0]
+    ent = struct.unpack_from("<Q", img, 20)[0]
+    if what == "truncated":
+        img = img[: len(img) // 2]
+    elif what == "version":
+        struct.pack_into("<i", img, 4, 2)
+    elif what == "magic":
+        img[0:4] = b"sfy5"
+    elif what == "entry_outside":
+        struct.pack_into("<Q", img, ent + 8 + 103, 1 << 40)             # EndOfs of the first entry
+    elif what == "concat_wraps":
+        struct.pack_into("<Q", img, blk + 8, (1 << 64) // 5 + 7)         # ConcatSeqLen * (1 + SfxElSize) wraps to a small number
+    elif what == "blk_ofs_wraps":
+        struct.pack_into("<Q", img, 44, (1 << 64) - 8)                   # SfxBlockOfs + header size wraps
+    p = str(tmp_path / "bad.sfx")
+    if what != "missing":
+        open(p, "wb").write(img)
+    with pytest.raises(bk.BkError) as e:
+        bk.Aligner(p, bk.AlignParams(max_subs=3))
+    assert e.value.rc == rc
+
+
+def test_small_chunks_forced_by_memory_pressure(golden_tmp):
+    """the chunk size follows the HBM that is free (align_device): with nearly all of it taken a batch runs in several chunks
+    (65 536 reads is the floor) and must give the results of the one-chunk run"""
+    import ctypes
+    import torch
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    offs, lens = offs[keep], lens[keep]
+    reps = 200_000 // len(lens) + 1
+    offs_r, lens_r = np.tile(offs, reps), np.tile(lens, reps)
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align(bases, offs_r, lens_r)
+        al.close()
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        free, _total = torch.cuda.mem_get_info(0)
+        hog = torch.empty(max(0, free - (220 << 20)), dtype=torch.uint8, device="cuda:0")      # leaves ~0.2 GB: half of it / 784 B per read < n
+        free2, _ = torch.cuda.mem_get_info(0)
+        try:
+            got = al.align(bases, offs_r, lens_r)
+        finally:
+            del hog
+            torch.cuda.empty_cache()                # or PyTorch's caching allocator keeps the HBM from the tests that follow
+    assert free2 < (300 << 20)
+    assert_hits_equal(got, ref)
+    assert len(lens_r) * 784 > free2 // 2          # the batch could not have fitted one chunk

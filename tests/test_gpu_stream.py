@@ -109,11 +109,12 @@ def test_stream_multi_loci_lists_travel_with_their_batch(golden_tmp):
     assert np.array_equal(np.concatenate(got_loci), rl)
 
 
-def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path):
-    from test_oracle_pe import PE_RUNS, pe_inputs, check_pe_hits_against_sam
+@pytest.mark.parametrize("fixture", ["pe", "pe150"])
+def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path, fixture):
+    from test_oracle_pe import pe_cfg, pe_inputs, check_pe_hits_against_sam
     bk = _bk()
-    cfg = PE_RUNS["U3"]
-    names, bases, offs, lens = pe_inputs(tmp_path)
+    cfg = pe_cfg(fixture, "U3")
+    names, bases, offs, lens = pe_inputs(tmp_path, fixture)
     cb = _contiguous(bases, offs, lens)
     coffs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
     n = len(lens)
@@ -134,7 +135,7 @@ def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path)
                 st.submit(cb[:int(lens[0])].copy(), None, lens[:1].copy(), out[:1])
     for f in FIELDS + ["flags"]:
         assert np.array_equal(out[f], ref[f]), f
-    check_pe_hits_against_sam(names, out, "U3", ["chrA", "chrB"])
+    check_pe_hits_against_sam(names, out, "U3", ["chrA", "chrB"], fixture)
 
 
 def test_seq_counts_allreduce_over_contexts(golden_tmp):

@@ -15,15 +15,25 @@ PE_RUNS = {
 }
 
 
-def pe_inputs(tmp_path):
+# C3 of SURVEY.md 8(d): 2 x 150 bp (MaxTotMM 8, 16-mer cores, 9 cores per strand) through AlignPairedRead's window scan
+PE150_RUNS = {"U3": dict(pe=3, d=200, D=400, s=5), "U1": dict(pe=1, d=200, D=400, s=5), "U2": dict(pe=2, d=200, D=400, s=5),
+              "U4": dict(pe=4, d=200, D=400, s=5)}
+ALL_PE_RUNS = [("pe", t) for t in PE_RUNS] + [("pe150", t) for t in PE150_RUNS]
+
+
+def pe_cfg(fixture, tag):
+    return (PE_RUNS if fixture == "pe" else PE150_RUNS)[tag]
+
+
+def pe_inputs(tmp_path, fixture="pe"):
     r1, r2 = str(tmp_path / "r1.fa"), str(tmp_path / "r2.fa")
-    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_1.fa.gz"), r1)
-    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "pe", "reads_2.fa.gz"), r2)
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, fixture, "reads_1.fa.gz"), r1)
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, fixture, "reads_2.fa.gz"), r2)
     return helpers.interleave_pe(r1, r2)
 
 
-def check_pe_hits_against_sam(names, hits, tag, chrom_names):
-    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "pe", f"{tag}.m6.sam.gz"))
+def check_pe_hits_against_sam(names, hits, tag, chrom_names, fixture="pe"):
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, fixture, f"{tag}.m6.sam.gz"))
     by = {r["qname"]: r for r in recs}
     assert len(by) == len(recs) == len(names)
     bad = []
@@ -38,17 +48,17 @@ def check_pe_hits_against_sam(names, hits, tag, chrom_names):
     assert not bad, (len(bad), bad[:8])
 
 
-@pytest.mark.parametrize("tag", list(PE_RUNS))
-def test_oracle_pe_matches_reference(golden_tmp, tmp_path, tag):
-    cfg = PE_RUNS[tag]
-    names, bases, offs, lens = pe_inputs(tmp_path)
+@pytest.mark.parametrize("fixture,tag", ALL_PE_RUNS)
+def test_oracle_pe_matches_reference(golden_tmp, tmp_path, fixture, tag):
+    cfg = pe_cfg(fixture, tag)
+    names, bases, offs, lens = pe_inputs(tmp_path, fixture)
     o = helpers.OracleSfx(os.path.join(golden_tmp["basic"], "genome.sfx"))
     p = helpers.make_params(max_subs=cfg["s"])
     hits, _ = o.align(bases, offs, lens, p, nthreads=8)
     helpers.oracle_process_pe(o, p, cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False), bases, offs, lens, hits)
-    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"])
+    check_pe_hits_against_sam(names, hits, tag, ["chrA", "chrB"], fixture)
     exp = {}
-    with open(os.path.join(helpers.GOLDEN, "pe", f"{tag}.nar.txt")) as f:
+    with open(os.path.join(helpers.GOLDEN, fixture, f"{tag}.nar.txt")) as f:
         for line in f:
             t = line.split()
             exp[t[1].strip("()")] = int(t[0])
