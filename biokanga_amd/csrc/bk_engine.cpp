@@ -655,7 +655,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         uint32_t n_ext = n_act;
         if (cmax > 0) {
             const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
-            const bool direct = c->use_direct && c->ix.k2 && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100;
+            const bool direct = c->use_direct && c->ix.k2 && c->d_sa_hi == nullptr && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100;
             hipEvent_t e1 = tm.begin(s);
             if (c->ix.k2) {
                 const uint64_t lanes = (uint64_t)n_act * (uint64_t)(cmax * nstr);

@@ -1370,6 +1370,10 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
     __shared__ uint16_t s_len[256], s_cl[256], s_cd[256];
     __shared__ uint8_t s_nc[256];
     __shared__ uint8_t s_rec[kFlatCap];
+    // 5-byte indexes: the reference's set of seen targets is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), so a
+    // candidate whose start lies a multiple of 2^32 bases from an earlier candidate of the same strand pass is taken for seen and
+    // skipped.  The low words travel with the result bytes and the replay applies exactly that rule.
+    __shared__ uint32_t s_key[WIDE ? kFlatCap : 1];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
@@ -1488,6 +1492,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
                 bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
                 for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
                 if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
+                if (WIDE) s_key[f] = (uint32_t)t0;
             }
             s_rec[f] = rec;
         }
@@ -1497,13 +1502,19 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             const uint32_t rb = s_off[t] - base;
             const int nslots = (s1 - s0 + 1) * nc;
             bool done = false;
-            uint32_t prev = 0;
+            uint32_t prev = 0, strand_first = 0;
             for (int q = 0; q < nslots && !done; q++) {
                 n_search++;
+                if (WIDE && q == nc) strand_first = prev;                   // the second strand pass starts with an empty set
                 const uint32_t upto = sp[q];
                 for (uint32_t x = prev; x < upto; x++) {
                     const int cm = s_rec[rb + x];
                     if (cm == kRecSkip) continue;
+                    if (WIDE) {
+                        bool seen = false;
+                        for (uint32_t y = strand_first; y < x; y++) seen |= s_rec[rb + y] != kRecSkip && s_key[rb + y] == s_key[rb + x];
+                        if (seen) continue;
+                    }
                     n_cand++;
                     if (cm > mm || cm >= nxt) continue;
                     if (cm < low_mm) {
@@ -1884,6 +1895,23 @@ __device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t ma
     }
 }
 
+// 5-byte indexes only: two candidates of one 64-candidate round whose target starts lie a multiple of 2^32 bases apart carry the
+// same truncated key (SfxArrayV2.cpp:5932).  The reference, walking them one after the other, takes the later one for seen; the
+// hash set is only consulted for what EARLIER rounds left in it, so the round is checked against itself here.
+__device__ __forceinline__ bool same_key_earlier_in_round(bool cand, uint32_t key, int lane)
+{
+    bool dup = false;
+    uint64_t vm = __ballot(cand);
+    if (__popcll(vm) > 1)
+        while (vm) {
+            const int l = __ffsll((unsigned long long)vm) - 1;
+            vm &= vm - 1;
+            const uint32_t k2 = __shfl(key, l);
+            dup |= cand && lane > l && key == k2;
+        }
+    return dup;
+}
+
 constexpr int kWaveGrab = 8;
 
 struct WaveCoreInfo {
@@ -2037,8 +2065,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     }
                     bool dup = false;
                     const uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
-                    if (HASH) dup = valid && htab_contains(tab, tmask, epoch, key);
-                    else for (int c2 = 0; c2 < c; c2++) {
+                    if (HASH) {
+                        dup = valid && htab_contains(tab, tmask, epoch, key);
+                        if (WIDE) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
+                    } else for (int c2 = 0; c2 < c; c2++) {
                         bool m = valid && !dup && core_clean<NW>(w, core[c2].ofs, cl);
                         if (__ballot(m)) {
                             if (m) {
@@ -2435,6 +2465,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     }
                     uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
                     bool isnew = valid && !htab_contains(tab, tmask, epoch, key);
+                    if (WIDE) isnew = isnew && !same_key_earlier_in_round(isnew, key, lane);
                     uint64_t newmask = __ballot(isnew);
                     uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
                     uint32_t iter_before = iter + pre;
