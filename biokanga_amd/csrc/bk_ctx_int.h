@@ -56,6 +56,11 @@ struct bk_ctx {
                              //    carry the window registers through the search - 160 VGPRs, 3 waves/SIMD against k_search_a's 31 / 8 - and
                              //    run four dependent random loads back to back)
     uint32_t *d_gen = nullptr;            // reads k_direct hands on to pass B + k_flat / k_wave
+    uint32_t *d_gen2 = nullptr;           // reads k_replay hands on to k_flat
+    int use_eval = 0;        // 1: k_eval + k_replay for the reads whose intervals are all <= 8 suffixes (4-byte indexes), k_flat for the rest.
+                             //    Off: measured on C2 the two streaming launches take 27.9 + 20.8 ms/step (+ 3.5 ms of k_flat for what they leave)
+                             //    against k_flat's 21 ms for everything: only ~30 % of k_eval's lanes own a candidate, k_flat packs one per lane
+    uint64_t *d_rec8 = nullptr;           // their hand-over: 8 result bytes per interval slot
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified

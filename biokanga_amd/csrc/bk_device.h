@@ -73,6 +73,7 @@ struct DevBatch {
     uint64_t *iv_first;         // core intervals [strand][core][read]: start (suffix array index) ...
     uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
     uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null
+    uint64_t *rec8;             // k_eval -> k_replay: up to 8 result bytes per slot, laid out like iv2; may be null
     bk_hit *out;
     unsigned long long *seq_counts;   // per entry accepted reads
     unsigned long long *ctr;          // [0] n_search [1] n_cand [2] n_lcm [3] n_heavy

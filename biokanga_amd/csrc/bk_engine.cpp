@@ -56,6 +56,11 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
                  int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
                  hipStream_t s);
+void launch_eval(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
+                 int nw, hipStream_t s);
+void launch_replay(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, uint32_t *next_act,
+                   uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt, uint32_t *flat, uint32_t *flat_cnt,
+                   uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
                    int lazy, uint32_t *slist, uint32_t *slist_cnt, uint32_t *general, uint32_t *general_cnt, uint32_t *next_act, uint32_t *next_cnt,
                    uint32_t *cmax_next, int nw, hipStream_t s);
@@ -410,8 +415,9 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen);
-    c->d_gen = nullptr;
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8);
+    c->d_gen = c->d_gen2 = nullptr;
+    c->d_rec8 = nullptr;
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     c->cap_reads = 0;
@@ -428,6 +434,8 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_gen, (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_gen2, (size_t)nr * 4));
+    if (c->d_iv2 && c->use_eval) HIP_TRY(hipMalloc(&c->d_rec8, (size_t)nr * 2 * kMaxCoresFast * 8));
     c->cap_reads = nr;
     c->cap_wpr = w;
     c->cap_rd2w = w2;
@@ -501,7 +509,7 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
 static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
 {
-    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 12 + 5 * 4;
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 6 * 4;
 }
 
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
@@ -625,6 +633,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
+    b.rec8 = c->d_rec8;
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
@@ -647,9 +656,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         n_act = 0;
     }
     for (int phase = 0; n_act > 0; phase++) {
-        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list, [9] general list
+        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list, [9] general list, [10] k_flat list of k_replay
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
-        HIP_TRY(hipMemsetAsync(sm + 6, 0, 4 * 4, s));
+        HIP_TRY(hipMemsetAsync(sm + 6, 0, 5 * 4, s));
         // the reads the extend kernels see: all active ones, or - after k_direct - those it did not finish itself
         const uint32_t *ext_list = c->d_act[cur];
         uint32_t n_ext = n_act;
@@ -701,6 +710,19 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             tm.end(0, e1, s);
         }
         hipEvent_t e2 = tm.begin(s);
+        // k_flat cut into two streaming launches for the reads whose intervals are all small (k_eval, k_replay); what they leave
+        // (an interval of 9 .. heavy_thresh suffixes) is k_flat's.  4-byte indexes, after the two-pass search.
+        if (n_ext && cmax > 0 && c->use_eval && b.rec8 && c->ix.k2 && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) {
+            launch_eval(c->ix, c->cfg, b, ext_list, n_ext, phase, cmax, nstr, nw16, s);
+            uint32_t *flat_list = ext_list == c->d_gen ? c->d_gen2 : c->d_gen;
+            launch_replay(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6, flat_list, sm + 10,
+                          sm + 3, nw16, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(hm + 10, sm + 10, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            ext_list = flat_list;
+            n_ext = hm[10];
+        }
         if (n_ext == 0) {}
         else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
             launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
@@ -1012,7 +1034,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_small);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_small);
     free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
@@ -1081,6 +1103,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->use_isa = value ? 1 : 0;
         int rc = build_isa(c);
         return rc ? rc : old;
+    }
+    if (n == "use_eval") {
+        int64_t old = c->use_eval;
+        c->use_eval = value ? 1 : 0;
+        if (c->use_eval && !c->d_rec8) c->cap_reads = 0;          // the result-word array is allocated with the batch scratch
+        return old;
     }
     if (n == "use_direct") {
         int64_t old = c->use_direct;

@@ -1603,6 +1603,208 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_eval + k_replay: k_flat cut into two streaming launches, for the reads whose core intervals all hold <= kEvalMax suffixes
+// (the great majority; k_flat keeps the rest).  k_flat does everything for 256 reads inside one block - count, prefix sums, one
+// candidate per lane, replay - with four block barriers and ~100 VGPRs: its waves spend their life waiting on each other and on
+// a chain of dependent loads at 4 waves/SIMD.  Here
+//   k_eval    one lane per (read, strand, core): the slot's interval record, then its few candidates one after the other - suffix
+//             array element, window compare (k_flat's evaluation, same result bytes) - packed into ONE 8-byte word per slot
+//             (DevBatch::rec8, laid out like the interval records so that neighbouring reads touch neighbouring words)
+//   k_replay  one lane per read: the slots' counts and result words in walk order (strand, core, suffix) through the Low / NxtLow /
+//             instances state machine; result record, next phase's list, or - a slot above kEvalMax / heavy_thresh - the list k_flat
+//             or k_wave continue from
+// No barrier, no LDS candidate table; the hand-over costs 8 bytes per slot of coalesced traffic.
+constexpr uint32_t kEvalMax = 8;
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_eval(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act, int phase,
+                                              int cmax, int nstr)
+{
+    // slot-major: neighbouring lanes work on neighbouring reads of ONE (strand, core), so that the interval records and the
+    // result words - both laid out [strand][core][read] - are touched a line at a time (a block = 256 reads of one slot)
+    const uint32_t rblocks = (n_act + 255) / 256;
+    const uint32_t q = blockIdx.x / rblocks;
+    const uint32_t a = (blockIdx.x - q * rblocks) * 256 + threadIdx.x;
+    if (a >= n_act) return;
+    const int si = (int)(q / (uint32_t)cmax), c = (int)(q % (uint32_t)cmax);
+    const uint32_t r = act[a];
+    const int strand = cfg.align_strand == 2 ? 1 : si;
+    const uint64_t slot = iv_slot(b, r, strand, c);
+    uint64_t first;
+    uint32_t nraw;
+    iv_get(b, slot, first, nraw);                  // slots beyond the read's own cores hold stale records: looked at only after the plan says c < nc
+    const int len = (int)b.lens[r];
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd, dummy[1];
+    phase_params(p, cfg, phase, mm, cl, cd);
+    const int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+    if (c >= nc || nc > kMaxCoresFast || len > 16 * NW) return;
+    const uint32_t n = nraw & ~kLazyFlag;
+    if (n == 0 || n > kEvalMax) return;
+    const bool lazy = (nraw & kLazyFlag) != 0;
+    const int last = len - cl;
+    const int ofs = c * cd < last ? c * cd : last;
+    uint64_t r2w[NW / 2], rnm[NW / 4], rw[NW];
+    const bool two_bit = b.rd2 != nullptr;
+    bool have_rw = false;
+    if (two_bit) load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + strand) * (3 * NW / 4), r2w, rnm);
+    uint64_t word = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        const uint64_t loci = sa_get<false>(ix, first + j);
+        uint32_t rec = kRecSkip;
+        if (loci >= (uint64_t)ofs) {
+            const uint64_t t0 = loci - (uint64_t)ofs;
+            Window<NW> w;
+            bool flg = true;
+            if (two_bit) {
+                flg = window_flagged(ix, t0, len);
+                eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t0, w);
+            }
+            if (flg) {                                                   // N/EOS nearby (rare): the 4-bit copy decides
+                if (!have_rw) { load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr, len, rw); have_rw = true; }
+                eval_window<NW>(rw, len, ix.tgt4, t0, w);
+            }
+            bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, cl));
+            for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * cd, cl);      // earlier cores never sit at the clipped offset
+            if (!skip) rec = (uint32_t)(w.mm < 127 ? w.mm : 127);
+        }
+        word |= (uint64_t)rec << (8 * j);
+    }
+    b.rec8[slot] = word;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_replay(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act, int phase,
+                                                uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
+                                                uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave, uint32_t *__restrict__ wave_cnt,
+                                                uint32_t *__restrict__ flat, uint32_t *__restrict__ flat_cnt, uint32_t *__restrict__ cmax_next)
+{
+    __shared__ uint32_t s_cnt[5], s_base[5], s_cmax;
+    __shared__ unsigned long long s_ctr[3];
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63;
+    if (t < 5) s_cnt[t] = 0;
+    if (t == 5) s_cmax = 0;
+    if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
+    __syncthreads();
+    const uint32_t a = blockIdx.x * blockDim.x + t;
+    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel, 4 = k_flat
+    uint32_t r = 0, my_cmax = 0;
+    if (a < n_act) {
+        r = act[a];
+        const int len = (int)b.lens[r];
+        ReadPlan p = make_plan(len, cfg);
+        int mm, cl, cd, dummy[1];
+        phase_params(p, cfg, phase, mm, cl, cd);
+        const int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+        const bool fits = nc <= kMaxCoresFast && len <= 16 * NW;
+        if (!fits) dest = 3;
+        else {
+            uint32_t biggest = 0;
+            for (int st = s0; st <= s1; st++)
+                for (int c = 0; c < nc; c++) {
+                    const uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
+                    biggest = cnt > biggest ? cnt : biggest;
+                }
+            if (biggest > (uint32_t)cfg.heavy_thresh) dest = wave != nullptr ? 2 : 3;
+            else if (biggest > kEvalMax) dest = 4;
+            else {
+                n_lcm = 1;
+                const int init = mm + cfg.mm_delta + 1;
+                int low_inst = 0, low_mm = init, nxt = init;
+                int best_c = 0, best_st = 0;
+                uint32_t best_j = 0;
+                uint64_t best_first = 0;
+                bool done = false;
+                for (int st = s0; st <= s1 && !done; st++)
+                    for (int c = 0; c < nc && !done; c++) {
+                        n_search++;
+                        const uint64_t slot = iv_slot(b, r, st, c);
+                        uint64_t first;
+                        uint32_t nraw;
+                        iv_get(b, slot, first, nraw);
+                        const uint32_t n = nraw & ~kLazyFlag;
+                        if (!n) continue;
+                        const uint64_t word = b.rec8[slot];
+                        for (uint32_t x = 0; x < n; x++) {
+                            const int cm = (int)((word >> (8 * x)) & 0xff);
+                            if (cm == kRecSkip) continue;
+                            n_cand++;
+                            if (cm > mm || cm >= nxt) continue;
+                            if (cm < low_mm) {
+                                low_inst = 1; nxt = low_mm; low_mm = cm;
+                                best_c = c; best_st = st; best_j = x; best_first = first;
+                            } else if (cm == low_mm)
+                                low_inst++;
+                            else
+                                nxt = cm;
+                            if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
+                        }
+                    }
+                const int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+                if (rslt != BK_HR_NONE) {
+                    uint64_t hit_left = 0;
+                    int hit_strand = '?', e = -1;
+                    if (low_inst >= 1) {
+                        const int last = len - cl;
+                        const int ofs = best_c * cd < last ? best_c * cd : last;
+                        hit_left = sa_get<false>(ix, best_first + best_j) - (uint64_t)ofs;
+                        hit_strand = best_st ? '-' : '+';
+                        e = find_entry(ix, hit_left);
+                    }
+                    write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
+                } else if (phase + 1 < p.n_phases) {
+                    int mm2, cl2, cd2;
+                    phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+                    const int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+                    if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
+                    dest = 1;
+                }
+            }
+        }
+    }
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_search += __shfl_down(n_search, off);
+        n_cand += __shfl_down(n_cand, off);
+        n_lcm += __shfl_down(n_lcm, off);
+        uint32_t m = __shfl_down(my_cmax, off);
+        my_cmax = m > my_cmax ? m : my_cmax;
+    }
+    uint32_t my_off = 0;
+#pragma unroll
+    for (int d = 1; d <= 4; d++) {
+        uint64_t m = __ballot(dest == d);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
+        }
+    }
+    if (lane == 0) {
+        if (my_cmax) atomicMax(&s_cmax, my_cmax);
+        if (n_search) atomicAdd(&s_ctr[0], n_search);
+        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
+        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
+    }
+    __syncthreads();
+    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
+    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
+    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
+    if (t == 4 && s_cnt[4]) s_base[4] = atomicAdd(flat_cnt, s_cnt[4]);
+    if (t == 5 && s_cmax) atomicMax(cmax_next, s_cmax);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    __syncthreads();
+    if (dest == 1) next_act[s_base[1] + my_off] = r;
+    else if (dest == 2) wave[s_base[2] + my_off] = r;
+    else if (dest == 3) heavy[s_base[3] + my_off] = r;
+    else if (dest == 4) flat[s_base[4] + my_off] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_direct: pass A of the two-pass search (exactly k_search_a: one lane per active read, strand and core) and, for the reads
 // whose EVERY core it settles with a handful of candidates, the rest of the LocateCoreMultiples call in the same launch: the
 // lane that located a core's few suffixes evaluates them itself (suffix array element, window compare, one result byte in LDS
@@ -3700,6 +3902,26 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (nw <= 8) { if (wide) BK_FLAT(true, 8); else BK_FLAT(false, 8); }
     else { if (wide) BK_FLAT(true, 16); else BK_FLAT(false, 16); }
 #undef BK_FLAT
+}
+
+void launch_eval(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
+                 int nw, hipStream_t s)
+{
+    const uint64_t nblk = (uint64_t)((n_act + 255) / 256) * (uint64_t)(cmax * nstr);      // 256 reads x one (strand, core) per block
+    const unsigned blocks = (unsigned)nblk;
+    if (!blocks) return;
+    if (nw <= 8) hipLaunchKernelGGL((k_eval<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
+    else hipLaunchKernelGGL((k_eval<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
+}
+
+void launch_replay(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, uint32_t *next_act,
+                   uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt, uint32_t *flat, uint32_t *flat_cnt,
+                   uint32_t *cmax_next, int nw, hipStream_t s)
+{
+    const unsigned blocks = (n_act + 255) / 256;
+    if (!blocks) return;
+    if (nw <= 8) hipLaunchKernelGGL((k_replay<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, flat, flat_cnt, cmax_next);
+    else hipLaunchKernelGGL((k_replay<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, flat, flat_cnt, cmax_next);
 }
 
 void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1028,10 +1029,63 @@ int cmd_align(int argc, char **argv, int first)
     return rr;
 }
 
+
+// CUtility::arg_parsefromfile (libbiokanga/Utility.cpp:793-910; called first thing by every sub-process, kanga.cpp:298): an argument
+// "@file" is replaced by the options found in that file - one or more per line, separated by blanks or tabs except inside quotes
+// (the quote characters stay part of the option, as they do there); empty lines and lines starting with '#', ';' or "//" are skipped
+bool expand_param_files(int argc, char **argv, std::vector<std::string> &out)
+{
+    for (int i = 0; i < argc; i++) {
+        if (argv[i][0] != '@') { out.push_back(argv[i]); continue; }
+        std::string fn = argv[i] + 1;
+        while (!fn.empty() && isspace((unsigned char)fn.back())) fn.pop_back();
+        size_t b0 = 0;
+        while (b0 < fn.size() && isspace((unsigned char)fn[b0])) b0++;
+        fn = fn.substr(b0);
+        FILE *f = fn.empty() ? nullptr : fopen(fn.c_str(), "r");
+        if (!f) { printf("Unable to open options file '%s'\nError: %s", fn.c_str(), strerror(errno)); return false; }
+        char line[8192];
+        while (fgets(line, sizeof(line), f)) {
+            std::string l = line;
+            while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();
+            size_t a = 0;
+            while (a < l.size() && isspace((unsigned char)l[a])) a++;
+            l = l.substr(a);
+            if (l.empty() || l[0] == '#' || l[0] == ';' || (l[0] == '/' && l.size() > 1 && l[1] == '/')) continue;
+            std::string opt;
+            bool in_quotes = false, in_param = false;
+            for (size_t k = 0; k <= l.size(); k++) {
+                char ch = k < l.size() ? l[k] : '\0';
+                if (ch == 0x16) ch = '-';
+                if (ch == '"' || ch == '\'') { in_quotes = !in_quotes; in_param = true; opt.push_back(ch); continue; }
+                if ((ch == ' ' || ch == '\t') && in_quotes) { opt.push_back(ch); continue; }
+                if (ch == ' ' || ch == '\t' || ch == '\0') {
+                    if (!in_param && ch != '\0') continue;
+                    out.push_back(opt);
+                    opt.clear();
+                    in_quotes = in_param = false;
+                    continue;
+                }
+                in_param = true;
+                opt.push_back(ch);
+            }
+        }
+        fclose(f);
+    }
+    return true;
+}
+
 }  // namespace
 
-int main(int argc, char **argv)
+int main(int argc_in, char **argv_in)
 {
+    std::vector<std::string> expanded;
+    if (!expand_param_files(argc_in, argv_in, expanded)) return 1;
+    std::vector<char *> argv_vec;
+    for (std::string &a : expanded) argv_vec.push_back(&a[0]);
+    argv_vec.push_back(nullptr);
+    const int argc = (int)expanded.size();
+    char **argv = argv_vec.data();
     // gszProcName: basename of argv[0] without extension (biokanga.cpp:236-246)
     std::string p = argv[0];
     size_t sl = p.find_last_of('/');

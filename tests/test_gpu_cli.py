@@ -591,3 +591,14 @@ def test_bam_gets_a_csi_index_when_a_sequence_reaches_512_mbp(tmp_path):
                 assert line.strip() in log
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_options_from_a_parameter_file(golden_tmp, tmp_path):
+    """`@file` arguments are replaced by the options in the file (CUtility::arg_parsefromfile, kanga.cpp:298): comment lines,
+    several options per line, mixed with ordinary arguments"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "o.sam")
+    pf = tmp_path / "align.params"
+    pf.write_text(f"# reads and index\n-i {os.path.join(d, 'reads.fa')}   -I {os.path.join(d, 'genome.sfx')}\n; output\n\n// format\n-M6\t-s3\n")
+    run(["align", f"@{pf}", "-o", out], str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
