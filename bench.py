@@ -337,6 +337,60 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def live_traffic(kernel, extra_args, budget_s=240):
+    """HBM bytes per launch of `kernel`, OBSERVED in this run: two child processes repeat one step of the same workload under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only - MI355X_MICROARCH.md's
+    recipe; KiB units; no 1/2 correction: calibrated at 64.0 B per random 8-byte load and 96 B per 80-byte window in this path's own
+    access patterns, profiles/*_fetch_calibration.csv).  Children, not an exec: this process has initialised the GPU.
+    Returns (bytes of the whole step, description) or (None, reason)."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    members = {"k_search": ("k_search_a", "k_search_b"), "k_wave": ("k_wave",), "k_flat": ("k_flat",)}[kernel]
+    tot = 0.0
+    launches = None
+    tmp = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"] + extra_args
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=budget_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} child exited with {r.returncode}"
+            files = [os.path.join(dp, f) for dp, _dn, fn in os.walk(d) for f in fn if f.endswith("_counter_collection.csv")]
+            if not files:
+                return None, "no counter_collection.csv written"
+            per = {m: [0.0, 0] for m in members}
+            seen = set()
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    m = re.search(r"bk::(k_\w+)", row["Kernel_Name"])
+                    key = (row["Process_Id"], row["Dispatch_Id"])
+                    if m and m.group(1) in per and row["Counter_Name"] == counter and key not in seen:
+                        seen.add(key)
+                        per[m.group(1)][0] += float(row["Counter_Value"])
+                        per[m.group(1)][1] += 1
+            log(f"live traffic: {counter}: files {len(files)}, " + ", ".join(f"{k}: {v[1]} launches, {v[0] * 1024 / 1e9:.1f} GB" for k, v in per.items()))
+            if any(v[1] == 0 for v in per.values()):
+                return None, f"kernel {kernel} not in the {counter} pass"
+            tot += sum(v[0] for v in per.values()) * 1024.0          # the whole step: the child may cut the batch into more chunks
+            launches = per[members[0]][1]                            # (it shares the HBM with this process), so per-launch follows below
+            log(f"live traffic: {counter} pass {time.time() - t0:.0f}s, {launches} launches of {members[0]}")
+        return tot, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of ONE step of this workload ({launches} launches there); "
+                     f"bytes of that step divided by this run's launches per step")
+    except Exception as e:
+        return None, f"live counter passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def profiled_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB units,
@@ -445,6 +499,8 @@ def main():
                     help="reads given to the real reference binary (oracle/_ref/biokanga) in the cpu_baseline leg; 0 = port only. "
                          "Kept at 2 M: the reference's loader hand-off breaks when loading takes > 3 s (Aligner.cpp:4822) - "
                          "3 M reads crash it on the MI355X host about every other run (tools/ref_scaling.py)")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) one step only, nothing reported: what the live counter passes profile")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
     ap.add_argument("--stream-steps", type=int, default=5, help="steps of the host-resident leg (bk_stream_*: host buffers in -> host "
                                                                 "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
@@ -457,6 +513,8 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
     ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
     args = ap.parse_args()
+    if args.pmc_child:
+        args.steps, args.warmup, args.cpu_baseline_secs, args.stream_steps, args.no_live_traffic = 1, 0, 0.0, 0, True
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -632,7 +690,19 @@ def main():
     ach = kern[dom]["GBs"]
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
     default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
-    traffic, traffic_src = profiled_traffic(dom) if default_workload else (None, None)
+    traffic, traffic_src = (None, None)
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        child_args = ["--config", args.config, "--reads", str(args.reads), "--genome-mbp", str(args.genome_mbp)] + \
+                     [x for kv in args.tune for x in ("--tune", kv)]
+        traffic, traffic_src = live_traffic(dom, child_args)
+        if traffic is None:
+            log(f"live traffic unavailable: {traffic_src}")
+        else:
+            traffic /= max(1.0, kern[dom]["launches"] / max(1, args.steps))
+    if traffic is None and default_workload:
+        traffic, traffic_src = profiled_traffic(dom)
+        if traffic_src:
+            traffic_src = f"committed profile {traffic_src} (not observed in this run)"
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, kern[dom]["launches"]),
