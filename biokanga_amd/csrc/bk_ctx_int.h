@@ -48,6 +48,10 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int use_hp = 0;          // prefix hash in front of k-mer table + keys (one line per search instead of two or three).  Off: measured on
+                             //    C2 it cuts k_search_a's HBM fetches by a third (14.9 -> 10.2 GB per launch) and its time by nothing (6.6 ms
+                             //    against 6.45), k_search_b gets 15 % slower, and it costs 34 GB + 0.24 s at load
+    uint64_t *d_hp = nullptr;
     uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)

@@ -53,6 +53,8 @@ struct DevIndex {
     const uint64_t *ktab64;
     const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
+    const uint64_t *hp;         // prefix hash: distinct hp_k-base prefixes of the suffixes -> their suffix array interval, 64-byte buckets
+    int hp_bits, hp_k;          //   of 8 entries {tag 21 | displacement 3 | count 8 | interval start 32}; 2^hp_bits buckets; may be null
     uint64_t n;                 // concat_len
     uint32_t n_ent;
     int k;                      // k-mer table order (0 = none)

@@ -41,6 +41,7 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s);
 void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
@@ -231,6 +232,44 @@ int build_k2(bk_ctx *c)
     return BK_OK;
 }
 
+// prefix hash over the distinct hp_k-base prefixes of the suffixes (DevIndex::hp; bk_kernels.hip).  4-byte indexes with the two-pass
+// search; skipped when it would not leave a quarter of the HBM free; dropped again should an entry not find a slot within 8 buckets
+int build_hp(bk_ctx *c)
+{
+    free_dev(c->d_hp);
+    c->d_hp = nullptr;
+    c->ix.hp = nullptr;
+    c->ix.hp_bits = c->ix.hp_k = 0;
+    if (!c->use_hp || !c->ix.k2 || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
+    int bits = 16;
+    while (bits < 30 && (5ULL << bits) < c->ix.n) bits++;          // <= 5 entries per 8-slot bucket on average
+    const int k = std::min(24, (bits + 21) / 2);
+    const uint64_t bytes = 64ULL << bits;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (bytes > free_b || free_b - bytes < total_b / 4) return BK_OK;
+    HIP_TRY(hipMalloc(&c->d_hp, bytes));
+    launch_fill_u64((unsigned long long *)c->d_hp, bytes / 8, ~0ULL, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
+    launch_build_hp(c->ix, (unsigned long long *)c->d_hp, bits, k, c->d_ctr + 7, c->stream);
+    HIP_TRY(hipGetLastError());
+    unsigned long long failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, c->d_ctr + 7, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
+    if (failed) {
+        fprintf(stderr, "biokanga_amd: prefix hash: %llu prefixes found no slot; the table is not used\n", failed);
+        free_dev(c->d_hp);
+        c->d_hp = nullptr;
+        return BK_OK;
+    }
+    c->ix.hp = c->d_hp;
+    c->ix.hp_bits = bits;
+    c->ix.hp_k = k;
+    return BK_OK;
+}
+
 int build_isa(bk_ctx *c)
 {
     free_dev(c->d_isa);
@@ -357,6 +396,8 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     clk.lap("k-mer table");
     if (!rc) rc = build_k2(c);
     clk.lap("second-level keys");
+    if (!rc) rc = build_hp(c);
+    clk.lap("prefix hash");
     if (rc) return rc;
     rc = build_isa(c);
     clk.lap("inverse suffix array");
@@ -1035,7 +1076,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_small);
-    free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
+    free_dev(c->d_isa); free_dev(c->d_hp); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1079,6 +1120,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
+        if (!rc) rc = build_hp(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_hp") {
+        int64_t old = c->use_hp;
+        c->use_hp = value ? 1 : 0;
+        int rc = build_hp(c);
         return rc ? rc : old;
     }
     if (n == "sort_lists") {
@@ -1124,6 +1172,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->use_k2;
         c->use_k2 = value ? 1 : 0;
         int rc = build_k2(c);
+        if (!rc) rc = build_hp(c);
         return rc ? rc : old;
     }
     if (n == "lazy_search") {

@@ -759,6 +759,97 @@ __global__ void k_check_k2(DevIndex ix, const uint64_t *__restrict__ k2, unsigne
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefix hash (DevIndex::hp): ONE cache line answers "where in the suffix array are the suffixes that start with these K
+// bases" for cores of K bases and more - the k-mer table + second-level key array need two or three.  Every distinct K-base
+// prefix (no N/EOS) of the indexed suffixes owns an 8-byte entry {interval start 32 | count 8 (255 = 255 or more: the caller
+// falls back to table + keys) | displacement 3 | tag 21}; 8 entries make a 64-byte bucket, 2^bits buckets.  The 2K-bit prefix
+// code goes through a bijective mix; its low `bits` bits pick the home bucket, the remaining 2K - bits <= 21 bits are the tag,
+// so (bucket, tag) identify the prefix EXACTLY - a hit needs no verification of the first K bases, and a miss proves the
+// prefix occurs nowhere.  An entry whose home bucket was full sits in one of the next 7 (displacement recorded); a look-up
+// stops at the first bucket that still has a free slot.
+constexpr uint64_t kHpEmpty = ~0ULL;
+
+__device__ __forceinline__ uint64_t hp_mix(uint64_t key, int k)       // bijective on 2k-bit values
+{
+    const uint64_t m = (1ULL << (2 * k)) - 1;
+    uint64_t x = (key * 0x9E3779B97F4A7C15ULL) & m;
+    x ^= x >> k;
+    x = (x * 0xC2B2AE3D27D4EB4FULL) & m;
+    x ^= x >> (k - 3);
+    x = (x * 0x165667B19E3779F9ULL) & m;
+    x ^= x >> (k + 1);
+    return x;
+}
+
+// 2K-bit code of the first K (<= 24) bases given nibbles 0..15 (w0) and 16..31 (w1); false when one of them is N/EOS
+__device__ __forceinline__ bool hp_key(uint64_t w0, uint64_t w1, int k, uint64_t &key)
+{
+    const uint64_t bad = k <= 16 ? (w0 & top_mask(k)) : (w0 | (w1 & top_mask(k - 16)));
+    if (bad & 0x4444444444444444ULL) return false;
+    const uint64_t full = ((uint64_t)squeeze2(w0) << 16) | (uint64_t)(squeeze2(w1) >> 16);      // 24 bases, 48 bits
+    key = full >> (2 * (24 - k));
+    return true;
+}
+
+// 1 = found (lo, cnt), 0 = the prefix does not occur
+__device__ __forceinline__ int hp_lookup(const DevIndex &ix, uint64_t key, uint32_t &lo, uint32_t &cnt)
+{
+    const uint64_t x = hp_mix(key, ix.hp_k);
+    const uint64_t mask = (1ULL << ix.hp_bits) - 1;
+    const uint64_t home = x & mask, tag = x >> ix.hp_bits;
+    for (uint64_t d = 0; d < 8; d++) {
+        const uint4 *bp = reinterpret_cast<const uint4 *>(ix.hp + (((home + d) & mask) << 3));
+        const uint64_t want = (tag << 3) | d;
+        bool full = true;
+        int hit = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = bp[q];
+            const uint64_t e0 = ((uint64_t)v.y << 32) | v.x, e1 = ((uint64_t)v.w << 32) | v.z;
+            if (e0 == kHpEmpty || e1 == kHpEmpty) full = false;
+            if (e0 != kHpEmpty && (e0 >> 40) == want) { lo = (uint32_t)e0; cnt = (uint32_t)(e0 >> 32) & 0xffu; hit = 1; }
+            if (e1 != kHpEmpty && (e1 >> 40) == want) { lo = (uint32_t)e1; cnt = (uint32_t)(e1 >> 32) & 0xffu; hit = 1; }
+        }
+        if (hit) return 1;
+        if (!full) return 0;
+    }
+    return 0;       // eight full buckets without it: the build refuses tables in which an entry could lie further away
+}
+
+__global__ void __launch_bounds__(256) k_build_hp(DevIndex ix, unsigned long long *__restrict__ tab, int bits, int k,
+                                                  unsigned long long *__restrict__ fail)
+{
+    const uint64_t mask = (1ULL << bits) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = ix.sa_lo[i];
+        uint64_t key;
+        if (!hp_key(nib16(ix.tgt4, pos), nib16(ix.tgt4, pos + 16), k, key)) continue;
+        if (i > 0) {                                          // only the first suffix of a run of equal prefixes inserts
+            const uint64_t pp = ix.sa_lo[i - 1];
+            uint64_t kp;
+            if (hp_key(nib16(ix.tgt4, pp), nib16(ix.tgt4, pp + 16), k, kp) && kp == key) continue;
+        }
+        uint32_t cnt = 1;
+        while (cnt < 255 && i + cnt < ix.n) {
+            const uint64_t pj = ix.sa_lo[i + cnt];
+            uint64_t kj;
+            if (!hp_key(nib16(ix.tgt4, pj), nib16(ix.tgt4, pj + 16), k, kj) || kj != key) break;
+            cnt++;
+        }
+        const uint64_t x = hp_mix(key, k);
+        const uint64_t home = x & mask, tag = x >> bits;
+        bool placed = false;
+        for (uint64_t d = 0; d < 8 && !placed; d++) {
+            const unsigned long long entry = (((tag << 3) | d) << 40) | ((unsigned long long)cnt << 32) | (unsigned long long)(uint32_t)i;
+            unsigned long long *bp = tab + (((home + d) & mask) << 3);
+            for (int q = 0; q < 8 && !placed; q++)
+                if (bp[q] == kHpEmpty) placed = atomicCAS(&bp[q], kHpEmpty, entry) == kHpEmpty;
+        }
+        if (!placed) atomicAdd(fail, 1ULL);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                   uint32_t n_act, int phase, int cmax, int nstr, int lazy,
                                                   uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
@@ -790,7 +881,23 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
             uint64_t first = 0;
             uint32_t nval = kKindFull << kKindShift;
             push = true;
-            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
+            // prefix hash first: one line settles the core's first hp_k bases (found with its interval, or proven absent)
+            bool settled = false;
+            if (ix.hp != nullptr && cl >= ix.hp_k) {
+                uint64_t hk;
+                if (hp_key(nib16(rdw, my_ofs), nib16(rdw, my_ofs + 16), ix.hp_k, hk)) {
+                    uint32_t lo = 0, cnt = 0;
+                    if (!hp_lookup(ix, hk, lo, cnt)) { first = 0; nval = 0; push = false; settled = true; }
+                    else if (cnt < 255) {
+                        first = lo;
+                        settled = true;
+                        if (cl == ix.hp_k) { nval = cnt; push = false; }                                   // the interval is exact
+                        else if (lazy && cnt <= kLazyBucket) { nval = cnt | kLazyFlag; push = false; }     // the extend kernels verify the rest
+                        else nval = cnt | (kKindDeep << kKindShift);                                       // pass B: the bases beyond hp_k
+                    }
+                }
+            }
+            if (!settled && cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
                 uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
                 uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
                 uint64_t size = hi - lo;
@@ -894,7 +1001,8 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         return;
     }
     {
-        const int start = k + 16;
+        // intervals handed on by the prefix hash agree with the core on hp_k bases only; comparing from there is right for both kinds
+        const int start = (ix.hp != nullptr && ix.hp_k < k + 16) ? ix.hp_k : k + 16;
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
@@ -3790,6 +3898,13 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
         uint32_t waves = n < 8192 ? n : 8192;
         hipLaunchKernelGGL(k_pe_orphan, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1);
     }
+}
+
+void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s)
+{
+    uint64_t blocks = (ix.n + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(k_build_hp, dim3((unsigned)blocks), dim3(256), 0, s, ix, tab, bits, k, fail);
 }
 
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s)
