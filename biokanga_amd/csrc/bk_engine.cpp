@@ -731,7 +731,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                     for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
                         if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
                         else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
-                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, s);
+                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8, s);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1122,6 +1122,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         if (!rc) rc = build_k2(c);
         if (!rc) rc = build_hp(c);
         return rc ? rc : old;
+    }
+    if (n == "search_ilp") {
+        int64_t old = c->search_ilp;
+        if (value != 1 && value != 2 && value != 4) return BK_ERR_PARAMS;
+        c->search_ilp = (int)value;
+        return old;
     }
     if (n == "use_hp") {
         int64_t old = c->use_hp;

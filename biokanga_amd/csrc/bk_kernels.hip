@@ -949,6 +949,122 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
     if (push) list[s_base + my_off] = (uint32_t)slot;
 }
 
+// k_search_a with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
+// keys) of all ILP searches are in flight together: item u of a lane is search number tid + u * (lanes of the grid), i.e. every u
+// keeps k_search_a's mapping of neighbouring lanes to neighbouring searches.  Same records, same work list (order aside).
+template <int ILP>
+__global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                      uint32_t n_act, int phase, int cmax, int nstr, int lazy,
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+{
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t per_read = (uint32_t)(nstr * cmax);
+    const uint64_t total = (uint64_t)n_act * per_read;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int k = ix.k;
+    bool on[ILP], push[ILP], have_code[ILP];
+    uint64_t slot[ILP], p0[ILP], q2raw[ILP], first[ILP], lo[ILP], hi[ILP];
+    uint32_t nval[ILP];
+    int cl[ILP];
+    // stage 1: the item, its read row
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + (uint64_t)u * stride;
+        on[u] = false; push[u] = false; have_code[u] = false; slot[u] = 0; p0[u] = 0; q2raw[u] = 0; first[u] = 0; nval[u] = 0; cl[u] = 1; lo[u] = hi[u] = 0;
+        if (tid < total) {
+            const uint64_t a = tid / per_read;
+            const uint32_t rem = (uint32_t)(tid - a * per_read);
+            const int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
+            const uint32_t r = act[a];
+            const int len = (int)b.lens[r];
+            ReadPlan p = make_plan(len, cfg);
+            int mm, cd, dummy[1];
+            phase_params(p, cfg, phase, mm, cl[u], cd);
+            const int nc = core_offsets(len, cl[u], cd, p.max_slides, dummy, 0);
+            if (c < nc && nc <= kMaxCoresFast) {
+                on[u] = true;
+                const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
+                const int strand = cfg.align_strand == 2 ? 1 : si;
+                const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+                slot[u] = iv_slot(b, r, strand, c);
+                p0[u] = nib16(rdw, my_ofs) & top_mask(cl[u]);
+                q2raw[u] = nib16(rdw, my_ofs + k);
+            }
+        }
+    }
+    // stage 2: k-mer table
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        nval[u] = kKindFull << kKindShift;
+        push[u] = on[u];
+        have_code[u] = on[u] && cl[u] >= k && !(p0[u] & 0x4444444444444444ULL & top_mask(k));
+        if (have_code[u]) {
+            const uint64_t code = (uint64_t)(squeeze2(p0[u]) >> (32 - 2 * k));
+            lo[u] = ktab_get(ix, code);
+            hi[u] = ktab_get(ix, code + 1);
+        }
+    }
+    // stage 3: small buckets from the key array
+    uint64_t key[ILP][kInlineBucket];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        const uint64_t size = hi[u] - lo[u];
+#pragma unroll
+        for (uint32_t j = 0; j < kInlineBucket; j++) key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ix.k2[lo[u] + j] : ~0ULL;
+    }
+    // stage 4: results
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        if (have_code[u]) {
+            const uint64_t size = hi[u] - lo[u];
+            if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; }
+            else if (size <= kInlineBucket) {
+                const int rem2 = cl[u] - k;
+                const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
+                const uint64_t q2 = rem2 <= 0 ? 0 : (q2raw[u] & m);
+                uint32_t lb = 0, ub = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kInlineBucket; j++) {
+                    const int cm = k2_cmp(key[u][j], m, q2);
+                    lb += cm < 0;
+                    ub += cm <= 0;
+                }
+                first[u] = lo[u] + lb;
+                const uint32_t cnt = ub - lb;
+                if (cnt == 0 || cl[u] <= k + 16) { nval[u] = cnt; push[u] = false; }
+                else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
+                else nval[u] = cnt | (kKindDeep << kKindShift);
+            } else if (size < (1ULL << kKindShift)) {
+                first[u] = lo[u];
+                nval[u] = (uint32_t)size | (kKindK2 << kKindShift);
+            }
+        }
+        if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
+    }
+    // work-list appends, one global atomic per block
+    const int lane = threadIdx.x & 63;
+    uint32_t my_off[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        my_off[u] = 0;
+        const uint64_t m = __ballot(push[u]);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            my_off[u] = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(list_cnt, s_cnt);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ILP; u++)
+        if (push[u]) list[s_base + my_off[u]] = (uint32_t)slot[u];
+}
+
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, DevBatch b, int phase, int lazy,
                                                   const uint32_t *__restrict__ list, uint32_t n_list)
@@ -1514,13 +1630,31 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
         if (fits) {
             uint32_t run = 0;
             int q = 0;
-            for (int st = s0; st <= s1; st++)
-                for (int c = 0; c < nc; c++) {
-                    uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
-                    if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
-                    run += is_heavy ? 0 : cnt;
-                    s_sp[t * slots_max + q++] = (uint16_t)run;
+            const int nslots = (s1 - s0 + 1) * nc;
+            if (nslots <= 8) {
+                // the slots' counts are requested together (a loop of nc runtime iterations waits for each load in turn: up to
+                // eight memory round trips on the block's critical path)
+                uint32_t cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int st = s0 + (u >= nc ? 1 : 0), c = u >= nc ? u - nc : u;
+                    cv[u] = u < nslots ? (iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag) : 0u;
                 }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (u < nslots) {
+                        if (cv[u] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                        run += is_heavy ? 0 : cv[u];
+                        s_sp[t * slots_max + q++] = (uint16_t)run;
+                    }
+            } else
+                for (int st = s0; st <= s1; st++)
+                    for (int c = 0; c < nc; c++) {
+                        uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
+                        if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                        run += is_heavy ? 0 : cnt;
+                        s_sp[t * slots_max + q++] = (uint16_t)run;
+                    }
             for (; q < slots_max; q++) s_sp[t * slots_max + q] = (uint16_t)run;
             my_total = is_heavy ? 0 : run;
         }
@@ -3973,6 +4107,15 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s)
 {
     uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    const int ilp = lazy >> 8;                         // bits 8..: searches per lane (0 / 1 = the plain kernel)
+    lazy &= 0xff;
+    if (ilp >= 2 && ix.hp == nullptr) {
+        const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
+        const unsigned blocks2 = (unsigned)((threads + per - 1) / per);
+        if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks2), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
+        else hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks2), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
+        return;
+    }
     unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(k_search_a, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
 }
