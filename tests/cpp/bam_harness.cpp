@@ -1,4 +1,4 @@
-// test harness (CPU): re-writes a BAM + BAI from the uncompressed BAM stream of a reference-made file through
+// test harness (CPU): re-writes a BAM + BAI (CSI when a header sequence reaches 512 Mbp) from the uncompressed BAM stream of a reference-made file through
 // biokanga_amd/csrc/host/bam_writer.cpp; the test compares the two files with the reference's.
 //   bam_harness <uncompressed.bam.bin> <out.bam> <threads>
 #include <cstdio>
@@ -21,7 +21,13 @@ int main(int argc, char **argv)
     size_t p = 4;
     uint32_t l_text = r32(p); p += 4 + l_text;
     uint32_t n_ref = r32(p); p += 4;
-    for (uint32_t i = 0; i < n_ref; i++) { uint32_t ln = r32(p); p += 4 + ln + 4; }
+    uint64_t max_ref_len = 0;
+    for (uint32_t i = 0; i < n_ref; i++) {
+        uint32_t ln = r32(p);
+        const uint32_t l_ref = r32(p + 4 + ln);
+        if (l_ref > max_ref_len) max_ref_len = l_ref;
+        p += 4 + ln + 4;
+    }
     std::vector<bk::BamAligned> al;
     uint64_t flush_at = 0;
     while (p < s.size()) {
@@ -37,7 +43,7 @@ int main(int argc, char **argv)
         p += 4 + block;
     }
     std::string err;
-    int rc = bk::write_bam_and_bai(argv[2], s, al, flush_at, n_ref, atoi(argv[3]), &err);
+    int rc = bk::write_bam_and_bai(argv[2], s, al, flush_at, n_ref, max_ref_len, atoi(argv[3]), &err);
     if (rc) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     return 0;
 }

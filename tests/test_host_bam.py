@@ -1,6 +1,6 @@
 """Host BAM/BAI writer (CPU only): feeding it the uncompressed record stream of a BAM the reference wrote must
 reproduce that file and its .bai byte for byte - the BGZF block cuts (0xff00 bytes, plus the flush after the
-last aligned record), zlib level 6 raw deflate, virtual offsets, chunk merging and the sparse linear index."""
+last aligned record), zlib level 6 raw deflate, virtual offsets, chunk merging and the sparse linear index; for sequences of 512 Mbp and more the CSI's bins, loffsets and its own BGZF stream."""
 import gzip
 import os
 import subprocess
@@ -19,7 +19,7 @@ def harness(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("fixture,name", [("basic", "s3.m6.bam"), ("basic", "s3.m5.bam"), ("pe", "U3.m6.bam")])
+@pytest.mark.parametrize("fixture,name", [("basic", "s3.m6.bam"), ("basic", "s3.m5.bam"), ("pe", "U3.m6.bam"), ("csi", "s3.m6.bam")])
 @pytest.mark.parametrize("threads", [1, 5])
 def test_bam_writer_reproduces_reference_files(harness, tmp_path, fixture, name, threads):
     ref = os.path.join(helpers.GOLDEN, fixture, name)
@@ -29,4 +29,6 @@ def test_bam_writer_reproduces_reference_files(harness, tmp_path, fixture, name,
     out = str(tmp_path / "out.bam")
     subprocess.check_call([harness, raw, out, str(threads)])
     assert open(out, "rb").read() == open(ref, "rb").read()
-    assert open(out + ".bai", "rb").read() == open(ref + ".bai", "rb").read()
+    idx = ".csi" if fixture == "csi" else ".bai"         # a 537 Mbp sequence in the header: BGZF-compressed CSI instead of the BAI
+    assert open(out + idx, "rb").read() == open(ref + idx, "rb").read()
+    assert not os.path.exists(out + (".bai" if fixture == "csi" else ".csi"))
