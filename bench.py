@@ -350,6 +350,8 @@ def live_traffic(kernel, extra_args, budget_s=240):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled (no nested profiler)"
     members = {"k_search": ("k_search_a", "k_search_b"), "k_wave": ("k_wave",), "k_flat": ("k_flat",)}[kernel]
     tot = 0.0
     launches = None
