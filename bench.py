@@ -84,7 +84,7 @@ def cpu_baseline(seq_t, sa_t, entries, reads_t, read_len, params_kw, gpu_hits, b
     seq = seq_t.cpu().numpy()
     sa = sa_t.cpu().numpy()
     log(f"cpu_baseline: index image copied to host in {time.time() - t0:.1f}s ({(seq.nbytes + sa.nbytes) / 1e9:.1f} GB)")
-    ora = helpers.OracleSfx(seq=seq, sa=sa, el_size=4, entries=entries)
+    ora = helpers.OracleSfx(seq=seq, sa=sa, el_size=5 if sa.dtype == np.uint8 else 4, entries=entries)
     p = helpers.make_params(**params_kw)
     n_avail = reads_t.numel() // read_len
     # probe run to size the sample for ~budget_s seconds of CPU work
@@ -483,6 +483,12 @@ CONFIGS = {
     "C3": dict(read_len=150, max_subs=5, reads=40_000_000, pe=dict(pe_mode=3, pair_min_len=200, pair_max_len=400),
                text="{pairs} x 2x{read_len} bp FR pairs per GPU per step = {reads} reads (insert ~N(300,50) in [200,400], 0-5 subs per read)",
                cli="biokanga align -s{max_subs} -U3 -d200 -D400"),
+    # BASELINE.json configuration 5 restated for ONE GPU: the 17 Gbp index (5-byte suffix elements, built on the device) fits a 288 GB
+    # MI355X, so the index is replicated and not partitioned; reads per step scaled to what is left of the HBM
+    "C5": dict(read_len=150, max_subs=5, reads=20_000_000, pe=dict(pe_mode=3, pair_min_len=200, pair_max_len=400),
+               genome_mbp=17000.0, n_seqs=21, repeat_frac=0.85, seed=17, no_reference=True,
+               text="{pairs} x 2x{read_len} bp FR pairs per GPU per step = {reads} reads (insert ~N(300,50) in [200,400], 0-5 subs per read), wheat-like",
+               cli="biokanga align -s{max_subs} -U3 -d200 -D400"),
 }
 
 
@@ -491,8 +497,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="C2 = BASELINE.json's headline workload (default); C3 = 2x150 bp paired ends")
-    ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (Mbp); 3100 = GRCh38 scale")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="C2 = BASELINE.json's headline workload (default); C3 = 2x150 bp paired ends; "
+                                                                             "C5 = the same pairs against a 17 Gbp index with 5-byte suffix elements")
+    ap.add_argument("--genome-mbp", type=float, default=0.0, help="synthetic genome size (Mbp); 0 = the config's own (3100 = GRCh38 scale; C5: 17000)")
     ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (0 = the config's own: 50 M for C2, 40 M = 20 M pairs for C3)")
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--max-subs", type=int, default=-1, help="`-s` of biokanga align")
@@ -523,6 +530,9 @@ def main():
         sys.exit(self_launch(args.gpus))          # before anything here touches a GPU
     cfg = CONFIGS[args.config]
     args.reads = args.reads or cfg["reads"]
+    args.genome_mbp = args.genome_mbp or cfg.get("genome_mbp", 3100.0)
+    if cfg.get("no_reference"):
+        args.reference_reads = 0           # a 102 GB .sfx for the reference binary is not written; the C restatement is the baseline
     args.read_len = args.read_len or cfg["read_len"]
     args.max_subs = cfg["max_subs"] if args.max_subs < 0 else args.max_subs
     pe = cfg["pe"]
@@ -570,13 +580,14 @@ def main():
     # ---------------------------------------------------------------- workload (untimed set-up)
     t0 = time.time()
     total_bp = int(args.genome_mbp * 1e6)
-    seq, seq_lens = synth.make_genome(total_bp, dev, seed=38)
+    seq, seq_lens = synth.make_genome(total_bp, dev, seed=cfg.get("seed", 38), n_seqs=cfg.get("n_seqs", 24), repeat_frac=cfg.get("repeat_frac", 0.45))
     n = seq.numel()
     torch.cuda.synchronize()
     log(f"genome: {n} concatenated bases, {len(seq_lens)} sequences, generated in {time.time() - t0:.1f}s")
     t0 = time.time()
-    sa = torch.empty(n, dtype=torch.int32, device=dev)
-    bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), 4, local_rank)
+    E = 5 if n >= 0xFFFFFFFF else 4            # SfxElSize, as `biokanga index` picks it
+    sa = torch.empty(n * (5 if E == 5 else 4), dtype=torch.uint8, device=dev) if E == 5 else torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), E, local_rank)
     torch.cuda.synchronize()
     log(f"suffix array built on the GPU in {time.time() - t0:.1f}s")
     entries = synth.entry_table(seq_lens)
@@ -587,7 +598,7 @@ def main():
     pe_params = bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], False) if pe else None
     t0 = time.time()
     al = bk.Aligner(None, bk.AlignParams(**params_kw), device=local_rank, d_seq=seq.data_ptr(), concat_len=n,
-                    d_sa=sa.data_ptr(), el_size=4, entries=ent)
+                    d_sa=sa.data_ptr(), el_size=E, entries=ent)
     if args.kmer_bits:
         al.tune("kmer_bits", args.kmer_bits)
     for kv in args.tune:
@@ -611,6 +622,12 @@ def main():
     torch.cuda.synchronize()
     log(f"reads: {args.reads} x {args.read_len} bp generated in {time.time() - t0:.1f}s")
     keep_index_for_baseline = args.cpu_baseline_secs > 0 and rank == 0 and world == 1
+    if E == 5:
+        # the context holds its own image; the bench's copies (17 + 85 GB at 17 Gbp) leave the HBM before the batch scratch is sized
+        t0 = time.time()
+        seq, sa = (seq.cpu(), sa.cpu()) if keep_index_for_baseline else (None, None)
+        torch.cuda.empty_cache()
+        log(f"index copies moved off the device in {time.time() - t0:.0f}s")
 
     def run_step(bases, offs, lens, nreads, dst):
         al.align_device(bases.data_ptr(), offs.data_ptr(), lens.data_ptr(), nreads, dst.data_ptr())
@@ -668,13 +685,12 @@ def main():
     value = total_reads / elapsed
 
     multi = None
-    if world > 1:
+    if world > 1 and E == 4:
         multi = multi_gpu_legs(al, make_set, run_step, counts_dev, args, rank, world, dev, barrier, all_reduce, dist)
 
     # roofline: algorithmic bytes over the kernel's summed launch time, measured with HIP
     # events on the stream the kernels run on.  Per search: ceil(log2 N) * (E + 8); per candidate
     # Hamming-extended: E + ceil(L/2).  The dominant kernel (largest share of device time) is quoted.
-    E = 4
     log2n = math.ceil(math.log2(n))
     per_search = log2n * (E + 8)
     per_cand = E + (args.read_len + 1) // 2
@@ -693,7 +709,7 @@ def main():
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
     default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
     traffic, traffic_src = (None, None)
-    if rank == 0 and world == 1 and not args.no_live_traffic:
+    if rank == 0 and world == 1 and not args.no_live_traffic and E == 4:       # (two more 17 Gbp set-ups would take minutes)
         child_args = ["--config", args.config, "--reads", str(args.reads), "--genome-mbp", str(args.genome_mbp)] + \
                      [x for kv in args.tune for x in ("--tune", kv)]
         traffic, traffic_src = live_traffic(dom, child_args)
@@ -720,8 +736,8 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic GRCh38-like genome of {total_bp} bp in {len(seq_lens)} "
-                               f"sequences (45% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
+        "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic {'wheat' if E == 5 else 'GRCh38'}-like genome of {total_bp} bp in "
+                               f"{len(seq_lens)} sequences ({int(100 * cfg.get('repeat_frac', 0.45))}% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
                    "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",
