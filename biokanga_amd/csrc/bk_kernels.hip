@@ -1745,17 +1745,21 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
             const int nslots = (s1 - s0 + 1) * nc;
             bool done = false;
             uint32_t prev = 0, strand_first = 0;
+            uint64_t bloom[4] = {0, 0, 0, 0};                                // of the low words seen in this strand pass: the scan below is for its hits only
             for (int q = 0; q < nslots && !done; q++) {
                 n_search++;
-                if (WIDE && q == nc) strand_first = prev;                   // the second strand pass starts with an empty set
+                if (WIDE && q == nc) { strand_first = prev; bloom[0] = bloom[1] = bloom[2] = bloom[3] = 0; }    // the second strand pass starts with an empty set
                 const uint32_t upto = sp[q];
                 for (uint32_t x = prev; x < upto; x++) {
                     const int cm = s_rec[rb + x];
                     if (cm == kRecSkip) continue;
                     if (WIDE) {
+                        const uint32_t kx = s_key[rb + x], hb = (kx * 2654435761u) >> 24;
                         bool seen = false;
-                        for (uint32_t y = strand_first; y < x; y++) seen |= s_rec[rb + y] != kRecSkip && s_key[rb + y] == s_key[rb + x];
+                        if ((bloom[hb >> 6] >> (hb & 63)) & 1)
+                            for (uint32_t y = strand_first; y < x; y++) seen |= s_rec[rb + y] != kRecSkip && s_key[rb + y] == kx;
                         if (seen) continue;
+                        bloom[hb >> 6] |= 1ULL << (hb & 63);
                     }
                     n_cand++;
                     if (cm > mm || cm >= nxt) continue;
