@@ -830,3 +830,43 @@ def test_small_chunks_forced_by_memory_pressure(golden_tmp):
     assert free2 < (300 << 20)
     assert_hits_equal(got, ref)
     assert len(lens_r) * 784 > free2 // 2          # the batch could not have fitted one chunk
+
+
+def test_clears_of_more_than_4_gib_reach_the_end_of_the_buffer():
+    """bk_snp_reset clears 24 bytes per target base: 6 GB at 250 Mbp.  Every plane is dirtied at both ends of the target (the last
+    plane's end lies 6 GB into the buffer), reset, and read back: a clear that stopped at 4 GiB would leave the far counts standing."""
+    import torch
+    bk = _bk()
+    from biokanga_amd import synth
+    dev = torch.device("cuda", 0)
+    seq, seq_lens = synth.make_genome(250_000_000, dev, seed=5, n_seqs=2, repeat_frac=0.0, n_gap_frac=0.0)
+    n = seq.numel()
+    assert n * 24 > (5 << 30)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    entries = synth.entry_table(seq_lens)
+    ent = np.zeros(len(entries), dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"s{eid}".encode(), b"")
+    last_id, last_len = entries[-1][0], entries[-1][1]
+    # two reads of 100 bases that differ from the target everywhere (all five "non reference" planes and the reference plane get counts)
+    places = [(1, 0), (last_id, last_len - 100)]
+    bases = np.zeros(200, dtype=np.uint8)
+    alns = np.zeros(2, dtype=bk.SNP_ALN_DTYPE)
+    seq_h = {eid: seq[so:so + slen] for eid, slen, so, _ in entries}
+    for k, (eid, lo) in enumerate(places):
+        t = seq_h[eid][lo:lo + 100].cpu().numpy()
+        r = t.copy()
+        r[0::5] = (t[0::5] + 1) & 3; r[1::5] = (t[1::5] + 2) & 3; r[2::5] = (t[2::5] + 3) & 3; r[3::5] = 4       # a,c,g,t substitutions, N; every fifth base matches
+        bases[100 * k:100 * k + 100] = r
+        alns[k] = (k, eid, lo, 100, 0, ord("+"), (0, 0, 0))
+    offs, lens = np.array([0, 100], dtype=np.uint64), np.array([100, 100], dtype=np.uint32)
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(), el_size=4, entries=ent) as al:
+        al.snp_reset()
+        al.snp_pileup(bases, offs, lens, alns)
+        for eid, lo in places:
+            c = al.snp_counts(eid, lo, 100)
+            assert (c[:, :6].sum(axis=0) > 0).all(), c[:, :6].sum(axis=0)         # every plane holds counts there
+        al.snp_reset()
+        for eid, lo in places:
+            assert int(al.snp_counts(eid, lo, 100)[:, :6].sum()) == 0
