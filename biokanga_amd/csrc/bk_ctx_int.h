@@ -48,6 +48,7 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
     int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)
     int use_hp = 0;          // prefix hash in front of k-mer table + keys (one line per search instead of two or three).  Off: measured on
                              //    C2 it cuts k_search_a's HBM fetches by a third (14.9 -> 10.2 GB per launch) and its time by nothing (6.6 ms

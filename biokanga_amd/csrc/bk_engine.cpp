@@ -767,7 +767,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         if (n_ext == 0) {}
         else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
             launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
-                        c->d_wave, sm + 6, sm + 3, nw16, s);
+                        c->d_wave, sm + 6, sm + 3, nw16 | (c->flat_block << 8), s);
         else if (reg_path)
             launch_light(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
                          sm + 3, nw16, s);
@@ -1122,6 +1122,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         if (!rc) rc = build_k2(c);
         if (!rc) rc = build_hp(c);
         return rc ? rc : old;
+    }
+    if (n == "flat_block") {
+        int64_t old = c->flat_block;
+        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return BK_ERR_PARAMS;
+        c->flat_block = (int)value;
+        return old;
     }
     if (n == "search_ilp") {
         int64_t old = c->search_ilp;

@@ -1581,24 +1581,24 @@ constexpr uint32_t kLdsEntries = 128;     // entry tables up to this size are se
 constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
 constexpr uint8_t kRecSkip = 255;
 
-template <bool WIDE, int NW>
-__global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+template <bool WIDE, int NW, int BS>
+__global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                               uint32_t n_act, int phase, int slots_max, uint32_t *__restrict__ next_act,
                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
                                               uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
                                               uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
 {
-    extern __shared__ uint16_t s_sp[];                  // [256][slots_max] running candidate count after each slot
-    __shared__ uint32_t s_off[257];                     // first candidate number of each read of the block
-    __shared__ uint32_t s_r[256];
-    __shared__ uint16_t s_len[256], s_cl[256], s_cd[256];
-    __shared__ uint8_t s_nc[256];
-    __shared__ uint8_t s_rec[kFlatCap];
+    extern __shared__ uint16_t s_sp[];                  // [BS][slots_max] running candidate count after each slot
+    __shared__ uint32_t s_off[BS + 1];                     // first candidate number of each read of the block
+    __shared__ uint32_t s_r[BS];
+    __shared__ uint16_t s_len[BS], s_cl[BS], s_cd[BS];
+    __shared__ uint8_t s_nc[BS];
+    __shared__ uint8_t s_rec[kFlatCap * BS / 256];
     // 5-byte indexes: the reference's set of seen targets is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), so a
     // candidate whose start lies a multiple of 2^32 bases from an earlier candidate of the same strand pass is taken for seen and
     // skipped.  The low words travel with the result bytes and the replay applies exactly that rule.
-    __shared__ uint32_t s_key[WIDE ? kFlatCap : 1];
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_key[WIDE ? kFlatCap * BS / 256 : 1];
+    __shared__ uint32_t s_wsum[BS / 64];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
     __shared__ uint64_t s_es[kLdsEntries], s_ee[kLdsEntries];          // entry table, when it is small enough
@@ -1671,7 +1671,7 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
         uint32_t add = 0;
         for (int w = 0; w < wid; w++) add += s_wsum[w];
         s_off[t] = add + v - my_total;
-        if (t == 255) s_off[256] = add + v;
+        if (t == BS - 1) s_off[BS] = add + v;
     }
     __syncthreads();
 
@@ -1681,17 +1681,17 @@ __global__ void __launch_bounds__(256) k_flat(DevIndex ix, DevAlignCfg cfg, DevB
     int best_q = -1;
     uint32_t best_j = 0;
 
-    for (uint32_t start = 0; start < 256;) {
+    for (uint32_t start = 0; start < BS;) {
         // reads [start, end): as many as fit the result buffer (a single read never exceeds it)
         const uint32_t base = s_off[start];
-        uint32_t lo = start + 1, hi = 256;
+        uint32_t lo = start + 1, hi = BS;
         while (lo < hi) {                                   // largest end with s_off[end] - base <= kFlatCap
             uint32_t mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] - base <= kFlatCap) lo = mid; else hi = mid - 1;
+            if (s_off[mid] - base <= kFlatCap * BS / 256) lo = mid; else hi = mid - 1;
         }
         const uint32_t end = lo;
         const uint32_t total = s_off[end] - base;
-        for (uint32_t f = t; f < total; f += 256) {
+        for (uint32_t f = t; f < total; f += BS) {
             const uint32_t g = base + f;
             uint32_t l2 = start, h2 = end - 1;              // read ri: last one with s_off[ri] <= g
             while (l2 < h2) {
@@ -4156,13 +4156,20 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s)
 {
-    unsigned blocks = (n_act + 255) / 256;
+    int bs = (nw >> 8) ? (nw >> 8) : 256;              // bits 8..: reads (= threads) per block, 64 .. 1024
+    nw &= 0xff;
     bool wide = ix.sa_hi != nullptr;
+    if (wide && bs > 256) bs = 256;                    // (the low words of the 5-byte form need 4 more bytes of LDS per candidate)
+    unsigned blocks = (n_act + (unsigned)bs - 1) / (unsigned)bs;
     if (slots_max < 1) slots_max = 1;
-    size_t lds = (size_t)256 * slots_max * sizeof(uint16_t);
-#define BK_FLAT(W, N) hipLaunchKernelGGL((k_flat<W, N>), dim3(blocks), dim3(256), lds, s, ix, cfg, b, act, n_act, phase, slots_max, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
-    if (nw <= 8) { if (wide) BK_FLAT(true, 8); else BK_FLAT(false, 8); }
-    else { if (wide) BK_FLAT(true, 16); else BK_FLAT(false, 16); }
+    size_t lds = (size_t)bs * slots_max * sizeof(uint16_t);
+#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, n_act, phase, slots_max, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
+#define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
+#define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
+    if (nw <= 8) { if (wide) BK_FLAT_W(8); else BK_FLAT_B(8); }
+    else { if (wide) BK_FLAT_W(16); else BK_FLAT_B(16); }
+#undef BK_FLAT_W
+#undef BK_FLAT_B
 #undef BK_FLAT
 }
 
