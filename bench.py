@@ -434,12 +434,22 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
     B = max(2, min(args.stream_batch, n))
     B -= B & 1
     cuts = list(range(0, n, B)) + [n]
-    log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step")
+    # the first step ramps its batch size up (B/16, B/8, ..): the pipeline has nothing to overlap the very first upload with, so
+    # the smaller it is the sooner the kernels start
+    ramp, at, sz = [0], 0, max(2, (B // 16) & ~1)
+    while at + sz < min(B, n):
+        at += sz
+        ramp.append(at)
+        sz = min(B, 2 * sz)
+    cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
+    log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step "
+        f"(first step: {len(cuts0) - 1} batches from {cuts0[1]} reads up)")
     result = {}
     with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
-        def one_step(k):
+        def one_step(k, first=False):
             out = h_out[k & 1]
-            return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+            cc = cuts0 if first else cuts
+            return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
         for t in one_step(0):            # warm-up (buffers touched, scratch sized)
             st.wait(t)
         st.stats(reset=True)
@@ -448,7 +458,7 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
         t_start = time.time()
         tickets = []
         for k in range(args.stream_steps):
-            tickets += one_step(k)
+            tickets += one_step(k, first=(k == 0))
             # keep at most one step of tickets un-waited so that the two result buffers are never overwritten early
             while len(tickets) > len(cuts) - 1:
                 st.wait(tickets.pop(0))
@@ -513,7 +523,7 @@ def main():
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
     ap.add_argument("--stream-steps", type=int, default=5, help="steps of the host-resident leg (bk_stream_*: host buffers in -> host "
                                                                 "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
-    ap.add_argument("--stream-batch", type=int, default=12_500_000, help="reads per submitted batch of the host-resident leg")
+    ap.add_argument("--stream-batch", type=int, default=25_000_000, help="reads per submitted batch of the host-resident leg (the first step ramps up to it)")
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
