@@ -62,9 +62,113 @@ static int calib()
     printf("calib: %llu accesses per kernel (k_calib8: 8 B each, k_calib80: 80 B each)\n", (unsigned long long)blocks * 256 * iters);
     return 0;
 }
+// ---- `bin`: the k_wave restructuring the round-1 review asked to be tried (candidates binned by target region so that the window
+// fetch hits the L2), reduced to its memory behaviour.  Three kernels, each moving what the real thing would move per candidate:
+//   k_now     one wave per read: the read's 2-bit row sits in registers, every lane fetches ONE random 32-byte window of the 2-bit
+//             target (1.56 GB: two copies of 0.78 GB) and compares                       = k_wave today
+//   k_binned  one lane per (read, candidate) pair record (8 bytes, streamed): the window comes from a 2 MB region (L2 resident,
+//             the bin), but the read's 48-byte row has to be fetched - from wherever in the 50 M-read batch that read lies
+//   k_scatter the binning pass itself: 8-byte pair records streamed in, appended to one of 390 bins (block-aggregated appends)
+// Prints G candidates/s of each; at 2.44 G candidates per step the binned form costs time(k_scatter) + time(k_binned) + a replay.
+__global__ void __launch_bounds__(256) k_now(const uint4 *__restrict__ tgt, uint64_t mask16, const uint4 *__restrict__ rows, uint64_t nrows,
+                                             uint64_t *out, int rounds)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t x = (wave * 64 + (threadIdx.x & 63)) * 0x9E3779B97F4A7C15ULL, acc = 0;
+    const uint64_t r = (wave * 0x9E3779B97F4A7C15ULL) % nrows;
+    const uint4 r0 = rows[r * 3], r1 = rows[r * 3 + 1];                    // wave-uniform: the read's row
+    for (int it = 0; it < rounds; it++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t i = (x >> 20) & mask16;
+        const uint4 a = tgt[i], b = tgt[i + 1];                            // 32 bytes inside one 64-byte line (i even)
+        acc += __popcll(((uint64_t)(a.x ^ r0.x) << 32) | (a.y ^ r0.y)) + __popcll(((uint64_t)(b.z ^ r1.z) << 32) | (b.w ^ r1.w));
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_binned(const uint4 *__restrict__ tgt, uint64_t region16, const uint4 *__restrict__ rows, uint64_t nrows,
+                                                const uint2 *__restrict__ pairs, uint64_t npairs, uint64_t *out)
+{
+    uint64_t acc = 0;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 pr = pairs[p];                                         // {read, position inside the bin's region}
+        const uint64_t r = pr.x % nrows, i = (pr.y % region16) & ~1ULL;
+        const uint4 r0 = rows[r * 3], r1 = rows[r * 3 + 1];                // random row: the line this form pays for
+        const uint4 a = tgt[i], b = tgt[i + 1];                            // the bin's region: 2 MB, L2 resident
+        acc += __popcll(((uint64_t)(a.x ^ r0.x) << 32) | (a.y ^ r0.y)) + __popcll(((uint64_t)(b.z ^ r1.z) << 32) | (b.w ^ r1.w));
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_scatter(const uint2 *__restrict__ pairs, uint64_t npairs, uint2 *__restrict__ binned, unsigned long long *__restrict__ cursors,
+                                                 uint32_t nbins, uint64_t cap)
+{
+    __shared__ uint32_t s_cnt[512], s_base_lo[512];
+    for (uint64_t base = (uint64_t)blockIdx.x * 4096; base < npairs; base += (uint64_t)gridDim.x * 4096) {
+        for (uint32_t q = threadIdx.x; q < nbins; q += 256) s_cnt[q] = 0;
+        __syncthreads();
+        uint2 v[16];
+        uint32_t off[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint64_t p = base + (uint64_t)k * 256 + threadIdx.x;
+            v[k] = p < npairs ? pairs[p] : make_uint2(0, 0);
+            off[k] = p < npairs ? atomicAdd(&s_cnt[v[k].y % nbins], 1u) : 0;
+        }
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < nbins; q += 256)
+            s_base_lo[q] = s_cnt[q] ? (uint32_t)atomicAdd(&cursors[q], (unsigned long long)s_cnt[q]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint64_t p = base + (uint64_t)k * 256 + threadIdx.x;
+            if (p < npairs) { const uint32_t bq = v[k].y % nbins; binned[(uint64_t)bq * cap + s_base_lo[bq] + off[k]] = v[k]; }
+        }
+        __syncthreads();
+    }
+}
+static int bin_bench()
+{
+    const uint64_t tgt_bytes = 1ULL << 31, rows_n = 100000000ULL, npairs = 1ULL << 30;      // 2 GB of 2-bit target (two copies), 100 M rows of 48 B
+    const uint32_t nbins = 390;
+    const uint64_t cap = npairs / nbins * 5 / 4 + 4096;
+    uint4 *tgt, *rows;
+    uint2 *pairs, *binned;
+    uint64_t *out;
+    unsigned long long *cursors;
+    hipMalloc(&tgt, tgt_bytes + 256); hipMalloc(&rows, rows_n * 48 + 256); hipMalloc(&pairs, npairs * 8); hipMalloc(&binned, (uint64_t)nbins * cap * 8);
+    hipMalloc(&out, 8); hipMalloc(&cursors, nbins * 8);
+    hipMemset(tgt, 1, tgt_bytes); hipMemset(rows, 2, rows_n * 48); hipMemset(cursors, 0, nbins * 8);
+    // pair records: pseudo-random read and position
+    {
+        std::vector<uint2> h(1 << 20);
+        uint64_t x = 88172645463325252ULL;
+        for (auto &e : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; e.x = (uint32_t)(x >> 11); e.y = (uint32_t)(x >> 33); }
+        for (uint64_t at = 0; at < npairs; at += h.size()) hipMemcpy(pairs + at, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms;
+    const int rounds = 64, blocks = 8192;             // 8192 x 4 waves, 64 candidates per lane
+    hipLaunchKernelGGL(k_now, dim3(blocks), dim3(256), 0, 0, tgt, tgt_bytes / 16 - 2, rows, rows_n, out, 2);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_now, dim3(blocks), dim3(256), 0, 0, tgt, tgt_bytes / 16 - 2, rows, rows_n, out, rounds);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    const double n_now = (double)blocks * 256 * rounds;
+    printf("bin: k_now     (row in registers, window random over %.2f GB): %6.1f G candidates/s\n", tgt_bytes / 1e9, n_now / ms / 1e6);
+    hipLaunchKernelGGL(k_binned, dim3(blocks), dim3(256), 0, 0, tgt, (uint64_t)(2 << 20) / 16, rows, rows_n, pairs, npairs / 64, out);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_binned, dim3(blocks), dim3(256), 0, 0, tgt, (uint64_t)(2 << 20) / 16, rows, rows_n, pairs, npairs, out);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("bin: k_binned  (window in a 2 MB region, row random over %.1f GB, pair records streamed): %6.1f G candidates/s\n", rows_n * 48 / 1e9, (double)npairs / ms / 1e6);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_scatter, dim3(4096), dim3(256), 0, 0, pairs, npairs, binned, cursors, nbins, cap);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("bin: k_scatter (8-byte pair records into %u bins): %6.1f G records/s (%.0f GB/s read + written)\n", nbins, (double)npairs / ms / 1e6, (double)npairs * 16 / ms / 1e6);
+    return 0;
+}
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "calib") return calib();
+    if (argc > 1 && std::string(argv[1]) == "bin") return bin_bench();
     uint64_t maxn = (16ULL << 30) / 8;
     uint64_t *tab, *out;
     hipMalloc(&tab, maxn * 8);
