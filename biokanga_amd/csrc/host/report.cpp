@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 #include "../sfx_file.h"
@@ -533,6 +534,27 @@ int report_text(Report &R)
         const bool timing = getenv("BK_TIMING") != nullptr;
         auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
         double t_fmt = 0, t_grow = 0, t_put = 0;
+        // The file's pages are allocated ahead of the writers by one background thread (posix_fallocate, 256 MB at a time, from an
+        // upper estimate of the text's size): a store into a page that already exists costs a minor fault, one into a hole of a tmpfs
+        // or ext4 file an allocation under the file's locks - with every writer thread doing that at once the copy-out ran at 3.7 GB/s.
+        // The file is cut to its real size at the end.
+        std::atomic<off_t> prealloc_size{0};
+        std::thread prealloc;
+        if (!out.gz && nr >= 200000) {
+            out.flush();
+            const bool with_qual = a.num("g", 3) != 3;                                 // QUAL is '*' unless FASTQ scores were loaded (-g0..2)
+            uint64_t est = (uint64_t)out.pos + rs.names.size() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
+            for (size_t k = 0; k < nr; k++) est += (with_qual ? 2ULL : 1ULL) * rs.lens[RD(k)];
+            const int pfd = out.fd;
+            prealloc = std::thread([pfd, est, &prealloc_size]() {
+                const off_t step = 256LL << 20;
+                for (off_t at = 0; at < (off_t)est; at += step) {
+                    const off_t len = std::min<off_t>(step, (off_t)est - at);
+                    if (posix_fallocate(pfd, at, len) != 0) return;                      // e.g. a pipe: the writers grow the file themselves
+                    prealloc_size.store(at + len);
+                }
+            });
+        }
         for (size_t k0 = 0; k0 < nr; k0 += per_thread * (size_t)nt) {
             const double tA = now();
             auto work = [&](int t) {
@@ -581,7 +603,12 @@ int report_text(Report &R)
             const off_t map_lo = at[0] & ~(off_t)4095;
             const size_t map_len = (size_t)(at[(size_t)nt] - map_lo);
             char *map = nullptr;
-            if (at[(size_t)nt] > at[0] && ftruncate(out.fd, at[(size_t)nt]) == 0) {
+            // the range must exist before it is mapped: already preallocated, or allocated here (posix_fallocate only ever grows a
+            // file, so it cannot collide with the background thread the way an ftruncate could)
+            const bool have_range = at[(size_t)nt] > at[0] &&
+                                    (prealloc.joinable() ? (prealloc_size.load() >= at[(size_t)nt] || posix_fallocate(out.fd, at[0], at[(size_t)nt] - at[0]) == 0)
+                                                         : ftruncate(out.fd, at[(size_t)nt]) == 0);
+            if (have_range) {
                 void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, out.fd, map_lo);
                 if (m != MAP_FAILED) map = (char *)m;
             }
@@ -604,6 +631,11 @@ int report_text(Report &R)
             if (map) munmap(map, map_len);
             t_put += now() - tC;
             out.pos = at[(size_t)nt];
+        }
+        if (prealloc.joinable()) {
+            prealloc.join();
+            out.flush();
+            if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
         }
         if (timing) fprintf(stderr, "bk timing: SAM format %.0f ms, grow + map %.0f ms, copy out %.0f ms (%d threads)\n", 1e3 * t_fmt, 1e3 * t_grow, 1e3 * t_put, nt);
         report_jct_for_sam(R);
