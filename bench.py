@@ -681,6 +681,8 @@ def main():
 
     ctr = al.counters()
     tim = al.timing()
+    if os.environ.get("BK_DIAG"):
+        print("diag counters:", ctr, file=sys.stderr)
     host_leg = None
     if args.stream_steps > 0:
         try:

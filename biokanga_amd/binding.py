@@ -419,7 +419,9 @@ class Aligner:
         rc = self.lib.bk_get_counters(self.h, ctypes.byref(c), 1 if reset else 0)
         if rc:
             raise BkError(rc, "bk_get_counters")
-        return {k: getattr(c, k) for k in ("n_search", "n_cand", "n_lcm_calls", "n_heavy", "n_cand_heavy")}
+        d = {k: getattr(c, k) for k in ("n_search", "n_cand", "n_lcm_calls", "n_heavy", "n_cand_heavy")}
+        d["reserved0"], d["reserved1"] = c.reserved[0], c.reserved[1]
+        return d
 
     def timing(self, reset=False):
         t = _Timing()

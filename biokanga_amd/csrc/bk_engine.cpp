@@ -1491,7 +1491,7 @@ int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
-    out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3]; out->n_cand_heavy = h[4];
+    out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3]; out->n_cand_heavy = h[4]; out->reserved[0] = h[5]; out->reserved[1] = h[6];
     if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(h)));
     return BK_OK;
 }

@@ -1296,6 +1296,35 @@ __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, c
     w.eos = eosacc != 0;
 }
 
+// eval_window for the rare window that the 2-bit compare cannot decide (N or a sequence end nearby): the same result, one 16-base
+// word of read and target at a time from memory, so that the path costs the kernels that carry it a few registers instead of the
+// NW + NW/2 + 2 words the all-at-once form holds
+template <int NW>
+__device__ __forceinline__ void eval_window_rare(const uint64_t *__restrict__ rdrow, int len, const uint64_t *__restrict__ tgt, uint64_t t,
+                                              Window<NW> &w)
+{
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) w.bm[k] = 0;
+    uint64_t eosacc = 0;
+    const int nk = (len + 15) >> 4;
+#pragma unroll 1
+    for (int k = 0; k < nk; k++) {
+        const uint64_t win = nib16(tgt, t + 16 * (uint64_t)k);
+        const uint64_t m = top_mask(len - 16 * k);
+        const uint64_t x = (rdrow[k] ^ win) & m;
+        const uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
+        eosacc |= win & (win >> 1) & (win >> 2) & m & 0x1111111111111111ULL;
+        const uint64_t bits = (uint64_t)flags_to_bits16(f) << (16 * (k & 3));
+#pragma unroll
+        for (int q = 0; q < NW / 4; q++) w.bm[q] |= (k >> 2) == q ? bits : 0ULL;
+    }
+    int mm = 0;
+#pragma unroll
+    for (int k = 0; k < NW / 4; k++) mm += __popcll(w.bm[k]);
+    w.mm = mm;
+    w.eos = eosacc != 0;
+}
+
 // true when bases [o, o+cl) of the read all match the window (cl >= 1)
 template <int NW>
 __device__ __forceinline__ bool core_clean(const Window<NW> &w, int o, int cl)
@@ -1422,6 +1451,139 @@ __device__ __forceinline__ void load_read_words2(const uint64_t *__restrict__ ro
     for (int k = 0; k < NW / 2; k++) r2w[k] = v[k];
 #pragma unroll
     for (int k = 0; k < NW / 4; k++) rnm[k] = v[NW / 2 + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The wave kernels' form of the 2-bit compare.  k_wave spends two thirds of its issue slots on vector ALU work, and half of
+// eval_window2 is the squeeze of the pair-per-base difference into one bit per base, which only exists so that core_clean can
+// build its masks in base units.  Here the map stays where the compare leaves it: word i covers bases 64i .. 64i + 63, base
+// 64i + j (j < 32) at bit 62 - 2j and base 64i + 32 + j at bit 63 - 2j (two 32-base compare words laid into each other, one
+// shift-or).  The Hamming distance still is the popcount, and "core c matches exactly here" is an AND with a mask of the same
+// layout that the wave computes once per read (the core geometry is the same for every candidate) and keeps in LDS.
+
+template <int NW>
+struct IWindow {
+    uint64_t im[NW / 4];
+    int mm;
+    bool eos;
+};
+
+__device__ __forceinline__ uint64_t spread32(uint32_t v)       // bit p -> bit 2p
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+// one bit per base (bit b = base b of the 64, Window::bm / the read rows' N words) -> the laid-together form
+__device__ __forceinline__ uint64_t bits_to_imap(uint64_t bm)
+{
+    return spread32(__brev((uint32_t)bm)) | (spread32(__brev((uint32_t)(bm >> 32))) << 1);
+}
+
+__device__ __forceinline__ uint64_t pair_mask32(int a, int b)   // bases [a, b) of one 32-base compare word, clamped to it
+{
+    a = a < 0 ? 0 : a;
+    b = b > 32 ? 32 : b;
+    return a < b ? ((~0ULL >> (2 * a)) & (~0ULL << (64 - 2 * b)) & 0x5555555555555555ULL) : 0ULL;
+}
+
+// word i of the mask selecting bases [o, h) in an IWindow map
+__device__ __forceinline__ uint64_t imask_word(int o, int h, int i)
+{
+    return pair_mask32(o - 64 * i, h - 64 * i) | (pair_mask32(o - 64 * i - 32, h - 64 * i - 32) << 1);
+}
+
+template <int NW>
+__device__ __forceinline__ bool im_clean(const uint64_t (&im)[NW / 4], const uint64_t *__restrict__ mask)
+{
+    uint64_t a = 0;
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) a |= im[i] & mask[i];
+    return a == 0;
+}
+
+template <int NW>
+__device__ __forceinline__ void window_to_iwindow(const Window<NW> &w4, IWindow<NW> &w)
+{
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) w.im[i] = bits_to_imap(w4.bm[i]);
+    w.mm = w4.mm;
+    w.eos = w4.eos;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ bool window_flagged_t(const DevIndex &ix, uint64_t t, int len)
+{
+    if (WIDE) return window_flagged(ix, t, len);
+    // 4-byte indexes: the same test in 32-bit arithmetic
+    const uint32_t t0 = (uint32_t)t;
+    uint32_t t1 = t0 + (uint32_t)(len - 1);
+    t1 = t1 < t0 ? 0xFFFFFFFFu : t1;
+    const uint32_t g0 = t0 >> ix.flag_shift, g1 = t1 >> ix.flag_shift;
+    return (((ix.nflag[g0 >> 3] >> (g0 & 7)) | (ix.nflag[g1 >> 3] >> (g1 & 7))) & 1) != 0;
+}
+
+template <int NW, bool WIDE>
+__device__ __forceinline__ void eval_window2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len,
+                                              const uint64_t *__restrict__ tgt2, const uint64_t *__restrict__ tgt2s, uint64_t t,
+                                              IWindow<NW> &w)
+{
+    // the loads of eval_window2 (4-byte indexes: block numbers fit 32 bits)
+    const unsigned s = (unsigned)(t & 31) << 1;
+    const bool odd = ((t >> 5) & 1) != 0;
+    const uint4 *__restrict__ blk;
+    if (WIDE) {
+        const uint64_t blk0 = t >> 6;
+        blk = (tgt2s != nullptr && (blk0 & 2)) ? reinterpret_cast<const uint4 *>(tgt2s) + (blk0 - 2) : reinterpret_cast<const uint4 *>(tgt2) + blk0;
+    } else {
+        const uint32_t blk0 = (uint32_t)t >> 6;
+        blk = (tgt2s != nullptr && (blk0 & 2)) ? reinterpret_cast<const uint4 *>(tgt2s) + (blk0 - 2) : reinterpret_cast<const uint4 *>(tgt2) + blk0;
+    }
+    constexpr int NB = NW / 4 + 1;
+    uint64_t r[2 * NB];
+    const int nwords = ((int)(t & 31) + len + 31) >> 5;
+    const int nblk = ((odd ? 1 : 0) + nwords + 1) >> 1;
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        if (q < nblk) {
+            uint4 v = blk[q];
+            r[2 * q] = ((uint64_t)v.y << 32) | v.x;
+            r[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+        } else {
+            r[2 * q] = 0;
+            r[2 * q + 1] = 0;
+        }
+    }
+    int mm = 0;
+    uint64_t even = 0;
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+        uint64_t y = 0;
+        if (32 * k < len) {
+            uint64_t a = odd ? r[k + 1] : r[k];
+            uint64_t b = odd ? r[k + 2] : r[k + 1];
+            uint64_t win = (a << s) | ((b >> 1) >> (63 - s));
+            uint64_t x = r2w[k] ^ win;
+            y = (x | (x >> 1)) & 0x5555555555555555ULL;                  // base j of the word: bit 62 - 2j
+            const int rem = len - 32 * k;
+            if (rem < 32) y &= ~0ULL << (64 - 2 * rem);
+        }
+        if (k & 1) {
+            // only even bits are set in y: the shift does not carry between the halves
+            const uint32_t lo = ((uint32_t)y << 1) | (uint32_t)even, hi = ((uint32_t)(y >> 32) << 1) | (uint32_t)(even >> 32);
+            const uint64_t m = (((uint64_t)hi << 32) | lo) | rni[k >> 1];
+            w.im[k >> 1] = m;
+            mm += __popcll(m);
+        } else
+            even = y;
+    }
+    w.mm = mm;
+    w.eos = false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1581,6 +1743,11 @@ constexpr uint32_t kLdsEntries = 128;     // entry tables up to this size are se
 constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
 constexpr uint8_t kRecSkip = 255;
 
+__host__ __device__ constexpr bool flat_caches_first(bool wide, int bs, int slots_max)
+{
+    return !wide && slots_max <= 32 && bs * slots_max * 6 <= 40960;
+}
+
 template <bool WIDE, int NW, int BS>
 __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                               uint32_t n_act, int phase, int slots_max, uint32_t *__restrict__ next_act,
@@ -1588,7 +1755,13 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                                               uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
                                               uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
 {
-    extern __shared__ uint16_t s_sp[];                  // [BS][slots_max] running candidate count after each slot
+    extern __shared__ uint32_t s_dyn[];
+    // 4-byte indexes: the interval starts (and the "unverified bucket" bits) the counting pass has loaded anyway stay in LDS, so that
+    // the evaluation's chain of dependent loads is suffix array element -> window instead of record -> element -> window
+    const bool cf = flat_caches_first(WIDE, BS, slots_max);
+    uint32_t *s_first = s_dyn;                          // [BS][slots_max] (when cf)
+    uint16_t *s_sp = reinterpret_cast<uint16_t *>(s_dyn + (cf ? BS * slots_max : 0));   // [BS][slots_max] running candidate count after each slot
+    __shared__ uint32_t s_lazy[BS];                     // bit q: slot q is an unverified bucket (when cf)
     __shared__ uint32_t s_off[BS + 1];                     // first candidate number of each read of the block
     __shared__ uint32_t s_r[BS];
     __shared__ uint16_t s_len[BS], s_cl[BS], s_cd[BS];
@@ -1631,30 +1804,44 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             uint32_t run = 0;
             int q = 0;
             const int nslots = (s1 - s0 + 1) * nc;
+            uint32_t lazy_bits = 0;
             if (nslots <= 8) {
-                // the slots' counts are requested together (a loop of nc runtime iterations waits for each load in turn: up to
+                // the slots' records are requested together (a loop of nc runtime iterations waits for each load in turn: up to
                 // eight memory round trips on the block's critical path)
-                uint32_t cv[8];
+                uint32_t cv[8], fv[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int st = s0 + (u >= nc ? 1 : 0), c = u >= nc ? u - nc : u;
-                    cv[u] = u < nslots ? (iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag) : 0u;
+                    cv[u] = 0; fv[u] = 0;
+                    if (u < nslots) {
+                        if (!WIDE) { const uint2 v = b.iv2[iv_slot(b, r, st, c)]; fv[u] = v.x; cv[u] = v.y; }
+                        else cv[u] = iv_count(b, iv_slot(b, r, st, c));
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (u < nslots) {
-                        if (cv[u] > (uint32_t)cfg.heavy_thresh) is_heavy = true;
-                        run += is_heavy ? 0 : cv[u];
+                        if (cv[u] & kLazyFlag) lazy_bits |= 1u << u;
+                        const uint32_t cnt = cv[u] & ~kLazyFlag;
+                        if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                        run += is_heavy ? 0 : cnt;
+                        if (cf) s_first[t * slots_max + q] = fv[u];
                         s_sp[t * slots_max + q++] = (uint16_t)run;
                     }
             } else
                 for (int st = s0; st <= s1; st++)
                     for (int c = 0; c < nc; c++) {
-                        uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
+                        uint64_t f64;
+                        uint32_t cnt;
+                        iv_get(b, iv_slot(b, r, st, c), f64, cnt);
+                        if (cnt & kLazyFlag) lazy_bits |= 1u << (q & 31);
+                        cnt &= ~kLazyFlag;
                         if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                         run += is_heavy ? 0 : cnt;
+                        if (cf) s_first[t * slots_max + q] = (uint32_t)f64;
                         s_sp[t * slots_max + q++] = (uint16_t)run;
                     }
+            s_lazy[t] = lazy_bits;
             for (; q < slots_max; q++) s_sp[t * slots_max + q] = (uint16_t)run;
             my_total = is_heavy ? 0 : run;
         }
@@ -1707,12 +1894,19 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             const int c_nc = s_nc[ri], c_len = s_len[ri], c_cl = s_cl[ri], c_cd = s_cd[ri];
             const int st = s0 + q / c_nc, c = q % c_nc;
             const uint32_t cr = s_r[ri];
-            const uint64_t slot = iv_slot(b, cr, st, c);
             uint64_t iv_f;
-            uint32_t iv_c;
-            iv_get(b, slot, iv_f, iv_c);
-            const bool lazy = (iv_c & kLazyFlag) != 0;
+            bool lazy;
+            if (cf) { iv_f = s_first[ri * slots_max + q]; lazy = ((s_lazy[ri] >> q) & 1) != 0; }
+            else {
+                uint32_t iv_c;
+                iv_get(b, iv_slot(b, cr, st, c), iv_f, iv_c);
+                lazy = (iv_c & kLazyFlag) != 0;
+            }
             const uint64_t loci = sa_get<WIDE>(ix, iv_f + j);
+            // the read's 2-bit row does not wait for the suffix array element
+            const bool two_bit = b.rd2 != nullptr;
+            uint64_t r2w[NW / 2], rnm[NW / 4];
+            if (two_bit && NW <= 8) load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);   // (longer rows: 24 registers held across the wait cost a wave of occupancy)
             const int last = c_len - c_cl;
             const int ofs = c * c_cd < last ? c * c_cd : last;
             uint8_t rec = kRecSkip;
@@ -1720,17 +1914,12 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 const uint64_t t0 = loci - (uint64_t)ofs;
                 Window<NW> w;
                 bool flg = true;
-                if (b.rd2 != nullptr) {
+                if (two_bit) {
                     flg = window_flagged(ix, t0, c_len);                 // issued together with the loads below
-                    uint64_t r2w[NW / 2], rnm[NW / 4];
-                    load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
+                    if (NW > 8) load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
                     eval_window2<NW>(r2w, rnm, c_len, ix.tgt2, ix.tgt2s, t0, w);
                 }
-                if (flg) {                                               // N/EOS nearby (rare): the 4-bit copy decides
-                    uint64_t rw[NW];
-                    load_read_words<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, rw);
-                    eval_window<NW>(rw, c_len, ix.tgt4, t0, w);
-                }
+                if (flg) eval_window_rare<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, ix.tgt4, t0, w);       // N/EOS nearby (rare): the 4-bit copy decides
                 bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
                 for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
                 if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
@@ -1788,7 +1977,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 const int st = s0 + best_q / nc, c = best_q % nc;
                 const int last = len - cl;
                 const int ofs = c * cd < last ? c * cd : last;
-                hit_left = sa_get<WIDE>(ix, iv_start(b, iv_slot(b, r, st, c)) + best_j) - (uint64_t)ofs;
+                const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, r, st, c));
+                hit_left = sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
                 hit_strand = st ? '-' : '+';
                 if (ent_lds) {
                     int lo = 0, hi = (int)ix.n_ent - 1;
@@ -2381,9 +2571,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                                               uint32_t *__restrict__ cmax_next)
 {
     __shared__ WaveCoreInfo s_core[4][kMaxCoresFast];
+    __shared__ uint64_t s_cmask[4][kMaxCoresFast][NW / 4];       // per core: its bases in the IWindow layout
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
+    uint64_t (*cmask)[NW / 4] = s_cmask[wib];
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     unsigned long long *tab = nullptr;
     uint32_t tmask = 0, epoch = 0;
@@ -2394,7 +2586,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         epoch = hs.slot_epoch[wave_slot];
     }
     const uint64_t lt_mask = (1ULL << lane) - 1;
-    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0, n_fetch = 0, n_dup = 0;
+    constexpr bool kDiag = false;
 
     // work items are claimed kWaveGrab at a time: one device-scope atomic on the shared cursor per
     // item serialises 8192 resident waves on a single address
@@ -2443,6 +2636,13 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
                 core[lane].ofs = o;
             }
+            __builtin_amdgcn_wave_barrier();
+            const int ncm = nc < kMaxCoresFast ? nc : kMaxCoresFast;
+            for (int idx = lane; idx < ncm * (NW / 4); idx += 64) {
+                const int cc = idx / (NW / 4), i = idx % (NW / 4);
+                const int o = core[cc].ofs;
+                cmask[cc][i] = imask_word(o, o + cl, i);
+            }
         }
         for (int st = s0; st <= s1 && !done; st++) {
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
@@ -2470,6 +2670,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 #pragma unroll
                 for (int k = 0; k < NW / 4; k++) rnm[k] = 0;
             }
+            uint64_t rni[NW / 4];                                        // "read base is N", in the IWindow layout
+#pragma unroll
+            for (int k = 0; k < NW / 4; k++) rni[k] = rnm[k] ? uniform64(bits_to_imap(rnm[k])) : 0ULL;
             if (lane < nc) {
                 uint64_t slot = iv_slot(b, r, st, lane);
                 uint64_t f;
@@ -2496,20 +2699,27 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
                     const uint64_t t = loci - (uint64_t)ofs;
                     bool valid = active && loci >= (uint64_t)ofs;
-                    Window<NW> w;
+                    IWindow<NW> w;
                     w.mm = 127; w.eos = true;
 #pragma unroll
-                    for (int k = 0; k < NW / 4; k++) w.bm[k] = ~0ULL;
+                    for (int k = 0; k < NW / 4; k++) w.im[k] = ~0ULL;
                     if (valid) {
                         // the block-flag load and the 2-bit window loads are issued together; only the rare
                         // flagged window is then fetched again from the 4-bit copy
                         if (two_bit) {
-                            const bool flg = window_flagged(ix, t, len);
-                            eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t, w);
-                            if (flg) eval_window<NW>(rw, len, ix.tgt4, t, w);
-                        } else
-                            eval_window<NW>(rw, len, ix.tgt4, t, w);
-                        valid = !w.eos && (!lazy || core_clean<NW>(w, ofs, cl));
+                            const bool flg = window_flagged_t<WIDE>(ix, t, len);
+                            eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
+                            if (flg) {
+                                Window<NW> w4;
+                                eval_window<NW>(rw, len, ix.tgt4, t, w4);
+                                window_to_iwindow<NW>(w4, w);
+                            }
+                        } else {
+                            Window<NW> w4;
+                            eval_window<NW>(rw, len, ix.tgt4, t, w4);
+                            window_to_iwindow<NW>(w4, w);
+                        }
+                        valid = !w.eos && (!lazy || im_clean<NW>(w.im, cmask[c]));
                     }
                     bool dup = false;
                     const uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
@@ -2517,7 +2727,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         dup = valid && htab_contains(tab, tmask, epoch, key);
                         if (WIDE) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
                     } else for (int c2 = 0; c2 < c; c2++) {
-                        bool m = valid && !dup && core_clean<NW>(w, core[c2].ofs, cl);
+                        bool m = valid && !dup && im_clean<NW>(w.im, cmask[c2]);
                         if (__ballot(m)) {
                             if (m) {
                                 if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
@@ -2529,6 +2739,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         }
                     }
                     const bool isnew = valid && !dup;
+                    if (kDiag) { n_fetch += __popcll(__ballot(active && loci >= (uint64_t)ofs)); n_dup += __popcll(__ballot(dup)); }
                     const uint64_t newmask = __ballot(isnew);
                     const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
                     const uint32_t iter_before = iter + pre;
@@ -2631,6 +2842,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (n_cand) atomicAdd(&b.ctr[1], n_cand);
         if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
         if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+        if (kDiag) { atomicAdd(&b.ctr[5], n_fetch); atomicAdd(&b.ctr[6], n_dup); }
     }
 }
 
@@ -4162,7 +4374,7 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (wide && bs > 256) bs = 256;                    // (the low words of the 5-byte form need 4 more bytes of LDS per candidate)
     unsigned blocks = (n_act + (unsigned)bs - 1) / (unsigned)bs;
     if (slots_max < 1) slots_max = 1;
-    size_t lds = (size_t)bs * slots_max * sizeof(uint16_t);
+    size_t lds = (size_t)bs * slots_max * (flat_caches_first(wide, bs, slots_max) ? 6 : 2);
 #define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, n_act, phase, slots_max, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
 #define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
 #define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
