@@ -683,6 +683,10 @@ def main():
     tim = al.timing()
     if os.environ.get("BK_DIAG"):
         print("diag counters:", ctr, file=sys.stderr)
+        import ctypes
+        arr = (ctypes.c_ulonglong * 16)()
+        if bk.load_library().bk_debug_prof(arr) == 0:
+            print("diag prof:", list(arr), file=sys.stderr)
     host_leg = None
     if args.stream_steps > 0:
         try:

@@ -94,7 +94,8 @@ class _StreamStats(ctypes.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libbiokanga_amd.so")
+    # BK_LIB: another build of the same library (kernel experiments: tools/quick_prof.sh)
+    return os.environ.get("BK_LIB") or os.path.join(_HERE, "lib", "libbiokanga_amd.so")
 
 
 _lib = None

@@ -30,6 +30,19 @@
 
 namespace bk {
 
+// A work list that every block of a launch appends to.  One shared counter means one L2 line retiring every block's atomic in
+// turn, 12 ns each (`tools/rand_access_bench atomic`: 200 000 blocks, one atomic each, 2.4 ms on one line, 0.07 ms on 64 lines) -
+// that, not memory latency, was what k_flat, pass A of the search and the read packing waited for.  So a block appends to stripe
+// (block number mod kListStripes): counters on the stripe's own line, its own region of `cap` entries per list; a small kernel then
+// copies the stripes into the dense list the next kernel reads and adds their sizes to the list's count (launch_compact).  The
+// "most cores any read of the next phase has" maximum travels the same way.
+constexpr int kListStripes = 64;
+struct StripeSet {
+    uint32_t *cnt;              // 2 * kListStripes lines of 16 words: line s [0..2] = sizes of stripe s of lists 0..2, line kListStripes + s [0] = a running maximum
+    uint32_t *stage[3];         // per list: kListStripes regions of cap entries
+    uint32_t cap;
+};
+constexpr int kCtrStripes = 64;       // copies of the DevBatch::ctr block (8 counters = one 64-byte line each)
 constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
 constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)
@@ -78,7 +91,7 @@ struct DevBatch {
     uint64_t *rec8;             // k_eval -> k_replay: up to 8 result bytes per slot, laid out like iv2; may be null
     bk_hit *out;
     unsigned long long *seq_counts;   // per entry accepted reads
-    unsigned long long *ctr;          // [0] n_search [1] n_cand [2] n_lcm [3] n_heavy
+    unsigned long long *ctr;          // kCtrStripes x 8: [0] n_search [1] n_cand [2] n_lcm [3] n_heavy
     uint32_t wpr;
     uint32_t n_reads;
     uint32_t nw;                // 4-bit words covered by an rd2 row (8 or 16), 0 without rd2

@@ -33,7 +33,8 @@ void launch_snp_sites(const DevIndex &ix, const uint32_t *planes, uint64_t g0, u
                       bk_snp_site *sites, uint32_t cap, uint32_t *n_sites, unsigned long long *totals, hipStream_t s);
 void launch_count_seqs(const bk_hit *out, uint32_t n, const uint32_t *id2idx, uint32_t n_ent, unsigned long long *counts, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);
-void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s);
+void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, uint32_t *stage,
+                 uint32_t *stripe_cnt, hipStream_t s);
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                    int phase, int cmax, int nstr, int lazy, hipStream_t s);
 void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
@@ -43,7 +44,8 @@ void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
 void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
-                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s);
+                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
+                     hipStream_t s);
 void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
                      uint32_t n_list, hipStream_t s);
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
@@ -53,7 +55,7 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
                   uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
-                 uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s);
+                 uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s);
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
                  int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
                  hipStream_t s);
@@ -384,8 +386,8 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     c->ix.n_ent = n_entries;
     HIP_TRY(hipMalloc(&c->d_seq_counts, n_entries * 8));
     HIP_TRY(hipMemset(c->d_seq_counts, 0, n_entries * 8));
-    HIP_TRY(hipMalloc(&c->d_ctr, 8 * 8));
-    HIP_TRY(hipMemset(c->d_ctr, 0, 8 * 8));
+    HIP_TRY(hipMalloc(&c->d_ctr, (size_t)kCtrStripes * 8 * 8));
+    HIP_TRY(hipMemset(c->d_ctr, 0, (size_t)kCtrStripes * 8 * 8));
     HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
     HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
     int rc = derive_cfg(c);
@@ -461,6 +463,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     c->d_rec8 = nullptr;
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
+    for (int i = 0; i < 3; i++) { free_dev(c->d_stage[i]); c->d_stage[i] = nullptr; }
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
     if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8));
@@ -474,6 +477,11 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipMalloc(&c->d_stage[i], ((size_t)nr + (kListStripes + 2) * 1024) * 4));      // striped forms of the lists (StripedList)
+    if (!c->d_stripe_cnt) {
+        HIP_TRY(hipMalloc(&c->d_stripe_cnt, (size_t)2 * kListStripes * 16 * 4));
+        HIP_TRY(hipMemset(c->d_stripe_cnt, 0, (size_t)2 * kListStripes * 16 * 4));
+    }
     HIP_TRY(hipMalloc(&c->d_gen, (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_gen2, (size_t)nr * 4));
     if (c->d_iv2 && c->use_eval) HIP_TRY(hipMalloc(&c->d_rec8, (size_t)nr * 2 * kMaxCoresFast * 8));
@@ -550,7 +558,7 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
 static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
 {
-    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 6 * 4;
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 9 * 4;
 }
 
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
@@ -681,7 +689,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
 
     hipEvent_t e0 = tm.begin(s);
-    launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, s);
+    launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, c->d_stage[0], c->d_stripe_cnt, s);
     HIP_TRY(hipGetLastError());
     tm.end(3, e0, s);
     HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
@@ -712,9 +720,11 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 if (lanes > c->cap_slist) {
                     HIP_TRY(hipStreamSynchronize(s));
                     free_dev(c->d_slist);
-                    c->d_slist = nullptr;
+                    free_dev(c->d_slist_stage);
+                    c->d_slist = c->d_slist_stage = nullptr;
                     c->cap_slist = 0;
                     HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
+                    HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
                     c->cap_slist = lanes;
                 }
                 if (direct) {
@@ -731,7 +741,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                     for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
                         if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
                         else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
-                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8, s);
+                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
+                                    c->d_slist_stage, c->d_stripe_cnt, s);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
@@ -767,7 +778,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         if (n_ext == 0) {}
         else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
             launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
-                        c->d_wave, sm + 6, sm + 3, nw16 | (c->flat_block << 8), s);
+                        c->d_wave, sm + 6, sm + 3, c->d_stage, c->d_stripe_cnt, nw16 | (c->flat_block << 8), s);
         else if (reg_path)
             launch_light(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
                          sm + 3, nw16, s);
@@ -1073,9 +1084,11 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_small);
+    for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
+    free_dev(c->d_stripe_cnt);
     free_dev(c->d_isa); free_dev(c->d_hp); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
@@ -1488,11 +1501,12 @@ int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
 {
     if (!c || !out) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[8];
-    HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long hs[kCtrStripes * 8], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(hs, c->d_ctr, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int i = 0; i < kCtrStripes * 8; i++) h[i & 7] += hs[i];
     memset(out, 0, sizeof(*out));
     out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3]; out->n_cand_heavy = h[4]; out->reserved[0] = h[5]; out->reserved[1] = h[6];
-    if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(h)));
+    if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(hs)));
     return BK_OK;
 }
 

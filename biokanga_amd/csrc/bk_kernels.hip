@@ -71,6 +71,78 @@ __device__ __forceinline__ void iv_put(const DevBatch &b, uint64_t slot, uint64_
     else { b.iv_first[slot] = first; b.iv_n[slot] = n; }
 }
 
+// The counters are kept kCtrStripes times, one 64-byte line each, and summed when they are read back: every block of every launch
+// adds to them, and atomics on ONE line are retired one after the other by the L2 (12 ns each, `tools/rand_access_bench atomic`).
+__device__ __forceinline__ uint32_t stripe_reserve(const StripeSet &l, int li, uint32_t n)
+{
+    return atomicAdd(&l.cnt[(blockIdx.x & (kListStripes - 1)) * 16 + li], n);
+}
+__device__ __forceinline__ void stripe_put(const StripeSet &l, int li, uint32_t at, uint32_t v)
+{
+    l.stage[li][(uint64_t)(blockIdx.x & (kListStripes - 1)) * l.cap + at] = v;
+}
+__device__ __forceinline__ void stripe_max(const StripeSet &l, uint32_t v)
+{
+    atomicMax(&l.cnt[(kListStripes + (blockIdx.x & (kListStripes - 1))) * 16], v);        // a line of its own (see StripeSet)
+}
+
+// stripes -> dense lists, appended behind what each list already holds; k_finish_lists then adds the sizes to the lists' counts,
+// folds the maximum into *max_out and clears the stripes' lines for the next launch
+struct CompactJobs { StripeSet set; uint32_t *dense[3]; uint32_t *total[3]; uint32_t *max_out; int n; };
+
+__global__ void __launch_bounds__(256) k_compact_lists(CompactJobs J)
+{
+    const int li = blockIdx.y;
+    __shared__ uint32_t s_pre[kListStripes + 1];
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (int s0 = 0; s0 < kListStripes; s0 += 64) {
+            uint32_t v = J.set.cnt[(s0 + threadIdx.x) * 16 + li];
+            for (int off = 1; off < 64; off <<= 1) { uint32_t u = __shfl_up(v, off); if ((int)threadIdx.x >= off) v += u; }
+            s_pre[s0 + threadIdx.x + 1] = run + v;
+            run += __shfl(v, 63);
+        }
+        if (threadIdx.x == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t tot = s_pre[kListStripes], old = *J.total[li];
+    const uint32_t *__restrict__ stage = J.set.stage[li];
+    uint32_t *__restrict__ dense = J.dense[li];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+        int lo = 0, hi = kListStripes - 1;                  // stripe s: s_pre[s] <= i < s_pre[s + 1]
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_pre[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        dense[old + i] = stage[(uint64_t)lo * J.set.cap + (i - s_pre[lo])];
+    }
+}
+
+__global__ void k_finish_lists(CompactJobs J)
+{
+    uint32_t sum[3] = {0, 0, 0}, mx = 0;
+    for (int s0 = threadIdx.x; s0 < kListStripes; s0 += 64) {
+        uint32_t *line = J.set.cnt + s0 * 16;
+#pragma unroll
+        for (int li = 0; li < 3; li++) { sum[li] += line[li]; line[li] = 0; }
+        uint32_t *mline = J.set.cnt + (kListStripes + s0) * 16;
+        mx = mline[0] > mx ? mline[0] : mx;
+        mline[0] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int li = 0; li < 3; li++) sum[li] += __shfl_down(sum[li], off);
+        const uint32_t q = __shfl_down(mx, off);
+        mx = q > mx ? q : mx;
+    }
+    if (threadIdx.x == 0) {
+        for (int li = 0; li < J.n; li++) if (sum[li]) *J.total[li] += sum[li];
+        if (J.max_out && mx > *J.max_out) *J.max_out = mx;
+    }
+}
+
+__device__ __forceinline__ uint32_t ctr_stripe() { return (blockIdx.x & (kCtrStripes - 1)) * 8; }
+
 template <bool WIDE>
 __device__ __forceinline__ uint64_t sa_get(const DevIndex &ix, uint64_t i)
 {
@@ -456,8 +528,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
 // writes whole rows, applies the N policy, initialises the result record and appends the read to the first
 // active list.  11.4 GB of traffic per 50 M reads instead of the 30 GB of the word-per-thread kernels.
 template <int NW>
-__global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
-                                                    uint32_t *__restrict__ act_cnt, uint32_t *__restrict__ cmax)
+__global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b, StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base, s_cmax;
     if (threadIdx.x == 0) { s_cnt = 0; s_cmax = 0; }
@@ -465,10 +536,12 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     bool go = false;
     uint32_t my_cmax = 0;
+    int len = 0;
+    uint64_t fw[NW], rv[NW];
+    bk_hit h;
     if (r < b.n_reads) {
-        const int len = (int)b.lens[r];
+        len = (int)b.lens[r];
         const uint8_t *s = b.bases + b.offs[r];
-        uint64_t fw[NW], rv[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             const int base0 = 16 * w;
@@ -490,6 +563,55 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
             fw[w] = f;
             rv[w] = v;
         }
+        // N policy and result record, as k_init_reads
+        h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
+        h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
+        int max_ns_seq = 0;
+        if (cfg.max_ns) {
+            max_ns_seq = (len * cfg.max_ns) / 100;
+            if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
+        }
+        int num_ns = 0;
+        bool bad = false;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (16 * w < len) {
+                uint64_t x = fw[w] & top_mask(len - 16 * w);
+                uint64_t hi = x & 0x4444444444444444ULL;
+                uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;
+                bad |= ((hi >> 2) & lo) != 0;
+                num_ns += __popcll(hi);
+            }
+        }
+        if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
+        if (h.nar != BK_NAR_NS) {
+            ReadPlan p = make_plan(len, cfg);
+            if (p.n_phases > 0) {
+                int mm, cl, cd, ofs[1];
+                phase_params(p, cfg, 0, mm, cl, cd);
+                int nc = core_offsets(len, cl, cd, p.max_slides, ofs, 0);
+                if (nc <= kMaxCoresFast) my_cmax = (uint32_t)nc;
+                go = true;
+            }
+        }
+    }
+    // the list append comes before the rows are written: its barriers wait for every store the wave has issued
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(go);
+    uint32_t my_off = 0;
+    for (int off = 32; off > 0; off >>= 1) { uint32_t q = __shfl_down(my_cmax, off); my_cmax = q > my_cmax ? q : my_cmax; }
+    if (m) {
+        uint32_t w = 0;
+        if (lane == 0) { w = atomicAdd(&s_cnt, (uint32_t)__popcll(m)); if (my_cmax) atomicMax(&s_cmax, my_cmax); }
+        w = __builtin_amdgcn_readfirstlane(w);
+        my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
+    if (threadIdx.x == 64 && s_cmax) stripe_max(out, s_cmax);
+    __syncthreads();
+    if (go) stripe_put(out, 0, s_base + my_off, r);
+    if (r < b.n_reads) {
         // rows: [read][strand][wpr] nibble words (zero padded), 16-byte aligned
         const uint32_t wpr = b.wpr;
         uint4 *row0 = reinterpret_cast<uint4 *>(b.rd4 + (uint64_t)r * 2 * wpr);
@@ -529,55 +651,8 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
                 t1[q] = make_uint4((uint32_t)o1[2 * q], (uint32_t)(o1[2 * q] >> 32), (uint32_t)o1[2 * q + 1], (uint32_t)(o1[2 * q + 1] >> 32));
             }
         }
-        // N policy and result record, as k_init_reads
-        bk_hit h;
-        h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
-        h.nar = BK_NAR_NOHIT; h.strand = '?'; h.low_mm = 0; h.nxt_low_mm = 0; h.num_hits = 0; h.mismatches = 0; h.flags = 0;
-        int max_ns_seq = 0;
-        if (cfg.max_ns) {
-            max_ns_seq = (len * cfg.max_ns) / 100;
-            if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
-        }
-        int num_ns = 0;
-        bool bad = false;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            if (16 * w < len) {
-                uint64_t x = fw[w] & top_mask(len - 16 * w);
-                uint64_t hi = x & 0x4444444444444444ULL;
-                uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;
-                bad |= ((hi >> 2) & lo) != 0;
-                num_ns += __popcll(hi);
-            }
-        }
-        if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
         b.out[r] = h;
-        if (h.nar != BK_NAR_NS) {
-            ReadPlan p = make_plan(len, cfg);
-            if (p.n_phases > 0) {
-                int mm, cl, cd, ofs[1];
-                phase_params(p, cfg, 0, mm, cl, cd);
-                int nc = core_offsets(len, cl, cd, p.max_slides, ofs, 0);
-                if (nc <= kMaxCoresFast) my_cmax = (uint32_t)nc;
-                go = true;
-            }
-        }
     }
-    const int lane = threadIdx.x & 63;
-    uint64_t m = __ballot(go);
-    uint32_t my_off = 0;
-    for (int off = 32; off > 0; off >>= 1) { uint32_t q = __shfl_down(my_cmax, off); my_cmax = q > my_cmax ? q : my_cmax; }
-    if (m) {
-        uint32_t w = 0;
-        if (lane == 0) { w = atomicAdd(&s_cnt, (uint32_t)__popcll(m)); if (my_cmax) atomicMax(&s_cmax, my_cmax); }
-        w = __builtin_amdgcn_readfirstlane(w);
-        my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(act_cnt, s_cnt);
-    if (threadIdx.x == 64 && s_cmax) atomicMax(cmax, s_cmax);
-    __syncthreads();
-    if (go) act[s_base + my_off] = r;
 }
 
 __global__ void __launch_bounds__(1024) k_init_reads(DevAlignCfg cfg, DevBatch b, uint32_t *__restrict__ act,
@@ -852,7 +927,7 @@ __global__ void __launch_bounds__(256) k_build_hp(DevIndex ix, unsigned long lon
 
 __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                   uint32_t n_act, int phase, int cmax, int nstr, int lazy,
-                                                  uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+                                                  StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -861,7 +936,8 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
     uint32_t per_read = (uint32_t)(nstr * cmax);
     uint64_t a = tid / per_read;
     bool push = false;
-    uint64_t slot = 0;
+    uint64_t slot = 0, st_first = 0;
+    uint32_t st_nval = 0;
     if (a < n_act) {
         uint32_t rem = (uint32_t)(tid - a * per_read);
         int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
@@ -929,9 +1005,8 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
             }
             // iv_n of the phase's slots is zeroed before the launch: empty results (about 40 % of the lanes)
             // store nothing - two partial-line writes less
-            if (nval != 0) {
-                iv_put(b, slot, first, nval);
-            }
+            st_first = first;                     // (stored after the list append, whose barriers wait for every store issued)
+            st_nval = nval;
         }
     }
     const int lane = threadIdx.x & 63;
@@ -944,9 +1019,10 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
         my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(list_cnt, s_cnt);
+    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
     __syncthreads();
-    if (push) list[s_base + my_off] = (uint32_t)slot;
+    if (push) stripe_put(out, 0, s_base + my_off, (uint32_t)slot);
+    if (st_nval != 0) iv_put(b, slot, st_first, st_nval);
 }
 
 // k_search_a with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
@@ -955,7 +1031,7 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
 template <int ILP>
 __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                       uint32_t n_act, int phase, int cmax, int nstr, int lazy,
-                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+                                                      StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -1041,9 +1117,9 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 nval[u] = (uint32_t)size | (kKindK2 << kKindShift);
             }
         }
-        if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
     }
-    // work-list appends, one global atomic per block
+    // work-list appends, one global atomic per block.  The interval records are stored after them: the barriers of the append
+    // wait for every store the wave has issued.
     const int lane = threadIdx.x & 63;
     uint32_t my_off[ILP];
 #pragma unroll
@@ -1058,11 +1134,13 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(list_cnt, s_cnt);
+    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < ILP; u++)
-        if (push[u]) list[s_base + my_off[u]] = (uint32_t)slot[u];
+    for (int u = 0; u < ILP; u++) {
+        if (push[u]) stripe_put(out, 0, s_base + my_off[u], (uint32_t)slot[u]);
+        if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
+    }
 }
 
 template <bool WIDE>
@@ -1223,9 +1301,9 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         n_lcm += __shfl_down(n_lcm, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&b.ctr[2], n_lcm);
+        if (n_search) atomicAdd(&b.ctr[ctr_stripe() + 0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 1], n_cand);
+        if (n_lcm) atomicAdd(&b.ctr[ctr_stripe() + 2], n_lcm);
     }
 }
 
@@ -1379,33 +1457,37 @@ __device__ __forceinline__ bool window_flagged(const DevIndex &ix, uint64_t t, i
     return (((ix.nflag[g0 >> 3] >> (g0 & 7)) | (ix.nflag[g1 >> 3] >> (g1 & 7))) & 1) != 0;
 }
 
+// The window's 16-byte blocks are requested by window2_load and consumed by window2_compare: a kernel that has several
+// candidates per lane (k_flat) issues the loads of all of them before it touches the first result.
 template <int NW>
-__device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], const uint64_t (&rnm)[NW / 4], int len,
-                                             const uint64_t *__restrict__ tgt2, const uint64_t *__restrict__ tgt2s, uint64_t t,
-                                             Window<NW> &w)
+__device__ __forceinline__ void window2_load(const uint64_t *__restrict__ tgt2, const uint64_t *__restrict__ tgt2s, uint64_t t, int len,
+                                             uint4 (&v)[NW / 4 + 1])
 {
     const uint64_t i0 = t >> 5;
-    const unsigned s = (unsigned)(t & 31) << 1;
     const bool odd = (i0 & 1) != 0;
     // tgt2s (optional) is the same data stored again 32 bytes later: a window that would straddle a 64-byte
     // line in one copy lies inside a line of the other (16-byte block index 2 or 3 within the line -> 0 or 1)
     const uint64_t blk0 = i0 >> 1;
     const uint4 *__restrict__ blk = (tgt2s != nullptr && (blk0 & 2)) ? reinterpret_cast<const uint4 *>(tgt2s) + (blk0 - 2)
                                                                       : reinterpret_cast<const uint4 *>(tgt2) + blk0;
-    constexpr int NB = NW / 4 + 1;
-    uint64_t r[2 * NB];
     const int nwords = ((int)(t & 31) + len + 31) >> 5;
     const int nblk = ((odd ? 1 : 0) + nwords + 1) >> 1;
 #pragma unroll
+    for (int q = 0; q < NW / 4 + 1; q++) v[q] = q < nblk ? blk[q] : make_uint4(0, 0, 0, 0);
+}
+
+template <int NW>
+__device__ __forceinline__ void window2_compare(const uint64_t (&r2w)[NW / 2], const uint64_t (&rnm)[NW / 4], int len, uint64_t t,
+                                                const uint4 (&v)[NW / 4 + 1], Window<NW> &w)
+{
+    const unsigned s = (unsigned)(t & 31) << 1;
+    const bool odd = ((t >> 5) & 1) != 0;
+    constexpr int NB = NW / 4 + 1;
+    uint64_t r[2 * NB];
+#pragma unroll
     for (int q = 0; q < NB; q++) {
-        if (q < nblk) {
-            uint4 v = blk[q];
-            r[2 * q] = ((uint64_t)v.y << 32) | v.x;
-            r[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
-        } else {
-            r[2 * q] = 0;
-            r[2 * q + 1] = 0;
-        }
+        r[2 * q] = ((uint64_t)v[q].y << 32) | v[q].x;
+        r[2 * q + 1] = ((uint64_t)v[q].w << 32) | v[q].z;
     }
 #pragma unroll
     for (int k = 0; k < NW / 4; k++) w.bm[k] = rnm[k];
@@ -1433,6 +1515,16 @@ __device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], cons
     for (int k = 0; k < NW / 4; k++) mm += __popcll(w.bm[k]);
     w.mm = mm;
     w.eos = false;
+}
+
+template <int NW>
+__device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], const uint64_t (&rnm)[NW / 4], int len,
+                                             const uint64_t *__restrict__ tgt2, const uint64_t *__restrict__ tgt2s, uint64_t t,
+                                             Window<NW> &w)
+{
+    uint4 v[NW / 4 + 1];
+    window2_load<NW>(tgt2, tgt2s, t, len, v);
+    window2_compare<NW>(r2w, rnm, len, t, v, w);
 }
 
 template <int NW>
@@ -1717,7 +1809,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
         if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
         if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
         if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-        if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+        if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
     }
     __syncthreads();
     if (dest == 1) next_act[s_base[1] + my_off] = r;
@@ -1743,18 +1835,41 @@ constexpr uint32_t kLdsEntries = 128;     // entry tables up to this size are se
 constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
 constexpr uint8_t kRecSkip = 255;
 
+// -DBK_PROF: where a k_flat block's time goes - thread 0 adds the cycles between its section marks to g_prof (summed over the
+// blocks, read with bk_debug_prof(); `BK_DIAG=1 python bench.py` prints them)
+__device__ unsigned long long g_prof[64 * 16];
+#ifdef BK_PROF
+#define PROF(k) do { if (t == 0) { const long long now_ = clock64(); pt[k] = now_ - last_; last_ = now_; } } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
+template <bool WIDE> struct FlatEntT { typedef uint64_t type; };
+template <> struct FlatEntT<false> { typedef uint32_t type; };
 __host__ __device__ constexpr bool flat_caches_first(bool wide, int bs, int slots_max)
 {
-    return !wide && slots_max <= 32 && bs * slots_max * 6 <= 40960;
+    return !wide && slots_max <= 16 && bs * slots_max * 6 <= 24576;
 }
+
+// per-read rows of the 2-bit read copy are staged in LDS (fetched once per block, with the lengths and the interval records)
+__host__ __device__ constexpr bool flat_rows_in_lds(bool wide, int nw, int bs) { return !wide && nw <= 8 && bs <= 256; }
 
 template <bool WIDE, int NW, int BS>
 __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                              uint32_t n_act, int phase, int slots_max, uint32_t *__restrict__ next_act,
-                                              uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
-                                              uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
-                                              uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
+                                              uint32_t n_act, int phase, int slots_max, StripeSet out, int have_wave)
 {
+    // A block's time is a chain of dependent memory round trips (its four waves per SIMD do not hide them), so the kernel is laid
+    // out to keep that chain short: everything that depends on the read number only - length, interval records, the read's 2-bit
+    // rows - is requested together; the suffix array elements of up to KB candidates per lane are requested together, then their
+    // windows, and only then the first compare runs.
+    constexpr bool ROWS = flat_rows_in_lds(WIDE, NW, BS);
+#ifdef BK_FLAT_KB
+    constexpr int KB = BK_FLAT_KB;
+#else
+    constexpr int KB = 1;                                   // candidates a lane has in flight (2 .. 4 measured: the registers cost more occupancy than the overlap buys)
+#endif
+    constexpr int NBLK = NW / 4 + 1;
+    constexpr uint32_t CAP = (ROWS ? kFlatCap / 4 : kFlatCap) * BS / 256;        // (LDS: four blocks per CU must fit 160 KB)
+    constexpr int SPEC = 8;                                 // interval records requested before the length is known
     extern __shared__ uint32_t s_dyn[];
     // 4-byte indexes: the interval starts (and the "unverified bucket" bits) the counting pass has loaded anyway stay in LDS, so that
     // the evaluation's chain of dependent loads is suffix array element -> window instead of record -> element -> window
@@ -1764,91 +1879,120 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     __shared__ uint32_t s_lazy[BS];                     // bit q: slot q is an unverified bucket (when cf)
     __shared__ uint32_t s_off[BS + 1];                     // first candidate number of each read of the block
     __shared__ uint32_t s_r[BS];
-    __shared__ uint16_t s_len[BS], s_cl[BS], s_cd[BS];
-    __shared__ uint8_t s_nc[BS];
-    __shared__ uint8_t s_rec[kFlatCap * BS / 256];
+    __shared__ uint32_t s_geo[BS];                         // read length | core length << 10 | core step << 20
+    __shared__ uint8_t s_hasn[BS];
+    // the per-read outcome is reduced over the candidates' lanes (4-byte indexes): smallest (mismatches << 16 | candidate number) of
+    // the acceptable candidates, how many share that mismatch count (low half) and how many were looked at (high half), and the
+    // smallest count above it.  One lane per read walking its own bytes made a wave wait for its read with the most candidates.
+    __shared__ uint32_t s_k1[WIDE ? 1 : BS], s_c2[WIDE ? 1 : BS], s_nx[WIDE ? 1 : BS];
+    __shared__ uint8_t s_mm[BS];                         // bit st: the read's strand-st row holds an N (the 4-bit compare decides its windows)
+    __shared__ uint8_t s_rec[CAP];
+    __shared__ uint4 s_row[ROWS ? BS * 2 * (NW / 4) : 1];  // [read][strand]: NW/2 words at 2 bit/base
     // 5-byte indexes: the reference's set of seen targets is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), so a
     // candidate whose start lies a multiple of 2^32 bases from an earlier candidate of the same strand pass is taken for seen and
     // skipped.  The low words travel with the result bytes and the replay applies exactly that rule.
-    __shared__ uint32_t s_key[WIDE ? kFlatCap * BS / 256 : 1];
+    __shared__ uint32_t s_key[WIDE ? CAP : 1];
     __shared__ uint32_t s_wsum[BS / 64];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
-    __shared__ uint64_t s_es[kLdsEntries], s_ee[kLdsEntries];          // entry table, when it is small enough
+    using EntT = typename FlatEntT<WIDE>::type;
+    __shared__ EntT s_es[kLdsEntries], s_ee[kLdsEntries];              // entry table, when it is small enough
     const uint32_t t = threadIdx.x;
+#ifdef BK_PROF
+    long long pt[10] = {0,0,0,0,0,0,0,0,0,0}, last_ = clock64();
+#endif
     const int lane = t & 63, wid = t >> 6;
     if (t < 4) s_cnt[t] = 0;
     if (t == 4) s_cmax = 0;
     if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
     const bool ent_lds = ix.n_ent <= kLdsEntries;
-    if (ent_lds && t < ix.n_ent) { s_es[t] = ix.ent_start[t]; s_ee[t] = ix.ent_end[t]; }
+    uint64_t es_v = 0, ee_v = 0;                            // stored after the counting pass: nothing here waits for them
+    if (ent_lds && t < ix.n_ent) { es_v = ix.ent_start[t]; ee_v = ix.ent_end[t]; }
 
     const uint32_t a = blockIdx.x * blockDim.x + t;
     const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
+    // slot q of a read = (strand pass q / cmaxs, core q % cmaxs): the numbering does not depend on the read's own core count,
+    // cores it does not have are empty slots
+    const int cmaxs = slots_max / (s1 - s0 + 1);
+    const bool two_bit = b.rd2 != nullptr;
+    uint32_t n_search = 0, n_cand = 0, n_lcm = 0;
     int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel
     uint32_t r = 0, my_cmax = 0, my_total = 0;
     int len = 0, mm = 0, cl = 1, cd = 1, nc = 0, n_phases = 0;
     bool mine = false;              // this lane's read is resolved here
     if (a < n_act) {
         r = act[a];
-        len = (int)b.lens[r];
+        const uint32_t len_v = b.lens[r];
+        const bool spec = !WIDE && slots_max <= SPEC;
+        uint2 sv[SPEC];
+        if (!WIDE) {
+#pragma unroll
+            for (int u = 0; u < SPEC; u++) {
+                sv[u] = make_uint2(0, 0);
+                if (spec && u < slots_max) {
+                    const int sti = u >= cmaxs ? 1 : 0;
+                    sv[u] = b.iv2[iv_slot(b, r, s0 + sti, u - sti * cmaxs)];
+                }
+            }
+        }
+        // both strands' rows (ROWS implies NW == 8): two blocks of bases and one of N bits each.  Named values, not an array: the
+        // compiler kept an array of them in scratch memory
+        uint4 rb00 = make_uint4(0, 0, 0, 0), rb01 = rb00, rn0 = rb00, rb10 = rb00, rb11 = rb00, rn1 = rb00;
+        if (ROWS && two_bit) {
+            const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(b.rd2 + (uint64_t)r * 2 * (3 * NW / 4));
+            rb00 = rp[0]; rb01 = rp[1]; rn0 = rp[2]; rb10 = rp[3]; rb11 = rp[4]; rn1 = rp[5];
+        }
+        len = (int)len_v;
         ReadPlan p = make_plan(len, cfg);
         n_phases = p.n_phases;
         int dummy[1];
         phase_params(p, cfg, phase, mm, cl, cd);
         nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
-        const bool fits = nc <= kMaxCoresFast && len <= 16 * NW && (s1 - s0 + 1) * nc <= slots_max;
+        const bool fits = nc <= kMaxCoresFast && len <= 16 * NW && nc <= cmaxs;
         bool is_heavy = !fits;
         if (fits) {
-            uint32_t run = 0;
-            int q = 0;
-            const int nslots = (s1 - s0 + 1) * nc;
-            uint32_t lazy_bits = 0;
-            if (nslots <= 8) {
-                // the slots' records are requested together (a loop of nc runtime iterations waits for each load in turn: up to
-                // eight memory round trips on the block's critical path)
-                uint32_t cv[8], fv[8];
+            uint32_t run = 0, lazy_bits = 0;
+            if (!WIDE && spec) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int st = s0 + (u >= nc ? 1 : 0), c = u >= nc ? u - nc : u;
-                    cv[u] = 0; fv[u] = 0;
-                    if (u < nslots) {
-                        if (!WIDE) { const uint2 v = b.iv2[iv_slot(b, r, st, c)]; fv[u] = v.x; cv[u] = v.y; }
-                        else cv[u] = iv_count(b, iv_slot(b, r, st, c));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (u < nslots) {
-                        if (cv[u] & kLazyFlag) lazy_bits |= 1u << u;
-                        const uint32_t cnt = cv[u] & ~kLazyFlag;
+                for (int u = 0; u < SPEC; u++)
+                    if (u < slots_max) {
+                        const int c = u >= cmaxs ? u - cmaxs : u;
+                        const uint32_t raw = c < nc ? sv[u].y : 0u;          // a core the read does not have: whatever the slot held
+                        if (raw & kLazyFlag) lazy_bits |= 1u << u;
+                        const uint32_t cnt = raw & ~kLazyFlag;
                         if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                         run += is_heavy ? 0 : cnt;
-                        if (cf) s_first[t * slots_max + q] = fv[u];
-                        s_sp[t * slots_max + q++] = (uint16_t)run;
+                        if (cf) s_first[t * slots_max + u] = sv[u].x;
+                        s_sp[t * slots_max + u] = (uint16_t)run;
                     }
             } else
-                for (int st = s0; st <= s1; st++)
-                    for (int c = 0; c < nc; c++) {
-                        uint64_t f64;
-                        uint32_t cnt;
-                        iv_get(b, iv_slot(b, r, st, c), f64, cnt);
-                        if (cnt & kLazyFlag) lazy_bits |= 1u << (q & 31);
-                        cnt &= ~kLazyFlag;
-                        if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
-                        run += is_heavy ? 0 : cnt;
-                        if (cf) s_first[t * slots_max + q] = (uint32_t)f64;
-                        s_sp[t * slots_max + q++] = (uint16_t)run;
-                    }
+                for (int q = 0; q < slots_max; q++) {
+                    const int sti = q >= cmaxs ? 1 : 0, c = q - sti * cmaxs;
+                    uint64_t f64 = 0;
+                    uint32_t cnt = 0;
+                    if (c < nc) iv_get(b, iv_slot(b, r, s0 + sti, c), f64, cnt);
+                    if (cnt & kLazyFlag) lazy_bits |= 1u << (q & 31);
+                    cnt &= ~kLazyFlag;
+                    if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    run += is_heavy ? 0 : cnt;
+                    if (cf) s_first[t * slots_max + q] = (uint32_t)f64;
+                    s_sp[t * slots_max + q] = (uint16_t)run;
+                }
             s_lazy[t] = lazy_bits;
-            for (; q < slots_max; q++) s_sp[t * slots_max + q] = (uint16_t)run;
             my_total = is_heavy ? 0 : run;
         }
-        if (is_heavy) dest = (fits && wave != nullptr) ? 2 : 3;
+        if (is_heavy) dest = (fits && have_wave) ? 2 : 3;
         else { mine = true; n_lcm = 1; }
+        if (ROWS && two_bit) {
+            s_row[t * 4 + 0] = rb00; s_row[t * 4 + 1] = rb01; s_row[t * 4 + 2] = rb10; s_row[t * 4 + 3] = rb11;
+            s_hasn[t] = (uint8_t)(((rn0.x | rn0.y | rn0.z | rn0.w) ? 1u : 0u) | ((rn1.x | rn1.y | rn1.z | rn1.w) ? 2u : 0u));
+        }
     }
-    s_r[t] = r; s_len[t] = (uint16_t)len; s_cl[t] = (uint16_t)cl; s_cd[t] = (uint16_t)cd; s_nc[t] = (uint8_t)nc;
+    PROF(0);
+    if (ent_lds && t < ix.n_ent) { s_es[t] = (EntT)es_v; s_ee[t] = (EntT)ee_v; }
+    if (!WIDE) { s_k1[t] = 0xFFFFFFFFu; s_c2[t] = 0; s_nx[t] = 0xFFFFFFFFu; }
+    s_mm[t] = (uint8_t)(mm < 255 ? mm : 255);
+    s_r[t] = r; s_geo[t] = (uint32_t)len | ((uint32_t)cl << 10) | ((uint32_t)cd << 20);
     // block-wide exclusive prefix sum of the candidate counts
     {
         uint32_t v = my_total;
@@ -1861,83 +2005,153 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
         if (t == BS - 1) s_off[BS] = add + v;
     }
     __syncthreads();
+    PROF(1);
 
     // replay state of this lane's read
     const int init = mm + cfg.mm_delta + 1;
     int low_inst = 0, low_mm = init, nxt = init;
     int best_q = -1;
     uint32_t best_j = 0;
+    constexpr uint32_t kNone = 0xFFFFFFFFu, kOffStart = 1u << 18, kLazyBit = 1u << 16;
 
     for (uint32_t start = 0; start < BS;) {
         // reads [start, end): as many as fit the result buffer (a single read never exceeds it)
         const uint32_t base = s_off[start];
         uint32_t lo = start + 1, hi = BS;
-        while (lo < hi) {                                   // largest end with s_off[end] - base <= kFlatCap
+        while (lo < hi) {                                   // largest end with s_off[end] - base <= CAP
             uint32_t mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] - base <= kFlatCap * BS / 256) lo = mid; else hi = mid - 1;
+            if (s_off[mid] - base <= CAP) lo = mid; else hi = mid - 1;
         }
         const uint32_t end = lo;
         const uint32_t total = s_off[end] - base;
-        for (uint32_t f = t; f < total; f += BS) {
-            const uint32_t g = base + f;
-            uint32_t l2 = start, h2 = end - 1;              // read ri: last one with s_off[ri] <= g
-            while (l2 < h2) {
-                uint32_t mid = (l2 + h2 + 1) >> 1;
-                if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
-            }
-            const uint32_t ri = l2;
-            const uint32_t local = g - s_off[ri];
-            const uint16_t *sp = s_sp + ri * slots_max;
-            int q = 0;
-            while (sp[q] <= local) q++;                      // slot holding candidate `local`
-            const uint32_t j = local - (q ? sp[q - 1] : 0);
-            const int c_nc = s_nc[ri], c_len = s_len[ri], c_cl = s_cl[ri], c_cd = s_cd[ri];
-            const int st = s0 + q / c_nc, c = q % c_nc;
-            const uint32_t cr = s_r[ri];
-            uint64_t iv_f;
-            bool lazy;
-            if (cf) { iv_f = s_first[ri * slots_max + q]; lazy = ((s_lazy[ri] >> q) & 1) != 0; }
-            else {
-                uint32_t iv_c;
-                iv_get(b, iv_slot(b, cr, st, c), iv_f, iv_c);
-                lazy = (iv_c & kLazyFlag) != 0;
-            }
-            const uint64_t loci = sa_get<WIDE>(ix, iv_f + j);
-            // the read's 2-bit row does not wait for the suffix array element
-            const bool two_bit = b.rd2 != nullptr;
-            uint64_t r2w[NW / 2], rnm[NW / 4];
-            if (two_bit && NW <= 8) load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);   // (longer rows: 24 registers held across the wait cost a wave of occupancy)
-            const int last = c_len - c_cl;
-            const int ofs = c * c_cd < last ? c * c_cd : last;
-            uint8_t rec = kRecSkip;
-            if (loci >= (uint64_t)ofs) {
-                const uint64_t t0 = loci - (uint64_t)ofs;
-                Window<NW> w;
-                bool flg = true;
-                if (two_bit) {
-                    flg = window_flagged(ix, t0, c_len);                 // issued together with the loads below
-                    if (NW > 8) load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
-                    eval_window2<NW>(r2w, rnm, c_len, ix.tgt2, ix.tgt2s, t0, w);
+        for (uint32_t f0 = 0; f0 < total; f0 += KB * BS) {
+            uint64_t tv[KB];                // suffix array element, then the window's start
+            uint32_t meta[KB];              // read of the block | slot << 10 | flags; kNone = no candidate
+            // ---- A: which candidate, and its suffix array element
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                const uint32_t f = f0 + (uint32_t)i * BS + t;
+                meta[i] = kNone;
+                tv[i] = 0;
+                if (f < total) {
+                    const uint32_t g = base + f;
+                    uint32_t l2 = start, h2 = end - 1;              // read ri: last one with s_off[ri] <= g
+                    while (l2 < h2) {
+                        uint32_t mid = (l2 + h2 + 1) >> 1;
+                        if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
+                    }
+                    const uint32_t ri = l2;
+                    const uint32_t local = g - s_off[ri];
+                    const uint16_t *sp = s_sp + ri * slots_max;
+                    int q = 0;
+                    while (sp[q] <= local) q++;                      // slot holding candidate `local`
+                    const uint32_t j = local - (q ? sp[q - 1] : 0);
+                    uint64_t iv_f;
+                    bool lazy;
+                    if (cf) { iv_f = s_first[ri * slots_max + q]; lazy = ((s_lazy[ri] >> q) & 1) != 0; }
+                    else {
+                        const int sti = q >= cmaxs ? 1 : 0;
+                        uint32_t iv_c;
+                        iv_get(b, iv_slot(b, s_r[ri], s0 + sti, q - sti * cmaxs), iv_f, iv_c);
+                        lazy = (iv_c & kLazyFlag) != 0;
+                    }
+                    tv[i] = sa_get<WIDE>(ix, iv_f + j);
+                    meta[i] = ri | ((uint32_t)q << 10) | (lazy ? kLazyBit : 0u);
                 }
-                if (flg) eval_window_rare<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, ix.tgt4, t0, w);       // N/EOS nearby (rare): the 4-bit copy decides
-                bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
-                for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
-                if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
-                if (WIDE) s_key[f] = (uint32_t)t0;
             }
-            s_rec[f] = rec;
+            // ---- B: window start; the region flags and the window's blocks are requested, nothing waits for them here
+            uint4 wv[KB][NBLK];
+            uint8_t fb0[KB], fb1[KB];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                fb0[i] = 0; fb1[i] = 0;
+#pragma unroll
+                for (int u = 0; u < NBLK; u++) wv[i][u] = make_uint4(0, 0, 0, 0);
+                if (meta[i] != kNone) {
+                    const uint32_t ri = meta[i] & 1023u;
+                    const int q = (int)((meta[i] >> 10) & 63u);
+                    const int c = q >= cmaxs ? q - cmaxs : q;
+                    const uint32_t geo = s_geo[ri];
+                    const int c_len = (int)(geo & 1023u), c_cl = (int)((geo >> 10) & 1023u), c_cd = (int)(geo >> 20);
+                    const int last = c_len - c_cl;
+                    const int ofs = c * c_cd < last ? c * c_cd : last;
+                    if (tv[i] >= (uint64_t)ofs) {
+                        const uint64_t t0 = tv[i] - (uint64_t)ofs;
+                        tv[i] = t0;
+                        if (two_bit) {
+                            const uint64_t g0 = t0 >> ix.flag_shift, g1 = (t0 + (uint64_t)c_len - 1) >> ix.flag_shift;
+                            fb0[i] = ix.nflag[g0 >> 3];
+                            fb1[i] = ix.nflag[g1 >> 3];
+                            window2_load<NW>(ix.tgt2, ix.tgt2s, t0, c_len, wv[i]);
+                        }
+                    } else
+                        meta[i] |= kOffStart;
+                }
+            }
+            // ---- C: compare, one result byte per candidate
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                if (meta[i] == kNone) continue;
+                const uint32_t f = f0 + (uint32_t)i * BS + t;
+                uint8_t rec = kRecSkip;
+                if (!(meta[i] & kOffStart)) {
+                    const uint32_t ri = meta[i] & 1023u;
+                    const int q = (int)((meta[i] >> 10) & 63u);
+                    const int sti = q >= cmaxs ? 1 : 0, c = q - sti * cmaxs, st = s0 + sti;
+                    const bool lazy = (meta[i] & kLazyBit) != 0;
+                    const uint32_t geo = s_geo[ri];
+                    const int c_len = (int)(geo & 1023u), c_cl = (int)((geo >> 10) & 1023u), c_cd = (int)(geo >> 20);
+                    const int last = c_len - c_cl;
+                    const int ofs = c * c_cd < last ? c * c_cd : last;
+                    const uint64_t t0 = tv[i];
+                    const uint32_t cr = s_r[ri];
+                    Window<NW> w;
+                    bool flg = true;
+                    if (two_bit) {
+                        const uint64_t g0 = t0 >> ix.flag_shift, g1 = (t0 + (uint64_t)c_len - 1) >> ix.flag_shift;
+                        flg = ((((uint32_t)fb0[i] >> (g0 & 7)) | ((uint32_t)fb1[i] >> (g1 & 7))) & 1) != 0;
+                        uint64_t r2w[NW / 2], rnm[NW / 4];
+                        if (ROWS) {
+                            flg |= ((s_hasn[ri] >> st) & 1) != 0;
+#pragma unroll
+                            for (int u = 0; u < NW / 4; u++) {
+                                const uint4 v = s_row[(ri * 2 + st) * (NW / 4) + u];
+                                r2w[2 * u] = ((uint64_t)v.y << 32) | v.x;
+                                r2w[2 * u + 1] = ((uint64_t)v.w << 32) | v.z;
+                            }
+#pragma unroll
+                            for (int u = 0; u < NW / 4; u++) rnm[u] = 0;
+                        } else
+                            load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
+                        window2_compare<NW>(r2w, rnm, c_len, t0, wv[i], w);
+                    }
+                    if (flg) eval_window_rare<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, ix.tgt4, t0, w);       // N/EOS nearby (rare): the 4-bit copy decides
+                    bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
+#pragma unroll 1
+                    for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
+                    if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
+                    if (WIDE) s_key[f] = (uint32_t)t0;
+                    if (!WIDE && rec != kRecSkip) {
+                        atomicAdd(&s_c2[ri], 1u << 16);
+                        if (rec <= s_mm[ri]) atomicMin(&s_k1[ri], ((uint32_t)rec << 16) | (base + f - s_off[ri]));
+                    }
+                }
+                s_rec[f] = rec;
+            }
         }
+        PROF(2);
         __syncthreads();
-        if (mine && t >= start && t < end) {
+        PROF(3);
+        auto replay_sequential = [&]() __attribute__((always_inline)) {
             const uint16_t *sp = s_sp + t * slots_max;
             const uint32_t rb = s_off[t] - base;
-            const int nslots = (s1 - s0 + 1) * nc;
             bool done = false;
             uint32_t prev = 0, strand_first = 0;
             uint64_t bloom[4] = {0, 0, 0, 0};                                // of the low words seen in this strand pass: the scan below is for its hits only
-            for (int q = 0; q < nslots && !done; q++) {
+            for (int q = 0; q < slots_max && !done; q++) {
+                if ((q >= cmaxs ? q - cmaxs : q) >= nc) continue;           // not a core of this read (an empty slot)
                 n_search++;
-                if (WIDE && q == nc) { strand_first = prev; bloom[0] = bloom[1] = bloom[2] = bloom[3] = 0; }    // the second strand pass starts with an empty set
+                if (WIDE && q == cmaxs) { strand_first = prev; bloom[0] = bloom[1] = bloom[2] = bloom[3] = 0; }    // the second strand pass starts with an empty set
                 const uint32_t upto = sp[q];
                 for (uint32_t x = prev; x < upto; x++) {
                     const int cm = s_rec[rb + x];
@@ -1963,36 +2177,59 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 }
                 prev = upto;
             }
+        };
+        if (WIDE) {
+            if (mine && t >= start && t < end) replay_sequential();
+        } else {
+            // second pass over the candidates: how many reach the read's smallest count, and the smallest count above it
+            for (uint32_t f = t; f < total; f += BS) {
+                const int cm = s_rec[f];
+                if (cm == kRecSkip) continue;
+                const uint32_t g = base + f;
+                uint32_t l2 = start, h2 = end - 1;
+                while (l2 < h2) {
+                    uint32_t mid = (l2 + h2 + 1) >> 1;
+                    if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
+                }
+                if (cm > (int)s_mm[l2]) continue;
+                if ((uint32_t)cm == (s_k1[l2] >> 16)) atomicAdd(&s_c2[l2], 1u);
+                else atomicMin(&s_nx[l2], (uint32_t)cm);
+            }
+            __syncthreads();
+            if (mine && t >= start && t < end) {
+                const uint32_t k1 = s_k1[t], c2 = s_c2[t];
+                if (k1 != 0xFFFFFFFFu && (k1 >> 16) == 0 && (int)(c2 & 0xFFFFu) > cfg.max_hits)
+                    replay_sequential();            // the reference stops at hit max_hits + 1 of an exact match: what it had seen until then counts
+                else {
+                    n_search += (uint32_t)((s1 - s0 + 1) * nc);
+                    n_cand += c2 >> 16;
+                    if (k1 != 0xFFFFFFFFu) {
+                        low_mm = (int)(k1 >> 16);
+                        low_inst = (int)(c2 & 0xFFFFu);
+                        const uint32_t nx = s_nx[t];
+                        nxt = nx < (uint32_t)init ? (int)nx : init;
+                        const uint32_t local = k1 & 0xFFFFu;
+                        const uint16_t *sp = s_sp + t * slots_max;
+                        int q = 0;
+                        while (sp[q] <= local) q++;
+                        best_q = q;
+                        best_j = local - (q ? sp[q - 1] : 0);
+                    }
+                }
+            }
         }
+        PROF(4);
         __syncthreads();
+        PROF(5);
         start = end;
     }
 
+    // what becomes of the read is decided first and the list appends are done BEFORE the result record is written: the barriers of
+    // the append wait for every store the wave has issued, and the scattered 20-byte records take long to drain
+    int rslt = BK_HR_NONE;
     if (mine) {
-        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-        if (rslt != BK_HR_NONE) {
-            uint64_t hit_left = 0;
-            int hit_strand = '?', e = -1;
-            if (low_inst >= 1) {
-                const int st = s0 + best_q / nc, c = best_q % nc;
-                const int last = len - cl;
-                const int ofs = c * cd < last ? c * cd : last;
-                const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, r, st, c));
-                hit_left = sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
-                hit_strand = st ? '-' : '+';
-                if (ent_lds) {
-                    int lo = 0, hi = (int)ix.n_ent - 1;
-                    while (lo <= hi) {
-                        int mid = (lo + hi) >> 1;
-                        if (hit_left < s_es[mid]) hi = mid - 1;
-                        else if (hit_left > s_ee[mid]) lo = mid + 1;
-                        else { e = mid; break; }
-                    }
-                } else
-                    e = find_entry(ix, hit_left);
-            }
-            write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
-        } else if (phase + 1 < n_phases) {
+        rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
+        if (rslt == BK_HR_NONE && phase + 1 < n_phases) {
             ReadPlan p = make_plan(len, cfg);
             int mm2, cl2, cd2, dummy[1];
             phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
@@ -2022,20 +2259,47 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     }
     if (lane == 0) {
         if (my_cmax) atomicMax(&s_cmax, my_cmax);
-        if (n_search) atomicAdd(&s_ctr[0], n_search);
-        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
+        if (n_search) atomicAdd(&s_ctr[0], (unsigned long long)n_search);
+        if (n_cand) atomicAdd(&s_ctr[1], (unsigned long long)n_cand);
+        if (n_lcm) atomicAdd(&s_ctr[2], (unsigned long long)n_lcm);
     }
+    PROF(6);
     __syncthreads();
-    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
-    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
-    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
-    if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    PROF(7);
+    // lists of the stripe set: 0 = next phase, 1 = wave kernel, 2 = general kernel
+    if (t >= 1 && t <= 3 && s_cnt[t]) s_base[t] = stripe_reserve(out, (int)t - 1, s_cnt[t]);
+    if (t == 4 && s_cmax) stripe_max(out, s_cmax);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
     __syncthreads();
-    if (dest == 1) next_act[s_base[1] + my_off] = r;
-    else if (dest == 2) wave[s_base[2] + my_off] = r;
-    else if (dest == 3) heavy[s_base[3] + my_off] = r;
+    PROF(8);
+    if (dest) stripe_put(out, dest - 1, s_base[dest] + my_off, r);
+    if (mine && rslt != BK_HR_NONE) {
+        uint64_t hit_left = 0;
+        int hit_strand = '?', e = -1;
+        if (low_inst >= 1) {
+            const int sti = best_q >= cmaxs ? 1 : 0, c = best_q - sti * cmaxs, st = s0 + sti;
+            const int last = len - cl;
+            const int ofs = c * cd < last ? c * cd : last;
+            const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, r, st, c));
+            hit_left = sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
+            hit_strand = st ? '-' : '+';
+            if (ent_lds) {
+                int lo = 0, hi = (int)ix.n_ent - 1;
+                while (lo <= hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (hit_left < (uint64_t)s_es[mid]) hi = mid - 1;
+                    else if (hit_left > (uint64_t)s_ee[mid]) lo = mid + 1;
+                    else { e = mid; break; }
+                }
+            } else
+                e = find_entry(ix, hit_left);
+        }
+        write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
+    }
+#ifdef BK_PROF
+    PROF(9);
+    if (t == 0) { for (int k = 0; k < 10; k++) atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + k], (unsigned long long)pt[k]); atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + 10], 1ULL); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2232,7 +2496,7 @@ __global__ void __launch_bounds__(256) k_replay(DevIndex ix, DevAlignCfg cfg, De
     if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
     if (t == 4 && s_cnt[4]) s_base[4] = atomicAdd(flat_cnt, s_cnt[4]);
     if (t == 5 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
     __syncthreads();
     if (dest == 1) next_act[s_base[1] + my_off] = r;
     else if (dest == 2) wave[s_base[2] + my_off] = r;
@@ -2480,7 +2744,7 @@ __global__ void __launch_bounds__(256) k_direct(DevIndex ix, DevAlignCfg cfg, De
     if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(general_cnt, s_cnt[2]);
     if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(slist_cnt, s_cnt[3]);
     if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[t - 8], s_ctr[t - 8]);
+    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
     __syncthreads();
     if (dest == 1) next_act[s_base[1] + my_off] = r;
     else if (dest == 2) general[s_base[2] + my_off] = r;
@@ -2838,11 +3102,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     if (pend_n) flush_pending();
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
     if (lane == 0) {
-        if (n_search) atomicAdd(&b.ctr[0], n_search);
-        if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-        if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
-        if (n_cand) atomicAdd(&b.ctr[4], n_cand);
-        if (kDiag) { atomicAdd(&b.ctr[5], n_fetch); atomicAdd(&b.ctr[6], n_dup); }
+        if (n_search) atomicAdd(&b.ctr[ctr_stripe() + 0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[ctr_stripe() + 2], n_lcm); atomicAdd(&b.ctr[ctr_stripe() + 3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 4], n_cand);
+        if (kDiag) { atomicAdd(&b.ctr[ctr_stripe() + 5], n_fetch); atomicAdd(&b.ctr[ctr_stripe() + 6], n_dup); }
     }
 }
 
@@ -3360,10 +3624,10 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
     if (lane == 0) {
         hs.slot_epoch[wave_slot] = epoch;
         if (!ENUM) {                                   // the ENUM replay is ours, not work the reference does
-            if (n_search) atomicAdd(&b.ctr[0], n_search);
-            if (n_cand) atomicAdd(&b.ctr[1], n_cand);
-            if (n_lcm) { atomicAdd(&b.ctr[2], n_lcm); atomicAdd(&b.ctr[3], n_lcm); }
-            if (n_cand) atomicAdd(&b.ctr[4], n_cand);
+            if (n_search) atomicAdd(&b.ctr[ctr_stripe() + 0], n_search);
+            if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 1], n_cand);
+            if (n_lcm) { atomicAdd(&b.ctr[ctr_stripe() + 2], n_lcm); atomicAdd(&b.ctr[ctr_stripe() + 3], n_lcm); }
+            if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 4], n_cand);
         }
     }
 }
@@ -4202,12 +4466,36 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
     hipLaunchKernelGGL(k_pack_target2, dim3((unsigned)blocks), dim3(256), 0, s, tgt4, nwords4, tgt2, nflag32, flag_shift);
 }
 
-void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, hipStream_t s)
+static uint32_t stripe_cap(unsigned blocks, unsigned per_block)
+{
+    return ((blocks + kListStripes - 1) / kListStripes) * per_block;
+}
+
+// the stripes of up to three lists -> their dense forms (appended behind total[i] entries; the counts and the maximum follow)
+static void launch_compact(const StripeSet &set, uint32_t *const *dense, uint32_t *const *total, int n, uint32_t *max_out, hipStream_t s)
+{
+    CompactJobs J;
+    J.set = set;
+    for (int i = 0; i < 3; i++) { J.dense[i] = dense[i < n ? i : 0]; J.total[i] = total[i < n ? i : 0]; }
+    J.max_out = max_out;
+    J.n = n;
+    hipLaunchKernelGGL(k_compact_lists, dim3(1024, (unsigned)n), dim3(256), 0, s, J);
+    hipLaunchKernelGGL(k_finish_lists, dim3(1), dim3(64), 0, s, J);
+}
+
+// stage: at least n_reads + (kListStripes + 2) * 1024 entries; stripe_cnt: kListStripes * 16 words, zero between launches
+void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, uint32_t *stage,
+                 uint32_t *stripe_cnt, hipStream_t s)
 {
     if (b.nw == 8 || b.nw == 16) {          // register-kernel path: fused pack + init
         const unsigned blocks = (b.n_reads + 255) / 256;
-        if (b.nw == 8) hipLaunchKernelGGL(k_prep_fused<8>, dim3(blocks), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
-        else hipLaunchKernelGGL(k_prep_fused<16>, dim3(blocks), dim3(256), 0, s, cfg, b, act, act_cnt, cmax);
+        StripeSet out;
+        out.cnt = stripe_cnt;
+        out.stage[0] = out.stage[1] = out.stage[2] = stage;
+        out.cap = stripe_cap(blocks, 256);
+        if (b.nw == 8) hipLaunchKernelGGL(k_prep_fused<8>, dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        else hipLaunchKernelGGL(k_prep_fused<16>, dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        launch_compact(out, &act, &act_cnt, 1, cmax, s);
         return;
     }
     const uint32_t rpb = 256 / (2 * b.wpr);
@@ -4319,21 +4607,26 @@ void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, cons
     if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys);
 }
 
+// stage: at least n_act * cmax * nstr + (kListStripes + 2) * 1024 entries; stripe_cnt: kListStripes * 16 words, zero between launches
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
-                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, hipStream_t s)
+                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
+                     hipStream_t s)
 {
     uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
-    const int ilp = lazy >> 8;                         // bits 8..: searches per lane (0 / 1 = the plain kernel)
+    int ilp = lazy >> 8;                               // bits 8..: searches per lane (0 / 1 = the plain kernel)
     lazy &= 0xff;
-    if (ilp >= 2 && ix.hp == nullptr) {
-        const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
-        const unsigned blocks2 = (unsigned)((threads + per - 1) / per);
-        if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks2), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
-        else hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks2), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
-        return;
-    }
-    unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(k_search_a, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, list, list_cnt);
+    if (ilp < 2 || ix.hp != nullptr) ilp = 1;
+    else if (ilp != 2) ilp = 4;
+    const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
+    const unsigned blocks = (unsigned)((threads + per - 1) / per);
+    StripeSet out;
+    out.cnt = stripe_cnt;
+    out.stage[0] = out.stage[1] = out.stage[2] = stage;
+    out.cap = stripe_cap(blocks, (unsigned)per);
+    if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    else hipLaunchKernelGGL(k_search_a, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    launch_compact(out, &list, &list_cnt, 1, nullptr, s);
 }
 
 void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
@@ -4364,9 +4657,10 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 #undef BK_LIGHT
 }
 
+// stage: three buffers of at least n_act + (kListStripes + 2) * 1024 entries, stripe_cnt: kListStripes * 16 words, zero between launches
 void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
-                 uint32_t *wave_cnt, uint32_t *cmax_next, int nw, hipStream_t s)
+                 uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s)
 {
     int bs = (nw >> 8) ? (nw >> 8) : 256;              // bits 8..: reads (= threads) per block, 64 .. 1024
     nw &= 0xff;
@@ -4375,7 +4669,12 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     unsigned blocks = (n_act + (unsigned)bs - 1) / (unsigned)bs;
     if (slots_max < 1) slots_max = 1;
     size_t lds = (size_t)bs * slots_max * (flat_caches_first(wide, bs, slots_max) ? 6 : 2);
-#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, n_act, phase, slots_max, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
+    StripeSet out;
+    out.cnt = stripe_cnt;
+    for (int i = 0; i < 3; i++) out.stage[i] = stage[i];
+    out.cap = stripe_cap(blocks, (unsigned)bs);
+    const int have_wave = wave != nullptr;
+#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, n_act, phase, slots_max, out, have_wave)
 #define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
 #define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
     if (nw <= 8) { if (wide) BK_FLAT_W(8); else BK_FLAT_B(8); }
@@ -4383,6 +4682,9 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 #undef BK_FLAT_W
 #undef BK_FLAT_B
 #undef BK_FLAT
+    // list order of the set: next phase, wave kernel, general kernel (the wave list may be absent: then it stays empty)
+    uint32_t *dense[3] = {next_act, have_wave ? wave : heavy, heavy}, *total[3] = {next_cnt, have_wave ? wave_cnt : heavy_cnt, heavy_cnt};
+    launch_compact(out, dense, total, 3, cmax_next, s);
 }
 
 void launch_eval(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
@@ -4658,3 +4960,12 @@ void launch_snp_sites(const DevIndex &ix, const uint32_t *planes, uint64_t g0, u
 }
 
 }  // namespace bk
+
+extern "C" int bk_debug_prof(unsigned long long *out16)
+{
+    unsigned long long h[64 * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bk::g_prof), sizeof(h)) != hipSuccess) return 1;
+    for (int k = 0; k < 16; k++) { out16[k] = 0; for (int s0 = 0; s0 < 64; s0++) out16[k] += h[s0 * 16 + k]; }
+    return 0;
+}
+

@@ -165,8 +165,49 @@ static int bin_bench()
     printf("bin: k_scatter (8-byte pair records into %u bins): %6.1f G records/s (%.0f GB/s read + written)\n", nbins, (double)npairs / ms / 1e6, (double)npairs * 16 / ms / 1e6);
     return 0;
 }
+// What do the per-block global atomics of the list-appending kernels cost?  200 000 blocks of 256 threads (k_flat's grid for 50 M
+// reads), each doing a little LDS work and then `nat` atomics: all blocks on the same words of one line (what the kernels did),
+// spread over `stripes` lines, or none.  `ret` != 0: one lane waits for the returned value (a list append needs its base).
+__global__ void __launch_bounds__(256) k_atomics(unsigned long long *__restrict__ ctr, int nat, int stripes, int ret, uint64_t *out)
+{
+    __shared__ uint32_t s_x[256];
+    s_x[threadIdx.x] = threadIdx.x * 2654435761u;
+    __syncthreads();
+    uint32_t v = s_x[(threadIdx.x * 7 + 3) & 255];
+    __syncthreads();
+    unsigned long long got = 0;
+    if (threadIdx.x < (unsigned)nat) {
+        unsigned long long *p = ctr + (uint64_t)(blockIdx.x % (unsigned)stripes) * 8 + threadIdx.x;
+        if (ret) got = atomicAdd(p, (unsigned long long)(v & 3)); else atomicAdd(p, (unsigned long long)(v & 3));
+    }
+    __syncthreads();
+    if (got == 0x123456789ULL) out[0] = got;
+}
+static int atomic_bench()
+{
+    unsigned long long *ctr;
+    uint64_t *out;
+    hipMalloc(&ctr, 4096 * 64); hipMalloc(&out, 8);
+    hipMemset(ctr, 0, 4096 * 64);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 200000;
+    for (int ret = 0; ret < 2; ret++)
+        for (int nat : {0, 1, 3, 7})
+            for (int stripes : {1, 64, 4096}) {
+                if (nat == 0 && stripes > 1) continue;
+                hipLaunchKernelGGL(k_atomics, dim3(blocks), dim3(256), 0, 0, ctr, nat, stripes, ret, out);
+                hipEventRecord(e0);
+                for (int rep = 0; rep < 5; rep++) hipLaunchKernelGGL(k_atomics, dim3(blocks), dim3(256), 0, 0, ctr, nat, stripes, ret, out);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("atomic: %d blocks, %d atomics each on %4d line(s), value %s: %7.3f ms per launch\n", blocks, nat, stripes, ret ? "awaited" : "dropped", ms / 5);
+            }
+    return 0;
+}
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "atomic") return atomic_bench();
     if (argc > 1 && std::string(argv[1]) == "calib") return calib();
     if (argc > 1 && std::string(argv[1]) == "bin") return bin_bench();
     uint64_t maxn = (16ULL << 30) / 8;
