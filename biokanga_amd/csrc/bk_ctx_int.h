@@ -39,15 +39,18 @@ struct bk_ctx {
     uint32_t cap_rd2w = 0;
     int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
     uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
+    uint64_t *d_k2s = nullptr;            // their sample levels (DevIndex::k2s)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
     void *d_sort_tmp = nullptr;
     uint64_t cap_sort = 0;
     size_t sort_tmp_bytes = 0;
-    int sort_lists = 1;      // bit 0: search work list, bit 1: wave list (no gain measured) are grouped by index position
+    int sort_lists = 7;      // bit 0: search work list grouped by index position; bit 1: wave list sorted, by index position or (bit 2) longest read first
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int k2s_levels = 6;      // how many of them (kK2Levels)
+    int use_k2s = 0;         // sample levels over the second-level keys (one line per level of 8 instead of one per halving): measured, no gain
     int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
     int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)
     int use_hp = 0;          // prefix hash in front of k-mer table + keys (one line per search instead of two or three).  Off: measured on

@@ -42,6 +42,7 @@ struct StripeSet {
     uint32_t *stage[3];         // per list: kListStripes regions of cap entries
     uint32_t cap;
 };
+constexpr int kK2Levels = 6;
 constexpr int kCtrStripes = 64;       // copies of the DevBatch::ctr block (8 counters = one 64-byte line each)
 constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
 constexpr int kWave = 64;
@@ -65,6 +66,9 @@ struct DevIndex {
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
     const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null
+    const uint64_t *k2s;        // every 8th, 64th, .. 8^kK2Levels-th key of k2 (level L at k2s + k2s_off[L - 1], L = 1..), the last key of
+    uint64_t k2s_off[6];        //   each group of 8^L: a bound inside a big bucket costs one line per level instead of one per halving; may be null
+    int k2s_levels;             //   levels built (1 .. kK2Levels)
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
     const uint64_t *hp;         // prefix hash: distinct hp_k-base prefixes of the suffixes -> their suffix array interval, 64-byte buckets
     int hp_bits, hp_k;          //   of 8 entries {tag 21 | displacement 3 | count 8 | interval start 32}; 2^hp_bits buckets; may be null

@@ -42,6 +42,7 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_build_k2s(const uint64_t *src, uint64_t n_src, uint64_t *dst, uint64_t n_dst, hipStream_t s);
 void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
@@ -209,8 +210,9 @@ int build_ktab(bk_ctx *c)
 int build_k2(bk_ctx *c)
 {
     free_dev(c->d_k2);
-    c->d_k2 = nullptr;
-    c->ix.k2 = nullptr;
+    free_dev(c->d_k2s);
+    c->d_k2 = c->d_k2s = nullptr;
+    c->ix.k2 = c->ix.k2s = nullptr;
     if (!c->use_k2 || c->ix.k <= 0) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -231,6 +233,23 @@ int build_k2(bk_ctx *c)
         return BK_OK;
     }
     c->ix.k2 = c->d_k2;
+    // sample levels over the keys (k2s_bounds): n / 7 more words
+    if (c->use_k2s) {
+        uint64_t nl[kK2Levels + 1], tot = 0;
+        nl[0] = c->ix.n;
+        const int nlev = c->k2s_levels < 1 ? 1 : (c->k2s_levels > kK2Levels ? kK2Levels : c->k2s_levels);
+        for (int L = 1; L <= kK2Levels; L++) { nl[L] = L <= nlev ? (nl[L - 1] + 7) / 8 : 0; c->ix.k2s_off[L - 1] = tot; tot += nl[L]; }
+        c->ix.k2s_levels = nlev;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (tot * 8 <= free_b && free_b - tot * 8 >= total_b / 4 && hipMalloc(&c->d_k2s, tot * 8) == hipSuccess) {
+            for (int L = 1; L <= nlev; L++)
+                launch_build_k2s(L == 1 ? c->d_k2 : c->d_k2s + c->ix.k2s_off[L - 2], nl[L - 1], c->d_k2s + c->ix.k2s_off[L - 1], nl[L], c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->ix.k2s = c->d_k2s;
+        } else
+            (void)hipGetLastError();
+    }
     return BK_OK;
 }
 
@@ -795,7 +814,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             if ((c->sort_lists & 2) && n_wave >= 4096) {
                 int rs = ensure_sort_scratch(c, n_wave, s);
                 if (rs) return rs;
-                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, c->sort_shift, c->d_sort[0], s);
+                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, (c->sort_lists & 4) ? -1 : c->sort_shift, c->d_sort[0], s);
                 rs = sort_work(c, c->d_wave, n_wave, s, &wlist);
                 if (rs) return rs;
             }
@@ -1084,7 +1103,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k2s); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
@@ -1156,7 +1175,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     }
     if (n == "sort_lists") {
         int64_t old = c->sort_lists;
-        c->sort_lists = (int)value & 3;
+        c->sort_lists = (int)value & 7;
         return old;
     }
     if (n == "use_tgt2") {
@@ -1196,6 +1215,20 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     if (n == "use_k2") {
         int64_t old = c->use_k2;
         c->use_k2 = value ? 1 : 0;
+        int rc = build_k2(c);
+        if (!rc) rc = build_hp(c);
+        return rc ? rc : old;
+    }
+    if (n == "k2s_levels") {
+        int64_t old = c->k2s_levels;
+        c->k2s_levels = (int)value;
+        int rc = build_k2(c);
+        if (!rc) rc = build_hp(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_k2s") {
+        int64_t old = c->use_k2s;
+        c->use_k2s = value ? 1 : 0;
         int rc = build_k2(c);
         if (!rc) rc = build_hp(c);
         return rc ? rc : old;

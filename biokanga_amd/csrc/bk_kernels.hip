@@ -799,6 +799,80 @@ __device__ __forceinline__ int k2_cmp(uint64_t key, uint64_t m, uint64_t q2)
     return key < q2 ? -1 : (key > q2 ? 1 : 0);
 }
 
+// Lower and upper bound of the masked probe q2 among the keys k2[lo, hi) of one k-mer bucket, through the sample levels
+// (DevIndex::k2s): at level L the bucket is a run of groups of 8^L keys, every group but the last lies inside the bucket whole and is
+// represented by its last key, so counting the groups whose key sorts below (at or below) the probe names the group that holds the
+// bound; eight groups are one 64-byte line.  l1 = first index with key >= q2, l2 = first index with key > q2.
+__device__ __forceinline__ void k2s_bounds(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t m, uint64_t q2, uint64_t &l1, uint64_t &l2)
+{
+    uint64_t a1 = lo, b1 = hi, a2 = lo, b2 = hi;
+    int L = 0;
+    while (L < ix.k2s_levels && ((hi - 1) >> (3 * L)) - (lo >> (3 * L)) >= 8) L++;
+    if (((hi - 1) >> (3 * L)) - (lo >> (3 * L)) >= 8) {
+        // wider than eight groups of the top level: halve over its samples first
+        const uint64_t *__restrict__ S = ix.k2s + ix.k2s_off[L - 1];
+        uint64_t g1 = lo >> (3 * L), h1 = (hi - 1) >> (3 * L), g2 = g1, h2 = h1;      // first group in [g, h) whose key is >= / > the probe, else h
+        while (g1 < h1 || g2 < h2) {
+            const bool o1 = g1 < h1, o2 = g2 < h2;
+            const uint64_t m1 = g1 + ((h1 - g1) >> 1), m2 = g2 + ((h2 - g2) >> 1);
+            const uint64_t v1 = o1 ? S[m1] : 0, v2 = o2 ? S[m2] : 0;
+            if (o1) { if (k2_cmp(v1, m, q2) < 0) g1 = m1 + 1; else h1 = m1; }
+            if (o2) { if (k2_cmp(v2, m, q2) <= 0) g2 = m2 + 1; else h2 = m2; }
+        }
+        a1 = a1 > (g1 << (3 * L)) ? a1 : (g1 << (3 * L));
+        b1 = b1 < ((g1 + 1) << (3 * L)) ? b1 : ((g1 + 1) << (3 * L));
+        a2 = a2 > (g2 << (3 * L)) ? a2 : (g2 << (3 * L));
+        b2 = b2 < ((g2 + 1) << (3 * L)) ? b2 : ((g2 + 1) << (3 * L));
+        L--;
+    }
+    for (; L >= 1; L--) {
+        const uint64_t *__restrict__ S = ix.k2s + ix.k2s_off[L - 1];
+        const uint64_t g1 = a1 >> (3 * L), e1 = (b1 - 1) >> (3 * L), g2 = a2 >> (3 * L), e2 = (b2 - 1) >> (3 * L);
+        uint64_t v1[8], v2[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // (always a load from inside the level, never an exec-masked one: see DESIGN.md on hipcc 7.2 and masked loads)
+            v1[j] = S[g1 + j < e1 ? g1 + j : g1];
+            v2[j] = S[g2 + j < e2 ? g2 + j : g2];
+        }
+        uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c1 += (g1 + j < e1 && k2_cmp(v1[j], m, q2) < 0) ? 1u : 0u;
+            c2 += (g2 + j < e2 && k2_cmp(v2[j], m, q2) <= 0) ? 1u : 0u;
+        }
+        const uint64_t s1 = (g1 + c1) << (3 * L), s2 = (g2 + c2) << (3 * L), w = 1ULL << (3 * L);
+        a1 = a1 > s1 ? a1 : s1;
+        b1 = b1 < s1 + w ? b1 : s1 + w;
+        a2 = a2 > s2 ? a2 : s2;
+        b2 = b2 < s2 + w ? b2 : s2 + w;
+    }
+    // at most eight keys left on either side
+    uint64_t v1[8], v2[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v1[j] = ix.k2[a1 + j < b1 ? a1 + j : a1];
+        v2[j] = ix.k2[a2 + j < b2 ? a2 + j : a2];
+    }
+    uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        c1 += (a1 + j < b1 && k2_cmp(v1[j], m, q2) < 0) ? 1u : 0u;
+        c2 += (a2 + j < b2 && k2_cmp(v2[j], m, q2) <= 0) ? 1u : 0u;
+    }
+    l1 = a1 + c1;
+    l2 = a2 + c2;
+}
+
+// level L of the samples from level L - 1 (level 0 = the keys): dst[i] = src[min(8 i + 7, n_src - 1)]
+__global__ void k_build_k2s(const uint64_t *__restrict__ src, uint64_t n_src, uint64_t *__restrict__ dst, uint64_t n_dst)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = 8 * i + 7;
+        dst[i] = src[j < n_src ? j : n_src - 1];
+    }
+}
+
 // as cmp_core, but only bases [start, cl) of the core are compared
 __device__ __forceinline__ int cmp_core_from(const uint64_t *__restrict__ rdw, int ofs, int cl, int start,
                                              const uint64_t *__restrict__ tgt, uint64_t pos)
@@ -1028,12 +1102,37 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
 // k_search_a with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
 // keys) of all ILP searches are in flight together: item u of a lane is search number tid + u * (lanes of the grid), i.e. every u
 // keeps k_search_a's mapping of neighbouring lanes to neighbouring searches.  Same records, same work list (order aside).
+// -DBK_PROF=1 (k_flat) / 2 (k_search_a_ilp): where a block's time goes - thread 0 adds the cycles between its section marks to
+// g_prof (summed over the blocks, read with bk_debug_prof(); `BK_DIAG=1 python bench.py` prints them)
+__device__ unsigned long long g_prof[64 * 16];
+#ifdef BK_PROF
+#define PROF_AT(k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long now_ = clock64(); pt[k] = now_ - last_; last_ = now_; } } while (0)
+#define PROF_BEGIN long long pt[10] = {0,0,0,0,0,0,0,0,0,0}, last_ = clock64()
+#define PROF_END do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + k_], (unsigned long long)pt[k_]); atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + 10], 1ULL); } } while (0)
+#else
+#define PROF_AT(k) do { } while (0)
+#define PROF_BEGIN do { } while (0)
+#define PROF_END do { } while (0)
+#endif
+#if defined(BK_PROF) && BK_PROF == 1
+#define PROF(k) PROF_AT(k)
+#else
+#define PROF(k) do { } while (0)
+#endif
+#if defined(BK_PROF) && BK_PROF == 2
+#define PROFS(k) PROF_AT(k)
+#else
+#define PROFS(k) do { } while (0)
+#endif
 template <int ILP>
 __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                       uint32_t n_act, int phase, int cmax, int nstr, int lazy,
                                                       StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base;
+#if defined(BK_PROF) && BK_PROF == 2
+    PROF_BEGIN;
+#endif
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const uint32_t per_read = (uint32_t)(nstr * cmax);
@@ -1070,6 +1169,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             }
         }
     }
+    PROFS(0);
     // stage 2: k-mer table
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
@@ -1082,6 +1182,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             hi[u] = ktab_get(ix, code + 1);
         }
     }
+    PROFS(1);
     // stage 3: small buckets from the key array
     uint64_t key[ILP][kInlineBucket];
 #pragma unroll
@@ -1090,6 +1191,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
 #pragma unroll
         for (uint32_t j = 0; j < kInlineBucket; j++) key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ix.k2[lo[u] + j] : ~0ULL;
     }
+    PROFS(2);
     // stage 4: results
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
@@ -1118,6 +1220,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             }
         }
     }
+    PROFS(3);
     // work-list appends, one global atomic per block.  The interval records are stored after them: the barriers of the append
     // wait for every store the wave has issued.
     const int lane = threadIdx.x & 63;
@@ -1133,14 +1236,20 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             my_off[u] = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
         }
     }
+    PROFS(4);
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
     __syncthreads();
+    PROFS(5);
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         if (push[u]) stripe_put(out, 0, s_base + my_off[u], (uint32_t)slot[u]);
         if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
     }
+#if defined(BK_PROF) && BK_PROF == 2
+    PROFS(6);
+    PROF_END;
+#endif
 }
 
 template <bool WIDE>
@@ -1149,6 +1258,10 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_list) return;
+#ifdef BK_DIAG_B
+    unsigned long long d_k2 = 0, d_deep = 0;
+    struct Fin { unsigned long long &a, &b; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (b) atomicAdd(&bb.ctr[ctr_stripe() + 6], b); } } fin{d_k2, d_deep, b};
+#endif
     const uint64_t slot = list[i];
     const uint32_t r = (uint32_t)(slot % b.n_reads), sc = (uint32_t)(slot / b.n_reads);
     const int strand = (int)(sc / kMaxCoresFast), c = (int)(sc % kMaxCoresFast);
@@ -1175,9 +1288,17 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
         // lower and upper bound in lock step: two independent loads per round
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
+        if (ix.k2s != nullptr && cnt > 0) {
+            k2s_bounds(ix, first, first + cnt, m, q2, l1, l2);
+            h1 = l1;
+            h2 = l2;
+        }
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
             const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+#ifdef BK_DIAG_B
+            d_k2 += 1 + (1ULL << 32) * ((a1 && (h1 - l1) > 8) + (a2 && (h2 - l2) > 8 && (m1 >> 3) != (m2 >> 3)));
+#endif
             const uint64_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
             if (a1) { if (k2_cmp(v1, m, q2) < 0) l1 = m1 + 1; else h1 = m1; }
             if (a2) { if (k2_cmp(v2, m, q2) <= 0) l2 = m2 + 1; else h2 = m2; }
@@ -1201,6 +1322,9 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
             const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+#ifdef BK_DIAG_B
+            d_deep += 1 + (1ULL << 32) * (a1 + (a2 && m1 != m2));
+#endif
             const uint64_t s1 = a1 ? sa_get<WIDE>(ix, m1) : 0, s2 = a2 ? sa_get<WIDE>(ix, m2) : 0;
             const int c1 = a1 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s1) : 0;
             const int c2 = a2 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s2) : 0;
@@ -1835,14 +1959,6 @@ constexpr uint32_t kLdsEntries = 128;     // entry tables up to this size are se
 constexpr uint32_t kFlatCap = 8192;        // result bytes held in LDS per pass over a block's reads
 constexpr uint8_t kRecSkip = 255;
 
-// -DBK_PROF: where a k_flat block's time goes - thread 0 adds the cycles between its section marks to g_prof (summed over the
-// blocks, read with bk_debug_prof(); `BK_DIAG=1 python bench.py` prints them)
-__device__ unsigned long long g_prof[64 * 16];
-#ifdef BK_PROF
-#define PROF(k) do { if (t == 0) { const long long now_ = clock64(); pt[k] = now_ - last_; last_ = now_; } } while (0)
-#else
-#define PROF(k) do { } while (0)
-#endif
 template <bool WIDE> struct FlatEntT { typedef uint64_t type; };
 template <> struct FlatEntT<false> { typedef uint32_t type; };
 __host__ __device__ constexpr bool flat_caches_first(bool wide, int bs, int slots_max)
@@ -1898,8 +2014,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     using EntT = typename FlatEntT<WIDE>::type;
     __shared__ EntT s_es[kLdsEntries], s_ee[kLdsEntries];              // entry table, when it is small enough
     const uint32_t t = threadIdx.x;
-#ifdef BK_PROF
-    long long pt[10] = {0,0,0,0,0,0,0,0,0,0}, last_ = clock64();
+#if defined(BK_PROF) && BK_PROF == 1
+    PROF_BEGIN;
 #endif
     const int lane = t & 63, wid = t >> 6;
     if (t < 4) s_cnt[t] = 0;
@@ -2296,9 +2412,9 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
         }
         write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
     }
-#ifdef BK_PROF
+#if defined(BK_PROF) && BK_PROF == 1
     PROF(9);
-    if (t == 0) { for (int k = 0; k < 10; k++) atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + k], (unsigned long long)pt[k]); atomicAdd(&g_prof[(blockIdx.x & 63) * 16 + 10], 1ULL); }
+    PROF_END;
 #endif
 }
 
@@ -4545,6 +4661,13 @@ void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int 
     hipLaunchKernelGGL(k_build_hp, dim3((unsigned)blocks), dim3(256), 0, s, ix, tab, bits, k, fail);
 }
 
+void launch_build_k2s(const uint64_t *src, uint64_t n_src, uint64_t *dst, uint64_t n_dst, hipStream_t s)
+{
+    uint64_t blocks = (n_dst + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (n_dst) hipLaunchKernelGGL(k_build_k2s, dim3((unsigned)blocks), dim3(256), 0, s, src, n_src, dst, n_dst);
+}
+
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s)
 {
     uint64_t blocks = (ix.n + 255) / 256;
@@ -4583,7 +4706,7 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
     if (nc > kMaxCoresFast) nc = kMaxCoresFast;
     const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
     uint32_t best_n = 0;
-    uint64_t best_first = 0;
+    uint64_t best_first = 0, work = 0;
     for (int st = s0; st <= s1; st++)
         for (int c = 0; c < nc; c++) {
             uint64_t slot = iv_slot(b, r, st, c);
@@ -4591,9 +4714,12 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
             uint32_t raw;
             iv_get(b, slot, f, raw);
             uint32_t cnt = raw & ~kLazyFlag;
+            work += cnt;
             if (cnt > best_n) { best_n = cnt; best_first = f; }
         }
-    keys[i] = (uint32_t)(best_first >> shift);
+    // shift < 0: longest job first (the reads are dealt to the waves in list order; a read with 10^5 candidates that comes up last
+    // keeps one wave busy long after the others have run dry)
+    keys[i] = shift < 0 ? 0xFFFFFFFFu - (uint32_t)(work < 0xFFFFFFFFULL ? work : 0xFFFFFFFFULL) : (uint32_t)(best_first >> shift);
 }
 
 void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s)
