@@ -80,7 +80,7 @@ void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
                   uint32_t *list_cnt_dev, uint32_t *list_cnt_host, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_unaligned_list(const bk_hit *out, uint32_t n, uint32_t *list, uint32_t *cnt, hipStream_t s);
 void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
-                     int min_pct, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
+                     int min_pct, int long_reads, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
                         hipStream_t s);
@@ -864,8 +864,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             }
         }
         if (eh == hipSuccess && c->params.min_chimeric_len > 0) {
-            if (maxlen > 512) rc2 = BK_ERR_PARAMS;                 // the device AdaptiveTrim keeps a 512-base mismatch map per lane
-            else rc2 = size_heavy_scratch(c);
+            rc2 = size_heavy_scratch(c);
             if (rc2 == BK_OK) {
                 eh = hipMemsetAsync(sm, 0, 16 * 4, s);
                 if (eh == hipSuccess) {
@@ -874,7 +873,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                 }
                 if (eh == hipSuccess) eh = hipStreamSynchronize(s);
                 if (eh == hipSuccess && hm[0]) {
-                    launch_chimeric(c->ix, c->cfg, b, c->hs, c->d_act[0], hm[0], c->params.min_chimeric_len, sm + 1, d_seg2, s);
+                    launch_chimeric(c->ix, c->cfg, b, c->hs, c->d_act[0], hm[0], c->params.min_chimeric_len, maxlen > 512 ? 1 : 0, sm + 1, d_seg2, s);
                     eh = hipGetLastError();
                 }
             }

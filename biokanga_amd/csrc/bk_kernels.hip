@@ -3237,11 +3237,12 @@ __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_
 // run of >= min_flank matching bases, is at least min_trim long and stays under (max_mm + 1) % mismatches - counting, as the
 // reference does, every base of a mismatching run against the length from the stretch's start (first test) and against the
 // stretch itself (second test), in double precision.  The reference keeps a table of match / mismatch runs; here the runs are
-// read off a bitmap of the mismatching positions (bit i of word i / 64), so a lane needs 8 words for reads of up to 512 bases.
-constexpr int kATWords = 8;
-
-__device__ __forceinline__ int at_run_end(const uint64_t (&bm)[kATWords], int p, int n)    // first q > p with bit(q) != bit(p), or n
+// read off a bitmap of the mismatching positions (bit i of word i / 64): ATW = 8 words for reads of up to 512 bases (registers), 32 for
+// the longest reads the boundary takes (2000 bases; the map then lives in scratch memory - its own instantiation of the kernel).
+template <int ATW>
+__device__ __forceinline__ int at_run_end(const uint64_t (&bm)[ATW], int p, int n)    // first q > p with bit(q) != bit(p), or n
 {
+    constexpr int kATWords = ATW;
     const int bit = (int)((bm[p >> 6] >> (p & 63)) & 1);
     int w = p >> 6;
     uint64_t x = (bit ? ~bm[w] : bm[w]) >> (p & 63);
@@ -3254,9 +3255,11 @@ __device__ __forceinline__ int at_run_end(const uint64_t (&bm)[kATWords], int p,
 }
 
 // returns the trimmed length (0 = nothing acceptable); trim5 / trim3 = bases cut from the start / end of the read as given
+template <int ATW>
 __device__ int adaptive_trim_dev(const uint64_t *__restrict__ rdw, const uint64_t *__restrict__ tgt, uint64_t t, int len, int min_trim, int max_mm,
                                  int min_flank, int &trim_mm, int &trim5, int &trim3)
 {
+    constexpr int kATWords = ATW;
     trim_mm = 0; trim5 = 0; trim3 = 0;
     if (len < 25 || len > 64 * kATWords || min_trim < 15 || min_trim > len || max_mm > 15 || min_flank > 10) return 0;
     if (min_flank == 0) min_flank = 1;
@@ -3273,7 +3276,7 @@ __device__ int adaptive_trim_dev(const uint64_t *__restrict__ rdw, const uint64_
     bool have8 = false;
     int first_start = -1, last_start = -1, last_end = -1, first_end = -1;
     for (int p = 0; p < len;) {
-        const int q = at_run_end(bm, p, len), rl = q - p;
+        const int q = at_run_end<ATW>(bm, p, len), rl = q - p;
         const bool mm = ((bm[p >> 6] >> (p & 63)) & 1) != 0;
         if (!mm) {
             if (rl >= 8) have8 = true;
@@ -3288,13 +3291,13 @@ __device__ int adaptive_trim_dev(const uint64_t *__restrict__ rdw, const uint64_
     const double lim = (max_mm + 1.0) / 100.0;
     int best_len = 0, best_mm = 0, best_start = 0, best_end = 0;
     for (int sp = first_start; sp <= last_start;) {
-        const int sq = at_run_end(bm, sp, len);
+        const int sq = at_run_end<ATW>(bm, sp, len);
         const bool smm = ((bm[sp >> 6] >> (sp & 63)) & 1) != 0;
         const bool can_start = !smm && (sq - sp) >= min_flank && sp <= len - min_trim;
         if (can_start) {
             int cur_len = 0, cur_mm = 0;
             for (int p = sp; p < len && p <= last_end;) {
-                const int q = at_run_end(bm, p, len), rl = q - p;
+                const int q = at_run_end<ATW>(bm, p, len), rl = q - p;
                 const bool mm = ((bm[p >> 6] >> (p & 63)) & 1) != 0;
                 const bool can_end = !mm && rl >= min_flank && p + rl >= min_trim;
                 cur_len += rl;
@@ -3350,7 +3353,8 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                                                const unsigned long long *__restrict__ loci_offs, bk_loci *__restrict__ loci_out,
                                                uint32_t *__restrict__ enum_err)
 {
-    constexpr bool ENUM = MODE == 1, BEST = MODE == 2, CHIM = MODE == 3;
+    constexpr bool ENUM = MODE == 1, BEST = MODE == 2, CHIM = MODE == 3 || MODE == 4;
+    constexpr int ATW = MODE == 4 ? 32 : 8;                // MODE 4: the chimeric form for reads of more than 512 bases
     __shared__ LdsEntries s_le;
     __shared__ uint32_t s_hist[BEST ? 4 : 1][64], s_pre[BEST ? 4 : 1][64], s_run[BEST ? 4 : 1][64];
     __shared__ bk_loci s_first[BEST ? 4 : 1];
@@ -3533,7 +3537,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     if (CHIM) {
                         int c_len = 0, c_mm = 0, c_t5 = 0, c_t3 = 0, e2 = -1;
                         if (proc) {
-                            c_len = adaptive_trim_dev(rdw, ix.tgt4, t, len, chim_min, mm, 3, c_mm, c_t5, c_t3);
+                            c_len = adaptive_trim_dev<ATW>(rdw, ix.tgt4, t, len, chim_min, mm, 3, c_mm, c_t5, c_t3);
                             if (c_len < chim_min) c_len = 0;
                             if (c_len) { e2 = find_entry_lds(s_le, ix, t + (uint64_t)c_t5); if (e2 < 0) e2 = e; }
                         }
@@ -4872,13 +4876,15 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 
 // -c: the chimeric LocateCoreMultiples call for every read of `list` (reads nothing else aligned); trims into seg2[]
 void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
-                     int min_pct, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
+                     int min_pct, int long_reads, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s)
 {
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 3>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr);
-    else hipLaunchKernelGGL((k_heavy<false, 3>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr);
+#define BK_CHIM(W, M) hipLaunchKernelGGL((k_heavy<W, M>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr)
+    if (long_reads) { if (ix.sa_hi) BK_CHIM(true, 4); else BK_CHIM(false, 4); }      // reads of more than 512 bases: 2048-base mismatch map per lane
+    else { if (ix.sa_hi) BK_CHIM(true, 3); else BK_CHIM(false, 3); }
+#undef BK_CHIM
 }
 
 // -N: LocateBestMatches for every read of `list`; cnt[r] = loci kept, dense[r * MaxHits ..] = the loci

@@ -582,6 +582,54 @@ def test_chimeric_placements_match_oracle(golden_tmp, fixture, kw):
         assert np.count_nonzero(eseg["flags"] & 8) > 100
 
 
+@pytest.mark.parametrize("kw", [dict(max_subs=1, min_chimeric_len=50), dict(max_subs=2, min_chimeric_len=70, align_strand=1), dict(max_subs=3, min_chimeric_len=50)])
+def test_chimeric_reads_longer_than_512_bases(tmp_path, kw):
+    """-c on reads of 520 .. 1900 bases (the device AdaptiveTrim keeps a 2048-base mismatch map for them): a genome piece with a few
+    substitutions, flanked on one or both sides by foreign sequence - records and trims against the oracle.  (AdaptiveTrim refuses
+    more than 15 allowed mismatches, SfxArrayV2.cpp:5523: at -s3 that is every read beyond 533 bases, at -s1 beyond 1599.)"""
+    import torch
+    bk = _bk()
+    rng = np.random.default_rng(4242)
+    seq, ents, _ = _synth_case(99, 400000, 10, 100, 0)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    path = str(tmp_path / "long.sfx")
+    helpers.write_sfx(path, "long", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, d_sa.cpu().numpy().view(np.uint32))
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    half = int(ents[0]["seq_len"])
+    reads = []
+    for i in range(600):
+        L = int(rng.integers(520, 1901))
+        keepf = float(rng.uniform(0.55, 1.0))                      # part of the read that comes from the genome
+        core = max(60, int(L * keepf))
+        st = int(rng.integers(0, half - core - 1))
+        r = seq[st:st + core].copy()
+        for q in rng.choice(core, int(rng.integers(0, 5)), replace=False):
+            r[q] = (r[q] + rng.integers(1, 4)) % 4
+        left = int(rng.integers(0, L - core + 1)) if rng.integers(0, 3) else 0
+        r = np.concatenate([rng.integers(0, 4, left, dtype=np.uint8), r, rng.integers(0, 4, L - core - left, dtype=np.uint8)])
+        if rng.integers(0, 2):
+            r = comp[r[::-1]]
+        reads.append(r.astype(np.uint8))
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    bases = np.concatenate(reads)
+    o = helpers.OracleSfx(path)
+    exp, eseg = helpers.oracle_align_indel(o, bases, offs, lens, helpers.make_params(**kw))
+    o.close()
+    with bk.Aligner(path, bk.AlignParams(**kw)) as al:
+        got = al.align(bases, offs, lens)
+        seg = al.batch_seg2()
+    assert_hits_equal(got, exp)
+    for f in ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score"):
+        assert np.array_equal(seg[f], eseg[f]), f
+    if kw["max_subs"] < 3:
+        assert np.count_nonzero(eseg["flags"] & 8) > (100 if kw["max_subs"] == 1 else 10)       # trimmed placements exist
+
+
 def _assert_sites_equal(got, gtot, exp, etot, what):
     assert np.array_equal(gtot, etot), (what, gtot, etot)
     assert len(got) == len(exp), (what, len(got), len(exp))
