@@ -2095,6 +2095,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     s_sp[t * slots_max + q] = (uint16_t)run;
                 }
             s_lazy[t] = lazy_bits;
+            if (run > CAP) is_heavy = true;                 // more candidates than one pass's result bytes hold (many cores, all near heavy_thresh): the wave kernel's
             my_total = is_heavy ? 0 : run;
         }
         if (is_heavy) dest = (fits && have_wave) ? 2 : 3;
