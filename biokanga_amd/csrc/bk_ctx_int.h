@@ -50,6 +50,7 @@ struct bk_ctx {
     uint64_t cap_slist = 0;
     int use_k2 = 1;
     int k2s_levels = 6;      // how many of them (kK2Levels)
+    int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases
     int use_k2s = 0;         // sample levels over the second-level keys (one line per level of 8 instead of one per halving): measured, no gain
     int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
     int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)
@@ -92,6 +93,7 @@ struct bk_ctx {
     uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
     uint2 *d_iv2 = nullptr;
     uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
+    uint2 *d_iv32 = nullptr;              // DevBatch::iv32
     uint32_t *d_stage[3] = {nullptr, nullptr, nullptr}, *d_stripe_cnt = nullptr, *d_slist_stage = nullptr;       // striped work lists (bk::StripeSet)
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror

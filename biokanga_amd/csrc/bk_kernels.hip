@@ -1143,23 +1143,37 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     uint64_t slot[ILP], p0[ILP], q2raw[ILP], first[ILP], lo[ILP], hi[ILP];
     uint32_t nval[ILP];
     int cl[ILP];
+    // The core at offset 0 of phases 0, 1, 2 .. begins with the same k + 16 bases whenever it is that long, so the interval those bases
+    // select is looked up once: phase 0 leaves it in iv32 (here, or pass B after its key bisection), the later phases' offset-0 lanes
+    // take it from there instead of fetching a k-mer table line and a key line each (a quarter of the searches at C2).
+    constexpr uint32_t kNoIv32 = 0xFFFFFFFFu;
+    uint32_t cix[ILP];                  // entry of iv32 this lane reads (phase > 0) or writes (phase 0); kNoIv32 = neither
+    uint2 cv[ILP];
+    bool cached[ILP];
     // stage 1: the item, its read row
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + (uint64_t)u * stride;
         on[u] = false; push[u] = false; have_code[u] = false; slot[u] = 0; p0[u] = 0; q2raw[u] = 0; first[u] = 0; nval[u] = 0; cl[u] = 1; lo[u] = hi[u] = 0;
+        cix[u] = kNoIv32; cv[u] = make_uint2(0, kNoIv32); cached[u] = false;
         if (tid < total) {
             const uint64_t a = tid / per_read;
             const uint32_t rem = (uint32_t)(tid - a * per_read);
             const int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
             const uint32_t r = act[a];
             const int len = (int)b.lens[r];
+            const int strand_c = cfg.align_strand == 2 ? 1 : si;
+            if (b.iv32 != nullptr && c == 0 && phase > 0) cv[u] = b.iv32[(uint32_t)strand_c * b.n_reads + r];     // (requested with the length)
             ReadPlan p = make_plan(len, cfg);
             int mm, cd, dummy[1];
             phase_params(p, cfg, phase, mm, cl[u], cd);
             const int nc = core_offsets(len, cl[u], cd, p.max_slides, dummy, 0);
             if (c < nc && nc <= kMaxCoresFast) {
                 on[u] = true;
+                if (b.iv32 != nullptr && c == 0 && cl[u] >= k + 16) {
+                    cix[u] = (uint32_t)strand_c * b.n_reads + r;
+                    cached[u] = phase > 0 && cv[u].y < (1u << kKindShift);
+                }
                 const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
                 const int strand = cfg.align_strand == 2 ? 1 : si;
                 const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
@@ -1175,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     for (int u = 0; u < ILP; u++) {
         nval[u] = kKindFull << kKindShift;
         push[u] = on[u];
-        have_code[u] = on[u] && cl[u] >= k && !(p0[u] & 0x4444444444444444ULL & top_mask(k));
+        have_code[u] = on[u] && !cached[u] && cl[u] >= k && !(p0[u] & 0x4444444444444444ULL & top_mask(k));
         if (have_code[u]) {
             const uint64_t code = (uint64_t)(squeeze2(p0[u]) >> (32 - 2 * k));
             lo[u] = ktab_get(ix, code);
@@ -1195,9 +1209,18 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     // stage 4: results
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
+        uint2 leave = make_uint2(0, kNoIv32);               // what phase 0 leaves in iv32 for this read and strand
+        if (cached[u]) {
+            // the interval of the first k + 16 bases, as the bucket compare below would have produced it
+            first[u] = cv[u].x;
+            const uint32_t cnt = cv[u].y;
+            if (cnt == 0 || cl[u] <= k + 16) { nval[u] = cnt; push[u] = false; }
+            else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
+            else nval[u] = cnt | (kKindDeep << kKindShift);
+        }
         if (have_code[u]) {
             const uint64_t size = hi[u] - lo[u];
-            if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; }
+            if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
             else if (size <= kInlineBucket) {
                 const int rem2 = cl[u] - k;
                 const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
@@ -1211,14 +1234,16 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 }
                 first[u] = lo[u] + lb;
                 const uint32_t cnt = ub - lb;
+                leave = make_uint2((uint32_t)first[u], cnt);
                 if (cnt == 0 || cl[u] <= k + 16) { nval[u] = cnt; push[u] = false; }
                 else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
                 else nval[u] = cnt | (kKindDeep << kKindShift);
             } else if (size < (1ULL << kKindShift)) {
                 first[u] = lo[u];
-                nval[u] = (uint32_t)size | (kKindK2 << kKindShift);
+                nval[u] = (uint32_t)size | (kKindK2 << kKindShift);        // (pass B leaves the interval in iv32 after its key bisection)
             }
         }
+        if (phase == 0 && cix[u] != kNoIv32) b.iv32[cix[u]] = leave;
     }
     PROFS(3);
     // work-list appends, one global atomic per block.  The interval records are stored after them: the barriers of the append
@@ -1305,6 +1330,8 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         }
         first = l1;
         cnt = l2 - l1;
+        if (!WIDE && b.iv32 != nullptr && phase == 0 && c == 0 && cl >= k + 16)       // see k_search_a_ilp
+            b.iv32[(uint32_t)strand * b.n_reads + r] = make_uint2((uint32_t)first, (uint32_t)cnt);
         if (cnt == 0 || cl <= k + 16) {
             iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
             return;
