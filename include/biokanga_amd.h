@@ -144,7 +144,7 @@ void bk_ctx_destroy(bk_ctx *ctx);
 int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
 /* tuning / cross-check knobs (results never depend on them; the test-suite runs every kernel family against the
  * others through these): name =
- *   "kmer_bits" (k of the k-mer table, 2..16)  "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)  "use_k2s" / "k2s_levels" (sample levels over it, 1..6)
+ *   "kmer_bits" (k of the k-mer table, 2..16)  "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)  "use_k2s" / "k2s_levels" (sample levels over it, 1..6)  "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)
  *   "lazy_search" (small buckets handed on unverified)   "sort_lists" (bit 0: group the search work list by bucket, bit 1: sort the wave list, bit 2: .. longest read first)
  *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)   "flat_block" (reads per block of k_flat: 64..1024)
  *   "use_hp" (prefix hash in front of table + keys)   "use_eval" (0: k_flat alone instead of k_eval + k_replay)   "use_direct" (search pass A evaluates
