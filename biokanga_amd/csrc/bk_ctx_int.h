@@ -94,6 +94,7 @@ struct bk_ctx {
     uint2 *d_iv2 = nullptr;
     uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;
     uint2 *d_iv32 = nullptr;              // DevBatch::iv32
+    uint32_t *d_wave_work = nullptr;      // DevBatch::wave_work
     uint32_t *d_stage[3] = {nullptr, nullptr, nullptr}, *d_stripe_cnt = nullptr, *d_slist_stage = nullptr;       // striped work lists (bk::StripeSet)
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror

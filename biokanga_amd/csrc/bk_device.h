@@ -93,6 +93,7 @@ struct DevBatch {
     uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
     uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null
     uint64_t *rec8;             // k_eval -> k_replay: up to 8 result bytes per slot, laid out like iv2; may be null
+    uint32_t *wave_work;        // per read: candidates the wave kernel will walk (sum of its core intervals), left by k_flat when it hands the read on; may be null
     uint2 *iv32;                // [strand][read]: suffix array interval of the read's first k + 16 bases {start, count; count 0xffffffff = not known},
                                 //   left by phase 0 for the offset-0 cores of the later phases (4-byte indexes); may be null
     bk_hit *out;

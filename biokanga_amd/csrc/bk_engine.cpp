@@ -90,7 +90,7 @@ int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t
                      void *tmp, size_t *tmp_bytes, hipStream_t s);
 void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s);
 void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
-                      hipStream_t s);
+                      const uint32_t *work_of, hipStream_t s);
 }  // namespace bk
 
 using namespace bk;
@@ -477,10 +477,11 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32); free_dev(c->d_wave_work);
     c->d_gen = c->d_gen2 = nullptr;
     c->d_rec8 = nullptr;
     c->d_iv32 = nullptr;
+    c->d_wave_work = nullptr;
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     for (int i = 0; i < 3; i++) { free_dev(c->d_stage[i]); c->d_stage[i] = nullptr; }
@@ -506,6 +507,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     HIP_TRY(hipMalloc(&c->d_gen2, (size_t)nr * 4));
     if (c->d_iv2 && c->use_eval) HIP_TRY(hipMalloc(&c->d_rec8, (size_t)nr * 2 * kMaxCoresFast * 8));
     if (c->d_iv2) HIP_TRY(hipMalloc(&c->d_iv32, (size_t)nr * 2 * 8));
+    HIP_TRY(hipMalloc(&c->d_wave_work, (size_t)nr * 4));
     c->cap_reads = nr;
     c->cap_wpr = w;
     c->cap_rd2w = w2;
@@ -579,7 +581,7 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
 static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
 {
-    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 9 * 4 + 16;
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 10 * 4 + 16;
 }
 
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
@@ -704,6 +706,8 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
     b.rec8 = c->d_rec8;
+    // (the wave list's job sizes come from k_flat only when every read on that list went through it)
+    b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100 && !c->use_eval && !c->use_direct) ? c->d_wave_work : nullptr;
     b.iv32 = (c->use_iv32 && c->ix.k2 && c->ix.hp == nullptr && c->search_ilp >= 2 && !c->use_direct) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
@@ -817,7 +821,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             if ((c->sort_lists & 2) && n_wave >= 4096) {
                 int rs = ensure_sort_scratch(c, n_wave, s);
                 if (rs) return rs;
-                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, (c->sort_lists & 4) ? -1 : c->sort_shift, c->d_sort[0], s);
+                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, (c->sort_lists & 4) ? -1 : c->sort_shift, c->d_sort[0], b.wave_work, s);
                 rs = sort_work(c, c->d_wave, n_wave, s, &wlist);
                 if (rs) return rs;
             }
@@ -1107,7 +1111,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k2s); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32); free_dev(c->d_small);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
     free_dev(c->d_stripe_cnt);
     free_dev(c->d_isa); free_dev(c->d_hp); free_dev(c->d_seg2); free_dev(c->d_seq_global);

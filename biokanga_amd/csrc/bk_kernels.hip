@@ -2094,7 +2094,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
         const bool fits = nc <= kMaxCoresFast && len <= 16 * NW && nc <= cmaxs;
         bool is_heavy = !fits;
         if (fits) {
-            uint32_t run = 0, lazy_bits = 0;
+            uint32_t run = 0, lazy_bits = 0, work = 0;          // work: every candidate of the read (the wave kernel's job size, should it go there)
             if (!WIDE && spec) {
 #pragma unroll
                 for (int u = 0; u < SPEC; u++)
@@ -2105,6 +2105,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                         const uint32_t cnt = raw & ~kLazyFlag;
                         if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                         run += is_heavy ? 0 : cnt;
+                        work = work + cnt < work ? 0xFFFFFFFFu : work + cnt;
                         if (cf) s_first[t * slots_max + u] = sv[u].x;
                         s_sp[t * slots_max + u] = (uint16_t)run;
                     }
@@ -2118,12 +2119,14 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     cnt &= ~kLazyFlag;
                     if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                     run += is_heavy ? 0 : cnt;
+                    work = work + cnt < work ? 0xFFFFFFFFu : work + cnt;
                     if (cf) s_first[t * slots_max + q] = (uint32_t)f64;
                     s_sp[t * slots_max + q] = (uint16_t)run;
                 }
             s_lazy[t] = lazy_bits;
             if (run > CAP) is_heavy = true;                 // more candidates than one pass's result bytes hold (many cores, all near heavy_thresh): the wave kernel's
             my_total = is_heavy ? 0 : run;
+            if (is_heavy && have_wave && b.wave_work != nullptr) b.wave_work[r] = work;
         }
         if (is_heavy) dest = (fits && have_wave) ? 2 : 3;
         else { mine = true; n_lcm = 1; }
@@ -4725,11 +4728,12 @@ __global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t 
 }
 
 __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, int phase, const uint32_t *__restrict__ list,
-                                                   uint32_t n, int shift, uint32_t *__restrict__ keys)
+                                                   uint32_t n, int shift, uint32_t *__restrict__ keys, const uint32_t *__restrict__ work_of)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = list[i];
+    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFFu - work_of[r]; return; }      // k_flat has added the intervals up already
     const int len = (int)b.lens[r];
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd, dummy[1];
@@ -4760,9 +4764,9 @@ void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int
 }
 
 void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
-                      hipStream_t s)
+                      const uint32_t *work_of, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys);
+    if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys, work_of);
 }
 
 // stage: at least n_act * cmax * nstr + (kListStripes + 2) * 1024 entries; stripe_cnt: kListStripes * 16 words, zero between launches
