@@ -10,7 +10,7 @@
 //   k_search_a/_b   LocateFirstExact (SfxArrayV2.cpp:7765) + extent of the matching run for every core of the phase:
 //                   k-mer table + contiguous second-level keys, work list grouped by bucket for the bisection pass
 //   k_flat          LocateCoreMultiples (SfxArrayV2.cpp:5830-6261) for reads whose core intervals are all short:
-//                   one candidate per lane, per-read replay of the best / next-best / instances state machine
+//                   one candidate per lane, the best / next-best / instances outcome reduced over the candidates' lanes
 //   k_wave          the same call for repeat reads: one wave per call, 64 candidates per round, ballot prefix sums
 //                   reproduce the reference's sequential order (100-candidate copy-count cut-off, MaxIter, node
 //                   cap, early exit); dedupe by inverse suffix array, or by the reference's hash set (5-byte indexes)
@@ -1974,8 +1974,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 // in the reference's walk order strand -> core -> suffix) are numbered consecutively and EVALUATED
 // one per lane - suffix array load, window compare, one result byte in LDS (mismatch count, or
 // "skip": off the read's start / unverified bucket member that does not match / crosses an entry
-// boundary / already reached through an earlier core).  Then each read's lane replays its own bytes
-// sequentially through the Low/NxtLow/instances state machine, which needs no memory access.
+// boundary / already reached through an earlier core).  The Low/NxtLow/instances outcome of a read is
+// then reduced over its candidates' lanes (4-byte indexes; the state machine is order-independent up to
+// its early exit, whose reads - and every read of a 5-byte index, where the truncated-key rule makes a
+// candidate depend on the ones before it - are replayed in order by their own lane).
 // In k_light a lane walked all candidates of its read itself, so a wave ran as long as its read with
 // the most candidates (up to 4 x 64) while the typical read has one or two.
 // Valid while no interval is longer than 100: then the reference's IterCnt==100 copy-count check and
