@@ -107,3 +107,70 @@ def test_device_bit_helpers_against_brute_force(tmp_path):
     subprocess.check_call(helpers.cxx() + ["-o", exe, src])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def _replay_in_order(recs, mm, init, max_hits):
+    """the Low / NxtLow / instances state machine of LocateCoreMultiples as k_flat's in-order replay runs it (SfxArrayV2.cpp:6093-6205):
+    recs = one result byte per candidate in walk order (255 = not a candidate)"""
+    low_inst, low_mm, nxt, best, n_cand = 0, init, init, -1, 0
+    for x, cm in enumerate(recs):
+        if cm == 255:
+            continue
+        n_cand += 1
+        if cm > mm or cm >= nxt:
+            continue
+        if cm < low_mm:
+            low_inst, nxt, low_mm, best = 1, low_mm, cm, x
+        elif cm == low_mm:
+            low_inst += 1
+        else:
+            nxt = cm
+        if low_inst > max_hits and low_mm == 0:
+            break
+    return low_inst, low_mm, nxt, best, n_cand
+
+
+def _reduced(recs, mm, init, max_hits):
+    """k_flat's reduction over the candidates' lanes: min of (mismatches << 16 | candidate number) over the acceptable candidates,
+    how many share that count, the smallest count above it, how many were looked at; None = the early exit applies (replayed in order)"""
+    k1, cnt_min, looked, nx = 0xFFFFFFFF, 0, 0, 0xFFFFFFFF
+    for x, cm in enumerate(recs):
+        if cm != 255:
+            looked += 1
+            if cm <= mm:
+                k1 = min(k1, (cm << 16) | x)
+    for cm in recs:
+        if cm != 255 and cm <= mm:
+            if cm == (k1 >> 16):
+                cnt_min += 1
+            else:
+                nx = min(nx, cm)
+    if k1 != 0xFFFFFFFF and (k1 >> 16) == 0 and cnt_min > max_hits:
+        return None
+    if k1 == 0xFFFFFFFF:
+        return 0, init, init, -1, looked
+    return cnt_min, k1 >> 16, min(nx, init), k1 & 0xFFFF, looked
+
+
+def test_flat_reduction_equals_the_in_order_replay():
+    """the claim behind k_flat's second half: up to the early exit after MaxHits + 1 exact matches the outcome of a read does not
+    depend on the order its candidates are looked at"""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    exits = 0
+    for _ in range(20000):
+        n = int(rng.integers(0, 40))
+        mm = int(rng.integers(0, 8))
+        delta = int(rng.integers(1, 3))
+        init = mm + delta + 1
+        max_hits = int(rng.choice([1, 1, 2, 5]))
+        hi = int(rng.choice([3, 6, 12]))
+        recs = [255 if rng.integers(0, 5) == 0 else int(rng.integers(0, hi)) for _ in range(n)]
+        want = _replay_in_order(recs, mm, init, max_hits)
+        got = _reduced(recs, mm, init, max_hits)
+        if got is None:
+            exits += 1
+            assert want[1] == 0 and want[0] == max_hits + 1           # the exit: exactly MaxHits + 1 exact instances counted
+            continue
+        assert got == want, (recs, mm, init, max_hits, got, want)
+    assert exits > 200
