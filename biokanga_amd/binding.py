@@ -12,7 +12,7 @@ NAR_TAGS = ["NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "F
 # every symbol include/biokanga_amd.h declares
 EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
-    "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
+    "bk_ctx_clone", "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
@@ -128,6 +128,8 @@ def load_library():
     lib.bk_ctx_create_from_device.argtypes = [ctypes.POINTER(vp), vp, u64, vp, i32, vp, u32, i32,
                                               ctypes.POINTER(AlignParams)]
     lib.bk_ctx_create_from_device.restype = i32
+    lib.bk_ctx_clone.argtypes = [ctypes.POINTER(vp), vp, i32]
+    lib.bk_ctx_clone.restype = i32
     lib.bk_ctx_destroy.argtypes = [vp]
     lib.bk_ctx_destroy.restype = None
     lib.bk_ctx_set_params.argtypes = [vp, ctypes.POINTER(AlignParams)]
@@ -236,11 +238,14 @@ class Aligner:
     """One context per GPU (mirror of CSfxArrayV3 opened for alignment + the CAligner parameters)."""
 
     def __init__(self, sfx_path=None, params=None, device=0, *, d_seq=None, concat_len=0, d_sa=None,
-                 el_size=4, entries=None):
+                 el_size=4, entries=None, clone_of=None):
         self.lib = load_library()
-        self.params = params or AlignParams()
+        self.params = params or (clone_of.params if clone_of is not None else AlignParams())
         self.h = ctypes.c_void_p()
-        if sfx_path is not None:
+        if clone_of is not None:
+            rc = self.lib.bk_ctx_clone(ctypes.byref(self.h), clone_of.h, device)
+            what = "bk_ctx_clone"
+        elif sfx_path is not None:
             rc = self.lib.bk_ctx_create(ctypes.byref(self.h), os.fsencode(sfx_path), device, ctypes.byref(self.params))
             what = f"bk_ctx_create({sfx_path})"
         else:

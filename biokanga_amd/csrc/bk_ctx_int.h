@@ -31,6 +31,7 @@ struct bk_ctx {
     uint64_t *d_ent_start = nullptr, *d_ent_end = nullptr;
     uint32_t *d_ent_id = nullptr, *d_id2idx = nullptr;
     void *d_ktab = nullptr;
+    size_t ktab_bytes = 0, nflag_bytes = 0;
     uint64_t *d_tgt2 = nullptr;           // 2 bit/base target copy (DevIndex::tgt2)
     uint64_t *d_tgt2s = nullptr;          // the same, stored 32 bytes later (DevIndex::tgt2s)
     uint8_t *d_nflag = nullptr;
@@ -39,7 +40,6 @@ struct bk_ctx {
     uint32_t cap_rd2w = 0;
     int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
     uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
-    uint64_t *d_k2s = nullptr;            // their sample levels (DevIndex::k2s)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
     void *d_sort_tmp = nullptr;
@@ -49,28 +49,12 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
-    int k2s_levels = 6;      // how many of them (kK2Levels)
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases
-    int use_k2s = 0;         // sample levels over the second-level keys (one line per level of 8 instead of one per halving): measured, no gain
     int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
     int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)
-    int use_hp = 0;          // prefix hash in front of k-mer table + keys (one line per search instead of two or three).  Off: measured on
-                             //    C2 it cuts k_search_a's HBM fetches by a third (14.9 -> 10.2 GB per launch) and its time by nothing (6.6 ms
-                             //    against 6.45), k_search_b gets 15 % slower, and it costs 34 GB + 0.24 s at load
-    uint64_t *d_hp = nullptr;
     uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
-    int use_direct = 0;      // 1: k_direct (pass A of the search + in-place evaluation of the reads it settles), 0: k_search_a then k_flat for all.
-                             //    Off: measured on C2 it is SLOWER (search 95 ms/step instead of 46, k_flat 9 instead of 21: the fused lanes
-                             //    carry the window registers through the search - 160 VGPRs, 3 waves/SIMD against k_search_a's 31 / 8 - and
-                             //    run four dependent random loads back to back)
-    uint32_t *d_gen = nullptr;            // reads k_direct hands on to pass B + k_flat / k_wave
-    uint32_t *d_gen2 = nullptr;           // reads k_replay hands on to k_flat
-    int use_eval = 0;        // 1: k_eval + k_replay for the reads whose intervals are all <= 8 suffixes (4-byte indexes), k_flat for the rest.
-                             //    Off: measured on C2 the two streaming launches take 27.9 + 20.8 ms/step (+ 3.5 ms of k_flat for what they leave)
-                             //    against k_flat's 21 ms for everything: only ~30 % of k_eval's lanes own a candidate, k_flat packs one per lane
-    uint64_t *d_rec8 = nullptr;           // their hand-over: 8 result bytes per interval slot
     uint32_t *d_isa = nullptr;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
@@ -103,6 +87,7 @@ struct bk_ctx {
     // heavy path scratch
     bk::HeavyScratch hs{};
     int max_read_len = 500;
+    bool debug = false;      // BK_DEBUG in the environment when the context was created: per-phase counts on stderr
     uint32_t chunk_reads = 64u << 20;
     // staging for host-buffer batches
     uint8_t *d_in_bases = nullptr;

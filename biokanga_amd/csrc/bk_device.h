@@ -42,7 +42,6 @@ struct StripeSet {
     uint32_t *stage[3];         // per list: kListStripes regions of cap entries
     uint32_t cap;
 };
-constexpr int kK2Levels = 6;
 constexpr int kCtrStripes = 64;       // copies of the DevBatch::ctr block (8 counters = one 64-byte line each)
 constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
 constexpr int kWave = 64;
@@ -66,12 +65,7 @@ struct DevIndex {
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
     const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null
-    const uint64_t *k2s;        // every 8th, 64th, .. 8^kK2Levels-th key of k2 (level L at k2s + k2s_off[L - 1], L = 1..), the last key of
-    uint64_t k2s_off[6];        //   each group of 8^L: a bound inside a big bucket costs one line per level instead of one per halving; may be null
-    int k2s_levels;             //   levels built (1 .. kK2Levels)
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
-    const uint64_t *hp;         // prefix hash: distinct hp_k-base prefixes of the suffixes -> their suffix array interval, 64-byte buckets
-    int hp_bits, hp_k;          //   of 8 entries {tag 21 | displacement 3 | count 8 | interval start 32}; 2^hp_bits buckets; may be null
     uint64_t n;                 // concat_len
     uint32_t n_ent;
     int k;                      // k-mer table order (0 = none)
@@ -92,7 +86,6 @@ struct DevBatch {
     uint64_t *iv_first;         // core intervals [strand][core][read]: start (suffix array index) ...
     uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
     uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null
-    uint64_t *rec8;             // k_eval -> k_replay: up to 8 result bytes per slot, laid out like iv2; may be null
     uint32_t *wave_work;        // per read: candidates the wave kernel will walk (sum of its core intervals), left by k_flat when it hands the read on; may be null
     uint2 *iv32;                // [strand][read]: suffix array interval of the read's first k + 16 bases {start, count; count 0xffffffff = not known},
                                 //   left by phase 0 for the offset-0 cores of the later phases (4-byte indexes); may be null

@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <ctime>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <dlfcn.h>
@@ -42,8 +45,6 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
-void launch_build_k2s(const uint64_t *src, uint64_t n_src, uint64_t *dst, uint64_t n_dst, hipStream_t s);
-void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s);
@@ -60,14 +61,6 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
                  int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
                  hipStream_t s);
-void launch_eval(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
-                 int nw, hipStream_t s);
-void launch_replay(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, uint32_t *next_act,
-                   uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt, uint32_t *flat, uint32_t *flat_cnt,
-                   uint32_t *cmax_next, int nw, hipStream_t s);
-void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
-                   int lazy, uint32_t *slist, uint32_t *slist_cnt, uint32_t *general, uint32_t *general_cnt, uint32_t *next_act, uint32_t *next_cnt,
-                   uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
@@ -194,6 +187,7 @@ int build_ktab(bk_ctx *c)
     c->ktab64 = c->ix.n >= (1ULL << 32);
     size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
     HIP_TRY(hipMalloc(&c->d_ktab, bytes));
+    c->ktab_bytes = bytes;
     DevIndex ix = c->ix;
     launch_build_ktab(ix, c->d_ktab, k, c->ktab64, c->stream);
     HIP_TRY(hipGetLastError());
@@ -210,9 +204,8 @@ int build_ktab(bk_ctx *c)
 int build_k2(bk_ctx *c)
 {
     free_dev(c->d_k2);
-    free_dev(c->d_k2s);
-    c->d_k2 = c->d_k2s = nullptr;
-    c->ix.k2 = c->ix.k2s = nullptr;
+    c->d_k2 = nullptr;
+    c->ix.k2 = nullptr;
     if (!c->use_k2 || c->ix.k <= 0) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -233,61 +226,6 @@ int build_k2(bk_ctx *c)
         return BK_OK;
     }
     c->ix.k2 = c->d_k2;
-    // sample levels over the keys (k2s_bounds): n / 7 more words
-    if (c->use_k2s) {
-        uint64_t nl[kK2Levels + 1], tot = 0;
-        nl[0] = c->ix.n;
-        const int nlev = c->k2s_levels < 1 ? 1 : (c->k2s_levels > kK2Levels ? kK2Levels : c->k2s_levels);
-        for (int L = 1; L <= kK2Levels; L++) { nl[L] = L <= nlev ? (nl[L - 1] + 7) / 8 : 0; c->ix.k2s_off[L - 1] = tot; tot += nl[L]; }
-        c->ix.k2s_levels = nlev;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (tot * 8 <= free_b && free_b - tot * 8 >= total_b / 4 && hipMalloc(&c->d_k2s, tot * 8) == hipSuccess) {
-            for (int L = 1; L <= nlev; L++)
-                launch_build_k2s(L == 1 ? c->d_k2 : c->d_k2s + c->ix.k2s_off[L - 2], nl[L - 1], c->d_k2s + c->ix.k2s_off[L - 1], nl[L], c->stream);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->ix.k2s = c->d_k2s;
-        } else
-            (void)hipGetLastError();
-    }
-    return BK_OK;
-}
-
-// prefix hash over the distinct hp_k-base prefixes of the suffixes (DevIndex::hp; bk_kernels.hip).  4-byte indexes with the two-pass
-// search; skipped when it would not leave a quarter of the HBM free; dropped again should an entry not find a slot within 8 buckets
-int build_hp(bk_ctx *c)
-{
-    free_dev(c->d_hp);
-    c->d_hp = nullptr;
-    c->ix.hp = nullptr;
-    c->ix.hp_bits = c->ix.hp_k = 0;
-    if (!c->use_hp || !c->ix.k2 || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
-    int bits = 16;
-    while (bits < 30 && (5ULL << bits) < c->ix.n) bits++;          // <= 5 entries per 8-slot bucket on average
-    const int k = std::min(24, (bits + 21) / 2);
-    const uint64_t bytes = 64ULL << bits;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (bytes > free_b || free_b - bytes < total_b / 4) return BK_OK;
-    HIP_TRY(hipMalloc(&c->d_hp, bytes));
-    launch_fill_u64((unsigned long long *)c->d_hp, bytes / 8, ~0ULL, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
-    launch_build_hp(c->ix, (unsigned long long *)c->d_hp, bits, k, c->d_ctr + 7, c->stream);
-    HIP_TRY(hipGetLastError());
-    unsigned long long failed = 0;
-    HIP_TRY(hipMemcpyAsync(&failed, c->d_ctr + 7, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
-    if (failed) {
-        fprintf(stderr, "biokanga_amd: prefix hash: %llu prefixes found no slot; the table is not used\n", failed);
-        free_dev(c->d_hp);
-        c->d_hp = nullptr;
-        return BK_OK;
-    }
-    c->ix.hp = c->d_hp;
-    c->ix.hp_bits = bits;
-    c->ix.hp_k = k;
     return BK_OK;
 }
 
@@ -320,6 +258,7 @@ int build_tgt2(bk_ctx *c)
     const uint64_t flag_bytes = (((((nblocks * 64) >> shift) + 1) + 31) / 32) * 4 + 16;
     HIP_TRY(hipMalloc(&c->d_tgt2, nblocks * 16 + 64));
     HIP_TRY(hipMalloc(&c->d_nflag, flag_bytes));
+    c->nflag_bytes = flag_bytes;
     HIP_TRY(hipMemsetAsync(c->d_nflag, 0, flag_bytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_tgt2 + nblocks * 2, 0, 64, c->stream));
     launch_pack_target2(c->d_tgt4, c->n_tgt4_words, c->d_tgt2, (unsigned int *)c->d_nflag, shift, c->stream);
@@ -367,7 +306,8 @@ int size_heavy_scratch(bk_ctx *c)
     return BK_OK;
 }
 
-int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
+// entry table, counters and the small per-context buffers; parameters -> DevAlignCfg
+int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
 {
     StageClock clk0;
     // entries
@@ -410,15 +350,19 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
     HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
     int rc = derive_cfg(c);
-    if (rc) return rc;
     clk0.lap("entry table, small buffers");
+    return rc;
+}
+
+int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
+{
+    int rc = setup_entries(c, entries, n_entries);
+    if (rc) return rc;
     StageClock clk;
     rc = build_ktab(c);
     clk.lap("k-mer table");
     if (!rc) rc = build_k2(c);
     clk.lap("second-level keys");
-    if (!rc) rc = build_hp(c);
-    clk.lap("prefix hash");
     if (rc) return rc;
     rc = build_isa(c);
     clk.lap("inverse suffix array");
@@ -440,6 +384,7 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     c->device = device_id;
     c->params = *p;
     c->cfg.heavy_thresh = 64;
+    c->debug = getenv("BK_DEBUG") != nullptr;
     if (c->params.max_ml == 0) c->params.max_ml = 1;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BK_ERR_INTERNAL; }
     *pc = c;
@@ -477,9 +422,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32); free_dev(c->d_wave_work);
-    c->d_gen = c->d_gen2 = nullptr;
-    c->d_rec8 = nullptr;
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work);
     c->d_iv32 = nullptr;
     c->d_wave_work = nullptr;
     c->d_rd4 = nullptr; c->d_iv_first = nullptr; c->d_iv_n = nullptr; c->d_rd2 = nullptr; c->d_iv2 = nullptr;
@@ -503,9 +446,6 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
         HIP_TRY(hipMalloc(&c->d_stripe_cnt, (size_t)2 * kListStripes * 16 * 4));
         HIP_TRY(hipMemset(c->d_stripe_cnt, 0, (size_t)2 * kListStripes * 16 * 4));
     }
-    HIP_TRY(hipMalloc(&c->d_gen, (size_t)nr * 4));
-    HIP_TRY(hipMalloc(&c->d_gen2, (size_t)nr * 4));
-    if (c->d_iv2 && c->use_eval) HIP_TRY(hipMalloc(&c->d_rec8, (size_t)nr * 2 * kMaxCoresFast * 8));
     if (c->d_iv2) HIP_TRY(hipMalloc(&c->d_iv32, (size_t)nr * 2 * 8));
     HIP_TRY(hipMalloc(&c->d_wave_work, (size_t)nr * 4));
     c->cap_reads = nr;
@@ -705,10 +645,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
-    b.rec8 = c->d_rec8;
     // (the wave list's job sizes come from k_flat only when every read on that list went through it)
-    b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100 && !c->use_eval && !c->use_direct) ? c->d_wave_work : nullptr;
-    b.iv32 = (c->use_iv32 && c->ix.k2 && c->ix.hp == nullptr && c->search_ilp >= 2 && !c->use_direct) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
+    b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) ? c->d_wave_work : nullptr;
+    b.iv32 = (c->use_iv32 && c->ix.k2 && c->search_ilp >= 2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n;
@@ -731,15 +670,13 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
         n_act = 0;
     }
     for (int phase = 0; n_act > 0; phase++) {
-        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list, [9] general list, [10] k_flat list of k_replay
+        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list
         HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
         HIP_TRY(hipMemsetAsync(sm + 6, 0, 5 * 4, s));
-        // the reads the extend kernels see: all active ones, or - after k_direct - those it did not finish itself
         const uint32_t *ext_list = c->d_act[cur];
-        uint32_t n_ext = n_act;
+        const uint32_t n_ext = n_act;
         if (cmax > 0) {
             const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
-            const bool direct = c->use_direct && c->ix.k2 && c->d_sa_hi == nullptr && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100;
             hipEvent_t e1 = tm.begin(s);
             if (c->ix.k2) {
                 const uint64_t lanes = (uint64_t)n_act * (uint64_t)(cmax * nstr);
@@ -753,26 +690,15 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
                     HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
                     c->cap_slist = lanes;
                 }
-                if (direct) {
-                    // pass A + the whole call for the reads it settles (k_direct); interval records only for the others, every slot written
-                    launch_direct(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, c->d_slist, sm + 8, c->d_gen, sm + 9,
-                                  c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, s);
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 8, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    ext_list = c->d_gen;
-                    n_ext = hm[9];
-                } else {
-                    // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
-                    for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                        if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
-                        else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
-                    launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
-                                    c->d_slist_stage, c->d_stripe_cnt, s);
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                }
+                // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
+                for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
+                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
+                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
+                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
+                                c->d_slist_stage, c->d_stripe_cnt, s);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
                 const uint32_t *slist = c->d_slist;
                 if ((c->sort_lists & 1) && hm[8] >= 4096) {
                     int rs = ensure_sort_scratch(c, hm[8], s);
@@ -788,28 +714,21 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             tm.end(0, e1, s);
         }
         hipEvent_t e2 = tm.begin(s);
-        // k_flat cut into two streaming launches for the reads whose intervals are all small (k_eval, k_replay); what they leave
-        // (an interval of 9 .. heavy_thresh suffixes) is k_flat's.  4-byte indexes, after the two-pass search.
-        if (n_ext && cmax > 0 && c->use_eval && b.rec8 && c->ix.k2 && reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) {
-            launch_eval(c->ix, c->cfg, b, ext_list, n_ext, phase, cmax, nstr, nw16, s);
-            uint32_t *flat_list = ext_list == c->d_gen ? c->d_gen2 : c->d_gen;
-            launch_replay(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6, flat_list, sm + 10,
-                          sm + 3, nw16, s);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(hm + 10, sm + 10, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            ext_list = flat_list;
-            n_ext = hm[10];
-        }
+        // 5-byte indexes: the reference's seen-target set is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), a
+        // rule that depends on every earlier candidate of the strand pass.  k_flat and the hash-set kernels reproduce it; the
+        // lane-per-read kernels dedupe on exact starts, so on an index of more than 2^32 bases they only finish the calls without candidates and hand
+        // every other one to the hash-set kernels.
+        DevAlignCfg cfg_lane = c->cfg;
+        if (c->ix.n > (1ULL << 32)) cfg_lane.heavy_thresh = 0;            // (below that the truncated keys are the exact ones)
         if (n_ext == 0) {}
         else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
             launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
                         c->d_wave, sm + 6, sm + 3, c->d_stage, c->d_stripe_cnt, nw16 | (c->flat_block << 8), s);
         else if (reg_path)
-            launch_light(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
+            launch_light(c->ix, cfg_lane, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
                          sm + 3, nw16, s);
         else
-            launch_extend(c->ix, c->cfg, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
+            launch_extend(c->ix, cfg_lane, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
         HIP_TRY(hipGetLastError());
         tm.end(1, e2, s);
         HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
@@ -841,7 +760,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
             HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
-        if (getenv("BK_DEBUG"))
+        if (c->debug)
             fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u n_wave %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, n_wave, hm[1], hm[3]);
         n_act = hm[1];
         cmax = (int)hm[3];
@@ -1103,18 +1022,72 @@ int bk_ctx_create_from_device(bk_ctx **out, const void *d_seq, uint64_t concat_l
     return BK_OK;
 }
 
+// The finished index image of `src` (packed target, suffix array, k-mer table, second-level keys, inverse suffix array, 2-bit target
+// copies) copied device to device - over xGMI between two GPUs - instead of loading the .sfx again over PCIe and rebuilding every
+// table: what `biokanga align --devices` does for the second and later GPUs.
+int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
+{
+    if (!src) return BK_ERR_PARAMS;
+    bk_ctx *c = nullptr;
+    int rc = new_ctx(out, device_id, &src->params, &c);
+    if (rc) return rc;
+    StageClock clk;
+    c->dataset = src->dataset;
+    c->el_size = src->el_size;
+    c->n_tgt4_words = src->n_tgt4_words;
+    c->sort_shift = src->sort_shift;
+    c->ktab64 = src->ktab64;
+    c->ktab_bytes = src->ktab_bytes;
+    c->nflag_bytes = src->nflag_bytes;
+    c->use_ktab = src->use_ktab; c->k_req = src->k_req; c->use_k2 = src->use_k2; c->use_isa = src->use_isa; c->use_wave = src->use_wave; c->use_tgt2 = src->use_tgt2;
+    c->ix.n = src->ix.n;
+    c->ix.k = src->ix.k;
+    c->ix.flag_shift = src->ix.flag_shift;
+    const uint64_t n = src->ix.n;
+    const uint64_t nblocks = src->n_tgt4_words / 4;
+    bool ok = true;
+    auto dup = [&](auto *&dst, const auto *from, size_t bytes) {
+        if (!ok || !from) return;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; rc = BK_ERR_MEM; return; }
+        dst = static_cast<std::remove_reference_t<decltype(dst)>>(p);
+        hipError_t e = c->device == src->device ? hipMemcpyAsync(p, from, bytes, hipMemcpyDeviceToDevice, c->stream)
+                                                : hipMemcpyPeerAsync(p, c->device, from, src->device, bytes, c->stream);
+        if (e != hipSuccess) { ok = false; rc = BK_ERR_INTERNAL; }
+    };
+    dup(c->d_tgt4, src->d_tgt4, (size_t)src->n_tgt4_words * 8);
+    dup(c->d_sa_lo, src->d_sa_lo, (size_t)n * 4);
+    dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
+    dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
+    dup(c->d_k2, src->d_k2, (size_t)n * 8);
+    dup(c->d_isa, src->d_isa, (size_t)n * 4);
+    dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
+    dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);
+    dup(c->d_nflag, src->d_nflag, src->nflag_bytes);
+    if (ok && hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; rc = BK_ERR_INTERNAL; }
+    if (!ok) { bk_ctx_destroy(c); return rc; }
+    c->ix.tgt4 = c->d_tgt4; c->ix.sa_lo = c->d_sa_lo; c->ix.sa_hi = c->d_sa_hi;
+    if (c->d_ktab) { if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab; else c->ix.ktab32 = (const uint32_t *)c->d_ktab; }
+    c->ix.k2 = c->d_k2; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
+    clk.lap("index image copied from the first device");
+    rc = setup_entries(c, src->entries.data(), (uint32_t)src->entries.size());
+    if (rc) { bk_ctx_destroy(c); return rc; }
+    *out = c;
+    return BK_OK;
+}
+
 void bk_ctx_destroy(bk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k2s); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
-    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_gen); free_dev(c->d_gen2); free_dev(c->d_rec8); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
+    free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
     free_dev(c->d_stripe_cnt);
-    free_dev(c->d_isa); free_dev(c->d_hp); free_dev(c->d_seg2); free_dev(c->d_seq_global);
+    free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1158,7 +1131,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
-        if (!rc) rc = build_hp(c);
         return rc ? rc : old;
     }
     if (n == "flat_block") {
@@ -1172,12 +1144,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         if (value != 1 && value != 2 && value != 4) return BK_ERR_PARAMS;
         c->search_ilp = (int)value;
         return old;
-    }
-    if (n == "use_hp") {
-        int64_t old = c->use_hp;
-        c->use_hp = value ? 1 : 0;
-        int rc = build_hp(c);
-        return rc ? rc : old;
     }
     if (n == "sort_lists") {
         int64_t old = c->sort_lists;
@@ -1202,17 +1168,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_isa(c);
         return rc ? rc : old;
     }
-    if (n == "use_eval") {
-        int64_t old = c->use_eval;
-        c->use_eval = value ? 1 : 0;
-        if (c->use_eval && !c->d_rec8) c->cap_reads = 0;          // the result-word array is allocated with the batch scratch
-        return old;
-    }
-    if (n == "use_direct") {
-        int64_t old = c->use_direct;
-        c->use_direct = value ? 1 : 0;
-        return old;
-    }
     if (n == "use_flat") {
         int64_t old = c->use_flat;
         c->use_flat = value ? 1 : 0;
@@ -1222,27 +1177,12 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->use_k2;
         c->use_k2 = value ? 1 : 0;
         int rc = build_k2(c);
-        if (!rc) rc = build_hp(c);
-        return rc ? rc : old;
-    }
-    if (n == "k2s_levels") {
-        int64_t old = c->k2s_levels;
-        c->k2s_levels = (int)value;
-        int rc = build_k2(c);
-        if (!rc) rc = build_hp(c);
         return rc ? rc : old;
     }
     if (n == "use_iv32") {
         int64_t old = c->use_iv32;
         c->use_iv32 = value ? 1 : 0;
         return old;
-    }
-    if (n == "use_k2s") {
-        int64_t old = c->use_k2s;
-        c->use_k2s = value ? 1 : 0;
-        int rc = build_k2(c);
-        if (!rc) rc = build_hp(c);
-        return rc ? rc : old;
     }
     if (n == "lazy_search") {
         int64_t old = c->lazy_search;
@@ -1638,11 +1578,21 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
         if (!rccl.ok) return BK_ERR_INTERNAL;
         std::vector<int> devs;
         for (int j : leaders) devs.push_back(ctxs[j]->device);
-        std::vector<ncclComm_t> comms(leaders.size());
-        if (rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data()) != ncclSuccess) {
-            fprintf(stderr, "biokanga_amd: ncclCommInitAll failed\n");
-            return BK_ERR_INTERNAL;
+        // one set of communicators per set of devices, made on first use and kept for the life of the process: creating them costs
+        // far more than the reduction of a few hundred bytes they carry
+        static std::mutex comm_mu;
+        static std::map<std::vector<int>, std::vector<ncclComm_t>> comm_cache;
+        std::lock_guard<std::mutex> comm_lock(comm_mu);
+        auto hit = comm_cache.find(devs);
+        if (hit == comm_cache.end()) {
+            std::vector<ncclComm_t> fresh(devs.size());
+            if (rccl.CommInitAll(fresh.data(), (int)devs.size(), devs.data()) != ncclSuccess) {
+                fprintf(stderr, "biokanga_amd: ncclCommInitAll failed\n");
+                return BK_ERR_INTERNAL;
+            }
+            hit = comm_cache.emplace(devs, std::move(fresh)).first;
         }
+        const std::vector<ncclComm_t> &comms = hit->second;
         ncclResult_t r = rccl.GroupStart();
         for (size_t k = 0; k < leaders.size() && r == ncclSuccess; k++) {
             bk_ctx *L = ctxs[leaders[k]];
@@ -1651,7 +1601,6 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
         }
         ncclResult_t r2 = rccl.GroupEnd();
         for (int j : leaders) { (void)hipSetDevice(ctxs[j]->device); (void)hipStreamSynchronize(ctxs[j]->stream); }
-        for (ncclComm_t cm : comms) (void)rccl.CommDestroy(cm);
         if (r != ncclSuccess || r2 != ncclSuccess) { fprintf(stderr, "biokanga_amd: ncclAllReduce failed\n"); return BK_ERR_INTERNAL; }
     }
     for (int i = 0; i < n; i++) {

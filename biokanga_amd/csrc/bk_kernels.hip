@@ -799,80 +799,6 @@ __device__ __forceinline__ int k2_cmp(uint64_t key, uint64_t m, uint64_t q2)
     return key < q2 ? -1 : (key > q2 ? 1 : 0);
 }
 
-// Lower and upper bound of the masked probe q2 among the keys k2[lo, hi) of one k-mer bucket, through the sample levels
-// (DevIndex::k2s): at level L the bucket is a run of groups of 8^L keys, every group but the last lies inside the bucket whole and is
-// represented by its last key, so counting the groups whose key sorts below (at or below) the probe names the group that holds the
-// bound; eight groups are one 64-byte line.  l1 = first index with key >= q2, l2 = first index with key > q2.
-__device__ __forceinline__ void k2s_bounds(const DevIndex &ix, uint64_t lo, uint64_t hi, uint64_t m, uint64_t q2, uint64_t &l1, uint64_t &l2)
-{
-    uint64_t a1 = lo, b1 = hi, a2 = lo, b2 = hi;
-    int L = 0;
-    while (L < ix.k2s_levels && ((hi - 1) >> (3 * L)) - (lo >> (3 * L)) >= 8) L++;
-    if (((hi - 1) >> (3 * L)) - (lo >> (3 * L)) >= 8) {
-        // wider than eight groups of the top level: halve over its samples first
-        const uint64_t *__restrict__ S = ix.k2s + ix.k2s_off[L - 1];
-        uint64_t g1 = lo >> (3 * L), h1 = (hi - 1) >> (3 * L), g2 = g1, h2 = h1;      // first group in [g, h) whose key is >= / > the probe, else h
-        while (g1 < h1 || g2 < h2) {
-            const bool o1 = g1 < h1, o2 = g2 < h2;
-            const uint64_t m1 = g1 + ((h1 - g1) >> 1), m2 = g2 + ((h2 - g2) >> 1);
-            const uint64_t v1 = o1 ? S[m1] : 0, v2 = o2 ? S[m2] : 0;
-            if (o1) { if (k2_cmp(v1, m, q2) < 0) g1 = m1 + 1; else h1 = m1; }
-            if (o2) { if (k2_cmp(v2, m, q2) <= 0) g2 = m2 + 1; else h2 = m2; }
-        }
-        a1 = a1 > (g1 << (3 * L)) ? a1 : (g1 << (3 * L));
-        b1 = b1 < ((g1 + 1) << (3 * L)) ? b1 : ((g1 + 1) << (3 * L));
-        a2 = a2 > (g2 << (3 * L)) ? a2 : (g2 << (3 * L));
-        b2 = b2 < ((g2 + 1) << (3 * L)) ? b2 : ((g2 + 1) << (3 * L));
-        L--;
-    }
-    for (; L >= 1; L--) {
-        const uint64_t *__restrict__ S = ix.k2s + ix.k2s_off[L - 1];
-        const uint64_t g1 = a1 >> (3 * L), e1 = (b1 - 1) >> (3 * L), g2 = a2 >> (3 * L), e2 = (b2 - 1) >> (3 * L);
-        uint64_t v1[8], v2[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            // (always a load from inside the level, never an exec-masked one: see DESIGN.md on hipcc 7.2 and masked loads)
-            v1[j] = S[g1 + j < e1 ? g1 + j : g1];
-            v2[j] = S[g2 + j < e2 ? g2 + j : g2];
-        }
-        uint32_t c1 = 0, c2 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c1 += (g1 + j < e1 && k2_cmp(v1[j], m, q2) < 0) ? 1u : 0u;
-            c2 += (g2 + j < e2 && k2_cmp(v2[j], m, q2) <= 0) ? 1u : 0u;
-        }
-        const uint64_t s1 = (g1 + c1) << (3 * L), s2 = (g2 + c2) << (3 * L), w = 1ULL << (3 * L);
-        a1 = a1 > s1 ? a1 : s1;
-        b1 = b1 < s1 + w ? b1 : s1 + w;
-        a2 = a2 > s2 ? a2 : s2;
-        b2 = b2 < s2 + w ? b2 : s2 + w;
-    }
-    // at most eight keys left on either side
-    uint64_t v1[8], v2[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        v1[j] = ix.k2[a1 + j < b1 ? a1 + j : a1];
-        v2[j] = ix.k2[a2 + j < b2 ? a2 + j : a2];
-    }
-    uint32_t c1 = 0, c2 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c1 += (a1 + j < b1 && k2_cmp(v1[j], m, q2) < 0) ? 1u : 0u;
-        c2 += (a2 + j < b2 && k2_cmp(v2[j], m, q2) <= 0) ? 1u : 0u;
-    }
-    l1 = a1 + c1;
-    l2 = a2 + c2;
-}
-
-// level L of the samples from level L - 1 (level 0 = the keys): dst[i] = src[min(8 i + 7, n_src - 1)]
-__global__ void k_build_k2s(const uint64_t *__restrict__ src, uint64_t n_src, uint64_t *__restrict__ dst, uint64_t n_dst)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t j = 8 * i + 7;
-        dst[i] = src[j < n_src ? j : n_src - 1];
-    }
-}
-
 // as cmp_core, but only bases [start, cl) of the core are compared
 __device__ __forceinline__ int cmp_core_from(const uint64_t *__restrict__ rdw, int ofs, int cl, int start,
                                              const uint64_t *__restrict__ tgt, uint64_t pos)
@@ -908,97 +834,6 @@ __global__ void k_check_k2(DevIndex ix, const uint64_t *__restrict__ k2, unsigne
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Prefix hash (DevIndex::hp): ONE cache line answers "where in the suffix array are the suffixes that start with these K
-// bases" for cores of K bases and more - the k-mer table + second-level key array need two or three.  Every distinct K-base
-// prefix (no N/EOS) of the indexed suffixes owns an 8-byte entry {interval start 32 | count 8 (255 = 255 or more: the caller
-// falls back to table + keys) | displacement 3 | tag 21}; 8 entries make a 64-byte bucket, 2^bits buckets.  The 2K-bit prefix
-// code goes through a bijective mix; its low `bits` bits pick the home bucket, the remaining 2K - bits <= 21 bits are the tag,
-// so (bucket, tag) identify the prefix EXACTLY - a hit needs no verification of the first K bases, and a miss proves the
-// prefix occurs nowhere.  An entry whose home bucket was full sits in one of the next 7 (displacement recorded); a look-up
-// stops at the first bucket that still has a free slot.
-constexpr uint64_t kHpEmpty = ~0ULL;
-
-__device__ __forceinline__ uint64_t hp_mix(uint64_t key, int k)       // bijective on 2k-bit values
-{
-    const uint64_t m = (1ULL << (2 * k)) - 1;
-    uint64_t x = (key * 0x9E3779B97F4A7C15ULL) & m;
-    x ^= x >> k;
-    x = (x * 0xC2B2AE3D27D4EB4FULL) & m;
-    x ^= x >> (k - 3);
-    x = (x * 0x165667B19E3779F9ULL) & m;
-    x ^= x >> (k + 1);
-    return x;
-}
-
-// 2K-bit code of the first K (<= 24) bases given nibbles 0..15 (w0) and 16..31 (w1); false when one of them is N/EOS
-__device__ __forceinline__ bool hp_key(uint64_t w0, uint64_t w1, int k, uint64_t &key)
-{
-    const uint64_t bad = k <= 16 ? (w0 & top_mask(k)) : (w0 | (w1 & top_mask(k - 16)));
-    if (bad & 0x4444444444444444ULL) return false;
-    const uint64_t full = ((uint64_t)squeeze2(w0) << 16) | (uint64_t)(squeeze2(w1) >> 16);      // 24 bases, 48 bits
-    key = full >> (2 * (24 - k));
-    return true;
-}
-
-// 1 = found (lo, cnt), 0 = the prefix does not occur
-__device__ __forceinline__ int hp_lookup(const DevIndex &ix, uint64_t key, uint32_t &lo, uint32_t &cnt)
-{
-    const uint64_t x = hp_mix(key, ix.hp_k);
-    const uint64_t mask = (1ULL << ix.hp_bits) - 1;
-    const uint64_t home = x & mask, tag = x >> ix.hp_bits;
-    for (uint64_t d = 0; d < 8; d++) {
-        const uint4 *bp = reinterpret_cast<const uint4 *>(ix.hp + (((home + d) & mask) << 3));
-        const uint64_t want = (tag << 3) | d;
-        bool full = true;
-        int hit = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint4 v = bp[q];
-            const uint64_t e0 = ((uint64_t)v.y << 32) | v.x, e1 = ((uint64_t)v.w << 32) | v.z;
-            if (e0 == kHpEmpty || e1 == kHpEmpty) full = false;
-            if (e0 != kHpEmpty && (e0 >> 40) == want) { lo = (uint32_t)e0; cnt = (uint32_t)(e0 >> 32) & 0xffu; hit = 1; }
-            if (e1 != kHpEmpty && (e1 >> 40) == want) { lo = (uint32_t)e1; cnt = (uint32_t)(e1 >> 32) & 0xffu; hit = 1; }
-        }
-        if (hit) return 1;
-        if (!full) return 0;
-    }
-    return 0;       // eight full buckets without it: the build refuses tables in which an entry could lie further away
-}
-
-__global__ void __launch_bounds__(256) k_build_hp(DevIndex ix, unsigned long long *__restrict__ tab, int bits, int k,
-                                                  unsigned long long *__restrict__ fail)
-{
-    const uint64_t mask = (1ULL << bits) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t pos = ix.sa_lo[i];
-        uint64_t key;
-        if (!hp_key(nib16(ix.tgt4, pos), nib16(ix.tgt4, pos + 16), k, key)) continue;
-        if (i > 0) {                                          // only the first suffix of a run of equal prefixes inserts
-            const uint64_t pp = ix.sa_lo[i - 1];
-            uint64_t kp;
-            if (hp_key(nib16(ix.tgt4, pp), nib16(ix.tgt4, pp + 16), k, kp) && kp == key) continue;
-        }
-        uint32_t cnt = 1;
-        while (cnt < 255 && i + cnt < ix.n) {
-            const uint64_t pj = ix.sa_lo[i + cnt];
-            uint64_t kj;
-            if (!hp_key(nib16(ix.tgt4, pj), nib16(ix.tgt4, pj + 16), k, kj) || kj != key) break;
-            cnt++;
-        }
-        const uint64_t x = hp_mix(key, k);
-        const uint64_t home = x & mask, tag = x >> bits;
-        bool placed = false;
-        for (uint64_t d = 0; d < 8 && !placed; d++) {
-            const unsigned long long entry = (((tag << 3) | d) << 40) | ((unsigned long long)cnt << 32) | (unsigned long long)(uint32_t)i;
-            unsigned long long *bp = tab + (((home + d) & mask) << 3);
-            for (int q = 0; q < 8 && !placed; q++)
-                if (bp[q] == kHpEmpty) placed = atomicCAS(&bp[q], kHpEmpty, entry) == kHpEmpty;
-        }
-        if (!placed) atomicAdd(fail, 1ULL);
-    }
-}
-
 __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
                                                   uint32_t n_act, int phase, int cmax, int nstr, int lazy,
                                                   StripeSet out)
@@ -1031,23 +866,7 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
             uint64_t first = 0;
             uint32_t nval = kKindFull << kKindShift;
             push = true;
-            // prefix hash first: one line settles the core's first hp_k bases (found with its interval, or proven absent)
-            bool settled = false;
-            if (ix.hp != nullptr && cl >= ix.hp_k) {
-                uint64_t hk;
-                if (hp_key(nib16(rdw, my_ofs), nib16(rdw, my_ofs + 16), ix.hp_k, hk)) {
-                    uint32_t lo = 0, cnt = 0;
-                    if (!hp_lookup(ix, hk, lo, cnt)) { first = 0; nval = 0; push = false; settled = true; }
-                    else if (cnt < 255) {
-                        first = lo;
-                        settled = true;
-                        if (cl == ix.hp_k) { nval = cnt; push = false; }                                   // the interval is exact
-                        else if (lazy && cnt <= kLazyBucket) { nval = cnt | kLazyFlag; push = false; }     // the extend kernels verify the rest
-                        else nval = cnt | (kKindDeep << kKindShift);                                       // pass B: the bases beyond hp_k
-                    }
-                }
-            }
-            if (!settled && cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
+            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
                 uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
                 uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
                 uint64_t size = hi - lo;
@@ -1313,11 +1132,6 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
         // lower and upper bound in lock step: two independent loads per round
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
-        if (ix.k2s != nullptr && cnt > 0) {
-            k2s_bounds(ix, first, first + cnt, m, q2, l1, l2);
-            h1 = l1;
-            h2 = l2;
-        }
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
             const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
@@ -1343,8 +1157,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         return;
     }
     {
-        // intervals handed on by the prefix hash agree with the core on hp_k bases only; comparing from there is right for both kinds
-        const int start = (ix.hp != nullptr && ix.hp_k < k + 16) ? ix.hp_k : k + 16;
+        const int start = k + 16;
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
@@ -2449,455 +2262,6 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     PROF(9);
     PROF_END;
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_eval + k_replay: k_flat cut into two streaming launches, for the reads whose core intervals all hold <= kEvalMax suffixes
-// (the great majority; k_flat keeps the rest).  k_flat does everything for 256 reads inside one block - count, prefix sums, one
-// candidate per lane, replay - with four block barriers and ~100 VGPRs: its waves spend their life waiting on each other and on
-// a chain of dependent loads at 4 waves/SIMD.  Here
-//   k_eval    one lane per (read, strand, core): the slot's interval record, then its few candidates one after the other - suffix
-//             array element, window compare (k_flat's evaluation, same result bytes) - packed into ONE 8-byte word per slot
-//             (DevBatch::rec8, laid out like the interval records so that neighbouring reads touch neighbouring words)
-//   k_replay  one lane per read: the slots' counts and result words in walk order (strand, core, suffix) through the Low / NxtLow /
-//             instances state machine; result record, next phase's list, or - a slot above kEvalMax / heavy_thresh - the list k_flat
-//             or k_wave continue from
-// No barrier, no LDS candidate table; the hand-over costs 8 bytes per slot of coalesced traffic.
-constexpr uint32_t kEvalMax = 8;
-
-template <int NW>
-__global__ void __launch_bounds__(256) k_eval(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act, int phase,
-                                              int cmax, int nstr)
-{
-    // slot-major: neighbouring lanes work on neighbouring reads of ONE (strand, core), so that the interval records and the
-    // result words - both laid out [strand][core][read] - are touched a line at a time (a block = 256 reads of one slot)
-    const uint32_t rblocks = (n_act + 255) / 256;
-    const uint32_t q = blockIdx.x / rblocks;
-    const uint32_t a = (blockIdx.x - q * rblocks) * 256 + threadIdx.x;
-    if (a >= n_act) return;
-    const int si = (int)(q / (uint32_t)cmax), c = (int)(q % (uint32_t)cmax);
-    const uint32_t r = act[a];
-    const int strand = cfg.align_strand == 2 ? 1 : si;
-    const uint64_t slot = iv_slot(b, r, strand, c);
-    uint64_t first;
-    uint32_t nraw;
-    iv_get(b, slot, first, nraw);                  // slots beyond the read's own cores hold stale records: looked at only after the plan says c < nc
-    const int len = (int)b.lens[r];
-    ReadPlan p = make_plan(len, cfg);
-    int mm, cl, cd, dummy[1];
-    phase_params(p, cfg, phase, mm, cl, cd);
-    const int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
-    if (c >= nc || nc > kMaxCoresFast || len > 16 * NW) return;
-    const uint32_t n = nraw & ~kLazyFlag;
-    if (n == 0 || n > kEvalMax) return;
-    const bool lazy = (nraw & kLazyFlag) != 0;
-    const int last = len - cl;
-    const int ofs = c * cd < last ? c * cd : last;
-    uint64_t r2w[NW / 2], rnm[NW / 4], rw[NW];
-    const bool two_bit = b.rd2 != nullptr;
-    bool have_rw = false;
-    if (two_bit) load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + strand) * (3 * NW / 4), r2w, rnm);
-    uint64_t word = 0;
-    for (uint32_t j = 0; j < n; j++) {
-        const uint64_t loci = sa_get<false>(ix, first + j);
-        uint32_t rec = kRecSkip;
-        if (loci >= (uint64_t)ofs) {
-            const uint64_t t0 = loci - (uint64_t)ofs;
-            Window<NW> w;
-            bool flg = true;
-            if (two_bit) {
-                flg = window_flagged(ix, t0, len);
-                eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t0, w);
-            }
-            if (flg) {                                                   // N/EOS nearby (rare): the 4-bit copy decides
-                if (!have_rw) { load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr, len, rw); have_rw = true; }
-                eval_window<NW>(rw, len, ix.tgt4, t0, w);
-            }
-            bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, cl));
-            for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * cd, cl);      // earlier cores never sit at the clipped offset
-            if (!skip) rec = (uint32_t)(w.mm < 127 ? w.mm : 127);
-        }
-        word |= (uint64_t)rec << (8 * j);
-    }
-    b.rec8[slot] = word;
-}
-
-template <int NW>
-__global__ void __launch_bounds__(256) k_replay(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act, int phase,
-                                                uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
-                                                uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave, uint32_t *__restrict__ wave_cnt,
-                                                uint32_t *__restrict__ flat, uint32_t *__restrict__ flat_cnt, uint32_t *__restrict__ cmax_next)
-{
-    __shared__ uint32_t s_cnt[5], s_base[5], s_cmax;
-    __shared__ unsigned long long s_ctr[3];
-    const uint32_t t = threadIdx.x;
-    const int lane = t & 63;
-    if (t < 5) s_cnt[t] = 0;
-    if (t == 5) s_cmax = 0;
-    if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
-    __syncthreads();
-    const uint32_t a = blockIdx.x * blockDim.x + t;
-    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
-    int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel, 4 = k_flat
-    uint32_t r = 0, my_cmax = 0;
-    if (a < n_act) {
-        r = act[a];
-        const int len = (int)b.lens[r];
-        ReadPlan p = make_plan(len, cfg);
-        int mm, cl, cd, dummy[1];
-        phase_params(p, cfg, phase, mm, cl, cd);
-        const int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
-        const bool fits = nc <= kMaxCoresFast && len <= 16 * NW;
-        if (!fits) dest = 3;
-        else {
-            uint32_t biggest = 0;
-            for (int st = s0; st <= s1; st++)
-                for (int c = 0; c < nc; c++) {
-                    const uint32_t cnt = iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag;
-                    biggest = cnt > biggest ? cnt : biggest;
-                }
-            if (biggest > (uint32_t)cfg.heavy_thresh) dest = wave != nullptr ? 2 : 3;
-            else if (biggest > kEvalMax) dest = 4;
-            else {
-                n_lcm = 1;
-                const int init = mm + cfg.mm_delta + 1;
-                int low_inst = 0, low_mm = init, nxt = init;
-                int best_c = 0, best_st = 0;
-                uint32_t best_j = 0;
-                uint64_t best_first = 0;
-                bool done = false;
-                for (int st = s0; st <= s1 && !done; st++)
-                    for (int c = 0; c < nc && !done; c++) {
-                        n_search++;
-                        const uint64_t slot = iv_slot(b, r, st, c);
-                        uint64_t first;
-                        uint32_t nraw;
-                        iv_get(b, slot, first, nraw);
-                        const uint32_t n = nraw & ~kLazyFlag;
-                        if (!n) continue;
-                        const uint64_t word = b.rec8[slot];
-                        for (uint32_t x = 0; x < n; x++) {
-                            const int cm = (int)((word >> (8 * x)) & 0xff);
-                            if (cm == kRecSkip) continue;
-                            n_cand++;
-                            if (cm > mm || cm >= nxt) continue;
-                            if (cm < low_mm) {
-                                low_inst = 1; nxt = low_mm; low_mm = cm;
-                                best_c = c; best_st = st; best_j = x; best_first = first;
-                            } else if (cm == low_mm)
-                                low_inst++;
-                            else
-                                nxt = cm;
-                            if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
-                        }
-                    }
-                const int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-                if (rslt != BK_HR_NONE) {
-                    uint64_t hit_left = 0;
-                    int hit_strand = '?', e = -1;
-                    if (low_inst >= 1) {
-                        const int last = len - cl;
-                        const int ofs = best_c * cd < last ? best_c * cd : last;
-                        hit_left = sa_get<false>(ix, best_first + best_j) - (uint64_t)ofs;
-                        hit_strand = best_st ? '-' : '+';
-                        e = find_entry(ix, hit_left);
-                    }
-                    write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
-                } else if (phase + 1 < p.n_phases) {
-                    int mm2, cl2, cd2;
-                    phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
-                    const int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                    if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
-                    dest = 1;
-                }
-            }
-        }
-    }
-    const uint64_t lt_mask = (1ULL << lane) - 1;
-    for (int off = 32; off > 0; off >>= 1) {
-        n_search += __shfl_down(n_search, off);
-        n_cand += __shfl_down(n_cand, off);
-        n_lcm += __shfl_down(n_lcm, off);
-        uint32_t m = __shfl_down(my_cmax, off);
-        my_cmax = m > my_cmax ? m : my_cmax;
-    }
-    uint32_t my_off = 0;
-#pragma unroll
-    for (int d = 1; d <= 4; d++) {
-        uint64_t m = __ballot(dest == d);
-        if (m) {
-            uint32_t w = 0;
-            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
-            w = __builtin_amdgcn_readfirstlane(w);
-            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
-        }
-    }
-    if (lane == 0) {
-        if (my_cmax) atomicMax(&s_cmax, my_cmax);
-        if (n_search) atomicAdd(&s_ctr[0], n_search);
-        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
-    }
-    __syncthreads();
-    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
-    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
-    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
-    if (t == 4 && s_cnt[4]) s_base[4] = atomicAdd(flat_cnt, s_cnt[4]);
-    if (t == 5 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
-    __syncthreads();
-    if (dest == 1) next_act[s_base[1] + my_off] = r;
-    else if (dest == 2) wave[s_base[2] + my_off] = r;
-    else if (dest == 3) heavy[s_base[3] + my_off] = r;
-    else if (dest == 4) flat[s_base[4] + my_off] = r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_direct: pass A of the two-pass search (exactly k_search_a: one lane per active read, strand and core) and, for the reads
-// whose EVERY core it settles with a handful of candidates, the rest of the LocateCoreMultiples call in the same launch: the
-// lane that located a core's few suffixes evaluates them itself (suffix array element, window compare, one result byte in LDS
-// - k_flat's evaluation), then one lane per read replays the bytes in the reference's walk order (strand, core, suffix)
-// through the Low / NxtLow / instances state machine and writes the result or hands the read to the next phase.  For these
-// reads - most reads of every phase - no interval record is ever written to or read back from HBM, no work-list item is
-// produced, and k_flat does not see them.  The other reads (a core that needs pass B, or an interval above the in-place
-// limit) get their interval records written as k_search_a writes them - every slot, empty ones included, so the phase's
-// slots need no clearing - and go on the `general` list that pass B + k_flat / k_wave continue from.
-constexpr uint32_t kDirectMax = kInlineBucket;     // candidates per core evaluated in place
-
-template <bool WIDE, int NW>
-__global__ void __launch_bounds__(256) k_direct(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act, uint32_t n_act,
-                                                int phase, int cmax, int nstr, int lazy, uint32_t *__restrict__ slist,
-                                                uint32_t *__restrict__ slist_cnt, uint32_t *__restrict__ general,
-                                                uint32_t *__restrict__ general_cnt, uint32_t *__restrict__ next_act,
-                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next)
-{
-    __shared__ uint8_t s_gen[256];                      // per read of the block: 1 = continues on the general path, 2 = does not fit these kernels
-    __shared__ uint8_t s_rec[256 * kDirectMax];         // [lane][candidate]: mismatches, or kRecSkip
-    __shared__ uint8_t s_n[256];                        // candidates of the lane's slot
-    __shared__ unsigned long long s_first[256];         // suffix array index of the slot's first candidate
-    __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
-    __shared__ unsigned long long s_ctr[3];
-    const uint32_t t = threadIdx.x;
-    const int lane = t & 63;
-    if (t < 4) s_cnt[t] = 0;
-    if (t == 4) s_cmax = 0;
-    if (t >= 8 && t < 11) s_ctr[t - 8] = 0;
-    s_gen[t] = 0;
-    s_n[t] = 0;
-    __syncthreads();
-
-    const uint32_t per_read = (uint32_t)(nstr * cmax);
-    const uint32_t rpb = 256u / per_read;               // reads per block
-    const uint32_t ri = t / per_read, q = t - ri * per_read;
-    const uint64_t a = (uint64_t)blockIdx.x * rpb + ri;
-    const bool have = ri < rpb && a < n_act;
-    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-
-    uint32_t r = 0;
-    int len = 0, mm = 0, cl = 1, cd = 1, nc = 0, n_phases = 0, c = 0, strand = 0, my_ofs = 0;
-    bool slot_lane = false, push = false, lazy_slot = false;
-    uint64_t slot = 0, first = 0;
-    uint32_t nval = 0, cnt = 0;
-    if (have) {
-        r = act[a];
-        len = (int)b.lens[r];
-        ReadPlan p = make_plan(len, cfg);
-        n_phases = p.n_phases;
-        int dummy[1];
-        phase_params(p, cfg, phase, mm, cl, cd);
-        nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
-        const bool fits = nc <= kMaxCoresFast && nc <= cmax && len <= 16 * NW;
-        const int si = (int)(q / (uint32_t)cmax);
-        c = (int)(q % (uint32_t)cmax);
-        strand = cfg.align_strand == 2 ? 1 : si;
-        if (!fits) {
-            if (q == 0) s_gen[ri] = 2;
-        } else if (c < nc) {
-            // ---- k_search_a, verbatim
-            slot_lane = true;
-            my_ofs = c * cd < len - cl ? c * cd : len - cl;
-            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
-            slot = iv_slot(b, r, strand, c);
-            const int k = ix.k;
-            const uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
-            nval = kKindFull << kKindShift;
-            push = true;
-            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
-                const uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
-                const uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
-                const uint64_t size = hi - lo;
-                if (size == 0) {
-                    first = lo; nval = 0; push = false;
-                } else if (size <= kInlineBucket) {
-                    const int rem2 = cl - k;
-                    const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-                    const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
-                    uint64_t key[kInlineBucket];
-#pragma unroll
-                    for (uint32_t j = 0; j < kInlineBucket; j++) key[j] = j < size ? ix.k2[lo + j] : ~0ULL;
-                    uint32_t lb = 0, ub = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < kInlineBucket; j++) {
-                        int cm = k2_cmp(key[j], m, q2);
-                        lb += cm < 0;
-                        ub += cm <= 0;
-                    }
-                    first = lo + lb;
-                    const uint32_t n2 = ub - lb;
-                    if (n2 == 0 || cl <= k + 16) { nval = n2; push = false; }
-                    else if (lazy && n2 <= kLazyBucket) { nval = n2 | kLazyFlag; push = false; }
-                    else nval = n2 | (kKindDeep << kKindShift);
-                } else if (size < (1ULL << kKindShift)) {
-                    first = lo;
-                    nval = (uint32_t)size | (kKindK2 << kKindShift);
-                }
-            }
-            cnt = nval & ~kLazyFlag;
-            lazy_slot = (nval & kLazyFlag) != 0;
-            const uint32_t lim = kDirectMax < (uint32_t)cfg.heavy_thresh ? kDirectMax : (uint32_t)cfg.heavy_thresh;
-            if (push || cnt > lim) s_gen[ri] = 1;
-        }
-    }
-    __syncthreads();
-    const int gen = have ? (int)s_gen[ri] : 0;
-    if (gen != 1) push = false;
-    if (gen == 1 && slot_lane) iv_put(b, slot, first, nval);           // every slot of the read, empty ones too
-
-    // ---- in-place evaluation (k_flat's candidate step)
-    if (have && gen == 0 && slot_lane && cnt > 0) {
-        s_n[t] = (uint8_t)cnt;
-        s_first[t] = first;
-        uint64_t r2w[NW / 2], rnm[NW / 4], rw[NW];
-        const bool two_bit = b.rd2 != nullptr;
-        if (two_bit) load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + strand) * (3 * NW / 4), r2w, rnm);
-        bool have_rw = false;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint64_t loci = sa_get<WIDE>(ix, first + j);
-            uint8_t rec = kRecSkip;
-            if (loci >= (uint64_t)my_ofs) {
-                const uint64_t t0 = loci - (uint64_t)my_ofs;
-                Window<NW> w;
-                bool flg = true;
-                if (two_bit) {
-                    flg = window_flagged(ix, t0, len);
-                    eval_window2<NW>(r2w, rnm, len, ix.tgt2, ix.tgt2s, t0, w);
-                }
-                if (flg) {                                               // N/EOS nearby (rare): the 4-bit copy decides
-                    if (!have_rw) { load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr, len, rw); have_rw = true; }
-                    eval_window<NW>(rw, len, ix.tgt4, t0, w);
-                }
-                bool skip = w.eos || (lazy_slot && !core_clean<NW>(w, my_ofs, cl));
-                for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * cd, cl);      // earlier cores never sit at the clipped offset
-                if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
-            }
-            s_rec[t * kDirectMax + j] = rec;
-        }
-    }
-    __syncthreads();
-
-    // ---- replay, one lane per read
-    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
-    int dest = 0;                   // 1 = next phase, 2 = general path
-    uint32_t my_cmax = 0;
-    if (have && q == 0) {
-        if (gen != 0) dest = 2;
-        else {
-            n_lcm = 1;
-            const int init = mm + cfg.mm_delta + 1;
-            int low_inst = 0, low_mm = init, nxt = init;
-            int best_lane = -1, best_c = 0, best_st = 0;
-            uint32_t best_j = 0;
-            bool done = false;
-            for (int st = s0; st <= s1 && !done; st++) {
-                const int si = cfg.align_strand == 2 ? 0 : st;
-                for (int cc = 0; cc < nc && !done; cc++) {
-                    n_search++;
-                    const uint32_t tl = ri * per_read + (uint32_t)(si * cmax + cc);
-                    const uint32_t n = s_n[tl];
-                    for (uint32_t x = 0; x < n; x++) {
-                        const int cm = s_rec[tl * kDirectMax + x];
-                        if (cm == kRecSkip) continue;
-                        n_cand++;
-                        if (cm > mm || cm >= nxt) continue;
-                        if (cm < low_mm) {
-                            low_inst = 1; nxt = low_mm; low_mm = cm;
-                            best_lane = (int)tl; best_j = x; best_c = cc; best_st = st;
-                        } else if (cm == low_mm)
-                            low_inst++;
-                        else
-                            nxt = cm;
-                        if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
-                    }
-                }
-            }
-            const int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-            if (rslt != BK_HR_NONE) {
-                uint64_t hit_left = 0;
-                int hit_strand = '?', e = -1;
-                if (low_inst >= 1) {
-                    const int last = len - cl;
-                    const int ofs = best_c * cd < last ? best_c * cd : last;
-                    hit_left = sa_get<WIDE>(ix, s_first[best_lane] + best_j) - (uint64_t)ofs;
-                    hit_strand = best_st ? '-' : '+';
-                    e = find_entry(ix, hit_left);
-                }
-                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
-            } else if (phase + 1 < n_phases) {
-                ReadPlan p = make_plan(len, cfg);
-                int mm2, cl2, cd2, dummy[1];
-                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
-                const int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
-                dest = 1;
-            }
-        }
-    }
-    // ---- appends (one global atomic per block and list) and counters
-    const uint64_t lt_mask = (1ULL << lane) - 1;
-    for (int off = 32; off > 0; off >>= 1) {
-        n_search += __shfl_down(n_search, off);
-        n_cand += __shfl_down(n_cand, off);
-        n_lcm += __shfl_down(n_lcm, off);
-        uint32_t m = __shfl_down(my_cmax, off);
-        my_cmax = m > my_cmax ? m : my_cmax;
-    }
-    uint32_t my_off = 0, my_soff = 0;
-#pragma unroll
-    for (int d = 1; d <= 2; d++) {
-        uint64_t m = __ballot(dest == d);
-        if (m) {
-            uint32_t w = 0;
-            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
-            w = __builtin_amdgcn_readfirstlane(w);
-            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
-        }
-    }
-    {
-        uint64_t m = __ballot(push);
-        if (m) {
-            uint32_t w = 0;
-            if (lane == 0) w = atomicAdd(&s_cnt[3], (uint32_t)__popcll(m));
-            w = __builtin_amdgcn_readfirstlane(w);
-            if (push) my_soff = w + (uint32_t)__popcll(m & lt_mask);
-        }
-    }
-    if (lane == 0) {
-        if (my_cmax) atomicMax(&s_cmax, my_cmax);
-        if (n_search) atomicAdd(&s_ctr[0], n_search);
-        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
-    }
-    __syncthreads();
-    if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
-    if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(general_cnt, s_cnt[2]);
-    if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(slist_cnt, s_cnt[3]);
-    if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-    if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
-    __syncthreads();
-    if (dest == 1) next_act[s_base[1] + my_off] = r;
-    else if (dest == 2) general[s_base[2] + my_off] = r;
-    if (push) slist[s_base[3] + my_soff] = (uint32_t)slot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4691,20 +4055,6 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
     }
 }
 
-void launch_build_hp(const DevIndex &ix, unsigned long long *tab, int bits, int k, unsigned long long *fail, hipStream_t s)
-{
-    uint64_t blocks = (ix.n + 255) / 256;
-    if (blocks > 262144) blocks = 262144;
-    hipLaunchKernelGGL(k_build_hp, dim3((unsigned)blocks), dim3(256), 0, s, ix, tab, bits, k, fail);
-}
-
-void launch_build_k2s(const uint64_t *src, uint64_t n_src, uint64_t *dst, uint64_t n_dst, hipStream_t s)
-{
-    uint64_t blocks = (n_dst + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    if (n_dst) hipLaunchKernelGGL(k_build_k2s, dim3((unsigned)blocks), dim3(256), 0, s, src, n_src, dst, n_dst);
-}
-
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s)
 {
     uint64_t blocks = (ix.n + 255) / 256;
@@ -4779,7 +4129,7 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
     uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
     int ilp = lazy >> 8;                               // bits 8..: searches per lane (0 / 1 = the plain kernel)
     lazy &= 0xff;
-    if (ilp < 2 || ix.hp != nullptr) ilp = 1;
+    if (ilp < 2) ilp = 1;
     else if (ilp != 2) ilp = 4;
     const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
     const unsigned blocks = (unsigned)((threads + per - 1) / per);
@@ -4849,39 +4199,6 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     // list order of the set: next phase, wave kernel, general kernel (the wave list may be absent: then it stays empty)
     uint32_t *dense[3] = {next_act, have_wave ? wave : heavy, heavy}, *total[3] = {next_cnt, have_wave ? wave_cnt : heavy_cnt, heavy_cnt};
     launch_compact(out, dense, total, 3, cmax_next, s);
-}
-
-void launch_eval(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
-                 int nw, hipStream_t s)
-{
-    const uint64_t nblk = (uint64_t)((n_act + 255) / 256) * (uint64_t)(cmax * nstr);      // 256 reads x one (strand, core) per block
-    const unsigned blocks = (unsigned)nblk;
-    if (!blocks) return;
-    if (nw <= 8) hipLaunchKernelGGL((k_eval<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
-    else hipLaunchKernelGGL((k_eval<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr);
-}
-
-void launch_replay(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, uint32_t *next_act,
-                   uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt, uint32_t *flat, uint32_t *flat_cnt,
-                   uint32_t *cmax_next, int nw, hipStream_t s)
-{
-    const unsigned blocks = (n_act + 255) / 256;
-    if (!blocks) return;
-    if (nw <= 8) hipLaunchKernelGGL((k_replay<8>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, flat, flat_cnt, cmax_next);
-    else hipLaunchKernelGGL((k_replay<16>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, flat, flat_cnt, cmax_next);
-}
-
-void launch_direct(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase, int cmax, int nstr,
-                   int lazy, uint32_t *slist, uint32_t *slist_cnt, uint32_t *general, uint32_t *general_cnt, uint32_t *next_act, uint32_t *next_cnt,
-                   uint32_t *cmax_next, int nw, hipStream_t s)
-{
-    const uint32_t rpb = 256u / (uint32_t)(nstr * cmax);
-    const unsigned blocks = (unsigned)(((uint64_t)n_act + rpb - 1) / rpb);
-    const bool wide = ix.sa_hi != nullptr;
-#define BK_DIRECT(W, N) hipLaunchKernelGGL((k_direct<W, N>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, slist, slist_cnt, general, general_cnt, next_act, next_cnt, cmax_next)
-    if (nw <= 8) { if (wide) BK_DIRECT(true, 8); else BK_DIRECT(false, 8); }
-    else { if (wide) BK_DIRECT(true, 16); else BK_DIRECT(false, 16); }
-#undef BK_DIRECT
 }
 
 void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,

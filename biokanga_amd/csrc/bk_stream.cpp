@@ -29,13 +29,15 @@ struct CastU64 {
     __host__ __device__ unsigned long long operator()(const uint32_t &v) const { return (unsigned long long)v; }
 };
 
-// max over reads of offs[i] + lens[i] (reads must lie inside the uploaded bases) and of lens[i]
+// max over reads of offs[i] + lens[i] (reads must lie inside the uploaded bases) and of lens[i].  Checked per element without a
+// sum that can wrap: a read that starts beyond `nbases` or runs past it reports an end of ~0.
 __global__ void __launch_bounds__(256) k_extent(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens, uint32_t n,
-                                                unsigned long long *__restrict__ out)
+                                                unsigned long long nbases, unsigned long long *__restrict__ out)
 {
     unsigned long long e = 0, l = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const unsigned long long len = lens[i], end = offs[i] + len;
+        const unsigned long long len = lens[i], o = offs[i];
+        const unsigned long long end = (o > nbases || len > nbases - o) ? ~0ULL : o + len;
         e = end > e ? end : e;
         l = len > l ? len : l;
     }
@@ -159,7 +161,7 @@ struct bk_stream {
                 if (e == hipSuccess) {
                     unsigned blocks = (j->n + 255) / 256;
                     if (blocks > 2048) blocks = 2048;
-                    hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s_al, sl.d_offs, sl.d_lens, j->n, d_ext);
+                    hipLaunchKernelGGL(k_extent, dim3(blocks), dim3(256), 0, s_al, sl.d_offs, sl.d_lens, j->n, (unsigned long long)j->nbases, d_ext);
                     e = hipGetLastError();
                 }
                 if (e == hipSuccess) e = hipMemcpyAsync(h_ext, d_ext, 16, hipMemcpyDeviceToHost, s_al);
@@ -196,8 +198,12 @@ struct bk_stream {
                 if (e == hipSuccess) e = hipMemcpyAsync(j->out, sl.d_out, (size_t)j->n * sizeof(bk_hit), hipMemcpyDeviceToHost, s_dn);
                 if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
                 if (e != hipSuccess) fail(j, rc_of(e));
-            } else if (j->rc != BK_OK)
-                (void)hipStreamSynchronize(s_up);           // nothing of a failed batch may still be in flight when its slot is reused
+            } else if (j->rc != BK_OK) {
+                // nothing of a failed batch may still be in flight when its slot (and the context's batch scratch) is reused
+                (void)hipStreamSynchronize(s_up);
+                (void)hipStreamSynchronize(s_al);
+                (void)hipStreamSynchronize(s_dn);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 j->done = true;

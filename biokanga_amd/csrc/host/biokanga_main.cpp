@@ -794,8 +794,14 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<bk_ctx *> ctxs(ndev, nullptr);
     std::vector<int> ctx_rc(ndev, 0);
     std::vector<std::thread> loaders;
-    for (size_t d = 0; d < ndev; d++)
-        loaders.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_create(&ctxs[d], a.str("I").c_str(), o.devices[d], &o.P); });
+    // the first device reads the .sfx and builds the tables; the others receive the finished image device to device (xGMI)
+    loaders.emplace_back([&]() {
+        ctx_rc[0] = bk_ctx_create(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P);
+        if (ctx_rc[0] || ndev == 1) return;
+        std::vector<std::thread> cloners;
+        for (size_t d = 1; d < ndev; d++) cloners.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_clone(&ctxs[d], ctxs[0], o.devices[d]); });
+        for (auto &t : cloners) t.join();
+    });
     auto destroy_ctxs = [&]() { for (bk_ctx *c : ctxs) bk_ctx_destroy(c); };
     ReadStore rs;
     int rc;

@@ -105,7 +105,10 @@ struct OutBuf {
     void open(const char *path)
     {
         size_t n = strlen(path);
-        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        // read-write: the SAM writer maps ranges of the file (a shared mapping needs a readable descriptor); write-only for what cannot
+        // be opened that way (a FIFO, /dev/stdout) - those are written with pwrite() / write()
+        fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz")) gz = gzdopen(fd, "wb");
         b.reserve(8 << 20);
         pos = 0;

@@ -534,7 +534,10 @@ int report_text(Report &R)
         const bool timing = getenv("BK_TIMING") != nullptr;
         auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
         double t_fmt = 0, t_grow = 0, t_put = 0;
-        // The file's pages are allocated ahead of the writers by one background thread (posix_fallocate, 256 MB at a time, from an
+        unsigned rounds_mapped = 0, rounds_pwrite = 0;
+        // The file's pages are allocated ahead of the writers by one background thread (Linux fallocate - which fails with EOPNOTSUPP
+        // where the file system cannot do it natively, instead of emulating it with reads and writes that would race the writers as
+        // glibc's posix_fallocate does; any failure just means "no preallocation" - 256 MB at a time, from an
         // upper estimate of the text's size): a store into a page that already exists costs a minor fault, one into a hole of a tmpfs
         // or ext4 file an allocation under the file's locks - with every writer thread doing that at once the copy-out ran at 3.7 GB/s.
         // The file is cut to its real size at the end.
@@ -550,7 +553,7 @@ int report_text(Report &R)
                 const off_t step = 256LL << 20;
                 for (off_t at = 0; at < (off_t)est; at += step) {
                     const off_t len = std::min<off_t>(step, (off_t)est - at);
-                    if (posix_fallocate(pfd, at, len) != 0) return;                      // e.g. a pipe: the writers grow the file themselves
+                    if (fallocate(pfd, 0, at, len) != 0) return;                         // e.g. a pipe, NFS: the writers grow the file themselves
                     prealloc_size.store(at + len);
                 }
             });
@@ -603,15 +606,16 @@ int report_text(Report &R)
             const off_t map_lo = at[0] & ~(off_t)4095;
             const size_t map_len = (size_t)(at[(size_t)nt] - map_lo);
             char *map = nullptr;
-            // the range must exist before it is mapped: already preallocated, or allocated here (posix_fallocate only ever grows a
-            // file, so it cannot collide with the background thread the way an ftruncate could)
+            // the range must exist before it is mapped: already preallocated, or allocated here (fallocate only ever grows a file, so
+            // it cannot collide with the background thread the way an ftruncate could)
             const bool have_range = at[(size_t)nt] > at[0] &&
-                                    (prealloc.joinable() ? (prealloc_size.load() >= at[(size_t)nt] || posix_fallocate(out.fd, at[0], at[(size_t)nt] - at[0]) == 0)
+                                    (prealloc.joinable() ? (prealloc_size.load() >= at[(size_t)nt] || fallocate(out.fd, 0, at[0], at[(size_t)nt] - at[0]) == 0)
                                                          : ftruncate(out.fd, at[(size_t)nt]) == 0);
             if (have_range) {
                 void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, out.fd, map_lo);
                 if (m != MAP_FAILED) map = (char *)m;
             }
+            if (map) rounds_mapped++; else rounds_pwrite++;
             const double tC = now();
             t_grow += tC - tB;
             auto put = [&](int t) {
@@ -637,7 +641,7 @@ int report_text(Report &R)
             out.flush();
             if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
         }
-        if (timing) fprintf(stderr, "bk timing: SAM format %.0f ms, grow + map %.0f ms, copy out %.0f ms (%d threads)\n", 1e3 * t_fmt, 1e3 * t_grow, 1e3 * t_put, nt);
+        if (timing) fprintf(stderr, "bk timing: SAM format %.0f ms, grow + map %.0f ms, copy out %.0f ms (%d threads; %u rounds through a shared mapping, %u through pwrite)\n", 1e3 * t_fmt, 1e3 * t_grow, 1e3 * t_put, nt, rounds_mapped, rounds_pwrite);
         report_jct_for_sam(R);
         diag("Completed reporting SAM %llu read alignments", (unsigned long long)n_reported);
     } else {

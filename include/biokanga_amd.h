@@ -138,19 +138,25 @@ int  bk_ctx_create_from_device(bk_ctx **out, const void *d_seq, uint64_t concat_
                                int sfx_el_size, const bk_entry_info *entries, uint32_t n_entries,
                                int device_id, const bk_align_params *p);
 
+/* A second context on another (or the same) device from the finished index image of `src`: every table is copied device to device
+ * (hipMemcpyPeer: over xGMI between two GPUs) instead of reading the .sfx again and rebuilding the tables there - how one process
+ * replicates the index over the GPUs of a node.  Parameters are those of `src`; tuning knobs set on `src` after its
+ * creation that change the image (kmer_bits, use_k2, use_isa, use_tgt2) are inherited with it. */
+int  bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id);
+
 void bk_ctx_destroy(bk_ctx *ctx);
 
 /* change alignment parameters (re-derives MinCoreLen, MaxIter, slides) */
 int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
-/* tuning / cross-check knobs (results never depend on them; the test-suite runs every kernel family against the
- * others through these): name =
- *   "kmer_bits" (k of the k-mer table, 2..16)  "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)  "use_k2s" / "k2s_levels" (sample levels over it, 1..6)  "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)
- *   "lazy_search" (small buckets handed on unverified)   "sort_lists" (bit 0: group the search work list by bucket, bit 1: sort the wave list, bit 2: .. longest read first)
- *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)   "flat_block" (reads per block of k_flat: 64..1024)
- *   "use_hp" (prefix hash in front of table + keys)   "use_eval" (0: k_flat alone instead of k_eval + k_replay)   "use_direct" (search pass A evaluates
- *   the reads it settles in place, 0: every read goes through interval records and the extend kernel)   "use_wave" (wave kernel + inverse suffix array,
- *   0: hash-set kernel)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat
- *   kernels take, 0..100)   "chunk_reads" (reads per pass over the phases)   "max_read_len"
+/* cross-check knobs: results never depend on them; the test-suite runs independent implementations of the same step against
+ * each other through these.  name =
+ *   "kmer_bits" (k of the k-mer table, 2..16)   "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)
+ *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
+ *   "sort_lists" (bit 0: search work list grouped by bucket, bit 1: wave list sorted, bit 2: .. longest read first)
+ *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)
+ *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
+ *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
+ *   "chunk_reads" (reads per pass over the phases)   "max_read_len"
  * returns the old value or <0 */
 int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
 

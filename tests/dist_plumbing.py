@@ -1,5 +1,5 @@
 """Multi-GPU plumbing of the hot path (one process per GPU, torch.distributed; backend "nccl" is
-RCCL over xGMI on ROCm, "gloo" in CPU tests).
+RCCL over xGMI on ROCm, "gloo" in CPU tests).  Test plumbing: bench.py shards on the device itself.
 
 The path shards trivially: reads are independent given a replicated index.  Read i goes to rank
 i mod world; the only exchange is the sum-reduction of the per-sequence accepted-read

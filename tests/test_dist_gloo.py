@@ -16,7 +16,7 @@ def _worker(rank, world, port, sfx_path, reads_path, out_dir):
     sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
     sys.path.insert(0, helpers.ROOT)
     import torch.distributed as dist
-    from biokanga_amd import dist as bkdist
+    import dist_plumbing as bkdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

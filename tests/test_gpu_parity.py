@@ -57,11 +57,14 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
-@pytest.mark.parametrize("knob", [("flat_block", 64), ("flat_block", 512), (("flat_block", 1024), ("heavy_thresh", 100)), ("search_ilp", 1), ("search_ilp", 4), (("search_ilp", 1), ("lazy_search", 0)), (("search_ilp", 4), ("kmer_bits", 9)), ("use_hp", 1), (("use_hp", 1), ("lazy_search", 0)), (("use_hp", 1), ("heavy_thresh", 7)), (("use_hp", 1), ("kmer_bits", 9)), ("use_eval", 1), (("use_eval", 1), ("heavy_thresh", 7)), (("use_eval", 1), ("lazy_search", 0)), (("use_direct", 1), ("use_eval", 1)), ("use_direct", 1), (("use_direct", 1), ("heavy_thresh", 7)), (("use_direct", 1), ("lazy_search", 0)), (("use_direct", 1), ("heavy_thresh", 3)), (("use_direct", 1), ("kmer_bits", 9)), ("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
-                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)), ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("sort_lists", 1), ("sort_lists", 6), ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)),
+@pytest.mark.parametrize("knob", [("flat_block", 64), ("flat_block", 512), (("flat_block", 1024), ("heavy_thresh", 100)), ("search_ilp", 1), ("search_ilp", 4),
+                                  (("search_ilp", 1), ("lazy_search", 0)), (("search_ilp", 4), ("kmer_bits", 9)),
+                                  ("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
+                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)),
+                                  ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("sort_lists", 1), ("sort_lists", 6),
+                                  ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
-                                  (("use_k2", 0), ("lazy_search", 0)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0)), ("use_k2s", 1), (("use_k2s", 1), ("kmer_bits", 4)), (("use_k2s", 1), ("k2s_levels", 1), ("kmer_bits", 4)), (("use_k2s", 1), ("k2s_levels", 2), ("kmer_bits", 6)),
-                                  (("use_k2s", 1), ("k2s_levels", 1), ("kmer_bits", 2), ("lazy_search", 0))])
+                                  (("use_k2", 0), ("lazy_search", 0)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""

@@ -91,6 +91,15 @@ def test_suffix_sort_of_more_than_2_32_bases():
             seq[p0 + (1 << 32):p0 + (1 << 32) + 100] = w1
             planted.append(p0)
     assert len(planted) > 100
+    # and 600-mers, for reads beyond the register kernels' 256 bases (the general search / extend / hash-set kernels)
+    planted_long = []
+    for i in range(200):
+        p0 = 1_125_000 + i * 250_003
+        w1, w2 = seq[p0:p0 + 600], seq[p0 + (1 << 32):p0 + (1 << 32) + 600]
+        if int(w1.max()) < 4 and int(w2.max()) < 4:
+            seq[p0 + (1 << 32):p0 + (1 << 32) + 600] = w1
+            planted_long.append(p0)
+    assert len(planted_long) > 50
     d_sa = torch.zeros(n * 5, dtype=torch.uint8, device=dev)
     bk.build_sa_device(seq.data_ptr(), n, d_sa.data_ptr(), 5, 0)
     v = d_sa.view(n, 5)
@@ -158,6 +167,43 @@ def test_suffix_sort_of_more_than_2_32_bases():
     # the planted reads: two true instances, one seen - accepted as unique
     tail = got[-len(extra):]
     assert int((tail["nar"] == 1).sum()) > len(extra) * 3 // 4
+    # the lane-per-read family (use_flat = 0: k_light hands what has candidates to the hash-set wave kernel) on the planted reads
+    pl_bases = np.concatenate(extra)
+    pl_offs = np.arange(len(extra), dtype=np.uint64) * 100
+    pl_lens = np.full(len(extra), 100, dtype=np.uint32)
+    # reads of 300 and 600 bases from the planted 600-mers (0..3 substitutions, either strand): beyond the register kernels
+    long_reads = []
+    for p0 in planted_long:
+        for ln, o in ((300, 150), (600, 0)):
+            w = seq[p0 + o:p0 + o + ln].cpu().numpy().copy()
+            for q in rng.choice(ln, size=int(rng.integers(0, 4)), replace=False):
+                w[q] = (w[q] + 1 + rng.integers(0, 3)) & 3
+            long_reads.append(w if rng.integers(0, 2) else (3 - w[::-1]).astype(np.uint8))
+    lg_lens = np.array([len(w) for w in long_reads], dtype=np.uint32)
+    lg_offs = np.concatenate([[0], np.cumsum(lg_lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    lg_bases = np.concatenate(long_reads)
+    ora = helpers.OracleSfx(seq=seq.cpu().numpy(), sa=d_sa.cpu().numpy(), el_size=5, entries=entries)
+    p3 = helpers.make_params(max_subs=3)
+    lexp, lctr = ora.align(lg_bases, lg_offs, lg_lens, p3, nthreads=16)
+    ora.close()
+    fields = ("chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm", "nxt_low_mm", "num_hits", "mismatches")
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(), el_size=5, entries=ent) as al:
+        al.tune("use_flat", 0)
+        got2 = al.align(pl_bases, pl_offs, pl_lens)
+        for f in fields:
+            assert np.array_equal(got2[f], tail[f]), ("use_flat=0", f)
+        al.tune("use_flat", 1)
+        for knobs in ((), (("use_wave", 0),)):
+            for kv in knobs:
+                al.tune(*kv)
+            al.counters(reset=True)
+            lgot = al.align(lg_bases, lg_offs, lg_lens)
+            c2 = al.counters()
+            for f in fields:
+                bad = np.nonzero(lgot[f] != lexp[f])[0]
+                assert len(bad) == 0, (knobs, f, len(bad), [(int(i), lgot[int(i)], lexp[int(i)]) for i in bad[:4]])
+            assert (c2["n_search"], c2["n_cand"]) == (lctr.n_search, lctr.n_cand)
+        assert int((lgot["nar"] == 1).sum()) > len(long_reads) * 3 // 4           # two true instances, one seen
     # paired ends on the 5-byte index (config 5's shape: 2 x 150 bp, -s5 -U3 -d200 -D400), a sample against the oracle
     pb, po, pl = synth.make_pairs(seq, seq_lens, 20_000, 150, dev, seed=6)
     pbases, poffs, plens = pb.cpu().numpy(), po.cpu().numpy().astype(np.uint64), pl.cpu().numpy().astype(np.uint32)

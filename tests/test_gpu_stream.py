@@ -70,6 +70,12 @@ def test_stream_rejects_reads_outside_the_batch(golden_tmp):
             with pytest.raises(bk.BkError) as e:
                 st.wait(t)
             assert e.value.rc == -100
+            # an offset near 2^64 whose end wraps to a small number is refused as well (checked per read, not by a sum)
+            howrap = np.array([0, 100, 0xFFFFFFFFFFFFFFF0, 300], dtype=np.uint64)
+            t = st.submit(hb, howrap, hl, out)
+            with pytest.raises(bk.BkError) as e:
+                st.wait(t)
+            assert e.value.rc == -100
             # the stream stays usable
             ho2 = np.array([0, 100, 900, 300], dtype=np.uint64)
             t = st.submit(hb, ho2, hl, out)
@@ -154,3 +160,46 @@ def test_seq_counts_allreduce_over_contexts(golden_tmp):
         assert np.array_equal(got, exp)
         assert got.sum() == int((hits["nar"] == 1).sum())
         assert a0.seq_counts().sum() == 0 and a1.seq_counts().sum() == 0          # reset
+
+
+def test_cloned_context_and_distinct_devices(golden_tmp):
+    """bk_ctx_clone copies the finished index image device to device; a clone aligns like its source.  With two GPUs visible the
+    clone lives on the second one and the exchange step takes the RCCL branch (ncclAllReduce between distinct devices)."""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    offs, lens = offs[keep], lens[keep]
+    sfx = os.path.join(d, "genome.sfx")
+    second = 1 if bk.device_count() >= 2 else 0
+    with bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as a0:
+        ref = a0.align(bases, offs, lens)
+        exp = a0.seq_counts(reset=True)
+        with bk.Aligner(clone_of=a0, device=second) as a1:
+            got = a1.align(bases, offs, lens)
+            assert_hits_equal(got, ref)
+            assert np.array_equal(a1.seq_counts(reset=True), exp)
+            a0.align(bases, offs[0::2], lens[0::2])
+            a1.align(bases, offs[1::2], lens[1::2])
+            assert np.array_equal(bk.seq_counts_allreduce([a0, a1], reset=True), exp)
+            # communicators are kept: a second reduction over the same devices
+            a0.align(bases, offs[1::2], lens[1::2])
+            a1.align(bases, offs[0::2], lens[0::2])
+            assert np.array_equal(bk.seq_counts_allreduce([a1, a0], reset=True), exp)
+
+
+@pytest.mark.skipif("__import__('biokanga_amd').device_count() < 2", reason="needs two GPUs: the RCCL branch between distinct devices")
+def test_seq_counts_allreduce_over_distinct_devices(golden_tmp):
+    """three contexts on two devices: the two sharing a GPU are added up there, RCCL sums across the GPUs"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    offs, lens = offs[keep], lens[keep]
+    sfx = os.path.join(d, "genome.sfx")
+    with bk.Aligner(sfx, bk.AlignParams(max_subs=3), device=0) as a0, bk.Aligner(sfx, bk.AlignParams(max_subs=3), device=1) as a1, \
+            bk.Aligner(clone_of=a1, device=1) as a2, bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as whole:
+        hits = whole.align(bases, offs, lens)
+        exp = whole.seq_counts()
+        a0.align(bases, offs[0::3], lens[0::3])
+        a1.align(bases, offs[1::3], lens[1::3])
+        a2.align(bases, offs[2::3], lens[2::3])
+        got = bk.seq_counts_allreduce([a0, a1, a2], reset=True)
+        assert np.array_equal(got, exp)
+        assert got.sum() == int((hits["nar"] == 1).sum())

@@ -1,6 +1,5 @@
 """Device helpers that are pure bit / index arithmetic, compiled for the host and checked against brute force (CPU only):
-k2s_bounds (lower / upper bound of a masked key through the sample levels over the second-level keys, knob use_k2s) against a
-linear scan; the layout helpers of k_wave's mismatch map (bits_to_imap, imask_word, im_clean) against per-base loops.
+the layout helpers of k_wave's mismatch map (bits_to_imap, imask_word, im_clean) against per-base loops.
 The function texts are taken from biokanga_amd/csrc/bk_kernels.hip as they stand (no copy kept here)."""
 import os
 import re
@@ -26,53 +25,9 @@ MAIN = r'''
 #include <cstdint>
 #include <cstdio>
 #include <vector>
-#include <algorithm>
 #include <random>
 static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) if (v >> i & 1) r |= 1u << (31 - i); return r; }
-constexpr int kK2Levels = 6;
-struct DevIndex { const uint64_t *k2; const uint64_t *k2s; uint64_t k2s_off[6]; int k2s_levels; };
 %s
-static int test_k2s()
-{
-    std::mt19937_64 rng(1);
-    for (int trial = 0; trial < 120; trial++) {
-        const uint64_t n = 1 + rng() %% (trial < 80 ? 5000 : 1500000);
-        const int nlev = 1 + rng() %% 6;
-        std::vector<uint64_t> k2(n);
-        std::vector<std::pair<uint64_t, uint64_t>> buckets;
-        for (uint64_t at = 0; at < n;) {
-            uint64_t sz = 1 + rng() %% (1 + (rng() %% 3 == 0 ? n : 300));
-            if (at + sz > n) sz = n - at;
-            const int bits = 1 + rng() %% 20;
-            for (uint64_t i = 0; i < sz; i++) k2[at + i] = (rng() & ((1ULL << bits) - 1)) << 40;
-            std::sort(k2.begin() + at, k2.begin() + at + sz);
-            if (rng() %% 4 == 0) k2[at + sz - 1] = ~0ULL;
-            buckets.push_back({at, at + sz});
-            at += sz;
-        }
-        DevIndex ix; ix.k2 = k2.data(); ix.k2s_levels = nlev;
-        std::vector<uint64_t> nl(7); nl[0] = n; uint64_t tot = 0;
-        for (int L = 1; L <= 6; L++) { nl[L] = L <= nlev ? (nl[L - 1] + 7) / 8 : 0; ix.k2s_off[L - 1] = tot; tot += nl[L]; }
-        std::vector<uint64_t> lev(tot);
-        for (int L = 1; L <= nlev; L++) {
-            const uint64_t *src = L == 1 ? k2.data() : lev.data() + ix.k2s_off[L - 2];
-            for (uint64_t i = 0; i < nl[L]; i++) { uint64_t j = 8 * i + 7; lev[ix.k2s_off[L - 1] + i] = src[j < nl[L - 1] ? j : nl[L - 1] - 1]; }
-        }
-        ix.k2s = lev.data();
-        for (auto &b : buckets)
-            for (int q = 0; q < 6; q++) {
-                const uint64_t m = ~0ULL << (rng() %% 50);
-                const uint64_t q2 = (q & 1) ? (k2[b.first + rng() %% (b.second - b.first)] & m) : (((rng() & ((1ULL << 20) - 1)) << 40) & m);
-                if (q2 == (~0ULL & m)) continue;
-                uint64_t l1, l2, e1 = b.first, e2;
-                k2s_bounds(ix, b.first, b.second, m, q2, l1, l2);
-                while (e1 < b.second && k2_cmp(k2[e1], m, q2) < 0) e1++;
-                for (e2 = e1; e2 < b.second && k2_cmp(k2[e2], m, q2) <= 0;) e2++;
-                if (l1 != e1 || l2 != e2) { printf("k2s_bounds: trial %%d bucket [%%llu,%%llu) got %%llu %%llu want %%llu %%llu\n", trial, (unsigned long long)b.first, (unsigned long long)b.second, (unsigned long long)l1, (unsigned long long)l2, (unsigned long long)e1, (unsigned long long)e2); return 1; }
-            }
-    }
-    return 0;
-}
 template <int NW> static int test_imap()
 {
     std::mt19937_64 rng(7);
@@ -91,16 +46,15 @@ template <int NW> static int test_imap()
     }
     return 0;
 }
-int main() { if (test_k2s() || test_imap<8>() || test_imap<16>()) return 1; printf("ok\n"); return 0; }
+int main() { if (test_imap<8>() || test_imap<16>()) return 1; printf("ok\n"); return 0; }
 '''
 
 
 def test_device_bit_helpers_against_brute_force(tmp_path):
     text = open(SRC).read()
-    parts = [_between(text, "__device__ __forceinline__ int k2_cmp(", "// level L of the samples from level L - 1"),
-             _between(text, "__device__ __forceinline__ uint64_t spread32(", "template <int NW>\n__device__ __forceinline__ void window_to_iwindow(")]
+    parts = [_between(text, "__device__ __forceinline__ uint64_t spread32(", "template <int NW>\n__device__ __forceinline__ void window_to_iwindow(")]
     code = MAIN % _hostify("\n".join(parts))
-    assert "k2s_bounds" in code and "imask_word" in code and "im_clean" in code
+    assert "imask_word" in code and "im_clean" in code
     src = str(tmp_path / "devlogic.cpp")
     exe = str(tmp_path / "devlogic")
     open(src, "w").write(code)

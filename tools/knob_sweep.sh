@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-only rate of the default workload under single tuning knobs (run through gpurun from the repo root):
-#   tools/knob_sweep.sh "search_ilp=4" "use_hp=1" ...
+#   tools/knob_sweep.sh "search_ilp=4" "use_iv32=0" ...
 for kv in "" "$@"; do
   args=""
   [ -n "$kv" ] && args="--tune $kv"
