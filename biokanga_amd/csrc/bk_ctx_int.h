@@ -36,6 +36,7 @@ struct bk_ctx {
     uint64_t *d_tgt2s = nullptr;          // the same, stored 32 bytes later (DevIndex::tgt2s)
     uint8_t *d_nflag = nullptr;
     uint64_t *d_rd2 = nullptr;            // 2-bit read rows
+    uint32_t *d_rmeta = nullptr;          // DevBatch::rmeta
     uint64_t n_tgt4_words = 0;
     uint32_t cap_rd2w = 0;
     int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)

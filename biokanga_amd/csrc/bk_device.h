@@ -48,6 +48,8 @@ constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)
 constexpr uint32_t kNodeCap = 1024000; // cMaxNumIdentNodes, SfxArrayV2.h:15
 constexpr uint64_t kEosWord = 0x7777777777777777ULL;
+constexpr uint32_t kReadHasN = 1u << 15;   // DevBatch::rmeta
+constexpr uint32_t kReadLenMask = kReadHasN - 1;
 
 struct DevIndex {
     const uint64_t *tgt4;
@@ -81,8 +83,12 @@ struct DevBatch {
     const uint8_t *bases;       // 1 B/base as CAligner holds them
     const uint64_t *offs;
     const uint32_t *lens;
-    uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp)
-    uint64_t *rd2;              // [read][strand][3*NW/4]: NW/2 words at 2 bit/base + NW/4 words of N mask; may be null
+    uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp).  With rd2 set ("lean" batches) only the rows of
+                                //   reads that hold an N are written by the read preparation; k_expand_rd4 fills in the rows of the few
+                                //   reads a kernel of the general family is about to see
+    uint64_t *rd2;              // [read][strand][nw/2]: the read and its reverse complement at 2 bit/base, 32 bases per word, first base
+                                //   in the top bits, N held as A, zero beyond the read's end; may be null (then rd4 holds every read)
+    uint32_t *rmeta;            // per read, written by the read preparation: length | has-N flag << 15 (kReadHasN)
     uint64_t *iv_first;         // core intervals [strand][core][read]: start (suffix array index) ...
     uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
     uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null

@@ -421,7 +421,8 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
 {
     if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
-    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2);
+    free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2); free_dev(c->d_rmeta);
+    c->d_rmeta = nullptr;
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work);
     c->d_iv32 = nullptr;
     c->d_wave_work = nullptr;
@@ -430,7 +431,8 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     for (int i = 0; i < 3; i++) { free_dev(c->d_stage[i]); c->d_stage[i] = nullptr; }
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
-    if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8));
+    if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8 + 64));        // (+ the words a 32-base fetch at a row's end runs into)
+    HIP_TRY(hipMalloc(&c->d_rmeta, (size_t)nr * 4));
     if (c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32))
         HIP_TRY(hipMalloc(&c->d_iv2, (size_t)nr * 2 * kMaxCoresFast * 8));
     else {
@@ -638,13 +640,14 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     const bool reg_path = c->use_wave && maxlen <= 256;
     const int nw16 = maxlen <= 128 ? 8 : 16;
     const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
-    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(3 * nw16 / 4) : 0u);
+    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u);
     if (rc) return rc;
 
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
+    b.rmeta = c->d_rmeta;
     // (the wave list's job sizes come from k_flat only when every read on that list went through it)
     b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) ? c->d_wave_work : nullptr;
     b.iv32 = (c->use_iv32 && c->ix.k2 && c->search_ilp >= 2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
@@ -1082,7 +1085,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);

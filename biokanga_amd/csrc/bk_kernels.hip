@@ -43,6 +43,51 @@ __device__ __forceinline__ uint64_t top_mask(int nibs)   // mask keeping the fir
     return nibs >= 16 ? ~0ULL : (~0ULL << (64 - 4 * nibs));
 }
 
+// 16 bases at 2 bit/base (first base in the top bits) -> 16 nibbles
+__device__ __forceinline__ uint64_t spread2to4(uint32_t v)
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    return x;
+}
+
+// 32 bases from base position pos of a 2 bit/base row (both words are always loaded: rows are followed by at least one more word)
+__device__ __forceinline__ uint64_t bits64_2(const uint64_t *__restrict__ w, int pos)
+{
+    const int i = pos >> 5;
+    const unsigned s = (unsigned)(pos & 31) << 1;
+    const uint64_t a = w[i], b = w[i + 1];
+    return (a << s) | ((b >> 1) >> (63 - s));
+}
+
+// One strand's row of a read, whichever form the batch holds it in: 4 bit/base words (rd4), or - lean batches, reads without an N -
+// 2 bit/base words (rd2) widened on the fly.  Bases beyond the read's end are whatever follows the row; every user masks by length.
+struct RdRow {
+    const uint64_t *p;
+    bool four;
+    __device__ __forceinline__ uint64_t nib16(int pos) const          // 16 nibbles from base position pos
+    {
+        return four ? bk::nib16(p, (uint64_t)pos) : spread2to4((uint32_t)(bits64_2(p, pos) >> 32));
+    }
+    __device__ __forceinline__ uint64_t word16(int k) const           // nibbles of bases 16k .. 16k + 15
+    {
+        if (four) return p[k];
+        const uint64_t v = p[k >> 1];
+        return spread2to4((k & 1) ? (uint32_t)v : (uint32_t)(v >> 32));
+    }
+};
+
+__device__ __forceinline__ RdRow read_row(const DevBatch &b, uint32_t r, int strand, bool has_n)
+{
+    RdRow q;
+    q.four = b.rd2 == nullptr || has_n;
+    q.p = q.four ? b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr : b.rd2 + ((uint64_t)r * 2 + strand) * (b.nw / 2);
+    return q;
+}
+
 // core interval slot of (read, strand, core): [strand][core][read], so that lanes working on
 // neighbouring reads touch neighbouring words
 __device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t r, int st, int c)
@@ -153,14 +198,18 @@ __device__ __forceinline__ uint64_t sa_get(const DevIndex &ix, uint64_t i)
 
 // probe core (cl bases at read offset ofs; p0 = its first 16 nibbles, masked) vs the suffix at pos.
 // <0 / 0 / >0 exactly as the reference's compare loops (EOS in target makes the probe lower).
-__device__ __forceinline__ int cmp_core(const uint64_t *__restrict__ rdw, int ofs, int cl, uint64_t p0,
+__device__ __forceinline__ uint64_t row_nib16(const uint64_t *__restrict__ rdw, int pos) { return nib16(rdw, (uint64_t)pos); }
+__device__ __forceinline__ uint64_t row_nib16(const RdRow &rdw, int pos) { return rdw.nib16(pos); }
+
+template <typename Row>
+__device__ __forceinline__ int cmp_core(const Row &rdw, int ofs, int cl, uint64_t p0,
                                         const uint64_t *__restrict__ tgt, uint64_t pos)
 {
     uint64_t t0 = nib16(tgt, pos) & top_mask(cl);
     if (p0 != t0) return p0 < t0 ? -1 : 1;
     for (int i = 16; i < cl; i += 16) {
         uint64_t m = top_mask(cl - i);
-        uint64_t p = nib16(rdw, ofs + i) & m;
+        uint64_t p = row_nib16(rdw, ofs + i) & m;
         uint64_t t = nib16(tgt, pos + i) & m;
         if (p != t) return p < t ? -1 : 1;
     }
@@ -280,11 +329,11 @@ __device__ __forceinline__ void core_range(const DevIndex &ix, uint64_t p0, int 
 }
 
 // lower bound (LocateFirstExact) + length of the matching run, capped at `cap`
-template <bool WIDE>
-__device__ __forceinline__ void search_core(const DevIndex &ix, const uint64_t *__restrict__ rdw, int ofs, int cl,
+template <bool WIDE, typename Row>
+__device__ __forceinline__ void search_core(const DevIndex &ix, const Row &rdw, int ofs, int cl,
                                             uint64_t cap, uint64_t &first, uint64_t &count)
 {
-    uint64_t p0 = nib16(rdw, ofs) & top_mask(cl);
+    uint64_t p0 = row_nib16(rdw, ofs) & top_mask(cl);
     uint64_t lo, hi;
     core_range(ix, p0, cl, lo, hi);
     uint64_t end = hi;
@@ -514,13 +563,6 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
         }
     }
     b.rd4[r * per_read + rem] = v;
-    if (b.rd2 != nullptr && w < b.nw) {
-        // the same 16 bases for the 2-bit window compare: half a word at 2 bit/base (N held as A) and 16 bits of
-        // "read base is N" in the mismatch-map format (see eval_window2); each thread stores its own piece
-        uint64_t *row = b.rd2 + (r * 2 + st) * (uint64_t)(3 * b.nw / 4);
-        reinterpret_cast<uint32_t *>(row)[2 * (w >> 1) + ((w & 1) ? 0 : 1)] = squeeze2(v);
-        reinterpret_cast<uint16_t *>(row + b.nw / 2)[w] = (uint16_t)flags_to_bits16((v >> 2) & 0x1111111111111111ULL);
-    }
 }
 
 // k_pack_reads + k_init_reads in one pass for reads of <= 16*NW bases (the register-kernel path): one lane per
@@ -534,7 +576,7 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
     if (threadIdx.x == 0) { s_cnt = 0; s_cmax = 0; }
     __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool go = false;
+    bool go = false, has_n = false;
     uint32_t my_cmax = 0;
     int len = 0;
     uint64_t fw[NW], rv[NW];
@@ -584,6 +626,7 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
             }
         }
         if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
+        has_n = bad || num_ns > 0;
         if (h.nar != BK_NAR_NS) {
             ReadPlan p = make_plan(len, cfg);
             if (p.n_phases > 0) {
@@ -612,41 +655,34 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
     __syncthreads();
     if (go) stripe_put(out, 0, s_base + my_off, r);
     if (r < b.n_reads) {
-        // rows: [read][strand][wpr] nibble words (zero padded), 16-byte aligned
-        const uint32_t wpr = b.wpr;
-        uint4 *row0 = reinterpret_cast<uint4 *>(b.rd4 + (uint64_t)r * 2 * wpr);
-        uint4 *row1 = reinterpret_cast<uint4 *>(b.rd4 + ((uint64_t)r * 2 + 1) * wpr);
+        const bool lean = b.rd2 != nullptr;
+        b.rmeta[r] = (uint32_t)len | (has_n ? kReadHasN : 0u);
+        if (!lean || has_n) {
+            // rows: [read][strand][wpr] nibble words (zero padded), 16-byte aligned.  Lean batches: only for the reads with an N
+            const uint32_t wpr = b.wpr;
+            uint4 *row0 = reinterpret_cast<uint4 *>(b.rd4 + (uint64_t)r * 2 * wpr);
+            uint4 *row1 = reinterpret_cast<uint4 *>(b.rd4 + ((uint64_t)r * 2 + 1) * wpr);
 #pragma unroll
-        for (int q = 0; q < NW / 2; q++) {
-            if (2 * q < (int)wpr) {
-                row0[q] = make_uint4((uint32_t)fw[2 * q], (uint32_t)(fw[2 * q] >> 32), (uint32_t)fw[2 * q + 1], (uint32_t)(fw[2 * q + 1] >> 32));
-                row1[q] = make_uint4((uint32_t)rv[2 * q], (uint32_t)(rv[2 * q] >> 32), (uint32_t)rv[2 * q + 1], (uint32_t)(rv[2 * q + 1] >> 32));
+            for (int q = 0; q < NW / 2; q++) {
+                if (2 * q < (int)wpr) {
+                    row0[q] = make_uint4((uint32_t)fw[2 * q], (uint32_t)(fw[2 * q] >> 32), (uint32_t)fw[2 * q + 1], (uint32_t)(fw[2 * q + 1] >> 32));
+                    row1[q] = make_uint4((uint32_t)rv[2 * q], (uint32_t)(rv[2 * q] >> 32), (uint32_t)rv[2 * q + 1], (uint32_t)(rv[2 * q + 1] >> 32));
+                }
             }
+            for (uint32_t q = NW / 2; 2 * q < wpr; q++) { row0[q] = make_uint4(0, 0, 0, 0); row1[q] = make_uint4(0, 0, 0, 0); }
         }
-        for (uint32_t q = NW / 2; 2 * q < wpr; q++) { row0[q] = make_uint4(0, 0, 0, 0); row1[q] = make_uint4(0, 0, 0, 0); }
-        if (b.rd2 != nullptr) {
-            // 2-bit rows: NW/2 words + NW/4 words of read-N mask (see eval_window2)
-            uint64_t o0[3 * NW / 4], o1[3 * NW / 4];
+        if (lean) {
+            // 2-bit rows of both strands, NW/2 words each
+            uint64_t o0[NW / 2], o1[NW / 2];
 #pragma unroll
             for (int k = 0; k < NW / 2; k++) {
                 o0[k] = ((uint64_t)squeeze2(fw[2 * k]) << 32) | squeeze2(fw[2 * k + 1]);
                 o1[k] = ((uint64_t)squeeze2(rv[2 * k]) << 32) | squeeze2(rv[2 * k + 1]);
             }
+            uint4 *t0 = reinterpret_cast<uint4 *>(b.rd2 + (uint64_t)r * 2 * (NW / 2));
+            uint4 *t1 = reinterpret_cast<uint4 *>(b.rd2 + ((uint64_t)r * 2 + 1) * (NW / 2));
 #pragma unroll
             for (int q = 0; q < NW / 4; q++) {
-                uint64_t m0 = 0, m1 = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    m0 |= (uint64_t)flags_to_bits16((fw[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
-                    m1 |= (uint64_t)flags_to_bits16((rv[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
-                }
-                o0[NW / 2 + q] = m0;
-                o1[NW / 2 + q] = m1;
-            }
-            uint4 *t0 = reinterpret_cast<uint4 *>(b.rd2 + (uint64_t)r * 2 * (3 * NW / 4));
-            uint4 *t1 = reinterpret_cast<uint4 *>(b.rd2 + ((uint64_t)r * 2 + 1) * (3 * NW / 4));
-#pragma unroll
-            for (int q = 0; q < 3 * NW / 8; q++) {
                 t0[q] = make_uint4((uint32_t)o0[2 * q], (uint32_t)(o0[2 * q] >> 32), (uint32_t)o0[2 * q + 1], (uint32_t)(o0[2 * q + 1] >> 32));
                 t1[q] = make_uint4((uint32_t)o1[2 * q], (uint32_t)(o1[2 * q] >> 32), (uint32_t)o1[2 * q + 1], (uint32_t)(o1[2 * q + 1] >> 32));
             }
@@ -686,6 +722,7 @@ __global__ void __launch_bounds__(1024) k_init_reads(DevAlignCfg cfg, DevBatch b
         }
         if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
         b.out[r] = h;
+        b.rmeta[r] = (uint32_t)len | ((bad || num_ns > 0) ? kReadHasN : 0u);
         if (h.nar != BK_NAR_NS) {
             ReadPlan p = make_plan(len, cfg);
             if (p.n_phases > 0) {
@@ -736,7 +773,8 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     uint32_t rem = (uint32_t)(tid - a * per_read);
     int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
     uint32_t r = act[a];
-    int len = (int)b.lens[r];
+    const uint32_t meta = b.rmeta[r];
+    int len = (int)(meta & kReadLenMask);
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd;
     phase_params(p, cfg, phase, mm, cl, cd);
@@ -750,11 +788,11 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     }
     if (my_ofs < 0 || n > kMaxCoresFast) return;
     int strand = cfg.align_strand == 2 ? 1 : si;
-    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+    const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
     uint64_t first, count;
     uint64_t slot = iv_slot(b, r, strand, c);
     if (lazy && ix.k > 0 && cl >= ix.k) {
-        uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
+        uint64_t p0 = rdw.nib16(my_ofs) & top_mask(cl);
         uint64_t lo, hi;
         core_range(ix, p0, cl, lo, hi);
         if (hi - lo <= kLazyBucket && !(lo == 0 && hi == ix.n)) {
@@ -800,12 +838,13 @@ __device__ __forceinline__ int k2_cmp(uint64_t key, uint64_t m, uint64_t q2)
 }
 
 // as cmp_core, but only bases [start, cl) of the core are compared
-__device__ __forceinline__ int cmp_core_from(const uint64_t *__restrict__ rdw, int ofs, int cl, int start,
+template <typename Row>
+__device__ __forceinline__ int cmp_core_from(const Row &rdw, int ofs, int cl, int start,
                                              const uint64_t *__restrict__ tgt, uint64_t pos)
 {
     for (int i = start; i < cl; i += 16) {
         uint64_t m = top_mask(cl - i);
-        uint64_t p = nib16(rdw, ofs + i) & m;
+        uint64_t p = row_nib16(rdw, ofs + i) & m;
         uint64_t t = nib16(tgt, pos + i) & m;
         if (p != t) return p < t ? -1 : 1;
     }
@@ -851,7 +890,8 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
         uint32_t rem = (uint32_t)(tid - a * per_read);
         int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
         uint32_t r = act[a];
-        int len = (int)b.lens[r];
+        const uint32_t meta = b.rmeta[r];
+        int len = (int)(meta & kReadLenMask);
         ReadPlan p = make_plan(len, cfg);
         int mm, cl, cd, dummy[1];
         phase_params(p, cfg, phase, mm, cl, cd);
@@ -859,10 +899,10 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
         if (c < nc && nc <= kMaxCoresFast) {
             int my_ofs = c * cd < len - cl ? c * cd : len - cl;
             int strand = cfg.align_strand == 2 ? 1 : si;
-            const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+            const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
             slot = iv_slot(b, r, strand, c);
             const int k = ix.k;
-            uint64_t p0 = nib16(rdw, my_ofs) & top_mask(cl);
+            uint64_t p0 = rdw.nib16(my_ofs) & top_mask(cl);
             uint64_t first = 0;
             uint32_t nval = kKindFull << kKindShift;
             push = true;
@@ -875,7 +915,7 @@ __global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, 
                 } else if (size <= kInlineBucket) {
                     const int rem2 = cl - k;
                     const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-                    const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
+                    const uint64_t q2 = rem2 <= 0 ? 0 : (rdw.nib16(my_ofs + k) & m);
                     uint64_t key[kInlineBucket];
 #pragma unroll
                     for (uint32_t j = 0; j < kInlineBucket; j++) key[j] = j < size ? ix.k2[lo + j] : ~0ULL;
@@ -980,7 +1020,8 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             const uint32_t rem = (uint32_t)(tid - a * per_read);
             const int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
             const uint32_t r = act[a];
-            const int len = (int)b.lens[r];
+            const uint32_t meta = b.rmeta[r];
+            const int len = (int)(meta & kReadLenMask);
             const int strand_c = cfg.align_strand == 2 ? 1 : si;
             if (b.iv32 != nullptr && c == 0 && phase > 0) cv[u] = b.iv32[(uint32_t)strand_c * b.n_reads + r];     // (requested with the length)
             ReadPlan p = make_plan(len, cfg);
@@ -995,10 +1036,18 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 }
                 const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
                 const int strand = cfg.align_strand == 2 ? 1 : si;
-                const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
                 slot[u] = iv_slot(b, r, strand, c);
-                p0[u] = nib16(rdw, my_ofs) & top_mask(cl[u]);
-                q2raw[u] = nib16(rdw, my_ofs + k);
+                if (b.rd2 != nullptr && !(meta & kReadHasN)) {
+                    // 32 bases from the core's start out of the 2-bit row: the k-mer code's bases and the 16 that follow them
+                    const uint64_t *row = b.rd2 + ((uint64_t)r * 2 + strand) * (b.nw / 2);
+                    const uint64_t x = bits64_2(row, my_ofs);
+                    p0[u] = spread2to4((uint32_t)(x >> 32)) & top_mask(cl[u]);
+                    q2raw[u] = k == 16 ? spread2to4((uint32_t)x) : spread2to4((uint32_t)(bits64_2(row, my_ofs + k) >> 32));
+                } else {
+                    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+                    p0[u] = nib16(rdw, my_ofs) & top_mask(cl[u]);
+                    q2raw[u] = nib16(rdw, my_ofs + k);
+                }
             }
         }
     }
@@ -1109,12 +1158,13 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     const uint64_t slot = list[i];
     const uint32_t r = (uint32_t)(slot % b.n_reads), sc = (uint32_t)(slot / b.n_reads);
     const int strand = (int)(sc / kMaxCoresFast), c = (int)(sc % kMaxCoresFast);
-    const int len = (int)b.lens[r];
+    const uint32_t meta = b.rmeta[r];
+    const int len = (int)(meta & kReadLenMask);
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd;
     phase_params(p, cfg, phase, mm, cl, cd);
     const int my_ofs = c * cd < len - cl ? c * cd : len - cl;
-    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+    const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
     uint64_t first;
     uint32_t raw;
     iv_get(b, slot, first, raw);
@@ -1129,7 +1179,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     if (kind == kKindK2) {
         const int rem2 = cl - k;
         const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-        const uint64_t q2 = rem2 <= 0 ? 0 : (nib16(rdw, my_ofs + k) & m);
+        const uint64_t q2 = rem2 <= 0 ? 0 : (rdw.nib16(my_ofs + k) & m);
         // lower and upper bound in lock step: two independent loads per round
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
@@ -1342,7 +1392,7 @@ __device__ __forceinline__ void eval_window(const uint64_t (&rw)[NW], int len, c
 // word of read and target at a time from memory, so that the path costs the kernels that carry it a few registers instead of the
 // NW + NW/2 + 2 words the all-at-once form holds
 template <int NW>
-__device__ __forceinline__ void eval_window_rare(const uint64_t *__restrict__ rdrow, int len, const uint64_t *__restrict__ tgt, uint64_t t,
+__device__ __forceinline__ void eval_window_rare(const RdRow &rdrow, int len, const uint64_t *__restrict__ tgt, uint64_t t,
                                               Window<NW> &w)
 {
 #pragma unroll
@@ -1353,7 +1403,7 @@ __device__ __forceinline__ void eval_window_rare(const uint64_t *__restrict__ rd
     for (int k = 0; k < nk; k++) {
         const uint64_t win = nib16(tgt, t + 16 * (uint64_t)k);
         const uint64_t m = top_mask(len - 16 * k);
-        const uint64_t x = (rdrow[k] ^ win) & m;
+        const uint64_t x = (rdrow.word16(k) ^ win) & m;
         const uint64_t f = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ULL;
         eosacc |= win & (win >> 1) & (win >> 2) & m & 0x1111111111111111ULL;
         const uint64_t bits = (uint64_t)flags_to_bits16(f) << (16 * (k & 3));
@@ -1492,21 +1542,16 @@ __device__ __forceinline__ void eval_window2(const uint64_t (&r2w)[NW / 2], cons
 }
 
 template <int NW>
-__device__ __forceinline__ void load_read_words2(const uint64_t *__restrict__ row, uint64_t (&r2w)[NW / 2], uint64_t (&rnm)[NW / 4])
+__device__ __forceinline__ void load_read_words2(const uint64_t *__restrict__ row, uint64_t (&r2w)[NW / 2])
 {
-    // rows are 3*NW/4 words = a multiple of 16 bytes
+    // rows are NW/2 words = a multiple of 16 bytes
     const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(row);
-    uint64_t v[3 * NW / 4];
 #pragma unroll
-    for (int q = 0; q < 3 * NW / 8; q++) {
+    for (int q = 0; q < NW / 4; q++) {
         uint4 u = p[q];
-        v[2 * q] = ((uint64_t)u.y << 32) | u.x;
-        v[2 * q + 1] = ((uint64_t)u.w << 32) | u.z;
+        r2w[2 * q] = ((uint64_t)u.y << 32) | u.x;
+        r2w[2 * q + 1] = ((uint64_t)u.w << 32) | u.z;
     }
-#pragma unroll
-    for (int k = 0; k < NW / 2; k++) r2w[k] = v[k];
-#pragma unroll
-    for (int k = 0; k < NW / 4; k++) rnm[k] = v[NW / 2 + k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1880,7 +1925,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     bool mine = false;              // this lane's read is resolved here
     if (a < n_act) {
         r = act[a];
-        const uint32_t len_v = b.lens[r];
+        const uint32_t len_v = b.rmeta[r];
         const bool spec = !WIDE && slots_max <= SPEC;
         uint2 sv[SPEC];
         if (!WIDE) {
@@ -1893,14 +1938,14 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 }
             }
         }
-        // both strands' rows (ROWS implies NW == 8): two blocks of bases and one of N bits each.  Named values, not an array: the
-        // compiler kept an array of them in scratch memory
-        uint4 rb00 = make_uint4(0, 0, 0, 0), rb01 = rb00, rn0 = rb00, rb10 = rb00, rb11 = rb00, rn1 = rb00;
+        // both strands' rows (ROWS implies NW == 8): two 16-byte blocks of bases each, one 64-byte line per read.  Named values, not
+        // an array: the compiler kept an array of them in scratch memory
+        uint4 rb00 = make_uint4(0, 0, 0, 0), rb01 = rb00, rb10 = rb00, rb11 = rb00;
         if (ROWS && two_bit) {
-            const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(b.rd2 + (uint64_t)r * 2 * (3 * NW / 4));
-            rb00 = rp[0]; rb01 = rp[1]; rn0 = rp[2]; rb10 = rp[3]; rb11 = rp[4]; rn1 = rp[5];
+            const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(b.rd2 + (uint64_t)r * 2 * (NW / 2));
+            rb00 = rp[0]; rb01 = rp[1]; rb10 = rp[2]; rb11 = rp[3];
         }
-        len = (int)len_v;
+        len = (int)(len_v & kReadLenMask);
         ReadPlan p = make_plan(len, cfg);
         n_phases = p.n_phases;
         int dummy[1];
@@ -1945,10 +1990,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
         }
         if (is_heavy) dest = (fits && have_wave) ? 2 : 3;
         else { mine = true; n_lcm = 1; }
-        if (ROWS && two_bit) {
-            s_row[t * 4 + 0] = rb00; s_row[t * 4 + 1] = rb01; s_row[t * 4 + 2] = rb10; s_row[t * 4 + 3] = rb11;
-            s_hasn[t] = (uint8_t)(((rn0.x | rn0.y | rn0.z | rn0.w) ? 1u : 0u) | ((rn1.x | rn1.y | rn1.z | rn1.w) ? 2u : 0u));
-        }
+        if (ROWS && two_bit) { s_row[t * 4 + 0] = rb00; s_row[t * 4 + 1] = rb01; s_row[t * 4 + 2] = rb10; s_row[t * 4 + 3] = rb11; }
+        s_hasn[t] = (len_v & kReadHasN) ? 1 : 0;           // a read with an N: the 4-bit compare decides its windows
     }
     PROF(0);
     if (ent_lds && t < ix.n_ent) { s_es[t] = (EntT)es_v; s_ee[t] = (EntT)ee_v; }
@@ -2073,21 +2116,21 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                         const uint64_t g0 = t0 >> ix.flag_shift, g1 = (t0 + (uint64_t)c_len - 1) >> ix.flag_shift;
                         flg = ((((uint32_t)fb0[i] >> (g0 & 7)) | ((uint32_t)fb1[i] >> (g1 & 7))) & 1) != 0;
                         uint64_t r2w[NW / 2], rnm[NW / 4];
+                        flg |= s_hasn[ri] != 0;
                         if (ROWS) {
-                            flg |= ((s_hasn[ri] >> st) & 1) != 0;
 #pragma unroll
                             for (int u = 0; u < NW / 4; u++) {
                                 const uint4 v = s_row[(ri * 2 + st) * (NW / 4) + u];
                                 r2w[2 * u] = ((uint64_t)v.y << 32) | v.x;
                                 r2w[2 * u + 1] = ((uint64_t)v.w << 32) | v.z;
                             }
-#pragma unroll
-                            for (int u = 0; u < NW / 4; u++) rnm[u] = 0;
                         } else
-                            load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (3 * NW / 4), r2w, rnm);
+                            load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (NW / 2), r2w);
+#pragma unroll
+                        for (int u = 0; u < NW / 4; u++) rnm[u] = 0;
                         window2_compare<NW>(r2w, rnm, c_len, t0, wv[i], w);
                     }
-                    if (flg) eval_window_rare<NW>(b.rd4 + ((uint64_t)cr * 2 + st) * b.wpr, c_len, ix.tgt4, t0, w);       // N/EOS nearby (rare): the 4-bit copy decides
+                    if (flg) eval_window_rare<NW>(read_row(b, cr, st, s_hasn[ri] != 0), c_len, ix.tgt4, t0, w);       // N/EOS nearby, or a read with an N (rare): the 4-bit compare decides
                     bool skip = w.eos || (lazy && !core_clean<NW>(w, ofs, c_cl));
 #pragma unroll 1
                     for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
@@ -2390,7 +2433,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         grab_left--;
         if (item >= n_list) break;
         const uint32_t r = list[item];
-        const int len = (int)b.lens[r];
+        const uint32_t meta = b.rmeta[r];
+        const int len = (int)(meta & kReadLenMask);
+        const bool has_n = (meta & kReadHasN) != 0;
         ReadPlan p = make_plan(len, cfg);
         int mm, cl, cd;
         phase_params(p, cfg, phase, mm, cl, cd);
@@ -2429,27 +2474,37 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     epoch = 1;
                 }
             }
-            uint64_t rw[NW];
-            load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
-#pragma unroll
-            for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);      // same read for the whole wave
-            uint64_t r2w[NW / 2], rnm[NW / 4];
+            // the read's row (the same for the whole wave: scalar registers).  Lean batches hold 2 bit/base rows; the 4-bit words a
+            // flagged window needs are widened from them, or - a read with an N - come from its rd4 row together with its N positions
+            uint64_t rw[NW], r2w[NW / 2], rni[NW / 4];                   // rni: "read base is N", in the IWindow layout
             const bool two_bit = b.rd2 != nullptr;
             if (two_bit) {
-                load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (3 * NW / 4), r2w, rnm);
+                load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (NW / 2), r2w);
 #pragma unroll
                 for (int k = 0; k < NW / 2; k++) r2w[k] = uniform64(r2w[k]);
-#pragma unroll
-                for (int k = 0; k < NW / 4; k++) rnm[k] = uniform64(rnm[k]);
             } else {
 #pragma unroll
                 for (int k = 0; k < NW / 2; k++) r2w[k] = 0;
-#pragma unroll
-                for (int k = 0; k < NW / 4; k++) rnm[k] = 0;
             }
-            uint64_t rni[NW / 4];                                        // "read base is N", in the IWindow layout
 #pragma unroll
-            for (int k = 0; k < NW / 4; k++) rni[k] = rnm[k] ? uniform64(bits_to_imap(rnm[k])) : 0ULL;
+            for (int k = 0; k < NW / 4; k++) rni[k] = 0;
+            if (!two_bit || has_n) {
+                load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
+#pragma unroll
+                for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);
+                if (two_bit) {
+#pragma unroll
+                    for (int q = 0; q < NW / 4; q++) {
+                        uint64_t nm = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) nm |= (uint64_t)flags_to_bits16((rw[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
+                        rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; k++) rw[k] = uniform64(spread2to4((k & 1) ? (uint32_t)r2w[k >> 1] : (uint32_t)(r2w[k >> 1] >> 32)));
+            }
             if (lane < nc) {
                 uint64_t slot = iv_slot(b, r, st, lane);
                 uint64_t f;
@@ -3586,6 +3641,33 @@ __global__ void __launch_bounds__(256) k_indel(DevIndex ix, DevAlignCfg cfg, Dev
 }
 
 // reads AlignReads' phases left without any result (candidates for the -a pass)
+// Lean batches keep 4 bit/base rows only for the reads with an N.  The kernels of the general family (k_heavy in all its forms,
+// k_indel) read rd4 rows; the few reads they are handed get theirs here, widened from the 2-bit rows: one lane per 16-base word.
+__global__ void __launch_bounds__(256) k_expand_rd4(DevBatch b, const uint32_t *__restrict__ list, uint32_t n_list)
+{
+    const uint32_t per_read = 2 * b.wpr;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t item = tid / per_read;
+    if (item >= n_list) return;
+    const uint32_t rem = (uint32_t)(tid - item * per_read);
+    const uint32_t r = list ? list[item] : (uint32_t)item;
+    if (b.rmeta[r] & kReadHasN) return;                          // its rows were written by the read preparation
+    const uint32_t st = rem >= b.wpr ? 1 : 0, w = rem - st * b.wpr;
+    uint64_t v = 0;
+    if (w < b.nw) {
+        const uint64_t x = b.rd2[((uint64_t)r * 2 + st) * (b.nw / 2) + (w >> 1)];
+        v = spread2to4((w & 1) ? (uint32_t)x : (uint32_t)(x >> 32));
+    }
+    b.rd4[((uint64_t)r * 2 + st) * b.wpr + w] = v;
+}
+
+static void expand_rd4(const DevBatch &b, const uint32_t *list, uint32_t n_list, hipStream_t s)
+{
+    if (b.rd2 == nullptr || !n_list) return;
+    const uint64_t threads = (uint64_t)n_list * 2 * b.wpr;
+    hipLaunchKernelGGL(k_expand_rd4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, b, list, n_list);
+}
+
 __global__ void __launch_bounds__(256) k_unaligned_list(const bk_hit *__restrict__ out, uint32_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ cnt)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3609,6 +3691,7 @@ void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     const uint32_t n_list = *list_cnt_host;
     if (!n_list) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n_list + 3) / 4, 8192);
+    expand_rd4(b, list, n_list, s);
     if (ix.sa_hi) hipLaunchKernelGGL((k_indel<true>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, keep_state, cursor, seg2);
     else hipLaunchKernelGGL((k_indel<false>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, list, n_list, max_indel, max_junct, keep_state, cursor, seg2);
 }
@@ -4221,6 +4304,7 @@ void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 {
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
+    expand_rd4(b, list, n_list, s);
     if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((k_heavy<false, 0>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next, nullptr, nullptr, nullptr);
 }
@@ -4232,6 +4316,7 @@ void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
+    expand_rd4(b, list, n_list, s);
 #define BK_CHIM(W, M) hipLaunchKernelGGL((k_heavy<W, M>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<bk_loci *>(seg2), nullptr)
     if (long_reads) { if (ix.sa_hi) BK_CHIM(true, 4); else BK_CHIM(false, 4); }      // reads of more than 512 bases: 2048-base mismatch map per lane
     else { if (ix.sa_hi) BK_CHIM(true, 3); else BK_CHIM(false, 3); }
@@ -4245,6 +4330,7 @@ void launch_best(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
+    expand_rd4(b, list, n_list, s);
     if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 2>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, cnt, dense, nullptr);
     else hipLaunchKernelGGL((k_heavy<false, 2>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, cnt, dense, nullptr);
 }
@@ -4284,6 +4370,7 @@ void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
+    expand_rd4(b, list, n_list, s);
     if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
     else hipLaunchKernelGGL((k_heavy<false, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
 }
