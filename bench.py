@@ -431,6 +431,14 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
     torch.from_numpy(h_lens.view(np.int32)).copy_(rd_lens[:n])
     h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(2)]
     expect = d_out.cpu().numpy().view(bk.HIT_DTYPE)
+    packed = args.stream_form == "packed"
+    if packed:
+        # the loader's side of the boundary: reads leave host memory at 2 bit/base (bk_pack_reads: host threads, untimed set-up here
+        # as parsing is), 16-bit lengths, and the list of the bases that are not a,c,g,t
+        tp = time.time()
+        p_words, p_lens16, p_exc = bk.pack_reads(h_bases, None, h_lens, pinned=True)
+        wpr = (L + 15) // 16
+        log(f"host-resident leg: {n} reads packed to {p_words.nbytes / n:.1f} + 2 B/read (+ {len(p_exc)} non-acgt bases) in {time.time() - tp:.1f}s")
     B = max(2, min(args.stream_batch, n))
     B -= B & 1
     cuts = list(range(0, n, B)) + [n]
@@ -446,9 +454,21 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
         f"(first step: {len(cuts0) - 1} batches from {cuts0[1]} reads up)")
     result = {}
     with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
+        exc_of = {}
+        if packed:
+            er = p_exc["read"]
+            for lo, hi in set(zip(cuts0[:-1], cuts0[1:])) | set(zip(cuts[:-1], cuts[1:])):
+                a, z = np.searchsorted(er, lo), np.searchsorted(er, hi)
+                e = bk.host_array(max(1, z - a), bk.NBASE_DTYPE)[: z - a]
+                e[:] = p_exc[a:z]
+                e["read"] -= lo                                      # exception read numbers are batch-relative
+                exc_of[(lo, hi)] = e
+
         def one_step(k, first=False):
             out = h_out[k & 1]
             cc = cuts0 if first else cuts
+            if packed:
+                return [st.submit_packed(p_words[lo * wpr: hi * wpr], p_lens16[lo:hi], exc_of[(lo, hi)], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
             return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
         for t in one_step(0):            # warm-up (buffers touched, scratch sized)
             st.wait(t)
@@ -477,12 +497,12 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
     same = all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in h_out[: min(2, args.stream_steps)])
     total = n * args.stream_steps * world
     result.update({"value": total / elapsed, "unit": "reads/s", "steps": args.stream_steps, "reads_per_step_per_gpu": n,
-                   "batch_reads": B, "depth": 3, "seconds": elapsed,
+                   "batch_reads": B, "depth": 3, "seconds": elapsed, "form": "packed: 2 bit/base words + 16-bit lengths + non-acgt list (bk_stream_submit_packed)" if packed else "1 byte/base (bk_stream_submit)",
                    "t_align_first_submit_to_last_result_s": stats["seconds_first_submit_to_last_result"],
                    "pcie_bytes_per_read": {"h2d": stats["bytes_h2d"] / max(1, stats["reads"]), "d2h": stats["bytes_d2h"] / max(1, stats["reads"])},
                    "device_ms_per_step": tim["ms_total"] / max(1, args.stream_steps),
                    "results_bit_identical_to_kernel_only_steps": same,
-                   "note": "host pinned buffers in -> host bk_hit out through bk_stream_* (3 HIP streams); never the headline `value`"})
+                   "note": "host pinned buffers in -> host bk_hit out through bk_stream_* (3 HIP streams)"})
     return result
 
 
@@ -530,6 +550,8 @@ def main():
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
     ap.add_argument("--stream-steps", type=int, default=5, help="steps of the host-resident leg (bk_stream_*: host buffers in -> host "
                                                                 "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
+    ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the host-resident leg's reads cross PCIe: "
+                    "2 bit/base (bk_stream_submit_packed) or 1 byte/base (bk_stream_submit)")
     ap.add_argument("--stream-batch", type=int, default=25_000_000, help="reads per submitted batch of the host-resident leg (the first step ramps up to it)")
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")

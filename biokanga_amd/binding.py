@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = [
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
+    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed",
 ]
 
 
@@ -188,6 +189,14 @@ def load_library():
     lib.bk_stream_create.restype = i32
     lib.bk_stream_submit.argtypes = [vp, vp, u64, vp, vp, u32, vp, ctypes.POINTER(u64)]
     lib.bk_stream_submit.restype = i32
+    lib.bk_stream_submit_packed.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, ctypes.POINTER(u64)]
+    lib.bk_stream_submit_packed.restype = i32
+    lib.bk_packed_words.argtypes = [vp, u32]
+    lib.bk_packed_words.restype = u64
+    lib.bk_pack_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, u64, ctypes.POINTER(u64)]
+    lib.bk_pack_reads.restype = i32
+    lib.bk_align_batch_packed.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp]
+    lib.bk_align_batch_packed.restype = i32
     lib.bk_stream_wait.argtypes = [vp, u64]
     lib.bk_stream_wait.restype = i32
     lib.bk_stream_batch_loci.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
@@ -226,6 +235,42 @@ def seq_counts_allreduce(aligners, reset=False):
     if rc:
         raise BkError(rc, "bk_seq_counts_allreduce")
     return out
+
+
+NBASE_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u2"), ("code", "u1"), ("reserved", "u1")])
+
+
+def pack_reads(bases, offs, lens, pinned=False):
+    """bk_pack_reads: 1 byte/base reads -> (words uint32, lens16 uint16, exc NBASE_DTYPE), the packed form of bk_align_batch_packed /
+    bk_stream_submit_packed.  offs may be None for reads lying back to back.  pinned: arrays from bk_host_alloc."""
+    lib = load_library()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    if offs is not None:
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(lens)
+    nw = int(lib.bk_packed_words(lens.ctypes.data, n))
+    mk = host_array if pinned else (lambda m, dt: np.zeros(m, dtype=dt))
+    words = mk(max(nw, 1), np.uint32)
+    lens16 = mk(max(n, 1), np.uint16)
+    cap = 1024
+    while True:
+        exc = np.zeros(cap, dtype=NBASE_DTYPE)
+        found = ctypes.c_uint64()
+        rc = lib.bk_pack_reads(bases.ctypes.data, None if offs is None else offs.ctypes.data, lens.ctypes.data, n, words.ctypes.data,
+                               lens16.ctypes.data, exc.ctypes.data, cap, ctypes.byref(found))
+        if rc == -95 and found.value > cap:
+            cap = int(found.value)
+            continue
+        if rc:
+            raise BkError(rc, "bk_pack_reads")
+        break
+    exc = exc[:found.value]
+    if pinned and len(exc):
+        pe = host_array(len(exc), NBASE_DTYPE)
+        pe[:] = exc
+        exc = pe
+    return words[:nw], lens16[:n], exc
 
 
 def build_sa_device(d_seq_ptr, concat_len, d_sa_ptr, el_size=4, device=0):
@@ -318,6 +363,18 @@ class Aligner:
                                      out.ctypes.data)
         if rc:
             raise BkError(rc, "bk_align_batch")
+        return out
+
+    def align_packed(self, words, lens16, exc):
+        """bk_align_batch_packed: the batch in the packed form pack_reads() makes"""
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens16 = np.ascontiguousarray(lens16, dtype=np.uint16)
+        exc = np.ascontiguousarray(exc, dtype=NBASE_DTYPE)
+        out = np.zeros(len(lens16), dtype=HIT_DTYPE)
+        rc = self.lib.bk_align_batch_packed(self.h, words.ctypes.data if len(words) else None, len(words), lens16.ctypes.data if len(lens16) else None,
+                                            len(lens16), exc.ctypes.data if len(exc) else None, len(exc), out.ctypes.data)
+        if rc:
+            raise BkError(rc, "bk_align_batch_packed")
         return out
 
     def batch_loci(self, nreads):
@@ -489,6 +546,19 @@ class Stream:
         if rc:
             raise BkError(rc, "bk_stream_submit")
         self._keep[t.value] = (bases, offs, lens, out)
+        return t.value
+
+    def submit_packed(self, words, lens16, exc, out):
+        """the batch in the packed form (pack_reads); arrays must stay alive and untouched until wait(ticket)"""
+        assert words.dtype == np.uint32 and lens16.dtype == np.uint16 and exc.dtype == NBASE_DTYPE and out.dtype == HIT_DTYPE and len(out) >= len(lens16)
+        for a in (words, lens16, exc, out):
+            assert a.flags["C_CONTIGUOUS"]
+        t = ctypes.c_uint64()
+        rc = self.lib.bk_stream_submit_packed(self.h, words.ctypes.data if len(words) else None, len(words), lens16.ctypes.data, len(lens16),
+                                              exc.ctypes.data if len(exc) else None, len(exc), out.ctypes.data, ctypes.byref(t))
+        if rc:
+            raise BkError(rc, "bk_stream_submit_packed")
+        self._keep[t.value] = (words, lens16, exc, out)
         return t.value
 
     def wait(self, ticket):

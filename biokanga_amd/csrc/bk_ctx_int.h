@@ -83,7 +83,7 @@ struct bk_ctx {
     uint32_t *d_stage[3] = {nullptr, nullptr, nullptr}, *d_stripe_cnt = nullptr, *d_slist_stage = nullptr;       // striped work lists (bk::StripeSet)
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
     uint32_t *h_small = nullptr;          // pinned mirror
-    unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr;
+    unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr, *d_ctr_aux = nullptr;
     unsigned long long *d_seq_global = nullptr;   // bk_seq_counts_allreduce: the counts summed over every context of the run
     // heavy path scratch
     bk::HeavyScratch hs{};
@@ -96,6 +96,14 @@ struct bk_ctx {
     uint32_t *d_in_lens = nullptr;
     bk_hit *d_in_out = nullptr;
     bk_seg2 *d_seg2 = nullptr;            // -a / -A / -c: second segments of a chunk (kept with the batch scratch)
+    // packed host batches (bk_align_batch_packed) and the offset scan of packed batches
+    uint32_t *d_in_words = nullptr;
+    uint16_t *d_in_lens16 = nullptr;
+    bk_nbase *d_in_exc = nullptr;
+    uint64_t cap_in_words = 0, cap_in_exc = 0;
+    uint32_t cap_in_lens16 = 0;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     uint32_t cap_seg2 = 0;
     uint64_t cap_in_bases = 0;
     uint32_t cap_in_reads = 0;
@@ -110,12 +118,23 @@ struct bk_ctx {
 
 
 namespace bk {
+// a batch of reads resident in HBM, in either form the boundary takes
+struct DevReads {
+    const uint8_t *bases = nullptr;       // 1 byte/base form: the bases, offs[i] = start of read i in them
+    const uint64_t *offs = nullptr;       //   (packed form: first word of read i in `words`)
+    const uint32_t *lens = nullptr;
+    const uint32_t *words = nullptr;      // packed form (bk_align_batch_packed): 2 bit/base words, then bases == nullptr
+    const bk_nbase *exc = nullptr;        //   + the bases that are not a,c,g,t
+    uint64_t n_exc = 0;
+};
 // batch driver entry points of bk_engine.cpp used by the stream pipeline (all blocking on `s`: the phase loop reads the
 // active counts back between phases)
-int engine_align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads, bk_hit *d_out,
-                        hipStream_t s);
-int engine_pair_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs, bk_hit *d_hits,
-                       uint32_t maxlen, const bk_pe_params *pe, hipStream_t s);
+int engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s);
+int engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s);
+// packed batches: lens16 -> d_lens32, word offsets of the reads -> d_offs (scan), the batch checked (word count, read lengths,
+// exception list); *maxlen = longest read.  Blocking on `s`.
+int engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nreads, uint64_t n_words, const bk_nbase *d_exc, uint64_t n_exc,
+                          uint32_t *d_lens32, uint64_t *d_offs, uint32_t *maxlen, hipStream_t s);
 }  // namespace bk
 
 namespace bk {

@@ -80,9 +80,13 @@ struct DevAlignCfg {            // derived once per context (CAligner::LocateCor
 };
 
 struct DevBatch {
-    const uint8_t *bases;       // 1 B/base as CAligner holds them
-    const uint64_t *offs;
+    const uint8_t *bases;       // 1 B/base as CAligner holds them; null when the batch came packed (pk_words)
+    const uint64_t *offs;       // start of every read in bases (or, packed batches, its first word in pk_words)
     const uint32_t *lens;
+    const uint32_t *pk_words;   // packed batches (bk_align_batch_packed): 16 bases per word at 2 bit/base, first base in the top bits
+    const bk_nbase *pk_exc;     //   the bases that are not a,c,g,t, sorted by (read, position); read numbers count from the first read
+    uint64_t pk_nexc;           //   of the submitted batch, of which this chunk holds reads pk_read0 .. pk_read0 + n_reads - 1
+    uint32_t pk_read0;
     uint64_t *rd4;              // [read][strand][wpr] packed nibble words (fwd, revcomp).  With rd2 set ("lean" batches) only the rows of
                                 //   reads that hold an N are written by the read preparation; k_expand_rd4 fills in the rows of the few
                                 //   reads a kernel of the general family is about to see

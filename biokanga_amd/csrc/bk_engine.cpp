@@ -3,6 +3,7 @@
 // Compiled with hipcc; device code lives in bk_kernels.hip.  No CPU fallback exists: every compute
 // entry point needs a HIP device and fails with BK_ERR_NODEVICE otherwise.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -28,6 +30,9 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
+void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s);
+void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s);
+void launch_packed_extent(const uint64_t *offs, const uint32_t *lens, uint32_t n, unsigned long long *out, hipStream_t s);
 void launch_snp_pileup(const DevIndex &ix, const uint8_t *bases, const uint64_t *offs, const uint32_t *id2idx, const bk_snp_aln *alns, uint64_t n_alns,
                        uint32_t *planes, hipStream_t s);
 void launch_snp_gather(const DevIndex &ix, const uint32_t *planes, uint64_t g0, uint32_t n, uint32_t *out, hipStream_t s);
@@ -348,6 +353,7 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     HIP_TRY(hipMalloc(&c->d_ctr, (size_t)kCtrStripes * 8 * 8));
     HIP_TRY(hipMemset(c->d_ctr, 0, (size_t)kCtrStripes * 8 * 8));
     HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
+    HIP_TRY(hipMalloc(&c->d_ctr_aux, 32));
     HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
     int rc = derive_cfg(c);
     clk0.lap("entry table, small buffers");
@@ -630,9 +636,11 @@ int best_matches_chunk(bk_ctx *c, const DevBatch &b, uint32_t n, const uint32_t 
     return BK_OK;
 }
 
-int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n, uint32_t maxlen,
-                bk_hit *d_out, hipStream_t s, EvTimer &tm)
+int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint32_t maxlen, bk_hit *d_out, hipStream_t s, EvTimer &tm)
 {
+    const uint8_t *d_bases = in.bases;
+    const uint64_t *d_offs = in.offs + first;
+    const uint32_t *d_lens = in.lens + first;
     uint32_t *sm = c->d_small, *hm = c->h_small;
     HIP_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
     const uint32_t wpr = words_per_read(maxlen);
@@ -645,6 +653,7 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
 
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
+    b.pk_words = in.words; b.pk_exc = in.exc; b.pk_nexc = in.words ? in.n_exc : 0; b.pk_read0 = first;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
     b.rmeta = c->d_rmeta;
@@ -826,9 +835,9 @@ int align_chunk(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const
     return BK_OK;
 }
 
-int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads,
-                 bk_hit *d_out, hipStream_t s)
+int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s)
 {
+    const uint32_t *d_lens = in.lens;
     EvTimer tm{c};
     hipEvent_t t0 = tm.begin(s);
     c->loci_offs.clear();
@@ -863,7 +872,7 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
     }
     for (uint32_t done = 0; done < nreads;) {
         uint32_t n = std::min(chunk, nreads - done);
-        int rc = align_chunk(c, d_bases, d_offs + done, d_lens + done, n, maxlen, d_out + done, s, tm);
+        int rc = align_chunk(c, in, done, n, maxlen, d_out + done, s, tm);
         if (rc) return rc;
         done += n;
     }
@@ -887,24 +896,64 @@ int align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, cons
 
 }  // namespace
 
-int bk::engine_align_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t nreads, bk_hit *d_out,
-                            hipStream_t s)
+int bk::engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s)
 {
-    return align_device(c, d_bases, d_offs, d_lens, nreads, d_out, s);
+    return align_device(c, in, nreads, d_out, s);
+}
+
+namespace {
+struct CastU64 {
+    __host__ __device__ unsigned long long operator()(const uint32_t &v) const { return (unsigned long long)v; }
+};
+}
+
+int bk::engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nreads, uint64_t n_words, const bk_nbase *d_exc, uint64_t n_exc,
+                              uint32_t *d_lens32, uint64_t *d_offs, uint32_t *maxlen, hipStream_t s)
+{
+    // words per read -> exclusive scan in place = first word of every read
+    launch_widen_lens(d_lens16, nreads, d_lens32, (unsigned long long *)d_offs, s);
+    HIP_TRY(hipGetLastError());
+    size_t need = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
+    if (need > c->scan_tmp_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        free_dev(c->d_scan_tmp);
+        c->d_scan_tmp = nullptr;
+        c->scan_tmp_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_scan_tmp, need + 256));
+        c->scan_tmp_bytes = need + 256;
+    }
+    size_t tb = c->scan_tmp_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, tb, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
+    // [0] max over reads of (first word + words) = the batch's word count, [1] longest read; exceptions in range and ascending
+    HIP_TRY(hipMemsetAsync(c->d_ctr_aux, 0, 32, s));
+    launch_packed_extent(d_offs, d_lens32, nreads, c->d_ctr_aux, s);
+    launch_check_exc(d_exc, n_exc, d_lens32, nreads, reinterpret_cast<uint32_t *>(c->d_ctr_aux + 2), s);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->d_ctr_aux, 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h[0] != n_words || h[1] > (unsigned long long)kMaxReadLenAbs || (uint32_t)h[2] != 0) return BK_ERR_PARAMS;
+    *maxlen = (uint32_t)h[1];
+    return BK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K4 on buffers resident in HBM (shared by bk_pair_batch, bk_pair_batch_device and the stream pipeline)
-int bk::engine_pair_device(bk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n_pairs,
-                           bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s)
+int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s)
 {
+    const uint8_t *d_bases = in.bases;
+    const uint64_t *d_offs = in.offs;
+    const uint32_t *d_lens = in.lens;
     const uint32_t nreads = 2 * n_pairs;
     const uint32_t wpr = words_per_read(maxlen);
     int rc = ensure_batch_scratch(c, nreads, wpr);
     if (rc) return rc;
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
+    b.pk_words = in.words; b.pk_exc = in.exc; b.pk_nexc = in.words ? in.n_exc : 0; b.pk_read0 = 0;
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
+    b.rmeta = c->d_rmeta;
     b.out = d_hits; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = nreads;
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
@@ -1093,6 +1142,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
+    free_dev(c->d_in_words); free_dev(c->d_in_lens16); free_dev(c->d_in_exc); free_dev(c->d_scan_tmp); free_dev(c->d_ctr_aux);
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1227,8 +1277,9 @@ int bk_align_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, co
     if (!nreads) return BK_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return align_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, nreads,
-                        (bk_hit *)d_out, s);
+    DevReads in;
+    in.bases = (const uint8_t *)d_bases; in.offs = (const uint64_t *)d_offs; in.lens = (const uint32_t *)d_lens;
+    return align_device(c, in, nreads, (bk_hit *)d_out, s);
 }
 
 int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, bk_hit *out)
@@ -1266,7 +1317,127 @@ int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const 
     HIP_TRY(hipMemcpyAsync(c->d_in_offs, rel.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int rc = align_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, nreads, c->d_in_out, c->stream);
+    DevReads in;
+    in.bases = c->d_in_bases; in.offs = c->d_in_offs; in.lens = c->d_in_lens;
+    int rc = align_device(c, in, nreads, c->d_in_out, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
+    return BK_OK;
+}
+
+uint64_t bk_packed_words(const uint32_t *lens, uint32_t nreads)
+{
+    uint64_t n = 0;
+    if (lens) for (uint32_t i = 0; i < nreads; i++) n += ((uint64_t)lens[i] + 15) >> 4;
+    return n;
+}
+
+int bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, uint32_t *words, uint16_t *lens16,
+                  bk_nbase *exc, uint64_t exc_cap, uint64_t *n_exc)
+{
+    if (!n_exc || (nreads && (!bases || !lens || !words || !lens16)) || (exc_cap && !exc)) return BK_ERR_PARAMS;
+    *n_exc = 0;
+    if (!nreads) return BK_OK;
+    // slices of reads, one thread each: first word and first base of every slice, then pack; exceptions are collected per slice
+    // and laid behind each other afterwards (ascending by read and position as the slices are)
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (nreads < 65536) nt = 1;
+    std::vector<uint64_t> w0(nt + 1, 0), b0(nt + 1, 0);
+    std::vector<uint32_t> r0(nt + 1);
+    for (unsigned t = 0; t <= nt; t++) r0[t] = (uint32_t)((uint64_t)nreads * t / nt);
+    bool too_long = false;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                uint64_t w = 0, bsum = 0;
+                for (uint32_t i = r0[t]; i < r0[t + 1]; i++) { w += ((uint64_t)lens[i] + 15) >> 4; bsum += lens[i]; if (lens[i] > (uint32_t)kMaxReadLenAbs) too_long = true; }
+                w0[t + 1] = w;
+                b0[t + 1] = bsum;
+            });
+        for (auto &x : th) x.join();
+    }
+    if (too_long) return BK_ERR_PARAMS;
+    for (unsigned t = 0; t < nt; t++) { w0[t + 1] += w0[t]; b0[t + 1] += b0[t]; }
+    std::vector<std::vector<bk_nbase>> found(nt);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                uint32_t *wp = words + w0[t];
+                uint64_t at = b0[t];
+                for (uint32_t i = r0[t]; i < r0[t + 1]; i++) {
+                    const uint32_t len = lens[i];
+                    const uint8_t *s = bases + (offs ? offs[i] : at);
+                    at += len;
+                    lens16[i] = (uint16_t)len;
+                    for (uint32_t j0 = 0; j0 < len; j0 += 16) {
+                        const uint32_t cnt = std::min<uint32_t>(16, len - j0);
+                        uint32_t v = 0;
+                        for (uint32_t k = 0; k < cnt; k++) {
+                            const uint32_t code = s[j0 + k] & 7u;
+                            if (code > 3) found[t].push_back(bk_nbase{i, (uint16_t)(j0 + k), (uint8_t)code, 0});
+                            else v |= code << (30 - 2 * k);
+                        }
+                        *wp++ = v;
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    uint64_t total = 0;
+    for (unsigned t = 0; t < nt; t++) {
+        for (const bk_nbase &e : found[t]) { if (total < exc_cap) exc[total] = e; total++; }
+    }
+    *n_exc = total;
+    return total > exc_cap ? BK_ERR_MEM : BK_OK;
+}
+
+int bk_align_batch_packed(bk_ctx *c, const uint32_t *words, uint64_t n_words, const uint16_t *lens, uint32_t nreads, const bk_nbase *exc,
+                          uint64_t n_exc, bk_hit *out)
+{
+    if (!c || (nreads && (!lens || !out)) || (n_words && !words) || (n_exc && !exc)) return BK_ERR_PARAMS;
+    if (!nreads) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (n_words + 1 > c->cap_in_words) {
+        free_dev(c->d_in_words);
+        c->d_in_words = nullptr;
+        c->cap_in_words = 0;
+        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + 1) * 4));
+        c->cap_in_words = n_words + 1;
+    }
+    if (n_exc > c->cap_in_exc) {
+        free_dev(c->d_in_exc);
+        c->d_in_exc = nullptr;
+        c->cap_in_exc = 0;
+        HIP_TRY(hipMalloc(&c->d_in_exc, n_exc * sizeof(bk_nbase)));
+        c->cap_in_exc = n_exc;
+    }
+    if (nreads > c->cap_in_reads) {
+        free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out); free_dev(c->d_in_lens16);
+        c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr; c->d_in_lens16 = nullptr;
+        c->cap_in_reads = 0;
+        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        c->cap_in_reads = nreads;
+    }
+    if (!c->d_in_lens16 || nreads > c->cap_in_lens16) {
+        free_dev(c->d_in_lens16);
+        c->d_in_lens16 = nullptr;
+        HIP_TRY(hipMalloc(&c->d_in_lens16, (size_t)std::max(nreads, c->cap_in_reads) * 2));
+        c->cap_in_lens16 = std::max(nreads, c->cap_in_reads);
+    }
+    if (n_words) HIP_TRY(hipMemcpyAsync(c->d_in_words, words, n_words * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_in_lens16, lens, (size_t)nreads * 2, hipMemcpyHostToDevice, s));
+    if (n_exc) HIP_TRY(hipMemcpyAsync(c->d_in_exc, exc, n_exc * sizeof(bk_nbase), hipMemcpyHostToDevice, s));
+    uint32_t maxlen = 0;
+    int rc = engine_prepare_packed(c, c->d_in_lens16, nreads, n_words, c->d_in_exc, n_exc, c->d_in_lens, c->d_in_offs, &maxlen, s);
+    if (rc) return rc;
+    DevReads in;
+    in.offs = c->d_in_offs; in.lens = c->d_in_lens; in.words = c->d_in_words; in.exc = c->d_in_exc; in.n_exc = n_exc;
+    rc = align_device(c, in, nreads, c->d_in_out, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
@@ -1314,7 +1485,9 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     HIP_TRY(hipMemcpyAsync(c->d_in_lens, lens, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_in_out, hits, (size_t)nreads * sizeof(bk_hit), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    int rc = engine_pair_device(c, c->d_in_bases, c->d_in_offs, c->d_in_lens, n_pairs, c->d_in_out, maxlen, pe, s);
+    DevReads in;
+    in.bases = c->d_in_bases; in.offs = c->d_in_offs; in.lens = c->d_in_lens;
+    int rc = engine_pair_device(c, in, n_pairs, c->d_in_out, maxlen, pe, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(hits, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
@@ -1338,8 +1511,9 @@ int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, con
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t maxlen = c->h_small[5];
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
-    return engine_pair_device(c, (const uint8_t *)d_bases, (const uint64_t *)d_offs, (const uint32_t *)d_lens, n_pairs, (bk_hit *)d_hits,
-                              maxlen, pe, s);
+    DevReads in;
+    in.bases = (const uint8_t *)d_bases; in.offs = (const uint64_t *)d_offs; in.lens = (const uint32_t *)d_lens;
+    return engine_pair_device(c, in, n_pairs, (bk_hit *)d_hits, maxlen, pe, s);
 }
 
 // ---- SNP pile-up and screening (see include/biokanga_amd.h) -------------------------------------

@@ -524,6 +524,176 @@ __device__ __forceinline__ uint64_t complement8(uint64_t x)       // A<->T, C<->
     return x ^ (((~x >> 2) & 0x0101010101010101ULL) * 3);
 }
 
+// ---- packed batches (bk_align_batch_packed): 16 bases per 32-bit word at 2 bit/base, first base in the top bits ----------------
+
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x)            // the 16 2-bit fields in reverse order
+{
+    x = __brev(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+__device__ __forceinline__ uint64_t rev2_64(uint64_t x)            // the 32 2-bit fields in reverse order
+{
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+// bases 16w .. 16w + 15 of a packed read (rc: of its reverse complement) as one 2-bit word, zero beyond the read's end.  W = the
+// read's words; the word behind its last one may be loaded (the buffers are followed by one more word), its bits are never used.
+__device__ __forceinline__ uint32_t packed_word16(const uint32_t *__restrict__ W, int len, int w, bool rc)
+{
+    const int rem = len - 16 * w;                     // bases of the read in this word
+    if (rem <= 0) return 0;
+    const uint32_t keep = rem >= 16 ? 0xFFFFFFFFu : ~0u << (32 - 2 * rem);
+    if (!rc) return W[w] & keep;
+    // reverse complement: its bases 16w .. are the complement of the forward bases p + 15 .. p, p = len - 16w - 16
+    const int p = len - 16 * w - 16;
+    uint32_t x;
+    if (p >= 0) {
+        const int i = p >> 4;
+        const unsigned s = (unsigned)(p & 15) << 1;
+        const uint64_t c = ((uint64_t)W[i] << 32) | W[i + 1];
+        x = (uint32_t)(c >> (32 - s));
+    } else
+        x = W[0] >> (unsigned)(2 * (-p));             // the read's first 16 + p bases, at the low end
+    return ~rev2_32(x) & keep;
+}
+
+// reverse complement of a read held as W words of 32 bases (first base in the top bits, zero beyond its end)
+template <int W>
+__device__ __forceinline__ void revcomp2(const uint64_t (&f)[W], int len, uint64_t (&r)[W])
+{
+    uint64_t t[W + 1], u[W + 1];
+#pragma unroll
+    for (int i = 0; i < W; i++) t[i] = ~rev2_64(f[W - 1 - i]);      // the whole row reversed: the read now ends flush with the row's end
+    t[W] = 0;
+    const int sh = 2 * (32 * W - len), q = sh >> 6;
+    const unsigned bsh = (unsigned)(sh & 63);
+#pragma unroll
+    for (int i = 0; i <= W; i++) u[i] = 0;
+#pragma unroll
+    for (int qq = 0; qq < W; qq++)
+        if (q == qq) {
+#pragma unroll
+            for (int i = 0; i + qq <= W; i++) u[i] = t[i + qq];
+        }
+#pragma unroll
+    for (int i = 0; i < W; i++) r[i] = bsh ? ((u[i] << bsh) | (u[i + 1] >> (64 - bsh))) : u[i];
+}
+
+// exceptions of a packed batch, one lane each.  k_mark_exc counts them into the reads' meta words BEFORE the read preparation runs
+// (bits 16..30: N bases, bit 31: a code the reference refuses - what the N policy needs to know); k_exc_rows gives the reads that
+// have one their 4-bit rows (lean batches; widened from the 2-bit rows), k_apply_exc then writes the codes into the rows of both strands
+__global__ void __launch_bounds__(256) k_mark_exc(DevBatch b)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.pk_nexc) return;
+    const bk_nbase e = b.pk_exc[i];
+    const uint32_t rr = e.read - b.pk_read0;
+    if (rr >= b.n_reads) return;
+    if (e.code == 4) atomicAdd(&b.rmeta[rr], 1u << 16);
+    else atomicOr(&b.rmeta[rr], 1u << 31);
+}
+
+__global__ void __launch_bounds__(256) k_exc_rows(DevBatch b)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.pk_nexc) return;
+    const uint32_t rd = b.pk_exc[i].read;
+    const uint32_t rr = rd - b.pk_read0;
+    if (rr >= b.n_reads || (i > 0 && b.pk_exc[i - 1].read == rd)) return;       // the first exception of a read does the read
+    for (uint32_t st = 0; st < 2; st++)
+        for (uint32_t w = 0; w < b.wpr; w++) {
+            uint64_t v = 0;
+            if (w < b.nw) {
+                const uint64_t x = b.rd2[((uint64_t)rr * 2 + st) * (b.nw / 2) + (w >> 1)];
+                v = spread2to4((w & 1) ? (uint32_t)x : (uint32_t)(x >> 32));
+            }
+            b.rd4[((uint64_t)rr * 2 + st) * b.wpr + w] = v;
+        }
+}
+
+__global__ void __launch_bounds__(256) k_apply_exc(DevBatch b)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.pk_nexc) return;
+    const bk_nbase e = b.pk_exc[i];
+    const uint32_t rr = e.read - b.pk_read0;
+    if (rr >= b.n_reads) return;
+    const int len = (int)b.lens[rr];
+    const int pos[2] = {(int)e.pos, len - 1 - (int)e.pos};            // codes 4..7 are their own complement (SeqTrans.cpp:458-512)
+    for (int st = 0; st < 2; st++) {
+        unsigned long long *p = reinterpret_cast<unsigned long long *>(b.rd4 + ((uint64_t)rr * 2 + st) * b.wpr + (pos[st] >> 4));
+        const unsigned sh = 60u - 4u * (unsigned)(pos[st] & 15);
+        atomicAnd(p, ~(0xFULL << sh));
+        atomicOr(p, (unsigned long long)(e.code & 7) << sh);
+    }
+}
+
+// one-time check of a packed batch's exception list (whole batch): codes 4..7, reads and positions in range, strictly ascending
+__global__ void __launch_bounds__(256) k_check_exc(const bk_nbase *__restrict__ exc, uint64_t n_exc, const uint32_t *__restrict__ lens, uint32_t n_reads,
+                                                   uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_exc) return;
+    const bk_nbase e = exc[i];
+    bool ok = e.read < n_reads && e.code >= 4 && e.code <= 7;
+    if (ok) ok = e.pos < lens[e.read];
+    if (ok && i > 0) {
+        const bk_nbase q = exc[i - 1];
+        ok = q.read < e.read || (q.read == e.read && q.pos < e.pos);
+    }
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+// lens16 -> lens32 and the words each read takes (the input of the offset scan)
+__global__ void __launch_bounds__(256) k_widen_lens(const uint16_t *__restrict__ lens16, uint32_t n, uint32_t *__restrict__ lens32,
+                                                    unsigned long long *__restrict__ nwords)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = lens16[i];
+    lens32[i] = l;
+    nwords[i] = (l + 15) >> 4;
+}
+
+// packed batch: [0] max over reads of (first word + words taken), [1] longest read
+__global__ void __launch_bounds__(256) k_packed_extent(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens, uint32_t n,
+                                                       unsigned long long *__restrict__ out)
+{
+    unsigned long long e = 0, l = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long len = lens[i], end = offs[i] + ((len + 15) >> 4);
+        e = end > e ? end : e;
+        l = len > l ? len : l;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long e2 = __shfl_down(e, off), l2 = __shfl_down(l, off);
+        e = e2 > e ? e2 : e;
+        l = l2 > l ? l2 : l;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (e) atomicMax(out + 0, e);
+        if (l) atomicMax(out + 1, l);
+    }
+}
+
+void launch_packed_extent(const uint64_t *offs, const uint32_t *lens, uint32_t n, unsigned long long *out, hipStream_t s)
+{
+    unsigned blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (n) hipLaunchKernelGGL(k_packed_extent, dim3(blocks), dim3(256), 0, s, offs, lens, n, out);
+}
+
+void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_widen_lens, dim3((n + 255) / 256), dim3(256), 0, s, lens16, n, lens32, nwords);
+}
+
+void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s)
+{
+    if (n_exc) hipLaunchKernelGGL(k_check_exc, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, s, exc, n_exc, lens, n_reads, bad);
+}
+
 __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
 {
     // a block packs 256 / (2 * wpr) whole reads: 32-bit index arithmetic only
@@ -537,6 +707,12 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
     const uint32_t rem = threadIdx.x - lr * per_read;
     const uint32_t st = rem >= wpr ? 1 : 0, w = rem - st * wpr;
     int len = (int)b.lens[r];
+    if (b.pk_words != nullptr) {
+        // packed batch: the word, or the 16 bases of the forward read whose reverse complement it is, straight from the 2-bit words
+        // (bases that are not a,c,g,t read as whatever their field holds; k_apply_exc writes their codes afterwards)
+        b.rd4[r * per_read + rem] = spread2to4(packed_word16(b.pk_words + b.offs[r], len, (int)w, st != 0));
+        return;
+    }
     const uint8_t *s = b.bases + b.offs[r];
     uint64_t v = 0;
     int base0 = 16 * (int)w;
@@ -565,45 +741,82 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
     b.rd4[r * per_read + rem] = v;
 }
 
-// k_pack_reads + k_init_reads in one pass for reads of <= 16*NW bases (the register-kernel path): one lane per
-// read builds both packed rows (and their 2-bit twins) in registers from 16-byte loads of the read's bytes,
-// writes whole rows, applies the N policy, initialises the result record and appends the read to the first
-// active list.  11.4 GB of traffic per 50 M reads instead of the 30 GB of the word-per-thread kernels.
-template <int NW>
+// k_pack_reads + k_init_reads in one pass for reads of <= 16*NW bases (the register-kernel path): one lane per read builds the
+// rows of both strands in registers - from 16-byte loads of the read's bytes, or (PACKED) from its 2-bit words, of which the forward
+// row is a copy - applies the N policy, initialises the result record and appends the read to the first active list.  Lean batches
+// (b.rd2 set) get 2 bit/base rows, and 4 bit/base rows only for the reads that hold an N: 60 bytes written per 100-base read
+// instead of the 248 of full rows in both forms.
+template <int NW, bool PACKED>
 __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b, StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base, s_cmax;
     if (threadIdx.x == 0) { s_cnt = 0; s_cmax = 0; }
     __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lean = b.rd2 != nullptr;
     bool go = false, has_n = false;
     uint32_t my_cmax = 0;
     int len = 0;
-    uint64_t fw[NW], rv[NW];
+    uint64_t fw[PACKED ? 1 : NW], rv[PACKED ? 1 : NW];              // 4 bit/base rows (1 byte/base input)
+    uint64_t f2[NW / 2], r2[NW / 2];                                // 2 bit/base rows
     bk_hit h;
     if (r < b.n_reads) {
         len = (int)b.lens[r];
-        const uint8_t *s = b.bases + b.offs[r];
+        int num_ns = 0;
+        bool bad = false;
+        if (PACKED) {
+            const uint32_t *__restrict__ W = b.pk_words + b.offs[r];
+            const int nwr = (len + 15) >> 4;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const int base0 = 16 * w;
-            uint64_t f = 0, v = 0;
-            if (base0 + 16 <= len) {
-                Bytes16 q = *reinterpret_cast<const Bytes16 *>(s + base0);
-                f = (pack8_msb(__builtin_bswap64(q.lo)) << 32) | pack8_msb(__builtin_bswap64(q.hi));
-                Bytes16 p = *reinterpret_cast<const Bytes16 *>(s + (len - 16 - base0));
-                v = (pack8_msb(complement8(p.hi)) << 32) | pack8_msb(complement8(p.lo));
-            } else if (base0 < len) {
-                const int cnt = len - base0;
-                for (int k = 0; k < cnt; k++) {
-                    f |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
-                    uint8_t x = s[len - 1 - base0 - k] & 7;
-                    x = x < 4 ? (uint8_t)(3 - x) : x;
-                    v |= (uint64_t)x << (60 - 4 * k);
+            for (int k = 0; k < NW / 2; k++) {
+                const uint32_t hi = 2 * k < nwr ? W[2 * k] : 0u, lo = 2 * k + 1 < nwr ? W[2 * k + 1] : 0u;
+                uint64_t v = ((uint64_t)hi << 32) | lo;
+                const int rem = len - 32 * k;                       // bases of the read in this word
+                if (rem < 32) v = rem <= 0 ? 0ULL : (v & (~0ULL << (64 - 2 * rem)));
+                f2[k] = v;
+            }
+            revcomp2<NW / 2>(f2, len, r2);
+            const uint32_t pre = b.rmeta[r];                        // k_mark_exc: what the exception list holds for this read
+            num_ns = (int)((pre >> 16) & 0x7FFFu);
+            bad = (pre >> 31) != 0;
+        } else {
+            const uint8_t *s = b.bases + b.offs[r];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int base0 = 16 * w;
+                uint64_t f = 0, v = 0;
+                if (base0 + 16 <= len) {
+                    Bytes16 q = *reinterpret_cast<const Bytes16 *>(s + base0);
+                    f = (pack8_msb(__builtin_bswap64(q.lo)) << 32) | pack8_msb(__builtin_bswap64(q.hi));
+                    Bytes16 p = *reinterpret_cast<const Bytes16 *>(s + (len - 16 - base0));
+                    v = (pack8_msb(complement8(p.hi)) << 32) | pack8_msb(complement8(p.lo));
+                } else if (base0 < len) {
+                    const int cnt = len - base0;
+                    for (int k = 0; k < cnt; k++) {
+                        f |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
+                        uint8_t x = s[len - 1 - base0 - k] & 7;
+                        x = x < 4 ? (uint8_t)(3 - x) : x;
+                        v |= (uint64_t)x << (60 - 4 * k);
+                    }
+                }
+                fw[w] = f;
+                rv[w] = v;
+            }
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                if (16 * w < len) {
+                    uint64_t x = fw[w] & top_mask(len - 16 * w);
+                    uint64_t hi = x & 0x4444444444444444ULL;
+                    uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;
+                    bad |= ((hi >> 2) & lo) != 0;
+                    num_ns += __popcll(hi);
                 }
             }
-            fw[w] = f;
-            rv[w] = v;
+#pragma unroll
+            for (int k = 0; k < NW / 2; k++) {
+                f2[k] = ((uint64_t)squeeze2(fw[2 * k]) << 32) | squeeze2(fw[2 * k + 1]);
+                r2[k] = ((uint64_t)squeeze2(rv[2 * k]) << 32) | squeeze2(rv[2 * k + 1]);
+            }
         }
         // N policy and result record, as k_init_reads
         h.chrom_id = 0; h.match_loci = 0; h.match_len = 0; h.low_hit_instances = 0; h.rslt = 0;
@@ -612,18 +825,6 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
         if (cfg.max_ns) {
             max_ns_seq = (len * cfg.max_ns) / 100;
             if (max_ns_seq < cfg.max_ns) max_ns_seq = cfg.max_ns;
-        }
-        int num_ns = 0;
-        bool bad = false;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            if (16 * w < len) {
-                uint64_t x = fw[w] & top_mask(len - 16 * w);
-                uint64_t hi = x & 0x4444444444444444ULL;
-                uint64_t lo = (x | (x >> 1)) & 0x1111111111111111ULL;
-                bad |= ((hi >> 2) & lo) != 0;
-                num_ns += __popcll(hi);
-            }
         }
         if (bad || num_ns > max_ns_seq) h.nar = BK_NAR_NS;
         has_n = bad || num_ns > 0;
@@ -655,36 +856,34 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
     __syncthreads();
     if (go) stripe_put(out, 0, s_base + my_off, r);
     if (r < b.n_reads) {
-        const bool lean = b.rd2 != nullptr;
         b.rmeta[r] = (uint32_t)len | (has_n ? kReadHasN : 0u);
-        if (!lean || has_n) {
-            // rows: [read][strand][wpr] nibble words (zero padded), 16-byte aligned.  Lean batches: only for the reads with an N
+        // 4 bit/base rows [read][strand][wpr] (zero padded, 16-byte aligned): every read of a batch without 2-bit rows; in lean
+        // batches only the reads with an N (1 byte/base input: here; packed input: k_exc_rows + k_apply_exc after this kernel)
+        if (PACKED ? !lean : (!lean || has_n)) {
             const uint32_t wpr = b.wpr;
             uint4 *row0 = reinterpret_cast<uint4 *>(b.rd4 + (uint64_t)r * 2 * wpr);
             uint4 *row1 = reinterpret_cast<uint4 *>(b.rd4 + ((uint64_t)r * 2 + 1) * wpr);
 #pragma unroll
             for (int q = 0; q < NW / 2; q++) {
                 if (2 * q < (int)wpr) {
-                    row0[q] = make_uint4((uint32_t)fw[2 * q], (uint32_t)(fw[2 * q] >> 32), (uint32_t)fw[2 * q + 1], (uint32_t)(fw[2 * q + 1] >> 32));
-                    row1[q] = make_uint4((uint32_t)rv[2 * q], (uint32_t)(rv[2 * q] >> 32), (uint32_t)rv[2 * q + 1], (uint32_t)(rv[2 * q + 1] >> 32));
+                    uint64_t a0, a1, c0, c1;
+                    if (PACKED) {
+                        a0 = spread2to4((uint32_t)(f2[q] >> 32)); a1 = spread2to4((uint32_t)f2[q]);
+                        c0 = spread2to4((uint32_t)(r2[q] >> 32)); c1 = spread2to4((uint32_t)r2[q]);
+                    } else { a0 = fw[PACKED ? 0 : 2 * q]; a1 = fw[PACKED ? 0 : 2 * q + 1]; c0 = rv[PACKED ? 0 : 2 * q]; c1 = rv[PACKED ? 0 : 2 * q + 1]; }
+                    row0[q] = make_uint4((uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32));
+                    row1[q] = make_uint4((uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32));
                 }
             }
             for (uint32_t q = NW / 2; 2 * q < wpr; q++) { row0[q] = make_uint4(0, 0, 0, 0); row1[q] = make_uint4(0, 0, 0, 0); }
         }
         if (lean) {
-            // 2-bit rows of both strands, NW/2 words each
-            uint64_t o0[NW / 2], o1[NW / 2];
-#pragma unroll
-            for (int k = 0; k < NW / 2; k++) {
-                o0[k] = ((uint64_t)squeeze2(fw[2 * k]) << 32) | squeeze2(fw[2 * k + 1]);
-                o1[k] = ((uint64_t)squeeze2(rv[2 * k]) << 32) | squeeze2(rv[2 * k + 1]);
-            }
             uint4 *t0 = reinterpret_cast<uint4 *>(b.rd2 + (uint64_t)r * 2 * (NW / 2));
             uint4 *t1 = reinterpret_cast<uint4 *>(b.rd2 + ((uint64_t)r * 2 + 1) * (NW / 2));
 #pragma unroll
             for (int q = 0; q < NW / 4; q++) {
-                t0[q] = make_uint4((uint32_t)o0[2 * q], (uint32_t)(o0[2 * q] >> 32), (uint32_t)o0[2 * q + 1], (uint32_t)(o0[2 * q + 1] >> 32));
-                t1[q] = make_uint4((uint32_t)o1[2 * q], (uint32_t)(o1[2 * q] >> 32), (uint32_t)o1[2 * q + 1], (uint32_t)(o1[2 * q + 1] >> 32));
+                t0[q] = make_uint4((uint32_t)f2[2 * q], (uint32_t)(f2[2 * q] >> 32), (uint32_t)f2[2 * q + 1], (uint32_t)(f2[2 * q + 1] >> 32));
+                t1[q] = make_uint4((uint32_t)r2[2 * q], (uint32_t)(r2[2 * q] >> 32), (uint32_t)r2[2 * q + 1], (uint32_t)(r2[2 * q + 1] >> 32));
             }
         }
         b.out[r] = h;
@@ -4087,19 +4286,31 @@ static void launch_compact(const StripeSet &set, uint32_t *const *dense, uint32_
 void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint32_t *act_cnt, uint32_t *cmax, uint32_t *stage,
                  uint32_t *stripe_cnt, hipStream_t s)
 {
+    const bool packed = b.pk_words != nullptr;
+    const unsigned eblocks = (unsigned)((b.pk_nexc + 255) / 256);
     if (b.nw == 8 || b.nw == 16) {          // register-kernel path: fused pack + init
         const unsigned blocks = (b.n_reads + 255) / 256;
         StripeSet out;
         out.cnt = stripe_cnt;
         out.stage[0] = out.stage[1] = out.stage[2] = stage;
         out.cap = stripe_cap(blocks, 256);
-        if (b.nw == 8) hipLaunchKernelGGL(k_prep_fused<8>, dim3(blocks), dim3(256), 0, s, cfg, b, out);
-        else hipLaunchKernelGGL(k_prep_fused<16>, dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        if (packed) {
+            // the exception list first tells every read how many N it holds (the N policy is decided in the fused kernel), and
+            // afterwards writes the codes into 4-bit rows: existing ones, or - lean batches - rows made for just these reads
+            (void)hipMemsetAsync(b.rmeta, 0, (size_t)b.n_reads * 4, s);
+            if (eblocks) hipLaunchKernelGGL(k_mark_exc, dim3(eblocks), dim3(256), 0, s, b);
+            if (b.nw == 8) hipLaunchKernelGGL((k_prep_fused<8, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+            else hipLaunchKernelGGL((k_prep_fused<16, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+            if (eblocks && b.rd2 != nullptr) hipLaunchKernelGGL(k_exc_rows, dim3(eblocks), dim3(256), 0, s, b);
+            if (eblocks) hipLaunchKernelGGL(k_apply_exc, dim3(eblocks), dim3(256), 0, s, b);
+        } else if (b.nw == 8) hipLaunchKernelGGL((k_prep_fused<8, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        else hipLaunchKernelGGL((k_prep_fused<16, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
         launch_compact(out, &act, &act_cnt, 1, cmax, s);
         return;
     }
     const uint32_t rpb = 256 / (2 * b.wpr);
     hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
+    if (packed && eblocks) hipLaunchKernelGGL(k_apply_exc, dim3(eblocks), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_init_reads, dim3((b.n_reads + 1023) / 1024), dim3(1024), 0, s, cfg, b, act, act_cnt, cmax);
 }
 
@@ -4128,6 +4339,7 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
     DevPE pe{pe_mode, min_len, max_len, pair_strand};
     const uint32_t rpb = 256 / (2 * b.wpr);
     hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
+    if (b.pk_words != nullptr && b.pk_nexc) hipLaunchKernelGGL(k_apply_exc, dim3((unsigned)((b.pk_nexc + 255) / 256)), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters);
     (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -58,6 +59,12 @@ struct Job {
     uint64_t nbases = 0;
     const uint64_t *offs = nullptr;
     const uint32_t *lens = nullptr;
+    // packed form (bk_stream_submit_packed): words != nullptr or n_words == 0 with lens16 set
+    const uint32_t *words = nullptr;
+    uint64_t n_words = 0;
+    const uint16_t *lens16 = nullptr;
+    const bk_nbase *exc = nullptr;
+    uint64_t n_exc = 0;
     uint32_t n = 0;
     bk_hit *out = nullptr;
     int slot = 0;
@@ -71,7 +78,10 @@ struct Job {
 };
 
 struct Slot {
-    uint8_t *d_bases = nullptr;
+    uint8_t *d_bases = nullptr;           // 1 byte/base reads, or the words of a packed batch
+    uint16_t *d_lens16 = nullptr;
+    bk_nbase *d_exc = nullptr;            // grown on demand
+    uint64_t cap_exc = 0;
     uint64_t *d_offs = nullptr;
     uint32_t *d_lens = nullptr;
     bk_hit *d_out = nullptr;
@@ -132,7 +142,24 @@ struct bk_stream {
         while (Job *j = pop(q_up)) {
             Slot &sl = slots[j->slot];
             hipError_t e = hipSuccess;
-            if (j->n) {
+            if (j->n && j->lens16) {
+                // packed batch: 2 bit/base words, 16-bit lengths, the few bases that are not a,c,g,t
+                const size_t wb = (size_t)j->n_words * 4;
+                if (wb) {
+                    if (bk::host_is_pinned(j->words)) e = hipMemcpyAsync(sl.d_bases, j->words, wb, hipMemcpyHostToDevice, s_up);
+                    else if (bk::upload_host(sl.d_bases, j->words, wb, ctx->device) != BK_OK) e = hipErrorUnknown;
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.d_lens16, j->lens16, (size_t)j->n * 2, hipMemcpyHostToDevice, s_up);
+                if (e == hipSuccess && j->n_exc > sl.cap_exc) {
+                    // (the slot is idle: its previous batch has been waited for)
+                    if (sl.d_exc) (void)hipFree(sl.d_exc);
+                    sl.d_exc = nullptr;
+                    sl.cap_exc = 0;
+                    e = hipMalloc(&sl.d_exc, (size_t)(j->n_exc + j->n_exc / 4 + 1024) * sizeof(bk_nbase));
+                    if (e == hipSuccess) sl.cap_exc = j->n_exc + j->n_exc / 4 + 1024;
+                }
+                if (e == hipSuccess && j->n_exc) e = hipMemcpyAsync(sl.d_exc, j->exc, (size_t)j->n_exc * sizeof(bk_nbase), hipMemcpyHostToDevice, s_up);
+            } else if (j->n) {
                 // the bases are the bulk: pageable buffers are staged by several threads (bk::upload_host), pinned ones DMA'd as they are
                 if (bk::host_is_pinned(j->bases)) e = hipMemcpyAsync(sl.d_bases, j->bases, j->nbases, hipMemcpyHostToDevice, s_up);
                 else if (bk::upload_host(sl.d_bases, j->bases, j->nbases, ctx->device) != BK_OK) e = hipErrorUnknown;
@@ -150,7 +177,26 @@ struct bk_stream {
         (void)hipSetDevice(ctx->device);
         while (Job *j = pop(q_al)) {
             Slot &sl = slots[j->slot];
-            if (j->rc == BK_OK && j->n) {
+            if (j->rc == BK_OK && j->n && j->lens16) {
+                hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
+                uint32_t maxlen = 0;
+                int rc = e == hipSuccess ? bk::engine_prepare_packed(ctx, sl.d_lens16, j->n, j->n_words, sl.d_exc, j->n_exc, sl.d_lens, sl.d_offs, &maxlen, s_al)
+                                         : rc_of(e);
+                bk::DevReads in;
+                in.offs = sl.d_offs; in.lens = sl.d_lens; in.words = reinterpret_cast<const uint32_t *>(sl.d_bases); in.exc = sl.d_exc; in.n_exc = j->n_exc;
+                if (rc == BK_OK) rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al);
+                if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
+                if (rc) fail(j, rc);
+                else if (list_modes) {
+                    j->loci_offs.swap(ctx->loci_offs);
+                    j->loci.swap(ctx->loci);
+                    j->seg2.swap(ctx->seg2);
+                }
+                if (j->rc == BK_OK) {
+                    e = hipEventRecord(sl.ev_al, s_al);
+                    if (e != hipSuccess) fail(j, rc_of(e));
+                }
+            } else if (j->rc == BK_OK && j->n) {
                 hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
                 if (e == hipSuccess && !j->offs) {          // contiguous reads: offsets = exclusive prefix sum of the lengths
                     size_t tb = scan_tmp_bytes;
@@ -170,8 +216,10 @@ struct bk_stream {
                 else if (h_ext[0] > j->nbases || h_ext[1] > (unsigned long long)bk::kMaxReadLenAbs) fail(j, BK_ERR_PARAMS);
                 const uint32_t maxlen = (uint32_t)h_ext[1];
                 if (j->rc == BK_OK) {
-                    int rc = bk::engine_align_device(ctx, sl.d_bases, sl.d_offs, sl.d_lens, j->n, sl.d_out, s_al);
-                    if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, sl.d_bases, sl.d_offs, sl.d_lens, j->n / 2, sl.d_out, maxlen, &pe, s_al);
+                    bk::DevReads in;
+                    in.bases = sl.d_bases; in.offs = sl.d_offs; in.lens = sl.d_lens;
+                    int rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al);
+                    if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
                     if (rc) fail(j, rc);
                     else if (list_modes) {
                         j->loci_offs.swap(ctx->loci_offs);
@@ -212,7 +260,7 @@ struct bk_stream {
                 n_done++;
                 stats.batches++;
                 stats.reads += j->n;
-                stats.bytes_h2d += j->nbases + (uint64_t)j->n * (j->offs ? 12 : 4);
+                stats.bytes_h2d += j->lens16 ? j->n_words * 4 + (uint64_t)j->n * 2 + j->n_exc * sizeof(bk_nbase) : j->nbases + (uint64_t)j->n * (j->offs ? 12 : 4);
                 stats.bytes_d2h += (uint64_t)j->n * sizeof(bk_hit);
                 stats.seconds_first_submit_to_last_result = t_last_done - t_first_submit;
             }
@@ -250,6 +298,8 @@ void bk_stream_destroy(bk_stream *s)
     (void)hipSetDevice(s->ctx->device);
     for (Slot &sl : s->slots) {
         if (sl.d_bases) (void)hipFree(sl.d_bases);
+        if (sl.d_lens16) (void)hipFree(sl.d_lens16);
+        if (sl.d_exc) (void)hipFree(sl.d_exc);
         if (sl.d_offs) (void)hipFree(sl.d_offs);
         if (sl.d_lens) (void)hipFree(sl.d_lens);
         if (sl.d_out) (void)hipFree(sl.d_out);
@@ -284,7 +334,9 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_al, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_dn, hipStreamNonBlocking);
     for (Slot &sl : s->slots) {
-        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, max_batch_bases + 16);
+        // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
+        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 16);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
         if (e == hipSuccess) e = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
         if (e == hipSuccess) e = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
         if (e == hipSuccess) e = hipMalloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
@@ -325,6 +377,29 @@ int bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const 
         j->slot = (int)((j->ticket - 1) % (uint64_t)s->depth);
         j->t_submit = now_s();
         if (!s->span_open) { s->t_first_submit = j->t_submit; s->span_open = true; }      // T_align: first batch submitted -> last result back
+        s->jobs[j->ticket] = j;
+        s->q_up.push_back(j);
+    }
+    s->cv.notify_all();
+    *ticket = j->ticket;
+    return BK_OK;
+}
+
+int bk_stream_submit_packed(bk_stream *s, const uint32_t *words, uint64_t n_words, const uint16_t *lens, uint32_t nreads,
+                            const bk_nbase *exc, uint64_t n_exc, bk_hit *out, uint64_t *ticket)
+{
+    if (!s || !ticket || (nreads && (!lens || !out)) || (n_words && !words) || (n_exc && !exc)) return BK_ERR_PARAMS;
+    // (a batch's words are bounded like its bases: 16 of them per word, a last partial word per read)
+    if (nreads > s->max_reads || n_words > s->max_bases / 16 + nreads || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
+    Job *j = new Job();
+    j->words = words; j->n_words = n_words; j->lens16 = lens; j->exc = exc; j->n_exc = n_exc; j->n = nreads; j->out = out;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->next_ticket - 1 - s->n_done < (uint64_t)s->depth; });     // a free set of device buffers
+        j->ticket = s->next_ticket++;
+        j->slot = (int)((j->ticket - 1) % (uint64_t)s->depth);
+        j->t_submit = now_s();
+        if (!s->span_open) { s->t_first_submit = j->t_submit; s->span_open = true; }
         s->jobs[j->ticket] = j;
         s->q_up.push_back(j);
     }

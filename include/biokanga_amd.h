@@ -181,6 +181,33 @@ int  bk_align_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, con
 int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
                            uint32_t nreads, void *d_out, void *stream, int sync);
 
+/* ---- packed reads: 2 bit/base across PCIe ------------------------------------------------------------------------
+ * The 1 byte/base form above is how CAligner holds reads; of its 8 bits the hot path uses 3 (Aligner.cpp:9038-9055) and almost
+ * always only 2.  Packed form of a batch:
+ *   words  read i owns ceil(lens[i] / 16) consecutive 32-bit words, reads back to back in order; base j of a read sits in bits
+ *          31-2(j%16) .. 30-2(j%16) of its word j/16 (first base in the top bits): 0 a, 1 c, 2 g, 3 t.  Bits past a read's end are ignored.
+ *   lens   16 bits per read (reads are <= 2000 bases)
+ *   exc    every base whose code (bits 0-2 of its byte in the 1 byte/base form) is not 0..3 - the indeterminate base N (4), or anything
+ *          else (5..7, which make the reference refuse the read) - with that code, strictly ascending by (read, pos); the 2-bit field
+ *          of such a base is ignored.  Empty for most batches.
+ * 100-base reads cross PCIe as 30 bytes instead of 104.  Results are those of the 1 byte/base calls, bit for bit. */
+typedef struct bk_nbase {
+    uint32_t read;               /* index of the read within the batch */
+    uint16_t pos;                /* base position within the read      */
+    uint8_t  code;               /* 4 (N) .. 7                         */
+    uint8_t  reserved;
+} bk_nbase;                      /* 8 bytes */
+/* number of words the packed form of these reads takes */
+uint64_t bk_packed_words(const uint32_t *lens, uint32_t nreads);
+/* host-side packer (the loader thread's job; uses a few threads): 1 byte/base reads -> the packed form.  offs == NULL: reads lie back
+ * to back.  words must hold bk_packed_words(lens, nreads) entries, lens16 nreads, exc exc_cap entries; *n_exc receives the number of exceptions FOUND - when it exceeds exc_cap only the first exc_cap were stored and the call fails
+ * with BK_ERR_MEM, to be repeated with a larger array.  Reads longer than 2000 bases: BK_ERR_PARAMS. */
+int  bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, uint32_t *words, uint16_t *lens16,
+                   bk_nbase *exc, uint64_t exc_cap, uint64_t *n_exc);
+/* bk_align_batch over the packed form (host buffers, blocking); n_words = bk_packed_words() of the batch */
+int  bk_align_batch_packed(bk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint16_t *lens, uint32_t nreads,
+                           const bk_nbase *exc, uint64_t n_exc, bk_hit *out);
+
 /* Paired-end association after the SE pass = CAligner::ProcessPairedEnds (biokanga/Aligner.cpp:
  * 2876-3489) incl. orphan recovery by CSfxArrayV3::AlignPairedRead (libbiokanga/SfxArrayV2.cpp:8247).
  * Reads and hits are interleaved PE1, PE2, PE1, PE2 ... (2 * n_pairs of each); hits must be the
@@ -265,6 +292,9 @@ int  bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, ui
  * buffer sets are busy); every buffer must stay valid and untouched until bk_stream_wait(ticket) has returned. */
 int  bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                       bk_hit *out, uint64_t *ticket);
+/* the same with the batch in the packed form (see bk_align_batch_packed) */
+int  bk_stream_submit_packed(bk_stream *s, const uint32_t *words, uint64_t n_words, const uint16_t *lens, uint32_t nreads,
+                             const bk_nbase *exc, uint64_t n_exc, bk_hit *out, uint64_t *ticket);
 /* blocks until the results of that batch are in its `out`; returns the batch's result code (each ticket once, unless the
  * context runs a list mode - then bk_stream_batch_loci / _seg2 stay available until bk_stream_release) */
 int  bk_stream_wait(bk_stream *s, uint64_t ticket);

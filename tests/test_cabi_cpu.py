@@ -73,3 +73,38 @@ def test_product_never_touches_oracle():
                     if "oracle" in txt.lower() and "bk_oracle" in txt or "ora_align" in txt or "libbk_oracle" in txt:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_packer_round_trip(lib):
+    """bk_pack_reads (host code, no device): every base ends up in its 2-bit field or, when it is not a,c,g,t, in the exception list
+    with its code; mask and quality bits are dropped; slices packed by different threads join up"""
+    import numpy as np
+    import biokanga_amd as bk
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 1000, 70000):
+        lens = rng.integers(1, 300, size=n).astype(np.uint32)
+        if n:
+            lens[0] = 2000
+        tot = int(lens.sum())
+        bases = rng.integers(0, 4, size=tot).astype(np.uint8)
+        if tot:
+            bases[rng.choice(tot, min(tot, 50), replace=False)] = 4
+            bases[rng.choice(tot, min(tot, 5), replace=False)] = 6
+        raw = bases | (rng.integers(0, 32, size=tot).astype(np.uint8) << 3)
+        for explicit in (False, True):
+            offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64) if n else np.zeros(0, np.uint64)
+            w, l16, exc = bk.pack_reads(raw, offs if explicit else None, lens)
+            assert np.array_equal(l16, lens.astype(np.uint16))
+            assert len(w) == int(((lens.astype(np.int64) + 15) // 16).sum())
+            # unpack with numpy
+            wofs = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 15) // 16)])[:-1] if n else np.zeros(0, np.int64)
+            read_of = np.repeat(np.arange(n), lens)
+            pos = np.arange(tot) - np.repeat(offs.astype(np.int64), lens)
+            got = (w[wofs[read_of] + pos // 16] >> (30 - 2 * (pos % 16)).astype(np.uint32)) & 3 if tot else np.zeros(0, np.uint32)
+            plain = bases < 4
+            assert np.array_equal(got[plain], bases[plain])
+            e_idx = np.nonzero(~plain)[0]
+            assert len(exc) == len(e_idx)
+            assert np.array_equal(exc["read"], read_of[e_idx]) and np.array_equal(exc["pos"], pos[e_idx]) and np.array_equal(exc["code"], bases[e_idx])
+    with pytest.raises(bk.BkError):
+        bk.pack_reads(np.zeros(2001, np.uint8), None, np.array([2001], np.uint32))

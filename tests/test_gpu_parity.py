@@ -85,6 +85,55 @@ def test_paths_agree(golden_tmp, fixture, knob):
         assert c1["n_heavy"] > c0["n_heavy"] and c1["n_heavy"] >= np.count_nonzero(ref["rslt"] != 0)
 
 
+@pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
+@pytest.mark.parametrize("knob", [(), ("use_flat", 0), ("chunk_reads", 333), ("use_tgt2", 0), ("use_k2", 0), ("heavy_thresh", 0), ("use_wave", 0)])
+def test_packed_batch_equals_byte_batch(golden_tmp, fixture, knob):
+    """bk_align_batch_packed (2 bit/base words + 16-bit lengths + the list of bases that are not a,c,g,t) gives the records and the
+    counters of bk_align_batch on the same reads: lean and full-row batches, the general path (reads > 256 bases), chunked batches
+    (exception read numbers are batch-wide), reads with N, reads refused for their Ns."""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3L" if fixture == "lengths" else "s3")
+    words, lens16, exc = bk.pack_reads(bases, offs[keep], lens[keep])
+    assert len(exc) > 0 or fixture != "basic"
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        if knob:
+            al.tune(*knob)
+        ref = al.align(bases, offs[keep], lens[keep])
+        c0 = al.counters(reset=True)
+        got = al.align_packed(words, lens16, exc)
+        c1 = al.counters()
+    assert_hits_equal(got, ref, [names[i] for i in keep])
+    for k in ("n_search", "n_cand", "n_lcm_calls"):
+        assert c0[k] == c1[k], (k, c0, c1)
+
+
+def test_packed_batch_is_checked(golden_tmp):
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    words, lens16, exc = bk.pack_reads(bases, offs[keep], lens[keep])
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align_packed(words, lens16, exc)
+        for what in ("words", "read", "pos", "code", "order", "len"):
+            w2, l2, e2 = words, lens16.copy(), exc.copy()
+            if what == "words":
+                w2 = words[:-1]
+            elif what == "read":
+                e2["read"][-1] = len(l2)
+            elif what == "pos":
+                e2["pos"][0] = l2[e2["read"][0]]
+            elif what == "code":
+                e2["code"][0] = 2
+            elif what == "order":
+                e2[[0, 1]] = e2[[1, 0]]
+            elif what == "len":
+                l2[3] = 2001
+            with pytest.raises(bk.BkError) as e:
+                al.align_packed(w2, l2, e2)
+            assert e.value.rc == -100, what
+        assert_hits_equal(al.align_packed(words, lens16, exc), ref)            # the context stays usable
+        assert len(al.align_packed(np.zeros(0, np.uint32), np.zeros(0, np.uint16), np.zeros(0, bk.NBASE_DTYPE))) == 0
+
+
 def test_seq_counts_and_empty(golden_tmp):
     bk = _bk()
     d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic")

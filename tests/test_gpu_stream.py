@@ -20,7 +20,8 @@ def _contiguous(bases, offs, lens):
 
 @pytest.mark.parametrize("fixture,tag", [("basic", "s3"), ("repeat", "s3"), ("lengths", "s3L")])
 @pytest.mark.parametrize("batch,depth,pinned,explicit_offs", [(257, 3, True, True), (1000, 2, False, False), (64, 4, True, False),
-                                                               (100000, 1, False, True)])
+                                                               (100000, 1, False, True), (257, 3, True, "packed"), (1000, 2, False, "packed"),
+                                                               (100000, 1, True, "packed")])
 def test_stream_equals_blocking_call_and_oracle(golden_tmp, fixture, tag, batch, depth, pinned, explicit_offs):
     bk = _bk()
     d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, tag)
@@ -41,6 +42,9 @@ def test_stream_equals_blocking_call_and_oracle(golden_tmp, fixture, tag, batch,
                 hb = mk(b1 - b0, np.uint8); hb[:] = cb[b0:b1]
                 hl = mk(hi - lo, np.uint32); hl[:] = lens[lo:hi]
                 ho = None
+                if explicit_offs == "packed":
+                    tickets.append(st.submit_packed(*bk.pack_reads(hb, None, hl, pinned=pinned), out[lo:hi]))
+                    continue
                 if explicit_offs:
                     ho = mk(hi - lo, np.uint64); ho[:] = coffs[lo:hi] - np.uint64(b0)
                 tickets.append(st.submit(hb, ho, hl, out[lo:hi]))
@@ -115,8 +119,9 @@ def test_stream_multi_loci_lists_travel_with_their_batch(golden_tmp):
     assert np.array_equal(np.concatenate(got_loci), rl)
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("fixture", ["pe", "pe150"])
-def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path, fixture):
+def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path, fixture, packed):
     from test_oracle_pe import pe_cfg, pe_inputs, check_pe_hits_against_sam
     bk = _bk()
     cfg = pe_cfg(fixture, "U3")
@@ -134,7 +139,10 @@ def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path,
             for lo in range(0, n, B):
                 hi = min(n, lo + B)
                 b0, b1 = int(coffs[lo]), int(coffs[hi - 1]) + int(lens[hi - 1])
-                tk.append(st.submit(cb[b0:b1].copy(), None, lens[lo:hi].copy(), out[lo:hi]))
+                if packed:
+                    tk.append(st.submit_packed(*bk.pack_reads(cb[b0:b1], None, lens[lo:hi]), out[lo:hi]))
+                else:
+                    tk.append(st.submit(cb[b0:b1].copy(), None, lens[lo:hi].copy(), out[lo:hi]))
             for t in tk:
                 st.wait(t)
             with pytest.raises(bk.BkError):                 # half a pair
