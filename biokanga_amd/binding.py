@@ -237,7 +237,7 @@ def seq_counts_allreduce(aligners, reset=False):
     return out
 
 
-NBASE_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u2"), ("code", "u1"), ("reserved", "u1")])
+NBASE_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u2"), ("code", "u1"), ("run", "u1")])
 
 
 def pack_reads(bases, offs, lens, pinned=False):

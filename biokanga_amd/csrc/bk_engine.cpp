@@ -1376,8 +1376,15 @@ int bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *le
                         uint32_t v = 0;
                         for (uint32_t k = 0; k < cnt; k++) {
                             const uint32_t code = s[j0 + k] & 7u;
-                            if (code > 3) found[t].push_back(bk_nbase{i, (uint16_t)(j0 + k), (uint8_t)code, 0});
-                            else v |= code << (30 - 2 * k);
+                            if (code > 3) {
+                                std::vector<bk_nbase> &f = found[t];
+                                if (!f.empty() && f.back().read == i && f.back().code == code && f.back().run < 255 &&
+                                    (uint32_t)f.back().pos + f.back().run + 1 == j0 + k)
+                                    f.back().run++;
+                                else
+                                    f.push_back(bk_nbase{i, (uint16_t)(j0 + k), (uint8_t)code, 0});
+                            } else
+                                v |= code << (30 - 2 * k);
                         }
                         *wp++ = v;
                     }

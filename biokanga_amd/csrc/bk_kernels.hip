@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) k_mark_exc(DevBatch b)
     const bk_nbase e = b.pk_exc[i];
     const uint32_t rr = e.read - b.pk_read0;
     if (rr >= b.n_reads) return;
-    if (e.code == 4) atomicAdd(&b.rmeta[rr], 1u << 16);
+    if (e.code == 4) atomicAdd(&b.rmeta[rr], ((uint32_t)e.run + 1u) << 16);
     else atomicOr(&b.rmeta[rr], 1u << 31);
 }
 
@@ -620,12 +620,17 @@ __global__ void __launch_bounds__(256) k_apply_exc(DevBatch b)
     const uint32_t rr = e.read - b.pk_read0;
     if (rr >= b.n_reads) return;
     const int len = (int)b.lens[rr];
-    const int pos[2] = {(int)e.pos, len - 1 - (int)e.pos};            // codes 4..7 are their own complement (SeqTrans.cpp:458-512)
+    // the run's bases [lo, hi] of each strand (codes 4..7 are their own complement, SeqTrans.cpp:458-512), one 16-base word at a time
+    const int lo2[2] = {(int)e.pos, len - 1 - (int)e.pos - (int)e.run}, hi2[2] = {(int)e.pos + (int)e.run, len - 1 - (int)e.pos};
+    const unsigned long long code16 = 0x1111111111111111ULL * (unsigned long long)(e.code & 7);
     for (int st = 0; st < 2; st++) {
-        unsigned long long *p = reinterpret_cast<unsigned long long *>(b.rd4 + ((uint64_t)rr * 2 + st) * b.wpr + (pos[st] >> 4));
-        const unsigned sh = 60u - 4u * (unsigned)(pos[st] & 15);
-        atomicAnd(p, ~(0xFULL << sh));
-        atomicOr(p, (unsigned long long)(e.code & 7) << sh);
+        for (int w = lo2[st] >> 4; w <= (hi2[st] >> 4); w++) {
+            const int a = lo2[st] > 16 * w ? lo2[st] - 16 * w : 0, z = hi2[st] < 16 * w + 15 ? hi2[st] - 16 * w : 15;      // nibbles a..z of the word
+            const unsigned long long m = (~0ULL >> (4 * a)) & (~0ULL << (60 - 4 * z));
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(b.rd4 + ((uint64_t)rr * 2 + st) * b.wpr + w);
+            atomicAnd(p, ~m);
+            atomicOr(p, code16 & m);
+        }
     }
 }
 
@@ -637,10 +642,10 @@ __global__ void __launch_bounds__(256) k_check_exc(const bk_nbase *__restrict__ 
     if (i >= n_exc) return;
     const bk_nbase e = exc[i];
     bool ok = e.read < n_reads && e.code >= 4 && e.code <= 7;
-    if (ok) ok = e.pos < lens[e.read];
+    if (ok) ok = (uint32_t)e.pos + e.run < lens[e.read];
     if (ok && i > 0) {
         const bk_nbase q = exc[i - 1];
-        ok = q.read < e.read || (q.read == e.read && q.pos < e.pos);
+        ok = q.read < e.read || (q.read == e.read && (uint32_t)q.pos + q.run < e.pos);
     }
     if (!ok) atomicAdd(bad, 1u);
 }

@@ -188,14 +188,15 @@ int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs,
  *          31-2(j%16) .. 30-2(j%16) of its word j/16 (first base in the top bits): 0 a, 1 c, 2 g, 3 t.  Bits past a read's end are ignored.
  *   lens   16 bits per read (reads are <= 2000 bases)
  *   exc    every base whose code (bits 0-2 of its byte in the 1 byte/base form) is not 0..3 - the indeterminate base N (4), or anything
- *          else (5..7, which make the reference refuse the read) - with that code, strictly ascending by (read, pos); the 2-bit field
- *          of such a base is ignored.  Empty for most batches.
+ *          else (5..7, which make the reference refuse the read) - as runs: `run` + 1 consecutive bases of a read from `pos` on
+ *          carry `code`; strictly ascending by (read, pos), runs do not overlap; the 2-bit fields of such bases are ignored.  Empty
+ *          for most batches; a read of nothing but N is one entry.
  * 100-base reads cross PCIe as 30 bytes instead of 104.  Results are those of the 1 byte/base calls, bit for bit. */
 typedef struct bk_nbase {
     uint32_t read;               /* index of the read within the batch */
-    uint16_t pos;                /* base position within the read      */
+    uint16_t pos;                /* first base of the run              */
     uint8_t  code;               /* 4 (N) .. 7                         */
-    uint8_t  reserved;
+    uint8_t  run;                /* further bases with the same code (0..255) */
 } bk_nbase;                      /* 8 bytes */
 /* number of words the packed form of these reads takes */
 uint64_t bk_packed_words(const uint32_t *lens, uint32_t nreads);

@@ -88,6 +88,8 @@ def test_host_packer_round_trip(lib):
         tot = int(lens.sum())
         bases = rng.integers(0, 4, size=tot).astype(np.uint8)
         if tot:
+            if n:
+                bases[100:700] = 4                                # a run longer than one entry holds, inside the 2000-base read
             bases[rng.choice(tot, min(tot, 50), replace=False)] = 4
             bases[rng.choice(tot, min(tot, 5), replace=False)] = 6
         raw = bases | (rng.integers(0, 32, size=tot).astype(np.uint8) << 3)
@@ -104,7 +106,10 @@ def test_host_packer_round_trip(lib):
             plain = bases < 4
             assert np.array_equal(got[plain], bases[plain])
             e_idx = np.nonzero(~plain)[0]
-            assert len(exc) == len(e_idx)
-            assert np.array_equal(exc["read"], read_of[e_idx]) and np.array_equal(exc["pos"], pos[e_idx]) and np.array_equal(exc["code"], bases[e_idx])
+            # the exceptions come as runs: expand them
+            rr = np.repeat(exc["read"], exc["run"].astype(np.int64) + 1)
+            pp = np.concatenate([np.arange(int(e["pos"]), int(e["pos"]) + int(e["run"]) + 1) for e in exc]) if len(exc) else np.zeros(0, np.int64)
+            cc = np.repeat(exc["code"], exc["run"].astype(np.int64) + 1)
+            assert np.array_equal(rr, read_of[e_idx]) and np.array_equal(pp, pos[e_idx]) and np.array_equal(cc, bases[e_idx])
     with pytest.raises(bk.BkError):
         bk.pack_reads(np.zeros(2001, np.uint8), None, np.array([2001], np.uint32))

@@ -205,8 +205,79 @@ static int atomic_bench()
             }
     return 0;
 }
+// "runs": what a suffix-ordered copy of the target windows would buy the wave kernel.  Today a candidate costs a coalesced 4-byte
+// suffix array element plus ONE RANDOM 64-byte line (its 25-byte window in the 2-bit target).  With the windows of all suffixes
+// stored in suffix array order (48 bytes each) the candidates of one core interval are a contiguous run: a wave reads 64 entries
+// = 3 KB per round from a random place of a 140 GB array.  k_runs: one wave per run of `rounds` x 64 entries, each lane its
+// entry's three 16-byte words; k_lines: the same number of candidates as random 64-byte lines out of a 1.5 GB table (+ the
+// coalesced element).
+__global__ void __launch_bounds__(256) k_runs(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int rounds, int runs_per_wave)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
+    for (int r = 0; r < runs_per_wave; r++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t start = (x >> 16) % (n_entries - (uint64_t)rounds * 64);
+        for (int k = 0; k < rounds; k++) {
+            const uint4 *e = tab + (start + (uint64_t)k * 64 + lane) * 3;
+            const uint4 a = e[0], b = e[1], c = e[2];
+            acc += a.x ^ b.y ^ c.z;
+        }
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_lines(const uint4 *__restrict__ tab, uint64_t n_lines, const uint32_t *__restrict__ sa, uint64_t n_sa, uint64_t *out,
+                                               int rounds, int runs_per_wave)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
+    for (int r = 0; r < runs_per_wave; r++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t start = (x >> 16) % (n_sa - (uint64_t)rounds * 64);
+        for (int k = 0; k < rounds; k++) {
+            const uint64_t t = ((uint64_t)sa[start + (uint64_t)k * 64 + lane] * 0x9E3779B97F4A7C15ULL >> 20) % n_lines;
+            const uint4 *e = tab + t * 4;
+            const uint4 a = e[0], b = e[1];
+            acc += a.x ^ b.y;
+        }
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+static int runs_bench()
+{
+    const uint64_t n_entries = 2900000000ULL;                 // x 48 B = 139 GB
+    uint4 *tab; uint64_t *out; uint32_t *sa;
+    if (hipMalloc(&tab, n_entries * 48) != hipSuccess) { printf("runs: cannot allocate %llu GB\n", (unsigned long long)(n_entries * 48 >> 30)); return 1; }
+    hipMalloc(&out, 8);
+    const uint64_t n_sa = 1ULL << 30;
+    hipMalloc(&sa, n_sa * 4);
+    hipMemset(sa, 0x5a, n_sa * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rounds : {1, 2, 4, 16, 64}) {
+        for (int waves : {8192, 16384}) {
+            const int rpw = 4096 / rounds;
+            float ms = 0;
+            hipLaunchKernelGGL(k_runs, dim3(waves / 4), dim3(256), 0, 0, tab, n_entries, out, rounds, rpw);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_runs, dim3(waves / 4), dim3(256), 0, 0, tab, n_entries, out, rounds, rpw);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            const double cands = (double)waves * rpw * rounds * 64;
+            printf("runs: %2d rounds per run, %5d waves: %6.1f G candidates/s (%5.2f TB/s of 48-byte entries)\n", rounds, waves, cands / ms / 1e6, cands * 48 / ms / 1e9);
+            hipLaunchKernelGGL(k_lines, dim3(waves / 4), dim3(256), 0, 0, tab, (3ULL << 29) / 64, sa, n_sa, out, rounds, rpw);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_lines, dim3(waves / 4), dim3(256), 0, 0, tab, (3ULL << 29) / 64, sa, n_sa, out, rounds, rpw);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("lines:%2d rounds per run, %5d waves: %6.1f G candidates/s (random 64-byte line + coalesced element each)\n", rounds, waves, cands / ms / 1e6);
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "runs") return runs_bench();
     if (argc > 1 && std::string(argv[1]) == "atomic") return atomic_bench();
     if (argc > 1 && std::string(argv[1]) == "calib") return calib();
     if (argc > 1 && std::string(argv[1]) == "bin") return bin_bench();
