@@ -450,23 +450,26 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
         ramp.append(at)
         sz = min(B, 2 * sz)
     cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
+    # .. and the last step ramps down the same way: the download of the very last batch has nothing to hide behind either
+    down = sorted({n - c for c in ramp})
+    cuts9 = [c for c in cuts if c < down[0]] + down
     log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step "
-        f"(first step: {len(cuts0) - 1} batches from {cuts0[1]} reads up)")
+        f"(first step: {len(cuts0) - 1} batches from {cuts0[1]} reads up; last step: {len(cuts9) - 1} batches down to {n - cuts9[-2]})")
     result = {}
     with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
         exc_of = {}
         if packed:
             er = p_exc["read"]
-            for lo, hi in set(zip(cuts0[:-1], cuts0[1:])) | set(zip(cuts[:-1], cuts[1:])):
+            for lo, hi in set(zip(cuts0[:-1], cuts0[1:])) | set(zip(cuts[:-1], cuts[1:])) | set(zip(cuts9[:-1], cuts9[1:])):
                 a, z = np.searchsorted(er, lo), np.searchsorted(er, hi)
                 e = bk.host_array(max(1, z - a), bk.NBASE_DTYPE)[: z - a]
                 e[:] = p_exc[a:z]
                 e["read"] -= lo                                      # exception read numbers are batch-relative
                 exc_of[(lo, hi)] = e
 
-        def one_step(k, first=False):
+        def one_step(k, first=False, last=False):
             out = h_out[k & 1]
-            cc = cuts0 if first else cuts
+            cc = cuts0 if first else (cuts9 if last else cuts)
             if packed:
                 return [st.submit_packed(p_words[lo * wpr: hi * wpr], p_lens16[lo:hi], exc_of[(lo, hi)], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
             return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
@@ -478,7 +481,7 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
         t_start = time.time()
         tickets = []
         for k in range(args.stream_steps):
-            tickets += one_step(k, first=(k == 0))
+            tickets += one_step(k, first=(k == 0), last=(k == args.stream_steps - 1 and k > 0))
             # keep at most one step of tickets un-waited so that the two result buffers are never overwritten early
             while len(tickets) > len(cuts) - 1:
                 st.wait(tickets.pop(0))

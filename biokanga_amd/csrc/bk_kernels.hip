@@ -2037,9 +2037,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 // one per lane - suffix array load, window compare, one result byte in LDS (mismatch count, or
 // "skip": off the read's start / unverified bucket member that does not match / crosses an entry
 // boundary / already reached through an earlier core).  The Low/NxtLow/instances outcome of a read is
-// then reduced over its candidates' lanes (4-byte indexes; the state machine is order-independent up to
-// its early exit, whose reads - and every read of a 5-byte index, where the truncated-key rule makes a
-// candidate depend on the ones before it - are replayed in order by their own lane).
+// then reduced over its candidates' lanes (the state machine is order-independent up to its early exit,
+// whose reads are replayed in order by their own lane; on 5-byte indexes the reference's truncated-key
+// rule - a candidate is taken for seen when an earlier one of the strand pass has the same low word - is
+// applied first, as a pass over the candidates' lanes).
 // In k_light a lane walked all candidates of its read itself, so a wave ran as long as its read with
 // the most candidates (up to 4 x 64) while the typical read has one or two.
 // Valid while no interval is longer than 100: then the reference's IterCnt==100 copy-count check and
@@ -2091,7 +2092,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     // the per-read outcome is reduced over the candidates' lanes (4-byte indexes): smallest (mismatches << 16 | candidate number) of
     // the acceptable candidates, how many share that mismatch count (low half) and how many were looked at (high half), and the
     // smallest count above it.  One lane per read walking its own bytes made a wave wait for its read with the most candidates.
-    __shared__ uint32_t s_k1[WIDE ? 1 : BS], s_c2[WIDE ? 1 : BS], s_nx[WIDE ? 1 : BS];
+    __shared__ uint32_t s_k1[BS], s_c2[BS], s_nx[BS];
     __shared__ uint8_t s_mm[BS];                         // bit st: the read's strand-st row holds an N (the 4-bit compare decides its windows)
     __shared__ uint8_t s_rec[CAP];
     __shared__ uint4 s_row[ROWS ? BS * 2 * (NW / 4) : 1];  // [read][strand]: NW/2 words at 2 bit/base
@@ -2199,7 +2200,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     }
     PROF(0);
     if (ent_lds && t < ix.n_ent) { s_es[t] = (EntT)es_v; s_ee[t] = (EntT)ee_v; }
-    if (!WIDE) { s_k1[t] = 0xFFFFFFFFu; s_c2[t] = 0; s_nx[t] = 0xFFFFFFFFu; }
+    s_k1[t] = 0xFFFFFFFFu; s_c2[t] = 0; s_nx[t] = 0xFFFFFFFFu;
     s_mm[t] = (uint8_t)(mm < 255 ? mm : 255);
     s_r[t] = r; s_geo[t] = (uint32_t)len | ((uint32_t)cl << 10) | ((uint32_t)cd << 20);
     // block-wide exclusive prefix sum of the candidate counts
@@ -2355,24 +2356,14 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             const uint16_t *sp = s_sp + t * slots_max;
             const uint32_t rb = s_off[t] - base;
             bool done = false;
-            uint32_t prev = 0, strand_first = 0;
-            uint64_t bloom[4] = {0, 0, 0, 0};                                // of the low words seen in this strand pass: the scan below is for its hits only
+            uint32_t prev = 0;
             for (int q = 0; q < slots_max && !done; q++) {
                 if ((q >= cmaxs ? q - cmaxs : q) >= nc) continue;           // not a core of this read (an empty slot)
                 n_search++;
-                if (WIDE && q == cmaxs) { strand_first = prev; bloom[0] = bloom[1] = bloom[2] = bloom[3] = 0; }    // the second strand pass starts with an empty set
                 const uint32_t upto = sp[q];
                 for (uint32_t x = prev; x < upto; x++) {
                     const int cm = s_rec[rb + x];
                     if (cm == kRecSkip) continue;
-                    if (WIDE) {
-                        const uint32_t kx = s_key[rb + x], hb = (kx * 2654435761u) >> 24;
-                        bool seen = false;
-                        if ((bloom[hb >> 6] >> (hb & 63)) & 1)
-                            for (uint32_t y = strand_first; y < x; y++) seen |= s_rec[rb + y] != kRecSkip && s_key[rb + y] == kx;
-                        if (seen) continue;
-                        bloom[hb >> 6] |= 1ULL << (hb & 63);
-                    }
                     n_cand++;
                     if (cm > mm || cm >= nxt) continue;
                     if (cm < low_mm) {
@@ -2388,8 +2379,43 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             }
         };
         if (WIDE) {
-            if (mine && t >= start && t < end) replay_sequential();
-        } else {
+            // 5-byte indexes: the reference keys its set of seen targets by the target start truncated to 32 bits (SfxArrayV2.cpp:5932): a
+            // candidate is taken for seen when an earlier candidate of the same strand pass (inside its entry, a match of its core) has
+            // the same low word.  That depends on the candidates' positions only, so it is a pass of its own over the candidates'
+            // lanes, in front of the reduction.  (A candidate marked here while another lane still scans past it changes nothing: the
+            // first candidate with a key is never marked, and every later one finds it.)
+            for (uint32_t f = t; f < total; f += BS) {
+                if (s_rec[f] == kRecSkip) continue;
+                const uint32_t g = base + f;
+                uint32_t l2 = start, h2 = end - 1;
+                while (l2 < h2) {
+                    uint32_t mid = (l2 + h2 + 1) >> 1;
+                    if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
+                }
+                const uint32_t rb = s_off[l2] - base, local = f - rb;
+                const uint32_t second = (s1 > s0) ? (uint32_t)s_sp[l2 * slots_max + cmaxs - 1] : 0xFFFFFFFFu;      // first candidate of the second strand pass
+                const uint32_t from = local >= second ? second : 0u;
+                const uint32_t kx = s_key[f];
+                bool seen = false;
+                for (uint32_t y = from; y < local && !seen; y++) seen = s_rec[rb + y] != kRecSkip && s_key[rb + y] == kx;
+                if (seen) s_rec[f] = kRecSkip;
+            }
+            __syncthreads();
+            for (uint32_t f = t; f < total; f += BS) {
+                const uint8_t rec = s_rec[f];
+                if (rec == kRecSkip) continue;
+                const uint32_t g = base + f;
+                uint32_t l2 = start, h2 = end - 1;
+                while (l2 < h2) {
+                    uint32_t mid = (l2 + h2 + 1) >> 1;
+                    if (s_off[mid] <= g) l2 = mid; else h2 = mid - 1;
+                }
+                atomicAdd(&s_c2[l2], 1u << 16);
+                if (rec <= s_mm[l2]) atomicMin(&s_k1[l2], ((uint32_t)rec << 16) | (g - s_off[l2]));
+            }
+            __syncthreads();
+        }
+        {
             // second pass over the candidates: how many reach the read's smallest count, and the smallest count above it
             for (uint32_t f = t; f < total; f += BS) {
                 const int cm = s_rec[f];
@@ -2574,6 +2600,30 @@ __device__ __forceinline__ bool same_key_earlier_in_round(bool cand, uint32_t ke
     return dup;
 }
 
+// the wave kernel's LDS set of seen keys (HASH form)
+constexpr uint32_t kLdsSet = 2048, kLdsSetFill = 1536, kLdsEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ bool lset_contains(const uint32_t *set, uint32_t key)
+{
+    uint32_t h = hash_key(key, kLdsSet - 1);
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v == kLdsEmpty) return false;
+        if (v == key) return true;
+        h = (h + 1) & (kLdsSet - 1);
+    }
+}
+
+__device__ __forceinline__ void lset_insert(uint32_t *set, uint32_t key)
+{
+    uint32_t h = hash_key(key, kLdsSet - 1);
+    for (;;) {
+        const uint32_t old = atomicCAS(&set[h], kLdsEmpty, key);
+        if (old == kLdsEmpty || old == key) return;
+        h = (h + 1) & (kLdsSet - 1);
+    }
+}
+
 constexpr int kWaveGrab = 8;
 
 struct WaveCoreInfo {
@@ -2596,10 +2646,17 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 {
     __shared__ WaveCoreInfo s_core[4][kMaxCoresFast];
     __shared__ uint64_t s_cmask[4][kMaxCoresFast][NW / 4];       // per core: its bases in the IWindow layout
+    // HASH: the set of seen target keys of a strand pass lives in LDS (kLdsSet keys per wave, open addressing) and spills into the
+    // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
+    // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
+    __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
     uint64_t (*cmask)[NW / 4] = s_cmask[wib];
+    uint32_t *lset = s_set[HASH ? wib : 0];
+    uint32_t lset_n = kLdsSet;                   // keys in the LDS set (kLdsSet: not cleared yet)
+    bool spilled = false;                        // this strand pass has keys in the HBM table as well
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     unsigned long long *tab = nullptr;
     uint32_t tmask = 0, epoch = 0;
@@ -2672,11 +2729,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         }
         for (int st = s0; st <= s1 && !done; st++) {
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
-                epoch++;
-                if (epoch == 0) {            // wrapped: really clear the table
-                    for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
-                    epoch = 1;
+                if (lset_n) {
+                    for (uint32_t i = lane; i < kLdsSet; i += 64) lset[i] = kLdsEmpty;
+                    lset_n = 0;
+                    __builtin_amdgcn_wave_barrier();
                 }
+                spilled = false;             // (the HBM table gets its new epoch when a pass first spills into it)
             }
             // the read's row (the same for the whole wave: scalar registers).  Lean batches hold 2 bit/base rows; the 4-bit words a
             // flagged window needs are widened from them, or - a read with an N - come from its rd4 row together with its N positions
@@ -2760,7 +2818,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     bool dup = false;
                     const uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
                     if (HASH) {
-                        dup = valid && htab_contains(tab, tmask, epoch, key);
+                        dup = valid && lset_n != 0 && lset_contains(lset, key);
+                        if (spilled) dup = dup || (valid && htab_contains(tab, tmask, epoch, key));
                         if (WIDE) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
                     } else for (int c2 = 0; c2 < c; c2++) {
                         bool m = valid && !dup && im_clean<NW>(w.im, cmask[c2]);
@@ -2797,7 +2856,28 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         }
                     }
                     const bool proc = active && j < cutoff && isnew;
-                    if (HASH && proc) htab_insert(tab, tmask, epoch, key);
+                    if (HASH) {
+                        const uint32_t nins = (uint32_t)__popcll(__ballot(proc));
+                        if (nins) {
+                            // (the key that looks like an empty slot, one in 2^32, always goes to the HBM table)
+                            const bool to_lds = lset_n + nins <= kLdsSetFill;
+                            if ((!to_lds || __ballot(proc && key == kLdsEmpty)) && !spilled) {
+                                spilled = true;
+                                epoch++;
+                                if (epoch == 0) {            // wrapped: really clear the table
+                                    for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
+                                    epoch = 1;
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            }
+                            if (proc) {
+                                if (to_lds && key != kLdsEmpty) lset_insert(lset, key);
+                                else htab_insert(tab, tmask, epoch, key);
+                            }
+                            if (to_lds) lset_n += nins;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
                     int cm = (proc && w.mm <= mm && w.mm < nxt) ? w.mm : 127;
                     bool acc = cm != 127;
                     uint64_t keep = ~0ULL;
