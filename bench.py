@@ -664,12 +664,14 @@ def main():
     torch.cuda.synchronize()
     log(f"reads: {args.reads} x {args.read_len} bp generated in {time.time() - t0:.1f}s")
     keep_index_for_baseline = args.cpu_baseline_secs > 0 and rank == 0 and world == 1
+    # the context holds its own image; the bench's copy of the suffix array (12 GB at 3.1 Gbp, 85 GB at 17 Gbp; with 5-byte elements
+    # the sequence too) leaves the HBM before the batch scratch - and the context's window array - are sized
+    t0 = time.time()
+    sa = sa.cpu() if keep_index_for_baseline else None
     if E == 5:
-        # the context holds its own image; the bench's copies (17 + 85 GB at 17 Gbp) leave the HBM before the batch scratch is sized
-        t0 = time.time()
-        seq, sa = (seq.cpu(), sa.cpu()) if keep_index_for_baseline else (None, None)
-        torch.cuda.empty_cache()
-        log(f"index copies moved off the device in {time.time() - t0:.0f}s")
+        seq = seq.cpu() if keep_index_for_baseline else None
+    torch.cuda.empty_cache()
+    log(f"index copies moved off the device in {time.time() - t0:.0f}s")
 
     def run_step(bases, offs, lens, nreads, dst):
         al.align_device(bases.data_ptr(), offs.data_ptr(), lens.data_ptr(), nreads, dst.data_ptr())
@@ -756,6 +758,15 @@ def main():
     ach = kern[dom]["GBs"]
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
     default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
+    # everything below runs in child processes (counter passes under rocprofv3, the command lines): this process hands its HBM back first
+    if keep_index_for_baseline:
+        seq = seq.cpu() if seq is not None else None
+        rd_bases = rd_bases.cpu()
+    al.close()
+    del out, rd_offs, rd_lens, counts_dev
+    if not keep_index_for_baseline:
+        del rd_bases, seq
+    torch.cuda.empty_cache()
     traffic, traffic_src = (None, None)
     if rank == 0 and world == 1 and not args.no_live_traffic and E == 4:       # (two more 17 Gbp set-ups would take minutes)
         child_args = ["--config", args.config, "--reads", str(args.reads), "--genome-mbp", str(args.genome_mbp)] + \

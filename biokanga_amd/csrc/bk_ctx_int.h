@@ -57,6 +57,8 @@ struct bk_ctx {
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
+    void *d_swin = nullptr;               // suffix-ordered window array (DevIndex::swin), built when the first batch it serves arrives
+    int use_swin = 1;
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;
@@ -74,7 +76,7 @@ struct bk_ctx {
     std::vector<bk_snp_site> snp_sites;
 
     // batch scratch (grown on demand)
-    uint32_t cap_reads = 0, cap_wpr = 0;
+    uint32_t cap_reads = 0, cap_wpr = 0, cap_iv_cores = 0;
     uint64_t *d_rd4 = nullptr, *d_iv_first = nullptr;
     uint2 *d_iv2 = nullptr;
     uint32_t *d_iv_n = nullptr, *d_act[2] = {nullptr, nullptr}, *d_heavy = nullptr, *d_wave = nullptr;

@@ -48,6 +48,7 @@ constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)
 constexpr uint32_t kNodeCap = 1024000; // cMaxNumIdentNodes, SfxArrayV2.h:15
 constexpr uint64_t kEosWord = 0x7777777777777777ULL;
+constexpr int kSwBases = 192, kSwPre = 92, kSwLen = 100;      // DevIndex::swin
 constexpr uint32_t kReadHasN = 1u << 15;   // DevBatch::rmeta
 constexpr uint32_t kReadLenMask = kReadHasN - 1;
 
@@ -68,6 +69,11 @@ struct DevIndex {
     const uint64_t *ktab64;
     const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
+    const uint4 *swin;          // suffix-ordered windows: for every suffix array index i the kSwBases bases of the 2-bit target from
+                                //   sa[i] - kSwPre on, 48 bytes each.  The candidates of a core interval - consecutive suffix array
+                                //   elements - then fetch their target windows from CONSECUTIVE entries (a streaming read, 130 G
+                                //   entries/s) instead of one random cache line each (50 G/s).  Reads of up to kSwLen bases whose
+                                //   core offsets stay within kSwPre; 4-byte indexes with 48 bytes per base of HBM to spare; may be null
     uint64_t n;                 // concat_len
     uint32_t n_ent;
     int k;                      // k-mer table order (0 = none)
@@ -105,6 +111,7 @@ struct DevBatch {
     uint32_t wpr;
     uint32_t n_reads;
     uint32_t nw;                // 4-bit words covered by an rd2 row (8 or 16), 0 without rd2
+    uint32_t iv_cores;          // cores per strand the interval slots are numbered for (<= kMaxCoresFast: the most a read of this batch can have)
 };
 
 struct HeavyScratch {

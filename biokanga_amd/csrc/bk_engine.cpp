@@ -49,6 +49,7 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
+void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
@@ -423,10 +424,11 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
     return BK_OK;
 }
 
-int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2w = 0)
+int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2w = 0, uint32_t iv_cores = kMaxCoresFast)
 {
-    if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w) return BK_OK;
+    if (n_reads <= c->cap_reads && wpr <= c->cap_wpr && rd2w <= c->cap_rd2w && iv_cores <= c->cap_iv_cores) return BK_OK;
     uint32_t nr = std::max(n_reads, c->cap_reads), w = std::max(wpr, c->cap_wpr), w2 = std::max(rd2w, c->cap_rd2w);
+    const uint32_t ivc = std::max(iv_cores, c->cap_iv_cores);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_rd2); free_dev(c->d_iv2); free_dev(c->d_rmeta);
     c->d_rmeta = nullptr;
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work);
@@ -438,12 +440,12 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     c->cap_reads = 0;
     HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
     if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8 + 64));        // (+ the words a 32-base fetch at a row's end runs into)
-    HIP_TRY(hipMalloc(&c->d_rmeta, (size_t)nr * 4));
+    HIP_TRY(hipMalloc(&c->d_rmeta, ((size_t)nr + 2) / 2 * 8));
     if (c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32))
-        HIP_TRY(hipMalloc(&c->d_iv2, (size_t)nr * 2 * kMaxCoresFast * 8));
+        HIP_TRY(hipMalloc(&c->d_iv2, (size_t)nr * 2 * ivc * 8));
     else {
-        HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * kMaxCoresFast * 8));
-        HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * kMaxCoresFast * 4));
+        HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * ivc * 8));
+        HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * ivc * 4));
     }
     HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
     HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
@@ -459,6 +461,7 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     c->cap_reads = nr;
     c->cap_wpr = w;
     c->cap_rd2w = w2;
+    c->cap_iv_cores = ivc;
     return BK_OK;
 }
 
@@ -527,9 +530,19 @@ static inline uint32_t words_per_read(uint32_t maxlen)
 }
 
 // per-read bytes of batch scratch (packed fwd+revcomp rows, core intervals, work lists)
-static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 12)
+// the most cores per strand a read of up to maxlen bases can have (LocateCoreMultiples' MaxNumSlides), capped at what the
+// interval-slot kernels take
+static inline uint32_t iv_cores_for(const bk_ctx *c, uint32_t maxlen)
 {
-    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * kMaxCoresFast * 20 + 10 * 4 + 16;
+    const uint32_t ms = std::max(1u, ((uint32_t)c->cfg.slides_per100 * maxlen + 99) / 100);
+    return std::min<uint32_t>(ms, kMaxCoresFast);
+}
+
+// per-read bytes of batch scratch: packed rows in both forms, interval records, work lists (reads, search items and their striped
+// forms), sort buffers
+static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 8, uint32_t iv_cores = kMaxCoresFast)
+{
+    return 2ULL * wpr * 8 + 2ULL * rd2w * 8 + 2ULL * iv_cores * (12 + 8) + 52 + 24;
 }
 
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
@@ -648,7 +661,8 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     const bool reg_path = c->use_wave && maxlen <= 256;
     const int nw16 = maxlen <= 128 ? 8 : 16;
     const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
-    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u);
+    const uint32_t ivc = iv_cores_for(c, maxlen);
+    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u, ivc);
     if (rc) return rc;
 
     DevBatch b{};
@@ -662,7 +676,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     b.iv32 = (c->use_iv32 && c->ix.k2 && c->search_ilp >= 2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
-    b.wpr = wpr; b.n_reads = n;
+    b.wpr = wpr; b.n_reads = n; b.iv_cores = ivc;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
 
     hipEvent_t e0 = tm.begin(s);
@@ -704,8 +718,8 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                 }
                 // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
                 for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 8, s));
-                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * kMaxCoresFast * n, (size_t)cmax * n * 4, s));
+                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * ivc * n, (size_t)cmax * n * 8, s));
+                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * ivc * n, (size_t)cmax * n * 4, s));
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
                                 c->d_slist_stage, c->d_stripe_cnt, s);
                 HIP_TRY(hipGetLastError());
@@ -835,6 +849,30 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     return BK_OK;
 }
 
+// The suffix-ordered window array (DevIndex::swin, 48 bytes per suffix) is built when the first batch it can serve arrives - reads of up
+// to kSwLen bases whose core offsets stay within kSwPre - and only if, next to it, the HBM still holds this batch's scratch with room to
+// spare: it trades capacity (149 GB for a 3.1 Gbp index on a 288 GB device) for locality.
+int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
+{
+    if (c->d_swin || !c->use_swin || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;
+    if (c->use_swin < 2 && (maxlen > (uint32_t)kSwLen || (int)maxlen - c->cfg.min_core_len > kSwPre)) return BK_OK;       // (2: whatever the batch - its short reads use it)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t need = c->ix.n * 48;
+    const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
+    const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);
+    const uint64_t missing = want > have ? want - have : 0;
+    if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) return BK_OK;  // (the chunk size is set from 3/4 of the free memory)
+    StageClock clk;
+    if (hipMalloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; return BK_OK; }
+    launch_build_swin(c->ix, c->d_swin, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
+    clk.lap("suffix-ordered windows");
+    return BK_OK;
+}
+
 int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s)
 {
     const uint32_t *d_lens = in.lens;
@@ -853,15 +891,16 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     if ((int)maxlen > c->max_read_len) {
         c->max_read_len = (int)maxlen;
     }
+    { int rw = maybe_build_swin(c, maxlen, nreads, s); if (rw) return rw; }
     // chunk size: as many reads as the knob allows and as fit in about half of the HBM still free
     // (the phase kernels run better the more reads they see: fewer launches, shorter tails)
     uint32_t chunk = c->chunk_reads;
     {
-        const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen));
+        const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr);
-        uint64_t fit = ((uint64_t)free_b + have) / 2 / per_read;
+        const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);
+        uint64_t fit = ((uint64_t)free_b + have) / 4 * 3 / per_read;
         if (fit < 65536) fit = 65536;
         if (fit < chunk) chunk = (uint32_t)fit;
         if (chunk > (1u << 27)) chunk = 1u << 27;       // 32 interval slots per read are indexed with 32 bits
@@ -955,7 +994,7 @@ int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_h
     b.rd4 = c->d_rd4; b.iv_first = c->d_iv_first; b.iv_n = c->d_iv_n; b.iv2 = c->d_iv2;
     b.rmeta = c->d_rmeta;
     b.out = d_hits; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
-    b.wpr = wpr; b.n_reads = nreads;
+    b.wpr = wpr; b.n_reads = nreads; b.iv_cores = c->cap_iv_cores ? c->cap_iv_cores : kMaxCoresFast;
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
     launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, d_hits, n_pairs,
               c->d_heavy, c->d_small, c->h_small, s);
@@ -1116,6 +1155,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
     dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);
     dup(c->d_nflag, src->d_nflag, src->nflag_bytes);
+    c->use_swin = src->use_swin;                                      // (the window array is built here when the first batch asks for it)
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; rc = BK_ERR_INTERNAL; }
     if (!ok) { bk_ctx_destroy(c); return rc; }
     c->ix.tgt4 = c->d_tgt4; c->ix.sa_lo = c->d_sa_lo; c->ix.sa_hi = c->d_sa_hi;
@@ -1139,7 +1179,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
     free_dev(c->d_stripe_cnt);
-    free_dev(c->d_isa); free_dev(c->d_seg2); free_dev(c->d_seq_global);
+    free_dev(c->d_isa); free_dev(c->d_swin); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     free_dev(c->d_in_words); free_dev(c->d_in_lens16); free_dev(c->d_in_exc); free_dev(c->d_scan_tmp); free_dev(c->d_ctr_aux);
@@ -1213,6 +1253,17 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->wave_waves;
         if (value < 64 || value > 65536) return BK_ERR_PARAMS;
         c->wave_waves = (uint32_t)value;
+        return old;
+    }
+    if (n == "use_swin") {
+        int64_t old = c->use_swin;
+        c->use_swin = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        if (!c->use_swin && c->d_swin) {
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            free_dev(c->d_swin);
+            c->d_swin = nullptr;
+            c->ix.swin = nullptr;
+        }
         return old;
     }
     if (n == "use_isa") {
@@ -1407,12 +1458,12 @@ int bk_align_batch_packed(bk_ctx *c, const uint32_t *words, uint64_t n_words, co
     if (!nreads) return BK_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (n_words + 1 > c->cap_in_words) {
+    if (n_words + 16 > c->cap_in_words) {                   // (the read preparation loads up to 16 words from a read's first one)
         free_dev(c->d_in_words);
         c->d_in_words = nullptr;
         c->cap_in_words = 0;
-        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + 1) * 4));
-        c->cap_in_words = n_words + 1;
+        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + 16) * 4));
+        c->cap_in_words = n_words + 16;
     }
     if (n_exc > c->cap_in_exc) {
         free_dev(c->d_in_exc);

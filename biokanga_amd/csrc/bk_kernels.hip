@@ -92,7 +92,7 @@ __device__ __forceinline__ RdRow read_row(const DevBatch &b, uint32_t r, int str
 // neighbouring reads touch neighbouring words
 __device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t r, int st, int c)
 {
-    return (uint64_t)(st * kMaxCoresFast + c) * b.n_reads + r;
+    return (uint64_t)(st * (int)b.iv_cores + c) * b.n_reads + r;
 }
 
 // core interval records.  4-byte indexes keep {start, count} of a slot in ONE 8-byte word (b.iv2), so every
@@ -558,26 +558,30 @@ __device__ __forceinline__ uint32_t packed_word16(const uint32_t *__restrict__ W
     return ~rev2_32(x) & keep;
 }
 
-// reverse complement of a read held as W words of 32 bases (first base in the top bits, zero beyond its end)
+// reverse complement of a read held as W words of 32 bases (first base in the top bits, zero beyond its end).  Straight-line code:
+// the word shift is a cascade of selects, one per bit of the shift count (a version that copied t[] into place under
+// `if (shift == k)` inside an unrolled loop came out of hipcc 7.2 reading registers it had never written - rows wrong only in
+// the blocks that did not start on a freshly zeroed register file; tools/prep_check.hip)
 template <int W>
 __device__ __forceinline__ void revcomp2(const uint64_t (&f)[W], int len, uint64_t (&r)[W])
 {
-    uint64_t t[W + 1], u[W + 1];
+    uint64_t v[W + 1];
 #pragma unroll
-    for (int i = 0; i < W; i++) t[i] = ~rev2_64(f[W - 1 - i]);      // the whole row reversed: the read now ends flush with the row's end
-    t[W] = 0;
-    const int sh = 2 * (32 * W - len), q = sh >> 6;
+    for (int i = 0; i < W; i++) v[i] = ~rev2_64(f[W - 1 - i]);      // the whole row reversed: the read now ends flush with the row's end
+    v[W] = 0;
+    const int sh = 2 * (32 * W - len), q = sh >> 6;                 // shift left by q words and bsh bits: 0 <= q <= W
     const unsigned bsh = (unsigned)(sh & 63);
 #pragma unroll
-    for (int i = 0; i <= W; i++) u[i] = 0;
+    for (int step = 1; step <= W; step <<= 1) {
+        const bool on = (q & step) != 0;
+        uint64_t nv[W + 1];
 #pragma unroll
-    for (int qq = 0; qq < W; qq++)
-        if (q == qq) {
+        for (int i = 0; i <= W; i++) nv[i] = on ? (i + step <= W ? v[i + step <= W ? i + step : W] : 0ULL) : v[i];
 #pragma unroll
-            for (int i = 0; i + qq <= W; i++) u[i] = t[i + qq];
-        }
+        for (int i = 0; i <= W; i++) v[i] = nv[i];
+    }
 #pragma unroll
-    for (int i = 0; i < W; i++) r[i] = bsh ? ((u[i] << bsh) | (u[i + 1] >> (64 - bsh))) : u[i];
+    for (int i = 0; i < W; i++) r[i] = bsh ? ((v[i] << bsh) | (v[i + 1] >> (64 - bsh))) : v[i];
 }
 
 // exceptions of a packed batch, one lane each.  k_mark_exc counts them into the reads' meta words BEFORE the read preparation runs
@@ -770,12 +774,15 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
         int num_ns = 0;
         bool bad = false;
         if (PACKED) {
+            // (all NW words are loaded whatever the read's length - straight-line loads, no exec-masked ones in an unrolled loop: see
+            // DESIGN.md on hipcc 7.2; the words buffer is followed by NW more words, and what lies behind the read is masked off)
             const uint32_t *__restrict__ W = b.pk_words + b.offs[r];
-            const int nwr = (len + 15) >> 4;
+            uint32_t wv[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) wv[k] = W[k];
 #pragma unroll
             for (int k = 0; k < NW / 2; k++) {
-                const uint32_t hi = 2 * k < nwr ? W[2 * k] : 0u, lo = 2 * k + 1 < nwr ? W[2 * k + 1] : 0u;
-                uint64_t v = ((uint64_t)hi << 32) | lo;
+                uint64_t v = ((uint64_t)wv[2 * k] << 32) | wv[2 * k + 1];
                 const int rem = len - 32 * k;                       // bases of the read in this word
                 if (rem < 32) v = rem <= 0 ? 0ULL : (v & (~0ULL << (64 - 2 * rem)));
                 f2[k] = v;
@@ -1361,7 +1368,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
 #endif
     const uint64_t slot = list[i];
     const uint32_t r = (uint32_t)(slot % b.n_reads), sc = (uint32_t)(slot / b.n_reads);
-    const int strand = (int)(sc / kMaxCoresFast), c = (int)(sc % kMaxCoresFast);
+    const int strand = (int)(sc / b.iv_cores), c = (int)(sc % b.iv_cores);
     const uint32_t meta = b.rmeta[r];
     const int len = (int)(meta & kReadLenMask);
     ReadPlan p = make_plan(len, cfg);
@@ -1889,6 +1896,80 @@ __device__ __forceinline__ void eval_window2i(const uint64_t (&r2w)[NW / 2], con
     }
     w.mm = mm;
     w.eos = false;
+}
+
+// eval_window2i with the window taken from the candidate's entry of the suffix-ordered window array (DevIndex::swin): the three
+// 16-byte words of entry `e`; the window starts bofs = kSwPre - (core offset) bases into it - the same for every lane of the wave.
+template <int NW>
+__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 *__restrict__ e,
+                                            int bofs, IWindow<NW> &w)
+{
+    uint64_t r[6], q[5];                                       // (reads of up to kSwLen <= 128 bases: four compare words at most)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const uint4 v = e[i];
+        r[2 * i] = ((uint64_t)v.y << 32) | v.x;
+        r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
+    }
+    const int w0 = bofs >> 5;                                  // 0..2
+    const unsigned s = (unsigned)(bofs & 31) << 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = w0 == 0 ? r[i] : (w0 == 1 ? r[i + 1] : (i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL));
+    int mm = 0;
+    uint64_t even = 0;
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+        uint64_t y = 0;
+        if (k < 4 && 32 * k < len) {
+            const uint64_t win = (q[k < 4 ? k : 0] << s) | ((q[k < 4 ? k + 1 : 0] >> 1) >> (63 - s));
+            const uint64_t x = r2w[k] ^ win;
+            y = (x | (x >> 1)) & 0x5555555555555555ULL;
+            const int rem = len - 32 * k;
+            if (rem < 32) y &= ~0ULL << (64 - 2 * rem);
+        }
+        if (k & 1) {
+            const uint32_t lo = ((uint32_t)y << 1) | (uint32_t)even, hi = ((uint32_t)(y >> 32) << 1) | (uint32_t)(even >> 32);
+            const uint64_t m = (((uint64_t)hi << 32) | lo) | rni[k >> 1];
+            w.im[k >> 1] = m;
+            mm += __popcll(m);
+        } else
+            even = y;
+    }
+    w.mm = mm;
+    w.eos = false;
+}
+
+// entry i of the suffix-ordered window array: kSwBases bases of the 2-bit target from sa[i] - kSwPre on (bases before the target's
+// start read as 0: no window that uses them passes the "candidate starts before the read does" test)
+__global__ void __launch_bounds__(256) k_build_swin(DevIndex ix, uint4 *__restrict__ swin)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t base0 = (int64_t)ix.sa_lo[i] - kSwPre;
+        uint64_t wd[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int64_t pos = base0 + 32 * k;
+            uint64_t v;
+            if (pos >= 0) {
+                const uint64_t wi = (uint64_t)pos >> 5;
+                const unsigned sh = (unsigned)(pos & 31) << 1;
+                const uint64_t a = ix.tgt2[wi], bq = ix.tgt2[wi + 1];
+                v = (a << sh) | ((bq >> 1) >> (63 - sh));
+            } else if (pos > -32)
+                v = ix.tgt2[0] >> (unsigned)(2 * (-pos));
+            else
+                v = 0;
+            wd[k] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            swin[i * 3 + q] = make_uint4((uint32_t)wd[2 * q], (uint32_t)(wd[2 * q] >> 32), (uint32_t)wd[2 * q + 1], (uint32_t)(wd[2 * q + 1] >> 32));
+    }
+}
+
+void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build_swin, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2637,7 +2718,8 @@ struct WaveCoreInfo {
 // (SfxArrayV2.cpp:5932), kept in HBM with epoch tags as in k_heavy.  This is the form for 5-byte indexes (no
 // inverse suffix array; and only the truncated keys reproduce the reference there, where two starts 2^32 apart
 // count as one) and for 4-byte indexes whose inverse suffix array was not built.
-template <int NW, bool WIDE, bool HASH>
+// SW: the index holds the suffix-ordered window array (DevIndex::swin) - reads it covers take their candidates' windows from it.
+template <int NW, bool WIDE, bool HASH, bool SW>
 __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                               const uint32_t *__restrict__ list,
                                               uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
@@ -2650,6 +2732,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
     // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
     __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
+    constexpr bool GROUP = NW > 8;               // (the 8-word form runs at five waves per SIMD with 92 registers; the group bookkeeping would cost it one)
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
@@ -2707,6 +2790,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         int hit_strand = '?';
         bool done = false;
         int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        const bool sw_read = SW && len <= kSwLen && len - cl <= kSwPre;       // every core offset of the read lies within an entry's lead
         // core geometry (same for both strands)
         int nc;
         {
@@ -2767,6 +2851,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 #pragma unroll
                 for (int k = 0; k < NW; k++) rw[k] = uniform64(spread2to4((k & 1) ? (uint32_t)r2w[k >> 1] : (uint32_t)(r2w[k >> 1] >> 32)));
             }
+            uint32_t my_cn = 0;                       // lane l < nc: suffixes in core l's interval
             if (lane < nc) {
                 uint64_t slot = iv_slot(b, r, st, lane);
                 uint64_t f;
@@ -2775,24 +2860,62 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 core[lane].first = f;
                 core[lane].n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
                 core[lane].walked = 0;
+                my_cn = cn & ~kLazyFlag;
             }
             __builtin_amdgcn_wave_barrier();
+            // GROUP: consecutive cores with small intervals share a round - one candidate per lane in walk order (core, then suffix) -
+            // instead of a round each: with a dozen cores per strand a wave otherwise spends most of its rounds on two or three
+            // candidates.  None of the reference's iteration rules can fire inside such a round (fewer than 100 candidates per core,
+            // the node cap checked before it), and a small interval is always walked to its end.
+            uint32_t pre_ex = 0;                      // GROUP: candidates of the cores before this lane's (cores counted as min(n, 65))
+            if (GROUP) {
+                uint32_t v = my_cn > 64 ? 65u : my_cn;
+                const uint32_t own = v;
+                for (int off = 1; off < 16; off <<= 1) { const uint32_t u = __shfl_up(v, off); if (lane >= off) v += u; }
+                pre_ex = v - own;
+            }
             uint32_t nodes = 0;
-            for (int c = 0; c < nc && !done && nodes < kNodeCap; c++) {
-                n_search++;
+            for (int c = 0; c < nc && !done && nodes < kNodeCap;) {
                 const uint64_t first = core[c].first;
                 const bool lazy = (core[c].n & kLazyFlag) != 0;
                 const uint64_t n = core[c].n & ~kLazyFlag;
                 const int ofs = core[c].ofs;
+                // the cores of this step: c alone (a long interval, 64 suffixes a round), or c .. ce - 1 in one round
+                int ce = c + 1;
+                uint32_t gtot = (uint32_t)(n > 64 ? 65 : n);
+                const bool grouped = GROUP && n <= 64 && nodes + 64 < kNodeCap;
+                uint32_t pre_c = 0;
+                if (GROUP && grouped) {
+                    pre_c = __shfl(pre_ex, c);
+                    const uint64_t stop_at = __ballot(lane > c && (lane >= nc || my_cn > 64 || pre_ex + my_cn - pre_c > 64));
+                    ce = stop_at ? __ffsll((unsigned long long)stop_at) - 1 : nc;
+                    gtot = __shfl(pre_ex, ce < 64 ? ce : 63) - pre_c;
+                    if (ce >= nc) gtot = __shfl(pre_ex + (my_cn > 64 ? 65u : my_cn), nc - 1) - pre_c;
+                    if (lane >= c && lane < ce) core[lane].walked = my_cn;       // (small intervals are walked whole)
+                    __builtin_amdgcn_wave_barrier();
+                }
+                int lc = c;                              // this lane's core, its suffix within the interval
+                uint64_t lfirst = first;
+                int lofs = ofs;
+                bool llazy = lazy;
+                uint32_t lj_g = 0;
+                if (GROUP && grouped) {
+                    for (int l = c + 1; l < ce; l++) lc += (__shfl(pre_ex, l) - pre_c) <= (uint32_t)lane ? 1 : 0;
+                    lj_g = (uint32_t)lane - (__shfl(pre_ex, lc) - pre_c);
+                    lfirst = core[lc].first;
+                    lofs = core[lc].ofs;
+                    llazy = (core[lc].n & kLazyFlag) != 0;
+                }
+                n_search += (unsigned long long)(ce - c);
                 uint32_t iter = 0;
                 bool copies_checked = false;
                 uint64_t walked = n;
-                for (uint64_t j0 = 0; j0 < n && !done; j0 += 64) {
-                    const uint64_t j = j0 + lane;
-                    const bool active = j < n;
-                    const uint64_t loci = active ? sa_get<WIDE>(ix, first + j) : 0;
-                    const uint64_t t = loci - (uint64_t)ofs;
-                    bool valid = active && loci >= (uint64_t)ofs;
+                for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
+                    const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
+                    const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
+                    const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
+                    const uint64_t t = loci - (uint64_t)lofs;
+                    bool valid = active && loci >= (uint64_t)lofs;
                     IWindow<NW> w;
                     w.mm = 127; w.eos = true;
 #pragma unroll
@@ -2802,7 +2925,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         // flagged window is then fetched again from the 4-bit copy
                         if (two_bit) {
                             const bool flg = window_flagged_t<WIDE>(ix, t, len);
-                            eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
+                            if (SW && sw_read) {
+                                if constexpr (SW) eval_swin2i<NW>(r2w, rni, len, ix.swin + (lfirst + j) * 3, kSwPre - lofs, w);
+                            } else
+                                eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
                             if (flg) {
                                 Window<NW> w4;
                                 eval_window<NW>(rw, len, ix.tgt4, t, w4);
@@ -2813,16 +2939,17 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             eval_window<NW>(rw, len, ix.tgt4, t, w4);
                             window_to_iwindow<NW>(w4, w);
                         }
-                        valid = !w.eos && (!lazy || im_clean<NW>(w.im, cmask[c]));
+                        valid = !w.eos && (!llazy || im_clean<NW>(w.im, cmask[lc]));
                     }
                     bool dup = false;
-                    const uint32_t key = (uint32_t)(1 + loci - (uint32_t)ofs);       // 32-bit truncation as :5932
+                    const uint32_t key = (uint32_t)(1 + loci - (uint32_t)lofs);       // 32-bit truncation as :5932
                     if (HASH) {
                         dup = valid && lset_n != 0 && lset_contains(lset, key);
                         if (spilled) dup = dup || (valid && htab_contains(tab, tmask, epoch, key));
-                        if (WIDE) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
-                    } else for (int c2 = 0; c2 < c; c2++) {
-                        bool m = valid && !dup && im_clean<NW>(w.im, cmask[c2]);
+                        // (a round against itself: two starts 2^32 apart in one interval; the same start reached through two cores of a group)
+                        if (WIDE || (GROUP && grouped)) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
+                    } else for (int c2 = 0; c2 < ce - 1; c2++) {
+                        bool m = valid && !dup && c2 < lc && im_clean<NW>(w.im, cmask[c2]);
                         if (__ballot(m)) {
                             if (m) {
                                 if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
@@ -2839,11 +2966,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
                     const uint32_t iter_before = iter + pre;
                     const uint32_t nodes_before = nodes + pre;
-                    bool stop = active && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
-                    uint64_t cutoff = n;
+                    bool stop = active && !(GROUP && grouped) && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
+                    uint64_t cutoff = (GROUP && grouped) ? 64 : n;
                     uint64_t stopmask = __ballot(stop);
                     if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
-                    if (!copies_checked) {
+                    if (!copies_checked && !(GROUP && grouped)) {
                         bool chk = active && j > 0 && iter_before == 100;
                         uint64_t chkmask = __ballot(chk);
                         if (chkmask) {
@@ -2855,7 +2982,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             }
                         }
                     }
-                    const bool proc = active && j < cutoff && isnew;
+                    const bool proc = active && ((GROUP && grouped) || j < cutoff) && isnew;
                     if (HASH) {
                         const uint32_t nins = (uint32_t)__popcll(__ballot(proc));
                         if (nins) {
@@ -2891,6 +3018,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         int cut_lane = __ffsll((unsigned long long)z) - 1;
                         keep = cut_lane >= 63 ? ~0ULL : ((2ULL << cut_lane) - 1);
                         exit_now = true;
+                        if (GROUP && grouped) n_search -= (unsigned long long)(ce - 1 - __shfl(lc, cut_lane));      // the cores behind the exit are never searched
                     }
                     uint64_t procmask = __ballot(proc) & keep;
                     uint32_t nproc = (uint32_t)__popcll(procmask);
@@ -2922,10 +3050,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             nxt = bmin;
                     }
                     if (exit_now) done = true;
-                    if (cutoff < j0 + 64) { walked = cutoff; break; }
+                    if (!(GROUP && grouped) && cutoff < j0 + 64) { walked = cutoff; break; }
                 }
-                if (lane == 0) core[c].walked = walked > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)walked;
+                if (!(GROUP && grouped) && lane == 0) core[c].walked = walked > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)walked;
                 __builtin_amdgcn_wave_barrier();
+                c = ce;
             }
         }
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
@@ -4382,7 +4511,7 @@ void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint3
         if (packed) {
             // the exception list first tells every read how many N it holds (the N policy is decided in the fused kernel), and
             // afterwards writes the codes into 4-bit rows: existing ones, or - lean batches - rows made for just these reads
-            (void)hipMemsetAsync(b.rmeta, 0, (size_t)b.n_reads * 4, s);
+            launch_fill_u64(reinterpret_cast<unsigned long long *>(b.rmeta), ((uint64_t)b.n_reads + 1) / 2, 0ULL, s);      // (rmeta is allocated in whole 8-byte words)
             if (eblocks) hipLaunchKernelGGL(k_mark_exc, dim3(eblocks), dim3(256), 0, s, b);
             if (b.nw == 8) hipLaunchKernelGGL((k_prep_fused<8, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
             else hipLaunchKernelGGL((k_prep_fused<16, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
@@ -4589,9 +4718,19 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     uint32_t waves = n_list < max_waves ? n_list : max_waves;
     if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-#define BK_WAVE(N, W, H) hipLaunchKernelGGL((k_wave<N, W, H>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
-    if (nw <= 8) { if (wide) BK_WAVE(8, true, true); else if (hash) BK_WAVE(8, false, true); else BK_WAVE(8, false, false); }
-    else { if (wide) BK_WAVE(16, true, true); else if (hash) BK_WAVE(16, false, true); else BK_WAVE(16, false, false); }
+#define BK_WAVE(N, W, H, S) hipLaunchKernelGGL((k_wave<N, W, H, S>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
+    const bool sw = ix.swin != nullptr && b.rd2 != nullptr;
+    if (nw <= 8) {
+        if (wide) BK_WAVE(8, true, true, false);
+        else if (hash) BK_WAVE(8, false, true, false);
+        else if (sw) BK_WAVE(8, false, false, true);
+        else BK_WAVE(8, false, false, false);
+    } else {
+        if (wide) BK_WAVE(16, true, true, false);
+        else if (hash) BK_WAVE(16, false, true, false);
+        else if (sw) BK_WAVE(16, false, false, true);
+        else BK_WAVE(16, false, false, false);
+    }
 #undef BK_WAVE
 }
 

@@ -335,7 +335,7 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_dn, hipStreamNonBlocking);
     for (Slot &sl : s->slots) {
         // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
-        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 16);
+        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64);
         if (e == hipSuccess) e = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
         if (e == hipSuccess) e = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
         if (e == hipSuccess) e = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);

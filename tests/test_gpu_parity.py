@@ -62,7 +62,8 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
                                   ("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
                                   ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)),
                                   ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("sort_lists", 1), ("sort_lists", 6),
-                                  ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)),
+                                  ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)), ("use_swin", 2), (("use_swin", 2), ("heavy_thresh", 0)), (("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 3)),
+                                  ("use_swin", 0),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
                                   (("use_k2", 0), ("lazy_search", 0)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
@@ -105,6 +106,39 @@ def test_packed_batch_equals_byte_batch(golden_tmp, fixture, knob):
     assert_hits_equal(got, ref, [names[i] for i in keep])
     for k in ("n_search", "n_cand", "n_lcm_calls"):
         assert c0[k] == c1[k], (k, c0, c1)
+
+
+@pytest.mark.parametrize("read_len", [100, 150])
+def test_packed_batch_of_many_reads(read_len):
+    """more reads than one launch's first round of blocks (the rows of the later blocks once came out wrong: a code-generation
+    hazard in the reverse complement of the 2-bit rows, tools/prep_check.hip), both row widths, paired ends through the stream"""
+    import torch
+    bk = _bk()
+    from biokanga_amd import synth
+    dev = torch.device("cuda", 0)
+    seq, seq_lens = synth.make_genome(8_000_000, dev, seed=23, n_seqs=3, repeat_frac=0.5)
+    n = seq.numel()
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), 4, 0)
+    entries = synth.entry_table(seq_lens)
+    ent = np.zeros(len(entries), dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"chr{eid}".encode(), b"")
+    pb, po, pl = synth.make_pairs(seq, seq_lens, 100_000, read_len, dev, seed=6, max_subs=3)
+    bases, offs, lens = pb.cpu().numpy(), po.cpu().numpy().astype(np.uint64), pl.cpu().numpy().astype(np.uint32)
+    words, lens16, exc = bk.pack_reads(bases, None, lens)
+    pe = bk.PEParams(3, 200, 400, False)
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(), el_size=4, entries=ent) as al:
+        ref = al.align(bases, offs, lens)
+        assert int((ref["nar"] == 1).sum()) > len(lens) // 2
+        got = al.align_packed(words, lens16, exc)
+        assert_hits_equal(got, ref)
+        paired = al.pair(bases, offs, lens, ref.copy(), pe)
+        out = np.zeros(len(lens), bk.HIT_DTYPE)
+        with bk.Stream(al, len(lens), len(bases), depth=2, pe=pe) as st:
+            st.wait(st.submit_packed(words, lens16, exc, out))
+        for f in FIELDS + ["flags"]:
+            assert np.array_equal(out[f], paired[f]), f
 
 
 def test_packed_batch_is_checked(golden_tmp):

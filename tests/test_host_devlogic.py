@@ -128,3 +128,59 @@ def test_flat_reduction_equals_the_in_order_replay():
             continue
         assert got == want, (recs, mm, init, max_hits, got, want)
     assert exits > 200
+
+
+PACKED_MAIN = r'''
+#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <vector>
+static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) if (v >> i & 1) r |= 1u << (31 - i); return r; }
+static inline uint64_t __brevll(uint64_t v) { uint64_t r = 0; for (int i = 0; i < 64; i++) if (v >> i & 1) r |= 1ULL << (63 - i); return r; }
+%s
+template <int W> static int test()
+{
+    std::mt19937_64 rng(3);
+    for (int trial = 0; trial < 20000; trial++) {
+        const int len = 1 + rng() %% (32 * W);
+        std::vector<int> b(len);
+        for (auto &x : b) x = rng() & 3;
+        uint64_t f[W] = {0}, r[W];
+        for (int j = 0; j < len; j++) f[j / 32] |= (uint64_t)b[j] << (62 - 2 * (j %% 32));
+        revcomp2<W>(f, len, r);
+        for (int j = 0; j < 32 * W; j++) {
+            const int got = (r[j / 32] >> (62 - 2 * (j %% 32))) & 3, want = j < len ? 3 - b[len - 1 - j] : 0;
+            if (got != want) { printf("revcomp2<%%d> len %%d base %%d: %%d, want %%d\n", W, len, j, got, want); return 1; }
+        }
+        // the same read as packed words, with rubbish behind its last base and behind its last word
+        std::vector<uint32_t> Wd((len + 15) / 16 + 2, 0xdeadbeefu);
+        for (int w = 0; w < (len + 15) / 16; w++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 16 && 16 * w + k < len; k++) v |= (uint32_t)b[16 * w + k] << (30 - 2 * k);
+            if (16 * w + 16 > len && (len %% 16)) v |= (uint32_t)rng() & (0xFFFFFFFFu >> (2 * (len %% 16)));
+            Wd[w] = v;
+        }
+        for (int w = 0; w < 2 * W; w++)
+            for (int rc = 0; rc < 2; rc++) {
+                const uint32_t got = packed_word16(Wd.data(), len, w, rc != 0);
+                uint32_t want = 0;
+                for (int k = 0; k < 16; k++) { const int j = 16 * w + k; if (j < len) want |= (uint32_t)(rc ? 3 - b[len - 1 - j] : b[j]) << (30 - 2 * k); }
+                if (got != want) { printf("packed_word16 len %%d word %%d rc %%d: %%08x, want %%08x\n", len, w, rc, got, want); return 1; }
+            }
+    }
+    return 0;
+}
+int main() { if (test<4>() || test<8>()) return 1; printf("ok\n"); return 0; }
+'''
+
+
+def test_packed_read_helpers_against_brute_force(tmp_path):
+    """revcomp2 (reverse complement of a 2 bit/base row) and packed_word16 (a 16-base word of a packed read or of its reverse
+    complement), as they stand in bk_kernels.hip, against per-base loops"""
+    text = open(SRC).read()
+    code = _between(text, "__device__ __forceinline__ uint32_t rev2_32(", "// exceptions of a packed batch, one lane each.")
+    src, exe = str(tmp_path / "packed.cpp"), str(tmp_path / "packed")
+    open(src, "w").write(PACKED_MAIN % _hostify(code))
+    subprocess.check_call(helpers.cxx() + ["-o", exe, src])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
