@@ -40,7 +40,7 @@ struct bk_ctx {
     uint64_t n_tgt4_words = 0;
     uint32_t cap_rd2w = 0;
     int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
-    uint64_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
+    uint32_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
     void *d_sort_tmp = nullptr;

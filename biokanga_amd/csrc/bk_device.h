@@ -15,9 +15,9 @@
 //   ktab   : uint32/uint64[4^k + 1]; ktab[c] = number of suffixes sorting before k-mer code c, i.e.
 //            the LocateFirstExact lower bound of c; a core whose first k bases have code c can only
 //            match inside [ktab[c], ktab[c+1])
-//   k2     : uint64[N] second-level search keys in suffix-array order: k2[i] = nibbles k..k+15 of suffix
-//            sa[i] (all-ones if its first k nibbles hold N/EOS); sorted inside every k-mer bucket, so
-//            cores are located by bisecting contiguous keys instead of chasing sa -> target
+//   k2     : uint32[N] second-level search keys in suffix-array order: the 15 bases that follow the first k of suffix sa[i]
+//            at 2 bit/base + a kind (see bk_kernels.hip); sorted inside every k-mer bucket, so cores are located by
+//            bisecting contiguous keys - sixteen to a cache line - instead of chasing sa -> target
 //   isa    : uint32[N] inverse suffix array (isa[sa[i]] = i); lets the wave kernel decide whether a
 //            target start already reached through an earlier, TRUNCATED core interval was inside
 //            the part of that interval the reference processed (replaces its per-thread hash set)
@@ -67,7 +67,7 @@ struct DevIndex {
     uint32_t max_id;
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
-    const uint64_t *k2;         // second-level keys: 16 nibbles following the first k bases of suffix sa[i]; may be null
+    const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
     const uint4 *swin;          // suffix-ordered windows: for every suffix array index i the kSwBases bases of the 2-bit target from
                                 //   sa[i] - kSwPre on, 48 bytes each.  The candidates of a core interval - consecutive suffix array

@@ -50,7 +50,7 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
-void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s);
@@ -215,9 +215,9 @@ int build_k2(bk_ctx *c)
     if (!c->use_k2 || c->ix.k <= 0) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = c->ix.n * 8;
-    if (need > free_b || free_b - need < total_b / 4) return BK_OK;
-    HIP_TRY(hipMalloc(&c->d_k2, need));
+    const uint64_t need = c->ix.n * 4;
+    if (need > free_b || free_b - need < total_b / 5) return BK_OK;
+    HIP_TRY(hipMalloc(&c->d_k2, need + 64));
     HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
     launch_build_k2(c->ix, c->d_k2, c->d_ctr + 7, c->stream);
     HIP_TRY(hipGetLastError());
@@ -673,7 +673,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     b.rmeta = c->d_rmeta;
     // (the wave list's job sizes come from k_flat only when every read on that list went through it)
     b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) ? c->d_wave_work : nullptr;
-    b.iv32 = (c->use_iv32 && c->ix.k2 && c->search_ilp >= 2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
+    b.iv32 = (c->use_iv32 && c->ix.k2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = n; b.iv_cores = ivc;
@@ -1150,7 +1150,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_sa_lo, src->d_sa_lo, (size_t)n * 4);
     dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
     dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
-    dup(c->d_k2, src->d_k2, (size_t)n * 8);
+    dup(c->d_k2, src->d_k2, (size_t)n * 4 + 64);
     dup(c->d_isa, src->d_isa, (size_t)n * 4);
     dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
     dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);

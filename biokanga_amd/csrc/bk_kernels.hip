@@ -1020,32 +1020,60 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
 
 // ------------------------------------------------------------------------------------------------
 // Two-pass search over the second-level key array (DevIndex::k2).
-//   k2[i] = the 16 nibbles that FOLLOW the first k bases of suffix sa[i]  (all-ones when one of those
-//           first k nibbles is N/EOS: such suffixes sit at the end of their k-mer bucket and compare
-//           above every N-free probe).  Inside one k-mer bucket k2 is non-decreasing, so bases
-//           k .. k+15 of a core are resolved by a bisection over CONTIGUOUS 8-byte keys - one load per
-//           step instead of the dependent suffix-array-then-target pair, and a bucket of <= 8
-//           suffixes is settled from one or two cache lines.
-//   pass A (lane per read/strand/core): k-mer table lookup; empty buckets and buckets of <= 8 keys are
+//   k2[i] = the kK2Bases = 15 bases that FOLLOW the first k bases of suffix sa[i], 2 bits each in the top 30 bits of a 32-bit
+//           word, and a kind in the low two: 0 = all of them a,c,g,t; 1 = an N or a sequence end among them - the bases in front
+//           of it are kept, everything behind is filled with ones, so that the key sorts where the suffix does (above every key
+//           that continues the same bases with a,c,g,t); the word 0xFFFFFFFF = an N / sequence end already inside the first k
+//           bases (such suffixes sit at the end of the k-mer bucket they sort into and compare above every N-free probe).
+//           Inside one k-mer bucket k2 is non-decreasing, so bases k .. k+14 of a core are resolved by a bisection over
+//           CONTIGUOUS 4-byte keys - one load per step instead of the dependent suffix-array-then-target pair, sixteen keys to a
+//           cache line - and a bucket of <= 16 suffixes is settled from one or two lines.
+//           A key of kind 1 can compare EQUAL to a probe that ends in t's where the suffix has its N (the fill): such keys lie at
+//           the END of the run of equal keys (the suffix sorts above every true match), so only the upper bound can be off; it
+//           is walked back over them with a look at the target itself.  Thousands of suffixes in a genome are of that kind.
+//   pass A (lane per read/strand/core): k-mer table lookup; empty buckets and buckets of <= 16 keys are
 //           finished here, everything else is appended to a work list.
-//   pass B (lane per work item): bisection over k2, then - for cores longer than k+16 bases whose
-//           sub-bucket is not handed on unverified - over suffix array + target from base k+16 on.
+//   pass B (lane per work item): bisection over k2, then - for cores longer than k+15 bases whose
+//           sub-bucket is not handed on unverified - over suffix array + target from base k+15 on.
 // The split keeps the lanes of pass B uniformly busy: in one combined kernel ~70 % of the lanes
 // finished after the table lookup and idled while their wave's longest bisection ran.
 // Work items: the slot index; its iv_first/iv_n entry carries (range start, size | kind << 30).
 
 constexpr uint32_t kKindShift = 30;
 constexpr uint32_t kKindK2 = 1;        // bisect k2 over [first, first+size)
-constexpr uint32_t kKindDeep = 2;      // [first, first+size) shares k+16 bases with the core: resolve the rest
+constexpr uint32_t kKindDeep = 2;      // [first, first+size) shares k+15 bases with the core: resolve the rest
 constexpr uint32_t kKindFull = 3;      // no usable k-mer bucket: full search
-constexpr uint32_t kInlineBucket = 8;
+constexpr uint32_t kInlineBucket = 16;
+constexpr int kK2Bases = 15;
+constexpr uint32_t kK2Above = 0xFFFFFFFFu;
 
-// -1 / 0 / +1: key (masked to the core's nibbles) vs probe; the all-ones key sorts above everything
-__device__ __forceinline__ int k2_cmp(uint64_t key, uint64_t m, uint64_t q2)
+// -1 / 0 / +1: key (masked to the core's bases) vs probe; the all-ones key sorts above everything
+__device__ __forceinline__ int k2_cmp(uint32_t key, uint32_t m, uint32_t q2)
 {
-    if (key == ~0ULL) return 1;
+    if (key == kK2Above) return 1;
     key &= m;
     return key < q2 ? -1 : (key > q2 ? 1 : 0);
+}
+__device__ __forceinline__ bool k2_nkind(uint32_t key) { return key != kK2Above && (key & 3u) == 1u; }
+
+// mask of the first L = min(rem2, kK2Bases) bases of a key; rem2 = bases of the core beyond the k-mer table's k
+__device__ __forceinline__ uint32_t k2_mask(int rem2)
+{
+    const int L = rem2 < kK2Bases ? rem2 : kK2Bases;
+    return L <= 0 ? 0u : ~0u << (32 - 2 * L);
+}
+
+// the key of the suffix at pos
+__device__ __forceinline__ uint32_t k2_make(const uint64_t *__restrict__ tgt4, uint64_t pos, int k)
+{
+    const uint64_t w0 = nib16(tgt4, pos);
+    if (w0 & top_mask(k) & 0x4444444444444444ULL) return kK2Above;
+    const uint64_t w1 = nib16(tgt4, pos + (uint64_t)k);
+    const uint64_t bad = w1 & 0x4444444444444440ULL;                 // N / sequence end among the 15 bases
+    const uint32_t code = squeeze2(w1) & ~3u;
+    if (!bad) return code;
+    const int j = __clzll((long long)bad) >> 2;                       // the first of them
+    return ((code | (0xFFFFFFFFu >> (2 * j))) & ~3u) | 1u;
 }
 
 // as cmp_core, but only bases [start, cl) of the core are compared
@@ -1063,19 +1091,15 @@ __device__ __forceinline__ int cmp_core_from(const Row &rdw, int ofs, int cl, in
 }
 
 template <bool WIDE>
-__global__ void k_build_k2(DevIndex ix, uint64_t *__restrict__ k2)
+__global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2)
 {
-    const uint64_t km = top_mask(ix.k) & 0x4444444444444444ULL;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t pos = sa_get<WIDE>(ix, i);
-        uint64_t w0 = nib16(ix.tgt4, pos);
-        k2[i] = (w0 & km) ? ~0ULL : nib16(ix.tgt4, pos + (uint64_t)ix.k);
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x)
+        k2[i] = k2_make(ix.tgt4, sa_get<WIDE>(ix, i), ix.k);
 }
 
 // the bisection needs k2 non-decreasing inside every k-mer bucket; count the places where it is not
 template <bool WIDE>
-__global__ void k_check_k2(DevIndex ix, const uint64_t *__restrict__ k2, unsigned long long *__restrict__ bad)
+__global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigned long long *__restrict__ bad)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (k2[i] <= k2[i + 1]) continue;
@@ -1084,94 +1108,9 @@ __global__ void k_check_k2(DevIndex ix, const uint64_t *__restrict__ k2, unsigne
     }
 }
 
-__global__ void __launch_bounds__(256) k_search_a(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                                  uint32_t n_act, int phase, int cmax, int nstr, int lazy,
-                                                  StripeSet out)
-{
-    __shared__ uint32_t s_cnt, s_base;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t per_read = (uint32_t)(nstr * cmax);
-    uint64_t a = tid / per_read;
-    bool push = false;
-    uint64_t slot = 0, st_first = 0;
-    uint32_t st_nval = 0;
-    if (a < n_act) {
-        uint32_t rem = (uint32_t)(tid - a * per_read);
-        int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
-        uint32_t r = act[a];
-        const uint32_t meta = b.rmeta[r];
-        int len = (int)(meta & kReadLenMask);
-        ReadPlan p = make_plan(len, cfg);
-        int mm, cl, cd, dummy[1];
-        phase_params(p, cfg, phase, mm, cl, cd);
-        int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
-        if (c < nc && nc <= kMaxCoresFast) {
-            int my_ofs = c * cd < len - cl ? c * cd : len - cl;
-            int strand = cfg.align_strand == 2 ? 1 : si;
-            const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
-            slot = iv_slot(b, r, strand, c);
-            const int k = ix.k;
-            uint64_t p0 = rdw.nib16(my_ofs) & top_mask(cl);
-            uint64_t first = 0;
-            uint32_t nval = kKindFull << kKindShift;
-            push = true;
-            if (cl >= k && !(p0 & 0x4444444444444444ULL & top_mask(k))) {
-                uint64_t code = (uint64_t)(squeeze2(p0) >> (32 - 2 * k));
-                uint64_t lo = ktab_get(ix, code), hi = ktab_get(ix, code + 1);
-                uint64_t size = hi - lo;
-                if (size == 0) {
-                    first = lo; nval = 0; push = false;
-                } else if (size <= kInlineBucket) {
-                    const int rem2 = cl - k;
-                    const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-                    const uint64_t q2 = rem2 <= 0 ? 0 : (rdw.nib16(my_ofs + k) & m);
-                    uint64_t key[kInlineBucket];
-#pragma unroll
-                    for (uint32_t j = 0; j < kInlineBucket; j++) key[j] = j < size ? ix.k2[lo + j] : ~0ULL;
-                    uint32_t lb = 0, ub = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < kInlineBucket; j++) {
-                        int cm = k2_cmp(key[j], m, q2);
-                        lb += cm < 0;
-                        ub += cm <= 0;
-                    }
-                    first = lo + lb;
-                    uint32_t cnt = ub - lb;
-                    if (cnt == 0 || cl <= k + 16) { nval = cnt; push = false; }
-                    else if (lazy && cnt <= kLazyBucket) { nval = cnt | kLazyFlag; push = false; }
-                    else nval = cnt | (kKindDeep << kKindShift);
-                } else if (size < (1ULL << kKindShift)) {
-                    first = lo;
-                    nval = (uint32_t)size | (kKindK2 << kKindShift);
-                }
-            }
-            // iv_n of the phase's slots is zeroed before the launch: empty results (about 40 % of the lanes)
-            // store nothing - two partial-line writes less
-            st_first = first;                     // (stored after the list append, whose barriers wait for every store issued)
-            st_nval = nval;
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    uint64_t m = __ballot(push);
-    uint32_t my_off = 0;
-    if (m) {
-        uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-        w = __builtin_amdgcn_readfirstlane(w);
-        my_off = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
-    __syncthreads();
-    if (push) stripe_put(out, 0, s_base + my_off, (uint32_t)slot);
-    if (st_nval != 0) iv_put(b, slot, st_first, st_nval);
-}
-
-// k_search_a with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
+// Pass A with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
 // keys) of all ILP searches are in flight together: item u of a lane is search number tid + u * (lanes of the grid), i.e. every u
-// keeps k_search_a's mapping of neighbouring lanes to neighbouring searches.  Same records, same work list (order aside).
+// maps neighbouring lanes to neighbouring searches.  Same records and work list for every ILP (order aside).
 // -DBK_PROF=1 (k_flat) / 2 (k_search_a_ilp): where a block's time goes - thread 0 adds the cycles between its section marks to
 // g_prof (summed over the blocks, read with bk_debug_prof(); `BK_DIAG=1 python bench.py` prints them)
 __device__ unsigned long long g_prof[64 * 16];
@@ -1210,10 +1149,10 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const int k = ix.k;
     bool on[ILP], push[ILP], have_code[ILP];
-    uint64_t slot[ILP], p0[ILP], q2raw[ILP], first[ILP], lo[ILP], hi[ILP];
-    uint32_t nval[ILP];
+    uint64_t slot[ILP], p0[ILP], first[ILP], lo[ILP], hi[ILP];
+    uint32_t nval[ILP], q2raw[ILP];            // q2raw: the 16 bases behind the k-mer's, 2 bits each
     int cl[ILP];
-    // The core at offset 0 of phases 0, 1, 2 .. begins with the same k + 16 bases whenever it is that long, so the interval those bases
+    // The core at offset 0 of phases 0, 1, 2 .. begins with the same k + 15 bases whenever it is that long, so the interval those bases
     // select is looked up once: phase 0 leaves it in iv32 (here, or pass B after its key bisection), the later phases' offset-0 lanes
     // take it from there instead of fetching a k-mer table line and a key line each (a quarter of the searches at C2).
     constexpr uint32_t kNoIv32 = 0xFFFFFFFFu;
@@ -1241,7 +1180,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             const int nc = core_offsets(len, cl[u], cd, p.max_slides, dummy, 0);
             if (c < nc && nc <= kMaxCoresFast) {
                 on[u] = true;
-                if (b.iv32 != nullptr && c == 0 && cl[u] >= k + 16) {
+                if (b.iv32 != nullptr && c == 0 && cl[u] >= k + kK2Bases) {
                     cix[u] = (uint32_t)strand_c * b.n_reads + r;
                     cached[u] = phase > 0 && cv[u].y < (1u << kKindShift);
                 }
@@ -1253,11 +1192,15 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                     const uint64_t *row = b.rd2 + ((uint64_t)r * 2 + strand) * (b.nw / 2);
                     const uint64_t x = bits64_2(row, my_ofs);
                     p0[u] = spread2to4((uint32_t)(x >> 32)) & top_mask(cl[u]);
-                    q2raw[u] = k == 16 ? spread2to4((uint32_t)x) : spread2to4((uint32_t)(bits64_2(row, my_ofs + k) >> 32));
+                    q2raw[u] = k == 16 ? (uint32_t)x : (uint32_t)(bits64_2(row, my_ofs + k) >> 32);
                 } else {
                     const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
                     p0[u] = nib16(rdw, my_ofs) & top_mask(cl[u]);
-                    q2raw[u] = nib16(rdw, my_ofs + k);
+                    const uint64_t q4 = nib16(rdw, my_ofs + k);
+                    q2raw[u] = squeeze2(q4);
+                    // an N among the core's bases behind the k-mer cannot be put to the 2-bit keys: the full search takes the core
+                    const int rem2 = cl[u] - k;
+                    if (rem2 > 0 && (q4 & 0x4444444444444444ULL & top_mask(rem2 < kK2Bases ? rem2 : kK2Bases))) p0[u] |= 0x4000000000000000ULL;
                 }
             }
         }
@@ -1277,12 +1220,23 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     }
     PROFS(1);
     // stage 3: small buckets from the key array
-    uint64_t key[ILP][kInlineBucket];
+    // (sixteen keys from the bucket's start as four unaligned 16-byte loads, whatever the bucket's size - straight-line loads; what
+    // lies behind the bucket is replaced afterwards; the key array is followed by 64 bytes)
+    uint32_t key[ILP][kInlineBucket];
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const uint64_t size = hi[u] - lo[u];
+        const bool small = have_code[u] && size <= kInlineBucket;
+        const Bytes16 *kp = reinterpret_cast<const Bytes16 *>(ix.k2 + (small ? lo[u] : 0));
+        Bytes16 kq[kInlineBucket / 4];
 #pragma unroll
-        for (uint32_t j = 0; j < kInlineBucket; j++) key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ix.k2[lo[u] + j] : ~0ULL;
+        for (uint32_t q = 0; q < kInlineBucket / 4; q++) kq[q] = kp[q];
+#pragma unroll
+        for (uint32_t q = 0; q < kInlineBucket / 4; q++) {
+            const uint32_t w4[4] = {(uint32_t)kq[q].lo, (uint32_t)(kq[q].lo >> 32), (uint32_t)kq[q].hi, (uint32_t)(kq[q].hi >> 32)};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) key[u][4 * q + j] = (small && 4 * q + j < size) ? w4[j] : kK2Above;
+        }
     }
     PROFS(2);
     // stage 4: results
@@ -1290,10 +1244,10 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     for (int u = 0; u < ILP; u++) {
         uint2 leave = make_uint2(0, kNoIv32);               // what phase 0 leaves in iv32 for this read and strand
         if (cached[u]) {
-            // the interval of the first k + 16 bases, as the bucket compare below would have produced it
+            // the interval of the first k + 15 bases, as the bucket compare below would have produced it
             first[u] = cv[u].x;
             const uint32_t cnt = cv[u].y;
-            if (cnt == 0 || cl[u] <= k + 16) { nval[u] = cnt; push[u] = false; }
+            if (cnt == 0 || cl[u] <= k + kK2Bases) { nval[u] = cnt; push[u] = false; }
             else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
             else nval[u] = cnt | (kKindDeep << kKindShift);
         }
@@ -1301,22 +1255,27 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             const uint64_t size = hi[u] - lo[u];
             if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
             else if (size <= kInlineBucket) {
-                const int rem2 = cl[u] - k;
-                const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-                const uint64_t q2 = rem2 <= 0 ? 0 : (q2raw[u] & m);
+                const uint32_t m = k2_mask(cl[u] - k), q2 = q2raw[u] & m;
                 uint32_t lb = 0, ub = 0;
+                bool suspect = false;                          // a key of the N kind counted as equal: pass B has a look at the target
 #pragma unroll
                 for (uint32_t j = 0; j < kInlineBucket; j++) {
                     const int cm = k2_cmp(key[u][j], m, q2);
                     lb += cm < 0;
                     ub += cm <= 0;
+                    suspect |= cm == 0 && k2_nkind(key[u][j]);
                 }
-                first[u] = lo[u] + lb;
-                const uint32_t cnt = ub - lb;
-                leave = make_uint2((uint32_t)first[u], cnt);
-                if (cnt == 0 || cl[u] <= k + 16) { nval[u] = cnt; push[u] = false; }
-                else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
-                else nval[u] = cnt | (kKindDeep << kKindShift);
+                if (suspect) {
+                    first[u] = lo[u];
+                    nval[u] = (uint32_t)size | (kKindK2 << kKindShift);
+                } else {
+                    first[u] = lo[u] + lb;
+                    const uint32_t cnt = ub - lb;
+                    leave = make_uint2((uint32_t)first[u], cnt);
+                    if (cnt == 0 || cl[u] <= k + kK2Bases) { nval[u] = cnt; push[u] = false; }
+                    else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
+                    else nval[u] = cnt | (kKindDeep << kKindShift);
+                }
             } else if (size < (1ULL << kKindShift)) {
                 first[u] = lo[u];
                 nval[u] = (uint32_t)size | (kKindK2 << kKindShift);        // (pass B leaves the interval in iv32 after its key bisection)
@@ -1388,9 +1347,8 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         return;
     }
     if (kind == kKindK2) {
-        const int rem2 = cl - k;
-        const uint64_t m = rem2 <= 0 ? 0 : top_mask(rem2 < 16 ? rem2 : 16);
-        const uint64_t q2 = rem2 <= 0 ? 0 : (rdw.nib16(my_ofs + k) & m);
+        const uint32_t m = k2_mask(cl - k);
+        const uint32_t q2 = squeeze2(rdw.nib16(my_ofs + k)) & m;
         // lower and upper bound in lock step: two independent loads per round
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
@@ -1399,26 +1357,35 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
 #ifdef BK_DIAG_B
             d_k2 += 1 + (1ULL << 32) * ((a1 && (h1 - l1) > 8) + (a2 && (h2 - l2) > 8 && (m1 >> 3) != (m2 >> 3)));
 #endif
-            const uint64_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
+            const uint32_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
             if (a1) { if (k2_cmp(v1, m, q2) < 0) l1 = m1 + 1; else h1 = m1; }
             if (a2) { if (k2_cmp(v2, m, q2) <= 0) l2 = m2 + 1; else h2 = m2; }
         }
+        // keys of the N kind at the end of the run of equal keys may be there for their fill only: the target decides
+        {
+            const int upto = cl < k + kK2Bases ? cl : k + kK2Bases;
+            while (l2 > l1) {
+                const uint32_t kv = ix.k2[l2 - 1];
+                if (!k2_nkind(kv) || cmp_core_from(rdw, my_ofs, upto, k, ix.tgt4, sa_get<WIDE>(ix, l2 - 1)) == 0) break;
+                l2--;
+            }
+        }
         first = l1;
         cnt = l2 - l1;
-        if (!WIDE && b.iv32 != nullptr && phase == 0 && c == 0 && cl >= k + 16)       // see k_search_a_ilp
+        if (!WIDE && b.iv32 != nullptr && phase == 0 && c == 0 && cl >= k + kK2Bases)       // see k_search_a_ilp
             b.iv32[(uint32_t)strand * b.n_reads + r] = make_uint2((uint32_t)first, (uint32_t)cnt);
-        if (cnt == 0 || cl <= k + 16) {
+        if (cnt == 0 || cl <= k + kK2Bases) {
             iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
             return;
         }
     }
-    // [first, first+cnt) agrees with the core on its first k+16 bases
+    // [first, first+cnt) agrees with the core on its first k+15 bases
     if (lazy && cnt <= kLazyBucket) {
         iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
         return;
     }
     {
-        const int start = k + 16;
+        const int start = k + kK2Bases;
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
@@ -1901,7 +1868,7 @@ __device__ __forceinline__ void eval_window2i(const uint64_t (&r2w)[NW / 2], con
 // eval_window2i with the window taken from the candidate's entry of the suffix-ordered window array (DevIndex::swin): the three
 // 16-byte words of entry `e`; the window starts bofs = kSwPre - (core offset) bases into it - the same for every lane of the wave.
 template <int NW>
-__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 *__restrict__ e,
+__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 (&e)[3],
                                             int bofs, IWindow<NW> &w)
 {
     uint64_t r[6], q[5];                                       // (reads of up to kSwLen <= 128 bases: four compare words at most)
@@ -2820,10 +2787,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 }
                 spilled = false;             // (the HBM table gets its new epoch when a pass first spills into it)
             }
-            // the read's row (the same for the whole wave: scalar registers).  Lean batches hold 2 bit/base rows; the 4-bit words a
-            // flagged window needs are widened from them, or - a read with an N - come from its rd4 row together with its N positions
-            uint64_t rw[NW], r2w[NW / 2], rni[NW / 4];                   // rni: "read base is N", in the IWindow layout
+            // the read's 2 bit/base row (the same for the whole wave: scalar registers).  The 4 bit/base words that a window near an
+            // N or a sequence end needs are not kept in registers: that path (eval_window_rare) fetches them as it goes - from the
+            // 2-bit row again, or, a read with an N, from its rd4 row, which also gives its N positions
+            uint64_t r2w[NW / 2], rni[NW / 4];                           // rni: "read base is N", in the IWindow layout
             const bool two_bit = b.rd2 != nullptr;
+            const RdRow row4 = read_row(b, r, st, has_n);
             if (two_bit) {
                 load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (NW / 2), r2w);
 #pragma unroll
@@ -2834,22 +2803,16 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             }
 #pragma unroll
             for (int k = 0; k < NW / 4; k++) rni[k] = 0;
-            if (!two_bit || has_n) {
-                load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
+            if (two_bit && has_n) {
+                const uint64_t *__restrict__ rp = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
 #pragma unroll
-                for (int k = 0; k < NW; k++) rw[k] = uniform64(rw[k]);
-                if (two_bit) {
+                for (int q = 0; q < NW / 4; q++) {
+                    uint64_t nm = 0;
 #pragma unroll
-                    for (int q = 0; q < NW / 4; q++) {
-                        uint64_t nm = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) nm |= (uint64_t)flags_to_bits16((rw[4 * q + k] >> 2) & 0x1111111111111111ULL) << (16 * k);
-                        rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
-                    }
+                    for (int k = 0; k < 4; k++)
+                        if (16 * (4 * q + k) < len) nm |= (uint64_t)flags_to_bits16((uniform64(rp[4 * q + k]) >> 2) & 0x1111111111111111ULL) << (16 * k);
+                    rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < NW; k++) rw[k] = uniform64(spread2to4((k & 1) ? (uint32_t)r2w[k >> 1] : (uint32_t)(r2w[k >> 1] >> 32)));
             }
             uint32_t my_cn = 0;                       // lane l < nc: suffixes in core l's interval
             if (lane < nc) {
@@ -2913,6 +2876,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
+                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip)
+                    uint4 ev[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                    if (SW && sw_read && active) {
+                        const uint4 *__restrict__ ep = ix.swin + (lfirst + j) * 3;
+                        ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
+                    }
                     const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
                     const uint64_t t = loci - (uint64_t)lofs;
                     bool valid = active && loci >= (uint64_t)lofs;
@@ -2926,17 +2895,17 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         if (two_bit) {
                             const bool flg = window_flagged_t<WIDE>(ix, t, len);
                             if (SW && sw_read) {
-                                if constexpr (SW) eval_swin2i<NW>(r2w, rni, len, ix.swin + (lfirst + j) * 3, kSwPre - lofs, w);
+                                if constexpr (SW) eval_swin2i<NW>(r2w, rni, len, ev, kSwPre - lofs, w);
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
                             if (flg) {
                                 Window<NW> w4;
-                                eval_window<NW>(rw, len, ix.tgt4, t, w4);
+                                eval_window_rare<NW>(row4, len, ix.tgt4, t, w4);
                                 window_to_iwindow<NW>(w4, w);
                             }
                         } else {
                             Window<NW> w4;
-                            eval_window<NW>(rw, len, ix.tgt4, t, w4);
+                            eval_window_rare<NW>(row4, len, ix.tgt4, t, w4);
                             window_to_iwindow<NW>(w4, w);
                         }
                         valid = !w.eos && (!llazy || im_clean<NW>(w.im, cmask[lc]));
@@ -4564,7 +4533,7 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
     }
 }
 
-void launch_build_k2(const DevIndex &ix, uint64_t *k2, unsigned long long *bad, hipStream_t s)
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s)
 {
     uint64_t blocks = (ix.n + 255) / 256;
     if (blocks > 262144) blocks = 262144;
@@ -4648,7 +4617,7 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
     out.cap = stripe_cap(blocks, (unsigned)per);
     if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
     else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
-    else hipLaunchKernelGGL(k_search_a, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    else hipLaunchKernelGGL(k_search_a_ilp<1>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
     launch_compact(out, &list, &list_cnt, 1, nullptr, s);
 }
 
