@@ -59,6 +59,8 @@ struct bk_ctx {
     uint32_t *d_isa = nullptr;
     void *d_swin = nullptr;               // suffix-ordered window array (DevIndex::swin), built when the first batch it serves arrives
     int use_swin = 1;
+    bool swin_denied = false; // it did not fit beside a batch's scratch when first asked for
+    int wave_group = 0;      // wave kernel, reads of <= 128 bases: consecutive small core intervals share a round (always so for longer reads)
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;
@@ -131,7 +133,7 @@ struct DevReads {
 };
 // batch driver entry points of bk_engine.cpp used by the stream pipeline (all blocking on `s`: the phase loop reads the
 // active counts back between phases)
-int engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s);
+int engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0);
 int engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s);
 // packed batches: lens16 -> d_lens32, word offsets of the reads -> d_offs (scan), the batch checked (word count, read lengths,
 // exception list); *maxlen = longest read.  Blocking on `s`.

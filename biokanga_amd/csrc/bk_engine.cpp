@@ -771,7 +771,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                 if (rs) return rs;
             }
             if (c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
-            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16, c->wave_waves, s);
+            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16 | (c->wave_group ? 0x100 : 0), c->wave_waves, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
@@ -854,7 +854,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
 // spare: it trades capacity (149 GB for a 3.1 Gbp index on a 288 GB device) for locality.
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
-    if (c->d_swin || !c->use_swin || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;
+    if (c->d_swin || !c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;
     if (c->use_swin < 2 && (maxlen > (uint32_t)kSwLen || (int)maxlen - c->cfg.min_core_len > kSwPre)) return BK_OK;       // (2: whatever the batch - its short reads use it)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -862,7 +862,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
     const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);
     const uint64_t missing = want > have ? want - have : 0;
-    if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) return BK_OK;  // (the chunk size is set from 3/4 of the free memory)
+    if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) { c->swin_denied = true; return BK_OK; }  // (the chunk size is set from 3/4 of the free memory; asked once)
     StageClock clk;
     if (hipMalloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; return BK_OK; }
     launch_build_swin(c->ix, c->d_swin, s);
@@ -873,7 +873,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     return BK_OK;
 }
 
-int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s)
+int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0)
 {
     const uint32_t *d_lens = in.lens;
     EvTimer tm{c};
@@ -881,12 +881,15 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     c->loci_offs.clear();
     c->loci.clear();
     c->seg2.clear();
-    // longest read of the call -> row width of the packed reads and the kernel family used
-    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
-    launch_max_len(d_lens, nreads, c->d_small + 5, s);
-    HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 16 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t maxlen = c->h_small[5];
+    // longest read of the call -> row width of the packed reads and the kernel family used (the pipeline knows it already)
+    uint32_t maxlen = maxlen_known;
+    if (!maxlen) {
+        HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
+        launch_max_len(d_lens, nreads, c->d_small + 5, s);
+        HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 16 * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        maxlen = c->h_small[5];
+    }
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
     if ((int)maxlen > c->max_read_len) {
         c->max_read_len = (int)maxlen;
@@ -895,7 +898,9 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     // chunk size: as many reads as the knob allows and as fit in about half of the HBM still free
     // (the phase kernels run better the more reads they see: fewer launches, shorter tails)
     uint32_t chunk = c->chunk_reads;
-    {
+    // (a batch the scratch already holds needs no look at the free memory)
+    if (!(std::min(chunk, nreads) <= c->cap_reads && words_per_read(maxlen) <= c->cap_wpr && iv_cores_for(c, maxlen) <= c->cap_iv_cores &&
+          (maxlen <= 128 ? 4u : 8u) <= std::max(c->cap_rd2w, 1u) && !c->params.best_matches)) {
         const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -935,9 +940,9 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
 
 }  // namespace
 
-int bk::engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s)
+int bk::engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known)
 {
-    return align_device(c, in, nreads, d_out, s);
+    return align_device(c, in, nreads, d_out, s, maxlen_known);
 }
 
 namespace {
@@ -1255,9 +1260,15 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->wave_waves = (uint32_t)value;
         return old;
     }
+    if (n == "wave_group") {
+        int64_t old = c->wave_group;
+        c->wave_group = value ? 1 : 0;
+        return old;
+    }
     if (n == "use_swin") {
         int64_t old = c->use_swin;
         c->use_swin = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        c->swin_denied = false;
         if (!c->use_swin && c->d_swin) {
             if (c->stream) (void)hipStreamSynchronize(c->stream);
             free_dev(c->d_swin);

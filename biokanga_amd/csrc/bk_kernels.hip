@@ -1220,23 +1220,14 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     }
     PROFS(1);
     // stage 3: small buckets from the key array
-    // (sixteen keys from the bucket's start as four unaligned 16-byte loads, whatever the bucket's size - straight-line loads; what
-    // lies behind the bucket is replaced afterwards; the key array is followed by 64 bytes)
+    // (a lane loads the keys its bucket has - one to three for most - and no more: this kernel lives on the rate at which the
+    // texture path takes lane requests, and sixteen keys for every lane cost a third more time than the search saved)
     uint32_t key[ILP][kInlineBucket];
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const uint64_t size = hi[u] - lo[u];
-        const bool small = have_code[u] && size <= kInlineBucket;
-        const Bytes16 *kp = reinterpret_cast<const Bytes16 *>(ix.k2 + (small ? lo[u] : 0));
-        Bytes16 kq[kInlineBucket / 4];
 #pragma unroll
-        for (uint32_t q = 0; q < kInlineBucket / 4; q++) kq[q] = kp[q];
-#pragma unroll
-        for (uint32_t q = 0; q < kInlineBucket / 4; q++) {
-            const uint32_t w4[4] = {(uint32_t)kq[q].lo, (uint32_t)(kq[q].lo >> 32), (uint32_t)kq[q].hi, (uint32_t)(kq[q].hi >> 32)};
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) key[u][4 * q + j] = (small && 4 * q + j < size) ? w4[j] : kK2Above;
-        }
+        for (uint32_t j = 0; j < kInlineBucket; j++) key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ix.k2[lo[u] + j] : kK2Above;
     }
     PROFS(2);
     // stage 4: results
@@ -2638,6 +2629,18 @@ __device__ __forceinline__ bool same_key_earlier_in_round(bool cand, uint32_t ke
 {
     bool dup = false;
     uint64_t vm = __ballot(cand);
+    if (__popcll(vm) > 1) {
+        // first a cheap look at six bits of a hash of the keys: lanes that share all six with no other candidate cannot have a twin
+        // (almost every round ends here); the exact pass over the candidates runs only for the others
+        const uint32_t h6 = (key * 2654435761u) >> 26;
+        uint64_t peers = vm;
+#pragma unroll
+        for (int bit = 0; bit < 6; bit++) {
+            const uint64_t bm = __ballot(cand && ((h6 >> bit) & 1));
+            peers &= ((h6 >> bit) & 1) ? bm : ~bm;
+        }
+        vm = __ballot(cand && (peers & (peers - 1)) != 0);          // candidates that share their six bits with another candidate
+    }
     if (__popcll(vm) > 1)
         while (vm) {
             const int l = __ffsll((unsigned long long)vm) - 1;
@@ -2686,7 +2689,7 @@ struct WaveCoreInfo {
 // inverse suffix array; and only the truncated keys reproduce the reference there, where two starts 2^32 apart
 // count as one) and for 4-byte indexes whose inverse suffix array was not built.
 // SW: the index holds the suffix-ordered window array (DevIndex::swin) - reads it covers take their candidates' windows from it.
-template <int NW, bool WIDE, bool HASH, bool SW>
+template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
 __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                               const uint32_t *__restrict__ list,
                                               uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
@@ -2699,7 +2702,6 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
     // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
     __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
-    constexpr bool GROUP = NW > 8;               // (the 8-word form runs at five waves per SIMD with 92 registers; the group bookkeeping would cost it one)
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
@@ -4687,18 +4689,20 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     uint32_t waves = n_list < max_waves ? n_list : max_waves;
     if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-#define BK_WAVE(N, W, H, S) hipLaunchKernelGGL((k_wave<N, W, H, S>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
+#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
     const bool sw = ix.swin != nullptr && b.rd2 != nullptr;
+    const bool group8 = (nw & 0x100) != 0;                 // 8-word form: small intervals share rounds (the 16-word form always does)
+    nw &= 0xff;
     if (nw <= 8) {
-        if (wide) BK_WAVE(8, true, true, false);
-        else if (hash) BK_WAVE(8, false, true, false);
-        else if (sw) BK_WAVE(8, false, false, true);
-        else BK_WAVE(8, false, false, false);
+        if (wide) BK_WAVE(8, true, true, false, true);
+        else if (hash) BK_WAVE(8, false, true, false, true);
+        else if (sw) { if (group8) BK_WAVE(8, false, false, true, true); else BK_WAVE(8, false, false, true, false); }
+        else { if (group8) BK_WAVE(8, false, false, false, true); else BK_WAVE(8, false, false, false, false); }
     } else {
-        if (wide) BK_WAVE(16, true, true, false);
-        else if (hash) BK_WAVE(16, false, true, false);
-        else if (sw) BK_WAVE(16, false, false, true);
-        else BK_WAVE(16, false, false, false);
+        if (wide) BK_WAVE(16, true, true, false, true);
+        else if (hash) BK_WAVE(16, false, true, false, true);
+        else if (sw) BK_WAVE(16, false, false, true, true);
+        else BK_WAVE(16, false, false, false, true);
     }
 #undef BK_WAVE
 }

@@ -184,7 +184,7 @@ struct bk_stream {
                                          : rc_of(e);
                 bk::DevReads in;
                 in.offs = sl.d_offs; in.lens = sl.d_lens; in.words = reinterpret_cast<const uint32_t *>(sl.d_bases); in.exc = sl.d_exc; in.n_exc = j->n_exc;
-                if (rc == BK_OK) rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al);
+                if (rc == BK_OK) rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al, maxlen);
                 if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
                 if (rc) fail(j, rc);
                 else if (list_modes) {
@@ -218,7 +218,7 @@ struct bk_stream {
                 if (j->rc == BK_OK) {
                     bk::DevReads in;
                     in.bases = sl.d_bases; in.offs = sl.d_offs; in.lens = sl.d_lens;
-                    int rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al);
+                    int rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al, maxlen);
                     if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
                     if (rc) fail(j, rc);
                     else if (list_modes) {

@@ -157,6 +157,7 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
  *   "use_swin" (suffix-ordered window array for reads of <= 100 bases, 0: windows from the 2-bit target, 2: built whatever the batch's longest read)
+ *   "wave_group" (wave kernel, reads of <= 128 bases: small core intervals share a round)
  *   "chunk_reads" (reads per pass over the phases)   "max_read_len"
  * returns the old value or <0 */
 int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
