@@ -1,0 +1,301 @@
+// bk_sam.hip - SAM records formatted on the device (bk_sam_format of include/biokanga_amd.h).
+//
+// CAligner::ReportBAMread (biokanga/Aligner.cpp:5768-6126) prints one text line per read with sprintf, ~4.5 us each on one
+// thread; formatting 50 M records is byte-parallel work: a lane per record measures its line, a prefix sum places it, the lane
+// writes it.  The host keeps what is serial by nature - the reference's output order (its quicksort replica) and the file itself.
+// The text leaves the device in slices through a pair of pinned buffers; the caller's sink receives them in file order.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "bk_ctx_int.h"
+
+namespace {
+
+struct SamDev {
+    const uint8_t *bases;
+    const uint64_t *offs;
+    const uint32_t *lens;
+    const char *names;
+    const uint64_t *name_ofs;        // n_reads + 1 entries: name i = [name_ofs[i], name_ofs[i + 1] - 1)
+    const bk_hit *hits;
+    const uint32_t *order;
+    const char *ent_names;           // n_ent x 81 bytes
+    uint32_t n_ent;
+    int fmt6, pe_mode;
+};
+
+__device__ __forceinline__ int n_digits(unsigned long v)
+{
+    int n = 1;
+    while (v >= 10) { v /= 10; n++; }
+    return n;
+}
+
+__device__ __forceinline__ char *put_num(char *w, long v)
+{
+    char t[24];
+    int n = 0;
+    const bool neg = v < 0;
+    unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) *w++ = '-';
+    while (n) *w++ = t[--n];
+    return w;
+}
+
+__device__ __forceinline__ char *put_str(char *w, const char *z)
+{
+    while (*z) *w++ = *z++;
+    return w;
+}
+
+__device__ const char kSamNarTag[20][3] = {"NA", "AA", "EN", "NL", "MH", "ML", "ET", "OJ", "OM", "DP", "DS", "FC", "PR", "UI", "OI", "UP", "IS", "IT", "NP", "LC"};
+
+// the fields of record k that both passes need
+struct SamRec {
+    uint32_t i, len, nml;
+    bool acc, reported, has_qual;
+    int flag, tlen;
+    long pnext;
+};
+
+__device__ __forceinline__ SamRec sam_rec(const SamDev &d, uint64_t k)
+{
+    SamRec r;
+    r.i = d.order[k];
+    const bk_hit h = d.hits[r.i];
+    r.acc = h.nar == BK_NAR_ACCEPTED;
+    r.reported = r.acc || d.fmt6;
+    r.len = d.lens[r.i];
+    r.nml = (uint32_t)(d.name_ofs[r.i + 1] - d.name_ofs[r.i] - 1);
+    r.flag = 0; r.tlen = 0; r.pnext = -1; r.has_qual = false;
+    if (!r.reported) return r;
+    if (!d.pe_mode) r.flag = r.acc ? (h.strand == '+' ? 0 : 16) : 4;
+    else {
+        // flags of CAligner::ReportBAMread for paired ends (Aligner.cpp:5850-5924)
+        const bool first_of_pair = (r.i & 1) == 0;
+        const bk_hit m = d.hits[first_of_pair ? r.i + 1 : r.i - 1];
+        r.flag = 0x1 | 0x2 | (first_of_pair ? 0x40 : 0x80);
+        r.flag |= r.acc ? (h.strand == '+' ? 0 : 0x10) : 0x4;
+        if ((h.flags & 0x80) && (m.flags & 0x80) && m.nar == BK_NAR_ACCEPTED) {
+            r.flag |= m.strand == '+' ? 0 : 0x20;
+            if (r.acc) {
+                r.pnext = (long)m.match_loci;
+                const long s0 = (long)h.match_loci, s1 = (long)m.match_loci;
+                r.tlen = (int)(s0 <= s1 ? (s1 - s0) + (long)m.match_len : (s0 - s1) + (long)h.match_len);
+            }
+        } else
+            r.flag |= 0x8;
+    }
+    // QUAL is '*' unless a base of the read carries a score (bits 4..7 of its byte)
+    const uint8_t *s = d.bases + d.offs[r.i];
+    uint32_t sum = 0;
+    for (uint32_t q = 0; q < r.len; q++) sum |= s[q] & 0xf0u;
+    r.has_qual = sum != 0;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_sam_measure(SamDev d, uint64_t k0, uint32_t n, unsigned long long *__restrict__ bytes, uint32_t *__restrict__ n_rep)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rep = 0;
+    if (j < n) {
+        const SamRec r = sam_rec(d, k0 + j);
+        unsigned long long b = 0;
+        if (r.reported) {
+            rep = 1;
+            const bk_hit h = d.hits[r.i];
+            b = r.nml + 1 + n_digits((unsigned long)r.flag);
+            const unsigned qual = r.has_qual ? r.len : 1u;
+            if (r.acc) {
+                const char *nm = d.ent_names + (size_t)(h.chrom_id - 1) * 81;
+                uint32_t cl = 0;
+                while (nm[cl]) cl++;
+                // \t RNAME \t POS \t255\t <len>M \t [*=] \t PNEXT \t TLEN \t SEQ \t QUAL \n
+                b += 1 + cl + 1 + n_digits((unsigned long)h.match_loci + 1) + 5 + n_digits(h.match_len) + 1 + 1 + 1 + 1 +
+                     n_digits((unsigned long)(r.pnext < 0 ? 0 : r.pnext + 1)) + 1 + n_digits((unsigned long)r.tlen) + 1 + r.len + 1 + qual + 1;
+            } else
+                // \t*\t0\t255\t <len>M\t*\t0\t0\t SEQ \t QUAL \t\tYU:Z:xx \n
+                b += 9 + n_digits(r.len) + 8 + r.len + 1 + qual + 7 + 2 + 1;
+        }
+        bytes[j] = b;
+    }
+    const uint64_t m = __ballot(rep != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_rep, (uint32_t)__popcll(m));
+}
+
+__global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint64_t k0, uint32_t n, const unsigned long long *__restrict__ at, char *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const SamRec r = sam_rec(d, k0 + j);
+    if (!r.reported) return;
+    const bk_hit h = d.hits[r.i];
+    const uint8_t *s = d.bases + d.offs[r.i];
+    char *w = out + at[j];
+    const char *nm = d.names + d.name_ofs[r.i];
+    for (uint32_t q = 0; q < r.nml; q++) *w++ = nm[q];
+    *w++ = '\t';
+    w = put_num(w, r.flag);
+    const char fwd[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'}, comp[8] = {'T', 'G', 'C', 'A', 'N', 'N', 'N', 'N'};
+    if (r.acc) {
+        *w++ = '\t';
+        w = put_str(w, d.ent_names + (size_t)(h.chrom_id - 1) * 81);
+        *w++ = '\t';
+        w = put_num(w, (long)h.match_loci + 1);
+        *w++ = '\t'; *w++ = '2'; *w++ = '5'; *w++ = '5'; *w++ = '\t';
+        w = put_num(w, h.match_len);
+        *w++ = 'M';
+        *w++ = '\t';
+        *w++ = r.pnext < 0 ? '*' : '=';
+        *w++ = '\t';
+        w = put_num(w, r.pnext < 0 ? 0L : r.pnext + 1);
+        *w++ = '\t';
+        w = put_num(w, r.tlen);
+        *w++ = '\t';
+        if (h.strand == '+') for (uint32_t q = 0; q < r.len; q++) w[q] = fwd[s[q] & 7];
+        else for (uint32_t q = 0; q < r.len; q++) w[q] = comp[s[r.len - 1 - q] & 7];
+        w += r.len;
+        *w++ = '\t';
+        if (!r.has_qual) *w++ = '*';
+        else {
+            const bool rev = h.strand != '+';
+            for (uint32_t q = 0; q < r.len; q++) w[q] = (char)(33 + ((((rev ? s[r.len - 1 - q] : s[q]) >> 4) & 15) * 40) / 15);
+            w += r.len;
+        }
+        *w++ = '\n';
+    } else {
+        w = put_str(w, "\t*\t0\t255\t");
+        w = put_num(w, r.len);
+        w = put_str(w, "M\t*\t0\t0\t");
+        for (uint32_t q = 0; q < r.len; q++) w[q] = fwd[s[q] & 7];
+        w += r.len;
+        *w++ = '\t';
+        if (!r.has_qual) *w++ = '*';
+        else {
+            for (uint32_t q = 0; q < r.len; q++) w[q] = (char)(33 + (((s[q] >> 4) & 15) * 40) / 15);
+            w += r.len;
+        }
+        w = put_str(w, "\t\tYU:Z:");                           // the doubled TAB is what the reference writes
+        w = put_str(w, kSamNarTag[h.nar < 20 ? h.nar : 0]);
+        *w++ = '\n';
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes)
+{
+    if (!c || !job || !sink || !n_reported || !n_bytes) return BK_ERR_PARAMS;
+    *n_reported = 0;
+    *n_bytes = 0;
+    if (!job->n_order) return BK_OK;
+    if (!job->bases || !job->offs || !job->lens || !job->names || !job->name_ofs || !job->hits || !job->order || !job->n_reads) return BK_ERR_PARAMS;
+    if (job->pe_mode && (job->n_reads & 1)) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t nr = job->n_reads;
+    const uint32_t n_ent = (uint32_t)c->entries.size();
+    // the read store, names, records and order travel to the device once (pageable memory: staged by a few threads)
+    DevBuf d_bases, d_offs, d_lens, d_names, d_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_text, d_cnt;
+#define SAM_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; } } while (0)
+    SAM_TRY(d_bases.alloc(job->n_bases + 16));
+    SAM_TRY(d_offs.alloc(nr * 8));
+    SAM_TRY(d_lens.alloc(nr * 4));
+    SAM_TRY(d_names.alloc(job->n_name_bytes + 16));
+    SAM_TRY(d_nofs.alloc((nr + 1) * 8));
+    SAM_TRY(d_hits.alloc(nr * sizeof(bk_hit)));
+    SAM_TRY(d_order.alloc(job->n_order * 4));
+    SAM_TRY(d_ent.alloc((size_t)n_ent * 81));
+    const uint32_t slice = (uint32_t)std::min<uint64_t>(job->n_order, 8u << 20);         // records per slice
+    SAM_TRY(d_bytes.alloc(((size_t)slice + 1) * 8));
+    SAM_TRY(d_at.alloc(((size_t)slice + 1) * 8));
+    SAM_TRY(d_cnt.alloc(16));
+    size_t tb = 0;
+    SAM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)slice + 1, s));
+    SAM_TRY(d_tmp.alloc(tb + 256));
+    if (bk::upload_host(d_bases.p, job->bases, job->n_bases, c->device) || bk::upload_host(d_offs.p, job->offs, nr * 8, c->device) ||
+        bk::upload_host(d_lens.p, job->lens, nr * 4, c->device) || bk::upload_host(d_names.p, job->names, job->n_name_bytes, c->device) ||
+        bk::upload_host(d_hits.p, job->hits, nr * sizeof(bk_hit), c->device) || bk::upload_host(d_order.p, job->order, job->n_order * 4, c->device))
+        return BK_ERR_INTERNAL;
+    {
+        std::vector<uint64_t> nofs(nr + 1);
+        memcpy(nofs.data(), job->name_ofs, nr * 8);
+        nofs[nr] = job->n_name_bytes;
+        if (bk::upload_host(d_nofs.p, nofs.data(), (nr + 1) * 8, c->device)) return BK_ERR_INTERNAL;
+        std::vector<char> en((size_t)n_ent * 81);
+        for (uint32_t e = 0; e < n_ent; e++) memcpy(&en[(size_t)e * 81], c->entries[e].name, 81);
+        HIP_TRY(hipMemcpy(d_ent.p, en.data(), en.size(), hipMemcpyHostToDevice));
+    }
+    SamDev d{};
+    d.bases = d_bases.as<uint8_t>(); d.offs = d_offs.as<uint64_t>(); d.lens = d_lens.as<uint32_t>(); d.names = d_names.as<char>();
+    d.name_ofs = d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
+    d.n_ent = n_ent; d.fmt6 = job->report_unaligned ? 1 : 0; d.pe_mode = job->pe_mode;
+    // chrom ids must name entries 1..n (the host checked its records when it made them; a stray id must not read out of bounds)
+    for (uint64_t i = 0; i < nr; i++)
+        if (job->hits[i].nar == BK_NAR_ACCEPTED && (job->hits[i].chrom_id < 1 || job->hits[i].chrom_id > n_ent)) return BK_ERR_PARAMS;
+    void *h_text[2] = {nullptr, nullptr};
+    uint64_t cap_text = 0;
+    auto free_host = [&]() { for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; } };
+    int rc = BK_OK;
+    uint64_t total_rep = 0, total_bytes = 0;
+    // a slice's text is handed to the sink on a thread of its own while the device formats the next slice into the other pinned
+    // buffer; the sink is told where in the text the slice starts, so two of its calls may overlap
+    std::thread sinker[2];
+    int sink_rc[2] = {0, 0};
+    auto settle = [&](int q) { if (sinker[q].joinable()) { sinker[q].join(); if (sink_rc[q] && rc == BK_OK) rc = BK_ERR_FILEACCESS; } };
+    for (uint64_t k0 = 0, si = 0; k0 < job->n_order && rc == BK_OK; k0 += slice, si++) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(slice, job->n_order - k0);
+        hipError_t e = hipMemsetAsync(d_cnt.p, 0, 16, s);
+        if (e == hipSuccess) e = hipMemsetAsync((char *)d_bytes.p + (size_t)n * 8, 0, 8, s);
+        hipLaunchKernelGGL(k_sam_measure, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_bytes.as<unsigned long long>(), d_cnt.as<uint32_t>());
+        size_t t2 = tb + 256;
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, t2, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)n + 1, s);
+        unsigned long long bytes = 0;
+        uint32_t rep = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bytes, d_at.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&rep, d_cnt.p, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { rc = BK_ERR_INTERNAL; break; }
+        if (bytes > cap_text) {
+            // (the text buffers follow the largest slice seen; the first slice sizes them for the run)
+            settle(0); settle(1);
+            if (d_text.p) { (void)hipFree(d_text.p); d_text.p = nullptr; }
+            free_host();
+            cap_text = bytes + bytes / 8 + (1u << 20);
+            bool ok = d_text.alloc(cap_text) == hipSuccess;
+            for (int q = 0; q < 2 && ok; q++) ok = hipHostMalloc(&h_text[q], cap_text, hipHostMallocDefault) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); rc = BK_ERR_MEM; break; }
+        }
+        const int q = (int)(si & 1);
+        settle(q);
+        if (rc != BK_OK) break;
+        hipLaunchKernelGGL(k_sam_write, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_at.as<unsigned long long>(), d_text.as<char>());
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h_text[q], d_text.p, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { rc = BK_ERR_INTERNAL; break; }
+        const uint64_t at = total_bytes;
+        if (bytes) sinker[q] = std::thread([&, q, bytes, at]() { sink_rc[q] = sink(user, reinterpret_cast<const char *>(h_text[q]), bytes, at); });
+        total_rep += rep;
+        total_bytes += bytes;
+    }
+    settle(0);
+    settle(1);
+    free_host();
+    *n_reported = total_rep;
+    *n_bytes = total_bytes;
+    return rc;
+#undef SAM_TRY
+}

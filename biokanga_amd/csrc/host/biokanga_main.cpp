@@ -1016,6 +1016,7 @@ int cmd_align(int argc, char **argv, int first)
     sorted_order(order);
 
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
+    R.ctx = ctx;
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");
     int rr = (o.fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);

@@ -525,6 +525,62 @@ int report_text(Report &R)
             st.n = (size_t)(w - st.d);
             return true;
         };
+        // Plain records - one segment, no end trims, one record per read - are formatted on the device (bk_sam_format): the host
+        // hands over reads, names, records and the output order, and copies the text it gets back, slice by slice, into the file.
+        // Whatever the device path cannot take, or fails on, is formatted below by the host threads.
+        bool device_done = false;
+        const char *dev_min = getenv("BK_SAM_DEVICE_MIN");                        // (records from which the device formats: tests set it to 1, a huge value keeps the host path)
+        if (R.ctx != nullptr && !out.gz && R.src.empty() && R.seg2.empty() && R.trims.empty() && nr >= (size_t)(dev_min ? strtoull(dev_min, nullptr, 10) : 100000ULL)) {
+            const bool timing0 = getenv("BK_TIMING") != nullptr;
+            timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
+            out.flush();
+            struct SinkState { int fd; off_t base; int nthreads; } st{out.fd, out.pos, std::max(1, nthreads / 2)};
+            auto sink = [](void *user, const char *text, uint64_t n, uint64_t ofs) -> int {
+                SinkState *S = static_cast<SinkState *>(user);
+                const off_t at = S->base + (off_t)ofs;
+                // the slice's range of the file is allocated and mapped, and the threads copy into the mapping (concurrent pwrite()s to one
+                // file queue up behind the inode lock); pwrite() remains for files that cannot be mapped
+                char *map = nullptr;
+                const off_t map_lo = at & ~(off_t)4095;
+                const size_t map_len = (size_t)(at + (off_t)n - map_lo);
+                if (fallocate(S->fd, 0, at, (off_t)n) == 0) {
+                    void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, S->fd, map_lo);
+                    if (m != MAP_FAILED) map = (char *)m;
+                }
+                const int nt = S->nthreads;
+                std::vector<std::thread> th;
+                std::atomic<int> bad{0};
+                auto put = [&](int t) {
+                    const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
+                    if (map) { memcpy(map + (at - map_lo) + lo, text + lo, hi - lo); return; }
+                    for (uint64_t o = lo; o < hi;) {
+                        ssize_t w = ::pwrite(S->fd, text + o, hi - o, at + (off_t)o);
+                        if (w <= 0) { bad = 1; return; }
+                        o += (uint64_t)w;
+                    }
+                };
+                for (int t = 1; t < nt; t++) th.emplace_back(put, t);
+                put(0);
+                for (auto &t : th) t.join();
+                if (map) munmap(map, map_len);
+                return bad.load();
+            };
+            bk_sam_job job{};
+            job.bases = rs.bases.data(); job.n_bases = rs.bases.size(); job.offs = rs.offs.data(); job.lens = rs.lens.data();
+            job.names = rs.names.data(); job.n_name_bytes = rs.names.size(); job.name_ofs = rs.name_ofs.data();
+            job.hits = hits.data(); job.n_reads = nr; job.order = order.data(); job.n_order = nr;
+            job.report_unaligned = fmt == 6 ? 1 : 0; job.pe_mode = pe_mode;
+            uint64_t n_rep = 0, n_bytes = 0;
+            const int drc = rs.lens.size() == nr ? bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes) : BK_ERR_PARAMS;
+            if (drc == BK_OK) {
+                out.pos += (off_t)n_bytes;
+                if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
+                n_reported = n_rep;
+                device_done = true;
+                if (timing0) { timespec t1s; clock_gettime(CLOCK_MONOTONIC, &t1s); fprintf(stderr, "bk timing: SAM formatted on the device and copied out: %.0f ms (%llu bytes)\n", 1e3 * ((double)(t1s.tv_sec - t0s.tv_sec) + 1e-9 * (double)(t1s.tv_nsec - t0s.tv_nsec)), (unsigned long long)n_bytes); }
+            } else if (timing0)
+                fprintf(stderr, "bk timing: device SAM formatter declined (%s): host threads format\n", bk_strerror(drc));
+        }
         // records are formatted by all host threads into per-thread buffers, one stripe of the sorted order
         // each, and written out in order (the reference formats serially, ~4.5 us per read)
         const size_t per_thread = 131072;
@@ -543,7 +599,7 @@ int report_text(Report &R)
         // The file is cut to its real size at the end.
         std::atomic<off_t> prealloc_size{0};
         std::thread prealloc;
-        if (!out.gz && nr >= 200000) {
+        if (!out.gz && nr >= 200000 && !device_done) {
             out.flush();
             const bool with_qual = a.num("g", 3) != 3;                                 // QUAL is '*' unless FASTQ scores were loaded (-g0..2)
             uint64_t est = (uint64_t)out.pos + rs.names.size() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
@@ -558,7 +614,7 @@ int report_text(Report &R)
                 }
             });
         }
-        for (size_t k0 = 0; k0 < nr; k0 += per_thread * (size_t)nt) {
+        for (size_t k0 = 0; k0 < nr && !device_done; k0 += per_thread * (size_t)nt) {
             const double tA = now();
             auto work = [&](int t) {
                 size_t lo = k0 + (size_t)t * per_thread, hi = std::min(nr, lo + per_thread);

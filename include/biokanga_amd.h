@@ -373,6 +373,32 @@ int  bk_snp_counts(bk_ctx *ctx, uint32_t chrom_id, uint32_t loci, uint32_t n, ui
 #define BK_SNP_CENTROIDS 16384
 int  bk_snp_centroid_insts(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, uint32_t *num_insts);
 
+/* ---- SAM records formatted on the device -------------------------------------------------------------------------
+ * CAligner::ReportBAMread (biokanga/Aligner.cpp:5768-6126; CSAMfile::AddAlignment, SAMfile.cpp:2100-2283) prints one text line per
+ * read; for tens of millions of reads that is byte-parallel work.  bk_sam_format() takes the reads, their names, their records and
+ * the order the lines are wanted in (the reference's sort order is the host's business) and hands the lines back as text, in
+ * slices: a lane per record measures its line, a prefix sum places it, the lane writes it.  Plain records only - one segment, no
+ * end trims (no -a / -A / -c / -x); with pe_mode the reads are interleaved PE1, PE2 and carry the flags bk_pair_batch left.
+ * The sink is called once per slice with the slice's text and its offset within the whole text; up to two calls may run at the
+ * same time (on threads of the library), each must return 0.  Lines are those of the reference's SAM body, byte for byte. */
+typedef struct bk_sam_job {
+    const uint8_t  *bases;        /* all reads, 1 byte/base as CAligner holds them (quality in bits 4-7 when loaded)      */
+    uint64_t        n_bases;
+    const uint64_t *offs;         /* n_reads: start of read i in bases                                                     */
+    const uint32_t *lens;         /* n_reads                                                                               */
+    const char     *names;        /* the reads' names, NUL-terminated, back to back in read order                          */
+    uint64_t        n_name_bytes;
+    const uint64_t *name_ofs;     /* n_reads: start of name i in names                                                     */
+    const bk_hit   *hits;         /* n_reads records                                                                       */
+    uint64_t        n_reads;
+    const uint32_t *order;        /* n_order read numbers: the lines in output order                                       */
+    uint64_t        n_order;
+    int32_t         report_unaligned;   /* -M6: reads without an accepted alignment get a line too (FLAG 4, YU:Z:<reason>) */
+    int32_t         pe_mode;            /* 0, or the -U mode the records were paired under                                 */
+} bk_sam_job;
+typedef int (*bk_sam_sink)(void *user, const char *text, uint64_t n_bytes, uint64_t text_offset);
+int  bk_sam_format(bk_ctx *ctx, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes);
+
 /* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
 /* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into
  * d_sa_out (sfx_el_size bytes/element) on the device: order = nibble-lexicographic exactly as

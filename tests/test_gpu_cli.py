@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 BIN = os.path.join(helpers.ROOT, "biokanga_amd", "bin", "biokanga")
 
 
-def run(args, cwd):
-    r = subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+def run(args, cwd, env=None):
+    r = subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-3000:]
     return r.stdout
 
@@ -606,3 +607,35 @@ def test_options_from_a_parameter_file(golden_tmp, tmp_path):
     pf.write_text(f"# reads and index\n-i {os.path.join(d, 'reads.fa')}   -I {os.path.join(d, 'genome.sfx')}\n; output\n\n// format\n-M6\t-s3\n")
     run(["align", f"@{pf}", "-o", out], str(tmp_path))
     assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
+
+
+@pytest.mark.parametrize("case", ["basic_m6", "basic_m5", "repeat_m6", "sortorder", "pe_U3", "pe_U2", "pe150_U3", "fq_g0", "fq_g1", "two_contexts"])
+def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
+    """bk_sam_format: the records of plain SAM runs formatted by the device (a lane per record) are the reference's lines byte for
+    byte - single and paired ends, -M5 / -M6, FASTQ scores in QUAL, the 30 000-read order.  Small runs use the host threads by default;
+    BK_SAM_DEVICE_MIN=1 sends these through the device, and the timing line says so."""
+    d = golden_tmp["basic"]
+    sfx = os.path.join(d, "genome.sfx")
+    out = str(tmp_path / "o.sam")
+    env = {"BK_SAM_DEVICE_MIN": "1", "BK_TIMING": "1"}
+    if case in ("basic_m6", "basic_m5", "two_contexts"):
+        args = ["-i", os.path.join(d, "reads.fa"), "-I", sfx, "-s3"] + (["-M6"] if case != "basic_m5" else []) + (["--devices", "0,0"] if case == "two_contexts" else [])
+        gold = ("basic", "s3.m5.sam.gz" if case == "basic_m5" else "s3.m6.sam.gz")
+    elif case == "repeat_m6":
+        args = ["-i", os.path.join(golden_tmp["repeat"], "reads.fa"), "-I", os.path.join(golden_tmp["repeat"], "genome.sfx"), "-s3", "-M6"]
+        gold = ("repeat", "s3.m6.sam.gz")
+    elif case == "sortorder":
+        args = ["-i", os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz"), "-I", sfx, "-s3"]
+        gold = ("sortorder", "s3.m5.sam.gz")
+    elif case.startswith("pe"):
+        fx, tag = case.split("_")
+        p = os.path.join(helpers.GOLDEN, fx)
+        args = ["-i", os.path.join(p, "reads_1.fa.gz"), "-u", os.path.join(p, "reads_2.fa.gz"), "-I", sfx, "-M6", f"-{tag}", "-d200", "-D400", "-s5"]
+        gold = (fx, f"{tag}.m6.sam.gz")
+    else:
+        g = case[-1]
+        args = ["-i", os.path.join(helpers.GOLDEN, "basic", "reads.fq.gz"), "-I", sfx, "-M6", "-s3", f"-g{g}"]
+        gold = ("basic", f"s3fqg{g}.m6.sam.gz")
+    log = run(["align", "-o", out] + args, str(tmp_path), env=env)
+    assert "SAM formatted on the device" in log, log[-1500:]
+    assert open(out, "rb").read() == golden_bytes(*gold)
