@@ -769,7 +769,7 @@ int cmd_align(int argc, char **argv, int first)
         {"mode", "m"}, {"alignstrand", "Q"}, {"editdelta", "e"}, {"substitutions", "s"}, {"maxns", "n"}, {"trim5", "y"},
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
-        {"quality", "g"}, {"device", "device"}, {"devices", "devices"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
+        {"quality", "g"}, {"device", "device"}, {"devices", "devices"}, {"window-array", "window-array"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
         {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
         {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}, {"snpcentroid", "7"}};
@@ -820,6 +820,26 @@ int cmd_align(int argc, char **argv, int first)
     diag("Genome assembly suffix array loaded");
 
     size_t nr = rs.size();
+    // The suffix-ordered window array (48 bytes per suffix: 149 GB and 2.6 s of set-up for a 3.1 Gbp index) serves long-running work;
+    // a run pays for it only from several hundred million reads per device on, or when asked to (--window-array)
+    {
+        const bool want = a.has("window-array") || nr / ctxs.size() >= 400000000ULL;
+        for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want ? 1 : 0);
+    }
+    // SAM text goes into a file of known approximate size: its pages are allocated in the background from now on (fallocate fills
+    // them with zeros at memory speed: 7 GB for 50 M reads of 100 bases), while the reads are aligned and sorted
+    SamPrealloc pre;
+    if (o.fmt >= 5) {
+        const std::string opath0 = a.str("o");
+        const size_t ol = opath0.size();
+        const bool bam = ol > 5 && !strcasecmp(opath0.c_str() + ol - 4, ".bam"), gz = ol > 3 && !strcasecmp(opath0.c_str() + ol - 3, ".gz");
+        const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)
+        if (!bam && !gz && nr >= (size_t)(min_env ? strtoull(min_env, nullptr, 10) : 200000ULL)) {
+            uint64_t est = (1u << 20) + rs.names.size() + 64ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
+            est += (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.bases.size();
+            pre.start(opath0.c_str(), est);
+        }
+    }
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
     AlignedSet A;
     if (o.pe_mode) diag("Paired end association and partner alignment processing runs with the alignment of each batch");
@@ -1017,6 +1037,7 @@ int cmd_align(int argc, char **argv, int first)
 
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
     R.ctx = ctx;
+    R.pre = pre.fd >= 0 ? &pre : nullptr;
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");
     int rr = (o.fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);

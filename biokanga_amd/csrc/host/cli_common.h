@@ -2,6 +2,9 @@
 // read store, buffered (optionally gzip'd) file output, the NAR tags.
 #pragma once
 #include <fcntl.h>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <sys/time.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -97,6 +100,34 @@ struct ReadStore {
     const char *name(size_t i) const { return names.data() + name_ofs[i]; }
 };
 
+// The output file of a SAM run, created early: one background thread allocates its pages (Linux fallocate - which fails where the
+// file system cannot do it natively instead of emulating it with racy reads and writes; then nothing is preallocated) 256 MB at a
+// time from an estimate of the text's size, while the run does everything else.  The writers later copy into pages that exist.
+struct SamPrealloc {
+    int fd = -1;
+    std::atomic<off_t> done{0};         // bytes from the file's start that are allocated
+    std::atomic<bool> quit{false}, ended{false};
+    off_t est = 0;
+    std::thread th;
+    void start(const char *path, uint64_t estimate)
+    {
+        fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return;
+        est = (off_t)estimate;
+        th = std::thread([this]() {
+            const off_t step = 256LL << 20;
+            for (off_t at = 0; at < est && !quit.load(); at += step) {
+                const off_t len = std::min<off_t>(step, est - at);
+                if (fallocate(fd, 0, at, len) != 0) break;
+                done.store(at + len);
+            }
+            ended.store(true);
+        });
+    }
+    void finish() { quit.store(true); if (th.joinable()) th.join(); }
+    ~SamPrealloc() { finish(); if (fd >= 0) ::close(fd); }
+};
+
 struct OutBuf {
     int fd = -1;
     gzFile gz = nullptr;                    // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337)
@@ -123,7 +154,8 @@ struct OutBuf {
         pos += (off_t)o;
         b.clear();
     }
-    void close() { flush(); if (gz) { gzclose(gz); gz = nullptr; fd = -1; } if (fd >= 0) { fsync(fd); ::close(fd); } fd = -1; }
+    bool borrowed = false;                  // the descriptor belongs to a SamPrealloc
+    void close() { flush(); if (gz) { gzclose(gz); gz = nullptr; fd = -1; } if (fd >= 0) { fsync(fd); if (!borrowed) ::close(fd); } fd = -1; }
 };
 
 }  // namespace bkcli

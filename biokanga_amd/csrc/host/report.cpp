@@ -390,7 +390,8 @@ int report_text(Report &R)
     auto a_mm = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_mm(h, i); };
     const int pe_mode = R.pe_mode, ml_mode = R.ml_mode, fmt = R.fmt, nthreads = R.nthreads, micro_indel = R.micro_indel, splice_len = R.splice_len, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
     OutBuf out;
-    out.open(a.str("o").c_str());
+    if (R.pre != nullptr && fmt >= 5) { out.fd = R.pre->fd; out.borrowed = true; out.b.reserve(8 << 20); }
+    else out.open(a.str("o").c_str());
     if (out.fd < 0) { diag("Fatal: unable to create '%s'", a.str("o").c_str()); return 1; }
     char line[8192];
     uint64_t n_reported = 0;
@@ -534,7 +535,7 @@ int report_text(Report &R)
             const bool timing0 = getenv("BK_TIMING") != nullptr;
             timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
             out.flush();
-            struct SinkState { int fd; off_t base; int nthreads; } st{out.fd, out.pos, std::max(1, nthreads / 2)};
+            struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; } st{out.fd, out.pos, std::max(1, nthreads / 2), R.pre};
             auto sink = [](void *user, const char *text, uint64_t n, uint64_t ofs) -> int {
                 SinkState *S = static_cast<SinkState *>(user);
                 const off_t at = S->base + (off_t)ofs;
@@ -543,7 +544,16 @@ int report_text(Report &R)
                 char *map = nullptr;
                 const off_t map_lo = at & ~(off_t)4095;
                 const size_t map_len = (size_t)(at + (off_t)n - map_lo);
-                if (fallocate(S->fd, 0, at, (off_t)n) == 0) {
+                // (pages the background thread has allocated, or is about to, are not allocated twice)
+                bool have = false;
+                if (S->pre != nullptr && S->pre->est >= at + (off_t)n) {
+                    while (S->pre->done.load() < at + (off_t)n && !S->pre->ended.load()) {
+                        timespec ts{0, 200000};
+                        nanosleep(&ts, nullptr);
+                    }
+                    have = S->pre->done.load() >= at + (off_t)n;
+                }
+                if (have || fallocate(S->fd, 0, at, (off_t)n) == 0) {
                     void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, S->fd, map_lo);
                     if (m != MAP_FAILED) map = (char *)m;
                 }
@@ -574,6 +584,7 @@ int report_text(Report &R)
             const int drc = rs.lens.size() == nr ? bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes) : BK_ERR_PARAMS;
             if (drc == BK_OK) {
                 out.pos += (off_t)n_bytes;
+                if (R.pre != nullptr) R.pre->finish();
                 if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
                 n_reported = n_rep;
                 device_done = true;
@@ -599,7 +610,8 @@ int report_text(Report &R)
         // The file is cut to its real size at the end.
         std::atomic<off_t> prealloc_size{0};
         std::thread prealloc;
-        if (!out.gz && nr >= 200000 && !device_done) {
+        if (R.pre != nullptr && !device_done) { R.pre->finish(); prealloc_size.store(R.pre->done.load()); }    // (what the early thread allocated counts; the rest as before)
+        if (!out.gz && nr >= 200000 && !device_done && R.pre == nullptr) {
             out.flush();
             const bool with_qual = a.num("g", 3) != 3;                                 // QUAL is '*' unless FASTQ scores were loaded (-g0..2)
             uint64_t est = (uint64_t)out.pos + rs.names.size() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
@@ -665,7 +677,7 @@ int report_text(Report &R)
             // the range must exist before it is mapped: already preallocated, or allocated here (fallocate only ever grows a file, so
             // it cannot collide with the background thread the way an ftruncate could)
             const bool have_range = at[(size_t)nt] > at[0] &&
-                                    (prealloc.joinable() ? (prealloc_size.load() >= at[(size_t)nt] || fallocate(out.fd, 0, at[0], at[(size_t)nt] - at[0]) == 0)
+                                    ((prealloc.joinable() || R.pre != nullptr) ? (prealloc_size.load() >= at[(size_t)nt] || fallocate(out.fd, 0, at[0], at[(size_t)nt] - at[0]) == 0)
                                                          : ftruncate(out.fd, at[(size_t)nt]) == 0);
             if (have_range) {
                 void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, out.fd, map_lo);
@@ -691,6 +703,10 @@ int report_text(Report &R)
             if (map) munmap(map, map_len);
             t_put += now() - tC;
             out.pos = at[(size_t)nt];
+        }
+        if (R.pre != nullptr && !device_done) {
+            out.flush();
+            if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
         }
         if (prealloc.joinable()) {
             prealloc.join();
