@@ -1456,12 +1456,6 @@ typedef struct at_region { uint16_t ofs, len; uint8_t mm, trim5, trim3; } at_reg
 /* AdaptiveTrim, SfxArrayV2.cpp:5482-5682 */
 static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
                             uint32_t min_flank, uint32_t *p_trim_mms, uint32_t *p_trim_start, uint32_t *p_trim_end);
-static int adaptive_trim(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
-                         uint32_t min_flank, uint32_t *p_trim_mms)
-{
-    uint32_t a, b;
-    return adaptive_trim_ex(seq_len, probe, targ, min_trim_len, max_mm, min_flank, p_trim_mms, &a, &b);
-}
 static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_t *targ, uint32_t min_trim_len, uint32_t max_mm,
                             uint32_t min_flank, uint32_t *p_trim_mms, uint32_t *p_trim_start, uint32_t *p_trim_end)
 {
@@ -1527,7 +1521,7 @@ static int adaptive_trim_ex(uint32_t seq_len, const uint8_t *probe, const uint8_
 
 /* AlignPairedRead, SfxArrayV2.cpp:8247-8433 (MinChimericLen = 0) */
 static int align_paired_read(const ora_sfx *s, int b3prime, int antisense, uint32_t chrom_id, uint32_t start_loci, uint32_t end_loci,
-                             int min_dist, int max_dist, int max_allowed_mm, int read_len, int core_len, int core_delta,
+                             int min_dist, int max_dist, int max_allowed_mm, int read_len, int min_chimeric_pct, int core_len, int core_delta,
                              const uint8_t *read, hit_rec *out)
 {
     if (min_dist < read_len || min_dist > max_dist) return 0;
@@ -1543,7 +1537,9 @@ static int align_paired_read(const ora_sfx *s, int b3prime, int antisense, uint3
     memcpy(rs, read, (size_t)read_len);
     rs[read_len] = B_EOS;
     if (antisense) revcomp(rs, read_len);
-    uint32_t min_put_len = (uint32_t)read_len, start_put, end_put;
+    /* MinChimericLen > 0: the partner may be end-trimmed down to that percentage of its length (:8327-8330) */
+    uint32_t min_put_len = min_chimeric_pct > 0 ? (uint32_t)((read_len * min_chimeric_pct + 50) / 100) : (uint32_t)read_len, start_put, end_put;
+    uint32_t t5, t3;
     if (b3prime) {
         start_put = (uint32_t)(targ_loci + min_dist);
         if (start_put + min_put_len >= targ_len) return 0;
@@ -1567,11 +1563,13 @@ static int align_paired_read(const ora_sfx *s, int b3prime, int antisense, uint3
                 uint32_t hit = (uint32_t)((uint64_t)pos - e->start_ofs);
                 if (hit < start_put || hit > end_put) continue;
                 if (core_ofs > hit || (hit + (uint32_t)read_len - core_ofs) >= targ_len) continue;
-                int r = adaptive_trim((uint32_t)read_len, rs, chrom + (hit - core_ofs), min_put_len, (uint32_t)max_allowed_mm, 3, &mms);
+                int r = adaptive_trim_ex((uint32_t)read_len, rs, chrom + (hit - core_ofs), min_put_len, (uint32_t)max_allowed_mm, 3, &mms, &t5, &t3);
                 if (r > (int)min_put_len || (r == (int)min_put_len && mms < prev_best)) {
                     prev_best = mms; min_put_len = (uint32_t)r;
                     out->strand = antisense ? '-' : '+'; out->chrom_id = chrom_id; out->match_loci = hit - core_ofs;
                     out->match_len = (uint16_t)read_len; out->mismatches = (uint8_t)mms;
+                    out->chimeric = (int)min_put_len == read_len ? 0 : 1;
+                    out->trim_left = (uint16_t)(antisense ? t3 : t5); out->trim_right = (uint16_t)(antisense ? t5 : t3);
                 }
             }
         }
@@ -1586,11 +1584,13 @@ static int align_paired_read(const ora_sfx *s, int b3prime, int antisense, uint3
                 }
                 win = tmpw;
             }
-            int r = adaptive_trim((uint32_t)read_len, rs, win, min_put_len, (uint32_t)max_allowed_mm, 3, &mms);
+            int r = adaptive_trim_ex((uint32_t)read_len, rs, win, min_put_len, (uint32_t)max_allowed_mm, 3, &mms, &t5, &t3);
             if (r > (int)min_put_len || (r == (int)min_put_len && mms < prev_best)) {
                 prev_best = mms; min_put_len = (uint32_t)r;
                 out->strand = antisense ? '-' : '+'; out->chrom_id = chrom_id; out->match_loci = hit;
                 out->match_len = (uint16_t)read_len; out->mismatches = (uint8_t)mms;
+                out->chimeric = (int)min_put_len == read_len ? 0 : 1;
+                out->trim_left = (uint16_t)(antisense ? t3 : t5); out->trim_right = (uint16_t)(antisense ? t5 : t3);
             }
         }
     }
@@ -1605,6 +1605,26 @@ int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, 
                             int pair_strand, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
                             uint32_t n_pairs, ora_hit *hits)
 {
+    return ora_process_paired_ends_ex(s, p, pe_mode, pair_min_len, pair_max_len, pair_strand, bases, offs, lens, n_pairs, hits, NULL);
+}
+
+/* AdjStartLoci / AdjEndLoci (Aligner.cpp:1528-1544) of a read's Seg[0]: the end trims of a chimeric placement (seg2 flags bit 3:
+ * match_len = TrimLeft, read_ofs = TrimRight) move them inwards */
+static void adj_loci(const ora_hit *h, const ora_seg2 *g, uint32_t *start, uint32_t *end)
+{
+    uint32_t tl = 0, tr = 0;
+    if (g != NULL && (g->flags & 8)) { tl = g->match_len; tr = g->read_ofs; }
+    if (h->strand == '+') { *start = h->match_loci + tl; *end = h->match_loci + (h->match_len - tr - 1); }
+    else { *start = h->match_loci + tr; *end = h->match_loci + (h->match_len - tl - 1); }
+}
+
+/* with seg2 != NULL (one entry per read, as ora_align_batch_ex left them): p->min_chimeric_len takes part - the pair rules look at the
+ * trimmed loci and the orphan recovery may place the partner end-trimmed, whose trims then replace its seg2 entry */
+int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mode, int pair_min_len, int pair_max_len,
+                               int pair_strand, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
+                               uint32_t n_pairs, ora_hit *hits, ora_seg2 *seg2)
+{
+    const int min_chim = seg2 != NULL ? p->min_chimeric_len : 0;
     int min_core = ora_min_core_len(s, p->pmode);
     int slides = ora_max_num_slides(p->pmode);
     for (uint32_t i = 0; i < n_pairs; i++) {
@@ -1623,8 +1643,12 @@ int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, 
             int frag = 0;
             if (f->num_hits == 1 && r->num_hits == 1) {                 /* AcceptProvPE */
                 if (f->chrom_id != r->chrom_id) frag = -2;
-                else frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, f->strand, f->match_loci,
-                                           f->match_loci + f->match_len - 1, r->strand, r->match_loci, r->match_loci + r->match_len - 1);
+                else {
+                    uint32_t fs, fe, rs_, re;
+                    adj_loci(f, seg2 ? &seg2[2 * i] : NULL, &fs, &fe);
+                    adj_loci(r, seg2 ? &seg2[2 * i + 1] : NULL, &rs_, &re);
+                    frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, f->strand, fs, fe, r->strand, rs_, re);
+                }
             }
             if (frag > 0) { f->flags |= 0x80; r->flags |= 0x80; continue; }
             switch (frag) {
@@ -1655,7 +1679,8 @@ int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, 
                     b3 = a->strand == '+'; anti = a->strand == '+';
                     if (pair_strand) { b3 = !b3; anti = !anti; }
                 }
-                uint32_t a_start = a->match_loci, a_end = a->match_loci + a->match_len - 1;
+                uint32_t a_start, a_end;
+                adj_loci(a, seg2 ? &seg2[2 * i + (anchor == 0 ? 0 : 1)] : NULL, &a_start, &a_end);
                 int probe_len = (int)lens[oi], match_len = probe_len - 1;
                 int max_tot_mm = p->max_subs == 0 ? 0 : imax(1, (int)(0.5 + (match_len * p->max_subs) / 100.0));
                 if (max_tot_mm > MAX_TOT_SUBS) max_tot_mm = MAX_TOT_SUBS;
@@ -1665,17 +1690,24 @@ int ora_process_paired_ends(const ora_sfx *s, const ora_params *p, int pe_mode, 
                 for (int k = 0; k < probe_len; k++) rs[k] = bases[offs[oi] + k] & 0x07;
                 hit_rec h;
                 int rc = align_paired_read(s, b3, anti, a->chrom_id, a_start, a_end, pair_min_len, pair_max_len, p->max_subs,
-                                           probe_len, core_len, core_delta, rs, &h);
+                                           probe_len, min_chim, core_len, core_delta, rs, &h);
                 if (rc == 1) {
                     int frag;
-                    uint32_t h_end = h.match_loci + h.match_len - 1;
-                    if (anchor == 0) frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, a->strand, a_start, a_end, h.strand, h.match_loci, h_end);
-                    else frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, h.strand, h.match_loci, h_end, a->strand, a_start, a_end);
+                    /* AdjStartLoci / AdjEndLoci of the placement just found */
+                    uint32_t h_start = h.match_loci + (h.strand == '+' ? h.trim_left : h.trim_right);
+                    uint32_t h_end = h.match_loci + (h.match_len - (h.strand == '+' ? h.trim_right : h.trim_left) - 1);
+                    if (anchor == 0) frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, a->strand, a_start, a_end, h.strand, h_start, h_end);
+                    else frag = pe_insert_size(pair_min_len, pair_max_len, pair_strand, h.strand, h_start, h_end, a->strand, a_start, a_end);
                     if (frag <= 0) rc = 0;
                 }
                 if (rc == 1) {
                     o->chrom_id = h.chrom_id; o->match_loci = h.match_loci; o->match_len = h.match_len; o->strand = h.strand;
                     o->mismatches = h.mismatches; o->num_hits = 1; o->low_mm = (int8_t)h.mismatches; o->low_hit_instances = 1;
+                    if (seg2 != NULL) {                          /* pXReadHit->HitLoci.Hit = HitLoci: the whole record is replaced */
+                        ora_seg2 *g = &seg2[oi];
+                        memset(g, 0, sizeof(*g));
+                        if (h.chimeric) { g->flags = 8; g->match_len = h.trim_left; g->read_ofs = h.trim_right; }
+                    }
                     f->flags |= 0x80; r->flags |= 0x80;
                     f->nar = r->nar = NAR_ACCEPTED;
                     done = 1;

@@ -918,6 +918,87 @@ def make_chimeric(tmp):
     shutil.copyfile(bam + ".bai", os.path.join(outdir, "c50.m6.bam.bai"))
 
 
+def make_pechim(tmp):
+    """chimeric trimming together with paired ends (-c with -U: the pair rules work on the trimmed loci, AdjStartLoci / AdjEndLoci,
+    Aligner.cpp:2750-2769, and the orphan recovery may return an end-trimmed partner, AlignPairedRead with MinChimericLen,
+    SfxArrayV2.cpp:8327): FR pairs on the chimeric fixture's genome, a mate's 5' and / or 3' end (10..45 bases) foreign in a third of
+    the mates, mates inside the duplicated region (orphan recovery), inserts in and out of the accepted range"""
+    rng = np.random.default_rng(31415)
+    outdir = os.path.join(HERE, "pechim")
+    os.makedirs(outdir, exist_ok=True)
+    fa = os.path.join(tmp, "pechim.fa")
+    with gzip.open(os.path.join(HERE, "chimeric", "genome.fa.gz"), "rb") as f, open(fa, "wb") as g_:
+        shutil.copyfileobj(f, g_)
+    seqs, name = {}, None
+    for line in open(fa):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = []
+        else:
+            seqs[name].append(line.upper())
+    g = {k: "".join(v) for k, v in seqs.items()}
+    names = list(g)
+    L = 100
+    r1, r2 = [], []
+
+    def foreign(k):
+        if rng.integers(0, 2):
+            return rand_seq(rng, k)
+        c2 = names[int(rng.integers(0, 2))]; q = int(rng.integers(0, len(g[c2]) - k))
+        return g[c2][q:q + k]
+
+    def chim(s):
+        """a read whose ends may come from elsewhere"""
+        if rng.integers(0, 3):
+            return s, 0, 0
+        k5 = int(rng.integers(10, 46)) if rng.integers(0, 3) else 0
+        k3 = int(rng.integers(10, 46)) if (rng.integers(0, 3) == 0 or k5 == 0) else 0
+        if k5 + k3 > 45:
+            k3 = 0
+        return foreign(k5) + s[k5:L - k3] + foreign(k3), k5, k3
+
+    for i in range(700):
+        c = names[int(rng.integers(0, 2))]
+        ins = int(np.clip(rng.normal(300, 70), 160, 560))
+        p = int(rng.integers(0, len(g[c]) - ins))
+        if i < 60:                                            # one mate inside the duplicated 400 bases (cA 7000.., cB 5000..)
+            c, p = "cA", 7000 + int(rng.integers(0, 250)) - (ins - L if rng.integers(0, 2) else 0)
+            p = max(0, p)
+        a = mutate(rng, g[c][p:p + L], int(rng.integers(0, 3)))
+        b = mutate(rng, g[c][p + ins - L:p + ins], int(rng.integers(0, 3)))
+        if len(a) < L or len(b) < L:
+            continue
+        a, a5, a3 = chim(a)
+        b, b5, b3 = chim(b)
+        b = revcomp(b)
+        if rng.integers(0, 2):                                # the pair read from the other strand
+            a, b = b, a
+        if i % 23 == 0:
+            b = rand_seq(rng, L)                              # mate 2 unalignable
+        r1.append((f"q{i}_{ins}_{a5}_{a3}/1", a))
+        r2.append((f"q{i}_{ins}_{b5}_{b3}/2", b))
+    f1, f2 = os.path.join(tmp, "pechim_1.fa"), os.path.join(tmp, "pechim_2.fa")
+    write_reads(f1, r1)
+    write_reads(f2, r2)
+    sfx = os.path.join(tmp, "pechim.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "chim", "-T4"], tmp)
+    gz_copy(f1, os.path.join(outdir, "reads_1.fa.gz"))
+    gz_copy(f2, os.path.join(outdir, "reads_2.fa.gz"))
+    for tag, flags in (("U3c50", ["-U3", "-c50", "-s3", "-d200", "-D400"]), ("U1c60", ["-U1", "-c60", "-s3", "-d200", "-D400"]),
+                       ("U4c50", ["-U4", "-c50", "-s3", "-d200", "-D400"]), ("U2c70s5", ["-U2", "-c70", "-s5", "-d200", "-D400"]),
+                       ("U3c50wide", ["-U3", "-c50", "-s3", "-d150", "-D1500"]), ("U3", ["-U3", "-s3", "-d200", "-D400"])):
+        out = os.path.join(tmp, f"pechim_{tag}.sam")
+        log = run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M6", "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(outdir, f"{tag}.m6.sam.gz"))
+        with open(os.path.join(outdir, f"{tag}.nar.txt"), "w") as f:
+            f.write(nar_summary(log))
+        print("  ran PE + chimeric", tag, flags)
+    out = os.path.join(tmp, "pechim_U3c50.m0.csv")
+    run([REF, "align", "-i", f1, "-u", f2, "-I", sfx, "-o", out, "-M0", "-T4", "-U3", "-c50", "-s3", "-d200", "-D400"], tmp)
+    gz_copy(out, os.path.join(outdir, "U3c50.m0.csv.gz"))
+
+
 def make_combined(tmp):
     """-a / -A / -c together (AlignReads tries them in that order and hands each one's leftover state to the next, :7722-7757):
     the indel, splice and chimeric reads in ONE run against a genome holding all three fixtures' sequences"""
@@ -1310,6 +1391,8 @@ def main():
             return
         if "--only-chimeric" in sys.argv:
             make_chimeric(tmp)
+        if "--only-pechim" in sys.argv:
+            make_pechim(tmp)
             return
         if "--only-splice" in sys.argv:
             make_splice(tmp)
