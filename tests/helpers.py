@@ -91,6 +91,10 @@ def oracle_lib():
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                             ctypes.c_void_p]
     lib.ora_process_paired_ends.restype = ctypes.c_int
+    lib.ora_process_paired_ends_ex.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                               ctypes.c_void_p]
+    lib.ora_process_paired_ends_ex.restype = ctypes.c_int
     lib.ora_snp_chrom_sites.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
     lib.ora_snp_chrom_sites.restype = ctypes.c_int64
@@ -247,12 +251,21 @@ def _remove_orphans(hits, seg2, flag, nar):
     return hits
 
 
-def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits):
-    """in-place PE association on `hits` (PE1/PE2 interleaved); flags bit 7 = FlgPEAligned"""
+def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits, seg2=None):
+    """in-place PE association on `hits` (PE1/PE2 interleaved); flags bit 7 = FlgPEAligned.  seg2 (one entry per read, from
+    oracle_align_indel with params.min_chimeric_len set): -c together with -U, trims of recovered partners are written there"""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     assert len(hits) % 2 == 0 and hits.flags["C_CONTIGUOUS"]
+    if seg2 is not None:
+        assert seg2.flags["C_CONTIGUOUS"] and len(seg2) == len(hits)
+        rc = osfx.lib.ora_process_paired_ends_ex(osfx.h, ctypes.byref(params), pe_mode, min_len, max_len, 1 if pair_strand else 0,
+                                                 bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2, hits.ctypes.data,
+                                                 seg2.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"ora_process_paired_ends_ex failed: {rc}")
+        return hits
     rc = osfx.lib.ora_process_paired_ends(osfx.h, ctypes.byref(params), pe_mode, min_len, max_len, 1 if pair_strand else 0,
                                           bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2, hits.ctypes.data)
     if rc != 0:
@@ -279,11 +292,39 @@ def interleave_pe(path1, path2, min_len=50, max_len=500):
     return names, np.concatenate(chunks), offs, lens
 
 
-def expected_pe_sam_fields(hits, i):
-    """(flag, pos1, rnext, pnext, tlen) of read i per CAligner::ReportBAMread (Aligner.cpp:5864-5924,6036-6054)"""
+def _adj(h, g):
+    """(AdjStartLoci, AdjHitLen, clip5, clip3) of a record whose end trims, if any, sit in its seg2 entry (flags bit 3)"""
+    tl = tr = 0
+    if g is not None and (int(g["flags"]) & 8):
+        tl, tr = int(g["match_len"]), int(g["read_ofs"])
+    plus = h["strand"] == ord("+")
+    return int(h["match_loci"]) + (tl if plus else tr), int(h["match_len"]) - tl - tr, (tl if plus else tr), (tr if plus else tl)
+
+
+def expected_pe_sam_fields(hits, i, seg2=None):
+    """(flag, pos1, rnext, pnext, tlen) of read i per CAligner::ReportBAMread (Aligner.cpp:5864-5924,6036-6054); with seg2 the
+    loci are the end-trimmed ones and a sixth value, the CIGAR, follows"""
     h = hits[i]
     first = i % 2 == 0
     m = hits[i + 1] if first else hits[i - 1]
+    if seg2 is not None:
+        mi = i + 1 if first else i - 1
+        flag = 0x1 | 0x2 | (0x40 if first else 0x80)
+        acc = h["nar"] == 1
+        flag |= (0x10 if h["strand"] != ord("+") else 0) if acc else 0x4
+        pe = bool(h["flags"] & 0x80) and bool(m["flags"] & 0x80) and m["nar"] == 1
+        rnext, pnext, tlen = "*", 0, 0
+        hs, hl, c5, c3 = _adj(h, seg2[i])
+        if pe:
+            flag |= 0x20 if m["strand"] != ord("+") else 0
+            if acc:
+                ms, ml, _, _ = _adj(m, seg2[mi])
+                rnext, pnext = "=", ms + 1
+                tlen = (ms - hs) + ml if hs <= ms else (hs - ms) + hl
+        else:
+            flag |= 0x8
+        cigar = (f"{c5}S" if c5 else "") + f"{hl}M" + (f"{c3}S" if c3 else "") if acc else None
+        return flag, (hs + 1 if acc else 0), rnext, pnext, tlen, cigar
     flag = 0x1 | 0x2 | (0x40 if first else 0x80)
     acc = h["nar"] == 1
     if acc:

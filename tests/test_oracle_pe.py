@@ -66,3 +66,40 @@ def test_oracle_pe_matches_reference(golden_tmp, tmp_path, fixture, tag):
     for k, tg in enumerate(helpers.NAR_TAGS):
         assert got[k] == exp[tg], (tg, got[k], exp[tg])
     o.close()
+
+
+# -c together with -U (tests/golden/pechim: the chimeric fixture's genome, a third of the mates with foreign ends): the pair rules on
+# end-trimmed loci, partners recovered end-trimmed
+PECHIM_RUNS = {"U3c50": dict(pe=3, d=200, D=400, s=3, c=50), "U1c60": dict(pe=1, d=200, D=400, s=3, c=60), "U4c50": dict(pe=4, d=200, D=400, s=3, c=50),
+               "U2c70s5": dict(pe=2, d=200, D=400, s=5, c=70), "U3c50wide": dict(pe=3, d=150, D=1500, s=3, c=50), "U3": dict(pe=3, d=200, D=400, s=3, c=0)}
+
+
+def check_pechim_against_sam(names, hits, seg2, tag):
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "pechim", f"{tag}.m6.sam.gz"))
+    by = {r["qname"]: r for r in recs}
+    assert len(by) == len(recs) == len(names)
+    chrom_names = ["cA", "cB"]
+    bad = []
+    for i, nm in enumerate(names):
+        r = by[nm]
+        flag, pos, rnext, pnext, tlen, cigar = helpers.expected_pe_sam_fields(hits, i, seg2)
+        nar = helpers.NAR_TAGS[hits[i]["nar"]]
+        got = (flag, pos, rnext, pnext, tlen, nar, chrom_names[hits[i]["chrom_id"] - 1] if nar == "AA" else "*", cigar if nar == "AA" else None)
+        exp = (r["flag"], r["pos"], r["rnext"], r["pnext"], r["tlen"], r["nar"], r["rname"], r["cigar"] if r["nar"] == "AA" else None)
+        if got != exp:
+            bad.append((nm, got, exp))
+    assert not bad, (len(bad), bad[:8])
+
+
+@pytest.mark.parametrize("tag", sorted(PECHIM_RUNS))
+def test_oracle_pe_with_chimeric_trimming_matches_reference(tmp_path, tag):
+    cfg = PECHIM_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path, "pechim")
+    sfx = str(tmp_path / "genome.sfx")
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "chimeric", "genome.sfx.gz"), sfx)
+    o = helpers.OracleSfx(sfx)
+    p = helpers.make_params(max_subs=cfg["s"], min_chimeric_len=cfg["c"])
+    hits, seg2 = helpers.oracle_align_indel(o, bases, offs, lens, p, nthreads=8)
+    helpers.oracle_process_pe(o, p, cfg["pe"], cfg["d"], cfg["D"], False, bases, offs, lens, hits, seg2)
+    check_pechim_against_sam(names, hits, seg2, tag)
+    o.close()
