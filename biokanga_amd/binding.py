@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "bk_version", "bk_strerror", "bk_device_count", "bk_ctx_create", "bk_ctx_create_from_device",
     "bk_ctx_clone", "bk_ctx_destroy", "bk_ctx_set_params", "bk_ctx_tune", "bk_num_entries", "bk_get_entry",
     "bk_dataset_name", "bk_concat_len", "bk_sfx_el_size", "bk_min_core_len", "bk_align_batch",
-    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
+    "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_pair_batch_seg2", "bk_pair_batch_seg2_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
     "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format",
@@ -157,6 +157,10 @@ def load_library():
     lib.bk_pair_batch.restype = i32
     lib.bk_pair_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(PEParams)]
     lib.bk_pair_batch_device.restype = i32
+    lib.bk_pair_batch_seg2.argtypes = [vp, vp, vp, vp, u32, vp, vp, ctypes.POINTER(PEParams)]
+    lib.bk_pair_batch_seg2.restype = i32
+    lib.bk_pair_batch_seg2_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, ctypes.POINTER(PEParams)]
+    lib.bk_pair_batch_seg2_device.restype = i32
     lib.bk_batch_loci.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.bk_batch_seg2.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
@@ -452,22 +456,34 @@ class Aligner:
         raw = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * SNP_SITE_DTYPE.itemsize,))
         return raw.view(SNP_SITE_DTYPE).copy(), tot
 
-    def pair(self, bases, offs, lens, hits, pe):
-        """PE association in place on `hits` (PE1/PE2 interleaved; the output of align() for the same reads)"""
+    def pair(self, bases, offs, lens, hits, pe, seg2=None):
+        """PE association in place on `hits` (PE1/PE2 interleaved; the output of align() for the same reads).  seg2 = batch_seg2() of that
+        align call (required on a context with min_chimeric_len > 0): updated in place too; returns hits, or (hits, seg2)"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         assert hits.dtype == HIT_DTYPE and len(hits) == len(lens) and len(hits) % 2 == 0
         hits = np.ascontiguousarray(hits)
-        rc = self.lib.bk_pair_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2,
-                                    hits.ctypes.data, ctypes.byref(pe))
+        if seg2 is None:
+            rc = self.lib.bk_pair_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2,
+                                        hits.ctypes.data, ctypes.byref(pe))
+            if rc:
+                raise BkError(rc, "bk_pair_batch")
+            return hits
+        assert seg2.dtype == SEG2_DTYPE and len(seg2) == len(hits)
+        seg2 = np.ascontiguousarray(seg2)
+        rc = self.lib.bk_pair_batch_seg2(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2,
+                                         hits.ctypes.data, seg2.ctypes.data, ctypes.byref(pe))
         if rc:
-            raise BkError(rc, "bk_pair_batch")
-        return hits
+            raise BkError(rc, "bk_pair_batch_seg2")
+        return hits, seg2
 
-    def pair_device(self, d_bases, d_offs, d_lens, n_pairs, d_hits, pe):
-        """PE association on device-resident buffers (ints = device pointers); hits updated in place."""
-        rc = self.lib.bk_pair_batch_device(self.h, d_bases, d_offs, d_lens, n_pairs, d_hits, ctypes.byref(pe))
+    def pair_device(self, d_bases, d_offs, d_lens, n_pairs, d_hits, pe, d_seg2=None):
+        """PE association on device-resident buffers (ints = device pointers); hits (and seg2 records, when given) updated in place."""
+        if d_seg2 is None:
+            rc = self.lib.bk_pair_batch_device(self.h, d_bases, d_offs, d_lens, n_pairs, d_hits, ctypes.byref(pe))
+        else:
+            rc = self.lib.bk_pair_batch_seg2_device(self.h, d_bases, d_offs, d_lens, n_pairs, d_hits, d_seg2, ctypes.byref(pe))
         if rc:
             raise BkError(rc, "bk_pair_batch_device")
 

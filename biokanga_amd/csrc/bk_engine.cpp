@@ -57,7 +57,8 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
 void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
                      uint32_t n_list, hipStream_t s);
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
-               bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, hipStream_t s);
+               bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, bk_seg2 *seg2, int min_chim,
+               int long_reads, hipStream_t s);
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                   uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
                   uint32_t *cmax_next, int nw, hipStream_t s);
@@ -983,8 +984,11 @@ int bk::engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nrea
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4 on buffers resident in HBM (shared by bk_pair_batch, bk_pair_batch_device and the stream pipeline)
-int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s)
+// K4 on buffers resident in HBM (shared by bk_pair_batch, bk_pair_batch_device and the stream pipeline).  seg2_host / seg2_dev: the
+// bk_seg2 records of these reads (one of the two, or neither) - required when the context trims chimeric reads (-c), whose pair rules
+// look at the trimmed loci and whose orphan recovery may place the partner end-trimmed; updated in place
+int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s,
+                           bk_seg2 *seg2_host, bk_seg2 *seg2_dev)
 {
     const uint8_t *d_bases = in.bases;
     const uint64_t *d_offs = in.offs;
@@ -1000,10 +1004,24 @@ int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_h
     b.rmeta = c->d_rmeta;
     b.out = d_hits; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
     b.wpr = wpr; b.n_reads = nreads; b.iv_cores = c->cap_iv_cores ? c->cap_iv_cores : kMaxCoresFast;
+    if (c->params.min_chimeric_len > 0 && !seg2_host && !seg2_dev) return BK_ERR_PARAMS;
+    bk_seg2 *d_seg2 = seg2_dev;
+    if (!d_seg2 && seg2_host) {
+        if (nreads > c->cap_seg2) {
+            free_dev(c->d_seg2);
+            c->d_seg2 = nullptr;
+            c->cap_seg2 = 0;
+            HIP_TRY(hipMalloc(&c->d_seg2, (size_t)nreads * sizeof(bk_seg2)));
+            c->cap_seg2 = nreads;
+        }
+        d_seg2 = c->d_seg2;
+        HIP_TRY(hipMemcpyAsync(d_seg2, seg2_host, (size_t)nreads * sizeof(bk_seg2), hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
     launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, d_hits, n_pairs,
-              c->d_heavy, c->d_small, c->h_small, s);
+              c->d_heavy, c->d_small, c->h_small, d_seg2, c->params.min_chimeric_len, maxlen > 512 ? 1 : 0, s);
     HIP_TRY(hipGetLastError());
+    if (seg2_host && !seg2_dev) HIP_TRY(hipMemcpyAsync(seg2_host, d_seg2, (size_t)nreads * sizeof(bk_seg2), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return BK_OK;
 }
@@ -1515,7 +1533,14 @@ int bk_align_batch_packed(bk_ctx *c, const uint32_t *words, uint64_t n_words, co
 int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs, bk_hit *hits,
                   const bk_pe_params *pe)
 {
+    return bk_pair_batch_seg2(c, bases, offs, lens, n_pairs, hits, nullptr, pe);
+}
+
+int bk_pair_batch_seg2(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs, bk_hit *hits,
+                       bk_seg2 *seg2, const bk_pe_params *pe)
+{
     if (!c || !pe || (n_pairs && (!bases || !offs || !lens || !hits))) return BK_ERR_PARAMS;
+    if (c->params.min_chimeric_len > 0 && n_pairs && !seg2) return BK_ERR_PARAMS;
     if (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len) return BK_ERR_PARAMS;
     if (!n_pairs) return BK_OK;
     if (n_pairs > 0x7fffffffu) return BK_ERR_PARAMS;
@@ -1556,7 +1581,7 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     HIP_TRY(hipStreamSynchronize(s));
     DevReads in;
     in.bases = c->d_in_bases; in.offs = c->d_in_offs; in.lens = c->d_in_lens;
-    int rc = engine_pair_device(c, in, n_pairs, c->d_in_out, maxlen, pe, s);
+    int rc = engine_pair_device(c, in, n_pairs, c->d_in_out, maxlen, pe, s, seg2, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(hits, c->d_in_out, (size_t)nreads * sizeof(bk_hit), hipMemcpyDeviceToHost));
     return BK_OK;
@@ -1567,7 +1592,14 @@ int bk_pair_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
 int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs, void *d_hits,
                          const bk_pe_params *pe)
 {
+    return bk_pair_batch_seg2_device(c, d_bases, d_offs, d_lens, n_pairs, d_hits, nullptr, pe);
+}
+
+int bk_pair_batch_seg2_device(bk_ctx *c, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs, void *d_hits,
+                              void *d_seg2, const bk_pe_params *pe)
+{
     if (!c || !pe || (n_pairs && (!d_bases || !d_offs || !d_lens || !d_hits))) return BK_ERR_PARAMS;
+    if (c->params.min_chimeric_len > 0 && n_pairs && !d_seg2) return BK_ERR_PARAMS;
     if (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len) return BK_ERR_PARAMS;
     if (!n_pairs) return BK_OK;
     if (n_pairs > 0x7fffffffu) return BK_ERR_PARAMS;
@@ -1582,7 +1614,7 @@ int bk_pair_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, con
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
     DevReads in;
     in.bases = (const uint8_t *)d_bases; in.offs = (const uint64_t *)d_offs; in.lens = (const uint32_t *)d_lens;
-    return engine_pair_device(c, in, n_pairs, (bk_hit *)d_hits, maxlen, pe, s);
+    return engine_pair_device(c, in, n_pairs, (bk_hit *)d_hits, maxlen, pe, s, nullptr, (bk_seg2 *)d_seg2);
 }
 
 // ---- SNP pile-up and screening (see include/biokanga_amd.h) -------------------------------------

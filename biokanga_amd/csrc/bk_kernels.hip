@@ -4174,8 +4174,21 @@ __device__ __forceinline__ void pe_finish(const DevPE &pe, bk_hit &f, bk_hit &r)
     }
 }
 
+// AdjStartLoci / AdjEndLoci of a read's Seg[0] (Aligner.cpp:1528-1544): a chimeric placement (bk_seg2.flags bit 3) carries its end trims
+__device__ __forceinline__ void pe_adj_loci(const bk_hit &h, const bk_seg2 *__restrict__ seg2, uint32_t idx, uint32_t &start, uint32_t &end)
+{
+    uint32_t tl = 0, tr = 0;
+    if (seg2 != nullptr) {
+        const bk_seg2 g = seg2[idx];
+        if (g.flags & 8) { tl = g.match_len; tr = g.read_ofs; }
+    }
+    if (h.strand == '+') { start = h.match_loci + tl; end = h.match_loci + (h.match_len - tr - 1); }
+    else { start = h.match_loci + tr; end = h.match_loci + (h.match_len - tl - 1); }
+}
+
 __global__ void __launch_bounds__(256) k_pe_classify(DevPE pe, bk_hit *__restrict__ hits, uint32_t n_pairs,
-                                                      uint32_t *__restrict__ orphans, uint32_t *__restrict__ orphan_cnt)
+                                                      uint32_t *__restrict__ orphans, uint32_t *__restrict__ orphan_cnt,
+                                                      const bk_seg2 *__restrict__ seg2)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
@@ -4195,8 +4208,12 @@ __global__ void __launch_bounds__(256) k_pe_classify(DevPE pe, bk_hit *__restric
             int frag = 0;
             if (f.num_hits == 1 && r.num_hits == 1) {
                 if (f.chrom_id != r.chrom_id) frag = -2;
-                else frag = pe_insert_size(pe, f.strand, f.match_loci, f.match_loci + f.match_len - 1, r.strand, r.match_loci,
-                                           r.match_loci + r.match_len - 1);
+                else {
+                    uint32_t fs, fe, rs, re;
+                    pe_adj_loci(f, seg2, 2 * i, fs, fe);
+                    pe_adj_loci(r, seg2, 2 * i + 1, rs, re);
+                    frag = pe_insert_size(pe, f.strand, fs, fe, r.strand, rs, re);
+                }
             }
             if (frag > 0) { f.flags |= 0x80; r.flags |= 0x80; paired = true; }
             else {
@@ -4256,8 +4273,33 @@ __device__ __forceinline__ bool pe_window_ok(const uint64_t *__restrict__ rdw, i
     return true;
 }
 
+// One candidate window of AlignPairedRead.  ATW == 0: the partner must fit whole (MinChimericLen == 0, MinPutLen = ReadLen); otherwise
+// AdaptiveTrim may cut its ends down to min_put bases (SfxArrayV2.cpp:8327-8330,8400-8470).  The reference raises MinPutLen to the length of
+// every placement it takes and hands that to the next AdaptiveTrim call; a call with the initial MinPutLen returns the same stretch whenever
+// that stretch is at least as long as the raised limit and nothing acceptable otherwise (the limit only removes shorter candidates from
+// AdaptiveTrim's scan), so the outcome of the scan is the first window with the longest stretch and, among those, the fewest mismatches.
+// key: smaller = better; ~0 = not a candidate.  Bits 52.. = 4095 - trimmed length, bits 40..51 = mismatches, low 40 bits = scan order.
+template <int ATW>
+__device__ __forceinline__ unsigned long long pe_window_key(const uint64_t *__restrict__ rdw, int len, const uint64_t *__restrict__ tgt, uint64_t t,
+                                                            int max_mm, int min_put, unsigned long long order, int &t5, int &t3)
+{
+    t5 = 0; t3 = 0;
+    if constexpr (ATW == 0) {
+        int mm;
+        if (!(pe_window_ok(rdw, len, tgt, t, max_mm, mm) && mm <= max_mm)) return ~0ULL;
+        return ((unsigned long long)(4095 - len) << 52) | ((unsigned long long)mm << 40) | order;
+    } else {
+        int mm;
+        const int r = adaptive_trim_dev<ATW>(rdw, tgt, t, len, min_put, max_mm, 3, mm, t5, t3);
+        if (r < min_put || r == 0 || (r == min_put && mm > max_mm)) return ~0ULL;
+        return ((unsigned long long)(4095 - r) << 52) | ((unsigned long long)mm << 40) | order;
+    }
+}
+
+template <int ATW>
 __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg, DevPE pe, DevBatch b, bk_hit *__restrict__ hits,
-                                                    const uint32_t *__restrict__ list, uint32_t n_list, uint32_t *__restrict__ cursor)
+                                                    const uint32_t *__restrict__ list, uint32_t n_list, uint32_t *__restrict__ cursor,
+                                                    bk_seg2 *__restrict__ seg2, int min_chim)
 {
     const int lane = threadIdx.x & 63;
     for (;;) {
@@ -4283,9 +4325,11 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
                 b3 = a.strand == '+'; anti = a.strand == '+';
                 if (pe.pair_strand) { b3 = !b3; anti = !anti; }
             }
-            const uint32_t a_start = a.match_loci, a_end = a.match_loci + a.match_len - 1;
+            uint32_t a_start, a_end;
+            pe_adj_loci(a, seg2, 2 * i + (anchor == 0 ? 0 : 1), a_start, a_end);
             const int read_len = (int)b.lens[oi];
             const int max_allowed = cfg.max_subs;
+            const int min_put = ATW != 0 && min_chim > 0 ? (read_len * min_chim + 50) / 100 : read_len;
             // AlignPairedRead set-up (:8270-8330)
             if (pe.min_len < read_len || pe.min_len > pe.max_len) continue;
             if (a.chrom_id < 1 || a.chrom_id > ix.max_id) continue;
@@ -4299,16 +4343,17 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
             uint32_t start_put, end_put;
             if (b3) {
                 start_put = (uint32_t)(targ_loci + pe.min_len);
-                if (start_put + (uint32_t)read_len >= targ_len) continue;
+                if (start_put + (uint32_t)min_put >= targ_len) continue;
                 end_put = (uint32_t)(targ_loci + pe.max_len);
             } else {
                 start_put = a_end < (uint32_t)pe.max_len ? 0 : a_end - (uint32_t)pe.max_len;
                 end_put = a_end - (uint32_t)pe.min_len;
             }
             const uint64_t *rdw = b.rd4 + ((uint64_t)oi * 2 + (anti ? 1 : 0)) * b.wpr;
-            // best = fewest mismatches, first in scan order; key = mm << 40 | order
+            // best = smallest pe_window_key
             unsigned long long best = ~0ULL;
             uint32_t best_loci = 0;
+            int best_t5 = 0, best_t3 = 0;
             if (end_put - start_put >= 1000) {
                 // cores of the read located through the suffix array (IterateExactsRange, :3382-3474)
                 int match_len = read_len - 1;
@@ -4329,26 +4374,26 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
                         uint64_t j = j0 + lane;
                         unsigned long long key = ~0ULL;
                         uint32_t loci = 0;
+                        int t5 = 0, t3 = 0;
                         if (j < n) {
                             uint64_t pos = ix.sa_hi ? sa_get<true>(ix, first + j) : sa_get<false>(ix, first + j);
                             if (pos >= c_start && pos <= ix.ent_end[a_ent]) {
                                 uint32_t hit = (uint32_t)(pos - c_start);
                                 if (hit >= start_put && hit <= end_put && (uint32_t)core_ofs <= hit &&
                                     (hit + (uint32_t)read_len - (uint32_t)core_ofs) < targ_len) {
-                                    int mm;
-                                    if (pe_window_ok(rdw, read_len, ix.tgt4, c_start + hit - (uint32_t)core_ofs, max_allowed, mm) && mm <= max_allowed) {
-                                        key = ((unsigned long long)mm << 40) | (order + j);
-                                        loci = hit - (uint32_t)core_ofs;
-                                    }
+                                    key = pe_window_key<ATW>(rdw, read_len, ix.tgt4, c_start + hit - (uint32_t)core_ofs, max_allowed, min_put, order + j, t5, t3);
+                                    loci = hit - (uint32_t)core_ofs;
                                 }
                             }
                         }
                         unsigned long long k2 = key;
                         for (int off = 32; off > 0; off >>= 1) { unsigned long long q = __shfl_xor(k2, off); k2 = q < k2 ? q : k2; }
-                        if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) {      // strictly fewer mismatches than the best so far
+                        if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) {      // strictly better than the best so far
                             int src = __ffsll((unsigned long long)__ballot(key == k2)) - 1;
                             best = k2;
                             best_loci = __shfl(loci, src);
+                            best_t5 = __shfl(t5, src);
+                            best_t3 = __shfl(t3, src);
                         }
                     }
                     order += n;
@@ -4357,25 +4402,40 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
                 for (uint32_t h0 = start_put; h0 <= end_put; h0 += 64) {
                     uint32_t hit = h0 + (uint32_t)lane;
                     unsigned long long key = ~0ULL;
-                    if (hit <= end_put && hit >= h0) {
-                        int mm;
-                        if (pe_window_ok(rdw, read_len, ix.tgt4, c_start + hit, max_allowed, mm) && mm <= max_allowed)
-                            key = ((unsigned long long)mm << 40) | hit;
-                    }
+                    int t5 = 0, t3 = 0;
+                    if (hit <= end_put && hit >= h0) key = pe_window_key<ATW>(rdw, read_len, ix.tgt4, c_start + hit, max_allowed, min_put, hit, t5, t3);
                     unsigned long long k2 = key;
                     for (int off = 32; off > 0; off >>= 1) { unsigned long long q = __shfl_xor(k2, off); k2 = q < k2 ? q : k2; }
-                    if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) { best = k2; best_loci = (uint32_t)(k2 & 0xFFFFFFFFFFULL); }
+                    if (k2 != ~0ULL && (k2 >> 40) < (best >> 40)) {
+                        best = k2;
+                        best_loci = (uint32_t)(k2 & 0xFFFFFFFFFFULL);
+                        const int src = (int)(best_loci - h0);
+                        best_t5 = __shfl(t5, src);
+                        best_t3 = __shfl(t3, src);
+                    }
                     if (h0 + 64 < h0) break;
                 }
             }
             if (best == ~0ULL) continue;
-            const int mm = (int)(best >> 40);
+            const int mm = (int)((best >> 40) & 0xFFF);
+            if (mm > max_allowed) continue;                                  // (a longer stretch may have displaced an acceptable one, :8472)
+            const int trimmed_len = 4095 - (int)(best >> 52);
             const uint8_t h_strand = anti ? '-' : '+';
-            const uint32_t h_end = best_loci + (uint32_t)read_len - 1;
+            // AdjStartLoci / AdjEndLoci of the placement: the trims are those of the sequence as matched, i.e. in target direction
+            const uint32_t h_start = best_loci + (uint32_t)best_t5, h_end = best_loci + (uint32_t)(read_len - best_t3) - 1;
             int frag;
-            if (anchor == 0) frag = pe_insert_size(pe, a.strand, a_start, a_end, h_strand, best_loci, h_end);
-            else frag = pe_insert_size(pe, h_strand, best_loci, h_end, a.strand, a_start, a_end);
+            if (anchor == 0) frag = pe_insert_size(pe, a.strand, a_start, a_end, h_strand, h_start, h_end);
+            else frag = pe_insert_size(pe, h_strand, h_start, h_end, a.strand, a_start, a_end);
             if (frag <= 0) continue;
+            if (seg2 != nullptr && lane == 0) {                              // the whole tsHitLoci is replaced (Aligner.cpp:3420)
+                bk_seg2 g{};
+                if (trimmed_len != read_len) {                               // FlgChimeric: TrimLeft / TrimRight in read orientation
+                    g.flags = 8;
+                    g.match_len = (uint16_t)(anti ? best_t3 : best_t5);
+                    g.read_ofs = (uint16_t)(anti ? best_t5 : best_t3);
+                }
+                seg2[oi] = g;
+            }
             o.chrom_id = a.chrom_id; o.match_loci = best_loci; o.match_len = (uint16_t)read_len; o.strand = h_strand;
             o.mismatches = (uint8_t)mm; o.num_hits = 1; o.low_mm = (int8_t)mm; o.low_hit_instances = 1;
             f.flags |= 0x80; r.flags |= 0x80;
@@ -4519,19 +4579,23 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
 
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters /*[0] count [1] cursor, zeroed*/,
-               uint32_t *h_count, hipStream_t s)
+               uint32_t *h_count, bk_seg2 *seg2, int min_chim, int long_reads, hipStream_t s)
 {
     DevPE pe{pe_mode, min_len, max_len, pair_strand};
     const uint32_t rpb = 256 / (2 * b.wpr);
     hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
     if (b.pk_words != nullptr && b.pk_nexc) hipLaunchKernelGGL(k_apply_exc, dim3((unsigned)((b.pk_nexc + 255) / 256)), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters);
+    hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters, seg2);
     (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
     uint32_t n = *h_count;
     if (n) {
         uint32_t waves = n < 8192 ? n : 8192;
-        hipLaunchKernelGGL(k_pe_orphan, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1);
+#define BK_ORPH(W) hipLaunchKernelGGL(k_pe_orphan<W>, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1, seg2, min_chim)
+        if (min_chim <= 0 || seg2 == nullptr) BK_ORPH(0);
+        else if (long_reads) BK_ORPH(32);                                     // reads of more than 512 bases: 2048-base mismatch map per lane
+        else BK_ORPH(8);
+#undef BK_ORPH
     }
 }
 

@@ -185,7 +185,7 @@ struct bk_stream {
                 bk::DevReads in;
                 in.offs = sl.d_offs; in.lens = sl.d_lens; in.words = reinterpret_cast<const uint32_t *>(sl.d_bases); in.exc = sl.d_exc; in.n_exc = j->n_exc;
                 if (rc == BK_OK) rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al, maxlen);
-                if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
+                if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al, ctx->seg2.empty() ? nullptr : ctx->seg2.data());
                 if (rc) fail(j, rc);
                 else if (list_modes) {
                     j->loci_offs.swap(ctx->loci_offs);
@@ -219,7 +219,7 @@ struct bk_stream {
                     bk::DevReads in;
                     in.bases = sl.d_bases; in.offs = sl.d_offs; in.lens = sl.d_lens;
                     int rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al, maxlen);
-                    if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al);
+                    if (rc == BK_OK && has_pe) rc = bk::engine_pair_device(ctx, in, j->n / 2, sl.d_out, maxlen, &pe, s_al, ctx->seg2.empty() ? nullptr : ctx->seg2.data());
                     if (rc) fail(j, rc);
                     else if (list_modes) {
                         j->loci_offs.swap(ctx->loci_offs);

@@ -498,7 +498,7 @@ int read_align_opts(Args &a, AlignOpts &o)
     // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
     o.min_chim = a.num("c", 0);
     if (o.min_chim != 0 && (o.min_chim < 50 || o.min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", o.min_chim < 0 ? -o.min_chim : o.min_chim); return 1; }
-    if (o.min_chim && (o.ml_mode || o.pe_mode)) { diag("Error: chimeric trimming '-c%d' together with '-r%d' / '-U%d' is not available in this build", o.min_chim, o.ml_mode, o.pe_mode); return 1; }
+    if (o.min_chim && o.ml_mode) { diag("Error: chimeric trimming '-c%d' together with '-r%d' is not available in this build", o.min_chim, o.ml_mode); return 1; }
     // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
 
     o.snp.min_reads = a.num("p", 0);

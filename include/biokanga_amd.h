@@ -228,6 +228,17 @@ int  bk_pair_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, cons
  * for exactly these reads); nothing crosses PCIe */
 int  bk_pair_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs,
                           void *d_hits, const bk_pe_params *pe);
+/* The same with the reads' bk_seg2 records (2 * n_pairs, what bk_batch_seg2() returned for exactly these reads; see below), updated in
+ * place.  Required on a context with min_chimeric_len > 0 (`-c` together with `-U`; BK_ERR_PARAMS without them): ProcessPairedEnds then
+ * measures inserts between the trimmed ends (AdjStartLoci / AdjEndLoci, Aligner.cpp:1528-1544) and AlignPairedRead may place the orphan's
+ * partner end-trimmed down to min_chimeric_len percent of its length (MinPutLen, SfxArrayV2.cpp:8327-8330), taking the longest trimmed
+ * stretch, then the fewest mismatches, first in scan order; a recovered partner's record is replaced as a whole - flags = FlgChimeric
+ * with its trims, or 0 (whatever second segment it had is gone).  A pipeline created with pe != NULL does this by itself. */
+struct bk_seg2;
+int  bk_pair_batch_seg2(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t n_pairs,
+                        bk_hit *hits, struct bk_seg2 *seg2, const bk_pe_params *pe);
+int  bk_pair_batch_seg2_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t n_pairs,
+                               void *d_hits, void *d_seg2, const bk_pe_params *pe);
 
 /* ---- multi-loci modes (-r1..-r5: AlignReads called with MaxHits = -R > 1) ---------------------- */
 /* One locus of a read that aligned to 1..MaxHits places with the same, lowest, number of mismatches: the

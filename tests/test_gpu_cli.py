@@ -119,6 +119,24 @@ def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags, fixture):
         assert open(out, "rb").read() == golden_bytes(fixture, "U3.m5.sam.gz")
 
 
+@pytest.mark.parametrize("tag,flags", [("U3c50", ["-U3", "-c50", "-s3", "-d200", "-D400"]), ("U1c60", ["-U1", "-c60", "-s3", "-d200", "-D400"]),
+                                       ("U4c50", ["-U4", "-c50", "-s3", "-d200", "-D400"]), ("U2c70s5", ["-U2", "-c70", "-s5", "-d200", "-D400"]),
+                                       ("U3c50wide", ["-U3", "-c50", "-s3", "-d150", "-D1500"]), ("U3", ["-U3", "-s3", "-d200", "-D400"])])
+def test_align_pe_with_chimeric_trimming_sam_byte_identical(golden_tmp, tmp_path, tag, flags):
+    """`-c` together with `-U`: soft-clipped mates, inserts between trimmed ends, end-trimmed recovered partners - the reference's SAM"""
+    d = golden_tmp["chimeric"]
+    pe = os.path.join(helpers.GOLDEN, "pechim")
+    out = str(tmp_path / "pechim.sam")
+    run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
+         "-o", out, "-M6"] + flags, str(tmp_path))
+    assert open(out, "rb").read() == golden_bytes("pechim", f"{tag}.m6.sam.gz")
+    if tag == "U3c50":
+        out = str(tmp_path / "pechim.csv")
+        run(["align", "-i", os.path.join(pe, "reads_1.fa.gz"), "-u", os.path.join(pe, "reads_2.fa.gz"), "-I", os.path.join(d, "genome.sfx"),
+             "-o", out, "-M0"] + flags, str(tmp_path))
+        assert open(out, "rb").read() == golden_bytes("pechim", "U3c50.m0.csv.gz")
+
+
 @pytest.mark.parametrize("fixture,name,flags", [
     ("basic", "s3.m6.bam", ["-M6", "-s3"]), ("basic", "s3.m5.bam", ["-M5", "-s3"]),
     ("pe", "U3.m6.bam", ["-M6", "-s5", "-U3", "-d200", "-D400"])])

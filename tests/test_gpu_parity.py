@@ -350,6 +350,134 @@ def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, fixture, tag):
     assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
 
 
+from test_oracle_pe import PECHIM_RUNS, check_pechim_against_sam
+
+SEG2_FIELDS = ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score")
+
+
+def assert_seg2_equal(seg, eseg, names=None):
+    for f in SEG2_FIELDS:
+        if not np.array_equal(seg[f], eseg[f]):
+            i = int(np.nonzero(seg[f] != eseg[f])[0][0])
+            raise AssertionError(f"seg2 field {f} differs at read {i} ({names[i] if names is not None else ''}): got {seg[i]} exp {eseg[i]}")
+
+
+@pytest.mark.parametrize("tag", sorted(PECHIM_RUNS))
+def test_pe_with_chimeric_trimming_matches_reference_and_oracle(golden_tmp, tmp_path, tag):
+    """-c together with -U: the pair rules on the trimmed loci and AlignPairedRead placing the partner end-trimmed, against the
+    reference's SAM (flags, POS, CIGAR with its soft clips, PNEXT, TLEN, NAR) and, field by field, against the oracle; the
+    device-resident entry point gives the same records"""
+    import torch
+    bk = _bk()
+    cfg = PECHIM_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path, "pechim")
+    sfx_path = os.path.join(golden_tmp["chimeric"], "genome.sfx")
+    pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], False)
+    with bk.Aligner(sfx_path, bk.AlignParams(max_subs=cfg["s"], min_chimeric_len=cfg["c"])) as al:
+        se = al.align(bases, offs, lens)
+        se_seg = al.batch_seg2()
+        if cfg["c"]:
+            assert len(se_seg) == len(lens)
+            with pytest.raises(bk.BkError):                 # the trims are part of the input
+                al.pair(bases, offs, lens, se.copy(), pe)
+            hits, seg = al.pair(bases, offs, lens, se.copy(), pe, seg2=se_seg.copy())
+            dev = torch.device("cuda", 0)
+            d_b = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+            d_o = torch.from_numpy(offs.astype(np.int64)).to(dev)
+            d_l = torch.from_numpy(lens.astype(np.int32)).to(dev)
+            d_h = torch.from_numpy(se.view(np.uint8).copy()).to(dev)
+            d_s = torch.from_numpy(se_seg.view(np.uint8).copy()).to(dev)
+            al.pair_device(d_b.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), len(lens) // 2, d_h.data_ptr(), pe, d_seg2=d_s.data_ptr())
+            assert np.array_equal(d_h.cpu().numpy().view(bk.HIT_DTYPE), hits)
+            assert np.array_equal(d_s.cpu().numpy().view(bk.SEG2_DTYPE), seg)
+        else:
+            assert len(se_seg) == 0
+            hits = al.pair(bases, offs, lens, se.copy(), pe)
+            seg = np.zeros(len(lens), bk.SEG2_DTYPE)
+    check_pechim_against_sam(names, hits, seg, tag)
+    o = helpers.OracleSfx(sfx_path)
+    p = helpers.make_params(max_subs=cfg["s"], min_chimeric_len=cfg["c"])
+    exp, eseg = helpers.oracle_align_indel(o, bases, offs, lens, p, nthreads=8)
+    helpers.oracle_process_pe(o, p, cfg["pe"], cfg["d"], cfg["D"], False, bases, offs, lens, exp, eseg)
+    o.close()
+    assert_hits_equal(hits, exp, names)
+    assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
+    assert_seg2_equal(seg, eseg, names)
+
+
+@pytest.mark.parametrize("read_len,d,D,subs,pct", [(100, 150, 600, 3, 50), (150, 200, 1600, 5, 60), (150, 200, 900, 3, 75), (600, 700, 1400, 2, 50),
+                                                   (600, 650, 2600, 2, 65)])
+def test_pe_chimeric_orphan_recovery_on_planted_pairs(tmp_path, read_len, d, D, subs, pct):
+    """AlignPairedRead with MinChimericLen on pairs built for it: one mate unique, the other inside a duplicated block (so the SE pass
+    leaves it with several loci) and with foreign bases at one or both ends in most pairs; window sizes either side of the 1000
+    bases that switch between the scan of every offset and the core lookups (SfxArrayV2.cpp:8332), reads either side of the
+    512 bases that switch the device's mismatch map - records, flags and trims against the oracle"""
+    import torch
+    bk = _bk()
+    rng = np.random.default_rng(read_len * 7 + D)
+    ng = 240000
+    g = rng.integers(0, 4, ng, dtype=np.uint8)
+    blk = 3 * read_len if read_len <= 150 else read_len + 150
+    blocks = []
+    for k in range(40):                                   # blocks present twice, well apart
+        a = 2000 + k * 2500
+        b = ng // 2 + 3000 + k * 2500
+        g[b:b + blk] = g[a:a + blk]
+        blocks.append(a)
+    cut = ng // 2
+    seq = np.concatenate([g[:cut], [7], g[cut:], [7]]).astype(np.uint8)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    path = str(tmp_path / "planted.sfx")
+    helpers.write_sfx(path, "planted", [("s1", cut), ("s2", ng - cut)], seq, d_sa.cpu().numpy().view(np.uint32))
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    reads = []
+    for i in range(400):
+        a = blocks[int(rng.integers(0, len(blocks)))]
+        inb = a + int(rng.integers(0, blk - read_len))                    # mate inside the block
+        ins = int(rng.integers(d - 40, min(D + 60, 1900)))
+        fwd_first = bool(rng.integers(0, 2))
+        p1 = inb - (ins - read_len) if fwd_first else inb + (ins - read_len)      # the unique mate, up- or downstream of the block
+        if p1 < 0 or p1 + read_len >= cut:
+            continue
+        u = g[p1:p1 + read_len].copy()
+        m = g[inb:inb + read_len].copy()
+        for q in rng.choice(read_len, int(rng.integers(0, subs + 1)), replace=False):
+            m[q] = (m[q] + 1 + rng.integers(0, 3)) % 4
+        if rng.integers(0, 4):                                            # foreign ends
+            k5 = int(rng.integers(5, read_len * (100 - pct) // 100 + 8)) if rng.integers(0, 3) else 0
+            k3 = int(rng.integers(5, read_len * (100 - pct) // 100 + 8)) if (k5 == 0 or rng.integers(0, 3) == 0) else 0
+            m[:k5] = rng.integers(0, 4, k5)
+            if k3:
+                m[read_len - k3:] = rng.integers(0, 4, k3)
+        left, right = (u, m) if fwd_first else (m, u)
+        right = comp[right[::-1]]
+        pair = [left, right] if rng.integers(0, 2) else [right, left]
+        reads += pair
+    reads = np.array(reads, dtype=np.uint8)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = np.arange(nreads, dtype=np.uint64) * read_len
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    o = helpers.OracleSfx(path)
+    prm = helpers.make_params(max_subs=subs, min_chimeric_len=pct)
+    exp, eseg = helpers.oracle_align_indel(o, bases, offs, lens, prm, nthreads=8)
+    se_exp = exp.copy()
+    helpers.oracle_process_pe(o, prm, 3, d, D, False, bases, offs, lens, exp, eseg)
+    o.close()
+    rec = np.nonzero((se_exp["match_loci"] != exp["match_loci"]) & (exp["nar"] == 1) & ((exp["flags"] & 0x80) != 0))[0]
+    assert len(rec) > 30 and np.count_nonzero(eseg["flags"][rec] & 8) > 10, (len(rec), np.count_nonzero(eseg["flags"][rec] & 8))
+    with bk.Aligner(path, bk.AlignParams(max_subs=subs, min_chimeric_len=pct)) as al:
+        se = al.align(bases, offs, lens)
+        hits, seg = al.pair(bases, offs, lens, se, bk.PEParams(3, d, D, False), seg2=al.batch_seg2())
+    assert_hits_equal(hits, exp)
+    assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
+    assert_seg2_equal(seg, eseg)
+
+
 @pytest.mark.parametrize("read_len", [100, 300])
 def test_five_byte_suffix_elements(tmp_path, read_len):
     """.sfx with 5-byte suffix elements (what the reference writes above 4 Gbp), forced onto a small

@@ -152,6 +152,44 @@ def test_stream_paired_end_association_on_resident_buffers(golden_tmp, tmp_path,
     check_pe_hits_against_sam(names, out, "U3", ["chrA", "chrB"], fixture)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_stream_paired_ends_with_chimeric_trimming(golden_tmp, tmp_path, packed):
+    """a pipeline with pe on a context that trims chimeric reads: the association sees each batch's bk_seg2 records and the batch's
+    records come back with the trims of the recovered partners"""
+    from test_oracle_pe import PECHIM_RUNS, pe_inputs, check_pechim_against_sam
+    bk = _bk()
+    cfg = PECHIM_RUNS["U3c50"]
+    names, bases, offs, lens = pe_inputs(tmp_path, "pechim")
+    cb = _contiguous(bases, offs, lens)
+    coffs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    n = len(lens)
+    pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], False)
+    with bk.Aligner(os.path.join(golden_tmp["chimeric"], "genome.sfx"), bk.AlignParams(max_subs=cfg["s"], min_chimeric_len=cfg["c"])) as al:
+        se = al.align(bases, offs, lens)
+        ref, ref_seg = al.pair(bases, offs, lens, se, pe, seg2=al.batch_seg2())
+        out = np.zeros(n, bk.HIT_DTYPE)
+        segs = []
+        B = 2 * 90
+        with bk.Stream(al, B, int(lens.max()) * B, depth=2, pe=pe) as st:
+            tk = []
+            for lo in range(0, n, B):
+                hi = min(n, lo + B)
+                b0, b1 = int(coffs[lo]), int(coffs[hi - 1]) + int(lens[hi - 1])
+                if packed:
+                    tk.append(st.submit_packed(*bk.pack_reads(cb[b0:b1], None, lens[lo:hi]), out[lo:hi]))
+                else:
+                    tk.append(st.submit(cb[b0:b1].copy(), None, lens[lo:hi].copy(), out[lo:hi]))
+            for t in tk:
+                st.wait(t)
+                segs.append(st.batch_seg2(t))
+                st.release(t)
+    seg = np.concatenate(segs)
+    for f in FIELDS + ["flags"]:
+        assert np.array_equal(out[f], ref[f]), f
+    assert np.array_equal(seg, ref_seg)
+    check_pechim_against_sam(names, out, seg, "U3c50")
+
+
 def test_seq_counts_allreduce_over_contexts(golden_tmp):
     """the exchange step: two contexts, each fed half of the reads, reduce to the counts of one context fed all of them"""
     bk = _bk()
