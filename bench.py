@@ -439,22 +439,23 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
         p_words, p_lens16, p_exc = bk.pack_reads(h_bases, None, h_lens, pinned=True)
         wpr = (L + 15) // 16
         log(f"host-resident leg: {n} reads packed to {p_words.nbytes / n:.1f} + 2 B/read (+ {len(p_exc)} non-acgt bases) in {time.time() - tp:.1f}s")
-    B = max(2, min(args.stream_batch, n))
+    B = max(2, min(args.stream_batch or n, n))
     B -= B & 1
     cuts = list(range(0, n, B)) + [n]
-    # the first step ramps its batch size up (B/16, B/8, ..): the pipeline has nothing to overlap the very first upload with, so
-    # the smaller it is the sooner the kernels start
-    ramp, at, sz = [0], 0, max(2, (B // 16) & ~1)
-    while at + sz < min(B, n):
-        at += sz
-        ramp.append(at)
-        sz = min(B, 2 * sz)
+    # The first step grows its batches by a factor of three (6 %, 18 %, 76 % of a batch): the pipeline has nothing to overlap the very first
+    # upload with, so the smaller it is the sooner the kernels start, and a batch crosses PCIe about 3.5 times faster than it is aligned, so
+    # each upload still hides behind the batch before it.  Small batches cost more per read (every phase's wave-per-read launch lasts at
+    # least as long as its heaviest read: 3 M reads take 3.7 ns each, 50 M 2.0 ns), hence no finer ramp than that.
+    def even(v):
+        return max(2, int(v) & ~1)
+    first = min(B, n)
+    ramp = [0, even(0.06 * first), even(0.24 * first)] if first >= 1000 else [0]
     cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
-    # .. and the last step ramps down the same way: the download of the very last batch has nothing to hide behind either
-    down = sorted({n - c for c in ramp})
-    cuts9 = [c for c in cuts if c < down[0]] + down
+    # .. and the last step ends on a tenth of a batch: the download of the very last batch has nothing to hide behind either
+    down = [n - even(0.1 * first)] if first >= 1000 else []
+    cuts9 = ([c for c in cuts if c < down[0]] + down + [n]) if down else cuts
     log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step "
-        f"(first step: {len(cuts0) - 1} batches from {cuts0[1]} reads up; last step: {len(cuts9) - 1} batches down to {n - cuts9[-2]})")
+        f"(first step: batches of {[b - a for a, b in zip(cuts0[:-1], cuts0[1:])]}; last step: {[b - a for a, b in zip(cuts9[:-1], cuts9[1:])]})")
     result = {}
     with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
         exc_of = {}
@@ -504,6 +505,7 @@ def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, d
                    "t_align_first_submit_to_last_result_s": stats["seconds_first_submit_to_last_result"],
                    "pcie_bytes_per_read": {"h2d": stats["bytes_h2d"] / max(1, stats["reads"]), "d2h": stats["bytes_d2h"] / max(1, stats["reads"])},
                    "device_ms_per_step": tim["ms_total"] / max(1, args.stream_steps),
+                   "device_ms_per_step_by_stage": {k: round(v / max(1, args.stream_steps), 2) for k, v in tim.items() if k.startswith("ms_") and k != "ms_total"},
                    "results_bit_identical_to_kernel_only_steps": same,
                    "note": "host pinned buffers in -> host bk_hit out through bk_stream_* (3 HIP streams)"})
     return result
@@ -555,7 +557,7 @@ def main():
                                                                 "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
     ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the host-resident leg's reads cross PCIe: "
                     "2 bit/base (bk_stream_submit_packed) or 1 byte/base (bk_stream_submit)")
-    ap.add_argument("--stream-batch", type=int, default=25_000_000, help="reads per submitted batch of the host-resident leg (the first step ramps up to it)")
+    ap.add_argument("--stream-batch", type=int, default=0, help="reads per submitted batch of the host-resident leg (0 = a whole step; the first step ramps up to it)")
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")

@@ -175,13 +175,19 @@ struct bk_stream {
     void run_align()
     {
         (void)hipSetDevice(ctx->device);
-        while (Job *j = pop(q_al)) {
+        double t_free = now_s();
+        for (;;) {
+            Job *j = pop(q_al);
+            if (!j) break;
+            const double t_got = now_s();
+            double t_prep = t_got;
             Slot &sl = slots[j->slot];
             if (j->rc == BK_OK && j->n && j->lens16) {
                 hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
                 uint32_t maxlen = 0;
                 int rc = e == hipSuccess ? bk::engine_prepare_packed(ctx, sl.d_lens16, j->n, j->n_words, sl.d_exc, j->n_exc, sl.d_lens, sl.d_offs, &maxlen, s_al)
                                          : rc_of(e);
+                t_prep = now_s();
                 bk::DevReads in;
                 in.offs = sl.d_offs; in.lens = sl.d_lens; in.words = reinterpret_cast<const uint32_t *>(sl.d_bases); in.exc = sl.d_exc; in.n_exc = j->n_exc;
                 if (rc == BK_OK) rc = bk::engine_align_device(ctx, in, j->n, sl.d_out, s_al, maxlen);
@@ -232,7 +238,11 @@ struct bk_stream {
                     if (e != hipSuccess) fail(j, rc_of(e));
                 }
             }
+            if (ctx->debug)
+                fprintf(stderr, "bk: stream batch of %u reads: waited %.2f ms for it, prepared in %.2f ms, aligned in %.2f ms\n", j->n, 1e3 * (t_got - t_free),
+                        1e3 * (t_prep - t_got), 1e3 * (now_s() - t_prep));
             push(q_dn, j);
+            t_free = now_s();
         }
     }
 

@@ -108,6 +108,49 @@ def test_packed_batch_equals_byte_batch(golden_tmp, fixture, knob):
         assert c0[k] == c1[k], (k, c0, c1)
 
 
+@pytest.mark.parametrize("el_size", [4, 5])
+@pytest.mark.parametrize("top", [150, 192])
+def test_reads_of_129_to_192_bases(tmp_path, top, el_size):
+    """batches whose longest read has 129 .. 192 bases (2 x 150 is the common case; the 16-word kernel family with a third of its
+    window unused): reads of 129 .. top bases and a few short ones against the oracle, every kernel family of that width, both
+    index element sizes, bytes and packed input"""
+    import torch
+    bk = _bk()
+    seq, ents, reads = _synth_case(1200 + top + el_size, 300000, 9000, top, 5, dup_len=top + 40)
+    n = len(seq)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 4, 0)
+    sa = d_sa.cpu().numpy().view(np.uint32)
+    path = str(tmp_path / "nw12.sfx")
+    helpers.write_sfx(path, "nw12", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa.astype(np.uint64) if el_size == 5 else sa,
+                      el_size=el_size)
+    rng = np.random.default_rng(top)
+    nreads = len(reads)
+    lens = rng.integers(129, top + 1, nreads).astype(np.uint32)
+    lens[rng.integers(0, nreads, 200)] = rng.integers(20, 129, 200)
+    lens[0] = top
+    offs = np.arange(nreads, dtype=np.uint64) * top
+    bases = reads.reshape(-1)
+    o = helpers.OracleSfx(path)
+    exp, octr = o.align(bases, offs, lens, helpers.make_params(max_subs=4), nthreads=8)
+    o.close()
+    words, lens16, exc = bk.pack_reads(bases, offs, lens)
+    with bk.Aligner(path, bk.AlignParams(max_subs=4)) as al:
+        for knobs in ([], [("heavy_thresh", 0)], [("heavy_thresh", 100)], [("use_flat", 0)], [("use_isa", 0)], [("use_tgt2", 0)]):
+            for k, v in knobs:
+                al.tune(k, v)
+            al.counters(reset=True)
+            got = al.align(bases, offs, lens)
+            ctr = al.counters(reset=True)
+            assert_hits_equal(got, exp)
+            assert (ctr["n_search"], ctr["n_cand"]) == (octr.n_search, octr.n_cand), knobs
+            assert_hits_equal(al.align_packed(words, lens16, exc), exp)
+            for k, v in knobs:
+                al.tune(k, 1 if k.startswith("use_") else 64)
+
+
 @pytest.mark.parametrize("read_len", [100, 150])
 def test_packed_batch_of_many_reads(read_len):
     """more reads than one launch's first round of blocks (the rows of the later blocks once came out wrong: a code-generation
