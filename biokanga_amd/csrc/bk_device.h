@@ -43,6 +43,8 @@ struct StripeSet {
     uint32_t cap;
 };
 constexpr int kCtrStripes = 64;       // copies of the DevBatch::ctr block (8 counters = one 64-byte line each)
+constexpr int kNwLong = 20;            // 16-base words of the wider register-window kernel families: reads of up to 320 bases (2 x 250, 2 x 300)
+constexpr int kNwLongest = 32;         // .. and of up to 512 bases
 constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
 constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)

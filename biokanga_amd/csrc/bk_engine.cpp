@@ -258,9 +258,10 @@ int build_tgt2(bk_ctx *c)
     c->ix.tgt2 = nullptr; c->ix.nflag = nullptr;
     if (!c->use_tgt2) return BK_OK;
     const uint64_t nblocks = c->n_tgt4_words / 4;
-    // flag granule: the smallest power of two that keeps the bitmap within 16 KB; at least 256 bases so that a
-    // window of the register kernels (<= 256 bases) spans at most two regions
-    int shift = 8;
+    // flag granule: the smallest power of two that keeps the bitmap within 16 KB; at least 512 bases so that a
+    // window of the register kernels (<= 16 * kNwLongest bases) spans at most two regions
+    static_assert(16 * kNwLongest <= 512, "a register-kernel window must not span more than two flag regions");
+    int shift = 9;
     while ((((nblocks * 64) >> shift) + 7) / 8 > 16384) shift++;
     const uint64_t flag_bytes = (((((nblocks * 64) >> shift) + 1) + 31) / 32) * 4 + 16;
     HIP_TRY(hipMalloc(&c->d_tgt2, nblocks * 16 + 64));
@@ -539,6 +540,12 @@ static inline uint32_t iv_cores_for(const bk_ctx *c, uint32_t maxlen)
     return std::min<uint32_t>(ms, kMaxCoresFast);
 }
 
+// 64-bit words of a read's 2 bit/base row in the register-window kernel family that takes reads of up to maxlen bases
+static inline uint32_t rd2w_for(uint32_t maxlen)
+{
+    return maxlen <= 128 ? 4u : (maxlen <= 256 ? 8u : (maxlen <= 16u * (uint32_t)kNwLong ? (uint32_t)kNwLong / 2 : (uint32_t)kNwLongest / 2));
+}
+
 // per-read bytes of batch scratch: packed rows in both forms, interval records, work lists (reads, search items and their striped
 // forms), sort buffers
 static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 8, uint32_t iv_cores = kMaxCoresFast)
@@ -658,9 +665,9 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     uint32_t *sm = c->d_small, *hm = c->h_small;
     HIP_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
     const uint32_t wpr = words_per_read(maxlen);
-    // register-resident window kernels handle reads of <= 128 / <= 256 bases
-    const bool reg_path = c->use_wave && maxlen <= 256;
-    const int nw16 = maxlen <= 128 ? 8 : 16;
+    // register-resident window kernels handle reads of <= 128 / <= 256 / <= 16 * kNwLong / <= 16 * kNwLongest bases
+    const bool reg_path = c->use_wave && maxlen <= 16u * (uint32_t)kNwLongest;
+    const int nw16 = maxlen <= 128 ? 8 : (maxlen <= 256 ? 16 : (maxlen <= 16u * (uint32_t)kNwLong ? kNwLong : kNwLongest));
     const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
     const uint32_t ivc = iv_cores_for(c, maxlen);
     int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u, ivc);
@@ -860,7 +867,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t need = c->ix.n * 48;
-    const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
+    const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), rd2w_for(maxlen), iv_cores_for(c, maxlen));
     const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);
     const uint64_t missing = want > have ? want - have : 0;
     if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) { c->swin_denied = true; return BK_OK; }  // (the chunk size is set from 3/4 of the free memory; asked once)
@@ -901,8 +908,8 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     uint32_t chunk = c->chunk_reads;
     // (a batch the scratch already holds needs no look at the free memory)
     if (!(std::min(chunk, nreads) <= c->cap_reads && words_per_read(maxlen) <= c->cap_wpr && iv_cores_for(c, maxlen) <= c->cap_iv_cores &&
-          (maxlen <= 128 ? 4u : 8u) <= std::max(c->cap_rd2w, 1u) && !c->params.best_matches)) {
-        const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen), 8, iv_cores_for(c, maxlen));
+          rd2w_for(maxlen) <= std::max(c->cap_rd2w, 1u) && !c->params.best_matches)) {
+        const uint64_t per_read = scratch_bytes_per_read(words_per_read(maxlen), rd2w_for(maxlen), iv_cores_for(c, maxlen));
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);

@@ -4533,7 +4533,7 @@ void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint3
 {
     const bool packed = b.pk_words != nullptr;
     const unsigned eblocks = (unsigned)((b.pk_nexc + 255) / 256);
-    if (b.nw == 8 || b.nw == 16) {          // register-kernel path: fused pack + init
+    if (b.nw == 8 || b.nw == 16 || b.nw == kNwLong || b.nw == kNwLongest) {          // register-kernel path: fused pack + init
         const unsigned blocks = (b.n_reads + 255) / 256;
         StripeSet out;
         out.cnt = stripe_cnt;
@@ -4545,11 +4545,15 @@ void launch_prep(const DevAlignCfg &cfg, const DevBatch &b, uint32_t *act, uint3
             launch_fill_u64(reinterpret_cast<unsigned long long *>(b.rmeta), ((uint64_t)b.n_reads + 1) / 2, 0ULL, s);      // (rmeta is allocated in whole 8-byte words)
             if (eblocks) hipLaunchKernelGGL(k_mark_exc, dim3(eblocks), dim3(256), 0, s, b);
             if (b.nw == 8) hipLaunchKernelGGL((k_prep_fused<8, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
-            else hipLaunchKernelGGL((k_prep_fused<16, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+            else if (b.nw == 16) hipLaunchKernelGGL((k_prep_fused<16, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+            else if (b.nw == kNwLong) hipLaunchKernelGGL((k_prep_fused<kNwLong, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+            else hipLaunchKernelGGL((k_prep_fused<kNwLongest, true>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
             if (eblocks && b.rd2 != nullptr) hipLaunchKernelGGL(k_exc_rows, dim3(eblocks), dim3(256), 0, s, b);
             if (eblocks) hipLaunchKernelGGL(k_apply_exc, dim3(eblocks), dim3(256), 0, s, b);
         } else if (b.nw == 8) hipLaunchKernelGGL((k_prep_fused<8, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
-        else hipLaunchKernelGGL((k_prep_fused<16, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        else if (b.nw == 16) hipLaunchKernelGGL((k_prep_fused<16, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        else if (b.nw == kNwLong) hipLaunchKernelGGL((k_prep_fused<kNwLong, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
+        else hipLaunchKernelGGL((k_prep_fused<kNwLongest, false>), dim3(blocks), dim3(256), 0, s, cfg, b, out);
         launch_compact(out, &act, &act_cnt, 1, cmax, s);
         return;
     }
@@ -4711,7 +4715,9 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
     bool wide = ix.sa_hi != nullptr;
 #define BK_LIGHT(W, N) hipLaunchKernelGGL((k_light<W, N>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
     if (nw <= 8) { if (wide) BK_LIGHT(true, 8); else BK_LIGHT(false, 8); }
-    else { if (wide) BK_LIGHT(true, 16); else BK_LIGHT(false, 16); }
+    else if (nw <= 16) { if (wide) BK_LIGHT(true, 16); else BK_LIGHT(false, 16); }
+    else if (nw <= kNwLong) { if (wide) BK_LIGHT(true, kNwLong); else BK_LIGHT(false, kNwLong); }
+    else { if (wide) BK_LIGHT(true, kNwLongest); else BK_LIGHT(false, kNwLongest); }
 #undef BK_LIGHT
 }
 
@@ -4736,7 +4742,9 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 #define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
 #define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
     if (nw <= 8) { if (wide) BK_FLAT_W(8); else BK_FLAT_B(8); }
-    else { if (wide) BK_FLAT_W(16); else BK_FLAT_B(16); }
+    else if (nw <= 16) { if (wide) BK_FLAT_W(16); else BK_FLAT_B(16); }
+    else if (nw <= kNwLong) { if (wide) BK_FLAT_W(kNwLong); else BK_FLAT_B(kNwLong); }
+    else { if (wide) BK_FLAT_W(kNwLongest); else BK_FLAT_B(kNwLongest); }
 #undef BK_FLAT_W
 #undef BK_FLAT_B
 #undef BK_FLAT
@@ -4762,11 +4770,19 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
         else if (hash) BK_WAVE(8, false, true, false, true);
         else if (sw) { if (group8) BK_WAVE(8, false, false, true, true); else BK_WAVE(8, false, false, true, false); }
         else { if (group8) BK_WAVE(8, false, false, false, true); else BK_WAVE(8, false, false, false, false); }
-    } else {
+    } else if (nw <= 16) {
         if (wide) BK_WAVE(16, true, true, false, true);
         else if (hash) BK_WAVE(16, false, true, false, true);
         else if (sw) BK_WAVE(16, false, false, true, true);
         else BK_WAVE(16, false, false, false, true);
+    } else if (nw <= kNwLong) {                            // reads of 257 .. 16 * kNwLong bases
+        if (wide) BK_WAVE(kNwLong, true, true, false, true);
+        else if (hash) BK_WAVE(kNwLong, false, true, false, true);
+        else BK_WAVE(kNwLong, false, false, false, true);
+    } else {                                               // .. 16 * kNwLongest bases
+        if (wide) BK_WAVE(kNwLongest, true, true, false, true);
+        else if (hash) BK_WAVE(kNwLongest, false, true, false, true);
+        else BK_WAVE(kNwLongest, false, false, false, true);
     }
 #undef BK_WAVE
 }

@@ -109,14 +109,14 @@ def test_packed_batch_equals_byte_batch(golden_tmp, fixture, knob):
 
 
 @pytest.mark.parametrize("el_size", [4, 5])
-@pytest.mark.parametrize("top", [150, 192])
-def test_reads_of_129_to_192_bases(tmp_path, top, el_size):
-    """batches whose longest read has 129 .. 192 bases (2 x 150 is the common case; the 16-word kernel family with a third of its
-    window unused): reads of 129 .. top bases and a few short ones against the oracle, every kernel family of that width, both
-    index element sizes, bytes and packed input"""
+@pytest.mark.parametrize("top", [150, 192, 256, 300, 320, 321, 450, 512])
+def test_reads_of_129_to_512_bases(tmp_path, top, el_size):
+    """batches whose longest read has 129 .. 256 bases (the 16-word register-window kernels; 2 x 150 is the common case), 257 .. 320
+    bases (the 20-word ones; 2 x 250 / 2 x 300) or 321 .. 512 bases (the 32-word ones): reads of that range and a few short ones
+    against the oracle, every kernel family of that width, both index element sizes, bytes and packed input"""
     import torch
     bk = _bk()
-    seq, ents, reads = _synth_case(1200 + top + el_size, 300000, 9000, top, 5, dup_len=top + 40)
+    seq, ents, reads = _synth_case(1200 + top + el_size, 300000, 9000 if top <= 320 else 5000, top, 5, dup_len=top + 40)
     n = len(seq)
     dev = torch.device("cuda:0")
     d_seq = torch.from_numpy(seq).to(dev)
@@ -128,7 +128,7 @@ def test_reads_of_129_to_192_bases(tmp_path, top, el_size):
                       el_size=el_size)
     rng = np.random.default_rng(top)
     nreads = len(reads)
-    lens = rng.integers(129, top + 1, nreads).astype(np.uint32)
+    lens = rng.integers(129 if top <= 256 else (257 if top <= 320 else 321), top + 1, nreads).astype(np.uint32)
     lens[rng.integers(0, nreads, 200)] = rng.integers(20, 129, 200)
     lens[0] = top
     offs = np.arange(nreads, dtype=np.uint64) * top
