@@ -1220,7 +1220,7 @@ static int imax(int a, int b) { return a > b ? a : b; }
 /* loci_out (optional): room for p->max_ml entries - the pHits[] contents of a read whose AlignReads returned
  * eHRhits, in the order LocateCoreMultiples left them (the multi-loci modes -r1..-r5 consume these) */
 static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *bases, int len,
-                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf, ora_loci *loci_out, ora_seg2 *seg2_out)
+                         ora_hit *out, ora_counters *ctr, scratch *sc, uint8_t *seqbuf, ora_loci *loci_out, ora_seg2 *seg2_out, ora_trims *trims_out)
 {
     if (seg2_out) memset(seg2_out, 0, sizeof(*seg2_out));
     memset(out, 0, sizeof(*out));
@@ -1288,6 +1288,12 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
             loci_out[k].chrom_id = hits[k].chrom_id; loci_out[k].match_loci = hits[k].match_loci;
             loci_out[k].match_len = hits[k].match_len; loci_out[k].strand = hits[k].strand;
             loci_out[k].mismatches = hits[k].mismatches;
+            if (trims_out) {                       /* chimeric placements (FlgChimeric) carry their end trims, every locus its own */
+                trims_out[k].left = hits[k].chimeric ? hits[k].trim_left : 0;
+                trims_out[k].right = hits[k].chimeric ? hits[k].trim_right : 0;
+                trims_out[k].chimeric = hits[k].chimeric ? 1 : 0;
+                trims_out[k].reserved = 0;
+            }
         }
 
     switch (rslt) {                                                                     /* :9311-9479 */
@@ -1350,7 +1356,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 {
     scratch *sc = scratch_new();
     uint8_t *buf = (uint8_t *)malloc((size_t)len + 16);
-    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf, NULL, NULL);
+    int r = align_read_sc(s, p, bases, len, out, ctr, sc, buf, NULL, NULL, NULL);
     free(buf);
     scratch_free(sc);
     return r;
@@ -1358,7 +1364,7 @@ int ora_align_read(const ora_sfx *s, const ora_params *p, const uint8_t *bases, 
 
 typedef struct worker {
     const ora_sfx *s; const ora_params *p; const uint8_t *bases; const uint64_t *offs;
-    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt; ora_loci *loci; ora_seg2 *seg2;
+    const uint32_t *lens; uint32_t lo, hi; ora_hit *out; ora_counters ctr; int rslt; ora_loci *loci; ora_seg2 *seg2; ora_trims *trims;
 } worker;
 
 static void *worker_main(void *arg)
@@ -1370,8 +1376,9 @@ static void *worker_main(void *arg)
     uint8_t *buf = (uint8_t *)malloc((size_t)maxlen + 16);
     for (uint32_t i = w->lo; i < w->hi; i++) {
         ora_loci *lo = w->loci ? w->loci + (size_t)i * (size_t)(w->p->max_ml > 0 ? w->p->max_ml : 1) : NULL;
+        ora_trims *tr = w->trims ? w->trims + (size_t)i * (size_t)(w->p->max_ml > 0 ? w->p->max_ml : 1) : NULL;
         int r = align_read_sc(w->s, w->p, w->bases + w->offs[i], (int)w->lens[i], &w->out[i], &w->ctr, sc, buf, lo,
-                              w->seg2 ? w->seg2 + i : NULL);
+                              w->seg2 ? w->seg2 + i : NULL, tr);
         if (r < 0) { w->rslt = r; break; }
     }
     free(buf);
@@ -1397,6 +1404,13 @@ int ora_align_batch_ex(const ora_sfx *s, const ora_params *p, const uint8_t *bas
                        const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
                        ora_hit *out, ora_loci *loci, ora_seg2 *seg2, ora_counters *ctr, int nthreads)
 {
+    return ora_align_batch_ex2(s, p, bases, offs, lens, nreads, out, loci, seg2, NULL, ctr, nthreads);
+}
+
+int ora_align_batch_ex2(const ora_sfx *s, const ora_params *p, const uint8_t *bases,
+                        const uint64_t *offs, const uint32_t *lens, uint32_t nreads,
+                        ora_hit *out, ora_loci *loci, ora_seg2 *seg2, ora_trims *trims, ora_counters *ctr, int nthreads)
+{
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > nreads) nthreads = nreads ? (int)nreads : 1;
     worker *w = (worker *)calloc((size_t)nthreads, sizeof(worker));
@@ -1405,7 +1419,7 @@ int ora_align_batch_ex(const ora_sfx *s, const ora_params *p, const uint8_t *bas
      * reads are independent so a static split gives the same answers */
     uint64_t per = ((uint64_t)nreads + nthreads - 1) / nthreads;
     for (int t = 0; t < nthreads; t++) {
-        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out; w[t].loci = loci; w[t].seg2 = seg2;
+        w[t].s = s; w[t].p = p; w[t].bases = bases; w[t].offs = offs; w[t].lens = lens; w[t].out = out; w[t].loci = loci; w[t].seg2 = seg2; w[t].trims = trims;
         uint64_t lo = per * t, hi = lo + per;
         if (lo > nreads) lo = nreads;
         if (hi > nreads) hi = nreads;

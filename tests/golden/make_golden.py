@@ -918,6 +918,83 @@ def make_chimeric(tmp):
     shutil.copyfile(bam + ".bai", os.path.join(outdir, "c50.m6.bam.bai"))
 
 
+CHIMML_RUNS = [("r1R5c50", ["-r1", "-R5", "-c50", "-s3", "-T4"], ["-M6"]), ("r2R5c50", ["-r2", "-R5", "-c50", "-s3", "-T1"], ["-M6"]),
+               ("r3R5c50", ["-r3", "-R5", "-c50", "-s3", "-T4"], ["-M6"]), ("r4R5c60", ["-r4", "-R5", "-c60", "-s3", "-T4"], ["-M6"]),
+               ("r5R5c50", ["-r5", "-R5", "-c50", "-s3", "-T1"], ["-M6", "-M0", "-M4"]), ("r5R3Xc50", ["-r5", "-R3", "-X", "-c50", "-s3", "-T1"], ["-M6"]),
+               ("r4R3Xc70s5", ["-r4", "-R3", "-X", "-c70", "-s5", "-T4"], ["-M6"]), ("r5R8c55e2", ["-r5", "-R8", "-c55", "-s3", "-e2", "-T1"], ["-M0"])]
+
+
+def make_chimml(tmp):
+    """chimeric trimming together with the multi-loci modes (-c with -r1..-r5: the chimeric LocateCoreMultiples call is made with
+    MaxHits = -R and every locus it returns keeps its own end trims, SfxArrayV2.cpp:5959-6080, Aligner.cpp:9222-9304): a genome
+    with 260-base segments present in 2..6 places (some copies a substitution away), reads from them and from their unique
+    surroundings, a 5' and / or 3' end (10..45 bases) foreign in half of the reads"""
+    rng = np.random.default_rng(16180)
+    outdir = os.path.join(HERE, "chimml")
+    os.makedirs(outdir, exist_ok=True)
+    g = [list(rand_seq(rng, 60000)), list(rand_seq(rng, 40000))]
+    segs = []
+    for k in range(40):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 260))
+        seg = g[c][p:p + 260]
+        places = [(c, p)]
+        for _ in range(int(rng.integers(1, 6))):
+            c2 = int(rng.integers(0, 2)); q = int(rng.integers(0, len(g[c2]) - 260))
+            cp = list(seg)
+            if rng.integers(0, 3) == 0:
+                j = int(rng.integers(0, 260)); cp[j] = "ACGT"[("ACGT".index(cp[j]) + 1) % 4]
+            g[c2][q:q + 260] = cp
+            places.append((c2, q))
+        segs.append(places)
+    g = ["".join(x) for x in g]
+    fa = os.path.join(tmp, "chimml.fa")
+    write_fasta(fa, [("mA", g[0]), ("mB", g[1])])
+
+    def foreign(k):
+        if rng.integers(0, 2):
+            return rand_seq(rng, k)
+        c2 = int(rng.integers(0, 2)); q = int(rng.integers(0, len(g[c2]) - k))
+        return g[c2][q:q + k]
+
+    reads = []
+    for i in range(900):
+        if i < 600:                                       # from a multi-copy segment (or straddling its edge)
+            c, p = segs[int(rng.integers(0, len(segs)))][0]
+            p = max(0, min(len(g[c]) - 100, p + int(rng.integers(-40, 200))))
+        else:
+            c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 100))
+        core = mutate(rng, g[c][p:p + 100], int(rng.integers(0, 3)))
+        k5 = k3 = 0
+        if rng.integers(0, 2):
+            k5 = int(rng.integers(10, 46)) if rng.integers(0, 3) else 0
+            k3 = int(rng.integers(10, 46)) if (rng.integers(0, 3) == 0 or k5 == 0) else 0
+            if k5 + k3 > 50:
+                k3 = 0
+        sq = foreign(k5) + core[k5:100 - k3] + foreign(k3)
+        if rng.integers(0, 2):
+            sq = revcomp(sq)
+        reads.append((f"m{i}_{k5}_{k3}", sq))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "chimml_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "chimml.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "chimml", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags, fmts in CHIMML_RUNS:
+        for fmt in fmts:
+            ext = {"-M6": "m6.sam", "-M0": "m0.csv", "-M4": "m4.bed"}[fmt]
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            log = run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            if fmt == fmts[0]:
+                with open(os.path.join(outdir, f"{tag}.nar.txt"), "w") as f:
+                    f.write(nar_summary(log))
+            print("  ran", tag, fmt, flags)
+
+
 def make_pechim(tmp):
     """chimeric trimming together with paired ends (-c with -U: the pair rules work on the trimmed loci, AdjStartLoci / AdjEndLoci,
     Aligner.cpp:2750-2769, and the orphan recovery may return an end-trimmed partner, AlignPairedRead with MinChimericLen,
@@ -1393,6 +1470,9 @@ def main():
             make_chimeric(tmp)
         if "--only-pechim" in sys.argv:
             make_pechim(tmp)
+            return
+        if "--only-chimml" in sys.argv:
+            make_chimml(tmp)
             return
         if "--only-splice" in sys.argv:
             make_splice(tmp)

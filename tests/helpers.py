@@ -87,6 +87,9 @@ def oracle_lib():
     lib.ora_align_batch_ex.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(OraCounters), ctypes.c_int]
     lib.ora_align_batch_ex.restype = ctypes.c_int
+    lib.ora_align_batch_ex2.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(OraCounters), ctypes.c_int]
+    lib.ora_align_batch_ex2.restype = ctypes.c_int
     lib.ora_process_paired_ends.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                             ctypes.c_void_p]
@@ -222,6 +225,35 @@ def oracle_align_multi_indel(osfx, bases, offs, lens, params, nthreads=4):
     lo[1:] = np.cumsum(cnt)
     mask = np.arange(ml)[None, :] < cnt[:, None]
     return out, lo, dense[mask], seg2
+
+
+TRIMS_DTYPE = np.dtype([("left", "<u2"), ("right", "<u2"), ("chimeric", "u1"), ("reserved", "u1")])
+
+
+def oracle_align_multi_chimeric(osfx, bases, offs, lens, params, nthreads=4):
+    """-r modes together with -c: (hits, offs[n+1], loci, trims, seg2) - every locus of a list with its own end trims (TRIMS_DTYPE, read
+    orientation; chimeric = the placement came from the chimeric call)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = len(lens)
+    ml = max(1, params.max_ml)
+    out = np.zeros(n, dtype=HIT_DTYPE)
+    dense = np.zeros((n, ml), dtype=LOCI_DTYPE)
+    trims = np.zeros((n, ml), dtype=TRIMS_DTYPE)
+    seg2 = np.zeros(n, dtype=SEG2_DTYPE)
+    ctr = OraCounters()
+    rc = osfx.lib.ora_align_batch_ex2(osfx.h, ctypes.byref(params), bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, n,
+                                      out.ctypes.data, dense.ctypes.data, seg2.ctypes.data, trims.ctypes.data, ctypes.byref(ctr), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"ora_align_batch_ex2 failed: {rc}")
+    cnt = np.where(out["rslt"] == 1, out["low_hit_instances"].astype(np.int64), 0)
+    if params.clamp_ml:
+        cnt = np.where(out["rslt"] == 3, ml, cnt)
+    lo = np.zeros(n + 1, dtype=np.uint64)
+    lo[1:] = np.cumsum(cnt)
+    mask = np.arange(ml)[None, :] < cnt[:, None]
+    return out, lo, dense[mask], trims[mask], seg2
 
 
 def remove_orphan_splices(hits, seg2):
