@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_pair_batch_seg2", "bk_pair_batch_seg2_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
-    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format",
+    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims",
 ]
 
 
@@ -53,6 +53,7 @@ HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", 
                       ("mismatches", "u1"), ("flags", "u1")])
 assert HIT_DTYPE.itemsize == 20
 LOCI_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"), ("strand", "u1"), ("mismatches", "u1")])
+LOCI_TRIMS_DTYPE = np.dtype([("left", "<u2"), ("right", "<u2"), ("chimeric", "u1"), ("reserved", "u1")])
 assert LOCI_DTYPE.itemsize == 12
 SEG2_DTYPE = np.dtype([("match_loci", "<u4"), ("match_len", "<u2"), ("read_ofs", "<u2"), ("mismatches", "u1"), ("flags", "u1"), ("score", "<u2")])
 assert SEG2_DTYPE.itemsize == 12
@@ -163,6 +164,8 @@ def load_library():
     lib.bk_pair_batch_seg2_device.restype = i32
     lib.bk_batch_loci.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.bk_batch_seg2.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_batch_loci_trims.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_batch_loci_trims.restype = i32
     lib.bk_get_counters.argtypes = [vp, ctypes.POINTER(_Counters), i32]
     lib.bk_get_counters.restype = i32
     lib.bk_get_timing.argtypes = [vp, ctypes.POINTER(_Timing), i32]
@@ -206,6 +209,8 @@ def load_library():
     lib.bk_stream_batch_loci.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.bk_stream_batch_loci.restype = i32
     lib.bk_stream_batch_seg2.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_stream_batch_loci_trims.argtypes = [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.bk_stream_batch_loci_trims.restype = i32
     lib.bk_stream_batch_seg2.restype = i32
     lib.bk_stream_release.argtypes = [vp, u64]
     lib.bk_stream_release.restype = i32
@@ -394,6 +399,17 @@ class Aligner:
             return offs, np.zeros(0, dtype=LOCI_DTYPE)
         raw = np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_DTYPE.itemsize,))
         return offs, raw.view(LOCI_DTYPE).copy()
+
+    def batch_loci_trims(self):
+        """End trims of every locus of batch_loci() (contexts with min_chimeric_len > 0 and max_ml > 1): LOCI_TRIMS_DTYPE array, a copy"""
+        pt, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self.lib.bk_batch_loci_trims(self.h, ctypes.byref(pt), ctypes.byref(n))
+        if rc:
+            raise BkError(rc, "bk_batch_loci_trims")
+        if not pt.value or n.value == 0:
+            return np.zeros(0, dtype=LOCI_TRIMS_DTYPE)
+        raw = np.ctypeslib.as_array(ctypes.cast(pt, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_TRIMS_DTYPE.itemsize,))
+        return raw.view(LOCI_TRIMS_DTYPE).copy()
 
     def batch_seg2(self):
         """Second segments of the last align call (contexts with micro_indel_len > 0): SEG2_DTYPE array, one per read (a copy)."""
@@ -595,6 +611,16 @@ class Stream:
             return offs, np.zeros(0, dtype=LOCI_DTYPE)
         raw = np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_DTYPE.itemsize,))
         return offs, raw.view(LOCI_DTYPE).copy()
+
+    def batch_loci_trims(self, ticket):
+        pt, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self.lib.bk_stream_batch_loci_trims(self.h, ticket, ctypes.byref(pt), ctypes.byref(n))
+        if rc:
+            raise BkError(rc, "bk_stream_batch_loci_trims")
+        if not pt.value or n.value == 0:
+            return np.zeros(0, dtype=LOCI_TRIMS_DTYPE)
+        raw = np.ctypeslib.as_array(ctypes.cast(pt, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value * LOCI_TRIMS_DTYPE.itemsize,))
+        return raw.view(LOCI_TRIMS_DTYPE).copy()
 
     def batch_seg2(self, ticket):
         ps, n = ctypes.c_void_p(), ctypes.c_uint64()

@@ -117,6 +117,7 @@ struct bk_ctx {
     // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)
     std::vector<uint64_t> loci_offs;
     std::vector<bk_loci> loci;
+    std::vector<bk_loci_trims> loci_trims;   // -c with the multi-loci modes: one per locus
     std::vector<bk_seg2> seg2;           // -a: second segments of the last align call, one per read
 };
 

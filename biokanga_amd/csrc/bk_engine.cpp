@@ -83,9 +83,10 @@ void launch_chimeric(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
                      int min_pct, int long_reads, uint32_t *cursor, bk_seg2 *seg2, hipStream_t s);
 void launch_loci_compact(const bk_loci *dense, uint32_t width, const unsigned long long *offs, uint32_t n, bk_loci *out, hipStream_t s);
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
-                        hipStream_t s);
+                        const bk_seg2 *seg2, bk_loci_trims *trims, hipStream_t s);
 void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
-                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, hipStream_t s);
+                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, int min_pct, int long_reads,
+                      bk_seg2 *seg2, bk_loci_trims *trims, hipStream_t s);
 int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
                      void *tmp, size_t *tmp_bytes, hipStream_t s);
 void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s);
@@ -115,7 +116,10 @@ int derive_cfg(bk_ctx *c)
     if (p.best_matches && p.max_ml < 2) return BK_ERR_PARAMS;
     if (p.micro_indel_len < 0 || p.micro_indel_len > 20) return BK_ERR_PARAMS;           // cMaxMicroInDelLen
     if ((p.micro_indel_len || p.splice_junct_len) && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;   // LocateBestMatches has no such branches
-    if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99 || p.max_ml > 1)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
+    if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
+    // -c with the multi-loci modes: the chimeric call lists its loci; not together with -N (no chimeric branch there) or -a / -A (a chimeric
+    // call that inherits an ambiguous microInDel search would have to list that search's loci too)
+    if (p.min_chimeric_len != 0 && p.max_ml > 1 && (p.best_matches || p.micro_indel_len || p.splice_junct_len)) return BK_ERR_PARAMS;
     if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
@@ -556,13 +560,15 @@ static inline uint64_t scratch_bytes_per_read(uint32_t wpr, uint32_t rd2w = 8, u
 // Multi-loci modes: the loci lists of one chunk (reads whose AlignReads returned eHRhits own LowHitInstances
 // entries each).  Counts -> offsets (scan) -> single loci copied from the result records, the others replayed
 // by the ENUM form of the wave-per-read kernel; appended to the context's host vectors.
-int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, hipStream_t s)
+int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, uint32_t maxlen, hipStream_t s)
 {
     unsigned long long *d_cnt = nullptr, *d_offs = nullptr;
     void *d_tmp = nullptr;
     bk_loci *d_loci = nullptr;
+    bk_loci_trims *d_trims = nullptr;
+    const bool chim = c->params.min_chimeric_len > 0 && c->d_seg2 != nullptr;       // every locus carries its end trims
     int rc = BK_OK;
-    auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_loci); };
+    auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_loci); free_dev(d_trims); };
 #define LOCI_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
     LOCI_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
     LOCI_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
@@ -582,21 +588,30 @@ int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, hipStream_t s)
     if (total) {
         uint32_t *sm = c->d_small;
         LOCI_TRY(hipMalloc(&d_loci, (size_t)total * sizeof(bk_loci)));
+        if (chim) {
+            LOCI_TRY(hipMalloc(&d_trims, (size_t)total * sizeof(bk_loci_trims)));
+            LOCI_TRY(clear_dev(d_trims, (size_t)total * sizeof(bk_loci_trims), s));
+        }
         LOCI_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
         uint32_t *list = c->d_act[0];                  // the phase work lists are free by now
-        launch_loci_single(b.out, n, d_offs, d_loci, list, sm + 0, s);
+        launch_loci_single(b.out, n, d_offs, d_loci, list, sm + 0, chim ? c->d_seg2 : nullptr, d_trims, s);
         LOCI_TRY(hipMemcpyAsync(c->h_small, sm, 16 * 4, hipMemcpyDeviceToHost, s));
         LOCI_TRY(hipStreamSynchronize(s));
         const uint32_t n_multi = c->h_small[0];
         if (n_multi) {
             rc = size_heavy_scratch(c);
             if (rc) { cleanup(); return rc; }
-            launch_loci_enum(c->ix, c->cfg, b, c->hs, list, n_multi, sm + 1, d_offs, d_loci, sm + 2, s);
+            launch_loci_enum(c->ix, c->cfg, b, c->hs, list, n_multi, sm + 1, d_offs, d_loci, sm + 2, chim ? c->params.min_chimeric_len : 0, maxlen > 512 ? 1 : 0,
+                             chim ? c->d_seg2 : nullptr, d_trims, s);
             LOCI_TRY(hipGetLastError());
             LOCI_TRY(hipMemcpyAsync(c->h_small, sm, 16 * 4, hipMemcpyDeviceToHost, s));
         }
         c->loci.resize(loci_base + total);
         LOCI_TRY(hipMemcpyAsync(c->loci.data() + loci_base, d_loci, (size_t)total * sizeof(bk_loci), hipMemcpyDeviceToHost, s));
+        if (chim) {
+            c->loci_trims.resize(loci_base + total);
+            LOCI_TRY(hipMemcpyAsync(c->loci_trims.data() + loci_base, d_trims, (size_t)total * sizeof(bk_loci_trims), hipMemcpyDeviceToHost, s));
+        }
         LOCI_TRY(hipStreamSynchronize(s));
         if (n_multi && c->h_small[2] != 0) {           // a replay that did not reproduce LowHitInstances: never ignore
             fprintf(stderr, "bk: loci replay disagreed with LowHitInstances for %u reads\n", c->h_small[2]);
@@ -844,6 +859,9 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         if (eh == hipSuccess) eh = hipStreamSynchronize(s);
         if (rc2 != BK_OK) return rc2;
         if (eh != hipSuccess) return BK_ERR_INTERNAL;
+        if (c->params.min_chimeric_len > 0 && c->cfg.max_hits > 1)          // (the chimeric call's note to the loci replay, see k_heavy)
+            for (size_t i = at; i < at + n; i++)
+                if (c->seg2[i].flags == 0x40) c->seg2[i] = bk_seg2{};
         tm.end(2, ei, s);
     }
     hipEvent_t e4 = tm.begin(s);
@@ -851,7 +869,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     HIP_TRY(hipGetLastError());
     tm.end(3, e4, s);
     if (c->cfg.max_hits > 1 && !c->params.best_matches) {
-        int rl = collect_loci(c, b, n, s);
+        int rl = collect_loci(c, b, n, maxlen, s);
         if (rl) return rl;
     }
     return BK_OK;
@@ -888,6 +906,7 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     hipEvent_t t0 = tm.begin(s);
     c->loci_offs.clear();
     c->loci.clear();
+    c->loci_trims.clear();
     c->seg2.clear();
     // longest read of the call -> row width of the packed reads and the kernel family used (the pipeline knows it already)
     uint32_t maxlen = maxlen_known;
@@ -1050,6 +1069,14 @@ int bk_batch_loci(bk_ctx *c, const uint64_t **offs, const bk_loci **loci, uint64
     *offs = c->loci_offs.data();
     *loci = c->loci.data();
     *n_loci = c->loci.size();
+    return BK_OK;
+}
+
+int bk_batch_loci_trims(bk_ctx *c, const bk_loci_trims **trims, uint64_t *n_loci)
+{
+    if (!c || !trims || !n_loci) return BK_ERR_PARAMS;
+    *trims = c->loci_trims.empty() ? nullptr : c->loci_trims.data();
+    *n_loci = c->loci_trims.size();
     return BK_OK;
 }
 

@@ -3187,10 +3187,11 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ next_act,
                                                uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ cmax_next,
                                                const unsigned long long *__restrict__ loci_offs, bk_loci *__restrict__ loci_out,
-                                               uint32_t *__restrict__ enum_err)
+                                               uint32_t *__restrict__ enum_err, bk_seg2 *__restrict__ seg2_aux = nullptr,
+                                               bk_loci_trims *__restrict__ trims_out = nullptr)
 {
-    constexpr bool ENUM = MODE == 1, BEST = MODE == 2, CHIM = MODE == 3 || MODE == 4;
-    constexpr int ATW = MODE == 4 ? 32 : 8;                // MODE 4: the chimeric form for reads of more than 512 bases
+    constexpr bool ENUM = MODE == 1 || MODE == 5, BEST = MODE == 2, CHIM = MODE == 3 || MODE == 4;
+    constexpr int ATW = (MODE == 4 || MODE == 5) ? 32 : 8;  // MODE 4 / 5: the chimeric form / its replay for reads of more than 512 bases
     __shared__ LdsEntries s_le;
     __shared__ uint32_t s_hist[BEST ? 4 : 1][64], s_pre[BEST ? 4 : 1][64], s_run[BEST ? 4 : 1][64];
     __shared__ bk_loci s_first[BEST ? 4 : 1];
@@ -3232,6 +3233,11 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
         uint32_t want_n = 0, emitted = 0;
         unsigned long long emit_base = 0;
         bool clamped = false;
+        // ENUM of a read whose result came from the chimeric call (`-c` with the multi-loci modes): that call is replayed and every
+        // candidate whose trimmed length and mismatches equal the best pair is a locus, with its own end trims.  k_heavy<.., CHIM>
+        // left the best trimmed length in the read's bk_seg2 record (flags 0x40, match_len; the host never sees it).
+        bool chim_replay = false;
+        int want_len = 0;
         if (ENUM) {
             const bk_hit h = b.out[r];
             phase = h.flags >> 1;
@@ -3239,13 +3245,18 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
             emit_base = loci_offs[r];
             want_n = (uint32_t)(loci_offs[r + 1] - emit_base);
             clamped = h.rslt == BK_HR_HITINSTS;      // -X: only the first MaxHits loci of a read with more
+            if (seg2_aux != nullptr && phase == p.n_phases) {
+                const bk_seg2 g = seg2_aux[r];
+                chim_replay = g.flags == 0x40;
+                want_len = g.match_len;
+            }
         }
         if (BEST) phase = p.n_phases - 1;                 // the caller's own MaxTotMM / CoreLen / CoreDelta
         phase_params(p, cfg, phase, mm, cl, cd);
         // CHIM (`-c`, AlignReads :7750-7757): the last call, with shorter cores; a placement is a candidate trimmed at its ends by
         // AdaptiveTrim to at least min_chimeric_len % of the read; longest first, then fewest mismatches (:5959-6080)
         int chim_min = 0, chim_best_len = 0, chim_best_mm = 0, chim_t5 = 0, chim_t3 = 0;
-        if (CHIM) {
+        if (CHIM || chim_replay) {
             phase = p.n_phases;
             mm = p.max_tot_mm;
             cl = len / (mm + 4) > cfg.min_core_len ? len / (mm + 4) : cfg.min_core_len;
@@ -3370,7 +3381,7 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     bool proc = active && j < cutoff && isnew;
                     if (proc) htab_insert(tab, tmask, epoch, key);
                     int cm = 127;
-                    if (CHIM) {
+                    if (CHIM || chim_replay) {
                         int c_len = 0, c_mm = 0, c_t5 = 0, c_t3 = 0, e2 = -1;
                         if (proc) {
                             c_len = adaptive_trim_dev<ATW>(rdw, ix.tgt4, t, len, chim_min, mm, 3, c_mm, c_t5, c_t3);
@@ -3381,6 +3392,31 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                         iter += np;
                         nodes += np;
                         n_cand += (lane == 0) ? np : 0;
+                        if (ENUM) {
+                            const bool hit = c_len > 0 && c_len == want_len && c_mm == want_mm;
+                            const uint64_t hmask = __ballot(hit);
+                            if (hit) {
+                                const uint32_t k = emitted + (uint32_t)__popcll(hmask & lt_mask);
+                                if (k < want_n) {
+                                    bk_loci L;
+                                    L.chrom_id = ix.ent_id[e2];
+                                    L.match_loci = (uint32_t)(t - ix.ent_start[e2]);
+                                    L.match_len = (uint16_t)len;
+                                    L.strand = (uint8_t)(st ? '-' : '+');
+                                    L.mismatches = (uint8_t)c_mm;
+                                    loci_out[emit_base + k] = L;
+                                    if (trims_out != nullptr) {
+                                        bk_loci_trims T;
+                                        T.left = (uint16_t)(st ? c_t3 : c_t5); T.right = (uint16_t)(st ? c_t5 : c_t3); T.chimeric = 1; T.reserved = 0;
+                                        trims_out[emit_base + k] = T;
+                                    }
+                                }
+                            }
+                            emitted += (uint32_t)__popcll(hmask);
+                            if (clamped && emitted >= want_n) done = true;
+                            if (cutoff < j0 + 64) break;
+                            continue;
+                        }
                         uint64_t hm = __ballot(c_len > 0);
                         while (hm && !done) {                       // in suffix-array order, as the reference meets them
                             const int src = __ffsll((unsigned long long)hm) - 1;
@@ -3564,6 +3600,11 @@ __global__ void __launch_bounds__(256) k_heavy(DevIndex ix, DevAlignCfg cfg, Dev
                     g.match_len = (uint16_t)(hit_strand == '+' ? chim_t5 : chim_t3);
                     g.read_ofs = (uint16_t)(hit_strand == '+' ? chim_t3 : chim_t5);
                     reinterpret_cast<bk_seg2 *>(loci_out)[r] = g;
+                } else if (CHIM && cfg.max_hits > 1 && low_inst > 1 && chim_best_len > 0 && (rslt == BK_HR_HITS || rslt == BK_HR_HITINSTS)) {
+                    bk_seg2 g;                                              // for the replay that lists the loci (see ENUM above)
+                    g.match_loci = 0; g.mismatches = 0; g.score = 0; g.flags = 0x40; g.read_ofs = 0;
+                    g.match_len = (uint16_t)chim_best_len;
+                    reinterpret_cast<bk_seg2 *>(loci_out)[r] = g;
                 }
             }
         } else if (phase + 1 < p.n_phases) {
@@ -3604,7 +3645,8 @@ __global__ void __launch_bounds__(256) k_loci_count(const bk_hit *__restrict__ o
 }
 
 __global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ out, uint32_t n, const unsigned long long *__restrict__ offs,
-                                                     bk_loci *__restrict__ loci, uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+                                                     bk_loci *__restrict__ loci, uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt,
+                                                     const bk_seg2 *__restrict__ seg2, bk_loci_trims *__restrict__ trims)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -3614,6 +3656,10 @@ __global__ void __launch_bounds__(256) k_loci_single(const bk_hit *__restrict__ 
         bk_loci L;
         L.chrom_id = h.chrom_id; L.match_loci = h.match_loci; L.match_len = h.match_len; L.strand = h.strand; L.mismatches = h.mismatches;
         loci[offs[r]] = L;
+        if (trims != nullptr && seg2 != nullptr) {             // a unique chimeric placement: its trims travel in the bk_seg2 record
+            const bk_seg2 g = seg2[r];
+            if (g.flags & 8) { bk_loci_trims T; T.left = g.match_len; T.right = g.read_ofs; T.chimeric = 1; T.reserved = 0; trims[offs[r]] = T; }
+        }
     } else
         list[atomicAdd(list_cnt, 1u)] = r;
 }
@@ -4848,20 +4894,25 @@ void launch_loci_count(const bk_hit *out, uint32_t n, int clamp_to, unsigned lon
 }
 
 void launch_loci_single(const bk_hit *out, uint32_t n, const unsigned long long *offs, bk_loci *loci, uint32_t *list, uint32_t *list_cnt,
-                        hipStream_t s)
+                        const bk_seg2 *seg2, bk_loci_trims *trims, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_loci_single, dim3((n + 255) / 256), dim3(256), 0, s, out, n, offs, loci, list, list_cnt);
+    if (n) hipLaunchKernelGGL(k_loci_single, dim3((n + 255) / 256), dim3(256), 0, s, out, n, offs, loci, list, list_cnt, seg2, trims);
 }
 
+// min_pct / seg2 / trims: contexts that trim chimeric reads (`-c` with the multi-loci modes) - the loci of a read the chimeric call placed
+// come from a replay of that call, each with its end trims
 void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
-                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, hipStream_t s)
+                      uint32_t n_list, uint32_t *cursor, const unsigned long long *offs, bk_loci *loci, uint32_t *err, int min_pct, int long_reads,
+                      bk_seg2 *seg2, bk_loci_trims *trims, hipStream_t s)
 {
     if (!n_list) return;
     uint32_t waves = n_list < hs.n_slots ? n_list : hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
     expand_rd4(b, list, n_list, s);
-    if (ix.sa_hi) hipLaunchKernelGGL((k_heavy<true, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
-    else hipLaunchKernelGGL((k_heavy<false, 1>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, 0, cursor, nullptr, nullptr, nullptr, offs, loci, err);
+#define BK_ENUM(W, M) hipLaunchKernelGGL((k_heavy<W, M>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, min_pct, cursor, nullptr, nullptr, nullptr, offs, loci, err, seg2, trims)
+    if (seg2 != nullptr && long_reads) { if (ix.sa_hi) BK_ENUM(true, 5); else BK_ENUM(false, 5); }
+    else { if (ix.sa_hi) BK_ENUM(true, 1); else BK_ENUM(false, 1); }
+#undef BK_ENUM
 }
 
 

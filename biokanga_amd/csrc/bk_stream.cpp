@@ -74,6 +74,7 @@ struct Job {
     // list modes: what the context held after this batch's align call
     std::vector<uint64_t> loci_offs;
     std::vector<bk_loci> loci;
+    std::vector<bk_loci_trims> loci_trims;
     std::vector<bk_seg2> seg2;
 };
 
@@ -196,6 +197,7 @@ struct bk_stream {
                 else if (list_modes) {
                     j->loci_offs.swap(ctx->loci_offs);
                     j->loci.swap(ctx->loci);
+                    j->loci_trims.swap(ctx->loci_trims);
                     j->seg2.swap(ctx->seg2);
                 }
                 if (j->rc == BK_OK) {
@@ -230,6 +232,7 @@ struct bk_stream {
                     else if (list_modes) {
                         j->loci_offs.swap(ctx->loci_offs);
                         j->loci.swap(ctx->loci);
+                    j->loci_trims.swap(ctx->loci_trims);
                         j->seg2.swap(ctx->seg2);
                     }
                 }
@@ -454,6 +457,18 @@ int bk_stream_batch_seg2(bk_stream *s, uint64_t ticket, const bk_seg2 **seg2, ui
     Job *j = it->second;
     *seg2 = j->seg2.empty() ? nullptr : j->seg2.data();
     *n = j->seg2.size();
+    return BK_OK;
+}
+
+int bk_stream_batch_loci_trims(bk_stream *s, uint64_t ticket, const bk_loci_trims **trims, uint64_t *n_loci)
+{
+    if (!s || !trims || !n_loci) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->jobs.find(ticket);
+    if (it == s->jobs.end() || !it->second->done) return BK_ERR_PARAMS;
+    Job *j = it->second;
+    *trims = j->loci_trims.empty() ? nullptr : j->loci_trims.data();
+    *n_loci = j->loci_trims.size();
     return BK_OK;
 }
 

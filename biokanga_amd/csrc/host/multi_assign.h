@@ -25,6 +25,8 @@ struct MultiHitRec {
     bool assigned;           // FlagMHA
     uint8_t how;             // FlagHL: 3 = clustered near unique reads, 4 = near other multi-loci reads
     uint16_t score;
+    uint16_t trim_left = 0, trim_right = 0;      // Seg[0].TrimLeft / TrimRight of a chimeric placement (read orientation), else 0
+    uint32_t src = 0;        // the caller's number for this locus
 };
 
 struct MultiAssignStats { int putative = 0, assigned = 0, near_unique = 0, near_multi = 0; };
@@ -64,7 +66,10 @@ class MultiAssign {
 public:
     std::vector<MultiHitRec> recs;
 
-    void add(uint32_t read_id, const bk_loci &l, bool multi) { recs.push_back({read_id, l, multi, false, 0, 0}); }
+    void add(uint32_t read_id, const bk_loci &l, bool multi, uint16_t trim_left = 0, uint16_t trim_right = 0, uint32_t src = 0)
+    {
+        recs.push_back({read_id, l, multi, false, 0, 0, trim_left, trim_right, src});
+    }
 
     // uniq_only: -r3 (cluster with uniquely aligned reads only); nthreads: the -T of the run; max_reads_len: longest loaded read
     MultiAssignStats assign(bool uniq_only, int nthreads, uint32_t max_reads_len)
@@ -100,9 +105,9 @@ public:
             if (a.read_id != b.read_id) return a.read_id < b.read_id;
             if (a.score != b.score) return a.score > b.score;
             if (a.loci.chrom_id != b.loci.chrom_id) return a.loci.chrom_id < b.loci.chrom_id;
-            if (a.loci.match_len != b.loci.match_len) return a.loci.match_len < b.loci.match_len;
+            if (len_of(a) != len_of(b)) return len_of(a) < len_of(b);
             if (a.loci.mismatches != b.loci.mismatches) return a.loci.mismatches < b.loci.mismatches;
-            if (a.loci.match_loci != b.loci.match_loci) return a.loci.match_loci < b.loci.match_loci;
+            if (start_of(a) != start_of(b)) return start_of(a) < start_of(b);
             return a.loci.strand < b.loci.strand;
         }, threads_);
         uint32_t cur_read = 0;
@@ -129,15 +134,15 @@ public:
             if (!accept) {
                 for (size_t k = i; k-- > 0;) {
                     const MultiHitRec &q = recs[k];
-                    const uint32_t dist = c.loci.match_loci - q.loci.match_loci;
-                    if (dist > (uint32_t)(kOverlap + (int)q.loci.match_len)) break;
+                    const uint32_t dist = start_of(c) - start_of(q);
+                    if (dist > (uint32_t)(kOverlap + (int)len_of(q))) break;
                     if (q.loci.chrom_id != c.loci.chrom_id) break;
                     if (!q.multi || q.assigned) { accept = true; break; }
                 }
                 for (size_t k = i + 1; !accept && k < n; k++) {
                     const MultiHitRec &q = recs[k];
-                    const uint32_t dist = q.loci.match_loci - c.loci.match_loci;
-                    if (dist > (uint32_t)(kOverlap + (int)c.loci.match_len)) break;
+                    const uint32_t dist = start_of(q) - start_of(c);
+                    if (dist > (uint32_t)(kOverlap + (int)len_of(c))) break;
                     if (q.loci.chrom_id != c.loci.chrom_id) break;
                     if (!q.multi || q.assigned) { accept = true; break; }
                 }
@@ -159,8 +164,10 @@ private:
     static constexpr int kScale = 10;                 // cClustScaleFact
     static constexpr uint32_t kMinScore = 50;         // cMHminScore
 
-    static uint32_t start_of(const MultiHitRec &r) { return r.loci.match_loci; }                                   // AdjStartLoci, no trims
-    static uint32_t end_of(const MultiHitRec &r) { return r.loci.match_loci + (uint32_t)r.loci.match_len - 1u; }   // AdjEndLoci
+    // AdjStartLoci / AdjEndLoci / AdjHitLen (Aligner.cpp:1528-1552): the end trims of a chimeric placement move them inwards
+    static uint32_t start_of(const MultiHitRec &r) { return r.loci.match_loci + (r.loci.strand == '+' ? r.trim_left : r.trim_right); }
+    static uint32_t end_of(const MultiHitRec &r) { return r.loci.match_loci + ((uint32_t)r.loci.match_len - (r.loci.strand == '+' ? r.trim_right : r.trim_left) - 1u); }
+    static uint32_t len_of(const MultiHitRec &r) { return (uint32_t)r.loci.match_len - r.trim_left - r.trim_right; }
 
     int threads_ = 1;
 
@@ -168,8 +175,8 @@ private:
     {
         par_sort(recs, [](const MultiHitRec &a, const MultiHitRec &b) {
             if (a.loci.chrom_id != b.loci.chrom_id) return a.loci.chrom_id < b.loci.chrom_id;
-            if (a.loci.match_loci != b.loci.match_loci) return a.loci.match_loci < b.loci.match_loci;
-            if (a.loci.match_len != b.loci.match_len) return a.loci.match_len < b.loci.match_len;
+            if (start_of(a) != start_of(b)) return start_of(a) < start_of(b);
+            if (len_of(a) != len_of(b)) return len_of(a) < len_of(b);
             if (a.loci.mismatches != b.loci.mismatches) return a.loci.mismatches < b.loci.mismatches;
             if (a.loci.strand != b.loci.strand) return a.loci.strand < b.loci.strand;
             return a.read_id < b.read_id;
@@ -204,7 +211,7 @@ private:
         for (size_t i = from; i < until; i++) {
             MultiHitRec &c = recs[i];
             if (!c.multi) continue;
-            if (prev && start_of(*prev) == start_of(c) && prev->loci.match_len == c.loci.match_len && prev->loci.strand == c.loci.strand &&
+            if (prev && start_of(*prev) == start_of(c) && len_of(*prev) == len_of(c) && prev->loci.strand == c.loci.strand &&
                 prev->loci.chrom_id == c.loci.chrom_id) {
                 c.score = prev->score;
                 continue;
@@ -217,7 +224,7 @@ private:
                 if ((uint32_t)(start_of(c) - start_of(q)) >= max_reads_len) break;
                 const uint32_t q_end = end_of(q);
                 if (q_end < start_of(c) + (uint32_t)kOverlap) continue;
-                const int overlap = (int)std::min<uint32_t>((uint32_t)c.loci.match_len, q_end - start_of(c));
+                const int overlap = (int)std::min<uint32_t>(len_of(c), q_end - start_of(c));
                 if (score_one(c, q, overlap, uniq_only, 0x1fff)) break;
             }
             for (size_t k = i + 1; k < n; k++) {                             // downstream
@@ -225,7 +232,7 @@ private:
                 if (q.loci.chrom_id != c.loci.chrom_id) break;
                 const uint32_t c_end = end_of(c);
                 if (start_of(q) > c_end - (uint32_t)kOverlap) break;
-                const int overlap = (int)std::min<uint32_t>((uint32_t)q.loci.match_len, c_end - start_of(q));
+                const int overlap = (int)std::min<uint32_t>(len_of(q), c_end - start_of(q));
                 if (score_one(c, q, overlap, uniq_only, 0x3fff)) break;
             }
             prev = &c;

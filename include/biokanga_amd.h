@@ -261,6 +261,16 @@ typedef struct bk_loci {
  * lists (*n_loci = 0, NULL pointers).  What to do with them (-r1 statistics, -r2 random pick, -r3/-r4
  * clustering, -r5 report all; Aligner.cpp:9328-9424,5105-5272) is host policy above this boundary. */
 int  bk_batch_loci(bk_ctx *ctx, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
+/* With min_chimeric_len > 0 as well (`-c` together with `-r1..5`): the chimeric LocateCoreMultiples call is made with MaxHits = max_ml
+ * too and every locus it returns keeps its own end trims (tsSegLoci.TrimLeft / TrimRight of a FlgChimeric hit, read orientation,
+ * SfxArrayV2.cpp:6027-6070).  One entry per locus of bk_batch_loci(), in the same order; all zero for loci of the ordinary calls.
+ * NULL / 0 on other contexts.  6 bytes. */
+typedef struct bk_loci_trims {
+    uint16_t left, right;        /* Seg[0].TrimLeft / TrimRight                                  */
+    uint8_t  chimeric;           /* FlgChimeric                                                  */
+    uint8_t  reserved;
+} bk_loci_trims;
+int  bk_batch_loci_trims(bk_ctx *ctx, const bk_loci_trims **trims, uint64_t *n_loci);
 
 /* ---- microInDels (-a) ---------------------------------------------------------------------- */
 /* Second segment of a read aligned with a microInDel (tsHitLoci.Seg[1] and flags, SfxArrayV2.h:219-240): the read's bk_hit holds
@@ -314,6 +324,7 @@ int  bk_stream_submit_packed(bk_stream *s, const uint32_t *words, uint64_t n_wor
 int  bk_stream_wait(bk_stream *s, uint64_t ticket);
 int  bk_stream_batch_loci(bk_stream *s, uint64_t ticket, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
 int  bk_stream_batch_seg2(bk_stream *s, uint64_t ticket, const bk_seg2 **seg2, uint64_t *n);
+int  bk_stream_batch_loci_trims(bk_stream *s, uint64_t ticket, const bk_loci_trims **trims, uint64_t *n_loci);
 int  bk_stream_release(bk_stream *s, uint64_t ticket);
 /* waits for everything submitted; first failing batch's code or BK_OK */
 int  bk_stream_drain(bk_stream *s);

@@ -1278,7 +1278,7 @@ static int align_read_sc(const ora_sfx *s, const ora_params *p, const uint8_t *b
         }
     }
     if (rslt < 0) { if (hits != hits_small) free(hits); return rslt; }
-    if (!got_indel && rslt == HR_HITS && hits[0].chimeric && seg2_out) {                /* trims of a chimeric placement travel in the seg2 record */
+    if (!got_indel && rslt == HR_HITS && low_inst == 1 && hits[0].chimeric && seg2_out) {   /* trims of a unique chimeric placement travel in the seg2 record */
         seg2_out->flags = 8; seg2_out->match_len = hits[0].trim_left; seg2_out->read_ofs = hits[0].trim_right;
     }
     if (low_inst > max_ml) low_inst = max_ml + 1;                                       /* :9241 */

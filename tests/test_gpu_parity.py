@@ -839,6 +839,53 @@ def test_chimeric_placements_match_oracle(golden_tmp, fixture, kw):
         assert np.count_nonzero(eseg["flags"] & 8) > 100
 
 
+@pytest.mark.parametrize("kw", [dict(max_subs=3, min_chimeric_len=50, max_ml=5), dict(max_subs=3, min_chimeric_len=55, max_ml=8, min_edit_dist=2),
+                                dict(max_subs=3, min_chimeric_len=50, max_ml=3, clamp_ml=1), dict(max_subs=5, min_chimeric_len=70, max_ml=3, clamp_ml=1),
+                                dict(max_subs=3, min_chimeric_len=60, max_ml=2, align_strand=1)])
+@pytest.mark.parametrize("fixture", ["chimml", "chimeric", "multi"])
+def test_chimeric_loci_lists_match_oracle(golden_tmp, fixture, kw):
+    """-c together with the multi-loci modes: the chimeric call lists its loci (up to MaxHits of the same trimmed length and mismatches, in
+    discovery order), each with its own end trims - result records, lists, trims and the per-read bk_seg2 records against the oracle,
+    which is pinned on the reference's -r5 -c runs; one chunk and many"""
+    bk = _bk()
+    d = golden_tmp[fixture]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    o = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, elo, eloci, etrims, eseg = helpers.oracle_align_multi_chimeric(o, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    o.close()
+    for knobs in ([], [("chunk_reads", 97)], [("use_wave", 0)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs, lens)
+            lo, loci = al.batch_loci(len(lens))
+            trims = al.batch_loci_trims()
+            seg = al.batch_seg2()
+        assert_hits_equal(got, exp, names)
+        assert np.array_equal(lo, elo)
+        for f in ("chrom_id", "match_loci", "match_len", "strand", "mismatches"):
+            assert np.array_equal(loci[f], eloci[f]), (f, knobs)
+        assert len(trims) == len(loci)
+        for f in ("left", "right", "chimeric"):
+            if not np.array_equal(trims[f], etrims[f]):
+                j = int(np.nonzero(trims[f] != etrims[f])[0][0])
+                i = int(np.searchsorted(lo, j, side="right") - 1)
+                raise AssertionError(f"trims field {f} differs at locus {j} of read {i} ({names[i]}): got {trims[j]} exp {etrims[j]} locus {loci[j]}")
+        assert_seg2_equal(seg, eseg, names)
+    if fixture == "chimml" and kw["min_chimeric_len"] <= 55:
+        n_multi_chim = sum(1 for i in range(len(names)) if elo[i + 1] - elo[i] > 1 and etrims["chimeric"][int(elo[i])])
+        assert n_multi_chim > 30
+
+
+def test_chimeric_with_loci_lists_refuses_what_it_cannot_list(golden_tmp):
+    bk = _bk()
+    sfx = os.path.join(golden_tmp["chimml"], "genome.sfx")
+    for kw in (dict(min_chimeric_len=50, max_ml=5, best_matches=1), dict(min_chimeric_len=50, max_ml=5, micro_indel_len=5),
+               dict(min_chimeric_len=50, max_ml=5, splice_junct_len=1000)):
+        with pytest.raises(bk.BkError):
+            bk.Aligner(sfx, bk.AlignParams(max_subs=3, **kw))
+
+
 @pytest.mark.parametrize("kw", [dict(max_subs=1, min_chimeric_len=50), dict(max_subs=2, min_chimeric_len=70, align_strand=1), dict(max_subs=3, min_chimeric_len=50)])
 def test_chimeric_reads_longer_than_512_bases(tmp_path, kw):
     """-c on reads of 520 .. 1900 bases (the device AdaptiveTrim keeps a 2048-base mismatch map for them): a genome piece with a few
