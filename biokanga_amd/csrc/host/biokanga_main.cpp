@@ -498,7 +498,10 @@ int read_align_opts(Args &a, AlignOpts &o)
     // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
     o.min_chim = a.num("c", 0);
     if (o.min_chim != 0 && (o.min_chim < 50 || o.min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", o.min_chim < 0 ? -o.min_chim : o.min_chim); return 1; }
-    if (o.min_chim && o.ml_mode) { diag("Error: chimeric trimming '-c%d' together with '-r%d' is not available in this build", o.min_chim, o.ml_mode); return 1; }
+    if (o.min_chim && o.ml_mode && (a.has("N") || a.num("a", 0) > 0 || a.num("A", 0) > 0)) {
+        diag("Error: chimeric trimming '-c%d' together with '-r%d' and '-N' / '-a' / '-A' is not available in this build", o.min_chim, o.ml_mode);
+        return 1;
+    }
     // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
 
     o.snp.min_reads = a.num("p", 0);
@@ -599,6 +602,7 @@ struct AlignedSet {
     std::vector<bk_hit> hits;                      // one per read, load order
     std::vector<uint64_t> l_offs;                  // multi-loci modes: read i owns loci [l_offs[i], l_offs[i+1])
     std::vector<bk_loci> loci;
+    std::vector<bk_loci_trims> loci_trims;         // -c with the multi-loci modes: end trims of every locus (else empty)
     std::vector<bk_seg2> seg2;                     // -a / -A / -c: second segment of each read (flags 0 = none)
     std::vector<uint64_t> seq_counts;              // per sequence: reads the SE pass accepted, summed over the devices (RCCL when > 1)
 };
@@ -654,6 +658,13 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Rea
             const uint64_t base = A.loci.size();
             for (size_t i = 1; i <= n; i++) A.l_offs.push_back(base + bo[i]);
             A.loci.insert(A.loci.end(), bl, bl + nl);
+            if (o.P.min_chimeric_len) {
+                const bk_loci_trims *bt = nullptr;
+                uint64_t nt = 0;
+                rc = bk_stream_batch_loci_trims(s, b.ticket, &bt, &nt);
+                if (rc || (nl && (!bt || nt != nl))) { diag("Fatal: loci trims unavailable: %s", bk_strerror(rc)); return rc ? rc : BK_ERR_INTERNAL; }
+                A.loci_trims.insert(A.loci_trims.end(), bt, bt + nt);
+            }
         }
         if (segs || lists) bk_stream_release(s, b.ticket);
         return BK_OK;
@@ -681,11 +692,21 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Rea
 // CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424): what becomes of the reads that aligned to more than one
 // locus (-r1 statistics, -r2 random pick, -r3 / -r4 clustering, -r5 every locus its own record).  `src` maps the records of -r5 back
 // to their reads; `nr` is the record count afterwards.
-void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, std::vector<uint32_t> &src, std::vector<int> &multi_dist, size_t &nr)
+// `rec_trims` (with -c only): per record the end trims its placement carries - those of the locus chosen for it, or of the read's own
+// unique chimeric placement.
+void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, std::vector<uint32_t> &src, std::vector<int> &multi_dist, size_t &nr,
+                        std::vector<bk_loci_trims> &rec_trims)
 {
     std::vector<bk_hit> &hits = A.hits;
     const std::vector<uint64_t> &l_offs = A.l_offs;
     const std::vector<bk_loci> &loci = A.loci;
+    const bool with_trims = o.P.min_chimeric_len > 0;
+    auto trims_of = [&](uint64_t locus) -> bk_loci_trims { return locus < A.loci_trims.size() ? A.loci_trims[locus] : bk_loci_trims{}; };
+    if (with_trims) {
+        rec_trims.assign(nr, bk_loci_trims{});
+        for (size_t i = 0; i < nr && i < A.seg2.size(); i++)
+            if (A.seg2[i].flags & 8) { rec_trims[i].left = A.seg2[i].match_len; rec_trims[i].right = A.seg2[i].read_ofs; rec_trims[i].chimeric = 1; }
+    }
     // CAligner::ProcCoredApprox for MLMode != eMLdefault (Aligner.cpp:9241-9424); reads in load order, as -T1 runs them
     auto eff_count = [&](size_t i) -> uint32_t {            // LowHitInstances of a read that counts as eHRhits (after -X)
         const bk_hit &h = hits[i];
@@ -716,6 +737,7 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
             if (!c) continue;
             const uint32_t k = (uint32_t)pick.next() % c;
             take(hits[i], loci[l_offs[i] + k]);
+            if (with_trims) rec_trims[i] = trims_of(l_offs[i] + k);
         }
     } else if (o.ml_mode == 3 || o.ml_mode == 4) {
         uint32_t max_reads_len = 0;
@@ -723,12 +745,18 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
         bk::MultiAssign ma;
         for (size_t i = 0; i < nr; i++) {
             const uint32_t c = eff_count(i);
-            for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[l_offs[i] + k], c > 1);
+            for (uint32_t k = 0; k < c; k++) {
+                const bk_loci_trims t = with_trims ? trims_of(l_offs[i] + k) : bk_loci_trims{};
+                ma.add((uint32_t)i + 1, loci[l_offs[i] + k], c > 1, t.left, t.right, (uint32_t)(l_offs[i] + k));
+            }
         }
         diag("Assigning %llu reads which aligned to multiple loci to a single loci", (unsigned long long)n_multi);
         bk::MultiAssignStats st = ma.assign(o.ml_mode == 3, o.nthreads, max_reads_len);
         for (const bk::MultiHitRec &m : ma.recs)
-            if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
+            if (m.multi && m.assigned) {
+                take(hits[m.read_id - 1], m.loci);
+                if (with_trims) rec_trims[m.read_id - 1] = trims_of(m.src);
+            }
         diag("Clustering completed, removed %d unclustered orphans from %d putative resulting in %d (%d clustered near unique, %d clustered near other multiloci reads) multihit reads accepted as assigned",
              st.putative - st.assigned, st.putative, st.assigned, st.near_unique, st.near_multi);
     } else if (o.ml_mode == 5) {
@@ -736,6 +764,7 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
         // Aligner.cpp:6666-6800); with -M6 reads without alignment (eHRnone, eHRHitInsts) are kept as one unaligned
         // record, everything else (EN, MMDelta) drops out (:9311-9352,9441-9449)
         std::vector<bk_hit> recs;
+        std::vector<bk_loci_trims> rt;
         for (size_t i = 0; i < nr; i++) {
             const bk_hit &h = hits[i];
             const uint32_t c = eff_count(i);
@@ -745,6 +774,7 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
                     take(r, loci[l_offs[i] + k]);
                     recs.push_back(r);
                     src.push_back((uint32_t)i);
+                    if (with_trims) rt.push_back(trims_of(l_offs[i] + k));
                 }
             } else if (o.fmt == 6 && h.nar != BK_NAR_NS && (h.rslt == BK_HR_NONE || h.rslt == BK_HR_HITINSTS)) {
                 bk_hit r = h;
@@ -752,8 +782,10 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
                 r.low_mm = 0;
                 recs.push_back(r);
                 src.push_back((uint32_t)i);
+                if (with_trims) rt.push_back(bk_loci_trims{});
             }
         }
+        if (with_trims) rec_trims.swap(rt);
         diag("Treating accepted %llu multialigned reads as uniquely aligned %llu source reads in subsequent processing",
              (unsigned long long)n_multi, (unsigned long long)(n_loci - n_uniq));
         hits.swap(recs);
@@ -851,7 +883,8 @@ int cmd_align(int argc, char **argv, int first)
 
     std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
     std::vector<int> multi_dist((size_t)o.max_ml, 0);
-    if (o.ml_mode) resolve_multi_loci(o, rs, A, src, multi_dist, nr);
+    std::vector<bk_loci_trims> rec_trims;          // -c with -r: per record (after -r5's expansion) the trims of the placement it took
+    if (o.ml_mode) resolve_multi_loci(o, rs, A, src, multi_dist, nr, rec_trims);
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 5); };       // FlgInDel or FlgSplice
     if (o.pe_mode) {
@@ -867,7 +900,10 @@ int cmd_align(int argc, char **argv, int first)
     auto TR = [&](size_t i) -> uint32_t { return trims.empty() ? 0u : trims.right[i]; };
     auto a_start = [&](const bk_hit &h, size_t i) -> uint32_t { return h.match_loci + (h.strand == '+' ? TL(i) : TR(i)); };      // AdjStartLoci
     auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return (uint32_t)h.match_len - TL(i) - TR(i); };                     // AdjHitLen
-    auto is_chimeric = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 8); };     // FlgChimeric: trims come with the hit
+    auto is_chimeric = [&](size_t i) -> bool {                                                          // FlgChimeric: trims come with the hit
+        if (!rec_trims.empty()) return rec_trims[i].chimeric != 0;
+        return !seg2.empty() && (seg2[RD(i)].flags & 8);
+    };
     if (o.min_chim) {
         // chimeric placements keep the trims AdaptiveTrim found (ProcCoredApprox :9292-9299); the flank trimmer leaves them alone (:1641)
         if (trims.empty()) {
@@ -876,7 +912,11 @@ int cmd_align(int argc, char **argv, int first)
         }
         size_t n_ch = 0;
         for (size_t i = 0; i < nr; i++)
-            if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) { trims.left[i] = seg2[RD(i)].match_len; trims.right[i] = seg2[RD(i)].read_ofs; n_ch++; }
+            if (hits[i].nar == BK_NAR_ACCEPTED && is_chimeric(i)) {
+                trims.left[i] = rec_trims.empty() ? seg2[RD(i)].match_len : rec_trims[i].left;
+                trims.right[i] = rec_trims.empty() ? seg2[RD(i)].read_ofs : rec_trims[i].right;
+                n_ch++;
+            }
         diag("Of the accepted aligned reads, %zu were chimeric", n_ch);
     }
     // CAligner::SortHitMatch (Aligner.cpp:10069-10114), ties left to the replica of the reference's sort.  The comparator's fields are

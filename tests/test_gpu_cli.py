@@ -137,6 +137,21 @@ def test_align_pe_with_chimeric_trimming_sam_byte_identical(golden_tmp, tmp_path
         assert open(out, "rb").read() == golden_bytes("pechim", "U3c50.m0.csv.gz")
 
 
+@pytest.mark.parametrize("tag,flags,fmts", [
+    ("r1R5c50", ["-r1", "-R5", "-c50", "-s3", "-T4"], ["m6.sam"]), ("r2R5c50", ["-r2", "-R5", "-c50", "-s3", "-T1"], ["m6.sam"]),
+    ("r3R5c50", ["-r3", "-R5", "-c50", "-s3", "-T4"], ["m6.sam"]), ("r4R5c60", ["-r4", "-R5", "-c60", "-s3", "-T4"], ["m6.sam"]),
+    ("r5R5c50", ["-r5", "-R5", "-c50", "-s3", "-T1"], ["m6.sam", "m0.csv", "m4.bed"]), ("r5R3Xc50", ["-r5", "-R3", "-X", "-c50", "-s3", "-T1"], ["m6.sam"]),
+    ("r4R3Xc70s5", ["-r4", "-R3", "-X", "-c70", "-s5", "-T4"], ["m6.sam"]), ("r5R8c55e2", ["-r5", "-R8", "-c55", "-s3", "-e2", "-T1"], ["m0.csv"])])
+def test_align_chimeric_with_multi_loci_modes_byte_identical(golden_tmp, tmp_path, tag, flags, fmts):
+    """`-c` together with `-r1..5`: the chimeric call lists up to -R loci, each with its own soft clips; the random pick, the clustering
+    (on trimmed loci) and the one-record-per-locus mode on top - the reference's files"""
+    d = golden_tmp["chimml"]
+    for ext in fmts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M" + ext[1]] + flags, str(tmp_path))
+        assert open(out, "rb").read() == golden_bytes("chimml", f"{tag}.{ext}.gz"), ext
+
+
 @pytest.mark.parametrize("fixture,name,flags", [
     ("basic", "s3.m6.bam", ["-M6", "-s3"]), ("basic", "s3.m5.bam", ["-M5", "-s3"]),
     ("pe", "U3.m6.bam", ["-M6", "-s5", "-U3", "-d200", "-D400"])])
