@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_pair_batch_seg2", "bk_pair_batch_seg2_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
-    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims",
+    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device",
 ]
 
 
@@ -198,6 +198,8 @@ def load_library():
     lib.bk_stream_submit.restype = i32
     lib.bk_stream_submit_packed.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, ctypes.POINTER(u64)]
     lib.bk_stream_submit_packed.restype = i32
+    lib.bk_stream_submit_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, ctypes.POINTER(u64)]
+    lib.bk_stream_submit_device.restype = i32
     lib.bk_packed_words.argtypes = [vp, u32]
     lib.bk_packed_words.restype = u64
     lib.bk_pack_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, u64, ctypes.POINTER(u64)]
@@ -591,6 +593,15 @@ class Stream:
         if rc:
             raise BkError(rc, "bk_stream_submit_packed")
         self._keep[t.value] = (words, lens16, exc, out)
+        return t.value
+
+    def submit_device(self, d_bases, d_offs, d_lens, nreads, d_hits, producer_stream=None):
+        """device pointers (ints) of buffers in HBM; returns at once - the batch is aligned after everything enqueued so far on
+        producer_stream (a hipStream_t as int, None = the default stream); results are in d_hits when wait(ticket) has returned"""
+        t = ctypes.c_uint64()
+        rc = self.lib.bk_stream_submit_device(self.h, d_bases, d_offs, d_lens, nreads, d_hits, producer_stream, ctypes.byref(t))
+        if rc:
+            raise BkError(rc, "bk_stream_submit_device")
         return t.value
 
     def wait(self, ticket):

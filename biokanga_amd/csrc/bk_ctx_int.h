@@ -92,6 +92,7 @@ struct bk_ctx {
     // heavy path scratch
     bk::HeavyScratch hs{};
     int max_read_len = 500;
+    uint32_t last_maxlen = 0;    // longest read of the last align call
     bool debug = false;      // BK_DEBUG in the environment when the context was created: per-phase counts on stderr
     uint32_t chunk_reads = 64u << 20;
     // staging for host-buffer batches

@@ -918,6 +918,7 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
         maxlen = c->h_small[5];
     }
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+    c->last_maxlen = maxlen;
     if ((int)maxlen > c->max_read_len) {
         c->max_read_len = (int)maxlen;
     }

@@ -67,6 +67,15 @@ struct Job {
     uint64_t n_exc = 0;
     uint32_t n = 0;
     bk_hit *out = nullptr;
+    // device-resident form (bk_stream_submit_device): the caller's buffers in HBM, results written where they say; ev_in = the point
+    // of the caller's stream the buffers are ready at
+    bool dev = false;
+    const uint8_t *d_bases = nullptr;
+    const uint64_t *d_offs = nullptr;
+    const uint32_t *d_lens = nullptr;
+    bk_hit *d_out = nullptr;
+    hipEvent_t ev_in = nullptr;
+    ~Job() { if (ev_in) (void)hipEventDestroy(ev_in); }
     int slot = 0;
     int rc = BK_OK;
     bool done = false;
@@ -143,6 +152,7 @@ struct bk_stream {
         while (Job *j = pop(q_up)) {
             Slot &sl = slots[j->slot];
             hipError_t e = hipSuccess;
+            if (j->dev) { push(q_al, j); continue; }          // nothing to upload: the batch keeps its place in the queue
             if (j->n && j->lens16) {
                 // packed batch: 2 bit/base words, 16-bit lengths, the few bases that are not a,c,g,t
                 const size_t wb = (size_t)j->n_words * 4;
@@ -183,6 +193,28 @@ struct bk_stream {
             const double t_got = now_s();
             double t_prep = t_got;
             Slot &sl = slots[j->slot];
+            if (j->dev) {
+                if (j->rc == BK_OK && j->n) {
+                    hipError_t e = hipStreamWaitEvent(s_al, j->ev_in, 0);          // the caller's kernels that fill the buffers come first
+                    bk::DevReads in;
+                    in.bases = j->d_bases; in.offs = j->d_offs; in.lens = j->d_lens;
+                    int rc = e == hipSuccess ? bk::engine_align_device(ctx, in, j->n, j->d_out, s_al, 0) : rc_of(e);
+                    if (rc == BK_OK && has_pe) {
+                        // (the longest read of the batch: the SE pass has just measured it)
+                        rc = bk::engine_pair_device(ctx, in, j->n / 2, j->d_out, (uint32_t)ctx->last_maxlen, &pe, s_al, ctx->seg2.empty() ? nullptr : ctx->seg2.data());
+                    }
+                    if (rc) fail(j, rc);
+                    else if (list_modes) {
+                        j->loci_offs.swap(ctx->loci_offs);
+                        j->loci.swap(ctx->loci);
+                        j->loci_trims.swap(ctx->loci_trims);
+                        j->seg2.swap(ctx->seg2);
+                    }
+                }
+                push(q_dn, j);
+                t_free = now_s();
+                continue;
+            }
             if (j->rc == BK_OK && j->n && j->lens16) {
                 hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
                 uint32_t maxlen = 0;
@@ -254,7 +286,9 @@ struct bk_stream {
         (void)hipSetDevice(ctx->device);
         while (Job *j = pop(q_dn)) {
             Slot &sl = slots[j->slot];
-            if (j->rc == BK_OK && j->n) {
+            if (j->dev) {
+                // results were written where the caller said and the aligner thread has waited for its last kernel
+            } else if (j->rc == BK_OK && j->n) {
                 hipError_t e = hipStreamWaitEvent(s_dn, sl.ev_al, 0);
                 if (e == hipSuccess) e = hipMemcpyAsync(j->out, sl.d_out, (size_t)j->n * sizeof(bk_hit), hipMemcpyDeviceToHost, s_dn);
                 if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
@@ -273,8 +307,8 @@ struct bk_stream {
                 n_done++;
                 stats.batches++;
                 stats.reads += j->n;
-                stats.bytes_h2d += j->lens16 ? j->n_words * 4 + (uint64_t)j->n * 2 + j->n_exc * sizeof(bk_nbase) : j->nbases + (uint64_t)j->n * (j->offs ? 12 : 4);
-                stats.bytes_d2h += (uint64_t)j->n * sizeof(bk_hit);
+                if (!j->dev) stats.bytes_h2d += j->lens16 ? j->n_words * 4 + (uint64_t)j->n * 2 + j->n_exc * sizeof(bk_nbase) : j->nbases + (uint64_t)j->n * (j->offs ? 12 : 4);
+                if (!j->dev) stats.bytes_d2h += (uint64_t)j->n * sizeof(bk_hit);
                 stats.seconds_first_submit_to_last_result = t_last_done - t_first_submit;
             }
             cv.notify_all();
@@ -390,6 +424,34 @@ int bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const 
         j->slot = (int)((j->ticket - 1) % (uint64_t)s->depth);
         j->t_submit = now_s();
         if (!s->span_open) { s->t_first_submit = j->t_submit; s->span_open = true; }      // T_align: first batch submitted -> last result back
+        s->jobs[j->ticket] = j;
+        s->q_up.push_back(j);
+    }
+    s->cv.notify_all();
+    *ticket = j->ticket;
+    return BK_OK;
+}
+
+int bk_stream_submit_device(bk_stream *s, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t nreads, void *d_hits,
+                            void *producer_stream, uint64_t *ticket)
+{
+    if (!s || !ticket || (nreads && (!d_bases || !d_offs || !d_lens || !d_hits))) return BK_ERR_PARAMS;
+    if (s->has_pe && (nreads & 1)) return BK_ERR_PARAMS;
+    Job *j = new Job();
+    j->dev = true;
+    j->d_bases = (const uint8_t *)d_bases; j->d_offs = (const uint64_t *)d_offs; j->d_lens = (const uint32_t *)d_lens; j->d_out = (bk_hit *)d_hits;
+    j->n = nreads;
+    hipError_t e = hipSetDevice(s->ctx->device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(j->ev_in, (hipStream_t)producer_stream);
+    if (e != hipSuccess) { delete j; return BK_ERR_INTERNAL; }
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->next_ticket - 1 - s->n_done < (uint64_t)s->depth; });     // at most `depth` batches in flight
+        j->ticket = s->next_ticket++;
+        j->slot = (int)((j->ticket - 1) % (uint64_t)s->depth);
+        j->t_submit = now_s();
+        if (!s->span_open) { s->t_first_submit = j->t_submit; s->span_open = true; }
         s->jobs[j->ticket] = j;
         s->q_up.push_back(j);
     }

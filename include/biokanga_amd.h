@@ -321,6 +321,14 @@ int  bk_stream_submit_packed(bk_stream *s, const uint32_t *words, uint64_t n_wor
                              const bk_nbase *exc, uint64_t n_exc, bk_hit *out, uint64_t *ticket);
 /* blocks until the results of that batch are in its `out`; returns the batch's result code (each ticket once, unless the
  * context runs a list mode - then bk_stream_batch_loci / _seg2 stay available until bk_stream_release) */
+/* Device-resident, asynchronous form of bk_align_batch_device (+ bk_pair_batch_device on a pipeline with pe): reads and result
+ * buffer already in HBM on the context's GPU.  The call records a point on `producer_stream` (a hipStream_t, NULL = the default stream)
+ * and returns; the batch is aligned, in submission order with the pipeline's other batches, once everything enqueued on that stream
+ * before the call has run - the caller's thread never waits for the phase loop (CAligner's loader || workers overlap, Aligner.cpp:4820-4860,
+ * for a producer that is itself device code).  d_hits is complete, visible to every stream, when bk_stream_wait(ticket) has returned; the
+ * buffers must stay untouched until then.  No size limit other than the context's own. */
+int  bk_stream_submit_device(bk_stream *s, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t nreads, void *d_hits,
+                             void *producer_stream, uint64_t *ticket);
 int  bk_stream_wait(bk_stream *s, uint64_t ticket);
 int  bk_stream_batch_loci(bk_stream *s, uint64_t ticket, const uint64_t **offs, const bk_loci **loci, uint64_t *n_loci);
 int  bk_stream_batch_seg2(bk_stream *s, uint64_t ticket, const bk_seg2 **seg2, uint64_t *n);

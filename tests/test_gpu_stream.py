@@ -190,6 +190,60 @@ def test_stream_paired_ends_with_chimeric_trimming(golden_tmp, tmp_path, packed)
     check_pechim_against_sam(names, out, seg, "U3c50")
 
 
+@pytest.mark.parametrize("fixture,pe_tag", [("basic", None), ("pe", "U3")])
+def test_stream_submit_device_is_asynchronous_and_ordered_behind_the_producer(golden_tmp, tmp_path, fixture, pe_tag):
+    """bk_stream_submit_device: buffers in HBM, the call returns before the batch has been aligned and the batch runs after the work the
+    caller had enqueued on its stream - here the copies that FILL the read buffers, issued on a side stream right before the submit
+    (submitted with the buffers still holding rubbish, the results must be those of the real reads)"""
+    import torch
+    bk = _bk()
+    if pe_tag:
+        from test_oracle_pe import pe_cfg, pe_inputs
+        cfg = pe_cfg(fixture, pe_tag)
+        names, bases, offs, lens = pe_inputs(tmp_path, fixture)
+        sfx, kw = os.path.join(golden_tmp["basic"], "genome.sfx"), dict(max_subs=cfg["s"])
+        pe = bk.PEParams(cfg["pe"], cfg["d"], cfg["D"], cfg.get("E", False))
+    else:
+        d, names, bases, offs, lens, keep = load_fixture(golden_tmp, fixture, "s3")
+        offs, lens = offs[keep], lens[keep]
+        sfx, kw, pe = os.path.join(d, "genome.sfx"), dict(max_subs=3), None
+    n = len(lens)
+    dev = torch.device("cuda", 0)
+    with bk.Aligner(sfx, bk.AlignParams(**kw)) as al:
+        ref = al.align(bases, offs, lens)
+        if pe:
+            ref = al.pair(bases, offs, lens, ref, pe)
+        h_b = torch.from_numpy(np.ascontiguousarray(bases)).pin_memory()
+        h_o = torch.from_numpy(offs.astype(np.int64)).pin_memory()
+        h_l = torch.from_numpy(lens.astype(np.int32)).pin_memory()
+        d_b = torch.full((len(bases),), 9, dtype=torch.uint8, device=dev)
+        d_o = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_l = torch.full((n,), 17, dtype=torch.int32, device=dev)
+        outs = [torch.zeros(n * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(3)]
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        with bk.Stream(al, max(n, 2), int(lens.sum()) + 16, depth=3, pe=pe) as st:
+            with torch.cuda.stream(side):
+                d_b.copy_(h_b, non_blocking=True)
+                d_o.copy_(h_o, non_blocking=True)
+                d_l.copy_(h_l, non_blocking=True)
+            tk = [st.submit_device(d_b.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), n, o.data_ptr(), side.cuda_stream) for o in outs]
+            h_mixed = np.zeros(n, bk.HIT_DTYPE)                            # a host-form batch between device-form ones keeps its place
+            cb = _contiguous(bases, offs, lens)
+            tk_h = st.submit(cb.copy(), None, lens.copy(), h_mixed)
+            for t in tk:
+                st.wait(t)
+            st.wait(tk_h)
+            with pytest.raises(bk.BkError):
+                st.submit_device(0, d_o.data_ptr(), d_l.data_ptr(), n, outs[0].data_ptr(), None)
+    for o in outs:
+        got = o.cpu().numpy().view(bk.HIT_DTYPE)
+        for f in FIELDS + ["flags"]:
+            assert np.array_equal(got[f], ref[f]), f
+    for f in FIELDS + ["flags"]:
+        assert np.array_equal(h_mixed[f], ref[f]), f
+
+
 def test_seq_counts_allreduce_over_contexts(golden_tmp):
     """the exchange step: two contexts, each fed half of the reads, reduce to the counts of one context fed all of them"""
     bk = _bk()
