@@ -92,11 +92,14 @@ def random_params(rng):
     mode = int(rng.integers(0, 4))
     if mode == 1:
         kw.update(max_ml=int(rng.choice([2, 3, 5, 20, 500])), clamp_ml=int(rng.integers(0, 2)))
-        if rng.integers(0, 3) == 0:                      # -r1..-r4 take -a / -A too
+        pick = int(rng.integers(0, 4))
+        if pick == 0:                                    # -r1..-r4 take -a / -A too
             if rng.integers(0, 2):
                 kw["micro_indel_len"] = int(rng.integers(1, 21))
             else:
                 kw["splice_junct_len"] = int(rng.choice([25, 100, 2000, 6000]))
+        elif pick == 1:                                  # .. and -c: the chimeric call lists its loci, each with its trims
+            kw["min_chimeric_len"] = int(rng.integers(50, 100))
     elif mode == 2:
         kw.update(max_ml=int(rng.choice([2, 5, 50])), best_matches=1)
     elif mode == 3:
@@ -140,21 +143,44 @@ def main():
     for it in range(rounds):
         if rng.integers(0, 5) == 0:                      # a paired-end round: SE pass, then the association on both sides
             kw = dict(max_subs=int(rng.choice([1, 3, 5, 8])), min_edit_dist=int(rng.integers(1, 3)), pmode=int(rng.integers(0, 4)))
-            L = int(rng.choice([50, 100, 150, 250]))
+            if rng.integers(0, 3) == 0:
+                kw["min_chimeric_len"] = int(rng.integers(50, 100))       # -c with -U: trims into and out of the association
+            L = int(rng.choice([50, 100, 150, 250, 300, 450]))
             bases, offs, lens = make_pairs(rng, seq_h, nreads // 2, L)
             pe = dict(pe_mode=int(rng.integers(1, 5)), pair_min_len=int(rng.choice([100, 200])), pair_max_len=int(rng.choice([400, 1000, 5000])),
                       pair_strand=int(rng.integers(0, 6) == 0))
             al.set_params(bk.AlignParams(**kw))
             al.tune("chunk_reads", 64 << 20); al.tune("use_wave", 1); al.tune("use_flat", 1)
+            if pe["pair_min_len"] < L:
+                pe["pair_min_len"] = L
+            if pe["pair_max_len"] < pe["pair_min_len"] + 100:
+                pe["pair_max_len"] = pe["pair_min_len"] + 300
+            if kw.get("min_chimeric_len"):                   # a third of the mates get a foreign end
+                for i in rng.choice(len(lens), len(lens) // 3, replace=False):
+                    k = int(rng.integers(5, L // 2))
+                    o = int(offs[i])
+                    if rng.integers(0, 2):
+                        bases[o:o + k] = rng.integers(0, 4, k, dtype=np.uint8)
+                    else:
+                        bases[o + L - k:o + L] = rng.integers(0, 4, k, dtype=np.uint8)
             got = al.align(bases, offs, lens)
             p = helpers.make_params(**kw)
-            exp, _ = ora.align(bases, offs, lens, p, nthreads=os.cpu_count())
+            exp, eseg = helpers.oracle_align_indel(ora, bases, offs, lens, p, nthreads=os.cpu_count())
             bad = None
             for f in FIELDS:
                 if not np.array_equal(got[f], exp[f]):
                     bad = "SE pass " + f
-            gp = al.pair(bases, offs, lens, got.copy(), bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"])))
-            ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy())
+            pep = bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]))
+            if kw.get("min_chimeric_len"):
+                gp, gseg = al.pair(bases, offs, lens, got.copy(), pep, seg2=al.batch_seg2())
+                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy(), eseg)
+                for f in SEG:
+                    if not bad and not np.array_equal(gseg[f], eseg[f]):
+                        i = int(np.nonzero(gseg[f] != eseg[f])[0][0])
+                        bad = f"PE seg2.{f} at read {i}: gpu {gseg[i]} {gp[i]} oracle {eseg[i]} {ep[i]}"
+            else:
+                gp = al.pair(bases, offs, lens, got.copy(), pep)
+                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy())
             for f in [x for x in FIELDS if x != "rslt"]:
                 if not np.array_equal(gp[f], ep[f]):
                     i = int(np.nonzero(gp[f] != ep[f])[0][0])
@@ -168,19 +194,29 @@ def main():
                 sys.exit(1)
             continue
         kw = random_params(rng)
-        max_len = 500 if kw.get("min_chimeric_len") else int(rng.choice([100, 150, 256, 400]))
+        max_len = int(rng.choice([300, 500, 600])) if kw.get("min_chimeric_len") else int(rng.choice([100, 150, 256, 320, 400, 512, 700]))
         bases, offs, lens = make_reads(rng, seq_h, nreads, max_len)
         p = helpers.make_params(**kw)
         al.set_params(bk.AlignParams(**kw))
         for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)), ("use_flat", int(rng.integers(0, 4) != 0))):
             al.tune(knob, val)
-        got = al.align(bases, offs, lens)
+        packed = bool(rng.integers(0, 2))                # the same reads across the boundary at 2 bit/base
+        got = al.align_packed(*bk.pack_reads(bases, offs, lens)) if packed else al.align(bases, offs, lens)
+        kw = dict(kw, packed=packed)
         bad = None
         if kw.get("max_ml", 1) > 1:
-            exp, eo, el, eseg = helpers.oracle_align_multi_indel(ora, bases, offs, lens, p, nthreads=os.cpu_count())
+            exp, eo, el, etr, eseg = helpers.oracle_align_multi_chimeric(ora, bases, offs, lens, p, nthreads=os.cpu_count())
             lo, loci = al.batch_loci(len(lens))
             if not np.array_equal(lo, eo) or any(not np.array_equal(loci[f], el[f]) for f in LOCI):
                 bad = "loci lists"
+            if kw.get("min_chimeric_len"):
+                tr = al.batch_loci_trims()
+                if len(tr) != len(etr) or any(not np.array_equal(tr[f], etr[f]) for f in ("left", "right", "chimeric")):
+                    bad = "loci trims"
+                seg = al.batch_seg2()
+                for f in SEG:
+                    if not np.array_equal(seg[f], eseg[f]):
+                        bad = f"seg2.{f} (multi-loci run with -c)"
             if kw.get("micro_indel_len") or kw.get("splice_junct_len"):
                 seg = al.batch_seg2()
                 for f in SEG:
