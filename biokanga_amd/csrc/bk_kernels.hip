@@ -1858,21 +1858,11 @@ __device__ __forceinline__ void eval_window2i(const uint64_t (&r2w)[NW / 2], con
 
 // eval_window2i with the window taken from the candidate's entry of the suffix-ordered window array (DevIndex::swin): the three
 // 16-byte words of entry `e`; the window starts bofs = kSwPre - (core offset) bases into it - the same for every lane of the wave.
+// the compare of eval_swin2i once the five words the window starts in are known
 template <int NW>
-__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 (&e)[3],
-                                            int bofs, IWindow<NW> &w)
+__device__ __forceinline__ void swin2i_compare(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint64_t (&q)[5], unsigned s,
+                                               IWindow<NW> &w)
 {
-    uint64_t r[6], q[5];                                       // (reads of up to kSwLen <= 128 bases: four compare words at most)
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const uint4 v = e[i];
-        r[2 * i] = ((uint64_t)v.y << 32) | v.x;
-        r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
-    }
-    const int w0 = bofs >> 5;                                  // 0..2
-    const unsigned s = (unsigned)(bofs & 31) << 1;
-#pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = w0 == 0 ? r[i] : (w0 == 1 ? r[i + 1] : (i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL));
     int mm = 0;
     uint64_t even = 0;
 #pragma unroll
@@ -1895,6 +1885,45 @@ __device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const
     }
     w.mm = mm;
     w.eos = false;
+}
+
+// UNIFORM: bofs is the same for every lane of the wave (one core per round) - the choice of the starting word is then a branch the scalar
+// unit takes instead of ten selects per lane
+template <int NW, bool UNIFORM>
+__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 (&e)[3],
+                                            int bofs, IWindow<NW> &w)
+{
+    uint64_t r[6], q[5];                                       // (reads of up to kSwLen <= 128 bases: four compare words at most)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const uint4 v = e[i];
+        r[2 * i] = ((uint64_t)v.y << 32) | v.x;
+        r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
+    }
+    if (UNIFORM) {
+        const int ub = __builtin_amdgcn_readfirstlane(bofs);
+        const int w0 = ub >> 5;
+        const unsigned s = (unsigned)(ub & 31) << 1;
+        if (w0 == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) q[i] = r[i];
+            swin2i_compare<NW>(r2w, rni, len, q, s, w);
+        } else if (w0 == 1) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) q[i] = r[i + 1];
+            swin2i_compare<NW>(r2w, rni, len, q, s, w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; i++) q[i] = i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL;
+            swin2i_compare<NW>(r2w, rni, len, q, s, w);
+        }
+        return;
+    }
+    const int w0 = bofs >> 5;                                  // 0..2
+    const unsigned s = (unsigned)(bofs & 31) << 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = w0 == 0 ? r[i] : (w0 == 1 ? r[i + 1] : (i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL));
+    swin2i_compare<NW>(r2w, rni, len, q, s, w);
 }
 
 // entry i of the suffix-ordered window array: kSwBases bases of the 2-bit target from sa[i] - kSwPre on (bases before the target's
@@ -2745,8 +2774,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         const uint32_t item = grab_next++;
         grab_left--;
         if (item >= n_list) break;
-        const uint32_t r = list[item];
-        const uint32_t meta = b.rmeta[r];
+        // (wave-uniform values that arrive through vector loads are handed to the scalar unit explicitly: the read's plan, its loop
+        // bounds and the window geometry then cost scalar instructions once instead of vector instructions in every lane)
+        const uint32_t r = __builtin_amdgcn_readfirstlane(list[item]);
+        const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
         const int len = (int)(meta & kReadLenMask);
         const bool has_n = (meta & kReadHasN) != 0;
         ReadPlan p = make_plan(len, cfg);
@@ -2841,10 +2872,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             }
             uint32_t nodes = 0;
             for (int c = 0; c < nc && !done && nodes < kNodeCap;) {
-                const uint64_t first = core[c].first;
-                const bool lazy = (core[c].n & kLazyFlag) != 0;
-                const uint64_t n = core[c].n & ~kLazyFlag;
-                const int ofs = core[c].ofs;
+                // (every lane reads the same LDS words: told so, the compiler keeps them and what follows from them in scalar registers)
+                const uint64_t first = uniform64(core[c].first);
+                const uint32_t cn_c = __builtin_amdgcn_readfirstlane(core[c].n);
+                const bool lazy = (cn_c & kLazyFlag) != 0;
+                const uint64_t n = cn_c & ~kLazyFlag;
+                const int ofs = __builtin_amdgcn_readfirstlane(core[c].ofs);
                 // the cores of this step: c alone (a long interval, 64 suffixes a round), or c .. ce - 1 in one round
                 int ce = c + 1;
                 uint32_t gtot = (uint32_t)(n > 64 ? 65 : n);
@@ -2897,7 +2930,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         if (two_bit) {
                             const bool flg = window_flagged_t<WIDE>(ix, t, len);
                             if (SW && sw_read) {
-                                if constexpr (SW) eval_swin2i<NW>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                if constexpr (SW) eval_swin2i<NW, !GROUP>(r2w, rni, len, ev, kSwPre - lofs, w);
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
                             if (flg) {
@@ -2999,13 +3032,16 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     acc = acc && ((keep >> lane) & 1);
                     uint64_t accmask = __ballot(acc);
                     if (accmask) {
-                        int v = acc ? cm : 127;
-                        int bmin = v;
-                        for (int off = 32; off > 0; off >>= 1) { int q = __shfl_xor(bmin, off); bmin = q < bmin ? q : bmin; }
-                        int v2 = (acc && cm > bmin) ? cm : 127;
-                        int bsec = v2;
-                        for (int off = 32; off > 0; off >>= 1) { int q = __shfl_xor(bsec, off); bsec = q < bsec ? q : bsec; }
-                        uint64_t minmask = __ballot(acc && cm == bmin);
+                        // smallest and second smallest count among the accepted lanes: the counts are at most mm, so one ballot per
+                        // value (scalar work) instead of two butterfly reductions through the LDS crossbar
+                        int bmin = 127, bsec = 127;
+                        uint64_t minmask = 0;
+                        for (int m = 0; m <= mm; m++) {
+                            const uint64_t bm = __ballot(acc && cm == m);
+                            if (!bm) continue;
+                            if (bmin == 127) { bmin = m; minmask = bm; }
+                            else { bsec = m; break; }
+                        }
                         int cnt = __popcll(minmask);
                         int fl = __ffsll((unsigned long long)minmask) - 1;
                         if (bmin < low_mm) {
