@@ -562,6 +562,7 @@ def main():
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
     ap.add_argument("--force-device", type=int, default=-1, help="dry runs: put every rank on this GPU instead of LOCAL_RANK")
+    ap.add_argument("--force-el5", action="store_true", help="experiments: 5-byte suffix elements (the > 4 Gbp kernels) on a smaller genome")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
     ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
@@ -629,7 +630,7 @@ def main():
     torch.cuda.synchronize()
     log(f"genome: {n} concatenated bases, {len(seq_lens)} sequences, generated in {time.time() - t0:.1f}s")
     t0 = time.time()
-    E = 5 if n >= 0xFFFFFFFF else 4            # SfxElSize, as `biokanga index` picks it
+    E = 5 if (n >= 0xFFFFFFFF or args.force_el5) else 4            # SfxElSize, as `biokanga index` picks it
     sa = torch.empty(n * (5 if E == 5 else 4), dtype=torch.uint8, device=dev) if E == 5 else torch.empty(n, dtype=torch.int32, device=dev)
     bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), E, local_rank)
     torch.cuda.synchronize()

@@ -1887,6 +1887,45 @@ __device__ __forceinline__ void swin2i_compare(const uint64_t (&r2w)[NW / 2], co
     w.eos = false;
 }
 
+// The same compare in 16-base dwords for a window start that is the same in every lane: window dword w is one funnel shift
+// (v_alignbit_b32) of entry dwords D2 + w and D2 + w + 1, whose registers are known at compile time once the scalar unit has branched
+// on D2; five vector instructions per 16 bases and six per 64-base map word instead of the 64-bit shifts, selects and splits above.
+template <int NW, int D2>
+__device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint32_t (&S)[13], unsigned sh,
+                                                 IWindow<NW> &w)
+{
+    static_assert(kSwPre / 16 + kSwLen / 16 + 2 <= 13 && D2 >= -1 && D2 <= kSwPre / 16, "window dwords stay inside the entry");
+    int mm = 0;
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        uint32_t y[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            constexpr int kDwords = (kSwLen + 15) / 16;
+            const int wd = 4 * i + d;
+            y[d] = 0;
+            if (wd < kDwords && 16 * wd < len) {
+                const uint32_t hi = D2 + wd >= 0 ? S[D2 + wd >= 0 ? D2 + wd : 0] : 0u;
+                const uint32_t lo = S[D2 + wd + 1 <= 12 ? D2 + wd + 1 : 12];
+                const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, sh);
+                const uint32_t rw = (wd & 1) ? (uint32_t)r2w[wd >> 1] : (uint32_t)(r2w[wd >> 1] >> 32);
+                const uint32_t x = rw ^ win;
+                uint32_t yy = (x | (x >> 1)) & 0x55555555u;                 // base j of the dword: bit 30 - 2j
+                const int rem = len - 16 * wd;
+                if (rem < 16) yy &= ~0u << (32 - 2 * rem);
+                y[d] = yy;
+            }
+        }
+        // the map word of these 64 bases: base j < 32 at bit 62 - 2j, base 32 + j at bit 63 - 2j
+        const uint32_t mhi = y[0] | (y[2] << 1), mlo = y[1] | (y[3] << 1);
+        const uint64_t m = (((uint64_t)mhi << 32) | mlo) | rni[i];
+        w.im[i] = m;
+        mm += __popcll(m);
+    }
+    w.mm = mm;
+    w.eos = false;
+}
+
 // UNIFORM: bofs is the same for every lane of the wave (one core per round) - the choice of the starting word is then a branch the scalar
 // unit takes instead of ten selects per lane
 template <int NW, bool UNIFORM>
@@ -1901,21 +1940,20 @@ __device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const
         r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
     }
     if (UNIFORM) {
+        // the entry as thirteen 16-base dwords in base order (the 64-bit words hold their first base in the top bits)
+        const uint32_t S[13] = {e[0].y, e[0].x, e[0].w, e[0].z, e[1].y, e[1].x, e[1].w, e[1].z, e[2].y, e[2].x, e[2].w, e[2].z, 0u};
         const int ub = __builtin_amdgcn_readfirstlane(bofs);
-        const int w0 = ub >> 5;
-        const unsigned s = (unsigned)(ub & 31) << 1;
-        if (w0 == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) q[i] = r[i];
-            swin2i_compare<NW>(r2w, rni, len, q, s, w);
-        } else if (w0 == 1) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) q[i] = r[i + 1];
-            swin2i_compare<NW>(r2w, rni, len, q, s, w);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 5; i++) q[i] = i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL;
-            swin2i_compare<NW>(r2w, rni, len, q, s, w);
+        const int rb = (ub & 15) << 1;
+        const unsigned sh = (unsigned)(32 - rb) & 31u;
+        const int d2 = (ub >> 4) - (rb ? 0 : 1);                  // -1 .. 5 (bofs <= kSwPre)
+        switch (d2) {
+        case -1: swin2i_compare32<NW, -1>(r2w, rni, len, S, sh, w); break;
+        case 0: swin2i_compare32<NW, 0>(r2w, rni, len, S, sh, w); break;
+        case 1: swin2i_compare32<NW, 1>(r2w, rni, len, S, sh, w); break;
+        case 2: swin2i_compare32<NW, 2>(r2w, rni, len, S, sh, w); break;
+        case 3: swin2i_compare32<NW, 3>(r2w, rni, len, S, sh, w); break;
+        case 4: swin2i_compare32<NW, 4>(r2w, rni, len, S, sh, w); break;
+        default: swin2i_compare32<NW, 5>(r2w, rni, len, S, sh, w); break;
         }
         return;
     }
