@@ -763,7 +763,9 @@ def main():
     }
     for k in kern.values():
         k["GBs"] = k["bytes"] / max(1e-9, k["ms"] * 1e-3) / 1e9
-    dom = max(kern, key=lambda k: kern[k]["ms"])
+    # (the search stage is two kernels - pass A about 0.52 and pass B 0.41 of it under rocprofv3, profiles/ - so it only counts as the
+    # dominant KERNEL when 0.6 of it outlasts the others)
+    dom = max(kern, key=lambda k: kern[k]["ms"] * (0.6 if k == "k_search" else 1.0))
     ach = kern[dom]["GBs"]
     whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
     default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)

@@ -617,22 +617,38 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Rea
     A.hits.resize(nr);
     const bool lists = o.ml_mode != 0, segs = o.P.micro_indel_len || o.P.splice_junct_len || o.P.min_chimeric_len;
     if (lists) A.l_offs.assign(1, 0);
-    size_t per = 8u << 20;                                                          // reads per batch
-    if (nr / ndev / 2 + 1 < per) per = std::max<size_t>(65536, nr / ndev / 2 + 1);   // at least two batches per device: overlap
+    // Reads per batch.  A batch costs less per read the larger it is (every phase's wave-per-read launch lasts at least as long as its
+    // heaviest read: 3 M reads take 3.7 ns each, 12 M 2.2 ns, 50 M 1.8 ns), but nothing overlaps the upload of a device's first batch:
+    // each device's batches grow by a factor of three from 4 M reads up to 32 M (an upload is about as fast as the alignment of the
+    // same reads at 1 byte per base, so it still hides behind the batch before it).  Small inputs: two batches per device.
+    size_t per = 32u << 20;
+    const bool ramp = nr / ndev >= (12u << 20);
+    if (!ramp) {
+        per = 8u << 20;
+        if (nr / ndev / 2 + 1 < per) per = std::max<size_t>(65536, nr / ndev / 2 + 1);
+    }
     per += per & 1;
     struct Batch { size_t lo, hi; uint64_t b0, b1, ticket; };
     std::vector<Batch> batches;
     uint64_t max_bases = 1;
-    for (size_t lo = 0; lo < nr; lo += per) {
-        Batch b{lo, std::min(nr, lo + per), rs.offs[lo], 0, 0};
+    size_t max_reads = 1;
+    for (size_t lo = 0, k = 0; lo < nr; k++) {
+        size_t n = per;
+        if (ramp) {
+            const size_t round = k / ndev;                                           // this device's round-th batch
+            n = round == 0 ? (4u << 20) : (round == 1 ? (12u << 20) : per);
+        }
+        Batch b{lo, std::min(nr, lo + n), rs.offs[lo], 0, 0};
         b.b1 = rs.offs[b.hi - 1] + rs.lens[b.hi - 1];
         max_bases = std::max(max_bases, b.b1 - b.b0);
+        max_reads = std::max(max_reads, b.hi - b.lo);
         batches.push_back(b);
+        lo = b.hi;
     }
     std::vector<bk_stream *> st(ndev, nullptr);
     auto close = [&]() { for (bk_stream *s : st) bk_stream_destroy(s); };
     for (size_t d = 0; d < ndev; d++) {
-        int rc = bk_stream_create(&st[d], ctxs[d], (uint32_t)std::min(per, std::max<size_t>(nr, 1)), max_bases, 3, o.pe_mode ? &o.PE : nullptr);
+        int rc = bk_stream_create(&st[d], ctxs[d], (uint32_t)max_reads, max_bases, 3, o.pe_mode ? &o.PE : nullptr);
         if (rc) { diag("Fatal: unable to set up the device pipeline: %s", bk_strerror(rc)); close(); return rc; }
     }
     // the read store keeps reads back to back in load order, so a batch is one span of bases and the offsets are rebuilt on the device
