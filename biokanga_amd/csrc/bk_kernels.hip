@@ -792,27 +792,22 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
             num_ns = (int)((pre >> 16) & 0x7FFFu);
             bad = (pre >> 31) != 0;
         } else {
+            // forward rows from the bytes; the reverse complement rows come from them by bit work (revcomp2) unless the read has an N
+            // or the batch keeps 4-bit rows for every read - then the bytes are walked a second time from the other end
             const uint8_t *s = b.bases + b.offs[r];
 #pragma unroll
             for (int w = 0; w < NW; w++) {
                 const int base0 = 16 * w;
-                uint64_t f = 0, v = 0;
+                uint64_t f = 0;
                 if (base0 + 16 <= len) {
                     Bytes16 q = *reinterpret_cast<const Bytes16 *>(s + base0);
                     f = (pack8_msb(__builtin_bswap64(q.lo)) << 32) | pack8_msb(__builtin_bswap64(q.hi));
-                    Bytes16 p = *reinterpret_cast<const Bytes16 *>(s + (len - 16 - base0));
-                    v = (pack8_msb(complement8(p.hi)) << 32) | pack8_msb(complement8(p.lo));
                 } else if (base0 < len) {
                     const int cnt = len - base0;
-                    for (int k = 0; k < cnt; k++) {
-                        f |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
-                        uint8_t x = s[len - 1 - base0 - k] & 7;
-                        x = x < 4 ? (uint8_t)(3 - x) : x;
-                        v |= (uint64_t)x << (60 - 4 * k);
-                    }
+                    for (int k = 0; k < cnt; k++) f |= (uint64_t)(s[base0 + k] & 7) << (60 - 4 * k);
                 }
                 fw[w] = f;
-                rv[w] = v;
+                rv[w] = 0;
             }
 #pragma unroll
             for (int w = 0; w < NW; w++) {
@@ -825,9 +820,28 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NW / 2; k++) {
-                f2[k] = ((uint64_t)squeeze2(fw[2 * k]) << 32) | squeeze2(fw[2 * k + 1]);
-                r2[k] = ((uint64_t)squeeze2(rv[2 * k]) << 32) | squeeze2(rv[2 * k + 1]);
+            for (int k = 0; k < NW / 2; k++) f2[k] = ((uint64_t)squeeze2(fw[2 * k]) << 32) | squeeze2(fw[2 * k + 1]);
+            if (lean && !bad && num_ns == 0) revcomp2<NW / 2>(f2, len, r2);
+            else {
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const int base0 = 16 * w;
+                    uint64_t v = 0;
+                    if (base0 + 16 <= len) {
+                        Bytes16 p = *reinterpret_cast<const Bytes16 *>(s + (len - 16 - base0));
+                        v = (pack8_msb(complement8(p.hi)) << 32) | pack8_msb(complement8(p.lo));
+                    } else if (base0 < len) {
+                        const int cnt = len - base0;
+                        for (int k = 0; k < cnt; k++) {
+                            uint8_t x = s[len - 1 - base0 - k] & 7;
+                            x = x < 4 ? (uint8_t)(3 - x) : x;
+                            v |= (uint64_t)x << (60 - 4 * k);
+                        }
+                    }
+                    rv[w] = v;
+                }
+#pragma unroll
+                for (int k = 0; k < NW / 2; k++) r2[k] = ((uint64_t)squeeze2(rv[2 * k]) << 32) | squeeze2(rv[2 * k + 1]);
             }
         }
         // N policy and result record, as k_init_reads
