@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "bk_align_batch_device", "bk_pair_batch", "bk_pair_batch_device", "bk_pair_batch_seg2", "bk_pair_batch_seg2_device", "bk_batch_loci", "bk_batch_seg2", "bk_snp_reset", "bk_snp_pileup", "bk_snp_pileup_device", "bk_snp_sites", "bk_snp_counts", "bk_snp_centroid_insts", "bk_get_counters", "bk_get_timing", "bk_seq_counts", "bk_seq_counts_allreduce", "bk_build_sa_device",
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
-    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device",
+    "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device", "bk_sam_prepare", "bk_sam_prep_free",
 ]
 
 

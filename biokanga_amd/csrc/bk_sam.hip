@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -195,9 +196,66 @@ struct DevBuf {
 
 }  // namespace
 
+// what bk_sam_prepare() starts: the job's read-side arrays on their way to the device and the pinned text buffers
+struct bk_sam_prep {
+    bk_ctx *ctx = nullptr;
+    DevBuf d_bases, d_offs, d_lens, d_names, d_nofs;
+    void *h_text[2] = {nullptr, nullptr};
+    uint64_t cap_text = 0;
+    uint64_t n_reads = 0, n_bases = 0, n_name_bytes = 0;
+    const uint8_t *bases = nullptr;
+    int rc = BK_OK;
+    std::thread worker;
+    ~bk_sam_prep()
+    {
+        if (worker.joinable()) worker.join();
+        for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; }
+    }
+};
+
+static int sam_upload_reads(bk_ctx *c, const bk_sam_job *job, DevBuf &d_bases, DevBuf &d_offs, DevBuf &d_lens, DevBuf &d_names, DevBuf &d_nofs)
+{
+    const uint64_t nr = job->n_reads;
+    if (d_bases.alloc(job->n_bases + 16) != hipSuccess || d_offs.alloc(nr * 8) != hipSuccess || d_lens.alloc(nr * 4) != hipSuccess ||
+        d_names.alloc(job->n_name_bytes + 16) != hipSuccess || d_nofs.alloc((nr + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
+    if (bk::upload_host(d_bases.p, job->bases, job->n_bases, c->device) || bk::upload_host(d_offs.p, job->offs, nr * 8, c->device) ||
+        bk::upload_host(d_lens.p, job->lens, nr * 4, c->device) || bk::upload_host(d_names.p, job->names, job->n_name_bytes, c->device) ||
+        bk::upload_host(d_nofs.p, job->name_ofs, nr * 8, c->device))
+        return BK_ERR_INTERNAL;
+    if (hipMemcpy((char *)d_nofs.p + nr * 8, &job->n_name_bytes, 8, hipMemcpyHostToDevice) != hipSuccess) return BK_ERR_INTERNAL;
+    return BK_OK;
+}
+
+extern "C" int bk_sam_prepare(bk_ctx *c, const bk_sam_job *job, uint32_t text_bytes_per_record, bk_sam_prep **out)
+{
+    if (!c || !job || !out || !job->n_reads || !job->bases || !job->offs || !job->lens || !job->names || !job->name_ofs) return BK_ERR_PARAMS;
+    bk_sam_prep *p = new bk_sam_prep();
+    p->ctx = c;
+    p->n_reads = job->n_reads; p->n_bases = job->n_bases; p->n_name_bytes = job->n_name_bytes; p->bases = job->bases;
+    const bk_sam_job j = *job;
+    p->worker = std::thread([p, j, text_bytes_per_record]() {
+        if (hipSetDevice(p->ctx->device) != hipSuccess) { p->rc = BK_ERR_INTERNAL; return; }
+        p->rc = sam_upload_reads(p->ctx, &j, p->d_bases, p->d_offs, p->d_lens, p->d_names, p->d_nofs);
+        if (p->rc == BK_OK && text_bytes_per_record) {
+            const uint64_t slice = std::min<uint64_t>(j.n_reads, 8u << 20);
+            const uint64_t cap = slice * (uint64_t)text_bytes_per_record + (1u << 20);
+            bool ok = true;
+            for (int q = 0; q < 2 && ok; q++) ok = hipHostMalloc(&p->h_text[q], cap, hipHostMallocDefault) == hipSuccess;
+            if (ok) p->cap_text = cap;
+            else { (void)hipGetLastError(); for (void *&h : p->h_text) if (h) { (void)hipHostFree(h); h = nullptr; } }      // (the first slice will size them)
+        }
+    });
+    *out = p;
+    return BK_OK;
+}
+
+extern "C" void bk_sam_prep_free(bk_sam_prep *prep) { delete prep; }
+
 extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes)
 {
-    if (!c || !job || !sink || !n_reported || !n_bytes) return BK_ERR_PARAMS;
+    if (!job) return BK_ERR_PARAMS;
+    std::unique_ptr<bk_sam_prep> prep(job->prep);          // consumed whatever happens
+    if (!c || !sink || !n_reported || !n_bytes) return BK_ERR_PARAMS;
     *n_reported = 0;
     *n_bytes = 0;
     if (!job->n_order) return BK_OK;
@@ -207,14 +265,23 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     hipStream_t s = c->stream;
     const uint64_t nr = job->n_reads;
     const uint32_t n_ent = (uint32_t)c->entries.size();
+    const bool timing = getenv("BK_TIMING") != nullptr;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double t_mark = now(), t_dev = 0, t_settle = 0, t_pin = 0;
+    auto lap = [&](const char *what) { const double t = now(); if (timing) fprintf(stderr, "bk timing: bk_sam_format %-28s %7.1f ms\n", what, 1e3 * (t - t_mark)); t_mark = t; };
     // the read store, names, records and order travel to the device once (pageable memory: staged by a few threads)
-    DevBuf d_bases, d_offs, d_lens, d_names, d_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_text, d_cnt;
+    DevBuf own_bases, own_offs, own_lens, own_names, own_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_text, d_cnt;
 #define SAM_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; } } while (0)
-    SAM_TRY(d_bases.alloc(job->n_bases + 16));
-    SAM_TRY(d_offs.alloc(nr * 8));
-    SAM_TRY(d_lens.alloc(nr * 4));
-    SAM_TRY(d_names.alloc(job->n_name_bytes + 16));
-    SAM_TRY(d_nofs.alloc((nr + 1) * 8));
+    // the read-side arrays: already on the device when bk_sam_prepare() was given these reads, else they travel now
+    if (prep) {
+        if (prep->worker.joinable()) prep->worker.join();
+        if (prep->ctx != c || prep->n_reads != nr || prep->n_bases != job->n_bases || prep->n_name_bytes != job->n_name_bytes || prep->bases != job->bases) return BK_ERR_PARAMS;
+        if (prep->rc != BK_OK) prep.reset();
+    }
+    lap(prep ? "head start taken, waited" : "no head start");
+    if (!prep) { int ru = sam_upload_reads(c, job, own_bases, own_offs, own_lens, own_names, own_nofs); if (ru) return ru; }
+    DevBuf &d_bases = prep ? prep->d_bases : own_bases, &d_offs = prep ? prep->d_offs : own_offs, &d_lens = prep ? prep->d_lens : own_lens,
+           &d_names = prep ? prep->d_names : own_names, &d_nofs = prep ? prep->d_nofs : own_nofs;
     SAM_TRY(d_hits.alloc(nr * sizeof(bk_hit)));
     SAM_TRY(d_order.alloc(job->n_order * 4));
     SAM_TRY(d_ent.alloc((size_t)n_ent * 81));
@@ -225,19 +292,14 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     size_t tb = 0;
     SAM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)slice + 1, s));
     SAM_TRY(d_tmp.alloc(tb + 256));
-    if (bk::upload_host(d_bases.p, job->bases, job->n_bases, c->device) || bk::upload_host(d_offs.p, job->offs, nr * 8, c->device) ||
-        bk::upload_host(d_lens.p, job->lens, nr * 4, c->device) || bk::upload_host(d_names.p, job->names, job->n_name_bytes, c->device) ||
-        bk::upload_host(d_hits.p, job->hits, nr * sizeof(bk_hit), c->device) || bk::upload_host(d_order.p, job->order, job->n_order * 4, c->device))
+    if (bk::upload_host(d_hits.p, job->hits, nr * sizeof(bk_hit), c->device) || bk::upload_host(d_order.p, job->order, job->n_order * 4, c->device))
         return BK_ERR_INTERNAL;
     {
-        std::vector<uint64_t> nofs(nr + 1);
-        memcpy(nofs.data(), job->name_ofs, nr * 8);
-        nofs[nr] = job->n_name_bytes;
-        if (bk::upload_host(d_nofs.p, nofs.data(), (nr + 1) * 8, c->device)) return BK_ERR_INTERNAL;
         std::vector<char> en((size_t)n_ent * 81);
         for (uint32_t e = 0; e < n_ent; e++) memcpy(&en[(size_t)e * 81], c->entries[e].name, 81);
         HIP_TRY(hipMemcpy(d_ent.p, en.data(), en.size(), hipMemcpyHostToDevice));
     }
+    lap("uploads");
     SamDev d{};
     d.bases = d_bases.as<uint8_t>(); d.offs = d_offs.as<uint64_t>(); d.lens = d_lens.as<uint32_t>(); d.names = d_names.as<char>();
     d.name_ofs = d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
@@ -245,8 +307,14 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     // chrom ids must name entries 1..n (the host checked its records when it made them; a stray id must not read out of bounds)
     for (uint64_t i = 0; i < nr; i++)
         if (job->hits[i].nar == BK_NAR_ACCEPTED && (job->hits[i].chrom_id < 1 || job->hits[i].chrom_id > n_ent)) return BK_ERR_PARAMS;
+    lap("record check");
     void *h_text[2] = {nullptr, nullptr};
     uint64_t cap_text = 0;
+    if (prep && prep->cap_text) {                      // (the pinned text buffers came with the head start; a slice that outgrows them replaces them)
+        for (int q = 0; q < 2; q++) { h_text[q] = prep->h_text[q]; prep->h_text[q] = nullptr; }
+        cap_text = prep->cap_text;
+        if (d_text.alloc(cap_text) != hipSuccess) { (void)hipGetLastError(); cap_text = 0; }
+    }
     auto free_host = [&]() { for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; } };
     int rc = BK_OK;
     uint64_t total_rep = 0, total_bytes = 0;
@@ -257,6 +325,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     auto settle = [&](int q) { if (sinker[q].joinable()) { sinker[q].join(); if (sink_rc[q] && rc == BK_OK) rc = BK_ERR_FILEACCESS; } };
     for (uint64_t k0 = 0, si = 0; k0 < job->n_order && rc == BK_OK; k0 += slice, si++) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(slice, job->n_order - k0);
+        double t0 = now();
         hipError_t e = hipMemsetAsync(d_cnt.p, 0, 16, s);
         if (e == hipSuccess) e = hipMemsetAsync((char *)d_bytes.p + (size_t)n * 8, 0, 8, s);
         hipLaunchKernelGGL(k_sam_measure, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_bytes.as<unsigned long long>(), d_cnt.as<uint32_t>());
@@ -268,8 +337,10 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
         if (e == hipSuccess) e = hipMemcpyAsync(&rep, d_cnt.p, 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = BK_ERR_INTERNAL; break; }
+        t_dev += now() - t0;
         if (bytes > cap_text) {
             // (the text buffers follow the largest slice seen; the first slice sizes them for the run)
+            const double tp = now();
             settle(0); settle(1);
             if (d_text.p) { (void)hipFree(d_text.p); d_text.p = nullptr; }
             free_host();
@@ -277,23 +348,29 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
             bool ok = d_text.alloc(cap_text) == hipSuccess;
             for (int q = 0; q < 2 && ok; q++) ok = hipHostMalloc(&h_text[q], cap_text, hipHostMallocDefault) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); rc = BK_ERR_MEM; break; }
+            t_pin += now() - tp;
         }
         const int q = (int)(si & 1);
+        t0 = now();
         settle(q);
+        t_settle += now() - t0;
         if (rc != BK_OK) break;
+        t0 = now();
         hipLaunchKernelGGL(k_sam_write, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_at.as<unsigned long long>(), d_text.as<char>());
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_text[q], d_text.p, bytes, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { rc = BK_ERR_INTERNAL; break; }
+        t_dev += now() - t0;
         const uint64_t at = total_bytes;
         if (bytes) sinker[q] = std::thread([&, q, bytes, at]() { sink_rc[q] = sink(user, reinterpret_cast<const char *>(h_text[q]), bytes, at); });
         total_rep += rep;
         total_bytes += bytes;
     }
-    settle(0);
-    settle(1);
+    { const double t0 = now(); settle(0); settle(1); t_settle += now() - t0; }
     free_host();
+    if (timing) fprintf(stderr, "bk timing: bk_sam_format slices: device (measure, scan, write, copy back) %.1f ms, text buffers %.1f ms, waiting for the sink %.1f ms\n",
+                        1e3 * t_dev, 1e3 * t_pin, 1e3 * t_settle);
     *n_reported = total_rep;
     *n_bytes = total_bytes;
     return rc;

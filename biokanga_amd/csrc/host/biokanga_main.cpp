@@ -896,6 +896,17 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<bk_hit> &hits = A.hits;
     std::vector<bk_seg2> &seg2 = A.seg2;
     diag("Alignment of %zu from %zu loaded completed", nr, nr);
+    // plain SAM records of a large run are formatted by the device (report.cpp): what it needs of the reads travels there while the
+    // host resolves, filters and sorts
+    bk_sam_prep *sam_prep = nullptr;
+    struct PrepGuard { bk_sam_prep *&p; ~PrepGuard() { if (p) { bk_sam_prep_free(p); p = nullptr; } } } prep_guard{sam_prep};      // (not consumed: given back)
+    if (pre.fd >= 0 && o.ml_mode != 5 && !o.micro_indel && !o.splice_len && !o.min_chim && !o.min_flank && nr == rs.lens.size()) {
+        bk_sam_job hj{};
+        hj.bases = rs.bases.data(); hj.n_bases = rs.bases.size(); hj.offs = rs.offs.data(); hj.lens = rs.lens.data();
+        hj.names = rs.names.data(); hj.n_name_bytes = rs.names.size(); hj.name_ofs = rs.name_ofs.data(); hj.n_reads = nr;
+        const uint64_t per_rec = (rs.names.size() + (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.bases.size()) / std::max<size_t>(nr, 1) + 64 + (o.pe_mode ? 24 : 0);
+        if (bk_sam_prepare(ctx, &hj, (uint32_t)std::min<uint64_t>(per_rec + per_rec / 8, 1u << 20), &sam_prep) != BK_OK) sam_prep = nullptr;
+    }
 
     std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
     std::vector<int> multi_dist((size_t)o.max_ml, 0);
@@ -1094,9 +1105,12 @@ int cmd_align(int argc, char **argv, int first)
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
     R.ctx = ctx;
     R.pre = pre.fd >= 0 ? &pre : nullptr;
+    R.sam_prep = sam_prep;
+    sam_prep = nullptr;                            // (the report owns it from here)
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");
     int rr = (o.fmt >= 5 && opath.size() > 5 && !strcasecmp(opath.c_str() + opath.size() - 4, ".bam")) ? report_bam(R, opath) : report_text(R);
+    if (R.sam_prep) { bk_sam_prep_free(R.sam_prep); R.sam_prep = nullptr; }        // (the report took another path)
     // SNPs: the file is only opened for '-M0' .. '-M5' (Aligner.cpp:4488), and only processed when reads were accepted (:746)
     if (rr == 0 && o.snp.min_reads > 0 && o.fmt <= 5) {
         o.snp.path = a.has("S") ? a.str("S") : opath + ".snp";

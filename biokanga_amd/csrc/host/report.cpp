@@ -580,6 +580,8 @@ int report_text(Report &R)
             job.names = rs.names.data(); job.n_name_bytes = rs.names.size(); job.name_ofs = rs.name_ofs.data();
             job.hits = hits.data(); job.n_reads = nr; job.order = order.data(); job.n_order = nr;
             job.report_unaligned = fmt == 6 ? 1 : 0; job.pe_mode = pe_mode;
+            job.prep = R.sam_prep;
+            R.sam_prep = nullptr;                                                    // (consumed by the call whatever its outcome)
             uint64_t n_rep = 0, n_bytes = 0;
             const int drc = rs.lens.size() == nr ? bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes) : BK_ERR_PARAMS;
             if (drc == BK_OK) {

@@ -24,6 +24,7 @@ struct Report {
     int pe_mode, ml_mode, max_ml, fmt, nthreads, micro_indel, splice_len, max_rpt_sam_seqs;
     bk_ctx *ctx = nullptr;                        // a context whose device formats plain SAM records (bk_sam_format); may be null
     SamPrealloc *pre = nullptr;                   // SAM text: the output file, created early and being preallocated; may be null
+    bk_sam_prep *sam_prep = nullptr;              // the device formatter's head start (bk_sam_prepare), consumed or freed by report_text / report_bam
 
     size_t RD(size_t i) const { return src.empty() ? i : (size_t)src[i]; }
     bool has_seg2(size_t i) const { return !seg2.empty() && (seg2[RD(i)].flags & 5); }       // FlgInDel or FlgSplice

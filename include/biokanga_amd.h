@@ -411,6 +411,7 @@ int  bk_snp_centroid_insts(bk_ctx *ctx, uint32_t chrom_id, int32_t min_reads, ui
  * end trims (no -a / -A / -c / -x); with pe_mode the reads are interleaved PE1, PE2 and carry the flags bk_pair_batch left.
  * The sink is called once per slice with the slice's text and its offset within the whole text; up to two calls may run at the
  * same time (on threads of the library), each must return 0.  Lines are those of the reference's SAM body, byte for byte. */
+struct bk_sam_prep;
 typedef struct bk_sam_job {
     const uint8_t  *bases;        /* all reads, 1 byte/base as CAligner holds them (quality in bits 4-7 when loaded)      */
     uint64_t        n_bases;
@@ -425,7 +426,16 @@ typedef struct bk_sam_job {
     uint64_t        n_order;
     int32_t         report_unaligned;   /* -M6: reads without an accepted alignment get a line too (FLAG 4, YU:Z:<reason>) */
     int32_t         pe_mode;            /* 0, or the -U mode the records were paired under                                 */
+    struct bk_sam_prep *prep;           /* NULL, or what bk_sam_prepare() started for exactly these reads (consumed by the call)   */
 } bk_sam_job;
+/* Optional head start: everything of a job that is known once the reads are aligned - the read store, the names, the buffers the
+ * text leaves the device through - can travel while the host still sorts.  bk_sam_prepare() returns at once (a thread of the library
+ * does the work; `job`'s bases / offs / lens / names / name_ofs must stay valid until bk_sam_format() or bk_sam_prep_free()), hits and
+ * order are not looked at.  text_bytes_per_record: expected length of a line (sizes the pinned text buffers; 0 = let the first slice
+ * size them).  Pass the handle in bk_sam_job.prep; a handle that is not used is given back with bk_sam_prep_free(). */
+typedef struct bk_sam_prep bk_sam_prep;
+int  bk_sam_prepare(bk_ctx *ctx, const bk_sam_job *job, uint32_t text_bytes_per_record, bk_sam_prep **out);
+void bk_sam_prep_free(bk_sam_prep *prep);
 typedef int (*bk_sam_sink)(void *user, const char *text, uint64_t n_bytes, uint64_t text_offset);
 int  bk_sam_format(bk_ctx *ctx, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes);
 
