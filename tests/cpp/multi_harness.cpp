@@ -1,5 +1,7 @@
 // drives host/multi_assign.h and host/glibc_rand.h the way the command line does for -r2 / -r3 / -r4:
-//   multi_harness <mode 2|3|4> <threads> <max_reads_len> <clamp 0|1> hits.bin offs.bin loci.bin out_hits.bin
+//   multi_harness <mode 2|3|4> <threads> <max_reads_len> <clamp 0|1> hits.bin offs.bin loci.bin out_hits.bin [trims.bin out_trims.bin]
+// trims.bin: one bk_loci_trims per locus (-c with the multi-loci modes); out_trims.bin: per read the trims of the locus it took (zeros
+// for reads the policy left alone)
 // hits.bin: bk_hit records (as bk_align_batch returns them with max_ml > 1), offs.bin: uint64[n+1], loci.bin: bk_loci
 #include <cstdio>
 #include <cstdlib>
@@ -37,7 +39,7 @@ int main(int argc, char **argv)
         printf("ok\n");
         return 0;
     }
-    if (argc != 9) return 2;
+    if (argc != 9 && argc != 11) return 2;
     const int mode = atoi(argv[1]), threads = atoi(argv[2]);
     const uint32_t max_reads_len = (uint32_t)atoi(argv[3]);
     const bool clamp = atoi(argv[4]) != 0;
@@ -45,6 +47,9 @@ int main(int argc, char **argv)
     std::vector<uint64_t> offs = slurp<uint64_t>(argv[6]);
     std::vector<bk_loci> loci = slurp<bk_loci>(argv[7]);
     const size_t nr = hits.size();
+    std::vector<bk_loci_trims> trims, rec_trims(nr, bk_loci_trims{});
+    if (argc == 11) trims = slurp<bk_loci_trims>(argv[9]);
+    auto trims_of = [&](uint64_t l) { return l < trims.size() ? trims[l] : bk_loci_trims{}; };
     auto count = [&](size_t i) -> uint32_t {
         const bk_hit &h = hits[i];
         if (h.rslt == BK_HR_HITS || (clamp && h.rslt == BK_HR_HITINSTS)) return (uint32_t)(offs[i + 1] - offs[i]);
@@ -58,20 +63,32 @@ int main(int argc, char **argv)
         bk::GlibcRand pick;
         for (size_t i = 0; i < nr; i++) {
             const uint32_t c = count(i);
-            if (c) take(hits[i], loci[offs[i] + (uint32_t)pick.next() % c]);
+            if (c) {
+                const uint64_t l = offs[i] + (uint32_t)pick.next() % c;
+                take(hits[i], loci[l]);
+                rec_trims[i] = trims_of(l);
+            }
         }
     } else {
         bk::MultiAssign ma;
         for (size_t i = 0; i < nr; i++) {
             const uint32_t c = count(i);
-            for (uint32_t k = 0; k < c; k++) ma.add((uint32_t)i + 1, loci[offs[i] + k], c > 1);
+            for (uint32_t k = 0; k < c; k++) {
+                const bk_loci_trims t = trims_of(offs[i] + k);
+                ma.add((uint32_t)i + 1, loci[offs[i] + k], c > 1, t.left, t.right, (uint32_t)(offs[i] + k));
+            }
         }
         ma.assign(mode == 3, threads, max_reads_len);
         for (const bk::MultiHitRec &m : ma.recs)
-            if (m.multi && m.assigned) take(hits[m.read_id - 1], m.loci);
+            if (m.multi && m.assigned) { take(hits[m.read_id - 1], m.loci); rec_trims[m.read_id - 1] = trims_of(m.src); }
     }
     FILE *f = fopen(argv[8], "wb");
     fwrite(hits.data(), sizeof(bk_hit), nr, f);
     fclose(f);
+    if (argc == 11) {
+        f = fopen(argv[10], "wb");
+        fwrite(rec_trims.data(), sizeof(bk_loci_trims), nr, f);
+        fclose(f);
+    }
     return 0;
 }

@@ -80,3 +80,43 @@ def test_r1_is_the_plain_result(multi_case):
 def test_parallel_sort_of_the_clustering(multi_harness):
     """par_sort (chunks sorted on all threads, merged pairwise) equals std::sort; sized so that the parallel path really runs"""
     assert subprocess.check_output([multi_harness, "sorttest", "3000000"]).strip() == b"ok"
+
+
+@pytest.mark.parametrize("tag,mode,kw,threads", [("r2R5c50", 2, dict(max_subs=3, min_chimeric_len=50, max_ml=5), 1),
+                                                 ("r3R5c50", 3, dict(max_subs=3, min_chimeric_len=50, max_ml=5), 4),
+                                                 ("r4R5c60", 4, dict(max_subs=3, min_chimeric_len=60, max_ml=5), 4),
+                                                 ("r4R3Xc70s5", 4, dict(max_subs=5, min_chimeric_len=70, max_ml=3, clamp_ml=1), 4)])
+def test_host_policies_with_chimeric_trims_match_reference(golden_tmp, multi_harness, tmp_path, tag, mode, kw, threads):
+    """-c with -r2 / -r3 / -r4: the loci the chimeric call lists carry their own end trims; the random pick takes them along and the
+    clustering sorts and scores on the trimmed loci (AdjStartLoci / AdjEndLoci / AdjHitLen) - fed with the oracle's lists, against
+    POS and CIGAR (soft clips) of the reference's SAM"""
+    d = golden_tmp["chimml"]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    hits, lo, loci, trims, seg2 = helpers.oracle_align_multi_chimeric(sfx, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    sfx.close()
+    hp, op, lp, rp, tp, otp = (str(tmp_path / n) for n in ("hits.bin", "offs.bin", "loci.bin", "out.bin", "trims.bin", "out_trims.bin"))
+    hits.tofile(hp); lo.tofile(op); loci.tofile(lp); trims.tofile(tp)
+    subprocess.check_call([multi_harness, str(mode), str(threads), str(int(lens.max())), str(kw.get("clamp_ml", 0)), hp, op, lp, rp, tp, otp])
+    got = np.fromfile(rp, dtype=helpers.HIT_DTYPE)
+    rt = np.fromfile(otp, dtype=helpers.TRIMS_DTYPE)
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "chimml", f"{tag}.m6.sam.gz"))
+    by = {r["qname"]: r for r in recs}
+    chrom = chrom_names_from_hdr(hdr)
+    n_trimmed = 0
+    for i, nm in enumerate(names):
+        h, r = got[i], by[nm]
+        assert helpers.NAR_TAGS[h["nar"]] == r["nar"], (nm, h, r)
+        if h["nar"] != 1:
+            continue
+        taken = not np.array_equal(got[i], hits[i])                       # the policy placed this read; else its own unique placement stands
+        if taken:
+            tl, tr = int(rt["left"][i]), int(rt["right"][i])
+        else:
+            tl, tr = (int(seg2["match_len"][i]), int(seg2["read_ofs"][i])) if seg2["flags"][i] & 8 else (0, 0)
+        n_trimmed += 1 if (taken and (tl or tr)) else 0
+        plus = chr(h["strand"]) == "+"
+        c5, c3 = (tl, tr) if plus else (tr, tl)
+        cig = (f"{c5}S" if c5 else "") + f"{int(h['match_len']) - tl - tr}M" + (f"{c3}S" if c3 else "")
+        assert (chrom[h["chrom_id"] - 1], int(h["match_loci"]) + (tl if plus else tr) + 1, cig) == (r["rname"], r["pos"], r["cigar"]), (nm, h, rt[i], r)
+    assert n_trimmed > 10, n_trimmed
