@@ -104,6 +104,8 @@ struct DevBatch {
     uint64_t *iv_first;         // core intervals [strand][core][read]: start (suffix array index) ...
     uint32_t *iv_n;             // ... and count | flags - separate arrays only for 5-byte indexes
     uint2 *iv2;                 // 4-byte indexes: {start, count | flags} in one word; then iv_first/iv_n are null
+    uint32_t iv_stride;         // records per (strand, core) plane of the interval arrays in this phase = length of its active list
+    const uint32_t *act;        // the phase's active list (read numbers): interval records and the wave list are indexed by position in it
     uint32_t *wave_work;        // per read: candidates the wave kernel will walk (sum of its core intervals), left by k_flat when it hands the read on; may be null
     uint2 *iv32;                // [strand][read]: suffix array interval of the read's first k + 16 bases {start, count; count 0xffffffff = not known},
                                 //   left by phase 0 for the offset-0 cores of the later phases (4-byte indexes); may be null

@@ -724,6 +724,8 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         HIP_TRY(hipMemsetAsync(sm + 6, 0, 5 * 4, s));
         const uint32_t *ext_list = c->d_act[cur];
         const uint32_t n_ext = n_act;
+        b.act = ext_list;                          // interval records and the wave list go by position in this list
+        b.iv_stride = n_act;
         if (cmax > 0) {
             const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
             hipEvent_t e1 = tm.begin(s);
@@ -739,10 +741,10 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                     HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
                     c->cap_slist = lanes;
                 }
-                // interval counts of the slots this phase can use: [strand][core][read] -> one contiguous range per strand
+                // interval counts of the slots this phase can use: [strand][core][position in the active list] -> one contiguous range per strand
                 for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * ivc * n, (size_t)cmax * n * 8, s));
-                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * ivc * n, (size_t)cmax * n * 4, s));
+                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 8, s));
+                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 4, s));
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
                                 c->d_slist_stage, c->d_stripe_cnt, s);
                 HIP_TRY(hipGetLastError());

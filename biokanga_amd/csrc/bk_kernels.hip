@@ -88,11 +88,13 @@ __device__ __forceinline__ RdRow read_row(const DevBatch &b, uint32_t r, int str
     return q;
 }
 
-// core interval slot of (read, strand, core): [strand][core][read], so that lanes working on
-// neighbouring reads touch neighbouring words
-__device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t r, int st, int c)
+// core interval slot of (read, strand, core): [strand][core][a], a = the read's position in the phase's ACTIVE list (DevBatch::act),
+// so that lanes working on neighbouring active reads touch neighbouring words in every phase - indexed by read number, a later
+// phase found one record in two to four of a line still in use.  The records live for one phase: written by its search passes,
+// read by its extend kernels (which reach a read of the wave list through its position, act[a]).
+__device__ __forceinline__ uint64_t iv_slot(const DevBatch &b, uint32_t a, int st, int c)
 {
-    return (uint64_t)(st * (int)b.iv_cores + c) * b.n_reads + r;
+    return (uint64_t)(st * (int)b.iv_cores + c) * b.iv_stride + a;
 }
 
 // core interval records.  4-byte indexes keep {start, count} of a slot in ONE 8-byte word (b.iv2), so every
@@ -1015,7 +1017,7 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
     int strand = cfg.align_strand == 2 ? 1 : si;
     const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
     uint64_t first, count;
-    uint64_t slot = iv_slot(b, r, strand, c);
+    uint64_t slot = iv_slot(b, (uint32_t)a, strand, c);
     if (lazy && ix.k > 0 && cl >= ix.k) {
         uint64_t p0 = rdw.nib16(my_ofs) & top_mask(cl);
         uint64_t lo, hi;
@@ -1200,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 }
                 const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
                 const int strand = cfg.align_strand == 2 ? 1 : si;
-                slot[u] = iv_slot(b, r, strand, c);
+                slot[u] = iv_slot(b, (uint32_t)a, strand, c);
                 if (b.rd2 != nullptr && !(meta & kReadHasN)) {
                     // 32 bases from the core's start out of the 2-bit row: the k-mer code's bases and the 16 that follow them
                     const uint64_t *row = b.rd2 + ((uint64_t)r * 2 + strand) * (b.nw / 2);
@@ -1331,7 +1333,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     struct Fin { unsigned long long &a, &b; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (b) atomicAdd(&bb.ctr[ctr_stripe() + 6], b); } } fin{d_k2, d_deep, b};
 #endif
     const uint64_t slot = list[i];
-    const uint32_t r = (uint32_t)(slot % b.n_reads), sc = (uint32_t)(slot / b.n_reads);
+    const uint32_t r = b.act[(uint32_t)(slot % b.iv_stride)], sc = (uint32_t)(slot / b.iv_stride);
     const int strand = (int)(sc / b.iv_cores), c = (int)(sc % b.iv_cores);
     const uint32_t meta = b.rmeta[r];
     const int len = (int)(meta & kReadLenMask);
@@ -1432,7 +1434,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
         if (!is_heavy)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if (iv_count(b, iv_slot(b, r, st, c)) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if (iv_count(b, iv_slot(b, a, st, c)) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             heavy[atomicAdd(heavy_cnt, 1u)] = r;
         } else {
@@ -1446,7 +1448,7 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
                 const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
-                    uint64_t slot = iv_slot(b, r, st, c);
+                    uint64_t slot = iv_slot(b, a, st, c);
                     uint32_t n;
                     uint64_t first;
                     iv_get(b, slot, first, n);
@@ -2050,7 +2052,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
         if (fits)
             for (int st = s0; st <= s1; st++)
                 for (int c = 0; c < nc; c++)
-                    if ((iv_count(b, iv_slot(b, r, st, c)) & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
+                    if ((iv_count(b, iv_slot(b, a, st, c)) & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
         if (is_heavy) {
             dest = (fits && wave != nullptr) ? 2 : 3;
         } else {
@@ -2065,7 +2067,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
                 load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
                 for (int c = 0; c < nc && !done; c++) {
                     n_search++;
-                    uint64_t slot = iv_slot(b, r, st, c);
+                    uint64_t slot = iv_slot(b, a, st, c);
                     uint32_t nraw;
                     uint64_t first;
                     iv_get(b, slot, first, nraw);
@@ -2146,7 +2148,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
     }
     __syncthreads();
     if (dest == 1) next_act[s_base[1] + my_off] = r;
-    else if (dest == 2) wave[s_base[2] + my_off] = r;
+    else if (dest == 2) wave[s_base[2] + my_off] = a;          // (the wave kernel finds the read's interval records by its position)
     else if (dest == 3) heavy[s_base[3] + my_off] = r;
 }
 
@@ -2259,7 +2261,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 sv[u] = make_uint2(0, 0);
                 if (spec && u < slots_max) {
                     const int sti = u >= cmaxs ? 1 : 0;
-                    sv[u] = b.iv2[iv_slot(b, r, s0 + sti, u - sti * cmaxs)];
+                    sv[u] = b.iv2[iv_slot(b, a, s0 + sti, u - sti * cmaxs)];
                 }
             }
         }
@@ -2299,7 +2301,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     const int sti = q >= cmaxs ? 1 : 0, c = q - sti * cmaxs;
                     uint64_t f64 = 0;
                     uint32_t cnt = 0;
-                    if (c < nc) iv_get(b, iv_slot(b, r, s0 + sti, c), f64, cnt);
+                    if (c < nc) iv_get(b, iv_slot(b, a, s0 + sti, c), f64, cnt);
                     if (cnt & kLazyFlag) lazy_bits |= 1u << (q & 31);
                     cnt &= ~kLazyFlag;
                     if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
@@ -2311,7 +2313,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             s_lazy[t] = lazy_bits;
             if (run > CAP) is_heavy = true;                 // more candidates than one pass's result bytes hold (many cores, all near heavy_thresh): the wave kernel's
             my_total = is_heavy ? 0 : run;
-            if (is_heavy && have_wave && b.wave_work != nullptr) b.wave_work[r] = work;
+            if (is_heavy && have_wave && b.wave_work != nullptr) b.wave_work[a] = work;
         }
         if (is_heavy) dest = (fits && have_wave) ? 2 : 3;
         else { mine = true; n_lcm = 1; }
@@ -2382,7 +2384,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     else {
                         const int sti = q >= cmaxs ? 1 : 0;
                         uint32_t iv_c;
-                        iv_get(b, iv_slot(b, s_r[ri], s0 + sti, q - sti * cmaxs), iv_f, iv_c);
+                        iv_get(b, iv_slot(b, blockIdx.x * blockDim.x + ri, s0 + sti, q - sti * cmaxs), iv_f, iv_c);
                         lazy = (iv_c & kLazyFlag) != 0;
                     }
                     tv[i] = sa_get<WIDE>(ix, iv_f + j);
@@ -2627,7 +2629,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
     __syncthreads();
     PROF(8);
-    if (dest) stripe_put(out, dest - 1, s_base[dest] + my_off, r);
+    if (dest) stripe_put(out, dest - 1, s_base[dest] + my_off, dest == 2 ? a : r);      // (wave list: the read's position, see iv_slot)
     if (mine && rslt != BK_HR_NONE) {
         uint64_t hit_left = 0;
         int hit_strand = '?', e = -1;
@@ -2635,7 +2637,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             const int sti = best_q >= cmaxs ? 1 : 0, c = best_q - sti * cmaxs, st = s0 + sti;
             const int last = len - cl;
             const int ofs = c * cd < last ? c * cd : last;
-            const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, r, st, c));
+            const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, a, st, c));
             hit_left = sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
             hit_strand = st ? '-' : '+';
             if (ent_lds) {
@@ -2828,7 +2830,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (item >= n_list) break;
         // (wave-uniform values that arrive through vector loads are handed to the scalar unit explicitly: the read's plan, its loop
         // bounds and the window geometry then cost scalar instructions once instead of vector instructions in every lane)
-        const uint32_t r = __builtin_amdgcn_readfirstlane(list[item]);
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(list[item]);          // position in the phase's active list: where its interval records lie
+        const uint32_t r = __builtin_amdgcn_readfirstlane(b.act[pos]);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
         const int len = (int)(meta & kReadLenMask);
         const bool has_n = (meta & kReadHasN) != 0;
@@ -2901,7 +2904,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
             }
             uint32_t my_cn = 0;                       // lane l < nc: suffixes in core l's interval
             if (lane < nc) {
-                uint64_t slot = iv_slot(b, r, st, lane);
+                uint64_t slot = iv_slot(b, pos, st, lane);
                 uint64_t f;
                 uint32_t cn;
                 iv_get(b, slot, f, cn);
@@ -4766,8 +4769,8 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t r = list[i];
-    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFFu - work_of[r]; return; }      // k_flat has added the intervals up already
+    const uint32_t pos = list[i], r = b.act[pos];
+    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFFu - work_of[pos]; return; }      // k_flat has added the intervals up already
     const int len = (int)b.lens[r];
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd, dummy[1];
@@ -4779,7 +4782,7 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
     uint64_t best_first = 0, work = 0;
     for (int st = s0; st <= s1; st++)
         for (int c = 0; c < nc; c++) {
-            uint64_t slot = iv_slot(b, r, st, c);
+            uint64_t slot = iv_slot(b, pos, st, c);
             uint64_t f;
             uint32_t raw;
             iv_get(b, slot, f, raw);
