@@ -2818,6 +2818,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if ((uint32_t)lane < pend_n) next_act[base + lane] = pend_r;
         pend_n = 0;
     };
+    int geo_len = -1, geo_mm = 0, geo_cl = 1, geo_cd = 1, geo_nc = 0;      // geometry of the reads of length geo_len in this phase
+    ReadPlan geo_p{};
     for (;;) {
         if (grab_left == 0) {
             uint32_t g = 0;
@@ -2835,9 +2837,32 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
         const int len = (int)(meta & kReadLenMask);
         const bool has_n = (meta & kReadHasN) != 0;
-        ReadPlan p = make_plan(len, cfg);
-        int mm, cl, cd;
-        phase_params(p, cfg, phase, mm, cl, cd);
+        // the plan of the read's length, the core offsets and the cores' masks only change with the length: a batch of equal-length reads
+        // computes them once per wave (they live in registers and in the wave's LDS words), not once per read
+        if (len != geo_len) {
+            geo_len = len;
+            geo_p = make_plan(len, cfg);
+            phase_params(geo_p, cfg, phase, geo_mm, geo_cl, geo_cd);
+            int ofs_tmp[kMaxCoresFast];
+            geo_nc = core_offsets(len, geo_cl, geo_cd, geo_p.max_slides, ofs_tmp, kMaxCoresFast);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < geo_nc && lane < kMaxCoresFast) {
+                int o = 0;
+#pragma unroll
+                for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
+                core[lane].ofs = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int ncm = geo_nc < kMaxCoresFast ? geo_nc : kMaxCoresFast;
+            for (int idx = lane; idx < ncm * (NW / 4); idx += 64) {
+                const int cc = idx / (NW / 4), i = idx % (NW / 4);
+                const int o = core[cc].ofs;
+                cmask[cc][i] = imask_word(o, o + geo_cl, i);
+            }
+        }
+        const ReadPlan p = geo_p;
+        const int mm = geo_mm, cl = geo_cl, cd = geo_cd, nc = geo_nc;
+        (void)cd;
         n_lcm++;
         const int init = mm + cfg.mm_delta + 1;
         int low_inst = 0, low_mm = init, nxt = init;
@@ -2846,26 +2871,6 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         bool done = false;
         int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
         const bool sw_read = SW && len <= kSwLen && len - cl <= kSwPre;       // every core offset of the read lies within an entry's lead
-        // core geometry (same for both strands)
-        int nc;
-        {
-            int ofs_tmp[kMaxCoresFast];
-            nc = core_offsets(len, cl, cd, p.max_slides, ofs_tmp, kMaxCoresFast);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < nc && lane < kMaxCoresFast) {
-                int o = 0;
-#pragma unroll
-                for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
-                core[lane].ofs = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int ncm = nc < kMaxCoresFast ? nc : kMaxCoresFast;
-            for (int idx = lane; idx < ncm * (NW / 4); idx += 64) {
-                const int cc = idx / (NW / 4), i = idx % (NW / 4);
-                const int o = core[cc].ofs;
-                cmask[cc][i] = imask_word(o, o + cl, i);
-            }
-        }
         for (int st = s0; st <= s1 && !done; st++) {
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
                 if (lset_n) {
