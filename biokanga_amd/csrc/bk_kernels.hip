@@ -2785,6 +2785,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
     // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
     __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
+    // the sequences' first and last base (up to 64 of them): a finished read finds its sequence without a trip to HBM at its very end
+    __shared__ uint64_t s_es[64], s_ee[64];
+    if (ix.n_ent <= 64) {
+        if (threadIdx.x < ix.n_ent) { s_es[threadIdx.x] = ix.ent_start[threadIdx.x]; s_ee[threadIdx.x] = ix.ent_end[threadIdx.x]; }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
@@ -3128,8 +3134,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (rslt != BK_HR_NONE) {
             int e = -1;
             if (low_inst >= 1) {
-                if (ix.n_ent <= 64) {       // one entry per lane, one round trip
-                    bool in = (uint32_t)lane < ix.n_ent && hit_left >= ix.ent_start[lane] && hit_left <= ix.ent_end[lane];
+                if (ix.n_ent <= 64) {       // one entry per lane
+                    bool in = (uint32_t)lane < ix.n_ent && hit_left >= s_es[lane] && hit_left <= s_ee[lane];
                     uint64_t m = __ballot(in);
                     e = m ? __ffsll((unsigned long long)m) - 1 : -1;
                 } else if (lane == 0)
