@@ -883,7 +883,8 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
     if (c->d_swin || !c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;
-    if (c->use_swin < 2 && (maxlen > (uint32_t)kSwLen || (int)maxlen - c->cfg.min_core_len > kSwPre)) return BK_OK;       // (2: whatever the batch - its short reads use it)
+    // (reads of up to kSwLen bases take every window from it, reads of up to kSwBases - 32 - 2 x 150 - those of their middle cores; 2: whatever the batch)
+    if (c->use_swin < 2 && (maxlen > (uint32_t)(kSwBases - 32) || (maxlen <= (uint32_t)kSwLen && (int)maxlen - c->cfg.min_core_len > kSwPre))) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t need = c->ix.n * 48;

@@ -1910,17 +1910,17 @@ template <int NW, int D2>
 __device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint32_t (&S)[13], unsigned sh,
                                                  IWindow<NW> &w)
 {
-    static_assert(kSwPre / 16 + kSwLen / 16 + 2 <= 13 && D2 >= -1 && D2 <= kSwPre / 16, "window dwords stay inside the entry");
+    static_assert(D2 >= -1 && D2 <= kSwPre / 16, "the window starts inside the entry's lead");
     int mm = 0;
 #pragma unroll
     for (int i = 0; i < NW / 4; i++) {
         uint32_t y[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            constexpr int kDwords = (kSwLen + 15) / 16;
             const int wd = 4 * i + d;
             y[d] = 0;
-            if (wd < kDwords && 16 * wd < len) {
+            // (dwords the entry does not hold are never asked for: the caller only comes here with the whole window inside the entry)
+            if (D2 + wd + 1 <= 12 && 16 * wd < len) {
                 const uint32_t hi = D2 + wd >= 0 ? S[D2 + wd >= 0 ? D2 + wd : 0] : 0u;
                 const uint32_t lo = S[D2 + wd + 1 <= 12 ? D2 + wd + 1 : 12];
                 const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, sh);
@@ -2974,12 +2974,16 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 uint32_t iter = 0;
                 bool copies_checked = false;
                 uint64_t walked = n;
+                // the window array serves a core when the read's whole window lies inside the candidate's entry: bases kSwPre - ofs ..
+                // + len of its kSwBases (every core of a read of up to kSwLen bases; of a longer read - 2 x 150 - the cores in the
+                // middle, when they are walked a round per 64 suffixes; rounds shared by several cores of such a read go to the target)
+                const bool sw_now = SW && ((GROUP && grouped) ? sw_read : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre));
                 for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
                     // (the candidate's entry of the window array is requested together with its suffix array element: one round trip)
                     uint4 ev[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-                    if (SW && sw_read && active) {
+                    if (SW && sw_now && active) {
                         const uint4 *__restrict__ ep = ix.swin + (lfirst + j) * 3;
                         ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
                     }
@@ -2995,8 +2999,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         // flagged window is then fetched again from the 4-bit copy
                         if (two_bit) {
                             const bool flg = window_flagged_t<WIDE>(ix, t, len);
-                            if (SW && sw_read) {
-                                if constexpr (SW) eval_swin2i<NW, !GROUP>(r2w, rni, len, ev, kSwPre - lofs, w);
+                            if (SW && sw_now) {
+                                if constexpr (SW) {
+                                    if (GROUP && grouped) eval_swin2i<NW, false>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                    else eval_swin2i<NW, true>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                }
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
                             if (flg) {

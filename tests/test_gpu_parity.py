@@ -138,7 +138,7 @@ def test_reads_of_129_to_512_bases(tmp_path, top, el_size):
     o.close()
     words, lens16, exc = bk.pack_reads(bases, offs, lens)
     with bk.Aligner(path, bk.AlignParams(max_subs=4)) as al:
-        for knobs in ([], [("heavy_thresh", 0)], [("heavy_thresh", 100)], [("use_flat", 0)], [("use_isa", 0)], [("use_tgt2", 0)]):
+        for knobs in ([], [("heavy_thresh", 0)], [("heavy_thresh", 100)], [("use_flat", 0)], [("use_isa", 0)], [("use_tgt2", 0)], [("use_swin", 0)]):
             for k, v in knobs:
                 al.tune(k, v)
             al.counters(reset=True)
