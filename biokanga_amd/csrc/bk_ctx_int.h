@@ -50,6 +50,8 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
+    int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
+    bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases
     int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
     int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)

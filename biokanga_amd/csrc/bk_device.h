@@ -69,6 +69,7 @@ struct DevIndex {
     uint32_t max_id;
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
+    const uint2 *ktab2;         // instead of ktab32 when the second-level keys exist: {ktab32[c], k2[ktab32[c]]} - a bucket of one suffix needs no second line
     const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
     const uint4 *swin;          // suffix-ordered windows: for every suffix array index i the kSwBases bases of the 2-bit target from

@@ -51,6 +51,7 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s);
@@ -189,6 +190,8 @@ int build_ktab(bk_ctx *c)
     c->d_ktab = nullptr;
     c->ix.ktab32 = nullptr;
     c->ix.ktab64 = nullptr;
+    c->ix.ktab2 = nullptr;
+    c->ktab_is2 = false;
     c->ix.k = 0;
     if (!c->use_ktab) return BK_OK;
     int k = c->k_req > 0 ? c->k_req : pick_k(c->ix.n);
@@ -237,6 +240,24 @@ int build_k2(bk_ctx *c)
         return BK_OK;
     }
     c->ix.k2 = c->d_k2;
+    // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
+    if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
+        const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        void *d2 = nullptr;
+        if (n_entries * 8 + (total_b / 5) < free_b && hipMalloc(&d2, n_entries * 8) == hipSuccess) {
+            launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, c->ix.n, d2, c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            free_dev(c->d_ktab);
+            c->d_ktab = d2;
+            c->ktab_bytes = (size_t)n_entries * 8;
+            c->ktab_is2 = true;
+            c->ix.ktab32 = nullptr;
+            c->ix.ktab2 = reinterpret_cast<const uint2 *>(d2);
+        } else
+            (void)hipGetLastError();
+    }
     return BK_OK;
 }
 
@@ -1189,6 +1210,8 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->n_tgt4_words = src->n_tgt4_words;
     c->sort_shift = src->sort_shift;
     c->ktab64 = src->ktab64;
+    c->ktab_is2 = src->ktab_is2;
+    c->use_ktab2 = src->use_ktab2;
     c->ktab_bytes = src->ktab_bytes;
     c->nflag_bytes = src->nflag_bytes;
     c->use_ktab = src->use_ktab; c->k_req = src->k_req; c->use_k2 = src->use_k2; c->use_isa = src->use_isa; c->use_wave = src->use_wave; c->use_tgt2 = src->use_tgt2;
@@ -1220,7 +1243,11 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     if (ok && hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; rc = BK_ERR_INTERNAL; }
     if (!ok) { bk_ctx_destroy(c); return rc; }
     c->ix.tgt4 = c->d_tgt4; c->ix.sa_lo = c->d_sa_lo; c->ix.sa_hi = c->d_sa_hi;
-    if (c->d_ktab) { if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab; else c->ix.ktab32 = (const uint32_t *)c->d_ktab; }
+    if (c->d_ktab) {
+        if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+        else if (c->ktab_is2) c->ix.ktab2 = (const uint2 *)c->d_ktab;
+        else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
+    }
     c->ix.k2 = c->d_k2; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
     clk.lap("index image copied from the first device");
     rc = setup_entries(c, src->entries.data(), (uint32_t)src->entries.size());
@@ -1283,6 +1310,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = n == "use_ktab" ? c->use_ktab : c->ix.k;
         if (n == "use_ktab") c->use_ktab = value ? 1 : 0;
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
+        int rc = build_ktab(c);
+        if (!rc) rc = build_k2(c);
+        return rc ? rc : old;
+    }
+    if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
+        int64_t old = c->use_ktab2;
+        c->use_ktab2 = value ? 1 : 0;
         int rc = build_ktab(c);
         if (!rc) rc = build_k2(c);
         return rc ? rc : old;

@@ -311,6 +311,7 @@ __device__ __forceinline__ uint32_t flags_to_bits16(uint64_t f)   // f: flags at
 
 __device__ __forceinline__ uint64_t ktab_get(const DevIndex &ix, uint64_t c)
 {
+    if (ix.ktab2) return (uint64_t)ix.ktab2[c].x;
     return ix.ktab32 ? (uint64_t)ix.ktab32[c] : ix.ktab64[c];
 }
 
@@ -1175,6 +1176,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     uint32_t cix[ILP];                  // entry of iv32 this lane reads (phase > 0) or writes (phase 0); kNoIv32 = neither
     uint2 cv[ILP];
     bool cached[ILP];
+    uint32_t key0[ILP];
     // stage 1: the item, its read row
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
@@ -1228,10 +1230,18 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
         nval[u] = kKindFull << kKindShift;
         push[u] = on[u];
         have_code[u] = on[u] && !cached[u] && cl[u] >= k && !(p0[u] & 0x4444444444444444ULL & top_mask(k));
+        key0[u] = kK2Above;
         if (have_code[u]) {
             const uint64_t code = (uint64_t)(squeeze2(p0[u]) >> (32 - 2 * k));
-            lo[u] = ktab_get(ix, code);
-            hi[u] = ktab_get(ix, code + 1);
+            if (ix.ktab2 != nullptr) {
+                // {bucket start, second-level key of its first suffix}: a bucket of one - every second one a read of a unique region
+                // meets, and a third of those its other strand runs into by chance - is settled by the line that names it
+                const uint2 e0 = ix.ktab2[code], e1 = ix.ktab2[code + 1];
+                lo[u] = e0.x; hi[u] = e1.x; key0[u] = e0.y;
+            } else {
+                lo[u] = ktab_get(ix, code);
+                hi[u] = ktab_get(ix, code + 1);
+            }
         }
     }
     PROFS(1);
@@ -1243,7 +1253,8 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     for (int u = 0; u < ILP; u++) {
         const uint64_t size = hi[u] - lo[u];
 #pragma unroll
-        for (uint32_t j = 0; j < kInlineBucket; j++) key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ix.k2[lo[u] + j] : kK2Above;
+        for (uint32_t j = 0; j < kInlineBucket; j++)
+            key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ((j == 0 && ix.ktab2 != nullptr) ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
     }
     PROFS(2);
     // stage 4: results
@@ -4756,6 +4767,21 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
         else BK_ORPH(8);
 #undef BK_ORPH
     }
+}
+
+// k-mer table entries {bucket start, second-level key of the bucket's first suffix} (DevIndex::ktab2)
+__global__ void __launch_bounds__(256) k_make_ktab2(const uint32_t *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries, uint64_t n,
+                                                    uint2 *__restrict__ out)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lo = tab[c];
+        out[c] = make_uint2(lo, lo < n ? k2[lo] : 0u);
+    }
+}
+
+void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out));
 }
 
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s)

@@ -152,6 +152,7 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  * each other through these.  name =
  *   "kmer_bits" (k of the k-mer table, 2..16)   "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)
  *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
+ *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
  *   "sort_lists" (bit 0: search work list grouped by bucket, bit 1: wave list sorted, bit 2: .. longest read first)
  *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)
  *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
