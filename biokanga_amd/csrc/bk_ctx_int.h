@@ -138,6 +138,7 @@ struct DevReads {
 // batch driver entry points of bk_engine.cpp used by the stream pipeline (all blocking on `s`: the phase loop reads the
 // active counts back between phases)
 int engine_align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0);
+void release_swin(bk_ctx *c);
 int engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_hit *d_hits, uint32_t maxlen, const bk_pe_params *pe, hipStream_t s,
                        bk_seg2 *seg2_host = nullptr, bk_seg2 *seg2_dev = nullptr);
 // packed batches: lens16 -> d_lens32, word offsets of the reads -> d_offs (scan), the batch checked (word count, read lengths,

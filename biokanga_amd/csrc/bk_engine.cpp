@@ -707,6 +707,11 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
     const uint32_t ivc = iv_cores_for(c, maxlen);
     int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u, ivc);
+    if (rc && c->d_swin) {                        // the window array is a luxury: it goes before a batch is refused for want of memory
+        (void)hipGetLastError();
+        bk::release_swin(c);
+        rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u, ivc);
+    }
     if (rc) return rc;
 
     DevBatch b{};
@@ -901,6 +906,24 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
 // The suffix-ordered window array (DevIndex::swin, 48 bytes per suffix) is built when the first batch it can serve arrives - reads of up
 // to kSwLen bases whose core offsets stay within kSwPre - and only if, next to it, the HBM still holds this batch's scratch with room to
 // spare: it trades capacity (149 GB for a 3.1 Gbp index on a 288 GB device) for locality.
+}  // (anonymous)
+
+// frees the suffix-ordered window array (and does not build it again): called when something else needs the HBM
+void bk::release_swin(bk_ctx *c)
+{
+    if (!c || !c->d_swin) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
+    free_dev(c->d_swin);
+    c->d_swin = nullptr;
+    c->ix.swin = nullptr;
+    c->swin_denied = true;
+    fprintf(stderr, "biokanga_amd: window array released to make room\n");
+}
+
+namespace {
+
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
     if (c->d_swin || !c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;

@@ -380,13 +380,32 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
     hipError_t e = hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_al, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_dn, hipStreamNonBlocking);
+    auto alloc_slots = [&]() {
+        hipError_t e2 = hipSuccess;
+        for (Slot &sl : s->slots) {
+            // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64);
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
+        }
+        return e2;
+    };
+    if (e == hipSuccess) {
+        e = alloc_slots();
+        if (e == hipErrorOutOfMemory && ctx->d_swin) {
+            // the context's window array (half of the HBM) goes before the pipeline is refused its buffers
+            (void)hipGetLastError();
+            for (Slot &sl : s->slots) {
+                for (void **pp : {(void **)&sl.d_bases, (void **)&sl.d_lens16, (void **)&sl.d_offs, (void **)&sl.d_lens, (void **)&sl.d_out})
+                    if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+            }
+            bk::release_swin(ctx);
+            e = alloc_slots();
+        }
+    }
     for (Slot &sl : s->slots) {
-        // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
-        if (e == hipSuccess) e = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64);
-        if (e == hipSuccess) e = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
-        if (e == hipSuccess) e = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
-        if (e == hipSuccess) e = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
-        if (e == hipSuccess) e = hipMalloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_al, hipEventDisableTiming);
     }
