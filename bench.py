@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the `biokanga align` hot path on MI355X.
 
-Metric (BASELINE.json): aligned reads/s, results identical to the reference, 100 bp SE reads vs a
-GRCh38-scale index.  One "step" = one pass of the hot path (bk_align_batch_device: pack, SA-interval
-search, candidate walk + Hamming extension, classification - every AlignReads phase) over one batch
-of synthetic reads that is already resident in HBM, followed by the path's only exchange step, the
-sum-reduction of the per-sequence hit counts (RCCL all-reduce when N > 1).
+Metric (BASELINE.json): aligned reads/s, results identical to the reference, 100 bp SE reads vs a GRCh38-scale index.
+One "step" = one pass of the hot path over one batch of synthetic reads: pack, SA-interval search, candidate walk + Hamming
+extension, classification - every AlignReads phase - followed by the path's only exchange step, the sum-reduction of the
+per-sequence hit counts (RCCL all-reduce when N > 1).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+`value` is the metric's own clock (T_align: first batch submitted -> last result back): the reads of every step leave
+pinned HOST buffers (2 bit/base, bk_stream_submit_packed), cross PCIe while the batch before them runs through the phases, and every
+bk_hit record is back in HOST memory when the clock stops.  `value_kernel_only` is the same steps with reads and results resident in
+HBM (bk_align_batch_device).  Both are measured in the index layout `biokanga align` itself would pick for the configuration's read
+count (the 149 GB suffix-ordered window array only from 400 M reads per device on, host/biokanga_main.cpp) and, beside it, in the
+other layout (`layouts`).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus N            (no WORLD_SIZE in the environment: starts the N ranks itself, same launcher)
     python bench.py --config C3         (2 x 150 bp paired ends, -s5 -U3 -d200 -D400: SE pass + PE association per step)
 
-Workload at N = 1: BASELINE.json configs[1] restated over a synthetic genome (SURVEY.md §8d "C2"):
+Workload at N = 1: BASELINE.json configs[1] restated over a synthetic genome (SURVEY.md 8d "C2"):
 50 M x 100 bp SE reads, 0-3 substitutions, vs a 24-sequence 3.1 Gbp GRCh38-like genome, `-s3`.
 Reads are sharded over ranks with the index replicated per GPU (weak scaling: per-GPU batch fixed).
 The genome, its suffix array (built on the GPU by bk_build_sa_device) and the reads are generated
@@ -29,6 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# `biokanga align` builds the suffix-ordered window array (149 GB, 2.6 s of set-up at 3.1 Gbp) from this many reads per device on, or
+# when told to with --window-array (host/biokanga_main.cpp, cmd_align): the layout the headline is measured in follows the same rule
+CLI_WINDOW_ARRAY_MIN_READS = 400_000_000
 
 
 def effective_cpus():
@@ -337,12 +346,40 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def live_traffic(kernel, extra_args, budget_s=240):
-    """HBM bytes per launch of `kernel`, OBSERVED in this run: two child processes repeat one step of the same workload under
+def fetch_correction(kernel, window_array):
+    """FETCH_SIZE calibration for `kernel`'s access pattern (MI355X_MICROARCH.md: the counter reports HALF of a wide coalesced
+    16 B/lane streaming read).  Our patterns were measured with tools/rand_access_bench under `rocprofv3 --pmc FETCH_SIZE`
+    (profiles/*_fetch_calibration.csv): random 8-byte loads count 64.0 B each and random 80-byte windows 96 B (no correction) - what
+    the search passes, k_flat and k_wave WITHOUT the window array do; runs of 64 consecutive 48-byte window-array entries plus their
+    coalesced suffix array elements - k_wave WITH the window array - count about half.  Returns (factor on FETCH_SIZE, source)."""
+    if not (kernel == "k_wave" and window_array):
+        return 1.0, "random-line pattern: FETCH_SIZE counts 64.0 B per random 8-byte load (calibrated, no correction)"
+    import csv
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fetch_calibration.csv"))):
+        rows, counts = {}, {}
+        for line in open(f):
+            if line.startswith("calib:"):
+                for name, n in re.findall(r"(k_calib_\w+): (\d+) entries", line):
+                    counts[name] = int(n)
+            elif line.startswith("k_calib"):
+                r = next(csv.reader([line]))
+                rows[r[0]] = float(r[3]) * 1024.0                        # FETCH_SIZE is in KiB
+        for name, per_entry in (("k_calib_wave", 52), ("k_calib_runs1", 48)):
+            if name in rows and name in counts:
+                best = (counts[name] * per_entry / rows[name], f"{os.path.basename(f)}: {name}, {counts[name]} entries of {per_entry} B "
+                        f"read as {rows[name] / counts[name]:.1f} B each")
+                break
+    return best if best else (2.0, "MI355X_MICROARCH.md: wide coalesced 16 B/lane reads count half (no calibration file found)")
+
+
+def live_traffic(kernel, extra_args, window_array, budget_s=240):
+    """HBM bytes of `kernel` in ONE step of this workload, OBSERVED in this run: two child processes repeat one step under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only - MI355X_MICROARCH.md's
-    recipe; KiB units; no 1/2 correction: calibrated at 64.0 B per random 8-byte load and 96 B per 80-byte window in this path's own
-    access patterns, profiles/*_fetch_calibration.csv).  Children, not an exec: this process has initialised the GPU.
-    Returns (bytes of the whole step, description) or (None, reason)."""
+    recipe; KiB units).  Children, not an exec: this process has initialised the GPU.
+    Returns ((fetch bytes as counted, write bytes, launches of the kernel in that step), description) or (None, reason)."""
     import csv
     import re
     import shutil
@@ -352,15 +389,14 @@ def live_traffic(kernel, extra_args, budget_s=240):
         return None, "rocprofv3 not on PATH"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself being profiled (no nested profiler)"
-    members = {"k_search": ("k_search_a", "k_search_b"), "k_wave": ("k_wave",), "k_flat": ("k_flat",)}[kernel]
-    tot = 0.0
+    got = {}
     launches = None
     tmp = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child"] + extra_args
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--window-array", "on" if window_array else "off"] + extra_args
             t0 = time.time()
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=budget_s)
@@ -369,24 +405,23 @@ def live_traffic(kernel, extra_args, budget_s=240):
             files = [os.path.join(dp, f) for dp, _dn, fn in os.walk(d) for f in fn if f.endswith("_counter_collection.csv")]
             if not files:
                 return None, "no counter_collection.csv written"
-            per = {m: [0.0, 0] for m in members}
+            tot, n = 0.0, 0
             seen = set()
             for f in files:
                 for row in csv.DictReader(open(f)):
                     m = re.search(r"bk::(k_\w+)", row["Kernel_Name"])
                     key = (row["Process_Id"], row["Dispatch_Id"])
-                    if m and m.group(1) in per and row["Counter_Name"] == counter and key not in seen:
+                    if m and m.group(1) == kernel and row["Counter_Name"] == counter and key not in seen:
                         seen.add(key)
-                        per[m.group(1)][0] += float(row["Counter_Value"])
-                        per[m.group(1)][1] += 1
-            log(f"live traffic: {counter}: files {len(files)}, " + ", ".join(f"{k}: {v[1]} launches, {v[0] * 1024 / 1e9:.1f} GB" for k, v in per.items()))
-            if any(v[1] == 0 for v in per.values()):
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            log(f"live traffic: {counter}: {kernel}: {n} launches, {tot * 1024 / 1e9:.1f} GB as counted ({time.time() - t0:.0f}s)")
+            if n == 0:
                 return None, f"kernel {kernel} not in the {counter} pass"
-            tot += sum(v[0] for v in per.values()) * 1024.0          # the whole step: the child may cut the batch into more chunks
-            launches = per[members[0]][1]                            # (it shares the HBM with this process), so per-launch follows below
-            log(f"live traffic: {counter} pass {time.time() - t0:.0f}s, {launches} launches of {members[0]}")
-        return tot, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of ONE step of this workload ({launches} launches there); "
-                     f"bytes of that step divided by this run's launches per step")
+            got[counter] = tot * 1024.0
+            launches = n
+        return (got["FETCH_SIZE"], got["WRITE_SIZE"], launches), \
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of ONE step of this workload; bytes of that step divided by this run's launches per step"
     except Exception as e:
         return None, f"live counter passes failed: {e!r}"
     finally:
@@ -394,128 +429,136 @@ def live_traffic(kernel, extra_args, budget_s=240):
 
 
 def profiled_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
-    (profiles/*_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB units,
-    calibrated in this path's access patterns - see profiles/README.md).  bench.py cannot collect
-    counters itself, so this is the last profiled value for the default workload, or None."""
+    """(fetch bytes as counted, write bytes) per launch of `kernel` from the last committed rocprofv3 PMC summary of this command
+    (profiles/*_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KiB units), or None."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
     if not files:
         return None, None
-    members = {"k_search": ("k_search_a", "k_search_b"), "k_wave": ("k_wave",), "k_flat": ("k_flat",)}[kernel]
-    tot = 0.0
-    seen = set()
+    got = {}
     for r in csv.DictReader(open(files[-1])):
-        if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and r["kernel"].split("<")[0] in members:
-            tot += float(r["mean_per_dispatch"]) * 1024.0
-            seen.add((r["kernel"].split("<")[0], r["counter"]))
-    if len(seen) != 2 * len(members):
+        if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and r["kernel"].split("<")[0] == kernel:
+            got[r["counter"]] = got.get(r["counter"], 0.0) + float(r["mean_per_dispatch"]) * 1024.0
+    if len(got) != 2:
         return None, None
-    return tot, os.path.basename(files[-1])
+    return (got["FETCH_SIZE"], got["WRITE_SIZE"]), os.path.basename(files[-1])
 
 
-def host_resident_leg(al, rd_bases, rd_lens, d_out, args, barrier, all_reduce, dev, pe_params=None):
-    """The metric's real T_align (first batch submitted -> last result back) with reads and results in HOST
-    memory: the same reads leave pinned host buffers in batches through bk_stream_submit, cross PCIe while the previous
-    batch runs through the AlignReads phases, and every bk_hit record is back in host memory when the clock stops.
-    Checked bit for bit against the records the kernel-only steps left in HBM."""
-    import numpy as np
-    import torch
-    import biokanga_amd as bk
-    n, L = args.reads, args.read_len
-    t0 = time.time()
-    h_bases = bk.host_array(n * L, np.uint8)
-    h_lens = bk.host_array(n, np.uint32)
-    torch.from_numpy(h_bases).copy_(rd_bases[: n * L])
-    torch.from_numpy(h_lens.view(np.int32)).copy_(rd_lens[:n])
-    h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(2)]
-    expect = d_out.cpu().numpy().view(bk.HIT_DTYPE)
-    packed = args.stream_form == "packed"
-    if packed:
-        # the loader's side of the boundary: reads leave host memory at 2 bit/base (bk_pack_reads: host threads, untimed set-up here
-        # as parsing is), 16-bit lengths, and the list of the bases that are not a,c,g,t
-        tp = time.time()
-        p_words, p_lens16, p_exc = bk.pack_reads(h_bases, None, h_lens, pinned=True)
-        wpr = (L + 15) // 16
-        log(f"host-resident leg: {n} reads packed to {p_words.nbytes / n:.1f} + 2 B/read (+ {len(p_exc)} non-acgt bases) in {time.time() - tp:.1f}s")
-    B = max(2, min(args.stream_batch or n, n))
-    B -= B & 1
-    cuts = list(range(0, n, B)) + [n]
-    # The first step grows its batches by a factor of three (6 %, 18 %, 76 % of a batch): the pipeline has nothing to overlap the very first
-    # upload with, so the smaller it is the sooner the kernels start, and a batch crosses PCIe about 3.5 times faster than it is aligned, so
-    # each upload still hides behind the batch before it.  Small batches cost more per read (every phase's wave-per-read launch lasts at
-    # least as long as its heaviest read: 3 M reads take 3.7 ns each, 50 M 2.0 ns), hence no finer ramp than that.
-    def even(v):
-        return max(2, int(v) & ~1)
-    first = min(B, n)
-    ramp = [0, even(0.06 * first), even(0.24 * first)] if first >= 1000 else [0]
-    cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
-    # .. and the last step ends on a tenth of a batch: the download of the very last batch has nothing to hide behind either
-    down = [n - even(0.1 * first)] if first >= 1000 else []
-    cuts9 = ([c for c in cuts if c < down[0]] + down + [n]) if down else cuts
-    log(f"host-resident leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batches of <= {B} reads per step "
-        f"(first step: batches of {[b - a for a, b in zip(cuts0[:-1], cuts0[1:])]}; last step: {[b - a for a, b in zip(cuts9[:-1], cuts9[1:])]})")
-    result = {}
-    with bk.Stream(al, B, B * L, depth=3, pe=pe_params) as st:
-        exc_of = {}
-        if packed:
-            er = p_exc["read"]
-            for lo, hi in set(zip(cuts0[:-1], cuts0[1:])) | set(zip(cuts[:-1], cuts[1:])) | set(zip(cuts9[:-1], cuts9[1:])):
+class HostLeg:
+    """The metric's own clock (SURVEY.md 8d T_align: first batch submitted -> last result back) with reads and results in HOST
+    memory: the same reads leave pinned host buffers in batches through bk_stream_submit[_packed], cross PCIe while the previous
+    batch runs through the AlignReads phases, and every bk_hit record is back in host memory when the clock stops."""
+
+    def __init__(self, rd_bases, rd_lens, args):
+        import numpy as np
+        import torch
+        import biokanga_amd as bk
+        self.args = args
+        n, L = args.reads, args.read_len
+        t0 = time.time()
+        self.h_lens = bk.host_array(n, np.uint32)
+        torch.from_numpy(self.h_lens.view(np.int32)).copy_(rd_lens[:n])
+        self.h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(2)]
+        self.packed = args.stream_form == "packed"
+        if self.packed:
+            # the loader's side of the boundary: reads leave host memory at 2 bit/base (bk_pack_reads: host threads, untimed set-up here
+            # as parsing is), 16-bit lengths, and the list of the bases that are not a,c,g,t
+            h_bases = rd_bases[: n * L].cpu().numpy()
+            self.p_words, self.p_lens16, self.p_exc = bk.pack_reads(h_bases, None, self.h_lens, pinned=True)
+            del h_bases
+            self.wpr = (L + 15) // 16
+            log(f"host leg: {n} reads packed to {self.p_words.nbytes / n:.1f} + 2 B/read (+ {len(self.p_exc)} non-acgt bases)")
+        else:
+            self.h_bases = bk.host_array(n * L, np.uint8)
+            torch.from_numpy(self.h_bases).copy_(rd_bases[: n * L])
+        B = max(2, min(args.stream_batch or n, n))
+        B -= B & 1
+        self.B = B
+        cuts = list(range(0, n, B)) + [n]
+
+        # The first step grows its batches by a factor of three (6 %, 18 %, 76 % of a batch): the pipeline has nothing to overlap the very
+        # first upload with, so the smaller it is the sooner the kernels start, and a batch crosses PCIe about 3.5 times faster than it
+        # is aligned, so each upload still hides behind the batch before it.  Small batches cost more per read (every phase's
+        # wave-per-read launch lasts at least as long as its heaviest read), hence no finer ramp than that.
+        def even(v):
+            return max(2, int(v) & ~1)
+        first = min(B, n)
+        ramp = [0, even(0.06 * first), even(0.24 * first)] if first >= 1000 else [0]
+        self.cuts = cuts
+        self.cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
+        # .. and the last step ends on a tenth of a batch: the download of the very last batch has nothing to hide behind either
+        down = [n - even(0.1 * first)] if first >= 1000 else []
+        self.cuts9 = ([c for c in cuts if c < down[0]] + down + [n]) if down else cuts
+        self.exc_of = {}
+        if self.packed:
+            er = self.p_exc["read"]
+            for lo, hi in set(zip(self.cuts0[:-1], self.cuts0[1:])) | set(zip(cuts[:-1], cuts[1:])) | set(zip(self.cuts9[:-1], self.cuts9[1:])):
                 a, z = np.searchsorted(er, lo), np.searchsorted(er, hi)
                 e = bk.host_array(max(1, z - a), bk.NBASE_DTYPE)[: z - a]
-                e[:] = p_exc[a:z]
+                e[:] = self.p_exc[a:z]
                 e["read"] -= lo                                      # exception read numbers are batch-relative
-                exc_of[(lo, hi)] = e
+                self.exc_of[(lo, hi)] = e
+        log(f"host leg: pinned buffers ready in {time.time() - t0:.1f}s; {len(cuts) - 1} batch(es) of <= {B} reads per step "
+            f"(first step: batches of {[b - a for a, b in zip(self.cuts0[:-1], self.cuts0[1:])]}; last step: {[b - a for a, b in zip(self.cuts9[:-1], self.cuts9[1:])]})")
 
-        def one_step(k, first=False, last=False):
-            out = h_out[k & 1]
-            cc = cuts0 if first else (cuts9 if last else cuts)
-            if packed:
-                return [st.submit_packed(p_words[lo * wpr: hi * wpr], p_lens16[lo:hi], exc_of[(lo, hi)], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
-            return [st.submit(h_bases[lo * L: hi * L], None, h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
-        for t in one_step(0):            # warm-up (buffers touched, scratch sized)
-            st.wait(t)
-        st.stats(reset=True)
-        al.timing(reset=True)
-        barrier()
-        t_start = time.time()
-        tickets = []
-        for k in range(args.stream_steps):
-            tickets += one_step(k, first=(k == 0), last=(k == args.stream_steps - 1 and k > 0))
-            # keep at most one step of tickets un-waited so that the two result buffers are never overwritten early
-            while len(tickets) > len(cuts) - 1:
-                st.wait(tickets.pop(0))
-        for t in tickets:
-            st.wait(t)
-        barrier()
-        elapsed = time.time() - t_start
-        stats = st.stats()
-        tim = al.timing()
-    if all_reduce is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        import torch.distributed as dist
-        all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    same = all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in h_out[: min(2, args.stream_steps)])
-    total = n * args.stream_steps * world
-    result.update({"value": total / elapsed, "unit": "reads/s", "steps": args.stream_steps, "reads_per_step_per_gpu": n,
-                   "batch_reads": B, "depth": 3, "seconds": elapsed, "form": "packed: 2 bit/base words + 16-bit lengths + non-acgt list (bk_stream_submit_packed)" if packed else "1 byte/base (bk_stream_submit)",
-                   "t_align_first_submit_to_last_result_s": stats["seconds_first_submit_to_last_result"],
-                   "pcie_bytes_per_read": {"h2d": stats["bytes_h2d"] / max(1, stats["reads"]), "d2h": stats["bytes_d2h"] / max(1, stats["reads"])},
-                   "device_ms_per_step": tim["ms_total"] / max(1, args.stream_steps),
-                   "device_ms_per_step_by_stage": {k: round(v / max(1, args.stream_steps), 2) for k, v in tim.items() if k.startswith("ms_") and k != "ms_total"},
-                   "results_bit_identical_to_kernel_only_steps": same,
-                   "note": "host pinned buffers in -> host bk_hit out through bk_stream_* (3 HIP streams)"})
-    return result
+    def run(self, al, warmup, steps, barrier, all_reduce, dev, pe_params=None):
+        """`warmup` untimed steps, then exactly `steps` steps between two barriers; returns the leg's record"""
+        import torch
+        import biokanga_amd as bk
+        n, L = self.args.reads, self.args.read_len
+        with bk.Stream(al, self.B, self.B * L, depth=3, pe=pe_params) as st:
+            def one_step(k, first=False, last=False):
+                out = self.h_out[k & 1]
+                cc = self.cuts0 if first else (self.cuts9 if last else self.cuts)
+                if self.packed:
+                    return [st.submit_packed(self.p_words[lo * self.wpr: hi * self.wpr], self.p_lens16[lo:hi], self.exc_of[(lo, hi)], out[lo:hi])
+                            for lo, hi in zip(cc[:-1], cc[1:])]
+                return [st.submit(self.h_bases[lo * L: hi * L], None, self.h_lens[lo:hi], out[lo:hi]) for lo, hi in zip(cc[:-1], cc[1:])]
+            for w in range(warmup):          # (buffers touched, scratch sized)
+                for t in one_step(w):
+                    st.wait(t)
+            st.stats(reset=True)
+            al.timing(reset=True)
+            barrier()
+            t_start = time.time()
+            tickets = []
+            for k in range(steps):
+                tickets += one_step(k, first=(k == 0), last=(k == steps - 1 and k > 0))
+                # keep at most one step of tickets un-waited so that the two result buffers are never overwritten early
+                while len(tickets) > len(self.cuts) - 1:
+                    st.wait(tickets.pop(0))
+            for t in tickets:
+                st.wait(t)
+            barrier()
+            elapsed = time.time() - t_start
+            stats = st.stats()
+            tim = al.timing(reset=True)
+        if all_reduce is not None:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        return {"value": n * steps * world / elapsed, "unit": "reads/s", "steps": steps, "warmup": warmup, "reads_per_step_per_gpu": n,
+                "batch_reads": self.B, "depth": 3, "seconds": elapsed, "ms_per_step": elapsed / steps * 1e3,
+                "form": "packed: 2 bit/base words + 16-bit lengths + non-acgt list (bk_stream_submit_packed)" if self.packed else "1 byte/base (bk_stream_submit)",
+                "t_align_first_submit_to_last_result_s": stats["seconds_first_submit_to_last_result"],
+                "pcie_bytes_per_read": {"h2d": stats["bytes_h2d"] / max(1, stats["reads"]), "d2h": stats["bytes_d2h"] / max(1, stats["reads"])},
+                "device_ms_per_step": tim["ms_total"] / max(1, steps),
+                "device_ms_per_step_by_stage": {k: round(v / max(1, steps), 2) for k, v in tim.items() if k.startswith("ms_") and k != "ms_total"},
+                "note": "host pinned buffers in -> host bk_hit out through bk_stream_* (3 HIP streams)"}
+
+    def same_as(self, expect, steps):
+        import numpy as np
+        return all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in self.h_out[: min(2, steps)])
 
 
 def metric_text(args, cfg, E):
     """BASELINE.json's metric, worded for the configuration that was actually run (C2 is the headline's own)"""
     shape = f"2x{args.read_len} bp PE" if cfg["pe"] else f"{args.read_len} bp SE"
     genome = "GRCh38" if E == 4 else "17 Gbp wheat-like genome (5-byte .sfx)"
-    return f"aligned reads/s (SAM-identical) on {shape} vs {genome}, 1->8 MI355X; reads resident in HBM when the clock starts"
+    return f"aligned reads/s (SAM-identical) on {shape} vs {genome}, 1->8 MI355X"
 
 
 CONFIGS = {
@@ -537,7 +580,7 @@ CONFIGS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="C2 = BASELINE.json's headline workload (default); C3 = 2x150 bp paired ends; "
                                                                              "C5 = the same pairs against a 17 Gbp index with 5-byte suffix elements")
@@ -553,11 +596,14 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help="(internal) one step only, nothing reported: what the live counter passes profile")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
-    ap.add_argument("--stream-steps", type=int, default=5, help="steps of the host-resident leg (bk_stream_*: host buffers in -> host "
-                                                                "bk_hit out, PCIe overlapped with the kernels); 0 disables it")
-    ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the host-resident leg's reads cross PCIe: "
+    ap.add_argument("--window-array", default="policy", choices=["policy", "on", "off"],
+                    help="index layout of the headline: 'policy' = what `biokanga align` picks for this many reads per device (the "
+                         "suffix-ordered window array from 400 M reads on); the other layout is measured beside it")
+    ap.add_argument("--no-other-layout", action="store_true", help="measure the headline's index layout only")
+    ap.add_argument("--no-host-leg", action="store_true", help="kernel-only steps only (profiling runs): `value` is then the kernel-only rate and says so")
+    ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the reads cross PCIe: "
                     "2 bit/base (bk_stream_submit_packed) or 1 byte/base (bk_stream_submit)")
-    ap.add_argument("--stream-batch", type=int, default=0, help="reads per submitted batch of the host-resident leg (0 = a whole step; the first step ramps up to it)")
+    ap.add_argument("--stream-batch", type=int, default=0, help="reads per submitted batch of the host-in / host-out steps (0 = a whole step; the first step ramps up to it)")
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
@@ -565,10 +611,10 @@ def main():
     ap.add_argument("--force-el5", action="store_true", help="experiments: 5-byte suffix elements (the > 4 Gbp kernels) on a smaller genome")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to bk_ctx_tune (repeatable)")
-    ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the steps for each value and log device ms")
+    ap.add_argument("--sweep", default="", help="name=v1,v2,..: re-time the kernel-only steps for each value and log device ms")
     args = ap.parse_args()
     if args.pmc_child:
-        args.steps, args.warmup, args.cpu_baseline_secs, args.stream_steps, args.no_live_traffic = 1, 0, 0.0, 0, True
+        args.steps, args.warmup, args.cpu_baseline_secs, args.no_live_traffic, args.no_host_leg, args.no_other_layout = 1, 0, 0.0, True, True, True
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -695,10 +741,55 @@ def main():
     def step():
         run_step(rd_bases, rd_offs, rd_lens, args.reads, out)
 
-    for _ in range(args.warmup):
-        step()
-    first_out = out.clone() if args.warmup > 0 else None       # results of an untimed step, to check repeatability
+    # ---------------------------------------------------------------- the index layout of the headline, and the other one
+    policy_on = args.reads >= CLI_WINDOW_ARRAY_MIN_READS
+    headline_on = {"policy": policy_on, "on": True, "off": False}[args.window_array]
+    host = None
+    if not args.no_host_leg:
+        try:
+            host = HostLeg(rd_bases, rd_lens, args)
+        except Exception as e:       # reporting only - never lose the measured line
+            log(f"host leg unavailable: {e!r}")
+
+    def measure(window_array):
+        """both clocks in one index layout: `warmup` untimed + exactly `steps` timed steps each, a barrier + device synchronisation on
+        both sides of the timed steps, the maximum over ranks"""
+        res = {}
+        t_set = time.time()
+        al.tune("use_swin", 1 if window_array else 0)
+        step()                                             # (builds the window array when it is asked for, fits and serves these reads)
+        torch.cuda.synchronize()
+        t_first = time.time() - t_set
+        res["window_array_resident"] = al.tune("swin_resident", 0) == 1
+        for _ in range(max(0, args.warmup - 1)):
+            step()
+        first_out = out.clone()                            # results of an untimed step, to check repeatability
+        al.counters(reset=True)
+        al.timing(reset=True)
+        barrier()
+        t_start = time.time()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.time() - t_start
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res.update(kernel_only_elapsed=elapsed, ctr=al.counters(), tim=al.timing(reset=True),
+                   repeatable=bool(torch.equal(first_out, out)), first_step_s=t_first)
+        del first_out
+        res["hits"] = out.cpu().numpy().view(bk.HIT_DTYPE).copy()
+        if host is not None:
+            try:
+                res["host"] = host.run(al, args.warmup, args.steps, barrier, all_reduce if dist is not None else None, dev, pe_params)
+                res["host"]["results_bit_identical_to_kernel_only_steps"] = host.same_as(res["hits"], args.steps)
+            except Exception as e:
+                res["host"] = {"value": None, "error": repr(e)}
+        return res
+
     if args.sweep:
+        al.tune("use_swin", 1 if headline_on else 0)
         name, vals = args.sweep.split("=")
         for v in vals.split(","):
             al.tune(name, int(v))
@@ -709,108 +800,145 @@ def main():
             step()
             torch.cuda.synchronize()
             log(f"sweep {name}={v}: {1e3 * (time.time() - t1):.1f} ms/step wall; device {al.timing(reset=True)}")
-    al.counters(reset=True)
-    al.timing(reset=True)
-    barrier()
-    t_start = time.time()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.time() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ctr = al.counters()
-    tim = al.timing()
+    main_leg = measure(headline_on)
+    if headline_on and not main_leg["window_array_resident"]:
+        headline_on = False              # (asked for, but this index / these reads cannot have it: 5-byte elements, long reads, no room)
+    other_leg = None
+    if not args.no_other_layout and E == 4:
+        other_leg = measure(not headline_on)
+        if not headline_on and not other_leg["window_array_resident"]:
+            other_leg = None             # the library did not build it: there is no second layout to report
+        al.tune("use_swin", 1 if headline_on else 0)
     if os.environ.get("BK_DIAG"):
-        print("diag counters:", ctr, file=sys.stderr)
+        print("diag counters:", main_leg["ctr"], file=sys.stderr)
         import ctypes
         arr = (ctypes.c_ulonglong * 16)()
         if bk.load_library().bk_debug_prof(arr) == 0:
             print("diag prof:", list(arr), file=sys.stderr)
-    host_leg = None
-    if args.stream_steps > 0:
-        try:
-            host_leg = host_resident_leg(al, rd_bases, rd_lens, out, args, barrier, all_reduce if dist is not None else None, dev, pe_params)
-        except Exception as e:       # reporting only - never lose the measured line
-            host_leg = {"value": None, "error": repr(e)}
-    repeatable = bool(torch.equal(first_out, out)) if first_out is not None else None
-    del first_out
-    hits = out.cpu().numpy().view(bk.HIT_DTYPE)
+    ctr, tim, hits = main_leg["ctr"], main_leg["tim"], main_leg["hits"]
     accepted = int((hits["nar"] == 1).sum())
     total_reads = args.reads * world * args.steps
-    value = total_reads / elapsed
+    kernel_only_value = total_reads / main_leg["kernel_only_elapsed"]
+    host_leg = main_leg.get("host")
+    host_ok = bool(host_leg and host_leg.get("value"))
+    value = host_leg["value"] if host_ok else kernel_only_value
+    ms_per_step = host_leg["ms_per_step"] if host_ok else main_leg["kernel_only_elapsed"] / args.steps * 1e3
 
     multi = None
     if world > 1 and E == 4:
         multi = multi_gpu_legs(al, make_set, run_step, counts_dev, args, rank, world, dev, barrier, all_reduce, dist)
 
-    # roofline: algorithmic bytes over the kernel's summed launch time, measured with HIP
-    # events on the stream the kernels run on.  Per search: ceil(log2 N) * (E + 8); per candidate
-    # Hamming-extended: E + ceil(L/2).  The dominant kernel (largest share of device time) is quoted.
+    # roofline: algorithmic bytes over the kernel's summed launch time, measured with HIP events on the stream the
+    # kernels run on, in the headline's layout.  Per search: ceil(log2 N) * (E + 8) - the formula prices a search whichever of the two
+    # passes settles it, so the search passes are timed separately (bk_timing) but priced as one stage; per candidate
+    # Hamming-extended: E + ceil(L/2).  The dominant kernel = the one with the largest summed launch time.
     log2n = math.ceil(math.log2(n))
     per_search = log2n * (E + 8)
     per_cand = E + (args.read_len + 1) // 2
     io_bytes = args.reads * args.steps * ((args.read_len + 3) // 4 + 16)
-    # (k_search = passes k_search_a + k_search_b of one phase, timed together; k_flat = the block-cooperative
-    # extend kernel; k_wave = the wave-per-call kernel for repeat reads)
-    kern = {
-        "k_search": dict(bytes=ctr["n_search"] * per_search, ms=tim["ms_search"], launches=tim["n_search_launches"]),
-        "k_wave": dict(bytes=ctr["n_cand_heavy"] * per_cand, ms=tim["ms_heavy"], launches=tim["n_heavy_launches"]),
-        "k_flat": dict(bytes=(ctr["n_cand"] - ctr["n_cand_heavy"]) * per_cand, ms=tim["ms_extend"], launches=tim["n_extend_launches"]),
-    }
-    for k in kern.values():
-        k["GBs"] = k["bytes"] / max(1e-9, k["ms"] * 1e-3) / 1e9
-    # (the search stage is two kernels - pass A about 0.52 and pass B 0.41 of it under rocprofv3, profiles/ - so it only counts as the
-    # dominant KERNEL when 0.6 of it outlasts the others)
-    dom = max(kern, key=lambda k: kern[k]["ms"] * (0.6 if k == "k_search" else 1.0))
+
+    def kernels_of(c, t):
+        stage_bytes = c["n_search"] * per_search
+        k = {
+            "k_search_a": dict(bytes=stage_bytes, ms=t["ms_search_a"], launches=t["n_search_launches"], priced_with="k_search stage"),
+            "k_search_b": dict(bytes=stage_bytes, ms=t["ms_search_b"], launches=t["n_search_b_launches"], priced_with="k_search stage"),
+            "k_wave": dict(bytes=c["n_cand_heavy"] * per_cand, ms=t["ms_heavy"], launches=t["n_heavy_launches"]),
+            "k_flat": dict(bytes=(c["n_cand"] - c["n_cand_heavy"]) * per_cand, ms=t["ms_extend"], launches=t["n_extend_launches"]),
+        }
+        stage = dict(bytes=stage_bytes, ms=t["ms_search"], launches=t["n_search_launches"])
+        for q in list(k.values()) + [stage]:
+            q["GBs"] = q["bytes"] / max(1e-9, q["ms"] * 1e-3) / 1e9
+        for nm in ("k_search_a", "k_search_b"):
+            k[nm]["GBs"] = stage["GBs"]              # (a pass alone has no algorithmic-bytes figure of its own)
+        return k, stage
+
+    kern, search_stage = kernels_of(ctr, tim)
+    dom = max(kern, key=lambda q: kern[q]["ms"])
+    dom_ms, dom_launches = kern[dom]["ms"], kern[dom]["launches"]
     ach = kern[dom]["GBs"]
-    whole = (sum(k["bytes"] for k in kern.values()) + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
+    whole = (search_stage["bytes"] + kern["k_wave"]["bytes"] + kern["k_flat"]["bytes"] + io_bytes) / max(1e-9, tim["ms_total"] * 1e-3) / 1e9
     default_workload = (args.config == "C2" and args.reads == 50_000_000 and args.read_len == 100 and args.max_subs == 3 and total_bp == 3_100_000_000)
     # everything below runs in child processes (counter passes under rocprofv3, the command lines): this process hands its HBM back first
     if keep_index_for_baseline:
         seq = seq.cpu() if seq is not None else None
         rd_bases = rd_bases.cpu()
     al.close()
+    host = None
     del out, rd_offs, rd_lens, counts_dev
     if not keep_index_for_baseline:
         del rd_bases, seq
     torch.cuda.empty_cache()
-    traffic, traffic_src = (None, None)
+    traffic = traffic_raw = None
+    traffic_src = None
+    corr, corr_src = fetch_correction(dom, headline_on)
     if rank == 0 and world == 1 and not args.no_live_traffic and E == 4:       # (two more 17 Gbp set-ups would take minutes)
         child_args = ["--config", args.config, "--reads", str(args.reads), "--genome-mbp", str(args.genome_mbp)] + \
                      [x for kv in args.tune for x in ("--tune", kv)]
-        traffic, traffic_src = live_traffic(dom, child_args)
-        if traffic is None:
+        got, traffic_src = live_traffic(dom, child_args, headline_on)
+        if got is None:
             log(f"live traffic unavailable: {traffic_src}")
         else:
-            traffic /= max(1.0, kern[dom]["launches"] / max(1, args.steps))
-    if traffic is None and default_workload:
-        traffic, traffic_src = profiled_traffic(dom)
-        if traffic_src:
-            traffic_src = f"committed profile {traffic_src} (not observed in this run)"
+            per = max(1.0, dom_launches / max(1, args.steps))                   # this run's launches per step
+            traffic_raw = (got[0] + got[1]) / per
+            traffic = (got[0] * corr + got[1]) / per
+    if traffic is None and default_workload and not headline_on:
+        got, src = profiled_traffic(dom)
+        if got:
+            traffic_raw, traffic = got[0] + got[1], got[0] * corr + got[1]
+            traffic_src = f"committed profile {src} (not observed in this run)"
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, kern[dom]["launches"]),
-                "avg_launch_ms": kern[dom]["ms"] / max(1, kern[dom]["launches"]),
-                "per_kernel": {k: {"algorithmic_GBs": round(v["GBs"], 1), "ms": round(v["ms"], 2), "launches": v["launches"]}
-                               for k, v in kern.items()},
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_as_counted": traffic_raw, "traffic_source": traffic_src,
+                "traffic_correction": {"factor_on_FETCH_SIZE": corr, "source": corr_src},
+                "window_array": "on" if headline_on else "off",
+                "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, dom_launches),
+                "avg_launch_ms": dom_ms / max(1, dom_launches),
+                "per_kernel": {k: {"algorithmic_GBs": round(v["GBs"], 1), "ms": round(v["ms"], 2), "launches": v["launches"],
+                                   **({"priced_with": v["priced_with"]} if "priced_with" in v else {})} for k, v in kern.items()},
+                "k_search_stage": {"algorithmic_GBs": round(search_stage["GBs"], 1), "ms": round(search_stage["ms"], 2),
+                                   "ms_pass_a": round(tim["ms_search_a"], 2), "ms_grouping": round(tim["ms_search_sort"], 2), "ms_pass_b": round(tim["ms_search_b"], 2)},
                 "whole_step_algorithmic_GBs": whole, "whole_step_frac": whole / HBM_PEAK_GBS,
-                "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other")}}
+                "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other", "ms_prep")}}
+
+    def layout_record(leg, on):
+        k2, st2 = kernels_of(leg["ctr"], leg["tim"])
+        d = max(k2, key=lambda q: k2[q]["ms"])
+        return {"window_array": "on" if on else "off",
+                "value_host_in_host_out": (leg.get("host") or {}).get("value"),
+                "value_kernel_only": total_reads / leg["kernel_only_elapsed"],
+                "ms_per_step_kernel_only": leg["kernel_only_elapsed"] / args.steps * 1e3,
+                "device_ms_per_step": {k: round(leg["tim"][k] / args.steps, 2) for k in ("ms_total", "ms_search", "ms_search_a", "ms_search_b", "ms_extend", "ms_heavy", "ms_other")},
+                "dominant_kernel": d, "dominant_kernel_frac_of_hbm_peak": k2[d]["GBs"] / HBM_PEAK_GBS,
+                "results_bitwise_equal_across_steps": leg["repeatable"],
+                "host_results_bit_identical": (leg.get("host") or {}).get("results_bit_identical_to_kernel_only_steps")}
+
+    layouts = {("window_array_on" if headline_on else "window_array_off"): layout_record(main_leg, headline_on)}
+    setup_s = None
+    if other_leg is not None:
+        layouts["window_array_on" if not headline_on else "window_array_off"] = layout_record(other_leg, not headline_on)
+        on_leg = other_leg if not headline_on else main_leg
+        # (first step in the layout - allocation of 48 B per suffix, k_build_swin - minus a steady kernel-only step)
+        setup_s = max(0.0, on_leg["first_step_s"] - on_leg["kernel_only_elapsed"] / args.steps)
+        same = bool(np.array_equal(main_leg["hits"].view(np.uint8), other_leg["hits"].view(np.uint8)))
+        layouts["results_bit_identical_between_layouts"] = same
+    on_rec, off_rec = layouts.get("window_array_on"), layouts.get("window_array_off")
 
     fmt = dict(reads=args.reads, pairs=args.reads // 2, read_len=args.read_len, max_subs=args.max_subs)
     result = {
         "metric": metric_text(args, cfg, E),
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        # the same workload on the metric's other clock (SURVEY 8d T_align: reads leave host memory, results are back in host memory);
-        # the harness's contract keeps `value` on inputs resident in HBM, so the PCIe-inclusive rate is reported beside it
-        "value_host_in_host_out": (host_leg or {}).get("value"),
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value_clock": ("T_align of SURVEY 8d: reads leave pinned host memory (2 bit/base), results are back in host memory; "
+                        f"{args.steps} steps between two barriers") if host_ok else
+                       "kernel-only: reads and results resident in HBM (the host-in / host-out steps were switched off or failed)",
+        "value_kernel_only": kernel_only_value,
+        "value_no_window_array": (off_rec or {}).get("value_host_in_host_out") or (off_rec or {}).get("value_kernel_only"),
+        "value_window_array": (on_rec or {}).get("value_host_in_host_out") or (on_rec or {}).get("value_kernel_only"),
+        "window_array_setup_s": setup_s,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic {'wheat' if E == 5 else 'GRCh38'}-like genome of {total_bp} bp in "
                                f"{len(seq_lens)} sequences ({int(100 * cfg.get('repeat_frac', 0.45))}% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
+                   "window_array": ("on" if headline_on else "off") + (f" (what `biokanga align` picks for {args.reads} reads per device: the suffix-ordered window "
+                                    f"array from {CLI_WINDOW_ARRAY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
                    "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",
@@ -818,8 +946,9 @@ def main():
                    "n_search_per_read": ctr["n_search"] / (args.reads * args.steps),
                    "n_cand_per_read": ctr["n_cand"] / (args.reads * args.steps),
                    "heavy_calls_frac": ctr["n_heavy"] / max(1, ctr["n_lcm_calls"]),
-                   "results_bitwise_equal_across_steps": repeatable},
+                   "results_bitwise_equal_across_steps": main_leg["repeatable"]},
         "roofline": roofline,
+        "layouts": layouts,
         "t_align_host_resident": host_leg,
     }
     if multi is not None:

@@ -87,7 +87,9 @@ class _Timing(ctypes.Structure):
     _fields_ = [("ms_total", ctypes.c_float), ("ms_search", ctypes.c_float), ("ms_extend", ctypes.c_float),
                 ("ms_heavy", ctypes.c_float), ("ms_other", ctypes.c_float),
                 ("n_search_launches", ctypes.c_uint32), ("n_extend_launches", ctypes.c_uint32),
-                ("n_heavy_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("n_heavy_launches", ctypes.c_uint32), ("n_search_b_launches", ctypes.c_uint32),
+                ("ms_search_a", ctypes.c_float), ("ms_search_sort", ctypes.c_float), ("ms_search_b", ctypes.c_float),
+                ("ms_prep", ctypes.c_float)]
 
 
 class _StreamStats(ctypes.Structure):

@@ -1,0 +1,80 @@
+// bk_dev_k2.h - the second-level search keys (DevIndex::k2): their layout, compare and construction helpers, shared by the index
+// set-up kernels (bk_index.hip) and the search passes (bk_search.hip).
+#pragma once
+#include "bk_dev_util.h"
+
+namespace bk {
+
+// ------------------------------------------------------------------------------------------------
+// Two-pass search over the second-level key array (DevIndex::k2).
+//   k2[i] = the kK2Bases = 15 bases that FOLLOW the first k bases of suffix sa[i], 2 bits each in the top 30 bits of a 32-bit
+//           word, and a kind in the low two: 0 = all of them a,c,g,t; 1 = an N or a sequence end among them - the bases in front
+//           of it are kept, everything behind is filled with ones, so that the key sorts where the suffix does (above every key
+//           that continues the same bases with a,c,g,t); the word 0xFFFFFFFF = an N / sequence end already inside the first k
+//           bases (such suffixes sit at the end of the k-mer bucket they sort into and compare above every N-free probe).
+//           Inside one k-mer bucket k2 is non-decreasing, so bases k .. k+14 of a core are resolved by a bisection over
+//           CONTIGUOUS 4-byte keys - one load per step instead of the dependent suffix-array-then-target pair, sixteen keys to a
+//           cache line - and a bucket of <= 16 suffixes is settled from one or two lines.
+//           A key of kind 1 can compare EQUAL to a probe that ends in t's where the suffix has its N (the fill): such keys lie at
+//           the END of the run of equal keys (the suffix sorts above every true match), so only the upper bound can be off; it
+//           is walked back over them with a look at the target itself.  Thousands of suffixes in a genome are of that kind.
+//   pass A (lane per read/strand/core): k-mer table lookup; empty buckets and buckets of <= 16 keys are
+//           finished here, everything else is appended to a work list.
+//   pass B (lane per work item): bisection over k2, then - for cores longer than k+15 bases whose
+//           sub-bucket is not handed on unverified - over suffix array + target from base k+15 on.
+// The split keeps the lanes of pass B uniformly busy: in one combined kernel ~70 % of the lanes
+// finished after the table lookup and idled while their wave's longest bisection ran.
+// Work items: the slot index; its iv_first/iv_n entry carries (range start, size | kind << 30).
+
+constexpr uint32_t kKindShift = 30;
+constexpr uint32_t kKindK2 = 1;        // bisect k2 over [first, first+size)
+constexpr uint32_t kKindDeep = 2;      // [first, first+size) shares k+15 bases with the core: resolve the rest
+constexpr uint32_t kKindFull = 3;      // no usable k-mer bucket: full search
+constexpr uint32_t kInlineBucket = 16;
+constexpr int kK2Bases = 15;
+constexpr uint32_t kK2Above = 0xFFFFFFFFu;
+
+// -1 / 0 / +1: key (masked to the core's bases) vs probe; the all-ones key sorts above everything
+__device__ __forceinline__ int k2_cmp(uint32_t key, uint32_t m, uint32_t q2)
+{
+    if (key == kK2Above) return 1;
+    key &= m;
+    return key < q2 ? -1 : (key > q2 ? 1 : 0);
+}
+__device__ __forceinline__ bool k2_nkind(uint32_t key) { return key != kK2Above && (key & 3u) == 1u; }
+
+// mask of the first L = min(rem2, kK2Bases) bases of a key; rem2 = bases of the core beyond the k-mer table's k
+__device__ __forceinline__ uint32_t k2_mask(int rem2)
+{
+    const int L = rem2 < kK2Bases ? rem2 : kK2Bases;
+    return L <= 0 ? 0u : ~0u << (32 - 2 * L);
+}
+
+// the key of the suffix at pos
+__device__ __forceinline__ uint32_t k2_make(const uint64_t *__restrict__ tgt4, uint64_t pos, int k)
+{
+    const uint64_t w0 = nib16(tgt4, pos);
+    if (w0 & top_mask(k) & 0x4444444444444444ULL) return kK2Above;
+    const uint64_t w1 = nib16(tgt4, pos + (uint64_t)k);
+    const uint64_t bad = w1 & 0x4444444444444440ULL;                 // N / sequence end among the 15 bases
+    const uint32_t code = squeeze2(w1) & ~3u;
+    if (!bad) return code;
+    const int j = __clzll((long long)bad) >> 2;                       // the first of them
+    return ((code | (0xFFFFFFFFu >> (2 * j))) & ~3u) | 1u;
+}
+
+// as cmp_core, but only bases [start, cl) of the core are compared
+template <typename Row>
+__device__ __forceinline__ int cmp_core_from(const Row &rdw, int ofs, int cl, int start,
+                                             const uint64_t *__restrict__ tgt, uint64_t pos)
+{
+    for (int i = start; i < cl; i += 16) {
+        uint64_t m = top_mask(cl - i);
+        uint64_t p = row_nib16(rdw, ofs + i) & m;
+        uint64_t t = nib16(tgt, pos + i) & m;
+        if (p != t) return p < t ? -1 : 1;
+    }
+    return 0;
+}
+
+}  // namespace bk

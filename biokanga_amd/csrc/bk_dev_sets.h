@@ -1,0 +1,94 @@
+// bk_dev_sets.h - the reference's set of seen target starts (SfxArrayV2.cpp:5932-5950) as the wave-per-read kernels keep it: epoch-tagged
+// open addressing in HBM (k_heavy, k_wave's HASH form), a per-wave set in LDS in front of it (k_wave).
+#pragma once
+#include "bk_dev_util.h"
+
+namespace bk {
+
+__device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask)
+{
+    return (key * 2654435761u) & mask;      // table size is a power of two
+}
+
+__device__ __forceinline__ bool htab_contains(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) return false;
+        if (v == mine) return true;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key)
+{
+    unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != epoch) {
+            unsigned long long old = atomicCAS(&tab[h], v, mine);
+            if (old == v) return;
+            continue;                       // somebody else took the slot: look at it again
+        }
+        if (v == mine) return;
+        h = (h + 1) & mask;
+    }
+}
+
+// 5-byte indexes only: two candidates of one 64-candidate round whose target starts lie a multiple of 2^32 bases apart carry the
+// same truncated key (SfxArrayV2.cpp:5932).  The reference, walking them one after the other, takes the later one for seen; the
+// hash set is only consulted for what EARLIER rounds left in it, so the round is checked against itself here.
+__device__ __forceinline__ bool same_key_earlier_in_round(bool cand, uint32_t key, int lane)
+{
+    bool dup = false;
+    uint64_t vm = __ballot(cand);
+    if (__popcll(vm) > 1) {
+        // first a cheap look at six bits of a hash of the keys: lanes that share all six with no other candidate cannot have a twin
+        // (almost every round ends here); the exact pass over the candidates runs only for the others
+        const uint32_t h6 = (key * 2654435761u) >> 26;
+        uint64_t peers = vm;
+#pragma unroll
+        for (int bit = 0; bit < 6; bit++) {
+            const uint64_t bm = __ballot(cand && ((h6 >> bit) & 1));
+            peers &= ((h6 >> bit) & 1) ? bm : ~bm;
+        }
+        vm = __ballot(cand && (peers & (peers - 1)) != 0);          // candidates that share their six bits with another candidate
+    }
+    if (__popcll(vm) > 1)
+        while (vm) {
+            const int l = __ffsll((unsigned long long)vm) - 1;
+            vm &= vm - 1;
+            const uint32_t k2 = __shfl(key, l);
+            dup |= cand && lane > l && key == k2;
+        }
+    return dup;
+}
+
+// the wave kernel's LDS set of seen keys (HASH form)
+constexpr uint32_t kLdsSet = 2048, kLdsSetFill = 1536, kLdsEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ bool lset_contains(const uint32_t *set, uint32_t key)
+{
+    uint32_t h = hash_key(key, kLdsSet - 1);
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v == kLdsEmpty) return false;
+        if (v == key) return true;
+        h = (h + 1) & (kLdsSet - 1);
+    }
+}
+
+__device__ __forceinline__ void lset_insert(uint32_t *set, uint32_t key)
+{
+    uint32_t h = hash_key(key, kLdsSet - 1);
+    for (;;) {
+        const uint32_t old = atomicCAS(&set[h], kLdsEmpty, key);
+        if (old == kLdsEmpty || old == key) return;
+        h = (h + 1) & (kLdsSet - 1);
+    }
+}
+
+}  // namespace bk

@@ -16,7 +16,7 @@
 //            the LocateFirstExact lower bound of c; a core whose first k bases have code c can only
 //            match inside [ktab[c], ktab[c+1])
 //   k2     : uint32[N] second-level search keys in suffix-array order: the 15 bases that follow the first k of suffix sa[i]
-//            at 2 bit/base + a kind (see bk_kernels.hip); sorted inside every k-mer bucket, so cores are located by
+//            at 2 bit/base + a kind (see bk_dev_k2.h); sorted inside every k-mer bucket, so cores are located by
 //            bisecting contiguous keys - sixteen to a cache line - instead of chasing sa -> target
 //   isa    : uint32[N] inverse suffix array (isa[sa[i]] = i); lets the wave kernel decide whether a
 //            target start already reached through an earlier, TRUNCATED core interval was inside
@@ -45,6 +45,8 @@ struct StripeSet {
 constexpr int kCtrStripes = 64;       // copies of the DevBatch::ctr block (8 counters = one 64-byte line each)
 constexpr int kNwLong = 20;            // 16-base words of the wider register-window kernel families: reads of up to 320 bases (2 x 250, 2 x 300)
 constexpr int kNwLongest = 32;         // .. and of up to 512 bases
+constexpr int kPackedPadWords = 32;    // 32-bit words every buffer of packed reads (DevBatch::pk_words) is padded by: the read preparation loads a
+                                       //   whole register window (up to kNwLongest words) from a read's first word, however short the read
 constexpr int kMaxCoresFast = 16;      // cores per strand the lane-per-read path handles
 constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)

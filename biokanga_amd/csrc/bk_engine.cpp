@@ -1,6 +1,6 @@
 // bk_engine.cpp - implementation of the C ABI in include/biokanga_amd.h: context (index image in
 // HBM), batch driver (phase loop of CSfxArrayV3::AlignReads over whole batches), counters, timing.
-// Compiled with hipcc; device code lives in bk_kernels.hip.  No CPU fallback exists: every compute
+// Compiled with hipcc; device code lives in the kernel files (bk_index / bk_prep / bk_search / bk_extend / bk_wave / bk_heavy / bk_rescue / bk_snp .hip).  No CPU fallback exists: every compute
 // entry point needs a HIP device and fails with BK_ERR_NODEVICE otherwise.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -24,7 +24,7 @@
 #include "sfx_file.h"
 
 namespace bk {
-// launchers defined in bk_kernels.hip
+// launchers defined in the kernel files (*.hip)
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
@@ -159,7 +159,7 @@ void free_dev(void *p)
     if (p) (void)hipFree(p);
 }
 
-// zero-fill that stays correct for spans of 4 GiB and more: hipMemsetAsync is not trusted with those (bk_kernels.hip,
+// zero-fill that stays correct for spans of 4 GiB and more: hipMemsetAsync is not trusted with those (bk_index.hip,
 // k_fill_u64), so large clears go through the fill kernel (8-byte words, plus a byte tail through hipMemsetAsync)
 hipError_t clear_dev(void *p, size_t bytes, hipStream_t s)
 {
@@ -731,7 +731,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     hipEvent_t e0 = tm.begin(s);
     launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, c->d_stage[0], c->d_stripe_cnt, s);
     HIP_TRY(hipGetLastError());
-    tm.end(3, e0, s);
+    tm.end(7, e0, s);
     HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     uint32_t n_act = hm[0];
@@ -771,20 +771,28 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                 for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
                     if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 8, s));
                     else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 4, s));
+                hipEvent_t ea = tm.begin(s);
                 launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
                                 c->d_slist_stage, c->d_stripe_cnt, s);
                 HIP_TRY(hipGetLastError());
+                tm.end(4, ea, s);
                 HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 const uint32_t *slist = c->d_slist;
                 if ((c->sort_lists & 1) && hm[8] >= 4096) {
                     int rs = ensure_sort_scratch(c, hm[8], s);
                     if (rs) return rs;
+                    hipEvent_t es = tm.begin(s);
                     launch_keys_search(b, c->d_slist, hm[8], c->sort_shift, c->d_sort[0], s);
                     rs = sort_work(c, c->d_slist, hm[8], s, &slist);
                     if (rs) return rs;
+                    tm.end(5, es, s);
                 }
-                launch_search_b(c->ix, c->cfg, b, phase, lazy, slist, hm[8], s);
+                if (hm[8]) {
+                    hipEvent_t eb = tm.begin(s);
+                    launch_search_b(c->ix, c->cfg, b, phase, lazy, slist, hm[8], s);
+                    tm.end(6, eb, s);
+                }
             } else
                 launch_search(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy, s);
             HIP_TRY(hipGetLastError());
@@ -937,7 +945,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     const uint64_t missing = want > have ? want - have : 0;
     if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) { c->swin_denied = true; return BK_OK; }  // (the chunk size is set from 3/4 of the free memory; asked once)
     StageClock clk;
-    if (hipMalloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; return BK_OK; }
+    if (hipMalloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }   // (asked once)
     launch_build_swin(c->ix, c->d_swin, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1007,6 +1015,10 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
         case 0: c->timing.ms_search += m; c->timing.n_search_launches++; break;
         case 1: c->timing.ms_extend += m; c->timing.n_extend_launches++; break;
         case 2: c->timing.ms_heavy += m; c->timing.n_heavy_launches++; break;
+        case 4: c->timing.ms_search_a += m; break;           // (inside a span of kind 0)
+        case 5: c->timing.ms_search_sort += m; break;
+        case 6: c->timing.ms_search_b += m; c->timing.n_search_b_launches++; break;
+        case 7: c->timing.ms_prep += m; c->timing.ms_other += m; break;
         default: c->timing.ms_other += m; break;
         }
     }
@@ -1069,7 +1081,14 @@ int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_h
     const uint32_t *d_lens = in.lens;
     const uint32_t nreads = 2 * n_pairs;
     const uint32_t wpr = words_per_read(maxlen);
-    int rc = ensure_batch_scratch(c, nreads, wpr);
+    // (launch_pe never touches the interval records: the slots keep whatever core count the SE pass sized them for)
+    const uint32_t ivc = c->cap_iv_cores ? c->cap_iv_cores : iv_cores_for(c, maxlen);
+    int rc = ensure_batch_scratch(c, nreads, wpr, 0, ivc);
+    if (rc && c->d_swin) {                        // the window array goes before a batch is refused for want of memory (as in align_chunk)
+        (void)hipGetLastError();
+        bk::release_swin(c);
+        rc = ensure_batch_scratch(c, nreads, wpr, 0, ivc);
+    }
     if (rc) return rc;
     DevBatch b{};
     b.bases = d_bases; b.offs = d_offs; b.lens = d_lens;
@@ -1378,6 +1397,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->wave_group = value ? 1 : 0;
         return old;
     }
+    if (n == "swin_resident") return c->d_swin != nullptr ? 1 : 0;      // (read only: whether the window array is in HBM right now)
     if (n == "use_swin") {
         int64_t old = c->use_swin;
         c->use_swin = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
@@ -1582,12 +1602,15 @@ int bk_align_batch_packed(bk_ctx *c, const uint32_t *words, uint64_t n_words, co
     if (!nreads) return BK_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (n_words + 16 > c->cap_in_words) {                   // (the read preparation loads up to 16 words from a read's first one)
+    // (k_prep_fused<NW, PACKED> loads NW words from a read's first one whatever its length - up to kNwLongest for a batch whose
+    // longest read has 257 .. 512 bases - so the buffer is padded by that many words behind the last read)
+    static_assert(kPackedPadWords >= kNwLongest, "packed read words must be padded by the widest register-window family");
+    if (n_words + kPackedPadWords > c->cap_in_words) {
         free_dev(c->d_in_words);
         c->d_in_words = nullptr;
         c->cap_in_words = 0;
-        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + 16) * 4));
-        c->cap_in_words = n_words + 16;
+        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + kPackedPadWords) * 4));
+        c->cap_in_words = n_words + kPackedPadWords;
     }
     if (n_exc > c->cap_in_exc) {
         free_dev(c->d_in_exc);

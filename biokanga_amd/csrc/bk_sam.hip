@@ -304,9 +304,32 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     d.bases = d_bases.as<uint8_t>(); d.offs = d_offs.as<uint64_t>(); d.lens = d_lens.as<uint32_t>(); d.names = d_names.as<char>();
     d.name_ofs = d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
     d.n_ent = n_ent; d.fmt6 = job->report_unaligned ? 1 : 0; d.pe_mode = job->pe_mode;
-    // chrom ids must name entries 1..n (the host checked its records when it made them; a stray id must not read out of bounds)
-    for (uint64_t i = 0; i < nr; i++)
-        if (job->hits[i].nar == BK_NAR_ACCEPTED && (job->hits[i].chrom_id < 1 || job->hits[i].chrom_id > n_ent)) return BK_ERR_PARAMS;
+    // Everything the device indexes with is checked here first (the command line passes consistent arrays; another caller of the ABI
+    // must get BK_ERR_PARAMS, not an out-of-bounds device access): chrom ids name entries 1..n, order[] names reads, every read lies
+    // inside the bases, names are '\0'-terminated stretches in ascending order inside the name bytes.  A few host threads, slices each.
+    {
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, std::max(nr, job->n_order) >> 16));
+        std::vector<int> bad(nt, 0);
+        auto check = [&](unsigned t) {
+            const uint64_t r0 = nr * t / nt, r1 = nr * (t + 1) / nt;
+            for (uint64_t i = r0; i < r1; i++) {
+                const bk_hit &h = job->hits[i];
+                if (h.nar == BK_NAR_ACCEPTED && (h.chrom_id < 1 || h.chrom_id > n_ent)) bad[t] = 1;
+                const uint64_t o = job->offs[i], l = job->lens[i];
+                if (o > job->n_bases || l > job->n_bases - o) bad[t] = 1;
+                const uint64_t a = job->name_ofs[i], z = i + 1 < nr ? job->name_ofs[i + 1] : job->n_name_bytes;
+                if (z > job->n_name_bytes || a >= z) bad[t] = 1;
+            }
+            const uint64_t k0 = job->n_order * t / nt, k1 = job->n_order * (t + 1) / nt;
+            for (uint64_t k = k0; k < k1; k++)
+                if (job->order[k] >= nr) bad[t] = 1;
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(check, t);
+        check(0);
+        for (auto &x : th) x.join();
+        for (int b : bad) if (b) return BK_ERR_PARAMS;
+    }
     lap("record check");
     void *h_text[2] = {nullptr, nullptr};
     uint64_t cap_text = 0;

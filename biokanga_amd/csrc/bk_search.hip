@@ -1,0 +1,405 @@
+// bk_search.hip - LocateFirstExact (SfxArrayV2.cpp:7765-7876) + the extent of the matching run for every core of a phase (gfx950):
+//   k_search          one pass over suffix array + target (indexes without second-level keys)
+//   k_search_a_ilp    pass A: k-mer table + small buckets out of the second-level keys
+//   k_search_b        pass B: bisection of the big buckets, work list grouped by bucket
+#include "bk_dev_k2.h"
+#include "bk_dev_prof.h"
+
+namespace bk {
+
+// ------------------------------------------------------------------------------------------------
+// K1: SA interval search, one lane per (active read, strand, core)
+
+// With `lazy` set (register-window path), a core whose k-mer table bucket holds <= kLazyBucket suffixes
+// is NOT bisected/verified here: the bucket is handed on as is (bit 31 of iv_n set) and the extend
+// kernels keep only the members whose core bases are clean in the window they evaluate anyway -
+// same candidates in the same SA order, two dependent HBM round trips fewer per probe.
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                uint32_t n_act, int phase, int cmax, int nstr, int lazy)
+{
+    uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t per_read = (uint32_t)(nstr * cmax);
+    uint64_t a = tid / per_read;
+    if (a >= n_act) return;
+    uint32_t rem = (uint32_t)(tid - a * per_read);
+    int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
+    uint32_t r = act[a];
+    const uint32_t meta = b.rmeta[r];
+    int len = (int)(meta & kReadLenMask);
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd;
+    phase_params(p, cfg, phase, mm, cl, cd);
+    // offset of core c by the sliding rule
+    int cur = cd, o = 0, n = 0, my_ofs = -1;
+    while (n < p.max_slides && o <= len - cl && cur > cl / 3) {
+        if (o + cl + cur > len) cur = len - (o + cl);
+        if (n == c) my_ofs = o;
+        n++;
+        o += cur;
+    }
+    if (my_ofs < 0 || n > kMaxCoresFast) return;
+    int strand = cfg.align_strand == 2 ? 1 : si;
+    const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
+    uint64_t first, count;
+    uint64_t slot = iv_slot(b, (uint32_t)a, strand, c);
+    if (lazy && ix.k > 0 && cl >= ix.k) {
+        uint64_t p0 = rdw.nib16(my_ofs) & top_mask(cl);
+        uint64_t lo, hi;
+        core_range(ix, p0, cl, lo, hi);
+        if (hi - lo <= kLazyBucket && !(lo == 0 && hi == ix.n)) {
+            iv_put(b, slot, lo, (uint32_t)(hi - lo) | (hi > lo ? kLazyFlag : 0u));
+            return;
+        }
+    }
+    search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, count);     // exact run length
+    iv_put(b, slot, first, count > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)count);
+}
+
+// Pass A with ILP searches per lane, written stage by stage so that the loads of a stage (read row, k-mer table, second-level
+// keys) of all ILP searches are in flight together: item u of a lane is search number tid + u * (lanes of the grid), i.e. every u
+// maps neighbouring lanes to neighbouring searches.  Same records and work list for every ILP (order aside).
+
+template <int ILP>
+__global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
+                                                      uint32_t n_act, int phase, int cmax, int nstr, int lazy,
+                                                      StripeSet out)
+{
+    __shared__ uint32_t s_cnt, s_base;
+#if defined(BK_PROF) && BK_PROF == 2
+    PROF_BEGIN;
+#endif
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t per_read = (uint32_t)(nstr * cmax);
+    const uint64_t total = (uint64_t)n_act * per_read;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int k = ix.k;
+    bool on[ILP], push[ILP], have_code[ILP];
+    uint64_t slot[ILP], p0[ILP], first[ILP], lo[ILP], hi[ILP];
+    uint32_t nval[ILP], q2raw[ILP];            // q2raw: the 16 bases behind the k-mer's, 2 bits each
+    int cl[ILP];
+    // The core at offset 0 of phases 0, 1, 2 .. begins with the same k + 15 bases whenever it is that long, so the interval those bases
+    // select is looked up once: phase 0 leaves it in iv32 (here, or pass B after its key bisection), the later phases' offset-0 lanes
+    // take it from there instead of fetching a k-mer table line and a key line each (a quarter of the searches at C2).
+    constexpr uint32_t kNoIv32 = 0xFFFFFFFFu;
+    uint32_t cix[ILP];                  // entry of iv32 this lane reads (phase > 0) or writes (phase 0); kNoIv32 = neither
+    uint2 cv[ILP];
+    bool cached[ILP];
+    uint32_t key0[ILP];
+    // stage 1: the item, its read row
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + (uint64_t)u * stride;
+        on[u] = false; push[u] = false; have_code[u] = false; slot[u] = 0; p0[u] = 0; q2raw[u] = 0; first[u] = 0; nval[u] = 0; cl[u] = 1; lo[u] = hi[u] = 0;
+        cix[u] = kNoIv32; cv[u] = make_uint2(0, kNoIv32); cached[u] = false;
+        if (tid < total) {
+            const uint64_t a = tid / per_read;
+            const uint32_t rem = (uint32_t)(tid - a * per_read);
+            const int si = (int)(rem / (uint32_t)cmax), c = (int)(rem % (uint32_t)cmax);
+            const uint32_t r = act[a];
+            const uint32_t meta = b.rmeta[r];
+            const int len = (int)(meta & kReadLenMask);
+            const int strand_c = cfg.align_strand == 2 ? 1 : si;
+            if (b.iv32 != nullptr && c == 0 && phase > 0) cv[u] = b.iv32[(uint32_t)strand_c * b.n_reads + r];     // (requested with the length)
+            ReadPlan p = make_plan(len, cfg);
+            int mm, cd, dummy[1];
+            phase_params(p, cfg, phase, mm, cl[u], cd);
+            const int nc = core_offsets(len, cl[u], cd, p.max_slides, dummy, 0);
+            if (c < nc && nc <= kMaxCoresFast) {
+                on[u] = true;
+                if (b.iv32 != nullptr && c == 0 && cl[u] >= k + kK2Bases) {
+                    cix[u] = (uint32_t)strand_c * b.n_reads + r;
+                    cached[u] = phase > 0 && cv[u].y < (1u << kKindShift);
+                }
+                const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
+                const int strand = cfg.align_strand == 2 ? 1 : si;
+                slot[u] = iv_slot(b, (uint32_t)a, strand, c);
+                if (b.rd2 != nullptr && !(meta & kReadHasN)) {
+                    // 32 bases from the core's start out of the 2-bit row: the k-mer code's bases and the 16 that follow them
+                    const uint64_t *row = b.rd2 + ((uint64_t)r * 2 + strand) * (b.nw / 2);
+                    const uint64_t x = bits64_2(row, my_ofs);
+                    p0[u] = spread2to4((uint32_t)(x >> 32)) & top_mask(cl[u]);
+                    q2raw[u] = k == 16 ? (uint32_t)x : (uint32_t)(bits64_2(row, my_ofs + k) >> 32);
+                } else {
+                    const uint64_t *rdw = b.rd4 + ((uint64_t)r * 2 + strand) * b.wpr;
+                    p0[u] = nib16(rdw, my_ofs) & top_mask(cl[u]);
+                    const uint64_t q4 = nib16(rdw, my_ofs + k);
+                    q2raw[u] = squeeze2(q4);
+                    // an N among the core's bases behind the k-mer cannot be put to the 2-bit keys: the full search takes the core
+                    const int rem2 = cl[u] - k;
+                    if (rem2 > 0 && (q4 & 0x4444444444444444ULL & top_mask(rem2 < kK2Bases ? rem2 : kK2Bases))) p0[u] |= 0x4000000000000000ULL;
+                }
+            }
+        }
+    }
+    PROFS(0);
+    // stage 2: k-mer table
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        nval[u] = kKindFull << kKindShift;
+        push[u] = on[u];
+        have_code[u] = on[u] && !cached[u] && cl[u] >= k && !(p0[u] & 0x4444444444444444ULL & top_mask(k));
+        key0[u] = kK2Above;
+        if (have_code[u]) {
+            const uint64_t code = (uint64_t)(squeeze2(p0[u]) >> (32 - 2 * k));
+            if (ix.ktab2 != nullptr) {
+                // {bucket start, second-level key of its first suffix}: a bucket of one - every second one a read of a unique region
+                // meets, and a third of those its other strand runs into by chance - is settled by the line that names it
+                const uint2 e0 = ix.ktab2[code], e1 = ix.ktab2[code + 1];
+                lo[u] = e0.x; hi[u] = e1.x; key0[u] = e0.y;
+            } else {
+                lo[u] = ktab_get(ix, code);
+                hi[u] = ktab_get(ix, code + 1);
+            }
+        }
+    }
+    PROFS(1);
+    // stage 3: small buckets from the key array
+    // (a lane loads the keys its bucket has - one to three for most - and no more: this kernel lives on the rate at which the
+    // texture path takes lane requests, and sixteen keys for every lane cost a third more time than the search saved)
+    uint32_t key[ILP][kInlineBucket];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        const uint64_t size = hi[u] - lo[u];
+#pragma unroll
+        for (uint32_t j = 0; j < kInlineBucket; j++)
+            key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ((j == 0 && ix.ktab2 != nullptr) ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
+    }
+    PROFS(2);
+    // stage 4: results
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        uint2 leave = make_uint2(0, kNoIv32);               // what phase 0 leaves in iv32 for this read and strand
+        if (cached[u]) {
+            // the interval of the first k + 15 bases, as the bucket compare below would have produced it
+            first[u] = cv[u].x;
+            const uint32_t cnt = cv[u].y;
+            if (cnt == 0 || cl[u] <= k + kK2Bases) { nval[u] = cnt; push[u] = false; }
+            else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
+            else nval[u] = cnt | (kKindDeep << kKindShift);
+        }
+        if (have_code[u]) {
+            const uint64_t size = hi[u] - lo[u];
+            if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
+            else if (size <= kInlineBucket) {
+                const uint32_t m = k2_mask(cl[u] - k), q2 = q2raw[u] & m;
+                uint32_t lb = 0, ub = 0;
+                bool suspect = false;                          // a key of the N kind counted as equal: pass B has a look at the target
+#pragma unroll
+                for (uint32_t j = 0; j < kInlineBucket; j++) {
+                    const int cm = k2_cmp(key[u][j], m, q2);
+                    lb += cm < 0;
+                    ub += cm <= 0;
+                    suspect |= cm == 0 && k2_nkind(key[u][j]);
+                }
+                if (suspect) {
+                    first[u] = lo[u];
+                    nval[u] = (uint32_t)size | (kKindK2 << kKindShift);
+                } else {
+                    first[u] = lo[u] + lb;
+                    const uint32_t cnt = ub - lb;
+                    leave = make_uint2((uint32_t)first[u], cnt);
+                    if (cnt == 0 || cl[u] <= k + kK2Bases) { nval[u] = cnt; push[u] = false; }
+                    else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
+                    else nval[u] = cnt | (kKindDeep << kKindShift);
+                }
+            } else if (size < (1ULL << kKindShift)) {
+                first[u] = lo[u];
+                nval[u] = (uint32_t)size | (kKindK2 << kKindShift);        // (pass B leaves the interval in iv32 after its key bisection)
+            }
+        }
+        if (phase == 0 && cix[u] != kNoIv32) b.iv32[cix[u]] = leave;
+    }
+    PROFS(3);
+    // work-list appends, one global atomic per block.  The interval records are stored after them: the barriers of the append
+    // wait for every store the wave has issued.
+    const int lane = threadIdx.x & 63;
+    uint32_t my_off[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        my_off[u] = 0;
+        const uint64_t m = __ballot(push[u]);
+        if (m) {
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            w = __builtin_amdgcn_readfirstlane(w);
+            my_off[u] = w + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+        }
+    }
+    PROFS(4);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
+    __syncthreads();
+    PROFS(5);
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        if (push[u]) stripe_put(out, 0, s_base + my_off[u], (uint32_t)slot[u]);
+        if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
+    }
+#if defined(BK_PROF) && BK_PROF == 2
+    PROFS(6);
+    PROF_END;
+#endif
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, DevBatch b, int phase, int lazy,
+                                                  const uint32_t *__restrict__ list, uint32_t n_list)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+#ifdef BK_DIAG_B
+    unsigned long long d_k2 = 0, d_deep = 0;
+    struct Fin { unsigned long long &a, &b; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (b) atomicAdd(&bb.ctr[ctr_stripe() + 6], b); } } fin{d_k2, d_deep, b};
+#endif
+    const uint64_t slot = list[i];
+    const uint32_t r = b.act[(uint32_t)(slot % b.iv_stride)], sc = (uint32_t)(slot / b.iv_stride);
+    const int strand = (int)(sc / b.iv_cores), c = (int)(sc % b.iv_cores);
+    const uint32_t meta = b.rmeta[r];
+    const int len = (int)(meta & kReadLenMask);
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd;
+    phase_params(p, cfg, phase, mm, cl, cd);
+    const int my_ofs = c * cd < len - cl ? c * cd : len - cl;
+    const RdRow rdw = read_row(b, r, strand, (meta & kReadHasN) != 0);
+    uint64_t first;
+    uint32_t raw;
+    iv_get(b, slot, first, raw);
+    const uint32_t kind = raw >> kKindShift;
+    uint64_t cnt = raw & ((1u << kKindShift) - 1);
+    const int k = ix.k;
+    if (kind == kKindFull) {
+        search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, cnt);
+        iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
+        return;
+    }
+    if (kind == kKindK2) {
+        const uint32_t m = k2_mask(cl - k);
+        const uint32_t q2 = squeeze2(rdw.nib16(my_ofs + k)) & m;
+        // lower and upper bound in lock step: two independent loads per round
+        uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
+        while (l1 < h1 || l2 < h2) {
+            const bool a1 = l1 < h1, a2 = l2 < h2;
+            const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+#ifdef BK_DIAG_B
+            d_k2 += 1 + (1ULL << 32) * ((a1 && (h1 - l1) > 8) + (a2 && (h2 - l2) > 8 && (m1 >> 3) != (m2 >> 3)));
+#endif
+            const uint32_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
+            if (a1) { if (k2_cmp(v1, m, q2) < 0) l1 = m1 + 1; else h1 = m1; }
+            if (a2) { if (k2_cmp(v2, m, q2) <= 0) l2 = m2 + 1; else h2 = m2; }
+        }
+        // keys of the N kind at the end of the run of equal keys may be there for their fill only: the target decides
+        {
+            const int upto = cl < k + kK2Bases ? cl : k + kK2Bases;
+            while (l2 > l1) {
+                const uint32_t kv = ix.k2[l2 - 1];
+                if (!k2_nkind(kv) || cmp_core_from(rdw, my_ofs, upto, k, ix.tgt4, sa_get<WIDE>(ix, l2 - 1)) == 0) break;
+                l2--;
+            }
+        }
+        first = l1;
+        cnt = l2 - l1;
+        if (!WIDE && b.iv32 != nullptr && phase == 0 && c == 0 && cl >= k + kK2Bases)       // see k_search_a_ilp
+            b.iv32[(uint32_t)strand * b.n_reads + r] = make_uint2((uint32_t)first, (uint32_t)cnt);
+        if (cnt == 0 || cl <= k + kK2Bases) {
+            iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
+            return;
+        }
+    }
+    // [first, first+cnt) agrees with the core on its first k+15 bases
+    if (lazy && cnt <= kLazyBucket) {
+        iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
+        return;
+    }
+    {
+        const int start = k + kK2Bases;
+        uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
+        while (l1 < h1 || l2 < h2) {
+            const bool a1 = l1 < h1, a2 = l2 < h2;
+            const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+#ifdef BK_DIAG_B
+            d_deep += 1 + (1ULL << 32) * (a1 + (a2 && m1 != m2));
+#endif
+            const uint64_t s1 = a1 ? sa_get<WIDE>(ix, m1) : 0, s2 = a2 ? sa_get<WIDE>(ix, m2) : 0;
+            const int c1 = a1 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s1) : 0;
+            const int c2 = a2 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s2) : 0;
+            if (a1) { if (c1 > 0) l1 = m1 + 1; else h1 = m1; }
+            if (a2) { if (c2 >= 0) l2 = m2 + 1; else h2 = m2; }
+        }
+        first = l1;
+        cnt = l2 - l1;
+    }
+    iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
+}
+
+void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                   int phase, int cmax, int nstr, int lazy, hipStream_t s)
+{
+    uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy);
+    else hipLaunchKernelGGL(k_search<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy);
+}
+
+// keys for grouping work items that touch the same part of the index (see bk_engine.cpp, sort_work):
+// search items by the start of their k-mer bucket, wave items by the start of their longest core interval
+__global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t *__restrict__ list, uint32_t n, int shift,
+                                                     uint32_t *__restrict__ keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (uint32_t)(iv_start(b, list[i]) >> shift);
+}
+
+void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_keys_search, dim3((n + 255) / 256), dim3(256), 0, s, b, list, n, shift, keys);
+}
+
+// stage: at least n_act * cmax * nstr + (kListStripes + 2) * 1024 entries; stripe_cnt: kListStripes * 16 words, zero between launches
+void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+                     int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
+                     hipStream_t s)
+{
+    uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    int ilp = lazy >> 8;                               // bits 8..: searches per lane (0 / 1 = the plain kernel)
+    lazy &= 0xff;
+    if (ilp < 2) ilp = 1;
+    else if (ilp != 2) ilp = 4;
+    const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
+    const unsigned blocks = (unsigned)((threads + per - 1) / per);
+    StripeSet out;
+    out.cnt = stripe_cnt;
+    out.stage[0] = out.stage[1] = out.stage[2] = stage;
+    out.cap = stripe_cap(blocks, (unsigned)per);
+    if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    else hipLaunchKernelGGL(k_search_a_ilp<1>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    launch_compact(out, &list, &list_cnt, 1, nullptr, s);
+}
+
+void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
+                     uint32_t n_list, hipStream_t s)
+{
+    if (!n_list) return;
+    unsigned blocks = (n_list + 255) / 256;
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search_b<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
+    else hipLaunchKernelGGL(k_search_b<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
+}
+
+}  // namespace bk
+
+// in-kernel section timers (bk_dev_prof.h): BK_PROF == 1 reads k_flat's, 2 pass A's
+namespace bk { int prof_read_flat(unsigned long long *out16); }
+extern "C" int bk_debug_prof(unsigned long long *out16)
+{
+#if defined(BK_PROF) && BK_PROF == 2
+    return bk::prof_read(out16);
+#elif defined(BK_PROF)
+    return bk::prof_read_flat(out16);
+#else
+    (void)out16;
+    return 1;
+#endif
+}

@@ -286,18 +286,19 @@ struct bk_stream {
         (void)hipSetDevice(ctx->device);
         while (Job *j = pop(q_dn)) {
             Slot &sl = slots[j->slot];
-            if (j->dev) {
+            if (j->rc != BK_OK) {
+                // nothing of a failed batch - device-resident ones included: their kernels read the caller's buffers and write the
+                // context's batch scratch - may still be in flight when its slot (and that scratch) is reused or the caller frees
+                (void)hipStreamSynchronize(s_up);
+                (void)hipStreamSynchronize(s_al);
+                (void)hipStreamSynchronize(s_dn);
+            } else if (j->dev) {
                 // results were written where the caller said and the aligner thread has waited for its last kernel
-            } else if (j->rc == BK_OK && j->n) {
+            } else if (j->n) {
                 hipError_t e = hipStreamWaitEvent(s_dn, sl.ev_al, 0);
                 if (e == hipSuccess) e = hipMemcpyAsync(j->out, sl.d_out, (size_t)j->n * sizeof(bk_hit), hipMemcpyDeviceToHost, s_dn);
                 if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
                 if (e != hipSuccess) fail(j, rc_of(e));
-            } else if (j->rc != BK_OK) {
-                // nothing of a failed batch may still be in flight when its slot (and the context's batch scratch) is reused
-                (void)hipStreamSynchronize(s_up);
-                (void)hipStreamSynchronize(s_al);
-                (void)hipStreamSynchronize(s_dn);
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -384,7 +385,8 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
         hipError_t e2 = hipSuccess;
         for (Slot &sl : s->slots) {
             // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64);
+            //  + the words the read preparation may load behind the last read of a packed batch, bk::kPackedPadWords)
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64 + 4ULL * bk::kPackedPadWords);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);

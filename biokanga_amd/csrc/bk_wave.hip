@@ -1,0 +1,503 @@
+// bk_wave.hip - LocateCoreMultiples for repeat reads (gfx950): one wave per call, 64 candidates of a core interval per round.
+#include "bk_dev_window.h"
+#include "bk_dev_sets.h"
+
+namespace bk {
+
+// ------------------------------------------------------------------------------------------------
+// k_wave: one wave per LocateCoreMultiples call for reads of <= 16*NW bases and <= 16 cores per
+// strand (4-byte suffix arrays).  64 candidates of a core interval per step; the reference's
+// SEQUENTIAL semantics are reproduced exactly with ballot prefix sums, as in k_heavy:
+//   IterCnt counts only new, in-bounds targets; at the first loop top with IterCnt == 100 the
+//   remaining copy count (n - j + 2) abandons the core when > MaxIter; MaxIter and the 1 024 000
+//   node cap stop it; after MaxHits+1 exact instances everything stops (SfxArrayV2.cpp:5857-5875,6206).
+// The reference's hash set of already-seen target starts is replaced by an equivalent test: target
+// start T reached through core c was already processed in this strand pass  <=>  for some earlier
+// core c2 the read's core c2 matches the target at T (so T+ofs[c2] lies in c2's suffix interval) AND
+// that suffix lay inside the prefix of c2's interval that was actually walked (rank from the inverse
+// suffix array; only looked up when c2's walk was cut short).
+
+
+struct WaveCoreInfo {
+    unsigned long long first;
+    uint32_t n;
+    uint32_t walked;        // number of leading SA entries of the interval whose loop body was reached
+    int ofs;
+};
+
+// HASH: the reference's own dedupe instead - a per-wave set of the 32-bit truncated target-start keys
+// (SfxArrayV2.cpp:5932), kept in HBM with epoch tags as in k_heavy.  This is the form for 5-byte indexes (no
+// inverse suffix array; and only the truncated keys reproduce the reference there, where two starts 2^32 apart
+// count as one) and for 4-byte indexes whose inverse suffix array was not built.
+// SW: the index holds the suffix-ordered window array (DevIndex::swin) - reads it covers take their candidates' windows from it.
+template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
+__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
+                                              const uint32_t *__restrict__ list,
+                                              uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
+                                              uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
+                                              uint32_t *__restrict__ cmax_next)
+{
+    __shared__ WaveCoreInfo s_core[4][kMaxCoresFast];
+    __shared__ uint64_t s_cmask[4][kMaxCoresFast][NW / 4];       // per core: its bases in the IWindow layout
+    // HASH: the set of seen target keys of a strand pass lives in LDS (kLdsSet keys per wave, open addressing) and spills into the
+    // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
+    // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
+    __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
+    // the sequences' first and last base (up to 64 of them): a finished read finds its sequence without a trip to HBM at its very end
+    __shared__ uint64_t s_es[64], s_ee[64];
+    if (ix.n_ent <= 64) {
+        if (threadIdx.x < ix.n_ent) { s_es[threadIdx.x] = ix.ent_start[threadIdx.x]; s_ee[threadIdx.x] = ix.ent_end[threadIdx.x]; }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    WaveCoreInfo *core = s_core[wib];
+    uint64_t (*cmask)[NW / 4] = s_cmask[wib];
+    uint32_t *lset = s_set[HASH ? wib : 0];
+    uint32_t lset_n = kLdsSet;                   // keys in the LDS set (kLdsSet: not cleared yet)
+    bool spilled = false;                        // this strand pass has keys in the HBM table as well
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned long long *tab = nullptr;
+    uint32_t tmask = 0, epoch = 0;
+    if (HASH) {
+        if (wave_slot >= hs.n_slots) return;
+        tab = hs.htab + (uint64_t)wave_slot * hs.tab_size;
+        tmask = hs.tab_size - 1;
+        epoch = hs.slot_epoch[wave_slot];
+    }
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0, n_fetch = 0, n_dup = 0;
+    constexpr bool kDiag = false;
+
+    // work items are claimed kWaveGrab at a time: one device-scope atomic on the shared cursor per
+    // item serialises 8192 resident waves on a single address
+    uint32_t grab_next = 0, grab_left = 0;
+    const int grab = kWaveGrab;
+    // reads that go on to the next phase are parked one per lane and appended 64 at a time
+    uint32_t pend_r = 0, pend_n = 0, cmax_loc = 0;
+    auto flush_pending = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_cnt, pend_n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((uint32_t)lane < pend_n) next_act[base + lane] = pend_r;
+        pend_n = 0;
+    };
+    int geo_len = -1, geo_mm = 0, geo_cl = 1, geo_cd = 1, geo_nc = 0;      // geometry of the reads of length geo_len in this phase
+    ReadPlan geo_p{};
+    for (;;) {
+        if (grab_left == 0) {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(cursor, (uint32_t)grab);
+            grab_next = __builtin_amdgcn_readfirstlane(g);
+            grab_left = (uint32_t)grab;
+        }
+        const uint32_t item = grab_next++;
+        grab_left--;
+        if (item >= n_list) break;
+        // (wave-uniform values that arrive through vector loads are handed to the scalar unit explicitly: the read's plan, its loop
+        // bounds and the window geometry then cost scalar instructions once instead of vector instructions in every lane)
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(list[item]);          // position in the phase's active list: where its interval records lie
+        const uint32_t r = __builtin_amdgcn_readfirstlane(b.act[pos]);
+        const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
+        const int len = (int)(meta & kReadLenMask);
+        const bool has_n = (meta & kReadHasN) != 0;
+        // the plan of the read's length, the core offsets and the cores' masks only change with the length: a batch of equal-length reads
+        // computes them once per wave (they live in registers and in the wave's LDS words), not once per read
+        if (len != geo_len) {
+            geo_len = len;
+            geo_p = make_plan(len, cfg);
+            phase_params(geo_p, cfg, phase, geo_mm, geo_cl, geo_cd);
+            int ofs_tmp[kMaxCoresFast];
+            geo_nc = core_offsets(len, geo_cl, geo_cd, geo_p.max_slides, ofs_tmp, kMaxCoresFast);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < geo_nc && lane < kMaxCoresFast) {
+                int o = 0;
+#pragma unroll
+                for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
+                core[lane].ofs = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int ncm = geo_nc < kMaxCoresFast ? geo_nc : kMaxCoresFast;
+            for (int idx = lane; idx < ncm * (NW / 4); idx += 64) {
+                const int cc = idx / (NW / 4), i = idx % (NW / 4);
+                const int o = core[cc].ofs;
+                cmask[cc][i] = imask_word(o, o + geo_cl, i);
+            }
+        }
+        const ReadPlan p = geo_p;
+        const int mm = geo_mm, cl = geo_cl, cd = geo_cd, nc = geo_nc;
+        (void)cd;
+        n_lcm++;
+        const int init = mm + cfg.mm_delta + 1;
+        int low_inst = 0, low_mm = init, nxt = init;
+        uint64_t hit_left = 0;
+        int hit_strand = '?';
+        bool done = false;
+        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+        const bool sw_read = SW && len <= kSwLen && len - cl <= kSwPre;       // every core offset of the read lies within an entry's lead
+        for (int st = s0; st <= s1 && !done; st++) {
+            if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
+                if (lset_n) {
+                    for (uint32_t i = lane; i < kLdsSet; i += 64) lset[i] = kLdsEmpty;
+                    lset_n = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                spilled = false;             // (the HBM table gets its new epoch when a pass first spills into it)
+            }
+            // the read's 2 bit/base row (the same for the whole wave: scalar registers).  The 4 bit/base words that a window near an
+            // N or a sequence end needs are not kept in registers: that path (eval_window_rare) fetches them as it goes - from the
+            // 2-bit row again, or, a read with an N, from its rd4 row, which also gives its N positions
+            uint64_t r2w[NW / 2], rni[NW / 4];                           // rni: "read base is N", in the IWindow layout
+            const bool two_bit = b.rd2 != nullptr;
+            const RdRow row4 = read_row(b, r, st, has_n);
+            if (two_bit) {
+                load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (NW / 2), r2w);
+#pragma unroll
+                for (int k = 0; k < NW / 2; k++) r2w[k] = uniform64(r2w[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW / 2; k++) r2w[k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < NW / 4; k++) rni[k] = 0;
+            if (two_bit && has_n) {
+                const uint64_t *__restrict__ rp = b.rd4 + ((uint64_t)r * 2 + st) * b.wpr;
+#pragma unroll
+                for (int q = 0; q < NW / 4; q++) {
+                    uint64_t nm = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (16 * (4 * q + k) < len) nm |= (uint64_t)flags_to_bits16((uniform64(rp[4 * q + k]) >> 2) & 0x1111111111111111ULL) << (16 * k);
+                    rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
+                }
+            }
+            uint32_t my_cn = 0;                       // lane l < nc: suffixes in core l's interval
+            if (lane < nc) {
+                uint64_t slot = iv_slot(b, pos, st, lane);
+                uint64_t f;
+                uint32_t cn;
+                iv_get(b, slot, f, cn);
+                core[lane].first = f;
+                core[lane].n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
+                core[lane].walked = 0;
+                my_cn = cn & ~kLazyFlag;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // GROUP: consecutive cores with small intervals share a round - one candidate per lane in walk order (core, then suffix) -
+            // instead of a round each: with a dozen cores per strand a wave otherwise spends most of its rounds on two or three
+            // candidates.  None of the reference's iteration rules can fire inside such a round (fewer than 100 candidates per core,
+            // the node cap checked before it), and a small interval is always walked to its end.
+            uint32_t pre_ex = 0;                      // GROUP: candidates of the cores before this lane's (cores counted as min(n, 65))
+            if (GROUP) {
+                uint32_t v = my_cn > 64 ? 65u : my_cn;
+                const uint32_t own = v;
+                for (int off = 1; off < 16; off <<= 1) { const uint32_t u = __shfl_up(v, off); if (lane >= off) v += u; }
+                pre_ex = v - own;
+            }
+            uint32_t nodes = 0;
+            for (int c = 0; c < nc && !done && nodes < kNodeCap;) {
+                // (every lane reads the same LDS words: told so, the compiler keeps them and what follows from them in scalar registers)
+                const uint64_t first = uniform64(core[c].first);
+                const uint32_t cn_c = __builtin_amdgcn_readfirstlane(core[c].n);
+                const bool lazy = (cn_c & kLazyFlag) != 0;
+                const uint64_t n = cn_c & ~kLazyFlag;
+                const int ofs = __builtin_amdgcn_readfirstlane(core[c].ofs);
+                // the cores of this step: c alone (a long interval, 64 suffixes a round), or c .. ce - 1 in one round
+                int ce = c + 1;
+                uint32_t gtot = (uint32_t)(n > 64 ? 65 : n);
+                const bool grouped = GROUP && n <= 64 && nodes + 64 < kNodeCap;
+                uint32_t pre_c = 0;
+                if (GROUP && grouped) {
+                    pre_c = __shfl(pre_ex, c);
+                    const uint64_t stop_at = __ballot(lane > c && (lane >= nc || my_cn > 64 || pre_ex + my_cn - pre_c > 64));
+                    ce = stop_at ? __ffsll((unsigned long long)stop_at) - 1 : nc;
+                    gtot = __shfl(pre_ex, ce < 64 ? ce : 63) - pre_c;
+                    if (ce >= nc) gtot = __shfl(pre_ex + (my_cn > 64 ? 65u : my_cn), nc - 1) - pre_c;
+                    if (lane >= c && lane < ce) core[lane].walked = my_cn;       // (small intervals are walked whole)
+                    __builtin_amdgcn_wave_barrier();
+                }
+                int lc = c;                              // this lane's core, its suffix within the interval
+                uint64_t lfirst = first;
+                int lofs = ofs;
+                bool llazy = lazy;
+                uint32_t lj_g = 0;
+                if (GROUP && grouped) {
+                    for (int l = c + 1; l < ce; l++) lc += (__shfl(pre_ex, l) - pre_c) <= (uint32_t)lane ? 1 : 0;
+                    lj_g = (uint32_t)lane - (__shfl(pre_ex, lc) - pre_c);
+                    lfirst = core[lc].first;
+                    lofs = core[lc].ofs;
+                    llazy = (core[lc].n & kLazyFlag) != 0;
+                }
+                n_search += (unsigned long long)(ce - c);
+                uint32_t iter = 0;
+                bool copies_checked = false;
+                uint64_t walked = n;
+                // the window array serves a core when the read's whole window lies inside the candidate's entry: bases kSwPre - ofs ..
+                // + len of its kSwBases (every core of a read of up to kSwLen bases; of a longer read - 2 x 150 - the cores in the
+                // middle, when they are walked a round per 64 suffixes; rounds shared by several cores of such a read go to the target)
+                const bool sw_now = SW && ((GROUP && grouped) ? sw_read : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre));
+                for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
+                    const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
+                    const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
+                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip)
+                    uint4 ev[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                    if (SW && sw_now && active) {
+                        const uint4 *__restrict__ ep = ix.swin + (lfirst + j) * 3;
+                        ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
+                    }
+                    const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
+                    const uint64_t t = loci - (uint64_t)lofs;
+                    bool valid = active && loci >= (uint64_t)lofs;
+                    IWindow<NW> w;
+                    w.mm = 127; w.eos = true;
+#pragma unroll
+                    for (int k = 0; k < NW / 4; k++) w.im[k] = ~0ULL;
+                    if (valid) {
+                        // the block-flag load and the 2-bit window loads are issued together; only the rare
+                        // flagged window is then fetched again from the 4-bit copy
+                        if (two_bit) {
+                            const bool flg = window_flagged_t<WIDE>(ix, t, len);
+                            if (SW && sw_now) {
+                                if constexpr (SW) {
+                                    if (GROUP && grouped) eval_swin2i<NW, false>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                    else eval_swin2i<NW, true>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                }
+                            } else
+                                eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
+                            if (flg) {
+                                Window<NW> w4;
+                                eval_window_rare<NW>(row4, len, ix.tgt4, t, w4);
+                                window_to_iwindow<NW>(w4, w);
+                            }
+                        } else {
+                            Window<NW> w4;
+                            eval_window_rare<NW>(row4, len, ix.tgt4, t, w4);
+                            window_to_iwindow<NW>(w4, w);
+                        }
+                        valid = !w.eos && (!llazy || im_clean<NW>(w.im, cmask[lc]));
+                    }
+                    bool dup = false;
+                    const uint32_t key = (uint32_t)(1 + loci - (uint32_t)lofs);       // 32-bit truncation as :5932
+                    if (HASH) {
+                        dup = valid && lset_n != 0 && lset_contains(lset, key);
+                        if (spilled) dup = dup || (valid && htab_contains(tab, tmask, epoch, key));
+                        // (a round against itself: two starts 2^32 apart in one interval; the same start reached through two cores of a group)
+                        if (WIDE || (GROUP && grouped)) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
+                    } else for (int c2 = 0; c2 < ce - 1; c2++) {
+                        bool m = valid && !dup && c2 < lc && im_clean<NW>(w.im, cmask[c2]);
+                        if (__ballot(m)) {
+                            if (m) {
+                                if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
+                                else {
+                                    uint64_t rank = (uint64_t)ix.isa[t + (uint64_t)core[c2].ofs] - core[c2].first;
+                                    dup = rank < (uint64_t)core[c2].walked;
+                                }
+                            }
+                        }
+                    }
+                    const bool isnew = valid && !dup;
+                    if (kDiag) { n_fetch += __popcll(__ballot(active && loci >= (uint64_t)ofs)); n_dup += __popcll(__ballot(dup)); }
+                    const uint64_t newmask = __ballot(isnew);
+                    const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
+                    const uint32_t iter_before = iter + pre;
+                    const uint32_t nodes_before = nodes + pre;
+                    bool stop = active && !(GROUP && grouped) && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
+                    uint64_t cutoff = (GROUP && grouped) ? 64 : n;
+                    uint64_t stopmask = __ballot(stop);
+                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                    if (!copies_checked && !(GROUP && grouped)) {
+                        bool chk = active && j > 0 && iter_before == 100;
+                        uint64_t chkmask = __ballot(chk);
+                        if (chkmask) {
+                            uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                            if (jc < cutoff) {
+                                copies_checked = true;
+                                uint64_t num_copies = n - jc + 2;
+                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                            }
+                        }
+                    }
+                    const bool proc = active && ((GROUP && grouped) || j < cutoff) && isnew;
+                    if (HASH) {
+                        const uint32_t nins = (uint32_t)__popcll(__ballot(proc));
+                        if (nins) {
+                            // (the key that looks like an empty slot, one in 2^32, always goes to the HBM table)
+                            const bool to_lds = lset_n + nins <= kLdsSetFill;
+                            if ((!to_lds || __ballot(proc && key == kLdsEmpty)) && !spilled) {
+                                spilled = true;
+                                epoch++;
+                                if (epoch == 0) {            // wrapped: really clear the table
+                                    for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
+                                    epoch = 1;
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            }
+                            if (proc) {
+                                if (to_lds && key != kLdsEmpty) lset_insert(lset, key);
+                                else htab_insert(tab, tmask, epoch, key);
+                            }
+                            if (to_lds) lset_n += nins;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    int cm = (proc && w.mm <= mm && w.mm < nxt) ? w.mm : 127;
+                    bool acc = cm != 127;
+                    uint64_t keep = ~0ULL;
+                    uint64_t zmask = __ballot(acc && cm == 0);
+                    int zc0 = low_mm == 0 ? low_inst : 0;
+                    bool exit_now = false;
+                    if (zmask && zc0 + __popcll(zmask) > cfg.max_hits) {
+                        int need = cfg.max_hits + 1 - zc0;
+                        uint64_t z = zmask;
+                        for (int q = 1; q < need; q++) z &= z - 1;
+                        int cut_lane = __ffsll((unsigned long long)z) - 1;
+                        keep = cut_lane >= 63 ? ~0ULL : ((2ULL << cut_lane) - 1);
+                        exit_now = true;
+                        if (GROUP && grouped) n_search -= (unsigned long long)(ce - 1 - __shfl(lc, cut_lane));      // the cores behind the exit are never searched
+                    }
+                    uint64_t procmask = __ballot(proc) & keep;
+                    uint32_t nproc = (uint32_t)__popcll(procmask);
+                    iter += nproc;
+                    nodes += nproc;
+                    n_cand += (lane == 0) ? nproc : 0;
+                    acc = acc && ((keep >> lane) & 1);
+                    uint64_t accmask = __ballot(acc);
+                    if (accmask) {
+                        // smallest and second smallest count among the accepted lanes: the counts are at most mm, so one ballot per
+                        // value (scalar work) instead of two butterfly reductions through the LDS crossbar
+                        int bmin = 127, bsec = 127;
+                        uint64_t minmask = 0;
+                        for (int m = 0; m <= mm; m++) {
+                            const uint64_t bm = __ballot(acc && cm == m);
+                            if (!bm) continue;
+                            if (bmin == 127) { bmin = m; minmask = bm; }
+                            else { bsec = m; break; }
+                        }
+                        int cnt = __popcll(minmask);
+                        int fl = __ffsll((unsigned long long)minmask) - 1;
+                        if (bmin < low_mm) {
+                            nxt = low_mm < bsec ? low_mm : bsec;
+                            low_mm = bmin;
+                            low_inst = cnt;
+                            hit_left = __shfl(t, fl);
+                            hit_strand = st ? '-' : '+';
+                        } else if (bmin == low_mm) {
+                            low_inst += cnt;
+                            if (bsec < nxt) nxt = bsec;
+                        } else if (bmin < nxt)
+                            nxt = bmin;
+                    }
+                    if (exit_now) done = true;
+                    if (!(GROUP && grouped) && cutoff < j0 + 64) { walked = cutoff; break; }
+                }
+                if (!(GROUP && grouped) && lane == 0) core[c].walked = walked > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)walked;
+                __builtin_amdgcn_wave_barrier();
+                c = ce;
+            }
+        }
+        int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
+        if (rslt != BK_HR_NONE) {
+            int e = -1;
+            if (low_inst >= 1) {
+                if (ix.n_ent <= 64) {       // one entry per lane
+                    bool in = (uint32_t)lane < ix.n_ent && hit_left >= s_es[lane] && hit_left <= s_ee[lane];
+                    uint64_t m = __ballot(in);
+                    e = m ? __ffsll((unsigned long long)m) - 1 : -1;
+                } else if (lane == 0)
+                    e = find_entry(ix, hit_left);
+            }
+            if (lane == 0) write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, (phase << 1) | 1);
+        } else if (phase + 1 < p.n_phases) {
+            int mm2, cl2, cd2, dummy[1];
+            phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
+            int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
+            if (nc2 <= kMaxCoresFast && (uint32_t)nc2 > cmax_loc) cmax_loc = (uint32_t)nc2;
+            if ((uint32_t)lane == pend_n) pend_r = r;
+            if (++pend_n == 64) flush_pending();
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (HASH && lane == 0) hs.slot_epoch[wave_slot] = epoch;
+    if (pend_n) flush_pending();
+    if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
+    if (lane == 0) {
+        if (n_search) atomicAdd(&b.ctr[ctr_stripe() + 0], n_search);
+        if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 1], n_cand);
+        if (n_lcm) { atomicAdd(&b.ctr[ctr_stripe() + 2], n_lcm); atomicAdd(&b.ctr[ctr_stripe() + 3], n_lcm); }
+        if (n_cand) atomicAdd(&b.ctr[ctr_stripe() + 4], n_cand);
+        if (kDiag) { atomicAdd(&b.ctr[ctr_stripe() + 5], n_fetch); atomicAdd(&b.ctr[ctr_stripe() + 6], n_dup); }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, int phase, const uint32_t *__restrict__ list,
+                                                   uint32_t n, int shift, uint32_t *__restrict__ keys, const uint32_t *__restrict__ work_of)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pos = list[i], r = b.act[pos];
+    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFFu - work_of[pos]; return; }      // k_flat has added the intervals up already
+    const int len = (int)b.lens[r];
+    ReadPlan p = make_plan(len, cfg);
+    int mm, cl, cd, dummy[1];
+    phase_params(p, cfg, phase, mm, cl, cd);
+    int nc = core_offsets(len, cl, cd, p.max_slides, dummy, 0);
+    if (nc > kMaxCoresFast) nc = kMaxCoresFast;
+    const int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
+    uint32_t best_n = 0;
+    uint64_t best_first = 0, work = 0;
+    for (int st = s0; st <= s1; st++)
+        for (int c = 0; c < nc; c++) {
+            uint64_t slot = iv_slot(b, pos, st, c);
+            uint64_t f;
+            uint32_t raw;
+            iv_get(b, slot, f, raw);
+            uint32_t cnt = raw & ~kLazyFlag;
+            work += cnt;
+            if (cnt > best_n) { best_n = cnt; best_first = f; }
+        }
+    // shift < 0: longest job first (the reads are dealt to the waves in list order; a read with 10^5 candidates that comes up last
+    // keeps one wave busy long after the others have run dry)
+    keys[i] = shift < 0 ? 0xFFFFFFFFu - (uint32_t)(work < 0xFFFFFFFFULL ? work : 0xFFFFFFFFULL) : (uint32_t)(best_first >> shift);
+}
+
+void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
+                      const uint32_t *work_of, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys, work_of);
+}
+
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+                 int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
+                 hipStream_t s)
+{
+    const bool wide = ix.sa_hi != nullptr, hash = ix.isa == nullptr;
+    uint32_t waves = n_list < max_waves ? n_list : max_waves;
+    if (hash && waves > hs.n_slots) waves = hs.n_slots;
+    unsigned blocks = (waves + 3) / 4;
+#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
+    const bool sw = ix.swin != nullptr && b.rd2 != nullptr;
+    const bool group8 = (nw & 0x100) != 0;                 // 8-word form: small intervals share rounds (the 16-word form always does)
+    nw &= 0xff;
+    if (nw <= 8) {
+        if (wide) BK_WAVE(8, true, true, false, true);
+        else if (hash) BK_WAVE(8, false, true, false, true);
+        else if (sw) { if (group8) BK_WAVE(8, false, false, true, true); else BK_WAVE(8, false, false, true, false); }
+        else { if (group8) BK_WAVE(8, false, false, false, true); else BK_WAVE(8, false, false, false, false); }
+    } else if (nw <= 16) {
+        if (wide) BK_WAVE(16, true, true, false, true);
+        else if (hash) BK_WAVE(16, false, true, false, true);
+        else if (sw) BK_WAVE(16, false, false, true, true);
+        else BK_WAVE(16, false, false, false, true);
+    } else if (nw <= kNwLong) {                            // reads of 257 .. 16 * kNwLong bases
+        if (wide) BK_WAVE(kNwLong, true, true, false, true);
+        else if (hash) BK_WAVE(kNwLong, false, true, false, true);
+        else BK_WAVE(kNwLong, false, false, false, true);
+    } else {                                               // .. 16 * kNwLongest bases
+        if (wide) BK_WAVE(kNwLongest, true, true, false, true);
+        else if (hash) BK_WAVE(kNwLongest, false, true, false, true);
+        else BK_WAVE(kNwLongest, false, false, false, true);
+    }
+#undef BK_WAVE
+}
+
+}  // namespace bk

@@ -106,7 +106,13 @@ typedef struct bk_timing {
     uint32_t n_search_launches;
     uint32_t n_extend_launches;
     uint32_t n_heavy_launches;
-    uint32_t reserved;
+    uint32_t n_search_b_launches;
+    /* the search stage by kernel (ms_search = their sum + the clears of the interval records): pass A (k-mer table + small buckets),
+     * the grouping of pass B's work list (keys + radix sort), pass B (bisection of the big buckets) */
+    float    ms_search_a;
+    float    ms_search_sort;
+    float    ms_search_b;
+    float    ms_prep;           /* read preparation (2-bit rows of both strands, N policy, first active list); part of ms_other */
 } bk_timing;
 
 typedef struct bk_entry_info {
@@ -158,6 +164,7 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
  *   "use_swin" (suffix-ordered window array for reads of <= 100 bases, 0: windows from the 2-bit target, 2: built whatever the batch's longest read)
+ *   "swin_resident" (read only, value ignored: 1 when the window array is in HBM right now)
  *   "wave_group" (wave kernel, reads of <= 128 bases: small core intervals share a round)
  *   "chunk_reads" (reads per pass over the phases)   "max_read_len"
  * returns the old value or <0 */

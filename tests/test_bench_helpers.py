@@ -44,4 +44,12 @@ def test_fasta_writer_and_profile_lookup(tmp_path):
     assert names == [f"r{i:09d}" for i in range(1, 8)] and list(lens) == [100] * 7
     assert np.array_equal(bases & 7, np.where(reads > 3, 4, reads))
     t, src = b.profiled_traffic("k_wave")
-    assert t is None or (t > 1e9 and src.endswith("_pmc_summary.csv"))
+    assert t is None or (t[0] > 1e9 and t[1] >= 0 and src.endswith("_pmc_summary.csv"))
+
+
+def test_fetch_size_correction_follows_the_committed_calibration():
+    """random-line patterns are counted exactly; the window array's streaming runs are counted at about half (profiles/*_fetch_calibration.csv)"""
+    b = _bench()
+    assert b.fetch_correction("k_flat", True)[0] == 1.0 and b.fetch_correction("k_wave", False)[0] == 1.0
+    f, src = b.fetch_correction("k_wave", True)
+    assert 1.5 < f < 2.5, (f, src)

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(bk.AlignParams) == 48              # bk_align_params
     assert bk.ENTRY_DTYPE.itemsize == 112                   # bk_entry_info (8-byte aligned)
     assert ctypes.sizeof(binding._Counters) == 64
-    assert ctypes.sizeof(binding._Timing) == 36
+    assert ctypes.sizeof(binding._Timing) == 52              # bk_timing: 5 + 4 floats, 4 launch counts
     assert helpers.HIT_DTYPE == bk.HIT_DTYPE                # oracle ora_hit has the same layout
 
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def test_two_ranks_shard_one_read_set_like_a_single_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--dist-backend", "gloo",
-           "--genome-mbp", "30", "--reads", "400000", "--steps", "1", "--warmup", "1", "--cpu-baseline-secs", "0", "--stream-steps", "1",
+           "--genome-mbp", "30", "--reads", "400000", "--steps", "1", "--warmup", "1", "--cpu-baseline-secs", "0",
            "--stream-batch", "100000", "--shard-check-reads", "300000", "--no-live-traffic"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -28,6 +28,9 @@ def test_two_ranks_shard_one_read_set_like_a_single_rank():
     assert sc["per_sequence_counts_equal_1gpu_run"] and sc["nar_histogram_equal_1gpu_run"] and sc["accepted"] > 0
     assert d["strong_scaling"]["reads_total_per_step"] == 400000 and d["strong_scaling"]["value"] > 0
     assert d["t_align_host_resident"]["results_bit_identical_to_kernel_only_steps"]
+    # `value` is the host-in / host-out clock (SURVEY 8d T_align), the kernel-only rate stands beside it
+    assert d["value"] == d["t_align_host_resident"]["value"] and d["value_kernel_only"] > 0 and "host memory" in d["value_clock"]
+    assert d["config"]["window_array"].startswith("off") and d["roofline"]["window_array"] == "off"
 
 
 def test_rank_count_mismatch_is_refused():

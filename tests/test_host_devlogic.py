@@ -1,13 +1,19 @@
 """Device helpers that are pure bit / index arithmetic, compiled for the host and checked against brute force (CPU only):
 the layout helpers of k_wave's mismatch map (bits_to_imap, imask_word, im_clean) against per-base loops.
-The function texts are taken from biokanga_amd/csrc/bk_kernels.hip as they stand (no copy kept here)."""
+The function texts are taken from the device sources under biokanga_amd/csrc/ (bk_dev_*.h, *.hip) as they stand (no copy kept here)."""
 import os
 import re
 import subprocess
 
 import helpers
 
-SRC = os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "bk_kernels.hip")
+CSRC = os.path.join(helpers.ROOT, "biokanga_amd", "csrc")
+
+
+def _device_sources():
+    """the text of every device source file, shared helper headers first"""
+    names = sorted(f for f in os.listdir(CSRC) if f.startswith("bk_dev_") and f.endswith(".h")) + sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return "\n".join(open(os.path.join(CSRC, f)).read() for f in names)
 
 
 def _between(text, start, end):
@@ -51,7 +57,7 @@ int main() { if (test_imap<8>() || test_imap<16>()) return 1; printf("ok\n"); re
 
 
 def test_device_bit_helpers_against_brute_force(tmp_path):
-    text = open(SRC).read()
+    text = _device_sources()
     parts = [_between(text, "__device__ __forceinline__ uint64_t spread32(", "template <int NW>\n__device__ __forceinline__ void window_to_iwindow(")]
     code = MAIN % _hostify("\n".join(parts))
     assert "imask_word" in code and "im_clean" in code
@@ -176,8 +182,8 @@ int main() { if (test<4>() || test<8>()) return 1; printf("ok\n"); return 0; }
 
 def test_packed_read_helpers_against_brute_force(tmp_path):
     """revcomp2 (reverse complement of a 2 bit/base row) and packed_word16 (a 16-base word of a packed read or of its reverse
-    complement), as they stand in bk_kernels.hip, against per-base loops"""
-    text = open(SRC).read()
+    complement), as they stand in the device sources, against per-base loops"""
+    text = _device_sources()
     code = _between(text, "__device__ __forceinline__ uint32_t rev2_32(", "// exceptions of a packed batch, one lane each.")
     src, exe = str(tmp_path / "packed.cpp"), str(tmp_path / "packed")
     open(src, "w").write(PACKED_MAIN % _hostify(code))

@@ -4,6 +4,6 @@
 for kv in "" "$@"; do
   args=""
   [ -n "$kv" ] && args="--tune $kv"
-  line=$(python3 bench.py --steps 3 --warmup 1 --cpu-baseline-secs 0 --stream-steps 0 --no-live-traffic $args 2>/dev/null | grep '^{' | tail -1)
+  line=$(python3 bench.py --steps 3 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic $args 2>/dev/null | grep '^{' | tail -1)
   echo "knob [$kv]: $(echo "$line" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,1), 'M reads/s', round(d['ms_per_step'],2), 'ms/step')")"
 done

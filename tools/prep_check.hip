@@ -1,5 +1,5 @@
 // debug harness: k_prep_fused<16, true> (packed input) on n reads of 150 bases, rows checked against host code
-#include "../biokanga_amd/csrc/bk_kernels.hip"
+#include "../biokanga_amd/csrc/bk_prep.hip"
 #include <vector>
 #include <random>
 #include <cstdio>

@@ -8,7 +8,7 @@ shift
 raw=gpurun_out/quick_$tag
 mkdir -p $raw
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -o run -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline-secs 0 --stream-steps 0 --no-live-traffic "$@" > $raw/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -o run -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic "$@" > $raw/stats.log 2>&1
 grep '^{' $raw/stats.log | tail -1 > $raw/bench_line.json
 python3 tools/summarize_prof.py stats $raw/stats > $raw/kernel_stats.csv
 rm -rf $raw/stats

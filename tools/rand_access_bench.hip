@@ -48,6 +48,51 @@ __global__ void k_calib80(const uint4 *__restrict__ tab, uint64_t mask16, uint64
     }
     if (acc == 0x1234567) out[0] = acc;
 }
+// the window array's pattern (k_wave with DevIndex::swin): a wave reads 64 CONSECUTIVE 48-byte entries per round - each lane three
+// 16-byte loads - from a random place of the table: the "wide coalesced 16 B/lane streaming read" the guide says FETCH_SIZE may
+// report at half its size.  runs of 1 round (what most k_wave rounds are) and of 16 rounds.
+template <int ROUNDS>
+__device__ __forceinline__ void calib_runs_body(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int runs_per_wave)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
+    for (int r = 0; r < runs_per_wave; r++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t start = (x >> 16) % (n_entries - (uint64_t)ROUNDS * 64);
+        for (int k = 0; k < ROUNDS; k++) {
+            const uint4 *e = tab + (start + (uint64_t)k * 64 + lane) * 3;
+            const uint4 a = e[0], b = e[1], c = e[2];
+            acc += a.x ^ b.y ^ c.z;
+        }
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_calib_runs1(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int rpw) { calib_runs_body<1>(tab, n_entries, out, rpw); }
+__global__ void __launch_bounds__(256) k_calib_runs16(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int rpw) { calib_runs_body<16>(tab, n_entries, out, rpw); }
+// k_wave's round with the window array, whole: the 64 consecutive 48-byte entries AND the 64 consecutive 4-byte suffix array
+// elements that go with them (52 bytes per candidate)
+__global__ void __launch_bounds__(256) k_calib_wave(const uint4 *__restrict__ tab, uint64_t n_entries, const uint32_t *__restrict__ sa, uint64_t *out, int rpw)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
+    for (int r = 0; r < rpw; r++) {
+        x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+        const uint64_t start = (x >> 16) % (n_entries - 64);
+        const uint4 *e = tab + (start + lane) * 3;
+        const uint4 a = e[0], b = e[1], c = e[2];
+        acc += a.x ^ b.y ^ c.z ^ sa[start + lane];
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+// .. and the plain streaming read the guide's own calibration used: every lane 16 bytes, consecutive lanes consecutive addresses
+__global__ void __launch_bounds__(256) k_calib_stream16(const uint4 *__restrict__ tab, uint64_t n16, uint64_t *out)
+{
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) { const uint4 v = tab[i]; acc += v.x ^ v.w; }
+    if (acc == 0x1234567) out[0] = acc;
+}
 static int calib()
 {
     uint64_t bytes = 16ULL << 30;
@@ -60,6 +105,19 @@ static int calib()
     hipLaunchKernelGGL(k_calib80, dim3(blocks), dim3(256), 0, 0, (const uint4 *)tab, bytes / 16 - 1, out, iters);
     hipDeviceSynchronize();
     printf("calib: %llu accesses per kernel (k_calib8: 8 B each, k_calib80: 80 B each)\n", (unsigned long long)blocks * 256 * iters);
+    const uint64_t n_entries = bytes / 48;
+    const int waves = 16384, rpw1 = 1024, rpw16 = 64;
+    hipLaunchKernelGGL(k_calib_runs1, dim3(waves / 4), dim3(256), 0, 0, (const uint4 *)tab, n_entries, out, rpw1);
+    hipLaunchKernelGGL(k_calib_runs16, dim3(waves / 4), dim3(256), 0, 0, (const uint4 *)tab, n_entries, out, rpw16);
+    hipLaunchKernelGGL(k_calib_stream16, dim3(16384), dim3(256), 0, 0, (const uint4 *)tab, bytes / 16, out);
+    uint32_t *sa;
+    hipMalloc(&sa, n_entries * 4);
+    hipMemset(sa, 1, n_entries * 4);
+    hipLaunchKernelGGL(k_calib_wave, dim3(waves / 4), dim3(256), 0, 0, (const uint4 *)tab, n_entries, sa, out, rpw1);
+    hipDeviceSynchronize();
+    printf("calib: k_calib_wave: %llu entries of 52 B (48-byte window entry + 4-byte suffix array element) in runs of 64\n", (unsigned long long)waves * rpw1 * 64);
+    printf("calib: k_calib_runs1: %llu entries of 48 B in runs of 64; k_calib_runs16: %llu entries of 48 B in runs of 1024; k_calib_stream16: %llu B streamed once\n",
+           (unsigned long long)waves * rpw1 * 64, (unsigned long long)waves * rpw16 * 16 * 64, (unsigned long long)bytes);
     return 0;
 }
 // ---- `bin`: the k_wave restructuring the round-1 review asked to be tried (candidates binned by target region so that the window
