@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
     "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device", "bk_sam_prepare", "bk_sam_prep_free",
+    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async",
 ]
 
 
@@ -138,6 +139,16 @@ def load_library():
     lib.bk_ctx_destroy.restype = None
     lib.bk_ctx_set_params.argtypes = [vp, ctypes.POINTER(AlignParams)]
     lib.bk_ctx_set_params.restype = i32
+    lib.bk_ctx_reserve.argtypes = [vp, u32, u32]
+    lib.bk_ctx_reserve.restype = i32
+    lib.bk_align_batch_device_async.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp]
+    lib.bk_align_batch_device_async.restype = i32
+    lib.bk_stream_create_packed.argtypes = [ctypes.POINTER(vp), vp, u32, u64, i32, vp]
+    lib.bk_stream_create_packed.restype = i32
+    lib.bk_host_register.argtypes = [vp, ctypes.c_size_t]
+    lib.bk_host_register.restype = i32
+    lib.bk_host_unregister.argtypes = [vp]
+    lib.bk_host_unregister.restype = None
     lib.bk_ctx_tune.argtypes = [vp, ctypes.c_char_p, i64]
     lib.bk_ctx_tune.restype = i64
     lib.bk_num_entries.argtypes = [vp]
@@ -513,6 +524,17 @@ class Aligner:
         if rc:
             raise BkError(rc, "bk_align_batch_device")
 
+    def align_device_async(self, d_bases, d_offs, d_lens, nreads, max_read_len, d_out, stream=None):
+        """bk_align_batch_device_async: every phase enqueued on `stream` (a hipStream_t as int, None = the context's own), nothing waited for"""
+        rc = self.lib.bk_align_batch_device_async(self.h, d_bases, d_offs, d_lens, nreads, int(max_read_len), d_out, stream)
+        if rc:
+            raise BkError(rc, "bk_align_batch_device_async")
+
+    def reserve(self, max_batch_reads, max_read_len):
+        rc = self.lib.bk_ctx_reserve(self.h, int(max_batch_reads), int(max_read_len))
+        if rc:
+            raise BkError(rc, "bk_ctx_reserve")
+
     def counters(self, reset=False):
         c = _Counters()
         rc = self.lib.bk_get_counters(self.h, ctypes.byref(c), 1 if reset else 0)
@@ -558,12 +580,17 @@ def host_array(n, dtype):
 class Stream:
     """bk_stream_*: overlapped upload / align / download of consecutive batches on one context."""
 
-    def __init__(self, aligner, max_batch_reads, max_batch_bases, depth=3, pe=None):
+    def __init__(self, aligner, max_batch_reads, max_batch_bases, depth=3, pe=None, packed_words=0):
+        """packed_words != 0: a pipeline for packed batches of at most that many words only (bk_stream_create_packed; max_batch_bases is ignored)"""
         self.lib = aligner.lib
         self.al = aligner
         self.h = ctypes.c_void_p()
-        rc = self.lib.bk_stream_create(ctypes.byref(self.h), aligner.h, int(max_batch_reads), int(max_batch_bases), int(depth),
-                                       ctypes.byref(pe) if pe is not None else None)
+        if packed_words:
+            rc = self.lib.bk_stream_create_packed(ctypes.byref(self.h), aligner.h, int(max_batch_reads), int(packed_words), int(depth),
+                                                  ctypes.byref(pe) if pe is not None else None)
+        else:
+            rc = self.lib.bk_stream_create(ctypes.byref(self.h), aligner.h, int(max_batch_reads), int(max_batch_bases), int(depth),
+                                           ctypes.byref(pe) if pe is not None else None)
         if rc:
             self.h = None
             raise BkError(rc, "bk_stream_create")

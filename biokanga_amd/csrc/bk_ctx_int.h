@@ -88,7 +88,16 @@ struct bk_ctx {
     uint32_t *d_wave_work = nullptr;      // DevBatch::wave_work
     uint32_t *d_stage[3] = {nullptr, nullptr, nullptr}, *d_stripe_cnt = nullptr, *d_slist_stage = nullptr;       // striped work lists (bk::StripeSet)
     uint32_t *d_small = nullptr;          // [0] act_cnt [1] next_cnt [2] heavy_cnt [3] cmax [4] cursor [5] maxlen [6] wave_cnt [7] wave cursor
-    uint32_t *h_small = nullptr;          // pinned mirror
+    uint32_t *h_small = nullptr;          // pinned mirror (two PhaseCtl lines when the phase loop reads its counts back)
+    bk::PhaseCtl *d_ctl = nullptr;        // kMaxPhases + 2 lines: the counts of a chunk's phases (bk_device.h)
+    bk::PhaseCtl *h_ctl = nullptr;        // pinned: the last chunk's counts, copied behind its kernels
+    hipEvent_t ev_ctl = nullptr;
+    bool ctl_pending = false, hist_valid = false;
+    uint32_t ctl_pending_reads = 0, ctl_pending_maxlen = 0;
+    int ctl_pending_phases = 0;
+    double hist_slist[bk::kMaxPhases] = {0}, hist_wave[bk::kMaxPhases] = {0};      // per phase: pass B items / wave-kernel reads per read of the chunk
+    int async_error = 0;     // what take_phase_history found wrong with a batch of bk_align_batch_device_async (reported by the next call)
+    int async_phases = 1;    // 1: the main path's phase loop launches without reading counts back (see align_chunk)
     unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr, *d_ctr_aux = nullptr;
     unsigned long long *d_seq_global = nullptr;   // bk_seq_counts_allreduce: the counts summed over every context of the run
     // heavy path scratch

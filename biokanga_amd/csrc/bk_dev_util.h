@@ -110,6 +110,15 @@ __device__ __forceinline__ void stripe_put(const StripeSet &l, int li, uint32_t 
 {
     l.stage[li][(uint64_t)(blockIdx.x & (kListStripes - 1)) * l.cap + at] = v;
 }
+// the same for a kernel whose blocks take several tiles of work: the stripe goes by the tile's number (the capacity is counted in tiles)
+__device__ __forceinline__ uint32_t stripe_reserve_tile(const StripeSet &l, int li, uint32_t n, uint64_t tile)
+{
+    return atomicAdd(&l.cnt[(uint32_t)(tile & (kListStripes - 1)) * 16 + li], n);
+}
+__device__ __forceinline__ void stripe_put_tile(const StripeSet &l, int li, uint32_t at, uint32_t v, uint64_t tile)
+{
+    l.stage[li][(tile & (kListStripes - 1)) * l.cap + at] = v;
+}
 __device__ __forceinline__ void stripe_max(const StripeSet &l, uint32_t v)
 {
     atomicMax(&l.cnt[(kListStripes + (blockIdx.x & (kListStripes - 1))) * 16], v);        // a line of its own (see StripeSet)

@@ -121,6 +121,21 @@ struct DevBatch {
     uint32_t iv_cores;          // cores per strand the interval slots are numbered for (<= kMaxCoresFast: the most a read of this batch can have)
 };
 
+// The counts of one AlignReads phase over a chunk of reads, in device memory: the phase loop's kernels size themselves by them, so
+// the host never has to read a count back between two launches (a launch's grid comes from a bound the host does know - a phase's
+// active list is never longer than the one before it - and blocks beyond the count have nothing to do).  One 64-byte line per phase,
+// zeroed when a chunk starts; phase p's kernels read ctl[p] and leave n_act of the next phase in ctl[p + 1].
+struct PhaseCtl {
+    uint32_t n_act;             // reads on the phase's active list
+    uint32_t cmax;              // most cores any of them has (informative: launches use the bound of the batch's longest read)
+    uint32_t n_slist;           // work items pass A left for pass B
+    uint32_t n_wave;            // reads k_flat handed to the wave kernel
+    uint32_t n_heavy;           // .. and to the general kernel
+    uint32_t wave_cursor, heavy_cursor;
+    uint32_t pad[9];
+};
+constexpr int kMaxPhases = 72;          // AlignReads runs at most MaxTotMM + 2 <= 65 LocateCoreMultiples calls (cMaxTotAllowedSubs 63)
+
 struct HeavyScratch {
     unsigned long long *htab;   // slots * tab_size entries of (epoch<<32 | key)
     uint32_t *slot_epoch;

@@ -52,23 +52,24 @@ void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
-void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s);
-void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
-                     uint32_t n_list, hipStream_t s);
+void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list, const uint32_t *sorted,
+                     uint32_t n_sorted, const uint32_t *p_n_list, uint64_t n_bound, hipStream_t s);
+void launch_clear_iv(const DevBatch &b, const uint32_t *p_n_act, uint32_t n_act_bound, int cmax, int st0, int st1, hipStream_t s);
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, bk_seg2 *seg2, int min_chim,
                int long_reads, hipStream_t s);
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                   uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
                   uint32_t *cmax_next, int nw, hipStream_t s);
-void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s);
-void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
-                 int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
-                 hipStream_t s);
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, const uint32_t *sorted,
+                 uint32_t n_sorted, const uint32_t *p_n_list, uint32_t n_bound, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt,
+                 uint32_t *cmax_next, int nw, uint32_t max_waves, hipStream_t s);
 void launch_heavy(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list,
                   uint32_t n_list, int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next,
                   hipStream_t s);
@@ -90,8 +91,8 @@ void launch_loci_enum(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch
                       bk_seg2 *seg2, bk_loci_trims *trims, hipStream_t s);
 int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n,
                      void *tmp, size_t *tmp_bytes, hipStream_t s);
-void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s);
-void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
+void launch_keys_search(const DevBatch &b, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys, hipStream_t s);
+void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys,
                       const uint32_t *work_of, hipStream_t s);
 }  // namespace bk
 
@@ -381,8 +382,11 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     HIP_TRY(hipMalloc(&c->d_ctr, (size_t)kCtrStripes * 8 * 8));
     HIP_TRY(hipMemset(c->d_ctr, 0, (size_t)kCtrStripes * 8 * 8));
     HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
+    HIP_TRY(hipMalloc(&c->d_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
+    HIP_TRY(hipHostMalloc(&c->h_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->d_ctr_aux, 32));
-    HIP_TRY(hipHostMalloc(&c->h_small, 16 * 4));
+    HIP_TRY(hipHostMalloc(&c->h_small, 2 * sizeof(PhaseCtl)));
     int rc = derive_cfg(c);
     clk0.lap("entry table, small buffers");
     return rc;
@@ -494,10 +498,12 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
 
 struct EvTimer {
     bk_ctx *c;
+    bool on = true;                     // off: no events (a call that returns before its kernels have run cannot read them)
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;   // kind, (start, stop)
     size_t next_ev = 0;
     hipEvent_t get()
     {
+        if (!on) return nullptr;
         if (next_ev == c->ev_pool.size()) {
             hipEvent_t e;
             (void)hipEventCreate(&e);
@@ -508,12 +514,13 @@ struct EvTimer {
     hipEvent_t begin(hipStream_t s)
     {
         hipEvent_t e = get();
-        (void)hipEventRecord(e, s);
+        if (e) (void)hipEventRecord(e, s);
         return e;
     }
     void end(int kind, hipEvent_t b, hipStream_t s)
     {
         hipEvent_t e = get();
+        if (!e) return;
         (void)hipEventRecord(e, s);
         spans.push_back({kind, {b, e}});
     }
@@ -728,14 +735,53 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     b.wpr = wpr; b.n_reads = n; b.iv_cores = ivc;
     const int nstr = c->cfg.align_strand == 0 ? 2 : 1;
 
+    // ---- the phase loop ---------------------------------------------------------------------------------------------------------
+    // Every count the phases produce (active reads, pass B's work items, reads for the wave kernel) stays in device memory (PhaseCtl,
+    // one line per phase) and the kernels size themselves by it.  On the main path - register-window kernels, k_flat, second-level
+    // keys - the host therefore launches the whole schedule without reading anything back: grids come from bounds it knows (an active
+    // list is never longer than the chunk; a read of up to maxlen bases has at most so many cores and phases), the two work-list sorts
+    // are sized from what the previous chunk needed (items beyond that run unsorted: order never changes a result).  The other
+    // configurations (general kernel family, lane-per-read kernels, no key array, -N, BK_DEBUG) keep reading the counts back, which
+    // sizes their launches exactly.
+    PhaseCtl *ctl = c->d_ctl;
+    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(PhaseCtl) * (kMaxPhases + 2), s));
+    auto P = [&](int ph) { return reinterpret_cast<uint32_t *>(ctl + ph); };      // words of ctl[ph]: [0] n_act [1] cmax [2] n_slist [3] n_wave [4] n_heavy [5] wave cursor [6] heavy cursor
+    // bounds of a read of up to maxlen bases: phases, cores per strand in each
+    int max_phases = 0, cmax_bound[kMaxPhases + 1] = {0};
+    bool cores_fit = true;
+    for (uint32_t len = 1; len <= maxlen; len++) {
+        const ReadPlan p = make_plan((int)len, c->cfg);
+        max_phases = std::max(max_phases, p.n_phases);
+        for (int ph = 0; ph < p.n_phases && ph <= kMaxPhases; ph++) {
+            int mm, cl, cd, dummy[1];
+            phase_params(p, c->cfg, ph, mm, cl, cd);
+            const int nc = core_offsets((int)len, cl, cd, p.max_slides, dummy, 0);
+            if (nc > kMaxCoresFast) cores_fit = false;
+            cmax_bound[ph] = std::max(cmax_bound[ph], std::min(nc, (int)kMaxCoresFast));
+        }
+    }
+    if (max_phases > kMaxPhases) return BK_ERR_INTERNAL;
+    const bool no_readback = reg_path && c->use_flat && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && cores_fit && !c->params.best_matches &&
+                             !c->debug && c->async_phases;
+    const bool check_maxlen = !tm.on;                 // (a call that only enqueues: its caller named the longest read, nobody has looked)
+    if (check_maxlen) launch_max_len(d_lens, n, P(kMaxPhases + 1) + 0, s);
     hipEvent_t e0 = tm.begin(s);
-    launch_prep(c->cfg, b, c->d_act[0], sm + 0, sm + 3, c->d_stage[0], c->d_stripe_cnt, s);
+    launch_prep(c->cfg, b, c->d_act[0], P(0) + 0, P(0) + 1, c->d_stage[0], c->d_stripe_cnt, s);
     HIP_TRY(hipGetLastError());
     tm.end(7, e0, s);
-    HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint32_t n_act = hm[0];
-    int cmax = (int)hm[3];
+    uint32_t n_act = n;
+    int cmax = cmax_bound[0];
+    auto read_ctl = [&](int ph) -> int {           // ctl[ph], ctl[ph + 1] -> hm[0..31]
+        HIP_TRY(hipMemcpyAsync(hm, ctl + ph, 2 * sizeof(PhaseCtl), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return BK_OK;
+    };
+    if (!no_readback) {
+        int rr = read_ctl(0);
+        if (rr) return rr;
+        n_act = hm[0];
+        cmax = (int)hm[1];
+    }
     int cur = 0;
     if (c->params.best_matches) {
         hipEvent_t eb = tm.begin(s);
@@ -744,19 +790,19 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         tm.end(2, eb, s);
         n_act = 0;
     }
-    for (int phase = 0; n_act > 0; phase++) {
-        // [1] next_cnt [2] heavy_cnt [3] cmax_next [4] cursor, [6] wave_cnt [7] wave cursor, [8] search work list
-        HIP_TRY(hipMemsetAsync(sm + 1, 0, 4 * 4, s));
-        HIP_TRY(hipMemsetAsync(sm + 6, 0, 5 * 4, s));
+    b.iv_stride = n;                               // interval records and the wave list go by position in the phase's active list
+    if (no_readback && c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe of the wave kernel
+    for (int phase = 0; no_readback ? phase < max_phases : n_act > 0; phase++) {
         const uint32_t *ext_list = c->d_act[cur];
-        const uint32_t n_ext = n_act;
-        b.act = ext_list;                          // interval records and the wave list go by position in this list
-        b.iv_stride = n_act;
+        b.act = ext_list;
+        if (no_readback) cmax = cmax_bound[phase];
+        const uint32_t n_bound = n_act;            // (no read-back: the chunk's size; else the list's length)
+        uint32_t *ctl_p = P(phase), *ctl_n = P(phase + 1);
+        const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
         if (cmax > 0) {
-            const int lazy = (reg_path && c->lazy_search) ? 1 : 0;
             hipEvent_t e1 = tm.begin(s);
             if (c->ix.k2) {
-                const uint64_t lanes = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+                const uint64_t lanes = (uint64_t)n_bound * (uint64_t)(cmax * nstr);
                 if (lanes > c->cap_slist) {
                     HIP_TRY(hipStreamSynchronize(s));
                     free_dev(c->d_slist);
@@ -767,30 +813,41 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                     HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
                     c->cap_slist = lanes;
                 }
-                // interval counts of the slots this phase can use: [strand][core][position in the active list] -> one contiguous range per strand
-                for (int st = (c->cfg.align_strand == 2 ? 1 : 0); st <= (c->cfg.align_strand == 1 ? 0 : 1); st++)
-                    if (c->d_iv2) HIP_TRY(clear_dev(c->d_iv2 + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 8, s));
-                    else HIP_TRY(clear_dev(c->d_iv_n + (size_t)st * ivc * n_act, (size_t)cmax * n_act * 4, s));
+                // interval counts of the slots this phase can use, zeroed (empty search results store nothing)
+                launch_clear_iv(b, ctl_p + 0, n_bound, cmax, c->cfg.align_strand == 2 ? 1 : 0, c->cfg.align_strand == 1 ? 0 : 1, s);
                 hipEvent_t ea = tm.begin(s);
-                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], n_act, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, sm + 8,
+                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], ctl_p + 0, n_bound, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, ctl_p + 2,
                                 c->d_slist_stage, c->d_stripe_cnt, s);
                 HIP_TRY(hipGetLastError());
                 tm.end(4, ea, s);
-                HIP_TRY(hipMemcpyAsync(hm + 8, sm + 8, 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                const uint32_t *slist = c->d_slist;
-                if ((c->sort_lists & 1) && hm[8] >= 4096) {
-                    int rs = ensure_sort_scratch(c, hm[8], s);
+                // pass B's work list, grouped by k-mer bucket: the sort's size is the list's length when that was read back, else what
+                // the previous chunk's phase needed (plus a margin; capped at the sort buffers)
+                uint64_t n_slist_bound = lanes;
+                uint32_t n_sort = 0;
+                if (!no_readback) {
+                    HIP_TRY(hipMemcpyAsync(hm + 2, ctl_p + 2, 4, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    n_slist_bound = hm[2];
+                    n_sort = hm[2];
+                } else {
+                    const double f = c->hist_valid ? c->hist_slist[phase] * 1.05 : 0.30;
+                    n_sort = (uint32_t)std::min<uint64_t>({(uint64_t)(f * n) + 4096, lanes, (uint64_t)0x7FFFFFF0});
+                }
+                if (no_readback && c->cap_sort >= 4096) n_sort = (uint32_t)std::min<uint64_t>(n_sort, c->cap_sort);      // (no growing - it waits for the stream - for a guess)
+                const uint32_t *sorted = nullptr;
+                if ((c->sort_lists & 1) && n_sort >= 4096) {
+                    int rs = ensure_sort_scratch(c, n_sort, s);
                     if (rs) return rs;
                     hipEvent_t es = tm.begin(s);
-                    launch_keys_search(b, c->d_slist, hm[8], c->sort_shift, c->d_sort[0], s);
-                    rs = sort_work(c, c->d_slist, hm[8], s, &slist);
+                    launch_keys_search(b, c->d_slist, ctl_p + 2, n_sort, c->sort_shift, c->d_sort[0], s);
+                    rs = sort_work(c, c->d_slist, n_sort, s, &sorted);
                     if (rs) return rs;
                     tm.end(5, es, s);
-                }
-                if (hm[8]) {
+                } else
+                    n_sort = 0;
+                if (n_slist_bound) {
                     hipEvent_t eb = tm.begin(s);
-                    launch_search_b(c->ix, c->cfg, b, phase, lazy, slist, hm[8], s);
+                    launch_search_b(c->ix, c->cfg, b, phase, lazy, c->d_slist, sorted, n_sort, ctl_p + 2, n_slist_bound, s);
                     tm.end(6, eb, s);
                 }
             } else
@@ -805,52 +862,73 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         // every other one to the hash-set kernels.
         DevAlignCfg cfg_lane = c->cfg;
         if (c->ix.n > (1ULL << 32)) cfg_lane.heavy_thresh = 0;            // (below that the truncated keys are the exact ones)
-        if (n_ext == 0) {}
+        if (n_bound == 0) {}
         else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
-            launch_flat(c->ix, c->cfg, b, ext_list, n_ext, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2,
-                        c->d_wave, sm + 6, sm + 3, c->d_stage, c->d_stripe_cnt, nw16 | (c->flat_block << 8), s);
+            launch_flat(c->ix, c->cfg, b, ext_list, ctl_p + 0, n_bound, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4,
+                        c->d_wave, ctl_p + 3, ctl_n + 1, c->d_stage, c->d_stripe_cnt, nw16 | (c->flat_block << 8), s);
         else if (reg_path)
-            launch_light(c->ix, cfg_lane, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, c->d_wave, sm + 6,
-                         sm + 3, nw16, s);
+            launch_light(c->ix, cfg_lane, b, ext_list, n_act, phase, c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4, c->d_wave, ctl_p + 3,
+                         ctl_n + 1, nw16, s);
         else
-            launch_extend(c->ix, cfg_lane, b, ext_list, n_ext, phase, c->d_act[cur ^ 1], sm + 1, c->d_heavy, sm + 2, sm + 3, s);
+            launch_extend(c->ix, cfg_lane, b, ext_list, n_act, phase, c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4, ctl_n + 1, s);
         HIP_TRY(hipGetLastError());
         tm.end(1, e2, s);
-        HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        uint32_t n_heavy = hm[2], n_wave = hm[6];
+        uint32_t n_heavy = 0, n_wave = n_bound;    // (no read-back: any read of the list may have gone to the wave kernel)
+        if (!no_readback) {
+            int rr = read_ctl(phase);
+            if (rr) return rr;
+            n_heavy = hm[4];
+            n_wave = hm[3];
+        }
         if (n_wave) {
             hipEvent_t e3 = tm.begin(s);
-            const uint32_t *wlist = c->d_wave;
-            if ((c->sort_lists & 2) && n_wave >= 4096) {
-                int rs = ensure_sort_scratch(c, n_wave, s);
-                if (rs) return rs;
-                launch_keys_wave(c->cfg, b, phase, c->d_wave, n_wave, (c->sort_lists & 4) ? -1 : c->sort_shift, c->d_sort[0], b.wave_work, s);
-                rs = sort_work(c, c->d_wave, n_wave, s, &wlist);
-                if (rs) return rs;
+            const uint32_t *wsorted = nullptr;
+            uint32_t n_sort = n_wave;
+            if (no_readback) {
+                const double f = c->hist_valid ? c->hist_wave[phase] * 1.05 : 0.25;
+                n_sort = (uint32_t)std::min<uint64_t>((uint64_t)(f * n) + 4096, n_wave);
+                if (c->cap_sort >= 4096) n_sort = (uint32_t)std::min<uint64_t>(n_sort, c->cap_sort);
             }
-            if (c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
-            launch_wave(c->ix, c->cfg, b, c->hs, wlist, n_wave, phase, sm + 7, c->d_act[cur ^ 1], sm + 1, sm + 3, nw16 | (c->wave_group ? 0x100 : 0), c->wave_waves, s);
+            if ((c->sort_lists & 2) && n_sort >= 4096) {
+                int rs = ensure_sort_scratch(c, n_sort, s);
+                if (rs) return rs;
+                launch_keys_wave(c->cfg, b, phase, c->d_wave, ctl_p + 3, n_sort, (c->sort_lists & 4) ? -1 : c->sort_shift, c->d_sort[0], b.wave_work, s);
+                rs = sort_work(c, c->d_wave, n_sort, s, &wsorted);
+                if (rs) return rs;
+            } else
+                n_sort = 0;
+            if (!no_readback && c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
+            launch_wave(c->ix, c->cfg, b, c->hs, c->d_wave, wsorted, n_sort, ctl_p + 3, n_wave, phase, ctl_p + 5, c->d_act[cur ^ 1], ctl_n + 0, ctl_n + 1,
+                        nw16 | (c->wave_group ? 0x100 : 0), c->wave_waves, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
         if (n_heavy) {
             hipEvent_t e3 = tm.begin(s);
             { int rh = size_heavy_scratch(c); if (rh) return rh; }
-            launch_heavy(c->ix, c->cfg, b, c->hs, c->d_heavy, n_heavy, phase, sm + 4, c->d_act[cur ^ 1], sm + 1, sm + 3, s);
+            launch_heavy(c->ix, c->cfg, b, c->hs, c->d_heavy, n_heavy, phase, ctl_p + 6, c->d_act[cur ^ 1], ctl_n + 0, ctl_n + 1, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
-        if (n_wave || n_heavy) {
-            HIP_TRY(hipMemcpyAsync(hm, sm, 16 * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+        if (!no_readback) {
+            if (n_wave || n_heavy) { int rr = read_ctl(phase); if (rr) return rr; }
+            if (c->debug)
+                fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u n_wave %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, n_wave, hm[16], hm[17]);
+            n_act = hm[16];                        // ctl[phase + 1].n_act, .cmax
+            cmax = (int)hm[17];
         }
-        if (c->debug)
-            fprintf(stderr, "bk: phase %d n_act %u cmax %d n_heavy %u n_wave %u -> next n_act %u cmax %u\n", phase, n_act, cmax, n_heavy, n_wave, hm[1], hm[3]);
-        n_act = hm[1];
-        cmax = (int)hm[3];
         cur ^= 1;
         if (phase > 70) return BK_ERR_INTERNAL;
+    }
+    if (no_readback) {
+        // what the phases needed goes to the host on its own time: it sizes the next chunk's sorts (and says whether a read was handed to the
+        // general kernel, which this schedule never launches: the core bound above rules it out)
+        HIP_TRY(hipMemcpyAsync(c->h_ctl, ctl, sizeof(PhaseCtl) * (kMaxPhases + 2), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_ctl, s));
+        c->ctl_pending = true;
+        c->ctl_pending_reads = n;
+        c->ctl_pending_phases = max_phases;
+        c->ctl_pending_maxlen = check_maxlen ? maxlen : 0;
     }
     if (c->params.micro_indel_len > 0 || c->params.splice_junct_len > 0 || c->params.min_chimeric_len > 0) {
         // AlignReads' branches for what is still unaligned (SfxArrayV2.cpp:7722-7757): microInDels, then splice junctions, then the
@@ -954,10 +1032,52 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     return BK_OK;
 }
 
-int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0)
+// What the last chunk that ran without read-backs needed, once its counts have arrived in h_ctl (the copy was enqueued behind its
+// kernels): work items of pass B and reads for the wave kernel per phase, as fractions of the chunk - the sizes of the next chunk's
+// sorts.  wait: block until they are there.  A read on a general-kernel list would mean the core bound of align_chunk was wrong.
+int take_phase_history(bk_ctx *c, bool wait)
+{
+    if (!c->ctl_pending) return BK_OK;
+    if (wait) HIP_TRY(hipEventSynchronize(c->ev_ctl));
+    else if (hipEventQuery(c->ev_ctl) != hipSuccess) { (void)hipGetLastError(); return BK_OK; }
+    c->ctl_pending = false;
+    const PhaseCtl *h = c->h_ctl;
+    const double n = (double)std::max<uint32_t>(c->ctl_pending_reads, 1);
+    for (int ph = 0; ph < kMaxPhases; ph++) {
+        c->hist_slist[ph] = ph < c->ctl_pending_phases ? (double)h[ph].n_slist / n : 0.0;
+        c->hist_wave[ph] = ph < c->ctl_pending_phases ? (double)h[ph].n_wave / n : 0.0;
+        if (h[ph].n_heavy) {
+            fprintf(stderr, "biokanga_amd: %u reads of phase %d were left for the general kernel by a schedule that does not run it\n", h[ph].n_heavy, ph);
+            c->async_error = BK_ERR_INTERNAL;
+        }
+    }
+    // (bk_align_batch_device_async: the longest read its caller promised against the longest the batch really held)
+    if (c->ctl_pending_maxlen && h[kMaxPhases + 1].n_act > c->ctl_pending_maxlen) {
+        fprintf(stderr, "biokanga_amd: a batch held a read of %u bases, its caller had promised at most %u\n", h[kMaxPhases + 1].n_act, c->ctl_pending_maxlen);
+        c->async_error = BK_ERR_PARAMS;
+    }
+    c->hist_valid = true;
+    if (c->async_error && wait) { const int e = c->async_error; c->async_error = 0; return e; }
+    return BK_OK;
+}
+
+// enqueue_only: everything is launched on `s` and the call returns without waiting for any of it (bk_align_batch_device_async): the
+// caller has named the longest read, the scratch is in place (bk_ctx_reserve) and the configuration is one whose phase loop reads
+// nothing back - else BK_ERR_PARAMS, before anything is launched.
+int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0, bool enqueue_only = false)
 {
     const uint32_t *d_lens = in.lens;
+    if (enqueue_only) {
+        const uint32_t ml = maxlen_known;
+        const bool plain = c->cfg.max_hits == 1 && !c->params.best_matches && !c->params.micro_indel_len && !c->params.splice_junct_len && !c->params.min_chimeric_len;
+        const bool fits = ml >= 1 && ml <= 16u * (uint32_t)kNwLongest && nreads <= c->cap_reads && nreads <= c->chunk_reads && words_per_read(ml) <= c->cap_wpr &&
+                          iv_cores_for(c, ml) <= c->cap_iv_cores && rd2w_for(ml) <= c->cap_rd2w &&
+                          (uint64_t)nreads * iv_cores_for(c, ml) * (c->cfg.align_strand == 0 ? 2u : 1u) <= c->cap_slist && (c->ix.isa != nullptr || c->hs.htab != nullptr);
+        const bool main_path = c->use_wave && c->use_flat && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && c->ix.tgt2 != nullptr && !c->debug && c->async_phases;
+        if (!plain || !fits || !main_path) return BK_ERR_PARAMS;
+    }
     EvTimer tm{c};
+    tm.on = !enqueue_only;
     hipEvent_t t0 = tm.begin(s);
     c->loci_offs.clear();
     c->loci.clear();
@@ -974,10 +1094,11 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     }
     if (maxlen > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
     c->last_maxlen = maxlen;
+    (void)take_phase_history(c, false);
     if ((int)maxlen > c->max_read_len) {
         c->max_read_len = (int)maxlen;
     }
-    { int rw = maybe_build_swin(c, maxlen, nreads, s); if (rw) return rw; }
+    if (!enqueue_only) { int rw = maybe_build_swin(c, maxlen, nreads, s); if (rw) return rw; }      // (the window array is used when it is there)
     // chunk size: as many reads as the knob allows and as fit in about half of the HBM still free
     // (the phase kernels run better the more reads they see: fewer launches, shorter tails)
     uint32_t chunk = c->chunk_reads;
@@ -1003,8 +1124,10 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
         if (rc) return rc;
         done += n;
     }
+    if (enqueue_only) return BK_OK;          // (the chunk's counts reach the host behind its kernels: take_phase_history of the next call)
     hipEvent_t t1 = tm.begin(s);
     HIP_TRY(hipStreamSynchronize(s));
+    { int rh = take_phase_history(c, true); if (rh) return rh; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t0, t1);
     c->timing.ms_total += ms;
@@ -1314,9 +1437,41 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     free_dev(c->d_in_words); free_dev(c->d_in_lens16); free_dev(c->d_in_exc); free_dev(c->d_scan_tmp); free_dev(c->d_ctr_aux);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    free_dev(c->d_ctl);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int bk_ctx_reserve(bk_ctx *c, uint32_t max_batch_reads, uint32_t max_read_len)
+{
+    if (!c || !max_batch_reads || !max_read_len || max_read_len > (uint32_t)kMaxReadLenAbs) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = std::min(max_batch_reads, c->chunk_reads);
+    const uint32_t wpr = words_per_read(max_read_len);
+    const bool reg_path = c->use_wave && max_read_len <= 16u * (uint32_t)kNwLongest;
+    const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
+    const uint32_t ivc = iv_cores_for(c, max_read_len);
+    int rc = ensure_batch_scratch(c, n, wpr, two_bit ? rd2w_for(max_read_len) : 0u, ivc);
+    if (rc) return rc;
+    if (c->ix.k2) {
+        // pass B's work list: at most one item per (read, strand, core)
+        const uint64_t lanes = (uint64_t)n * ivc * (c->cfg.align_strand == 0 ? 2u : 1u);
+        if (lanes > c->cap_slist) {
+            free_dev(c->d_slist);
+            free_dev(c->d_slist_stage);
+            c->d_slist = c->d_slist_stage = nullptr;
+            c->cap_slist = 0;
+            HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
+            HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));
+            c->cap_slist = lanes;
+        }
+    }
+    if (c->sort_lists) { rc = ensure_sort_scratch(c, n, c->stream); if (rc) return rc; }      // (grown when a phase's list is longer)
+    if (c->use_wave && c->ix.isa == nullptr) { rc = size_heavy_scratch(c); if (rc) return rc; }     // hash-set dedupe of the wave kernel
+    return BK_OK;
 }
 
 int bk_ctx_set_params(bk_ctx *c, const bk_align_params *p)
@@ -1397,6 +1552,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->wave_group = value ? 1 : 0;
         return old;
     }
+    if (n == "async_phases") {             // 0: the phase loop reads its counts back between launches (exact launch sizes), as every other configuration does
+        int64_t old = c->async_phases;
+        c->async_phases = value ? 1 : 0;
+        return old;
+    }
     if (n == "swin_resident") return c->d_swin != nullptr ? 1 : 0;      // (read only: whether the window array is in HBM right now)
     if (n == "use_swin") {
         int64_t old = c->use_swin;
@@ -1475,6 +1635,20 @@ int bk_align_batch_device(bk_ctx *c, const void *d_bases, const void *d_offs, co
     DevReads in;
     in.bases = (const uint8_t *)d_bases; in.offs = (const uint64_t *)d_offs; in.lens = (const uint32_t *)d_lens;
     return align_device(c, in, nreads, (bk_hit *)d_out, s);
+}
+
+int bk_align_batch_device_async(bk_ctx *c, const void *d_bases, const void *d_offs, const void *d_lens, uint32_t nreads, uint32_t max_read_len,
+                                void *d_out, void *stream)
+{
+    if (!c || !max_read_len || (nreads && (!d_bases || !d_offs || !d_lens || !d_out))) return BK_ERR_PARAMS;
+    if (!nreads) return BK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rh = take_phase_history(c, false); if (rh) return rh; }       // (also: what an earlier call of this kind found wrong with its batch)
+    if (c->async_error) { const int e = c->async_error; c->async_error = 0; return e; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    DevReads in;
+    in.bases = (const uint8_t *)d_bases; in.offs = (const uint64_t *)d_offs; in.lens = (const uint32_t *)d_lens;
+    return align_device(c, in, nreads, (bk_hit *)d_out, s, max_read_len, true);
 }
 
 int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, bk_hit *out)

@@ -276,8 +276,11 @@ __host__ __device__ constexpr bool flat_rows_in_lds(bool wide, int nw, int bs) {
 
 template <bool WIDE, int NW, int BS>
 __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                              uint32_t n_act, int phase, int slots_max, StripeSet out, int have_wave)
+                                              const uint32_t *__restrict__ p_n_act, int phase, int slots_max, StripeSet out, int have_wave)
 {
+    // (the active list's length lives in device memory - PhaseCtl; the launch covers a bound of it, a block beyond the list is done)
+    const uint32_t n_act = *p_n_act;
+    if ((uint64_t)blockIdx.x * BS >= n_act) return;
     // A block's time is a chain of dependent memory round trips (its four waves per SIMD do not hide them), so the kernel is laid
     // out to keep that chain short: everything that depends on the read number only - length, interval records, the read's 2-bit
     // rows - is requested together; the suffix array elements of up to KB candidates per lane are requested together, then their
@@ -774,7 +777,8 @@ void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 }
 
 // stage: three buffers of at least n_act + (kListStripes + 2) * 1024 entries, stripe_cnt: kListStripes * 16 words, zero between launches
-void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
+// n_act_bound: no more reads than this are on the active list (its length is *p_n_act, in device memory)
+void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s)
 {
@@ -782,7 +786,8 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     nw &= 0xff;
     bool wide = ix.sa_hi != nullptr;
     if (wide && bs > 256) bs = 256;                    // (the low words of the 5-byte form need 4 more bytes of LDS per candidate)
-    unsigned blocks = (n_act + (unsigned)bs - 1) / (unsigned)bs;
+    if (!n_act_bound) return;
+    unsigned blocks = (n_act_bound + (unsigned)bs - 1) / (unsigned)bs;
     if (slots_max < 1) slots_max = 1;
     size_t lds = (size_t)bs * slots_max * (flat_caches_first(wide, bs, slots_max) ? 6 : 2);
     StripeSet out;
@@ -790,7 +795,7 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     for (int i = 0; i < 3; i++) out.stage[i] = stage[i];
     out.cap = stripe_cap(blocks, (unsigned)bs);
     const int have_wave = wave != nullptr;
-#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, n_act, phase, slots_max, out, have_wave)
+#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, p_n_act, phase, slots_max, out, have_wave)
 #define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
 #define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
     if (nw <= 8) { if (wide) BK_FLAT_W(8); else BK_FLAT_B(8); }

@@ -2,6 +2,8 @@
 //   k_search          one pass over suffix array + target (indexes without second-level keys)
 //   k_search_a_ilp    pass A: k-mer table + small buckets out of the second-level keys
 //   k_search_b        pass B: bisection of the big buckets, work list grouped by bucket
+#include <algorithm>
+
 #include "bk_dev_k2.h"
 #include "bk_dev_prof.h"
 
@@ -63,19 +65,22 @@ __global__ void __launch_bounds__(256) k_search(DevIndex ix, DevAlignCfg cfg, De
 
 template <int ILP>
 __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                                      uint32_t n_act, int phase, int cmax, int nstr, int lazy,
+                                                      const uint32_t *__restrict__ p_n_act, int phase, int cmax, int nstr, int lazy,
                                                       StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base;
 #if defined(BK_PROF) && BK_PROF == 2
     PROF_BEGIN;
 #endif
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
+    // the length of the active list lives in device memory (PhaseCtl); a block takes tiles of 256 * ILP searches until the list is done
+    const uint32_t n_act = *p_n_act;
     const uint32_t per_read = (uint32_t)(nstr * cmax);
     const uint64_t total = (uint64_t)n_act * per_read;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    constexpr uint64_t stride = 256;                        // item u of a lane: tile start + lane + 256 u - neighbouring lanes, neighbouring searches
     const int k = ix.k;
+  for (uint64_t tile0 = (uint64_t)blockIdx.x * (256 * ILP); tile0 < total; tile0 += (uint64_t)gridDim.x * (256 * ILP)) {
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     bool on[ILP], push[ILP], have_code[ILP];
     uint64_t slot[ILP], p0[ILP], first[ILP], lo[ILP], hi[ILP];
     uint32_t nval[ILP], q2raw[ILP];            // q2raw: the 16 bases behind the k-mer's, 2 bits each
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     // stage 1: the item, its read row
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + (uint64_t)u * stride;
+        const uint64_t tid = tile0 + threadIdx.x + (uint64_t)u * stride;
         on[u] = false; push[u] = false; have_code[u] = false; slot[u] = 0; p0[u] = 0; q2raw[u] = 0; first[u] = 0; nval[u] = 0; cl[u] = 1; lo[u] = hi[u] = 0;
         cix[u] = kNoIv32; cv[u] = make_uint2(0, kNoIv32); cached[u] = false;
         if (tid < total) {
@@ -230,14 +235,17 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     }
     PROFS(4);
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve(out, 0, s_cnt);
+    const uint64_t tile = tile0 / (256 * ILP);
+    if (threadIdx.x == 0 && s_cnt) s_base = stripe_reserve_tile(out, 0, s_cnt, tile);
     __syncthreads();
     PROFS(5);
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        if (push[u]) stripe_put(out, 0, s_base + my_off[u], (uint32_t)slot[u]);
+        if (push[u]) stripe_put_tile(out, 0, s_base + my_off[u], (uint32_t)slot[u], tile);
         if (on[u] && nval[u] != 0) iv_put(b, slot[u], first[u], nval[u]);
     }
+    __syncthreads();                                        // (s_cnt / s_base are the next tile's, too)
+  }
 #if defined(BK_PROF) && BK_PROF == 2
     PROFS(6);
     PROF_END;
@@ -246,15 +254,20 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, DevBatch b, int phase, int lazy,
-                                                  const uint32_t *__restrict__ list, uint32_t n_list)
+                                                  const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
+                                                  const uint32_t *__restrict__ p_n_list)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_list) return;
+    // the work list's length lives in device memory; its first min(length, n_sorted) items are taken from `sorted` (the grouped copy:
+    // the launch had to size the sort before the length was known), the others from the list as pass A left it - the order of the
+    // items never changes a result
+    const uint32_t n_list = *p_n_list;
+    const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
 #ifdef BK_DIAG_B
     unsigned long long d_k2 = 0, d_deep = 0;
     struct Fin { unsigned long long &a, &b; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (b) atomicAdd(&bb.ctr[ctr_stripe() + 6], b); } } fin{d_k2, d_deep, b};
 #endif
-    const uint64_t slot = list[i];
+    const uint64_t slot = i < n_grouped ? sorted[i] : list[i];
     const uint32_t r = b.act[(uint32_t)(slot % b.iv_stride)], sc = (uint32_t)(slot / b.iv_stride);
     const int strand = (int)(sc / b.iv_cores), c = (int)(sc % b.iv_cores);
     const uint32_t meta = b.rmeta[r];
@@ -273,7 +286,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     if (kind == kKindFull) {
         search_core<WIDE>(ix, rdw, my_ofs, cl, ~0ULL >> 1, first, cnt);
         iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
-        return;
+        continue;
     }
     if (kind == kKindK2) {
         const uint32_t m = k2_mask(cl - k);
@@ -305,13 +318,13 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
             b.iv32[(uint32_t)strand * b.n_reads + r] = make_uint2((uint32_t)first, (uint32_t)cnt);
         if (cnt == 0 || cl <= k + kK2Bases) {
             iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
-            return;
+            continue;
         }
     }
     // [first, first+cnt) agrees with the core on its first k+15 bases
     if (lazy && cnt <= kLazyBucket) {
         iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
-        return;
+        continue;
     }
     {
         const int start = k + kK2Bases;
@@ -332,6 +345,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         cnt = l2 - l1;
     }
     iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
+  }
 }
 
 void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
@@ -345,47 +359,78 @@ void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
 
 // keys for grouping work items that touch the same part of the index (see bk_engine.cpp, sort_work):
 // search items by the start of their k-mer bucket, wave items by the start of their longest core interval
-__global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t *__restrict__ list, uint32_t n, int shift,
+__global__ void __launch_bounds__(256) k_keys_search(DevBatch b, const uint32_t *__restrict__ list, const uint32_t *__restrict__ p_n, uint32_t n_sort, int shift,
                                                      uint32_t *__restrict__ keys)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = (uint32_t)(iv_start(b, list[i]) >> shift);
+    // keys of the first min(*p_n, n_sort) items; what the sort was sized for beyond the list's real length sorts to the end
+    const uint32_t n = *p_n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sort; i += gridDim.x * blockDim.x)
+        keys[i] = i < n ? (uint32_t)(iv_start(b, list[i]) >> shift) : 0xFFFFFFFFu;
 }
 
-void launch_keys_search(const DevBatch &b, const uint32_t *list, uint32_t n, int shift, uint32_t *keys, hipStream_t s)
+void launch_keys_search(const DevBatch &b, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_keys_search, dim3((n + 255) / 256), dim3(256), 0, s, b, list, n, shift, keys);
+    if (!n_sort) return;
+    unsigned blocks = (n_sort + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_keys_search, dim3(blocks), dim3(256), 0, s, b, list, p_n, n_sort, shift, keys);
 }
 
 // stage: at least n_act * cmax * nstr + (kListStripes + 2) * 1024 entries; stripe_cnt: kListStripes * 16 words, zero between launches
-void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
+// n_act_bound: no more reads than this are on the active list (its length is *p_n_act, in device memory)
+void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s)
 {
-    uint64_t threads = (uint64_t)n_act * (uint64_t)(cmax * nstr);
+    uint64_t threads = (uint64_t)n_act_bound * (uint64_t)(cmax * nstr);
+    if (!threads) return;
     int ilp = lazy >> 8;                               // bits 8..: searches per lane (0 / 1 = the plain kernel)
     lazy &= 0xff;
     if (ilp < 2) ilp = 1;
     else if (ilp != 2) ilp = 4;
     const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
-    const unsigned blocks = (unsigned)((threads + per - 1) / per);
+    const uint64_t tiles = (threads + per - 1) / per;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(tiles, 16384);       // (a block takes tiles until the list is done)
     StripeSet out;
     out.cnt = stripe_cnt;
     out.stage[0] = out.stage[1] = out.stage[2] = stage;
-    out.cap = stripe_cap(blocks, (unsigned)per);
-    if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
-    else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
-    else hipLaunchKernelGGL(k_search_a_ilp<1>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, cmax, nstr, lazy, out);
+    out.cap = stripe_cap((unsigned)tiles, (unsigned)per);             // (stripes go by tile number)
+    if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
+    else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
+    else hipLaunchKernelGGL(k_search_a_ilp<1>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
     launch_compact(out, &list, &list_cnt, 1, nullptr, s);
 }
 
-void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list,
-                     uint32_t n_list, hipStream_t s)
+// list: the work items as pass A left them (*p_n_list of them, at most n_bound); sorted / n_sorted: the grouped copy of the first n_sorted (or null)
+void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int phase, int lazy, const uint32_t *list, const uint32_t *sorted,
+                     uint32_t n_sorted, const uint32_t *p_n_list, uint64_t n_bound, hipStream_t s)
 {
-    if (!n_list) return;
-    unsigned blocks = (n_list + 255) / 256;
-    if (ix.sa_hi) hipLaunchKernelGGL(k_search_b<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
-    else hipLaunchKernelGGL(k_search_b<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, n_list);
+    if (!n_bound) return;
+    unsigned blocks = (unsigned)std::min<uint64_t>((n_bound + 255) / 256, 32768);
+    if (ix.sa_hi) hipLaunchKernelGGL(k_search_b<true>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, sorted, n_sorted, p_n_list);
+    else hipLaunchKernelGGL(k_search_b<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, phase, lazy, list, sorted, n_sorted, p_n_list);
+}
+
+// the interval records of the slots a phase can use, zeroed: [strand][core][position in the active list] for every core below cmax
+__global__ void __launch_bounds__(256) k_clear_iv(DevBatch b, const uint32_t *__restrict__ p_n_act, int cmax, int st0, int st1)
+{
+    const uint32_t n_act = *p_n_act;
+    const uint64_t per_strand = (uint64_t)cmax * n_act, total = per_strand * (uint64_t)(st1 - st0 + 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int st = st0 + (int)(i / per_strand);
+        const uint64_t q = i % per_strand;
+        const uint64_t slot = iv_slot(b, (uint32_t)(q % n_act), st, (int)(q / n_act));
+        if (b.iv2) b.iv2[slot] = make_uint2(0, 0);
+        else b.iv_n[slot] = 0;
+    }
+}
+
+void launch_clear_iv(const DevBatch &b, const uint32_t *p_n_act, uint32_t n_act_bound, int cmax, int st0, int st1, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)n_act_bound * (uint64_t)cmax * (uint64_t)(st1 - st0 + 1);
+    if (!total) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_clear_iv, dim3(blocks), dim3(256), 0, s, b, p_n_act, cmax, st0, st1);
 }
 
 }  // namespace bk

@@ -112,6 +112,7 @@ struct bk_stream {
     int depth = 0;
     uint32_t max_reads = 0;
     uint64_t max_bases = 0;
+    uint64_t max_words = 0;            // != 0: packed batches only, of at most this many words
     std::vector<Slot> slots;
     hipStream_t s_up = nullptr, s_al = nullptr, s_dn = nullptr;
     void *d_scan_tmp = nullptr;
@@ -331,6 +332,18 @@ void bk_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+int bk_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return BK_ERR_PARAMS;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
+    return BK_OK;
+}
+
+void bk_host_unregister(void *p)
+{
+    if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
+
 void bk_stream_destroy(bk_stream *s)
 {
     if (!s) return;
@@ -364,8 +377,24 @@ void bk_stream_destroy(bk_stream *s)
     delete s;
 }
 
+static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, uint64_t max_batch_words, int depth, const bk_pe_params *pe);
+
 int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, int depth, const bk_pe_params *pe)
 {
+    return stream_create(out, ctx, max_batch_reads, max_batch_bases, 0, depth, pe);
+}
+
+int bk_stream_create_packed(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_words, int depth, const bk_pe_params *pe)
+{
+    if (!max_batch_words) return BK_ERR_PARAMS;
+    return stream_create(out, ctx, max_batch_reads, 0, max_batch_words, depth, pe);
+}
+
+// max_batch_words != 0: a pipeline for packed batches only - its device buffers hold 4 bytes per 16 bases instead of 16
+static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, uint64_t max_batch_words, int depth, const bk_pe_params *pe)
+{
+    const bool packed_only = max_batch_words != 0;
+    if (packed_only) max_batch_bases = 16 * max_batch_words;       // (what submit_packed's bound is derived from; no 1 byte/base batch is accepted)
     if (!out || !ctx || !max_batch_reads || !max_batch_bases || depth < 1 || depth > 8) return BK_ERR_PARAMS;
     if (pe && (pe->pe_mode < 1 || pe->pe_mode > 4 || pe->pair_min_len < 1 || pe->pair_max_len < pe->pair_min_len)) return BK_ERR_PARAMS;
     *out = nullptr;
@@ -375,6 +404,7 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
     s->depth = depth;
     s->max_reads = max_batch_reads;
     s->max_bases = max_batch_bases;
+    s->max_words = max_batch_words;
     s->list_modes = ctx->params.max_ml > 1 || ctx->params.micro_indel_len > 0 || ctx->params.splice_junct_len > 0 || ctx->params.min_chimeric_len > 0;
     if (pe) { s->has_pe = true; s->pe = *pe; }
     s->slots.resize((size_t)depth);
@@ -386,7 +416,8 @@ int bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uin
         for (Slot &sl : s->slots) {
             // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
             //  + the words the read preparation may load behind the last read of a packed batch, bk::kPackedPadWords)
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads) + 64 + 4ULL * bk::kPackedPadWords);
+            const uint64_t bytes = packed_only ? 4ULL * max_batch_words : std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads);
+            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, bytes + 64 + 4ULL * bk::kPackedPadWords);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
             if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
@@ -435,7 +466,7 @@ int bk_stream_submit(bk_stream *s, const uint8_t *bases, uint64_t nbases, const 
                      bk_hit *out, uint64_t *ticket)
 {
     if (!s || !ticket || (nreads && (!bases || !lens || !out))) return BK_ERR_PARAMS;
-    if (nreads > s->max_reads || nbases > s->max_bases || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
+    if (nreads > s->max_reads || nbases > s->max_bases || s->max_words || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
     Job *j = new Job();
     j->bases = bases; j->nbases = nbases; j->offs = offs; j->lens = lens; j->n = nreads; j->out = out;
     {
@@ -486,7 +517,7 @@ int bk_stream_submit_packed(bk_stream *s, const uint32_t *words, uint64_t n_word
 {
     if (!s || !ticket || (nreads && (!lens || !out)) || (n_words && !words) || (n_exc && !exc)) return BK_ERR_PARAMS;
     // (a batch's words are bounded like its bases: 16 of them per word, a last partial word per read)
-    if (nreads > s->max_reads || n_words > s->max_bases / 16 + nreads || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
+    if (nreads > s->max_reads || n_words > (s->max_words ? s->max_words : s->max_bases / 16 + nreads) || (s->has_pe && (nreads & 1))) return BK_ERR_PARAMS;
     Job *j = new Job();
     j->words = words; j->n_words = n_words; j->lens16 = lens; j->exc = exc; j->n_exc = n_exc; j->n = nreads; j->out = out;
     {

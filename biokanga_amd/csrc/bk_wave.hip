@@ -32,8 +32,8 @@ struct WaveCoreInfo {
 // SW: the index holds the suffix-ordered window array (DevIndex::swin) - reads it covers take their candidates' windows from it.
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
 __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
-                                              const uint32_t *__restrict__ list,
-                                              uint32_t n_list, int phase, uint32_t *__restrict__ cursor,
+                                              const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
+                                              const uint32_t *__restrict__ p_n_list, int phase, uint32_t *__restrict__ cursor,
                                               uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
                                               uint32_t *__restrict__ cmax_next)
 {
@@ -49,6 +49,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (threadIdx.x < ix.n_ent) { s_es[threadIdx.x] = ix.ent_start[threadIdx.x]; s_ee[threadIdx.x] = ix.ent_end[threadIdx.x]; }
         __syncthreads();
     }
+    // the list's length lives in device memory (PhaseCtl); its first min(length, n_sorted) items come from the sorted copy, whose size the
+    // launch had to fix before the length was known - the order of the items never changes a result
+    const uint32_t n_list = *p_n_list;
+    const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     WaveCoreInfo *core = s_core[wib];
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         if (item >= n_list) break;
         // (wave-uniform values that arrive through vector loads are handed to the scalar unit explicitly: the read's plan, its loop
         // bounds and the window geometry then cost scalar instructions once instead of vector instructions in every lane)
-        const uint32_t pos = __builtin_amdgcn_readfirstlane(list[item]);          // position in the phase's active list: where its interval records lie
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(item < n_grouped ? sorted[item] : list[item]);          // position in the phase's active list: where its interval records lie
         const uint32_t r = __builtin_amdgcn_readfirstlane(b.act[pos]);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
         const int len = (int)(meta & kReadLenMask);
@@ -430,12 +434,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 }
 
 __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, int phase, const uint32_t *__restrict__ list,
-                                                   uint32_t n, int shift, uint32_t *__restrict__ keys, const uint32_t *__restrict__ work_of)
+                                                   const uint32_t *__restrict__ p_n, uint32_t n_sort, int shift, uint32_t *__restrict__ keys, const uint32_t *__restrict__ work_of)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+  // keys of the first min(*p_n, n_sort) items; what the sort was sized for beyond the list's real length sorts to the end
+  const uint32_t n = *p_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sort; i += gridDim.x * blockDim.x) {
+    if (i >= n) { keys[i] = 0xFFFFFFFFu; continue; }
     const uint32_t pos = list[i], r = b.act[pos];
-    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFFu - work_of[pos]; return; }      // k_flat has added the intervals up already
+    if (shift < 0 && work_of != nullptr) { keys[i] = 0xFFFFFFFEu - (work_of[pos] < 0xFFFFFFFEu ? work_of[pos] : 0xFFFFFFFEu); continue; }      // k_flat has added the intervals up already
     const int len = (int)b.lens[r];
     ReadPlan p = make_plan(len, cfg);
     int mm, cl, cd, dummy[1];
@@ -457,24 +463,31 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
         }
     // shift < 0: longest job first (the reads are dealt to the waves in list order; a read with 10^5 candidates that comes up last
     // keeps one wave busy long after the others have run dry)
-    keys[i] = shift < 0 ? 0xFFFFFFFFu - (uint32_t)(work < 0xFFFFFFFFULL ? work : 0xFFFFFFFFULL) : (uint32_t)(best_first >> shift);
+    keys[i] = shift < 0 ? 0xFFFFFFFEu - (uint32_t)(work < 0xFFFFFFFEULL ? work : 0xFFFFFFFEULL) : (uint32_t)(best_first >> shift);
+  }
 }
 
-void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, uint32_t n, int shift, uint32_t *keys,
+void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys,
                       const uint32_t *work_of, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_keys_wave, dim3((n + 255) / 256), dim3(256), 0, s, cfg, b, phase, list, n, shift, keys, work_of);
+    if (!n_sort) return;
+    unsigned blocks = (n_sort + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_keys_wave, dim3(blocks), dim3(256), 0, s, cfg, b, phase, list, p_n, n_sort, shift, keys, work_of);
 }
 
-void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, uint32_t n_list,
+// list: the reads k_flat handed on (*p_n_list of them, at most n_bound); sorted / n_sorted: the sorted copy of the first n_sorted (or null)
+void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const HeavyScratch &hs, const uint32_t *list, const uint32_t *sorted,
+                 uint32_t n_sorted, const uint32_t *p_n_list, uint32_t n_bound,
                  int phase, uint32_t *cursor, uint32_t *next_act, uint32_t *next_cnt, uint32_t *cmax_next, int nw, uint32_t max_waves,
                  hipStream_t s)
 {
+    if (!n_bound) return;
     const bool wide = ix.sa_hi != nullptr, hash = ix.isa == nullptr;
-    uint32_t waves = n_list < max_waves ? n_list : max_waves;
+    uint32_t waves = n_bound < max_waves ? n_bound : max_waves;
     if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, n_list, phase, cursor, next_act, next_cnt, cmax_next)
+#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, sorted, n_sorted, p_n_list, phase, cursor, next_act, next_cnt, cmax_next)
     const bool sw = ix.swin != nullptr && b.rd2 != nullptr;
     const bool group8 = (nw & 0x100) != 0;                 // 8-word form: small intervals share rounds (the 16-word form always does)
     nw &= 0xff;

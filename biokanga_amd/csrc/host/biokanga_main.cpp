@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cerrno>
 #include <cstdarg>
@@ -597,6 +598,12 @@ int read_align_opts(Args &a, AlignOpts &o)
     return 0;
 }
 
+// The suffix-ordered window array (48 bytes per suffix: 149 GB and 2.6 s of set-up for a 3.1 Gbp index) serves long-running work: a run
+// pays for it only from this many reads per device on, or when asked to (--window-array).  Break-even, measured on C2 (round 4): the
+// array saves 0.35 ns per read (98.9 -> 81.4 ms per 50 M reads) and costs 0.2 s of k_build_swin even with its allocation hidden
+// behind the index load, i.e. nothing below 570 M reads; bench.py measures its headline in the layout this rule picks.
+constexpr unsigned long long kWindowArrayMinReads = 400000000ULL;
+
 // what the alignment pass leaves for the policies above the boundary
 struct AlignedSet {
     std::vector<bk_hit> hits;                      // one per read, load order
@@ -607,53 +614,148 @@ struct AlignedSet {
     std::vector<uint64_t> seq_counts;              // per sequence: reads the SE pass accepted, summed over the devices (RCCL when > 1)
 };
 
-// CAligner::LocateCoredApprox over every loaded read: the reads leave the read store in batches through one upload / align /
-// download pipeline per device (bk_stream_*), batch b on device b mod N; with -U the paired-end association runs on the
-// device-resident batch right after its SE pass (batches hold whole pairs).  Results land in load order whatever the
-// number of devices, so everything downstream - the reference's sort order included - is the same as on one GPU.
-int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const ReadStore &rs, AlignedSet &A)
+// The reads as they cross the boundary (the reference's loader hands its workers 1 byte/base, Aligner.cpp:9038-9055, of which three bits
+// reach the hot path): 2 bit/base words + 16-bit lengths + the bases that are not a,c,g,t (bk_pack_reads), cut into the batches the
+// pipelines will be fed, in page-locked memory - made by the host threads while the index image is still on its way to the device.
+struct Submission {
+    struct Batch { size_t lo, hi; uint64_t w0, w1, e0, e1, ticket; };
+    std::vector<Batch> batches;
+    uint32_t *words = nullptr;
+    uint16_t *lens16 = nullptr;
+    bk_nbase *exc = nullptr;
+    uint64_t n_words = 0, cap_exc = 0, max_words = 1;
+    size_t max_reads = 1;
+    uint32_t max_len = 0;
+    void *registered = nullptr;                    // the result array, page-locked in place while results arrive in it
+    void release_results() { if (registered) { bk_host_unregister(registered); registered = nullptr; } }
+    ~Submission() { release_results(); bk_host_free(words); bk_host_free(lens16); bk_host_free(exc); }
+};
+
+// Reads per batch.  A batch costs less per read the larger it is (every phase's wave-per-read launch lasts at least as long as its
+// heaviest read: 3 M reads take 3.3 ns each, 12 M 2.2 ns, 50 M 2.0 ns) - but its scratch is allocated at 16 ms per GB (0.5 KB per
+// read), and nothing overlaps the upload of a device's first batch.  Runs below the window array's threshold are over in a fraction
+// of a second: 4 M reads first, then batches of 12 M; long runs grow to 32 M.  Small inputs: two batches per device.
+int prepare_submission(const AlignOpts &o, const ReadStore &rs, size_t ndev, bool long_run, AlignedSet &A, Submission &S)
 {
-    const size_t nr = rs.size(), ndev = ctxs.size();
-    A.hits.resize(nr);
-    const bool lists = o.ml_mode != 0, segs = o.P.micro_indel_len || o.P.splice_junct_len || o.P.min_chimeric_len;
-    if (lists) A.l_offs.assign(1, 0);
-    // Reads per batch.  A batch costs less per read the larger it is (every phase's wave-per-read launch lasts at least as long as its
-    // heaviest read: 3 M reads take 3.7 ns each, 12 M 2.2 ns, 50 M 1.8 ns), but nothing overlaps the upload of a device's first batch:
-    // each device's batches grow by a factor of three from 4 M reads up to 32 M (an upload is about as fast as the alignment of the
-    // same reads at 1 byte per base, so it still hides behind the batch before it).  Small inputs: two batches per device.
-    size_t per = 32u << 20;
+    const size_t nr = rs.size();
+    std::thread results([&]() {                    // (the record array is touched page by page: a thread of its own)
+        A.hits.resize(nr);
+        if (nr && bk_host_register(A.hits.data(), nr * sizeof(bk_hit)) == BK_OK) S.registered = A.hits.data();
+    });
+    size_t per = long_run ? (32u << 20) : (12u << 20);
     const bool ramp = nr / ndev >= (12u << 20);
     if (!ramp) {
         per = 8u << 20;
         if (nr / ndev / 2 + 1 < per) per = std::max<size_t>(65536, nr / ndev / 2 + 1);
     }
     per += per & 1;
-    struct Batch { size_t lo, hi; uint64_t b0, b1, ticket; };
-    std::vector<Batch> batches;
-    uint64_t max_bases = 1;
-    size_t max_reads = 1;
     for (size_t lo = 0, k = 0; lo < nr; k++) {
         size_t n = per;
         if (ramp) {
             const size_t round = k / ndev;                                           // this device's round-th batch
             n = round == 0 ? (4u << 20) : (round == 1 ? (12u << 20) : per);
         }
-        Batch b{lo, std::min(nr, lo + n), rs.offs[lo], 0, 0};
-        b.b1 = rs.offs[b.hi - 1] + rs.lens[b.hi - 1];
-        max_bases = std::max(max_bases, b.b1 - b.b0);
-        max_reads = std::max(max_reads, b.hi - b.lo);
-        batches.push_back(b);
+        if (nr - lo < n + n / 4) n = nr - lo;                                        // (no small last batch: it joins the one before)
+        n += n & 1;
+        Submission::Batch b{lo, std::min(nr, lo + n), 0, 0, 0, 0, 0};
+        S.max_reads = std::max(S.max_reads, b.hi - b.lo);
+        S.batches.push_back(b);
         lo = b.hi;
     }
-    std::vector<bk_stream *> st(ndev, nullptr);
-    auto close = [&]() { for (bk_stream *s : st) bk_stream_destroy(s); };
-    for (size_t d = 0; d < ndev; d++) {
-        int rc = bk_stream_create(&st[d], ctxs[d], (uint32_t)max_reads, max_bases, 3, o.pe_mode ? &o.PE : nullptr);
-        if (rc) { diag("Fatal: unable to set up the device pipeline: %s", bk_strerror(rc)); close(); return rc; }
+    // words per batch (a read takes ceil(len / 16) of them), longest read
+    {
+        const int nt = std::max(1, std::min(o.nthreads, (int)S.batches.size()));
+        std::vector<uint32_t> ml(S.batches.size(), 0);
+        std::atomic<size_t> next{0};
+        auto count = [&]() {
+            for (size_t k; (k = next.fetch_add(1)) < S.batches.size();) {
+                Submission::Batch &b = S.batches[k];
+                uint64_t w = 0;
+                uint32_t m = 0;
+                for (size_t i = b.lo; i < b.hi; i++) { w += ((uint64_t)rs.lens[i] + 15) >> 4; m = std::max(m, rs.lens[i]); }
+                b.w1 = w;
+                ml[k] = m;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(count);
+        count();
+        for (auto &t : th) t.join();
+        uint64_t at = 0;
+        for (size_t k = 0; k < S.batches.size(); k++) {
+            Submission::Batch &b = S.batches[k];
+            S.max_words = std::max(S.max_words, b.w1);
+            b.w0 = at; at += b.w1; b.w1 = at;
+            S.max_len = std::max(S.max_len, ml[k]);
+        }
+        S.n_words = at;
     }
-    // the read store keeps reads back to back in load order, so a batch is one span of bases and the offsets are rebuilt on the device
+    S.words = (uint32_t *)bk_host_alloc((S.n_words + 64) * 4);
+    S.lens16 = (uint16_t *)bk_host_alloc((nr + 64) * 2);
+    S.cap_exc = nr / 4 + (1u << 20);
+    S.exc = (bk_nbase *)bk_host_alloc(S.cap_exc * sizeof(bk_nbase));
+    int rc = (S.words && S.lens16 && S.exc) ? BK_OK : BK_ERR_MEM;
+    uint64_t e_at = 0;
+    for (size_t k = 0; k < S.batches.size() && rc == BK_OK; k++) {
+        Submission::Batch &b = S.batches[k];
+        uint64_t n_exc = 0;
+        rc = bk_pack_reads(rs.bases.data(), rs.offs.data() + b.lo, rs.lens.data() + b.lo, (uint32_t)(b.hi - b.lo), S.words + b.w0, S.lens16 + b.lo,
+                           S.exc + e_at, S.cap_exc - e_at, &n_exc);
+        if (rc == BK_ERR_MEM) {
+            // more bases that are not a,c,g,t than room was made for: a larger list (what is packed so far is kept), this batch again
+            const uint64_t cap2 = std::max<uint64_t>(2 * S.cap_exc, e_at + n_exc + (1u << 20));
+            bk_nbase *e2 = (bk_nbase *)bk_host_alloc(cap2 * sizeof(bk_nbase));
+            if (!e2) break;
+            memcpy(e2, S.exc, e_at * sizeof(bk_nbase));
+            bk_host_free(S.exc);
+            S.exc = e2;
+            S.cap_exc = cap2;
+            rc = BK_OK;
+            k--;
+            continue;
+        }
+        b.e0 = e_at; e_at += n_exc; b.e1 = e_at;
+    }
+    results.join();
+    if (rc) diag("Fatal: unable to pack the reads for the device: %s", bk_strerror(rc));
+    return rc;
+}
+
+// CAligner::LocateCoredApprox over every loaded read: the packed batches go through one upload / align / download pipeline per device
+// (bk_stream_*), batch b on device b mod N; with -U the paired-end association runs on the device-resident batch right after its SE
+// pass (batches hold whole pairs).  Results land in load order whatever the number of devices, so everything downstream - the
+// reference's sort order included - is the same as on one GPU.  The pipelines (their device buffers, the contexts' batch scratch)
+// are set up by open_pipelines() BEFORE the clock of T_align starts: align_reads() only submits and collects.
+int open_pipelines(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Submission &S, std::vector<bk_stream *> &st)
+{
+    st.assign(ctxs.size(), nullptr);
+    std::vector<int> rcs(ctxs.size(), 0);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < ctxs.size(); d++)
+        th.emplace_back([&, d]() {
+            rcs[d] = bk_ctx_reserve(ctxs[d], (uint32_t)S.max_reads, std::max<uint32_t>(S.max_len, 16));
+            if (!rcs[d]) rcs[d] = bk_stream_create_packed(&st[d], ctxs[d], (uint32_t)S.max_reads, S.max_words, 3, o.pe_mode ? &o.PE : nullptr);
+        });
+    for (auto &t : th) t.join();
+    for (size_t d = 0; d < ctxs.size(); d++)
+        if (rcs[d]) {
+            diag("Fatal: unable to set up the device pipeline: %s", bk_strerror(rcs[d]));
+            for (bk_stream *s : st) bk_stream_destroy(s);
+            st.clear();
+            return rcs[d];
+        }
+    return BK_OK;
+}
+
+int align_reads(const std::vector<bk_ctx *> &ctxs, std::vector<bk_stream *> &st, const AlignOpts &o, const ReadStore &rs, Submission &S, AlignedSet &A)
+{
+    const size_t ndev = ctxs.size();
+    const bool lists = o.ml_mode != 0, segs = o.P.micro_indel_len || o.P.splice_junct_len || o.P.min_chimeric_len;
+    if (lists) A.l_offs.assign(1, 0);
+    std::vector<Submission::Batch> &batches = S.batches;
+    auto close = [&]() { for (bk_stream *s : st) bk_stream_destroy(s); st.clear(); };
     auto collect = [&](size_t k) -> int {
-        Batch &b = batches[k];
+        Submission::Batch &b = batches[k];
         bk_stream *s = st[k % ndev];
         int rc = bk_stream_wait(s, b.ticket);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); return rc; }
@@ -690,14 +792,30 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, const AlignOpts &o, const Rea
     size_t next_collect = 0;
     const size_t lag = 3 * ndev;
     for (size_t k = 0; k < batches.size(); k++) {
-        Batch &b = batches[k];
-        int rc = bk_stream_submit(st[k % ndev], rs.bases.data() + b.b0, b.b1 - b.b0, nullptr, rs.lens.data() + b.lo, (uint32_t)(b.hi - b.lo),
-                                  A.hits.data() + b.lo, &b.ticket);
+        Submission::Batch &b = batches[k];
+        int rc = bk_stream_submit_packed(st[k % ndev], S.words + b.w0, b.w1 - b.w0, S.lens16 + b.lo, (uint32_t)(b.hi - b.lo), S.exc + b.e0, b.e1 - b.e0,
+                                         A.hits.data() + b.lo, &b.ticket);
         if (rc) { diag("Fatal: alignment failed: %s", bk_strerror(rc)); close(); return rc; }
         while (next_collect + lag <= k) { rc = collect(next_collect++); if (rc) { close(); return rc; } }
     }
     while (next_collect < batches.size()) { int rc = collect(next_collect++); if (rc) { close(); return rc; } }
+    // what crossed PCIe, and the pipelines' own clock (first batch submitted -> last result back, the slowest device)
+    {
+        bk_stream_stats tot{};
+        for (bk_stream *s : st) {
+            bk_stream_stats x{};
+            if (bk_stream_get_stats(s, &x, 0) == BK_OK) {
+                tot.batches += x.batches; tot.reads += x.reads; tot.bytes_h2d += x.bytes_h2d; tot.bytes_d2h += x.bytes_d2h;
+                tot.seconds_first_submit_to_last_result = std::max(tot.seconds_first_submit_to_last_result, x.seconds_first_submit_to_last_result);
+            }
+        }
+        if (tot.reads)
+            diag("Device pipeline: %llu reads in %llu batches over %zu device(s), %.1f bytes per read host to device (2 bit/base), %.1f back, first submit to last result %.3f seconds",
+                 (unsigned long long)tot.reads, (unsigned long long)tot.batches, ndev, (double)tot.bytes_h2d / (double)tot.reads, (double)tot.bytes_d2h / (double)tot.reads,
+                 tot.seconds_first_submit_to_last_result);
+    }
     close();
+    S.release_results();
     // the path's one exchange step: per-sequence accepted-read counts summed over the devices
     A.seq_counts.assign(bk_num_entries(ctxs[0]), 0);
     int rc = bk_seq_counts_allreduce((bk_ctx *const *)ctxs.data(), (int)ndev, A.seq_counts.data(), (uint32_t)A.seq_counts.size(), 1);
@@ -855,6 +973,11 @@ int cmd_align(int argc, char **argv, int first)
     int rc;
     if (o.pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
     else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
+    // .. and, still behind the index load: the reads packed for the boundary, the result array page-locked
+    AlignedSet A;
+    Submission S;
+    const bool long_run = a.has("window-array") || rs.size() / ndev >= kWindowArrayMinReads;
+    if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
     for (auto &t : loaders) t.join();
     for (size_t d = 0; d < ndev; d++)
         if (ctx_rc[d]) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(ctx_rc[d])); destroy_ctxs(); return 1; }
@@ -870,10 +993,9 @@ int cmd_align(int argc, char **argv, int first)
     size_t nr = rs.size();
     // The suffix-ordered window array (48 bytes per suffix: 149 GB and 2.6 s of set-up for a 3.1 Gbp index) serves long-running work;
     // a run pays for it only from several hundred million reads per device on, or when asked to (--window-array)
-    {
-        const bool want = a.has("window-array") || nr / ctxs.size() >= 400000000ULL;
-        for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want ? 1 : 0);
-    }
+    for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", long_run ? 1 : 0);
+    diag("Suffix-ordered window array: %s (%zu reads per device; it is built from %llu reads per device on, or with --window-array)", long_run ? "on" : "off",
+         nr / ctxs.size(), (unsigned long long)kWindowArrayMinReads);
     // SAM text goes into a file of known approximate size: its pages are allocated in the background from now on (fallocate fills
     // them with zeros at memory speed: 7 GB for 50 M reads of 100 bases), while the reads are aligned and sorted
     SamPrealloc pre;
@@ -888,11 +1010,15 @@ int cmd_align(int argc, char **argv, int first)
             pre.start(opath0.c_str(), est);
         }
     }
+    // the pipelines' device buffers and the contexts' batch scratch are in place before the clock of T_align starts (the reference sizes its
+    // per-thread scratch before its workers start, Aligner.cpp:8771-8790)
+    std::vector<bk_stream *> streams;
+    if (nr && open_pipelines(ctxs, o, S, streams)) { destroy_ctxs(); return 1; }
     diag("Now aligning with minimum core size of %dbp...\n", bk_min_core_len(ctx));
-    AlignedSet A;
     if (o.pe_mode) diag("Paired end association and partner alignment processing runs with the alignment of each batch");
-    rc = align_reads(ctxs, o, rs, A);
+    rc = nr ? align_reads(ctxs, streams, o, rs, S, A) : BK_OK;
     if (rc) { destroy_ctxs(); return 1; }
+    if (!nr) A.seq_counts.assign(n_ent, 0);
     std::vector<bk_hit> &hits = A.hits;
     std::vector<bk_seg2> &seg2 = A.seg2;
     diag("Alignment of %zu from %zu loaded completed", nr, nr);

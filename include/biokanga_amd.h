@@ -152,6 +152,12 @@ int  bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id);
 
 void bk_ctx_destroy(bk_ctx *ctx);
 
+/* Sizes the context's batch scratch (read rows, interval records, work lists, sort buffers) for batches of up to max_batch_reads reads
+ * of up to max_read_len bases NOW, so that no allocation is left for the first batch to pay inside T_align - the reference sizes its
+ * per-thread scratch before its workers start, too (CAligner::LocateCoredApprox, Aligner.cpp:8771-8790).  Optional for the blocking
+ * calls and the pipeline (batches grow the scratch on demand), required by bk_align_batch_device_async. */
+int  bk_ctx_reserve(bk_ctx *ctx, uint32_t max_batch_reads, uint32_t max_read_len);
+
 /* change alignment parameters (re-derives MinCoreLen, MaxIter, slides) */
 int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
 /* cross-check knobs: results never depend on them; the test-suite runs independent implementations of the same step against
@@ -166,6 +172,8 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_swin" (suffix-ordered window array for reads of <= 100 bases, 0: windows from the 2-bit target, 2: built whatever the batch's longest read)
  *   "swin_resident" (read only, value ignored: 1 when the window array is in HBM right now)
  *   "wave_group" (wave kernel, reads of <= 128 bases: small core intervals share a round)
+ *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's
+ *   needs; 0: counts read back between launches, as every other configuration does)
  *   "chunk_reads" (reads per pass over the phases)   "max_read_len"
  * returns the old value or <0 */
 int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
@@ -185,11 +193,23 @@ int  bk_align_batch(bk_ctx *ctx, const uint8_t *bases, const uint64_t *offs, con
 
 /* Same over buffers already resident in HBM on the context's device.  The kernels are launched on `stream` (a
  * hipStream_t, NULL = the context's own stream), after whatever that stream already holds.  The call is
- * HOST-SYNCHRONOUS: the phase loop of AlignReads reads the number of still-unaligned reads back between phases to size
- * the next launches, so it returns when the results are in d_out; `sync` is accepted and has no effect.  The
- * overlapped form (uploads, kernels and downloads of consecutive batches running concurrently) is bk_stream_*. */
+ * HOST-SYNCHRONOUS: it measures the batch's longest read, sizes (and may allocate) the batch scratch, and returns when the
+ * results are in d_out; `sync` is accepted and has no effect.  The overlapped form (uploads, kernels and downloads of
+ * consecutive batches running concurrently) is bk_stream_*; the form that only enqueues is below. */
 int  bk_align_batch_device(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
                            uint32_t nreads, void *d_out, void *stream, int sync);
+
+/* The same batch ENQUEUED on `stream` - every phase of AlignReads, none of it waited for: the call returns as soon as the launches
+ * are made, d_out is complete when `stream` reaches that point.  A consumer kernel enqueued on the same stream (or on another
+ * one behind an event recorded there) sees the results without the host ever waiting: the counts the phases produce - reads still
+ * unaligned, work items, reads for the wave kernel - stay in device memory and the kernels size themselves by them
+ * (the reference's workers never leave their loop either, Aligner.cpp:8943-9527).
+ * Needs: the scratch in place for batches of this size and read length (bk_ctx_reserve), max_read_len >= the longest read of the
+ * batch (the kernel family is picked by it; a longer read is reported by the NEXT call as BK_ERR_PARAMS), reads of at most 512
+ * bases, the default result form (no multi-loci lists, -a / -A / -c, -N), one batch of a context in flight per stream - the
+ * scratch belongs to the context.  Otherwise BK_ERR_PARAMS before anything is launched: use the blocking call. */
+int  bk_align_batch_device_async(bk_ctx *ctx, const void *d_bases, const void *d_offs, const void *d_lens,
+                                 uint32_t nreads, uint32_t max_read_len, void *d_out, void *stream);
 
 /* ---- packed reads: 2 bit/base across PCIe ------------------------------------------------------------------------
  * The 1 byte/base form above is how CAligner holds reads; of its 8 bits the hot path uses 3 (Aligner.cpp:9038-9055) and almost
@@ -314,10 +334,18 @@ typedef struct bk_stream_stats {
  * too and are staged by the HIP runtime (slower). */
 void *bk_host_alloc(size_t bytes);
 void  bk_host_free(void *p);
+/* .. or memory the caller already owns, page-locked in place (hipHostRegister) for as long as results or reads travel through it:
+ * what the command line does with its result array.  0 or a negative code; unregister before the memory is freed. */
+int   bk_host_register(void *p, size_t bytes);
+void  bk_host_unregister(void *p);
 /* depth = sets of device buffers (2..4 is useful: one uploading, one aligning, one downloading); every batch may hold up to
  * max_batch_reads reads in max_batch_bases bytes.  pe != NULL: batches hold whole pairs interleaved PE1, PE2 and the
  * paired-end association (bk_pair_batch_device) runs on the resident buffers right after the SE pass. */
 int  bk_stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_bases, int depth, const bk_pe_params *pe);
+/* The same for a caller that only submits packed batches (bk_stream_submit_packed) of at most max_batch_words 32-bit words: the device
+ * buffers hold 4 bytes per 16 bases instead of 16, a quarter of the memory (and of the allocation time) of the general form.
+ * bk_stream_submit() on such a pipeline is refused. */
+int  bk_stream_create_packed(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads, uint64_t max_batch_words, int depth, const bk_pe_params *pe);
 /* bases[0 .. nbases) holds the reads of this batch, 1 byte/base as CAligner holds them; offs[i] = start of read i within
  * bases, or offs == NULL when the reads lie back to back in lens order (the offsets are then computed on the device and
  * 8 bytes per read stay off PCIe); out[nreads].  Returns once the batch is queued (it blocks only while all `depth`

@@ -65,7 +65,8 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
                                   ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)), ("use_swin", 2), (("use_swin", 2), ("heavy_thresh", 0)), (("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 3)),
                                   ("use_swin", 0), ("wave_group", 1), (("wave_group", 1), ("heavy_thresh", 0)), (("wave_group", 1), ("use_isa", 0)), (("wave_group", 1), ("use_swin", 2), ("heavy_thresh", 3)),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
-                                  (("use_k2", 0), ("lazy_search", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0))])
+                                  (("use_k2", 0), ("lazy_search", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0)),
+                                  ("async_phases", 0), (("async_phases", 0), ("chunk_reads", 333)), (("async_phases", 0), ("sort_lists", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""
@@ -1223,3 +1224,98 @@ def test_clears_of_more_than_4_gib_reach_the_end_of_the_buffer():
         al.snp_reset()
         for eid, lo in places:
             assert int(al.snp_counts(eid, lo, 100)[:, :6].sum()) == 0
+
+
+def _synth_index(bk, bp, seed, repeat_frac=0.5):
+    import torch
+    from biokanga_amd import synth
+    dev = torch.device("cuda", 0)
+    seq, seq_lens = synth.make_genome(bp, dev, seed=seed, n_seqs=3, repeat_frac=repeat_frac)
+    n = seq.numel()
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    bk.build_sa_device(seq.data_ptr(), n, sa.data_ptr(), 4, 0)
+    entries = synth.entry_table(seq_lens)
+    ent = np.zeros(len(entries), dtype=bk.ENTRY_DTYPE)
+    for i, (eid, slen, so, eo) in enumerate(entries):
+        ent[i] = (eid, slen, so, eo, f"chr{eid}".encode(), b"")
+    return dev, seq, seq_lens, n, sa, ent
+
+
+def test_phase_loop_without_readbacks_and_the_enqueue_only_call():
+    """The main path's phase loop keeps every count in device memory (PhaseCtl): launches are sized by bounds, the two work-list sorts
+    by what the PREVIOUS chunk needed.  Batches that follow each other with very different needs (reads without substitutions out of
+    unique sequence, then repeat-rich reads with three) must come out exactly as the loop that reads its counts back produces them,
+    counters included; bk_align_batch_device_async enqueues the same batch on a caller's stream and a consumer kernel behind it on that
+    stream sees the finished records without the host having waited."""
+    import torch
+    bk = _bk()
+    from biokanga_amd import synth
+    dev, seq, seq_lens, n, sa, ent = _synth_index(bk, 12_000_000, 29, repeat_frac=0.6)
+    sets = []
+    for seed, subs, cnt in ((11, 0, 150_000), (12, 3, 300_000), (13, 1, 80_000)):
+        b, o, l, _ = synth.make_reads(seq, seq_lens, cnt, 100, dev, seed=seed, max_subs=subs)
+        sets.append((b, o, l, cnt))
+    with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(), el_size=4, entries=ent) as al:
+        def run(which, out):
+            b, o, l, cnt = sets[which]
+            al.align_device(b.data_ptr(), o.data_ptr(), l.data_ptr(), cnt, out.data_ptr())
+            return out.cpu().numpy().view(bk.HIT_DTYPE).copy()
+        outs = [torch.zeros(s[3] * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for s in sets]
+        al.tune("async_phases", 0)
+        ref, ref_ctr = [], []
+        for w in range(3):
+            al.counters(reset=True)
+            ref.append(run(w, outs[w]))
+            ref_ctr.append(al.counters())
+        assert int((ref[1]["nar"] == 1).sum()) > sets[1][3] // 2
+        al.tune("async_phases", 1)
+        for order in ((0, 1, 2), (2, 1, 0), (1, 1, 0)):          # the guesses of a phase's sort sizes come from whichever batch ran before
+            for w in order:
+                outs[w].zero_()
+                al.counters(reset=True)
+                got = run(w, outs[w])
+                assert_hits_equal(got, ref[w])
+                c = al.counters()
+                for k in ("n_search", "n_cand", "n_lcm_calls"):
+                    assert c[k] == ref_ctr[w][k], (order, w, k)
+        # chunked batches: every chunk its own PhaseCtl lines, the history follows the last chunk
+        al.tune("chunk_reads", 70_001)
+        outs[1].zero_()
+        assert_hits_equal(run(1, outs[1]), ref[1])
+        al.tune("chunk_reads", 1 << 26)
+        # ---- the call that only enqueues
+        b, o, l, cnt = sets[1]
+        with pytest.raises(bk.BkError):                          # scratch for 100-base reads only: a longer promise is refused before anything is launched
+            al.align_device_async(b.data_ptr(), o.data_ptr(), l.data_ptr(), cnt, 400, outs[1].data_ptr())
+        al.reserve(cnt, 100)
+        st = torch.cuda.Stream(device=dev)
+        outs[1].zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            al.align_device_async(b.data_ptr(), o.data_ptr(), l.data_ptr(), cnt, 100, outs[1].data_ptr(), stream=st.cuda_stream)
+            # the consumer: a kernel on the same stream, enqueued while the phases have not run yet
+            accepted = (outs[1].view(cnt, bk.HIT_DTYPE.itemsize)[:, bk.HIT_DTYPE.fields["nar"][1]] == 1).sum()
+            snapshot = outs[1].clone()
+        assert int(accepted.item()) == int((ref[1]["nar"] == 1).sum())
+        assert_hits_equal(snapshot.cpu().numpy().view(bk.HIT_DTYPE), ref[1])
+        # .. twice in a row on one stream (the second call's sorts are sized from the first one's counts when they have arrived), then a blocking call
+        with torch.cuda.stream(st):
+            for w in (0, 2):
+                bb, oo, ll, cc = sets[w]
+                outs[w].zero_()
+                al.align_device_async(bb.data_ptr(), oo.data_ptr(), ll.data_ptr(), cc, 100, outs[w].data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        for w in (0, 2):
+            assert_hits_equal(outs[w].cpu().numpy().view(bk.HIT_DTYPE), ref[w])
+        outs[1].zero_()
+        assert_hits_equal(run(1, outs[1]), ref[1])
+        # a read longer than promised is reported by the next call
+        b2, o2, l2, _ = synth.make_reads(seq, seq_lens, 10_000, 120, dev, seed=14, max_subs=1)
+        al.reserve(10_000, 120)
+        out2 = torch.zeros(10_000 * bk.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        al.align_device_async(b2.data_ptr(), o2.data_ptr(), l2.data_ptr(), 10_000, 100, out2.data_ptr())
+        torch.cuda.synchronize()
+        with pytest.raises(bk.BkError):
+            for _ in range(50):                                   # (the counts travel behind the kernels; the next call that finds them there reports)
+                al.align_device_async(b2.data_ptr(), o2.data_ptr(), l2.data_ptr(), 10_000, 120, out2.data_ptr())
+                torch.cuda.synchronize()
