@@ -441,13 +441,18 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
     c->n_tgt4_words = nwords;
     c->sort_shift = 0;
     while ((n >> c->sort_shift) >= (1ULL << 32)) c->sort_shift++;
-    HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
-    if (el == 5) {
-        HIP_TRY(hipMalloc(&c->d_sa_hi, n));
-        launch_split_sa5(d_sa, n, c->d_sa_lo, c->d_sa_hi, c->stream);
-        HIP_TRY(hipGetLastError());
-    } else
-        HIP_TRY(hipMemcpyAsync(c->d_sa_lo, d_sa, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (d_sa == nullptr) {
+        // (4-byte elements that the caller has put where they stay: c->d_sa_lo is allocated and filled)
+        if (el != 4 || !c->d_sa_lo) return BK_ERR_INTERNAL;
+    } else {
+        HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
+        if (el == 5) {
+            HIP_TRY(hipMalloc(&c->d_sa_hi, n));
+            launch_split_sa5(d_sa, n, c->d_sa_lo, c->d_sa_hi, c->stream);
+            HIP_TRY(hipGetLastError());
+        } else
+            HIP_TRY(hipMemcpyAsync(c->d_sa_lo, d_sa, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->ix.tgt4 = c->d_tgt4;
     c->ix.sa_lo = c->d_sa_lo;
@@ -1298,12 +1303,18 @@ int bk_device_count(void)
 
 int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p)
 {
+    return bk_ctx_create_ex(out, sfx_path, device_id, p, 0);
+}
+
+int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags)
+{
     if (!sfx_path) return BK_ERR_PARAMS;
     bk_ctx *c = nullptr;
     StageClock clk;
     int rc = new_ctx(out, device_id, p, &c);
     if (rc) return rc;
     clk.lap("HIP runtime + device + stream");
+    if (flags & BK_CTX_LEAN_IMAGE) c->use_ktab2 = 0;
     SfxFile f;
     std::string err;
     rc = sfx_open(sfx_path, f, &err);
@@ -1314,18 +1325,32 @@ int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_al
         return rc;
     }
     c->dataset = f.dataset;
+    // the window array's memory, when the caller wants the array from the start: a fresh process spends longer in this one allocation
+    // (16 ms per GB) than in the upload below, so a thread of its own makes it meanwhile
+    void *swin_mem = nullptr;
+    std::thread swin_alloc;
+    const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32);
+    if (eager_swin)
+        swin_alloc = std::thread([&swin_mem, &f, device_id]() {
+            if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&swin_mem, f.concat_len * 48) != hipSuccess) { (void)hipGetLastError(); swin_mem = nullptr; }
+        });
+    struct JoinSwin { std::thread &t; void *&mem; bool keep = false; ~JoinSwin() { if (t.joinable()) t.join(); if (!keep && mem) { (void)hipFree(mem); mem = nullptr; } } } join_swin{swin_alloc, swin_mem};
     // stage the file image through HBM: bases and suffix array as they are on disk
+    // (4-byte suffix array elements are stored as the file holds them: they travel straight to where they stay)
     uint8_t *d_seq = nullptr, *d_sa = nullptr;
+    const bool sa_in_place = f.el_size == 4;
     auto cleanup = [&]() { free_dev(d_seq); free_dev(d_sa); };
-    if (hipMalloc(&d_seq, f.concat_len + 16) != hipSuccess || hipMalloc(&d_sa, f.concat_len * f.el_size) != hipSuccess) {
+    if (hipMalloc(&d_seq, f.concat_len + 16) != hipSuccess ||
+        (sa_in_place ? hipMalloc(&c->d_sa_lo, f.concat_len * 4) : hipMalloc(&d_sa, f.concat_len * f.el_size)) != hipSuccess) {
         cleanup(); bk_ctx_destroy(c); return BK_ERR_MEM;
     }
     clk.lap("device allocations");
-    if (upload_host(d_seq, f.seq, f.concat_len, device_id) != BK_OK || upload_host(d_sa, f.sa, f.concat_len * f.el_size, device_id) != BK_OK) {
+    if (upload_host(d_seq, f.seq, f.concat_len, device_id) != BK_OK ||
+        upload_host(sa_in_place ? (void *)c->d_sa_lo : (void *)d_sa, f.sa, f.concat_len * f.el_size, device_id) != BK_OK) {
         cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL;
     }
     clk.lap("upload bases + suffix array");
-    rc = adopt_device_image(c, d_seq, f.concat_len, d_sa, (int)f.el_size);
+    rc = adopt_device_image(c, d_seq, f.concat_len, sa_in_place ? nullptr : d_sa, (int)f.el_size);
     clk.lap("pack target, adopt");
     cleanup();
     clk.lap("free staging");
@@ -1340,8 +1365,20 @@ int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_al
     }
     rc = finish_ctx(c, ents.data(), (uint32_t)ents.size());
     if (rc) { bk_ctx_destroy(c); return rc; }
-    *out = c;
     clk.lap("(rest of bk_ctx_create)");
+    if (eager_swin) {
+        swin_alloc.join();
+        clk.lap("waited for the window array's memory");
+        if (swin_mem && c->ix.tgt2 && c->ix.isa && c->use_wave && c->use_flat) {
+            c->d_swin = swin_mem;
+            join_swin.keep = true;
+            launch_build_swin(c->ix, c->d_swin, c->stream);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
+            c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
+            clk.lap("suffix-ordered windows");
+        }
+    }
+    *out = c;
     return BK_OK;
 }
 
@@ -1701,9 +1738,31 @@ uint64_t bk_packed_words(const uint32_t *lens, uint32_t nreads)
     return n;
 }
 
+namespace {
+// 16 bases (bytes, bits 0-2 = the code) -> one packed word, when none of them is above 3: the two low bits of every byte gathered with the
+// bit-extract instruction (first base into the top bits: the bytes are swapped first).  *clean = every code was 0..3.
+__attribute__((target("bmi2"))) inline uint32_t pack16_bmi2(const uint8_t *s, bool *clean)
+{
+    uint64_t a, b;
+    memcpy(&a, s, 8);
+    memcpy(&b, s + 8, 8);
+    *clean = ((a | b) & 0x0404040404040404ULL) == 0;
+    const uint64_t m = 0x0303030303030303ULL;
+    return (uint32_t)(__builtin_ia32_pext_di(__builtin_bswap64(a), m) << 16) | (uint32_t)__builtin_ia32_pext_di(__builtin_bswap64(b), m);
+}
+inline uint32_t pack16_plain(const uint8_t *s, bool *clean)
+{
+    uint32_t v = 0, bad = 0;
+    for (uint32_t k = 0; k < 16; k++) { const uint32_t code = s[k] & 7u; bad |= code & 4u; v |= (code & 3u) << (30 - 2 * k); }
+    *clean = bad == 0;
+    return v;
+}
+}  // namespace
+
 int bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *lens, uint32_t nreads, uint32_t *words, uint16_t *lens16,
                   bk_nbase *exc, uint64_t exc_cap, uint64_t *n_exc)
 {
+    static const bool have_bmi2 = __builtin_cpu_supports("bmi2");
     if (!n_exc || (nreads && (!bases || !lens || !words || !lens16)) || (exc_cap && !exc)) return BK_ERR_PARAMS;
     *n_exc = 0;
     if (!nreads) return BK_OK;
@@ -1742,6 +1801,11 @@ int bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *le
                     lens16[i] = (uint16_t)len;
                     for (uint32_t j0 = 0; j0 < len; j0 += 16) {
                         const uint32_t cnt = std::min<uint32_t>(16, len - j0);
+                        if (cnt == 16) {                       // a whole word of a, c, g, t: sixteen bytes at once
+                            bool clean;
+                            const uint32_t w16 = have_bmi2 ? pack16_bmi2(s + j0, &clean) : pack16_plain(s + j0, &clean);
+                            if (clean) { *wp++ = w16; continue; }
+                        }
                         uint32_t v = 0;
                         for (uint32_t k = 0; k < cnt; k++) {
                             const uint32_t code = s[j0 + k] & 7u;

@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -187,6 +188,7 @@ struct bk_stream {
     void run_align()
     {
         (void)hipSetDevice(ctx->device);
+        const bool timing = getenv("BK_TIMING") != nullptr;       // per batch on stderr: how long the aligner thread waited for it, prepared it, aligned it
         double t_free = now_s();
         for (;;) {
             Job *j = pop(q_al);
@@ -274,7 +276,7 @@ struct bk_stream {
                     if (e != hipSuccess) fail(j, rc_of(e));
                 }
             }
-            if (ctx->debug)
+            if (ctx->debug || timing)
                 fprintf(stderr, "bk: stream batch of %u reads: waited %.2f ms for it, prepared in %.2f ms, aligned in %.2f ms\n", j->n, 1e3 * (t_got - t_free),
                         1e3 * (t_prep - t_got), 1e3 * (now_s() - t_prep));
             push(q_dn, j);
@@ -323,7 +325,7 @@ extern "C" {
 void *bk_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }     // (every device's pipeline may DMA from it)
     return p;
 }
 
@@ -335,7 +337,7 @@ void bk_host_free(void *p)
 int bk_host_register(void *p, size_t bytes)
 {
     if (!p || !bytes) return BK_ERR_PARAMS;
-    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
     return BK_OK;
 }
 

@@ -75,8 +75,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 
     // work items are claimed kWaveGrab at a time: one device-scope atomic on the shared cursor per
     // item serialises 8192 resident waves on a single address
+    // .. but no more of them than leaves every wave several claims to make: the list comes longest job first, and eight items at a time
+    // hand the eight heaviest reads of a short list to ONE wave (a batch of 3 M reads then lasts as long as those eight, one after the other)
     uint32_t grab_next = 0, grab_left = 0;
-    const int grab = kWaveGrab;
+    const uint32_t per_wave = n_list / (gridDim.x * 4u * 4u);
+    const int grab = per_wave >= (uint32_t)kWaveGrab ? kWaveGrab : (per_wave < 1 ? 1 : (int)per_wave);
     // reads that go on to the next phase are parked one per lane and appended 64 at a time
     uint32_t pend_r = 0, pend_n = 0, cmax_loc = 0;
     auto flush_pending = [&]() {

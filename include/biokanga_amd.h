@@ -134,6 +134,17 @@ int  bk_device_count(void);
  * MinCoreLen/MaxIter set-up of CAligner::Align / LocateCoredApprox (Aligner.cpp:341-356,8725-8761):
  * reads the .sfx file, uploads target + suffix array to HBM, builds the k-mer interval table. */
 int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p);
+/* The same with flags.  BK_CTX_WINDOW_ARRAY_EAGER: the suffix-ordered window array (48 bytes per suffix, 4-byte indexes) is part of
+ * the image from the start - its memory is allocated by a thread of its own from the moment the file's header is read (on a fresh
+ * process the allocation of 149 GB takes longer than the upload of a 3.1 Gbp index, and hides behind it) and it is built when the other
+ * tables are; without the flag the array is built when the first batch it can serve arrives (tuning knob "use_swin").  What a caller
+ * that knows it has several hundred million reads to align asks for (`biokanga align` decides from the size of its input files). */
+#define BK_CTX_WINDOW_ARRAY_EAGER 1u
+/* BK_CTX_LEAN_IMAGE: tables that pay only over hundreds of millions of reads are left out - today the k-mer table entries that carry
+ * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read).  Results never depend
+ * on it. */
+#define BK_CTX_LEAN_IMAGE 2u
+int  bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags);
 
 /* Same, from an index image already resident in HBM (synthetic benchmarks, GPU-built indexes):
  * d_seq  = concat_len bytes, 1 byte/base, eBaseEOS(7) after every entry (tsSfxBlock.SeqSuffix)

@@ -1319,6 +1319,25 @@ def make_multi_rescue(tmp, only=None):
         print("  ran", tag)
 
 
+def make_lifted(tmp):
+    """Option combinations the reference takes and the MI355X command line refused until round 4 (kanga.cpp:648-660,712,719-725,980-995):
+    -k / -x / -Z / -z with -r5 (every locus a record of its own: the filters see the records).  -T1: the record numbering follows thread
+    timing otherwise.  (-Z / -z with -U is still refused: the reference consults the filters inside its pair rules, Aligner.cpp:2771-2786.)"""
+    def unz(fix, name, dst):
+        with gzip.open(os.path.join(HERE, fix, name), "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+        return dst
+    ms, mr = unz("multi", "genome.sfx.gz", os.path.join(tmp, "lm.sfx")), unz("multi", "reads.fa.gz", os.path.join(tmp, "lm.fa"))
+    for tag, flags, fmt, ext in (("r5R5k0", ["-r5", "-R5", "-s3", "-k0"], "-M6", "m6.sam"), ("r5R5k0", ["-r5", "-R5", "-s3", "-k0"], "-M0", "m0.csv"),
+                                 ("r5R5x4", ["-r5", "-R5", "-s3", "-x4"], "-M6", "m6.sam"), ("r5R5x4", ["-r5", "-R5", "-s3", "-x4"], "-M0", "m0.csv"),
+                                 ("r5R5ZmB", ["-r5", "-R5", "-s3", "-Z", "mB"], "-M6", "m6.sam"), ("r5R3XzmA", ["-r5", "-R3", "-X", "-s3", "-z", "^ma$"], "-M5", "m5.sam"),
+                                 ("r5R5k20x3Z", ["-r5", "-R5", "-s3", "-k20", "-x3", "-Z", "mB"], "-M4", "m4.bed")):
+        out = os.path.join(tmp, f"{tag}.{ext}")
+        run([REF, "align", "-i", mr, "-I", ms, "-o", out, fmt, "-T1"] + flags, tmp)
+        gz_copy(out, os.path.join(HERE, "multi", f"{tag}.{ext}.gz"))
+        print("  ran multi", tag, fmt)
+
+
 def make_simreads(tmp):
     """Reads named the way `biokanga simreads` names them (lcl|usimreads|id|chrom|start|end|len|strand|...): the reference's only
     built-in correctness signal is the truth-check line of CAligner::ReportAlignStats (Aligner.cpp:3581-3728) - "There are N (a 2
@@ -1442,6 +1461,9 @@ def main():
         if "--only-multi-rescue-n" in sys.argv:
             make_multi_rescue(tmp, only="xn_")
             return
+        if "--only-lifted" in sys.argv:
+            make_lifted(tmp)
+            return
         if "--only-snp" in sys.argv:
             make_snp(tmp)
             return
@@ -1527,6 +1549,7 @@ def main():
         make_quality(tmp)
         make_pcr(tmp)
         make_simreads(tmp)
+        make_lifted(tmp)
     print("done")
 
 

@@ -247,7 +247,12 @@ MULTI_CASES = [("r1R5", ["-r1", "-R5"], ["m6.sam"]), ("r2R5", ["-r2", "-R5"], ["
                ("r5R3X", ["-r5", "-R3", "-X"], ["m6.sam"]),
                # -N: LocateBestMatches instead of the AlignReads schedule
                ("r5R5N", ["-r5", "-R5", "-N"], ["m6.sam", "m0.csv"]), ("r5R2Ns1", ["-r5", "-R2", "-N", "-s1"], ["m0.csv"]),
-               ("r3R4N", ["-r3", "-R4", "-N", "-T4"], ["m6.sam"]), ("r2R3N", ["-r2", "-R3", "-N"], ["m6.sam"]), ("r1R5N", ["-r1", "-R5", "-N"], ["m6.sam"])]
+               ("r3R4N", ["-r3", "-R4", "-N", "-T4"], ["m6.sam"]), ("r2R3N", ["-r2", "-R3", "-N"], ["m6.sam"]), ("r1R5N", ["-r1", "-R5", "-N"], ["m6.sam"]),
+               # round 4: the filters the reference also runs over -r5's records (kanga.cpp:719-725,980-995 do not bar them): PCR artefact
+               # reduction, flank trimming, chromosome filters
+               ("r5R5k0", ["-r5", "-R5", "-k0"], ["m6.sam", "m0.csv"]), ("r5R5x4", ["-r5", "-R5", "-x4"], ["m6.sam", "m0.csv"]),
+               ("r5R5ZmB", ["-r5", "-R5", "-Z", "mB"], ["m6.sam"]), ("r5R3XzmA", ["-r5", "-R3", "-X", "-z", "^ma$"], ["m5.sam"]),
+               ("r5R5k20x3Z", ["-r5", "-R5", "-k20", "-x3", "-Z", "mB"], ["m4.bed"])]
 FMT_FLAG = {"m6.sam": "-M6", "m5.sam": "-M5", "m0.csv": "-M0", "m4.bed": "-M4"}
 
 

@@ -34,7 +34,7 @@ def main():
         wall = time.time() - t
         print(f"rc {rc}; T_e2e {wall:.2f} s for {n_reads} reads = {n_reads / wall / 1e6:.2f} M reads/s; SAM {os.path.getsize(sam) / 1e9:.2f} GB")
         keys = ("Loading suffix", "suffix array loaded", "Loading reads", "Load:", "Now aligning", "Alignment of", "Sorting",
-                "Header written", "Completed reporting", "Reporting of aligned result set completed", "phase:")
+                "Header written", "Completed reporting", "Reporting of aligned result set completed", "phase:", "Device pipeline", "window array", "Exit code")
         print(open(logf + ".err").read())
         for line in open(logf, errors="replace"):
             if any(k in line for k in keys):
