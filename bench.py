@@ -594,7 +594,7 @@ def main():
     ap.add_argument("--reference-reads", type=int, default=2_000_000,
                     help="reads given to the real reference binary (oracle/_ref/biokanga) in the cpu_baseline leg; 0 = port only. "
                          "Kept at 2 M: the reference's loader hand-off breaks when loading takes > 3 s (Aligner.cpp:4822) - "
-                         "3 M reads crash it on the MI355X host about every other run (tools/ref_scaling.py)")
+                         "3 M reads crash it on the MI355X host about every other run (profiles/r01_host_cpu_scaling.md)")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) one step only, nothing reported: what the live counter passes profile")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")

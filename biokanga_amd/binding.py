@@ -99,7 +99,7 @@ class _StreamStats(ctypes.Structure):
 
 
 def lib_path():
-    # BK_LIB: another build of the same library (kernel experiments: tools/quick_prof.sh)
+    # BK_LIB: another build of the same library (kernel experiments)
     return os.environ.get("BK_LIB") or os.path.join(_HERE, "lib", "libbiokanga_amd.so")
 
 

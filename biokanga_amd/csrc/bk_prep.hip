@@ -121,7 +121,7 @@ __device__ __forceinline__ uint32_t packed_word16(const uint32_t *__restrict__ W
 // reverse complement of a read held as W words of 32 bases (first base in the top bits, zero beyond its end).  Straight-line code:
 // the word shift is a cascade of selects, one per bit of the shift count (a version that copied t[] into place under
 // `if (shift == k)` inside an unrolled loop came out of hipcc 7.2 reading registers it had never written - rows wrong only in
-// the blocks that did not start on a freshly zeroed register file; tools/prep_check.hip)
+// the blocks that did not start on a freshly zeroed register file; profiles/NOTES.md)
 template <int W>
 __device__ __forceinline__ void revcomp2(const uint64_t (&f)[W], int len, uint64_t (&r)[W])
 {

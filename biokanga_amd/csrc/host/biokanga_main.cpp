@@ -202,15 +202,20 @@ int cmd_index(int argc, char **argv, int first)
 // The acceptance rules of load_reads() applied to a file that was parsed whole (fasta.h, ParsedChunk): every
 // chunk is filtered and measured by its own thread, a prefix sum gives each chunk its place in the read
 // store, and the threads copy their accepted records there.  Same records, same order, same log lines.
-int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, int trim5, int trim3, int min_len, int max_len,
+// An empty read store ADOPTS the parser's bases buffer (fasta.h, ParsedFile): the bases stay where the pieces wrote them and the store's
+// offsets point there - no placement pass over the 5 GB of a 50 M-read file; only the names are laid back to back.  A second input
+// file is appended to the store by copy.
+int accept_chunks(bk::ParsedFile &file, const std::string &fn, int trim5, int trim3, int min_len, int max_len,
                   int nthreads, ReadStore &rs)
 {
+    std::vector<bk::ParsedChunk> &chunks = file.chunks;
     const size_t nc = chunks.size();
+    const bool adopt = rs.lens.empty() && rs.bases.empty();
     bool sim = false;
     for (const auto &c : chunks)
         if (!c.lens.empty()) {
             size_t dl = std::min<size_t>(c.descr_lens[0], 127);
-            sim = dl >= 14 && (!strncmp(c.descr.data(), "lcl|usimreads|", 14) || !strncmp(c.descr.data(), "lcr|usimreads|", 14));
+            sim = dl >= 14 && (!strncmp(c.descr, "lcl|usimreads|", 14) || !strncmp(c.descr, "lcr|usimreads|", 14));
             break;
         }
     struct Tot { uint64_t n_acc = 0, n_bases = 0, n_names = 0, n_under = 0, n_over = 0, n_rec = 0; long bad_at = -1; };
@@ -243,7 +248,7 @@ int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, i
             else if (trim5 + trim3 + min_len > len) t.n_under++;
             else if (trim5 + trim3 + max_len < len) t.n_over++;
             else {
-                size_t nl = name_len(c.descr.data() + dofs, dl);
+                size_t nl = name_len(c.descr + dofs, dl);
                 kn[i] = (uint32_t)nl + 1;
                 t.n_acc++;
                 t.n_bases += (uint64_t)(len - trim5 - trim3);
@@ -276,7 +281,7 @@ int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, i
         m0[ci + 1] = m0[ci] + tot[ci].n_names;
     }
     rs.lens.resize(r0[nc]); rs.offs.resize(r0[nc]); rs.name_ofs.resize(r0[nc]);
-    rs.bases.resize(b0[nc]);
+    if (!adopt) rs.bases.resize(b0[nc]);
     rs.names.resize(m0[nc]);
     run([&](size_t ci) {
         bk::ParsedChunk &c = chunks[ci];
@@ -287,20 +292,26 @@ int accept_chunks(std::vector<bk::ParsedChunk> &chunks, const std::string &fn, i
             const uint32_t len = c.lens[i];
             if (kn[i]) {
                 const uint32_t keep = len - (uint32_t)trim5 - (uint32_t)trim3, nl = kn[i] - 1;
-                rs.offs[r] = bo;
                 rs.lens[r] = keep;
-                memcpy(rs.bases.data() + bo, c.bases.data() + sofs + trim5, keep);
-                rs.name_ofs[r] = mo;
-                memcpy(rs.names.data() + mo, c.descr.data() + dofs, nl);
+                if (adopt) rs.offs[r] = (uint64_t)(c.bases - file.bases.data()) + sofs + (uint64_t)trim5;
+                else {
+                    rs.offs[r] = bo;
+                    memcpy(rs.bases.data() + bo, c.bases + sofs + trim5, keep);
+                }
+                rs.name_ofs[r] = mo;                           // (the names - a tenth of the bases - are laid back to back)
+                memcpy(rs.names.data() + mo, c.descr + dofs, nl);
                 rs.names[mo + nl] = '\0';
                 r++; bo += keep; mo += nl + 1;
             }
             dofs += c.descr_lens[i];
             sofs += len;
         }
-        bk::ParsedChunk().bases.swap(c.bases);
-        bk::ParsedChunk().descr.swap(c.descr);
     });
+    if (adopt) {
+        rs.bases.swap(file.bases);
+        rs.used_bases = b0[nc];
+    } else
+        rs.used_bases = 0;
     diag("Load: %llu reads parsed, %llu accepted, %llu under length, %llu over length from '%s'", (unsigned long long)n_descr,
          (unsigned long long)n_acc, (unsigned long long)n_under, (unsigned long long)n_over, fn.c_str());
     return 0;
@@ -320,7 +331,7 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading reads from '%s'", fn.c_str());
         if (rd.parsed() && g_sample_nth <= 1) {
-            rc = accept_chunks(rd.chunks(), fn, trim5, trim3, min_len, max_len, nthreads, rs);
+            rc = accept_chunks(rd.file(), fn, trim5, trim3, min_len, max_len, nthreads, rs);
             if (rc) return rc;
             continue;
         }
@@ -940,19 +951,36 @@ void resolve_multi_loci(const AlignOpts &o, const ReadStore &rs, AlignedSet &A, 
             if (c) {
                 // loci on sequences the -Z / -z filters reject never become records (CAligner::WriteHitLoci, Aligner.cpp:6739-6760); a read
                 // that loses all of them is kept as one record without a hit in '-M6' only
-                uint32_t kept = 0;
-                for (uint32_t k = 0; k < c; k++) {
-                    if (chrom_ok && !(*chrom_ok)[loci[l_offs[i] + k].chrom_id]) continue;
+                // The reference compacts the accepted loci in place with `if(pAcceptHit != pHit) *pAcceptHit++ = *pHit;` (:6748-6752): the
+                // write position only moves when it differs from the read position, so an accepted locus at the front is overwritten by the
+                // next accepted one and the LAST one kept comes out twice.  Reproduced as it stands.
+                uint32_t kept = c;
+                std::vector<uint32_t> pick(c);
+                for (uint32_t k = 0; k < c; k++) pick[k] = k;
+                if (chrom_ok) {
+                    uint32_t acc = 0;
+                    kept = 0;
+                    for (uint32_t k = 0; k < c; k++) {
+                        if (!(*chrom_ok)[loci[l_offs[i] + pick[k]].chrom_id]) continue;
+                        kept++;
+                        if (acc != k) pick[acc++] = pick[k];
+                    }
+                }
+                for (uint32_t q = 0; q < kept; q++) {
+                    const uint32_t k = pick[q];
                     bk_hit r = h;
                     take(r, loci[l_offs[i] + k]);
                     recs.push_back(r);
                     src.push_back((uint32_t)i);
                     if (with_trims) rt.push_back(trims_of(l_offs[i] + k));
-                    kept++;
                 }
                 if (!kept && o.fmt == 6) {
+                    // (the record the reference keeps of such a read comes out of its FiltByChroms pass as "aligned to filtered target
+                    // sequence": observed on the reference's own output, tests/golden/multi/r5R5ZmB.m6.sam.gz)
                     bk_hit r = h;
+                    r.nar = 11;
                     r.num_hits = 0;
+                    r.low_hit_instances = 0;
                     recs.push_back(r);
                     src.push_back((uint32_t)i);
                     if (with_trims) rt.push_back(bk_loci_trims{});
@@ -1082,8 +1110,8 @@ int cmd_align(int argc, char **argv, int first)
         const bool bam = ol > 5 && !strcasecmp(opath0.c_str() + ol - 4, ".bam"), gz = ol > 3 && !strcasecmp(opath0.c_str() + ol - 3, ".gz");
         const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)
         if (!bam && !gz && nr >= (size_t)(min_env ? strtoull(min_env, nullptr, 10) : 200000ULL)) {
-            uint64_t est = (1u << 20) + rs.names.size() + 64ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
-            est += (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.bases.size();
+            uint64_t est = (1u << 20) + rs.name_bytes() + 64ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
+            est += (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.base_bytes();
             pre.start(opath0.c_str(), est);
         }
     }
@@ -1107,7 +1135,7 @@ int cmd_align(int argc, char **argv, int first)
         bk_sam_job hj{};
         hj.bases = rs.bases.data(); hj.n_bases = rs.bases.size(); hj.offs = rs.offs.data(); hj.lens = rs.lens.data();
         hj.names = rs.names.data(); hj.n_name_bytes = rs.names.size(); hj.name_ofs = rs.name_ofs.data(); hj.n_reads = nr;
-        const uint64_t per_rec = (rs.names.size() + (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.bases.size()) / std::max<size_t>(nr, 1) + 64 + (o.pe_mode ? 24 : 0);
+        const uint64_t per_rec = (rs.name_bytes() + (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.base_bytes()) / std::max<size_t>(nr, 1) + 64 + (o.pe_mode ? 24 : 0);
         if (bk_sam_prepare(ctx, &hj, (uint32_t)std::min<uint64_t>(per_rec + per_rec / 8, 1u << 20), &sam_prep) != BK_OK) sam_prep = nullptr;
     }
 

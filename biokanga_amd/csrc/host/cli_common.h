@@ -96,6 +96,11 @@ struct ReadStore {
     bk::RawVec<uint32_t> lens;
     bk::RawVec<char> names;                // '\0' separated
     bk::RawVec<uint64_t> name_ofs;
+    // bytes of `bases` the reads really occupy: the buffer itself may be the parser's, as large as the input file, with the reads lying
+    // where its pieces wrote them (fasta.h, ParsedFile); 0 = the buffer holds nothing else
+    uint64_t used_bases = 0;
+    uint64_t base_bytes() const { return used_bases ? used_bases : bases.size(); }
+    uint64_t name_bytes() const { return names.size(); }
     size_t size() const { return lens.size(); }
     const char *name(size_t i) const { return names.data() + name_ofs[i]; }
 };

@@ -175,15 +175,14 @@ struct SeqLut {
 };
 const SeqLut g_seq_lut;
 
-void parse_range(const uint8_t *p, const uint8_t *e, ParsedChunk &out)
+// bw / dw: where this piece's bases and descriptors go (the piece's offset in the file-sized buffers of its ParsedFile)
+void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, char *dw, ParsedChunk &out)
 {
     const size_t approx = (size_t)(e - p);
-    out.bases.resize(approx);
-    out.descr.resize(approx);
+    out.bases = bw;
+    out.descr = dw;
     out.lens.reserve(approx / 64 + 16);
     out.descr_lens.reserve(approx / 64 + 16);
-    uint8_t *bw = out.bases.data();
-    char *dw = out.descr.data();
     const uint8_t *lut = g_seq_lut.t;
     while (p < e) {
         p = (const uint8_t *)memchr(p, '>', (size_t)(e - p));          // skip to the next descriptor
@@ -205,8 +204,6 @@ void parse_range(const uint8_t *p, const uint8_t *e, ParsedChunk &out)
         }
         out.lens.push_back((uint32_t)(bw - b0));
     }
-    out.bases.resize((size_t)(bw - out.bases.data()));
-    out.descr.resize((size_t)(dw - out.descr.data()));
 }
 
 // first record start at or after q: a '>' with no other '>' between it and the preceding line break
@@ -231,9 +228,9 @@ const uint8_t *next_record_start(const uint8_t *base, const uint8_t *q, const ui
 
 }  // namespace
 
-int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<ParsedChunk> &out, std::string *err)
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err)
 {
-    out.clear();
+    out.chunks.clear();
     int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) {
         if (err) *err = "unable to open '" + path + "'";
@@ -257,10 +254,15 @@ int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<Pars
     cut[pieces] = end;
     for (size_t t = 1; t < pieces; t++) cut[t] = next_record_start(base, base + size / pieces * t, end);
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-    out.resize(pieces);
+    out.chunks.resize(pieces);
+    out.bases.resize(size + 64);                          // (sized, not touched: the pieces' own pages are the only ones that become real)
+    out.descr.resize(size + 64);
     std::vector<std::thread> th;
     for (int w = 0; w < nthreads; w++)
-        th.emplace_back([&, w]() { for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads) parse_range(cut[t], cut[t + 1], out[t]); });
+        th.emplace_back([&, w]() {
+            for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads)
+                parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.descr.data() + (cut[t] - base), out.chunks[t]);
+        });
     for (auto &t : th) t.join();
     munmap(m, size);
     return 1;
@@ -268,7 +270,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<Pars
 
 int RecordStream::open(const std::string &path, int nthreads, std::string *err)
 {
-    int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, chunks_, err) : 0;
+    int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, file_, err) : 0;
     if (rc < 0) return rc;
     parsed_ = rc == 1;
     ci_ = ri_ = bo_ = dofs_ = 0;
@@ -283,15 +285,12 @@ int RecordStream::next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl
         d = d_.data(); dl = d_.size(); b = b_.data(); bl = b_.size();
         return 1;
     }
-    while (ci_ < chunks_.size() && ri_ >= chunks_[ci_].lens.size()) {
-        ParsedChunk().bases.swap(chunks_[ci_].bases);      // release a finished chunk
-        ParsedChunk().descr.swap(chunks_[ci_].descr);
-        ci_++; ri_ = 0; bo_ = 0; dofs_ = 0;
-    }
+    std::vector<ParsedChunk> &chunks_ = file_.chunks;
+    while (ci_ < chunks_.size() && ri_ >= chunks_[ci_].lens.size()) { ci_++; ri_ = 0; bo_ = 0; dofs_ = 0; }
     if (ci_ >= chunks_.size()) return 0;
     const ParsedChunk &c = chunks_[ci_];
-    d = c.descr.data() + dofs_; dl = c.descr_lens[ri_];
-    b = c.bases.data() + bo_; bl = c.lens[ri_];
+    d = c.descr + dofs_; dl = c.descr_lens[ri_];
+    b = c.bases + bo_; bl = c.lens[ri_];
     dofs_ += dl; bo_ += bl; ri_++;
     return 1;
 }

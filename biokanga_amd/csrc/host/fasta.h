@@ -45,19 +45,28 @@ private:
     std::string path_;
 };
 
-// A run of parsed records held in memory (file order inside a chunk, chunks in file order).
+// A run of parsed records (file order inside a chunk, chunks in file order): views into the two buffers of a ParsedFile.
 struct ParsedChunk {
-    RawVec<uint8_t> bases;              // all records' bases back to back, Ascii2Sense-mapped
+    uint8_t *bases = nullptr;           // the chunk's bases back to back, Ascii2Sense-mapped
+    char *descr = nullptr;              // its descriptors back to back (as SeqReader::next returns them)
     std::vector<uint32_t> lens;
-    RawVec<char> descr;                 // descriptors back to back (as SeqReader::next returns them)
     std::vector<uint32_t> descr_lens;
+};
+
+// A whole file parsed in pieces.  Both buffers are as large as the file and every piece writes from its own offset in the file on
+// (a record's bases, and its descriptor, are never longer than the record's text), so the pieces need no placement pass: a consumer
+// that keeps the reads can take the bases buffer as it is (the read store of `biokanga align` does).
+struct ParsedFile {
+    RawVec<uint8_t> bases;
+    RawVec<char> descr;
+    std::vector<ParsedChunk> chunks;
 };
 
 // Parses a whole plain-text (not gzip'd) FASTA file with `nthreads` threads: the file is mapped, cut at
 // record starts (the first '>' of a line) and every piece goes through the same state machine as
 // SeqReader::next.  Returns 1 and fills `out` when it handled the file, 0 when the file is not eligible
 // (gzip, FASTQ, tiny: use SeqReader), < 0 on error.
-int parse_fasta_parallel(const std::string &path, int nthreads, std::vector<ParsedChunk> &out, std::string *err);
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err);
 
 // One stream of records, from either source.
 class RecordStream {
@@ -68,12 +77,13 @@ public:
     int next(const char *&d, size_t &dl, const uint8_t *&b, size_t &bl);
     // whole-file parse available: the chunks in file order (then next() need not be used)
     bool parsed() const { return parsed_; }
-    std::vector<ParsedChunk> &chunks() { return chunks_; }
+    std::vector<ParsedChunk> &chunks() { return file_.chunks; }
+    ParsedFile &file() { return file_; }
 
 private:
     SeqReader rd_;
     bool parsed_ = false;
-    std::vector<ParsedChunk> chunks_;
+    ParsedFile file_;
     size_t ci_ = 0, ri_ = 0, bo_ = 0, dofs_ = 0;
     std::string d_;
     std::vector<uint8_t> b_;

@@ -616,7 +616,7 @@ int report_text(Report &R)
         if (!out.gz && nr >= 200000 && !device_done && R.pre == nullptr) {
             out.flush();
             const bool with_qual = a.num("g", 3) != 3;                                 // QUAL is '*' unless FASTQ scores were loaded (-g0..2)
-            uint64_t est = (uint64_t)out.pos + rs.names.size() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
+            uint64_t est = (uint64_t)out.pos + rs.name_bytes() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
             for (size_t k = 0; k < nr; k++) est += (with_qual ? 2ULL : 1ULL) * rs.lens[RD(k)];
             const int pfd = out.fd;
             prealloc = std::thread([pfd, est, &prealloc_size]() {

@@ -15,7 +15,7 @@ int main(int argc, char **argv)
     if (rd.open(argv[1], &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
     bk::RecordStream rs;
     if (rs.open(argv[1], nthreads, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
-    std::vector<bk::ParsedChunk> probe;
+    bk::ParsedFile probe;
     int handled = bk::parse_fasta_parallel(argv[1], nthreads, probe, &err);
     std::string d;
     std::vector<uint8_t> b;
@@ -33,6 +33,6 @@ int main(int argc, char **argv)
         n++;
         nbases += bl;
     }
-    printf("OK records %lu bases %lu parallel %d pieces %zu\n", n, nbases, handled, probe.size());
+    printf("OK records %lu bases %lu parallel %d pieces %zu\n", n, nbases, handled, probe.chunks.size());
     return 0;
 }

@@ -155,7 +155,7 @@ def test_reads_of_129_to_512_bases(tmp_path, top, el_size):
 @pytest.mark.parametrize("read_len", [100, 150])
 def test_packed_batch_of_many_reads(read_len):
     """more reads than one launch's first round of blocks (the rows of the later blocks once came out wrong: a code-generation
-    hazard in the reverse complement of the 2-bit rows, tools/prep_check.hip), both row widths, paired ends through the stream"""
+    hazard in the reverse complement of the 2-bit rows, profiles/NOTES.md), both row widths, paired ends through the stream"""
     import torch
     bk = _bk()
     from biokanga_amd import synth

@@ -33,6 +33,15 @@ def main():
                              "-s3", "-M6", "-F", logf] + sys.argv[2:], stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1")).returncode
         wall = time.time() - t
         print(f"rc {rc}; T_e2e {wall:.2f} s for {n_reads} reads = {n_reads / wall / 1e6:.2f} M reads/s; SAM {os.path.getsize(sam) / 1e9:.2f} GB")
+        # process start -> first log line, last log line -> process gone (what the exit takes: the address space, the device memory)
+        import datetime, re
+        stamps = []
+        for line in open(logf, errors="replace"):
+            m = re.match(r"\[(\w+\s+\d+ \d+:\d+:\d+\.\d+ \d+)\]", line)
+            if m:
+                stamps.append(datetime.datetime.strptime(re.sub(r"\s+", " ", m.group(1)), "%b %d %H:%M:%S.%f %Y").timestamp())
+        if stamps:
+            print(f"start-up (spawn -> first log line) {stamps[0] - t:.2f} s; log span {stamps[-1] - stamps[0]:.2f} s; tear-down (last log line -> process gone) {t + wall - stamps[-1]:.2f} s")
         keys = ("Loading suffix", "suffix array loaded", "Loading reads", "Load:", "Now aligning", "Alignment of", "Sorting",
                 "Header written", "Completed reporting", "Reporting of aligned result set completed", "phase:", "Device pipeline", "window array", "Exit code")
         print(open(logf + ".err").read())

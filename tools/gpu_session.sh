@@ -1,0 +1,46 @@
+#!/bin/bash
+# One session on the GPU box (run through gpurun from the repo root; everything lands under gpurun_out/<tag>/):
+#   tools/gpu_session.sh <tag> <what> [<what> ..]
+#     tests     the whole GPU suite (python -m pytest tests -m gpu)
+#     cli       the command-line golden tests only
+#     bench     python bench.py (the driver's command) -> bench.json / bench.err
+#     quick     kernel-only bench lines of 3 M and 50 M reads per step, both index layouts
+#     calib     FETCH_SIZE in our access patterns (tools/rand_access_bench calib under rocprofv3 --pmc)
+#     prof      tools/profile_round.sh + tools/pmc_busy.sh (kernel stats, counters, ALU busy) -> gpurun_out/profiles_<tag>/
+#     e2e       T_e2e of `biokanga align` on a whole C2 step with the stage clocks on (tools/e2e_cli.py)
+#     upload    host -> device upload methods (tools/upload_bench)
+set -u
+tag=${1:-x}
+shift
+O=gpurun_out/$tag
+mkdir -p $O
+export TMPDIR=/tmp
+for what in "$@"; do
+  case $what in
+    tests) python3 -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -4 $O/gputests.log ;;
+    cli)   python3 -m pytest tests/test_gpu_cli.py -x -q > $O/cli_tests.log 2>&1; tail -12 $O/cli_tests.log ;;
+    bench) python3 bench.py > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err; head -c 2500 $O/bench.json; echo ;;
+    quick)
+      python3 bench.py --reads 3000000 --no-host-leg --cpu-baseline-secs 0 --no-live-traffic > $O/b3m.json 2> $O/b3m.err
+      python3 bench.py --no-host-leg --cpu-baseline-secs 0 --no-live-traffic > $O/b50m.json 2> $O/b50m.err
+      python3 - "$O" <<'PY'
+import json, sys
+for f in ("b3m", "b50m"):
+    d = json.load(open(f"{sys.argv[1]}/{f}.json"))
+    for k, v in d["layouts"].items():
+        if isinstance(v, dict):
+            print(f, k, "kernel-only %.1f M reads/s, %.2f ms/step" % (v["value_kernel_only"] / 1e6, v["ms_per_step_kernel_only"]), v["device_ms_per_step"])
+PY
+      ;;
+    calib)
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib -o run -- $PWD/tools/rand_access_bench calib > $O/calib.log 2>&1
+      python3 tools/summarize_prof.py pmc $O/calib > $O/fetch_calibration.csv; grep calib: $O/calib.log >> $O/fetch_calibration.csv; rm -rf $O/calib
+      cat $O/fetch_calibration.csv ;;
+    prof)  tools/profile_round.sh $tag > $O/profile_round.log 2>&1; tail -25 $O/profile_round.log; tools/pmc_busy.sh $tag > $O/busy.log 2>&1; tail -8 $O/busy.log ;;
+    e2e)   python3 tools/e2e_cli.py 50000000 > $O/e2e.log 2>&1; grep -v "^\[" $O/e2e.log | cut -c1-200; grep "^\[" $O/e2e.log | cut -c1-200 ;;
+    upload)
+      python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
+      tools/upload_bench /dev/shm/upload_bench.bin 6 > $O/upload_methods.txt 2>&1; cat $O/upload_methods.txt; rm -f /dev/shm/upload_bench.bin ;;
+    *) echo "gpu_session.sh: unknown step '$what'" ;;
+  esac
+done

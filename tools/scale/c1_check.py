@@ -3,9 +3,9 @@
 SE reads without substitutions named like simreads output (seed 1), `index` + `align -s0 -M6` through the REAL reference
 (oracle/_ref/biokanga, all host threads) and through our command line; the two .sfx and the two SAM files are compared
 byte for byte and the wall-clock times reported.
-  python tools/c1_check.py [n_reads]"""
+  python tools/scale/c1_check.py [n_reads]"""
 import os, sys, time, subprocess, shutil, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 def run(cmd):

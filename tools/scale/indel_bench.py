@@ -2,9 +2,9 @@
 """microInDels at C2 scale: the bench workload (100 bp SE reads, 0-3 subs, -s3, synthetic GRCh38-like genome) with a share of the
 reads carrying a 1..8-base insertion or deletion, aligned with and without -a10: time of the extra pass, reads recovered,
 and a sample checked against the CPU oracle (result records and second segments).
-  python tools/indel_bench.py [n_reads] [genome_mbp] [indel_frac]"""
+  python tools/scale/indel_bench.py [n_reads] [genome_mbp] [indel_frac]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import biokanga_amd as bk

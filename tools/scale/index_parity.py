@@ -3,10 +3,10 @@
 families, long N runs (so that the kangax N mutation and its libc rand() stream matter) and soft-masked
 stretches is indexed by the real reference (oracle/_ref/biokanga) and by our front end; header, bases and entries
 must be byte-identical and the suffix arrays may differ only among suffixes tied through an EOS.
-  python tools/index_parity.py [genome_mbp]"""
+  python tools/scale/index_parity.py [genome_mbp]"""
 import os, struct, subprocess, sys, tempfile, time, shutil
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0

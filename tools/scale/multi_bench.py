@@ -2,9 +2,9 @@
 """Multi-loci modes at C2 scale: the bench workload (100 bp SE reads, 0-3 subs, -s3, synthetic GRCh38-like genome) aligned
 with MaxHits = -R (default 5): time of the align call with and without the loci lists, share of reads with several loci,
 and a sample checked against the CPU oracle (result records and the pHits[] lists, in order).
-  python tools/multi_bench.py [n_reads] [genome_mbp] [max_ml] [clamp] [best_matches]"""
+  python tools/scale/multi_bench.py [n_reads] [genome_mbp] [max_ml] [clamp] [best_matches]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import biokanga_amd as bk

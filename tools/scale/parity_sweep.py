@@ -2,9 +2,9 @@
 """Parity at full genome scale across option sets: for every set, a sample of the bench workload (and of a
 mixed-length variant) is aligned on the GPU and by the CPU oracle on the same 3.1 Gbp index; every bk_hit field
 and the n_search / n_cand / n_lcm counters must agree.  Prints one line per set.
-  python tools/parity_sweep.py [reads_per_set]"""
+  python tools/scale/parity_sweep.py [reads_per_set]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import biokanga_amd as bk

@@ -2,9 +2,9 @@
 """C3-shaped sanity run: 2 x 150 bp FR pairs, insert ~N(300,50) in [200,400], 0..5 subs per
 read, `-s5 -U3 -d200 -D400` against the synthetic GRCh38-like genome: SE pass (device-resident), then
 bk_pair_batch; a sample is checked against the CPU oracle (SE fields and PE outcome).
-  python tools/pe_bench.py [n_pairs] [genome_mbp]"""
+  python tools/scale/pe_bench.py [n_pairs] [genome_mbp]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import biokanga_amd as bk

@@ -2,9 +2,9 @@
 """Paired-end end-to-end parity at genome scale: 2 x 150 bp FR pairs against the 3.1 Gbp synthetic index are run
 through the real reference (oracle/_ref/biokanga align -U3 -d200 -D400 -s5 -M6) and through our command line;
 the two SAM files must be byte-identical.  The pair count is limited by the reference's loader (2 M reads).
-  python tools/pe_e2e.py [n_pairs]"""
+  python tools/scale/pe_e2e.py [n_pairs]"""
 import os, sys, time, subprocess, shutil, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import biokanga_amd as bk

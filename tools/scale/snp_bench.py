@@ -2,9 +2,9 @@
 """SNP pile-up and screening at C2 scale: the bench workload (100 bp SE reads, 0-3 subs, -s3, synthetic GRCh38-like genome) aligned on
 the device, every accepted read piled up over the 6 count planes in HBM (bk_snp_pileup, host-resident reads as the CLI hands them over),
 every sequence screened (bk_snp_sites); wall time of each step, and the smallest sequences checked against the CPU oracle.
-  python tools/snp_bench.py [n_reads] [genome_mbp]"""
+  python tools/scale/snp_bench.py [n_reads] [genome_mbp]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import biokanga_amd as bk

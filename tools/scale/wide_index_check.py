@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Suffix sort at wheat scale (BASELINE.json config 5: 17 Gbp, 5-byte elements): builds the suffix array of a synthetic
 "wheat-like" genome (21 sequences, 85 % repeat-derived) on one MI355X and checks it by properties - every position once,
-sampled neighbours in nibble-lexicographic order.  python tools/wide_index_check.py [genome_mbp]"""
+sampled neighbours in nibble-lexicographic order.  python tools/scale/wide_index_check.py [genome_mbp]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import biokanga_amd as bk
