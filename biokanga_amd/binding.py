@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
     "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device", "bk_sam_prepare", "bk_sam_prep_free",
-    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex",
+    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex", "bk_ctx_set_chrom_filter",
 ]
 
 
@@ -139,6 +139,8 @@ def load_library():
     lib.bk_ctx_destroy.restype = None
     lib.bk_ctx_set_params.argtypes = [vp, ctypes.POINTER(AlignParams)]
     lib.bk_ctx_set_params.restype = i32
+    lib.bk_ctx_set_chrom_filter.argtypes = [vp, vp, u32]
+    lib.bk_ctx_set_chrom_filter.restype = i32
     lib.bk_ctx_reserve.argtypes = [vp, u32, u32]
     lib.bk_ctx_reserve.restype = i32
     lib.bk_align_batch_device_async.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp]
@@ -529,6 +531,16 @@ class Aligner:
         rc = self.lib.bk_align_batch_device_async(self.h, d_bases, d_offs, d_lens, nreads, int(max_read_len), d_out, stream)
         if rc:
             raise BkError(rc, "bk_align_batch_device_async")
+
+    def set_chrom_filter(self, accept):
+        """accept: uint8 table by sequence id (helpers.chrom_accept_table), or None to remove it"""
+        if accept is None:
+            rc = self.lib.bk_ctx_set_chrom_filter(self.h, None, 0)
+        else:
+            a = np.ascontiguousarray(accept, dtype=np.uint8)
+            rc = self.lib.bk_ctx_set_chrom_filter(self.h, a.ctypes.data, len(a))
+        if rc:
+            raise BkError(rc, "bk_ctx_set_chrom_filter")
 
     def reserve(self, max_batch_reads, max_read_len):
         rc = self.lib.bk_ctx_reserve(self.h, int(max_batch_reads), int(max_read_len))

@@ -124,6 +124,8 @@ struct bk_ctx {
     uint64_t cap_in_bases = 0;
     uint32_t cap_in_reads = 0;
 
+    uint8_t *d_chrom_accept = nullptr;    // bk_ctx_set_chrom_filter: by sequence id, what the PE rules ask of the -Z / -z filters
+    uint32_t n_chrom_accept = 0;
     bk_timing timing{};
     std::vector<hipEvent_t> ev_pool;
     // multi-loci modes: loci lists of the last align call (host side, see bk_batch_loci)

@@ -60,7 +60,7 @@ void launch_search_b(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
 void launch_clear_iv(const DevBatch &b, const uint32_t *p_n_act, uint32_t n_act_bound, int cmax, int st0, int st1, hipStream_t s);
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, bk_seg2 *seg2, int min_chim,
-               int long_reads, hipStream_t s);
+               int long_reads, const uint8_t *accept, uint32_t n_accept, hipStream_t s);
 void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
                   uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
                   uint32_t *cmax_next, int nw, hipStream_t s);
@@ -1240,7 +1240,7 @@ int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_h
     }
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16 * 4, s));
     launch_pe(c->ix, c->cfg, b, pe->pe_mode, pe->pair_min_len, pe->pair_max_len, pe->pair_strand ? 1 : 0, d_hits, n_pairs,
-              c->d_heavy, c->d_small, c->h_small, d_seg2, c->params.min_chimeric_len, maxlen > 512 ? 1 : 0, s);
+              c->d_heavy, c->d_small, c->h_small, d_seg2, c->params.min_chimeric_len, maxlen > 512 ? 1 : 0, c->d_chrom_accept, c->n_chrom_accept, s);
     HIP_TRY(hipGetLastError());
     if (seg2_host && !seg2_dev) HIP_TRY(hipMemcpyAsync(seg2_host, d_seg2, (size_t)nreads * sizeof(bk_seg2), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1475,6 +1475,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_in_words); free_dev(c->d_in_lens16); free_dev(c->d_in_exc); free_dev(c->d_scan_tmp); free_dev(c->d_ctr_aux);
     if (c->h_small) (void)hipHostFree(c->h_small);
     free_dev(c->d_ctl);
+    free_dev(c->d_chrom_accept);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1508,6 +1509,21 @@ int bk_ctx_reserve(bk_ctx *c, uint32_t max_batch_reads, uint32_t max_read_len)
     }
     if (c->sort_lists) { rc = ensure_sort_scratch(c, n, c->stream); if (rc) return rc; }      // (grown when a phase's list is longer)
     if (c->use_wave && c->ix.isa == nullptr) { rc = size_heavy_scratch(c); if (rc) return rc; }     // hash-set dedupe of the wave kernel
+    return BK_OK;
+}
+
+int bk_ctx_set_chrom_filter(bk_ctx *c, const uint8_t *accept, uint32_t n)
+{
+    if (!c || (n && !accept)) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_dev(c->d_chrom_accept);
+    c->d_chrom_accept = nullptr;
+    c->n_chrom_accept = 0;
+    if (!n) return BK_OK;
+    HIP_TRY(hipMalloc(&c->d_chrom_accept, n));
+    HIP_TRY(hipMemcpy(c->d_chrom_accept, accept, n, hipMemcpyHostToDevice));
+    c->n_chrom_accept = n;
     return BK_OK;
 }
 

@@ -449,7 +449,13 @@ void launch_indel(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b,
 // compare, MaxMM = the -s value, <= 15); the FIRST window with the fewest mismatches wins.
 // hits[2i] / hits[2i+1] = PE1 / PE2; bk_hit.flags bit 7 = FlgPEAligned.
 
-struct DevPE { int pe_mode, min_len, max_len, pair_strand; };
+struct DevPE {
+    int pe_mode, min_len, max_len, pair_strand;
+    const uint8_t *accept;      // the -Z / -z filters as CAligner::AcceptThisChromID answers them, by sequence id; null = every sequence passes
+    uint32_t n_accept;
+};
+
+__device__ __forceinline__ bool pe_chrom_ok(const DevPE &pe, uint32_t id) { return pe.accept == nullptr || id >= pe.n_accept || pe.accept[id] != 0; }
 
 enum { NAR_CHROMFILT = 11, NAR_PEINSERTMIN = 13, NAR_PEINSERTMAX = 14, NAR_PENOHIT = 15, NAR_PESTRAND = 16, NAR_PECHROM = 17,
        NAR_PEUNALIGN = 18 };
@@ -480,7 +486,8 @@ __device__ __forceinline__ void pe_finish(const DevPE &pe, bk_hit &f, bk_hit &r)
     bk_hit *hh[2] = {&f, &r};
     for (int k = 0; k < 2; k++) {
         bk_hit &h = *hh[k];
-        if (h.num_hits != 1) {
+        // (a unique alignment on a filtered sequence is not accepted as single-ended either; Aligner.cpp:3445-3473 names it "PE partner not aligned")
+        if (h.num_hits != 1 || !pe_chrom_ok(pe, h.chrom_id)) {
             h.num_hits = 0; h.low_hit_instances = 0;
             if (h.nar == BK_NAR_ACCEPTED) h.nar = NAR_PEUNALIGN;
         } else
@@ -521,7 +528,12 @@ __global__ void __launch_bounds__(256) k_pe_classify(DevPE pe, bk_hit *__restric
         if (f.nar == BK_NAR_ACCEPTED && r.nar == BK_NAR_ACCEPTED) {
             int frag = 0;
             if (f.num_hits == 1 && r.num_hits == 1) {
-                if (f.chrom_id != r.chrom_id) frag = -2;
+                // AcceptProvPE with the chromosome filters (Aligner.cpp:2771-2786): -3 both ends filtered, -4 / -5 the first / second
+                const bool f_ok = pe_chrom_ok(pe, f.chrom_id);
+                if (f.chrom_id != r.chrom_id) {
+                    const bool r_ok = pe_chrom_ok(pe, r.chrom_id);
+                    frag = (f_ok && r_ok) ? -2 : ((!f_ok && !r_ok) ? -3 : (!f_ok ? -4 : -5));
+                } else if (!f_ok) frag = -3;
                 else {
                     uint32_t fs, fe, rs, re;
                     pe_adj_loci(f, seg2, 2 * i, fs, fe);
@@ -534,10 +546,13 @@ __global__ void __launch_bounds__(256) k_pe_classify(DevPE pe, bk_hit *__restric
                 switch (frag) {
                 case -1: f.nar = r.nar = NAR_PESTRAND; break;
                 case -2: f.nar = r.nar = NAR_PECHROM; break;
+                case -3: f.num_hits = 0; f.low_hit_instances = 0; r.num_hits = 0; r.low_hit_instances = 0; f.nar = r.nar = NAR_CHROMFILT; stop = true; break;
+                case -4: f.nar = NAR_CHROMFILT; f.num_hits = 0; f.low_hit_instances = 0; break;
+                case -5: r.nar = NAR_CHROMFILT; r.num_hits = 0; r.low_hit_instances = 0; break;
                 case -6: f.nar = r.nar = NAR_PEINSERTMIN; break;
                 case -7: f.nar = r.nar = NAR_PEINSERTMAX; break;
                 }
-                if (pe.pe_mode == 2) {
+                if (pe.pe_mode == 2 && !stop) {
                     f.num_hits = 0; f.low_hit_instances = 0; r.num_hits = 0; r.low_hit_instances = 0;
                     if (f.nar == BK_NAR_ACCEPTED) f.nar = NAR_PENOHIT;
                     if (r.nar == BK_NAR_ACCEPTED) r.nar = NAR_PENOHIT;
@@ -630,6 +645,11 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
             bk_hit &o = anchor == 0 ? r : f;
             const bool o_un = anchor == 0 ? r_un : f_un;
             if (!(a.num_hits == 1 && !o_un)) continue;
+            if (!pe_chrom_ok(pe, a.chrom_id)) {
+                // an anchor on a filtered sequence is not used; the reference marks the FIRST read's record for either anchor (:3316-3322,3416-3421)
+                if (a.nar == BK_NAR_ACCEPTED) { f.num_hits = 0; f.low_hit_instances = 0; f.nar = NAR_CHROMFILT; }
+                continue;
+            }
             const uint32_t oi = 2 * i + (anchor == 0 ? 1 : 0);
             bool b3, anti;
             if (anchor == 0) {
@@ -764,9 +784,9 @@ __global__ void __launch_bounds__(256) k_pe_orphan(DevIndex ix, DevAlignCfg cfg,
 
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters /*[0] count [1] cursor, zeroed*/,
-               uint32_t *h_count, bk_seg2 *seg2, int min_chim, int long_reads, hipStream_t s)
+               uint32_t *h_count, bk_seg2 *seg2, int min_chim, int long_reads, const uint8_t *accept, uint32_t n_accept, hipStream_t s)
 {
-    DevPE pe{pe_mode, min_len, max_len, pair_strand};
+    DevPE pe{pe_mode, min_len, max_len, pair_strand, accept, n_accept};
     launch_pack_rows(b, s);
     hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters, seg2);
     (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);

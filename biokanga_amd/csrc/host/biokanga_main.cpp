@@ -11,6 +11,7 @@
 //                  [-U 1..4 -u mates.fa -d minins -D maxins [-E]] [-T threads(ignored)] [-F logfile] [--device n]
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -547,7 +548,6 @@ int read_align_opts(Args &a, AlignOpts &o)
                 (opt[0] == 'Z' ? o.re_excl : o.re_incl).push_back(re);
             }
     // (with -U the reference consults the filters inside its pair rules, AcceptThisChromID at Aligner.cpp:2771-2786,3224,3323,3445: not built)
-    if ((!o.re_excl.empty() || !o.re_incl.empty()) && o.pe_mode) { diag("Error: chromosome filters '-Z/-z' together with '-U%d' are not available in this build", o.pe_mode); return 1; }
     o.min_flank = a.num("x", 0);
     if (o.min_flank < 0 || o.min_flank > 7) { diag("Error: Max flank trimming '-x%d' specified outside of range 0..7", o.min_flank); return 1; }      // cMaxAllowedSubs / 2
     o.P = bk_align_params{};
@@ -675,6 +675,12 @@ int prepare_submission(const AlignOpts &o, const ReadStore &rs, size_t ndev, boo
     HostClock clk;
     std::thread results([&]() {                    // (the record array is touched page by page: a thread of its own)
         HostClock c2;
+        A.hits.reserve(nr);                        // (room first, marked for huge pages, then the records: 500 page faults per GB instead of 260 000)
+        if (nr * sizeof(bk_hit) >= bk::kHugeFrom) {
+            const uintptr_t lo = ((uintptr_t)A.hits.data() + bk::kHugePage - 1) & ~(uintptr_t)(bk::kHugePage - 1);
+            const uintptr_t hi = ((uintptr_t)A.hits.data() + nr * sizeof(bk_hit)) & ~(uintptr_t)(bk::kHugePage - 1);
+            if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+        }
         A.hits.resize(nr);
         c2.lap("result array sized");
         if (nr && bk_host_register(A.hits.data(), nr * sizeof(bk_hit)) == BK_OK) S.registered = A.hits.data();
@@ -1115,6 +1121,26 @@ int cmd_align(int argc, char **argv, int first)
             pre.start(opath0.c_str(), est);
         }
     }
+    // CAligner::AcceptThisChromID (Aligner.cpp:2651-2715): a sequence passes unless an exclude expression matches its name, and - with include
+    // expressions present - only if one of those does too (exclusion first: not the rule of FiltByChroms further down)
+    std::vector<uint8_t> chrom_ok;
+    if (!o.re_excl.empty() || !o.re_incl.empty()) {
+        chrom_ok.assign(n_ent + 1, 1);
+        for (uint32_t c = 1; c <= n_ent; c++) {
+            regmatch_t mc;
+            bool ok = true;
+            for (regex_t &re : o.re_excl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = false; break; }
+            if (ok && !o.re_incl.empty()) {
+                ok = false;
+                for (regex_t &re : o.re_incl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = true; break; }
+            }
+            chrom_ok[c] = ok ? 1 : 0;
+        }
+    }
+    // the paired-end rules consult the filters while they pair (AcceptProvPE, the orphan recovery's anchors, the single-end acceptance)
+    if (o.pe_mode && !chrom_ok.empty())
+        for (bk_ctx *c : ctxs)
+            if ((rc = bk_ctx_set_chrom_filter(c, chrom_ok.data(), (uint32_t)chrom_ok.size())) != BK_OK) { diag("Error: chromosome filter table: %s", bk_strerror(rc)); destroy_ctxs(); return 1; }
     // the pipelines' device buffers and the contexts' batch scratch are in place before the clock of T_align starts (the reference sizes its
     // per-thread scratch before its workers start, Aligner.cpp:8771-8790)
     std::vector<bk_stream *> streams;
@@ -1142,22 +1168,6 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
     std::vector<int> multi_dist((size_t)o.max_ml, 0);
     std::vector<bk_loci_trims> rec_trims;          // -c with -r: per record (after -r5's expansion) the trims of the placement it took
-    // CAligner::AcceptThisChromID (Aligner.cpp:2651-2715): a sequence passes unless an exclude expression matches its name, and - with include
-    // expressions present - only if one of those does too (exclusion first: not the rule of FiltByChroms further down)
-    std::vector<uint8_t> chrom_ok;
-    if (!o.re_excl.empty() || !o.re_incl.empty()) {
-        chrom_ok.assign(n_ent + 1, 1);
-        for (uint32_t c = 1; c <= n_ent; c++) {
-            regmatch_t mc;
-            bool ok = true;
-            for (regex_t &re : o.re_excl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = false; break; }
-            if (ok && !o.re_incl.empty()) {
-                ok = false;
-                for (regex_t &re : o.re_incl) if (!regexec(&re, ents[c - 1].name, 1, &mc, 0)) { ok = true; break; }
-            }
-            chrom_ok[c] = ok ? 1 : 0;
-        }
-    }
     if (o.ml_mode) resolve_multi_loci(o, rs, A, src, multi_dist, nr, rec_trims, chrom_ok.empty() ? nullptr : &chrom_ok);
     auto RD = [&](size_t i) -> size_t { return src.empty() ? i : (size_t)src[i]; };
     auto has_seg2 = [&](size_t i) -> bool { return !seg2.empty() && (seg2[RD(i)].flags & 5); };       // FlgInDel or FlgSplice

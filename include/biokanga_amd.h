@@ -169,6 +169,12 @@ void bk_ctx_destroy(bk_ctx *ctx);
  * calls and the pipeline (batches grow the scratch on demand), required by bk_align_batch_device_async. */
 int  bk_ctx_reserve(bk_ctx *ctx, uint32_t max_batch_reads, uint32_t max_read_len);
 
+/* The chromosome filters (-Z / -z) as the paired-end rules see them: accept[id] != 0 <=> CAligner::AcceptThisChromID(id) (Aligner.cpp:2651-2715),
+ * consulted by AcceptProvPE (:2771-2786), by the anchors of the orphan recovery (:3224,3323) and by the single-end acceptance at the end of
+ * ProcessPairedEnds (:3445-3473).  ids >= n pass; n == 0 removes the table.  Only bk_pair_batch* (and pipelines created with `pe`) look at it:
+ * the filters never change a single read's alignment. */
+int  bk_ctx_set_chrom_filter(bk_ctx *ctx, const uint8_t *accept, uint32_t n);
+
 /* change alignment parameters (re-derives MinCoreLen, MaxIter, slides) */
 int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
 /* cross-check knobs: results never depend on them; the test-suite runs independent implementations of the same step against

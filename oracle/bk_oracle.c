@@ -1638,6 +1638,19 @@ int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mod
                                int pair_strand, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
                                uint32_t n_pairs, ora_hit *hits, ora_seg2 *seg2)
 {
+    return ora_process_paired_ends_filt(s, p, pe_mode, pair_min_len, pair_max_len, pair_strand, bases, offs, lens, n_pairs, hits, seg2, NULL, 0);
+}
+
+/* .. with the chromosome filters (-Z / -z) the reference consults INSIDE its pair rules: accept[id] != 0 <=> CAligner::AcceptThisChromID(id)
+ * (Aligner.cpp:2651-2715); ids beyond n_accept - 1 and a NULL table accept everything.  AcceptProvPE's results -3 / -4 / -5 (:2771-2786), their
+ * handling (:3166-3187), the anchors of the orphan recovery (:3224,3316-3322,3323,3416-3421 - the second of which changes the FIRST read's
+ * record, as it stands there) and the single-end acceptance at the end (:3442-3473). */
+static int chrom_accepted(const uint8_t *accept, uint32_t n_accept, uint32_t id) { return accept == NULL || id >= n_accept || accept[id] != 0; }
+
+int ora_process_paired_ends_filt(const ora_sfx *s, const ora_params *p, int pe_mode, int pair_min_len, int pair_max_len,
+                                 int pair_strand, const uint8_t *bases, const uint64_t *offs, const uint32_t *lens,
+                                 uint32_t n_pairs, ora_hit *hits, ora_seg2 *seg2, const uint8_t *accept, uint32_t n_accept)
+{
     const int min_chim = seg2 != NULL ? p->min_chimeric_len : 0;
     int min_core = ora_min_core_len(s, p->pmode);
     int slides = ora_max_num_slides(p->pmode);
@@ -1656,7 +1669,11 @@ int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mod
         if (f->nar == NAR_ACCEPTED && r->nar == NAR_ACCEPTED) {
             int frag = 0;
             if (f->num_hits == 1 && r->num_hits == 1) {                 /* AcceptProvPE */
-                if (f->chrom_id != r->chrom_id) frag = -2;
+                const int f_ok = chrom_accepted(accept, n_accept, f->chrom_id);
+                if (f->chrom_id != r->chrom_id) {
+                    const int r_ok = chrom_accepted(accept, n_accept, r->chrom_id);
+                    frag = (f_ok && r_ok) ? -2 : ((!f_ok && !r_ok) ? -3 : (!f_ok ? -4 : -5));
+                } else if (!f_ok) frag = -3;
                 else {
                     uint32_t fs, fe, rs_, re;
                     adj_loci(f, seg2 ? &seg2[2 * i] : NULL, &fs, &fe);
@@ -1668,9 +1685,13 @@ int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mod
             switch (frag) {
             case -1: f->nar = r->nar = NAR_PESTRAND; break;
             case -2: f->nar = r->nar = NAR_PECHROM; break;
+            case -3: pe_clear(f); pe_clear(r); f->nar = r->nar = NAR_CHROMFILT; break;      /* both ends on filtered sequences: next pair */
+            case -4: f->nar = NAR_CHROMFILT; pe_clear(f); break;
+            case -5: r->nar = NAR_CHROMFILT; pe_clear(r); break;
             case -6: f->nar = r->nar = NAR_PEINSERTMIN; break;
             case -7: f->nar = r->nar = NAR_PEINSERTMAX; break;
             }
+            if (frag == -3) continue;
             if (pe_mode == PE_UNIQUE) {
                 pe_clear(f); pe_clear(r);
                 if (f->nar == NAR_ACCEPTED) f->nar = NAR_PENOHIT;
@@ -1684,6 +1705,11 @@ int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mod
                 ora_hit *a = anchor == 0 ? f : r, *o = anchor == 0 ? r : f;
                 int o_un = anchor == 0 ? r_un : f_un;
                 if (!(a->num_hits == 1 && !o_un)) continue;
+                if (!chrom_accepted(accept, n_accept, a->chrom_id)) {
+                    /* an anchor on a filtered sequence is not used; :3316-3322 marks the first read, and so does :3416-3421 for the second */
+                    if (a->nar == NAR_ACCEPTED) { pe_clear(f); f->nar = NAR_CHROMFILT; }
+                    continue;
+                }
                 uint32_t oi = 2 * i + (anchor == 0 ? 1 : 0);
                 int b3, anti;
                 if (anchor == 0) {
@@ -1737,7 +1763,7 @@ int ora_process_paired_ends_ex(const ora_sfx *s, const ora_params *p, int pe_mod
         }
         for (int k = 0; k < 2; k++) {                    /* accept as SE what aligned uniquely */
             ora_hit *h = k == 0 ? f : r;
-            int chrom_ok = h->num_hits == 1;             /* AcceptThisChromID() is always true without filters */
+            int chrom_ok = h->num_hits == 1 ? chrom_accepted(accept, n_accept, h->chrom_id) : 0;
             if (h->num_hits != 1 || !chrom_ok) {
                 pe_clear(h);
                 if (h->nar == NAR_ACCEPTED) h->nar = chrom_ok ? NAR_CHROMFILT : NAR_PEUNALIGN;

@@ -1322,7 +1322,7 @@ def make_multi_rescue(tmp, only=None):
 def make_lifted(tmp):
     """Option combinations the reference takes and the MI355X command line refused until round 4 (kanga.cpp:648-660,712,719-725,980-995):
     -k / -x / -Z / -z with -r5 (every locus a record of its own: the filters see the records).  -T1: the record numbering follows thread
-    timing otherwise.  (-Z / -z with -U is still refused: the reference consults the filters inside its pair rules, Aligner.cpp:2771-2786.)"""
+    timing otherwise.  -Z / -z with -U: the filters act inside the pair rules."""
     def unz(fix, name, dst):
         with gzip.open(os.path.join(HERE, fix, name), "rb") as f, open(dst, "wb") as g:
             shutil.copyfileobj(f, g)
@@ -1336,6 +1336,17 @@ def make_lifted(tmp):
         run([REF, "align", "-i", mr, "-I", ms, "-o", out, fmt, "-T1"] + flags, tmp)
         gz_copy(out, os.path.join(HERE, "multi", f"{tag}.{ext}.gz"))
         print("  ran multi", tag, fmt)
+    # -Z / -z with -U: the reference consults the filters inside its pair rules (AcceptThisChromID, Aligner.cpp:2771-2786,3224,3323,3445)
+    ps = unz("basic", "genome.sfx.gz", os.path.join(tmp, "lp.sfx"))
+    p1, p2 = unz("pe", "reads_1.fa.gz", os.path.join(tmp, "lp_1.fa")), unz("pe", "reads_2.fa.gz", os.path.join(tmp, "lp_2.fa"))
+    for tag, flags in (("U3ZchrB", ["-U3", "-d200", "-D400", "-s5", "-Z", "chrB"]), ("U2zchrA", ["-U2", "-d200", "-D400", "-s5", "-z", "chra"]),
+                       ("U4ZchrA", ["-U4", "-d200", "-D400", "-s5", "-Z", "chrA$"]), ("U1ZchrB", ["-U1", "-d200", "-D400", "-s5", "-Z", "chrB"])):
+        out = os.path.join(tmp, f"{tag}.m6.sam")
+        log = run([REF, "align", "-i", p1, "-u", p2, "-I", ps, "-o", out, "-M6", "-T4"] + flags, tmp)
+        gz_copy(out, os.path.join(HERE, "pe", f"{tag}.m6.sam.gz"))
+        with open(os.path.join(HERE, "pe", f"{tag}.nar.txt"), "w") as f:
+            f.write(nar_summary(log))
+        print("  ran pe", tag)
 
 
 def make_simreads(tmp):

@@ -98,6 +98,10 @@ def oracle_lib():
                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                                ctypes.c_void_p]
     lib.ora_process_paired_ends_ex.restype = ctypes.c_int
+    lib.ora_process_paired_ends_filt.argtypes = [ctypes.c_void_p, ctypes.POINTER(OraParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.ora_process_paired_ends_filt.restype = ctypes.c_int
     lib.ora_snp_chrom_sites.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
     lib.ora_snp_chrom_sites.restype = ctypes.c_int64
@@ -283,13 +287,36 @@ def _remove_orphans(hits, seg2, flag, nar):
     return hits
 
 
-def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits, seg2=None):
+def chrom_accept_table(names, exclude=(), include=()):
+    """CAligner::AcceptThisChromID (Aligner.cpp:2651-2715) as a table by sequence id (1-based; entry 0 unused): a sequence passes unless an
+    exclude expression matches its name and - with include expressions - only if one of those does (POSIX extended, case-insensitive)"""
+    import re
+    t = np.ones(len(names) + 1, dtype=np.uint8)
+    for i, nm in enumerate(names):
+        ok = not any(re.search(e, nm, re.I) for e in exclude)
+        if ok and include:
+            ok = any(re.search(e, nm, re.I) for e in include)
+        t[i + 1] = 1 if ok else 0
+    return t
+
+
+def oracle_process_pe(osfx, params, pe_mode, min_len, max_len, pair_strand, bases, offs, lens, hits, seg2=None, accept=None):
     """in-place PE association on `hits` (PE1/PE2 interleaved); flags bit 7 = FlgPEAligned.  seg2 (one entry per read, from
-    oracle_align_indel with params.min_chimeric_len set): -c together with -U, trims of recovered partners are written there"""
+    oracle_align_indel with params.min_chimeric_len set): -c together with -U, trims of recovered partners are written there.
+    accept (chrom_accept_table): the -Z / -z filters, which the reference consults inside its pair rules"""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     assert len(hits) % 2 == 0 and hits.flags["C_CONTIGUOUS"]
+    if accept is not None:
+        accept = np.ascontiguousarray(accept, dtype=np.uint8)
+        assert seg2 is None or (seg2.flags["C_CONTIGUOUS"] and len(seg2) == len(hits))
+        rc = osfx.lib.ora_process_paired_ends_filt(osfx.h, ctypes.byref(params), pe_mode, min_len, max_len, 1 if pair_strand else 0,
+                                                   bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(hits) // 2, hits.ctypes.data,
+                                                   None if seg2 is None else seg2.ctypes.data, accept.ctypes.data, len(accept))
+        if rc != 0:
+            raise RuntimeError(f"ora_process_paired_ends_filt failed: {rc}")
+        return hits
     if seg2 is not None:
         assert seg2.flags["C_CONTIGUOUS"] and len(seg2) == len(hits)
         rc = osfx.lib.ora_process_paired_ends_ex(osfx.h, ctypes.byref(params), pe_mode, min_len, max_len, 1 if pair_strand else 0,

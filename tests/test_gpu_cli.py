@@ -102,7 +102,10 @@ def test_align_30000_reads_order_byte_identical(golden_tmp, tmp_path):
 @pytest.mark.parametrize("tag,flags", [("U3", ["-U3", "-d200", "-D400", "-s5"]), ("U1", ["-U1", "-d200", "-D400", "-s5"]),
                                        ("U2", ["-U2", "-d200", "-D400", "-s5"]), ("U4", ["-U4", "-d200", "-D400", "-s5"]),
                                        ("U3dflt", ["-U3", "-s3"]), ("U3wide", ["-U3", "-d150", "-D1500", "-s5"]),
-                                       ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"])])
+                                       ("U3E", ["-U3", "-d200", "-D400", "-s5", "-E"]),
+                                       # chromosome filters inside the pair rules (AcceptThisChromID, Aligner.cpp:2771-2786,3224,3323,3445)
+                                       ("U3ZchrB", ["-U3", "-d200", "-D400", "-s5", "-Z", "chrB"]), ("U2zchrA", ["-U2", "-d200", "-D400", "-s5", "-z", "chra"]),
+                                       ("U4ZchrA", ["-U4", "-d200", "-D400", "-s5", "-Z", "chrA$"]), ("U1ZchrB", ["-U1", "-d200", "-D400", "-s5", "-Z", "chrB"])])
 @pytest.mark.parametrize("fixture", ["pe", "pe150"])
 def test_align_pe_sam_byte_identical(golden_tmp, tmp_path, tag, flags, fixture):
     if fixture == "pe150" and tag not in ("U1", "U2", "U3", "U4"):

@@ -394,6 +394,40 @@ def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, fixture, tag):
     assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
 
 
+from test_oracle_pe import PE_FILT_RUNS, filt_by_chroms
+
+
+@pytest.mark.parametrize("tag", sorted(PE_FILT_RUNS))
+def test_pe_with_chromosome_filters_matches_reference_and_oracle(golden_tmp, tmp_path, tag):
+    """-Z / -z with -U: the pair rules ask AcceptThisChromID (bk_ctx_set_chrom_filter) - vs the oracle, record by record, and - after the
+    host's FiltByChroms - vs the reference's SAM"""
+    bk = _bk()
+    cfg = PE_FILT_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path, "pe")
+    sfx_path = os.path.join(golden_tmp["basic"], "genome.sfx")
+    chroms = ["chrA", "chrB"]
+    accept = helpers.chrom_accept_table(chroms, exclude=cfg.get("Z", ()), include=cfg.get("z", ()))
+    with bk.Aligner(sfx_path, bk.AlignParams(max_subs=5)) as al:
+        se = al.align(bases, offs, lens)
+        al.set_chrom_filter(accept)
+        hits = al.pair(bases, offs, lens, se.copy(), bk.PEParams(cfg["pe"], 200, 400, False))
+        al.set_chrom_filter(None)
+        plain = al.pair(bases, offs, lens, se.copy(), bk.PEParams(cfg["pe"], 200, 400, False))
+    o = helpers.OracleSfx(sfx_path)
+    p = helpers.make_params(max_subs=5)
+    exp, _ = o.align(bases, offs, lens, p, nthreads=8)
+    exp_plain = exp.copy()
+    helpers.oracle_process_pe(o, p, cfg["pe"], 200, 400, False, bases, offs, lens, exp, accept=accept)
+    helpers.oracle_process_pe(o, p, cfg["pe"], 200, 400, False, bases, offs, lens, exp_plain)
+    o.close()
+    assert_hits_equal(hits, exp, names)
+    assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
+    assert_hits_equal(plain, exp_plain, names)                   # the table is gone with set_chrom_filter(None)
+    assert not np.array_equal(hits["nar"], plain["nar"])
+    filt_by_chroms(hits, chroms, cfg.get("Z", ()), cfg.get("z", ()))
+    check_pe_hits_against_sam(names, hits, tag, chroms, "pe")
+
+
 from test_oracle_pe import PECHIM_RUNS, check_pechim_against_sam
 
 SEG2_FIELDS = ("match_loci", "match_len", "read_ofs", "mismatches", "flags", "score")

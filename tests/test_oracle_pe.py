@@ -68,6 +68,51 @@ def test_oracle_pe_matches_reference(golden_tmp, tmp_path, fixture, tag):
     o.close()
 
 
+# -Z / -z together with -U (round 4): the reference consults the filters INSIDE its pair rules (AcceptThisChromID, Aligner.cpp:2771-2786,
+# 3224,3323,3445,3462), then runs FiltByChroms over what is left (:4019-4120) - four reference runs on the pe fixture
+PE_FILT_RUNS = {"U3ZchrB": dict(pe=3, Z=["chrB"]), "U2zchrA": dict(pe=2, z=["chra"]), "U4ZchrA": dict(pe=4, Z=["chrA$"]), "U1ZchrB": dict(pe=1, Z=["chrB"])}
+
+
+def filt_by_chroms(hits, names, exclude, include):
+    """CAligner::FiltByChroms on the records the pair rules left: a sequence stays if an include expression matches, or - without include
+    expressions - if no exclude expression does (include first: not AcceptThisChromID's order)"""
+    import re
+    keep = [True] * (len(names) + 1)
+    for i, nm in enumerate(names):
+        ok = any(re.search(e, nm, re.I) for e in include)
+        if not ok and not include:
+            ok = not any(re.search(e, nm, re.I) for e in exclude)
+        keep[i + 1] = ok
+    for h in hits:
+        if h["nar"] == 1 and not keep[h["chrom_id"]]:
+            h["nar"] = 11
+            h["num_hits"] = 0
+            h["low_hit_instances"] = 0
+
+
+@pytest.mark.parametrize("tag", sorted(PE_FILT_RUNS))
+def test_oracle_pe_with_chromosome_filters_matches_reference(golden_tmp, tmp_path, tag):
+    cfg = PE_FILT_RUNS[tag]
+    names, bases, offs, lens = pe_inputs(tmp_path, "pe")
+    o = helpers.OracleSfx(os.path.join(golden_tmp["basic"], "genome.sfx"))
+    p = helpers.make_params(max_subs=5)
+    hits, _ = o.align(bases, offs, lens, p, nthreads=8)
+    chroms = ["chrA", "chrB"]
+    accept = helpers.chrom_accept_table(chroms, exclude=cfg.get("Z", ()), include=cfg.get("z", ()))
+    helpers.oracle_process_pe(o, p, cfg["pe"], 200, 400, False, bases, offs, lens, hits, accept=accept)
+    filt_by_chroms(hits, chroms, cfg.get("Z", ()), cfg.get("z", ()))
+    check_pe_hits_against_sam(names, hits, tag, chroms, "pe")
+    exp = {}
+    with open(os.path.join(helpers.GOLDEN, "pe", f"{tag}.nar.txt")) as f:
+        for line in f:
+            t = line.split()
+            exp[t[1].strip("()")] = int(t[0])
+    got = np.bincount(hits["nar"], minlength=20)
+    for k, tg in enumerate(helpers.NAR_TAGS):
+        assert got[k] == exp[tg], (tg, got[k], exp[tg])
+    o.close()
+
+
 # -c together with -U (tests/golden/pechim: the chimeric fixture's genome, a third of the mates with foreign ends): the pair rules on
 # end-trimmed loci, partners recovered end-trimmed
 PECHIM_RUNS = {"U3c50": dict(pe=3, d=200, D=400, s=3, c=50), "U1c60": dict(pe=1, d=200, D=400, s=3, c=60), "U4c50": dict(pe=4, d=200, D=400, s=3, c=50),
