@@ -124,6 +124,8 @@ struct bk_ctx {
     uint64_t cap_in_bases = 0;
     uint32_t cap_in_reads = 0;
 
+    void *sam_text[2] = {nullptr, nullptr};   // bk_sam_format's page-locked text buffers, kept for the next call (giving page-locked memory back costs 0.1 s per GB)
+    uint64_t sam_text_cap = 0;
     uint8_t *d_chrom_accept = nullptr;    // bk_ctx_set_chrom_filter: by sequence id, what the PE rules ask of the -Z / -z filters
     uint32_t n_chrom_accept = 0;
     bk_timing timing{};
@@ -164,5 +166,6 @@ namespace bk {
 // its own HIP stream, so that the DRAM / page-cache reads and the DMAs of different slices overlap (a plain hipMemcpy stages
 // through one thread: 6-8 GB/s).  Returns when the bytes are on the device.  bk_upload.cpp
 int upload_host(void *d_dst, const void *h_src, size_t bytes, int device);
+int upload_file(void *d_dst, int fd, uint64_t file_ofs, size_t bytes, int device);       // the same from a file range, read() into the staging buffers
 bool host_is_pinned(const void *p);
 }  // namespace bk

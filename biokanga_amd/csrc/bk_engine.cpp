@@ -3,6 +3,8 @@
 // Compiled with hipcc; device code lives in the kernel files (bk_index / bk_prep / bk_search / bk_extend / bk_wave / bk_heavy / bk_rescue / bk_snp .hip).  No CPU fallback exists: every compute
 // entry point needs a HIP device and fails with BK_ERR_NODEVICE otherwise.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -105,7 +107,8 @@ struct StageClock {
     bool on = getenv("BK_TIMING") != nullptr;
     double t0 = now();
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: %-28s %7.1f ms\n", what, 1e3 * (t - t0)); t0 = t; }
+    static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (a log's seconds)
+    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: %-28s %7.1f ms   (done at :%06.3f)\n", what, 1e3 * (t - t0), wall()); t0 = t; }
 };
 
 int derive_cfg(bk_ctx *c)
@@ -1345,10 +1348,13 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         cleanup(); bk_ctx_destroy(c); return BK_ERR_MEM;
     }
     clk.lap("device allocations");
-    if (upload_host(d_seq, f.seq, f.concat_len, device_id) != BK_OK ||
-        upload_host(sa_in_place ? (void *)c->d_sa_lo : (void *)d_sa, f.sa, f.concat_len * f.el_size, device_id) != BK_OK) {
-        cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL;
-    }
+    // (read() into the staging buffers, not through the mapping: its pages would be faulted in one by one, and handed back one by one at exit)
+    const int fd = ::open(sfx_path, O_RDONLY);
+    if (fd < 0) { cleanup(); bk_ctx_destroy(c); return BK_ERR_OPNFILE; }
+    const bool sent = upload_file(d_seq, fd, (uint64_t)(f.seq - (const uint8_t *)f.map_base), f.concat_len, device_id) == BK_OK &&
+                      upload_file(sa_in_place ? (void *)c->d_sa_lo : (void *)d_sa, fd, (uint64_t)(f.sa - (const uint8_t *)f.map_base), f.concat_len * f.el_size, device_id) == BK_OK;
+    ::close(fd);
+    if (!sent) { cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
     clk.lap("upload bases + suffix array");
     rc = adopt_device_image(c, d_seq, f.concat_len, sa_in_place ? nullptr : d_sa, (int)f.el_size);
     clk.lap("pack target, adopt");
@@ -1476,6 +1482,7 @@ void bk_ctx_destroy(bk_ctx *c)
     if (c->h_small) (void)hipHostFree(c->h_small);
     free_dev(c->d_ctl);
     free_dev(c->d_chrom_accept);
+    for (void *&t : c->sam_text) if (t) { (void)hipHostFree(t); t = nullptr; }
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -196,6 +196,10 @@ struct DevBuf {
 
 }  // namespace
 
+// Records per slice.  A slice's text (150 bytes a record for 100-base reads) passes through two page-locked buffers, and page-locked memory
+// costs 0.18 s per GB to make and about as much to give back: 2 M records keep the pair at 0.6 GB and still fill the device.
+constexpr uint64_t kSamSliceRecords = 2u << 20;
+
 // what bk_sam_prepare() starts: the job's read-side arrays on their way to the device and the pinned text buffers
 struct bk_sam_prep {
     bk_ctx *ctx = nullptr;
@@ -237,7 +241,7 @@ extern "C" int bk_sam_prepare(bk_ctx *c, const bk_sam_job *job, uint32_t text_by
         if (hipSetDevice(p->ctx->device) != hipSuccess) { p->rc = BK_ERR_INTERNAL; return; }
         p->rc = sam_upload_reads(p->ctx, &j, p->d_bases, p->d_offs, p->d_lens, p->d_names, p->d_nofs);
         if (p->rc == BK_OK && text_bytes_per_record) {
-            const uint64_t slice = std::min<uint64_t>(j.n_reads, 8u << 20);
+            const uint64_t slice = std::min<uint64_t>(j.n_reads, kSamSliceRecords);
             const uint64_t cap = slice * (uint64_t)text_bytes_per_record + (1u << 20);
             bool ok = true;
             for (int q = 0; q < 2 && ok; q++) ok = hipHostMalloc(&p->h_text[q], cap, hipHostMallocDefault) == hipSuccess;
@@ -270,7 +274,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     double t_mark = now(), t_dev = 0, t_settle = 0, t_pin = 0;
     auto lap = [&](const char *what) { const double t = now(); if (timing) fprintf(stderr, "bk timing: bk_sam_format %-28s %7.1f ms\n", what, 1e3 * (t - t_mark)); t_mark = t; };
     // the read store, names, records and order travel to the device once (pageable memory: staged by a few threads)
-    DevBuf own_bases, own_offs, own_lens, own_names, own_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_text, d_cnt;
+    DevBuf own_bases, own_offs, own_lens, own_names, own_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_cnt;
 #define SAM_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; } } while (0)
     // the read-side arrays: already on the device when bk_sam_prepare() was given these reads, else they travel now
     if (prep) {
@@ -285,7 +289,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     SAM_TRY(d_hits.alloc(nr * sizeof(bk_hit)));
     SAM_TRY(d_order.alloc(job->n_order * 4));
     SAM_TRY(d_ent.alloc((size_t)n_ent * 81));
-    const uint32_t slice = (uint32_t)std::min<uint64_t>(job->n_order, 8u << 20);         // records per slice
+    const uint32_t slice = (uint32_t)std::min<uint64_t>(job->n_order, kSamSliceRecords);
     SAM_TRY(d_bytes.alloc(((size_t)slice + 1) * 8));
     SAM_TRY(d_at.alloc(((size_t)slice + 1) * 8));
     SAM_TRY(d_cnt.alloc(16));
@@ -332,20 +336,42 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     }
     lap("record check");
     void *h_text[2] = {nullptr, nullptr};
+    DevBuf d_text[2];
     uint64_t cap_text = 0;
     if (prep && prep->cap_text) {                      // (the pinned text buffers came with the head start; a slice that outgrows them replaces them)
         for (int q = 0; q < 2; q++) { h_text[q] = prep->h_text[q]; prep->h_text[q] = nullptr; }
         cap_text = prep->cap_text;
-        if (d_text.alloc(cap_text) != hipSuccess) { (void)hipGetLastError(); cap_text = 0; }
+    } else if (c->sam_text_cap) {                      // (.. or were left by the previous call)
+        for (int q = 0; q < 2; q++) { h_text[q] = c->sam_text[q]; c->sam_text[q] = nullptr; }
+        cap_text = c->sam_text_cap;
+        c->sam_text_cap = 0;
+    }
+    if (cap_text && (d_text[0].alloc(cap_text) != hipSuccess || d_text[1].alloc(cap_text) != hipSuccess)) {
+        (void)hipGetLastError();
+        for (int q = 0; q < 2; q++) if (d_text[q].p) { (void)hipFree(d_text[q].p); d_text[q].p = nullptr; }
+        for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; }
+        cap_text = 0;
     }
     auto free_host = [&]() { for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; } };
     int rc = BK_OK;
     uint64_t total_rep = 0, total_bytes = 0;
-    // a slice's text is handed to the sink on a thread of its own while the device formats the next slice into the other pinned
-    // buffer; the sink is told where in the text the slice starts, so two of its calls may overlap
+    // A slice's text is written into one of two device buffers, copied back by the copy stream into the pinned buffer of the same number
+    // and handed to the sink by a thread of its own (which waits for the copy): the device formats slice i + 1 while slice i crosses
+    // PCIe and slice i - 1 is still being stored.  The sink is told where in the text a slice starts, so two of its calls may overlap.
+    hipStream_t cs = nullptr;
+    hipEvent_t ev_written[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    bool ev_ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    for (int q = 0; q < 2 && ev_ok; q++)
+        ev_ok = hipEventCreateWithFlags(&ev_written[q], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_copied[q], hipEventDisableTiming) == hipSuccess;
+    auto free_events = [&]() {
+        for (int q = 0; q < 2; q++) { if (ev_written[q]) (void)hipEventDestroy(ev_written[q]); if (ev_copied[q]) (void)hipEventDestroy(ev_copied[q]); }
+        if (cs) (void)hipStreamDestroy(cs);
+    };
+    if (!ev_ok) { (void)hipGetLastError(); free_events(); free_host(); return BK_ERR_INTERNAL; }
     std::thread sinker[2];
     int sink_rc[2] = {0, 0};
-    auto settle = [&](int q) { if (sinker[q].joinable()) { sinker[q].join(); if (sink_rc[q] && rc == BK_OK) rc = BK_ERR_FILEACCESS; } };
+    auto settle = [&](int q) { if (sinker[q].joinable()) { sinker[q].join(); if (sink_rc[q] && rc == BK_OK) rc = sink_rc[q] < 0 ? BK_ERR_INTERNAL : BK_ERR_FILEACCESS; } };
+    lap("text buffers, streams");
     for (uint64_t k0 = 0, si = 0; k0 < job->n_order && rc == BK_OK; k0 += slice, si++) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(slice, job->n_order - k0);
         double t0 = now();
@@ -365,34 +391,48 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
             // (the text buffers follow the largest slice seen; the first slice sizes them for the run)
             const double tp = now();
             settle(0); settle(1);
-            if (d_text.p) { (void)hipFree(d_text.p); d_text.p = nullptr; }
+            for (int q = 0; q < 2; q++) if (d_text[q].p) { (void)hipFree(d_text[q].p); d_text[q].p = nullptr; }
             free_host();
             cap_text = bytes + bytes / 8 + (1u << 20);
-            bool ok = d_text.alloc(cap_text) == hipSuccess;
+            bool ok = d_text[0].alloc(cap_text) == hipSuccess && d_text[1].alloc(cap_text) == hipSuccess;
             for (int q = 0; q < 2 && ok; q++) ok = hipHostMalloc(&h_text[q], cap_text, hipHostMallocDefault) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); rc = BK_ERR_MEM; break; }
             t_pin += now() - tp;
         }
         const int q = (int)(si & 1);
         t0 = now();
-        settle(q);
+        settle(q);                                      // (slice i - 2 is stored: both buffers of this number are free)
         t_settle += now() - t0;
         if (rc != BK_OK) break;
         t0 = now();
-        hipLaunchKernelGGL(k_sam_write, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_at.as<unsigned long long>(), d_text.as<char>());
+        hipLaunchKernelGGL(k_sam_write, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_at.as<unsigned long long>(), d_text[q].as<char>());
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(h_text[q], d_text.p, bytes, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipEventRecord(ev_written[q], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev_written[q], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_text[q], d_text[q].p, bytes, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipEventRecord(ev_copied[q], cs);
         if (e != hipSuccess) { rc = BK_ERR_INTERNAL; break; }
         t_dev += now() - t0;
         const uint64_t at = total_bytes;
-        if (bytes) sinker[q] = std::thread([&, q, bytes, at]() { sink_rc[q] = sink(user, reinterpret_cast<const char *>(h_text[q]), bytes, at); });
+        const int dev = c->device;
+        sinker[q] = std::thread([&, q, bytes, at, dev]() {
+            if (hipSetDevice(dev) != hipSuccess || hipEventSynchronize(ev_copied[q]) != hipSuccess) { (void)hipGetLastError(); sink_rc[q] = -1; return; }
+            sink_rc[q] = bytes ? sink(user, reinterpret_cast<const char *>(h_text[q]), bytes, at) : 0;
+        });
         total_rep += rep;
         total_bytes += bytes;
     }
     { const double t0 = now(); settle(0); settle(1); t_settle += now() - t0; }
+    (void)hipStreamSynchronize(cs);
+    lap("slices");
+    free_events();
+    if (rc == BK_OK && h_text[0] && h_text[1] && !c->sam_text_cap) {       // kept with the context for its next call
+        for (int q = 0; q < 2; q++) { c->sam_text[q] = h_text[q]; h_text[q] = nullptr; }
+        c->sam_text_cap = cap_text;
+    }
     free_host();
-    if (timing) fprintf(stderr, "bk timing: bk_sam_format slices: device (measure, scan, write, copy back) %.1f ms, text buffers %.1f ms, waiting for the sink %.1f ms\n",
+    lap("text buffers put away");
+    if (timing) fprintf(stderr, "bk timing: bk_sam_format slices: device (measure, scan, write enqueued) %.1f ms, text buffers %.1f ms, waiting for the sink %.1f ms\n",
                         1e3 * t_dev, 1e3 * t_pin, 1e3 * t_settle);
     *n_reported = total_rep;
     *n_bytes = total_bytes;

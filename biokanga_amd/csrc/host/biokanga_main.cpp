@@ -19,6 +19,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cctype>
 #include <cerrno>
@@ -630,7 +631,8 @@ struct HostClock {
     bool on = getenv("BK_TIMING") != nullptr;
     double t0 = now();
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: host: %-40s %7.1f ms\n", what, 1e3 * (t - t0)); t0 = t; }
+    static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (the log's seconds)
+    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: host: %-40s %7.1f ms   (done at :%06.3f)\n", what, 1e3 * (t - t0), wall()); t0 = t; }
 };
 
 // The reads as they cross the boundary (the reference's loader hands its workers 1 byte/base, Aligner.cpp:9038-9055, of which three bits
@@ -662,7 +664,22 @@ struct Submission {
         });
     }
     void release_results() { if (registered) { bk_host_unregister(registered); registered = nullptr; } }
-    ~Submission() { if (early.joinable()) early.join(); release_results(); bk_host_free(words); bk_host_free(lens16); bk_host_free(exc); }
+    // the packed reads have served once the last batch is back: their page-locked memory is given back (0.18 s per GB) by a thread of its
+    // own while the records are sorted, instead of at the end of the run
+    std::thread releaser;
+    void release_packed_in_background()
+    {
+        if (early.joinable()) early.join();
+        uint32_t *w = words; uint16_t *l = lens16; bk_nbase *e = exc;
+        words = nullptr; lens16 = nullptr; exc = nullptr; cap_words = cap_lens = cap_exc = 0;
+        releaser = std::thread([w, l, e]() { bk_host_free(w); bk_host_free(l); bk_host_free(e); });
+    }
+    ~Submission()
+    {
+        if (early.joinable()) early.join();
+        if (releaser.joinable()) releaser.join();
+        release_results(); bk_host_free(words); bk_host_free(lens16); bk_host_free(exc);
+    }
 };
 
 // Reads per batch.  A batch costs less per read the larger it is (every phase's wave-per-read launch lasts at least as long as its
@@ -1015,6 +1032,15 @@ time_t g_t0 = 0;
 [[noreturn]] void end_process(int rc)
 {
     diag("Exit code: %d Total processing time: %ld seconds", rc, (long)(time(nullptr) - g_t0));
+    if (getenv("BK_TIMING")) {                     // what the exit has to give back
+        if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, f))
+                if (!strncmp(line, "Rss:", 4) || !strncmp(line, "Anonymous:", 10) || !strncmp(line, "AnonHugePages:", 14) || !strncmp(line, "Shared_", 7) || !strncmp(line, "Private_", 8) || !strncmp(line, "ShmemPmdMapped:", 15))
+                    fprintf(stderr, "bk timing: host: at exit %s", line);
+            fclose(f);
+        }
+    }
     fflush(nullptr);
     _exit(rc);
 }
@@ -1073,6 +1099,20 @@ int cmd_align(int argc, char **argv, int first)
             }
     Submission S;
     if (all_plain && plain_bytes >= (256u << 20)) S.start_early(plain_bytes, (uint32_t)std::max(15, o.min_len));
+    // SAM text goes into a file of known approximate size.  A large plain-text input tells that size now (a record is the read's name and
+    // bases - and qualities - as the input holds them plus about 31 bytes, 55 for a paired end; a FASTA record of 100 bases is 117 bytes):
+    // the file's pages are allocated, zeroed and mapped by background threads from here on - 7 GB for 50 M reads of 100 bases, which the
+    // writers would otherwise wait for.  Other inputs: once the reads are loaded (below).
+    SamPrealloc pre;
+    const std::string opath0 = a.str("o");
+    const bool sam_plain = o.fmt >= 5 && !(opath0.size() > 5 && !strcasecmp(opath0.c_str() + opath0.size() - 4, ".bam")) &&
+                           !(opath0.size() > 3 && !strcasecmp(opath0.c_str() + opath0.size() - 3, ".gz"));
+    const char *early_env = getenv("BK_SAM_EARLY_MIN");                   // (tests lower the input size from which the file is started early)
+    const bool pre_early = sam_plain && all_plain && plain_bytes >= (early_env ? strtoull(early_env, nullptr, 10) : (256ULL << 20));
+    const uint64_t pre_early_est = (1u << 20) + plain_bytes + plain_bytes / (o.pe_mode ? 2 : 3);
+    const char *pre_when = getenv("BK_PREALLOC_WHEN");                    // experiment knob: "packed" = once the reads are packed
+    const int pre_threads = getenv("BK_PREALLOC_THREADS") ? atoi(getenv("BK_PREALLOC_THREADS")) : 2;
+    if (pre_early && !(pre_when && !strcmp(pre_when, "packed"))) pre.start(opath0.c_str(), pre_early_est, pre_threads);
     const bool long_run = a.has("window-array") || est_reads / ndev >= kWindowArrayMinReads;
     loaders.emplace_back([&]() {
         ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, long_run ? BK_CTX_WINDOW_ARRAY_EAGER : BK_CTX_LEAN_IMAGE);
@@ -1084,12 +1124,16 @@ int cmd_align(int argc, char **argv, int first)
     auto destroy_ctxs = [&]() { for (bk_ctx *c : ctxs) bk_ctx_destroy(c); };
     ReadStore rs;
     int rc;
-    if (o.pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
-    else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, rs);
+    // (the index loader's threads - the HIP runtime coming up, four feeding the upload - the page-locking of the packed reads' buffers and
+    // the output file's pages run meanwhile: the parser leaves them their share of the cores, or a CPU quota stalls all of them in turn)
+    const int parse_threads = getenv("BK_PARSE_THREADS") ? atoi(getenv("BK_PARSE_THREADS")) : std::max(std::min(o.nthreads, 4), o.nthreads - 6);
+    if (o.pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
+    else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
     // .. and, still behind the index load: the reads packed for the boundary, the result array page-locked
     AlignedSet A;
     if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
-    for (auto &t : loaders) t.join();
+    if (!rc && pre_early && pre.fd < 0) pre.start(opath0.c_str(), pre_early_est, pre_threads);
+    { HostClock jc; for (auto &t : loaders) t.join(); jc.lap("waited for the index image"); }
     for (size_t d = 0; d < ndev; d++)
         if (ctx_rc[d]) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(ctx_rc[d])); destroy_ctxs(); return 1; }
     if (rc) { destroy_ctxs(); return 1; }
@@ -1107,16 +1151,11 @@ int cmd_align(int argc, char **argv, int first)
     for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", long_run ? 1 : 0);
     diag("Suffix-ordered window array: %s (%zu reads per device, %llu estimated from the input files' sizes; it comes with the index from %llu reads per device on, or with --window-array)",
          long_run ? "on" : "off", nr / ctxs.size(), (unsigned long long)(est_reads / ndev), (unsigned long long)kWindowArrayMinReads);
-    // SAM text goes into a file of known approximate size: its pages are allocated in the background from now on (fallocate fills
-    // them with zeros at memory speed: 7 GB for 50 M reads of 100 bases), while the reads are aligned and sorted
-    SamPrealloc pre;
-    if (o.fmt >= 5) {
-        const std::string opath0 = a.str("o");
-        const size_t ol = opath0.size();
-        const bool bam = ol > 5 && !strcasecmp(opath0.c_str() + ol - 4, ".bam"), gz = ol > 3 && !strcasecmp(opath0.c_str() + ol - 3, ".gz");
+    // (the SAM file of any other large run is started now: name + bases (+ qualities) + about 31 bytes per record, 55 for a paired end)
+    if (sam_plain && pre.fd < 0) {
         const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)
-        if (!bam && !gz && nr >= (size_t)(min_env ? strtoull(min_env, nullptr, 10) : 200000ULL)) {
-            uint64_t est = (1u << 20) + rs.name_bytes() + 64ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
+        if (nr >= (size_t)(min_env ? strtoull(min_env, nullptr, 10) : 200000ULL)) {
+            uint64_t est = (1u << 20) + rs.name_bytes() + 40ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
             est += (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.base_bytes();
             pre.start(opath0.c_str(), est);
         }
@@ -1149,6 +1188,7 @@ int cmd_align(int argc, char **argv, int first)
     if (o.pe_mode) diag("Paired end association and partner alignment processing runs with the alignment of each batch");
     rc = nr ? align_reads(ctxs, streams, o, rs, S, A) : BK_OK;
     if (rc) { destroy_ctxs(); return 1; }
+    S.release_packed_in_background();
     if (!nr) A.seq_counts.assign(n_ent, 0);
     std::vector<bk_hit> &hits = A.hits;
     std::vector<bk_seg2> &seg2 = A.seg2;
@@ -1233,14 +1273,14 @@ int cmd_align(int argc, char **argv, int first)
                 }
             }
         };
-        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)o.nthreads, nr / 65536));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back(fill, nr * (size_t)t / (size_t)nt, nr * (size_t)(t + 1) / (size_t)nt);
-        fill(0, nr / (size_t)nt);
-        for (auto &t : th) t.join();
+        HostClock clk;
+        par_ranges(nr, o.nthreads, [&](size_t lo, size_t hi, int) { fill(lo, hi); });
+        clk.lap("sort records filled");
         bk::ref_order_sort(recs.data(), (int64_t)nr, sort_cmp, o.nthreads);
+        clk.lap("sorted (the reference's order of equal records)");
         ord.resize(nr);
-        for (size_t i = 0; i < nr; i++) ord[i] = recs[i].idx;
+        par_ranges(nr, o.nthreads, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; i++) ord[i] = recs[i].idx; });
+        clk.lap("order taken");
     };
     if (o.pcr_win >= 0 && !o.pe_mode) {
         // CAligner::ReducePCRduplicates runs on the sorted set, before the flank trimmer (Aligner.cpp:598-610)
@@ -1301,7 +1341,29 @@ int cmd_align(int argc, char **argv, int first)
 
     // CAligner::ReportAlignStats (Aligner.cpp:3493-3822): strand counts, the simulated-reads truth check, NAR histogram
     uint64_t nar[20] = {0};
-    for (const bk_hit &h : hits) nar[h.nar < 20 ? h.nar : 0]++;
+    uint64_t tot_acc = 0, tot_plus = 0;
+    size_t first_acc = nr;                         // the first accepted read, in load order
+    {
+        const int nt = std::max(1, o.nthreads);
+        std::vector<std::array<uint64_t, 24>> part((size_t)nt);
+        std::vector<size_t> first((size_t)nt, nr);
+        for (auto &pt : part) pt.fill(0);
+        par_ranges(nr, nt, [&](size_t lo, size_t hi, int t) {
+            std::array<uint64_t, 24> c{};
+            size_t f = nr;
+            for (size_t i = lo; i < hi; i++) {
+                const bk_hit &h = hits[i];
+                c[h.nar < 20 ? h.nar : 0]++;
+                if (h.nar == BK_NAR_ACCEPTED) { c[20]++; c[21] += h.strand == '+'; if (f == nr) f = i; }
+            }
+            part[(size_t)t] = c; first[(size_t)t] = f;
+        });
+        for (int t = 0; t < nt; t++) {
+            for (int k = 0; k < 20; k++) nar[k] += part[(size_t)t][(size_t)k];
+            tot_acc += part[(size_t)t][20]; tot_plus += part[(size_t)t][21];
+            first_acc = std::min(first_acc, first[(size_t)t]);
+        }
+    }
     {
         // Reads named by `biokanga simreads` carry where they came from (lcl|usimreads|id|chrom|start|end|len|strand|..): an accepted
         // alignment on the named sequence counts as high confidence when one or both of its ends are the named ones, anything
@@ -1310,12 +1372,11 @@ int cmd_align(int argc, char **argv, int first)
         // (:3560-3650).  The descriptors are parsed with the reference's own sscanf formats.
         uint64_t n_plus = 0, n_acc = 0, n2 = 0, n1 = 0, n_mis = 0;
         bool sim = false;
-        for (size_t i = 0; i < nr; i++) {
+        n_acc = tot_acc; n_plus = tot_plus;        // (counted above by all threads; the truth check below visits reads only while the set looks simulated)
+        for (size_t i = first_acc; i < nr; i++) {
             const bk_hit &h = hits[i];
             if (h.nar != BK_NAR_ACCEPTED) continue;
-            n_acc++;
-            n_plus += h.strand == '+';
-            if (!(sim || n_acc == 1)) continue;
+            if (!(sim || i == first_acc)) break;
             char typ[100], xchrom[300], x1c[100], x2c[100], xstrand;
             int id, xs, xe, xl, xerrs;
             const char *nm = rs.name(RD(i));
@@ -1380,11 +1441,21 @@ int cmd_align(int argc, char **argv, int first)
         if (any) rr = process_snps(ctx, R, o.snp);
         else for (const char *ext : {"", ".disnp.csv", ".trisnp.csv", ".markers"}) { if (ext[1] == 'm' && !o.snp.marker_len) continue; OutBuf e; e.open((o.snp.path + ext).c_str()); e.close(); }
     }
-    { HostClock clk; destroy_ctxs(); clk.lap("contexts destroyed"); }
     if (rr == 0 && nr >= 1000000) {                // (small runs unwind normally: leak checkers and tests see every destructor)
         pre.finish();
-        end_process(rr);
+        if (getenv("BK_EXIT_PROBE")) {             // what each thing the exit gives back wholesale would cost to give back piece by piece
+            HostClock clk;
+            S.release_results(); clk.lap("exit probe: result array unregistered");
+            bk_host_free(S.words); bk_host_free(S.lens16); bk_host_free(S.exc); S.words = nullptr; S.lens16 = nullptr; S.exc = nullptr; clk.lap("exit probe: packed reads' page-locked buffers freed");
+            { ReadStore none; std::swap(rs, none); } clk.lap("exit probe: read store freed");
+            { AlignedSet none; std::swap(A, none); } clk.lap("exit probe: result records freed");
+            destroy_ctxs(); clk.lap("exit probe: contexts destroyed");
+            if (pre.map) { munmap(pre.map, (size_t)pre.est); pre.map = nullptr; } clk.lap("exit probe: SAM file unmapped");
+            (void)hipDeviceReset(); clk.lap("exit probe: hipDeviceReset");
+        }
+        end_process(rr);                           // (contexts, page-locked buffers and the address space go with the process)
     }
+    { HostClock clk; destroy_ctxs(); clk.lap("contexts destroyed"); }
     return rr;
 }
 

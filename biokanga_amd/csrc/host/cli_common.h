@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
+#include <mutex>
+#include <sys/mman.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -23,6 +26,18 @@
 
 namespace bkcli {
 
+
+// [0, n) cut into one contiguous range per thread: fn(lo, hi, t) with t < nthreads.  Small n runs on the caller's thread.
+template <class Fn>
+inline void par_ranges(size_t n, int nthreads, Fn fn)
+{
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), n / 65536));
+    if (nt <= 1) { fn((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) th.emplace_back([&fn, n, nt, t]() { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
+    fn((size_t)0, n / nt, 0);
+    for (auto &x : th) x.join();
+}
 
 inline const char *kProgVer = "4.4.2";          // cpszProgVer of the release whose formats are kept (biokanga.cpp:33)
 inline std::string g_proc = "biokanga";          // gszProcName = basename(argv[0]) (used for @PG ID:)
@@ -110,16 +125,54 @@ struct ReadStore {
 // time from an estimate of the text's size, while the run does everything else.  The writers later copy into pages that exist.
 struct SamPrealloc {
     int fd = -1;
-    std::atomic<off_t> done{0};         // bytes from the file's start that are allocated
+    std::atomic<off_t> done{0};         // bytes from the file's start whose pages exist (and, with `map`, are in the page table)
     std::atomic<bool> quit{false}, ended{false};
     off_t est = 0;
-    std::thread th;
-    void start(const char *path, uint64_t estimate)
+    char *map = nullptr;                // the whole estimate mapped shared: writers memcpy into it below `done` without a single fault
+    bool kept = false;                  // (set once the text is complete: a file abandoned before that is emptied)
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::vector<uint8_t> chunk_done;
+    static constexpr off_t kStep = 128LL << 20;
+    // Pages of a new tmpfs / ext4 file are allocated and zeroed one by one whoever asks: fallocate() does it under the file's lock - one
+    // thread's worth, 3.5 GB/s, which a 7 GB SAM file of a 50 M-read run waited for - while MADV_POPULATE_WRITE (Linux 5.14) on a shared
+    // mapping of the hole allocates, zeroes and maps from as many threads as call it, and reports failure instead of raising SIGBUS.
+    // Without it: the old single fallocate thread, and writers map the ranges they need.
+    void start(const char *path, uint64_t estimate, int nthreads = 3)
     {
         fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) return;
         est = (off_t)estimate;
-        th = std::thread([this]() {
+        if (est > 0 && ftruncate(fd, est) == 0) {
+            void *m = mmap(nullptr, (size_t)est, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                if (madvise(m, 4096, 23 /* MADV_POPULATE_WRITE */) == 0) map = (char *)m;
+                else munmap(m, (size_t)est);
+            }
+        }
+        if (map) {
+            const size_t n_chunks = (size_t)((est + kStep - 1) / kStep);
+            chunk_done.assign(n_chunks, 0);
+            auto next = std::make_shared<std::atomic<size_t>>(0);
+            auto live = std::make_shared<std::atomic<int>>(nthreads);
+            for (int t = 0; t < nthreads; t++)
+                th.emplace_back([this, next, live, n_chunks]() {
+                    for (;;) {
+                        const size_t k = next->fetch_add(1);
+                        if (k >= n_chunks || quit.load()) break;
+                        const off_t at = (off_t)k * kStep, len = std::min<off_t>(kStep, est - at);
+                        if (madvise(map + at, (size_t)len, 23) != 0) { quit.store(true); break; }
+                        std::lock_guard<std::mutex> g(mu);
+                        chunk_done[k] = 1;
+                        off_t d = done.load();
+                        while (d < est && chunk_done[(size_t)(d / kStep)]) d = std::min<off_t>(est, (d / kStep + 1) * kStep);
+                        done.store(d);
+                    }
+                    if (live->fetch_sub(1) == 1) ended.store(true);
+                });
+            return;
+        }
+        th.emplace_back([this]() {
             const off_t step = 256LL << 20;
             for (off_t at = 0; at < est && !quit.load(); at += step) {
                 const off_t len = std::min<off_t>(step, est - at);
@@ -129,8 +182,13 @@ struct SamPrealloc {
             ended.store(true);
         });
     }
-    void finish() { quit.store(true); if (th.joinable()) th.join(); }
-    ~SamPrealloc() { finish(); if (fd >= 0) ::close(fd); }
+    void finish() { quit.store(true); for (auto &t : th) if (t.joinable()) t.join(); }
+    ~SamPrealloc()
+    {
+        finish();
+        if (map) munmap(map, (size_t)est);
+        if (fd >= 0) { if (!kept && ftruncate(fd, 0) != 0) {} ::close(fd); }
+    }
 };
 
 struct OutBuf {

@@ -9,6 +9,9 @@
 #include <unistd.h>
 
 #include <cctype>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstring>
 #include <thread>
 
@@ -175,27 +178,64 @@ struct SeqLut {
 };
 const SeqLut g_seq_lut;
 
-// bw / dw: where this piece's bases and descriptors go (the piece's offset in the file-sized buffers of its ParsedFile)
-void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, char *dw, ParsedChunk &out)
+// 32 sequence characters at a time: while they are all of a,c,g,t / A,C,G,T (what a read's line is made of but for its end) their codes
+// come from bit arithmetic - ((c >> 1) ^ (c >> 2)) & 3 is 0,1,2,3 for a,c,g,t in either case, bit 5 of the letter is the soft-mask flag
+// (0x08 of the code).  Returns how many leading characters of the 32 it translated (all stored; the caller advances by that many).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline unsigned acgt_run32(const uint8_t *p, uint8_t *bw)
+{
+    const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+    const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xdf));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(up, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(up, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(up, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(up, _mm256_set1_epi8('T'))));
+    const unsigned m = (unsigned)_mm256_movemask_epi8(ok);
+    const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), _mm256_set1_epi8(3));
+    const __m256i soft = _mm256_srli_epi16(_mm256_and_si256(v, _mm256_set1_epi8(0x20)), 2);
+    _mm256_storeu_si256((__m256i *)bw, _mm256_or_si256(code, soft));
+    return m == 0xffffffffu ? 32u : (unsigned)__builtin_ctz(~m);
+}
+const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+#else
+inline unsigned acgt_run32(const uint8_t *, uint8_t *) { return 0; }
+const bool g_have_avx2 = false;
+#endif
+
+// bw: where this piece's bases go (the piece's offset in the file-sized buffer of its ParsedFile)
+void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, ParsedChunk &out)
 {
     const size_t approx = (size_t)(e - p);
     out.bases = bw;
-    out.descr = dw;
     out.lens.reserve(approx / 64 + 16);
     out.descr_lens.reserve(approx / 64 + 16);
+    RawVec<char> &dv = out.descr_own;
+    dv.resize(approx / 4 + 256);
+    size_t dn = 0;
     const uint8_t *lut = g_seq_lut.t;
     while (p < e) {
         p = (const uint8_t *)memchr(p, '>', (size_t)(e - p));          // skip to the next descriptor
         if (!p) break;
         p++;
-        char *d0 = dw;
-        while (p < e && *p != '\n' && *p != '\r') {
-            const uint8_t c = *p++;
-            *dw++ = c > 0x7f ? '?' : (char)c;
-        }
-        out.descr_lens.push_back((uint32_t)(dw - d0));
+        // the descriptor: up to the line's end ('\n' or '\r')
+        const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) q = e;
+        if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(q - p))) q = cr;
+        const size_t dl = (size_t)(q - p);
+        if (dn + dl > dv.size()) dv.resize(std::max(dv.size() * 2, dn + dl + 256));
+        char *d0 = dv.data() + dn;
+        uint8_t high = 0;
+        for (size_t i = 0; i < dl; i++) { d0[i] = (char)p[i]; high |= p[i]; }
+        if (high & 0x80) for (size_t i = 0; i < dl; i++) if ((uint8_t)d0[i] > 0x7f) d0[i] = '?';
+        dn += dl;
+        p = q;
+        out.descr_lens.push_back((uint32_t)dl);
         uint8_t *b0 = bw;
         while (p < e) {
+            // (a piece never writes more bases than it has read characters: 32 bytes stored at bw stay inside the piece while p + 32 <= e)
+            if (g_have_avx2 && p + 32 <= e) {
+                const unsigned k = acgt_run32(p, bw);
+                p += k; bw += k;
+                if (k == 32) continue;
+            }
             const uint8_t v = lut[*p];
             if (v == 0xfe) break;                                      // '>': the next record
             p++;
@@ -204,6 +244,7 @@ void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, char *dw, Pars
         }
         out.lens.push_back((uint32_t)(bw - b0));
     }
+    out.descr = dv.data();
 }
 
 // first record start at or after q: a '>' with no other '>' between it and the preceding line break
@@ -256,12 +297,11 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     out.chunks.resize(pieces);
     out.bases.resize(size + 64);                          // (sized, not touched: the pieces' own pages are the only ones that become real)
-    out.descr.resize(size + 64);
     std::vector<std::thread> th;
     for (int w = 0; w < nthreads; w++)
         th.emplace_back([&, w]() {
             for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads)
-                parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.descr.data() + (cut[t] - base), out.chunks[t]);
+                parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.chunks[t]);
         });
     for (auto &t : th) t.join();
     munmap(m, size);

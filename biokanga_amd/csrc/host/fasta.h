@@ -47,18 +47,19 @@ private:
 
 // A run of parsed records (file order inside a chunk, chunks in file order): views into the two buffers of a ParsedFile.
 struct ParsedChunk {
-    uint8_t *bases = nullptr;           // the chunk's bases back to back, Ascii2Sense-mapped
-    char *descr = nullptr;              // its descriptors back to back (as SeqReader::next returns them)
+    uint8_t *bases = nullptr;           // the chunk's bases back to back, Ascii2Sense-mapped: a view into its ParsedFile's buffer
+    char *descr = nullptr;              // its descriptors back to back (as SeqReader::next returns them): descr_own's bytes
     std::vector<uint32_t> lens;
     std::vector<uint32_t> descr_lens;
+    RawVec<char> descr_own;
 };
 
-// A whole file parsed in pieces.  Both buffers are as large as the file and every piece writes from its own offset in the file on
-// (a record's bases, and its descriptor, are never longer than the record's text), so the pieces need no placement pass: a consumer
-// that keeps the reads can take the bases buffer as it is (the read store of `biokanga align` does).
+// A whole file parsed in pieces.  The bases buffer is as large as the file and every piece writes from its own offset in the file on
+// (a record's bases are never longer than the record's text), so the pieces need no placement pass: a consumer that keeps the reads
+// can take the buffer as it is (the read store of `biokanga align` does).  Descriptors - a small part of a read file, copied on by
+// every consumer - are the pieces' own.
 struct ParsedFile {
     RawVec<uint8_t> bases;
-    RawVec<char> descr;
     std::vector<ParsedChunk> chunks;
 };
 

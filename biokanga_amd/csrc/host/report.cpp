@@ -193,6 +193,21 @@ void report_jct_for_sam(Report &R)
     j.close();
 }
 
+// which sequences hold at least one accepted alignment (the header lists those, CSAMfile::AddRefSeq)
+static std::vector<uint8_t> seqs_with_hits(const std::vector<bk_hit> &hits, uint32_t n_ent, int nthreads)
+{
+    const int nt = std::max(1, nthreads);
+    std::vector<std::vector<uint8_t>> part((size_t)nt);
+    par_ranges(hits.size(), nt, [&](size_t lo, size_t hi, int t) {
+        std::vector<uint8_t> m(n_ent + 1, 0);
+        for (size_t i = lo; i < hi; i++) { const bk_hit &h = hits[i]; if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) m[h.chrom_id] = 1; }
+        part[(size_t)t].swap(m);
+    });
+    std::vector<uint8_t> has(n_ent + 1, 0);
+    for (auto &m : part) for (size_t c = 0; c < m.size(); c++) has[c] |= m[c];
+    return has;
+}
+
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index
 int report_bam(Report &R, const std::string &opath)
 {
@@ -212,8 +227,7 @@ int report_bam(Report &R, const std::string &opath)
     auto a_len = [&](const bk_hit &h, size_t i) -> uint32_t { return R.a_len(h, i); };
     const int pe_mode = R.pe_mode, fmt = R.fmt, nthreads = R.nthreads, max_rpt_sam_seqs = R.max_rpt_sam_seqs;
     int rc = 0;
-    std::vector<uint8_t> has_hit(n_ent + 1, 0);
-    for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) has_hit[h.chrom_id] = 1;
+    std::vector<uint8_t> has_hit = seqs_with_hits(hits, n_ent, nthreads);
     const bool all = (uint32_t)max_rpt_sam_seqs >= n_ent;
     std::string text = "@HD\tVN:1.4\tSO:coordinate";
     std::vector<int32_t> ref_of(n_ent + 1, -1);
@@ -397,8 +411,7 @@ int report_text(Report &R)
     uint64_t n_reported = 0;
     if (fmt >= 5) {
         // header: CSAMfile::Create/AddRefSeq/StartAlignments
-        std::vector<uint8_t> has_hit(n_ent + 1, 0);
-        for (const bk_hit &h : hits) if (h.nar == BK_NAR_ACCEPTED && h.chrom_id <= n_ent) has_hit[h.chrom_id] = 1;
+        std::vector<uint8_t> has_hit = seqs_with_hits(hits, n_ent, nthreads);
         bool all = (uint32_t)max_rpt_sam_seqs >= n_ent;
         out.put("@HD\tVN:1.4\tSO:coordinate");
         int n_hdr = 0, n_with = 0;
@@ -553,7 +566,10 @@ int report_text(Report &R)
                     }
                     have = S->pre->done.load() >= at + (off_t)n;
                 }
-                if (have || fallocate(S->fd, 0, at, (off_t)n) == 0) {
+                // (a range the background threads have populated is written through their mapping: no fault, no mmap)
+                const bool through_pre = have && S->pre->map != nullptr;
+                if (through_pre) map = S->pre->map + map_lo;
+                else if (have || fallocate(S->fd, 0, at, (off_t)n) == 0) {
                     void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, S->fd, map_lo);
                     if (m != MAP_FAILED) map = (char *)m;
                 }
@@ -572,7 +588,13 @@ int report_text(Report &R)
                 for (int t = 1; t < nt; t++) th.emplace_back(put, t);
                 put(0);
                 for (auto &t : th) t.join();
-                if (map) munmap(map, map_len);
+                if (map && !through_pre) munmap(map, map_len);
+                else if (through_pre) {
+                    // the written range leaves the page table now, on this thread (the file keeps the pages): what is still mapped when the
+                    // process ends is unmapped then, at 40 ms per GB
+                    const off_t lo_al = (at + 4095) & ~(off_t)4095, hi_al = (at + (off_t)n) & ~(off_t)4095;
+                    if (hi_al > lo_al) (void)madvise(S->pre->map + lo_al, (size_t)(hi_al - lo_al), MADV_DONTNEED);
+                }
                 return bad.load();
             };
             bk_sam_job job{};
@@ -586,8 +608,11 @@ int report_text(Report &R)
             const int drc = rs.lens.size() == nr ? bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes) : BK_ERR_PARAMS;
             if (drc == BK_OK) {
                 out.pos += (off_t)n_bytes;
+                timespec ta; clock_gettime(CLOCK_MONOTONIC, &ta);
                 if (R.pre != nullptr) R.pre->finish();
                 if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
+                if (R.pre != nullptr) R.pre->kept = true;
+                if (timing0) { timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb); fprintf(stderr, "bk timing: SAM file cut to its size: %.0f ms\n", 1e3 * ((double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec))); }
                 n_reported = n_rep;
                 device_done = true;
                 if (timing0) { timespec t1s; clock_gettime(CLOCK_MONOTONIC, &t1s); fprintf(stderr, "bk timing: SAM formatted on the device and copied out: %.0f ms (%llu bytes)\n", 1e3 * ((double)(t1s.tv_sec - t0s.tv_sec) + 1e-9 * (double)(t1s.tv_nsec - t0s.tv_nsec)), (unsigned long long)n_bytes); }
@@ -709,6 +734,7 @@ int report_text(Report &R)
         if (R.pre != nullptr && !device_done) {
             out.flush();
             if (ftruncate(out.fd, out.pos) != 0) { diag("Fatal: unable to size '%s'", a.str("o").c_str()); return 1; }
+            R.pre->kept = true;
         }
         if (prealloc.joinable()) {
             prealloc.join();

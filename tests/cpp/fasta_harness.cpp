@@ -3,14 +3,28 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "../../biokanga_amd/csrc/host/fasta.h"
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) return 2;
+    if (argc != 3 && argc != 4) return 2;
     const int nthreads = atoi(argv[2]);
     std::string err;
+    if (argc == 4) {                               // "time": the parallel parser alone, three times
+        for (int k = 0; k < 3; k++) {
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            bk::ParsedFile pf;
+            int h = bk::parse_fasta_parallel(argv[1], nthreads, pf, &err);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            size_t n = 0;
+            for (auto &c : pf.chunks) n += c.lens.size();
+            printf("parse %d: %.3f s, %zu records, handled %d\n", k, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), n, h);
+        }
+        return 0;
+    }
     bk::SeqReader rd;
     if (rd.open(argv[1], &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
     bk::RecordStream rs;

@@ -650,7 +650,7 @@ def test_options_from_a_parameter_file(golden_tmp, tmp_path):
     assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
 
 
-@pytest.mark.parametrize("case", ["basic_m6", "basic_m5", "repeat_m6", "sortorder", "pe_U3", "pe_U2", "pe150_U3", "fq_g0", "fq_g1", "two_contexts"])
+@pytest.mark.parametrize("case", ["basic_m6", "basic_m6_early", "basic_m5", "repeat_m6", "sortorder", "pe_U3", "pe_U2", "pe150_U3", "fq_g0", "fq_g1", "two_contexts"])
 def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
     """bk_sam_format: the records of plain SAM runs formatted by the device (a lane per record) are the reference's lines byte for
     byte - single and paired ends, -M5 / -M6, FASTQ scores in QUAL, the 30 000-read order.  Small runs use the host threads by default;
@@ -659,7 +659,9 @@ def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
     sfx = os.path.join(d, "genome.sfx")
     out = str(tmp_path / "o.sam")
     env = {"BK_SAM_DEVICE_MIN": "1", "BK_TIMING": "1"}
-    if case in ("basic_m6", "basic_m5", "two_contexts"):
+    if case == "basic_m6_early":                                  # the SAM file started from the input file's size, before a read is parsed
+        env["BK_SAM_EARLY_MIN"] = "1"
+    if case in ("basic_m6", "basic_m6_early", "basic_m5", "two_contexts"):
         args = ["-i", os.path.join(d, "reads.fa"), "-I", sfx, "-s3"] + (["-M6"] if case != "basic_m5" else []) + (["--devices", "0,0"] if case == "two_contexts" else [])
         gold = ("basic", "s3.m5.sam.gz" if case == "basic_m5" else "s3.m6.sam.gz")
     elif case == "repeat_m6":
@@ -681,3 +683,16 @@ def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
     assert "SAM formatted on the device" in log, log[-1500:]
     assert "head start taken" in log, log[-1500:]                 # bk_sam_prepare: the read store travelled while the host sorted
     assert open(out, "rb").read() == golden_bytes(*gold)
+
+
+def test_sam_file_started_early_host_formatted(golden_tmp, tmp_path):
+    """the file a large plain-text input starts early (pages allocated and mapped by background threads) also takes the host threads' text,
+    and a run that fails after the start leaves it empty"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "o.sam")
+    run(["align", "-o", out, "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-s3", "-M6"], str(tmp_path), env={"BK_SAM_EARLY_MIN": "1"})
+    assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
+    p = subprocess.run([BIN, "align", "-o", out, "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "no_such.sfx"), "-s3", "-M6"], cwd=str(tmp_path),
+                       env=dict(os.environ, BK_SAM_EARLY_MIN="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode != 0
+    assert os.path.getsize(out) == 0

@@ -73,3 +73,23 @@ def test_small_gzip_and_fastq_take_the_serial_reader(harness, tmp_path):
             f.write(b"@q%d\nACGTNACGTTGCA\n+\nIIIIIIIIIIIII\n" % i)
     out = subprocess.check_output([harness, fq, "4"]).decode()
     assert out.startswith("OK records 30000") and "parallel 0" in out, out
+
+
+@pytest.mark.parametrize("est", [1000, 4096, (128 << 20), (128 << 20) + 5, (300 << 20) + 12345])
+def test_output_file_pages_made_in_the_background(tmp_path_factory, est):
+    """SamPrealloc: every estimate - below, at and off the threads' 128 MB step - ends with the whole range ready; a kept file has the
+    text's size and bytes, an abandoned one is empty"""
+    d = tmp_path_factory.mktemp("pre")
+    exe = str(d / "prealloc_harness")
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "prealloc_harness.cpp"), "-lz"])
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else str(d)
+    f = os.path.join(shm, f"bk_prealloc_test_{os.getpid()}_{est}.bin")
+    try:
+        put = min(est, 777)
+        subprocess.run([exe, f, str(est), str(put), "1"], check=True, timeout=120)
+        assert open(f, "rb").read() == bytes(ord("a") + i % 23 for i in range(put))
+        subprocess.run([exe, f, str(est), str(put), "0"], check=True, timeout=120)
+        assert os.path.getsize(f) == 0
+    finally:
+        if os.path.exists(f):
+            os.unlink(f)

@@ -8,7 +8,8 @@
 #     calib     FETCH_SIZE in our access patterns (tools/rand_access_bench calib under rocprofv3 --pmc)
 #     prof      tools/profile_round.sh + tools/pmc_busy.sh (kernel stats, counters, ALU busy) -> gpurun_out/profiles_<tag>/
 #     e2e       T_e2e of `biokanga align` on a whole C2 step with the stage clocks on (tools/e2e_cli.py)
-#     upload    host -> device upload methods (tools/upload_bench)
+#     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
+#     upload    host -> device upload methods, wall-clock and CPU seconds (tools/upload_bench)
 set -u
 tag=${1:-x}
 shift
@@ -17,9 +18,9 @@ mkdir -p $O
 export TMPDIR=/tmp
 for what in "$@"; do
   case $what in
-    tests) python3 -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -4 $O/gputests.log ;;
-    cli)   python3 -m pytest tests/test_gpu_cli.py -x -q > $O/cli_tests.log 2>&1; tail -12 $O/cli_tests.log ;;
-    bench) python3 bench.py > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err; head -c 2500 $O/bench.json; echo ;;
+    tests) timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -4 $O/gputests.log ;;
+    cli)   timeout 600 python3 -m pytest tests/test_gpu_cli.py -x -q > $O/cli_tests.log 2>&1; tail -12 $O/cli_tests.log ;;
+    bench) timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err; head -c 2500 $O/bench.json; echo ;;
     quick)
       python3 bench.py --reads 3000000 --no-host-leg --cpu-baseline-secs 0 --no-live-traffic > $O/b3m.json 2> $O/b3m.err
       python3 bench.py --no-host-leg --cpu-baseline-secs 0 --no-live-traffic > $O/b50m.json 2> $O/b50m.err
@@ -37,7 +38,8 @@ PY
       python3 tools/summarize_prof.py pmc $O/calib > $O/fetch_calibration.csv; grep calib: $O/calib.log >> $O/fetch_calibration.csv; rm -rf $O/calib
       cat $O/fetch_calibration.csv ;;
     prof)  tools/profile_round.sh $tag > $O/profile_round.log 2>&1; tail -25 $O/profile_round.log; tools/pmc_busy.sh $tag > $O/busy.log 2>&1; tail -8 $O/busy.log ;;
-    e2e)   python3 tools/e2e_cli.py 50000000 > $O/e2e.log 2>&1; grep -v "^\[" $O/e2e.log | cut -c1-200; grep "^\[" $O/e2e.log | cut -c1-200 ;;
+    e2e)   timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e.log 2>&1; grep -v "^\[" $O/e2e.log | cut -c1-200; grep "^\[" $O/e2e.log | cut -c1-200 ;;
+    e2e_probe) BK_EXIT_PROBE=1 timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e_probe.log 2>&1; grep -a "exit probe\|T_e2e\|tear-down" $O/e2e_probe.log | cut -c1-200 ;;
     upload)
       python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
       tools/upload_bench /dev/shm/upload_bench.bin 6 > $O/upload_methods.txt 2>&1; cat $O/upload_methods.txt; rm -f /dev/shm/upload_bench.bin ;;
