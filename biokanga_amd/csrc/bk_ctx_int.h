@@ -165,6 +165,11 @@ namespace bk {
 // ones (file mappings, std::vector) are copied by a few host threads into a pool of pinned staging buffers, each thread feeding
 // its own HIP stream, so that the DRAM / page-cache reads and the DMAs of different slices overlap (a plain hipMemcpy stages
 // through one thread: 6-8 GB/s).  Returns when the bytes are on the device.  bk_upload.cpp
+// hipMalloc for everything the context and its pipelines own.  BK_POISON=<byte> (debugging aid) fills every allocation with that byte, so a
+// kernel that reads device memory nobody wrote meets the same bytes on every box, not whatever the previous process left in HBM.
+hipError_t dev_malloc_bytes(void **p, size_t bytes);
+hipError_t dev_zero_now(void *p, size_t bytes);
+template <class T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
 int upload_host(void *d_dst, const void *h_src, size_t bytes, int device);
 int upload_file(void *d_dst, int fd, uint64_t file_ofs, size_t bytes, int device);       // the same from a file range, read() into the staging buffers
 bool host_is_pinned(const void *p);

@@ -96,6 +96,26 @@ int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t
 void launch_keys_search(const DevBatch &b, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys, hipStream_t s);
 void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, const uint32_t *list, const uint32_t *p_n, uint32_t n_sort, int shift, uint32_t *keys,
                       const uint32_t *work_of, hipStream_t s);
+// hipMemset that has happened when it returns: a memset only joins the null stream's queue, and the pipelines' streams (non-blocking) do
+// not wait for that queue - a kernel launched on one of them right after could meet the old bytes, or have its own writes zeroed later
+hipError_t dev_zero_now(void *p, size_t bytes)
+{
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
+hipError_t dev_malloc_bytes(void **p, size_t bytes)
+{
+    static const int poison = getenv("BK_POISON") ? atoi(getenv("BK_POISON")) : -1;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison >= 0 && bytes) {
+        e = hipMemset(*p, poison & 0xff, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();       // (a memset returns before it is done, and the contexts' streams do not wait for the null stream)
+    }
+    return e;
+}
+
 }  // namespace bk
 
 using namespace bk;
@@ -204,7 +224,7 @@ int build_ktab(bk_ctx *c)
     uint64_t ncodes = 1ULL << (2 * k);
     c->ktab64 = c->ix.n >= (1ULL << 32);
     size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
-    HIP_TRY(hipMalloc(&c->d_ktab, bytes));
+    HIP_TRY(dev_malloc(&c->d_ktab, bytes));
     c->ktab_bytes = bytes;
     DevIndex ix = c->ix;
     launch_build_ktab(ix, c->d_ktab, k, c->ktab64, c->stream);
@@ -229,7 +249,7 @@ int build_k2(bk_ctx *c)
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t need = c->ix.n * 4;
     if (need > free_b || free_b - need < total_b / 5) return BK_OK;
-    HIP_TRY(hipMalloc(&c->d_k2, need + 64));
+    HIP_TRY(dev_malloc(&c->d_k2, need + 64));
     HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
     launch_build_k2(c->ix, c->d_k2, c->d_ctr + 7, c->stream);
     HIP_TRY(hipGetLastError());
@@ -249,7 +269,7 @@ int build_k2(bk_ctx *c)
         const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         void *d2 = nullptr;
-        if (n_entries * 8 + (total_b / 5) < free_b && hipMalloc(&d2, n_entries * 8) == hipSuccess) {
+        if (n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&d2, n_entries * 8) == hipSuccess) {
             launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, c->ix.n, d2, c->stream);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -271,7 +291,7 @@ int build_isa(bk_ctx *c)
     c->d_isa = nullptr;
     c->ix.isa = nullptr;
     if (!c->use_wave || !c->use_isa || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
-    HIP_TRY(hipMalloc(&c->d_isa, c->ix.n * 4));
+    HIP_TRY(dev_malloc(&c->d_isa, c->ix.n * 4));
     launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -293,8 +313,8 @@ int build_tgt2(bk_ctx *c)
     int shift = 9;
     while ((((nblocks * 64) >> shift) + 7) / 8 > 16384) shift++;
     const uint64_t flag_bytes = (((((nblocks * 64) >> shift) + 1) + 31) / 32) * 4 + 16;
-    HIP_TRY(hipMalloc(&c->d_tgt2, nblocks * 16 + 64));
-    HIP_TRY(hipMalloc(&c->d_nflag, flag_bytes));
+    HIP_TRY(dev_malloc(&c->d_tgt2, nblocks * 16 + 64));
+    HIP_TRY(dev_malloc(&c->d_nflag, flag_bytes));
     c->nflag_bytes = flag_bytes;
     HIP_TRY(hipMemsetAsync(c->d_nflag, 0, flag_bytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_tgt2 + nblocks * 2, 0, 64, c->stream));
@@ -308,7 +328,7 @@ int build_tgt2(bk_ctx *c)
     c->ix.tgt2s = nullptr;
     if (c->use_tgt2 >= 2) {
         // second copy: element j holds tgt2[j + 4], i.e. logical byte p sits at physical byte p - 32
-        HIP_TRY(hipMalloc(&c->d_tgt2s, nblocks * 16 + 64));
+        HIP_TRY(dev_malloc(&c->d_tgt2s, nblocks * 16 + 64));
         HIP_TRY(clear_dev(c->d_tgt2s, nblocks * 16 + 64, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_tgt2s, c->d_tgt2 + 4, (nblocks * 2 - 4) * 8, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -332,8 +352,8 @@ int size_heavy_scratch(bk_ctx *c)
     free_dev(c->hs.htab);
     free_dev(c->hs.slot_epoch);
     c->hs = HeavyScratch{};
-    HIP_TRY(hipMalloc(&c->hs.htab, (size_t)slots * ts * 8));
-    HIP_TRY(hipMalloc(&c->hs.slot_epoch, (size_t)slots * 4));
+    HIP_TRY(dev_malloc(&c->hs.htab, (size_t)slots * ts * 8));
+    HIP_TRY(dev_malloc(&c->hs.slot_epoch, (size_t)slots * 4));
     launch_fill_u64(c->hs.htab, (uint64_t)slots * ts, 0ULL, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(c->hs.slot_epoch, 0, (size_t)slots * 4, c->stream));
@@ -359,9 +379,9 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
         c->tot_seq_len += entries[i].seq_len;
         if (i && es[i] <= ee[i - 1]) return BK_ERR_PARAMS;
     }
-    HIP_TRY(hipMalloc(&c->d_ent_start, n_entries * 8));
-    HIP_TRY(hipMalloc(&c->d_ent_end, n_entries * 8));
-    HIP_TRY(hipMalloc(&c->d_ent_id, n_entries * 4));
+    HIP_TRY(dev_malloc(&c->d_ent_start, n_entries * 8));
+    HIP_TRY(dev_malloc(&c->d_ent_end, n_entries * 8));
+    HIP_TRY(dev_malloc(&c->d_ent_id, n_entries * 4));
     HIP_TRY(hipMemcpy(c->d_ent_start, es.data(), n_entries * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ent_end, ee.data(), n_entries * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ent_id, ei.data(), n_entries * 4, hipMemcpyHostToDevice));
@@ -374,21 +394,21 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
         if ((uint64_t)max_id > 16ULL * n_entries + (1u << 20)) return BK_ERR_PARAMS;
         std::vector<uint32_t> map((size_t)max_id + 1, 0xFFFFFFFFu);
         for (uint32_t i = 0; i < n_entries; i++) map[ei[i]] = i;
-        HIP_TRY(hipMalloc(&c->d_id2idx, map.size() * 4));
+        HIP_TRY(dev_malloc(&c->d_id2idx, map.size() * 4));
         HIP_TRY(hipMemcpy(c->d_id2idx, map.data(), map.size() * 4, hipMemcpyHostToDevice));
         c->ix.id2idx = c->d_id2idx;
         c->ix.max_id = max_id;
     }
     c->ix.n_ent = n_entries;
-    HIP_TRY(hipMalloc(&c->d_seq_counts, n_entries * 8));
-    HIP_TRY(hipMemset(c->d_seq_counts, 0, n_entries * 8));
-    HIP_TRY(hipMalloc(&c->d_ctr, (size_t)kCtrStripes * 8 * 8));
-    HIP_TRY(hipMemset(c->d_ctr, 0, (size_t)kCtrStripes * 8 * 8));
-    HIP_TRY(hipMalloc(&c->d_small, 16 * 4));
-    HIP_TRY(hipMalloc(&c->d_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
+    HIP_TRY(dev_malloc(&c->d_seq_counts, n_entries * 8));
+    HIP_TRY(dev_zero_now(c->d_seq_counts, n_entries * 8));
+    HIP_TRY(dev_malloc(&c->d_ctr, (size_t)kCtrStripes * 8 * 8));
+    HIP_TRY(dev_zero_now(c->d_ctr, (size_t)kCtrStripes * 8 * 8));
+    HIP_TRY(dev_malloc(&c->d_small, 16 * 4));
+    HIP_TRY(dev_malloc(&c->d_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
     HIP_TRY(hipHostMalloc(&c->h_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(&c->d_ctr_aux, 32));
+    HIP_TRY(dev_malloc(&c->d_ctr_aux, 32));
     HIP_TRY(hipHostMalloc(&c->h_small, 2 * sizeof(PhaseCtl)));
     int rc = derive_cfg(c);
     clk0.lap("entry table, small buffers");
@@ -438,7 +458,7 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
     c->el_size = (uint32_t)el;
     c->ix.n = n;
     uint64_t nwords = ((n + 15) / 16 + (kMaxReadLenAbs / 16) + 4 + 3) & ~3ULL;      // whole 64-base blocks
-    HIP_TRY(hipMalloc(&c->d_tgt4, nwords * 8));
+    HIP_TRY(dev_malloc(&c->d_tgt4, nwords * 8));
     launch_pack_target(d_seq, n, c->d_tgt4, nwords, c->stream);
     HIP_TRY(hipGetLastError());
     c->n_tgt4_words = nwords;
@@ -448,9 +468,9 @@ int adopt_device_image(bk_ctx *c, const uint8_t *d_seq, uint64_t n, const uint8_
         // (4-byte elements that the caller has put where they stay: c->d_sa_lo is allocated and filled)
         if (el != 4 || !c->d_sa_lo) return BK_ERR_INTERNAL;
     } else {
-        HIP_TRY(hipMalloc(&c->d_sa_lo, n * 4));
+        HIP_TRY(dev_malloc(&c->d_sa_lo, n * 4));
         if (el == 5) {
-            HIP_TRY(hipMalloc(&c->d_sa_hi, n));
+            HIP_TRY(dev_malloc(&c->d_sa_hi, n));
             launch_split_sa5(d_sa, n, c->d_sa_lo, c->d_sa_hi, c->stream);
             HIP_TRY(hipGetLastError());
         } else
@@ -477,26 +497,26 @@ int ensure_batch_scratch(bk_ctx *c, uint32_t n_reads, uint32_t wpr, uint32_t rd2
     c->d_act[0] = c->d_act[1] = c->d_heavy = c->d_wave = nullptr;
     for (int i = 0; i < 3; i++) { free_dev(c->d_stage[i]); c->d_stage[i] = nullptr; }
     c->cap_reads = 0;
-    HIP_TRY(hipMalloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
-    if (w2) HIP_TRY(hipMalloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8 + 64));        // (+ the words a 32-base fetch at a row's end runs into)
-    HIP_TRY(hipMalloc(&c->d_rmeta, ((size_t)nr + 2) / 2 * 8));
+    HIP_TRY(dev_malloc(&c->d_rd4, (size_t)nr * 2 * w * 8));
+    if (w2) HIP_TRY(dev_malloc(&c->d_rd2, (size_t)nr * 2 * w2 * 8 + 64));        // (+ the words a 32-base fetch at a row's end runs into)
+    HIP_TRY(dev_malloc(&c->d_rmeta, ((size_t)nr + 2) / 2 * 8));
     if (c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32))
-        HIP_TRY(hipMalloc(&c->d_iv2, (size_t)nr * 2 * ivc * 8));
+        HIP_TRY(dev_malloc(&c->d_iv2, (size_t)nr * 2 * ivc * 8));
     else {
-        HIP_TRY(hipMalloc(&c->d_iv_first, (size_t)nr * 2 * ivc * 8));
-        HIP_TRY(hipMalloc(&c->d_iv_n, (size_t)nr * 2 * ivc * 4));
+        HIP_TRY(dev_malloc(&c->d_iv_first, (size_t)nr * 2 * ivc * 8));
+        HIP_TRY(dev_malloc(&c->d_iv_n, (size_t)nr * 2 * ivc * 4));
     }
-    HIP_TRY(hipMalloc(&c->d_act[0], (size_t)nr * 4));
-    HIP_TRY(hipMalloc(&c->d_act[1], (size_t)nr * 4));
-    HIP_TRY(hipMalloc(&c->d_heavy, (size_t)nr * 4));
-    HIP_TRY(hipMalloc(&c->d_wave, (size_t)nr * 4));
-    for (int i = 0; i < 3; i++) HIP_TRY(hipMalloc(&c->d_stage[i], ((size_t)nr + (kListStripes + 2) * 1024) * 4));      // striped forms of the lists (StripedList)
+    HIP_TRY(dev_malloc(&c->d_act[0], (size_t)nr * 4));
+    HIP_TRY(dev_malloc(&c->d_act[1], (size_t)nr * 4));
+    HIP_TRY(dev_malloc(&c->d_heavy, (size_t)nr * 4));
+    HIP_TRY(dev_malloc(&c->d_wave, (size_t)nr * 4));
+    for (int i = 0; i < 3; i++) HIP_TRY(dev_malloc(&c->d_stage[i], ((size_t)nr + (kListStripes + 2) * 1024) * 4));      // striped forms of the lists (StripedList)
     if (!c->d_stripe_cnt) {
-        HIP_TRY(hipMalloc(&c->d_stripe_cnt, (size_t)2 * kListStripes * 16 * 4));
-        HIP_TRY(hipMemset(c->d_stripe_cnt, 0, (size_t)2 * kListStripes * 16 * 4));
+        HIP_TRY(dev_malloc(&c->d_stripe_cnt, (size_t)2 * kListStripes * 16 * 4));
+        HIP_TRY(dev_zero_now(c->d_stripe_cnt, (size_t)2 * kListStripes * 16 * 4));
     }
-    if (c->d_iv2) HIP_TRY(hipMalloc(&c->d_iv32, (size_t)nr * 2 * 8));
-    HIP_TRY(hipMalloc(&c->d_wave_work, (size_t)nr * 4));
+    if (c->d_iv2) HIP_TRY(dev_malloc(&c->d_iv32, (size_t)nr * 2 * 8));
+    HIP_TRY(dev_malloc(&c->d_wave_work, (size_t)nr * 4));
     c->cap_reads = nr;
     c->cap_wpr = w;
     c->cap_rd2w = w2;
@@ -548,10 +568,10 @@ static int ensure_sort_scratch(bk_ctx *c, uint32_t n, hipStream_t s)
     c->d_sort_tmp = nullptr;
     c->cap_sort = 0;
     const uint64_t cap = (uint64_t)n + n / 4;
-    for (auto &p : c->d_sort) HIP_TRY(hipMalloc(&p, cap * 4));
+    for (auto &p : c->d_sort) HIP_TRY(dev_malloc(&p, cap * 4));
     size_t tb = 0;
     if (sort_list_by_key(nullptr, nullptr, nullptr, nullptr, (uint32_t)cap, nullptr, &tb, s)) return BK_ERR_INTERNAL;
-    HIP_TRY(hipMalloc(&c->d_sort_tmp, tb));
+    HIP_TRY(dev_malloc(&c->d_sort_tmp, tb));
     c->sort_tmp_bytes = tb;
     c->cap_sort = cap;
     return BK_OK;
@@ -606,13 +626,13 @@ int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, uint32_t maxlen, hipS
     int rc = BK_OK;
     auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_loci); free_dev(d_trims); };
 #define LOCI_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
-    LOCI_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
-    LOCI_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
+    LOCI_TRY(dev_malloc(&d_cnt, ((size_t)n + 1) * 8));
+    LOCI_TRY(dev_malloc(&d_offs, ((size_t)n + 1) * 8));
     LOCI_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 8, s));
     launch_loci_count(b.out, n, c->params.clamp_ml ? c->cfg.max_hits : 0, d_cnt, s);
     size_t tb = 0;
     if (scan_counts_u64(nullptr, nullptr, n + 1, nullptr, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
-    LOCI_TRY(hipMalloc(&d_tmp, tb ? tb : 16));
+    LOCI_TRY(dev_malloc(&d_tmp, tb ? tb : 16));
     if (scan_counts_u64(d_cnt, d_offs, n + 1, d_tmp, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
     const size_t base = c->loci_offs.empty() ? 0 : c->loci_offs.size() - 1;      // reads of earlier chunks
     const uint64_t loci_base = c->loci.size();
@@ -623,9 +643,9 @@ int collect_loci(bk_ctx *c, const DevBatch &b, uint32_t n, uint32_t maxlen, hipS
     const uint64_t total = c->loci_offs[base + n];
     if (total) {
         uint32_t *sm = c->d_small;
-        LOCI_TRY(hipMalloc(&d_loci, (size_t)total * sizeof(bk_loci)));
+        LOCI_TRY(dev_malloc(&d_loci, (size_t)total * sizeof(bk_loci)));
         if (chim) {
-            LOCI_TRY(hipMalloc(&d_trims, (size_t)total * sizeof(bk_loci_trims)));
+            LOCI_TRY(dev_malloc(&d_trims, (size_t)total * sizeof(bk_loci_trims)));
             LOCI_TRY(clear_dev(d_trims, (size_t)total * sizeof(bk_loci_trims), s));
         }
         LOCI_TRY(hipMemsetAsync(sm, 0, 16 * 4, s));
@@ -672,9 +692,9 @@ int best_matches_chunk(bk_ctx *c, const DevBatch &b, uint32_t n, const uint32_t 
     const uint32_t width = (uint32_t)c->cfg.max_hits;
     auto cleanup = [&]() { free_dev(d_cnt); free_dev(d_offs); free_dev(d_tmp); free_dev(d_dense); free_dev(d_loci); };
 #define BEST_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
-    BEST_TRY(hipMalloc(&d_cnt, ((size_t)n + 1) * 8));
-    BEST_TRY(hipMalloc(&d_offs, ((size_t)n + 1) * 8));
-    BEST_TRY(hipMalloc(&d_dense, (size_t)n * width * sizeof(bk_loci)));
+    BEST_TRY(dev_malloc(&d_cnt, ((size_t)n + 1) * 8));
+    BEST_TRY(dev_malloc(&d_offs, ((size_t)n + 1) * 8));
+    BEST_TRY(dev_malloc(&d_dense, (size_t)n * width * sizeof(bk_loci)));
     BEST_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 8, s));
     int rc = size_heavy_scratch(c);
     if (rc) { cleanup(); return rc; }
@@ -684,7 +704,7 @@ int best_matches_chunk(bk_ctx *c, const DevBatch &b, uint32_t n, const uint32_t 
     BEST_TRY(hipGetLastError());
     size_t tb = 0;
     if (scan_counts_u64(nullptr, nullptr, n + 1, nullptr, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
-    BEST_TRY(hipMalloc(&d_tmp, tb ? tb : 16));
+    BEST_TRY(dev_malloc(&d_tmp, tb ? tb : 16));
     if (scan_counts_u64(d_cnt, d_offs, n + 1, d_tmp, &tb, s)) { cleanup(); return BK_ERR_INTERNAL; }
     const size_t base = c->loci_offs.empty() ? 0 : c->loci_offs.size() - 1;
     const uint64_t loci_base = c->loci.size();
@@ -694,7 +714,7 @@ int best_matches_chunk(bk_ctx *c, const DevBatch &b, uint32_t n, const uint32_t 
     BEST_TRY(hipStreamSynchronize(s));
     const uint64_t total = c->loci_offs[base + n];
     if (total) {
-        BEST_TRY(hipMalloc(&d_loci, (size_t)total * sizeof(bk_loci)));
+        BEST_TRY(dev_malloc(&d_loci, (size_t)total * sizeof(bk_loci)));
         launch_loci_compact(d_dense, width, d_offs, n, d_loci, s);
         BEST_TRY(hipGetLastError());
         c->loci.resize(loci_base + total);
@@ -817,8 +837,8 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                     free_dev(c->d_slist_stage);
                     c->d_slist = c->d_slist_stage = nullptr;
                     c->cap_slist = 0;
-                    HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
-                    HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
+                    HIP_TRY(dev_malloc(&c->d_slist, lanes * 4));
+                    HIP_TRY(dev_malloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));     // its striped form (StripeSet)
                     c->cap_slist = lanes;
                 }
                 // interval counts of the slots this phase can use, zeroed (empty search results store nothing)
@@ -946,7 +966,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
             free_dev(c->d_seg2);
             c->d_seg2 = nullptr;
             c->cap_seg2 = 0;
-            HIP_TRY(hipMalloc(&c->d_seg2, (size_t)n * sizeof(bk_seg2)));
+            HIP_TRY(dev_malloc(&c->d_seg2, (size_t)n * sizeof(bk_seg2)));
             c->cap_seg2 = n;
         }
         bk_seg2 *d_seg2 = c->d_seg2;
@@ -1031,7 +1051,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     const uint64_t missing = want > have ? want - have : 0;
     if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) { c->swin_denied = true; return BK_OK; }  // (the chunk size is set from 3/4 of the free memory; asked once)
     StageClock clk;
-    if (hipMalloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }   // (asked once)
+    if (dev_malloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }   // (asked once)
     launch_build_swin(c->ix, c->d_swin, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1182,7 +1202,7 @@ int bk::engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nrea
         free_dev(c->d_scan_tmp);
         c->d_scan_tmp = nullptr;
         c->scan_tmp_bytes = 0;
-        HIP_TRY(hipMalloc(&c->d_scan_tmp, need + 256));
+        HIP_TRY(dev_malloc(&c->d_scan_tmp, need + 256));
         c->scan_tmp_bytes = need + 256;
     }
     size_t tb = c->scan_tmp_bytes;
@@ -1235,7 +1255,7 @@ int bk::engine_pair_device(bk_ctx *c, const DevReads &in, uint32_t n_pairs, bk_h
             free_dev(c->d_seg2);
             c->d_seg2 = nullptr;
             c->cap_seg2 = 0;
-            HIP_TRY(hipMalloc(&c->d_seg2, (size_t)nreads * sizeof(bk_seg2)));
+            HIP_TRY(dev_malloc(&c->d_seg2, (size_t)nreads * sizeof(bk_seg2)));
             c->cap_seg2 = nreads;
         }
         d_seg2 = c->d_seg2;
@@ -1335,7 +1355,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32);
     if (eager_swin)
         swin_alloc = std::thread([&swin_mem, &f, device_id]() {
-            if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&swin_mem, f.concat_len * 48) != hipSuccess) { (void)hipGetLastError(); swin_mem = nullptr; }
+            if (hipSetDevice(device_id) != hipSuccess || dev_malloc(&swin_mem, f.concat_len * 48) != hipSuccess) { (void)hipGetLastError(); swin_mem = nullptr; }
         });
     struct JoinSwin { std::thread &t; void *&mem; bool keep = false; ~JoinSwin() { if (t.joinable()) t.join(); if (!keep && mem) { (void)hipFree(mem); mem = nullptr; } } } join_swin{swin_alloc, swin_mem};
     // stage the file image through HBM: bases and suffix array as they are on disk
@@ -1343,8 +1363,8 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     uint8_t *d_seq = nullptr, *d_sa = nullptr;
     const bool sa_in_place = f.el_size == 4;
     auto cleanup = [&]() { free_dev(d_seq); free_dev(d_sa); };
-    if (hipMalloc(&d_seq, f.concat_len + 16) != hipSuccess ||
-        (sa_in_place ? hipMalloc(&c->d_sa_lo, f.concat_len * 4) : hipMalloc(&d_sa, f.concat_len * f.el_size)) != hipSuccess) {
+    if (dev_malloc(&d_seq, f.concat_len + 16) != hipSuccess ||
+        (sa_in_place ? dev_malloc(&c->d_sa_lo, f.concat_len * 4) : dev_malloc(&d_sa, f.concat_len * f.el_size)) != hipSuccess) {
         cleanup(); bk_ctx_destroy(c); return BK_ERR_MEM;
     }
     clk.lap("device allocations");
@@ -1432,7 +1452,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     auto dup = [&](auto *&dst, const auto *from, size_t bytes) {
         if (!ok || !from) return;
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; rc = BK_ERR_MEM; return; }
+        if (dev_malloc(&p, bytes) != hipSuccess) { ok = false; rc = BK_ERR_MEM; return; }
         dst = static_cast<std::remove_reference_t<decltype(dst)>>(p);
         hipError_t e = c->device == src->device ? hipMemcpyAsync(p, from, bytes, hipMemcpyDeviceToDevice, c->stream)
                                                 : hipMemcpyPeerAsync(p, c->device, from, src->device, bytes, c->stream);
@@ -1509,8 +1529,8 @@ int bk_ctx_reserve(bk_ctx *c, uint32_t max_batch_reads, uint32_t max_read_len)
             free_dev(c->d_slist_stage);
             c->d_slist = c->d_slist_stage = nullptr;
             c->cap_slist = 0;
-            HIP_TRY(hipMalloc(&c->d_slist, lanes * 4));
-            HIP_TRY(hipMalloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));
+            HIP_TRY(dev_malloc(&c->d_slist, lanes * 4));
+            HIP_TRY(dev_malloc(&c->d_slist_stage, (lanes + (kListStripes + 2) * 1024) * 4));
             c->cap_slist = lanes;
         }
     }
@@ -1528,7 +1548,7 @@ int bk_ctx_set_chrom_filter(bk_ctx *c, const uint8_t *accept, uint32_t n)
     c->d_chrom_accept = nullptr;
     c->n_chrom_accept = 0;
     if (!n) return BK_OK;
-    HIP_TRY(hipMalloc(&c->d_chrom_accept, n));
+    HIP_TRY(dev_malloc(&c->d_chrom_accept, n));
     HIP_TRY(hipMemcpy(c->d_chrom_accept, accept, n, hipMemcpyHostToDevice));
     c->n_chrom_accept = n;
     return BK_OK;
@@ -1728,16 +1748,16 @@ int bk_align_batch(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const 
         free_dev(c->d_in_bases);
         c->d_in_bases = nullptr;
         c->cap_in_bases = 0;
-        HIP_TRY(hipMalloc(&c->d_in_bases, nbytes + 16));
+        HIP_TRY(dev_malloc(&c->d_in_bases, nbytes + 16));
         c->cap_in_bases = nbytes + 16;
     }
     if (nreads > c->cap_in_reads) {
         free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
         c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr;
         c->cap_in_reads = 0;
-        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
-        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
-        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        HIP_TRY(dev_malloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(dev_malloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(dev_malloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
         c->cap_in_reads = nreads;
     }
     std::vector<uint64_t> rel(nreads);
@@ -1870,29 +1890,29 @@ int bk_align_batch_packed(bk_ctx *c, const uint32_t *words, uint64_t n_words, co
         free_dev(c->d_in_words);
         c->d_in_words = nullptr;
         c->cap_in_words = 0;
-        HIP_TRY(hipMalloc(&c->d_in_words, (n_words + kPackedPadWords) * 4));
+        HIP_TRY(dev_malloc(&c->d_in_words, (n_words + kPackedPadWords) * 4));
         c->cap_in_words = n_words + kPackedPadWords;
     }
     if (n_exc > c->cap_in_exc) {
         free_dev(c->d_in_exc);
         c->d_in_exc = nullptr;
         c->cap_in_exc = 0;
-        HIP_TRY(hipMalloc(&c->d_in_exc, n_exc * sizeof(bk_nbase)));
+        HIP_TRY(dev_malloc(&c->d_in_exc, n_exc * sizeof(bk_nbase)));
         c->cap_in_exc = n_exc;
     }
     if (nreads > c->cap_in_reads) {
         free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out); free_dev(c->d_in_lens16);
         c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr; c->d_in_lens16 = nullptr;
         c->cap_in_reads = 0;
-        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
-        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
-        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        HIP_TRY(dev_malloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(dev_malloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(dev_malloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
         c->cap_in_reads = nreads;
     }
     if (!c->d_in_lens16 || nreads > c->cap_in_lens16) {
         free_dev(c->d_in_lens16);
         c->d_in_lens16 = nullptr;
-        HIP_TRY(hipMalloc(&c->d_in_lens16, (size_t)std::max(nreads, c->cap_in_reads) * 2));
+        HIP_TRY(dev_malloc(&c->d_in_lens16, (size_t)std::max(nreads, c->cap_in_reads) * 2));
         c->cap_in_lens16 = std::max(nreads, c->cap_in_reads);
     }
     if (n_words) HIP_TRY(hipMemcpyAsync(c->d_in_words, words, n_words * 4, hipMemcpyHostToDevice, s));
@@ -1938,16 +1958,16 @@ int bk_pair_batch_seg2(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, co
         free_dev(c->d_in_bases);
         c->d_in_bases = nullptr;
         c->cap_in_bases = 0;
-        HIP_TRY(hipMalloc(&c->d_in_bases, nbytes + 16));
+        HIP_TRY(dev_malloc(&c->d_in_bases, nbytes + 16));
         c->cap_in_bases = nbytes + 16;
     }
     if (nreads > c->cap_in_reads) {
         free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
         c->d_in_offs = nullptr; c->d_in_lens = nullptr; c->d_in_out = nullptr;
         c->cap_in_reads = 0;
-        HIP_TRY(hipMalloc(&c->d_in_offs, (size_t)nreads * 8));
-        HIP_TRY(hipMalloc(&c->d_in_lens, (size_t)nreads * 4));
-        HIP_TRY(hipMalloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
+        HIP_TRY(dev_malloc(&c->d_in_offs, (size_t)nreads * 8));
+        HIP_TRY(dev_malloc(&c->d_in_lens, (size_t)nreads * 4));
+        HIP_TRY(dev_malloc(&c->d_in_out, (size_t)nreads * sizeof(bk_hit)));
         c->cap_in_reads = nreads;
     }
     std::vector<uint64_t> rel(nreads);
@@ -2002,8 +2022,8 @@ int bk_snp_reset(bk_ctx *c)
     if (!c) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)c->ix.n * 6 * sizeof(uint32_t);
-    if (!c->d_snp_planes) HIP_TRY(hipMalloc(&c->d_snp_planes, bytes));
-    if (!c->d_snp_tot) HIP_TRY(hipMalloc(&c->d_snp_tot, 4 * 8));
+    if (!c->d_snp_planes) HIP_TRY(dev_malloc(&c->d_snp_planes, bytes));
+    if (!c->d_snp_tot) HIP_TRY(dev_malloc(&c->d_snp_tot, 4 * 8));
     HIP_TRY(clear_dev(c->d_snp_planes, bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BK_OK;
@@ -2033,7 +2053,7 @@ int bk_snp_pileup(bk_ctx *c, const uint8_t *bases, const uint64_t *offs, const u
     for (uint32_t i = 0; i < nreads; i++) rel[i] = offs[i] - lo;
     int rc = BK_OK;
     auto try_ = [&](hipError_t e) { if (e != hipSuccess && rc == BK_OK) rc = e == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; return e == hipSuccess; };
-    if (try_(hipMalloc(&d_bases, hi - lo + 16)) && try_(hipMalloc(&d_offs, (size_t)nreads * 8)) && try_(hipMalloc(&d_alns, (size_t)n_alns * sizeof(bk_snp_aln)))) {
+    if (try_(dev_malloc(&d_bases, hi - lo + 16)) && try_(dev_malloc(&d_offs, (size_t)nreads * 8)) && try_(dev_malloc(&d_alns, (size_t)n_alns * sizeof(bk_snp_aln)))) {
         try_(hipMemcpyAsync(d_bases, bases + lo, hi - lo, hipMemcpyHostToDevice, s));
         try_(hipMemcpyAsync(d_offs, rel.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
         try_(hipMemcpyAsync(d_alns, alns, (size_t)n_alns * sizeof(bk_snp_aln), hipMemcpyHostToDevice, s));
@@ -2068,7 +2088,7 @@ int bk_snp_counts(bk_ctx *c, uint32_t chrom_id, uint32_t loci, uint32_t n, uint3
     if (!n) return BK_OK;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, (size_t)n * 7 * 4));
+    HIP_TRY(dev_malloc(&d_out, (size_t)n * 7 * 4));
     launch_snp_gather(c->ix, c->d_snp_planes, ent->start_ofs + loci, n, d_out, c->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 7 * 4, hipMemcpyDeviceToHost, c->stream);
@@ -2085,7 +2105,7 @@ int bk_snp_centroid_insts(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, uint3
     if (!ent) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t *d_hist = nullptr;
-    HIP_TRY(hipMalloc(&d_hist, BK_SNP_CENTROIDS * 4));
+    HIP_TRY(dev_malloc(&d_hist, BK_SNP_CENTROIDS * 4));
     std::vector<uint32_t> h(BK_SNP_CENTROIDS);
     hipError_t e = hipMemsetAsync(d_hist, 0, BK_SNP_CENTROIDS * 4, c->stream);
     if (e == hipSuccess) { launch_snp_centroids(c->ix, c->d_snp_planes, ent->start_ofs, (uint32_t)ent->seq_len, (uint32_t)min_reads, d_hist, c->stream); e = hipGetLastError(); }
@@ -2108,7 +2128,7 @@ int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_non
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!c->cap_snp_sites) {
-        HIP_TRY(hipMalloc(&c->d_snp_sites, (size_t)(1u << 20) * sizeof(bk_snp_site)));
+        HIP_TRY(dev_malloc(&c->d_snp_sites, (size_t)(1u << 20) * sizeof(bk_snp_site)));
         c->cap_snp_sites = 1u << 20;
     }
     unsigned long long h_tot[4] = {0, 0, 0, 0};
@@ -2126,7 +2146,7 @@ int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_non
         free_dev(c->d_snp_sites);
         c->d_snp_sites = nullptr;
         c->cap_snp_sites = 0;
-        HIP_TRY(hipMalloc(&c->d_snp_sites, (size_t)n * sizeof(bk_snp_site)));
+        HIP_TRY(dev_malloc(&c->d_snp_sites, (size_t)n * sizeof(bk_snp_site)));
         c->cap_snp_sites = n;
     }
     c->snp_sites.resize(n);
@@ -2147,7 +2167,7 @@ int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
     for (int i = 0; i < kCtrStripes * 8; i++) h[i & 7] += hs[i];
     memset(out, 0, sizeof(*out));
     out->n_search = h[0]; out->n_cand = h[1]; out->n_lcm_calls = h[2]; out->n_heavy = h[3]; out->n_cand_heavy = h[4]; out->reserved[0] = h[5]; out->reserved[1] = h[6];
-    if (reset) HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(hs)));
+    if (reset) HIP_TRY(dev_zero_now(c->d_ctr, sizeof(hs)));
     return BK_OK;
 }
 
@@ -2164,7 +2184,7 @@ int bk_seq_counts(bk_ctx *c, uint64_t *per_entry_hits, uint32_t n, int reset)
     if (!c || !per_entry_hits || n != c->entries.size()) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpy(per_entry_hits, c->d_seq_counts, (size_t)n * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_seq_counts, 0, (size_t)n * 8));
+    if (reset) HIP_TRY(dev_zero_now(c->d_seq_counts, (size_t)n * 8));
     return BK_OK;
 }
 
@@ -2218,7 +2238,7 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
     for (int i = 0; i < n; i++) {
         bk_ctx *c = ctxs[i];
         HIP_TRY(hipSetDevice(c->device));
-        if (!c->d_seq_global) HIP_TRY(hipMalloc(&c->d_seq_global, bytes ? bytes : 8));
+        if (!c->d_seq_global) HIP_TRY(dev_malloc(&c->d_seq_global, bytes ? bytes : 8));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < n; i++) {
@@ -2265,7 +2285,7 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(L->stream));
         if (c != L) HIP_TRY(hipMemcpy(c->d_seq_global, L->d_seq_global, bytes, hipMemcpyDeviceToDevice));
-        if (reset) HIP_TRY(hipMemset(c->d_seq_counts, 0, bytes));
+        if (reset) HIP_TRY(dev_zero_now(c->d_seq_counts, bytes));
     }
     if (out) {
         HIP_TRY(hipSetDevice(ctxs[0]->device));

@@ -168,7 +168,7 @@ struct bk_stream {
                     if (sl.d_exc) (void)hipFree(sl.d_exc);
                     sl.d_exc = nullptr;
                     sl.cap_exc = 0;
-                    e = hipMalloc(&sl.d_exc, (size_t)(j->n_exc + j->n_exc / 4 + 1024) * sizeof(bk_nbase));
+                    e = bk::dev_malloc(&sl.d_exc, (size_t)(j->n_exc + j->n_exc / 4 + 1024) * sizeof(bk_nbase));
                     if (e == hipSuccess) sl.cap_exc = j->n_exc + j->n_exc / 4 + 1024;
                 }
                 if (e == hipSuccess && j->n_exc) e = hipMemcpyAsync(sl.d_exc, j->exc, (size_t)j->n_exc * sizeof(bk_nbase), hipMemcpyHostToDevice, s_up);
@@ -419,11 +419,11 @@ static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads,
             // (either form of a batch: max_batch_bases bytes, or one word per 16 bases and at most one more per read)
             //  + the words the read preparation may load behind the last read of a packed batch, bk::kPackedPadWords)
             const uint64_t bytes = packed_only ? 4ULL * max_batch_words : std::max<uint64_t>(max_batch_bases, max_batch_bases / 4 + 4ULL * max_batch_reads);
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_bases, bytes + 64 + 4ULL * bk::kPackedPadWords);
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_offs, (size_t)max_batch_reads * 8);
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_lens, (size_t)max_batch_reads * 4);
-            if (e2 == hipSuccess) e2 = hipMalloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
+            if (e2 == hipSuccess) e2 = bk::dev_malloc(&sl.d_bases, bytes + 64 + 4ULL * bk::kPackedPadWords);
+            if (e2 == hipSuccess) e2 = bk::dev_malloc(&sl.d_lens16, (size_t)max_batch_reads * 2);
+            if (e2 == hipSuccess) e2 = bk::dev_malloc(&sl.d_offs, (size_t)max_batch_reads * 8);
+            if (e2 == hipSuccess) e2 = bk::dev_malloc(&sl.d_lens, (size_t)max_batch_reads * 4);
+            if (e2 == hipSuccess) e2 = bk::dev_malloc(&sl.d_out, (size_t)max_batch_reads * sizeof(bk_hit));
         }
         return e2;
     };
@@ -448,8 +448,8 @@ static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads,
         hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t *> in(nullptr, CastU64());
         e = hipcub::DeviceScan::ExclusiveSum(nullptr, s->scan_tmp_bytes, in, (unsigned long long *)nullptr, (size_t)max_batch_reads, s->s_al);
     }
-    if (e == hipSuccess) e = hipMalloc(&s->d_scan_tmp, s->scan_tmp_bytes ? s->scan_tmp_bytes : 16);
-    if (e == hipSuccess) e = hipMalloc(&s->d_ext, 16);
+    if (e == hipSuccess) e = bk::dev_malloc(&s->d_scan_tmp, s->scan_tmp_bytes ? s->scan_tmp_bytes : 16);
+    if (e == hipSuccess) e = bk::dev_malloc(&s->d_ext, 16);
     if (e == hipSuccess) e = hipHostMalloc(&s->h_ext, 16, hipHostMallocDefault);
     if (e != hipSuccess) {
         fprintf(stderr, "biokanga_amd: bk_stream_create: %s\n", hipGetErrorString(e));

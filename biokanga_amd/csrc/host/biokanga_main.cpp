@@ -1110,9 +1110,7 @@ int cmd_align(int argc, char **argv, int first)
     const char *early_env = getenv("BK_SAM_EARLY_MIN");                   // (tests lower the input size from which the file is started early)
     const bool pre_early = sam_plain && all_plain && plain_bytes >= (early_env ? strtoull(early_env, nullptr, 10) : (256ULL << 20));
     const uint64_t pre_early_est = (1u << 20) + plain_bytes + plain_bytes / (o.pe_mode ? 2 : 3);
-    const char *pre_when = getenv("BK_PREALLOC_WHEN");                    // experiment knob: "packed" = once the reads are packed
-    const int pre_threads = getenv("BK_PREALLOC_THREADS") ? atoi(getenv("BK_PREALLOC_THREADS")) : 2;
-    if (pre_early && !(pre_when && !strcmp(pre_when, "packed"))) pre.start(opath0.c_str(), pre_early_est, pre_threads);
+    if (pre_early) pre.start(opath0.c_str(), pre_early_est, 2);
     const bool long_run = a.has("window-array") || est_reads / ndev >= kWindowArrayMinReads;
     loaders.emplace_back([&]() {
         ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, long_run ? BK_CTX_WINDOW_ARRAY_EAGER : BK_CTX_LEAN_IMAGE);
@@ -1126,13 +1124,12 @@ int cmd_align(int argc, char **argv, int first)
     int rc;
     // (the index loader's threads - the HIP runtime coming up, four feeding the upload - the page-locking of the packed reads' buffers and
     // the output file's pages run meanwhile: the parser leaves them their share of the cores, or a CPU quota stalls all of them in turn)
-    const int parse_threads = getenv("BK_PARSE_THREADS") ? atoi(getenv("BK_PARSE_THREADS")) : std::max(std::min(o.nthreads, 4), o.nthreads - 6);
+    const int parse_threads = std::max(std::min(o.nthreads, 4), o.nthreads - 6);
     if (o.pe_mode) rc = load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
     else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
     // .. and, still behind the index load: the reads packed for the boundary, the result array page-locked
     AlignedSet A;
     if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
-    if (!rc && pre_early && pre.fd < 0) pre.start(opath0.c_str(), pre_early_est, pre_threads);
     { HostClock jc; for (auto &t : loaders) t.join(); jc.lap("waited for the index image"); }
     for (size_t d = 0; d < ndev; d++)
         if (ctx_rc[d]) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(ctx_rc[d])); destroy_ctxs(); return 1; }

@@ -548,10 +548,12 @@ int report_text(Report &R)
             const bool timing0 = getenv("BK_TIMING") != nullptr;
             timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
             out.flush();
-            struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; } st{out.fd, out.pos, std::max(1, nthreads / 2), R.pre};
+            struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; std::atomic<long> us_wait{0}, us_copy{0}, us_zap{0}; } st{out.fd, out.pos, std::max(1, nthreads / 2), R.pre};
             auto sink = [](void *user, const char *text, uint64_t n, uint64_t ofs) -> int {
                 SinkState *S = static_cast<SinkState *>(user);
                 const off_t at = S->base + (off_t)ofs;
+                auto us_now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long)ts.tv_sec * 1000000L + ts.tv_nsec / 1000; };
+                const long u0 = us_now();
                 // the slice's range of the file is allocated and mapped, and the threads copy into the mapping (concurrent pwrite()s to one
                 // file queue up behind the inode lock); pwrite() remains for files that cannot be mapped
                 char *map = nullptr;
@@ -573,6 +575,7 @@ int report_text(Report &R)
                     void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, S->fd, map_lo);
                     if (m != MAP_FAILED) map = (char *)m;
                 }
+                const long u1 = us_now();
                 const int nt = S->nthreads;
                 std::vector<std::thread> th;
                 std::atomic<int> bad{0};
@@ -588,6 +591,9 @@ int report_text(Report &R)
                 for (int t = 1; t < nt; t++) th.emplace_back(put, t);
                 put(0);
                 for (auto &t : th) t.join();
+                const long u2 = us_now();
+                S->us_wait += u1 - u0; S->us_copy += u2 - u1;
+                struct Zap { SinkState *S; long u; decltype(us_now) &now; ~Zap() { S->us_zap += now() - u; } } zap{S, u2, us_now};
                 if (map && !through_pre) munmap(map, map_len);
                 else if (through_pre) {
                     // the written range leaves the page table now, on this thread (the file keeps the pages): what is still mapped when the
@@ -615,6 +621,7 @@ int report_text(Report &R)
                 if (timing0) { timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb); fprintf(stderr, "bk timing: SAM file cut to its size: %.0f ms\n", 1e3 * ((double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec))); }
                 n_reported = n_rep;
                 device_done = true;
+                if (timing0) fprintf(stderr, "bk timing: SAM sink (summed over its calls, two may overlap): waited for the file's pages %ld ms, copied %ld ms, unmapped %ld ms\n", st.us_wait.load() / 1000, st.us_copy.load() / 1000, st.us_zap.load() / 1000);
                 if (timing0) { timespec t1s; clock_gettime(CLOCK_MONOTONIC, &t1s); fprintf(stderr, "bk timing: SAM formatted on the device and copied out: %.0f ms (%llu bytes)\n", 1e3 * ((double)(t1s.tv_sec - t0s.tv_sec) + 1e-9 * (double)(t1s.tv_nsec - t0s.tv_nsec)), (unsigned long long)n_bytes); }
             } else if (timing0)
                 fprintf(stderr, "bk timing: device SAM formatter declined (%s): host threads format\n", bk_strerror(drc));
