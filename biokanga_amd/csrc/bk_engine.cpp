@@ -30,7 +30,7 @@ namespace bk {
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s);
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s);
 void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s);
@@ -50,9 +50,9 @@ void launch_search(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
 void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act,
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
-void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s);
+void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s);
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
@@ -208,95 +208,118 @@ int pick_k(uint64_t n)
     return k < 8 ? 8 : k;
 }
 
-int build_ktab(bk_ctx *c)
+// The k-mer table, the second-level keys and the inverse suffix array are all made by one pass over suffix array indexes, so they can be
+// made range by range: behind the suffix array's upload (bk_ctx_create_ex sends it in slices and these kernels work on a slice while the
+// next crosses PCIe), or in one go.  tables_begin decides and allocates, tables_range enqueues, tables_end checks and publishes.
+struct TablePlan {
+    bool ktab = false, k2 = false, isa = false;
+    int k = 0;
+    unsigned long long *d_bad = nullptr;           // places where the second-level keys are not in order inside a bucket
+    ~TablePlan() { free_dev(d_bad); }
+};
+
+int tables_begin(bk_ctx *c, TablePlan &tp)
 {
-    free_dev(c->d_ktab);
-    c->d_ktab = nullptr;
-    c->ix.ktab32 = nullptr;
-    c->ix.ktab64 = nullptr;
-    c->ix.ktab2 = nullptr;
+    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_isa);
+    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
+    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
     c->ix.k = 0;
-    if (!c->use_ktab) return BK_OK;
-    int k = c->k_req > 0 ? c->k_req : pick_k(c->ix.n);
-    if (k > 16) k = 16;
-    if (k < 2) k = 2;
-    uint64_t ncodes = 1ULL << (2 * k);
-    c->ktab64 = c->ix.n >= (1ULL << 32);
-    size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
-    HIP_TRY(dev_malloc(&c->d_ktab, bytes));
-    c->ktab_bytes = bytes;
-    DevIndex ix = c->ix;
-    launch_build_ktab(ix, c->d_ktab, k, c->ktab64, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
-    else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
-    c->ix.k = k;
+    if (c->use_ktab) {
+        int k = c->k_req > 0 ? c->k_req : pick_k(c->ix.n);
+        if (k > 16) k = 16;
+        if (k < 2) k = 2;
+        const uint64_t ncodes = 1ULL << (2 * k);
+        c->ktab64 = c->ix.n >= (1ULL << 32);
+        const size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
+        HIP_TRY(dev_malloc(&c->d_ktab, bytes));
+        c->ktab_bytes = bytes;
+        tp.ktab = true;
+        tp.k = k;
+    }
+    // second-level key array; needs the k-mer table.  Skipped (search falls back to the one-pass kernel) when it would not leave a
+    // quarter of the HBM free, or - found in tables_end - if the suffix array is not ordered the way the bisection needs (never
+    // seen; checked because .sfx files come from outside).
+    if (c->use_k2 && tp.ktab) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t need = c->ix.n * 4;
+        if (need <= free_b && free_b - need >= total_b / 5) {
+            HIP_TRY(dev_malloc(&c->d_k2, need + 64));
+            HIP_TRY(dev_malloc(&tp.d_bad, 8));
+            HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 8, c->stream));
+            tp.k2 = true;
+        }
+    }
+    if (c->use_wave && c->use_isa && c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32)) {
+        HIP_TRY(dev_malloc(&c->d_isa, c->ix.n * 4));
+        tp.isa = true;
+    }
     return BK_OK;
 }
 
-// second-level key array; needs the k-mer table.  Skipped (search falls back to the one-pass kernel)
-// when it would not leave a quarter of the HBM free, or if the suffix array is not ordered the way
-// the bisection needs (never seen; checked because .sfx files come from outside).
-int build_k2(bk_ctx *c)
+// suffix array indexes [i0, i1) have arrived
+int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1)
 {
-    free_dev(c->d_k2);
-    c->d_k2 = nullptr;
-    c->ix.k2 = nullptr;
-    if (!c->use_k2 || c->ix.k <= 0) return BK_OK;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = c->ix.n * 4;
-    if (need > free_b || free_b - need < total_b / 5) return BK_OK;
-    HIP_TRY(dev_malloc(&c->d_k2, need + 64));
-    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
-    launch_build_k2(c->ix, c->d_k2, c->d_ctr + 7, c->stream);
+    DevIndex ix = c->ix;
+    ix.k = tp.k;
+    const bool last = i1 >= c->ix.n;
+    if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1);
+    if (tp.k2) launch_build_k2(ix, c->d_k2, tp.d_bad, c->stream, i0, i1);
+    if (tp.isa) launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream, i0, i1);
     HIP_TRY(hipGetLastError());
+    return BK_OK;
+}
+
+int tables_end(bk_ctx *c, TablePlan &tp)
+{
     unsigned long long bad = 0;
-    HIP_TRY(hipMemcpyAsync(&bad, c->d_ctr + 7, 8, hipMemcpyDeviceToHost, c->stream));
+    if (tp.k2) HIP_TRY(hipMemcpyAsync(&bad, tp.d_bad, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_ctr + 7, 0, 8, c->stream));
-    if (bad) {
+    if (tp.ktab) {
+        if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+        else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
+        c->ix.k = tp.k;
+    }
+    if (tp.k2 && bad) {
         fprintf(stderr, "biokanga_amd: suffix array not in nibble order inside %llu k-mer bucket(s); second-level keys disabled\n", bad);
         free_dev(c->d_k2);
         c->d_k2 = nullptr;
-        return BK_OK;
+    } else if (tp.k2) {
+        c->ix.k2 = c->d_k2;
+        // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
+        if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
+            const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            void *d2 = nullptr;
+            if (n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&d2, n_entries * 8) == hipSuccess) {
+                launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, c->ix.n, d2, c->stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                free_dev(c->d_ktab);
+                c->d_ktab = d2;
+                c->ktab_bytes = (size_t)n_entries * 8;
+                c->ktab_is2 = true;
+                c->ix.ktab32 = nullptr;
+                c->ix.ktab2 = reinterpret_cast<const uint2 *>(d2);
+            } else
+                (void)hipGetLastError();
+        }
     }
-    c->ix.k2 = c->d_k2;
-    // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
-    if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
-        const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        void *d2 = nullptr;
-        if (n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&d2, n_entries * 8) == hipSuccess) {
-            launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, c->ix.n, d2, c->stream);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            free_dev(c->d_ktab);
-            c->d_ktab = d2;
-            c->ktab_bytes = (size_t)n_entries * 8;
-            c->ktab_is2 = true;
-            c->ix.ktab32 = nullptr;
-            c->ix.ktab2 = reinterpret_cast<const uint2 *>(d2);
-        } else
-            (void)hipGetLastError();
-    }
+    if (tp.isa) c->ix.isa = c->d_isa;
+    c->tables_built = true;
     return BK_OK;
 }
 
-int build_isa(bk_ctx *c)
+// (re)builds all three over the whole array: contexts made from a device image, and the knobs that change a table's shape
+int build_tables(bk_ctx *c)
 {
-    free_dev(c->d_isa);
-    c->d_isa = nullptr;
-    c->ix.isa = nullptr;
-    if (!c->use_wave || !c->use_isa || c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32)) return BK_OK;
-    HIP_TRY(dev_malloc(&c->d_isa, c->ix.n * 4));
-    launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->ix.isa = c->d_isa;
-    return BK_OK;
+    TablePlan tp;
+    int rc = tables_begin(c, tp);
+    if (!rc) rc = tables_range(c, tp, 0, c->ix.n);
+    if (!rc) rc = tables_end(c, tp);
+    return rc;
 }
 
 // 2 bit/base target copy + N/EOS block bitmap for the window compare of the extend kernels
@@ -420,14 +443,11 @@ int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     int rc = setup_entries(c, entries, n_entries);
     if (rc) return rc;
     StageClock clk;
-    rc = build_ktab(c);
-    clk.lap("k-mer table");
-    if (!rc) rc = build_k2(c);
-    clk.lap("second-level keys");
-    if (rc) return rc;
-    rc = build_isa(c);
-    clk.lap("inverse suffix array");
-    if (rc) return rc;
+    if (!c->tables_built) {                // (bk_ctx_create_ex makes them behind the suffix array's upload)
+        rc = build_tables(c);
+        clk.lap("k-mer table, second-level keys, inverse suffix array");
+        if (rc) return rc;
+    }
     rc = build_tgt2(c);          // the hash scratch of the general kernels is sized when they first run
     clk.lap("2-bit target");
     return rc;
@@ -1371,15 +1391,36 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     // (read() into the staging buffers, not through the mapping: its pages would be faulted in one by one, and handed back one by one at exit)
     const int fd = ::open(sfx_path, O_RDONLY);
     if (fd < 0) { cleanup(); bk_ctx_destroy(c); return BK_ERR_OPNFILE; }
-    const bool sent = upload_file(d_seq, fd, (uint64_t)(f.seq - (const uint8_t *)f.map_base), f.concat_len, device_id) == BK_OK &&
-                      upload_file(sa_in_place ? (void *)c->d_sa_lo : (void *)d_sa, fd, (uint64_t)(f.sa - (const uint8_t *)f.map_base), f.concat_len * f.el_size, device_id) == BK_OK;
+    const uint64_t seq_ofs = (uint64_t)(f.seq - (const uint8_t *)f.map_base), sa_ofs = (uint64_t)(f.sa - (const uint8_t *)f.map_base);
+    bool sent = upload_file(d_seq, fd, seq_ofs, f.concat_len, device_id) == BK_OK;
+    clk.lap("upload bases");
+    if (sent && sa_in_place) {
+        // 4-byte elements: the bases are packed at once, and the suffix array follows in slices - the tables that are one pass over its
+        // indexes (k-mer table, second-level keys, inverse suffix array) are made of slice i while slice i + 1 crosses PCIe
+        rc = adopt_device_image(c, d_seq, f.concat_len, nullptr, 4);
+        free_dev(d_seq);
+        d_seq = nullptr;
+        TablePlan tp;
+        if (!rc) rc = tables_begin(c, tp);
+        const uint64_t n = f.concat_len;
+        const uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 26));       // (slices of at least 256 MB)
+        for (uint64_t k = 0; k < n_slices && !rc && sent; k++) {
+            const uint64_t i0 = n * k / n_slices, i1 = n * (k + 1) / n_slices;
+            sent = upload_file(c->d_sa_lo + i0, fd, sa_ofs + i0 * 4, (i1 - i0) * 4, device_id) == BK_OK;
+            if (sent) rc = tables_range(c, tp, i0, i1);
+        }
+        clk.lap("upload suffix array, tables enqueued behind its slices");
+        if (!rc && sent) rc = tables_end(c, tp);
+        clk.lap("tables finished");
+    } else if (sent) {
+        sent = upload_file(d_sa, fd, sa_ofs, f.concat_len * f.el_size, device_id) == BK_OK;
+        clk.lap("upload suffix array");
+        if (sent) rc = adopt_device_image(c, d_seq, f.concat_len, d_sa, (int)f.el_size);
+        clk.lap("pack target, adopt");
+    }
     ::close(fd);
-    if (!sent) { cleanup(); bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
-    clk.lap("upload bases + suffix array");
-    rc = adopt_device_image(c, d_seq, f.concat_len, sa_in_place ? nullptr : d_sa, (int)f.el_size);
-    clk.lap("pack target, adopt");
     cleanup();
-    clk.lap("free staging");
+    if (!sent) { bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
     if (rc) { bk_ctx_destroy(c); return rc; }
     std::vector<bk_entry_info> ents(f.entries.size());
     for (size_t i = 0; i < ents.size(); i++) {
@@ -1587,15 +1628,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = n == "use_ktab" ? c->use_ktab : c->ix.k;
         if (n == "use_ktab") c->use_ktab = value ? 1 : 0;
         else { if (value < 2 || value > 16) return BK_ERR_PARAMS; c->k_req = (int)value; }
-        int rc = build_ktab(c);
-        if (!rc) rc = build_k2(c);
+        int rc = build_tables(c);
         return rc ? rc : old;
     }
     if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
         int64_t old = c->use_ktab2;
         c->use_ktab2 = value ? 1 : 0;
-        int rc = build_ktab(c);
-        if (!rc) rc = build_k2(c);
+        int rc = build_tables(c);
         return rc ? rc : old;
     }
     if (n == "flat_block") {
@@ -1653,7 +1692,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     if (n == "use_isa") {
         int64_t old = c->use_isa;
         c->use_isa = value ? 1 : 0;
-        int rc = build_isa(c);
+        int rc = build_tables(c);
         return rc ? rc : old;
     }
     if (n == "use_flat") {
@@ -1664,7 +1703,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     if (n == "use_k2") {
         int64_t old = c->use_k2;
         c->use_k2 = value ? 1 : 0;
-        int rc = build_k2(c);
+        int rc = build_tables(c);
         return rc ? rc : old;
     }
     if (n == "use_iv32") {
@@ -1680,7 +1719,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     if (n == "use_wave") {
         int64_t old = c->use_wave;
         c->use_wave = value ? 1 : 0;
-        int rc = build_isa(c);
+        int rc = build_tables(c);
         return rc ? rc : old;
     }
     if (n == "max_read_len") {

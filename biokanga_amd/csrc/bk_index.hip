@@ -80,13 +80,14 @@ __device__ __forceinline__ uint64_t suffix_bucket(const uint64_t *__restrict__ t
 }
 
 template <bool WIDE, typename TabT>
-__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k)
+__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_t i0, uint64_t i1)
 {
+    // (suffix array indexes [i0, i1) of 0 .. n: a table can be made range by range, as the array arrives)
     uint64_t n = ix.n;
     uint64_t ncodes = 1ULL << (2 * k);
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i <= n; i += stride) {
+    for (; i < i1; i += stride) {
         // entries (prev, cur] receive i; prev = bucket(i-1) (or -1), cur = bucket(i) (or ncodes at i == n)
         uint64_t cur = i < n ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), k) : ncodes;
         uint64_t from = i > 0 ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i - 1), k) + 1 : 0;
@@ -95,17 +96,18 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k)
 }
 
 template <bool WIDE>
-__global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2)
+__global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2, uint64_t i0, uint64_t i1)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x)
+    for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (uint64_t)gridDim.x * blockDim.x)
         k2[i] = k2_make(ix.tgt4, sa_get<WIDE>(ix, i), ix.k);
 }
 
 // the bisection needs k2 non-decreasing inside every k-mer bucket; count the places where it is not
 template <bool WIDE>
-__global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigned long long *__restrict__ bad)
+__global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigned long long *__restrict__ bad, uint64_t i0, uint64_t i1)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    // (the pairs (i, i + 1) with i in [i0, i1))
+    for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1 && i + 1 < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (k2[i] <= k2[i + 1]) continue;
         if (suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), ix.k) == suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i + 1), ix.k))
             atomicAdd(bad, 1ULL);
@@ -145,11 +147,11 @@ void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s)
     hipLaunchKernelGGL(k_build_swin, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
 }
 
-__global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t n, uint32_t *__restrict__ isa)
+__global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t i0, uint64_t i1, uint32_t *__restrict__ isa)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) isa[sa[i]] = (uint32_t)i;
+    for (; i < i1; i += stride) isa[sa[i]] = (uint32_t)i;
 }
 
 __global__ void k_fill_u64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v)
@@ -176,17 +178,20 @@ void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi,
     hipLaunchKernelGGL(k_split_sa5, dim3((unsigned)blocks), dim3(256), 0, s, sa5, n, lo, hi);
 }
 
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s)
+// (every table builder takes a range [i0, i1) of suffix array indexes; i1 = 0 stands for the whole array)
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0, uint64_t i1)
 {
-    uint64_t blocks = (ix.n + 1 + 255) / 256;
+    if (i1 == 0) i1 = ix.n + 1;                      // (the entry past the last bucket comes with index n)
+    if (i1 <= i0) return;
+    uint64_t blocks = (i1 - i0 + 255) / 256;
     if (blocks > 262144) blocks = 262144;
     bool wide = ix.sa_hi != nullptr;
     if (wide) {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k);
-        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1);
+        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1);
     } else {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k);
-        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1);
+        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1);
     }
 }
 
@@ -221,26 +226,32 @@ void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entri
     hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out));
 }
 
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s)
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1)
 {
-    uint64_t blocks = (ix.n + 255) / 256;
+    if (i1 == 0) i1 = ix.n;
+    if (i1 <= i0) return;
+    uint64_t blocks = (i1 - i0 + 255) / 256;
     if (blocks > 262144) blocks = 262144;
     DevIndex t = ix;
     t.k2 = k2;
+    // the order check looks at pairs (i, i + 1): a range checks the pair that straddles its start, and leaves the one at its end to the next
+    const uint64_t c0 = i0 ? i0 - 1 : 0, c1 = i1 == ix.n ? i1 : i1 - 1;
     if (ix.sa_hi) {
-        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2);
-        hipLaunchKernelGGL(k_check_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad);
+        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, i0, i1);
+        hipLaunchKernelGGL(k_check_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     } else {
-        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2);
-        hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad);
+        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, i0, i1);
+        hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     }
 }
 
-void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s)
+void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0, uint64_t i1)
 {
-    uint64_t blocks = (n + 255) / 256;
+    if (i1 == 0) i1 = n;
+    if (i1 <= i0) return;
+    uint64_t blocks = (i1 - i0 + 255) / 256;
     if (blocks > 262144) blocks = 262144;
-    hipLaunchKernelGGL(k_build_isa, dim3((unsigned)blocks), dim3(256), 0, s, sa, n, isa);
+    hipLaunchKernelGGL(k_build_isa, dim3((unsigned)blocks), dim3(256), 0, s, sa, i0, i1, isa);
 }
 
 }  // namespace bk

@@ -27,6 +27,7 @@ struct SamDev {
     const char *ent_names;           // n_ent x 81 bytes
     uint32_t n_ent;
     int fmt6, pe_mode;
+    const uint32_t *any_qual;        // one word: non-zero when some base of the read store carries a score (else every QUAL is '*' and nobody looks)
 };
 
 __device__ __forceinline__ int n_digits(unsigned long v)
@@ -92,20 +93,60 @@ __device__ __forceinline__ SamRec sam_rec(const SamDev &d, uint64_t k)
         } else
             r.flag |= 0x8;
     }
-    // QUAL is '*' unless a base of the read carries a score (bits 4..7 of its byte)
-    const uint8_t *s = d.bases + d.offs[r.i];
-    uint32_t sum = 0;
-    for (uint32_t q = 0; q < r.len; q++) sum |= s[q] & 0xf0u;
-    r.has_qual = sum != 0;
     return r;
+}
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
+}
+
+// QUAL is '*' unless a base of the read carries a score (bits 4..7 of its byte).  The wave looks at its 64 records together: the lanes
+// read a record's bases side by side (one or two cache lines per step) instead of each lane walking its own read byte by byte.
+// Called by all lanes of a wave; len = 0 for a lane without a record.
+__device__ __forceinline__ bool wave_has_qual(const SamDev &d, uint64_t off, uint32_t len)
+{
+    if (*d.any_qual == 0) return false;
+    const int lane = (int)(threadIdx.x & 63);
+    bool mine = false;
+    for (int rr = 0; rr < 64; rr++) {
+        const uint32_t l = (uint32_t)__shfl((int)len, rr);
+        if (!l) continue;
+        const uint8_t *s = d.bases + shfl64(off, rr);
+        uint32_t acc = 0;
+        for (uint32_t q = (uint32_t)lane; q < l; q += 64) acc |= s[q] & 0xf0u;
+        const bool any = __ballot(acc != 0) != 0;
+        if (lane == rr) mine = any;
+    }
+    return mine;
+}
+
+// non-zero when any base of the store carries a score
+__global__ void __launch_bounds__(256) k_sam_any_qual(const uint8_t *__restrict__ bases, uint64_t n, uint32_t *__restrict__ flag)
+{
+    uint32_t acc = 0;
+    const uint64_t n16 = n / 16;
+    const uint4 *b16 = reinterpret_cast<const uint4 *>(bases);
+    if ((reinterpret_cast<uintptr_t>(bases) & 15) == 0)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+            const uint4 v = b16[i];
+            acc |= (v.x | v.y | v.z | v.w) & 0xf0f0f0f0u;
+        }
+    else
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16 * 16; i += (uint64_t)gridDim.x * blockDim.x) acc |= bases[i] & 0xf0u;
+    for (uint64_t i = n16 * 16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc |= bases[i] & 0xf0u;
+    if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 __global__ void __launch_bounds__(256) k_sam_measure(SamDev d, uint64_t k0, uint32_t n, unsigned long long *__restrict__ bytes, uint32_t *__restrict__ n_rep)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t rep = 0;
+    SamRec r;
+    r.reported = false; r.len = 0; r.i = 0;
+    if (j < n) r = sam_rec(d, k0 + j);
+    r.has_qual = wave_has_qual(d, r.reported ? d.offs[r.i] : 0, r.reported ? r.len : 0);
     if (j < n) {
-        const SamRec r = sam_rec(d, k0 + j);
         unsigned long long b = 0;
         if (r.reported) {
             rep = 1;
@@ -129,62 +170,83 @@ __global__ void __launch_bounds__(256) k_sam_measure(SamDev d, uint64_t k0, uint
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_rep, (uint32_t)__popcll(m));
 }
 
+// One bulk piece of a line - name, sequence, scores - copied by the whole wave: lane q moves byte q, q + 64, .. of the piece of record rr,
+// for rr = 0 .. 63 in turn (coalesced loads and stores; the lanes' own small fields went out before).  mode 0: bytes as they are;
+// 1: base letters; 2: complement letters, read backwards; 3: scores; 4: scores, read backwards.
+__device__ __forceinline__ void wave_copy(const uint8_t *src, char *dst, uint32_t len, int mode)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint64_t fwd = 0x4E4E4E4E54474341ULL, comp = 0x4E4E4E4E41434754ULL;      // "ACGTNNNN", "TGCANNNN": letter of code c = byte c
+    for (int rr = 0; rr < 64; rr++) {
+        const uint32_t l = (uint32_t)__shfl((int)len, rr);
+        if (!l) continue;
+        const uint8_t *s = reinterpret_cast<const uint8_t *>(shfl64(reinterpret_cast<uint64_t>(src), rr));
+        char *w = reinterpret_cast<char *>(shfl64(reinterpret_cast<uint64_t>(dst), rr));
+        const int m = __shfl(mode, rr);
+        for (uint32_t q = (uint32_t)lane; q < l; q += 64) {
+            const uint8_t c = (m == 2 || m == 4) ? s[l - 1 - q] : s[q];
+            w[q] = m == 0 ? (char)c : (m <= 2 ? (char)(((m == 1 ? fwd : comp) >> (8 * (c & 7))) & 0xff) : (char)(33 + (((c >> 4) & 15) * 40) / 15));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint64_t k0, uint32_t n, const unsigned long long *__restrict__ at, char *__restrict__ out)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const SamRec r = sam_rec(d, k0 + j);
-    if (!r.reported) return;
-    const bk_hit h = d.hits[r.i];
-    const uint8_t *s = d.bases + d.offs[r.i];
-    char *w = out + at[j];
-    const char *nm = d.names + d.name_ofs[r.i];
-    for (uint32_t q = 0; q < r.nml; q++) *w++ = nm[q];
-    *w++ = '\t';
-    w = put_num(w, r.flag);
-    const char fwd[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'}, comp[8] = {'T', 'G', 'C', 'A', 'N', 'N', 'N', 'N'};
-    if (r.acc) {
+    SamRec r;
+    r.reported = false; r.len = 0; r.i = 0; r.nml = 0; r.acc = false;
+    if (j < n) r = sam_rec(d, k0 + j);
+    const uint8_t *s = r.reported ? d.bases + d.offs[r.i] : nullptr;
+    r.has_qual = wave_has_qual(d, r.reported ? d.offs[r.i] : 0, r.reported ? r.len : 0);
+    // the lane writes its record's small fields and notes where the three bulk pieces go
+    char *w_name = nullptr, *w_seq = nullptr, *w_qual = nullptr;
+    int seq_mode = 1, qual_mode = 3;
+    if (r.reported) {
+        const bk_hit h = d.hits[r.i];
+        char *w = out + at[j];
+        w_name = w;
+        w += r.nml;
         *w++ = '\t';
-        w = put_str(w, d.ent_names + (size_t)(h.chrom_id - 1) * 81);
-        *w++ = '\t';
-        w = put_num(w, (long)h.match_loci + 1);
-        *w++ = '\t'; *w++ = '2'; *w++ = '5'; *w++ = '5'; *w++ = '\t';
-        w = put_num(w, h.match_len);
-        *w++ = 'M';
-        *w++ = '\t';
-        *w++ = r.pnext < 0 ? '*' : '=';
-        *w++ = '\t';
-        w = put_num(w, r.pnext < 0 ? 0L : r.pnext + 1);
-        *w++ = '\t';
-        w = put_num(w, r.tlen);
-        *w++ = '\t';
-        if (h.strand == '+') for (uint32_t q = 0; q < r.len; q++) w[q] = fwd[s[q] & 7];
-        else for (uint32_t q = 0; q < r.len; q++) w[q] = comp[s[r.len - 1 - q] & 7];
-        w += r.len;
-        *w++ = '\t';
-        if (!r.has_qual) *w++ = '*';
-        else {
-            const bool rev = h.strand != '+';
-            for (uint32_t q = 0; q < r.len; q++) w[q] = (char)(33 + ((((rev ? s[r.len - 1 - q] : s[q]) >> 4) & 15) * 40) / 15);
+        w = put_num(w, r.flag);
+        if (r.acc) {
+            *w++ = '\t';
+            w = put_str(w, d.ent_names + (size_t)(h.chrom_id - 1) * 81);
+            *w++ = '\t';
+            w = put_num(w, (long)h.match_loci + 1);
+            *w++ = '\t'; *w++ = '2'; *w++ = '5'; *w++ = '5'; *w++ = '\t';
+            w = put_num(w, h.match_len);
+            *w++ = 'M';
+            *w++ = '\t';
+            *w++ = r.pnext < 0 ? '*' : '=';
+            *w++ = '\t';
+            w = put_num(w, r.pnext < 0 ? 0L : r.pnext + 1);
+            *w++ = '\t';
+            w = put_num(w, r.tlen);
+            *w++ = '\t';
+            w_seq = w;
+            seq_mode = h.strand == '+' ? 1 : 2;
             w += r.len;
-        }
-        *w++ = '\n';
-    } else {
-        w = put_str(w, "\t*\t0\t255\t");
-        w = put_num(w, r.len);
-        w = put_str(w, "M\t*\t0\t0\t");
-        for (uint32_t q = 0; q < r.len; q++) w[q] = fwd[s[q] & 7];
-        w += r.len;
-        *w++ = '\t';
-        if (!r.has_qual) *w++ = '*';
-        else {
-            for (uint32_t q = 0; q < r.len; q++) w[q] = (char)(33 + (((s[q] >> 4) & 15) * 40) / 15);
+            *w++ = '\t';
+            if (!r.has_qual) *w++ = '*';
+            else { w_qual = w; qual_mode = h.strand == '+' ? 3 : 4; w += r.len; }
+            *w++ = '\n';
+        } else {
+            w = put_str(w, "\t*\t0\t255\t");
+            w = put_num(w, r.len);
+            w = put_str(w, "M\t*\t0\t0\t");
+            w_seq = w;
             w += r.len;
+            *w++ = '\t';
+            if (!r.has_qual) *w++ = '*';
+            else { w_qual = w; w += r.len; }
+            w = put_str(w, "\t\tYU:Z:");                           // the doubled TAB is what the reference writes
+            w = put_str(w, kSamNarTag[h.nar < 20 ? h.nar : 0]);
+            *w++ = '\n';
         }
-        w = put_str(w, "\t\tYU:Z:");                           // the doubled TAB is what the reference writes
-        w = put_str(w, kSamNarTag[h.nar < 20 ? h.nar : 0]);
-        *w++ = '\n';
     }
+    wave_copy(r.reported ? reinterpret_cast<const uint8_t *>(d.names + d.name_ofs[r.i]) : nullptr, w_name, r.reported ? r.nml : 0, 0);
+    wave_copy(s, w_seq, r.reported ? r.len : 0, seq_mode);
+    wave_copy(s, w_qual, w_qual ? r.len : 0, qual_mode);
 }
 
 struct DevBuf {
@@ -308,6 +370,13 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     d.bases = d_bases.as<uint8_t>(); d.offs = d_offs.as<uint64_t>(); d.lens = d_lens.as<uint32_t>(); d.names = d_names.as<char>();
     d.name_ofs = d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
     d.n_ent = n_ent; d.fmt6 = job->report_unaligned ? 1 : 0; d.pe_mode = job->pe_mode;
+    // does any base carry a score at all?  (one streaming pass; without scores - FASTA input, or -g3 - no record is scanned for them)
+    DevBuf d_anyq;
+    SAM_TRY(d_anyq.alloc(16));
+    SAM_TRY(hipMemsetAsync(d_anyq.p, 0, 16, s));
+    hipLaunchKernelGGL(k_sam_any_qual, dim3(4096), dim3(256), 0, s, d.bases, job->n_bases, d_anyq.as<uint32_t>());
+    SAM_TRY(hipGetLastError());
+    d.any_qual = d_anyq.as<uint32_t>();
     // Everything the device indexes with is checked here first (the command line passes consistent arrays; another caller of the ABI
     // must get BK_ERR_PARAMS, not an out-of-bounds device access): chrom ids name entries 1..n, order[] names reads, every read lies
     // inside the bases, names are '\0'-terminated stretches in ascending order inside the name bytes.  A few host threads, slices each.

@@ -884,7 +884,8 @@ int align_reads(const std::vector<bk_ctx *> &ctxs, std::vector<bk_stream *> &st,
                  tot.seconds_first_submit_to_last_result);
     }
     close();
-    S.release_results();
+    // (the result array stays page-locked while nothing replaces it: the SAM formatter's upload of the records then is one DMA)
+    if (o.ml_mode) S.release_results();
     // the path's one exchange step: per-sequence accepted-read counts summed over the devices
     A.seq_counts.assign(bk_num_entries(ctxs[0]), 0);
     int rc = bk_seq_counts_allreduce((bk_ctx *const *)ctxs.data(), (int)ndev, A.seq_counts.data(), (uint32_t)A.seq_counts.size(), 1);
@@ -1129,6 +1130,7 @@ int cmd_align(int argc, char **argv, int first)
     else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
     // .. and, still behind the index load: the reads packed for the boundary, the result array page-locked
     AlignedSet A;
+    struct Unlock { Submission &S; ~Unlock() { S.release_results(); } } unlock_results{S};        // (before A's records are freed: declared after A)
     if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
     { HostClock jc; for (auto &t : loaders) t.join(); jc.lap("waited for the index image"); }
     for (size_t d = 0; d < ndev; d++)

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <sys/mman.h>
@@ -183,9 +184,36 @@ struct SamPrealloc {
         });
     }
     void finish() { quit.store(true); for (auto &t : th) if (t.joinable()) t.join(); }
+    // Written ranges leave the page table behind the writers (the file keeps the pages): 60 ms per GB of page-table and reverse-map work
+    // that would otherwise be the process's last act.  A thread of its own does it, nobody waits for it; a large run ends the process
+    // under it (what it has not reached goes with the address space), a small one joins it here.
+    std::mutex um;
+    std::condition_variable ucv;
+    std::vector<std::pair<char *, size_t>> uq;
+    bool ustop = false;
+    std::thread uth;
+    void unmap_behind(char *p, size_t n)
+    {
+        {
+            std::lock_guard<std::mutex> lk(um);
+            uq.emplace_back(p, n);
+            if (!uth.joinable())
+                uth = std::thread([this]() {
+                    for (;;) {
+                        std::pair<char *, size_t> r;
+                        { std::unique_lock<std::mutex> lk2(um); ucv.wait(lk2, [&] { return ustop || !uq.empty(); }); if (uq.empty()) return; r = uq.back(); uq.pop_back(); }
+                        (void)madvise(r.first, r.second, MADV_DONTNEED);
+                    }
+                });
+        }
+        ucv.notify_one();
+    }
     ~SamPrealloc()
     {
         finish();
+        { std::lock_guard<std::mutex> lk(um); ustop = true; }
+        ucv.notify_all();
+        if (uth.joinable()) uth.join();
         if (map) munmap(map, (size_t)est);
         if (fd >= 0) { if (!kept && ftruncate(fd, 0) != 0) {} ::close(fd); }
     }

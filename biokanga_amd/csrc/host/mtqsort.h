@@ -32,6 +32,126 @@ void selection_finish(T *left, T *right, Cmp cmp)
     }
 }
 
+// The partition loop of the scheme from a given state (pl, ph, mid: the pivot element, which moves when it is swapped), to its end:
+// afterwards [lo, ph] and [pl, hi] are the two sides still to sort.  The serial sort enters it with pl = lo, ph = hi; the parallel
+// partition below enters it after its threads have done most of the swaps.
+template <typename T, typename Cmp>
+inline void hoare_run(T *lo, T *hi, T *&pl, T *&ph, T *mid, Cmp cmp)
+{
+    for (;;) {
+        if (mid > pl)
+            do { ++pl; } while (pl < mid && cmp(*pl, *mid) <= 0);
+        if (mid <= pl)
+            do { ++pl; } while (pl <= hi && cmp(*pl, *mid) <= 0);
+        do { --ph; } while (ph > mid && cmp(*ph, *mid) > 0);
+        if (ph < pl) break;
+        std::swap(*pl, *ph);
+        if (mid == ph) mid = pl;
+    }
+    ++ph;
+    if (mid < ph)
+        do { --ph; } while (ph > mid && cmp(*ph, *mid) == 0);
+    if (mid >= ph)
+        do { --ph; } while (ph > lo && cmp(*ph, *mid) == 0);
+}
+
+// One partition step of a LARGE span by all threads, with exactly the serial outcome.  In the serial loop pl stops at the elements
+// greater than the pivot, in ascending position (L_1 < L_2 < ..), ph at those not greater, in descending position (R_1 > R_2 > ..;
+// the pivot's own position among them), and the k-th stops swap while L_k < R_k: which elements pair up depends only on the array as
+// it stands after the median-of-three step.  So: blocks count their L's and R's, prefix sums give every k its two blocks, all k whose
+// blocks lie apart (L's left of R's: certainly L_k < R_k) are swapped by the threads, each over its own range of k - its L's and R's
+// lie in two position ranges no other thread touches - and the serial loop finishes from there (pl = L_k0, ph = R_k0): a few blocks.
+template <typename T, typename Cmp>
+void par_partition(T *lo, T *hi, Cmp cmp, int nthreads, T *&out_pl, T *&out_ph)
+{
+    const size_t cnt = (size_t)(hi - lo) + 1;
+    T *mid = lo + cnt / 2;
+    if (cmp(*lo, *mid) > 0) std::swap(*lo, *mid);
+    if (cmp(*lo, *hi) > 0) std::swap(*lo, *hi);
+    if (cmp(*mid, *hi) > 0) std::swap(*mid, *hi);
+    const T pivot = *mid;                              // (a copy: the element itself may move under the threads)
+    const size_t nb = (size_t)nthreads * 8;
+    const size_t bs = (cnt + nb - 1) / nb;
+    // L candidates live in [lo + 1, hi], R candidates in [lo, hi - 1]
+    std::vector<uint64_t> cl(nb + 1, 0), cr(nb + 1, 0);          // cl[b + 1]: L's in block b; then prefix sums
+    auto run_threads = [&](auto fn) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    run_threads([&](int t) {
+        for (size_t b = (size_t)t; b < nb; b += (size_t)nthreads) {
+            const size_t i0 = b * bs, i1 = std::min(cnt, i0 + bs);
+            uint64_t nl = 0, nr = 0;
+            for (size_t i = i0; i < i1; i++) {
+                const bool gt = cmp(lo[i], pivot) > 0;
+                nl += (gt && i >= 1) ? 1 : 0;
+                nr += (!gt && i + 1 < cnt) ? 1 : 0;
+            }
+            cl[b + 1] = nl; cr[b + 1] = nr;
+        }
+    });
+    // CL[b] = L's in blocks < b (ascending rank base); CRr[b] = R's in blocks > b (descending rank base)
+    std::vector<uint64_t> CL(nb + 1, 0), CRr(nb + 1, 0);
+    for (size_t b = 0; b < nb; b++) CL[b + 1] = CL[b] + cl[b + 1];
+    for (size_t b = nb; b-- > 0;) CRr[b] = (b + 1 < nb ? CRr[b + 1] : 0) + (b + 1 < nb ? cr[b + 2] : 0);
+    const uint64_t totL = CL[nb], totR = CRr[0] + cr[1];
+    // block of the k-th L (1-based): the b with CL[b] < k <= CL[b + 1]; block of the k-th R: the b with CRr[b] < k <= CRr[b] + cr[b + 1]
+    auto block_of_L = [&](uint64_t k) { size_t a = 0, z = nb; while (z - a > 1) { const size_t m = (a + z) / 2; if (CL[m] < k) a = m; else z = m; } return a; };
+    auto block_of_R = [&](uint64_t k) { size_t a = 0, z = nb; while (z - a > 1) { const size_t m = (a + z) / 2; if (CRr[m] + cr[m + 1] >= k) a = m; else z = m; } return a; };
+    uint64_t k0 = 0;
+    {
+        uint64_t a = 0, z = std::min(totL, totR) + 1;          // invariant: k = a qualifies (or is 0), k = z does not
+        while (z - a > 1) {
+            const uint64_t m = (a + z) / 2;
+            if (block_of_L(m) < block_of_R(m)) a = m; else z = m;
+        }
+        k0 = a;
+    }
+    T *pl = lo, *ph = hi;
+    if (k0) {
+        // thread t swaps the pairs k in (k0 * t / nt, k0 * (t + 1) / nt].  First every thread finds where its range starts (nothing has
+        // moved yet: the ranks inside a block are those of the counting pass), then all swap.
+        std::vector<T *> moved((size_t)nthreads, nullptr), last_l((size_t)nthreads, nullptr), last_r((size_t)nthreads, nullptr);
+        std::vector<T *> first_l((size_t)nthreads, nullptr), first_r((size_t)nthreads, nullptr);
+        T *const pivot_at = mid;
+        run_threads([&](int t) {
+            const uint64_t ka = k0 * (uint64_t)t / (uint64_t)nthreads, kb = k0 * (uint64_t)(t + 1) / (uint64_t)nthreads;
+            if (kb <= ka) return;
+            // position of L_{ka + 1}: inside its block, the (ka + 1 - CL[b])-th L from the block's start
+            size_t b = block_of_L(ka + 1);
+            uint64_t skip = ka + 1 - CL[b];
+            T *l = lo + b * bs;
+            for (;; ++l) { if (l > lo && cmp(*l, pivot) > 0 && --skip == 0) break; }
+            // position of R_{ka + 1}: inside its block, the (ka + 1 - CRr[b])-th R from the block's end
+            b = block_of_R(ka + 1);
+            skip = ka + 1 - CRr[b];
+            T *r = lo + std::min(cnt, b * bs + bs) - 1;
+            for (;; --r) { if (r < hi && cmp(*r, pivot) <= 0 && --skip == 0) break; }
+            first_l[(size_t)t] = l; first_r[(size_t)t] = r;
+        });
+        run_threads([&](int t) {
+            const uint64_t ka = k0 * (uint64_t)t / (uint64_t)nthreads, kb = k0 * (uint64_t)(t + 1) / (uint64_t)nthreads;
+            if (kb <= ka) return;
+            T *l = first_l[(size_t)t], *r = first_r[(size_t)t], *mv = nullptr;
+            for (uint64_t k = ka + 1;; k++) {
+                if (r == pivot_at) mv = l;                     // the pivot element goes to l
+                std::swap(*l, *r);
+                if (k == kb) break;
+                do { ++l; } while (!(cmp(*l, pivot) > 0));
+                do { --r; } while (!(cmp(*r, pivot) <= 0));
+            }
+            moved[(size_t)t] = mv; last_l[(size_t)t] = l; last_r[(size_t)t] = r;      // (once: neighbours in these arrays are other threads')
+        });
+        for (int t = nthreads - 1; t >= 0; t--) if (last_l[(size_t)t]) { pl = last_l[(size_t)t]; ph = last_r[(size_t)t]; break; }
+        for (int t = 0; t < nthreads; t++) if (moved[(size_t)t]) mid = moved[(size_t)t];
+    }
+    hoare_run(lo, hi, pl, ph, mid, cmp);
+    out_pl = pl;
+    out_ph = ph;
+}
+
 // One span and everything below it; sub-spans of more than `share_above` elements are handed to
 // `share` (another thread's work) instead of the local stack.  Partitions never overlap, so the
 // result does not depend on who sorts which span or in what order.
@@ -56,21 +176,7 @@ void ref_order_span(T *lo, T *hi, Cmp cmp, size_t share_above, Share share)
             if (cmp(*lo, *hi) > 0) std::swap(*lo, *hi);
             if (cmp(*mid, *hi) > 0) std::swap(*mid, *hi);
             T *pl = lo, *ph = hi;
-            for (;;) {
-                if (mid > pl)
-                    do { ++pl; } while (pl < mid && cmp(*pl, *mid) <= 0);
-                if (mid <= pl)
-                    do { ++pl; } while (pl <= hi && cmp(*pl, *mid) <= 0);
-                do { --ph; } while (ph > mid && cmp(*ph, *mid) > 0);
-                if (ph < pl) break;
-                std::swap(*pl, *ph);
-                if (mid == ph) mid = pl;
-            }
-            ++ph;
-            if (mid < ph)
-                do { --ph; } while (ph > mid && cmp(*ph, *mid) == 0);
-            if (mid >= ph)
-                do { --ph; } while (ph > lo && cmp(*ph, *mid) == 0);
+            hoare_run(lo, hi, pl, ph, mid, cmp);
             // larger side is deferred, smaller side is continued with
             if (ph - lo >= hi - pl) {
                 if (lo < ph) defer(lo, ph);
@@ -107,6 +213,20 @@ void ref_order_sort(T *a, int64_t n, Cmp cmp, int nthreads = 1)
     std::vector<Span> queue;
     int active = 0;
     queue.push_back({a, a + (n - 1)});
+    // the first levels, where there are fewer spans than threads: the largest span is partitioned by all threads together
+    const size_t par_min = (size_t)1 << 20;
+    while (queue.size() < (size_t)nthreads * 2) {
+        size_t big = 0;
+        for (size_t i = 1; i < queue.size(); i++) if (queue[i].r - queue[i].l > queue[big].r - queue[big].l) big = i;
+        const Span sp = queue[big];
+        if ((size_t)(sp.r - sp.l) + 1 < par_min) break;
+        queue.erase(queue.begin() + (ptrdiff_t)big);
+        T *pl = nullptr, *ph = nullptr;
+        par_partition(sp.l, sp.r, cmp, nthreads, pl, ph);
+        if (sp.l < ph) queue.push_back({sp.l, ph});
+        if (pl < sp.r) queue.push_back({pl, sp.r});
+        if (queue.empty()) return;
+    }
     auto share = [&](T *l, T *r) {
         { std::lock_guard<std::mutex> g(mu); queue.push_back({l, r}); }
         cv.notify_one();

@@ -6,6 +6,8 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <mutex>
+#include <condition_variable>
 #include <atomic>
 #include <thread>
 
@@ -548,7 +550,8 @@ int report_text(Report &R)
             const bool timing0 = getenv("BK_TIMING") != nullptr;
             timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
             out.flush();
-            struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; std::atomic<long> us_wait{0}, us_copy{0}, us_zap{0}; } st{out.fd, out.pos, std::max(1, nthreads / 2), R.pre};
+            struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; std::atomic<long> us_wait{0}, us_copy{0}, us_zap{0}; };
+            SinkState st{out.fd, out.pos, std::max(1, nthreads / 2), R.pre};
             auto sink = [](void *user, const char *text, uint64_t n, uint64_t ofs) -> int {
                 SinkState *S = static_cast<SinkState *>(user);
                 const off_t at = S->base + (off_t)ofs;
@@ -596,10 +599,9 @@ int report_text(Report &R)
                 struct Zap { SinkState *S; long u; decltype(us_now) &now; ~Zap() { S->us_zap += now() - u; } } zap{S, u2, us_now};
                 if (map && !through_pre) munmap(map, map_len);
                 else if (through_pre) {
-                    // the written range leaves the page table now, on this thread (the file keeps the pages): what is still mapped when the
-                    // process ends is unmapped then, at 40 ms per GB
+                    // (the written range leaves the page table behind us: the unmapper thread's work)
                     const off_t lo_al = (at + 4095) & ~(off_t)4095, hi_al = (at + (off_t)n) & ~(off_t)4095;
-                    if (hi_al > lo_al) (void)madvise(S->pre->map + lo_al, (size_t)(hi_al - lo_al), MADV_DONTNEED);
+                    if (hi_al > lo_al) S->pre->unmap_behind(S->pre->map + lo_al, (size_t)(hi_al - lo_al));
                 }
                 return bad.load();
             };

@@ -59,7 +59,7 @@ def test_sort_threads_do_not_change_the_order(harness, tmp_path):
     the order of tied records must be the single-threaded one"""
     import biokanga_amd.binding as b
     rng = np.random.default_rng(11)
-    n = 700_000
+    n = 2_500_000                                            # (spans of 1 M elements and more are partitioned by all threads together)
     hits = np.zeros(n, dtype=b.HIT_DTYPE)
     hits["nar"] = rng.choice([1, 1, 1, 4, 6], n)
     hits["num_hits"] = (hits["nar"] == 1).astype(np.uint8)
@@ -71,11 +71,11 @@ def test_sort_threads_do_not_change_the_order(harness, tmp_path):
     hp = str(tmp_path / "hits.bin")
     hits.tofile(hp)
     orders = []
-    for t in (1, 8):
+    for t in (1, 8, 3):
         op = str(tmp_path / f"order{t}.bin")
         subprocess.check_call([harness, hp, op, str(t)])
         orders.append(np.fromfile(op, dtype=np.uint32))
-    assert np.array_equal(orders[0], orders[1])
+    assert np.array_equal(orders[0], orders[1]) and np.array_equal(orders[0], orders[2])
     srt = hits[orders[0]]
     assert np.all(np.diff(srt["nar"].astype(int)) >= 0)
 
