@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
     "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device", "bk_sam_prepare", "bk_sam_prep_free",
-    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex", "bk_ctx_set_chrom_filter",
+    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex", "bk_ctx_set_chrom_filter", "bk_sam_prep_wait",
 ]
 
 

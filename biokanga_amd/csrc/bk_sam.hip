@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -28,7 +29,15 @@ struct SamDev {
     uint32_t n_ent;
     int fmt6, pe_mode;
     const uint32_t *any_qual;        // one word: non-zero when some base of the read store carries a score (else every QUAL is '*' and nobody looks)
+    // packed reads (bases == nullptr): 16 bases per word, first base in the top bits; word offset of every read; the exceptions (non-acgt
+    // runs) sorted by (read, pos) and, per read, the index of its first one (kNoExc = none)
+    const uint32_t *pk_words;
+    const uint64_t *pk_wofs;
+    const bk_nbase *pk_exc;
+    const uint32_t *pk_efirst;
+    uint64_t n_pk_exc;
 };
+constexpr uint32_t kNoExc = 0xFFFFFFFFu;
 
 __device__ __forceinline__ int n_digits(unsigned long v)
 {
@@ -106,7 +115,7 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 // Called by all lanes of a wave; len = 0 for a lane without a record.
 __device__ __forceinline__ bool wave_has_qual(const SamDev &d, uint64_t off, uint32_t len)
 {
-    if (*d.any_qual == 0) return false;
+    if (d.bases == nullptr || *d.any_qual == 0) return false;
     const int lane = (int)(threadIdx.x & 63);
     bool mine = false;
     for (int rr = 0; rr < 64; rr++) {
@@ -145,7 +154,7 @@ __global__ void __launch_bounds__(256) k_sam_measure(SamDev d, uint64_t k0, uint
     SamRec r;
     r.reported = false; r.len = 0; r.i = 0;
     if (j < n) r = sam_rec(d, k0 + j);
-    r.has_qual = wave_has_qual(d, r.reported ? d.offs[r.i] : 0, r.reported ? r.len : 0);
+    r.has_qual = wave_has_qual(d, (r.reported && d.bases) ? d.offs[r.i] : 0, (r.reported && d.bases) ? r.len : 0);
     if (j < n) {
         unsigned long long b = 0;
         if (r.reported) {
@@ -172,7 +181,8 @@ __global__ void __launch_bounds__(256) k_sam_measure(SamDev d, uint64_t k0, uint
 
 // One bulk piece of a line - name, sequence, scores - copied by the whole wave: lane q moves byte q, q + 64, .. of the piece of record rr,
 // for rr = 0 .. 63 in turn (coalesced loads and stores; the lanes' own small fields went out before).  mode 0: bytes as they are;
-// 1: base letters; 2: complement letters, read backwards; 3: scores; 4: scores, read backwards.
+// 1: base letters; 2: complement letters, read backwards; 3: scores; 4: scores, read backwards; 5 / 6: as 1 / 2 from packed words
+// (src = the read's first word; the bases that are not a,c,g,t are written over afterwards by the record's own lane).
 __device__ __forceinline__ void wave_copy(const uint8_t *src, char *dst, uint32_t len, int mode)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -183,6 +193,15 @@ __device__ __forceinline__ void wave_copy(const uint8_t *src, char *dst, uint32_
         const uint8_t *s = reinterpret_cast<const uint8_t *>(shfl64(reinterpret_cast<uint64_t>(src), rr));
         char *w = reinterpret_cast<char *>(shfl64(reinterpret_cast<uint64_t>(dst), rr));
         const int m = __shfl(mode, rr);
+        if (m >= 5) {
+            const uint32_t *w32 = reinterpret_cast<const uint32_t *>(s);
+            for (uint32_t q = (uint32_t)lane; q < l; q += 64) {
+                const uint32_t qq = m == 6 ? l - 1 - q : q;
+                const uint32_t code = (w32[qq >> 4] >> (30 - 2 * (qq & 15))) & 3;
+                w[q] = (char)(((m == 5 ? fwd : comp) >> (8 * code)) & 0xff);
+            }
+            continue;
+        }
         for (uint32_t q = (uint32_t)lane; q < l; q += 64) {
             const uint8_t c = (m == 2 || m == 4) ? s[l - 1 - q] : s[q];
             w[q] = m == 0 ? (char)c : (m <= 2 ? (char)(((m == 1 ? fwd : comp) >> (8 * (c & 7))) & 0xff) : (char)(33 + (((c >> 4) & 15) * 40) / 15));
@@ -196,8 +215,9 @@ __global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint64_t k0, uint32
     SamRec r;
     r.reported = false; r.len = 0; r.i = 0; r.nml = 0; r.acc = false;
     if (j < n) r = sam_rec(d, k0 + j);
-    const uint8_t *s = r.reported ? d.bases + d.offs[r.i] : nullptr;
-    r.has_qual = wave_has_qual(d, r.reported ? d.offs[r.i] : 0, r.reported ? r.len : 0);
+    const bool packed = d.bases == nullptr;
+    const uint8_t *s = !r.reported ? nullptr : (packed ? reinterpret_cast<const uint8_t *>(d.pk_words + d.pk_wofs[r.i]) : d.bases + d.offs[r.i]);
+    r.has_qual = wave_has_qual(d, (r.reported && !packed) ? d.offs[r.i] : 0, (r.reported && !packed) ? r.len : 0);
     // the lane writes its record's small fields and notes where the three bulk pieces go
     char *w_name = nullptr, *w_seq = nullptr, *w_qual = nullptr;
     int seq_mode = 1, qual_mode = 3;
@@ -245,8 +265,38 @@ __global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint64_t k0, uint32
         }
     }
     wave_copy(r.reported ? reinterpret_cast<const uint8_t *>(d.names + d.name_ofs[r.i]) : nullptr, w_name, r.reported ? r.nml : 0, 0);
-    wave_copy(s, w_seq, r.reported ? r.len : 0, seq_mode);
+    wave_copy(s, w_seq, r.reported ? r.len : 0, packed ? seq_mode + 4 : seq_mode);
     wave_copy(s, w_qual, w_qual ? r.len : 0, qual_mode);
+    if (packed && r.reported) {
+        // the record's bases that are not a,c,g,t: every code prints as N (the few there are: the lane walks its own runs)
+        uint32_t e = d.pk_efirst[r.i];
+        if (e != kNoExc) {
+            __threadfence_block();                         // (after the wave's letters, whichever lanes stored them)
+            for (; e < d.n_pk_exc && d.pk_exc[e].read == r.i; e++) {
+                const bk_nbase x = d.pk_exc[e];
+                for (uint32_t t = 0; t <= x.run; t++) {
+                    const uint32_t pp = (uint32_t)x.pos + t;
+                    if (pp < r.len) w_seq[seq_mode == 2 ? r.len - 1 - pp : pp] = 'N';
+                }
+            }
+        }
+    }
+}
+
+// packed reads: lengths as 32-bit words, words per read (for the offsets' prefix sum), first exception per read
+__global__ void __launch_bounds__(256) k_sam_unpack_lens(const uint16_t *__restrict__ lens16, uint64_t n, uint32_t *__restrict__ lens, unsigned long long *__restrict__ nwords)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = lens16[i];
+        lens[i] = l;
+        nwords[i] = (l + 15) / 16;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sam_first_exc(const bk_nbase *__restrict__ exc, uint64_t n_exc, uint32_t *__restrict__ first)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_exc; e += (uint64_t)gridDim.x * blockDim.x)
+        if (e == 0 || exc[e - 1].read != exc[e].read) first[exc[e].read] = (uint32_t)e;
 }
 
 struct DevBuf {
@@ -262,46 +312,101 @@ struct DevBuf {
 // costs 0.18 s per GB to make and about as much to give back: 2 M records keep the pair at 0.6 GB and still fill the device.
 constexpr uint64_t kSamSliceRecords = 2u << 20;
 
+// the read side of a job on the device: 1 byte/base reads (bases, offs) or the packed form (words, their offsets, exceptions), lengths, names
+struct SamReads {
+    DevBuf d_bases, d_offs, d_lens, d_names, d_nofs;
+    DevBuf d_words, d_wofs, d_exc, d_efirst;
+};
+
 // what bk_sam_prepare() starts: the job's read-side arrays on their way to the device and the pinned text buffers
 struct bk_sam_prep {
     bk_ctx *ctx = nullptr;
-    DevBuf d_bases, d_offs, d_lens, d_names, d_nofs;
+    SamReads rd;
     void *h_text[2] = {nullptr, nullptr};
     uint64_t cap_text = 0;
     uint64_t n_reads = 0, n_bases = 0, n_name_bytes = 0;
     const uint8_t *bases = nullptr;
+    const uint32_t *pk_words = nullptr;
     int rc = BK_OK;
     std::thread worker;
+    std::mutex join_mu;
     ~bk_sam_prep()
     {
-        if (worker.joinable()) worker.join();
+        { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.join(); }
         for (void *&p : h_text) if (p) { (void)hipHostFree(p); p = nullptr; }
     }
 };
 
-static int sam_upload_reads(bk_ctx *c, const bk_sam_job *job, DevBuf &d_bases, DevBuf &d_offs, DevBuf &d_lens, DevBuf &d_names, DevBuf &d_nofs)
+static bool sam_job_reads_ok(const bk_sam_job *job)
+{
+    if (!job->n_reads || !job->names || !job->name_ofs) return false;
+    if (job->pk_words) return job->pk_lens16 != nullptr && (job->n_pk_exc == 0 || job->pk_exc != nullptr);
+    return job->bases && job->offs && job->lens;
+}
+
+static int sam_upload_reads(bk_ctx *c, const bk_sam_job *job, SamReads &rd)
 {
     const uint64_t nr = job->n_reads;
-    if (d_bases.alloc(job->n_bases + 16) != hipSuccess || d_offs.alloc(nr * 8) != hipSuccess || d_lens.alloc(nr * 4) != hipSuccess ||
-        d_names.alloc(job->n_name_bytes + 16) != hipSuccess || d_nofs.alloc((nr + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
-    if (bk::upload_host(d_bases.p, job->bases, job->n_bases, c->device) || bk::upload_host(d_offs.p, job->offs, nr * 8, c->device) ||
-        bk::upload_host(d_lens.p, job->lens, nr * 4, c->device) || bk::upload_host(d_names.p, job->names, job->n_name_bytes, c->device) ||
-        bk::upload_host(d_nofs.p, job->name_ofs, nr * 8, c->device))
+    if (rd.d_lens.alloc(nr * 4) != hipSuccess || rd.d_names.alloc(job->n_name_bytes + 16) != hipSuccess || rd.d_nofs.alloc((nr + 1) * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return BK_ERR_MEM;
+    }
+    if (bk::upload_host(rd.d_names.p, job->names, job->n_name_bytes, c->device) || bk::upload_host(rd.d_nofs.p, job->name_ofs, nr * 8, c->device)) return BK_ERR_INTERNAL;
+    if (hipMemcpy((char *)rd.d_nofs.p + nr * 8, &job->n_name_bytes, 8, hipMemcpyHostToDevice) != hipSuccess) return BK_ERR_INTERNAL;
+    if (!job->pk_words) {
+        if (rd.d_bases.alloc(job->n_bases + 16) != hipSuccess || rd.d_offs.alloc(nr * 8) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; }
+        if (bk::upload_host(rd.d_bases.p, job->bases, job->n_bases, c->device) || bk::upload_host(rd.d_offs.p, job->offs, nr * 8, c->device) ||
+            bk::upload_host(rd.d_lens.p, job->lens, nr * 4, c->device))
+            return BK_ERR_INTERNAL;
+        return BK_OK;
+    }
+    // (the exceptions are checked here, while the caller's arrays are certainly there: ascending (read, pos), inside their reads)
+    for (uint64_t e = 0; e < job->n_pk_exc; e++) {
+        const bk_nbase &x = job->pk_exc[e];
+        if (x.read >= nr || (uint32_t)x.pos + x.run >= job->pk_lens16[x.read]) return BK_ERR_PARAMS;
+        if (e && (job->pk_exc[e - 1].read > x.read || (job->pk_exc[e - 1].read == x.read && (uint32_t)job->pk_exc[e - 1].pos + job->pk_exc[e - 1].run >= x.pos))) return BK_ERR_PARAMS;
+    }
+    // packed reads: words, 16-bit lengths and exceptions travel (page-locked buffers: plain DMA); lengths, word offsets and every read's
+    // first exception are made here, on a stream of this call's own
+    DevBuf d_l16, d_nw, d_tmp;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_INTERNAL; }
+    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } guard{s};
+    if (rd.d_words.alloc((job->n_pk_words + 16) * 4) != hipSuccess || rd.d_wofs.alloc((nr + 1) * 8) != hipSuccess || d_l16.alloc(nr * 2) != hipSuccess ||
+        d_nw.alloc((nr + 1) * 8) != hipSuccess || rd.d_efirst.alloc(nr * 4) != hipSuccess || rd.d_exc.alloc((job->n_pk_exc + 1) * sizeof(bk_nbase)) != hipSuccess) {
+        (void)hipGetLastError();
+        return BK_ERR_MEM;
+    }
+    if (bk::upload_host(rd.d_words.p, job->pk_words, job->n_pk_words * 4, c->device) || bk::upload_host(d_l16.p, job->pk_lens16, nr * 2, c->device) ||
+        (job->n_pk_exc && bk::upload_host(rd.d_exc.p, job->pk_exc, job->n_pk_exc * sizeof(bk_nbase), c->device)))
         return BK_ERR_INTERNAL;
-    if (hipMemcpy((char *)d_nofs.p + nr * 8, &job->n_name_bytes, 8, hipMemcpyHostToDevice) != hipSuccess) return BK_ERR_INTERNAL;
+    hipError_t e = hipMemsetAsync((char *)d_nw.p + nr * 8, 0, 8, s);
+    if (e == hipSuccess) e = hipMemsetAsync(rd.d_efirst.p, 0xff, nr * 4, s);
+    if (e != hipSuccess) return BK_ERR_INTERNAL;
+    hipLaunchKernelGGL(k_sam_unpack_lens, dim3(4096), dim3(256), 0, s, d_l16.as<uint16_t>(), nr, rd.d_lens.as<uint32_t>(), d_nw.as<unsigned long long>());
+    if (job->n_pk_exc) hipLaunchKernelGGL(k_sam_first_exc, dim3(1024), dim3(256), 0, s, rd.d_exc.as<bk_nbase>(), job->n_pk_exc, rd.d_efirst.as<uint32_t>());
+    size_t tb = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
+    if (e == hipSuccess) e = d_tmp.alloc(tb + 256);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
+    unsigned long long total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, rd.d_wofs.as<unsigned long long>() + nr, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipGetLastError(); return BK_ERR_INTERNAL; }
+    if (total != job->n_pk_words) return BK_ERR_PARAMS;           // (the lengths do not add up to the words given)
     return BK_OK;
 }
 
 extern "C" int bk_sam_prepare(bk_ctx *c, const bk_sam_job *job, uint32_t text_bytes_per_record, bk_sam_prep **out)
 {
-    if (!c || !job || !out || !job->n_reads || !job->bases || !job->offs || !job->lens || !job->names || !job->name_ofs) return BK_ERR_PARAMS;
+    if (!c || !job || !out || !sam_job_reads_ok(job)) return BK_ERR_PARAMS;
     bk_sam_prep *p = new bk_sam_prep();
     p->ctx = c;
-    p->n_reads = job->n_reads; p->n_bases = job->n_bases; p->n_name_bytes = job->n_name_bytes; p->bases = job->bases;
+    p->n_reads = job->n_reads; p->n_bases = job->n_bases; p->n_name_bytes = job->n_name_bytes; p->bases = job->bases; p->pk_words = job->pk_words;
     const bk_sam_job j = *job;
     p->worker = std::thread([p, j, text_bytes_per_record]() {
         if (hipSetDevice(p->ctx->device) != hipSuccess) { p->rc = BK_ERR_INTERNAL; return; }
-        p->rc = sam_upload_reads(p->ctx, &j, p->d_bases, p->d_offs, p->d_lens, p->d_names, p->d_nofs);
+        p->rc = sam_upload_reads(p->ctx, &j, p->rd);
         if (p->rc == BK_OK && text_bytes_per_record) {
             const uint64_t slice = std::min<uint64_t>(j.n_reads, kSamSliceRecords);
             const uint64_t cap = slice * (uint64_t)text_bytes_per_record + (1u << 20);
@@ -317,6 +422,14 @@ extern "C" int bk_sam_prepare(bk_ctx *c, const bk_sam_job *job, uint32_t text_by
 
 extern "C" void bk_sam_prep_free(bk_sam_prep *prep) { delete prep; }
 
+extern "C" int bk_sam_prep_wait(bk_sam_prep *prep)
+{
+    if (!prep) return BK_ERR_PARAMS;
+    std::lock_guard<std::mutex> lk(prep->join_mu);             // (the format call may be joining too)
+    if (prep->worker.joinable()) prep->worker.join();
+    return prep->rc;
+}
+
 extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes)
 {
     if (!job) return BK_ERR_PARAMS;
@@ -325,7 +438,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     *n_reported = 0;
     *n_bytes = 0;
     if (!job->n_order) return BK_OK;
-    if (!job->bases || !job->offs || !job->lens || !job->names || !job->name_ofs || !job->hits || !job->order || !job->n_reads) return BK_ERR_PARAMS;
+    if (!sam_job_reads_ok(job) || !job->hits || !job->order) return BK_ERR_PARAMS;
     if (job->pe_mode && (job->n_reads & 1)) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -336,18 +449,21 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     double t_mark = now(), t_dev = 0, t_settle = 0, t_pin = 0;
     auto lap = [&](const char *what) { const double t = now(); if (timing) fprintf(stderr, "bk timing: bk_sam_format %-28s %7.1f ms\n", what, 1e3 * (t - t_mark)); t_mark = t; };
     // the read store, names, records and order travel to the device once (pageable memory: staged by a few threads)
-    DevBuf own_bases, own_offs, own_lens, own_names, own_nofs, d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_cnt;
+    SamReads own;
+    DevBuf d_hits, d_order, d_ent, d_bytes, d_at, d_tmp, d_cnt;
 #define SAM_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return BK_ERR_MEM; } } while (0)
     // the read-side arrays: already on the device when bk_sam_prepare() was given these reads, else they travel now
     if (prep) {
-        if (prep->worker.joinable()) prep->worker.join();
-        if (prep->ctx != c || prep->n_reads != nr || prep->n_bases != job->n_bases || prep->n_name_bytes != job->n_name_bytes || prep->bases != job->bases) return BK_ERR_PARAMS;
+        { std::lock_guard<std::mutex> lk(prep->join_mu); if (prep->worker.joinable()) prep->worker.join(); }
+        if (prep->ctx != c || prep->n_reads != nr || prep->n_bases != job->n_bases || prep->n_name_bytes != job->n_name_bytes || prep->bases != job->bases ||
+            prep->pk_words != job->pk_words)
+            return BK_ERR_PARAMS;
         if (prep->rc != BK_OK) prep.reset();
     }
     lap(prep ? "head start taken, waited" : "no head start");
-    if (!prep) { int ru = sam_upload_reads(c, job, own_bases, own_offs, own_lens, own_names, own_nofs); if (ru) return ru; }
-    DevBuf &d_bases = prep ? prep->d_bases : own_bases, &d_offs = prep ? prep->d_offs : own_offs, &d_lens = prep ? prep->d_lens : own_lens,
-           &d_names = prep ? prep->d_names : own_names, &d_nofs = prep ? prep->d_nofs : own_nofs;
+    if (!prep) { int ru = sam_upload_reads(c, job, own); if (ru) return ru; }
+    SamReads &rd = prep ? prep->rd : own;
+    const bool packed = job->pk_words != nullptr;
     SAM_TRY(d_hits.alloc(nr * sizeof(bk_hit)));
     SAM_TRY(d_order.alloc(job->n_order * 4));
     SAM_TRY(d_ent.alloc((size_t)n_ent * 81));
@@ -367,14 +483,16 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     }
     lap("uploads");
     SamDev d{};
-    d.bases = d_bases.as<uint8_t>(); d.offs = d_offs.as<uint64_t>(); d.lens = d_lens.as<uint32_t>(); d.names = d_names.as<char>();
-    d.name_ofs = d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
+    d.bases = packed ? nullptr : rd.d_bases.as<uint8_t>(); d.offs = rd.d_offs.as<uint64_t>(); d.lens = rd.d_lens.as<uint32_t>(); d.names = rd.d_names.as<char>();
+    d.name_ofs = rd.d_nofs.as<uint64_t>(); d.hits = d_hits.as<bk_hit>(); d.order = d_order.as<uint32_t>(); d.ent_names = d_ent.as<char>();
+    d.pk_words = rd.d_words.as<uint32_t>(); d.pk_wofs = rd.d_wofs.as<uint64_t>(); d.pk_exc = rd.d_exc.as<bk_nbase>(); d.pk_efirst = rd.d_efirst.as<uint32_t>();
+    d.n_pk_exc = packed ? job->n_pk_exc : 0;
     d.n_ent = n_ent; d.fmt6 = job->report_unaligned ? 1 : 0; d.pe_mode = job->pe_mode;
     // does any base carry a score at all?  (one streaming pass; without scores - FASTA input, or -g3 - no record is scanned for them)
     DevBuf d_anyq;
     SAM_TRY(d_anyq.alloc(16));
     SAM_TRY(hipMemsetAsync(d_anyq.p, 0, 16, s));
-    hipLaunchKernelGGL(k_sam_any_qual, dim3(4096), dim3(256), 0, s, d.bases, job->n_bases, d_anyq.as<uint32_t>());
+    if (!packed) hipLaunchKernelGGL(k_sam_any_qual, dim3(4096), dim3(256), 0, s, d.bases, job->n_bases, d_anyq.as<uint32_t>());
     SAM_TRY(hipGetLastError());
     d.any_qual = d_anyq.as<uint32_t>();
     // Everything the device indexes with is checked here first (the command line passes consistent arrays; another caller of the ABI
@@ -388,8 +506,10 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
             for (uint64_t i = r0; i < r1; i++) {
                 const bk_hit &h = job->hits[i];
                 if (h.nar == BK_NAR_ACCEPTED && (h.chrom_id < 1 || h.chrom_id > n_ent)) bad[t] = 1;
-                const uint64_t o = job->offs[i], l = job->lens[i];
-                if (o > job->n_bases || l > job->n_bases - o) bad[t] = 1;
+                if (!packed) {
+                    const uint64_t o = job->offs[i], l = job->lens[i];
+                    if (o > job->n_bases || l > job->n_bases - o) bad[t] = 1;
+                }                                          // (packed reads: the lengths were checked against the word count when they were uploaded)
                 const uint64_t a = job->name_ofs[i], z = i + 1 < nr ? job->name_ofs[i + 1] : job->n_name_bytes;
                 if (z > job->n_name_bytes || a >= z) bad[t] = 1;
             }

@@ -27,6 +27,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <future>
+#include <memory>
 #include <ctime>
 #include <map>
 #include <string>
@@ -201,6 +204,15 @@ int cmd_index(int argc, char **argv, int first)
 // ---------------------------------------------------------------------------------------------
 // align
 
+// BK_TIMING=1: wall-clock of the front end's own stages on stderr (the library prints its own)
+struct HostClock {
+    bool on = getenv("BK_TIMING") != nullptr;
+    double t0 = now();
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (the log's seconds)
+    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: host: %-40s %7.1f ms   (done at :%06.3f)\n", what, 1e3 * (t - t0), wall()); t0 = t; }
+};
+
 // The acceptance rules of load_reads() applied to a file that was parsed whole (fasta.h, ParsedChunk): every
 // chunk is filtered and measured by its own thread, a prefix sum gives each chunk its place in the read
 // store, and the threads copy their accepted records there.  Same records, same order, same log lines.
@@ -223,9 +235,9 @@ int accept_chunks(bk::ParsedFile &file, const std::string &fn, int trim5, int tr
     struct Tot { uint64_t n_acc = 0, n_bases = 0, n_names = 0, n_under = 0, n_over = 0, n_rec = 0; long bad_at = -1; };
     std::vector<Tot> tot(nc);
     std::vector<std::vector<uint32_t>> keep_name_len(nc);       // per record: accepted name length + 1, or 0 when sloughed
-    auto name_len = [&](const char *d, size_t dl) {
+    auto name_len = [](const char *d, size_t dl, bool sim_) {
         if (dl > 127) dl = 127;
-        if (sim) return dl;
+        if (sim_) return dl;
         size_t k = 0;
         while (k < 79 && k < dl && !isspace((unsigned char)d[k])) k++;
         return k;
@@ -237,27 +249,38 @@ int accept_chunks(bk::ParsedFile &file, const std::string &fn, int trim5, int tr
         for (auto &t : th) t.join();
     };
     run([&](size_t ci) {
+        // Everything the record loop reads is a copy of this call's own: the function's parameters and flags live in the frame of the thread
+        // that also works through chunks here - its stores to that frame would take the cache line away from every other thread once per
+        // record (seen: this pass between 0.1 and 3.7 s for the same input, depending on how a build laid the frame out).  The counts go
+        // to `tot` once, for the same reason: neighbours there belong to other threads' chunks.
         const bk::ParsedChunk &c = chunks[ci];
-        Tot &t = tot[ci];
-        auto &kn = keep_name_len[ci];
-        kn.assign(c.lens.size(), 0);
+        const int t5 = trim5, t3 = trim3, mn = min_len, mx = max_len;
+        const bool sim_ = sim;
+        const size_t n_rec = c.lens.size();
+        const uint32_t *lens_ = c.lens.data(), *dlens_ = c.descr_lens.data();
+        const char *descr_ = c.descr;
+        Tot t;
+        auto &kn_v = keep_name_len[ci];
+        kn_v.assign(n_rec, 0);
+        uint32_t *kn = kn_v.data();
         size_t dofs = 0;
-        for (size_t i = 0; i < c.lens.size(); i++) {
-            const int len = (int)c.lens[i];
-            const size_t dl = c.descr_lens[i];
+        for (size_t i = 0; i < n_rec; i++) {
+            const int len = (int)lens_[i];
+            const size_t dl = dlens_[i];
             t.n_rec++;
             if (len < 1 || len > 0x30000) { if (t.bad_at < 0) t.bad_at = (long)i; }
-            else if (trim5 + trim3 + min_len > len) t.n_under++;
-            else if (trim5 + trim3 + max_len < len) t.n_over++;
+            else if (t5 + t3 + mn > len) t.n_under++;
+            else if (t5 + t3 + mx < len) t.n_over++;
             else {
-                size_t nl = name_len(c.descr + dofs, dl);
+                size_t nl = name_len(descr_ + dofs, dl, sim_);
                 kn[i] = (uint32_t)nl + 1;
                 t.n_acc++;
-                t.n_bases += (uint64_t)(len - trim5 - trim3);
+                t.n_bases += (uint64_t)(len - t5 - t3);
                 t.n_names += nl + 1;
             }
             dofs += dl;
         }
+        tot[ci] = t;
     });
     // log lines in file order, as the serial loader prints them
     uint64_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
@@ -286,26 +309,37 @@ int accept_chunks(bk::ParsedFile &file, const std::string &fn, int trim5, int tr
     if (!adopt) rs.bases.resize(b0[nc]);
     rs.names.resize(m0[nc]);
     run([&](size_t ci) {
+        // (copies again: see the first pass)
         bk::ParsedChunk &c = chunks[ci];
-        const auto &kn = keep_name_len[ci];
+        const uint32_t *kn = keep_name_len[ci].data(), *lens_ = c.lens.data(), *dlens_ = c.descr_lens.data();
+        const size_t n_rec = c.lens.size();
+        const uint32_t t5 = (uint32_t)trim5, t3 = (uint32_t)trim3;
+        const bool adopt_ = adopt;
+        const uint8_t *cbases = c.bases;
+        const char *descr_ = c.descr;
+        const uint64_t chunk_at = adopt_ ? (uint64_t)(c.bases - file.bases.data()) : 0;
+        uint32_t *o_lens = rs.lens.data();
+        uint64_t *o_offs = rs.offs.data(), *o_nofs = rs.name_ofs.data();
+        uint8_t *o_bases = adopt_ ? nullptr : rs.bases.data();
+        char *o_names = rs.names.data();
         uint64_t r = r0[ci], bo = b0[ci], mo = m0[ci];
         size_t dofs = 0, sofs = 0;
-        for (size_t i = 0; i < c.lens.size(); i++) {
-            const uint32_t len = c.lens[i];
+        for (size_t i = 0; i < n_rec; i++) {
+            const uint32_t len = lens_[i];
             if (kn[i]) {
-                const uint32_t keep = len - (uint32_t)trim5 - (uint32_t)trim3, nl = kn[i] - 1;
-                rs.lens[r] = keep;
-                if (adopt) rs.offs[r] = (uint64_t)(c.bases - file.bases.data()) + sofs + (uint64_t)trim5;
+                const uint32_t keep = len - t5 - t3, nl = kn[i] - 1;
+                o_lens[r] = keep;
+                if (adopt_) o_offs[r] = chunk_at + sofs + (uint64_t)t5;
                 else {
-                    rs.offs[r] = bo;
-                    memcpy(rs.bases.data() + bo, c.bases + sofs + trim5, keep);
+                    o_offs[r] = bo;
+                    memcpy(o_bases + bo, cbases + sofs + t5, keep);
                 }
-                rs.name_ofs[r] = mo;                           // (the names - a tenth of the bases - are laid back to back)
-                memcpy(rs.names.data() + mo, c.descr + dofs, nl);
-                rs.names[mo + nl] = '\0';
+                o_nofs[r] = mo;                                // (the names - a tenth of the bases - are laid back to back)
+                memcpy(o_names + mo, descr_ + dofs, nl);
+                o_names[mo + nl] = '\0';
                 r++; bo += keep; mo += nl + 1;
             }
-            dofs += c.descr_lens[i];
+            dofs += dlens_[i];
             sofs += len;
         }
     });
@@ -626,14 +660,6 @@ struct AlignedSet {
     std::vector<uint64_t> seq_counts;              // per sequence: reads the SE pass accepted, summed over the devices (RCCL when > 1)
 };
 
-// BK_TIMING=1: wall-clock of the front end's own stages on stderr (the library prints its own)
-struct HostClock {
-    bool on = getenv("BK_TIMING") != nullptr;
-    double t0 = now();
-    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-    static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (the log's seconds)
-    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "bk timing: host: %-40s %7.1f ms   (done at :%06.3f)\n", what, 1e3 * (t - t0), wall()); t0 = t; }
-};
 
 // The reads as they cross the boundary (the reference's loader hands its workers 1 byte/base, Aligner.cpp:9038-9055, of which three bits
 // reach the hot path): 2 bit/base words + 16-bit lengths + the bases that are not a,c,g,t (bk_pack_reads), cut into the batches the
@@ -667,13 +693,30 @@ struct Submission {
     // the packed reads have served once the last batch is back: their page-locked memory is given back (0.18 s per GB) by a thread of its
     // own while the records are sorted, instead of at the end of the run
     std::thread releaser;
-    void release_packed_in_background()
+    std::vector<bk_nbase> exc_job;                 // the exceptions of all batches with `read` counting from the first read of the run
+    // (with a SAM head start that reads the packed form: once that has taken it to the device; kept if the head start failed - the
+    // formatter then uploads for itself)
+    void release_packed_in_background(bk_sam_prep *after = nullptr, std::function<void()> then = nullptr)
     {
         if (early.joinable()) early.join();
         uint32_t *w = words; uint16_t *l = lens16; bk_nbase *e = exc;
         words = nullptr; lens16 = nullptr; exc = nullptr; cap_words = cap_lens = cap_exc = 0;
-        releaser = std::thread([w, l, e]() { bk_host_free(w); bk_host_free(l); bk_host_free(e); });
+        looked = std::async(std::launch::deferred, []() {});       // (reset below when there is a head start to look at)
+        if (after != nullptr) {
+            auto seen = std::make_shared<std::promise<void>>();
+            looked = seen->get_future();
+            releaser = std::thread([w, l, e, after, seen, then]() {
+                const int rc = bk_sam_prep_wait(after);
+                seen->set_value();                      // (`after` may be consumed from here on)
+                if (rc != BK_OK) return;
+                if (then) then();
+                bk_host_free(w); bk_host_free(l); bk_host_free(e);
+            });
+        } else
+            releaser = std::thread([w, l, e]() { bk_host_free(w); bk_host_free(l); bk_host_free(e); });
     }
+    std::future<void> looked;                      // ready once the releaser no longer needs the head start's handle
+    void done_with_head_start() { if (looked.valid()) looked.wait(); }
     ~Submission()
     {
         if (early.joinable()) early.join();
@@ -782,6 +825,11 @@ int prepare_submission(const AlignOpts &o, const ReadStore &rs, size_t ndev, boo
             continue;
         }
         b.e0 = e_at; e_at += n_exc; b.e1 = e_at;
+    }
+    if (rc == BK_OK) {
+        S.exc_job.assign(S.exc, S.exc + e_at);
+        for (const Submission::Batch &b : S.batches)
+            for (uint64_t e = b.e0; e < b.e1; e++) S.exc_job[e].read += (uint32_t)b.lo;
     }
     clk.lap("reads packed to 2 bit/base");
     results.join();
@@ -1132,6 +1180,7 @@ int cmd_align(int argc, char **argv, int first)
     AlignedSet A;
     struct Unlock { Submission &S; ~Unlock() { S.release_results(); } } unlock_results{S};        // (before A's records are freed: declared after A)
     if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
+    if (!rc && pre_early) pre.add_threads(2);       // (two while the parser's threads allocate their own memory, four from here on)
     { HostClock jc; for (auto &t : loaders) t.join(); jc.lap("waited for the index image"); }
     for (size_t d = 0; d < ndev; d++)
         if (ctx_rc[d]) { diag("Fatal: unable to load genome assembly suffix array: %s", bk_strerror(ctx_rc[d])); destroy_ctxs(); return 1; }
@@ -1187,7 +1236,6 @@ int cmd_align(int argc, char **argv, int first)
     if (o.pe_mode) diag("Paired end association and partner alignment processing runs with the alignment of each batch");
     rc = nr ? align_reads(ctxs, streams, o, rs, S, A) : BK_OK;
     if (rc) { destroy_ctxs(); return 1; }
-    S.release_packed_in_background();
     if (!nr) A.seq_counts.assign(n_ent, 0);
     std::vector<bk_hit> &hits = A.hits;
     std::vector<bk_seg2> &seg2 = A.seg2;
@@ -1195,14 +1243,43 @@ int cmd_align(int argc, char **argv, int first)
     // plain SAM records of a large run are formatted by the device (report.cpp): what it needs of the reads travels there while the
     // host resolves, filters and sorts
     bk_sam_prep *sam_prep = nullptr;
-    struct PrepGuard { bk_sam_prep *&p; ~PrepGuard() { if (p) { bk_sam_prep_free(p); p = nullptr; } } } prep_guard{sam_prep};      // (not consumed: given back)
+    bk_sam_job pk_job{};
+    struct PrepGuard { bk_sam_prep *&p; Submission &S; ~PrepGuard() { if (p) { S.done_with_head_start(); bk_sam_prep_free(p); p = nullptr; } } } prep_guard{sam_prep, S};      // (not consumed: given back)
     if (pre.fd >= 0 && o.ml_mode != 5 && !o.micro_indel && !o.splice_len && !o.min_chim && !o.min_flank && nr == rs.lens.size()) {
         bk_sam_job hj{};
         hj.bases = rs.bases.data(); hj.n_bases = rs.bases.size(); hj.offs = rs.offs.data(); hj.lens = rs.lens.data();
         hj.names = rs.names.data(); hj.n_name_bytes = rs.names.size(); hj.name_ofs = rs.name_ofs.data(); hj.n_reads = nr;
+        // without scores in the read store (FASTA, or -g3) the formatter reads the packed form the alignment was fed from: page-locked,
+        // a quarter of the bytes, no host thread copies anything
+        if (g_qual_mode == 3 && S.words != nullptr && S.lens16 != nullptr) {
+            hj.pk_words = S.words; hj.n_pk_words = S.n_words; hj.pk_lens16 = S.lens16; hj.pk_exc = S.exc_job.data(); hj.n_pk_exc = S.exc_job.size();
+            hj.bases = nullptr; hj.n_bases = 0; hj.offs = nullptr; hj.lens = nullptr;
+        }
+        pk_job = hj;
         const uint64_t per_rec = (rs.name_bytes() + (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.base_bytes()) / std::max<size_t>(nr, 1) + 64 + (o.pe_mode ? 24 : 0);
-        if (bk_sam_prepare(ctx, &hj, (uint32_t)std::min<uint64_t>(per_rec + per_rec / 8, 1u << 20), &sam_prep) != BK_OK) sam_prep = nullptr;
+        if (bk_sam_prepare(ctx, &hj, (uint32_t)std::min<uint64_t>(per_rec + per_rec / 8, 1u << 20), &sam_prep) != BK_OK) { sam_prep = nullptr; pk_job = bk_sam_job{}; }
     }
+    // The read store's bases - 5 GB of a 50 M-read run, a third of a second to hand back at the exit - have served too once the device
+    // holds the packed reads, unless an output of this run still reads them (-j / -J, -O, SNP calling); should the device decline
+    // after all, the host formatter loads them again (restore_reads)
+    bool bases_dropped = false;
+    const bool may_drop_bases = pk_job.pk_words != nullptr && sam_prep != nullptr && !a.has("j") && !a.has("J") && !a.has("O") && o.snp.min_reads <= 0;
+    if (nr)
+        S.release_packed_in_background(pk_job.pk_words != nullptr ? sam_prep : nullptr,
+                                       may_drop_bases ? std::function<void()>([&rs, &bases_dropped]() { bk::RawVec<uint8_t> none; rs.bases.swap(none); bases_dropped = true; })
+                                                      : std::function<void()>());
+    auto restore_reads = [&]() -> int {
+        if (S.releaser.joinable()) S.releaser.join();
+        if (!bases_dropped) return 0;
+        diag("The device declined the SAM records: loading the reads again for the host's formatter");
+        ReadStore again;
+        const int rl = o.pe_mode ? load_reads_pe(a.v["i"], a.v["u"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, again)
+                                 : load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, o.nthreads, again);
+        if (rl || again.size() != rs.size()) return 1;
+        rs.bases.swap(again.bases); rs.offs.swap(again.offs); rs.used_bases = again.used_bases;
+        bases_dropped = false;
+        return 0;
+    };
 
     std::vector<uint32_t> src;                     // -r5: record -> read it came from (records replace the reads)
     std::vector<int> multi_dist((size_t)o.max_ml, 0);
@@ -1422,7 +1499,10 @@ int cmd_align(int argc, char **argv, int first)
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, o.pe_mode, o.ml_mode, o.max_ml, o.fmt, o.nthreads, o.micro_indel, o.splice_len, o.max_rpt_sam_seqs};
     R.ctx = ctx;
     R.pre = pre.fd >= 0 ? &pre : nullptr;
+    S.done_with_head_start();
+    R.restore_reads = restore_reads;
     R.sam_prep = sam_prep;
+    R.pk_words = pk_job.pk_words; R.n_pk_words = pk_job.n_pk_words; R.pk_lens16 = pk_job.pk_lens16; R.pk_exc = pk_job.pk_exc; R.n_pk_exc = pk_job.n_pk_exc;
     sam_prep = nullptr;                            // (the report owns it from here)
     // ".bam" (more than 5 characters of name, kanga.cpp:848-857): BGZF-compressed BAM with its BAI index; else SAM / CSV / BED text
     const std::string opath = a.str("o");

@@ -152,25 +152,9 @@ struct SamPrealloc {
             }
         }
         if (map) {
-            const size_t n_chunks = (size_t)((est + kStep - 1) / kStep);
+            n_chunks = (size_t)((est + kStep - 1) / kStep);
             chunk_done.assign(n_chunks, 0);
-            auto next = std::make_shared<std::atomic<size_t>>(0);
-            auto live = std::make_shared<std::atomic<int>>(nthreads);
-            for (int t = 0; t < nthreads; t++)
-                th.emplace_back([this, next, live, n_chunks]() {
-                    for (;;) {
-                        const size_t k = next->fetch_add(1);
-                        if (k >= n_chunks || quit.load()) break;
-                        const off_t at = (off_t)k * kStep, len = std::min<off_t>(kStep, est - at);
-                        if (madvise(map + at, (size_t)len, 23) != 0) { quit.store(true); break; }
-                        std::lock_guard<std::mutex> g(mu);
-                        chunk_done[k] = 1;
-                        off_t d = done.load();
-                        while (d < est && chunk_done[(size_t)(d / kStep)]) d = std::min<off_t>(est, (d / kStep + 1) * kStep);
-                        done.store(d);
-                    }
-                    if (live->fetch_sub(1) == 1) ended.store(true);
-                });
+            add_threads(nthreads);
             return;
         }
         th.emplace_back([this]() {
@@ -183,6 +167,36 @@ struct SamPrealloc {
             ended.store(true);
         });
     }
+    // (more threads for the populating form; nothing to add to a finished or a fallocate-only one)
+    size_t n_chunks = 0;
+    std::atomic<size_t> next_chunk{0};
+    std::atomic<int> live{0};
+    void add_threads(int n)
+    {
+        if (!map || ended.load()) return;
+        for (int t = 0; t < n; t++) {
+            live.fetch_add(1);
+            th.emplace_back([this]() {
+                for (;;) {
+                    const size_t k = next_chunk.fetch_add(1);
+                    if (k >= n_chunks || quit.load()) break;
+                    const off_t at = (off_t)k * kStep, len = std::min<off_t>(kStep, est - at);
+                    // (a few MB per call: the call holds the address space's lock shared, and a thread that wants it exclusively - any
+                    // large allocation of the parser's - makes everybody else's page faults queue up behind it until the call returns)
+                    bool ok = true;
+                    for (off_t o = 0; o < len && ok && !quit.load(); o += (4 << 20)) ok = madvise(map + at + o, (size_t)std::min<off_t>(4 << 20, len - o), 23) == 0;
+                    if (!ok) { quit.store(true); break; }
+                    if (quit.load()) break;
+                    std::lock_guard<std::mutex> g(mu);
+                    chunk_done[k] = 1;
+                    off_t d = done.load();
+                    while (d < est && chunk_done[(size_t)(d / kStep)]) d = std::min<off_t>(est, (d / kStep + 1) * kStep);
+                    done.store(d);
+                }
+                if (live.fetch_sub(1) == 1) ended.store(true);
+            });
+        }
+    }
     void finish() { quit.store(true); for (auto &t : th) if (t.joinable()) t.join(); }
     // Written ranges leave the page table behind the writers (the file keeps the pages): 60 ms per GB of page-table and reverse-map work
     // that would otherwise be the process's last act.  A thread of its own does it, nobody waits for it; a large run ends the process
@@ -191,14 +205,15 @@ struct SamPrealloc {
     std::condition_variable ucv;
     std::vector<std::pair<char *, size_t>> uq;
     bool ustop = false;
-    std::thread uth;
+    std::vector<std::thread> uth;                  // (two: one falls behind a 50 GB/s stream of text)
     void unmap_behind(char *p, size_t n)
     {
         {
             std::lock_guard<std::mutex> lk(um);
-            uq.emplace_back(p, n);
-            if (!uth.joinable())
-                uth = std::thread([this]() {
+            // (pieces of 64 MB: both threads get work out of one slice)
+            for (size_t o = 0; o < n; o += (64u << 20)) uq.emplace_back(p + o, std::min<size_t>(64u << 20, n - o));
+            while (uth.size() < 2)
+                uth.emplace_back([this]() {
                     for (;;) {
                         std::pair<char *, size_t> r;
                         { std::unique_lock<std::mutex> lk2(um); ucv.wait(lk2, [&] { return ustop || !uq.empty(); }); if (uq.empty()) return; r = uq.back(); uq.pop_back(); }
@@ -206,14 +221,14 @@ struct SamPrealloc {
                     }
                 });
         }
-        ucv.notify_one();
+        ucv.notify_all();
     }
     ~SamPrealloc()
     {
         finish();
         { std::lock_guard<std::mutex> lk(um); ustop = true; }
         ucv.notify_all();
-        if (uth.joinable()) uth.join();
+        for (auto &t : uth) if (t.joinable()) t.join();
         if (map) munmap(map, (size_t)est);
         if (fd >= 0) { if (!kept && ftruncate(fd, 0) != 0) {} ::close(fd); }
     }

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -80,14 +81,20 @@ void par_partition(T *lo, T *hi, Cmp cmp, int nthreads, T *&out_pl, T *&out_ph)
         fn(0);
         for (auto &x : th) x.join();
     };
+    // (every thread works on copies of what its loops read: the originals live in this function's frame, which the calling thread - a
+    // worker too - writes to; a shared cache line per element would cost more than the threads bring)
     run_threads([&](int t) {
-        for (size_t b = (size_t)t; b < nb; b += (size_t)nthreads) {
-            const size_t i0 = b * bs, i1 = std::min(cnt, i0 + bs);
+        const T pv = pivot;
+        T *const lo_ = lo;
+        const size_t cnt_ = cnt, bs_ = bs, nb_ = nb, nt_ = (size_t)nthreads;
+        Cmp cmp_ = cmp;
+        for (size_t b = (size_t)t; b < nb_; b += nt_) {
+            const size_t i0 = b * bs_, i1 = std::min(cnt_, i0 + bs_);
             uint64_t nl = 0, nr = 0;
             for (size_t i = i0; i < i1; i++) {
-                const bool gt = cmp(lo[i], pivot) > 0;
+                const bool gt = cmp_(lo_[i], pv) > 0;
                 nl += (gt && i >= 1) ? 1 : 0;
-                nr += (!gt && i + 1 < cnt) ? 1 : 0;
+                nr += (!gt && i + 1 < cnt_) ? 1 : 0;
             }
             cl[b + 1] = nl; cr[b + 1] = nr;
         }
@@ -135,12 +142,15 @@ void par_partition(T *lo, T *hi, Cmp cmp, int nthreads, T *&out_pl, T *&out_ph)
             const uint64_t ka = k0 * (uint64_t)t / (uint64_t)nthreads, kb = k0 * (uint64_t)(t + 1) / (uint64_t)nthreads;
             if (kb <= ka) return;
             T *l = first_l[(size_t)t], *r = first_r[(size_t)t], *mv = nullptr;
+            const T pv = pivot;
+            T *const pivot_at_ = pivot_at;
+            Cmp cmp_ = cmp;
             for (uint64_t k = ka + 1;; k++) {
-                if (r == pivot_at) mv = l;                     // the pivot element goes to l
+                if (r == pivot_at_) mv = l;                    // the pivot element goes to l
                 std::swap(*l, *r);
                 if (k == kb) break;
-                do { ++l; } while (!(cmp(*l, pivot) > 0));
-                do { --r; } while (!(cmp(*r, pivot) <= 0));
+                do { ++l; } while (!(cmp_(*l, pv) > 0));
+                do { --r; } while (!(cmp_(*r, pv) <= 0));
             }
             moved[(size_t)t] = mv; last_l[(size_t)t] = l; last_r[(size_t)t] = r;      // (once: neighbours in these arrays are other threads')
         });
@@ -215,7 +225,9 @@ void ref_order_sort(T *a, int64_t n, Cmp cmp, int nthreads = 1)
     queue.push_back({a, a + (n - 1)});
     // the first levels, where there are fewer spans than threads: the largest span is partitioned by all threads together
     const size_t par_min = (size_t)1 << 20;
-    while (queue.size() < (size_t)nthreads * 2) {
+    // (the first two levels only: on a host that gives the process a CPU quota the parallel form's second pass over a span costs more than
+    // the idle threads it replaces are worth from the third level on - measured, profiles/NOTES.md round 4)
+    while (queue.size() < 4) {
         size_t big = 0;
         for (size_t i = 1; i < queue.size(); i++) if (queue[i].r - queue[i].l > queue[big].r - queue[big].l) big = i;
         const Span sp = queue[big];

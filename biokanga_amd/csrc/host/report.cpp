@@ -606,14 +606,17 @@ int report_text(Report &R)
                 return bad.load();
             };
             bk_sam_job job{};
-            job.bases = rs.bases.data(); job.n_bases = rs.bases.size(); job.offs = rs.offs.data(); job.lens = rs.lens.data();
+            if (R.pk_words == nullptr) { job.bases = rs.bases.data(); job.n_bases = rs.bases.size(); job.offs = rs.offs.data(); job.lens = rs.lens.data(); }
             job.names = rs.names.data(); job.n_name_bytes = rs.names.size(); job.name_ofs = rs.name_ofs.data();
             job.hits = hits.data(); job.n_reads = nr; job.order = order.data(); job.n_order = nr;
             job.report_unaligned = fmt == 6 ? 1 : 0; job.pe_mode = pe_mode;
+            job.pk_words = R.pk_words; job.n_pk_words = R.n_pk_words; job.pk_lens16 = R.pk_lens16; job.pk_exc = R.pk_exc; job.n_pk_exc = R.n_pk_exc;
             job.prep = R.sam_prep;
             R.sam_prep = nullptr;                                                    // (consumed by the call whatever its outcome)
             uint64_t n_rep = 0, n_bytes = 0;
-            const int drc = rs.lens.size() == nr ? bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes) : BK_ERR_PARAMS;
+            int drc = BK_ERR_PARAMS;
+            if (getenv("BK_SAM_DEVICE_FAIL")) { if (job.prep) bk_sam_prep_free(job.prep); }       // (tests: the device declines after its head start)
+            else if (rs.lens.size() == nr) drc = bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes);
             if (drc == BK_OK) {
                 out.pos += (off_t)n_bytes;
                 timespec ta; clock_gettime(CLOCK_MONOTONIC, &ta);
@@ -628,6 +631,7 @@ int report_text(Report &R)
             } else if (timing0)
                 fprintf(stderr, "bk timing: device SAM formatter declined (%s): host threads format\n", bk_strerror(drc));
         }
+        if (!device_done && R.restore_reads && R.restore_reads() != 0) { diag("Fatal: unable to reload the reads for the host formatter"); return 1; }
         // records are formatted by all host threads into per-thread buffers, one stripe of the sorted order
         // each, and written out in order (the reference formats serially, ~4.5 us per read)
         const size_t per_thread = 131072;

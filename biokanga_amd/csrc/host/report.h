@@ -1,6 +1,7 @@
 // report.h - output side of `biokanga align`: SAM / BAM / CSV / BED writers, -O statistics, -j / -J read subsets, .jct / .ind files
 // (CAligner::WriteBAMReadHits, ReportBAMread, WriteReadHits, WriteBasicCountStats, ReportNoneAligned / ReportMultiAlign).
 #pragma once
+#include <functional>
 #include "../../../include/biokanga_amd.h"
 #include "cli_common.h"
 #include "post_filters.h"
@@ -25,6 +26,16 @@ struct Report {
     bk_ctx *ctx = nullptr;                        // a context whose device formats plain SAM records (bk_sam_format); may be null
     SamPrealloc *pre = nullptr;                   // SAM text: the output file, created early and being preallocated; may be null
     bk_sam_prep *sam_prep = nullptr;              // the device formatter's head start (bk_sam_prepare), consumed or freed by report_text / report_bam
+    // the reads in the packed form the alignment was fed from, as the head start was given them (bk_sam_job.pk_*); the arrays themselves
+    // may be gone once the head start has taken them to the device
+    // .. and the read store's bases too, when nothing but the host's own formatter could still want them: restore_reads() brings them
+    // back (null: they never left)
+    std::function<int()> restore_reads;
+    const uint32_t *pk_words = nullptr;
+    uint64_t n_pk_words = 0;
+    const uint16_t *pk_lens16 = nullptr;
+    const bk_nbase *pk_exc = nullptr;
+    uint64_t n_pk_exc = 0;
 
     size_t RD(size_t i) const { return src.empty() ? i : (size_t)src[i]; }
     bool has_seg2(size_t i) const { return !seg2.empty() && (seg2[RD(i)].flags & 5); }       // FlgInDel or FlgSplice

@@ -480,6 +480,14 @@ typedef struct bk_sam_job {
     int32_t         report_unaligned;   /* -M6: reads without an accepted alignment get a line too (FLAG 4, YU:Z:<reason>) */
     int32_t         pe_mode;            /* 0, or the -U mode the records were paired under                                 */
     struct bk_sam_prep *prep;           /* NULL, or what bk_sam_prepare() started for exactly these reads (consumed by the call)   */
+    /* The reads in the packed form of bk_pack_reads instead of bases / offs / lens (those may then be NULL; QUAL is '*'): all reads'
+     * words back to back in read order, their 16-bit lengths, and the exceptions with `read` counting from the job's first read.
+     * A 100-base read then travels as 30 bytes instead of 112 - from the buffers the alignment was fed from, when those are still there. */
+    const uint32_t *pk_words;
+    uint64_t        n_pk_words;
+    const uint16_t *pk_lens16;
+    const bk_nbase *pk_exc;
+    uint64_t        n_pk_exc;
 } bk_sam_job;
 /* Optional head start: everything of a job that is known once the reads are aligned - the read store, the names, the buffers the
  * text leaves the device through - can travel while the host still sorts.  bk_sam_prepare() returns at once (a thread of the library
@@ -489,6 +497,8 @@ typedef struct bk_sam_job {
 typedef struct bk_sam_prep bk_sam_prep;
 int  bk_sam_prepare(bk_ctx *ctx, const bk_sam_job *job, uint32_t text_bytes_per_record, bk_sam_prep **out);
 void bk_sam_prep_free(bk_sam_prep *prep);
+/* blocks until the head start's transfers are over (the job's read-side arrays may be released then); returns their result code */
+int  bk_sam_prep_wait(bk_sam_prep *prep);
 typedef int (*bk_sam_sink)(void *user, const char *text, uint64_t n_bytes, uint64_t text_offset);
 int  bk_sam_format(bk_ctx *ctx, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes);
 

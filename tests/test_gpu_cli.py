@@ -685,6 +685,18 @@ def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
     assert open(out, "rb").read() == golden_bytes(*gold)
 
 
+def test_device_declines_after_its_head_start(golden_tmp, tmp_path):
+    """the packed reads are on the device, the read store's bases and the packed buffers have been given back - and then the device
+    declines (forced): the host formatter loads the reads again and writes the same file"""
+    d = golden_tmp["basic"]
+    out = str(tmp_path / "o.sam")
+    log = run(["align", "-o", out, "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-s3", "-M6"], str(tmp_path),
+              env={"BK_SAM_DEVICE_MIN": "1", "BK_SAM_EARLY_MIN": "1", "BK_SAM_DEVICE_FAIL": "1", "BK_TIMING": "1"})
+    assert "loading the reads again" in log, log[-2000:]
+    assert "SAM formatted on the device" not in log
+    assert open(out, "rb").read() == golden_bytes("basic", "s3.m6.sam.gz")
+
+
 def test_sam_file_started_early_host_formatted(golden_tmp, tmp_path):
     """the file a large plain-text input starts early (pages allocated and mapped by background threads) also takes the host threads' text,
     and a run that fails after the start leaves it empty"""

@@ -42,7 +42,13 @@ def main():
         quota = open("/sys/fs/cgroup/cpu.max").read().strip()
     except OSError:
         quota = "?"
+    def cg(name):
+        try:
+            return open("/sys/fs/cgroup/" + name).read().strip().replace("\n", " ")
+        except OSError:
+            return "?"
     print("kernel", os.uname().release)
+    print("cgroup memory: max", cg("memory.max"), "high", cg("memory.high"), "current", cg("memory.current"), "swap.max", cg("memory.swap.max"))
     print(f"host: {os.cpu_count()} cpus, {len(os.sched_getaffinity(0))} in the affinity mask, cgroup cpu.max '{quota}'")
     dev = torch.device("cuda", 0)
     seq, seq_lens = synth.make_genome(3_100_000_000, dev, seed=38)
@@ -67,9 +73,10 @@ def main():
                     if os.path.exists(f):
                         os.unlink(f)
                 t = time.time()
-                rc = subprocess.run([os.path.join(ROOT, "biokanga_amd", "bin", "biokanga"), "align", "-i", fa, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra,
+                rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra,
                                     stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1", **env), timeout=300).returncode
                 wall = time.time() - t
+                print("   cgroup memory.current", cg("memory.current"), "events:", cg("memory.events"), "peak", cg("memory.peak"))
                 size = os.path.getsize(sam) if os.path.exists(sam) else 0
                 first_size = first_size or size
                 st = stamps_of(logf)
