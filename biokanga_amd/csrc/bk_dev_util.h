@@ -370,7 +370,7 @@ constexpr int kWaveGrab = 8;            // work items a wave of the wave-per-rea
 void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hipStream_t s);       // bk_index.hip
 // 4-bit rows of both strands for every read of the batch (general kernel family, paired-end kernels): k_pack_reads (+ the exceptions
 // of a packed batch), bk_prep.hip
-void launch_pack_rows(const DevBatch &b, hipStream_t s);
+void launch_pack_rows(const DevBatch &b, hipStream_t s, const uint32_t *pairs = nullptr, uint32_t n_pairs = 0);
 struct CompactJobs { StripeSet set; uint32_t *dense[3]; uint32_t *total[3]; uint32_t *max_out; int n; };
 // capacity of one stripe of a list that `blocks` blocks append at most `per_block` entries each to (bk::StripeSet)
 inline uint32_t stripe_cap(unsigned blocks, unsigned per_block) { return ((blocks + kListStripes - 1) / kListStripes) * per_block; }

@@ -263,7 +263,9 @@ void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens,
     if (n_exc) hipLaunchKernelGGL(k_check_exc, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, s, exc, n_exc, lens, n_reads, bad);
 }
 
-__global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
+// pairs != nullptr: only the two reads of each listed pair (the paired-end kernels look at the rows of the pairs they were handed, a
+// few per cent of a batch)
+__global__ void __launch_bounds__(256) k_pack_reads(DevBatch b, const uint32_t *__restrict__ pairs, uint32_t n_pairs)
 {
     // a block packs 256 / (2 * wpr) whole reads: 32-bit index arithmetic only
     const uint32_t wpr = b.wpr;
@@ -271,7 +273,11 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b)
     const uint32_t rpb = 256 / per_read;
     const uint32_t lr = threadIdx.x / per_read;
     if (lr >= rpb) return;
-    const uint64_t r = (uint64_t)blockIdx.x * rpb + lr;
+    uint64_t r = (uint64_t)blockIdx.x * rpb + lr;
+    if (pairs != nullptr) {
+        if (r >= 2ULL * n_pairs) return;
+        r = 2ULL * pairs[r >> 1] + (r & 1);
+    }
     if (r >= b.n_reads) return;
     const uint32_t rem = threadIdx.x - lr * per_read;
     const uint32_t st = rem >= wpr ? 1 : 0, w = rem - st * wpr;
@@ -600,10 +606,12 @@ void launch_compact(const StripeSet &set, uint32_t *const *dense, uint32_t *cons
     hipLaunchKernelGGL(k_finish_lists, dim3(1), dim3(64), 0, s, J);
 }
 
-void launch_pack_rows(const DevBatch &b, hipStream_t s)
+void launch_pack_rows(const DevBatch &b, hipStream_t s, const uint32_t *pairs, uint32_t n_pairs)
 {
     const uint32_t rpb = 256 / (2 * b.wpr);
-    hipLaunchKernelGGL(k_pack_reads, dim3((b.n_reads + rpb - 1) / rpb), dim3(256), 0, s, b);
+    const uint64_t n = pairs != nullptr ? 2ULL * n_pairs : b.n_reads;
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, s, b, pairs, n_pairs);
     if (b.pk_words != nullptr && b.pk_nexc) hipLaunchKernelGGL(k_apply_exc, dim3((unsigned)((b.pk_nexc + 255) / 256)), dim3(256), 0, s, b);
 }
 

@@ -787,12 +787,14 @@ void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, in
                uint32_t *h_count, bk_seg2 *seg2, int min_chim, int long_reads, const uint8_t *accept, uint32_t n_accept, hipStream_t s)
 {
     DevPE pe{pe_mode, min_len, max_len, pair_strand, accept, n_accept};
-    launch_pack_rows(b, s);
     hipLaunchKernelGGL(k_pe_classify, dim3((n_pairs + 255) / 256), dim3(256), 0, s, pe, hits, n_pairs, orphans, counters, seg2);
     (void)hipMemcpyAsync(h_count, counters, 4, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
     uint32_t n = *h_count;
     if (n) {
+        // the 4-bit rows of the pairs the recovery will look at (a lean batch holds rows for its N reads only): 6 % of a C3 step went into
+        // packing the rows of every read here
+        launch_pack_rows(b, s, orphans, n);
         uint32_t waves = n < 8192 ? n : 8192;
 #define BK_ORPH(W) hipLaunchKernelGGL(k_pe_orphan<W>, dim3((waves + 3) / 4), dim3(256), 0, s, ix, cfg, pe, b, hits, orphans, n, counters + 1, seg2, min_chim)
         if (min_chim <= 0 || seg2 == nullptr) BK_ORPH(0);

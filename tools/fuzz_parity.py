@@ -171,16 +171,24 @@ def main():
                 if not np.array_equal(got[f], exp[f]):
                     bad = "SE pass " + f
             pep = bk.PEParams(pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]))
+            # one round in three: chromosome filters inside the pair rules (-Z / -z with -U): a random accept table by sequence id
+            accept = None
+            if rng.integers(0, 3) == 0:
+                accept = np.ones(int(max(e[0] for e in entries)) + 1, dtype=np.uint8)
+                accept[rng.integers(1, len(accept), max(1, len(accept) // 3))] = 0
+                pe["filtered_ids"] = [int(i) for i in np.nonzero(accept == 0)[0]]
+            al.set_chrom_filter(accept)
             if kw.get("min_chimeric_len"):
                 gp, gseg = al.pair(bases, offs, lens, got.copy(), pep, seg2=al.batch_seg2())
-                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy(), eseg)
+                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy(), eseg, accept=accept)
                 for f in SEG:
                     if not bad and not np.array_equal(gseg[f], eseg[f]):
                         i = int(np.nonzero(gseg[f] != eseg[f])[0][0])
                         bad = f"PE seg2.{f} at read {i}: gpu {gseg[i]} {gp[i]} oracle {eseg[i]} {ep[i]}"
             else:
                 gp = al.pair(bases, offs, lens, got.copy(), pep)
-                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy())
+                ep = helpers.oracle_process_pe(ora, p, pe["pe_mode"], pe["pair_min_len"], pe["pair_max_len"], bool(pe["pair_strand"]), bases, offs, lens, exp.copy(), accept=accept)
+            al.set_chrom_filter(None)
             for f in [x for x in FIELDS if x != "rslt"]:
                 if not np.array_equal(gp[f], ep[f]):
                     i = int(np.nonzero(gp[f] != ep[f])[0][0])
