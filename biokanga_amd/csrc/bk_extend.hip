@@ -310,12 +310,12 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     // smallest count above it.  One lane per read walking its own bytes made a wave wait for its read with the most candidates.
     __shared__ uint32_t s_k1[BS], s_c2[BS], s_nx[BS];
     __shared__ uint8_t s_mm[BS];                         // bit st: the read's strand-st row holds an N (the 4-bit compare decides its windows)
-    __shared__ uint8_t s_rec[CAP];
+    __shared__ alignas(16) uint8_t s_rec[CAP];
     __shared__ uint4 s_row[ROWS ? BS * 2 * (NW / 4) : 1];  // [read][strand]: NW/2 words at 2 bit/base
     // 5-byte indexes: the reference's set of seen targets is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), so a
     // candidate whose start lies a multiple of 2^32 bases from an earlier candidate of the same strand pass is taken for seen and
     // skipped.  The low words travel with the result bytes and the replay applies exactly that rule.
-    __shared__ uint32_t s_key[WIDE ? CAP : 1];
+    __shared__ alignas(16) uint32_t s_key[WIDE ? CAP : 1];
     __shared__ uint32_t s_wsum[BS / 64];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
@@ -613,7 +613,17 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                 const uint32_t from = local >= second ? second : 0u;
                 const uint32_t kx = s_key[f];
                 bool seen = false;
-                for (uint32_t y = from; y < local && !seen; y++) seen = s_rec[rb + y] != kRecSkip && s_key[rb + y] == kx;
+                // (four earlier candidates per step: their keys as one 16-byte word, their result bytes as one dword)
+                uint32_t i = rb + from;
+                const uint32_t i1 = rb + local;
+                for (; i < i1 && (i & 3) != 0; i++) seen |= s_rec[i] != kRecSkip && s_key[i] == kx;
+                for (; i + 4 <= i1 && !seen; i += 4) {
+                    const uint4 k4 = *reinterpret_cast<const uint4 *>(&s_key[i]);
+                    const uint32_t r4 = *reinterpret_cast<const uint32_t *>(&s_rec[i]);
+                    seen = (k4.x == kx && (r4 & 0xffu) != kRecSkip) || (k4.y == kx && ((r4 >> 8) & 0xffu) != kRecSkip) ||
+                           (k4.z == kx && ((r4 >> 16) & 0xffu) != kRecSkip) || (k4.w == kx && (r4 >> 24) != kRecSkip);
+                }
+                for (; i < i1 && !seen; i++) seen = s_rec[i] != kRecSkip && s_key[i] == kx;
                 if (seen) s_rec[f] = kRecSkip;
             }
             __syncthreads();
