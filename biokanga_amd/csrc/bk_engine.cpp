@@ -1403,7 +1403,8 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         TablePlan tp;
         if (!rc) rc = tables_begin(c, tp);
         const uint64_t n = f.concat_len;
-        const uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 26));       // (slices of at least 256 MB)
+        uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 26));             // (slices of at least 256 MB)
+        if (const char *e = getenv("BK_TABLE_SLICES")) n_slices = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)atoi(e), n));      // (tests: small indexes in several slices)
         for (uint64_t k = 0; k < n_slices && !rc && sent; k++) {
             const uint64_t i0 = n * k / n_slices, i1 = n * (k + 1) / n_slices;
             sent = upload_file(c->d_sa_lo + i0, fd, sa_ofs + i0 * 4, (i1 - i0) * 4, device_id) == BK_OK;

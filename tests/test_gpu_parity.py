@@ -394,6 +394,29 @@ def test_pe_matches_reference_and_oracle(golden_tmp, tmp_path, fixture, tag):
     assert np.array_equal(hits["flags"] & 0x80, exp["flags"] & 0x80)
 
 
+@pytest.mark.parametrize("slices", [1, 3, 7])
+def test_tables_made_behind_the_suffix_arrays_slices(golden_tmp, slices):
+    """bk_ctx_create sends a 4-byte suffix array in slices and makes k-mer table, second-level keys and inverse suffix array of slice i
+    while slice i + 1 crosses PCIe (eight slices of a 3.1 Gbp index; BK_TABLE_SLICES forces several on a small one): the tables must be
+    those of one pass - same hits, same counters, as the context made from the image already in HBM"""
+    import torch
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "repeat", "s3")
+    sfx_path = os.path.join(d, "genome.sfx")
+    os.environ["BK_TABLE_SLICES"] = str(slices)
+    try:
+        with bk.Aligner(sfx_path, bk.AlignParams(max_subs=3)) as al:
+            got = al.align(bases, offs[keep], lens[keep])
+            ctr = al.counters()
+    finally:
+        del os.environ["BK_TABLE_SLICES"]
+    sfx = helpers.OracleSfx(sfx_path)
+    exp, octr = sfx.align(bases, offs[keep], lens[keep], helpers.make_params(max_subs=3))
+    sfx.close()
+    assert_hits_equal(got, exp, [names[i] for i in keep])
+    assert ctr["n_search"] == octr.n_search and ctr["n_cand"] == octr.n_cand
+
+
 from test_oracle_pe import PE_FILT_RUNS, filt_by_chroms
 
 
