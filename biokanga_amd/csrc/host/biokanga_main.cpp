@@ -546,8 +546,13 @@ int read_align_opts(Args &a, AlignOpts &o)
     // -c chimeric trimming (kanga.cpp:648-664): reads nothing else aligned may be placed with their ends trimmed off
     o.min_chim = a.num("c", 0);
     if (o.min_chim != 0 && (o.min_chim < 50 || o.min_chim > 99)) { diag("Error: minimum chimeric length percentage '-c%d' specified outside of range 50..99", o.min_chim < 0 ? -o.min_chim : o.min_chim); return 1; }
-    if (o.min_chim && o.ml_mode && (a.has("N") || a.num("a", 0) > 0 || a.num("A", 0) > 0)) {
-        diag("Error: chimeric trimming '-c%d' together with '-r%d' and '-N' / '-a' / '-A' is not available in this build", o.min_chim, o.ml_mode);
+    // (-c with -N: the reference refuses it itself, kanga.cpp:712-716)
+    if (o.min_chim && o.ml_mode && a.has("N")) {
+        diag("Error: Sorry, chimeric read processing not supported in this release if either SOLiD or locating multiple best matches also requested");
+        return 1;
+    }
+    if (o.min_chim && o.ml_mode && (a.num("a", 0) > 0 || a.num("A", 0) > 0)) {
+        diag("Error: chimeric trimming '-c%d' together with '-r%d' and '-a' / '-A' is not available in this build", o.min_chim, o.ml_mode);
         return 1;
     }
     // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
