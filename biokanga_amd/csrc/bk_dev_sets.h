@@ -38,6 +38,35 @@ __device__ __forceinline__ void htab_insert(unsigned long long *tab, uint32_t ma
     }
 }
 
+// The wave kernel's form for a strand pass that already lives in the HBM table: look-up and insert are one walk of the probe sequence
+// (two dependent random lines per candidate round become one).  A key is inserted before the kernel knows whether its candidate is
+// processed at all - the MaxIter cut and the copy check come later in the round - so a lane whose candidate is cut off takes its key
+// back: the slot keeps this pass's epoch with kTombBit set, occupied for the probing of others, matching nothing.  (Epochs stay below
+// kTombBit; entries of other passes - k_heavy's included, which shares the tables - read as stale to everybody, as before.)
+constexpr uint32_t kTombBit = 0x80000000u;
+
+__device__ __forceinline__ bool htab_find_or_insert(unsigned long long *tab, uint32_t mask, uint32_t epoch, uint32_t key, uint32_t &slot)
+{
+    const unsigned long long mine = ((unsigned long long)epoch << 32) | key;
+    uint32_t h = hash_key(key, mask);
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t e = (uint32_t)(v >> 32);
+        if (e == epoch) {
+            if (v == mine) return true;             // seen
+        } else if (e != (epoch | kTombBit)) {       // stale or empty: take it
+            if (atomicCAS(&tab[h], v, mine) == v) { slot = h; return false; }
+            continue;                               // somebody else took the slot: look at it again
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ void htab_retract(unsigned long long *tab, uint32_t slot, uint32_t epoch)
+{
+    __hip_atomic_store(&tab[slot], (unsigned long long)(epoch | kTombBit) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 5-byte indexes only: two candidates of one 64-candidate round whose target starts lie a multiple of 2^32 bases apart carry the
 // same truncated key (SfxArrayV2.cpp:5932).  The reference, walking them one after the other, takes the later one for seen; the
 // hash set is only consulted for what EARLIER rounds left in it, so the round is checked against itself here.

@@ -285,11 +285,13 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     }
                     bool dup = false;
                     const uint32_t key = (uint32_t)(1 + loci - (uint32_t)lofs);       // 32-bit truncation as :5932
+                    const bool fused = HASH && spilled;          // the pass lives in the HBM table since an earlier round: look-up and insert are one walk
+                    uint32_t hslot = 0xFFFFFFFFu;               // .. and this is the slot this lane's key went into
                     if (HASH) {
                         dup = valid && lset_n != 0 && lset_contains(lset, key);
-                        if (spilled) dup = dup || (valid && htab_contains(tab, tmask, epoch, key));
                         // (a round against itself: two starts 2^32 apart in one interval; the same start reached through two cores of a group)
                         if (WIDE || (GROUP && grouped)) dup |= same_key_earlier_in_round(valid && !dup, key, lane);
+                        if (fused && valid && !dup) dup = htab_find_or_insert(tab, tmask, epoch, key, hslot);
                     } else for (int c2 = 0; c2 < ce - 1; c2++) {
                         bool m = valid && !dup && c2 < lc && im_clean<NW>(w.im, cmask[c2]);
                         if (__ballot(m)) {
@@ -325,7 +327,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         }
                     }
                     const bool proc = active && ((GROUP && grouped) || j < cutoff) && isnew;
-                    if (HASH) {
+                    if (fused) {
+                        // (the keys are in the table; that of a candidate the cuts above left unprocessed comes out again)
+                        if (hslot != 0xFFFFFFFFu && !proc) htab_retract(tab, hslot, epoch);
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (HASH) {
                         const uint32_t nins = (uint32_t)__popcll(__ballot(proc));
                         if (nins) {
                             // (the key that looks like an empty slot, one in 2^32, always goes to the HBM table)
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             if ((!to_lds || __ballot(proc && key == kLdsEmpty)) && !spilled) {
                                 spilled = true;
                                 epoch++;
-                                if (epoch == 0) {            // wrapped: really clear the table
+                                if (epoch >= kTombBit) {     // wrapped: really clear the table
                                     for (uint32_t i = lane; i < hs.tab_size; i += 64) tab[i] = 0;
                                     epoch = 1;
                                     __builtin_amdgcn_wave_barrier();
