@@ -1183,7 +1183,8 @@ int cmd_align(int argc, char **argv, int first)
     else rc = load_reads(a.v["i"], o.trim5, o.trim3, o.min_len, o.max_len, parse_threads, rs);
     // .. and, still behind the index load: the reads packed for the boundary, the result array page-locked
     AlignedSet A;
-    struct Unlock { Submission &S; ~Unlock() { S.release_results(); } } unlock_results{S};        // (before A's records are freed: declared after A)
+    // (declared after the read store and A: runs before either goes - the releaser thread may still be giving the read store's bases back)
+    struct Unlock { Submission &S; ~Unlock() { if (S.releaser.joinable()) S.releaser.join(); S.release_results(); } } unlock_results{S};
     if (!rc && rs.size()) rc = prepare_submission(o, rs, ndev, long_run, A, S);
     if (!rc && pre_early) pre.add_threads(2);       // (two while the parser's threads allocate their own memory, four from here on)
     { HostClock jc; for (auto &t : loaders) t.join(); jc.lap("waited for the index image"); }
