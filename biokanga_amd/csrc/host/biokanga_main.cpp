@@ -418,6 +418,155 @@ int load_reads(const std::vector<std::string> &files, int trim5, int trim3, int 
 
 // paired end loading: PE1/PE2 records in lockstep, both ends must pass the length acceptance
 // (Aligner.cpp:11080-11130); stored interleaved PE1, PE2
+// The paired loader's loop over two whole-file parses, by all threads: records i of the two files are the mates of pair i, a pair is
+// kept when both mates pass the length rules (the first failing mate decides which counter it goes to), kept pairs are laid out PE1, PE2,
+// PE1, PE2 .. with their bases and names back to back - what the serial loop below produces record by record at 60 ns each (2.5 s of a
+// 20 M-pair run).  Prefix sums over blocks of pairs give every piece of either file its place; each piece's thread places its own records.
+// Returns 0, a negative code after the message the serial loop would have printed, or 1 when the files are not eligible (then the
+// serial loop runs).
+int accept_pairs(bk::ParsedFile &fa, bk::ParsedFile &fb, const std::string &na, const std::string &nb, int trim5, int trim3, int min_len, int max_len,
+                 int nthreads, ReadStore &rs)
+{
+    bk::ParsedFile *F[2] = {&fa, &fb};
+    size_t nc[2], N[2];
+    std::vector<uint64_t> r0[2];                   // first record number of every piece
+    for (int e = 0; e < 2; e++) {
+        nc[e] = F[e]->chunks.size();
+        r0[e].assign(nc[e] + 1, 0);
+        for (size_t c = 0; c < nc[e]; c++) r0[e][c + 1] = r0[e][c] + F[e]->chunks[c].lens.size();
+        N[e] = r0[e][nc[e]];
+    }
+    if (N[0] == 0 || N[0] >= 0xFFFFFFFFull) return 1;
+    if (N[1] < N[0]) return 1;                     // (the serial loop says where the second file ends)
+    const size_t P = N[0];                         // pairs (surplus records of the second file are never looked at)
+    bool sim[2] = {false, false};
+    for (int e = 0; e < 2; e++)
+        for (const auto &c : F[e]->chunks)
+            if (!c.lens.empty()) {
+                const size_t dl = std::min<size_t>(c.descr_lens[0], 127);
+                sim[e] = dl >= 14 && (!strncmp(c.descr, "lcl|usimreads|", 14) || !strncmp(c.descr, "lcr|usimreads|", 14));
+                break;
+            }
+    // per record: status (0 kept so far, 1 under length, 2 over length, 3 unusable), kept bases, name length + 1
+    bk::RawVec<uint8_t> st[2], nl[2];
+    bk::RawVec<uint32_t> kl[2];
+    for (int e = 0; e < 2; e++) { st[e].resize(P); nl[e].resize(P); kl[e].resize(P); }
+    auto run = [&](size_t n_items, auto fn_) {
+        std::vector<std::thread> th;
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n_items;) fn_(i); };
+        for (int w = 1; w < nthreads; w++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    };
+    run(nc[0] + nc[1], [&](size_t item) {
+        // (copies of what the record loop reads: see accept_chunks)
+        const int e = item < nc[0] ? 0 : 1;
+        const bk::ParsedChunk &c = F[e]->chunks[item - (e ? nc[0] : 0)];
+        const uint64_t g0 = r0[e][item - (e ? nc[0] : 0)];
+        const int t5 = trim5, t3 = trim3, mn = min_len, mx = max_len;
+        const bool sim_ = sim[e];
+        const uint32_t *lens_ = c.lens.data(), *dlens_ = c.descr_lens.data();
+        const char *descr_ = c.descr;
+        uint8_t *st_ = st[e].data(), *nl_ = nl[e].data();
+        uint32_t *kl_ = kl[e].data();
+        const size_t n_rec = c.lens.size(), pairs = P;
+        size_t dofs = 0;
+        for (size_t i = 0; i < n_rec && g0 + i < pairs; i++) {
+            const int len = (int)lens_[i];
+            size_t dl = dlens_[i];
+            uint8_t s = 0;
+            if (len < 1 || len > 0x30000) s = 3;
+            else if (t5 + t3 + mn > len) s = 1;
+            else if (t5 + t3 + mx < len) s = 2;
+            if (dl > 127) dl = 127;
+            size_t q = dl;
+            if (!sim_) { q = 0; while (q < 79 && q < dl && !isspace((unsigned char)descr_[dofs + q])) q++; }
+            st_[g0 + i] = s;
+            nl_[g0 + i] = (uint8_t)(q + 1);
+            kl_[g0 + i] = s == 0 ? (uint32_t)(len - t5 - t3) : 0u;
+            dofs += dlens_[i];
+        }
+    });
+    // pairs in blocks: kept pairs, their bases and name bytes, the counters, the first unusable record
+    const size_t kBlock = 65536, nblk = (P + kBlock - 1) / kBlock;
+    struct Blk { uint64_t kept = 0, bases = 0, names = 0, under = 0, over = 0; long bad = -1; };
+    std::vector<Blk> blk(nblk);
+    run(nblk, [&](size_t b) {
+        const uint8_t *sa = st[0].data(), *sb = st[1].data(), *la = nl[0].data(), *lb = nl[1].data();
+        const uint32_t *ka = kl[0].data(), *kb = kl[1].data();
+        Blk t;
+        const size_t lo = b * kBlock, hi = std::min(P, lo + kBlock);
+        for (size_t i = lo; i < hi; i++) {
+            const uint8_t a = sa[i], z = sb[i];
+            if (a == 3 || z == 3) { if (t.bad < 0) t.bad = (long)i; continue; }
+            if (a == 1) t.under++;
+            else if (a == 2) t.over++;
+            else if (z == 1) t.under++;
+            else if (z == 2) t.over++;
+            else { t.kept++; t.bases += (uint64_t)ka[i] + kb[i]; t.names += (uint64_t)la[i] + lb[i]; }
+        }
+        blk[b] = t;
+    });
+    uint64_t n_under = 0, n_over = 0;
+    std::vector<uint64_t> k0(nblk + 1, 0), b0(nblk + 1, 0), m0(nblk + 1, 0);
+    for (size_t b = 0; b < nblk; b++) {
+        if (blk[b].bad >= 0) { diag("Problem parsing sequence after %u reads parsed", (uint32_t)(blk[b].bad + 1)); return -63; }
+        k0[b + 1] = k0[b] + blk[b].kept; b0[b + 1] = b0[b] + blk[b].bases; m0[b + 1] = m0[b] + blk[b].names;
+        n_under += blk[b].under; n_over += blk[b].over;
+    }
+    const uint64_t K = k0[nblk];
+    const uint64_t rd_at = rs.lens.size(), bs_at = rs.bases.size(), nm_at = rs.names.size();
+    rs.lens.resize(rd_at + 2 * K); rs.offs.resize(rd_at + 2 * K); rs.name_ofs.resize(rd_at + 2 * K);
+    rs.bases.resize(bs_at + b0[nblk]);
+    rs.names.resize(nm_at + m0[nblk]);
+    rs.used_bases = 0;
+    // placement: every piece of either file walks its records with the running place of their pairs
+    run(nc[0] + nc[1], [&](size_t item) {
+        const int e = item < nc[0] ? 0 : 1;
+        const bk::ParsedChunk &c = F[e]->chunks[item - (e ? nc[0] : 0)];
+        const uint64_t g0 = r0[e][item - (e ? nc[0] : 0)];
+        if (g0 >= P) return;
+        const uint8_t *sa = st[0].data(), *sb = st[1].data(), *la = nl[0].data(), *lb = nl[1].data();
+        const uint32_t *ka = kl[0].data(), *kb = kl[1].data();
+        const uint32_t *lens_ = c.lens.data(), *dlens_ = c.descr_lens.data();
+        const uint8_t *cbases = c.bases;
+        const char *descr_ = c.descr;
+        const uint32_t t5 = (uint32_t)trim5;
+        uint32_t *o_lens = rs.lens.data() + rd_at;
+        uint64_t *o_offs = rs.offs.data() + rd_at, *o_nofs = rs.name_ofs.data() + rd_at;
+        uint8_t *o_bases = rs.bases.data();
+        char *o_names = rs.names.data();
+        // place of pair g0: its block's, plus the kept pairs of the block in front of it
+        const size_t b = g0 / kBlock;
+        uint64_t k = k0[b], bo = bs_at + b0[b], mo = nm_at + m0[b];
+        for (size_t i = b * kBlock; i < g0; i++)
+            if (sa[i] == 0 && sb[i] == 0) { k++; bo += (uint64_t)ka[i] + kb[i]; mo += (uint64_t)la[i] + lb[i]; }
+        const size_t n_rec = c.lens.size();
+        size_t dofs = 0, sofs = 0;
+        for (size_t i = 0; i < n_rec && g0 + i < P; i++) {
+            const size_t g = g0 + i;
+            if (sa[g] == 0 && sb[g] == 0) {
+                const uint64_t r = 2 * k + (uint64_t)e;
+                const uint64_t my_b = bo + (e ? ka[g] : 0), my_m = mo + (e ? la[g] : 0);
+                const uint32_t keep = e ? kb[g] : ka[g], nlen = (uint32_t)(e ? lb[g] : la[g]) - 1;
+                o_lens[r] = keep;
+                o_offs[r] = my_b;
+                memcpy(o_bases + my_b, cbases + sofs + t5, keep);
+                o_nofs[r] = my_m;
+                memcpy(o_names + my_m, descr_ + dofs, nlen);
+                o_names[my_m + nlen] = '\0';
+                k++; bo += (uint64_t)ka[g] + kb[g]; mo += (uint64_t)la[g] + lb[g];
+            }
+            dofs += dlens_[i];
+            sofs += lens_[i];
+        }
+    });
+    diag("Load: %u pairs parsed, %u accepted, %u under length, %u over length", (uint32_t)P, (uint32_t)K, (uint32_t)n_under, (uint32_t)n_over);
+    (void)na; (void)nb;
+    return 0;
+}
+
 int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::string> &f2, int trim5, int trim3, int min_len, int max_len,
                   int nthreads, ReadStore &rs)
 {
@@ -431,6 +580,11 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
         rc = rd[1].open(f2[k], nthreads, &err);
         if (rc) { diag("Load: %s", err.c_str()); return rc; }
         diag("Loading paired end reads from '%s' and '%s'", f1[k].c_str(), f2[k].c_str());
+        if (rd[0].parsed() && rd[1].parsed() && g_sample_nth <= 1) {
+            rc = accept_pairs(rd[0].file(), rd[1].file(), f1[k], f2[k], trim5, trim3, min_len, max_len, nthreads, rs);
+            if (rc < 0) return rc;
+            if (rc == 0) continue;
+        }
         const char *d[2];
         const uint8_t *b[2];
         size_t dl[2], bl[2];

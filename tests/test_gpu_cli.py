@@ -685,6 +685,39 @@ def test_sam_formatted_on_the_device_byte_identical(golden_tmp, tmp_path, case):
     assert open(out, "rb").read() == golden_bytes(*gold)
 
 
+def test_paired_files_accepted_by_all_threads_like_the_serial_loader(golden_tmp, tmp_path):
+    """plain-text mate files of more than 1 MB are parsed whole and their pairs accepted by all threads (accept_pairs); -T1 keeps the
+    record-by-record loop: same SAM, same load line - with mates that fail the length rules on either side in the mix"""
+    d = golden_tmp["basic"]
+    pe = os.path.join(helpers.GOLDEN, "pe")
+    recs = []
+    for fn in ("reads_1.fa.gz", "reads_2.fa.gz"):
+        txt = gzip.open(os.path.join(pe, fn), "rt").read().split(">")[1:]
+        recs.append([(r.split("\n", 1)[0], "".join(r.split("\n")[1:])) for r in txt])
+    files = [str(tmp_path / "big_1.fa"), str(tmp_path / "big_2.fa")]
+    copies = 1 + (1 << 21) // (len(recs[0]) * 120)
+    for e in (0, 1):
+        with open(files[e], "w") as f:
+            k = 0
+            for c in range(copies):
+                for name, seq in recs[e]:
+                    k += 1
+                    if k % 11 == 3 and e == 0: seq = seq[:30]                  # first mate under length
+                    if k % 13 == 5 and e == 1: seq = seq[:20]                  # second mate under length
+                    if k % 17 == 7 and e == 1: seq = seq * 7                   # second mate over length
+                    f.write(f">{name}_{c}\n{seq}\n")
+        assert os.path.getsize(files[e]) > (1 << 20)
+    outs, loads = [], []
+    for T in ("1", "8"):
+        out = str(tmp_path / f"t{T}.sam")
+        log = run(["align", "-i", files[0], "-u", files[1], "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-U3", "-d200", "-D400", "-s5", f"-T{T}"], str(tmp_path))
+        outs.append(open(out, "rb").read())
+        loads.append([l.split("](biokanga) ", 1)[1] for l in log.splitlines() if "pairs parsed" in l])
+    assert loads[0] == loads[1] and loads[0], loads
+    assert " 0 under length" not in loads[0][0] and " 0 over length" not in loads[0][0]
+    assert outs[0] == outs[1] and len(outs[0]) > (1 << 20)
+
+
 def test_device_declines_after_its_head_start(golden_tmp, tmp_path):
     """the packed reads are on the device, the read store's bases and the packed buffers have been given back - and then the device
     declines (forced): the host formatter loads the reads again and writes the same file"""
