@@ -64,8 +64,18 @@ int SeqReader::open(const std::string &path, std::string *err)
     return 0;
 }
 
+void SeqReader::stop_ahead()
+{
+    if (!ahead_) return;
+    { std::lock_guard<std::mutex> lk(ahead_->mu); ahead_->stop = true; }
+    ahead_->cv.notify_all();
+    if (ahead_->th.joinable()) ahead_->th.join();
+    ahead_.reset();
+}
+
 void SeqReader::close()
 {
+    stop_ahead();
     if (gz_) gzclose(gz_);
     gz_ = nullptr;
 }
@@ -73,7 +83,40 @@ void SeqReader::close()
 int SeqReader::fill()
 {
     if (eof_) return 0;
-    int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+    if (!ahead_) {
+        // the first buffer is read here; from the second on a thread reads one buffer ahead (only it touches gz_ from now on)
+        int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) { eof_ = true; len_ = pos_ = 0; return n < 0 ? -85 : 0; }
+        len_ = (size_t)n;
+        pos_ = 0;
+        if ((size_t)n == buf_.size()) {              // (a file that fits one buffer needs no thread)
+            ahead_.reset(new Ahead());
+            Ahead *a = ahead_.get();
+            a->buf.resize(buf_.size());
+            a->want = true;
+            gzFile gz = gz_;
+            a->th = std::thread([a, gz]() {
+                for (;;) {
+                    { std::unique_lock<std::mutex> lk(a->mu); a->cv.wait(lk, [&] { return a->want || a->stop; }); if (a->stop) return; a->want = false; }
+                    const int got = gzread(gz, a->buf.data(), (unsigned)a->buf.size());
+                    { std::lock_guard<std::mutex> lk(a->mu); a->n = got; a->ready = true; }
+                    a->cv.notify_all();
+                    if (got <= 0) return;
+                }
+            });
+        }
+        return n;
+    }
+    Ahead *a = ahead_.get();
+    int n;
+    {
+        std::unique_lock<std::mutex> lk(a->mu);
+        a->cv.wait(lk, [&] { return a->ready; });
+        a->ready = false;
+        n = a->n;
+        if (n > 0) { buf_.swap(a->buf); a->want = true; }
+    }
+    a->cv.notify_all();
     if (n <= 0) { eof_ = true; len_ = pos_ = 0; return n < 0 ? -85 : 0; }
     len_ = (size_t)n;
     pos_ = 0;

@@ -8,7 +8,11 @@
 #pragma once
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -37,6 +41,18 @@ private:
     int getc_();
     void ungetc_() { --pos_; }
     gzFile gz_ = nullptr;
+    // the next buffer is inflated by a thread of the reader's own while the parser works through the current one: inflate is nine tenths
+    // of a gzip'd file's ingest, and the mate files of a paired run inflate side by side
+    struct Ahead {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<uint8_t> buf;
+        int n = 0;
+        bool ready = false, want = false, stop = false;
+    };
+    std::unique_ptr<Ahead> ahead_;
+    void stop_ahead();
     std::vector<uint8_t> buf_;
     size_t pos_ = 0, len_ = 0;
     bool eof_ = false, fastq_ = false, started_ = false;

@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     std::string d;
     std::vector<uint8_t> b;
     unsigned long n = 0, nbases = 0;
+    unsigned long long sum = 1469598103934665603ULL;                      // FNV-1a over every descriptor and base: the same for a file and its gzip'd copy
     for (;;) {
         int r1 = rd.next(d, b);
         const char *pd; const uint8_t *pb; size_t dl, bl;
@@ -46,7 +47,9 @@ int main(int argc, char **argv)
         }
         n++;
         nbases += bl;
+        for (size_t i = 0; i < dl; i++) sum = (sum ^ (unsigned char)pd[i]) * 1099511628211ULL;
+        for (size_t i = 0; i < bl; i++) sum = (sum ^ pb[i]) * 1099511628211ULL;
     }
-    printf("OK records %lu bases %lu parallel %d pieces %zu\n", n, nbases, handled, probe.chunks.size());
+    printf("OK records %lu bases %lu sum %016llx parallel %d pieces %zu\n", n, nbases, sum, handled, probe.chunks.size());
     return 0;
 }

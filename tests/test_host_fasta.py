@@ -93,3 +93,26 @@ def test_output_file_pages_made_in_the_background(tmp_path_factory, est):
     finally:
         if os.path.exists(f):
             os.unlink(f)
+
+
+def test_gzip_read_ahead_gives_the_plain_files_records(harness, tmp_path):
+    """a gzip'd file larger than the reader's buffer is inflated one buffer ahead by a thread of the reader's own: same records, byte for
+    byte, as the plain file (FASTA over several buffers, FASTQ with its four-line records across buffer ends)"""
+    import gzip
+    fa = str(tmp_path / "big.fa")
+    nasty_fasta(fa, 60000, seed=5)
+    assert os.path.getsize(fa) > (9 << 20)                       # more than two 4 MB buffers
+    fq = str(tmp_path / "big.fq")
+    rng = np.random.default_rng(3)
+    with open(fq, "wb") as f:
+        for i in range(120000):
+            L = int(rng.integers(30, 151))
+            f.write(b"@q%d extra\n" % i + np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, L)].tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    for plain in (fa, fq):
+        gz = plain + ".gz"
+        with open(plain, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+            g.write(f.read())
+        a = subprocess.check_output([harness, plain, "1"]).decode()
+        b = subprocess.check_output([harness, gz, "1"]).decode()
+        assert a.startswith("OK") and b.startswith("OK"), (a, b)
+        assert a.split("parallel")[0] == b.split("parallel")[0], (a, b)      # records, bases, checksum
