@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cctype>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -310,9 +311,124 @@ const uint8_t *next_record_start(const uint8_t *base, const uint8_t *q, const ui
     return end;
 }
 
+
+// ---- FASTQ, the same way ----------------------------------------------------------------------------------------------------------
+// SeqReader::next's FASTQ state machine over [p, e), p a record start: '@' id line, ONE sequence line of a,c,g,t,n (either case), '+' line,
+// ONE quality line of the sequence's length; blank lines between the elements are sloughed.  Anything the serial reader would refuse -
+// and anything this form does not want to decide (a record cut by e) - makes the piece give up: the file then goes through the serial
+// reader, which says what is wrong and where.
+inline bool fq_bad_chr(uint8_t c) { return !isspace(c) && (c < 0x20 || c > 0x7f); }
+
+inline uint8_t fq_score_nibble(int q, int qmode)
+{
+    int ph;
+    switch (qmode) {
+    case 0: if (q < 33) q = 33; else if (q >= 126) q = 125; ph = q - 33; break;
+    case 1: if (q < 64) q = 64; else if (q >= 126) q = 125; ph = q - 64; break;
+    default:
+        if (q < 59 || q >= 126) q = q < 64 ? 64 : 125;
+        ph = q - 59;
+        ph = (int)(uint8_t)(10 * log(1 + pow(10.0, ((double)ph / 10.0) / log(10.0))));
+        break;
+    }
+    if (ph > 40) ph = 40;
+    return (uint8_t)((((uint32_t)ph + 2) * 15) / 40);
+}
+
+bool parse_fastq_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, int qmode, ParsedChunk &out)
+{
+    const size_t approx = (size_t)(e - p);
+    out.bases = bw;
+    out.lens.reserve(approx / 200 + 16);
+    out.descr_lens.reserve(approx / 200 + 16);
+    RawVec<char> &dv = out.descr_own;
+    dv.resize(approx / 6 + 256);
+    size_t dn = 0;
+    uint8_t score[256];
+    if (qmode != 3) for (int q = 0; q < 256; q++) score[q] = (uint8_t)(fq_score_nibble(q, qmode) << 4);
+    for (;;) {
+        while (p < e && isspace(*p)) p++;
+        if (p >= e) break;
+        if (*p != '@') return false;
+        p++;
+        // id line
+        const uint8_t *q = p;
+        while (q < e && *q != '\n' && *q != '\r') { if (fq_bad_chr(*q)) return false; q++; }
+        if (q >= e) return false;
+        size_t dl = std::min<size_t>((size_t)(q - p), 8192);               // cMaxFastaDescrLen
+        if (dn + dl > dv.size()) dv.resize(std::max(dv.size() * 2, dn + dl + 256));
+        memcpy(dv.data() + dn, p, dl);
+        p = q;
+        // sequence line (leading blank lines sloughed)
+        while (p < e && (*p == '\n' || *p == '\r')) p++;
+        uint8_t *b0 = bw;
+        size_t nb = 0;
+        while (p < e && *p != '\n' && *p != '\r') {
+            const uint8_t c = *p++;
+            uint8_t v;
+            switch (c) {
+            case 'a': v = 0 | 8; break; case 'A': v = 0; break;
+            case 'c': v = 1 | 8; break; case 'C': v = 1; break;
+            case 'g': v = 2 | 8; break; case 'G': v = 2; break;
+            case 't': v = 3 | 8; break; case 'T': v = 3; break;
+            case 'n': case 'N': v = 4; break;
+            default: return false;
+            }
+            if (nb < 0x30000) { *bw++ = v; nb++; }                          // cMaxFastQSeqLen: silently truncated
+        }
+        if (p >= e) return false;
+        // '+' line
+        while (p < e && (*p == '\n' || *p == '\r')) p++;
+        if (p >= e || *p != '+') return false;
+        p++;
+        while (p < e && *p != '\n' && *p != '\r') { if (fq_bad_chr(*p)) return false; p++; }
+        if (p >= e) return false;
+        // quality line (leading blank lines sloughed); the file's last line may end without a line break
+        while (p < e && (*p == '\n' || *p == '\r')) p++;
+        size_t nq = 0;
+        while (p < e && *p != '\n' && *p != '\r') {
+            const uint8_t c = *p++;
+            if (fq_bad_chr(c)) return false;
+            if (nq < 0x30000) { if (qmode != 3 && nq < nb) b0[nq] |= score[c]; nq++; }
+        }
+        if (dl == 0 || nb == 0 || nq != nb) return false;
+        dn += dl;
+        out.descr_lens.push_back((uint32_t)dl);
+        out.lens.push_back((uint32_t)nb);
+    }
+    out.descr = dv.data();
+    return true;
+}
+
+// first record start at or after q: a line that begins with '@', followed by a line of nothing but a,c,g,t,n, a line that begins with
+// '+', and a line of the sequence line's length - in a file of such records no other line passes (the one quality line that may begin with
+// '@' is followed by an id line, which is no sequence)
+const uint8_t *next_fastq_record(const uint8_t *base, const uint8_t *q, const uint8_t *end)
+{
+    auto line_end = [&](const uint8_t *x) { while (x < end && *x != '\n' && *x != '\r') x++; return x; };
+    auto next_line = [&](const uint8_t *x) { while (x < end && (*x == '\n' || *x == '\r')) x++; return x; };
+    // to the start of a line
+    while (q > base && q[-1] != '\n' && q[-1] != '\r') q--;
+    for (int tries = 0; q < end && tries < 64; tries++) {
+        q = next_line(q);
+        if (q >= end) return end;
+        if (*q == '@') {
+            const uint8_t *l1e = line_end(q), *l2 = next_line(l1e), *l2e = line_end(l2), *l3 = next_line(l2e), *l3e = line_end(l3), *l4 = next_line(l3e), *l4e = line_end(l4);
+            bool ok = l2 < l2e && l3 < end && *l3 == '+' && (l4e - l4) == (l2e - l2);
+            for (const uint8_t *x = l2; ok && x < l2e; x++) {
+                const uint8_t c = (uint8_t)(*x | 0x20);
+                ok = c == 'a' || c == 'c' || c == 'g' || c == 't' || c == 'n';
+            }
+            if (ok) return q;
+        }
+        q = line_end(q);
+    }
+    return nullptr;                                     // nothing like a record near here: the serial reader takes the file
+}
+
 }  // namespace
 
-int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err)
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode)
 {
     out.chunks.clear();
     int fd = ::open(path.c_str(), O_RDONLY);
@@ -329,31 +445,39 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     const uint8_t *base = (const uint8_t *)m, *end = base + size;
     const uint8_t *p = base;
     while (p < end && isspace(*p)) p++;
-    if ((base[0] == 0x1f && base[1] == 0x8b) || p >= end || *p != '>') { munmap(m, size); return 0; }
+    if ((base[0] == 0x1f && base[1] == 0x8b) || p >= end || (*p != '>' && *p != '@')) { munmap(m, size); return 0; }
+    const bool fastq = *p == '@';
     if (nthreads < 1) nthreads = 1;
     size_t pieces = (size_t)nthreads * 4;                 // a few pieces per thread evens out the tail
     if (pieces > size / (256 << 10) + 1) pieces = size / (256 << 10) + 1;
     std::vector<const uint8_t *> cut(pieces + 1);
     cut[0] = p;
     cut[pieces] = end;
-    for (size_t t = 1; t < pieces; t++) cut[t] = next_record_start(base, base + size / pieces * t, end);
+    for (size_t t = 1; t < pieces; t++) {
+        cut[t] = fastq ? next_fastq_record(base, base + size / pieces * t, end) : next_record_start(base, base + size / pieces * t, end);
+        if (cut[t] == nullptr) { munmap(m, size); return 0; }
+    }
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     out.chunks.resize(pieces);
     out.bases.resize(size + 64);                          // (sized, not touched: the pieces' own pages are the only ones that become real)
+    std::atomic<int> gave_up{0};
     std::vector<std::thread> th;
     for (int w = 0; w < nthreads; w++)
         th.emplace_back([&, w]() {
-            for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads)
-                parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.chunks[t]);
+            for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads) {
+                if (!fastq) parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.chunks[t]);
+                else if (!parse_fastq_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), qmode, out.chunks[t])) gave_up = 1;
+            }
         });
     for (auto &t : th) t.join();
     munmap(m, size);
+    if (gave_up) { out.chunks.clear(); RawVec<uint8_t>().swap(out.bases); return 0; }      // (the serial reader says what is wrong, and where)
     return 1;
 }
 
 int RecordStream::open(const std::string &path, int nthreads, std::string *err)
 {
-    int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, file_, err) : 0;
+    int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, file_, err, rd_.quality_mode()) : 0;
     if (rc < 0) return rc;
     parsed_ = rc == 1;
     ci_ = ri_ = bo_ = dofs_ = 0;

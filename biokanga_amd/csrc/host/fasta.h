@@ -35,6 +35,7 @@ public:
     // 2 Solexa, 3 ignore (default).  Unless ignored, the score of every base is reduced to 4 bits, ((Qphred + 2) * 15) / 40, and
     // travels in bits 4..7 of the base's byte - where the reference keeps it.
     void set_quality_mode(int m) { qmode_ = m; }
+    int quality_mode() const { return qmode_; }
 
 private:
     int fill();
@@ -79,11 +80,12 @@ struct ParsedFile {
     std::vector<ParsedChunk> chunks;
 };
 
+// (FASTQ files go the same way: pieces cut at records whose four lines check out, scores - unless qmode is 3 - into bits 4..7.)
 // Parses a whole plain-text (not gzip'd) FASTA file with `nthreads` threads: the file is mapped, cut at
 // record starts (the first '>' of a line) and every piece goes through the same state machine as
 // SeqReader::next.  Returns 1 and fills `out` when it handled the file, 0 when the file is not eligible
 // (gzip, FASTQ, tiny: use SeqReader), < 0 on error.
-int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err);
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode = 3);
 
 // One stream of records, from either source.
 class RecordStream {

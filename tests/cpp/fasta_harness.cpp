@@ -12,7 +12,8 @@ int main(int argc, char **argv)
     if (argc != 3 && argc != 4) return 2;
     const int nthreads = atoi(argv[2]);
     std::string err;
-    if (argc == 4) {                               // "time": the parallel parser alone, three times
+    const int qmode = (argc == 4 && argv[3][0] == 'q') ? atoi(argv[3] + 1) : 3;      // "q0" .. "q3": how FASTQ scores are kept (-g)
+    if (argc == 4 && argv[3][0] != 'q') {          // "time": the parallel parser alone, three times
         for (int k = 0; k < 3; k++) {
             timespec t0, t1;
             clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -26,11 +27,13 @@ int main(int argc, char **argv)
         return 0;
     }
     bk::SeqReader rd;
+    rd.set_quality_mode(qmode);
     if (rd.open(argv[1], &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
     bk::RecordStream rs;
+    rs.set_quality_mode(qmode);
     if (rs.open(argv[1], nthreads, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
     bk::ParsedFile probe;
-    int handled = bk::parse_fasta_parallel(argv[1], nthreads, probe, &err);
+    int handled = bk::parse_fasta_parallel(argv[1], nthreads, probe, &err, qmode);
     std::string d;
     std::vector<uint8_t> b;
     unsigned long n = 0, nbases = 0;

@@ -718,6 +718,27 @@ def test_paired_files_accepted_by_all_threads_like_the_serial_loader(golden_tmp,
     assert outs[0] == outs[1] and len(outs[0]) > (1 << 20)
 
 
+@pytest.mark.parametrize("g", ["0", "3"])
+def test_plain_fastq_parsed_by_all_threads_like_the_serial_reader(golden_tmp, tmp_path, g):
+    """a plain FASTQ file of more than 1 MB is parsed whole by all threads, scores packed as -g asks; -T1 keeps the serial reader: same SAM
+    (QUAL included), same load line"""
+    d = golden_tmp["basic"]
+    txt = gzip.open(os.path.join(helpers.GOLDEN, "basic", "reads.fq.gz"), "rb").read()
+    fq = str(tmp_path / "big.fq")
+    with open(fq, "wb") as f:
+        for c in range(1 + (3 << 20) // len(txt)):
+            f.write(txt)
+    assert os.path.getsize(fq) > (2 << 20)
+    outs, loads = [], []
+    for T in ("1", "8"):
+        out = str(tmp_path / f"t{T}.sam")
+        log = run(["align", "-i", fq, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3", f"-g{g}", f"-T{T}"], str(tmp_path))
+        outs.append(open(out, "rb").read())
+        loads.append([l.split("](biokanga) ", 1)[1] for l in log.splitlines() if "reads parsed" in l])
+    assert loads[0] == loads[1] and loads[0], loads
+    assert outs[0] == outs[1] and len(outs[0]) > (1 << 20)
+
+
 def test_device_declines_after_its_head_start(golden_tmp, tmp_path):
     """the packed reads are on the device, the read store's bases and the packed buffers have been given back - and then the device
     declines (forced): the host formatter loads the reads again and writes the same file"""
