@@ -319,6 +319,22 @@ const uint8_t *next_record_start(const uint8_t *base, const uint8_t *q, const ui
 // reader, which says what is wrong and where.
 inline bool fq_bad_chr(uint8_t c) { return !isspace(c) && (c < 0x20 || c > 0x7f); }
 
+// no character of [p, p + n) is one the reader refuses (eight at a time: a byte below 0x20 or above 0x7f sends the stretch to the exact test)
+inline bool fq_clean(const uint8_t *p, size_t n)
+{
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, p + i, 8);
+        // high bit set, or a byte below 0x20 (the subtraction borrows into bit 7 of such a byte; bytes with the high bit set are caught by the first test)
+        if ((x & 0x8080808080808080ULL) || ((x - 0x2020202020202020ULL) & ~x & 0x8080808080808080ULL)) {
+            for (size_t k = i; k < i + 8; k++) if (fq_bad_chr(p[k])) return false;
+        }
+    }
+    for (; i < n; i++) if (fq_bad_chr(p[i])) return false;
+    return true;
+}
+
 inline uint8_t fq_score_nibble(int q, int qmode)
 {
     int ph;
@@ -352,9 +368,10 @@ bool parse_fastq_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, int qmod
         if (*p != '@') return false;
         p++;
         // id line
-        const uint8_t *q = p;
-        while (q < e && *q != '\n' && *q != '\r') { if (fq_bad_chr(*q)) return false; q++; }
-        if (q >= e) return false;
+        const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) return false;
+        if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(q - p))) q = cr;
+        if (!fq_clean(p, (size_t)(q - p))) return false;
         size_t dl = std::min<size_t>((size_t)(q - p), 8192);               // cMaxFastaDescrLen
         if (dn + dl > dv.size()) dv.resize(std::max(dv.size() * 2, dn + dl + 256));
         memcpy(dv.data() + dn, p, dl);
@@ -364,6 +381,13 @@ bool parse_fastq_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, int qmod
         uint8_t *b0 = bw;
         size_t nb = 0;
         while (p < e && *p != '\n' && *p != '\r') {
+            // (32 letters of a,c,g,t at a time, as in the FASTA pieces; an N, the line's end or anything else goes the exact way)
+            if (g_have_avx2 && p + 32 <= e && nb + 32 <= 0x30000) {
+                const unsigned k = acgt_run32(p, bw);
+                p += k; bw += k; nb += k;
+                if (k == 32) continue;
+                if (p >= e || *p == '\n' || *p == '\r') break;
+            }
             const uint8_t c = *p++;
             uint8_t v;
             switch (c) {
@@ -381,15 +405,25 @@ bool parse_fastq_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, int qmod
         while (p < e && (*p == '\n' || *p == '\r')) p++;
         if (p >= e || *p != '+') return false;
         p++;
-        while (p < e && *p != '\n' && *p != '\r') { if (fq_bad_chr(*p)) return false; p++; }
-        if (p >= e) return false;
+        {
+            const uint8_t *z = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+            if (!z) return false;
+            if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(z - p))) z = cr;
+            if (!fq_clean(p, (size_t)(z - p))) return false;
+            p = z;
+        }
         // quality line (leading blank lines sloughed); the file's last line may end without a line break
         while (p < e && (*p == '\n' || *p == '\r')) p++;
         size_t nq = 0;
-        while (p < e && *p != '\n' && *p != '\r') {
-            const uint8_t c = *p++;
-            if (fq_bad_chr(c)) return false;
-            if (nq < 0x30000) { if (qmode != 3 && nq < nb) b0[nq] |= score[c]; nq++; }
+        {
+            const uint8_t *z = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+            if (!z) z = e;
+            if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(z - p))) z = cr;
+            const size_t n = (size_t)(z - p);
+            if (!fq_clean(p, n)) return false;
+            nq = std::min<size_t>(n, 0x30000);
+            if (qmode != 3) for (size_t i = 0; i < nq && i < nb; i++) b0[i] |= score[p[i]];
+            p = z;
         }
         if (dl == 0 || nb == 0 || nq != nb) return false;
         dn += dl;
