@@ -462,6 +462,71 @@ const uint8_t *next_fastq_record(const uint8_t *base, const uint8_t *q, const ui
 
 }  // namespace
 
+// A bgzip'd file (the BGZF framing of SAMtools' bgzip: gzip members of <= 64 KB that carry their own size in a 'BC' extra field) is
+// the one gzip layout whose members can be found without inflating: walk the headers, then every thread inflates members of its
+// own straight to their place in the text.  Anything else - an ordinary .gz, a member without the field, a size, length or CRC-32
+// that does not hold - is not ours: false, and the serial reader (gzread) takes the file and says what it finds.
+static bool inflate_bgzf(const uint8_t *base, size_t size, int nthreads, RawVec<uint8_t> &text)
+{
+    struct Member { size_t src, clen, dst; uint32_t isize, crc; };
+    std::vector<Member> mem;
+    size_t o = 0, total = 0;
+    while (o < size) {
+        if (size - o < 28) return false;
+        const uint8_t *h = base + o;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;
+        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+        if (12 + xlen + 8 > size - o) return false;
+        size_t bsize = 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *f = h + 12 + x;
+            const size_t slen = (size_t)f[2] | ((size_t)f[3] << 8);
+            if (x + 4 + slen > xlen) return false;
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2) bsize = ((size_t)f[4] | ((size_t)f[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > size - o) return false;
+        auto le32 = [](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+        Member m{o + 12 + xlen, bsize - 12 - xlen - 8, total, le32(h + bsize - 4), le32(h + bsize - 8)};
+        mem.push_back(m);
+        total += m.isize;
+        o += bsize;
+    }
+    if (total < (1u << 20)) return false;
+    text.resize(total + 64);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::thread> th;
+    for (int w = 0; w < nthreads; w++)
+        th.emplace_back([&]() {
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) { bad = 1; return; }
+            for (;;) {
+                const size_t i0 = next.fetch_add(16);
+                if (i0 >= mem.size() || bad) break;
+                for (size_t i = i0; i < std::min(mem.size(), i0 + 16); i++) {
+                    const Member &m = mem[i];
+                    uint8_t *dst = text.data() + m.dst;
+                    z.next_in = const_cast<Bytef *>(base + m.src);
+                    z.avail_in = (uInt)m.clen;
+                    z.next_out = dst;
+                    z.avail_out = m.isize;
+                    const int rc = inflate(&z, Z_FINISH);
+                    if (rc != Z_STREAM_END || z.avail_in != 0 || z.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, m.isize) != m.crc) { bad = 1; break; }
+                    inflateReset(&z);
+                }
+            }
+            inflateEnd(&z);
+        });
+    for (auto &t : th) t.join();
+    if (bad) { RawVec<uint8_t>().swap(text); return false; }
+    memset(text.data() + total, '\n', 64);
+    text.resize(total);
+    return true;
+}
+
 int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode)
 {
     out.chunks.clear();
@@ -471,17 +536,29 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
         return -90;
     }
     struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < (1 << 20)) { ::close(fd); return 0; }
+    if (fstat(fd, &st) != 0 || st.st_size < (64 << 10)) { ::close(fd); return 0; }
     size_t size = (size_t)st.st_size;
     void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (m == MAP_FAILED) return 0;
-    const uint8_t *base = (const uint8_t *)m, *end = base + size;
+    if (nthreads < 1) nthreads = 1;
+    const uint8_t *base = (const uint8_t *)m;
+    RawVec<uint8_t> text;                                 // a bgzip'd file's text, inflated by all threads
+    if (base[0] == 0x1f && base[1] == 0x8b) {
+        const bool ours = inflate_bgzf(base, size, nthreads, text);
+        munmap(m, size);
+        m = nullptr;
+        if (!ours) return 0;
+        base = text.data();
+        size = text.size();
+    }
+    auto unmap = [&]() { if (m) munmap(m, size); };
+    if (size < (1u << 20)) { unmap(); return 0; }
+    const uint8_t *end = base + size;
     const uint8_t *p = base;
     while (p < end && isspace(*p)) p++;
-    if ((base[0] == 0x1f && base[1] == 0x8b) || p >= end || (*p != '>' && *p != '@')) { munmap(m, size); return 0; }
+    if (p >= end || (*p != '>' && *p != '@')) { unmap(); return 0; }
     const bool fastq = *p == '@';
-    if (nthreads < 1) nthreads = 1;
     size_t pieces = (size_t)nthreads * 4;                 // a few pieces per thread evens out the tail
     if (pieces > size / (256 << 10) + 1) pieces = size / (256 << 10) + 1;
     std::vector<const uint8_t *> cut(pieces + 1);
@@ -489,7 +566,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     cut[pieces] = end;
     for (size_t t = 1; t < pieces; t++) {
         cut[t] = fastq ? next_fastq_record(base, base + size / pieces * t, end) : next_record_start(base, base + size / pieces * t, end);
-        if (cut[t] == nullptr) { munmap(m, size); return 0; }
+        if (cut[t] == nullptr) { unmap(); return 0; }
     }
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     out.chunks.resize(pieces);
@@ -504,7 +581,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
             }
         });
     for (auto &t : th) t.join();
-    munmap(m, size);
+    unmap();
     if (gave_up) { out.chunks.clear(); RawVec<uint8_t>().swap(out.bases); return 0; }      // (the serial reader says what is wrong, and where)
     return 1;
 }

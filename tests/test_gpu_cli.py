@@ -739,6 +739,27 @@ def test_plain_fastq_parsed_by_all_threads_like_the_serial_reader(golden_tmp, tm
     assert outs[0] == outs[1] and len(outs[0]) > (1 << 20)
 
 
+def test_bgzip_input_inflated_by_all_threads_like_the_plain_file(golden_tmp, tmp_path):
+    """a bgzip'd FASTQ (members that name their size) is inflated and parsed by all threads: the plain file's SAM, QUAL included, and the
+    plain file's load line; an ordinary gzip of the same text goes through gzread and gives the same again"""
+    from test_host_fasta import write_bgzf
+    d = golden_tmp["basic"]
+    txt = gzip.open(os.path.join(helpers.GOLDEN, "basic", "reads.fq.gz"), "rb").read()
+    data = txt * (1 + (3 << 20) // len(txt))
+    names = {"plain": str(tmp_path / "big.fq"), "bgzf": str(tmp_path / "big.fq.bgz"), "gz": str(tmp_path / "big.fq.gz")}
+    open(names["plain"], "wb").write(data)
+    write_bgzf(names["bgzf"], data)
+    open(names["gz"], "wb").write(gzip.compress(data, 1))
+    outs, loads = {}, {}
+    for k, path in names.items():
+        out = str(tmp_path / f"{k}.sam")
+        log = run(["align", "-i", path, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3", "-g0", "-T8"], str(tmp_path))
+        outs[k] = open(out, "rb").read()
+        loads[k] = [l.split("](biokanga) ", 1)[1].replace(path, "F") for l in log.splitlines() if "reads parsed" in l]
+    assert loads["plain"] and loads["plain"] == loads["bgzf"] == loads["gz"], loads
+    assert outs["plain"] == outs["bgzf"] == outs["gz"] and len(outs["plain"]) > (1 << 20)
+
+
 def test_device_declines_after_its_head_start(golden_tmp, tmp_path):
     """the packed reads are on the device, the read store's bases and the packed buffers have been given back - and then the device
     declines (forced): the host formatter loads the reads again and writes the same file"""

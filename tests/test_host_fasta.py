@@ -164,3 +164,67 @@ def test_a_fastq_file_the_serial_reader_refuses_is_left_to_it(harness, tmp_path)
     out = r.stdout.decode()
     # the parallel parse declines (parallel 0); both readers of the harness are then the serial one and stop at the same record with the same code
     assert "parallel 0" in out or r.returncode != 0, out
+
+
+def write_bgzf(path, data, block=0xff00, level=6, eof_block=True):
+    """the BGZF framing of SAMtools' bgzip: gzip members of <= 64 KB, each with its whole size (minus one) in a 'BC' extra field"""
+    import struct, zlib
+    with open(path, "wb") as f:
+        pieces = [data[o:o + block] for o in range(0, len(data), block)] + ([b""] if eof_block else [])
+        for piece in pieces:
+            z = zlib.compressobj(level, zlib.DEFLATED, -15)
+            c = z.compress(piece) + z.flush()
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(c) + 25))
+            f.write(c + struct.pack("<II", zlib.crc32(piece), len(piece)))
+
+
+@pytest.mark.parametrize("threads", [2, 8])
+def test_bgzip_files_are_inflated_and_parsed_by_all_threads(harness, tmp_path, threads):
+    """a bgzip'd FASTA / FASTQ names its members' sizes: inflated member by member by every thread, parsed whole like a plain file, and
+    the records are those gzread's stream gives the serial reader (the harness compares the two record by record)"""
+    fa = str(tmp_path / "big.fa")
+    nasty_fasta(fa, 30000, seed=11)
+    fq = str(tmp_path / "big.fq")
+    nasty_fastq(fq, 40000, seed=12)
+    for plain in (fa, fq):
+        data = open(plain, "rb").read()
+        assert len(data) > (2 << 20)
+        gz = plain + ".bgz"
+        write_bgzf(gz, data)
+        a = subprocess.check_output([harness, plain, str(threads)]).decode()
+        b = subprocess.check_output([harness, gz, str(threads)]).decode()
+        assert a.startswith("OK") and b.startswith("OK") and "parallel 1" in a and "parallel 1" in b, (a, b)
+        assert a.split("parallel")[0] == b.split("parallel")[0], (a, b)
+        write_bgzf(gz, data, block=777, level=1, eof_block=False)            # small members, no empty last one
+        b = subprocess.check_output([harness, gz, str(threads)]).decode()
+        assert b.startswith("OK") and "parallel 1" in b and a.split("parallel")[0] == b.split("parallel")[0], (a, b)
+
+
+def test_gzip_layouts_that_are_not_bgzip_stay_with_the_serial_reader(harness, tmp_path):
+    """ordinary members after bgzip ones, a wrong CRC-32, a wrong length, a cut-off file: not taken member by member; gzread decides"""
+    import gzip
+    fa = str(tmp_path / "big.fa")
+    nasty_fasta(fa, 30000, seed=13)
+    data = open(fa, "rb").read()
+    want = subprocess.check_output([harness, fa, "4"]).decode().split("parallel")[0]
+    gz = str(tmp_path / "mixed.gz")
+    write_bgzf(gz, data[:1 << 20], eof_block=False)
+    with open(gz, "ab") as f:
+        f.write(gzip.compress(data[1 << 20:]))
+    out = subprocess.check_output([harness, gz, "4"]).decode()
+    assert out.startswith("OK") and "parallel 0" in out and out.split("parallel")[0] == want, out
+    good = str(tmp_path / "good.bgz")
+    write_bgzf(good, data)
+    raw = bytearray(open(good, "rb").read())
+    bsize = int.from_bytes(raw[16:18], "little") + 1
+    for name, at in (("crc", bsize - 8), ("isize", bsize - 4)):
+        bad = bytearray(raw)
+        bad[at] ^= 0x55
+        q = str(tmp_path / (name + ".bgz"))
+        open(q, "wb").write(bad)
+        r = subprocess.run([harness, q, "4"], capture_output=True)
+        assert b"parallel 1" not in r.stdout, r.stdout                          # (gzread reports the damage its own way)
+    q = str(tmp_path / "cut.bgz")
+    open(q, "wb").write(raw[: len(raw) // 2 + 5])
+    r = subprocess.run([harness, q, "4"], capture_output=True)
+    assert b"parallel 1" not in r.stdout, r.stdout
