@@ -13,7 +13,8 @@ import helpers
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("f") / "fasta_harness")
     src = [os.path.join(helpers.ROOT, "tests", "cpp", "fasta_harness.cpp"),
-           os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "fasta.cpp")]
+           os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "fasta.cpp"),
+           os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host", "fast_inflate.cpp")]
     subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe] + src + ["-lz"])
     return exe
 
@@ -55,7 +56,7 @@ def test_parallel_parse_equals_serial(harness, tmp_path, threads):
     assert "parallel 1" in out and int(out.split("pieces")[1]) > 1, out
 
 
-def test_small_and_gzip_files_take_the_serial_reader(harness, tmp_path):
+def test_small_files_take_the_serial_reader_and_gzip_files_are_inflated_whole(harness, tmp_path):
     import gzip
     p = str(tmp_path / "small.fa")
     nasty_fasta(p, 50, seed=1)
@@ -66,7 +67,8 @@ def test_small_and_gzip_files_take_the_serial_reader(harness, tmp_path):
     with open(big, "rb") as f, gzip.open(gz, "wb") as g:
         g.write(f.read())
     out = subprocess.check_output([harness, gz, "4"]).decode()
-    assert out.startswith("OK") and "parallel 0" in out, out
+    assert out.startswith("OK") and "parallel 1" in out, out                    # (inflated into one buffer by fast_inflate, then parsed whole)
+    assert out.split("parallel")[0] == subprocess.check_output([harness, big, "4"]).decode().split("parallel")[0]
     fq = str(tmp_path / "r.fq")
     with open(fq, "wb") as f:
         for i in range(30000):
@@ -200,9 +202,10 @@ def test_bgzip_files_are_inflated_and_parsed_by_all_threads(harness, tmp_path, t
         assert b.startswith("OK") and "parallel 1" in b and a.split("parallel")[0] == b.split("parallel")[0], (a, b)
 
 
-def test_gzip_layouts_that_are_not_bgzip_stay_with_the_serial_reader(harness, tmp_path):
-    """ordinary members after bgzip ones, a wrong CRC-32, a wrong length, a cut-off file: not taken member by member; gzread decides"""
-    import gzip
+def test_other_gzip_layouts_are_inflated_by_one_thread_and_damaged_files_go_to_gzread(harness, tmp_path):
+    """ordinary members (after bgzip ones, with a file name in the header) are inflated into one buffer and parsed whole; a wrong CRC-32, a
+    wrong length, a cut-off file, bytes after the last member: the whole-file path declines and gzread decides"""
+    import gzip, io
     fa = str(tmp_path / "big.fa")
     nasty_fasta(fa, 30000, seed=13)
     data = open(fa, "rb").read()
@@ -210,21 +213,30 @@ def test_gzip_layouts_that_are_not_bgzip_stay_with_the_serial_reader(harness, tm
     gz = str(tmp_path / "mixed.gz")
     write_bgzf(gz, data[:1 << 20], eof_block=False)
     with open(gz, "ab") as f:
-        f.write(gzip.compress(data[1 << 20:]))
+        f.write(gzip.compress(data[1 << 20:3 << 20]))
+        buf = io.BytesIO()
+        with gzip.GzipFile(filename="a name in the header", mode="wb", fileobj=buf, compresslevel=1) as g:
+            g.write(data[3 << 20:])
+        f.write(buf.getvalue())
     out = subprocess.check_output([harness, gz, "4"]).decode()
-    assert out.startswith("OK") and "parallel 0" in out and out.split("parallel")[0] == want, out
+    assert out.startswith("OK") and "parallel 1" in out and out.split("parallel")[0] == want, out
+    with open(gz, "ab") as f:
+        f.write(b"bytes that are no gzip member")
+    r = subprocess.run([harness, gz, "4"], capture_output=True)
+    assert b"parallel 1" not in r.stdout, r.stdout
     good = str(tmp_path / "good.bgz")
     write_bgzf(good, data)
-    raw = bytearray(open(good, "rb").read())
-    bsize = int.from_bytes(raw[16:18], "little") + 1
-    for name, at in (("crc", bsize - 8), ("isize", bsize - 4)):
-        bad = bytearray(raw)
-        bad[at] ^= 0x55
-        q = str(tmp_path / (name + ".bgz"))
-        open(q, "wb").write(bad)
+    plain = gzip.compress(data, 6)
+    for kind, raw, first_end in (("bgz", bytearray(open(good, "rb").read()), None), ("gz", bytearray(plain), len(plain))):
+        end = first_end or int.from_bytes(raw[16:18], "little") + 1                 # end of the first (or only) member
+        for name, at in (("crc", end - 8), ("isize", end - 4)):
+            bad = bytearray(raw)
+            bad[at] ^= 0x55
+            q = str(tmp_path / f"{name}.{kind}")
+            open(q, "wb").write(bad)
+            r = subprocess.run([harness, q, "4"], capture_output=True)
+            assert b"parallel 1" not in r.stdout, (kind, name, r.stdout)                # (gzread reports the damage its own way)
+        q = str(tmp_path / f"cut.{kind}")
+        open(q, "wb").write(raw[: len(raw) // 2 + 5])
         r = subprocess.run([harness, q, "4"], capture_output=True)
-        assert b"parallel 1" not in r.stdout, r.stdout                          # (gzread reports the damage its own way)
-    q = str(tmp_path / "cut.bgz")
-    open(q, "wb").write(raw[: len(raw) // 2 + 5])
-    r = subprocess.run([harness, q, "4"], capture_output=True)
-    assert b"parallel 1" not in r.stdout, r.stdout
+        assert b"parallel 1" not in r.stdout, (kind, r.stdout)

@@ -15,7 +15,8 @@ from test_host_fasta import write_bgzf
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("l") / "loader_harness")
     host = os.path.join(helpers.ROOT, "biokanga_amd", "csrc", "host")
-    src = [os.path.join(helpers.ROOT, "tests", "cpp", "loader_harness.cpp"), os.path.join(host, "read_loader.cpp"), os.path.join(host, "fasta.cpp")]
+    src = [os.path.join(helpers.ROOT, "tests", "cpp", "loader_harness.cpp"), os.path.join(host, "read_loader.cpp"), os.path.join(host, "fasta.cpp"),
+           os.path.join(host, "fast_inflate.cpp")]
     subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe] + src + ["-lz"])
     return exe
 
