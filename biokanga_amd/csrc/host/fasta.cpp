@@ -15,6 +15,7 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -629,6 +630,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     const uint8_t *base = (const uint8_t *)m;
     RawVec<uint8_t> text;                                 // a gzip'd file's text: bgzip members by all threads, other layouts by one
     if (base[0] == 0x1f && base[1] == 0x8b) {
+        if (getenv("BK_GZ_SERIAL")) { munmap(m, size); return 0; }       // (measurements: the record-by-record gzread reader)
         const bool ours = inflate_bgzf(base, size, nthreads, text) || inflate_gzip(base, size, nthreads, text);
         munmap(m, size);
         m = nullptr;

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """End-to-end timing of our command line (`biokanga_amd/bin/biokanga align`) on the bench workload:
 T_e2e (process start -> exit) and the phases from its time-stamped log.  Files live in /dev/shm.
-  python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--quiet] [-- extra options of biokanga align]
-Every variant is the same command with its own environment (the first run, "default", has none); the files are written once."""
-import os, sys, time, subprocess, shutil, tempfile, datetime, re
+  python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--quiet] [--gz] [-- extra options of biokanga align]
+Every variant is the same command with its own environment (the first run, "default", has none); the files are written once.
+--gz: the reads also as reads.fa.gz (one member, level 1) and reads.fa.bgz (bgzip members); every variant then runs on the three inputs,
+and the gzip'd ones once more with BK_GZ_SERIAL=1 (the record-by-record gzread reader)."""
+import os, sys, time, subprocess, shutil, tempfile, datetime, re, struct, zlib
+from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -24,6 +27,37 @@ def stamps_of(logf):
     return out
 
 
+def bgzf_blocks(data):
+    out = []
+    for o in range(0, len(data), 0xff00):
+        piece = data[o:o + 0xff00]
+        z = zlib.compressobj(1, zlib.DEFLATED, -15)
+        c = z.compress(piece) + z.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(c) + 25) + c + struct.pack("<II", zlib.crc32(piece), len(piece)))
+    return b"".join(out)
+
+
+def write_gzip_copies(fa):
+    """reads.fa -> reads.fa.gz (zlib level 1, one member) and reads.fa.bgz (bgzip members made by every core)"""
+    t = time.time()
+    z = zlib.compressobj(1, zlib.DEFLATED, 31)
+    with open(fa, "rb") as f, open(fa + ".gz", "wb") as g:
+        while True:
+            buf = f.read(64 << 20)
+            if not buf:
+                break
+            g.write(z.compress(buf))
+        g.write(z.flush())
+    t1 = time.time()
+    with open(fa, "rb") as f, open(fa + ".bgz", "wb") as g, ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:    # (zlib works outside the interpreter's lock)
+        step = 0xff00 * 256
+        chunks = iter(lambda: f.read(step), b"")
+        for out in ex.map(bgzf_blocks, chunks):
+            g.write(out)
+        g.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+    print(f"gzip copies written: .gz {os.path.getsize(fa + '.gz') / 1e9:.2f} GB in {t1 - t:.1f} s, .bgz {os.path.getsize(fa + '.bgz') / 1e9:.2f} GB in {time.time() - t1:.1f} s")
+
+
 def main():
     argv = sys.argv[1:]
     extra = []
@@ -38,6 +72,7 @@ def main():
             variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
     repeat = int(argv[argv.index("--repeat") + 1]) if "--repeat" in argv else 1
     quiet = "--quiet" in argv
+    with_gz = "--gz" in argv
     try:
         quota = open("/sys/fs/cgroup/cpu.max").read().strip()
     except OSError:
@@ -66,14 +101,22 @@ def main():
         bench.write_sfx_file(sfx, seq_h, sa_h, [(f"chr{e[0]}", e[1]) for e in entries])
         bench.write_fasta_file(fa, reads_h, n_reads, 100)
         del seq_h, sa_h, reads_h
+        inputs = [("", fa)]
+        if with_gz:
+            write_gzip_copies(fa)
+            inputs += [(" .gz", fa + ".gz"), (" .bgz", fa + ".bgz")]
+            variants = [(n + tag, dict(e, BK_E2E_INPUT=path)) for n, e in variants for tag, path in inputs] + \
+                       [(n + tag + " gzread", dict(e, BK_E2E_INPUT=path, BK_GZ_SERIAL="1")) for n, e in variants for tag, path in inputs[1:]]
         first_size = None
         for name, env in variants:
+            env = dict(env)
+            fa_in = env.pop("BK_E2E_INPUT", fa)
             for rep in range(repeat):
                 for f in (sam, logf, logf + ".err"):
                     if os.path.exists(f):
                         os.unlink(f)
                 t = time.time()
-                rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra,
+                rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa_in, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra,
                                     stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1", **env), timeout=300).returncode
                 wall = time.time() - t
                 print("   cgroup memory.current", cg("memory.current"), "events:", cg("memory.events"), "peak", cg("memory.peak"))
