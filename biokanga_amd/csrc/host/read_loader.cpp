@@ -383,10 +383,20 @@ int load_reads_pe(const std::vector<std::string> &f1, const std::vector<std::str
         std::string err;
         rd[0].set_quality_mode(g_qual_mode);
         rd[1].set_quality_mode(g_qual_mode);
-        int rc = rd[0].open(f1[k], nthreads, &err);
-        if (rc) { diag("Load: %s", err.c_str()); return rc; }
-        rc = rd[1].open(f2[k], nthreads, &err);
-        if (rc) { diag("Load: %s", err.c_str()); return rc; }
+        // the mate files are opened side by side, half of the threads each: a file that is one gzip member is inflated by one thread
+        // however many there are, and two such files should not wait for each other
+        int rc, rc2 = 0;
+        if (nthreads >= 4) {
+            std::string err2;
+            std::thread second([&]() { rc2 = rd[1].open(f2[k], nthreads - nthreads / 2, &err2); });
+            rc = rd[0].open(f1[k], nthreads / 2, &err);
+            second.join();
+            if (!rc && rc2) err = err2;
+        } else {
+            rc = rd[0].open(f1[k], nthreads, &err);
+            if (!rc) rc2 = rd[1].open(f2[k], nthreads, &err);
+        }
+        if (rc || rc2) { diag("Load: %s", err.c_str()); return rc ? rc : rc2; }
         diag("Loading paired end reads from '%s' and '%s'", f1[k].c_str(), f2[k].c_str());
         if (rd[0].parsed() && rd[1].parsed() && g_sample_nth <= 1) {
             rc = accept_pairs(rd[0].file(), rd[1].file(), f1[k], f2[k], trim5, trim3, min_len, max_len, nthreads, rs);

@@ -100,3 +100,19 @@ def test_a_short_second_mate_file_is_reported_as_the_serial_loader_does(harness,
     reads_file(b, 11000, 32)
     one, many = both(harness, ["pe", 0, 0, 50, 250, 3, 1, a, b], whole=0)
     assert one == many and one[0].startswith("rc -63") and any("fewer reads" in l for l in one[1]), (one, many)
+
+
+def test_gzip_mate_files_opened_side_by_side_give_the_plain_files_store(harness, tmp_path):
+    """mates as one gzip member each, and bgzip'd: inflated whole, side by side, accepted by all threads - the plain files' store"""
+    import gzip
+    a, b = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    reads_file(a, 12000, 41, fastq=True)
+    reads_file(b, 12000, 42, fastq=True)
+    for f in (a, b):
+        data = open(f, "rb").read()
+        open(f + ".gz", "wb").write(gzip.compress(data, 4))
+        write_bgzf(f + ".bgz", data)
+    plain = both(harness, ["pe", 3, 2, 50, 250, 0, 1, a, b], whole=2)
+    gz = both(harness, ["pe", 3, 2, 50, 250, 0, 1, a + ".gz", b + ".gz"], whole=2)
+    bgz = both(harness, ["pe", 3, 2, 50, 250, 0, 1, a + ".bgz", b + ".gz"], whole=2)
+    assert plain[0][0] == plain[1][0] == gz[0][0] == gz[1][0] == bgz[0][0] == bgz[1][0], (plain, gz, bgz)
