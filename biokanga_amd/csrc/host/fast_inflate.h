@@ -23,4 +23,9 @@ namespace bk {
 long inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, const uint8_t *hist, size_t *in_used,
                  std::atomic<size_t> *progress = nullptr);
 
+// The same stream by up to `nthreads` threads, when it is text: threads start at guessed block starts and decode with the 32 KB in
+// front of them unknown (see the .cpp); a stream of less than 16 MB, or one where a guess does not hold, is decoded by one thread.
+// `out` is also the history's start.  *pieces_used = the number of threads whose work made the result (1: the plain way).
+long inflate_raw_parallel(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *in_used, int nthreads, int *pieces_used = nullptr);
+
 }  // namespace bk

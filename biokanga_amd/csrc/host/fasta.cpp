@@ -536,11 +536,11 @@ static bool inflate_bgzf(const uint8_t *base, size_t size, int nthreads, RawVec<
     return true;
 }
 
-// Any other gzip file: its members one after the other by one thread (a deflate stream has no entry points), but by the decoder of
-// fast_inflate.h - two to three times zlib's pace on read files - into one buffer, and the CRC-32 of every member by all threads
-// afterwards.  The text's size is not known up front (the trailer's length is modulo 4 GB and says nothing of other members): the
-// buffer is sized for eight times the file, untouched pages costing nothing, and a file that inflates beyond that - or holds
-// anything the decoder or this reader of RFC 1952 headers does not take - goes to the serial reader.
+// Any other gzip file: its members one after the other (a deflate stream has no entry points) by the decoder of fast_inflate.h - a
+// large member of text by several threads that start at guessed block boundaries, see there - into one buffer, and the CRC-32 of
+// every member by all threads afterwards.  The text's size is not known up front (the trailer's length is modulo 4 GB and says
+// nothing of other members): the buffer is sized for eight times the file, untouched pages costing nothing, and a file that
+// inflates beyond that - or holds anything the decoder or this reader of RFC 1952 headers does not take - goes to the serial reader.
 static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<uint8_t> &text)
 {
     if (size < 18) return false;
@@ -569,7 +569,7 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
         if (ok && (h[3] & 2)) p += 2;
         if (!ok || p + 8 > size) { ok = false; break; }
         size_t used = 0;
-        const long n = inflate_raw(base + p, size - p - 8, text.data() + w, cap - w, text.data() + w, &used);
+        const long n = inflate_raw_parallel(base + p, size - p - 8, text.data() + w, cap - w, &used, nthreads);    // (one thread for a small member)
         if (n < 0 || size - p - used < 8) { ok = false; break; }
         p += used;
         if ((uint32_t)n != le32(base + p + 4)) { ok = false; break; }

@@ -2,7 +2,8 @@
 //   inflate_harness check <file.deflate> <file.expected>     the decoder's output must be the expected bytes, all input consumed: "OK n"
 //                                                            (or "NO" when it declines; never anything else, never out of bounds)
 //   inflate_harness time <file.deflate> <expected size>      the best of seven timed runs of either decoder
-//   inflate_harness fuzz <file.deflate> <seed> <rounds>      damaged copies: the decoder may decline or agree with zlib, nothing else
+//   inflate_harness par <file.deflate> <threads>             inflate_raw_parallel must give inflate_raw's bytes: "OK bytes n pieces p"
+//   inflate_harness fuzz <file.deflate> <seed> <rounds> [threads]   damaged copies: the decoder may decline or agree with zlib, nothing else
 #include <zlib.h>
 
 #include <algorithm>
@@ -84,9 +85,25 @@ int main(int argc, char **argv)
         printf("best of 7: ours %ld bytes %.3f s %.0f MB/s | zlib %ld bytes %.3f s %.0f MB/s | %s\n", n1, best1, n1 / best1 / 1e6, n2, best2, n2 / best2 / 1e6, same ? "same" : "DIFFERENT");
         return 0;
     }
+    if (mode == "par") {                                 // <threads>: the several-thread decoder against the one-thread one
+        const int nt = atoi(argv[3]);
+        const size_t cap = in.size() * 12 + (1u << 20);
+        std::vector<uint8_t> a(cap), b(cap);
+        size_t u1 = 0, u2 = 0;
+        int pieces = 0;
+        double t0 = now();
+        const long n1 = bk::inflate_raw(in.data(), in.size(), a.data(), cap, a.data(), &u1);
+        double t1 = now();
+        const long n2 = bk::inflate_raw_parallel(in.data(), in.size(), b.data(), cap, &u2, nt, &pieces);
+        double t2 = now();
+        const bool same = n1 == n2 && u1 == u2 && (n1 <= 0 || !memcmp(a.data(), b.data(), (size_t)n1));
+        printf("%s bytes %ld pieces %d | one thread %.3f s, %d threads %.3f s\n", same ? "OK" : "WRONG", n1, pieces, t1 - t0, nt, t2 - t1);
+        return same ? 0 : 1;
+    }
     if (mode == "fuzz") {
         unsigned seed = (unsigned)atoi(argv[3]);
         const int rounds = argc > 4 ? atoi(argv[4]) : 1000;
+        const int par = argc > 5 ? atoi(argv[5]) : 0;      // > 0: through inflate_raw_parallel with that many threads
         const size_t cap = 1 << 22;
         std::vector<uint8_t> a(cap), b(cap);
         int declined = 0, agreed = 0, zlib_no = 0;
@@ -101,7 +118,7 @@ int main(int argc, char **argv)
             uint8_t *src = (uint8_t *)malloc(d.size() ? d.size() : 1);
             memcpy(src, d.data(), d.size());
             size_t u1 = 0, u2 = 0;
-            const long n1 = bk::inflate_raw(src, d.size(), a.data(), cap, a.data(), &u1);
+            const long n1 = par ? bk::inflate_raw_parallel(src, d.size(), a.data(), cap, &u1, par) : bk::inflate_raw(src, d.size(), a.data(), cap, a.data(), &u1);
             const long n2 = zlib_raw(src, d.size(), b.data(), cap, &u2);
             free(src);
             if (n2 < 0) zlib_no++;

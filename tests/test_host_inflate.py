@@ -67,3 +67,28 @@ def test_damaged_streams_are_declined_or_inflate_as_zlib_does(harness, tmp_path,
     assert out.returncode == 0 and out.stdout.decode().startswith("OK rounds 400"), (out.stdout, out.stderr[-3000:])
     f = out.stdout.decode().split()
     assert int(f[f.index("agreed") + 1]) > 50 and int(f[f.index("declined") + 1]) > 50, out.stdout      # (both outcomes were seen)
+
+
+@pytest.mark.parametrize("name,several", [("fastq level 6", True), ("fastq level 1", True), ("fastq level 9", True), ("flushed blocks", True), ("text", False),
+                                          ("literals only", True), ("incompressible", False), ("stored", False), ("one long run", False), ("short distances", False)])
+def test_one_stream_by_several_threads_gives_the_one_thread_bytes(harness, tmp_path, name, several):
+    """threads that start at guessed block starts, with the 32 KB in front of them unknown until the thread in front is done: the bytes
+    of the one-thread decoder, for text in several pieces; streams with no block start to be found (binary, one block) fall back to it"""
+    data, level, strategy, flush = streams()[name]
+    d = str(tmp_path / "s.deflate")
+    open(d, "wb").write(deflate(data, level, strategy, flush))
+    for threads in (2, 5, 8):
+        out = subprocess.run([harness, "par", d, str(threads)], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", BK_INFLATE_PIECE_MIN="40000"))
+        assert out.returncode == 0 and out.stdout.decode().startswith(f"OK bytes {len(data)}"), (out.stdout, out.stderr[-3000:])
+        pieces = int(out.stdout.decode().split("pieces")[1].split()[0])
+        assert (pieces > 1) if several else (pieces >= 1), out.stdout
+
+
+@pytest.mark.parametrize("name", ["fastq level 6", "flushed blocks"])
+def test_damaged_streams_through_several_threads(harness, tmp_path, name):
+    """a damaged stream whose pieces do not meet is decoded again by one thread: declined, or zlib's bytes, as before"""
+    data, level, strategy, flush = streams()[name]
+    d = str(tmp_path / "s.deflate")
+    open(d, "wb").write(deflate(data, level, strategy, flush))
+    out = subprocess.run([harness, "fuzz", d, "23", "300", "4"], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", BK_INFLATE_PIECE_MIN="40000"))
+    assert out.returncode == 0 and out.stdout.decode().startswith("OK rounds 300"), (out.stdout, out.stderr[-3000:])

@@ -9,6 +9,7 @@
 #     prof      tools/profile_round.sh + tools/pmc_busy.sh (kernel stats, counters, ALU busy) -> gpurun_out/profiles_<tag>/
 #     e2e       T_e2e of `biokanga align` on a whole C2 step with the stage clocks on (tools/e2e_cli.py)
 #     e2e_gz    the same on 20 M reads, from the plain file, its .gz and its .bgz, and the gzip'd ones through gzread as well
+#     inflate   the loaders' DEFLATE decoder on the box's host: one thread, 2 .. 16 threads, zlib (tools/inflate_bench.sh; no GPU work)
 #     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
 #     upload    host -> device upload methods, wall-clock and CPU seconds (tools/upload_bench)
 set -u
@@ -41,6 +42,7 @@ PY
     prof)  tools/profile_round.sh $tag > $O/profile_round.log 2>&1; tail -25 $O/profile_round.log; tools/pmc_busy.sh $tag > $O/busy.log 2>&1; tail -8 $O/busy.log ;;
     e2e)   timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e.log 2>&1; grep -v "^\[" $O/e2e.log | cut -c1-200; grep "^\[" $O/e2e.log | cut -c1-200 ;;
     e2e_gz) timeout 560 python3 tools/e2e_cli.py 20000000 --gz --quiet > $O/e2e_gz.log 2>&1; grep -a "gzip copies\|T_e2e\|load " $O/e2e_gz.log | cut -c1-220 ;;
+    inflate) BK_INFLATE_DEBUG=1 timeout 300 bash tools/inflate_bench.sh 600 > $O/inflate_bench.txt 2>&1; grep -v "piece at" $O/inflate_bench.txt | tail -14 ;;
     e2e_probe) BK_EXIT_PROBE=1 timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e_probe.log 2>&1; grep -a "exit probe\|T_e2e\|tear-down" $O/e2e_probe.log | cut -c1-200 ;;
     upload)
       python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
