@@ -550,7 +550,7 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
     std::vector<Member> mem;
     auto le32 = [](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
     size_t o = 0, w = 0;
-    bool ok = true;
+    bool ok = true, several = nthreads > 1;
     while (ok && o < size) {
         const uint8_t *h = base + o;
         if (size - o < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xe0)) { ok = false; break; }
@@ -569,7 +569,12 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
         if (ok && (h[3] & 2)) p += 2;
         if (!ok || p + 8 > size) { ok = false; break; }
         size_t used = 0;
-        const long n = inflate_raw_parallel(base + p, size - p - 8, text.data() + w, cap - w, &used, nthreads);    // (one thread for a small member)
+        // (several threads for a large member - until one attempt comes back as one thread's work: then the file is not one stream of
+        // text to its end, and every further attempt would decode the rest of the file only to find that out again)
+        int pieces = 1;
+        const long n = several ? inflate_raw_parallel(base + p, size - p - 8, text.data() + w, cap - w, &used, nthreads, &pieces)
+                               : inflate_raw(base + p, size - p - 8, text.data() + w, cap - w, text.data() + w, &used);
+        if (pieces < 2) several = false;
         if (n < 0 || size - p - used < 8) { ok = false; break; }
         p += used;
         if ((uint32_t)n != le32(base + p + 4)) { ok = false; break; }

@@ -240,3 +240,24 @@ def test_other_gzip_layouts_are_inflated_by_one_thread_and_damaged_files_go_to_g
         open(q, "wb").write(raw[: len(raw) // 2 + 5])
         r = subprocess.run([harness, q, "4"], capture_output=True)
         assert b"parallel 1" not in r.stdout, (kind, r.stdout)
+
+
+def test_one_gzip_member_by_several_threads_gives_the_plain_files_records(harness, tmp_path):
+    """a gzip member large enough for several threads (here: made small enough by BK_INFLATE_PIECE_MIN) is inflated in pieces that start
+    at guessed block boundaries; FASTA and FASTQ, against the plain files; a file of two such members keeps to one thread per member
+    after the first attempt"""
+    import gzip
+    fa, fq = str(tmp_path / "big.fa"), str(tmp_path / "big.fq")
+    nasty_fasta(fa, 40000, seed=21)
+    nasty_fastq(fq, 30000, seed=22)
+    env = dict(os.environ, BK_INFLATE_PIECE_MIN="150000", BK_INFLATE_DEBUG="1")
+    for plain in (fa, fq):
+        data = open(plain, "rb").read()
+        open(plain + ".gz", "wb").write(gzip.compress(data, 6))
+        want = subprocess.check_output([harness, plain, "8"]).decode().split("parallel")[0]
+        r = subprocess.run([harness, plain + ".gz", "8"], capture_output=True, env=env)
+        assert r.stdout.decode().startswith("OK") and "parallel 1" in r.stdout.decode() and r.stdout.decode().split("parallel")[0] == want, r.stdout
+        assert int(r.stderr.decode().split("inflate: ")[1].split()[0]) > 1, r.stderr                 # pieces
+        open(plain + ".2.gz", "wb").write(gzip.compress(data[:len(data) // 2], 6) + gzip.compress(data[len(data) // 2:], 6))
+        r = subprocess.run([harness, plain + ".2.gz", "8"], capture_output=True, env=env)
+        assert r.stdout.decode().startswith("OK") and "parallel 1" in r.stdout.decode() and r.stdout.decode().split("parallel")[0] == want, r.stdout
