@@ -365,7 +365,8 @@ long inflate_span(const uint8_t *in, size_t in_len, uint64_t start, uint64_t sto
 
 constexpr size_t kWin = 32768;
 
-inline bool text_byte(uint32_t c) { return (c >= 0x20 && c < 0x7f) || c == '\n' || c == '\r' || c == '\t'; }
+// (bytes of UTF-8 names count as text; what rules a trial block out is a control character - one literal in nine of anything binary)
+inline bool text_byte(uint32_t c) { return (c >= 0x20 && c != 0x7f) || c == '\n' || c == '\r' || c == '\t'; }
 
 // one block's symbols as 16-bit values behind `o`; `base` is the start of the buffer (the unknown window included)
 bool decode_block_sym(Bits &c, const Tables &t, uint16_t *&out, uint16_t *const oend, const uint16_t *base, bool text_only)
