@@ -874,14 +874,13 @@ int cmd_align(int argc, char **argv, int first)
     for (const char *opt : {"i", "u"})
         if (a.has(opt))
             for (const std::string &fn : a.v[opt]) {
-                struct stat st;
-                if (stat(fn.c_str(), &st) != 0) continue;
-                const size_t l = fn.size();
-                const bool gz = l > 3 && !strcasecmp(fn.c_str() + l - 3, ".gz");
+                // (gzip'd files too: they are inflated whole like plain ones are mapped, and say - bgzip'd ones exactly - how much text they hold)
+                const uint64_t text = bk::text_bytes_estimate(fn);
+                if (!text) continue;
                 const bool fq = fn.find(".fq") != std::string::npos || fn.find(".fastq") != std::string::npos;
-                est_reads += (uint64_t)st.st_size * (gz ? 4 : 1) / (fq ? 250 : 120);
-                plain_bytes += (uint64_t)st.st_size;
-                all_plain = all_plain && !gz;
+                est_reads += text / (fq ? 250 : 120);
+                plain_bytes += text;
+                all_plain = all_plain && o.nthreads > 1 && !getenv("BK_GZ_SERIAL");
             }
     Submission S;
     if (all_plain && plain_bytes >= (256u << 20)) S.start_early(plain_bytes, (uint32_t)std::max(15, o.min_len));

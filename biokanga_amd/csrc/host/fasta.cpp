@@ -677,6 +677,50 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     return 1;
 }
 
+uint64_t text_bytes_estimate(const std::string &path)
+{
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return 0; }
+    const size_t size = (size_t)st.st_size;
+    uint8_t head[18] = {0}, tail[8] = {0};
+    const bool gz = size >= 26 && pread(fd, head, 18, 0) == 18 && head[0] == 0x1f && head[1] == 0x8b && pread(fd, tail, 8, (off_t)(size - 8)) == 8;
+    if (!gz) { ::close(fd); return size; }
+    auto le32 = [](const uint8_t *q) { return (uint64_t)q[0] | ((uint64_t)q[1] << 8) | ((uint64_t)q[2] << 16) | ((uint64_t)q[3] << 24); };
+    if (head[3] == 4 && head[12] == 'B' && head[13] == 'C') {
+        // bgzip: from header to header (the common layout: 'BC' is the only extra field)
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            const uint8_t *base = (const uint8_t *)m;
+            uint64_t total = 0;
+            size_t o = 0;
+            bool ok = true;
+            while (o < size) {
+                const uint8_t *h = base + o;
+                if (size - o < 28 || h[0] != 0x1f || h[1] != 0x8b || h[3] != 4 || h[12] != 'B' || h[13] != 'C') { ok = false; break; }
+                const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
+                if (bsize < 26 || bsize > size - o) { ok = false; break; }
+                total += le32(h + bsize - 4);
+                o += bsize;
+            }
+            munmap(m, size);
+            if (ok) { ::close(fd); return total; }
+        }
+    }
+    ::close(fd);
+    // the length word counts modulo 4 GB: of the texts it can stand for, the one whose ratio to the file is nearest to 3.5 (read files
+    // deflate to between a fifth and a third)
+    const uint64_t word = le32(tail + 4);
+    uint64_t best = word;
+    double best_off = 1e30;
+    for (uint64_t est = word; est <= (uint64_t)size * 12 + (1ull << 32); est += 1ull << 32) {
+        const double off = fabs((double)est / (double)size - 3.5);
+        if (off < best_off) { best_off = off; best = est; }
+    }
+    return best;
+}
+
 int RecordStream::open(const std::string &path, int nthreads, std::string *err)
 {
     int rc = nthreads > 1 ? parse_fasta_parallel(path, nthreads, file_, err, rd_.quality_mode()) : 0;

@@ -87,6 +87,12 @@ struct ParsedFile {
 // (gzip, FASTQ, tiny: use SeqReader), < 0 on error.
 int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode = 3);
 
+// The text a read file holds, in bytes, without reading it: a plain file's size; a bgzip'd file's members' lengths, summed from
+// their headers (exact); for any other gzip file the last member's length word - which counts modulo 4 GB - raised by the multiple
+// of 4 GB that brings the text nearest to 3.5 times the file's size (an estimate: sizes buffers and the output file ahead of time,
+// nothing depends on its being right).  0 when the file cannot be read.
+uint64_t text_bytes_estimate(const std::string &path);
+
 // One stream of records, from either source.
 class RecordStream {
 public:

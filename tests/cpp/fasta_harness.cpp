@@ -13,6 +13,10 @@ int main(int argc, char **argv)
     const int nthreads = atoi(argv[2]);
     std::string err;
     const int qmode = (argc == 4 && argv[3][0] == 'q') ? atoi(argv[3] + 1) : 3;      // "q0" .. "q3": how FASTQ scores are kept (-g)
+    if (argc == 4 && !strcmp(argv[3], "est")) {     // the text the file holds, by its own account
+        printf("text %llu\n", (unsigned long long)bk::text_bytes_estimate(argv[1]));
+        return 0;
+    }
     if (argc == 4 && argv[3][0] != 'q') {          // "time": the parallel parser alone, three times
         for (int k = 0; k < 3; k++) {
             timespec t0, t1;

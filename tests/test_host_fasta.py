@@ -261,3 +261,16 @@ def test_one_gzip_member_by_several_threads_gives_the_plain_files_records(harnes
         open(plain + ".2.gz", "wb").write(gzip.compress(data[:len(data) // 2], 6) + gzip.compress(data[len(data) // 2:], 6))
         r = subprocess.run([harness, plain + ".2.gz", "8"], capture_output=True, env=env)
         assert r.stdout.decode().startswith("OK") and "parallel 1" in r.stdout.decode() and r.stdout.decode().split("parallel")[0] == want, r.stdout
+
+
+def test_text_size_of_a_read_file_without_reading_it(harness, tmp_path):
+    """plain: the file's size; bgzip'd: the members' lengths summed (exact); one gzip member: its length word, which is the size below 4 GB"""
+    import gzip
+    fa = str(tmp_path / "r.fa")
+    nasty_fasta(fa, 9000, seed=31)
+    data = open(fa, "rb").read()
+    write_bgzf(fa + ".bgz", data)
+    open(fa + ".gz", "wb").write(gzip.compress(data, 6))
+    for f in (fa, fa + ".bgz", fa + ".gz"):
+        assert subprocess.check_output([harness, f, "1", "est"]).decode().split() == ["text", str(len(data))], f
+    assert subprocess.check_output([harness, str(tmp_path / "none"), "1", "est"]).decode().split() == ["text", "0"]
