@@ -274,3 +274,19 @@ def test_text_size_of_a_read_file_without_reading_it(harness, tmp_path):
     for f in (fa, fa + ".bgz", fa + ".gz"):
         assert subprocess.check_output([harness, f, "1", "est"]).decode().split() == ["text", str(len(data))], f
     assert subprocess.check_output([harness, str(tmp_path / "none"), "1", "est"]).decode().split() == ["text", "0"]
+
+
+@pytest.mark.parametrize("file_gb,word_gb,want_gb", [(1.0, 0.2, 4.2), (1.0, 3.9, 3.9), (2.0, 0.3, 8.3), (0.5, 1.6, 1.6), (3.0, 2.5, 10.5)])
+def test_text_size_of_a_large_gzip_member_from_its_length_word(harness, tmp_path, file_gb, word_gb, want_gb):
+    """the length word counts modulo 4 GB: the text nearest to 3.5 times the file is taken (a sparse file stands in: only its first and last
+    bytes are looked at)"""
+    import struct
+    p = str(tmp_path / "big.gz")
+    size, word = int(file_gb * (1 << 30)), int(word_gb * (1 << 30))
+    with open(p, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00" + b"\0" * 6)
+        f.truncate(size)
+        f.seek(size - 8)
+        f.write(struct.pack("<II", 0, word))
+    got = int(subprocess.check_output([harness, p, "1", "est"]).decode().split()[1])
+    assert got == word + int(round((want_gb - word_gb) / 4)) * (1 << 32), (got, word)
