@@ -40,6 +40,7 @@
 #include "../sfx_file.h"
 #include "bam_writer.h"
 #include "fasta.h"
+#include "genome_loader.h"
 #include "glibc_rand.h"
 #include "mtqsort.h"
 #include "multi_assign.h"
@@ -115,69 +116,16 @@ int cmd_index(int argc, char **argv, int first)
     std::string descr = a.has("d") ? a.str("d").substr(0, 1023) : ref;
     diag("Subprocess index Version %s starting", kProgVer);
 
-    // CreateBioseqSuffixFile / ProcessFastaFile (kangax.cpp:545-690,774-926)
-    std::vector<uint8_t> seq;
-    std::vector<bk::SfxEntry> entries;
-    const size_t kChunk = 0x00ffffff;                                    // cMaxAllocBuffChunk, kangax.cpp:37
-    uint32_t n_under = 0;
-    bk::GlibcRand nrun_rand;                                             // one sequence over all files, as the process-wide rand()
+    // CreateBioseqSuffixFile / ProcessFastaFile (kangax.cpp:545-690,774-926): genome_loader.cpp
     std::vector<std::string> files = a.v["i"];
     std::sort(files.begin(), files.end());                               // SG_GLOB_FULLSORT
-    for (const std::string &fn : files) {
-        bk::SeqReader rd;
-        int rc = rd.open(fn, &err);
-        if (rc) { diag("ProcessFastaFile: Unable to open '%s' %s", fn.c_str(), err.c_str()); return 1; }
-        diag("ProcessFastaFile:- Adding %s..", fn.c_str());
-        // the reference's read buffer bookkeeping decides where its 16 M-base chunks fall, and the
-        // N-run mutation state is reset at every chunk boundary (kangax.cpp:572,589,626-660)
-        size_t allocd = kChunk * 16, avail = allocd;
-        std::string d;
-        std::vector<uint8_t> bases;
-        int seq_id = 0;
-        while ((rc = rd.next(d, bases)) > 0) {
-            seq_id++;
-            char name[256];
-            if (sscanf(d.c_str(), " %255s", name) != 1) snprintf(name, sizeof(name), "%s.%d", fn.c_str(), ++seq_id);
-            size_t buff_ofs = 0, len = bases.size();
-            while (buff_ofs < len) {
-                size_t chunk = std::min(std::min(avail, kChunk), len - buff_ofs);
-                uint8_t *p = bases.data() + buff_ofs;
-                int seq_ns = 0;
-                for (size_t k = 0; k < chunk; k++) {
-                    p[k] &= ~0x08;
-                    if (p[k] == bk::kBaseN && (k + 5) < chunk) {
-                        if (++seq_ns > 25 && p[k + 1] == bk::kBaseN && p[k + 2] == bk::kBaseN && p[k + 3] == bk::kBaseN &&
-                            p[k + 4] == bk::kBaseN) {
-                            if (!(seq_ns % 13)) p[k] = (uint8_t)(nrun_rand.next() % 4);      // the reference's unseeded rand()
-                        }
-                    } else
-                        seq_ns = 0;
-                }
-                buff_ofs += chunk;
-                avail -= chunk;
-                if (avail < kChunk / 8) {
-                    allocd += kChunk;
-                    avail = allocd - buff_ofs;
-                }
-            }
-            if (len < (size_t)min_seq_len) { n_under++; continue; }
-            if (len > 0xfff00000ULL) { diag("AddEntry: SeqLen %zu not in range 1..%u", len, 0xfff00000u); return 1; }
-            bk::SfxEntry e;
-            e.entry_id = (uint32_t)entries.size() + 1;
-            e.fblock_id = 1;
-            strncpy(e.name, name, 80);
-            e.name_hash = bk::gen_hash16(name);
-            e.seq_len = (uint32_t)len;
-            e.start_ofs = seq.size();
-            e.end_ofs = seq.size() + len - 1;
-            for (const bk::SfxEntry &o : entries)
-                if (!strcasecmp(o.name, e.name)) { diag("CreateBioseqSuffixFile, duplicate sequence entry name '%s' in file '%s'", e.name, fn.c_str()); return 1; }
-            entries.push_back(e);
-            seq.insert(seq.end(), bases.begin(), bases.end());
-            seq.push_back(bk::kBaseEOS);
-        }
-        if (rc < 0) { diag("ProcessFastaFile: errors whilst reading '%s'", fn.c_str()); return 1; }
-    }
+    int nthreads = a.num("T", 0);
+    if (nthreads <= 0) nthreads = effective_cpus();
+    Genome G;
+    if (load_genome(files, min_seq_len, std::max(1, std::min(nthreads, 128)), G)) return 1;
+    bk::RawVec<uint8_t> &seq = G.seq;
+    std::vector<bk::SfxEntry> &entries = G.entries;
+    const uint32_t n_under = G.n_under;
     if (n_under) diag("ProcessFastaFile - %u sequences not accepted for indexing as length under %dbp ", n_under, min_seq_len);
     if (entries.empty()) { diag("Nothing to index"); return 1; }
 
@@ -192,7 +140,8 @@ int cmd_index(int argc, char **argv, int first)
     if (hipMemcpy(d_seq, seq.data(), n, hipMemcpyHostToDevice) != hipSuccess) { diag("Fatal: upload failed"); return 1; }
     int rc = bk_build_sa_device(d_seq, n, d_sa, (int)el, dev);
     if (rc) { diag("Fatal: suffix sort failed: %s", bk_strerror(rc)); return 1; }
-    std::vector<uint8_t> sa(n * el);
+    bk::RawVec<uint8_t> sa;                                              // (12 GB for a human genome: sized, not zeroed first)
+    sa.resize(n * el);
     if (hipMemcpy(sa.data(), d_sa, n * el, hipMemcpyDeviceToHost) != hipSuccess) { diag("Fatal: download failed"); return 1; }
     (void)hipFree(d_seq);
     (void)hipFree(d_sa);

@@ -248,7 +248,7 @@ const bool g_have_avx2 = false;
 #endif
 
 // bw: where this piece's bases go (the piece's offset in the file-sized buffer of its ParsedFile)
-void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, ParsedChunk &out)
+void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, ParsedChunk &out, bool mid = false)
 {
     const size_t approx = (size_t)(e - p);
     out.bases = bw;
@@ -258,23 +258,30 @@ void parse_range(const uint8_t *p, const uint8_t *e, uint8_t *bw, ParsedChunk &o
     dv.resize(approx / 4 + 256);
     size_t dn = 0;
     const uint8_t *lut = g_seq_lut.t;
+    out.continues = mid;
     while (p < e) {
-        p = (const uint8_t *)memchr(p, '>', (size_t)(e - p));          // skip to the next descriptor
-        if (!p) break;
-        p++;
-        // the descriptor: up to the line's end ('\n' or '\r')
-        const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
-        if (!q) q = e;
-        if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(q - p))) q = cr;
-        const size_t dl = (size_t)(q - p);
-        if (dn + dl > dv.size()) dv.resize(std::max(dv.size() * 2, dn + dl + 256));
-        char *d0 = dv.data() + dn;
-        uint8_t high = 0;
-        for (size_t i = 0; i < dl; i++) { d0[i] = (char)p[i]; high |= p[i]; }
-        if (high & 0x80) for (size_t i = 0; i < dl; i++) if ((uint8_t)d0[i] > 0x7f) d0[i] = '?';
-        dn += dl;
-        p = q;
-        out.descr_lens.push_back((uint32_t)dl);
+        if (mid) {
+            // a piece that starts at a line inside a record (split_records): its first bases go on with the record in the piece in front
+            mid = false;
+            out.descr_lens.push_back(0);
+        } else {
+            p = (const uint8_t *)memchr(p, '>', (size_t)(e - p));      // skip to the next descriptor
+            if (!p) break;
+            p++;
+            // the descriptor: up to the line's end ('\n' or '\r')
+            const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+            if (!q) q = e;
+            if (const uint8_t *cr = (const uint8_t *)memchr(p, '\r', (size_t)(q - p))) q = cr;
+            const size_t dl = (size_t)(q - p);
+            if (dn + dl > dv.size()) dv.resize(std::max(dv.size() * 2, dn + dl + 256));
+            char *d0 = dv.data() + dn;
+            uint8_t high = 0;
+            for (size_t i = 0; i < dl; i++) { d0[i] = (char)p[i]; high |= p[i]; }
+            if (high & 0x80) for (size_t i = 0; i < dl; i++) if ((uint8_t)d0[i] > 0x7f) d0[i] = '?';
+            dn += dl;
+            p = q;
+            out.descr_lens.push_back((uint32_t)dl);
+        }
         uint8_t *b0 = bw;
         while (p < e) {
             // (a piece never writes more bases than it has read characters: 32 bytes stored at bw stay inside the piece while p + 32 <= e)
@@ -617,7 +624,7 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
     return true;
 }
 
-int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode)
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode, bool split_records)
 {
     out.chunks.clear();
     int fd = ::open(path.c_str(), O_RDONLY);
@@ -656,7 +663,14 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     cut[0] = p;
     cut[pieces] = end;
     for (size_t t = 1; t < pieces; t++) {
-        cut[t] = fastq ? next_fastq_record(base, base + size / pieces * t, end) : next_record_start(base, base + size / pieces * t, end);
+        const uint8_t *mid = base + size / pieces * t;
+        if (!fastq && split_records) {
+            // (a genome: a few records of any length; the pieces are cut at line starts, wherever in a record those are)
+            const uint8_t *nl = (const uint8_t *)memchr(mid, '\n', (size_t)(end - mid));
+            cut[t] = nl ? nl + 1 : end;
+            continue;
+        }
+        cut[t] = fastq ? next_fastq_record(base, mid, end) : next_record_start(base, mid, end);
         if (cut[t] == nullptr) { unmap(); return 0; }
     }
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
@@ -667,7 +681,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     for (int w = 0; w < nthreads; w++)
         th.emplace_back([&, w]() {
             for (size_t t = (size_t)w; t < pieces; t += (size_t)nthreads) {
-                if (!fastq) parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.chunks[t]);
+                if (!fastq) parse_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), out.chunks[t], split_records && t > 0 && cut[t] < cut[t + 1] && *cut[t] != '>');
                 else if (!parse_fastq_range(cut[t], cut[t + 1], out.bases.data() + (cut[t] - base), qmode, out.chunks[t])) gave_up = 1;
             }
         });

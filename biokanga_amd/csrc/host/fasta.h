@@ -69,6 +69,7 @@ struct ParsedChunk {
     std::vector<uint32_t> lens;
     std::vector<uint32_t> descr_lens;
     RawVec<char> descr_own;
+    bool continues = false;             // split_records: the chunk's first record (descriptor length 0) goes on with the chunk's in front
 };
 
 // A whole file parsed in pieces.  The bases buffer is as large as the file and every piece writes from its own offset in the file on
@@ -85,7 +86,9 @@ struct ParsedFile {
 // record starts (the first '>' of a line) and every piece goes through the same state machine as
 // SeqReader::next.  Returns 1 and fills `out` when it handled the file, 0 when the file is not eligible
 // (gzip, FASTQ, tiny: use SeqReader), < 0 on error.
-int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode = 3);
+// split_records (FASTA only): the pieces are cut at line starts wherever those fall, for files of a few long records - a genome -
+// and a piece that starts inside a record says so (ParsedChunk::continues); the read loaders do not ask for this.
+int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode = 3, bool split_records = false);
 
 // The text a read file holds, in bytes, without reading it: a plain file's size; a bgzip'd file's members' lengths, summed from
 // their headers (exact); for any other gzip file the last member's length word - which counts modulo 4 GB - raised by the multiple

@@ -52,6 +52,20 @@ def test_index_writes_the_reference_sfx(golden_tmp, tmp_path, fixture):
         assert 7 in seq[a:a + l], (j, a, b)
 
 
+def test_index_of_a_large_genome_file_by_all_threads_equals_one_thread(tmp_path):
+    """a genome file of more than 1 MB is parsed by all threads in pieces cut at line starts (records of megabases, N runs, CRLF lines); -T1 keeps the record-by-record reader: the same .sfx, byte for byte - also from the gzip'd file"""
+    from test_host_genome import genome_file
+    fa = str(tmp_path / "g.fa")
+    genome_file(fa, 5, [2_200_000, 40, 1_300_001])           # (three records: the fourth would be the nameless one, named after its file)
+    open(fa + ".gz", "wb").write(gzip.compress(open(fa, "rb").read(), 4))
+    outs = []
+    for k, (T, f) in enumerate((("1", fa), ("8", fa), ("8", fa + ".gz"))):
+        out = str(tmp_path / f"g{k}.sfx")
+        run(["index", "-i", f, "-o", out, "-r", "big", f"-T{T}"], str(tmp_path))
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 5 * 3_400_000
+
+
 @pytest.mark.parametrize("fixture,tag,flags", [
     ("basic", "s3", ["-s3"]), ("repeat", "s3", ["-s3"]), ("basic", "dflt", []), ("basic", "s3m2", ["-s3", "-m2"]),
     ("basic", "s3Q2", ["-s3", "-Q2"]), ("basic", "s2l30", ["-s2", "-l30"]), ("repeat", "s3m3", ["-s3", "-m3"])])
