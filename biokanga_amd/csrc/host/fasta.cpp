@@ -548,6 +548,19 @@ static bool inflate_bgzf(const uint8_t *base, size_t size, int nthreads, RawVec<
 // every member by all threads afterwards.  The text's size is not known up front (the trailer's length is modulo 4 GB and says
 // nothing of other members): the buffer is sized for eight times the file, untouched pages costing nothing, and a file that
 // inflates beyond that - or holds anything the decoder or this reader of RFC 1952 headers does not take - goes to the serial reader.
+// the memory this process may use: the machine's, or the control group's limit where one is set
+static uint64_t memory_budget()
+{
+    uint64_t m = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGESIZE);
+    for (const char *f : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"})
+        if (FILE *h = fopen(f, "r")) {
+            unsigned long long v = 0;
+            if (fscanf(h, "%llu", &v) == 1 && v > 0 && v < m) m = v;
+            fclose(h);
+        }
+    return m;
+}
+
 static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<uint8_t> &text)
 {
     if (size < 18) return false;
@@ -557,7 +570,9 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
     std::vector<Member> mem;
     auto le32 = [](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
     size_t o = 0, w = 0;
-    bool ok = true, several = nthreads > 1;
+    // (several threads hold the text once as bytes and about twice as 16-bit symbols until the pieces are joined: some three times a text
+    // of about four times the file - only where that is well within the memory at hand)
+    bool ok = true, several = nthreads > 1 && (uint64_t)size * 13 < memory_budget() / 2;
     while (ok && o < size) {
         const uint8_t *h = base + o;
         if (size - o < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xe0)) { ok = false; break; }
