@@ -145,7 +145,7 @@ int cmd_index(int argc, char **argv, int first)
     if (hipMemcpy(sa.data(), d_sa, n * el, hipMemcpyDeviceToHost) != hipSuccess) { diag("Fatal: download failed"); return 1; }
     (void)hipFree(d_seq);
     (void)hipFree(d_sa);
-    rc = bk::sfx_write(a.str("o").c_str(), ref, descr, title, entries, seq.data(), n, sa.data(), el, &err);
+    rc = bk::sfx_write(a.str("o").c_str(), ref, descr, title, entries, seq.data(), n, sa.data(), el, &err, std::max(1, std::min(nthreads, 16)));
     if (rc) { diag("Fatal: %s", err.c_str()); return 1; }
     diag("CreateBioseqSuffixFile: completed...");
     return 0;

@@ -59,9 +59,10 @@ int sfx_open(const char *path, SfxFile &out, std::string *err = nullptr);
 uint16_t gen_hash16(const char *name);   // CUtility::GenHash16, libbiokanga/Utility.cpp:17-37
 
 // writes header + block + entries exactly as CSfxArrayV3::Finalise does.  sa holds concat_len
-// elements of el_size bytes.  entries must have start/end offsets filled in.
+// elements of el_size bytes.  entries must have start/end offsets filled in.  Images of 16 M bases and more are written by
+// `nthreads` threads, each at its own offsets.
 int sfx_write(const char *path, const std::string &dataset, const std::string &description,
               const std::string &title, const std::vector<SfxEntry> &entries, const uint8_t *seq,
-              uint64_t concat_len, const uint8_t *sa, uint32_t el_size, std::string *err = nullptr);
+              uint64_t concat_len, const uint8_t *sa, uint32_t el_size, std::string *err = nullptr, int nthreads = 1);
 
 }  // namespace bk
