@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <cerrno>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -234,9 +235,39 @@ struct SamPrealloc {
     }
 };
 
+// `n` bytes as gzip members (RFC 1952; level 6, what gzopen's default gives) appended to `out`: a gzip file is any number of members
+// one after the other, so threads can compress their own stretches of an output and the members go out in order
+inline bool gzip_members(const char *s, size_t n, std::vector<uint8_t> &out)
+{
+    const size_t kMost = (size_t)1 << 30;
+    do {
+        const size_t k = std::min(n, kMost);
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (deflateInit2(&z, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        const size_t at = out.size(), room = (size_t)deflateBound(&z, (uLong)k) + 64;
+        out.resize(at + room);
+        z.next_in = (Bytef *)const_cast<char *>(s);
+        z.avail_in = (uInt)k;
+        z.next_out = out.data() + at;
+        z.avail_out = (uInt)room;
+        const int rc = deflate(&z, Z_FINISH);
+        const size_t made = room - z.avail_out;
+        deflateEnd(&z);
+        if (rc != Z_STREAM_END) { out.resize(at); return false; }
+        out.resize(at + made);
+        s += k;
+        n -= k;
+    } while (n);
+    return true;
+}
+
 struct OutBuf {
     int fd = -1;
-    gzFile gz = nullptr;                    // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337)
+    // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337): what is put goes out as gzip members - one per
+    // flush from here, or made by the caller's own threads (put_members) - where the reference has gzwrite's single stream; readers
+    // see the same text
+    bool gz = false, gz_wrote = false, failed = false;
     off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
     std::vector<char> b;
     void open(const char *path)
@@ -246,22 +277,46 @@ struct OutBuf {
         // be opened that way (a FIFO, /dev/stdout) - those are written with pwrite() / write()
         fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz")) gz = gzdopen(fd, "wb");
+        gz = fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz");
         b.reserve(8 << 20);
         pos = 0;
     }
     void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
     void put(const std::string &s) { put(s.data(), s.size()); }
-    void flush()
+    void write_raw(const void *p, size_t n)
     {
         size_t o = 0;
-        if (gz) { if (!b.empty()) gzwrite(gz, b.data(), (unsigned)b.size()); b.clear(); return; }
-        while (o < b.size()) { ssize_t w = ::pwrite(fd, b.data() + o, b.size() - o, pos + (off_t)o); if (w <= 0) break; o += (size_t)w; }
+        while (o < n) {
+            ssize_t w = ::pwrite(fd, (const char *)p + o, n - o, pos + (off_t)o);
+            if (w < 0 && errno == ESPIPE) w = ::write(fd, (const char *)p + o, n - o);      // (a pipe has no offsets)
+            if (w <= 0) { failed = true; break; }
+            o += (size_t)w;
+        }
         pos += (off_t)o;
+    }
+    void flush()
+    {
+        if (gz) {
+            if (!b.empty()) {
+                std::vector<uint8_t> m;
+                if (gzip_members(b.data(), b.size(), m)) { write_raw(m.data(), m.size()); gz_wrote = true; } else failed = true;
+            }
+            b.clear();
+            return;
+        }
+        write_raw(b.data(), b.size());
         b.clear();
     }
+    // gzip members the caller made of the text that follows what was put so far
+    void put_members(const uint8_t *m, size_t n) { flush(); if (n) { write_raw(m, n); gz_wrote = true; } }
     bool borrowed = false;                  // the descriptor belongs to a SamPrealloc
-    void close() { flush(); if (gz) { gzclose(gz); gz = nullptr; fd = -1; } if (fd >= 0) { fsync(fd); if (!borrowed) ::close(fd); } fd = -1; }
+    void close()
+    {
+        flush();
+        if (gz && !gz_wrote && fd >= 0) { std::vector<uint8_t> m; if (gzip_members("", 0, m)) write_raw(m.data(), m.size()); }   // (an empty text is one empty member)
+        if (fd >= 0) { fsync(fd); if (!borrowed) ::close(fd); }
+        fd = -1;
+    }
 };
 
 }  // namespace bkcli

@@ -638,6 +638,7 @@ int report_text(Report &R)
         const int nt = (int)std::min<size_t>((size_t)nthreads, (nr + per_thread - 1) / per_thread ? (nr + per_thread - 1) / per_thread : 1);
         std::vector<Stripe> bufs((size_t)nt);
         std::vector<uint64_t> cnts((size_t)nt);
+        std::vector<std::vector<uint8_t>> zbufs((size_t)nt);
         const bool timing = getenv("BK_TIMING") != nullptr;
         auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
         double t_fmt = 0, t_grow = 0, t_put = 0;
@@ -693,6 +694,9 @@ int report_text(Report &R)
                     c += format_rec(k, buf) ? 1 : 0;
                 }
                 cnts[(size_t)t] = c;
+                // compressed SAM: every thread makes gzip members of its own stretch (one deflate stream through one thread takes minutes
+                // for what the threads format in a second; a gzip file may be any number of members)
+                if (out.gz) { zbufs[(size_t)t].clear(); if (buf.n && !gzip_members(buf.d, buf.n, zbufs[(size_t)t])) out.failed = true; }
             };
             std::vector<std::thread> th;
             for (int t = 1; t < nt; t++) th.emplace_back(work, t);
@@ -700,8 +704,8 @@ int report_text(Report &R)
             for (auto &t : th) t.join();
             const double tB = now();
             t_fmt += tB - tA;
-            if (out.gz) {                    // compressed SAM: one deflate stream, in order
-                for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t].d, bufs[(size_t)t].n); n_reported += cnts[(size_t)t]; }
+            if (out.gz) {                    // compressed SAM: the threads' members, in order
+                for (int t = 0; t < nt; t++) { out.put_members(zbufs[(size_t)t].data(), zbufs[(size_t)t].size()); n_reported += cnts[(size_t)t]; }
                 continue;
             }
             // the stripes go to their places in the file in parallel as well: the file is grown by the round's bytes and the threads

@@ -774,6 +774,24 @@ def test_bgzip_input_inflated_by_all_threads_like_the_plain_file(golden_tmp, tmp
     assert outs["plain"] == outs["bgzf"] == outs["gz"] and len(outs["plain"]) > (1 << 20)
 
 
+def test_large_gz_sam_made_by_all_threads_holds_the_plain_sam(golden_tmp, tmp_path):
+    """-o out.sam.gz on some 400 000 reads: every formatting thread makes gzip members of its own stretch and they go out in order - the
+    text of the plain file"""
+    d = golden_tmp["basic"]
+    txt = gzip.open(os.path.join(helpers.GOLDEN, "basic", "reads.fa.gz"), "rb").read()
+    n1 = txt.count(b">")
+    fa = str(tmp_path / "big.fa")
+    with open(fa, "wb") as f:
+        for c in range(1 + 400000 // n1):
+            f.write(txt)
+    plain, packed = str(tmp_path / "o.sam"), str(tmp_path / "o.sam.gz")
+    for out in (plain, packed):
+        run(["align", "-i", fa, "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M6", "-s3", "-T8"], str(tmp_path))
+    want = open(plain, "rb").read()
+    assert want.count(b"\n") > 400000 and gzip.open(packed, "rb").read() == want
+    assert open(packed, "rb").read().count(b"\x1f\x8b\x08\x00") >= 3                # (several members)
+
+
 def test_device_declines_after_its_head_start(golden_tmp, tmp_path):
     """the packed reads are on the device, the read store's bases and the packed buffers have been given back - and then the device
     declines (forced): the host formatter loads the reads again and writes the same file"""

@@ -290,3 +290,24 @@ def test_text_size_of_a_large_gzip_member_from_its_length_word(harness, tmp_path
         f.write(struct.pack("<II", 0, word))
     got = int(subprocess.check_output([harness, p, "1", "est"]).decode().split()[1])
     assert got == word + int(round((want_gb - word_gb) / 4)) * (1 << 32), (got, word)
+
+
+@pytest.mark.parametrize("lines", [0, 1, 260000])
+def test_outputs_named_gz_are_gzip_members_in_order(tmp_path, lines):
+    """an output whose name ends in .gz: what is put and the members the writer's threads hand over come out as one gzip file - any number
+    of members, the text in order; nothing put: an empty text"""
+    import gzip
+    exe = str(tmp_path / "outbuf_harness")
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "outbuf_harness.cpp"), "-lz"])
+    out = str(tmp_path / "o.txt.gz")
+    h, total, failed = subprocess.check_output([exe, out, str(lines)]).decode().split()
+    text = gzip.open(out, "rb").read()
+    assert failed == "0" and len(text) == int(total)
+    f = 1469598103934665603
+    if lines <= 1:
+        for c in text:
+            f = ((f ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert "%016x" % f == h
+    else:
+        assert text.startswith(b"read0\t0\tchr0\t0\t") and text.endswith(b"ACGTACGTTTGACCAGT%d\n" % ((lines - 1) % 1000)) and text.count(b"\n") == lines
+        assert [l.split(b"\t")[0] for l in text.split(b"\n")[49990:50010]] == [b"read%d" % i for i in range(49990, 50010)]      # across the hand-over
