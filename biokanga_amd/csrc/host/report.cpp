@@ -850,6 +850,10 @@ int report_text(Report &R)
         if (jct.fd >= 0) jct.close();
     }
     out.close();
+    if (out.failed) {                                // (eBSFerrFileAccess: the reference's WriteReadHits gives up on a short write too)
+        diag("Fatal error: unable to write all of the results to '%s' - disk full?", a.str("o").c_str());
+        return -85;
+    }
     diag("Reporting of aligned result set completed");
 
     report_read_subset(R, "j", "na", [](uint8_t nar) { return nar == BK_NAR_NS || nar == BK_NAR_NOHIT; });

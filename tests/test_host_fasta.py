@@ -311,3 +311,10 @@ def test_outputs_named_gz_are_gzip_members_in_order(tmp_path, lines):
     else:
         assert text.startswith(b"read0\t0\tchr0\t0\t") and text.endswith(b"ACGTACGTTTGACCAGT%d\n" % ((lines - 1) % 1000)) and text.count(b"\n") == lines
         assert [l.split(b"\t")[0] for l in text.split(b"\n")[49990:50010]] == [b"read%d" % i for i in range(49990, 50010)]      # across the hand-over
+
+
+def test_a_full_device_is_noticed_by_the_output_buffer(tmp_path):
+    """writes that do not go through (here: /dev/full) leave the buffer marked as failed - the report ends with an error, not with a short file"""
+    exe = str(tmp_path / "outbuf_harness")
+    subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "outbuf_harness.cpp"), "-lz"])
+    assert subprocess.check_output([exe, "/dev/full", "200000"]).decode().split()[2] == "1"
