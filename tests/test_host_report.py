@@ -1,0 +1,59 @@
+"""The CSV (-M0..3) and BED (-M4, with .ind / .jct) writers of `biokanga align` (host/report.cpp; CAligner::WriteReadHits,
+Aligner.cpp:6336-6660): the lines are made by all threads and written in order.  A made-up result set (tests/cpp/report_harness.cpp)
+must give, for any thread count, the files the one-thread loop gave before the threads came - their MD5 sums are kept here - and the
+same text through a .gz name.  CPU only (the harness links the library but never touches a device)."""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+import helpers
+
+# 300 000 records, seeds 1 and 2, from the record-by-record writer (commit fbaac2d)
+WANT = {
+    (0, 1): "fd1d4d573531daaa4e3ce6f12ad9a2a9", (0, 2): "fa4656685350d12ea8cdfeec61e5e78d",
+    (1, 1): "316a025f2ada366e814ea80fe245f290", (1, 2): "f843dbd7ab6d66cf08e06a5f33b2d71a",
+    (2, 1): "9e47879b64bc7ac6ffbbb3d29638c344", (2, 2): "2933c37b75e3a865aa772f6155d9e5bb",
+    (3, 1): "36610765f93bce2737b8f4a673ab24bc", (3, 2): "9cbd69215e16e9d8f441b0448c256bfe",
+    (4, 1): "3a8cc270c45ab77cf031f8f5b0999975", (4, 2): "31bf8e0919dfd19ee0ec3f23c2886ae1",
+    (4, 1, "ind"): "61580de94d80683401e3e2efd01db637", (4, 2, "ind"): "4de8b2624f444731277a3a08fdaf5c28",
+    (4, 1, "jct"): "438cdf4827c65af9d32eed5bff04ab33", (4, 2, "jct"): "a976c8b4b1e549417fef90d99cf0c010",
+}
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    lib = os.path.join(helpers.ROOT, "biokanga_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libbiokanga_amd.so")):
+        pytest.skip("library not built")
+    exe = str(tmp_path_factory.mktemp("r") / "report_harness")
+    c = os.path.join(helpers.ROOT, "biokanga_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "report_harness.cpp"),
+                           os.path.join(c, "host", "report.cpp"), os.path.join(c, "host", "bam_writer.cpp"), os.path.join(c, "sfx_file.cpp"),
+                           "-L" + lib, "-lbiokanga_amd", "-lz", "-lpthread", "-Wl,-rpath," + lib])
+    return exe
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("fmt,seed,threads", [(f, s, 8) for f in range(5) for s in (1, 2)] + [(3, 1, 1), (4, 2, 1), (0, 2, 3)])
+def test_lines_made_by_all_threads_are_the_one_thread_writers_file(harness, tmp_path, fmt, seed, threads):
+    out = str(tmp_path / "o.txt")
+    args = [harness, str(fmt), str(threads), "300000", str(seed), out] + ([str(tmp_path / "g.sfx")] if fmt in (1, 3) else [])
+    r = subprocess.run(args, capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"rc 0" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    assert md5(out) == WANT[(fmt, seed)]
+    if fmt == 4:
+        assert md5(out + ".ind") == WANT[(4, seed, "ind")] and md5(out + ".jct") == WANT[(4, seed, "jct")]
+
+
+def test_csv_through_a_gz_name_holds_the_same_text(harness, tmp_path):
+    out = str(tmp_path / "o.csv.gz")
+    r = subprocess.run([harness, "2", "8", "300000", "1", out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert hashlib.md5(gzip.open(out, "rb").read()).hexdigest() == WANT[(2, 1)]
+    assert open(out, "rb").read().count(b"\x1f\x8b\x08\x00") >= 4                # (the threads' own members)
