@@ -20,6 +20,8 @@ WANT = {
     (4, 1): "3a8cc270c45ab77cf031f8f5b0999975", (4, 2): "31bf8e0919dfd19ee0ec3f23c2886ae1",
     (4, 1, "ind"): "61580de94d80683401e3e2efd01db637", (4, 2, "ind"): "4de8b2624f444731277a3a08fdaf5c28",
     (4, 1, "jct"): "438cdf4827c65af9d32eed5bff04ab33", (4, 2, "jct"): "a976c8b4b1e549417fef90d99cf0c010",
+    # the host's SAM formatter (-M5, -M6) on the same records, as of the commit whose GPU suite checked it against the reference's files
+    (5, 1): "8a4dca53038dc710eb2ddd266c68f8bf", (6, 1): "055b2a2a938232e4b3795b8f71639e19",
 }
 
 
@@ -40,7 +42,7 @@ def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 
 
-@pytest.mark.parametrize("fmt,seed,threads", [(f, s, 8) for f in range(5) for s in (1, 2)] + [(3, 1, 1), (4, 2, 1), (0, 2, 3)])
+@pytest.mark.parametrize("fmt,seed,threads", [(f, s, 8) for f in range(5) for s in (1, 2)] + [(3, 1, 1), (4, 2, 1), (0, 2, 3), (5, 1, 8), (6, 1, 8), (6, 1, 1)])
 def test_lines_made_by_all_threads_are_the_one_thread_writers_file(harness, tmp_path, fmt, seed, threads):
     out = str(tmp_path / "o.txt")
     args = [harness, str(fmt), str(threads), "300000", str(seed), out] + ([str(tmp_path / "g.sfx")] if fmt in (1, 3) else [])
@@ -57,3 +59,12 @@ def test_csv_through_a_gz_name_holds_the_same_text(harness, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert hashlib.md5(gzip.open(out, "rb").read()).hexdigest() == WANT[(2, 1)]
     assert open(out, "rb").read().count(b"\x1f\x8b\x08\x00") >= 4                # (the threads' own members)
+
+
+def test_sam_through_a_gz_name_holds_the_plain_files_text(harness, tmp_path):
+    """every formatting thread's stretch as gzip members of its own, in order"""
+    out = str(tmp_path / "o.sam.gz")
+    r = subprocess.run([harness, "6", "8", "300000", "1", out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert hashlib.md5(gzip.open(out, "rb").read()).hexdigest() == WANT[(6, 1)]
+    assert open(out, "rb").read().count(b"\x1f\x8b\x08\x00") >= 3
