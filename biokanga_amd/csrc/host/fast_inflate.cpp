@@ -510,6 +510,8 @@ int64_t find_block_start(const uint8_t *in, size_t in_len, uint64_t from, uint64
     return -1;
 }
 
+const bool g_debug = getenv("BK_INFLATE_DEBUG") != nullptr;      // pieces, sizes and stage times on stderr (tools/inflate_bench.sh)
+
 inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 struct Piece {
@@ -530,8 +532,11 @@ void *lazy_pages(size_t bytes)
 
 void decode_piece(const uint8_t *in, size_t in_len, Piece &pc, bool first)
 {
-    const double T0 = now_s();
-    struct Say { Piece &p; double t0; ~Say() { if (getenv("BK_INFLATE_DEBUG")) fprintf(stderr, "  piece at bit %llu took %.3f s\n", (unsigned long long)p.start, now_s() - t0); } } say{pc, T0};
+    const double t_start = g_debug ? now_s() : 0;
+    struct Say {
+        const Piece &p; double t0;
+        ~Say() { if (g_debug) fprintf(stderr, "  piece at bit %llu took %.3f s\n", (unsigned long long)p.start, now_s() - t0); }
+    } say{pc, t_start};
     const uint64_t span_bits = (pc.stop == kNoStop ? (uint64_t)in_len * 8 : pc.stop) - pc.start;
     const size_t room = (size_t)(span_bits / 8) * 8 + (4u << 20);          // text of eight times the compressed bytes, as for the whole
     pc.tail_cap = kWin + room;
@@ -605,7 +610,7 @@ long inflate_raw_parallel(const uint8_t *in, size_t in_len, uint8_t *out, size_t
     size_t want = std::min<size_t>((size_t)std::max(1, nthreads), in_len / piece_min);
     if (want < 2) return inflate_raw(in, in_len, out, out_cap, out, in_used);
     // where the pieces start
-    const double Tstart = getenv("BK_INFLATE_DEBUG") ? now_s() : 0;
+    const double Tstart = g_debug ? now_s() : 0;
     std::vector<int64_t> found(want, -1);
     found[0] = 0;
     {
@@ -620,7 +625,7 @@ long inflate_raw_parallel(const uint8_t *in, size_t in_len, uint8_t *out, size_t
             });
         for (auto &t : th) t.join();
     }
-    const bool dbg = getenv("BK_INFLATE_DEBUG") != nullptr;
+    const bool dbg = g_debug;
     const double T0 = dbg ? now_s() : 0;
     std::vector<Piece> pcs;
     for (size_t k = 0; k < want; k++)
