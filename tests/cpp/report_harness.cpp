@@ -1,6 +1,7 @@
 // report_harness - host/report.cpp's report_text() on a made-up result set: the CSV forms (-M0..3) and BED (-M4, with its .ind / .jct
 // files), plain or .gz, with a given number of threads.  The records are a function of the seed alone, so the files of any two
 // thread counts - and of any two builds - can be compared.   report_harness <fmt> <threads> <records> <seed> <out> [sfx]
+//   (an <out> that ends in .bam with fmt 5 / 6: report_bam(), the BAM file and its index)
 //   (fmt 1 / 3 print target bases: <sfx> is a .sfx the harness writes first and report_text reads back)
 #include <cstdio>
 #include <cstdlib>
@@ -87,7 +88,8 @@ int main(int argc, char **argv)
     std::vector<int> multi_dist;
     const std::string species = "synthetic";
     Report R{a, rs, hits, ents, species, n_ent, src, seg2, trims, multi_dist, order, 0, 0, 1, fmt, nthreads, 5, 2000, 10000};
-    const int rc = report_text(R);
+    const std::string op = argv[5];
+    const int rc = (op.size() > 4 && op.substr(op.size() - 4) == ".bam") ? report_bam(R, op) : report_text(R);     // (as cmd_align picks)
     printf("rc %d\n", rc);
     return rc ? 1 : 0;
 }

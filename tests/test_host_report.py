@@ -68,3 +68,14 @@ def test_sam_through_a_gz_name_holds_the_plain_files_text(harness, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert hashlib.md5(gzip.open(out, "rb").read()).hexdigest() == WANT[(6, 1)]
     assert open(out, "rb").read().count(b"\x1f\x8b\x08\x00") >= 3
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+def test_bam_and_its_index_do_not_depend_on_the_thread_count(harness, tmp_path, threads):
+    """report_bam(): records formatted and BGZF blocks deflated by all threads; the files of the commit whose GPU suite compared them with
+    the reference's (byte-identical BAM + BAI)"""
+    out = str(tmp_path / "o.bam")
+    r = subprocess.run([harness, "6", str(threads), "300000", "1", out], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert md5(out) == "bd47269729b2794ff0cd3d61fa50f3d6" and md5(out + ".bai") == "2f410f7332ecd6dfa287e8319050e018"
+    assert gzip.open(out, "rb").read(4) == b"BAM\x01"
