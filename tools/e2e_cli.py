@@ -97,7 +97,7 @@ def main():
     torch.cuda.empty_cache()
     tmp = tempfile.mkdtemp(prefix="bk_e2e_", dir="/dev/shm")
     try:
-        sfx, fa, sam, logf = (os.path.join(tmp, x) for x in ("genome.sfx", "reads.fa", "out.sam", "log.txt"))
+        sfx, fa, sam, logf = (os.path.join(tmp, x) for x in ("genome.sfx", "reads.fa", os.environ.get("BK_E2E_OUT", "out.sam"), "log.txt"))     # (BK_E2E_OUT=out.sam.gz / out.bam: the other writers)
         bench.write_sfx_file(sfx, seq_h, sa_h, [(f"chr{e[0]}", e[1]) for e in entries])
         bench.write_fasta_file(fa, reads_h, n_reads, 100)
         del seq_h, sa_h, reads_h

@@ -8,6 +8,7 @@
 #     calib     FETCH_SIZE in our access patterns (tools/rand_access_bench calib under rocprofv3 --pmc)
 #     prof      tools/profile_round.sh + tools/pmc_busy.sh (kernel stats, counters, ALU busy) -> gpurun_out/profiles_<tag>/
 #     e2e       T_e2e of `biokanga align` on a whole C2 step with the stage clocks on (tools/e2e_cli.py)
+#     e2e_csv   the same with -M0 (the reference's default CSV) and with -o ending in .sam.gz: the writers that all threads share since round 4
 #     e2e_gz    the same on 20 M reads, from the plain file, its .gz and its .bgz, and the gzip'd ones through gzread as well
 #     inflate   the loaders' DEFLATE decoder on the box's host: one thread, 2 .. 16 threads, zlib (tools/inflate_bench.sh; no GPU work)
 #     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
@@ -41,6 +42,8 @@ PY
       cat $O/fetch_calibration.csv ;;
     prof)  tools/profile_round.sh $tag > $O/profile_round.log 2>&1; tail -25 $O/profile_round.log; tools/pmc_busy.sh $tag > $O/busy.log 2>&1; tail -8 $O/busy.log ;;
     e2e)   timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e.log 2>&1; grep -v "^\[" $O/e2e.log | cut -c1-200; grep "^\[" $O/e2e.log | cut -c1-200 ;;
+    e2e_csv) timeout 560 python3 tools/e2e_cli.py 20000000 --quiet -- -M0 > $O/e2e_csv.log 2>&1; grep -a "T_e2e\|load " $O/e2e_csv.log | cut -c1-220
+             BK_E2E_OUT=out.sam.gz timeout 560 python3 tools/e2e_cli.py 20000000 --quiet > $O/e2e_samgz.log 2>&1; grep -a "T_e2e\|load " $O/e2e_samgz.log | cut -c1-220 ;;
     e2e_gz) timeout 560 python3 tools/e2e_cli.py 20000000 --gz --quiet > $O/e2e_gz.log 2>&1; grep -a "gzip copies\|T_e2e\|load " $O/e2e_gz.log | cut -c1-220 ;;
     inflate) BK_INFLATE_DEBUG=1 timeout 300 bash tools/inflate_bench.sh 600 > $O/inflate_bench.txt 2>&1; grep -v "piece at" $O/inflate_bench.txt | tail -14 ;;
     e2e_probe) BK_EXIT_PROBE=1 timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e_probe.log 2>&1; grep -a "exit probe\|T_e2e\|tear-down" $O/e2e_probe.log | cut -c1-200 ;;
