@@ -839,7 +839,9 @@ int cmd_align(int argc, char **argv, int first)
     // writers would otherwise wait for.  Other inputs: once the reads are loaded (below).
     SamPrealloc pre;
     const std::string opath0 = a.str("o");
-    const bool sam_plain = o.fmt >= 5 && !(opath0.size() > 5 && !strcasecmp(opath0.c_str() + opath0.size() - 4, ".bam")) &&
+    struct stat ost;
+    const bool out_special = stat(opath0.c_str(), &ost) == 0 && !S_ISREG(ost.st_mode);      // a FIFO, /dev/fd/N of a process substitution, /dev/null
+    const bool sam_plain = o.fmt >= 5 && !out_special && !(opath0.size() > 5 && !strcasecmp(opath0.c_str() + opath0.size() - 4, ".bam")) &&
                            !(opath0.size() > 3 && !strcasecmp(opath0.c_str() + opath0.size() - 3, ".gz"));
     const char *early_env = getenv("BK_SAM_EARLY_MIN");                   // (tests lower the input size from which the file is started early)
     const bool pre_early = sam_plain && all_plain && plain_bytes >= (early_env ? strtoull(early_env, nullptr, 10) : (256ULL << 20));

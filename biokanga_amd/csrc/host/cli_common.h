@@ -268,6 +268,7 @@ struct OutBuf {
     // flush from here, or made by the caller's own threads (put_members) - where the reference has gzwrite's single stream; readers
     // see the same text
     bool gz = false, gz_wrote = false, failed = false;
+    bool pipe = false;                      // a FIFO or a pipe (-o >(samtools ..)): no offsets - everything in order through write()
     off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
     std::vector<char> b;
     void open(const char *path)
@@ -278,6 +279,7 @@ struct OutBuf {
         fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
         gz = fd >= 0 && n > 3 && !strcasecmp(path + n - 3, ".gz");
+        pipe = fd >= 0 && lseek(fd, 0, SEEK_CUR) == (off_t)-1 && errno == ESPIPE;
         b.reserve(8 << 20);
         pos = 0;
     }

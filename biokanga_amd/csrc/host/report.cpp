@@ -546,7 +546,7 @@ int report_text(Report &R)
         // Whatever the device path cannot take, or fails on, is formatted below by the host threads.
         bool device_done = false;
         const char *dev_min = getenv("BK_SAM_DEVICE_MIN");                        // (records from which the device formats: tests set it to 1, a huge value keeps the host path)
-        if (R.ctx != nullptr && !out.gz && R.src.empty() && R.seg2.empty() && R.trims.empty() && nr >= (size_t)(dev_min ? strtoull(dev_min, nullptr, 10) : 100000ULL)) {
+        if (R.ctx != nullptr && !out.gz && !out.pipe && R.src.empty() && R.seg2.empty() && R.trims.empty() && nr >= (size_t)(dev_min ? strtoull(dev_min, nullptr, 10) : 100000ULL)) {
             const bool timing0 = getenv("BK_TIMING") != nullptr;
             timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
             out.flush();
@@ -652,7 +652,7 @@ int report_text(Report &R)
         std::atomic<off_t> prealloc_size{0};
         std::thread prealloc;
         if (R.pre != nullptr && !device_done) { R.pre->finish(); prealloc_size.store(R.pre->done.load()); }    // (what the early thread allocated counts; the rest as before)
-        if (!out.gz && nr >= 200000 && !device_done && R.pre == nullptr) {
+        if (!out.gz && !out.pipe && nr >= 200000 && !device_done && R.pre == nullptr) {
             out.flush();
             const bool with_qual = a.num("g", 3) != 3;                                 // QUAL is '*' unless FASTQ scores were loaded (-g0..2)
             uint64_t est = (uint64_t)out.pos + rs.name_bytes() + 64ULL * nr + (pe_mode ? 24ULL * nr : 0);
@@ -706,6 +706,10 @@ int report_text(Report &R)
             t_fmt += tB - tA;
             if (out.gz) {                    // compressed SAM: the threads' members, in order
                 for (int t = 0; t < nt; t++) { out.put_members(zbufs[(size_t)t].data(), zbufs[(size_t)t].size()); n_reported += cnts[(size_t)t]; }
+                continue;
+            }
+            if (out.pipe) {                  // a FIFO / pipe takes the text in order, through write()
+                for (int t = 0; t < nt; t++) { out.put(bufs[(size_t)t].d, bufs[(size_t)t].n); n_reported += cnts[(size_t)t]; }
                 continue;
             }
             // the stripes go to their places in the file in parallel as well: the file is grown by the round's bytes and the threads

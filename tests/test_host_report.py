@@ -79,3 +79,30 @@ def test_bam_and_its_index_do_not_depend_on_the_thread_count(harness, tmp_path, 
     assert r.returncode == 0, r.stderr[-2000:]
     assert md5(out) == "bd47269729b2794ff0cd3d61fa50f3d6" and md5(out + ".bai") == "2f410f7332ecd6dfa287e8319050e018"
     assert gzip.open(out, "rb").read(4) == b"BAM\x01"
+
+
+@pytest.mark.parametrize("fmt", [6, 0])
+def test_a_fifo_gets_the_whole_text_in_order(harness, tmp_path, fmt):
+    """-o names a FIFO (or the /dev/fd/N of a process substitution): no offsets to write at, so the threads' text goes out in order through
+    write() - the regular file's bytes"""
+    import threading
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        h = hashlib.md5()
+        with open(fifo, "rb") as f:
+            while True:
+                b = f.read(1 << 20)
+                if not b:
+                    break
+                h.update(b)
+        got["md5"] = h.hexdigest()
+
+    t = threading.Thread(target=reader)
+    t.start()
+    r = subprocess.run([harness, str(fmt), "8", "300000", "1", fifo], capture_output=True, timeout=600)
+    t.join(timeout=60)
+    assert r.returncode == 0 and not t.is_alive(), r.stderr[-2000:]
+    assert got["md5"] == WANT[(fmt, 1)]
