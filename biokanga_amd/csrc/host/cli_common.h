@@ -283,7 +283,12 @@ struct OutBuf {
         b.reserve(8 << 20);
         pos = 0;
     }
-    void put(const char *s, size_t n) { b.insert(b.end(), s, s + n); if (b.size() > (4u << 20)) flush(); }
+    void put(const char *s, size_t n)
+    {
+        if (!gz && n >= (1u << 20)) { flush(); write_raw(s, n); return; }          // (a thread's whole stretch: no second copy)
+        b.insert(b.end(), s, s + n);
+        if (b.size() > (4u << 20)) flush();
+    }
     void put(const std::string &s) { put(s.data(), s.size()); }
     void write_raw(const void *p, size_t n)
     {
