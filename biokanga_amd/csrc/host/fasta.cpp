@@ -642,12 +642,13 @@ static bool inflate_gzip(const uint8_t *base, size_t size, int nthreads, RawVec<
 int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out, std::string *err, int qmode, bool split_records)
 {
     out.chunks.clear();
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && !S_ISREG(st.st_mode)) return 0;       // a FIFO, a pipe of a process substitution: the serial reader's
     int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) {
         if (err) *err = "unable to open '" + path + "'";
         return -90;
     }
-    struct stat st;
     if (fstat(fd, &st) != 0 || st.st_size < (64 << 10)) { ::close(fd); return 0; }
     size_t size = (size_t)st.st_size;
     void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -708,10 +709,10 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
 
 uint64_t text_bytes_estimate(const std::string &path)
 {
-    int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return 0;
     struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return 0; }
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return 0;     // (a FIFO is not opened just to be looked at:
+    int fd = ::open(path.c_str(), O_RDONLY);                                                      // its writer would see its reader go away)
+    if (fd < 0) return 0;
     const size_t size = (size_t)st.st_size;
     uint8_t head[18] = {0}, tail[8] = {0};
     const bool gz = size >= 26 && pread(fd, head, 18, 0) == 18 && head[0] == 0x1f && head[1] == 0x8b && pread(fd, tail, 8, (off_t)(size - 8)) == 8;

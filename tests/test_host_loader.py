@@ -116,3 +116,18 @@ def test_gzip_mate_files_opened_side_by_side_give_the_plain_files_store(harness,
     gz = both(harness, ["pe", 3, 2, 50, 250, 0, 1, a + ".gz", b + ".gz"], whole=2)
     bgz = both(harness, ["pe", 3, 2, 50, 250, 0, 1, a + ".bgz", b + ".gz"], whole=2)
     assert plain[0][0] == plain[1][0] == gz[0][0] == gz[1][0] == bgz[0][0] == bgz[1][0], (plain, gz, bgz)
+
+
+def test_a_fifo_as_read_file_is_opened_once_and_read_to_its_end(harness, tmp_path):
+    """-i names a FIFO (or a process substitution's pipe): it is not opened to be looked at first - its writer would lose its reader and
+    die of SIGPIPE - and the record-by-record reader takes it: the plain file's store, the writer ends normally"""
+    a, fifo = str(tmp_path / "a.fq"), str(tmp_path / "in.fifo")
+    reads_file(a, 14000, 51, fastq=True)
+    want = both(harness, ["se", 0, 0, 50, 250, 0, 1, a], whole=1)[0][0]
+    os.mkfifo(fifo)
+    for T in ("1", "8"):
+        writer = subprocess.Popen(["sh", "-c", f"cat '{a}' > '{fifo}'"])
+        r = subprocess.run([harness, "se", T, "0", "0", "50", "250", "0", "1", fifo], capture_output=True, timeout=300)
+        assert writer.wait(timeout=60) == 0
+        lines = [l for l in r.stdout.decode().splitlines() if not l.startswith("[")]
+        assert r.returncode == 0 and "".join(lines) == want, (r.stdout[-500:], r.stderr[-500:])
