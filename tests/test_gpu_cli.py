@@ -15,7 +15,7 @@ BIN = os.path.join(helpers.ROOT, "biokanga_amd", "bin", "biokanga")
 
 
 def run(args, cwd, env=None):
-    r = subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+    r = subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,     # (a hang is a failure)
                        env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-3000:]
     return r.stdout
