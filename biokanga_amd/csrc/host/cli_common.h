@@ -235,31 +235,48 @@ struct SamPrealloc {
     }
 };
 
-// `n` bytes as gzip members (RFC 1952; level 6, what gzopen's default gives) appended to `out`: a gzip file is any number of members
-// one after the other, so threads can compress their own stretches of an output and the members go out in order
+// `n` bytes as gzip members appended to `out`: a gzip file is any number of members one after the other, so threads can compress
+// their own stretches of an output and the members go out in order.  The members are bgzip's (BGZF: at most 0xff00 bytes of text
+// each, its whole size in a 'BC' extra field; level 6, gzopen's default): every gzip reader takes the file as it would one stream,
+// and readers that know the framing - samtools, tabix, this package's own loader - can inflate it by all their threads.
 inline bool gzip_members(const char *s, size_t n, std::vector<uint8_t> &out)
 {
-    const size_t kMost = (size_t)1 << 30;
-    do {
-        const size_t k = std::min(n, kMost);
-        z_stream z;
-        memset(&z, 0, sizeof(z));
-        if (deflateInit2(&z, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        const size_t at = out.size(), room = (size_t)deflateBound(&z, (uLong)k) + 64;
-        out.resize(at + room);
-        z.next_in = (Bytef *)const_cast<char *>(s);
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    const size_t kText = 0xff00, kRoom = 0x10000;
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.reserve(out.size() + n / 3 + kRoom);
+    bool ok = true;
+    for (size_t o = 0; ok && o < n; o += kText) {
+        const size_t k = std::min(kText, n - o), at = out.size();
+        out.resize(at + kRoom);
+        uint8_t *b = out.data() + at;
+        memcpy(b, hdr, 16);
+        z.next_in = (Bytef *)const_cast<char *>(s + o);
         z.avail_in = (uInt)k;
-        z.next_out = out.data() + at;
-        z.avail_out = (uInt)room;
-        const int rc = deflate(&z, Z_FINISH);
-        const size_t made = room - z.avail_out;
-        deflateEnd(&z);
-        if (rc != Z_STREAM_END) { out.resize(at); return false; }
-        out.resize(at + made);
-        s += k;
-        n -= k;
-    } while (n);
-    return true;
+        z.next_out = b + 18;
+        z.avail_out = (uInt)(kRoom - 18 - 8);
+        ok = deflate(&z, Z_FINISH) == Z_STREAM_END;
+        const size_t made = kRoom - 18 - 8 - z.avail_out, total = 18 + made + 8;
+        const uint16_t bsize = (uint16_t)(total - 1);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(s + o), (uInt)k), isize = (uint32_t)k;
+        memcpy(b + 16, &bsize, 2);
+        memcpy(b + 18 + made, &crc, 4);
+        memcpy(b + 18 + made + 4, &isize, 4);
+        out.resize(at + (ok ? total : 0));
+        deflateReset(&z);
+    }
+    deflateEnd(&z);
+    return ok;
+}
+
+// the empty member that ends a bgzip'd file (and is all of an empty one)
+inline const uint8_t *bgzf_eof(size_t *n)
+{
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    *n = sizeof(eof);
+    return eof;
 }
 
 struct OutBuf {
@@ -320,7 +337,7 @@ struct OutBuf {
     void close()
     {
         flush();
-        if (gz && !gz_wrote && fd >= 0) { std::vector<uint8_t> m; if (gzip_members("", 0, m)) write_raw(m.data(), m.size()); }   // (an empty text is one empty member)
+        if (gz && fd >= 0) { size_t n; const uint8_t *e = bgzf_eof(&n); write_raw(e, n); }       // (bgzip's end mark; an empty text is just that)
         if (fd >= 0) { fsync(fd); if (!borrowed) ::close(fd); }
         fd = -1;
     }

@@ -293,9 +293,10 @@ def test_text_size_of_a_large_gzip_member_from_its_length_word(harness, tmp_path
 
 
 @pytest.mark.parametrize("lines", [0, 1, 260000])
-def test_outputs_named_gz_are_gzip_members_in_order(tmp_path, lines):
-    """an output whose name ends in .gz: what is put and the members the writer's threads hand over come out as one gzip file - any number
-    of members, the text in order; nothing put: an empty text"""
+def test_outputs_named_gz_are_gzip_members_in_order(harness, tmp_path, lines):
+    """an output whose name ends in .gz: what is put and the members the writer's threads hand over come out as one gzip file - bgzip
+    members, the text in order; nothing put: an empty text.  This package's loader takes such a file by all threads (its size estimate
+    reads the members' lengths)"""
     import gzip
     exe = str(tmp_path / "outbuf_harness")
     subprocess.check_call(helpers.cxx() + ["-pthread", "-o", exe, os.path.join(helpers.ROOT, "tests", "cpp", "outbuf_harness.cpp"), "-lz"])
@@ -303,6 +304,10 @@ def test_outputs_named_gz_are_gzip_members_in_order(tmp_path, lines):
     h, total, failed = subprocess.check_output([exe, out, str(lines)]).decode().split()
     text = gzip.open(out, "rb").read()
     assert failed == "0" and len(text) == int(total)
+    raw = open(out, "rb").read()
+    assert raw.startswith(b"\x1f\x8b\x08\x04") and raw[12:14] == b"BC" and raw.endswith(b"\x1b\0\x03\0" + b"\0" * 8)
+    if lines:
+        assert subprocess.check_output([harness, out, "1", "est"]).decode().split() == ["text", total]         # the loader's walk over the members
     f = 1469598103934665603
     if lines <= 1:
         for c in text:
