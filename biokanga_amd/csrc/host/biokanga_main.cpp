@@ -5,10 +5,11 @@
 // the reference writes (libbiokanga/SAMfile.cpp:1521,1573-1575,1766,2110-2283).  The alignment
 // itself is ONLY available through libbiokanga_amd (HIP kernels); there is no host fallback.
 //
-//   biokanga index -i genome.fa [-i more.fa] -o genome.sfx -r name [-l minseqlen] [-d descr] [-t title]
+//   biokanga index -i genome.fa[.gz] [-i more.fa] -o genome.sfx -r name [-l minseqlen] [-d descr] [-t title] [-T threads] [--device n]
 //   biokanga align -i reads.fa[.gz] -I genome.sfx -o out.sam [-s subs] [-e 1|2] [-Q 0|1|2] [-m 0..3]
 //                  [-n maxNs] [-l minlen] [-L maxlen] [-y trim5] [-Y trim3] [-M 0|5|6] [-O stats.csv]
-//                  [-U 1..4 -u mates.fa -d minins -D maxins [-E]] [-T threads(ignored)] [-F logfile] [--device n]
+//                  [-U 1..4 -u mates.fa -d minins -D maxins [-E]] [-T host threads] [-F logfile] [--device n | --devices 0-7]
+//   (reads: FASTA / FASTQ, plain, gzip'd or bgzip'd, also through a FIFO; -o: a file, a name ending in .gz or .bam, or a FIFO)
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
@@ -104,7 +105,7 @@ int cmd_index(int argc, char **argv, int first)
         return 1;
     }
     if (!a.has("i") || !a.has("o") || !a.has("r")) {
-        fprintf(stderr, "usage: %s index -i <fasta> [-i <fasta>..] -o <out.sfx> -r <refspecies> [-l minseqlen] [-d descr] [-t title]\n", g_proc.c_str());
+        fprintf(stderr, "usage: %s index -i <fasta[.gz]> [-i <fasta>..] -o <out.sfx> -r <refspecies> [-l minseqlen] [-d descr] [-t title] [-T threads] [--device n]\n", g_proc.c_str());
         return 1;
     }
     if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
