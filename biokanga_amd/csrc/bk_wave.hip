@@ -18,6 +18,14 @@ namespace bk {
 // suffix array; only looked up when c2's walk was cut short).
 
 
+// -DBK_CAND_HIST (a measurement build, tools/cand_hist.py): where in the suffix array the windows this kernel fetches lie - per block of
+// 2^kHistShift suffix array indexes - and how they spread over the lengths of the core intervals they came from
+#ifdef BK_CAND_HIST
+constexpr int kHistShift = 6;
+__device__ uint32_t *g_hist_blk;                      // windows fetched per block
+__device__ unsigned long long g_hist_len[3][40];      // by floor(log2(interval length)): intervals, windows fetched, candidates processed
+#endif
+
 struct WaveCoreInfo {
     unsigned long long first;
     uint32_t n;
@@ -255,6 +263,17 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
                     const uint64_t t = loci - (uint64_t)lofs;
                     bool valid = active && loci >= (uint64_t)lofs;
+#ifdef BK_CAND_HIST
+                    {
+                        const uint32_t ln = core[lc].n & ~kLazyFlag;
+                        const int lb = ln ? 31 - __clz((int)ln) : 0;
+                        if (valid) {
+                            if (g_hist_blk) atomicAdd(&g_hist_blk[(lfirst + j) >> kHistShift], 1u);
+                            atomicAdd(&g_hist_len[1][lb], 1ULL);
+                        }
+                        if (active && j == 0) atomicAdd(&g_hist_len[0][lb], 1ULL);
+                    }
+#endif
                     IWindow<NW> w;
                     w.mm = 127; w.eos = true;
 #pragma unroll
@@ -368,6 +387,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                         exit_now = true;
                         if (GROUP && grouped) n_search -= (unsigned long long)(ce - 1 - __shfl(lc, cut_lane));      // the cores behind the exit are never searched
                     }
+#ifdef BK_CAND_HIST
+                    if (proc && ((keep >> lane) & 1)) { const uint32_t ln = core[lc].n & ~kLazyFlag; atomicAdd(&g_hist_len[2][ln ? 31 - __clz((int)ln) : 0], 1ULL); }
+#endif
                     uint64_t procmask = __ballot(proc) & keep;
                     uint32_t nproc = (uint32_t)__popcll(procmask);
                     iter += nproc;
@@ -523,3 +545,29 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 }
 
 }  // namespace bk
+
+#ifdef BK_CAND_HIST
+// op 0: (re)allocate and zero the per-block histogram for n suffix array indexes, zero the per-length one; op 1: copy the per-block counts
+// (n of them) to out; op 2: the per-length histogram (3 x 40 x 8 bytes); op 3: free
+extern "C" int bk_debug_cand_hist(int op, void *out, unsigned long long n)
+{
+    static uint32_t *d_blk = nullptr;
+    static unsigned long long n_blk = 0;
+    if (op == 0 || op == 3) {
+        if (d_blk) (void)hipFree(d_blk);
+        d_blk = nullptr;
+        n_blk = 0;
+        if (op == 0) {
+            n_blk = (n >> bk::kHistShift) + 2;
+            if (hipMalloc(&d_blk, n_blk * 4) != hipSuccess || hipMemset(d_blk, 0, n_blk * 4) != hipSuccess) return 1;
+        }
+        unsigned long long z[3][40] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bk::g_hist_blk), &d_blk, sizeof(d_blk)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bk::g_hist_len), z, sizeof(z)) != hipSuccess) return 1;
+        return hipDeviceSynchronize() != hipSuccess;
+    }
+    if (op == 1) return hipMemcpy(out, d_blk, (n < n_blk ? n : n_blk) * 4, hipMemcpyDeviceToHost) != hipSuccess;
+    if (op == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::g_hist_len), 3 * 40 * 8) != hipSuccess;
+    return 1;
+}
+#endif
