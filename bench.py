@@ -346,13 +346,16 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+SWIN_TUNE = {"off": 0, "partial": 1, "full": 3}       # bk_ctx_tune("use_swin", ..) per index layout
+
+
 def fetch_correction(kernel, window_array):
     """FETCH_SIZE calibration for `kernel`'s access pattern (MI355X_MICROARCH.md: the counter reports HALF of a wide coalesced
     16 B/lane streaming read).  Our patterns were measured with tools/rand_access_bench under `rocprofv3 --pmc FETCH_SIZE`
     (profiles/*_fetch_calibration.csv): random 8-byte loads count 64.0 B each and random 80-byte windows 96 B (no correction) - what
     the search passes, k_flat and k_wave WITHOUT the window array do; runs of 64 consecutive 48-byte window-array entries plus their
     coalesced suffix array elements - k_wave WITH the window array - count about half.  Returns (factor on FETCH_SIZE, source)."""
-    if not (kernel == "k_wave" and window_array):
+    if not (kernel == "k_wave" and window_array in ("partial", "full", True)):
         return 1.0, "random-line pattern: FETCH_SIZE counts 64.0 B per random 8-byte load (calibrated, no correction)"
     import csv
     import glob
@@ -396,7 +399,7 @@ def live_traffic(kernel, extra_args, window_array, budget_s=240):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--window-array", "on" if window_array else "off"] + extra_args
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--window-array", window_array] + extra_args
             t0 = time.time()
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=budget_s)
@@ -598,10 +601,12 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help="(internal) one step only, nothing reported: what the live counter passes profile")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
-    ap.add_argument("--window-array", default="policy", choices=["policy", "on", "off"],
-                    help="index layout of the headline: 'policy' = what `biokanga align` picks for this many reads per device (the "
-                         "suffix-ordered window array from 600 M reads on); the other layout is measured beside it")
+    ap.add_argument("--window-array", default="policy", choices=["policy", "partial", "on", "off", "full"],
+                    help="index layout of the headline: 'policy' = what `biokanga align` picks for this many reads per device; 'partial' (= 'on') = the "
+                         "suffix-ordered window array for the part of the suffix array the wave kernel's long walks visit; 'full' = for every suffix "
+                         "(149 GB at 3.1 Gbp); the other layouts are measured beside it")
     ap.add_argument("--no-other-layout", action="store_true", help="measure the headline's index layout only")
+    ap.add_argument("--other-layouts", default="off,partial,full", help="which of off / partial / full to measure beside the headline's")
     ap.add_argument("--no-host-leg", action="store_true", help="kernel-only steps only (profiling runs): `value` is then the kernel-only rate and says so")
     ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the reads cross PCIe: "
                     "2 bit/base (bk_stream_submit_packed) or 1 byte/base (bk_stream_submit)")
@@ -745,8 +750,8 @@ def main():
 
     # ---------------------------------------------------------------- the index layout of the headline, and the other one
     job_reads = max(args.reads, cfg.get("job_reads_per_gpu", args.reads))
-    policy_on = job_reads >= CLI_WINDOW_ARRAY_MIN_READS
-    headline_on = {"policy": policy_on, "on": True, "off": False}[args.window_array]
+    policy_layout = "partial" if job_reads >= CLI_WINDOW_ARRAY_MIN_READS else "off"
+    headline = {"policy": policy_layout, "on": "partial"}.get(args.window_array, args.window_array)
     host = None
     if not args.no_host_leg:
         try:
@@ -754,16 +759,20 @@ def main():
         except Exception as e:       # reporting only - never lose the measured line
             log(f"host leg unavailable: {e!r}")
 
-    def measure(window_array):
+    def measure(layout):
         """both clocks in one index layout: `warmup` untimed + exactly `steps` timed steps each, a barrier + device synchronisation on
         both sides of the timed steps, the maximum over ranks"""
-        res = {}
+        res = {"layout": layout}
         t_set = time.time()
-        al.tune("use_swin", 1 if window_array else 0)
+        al.tune("use_swin", SWIN_TUNE[layout])
         step()                                             # (builds the window array when it is asked for, fits and serves these reads)
         torch.cuda.synchronize()
         t_first = time.time() - t_set
         res["window_array_resident"] = al.tune("swin_resident", 0) == 1
+        if res["window_array_resident"]:
+            # the library's own clock around allocation + construction, what array and map occupy, the share of the suffix array held
+            res["window_array"] = {"setup_s": al.tune("swin_setup_us", 0) / 1e6, "gb": al.tune("swin_mbytes", 0) * 1048576 / 1e9,
+                                   "share_of_suffix_array": al.tune("swin_covered_ppm", 0) / 1e6}
         for _ in range(max(0, args.warmup - 1)):
             step()
         first_out = out.clone()                            # results of an untimed step, to check repeatability
@@ -792,7 +801,7 @@ def main():
         return res
 
     if args.sweep:
-        al.tune("use_swin", 1 if headline_on else 0)
+        al.tune("use_swin", SWIN_TUNE[headline])
         name, vals = args.sweep.split("=")
         for v in vals.split(","):
             al.tune(name, int(v))
@@ -805,20 +814,22 @@ def main():
             log(f"sweep {name}={v}: {1e3 * (time.time() - t1):.1f} ms/step wall; device {al.timing(reset=True)}")
     if args.pmc_child:
         # what the counter passes profile: ONE step in the headline's layout, nothing reported
-        al.tune("use_swin", 1 if headline_on else 0)
+        al.tune("use_swin", SWIN_TUNE[headline])
         step()
         torch.cuda.synchronize()
         al.close()
         return
-    main_leg = measure(headline_on)
-    if headline_on and not main_leg["window_array_resident"]:
-        headline_on = False              # (asked for, but this index / these reads cannot have it: 5-byte elements, long reads, no room)
-    other_leg = None
+    main_leg = measure(headline)
+    if headline != "off" and not main_leg["window_array_resident"]:
+        headline = "off"                 # (asked for, but this index / these reads cannot have it: 5-byte elements, long reads, no room)
+    other_legs = {}
     if not args.no_other_layout and E == 4:
-        other_leg = measure(not headline_on)
-        if not headline_on and not other_leg["window_array_resident"]:
-            other_leg = None             # the library did not build it: there is no second layout to report
-        al.tune("use_swin", 1 if headline_on else 0)
+        for lay in [x for x in args.other_layouts.split(",") if x in SWIN_TUNE and x != headline]:
+            leg = measure(lay)
+            if lay == "off" or leg["window_array_resident"]:      # (else the library did not build it: there is no such layout to report)
+                other_legs[lay] = leg
+        al.tune("use_swin", SWIN_TUNE[headline])
+    headline_on = headline != "off"
     if os.environ.get("BK_DIAG"):
         print("diag counters:", main_leg["ctr"], file=sys.stderr)
         import ctypes
@@ -880,11 +891,11 @@ def main():
     torch.cuda.empty_cache()
     traffic = traffic_raw = None
     traffic_src = None
-    corr, corr_src = fetch_correction(dom, headline_on)
+    corr, corr_src = fetch_correction(dom, headline)
     if rank == 0 and world == 1 and not args.no_live_traffic and E == 4:       # (two more 17 Gbp set-ups would take minutes)
         child_args = ["--config", args.config, "--reads", str(args.reads), "--genome-mbp", str(args.genome_mbp)] + \
                      [x for kv in args.tune for x in ("--tune", kv)]
-        got, traffic_src = live_traffic(dom, child_args, headline_on)
+        got, traffic_src = live_traffic(dom, child_args, headline)
         if got is None:
             log(f"live traffic unavailable: {traffic_src}")
         else:
@@ -899,7 +910,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_as_counted": traffic_raw, "traffic_source": traffic_src,
                 "traffic_correction": {"factor_on_FETCH_SIZE": corr, "source": corr_src},
-                "window_array": "on" if headline_on else "off",
+                "window_array": headline,
                 "algorithmic_bytes_per_launch": kern[dom]["bytes"] / max(1, dom_launches),
                 "avg_launch_ms": dom_ms / max(1, dom_launches),
                 "per_kernel": {k: {"algorithmic_GBs": round(v["GBs"], 1), "ms": round(v["ms"], 2), "launches": v["launches"],
@@ -909,10 +920,10 @@ def main():
                 "whole_step_algorithmic_GBs": whole, "whole_step_frac": whole / HBM_PEAK_GBS,
                 "device_ms": {k: tim[k] for k in ("ms_total", "ms_search", "ms_extend", "ms_heavy", "ms_other", "ms_prep")}}
 
-    def layout_record(leg, on):
+    def layout_record(leg):
         k2, st2 = kernels_of(leg["ctr"], leg["tim"])
         d = max(k2, key=lambda q: k2[q]["ms"])
-        return {"window_array": "on" if on else "off",
+        return {"window_array": leg["layout"], **({"window_array_built": leg["window_array"]} if "window_array" in leg else {}),
                 "value_host_in_host_out": (leg.get("host") or {}).get("value"),
                 "value_kernel_only": total_reads / leg["kernel_only_elapsed"],
                 "ms_per_step_kernel_only": leg["kernel_only_elapsed"] / args.steps * 1e3,
@@ -921,16 +932,15 @@ def main():
                 "results_bitwise_equal_across_steps": leg["repeatable"],
                 "host_results_bit_identical": (leg.get("host") or {}).get("results_bit_identical_to_kernel_only_steps")}
 
-    layouts = {("window_array_on" if headline_on else "window_array_off"): layout_record(main_leg, headline_on)}
-    setup_s = None
-    if other_leg is not None:
-        layouts["window_array_on" if not headline_on else "window_array_off"] = layout_record(other_leg, not headline_on)
-        on_leg = other_leg if not headline_on else main_leg
-        # (first step in the layout - allocation of 48 B per suffix, k_build_swin - minus a steady kernel-only step)
-        setup_s = max(0.0, on_leg["first_step_s"] - on_leg["kernel_only_elapsed"] / args.steps)
-        same = bool(np.array_equal(main_leg["hits"].view(np.uint8), other_leg["hits"].view(np.uint8)))
-        layouts["results_bit_identical_between_layouts"] = same
-    on_rec, off_rec = layouts.get("window_array_on"), layouts.get("window_array_off")
+    layouts = {"window_array_" + headline: layout_record(main_leg)}
+    for lay, leg in other_legs.items():
+        layouts["window_array_" + lay] = layout_record(leg)
+    if other_legs:
+        layouts["results_bit_identical_between_layouts"] = bool(all(np.array_equal(main_leg["hits"].view(np.uint8), leg["hits"].view(np.uint8))
+                                                                    for leg in other_legs.values()))
+    part_rec, full_rec, off_rec = layouts.get("window_array_partial"), layouts.get("window_array_full"), layouts.get("window_array_off")
+    built = ((layouts.get("window_array_" + headline) or {}).get("window_array_built") or (part_rec or {}).get("window_array_built") or {})
+    setup_s = built.get("setup_s")
 
     fmt = dict(reads=args.reads, pairs=args.reads // 2, read_len=args.read_len, max_subs=args.max_subs)
     result = {
@@ -941,14 +951,15 @@ def main():
                        "kernel-only: reads and results resident in HBM (the host-in / host-out steps were switched off or failed)",
         "value_kernel_only": kernel_only_value,
         "value_no_window_array": (off_rec or {}).get("value_host_in_host_out") or (off_rec or {}).get("value_kernel_only"),
-        "value_window_array": (on_rec or {}).get("value_host_in_host_out") or (on_rec or {}).get("value_kernel_only"),
-        "window_array_setup_s": setup_s,
+        "value_window_array": (part_rec or {}).get("value_host_in_host_out") or (part_rec or {}).get("value_kernel_only"),
+        "value_window_array_full": (full_rec or {}).get("value_host_in_host_out") or (full_rec or {}).get("value_kernel_only"),
+        "window_array_setup_s": setup_s, "window_array_gb": built.get("gb"), "window_array_share_of_suffix_array": built.get("share_of_suffix_array"),
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic {'wheat' if E == 5 else 'GRCh38'}-like genome of {total_bp} bp in "
                                f"{len(seq_lens)} sequences ({int(100 * cfg.get('repeat_frac', 0.45))}% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
-                   "window_array": ("on" if headline_on else "off") + (f" (what `biokanga align` picks for the {job_reads} reads a device aligns in this configuration: the suffix-ordered window "
-                                    f"array from {CLI_WINDOW_ARRAY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
+                   "window_array": headline + (f" (what `biokanga align` picks for the {job_reads} reads a device aligns in this configuration: the partial suffix-ordered "
+                                    f"window array from {CLI_WINDOW_ARRAY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
                    "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",

@@ -60,7 +60,13 @@ struct bk_ctx {
     int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
     void *d_swin = nullptr;               // suffix-ordered window array (DevIndex::swin), built when the first batch it serves arrives
-    int use_swin = 1;
+    uint32_t *d_swmap = nullptr;          // .. and which blocks of the suffix array it holds (DevIndex::swmap; null: all of them)
+    int use_swin = 1;         // 0: none; 1: the part of the suffix array the wave kernel's long walks visit; 2: the same, whatever the batch's read lengths; 3: every suffix
+    uint64_t swin_budget = 0; // most bytes the partial array may take (0: by the free memory)
+    int swin_w = 0;           // the core length the partial array's coverage was made for
+    uint64_t swin_bytes = 0;  // what array and map occupy
+    double swin_setup_s = 0;  // .. and what making them took (allocation included)
+    double swin_covered = 0;  // .. share of the suffix array it holds
     bool swin_denied = false; // it did not fit beside a batch's scratch when first asked for
     int wave_group = 0;      // wave kernel, reads of <= 128 bases: consecutive small core intervals share a round (always so for longer reads)
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only

@@ -44,7 +44,7 @@ __device__ __forceinline__ int k2_cmp(uint32_t key, uint32_t m, uint32_t q2)
 __device__ __forceinline__ bool k2_nkind(uint32_t key) { return key != kK2Above && (key & 3u) == 1u; }
 
 // mask of the first L = min(rem2, kK2Bases) bases of a key; rem2 = bases of the core beyond the k-mer table's k
-__device__ __forceinline__ uint32_t k2_mask(int rem2)
+__host__ __device__ __forceinline__ uint32_t k2_mask(int rem2)
 {
     const int L = rem2 < kK2Bases ? rem2 : kK2Bases;
     return L <= 0 ? 0u : ~0u << (32 - 2 * L);

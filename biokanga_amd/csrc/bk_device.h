@@ -53,6 +53,10 @@ constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Ali
 constexpr uint32_t kNodeCap = 1024000; // cMaxNumIdentNodes, SfxArrayV2.h:15
 constexpr uint64_t kEosWord = 0x7777777777777777ULL;
 constexpr int kSwBases = 192, kSwPre = 92, kSwLen = 100;      // DevIndex::swin
+constexpr int kSwBlkShift = 5;                                // DevIndex::swmap: coverage goes by blocks of 32 suffix array indexes
+constexpr uint32_t kSwNone = 0xFFFFFFFFu;                     //   .. a block the window array does not hold
+constexpr uint32_t kSwMinRun = 65, kSwHead = 192;             //   .. the coverage rule (bk_index.hip, k_swin_cover)
+constexpr int kSwLevels = 4;                                  //   .. applied for this many core lengths at most (the reads' last phases)
 constexpr uint32_t kReadHasN = 1u << 15;   // DevBatch::rmeta
 constexpr uint32_t kReadLenMask = kReadHasN - 1;
 
@@ -79,6 +83,10 @@ struct DevIndex {
                                 //   elements - then fetch their target windows from CONSECUTIVE entries (a streaming read, 130 G
                                 //   entries/s) instead of one random cache line each (50 G/s).  Reads of up to kSwLen bases whose
                                 //   core offsets stay within kSwPre; 4-byte indexes with 48 bytes per base of HBM to spare; may be null
+    const uint32_t *swmap;      // null: swin holds every suffix.  Else swin holds only the blocks of 2^kSwBlkShift suffix array indexes that the
+                                //   wave kernel's long walks visit: swmap[i >> kSwBlkShift] = the block's number in swin, or kSwNone.
+                                //   Neighbouring covered blocks have neighbouring numbers, so a core interval whose first and last
+                                //   block are as far apart in swin as in the suffix array reads its entries from ONE run of swin
     uint64_t n;                 // concat_len
     uint32_t n_ent;
     int k;                      // k-mer table order (0 = none)

@@ -52,6 +52,10 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
+void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t n_words, hipStream_t s);
+void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
+void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *map, hipStream_t s);
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -1037,9 +1041,9 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     return BK_OK;
 }
 
-// The suffix-ordered window array (DevIndex::swin, 48 bytes per suffix) is built when the first batch it can serve arrives - reads of up
-// to kSwLen bases whose core offsets stay within kSwPre - and only if, next to it, the HBM still holds this batch's scratch with room to
-// spare: it trades capacity (149 GB for a 3.1 Gbp index on a 288 GB device) for locality.
+// The suffix-ordered window array (DevIndex::swin, 48 bytes per suffix it holds) is built when the first batch it can serve arrives - reads
+// of up to kSwLen bases whose core offsets stay within kSwPre - for the part of the suffix array the wave kernel's long walks visit
+// (bk_index.hip, k_swin_cover: a tenth of a 3.1 Gbp index), within a budget of the HBM that is free next to this batch's scratch.
 }  // (anonymous)
 
 // frees the suffix-ordered window array (and does not build it again): called when something else needs the HBM
@@ -1050,32 +1054,137 @@ void bk::release_swin(bk_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     free_dev(c->d_swin);
+    free_dev(c->d_swmap);
     c->d_swin = nullptr;
+    c->d_swmap = nullptr;
     c->ix.swin = nullptr;
+    c->ix.swmap = nullptr;
+    c->swin_bytes = 0;
     c->swin_denied = true;
     fprintf(stderr, "biokanga_amd: window array released to make room\n");
 }
 
 namespace {
 
+// the core lengths reads of maxlen bases are searched with, shortest first (LocateCoreMultiples' CoreLen per phase of AlignReads' schedule):
+// the last phase's, then the ones before it; at most kSwLevels of them.  Returns their number
+int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w)
+{
+    const ReadPlan p = make_plan((int)std::max<uint32_t>(maxlen, 1), c->cfg);
+    int n = 0;
+    for (int ph = p.n_phases - 1; ph >= 0 && n < kSwLevels; ph--) {
+        int mm, cl, cd;
+        phase_params(p, c->cfg, ph, mm, cl, cd);
+        cl = std::min(std::max(cl, c->ix.k), 120);
+        if (n == 0 || cl > w[n - 1]) w[n++] = cl;
+    }
+    return n;
+}
+
+// The partial array: per level (core length) the break bitmap of the runs of suffixes sharing that many bases and the per-block coverage
+// it implies, block numbers by a scan, then the entries - no more of them than `budget` bytes hold (blocks beyond it stay uncovered:
+// coverage never changes a result).
+int build_partial_swin(bk_ctx *c, const int *w, int n_levels, uint64_t budget, hipStream_t s)
+{
+    const uint64_t n = c->ix.n;
+    const uint64_t n_blocks = (n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
+    const uint64_t n_words = (n >> 6) + 4;
+    unsigned long long *d_brk[kSwLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_flags = nullptr, *d_incl = nullptr, *d_map = nullptr;
+    void *d_tmp = nullptr, *d_ent = nullptr;
+    auto cleanup = [&]() { for (auto &q : d_brk) { free_dev(q); q = nullptr; } free_dev(d_flags); free_dev(d_incl); free_dev(d_tmp); };
+    auto fail = [&](int rc) { cleanup(); free_dev(d_map); free_dev(d_ent); return rc; };
+#define SW_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL); } } while (0)
+    StageClock clk;
+    auto lap = [&](const char *what) { if (clk.on) { (void)hipStreamSynchronize(s); clk.lap(what); } };
+    for (int l = 0; l < n_levels; l++) SW_TRY(dev_malloc(&d_brk[l], n_words * 8));
+    SW_TRY(dev_malloc(&d_flags, n_blocks * 4));
+    SW_TRY(dev_malloc(&d_incl, n_blocks * 4));
+    SW_TRY(dev_malloc(&d_map, n_blocks * 4));
+    lap("  window array: scratch");
+    launch_swin_breaks(c->ix, w, n_levels, d_brk, n_words, s);
+    lap("  window array: run starts");
+    // a run is walked whole when the copy-count check at IterCnt == 100 lets it pass: up to MaxIter + 100-odd suffixes
+    const uint32_t max_run = c->cfg.max_iter > 0 ? (uint32_t)c->cfg.max_iter + 256u : 1u << 20;
+    for (int l = 0; l < n_levels; l++) launch_swin_cover(d_brk[l], n, max_run, d_flags, n_blocks, l == 0, s);
+    SW_TRY(hipGetLastError());
+    size_t tb = 0;
+    SW_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_flags, d_incl, (size_t)n_blocks, s));
+    SW_TRY(dev_malloc(&d_tmp, tb + 256));
+    SW_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tb, d_flags, d_incl, (size_t)n_blocks, s));
+    uint32_t covered = 0;
+    SW_TRY(hipMemcpyAsync(&covered, d_incl + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
+    SW_TRY(hipStreamSynchronize(s));
+    lap("  window array: coverage + scan");
+    const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
+    const uint32_t cap_blocks = (uint32_t)std::min<uint64_t>(covered, budget / block_bytes);
+    if (cap_blocks == 0) { cleanup(); free_dev(d_map); return 1; }          // (nothing to hold, or no room for any of it)
+    launch_swin_map(d_flags, d_incl, n_blocks, cap_blocks, d_map, s);
+    SW_TRY(hipGetLastError());
+    for (auto &q : d_brk) { free_dev(q); q = nullptr; }
+    SW_TRY(dev_malloc(&d_ent, (uint64_t)cap_blocks * block_bytes));
+    lap("  window array: allocation");
+    launch_swin_fill(c->ix, d_map, d_ent, s);
+    SW_TRY(hipGetLastError());
+    SW_TRY(hipStreamSynchronize(s));
+    lap("  window array: entries");
+#undef SW_TRY
+    cleanup();
+    c->d_swin = d_ent;
+    c->d_swmap = d_map;
+    c->swin_w = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16);
+    c->swin_bytes = (uint64_t)cap_blocks * block_bytes + n_blocks * 4;
+    c->swin_covered = (double)cap_blocks / (double)n_blocks;
+    return BK_OK;
+}
+
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
-    if (c->d_swin || !c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->use_wave || !c->use_flat) return BK_OK;
+    if (!c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->ix.k2 || !c->use_wave || !c->use_flat) return BK_OK;
+    const bool full = c->use_swin == 3;
+    int w[kSwLevels];
+    const int n_levels = swin_core_lens(c, maxlen, w);
+    const int w_key = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16);
+    if (c->d_swin) {
+        // (a partial array made for other core lengths - another read length, an eager build's guess - is made again: it costs little)
+        if (full == (c->d_swmap == nullptr) && (full || c->swin_w == w_key)) return BK_OK;
+        HIP_TRY(hipStreamSynchronize(s));
+        free_dev(c->d_swin); free_dev(c->d_swmap);
+        c->d_swin = nullptr; c->d_swmap = nullptr; c->ix.swin = nullptr; c->ix.swmap = nullptr; c->swin_bytes = 0;
+    }
     // (reads of up to kSwLen bases take every window from it, reads of up to kSwBases - 32 - 2 x 150 - those of their middle cores; 2: whatever the batch)
-    if (c->use_swin < 2 && (maxlen > (uint32_t)(kSwBases - 32) || (maxlen <= (uint32_t)kSwLen && (int)maxlen - c->cfg.min_core_len > kSwPre))) return BK_OK;
+    if (c->use_swin == 1 && (maxlen > (uint32_t)(kSwBases - 32) || (maxlen <= (uint32_t)kSwLen && (int)maxlen - make_plan((int)maxlen, c->cfg).core_len > kSwPre))) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = c->ix.n * 48;
     const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), rd2w_for(maxlen), iv_cores_for(c, maxlen));
     const uint64_t have = (uint64_t)c->cap_reads * scratch_bytes_per_read(c->cap_wpr, c->cap_rd2w, c->cap_iv_cores);
     const uint64_t missing = want > have ? want - have : 0;
-    if ((uint64_t)free_b < need + missing * 4 / 3 + (6ULL << 30)) { c->swin_denied = true; return BK_OK; }  // (the chunk size is set from 3/4 of the free memory; asked once)
+    const uint64_t reserve = missing * 4 / 3 + (6ULL << 30);                // (the chunk size is set from 3/4 of the free memory)
     StageClock clk;
-    if (dev_malloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }   // (asked once)
-    launch_build_swin(c->ix, c->d_swin, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    const double t0 = StageClock::now();
+    if (full) {
+        const uint64_t need = c->ix.n * 48;
+        if ((uint64_t)free_b < need + reserve) { c->swin_denied = true; return BK_OK; }      // (asked once)
+        if (dev_malloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }
+        launch_build_swin(c->ix, c->d_swin, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        c->swin_bytes = need;
+        c->swin_covered = 1.0;
+    } else {
+        // at most a third of what every suffix would take, and no more than half of what is free beyond the batch's own needs
+        const uint64_t work = ((c->ix.n >> kSwBlkShift) + 1) * 12 + (c->ix.n >> 3) * kSwLevels + (64ULL << 20);      // (flags, scan, map, break bitmaps while it is made)
+        if ((uint64_t)free_b < reserve + work + (1ULL << 30)) { c->swin_denied = true; return BK_OK; }
+        uint64_t budget = std::min<uint64_t>(c->ix.n * 16, ((uint64_t)free_b - reserve - work) / 2);
+        if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
+        const int rb = build_partial_swin(c, w, n_levels, budget, s);
+        if (rb == BK_ERR_INTERNAL) return rb;
+        if (rb) { c->swin_denied = true; return BK_OK; }                   // (no room, or nothing worth covering: asked once)
+    }
     c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
+    c->ix.swmap = c->d_swmap;
+    c->swin_setup_s = StageClock::now() - t0;
+    if (clk.on) fprintf(stderr, "biokanga_amd: window array for %.1f %% of the suffix array (runs sharing %d .. %d bases, %d levels), %.2f GB\n", 100.0 * c->swin_covered, w[0], w[n_levels - 1], n_levels, c->swin_bytes / 1e9);
     clk.lap("suffix-ordered windows");
     return BK_OK;
 }
@@ -1368,16 +1477,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         return rc;
     }
     c->dataset = f.dataset;
-    // the window array's memory, when the caller wants the array from the start: a fresh process spends longer in this one allocation
-    // (16 ms per GB) than in the upload below, so a thread of its own makes it meanwhile
-    void *swin_mem = nullptr;
-    std::thread swin_alloc;
     const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32);
-    if (eager_swin)
-        swin_alloc = std::thread([&swin_mem, &f, device_id]() {
-            if (hipSetDevice(device_id) != hipSuccess || dev_malloc(&swin_mem, f.concat_len * 48) != hipSuccess) { (void)hipGetLastError(); swin_mem = nullptr; }
-        });
-    struct JoinSwin { std::thread &t; void *&mem; bool keep = false; ~JoinSwin() { if (t.joinable()) t.join(); if (!keep && mem) { (void)hipFree(mem); mem = nullptr; } } } join_swin{swin_alloc, swin_mem};
     // stage the file image through HBM: bases and suffix array as they are on disk
     // (4-byte suffix array elements are stored as the file holds them: they travel straight to where they stay)
     uint8_t *d_seq = nullptr, *d_sa = nullptr;
@@ -1435,16 +1535,9 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     if (rc) { bk_ctx_destroy(c); return rc; }
     clk.lap("(rest of bk_ctx_create)");
     if (eager_swin) {
-        swin_alloc.join();
-        clk.lap("waited for the window array's memory");
-        if (swin_mem && c->ix.tgt2 && c->ix.isa && c->use_wave && c->use_flat) {
-            c->d_swin = swin_mem;
-            join_swin.keep = true;
-            launch_build_swin(c->ix, c->d_swin, c->stream);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
-            c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
-            clk.lap("suffix-ordered windows");
-        }
+        // (made for reads of a hundred bases; a first batch of another shortest core length makes it again, which costs little)
+        rc = maybe_build_swin(c, 100, c->chunk_reads, c->stream);
+        if (rc) { bk_ctx_destroy(c); return rc; }
     }
     *out = c;
     return BK_OK;
@@ -1537,7 +1630,7 @@ void bk_ctx_destroy(bk_ctx *c)
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
     free_dev(c->d_stripe_cnt);
-    free_dev(c->d_isa); free_dev(c->d_swin); free_dev(c->d_seg2); free_dev(c->d_seq_global);
+    free_dev(c->d_isa); free_dev(c->d_swin); free_dev(c->d_swmap); free_dev(c->d_seg2); free_dev(c->d_seq_global);
     free_dev(c->d_seq_counts); free_dev(c->d_ctr); free_dev(c->hs.htab); free_dev(c->hs.slot_epoch);
     free_dev(c->d_in_bases); free_dev(c->d_in_offs); free_dev(c->d_in_lens); free_dev(c->d_in_out);
     free_dev(c->d_in_words); free_dev(c->d_in_lens16); free_dev(c->d_in_exc); free_dev(c->d_scan_tmp); free_dev(c->d_ctr_aux);
@@ -1680,16 +1773,30 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     if (n == "swin_resident") return c->d_swin != nullptr ? 1 : 0;      // (read only: whether the window array is in HBM right now)
     if (n == "use_swin") {
         int64_t old = c->use_swin;
-        c->use_swin = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        c->use_swin = value < 0 ? 0 : (value > 3 ? 3 : (int)value);
         c->swin_denied = false;
-        if (!c->use_swin && c->d_swin) {
+        if (c->d_swin && (!c->use_swin || (c->use_swin == 3) != (c->d_swmap == nullptr))) {
             if (c->stream) (void)hipStreamSynchronize(c->stream);
             free_dev(c->d_swin);
+            free_dev(c->d_swmap);
             c->d_swin = nullptr;
+            c->d_swmap = nullptr;
             c->ix.swin = nullptr;
+            c->ix.swmap = nullptr;
+            c->swin_bytes = 0;
         }
         return old;
     }
+    if (n == "swin_budget_kb") {            // most the partial window array may take (0: what the free memory allows); applies to the next build
+        int64_t old = (int64_t)(c->swin_budget >> 10);
+        c->swin_budget = value > 0 ? (uint64_t)value << 10 : 0;
+        return old;
+    }
+    // (read only) what the window array occupies, what making it took, how much of the suffix array it holds
+    if (n == "swin_mbytes") return (int64_t)(c->swin_bytes >> 20);
+    if (n == "swin_setup_us") return (int64_t)(c->swin_setup_s * 1e6);
+    if (n == "swin_covered_ppm") return c->d_swin ? (int64_t)(c->swin_covered * 1e6) : 0;
+    if (n == "swin_core_lens") return c->d_swmap ? c->swin_w : 0;      // shortest | longest << 8 | levels << 16 of the core lengths its coverage was made for
     if (n == "use_isa") {
         int64_t old = c->use_isa;
         c->use_isa = value ? 1 : 0;

@@ -5,6 +5,9 @@
 //   k_build_k2 / k_check_k2          second-level keys
 //   k_build_isa                      inverse suffix array
 //   k_build_swin                     suffix-ordered window array
+//   k_swin_*                         .. for the part of the suffix array the wave kernel's long walks visit
+#include <algorithm>
+
 #include "bk_dev_k2.h"
 #include "bk_dev_window.h"
 
@@ -116,35 +119,229 @@ __global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigne
 
 // entry i of the suffix-ordered window array: kSwBases bases of the 2-bit target from sa[i] - kSwPre on (bases before the target's
 // start read as 0: no window that uses them passes the "candidate starts before the read does" test)
+__device__ __forceinline__ void swin_entry(const DevIndex &ix, uint64_t i, uint4 *__restrict__ dst)
+{
+    const int64_t base0 = (int64_t)ix.sa_lo[i] - kSwPre;
+    uint64_t wd[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int64_t pos = base0 + 32 * k;
+        uint64_t v;
+        if (pos >= 0) {
+            const uint64_t wi = (uint64_t)pos >> 5;
+            const unsigned sh = (unsigned)(pos & 31) << 1;
+            const uint64_t a = ix.tgt2[wi], bq = ix.tgt2[wi + 1];
+            v = (a << sh) | ((bq >> 1) >> (63 - sh));
+        } else if (pos > -32)
+            v = ix.tgt2[0] >> (unsigned)(2 * (-pos));
+        else
+            v = 0;
+        wd[k] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        dst[q] = make_uint4((uint32_t)wd[2 * q], (uint32_t)(wd[2 * q] >> 32), (uint32_t)wd[2 * q + 1], (uint32_t)(wd[2 * q + 1] >> 32));
+}
+
 __global__ void __launch_bounds__(256) k_build_swin(DevIndex ix, uint4 *__restrict__ swin)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t base0 = (int64_t)ix.sa_lo[i] - kSwPre;
-        uint64_t wd[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int64_t pos = base0 + 32 * k;
-            uint64_t v;
-            if (pos >= 0) {
-                const uint64_t wi = (uint64_t)pos >> 5;
-                const unsigned sh = (unsigned)(pos & 31) << 1;
-                const uint64_t a = ix.tgt2[wi], bq = ix.tgt2[wi + 1];
-                v = (a << sh) | ((bq >> 1) >> (63 - sh));
-            } else if (pos > -32)
-                v = ix.tgt2[0] >> (unsigned)(2 * (-pos));
-            else
-                v = 0;
-            wd[k] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            swin[i * 3 + q] = make_uint4((uint32_t)wd[2 * q], (uint32_t)(wd[2 * q] >> 32), (uint32_t)wd[2 * q + 1], (uint32_t)(wd[2 * q + 1] >> 32));
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x)
+        swin_entry(ix, i, swin + i * 3);
 }
 
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s)
 {
     hipLaunchKernelGGL(k_build_swin, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The window array for PART of the suffix array (DevIndex::swmap).  k_wave's candidates are not spread evenly: it walks core intervals
+// of more than 64 suffixes, whole when they hold up to MaxIter + ~100 of them and for their first ~100 - 130 entries when they hold more
+// (the reference's copy-count check at IterCnt == 100, SfxArrayV2.cpp:5868-5875) - profiles/r05_a_cand_hist.csv: a tenth of the suffix
+// array holds 98 % of the windows a C2 step fetches.  Which tenth follows from the index alone: the runs of suffixes that share their
+// first W bases (W = the core length of the reads' last phase, the shortest cores they are searched with; longer cores select parts of
+// such runs).  A run of kSwMinRun .. max_run suffixes is covered whole, a longer one for its first kSwHead suffixes, a shorter one -
+// the lane-per-candidate kernel's - not at all; coverage goes by blocks of 2^kSwBlkShift suffixes that hold any covered suffix.
+// The same rule is applied for the core lengths of the reads' earlier phases (a 50-base core's interval is a run of ITS length, and the
+// start of one that long lies anywhere inside the 25-base run around it): a block is covered when any level's rule covers it.
+//   k_swin_breaks         per level: bit i = a run starts at i, as far as second-level keys and target tell
+//   k_swin_bucket_starts  .. and as far as the k-mer table tells (first k bases differ)
+//   k_swin_cover          per block: covered or not, level by level
+//   k_swin_map / _fill    block numbers in the array (scan of the flags), the entries themselves
+// Whatever these decide changes no result: an uncovered candidate takes its window from the 2-bit target as before.
+
+// up to kSwLevels core lengths (ascending): level l's bitmap has bit i set when suffixes i - 1 and i share fewer than w[l] bases.  Levels
+// up to k + 15 bases are read off the second-level keys; deeper ones compare the 2-bit target from base k + 15 on (two random lines per
+// pair of neighbours - but only for the pairs that agree that far, a tenth of a genome's suffixes)
+struct SwinLevels {
+    int n;
+    int w[kSwLevels];
+    unsigned long long *brk[kSwLevels];
+};
+
+__device__ __forceinline__ uint64_t tgt2_bases32(const uint64_t *__restrict__ tgt2, uint64_t pos)
+{
+    const uint64_t wi = pos >> 5;
+    const unsigned sh = (unsigned)(pos & 31) << 1;
+    const uint64_t a = tgt2[wi], bq = tgt2[wi + 1];
+    return (a << sh) | ((bq >> 1) >> (63 - sh));
+}
+
+__global__ void __launch_bounds__(256) k_swin_breaks(DevIndex ix, SwinLevels lv, uint64_t n_words)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t n = ix.n;
+    const int k = ix.k, deep_from = k + kK2Bases;
+    const int w_max = lv.w[lv.n - 1];
+    for (uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        const uint64_t i = (w << 6) + lane;
+        int shared = (i == 0 || i == n) ? 0 : 1 << 20;           // bases suffixes i - 1 and i share, as far as this kernel looks (past the end: no break)
+        if (i > 0 && i < n) {
+            const uint32_t a = ix.k2[i - 1], c = ix.k2[i];
+            if (a == kK2Above || c == kK2Above) shared = 0;
+            else {
+                const uint32_t x = (a ^ c) & ~3u;
+                if (x) shared = k + (__clz((int)x) >> 1);
+                else if ((a | c) & 3u) shared = deep_from - 1;   // an N or a sequence end among the 15 bases: no deeper than the keys
+                else if (w_max > deep_from) {
+                    const uint64_t pa = (uint64_t)ix.sa_lo[i - 1] + (uint64_t)deep_from, pb = (uint64_t)ix.sa_lo[i] + (uint64_t)deep_from;
+                    const int span = w_max - deep_from;
+                    shared = deep_from;
+                    if (pa + (uint64_t)span < n && pb + (uint64_t)span < n && !window_flagged(ix, pa, span) && !window_flagged(ix, pb, span)) {
+                        for (int q = 0; q < span; q += 32) {
+                            const uint64_t d = tgt2_bases32(ix.tgt2, pa + (uint64_t)q) ^ tgt2_bases32(ix.tgt2, pb + (uint64_t)q);
+                            if (d) { shared += __clzll((long long)d) >> 1; break; }
+                            shared += 32;
+                        }
+                    }
+                }
+            }
+        }
+        for (int l = 0; l < lv.n; l++) {
+            const unsigned long long m = __ballot(i <= n && shared < lv.w[l]);
+            if (lane == 0) lv.brk[l][w] = m;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_swin_bucket_starts(DevIndex ix, uint64_t n_codes, SwinLevels lv)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t span = (n_codes + 63) & ~63ULL;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+        if (c < n_codes) {
+            if (ix.ktab2) { lo = ix.ktab2[c].x; hi = ix.ktab2[c + 1].x; }
+            else { lo = ix.ktab32[c]; hi = ix.ktab32[c + 1]; }
+        }
+        // neighbouring codes' buckets start in the same word of the bitmap: their bits are OR-ed along the lanes first (the starts
+        // are non-decreasing), so that a word takes one atomic from the wave instead of twenty
+        const uint32_t w = lo >> 5;
+        uint32_t bits = (c < n_codes && hi != lo) ? 1u << (lo & 31) : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ob = __shfl_up(bits, off), ow = __shfl_up(w, off);
+            if (lane >= off && ow == w) bits |= ob;
+        }
+        const uint32_t nw = __shfl_down(w, 1);
+        if (bits && (lane == 63 || nw != w))
+            for (int l = 0; l < lv.n; l++) atomicOr(reinterpret_cast<uint32_t *>(lv.brk[l]) + w, bits);
+    }
+}
+
+// first set bit above position p, looking at no more than `limit` positions (p + 1 .. p + limit); 0 = none there
+__device__ __forceinline__ uint64_t swin_next_break(const unsigned long long *__restrict__ brk, uint64_t p, uint64_t limit)
+{
+    const uint64_t last = p + limit;
+    uint64_t q = p + 1;
+    while (q <= last) {
+        unsigned long long w = brk[q >> 6] >> (q & 63);
+        if (w) { const uint64_t r = q + (uint64_t)(__ffsll(w) - 1); return r <= last ? r : 0; }
+        q = (q | 63) + 1;
+    }
+    return 0;
+}
+
+// last set bit at or below p, looking down to p - limit; ~0 = none there
+__device__ __forceinline__ uint64_t swin_prev_break(const unsigned long long *__restrict__ brk, uint64_t p, uint64_t limit)
+{
+    const uint64_t first = p > limit ? p - limit : 0;
+    uint64_t q = p;
+    for (;;) {
+        unsigned long long w = brk[q >> 6] << (63 - (q & 63));
+        if (w) { const uint64_t r = q - (uint64_t)__clzll((long long)w); return r >= first ? r : ~0ULL; }
+        if ((q >> 6) == 0 || (q & ~63ULL) <= first) return ~0ULL;
+        q = (q & ~63ULL) - 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__restrict__ brk, uint64_t n, uint32_t max_run, uint32_t *__restrict__ flags, uint64_t n_blocks, int first_level)
+{
+    constexpr uint64_t B = 1ULL << kSwBlkShift;
+    for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b0 = blk << kSwBlkShift;
+        bool cov = !first_level && flags[blk] != 0;           // (covered by an earlier level's rule)
+        if (cov) continue;
+        // the run the block's first suffix lies in
+        const uint64_t s0 = swin_prev_break(brk, b0, max_run);
+        if (s0 != ~0ULL) {
+            const uint64_t e0 = swin_next_break(brk, b0, s0 + max_run - b0);        // (0: the run is longer than max_run)
+            if (e0) cov = e0 - s0 >= kSwMinRun;
+            else cov = b0 - s0 < kSwHead;
+        }
+        // the runs that start inside the block: only the last of them can be long enough (the others end inside the block)
+        if (!cov) {
+            const unsigned long long w = (brk[b0 >> 6] >> (b0 & 63)) & ((1ULL << B) - 1) & ~1ULL;
+            if (w) {
+                const uint64_t s = b0 + (uint64_t)(63 - __clzll((long long)w));
+                if (s < n) cov = swin_next_break(brk, s, kSwMinRun - 1) == 0;
+            }
+        }
+        flags[blk] = cov ? 1u : 0u;
+    }
+}
+
+// incl: inclusive scan of the flags.  A covered block's number is its rank among the covered ones; blocks beyond the budget stay out
+__global__ void __launch_bounds__(256) k_swin_map(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *__restrict__ map)
+{
+    for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x)
+        map[blk] = (flags[blk] && incl[blk] - 1 < cap_blocks) ? incl[blk] - 1 : kSwNone;
+}
+
+__global__ void __launch_bounds__(256) k_swin_fill(DevIndex ix, const uint32_t *__restrict__ map, uint4 *__restrict__ swin)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = map[i >> kSwBlkShift];
+        if (s == kSwNone) continue;
+        swin_entry(ix, i, swin + (((uint64_t)s << kSwBlkShift) + (i & ((1u << kSwBlkShift) - 1))) * 3);
+    }
+}
+
+// w: n_levels core lengths, ascending; brk: a bitmap of n_words 64-bit words per level
+void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t n_words, hipStream_t s)
+{
+    SwinLevels lv{};
+    lv.n = n_levels;
+    for (int l = 0; l < n_levels; l++) { lv.w[l] = w[l]; lv.brk[l] = brk[l]; }
+    hipLaunchKernelGGL(k_swin_breaks, dim3(32768), dim3(256), 0, s, ix, lv, n_words);
+    const uint64_t n_codes = 1ULL << (2 * ix.k);
+    hipLaunchKernelGGL(k_swin_bucket_starts, dim3(65536), dim3(256), 0, s, ix, n_codes, lv);
+}
+
+void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_blocks + 255) / 256, 262144);
+    hipLaunchKernelGGL(k_swin_cover, dim3(blocks), dim3(256), 0, s, brk, n, max_run, flags, n_blocks, first_level);
+}
+
+void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *map, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_blocks + 255) / 256, 262144);
+    hipLaunchKernelGGL(k_swin_map, dim3(blocks), dim3(256), 0, s, flags, incl, n_blocks, cap_blocks, map);
+}
+
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_swin_fill, dim3(65536), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin));
 }
 
 __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t i0, uint64_t i1, uint32_t *__restrict__ isa)

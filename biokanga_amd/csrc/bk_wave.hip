@@ -24,6 +24,7 @@ namespace bk {
 constexpr int kHistShift = 6;
 __device__ uint32_t *g_hist_blk;                      // windows fetched per block
 __device__ unsigned long long g_hist_len[3][40];      // by floor(log2(interval length)): intervals, windows fetched, candidates processed
+__device__ unsigned long long g_hist_ph[8][40][2];    // by phase and floor(log2(interval length)): windows fetched, .. of them from the window array
 #endif
 
 struct WaveCoreInfo {
@@ -31,6 +32,8 @@ struct WaveCoreInfo {
     uint32_t n;
     uint32_t walked;        // number of leading SA entries of the interval whose loop body was reached
     int ofs;
+    uint32_t sw_base;       // SW: the window array's entry of the interval's first suffix ..
+    uint32_t sw_n;          // .. and how many of the interval's leading suffixes have their entries in one run from there (0: none)
 };
 
 // HASH: the reference's own dedupe instead - a per-wave set of the 32-bit truncated target-start keys
@@ -196,6 +199,31 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 core[lane].n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
                 core[lane].walked = 0;
                 my_cn = cn & ~kLazyFlag;
+                if (SW) {
+                    // which of the interval's candidates take their windows from the window array: all of them when it holds every suffix;
+                    // else (DevIndex::swmap) the interval when its first and last block lie as far apart in the array as in the suffix
+                    // array - every block between them is there too, in order -, or, failing that, its first kSwHead suffixes by the
+                    // same test (an interval beyond MaxIter is left after a hundred-odd candidates)
+                    uint32_t sb = (uint32_t)f, sn = my_cn;
+                    if (ix.swmap != nullptr) {
+                        sn = 0;
+                        if (my_cn) {
+                            const uint32_t head = my_cn < kSwHead ? my_cn : kSwHead;
+                            const uint32_t b0 = (uint32_t)(f >> kSwBlkShift), bl = (uint32_t)((f + my_cn - 1) >> kSwBlkShift), bh = (uint32_t)((f + head - 1) >> kSwBlkShift);
+                            const uint32_t m0 = ix.swmap[b0], ml = ix.swmap[bl], mh = ix.swmap[bh];
+                            if (m0 != kSwNone) {
+                                sb = (m0 << kSwBlkShift) + ((uint32_t)f & ((1u << kSwBlkShift) - 1));
+                                if (ml != kSwNone && ml - m0 == bl - b0) sn = my_cn;
+                                else if (mh != kSwNone && mh - m0 == bh - b0) {
+                                    const uint64_t upto = ((uint64_t)(bh + 1) << kSwBlkShift) - f;
+                                    sn = upto < my_cn ? (uint32_t)upto : my_cn;
+                                }
+                            }
+                        }
+                    }
+                    core[lane].sw_base = sb;
+                    core[lane].sw_n = sn;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             // GROUP: consecutive cores with small intervals share a round - one candidate per lane in walk order (core, then suffix) -
@@ -243,6 +271,15 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     lofs = core[lc].ofs;
                     llazy = (core[lc].n & kLazyFlag) != 0;
                 }
+                // SW: the window array's entry of this lane's first candidate, and how far the array serves the interval
+                uint32_t lsw_base = 0, sw_n_c = 0;
+                bool grp_sw = false;
+                if (SW) {
+                    lsw_base = (GROUP && grouped) ? core[lc].sw_base : (uint32_t)__builtin_amdgcn_readfirstlane(core[c].sw_base);
+                    sw_n_c = __builtin_amdgcn_readfirstlane(core[c].sw_n);
+                    // a shared round goes to the array when it serves every one of its cores whole
+                    if (GROUP && grouped) grp_sw = __ballot((uint32_t)lane < gtot && core[lc].sw_n < (core[lc].n & ~kLazyFlag)) == 0;
+                }
                 n_search += (unsigned long long)(ce - c);
                 uint32_t iter = 0;
                 bool copies_checked = false;
@@ -250,14 +287,16 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 // the window array serves a core when the read's whole window lies inside the candidate's entry: bases kSwPre - ofs ..
                 // + len of its kSwBases (every core of a read of up to kSwLen bases; of a longer read - 2 x 150 - the cores in the
                 // middle, when they are walked a round per 64 suffixes; rounds shared by several cores of such a read go to the target)
-                const bool sw_now = SW && ((GROUP && grouped) ? sw_read : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre));
+                const bool sw_core = SW && ((GROUP && grouped) ? (sw_read && grp_sw) : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre && sw_n_c != 0));
                 for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
+                    // (a round takes its windows from the array when every candidate of it has its entry there)
+                    const bool sw_now = SW && sw_core && ((GROUP && grouped) || (j0 + 64 < n ? j0 + 64 : n) <= (uint64_t)sw_n_c);
                     // (the candidate's entry of the window array is requested together with its suffix array element: one round trip)
                     uint4 ev[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
                     if (SW && sw_now && active) {
-                        const uint4 *__restrict__ ep = ix.swin + (lfirst + j) * 3;
+                        const uint4 *__restrict__ ep = ix.swin + (uint64_t)(lsw_base + (uint32_t)j) * 3;
                         ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
                     }
                     const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
@@ -272,6 +311,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             atomicAdd(&g_hist_len[1][lb], 1ULL);
                         }
                         if (active && j == 0) atomicAdd(&g_hist_len[0][lb], 1ULL);
+                    }
+#endif
+#ifdef BK_CAND_HIST
+                    if (valid) {
+                        const uint32_t ln = core[lc].n & ~kLazyFlag;
+                        const int lb = ln ? 31 - __clz((int)ln) : 0;
+                        atomicAdd(&g_hist_ph[phase < 8 ? phase : 7][lb][0], 1ULL);
+                        if (SW && sw_now) atomicAdd(&g_hist_ph[phase < 8 ? phase : 7][lb][1], 1ULL);
                     }
 #endif
                     IWindow<NW> w;
@@ -548,7 +595,7 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 
 #ifdef BK_CAND_HIST
 // op 0: (re)allocate and zero the per-block histogram for n suffix array indexes, zero the per-length one; op 1: copy the per-block counts
-// (n of them) to out; op 2: the per-length histogram (3 x 40 x 8 bytes); op 3: free
+// (n of them) to out; op 2: the per-length histogram (3 x 40 x 8 bytes); op 3: free; op 4: the per-phase one (8 x 40 x 2 x 8 bytes)
 extern "C" int bk_debug_cand_hist(int op, void *out, unsigned long long n)
 {
     static uint32_t *d_blk = nullptr;
@@ -561,13 +608,15 @@ extern "C" int bk_debug_cand_hist(int op, void *out, unsigned long long n)
             n_blk = (n >> bk::kHistShift) + 2;
             if (hipMalloc(&d_blk, n_blk * 4) != hipSuccess || hipMemset(d_blk, 0, n_blk * 4) != hipSuccess) return 1;
         }
-        unsigned long long z[3][40] = {};
+        unsigned long long z[3][40] = {}, zp[8][40][2] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(bk::g_hist_blk), &d_blk, sizeof(d_blk)) != hipSuccess) return 1;
         if (hipMemcpyToSymbol(HIP_SYMBOL(bk::g_hist_len), z, sizeof(z)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bk::g_hist_ph), zp, sizeof(zp)) != hipSuccess) return 1;
         return hipDeviceSynchronize() != hipSuccess;
     }
     if (op == 1) return hipMemcpy(out, d_blk, (n < n_blk ? n : n_blk) * 4, hipMemcpyDeviceToHost) != hipSuccess;
     if (op == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::g_hist_len), 3 * 40 * 8) != hipSuccess;
+    if (op == 4) return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::g_hist_ph), 8 * 40 * 2 * 8) != hipSuccess;
     return 1;
 }
 #endif

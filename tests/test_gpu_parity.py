@@ -63,6 +63,7 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
                                   ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)),
                                   ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("sort_lists", 1), ("sort_lists", 6),
                                   ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)), ("use_swin", 2), (("use_swin", 2), ("heavy_thresh", 0)), (("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 3)),
+                                  ("use_swin", 3), (("use_swin", 3), ("heavy_thresh", 0)), (("wave_group", 1), ("use_swin", 3), ("heavy_thresh", 3)),
                                   ("use_swin", 0), ("wave_group", 1), (("wave_group", 1), ("heavy_thresh", 0)), (("wave_group", 1), ("use_isa", 0)), (("wave_group", 1), ("use_swin", 2), ("heavy_thresh", 3)),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
                                   (("use_k2", 0), ("lazy_search", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0)),

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--max-subs", type=int, default=3)
     ap.add_argument("--pairs", action="store_true", help="2 x read-len FR pairs (C3's reads) instead of single ends")
+    ap.add_argument("--window-array", type=int, default=0, help="bk_ctx_tune use_swin of the measured step (0 none, 1 partial, 3 every suffix): the per-phase "
+                                                                    "section then says which windows the array served")
+    ap.add_argument("--no-rules", action="store_true", help="skip the pricing of coverage rules")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import numpy as np
@@ -48,7 +51,7 @@ def main():
     for i, (eid, slen, so, eo) in enumerate(entries):
         ent[i] = (eid, slen, so, eo, f"chr{eid}".encode(), b"")
     al = bk.Aligner(None, bk.AlignParams(max_subs=args.max_subs), device=0, d_seq=seq.data_ptr(), concat_len=n, d_sa=sa.data_ptr(), el_size=4, entries=ent)
-    al.tune("use_swin", 0)
+    al.tune("use_swin", args.window_array)
     if args.pairs:
         bases, offs, lens = synth.make_pairs(seq, seq_lens, args.reads // 2, args.read_len, dev, seed=1000, max_subs=args.max_subs)
     else:
@@ -68,6 +71,8 @@ def main():
         raise SystemExit("histogram read-back failed")
     hl = np.zeros((3, 40), dtype=np.uint64)
     lib.bk_debug_cand_hist(2, hl.ctypes.data, 0)
+    hp = np.zeros((8, 40, 2), dtype=np.uint64)
+    lib.bk_debug_cand_hist(4, hp.ctypes.data, 0)
     lib.bk_debug_cand_hist(3, None, 0)
     total = int(blk.sum(dtype=np.uint64))
     lines = []
@@ -78,6 +83,21 @@ def main():
     for b in range(40):
         if hl[0, b] or hl[1, b]:
             w(f"by_interval_length,{1 << b},{(2 << b) - 1},{int(hl[0, b])},{int(hl[1, b])},{int(hl[2, b])},{int(hl[1, b]) / max(1, total):.4f}")
+    w("section,phase,interval_length_from,interval_length_to,windows_fetched,from_the_window_array,share_of_all_windows,share_served")
+    for ph in range(8):
+        for b in range(40):
+            if hp[ph, b, 0]:
+                w(f"by_phase,{ph},{1 << b},{(2 << b) - 1},{int(hp[ph, b, 0])},{int(hp[ph, b, 1])},{int(hp[ph, b, 0]) / max(1, total):.4f},{int(hp[ph, b, 1]) / int(hp[ph, b, 0]):.3f}")
+        if hp[ph, :, 0].sum():
+            w(f"by_phase_total,{ph},,,{int(hp[ph, :, 0].sum())},{int(hp[ph, :, 1].sum())},{int(hp[ph, :, 0].sum()) / max(1, total):.4f},{int(hp[ph, :, 1].sum()) / int(hp[ph, :, 0].sum()):.3f}")
+    if args.no_rules:
+        text = "\n".join(lines) + "\n"
+        if args.out:
+            os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+            open(args.out, "w").write(text)
+        sys.stdout.write(text)
+        al.close()
+        return
     # the best any rule could do: blocks by count
     order = np.sort(blk)[::-1].astype(np.uint64)
     cum = np.cumsum(order)

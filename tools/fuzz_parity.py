@@ -206,7 +206,9 @@ def main():
         bases, offs, lens = make_reads(rng, seq_h, nreads, max_len)
         p = helpers.make_params(**kw)
         al.set_params(bk.AlignParams(**kw))
-        for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)), ("use_flat", int(rng.integers(0, 4) != 0))):
+        # (the window array: none / the partial one / one cut off by a byte budget / every suffix - dropped first so that the next batch makes its own)
+        for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)), ("use_flat", int(rng.integers(0, 4) != 0)),
+                          ("use_swin", 0), ("swin_budget_kb", int(rng.choice([0, 0, 3, 30, 300]))), ("use_swin", int(rng.choice([0, 1, 2, 2, 3])))):
             al.tune(knob, val)
         packed = bool(rng.integers(0, 2))                # the same reads across the boundary at 2 bit/base
         got = al.align_packed(*bk.pack_reads(bases, offs, lens)) if packed else al.align(bases, offs, lens)

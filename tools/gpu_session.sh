@@ -33,7 +33,7 @@ for f in ("b3m", "b50m"):
     d = json.load(open(f"{sys.argv[1]}/{f}.json"))
     for k, v in d["layouts"].items():
         if isinstance(v, dict):
-            print(f, k, "kernel-only %.1f M reads/s, %.2f ms/step" % (v["value_kernel_only"] / 1e6, v["ms_per_step_kernel_only"]), v["device_ms_per_step"])
+            print(f, k, "kernel-only %.1f M reads/s, %.2f ms/step" % (v["value_kernel_only"] / 1e6, v["ms_per_step_kernel_only"]), v["device_ms_per_step"], v.get("window_array_built", ""))
 PY
       ;;
     calib)
