@@ -35,9 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# `biokanga align` builds the suffix-ordered window array (149 GB at 3.1 Gbp; break-even 570 M reads, see kWindowArrayMinReads) from this many reads per device on, or
-# when told to with --window-array (host/biokanga_main.cpp, cmd_align): the layout the headline is measured in follows the same rule
-CLI_WINDOW_ARRAY_MIN_READS = 600_000_000
+# `biokanga align` makes the partial suffix-ordered window array (25 GB at 3.1 Gbp, behind the suffix array's upload; see kWindowArrayMinReads) from this many reads
+# per device on, or when told to with --window-array (host/biokanga_main.cpp, cmd_align): the layout the headline is measured in follows the same rule
+CLI_WINDOW_ARRAY_MIN_READS = 20_000_000
 
 
 def effective_cpus():

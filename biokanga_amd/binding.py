@@ -130,6 +130,8 @@ def load_library():
     lib.bk_device_count.restype = i32
     lib.bk_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, i32, ctypes.POINTER(AlignParams)]
     lib.bk_ctx_create.restype = i32
+    lib.bk_ctx_create_ex.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, i32, ctypes.POINTER(AlignParams), u32]
+    lib.bk_ctx_create_ex.restype = i32
     lib.bk_ctx_create_from_device.argtypes = [ctypes.POINTER(vp), vp, u64, vp, i32, vp, u32, i32,
                                               ctypes.POINTER(AlignParams)]
     lib.bk_ctx_create_from_device.restype = i32
@@ -309,7 +311,7 @@ class Aligner:
     """One context per GPU (mirror of CSfxArrayV3 opened for alignment + the CAligner parameters)."""
 
     def __init__(self, sfx_path=None, params=None, device=0, *, d_seq=None, concat_len=0, d_sa=None,
-                 el_size=4, entries=None, clone_of=None):
+                 el_size=4, entries=None, clone_of=None, flags=0):
         self.lib = load_library()
         self.params = params or (clone_of.params if clone_of is not None else AlignParams())
         self.h = ctypes.c_void_p()
@@ -317,8 +319,9 @@ class Aligner:
             rc = self.lib.bk_ctx_clone(ctypes.byref(self.h), clone_of.h, device)
             what = "bk_ctx_clone"
         elif sfx_path is not None:
-            rc = self.lib.bk_ctx_create(ctypes.byref(self.h), os.fsencode(sfx_path), device, ctypes.byref(self.params))
-            what = f"bk_ctx_create({sfx_path})"
+            # flags: BK_CTX_WINDOW_ARRAY_EAGER (1), BK_CTX_LEAN_IMAGE (2) of bk_ctx_create_ex
+            rc = self.lib.bk_ctx_create_ex(ctypes.byref(self.h), os.fsencode(sfx_path), device, ctypes.byref(self.params), int(flags))
+            what = f"bk_ctx_create_ex({sfx_path})"
         else:
             ent = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
             rc = self.lib.bk_ctx_create_from_device(ctypes.byref(self.h), d_seq, concat_len, d_sa, el_size,

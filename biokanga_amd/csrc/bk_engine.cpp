@@ -30,7 +30,7 @@ namespace bk {
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, unsigned long long *starts = nullptr);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s);
 void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s);
@@ -52,10 +52,11 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
-void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t n_words, hipStream_t s);
+void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t a, uint64_t e, uint64_t n_words,
+                        const unsigned long long *starts, hipStream_t s);
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
-void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *map, hipStream_t s);
-void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, hipStream_t s);
+void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, uint64_t a, uint64_t e, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -263,12 +264,12 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
 }
 
 // suffix array indexes [i0, i1) have arrived
-int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1)
+int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1, unsigned long long *bucket_starts = nullptr)
 {
     DevIndex ix = c->ix;
     ix.k = tp.k;
     const bool last = i1 >= c->ix.n;
-    if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1);
+    if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1, bucket_starts);
     if (tp.k2) launch_build_k2(ix, c->d_k2, tp.d_bad, c->stream, i0, i1);
     if (tp.isa) launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream, i0, i1);
     HIP_TRY(hipGetLastError());
@@ -444,16 +445,19 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
 
 int finish_ctx(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
 {
-    int rc = setup_entries(c, entries, n_entries);
+    int rc = c->entries_set ? BK_OK : setup_entries(c, entries, n_entries);
     if (rc) return rc;
+    c->entries_set = true;
     StageClock clk;
     if (!c->tables_built) {                // (bk_ctx_create_ex makes them behind the suffix array's upload)
         rc = build_tables(c);
         clk.lap("k-mer table, second-level keys, inverse suffix array");
         if (rc) return rc;
     }
-    rc = build_tgt2(c);          // the hash scratch of the general kernels is sized when they first run
-    clk.lap("2-bit target");
+    if (!c->tgt2_built) {
+        rc = build_tgt2(c);      // the hash scratch of the general kernels is sized when they first run
+        clk.lap("2-bit target");
+    }
     return rc;
 }
 
@@ -1068,74 +1072,150 @@ namespace {
 
 // the core lengths reads of maxlen bases are searched with, shortest first (LocateCoreMultiples' CoreLen per phase of AlignReads' schedule):
 // the last phase's, then the ones before it; at most kSwLevels of them.  Returns their number
-int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w)
+int swin_core_lens_k(const bk_ctx *c, uint32_t maxlen, int k, int *w)
 {
     const ReadPlan p = make_plan((int)std::max<uint32_t>(maxlen, 1), c->cfg);
     int n = 0;
     for (int ph = p.n_phases - 1; ph >= 0 && n < kSwLevels; ph--) {
         int mm, cl, cd;
         phase_params(p, c->cfg, ph, mm, cl, cd);
-        cl = std::min(std::max(cl, c->ix.k), 120);
+        cl = std::min(std::max(cl, k), 120);
         if (n == 0 || cl > w[n - 1]) w[n++] = cl;
     }
     return n;
 }
+int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w) { return swin_core_lens_k(c, maxlen, c->ix.k, w); }
 
-// The partial array: per level (core length) the break bitmap of the runs of suffixes sharing that many bases and the per-block coverage
-// it implies, block numbers by a scan, then the entries - no more of them than `budget` bytes hold (blocks beyond it stay uncovered:
-// coverage never changes a result).
-int build_partial_swin(bk_ctx *c, const int *w, int n_levels, uint64_t budget, hipStream_t s)
+// The partial array is made range by range of the suffix array (one range when the index is already there; behind the slices of the
+// suffix array's upload when it is still arriving - bk_ctx_create_ex): per level (core length) the break bitmap of the runs of suffixes
+// sharing that many bases and the per-block coverage it implies, block numbers by a scan that continues the ranges before, then the
+// entries - no more of them than `budget` bytes hold (blocks beyond it stay uncovered: coverage never changes a result).  Nothing waits
+// for the host between ranges: the number of covered blocks lives in device memory until swin_end.
+struct SwinBuild {
+    int w[kSwLevels] = {0, 0, 0, 0}, n_levels = 0;
+    uint32_t max_run = 0, cap_blocks = 0;
+    uint64_t done = 0;                        // suffix array indexes below this are dealt with (a multiple of 64, or n)
+    uint64_t range_cap = 0;                   // most indexes one range may hold (what the scratch is sized for)
+    unsigned long long *d_brk[kSwLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_flags = nullptr, *d_incl = nullptr, *d_map = nullptr, *d_used = nullptr;
+    void *d_tmp = nullptr, *d_ent = nullptr;
+    size_t tmp_bytes = 0;
+    unsigned long long *d_starts = nullptr;   // bucket-start bitmap from k_build_ktab (null: read off the finished k-mer table)
+    double t0 = 0;
+    void drop_scratch() { for (auto &q : d_brk) { free_dev(q); q = nullptr; } free_dev(d_flags); free_dev(d_incl); free_dev(d_tmp); free_dev(d_starts); d_flags = d_incl = nullptr; d_tmp = nullptr; d_starts = nullptr; }
+    ~SwinBuild() { drop_scratch(); free_dev(d_map); free_dev(d_ent); free_dev(d_used); }
+};
+
+// sliced: the suffix array arrives in ranges (swin_range per range, entries allocated by the budget up front, bucket starts noted by the
+// k-mer table's builder); else ONE swin_range call over the whole array, which allocates what its coverage turned out to need
+int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, uint64_t budget, uint64_t range_cap, bool sliced, hipStream_t s)
 {
     const uint64_t n = c->ix.n;
     const uint64_t n_blocks = (n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
-    const uint64_t n_words = (n >> 6) + 4;
-    unsigned long long *d_brk[kSwLevels] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_flags = nullptr, *d_incl = nullptr, *d_map = nullptr;
-    void *d_tmp = nullptr, *d_ent = nullptr;
-    auto cleanup = [&]() { for (auto &q : d_brk) { free_dev(q); q = nullptr; } free_dev(d_flags); free_dev(d_incl); free_dev(d_tmp); };
-    auto fail = [&](int rc) { cleanup(); free_dev(d_map); free_dev(d_ent); return rc; };
-#define SW_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL); } } while (0)
-    StageClock clk;
-    auto lap = [&](const char *what) { if (clk.on) { (void)hipStreamSynchronize(s); clk.lap(what); } };
-    for (int l = 0; l < n_levels; l++) SW_TRY(dev_malloc(&d_brk[l], n_words * 8));
-    SW_TRY(dev_malloc(&d_flags, n_blocks * 4));
-    SW_TRY(dev_malloc(&d_incl, n_blocks * 4));
-    SW_TRY(dev_malloc(&d_map, n_blocks * 4));
-    lap("  window array: scratch");
-    launch_swin_breaks(c->ix, w, n_levels, d_brk, n_words, s);
-    lap("  window array: run starts");
-    // a run is walked whole when the copy-count check at IterCnt == 100 lets it pass: up to MaxIter + 100-odd suffixes
-    const uint32_t max_run = c->cfg.max_iter > 0 ? (uint32_t)c->cfg.max_iter + 256u : 1u << 20;
-    for (int l = 0; l < n_levels; l++) launch_swin_cover(d_brk[l], n, max_run, d_flags, n_blocks, l == 0, s);
-    SW_TRY(hipGetLastError());
-    size_t tb = 0;
-    SW_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_flags, d_incl, (size_t)n_blocks, s));
-    SW_TRY(dev_malloc(&d_tmp, tb + 256));
-    SW_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tb, d_flags, d_incl, (size_t)n_blocks, s));
-    uint32_t covered = 0;
-    SW_TRY(hipMemcpyAsync(&covered, d_incl + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
-    SW_TRY(hipStreamSynchronize(s));
-    lap("  window array: coverage + scan");
     const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
-    const uint32_t cap_blocks = (uint32_t)std::min<uint64_t>(covered, budget / block_bytes);
-    if (cap_blocks == 0) { cleanup(); free_dev(d_map); return 1; }          // (nothing to hold, or no room for any of it)
-    launch_swin_map(d_flags, d_incl, n_blocks, cap_blocks, d_map, s);
-    SW_TRY(hipGetLastError());
-    for (auto &q : d_brk) { free_dev(q); q = nullptr; }
-    SW_TRY(dev_malloc(&d_ent, (uint64_t)cap_blocks * block_bytes));
-    lap("  window array: allocation");
-    launch_swin_fill(c->ix, d_map, d_ent, s);
-    SW_TRY(hipGetLastError());
-    SW_TRY(hipStreamSynchronize(s));
-    lap("  window array: entries");
-#undef SW_TRY
-    cleanup();
-    c->d_swin = d_ent;
-    c->d_swmap = d_map;
-    c->swin_w = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16);
-    c->swin_bytes = (uint64_t)cap_blocks * block_bytes + n_blocks * 4;
-    c->swin_covered = (double)cap_blocks / (double)n_blocks;
+    sb.t0 = StageClock::now();
+    sb.n_levels = n_levels;
+    for (int l = 0; l < n_levels; l++) sb.w[l] = w[l];
+    // a run is walked whole when the copy-count check at IterCnt == 100 lets it pass: up to MaxIter + 100-odd suffixes
+    sb.max_run = c->cfg.max_iter > 0 ? (uint32_t)c->cfg.max_iter + 256u : 1u << 20;
+    sb.cap_blocks = (uint32_t)std::min<uint64_t>(n_blocks, budget / block_bytes);
+    if (sb.cap_blocks == 0) return 1;
+    sb.range_cap = std::min<uint64_t>(range_cap, n) + 64;
+    const uint64_t words = (sb.range_cap >> 6) + 4, blocks = (sb.range_cap >> kSwBlkShift) + 2;
+#define SW_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
+    for (int l = 0; l < n_levels; l++) SW_TRY(dev_malloc(&sb.d_brk[l], words * 8));
+    SW_TRY(dev_malloc(&sb.d_flags, blocks * 4));
+    SW_TRY(dev_malloc(&sb.d_incl, blocks * 4));
+    SW_TRY(dev_malloc(&sb.d_map, n_blocks * 4));
+    SW_TRY(dev_malloc(&sb.d_used, 4));
+    SW_TRY(hipMemsetAsync(sb.d_used, 0, 4, s));
+    SW_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sb.tmp_bytes, sb.d_flags, sb.d_incl, (size_t)blocks, s));
+    SW_TRY(dev_malloc(&sb.d_tmp, sb.tmp_bytes + 256));
+    if (sliced) {
+        SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)sb.cap_blocks * block_bytes));
+        SW_TRY(dev_malloc(&sb.d_starts, ((n >> 6) + 4) * 8));
+        SW_TRY(clear_dev(sb.d_starts, ((n >> 6) + 4) * 8, s));
+    }
     return BK_OK;
+}
+
+// suffix array indexes below `upto` are in place (with their second-level keys): whole 64-index words of them are dealt with
+int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipStream_t s)
+{
+    const uint64_t n = ix.n;
+    while (sb.done < n) {
+        uint64_t e = upto >= n ? n : (upto & ~63ULL);
+        if (e > sb.done && e - sb.done > sb.range_cap - 64) e = (sb.done + sb.range_cap - 64) & ~63ULL;      // (no more than the scratch holds at a time)
+        if (e <= sb.done) break;
+        const uint64_t a = sb.done, len = e - a;
+        const uint64_t n_words = (len >> 6) + 2, n_blocks = (len + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
+        launch_swin_breaks(ix, sb.w, sb.n_levels, sb.d_brk, a, e, n_words, sb.d_starts, s);
+        for (int l = 0; l < sb.n_levels; l++) launch_swin_cover(sb.d_brk[l], len, sb.max_run, sb.d_flags, n_blocks, l == 0, s);
+        SW_TRY(hipGetLastError());
+        size_t tb = sb.tmp_bytes;
+        SW_TRY(hipcub::DeviceScan::InclusiveSum(sb.d_tmp, tb, sb.d_flags, sb.d_incl, (size_t)n_blocks, s));
+        launch_swin_map(sb.d_flags, sb.d_incl, n_blocks, sb.cap_blocks, sb.d_used, sb.d_map + (a >> kSwBlkShift), s);
+        if (sb.d_ent == nullptr) {
+            // (the whole array in one range: the entries take what the coverage needs, known now)
+            if (a != 0 || e != n) return BK_ERR_INTERNAL;
+            uint32_t used = 0;
+            SW_TRY(hipMemcpyAsync(&used, sb.d_used, 4, hipMemcpyDeviceToHost, s));
+            SW_TRY(hipStreamSynchronize(s));
+            if (used == 0) { sb.done = e; return BK_OK; }
+            sb.cap_blocks = used;
+            SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)used * ((uint64_t)48 << kSwBlkShift)));
+        }
+        launch_swin_fill(ix, sb.d_map, sb.d_ent, a, e, s);
+        SW_TRY(hipGetLastError());
+        sb.done = e;
+    }
+    return BK_OK;
+}
+
+// publishes the array (the context takes the buffers over); 1 = nothing was worth covering
+int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
+{
+    uint32_t used = 0;
+    SW_TRY(hipMemcpyAsync(&used, sb.d_used, 4, hipMemcpyDeviceToHost, s));
+    SW_TRY(hipStreamSynchronize(s));
+    sb.drop_scratch();
+    if (sb.done < c->ix.n) return BK_ERR_INTERNAL;
+    if (used == 0) return 1;
+    const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
+    if ((uint64_t)used * 4 < (uint64_t)sb.cap_blocks * 3) {
+        // (sized by the budget before the coverage was known: what was not needed goes back)
+        void *fit = nullptr;
+        if (dev_malloc(&fit, (uint64_t)used * block_bytes) == hipSuccess) {
+            SW_TRY(hipMemcpyAsync(fit, sb.d_ent, (uint64_t)used * block_bytes, hipMemcpyDeviceToDevice, s));
+            SW_TRY(hipStreamSynchronize(s));
+            free_dev(sb.d_ent);
+            sb.d_ent = fit;
+        } else
+            (void)hipGetLastError();
+    }
+#undef SW_TRY
+    const uint64_t n_blocks = (c->ix.n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
+    c->d_swin = sb.d_ent;
+    c->d_swmap = sb.d_map;
+    sb.d_ent = nullptr;
+    sb.d_map = nullptr;
+    c->swin_w = sb.w[0] | (sb.w[sb.n_levels - 1] << 8) | (sb.n_levels << 16);
+    c->swin_bytes = (uint64_t)used * block_bytes + n_blocks * 4;
+    c->swin_covered = (double)used / (double)n_blocks;
+    c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
+    c->ix.swmap = c->d_swmap;
+    c->swin_setup_s = StageClock::now() - sb.t0;
+    return BK_OK;
+}
+
+// most bytes the partial array may take: a third of what every suffix would, half of what is free beyond `reserve`, the caller's cap
+uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve)
+{
+    const uint64_t work = ((c->ix.n >> kSwBlkShift) + 1) * 12 + (c->ix.n >> 3) * (kSwLevels + 1) + (64ULL << 20);      // (flags, scan, map, break bitmaps while it is made)
+    if (free_b < reserve + work + (1ULL << 30)) return 0;
+    uint64_t budget = std::min<uint64_t>(c->ix.n * 16, (free_b - reserve - work) / 2);
+    if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
+    return budget;
 }
 
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
@@ -1172,18 +1252,18 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
         c->swin_bytes = need;
         c->swin_covered = 1.0;
     } else {
-        // at most a third of what every suffix would take, and no more than half of what is free beyond the batch's own needs
-        const uint64_t work = ((c->ix.n >> kSwBlkShift) + 1) * 12 + (c->ix.n >> 3) * kSwLevels + (64ULL << 20);      // (flags, scan, map, break bitmaps while it is made)
-        if ((uint64_t)free_b < reserve + work + (1ULL << 30)) { c->swin_denied = true; return BK_OK; }
-        uint64_t budget = std::min<uint64_t>(c->ix.n * 16, ((uint64_t)free_b - reserve - work) / 2);
-        if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
-        const int rb = build_partial_swin(c, w, n_levels, budget, s);
+        const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve);
+        if (!budget) { c->swin_denied = true; return BK_OK; }
+        SwinBuild sb;
+        int rb = swin_begin(c, sb, w, n_levels, budget, c->ix.n, false, s);
+        if (!rb) rb = swin_range(c, sb, c->ix, c->ix.n, s);
+        if (!rb) rb = swin_end(c, sb, s);
         if (rb == BK_ERR_INTERNAL) return rb;
         if (rb) { c->swin_denied = true; return BK_OK; }                   // (no room, or nothing worth covering: asked once)
     }
     c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
     c->ix.swmap = c->d_swmap;
-    c->swin_setup_s = StageClock::now() - t0;
+    if (full) c->swin_setup_s = StageClock::now() - t0;
     if (clk.on) fprintf(stderr, "biokanga_amd: window array for %.1f %% of the suffix array (runs sharing %d .. %d bases, %d levels), %.2f GB\n", 100.0 * c->swin_covered, w[0], w[n_levels - 1], n_levels, c->swin_bytes / 1e9);
     clk.lap("suffix-ordered windows");
     return BK_OK;
@@ -1478,6 +1558,14 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     }
     c->dataset = f.dataset;
     const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32);
+    std::vector<bk_entry_info> ents(f.entries.size());
+    for (size_t i = 0; i < ents.size(); i++) {
+        ents[i].entry_id = f.entries[i].entry_id;
+        ents[i].seq_len = f.entries[i].seq_len;
+        ents[i].start_ofs = f.entries[i].start_ofs;
+        ents[i].end_ofs = f.entries[i].end_ofs;
+        memcpy(ents[i].name, f.entries[i].name, 81);
+    }
     // stage the file image through HBM: bases and suffix array as they are on disk
     // (4-byte suffix array elements are stored as the file holds them: they travel straight to where they stay)
     uint8_t *d_seq = nullptr, *d_sa = nullptr;
@@ -1505,14 +1593,51 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         const uint64_t n = f.concat_len;
         uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 26));             // (slices of at least 256 MB)
         if (const char *e = getenv("BK_TABLE_SLICES")) n_slices = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)atoi(e), n));      // (tests: small indexes in several slices)
+        // The window array, when the caller wants it from the start, is made behind the slices as well (for reads of a hundred bases: a
+        // first batch of another shortest core length makes it again, which costs little): what it reads besides suffix array and keys -
+        // entry table, alignment parameters, 2-bit target - is made now instead of after the upload.
+        SwinBuild sb;
+        bool swin_sliced = false;
+        if (!rc && eager_swin && c->use_swin && c->use_swin != 3 && tp.ktab && tp.k2 && tp.isa && !c->ktab64 && c->use_wave && c->use_flat && c->use_tgt2) {
+            rc = setup_entries(c, ents.data(), (uint32_t)ents.size());
+            if (!rc) { c->entries_set = true; rc = build_tgt2(c); }
+            if (!rc) {
+                c->tgt2_built = true;
+                clk.lap("entry table, 2-bit target");
+                int w[kSwLevels];
+                const int n_levels = swin_core_lens_k(c, 100, tp.k, w);
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const uint64_t batch = (uint64_t)c->chunk_reads * scratch_bytes_per_read(words_per_read(100), rd2w_for(100), iv_cores_for(c, 100));
+                    const uint64_t reserve = batch * 4 / 3 + (6ULL << 30) + (c->use_ktab2 ? ((1ULL << (2 * tp.k)) + 1) * 8 : 0);
+                    const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve);
+                    swin_sliced = budget != 0 && swin_begin(c, sb, w, n_levels, budget, n / n_slices + 128, true, c->stream) == BK_OK;
+                }
+                if (!swin_sliced) (void)hipGetLastError();
+            }
+        }
         for (uint64_t k = 0; k < n_slices && !rc && sent; k++) {
-            const uint64_t i0 = n * k / n_slices, i1 = n * (k + 1) / n_slices;
+            // (slices start at multiples of 64 indexes: the k-mer table's builder notes the bucket starts a word of a bitmap at a time)
+            const uint64_t i0 = (n * k / n_slices) & ~63ULL, i1 = k + 1 == n_slices ? n : (n * (k + 1) / n_slices) & ~63ULL;
+            if (i1 <= i0) continue;
             sent = upload_file(c->d_sa_lo + i0, fd, sa_ofs + i0 * 4, (i1 - i0) * 4, device_id) == BK_OK;
-            if (sent) rc = tables_range(c, tp, i0, i1);
+            if (sent) rc = tables_range(c, tp, i0, i1, swin_sliced ? sb.d_starts : nullptr);
+            if (sent && !rc && swin_sliced) {
+                DevIndex ix = c->ix;
+                ix.k = tp.k;
+                ix.k2 = c->d_k2;
+                if (swin_range(c, sb, ix, i1, c->stream) != BK_OK) { (void)hipGetLastError(); swin_sliced = false; }
+            }
         }
         clk.lap("upload suffix array, tables enqueued behind its slices");
         if (!rc && sent) rc = tables_end(c, tp);
         clk.lap("tables finished");
+        if (!rc && sent && swin_sliced && c->ix.k2 != nullptr) {
+            const int re = swin_end(c, sb, c->stream);
+            if (re == BK_ERR_INTERNAL) rc = re;
+            clk.lap("window array finished");
+            if (clk.on && c->d_swin) fprintf(stderr, "biokanga_amd: window array for %.1f %% of the suffix array, %.2f GB, made behind the upload\n", 100.0 * c->swin_covered, c->swin_bytes / 1e9);
+        }
     } else if (sent) {
         sent = upload_file(d_sa, fd, sa_ofs, f.concat_len * f.el_size, device_id) == BK_OK;
         clk.lap("upload suffix array");
@@ -1523,14 +1648,6 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     cleanup();
     if (!sent) { bk_ctx_destroy(c); return BK_ERR_INTERNAL; }
     if (rc) { bk_ctx_destroy(c); return rc; }
-    std::vector<bk_entry_info> ents(f.entries.size());
-    for (size_t i = 0; i < ents.size(); i++) {
-        ents[i].entry_id = f.entries[i].entry_id;
-        ents[i].seq_len = f.entries[i].seq_len;
-        ents[i].start_ofs = f.entries[i].start_ofs;
-        ents[i].end_ofs = f.entries[i].end_ofs;
-        memcpy(ents[i].name, f.entries[i].name, 81);
-    }
     rc = finish_ctx(c, ents.data(), (uint32_t)ents.size());
     if (rc) { bk_ctx_destroy(c); return rc; }
     clk.lap("(rest of bk_ctx_create)");

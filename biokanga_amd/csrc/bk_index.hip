@@ -83,9 +83,11 @@ __device__ __forceinline__ uint64_t suffix_bucket(const uint64_t *__restrict__ t
 }
 
 template <bool WIDE, typename TabT>
-__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_t i0, uint64_t i1)
+__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_t i0, uint64_t i1, unsigned long long *__restrict__ starts)
 {
     // (suffix array indexes [i0, i1) of 0 .. n: a table can be made range by range, as the array arrives)
+    // starts (optional; i0 a multiple of 64, the bitmap zeroed): bit i = a bucket starts at suffix array index i - what this pass finds
+    // out anyway, kept for the partial window array's coverage (k_swin_breaks)
     uint64_t n = ix.n;
     uint64_t ncodes = 1ULL << (2 * k);
     uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,6 +97,10 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_
         uint64_t cur = i < n ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), k) : ncodes;
         uint64_t from = i > 0 ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i - 1), k) + 1 : 0;
         for (uint64_t c = from; c <= cur; c++) tab[c] = (TabT)i;
+        if (starts != nullptr) {
+            const unsigned long long m = __ballot(from != cur + 1);           // (the lanes of a wave hold 64 consecutive indexes from a multiple of 64 on)
+            if ((i & 63) == 0 && m) atomicOr(&starts[i >> 6], m);
+        }
     }
 }
 
@@ -187,16 +193,20 @@ __device__ __forceinline__ uint64_t tgt2_bases32(const uint64_t *__restrict__ tg
     return (a << sh) | ((bq >> 1) >> (63 - sh));
 }
 
-__global__ void __launch_bounds__(256) k_swin_breaks(DevIndex ix, SwinLevels lv, uint64_t n_words)
+// the suffix array indexes [a, e) (a multiple of 64): bit i - a of a level's bitmap.  The range is taken for itself - a run starts at a
+// and one ends at e - so that an array can be made range by range, behind the suffix array's upload.  starts (optional): the bucket-start
+// bitmap k_build_ktab left (else k_swin_bucket_starts adds those bits)
+__global__ void __launch_bounds__(256) k_swin_breaks(DevIndex ix, SwinLevels lv, uint64_t a, uint64_t e, uint64_t n_words, const unsigned long long *__restrict__ starts)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t n = ix.n;
     const int k = ix.k, deep_from = k + kK2Bases;
     const int w_max = lv.w[lv.n - 1];
     for (uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
-        const uint64_t i = (w << 6) + lane;
-        int shared = (i == 0 || i == n) ? 0 : 1 << 20;           // bases suffixes i - 1 and i share, as far as this kernel looks (past the end: no break)
-        if (i > 0 && i < n) {
+        const uint64_t i = a + (w << 6) + lane;
+        int shared = (i == a || i == e) ? 0 : 1 << 20;           // bases suffixes i - 1 and i share, as far as this kernel looks (past the end: no break)
+        if (starts != nullptr && i < e && ((starts[i >> 6] >> (i & 63)) & 1)) shared = 0;
+        if (shared && i > a && i < e) {
             const uint32_t a = ix.k2[i - 1], c = ix.k2[i];
             if (a == kK2Above || c == kK2Above) shared = 0;
             else {
@@ -218,13 +228,13 @@ __global__ void __launch_bounds__(256) k_swin_breaks(DevIndex ix, SwinLevels lv,
             }
         }
         for (int l = 0; l < lv.n; l++) {
-            const unsigned long long m = __ballot(i <= n && shared < lv.w[l]);
+            const unsigned long long m = __ballot(i <= e && shared < lv.w[l]);
             if (lane == 0) lv.brk[l][w] = m;
         }
     }
 }
 
-__global__ void __launch_bounds__(256) k_swin_bucket_starts(DevIndex ix, uint64_t n_codes, SwinLevels lv)
+__global__ void __launch_bounds__(256) k_swin_bucket_starts(DevIndex ix, uint64_t n_codes, SwinLevels lv, uint64_t a, uint64_t e)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t span = (n_codes + 63) & ~63ULL;
@@ -236,8 +246,9 @@ __global__ void __launch_bounds__(256) k_swin_bucket_starts(DevIndex ix, uint64_
         }
         // neighbouring codes' buckets start in the same word of the bitmap: their bits are OR-ed along the lanes first (the starts
         // are non-decreasing), so that a word takes one atomic from the wave instead of twenty
-        const uint32_t w = lo >> 5;
-        uint32_t bits = (c < n_codes && hi != lo) ? 1u << (lo & 31) : 0u;
+        const bool in = c < n_codes && hi != lo && lo >= a && lo < e;
+        const uint32_t w = in ? (uint32_t)((lo - a) >> 5) : 0xFFFFFFFFu;
+        uint32_t bits = in ? 1u << (lo & 31) : 0u;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t ob = __shfl_up(bits, off), ow = __shfl_up(w, off);
             if (lane >= off && ow == w) bits |= ob;
@@ -301,15 +312,26 @@ __global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__
 }
 
 // incl: inclusive scan of the flags.  A covered block's number is its rank among the covered ones; blocks beyond the budget stay out
-__global__ void __launch_bounds__(256) k_swin_map(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *__restrict__ map)
+// used: covered blocks of the ranges before this one (device memory: no range waits for the host)
+__global__ void __launch_bounds__(256) k_swin_map(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ incl, uint64_t n_blocks, uint32_t cap_blocks,
+                                                  const uint32_t *__restrict__ used, uint32_t *__restrict__ map)
 {
-    for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x)
-        map[blk] = (flags[blk] && incl[blk] - 1 < cap_blocks) ? incl[blk] - 1 : kSwNone;
+    const uint32_t base = *used;
+    for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t slot = (uint64_t)base + incl[blk] - 1;
+        map[blk] = (flags[blk] && slot < cap_blocks) ? (uint32_t)slot : kSwNone;
+    }
 }
 
-__global__ void __launch_bounds__(256) k_swin_fill(DevIndex ix, const uint32_t *__restrict__ map, uint4 *__restrict__ swin)
+__global__ void k_swin_advance(const uint32_t *__restrict__ incl_last, uint32_t cap_blocks, uint32_t *__restrict__ used)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t u = (uint64_t)*used + *incl_last;
+    *used = u < cap_blocks ? (uint32_t)u : cap_blocks;
+}
+
+__global__ void __launch_bounds__(256) k_swin_fill(DevIndex ix, const uint32_t *__restrict__ map, uint4 *__restrict__ swin, uint64_t a, uint64_t e)
+{
+    for (uint64_t i = a + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = map[i >> kSwBlkShift];
         if (s == kSwNone) continue;
         swin_entry(ix, i, swin + (((uint64_t)s << kSwBlkShift) + (i & ((1u << kSwBlkShift) - 1))) * 3);
@@ -317,14 +339,19 @@ __global__ void __launch_bounds__(256) k_swin_fill(DevIndex ix, const uint32_t *
 }
 
 // w: n_levels core lengths, ascending; brk: a bitmap of n_words 64-bit words per level
-void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t n_words, hipStream_t s)
+// the suffix array indexes [a, e), a a multiple of 64; brk: a bitmap of n_words = (e - a) / 64 + 2 or more 64-bit words per level
+void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t a, uint64_t e, uint64_t n_words,
+                        const unsigned long long *starts, hipStream_t s)
 {
     SwinLevels lv{};
     lv.n = n_levels;
     for (int l = 0; l < n_levels; l++) { lv.w[l] = w[l]; lv.brk[l] = brk[l]; }
-    hipLaunchKernelGGL(k_swin_breaks, dim3(32768), dim3(256), 0, s, ix, lv, n_words);
-    const uint64_t n_codes = 1ULL << (2 * ix.k);
-    hipLaunchKernelGGL(k_swin_bucket_starts, dim3(65536), dim3(256), 0, s, ix, n_codes, lv);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_words + 3) / 4, 32768);
+    hipLaunchKernelGGL(k_swin_breaks, dim3(blocks), dim3(256), 0, s, ix, lv, a, e, n_words, starts);
+    if (starts == nullptr) {
+        const uint64_t n_codes = 1ULL << (2 * ix.k);
+        hipLaunchKernelGGL(k_swin_bucket_starts, dim3((unsigned)std::min<uint64_t>((n_codes + 255) / 256, 65536)), dim3(256), 0, s, ix, n_codes, lv, a, e);
+    }
 }
 
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s)
@@ -333,15 +360,21 @@ void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_r
     hipLaunchKernelGGL(k_swin_cover, dim3(blocks), dim3(256), 0, s, brk, n, max_run, flags, n_blocks, first_level);
 }
 
-void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *map, hipStream_t s)
+// map: the n_blocks entries of the range's blocks; `used` moves on by the range's covered blocks
+void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s)
 {
+    if (!n_blocks) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>((n_blocks + 255) / 256, 262144);
-    hipLaunchKernelGGL(k_swin_map, dim3(blocks), dim3(256), 0, s, flags, incl, n_blocks, cap_blocks, map);
+    hipLaunchKernelGGL(k_swin_map, dim3(blocks), dim3(256), 0, s, flags, incl, n_blocks, cap_blocks, used, map);
+    hipLaunchKernelGGL(k_swin_advance, dim3(1), dim3(1), 0, s, incl + (n_blocks - 1), cap_blocks, used);
 }
 
-void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, hipStream_t s)
+// map: the whole map (indexed by suffix array index >> kSwBlkShift); entries of the indexes [a, e)
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, uint64_t a, uint64_t e, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_swin_fill, dim3(65536), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin));
+    if (e <= a) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((e - a + 255) / 256, 65536);
+    hipLaunchKernelGGL(k_swin_fill, dim3(blocks), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin), a, e);
 }
 
 __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t i0, uint64_t i1, uint32_t *__restrict__ isa)
@@ -376,19 +409,20 @@ void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi,
 }
 
 // (every table builder takes a range [i0, i1) of suffix array indexes; i1 = 0 stands for the whole array)
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0, uint64_t i1)
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0, uint64_t i1, unsigned long long *starts)
 {
+    if (i0 & 63) starts = nullptr;
     if (i1 == 0) i1 = ix.n + 1;                      // (the entry past the last bucket comes with index n)
     if (i1 <= i0) return;
     uint64_t blocks = (i1 - i0 + 255) / 256;
     if (blocks > 262144) blocks = 262144;
     bool wide = ix.sa_hi != nullptr;
     if (wide) {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1);
-        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts);
+        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts);
     } else {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1);
-        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts);
+        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts);
     }
 }
 

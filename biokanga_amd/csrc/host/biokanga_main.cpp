@@ -330,12 +330,15 @@ int read_align_opts(Args &a, AlignOpts &o)
     return 0;
 }
 
-// The suffix-ordered window array (48 bytes per suffix: 149 GB for a 3.1 Gbp index) serves long-running work: a run pays for it only
-// from this many reads per device on, or when asked to (--window-array).  Break-even, measured on C2 (round 4,
-// profiles/r04_*_bench_line.json): the array saves 0.35 ns per read (98.0 -> 80.7 ms per 50 M reads of 100 bases) and costs 0.2 s of
-// k_build_swin once its allocation hides behind the index load (BK_CTX_WINDOW_ARRAY_EAGER) - 570 M reads; bench.py measures its
-// headline in the layout this rule picks.
-constexpr unsigned long long kWindowArrayMinReads = 600000000ULL;
+// Long runs - from this many reads per device on - get the tables that pay only then (k-mer table entries with their bucket's first
+// key: 17 GB more to make for 0.06 ns per read) and larger batches.
+constexpr unsigned long long kLongRunMinReads = 600000000ULL;
+// The suffix-ordered window array holds the part of the suffix array the wave kernel's long walks visit (a sixth of a 3.1 Gbp index,
+// 25 GB) and is made behind the suffix array's upload (BK_CTX_WINDOW_ARRAY_EAGER), slice by slice while the next slice crosses PCIe:
+// what is left after the last slice is a few milliseconds, against 0.3 ns per read that the array saves (round 5, C2: 98 -> 83 ms per
+// 50 M reads of 100 bases; profiles/r05_*).  It comes with the index from this many reads per device on, or with --window-array;
+// bench.py measures its headline in the layout this rule picks.
+constexpr unsigned long long kWindowArrayMinReads = 20000000ULL;
 
 // what the alignment pass leaves for the policies above the boundary
 struct AlignedSet {
@@ -799,7 +802,7 @@ int cmd_align(int argc, char **argv, int first)
     }
     if (!a.has("i") || !a.has("I") || !a.has("o")) {
         fprintf(stderr, "usage: %s align -i <reads> -I <genome.sfx> -o <out.sam> [-s subs] [-e delta] [-Q strand] [-m mode] [-n maxNs] "
-                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats] [--device n | --devices a-b]\n", g_proc.c_str());
+                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats] [--device n | --devices a-b] [--window-array on|off]\n", g_proc.c_str());
         return 1;
     }
     if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
@@ -816,9 +819,9 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<std::thread> loaders;
     // the first device reads the .sfx and builds the tables; the others receive the finished image device to device (xGMI)
     // The suffix-ordered window array pays from kWindowArrayMinReads reads per device on.  The decision is made HERE, from the size of
-    // the input files, before a single read is parsed: the array's memory then comes with the index image (allocated by a thread of its
-    // own while the .sfx crosses PCIe) instead of in front of the first batch.  A FASTA record of a 100-base read is about 120 bytes, a
-    // FASTQ one about 250; gzip'd files hold about four times their size.
+    // the input files, before a single read is parsed: the array then comes with the index image (made behind the slices of the suffix
+    // array's upload) instead of in front of the first batch.  A FASTA record of a 100-base read is about 120 bytes, a FASTQ one about
+    // 250; gzip'd files hold about four times their size.
     uint64_t est_reads = 0, plain_bytes = 0;
     bool all_plain = true;
     for (const char *opt : {"i", "u"})
@@ -848,9 +851,13 @@ int cmd_align(int argc, char **argv, int first)
     const bool pre_early = sam_plain && all_plain && plain_bytes >= (early_env ? strtoull(early_env, nullptr, 10) : (256ULL << 20));
     const uint64_t pre_early_est = (1u << 20) + plain_bytes + plain_bytes / (o.pe_mode ? 2 : 3);
     if (pre_early) pre.start(opath0.c_str(), pre_early_est, 2);
-    const bool long_run = a.has("window-array") || est_reads / ndev >= kWindowArrayMinReads;
+    const bool long_run = est_reads / ndev >= kLongRunMinReads;
+    // (--window-array on | off overrides the rule)
+    const std::string wa = a.has("window-array") ? a.str("window-array") : std::string();
+    const bool wa_off = wa == "off" || wa == "0" || wa == "no";
+    const bool want_array = !wa_off && (!wa.empty() || est_reads / ndev >= kWindowArrayMinReads);
     loaders.emplace_back([&]() {
-        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, long_run ? BK_CTX_WINDOW_ARRAY_EAGER : BK_CTX_LEAN_IMAGE);
+        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, (want_array ? BK_CTX_WINDOW_ARRAY_EAGER : 0u) | (long_run ? 0u : BK_CTX_LEAN_IMAGE));
         if (ctx_rc[0] || ndev == 1) return;
         std::vector<std::thread> cloners;
         for (size_t d = 1; d < ndev; d++) cloners.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_clone(&ctxs[d], ctxs[0], o.devices[d]); });
@@ -883,11 +890,10 @@ int cmd_align(int argc, char **argv, int first)
     diag("Genome assembly suffix array loaded");
 
     size_t nr = rs.size();
-    // The suffix-ordered window array (48 bytes per suffix: 149 GB and 2.6 s of set-up for a 3.1 Gbp index) serves long-running work;
-    // a run pays for it only from several hundred million reads per device on, or when asked to (--window-array)
-    for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", long_run ? 1 : 0);
-    diag("Suffix-ordered window array: %s (%zu reads per device, %llu estimated from the input files' sizes; it comes with the index from %llu reads per device on, or with --window-array)",
-         long_run ? "on" : "off", nr / ctxs.size(), (unsigned long long)(est_reads / ndev), (unsigned long long)kWindowArrayMinReads);
+    // (the other devices' contexts, copies of the first's image, make their window arrays when their first batch arrives)
+    for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want_array ? 1 : 0);
+    diag("Suffix-ordered window array: %s (%zu reads per device, %llu estimated from the input files' sizes; it comes with the index from %llu reads per device on; --window-array on | off overrides)",
+         want_array ? "on" : "off", nr / ctxs.size(), (unsigned long long)(est_reads / ndev), (unsigned long long)kWindowArrayMinReads);
     // (the SAM file of any other large run is started now: name + bases (+ qualities) + about 31 bytes per record, 55 for a paired end)
     if (sam_plain && pre.fd < 0) {
         const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)

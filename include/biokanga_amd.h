@@ -134,11 +134,12 @@ int  bk_device_count(void);
  * MinCoreLen/MaxIter set-up of CAligner::Align / LocateCoredApprox (Aligner.cpp:341-356,8725-8761):
  * reads the .sfx file, uploads target + suffix array to HBM, builds the k-mer interval table. */
 int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p);
-/* The same with flags.  BK_CTX_WINDOW_ARRAY_EAGER: the suffix-ordered window array (48 bytes per suffix, 4-byte indexes) is part of
- * the image from the start - its memory is allocated by a thread of its own from the moment the file's header is read (on a fresh
- * process the allocation of 149 GB takes longer than the upload of a 3.1 Gbp index, and hides behind it) and it is built when the other
- * tables are; without the flag the array is built when the first batch it can serve arrives (tuning knob "use_swin").  What a caller
- * that knows it has several hundred million reads to align asks for (`biokanga align` decides from the size of its input files). */
+/* The same with flags.  BK_CTX_WINDOW_ARRAY_EAGER: the suffix-ordered window array - 48 bytes for every suffix of the part of the suffix
+ * array the wave kernel's long walks visit, a sixth of a 3.1 Gbp index (25 GB) - is part of the image from the start: made slice by
+ * slice behind the suffix array's upload, as the other tables are, for reads of a hundred bases (a first batch that is searched with
+ * other core lengths makes it again: 0.1 s); without the flag the array is made when the first batch it can serve arrives (tuning knob
+ * "use_swin").  Replaces the candidates' random target reads of LocateCoreMultiples' walk (libbiokanga/SfxArrayV2.cpp:5862-5915) by a
+ * streaming read; results never depend on it. */
 #define BK_CTX_WINDOW_ARRAY_EAGER 1u
 /* BK_CTX_LEAN_IMAGE: tables that pay only over hundreds of millions of reads are left out - today the k-mer table entries that carry
  * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read).  Results never depend
@@ -186,8 +187,11 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)
  *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
- *   "use_swin" (suffix-ordered window array for reads of <= 100 bases, 0: windows from the 2-bit target, 2: built whatever the batch's longest read)
- *   "swin_resident" (read only, value ignored: 1 when the window array is in HBM right now)
+ *   "use_swin" (suffix-ordered window array: 0 none - every window from the 2-bit target; 1 for the part of the suffix array the wave kernel's long
+ *   walks visit, reads of <= 100 bases and the middle cores of reads of <= 160; 2 the same whatever the batch's longest read; 3 for every suffix)
+ *   "swin_budget_kb" (most the partial array may take; 0: a third of what every suffix would, within half of the free HBM)
+ *   "swin_resident", "swin_mbytes", "swin_setup_us", "swin_covered_ppm", "swin_core_lens" (read only, value ignored: whether the window array
+ *   is in HBM right now, what it occupies, what making it took, the share of the suffix array it holds, the core lengths its coverage is for)
  *   "wave_group" (wave kernel, reads of <= 128 bases: small core intervals share a round)
  *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's
  *   needs; 0: counts read back between launches, as every other configuration does)

@@ -140,3 +140,37 @@ def test_partial_window_array_follows_the_batch(tmp_path):
             seen.append(al.tune("swin_core_lens", 0) & 0xff)
         assert seen == [25, 20, 25, 22]                  # (the last phase's core length of each batch)
     o.close()
+
+
+@pytest.mark.parametrize("slices", [1, 3, 7])
+def test_window_array_made_behind_the_suffix_arrays_upload(tmp_path, slices):
+    """BK_CTX_WINDOW_ARRAY_EAGER: the partial array is made range by range behind the slices of the suffix array's upload (a run of equal
+    suffixes that crosses a slice's end is cut there) - it is in place before the first batch, and the results are the oracle's"""
+    bk = _bk()
+    seq, ents, reads = _family_genome(900 + slices, 600000, 100, 16000, 4)
+    path = _index(tmp_path, seq, ents, f"eager{slices}")
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = np.arange(nreads, dtype=np.uint64) * 100
+    lens = np.full(nreads, 100, dtype=np.uint32)
+    o = helpers.OracleSfx(path)
+    exp, octr = o.align(bases, offs, lens, helpers.make_params(max_subs=3), nthreads=8)
+    o.close()
+    os.environ["BK_TABLE_SLICES"] = str(slices)
+    try:
+        with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=1) as al:
+            assert al.tune("swin_resident", 0) == 1 and al.tune("swin_core_lens", 0) & 0xff == 25
+            covered = al.tune("swin_covered_ppm", 0)
+            got = al.align(bases, offs, lens)
+            ctr = al.counters()
+            assert al.tune("swin_covered_ppm", 0) == covered           # (the batch found the array it needs)
+            _same(got, exp, f"{slices} slices")
+            assert (ctr["n_search"], ctr["n_cand"], ctr["n_lcm_calls"]) == (octr.n_search, octr.n_cand, octr.n_lcm_calls)
+            # the same index without the flag: the array of one pass holds about as much
+            with bk.Aligner(path, bk.AlignParams(max_subs=3)) as al2:
+                got2 = al2.align(bases, offs, lens)
+                _same(got2, exp, "made by the first batch")
+                lazy = al2.tune("swin_covered_ppm", 0)
+            assert 0 < covered <= lazy * 1.05 + 2000 and covered >= lazy * 0.8
+    finally:
+        del os.environ["BK_TABLE_SLICES"]

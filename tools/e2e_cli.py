@@ -2,7 +2,8 @@
 """End-to-end timing of our command line (`biokanga_amd/bin/biokanga align`) on the bench workload:
 T_e2e (process start -> exit) and the phases from its time-stamped log.  Files live in /dev/shm.
   python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--quiet] [--gz] [-- extra options of biokanga align]
-Every variant is the same command with its own environment (the first run, "default", has none); the files are written once.
+Every variant is the same command with its own environment (the first run, "default", has none; BK_E2E_ARGS=<options> adds options of
+biokanga align to a variant's command); the files are written once.
 --gz: the reads also as reads.fa.gz (one member, level 1) and reads.fa.bgz (bgzip members); every variant then runs on the three inputs,
 and the gzip'd ones once more with BK_GZ_SERIAL=1 (the record-by-record gzread reader)."""
 import os, sys, time, subprocess, shutil, tempfile, datetime, re, struct, zlib
@@ -111,12 +112,13 @@ def main():
         for name, env in variants:
             env = dict(env)
             fa_in = env.pop("BK_E2E_INPUT", fa)
+            more = env.pop("BK_E2E_ARGS", "").split()              # (a variant's own options of biokanga align: "name:BK_E2E_ARGS=--no-window-array")
             for rep in range(repeat):
                 for f in (sam, logf, logf + ".err"):
                     if os.path.exists(f):
                         os.unlink(f)
                 t = time.time()
-                rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa_in, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra,
+                rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa_in, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra + more,
                                     stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1", **env), timeout=300).returncode
                 wall = time.time() - t
                 print("   cgroup memory.current", cg("memory.current"), "events:", cg("memory.events"), "peak", cg("memory.peak"))
