@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -1101,9 +1102,27 @@ struct SwinBuild {
     void *d_tmp = nullptr, *d_ent = nullptr;
     size_t tmp_bytes = 0;
     unsigned long long *d_starts = nullptr;   // bucket-start bitmap from k_build_ktab (null: read off the finished k-mer table)
+    // sliced builds: the entries' memory is allocated by a thread of its own from the moment the index's size is known (a large
+    // allocation takes the driver 16 ms per GB and more when another process has just given memory back): ranges whose turn comes
+    // before it is there have their entries made later
+    std::thread ent_alloc;
+    std::atomic<int> ent_state{0};            // 0 not asked for, 1 being allocated, 2 there, 3 failed
+    void *ent_mem = nullptr;
+    uint64_t filled = 0;                      // entries of the suffix array indexes below this are made
     double t0 = 0;
     void drop_scratch() { for (auto &q : d_brk) { free_dev(q); q = nullptr; } free_dev(d_flags); free_dev(d_incl); free_dev(d_tmp); free_dev(d_starts); d_flags = d_incl = nullptr; d_tmp = nullptr; d_starts = nullptr; }
-    ~SwinBuild() { drop_scratch(); free_dev(d_map); free_dev(d_ent); free_dev(d_used); }
+    ~SwinBuild() { if (ent_alloc.joinable()) ent_alloc.join(); if (ent_mem && ent_mem != d_ent) free_dev(ent_mem); drop_scratch(); free_dev(d_map); free_dev(d_ent); free_dev(d_used); }
+    // the entries' memory, asked for ahead of swin_begin: `bytes` on `device`
+    void alloc_ahead(int device, uint64_t bytes)
+    {
+        ent_state = 1;
+        ent_alloc = std::thread([this, device, bytes]() {
+            void *p = nullptr;
+            if (hipSetDevice(device) != hipSuccess || dev_malloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); ent_state = 3; return; }
+            ent_mem = p;
+            ent_state = 2;
+        });
+    }
 };
 
 // sliced: the suffix array arrives in ranges (swin_range per range, entries allocated by the budget up front, bucket starts noted by the
@@ -1132,7 +1151,7 @@ int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, uint64_t bu
     SW_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sb.tmp_bytes, sb.d_flags, sb.d_incl, (size_t)blocks, s));
     SW_TRY(dev_malloc(&sb.d_tmp, sb.tmp_bytes + 256));
     if (sliced) {
-        SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)sb.cap_blocks * block_bytes));
+        if (sb.ent_state == 0) SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)sb.cap_blocks * block_bytes));      // (else: alloc_ahead's thread brings it)
         SW_TRY(dev_malloc(&sb.d_starts, ((n >> 6) + 4) * 8));
         SW_TRY(clear_dev(sb.d_starts, ((n >> 6) + 4) * 8, s));
     }
@@ -1155,6 +1174,9 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
         size_t tb = sb.tmp_bytes;
         SW_TRY(hipcub::DeviceScan::InclusiveSum(sb.d_tmp, tb, sb.d_flags, sb.d_incl, (size_t)n_blocks, s));
         launch_swin_map(sb.d_flags, sb.d_incl, n_blocks, sb.cap_blocks, sb.d_used, sb.d_map + (a >> kSwBlkShift), s);
+        if (sb.d_ent == nullptr && sb.ent_state == 2) sb.d_ent = sb.ent_mem;
+        if (sb.d_ent == nullptr && sb.ent_state == 1) { sb.done = e; continue; }       // (its memory is not there yet: the entries follow)
+        if (sb.d_ent == nullptr && sb.ent_state == 3) return BK_ERR_MEM;
         if (sb.d_ent == nullptr) {
             // (the whole array in one range: the entries take what the coverage needs, known now)
             if (a != 0 || e != n) return BK_ERR_INTERNAL;
@@ -1165,8 +1187,9 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
             sb.cap_blocks = used;
             SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)used * ((uint64_t)48 << kSwBlkShift)));
         }
-        launch_swin_fill(ix, sb.d_map, sb.d_ent, a, e, s);
+        launch_swin_fill(ix, sb.d_map, sb.d_ent, sb.filled, e, s);
         SW_TRY(hipGetLastError());
+        sb.filled = e;
         sb.done = e;
     }
     return BK_OK;
@@ -1175,6 +1198,13 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
 // publishes the array (the context takes the buffers over); 1 = nothing was worth covering
 int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
 {
+    if (sb.ent_alloc.joinable()) sb.ent_alloc.join();
+    if (sb.ent_state == 3) return BK_ERR_MEM;
+    if (sb.ent_state == 2 && sb.d_ent == nullptr) sb.d_ent = sb.ent_mem;
+    if (sb.d_ent != nullptr && sb.filled < sb.done) {       // (the ranges that came before the entries' memory did)
+        launch_swin_fill(c->ix, sb.d_map, sb.d_ent, sb.filled, sb.done, s);
+        sb.filled = sb.done;
+    }
     uint32_t used = 0;
     SW_TRY(hipMemcpyAsync(&used, sb.d_used, 4, hipMemcpyDeviceToHost, s));
     SW_TRY(hipStreamSynchronize(s));
@@ -1182,25 +1212,15 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
     if (sb.done < c->ix.n) return BK_ERR_INTERNAL;
     if (used == 0) return 1;
     const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
-    if ((uint64_t)used * 4 < (uint64_t)sb.cap_blocks * 3) {
-        // (sized by the budget before the coverage was known: what was not needed goes back)
-        void *fit = nullptr;
-        if (dev_malloc(&fit, (uint64_t)used * block_bytes) == hipSuccess) {
-            SW_TRY(hipMemcpyAsync(fit, sb.d_ent, (uint64_t)used * block_bytes, hipMemcpyDeviceToDevice, s));
-            SW_TRY(hipStreamSynchronize(s));
-            free_dev(sb.d_ent);
-            sb.d_ent = fit;
-        } else
-            (void)hipGetLastError();
-    }
 #undef SW_TRY
     const uint64_t n_blocks = (c->ix.n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
     c->d_swin = sb.d_ent;
     c->d_swmap = sb.d_map;
     sb.d_ent = nullptr;
+    sb.ent_mem = nullptr;
     sb.d_map = nullptr;
     c->swin_w = sb.w[0] | (sb.w[sb.n_levels - 1] << 8) | (sb.n_levels << 16);
-    c->swin_bytes = (uint64_t)used * block_bytes + n_blocks * 4;
+    c->swin_bytes = (uint64_t)std::max(used, sb.cap_blocks) * block_bytes + n_blocks * 4;      // (what is allocated: a sliced build's entries were sized before its coverage was known)
     c->swin_covered = (double)used / (double)n_blocks;
     c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
     c->ix.swmap = c->d_swmap;
@@ -1557,7 +1577,20 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         return rc;
     }
     c->dataset = f.dataset;
-    const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32);
+    const bool eager_swin = (flags & BK_CTX_WINDOW_ARRAY_EAGER) && f.el_size == 4 && f.concat_len < (1ULL << 32) && c->use_swin && c->use_swin != 3;
+    // The window array's entries, when the caller wants the array from the start: 10 bytes per suffix (a 3.1 Gbp genome with 45 % of
+    // repeat-derived bases needs 8), no more than a quarter of the HBM - allocated by a thread of its own while the suffix array crosses
+    // PCIe, once every other allocation of the set-up is made (a large allocation holds the driver's lock for as long as it takes)
+    SwinBuild sb;
+    uint64_t swin_ahead = 0;
+    if (eager_swin) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > f.concat_len * 24 + (16ULL << 30)) {
+            swin_ahead = std::min<uint64_t>(f.concat_len * 10, total_b / 4);
+            if (c->swin_budget) swin_ahead = std::min<uint64_t>(swin_ahead, c->swin_budget);
+        } else
+            (void)hipGetLastError();
+    }
     std::vector<bk_entry_info> ents(f.entries.size());
     for (size_t i = 0; i < ents.size(); i++) {
         ents[i].entry_id = f.entries[i].entry_id;
@@ -1596,9 +1629,8 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         // The window array, when the caller wants it from the start, is made behind the slices as well (for reads of a hundred bases: a
         // first batch of another shortest core length makes it again, which costs little): what it reads besides suffix array and keys -
         // entry table, alignment parameters, 2-bit target - is made now instead of after the upload.
-        SwinBuild sb;
         bool swin_sliced = false;
-        if (!rc && eager_swin && c->use_swin && c->use_swin != 3 && tp.ktab && tp.k2 && tp.isa && !c->ktab64 && c->use_wave && c->use_flat && c->use_tgt2) {
+        if (!rc && eager_swin && swin_ahead && tp.ktab && tp.k2 && tp.isa && !c->ktab64 && c->use_wave && c->use_flat && c->use_tgt2) {
             rc = setup_entries(c, ents.data(), (uint32_t)ents.size());
             if (!rc) { c->entries_set = true; rc = build_tgt2(c); }
             if (!rc) {
@@ -1606,14 +1638,10 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
                 clk.lap("entry table, 2-bit target");
                 int w[kSwLevels];
                 const int n_levels = swin_core_lens_k(c, 100, tp.k, w);
-                size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                    const uint64_t batch = (uint64_t)c->chunk_reads * scratch_bytes_per_read(words_per_read(100), rd2w_for(100), iv_cores_for(c, 100));
-                    const uint64_t reserve = batch * 4 / 3 + (6ULL << 30) + (c->use_ktab2 ? ((1ULL << (2 * tp.k)) + 1) * 8 : 0);
-                    const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve);
-                    swin_sliced = budget != 0 && swin_begin(c, sb, w, n_levels, budget, n / n_slices + 128, true, c->stream) == BK_OK;
-                }
-                if (!swin_sliced) (void)hipGetLastError();
+                sb.ent_state = 1;                                   // (its entries come from alloc_ahead's thread, started below)
+                swin_sliced = swin_begin(c, sb, w, n_levels, swin_ahead, n / n_slices + 128, true, c->stream) == BK_OK;
+                if (!swin_sliced) { (void)hipGetLastError(); sb.ent_state = 0; }
+                else sb.alloc_ahead(device_id, swin_ahead);
             }
         }
         for (uint64_t k = 0; k < n_slices && !rc && sent; k++) {

@@ -171,6 +171,7 @@ def test_window_array_made_behind_the_suffix_arrays_upload(tmp_path, slices):
                 got2 = al2.align(bases, offs, lens)
                 _same(got2, exp, "made by the first batch")
                 lazy = al2.tune("swin_covered_ppm", 0)
-            assert 0 < covered <= lazy * 1.05 + 2000 and covered >= lazy * 0.8
+            # (.. or less: its memory was sized before its coverage was known, 10 bytes per suffix)
+            assert 0 < covered <= lazy * 1.05 + 2000 and covered >= min(lazy * 0.8, 180_000)
     finally:
         del os.environ["BK_TABLE_SLICES"]
