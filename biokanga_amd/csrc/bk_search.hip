@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
 #ifdef BK_DIAG_B
-    unsigned long long d_k2 = 0, d_deep = 0;
-    struct Fin { unsigned long long &a, &b; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (b) atomicAdd(&bb.ctr[ctr_stripe() + 6], b); } } fin{d_k2, d_deep, b};
+    unsigned long long d_k2 = 0, d_deep = 0, d_empty = 0;
+    struct Fin { unsigned long long &a, &b, &c; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (c) atomicAdd(&bb.ctr[ctr_stripe() + 6], c); (void)b; }       /* (slot 6: the deep items' outcome instead of their loads) */ } fin{d_k2, d_deep, d_empty, b};
 #endif
     const uint64_t slot = i < n_grouped ? sorted[i] : list[i];
     const uint32_t r = b.act[(uint32_t)(slot % b.iv_stride)], sc = (uint32_t)(slot / b.iv_stride);
@@ -342,6 +342,13 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
             if (a2) { if (c2 >= 0) l2 = m2 + 1; else h2 = m2; }
         }
         first = l1;
+#ifdef BK_DIAG_B
+        {   // deep items, the ones that end empty, the rounds those took (16 bits items | 24 bits empty items | 24 bits rounds of the empty ones - per lane, summed)
+            uint64_t rounds = 0;
+            for (uint64_t q = cnt; q > 0; q >>= 1) rounds++;
+            d_empty += (l2 == l1) ? 1ULL + (rounds << 32) : 0ULL;          // (low word: empty items; high word: the halvings their intervals needed)
+        }
+#endif
         cnt = l2 - l1;
     }
     iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);

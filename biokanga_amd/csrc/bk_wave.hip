@@ -27,6 +27,9 @@ __device__ unsigned long long g_hist_len[3][40];      // by floor(log2(interval 
 __device__ unsigned long long g_hist_ph[8][40][2];    // by phase and floor(log2(interval length)): windows fetched, .. of them from the window array
 #endif
 
+template <bool WIDE> struct PosT { typedef uint64_t type; };
+template <> struct PosT<false> { typedef uint32_t type; };
+
 struct WaveCoreInfo {
     unsigned long long first;
     uint32_t n;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 const uint64_t first = uniform64(core[c].first);
                 const uint32_t cn_c = __builtin_amdgcn_readfirstlane(core[c].n);
                 const bool lazy = (cn_c & kLazyFlag) != 0;
-                const uint64_t n = cn_c & ~kLazyFlag;
+                const uint32_t n = cn_c & ~kLazyFlag;                    // (an interval's count is capped at 2^31 - 1)
                 const int ofs = __builtin_amdgcn_readfirstlane(core[c].ofs);
                 // the cores of this step: c alone (a long interval, 64 suffixes a round), or c .. ce - 1 in one round
                 int ce = c + 1;
@@ -283,25 +286,32 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 n_search += (unsigned long long)(ce - c);
                 uint32_t iter = 0;
                 bool copies_checked = false;
-                uint64_t walked = n;
+                uint32_t walked = n;
                 // the window array serves a core when the read's whole window lies inside the candidate's entry: bases kSwPre - ofs ..
                 // + len of its kSwBases (every core of a read of up to kSwLen bases; of a longer read - 2 x 150 - the cores in the
                 // middle, when they are walked a round per 64 suffixes; rounds shared by several cores of such a read go to the target)
                 const bool sw_core = SW && ((GROUP && grouped) ? (sw_read && grp_sw) : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre && sw_n_c != 0));
-                for (uint64_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
-                    const uint64_t j = (GROUP && grouped) ? (uint64_t)lj_g : j0 + lane;
+                for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
+                    const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
                     // (a round takes its windows from the array when every candidate of it has its entry there)
-                    const bool sw_now = SW && sw_core && ((GROUP && grouped) || (j0 + 64 < n ? j0 + 64 : n) <= (uint64_t)sw_n_c);
-                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip)
-                    uint4 ev[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                    const bool sw_now = SW && sw_core && ((GROUP && grouped) || (j0 + 64 < n ? j0 + 64 : n) <= sw_n_c);
+                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip;
+                    // a lane without a candidate leaves the words undefined - nothing of them is looked at below)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+                    uint4 ev[3];
                     if (SW && sw_now && active) {
-                        const uint4 *__restrict__ ep = ix.swin + (uint64_t)(lsw_base + (uint32_t)j) * 3;
+                        const uint4 *__restrict__ ep = ix.swin + (uint64_t)(lsw_base + j) * 3;
                         ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
                     }
-                    const uint64_t loci = active ? sa_get<WIDE>(ix, lfirst + j) : 0;
-                    const uint64_t t = loci - (uint64_t)lofs;
-                    bool valid = active && loci >= (uint64_t)lofs;
+                    // (target positions of an index of 4-byte elements: 32-bit arithmetic)
+                    using P = typename PosT<WIDE>::type;
+                    const P loci = active ? (P)sa_get<WIDE>(ix, lfirst + j) : (P)0;
+                    const P t = loci - (P)lofs;
+                    bool valid = active && loci >= (P)lofs;
 #ifdef BK_CAND_HIST
                     {
                         const uint32_t ln = core[lc].n & ~kLazyFlag;
@@ -322,9 +332,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     }
 #endif
                     IWindow<NW> w;
-                    w.mm = 127; w.eos = true;
-#pragma unroll
-                    for (int k = 0; k < NW / 4; k++) w.im[k] = ~0ULL;
+                    w.mm = 127; w.eos = true;                             // (the map of a lane without a valid candidate stays undefined: every use is behind `valid`)
                     if (valid) {
                         // the block-flag load and the 2-bit window loads are issued together; only the rare
                         // flagged window is then fetched again from the 4-bit copy
@@ -364,7 +372,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             if (m) {
                                 if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
                                 else {
-                                    uint64_t rank = (uint64_t)ix.isa[t + (uint64_t)core[c2].ofs] - core[c2].first;
+                                    uint64_t rank = (uint64_t)ix.isa[(P)(t + (P)core[c2].ofs)] - core[c2].first;
                                     dup = rank < (uint64_t)core[c2].walked;
                                 }
                             }
@@ -377,18 +385,18 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     const uint32_t iter_before = iter + pre;
                     const uint32_t nodes_before = nodes + pre;
                     bool stop = active && !(GROUP && grouped) && ((cfg.max_iter && iter_before >= (uint32_t)cfg.max_iter) || nodes_before >= kNodeCap);
-                    uint64_t cutoff = (GROUP && grouped) ? 64 : n;
+                    uint32_t cutoff = (GROUP && grouped) ? 64u : n;
                     uint64_t stopmask = __ballot(stop);
-                    if (stopmask) cutoff = j0 + (uint64_t)(__ffsll((unsigned long long)stopmask) - 1);
+                    if (stopmask) cutoff = j0 + (uint32_t)(__ffsll((unsigned long long)stopmask) - 1);
                     if (!copies_checked && !(GROUP && grouped)) {
                         bool chk = active && j > 0 && iter_before == 100;
                         uint64_t chkmask = __ballot(chk);
                         if (chkmask) {
-                            uint64_t jc = j0 + (uint64_t)(__ffsll((unsigned long long)chkmask) - 1);
+                            uint32_t jc = j0 + (uint32_t)(__ffsll((unsigned long long)chkmask) - 1);
                             if (jc < cutoff) {
                                 copies_checked = true;
-                                uint64_t num_copies = n - jc + 2;
-                                if (cfg.max_iter && (uint32_t)num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
+                                uint32_t num_copies = n - jc + 2;
+                                if (cfg.max_iter && num_copies > (uint32_t)cfg.max_iter) cutoff = jc;
                             }
                         }
                     }
@@ -441,7 +449,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     uint32_t nproc = (uint32_t)__popcll(procmask);
                     iter += nproc;
                     nodes += nproc;
-                    n_cand += (lane == 0) ? nproc : 0;
+                    n_cand += nproc;                                        // (the same in every lane: a scalar)
                     acc = acc && ((keep >> lane) & 1);
                     uint64_t accmask = __ballot(acc);
                     if (accmask) {
@@ -461,7 +469,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             nxt = low_mm < bsec ? low_mm : bsec;
                             low_mm = bmin;
                             low_inst = cnt;
-                            hit_left = __shfl(t, fl);
+                            hit_left = (uint64_t)__shfl(t, fl);
                             hit_strand = st ? '-' : '+';
                         } else if (bmin == low_mm) {
                             low_inst += cnt;
@@ -471,8 +479,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                     }
                     if (exit_now) done = true;
                     if (!(GROUP && grouped) && cutoff < j0 + 64) { walked = cutoff; break; }
+#pragma clang diagnostic pop
                 }
-                if (!(GROUP && grouped) && lane == 0) core[c].walked = walked > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)walked;
+                if (!(GROUP && grouped) && lane == 0) core[c].walked = walked;
                 __builtin_amdgcn_wave_barrier();
                 c = ce;
             }
