@@ -362,15 +362,18 @@ def fetch_correction(kernel, window_array):
     import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fetch_calibration.csv"))):
-        rows, counts = {}, {}
+        rows, counts, sizes = {}, {}, {}
         for line in open(f):
             if line.startswith("calib:"):
                 for name, n in re.findall(r"(k_calib_\w+): (\d+) entries", line):
                     counts[name] = int(n)
+                for name, b in re.findall(r"(k_calib_\w+): \d+ entries of (\d+) B", line):
+                    sizes[name] = int(b)
             elif line.startswith("k_calib"):
                 r = next(csv.reader([line]))
                 rows[r[0]] = float(r[3]) * 1024.0                        # FETCH_SIZE is in KiB
-        for name, per_entry in (("k_calib_wave", 52), ("k_calib_runs1", 48)):
+        for name, per_entry in (("k_calib_wave", 40), ("k_calib_runs1", 48)):
+            per_entry = sizes.get(name, per_entry)                       # (what the file itself says an entry moved: the layout changed in round 5)
             if name in rows and name in counts:
                 best = (counts[name] * per_entry / rows[name], f"{os.path.basename(f)}: {name}, {counts[name]} entries of {per_entry} B "
                         f"read as {rows[name] / counts[name]:.1f} B each")

@@ -400,11 +400,11 @@ __device__ __forceinline__ void swin2i_compare(const uint64_t (&r2w)[NW / 2], co
 // The same compare in 16-base dwords for a window start that is the same in every lane: window dword w is one funnel shift
 // (v_alignbit_b32) of entry dwords D2 + w and D2 + w + 1, whose registers are known at compile time once the scalar unit has branched
 // on D2; five vector instructions per 16 bases and six per 64-base map word instead of the 64-bit shifts, selects and splits above.
-template <int NW, int D2>
-__device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint32_t (&S)[13], unsigned sh,
+template <int NW, int D2, int E>
+__device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint32_t (&S)[4 * E + 1], unsigned sh,
                                                  IWindow<NW> &w)
 {
-    static_assert(D2 >= -1 && D2 <= kSwPre / 16, "the window starts inside the entry's lead");
+    static_assert(D2 >= -1 && D2 <= SwGeo<E>::pre / 16, "the window starts inside the entry's lead");
     int mm = 0;
 #pragma unroll
     for (int i = 0; i < NW / 4; i++) {
@@ -414,9 +414,9 @@ __device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], 
             const int wd = 4 * i + d;
             y[d] = 0;
             // (dwords the entry does not hold are never asked for: the caller only comes here with the whole window inside the entry)
-            if (D2 + wd + 1 <= 12 && 16 * wd < len) {
+            if (D2 + wd + 1 <= 4 * E && 16 * wd < len) {
                 const uint32_t hi = D2 + wd >= 0 ? S[D2 + wd >= 0 ? D2 + wd : 0] : 0u;
-                const uint32_t lo = S[D2 + wd + 1 <= 12 ? D2 + wd + 1 : 12];
+                const uint32_t lo = S[D2 + wd + 1 <= 4 * E ? D2 + wd + 1 : 4 * E];
                 const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, sh);
                 const uint32_t rw = (wd & 1) ? (uint32_t)r2w[wd >> 1] : (uint32_t)(r2w[wd >> 1] >> 32);
                 const uint32_t x = rw ^ win;
@@ -437,41 +437,63 @@ __device__ __forceinline__ void swin2i_compare32(const uint64_t (&r2w)[NW / 2], 
 }
 
 // UNIFORM: bofs is the same for every lane of the wave (one core per round) - the choice of the starting word is then a branch the scalar
-// unit takes instead of ten selects per lane
-template <int NW, bool UNIFORM>
-__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 (&e)[3],
+// unit takes instead of ten selects per lane.  E: 16-byte words of an entry (SwGeo); the per-lane form exists for E = 3 only
+template <int NW, int E, int D2, int LAST>
+__device__ __forceinline__ void swin2i_case(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint32_t (&S)[4 * E + 1], unsigned sh, int d2,
+                                            IWindow<NW> &w)
+{
+    // (a chain of scalar branches over the starting dwords D2 .. LAST)
+    if constexpr (D2 > LAST) return;
+    else {
+        if (d2 == D2 || D2 == LAST) swin2i_compare32<NW, D2, E>(r2w, rni, len, S, sh, w);
+        else swin2i_case<NW, E, D2 + 1, LAST>(r2w, rni, len, S, sh, d2, w);
+    }
+}
+
+template <int NW, bool UNIFORM, int E = 3>
+__device__ __forceinline__ void eval_swin2i(const uint64_t (&r2w)[NW / 2], const uint64_t (&rni)[NW / 4], int len, const uint4 (&e)[E],
                                             int bofs, IWindow<NW> &w)
 {
-    uint64_t r[6], q[5];                                       // (reads of up to kSwLen <= 128 bases: four compare words at most)
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const uint4 v = e[i];
-        r[2 * i] = ((uint64_t)v.y << 32) | v.x;
-        r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
-    }
     if (UNIFORM) {
-        // the entry as thirteen 16-base dwords in base order (the 64-bit words hold their first base in the top bits)
-        const uint32_t S[13] = {e[0].y, e[0].x, e[0].w, e[0].z, e[1].y, e[1].x, e[1].w, e[1].z, e[2].y, e[2].x, e[2].w, e[2].z, 0u};
+        // the entry as 4 E + 1 16-base dwords in base order (the 64-bit words hold their first base in the top bits)
+        uint32_t S[4 * E + 1];
+#pragma unroll
+        for (int i = 0; i < E; i++) { S[4 * i] = e[i].y; S[4 * i + 1] = e[i].x; S[4 * i + 2] = e[i].w; S[4 * i + 3] = e[i].z; }
+        S[4 * E] = 0u;
         const int ub = __builtin_amdgcn_readfirstlane(bofs);
         const int rb = (ub & 15) << 1;
         const unsigned sh = (unsigned)(32 - rb) & 31u;
-        const int d2 = (ub >> 4) - (rb ? 0 : 1);                  // -1 .. 5 (bofs <= kSwPre)
-        switch (d2) {
-        case -1: swin2i_compare32<NW, -1>(r2w, rni, len, S, sh, w); break;
-        case 0: swin2i_compare32<NW, 0>(r2w, rni, len, S, sh, w); break;
-        case 1: swin2i_compare32<NW, 1>(r2w, rni, len, S, sh, w); break;
-        case 2: swin2i_compare32<NW, 2>(r2w, rni, len, S, sh, w); break;
-        case 3: swin2i_compare32<NW, 3>(r2w, rni, len, S, sh, w); break;
-        case 4: swin2i_compare32<NW, 4>(r2w, rni, len, S, sh, w); break;
-        default: swin2i_compare32<NW, 5>(r2w, rni, len, S, sh, w); break;
-        }
+        const int d2 = (ub >> 4) - (rb ? 0 : 1);                  // -1 .. pre / 16 (bofs <= pre)
+        if constexpr (E == 3) {
+            switch (d2) {
+            case -1: swin2i_compare32<NW, -1, 3>(r2w, rni, len, S, sh, w); break;
+            case 0: swin2i_compare32<NW, 0, 3>(r2w, rni, len, S, sh, w); break;
+            case 1: swin2i_compare32<NW, 1, 3>(r2w, rni, len, S, sh, w); break;
+            case 2: swin2i_compare32<NW, 2, 3>(r2w, rni, len, S, sh, w); break;
+            case 3: swin2i_compare32<NW, 3, 3>(r2w, rni, len, S, sh, w); break;
+            case 4: swin2i_compare32<NW, 4, 3>(r2w, rni, len, S, sh, w); break;
+            default: swin2i_compare32<NW, 5, 3>(r2w, rni, len, S, sh, w); break;
+            }
+        } else if (d2 < 4)
+            swin2i_case<NW, E, -1, 3>(r2w, rni, len, S, sh, d2, w);
+        else
+            swin2i_case<NW, E, 4, SwGeo<E>::pre / 16>(r2w, rni, len, S, sh, d2, w);
         return;
     }
-    const int w0 = bofs >> 5;                                  // 0..2
-    const unsigned s = (unsigned)(bofs & 31) << 1;
+    if constexpr (E == 3) {
+        uint64_t r[6], q[5];                                   // (reads of up to kSwLen <= 128 bases: four compare words at most)
 #pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = w0 == 0 ? r[i] : (w0 == 1 ? r[i + 1] : (i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL));
-    swin2i_compare<NW>(r2w, rni, len, q, s, w);
+        for (int i = 0; i < 3; i++) {
+            const uint4 v = e[i];
+            r[2 * i] = ((uint64_t)v.y << 32) | v.x;
+            r[2 * i + 1] = ((uint64_t)v.w << 32) | v.z;
+        }
+        const int w0 = bofs >> 5;                                  // 0..2
+        const unsigned s = (unsigned)(bofs & 31) << 1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) q[i] = w0 == 0 ? r[i] : (w0 == 1 ? r[i + 1] : (i + 2 < 6 ? r[i + 2 < 6 ? i + 2 : 5] : 0ULL));
+        swin2i_compare<NW>(r2w, rni, len, q, s, w);
+    }
 }
 
 }  // namespace bk

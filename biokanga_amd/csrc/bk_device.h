@@ -52,11 +52,18 @@ constexpr int kWave = 64;
 constexpr int kMaxReadLenAbs = 2000;   // cMaxFastQSeqLen upper bound of -L (Aligner.h:94)
 constexpr uint32_t kNodeCap = 1024000; // cMaxNumIdentNodes, SfxArrayV2.h:15
 constexpr uint64_t kEosWord = 0x7777777777777777ULL;
-constexpr int kSwBases = 192, kSwPre = 92, kSwLen = 100;      // DevIndex::swin
+constexpr int kSwBases = 192, kSwPre = 92, kSwLen = 100;      // DevIndex::swin, entries of three 16-byte words (reads of up to 128 bases)
+// .. and by the entry's size in 16-byte words: 3 = 192 bases from 92 before the suffix on (every core of a read of <= 100 bases), 5 = 320
+// bases from 160 before it on (every core of a read of <= 160 bases: 2 x 150), which the 16-word kernel family takes its windows from
+template <int E> struct SwGeo { static constexpr int bases = 64 * E, pre = E == 3 ? 92 : 32 * E; };
+// Where word q (0 .. E - 1) of entry idx lies in swin, in 16-byte units: the entries of a block of 32 are stored word by word - 32 first
+// words, 32 second words, .. - so that the 64 lanes of a round read each word from contiguous memory, and a core whose window does not
+// reach into an entry's first or last 64 bases (two of a 100-base read's four cores at 25 bases) leaves those words' lines untouched.
+template <int E> __host__ __device__ inline uint64_t sw_word_at(uint64_t idx, int q) { return (idx >> 5) * (32ULL * E) + (uint64_t)q * 32 + (idx & 31); }
 constexpr int kSwBlkShift = 5;                                // DevIndex::swmap: coverage goes by blocks of 32 suffix array indexes
 constexpr uint32_t kSwNone = 0xFFFFFFFFu;                     //   .. a block the window array does not hold
 constexpr uint32_t kSwMinRun = 65, kSwHead = 192;             //   .. the coverage rule (bk_index.hip, k_swin_cover)
-constexpr int kSwLevels = 4;                                  //   .. applied for this many core lengths at most (the reads' last phases)
+constexpr int kSwLevels = 8;                                  //   .. applied for this many core lengths at most (the reads' last phases)
 constexpr uint32_t kReadHasN = 1u << 15;   // DevBatch::rmeta
 constexpr uint32_t kReadLenMask = kReadHasN - 1;
 
@@ -83,6 +90,7 @@ struct DevIndex {
                                 //   elements - then fetch their target windows from CONSECUTIVE entries (a streaming read, 130 G
                                 //   entries/s) instead of one random cache line each (50 G/s).  Reads of up to kSwLen bases whose
                                 //   core offsets stay within kSwPre; 4-byte indexes with 48 bytes per base of HBM to spare; may be null
+    int sw_words;               // 16-byte words per entry of swin: 3 or 5 (SwGeo)
     const uint32_t *swmap;      // null: swin holds every suffix.  Else swin holds only the blocks of 2^kSwBlkShift suffix array indexes that the
                                 //   wave kernel's long walks visit: swmap[i >> kSwBlkShift] = the block's number in swin, or kSwNone.
                                 //   Neighbouring covered blocks have neighbouring numbers, so a core interval whose first and last

@@ -52,12 +52,12 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
                    int phase, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt,
                    uint32_t *cmax_next, hipStream_t s);
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
-void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s);
+void launch_build_swin(const DevIndex &ix, void *swin, int words, hipStream_t s);
 void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t a, uint64_t e, uint64_t n_words,
                         const unsigned long long *starts, hipStream_t s);
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
-void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, uint64_t a, uint64_t e, hipStream_t s);
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -1093,11 +1093,12 @@ int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w) { return swin_core_
 // entries - no more of them than `budget` bytes hold (blocks beyond it stay uncovered: coverage never changes a result).  Nothing waits
 // for the host between ranges: the number of covered blocks lives in device memory until swin_end.
 struct SwinBuild {
-    int w[kSwLevels] = {0, 0, 0, 0}, n_levels = 0;
+    int w[kSwLevels] = {}, n_levels = 0;
+    int words = 3;                            // 16-byte words per entry (SwGeo)
     uint32_t max_run = 0, cap_blocks = 0;
     uint64_t done = 0;                        // suffix array indexes below this are dealt with (a multiple of 64, or n)
     uint64_t range_cap = 0;                   // most indexes one range may hold (what the scratch is sized for)
-    unsigned long long *d_brk[kSwLevels] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long *d_brk[kSwLevels] = {};
     uint32_t *d_flags = nullptr, *d_incl = nullptr, *d_map = nullptr, *d_used = nullptr;
     void *d_tmp = nullptr, *d_ent = nullptr;
     size_t tmp_bytes = 0;
@@ -1127,11 +1128,12 @@ struct SwinBuild {
 
 // sliced: the suffix array arrives in ranges (swin_range per range, entries allocated by the budget up front, bucket starts noted by the
 // k-mer table's builder); else ONE swin_range call over the whole array, which allocates what its coverage turned out to need
-int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, uint64_t budget, uint64_t range_cap, bool sliced, hipStream_t s)
+int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, int words, uint64_t budget, uint64_t range_cap, bool sliced, hipStream_t s)
 {
     const uint64_t n = c->ix.n;
     const uint64_t n_blocks = (n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
-    const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
+    sb.words = words;
+    const uint64_t block_bytes = (uint64_t)(16 * words) << kSwBlkShift;
     sb.t0 = StageClock::now();
     sb.n_levels = n_levels;
     for (int l = 0; l < n_levels; l++) sb.w[l] = w[l];
@@ -1140,9 +1142,9 @@ int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, uint64_t bu
     sb.cap_blocks = (uint32_t)std::min<uint64_t>(n_blocks, budget / block_bytes);
     if (sb.cap_blocks == 0) return 1;
     sb.range_cap = std::min<uint64_t>(range_cap, n) + 64;
-    const uint64_t words = (sb.range_cap >> 6) + 4, blocks = (sb.range_cap >> kSwBlkShift) + 2;
+    const uint64_t brk_words = (sb.range_cap >> 6) + 4, blocks = (sb.range_cap >> kSwBlkShift) + 2;
 #define SW_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); return e_ == hipErrorOutOfMemory ? BK_ERR_MEM : BK_ERR_INTERNAL; } } while (0)
-    for (int l = 0; l < n_levels; l++) SW_TRY(dev_malloc(&sb.d_brk[l], words * 8));
+    for (int l = 0; l < n_levels; l++) SW_TRY(dev_malloc(&sb.d_brk[l], brk_words * 8));
     SW_TRY(dev_malloc(&sb.d_flags, blocks * 4));
     SW_TRY(dev_malloc(&sb.d_incl, blocks * 4));
     SW_TRY(dev_malloc(&sb.d_map, n_blocks * 4));
@@ -1185,9 +1187,9 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
             SW_TRY(hipStreamSynchronize(s));
             if (used == 0) { sb.done = e; return BK_OK; }
             sb.cap_blocks = used;
-            SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)used * ((uint64_t)48 << kSwBlkShift)));
+            SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)used * ((uint64_t)(16 * sb.words) << kSwBlkShift)));
         }
-        launch_swin_fill(ix, sb.d_map, sb.d_ent, sb.filled, e, s);
+        launch_swin_fill(ix, sb.d_map, sb.d_ent, sb.words, sb.filled, e, s);
         SW_TRY(hipGetLastError());
         sb.filled = e;
         sb.done = e;
@@ -1202,7 +1204,7 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
     if (sb.ent_state == 3) return BK_ERR_MEM;
     if (sb.ent_state == 2 && sb.d_ent == nullptr) sb.d_ent = sb.ent_mem;
     if (sb.d_ent != nullptr && sb.filled < sb.done) {       // (the ranges that came before the entries' memory did)
-        launch_swin_fill(c->ix, sb.d_map, sb.d_ent, sb.filled, sb.done, s);
+        launch_swin_fill(c->ix, sb.d_map, sb.d_ent, sb.words, sb.filled, sb.done, s);
         sb.filled = sb.done;
     }
     uint32_t used = 0;
@@ -1211,7 +1213,7 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
     sb.drop_scratch();
     if (sb.done < c->ix.n) return BK_ERR_INTERNAL;
     if (used == 0) return 1;
-    const uint64_t block_bytes = (uint64_t)48 << kSwBlkShift;
+    const uint64_t block_bytes = (uint64_t)(16 * sb.words) << kSwBlkShift;
 #undef SW_TRY
     const uint64_t n_blocks = (c->ix.n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
     c->d_swin = sb.d_ent;
@@ -1219,7 +1221,8 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
     sb.d_ent = nullptr;
     sb.ent_mem = nullptr;
     sb.d_map = nullptr;
-    c->swin_w = sb.w[0] | (sb.w[sb.n_levels - 1] << 8) | (sb.n_levels << 16);
+    c->swin_w = sb.w[0] | (sb.w[sb.n_levels - 1] << 8) | (sb.n_levels << 16) | (sb.words << 24);
+    c->ix.sw_words = sb.words;
     c->swin_bytes = (uint64_t)std::max(used, sb.cap_blocks) * block_bytes + n_blocks * 4;      // (what is allocated: a sliced build's entries were sized before its coverage was known)
     c->swin_covered = (double)used / (double)n_blocks;
     c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
@@ -1229,11 +1232,11 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
 }
 
 // most bytes the partial array may take: a third of what every suffix would, half of what is free beyond `reserve`, the caller's cap
-uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve)
+uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve, int words = 3)
 {
     const uint64_t work = ((c->ix.n >> kSwBlkShift) + 1) * 12 + (c->ix.n >> 3) * (kSwLevels + 1) + (64ULL << 20);      // (flags, scan, map, break bitmaps while it is made)
     if (free_b < reserve + work + (1ULL << 30)) return 0;
-    uint64_t budget = std::min<uint64_t>(c->ix.n * 16, (free_b - reserve - work) / 2);
+    uint64_t budget = std::min<uint64_t>(c->ix.n * 16 * (uint64_t)words / 3, (free_b - reserve - work) / 2);
     if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
     return budget;
 }
@@ -1244,16 +1247,19 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     const bool full = c->use_swin == 3;
     int w[kSwLevels];
     const int n_levels = swin_core_lens(c, maxlen, w);
-    const int w_key = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16);
+    // entries of three 16-byte words for the kernel family of reads of up to 128 bases, of five for the one of up to 256 (SwGeo)
+    const int words = maxlen <= 128 ? 3 : 5;
+    const int w_key = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16) | (words << 24);
     if (c->d_swin) {
         // (a partial array made for other core lengths - another read length, an eager build's guess - is made again: it costs little)
-        if (full == (c->d_swmap == nullptr) && (full || c->swin_w == w_key)) return BK_OK;
+        if (full == (c->d_swmap == nullptr) && (full ? c->ix.sw_words == words : c->swin_w == w_key)) return BK_OK;
         HIP_TRY(hipStreamSynchronize(s));
         free_dev(c->d_swin); free_dev(c->d_swmap);
         c->d_swin = nullptr; c->d_swmap = nullptr; c->ix.swin = nullptr; c->ix.swmap = nullptr; c->swin_bytes = 0;
     }
-    // (reads of up to kSwLen bases take every window from it, reads of up to kSwBases - 32 - 2 x 150 - those of their middle cores; 2: whatever the batch)
-    if (c->use_swin == 1 && (maxlen > (uint32_t)(kSwBases - 32) || (maxlen <= (uint32_t)kSwLen && (int)maxlen - make_plan((int)maxlen, c->cfg).core_len > kSwPre))) return BK_OK;
+    // (it serves the register-window kernel families of reads of up to 128 and up to 256 bases: every core of reads of up to 100 / 160
+    // bases, the middle cores of longer ones; 2: made whatever the batch)
+    if (c->use_swin == 1 && maxlen > 256) return BK_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t want = (uint64_t)std::min(nreads, c->chunk_reads) * scratch_bytes_per_read(words_per_read(maxlen), rd2w_for(maxlen), iv_cores_for(c, maxlen));
@@ -1263,19 +1269,20 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     StageClock clk;
     const double t0 = StageClock::now();
     if (full) {
-        const uint64_t need = c->ix.n * 48;
+        const uint64_t need = ((c->ix.n + 31) & ~31ULL) * 16 * (uint64_t)words;             // (whole blocks of 32 entries: sw_word_at)
         if ((uint64_t)free_b < need + reserve) { c->swin_denied = true; return BK_OK; }      // (asked once)
         if (dev_malloc(&c->d_swin, need) != hipSuccess) { (void)hipGetLastError(); c->d_swin = nullptr; c->swin_denied = true; return BK_OK; }
-        launch_build_swin(c->ix, c->d_swin, s);
+        launch_build_swin(c->ix, c->d_swin, words, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));
         c->swin_bytes = need;
         c->swin_covered = 1.0;
+        c->ix.sw_words = words;
     } else {
-        const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve);
+        const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve, words);
         if (!budget) { c->swin_denied = true; return BK_OK; }
         SwinBuild sb;
-        int rb = swin_begin(c, sb, w, n_levels, budget, c->ix.n, false, s);
+        int rb = swin_begin(c, sb, w, n_levels, words, budget, c->ix.n, false, s);
         if (!rb) rb = swin_range(c, sb, c->ix, c->ix.n, s);
         if (!rb) rb = swin_end(c, sb, s);
         if (rb == BK_ERR_INTERNAL) return rb;
@@ -1284,7 +1291,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     c->ix.swin = reinterpret_cast<const uint4 *>(c->d_swin);
     c->ix.swmap = c->d_swmap;
     if (full) c->swin_setup_s = StageClock::now() - t0;
-    if (clk.on) fprintf(stderr, "biokanga_amd: window array for %.1f %% of the suffix array (runs sharing %d .. %d bases, %d levels), %.2f GB\n", 100.0 * c->swin_covered, w[0], w[n_levels - 1], n_levels, c->swin_bytes / 1e9);
+    if (clk.on) fprintf(stderr, "biokanga_amd: window array for %.1f %% of the suffix array (runs sharing %d .. %d bases, %d levels), entries of %d bytes, %.2f GB\n", 100.0 * c->swin_covered, w[0], w[n_levels - 1], n_levels, 16 * words, c->swin_bytes / 1e9);
     clk.lap("suffix-ordered windows");
     return BK_OK;
 }
@@ -1639,7 +1646,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
                 int w[kSwLevels];
                 const int n_levels = swin_core_lens_k(c, 100, tp.k, w);
                 sb.ent_state = 1;                                   // (its entries come from alloc_ahead's thread, started below)
-                swin_sliced = swin_begin(c, sb, w, n_levels, swin_ahead, n / n_slices + 128, true, c->stream) == BK_OK;
+                swin_sliced = swin_begin(c, sb, w, n_levels, 3, swin_ahead, n / n_slices + 128, true, c->stream) == BK_OK;
                 if (!swin_sliced) { (void)hipGetLastError(); sb.ent_state = 0; }
                 else sb.alloc_ahead(device_id, swin_ahead);
             }

@@ -123,14 +123,15 @@ __global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigne
     }
 }
 
-// entry i of the suffix-ordered window array: kSwBases bases of the 2-bit target from sa[i] - kSwPre on (bases before the target's
-// start read as 0: no window that uses them passes the "candidate starts before the read does" test)
-__device__ __forceinline__ void swin_entry(const DevIndex &ix, uint64_t i, uint4 *__restrict__ dst)
+// entry i of the suffix-ordered window array: SwGeo<E>::bases bases of the 2-bit target from sa[i] - SwGeo<E>::pre on (bases before the
+// target's start read as 0: no window that uses them passes the "candidate starts before the read does" test)
+template <int E>
+__device__ __forceinline__ void swin_entry(const DevIndex &ix, uint64_t i, uint4 *__restrict__ swin, uint64_t idx)
 {
-    const int64_t base0 = (int64_t)ix.sa_lo[i] - kSwPre;
-    uint64_t wd[6];
+    const int64_t base0 = (int64_t)ix.sa_lo[i] - SwGeo<E>::pre;
+    uint64_t wd[2 * E];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 2 * E; k++) {
         const int64_t pos = base0 + 32 * k;
         uint64_t v;
         if (pos >= 0) {
@@ -145,19 +146,22 @@ __device__ __forceinline__ void swin_entry(const DevIndex &ix, uint64_t i, uint4
         wd[k] = v;
     }
 #pragma unroll
-    for (int q = 0; q < 3; q++)
-        dst[q] = make_uint4((uint32_t)wd[2 * q], (uint32_t)(wd[2 * q] >> 32), (uint32_t)wd[2 * q + 1], (uint32_t)(wd[2 * q + 1] >> 32));
+    for (int q = 0; q < E; q++)
+        swin[sw_word_at<E>(idx, q)] = make_uint4((uint32_t)wd[2 * q], (uint32_t)(wd[2 * q] >> 32), (uint32_t)wd[2 * q + 1], (uint32_t)(wd[2 * q + 1] >> 32));
 }
 
+// (the array for every suffix: entry i is suffix i's; room for whole blocks of 32 entries)
+template <int E>
 __global__ void __launch_bounds__(256) k_build_swin(DevIndex ix, uint4 *__restrict__ swin)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n; i += (uint64_t)gridDim.x * blockDim.x)
-        swin_entry(ix, i, swin + i * 3);
+        swin_entry<E>(ix, i, swin, i);
 }
 
-void launch_build_swin(const DevIndex &ix, void *swin, hipStream_t s)
+void launch_build_swin(const DevIndex &ix, void *swin, int words, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_build_swin, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
+    if (words == 5) hipLaunchKernelGGL(k_build_swin<5>, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
+    else hipLaunchKernelGGL(k_build_swin<3>, dim3(65536), dim3(256), 0, s, ix, reinterpret_cast<uint4 *>(swin));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -329,12 +333,13 @@ __global__ void k_swin_advance(const uint32_t *__restrict__ incl_last, uint32_t 
     *used = u < cap_blocks ? (uint32_t)u : cap_blocks;
 }
 
+template <int E>
 __global__ void __launch_bounds__(256) k_swin_fill(DevIndex ix, const uint32_t *__restrict__ map, uint4 *__restrict__ swin, uint64_t a, uint64_t e)
 {
     for (uint64_t i = a + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = map[i >> kSwBlkShift];
         if (s == kSwNone) continue;
-        swin_entry(ix, i, swin + (((uint64_t)s << kSwBlkShift) + (i & ((1u << kSwBlkShift) - 1))) * 3);
+        swin_entry<E>(ix, i, swin, ((uint64_t)s << kSwBlkShift) + (i & ((1u << kSwBlkShift) - 1)));
     }
 }
 
@@ -370,11 +375,12 @@ void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blo
 }
 
 // map: the whole map (indexed by suffix array index >> kSwBlkShift); entries of the indexes [a, e)
-void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, uint64_t a, uint64_t e, hipStream_t s)
+void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s)
 {
     if (e <= a) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>((e - a + 255) / 256, 65536);
-    hipLaunchKernelGGL(k_swin_fill, dim3(blocks), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin), a, e);
+    if (words == 5) hipLaunchKernelGGL(k_swin_fill<5>, dim3(blocks), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin), a, e);
+    else hipLaunchKernelGGL(k_swin_fill<3>, dim3(blocks), dim3(256), 0, s, ix, map, reinterpret_cast<uint4 *>(swin), a, e);
 }
 
 __global__ void k_build_isa(const uint32_t *__restrict__ sa, uint64_t i0, uint64_t i1, uint32_t *__restrict__ isa)

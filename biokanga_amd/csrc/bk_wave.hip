@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
         int hit_strand = '?';
         bool done = false;
         int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-        const bool sw_read = SW && len <= kSwLen && len - cl <= kSwPre;       // every core offset of the read lies within an entry's lead
+        constexpr int E = NW <= 8 ? 3 : 5;                     // 16-byte words of a window array entry of this kernel family (SwGeo)
+        // every core offset of the read lies within an entry's lead, and the read's end within the entry; shared rounds take their
+        // windows from three-word entries only
+        const bool sw_read = SW && E == 3 && len <= SwGeo<E>::bases - SwGeo<E>::pre && len - cl <= SwGeo<E>::pre;
         for (int st = s0; st <= s1 && !done; st++) {
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
                 if (lset_n) {
@@ -290,7 +293,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                 // the window array serves a core when the read's whole window lies inside the candidate's entry: bases kSwPre - ofs ..
                 // + len of its kSwBases (every core of a read of up to kSwLen bases; of a longer read - 2 x 150 - the cores in the
                 // middle, when they are walked a round per 64 suffixes; rounds shared by several cores of such a read go to the target)
-                const bool sw_core = SW && ((GROUP && grouped) ? (sw_read && grp_sw) : (ofs <= kSwPre && len - ofs <= kSwBases - kSwPre && sw_n_c != 0));
+                const bool sw_core = SW && ((GROUP && grouped) ? (sw_read && grp_sw) : (ofs <= SwGeo<E>::pre && len - ofs <= SwGeo<E>::bases - SwGeo<E>::pre && sw_n_c != 0));
+                // the entry's 16-byte words (64 bases each) the window lies in; a shared round's cores differ in it: every word
+                const int sw_q0 = (GROUP && grouped) ? 0 : (SwGeo<E>::pre - ofs) >> 6, sw_q1 = (GROUP && grouped) ? E - 1 : (SwGeo<E>::pre - ofs + len - 1) >> 6;
                 for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
@@ -302,10 +307,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
-                    uint4 ev[3];
+                    uint4 ev[E];
                     if (SW && sw_now && active) {
-                        const uint4 *__restrict__ ep = ix.swin + (uint64_t)(lsw_base + j) * 3;
-                        ev[0] = ep[0]; ev[1] = ep[1]; ev[2] = ep[2];
+                        // (only the words the core's window reaches into: which, is the same for every candidate of the core)
+                        const uint32_t eidx = lsw_base + j;
+                        const uint4 *__restrict__ ep = ix.swin + ((uint64_t)(eidx >> 5) * (32u * E) + (eidx & 31u));
+#pragma unroll
+                        for (int q = 0; q < E; q++)
+                            if (q >= sw_q0 && q <= sw_q1) ev[q] = ep[q * 32];
                     }
                     // (target positions of an index of 4-byte elements: 32-bit arithmetic)
                     using P = typename PosT<WIDE>::type;
@@ -340,8 +349,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevA
                             const bool flg = window_flagged_t<WIDE>(ix, t, len);
                             if (SW && sw_now) {
                                 if constexpr (SW) {
-                                    if (GROUP && grouped) eval_swin2i<NW, false>(r2w, rni, len, ev, kSwPre - lofs, w);
-                                    else eval_swin2i<NW, true>(r2w, rni, len, ev, kSwPre - lofs, w);
+                                    if (GROUP && grouped) eval_swin2i<NW, false, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
+                                    else eval_swin2i<NW, true, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
                                 }
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
@@ -575,7 +584,7 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
 #define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, sorted, n_sorted, p_n_list, phase, cursor, next_act, next_cnt, cmax_next)
-    const bool sw = ix.swin != nullptr && b.rd2 != nullptr;
+    const bool sw = ix.swin != nullptr && b.rd2 != nullptr && ix.sw_words == ((nw & 0xff) <= 8 ? 3 : 5);      // (entries of this kernel family's size)
     const bool group8 = (nw & 0x100) != 0;                 // 8-word form: small intervals share rounds (the 16-word form always does)
     nw &= 0xff;
     if (nw <= 8) {

@@ -48,9 +48,11 @@ __global__ void k_calib80(const uint4 *__restrict__ tab, uint64_t mask16, uint64
     }
     if (acc == 0x1234567) out[0] = acc;
 }
-// the window array's pattern (k_wave with DevIndex::swin): a wave reads 64 CONSECUTIVE 48-byte entries per round - each lane three
-// 16-byte loads - from a random place of the table: the "wide coalesced 16 B/lane streaming read" the guide says FETCH_SIZE may
-// report at half its size.  runs of 1 round (what most k_wave rounds are) and of 16 rounds.
+// the window array's pattern (k_wave with DevIndex::swin): a wave reads 64 CONSECUTIVE entries per round from a random place of the
+// table.  The entries of a block of 32 are stored word by word (bk_device.h, sw_word_at: 32 first 16-byte words, 32 second ones, 32
+// third ones), so every load instruction of the round reads contiguous memory - the "wide coalesced 16 B/lane streaming read" the guide
+// says FETCH_SIZE may report at half its size.  runs of 1 round (what most k_wave rounds are) and of 16 rounds, all three words.
+__device__ __forceinline__ const uint4 *calib_word_at(const uint4 *__restrict__ tab, uint64_t idx, int q) { return tab + ((idx >> 5) * 96 + (uint64_t)q * 32 + (idx & 31)); }
 template <int ROUNDS>
 __device__ __forceinline__ void calib_runs_body(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int runs_per_wave)
 {
@@ -59,10 +61,10 @@ __device__ __forceinline__ void calib_runs_body(const uint4 *__restrict__ tab, u
     uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
     for (int r = 0; r < runs_per_wave; r++) {
         x = x * 6364136223846793005ULL + 1442695040888963407ULL;
-        const uint64_t start = (x >> 16) % (n_entries - (uint64_t)ROUNDS * 64);
+        const uint64_t start = (x >> 16) % (n_entries - (uint64_t)ROUNDS * 64 - 64);
         for (int k = 0; k < ROUNDS; k++) {
-            const uint4 *e = tab + (start + (uint64_t)k * 64 + lane) * 3;
-            const uint4 a = e[0], b = e[1], c = e[2];
+            const uint64_t idx = start + (uint64_t)k * 64 + lane;
+            const uint4 a = *calib_word_at(tab, idx, 0), b = *calib_word_at(tab, idx, 1), c = *calib_word_at(tab, idx, 2);
             acc += a.x ^ b.y ^ c.z;
         }
     }
@@ -70,8 +72,9 @@ __device__ __forceinline__ void calib_runs_body(const uint4 *__restrict__ tab, u
 }
 __global__ void __launch_bounds__(256) k_calib_runs1(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int rpw) { calib_runs_body<1>(tab, n_entries, out, rpw); }
 __global__ void __launch_bounds__(256) k_calib_runs16(const uint4 *__restrict__ tab, uint64_t n_entries, uint64_t *out, int rpw) { calib_runs_body<16>(tab, n_entries, out, rpw); }
-// k_wave's round with the window array, whole: the 64 consecutive 48-byte entries AND the 64 consecutive 4-byte suffix array
-// elements that go with them (52 bytes per candidate)
+// k_wave's round with the window array, whole: of the 64 consecutive entries the words the core's window reaches into - two of the
+// three for the cores of a 100-base read at offsets 0, 25 and 75, all three at 50: 36 bytes on average - AND the 64 consecutive 4-byte
+// suffix array elements that go with them (40 bytes per candidate)
 __global__ void __launch_bounds__(256) k_calib_wave(const uint4 *__restrict__ tab, uint64_t n_entries, const uint32_t *__restrict__ sa, uint64_t *out, int rpw)
 {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -79,10 +82,13 @@ __global__ void __launch_bounds__(256) k_calib_wave(const uint4 *__restrict__ ta
     uint64_t x = wave * 0x9E3779B97F4A7C15ULL + 12345, acc = 0;
     for (int r = 0; r < rpw; r++) {
         x = x * 6364136223846793005ULL + 1442695040888963407ULL;
-        const uint64_t start = (x >> 16) % (n_entries - 64);
-        const uint4 *e = tab + (start + lane) * 3;
-        const uint4 a = e[0], b = e[1], c = e[2];
-        acc += a.x ^ b.y ^ c.z ^ sa[start + lane];
+        const uint64_t idx = (x >> 16) % (n_entries - 128) + lane;
+        const int core = r & 3;                                  // offsets 0, 25, 50, 75: words {1,2} {1,2} {0,1,2} {0,1}
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (core >= 2) a = *calib_word_at(tab, idx, 0);
+        const uint4 b = *calib_word_at(tab, idx, 1);
+        if (core <= 2) c = *calib_word_at(tab, idx, 2);
+        acc += a.x ^ b.y ^ c.z ^ sa[idx];
     }
     if (acc == 0x1234567) out[0] = acc;
 }
@@ -115,7 +121,7 @@ static int calib()
     hipMemset(sa, 1, n_entries * 4);
     hipLaunchKernelGGL(k_calib_wave, dim3(waves / 4), dim3(256), 0, 0, (const uint4 *)tab, n_entries, sa, out, rpw1);
     hipDeviceSynchronize();
-    printf("calib: k_calib_wave: %llu entries of 52 B (48-byte window entry + 4-byte suffix array element) in runs of 64\n", (unsigned long long)waves * rpw1 * 64);
+    printf("calib: k_calib_wave: %llu entries of 40 B (36 bytes of a 48-byte window entry + 4-byte suffix array element) in runs of 64\n", (unsigned long long)waves * rpw1 * 64);
     printf("calib: k_calib_runs1: %llu entries of 48 B in runs of 64; k_calib_runs16: %llu entries of 48 B in runs of 1024; k_calib_stream16: %llu B streamed once\n",
            (unsigned long long)waves * rpw1 * 64, (unsigned long long)waves * rpw16 * 16 * 64, (unsigned long long)bytes);
     return 0;
