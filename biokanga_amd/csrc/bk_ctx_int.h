@@ -130,6 +130,7 @@ struct bk_ctx {
     uint64_t cap_in_bases = 0;
     uint32_t cap_in_reads = 0;
 
+    hipEvent_t ev_wait = nullptr;         // an event the caller's thread sleeps on (bk_wait.h)
     bool entries_set = false, tgt2_built = false;     // .. and so do the entry table / the 2-bit target (made early for a window array that is made behind the upload too)
     bool tables_built = false;            // k-mer table, second-level keys, inverse suffix array exist (made behind the suffix array's upload)
     void *sam_text[2] = {nullptr, nullptr};   // bk_sam_format's page-locked text buffers, kept for the next call (giving page-locked memory back costs 0.1 s per GB)

@@ -24,6 +24,8 @@
 #include <rccl/rccl.h>
 
 #include "bk_ctx_int.h"
+#include "bk_cpus.h"
+#include "bk_wait.h"
 #include "sfx_file.h"
 
 namespace bk {
@@ -436,7 +438,8 @@ int setup_entries(bk_ctx *c, const bk_entry_info *entries, uint32_t n_entries)
     HIP_TRY(dev_malloc(&c->d_small, 16 * 4));
     HIP_TRY(dev_malloc(&c->d_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
     HIP_TRY(hipHostMalloc(&c->h_ctl, sizeof(PhaseCtl) * (kMaxPhases + 2)));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
+    HIP_TRY(bk::make_wait_event(&c->ev_ctl));
+    HIP_TRY(bk::make_wait_event(&c->ev_wait));
     HIP_TRY(dev_malloc(&c->d_ctr_aux, 32));
     HIP_TRY(hipHostMalloc(&c->h_small, 2 * sizeof(PhaseCtl)));
     int rc = derive_cfg(c);
@@ -470,6 +473,9 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BK_ERR_NODEVICE;
     if (device_id < 0 || device_id >= ndev) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(device_id));
+    // host threads sleep while they wait for the device instead of spinning (only takes before the process's first real use of the
+    // device: a host that has initialised it - PyTorch - keeps its own choice; the pipelines' long waits sleep either way, bk_wait.h)
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     bk_ctx *c = new bk_ctx();
     c->device = device_id;
     c->params = *p;
@@ -1390,7 +1396,7 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
     }
     if (enqueue_only) return BK_OK;          // (the chunk's counts reach the host behind its kernels: take_phase_history of the next call)
     hipEvent_t t1 = tm.begin(s);
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(bk::wait_stream(s, c->ev_wait));             // (asleep: the caller's thread leaves its CPU to others meanwhile)
     { int rh = take_phase_history(c, true); if (rh) return rh; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t0, t1);
@@ -1792,6 +1798,7 @@ void bk_ctx_destroy(bk_ctx *c)
     for (void *&t : c->sam_text) if (t) { (void)hipHostFree(t); t = nullptr; }
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
+    if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2110,7 +2117,7 @@ int bk_pack_reads(const uint8_t *bases, const uint64_t *offs, const uint32_t *le
     if (!nreads) return BK_OK;
     // slices of reads, one thread each: first word and first base of every slice, then pack; exceptions are collected per slice
     // and laid behind each other afterwards (ascending by read and position as the slices are)
-    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    unsigned nt = (unsigned)std::max(1, std::min(16, bk::effective_cpus()));         // (affinity mask and cgroup quota, not the host's hardware threads)
     if (nreads < 65536) nt = 1;
     std::vector<uint64_t> w0(nt + 1, 0), b0(nt + 1, 0);
     std::vector<uint32_t> r0(nt + 1);

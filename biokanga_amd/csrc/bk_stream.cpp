@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "bk_ctx_int.h"
+#include "bk_wait.h"
 
 namespace {
 
@@ -120,6 +121,7 @@ struct bk_stream {
     size_t scan_tmp_bytes = 0;
     unsigned long long *d_ext = nullptr, *h_ext = nullptr;     // [0] max read end [1] max read length
     std::thread t_up, t_al, t_dn;
+    hipEvent_t ev_w_al = nullptr, ev_w_dn = nullptr;       // what the aligner and the download thread sleep on (bk_wait.h)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Job *> q_up, q_al, q_dn;
@@ -254,7 +256,7 @@ struct bk_stream {
                     e = hipGetLastError();
                 }
                 if (e == hipSuccess) e = hipMemcpyAsync(h_ext, d_ext, 16, hipMemcpyDeviceToHost, s_al);
-                if (e == hipSuccess) e = hipStreamSynchronize(s_al);
+                if (e == hipSuccess) e = bk::wait_stream(s_al, ev_w_al);
                 if (e != hipSuccess) fail(j, rc_of(e));
                 else if (h_ext[0] > j->nbases || h_ext[1] > (unsigned long long)bk::kMaxReadLenAbs) fail(j, BK_ERR_PARAMS);
                 const uint32_t maxlen = (uint32_t)h_ext[1];
@@ -300,7 +302,7 @@ struct bk_stream {
             } else if (j->n) {
                 hipError_t e = hipStreamWaitEvent(s_dn, sl.ev_al, 0);
                 if (e == hipSuccess) e = hipMemcpyAsync(j->out, sl.d_out, (size_t)j->n * sizeof(bk_hit), hipMemcpyDeviceToHost, s_dn);
-                if (e == hipSuccess) e = hipStreamSynchronize(s_dn);
+                if (e == hipSuccess) e = bk::wait_stream(s_dn, ev_w_dn);         // (asleep until the records are back)
                 if (e != hipSuccess) fail(j, rc_of(e));
             }
             {
@@ -375,6 +377,8 @@ void bk_stream_destroy(bk_stream *s)
     if (s->s_up) (void)hipStreamDestroy(s->s_up);
     if (s->s_al) (void)hipStreamDestroy(s->s_al);
     if (s->s_dn) (void)hipStreamDestroy(s->s_dn);
+    if (s->ev_w_al) (void)hipEventDestroy(s->ev_w_al);
+    if (s->ev_w_dn) (void)hipEventDestroy(s->ev_w_dn);
     for (auto &kv : s->jobs) delete kv.second;
     delete s;
 }
@@ -413,6 +417,8 @@ static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads,
     hipError_t e = hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_al, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_dn, hipStreamNonBlocking);
+    if (e == hipSuccess) e = bk::make_wait_event(&s->ev_w_al);
+    if (e == hipSuccess) e = bk::make_wait_event(&s->ev_w_dn);
     auto alloc_slots = [&]() {
         hipError_t e2 = hipSuccess;
         for (Slot &sl : s->slots) {

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "bk_ctx_int.h"
+#include "bk_cpus.h"
+#include "bk_wait.h"
 
 namespace {
 
@@ -87,7 +89,8 @@ template <class Fill>
 int upload_staged(void *d_dst, size_t bytes, int device, int max_threads, Fill fill)
 {
     const size_t n_slices = (bytes + kSlice - 1) / kSlice;
-    const int nt = (int)std::min<size_t>((size_t)max_threads, std::min<size_t>(n_slices, std::max(1u, std::thread::hardware_concurrency() / 2)));
+    // (threads by the CPUs this process may really use - affinity mask and cgroup quota -, not by the host's hardware threads)
+    const int nt = (int)std::min<size_t>((size_t)max_threads, std::min<size_t>(n_slices, (size_t)std::max(1, bk::effective_cpus() / 2)));
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
     auto work = [&]() {
@@ -96,7 +99,7 @@ int upload_staged(void *d_dst, size_t bytes, int device, int max_threads, Fill f
         hipEvent_t ev[2] = {nullptr, nullptr};
         void *buf[2] = {g_pool.get(), g_pool.get()};
         bool ok = buf[0] && buf[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+                  bk::make_wait_event(&ev[0]) == hipSuccess && bk::make_wait_event(&ev[1]) == hipSuccess;      // (waited for asleep)
         bool used[2] = {false, false};
         for (int k = 0; ok && !failed; k ^= 1) {
             const size_t s = next.fetch_add(1);
@@ -107,8 +110,9 @@ int upload_staged(void *d_dst, size_t bytes, int device, int max_threads, Fill f
             ok = hipMemcpyAsync((uint8_t *)d_dst + off, buf[k], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[k], st) == hipSuccess;
             used[k] = true;
         }
-        if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
-        if (!ok) failed = 1;
+        for (int k = 0; k < 2; k++)
+            if (ok && used[k] && hipEventSynchronize(ev[k]) != hipSuccess) ok = false;
+        if (!ok) { if (st) (void)hipStreamSynchronize(st); failed = 1; }
         for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (buf[k]) g_pool.put(buf[k]); }
         if (st) (void)hipStreamDestroy(st);
     };

@@ -22,6 +22,7 @@
 #include <sys/mman.h>
 #include <map>
 #include <string>
+#include "../bk_cpus.h"
 #include <vector>
 
 #include "noinit.h"
@@ -84,28 +85,8 @@ inline const char *kNarDescr[20] = {"Not processed for alignment", "Alignment ac
                              "PE partner aligned to different target sequence", "PE alignment not accepted",
                              "Alignment violated loci base constraints"};
 
-// CPUs this process can actually keep busy: the hardware threads it may run on, cut down to the cgroup's CPU quota when there is
-// one (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1).  More runnable threads than that only buy throttling.
-inline int effective_cpus()
-{
-    long n = sysconf(_SC_NPROCESSORS_ONLN);
-    if (n < 1) n = 1;
-    long long quota = -1, period = 100000;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[64];
-        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-        fclose(g);
-        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
-    }
-    if (quota > 0 && period > 0) {
-        const long lim = (long)((quota + period - 1) / period);
-        if (lim >= 1 && lim < n) n = lim;
-    }
-    return (int)n;
-}
+// (CPUs this process can actually keep busy - affinity mask and cgroup quota: the library's own reader, bk_cpus.h)
+inline int effective_cpus() { return bk::effective_cpus(); }
 
 struct ReadStore {
     bk::RawVec<uint8_t> bases;             // (RawVec: sized once, filled by all threads - see noinit.h)

@@ -611,6 +611,28 @@ def test_align_over_several_contexts_sam_byte_identical(golden_tmp, tmp_path, fi
         assert f"reduced over {2 if devices == '0-1' else devices.count(',') + 1} devices" in log
 
 
+def test_four_contexts_on_four_cpus(golden_tmp, tmp_path):
+    """`--devices 0,0,0,0` with the process held to four CPUs (what a rank of an 8-GPU job gets under the box's CPU quota): four pipelines
+    of three threads each wait for the device asleep (bk_wait.h) and size their thread pools by the CPUs they may use (bk_cpus.h) - the
+    run finishes in about the time of the unconstrained one, and its file is the single-context run's, byte for byte"""
+    import time
+    d = golden_tmp["basic"]
+    inputs = ["-i", os.path.join(helpers.GOLDEN, "sortorder", "reads.fa.gz")]
+    cpus = sorted(os.sched_getaffinity(0))[:4]
+    took = {}
+    for name, pre in (("free", None), ("four", lambda: os.sched_setaffinity(0, set(cpus)))):
+        out = str(tmp_path / f"{name}.sam")
+        t = time.time()
+        r = subprocess.run([BIN, "align"] + inputs + ["-I", os.path.join(d, "genome.sfx"), "-o", out, "--devices", "0,0,0,0", "-s3"], cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, preexec_fn=pre)
+        took[name] = time.time() - t
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert open(out, "rb").read() == golden_bytes("sortorder", "s3.m5.sam.gz")
+        assert "reduced over 4 devices" in r.stdout
+    print(f"four contexts: {took['free']:.2f} s unconstrained, {took['four']:.2f} s on CPUs {cpus}")
+    assert took["four"] < 3 * took["free"] + 5
+
+
 @pytest.mark.parametrize("tag", ["sim", "mixed"])
 def test_simreads_truth_check_line(golden_tmp, tmp_path, tag):
     """the reference's built-in correctness signal (CAligner::ReportAlignStats, Aligner.cpp:3581-3728): reads named by
