@@ -473,9 +473,6 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BK_ERR_NODEVICE;
     if (device_id < 0 || device_id >= ndev) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(device_id));
-    // host threads sleep while they wait for the device instead of spinning (only takes before the process's first real use of the
-    // device: a host that has initialised it - PyTorch - keeps its own choice; the pipelines' long waits sleep either way, bk_wait.h)
-    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     bk_ctx *c = new bk_ctx();
     c->device = device_id;
     c->params = *p;

@@ -13,6 +13,7 @@
 #     inflate   the loaders' DEFLATE decoder on the box's host: one thread, 2 .. 16 threads, zlib (tools/inflate_bench.sh; no GPU work)
 #     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
 #     upload    host -> device upload methods, wall-clock and CPU seconds (tools/upload_bench)
+#     quota     two bench ranks / four command-line contexts on the one GPU, unconstrained and under `taskset -c 0-3`
 set -u
 tag=${1:-x}
 shift
@@ -50,6 +51,23 @@ PY
     upload)
       python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
       tools/upload_bench /dev/shm/upload_bench.bin 6 > $O/upload_methods.txt 2>&1; cat $O/upload_methods.txt; rm -f /dev/shm/upload_bench.bin ;;
+    quota)
+      # two ranks on the one GPU and four contexts of the command line, unconstrained and held to four CPUs (what a rank of an 8-GPU job
+      # gets of the box's 16-CPU quota): the host side must not need more
+      B="python3 bench.py --gpus 2 --force-device 0 --dist-backend gloo --genome-mbp 800 --reads 12000000 --cpu-baseline-secs 0 --no-live-traffic --no-other-layout --steps 3"
+      timeout 300 $B > $O/quota_2ranks_free.json 2> $O/quota_2ranks_free.err
+      timeout 300 taskset -c 0-3 $B > $O/quota_2ranks_4cpus.json 2> $O/quota_2ranks_4cpus.err
+      python3 - "$O" <<'PY'
+import json, sys
+for f in ("quota_2ranks_free", "quota_2ranks_4cpus"):
+    try:
+        d = json.load(open(f"{sys.argv[1]}/{f}.json"))
+        print(f, "host-in/host-out %.1f M reads/s, kernel-only %.1f M reads/s over %d ranks" % (d["value"] / 1e6, d["value_kernel_only"] / 1e6, d["n_gpus"]))
+    except Exception as e:
+        print(f, "failed:", e)
+PY
+      timeout 600 python3 tools/e2e_cli.py 20000000 --quiet --repeat 2 -- --devices 0,0,0,0 > $O/quota_cli_free.log 2>&1; grep -a "T_e2e\|load " $O/quota_cli_free.log | cut -c1-220
+      timeout 600 taskset -c 0-3 python3 tools/e2e_cli.py 20000000 --quiet --repeat 2 -- --devices 0,0,0,0 > $O/quota_cli_4cpus.log 2>&1; grep -a "T_e2e\|load " $O/quota_cli_4cpus.log | cut -c1-220 ;;
     *) echo "gpu_session.sh: unknown step '$what'" ;;
   esac
 done
