@@ -483,14 +483,14 @@ class HostLeg:
         self.B = B
         cuts = list(range(0, n, B)) + [n]
 
-        # The first step grows its batches by a factor of three (6 %, 18 %, 76 % of a batch): the pipeline has nothing to overlap the very
-        # first upload with, so the smaller it is the sooner the kernels start, and a batch crosses PCIe about 3.5 times faster than it
-        # is aligned, so each upload still hides behind the batch before it.  Small batches cost more per read (every phase's
-        # wave-per-read launch lasts at least as long as its heaviest read), hence no finer ramp than that.
+        # The first step grows its batches (6 %, 28 %, 66 % of a batch): the pipeline has nothing to overlap the very first upload with,
+        # so the smaller it is the sooner the kernels start, and a batch crosses PCIe about 2.7 times faster than it is aligned (0.62 ns
+        # against 1.65 ns per read, plus about 4 ms a batch), so each upload still hides behind the batch before it.  Small batches cost
+        # more per read (every phase's wave-per-read launch lasts at least as long as its heaviest read), hence no finer ramp than that.
         def even(v):
             return max(2, int(v) & ~1)
         first = min(B, n)
-        ramp = [0, even(0.06 * first), even(0.24 * first)] if first >= 1000 else [0]
+        ramp = [0, even(0.06 * first), even(0.34 * first)] if first >= 1000 else [0]
         self.cuts = cuts
         self.cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
         # .. and the last step ends on a tenth of a batch: the download of the very last batch has nothing to hide behind either

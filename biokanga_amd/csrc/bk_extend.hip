@@ -271,8 +271,12 @@ __host__ __device__ constexpr bool flat_caches_first(bool wide, int bs, int slot
     return !wide && slots_max <= 16 && bs * slots_max * 6 <= 24576;
 }
 
-// per-read rows of the 2-bit read copy are staged in LDS (fetched once per block, with the lengths and the interval records)
-__host__ __device__ constexpr bool flat_rows_in_lds(bool wide, int nw, int bs) { return !wide && nw <= 8 && bs <= 256; }
+// Rows of the 2-bit read copy: a candidate's lane fetches its read's row (one strand: 32 bytes of a 100-base read) together with the
+// candidate's window.  (They used to be staged in LDS, both strands of every read of the block fetched up front: 64 bytes for each of
+// the many reads of a phase that turn out to have no candidate at all - three reads in four in phase 0 - and 16 KB of LDS per block.)
+__host__ __device__ constexpr bool flat_rows_in_lds(bool wide, int nw, int bs) { return false; }
+// .. but the result bytes of a pass stay at what that form left room for (the target starts of a pass's candidates take their place)
+__host__ __device__ constexpr bool flat_small_pass(bool wide, int nw, int bs) { return !wide && nw <= 8 && bs <= 256; }
 
 template <bool WIDE, int NW, int BS>
 __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
@@ -292,7 +296,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     constexpr int KB = 1;                                   // candidates a lane has in flight (2 .. 4 measured: the registers cost more occupancy than the overlap buys)
 #endif
     constexpr int NBLK = NW / 4 + 1;
-    constexpr uint32_t CAP = (ROWS ? kFlatCap / 4 : kFlatCap) * BS / 256;        // (LDS: four blocks per CU must fit 160 KB)
+    constexpr bool SMALL = flat_small_pass(WIDE, NW, BS);
+    constexpr uint32_t CAP = (SMALL ? kFlatCap / 4 : kFlatCap) * BS / 256;       // (LDS: four blocks per CU must fit 160 KB)
     constexpr int SPEC = 8;                                 // interval records requested before the length is known
     extern __shared__ uint32_t s_dyn[];
     // 4-byte indexes: the interval starts (and the "unverified bucket" bits) the counting pass has loaded anyway stay in LDS, so that
@@ -316,6 +321,9 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     // candidate whose start lies a multiple of 2^32 bases from an earlier candidate of the same strand pass is taken for seen and
     // skipped.  The low words travel with the result bytes and the replay applies exactly that rule.
     __shared__ alignas(16) uint32_t s_key[WIDE ? CAP : 1];
+    // 4-byte indexes: the target start of every candidate of the pass - the accepted read's locus is read from here instead of from
+    // the suffix array again (a random line, and a dependent trip at the block's very end)
+    __shared__ uint32_t s_t[SMALL ? CAP : 1];
     __shared__ uint32_t s_wsum[BS / 64];
     __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
     __shared__ unsigned long long s_ctr[3];
@@ -437,7 +445,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
     const int init = mm + cfg.mm_delta + 1;
     int low_inst = 0, low_mm = init, nxt = init;
     int best_q = -1;
-    uint32_t best_j = 0;
+    uint32_t best_j = 0, best_x = 0, my_hit_t = 0;       // best_x: the best candidate's number among the read's; my_hit_t: its target start (SMALL)
     constexpr uint32_t kNone = 0xFFFFFFFFu, kOffStart = 1u << 18, kLazyBit = 1u << 16;
 
     for (uint32_t start = 0; start < BS;) {
@@ -487,6 +495,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             }
             // ---- B: window start; the region flags and the window's blocks are requested, nothing waits for them here
             uint4 wv[KB][NBLK];
+            uint4 rowv[KB][NW / 4];         // the read's 2-bit row of the candidate's strand (when it is not taken from LDS)
             uint8_t fb0[KB], fb1[KB];
 #pragma unroll
             for (int i = 0; i < KB; i++) {
@@ -509,6 +518,12 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                             fb0[i] = ix.nflag[g0 >> 3];
                             fb1[i] = ix.nflag[g1 >> 3];
                             window2_load<NW>(ix.tgt2, ix.tgt2s, t0, c_len, wv[i]);
+                            if (!ROWS) {
+                                const int sti = q >= cmaxs ? 1 : 0;
+                                const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(b.rd2 + ((uint64_t)s_r[ri] * 2 + (uint64_t)(s0 + sti)) * (NW / 2));
+#pragma unroll
+                                for (int u = 0; u < NW / 4; u++) rowv[i][u] = rp[u];
+                            }
                         }
                     } else
                         meta[i] |= kOffStart;
@@ -545,8 +560,13 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                                 r2w[2 * u] = ((uint64_t)v.y << 32) | v.x;
                                 r2w[2 * u + 1] = ((uint64_t)v.w << 32) | v.z;
                             }
-                        } else
-                            load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (NW / 2), r2w);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < NW / 4; u++) {
+                                r2w[2 * u] = ((uint64_t)rowv[i][u].y << 32) | rowv[i][u].x;
+                                r2w[2 * u + 1] = ((uint64_t)rowv[i][u].w << 32) | rowv[i][u].z;
+                            }
+                        }
 #pragma unroll
                         for (int u = 0; u < NW / 4; u++) rnm[u] = 0;
                         window2_compare<NW>(r2w, rnm, c_len, t0, wv[i], w);
@@ -557,6 +577,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     for (int c2 = 0; c2 < c; c2++) skip |= core_clean<NW>(w, c2 * c_cd, c_cl);   // earlier cores never sit at the clipped offset
                     if (!skip) rec = (uint8_t)(w.mm < 127 ? w.mm : 127);
                     if (WIDE) s_key[f] = (uint32_t)t0;
+                    if (SMALL) s_t[f] = (uint32_t)t0;
                     if (!WIDE && rec != kRecSkip) {
                         atomicAdd(&s_c2[ri], 1u << 16);
                         if (rec <= s_mm[ri]) atomicMin(&s_k1[ri], ((uint32_t)rec << 16) | (base + f - s_off[ri]));
@@ -584,7 +605,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     if (cm > mm || cm >= nxt) continue;
                     if (cm < low_mm) {
                         low_inst = 1; nxt = low_mm; low_mm = cm;
-                        best_q = q; best_j = x - prev;
+                        best_q = q; best_j = x - prev; best_x = x;
                     } else if (cm == low_mm)
                         low_inst++;
                     else
@@ -675,8 +696,10 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                         while (sp[q] <= local) q++;
                         best_q = q;
                         best_j = local - (q ? sp[q - 1] : 0);
+                        best_x = local;
                     }
                 }
+                if (SMALL && best_q >= 0) my_hit_t = s_t[s_off[t] - base + best_x];      // (this pass's candidates are still in LDS)
             }
         }
         PROF(4);
@@ -742,7 +765,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             const int last = len - cl;
             const int ofs = c * cd < last ? c * cd : last;
             const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, a, st, c));
-            hit_left = sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
+            hit_left = SMALL ? (uint64_t)my_hit_t : sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
             hit_strand = st ? '-' : '+';
             if (ent_lds) {
                 int lo = 0, hi = (int)ix.n_ent - 1;

@@ -122,8 +122,20 @@ int cmd_index(int argc, char **argv, int first)
     std::sort(files.begin(), files.end());                               // SG_GLOB_FULLSORT
     int nthreads = a.num("T", 0);
     if (nthreads <= 0) nthreads = effective_cpus();
+    // (BK_TIMING=1: the stages' wall-clock on stderr)
+    const bool timing = getenv("BK_TIMING") != nullptr;
+    timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        fprintf(stderr, "bk timing: index: %-44s %8.1f ms\n", what, 1e3 * (double)(ts.tv_sec - ts0.tv_sec) + 1e-6 * (double)(ts.tv_nsec - ts0.tv_nsec));
+        ts0 = ts;
+    };
     Genome G;
     if (load_genome(files, min_seq_len, std::max(1, std::min(nthreads, 128)), G)) return 1;
+    lap("genome files taken in (parse, N runs)");
     bk::RawVec<uint8_t> &seq = G.seq;
     std::vector<bk::SfxEntry> &entries = G.entries;
     const uint32_t n_under = G.n_under;
@@ -139,15 +151,20 @@ int cmd_index(int argc, char **argv, int first)
     uint8_t *d_seq = nullptr, *d_sa = nullptr;
     if (hipMalloc(&d_seq, n) != hipSuccess || hipMalloc(&d_sa, n * el) != hipSuccess) { diag("Fatal: unable to allocate device memory"); return 1; }
     if (hipMemcpy(d_seq, seq.data(), n, hipMemcpyHostToDevice) != hipSuccess) { diag("Fatal: upload failed"); return 1; }
+    lap("HIP start-up, device buffers, bases uploaded");
     int rc = bk_build_sa_device(d_seq, n, d_sa, (int)el, dev);
     if (rc) { diag("Fatal: suffix sort failed: %s", bk_strerror(rc)); return 1; }
+    lap("suffix array sorted on the device");
     bk::RawVec<uint8_t> sa;                                              // (12 GB for a human genome: sized, not zeroed first)
     sa.resize(n * el);
     if (hipMemcpy(sa.data(), d_sa, n * el, hipMemcpyDeviceToHost) != hipSuccess) { diag("Fatal: download failed"); return 1; }
+    lap("suffix array downloaded (pageable)");
     (void)hipFree(d_seq);
     (void)hipFree(d_sa);
+    lap("device buffers given back");
     rc = bk::sfx_write(a.str("o").c_str(), ref, descr, title, entries, seq.data(), n, sa.data(), el, &err, std::max(1, std::min(nthreads, 16)));
     if (rc) { diag("Fatal: %s", err.c_str()); return 1; }
+    lap(".sfx written");
     diag("CreateBioseqSuffixFile: completed...");
     return 0;
 }

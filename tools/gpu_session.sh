@@ -13,6 +13,7 @@
 #     inflate   the loaders' DEFLATE decoder on the box's host: one thread, 2 .. 16 threads, zlib (tools/inflate_bench.sh; no GPU work)
 #     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
 #     upload    host -> device upload methods, wall-clock and CPU seconds (tools/upload_bench)
+#     index_e2e `biokanga index` end to end on a 3.1 Gbp FASTA in /dev/shm with the stage clocks (tools/index_e2e.py)
 #     quota     two bench ranks / four command-line contexts on the one GPU, unconstrained and under `taskset -c 0-3`
 set -u
 tag=${1:-x}
@@ -51,6 +52,7 @@ PY
     upload)
       python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
       tools/upload_bench /dev/shm/upload_bench.bin 6 > $O/upload_methods.txt 2>&1; cat $O/upload_methods.txt; rm -f /dev/shm/upload_bench.bin ;;
+    index_e2e) timeout 1200 python3 tools/index_e2e.py 3100 --repeat 2 > $O/index_e2e.txt 2>&1; grep -v "^   .*host: at exit" $O/index_e2e.txt | cut -c1-200 | tail -60 ;;
     quota)
       # two ranks on the one GPU and four contexts of the command line, unconstrained and held to four CPUs (what a rank of an 8-GPU job
       # gets of the box's 16-CPU quota): the host side must not need more
