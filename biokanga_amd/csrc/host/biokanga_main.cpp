@@ -975,7 +975,13 @@ int cmd_align(int argc, char **argv, int first)
     // holds the packed reads, unless an output of this run still reads them (-j / -J, -O, SNP calling); should the device decline
     // after all, the host formatter loads them again (restore_reads)
     bool bases_dropped = false;
-    const bool may_drop_bases = pk_job.pk_words != nullptr && sam_prep != nullptr && !a.has("j") && !a.has("J") && !a.has("O") && o.snp.min_reads <= 0;
+    // (.. and only when every read file can be read a second time - a FIFO or a process substitution cannot: should the device decline
+    // the SAM records, the host formatter reloads the reads)
+    bool inputs_regular = true;
+    for (const char *opt : {"i", "u"})
+        if (a.has(opt))
+            for (const std::string &fn : a.v[opt]) { struct stat ist; inputs_regular = inputs_regular && stat(fn.c_str(), &ist) == 0 && S_ISREG(ist.st_mode); }
+    const bool may_drop_bases = inputs_regular && pk_job.pk_words != nullptr && sam_prep != nullptr && !a.has("j") && !a.has("J") && !a.has("O") && o.snp.min_reads <= 0;
     if (nr)
         S.release_packed_in_background(pk_job.pk_words != nullptr ? sam_prep : nullptr,
                                        may_drop_bases ? std::function<void()>([&rs, &bases_dropped]() { bk::RawVec<uint8_t> none; rs.bases.swap(none); bases_dropped = true; })

@@ -265,7 +265,8 @@ struct OutBuf {
     // set when the name ends in ".gz" (CAligner::FileReqWriteCompr, Aligner.cpp:4337): what is put goes out as gzip members - one per
     // flush from here, or made by the caller's own threads (put_members) - where the reference has gzwrite's single stream; readers
     // see the same text
-    bool gz = false, gz_wrote = false, failed = false;
+    bool gz = false, gz_wrote = false;
+    std::atomic<bool> failed{false};        // a write came up short (several formatting threads may say so)
     bool pipe = false;                      // a FIFO or a pipe (-o >(samtools ..)): no offsets - everything in order through write()
     off_t pos = 0;                          // file offset of the next byte (everything goes through pwrite)
     std::vector<char> b;

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <new>
 #include <cctype>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -498,12 +499,13 @@ static bool inflate_bgzf(const uint8_t *base, size_t size, int nthreads, RawVec<
         if (bsize < 12 + xlen + 8 || bsize > size - o) return false;
         auto le32 = [](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
         Member m{o + 12 + xlen, bsize - 12 - xlen - 8, total, le32(h + bsize - 4), le32(h + bsize - 8)};
+        if (m.isize > 65536) return false;                 // (a BGZF member holds at most 64 KB of text: a file whose trailers claim more is not one - the serial reader takes it)
         mem.push_back(m);
         total += m.isize;
         o += bsize;
     }
     if (total < (1u << 20)) return false;
-    text.resize(total + 64);
+    try { text.resize(total + 64); } catch (const std::bad_alloc &) { return false; }       // (no room: the serial reader takes the file)
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     if (nthreads < 1) nthreads = 1;
@@ -691,7 +693,7 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     }
     for (size_t t = 1; t < pieces; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     out.chunks.resize(pieces);
-    out.bases.resize(size + 64);                          // (sized, not touched: the pieces' own pages are the only ones that become real)
+    try { out.bases.resize(size + 64); } catch (const std::bad_alloc &) { unmap(); return 0; }      // (sized, not touched: the pieces' own pages are the only ones that become real; no room: the serial reader takes the file)
     std::atomic<int> gave_up{0};
     std::vector<std::thread> th;
     for (int w = 0; w < nthreads; w++)

@@ -85,14 +85,16 @@ int accept_chunks(bk::ParsedFile &file, const std::string &fn, int trim5, int tr
     uint64_t n_descr = 0, n_under = 0, n_over = 0, n_acc = 0;
     for (size_t ci = 0; ci < nc; ci++) {
         const bk::ParsedChunk &c = chunks[ci];
-        if (tot[ci].bad_at >= 0) { diag("Problem parsing sequence after %llu reads parsed", (unsigned long long)(n_descr + tot[ci].bad_at + 1)); return -63; }
-        if ((n_under < 10 && tot[ci].n_under) || (n_over < 10 && tot[ci].n_over))
-            for (size_t i = 0; i < c.lens.size(); i++) {
+        // (a chunk with an unusable record: the lines of the records in front of it first, as the serial loader would have printed them)
+        const size_t upto = tot[ci].bad_at >= 0 ? (size_t)tot[ci].bad_at : c.lens.size();
+        if (tot[ci].bad_at >= 0 || (n_under < 10 && tot[ci].n_under) || (n_over < 10 && tot[ci].n_over))
+            for (size_t i = 0; i < upto; i++) {
                 const int len = (int)c.lens[i];
                 if (trim5 + trim3 + min_len > len) { if (++n_under <= 10) diag("Load: under length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str()); }
                 else if (trim5 + trim3 + max_len < len) { if (++n_over <= 10) diag("Load: over length (%d) sequence in '%s' after end trims has been sloughed..", len, fn.c_str()); }
             }
         else { n_under += tot[ci].n_under; n_over += tot[ci].n_over; }
+        if (tot[ci].bad_at >= 0) { diag("Problem parsing sequence after %llu reads parsed", (unsigned long long)(n_descr + tot[ci].bad_at + 1)); return -63; }
         n_descr += tot[ci].n_rec;
         n_acc += tot[ci].n_acc;
     }

@@ -740,7 +740,8 @@ int report_text(Report &R)
                 size_t o = 0;
                 while (o < bf.n) {
                     ssize_t w = ::pwrite(out.fd, bf.d + o, bf.n - o, at[(size_t)t] + (off_t)o);
-                    if (w <= 0) break;
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w <= 0) { out.failed = true; break; }          // (a full disk ends the report with an error, not with a short file)
                     o += (size_t)w;
                 }
             };
@@ -881,6 +882,7 @@ int report_text(Report &R)
         }
         if (ind.fd >= 0) ind.close();
         if (jct.fd >= 0) jct.close();
+        if (ind.failed || jct.failed) out.failed = true;                    // (the microInDel / junction files count like the results file)
     }
     out.close();
     if (out.failed) {                                // (eBSFerrFileAccess: the reference's WriteReadHits gives up on a short write too)

@@ -44,8 +44,8 @@ bool pwrite_all(int fd, const uint8_t *p, uint64_t len, uint64_t at, int nthread
             uint64_t o = i * slice, n = std::min(slice, len - o);
             while (n) {
                 const ssize_t w = ::pwrite(fd, p + o, (size_t)n, (off_t)(at + o));
-                if (w <= 0) {
-                    if (errno == EINTR) continue;
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) {                   // (nothing written without an error counts as one: errno is then whatever an earlier call left)
                     ok = false;
                     break;
                 }
@@ -247,7 +247,10 @@ int sfx_write(const char *path, const std::string &dataset, const std::string &d
              write_all(fd, eb.data(), eb.size());
     if (fsync(fd) != 0) ok = false;
     ::close(fd);
-    if (!ok) return fail(err, -85, std::string("write failed on ") + path);
+    if (!ok) {
+        (void)::unlink(path);                      // (no partly written index under the final name)
+        return fail(err, -85, std::string("write failed on ") + path);
+    }
     return 0;
 }
 
