@@ -53,11 +53,8 @@ struct bk_ctx {
     int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
     bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases
-    int flat_block = 256;    // reads per block of k_flat (64 / 128 / 256)
-    int search_ilp = 2;      // searches per lane of pass A (1: k_search_a; 2 / 4: k_search_a_ilp, the loads of each stage of all of them in flight together; measured on C2: 45.5 / 42.7 / 43.6 ms of search per step)
     uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with
     int use_isa = 1;         // 0: no inverse suffix array - the wave kernel dedupes with its hash set (as it does for 5-byte indexes)
-    int use_flat = 1;        // 1: block-cooperative k_flat, 0: lane-per-read k_light (same results)
     uint32_t *d_isa = nullptr;
     void *d_swin = nullptr;               // suffix-ordered window array (DevIndex::swin), built when the first batch it serves arrives
     uint32_t *d_swmap = nullptr;          // .. and which blocks of the suffix array it holds (DevIndex::swmap; null: all of them)
@@ -68,7 +65,6 @@ struct bk_ctx {
     double swin_setup_s = 0;  // .. and what making them took (allocation included)
     double swin_covered = 0;  // .. share of the suffix array it holds
     bool swin_denied = false; // it did not fit beside a batch's scratch when first asked for
-    int wave_group = 0;      // wave kernel, reads of <= 128 bases: consecutive small core intervals share a round (always so for longer reads)
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <unistd.h>
-#include <hipcub/hipcub.hpp>
+#include "bk_prim.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -71,9 +71,6 @@ void launch_clear_iv(const DevBatch &b, const uint32_t *p_n_act, uint32_t n_act_
 void launch_pe(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, int pe_mode, int min_len, int max_len, int pair_strand,
                bk_hit *hits, uint32_t n_pairs, uint32_t *orphans, uint32_t *counters, uint32_t *h_count, bk_seg2 *seg2, int min_chim,
                int long_reads, const uint8_t *accept, uint32_t n_accept, hipStream_t s);
-void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
-                  uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
-                  uint32_t *cmax_next, int nw, hipStream_t s);
 void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s);
@@ -771,7 +768,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     // register-resident window kernels handle reads of <= 128 / <= 256 / <= 16 * kNwLong / <= 16 * kNwLongest bases
     const bool reg_path = c->use_wave && maxlen <= 16u * (uint32_t)kNwLongest;
     const int nw16 = maxlen <= 128 ? 8 : (maxlen <= 256 ? 16 : (maxlen <= 16u * (uint32_t)kNwLong ? kNwLong : kNwLongest));
-    const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
+    const bool two_bit = reg_path && c->ix.tgt2 != nullptr;
     const uint32_t ivc = iv_cores_for(c, maxlen);
     int rc = ensure_batch_scratch(c, n, wpr, two_bit ? (uint32_t)(nw16 / 2) : 0u, ivc);
     if (rc && c->d_swin) {                        // the window array is a luxury: it goes before a batch is refused for want of memory
@@ -788,7 +785,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
     b.rd2 = two_bit ? c->d_rd2 : nullptr;
     b.rmeta = c->d_rmeta;
     // (the wave list's job sizes come from k_flat only when every read on that list went through it)
-    b.wave_work = (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100) ? c->d_wave_work : nullptr;
+    b.wave_work = (reg_path && c->cfg.heavy_thresh <= 100) ? c->d_wave_work : nullptr;
     b.iv32 = (c->use_iv32 && c->ix.k2) ? c->d_iv32 : nullptr;      // (written by k_search_a_ilp and pass B in phase 0)
     b.nw = reg_path ? (uint32_t)nw16 : 0u;       // the fused prep kernel packs reads of the register-kernel path
     b.out = d_out; b.seq_counts = c->d_seq_counts; b.ctr = c->d_ctr;
@@ -821,7 +818,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         }
     }
     if (max_phases > kMaxPhases) return BK_ERR_INTERNAL;
-    const bool no_readback = reg_path && c->use_flat && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && cores_fit && !c->params.best_matches &&
+    const bool no_readback = reg_path && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && cores_fit && !c->params.best_matches &&
                              !c->debug && c->async_phases;
     const bool check_maxlen = !tm.on;                 // (a call that only enqueues: its caller named the longest read, nobody has looked)
     if (check_maxlen) launch_max_len(d_lens, n, P(kMaxPhases + 1) + 0, s);
@@ -876,7 +873,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                 // interval counts of the slots this phase can use, zeroed (empty search results store nothing)
                 launch_clear_iv(b, ctl_p + 0, n_bound, cmax, c->cfg.align_strand == 2 ? 1 : 0, c->cfg.align_strand == 1 ? 0 : 1, s);
                 hipEvent_t ea = tm.begin(s);
-                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], ctl_p + 0, n_bound, phase, cmax, nstr, lazy | (c->search_ilp << 8), c->d_slist, ctl_p + 2,
+                launch_search_a(c->ix, c->cfg, b, c->d_act[cur], ctl_p + 0, n_bound, phase, cmax, nstr, lazy, c->d_slist, ctl_p + 2,
                                 c->d_slist_stage, c->d_stripe_cnt, s);
                 HIP_TRY(hipGetLastError());
                 tm.end(4, ea, s);
@@ -923,12 +920,9 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         DevAlignCfg cfg_lane = c->cfg;
         if (c->ix.n > (1ULL << 32)) cfg_lane.heavy_thresh = 0;            // (below that the truncated keys are the exact ones)
         if (n_bound == 0) {}
-        else if (reg_path && c->use_flat && c->cfg.heavy_thresh <= 100)
+        else if (reg_path && c->cfg.heavy_thresh <= 100)
             launch_flat(c->ix, c->cfg, b, ext_list, ctl_p + 0, n_bound, phase, nstr * std::max(cmax, 1), c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4,
-                        c->d_wave, ctl_p + 3, ctl_n + 1, c->d_stage, c->d_stripe_cnt, nw16 | (c->flat_block << 8), s);
-        else if (reg_path)
-            launch_light(c->ix, cfg_lane, b, ext_list, n_act, phase, c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4, c->d_wave, ctl_p + 3,
-                         ctl_n + 1, nw16, s);
+                        c->d_wave, ctl_p + 3, ctl_n + 1, c->d_stage, c->d_stripe_cnt, nw16, s);
         else
             launch_extend(c->ix, cfg_lane, b, ext_list, n_act, phase, c->d_act[cur ^ 1], ctl_n + 0, c->d_heavy, ctl_p + 4, ctl_n + 1, s);
         HIP_TRY(hipGetLastError());
@@ -959,7 +953,7 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
                 n_sort = 0;
             if (!no_readback && c->ix.isa == nullptr) { int rh = size_heavy_scratch(c); if (rh) return rh; }      // hash-set dedupe
             launch_wave(c->ix, c->cfg, b, c->hs, c->d_wave, wsorted, n_sort, ctl_p + 3, n_wave, phase, ctl_p + 5, c->d_act[cur ^ 1], ctl_n + 0, ctl_n + 1,
-                        nw16 | (c->wave_group ? 0x100 : 0), c->wave_waves, s);
+                        nw16, c->wave_waves, s);
             HIP_TRY(hipGetLastError());
             tm.end(2, e3, s);
         }
@@ -1153,7 +1147,7 @@ int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, int words, 
     SW_TRY(dev_malloc(&sb.d_map, n_blocks * 4));
     SW_TRY(dev_malloc(&sb.d_used, 4));
     SW_TRY(hipMemsetAsync(sb.d_used, 0, 4, s));
-    SW_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sb.tmp_bytes, sb.d_flags, sb.d_incl, (size_t)blocks, s));
+    SW_TRY(bk::prim::inclusive_sum(nullptr, sb.tmp_bytes, sb.d_flags, sb.d_incl, (size_t)blocks, s));
     SW_TRY(dev_malloc(&sb.d_tmp, sb.tmp_bytes + 256));
     if (sliced) {
         if (sb.ent_state == 0) SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)sb.cap_blocks * block_bytes));      // (else: alloc_ahead's thread brings it)
@@ -1177,7 +1171,7 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
         for (int l = 0; l < sb.n_levels; l++) launch_swin_cover(sb.d_brk[l], len, sb.max_run, sb.d_flags, n_blocks, l == 0, s);
         SW_TRY(hipGetLastError());
         size_t tb = sb.tmp_bytes;
-        SW_TRY(hipcub::DeviceScan::InclusiveSum(sb.d_tmp, tb, sb.d_flags, sb.d_incl, (size_t)n_blocks, s));
+        SW_TRY(bk::prim::inclusive_sum(sb.d_tmp, tb, sb.d_flags, sb.d_incl, (size_t)n_blocks, s));
         launch_swin_map(sb.d_flags, sb.d_incl, n_blocks, sb.cap_blocks, sb.d_used, sb.d_map + (a >> kSwBlkShift), s);
         if (sb.d_ent == nullptr && sb.ent_state == 2) sb.d_ent = sb.ent_mem;
         if (sb.d_ent == nullptr && sb.ent_state == 1) { sb.done = e; continue; }       // (its memory is not there yet: the entries follow)
@@ -1246,7 +1240,7 @@ uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve, int
 
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
-    if (!c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->ix.k2 || !c->use_wave || !c->use_flat) return BK_OK;
+    if (!c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->ix.k2 || !c->use_wave) return BK_OK;
     const bool full = c->use_swin == 3;
     int w[kSwLevels];
     const int n_levels = swin_core_lens(c, maxlen, w);
@@ -1340,7 +1334,7 @@ int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, 
         const bool fits = ml >= 1 && ml <= 16u * (uint32_t)kNwLongest && nreads <= c->cap_reads && nreads <= c->chunk_reads && words_per_read(ml) <= c->cap_wpr &&
                           iv_cores_for(c, ml) <= c->cap_iv_cores && rd2w_for(ml) <= c->cap_rd2w &&
                           (uint64_t)nreads * iv_cores_for(c, ml) * (c->cfg.align_strand == 0 ? 2u : 1u) <= c->cap_slist && (c->ix.isa != nullptr || c->hs.htab != nullptr);
-        const bool main_path = c->use_wave && c->use_flat && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && c->ix.tgt2 != nullptr && !c->debug && c->async_phases;
+        const bool main_path = c->use_wave && c->cfg.heavy_thresh <= 100 && c->ix.k2 != nullptr && c->ix.tgt2 != nullptr && !c->debug && c->async_phases;
         if (!plain || !fits || !main_path) return BK_ERR_PARAMS;
     }
     EvTimer tm{c};
@@ -1435,7 +1429,7 @@ int bk::engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nrea
     launch_widen_lens(d_lens16, nreads, d_lens32, (unsigned long long *)d_offs, s);
     HIP_TRY(hipGetLastError());
     size_t need = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
+    HIP_TRY(bk::prim::exclusive_sum(nullptr, need, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
     if (need > c->scan_tmp_bytes) {
         HIP_TRY(hipStreamSynchronize(s));
         free_dev(c->d_scan_tmp);
@@ -1445,7 +1439,7 @@ int bk::engine_prepare_packed(bk_ctx *c, const uint16_t *d_lens16, uint32_t nrea
         c->scan_tmp_bytes = need + 256;
     }
     size_t tb = c->scan_tmp_bytes;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, tb, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
+    HIP_TRY(bk::prim::exclusive_sum(c->d_scan_tmp, tb, (unsigned long long *)d_offs, (unsigned long long *)d_offs, (size_t)nreads, s));
     // [0] max over reads of (first word + words) = the batch's word count, [1] longest read; exceptions in range and ascending
     HIP_TRY(hipMemsetAsync(c->d_ctr_aux, 0, 32, s));
     launch_packed_extent(d_offs, d_lens32, nreads, c->d_ctr_aux, s);
@@ -1640,7 +1634,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         // first batch of another shortest core length makes it again, which costs little): what it reads besides suffix array and keys -
         // entry table, alignment parameters, 2-bit target - is made now instead of after the upload.
         bool swin_sliced = false;
-        if (!rc && eager_swin && swin_ahead && tp.ktab && tp.k2 && tp.isa && !c->ktab64 && c->use_wave && c->use_flat && c->use_tgt2) {
+        if (!rc && eager_swin && swin_ahead && tp.ktab && tp.k2 && tp.isa && !c->ktab64 && c->use_wave && c->use_tgt2) {
             rc = setup_entries(c, ents.data(), (uint32_t)ents.size());
             if (!rc) { c->entries_set = true; rc = build_tgt2(c); }
             if (!rc) {
@@ -1808,7 +1802,7 @@ int bk_ctx_reserve(bk_ctx *c, uint32_t max_batch_reads, uint32_t max_read_len)
     const uint32_t n = std::min(max_batch_reads, c->chunk_reads);
     const uint32_t wpr = words_per_read(max_read_len);
     const bool reg_path = c->use_wave && max_read_len <= 16u * (uint32_t)kNwLongest;
-    const bool two_bit = reg_path && c->use_flat && c->ix.tgt2 != nullptr;
+    const bool two_bit = reg_path && c->ix.tgt2 != nullptr;
     const uint32_t ivc = iv_cores_for(c, max_read_len);
     int rc = ensure_batch_scratch(c, n, wpr, two_bit ? rd2w_for(max_read_len) : 0u, ivc);
     if (rc) return rc;
@@ -1887,18 +1881,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_tables(c);
         return rc ? rc : old;
     }
-    if (n == "flat_block") {
-        int64_t old = c->flat_block;
-        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return BK_ERR_PARAMS;
-        c->flat_block = (int)value;
-        return old;
-    }
-    if (n == "search_ilp") {
-        int64_t old = c->search_ilp;
-        if (value != 1 && value != 2 && value != 4) return BK_ERR_PARAMS;
-        c->search_ilp = (int)value;
-        return old;
-    }
     if (n == "sort_lists") {
         int64_t old = c->sort_lists;
         c->sort_lists = (int)value & 7;
@@ -1914,11 +1896,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int64_t old = c->wave_waves;
         if (value < 64 || value > 65536) return BK_ERR_PARAMS;
         c->wave_waves = (uint32_t)value;
-        return old;
-    }
-    if (n == "wave_group") {
-        int64_t old = c->wave_group;
-        c->wave_group = value ? 1 : 0;
         return old;
     }
     if (n == "async_phases") {             // 0: the phase loop reads its counts back between launches (exact launch sizes), as every other configuration does
@@ -1958,11 +1935,6 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->use_isa = value ? 1 : 0;
         int rc = build_tables(c);
         return rc ? rc : old;
-    }
-    if (n == "use_flat") {
-        int64_t old = c->use_flat;
-        c->use_flat = value ? 1 : 0;
-        return old;
     }
     if (n == "use_k2") {
         int64_t old = c->use_k2;

@@ -105,146 +105,8 @@ __global__ void __launch_bounds__(256) k_extend(DevIndex ix, DevAlignCfg cfg, De
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_light: one lane per read, reads of <= 16*NW bases whose core intervals are all <= heavy_thresh
-// long.  Same contract as k_extend (which stays for longer reads); differences: the window is
-// evaluated once in registers, bounds come from the EOS test instead of the entry table, and calls
-// it cannot take go to the wave kernel (`wave`) or to the general kernel (`heavy`).
-
-template <bool WIDE, int NW>
-__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, DevAlignCfg cfg, DevBatch b, const uint32_t *__restrict__ act,
-                                               uint32_t n_act, int phase, uint32_t *__restrict__ next_act,
-                                               uint32_t *__restrict__ next_cnt, uint32_t *__restrict__ heavy,
-                                               uint32_t *__restrict__ heavy_cnt, uint32_t *__restrict__ wave,
-                                               uint32_t *__restrict__ wave_cnt, uint32_t *__restrict__ cmax_next)
-{
-    // list appends, the next phase's core maximum and the counters are combined per block in LDS:
-    // one global atomic per block and list instead of one per wave (same-address returning atomics
-    // retire at only ~170 M/s on this part)
-    __shared__ uint32_t s_cnt[4], s_base[4], s_cmax;
-    __shared__ unsigned long long s_ctr[3];
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 4) s_cmax = 0;
-    if (threadIdx.x >= 8 && threadIdx.x < 11) s_ctr[threadIdx.x - 8] = 0;
-    __syncthreads();
-    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long n_search = 0, n_cand = 0, n_lcm = 0;
-    int dest = 0;                   // 1 = next phase, 2 = wave kernel, 3 = general kernel
-    uint32_t r = 0, my_cmax = 0;
-    if (a < n_act) {
-        r = act[a];
-        int len = (int)b.lens[r];
-        ReadPlan p = make_plan(len, cfg);
-        int mm, cl, cd, ofs[kMaxCoresFast];
-        phase_params(p, cfg, phase, mm, cl, cd);
-        int nc = core_offsets(len, cl, cd, p.max_slides, ofs, kMaxCoresFast);
-        int s0 = cfg.align_strand == 2 ? 1 : 0, s1 = cfg.align_strand == 1 ? 0 : 1;
-        bool fits = nc <= kMaxCoresFast && len <= 16 * NW;
-        bool is_heavy = !fits;
-        if (fits)
-            for (int st = s0; st <= s1; st++)
-                for (int c = 0; c < nc; c++)
-                    if ((iv_count(b, iv_slot(b, a, st, c)) & ~kLazyFlag) > (uint32_t)cfg.heavy_thresh) is_heavy = true;
-        if (is_heavy) {
-            dest = (fits && wave != nullptr) ? 2 : 3;
-        } else {
-            n_lcm = 1;
-            const int init = mm + cfg.mm_delta + 1;
-            int low_inst = 0, low_mm = init, nxt = init;
-            uint64_t hit_left = 0;
-            int hit_strand = '?';
-            bool done = false;
-            for (int st = s0; st <= s1 && !done; st++) {
-                uint64_t rw[NW];
-                load_read_words<NW>(b.rd4 + ((uint64_t)r * 2 + st) * b.wpr, len, rw);
-                for (int c = 0; c < nc && !done; c++) {
-                    n_search++;
-                    uint64_t slot = iv_slot(b, a, st, c);
-                    uint32_t nraw;
-                    uint64_t first;
-                    iv_get(b, slot, first, nraw);
-                    const uint32_t n = nraw & ~kLazyFlag;
-                    const bool lazy = (nraw & kLazyFlag) != 0;
-                    for (uint32_t j = 0; j < n; j++) {
-                        uint64_t loci = sa_get<WIDE>(ix, first + j);
-                        if (loci < (uint64_t)ofs[c]) continue;
-                        uint64_t t = loci - (uint64_t)ofs[c];
-                        Window<NW> w;
-                        eval_window<NW>(rw, len, ix.tgt4, t, w);
-                        if (lazy && !core_clean<NW>(w, ofs[c], cl)) continue;    // bucket member that is not a match of this core
-                        if (w.eos) continue;                                    // crosses an entry boundary
-                        bool dup = false;                                       // reached through an earlier core already?
-                        for (int c2 = 0; c2 < c; c2++) dup |= core_clean<NW>(w, ofs[c2], cl);
-                        if (dup) continue;
-                        n_cand++;
-                        int cm = w.mm;
-                        if (cm > mm || cm >= nxt) continue;
-                        if (cm < low_mm) {
-                            low_inst = 1; nxt = low_mm; low_mm = cm;
-                            hit_left = t; hit_strand = st ? '-' : '+';
-                        } else if (cm == low_mm)
-                            low_inst++;
-                        else
-                            nxt = cm;
-                        if (low_inst > cfg.max_hits && low_mm == 0) { done = true; break; }
-                    }
-                }
-            }
-            int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);
-            if (rslt != BK_HR_NONE) {
-                int e = low_inst >= 1 ? find_entry(ix, hit_left) : -1;
-                write_result(ix, cfg, b, r, len, rslt, low_inst, low_mm, nxt, hit_left, e, hit_strand, phase << 1);
-            } else if (phase + 1 < p.n_phases) {
-                int mm2, cl2, cd2, dummy[1];
-                phase_params(p, cfg, phase + 1, mm2, cl2, cd2);
-                int nc2 = core_offsets(len, cl2, cd2, p.max_slides, dummy, 0);
-                if (nc2 <= kMaxCoresFast) my_cmax = (uint32_t)nc2;
-                dest = 1;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    const uint64_t lt_mask = (1ULL << lane) - 1;
-    for (int off = 32; off > 0; off >>= 1) {
-        n_search += __shfl_down(n_search, off);
-        n_cand += __shfl_down(n_cand, off);
-        n_lcm += __shfl_down(n_lcm, off);
-        uint32_t m = __shfl_down(my_cmax, off);
-        my_cmax = m > my_cmax ? m : my_cmax;
-    }
-    uint32_t my_off = 0;
-#pragma unroll
-    for (int d = 1; d <= 3; d++) {
-        uint64_t m = __ballot(dest == d);
-        if (m) {
-            uint32_t w = 0;
-            if (lane == 0) w = atomicAdd(&s_cnt[d], (uint32_t)__popcll(m));
-            w = __builtin_amdgcn_readfirstlane(w);
-            if (dest == d) my_off = w + (uint32_t)__popcll(m & lt_mask);
-        }
-    }
-    if (lane == 0) {
-        if (my_cmax) atomicMax(&s_cmax, my_cmax);
-        if (n_search) atomicAdd(&s_ctr[0], n_search);
-        if (n_cand) atomicAdd(&s_ctr[1], n_cand);
-        if (n_lcm) atomicAdd(&s_ctr[2], n_lcm);
-    }
-    __syncthreads();
-    {
-        const uint32_t t = threadIdx.x;
-        if (t == 1 && s_cnt[1]) s_base[1] = atomicAdd(next_cnt, s_cnt[1]);
-        if (t == 2 && s_cnt[2]) s_base[2] = atomicAdd(wave_cnt, s_cnt[2]);
-        if (t == 3 && s_cnt[3]) s_base[3] = atomicAdd(heavy_cnt, s_cnt[3]);
-        if (t == 4 && s_cmax) atomicMax(cmax_next, s_cmax);
-        if (t >= 8 && t < 11 && s_ctr[t - 8]) atomicAdd(&b.ctr[ctr_stripe() + t - 8], s_ctr[t - 8]);
-    }
-    __syncthreads();
-    if (dest == 1) next_act[s_base[1] + my_off] = r;
-    else if (dest == 2) wave[s_base[2] + my_off] = a;          // (the wave kernel finds the read's interval records by its position)
-    else if (dest == 3) heavy[s_base[3] + my_off] = r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_flat: the same contract as k_light, organised so that every lane does the same amount of work.
+// k_flat: reads of <= 16*NW bases whose core intervals are all <= heavy_thresh long - the same contract as k_extend (which stays for
+// longer reads), organised so that every lane does the same amount of work; calls it cannot take go to the wave kernel or to the general one.
 // A block owns 256 consecutive active reads.  Their candidates (every suffix of every core interval,
 // in the reference's walk order strand -> core -> suffix) are numbered consecutively and EVALUATED
 // one per lane - suffix array load, window compare, one result byte in LDS (mismatch count, or
@@ -254,8 +116,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_light(DevIndex ix, Dev
 // whose reads are replayed in order by their own lane; on 5-byte indexes the reference's truncated-key
 // rule - a candidate is taken for seen when an earlier one of the strand pass has the same low word - is
 // applied first, as a pass over the candidates' lanes).
-// In k_light a lane walked all candidates of its read itself, so a wave ran as long as its read with
-// the most candidates (up to 4 x 64) while the typical read has one or two.
+// (A lane per read that walks all candidates of its read itself makes a wave run as long as its read with the most candidates - up to
+// 4 x 64 - while the typical read has one or two: that form, k_light, left the tree in round 5.)
 // Valid while no interval is longer than 100: then the reference's IterCnt==100 copy-count check and
 // MaxIter cannot trigger, every interval is walked to its end, and "already reached through an
 // earlier core" is exactly "that earlier core matches here" (see k_wave for the general case).
@@ -795,30 +657,15 @@ void launch_extend(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b
     else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, cmax_next);
 }
 
-void launch_light(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, uint32_t n_act, int phase,
-                  uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave, uint32_t *wave_cnt,
-                  uint32_t *cmax_next, int nw, hipStream_t s)
-{
-    unsigned blocks = (n_act + 255) / 256;
-    bool wide = ix.sa_hi != nullptr;
-#define BK_LIGHT(W, N) hipLaunchKernelGGL((k_light<W, N>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, n_act, phase, next_act, next_cnt, heavy, heavy_cnt, wave, wave_cnt, cmax_next)
-    if (nw <= 8) { if (wide) BK_LIGHT(true, 8); else BK_LIGHT(false, 8); }
-    else if (nw <= 16) { if (wide) BK_LIGHT(true, 16); else BK_LIGHT(false, 16); }
-    else if (nw <= kNwLong) { if (wide) BK_LIGHT(true, kNwLong); else BK_LIGHT(false, kNwLong); }
-    else { if (wide) BK_LIGHT(true, kNwLongest); else BK_LIGHT(false, kNwLongest); }
-#undef BK_LIGHT
-}
-
 // stage: three buffers of at least n_act + (kListStripes + 2) * 1024 entries, stripe_cnt: kListStripes * 16 words, zero between launches
 // n_act_bound: no more reads than this are on the active list (its length is *p_n_act, in device memory)
 void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound, int phase,
                  int slots_max, uint32_t *next_act, uint32_t *next_cnt, uint32_t *heavy, uint32_t *heavy_cnt, uint32_t *wave,
                  uint32_t *wave_cnt, uint32_t *cmax_next, uint32_t *const *stage, uint32_t *stripe_cnt, int nw, hipStream_t s)
 {
-    int bs = (nw >> 8) ? (nw >> 8) : 256;              // bits 8..: reads (= threads) per block, 64 .. 1024
+    constexpr int bs = 256;                            // reads (= threads) per block: 64 .. 1024 measured, 256 best (profiles/NOTES.md, round 2)
     nw &= 0xff;
     bool wide = ix.sa_hi != nullptr;
-    if (wide && bs > 256) bs = 256;                    // (the low words of the 5-byte form need 4 more bytes of LDS per candidate)
     if (!n_act_bound) return;
     unsigned blocks = (n_act_bound + (unsigned)bs - 1) / (unsigned)bs;
     if (slots_max < 1) slots_max = 1;
@@ -828,15 +675,11 @@ void launch_flat(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     for (int i = 0; i < 3; i++) out.stage[i] = stage[i];
     out.cap = stripe_cap(blocks, (unsigned)bs);
     const int have_wave = wave != nullptr;
-#define BK_FLAT(W, N, B) hipLaunchKernelGGL((k_flat<W, N, B>), dim3(blocks), dim3(B), lds, s, ix, cfg, b, act, p_n_act, phase, slots_max, out, have_wave)
-#define BK_FLAT_W(N) do { if (bs == 64) BK_FLAT(true, N, 64); else if (bs == 128) BK_FLAT(true, N, 128); else BK_FLAT(true, N, 256); } while (0)
-#define BK_FLAT_B(N) do { if (bs == 64) BK_FLAT(false, N, 64); else if (bs == 128) BK_FLAT(false, N, 128); else if (bs == 512) BK_FLAT(false, N, 512); else if (bs == 1024) BK_FLAT(false, N, 1024); else BK_FLAT(false, N, 256); } while (0)
-    if (nw <= 8) { if (wide) BK_FLAT_W(8); else BK_FLAT_B(8); }
-    else if (nw <= 16) { if (wide) BK_FLAT_W(16); else BK_FLAT_B(16); }
-    else if (nw <= kNwLong) { if (wide) BK_FLAT_W(kNwLong); else BK_FLAT_B(kNwLong); }
-    else { if (wide) BK_FLAT_W(kNwLongest); else BK_FLAT_B(kNwLongest); }
-#undef BK_FLAT_W
-#undef BK_FLAT_B
+#define BK_FLAT(W, N) hipLaunchKernelGGL((k_flat<W, N, 256>), dim3(blocks), dim3(256), lds, s, ix, cfg, b, act, p_n_act, phase, slots_max, out, have_wave)
+    if (nw <= 8) { if (wide) BK_FLAT(true, 8); else BK_FLAT(false, 8); }
+    else if (nw <= 16) { if (wide) BK_FLAT(true, 16); else BK_FLAT(false, 16); }
+    else if (nw <= kNwLong) { if (wide) BK_FLAT(true, kNwLong); else BK_FLAT(false, kNwLong); }
+    else { if (wide) BK_FLAT(true, kNwLongest); else BK_FLAT(false, kNwLongest); }
 #undef BK_FLAT
     // list order of the set: next phase, wave kernel, general kernel (the wave list may be absent: then it stays empty)
     uint32_t *dense[3] = {next_act, have_wave ? wave : heavy, heavy}, *total[3] = {next_cnt, have_wave ? wave_cnt : heavy_cnt, heavy_cnt};

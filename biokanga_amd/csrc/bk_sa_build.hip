@@ -12,10 +12,10 @@
 //
 // Method: prefix doubling.  Round 0 sorts suffixes by their first 16 bases (one 64-bit nibble
 // word); round r sorts by (rank[i], rank[i+h]), h = 16*2^(r-1), with rocPRIM's LSD radix sort
-// (hipcub::DeviceRadixSort) - bandwidth-bound streaming passes over HBM.  Stops when all ranks are
+// (rocPRIM radix sort) - bandwidth-bound streaming passes over HBM.  Stops when all ranks are
 // distinct or h >= 2^20.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "bk_prim.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -268,11 +268,11 @@ int build_sa_device_wide(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int e
         hipError_t e = hipSuccess;
         for (int k = 0; k < 2 && e == hipSuccess; k++) { e = hipMalloc(&key[k], m * 8); if (e == hipSuccess) e = hipMalloc(&val[k], m * 8); }
         size_t t1 = 0, t2 = 0, t3 = 0;
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, t1, key[0], key[1], val[0], val[1], (size_t)m, 0, 64, s);
-        if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveScan(nullptr, t2, key[0], key[0], hipcub::Max(), (size_t)m, s);
+        if (e == hipSuccess) e = bk::prim::sort_pairs(nullptr, t1, key[0], key[1], val[0], val[1], (size_t)m, 0, 64, s);
+        if (e == hipSuccess) e = bk::prim::inclusive_max(nullptr, t2, key[0], key[0], (size_t)m, s);
         if (e == hipSuccess) {
-            hipcub::CountingInputIterator<unsigned long long> it(0ULL);
-            e = hipcub::DeviceSelect::If(nullptr, t3, it, val[0], d_small, (int64_t)(1LL << 30), InBuckets{d_seq, n, 0, 0}, s);
+            rocprim::counting_iterator<unsigned long long> it(0ULL);
+            e = bk::prim::select_if(nullptr, t3, it, val[0], d_small, (size_t)(1ULL << 30), InBuckets{d_seq, n, 0, 0}, s);
         }
         tmp_bytes = std::max(t1, std::max(t2, t3));
         if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes);
@@ -282,11 +282,11 @@ int build_sa_device_wide(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int e
     // sorts the m (key[0], val[0]) pairs of a stretch that starts at suffix array index j0, writes SA and ranks back
     auto sort_and_store = [&](uint64_t j0, uint64_t m, int end_bit) -> hipError_t {
         size_t tb = tmp_bytes;
-        hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, key[0], key[1], val[0], val[1], (size_t)m, 0, end_bit, s);
+        hipError_t e = bk::prim::sort_pairs(tmp, tb, key[0], key[1], val[0], val[1], (size_t)m, 0, end_bit, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_w_heads, dim3(grid_for(m)), dim3(256), 0, s, key[1], m, key[0]);
         tb = tmp_bytes;
-        e = hipcub::DeviceScan::InclusiveScan(tmp, tb, key[0], val[0], hipcub::Max(), (size_t)m, s);
+        e = bk::prim::inclusive_max(tmp, tb, key[0], val[0], (size_t)m, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_w_store, dim3(grid_for(m)), dim3(256), 0, s, val[1], val[0], m, j0, sa_lo, sa_hi, rk_lo, rk_hi, d_small + 1);
         return hipGetLastError();
@@ -320,9 +320,9 @@ int build_sa_device_wide(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int e
                 uint64_t got = 0;
                 for (uint64_t at = 0; at < n; at += 1ULL << 30) {
                     const uint64_t cnt = std::min<uint64_t>(1ULL << 30, n - at);
-                    hipcub::CountingInputIterator<unsigned long long> it((unsigned long long)at);
+                    rocprim::counting_iterator<unsigned long long> it((unsigned long long)at);
                     size_t tb = tmp_bytes;
-                    SA_TRY(hipcub::DeviceSelect::If(tmp, tb, it, val[0] + got, d_small, (int64_t)cnt, InBuckets{d_seq, n, b0, b1}, s));
+                    SA_TRY(bk::prim::select_if(tmp, tb, it, val[0] + got, d_small, (size_t)cnt, InBuckets{d_seq, n, b0, b1}, s));
                     SA_TRY(hipMemcpyAsync(h_small, d_small, 8, hipMemcpyDeviceToHost, s));
                     SA_TRY(hipStreamSynchronize(s));
                     got += h_small[0];
@@ -415,8 +415,8 @@ int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_siz
     SA_TRY(hipMalloc(&rank, n * 4));
     SA_TRY(hipMalloc(&d_groups, 8));
     head = (uint32_t *)key[0];      // key[in] is dead once sorted: its storage is reused for heads/groups
-    SA_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key[0], key[1], val[0], val[1], (size_t)n, 0, 64, s));
-    SA_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, head, head, hipcub::Max(), (size_t)n, s));
+    SA_TRY(bk::prim::sort_pairs(nullptr, tmp_sort, key[0], key[1], val[0], val[1], (size_t)n, 0, 64, s));
+    SA_TRY(bk::prim::inclusive_max(nullptr, tmp_scan, head, head, (size_t)n, s));
     tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     SA_TRY(hipMalloc(&tmp, tmp_bytes));
 
@@ -424,7 +424,7 @@ int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_siz
     for (uint64_t h = 16;; h <<= 1) {
         // sort (key[0], val[cur]) -> (key[1], val[cur^1])
         size_t tb = tmp_bytes;
-        SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key[0], key[1], val[cur], val[cur ^ 1], (size_t)n, 0, 64, s));
+        SA_TRY(bk::prim::sort_pairs(tmp, tb, key[0], key[1], val[cur], val[cur ^ 1], (size_t)n, 0, 64, s));
         cur ^= 1;
         SA_TRY(hipMemsetAsync(d_groups, 0, 8, s));
         head = (uint32_t *)key[0];
@@ -434,7 +434,7 @@ int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_siz
         SA_TRY(hipStreamSynchronize(s));
         if (h_groups == n || h >= (1ULL << 20)) break;
         tb = tmp_bytes;
-        SA_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, grp, hipcub::Max(), (size_t)n, s));
+        SA_TRY(bk::prim::inclusive_max(tmp, tb, head, grp, (size_t)n, s));
         hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, s, grp, val[cur], n, rank);
         hipLaunchKernelGGL(k_sa_make_keys, dim3(g), dim3(256), 0, s, rank, val[cur], n, h, key[0]);
         SA_TRY(hipGetLastError());
@@ -458,7 +458,7 @@ int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t
                      void *tmp, size_t *tmp_bytes, hipStream_t s)
 {
     size_t tb = *tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 32, s);
+    hipError_t e = bk::prim::sort_pairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 32, s);
     if (tmp == nullptr) *tmp_bytes = tb;
     return e == hipSuccess ? 0 : -100;
 }
@@ -467,7 +467,7 @@ int sort_list_by_key(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t
 int scan_counts_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, void *tmp, size_t *tmp_bytes, hipStream_t s)
 {
     size_t tb = *tmp_bytes;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, in, out, (size_t)n, s);
+    hipError_t e = bk::prim::exclusive_sum(tmp, tb, in, out, (size_t)n, s);
     if (tmp == nullptr) *tmp_bytes = tb;
     return e == hipSuccess ? 0 : -100;
 }

@@ -5,7 +5,7 @@
 // writes it.  The host keeps what is serial by nature - the reference's output order (its quicksort replica) and the file itself.
 // The text leaves the device in slices through a pair of pinned buffers; the caller's sink receives them in file order.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "bk_prim.h"
 
 #include <algorithm>
 #include <memory>
@@ -386,9 +386,9 @@ static int sam_upload_reads(bk_ctx *c, const bk_sam_job *job, SamReads &rd)
     hipLaunchKernelGGL(k_sam_unpack_lens, dim3(4096), dim3(256), 0, s, d_l16.as<uint16_t>(), nr, rd.d_lens.as<uint32_t>(), d_nw.as<unsigned long long>());
     if (job->n_pk_exc) hipLaunchKernelGGL(k_sam_first_exc, dim3(1024), dim3(256), 0, s, rd.d_exc.as<bk_nbase>(), job->n_pk_exc, rd.d_efirst.as<uint32_t>());
     size_t tb = 0;
-    e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
+    e = bk::prim::exclusive_sum(nullptr, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
     if (e == hipSuccess) e = d_tmp.alloc(tb + 256);
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
+    if (e == hipSuccess) e = bk::prim::exclusive_sum(d_tmp.p, tb, d_nw.as<unsigned long long>(), rd.d_wofs.as<unsigned long long>(), (size_t)nr + 1, s);
     unsigned long long total = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&total, rd.d_wofs.as<unsigned long long>() + nr, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -472,7 +472,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     SAM_TRY(d_at.alloc(((size_t)slice + 1) * 8));
     SAM_TRY(d_cnt.alloc(16));
     size_t tb = 0;
-    SAM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)slice + 1, s));
+    SAM_TRY(bk::prim::exclusive_sum(nullptr, tb, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)slice + 1, s));
     SAM_TRY(d_tmp.alloc(tb + 256));
     if (bk::upload_host(d_hits.p, job->hits, nr * sizeof(bk_hit), c->device) || bk::upload_host(d_order.p, job->order, job->n_order * 4, c->device))
         return BK_ERR_INTERNAL;
@@ -568,7 +568,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
         if (e == hipSuccess) e = hipMemsetAsync((char *)d_bytes.p + (size_t)n * 8, 0, 8, s);
         hipLaunchKernelGGL(k_sam_measure, dim3((n + 255) / 256), dim3(256), 0, s, d, k0, n, d_bytes.as<unsigned long long>(), d_cnt.as<uint32_t>());
         size_t t2 = tb + 256;
-        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, t2, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)n + 1, s);
+        if (e == hipSuccess) e = bk::prim::exclusive_sum(d_tmp.p, t2, d_bytes.as<unsigned long long>(), d_at.as<unsigned long long>(), (size_t)n + 1, s);
         unsigned long long bytes = 0;
         uint32_t rep = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(&bytes, d_at.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, s);

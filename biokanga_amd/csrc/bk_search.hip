@@ -391,10 +391,8 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
 {
     uint64_t threads = (uint64_t)n_act_bound * (uint64_t)(cmax * nstr);
     if (!threads) return;
-    int ilp = lazy >> 8;                               // bits 8..: searches per lane (0 / 1 = the plain kernel)
     lazy &= 0xff;
-    if (ilp < 2) ilp = 1;
-    else if (ilp != 2) ilp = 4;
+    constexpr int ilp = 2;                             // searches per lane: 1, 2, 4 measured (45.5 / 42.7 / 43.6 ms of search per C2 step, round 2)
     const uint64_t per = (uint64_t)256 * (uint64_t)ilp;
     const uint64_t tiles = (threads + per - 1) / per;
     const unsigned blocks = (unsigned)std::min<uint64_t>(tiles, 16384);       // (a block takes tiles until the list is done)
@@ -402,9 +400,7 @@ void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch 
     out.cnt = stripe_cnt;
     out.stage[0] = out.stage[1] = out.stage[2] = stage;
     out.cap = stripe_cap((unsigned)tiles, (unsigned)per);             // (stripes go by tile number)
-    if (ilp == 2) hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
-    else if (ilp == 4) hipLaunchKernelGGL(k_search_a_ilp<4>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
-    else hipLaunchKernelGGL(k_search_a_ilp<1>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
+    hipLaunchKernelGGL(k_search_a_ilp<2>, dim3(blocks), dim3(256), 0, s, ix, cfg, b, act, p_n_act, phase, cmax, nstr, lazy, out);
     launch_compact(out, &list, &list_cnt, 1, nullptr, s);
 }
 

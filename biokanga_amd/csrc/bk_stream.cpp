@@ -13,7 +13,7 @@
 // result records are multi-buffered.  Host buffers obtained from bk_host_alloc() (pinned) are DMA'd directly;
 // pageable ones go through the HIP runtime's staging copies (slower, still overlapped with the kernels).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "bk_prim.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -245,8 +245,8 @@ struct bk_stream {
                 hipError_t e = hipStreamWaitEvent(s_al, sl.ev_up, 0);
                 if (e == hipSuccess && !j->offs) {          // contiguous reads: offsets = exclusive prefix sum of the lengths
                     size_t tb = scan_tmp_bytes;
-                    hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t *> in(sl.d_lens, CastU64());
-                    e = hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, in, (unsigned long long *)sl.d_offs, (size_t)j->n, s_al);
+                    rocprim::transform_iterator<const uint32_t *, CastU64, unsigned long long> in(sl.d_lens, CastU64());
+                    e = bk::prim::exclusive_sum(d_scan_tmp, tb, in, (unsigned long long *)sl.d_offs, (size_t)j->n, s_al);
                 }
                 if (e == hipSuccess) e = hipMemsetAsync(d_ext, 0, 16, s_al);
                 if (e == hipSuccess) {
@@ -451,8 +451,8 @@ static int stream_create(bk_stream **out, bk_ctx *ctx, uint32_t max_batch_reads,
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_al, hipEventDisableTiming);
     }
     if (e == hipSuccess) {
-        hipcub::TransformInputIterator<unsigned long long, CastU64, const uint32_t *> in(nullptr, CastU64());
-        e = hipcub::DeviceScan::ExclusiveSum(nullptr, s->scan_tmp_bytes, in, (unsigned long long *)nullptr, (size_t)max_batch_reads, s->s_al);
+        rocprim::transform_iterator<const uint32_t *, CastU64, unsigned long long> in(nullptr, CastU64());
+        e = bk::prim::exclusive_sum(nullptr, s->scan_tmp_bytes, in, (unsigned long long *)nullptr, (size_t)max_batch_reads, s->s_al);
     }
     if (e == hipSuccess) e = bk::dev_malloc(&s->d_scan_tmp, s->scan_tmp_bytes ? s->scan_tmp_bytes : 16);
     if (e == hipSuccess) e = bk::dev_malloc(&s->d_ext, 16);

@@ -585,13 +585,14 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     unsigned blocks = (waves + 3) / 4;
 #define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, sorted, n_sorted, p_n_list, phase, cursor, next_act, next_cnt, cmax_next)
     const bool sw = ix.swin != nullptr && b.rd2 != nullptr && ix.sw_words == ((nw & 0xff) <= 8 ? 3 : 5);      // (entries of this kernel family's size)
-    const bool group8 = (nw & 0x100) != 0;                 // 8-word form: small intervals share rounds (the 16-word form always does)
+    // (reads of up to 128 bases have four cores or so per strand: their small intervals take a round each; sharing rounds, as the wider
+    // forms and the hash-set forms do, cost the 8-word inverse-suffix-array forms more registers than it saved rounds - round 3)
     nw &= 0xff;
     if (nw <= 8) {
         if (wide) BK_WAVE(8, true, true, false, true);
         else if (hash) BK_WAVE(8, false, true, false, true);
-        else if (sw) { if (group8) BK_WAVE(8, false, false, true, true); else BK_WAVE(8, false, false, true, false); }
-        else { if (group8) BK_WAVE(8, false, false, false, true); else BK_WAVE(8, false, false, false, false); }
+        else if (sw) BK_WAVE(8, false, false, true, false);
+        else BK_WAVE(8, false, false, false, false);
     } else if (nw <= 16) {
         if (wide) BK_WAVE(16, true, true, false, true);
         else if (hash) BK_WAVE(16, false, true, false, true);

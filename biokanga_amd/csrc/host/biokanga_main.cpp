@@ -850,7 +850,7 @@ int cmd_align(int argc, char **argv, int first)
                 const bool fq = fn.find(".fq") != std::string::npos || fn.find(".fastq") != std::string::npos;
                 est_reads += text / (fq ? 250 : 120);
                 plain_bytes += text;
-                all_plain = all_plain && o.nthreads > 1 && !getenv("BK_GZ_SERIAL");
+                all_plain = all_plain && o.nthreads > 1;
             }
     Submission S;
     if (all_plain && plain_bytes >= (256u << 20)) S.start_early(plain_bytes, (uint32_t)std::max(15, o.min_len));
@@ -1240,16 +1240,6 @@ int cmd_align(int argc, char **argv, int first)
     }
     if (rr == 0 && nr >= 1000000) {                // (small runs unwind normally: leak checkers and tests see every destructor)
         pre.finish();
-        if (getenv("BK_EXIT_PROBE")) {             // what each thing the exit gives back wholesale would cost to give back piece by piece
-            HostClock clk;
-            S.release_results(); clk.lap("exit probe: result array unregistered");
-            bk_host_free(S.words); bk_host_free(S.lens16); bk_host_free(S.exc); S.words = nullptr; S.lens16 = nullptr; S.exc = nullptr; clk.lap("exit probe: packed reads' page-locked buffers freed");
-            { ReadStore none; std::swap(rs, none); } clk.lap("exit probe: read store freed");
-            { AlignedSet none; std::swap(A, none); } clk.lap("exit probe: result records freed");
-            destroy_ctxs(); clk.lap("exit probe: contexts destroyed");
-            if (pre.map) { munmap(pre.map, (size_t)pre.est); pre.map = nullptr; } clk.lap("exit probe: SAM file unmapped");
-            (void)hipDeviceReset(); clk.lap("exit probe: hipDeviceReset");
-        }
         end_process(rr);                           // (contexts, page-locked buffers and the address space go with the process)
     }
     { HostClock clk; destroy_ctxs(); clk.lap("contexts destroyed"); }

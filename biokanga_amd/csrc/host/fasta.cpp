@@ -660,7 +660,6 @@ int parse_fasta_parallel(const std::string &path, int nthreads, ParsedFile &out,
     const uint8_t *base = (const uint8_t *)m;
     RawVec<uint8_t> text;                                 // a gzip'd file's text: bgzip members by all threads, other layouts by one
     if (base[0] == 0x1f && base[1] == 0x8b) {
-        if (getenv("BK_GZ_SERIAL")) { munmap(m, size); return 0; }       // (measurements: the record-by-record gzread reader)
         const bool ours = inflate_bgzf(base, size, nthreads, text) || inflate_gzip(base, size, nthreads, text);
         munmap(m, size);
         m = nullptr;

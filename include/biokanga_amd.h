@@ -184,15 +184,13 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
  *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
  *   "sort_lists" (bit 0: search work list grouped by bucket, bit 1: wave list sorted, bit 2: .. longest read first)
- *   "use_flat" (block-cooperative extend kernel, 0: lane per read)   "search_ilp" (searches per lane of pass A: 1, 2, 4)
- *   "flat_block" (reads per block of k_flat: 64..1024)   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
+ *   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
  *   "use_swin" (suffix-ordered window array: 0 none - every window from the 2-bit target; 1 for the part of the suffix array the wave kernel's long
  *   walks visit, reads of <= 100 bases and the middle cores of reads of <= 160; 2 the same whatever the batch's longest read; 3 for every suffix)
  *   "swin_budget_kb" (most the partial array may take; 0: a third of what every suffix would, within half of the free HBM)
  *   "swin_resident", "swin_mbytes", "swin_setup_us", "swin_covered_ppm", "swin_core_lens" (read only, value ignored: whether the window array
  *   is in HBM right now, what it occupies, what making it took, the share of the suffix array it holds, the core lengths its coverage is for)
- *   "wave_group" (wave kernel, reads of <= 128 bases: small core intervals share a round)
  *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's
  *   needs; 0: counts read back between launches, as every other configuration does)
  *   "chunk_reads" (reads per pass over the phases)   "max_read_len"

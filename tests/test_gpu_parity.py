@@ -57,16 +57,13 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
-@pytest.mark.parametrize("knob", [("flat_block", 64), ("flat_block", 512), (("flat_block", 1024), ("heavy_thresh", 100)), ("search_ilp", 1), ("search_ilp", 4),
-                                  (("search_ilp", 1), ("lazy_search", 0)), (("search_ilp", 4), ("kmer_bits", 9)),
-                                  ("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
-                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), ("use_k2", 0), ("use_flat", 0), (("use_flat", 0), ("heavy_thresh", 7)),
+@pytest.mark.parametrize("knob", [("heavy_thresh", 3), ("heavy_thresh", 0), ("heavy_thresh", 7), ("heavy_thresh", 100), ("use_ktab", 0), ("kmer_bits", 4),
+                                  ("kmer_bits", 12), ("chunk_reads", 333), ("use_wave", 0), ("lazy_search", 0), (("kmer_bits", 9), ("lazy_search", 0)), ("use_k2", 0),
                                   ("use_tgt2", 0), ("use_tgt2", 1), (("use_tgt2", 0), ("heavy_thresh", 0)), ("sort_lists", 0), ("sort_lists", 3), ("sort_lists", 1), ("sort_lists", 6),
                                   ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)), ("use_swin", 2), (("use_swin", 2), ("heavy_thresh", 0)), (("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 3)),
-                                  ("use_swin", 3), (("use_swin", 3), ("heavy_thresh", 0)), (("wave_group", 1), ("use_swin", 3), ("heavy_thresh", 3)),
-                                  ("use_swin", 0), ("wave_group", 1), (("wave_group", 1), ("heavy_thresh", 0)), (("wave_group", 1), ("use_isa", 0)), (("wave_group", 1), ("use_swin", 2), ("heavy_thresh", 3)),
+                                  ("use_swin", 3), (("use_swin", 3), ("heavy_thresh", 0)), ("use_swin", 0),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
-                                  (("use_k2", 0), ("lazy_search", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)), (("kmer_bits", 9), ("lazy_search", 0)),
+                                  (("use_k2", 0), ("lazy_search", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)),
                                   ("async_phases", 0), (("async_phases", 0), ("chunk_reads", 333)), (("async_phases", 0), ("sort_lists", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
@@ -89,7 +86,7 @@ def test_paths_agree(golden_tmp, fixture, knob):
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
-@pytest.mark.parametrize("knob", [(), ("use_flat", 0), ("chunk_reads", 333), ("use_tgt2", 0), ("use_k2", 0), ("heavy_thresh", 0), ("use_wave", 0)])
+@pytest.mark.parametrize("knob", [(), ("chunk_reads", 333), ("use_tgt2", 0), ("use_k2", 0), ("heavy_thresh", 0), ("use_wave", 0)])
 def test_packed_batch_equals_byte_batch(golden_tmp, fixture, knob):
     """bk_align_batch_packed (2 bit/base words + 16-bit lengths + the list of bases that are not a,c,g,t) gives the records and the
     counters of bk_align_batch on the same reads: lean and full-row batches, the general path (reads > 256 bases), chunked batches
@@ -140,7 +137,7 @@ def test_reads_of_129_to_512_bases(tmp_path, top, el_size):
     o.close()
     words, lens16, exc = bk.pack_reads(bases, offs, lens)
     with bk.Aligner(path, bk.AlignParams(max_subs=4)) as al:
-        for knobs in ([], [("heavy_thresh", 0)], [("heavy_thresh", 100)], [("use_flat", 0)], [("use_isa", 0)], [("use_tgt2", 0)], [("use_swin", 0)]):
+        for knobs in ([], [("heavy_thresh", 0)], [("heavy_thresh", 100)], [("use_isa", 0)], [("use_tgt2", 0)], [("use_swin", 0)]):
             for k, v in knobs:
                 al.tune(k, v)
             al.counters(reset=True)

@@ -167,7 +167,7 @@ def test_suffix_sort_of_more_than_2_32_bases():
     # the planted reads: two true instances, one seen - accepted as unique
     tail = got[-len(extra):]
     assert int((tail["nar"] == 1).sum()) > len(extra) * 3 // 4
-    # the lane-per-read family (use_flat = 0: k_light hands what has candidates to the hash-set wave kernel) on the planted reads
+    # the planted reads on their own, every read through the hash-set wave kernel (heavy_thresh 0)
     pl_bases = np.concatenate(extra)
     pl_offs = np.arange(len(extra), dtype=np.uint64) * 100
     pl_lens = np.full(len(extra), 100, dtype=np.uint32)
@@ -188,11 +188,11 @@ def test_suffix_sort_of_more_than_2_32_bases():
     ora.close()
     fields = ("chrom_id", "match_loci", "match_len", "low_hit_instances", "rslt", "nar", "strand", "low_mm", "nxt_low_mm", "num_hits", "mismatches")
     with bk.Aligner(None, bk.AlignParams(max_subs=3), d_seq=seq.data_ptr(), concat_len=n, d_sa=d_sa.data_ptr(), el_size=5, entries=ent) as al:
-        al.tune("use_flat", 0)
+        al.tune("heavy_thresh", 0)
         got2 = al.align(pl_bases, pl_offs, pl_lens)
         for f in fields:
-            assert np.array_equal(got2[f], tail[f]), ("use_flat=0", f)
-        al.tune("use_flat", 1)
+            assert np.array_equal(got2[f], tail[f]), ("heavy_thresh=0", f)
+        al.tune("heavy_thresh", 64)
         for knobs in ((), (("use_wave", 0),)):
             for kv in knobs:
                 al.tune(*kv)

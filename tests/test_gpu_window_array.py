@@ -100,8 +100,8 @@ def test_partial_window_array_changes_no_result(tmp_path, read_len, max_subs):
                             ("partial, 40 KB", [("use_swin", 0), ("swin_budget_kb", 40), ("use_swin", 2)]),
                             ("partial, 700 KB", [("use_swin", 0), ("swin_budget_kb", 700), ("use_swin", 2)]),
                             ("partial, 700 KB, every read through the wave kernel", [("heavy_thresh", 0)]),
-                            ("partial, 5 MB, shared rounds", [("use_swin", 0), ("swin_budget_kb", 5000), ("use_swin", 2), ("wave_group", 1), ("heavy_thresh", 3)]),
-                            ("partial again", [("use_swin", 0), ("swin_budget_kb", 0), ("use_swin", 2), ("wave_group", 0), ("heavy_thresh", 64)])):
+                            ("partial, 5 MB, short intervals through the wave kernel", [("use_swin", 0), ("swin_budget_kb", 5000), ("use_swin", 2), ("heavy_thresh", 3)]),
+                            ("partial again", [("use_swin", 0), ("swin_budget_kb", 0), ("use_swin", 2), ("heavy_thresh", 64)])):
             for kv in knobs:
                 al.tune(*kv)
             al.counters(reset=True)

@@ -4,8 +4,9 @@ T_e2e (process start -> exit) and the phases from its time-stamped log.  Files l
   python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--quiet] [--gz] [-- extra options of biokanga align]
 Every variant is the same command with its own environment (the first run, "default", has none; BK_E2E_ARGS=<options> adds options of
 biokanga align to a variant's command); the files are written once.
---gz: the reads also as reads.fa.gz (one member, level 1) and reads.fa.bgz (bgzip members); every variant then runs on the three inputs,
-and the gzip'd ones once more with BK_GZ_SERIAL=1 (the record-by-record gzread reader)."""
+--gz: the reads also as reads.fa.gz (one member, level 1) and reads.fa.bgz (bgzip members); every variant then runs on the three inputs
+(the record-by-record gzread reader these were measured against in round 4 - BK_GZ_SERIAL - is still what takes the files the whole-file
+decoder declines, but no longer something to switch to)."""
 import os, sys, time, subprocess, shutil, tempfile, datetime, re, struct, zlib
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -106,8 +107,7 @@ def main():
         if with_gz:
             write_gzip_copies(fa)
             inputs += [(" .gz", fa + ".gz"), (" .bgz", fa + ".bgz")]
-            variants = [(n + tag, dict(e, BK_E2E_INPUT=path)) for n, e in variants for tag, path in inputs] + \
-                       [(n + tag + " gzread", dict(e, BK_E2E_INPUT=path, BK_GZ_SERIAL="1")) for n, e in variants for tag, path in inputs[1:]]
+            variants = [(n + tag, dict(e, BK_E2E_INPUT=path)) for n, e in variants for tag, path in inputs]
         first_size = None
         for name, env in variants:
             env = dict(env)

@@ -150,7 +150,7 @@ def main():
             pe = dict(pe_mode=int(rng.integers(1, 5)), pair_min_len=int(rng.choice([100, 200])), pair_max_len=int(rng.choice([400, 1000, 5000])),
                       pair_strand=int(rng.integers(0, 6) == 0))
             al.set_params(bk.AlignParams(**kw))
-            al.tune("chunk_reads", 64 << 20); al.tune("use_wave", 1); al.tune("use_flat", 1)
+            al.tune("chunk_reads", 64 << 20); al.tune("use_wave", 1)
             if pe["pair_min_len"] < L:
                 pe["pair_min_len"] = L
             if pe["pair_max_len"] < pe["pair_min_len"] + 100:
@@ -207,7 +207,7 @@ def main():
         p = helpers.make_params(**kw)
         al.set_params(bk.AlignParams(**kw))
         # (the window array: none / the partial one / one cut off by a byte budget / every suffix - dropped first so that the next batch makes its own)
-        for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)), ("use_flat", int(rng.integers(0, 4) != 0)),
+        for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)),
                           ("use_swin", 0), ("swin_budget_kb", int(rng.choice([0, 0, 3, 30, 300]))), ("use_swin", int(rng.choice([0, 1, 2, 2, 3])))):
             al.tune(knob, val)
         packed = bool(rng.integers(0, 2))                # the same reads across the boundary at 2 bit/base

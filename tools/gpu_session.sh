@@ -11,7 +11,6 @@
 #     e2e_csv   the same with -M0 (the reference's default CSV) and with -o ending in .sam.gz: the writers that all threads share since round 4
 #     e2e_gz    the same on 20 M reads, from the plain file, its .gz and its .bgz, and the gzip'd ones through gzread as well
 #     inflate   the loaders' DEFLATE decoder on the box's host: one thread, 2 .. 16 threads, zlib (tools/inflate_bench.sh; no GPU work)
-#     e2e_probe the same with BK_EXIT_PROBE=1: what the exit gives back, released piece by piece and timed
 #     upload    host -> device upload methods, wall-clock and CPU seconds (tools/upload_bench)
 #     index_e2e `biokanga index` end to end on a 3.1 Gbp FASTA in /dev/shm with the stage clocks (tools/index_e2e.py)
 #     quota     two bench ranks / four command-line contexts on the one GPU, unconstrained and under `taskset -c 0-3`
@@ -48,7 +47,6 @@ PY
              BK_E2E_OUT=out.sam.gz timeout 560 python3 tools/e2e_cli.py 20000000 --quiet > $O/e2e_samgz.log 2>&1; grep -a "T_e2e\|load " $O/e2e_samgz.log | cut -c1-220 ;;
     e2e_gz) timeout 560 python3 tools/e2e_cli.py 20000000 --gz --quiet > $O/e2e_gz.log 2>&1; grep -a "gzip copies\|T_e2e\|load " $O/e2e_gz.log | cut -c1-220 ;;
     inflate) BK_INFLATE_DEBUG=1 timeout 300 bash tools/inflate_bench.sh 600 > $O/inflate_bench.txt 2>&1; grep -v "piece at" $O/inflate_bench.txt | tail -14 ;;
-    e2e_probe) BK_EXIT_PROBE=1 timeout 600 python3 tools/e2e_cli.py 50000000 > $O/e2e_probe.log 2>&1; grep -a "exit probe\|T_e2e\|tear-down" $O/e2e_probe.log | cut -c1-200 ;;
     upload)
       python3 -c "import numpy as np; np.random.default_rng(1).integers(0, 255, size=6 << 30, dtype=np.uint8).tofile('/dev/shm/upload_bench.bin')"
       tools/upload_bench /dev/shm/upload_bench.bin 6 > $O/upload_methods.txt 2>&1; cat $O/upload_methods.txt; rm -f /dev/shm/upload_bench.bin ;;
