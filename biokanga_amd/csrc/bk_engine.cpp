@@ -1299,7 +1299,7 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 int take_phase_history(bk_ctx *c, bool wait)
 {
     if (!c->ctl_pending) return BK_OK;
-    if (wait) HIP_TRY(hipEventSynchronize(c->ev_ctl));
+    if (wait) HIP_TRY(bk::wait_event(c->ev_ctl));
     else if (hipEventQuery(c->ev_ctl) != hipSuccess) { (void)hipGetLastError(); return BK_OK; }
     c->ctl_pending = false;
     const PhaseCtl *h = c->h_ctl;

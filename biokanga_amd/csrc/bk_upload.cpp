@@ -105,13 +105,13 @@ int upload_staged(void *d_dst, size_t bytes, int device, int max_threads, Fill f
             const size_t s = next.fetch_add(1);
             if (s >= n_slices) break;
             const size_t off = s * kSlice, n = std::min(kSlice, bytes - off);
-            if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { ok = false; break; }
+            if (used[k] && bk::wait_event(ev[k]) != hipSuccess) { ok = false; break; }
             if (!fill(buf[k], off, n)) { ok = false; break; }
             ok = hipMemcpyAsync((uint8_t *)d_dst + off, buf[k], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[k], st) == hipSuccess;
             used[k] = true;
         }
         for (int k = 0; k < 2; k++)
-            if (ok && used[k] && hipEventSynchronize(ev[k]) != hipSuccess) ok = false;
+            if (ok && used[k] && bk::wait_event(ev[k]) != hipSuccess) ok = false;
         if (!ok) { if (st) (void)hipStreamSynchronize(st); failed = 1; }
         for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (buf[k]) g_pool.put(buf[k]); }
         if (st) (void)hipStreamDestroy(st);
