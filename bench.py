@@ -465,7 +465,9 @@ class HostLeg:
         t0 = time.time()
         self.h_lens = bk.host_array(n, np.uint32)
         torch.from_numpy(self.h_lens.view(np.int32)).copy_(rd_lens[:n])
-        self.h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(2)]
+        # (three sets of result records: a step's batches go in while the step before is aligned and the one before that comes back - with
+        # two, a step's upload could only start once the step two back had come home, and a 2 x 150 step's 1.8 GB did not make it in time)
+        self.h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(3)]
         self.packed = args.stream_form == "packed"
         if self.packed:
             # the loader's side of the boundary: reads leave host memory at 2 bit/base (bk_pack_reads: host threads, untimed set-up here
@@ -515,7 +517,7 @@ class HostLeg:
         n, L = self.args.reads, self.args.read_len
         with bk.Stream(al, self.B, self.B * L, depth=3, pe=pe_params) as st:
             def one_step(k, first=False, last=False):
-                out = self.h_out[k & 1]
+                out = self.h_out[k % 3]
                 cc = self.cuts0 if first else (self.cuts9 if last else self.cuts)
                 if self.packed:
                     return [st.submit_packed(self.p_words[lo * self.wpr: hi * self.wpr], self.p_lens16[lo:hi], self.exc_of[(lo, hi)], out[lo:hi])
@@ -531,8 +533,8 @@ class HostLeg:
             tickets = []
             for k in range(steps):
                 tickets += one_step(k, first=(k == 0), last=(k == steps - 1 and k > 0))
-                # keep at most one step of tickets un-waited so that the two result buffers are never overwritten early
-                while len(tickets) > len(self.cuts) - 1:
+                # keep at most two steps of tickets un-waited so that a set of result records is never overwritten early
+                while len(tickets) > 2 * (len(self.cuts) - 1):
                     st.wait(tickets.pop(0))
             for t in tickets:
                 st.wait(t)
@@ -557,7 +559,7 @@ class HostLeg:
 
     def same_as(self, expect, steps):
         import numpy as np
-        return all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in self.h_out[: min(2, steps)])
+        return all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in self.h_out[: min(3, steps)])
 
 
 def metric_text(args, cfg, E):

@@ -1,18 +1,18 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh r01_c
-# Writes raw output under gpurun_out/prof_<tag>/ and the condensed summaries that get committed
+# Writes raw output under /tmp/prof_<tag>/ and the condensed summaries that get committed
 # under gpurun_out/profiles_<tag>/ (copy those into profiles/).
 # Counters are collected in their own runs (no trace domains besides --kernel-trace), FETCH_SIZE and
 # WRITE_SIZE in separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
 tag=${1:-rXX}
 root=$(pwd)
-raw=gpurun_out/prof_$tag
+raw=/tmp/prof_$tag                 # (the raw rocprofv3 output stays on the box: gpurun brings back 64 MiB at most)
 out=gpurun_out/profiles_$tag
 mkdir -p $raw $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic"
+BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic --no-other-layout"      # (the layout the policy picks, nothing else in the trace)
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -o run -- $BENCH > $raw/stats.log 2>&1
 grep '^{' $raw/stats.log | tail -1 > $out/${tag}_bench_line_under_rocprof.json
