@@ -467,7 +467,8 @@ class HostLeg:
         torch.from_numpy(self.h_lens.view(np.int32)).copy_(rd_lens[:n])
         # (three sets of result records: a step's batches go in while the step before is aligned and the one before that comes back - with
         # two, a step's upload could only start once the step two back had come home, and a 2 x 150 step's 1.8 GB did not make it in time)
-        self.h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(3)]
+        self.n_sets = max(2, int(args.host_sets))
+        self.h_out = [bk.host_array(n, bk.HIT_DTYPE) for _ in range(self.n_sets)]
         self.packed = args.stream_form == "packed"
         if self.packed:
             # the loader's side of the boundary: reads leave host memory at 2 bit/base (bk_pack_reads: host threads, untimed set-up here
@@ -492,7 +493,7 @@ class HostLeg:
         def even(v):
             return max(2, int(v) & ~1)
         first = min(B, n)
-        ramp = [0, even(0.06 * first), even(0.34 * first)] if first >= 1000 else [0]
+        ramp = ([0] + [even(float(x) * first) for x in args.host_ramp.split(",") if x]) if first >= 1000 else [0]
         self.cuts = cuts
         self.cuts0 = ramp + [c for c in cuts if c > ramp[-1]]
         # .. and the last step ends on a tenth of a batch: the download of the very last batch has nothing to hide behind either
@@ -517,7 +518,7 @@ class HostLeg:
         n, L = self.args.reads, self.args.read_len
         with bk.Stream(al, self.B, self.B * L, depth=3, pe=pe_params) as st:
             def one_step(k, first=False, last=False):
-                out = self.h_out[k % 3]
+                out = self.h_out[k % self.n_sets]
                 cc = self.cuts0 if first else (self.cuts9 if last else self.cuts)
                 if self.packed:
                     return [st.submit_packed(self.p_words[lo * self.wpr: hi * self.wpr], self.p_lens16[lo:hi], self.exc_of[(lo, hi)], out[lo:hi])
@@ -534,7 +535,7 @@ class HostLeg:
             for k in range(steps):
                 tickets += one_step(k, first=(k == 0), last=(k == steps - 1 and k > 0))
                 # keep at most two steps of tickets un-waited so that a set of result records is never overwritten early
-                while len(tickets) > 2 * (len(self.cuts) - 1):
+                while len(tickets) > (self.n_sets - 1) * (len(self.cuts) - 1):
                     st.wait(tickets.pop(0))
             for t in tickets:
                 st.wait(t)
@@ -559,7 +560,7 @@ class HostLeg:
 
     def same_as(self, expect, steps):
         import numpy as np
-        return all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in self.h_out[: min(3, steps)])
+        return all(bool(np.array_equal(h.view(np.uint8), expect.view(np.uint8))) for h in self.h_out[: min(self.n_sets, steps)])
 
 
 def metric_text(args, cfg, E):
@@ -615,6 +616,8 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="kernel-only steps only (profiling runs): `value` is then the kernel-only rate and says so")
     ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the reads cross PCIe: "
                     "2 bit/base (bk_stream_submit_packed) or 1 byte/base (bk_stream_submit)")
+    ap.add_argument("--host-ramp", default="0.06,0.34", help="the first host-in / host-out step's batches end at these fractions of a step (then the rest)")
+    ap.add_argument("--host-sets", type=int, default=3, help="sets of host result records of the host-in / host-out steps (steps in flight + 1)")
     ap.add_argument("--stream-batch", type=int, default=0, help="reads per submitted batch of the host-in / host-out steps (0 = a whole step; the first step ramps up to it)")
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")

@@ -471,12 +471,13 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     if (device_id < 0 || device_id >= ndev) return BK_ERR_PARAMS;
     HIP_TRY(hipSetDevice(device_id));
     bk_ctx *c = new bk_ctx();
+    bk::live_contexts()++;                         // (how host threads wait depends on how many contexts share the process's CPUs: bk_wait.h)
     c->device = device_id;
     c->params = *p;
     c->cfg.heavy_thresh = 64;
     c->debug = getenv("BK_DEBUG") != nullptr;
     if (c->params.max_ml == 0) c->params.max_ml = 1;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BK_ERR_INTERNAL; }
+    if (hipStreamCreate(&c->stream) != hipSuccess) { bk::live_contexts()--; delete c; return BK_ERR_INTERNAL; }
     *pc = c;
     return BK_OK;
 }
@@ -1792,6 +1793,7 @@ void bk_ctx_destroy(bk_ctx *c)
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    bk::live_contexts()--;
     delete c;
 }
 

@@ -110,9 +110,8 @@ int upload_staged(void *d_dst, size_t bytes, int device, int max_threads, Fill f
             ok = hipMemcpyAsync((uint8_t *)d_dst + off, buf[k], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[k], st) == hipSuccess;
             used[k] = true;
         }
-        for (int k = 0; k < 2; k++)
-            if (ok && used[k] && bk::wait_event(ev[k]) != hipSuccess) ok = false;
-        if (!ok) { if (st) (void)hipStreamSynchronize(st); failed = 1; }
+        if (st && bk::wait_stream(st, ev[0]) != hipSuccess) ok = false;
+        if (!ok) failed = 1;
         for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (buf[k]) g_pool.put(buf[k]); }
         if (st) (void)hipStreamDestroy(st);
     };
