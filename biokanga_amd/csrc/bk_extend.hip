@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                             fb0[i] = ix.nflag[g0 >> 3];
                             fb1[i] = ix.nflag[g1 >> 3];
                             window2_load<NW>(ix.tgt2, ix.tgt2s, t0, c_len, wv[i]);
-                            if (!ROWS) {
+                            if (!ROWS && NW <= 8) {            // (the wider forms fetch the row when they compare: sixteen more live registers cost them more than the trip)
                                 const int sti = q >= cmaxs ? 1 : 0;
                                 const uint4 *__restrict__ rp = reinterpret_cast<const uint4 *>(b.rd2 + ((uint64_t)s_r[ri] * 2 + (uint64_t)(s0 + sti)) * (NW / 2));
 #pragma unroll
@@ -422,13 +422,14 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                                 r2w[2 * u] = ((uint64_t)v.y << 32) | v.x;
                                 r2w[2 * u + 1] = ((uint64_t)v.w << 32) | v.z;
                             }
-                        } else {
+                        } else if (NW <= 8) {
 #pragma unroll
                             for (int u = 0; u < NW / 4; u++) {
                                 r2w[2 * u] = ((uint64_t)rowv[i][u].y << 32) | rowv[i][u].x;
                                 r2w[2 * u + 1] = ((uint64_t)rowv[i][u].w << 32) | rowv[i][u].z;
                             }
-                        }
+                        } else
+                            load_read_words2<NW>(b.rd2 + ((uint64_t)cr * 2 + st) * (NW / 2), r2w);
 #pragma unroll
                         for (int u = 0; u < NW / 4; u++) rnm[u] = 0;
                         window2_compare<NW>(r2w, rnm, c_len, t0, wv[i], w);

@@ -44,8 +44,13 @@ struct WaveCoreInfo {
 // inverse suffix array; and only the truncated keys reproduce the reference there, where two starts 2^32 apart
 // count as one) and for 4-byte indexes whose inverse suffix array was not built.
 // SW: the index holds the suffix-ordered window array (DevIndex::swin) - reads it covers take their candidates' windows from it.
+// (16-word inverse-suffix-array forms: five waves per SIMD at 96 registers and a dozen of them spilled beat four at 116 - 2 x 150's
+// k_wave 77.1 -> 70.5 ms per step, round 5; the hash-set forms lose by the same move, round 4)
+#ifndef BK_WAVE16_BLOCKS
+#define BK_WAVE16_BLOCKS 5
+#endif
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
-__global__ void __launch_bounds__(256, NW <= 8 ? 4 : 2) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
+__global__ void __launch_bounds__(256, NW <= 8 ? 4 : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
                                               const uint32_t *__restrict__ p_n_list, int phase, uint32_t *__restrict__ cursor,
                                               uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
