@@ -49,12 +49,13 @@ struct WaveCoreInfo {
 #ifndef BK_WAVE16_BLOCKS
 #define BK_WAVE16_BLOCKS 5
 #endif
-// (8-word inverse-suffix-array forms: eight waves per SIMD at 64 registers - two spilled - against seven at 70: C2's k_wave 31.0 -> 29.6 ms)
+// (the 8-word window-array form: eight waves per SIMD at 64 registers - two spilled - against seven at 70: C2's k_wave 31.0 -> 29.6 ms; the form
+// without the array has its eight waves at 53 registers anyway and lost 4 % under the same bound)
 #ifndef BK_WAVE8_BLOCKS
 #define BK_WAVE8_BLOCKS 8
 #endif
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
-__global__ void __launch_bounds__(256, NW <= 8 ? (HASH ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
+__global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
                                               const uint32_t *__restrict__ p_n_list, int phase, uint32_t *__restrict__ cursor,
                                               uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
