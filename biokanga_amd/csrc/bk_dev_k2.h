@@ -63,6 +63,74 @@ __device__ __forceinline__ uint32_t k2_make(const uint64_t *__restrict__ tgt4, u
     return ((code | (0xFFFFFFFFu >> (2 * j))) & ~3u) | 1u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sampled levels behind the keys (same allocation): level j (1 .. kK2Levels) holds the key of every 16^j-th suffix - entry g is
+// k2[(g + 1) * 16^j - 1] - so a bucket of S keys is bisected sixteen ways a step: a line of the highest level with a sample inside
+// the bucket, one line of every level below it, one line of the keys themselves - ceil(log16 S) + 1 lines per bound where halving the
+// interval over the keys costs log2 S - 3, and as many dependent trips.  A sample may be used whenever the key it copies lies inside
+// the interval at hand (the keys of other buckets say nothing), which is all the narrowing below relies on.
+// (layout: kK2Levels, k2s_start .. in bk_device.h)
+
+// entries [a, b) of L (sorted where it matters: inside the interval): how many lie below the probe, how many not above it.  Whole
+// aligned lines are loaded - four 16-byte requests, no dependent trips inside a line - and the second line of a range that straddles
+// two is only fetched when the first did not end both counts.
+#ifdef BK_DIAG_B
+#define BK_K2_LINE(ctr) (ctr)++
+#else
+#define BK_K2_LINE(ctr) (void)0
+#endif
+__device__ __forceinline__ void k2_count_range(const uint32_t *__restrict__ L, uint64_t a, uint64_t b, uint32_t m, uint32_t q2, uint32_t &n_lt, uint32_t &n_le,
+                                               unsigned long long &lines)
+{
+    n_lt = 0; n_le = 0;
+    (void)lines;
+    for (uint64_t base = a & ~15ULL; base < b; base += 16) {
+        const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(L + base);
+        const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        BK_K2_LINE(lines);
+        const uint32_t key[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+        const uint32_t lo = a > base ? (uint32_t)(a - base) : 0u, hi = b - base < 16 ? (uint32_t)(b - base) : 16u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const bool in = j >= lo && j < hi;
+            const uint32_t km = key[j] == kK2Above ? 0xFFFFFFFFu : (key[j] & m);         // (the probe's low two bits are clear)
+            n_lt += (in && km < q2) ? 1u : 0u;
+            n_le += (in && km <= q2) ? 1u : 0u;
+        }
+        if ((uint64_t)n_le < base + hi - a) break;
+    }
+}
+
+// lower and upper bound of the probe among the keys [first, first + cnt) of one k-mer bucket; lv[j] = k2s_start(n, j)
+__device__ __forceinline__ void k2_bounds(const uint32_t *__restrict__ k2, const uint64_t *lv, uint64_t first, uint64_t cnt, uint32_t m, uint32_t q2,
+                                          uint64_t &lb, uint64_t &ub, unsigned long long &lines)
+{
+    uint64_t l1 = first, h1 = first + cnt, l2 = l1, h2 = h1;
+    int ktop = cnt >= 16 ? (63 - __clzll((long long)cnt)) >> 2 : 0;                    // the highest level with a sample inside
+    if (ktop > kK2Levels) ktop = kK2Levels;
+    for (int j = ktop; j >= 0; j--) {
+        const int sh = 4 * j;
+        const uint32_t *__restrict__ L = j ? k2 + lv[j] : k2;
+        // sample g of this level is key (g + 1) * 16^j - 1: inside [l, h) for g in [l >> sh, h >> sh)
+        const uint64_t a1 = l1 >> sh, b1 = h1 >> sh, a2 = l2 >> sh, b2 = h2 >> sh;
+        uint32_t lt = 0, le = 0;
+        if (a1 < b1) {
+            k2_count_range(L, a1, b1, m, q2, lt, le, lines);
+            const uint64_t g = a1 + lt;                  // the first sample that is not below the probe
+            if (lt) l1 = g << sh;
+            if (g < b1) h1 = ((g + 1) << sh) - 1;
+        }
+        if (a2 < b2) {
+            if (a2 != a1 || b2 != b1) { uint32_t lt2; k2_count_range(L, a2, b2, m, q2, lt2, le, lines); }
+            const uint64_t g = a2 + le;                  // the first sample above the probe
+            if (le) l2 = g << sh;
+            if (g < b2) h2 = ((g + 1) << sh) - 1;
+        }
+    }
+    lb = l1;
+    ub = l2;
+}
+
 // as cmp_core, but only bases [start, cl) of the core are compared
 template <typename Row>
 __device__ __forceinline__ int cmp_core_from(const Row &rdw, int ofs, int cl, int start,

@@ -30,6 +30,22 @@
 
 namespace bk {
 
+// sampled levels of the second-level keys, stored behind them in the same allocation (bk_dev_k2.h)
+constexpr int kK2Levels = 7;                        // 16^8 > the largest interval a work item carries (2^kKindShift)
+
+__host__ __device__ __forceinline__ uint64_t k2s_pad(uint64_t words) { return (words + 15) & ~15ULL; }
+// entries of level j
+__host__ __device__ __forceinline__ uint64_t k2s_count(uint64_t n, int j) { return (n + (1ULL << (4 * j)) - 1) >> (4 * j); }
+// where level j starts, in 4-byte words from k2[0] (level kK2Levels + 1 "starts" where the allocation ends); every level starts on
+// a 64-byte line and is followed by a line of padding, so whole lines may be loaded around any entry
+__host__ __device__ __forceinline__ uint64_t k2s_start(uint64_t n, int j)
+{
+    uint64_t o = k2s_pad(n) + 16;
+    for (int i = 1; i < j; i++) o += k2s_pad(k2s_count(n, i)) + 16;
+    return o;
+}
+
+
 // A work list that every block of a launch appends to.  One shared counter means one L2 line retiring every block's atomic in
 // turn, 12 ns each (`tools/rand_access_bench atomic`: 200 000 blocks, one atomic each, 2.4 ms on one line, 0.07 ms on 64 lines) -
 // that, not memory latency, was what k_flat, pass A of the search and the read packing waited for.  So a block appends to stripe

@@ -61,6 +61,7 @@ void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_r
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
+void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
@@ -248,9 +249,9 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
     if (c->use_k2 && tp.ktab) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t need = c->ix.n * 4;
+        const uint64_t need = k2s_start(c->ix.n, kK2Levels + 1) * 4;          // (the keys and their sampled levels, bk_dev_k2.h)
         if (need <= free_b && free_b - need >= total_b / 5) {
-            HIP_TRY(dev_malloc(&c->d_k2, need + 64));
+            HIP_TRY(dev_malloc(&c->d_k2, need));
             HIP_TRY(dev_malloc(&tp.d_bad, 8));
             HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 8, c->stream));
             tp.k2 = true;
@@ -291,6 +292,8 @@ int tables_end(bk_ctx *c, TablePlan &tp)
         free_dev(c->d_k2);
         c->d_k2 = nullptr;
     } else if (tp.k2) {
+        launch_build_k2_levels(c->d_k2, c->ix.n, c->stream);
+        HIP_TRY(hipGetLastError());
         c->ix.k2 = c->d_k2;
         // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
         if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
@@ -1747,7 +1750,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_sa_lo, src->d_sa_lo, (size_t)n * 4);
     dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
     dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
-    dup(c->d_k2, src->d_k2, (size_t)n * 4 + 64);
+    dup(c->d_k2, src->d_k2, (size_t)k2s_start(n, kK2Levels + 1) * 4);
     dup(c->d_isa, src->d_isa, (size_t)n * 4);
     dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
     dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);

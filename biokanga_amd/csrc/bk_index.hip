@@ -2,7 +2,7 @@
 //   k_pack_target / k_pack_target2   1 B/base target -> 4 bit/base words; 2 bit/base copy + N/EOS region bitmap
 //   k_split_sa5                      5-byte suffix elements -> lo32 + hi8 arrays
 //   k_build_ktab / k_make_ktab2      k-mer table (+ entries that carry their bucket's first second-level key)
-//   k_build_k2 / k_check_k2          second-level keys
+//   k_build_k2 / k_check_k2          second-level keys; k_build_k2_levels: every 16th, 256th .. of them behind the keys
 //   k_build_isa                      inverse suffix array
 //   k_build_swin                     suffix-ordered window array
 //   k_swin_*                         .. for the part of the suffix array the wave kernel's long walks visit
@@ -109,6 +109,27 @@ __global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2, uint64_t i0, 
 {
     for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (uint64_t)gridDim.x * blockDim.x)
         k2[i] = k2_make(ix.tgt4, sa_get<WIDE>(ix, i), ix.k);
+}
+
+// the sampled levels behind the keys (bk_dev_k2.h): one thread per word between the keys' end and the allocation's - level entries
+// and the padding between levels alike
+__global__ void k_build_k2_levels(uint32_t *__restrict__ k2, uint64_t n)
+{
+    const uint64_t w0 = n, w1 = k2s_start(n, kK2Levels + 1);
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = kK2Above;
+        uint64_t start = k2s_start(n, 1);
+        for (int j = 1; j <= kK2Levels && w >= start; j++) {
+            const uint64_t cnt = k2s_count(n, j);
+            if (w - start < cnt) {
+                const uint64_t src = ((w - start + 1) << (4 * j)) - 1;
+                v = k2[src < n ? src : n - 1];
+                break;
+            }
+            start += k2s_pad(cnt) + 16;
+        }
+        k2[w] = v;
+    }
 }
 
 // the bisection needs k2 non-decreasing inside every k-mer bucket; count the places where it is not
@@ -480,6 +501,14 @@ void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, 
         hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, i0, i1);
         hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     }
+}
+
+void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s)
+{
+    const uint64_t words = k2s_start(n, kK2Levels + 1) - n;
+    uint64_t blocks = (words + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(k_build_k2_levels, dim3((unsigned)blocks), dim3(256), 0, s, k2, n);
 }
 
 void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t s, uint64_t i0, uint64_t i1)

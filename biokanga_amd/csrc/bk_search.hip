@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     // the work list's length lives in device memory; its first min(length, n_sorted) items are taken from `sorted` (the grouped copy:
     // the launch had to size the sort before the length was known), the others from the list as pass A left it - the order of the
     // items never changes a result
+    __shared__ uint64_t s_lv[kK2Levels + 1];                // where the sampled levels of the keys start (k2s_start)
+    if (threadIdx.x <= (unsigned)kK2Levels) s_lv[threadIdx.x] = threadIdx.x ? k2s_start(ix.n, (int)threadIdx.x) : 0;
+    __syncthreads();
     const uint32_t n_list = *p_n_list;
     const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
@@ -291,18 +294,16 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     if (kind == kKindK2) {
         const uint32_t m = k2_mask(cl - k);
         const uint32_t q2 = squeeze2(rdw.nib16(my_ofs + k)) & m;
-        // lower and upper bound in lock step: two independent loads per round
-        uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
-        while (l1 < h1 || l2 < h2) {
-            const bool a1 = l1 < h1, a2 = l2 < h2;
-            const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
+        // lower and upper bound through the sampled levels: a line per level and bound (bk_dev_k2.h)
+        uint64_t l1, l2;
 #ifdef BK_DIAG_B
-            d_k2 += 1 + (1ULL << 32) * ((a1 && (h1 - l1) > 8) + (a2 && (h2 - l2) > 8 && (m1 >> 3) != (m2 >> 3)));
+        unsigned long long k2_lines = 0;
+        k2_bounds(ix.k2, s_lv, first, cnt, m, q2, l1, l2, k2_lines);
+        d_k2 += 1 + (k2_lines << 32);                       // (low word: items of this kind; high word: their lines)
+#else
+        unsigned long long k2_lines = 0;
+        k2_bounds(ix.k2, s_lv, first, cnt, m, q2, l1, l2, k2_lines);
 #endif
-            const uint32_t v1 = a1 ? ix.k2[m1] : 0, v2 = a2 ? ix.k2[m2] : 0;
-            if (a1) { if (k2_cmp(v1, m, q2) < 0) l1 = m1 + 1; else h1 = m1; }
-            if (a2) { if (k2_cmp(v2, m, q2) <= 0) l2 = m2 + 1; else h2 = m2; }
-        }
         // keys of the N kind at the end of the run of equal keys may be there for their fill only: the target decides
         {
             const int upto = cl < k + kK2Bases ? cl : k + kK2Bases;
