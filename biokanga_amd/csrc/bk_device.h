@@ -100,6 +100,7 @@ struct DevIndex {
     const uint64_t *ktab64;
     const uint2 *ktab2;         // instead of ktab32 when the second-level keys exist: {ktab32[c], k2[ktab32[c]]} - a bucket of one suffix needs no second line
     const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null
+    const uint32_t *k3;         // third-level keys: the 15 bases after those, same form; all ones where k2's kind is not 0; may be null
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
     const uint4 *swin;          // suffix-ordered windows: for every suffix array index i the kSwBases bases of the 2-bit target from
                                 //   sa[i] - kSwPre on, 48 bytes each.  The candidates of a core interval - consecutive suffix array

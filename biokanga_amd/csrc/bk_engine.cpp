@@ -60,7 +60,7 @@ void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -218,17 +218,17 @@ int pick_k(uint64_t n)
 // made range by range: behind the suffix array's upload (bk_ctx_create_ex sends it in slices and these kernels work on a slice while the
 // next crosses PCIe), or in one go.  tables_begin decides and allocates, tables_range enqueues, tables_end checks and publishes.
 struct TablePlan {
-    bool ktab = false, k2 = false, isa = false;
+    bool ktab = false, k2 = false, k3 = false, isa = false;
     int k = 0;
-    unsigned long long *d_bad = nullptr;           // places where the second-level keys are not in order inside a bucket
+    unsigned long long *d_bad = nullptr;           // places where the second-level keys are not in order inside a bucket; the third-level keys inside a run of equal second-level keys
     ~TablePlan() { free_dev(d_bad); }
 };
 
 int tables_begin(bk_ctx *c, TablePlan &tp)
 {
-    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_isa);
-    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
-    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
+    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k3); free_dev(c->d_isa);
+    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_k3 = nullptr; c->d_isa = nullptr;
+    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.k3 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
     c->ix.k = 0;
     if (c->use_ktab) {
@@ -252,9 +252,15 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
         const uint64_t need = k2s_start(c->ix.n, kK2Levels + 1) * 4;          // (the keys and their sampled levels, bk_dev_k2.h)
         if (need <= free_b && free_b - need >= total_b / 5) {
             HIP_TRY(dev_malloc(&c->d_k2, need));
-            HIP_TRY(dev_malloc(&tp.d_bad, 8));
-            HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 8, c->stream));
+            HIP_TRY(dev_malloc(&tp.d_bad, 16));
+            HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 16, c->stream));
             tp.k2 = true;
+            // third-level keys (the 15 bases after those): as much again, for the cores of more than k + 15 bases - where that leaves
+            // the same reserve, and the context is one for a long run
+            if (c->use_k3 && 2 * need <= free_b && free_b - 2 * need >= total_b / 5) {
+                HIP_TRY(dev_malloc(&c->d_k3, need));
+                tp.k3 = true;
+            }
         }
     }
     if (c->use_wave && c->use_isa && c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32)) {
@@ -271,7 +277,7 @@ int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1, unsig
     ix.k = tp.k;
     const bool last = i1 >= c->ix.n;
     if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1, bucket_starts);
-    if (tp.k2) launch_build_k2(ix, c->d_k2, tp.d_bad, c->stream, i0, i1);
+    if (tp.k2) launch_build_k2(ix, c->d_k2, tp.k3 ? c->d_k3 : nullptr, tp.d_bad, c->stream, i0, i1);
     if (tp.isa) launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream, i0, i1);
     HIP_TRY(hipGetLastError());
     return BK_OK;
@@ -279,13 +285,20 @@ int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1, unsig
 
 int tables_end(bk_ctx *c, TablePlan &tp)
 {
-    unsigned long long bad = 0;
-    if (tp.k2) HIP_TRY(hipMemcpyAsync(&bad, tp.d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long bad2[2] = {0, 0};
+    if (tp.k2) HIP_TRY(hipMemcpyAsync(bad2, tp.d_bad, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (tp.ktab) {
         if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
         c->ix.k = tp.k;
+    }
+    const unsigned long long bad = bad2[0];
+    if (tp.k3 && (bad || bad2[1])) {
+        if (!bad) fprintf(stderr, "biokanga_amd: suffix array not in nibble order at %llu place(s) beyond the second-level keys; third-level keys disabled\n", bad2[1]);
+        free_dev(c->d_k3);
+        c->d_k3 = nullptr;
+        tp.k3 = false;
     }
     if (tp.k2 && bad) {
         fprintf(stderr, "biokanga_amd: suffix array not in nibble order inside %llu k-mer bucket(s); second-level keys disabled\n", bad);
@@ -293,8 +306,10 @@ int tables_end(bk_ctx *c, TablePlan &tp)
         c->d_k2 = nullptr;
     } else if (tp.k2) {
         launch_build_k2_levels(c->d_k2, c->ix.n, c->stream);
+        if (tp.k3) launch_build_k2_levels(c->d_k3, c->ix.n, c->stream);
         HIP_TRY(hipGetLastError());
         c->ix.k2 = c->d_k2;
+        c->ix.k3 = tp.k3 ? c->d_k3 : nullptr;
         // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
         if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
             const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
@@ -1574,7 +1589,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     int rc = new_ctx(out, device_id, p, &c);
     if (rc) return rc;
     clk.lap("HIP runtime + device + stream");
-    if (flags & BK_CTX_LEAN_IMAGE) c->use_ktab2 = 0;
+    if (flags & BK_CTX_LEAN_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; }
     SfxFile f;
     std::string err;
     rc = sfx_open(sfx_path, f, &err);
@@ -1728,6 +1743,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->ktab64 = src->ktab64;
     c->ktab_is2 = src->ktab_is2;
     c->use_ktab2 = src->use_ktab2;
+    c->use_k3 = src->use_k3;
     c->ktab_bytes = src->ktab_bytes;
     c->nflag_bytes = src->nflag_bytes;
     c->use_ktab = src->use_ktab; c->k_req = src->k_req; c->use_k2 = src->use_k2; c->use_isa = src->use_isa; c->use_wave = src->use_wave; c->use_tgt2 = src->use_tgt2;
@@ -1751,6 +1767,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
     dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
     dup(c->d_k2, src->d_k2, (size_t)k2s_start(n, kK2Levels + 1) * 4);
+    dup(c->d_k3, src->d_k3, (size_t)k2s_start(n, kK2Levels + 1) * 4);
     dup(c->d_isa, src->d_isa, (size_t)n * 4);
     dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
     dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);
@@ -1764,7 +1781,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
         else if (c->ktab_is2) c->ix.ktab2 = (const uint2 *)c->d_ktab;
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
     }
-    c->ix.k2 = c->d_k2; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
+    c->ix.k2 = c->d_k2; c->ix.k3 = c->d_k3; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
     clk.lap("index image copied from the first device");
     rc = setup_entries(c, src->entries.data(), (uint32_t)src->entries.size());
     if (rc) { bk_ctx_destroy(c); return rc; }
@@ -1778,7 +1795,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k3); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
@@ -1880,6 +1897,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_tables(c);
         return rc ? rc : old;
     }
+    if (n == "use_k3") {                   // third-level keys (rebuilt with the tables)
+        int64_t old = c->use_k3;
+        c->use_k3 = value ? 1 : 0;
+        int rc = build_tables(c);
+        return rc ? rc : old;
+    }
+    if (n == "k3_resident") return c->ix.k3 != nullptr;
     if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
         int64_t old = c->use_ktab2;
         c->use_ktab2 = value ? 1 : 0;

@@ -327,8 +327,40 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
         continue;
     }
+    int start = k + kK2Bases;
+    // the next 15 bases from the third-level keys, the way the second-level keys gave theirs (an N among them in the read: not
+    // expressible in 2 bits, the suffix array and the target take over here)
+    const uint64_t p3 = rdw.nib16(my_ofs + start);
+    if (ix.k3 != nullptr && !(p3 & 0x4444444444444444ULL & top_mask(cl - start < kK2Bases ? cl - start : kK2Bases))) {
+        const uint32_t m3 = k2_mask(cl - start);
+        const uint32_t q3 = squeeze2(p3) & m3;
+        uint64_t l1, l2;
+        unsigned long long k3_lines = 0;
+        k2_bounds(ix.k3, s_lv, first, cnt, m3, q3, l1, l2, k3_lines);
+#ifdef BK_DIAG_B
+        d_deep += 1 + (k3_lines << 32);                     // (low word: items that consult the third-level keys; high word: their lines)
+#endif
+        {
+            const int upto = cl < start + kK2Bases ? cl : start + kK2Bases;
+            while (l2 > l1) {
+                const uint32_t kv = ix.k3[l2 - 1];
+                if (!k2_nkind(kv) || cmp_core_from(rdw, my_ofs, upto, start, ix.tgt4, sa_get<WIDE>(ix, l2 - 1)) == 0) break;
+                l2--;
+            }
+        }
+        first = l1;
+        cnt = l2 - l1;
+        start += kK2Bases;
+        if (cnt == 0 || cl <= start) {
+            iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
+            continue;
+        }
+        if (lazy && cnt <= kLazyBucket) {
+            iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
+            continue;
+        }
+    }
     {
-        const int start = k + kK2Bases;
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
