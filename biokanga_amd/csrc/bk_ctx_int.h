@@ -41,7 +41,7 @@ struct bk_ctx {
     uint32_t cap_rd2w = 0;
     int use_tgt2 = 2;        // 0: 4-bit windows only, 1: 2-bit copy, 2: 2-bit copy stored twice (32 bytes apart)
     uint32_t *d_k2 = nullptr;             // second-level search keys (DevIndex::k2)
-    uint32_t *d_k3 = nullptr;             // third-level search keys (DevIndex::k3)
+    uint32_t *d_kx[bk::kMoreKeys] = {nullptr, nullptr};   // third-, fourth-level search keys (DevIndex::kx)
     uint32_t *d_slist = nullptr;          // work list of the two-pass search
     uint32_t *d_sort[3] = {nullptr, nullptr, nullptr};   // keys in, keys out, list out of sort_work
     void *d_sort_tmp = nullptr;
@@ -51,7 +51,7 @@ struct bk_ctx {
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;
-    int use_k3 = 1;          // third-level search keys (DevIndex::k3), where the HBM has the room
+    int use_k3 = bk::kMoreKeys;  // key arrays behind the second-level keys (DevIndex::kx): at most this many, where the HBM has the room
     int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
     bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases

@@ -21,8 +21,8 @@ namespace bk {
 //   pass A (lane per read/strand/core): k-mer table lookup; empty buckets and buckets of <= 16 keys are
 //           finished here, everything else is appended to a work list.
 //   pass B (lane per work item): bisection over k2, then - for cores longer than k+15 bases whose
-//           sub-bucket is not handed on unverified - over k3 (DevIndex::k3, the next 15 bases, when the index has it) and
-//           over suffix array + target from the first base no key holds on.
+//           sub-bucket is not handed on unverified - over the key arrays of the next 15 and the 15 bases after those (DevIndex::kx,
+//           when the index has them) and over suffix array + target from the first base no key holds on.
 // The split keeps the lanes of pass B uniformly busy: in one combined kernel ~70 % of the lanes
 // finished after the table lookup and idled while their wave's longest bisection ran.
 // Work items: the slot index; its iv_first/iv_n entry carries (range start, size | kind << 30).
@@ -132,13 +132,14 @@ __device__ __forceinline__ void k2_bounds(const uint32_t *__restrict__ k2, const
     ub = l2;
 }
 
-// the third-level key of the suffix at pos (DevIndex::k3): bases k + 15 .. k + 29, in the form of the second-level key.  Inside a run
-// of suffixes whose second-level keys are equal and of kind 0 - the only runs it is ever consulted for: an interval that agrees with an
-// N-free core on k + 15 bases - the third-level keys are non-decreasing, for the reasons the second-level keys are inside a bucket.
-__device__ __forceinline__ uint32_t k3_make(const uint64_t *__restrict__ tgt4, uint64_t pos, int k, uint32_t key2)
+// the next key of the suffix at pos (DevIndex::kx): the 15 bases from `from` on (k + 15 for the third-level key, k + 30 for the fourth), in
+// the form of the second-level key; `before` = its key of the level before.  Inside a run of suffixes whose keys of the level before are
+// equal and of kind 0 - the only runs a level is ever consulted for: an interval that agrees with an N-free core on every base before
+// `from` - these keys are non-decreasing, for the reasons the second-level keys are inside a bucket.
+__device__ __forceinline__ uint32_t kx_make(const uint64_t *__restrict__ tgt4, uint64_t pos, int from, uint32_t before)
 {
-    if (key2 == kK2Above || (key2 & 3u) != 0u) return kK2Above;
-    const uint64_t w1 = nib16(tgt4, pos + (uint64_t)(k + kK2Bases));
+    if (before == kK2Above || (before & 3u) != 0u) return kK2Above;
+    const uint64_t w1 = nib16(tgt4, pos + (uint64_t)from);
     const uint64_t bad = w1 & 0x4444444444444440ULL;
     const uint32_t code = squeeze2(w1) & ~3u;
     if (!bad) return code;

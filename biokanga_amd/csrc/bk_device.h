@@ -31,6 +31,7 @@
 namespace bk {
 
 // sampled levels of the second-level keys, stored behind them in the same allocation (bk_dev_k2.h)
+constexpr int kMoreKeys = 2;                        // key arrays behind the second-level keys (DevIndex::kx)
 constexpr int kK2Levels = 7;                        // 16^8 > the largest interval a work item carries (2^kKindShift)
 
 __host__ __device__ __forceinline__ uint64_t k2s_pad(uint64_t words) { return (words + 15) & ~15ULL; }
@@ -100,7 +101,7 @@ struct DevIndex {
     const uint64_t *ktab64;
     const uint2 *ktab2;         // instead of ktab32 when the second-level keys exist: {ktab32[c], k2[ktab32[c]]} - a bucket of one suffix needs no second line
     const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null
-    const uint32_t *k3;         // third-level keys: the 15 bases after those, same form; all ones where k2's kind is not 0; may be null
+    const uint32_t *kx[kMoreKeys];   // third-, fourth-level keys: the 15 bases after those and the 15 after these, same form; all ones where the level before is not of kind 0; null from the first level the index does without
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null
     const uint4 *swin;          // suffix-ordered windows: for every suffix array index i the kSwBases bases of the 2-bit target from
                                 //   sa[i] - kSwPre on, 48 bytes each.  The candidates of a core interval - consecutive suffix array

@@ -60,7 +60,7 @@ void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
 void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -218,7 +218,8 @@ int pick_k(uint64_t n)
 // made range by range: behind the suffix array's upload (bk_ctx_create_ex sends it in slices and these kernels work on a slice while the
 // next crosses PCIe), or in one go.  tables_begin decides and allocates, tables_range enqueues, tables_end checks and publishes.
 struct TablePlan {
-    bool ktab = false, k2 = false, k3 = false, isa = false;
+    bool ktab = false, k2 = false, isa = false;
+    int kx = 0;                                    // key arrays behind the second-level keys (DevIndex::kx)
     int k = 0;
     unsigned long long *d_bad = nullptr;           // places where the second-level keys are not in order inside a bucket; the third-level keys inside a run of equal second-level keys
     ~TablePlan() { free_dev(d_bad); }
@@ -226,9 +227,10 @@ struct TablePlan {
 
 int tables_begin(bk_ctx *c, TablePlan &tp)
 {
-    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k3); free_dev(c->d_isa);
-    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_k3 = nullptr; c->d_isa = nullptr;
-    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.k3 = nullptr; c->ix.isa = nullptr;
+    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_isa);
+    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
+    for (int i = 0; i < kMoreKeys; i++) { free_dev(c->d_kx[i]); c->d_kx[i] = nullptr; c->ix.kx[i] = nullptr; }
+    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
     c->ix.k = 0;
     if (c->use_ktab) {
@@ -255,11 +257,12 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
             HIP_TRY(dev_malloc(&tp.d_bad, 16));
             HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 16, c->stream));
             tp.k2 = true;
-            // third-level keys (the 15 bases after those): as much again, for the cores of more than k + 15 bases - where that leaves
-            // the same reserve, and the context is one for a long run
-            if (c->use_k3 && 2 * need <= free_b && free_b - 2 * need >= total_b / 5) {
-                HIP_TRY(dev_malloc(&c->d_k3, need));
-                tp.k3 = true;
+            // third- and fourth-level keys (the 15 bases after those, and the 15 after these): as much again each, for the cores of
+            // more than k + 15 bases - where that leaves the same reserve, and the context is one for a long run
+            for (int i = 0; i < kMoreKeys && i < c->use_k3; i++) {
+                if ((uint64_t)(2 + i) * need > free_b || free_b - (uint64_t)(2 + i) * need < total_b / 5) break;
+                HIP_TRY(dev_malloc(&c->d_kx[i], need));
+                tp.kx = i + 1;
             }
         }
     }
@@ -277,7 +280,7 @@ int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1, unsig
     ix.k = tp.k;
     const bool last = i1 >= c->ix.n;
     if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1, bucket_starts);
-    if (tp.k2) launch_build_k2(ix, c->d_k2, tp.k3 ? c->d_k3 : nullptr, tp.d_bad, c->stream, i0, i1);
+    if (tp.k2) launch_build_k2(ix, c->d_k2, tp.kx > 0 ? c->d_kx[0] : nullptr, tp.kx > 1 ? c->d_kx[1] : nullptr, tp.d_bad, c->stream, i0, i1);
     if (tp.isa) launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream, i0, i1);
     HIP_TRY(hipGetLastError());
     return BK_OK;
@@ -294,11 +297,10 @@ int tables_end(bk_ctx *c, TablePlan &tp)
         c->ix.k = tp.k;
     }
     const unsigned long long bad = bad2[0];
-    if (tp.k3 && (bad || bad2[1])) {
+    if (tp.kx && (bad || bad2[1])) {
         if (!bad) fprintf(stderr, "biokanga_amd: suffix array not in nibble order at %llu place(s) beyond the second-level keys; third-level keys disabled\n", bad2[1]);
-        free_dev(c->d_k3);
-        c->d_k3 = nullptr;
-        tp.k3 = false;
+        for (int i = 0; i < kMoreKeys; i++) { free_dev(c->d_kx[i]); c->d_kx[i] = nullptr; }
+        tp.kx = 0;
     }
     if (tp.k2 && bad) {
         fprintf(stderr, "biokanga_amd: suffix array not in nibble order inside %llu k-mer bucket(s); second-level keys disabled\n", bad);
@@ -306,10 +308,10 @@ int tables_end(bk_ctx *c, TablePlan &tp)
         c->d_k2 = nullptr;
     } else if (tp.k2) {
         launch_build_k2_levels(c->d_k2, c->ix.n, c->stream);
-        if (tp.k3) launch_build_k2_levels(c->d_k3, c->ix.n, c->stream);
+        for (int i = 0; i < tp.kx; i++) launch_build_k2_levels(c->d_kx[i], c->ix.n, c->stream);
         HIP_TRY(hipGetLastError());
         c->ix.k2 = c->d_k2;
-        c->ix.k3 = tp.k3 ? c->d_k3 : nullptr;
+        for (int i = 0; i < kMoreKeys; i++) c->ix.kx[i] = i < tp.kx ? c->d_kx[i] : nullptr;
         // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
         if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
             const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
@@ -1767,7 +1769,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
     dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
     dup(c->d_k2, src->d_k2, (size_t)k2s_start(n, kK2Levels + 1) * 4);
-    dup(c->d_k3, src->d_k3, (size_t)k2s_start(n, kK2Levels + 1) * 4);
+    for (int i = 0; i < kMoreKeys; i++) dup(c->d_kx[i], src->d_kx[i], (size_t)k2s_start(n, kK2Levels + 1) * 4);
     dup(c->d_isa, src->d_isa, (size_t)n * 4);
     dup(c->d_tgt2, src->d_tgt2, (size_t)nblocks * 16 + 64);
     dup(c->d_tgt2s, src->d_tgt2s, (size_t)nblocks * 16 + 64);
@@ -1781,7 +1783,8 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
         else if (c->ktab_is2) c->ix.ktab2 = (const uint2 *)c->d_ktab;
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
     }
-    c->ix.k2 = c->d_k2; c->ix.k3 = c->d_k3; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
+    for (int i = 0; i < kMoreKeys; i++) c->ix.kx[i] = c->d_kx[i];
+    c->ix.k2 = c->d_k2; c->ix.isa = c->d_isa; c->ix.tgt2 = c->d_tgt2; c->ix.tgt2s = c->d_tgt2s; c->ix.nflag = c->d_nflag;
     clk.lap("index image copied from the first device");
     rc = setup_entries(c, src->entries.data(), (uint32_t)src->entries.size());
     if (rc) { bk_ctx_destroy(c); return rc; }
@@ -1795,7 +1798,7 @@ void bk_ctx_destroy(bk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_k3); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_kx[0]); free_dev(c->d_kx[1]); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);
@@ -1897,13 +1900,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_tables(c);
         return rc ? rc : old;
     }
-    if (n == "use_k3") {                   // third-level keys (rebuilt with the tables)
+    if (n == "use_k3") {                   // how many key arrays behind the second-level keys (rebuilt with the tables)
         int64_t old = c->use_k3;
-        c->use_k3 = value ? 1 : 0;
+        c->use_k3 = value < 0 ? 0 : (value > kMoreKeys ? kMoreKeys : (int)value);
         int rc = build_tables(c);
         return rc ? rc : old;
     }
-    if (n == "k3_resident") return c->ix.k3 != nullptr;
+    if (n == "k3_resident") return (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr);
     if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
         int64_t old = c->use_ktab2;
         c->use_ktab2 = value ? 1 : 0;

@@ -105,13 +105,17 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_
 }
 
 template <bool WIDE>
-__global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2, uint32_t *__restrict__ k3, uint64_t i0, uint64_t i1)
+__global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2, uint32_t *__restrict__ k3, uint32_t *__restrict__ k4, uint64_t i0, uint64_t i1)
 {
     for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t pos = sa_get<WIDE>(ix, i);
         const uint32_t key = k2_make(ix.tgt4, pos, ix.k);
         k2[i] = key;
-        if (k3 != nullptr) k3[i] = k3_make(ix.tgt4, pos, ix.k, key);         // (the same lines of the target, or the next)
+        if (k3 != nullptr) {                                 // (the same lines of the target, or the next)
+            const uint32_t key3 = kx_make(ix.tgt4, pos, ix.k + kK2Bases, key);
+            k3[i] = key3;
+            if (k4 != nullptr) k4[i] = kx_make(ix.tgt4, pos, ix.k + 2 * kK2Bases, key3);
+        }
     }
 }
 
@@ -144,8 +148,14 @@ __global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigne
     for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1 && i + 1 < ix.n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t a = k2[i], c = k2[i + 1];
         if (a < c) continue;
-        // equal second-level keys of kind 0: the third-level keys must be in order - bad[1] counts where they are not
-        if (a == c && (ix.k3 == nullptr || (a & 3u) != 0u || ix.k3[i] <= ix.k3[i + 1])) continue;
+        // equal second-level keys of kind 0: the third-level keys must be in order, and the fourth-level keys where those are equal and
+        // of kind 0 - bad[1] counts where they are not
+        if (a == c) {
+            if ((a & 3u) != 0u || ix.kx[0] == nullptr) continue;
+            const uint32_t a3 = ix.kx[0][i], c3 = ix.kx[0][i + 1];
+            if (a3 < c3) continue;
+            if (a3 == c3 && ((a3 & 3u) != 0u || ix.kx[1] == nullptr || ix.kx[1][i] <= ix.kx[1][i + 1])) continue;
+        }
         if (suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), ix.k) == suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i + 1), ix.k))
             atomicAdd(bad + (a == c ? 1 : 0), 1ULL);
     }
@@ -491,7 +501,7 @@ void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entri
     hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out));
 }
 
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1)
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1)
 {
     if (i1 == 0) i1 = ix.n;
     if (i1 <= i0) return;
@@ -499,14 +509,15 @@ void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, unsigned lo
     if (blocks > 262144) blocks = 262144;
     DevIndex t = ix;
     t.k2 = k2;
-    t.k3 = k3;
+    t.kx[0] = k3;
+    t.kx[1] = k3 ? k4 : nullptr;
     // the order check looks at pairs (i, i + 1): a range checks the pair that straddles its start, and leaves the one at its end to the next
     const uint64_t c0 = i0 ? i0 - 1 : 0, c1 = i1 == ix.n ? i1 : i1 - 1;
     if (ix.sa_hi) {
-        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, i0, i1);
+        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, t.kx[1] ? k4 : nullptr, i0, i1);
         hipLaunchKernelGGL(k_check_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     } else {
-        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, i0, i1);
+        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, t.kx[1] ? k4 : nullptr, i0, i1);
         hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     }
 }

@@ -267,8 +267,10 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
     const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
 #ifdef BK_DIAG_B
-    unsigned long long d_k2 = 0, d_deep = 0, d_empty = 0;
-    struct Fin { unsigned long long &a, &b, &c; DevBatch &bb; __device__ ~Fin() { if (a) atomicAdd(&bb.ctr[ctr_stripe() + 5], a); if (c) atomicAdd(&bb.ctr[ctr_stripe() + 6], c); (void)b; }       /* (slot 6: the deep items' outcome instead of their loads) */ } fin{d_k2, d_deep, d_empty, b};
+    // counted per item kind, low word items, high word 64-byte lines: counter 5 = the bisections over the second- and the third-level
+    // keys (items of both added up), counter 6 = what is left for suffix array + target after them
+    unsigned long long d_k2 = 0, d_deep = 0, d_sa = 0;
+    struct Fin { unsigned long long &a, &b, &c; DevBatch &bb; __device__ ~Fin() { if (a + b) atomicAdd(&bb.ctr[ctr_stripe() + 5], a + b); if (c) atomicAdd(&bb.ctr[ctr_stripe() + 6], c); } } fin{d_k2, d_deep, d_sa, b};
 #endif
     const uint64_t slot = i < n_grouped ? sorted[i] : list[i];
     const uint32_t r = b.act[(uint32_t)(slot % b.iv_stride)], sc = (uint32_t)(slot / b.iv_stride);
@@ -328,22 +330,25 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         continue;
     }
     int start = k + kK2Bases;
-    // the next 15 bases from the third-level keys, the way the second-level keys gave theirs (an N among them in the read: not
-    // expressible in 2 bits, the suffix array and the target take over here)
-    const uint64_t p3 = rdw.nib16(my_ofs + start);
-    if (ix.k3 != nullptr && !(p3 & 0x4444444444444444ULL & top_mask(cl - start < kK2Bases ? cl - start : kK2Bases))) {
+    // the next 15 bases from the third-level keys and the 15 after those from the fourth-level keys, the way the second-level keys gave
+    // theirs (an N among them in the read: not expressible in 2 bits, the suffix array and the target take over there)
+    bool settled = false;
+    for (int lv = 0; lv < kMoreKeys && ix.kx[lv] != nullptr; lv++) {
+        const uint32_t *__restrict__ kx = ix.kx[lv];
+        const uint64_t p3 = rdw.nib16(my_ofs + start);
+        if (p3 & 0x4444444444444444ULL & top_mask(cl - start < kK2Bases ? cl - start : kK2Bases)) break;
         const uint32_t m3 = k2_mask(cl - start);
         const uint32_t q3 = squeeze2(p3) & m3;
         uint64_t l1, l2;
         unsigned long long k3_lines = 0;
-        k2_bounds(ix.k3, s_lv, first, cnt, m3, q3, l1, l2, k3_lines);
+        k2_bounds(kx, s_lv, first, cnt, m3, q3, l1, l2, k3_lines);
 #ifdef BK_DIAG_B
         d_deep += 1 + (k3_lines << 32);                     // (low word: items that consult the third-level keys; high word: their lines)
 #endif
         {
             const int upto = cl < start + kK2Bases ? cl : start + kK2Bases;
             while (l2 > l1) {
-                const uint32_t kv = ix.k3[l2 - 1];
+                const uint32_t kv = kx[l2 - 1];
                 if (!k2_nkind(kv) || cmp_core_from(rdw, my_ofs, upto, start, ix.tgt4, sa_get<WIDE>(ix, l2 - 1)) == 0) break;
                 l2--;
             }
@@ -353,20 +358,23 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         start += kK2Bases;
         if (cnt == 0 || cl <= start) {
             iv_put(b, slot, first, cnt > 0x7FFFFFFFULL ? 0x7FFFFFFFu : (uint32_t)cnt);
-            continue;
+            settled = true;
+            break;
         }
         if (lazy && cnt <= kLazyBucket) {
             iv_put(b, slot, first, (uint32_t)cnt | kLazyFlag);
-            continue;
+            settled = true;
+            break;
         }
     }
+    if (settled) continue;
     {
         uint64_t l1 = first, h1 = first + cnt, l2 = first, h2 = first + cnt;
         while (l1 < h1 || l2 < h2) {
             const bool a1 = l1 < h1, a2 = l2 < h2;
             const uint64_t m1 = l1 + ((h1 - l1) >> 1), m2 = l2 + ((h2 - l2) >> 1);
 #ifdef BK_DIAG_B
-            d_deep += 1 + (1ULL << 32) * (a1 + (a2 && m1 != m2));
+            d_sa += (2ULL << 32) * (a1 + (a2 && m1 != m2));            // (an element of the suffix array and a window of the target per probe)
 #endif
             const uint64_t s1 = a1 ? sa_get<WIDE>(ix, m1) : 0, s2 = a2 ? sa_get<WIDE>(ix, m2) : 0;
             const int c1 = a1 ? cmp_core_from(rdw, my_ofs, cl, start, ix.tgt4, s1) : 0;
@@ -376,11 +384,7 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         }
         first = l1;
 #ifdef BK_DIAG_B
-        {   // deep items, the ones that end empty, the rounds those took (16 bits items | 24 bits empty items | 24 bits rounds of the empty ones - per lane, summed)
-            uint64_t rounds = 0;
-            for (uint64_t q = cnt; q > 0; q >>= 1) rounds++;
-            d_empty += (l2 == l1) ? 1ULL + (rounds << 32) : 0ULL;          // (low word: empty items; high word: the halvings their intervals needed)
-        }
+        d_sa += 1;
 #endif
         cnt = l2 - l1;
     }

@@ -142,8 +142,8 @@ int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_a
  * streaming read; results never depend on it. */
 #define BK_CTX_WINDOW_ARRAY_EAGER 1u
 /* BK_CTX_LEAN_IMAGE: tables that pay only over hundreds of millions of reads are left out - today the k-mer table entries that carry
- * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read) and the third-level
- * search keys ("use_k3": 4 bytes per suffix).  Results never depend on it. */
+ * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read) and the third- and
+ * fourth-level search keys ("use_k3": 4 bytes per suffix each).  Results never depend on it. */
 #define BK_CTX_LEAN_IMAGE 2u
 int  bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags);
 
@@ -183,7 +183,8 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "kmer_bits" (k of the k-mer table, 2..16)   "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)
  *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
  *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
- *   "use_k3" (third-level key array: the 15 bases behind the second-level keys' - 4 bytes per suffix more, where the HBM has the room; read back: "k3_resident")
+ *   "use_k3" (0..2: key arrays of the 15 bases behind the second-level keys' and of the 15 behind those - 4 bytes per suffix each, where the
+ *   HBM has the room; how many there are: "k3_resident")
  *   "sort_lists" (bit 0: search work list grouped by bucket, bit 1: wave list sorted, bit 2: .. longest read first)
  *   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)

@@ -210,8 +210,8 @@ def main():
         for knob, val in (("chunk_reads", int(rng.choice([64 << 20, 7001]))), ("use_wave", int(rng.integers(0, 5) != 0)),
                           ("use_swin", 0), ("swin_budget_kb", int(rng.choice([0, 0, 3, 30, 300]))), ("use_swin", int(rng.choice([0, 1, 2, 2, 3])))):
             al.tune(knob, val)
-        if int(rng.integers(0, 6)) == 0:                 # (the third-level keys of the search: off / on again - the tables are rebuilt)
-            al.tune("use_k3", 1 - al.tune("k3_resident", 0))
+        if int(rng.integers(0, 6)) == 0:                 # (the key arrays behind the second-level keys: none, one, both - the tables are rebuilt)
+            al.tune("use_k3", int(rng.integers(0, 3)))
         packed = bool(rng.integers(0, 2))                # the same reads across the boundary at 2 bit/base
         got = al.align_packed(*bk.pack_reads(bases, offs, lens)) if packed else al.align(bases, offs, lens)
         kw = dict(kw, packed=packed)
