@@ -48,6 +48,7 @@ struct bk_ctx {
     uint64_t cap_sort = 0;
     size_t sort_tmp_bytes = 0;
     int sort_lists = 7;      // bit 0: search work list grouped by index position; bit 1: wave list sorted, by index position or (bit 2) longest read first
+    bool sort_lists_set = false;   // .. as the caller's knob left it; else bit 0 follows the index: off where it has third-level keys (tables_end)
     int sort_shift = 0;      // keys = suffix array index >> sort_shift (fits 32 bits)
     uint64_t cap_slist = 0;
     int use_k2 = 1;

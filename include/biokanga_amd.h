@@ -185,7 +185,8 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
  *   "use_k3" (0..2: key arrays of the 15 bases behind the second-level keys' and of the 15 behind those - 4 bytes per suffix each, where the
  *   HBM has the room; how many there are: "k3_resident")
- *   "sort_lists" (bit 0: search work list grouped by bucket, bit 1: wave list sorted, bit 2: .. longest read first)
+ *   "sort_lists" (bit 0: search work list grouped by bucket - by default only where the index has no third-level keys -, bit 1: wave list
+ *   sorted, bit 2: .. longest read first)
  *   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
  *   "use_swin" (suffix-ordered window array: 0 none - every window from the 2-bit target; 1 for the part of the suffix array the wave kernel's long
