@@ -319,7 +319,7 @@ class Aligner:
             rc = self.lib.bk_ctx_clone(ctypes.byref(self.h), clone_of.h, device)
             what = "bk_ctx_clone"
         elif sfx_path is not None:
-            # flags: BK_CTX_WINDOW_ARRAY_EAGER (1), BK_CTX_LEAN_IMAGE (2) of bk_ctx_create_ex
+            # flags: BK_CTX_WINDOW_ARRAY_EAGER (1), BK_CTX_LEAN_IMAGE (2), BK_CTX_NO_DEEP_KEYS (4), BK_CTX_GROW_IMAGE (8) of bk_ctx_create_ex
             rc = self.lib.bk_ctx_create_ex(ctypes.byref(self.h), os.fsencode(sfx_path), device, ctypes.byref(self.params), int(flags))
             what = f"bk_ctx_create_ex({sfx_path})"
         else:

@@ -1,6 +1,8 @@
 // bk_ctx_int.h - internal: the context behind the C ABI (include/biokanga_amd.h), shared by bk_engine.cpp (batch driver)
 // and bk_stream.cpp (overlapped host <-> device pipeline).  Not part of the boundary.
 #pragma once
+#include <atomic>
+#include <thread>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -53,6 +55,14 @@ struct bk_ctx {
     uint64_t cap_slist = 0;
     int use_k2 = 1;
     int use_k3 = bk::kMoreKeys;  // key arrays behind the second-level keys (DevIndex::kx): at most this many, where the HBM has the room
+    // BK_CTX_GROW_IMAGE: the tables that only pay over long runs (key arrays behind the second-level keys, k-mer table entries with their
+    // bucket's first key) are made by a thread of their own once the context has aligned grow_after reads, and taken in between two batches
+    bool grow_enabled = false;
+    uint64_t grow_after = 1000000000ULL, grow_seen = 0;
+    std::atomic<int> grow_state{0};          // 0 not started, 1 being made, 2 made, 3 nothing made (no room / not in order), 4 taken in
+    std::thread grow_thread;
+    uint32_t *grow_kx[bk::kMoreKeys] = {nullptr, nullptr};
+    void *grow_ktab2 = nullptr;
     int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
     bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases

@@ -60,7 +60,7 @@ void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0);
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, bool write_k2 = true);
 void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s);
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
@@ -225,8 +225,115 @@ struct TablePlan {
     ~TablePlan() { free_dev(d_bad); }
 };
 
+// ------------------------------------------------------------------------------------------------
+// BK_CTX_GROW_IMAGE: a context starts with the image a short job wants and grows the tables that pay over thousands of millions of reads
+// - the key arrays behind the second-level keys, the k-mer table entries that carry their bucket's first key - while it works: a thread
+// of its own allocates and fills them on a stream of its own (they are made of the suffix array, the target and the second-level keys,
+// which the batches under way only read), and the next batch after they are complete takes them in.  Results never depend on which
+// image a batch ran on.
+void grow_worker(bk_ctx *c)
+{
+    int st = 3;
+    hipStream_t s = nullptr;
+    unsigned long long *d_bad = nullptr;
+    do {
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        const uint64_t n = c->ix.n;
+        const uint64_t need = k2s_start(n, kK2Levels + 1) * 4;
+        int nk = 0;
+        if (c->ix.k2 != nullptr && c->ix.kx[0] == nullptr) {
+            for (int i = 0; i < kMoreKeys; i++) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b || free_b - need < total_b / 5) break;
+                if (dev_malloc(&c->grow_kx[i], need) != hipSuccess) { (void)hipGetLastError(); c->grow_kx[i] = nullptr; break; }
+                nk = i + 1;
+            }
+        }
+        if (nk) {
+            unsigned long long bad2[2] = {0, 0};
+            bool ok = dev_malloc(&d_bad, 16) == hipSuccess && hipMemsetAsync(d_bad, 0, 16, s) == hipSuccess;
+            if (ok) {
+                launch_build_k2(c->ix, c->d_k2, c->grow_kx[0], nk > 1 ? c->grow_kx[1] : nullptr, d_bad, s, 0, n, false);
+                ok = hipMemcpyAsync(bad2, d_bad, 16, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && !bad2[0] && !bad2[1];
+            }
+            if (ok) {
+                for (int i = 0; i < nk; i++) launch_build_k2_levels(c->grow_kx[i], n, s);
+                ok = hipStreamSynchronize(s) == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                for (int i = 0; i < kMoreKeys; i++) { free_dev(c->grow_kx[i]); c->grow_kx[i] = nullptr; }
+                nk = 0;
+            }
+        }
+        if (c->ix.k2 != nullptr && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
+            const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&c->grow_ktab2, n_entries * 8) == hipSuccess) {
+                launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, n, c->grow_ktab2, s);
+                if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); free_dev(c->grow_ktab2); c->grow_ktab2 = nullptr; }
+            } else
+                (void)hipGetLastError();
+        }
+        st = (nk || c->grow_ktab2) ? 2 : 3;
+    } while (false);
+    free_dev(d_bad);
+    if (s) (void)hipStreamDestroy(s);
+    c->grow_state.store(st, std::memory_order_release);
+}
+
+// the worker's tables become the context's (between two batches: the device is idle when the k-mer table it replaces is given back)
+void grow_take_in(bk_ctx *c)
+{
+    if (c->grow_thread.joinable()) c->grow_thread.join();
+    if (c->grow_state.load(std::memory_order_acquire) == 2) {
+        for (int i = 0; i < kMoreKeys; i++)
+            if (c->grow_kx[i]) { c->d_kx[i] = c->grow_kx[i]; c->ix.kx[i] = c->grow_kx[i]; c->grow_kx[i] = nullptr; }
+        if (c->ix.kx[0]) c->use_k3 = kMoreKeys;
+        if (c->grow_ktab2) {
+            (void)hipStreamSynchronize(c->stream);
+            free_dev(c->d_ktab);
+            c->d_ktab = c->grow_ktab2;
+            c->grow_ktab2 = nullptr;
+            c->ktab_bytes = (size_t)((1ULL << (2 * c->ix.k)) + 1) * 8;
+            c->ktab_is2 = true;
+            c->use_ktab2 = 1;
+            c->ix.ktab32 = nullptr;
+            c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab);
+        }
+        if (!c->sort_lists_set) c->sort_lists = (c->sort_lists & ~1) | (c->ix.kx[0] == nullptr ? 1 : 0);
+    }
+    c->grow_state.store(4, std::memory_order_release);
+}
+
+// whatever the worker has made is dropped (the tables are about to be rebuilt, or the context ends)
+void grow_drop(bk_ctx *c)
+{
+    if (c->grow_thread.joinable()) c->grow_thread.join();
+    for (int i = 0; i < kMoreKeys; i++) { free_dev(c->grow_kx[i]); c->grow_kx[i] = nullptr; }
+    free_dev(c->grow_ktab2);
+    c->grow_ktab2 = nullptr;
+    if (c->grow_state.load() != 0) c->grow_state.store(4);
+}
+
+// called with every batch: starts the worker once the context has seen enough reads, takes its tables in when they are complete
+void grow_tick(bk_ctx *c, uint64_t nreads, bool now = false)
+{
+    if (!c->grow_enabled) return;
+    const int st = c->grow_state.load(std::memory_order_acquire);
+    if (st == 0) {
+        c->grow_seen += nreads;
+        if ((now || c->grow_seen >= c->grow_after) && c->tables_built && c->ix.k2 != nullptr) {
+            c->grow_state.store(1);
+            c->grow_thread = std::thread(grow_worker, c);
+        }
+    } else if (st == 2 || st == 3)
+        grow_take_in(c);
+}
+
 int tables_begin(bk_ctx *c, TablePlan &tp)
 {
+    grow_drop(c);
     free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_isa);
     c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
     for (int i = 0; i < kMoreKeys; i++) { free_dev(c->d_kx[i]); c->d_kx[i] = nullptr; c->ix.kx[i] = nullptr; }
@@ -1351,6 +1458,7 @@ int take_phase_history(bk_ctx *c, bool wait)
 // nothing back - else BK_ERR_PARAMS, before anything is launched.
 int align_device(bk_ctx *c, const DevReads &in, uint32_t nreads, bk_hit *d_out, hipStream_t s, uint32_t maxlen_known = 0, bool enqueue_only = false)
 {
+    grow_tick(c, nreads);                      // (BK_CTX_GROW_IMAGE: the long-run tables are started, or taken in, between batches)
     const uint32_t *d_lens = in.lens;
     if (enqueue_only) {
         const uint32_t ml = maxlen_known;
@@ -1595,6 +1703,8 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     if (rc) return rc;
     clk.lap("HIP runtime + device + stream");
     if (flags & BK_CTX_LEAN_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; }
+    if (flags & BK_CTX_NO_DEEP_KEYS) c->use_k3 = 0;
+    if (flags & BK_CTX_GROW_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; c->grow_enabled = true; }
     SfxFile f;
     std::string err;
     rc = sfx_open(sfx_path, f, &err);
@@ -1750,6 +1860,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->use_ktab2 = src->use_ktab2;
     c->use_k3 = src->use_k3;
     c->sort_lists = src->sort_lists; c->sort_lists_set = src->sort_lists_set;
+    c->grow_enabled = src->grow_enabled && src->grow_state.load() != 4; c->grow_after = src->grow_after;       // (a clone of a grown context has what it grew)
     c->ktab_bytes = src->ktab_bytes;
     c->nflag_bytes = src->nflag_bytes;
     c->use_ktab = src->use_ktab; c->k_req = src->k_req; c->use_k2 = src->use_k2; c->use_isa = src->use_isa; c->use_wave = src->use_wave; c->use_tgt2 = src->use_tgt2;
@@ -1800,6 +1911,7 @@ void bk_ctx_destroy(bk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    grow_drop(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
     free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_kx[0]); free_dev(c->d_kx[1]); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
@@ -1911,6 +2023,16 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         return rc ? rc : old;
     }
     if (n == "k3_resident") return (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr);
+    if (n == "ktab2_resident") return c->ix.ktab2 != nullptr;
+    if (n == "grow_after_reads") { int64_t old = (int64_t)c->grow_after; if (value > 0) c->grow_after = (uint64_t)value; return old; }
+    if (n == "grow_state") return c->grow_enabled ? c->grow_state.load() : 5;          // (0 .. 4: bk_ctx_int.h; 5: not a growing context)
+    if (n == "image_wait") {               // BK_CTX_GROW_IMAGE: make the long-run tables now if they are not under way, wait for them, take them in
+        if (c->grow_enabled) {
+            grow_tick(c, 0, true);
+            if (c->grow_state.load() != 4 && c->grow_state.load() != 0) grow_take_in(c);
+        }
+        return (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr) + (c->ix.ktab2 != nullptr ? 4 : 0);
+    }
     if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
         int64_t old = c->use_ktab2;
         c->use_ktab2 = value ? 1 : 0;

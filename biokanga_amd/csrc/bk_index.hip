@@ -110,7 +110,7 @@ __global__ void k_build_k2(DevIndex ix, uint32_t *__restrict__ k2, uint32_t *__r
     for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t pos = sa_get<WIDE>(ix, i);
         const uint32_t key = k2_make(ix.tgt4, pos, ix.k);
-        k2[i] = key;
+        if (k2 != nullptr) k2[i] = key;                    // (null: the keys are there already and in use - BK_CTX_GROW_IMAGE adds the arrays behind them)
         if (k3 != nullptr) {                                 // (the same lines of the target, or the next)
             const uint32_t key3 = kx_make(ix.tgt4, pos, ix.k + kK2Bases, key);
             k3[i] = key3;
@@ -501,7 +501,7 @@ void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entri
     hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out));
 }
 
-void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1)
+void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1, bool write_k2)
 {
     if (i1 == 0) i1 = ix.n;
     if (i1 <= i0) return;
@@ -514,10 +514,10 @@ void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k
     // the order check looks at pairs (i, i + 1): a range checks the pair that straddles its start, and leaves the one at its end to the next
     const uint64_t c0 = i0 ? i0 - 1 : 0, c1 = i1 == ix.n ? i1 : i1 - 1;
     if (ix.sa_hi) {
-        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, t.kx[1] ? k4 : nullptr, i0, i1);
+        hipLaunchKernelGGL(k_build_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, write_k2 ? k2 : nullptr, k3, t.kx[1] ? k4 : nullptr, i0, i1);
         hipLaunchKernelGGL(k_check_k2<true>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     } else {
-        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, k3, t.kx[1] ? k4 : nullptr, i0, i1);
+        hipLaunchKernelGGL(k_build_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, write_k2 ? k2 : nullptr, k3, t.kx[1] ? k4 : nullptr, i0, i1);
         hipLaunchKernelGGL(k_check_k2<false>, dim3((unsigned)blocks), dim3(256), 0, s, t, k2, bad, c0, c1);
     }
 }

@@ -347,8 +347,8 @@ int read_align_opts(Args &a, AlignOpts &o)
     return 0;
 }
 
-// Long runs - from this many reads per device on - get the tables that pay only then (k-mer table entries with their bucket's first
-// key: 17 GB more to make for 0.06 ns per read) and larger batches.
+// Long runs - from this many reads per device on - are cut into larger batches.  (The tables that only pay over long runs are grown in
+// the background by the library itself: BK_CTX_GROW_IMAGE, below.)
 constexpr unsigned long long kLongRunMinReads = 600000000ULL;
 // The suffix-ordered window array holds the part of the suffix array the wave kernel's long walks visit (a sixth of a 3.1 Gbp index,
 // 25 GB) and is made behind the suffix array's upload (BK_CTX_WINDOW_ARRAY_EAGER), slice by slice while the next slice crosses PCIe:
@@ -809,7 +809,7 @@ int cmd_align(int argc, char **argv, int first)
         {"mode", "m"}, {"alignstrand", "Q"}, {"editdelta", "e"}, {"substitutions", "s"}, {"maxns", "n"}, {"trim5", "y"},
         {"trim3", "Y"}, {"minacceptreadlen", "l"}, {"maxacceptreadlen", "L"}, {"format", "M"}, {"in", "i"}, {"sfx", "I"},
         {"out", "o"}, {"stats", "O"}, {"threads", "T"}, {"log", "F"}, {"FileLogLevel", "f"}, {"pemode", "U"}, {"mlmode", "r"},
-        {"quality", "g"}, {"device", "device"}, {"devices", "devices"}, {"window-array", "window-array"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
+        {"quality", "g"}, {"device", "device"}, {"devices", "devices"}, {"window-array", "window-array"}, {"index-image", "index-image"}, {"rptsamseqsthres", "4"}, {"pair", "u"}, {"pairminlen", "d"}, {"pairmaxlen", "D"},
         {"pairstrand", "E"}, {"nonealign", "j"}, {"multialign", "J"}, {"title", "t"}, {"maxmulti", "R"}, {"clampmaxmulti", "X"},
         {"bestmatches", "N"}, {"microindellen", "a"}, {"minflankexacts", "x"}, {"splicejunctlen", "A"}, {"minchimeric", "c"}, {"pcrwin", "k"}, {"samplenthrawread", "#"}, {"chromexclude", "Z"}, {"chromeinclude", "z"},
         {"minsnpreads", "p"}, {"qvalue", "P"}, {"snpnonrefpcnt", "1"}, {"snpfile", "S"}, {"markerlen", "K"}, {"markerpolythres", "G"}, {"snpcentroid", "7"}};
@@ -819,7 +819,7 @@ int cmd_align(int argc, char **argv, int first)
     }
     if (!a.has("i") || !a.has("I") || !a.has("o")) {
         fprintf(stderr, "usage: %s align -i <reads> -I <genome.sfx> -o <out.sam> [-s subs] [-e delta] [-Q strand] [-m mode] [-n maxNs] "
-                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats] [--device n | --devices a-b] [--window-array on|off]\n", g_proc.c_str());
+                        "[-l minlen] [-L maxlen] [-M 0|5|6] [-O stats] [--device n | --devices a-b] [--window-array on|off] [--index-image lean|full]\n", g_proc.c_str());
         return 1;
     }
     if (a.has("F")) g_logfile = fopen(a.str("F").c_str(), "a");
@@ -873,8 +873,14 @@ int cmd_align(int argc, char **argv, int first)
     const std::string wa = a.has("window-array") ? a.str("window-array") : std::string();
     const bool wa_off = wa == "off" || wa == "0" || wa == "no";
     const bool want_array = !wa_off && (!wa.empty() || est_reads / ndev >= kWindowArrayMinReads);
+    // The tables that only pay over long runs - k-mer table entries with their bucket's first key, third- and fourth-level search keys:
+    // 43 GB more at 3.1 Gbp, 3 s more before the first batch when they are made up front (round 5, `tools/e2e_cli.py`: T_e2e of 50 M reads
+    // 6.0 s against 3.2 s) for 0.18 ns per read - are made in the background once a device has aligned a thousand million reads
+    // (BK_CTX_GROW_IMAGE); --index-image lean | full overrides: never, or up front
+    const std::string img = a.has("index-image") ? a.str("index-image") : std::string();
+    const uint32_t img_flags = img == "full" ? 0u : (img == "lean" ? BK_CTX_LEAN_IMAGE : BK_CTX_GROW_IMAGE);
     loaders.emplace_back([&]() {
-        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, (want_array ? BK_CTX_WINDOW_ARRAY_EAGER : 0u) | (long_run ? 0u : BK_CTX_LEAN_IMAGE));
+        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, (want_array ? BK_CTX_WINDOW_ARRAY_EAGER : 0u) | img_flags);
         if (ctx_rc[0] || ndev == 1) return;
         std::vector<std::thread> cloners;
         for (size_t d = 1; d < ndev; d++) cloners.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_clone(&ctxs[d], ctxs[0], o.devices[d]); });

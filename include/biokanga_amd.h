@@ -145,6 +145,16 @@ int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_a
  * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read) and the third- and
  * fourth-level search keys ("use_k3": 4 bytes per suffix each).  Results never depend on it. */
 #define BK_CTX_LEAN_IMAGE 2u
+/* BK_CTX_NO_DEEP_KEYS: the third- and fourth-level search keys alone are left out (8 bytes per suffix: 26 GB at 3.1 Gbp, 0.4 s to allocate
+ * on a fresh process, for 0.12 ns per read of a hundred bases - they pay from three or four thousand million reads per device on, or in
+ * a service that keeps its context).  Results never depend on it. */
+#define BK_CTX_NO_DEEP_KEYS 4u
+/* BK_CTX_GROW_IMAGE: the context starts with the lean image and makes the tables BK_CTX_LEAN_IMAGE leaves out in the background once it has
+ * aligned a thousand million reads (tuning knob "grow_after_reads"): a thread of its own allocates and fills them on a stream of its own -
+ * 3 s beside the batches under way on a 3.1 Gbp index, where making them up front delays the first batch by as much - and the next batch
+ * after they are complete takes them in.  "image_wait" makes them at once and waits (benchmarks that measure the grown image).  Results
+ * never depend on it. */
+#define BK_CTX_GROW_IMAGE 8u
 int  bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags);
 
 /* Same, from an index image already resident in HBM (synthetic benchmarks, GPU-built indexes):
@@ -183,6 +193,8 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "kmer_bits" (k of the k-mer table, 2..16)   "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)
  *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
  *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
+ *   "grow_after_reads" / "grow_state" / "image_wait" (BK_CTX_GROW_IMAGE: the reads after which the long-run tables are made; 0 not started, 1 being
+ *   made, 2 made, 3 nothing made, 4 taken in, 5 not a growing context; make them now and wait: returns key arrays + 4 if the k-mer table carries keys)
  *   "use_k3" (0..2: key arrays of the 15 bases behind the second-level keys' and of the 15 behind those - 4 bytes per suffix each, where the
  *   HBM has the room; how many there are: "k3_resident")
  *   "sort_lists" (bit 0: search work list grouped by bucket - by default only where the index has no third-level keys -, bit 1: wave list
