@@ -30,6 +30,6 @@ python3 tools/summarize_prof.py pmc $raw/calib > $out/${tag}_fetch_calibration.c
 grep calib: $raw/calib.log >> $out/${tag}_fetch_calibration.csv
 
 # a plain run for the bench line without profiler overhead, with the CPU baseline
-python3 bench.py > $out/${tag}_bench_line.json 2> $raw/bench.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_line.json 2> $raw/bench.log      # (the driver's command)
 tail -2 $raw/bench.log
 cat $out/${tag}_kernel_stats.csv
