@@ -54,6 +54,21 @@ struct WaveCoreInfo {
 #ifndef BK_WAVE8_BLOCKS
 #define BK_WAVE8_BLOCKS 8
 #endif
+#if defined(BK_PROF) && BK_PROF == 3
+// where a wave's cycles go (lane 0 of every wave; sums over the launch): 0 claiming an item and its read's plan, 1 a strand pass's set-up
+// (read row, interval records, window array map), 2 a core's set-up, 3 the rounds, 4 a read's end; 5 = strand passes, 6 = rounds
+static __device__ unsigned long long g_wprof[64 * 8];
+#define WPROF_DECL long long wp_last = clock64(); unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WPROF(k) do { const long long now_ = clock64(); wp[k] += (unsigned long long)(now_ - wp_last); wp_last = now_; } while (0)
+#define WPROF_N(k) wp[k]++
+#define WPROF_END do { if (lane == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_wprof[(blockIdx.x & 63) * 8 + k_], wp[k_]); } while (0)
+#else
+#define WPROF_DECL do { } while (0)
+#define WPROF(k) do { } while (0)
+#define WPROF_N(k) do { } while (0)
+#define WPROF_END do { } while (0)
+#endif
+
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
 __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
@@ -115,6 +130,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
     };
     int geo_len = -1, geo_mm = 0, geo_cl = 1, geo_cd = 1, geo_nc = 0;      // geometry of the reads of length geo_len in this phase
     ReadPlan geo_p{};
+    WPROF_DECL;
     for (;;) {
         if (grab_left == 0) {
             uint32_t g = 0;
@@ -170,6 +186,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
         // windows from three-word entries only
         const bool sw_read = SW && E == 3 && len <= SwGeo<E>::bases - SwGeo<E>::pre && len - cl <= SwGeo<E>::pre;
         for (int st = s0; st <= s1 && !done; st++) {
+            WPROF(st == s0 ? 0 : 2);
+            WPROF_N(5);
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
                 if (lset_n) {
                     for (uint32_t i = lane; i < kLdsSet; i += 64) lset[i] = kLdsEmpty;
@@ -254,6 +272,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 pre_ex = v - own;
             }
             uint32_t nodes = 0;
+            WPROF(1);
             for (int c = 0; c < nc && !done && nodes < kNodeCap;) {
                 // (every lane reads the same LDS words: told so, the compiler keeps them and what follows from them in scalar registers)
                 const uint64_t first = uniform64(core[c].first);
@@ -306,7 +325,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 const bool sw_core = SW && ((GROUP && grouped) ? (sw_read && grp_sw) : (ofs <= SwGeo<E>::pre && len - ofs <= SwGeo<E>::bases - SwGeo<E>::pre && sw_n_c != 0));
                 // the entry's 16-byte words (64 bases each) the window lies in; a shared round's cores differ in it: every word
                 const int sw_q0 = (GROUP && grouped) ? 0 : (SwGeo<E>::pre - ofs) >> 6, sw_q1 = (GROUP && grouped) ? E - 1 : (SwGeo<E>::pre - ofs + len - 1) >> 6;
+                WPROF(2);
                 for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
+                    WPROF_N(6);
                     const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
                     const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
                     // (a round takes its windows from the array when every candidate of it has its entry there)
@@ -500,11 +521,13 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     if (!(GROUP && grouped) && cutoff < j0 + 64) { walked = cutoff; break; }
 #pragma clang diagnostic pop
                 }
+                WPROF(3);
                 if (!(GROUP && grouped) && lane == 0) core[c].walked = walked;
                 __builtin_amdgcn_wave_barrier();
                 c = ce;
             }
         }
+        WPROF(2);
         int rslt = classify(low_inst, low_mm, nxt, init, cfg.mm_delta, cfg.max_hits);      // wave-uniform
         if (rslt != BK_HR_NONE) {
             int e = -1;
@@ -526,7 +549,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
             if (++pend_n == 64) flush_pending();
         }
         __builtin_amdgcn_wave_barrier();
+        WPROF(4);
     }
+    WPROF_END;
     if (HASH && lane == 0) hs.slot_epoch[wave_slot] = epoch;
     if (pend_n) flush_pending();
     if (lane == 0 && cmax_loc) atomicMax(cmax_next, cmax_loc);
@@ -647,5 +672,15 @@ extern "C" int bk_debug_cand_hist(int op, void *out, unsigned long long n)
     if (op == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::g_hist_len), 3 * 40 * 8) != hipSuccess;
     if (op == 4) return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::g_hist_ph), 8 * 40 * 2 * 8) != hipSuccess;
     return 1;
+}
+#endif
+
+#if defined(BK_PROF) && BK_PROF == 3
+extern "C" int bk_debug_prof_wave(unsigned long long *out8)
+{
+    unsigned long long h[64 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bk::g_wprof), sizeof(h)) != hipSuccess) return 1;
+    for (int k = 0; k < 8; k++) { out8[k] = 0; for (int q = 0; q < 64; q++) out8[k] += h[q * 8 + k]; }
+    return 0;
 }
 #endif
