@@ -298,13 +298,10 @@ __global__ void __launch_bounds__(256) k_search_b(DevIndex ix, DevAlignCfg cfg, 
         const uint32_t q2 = squeeze2(rdw.nib16(my_ofs + k)) & m;
         // lower and upper bound through the sampled levels: a line per level and bound (bk_dev_k2.h)
         uint64_t l1, l2;
+        unsigned long long k2_lines = 0;                    // (counted by -DBK_DIAG_B builds only)
+        k2_bounds(ix.k2, s_lv, first, cnt, m, q2, l1, l2, k2_lines);
 #ifdef BK_DIAG_B
-        unsigned long long k2_lines = 0;
-        k2_bounds(ix.k2, s_lv, first, cnt, m, q2, l1, l2, k2_lines);
         d_k2 += 1 + (k2_lines << 32);                       // (low word: items of this kind; high word: their lines)
-#else
-        unsigned long long k2_lines = 0;
-        k2_bounds(ix.k2, s_lv, first, cnt, m, q2, l1, l2, k2_lines);
 #endif
         // keys of the N kind at the end of the run of equal keys may be there for their fill only: the target decides
         {
