@@ -857,6 +857,14 @@ def main():
             lean_image = {"value_kernel_only": args.reads * args.steps / dt, "ms_per_step_kernel_only": 1e3 * dt / args.steps,
                           "device_ms_per_step": {k: round(tl[k] / args.steps, 2) for k in ("ms_total", "ms_search", "ms_search_a", "ms_search_b", "ms_extend", "ms_heavy")},
                           "results_bit_identical_to_the_headline_image": bool(np.array_equal(main_leg["hits"].view(np.uint8), out.cpu().numpy()))}
+            if host is not None:
+                try:
+                    hl = host.run(al, args.warmup, args.steps, barrier, None, dev, pe_params)
+                    lean_image["value_host_in_host_out"] = hl.get("value")
+                    lean_image["host_results_bit_identical"] = host.same_as(main_leg["hits"], args.steps)
+                except Exception as e:
+                    lean_image["value_host_in_host_out"] = None
+                    lean_image["host_error"] = repr(e)
         except Exception as e:       # reporting only
             lean_image = {"value_kernel_only": None, "error": repr(e)}
         al.tune("use_ktab2", 1)
