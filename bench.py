@@ -1002,6 +1002,8 @@ def main():
                                f"{len(seq_lens)} sequences ({int(100 * cfg.get('repeat_frac', 0.45))}% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
                    "window_array": headline + (f" (what `biokanga align` picks for the {job_reads} reads a device aligns in this configuration: the partial suffix-ordered "
                                     f"window array from {CLI_WINDOW_ARRAY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
+                   "index_image": "grown (k-mer table entries with first keys, third- and fourth-level search keys): the image a context holds after a thousand million "
+                                  "reads; the lean image every `biokanga align` job starts with is measured beside it (index_image.lean)",
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
                    "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",
