@@ -57,7 +57,7 @@ struct bk_ctx {
     int use_k3 = bk::kMoreKeys;  // key arrays behind the second-level keys (DevIndex::kx): at most this many, where the HBM has the room
     // BK_CTX_GROW_IMAGE: the tables that only pay over long runs (key arrays behind the second-level keys, k-mer table entries with their
     // bucket's first key) are made by a thread of their own once the context has aligned grow_after reads, and taken in between two batches
-    bool grow_enabled = false;
+    bool grow_enabled = false, grow_wait = false;
     uint64_t grow_after = 1000000000ULL, grow_seen = 0;
     std::atomic<int> grow_state{0};          // 0 not started, 1 being made, 2 made, 3 nothing made (no room / not in order), 4 taken in
     std::thread grow_thread;

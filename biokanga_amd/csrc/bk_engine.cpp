@@ -302,6 +302,9 @@ void grow_take_in(bk_ctx *c)
             c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab);
         }
         if (!c->sort_lists_set) c->sort_lists = (c->sort_lists & ~1) | (c->ix.kx[0] == nullptr ? 1 : 0);
+        if (getenv("BK_TIMING"))
+            fprintf(stderr, "biokanga_amd: long-run tables taken in after %llu reads: %d key array(s) behind the second-level keys%s\n",
+                    (unsigned long long)c->grow_seen, (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr), c->ix.ktab2 ? ", first keys in the k-mer table" : "");
     }
     c->grow_state.store(4, std::memory_order_release);
 }
@@ -321,13 +324,14 @@ void grow_tick(bk_ctx *c, uint64_t nreads, bool now = false)
 {
     if (!c->grow_enabled) return;
     const int st = c->grow_state.load(std::memory_order_acquire);
+    if (st != 0 && st != 4) c->grow_seen += nreads;
     if (st == 0) {
         c->grow_seen += nreads;
         if ((now || c->grow_seen >= c->grow_after) && c->tables_built && c->ix.k2 != nullptr) {
             c->grow_state.store(1);
             c->grow_thread = std::thread(grow_worker, c);
         }
-    } else if (st == 2 || st == 3)
+    } else if (st == 2 || st == 3 || (st == 1 && c->grow_wait))
         grow_take_in(c);
 }
 
@@ -1704,7 +1708,11 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     clk.lap("HIP runtime + device + stream");
     if (flags & BK_CTX_LEAN_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; }
     if (flags & BK_CTX_NO_DEEP_KEYS) c->use_k3 = 0;
-    if (flags & BK_CTX_GROW_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; c->grow_enabled = true; }
+    if (flags & BK_CTX_GROW_IMAGE) {
+        c->use_ktab2 = 0; c->use_k3 = 0; c->grow_enabled = true;
+        // (tests: a small run that grows - and, so that it does before it is over, waits for the tables at the batch after the one that started them)
+        if (const char *e = getenv("BK_GROW_AFTER_READS")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) { c->grow_after = v; c->grow_wait = true; } }
+    }
     SfxFile f;
     std::string err;
     rc = sfx_open(sfx_path, f, &err);

@@ -152,8 +152,9 @@ int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_a
 /* BK_CTX_GROW_IMAGE: the context starts with the lean image and makes the tables BK_CTX_LEAN_IMAGE leaves out in the background once it has
  * aligned a thousand million reads (tuning knob "grow_after_reads"): a thread of its own allocates and fills them on a stream of its own -
  * 3 s beside the batches under way on a 3.1 Gbp index, where making them up front delays the first batch by as much - and the next batch
- * after they are complete takes them in.  "image_wait" makes them at once and waits (benchmarks that measure the grown image).  Results
- * never depend on it. */
+ * after they are complete takes them in.  "image_wait" makes them at once and waits (benchmarks that measure the grown image); the
+ * environment's BK_GROW_AFTER_READS=<n> sets the threshold of every context created with the flag and makes the batch after the one
+ * that started the worker wait for it (tests: a small run that grows).  Results never depend on it. */
 #define BK_CTX_GROW_IMAGE 8u
 int  bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags);
 

@@ -65,6 +65,13 @@ def test_c1_through_both_command_lines(tmp_path):
     assert a == b, "SAM differs"
     n_acc = sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"@") and ln.split(b"\t")[1] in (b"0", b"16"))
     assert n_acc > 0.99 * n_reads
+    # the same run with the long-run tables made by the library's worker thread after the first batch's reads and taken in by a later one
+    sam2 = str(tmp_path / "ours_grown.sam")
+    r3 = subprocess.run([ours, "align", "-i", rd, "-I", out["ours"][0], "-o", sam2, "-s0", "-M6"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                        env=dict(os.environ, BK_GROW_AFTER_READS="1", BK_TIMING="1"))
+    assert r3.returncode == 0, r3.stderr[-800:]
+    assert "long-run tables taken in" in r3.stderr, r3.stderr[-1500:]
+    assert open(sam2, "rb").read() == b, "SAM differs when the image grows between batches"
     bk = _bk()
     with bk.Aligner(out["ours"][0], bk.AlignParams(max_subs=0)) as al:
         assert al.min_core_len == 9
