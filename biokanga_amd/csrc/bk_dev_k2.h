@@ -35,6 +35,16 @@ constexpr uint32_t kInlineBucket = 16;
 constexpr int kK2Bases = 15;
 constexpr uint32_t kK2Above = 0xFFFFFFFFu;
 
+// DevIndex::ktab2's word of a bucket of two or more suffixes (k_make_ktab2): does no key of the bucket agree with the probe on the bits
+// the mask keeps of the first five behind the k-mer?  (A mask that keeps fewer asks for any of the values they leave open.)
+constexpr uint64_t kTab2BitmapMax = 64;
+__device__ __forceinline__ bool ktab2_absent(uint32_t bitmap, uint32_t m, uint32_t q2)
+{
+    const uint32_t m5 = m >> 27, lo5 = (q2 >> 27) & m5, hi5 = lo5 | (~m5 & 31u);
+    const uint32_t upto = hi5 == 31u ? 0xFFFFFFFFu : (1u << (hi5 + 1)) - 1u;
+    return (bitmap & upto & ~((1u << lo5) - 1u)) == 0u;
+}
+
 // -1 / 0 / +1: key (masked to the core's bases) vs probe; the all-ones key sorts above everything
 __device__ __forceinline__ int k2_cmp(uint32_t key, uint32_t m, uint32_t q2)
 {

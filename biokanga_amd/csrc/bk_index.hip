@@ -486,13 +486,25 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
     hipLaunchKernelGGL(k_pack_target2, dim3((unsigned)blocks), dim3(256), 0, s, tgt4, nwords4, tgt2, nflag32, flag_shift);
 }
 
-// k-mer table entries {bucket start, second-level key of the bucket's first suffix} (DevIndex::ktab2)
+// k-mer table entries {bucket start, y} (DevIndex::ktab2).  y of a bucket of one suffix: its second-level key - the line that names the
+// bucket settles the search.  y of a larger bucket: which values the first five bits behind the k-mer take among its keys (bit v set:
+// some suffix of the bucket continues with v; keys of suffixes with an N / sequence end inside the k-mer match nothing and set nothing) -
+// a probe whose own five bits find no bit set has an empty interval, and the key line is not fetched to learn it (ktab2_absent)
 __global__ void __launch_bounds__(256) k_make_ktab2(const uint32_t *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries, uint64_t n,
                                                     uint2 *__restrict__ out)
 {
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t lo = tab[c];
-        out[c] = make_uint2(lo, lo < n ? k2[lo] : 0u);
+        const uint64_t hi = c + 1 < n_entries ? (uint64_t)tab[c + 1] : (uint64_t)lo;
+        uint32_t y = 0u;
+        if (hi == (uint64_t)lo + 1) y = k2[lo];
+        else if (hi > (uint64_t)lo + kTab2BitmapMax) y = 0xFFFFFFFFu;           // (a bucket this large has every bit set, or as good as)
+        else
+            for (uint64_t i = lo; i < hi; i++) {
+                const uint32_t key = k2[i];
+                if (key != kK2Above) y |= 1u << (key >> 27);
+            }
+        out[c] = make_uint2(lo, y);
     }
 }
 

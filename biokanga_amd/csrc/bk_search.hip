@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 // {bucket start, second-level key of its first suffix}: a bucket of one - every second one a read of a unique region
                 // meets, and a third of those its other strand runs into by chance - is settled by the line that names it
                 const uint2 e0 = ix.ktab2[code], e1 = ix.ktab2[code + 1];
-                lo[u] = e0.x; hi[u] = e1.x; key0[u] = e0.y;
+                lo[u] = e0.x; hi[u] = e1.x; key0[u] = e0.y;             // (a bucket of one: its key; a larger one: the map of its keys' first five bits)
             } else {
                 lo[u] = ktab_get(ix, code);
                 hi[u] = ktab_get(ix, code + 1);
@@ -165,12 +165,15 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     // (a lane loads the keys its bucket has - one to three for most - and no more: this kernel lives on the rate at which the
     // texture path takes lane requests, and sixteen keys for every lane cost a third more time than the search saved)
     uint32_t key[ILP][kInlineBucket];
+    bool absent[ILP];                   // the table's line says that no key of the bucket continues the way the core does
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const uint64_t size = hi[u] - lo[u];
+        const uint32_t m = k2_mask(cl[u] - k);
+        absent[u] = have_code[u] && ix.ktab2 != nullptr && size >= 2 && ktab2_absent(key0[u], m, q2raw[u] & m);
 #pragma unroll
         for (uint32_t j = 0; j < kInlineBucket; j++)
-            key[u][j] = (have_code[u] && size <= kInlineBucket && j < size) ? ((j == 0 && ix.ktab2 != nullptr) ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
+            key[u][j] = (have_code[u] && !absent[u] && size <= kInlineBucket && j < size) ? ((size == 1 && ix.ktab2 != nullptr) ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
     }
     PROFS(2);
     // stage 4: results
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
         }
         if (have_code[u]) {
             const uint64_t size = hi[u] - lo[u];
-            if (size == 0) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
+            if (size == 0 || absent[u]) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
             else if (size <= kInlineBucket) {
                 const uint32_t m = k2_mask(cl[u] - k), q2 = q2raw[u] & m;
                 uint32_t lb = 0, ub = 0;
