@@ -63,6 +63,8 @@ struct bk_ctx {
     std::thread grow_thread;
     uint32_t *grow_kx[bk::kMoreKeys] = {nullptr, nullptr};
     void *grow_ktab2 = nullptr;
+    bk::DevIndex grow_ix{};                  // the index as it was when the worker started (its own copy: the batches' thread goes on changing ix - the window array)
+    bool grow_want_ktab2 = false;
     int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
     bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases

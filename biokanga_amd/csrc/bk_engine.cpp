@@ -238,10 +238,11 @@ void grow_worker(bk_ctx *c)
     unsigned long long *d_bad = nullptr;
     do {
         if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
-        const uint64_t n = c->ix.n;
+        const DevIndex &ix = c->grow_ix;             // (set by the thread that started this one, before it did)
+        const uint64_t n = ix.n;
         const uint64_t need = k2s_start(n, kK2Levels + 1) * 4;
         int nk = 0;
-        if (c->ix.k2 != nullptr && c->ix.kx[0] == nullptr) {
+        if (ix.k2 != nullptr && ix.kx[0] == nullptr) {
             for (int i = 0; i < kMoreKeys; i++) {
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b || free_b - need < total_b / 5) break;
@@ -253,7 +254,7 @@ void grow_worker(bk_ctx *c)
             unsigned long long bad2[2] = {0, 0};
             bool ok = dev_malloc(&d_bad, 16) == hipSuccess && hipMemsetAsync(d_bad, 0, 16, s) == hipSuccess;
             if (ok) {
-                launch_build_k2(c->ix, c->d_k2, c->grow_kx[0], nk > 1 ? c->grow_kx[1] : nullptr, d_bad, s, 0, n, false);
+                launch_build_k2(ix, const_cast<uint32_t *>(ix.k2), c->grow_kx[0], nk > 1 ? c->grow_kx[1] : nullptr, d_bad, s, 0, n, false);
                 ok = hipMemcpyAsync(bad2, d_bad, 16, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && !bad2[0] && !bad2[1];
             }
             if (ok) {
@@ -266,11 +267,11 @@ void grow_worker(bk_ctx *c)
                 nk = 0;
             }
         }
-        if (c->ix.k2 != nullptr && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
-            const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
+        if (c->grow_want_ktab2 && ix.k2 != nullptr && ix.ktab32 != nullptr) {
+            const uint64_t n_entries = (1ULL << (2 * ix.k)) + 1;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&c->grow_ktab2, n_entries * 8) == hipSuccess) {
-                launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, n, c->grow_ktab2, s);
+                launch_make_ktab2(ix.ktab32, ix.k2, n_entries, n, c->grow_ktab2, s);
                 if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); free_dev(c->grow_ktab2); c->grow_ktab2 = nullptr; }
             } else
                 (void)hipGetLastError();
@@ -328,6 +329,8 @@ void grow_tick(bk_ctx *c, uint64_t nreads, bool now = false)
     if (st == 0) {
         c->grow_seen += nreads;
         if ((now || c->grow_seen >= c->grow_after) && c->tables_built && c->ix.k2 != nullptr) {
+            c->grow_ix = c->ix;
+            c->grow_want_ktab2 = !c->ktab64 && !c->ktab_is2;
             c->grow_state.store(1);
             c->grow_thread = std::thread(grow_worker, c);
         }
