@@ -6,7 +6,7 @@ kernels for gfx950 + C++ host code, see include/biokanga_amd.h) and the C++ comm
 bench.py: a ctypes binding of the C ABI.  There is no CPU fallback anywhere - if the library is
 missing, or no HIP device is present, calls fail loudly.
 """
-from .binding import (Aligner, AlignParams, PEParams, HIT_DTYPE, LOCI_DTYPE, LOCI_TRIMS_DTYPE, SEG2_DTYPE, SNP_ALN_DTYPE, SNP_SITE_DTYPE, ENTRY_DTYPE, BkError, lib_path, load_library,
+from .binding import (Aligner, AlignParams, PEParams, CTX_WINDOW_ARRAY_EAGER, CTX_LEAN_IMAGE, CTX_NO_DEEP_KEYS, CTX_GROW_IMAGE, HIT_DTYPE, LOCI_DTYPE, LOCI_TRIMS_DTYPE, SEG2_DTYPE, SNP_ALN_DTYPE, SNP_SITE_DTYPE, ENTRY_DTYPE, BkError, lib_path, load_library,
                       device_count, build_sa_device, NAR_TAGS, Stream, host_array, seq_counts_allreduce, pack_reads, NBASE_DTYPE)
 
 __all__ = ["Aligner", "AlignParams", "PEParams", "HIT_DTYPE", "LOCI_DTYPE", "LOCI_TRIMS_DTYPE", "SEG2_DTYPE", "SNP_ALN_DTYPE", "SNP_SITE_DTYPE", "ENTRY_DTYPE", "BkError", "lib_path", "load_library",

@@ -48,6 +48,9 @@ class AlignParams(ctypes.Structure):
         self.pmode, self.max_ns, self.max_ml = pmode, max_ns, max_ml
 
 
+# flags of bk_ctx_create_ex (include/biokanga_amd.h)
+CTX_WINDOW_ARRAY_EAGER, CTX_LEAN_IMAGE, CTX_NO_DEEP_KEYS, CTX_GROW_IMAGE = 1, 2, 4, 8
+
 HIT_DTYPE = np.dtype([("chrom_id", "<u4"), ("match_loci", "<u4"), ("match_len", "<u2"),
                       ("low_hit_instances", "<i2"), ("rslt", "u1"), ("nar", "u1"), ("strand", "u1"),
                       ("low_mm", "i1"), ("nxt_low_mm", "i1"), ("num_hits", "u1"),

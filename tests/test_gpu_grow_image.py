@@ -14,7 +14,6 @@ from test_gpu_window_array import _family_genome, _index, _same  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-BK_CTX_LEAN_IMAGE, BK_CTX_GROW_IMAGE = 2, 8
 
 
 def _bk():
@@ -41,7 +40,7 @@ def test_image_grows_between_batches(tmp_path):
         _same(got, exp, what)
         assert (ctr["n_search"], ctr["n_cand"], ctr["n_lcm_calls"]) == (octr.n_search, octr.n_cand, octr.n_lcm_calls), what
 
-    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=BK_CTX_GROW_IMAGE) as al:
+    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=_bk().CTX_GROW_IMAGE) as al:
         assert al.tune("grow_state", 0) == 0 and al.tune("k3_resident", 0) == 0 and al.tune("ktab2_resident", 0) == 0
         al.tune("grow_after_reads", 3 * nreads)
         check(al, "lean image, first batch")
@@ -62,15 +61,15 @@ def test_image_grows_between_batches(tmp_path):
             al.tune(*kv)
         check(al, "grown image, window array, every read through the wave kernel")
     # asked for at once; a knob that rebuilds the tables while the worker runs
-    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=BK_CTX_GROW_IMAGE) as al:
+    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=_bk().CTX_GROW_IMAGE) as al:
         assert al.tune("image_wait", 0) == 2 + 4
         check(al, "image_wait")
-    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=BK_CTX_GROW_IMAGE) as al:
+    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=_bk().CTX_GROW_IMAGE) as al:
         al.tune("grow_after_reads", 1)
         check(al, "starts the worker")
         al.tune("kmer_bits", 9)                        # (the tables are made again: what the worker made is dropped)
         assert al.tune("k3_resident", 0) == 0
         check(al, "tables rebuilt under the worker")
-    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=BK_CTX_LEAN_IMAGE) as al:
+    with bk.Aligner(path, bk.AlignParams(max_subs=3), flags=_bk().CTX_LEAN_IMAGE) as al:
         assert al.tune("image_wait", 0) == 0 and al.tune("grow_state", 0) == 5
         check(al, "lean image, nothing grows")
