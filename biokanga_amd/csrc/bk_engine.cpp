@@ -150,7 +150,7 @@ int derive_cfg(bk_ctx *c)
     if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
     // -c with the multi-loci modes: the chimeric call lists its loci; not together with -N (no chimeric branch there) or -a / -A (a chimeric
     // call that inherits an ambiguous microInDel search would have to list that search's loci too)
-    if (p.min_chimeric_len != 0 && p.max_ml > 1 && (p.best_matches || p.micro_indel_len || p.splice_junct_len)) return BK_ERR_PARAMS;
+    if (p.min_chimeric_len != 0 && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;          // (kanga.cpp:712-716; with -a / -A the combination is the reference's own: tests/golden/chimmlindel)
     if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;

@@ -250,10 +250,8 @@ int read_align_opts(Args &a, AlignOpts &o)
         diag("Error: Sorry, chimeric read processing not supported in this release if either SOLiD or locating multiple best matches also requested");
         return 1;
     }
-    if (o.min_chim && o.ml_mode && (a.num("a", 0) > 0 || a.num("A", 0) > 0)) {
-        diag("Error: chimeric trimming '-c%d' together with '-r%d' and '-a' / '-A' is not available in this build", o.min_chim, o.ml_mode);
-        return 1;
-    }
+    // (-c with -r1..4 and -a / -A: AlignReads runs the microInDel / splice junction searches between the substitution-only phases and the
+    // chimeric call on one set of counts and hits, SfxArrayV2.cpp:7722-7757 - five reference runs byte-identical, tests/golden/chimmlindel)
     // -p / -P / -1 / -S SNP calling (kanga.cpp:866-925)
 
     o.snp.min_reads = a.num("p", 0);

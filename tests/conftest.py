@@ -17,7 +17,7 @@ def golden_tmp(tmp_path_factory):
     import helpers
     d = tmp_path_factory.mktemp("golden")
     out = {}
-    for name in ("basic", "repeat", "multi", "indel", "splice", "chimeric", "chimml", "combined", "snp"):
+    for name in ("basic", "repeat", "multi", "indel", "splice", "chimeric", "chimml", "chimmlindel", "combined", "snp"):
         src = os.path.join(helpers.GOLDEN, name)
         dst = d / name
         dst.mkdir()

@@ -995,6 +995,92 @@ def make_chimml(tmp):
             print("  ran", tag, fmt, flags)
 
 
+CHIMMLINDEL_RUNS = [("r1R5c50a8", ["-r1", "-R5", "-c50", "-a8", "-s3", "-T4"], ["-M6"]), ("r2R5c50a8", ["-r2", "-R5", "-c50", "-a8", "-s3", "-T1"], ["-M6"]),
+                    ("r3R5c50a8", ["-r3", "-R5", "-c50", "-a8", "-s3", "-T4"], ["-M6", "-M0"]), ("r4R5c60a5", ["-r4", "-R5", "-c60", "-a5", "-s3", "-T4"], ["-M6"]),
+                    ("r3R3Xc55a10A200", ["-r3", "-R3", "-X", "-c55", "-a10", "-A200", "-s3", "-T1"], ["-M6"])]
+
+
+def make_chimmlindel(tmp):
+    """chimeric trimming together with a multi-loci mode AND microInDels / splice junctions (-c with -r1..-r4 and -a / -A: AlignReads runs
+    LocateInDels / LocateSpliceJuncts with one hit between the substitution-only phases and the chimeric LocateCoreMultiples call, on
+    the same in / out counts and hit buffer, SfxArrayV2.cpp:7722-7757): chimml's kind of genome (260-base segments in 2..6 places),
+    reads from them and from unique places with a small insertion or deletion in a third of them - so that a microInDel search on a
+    multi-copy segment is ambiguous -, a foreign end in half of them, both in some"""
+    rng = np.random.default_rng(27182)
+    outdir = os.path.join(HERE, "chimmlindel")
+    os.makedirs(outdir, exist_ok=True)
+    g = [list(rand_seq(rng, 60000)), list(rand_seq(rng, 40000))]
+    segs = []
+    for k in range(40):
+        c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 260))
+        seg = g[c][p:p + 260]
+        places = [(c, p)]
+        for _ in range(int(rng.integers(1, 6))):
+            c2 = int(rng.integers(0, 2)); q = int(rng.integers(0, len(g[c2]) - 260))
+            cp = list(seg)
+            if rng.integers(0, 3) == 0:
+                j = int(rng.integers(0, 260)); cp[j] = "ACGT"[("ACGT".index(cp[j]) + 1) % 4]
+            g[c2][q:q + 260] = cp
+            places.append((c2, q))
+        segs.append(places)
+    g = ["".join(x) for x in g]
+    fa = os.path.join(tmp, "chimmlindel.fa")
+    write_fasta(fa, [("mA", g[0]), ("mB", g[1])])
+
+    def foreign(k):
+        if rng.integers(0, 2):
+            return rand_seq(rng, k)
+        c2 = int(rng.integers(0, 2)); q = int(rng.integers(0, len(g[c2]) - k))
+        return g[c2][q:q + k]
+
+    reads = []
+    for i in range(1200):
+        if i < 800:                                       # from a multi-copy segment (or straddling its edge)
+            c, p = segs[int(rng.integers(0, len(segs)))][0]
+            p = max(0, min(len(g[c]) - 120, p + int(rng.integers(-40, 200))))
+        else:
+            c = int(rng.integers(0, 2)); p = int(rng.integers(0, len(g[c]) - 120))
+        src = g[c][p:p + 120]
+        kind = int(rng.integers(0, 3))
+        d = 0
+        if kind == 0:                                     # a deletion or an insertion of 1..9 bases somewhere in the middle
+            at = int(rng.integers(25, 75)); d = int(rng.integers(1, 10))
+            if rng.integers(0, 2):
+                src = src[:at] + src[at + d:]
+            else:
+                src = src[:at] + rand_seq(rng, d) + src[at:]; d = -d
+        core = mutate(rng, src[:100], int(rng.integers(0, 3)))
+        k5 = k3 = 0
+        if rng.integers(0, 2):
+            k5 = int(rng.integers(10, 46)) if rng.integers(0, 3) else 0
+            k3 = int(rng.integers(10, 46)) if (rng.integers(0, 3) == 0 or k5 == 0) else 0
+            if k5 + k3 > 50:
+                k3 = 0
+        sq = foreign(k5) + core[k5:100 - k3] + foreign(k3)
+        if rng.integers(0, 2):
+            sq = revcomp(sq)
+        reads.append((f"x{i}_{k5}_{k3}_{d}", sq))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    rd = os.path.join(tmp, "chimmlindel_reads.fa")
+    write_reads(rd, reads)
+    sfx = os.path.join(tmp, "chimmlindel.sfx")
+    run([REF, "index", "-i", fa, "-o", sfx, "-r", "chimmlindel", "-T4"], tmp)
+    gz_copy(fa, os.path.join(outdir, "genome.fa.gz"))
+    gz_copy(sfx, os.path.join(outdir, "genome.sfx.gz"))
+    gz_copy(rd, os.path.join(outdir, "reads.fa.gz"))
+    for tag, flags, fmts in CHIMMLINDEL_RUNS:
+        for fmt in fmts:
+            ext = {"-M6": "m6.sam", "-M0": "m0.csv", "-M4": "m4.bed"}[fmt]
+            out = os.path.join(tmp, f"{tag}.{ext}")
+            log = run([REF, "align", "-i", rd, "-I", sfx, "-o", out, fmt] + flags, tmp)
+            gz_copy(out, os.path.join(outdir, f"{tag}.{ext}.gz"))
+            if fmt == fmts[0]:
+                with open(os.path.join(outdir, f"{tag}.nar.txt"), "w") as f:
+                    f.write(nar_summary(log))
+            print("  ran", tag, fmt, flags)
+
+
 def make_pechim(tmp):
     """chimeric trimming together with paired ends (-c with -U: the pair rules work on the trimmed loci, AdjStartLoci / AdjEndLoci,
     Aligner.cpp:2750-2769, and the orphan recovery may return an end-trimmed partner, AlignPairedRead with MinChimericLen,
@@ -1506,6 +1592,9 @@ def main():
             return
         if "--only-chimml" in sys.argv:
             make_chimml(tmp)
+            return
+        if "--only-chimmlindel" in sys.argv:
+            make_chimmlindel(tmp)
             return
         if "--only-splice" in sys.argv:
             make_splice(tmp)

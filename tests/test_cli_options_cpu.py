@@ -1,5 +1,6 @@
 """Option checks of `biokanga align` that end before anything touches a device: the messages and exit codes of kanga.cpp's own checks
-(kanga.cpp:648-660,712-716), and of the one combination this build still refuses - CPU only."""
+(kanga.cpp:648-660,712-716) - CPU only.  (The one combination earlier rounds refused, -c with -r and -a / -A, is pinned on reference runs since
+round 5: tests/test_gpu_cli.py, tests/golden/chimmlindel.)"""
 import os
 import subprocess
 
@@ -20,9 +21,6 @@ def run(args):
     (["-c40"], "minimum chimeric length percentage '-c40' specified outside of range 50..99"),
     # the reference refuses this one itself, in these words (kanga.cpp:712-716)
     (["-c50", "-r3", "-R5", "-N"], "Error: Sorry, chimeric read processing not supported in this release if either SOLiD or locating multiple best matches also requested"),
-    # .. and this is the one combination it takes that this build does not
-    (["-c50", "-r3", "-R5", "-a5"], "chimeric trimming '-c50' together with '-r3' and '-a' / '-A' is not available in this build"),
-    (["-c50", "-r2", "-R5", "-A100"], "chimeric trimming '-c50' together with '-r2' and '-a' / '-A' is not available in this build"),
     (["-r5", "-R5", "-A100"], "in report all multiloci mode '-r5', there is no splice junction processing"),
 ])
 def test_refusals_before_any_device_work(args, text):

@@ -169,6 +169,21 @@ def test_align_chimeric_with_multi_loci_modes_byte_identical(golden_tmp, tmp_pat
         assert open(out, "rb").read() == golden_bytes("chimml", f"{tag}.{ext}.gz"), ext
 
 
+@pytest.mark.parametrize("tag,flags,fmts", [
+    ("r1R5c50a8", ["-r1", "-R5", "-c50", "-a8", "-s3", "-T4"], ["m6.sam"]), ("r2R5c50a8", ["-r2", "-R5", "-c50", "-a8", "-s3", "-T1"], ["m6.sam"]),
+    ("r3R5c50a8", ["-r3", "-R5", "-c50", "-a8", "-s3", "-T4"], ["m6.sam", "m0.csv"]), ("r4R5c60a5", ["-r4", "-R5", "-c60", "-a5", "-s3", "-T4"], ["m6.sam"]),
+    ("r3R3Xc55a10A200", ["-r3", "-R3", "-X", "-c55", "-a10", "-A200", "-s3", "-T1"], ["m6.sam"])])
+def test_align_chimeric_with_multi_loci_modes_and_indels_byte_identical(golden_tmp, tmp_path, tag, flags, fmts):
+    """`-c` together with `-r1..4` AND `-a` / `-A` (the last combination earlier rounds refused): reads with small insertions and deletions
+    from segments present in several places, foreign ends on half of them - the microInDel / splice junction searches and the chimeric call
+    run on one set of counts and hits (SfxArrayV2.cpp:7722-7757) - the reference's files"""
+    d = golden_tmp["chimmlindel"]
+    for ext in fmts:
+        out = str(tmp_path / f"o.{ext}")
+        run(["align", "-i", os.path.join(d, "reads.fa"), "-I", os.path.join(d, "genome.sfx"), "-o", out, "-M" + ext[1]] + flags, str(tmp_path))
+        assert open(out, "rb").read() == golden_bytes("chimmlindel", f"{tag}.{ext}.gz"), ext
+
+
 @pytest.mark.parametrize("fixture,name,flags", [
     ("basic", "s3.m6.bam", ["-M6", "-s3"]), ("basic", "s3.m5.bam", ["-M5", "-s3"]),
     ("pe", "U3.m6.bam", ["-M6", "-s5", "-U3", "-d200", "-D400"])])
