@@ -933,6 +933,36 @@ def test_chimeric_loci_lists_match_oracle(golden_tmp, fixture, kw):
         assert n_multi_chim > 30
 
 
+@pytest.mark.parametrize("kw", [dict(max_subs=3, min_chimeric_len=50, max_ml=5, micro_indel_len=8), dict(max_subs=3, min_chimeric_len=60, max_ml=5, micro_indel_len=5),
+                                dict(max_subs=3, min_chimeric_len=55, max_ml=3, clamp_ml=1, micro_indel_len=10, splice_junct_len=200)])
+def test_chimeric_loci_lists_with_indels_match_oracle(golden_tmp, kw):
+    """-c with a multi-loci mode AND -a / -A: the microInDel / splice junction searches run between the substitution-only phases and the
+    chimeric call (SfxArrayV2.cpp:7722-7757) - records, loci lists, trims and two-segment records against the oracle on the reads the
+    reference's own runs of the combination are pinned on (tests/golden/chimmlindel, tests/test_gpu_cli.py)"""
+    bk = _bk()
+    d = golden_tmp["chimmlindel"]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    o = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    exp, elo, eloci, etrims, eseg = helpers.oracle_align_multi_chimeric(o, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    o.close()
+    for knobs in ([], [("chunk_reads", 97)]):
+        with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(**kw)) as al:
+            for k, v in knobs:
+                al.tune(k, v)
+            got = al.align(bases, offs, lens)
+            lo, loci = al.batch_loci(len(lens))
+            trims = al.batch_loci_trims()
+            seg = al.batch_seg2()
+        assert_hits_equal(got, exp, names)
+        assert np.array_equal(lo, elo)
+        for f in ("chrom_id", "match_loci", "match_len", "strand", "mismatches"):
+            assert np.array_equal(loci[f], eloci[f]), (f, knobs)
+        for f in ("left", "right", "chimeric"):
+            assert np.array_equal(trims[f], etrims[f]), (f, knobs)
+        assert_seg2_equal(seg, eseg, names)
+    assert np.count_nonzero(eseg["match_len"]) > 20           # (reads placed as two segments)
+
+
 def test_chimeric_with_loci_lists_refuses_what_it_cannot_list(golden_tmp):
     bk = _bk()
     sfx = os.path.join(golden_tmp["chimml"], "genome.sfx")
