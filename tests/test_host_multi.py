@@ -120,3 +120,77 @@ def test_host_policies_with_chimeric_trims_match_reference(golden_tmp, multi_har
         cig = (f"{c5}S" if c5 else "") + f"{int(h['match_len']) - tl - tr}M" + (f"{c3}S" if c3 else "")
         assert (chrom[h["chrom_id"] - 1], int(h["match_loci"]) + (tl if plus else tr) + 1, cig) == (r["rname"], r["pos"], r["cigar"]), (nm, h, rt[i], r)
     assert n_trimmed > 10, n_trimmed
+
+@pytest.mark.parametrize("tag,kw", [("r1R5c50a8", dict(max_subs=3, min_chimeric_len=50, max_ml=5, micro_indel_len=8))])
+def test_r1_with_chimeric_trims_and_indels_is_the_plain_result(golden_tmp, tag, kw):
+    """-c with -r1 AND -a (the combination pinned in round 5, tests/golden/chimmlindel): what AlignReads returned with MaxHits = -R - the
+    oracle's records against the reference's SAM: every read's outcome (a read placed as two segments around a microInDel is the
+    reference's 'orphaned microInDel'), and locus + CIGAR with the chimeric call's soft clips of every read placed in one piece"""
+    d = golden_tmp["chimmlindel"]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    hits, lo, loci, trims, seg2 = helpers.oracle_align_multi_chimeric(sfx, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    sfx.close()
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "chimmlindel", f"{tag}.m6.sam.gz"))
+    by = {r["qname"]: r for r in recs}
+    chrom = chrom_names_from_hdr(hdr)
+    n_two = n_clipped = 0
+    for i, nm in enumerate(names):
+        h, r = hits[i], by[nm]
+        two = (int(seg2["flags"][i]) & 7) != 0                      # a microInDel / splice junction placement: two segments
+        assert ("OM" if (two and h["nar"] == 1) else helpers.NAR_TAGS[h["nar"]]) == r["nar"], (nm, h, seg2[i], r)
+        n_two += 1 if two else 0
+        if h["nar"] != 1 or two:
+            continue
+        tl, tr = (int(seg2["match_len"][i]), int(seg2["read_ofs"][i])) if int(seg2["flags"][i]) & 8 else (0, 0)
+        n_clipped += 1 if (tl or tr) else 0
+        plus = chr(h["strand"]) == "+"
+        c5, c3 = (tl, tr) if plus else (tr, tl)
+        cig = (f"{c5}S" if c5 else "") + f"{int(h['match_len']) - tl - tr}M" + (f"{c3}S" if c3 else "")
+        assert (chrom[h["chrom_id"] - 1], int(h["match_loci"]) + (tl if plus else tr) + 1, cig) == (r["rname"], r["pos"], r["cigar"]), (nm, h, seg2[i], r)
+    assert n_two > 40 and n_clipped > 100, (n_two, n_clipped)
+
+@pytest.mark.parametrize("tag,mode,kw,threads", [("r2R5c50a8", 2, dict(max_subs=3, min_chimeric_len=50, max_ml=5, micro_indel_len=8), 1),
+                                                 ("r3R5c50a8", 3, dict(max_subs=3, min_chimeric_len=50, max_ml=5, micro_indel_len=8), 4),
+                                                 ("r4R5c60a5", 4, dict(max_subs=3, min_chimeric_len=60, max_ml=5, micro_indel_len=5), 4),
+                                                 ("r3R3Xc55a10A200", 3, dict(max_subs=3, min_chimeric_len=55, max_ml=3, clamp_ml=1, micro_indel_len=10, splice_junct_len=200), 4)])
+def test_host_policies_with_chimeric_trims_and_indels_match_reference(golden_tmp, multi_harness, tmp_path, tag, mode, kw, threads):
+    """-c with -r2 / -r3 / -r4 AND -a / -A: the random pick and the clustering over the chimeric call's lists, beside reads the microInDel /
+    splice junction searches placed as two segments - fed with the oracle's lists, against the reference's SAM of the same options"""
+    d = golden_tmp["chimmlindel"]
+    names, bases, offs, lens = helpers.read_fasta_reads(os.path.join(d, "reads.fa"))
+    sfx = helpers.OracleSfx(os.path.join(d, "genome.sfx"))
+    hits, lo, loci, trims, seg2 = helpers.oracle_align_multi_chimeric(sfx, bases, offs, lens, helpers.make_params(**kw), nthreads=8)
+    sfx.close()
+    hp, op, lp, rp, tp, otp = (str(tmp_path / n) for n in ("hits.bin", "offs.bin", "loci.bin", "out.bin", "trims.bin", "out_trims.bin"))
+    hits.tofile(hp); lo.tofile(op); loci.tofile(lp); trims.tofile(tp)
+    subprocess.check_call([multi_harness, str(mode), str(threads), str(int(lens.max())), str(kw.get("clamp_ml", 0)), hp, op, lp, rp, tp, otp])
+    got = np.fromfile(rp, dtype=helpers.HIT_DTYPE)
+    rt = np.fromfile(otp, dtype=helpers.TRIMS_DTYPE)
+    hdr, recs = helpers.parse_sam(os.path.join(helpers.GOLDEN, "chimmlindel", f"{tag}.m6.sam.gz"))
+    by = {r["qname"]: r for r in recs}
+    chrom = chrom_names_from_hdr(hdr)
+    n_taken = n_two = 0
+    for i, nm in enumerate(names):
+        h, r = got[i], by[nm]
+        two = (int(seg2["flags"][i]) & 7) != 0 and np.array_equal(got[i], hits[i])
+        if two and h["nar"] == 1:
+            # (placed as two segments: kept, or dropped by the orphan filters that follow - Aligner.cpp:630-650, tests/test_host_filters.py - as
+            # an orphaned microInDel or splice junction)
+            assert r["nar"] in ("AA", "OM", "OJ"), (nm, h, seg2[i], r)
+        else:
+            assert helpers.NAR_TAGS[h["nar"]] == r["nar"], (nm, h, seg2[i], r)
+        n_two += 1 if two else 0
+        if h["nar"] != 1 or two:
+            continue
+        taken = not np.array_equal(got[i], hits[i])
+        if taken:
+            tl, tr = int(rt["left"][i]), int(rt["right"][i])
+            n_taken += 1
+        else:
+            tl, tr = (int(seg2["match_len"][i]), int(seg2["read_ofs"][i])) if int(seg2["flags"][i]) & 8 else (0, 0)
+        plus = chr(h["strand"]) == "+"
+        c5, c3 = (tl, tr) if plus else (tr, tl)
+        cig = (f"{c5}S" if c5 else "") + f"{int(h['match_len']) - tl - tr}M" + (f"{c3}S" if c3 else "")
+        assert (chrom[h["chrom_id"] - 1], int(h["match_loci"]) + (tl if plus else tr) + 1, cig) == (r["rname"], r["pos"], r["cigar"]), (nm, h, rt[i], r)
+    assert n_taken > 30 and n_two > 30, (n_taken, n_two)
