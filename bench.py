@@ -35,9 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# `biokanga align` makes the partial suffix-ordered window array (25 GB at 3.1 Gbp, behind the suffix array's upload; see kWindowArrayMinReads) from this many reads
-# per device on, or when told to with --window-array (host/biokanga_main.cpp, cmd_align): the layout the headline is measured in follows the same rule
-CLI_WINDOW_ARRAY_MIN_READS = 20_000_000
+# The index image and layout of the headline follow the library's one rule, bk_image_policy(reads a device aligns in the configuration) - the
+# function `biokanga align` calls (host/biokanga_main.cpp, cmd_align): from BK_POLICY_MIN_READS reads per device on every table (k-mer table
+# entries of two words, third- and fourth-level search keys) and the partial suffix-ordered window array come with the index, made behind
+# the suffix array's upload; below, the lean image without the array.  --index-image / --window-array force either half.
 
 
 def effective_cpus():
@@ -611,7 +612,10 @@ def main():
                     help="index layout of the headline: 'policy' = what `biokanga align` picks for this many reads per device; 'partial' (= 'on') = the "
                          "suffix-ordered window array for the part of the suffix array the wave kernel's long walks visit; 'full' = for every suffix "
                          "(149 GB at 3.1 Gbp); the other layouts are measured beside it")
-    ap.add_argument("--no-other-layout", action="store_true", help="measure the headline's index layout only")
+    ap.add_argument("--index-image", default="policy", choices=["policy", "full", "lean"],
+                    help="index image of the headline: 'policy' = what bk_image_policy gives this many reads per device; 'full' = every table; "
+                         "'lean' = no second words in the k-mer table, no third- / fourth-level search keys; the other image is measured beside it")
+    ap.add_argument("--no-other-layout", action="store_true", help="measure the headline's index layout and image only")
     ap.add_argument("--other-layouts", default="off,partial,full", help="which of off / partial / full to measure beside the headline's")
     ap.add_argument("--no-host-leg", action="store_true", help="kernel-only steps only (profiling runs): `value` is then the kernel-only rate and says so")
     ap.add_argument("--stream-form", default="packed", choices=["packed", "bytes"], help="form in which the reads cross PCIe: "
@@ -622,6 +626,8 @@ def main():
     ap.add_argument("--shard-check-reads", type=int, default=8_000_000, help="N > 1: size of the ONE read set that is sharded i mod N and "
                                                                               "whose reduced counts are compared with a 1-GPU run of all of it")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; 'gloo' only for dry runs of the multi-rank path")
+    ap.add_argument("--no-rccl-world1", action="store_true", help="N = 1: no torch.distributed process group of one rank (default: RCCL is initialised and the "
+                                                                   "per-step all-reduce of the sequence counts runs through it, as at N > 1)")
     ap.add_argument("--force-device", type=int, default=-1, help="dry runs: put every rank on this GPU instead of LOCAL_RANK")
     ap.add_argument("--force-el5", action="store_true", help="experiments: 5-byte suffix elements (the > 4 Gbp kernels) on a smaller genome")
     ap.add_argument("--kmer-bits", type=int, default=0, help="override the k of the k-mer interval table")
@@ -661,12 +667,34 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_info = None
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+    elif args.dist_backend == "nccl" and not args.pmc_child and not args.no_rccl_world1:
+        # N = 1 goes through RCCL too: a process group of ONE rank (no launcher, so the rendezvous is a TCP store of our own on 127.0.0.1),
+        # the same per-step all-reduce of the per-sequence counts, the same barriers - the exchange step's code path runs on hardware
+        # wherever this bench does.  Reporting only: a set-up that fails is noted and the run goes on without it.
+        try:
+            import datetime
+            import socket
+            import torch.distributed as dist_mod
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist_mod.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                                        timeout=datetime.timedelta(seconds=120))
+            one = torch.ones(1, dtype=torch.int64, device=dev)
+            dist_mod.all_reduce(one)
+            torch.cuda.synchronize()
+            rccl_info = {"backend": "nccl (RCCL)", "world_size": 1, "rccl_ranks_seen": int(one.item()), "per_step_allreduce_of_sequence_counts": True}
+            dist = dist_mod
+        except Exception as e:
+            rccl_info = {"backend": "nccl (RCCL)", "world_size": 1, "error": repr(e)}
+            dist = None
 
     def all_reduce(t, op=None):
         """in place; through host memory when the backend is not RCCL"""
@@ -758,7 +786,24 @@ def main():
 
     # ---------------------------------------------------------------- the index layout of the headline, and the other one
     job_reads = max(args.reads, cfg.get("job_reads_per_gpu", args.reads))
-    policy_layout = "partial" if job_reads >= CLI_WINDOW_ARRAY_MIN_READS else "off"
+    policy_flags = bk.image_policy(job_reads)                       # (the function `biokanga align` calls)
+    policy_layout = "partial" if policy_flags & bk.CTX_WINDOW_ARRAY_EAGER else "off"
+    policy_image = "lean" if policy_flags & (bk.CTX_LEAN_IMAGE | bk.CTX_GROW_IMAGE) else "full"
+    headline_image = policy_image if args.index_image == "policy" else args.index_image
+    if E != 4:
+        headline_image = "full"                                       # (5-byte indexes: whatever of the tables fits is made; there is no second image to switch to)
+
+    def set_image(image):
+        """the context was made with every table the HBM has room for; 'lean' drops the k-mer table's second words and the key arrays
+        behind the second-level keys (the tables are made again: untimed set-up)"""
+        if E != 4:
+            return
+        al.tune("use_ktab2", 1 if image == "full" else 0)
+        al.tune("use_k3", 2 if image == "full" else 0)
+
+    if headline_image == "lean":
+        set_image("lean")
+    image_resident = {"k_mer_table_second_words": al.tune("ktab2_resident", 0) == 1, "key_arrays_behind_the_second_level_keys": al.tune("k3_resident", 0)}
     headline = {"policy": policy_layout, "on": "partial"}.get(args.window_array, args.window_array)
     host = None
     if not args.no_host_leg:
@@ -837,14 +882,14 @@ def main():
             if lay == "off" or leg["window_array_resident"]:      # (else the library did not build it: there is no such layout to report)
                 other_legs[lay] = leg
         al.tune("use_swin", SWIN_TUNE[headline])
-    # the image `biokanga align` starts every job with (BK_CTX_GROW_IMAGE): no first keys in the k-mer table, no key arrays behind the
-    # second-level keys; it grows the headline's image in the background once a device has aligned a thousand million reads
-    lean_image = None
+    # the other index image, beside the headline's: lean (what bk_image_policy gives a job below BK_POLICY_MIN_READS reads per device: no
+    # second words in the k-mer table, no key arrays behind the second-level keys) when the headline's holds every table, and the other way round
+    other_image_name = "lean" if headline_image == "full" else "full"
+    other_image = None
     if not args.no_other_layout and E == 4 and world == 1:
         try:
             al.tune("use_swin", SWIN_TUNE[headline])
-            al.tune("use_ktab2", 0)
-            al.tune("use_k3", 0)
+            set_image(other_image_name)
             step()
             torch.cuda.synchronize()
             al.timing(reset=True)
@@ -854,23 +899,37 @@ def main():
             torch.cuda.synchronize()
             dt = time.time() - t1
             tl = al.timing(reset=True)
-            lean_image = {"value_kernel_only": args.reads * args.steps / dt, "ms_per_step_kernel_only": 1e3 * dt / args.steps,
-                          "device_ms_per_step": {k: round(tl[k] / args.steps, 2) for k in ("ms_total", "ms_search", "ms_search_a", "ms_search_b", "ms_extend", "ms_heavy")},
-                          "results_bit_identical_to_the_headline_image": bool(np.array_equal(main_leg["hits"].view(np.uint8), out.cpu().numpy()))}
+            other_image = {"image": other_image_name, "value_kernel_only": args.reads * args.steps / dt, "ms_per_step_kernel_only": 1e3 * dt / args.steps,
+                           "device_ms_per_step": {k: round(tl[k] / args.steps, 2) for k in ("ms_total", "ms_search", "ms_search_a", "ms_search_b", "ms_extend", "ms_heavy")},
+                           "results_bit_identical_to_the_headline_image": bool(np.array_equal(main_leg["hits"].view(np.uint8), out.cpu().numpy()))}
             if host is not None:
                 try:
                     hl = host.run(al, args.warmup, args.steps, barrier, None, dev, pe_params)
-                    lean_image["value_host_in_host_out"] = hl.get("value")
-                    lean_image["host_results_bit_identical"] = host.same_as(main_leg["hits"], args.steps)
+                    other_image["value_host_in_host_out"] = hl.get("value")
+                    other_image["host_results_bit_identical"] = host.same_as(main_leg["hits"], args.steps)
                 except Exception as e:
-                    lean_image["value_host_in_host_out"] = None
-                    lean_image["host_error"] = repr(e)
+                    other_image["value_host_in_host_out"] = None
+                    other_image["host_error"] = repr(e)
         except Exception as e:       # reporting only
-            lean_image = {"value_kernel_only": None, "error": repr(e)}
-        al.tune("use_ktab2", 1)
-        al.tune("use_k3", 2)
+            other_image = {"image": other_image_name, "value_kernel_only": None, "error": repr(e)}
+        set_image(headline_image)
         step()
         torch.cuda.synchronize()
+    # the library's own exchange step (`biokanga align --devices`: bk_seq_counts_allreduce) through its RCCL binding on this one device
+    lib_rccl = None
+    if world == 1 and not args.no_rccl_world1:
+        try:
+            step()
+            torch.cuda.synchronize()
+            al.align_device(rd_bases.data_ptr(), rd_offs.data_ptr(), rd_lens.data_ptr(), min(args.reads, 1_000_000), out.data_ptr())
+            plain = al.seq_counts(reset=False)
+            al.tune("force_rccl", 1)
+            through = bk.seq_counts_allreduce([al], reset=True)
+            lib_rccl = {"counts_equal_plain_path": bool(np.array_equal(plain, through)), "allreduces_through_rccl": al.tune("rccl_allreduces", 0),
+                        "communicator_ranks": al.tune("rccl_ranks", 0)}
+            al.tune("force_rccl", 0)
+        except Exception as e:
+            lib_rccl = {"error": repr(e)}
     headline_on = headline != "off"
     if os.environ.get("BK_DIAG"):
         print("diag counters:", main_leg["ctr"], file=sys.stderr)
@@ -1001,9 +1060,9 @@ def main():
         "config": {"workload": f"{args.config}: {cfg['text'].format(**fmt)} vs synthetic {'wheat' if E == 5 else 'GRCh38'}-like genome of {total_bp} bp in "
                                f"{len(seq_lens)} sequences ({int(100 * cfg.get('repeat_frac', 0.45))}% repeat-derived, N gaps), {cfg['cli'].format(**fmt)}",
                    "window_array": headline + (f" (what `biokanga align` picks for the {job_reads} reads a device aligns in this configuration: the partial suffix-ordered "
-                                    f"window array from {CLI_WINDOW_ARRAY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
-                   "index_image": "grown (k-mer table entries with first keys, third- and fourth-level search keys): the image a context holds after a thousand million "
-                                  "reads; the lean image every `biokanga align` job starts with is measured beside it (index_image.lean)",
+                                    f"window array from {bk.POLICY_MIN_READS} reads on, or --window-array)" if args.window_array == "policy" else " (forced with --window-array)"),
+                   "index_image": headline_image + (f" (what bk_image_policy - the function `biokanga align` calls - gives the {job_reads} reads a device aligns in this "
+                                                    f"configuration: every table from {bk.POLICY_MIN_READS} reads on)" if args.index_image == "policy" else " (forced with --index-image)"),
                    "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "genome_bp": total_bp,
                    "concat_len": n, "sfx_el_size": E, "index": "replicated per GPU, built on device",
                    "parallelism": f"reads sharded over {world} GPU(s): read g of the job's set = read g // {world} of rank g % {world}",
@@ -1014,12 +1073,13 @@ def main():
                    "results_bitwise_equal_across_steps": main_leg["repeatable"]},
         "roofline": roofline,
         "layouts": layouts,
-        "index_image": {"headline": "grown: k-mer table entries with their bucket's first key, third- and fourth-level search keys (43 GB more at 3.1 Gbp) - what a "
-                                    "context holds once it has aligned a thousand million reads (BK_CTX_GROW_IMAGE makes them in the background; the bench's steps are "
-                                    f"{args.steps + args.warmup} x {args.reads} reads on one context)",
-                        "lean": lean_image,
-                        "lean_is": "the image every `biokanga align` job starts with, and a job of fewer than a thousand million reads per device ends with"},
+        "index_image": {"headline": headline_image, "policy": policy_image, "policy_flags_of_bk_image_policy": policy_flags, "job_reads_per_gpu": job_reads,
+                        "resident": image_resident,
+                        "full_is": "k-mer table entries of two words (a bucket's only key, or the map of its keys' first five bits), third- and fourth-level search keys: 43 GB "
+                                   "more at 3.1 Gbp, made behind the suffix array's upload with the other tables",
+                        "other": other_image},
         "t_align_host_resident": host_leg,
+        "rccl": {"torch_distributed": rccl_info, "library_binding_one_device": lib_rccl} if world == 1 else {"torch_distributed": {"backend": args.dist_backend, "world_size": world}},
     }
     if multi is not None:
         result.update(multi)

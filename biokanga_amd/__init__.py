@@ -7,7 +7,7 @@ bench.py: a ctypes binding of the C ABI.  There is no CPU fallback anywhere - if
 missing, or no HIP device is present, calls fail loudly.
 """
 from .binding import (Aligner, AlignParams, PEParams, CTX_WINDOW_ARRAY_EAGER, CTX_LEAN_IMAGE, CTX_NO_DEEP_KEYS, CTX_GROW_IMAGE, HIT_DTYPE, LOCI_DTYPE, LOCI_TRIMS_DTYPE, SEG2_DTYPE, SNP_ALN_DTYPE, SNP_SITE_DTYPE, ENTRY_DTYPE, BkError, lib_path, load_library,
-                      device_count, build_sa_device, NAR_TAGS, Stream, host_array, seq_counts_allreduce, pack_reads, NBASE_DTYPE)
+                      device_count, build_sa_device, NAR_TAGS, Stream, host_array, seq_counts_allreduce, pack_reads, NBASE_DTYPE, image_policy, POLICY_MIN_READS)
 
 __all__ = ["Aligner", "AlignParams", "PEParams", "HIT_DTYPE", "LOCI_DTYPE", "LOCI_TRIMS_DTYPE", "SEG2_DTYPE", "SNP_ALN_DTYPE", "SNP_SITE_DTYPE", "ENTRY_DTYPE", "BkError", "lib_path", "load_library",
-           "device_count", "build_sa_device", "NAR_TAGS", "Stream", "host_array", "seq_counts_allreduce", "pack_reads", "NBASE_DTYPE"]
+           "device_count", "build_sa_device", "NAR_TAGS", "Stream", "host_array", "seq_counts_allreduce", "pack_reads", "NBASE_DTYPE", "image_policy", "POLICY_MIN_READS"]

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "bk_host_alloc", "bk_host_free", "bk_stream_create", "bk_stream_submit", "bk_stream_wait", "bk_stream_batch_loci",
     "bk_stream_batch_seg2", "bk_stream_release", "bk_stream_drain", "bk_stream_get_stats", "bk_stream_destroy",
     "bk_packed_words", "bk_pack_reads", "bk_align_batch_packed", "bk_stream_submit_packed", "bk_sam_format", "bk_batch_loci_trims", "bk_stream_batch_loci_trims", "bk_stream_submit_device", "bk_sam_prepare", "bk_sam_prep_free",
-    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex", "bk_ctx_set_chrom_filter", "bk_sam_prep_wait",
+    "bk_host_register", "bk_host_unregister", "bk_ctx_reserve", "bk_stream_create_packed", "bk_align_batch_device_async", "bk_ctx_create_ex", "bk_ctx_set_chrom_filter", "bk_sam_prep_wait", "bk_debug_intervals", "bk_image_policy",
 ]
 
 
@@ -158,6 +158,10 @@ def load_library():
     lib.bk_host_unregister.restype = None
     lib.bk_ctx_tune.argtypes = [vp, ctypes.c_char_p, i64]
     lib.bk_ctx_tune.restype = i64
+    lib.bk_image_policy.argtypes = [u64]
+    lib.bk_image_policy.restype = u32
+    lib.bk_debug_intervals.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), vp, vp, vp]
+    lib.bk_debug_intervals.restype = i32
     lib.bk_num_entries.argtypes = [vp]
     lib.bk_num_entries.restype = u32
     lib.bk_get_entry.argtypes = [vp, u32, vp]
@@ -251,6 +255,14 @@ def _strerror(rc):
         return load_library().bk_strerror(rc).decode()
     except Exception:
         return "?"
+
+
+def image_policy(reads_per_device):
+    """bk_image_policy: the bk_ctx_create_ex flags `biokanga align` picks for a job of this many reads per device"""
+    return int(load_library().bk_image_policy(int(reads_per_device)))
+
+
+POLICY_MIN_READS = 20_000_000          # BK_POLICY_MIN_READS
 
 
 def device_count():
@@ -383,6 +395,29 @@ class Aligner:
         if r < 0:
             raise BkError(int(r), f"bk_ctx_tune({name})")
         return r
+
+    def search_intervals(self, bases, offs, lens, phase):
+        """Test hook (bk_debug_intervals): runs the batch up to and including the search of `phase` of AlignReads' schedule and returns
+        (act[n_act], first[2 * iv_cores, n_act] uint64, count[2 * iv_cores, n_act] uint32, iv_cores): the interval records of the reads
+        still unaligned in that phase, planes numbered strand * iv_cores + core."""
+        self.tune("debug_stop_phase", phase + 1)
+        try:
+            self.align(bases, offs, lens)
+            na, ivc = ctypes.c_uint32(0), ctypes.c_uint32(0)
+            rc = self.lib.bk_debug_intervals(self.h, 0, ctypes.byref(na), ctypes.byref(ivc), None, None, None)
+            if rc:
+                raise BkError(rc, "bk_debug_intervals")
+            n, c = int(na.value), int(ivc.value)
+            act = np.zeros(max(n, 1), dtype=np.uint32)
+            first = np.zeros((2 * c, max(n, 1)), dtype=np.uint64)
+            count = np.zeros((2 * c, max(n, 1)), dtype=np.uint32)
+            if n:
+                rc = self.lib.bk_debug_intervals(self.h, n, ctypes.byref(na), ctypes.byref(ivc), act.ctypes.data, first.ctypes.data, count.ctypes.data)
+                if rc:
+                    raise BkError(rc, "bk_debug_intervals")
+            return act[:n], first[:, :n], count[:, :n], c
+        finally:
+            self.tune("debug_stop_phase", 0)
 
     # -- alignment
     def align(self, bases, offs, lens):

@@ -58,7 +58,7 @@ struct bk_ctx {
     // BK_CTX_GROW_IMAGE: the tables that only pay over long runs (key arrays behind the second-level keys, k-mer table entries with their
     // bucket's first key) are made by a thread of their own once the context has aligned grow_after reads, and taken in between two batches
     bool grow_enabled = false, grow_wait = false;
-    uint64_t grow_after = 1000000000ULL, grow_seen = 0;
+    uint64_t grow_after = 5 * BK_POLICY_MIN_READS, grow_seen = 0;      // (a context that was started lean for a short job and turned out to run a long one)
     std::atomic<int> grow_state{0};          // 0 not started, 1 being made, 2 made, 3 nothing made (no room / not in order), 4 taken in
     std::thread grow_thread;
     uint32_t *grow_kx[bk::kMoreKeys] = {nullptr, nullptr};
@@ -117,10 +117,17 @@ struct bk_ctx {
     int async_phases = 1;    // 1: the main path's phase loop launches without reading counts back (see align_chunk)
     unsigned long long *d_seq_counts = nullptr, *d_ctr = nullptr, *d_ctr_aux = nullptr;
     unsigned long long *d_seq_global = nullptr;   // bk_seq_counts_allreduce: the counts summed over every context of the run
+    bool force_rccl = false;                      // .. through RCCL even on one device ("force_rccl")
+    uint64_t rccl_allreduces = 0;                 // .. how many of this context's reductions went through RCCL, the ranks of the last one's communicator
+    int rccl_ranks = 0;
     // heavy path scratch
     bk::HeavyScratch hs{};
     int max_read_len = 500;
     uint32_t last_maxlen = 0;    // longest read of the last align call
+    // test hook (bk_debug_intervals): batches stop behind the search of this phase and leave its interval records in the scratch
+    int dbg_stop_phase = -1, dbg_phase = 0, dbg_cur = 0;
+    uint32_t dbg_n = 0, dbg_ivc = 0;
+    bool dbg_valid = false;
     bool debug = false;      // BK_DEBUG in the environment when the context was created: per-phase counts on stderr
     uint32_t chunk_reads = 64u << 20;
     // staging for host-buffer batches

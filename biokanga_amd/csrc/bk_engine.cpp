@@ -33,7 +33,8 @@ namespace bk {
 void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t nwords, hipStream_t s);
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, unsigned long long *starts = nullptr);
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, unsigned long long *starts = nullptr, bool pairs = false);
+void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s);
 void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s);
@@ -114,7 +115,15 @@ hipError_t dev_zero_now(void *p, size_t bytes)
 hipError_t dev_malloc_bytes(void **p, size_t bytes)
 {
     static const int poison = getenv("BK_POISON") ? atoi(getenv("BK_POISON")) : -1;
+    static const bool timing = getenv("BK_TIMING") != nullptr;
+    timespec ta, tb;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &ta);
     hipError_t e = hipMalloc(p, bytes);
+    if (timing) {          // (BK_TIMING: an allocation that took the driver more than 2 ms says so)
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+        const double ms = 1e3 * (double)(tb.tv_sec - ta.tv_sec) + 1e-6 * (double)(tb.tv_nsec - ta.tv_nsec);
+        if (ms > 2.0) fprintf(stderr, "bk timing: hipMalloc of %.2f GB took %.1f ms\n", (double)bytes / 1e9, ms);
+    }
     if (e == hipSuccess && poison >= 0 && bytes) {
         e = hipMemset(*p, poison & 0xff, bytes);
         if (e == hipSuccess) e = hipDeviceSynchronize();       // (a memset returns before it is done, and the contexts' streams do not wait for the null stream)
@@ -186,7 +195,16 @@ int derive_cfg(bk_ctx *c)
 
 void free_dev(void *p)
 {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    static const bool timing = getenv("BK_TIMING") != nullptr;
+    timespec ta, tb;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &ta);
+    (void)hipFree(p);
+    if (timing) {
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+        const double ms = 1e3 * (double)(tb.tv_sec - ta.tv_sec) + 1e-6 * (double)(tb.tv_nsec - ta.tv_nsec);
+        if (ms > 2.0) fprintf(stderr, "bk timing: hipFree took %.1f ms\n", ms);
+    }
 }
 
 // zero-fill that stays correct for spans of 4 GiB and more: hipMemsetAsync is not trusted with those (bk_index.hip,
@@ -219,6 +237,7 @@ int pick_k(uint64_t n)
 // next crosses PCIe), or in one go.  tables_begin decides and allocates, tables_range enqueues, tables_end checks and publishes.
 struct TablePlan {
     bool ktab = false, k2 = false, isa = false;
+    bool ktab2 = false;                            // the k-mer table's entries are pairs {bucket start, y} from the start (DevIndex::ktab2): starts written in place, y filled in tables_end
     int kx = 0;                                    // key arrays behind the second-level keys (DevIndex::kx)
     int k = 0;
     unsigned long long *d_bad = nullptr;           // places where the second-level keys are not in order inside a bucket; the third-level keys inside a run of equal second-level keys
@@ -283,7 +302,7 @@ void grow_worker(bk_ctx *c)
     c->grow_state.store(st, std::memory_order_release);
 }
 
-// the worker's tables become the context's (between two batches: the device is idle when the k-mer table it replaces is given back)
+// the worker's tables become the context's (between two batches; the device is made idle before the k-mer table it replaces is given back)
 void grow_take_in(bk_ctx *c)
 {
     if (c->grow_thread.joinable()) c->grow_thread.join();
@@ -292,7 +311,9 @@ void grow_take_in(bk_ctx *c)
             if (c->grow_kx[i]) { c->d_kx[i] = c->grow_kx[i]; c->ix.kx[i] = c->grow_kx[i]; c->grow_kx[i] = nullptr; }
         if (c->ix.kx[0]) c->use_k3 = kMoreKeys;
         if (c->grow_ktab2) {
-            (void)hipStreamSynchronize(c->stream);
+            // (earlier batches may still run on a caller's stream - bk_stream's, bk_align_batch_device_async's - with the old table's
+            // address in their kernel arguments: the whole device is waited for, not the context's own stream)
+            (void)hipDeviceSynchronize();
             free_dev(c->d_ktab);
             c->d_ktab = c->grow_ktab2;
             c->grow_ktab2 = nullptr;
@@ -347,37 +368,47 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
     c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
     c->ix.k = 0;
+    // What the HBM has room for is decided before anything is allocated, in the order of what a byte buys: k-mer table, second-level
+    // keys, inverse suffix array, the key arrays behind the second-level keys, then the k-mer table's second words - each only where a
+    // fifth of the HBM stays free behind it (batch scratch, window array).  Nothing is given back or allocated again afterwards: an
+    // allocation made after a large hipFree waits for the driver to wipe what was freed (profiles/NOTES.md, round 6).
     if (c->use_ktab) {
         int k = c->k_req > 0 ? c->k_req : pick_k(c->ix.n);
         if (k > 16) k = 16;
         if (k < 2) k = 2;
         const uint64_t ncodes = 1ULL << (2 * k);
         c->ktab64 = c->ix.n >= (1ULL << 32);
-        const size_t bytes = (size_t)(ncodes + 1) * (c->ktab64 ? 8 : 4);
+        const uint64_t ktab_bytes = (ncodes + 1) * (c->ktab64 ? 8 : 4);
+        const uint64_t need = k2s_start(c->ix.n, kK2Levels + 1) * 4;          // (the keys and their sampled levels, bk_dev_k2.h)
+        const bool want_isa = c->use_wave && c->use_isa && c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t planned = ktab_bytes;
+        auto fits = [&](uint64_t more) { return planned + more <= free_b && free_b - planned - more >= total_b / 5; };
+        // second-level key array; needs the k-mer table.  Skipped (search falls back to the one-pass kernel) when it would not leave a
+        // fifth of the HBM free, or - found in tables_end - if the suffix array is not ordered the way the bisection needs (never
+        // seen; checked because .sfx files come from outside).
+        if (c->use_k2 && fits(need)) { tp.k2 = true; planned += need; }
+        if (want_isa) planned += c->ix.n * 4;
+        // third- and fourth-level keys (the 15 bases after those, and the 15 after these): as much again each, for the cores of
+        // more than k + 15 bases
+        for (int i = 0; tp.k2 && i < kMoreKeys && i < c->use_k3; i++) {
+            if (!fits(need)) break;
+            tp.kx = i + 1;
+            planned += need;
+        }
+        // the k-mer table's entries as pairs (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
+        if (tp.k2 && c->use_ktab2 && !c->ktab64 && fits(ktab_bytes)) tp.ktab2 = true;
+        const size_t bytes = (size_t)ktab_bytes * (tp.ktab2 ? 2 : 1);
         HIP_TRY(dev_malloc(&c->d_ktab, bytes));
         c->ktab_bytes = bytes;
         tp.ktab = true;
         tp.k = k;
-    }
-    // second-level key array; needs the k-mer table.  Skipped (search falls back to the one-pass kernel) when it would not leave a
-    // quarter of the HBM free, or - found in tables_end - if the suffix array is not ordered the way the bisection needs (never
-    // seen; checked because .sfx files come from outside).
-    if (c->use_k2 && tp.ktab) {
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t need = k2s_start(c->ix.n, kK2Levels + 1) * 4;          // (the keys and their sampled levels, bk_dev_k2.h)
-        if (need <= free_b && free_b - need >= total_b / 5) {
+        if (tp.k2) {
             HIP_TRY(dev_malloc(&c->d_k2, need));
             HIP_TRY(dev_malloc(&tp.d_bad, 16));
             HIP_TRY(hipMemsetAsync(tp.d_bad, 0, 16, c->stream));
-            tp.k2 = true;
-            // third- and fourth-level keys (the 15 bases after those, and the 15 after these): as much again each, for the cores of
-            // more than k + 15 bases - where that leaves the same reserve, and the context is one for a long run
-            for (int i = 0; i < kMoreKeys && i < c->use_k3; i++) {
-                if ((uint64_t)(2 + i) * need > free_b || free_b - (uint64_t)(2 + i) * need < total_b / 5) break;
-                HIP_TRY(dev_malloc(&c->d_kx[i], need));
-                tp.kx = i + 1;
-            }
+            for (int i = 0; i < tp.kx; i++) HIP_TRY(dev_malloc(&c->d_kx[i], need));
         }
     }
     if (c->use_wave && c->use_isa && c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32)) {
@@ -393,7 +424,7 @@ int tables_range(bk_ctx *c, const TablePlan &tp, uint64_t i0, uint64_t i1, unsig
     DevIndex ix = c->ix;
     ix.k = tp.k;
     const bool last = i1 >= c->ix.n;
-    if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1, bucket_starts);
+    if (tp.ktab) launch_build_ktab(ix, c->d_ktab, tp.k, c->ktab64, c->stream, i0, last ? c->ix.n + 1 : i1, bucket_starts, tp.ktab2);
     if (tp.k2) launch_build_k2(ix, c->d_k2, tp.kx > 0 ? c->d_kx[0] : nullptr, tp.kx > 1 ? c->d_kx[1] : nullptr, tp.d_bad, c->stream, i0, i1);
     if (tp.isa) launch_build_isa(c->d_sa_lo, c->ix.n, c->d_isa, c->stream, i0, i1);
     HIP_TRY(hipGetLastError());
@@ -407,6 +438,7 @@ int tables_end(bk_ctx *c, TablePlan &tp)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (tp.ktab) {
         if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+        else if (tp.ktab2) { c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab); c->ktab_is2 = true; }
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
         c->ix.k = tp.k;
     }
@@ -426,27 +458,15 @@ int tables_end(bk_ctx *c, TablePlan &tp)
         HIP_TRY(hipGetLastError());
         c->ix.k2 = c->d_k2;
         for (int i = 0; i < kMoreKeys; i++) c->ix.kx[i] = i < tp.kx ? c->d_kx[i] : nullptr;
-        // the k-mer table takes the first key of every bucket in (4-byte indexes; 17 GB more at k = 16): see DevIndex::ktab2
-        if (c->use_ktab2 && !c->ktab64 && !c->ktab_is2 && c->ix.ktab32 != nullptr) {
-            const uint64_t n_entries = (1ULL << (2 * c->ix.k)) + 1;
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            void *d2 = nullptr;
-            if (n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&d2, n_entries * 8) == hipSuccess) {
-                launch_make_ktab2(c->ix.ktab32, c->d_k2, n_entries, c->ix.n, d2, c->stream);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                free_dev(c->d_ktab);
-                c->d_ktab = d2;
-                c->ktab_bytes = (size_t)n_entries * 8;
-                c->ktab_is2 = true;
-                c->ix.ktab32 = nullptr;
-                c->ix.ktab2 = reinterpret_cast<const uint2 *>(d2);
-            } else
-                (void)hipGetLastError();
-        }
+    }
+    // the second words of a k-mer table of pairs (its first words, the bucket starts, are in place): a bucket's only key or the map of
+    // its keys' first five bits - or maps that hide nothing where the keys turned out unusable
+    if (tp.ktab2) {
+        launch_fill_ktab2_y(c->d_ktab, c->d_k2, (1ULL << (2 * tp.k)) + 1, c->stream);
+        HIP_TRY(hipGetLastError());
     }
     if (tp.isa) c->ix.isa = c->d_isa;
+    HIP_TRY(hipStreamSynchronize(c->stream));       // (batches run on their callers' streams, which do not wait for this one)
     // pass B's items grouped by bucket: 1.6 ms of a C2 step's pass B for 2.2 ms of sorting once the deep bisections run over key arrays
     // (profiles/NOTES.md, round 5) - grouped only where they still run over suffix array + target
     if (!c->sort_lists_set) c->sort_lists = (c->sort_lists & ~1) | (c->ix.kx[0] == nullptr ? 1 : 0);
@@ -1050,6 +1070,12 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
             HIP_TRY(hipGetLastError());
             tm.end(0, e1, s);
         }
+        if (phase == c->dbg_stop_phase) {
+            // (test hook, bk_debug_intervals: the interval records the search of this phase wrote stay where they are; nothing of the
+            // phase's extension or of the phases behind it runs, so the batch's result records are not to be used)
+            c->dbg_n = n; c->dbg_ivc = ivc; c->dbg_cur = cur; c->dbg_phase = phase; c->dbg_valid = true;
+            break;
+        }
         hipEvent_t e2 = tm.begin(s);
         // 5-byte indexes: the reference's seen-target set is keyed by the target start truncated to 32 bits (SfxArrayV2.cpp:5932), a
         // rule that depends on every earlier candidate of the strand pass.  k_flat and the hash-set kernels reproduce it; the
@@ -1111,6 +1137,9 @@ int align_chunk(bk_ctx *c, const DevReads &in, uint32_t first, uint32_t n, uint3
         }
         cur ^= 1;
         if (phase > 70) return BK_ERR_INTERNAL;
+    }
+    if (c->dbg_stop_phase >= 0 && !c->dbg_valid) {       // (no read reached that phase: an empty list - ctl[kMaxPhases] is never written)
+        c->dbg_n = n; c->dbg_ivc = ivc; c->dbg_cur = cur; c->dbg_phase = kMaxPhases; c->dbg_valid = true;
     }
     if (no_readback) {
         // what the phases needed goes to the host on its own time: it sizes the next chunk's sorts (and says whether a read was handed to the
@@ -1696,6 +1725,12 @@ int bk_device_count(void)
     return n;
 }
 
+// One rule for the command line, the benchmark and any other caller (include/biokanga_amd.h)
+uint32_t bk_image_policy(uint64_t reads_per_device)
+{
+    return reads_per_device >= BK_POLICY_MIN_READS ? BK_CTX_WINDOW_ARRAY_EAGER : BK_CTX_GROW_IMAGE;
+}
+
 int bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p)
 {
     return bk_ctx_create_ex(out, sfx_path, device_id, p, 0);
@@ -1773,7 +1808,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         TablePlan tp;
         if (!rc) rc = tables_begin(c, tp);
         const uint64_t n = f.concat_len;
-        uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 26));             // (slices of at least 256 MB)
+        uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(16, n >> 26));            // (slices of at least 256 MB; what the tables still owe when the last one has arrived is a slice's worth)
         if (const char *e = getenv("BK_TABLE_SLICES")) n_slices = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)atoi(e), n));      // (tests: small indexes in several slices)
         // The window array, when the caller wants it from the start, is made behind the slices as well (for reads of a hundred bases: a
         // first batch of another shortest core length makes it again, which costs little): what it reads besides suffix array and keys -
@@ -1871,7 +1906,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->use_ktab2 = src->use_ktab2;
     c->use_k3 = src->use_k3;
     c->sort_lists = src->sort_lists; c->sort_lists_set = src->sort_lists_set;
-    c->grow_enabled = src->grow_enabled && src->grow_state.load() != 4; c->grow_after = src->grow_after;       // (a clone of a grown context has what it grew)
+    c->grow_enabled = src->grow_enabled && src->grow_state.load() != 4; c->grow_after = src->grow_after; c->grow_wait = src->grow_wait;       // (a clone of a grown context has what it grew)
     c->ktab_bytes = src->ktab_bytes;
     c->nflag_bytes = src->nflag_bytes;
     c->use_ktab = src->use_ktab; c->k_req = src->k_req; c->use_k2 = src->use_k2; c->use_isa = src->use_isa; c->use_wave = src->use_wave; c->use_tgt2 = src->use_tgt2;
@@ -2127,6 +2162,19 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         c->use_wave = value ? 1 : 0;
         int rc = build_tables(c);
         return rc ? rc : old;
+    }
+    if (n == "force_rccl") {              // bk_seq_counts_allreduce goes through RCCL even when every context sits on one device
+        int64_t old = c->force_rccl ? 1 : 0;
+        c->force_rccl = value != 0;
+        return old;
+    }
+    if (n == "rccl_allreduces") return (int64_t)c->rccl_allreduces;      // (read only) reductions of this context that went through RCCL
+    if (n == "rccl_ranks") return (int64_t)c->rccl_ranks;                // (read only) .. and the ranks of the last one's communicator
+    if (n == "debug_stop_phase") {        // test hook: the next batches stop behind the search of phase value - 1 (bk_debug_intervals); 0: off
+        int64_t old = c->dbg_stop_phase + 1;
+        c->dbg_stop_phase = value <= 0 ? -1 : (int)value - 1;
+        c->dbg_valid = false;
+        return old;
     }
     if (n == "max_read_len") {
         int64_t old = c->max_read_len;
@@ -2603,6 +2651,40 @@ int bk_snp_sites(bk_ctx *c, uint32_t chrom_id, int32_t min_reads, double min_non
     return BK_OK;
 }
 
+// Test hook for the search stage (tests/test_gpu_search_stage.py): what LocateFirstExact / LocateLastExact's device form left for every
+// (read, strand, core) of the phase named with "debug_stop_phase", as the kernels behind it would have read it
+int bk_debug_intervals(bk_ctx *c, uint32_t cap_reads, uint32_t *n_act, uint32_t *iv_cores, uint32_t *act, uint64_t *first, uint32_t *count)
+{
+    if (!c || !n_act || !iv_cores) return BK_ERR_PARAMS;
+    if (!c->dbg_valid) return BK_ERR_PARAMS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    PhaseCtl ctl{};
+    HIP_TRY(hipMemcpy(&ctl, c->d_ctl + c->dbg_phase, sizeof(PhaseCtl), hipMemcpyDeviceToHost));
+    *n_act = ctl.n_act;
+    *iv_cores = c->dbg_ivc;
+    if (!act && !first && !count) return BK_OK;
+    if (!act || !first || !count || ctl.n_act > cap_reads || ctl.n_act > c->dbg_n) return BK_ERR_PARAMS;
+    const uint32_t na = ctl.n_act, stride = c->dbg_n, planes = 2 * c->dbg_ivc;
+    HIP_TRY(hipMemcpy(act, c->d_act[c->dbg_cur], (size_t)na * 4, hipMemcpyDeviceToHost));
+    std::vector<uint2> h2;
+    std::vector<uint32_t> hn;
+    if (c->d_iv2) h2.resize(na);
+    else hn.resize(na);
+    for (uint32_t pl = 0; pl < planes; pl++) {
+        uint64_t *f = first + (size_t)pl * na;
+        uint32_t *q = count + (size_t)pl * na;
+        if (c->d_iv2) {
+            HIP_TRY(hipMemcpy(h2.data(), c->d_iv2 + (size_t)pl * stride, (size_t)na * 8, hipMemcpyDeviceToHost));
+            for (uint32_t a = 0; a < na; a++) { f[a] = h2[a].x; q[a] = h2[a].y; }
+        } else {
+            HIP_TRY(hipMemcpy(f, c->d_iv_first + (size_t)pl * stride, (size_t)na * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(q, c->d_iv_n + (size_t)pl * stride, (size_t)na * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return BK_OK;
+}
+
 int bk_get_counters(bk_ctx *c, bk_counters *out, int reset)
 {
     if (!c || !out) return BK_ERR_PARAMS;
@@ -2695,7 +2777,9 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
             HIP_TRY(hipGetLastError());
         }
     }
-    if (leaders.size() > 1) {
+    // ("force_rccl": a run on ONE device takes the RCCL branch too - a communicator of one rank - so that the binding, the communicator
+    // set-up and the grouped all-reduce run on hardware wherever the library does, not only on a multi-GPU node)
+    if (leaders.size() > 1 || ctxs[0]->force_rccl) {
         static Rccl rccl;
         if (!rccl.ok) return BK_ERR_INTERNAL;
         std::vector<int> devs;
@@ -2724,6 +2808,7 @@ int bk_seq_counts_allreduce(bk_ctx *const *ctxs, int n, uint64_t *out, uint32_t 
         ncclResult_t r2 = rccl.GroupEnd();
         for (int j : leaders) { (void)hipSetDevice(ctxs[j]->device); (void)hipStreamSynchronize(ctxs[j]->stream); }
         if (r != ncclSuccess || r2 != ncclSuccess) { fprintf(stderr, "biokanga_amd: ncclAllReduce failed\n"); return BK_ERR_INTERNAL; }
+        for (int i = 0; i < n; i++) { ctxs[i]->rccl_allreduces++; ctxs[i]->rccl_ranks = (int)leaders.size(); }
     }
     for (int i = 0; i < n; i++) {
         bk_ctx *c = ctxs[i], *L = ctxs[leader_of[i]];

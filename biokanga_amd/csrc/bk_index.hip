@@ -83,8 +83,10 @@ __device__ __forceinline__ uint64_t suffix_bucket(const uint64_t *__restrict__ t
 }
 
 template <bool WIDE, typename TabT>
-__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_t i0, uint64_t i1, unsigned long long *__restrict__ starts)
+__global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_t i0, uint64_t i1, unsigned long long *__restrict__ starts, int tab_stride)
 {
+    // stride 2 (TabT = uint32_t): the entries of DevIndex::ktab2, {bucket start, y} - the starts are written where they stay and
+    // k_fill_ktab2_y adds the second words once the second-level keys are there
     // (suffix array indexes [i0, i1) of 0 .. n: a table can be made range by range, as the array arrives)
     // starts (optional; i0 a multiple of 64, the bitmap zeroed): bit i = a bucket starts at suffix array index i - what this pass finds
     // out anyway, kept for the partial window array's coverage (k_swin_breaks)
@@ -96,7 +98,7 @@ __global__ void k_build_ktab(DevIndex ix, TabT *__restrict__ tab, int k, uint64_
         // entries (prev, cur] receive i; prev = bucket(i-1) (or -1), cur = bucket(i) (or ncodes at i == n)
         uint64_t cur = i < n ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i), k) : ncodes;
         uint64_t from = i > 0 ? suffix_bucket(ix.tgt4, sa_get<WIDE>(ix, i - 1), k) + 1 : 0;
-        for (uint64_t c = from; c <= cur; c++) tab[c] = (TabT)i;
+        for (uint64_t c = from; c <= cur; c++) tab[c * (uint64_t)tab_stride] = (TabT)i;
         if (starts != nullptr) {
             const unsigned long long m = __ballot(from != cur + 1);           // (the lanes of a wave hold 64 consecutive indexes from a multiple of 64 on)
             if ((i & 63) == 0 && m) atomicOr(&starts[i >> 6], m);
@@ -453,8 +455,9 @@ void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi,
 }
 
 // (every table builder takes a range [i0, i1) of suffix array indexes; i1 = 0 stands for the whole array)
-void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0, uint64_t i1, unsigned long long *starts)
+void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0, uint64_t i1, unsigned long long *starts, bool pairs)
 {
+    const int stride = (pairs && !tab64) ? 2 : 1;
     if (i0 & 63) starts = nullptr;
     if (i1 == 0) i1 = ix.n + 1;                      // (the entry past the last bucket comes with index n)
     if (i1 <= i0) return;
@@ -462,11 +465,11 @@ void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStre
     if (blocks > 262144) blocks = 262144;
     bool wide = ix.sa_hi != nullptr;
     if (wide) {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts);
-        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<true, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts, stride);
+        else hipLaunchKernelGGL((k_build_ktab<true, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts, stride);
     } else {
-        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts);
-        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts);
+        if (tab64) hipLaunchKernelGGL((k_build_ktab<false, uint64_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint64_t *)tab, k, i0, i1, starts, stride);
+        else hipLaunchKernelGGL((k_build_ktab<false, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (uint32_t *)tab, k, i0, i1, starts, stride);
     }
 }
 
@@ -506,6 +509,31 @@ __global__ void __launch_bounds__(256) k_make_ktab2(const uint32_t *__restrict__
             }
         out[c] = make_uint2(lo, y);
     }
+}
+
+// the same for a table whose entries already are pairs with their first words - the bucket starts - in place (k_build_ktab, stride 2):
+// the second words alone.  k2 == nullptr (the keys turned out unusable: the one-pass search reads the starts only): maps that hide nothing
+__global__ void __launch_bounds__(256) k_fill_ktab2_y(uint2 *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lo = tab[c].x;
+        const uint64_t hi = c + 1 < n_entries ? (uint64_t)tab[c + 1].x : (uint64_t)lo;
+        uint32_t y = 0u;
+        if (k2 == nullptr) y = 0xFFFFFFFFu;
+        else if (hi == (uint64_t)lo + 1) y = k2[lo];
+        else if (hi > (uint64_t)lo + kTab2BitmapMax) y = 0xFFFFFFFFu;
+        else
+            for (uint64_t i = lo; i < hi; i++) {
+                const uint32_t key = k2[i];
+                if (key != kK2Above) y |= 1u << (key >> 27);
+            }
+        tab[c].y = y;
+    }
+}
+
+void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_ktab2_y, dim3(65536), dim3(256), 0, s, reinterpret_cast<uint2 *>(tab2), k2, n_entries);
 }
 
 void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s)

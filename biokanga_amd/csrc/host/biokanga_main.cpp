@@ -345,15 +345,13 @@ int read_align_opts(Args &a, AlignOpts &o)
     return 0;
 }
 
-// Long runs - from this many reads per device on - are cut into larger batches.  (The tables that only pay over long runs are grown in
-// the background by the library itself: BK_CTX_GROW_IMAGE, below.)
+// Long runs - from this many reads per device on - are cut into larger batches.
 constexpr unsigned long long kLongRunMinReads = 600000000ULL;
-// The suffix-ordered window array holds the part of the suffix array the wave kernel's long walks visit (a sixth of a 3.1 Gbp index,
-// 25 GB) and is made behind the suffix array's upload (BK_CTX_WINDOW_ARRAY_EAGER), slice by slice while the next slice crosses PCIe:
-// what is left after the last slice is a few milliseconds, against 0.3 ns per read that the array saves (round 5, C2: 98 -> 83 ms per
-// 50 M reads of 100 bases; profiles/r05_*).  It comes with the index from this many reads per device on, or with --window-array;
-// bench.py measures its headline in the layout this rule picks.
-constexpr unsigned long long kWindowArrayMinReads = 20000000ULL;
+// The index image a job gets - the suffix-ordered window array (a sixth of a 3.1 Gbp index, 25 GB), the k-mer table's second words, the
+// third- and fourth-level search keys: all made behind the suffix array's upload, slice by slice while the next slice crosses PCIe -
+// follows the library's one rule, bk_image_policy(reads per device): everything from BK_POLICY_MIN_READS reads on (0.1 - 0.2 s more load
+// on a 3.1 Gbp index for 0.7 ns less per read of a hundred bases), the lean image that grows should the run turn out long below.
+// bench.py measures its headline on the image this rule picks.
 
 // what the alignment pass leaves for the policies above the boundary
 struct AlignedSet {
@@ -833,7 +831,7 @@ int cmd_align(int argc, char **argv, int first)
     std::vector<int> ctx_rc(ndev, 0);
     std::vector<std::thread> loaders;
     // the first device reads the .sfx and builds the tables; the others receive the finished image device to device (xGMI)
-    // The suffix-ordered window array pays from kWindowArrayMinReads reads per device on.  The decision is made HERE, from the size of
+    // The image pays from BK_POLICY_MIN_READS reads per device on (bk_image_policy).  The decision is made HERE, from the size of
     // the input files, before a single read is parsed: the array then comes with the index image (made behind the slices of the suffix
     // array's upload) instead of in front of the first batch.  A FASTA record of a 100-base read is about 120 bytes, a FASTQ one about
     // 250; gzip'd files hold about four times their size.
@@ -867,18 +865,18 @@ int cmd_align(int argc, char **argv, int first)
     const uint64_t pre_early_est = (1u << 20) + plain_bytes + plain_bytes / (o.pe_mode ? 2 : 3);
     if (pre_early) pre.start(opath0.c_str(), pre_early_est, 2);
     const bool long_run = est_reads / ndev >= kLongRunMinReads;
-    // (--window-array on | off overrides the rule)
+    // bk_image_policy, from the reads a device is going to align; --window-array on | off and --index-image lean | full override its two halves
+    uint32_t ctx_flags = bk_image_policy(est_reads / ndev);
     const std::string wa = a.has("window-array") ? a.str("window-array") : std::string();
     const bool wa_off = wa == "off" || wa == "0" || wa == "no";
-    const bool want_array = !wa_off && (!wa.empty() || est_reads / ndev >= kWindowArrayMinReads);
-    // The tables that only pay over long runs - k-mer table entries with their bucket's first key, third- and fourth-level search keys:
-    // 43 GB more at 3.1 Gbp, 3 s more before the first batch when they are made up front (round 5, `tools/e2e_cli.py`: T_e2e of 50 M reads
-    // 6.0 s against 3.2 s) for 0.18 ns per read - are made in the background once a device has aligned a thousand million reads
-    // (BK_CTX_GROW_IMAGE); --index-image lean | full overrides: never, or up front
+    if (wa_off) ctx_flags &= ~BK_CTX_WINDOW_ARRAY_EAGER;
+    else if (!wa.empty()) ctx_flags |= BK_CTX_WINDOW_ARRAY_EAGER;
+    const bool want_array = (ctx_flags & BK_CTX_WINDOW_ARRAY_EAGER) != 0;
     const std::string img = a.has("index-image") ? a.str("index-image") : std::string();
-    const uint32_t img_flags = img == "full" ? 0u : (img == "lean" ? BK_CTX_LEAN_IMAGE : BK_CTX_GROW_IMAGE);
+    if (img == "full") ctx_flags &= ~(BK_CTX_GROW_IMAGE | BK_CTX_LEAN_IMAGE);
+    else if (img == "lean") ctx_flags = (ctx_flags & ~BK_CTX_GROW_IMAGE) | BK_CTX_LEAN_IMAGE;
     loaders.emplace_back([&]() {
-        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, (want_array ? BK_CTX_WINDOW_ARRAY_EAGER : 0u) | img_flags);
+        ctx_rc[0] = bk_ctx_create_ex(&ctxs[0], a.str("I").c_str(), o.devices[0], &o.P, ctx_flags);
         if (ctx_rc[0] || ndev == 1) return;
         std::vector<std::thread> cloners;
         for (size_t d = 1; d < ndev; d++) cloners.emplace_back([&, d]() { ctx_rc[d] = bk_ctx_clone(&ctxs[d], ctxs[0], o.devices[d]); });
@@ -913,8 +911,9 @@ int cmd_align(int argc, char **argv, int first)
     size_t nr = rs.size();
     // (the other devices' contexts, copies of the first's image, make their window arrays when their first batch arrives)
     for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want_array ? 1 : 0);
-    diag("Suffix-ordered window array: %s (%zu reads per device, %llu estimated from the input files' sizes; it comes with the index from %llu reads per device on; --window-array on | off overrides)",
-         want_array ? "on" : "off", nr / ctxs.size(), (unsigned long long)(est_reads / ndev), (unsigned long long)kWindowArrayMinReads);
+    diag("Index image: %s, suffix-ordered window array %s (%zu reads per device, %llu estimated from the input files' sizes; every table comes with the index from %llu reads per device on; --index-image lean | full and --window-array on | off override)",
+         (ctx_flags & BK_CTX_LEAN_IMAGE) ? "lean" : ((ctx_flags & BK_CTX_GROW_IMAGE) ? "lean, grows on a long run" : "every table"), want_array ? "on" : "off", nr / ctxs.size(),
+         (unsigned long long)(est_reads / ndev), (unsigned long long)BK_POLICY_MIN_READS);
     // (the SAM file of any other large run is started now: name + bases (+ qualities) + about 31 bytes per record, 55 for a paired end)
     if (sam_plain && pre.fd < 0) {
         const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)

@@ -141,21 +141,28 @@ int  bk_ctx_create(bk_ctx **out, const char *sfx_path, int device_id, const bk_a
  * "use_swin").  Replaces the candidates' random target reads of LocateCoreMultiples' walk (libbiokanga/SfxArrayV2.cpp:5862-5915) by a
  * streaming read; results never depend on it. */
 #define BK_CTX_WINDOW_ARRAY_EAGER 1u
-/* BK_CTX_LEAN_IMAGE: tables that pay only over hundreds of millions of reads are left out - today the k-mer table entries that carry
- * their bucket's first key ("use_ktab2": 17 GB more to allocate, 0.3 s on a fresh process, for 0.06 ns per read) and the third- and
- * fourth-level search keys ("use_k3": 4 bytes per suffix each).  Results never depend on it. */
+/* BK_CTX_LEAN_IMAGE: the tables that only pay from tens of millions of reads on are left out - the k-mer table's second words (a
+ * bucket's only key, or the map of its keys' first five bits; "use_ktab2": 17 GB more at 3.1 Gbp, 0.18 ns per read of a hundred bases
+ * together with the next) and the third- and fourth-level search keys ("use_k3": 4 bytes per suffix each).  Without the flag they are
+ * part of the image wherever a fifth of the HBM stays free behind them, made behind the suffix array's upload like the other tables
+ * (0.05 - 0.2 s of a 3.1 Gbp index's load on an idle device: profiles/r06_*_e2e_image*.txt).  Results never depend on it. */
 #define BK_CTX_LEAN_IMAGE 2u
-/* BK_CTX_NO_DEEP_KEYS: the third- and fourth-level search keys alone are left out (8 bytes per suffix: 26 GB at 3.1 Gbp, 0.4 s to allocate
- * on a fresh process, for 0.12 ns per read of a hundred bases - they pay from three or four thousand million reads per device on, or in
- * a service that keeps its context).  Results never depend on it. */
+/* BK_CTX_NO_DEEP_KEYS: the third- and fourth-level search keys alone are left out (8 bytes per suffix: 26 GB at 3.1 Gbp).  Results
+ * never depend on it. */
 #define BK_CTX_NO_DEEP_KEYS 4u
-/* BK_CTX_GROW_IMAGE: the context starts with the lean image and makes the tables BK_CTX_LEAN_IMAGE leaves out in the background once it has
- * aligned a thousand million reads (tuning knob "grow_after_reads"): a thread of its own allocates and fills them on a stream of its own -
- * 3 s beside the batches under way on a 3.1 Gbp index, where making them up front delays the first batch by as much - and the next batch
- * after they are complete takes them in.  "image_wait" makes them at once and waits (benchmarks that measure the grown image); the
- * environment's BK_GROW_AFTER_READS=<n> sets the threshold of every context created with the flag and makes the batch after the one
- * that started the worker wait for it (tests: a small run that grows).  Results never depend on it. */
+/* BK_CTX_GROW_IMAGE: the context starts with the lean image - what a job of a few million reads wants - and, should it turn out to
+ * align 5 x BK_POLICY_MIN_READS reads after all (tuning knob "grow_after_reads"), makes the tables BK_CTX_LEAN_IMAGE leaves out in the
+ * background: a thread of its own allocates and fills them on a stream of its own and the next batch after they are complete takes
+ * them in.  "image_wait" makes them at once and waits; the environment's BK_GROW_AFTER_READS=<n> sets the threshold of every context
+ * created with the flag and makes the batch after the one that started the worker wait for it (tests: a small run that grows).
+ * Results never depend on it. */
 #define BK_CTX_GROW_IMAGE 8u
+/* The image a job gets, by ONE rule for the command line (`biokanga align`, which knows its read count from the input files' sizes),
+ * the benchmark and any other caller: the flags for bk_ctx_create_ex from the reads one device is going to align.  From
+ * BK_POLICY_MIN_READS on: every table and the window array from the start (BK_CTX_WINDOW_ARRAY_EAGER - 0.1 - 0.2 s more load for 0.7 ns
+ * less per read of a hundred bases at 3.1 Gbp); below, or when the count is not known (0): BK_CTX_GROW_IMAGE. */
+#define BK_POLICY_MIN_READS 20000000ULL
+uint32_t bk_image_policy(uint64_t reads_per_device);
 int  bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk_align_params *p, uint32_t flags);
 
 /* Same, from an index image already resident in HBM (synthetic benchmarks, GPU-built indexes):
@@ -209,6 +216,9 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   is in HBM right now, what it occupies, what making it took, the share of the suffix array it holds, the core lengths its coverage is for)
  *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's
  *   needs; 0: counts read back between launches, as every other configuration does)
+ *   "force_rccl" (bk_seq_counts_allreduce goes through RCCL - a communicator of one rank - even when every context sits on one device; how many
+ *   of a context's reductions did, and the ranks of the last one's communicator: "rccl_allreduces", "rccl_ranks", read only)
+ *   "debug_stop_phase" (test hook, see bk_debug_intervals)
  *   "chunk_reads" (reads per pass over the phases)   "max_read_len"
  * returns the old value or <0 */
 int64_t bk_ctx_tune(bk_ctx *ctx, const char *name, int64_t value);
@@ -519,6 +529,19 @@ void bk_sam_prep_free(bk_sam_prep *prep);
 int  bk_sam_prep_wait(bk_sam_prep *prep);
 typedef int (*bk_sam_sink)(void *user, const char *text, uint64_t n_bytes, uint64_t text_offset);
 int  bk_sam_format(bk_ctx *ctx, const bk_sam_job *job, bk_sam_sink sink, void *user, uint64_t *n_reported, uint64_t *n_bytes);
+
+/* ---- test hook: the search stage on its own ------------------------------------------------------------------------
+ * LocateFirstExact / LocateLastExact (SfxArrayV2.cpp:7765-7876, :7914-8027) are two kernels here (k-mer table + key arrays, bk_search.hip); to
+ * hold them to the reference's functions probe by probe, a context can be told to stop a batch behind the search of one phase of
+ * AlignReads' schedule - bk_ctx_tune(ctx, "debug_stop_phase", p + 1), 0 = off; the batch's result records are then meaningless - and this call
+ * returns what that search wrote for the reads still unaligned in that phase (one chunk: batches of at most "chunk_reads" reads):
+ *   n_act, iv_cores   reads on the phase's list, cores per strand the records are numbered for
+ *   act[n_act]        their numbers in the batch
+ *   first / count     [(strand * iv_cores + core) * n_act + position in act]: the suffix array interval [first, first + (count & 0x3fffffff))
+ *                     of the core's exact matches; bit 31 of count: a k-mer bucket of at most four suffixes handed on unverified
+ *                     ("lazy_search" 1 - the extension drops the members whose core bases differ); a core the read does not have: count 0
+ * act == NULL: only n_act and iv_cores.  cap_reads: what the arrays hold per plane. */
+int  bk_debug_intervals(bk_ctx *ctx, uint32_t cap_reads, uint32_t *n_act, uint32_t *iv_cores, uint32_t *act, uint64_t *first, uint32_t *count);
 
 /* ---- .sfx index construction (CSfxArrayV3::AddEntry/Finalise, kangax.cpp:774-926) ------------ */
 /* Suffix-sorts `concat_len` bases resident in HBM (1 byte/base, EOS terminated entries) into

@@ -1846,3 +1846,35 @@ int64_t ora_snp_chrom_sites(const ora_sfx *s, const uint8_t *bases, const uint64
     free(cnts);
     return (int64_t)n_sites;
 }
+
+/* Test helper for the stage-level search parity (tests/test_gpu_search_stage.py): LocateFirstExact and LocateLastExact over the whole
+ * suffix array for n probes cut from `bases` (probe i = bases[probe_ofs[i] .. + probe_len[i])), by nthreads threads.  first / last:
+ * index + 1 of the lowest / highest matching suffix array element, 0 = no match - what the two reference functions return. */
+typedef struct { const ora_sfx *s; const uint8_t *bases; const uint64_t *ofs; const int32_t *len; int64_t *first, *last; uint64_t lo, hi; } locate_job;
+static void *locate_main(void *arg)
+{
+    locate_job *j = (locate_job *)arg;
+    const int64_t top = (int64_t)j->s->concat_len - 1;
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+        j->first[i] = ora_locate_first_exact(j->s, j->bases + j->ofs[i], j->len[i], 0, top, NULL);
+        j->last[i] = j->first[i] ? ora_locate_last_exact(j->s, j->bases + j->ofs[i], j->len[i], 0, top, NULL) : 0;
+    }
+    return NULL;
+}
+void ora_locate_cores(const ora_sfx *s, const uint8_t *bases, const uint64_t *probe_ofs, const int32_t *probe_len, uint64_t n,
+                      int64_t *first, int64_t *last, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    locate_job job[64];
+    pthread_t th[64];
+    const uint64_t per = (n + (uint64_t)nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t lo = per * (uint64_t)t, hi = lo + per;
+        if (lo > n) lo = n;
+        if (hi > n) hi = n;
+        job[t] = (locate_job){s, bases, probe_ofs, probe_len, first, last, lo, hi};
+        pthread_create(&th[t], NULL, locate_main, &job[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}

@@ -112,6 +112,8 @@ def oracle_lib():
     lib.ora_locate_first_exact.restype = ctypes.c_int64
     lib.ora_locate_last_exact.argtypes = lib.ora_locate_first_exact.argtypes
     lib.ora_locate_last_exact.restype = ctypes.c_int64
+    lib.ora_locate_cores.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.ora_locate_cores.restype = None
     _oracle = lib
     return lib
 

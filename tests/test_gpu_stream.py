@@ -262,6 +262,34 @@ def test_seq_counts_allreduce_over_contexts(golden_tmp):
         assert a0.seq_counts().sum() == 0 and a1.seq_counts().sum() == 0          # reset
 
 
+def test_exchange_step_through_rccl_on_one_device(golden_tmp):
+    """the library's own RCCL binding on hardware: dlopen of librccl, ncclCommInitAll (a communicator of one rank), the grouped
+    ncclAllReduce on the context's stream - forced for contexts that share the one GPU ("force_rccl"), where the reduction would
+    otherwise be a device-side add.  Same counts as the plain path, twice (communicators are kept)."""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "basic", "s3")
+    offs, lens = offs[keep], lens[keep]
+    sfx = os.path.join(d, "genome.sfx")
+    with bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as a0, bk.Aligner(sfx, bk.AlignParams(max_subs=3)) as a1:
+        hits = a0.align(bases, offs, lens)
+        exp = a0.seq_counts(reset=True)
+        assert a0.tune("rccl_allreduces", 0) == 0
+        a0.tune("force_rccl", 1)
+        a0.align(bases, offs, lens)
+        got = bk.seq_counts_allreduce([a0], reset=True)
+        assert np.array_equal(got, exp) and got.sum() == int((hits["nar"] == 1).sum())
+        assert a0.tune("rccl_allreduces", 0) == 1 and a0.tune("rccl_ranks", 0) == 1
+        # two contexts on the device: added up on the device first, then the one-rank all-reduce
+        a0.align(bases, offs[0::2], lens[0::2])
+        a1.align(bases, offs[1::2], lens[1::2])
+        assert np.array_equal(bk.seq_counts_allreduce([a0, a1], reset=True), exp)
+        assert a0.tune("rccl_allreduces", 0) == 2 and a1.tune("rccl_allreduces", 0) == 1
+        a0.tune("force_rccl", 0)
+        a0.align(bases, offs, lens)
+        assert np.array_equal(bk.seq_counts_allreduce([a0], reset=True), exp)
+        assert a0.tune("rccl_allreduces", 0) == 2
+
+
 def test_cloned_context_and_distinct_devices(golden_tmp):
     """bk_ctx_clone copies the finished index image device to device; a clone aligns like its source.  With two GPUs visible the
     clone lives on the second one and the exchange step takes the RCCL branch (ncclAllReduce between distinct devices)."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end timing of our command line (`biokanga_amd/bin/biokanga align`) on the bench workload:
 T_e2e (process start -> exit) and the phases from its time-stamped log.  Files live in /dev/shm.
-  python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--quiet] [--gz] [-- extra options of biokanga align]
+  python tools/e2e_cli.py [n_reads] [--variants "name:ENV=V,ENV2=V;other:ENV=W"] [--repeat N] [--pause S] [--quiet] [--gz] [-- extra options of biokanga align]
 Every variant is the same command with its own environment (the first run, "default", has none; BK_E2E_ARGS=<options> adds options of
 biokanga align to a variant's command); the files are written once.
 --gz: the reads also as reads.fa.gz (one member, level 1) and reads.fa.bgz (bgzip members); every variant then runs on the three inputs
@@ -74,6 +74,7 @@ def main():
             variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
     repeat = int(argv[argv.index("--repeat") + 1]) if "--repeat" in argv else 1
     quiet = "--quiet" in argv
+    pause = float(argv[argv.index("--pause") + 1]) if "--pause" in argv else 0.0      # seconds of rest before every run: the driver wipes what the process before gave back at about 40 GB/s, and a run that starts meanwhile waits for it
     with_gz = "--gz" in argv
     try:
         quota = open("/sys/fs/cgroup/cpu.max").read().strip()
@@ -112,11 +113,14 @@ def main():
         for name, env in variants:
             env = dict(env)
             fa_in = env.pop("BK_E2E_INPUT", fa)
+            pause_v = float(env.pop("BK_E2E_PAUSE", pause))        # (a variant's own rest before its runs)
             more = env.pop("BK_E2E_ARGS", "").split()              # (a variant's own options of biokanga align: "name:BK_E2E_ARGS=--no-window-array")
             for rep in range(repeat):
                 for f in (sam, logf, logf + ".err"):
                     if os.path.exists(f):
                         os.unlink(f)
+                if pause_v:
+                    time.sleep(pause_v)
                 t = time.time()
                 rc = subprocess.run([os.path.join(ROOT, env.get("BK_E2E_BIN", os.path.join("biokanga_amd", "bin", "biokanga"))), "align", "-i", fa_in, "-I", sfx, "-o", sam, "-s3", "-M6", "-F", logf] + extra + more,
                                     stdout=subprocess.DEVNULL, stderr=open(logf + ".err", "w"), env=dict(os.environ, BK_TIMING="1", **env), timeout=300).returncode
