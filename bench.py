@@ -60,6 +60,9 @@ def effective_cpus():
     return n
 
 
+_REAL_STDOUT = None       # the process's own stdout, kept aside by main() (see there)
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
     touched a GPU yet) through the same torch.distributed.run command line the driver uses, and hand their exit code back."""
@@ -640,6 +643,14 @@ def main():
         ap.error("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))          # before anything here touches a GPU
+    # ONE JSON line on stdout is the contract; libraries underneath (RCCL prints its version banner there when a communicator comes up) write
+    # to file descriptor 1 behind Python's back - so descriptor 1 is pointed at stderr for the whole run and the line goes out through a
+    # copy of the real one at the end
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     cfg = CONFIGS[args.config]
     args.reads = args.reads or cfg["reads"]
     args.genome_mbp = args.genome_mbp or cfg.get("genome_mbp", 3100.0)
@@ -1096,7 +1107,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=_REAL_STDOUT or sys.stdout, flush=True)
 
 
 def multi_gpu_legs(al, make_set, run_step, counts_dev, args, rank, world, dev, barrier, all_reduce, dist):

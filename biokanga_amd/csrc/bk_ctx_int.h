@@ -80,6 +80,7 @@ struct bk_ctx {
     double swin_setup_s = 0;  // .. and what making them took (allocation included)
     double swin_covered = 0;  // .. share of the suffix array it holds
     bool swin_denied = false; // it did not fit beside a batch's scratch when first asked for
+    bool swin_rebuilt = false; // a batch has already made the partial array again for its own core lengths (maybe_build_swin does that once)
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;

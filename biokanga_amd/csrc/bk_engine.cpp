@@ -157,9 +157,10 @@ int derive_cfg(bk_ctx *c)
     if (p.micro_indel_len < 0 || p.micro_indel_len > 20) return BK_ERR_PARAMS;           // cMaxMicroInDelLen
     if ((p.micro_indel_len || p.splice_junct_len) && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;   // LocateBestMatches has no such branches
     if (p.min_chimeric_len != 0 && (p.min_chimeric_len < 50 || p.min_chimeric_len > 99)) return BK_ERR_PARAMS;          // kanga.cpp:648-653
-    // -c with the multi-loci modes: the chimeric call lists its loci; not together with -N (no chimeric branch there) or -a / -A (a chimeric
-    // call that inherits an ambiguous microInDel search would have to list that search's loci too)
-    if (p.min_chimeric_len != 0 && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;          // (kanga.cpp:712-716; with -a / -A the combination is the reference's own: tests/golden/chimmlindel)
+    // -c with the multi-loci modes: the chimeric call lists its loci - also together with -a / -A (the microInDel / splice searches and the
+    // chimeric call run on one set of counts and hits; pinned by tests/golden/chimmlindel).  Only -N is refused, as the reference refuses
+    // it itself (no chimeric branch in LocateBestMatches; kanga.cpp:712-716)
+    if (p.min_chimeric_len != 0 && p.max_ml > 1 && p.best_matches) return BK_ERR_PARAMS;
     if (p.splice_junct_len != 0 && (p.splice_junct_len < 25 || p.splice_junct_len > 100000)) return BK_ERR_PARAMS;   // cMin/cMaxJunctAlignSep
     DevAlignCfg &g = c->cfg;
     g.max_subs = p.max_subs;
@@ -1415,8 +1416,12 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     const int words = maxlen <= 128 ? 3 : 5;
     const int w_key = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16) | (words << 24);
     if (c->d_swin) {
-        // (a partial array made for other core lengths - another read length, an eager build's guess - is made again: it costs little)
-        if (full == (c->d_swmap == nullptr) && (full ? c->ix.sw_words == words : c->swin_w == w_key)) return BK_OK;
+        // (a partial array made for other core lengths is made again ONCE - the eager build's guess of a hundred bases against what the
+        // first batch really holds; after that an array of the right entry size is kept whatever the next batch's longest read: coverage
+        // never changes a result, and batches of variable-length reads would otherwise drop and rebuild 25 GB every time their longest
+        // read crosses a core length)
+        if (full == (c->d_swmap == nullptr) && (full ? c->ix.sw_words == words : (c->swin_w == w_key || (c->swin_rebuilt && c->ix.sw_words == words)))) return BK_OK;
+        c->swin_rebuilt = true;
         HIP_TRY(hipStreamSynchronize(s));
         free_dev(c->d_swin); free_dev(c->d_swmap);
         c->d_swin = nullptr; c->d_swmap = nullptr; c->ix.swin = nullptr; c->ix.swmap = nullptr; c->swin_bytes = 0;

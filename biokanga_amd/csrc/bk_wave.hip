@@ -69,14 +69,33 @@ static __device__ unsigned long long g_wprof[64 * 8];
 #define WPROF_END do { } while (0)
 #endif
 
+// the kernel's arguments as one structure
+struct WaveArgs {
+    DevIndex ix; DevAlignCfg cfg; DevBatch b; HeavyScratch hs;
+    const uint32_t *list, *sorted;
+    uint32_t n_sorted;
+    const uint32_t *p_n_list;
+    int phase;
+    uint32_t *cursor, *next_act, *next_cnt, *cmax_next;
+};
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
-__global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(DevIndex ix, DevAlignCfg cfg, DevBatch b, HeavyScratch hs,
-                                              const uint32_t *__restrict__ list, const uint32_t *__restrict__ sorted, uint32_t n_sorted,
-                                              const uint32_t *__restrict__ p_n_list, int phase, uint32_t *__restrict__ cursor,
-                                              uint32_t *__restrict__ next_act, uint32_t *__restrict__ next_cnt,
-                                              uint32_t *__restrict__ cmax_next)
+__global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(WaveArgs wa)
 {
-    __shared__ WaveCoreInfo s_core[4][kMaxCoresFast];
+    const DevIndex &ix = wa.ix;
+    const DevAlignCfg &cfg = wa.cfg;
+    const DevBatch &b = wa.b;
+    const HeavyScratch &hs = wa.hs;
+    const uint32_t *__restrict__ list = wa.list, *__restrict__ sorted = wa.sorted, *__restrict__ p_n_list = wa.p_n_list;
+    const uint32_t n_sorted = wa.n_sorted;
+    const int phase = wa.phase;
+    uint32_t *__restrict__ cursor = wa.cursor, *__restrict__ next_act = wa.next_act, *__restrict__ next_cnt = wa.next_cnt, *__restrict__ cmax_next = wa.cmax_next;
+    // Both strand passes of a read are set up at once - interval records, window array map, 2-bit rows: one chain of dependent trips per
+    // read where a chain per strand pass left the wave without work twice - into the wave's own words of LDS
+    __shared__ WaveCoreInfo s_core[4][2][kMaxCoresFast];
+    __shared__ uint64_t s_row2[4][2][NW / 2];                    // the read's 2 bit/base rows, first and second strand pass
+    // .. and the work items are resolved a claim at a time: lane l follows item l of the claim through list -> active list -> read
+    // metadata, kGrabMax chains side by side where every item used to walk its own
+    __shared__ uint32_t s_grab[4][3][kWaveGrab];
     __shared__ uint64_t s_cmask[4][kMaxCoresFast][NW / 4];       // per core: its bases in the IWindow layout
     // HASH: the set of seen target keys of a strand pass lives in LDS (kLdsSet keys per wave, open addressing) and spills into the
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
@@ -93,8 +112,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
     const uint32_t n_list = *p_n_list;
     const uint32_t n_grouped = sorted != nullptr ? (n_list < n_sorted ? n_list : n_sorted) : 0u;
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    WaveCoreInfo *core = s_core[wib];
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (the compiler does not know it for wave-uniform: addresses in the wave's LDS words would each keep a vector register)
+    WaveCoreInfo *core = s_core[wib][0];
     uint64_t (*cmask)[NW / 4] = s_cmask[wib];
     uint32_t *lset = s_set[HASH ? wib : 0];
     uint32_t lset_n = kLdsSet;                   // keys in the LDS set (kLdsSet: not cleared yet)
@@ -116,7 +135,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
     // item serialises 8192 resident waves on a single address
     // .. but no more of them than leaves every wave several claims to make: the list comes longest job first, and eight items at a time
     // hand the eight heaviest reads of a short list to ONE wave (a batch of 3 M reads then lasts as long as those eight, one after the other)
-    uint32_t grab_next = 0, grab_left = 0;
+    uint32_t grab_next = 0, grab_left = 0, grab_at = 0;
     const uint32_t per_wave = n_list / (gridDim.x * 4u * 4u);
     const int grab = per_wave >= (uint32_t)kWaveGrab ? kWaveGrab : (per_wave < 1 ? 1 : (int)per_wave);
     // reads that go on to the next phase are parked one per lane and appended 64 at a time
@@ -137,15 +156,31 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
             if (lane == 0) g = atomicAdd(cursor, (uint32_t)grab);
             grab_next = __builtin_amdgcn_readfirstlane(g);
             grab_left = (uint32_t)grab;
+            grab_at = 0;
+            __builtin_amdgcn_wave_barrier();
+            // (the lane's number through an opaque move: what is derived from it here - addresses in the wave's LDS words - is then made
+            // where it is used, not kept in vector registers across the whole item loop as loop invariants)
+            int lg = lane;
+            asm volatile("" : "+v"(lg));
+            if (lg < grab && grab_next + (uint32_t)lg < n_list) {
+                const uint32_t it = grab_next + (uint32_t)lg;
+                const uint32_t gp = it < n_grouped ? sorted[it] : list[it];       // position in the phase's active list: where its interval records lie
+                const uint32_t gr = b.act[gp];
+                s_grab[wib][0][lg] = gp;
+                s_grab[wib][1][lg] = gr;
+                s_grab[wib][2][lg] = b.rmeta[gr];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         const uint32_t item = grab_next++;
         grab_left--;
         if (item >= n_list) break;
         // (wave-uniform values that arrive through vector loads are handed to the scalar unit explicitly: the read's plan, its loop
         // bounds and the window geometry then cost scalar instructions once instead of vector instructions in every lane)
-        const uint32_t pos = __builtin_amdgcn_readfirstlane(item < n_grouped ? sorted[item] : list[item]);          // position in the phase's active list: where its interval records lie
-        const uint32_t r = __builtin_amdgcn_readfirstlane(b.act[pos]);
-        const uint32_t meta = __builtin_amdgcn_readfirstlane(b.rmeta[r]);
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(s_grab[wib][0][grab_at]);
+        const uint32_t r = __builtin_amdgcn_readfirstlane(s_grab[wib][1][grab_at]);
+        const uint32_t meta = __builtin_amdgcn_readfirstlane(s_grab[wib][2][grab_at]);
+        grab_at++;
         const int len = (int)(meta & kReadLenMask);
         const bool has_n = (meta & kReadHasN) != 0;
         // the plan of the read's length, the core offsets and the cores' masks only change with the length: a batch of equal-length reads
@@ -161,13 +196,14 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 int o = 0;
 #pragma unroll
                 for (int q = 0; q < kMaxCoresFast; q++) if (q == lane) o = ofs_tmp[q];
-                core[lane].ofs = o;
+                s_core[wib][0][lane].ofs = o;
+                s_core[wib][1][lane].ofs = o;
             }
             __builtin_amdgcn_wave_barrier();
             const int ncm = geo_nc < kMaxCoresFast ? geo_nc : kMaxCoresFast;
             for (int idx = lane; idx < ncm * (NW / 4); idx += 64) {
                 const int cc = idx / (NW / 4), i = idx % (NW / 4);
-                const int o = core[cc].ofs;
+                const int o = s_core[wib][0][cc].ofs;
                 cmask[cc][i] = imask_word(o, o + geo_cl, i);
             }
         }
@@ -185,8 +221,58 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
         // every core offset of the read lies within an entry's lead, and the read's end within the entry; shared rounds take their
         // windows from three-word entries only
         const bool sw_read = SW && E == 3 && len <= SwGeo<E>::bases - SwGeo<E>::pre && len - cl <= SwGeo<E>::pre;
+        const bool two_bit = b.rd2 != nullptr;
+        WPROF(0);
+        {
+            // lanes 0 .. 15: the cores of the first strand pass, 16 .. 31: of the second; lanes 32 ..: the words of the two rows
+            int ls = lane;
+            asm volatile("" : "+v"(ls));                // (as in the claim: nothing derived from the lane's number here outlives the block)
+            const int sti_l = ls >> 4, c_l = ls & 15, st_l = s0 + sti_l;
+            if (ls < 32 && c_l < nc && st_l <= s1) {
+                uint64_t f;
+                uint32_t cn;
+                iv_get(b, iv_slot(b, pos, st_l, c_l), f, cn);
+                WaveCoreInfo &ci = s_core[wib][sti_l][c_l];
+                ci.first = f;
+                ci.n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
+                ci.walked = 0;
+                const uint32_t cnt_l = cn & ~kLazyFlag;
+                if (SW) {
+                    // which of the interval's candidates take their windows from the window array: all of them when it holds every suffix;
+                    // else (DevIndex::swmap) the interval when its first and last block lie as far apart in the array as in the suffix
+                    // array - every block between them is there too, in order -, or, failing that, its first kSwHead suffixes by the
+                    // same test (an interval beyond MaxIter is left after a hundred-odd candidates)
+                    uint32_t sb = (uint32_t)f, sn = cnt_l;
+                    if (ix.swmap != nullptr) {
+                        sn = 0;
+                        if (cnt_l) {
+                            const uint32_t head = cnt_l < kSwHead ? cnt_l : kSwHead;
+                            const uint32_t b0 = (uint32_t)(f >> kSwBlkShift), bl = (uint32_t)((f + cnt_l - 1) >> kSwBlkShift), bh = (uint32_t)((f + head - 1) >> kSwBlkShift);
+                            const uint32_t m0 = ix.swmap[b0], ml = ix.swmap[bl], mh = ix.swmap[bh];
+                            if (m0 != kSwNone) {
+                                sb = (m0 << kSwBlkShift) + ((uint32_t)f & ((1u << kSwBlkShift) - 1));
+                                if (ml != kSwNone && ml - m0 == bl - b0) sn = cnt_l;
+                                else if (mh != kSwNone && mh - m0 == bh - b0) {
+                                    const uint64_t upto = ((uint64_t)(bh + 1) << kSwBlkShift) - f;
+                                    sn = upto < cnt_l ? (uint32_t)upto : cnt_l;
+                                }
+                            }
+                        }
+                    }
+                    ci.sw_base = sb;
+                    ci.sw_n = sn;
+                }
+            }
+            if (two_bit && ls >= 32 && ls < 32 + NW) {
+                const int q = ls - 32, sti_r = q / (NW / 2), k = q % (NW / 2);
+                if (s0 + sti_r <= s1) s_row2[wib][sti_r][k] = b.rd2[((uint64_t)r * 2 + (uint64_t)(s0 + sti_r)) * (NW / 2) + k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        WPROF(1);
         for (int st = s0; st <= s1 && !done; st++) {
-            WPROF(st == s0 ? 0 : 2);
+            core = s_core[wib][st - s0];
+            WPROF(2);
             WPROF_N(5);
             if (HASH) {                      // a new dedupe set per strand pass (SfxArrayV2.cpp:5834)
                 if (lset_n) {
@@ -200,16 +286,9 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
             // N or a sequence end needs are not kept in registers: that path (eval_window_rare) fetches them as it goes - from the
             // 2-bit row again, or, a read with an N, from its rd4 row, which also gives its N positions
             uint64_t r2w[NW / 2], rni[NW / 4];                           // rni: "read base is N", in the IWindow layout
-            const bool two_bit = b.rd2 != nullptr;
             const RdRow row4 = read_row(b, r, st, has_n);
-            if (two_bit) {
-                load_read_words2<NW>(b.rd2 + ((uint64_t)r * 2 + st) * (NW / 2), r2w);
 #pragma unroll
-                for (int k = 0; k < NW / 2; k++) r2w[k] = uniform64(r2w[k]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NW / 2; k++) r2w[k] = 0;
-            }
+            for (int k = 0; k < NW / 2; k++) r2w[k] = two_bit ? uniform64(s_row2[wib][st - s0][k]) : 0ULL;
 #pragma unroll
             for (int k = 0; k < NW / 4; k++) rni[k] = 0;
             if (two_bit && has_n) {
@@ -223,43 +302,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
                 }
             }
-            uint32_t my_cn = 0;                       // lane l < nc: suffixes in core l's interval
-            if (lane < nc) {
-                uint64_t slot = iv_slot(b, pos, st, lane);
-                uint64_t f;
-                uint32_t cn;
-                iv_get(b, slot, f, cn);
-                core[lane].first = f;
-                core[lane].n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
-                core[lane].walked = 0;
-                my_cn = cn & ~kLazyFlag;
-                if (SW) {
-                    // which of the interval's candidates take their windows from the window array: all of them when it holds every suffix;
-                    // else (DevIndex::swmap) the interval when its first and last block lie as far apart in the array as in the suffix
-                    // array - every block between them is there too, in order -, or, failing that, its first kSwHead suffixes by the
-                    // same test (an interval beyond MaxIter is left after a hundred-odd candidates)
-                    uint32_t sb = (uint32_t)f, sn = my_cn;
-                    if (ix.swmap != nullptr) {
-                        sn = 0;
-                        if (my_cn) {
-                            const uint32_t head = my_cn < kSwHead ? my_cn : kSwHead;
-                            const uint32_t b0 = (uint32_t)(f >> kSwBlkShift), bl = (uint32_t)((f + my_cn - 1) >> kSwBlkShift), bh = (uint32_t)((f + head - 1) >> kSwBlkShift);
-                            const uint32_t m0 = ix.swmap[b0], ml = ix.swmap[bl], mh = ix.swmap[bh];
-                            if (m0 != kSwNone) {
-                                sb = (m0 << kSwBlkShift) + ((uint32_t)f & ((1u << kSwBlkShift) - 1));
-                                if (ml != kSwNone && ml - m0 == bl - b0) sn = my_cn;
-                                else if (mh != kSwNone && mh - m0 == bh - b0) {
-                                    const uint64_t upto = ((uint64_t)(bh + 1) << kSwBlkShift) - f;
-                                    sn = upto < my_cn ? (uint32_t)upto : my_cn;
-                                }
-                            }
-                        }
-                    }
-                    core[lane].sw_base = sb;
-                    core[lane].sw_n = sn;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+            const uint32_t my_cn = lane < nc ? core[lane].n & ~kLazyFlag : 0u;       // lane l < nc: suffixes in core l's interval
             // GROUP: consecutive cores with small intervals share a round - one candidate per lane in walk order (core, then suffix) -
             // instead of a round each: with a dozen cores per strand a wave otherwise spends most of its rounds on two or three
             // candidates.  None of the reference's iteration rules can fire inside such a round (fewer than 100 candidates per core,
@@ -272,7 +315,6 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 pre_ex = v - own;
             }
             uint32_t nodes = 0;
-            WPROF(1);
             for (int c = 0; c < nc && !done && nodes < kNodeCap;) {
                 // (every lane reads the same LDS words: told so, the compiler keeps them and what follows from them in scalar registers)
                 const uint64_t first = uniform64(core[c].first);
@@ -346,6 +388,18 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
 #pragma unroll
                         for (int q = 0; q < E; q++)
                             if (q >= sw_q0 && q <= sw_q1) ev[q] = ep[q * 32];
+#ifdef BK_EXP_DOUBLE_LOADS
+                        // (measurement build: the same words of another entry a megabyte away, folded in so that they are really fetched -
+                        // what the kernel's time does with twice the window array traffic)
+                        {
+                            const uint4 *__restrict__ ep2 = ep + (eidx < (1u << 20) ? 65536 * 3 : -65536 * 3);       // (inside the array either way: 65 536 entries on)
+                            uint32_t acc2 = 0;
+#pragma unroll
+                            for (int q = 0; q < E; q++)
+                                if (q >= sw_q0 && q <= sw_q1) { const uint4 v2 = ep2[q * 32]; acc2 |= v2.x & v2.y & v2.z & v2.w; }
+                            if (acc2 == 0xDEADBEEFu) ev[sw_q0 < E ? sw_q0 : 0].x ^= 1u;          // (never, but the compiler cannot know)
+                        }
+#endif
                     }
                     // (target positions of an index of 4-byte elements: 32-bit arithmetic)
                     using P = typename PosT<WIDE>::type;
@@ -382,6 +436,18 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                                 if constexpr (SW) {
                                     if (GROUP && grouped) eval_swin2i<NW, false, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
                                     else eval_swin2i<NW, true, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
+#ifdef BK_EXP_DOUBLE_COMPARE
+                                    // (measurement build: the compare once more on an entry the compiler cannot prove equal - what the
+                                    // kernel's time does with fifty more vector instructions a round)
+                                    {
+                                        uint4 ev2[E];
+#pragma unroll
+                                        for (int q = 0; q < E; q++) { ev2[q] = ev[q]; asm volatile("" : "+v"(ev2[q].x), "+v"(ev2[q].y), "+v"(ev2[q].z), "+v"(ev2[q].w)); }
+                                        IWindow<NW> w2;
+                                        eval_swin2i<NW, true, E>(r2w, rni, len, ev2, SwGeo<E>::pre - lofs, w2);
+                                        if (w2.mm != w.mm) w.mm = 127;        // (never)
+                                    }
+#endif
                                 }
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);
@@ -618,7 +684,8 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     uint32_t waves = n_bound < max_waves ? n_bound : max_waves;
     if (hash && waves > hs.n_slots) waves = hs.n_slots;
     unsigned blocks = (waves + 3) / 4;
-#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, ix, cfg, b, hs, list, sorted, n_sorted, p_n_list, phase, cursor, next_act, next_cnt, cmax_next)
+    const WaveArgs wa{ix, cfg, b, hs, list, sorted, n_sorted, p_n_list, phase, cursor, next_act, next_cnt, cmax_next};
+#define BK_WAVE(N, W, H, S, G) hipLaunchKernelGGL((k_wave<N, W, H, S, G>), dim3(blocks), dim3(256), 0, s, wa)
     const bool sw = ix.swin != nullptr && b.rd2 != nullptr && ix.sw_words == ((nw & 0xff) <= 8 ? 3 : 5);      // (entries of this kernel family's size)
     // (reads of up to 128 bases have four cores or so per strand: their small intervals take a round each; sharing rounds, as the wider
     // forms and the hash-set forms do, cost the 8-word inverse-suffix-array forms more registers than it saved rounds - round 3)
@@ -626,7 +693,11 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     if (nw <= 8) {
         if (wide) BK_WAVE(8, true, true, false, true);
         else if (hash) BK_WAVE(8, false, true, false, true);
+#ifdef BK_WAVE8_GROUP
+        else if (sw) BK_WAVE(8, false, false, true, true);
+#else
         else if (sw) BK_WAVE(8, false, false, true, false);
+#endif
         else BK_WAVE(8, false, false, false, false);
     } else if (nw <= 16) {
         if (wide) BK_WAVE(16, true, true, false, true);
