@@ -90,6 +90,7 @@ struct DevIndex {
     const uint64_t *tgt2s;      // tgt2 again, physically shifted by 32 bytes (windows never straddle a 64-byte line); may be null
     const uint8_t *nflag;       // bit per 2^flag_shift bases: region holds N/EOS (tgt2 unusable there); <= 16 KB, L1 resident
     int flag_shift;
+    uint32_t nflag_bytes;       // .. its size (a kernel may keep a copy of it in LDS)
     const uint32_t *sa_lo;
     const uint8_t *sa_hi;       // null unless 5-byte elements
     const uint64_t *ent_start;

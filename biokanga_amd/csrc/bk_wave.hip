@@ -27,6 +27,14 @@ __device__ unsigned long long g_hist_len[3][40];      // by floor(log2(interval 
 __device__ unsigned long long g_hist_ph[8][40][2];    // by phase and floor(log2(interval length)): windows fetched, .. of them from the window array
 #endif
 
+#ifndef BK_WAVE_ROUND_AHEAD
+#define BK_WAVE_ROUND_AHEAD 1
+#endif
+#ifndef BK_WAVE_NFLAG_LDS
+#define BK_WAVE_NFLAG_LDS 1
+#endif
+constexpr int kNflagLds = 12288;
+
 template <bool WIDE> struct PosT { typedef uint64_t type; };
 template <> struct PosT<false> { typedef uint32_t type; };
 
@@ -97,6 +105,17 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
     // metadata, kGrabMax chains side by side where every item used to walk its own
     __shared__ uint32_t s_grab[4][3][kWaveGrab];
     __shared__ uint64_t s_cmask[4][kMaxCoresFast][NW / 4];       // per core: its bases in the IWindow layout
+    // NFL: the block's own copy of the "region holds N / sequence end" bitmap (<= kNflagLds bytes: a 3.1 Gbp index has 12 KB).  A round's
+    // chain of dependent trips is suffix array element -> the two flag bytes of the window it names -> compare; the flag bytes came out
+    // of the L1, which is still a trip of the vector memory path, in order behind every load the wave has in flight.  From LDS they cost
+    // a hundred cycles and wait for nothing else.
+    constexpr bool NFL = SW && !HASH && BK_WAVE_NFLAG_LDS;
+    __shared__ uint32_t s_nflag[NFL ? kNflagLds / 4 : 1];
+    const bool nfl = NFL && ix.nflag != nullptr && ix.nflag_bytes <= (uint32_t)kNflagLds;
+    if (NFL && nfl) {
+        for (uint32_t i = threadIdx.x; i < ix.nflag_bytes / 4; i += blockDim.x) s_nflag[i] = reinterpret_cast<const uint32_t *>(ix.nflag)[i];
+        __syncthreads();
+    }
     // HASH: the set of seen target keys of a strand pass lives in LDS (kLdsSet keys per wave, open addressing) and spills into the
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
     // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
@@ -368,42 +387,54 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 // the entry's 16-byte words (64 bases each) the window lies in; a shared round's cores differ in it: every word
                 const int sw_q0 = (GROUP && grouped) ? 0 : (SwGeo<E>::pre - ofs) >> 6, sw_q1 = (GROUP && grouped) ? E - 1 : (SwGeo<E>::pre - ofs + len - 1) >> 6;
                 WPROF(2);
-                for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
-                    WPROF_N(6);
-                    const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
-                    const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
-                    // (a round takes its windows from the array when every candidate of it has its entry there)
-                    const bool sw_now = SW && sw_core && ((GROUP && grouped) || (j0 + 64 < n ? j0 + 64 : n) <= sw_n_c);
-                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip;
-                    // a lane without a candidate leaves the words undefined - nothing of them is looked at below)
+                // A round's loads - the candidate's suffix array element and the words of its window array entry - are requested a round
+                // ahead (RA): round k's are under way while round k - 1 computes, so a core of several rounds waits for memory once, not once
+                // a round.  Nothing else of a round's usual path goes through the vector memory unit (the flag bytes come from LDS), so the
+                // loads stay in flight across the compare; the rare paths that do load - a flagged window, an inverse suffix array look-up,
+                // windows from the 2-bit target - wait for them a round early, which costs what it cost before.
+                using P = typename PosT<WIDE>::type;
+                constexpr bool RA = SW && !HASH && !WIDE && BK_WAVE_ROUND_AHEAD;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
-                    uint4 ev[E];
-                    if (SW && sw_now && active) {
+                uint4 ev_a[RA ? E : 1];                  // RA: the round ahead's entry words, suffix array element, and whether it reads the array
+                P loci_a = 0;
+                bool sw_a = false;
+                auto request = [&](uint32_t jj0, bool &sw_r, uint4 (&e)[E], P &lo) __attribute__((always_inline)) {
+                    const uint32_t jj = (GROUP && grouped) ? lj_g : jj0 + (uint32_t)lane;
+                    const bool act = (GROUP && grouped) ? (uint32_t)lane < gtot : jj < n;
+                    // (a round takes its windows from the array when every candidate of it has its entry there)
+                    sw_r = SW && sw_core && ((GROUP && grouped) || (jj0 + 64 < n ? jj0 + 64 : n) <= sw_n_c);
+                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip;
+                    // a lane without a candidate leaves the words undefined - nothing of them is looked at below)
+                    if (SW && sw_r && act) {
                         // (only the words the core's window reaches into: which, is the same for every candidate of the core)
-                        const uint32_t eidx = lsw_base + j;
+                        const uint32_t eidx = lsw_base + jj;
                         const uint4 *__restrict__ ep = ix.swin + ((uint64_t)(eidx >> 5) * (32u * E) + (eidx & 31u));
 #pragma unroll
                         for (int q = 0; q < E; q++)
-                            if (q >= sw_q0 && q <= sw_q1) ev[q] = ep[q * 32];
-#ifdef BK_EXP_DOUBLE_LOADS
-                        // (measurement build: the same words of another entry a megabyte away, folded in so that they are really fetched -
-                        // what the kernel's time does with twice the window array traffic)
-                        {
-                            const uint4 *__restrict__ ep2 = ep + (eidx < (1u << 20) ? 65536 * 3 : -65536 * 3);       // (inside the array either way: 65 536 entries on)
-                            uint32_t acc2 = 0;
-#pragma unroll
-                            for (int q = 0; q < E; q++)
-                                if (q >= sw_q0 && q <= sw_q1) { const uint4 v2 = ep2[q * 32]; acc2 |= v2.x & v2.y & v2.z & v2.w; }
-                            if (acc2 == 0xDEADBEEFu) ev[sw_q0 < E ? sw_q0 : 0].x ^= 1u;          // (never, but the compiler cannot know)
-                        }
-#endif
+                            if (q >= sw_q0 && q <= sw_q1) e[q] = ep[q * 32];
                     }
                     // (target positions of an index of 4-byte elements: 32-bit arithmetic)
-                    using P = typename PosT<WIDE>::type;
-                    const P loci = active ? (P)sa_get<WIDE>(ix, lfirst + j) : (P)0;
+                    lo = act ? (P)sa_get<WIDE>(ix, lfirst + jj) : (P)0;
+                };
+                if constexpr (RA) request(0, sw_a, ev_a, loci_a);
+                for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
+                    WPROF_N(6);
+                    const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
+                    const bool active = (GROUP && grouped) ? (uint32_t)lane < gtot : j < n;
+                    uint4 ev[E];
+                    P loci;
+                    bool sw_now;
+                    if constexpr (RA) {
+#pragma unroll
+                        for (int q = 0; q < E; q++) ev[q] = ev_a[q];
+                        loci = loci_a;
+                        sw_now = sw_a;
+                        if (!(GROUP && grouped) && j0 + 64 < n) request(j0 + 64, sw_a, ev_a, loci_a);
+                    } else
+                        request(j0, sw_now, ev, loci);
                     const P t = loci - (P)lofs;
                     bool valid = active && loci >= (P)lofs;
 #ifdef BK_CAND_HIST
@@ -431,23 +462,21 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         // the block-flag load and the 2-bit window loads are issued together; only the rare
                         // flagged window is then fetched again from the 4-bit copy
                         if (two_bit) {
-                            const bool flg = window_flagged_t<WIDE>(ix, t, len);
+                            bool flg;
+                            if (NFL && nfl) {
+                                // (4-byte indexes: 32-bit arithmetic, as window_flagged_t)
+                                const uint32_t t0 = (uint32_t)t;
+                                uint32_t t1 = t0 + (uint32_t)(len - 1);
+                                t1 = t1 < t0 ? 0xFFFFFFFFu : t1;
+                                const uint32_t g0 = t0 >> ix.flag_shift, g1 = t1 >> ix.flag_shift;
+                                const uint8_t *fl = reinterpret_cast<const uint8_t *>(s_nflag);
+                                flg = ((((uint32_t)fl[g0 >> 3] >> (g0 & 7)) | ((uint32_t)fl[g1 >> 3] >> (g1 & 7))) & 1) != 0;
+                            } else
+                                flg = window_flagged_t<WIDE>(ix, t, len);
                             if (SW && sw_now) {
                                 if constexpr (SW) {
                                     if (GROUP && grouped) eval_swin2i<NW, false, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
                                     else eval_swin2i<NW, true, E>(r2w, rni, len, ev, SwGeo<E>::pre - lofs, w);
-#ifdef BK_EXP_DOUBLE_COMPARE
-                                    // (measurement build: the compare once more on an entry the compiler cannot prove equal - what the
-                                    // kernel's time does with fifty more vector instructions a round)
-                                    {
-                                        uint4 ev2[E];
-#pragma unroll
-                                        for (int q = 0; q < E; q++) { ev2[q] = ev[q]; asm volatile("" : "+v"(ev2[q].x), "+v"(ev2[q].y), "+v"(ev2[q].z), "+v"(ev2[q].w)); }
-                                        IWindow<NW> w2;
-                                        eval_swin2i<NW, true, E>(r2w, rni, len, ev2, SwGeo<E>::pre - lofs, w2);
-                                        if (w2.mm != w.mm) w.mm = 127;        // (never)
-                                    }
-#endif
                                 }
                             } else
                                 eval_window2i<NW, WIDE>(r2w, rni, len, ix.tgt2, ix.tgt2s, t, w);

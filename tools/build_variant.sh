@@ -12,7 +12,7 @@ var=$root/build/obj_$name
 mkdir -p "$var"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 objs=""
-for o in bk_index bk_prep bk_search bk_extend bk_wave bk_heavy bk_rescue bk_snp bk_sam bk_sa_build bk_engine bk_stream bk_upload sfx_file; do
+for o in bk_index bk_prep bk_search bk_extend bk_wave bk_heavy bk_rescue bk_snp bk_sam bk_sa_build bk_image bk_engine bk_tune bk_exchange bk_snp_host bk_stream bk_upload sfx_file; do
   f=""
   for s in "$@"; do case $s in $o.hip|$o.cpp) f=$s ;; esac; done
   if [ -n "$f" ]; then
