@@ -27,9 +27,6 @@ __device__ unsigned long long g_hist_len[3][40];      // by floor(log2(interval 
 __device__ unsigned long long g_hist_ph[8][40][2];    // by phase and floor(log2(interval length)): windows fetched, .. of them from the window array
 #endif
 
-#ifndef BK_WAVE_ROUND_AHEAD
-#define BK_WAVE_ROUND_AHEAD 1
-#endif
 #ifndef BK_WAVE_NFLAG_LDS
 #define BK_WAVE_NFLAG_LDS 1
 #endif
@@ -387,20 +384,11 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 // the entry's 16-byte words (64 bases each) the window lies in; a shared round's cores differ in it: every word
                 const int sw_q0 = (GROUP && grouped) ? 0 : (SwGeo<E>::pre - ofs) >> 6, sw_q1 = (GROUP && grouped) ? E - 1 : (SwGeo<E>::pre - ofs + len - 1) >> 6;
                 WPROF(2);
-                // A round's loads - the candidate's suffix array element and the words of its window array entry - are requested a round
-                // ahead (RA): round k's are under way while round k - 1 computes, so a core of several rounds waits for memory once, not once
-                // a round.  Nothing else of a round's usual path goes through the vector memory unit (the flag bytes come from LDS), so the
-                // loads stay in flight across the compare; the rare paths that do load - a flagged window, an inverse suffix array look-up,
-                // windows from the 2-bit target - wait for them a round early, which costs what it cost before.
                 using P = typename PosT<WIDE>::type;
-                constexpr bool RA = SW && !HASH && !WIDE && BK_WAVE_ROUND_AHEAD;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
-                uint4 ev_a[RA ? E : 1];                  // RA: the round ahead's entry words, suffix array element, and whether it reads the array
-                P loci_a = 0;
-                bool sw_a = false;
                 auto request = [&](uint32_t jj0, bool &sw_r, uint4 (&e)[E], P &lo) __attribute__((always_inline)) {
                     const uint32_t jj = (GROUP && grouped) ? lj_g : jj0 + (uint32_t)lane;
                     const bool act = (GROUP && grouped) ? (uint32_t)lane < gtot : jj < n;
@@ -419,7 +407,6 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     // (target positions of an index of 4-byte elements: 32-bit arithmetic)
                     lo = act ? (P)sa_get<WIDE>(ix, lfirst + jj) : (P)0;
                 };
-                if constexpr (RA) request(0, sw_a, ev_a, loci_a);
                 for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     WPROF_N(6);
                     const uint32_t j = (GROUP && grouped) ? lj_g : j0 + (uint32_t)lane;
@@ -427,14 +414,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     uint4 ev[E];
                     P loci;
                     bool sw_now;
-                    if constexpr (RA) {
-#pragma unroll
-                        for (int q = 0; q < E; q++) ev[q] = ev_a[q];
-                        loci = loci_a;
-                        sw_now = sw_a;
-                        if (!(GROUP && grouped) && j0 + 64 < n) request(j0 + 64, sw_a, ev_a, loci_a);
-                    } else
-                        request(j0, sw_now, ev, loci);
+                    request(j0, sw_now, ev, loci);
                     const P t = loci - (P)lofs;
                     bool valid = active && loci >= (P)lofs;
 #ifdef BK_CAND_HIST

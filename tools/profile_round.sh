@@ -12,7 +12,7 @@ raw=/tmp/prof_$tag                 # (the raw rocprofv3 output stays on the box:
 out=gpurun_out/profiles_$tag
 mkdir -p $raw $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic --no-other-layout"      # (the layout the policy picks, nothing else in the trace)
+BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-baseline-secs 0 --no-host-leg --no-live-traffic --no-other-layout --no-rccl-world1"      # (the layout the policy picks, nothing else in the trace)
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -o run -- $BENCH > $raw/stats.log 2>&1
 grep '^{' $raw/stats.log | tail -1 > $out/${tag}_bench_line_under_rocprof.json
