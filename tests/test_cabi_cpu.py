@@ -113,3 +113,17 @@ def test_host_packer_round_trip(lib):
             assert np.array_equal(rr, read_of[e_idx]) and np.array_equal(pp, pos[e_idx]) and np.array_equal(cc, bases[e_idx])
     with pytest.raises(bk.BkError):
         bk.pack_reads(np.zeros(2001, np.uint8), None, np.array([2001], np.uint32))
+
+
+def test_image_policy_is_one_pure_rule():
+    """bk_image_policy - the flags `biokanga align` and bench.py both take from it: lean and growing below BK_POLICY_MIN_READS reads per
+    device (or when the count is unknown), every table and the window array from there on; no device needed"""
+    import biokanga_amd as bk
+    assert bk.POLICY_MIN_READS == 20_000_000
+    for n in (0, 1, 1_000_000, bk.POLICY_MIN_READS - 1):
+        assert bk.image_policy(n) == bk.CTX_GROW_IMAGE
+    for n in (bk.POLICY_MIN_READS, 50_000_000, 125_000_000, 10**12):
+        assert bk.image_policy(n) == bk.CTX_WINDOW_ARRAY_EAGER
+    # the header's constant is the one the library was built with
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "biokanga_amd.h")).read()
+    assert "#define BK_POLICY_MIN_READS 20000000ULL" in hdr
