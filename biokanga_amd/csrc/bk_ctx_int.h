@@ -65,7 +65,8 @@ struct bk_ctx {
     void *grow_ktab2 = nullptr;
     bk::DevIndex grow_ix{};                  // the index as it was when the worker started (its own copy: the batches' thread goes on changing ix - the window array)
     bool grow_want_ktab2 = false;
-    int use_ktab2 = 1;       // k-mer table entries carry the second-level key of their bucket's first suffix (DevIndex::ktab2)
+    bool grow_elem = false, grow_want_elem = false;        // the worker's k-mer table of pairs carries suffix array elements for buckets of one suffix ("use_ktab2" 2)
+    int use_ktab2 = 1;       // k-mer table entries of two words (DevIndex::ktab2): 1 - a bucket of one suffix carries its second-level key; 2 - its suffix array element (DevIndex::ktab2_elem: the search hands the suffix on, kElemFlag - measured slower, round 6: the buckets whose key the search would have turned down reach the extension as candidates)
     bool ktab_is2 = false;
     int use_iv32 = 1;        // phase 0 leaves the interval of a read's first k + 16 bases for the offset-0 cores of the later phases
     uint32_t wave_waves = 256u * 8u * 4u;   // resident waves the wave kernel is launched with

@@ -364,6 +364,12 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)      // value known to
 // kernels keep the members whose core bases are clean in the window they evaluate anyway (bk_search.hip)
 constexpr uint32_t kLazyBucket = 4;
 constexpr uint32_t kLazyFlag = 0x80000000u;
+// .. and of a bucket of ONE suffix the search may hand on the suffix itself: with kElemFlag (and kLazyFlag, count 1) the record's `first` is
+// the suffix array ELEMENT - the target position - that the k-mer table's entry carried (DevIndex::ktab2_elem), not the suffix's index:
+// the candidate's window is fetched without the trip to the suffix array in front of it (k_flat's chain: record -> window instead of
+// record -> element -> window; the kernel that evaluates the window checks the core's bases there, as for every unverified bucket)
+constexpr uint32_t kElemFlag = 0x40000000u;
+constexpr uint32_t kIvFlags = kLazyFlag | kElemFlag;
 constexpr int kWaveGrab = 8;            // work items a wave of the wave-per-read kernels claims per atomic on the shared cursor
 
 // ---- host side, shared by the launchers of the kernel files ----------------------------------

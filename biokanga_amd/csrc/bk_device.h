@@ -101,6 +101,7 @@ struct DevIndex {
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
     const uint2 *ktab2;         // instead of ktab32 when the second-level keys exist: {ktab32[c], y} - y = the key of a bucket of one suffix (no second line), the map of the first five bits of a larger bucket's keys (k_make_ktab2)
+    int ktab2_elem;             // ktab2's second word of a bucket of one suffix is that suffix's array ELEMENT (its target position), not its second-level key: the search hands it on (kElemFlag)
     const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null
     const uint32_t *kx[kMoreKeys];   // third-, fourth-level keys: the 15 bases after those and the 15 after these, same form; all ones where the level before is not of kind 0; null from the first level the index does without
     const uint32_t *isa;        // inverse suffix array (rank of every position), 4-byte indexes only; may be null

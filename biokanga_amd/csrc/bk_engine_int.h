@@ -36,7 +36,7 @@ void launch_pack_target(const uint8_t *seq, uint64_t n, uint64_t *tgt4, uint64_t
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s);
 void launch_split_sa5(const uint8_t *sa5, uint64_t n, uint32_t *lo, uint8_t *hi, hipStream_t s);
 void launch_build_ktab(const DevIndex &ix, void *tab, int k, bool tab64, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, unsigned long long *starts = nullptr, bool pairs = false);
-void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s);
+void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s, const uint32_t *sa_elem = nullptr);
 void launch_max_len(const uint32_t *lens, uint32_t n, uint32_t *out, hipStream_t s);
 void launch_widen_lens(const uint16_t *lens16, uint32_t n, uint32_t *lens32, unsigned long long *nwords, hipStream_t s);
 void launch_check_exc(const bk_nbase *exc, uint64_t n_exc, const uint32_t *lens, uint32_t n_reads, uint32_t *bad, hipStream_t s);
@@ -65,7 +65,7 @@ void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blo
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, bool write_k2 = true);
 void launch_build_k2_levels(uint32_t *k2, uint64_t n, hipStream_t s);
-void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s);
+void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s, const uint32_t *sa_elem = nullptr);
 void launch_search_a(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, const uint32_t *act, const uint32_t *p_n_act, uint32_t n_act_bound,
                      int phase, int cmax, int nstr, int lazy, uint32_t *list, uint32_t *list_cnt, uint32_t *stage, uint32_t *stripe_cnt,
                      hipStream_t s);

@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                         const int c = u >= cmaxs ? u - cmaxs : u;
                         const uint32_t raw = c < nc ? sv[u].y : 0u;          // a core the read does not have: whatever the slot held
                         if (raw & kLazyFlag) lazy_bits |= 1u << u;
-                        const uint32_t cnt = raw & ~kLazyFlag;
+                        if (raw & kElemFlag) lazy_bits |= 0x10000u << u;     // (a bucket of one suffix handed on as its suffix array element: the upper half, slot by slot)
+                        const uint32_t cnt = raw & ~kIvFlags;
                         if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                         run += is_heavy ? 0 : cnt;
                         work = work + cnt < work ? 0xFFFFFFFFu : work + cnt;
@@ -267,7 +268,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     uint32_t cnt = 0;
                     if (c < nc) iv_get(b, iv_slot(b, a, s0 + sti, c), f64, cnt);
                     if (cnt & kLazyFlag) lazy_bits |= 1u << (q & 31);
-                    cnt &= ~kLazyFlag;
+                    if ((cnt & kElemFlag) && cf) lazy_bits |= 0x10000u << q;       // (cf: at most sixteen slots; else the evaluation reads the records again)
+                    cnt &= ~kIvFlags;
                     if (cnt > (uint32_t)cfg.heavy_thresh) is_heavy = true;
                     run += is_heavy ? 0 : cnt;
                     work = work + cnt < work ? 0xFFFFFFFFu : work + cnt;
@@ -343,15 +345,17 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
                     while (sp[q] <= local) q++;                      // slot holding candidate `local`
                     const uint32_t j = local - (q ? sp[q - 1] : 0);
                     uint64_t iv_f;
-                    bool lazy;
-                    if (cf) { iv_f = s_first[ri * slots_max + q]; lazy = ((s_lazy[ri] >> q) & 1) != 0; }
+                    bool lazy, elem;
+                    if (cf) { iv_f = s_first[ri * slots_max + q]; lazy = ((s_lazy[ri] >> q) & 1) != 0; elem = ((s_lazy[ri] >> (16 + q)) & 1) != 0; }
                     else {
                         const int sti = q >= cmaxs ? 1 : 0;
                         uint32_t iv_c;
                         iv_get(b, iv_slot(b, blockIdx.x * blockDim.x + ri, s0 + sti, q - sti * cmaxs), iv_f, iv_c);
                         lazy = (iv_c & kLazyFlag) != 0;
+                        elem = (iv_c & kElemFlag) != 0;
                     }
-                    tv[i] = sa_get<WIDE>(ix, iv_f + j);
+                    // (kElemFlag: the record holds the suffix itself - no trip to the suffix array in front of the window's)
+                    tv[i] = elem ? iv_f : sa_get<WIDE>(ix, iv_f + j);
                     meta[i] = ri | ((uint32_t)q << 10) | (lazy ? kLazyBit : 0u);
                 }
             }
@@ -628,7 +632,8 @@ __global__ void __launch_bounds__(BS) k_flat(DevIndex ix, DevAlignCfg cfg, DevBa
             const int last = len - cl;
             const int ofs = c * cd < last ? c * cd : last;
             const uint64_t bf = cf ? (uint64_t)s_first[t * slots_max + best_q] : iv_start(b, iv_slot(b, a, st, c));
-            hit_left = SMALL ? (uint64_t)my_hit_t : sa_get<WIDE>(ix, bf + best_j) - (uint64_t)ofs;
+            const bool belem = cf ? ((s_lazy[t] >> (16 + best_q)) & 1) != 0 : (iv_count(b, iv_slot(b, a, st, c)) & kElemFlag) != 0;
+            hit_left = SMALL ? (uint64_t)my_hit_t : (belem ? bf : sa_get<WIDE>(ix, bf + best_j)) - (uint64_t)ofs;
             hit_strand = st ? '-' : '+';
             if (ent_lds) {
                 int lo = 0, hi = (int)ix.n_ent - 1;

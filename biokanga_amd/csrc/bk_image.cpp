@@ -174,7 +174,7 @@ void grow_worker(bk_ctx *c)
             const uint64_t n_entries = (1ULL << (2 * ix.k)) + 1;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_entries * 8 + (total_b / 5) < free_b && dev_malloc(&c->grow_ktab2, n_entries * 8) == hipSuccess) {
-                launch_make_ktab2(ix.ktab32, ix.k2, n_entries, n, c->grow_ktab2, s);
+                launch_make_ktab2(ix.ktab32, ix.k2, n_entries, n, c->grow_ktab2, s, c->grow_want_elem ? ix.sa_lo : nullptr);
                 if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); free_dev(c->grow_ktab2); c->grow_ktab2 = nullptr; }
             } else
                 (void)hipGetLastError();
@@ -203,7 +203,8 @@ void grow_take_in(bk_ctx *c)
             c->grow_ktab2 = nullptr;
             c->ktab_bytes = (size_t)((1ULL << (2 * c->ix.k)) + 1) * 8;
             c->ktab_is2 = true;
-            c->use_ktab2 = 1;
+            c->use_ktab2 = c->grow_want_elem ? 2 : 1;
+            c->ix.ktab2_elem = c->grow_want_elem ? 1 : 0;
             c->ix.ktab32 = nullptr;
             c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab);
         }
@@ -236,6 +237,7 @@ void grow_tick(bk_ctx *c, uint64_t nreads, bool now)
         if ((now || c->grow_seen >= c->grow_after) && c->tables_built && c->ix.k2 != nullptr) {
             c->grow_ix = c->ix;
             c->grow_want_ktab2 = !c->ktab64 && !c->ktab_is2;
+            c->grow_want_elem = c->grow_elem && c->d_sa_hi == nullptr;
             c->grow_state.store(1);
             c->grow_thread = std::thread(grow_worker, c);
         }
@@ -251,6 +253,7 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
     for (int i = 0; i < kMoreKeys; i++) { free_dev(c->d_kx[i]); c->d_kx[i] = nullptr; c->ix.kx[i] = nullptr; }
     c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
+    c->ix.ktab2_elem = 0;
     c->ix.k = 0;
     // What the HBM has room for is decided before anything is allocated, in the order of what a byte buys: k-mer table, second-level
     // keys, inverse suffix array, the key arrays behind the second-level keys, then the k-mer table's second words - each only where a
@@ -322,7 +325,7 @@ int tables_end(bk_ctx *c, TablePlan &tp)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (tp.ktab) {
         if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
-        else if (tp.ktab2) { c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab); c->ktab_is2 = true; }
+        else if (tp.ktab2) { c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab); c->ktab_is2 = true; c->ix.ktab2_elem = (c->use_ktab2 >= 2 && c->d_sa_hi == nullptr) ? 1 : 0; }
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
         c->ix.k = tp.k;
     }
@@ -346,7 +349,8 @@ int tables_end(bk_ctx *c, TablePlan &tp)
     // the second words of a k-mer table of pairs (its first words, the bucket starts, are in place): a bucket's only key or the map of
     // its keys' first five bits - or maps that hide nothing where the keys turned out unusable
     if (tp.ktab2) {
-        launch_fill_ktab2_y(c->d_ktab, c->d_k2, (1ULL << (2 * tp.k)) + 1, c->stream);
+        if (c->d_k2 == nullptr) c->ix.ktab2_elem = 0;       // (no keys, no two-pass search: nothing hands elements on)
+        launch_fill_ktab2_y(c->d_ktab, c->d_k2, (1ULL << (2 * tp.k)) + 1, c->stream, c->ix.ktab2_elem ? c->d_sa_lo : nullptr);
         HIP_TRY(hipGetLastError());
     }
     if (tp.isa) c->ix.isa = c->d_isa;
@@ -814,7 +818,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     int rc = new_ctx(out, device_id, p, &c);
     if (rc) return rc;
     clk.lap("HIP runtime + device + stream");
-    if (flags & BK_CTX_LEAN_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; }
+    if (flags & BK_CTX_LEAN_IMAGE) { c->use_ktab2 = 0; c->use_k3 = 0; }          // (BK_CTX_GROW_IMAGE below: the worker makes the table's second words the default way, grow_elem)
     if (flags & BK_CTX_NO_DEEP_KEYS) c->use_k3 = 0;
     if (flags & BK_CTX_GROW_IMAGE) {
         c->use_ktab2 = 0; c->use_k3 = 0; c->grow_enabled = true;
@@ -974,6 +978,8 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->ktab64 = src->ktab64;
     c->ktab_is2 = src->ktab_is2;
     c->use_ktab2 = src->use_ktab2;
+    c->grow_elem = src->grow_elem;
+    c->ix.ktab2_elem = src->ix.ktab2_elem;
     c->use_k3 = src->use_k3;
     c->sort_lists = src->sort_lists; c->sort_lists_set = src->sort_lists_set;
     c->grow_enabled = src->grow_enabled && src->grow_state.load() != 4; c->grow_after = src->grow_after; c->grow_wait = src->grow_wait;       // (a clone of a grown context has what it grew)

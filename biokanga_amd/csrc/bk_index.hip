@@ -494,13 +494,13 @@ void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2,
 // some suffix of the bucket continues with v; keys of suffixes with an N / sequence end inside the k-mer match nothing and set nothing) -
 // a probe whose own five bits find no bit set has an empty interval, and the key line is not fetched to learn it (ktab2_absent)
 __global__ void __launch_bounds__(256) k_make_ktab2(const uint32_t *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries, uint64_t n,
-                                                    uint2 *__restrict__ out)
+                                                    uint2 *__restrict__ out, const uint32_t *__restrict__ sa_elem)
 {
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t lo = tab[c];
         const uint64_t hi = c + 1 < n_entries ? (uint64_t)tab[c + 1] : (uint64_t)lo;
         uint32_t y = 0u;
-        if (hi == (uint64_t)lo + 1) y = k2[lo];
+        if (hi == (uint64_t)lo + 1) y = sa_elem != nullptr ? sa_elem[lo] : k2[lo];
         else if (hi > (uint64_t)lo + kTab2BitmapMax) y = 0xFFFFFFFFu;           // (a bucket this large has every bit set, or as good as)
         else
             for (uint64_t i = lo; i < hi; i++) {
@@ -513,14 +513,15 @@ __global__ void __launch_bounds__(256) k_make_ktab2(const uint32_t *__restrict__
 
 // the same for a table whose entries already are pairs with their first words - the bucket starts - in place (k_build_ktab, stride 2):
 // the second words alone.  k2 == nullptr (the keys turned out unusable: the one-pass search reads the starts only): maps that hide nothing
-__global__ void __launch_bounds__(256) k_fill_ktab2_y(uint2 *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries)
+__global__ void __launch_bounds__(256) k_fill_ktab2_y(uint2 *__restrict__ tab, const uint32_t *__restrict__ k2, uint64_t n_entries, const uint32_t *__restrict__ sa_elem)
 {
+    // sa_elem (optional): the suffix array - a bucket of one suffix then carries the suffix's element instead of its key (DevIndex::ktab2_elem)
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t lo = tab[c].x;
         const uint64_t hi = c + 1 < n_entries ? (uint64_t)tab[c + 1].x : (uint64_t)lo;
         uint32_t y = 0u;
         if (k2 == nullptr) y = 0xFFFFFFFFu;
-        else if (hi == (uint64_t)lo + 1) y = k2[lo];
+        else if (hi == (uint64_t)lo + 1) y = sa_elem != nullptr ? sa_elem[lo] : k2[lo];
         else if (hi > (uint64_t)lo + kTab2BitmapMax) y = 0xFFFFFFFFu;
         else
             for (uint64_t i = lo; i < hi; i++) {
@@ -531,14 +532,14 @@ __global__ void __launch_bounds__(256) k_fill_ktab2_y(uint2 *__restrict__ tab, c
     }
 }
 
-void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s)
+void launch_fill_ktab2_y(void *tab2, const uint32_t *k2, uint64_t n_entries, hipStream_t s, const uint32_t *sa_elem)
 {
-    hipLaunchKernelGGL(k_fill_ktab2_y, dim3(65536), dim3(256), 0, s, reinterpret_cast<uint2 *>(tab2), k2, n_entries);
+    hipLaunchKernelGGL(k_fill_ktab2_y, dim3(65536), dim3(256), 0, s, reinterpret_cast<uint2 *>(tab2), k2, n_entries, sa_elem);
 }
 
-void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s)
+void launch_make_ktab2(const uint32_t *tab, const uint32_t *k2, uint64_t n_entries, uint64_t n, void *out, hipStream_t s, const uint32_t *sa_elem)
 {
-    hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out));
+    hipLaunchKernelGGL(k_make_ktab2, dim3(65536), dim3(256), 0, s, tab, k2, n_entries, n, reinterpret_cast<uint2 *>(out), sa_elem);
 }
 
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0, uint64_t i1, bool write_k2)

@@ -116,7 +116,9 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 on[u] = true;
                 if (b.iv32 != nullptr && c == 0 && cl[u] >= k + kK2Bases) {
                     cix[u] = (uint32_t)strand_c * b.n_reads + r;
-                    cached[u] = phase > 0 && cv[u].y < (1u << kKindShift);
+                    // (a plain count, or the record of a bucket of one suffix handed on as it is - kElemFlag: the same bucket, the same suffix,
+                    // whatever the core's length - where unverified buckets may be handed on at all)
+                    cached[u] = phase > 0 && cv[u].y != kNoIv32 && (cv[u].y < (1u << kKindShift) || (lazy && (cv[u].y & kIvFlags) == kIvFlags));
                 }
                 const int my_ofs = c * cd < len - cl[u] ? c * cd : len - cl[u];
                 const int strand = cfg.align_strand == 2 ? 1 : si;
@@ -166,21 +168,29 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
     // texture path takes lane requests, and sixteen keys for every lane cost a third more time than the search saved)
     uint32_t key[ILP][kInlineBucket];
     bool absent[ILP];                   // the table's line says that no key of the bucket continues the way the core does
+    bool carry[ILP];                    // a bucket of one suffix whose table entry carries the suffix itself: handed on as it is (kElemFlag)
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const uint64_t size = hi[u] - lo[u];
         const uint32_t m = k2_mask(cl[u] - k);
         absent[u] = have_code[u] && ix.ktab2 != nullptr && size >= 2 && ktab2_absent(key0[u], m, q2raw[u] & m);
+        carry[u] = have_code[u] && lazy && ix.ktab2 != nullptr && ix.ktab2_elem && size == 1;
+        const bool key_in_entry = size == 1 && ix.ktab2 != nullptr && !ix.ktab2_elem;
 #pragma unroll
         for (uint32_t j = 0; j < kInlineBucket; j++)
-            key[u][j] = (have_code[u] && !absent[u] && size <= kInlineBucket && j < size) ? ((size == 1 && ix.ktab2 != nullptr) ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
+            key[u][j] = (have_code[u] && !absent[u] && !carry[u] && size <= kInlineBucket && j < size) ? (key_in_entry ? key0[u] : ix.k2[lo[u] + j]) : kK2Above;
     }
     PROFS(2);
     // stage 4: results
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         uint2 leave = make_uint2(0, kNoIv32);               // what phase 0 leaves in iv32 for this read and strand
-        if (cached[u]) {
+        if (cached[u] && (cv[u].y & kElemFlag)) {
+            // phase 0 met a bucket of one suffix here and handed the suffix on: so does this phase
+            first[u] = cv[u].x;
+            nval[u] = cv[u].y;
+            push[u] = false;
+        } else if (cached[u]) {
             // the interval of the first k + 15 bases, as the bucket compare below would have produced it
             first[u] = cv[u].x;
             const uint32_t cnt = cv[u].y;
@@ -188,7 +198,14 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
             else if (lazy && cnt <= kLazyBucket) { nval[u] = cnt | kLazyFlag; push[u] = false; }
             else nval[u] = cnt | (kKindDeep << kKindShift);
         }
-        if (have_code[u]) {
+        if (carry[u]) {
+            // (the table's line named the bucket and the suffix in it: no key line, no suffix array line - the window the extension fetches
+            // says whether the core is there)
+            first[u] = key0[u];
+            nval[u] = 1u | kIvFlags;
+            push[u] = false;
+            leave = make_uint2(key0[u], 1u | kIvFlags);
+        } else if (have_code[u]) {
             const uint64_t size = hi[u] - lo[u];
             if (size == 0 || absent[u]) { first[u] = lo[u]; nval[u] = 0; push[u] = false; leave = make_uint2((uint32_t)lo[u], 0u); }
             else if (size <= kInlineBucket) {

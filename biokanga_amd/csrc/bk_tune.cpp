@@ -95,6 +95,7 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
     }
     if (n == "k3_resident") return (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr);
     if (n == "ktab2_resident") return c->ix.ktab2 != nullptr;
+    if (n == "ktab2_elem") return c->ix.ktab2 != nullptr && c->ix.ktab2_elem;      // (read only) .. and its buckets of one suffix carry suffix array elements
     if (n == "grow_after_reads") { int64_t old = (int64_t)c->grow_after; if (value > 0) c->grow_after = (uint64_t)value; return old; }
     if (n == "grow_state") return c->grow_enabled ? c->grow_state.load() : 5;          // (0 .. 4: bk_ctx_int.h; 5: not a growing context)
     if (n == "image_wait") {               // BK_CTX_GROW_IMAGE: make the long-run tables now if they are not under way, wait for them, take them in
@@ -104,9 +105,10 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         }
         return (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr) + (c->ix.ktab2 != nullptr ? 4 : 0);
     }
-    if (n == "use_ktab2") {                // k-mer table entries with the first key of their bucket (rebuilt with the tables)
+    if (n == "use_ktab2") {                // k-mer table entries of two words: 0 no, 1 a bucket of one suffix carries its key, 2 its suffix array element (rebuilt with the tables)
         int64_t old = c->use_ktab2;
-        c->use_ktab2 = value ? 1 : 0;
+        c->use_ktab2 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        c->grow_elem = c->use_ktab2 == 2;
         int rc = build_tables(c);
         return rc ? rc : old;
     }

@@ -252,14 +252,15 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 ci.first = f;
                 ci.n = cn;                    // bit 31: unverified bucket (<= kLazyBucket members)
                 ci.walked = 0;
-                const uint32_t cnt_l = cn & ~kLazyFlag;
+                const uint32_t cnt_l = cn & ~kIvFlags;
                 if (SW) {
                     // which of the interval's candidates take their windows from the window array: all of them when it holds every suffix;
                     // else (DevIndex::swmap) the interval when its first and last block lie as far apart in the array as in the suffix
                     // array - every block between them is there too, in order -, or, failing that, its first kSwHead suffixes by the
                     // same test (an interval beyond MaxIter is left after a hundred-odd candidates)
                     uint32_t sb = (uint32_t)f, sn = cnt_l;
-                    if (ix.swmap != nullptr) {
+                    if (cn & kElemFlag) sn = 0;         // (the record holds the suffix itself, not its place in the suffix array: its window comes from the target)
+                    else if (ix.swmap != nullptr) {
                         sn = 0;
                         if (cnt_l) {
                             const uint32_t head = cnt_l < kSwHead ? cnt_l : kSwHead;
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     rni[q] = nm ? uniform64(bits_to_imap(nm)) : 0ULL;
                 }
             }
-            const uint32_t my_cn = lane < nc ? core[lane].n & ~kLazyFlag : 0u;       // lane l < nc: suffixes in core l's interval
+            const uint32_t my_cn = lane < nc ? core[lane].n & ~kIvFlags : 0u;       // lane l < nc: suffixes in core l's interval
             // GROUP: consecutive cores with small intervals share a round - one candidate per lane in walk order (core, then suffix) -
             // instead of a round each: with a dozen cores per strand a wave otherwise spends most of its rounds on two or three
             // candidates.  None of the reference's iteration rules can fire inside such a round (fewer than 100 candidates per core,
@@ -336,7 +337,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 const uint64_t first = uniform64(core[c].first);
                 const uint32_t cn_c = __builtin_amdgcn_readfirstlane(core[c].n);
                 const bool lazy = (cn_c & kLazyFlag) != 0;
-                const uint32_t n = cn_c & ~kLazyFlag;                    // (an interval's count is capped at 2^31 - 1)
+                const bool elem = (cn_c & kElemFlag) != 0;               // the record's start is the one suffix's array ELEMENT (its target position)
+                const uint32_t n = cn_c & ~kIvFlags;                     // (an interval's count stays below 2^30)
                 const int ofs = __builtin_amdgcn_readfirstlane(core[c].ofs);
                 // the cores of this step: c alone (a long interval, 64 suffixes a round), or c .. ce - 1 in one round
                 int ce = c + 1;
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                 int lc = c;                              // this lane's core, its suffix within the interval
                 uint64_t lfirst = first;
                 int lofs = ofs;
-                bool llazy = lazy;
+                bool llazy = lazy, lelem = elem;
                 uint32_t lj_g = 0;
                 if (GROUP && grouped) {
                     for (int l = c + 1; l < ce; l++) lc += (__shfl(pre_ex, l) - pre_c) <= (uint32_t)lane ? 1 : 0;
@@ -363,6 +365,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     lfirst = core[lc].first;
                     lofs = core[lc].ofs;
                     llazy = (core[lc].n & kLazyFlag) != 0;
+                    lelem = (core[lc].n & kElemFlag) != 0;
                 }
                 // SW: the window array's entry of this lane's first candidate, and how far the array serves the interval
                 uint32_t lsw_base = 0, sw_n_c = 0;
@@ -371,7 +374,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     lsw_base = (GROUP && grouped) ? core[lc].sw_base : (uint32_t)__builtin_amdgcn_readfirstlane(core[c].sw_base);
                     sw_n_c = __builtin_amdgcn_readfirstlane(core[c].sw_n);
                     // a shared round goes to the array when it serves every one of its cores whole
-                    if (GROUP && grouped) grp_sw = __ballot((uint32_t)lane < gtot && core[lc].sw_n < (core[lc].n & ~kLazyFlag)) == 0;
+                    if (GROUP && grouped) grp_sw = __ballot((uint32_t)lane < gtot && core[lc].sw_n < (core[lc].n & ~kIvFlags)) == 0;
                 }
                 n_search += (unsigned long long)(ce - c);
                 uint32_t iter = 0;
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                             if (q >= sw_q0 && q <= sw_q1) e[q] = ep[q * 32];
                     }
                     // (target positions of an index of 4-byte elements: 32-bit arithmetic)
-                    lo = act ? (P)sa_get<WIDE>(ix, lfirst + jj) : (P)0;
+                    lo = act ? (lelem ? (P)lfirst : (P)sa_get<WIDE>(ix, lfirst + jj)) : (P)0;
                 };
                 for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     WPROF_N(6);
@@ -419,7 +422,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     bool valid = active && loci >= (P)lofs;
 #ifdef BK_CAND_HIST
                     {
-                        const uint32_t ln = core[lc].n & ~kLazyFlag;
+                        const uint32_t ln = core[lc].n & ~kIvFlags;
                         const int lb = ln ? 31 - __clz((int)ln) : 0;
                         if (valid) {
                             if (g_hist_blk) atomicAdd(&g_hist_blk[(lfirst + j) >> kHistShift], 1u);
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
 #endif
 #ifdef BK_CAND_HIST
                     if (valid) {
-                        const uint32_t ln = core[lc].n & ~kLazyFlag;
+                        const uint32_t ln = core[lc].n & ~kIvFlags;
                         const int lb = ln ? 31 - __clz((int)ln) : 0;
                         atomicAdd(&g_hist_ph[phase < 8 ? phase : 7][lb][0], 1ULL);
                         if (SW && sw_now) atomicAdd(&g_hist_ph[phase < 8 ? phase : 7][lb][1], 1ULL);
@@ -485,7 +488,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         bool m = valid && !dup && c2 < lc && im_clean<NW>(w.im, cmask[c2]);
                         if (__ballot(m)) {
                             if (m) {
-                                if (core[c2].walked >= (core[c2].n & ~kLazyFlag)) dup = true;
+                                if (core[c2].walked >= (core[c2].n & ~kIvFlags)) dup = true;
                                 else {
                                     uint64_t rank = (uint64_t)ix.isa[(P)(t + (P)core[c2].ofs)] - core[c2].first;
                                     dup = rank < (uint64_t)core[c2].walked;
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         if (GROUP && grouped) n_search -= (unsigned long long)(ce - 1 - __shfl(lc, cut_lane));      // the cores behind the exit are never searched
                     }
 #ifdef BK_CAND_HIST
-                    if (proc && ((keep >> lane) & 1)) { const uint32_t ln = core[lc].n & ~kLazyFlag; atomicAdd(&g_hist_len[2][ln ? 31 - __clz((int)ln) : 0], 1ULL); }
+                    if (proc && ((keep >> lane) & 1)) { const uint32_t ln = core[lc].n & ~kIvFlags; atomicAdd(&g_hist_len[2][ln ? 31 - __clz((int)ln) : 0], 1ULL); }
 #endif
                     uint64_t procmask = __ballot(proc) & keep;
                     uint32_t nproc = (uint32_t)__popcll(procmask);
@@ -663,7 +666,7 @@ __global__ void __launch_bounds__(256) k_keys_wave(DevAlignCfg cfg, DevBatch b, 
             uint64_t f;
             uint32_t raw;
             iv_get(b, slot, f, raw);
-            uint32_t cnt = raw & ~kLazyFlag;
+            uint32_t cnt = raw & ~kIvFlags;
             work += cnt;
             if (cnt > best_n) { best_n = cnt; best_first = f; }
         }

@@ -200,7 +200,9 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  * each other through these.  name =
  *   "kmer_bits" (k of the k-mer table, 2..16)   "use_ktab" (0: plain bisection)   "use_k2" (second-level key array)
  *   "use_iv32" (phase 0 hands the interval of a read's first k + 16 bases to the later phases)   "lazy_search" (small buckets handed on unverified)
- *   "use_ktab2" (k-mer table entries carry the first second-level key of their bucket: a bucket of one suffix costs one line, 17 GB more at k = 16)
+ *   "use_ktab2" (k-mer table entries of two words, 17 GB more at k = 16: 1, the default - a bucket of one suffix carries its second-level key and is
+ *   settled by the line that names it; 2 - it carries the suffix array element and the search hands the suffix on for the extension to check:
+ *   no trip to the suffix array for it, but every bucket whose key the search would have turned down is a candidate - slower, round 6)
  *   "grow_after_reads" / "grow_state" / "image_wait" (BK_CTX_GROW_IMAGE: the reads after which the long-run tables are made; 0 not started, 1 being
  *   made, 2 made, 3 nothing made, 4 taken in, 5 not a growing context; make them now and wait: returns key arrays + 4 if the k-mer table carries keys)
  *   "use_k3" (0..2: key arrays of the 15 bases behind the second-level keys' and of the 15 behind those - 4 bytes per suffix each, where the
@@ -539,7 +541,10 @@ int  bk_sam_format(bk_ctx *ctx, const bk_sam_job *job, bk_sam_sink sink, void *u
  *   act[n_act]        their numbers in the batch
  *   first / count     [(strand * iv_cores + core) * n_act + position in act]: the suffix array interval [first, first + (count & 0x3fffffff))
  *                     of the core's exact matches; bit 31 of count: a k-mer bucket of at most four suffixes handed on unverified
- *                     ("lazy_search" 1 - the extension drops the members whose core bases differ); a core the read does not have: count 0
+ *                     ("lazy_search" 1 - the extension drops the members whose core bases differ); bits 31 and 30: a bucket of ONE suffix
+ *                     handed on as the suffix itself - `first` is its suffix array ELEMENT, the target position ("use_ktab2" 2: the k-mer
+ *                     table's entry carries it, and the extension fetches the window without a trip to the suffix array); a core the
+ *                     read does not have: count 0
  * act == NULL: only n_act and iv_cores.  cap_reads: what the arrays hold per plane. */
 int  bk_debug_intervals(bk_ctx *ctx, uint32_t cap_reads, uint32_t *n_act, uint32_t *iv_cores, uint32_t *act, uint64_t *first, uint32_t *count);
 

@@ -1878,3 +1878,9 @@ void ora_locate_cores(const ora_sfx *s, const uint8_t *bases, const uint64_t *pr
     }
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
 }
+
+/* Test helper: element idx of the suffix array (the stage-level search test maps a handed-on suffix back to its index) */
+int64_t ora_sa_element(const ora_sfx *s, int64_t idx)
+{
+    return (idx < 0 || (uint64_t)idx >= s->concat_len) ? -1 : (int64_t)sa_at(s, idx);
+}

@@ -114,6 +114,8 @@ def oracle_lib():
     lib.ora_locate_last_exact.restype = ctypes.c_int64
     lib.ora_locate_cores.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     lib.ora_locate_cores.restype = None
+    lib.ora_sa_element.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    lib.ora_sa_element.restype = ctypes.c_int64
     _oracle = lib
     return lib
 

@@ -63,7 +63,7 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
                                   ("use_isa", 0), (("use_isa", 0), ("heavy_thresh", 0)), ("use_swin", 2), (("use_swin", 2), ("heavy_thresh", 0)), (("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 3)),
                                   ("use_swin", 3), (("use_swin", 3), ("heavy_thresh", 0)), ("use_swin", 0),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
-                                  (("use_k2", 0), ("lazy_search", 0)), ("use_k3", 0), ("use_k3", 1), (("use_k3", 0), ("lazy_search", 0)), (("use_k3", 1), ("lazy_search", 0)), (("use_k3", 0), ("kmer_bits", 6)), (("kmer_bits", 6), ("heavy_thresh", 0)), ("use_ktab2", 0), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)),
+                                  (("use_k2", 0), ("lazy_search", 0)), ("use_k3", 0), ("use_k3", 1), (("use_k3", 0), ("lazy_search", 0)), (("use_k3", 1), ("lazy_search", 0)), (("use_k3", 0), ("kmer_bits", 6)), (("kmer_bits", 6), ("heavy_thresh", 0)), ("use_ktab2", 0), ("use_ktab2", 2), (("use_ktab2", 2), ("lazy_search", 0)), (("use_ktab2", 2), ("heavy_thresh", 0)), (("use_ktab2", 2), ("use_iv32", 0)), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)),
                                   ("async_phases", 0), (("async_phases", 0), ("chunk_reads", 333)), (("async_phases", 0), ("sort_lists", 0))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;

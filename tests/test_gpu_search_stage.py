@@ -22,6 +22,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 COMP = np.array([3, 2, 1, 0, 4, 5, 6, 7], dtype=np.uint8)
 KIND_MASK = (1 << 30) - 1
 LAZY = 1 << 31
+ELEM = 1 << 30          # with LAZY and a count of 1: `first` is the one suffix's array element, not its index (kElemFlag)
 
 
 def _bk():
@@ -102,9 +103,15 @@ def _check_phase(al, osfx, bases, offs, lens, phase, max_subs, min_core_len, laz
     for i, (plane, a, r, st, c, co, cl) in enumerate(where):
         got_first, raw = int(first[plane, a]), int(count[plane, a])
         got_n = raw & KIND_MASK
-        assert (raw >> 30) in (0, 2), f"{what}: read {r} strand {st} core {c}: a work item's kind left in the record ({raw:#x})"
+        assert (raw >> 30) in (0, 2, 3), f"{what}: read {r} strand {st} core {c}: a work item's kind left in the record ({raw:#x})"
         exp_first, exp_n = (int(f[i]) - 1, int(l[i]) - int(f[i]) + 1) if f[i] else (None, 0)
-        if raw & LAZY:
+        if (raw >> 30) == 3:
+            # a k-mer bucket of ONE suffix handed on as the suffix itself (its target position): where the core has a match at all it is
+            # that suffix - the only one that begins with the core's first k bases
+            n_lazy += 1
+            assert lazy, f"{what}: element record with lazy_search off"
+            ok = got_n == 1 and (exp_n == 0 or (exp_n == 1 and int(osfx.lib.ora_sa_element(osfx.h, exp_first)) == got_first))
+        elif raw & LAZY:
             # an unverified k-mer bucket of at most four suffixes: the exact interval lies inside it
             n_lazy += 1
             assert lazy, f"{what}: lazy record with lazy_search off"
@@ -195,12 +202,16 @@ def test_intervals_on_a_200_mbp_repeat_rich_index(el_size):
             images = [("every table", ())]
             if el_size == 4:
                 assert al.tune("k3_resident", 0) == 2 and al.tune("ktab2_resident", 0) == 1
+                assert al.tune("ktab2_elem", 0) == 0
+                images.append(("k-mer table entries that carry the suffix of a bucket of one", (("use_ktab2", 2),)))
                 images.append(("lean image", (("use_k3", 0), ("use_ktab2", 0))))
             for image, knobs in images:
                 for kv in knobs:
                     al.tune(*kv)
-                if knobs:
+                if image == "lean image":
                     assert al.tune("k3_resident", 0) == 0 and al.tune("ktab2_resident", 0) == 0
+                elif knobs:
+                    assert al.tune("ktab2_resident", 0) == 1 and al.tune("ktab2_elem", 0) == 1
                 for lazy in (0, 1):
                     al.tune("lazy_search", lazy)
                     for phase in range(n_phases):
