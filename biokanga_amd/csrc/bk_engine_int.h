@@ -26,6 +26,7 @@
 #include "bk_ctx_int.h"
 #include "bk_cpus.h"
 #include "bk_wait.h"
+#include "bk_env.h"
 #include "sfx_file.h"
 
 
@@ -108,7 +109,7 @@ void launch_keys_wave(const DevAlignCfg &cfg, const DevBatch &b, int phase, cons
 
 // BK_TIMING=1: wall-clock of the set-up stages on stderr
 struct StageClock {
-    bool on = getenv("BK_TIMING") != nullptr;
+    bool on = env::timing();
     double t0 = now();
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (a log's seconds)

@@ -17,8 +17,8 @@ hipError_t dev_zero_now(void *p, size_t bytes)
 
 hipError_t dev_malloc_bytes(void **p, size_t bytes)
 {
-    static const int poison = getenv("BK_POISON") ? atoi(getenv("BK_POISON")) : -1;
-    static const bool timing = getenv("BK_TIMING") != nullptr;
+    const int poison = env::poison();
+    const bool timing = env::timing();
     timespec ta, tb;
     if (timing) clock_gettime(CLOCK_MONOTONIC, &ta);
     hipError_t e = hipMalloc(p, bytes);
@@ -87,7 +87,7 @@ int derive_cfg(bk_ctx *c)
 void free_dev(void *p)
 {
     if (!p) return;
-    static const bool timing = getenv("BK_TIMING") != nullptr;
+    const bool timing = env::timing();
     timespec ta, tb;
     if (timing) clock_gettime(CLOCK_MONOTONIC, &ta);
     (void)hipFree(p);
@@ -209,7 +209,7 @@ void grow_take_in(bk_ctx *c)
             c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab);
         }
         if (!c->sort_lists_set) c->sort_lists = (c->sort_lists & ~1) | (c->ix.kx[0] == nullptr ? 1 : 0);
-        if (getenv("BK_TIMING"))
+        if (env::timing())
             fprintf(stderr, "biokanga_amd: long-run tables taken in after %llu reads: %d key array(s) behind the second-level keys%s\n",
                     (unsigned long long)c->grow_seen, (c->ix.kx[0] != nullptr) + (c->ix.kx[1] != nullptr), c->ix.ktab2 ? ", first keys in the k-mer table" : "");
     }
@@ -497,7 +497,7 @@ int new_ctx(bk_ctx **out, int device_id, const bk_align_params *p, bk_ctx **pc)
     c->device = device_id;
     c->params = *p;
     c->cfg.heavy_thresh = 64;
-    c->debug = getenv("BK_DEBUG") != nullptr;
+    c->debug = env::debug_phases();
     if (c->params.max_ml == 0) c->params.max_ml = 1;
     if (hipStreamCreate(&c->stream) != hipSuccess) { bk::live_contexts()--; delete c; return BK_ERR_INTERNAL; }
     *pc = c;
@@ -823,7 +823,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
     if (flags & BK_CTX_GROW_IMAGE) {
         c->use_ktab2 = 0; c->use_k3 = 0; c->grow_enabled = true;
         // (tests: a small run that grows - and, so that it does before it is over, waits for the tables at the batch after the one that started them)
-        if (const char *e = getenv("BK_GROW_AFTER_READS")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) { c->grow_after = v; c->grow_wait = true; } }
+        if (const unsigned long long v = env::grow_after_reads()) { c->grow_after = v; c->grow_wait = true; }
     }
     SfxFile f;
     std::string err;
@@ -883,7 +883,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
         if (!rc) rc = tables_begin(c, tp);
         const uint64_t n = f.concat_len;
         uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(16, n >> 26));            // (slices of at least 256 MB; what the tables still owe when the last one has arrived is a slice's worth)
-        if (const char *e = getenv("BK_TABLE_SLICES")) n_slices = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)atoi(e), n));      // (tests: small indexes in several slices)
+        if (const unsigned long long ts = env::table_slices()) n_slices = std::max<uint64_t>(1, std::min<uint64_t>(ts, n));      // (tests: small indexes in several slices)
         // The window array, when the caller wants it from the start, is made behind the slices as well (for reads of a hundred bases: a
         // first batch of another shortest core length makes it again, which costs little): what it reads besides suffix array and keys -
         // entry table, alignment parameters, 2-bit target - is made now instead of after the upload.

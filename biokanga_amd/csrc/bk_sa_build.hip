@@ -16,6 +16,7 @@
 // distinct or h >= 2^20.
 #include <hip/hip_runtime.h>
 #include "bk_prim.h"
+#include "bk_env.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -396,8 +397,8 @@ int build_sa_device(const uint8_t *d_seq, uint64_t n, void *d_sa_out, int el_siz
     int rc = 0;
     {
         // BK_SA_WIDE_CHUNK=<elements>: force the chunked 40-bit path (tests run it on small inputs with small stretches)
-        const char *force = getenv("BK_SA_WIDE_CHUNK");
-        if (n >= 0xFFFFFFFFULL || (force && atoll(force) > 0)) return build_sa_device_wide(d_seq, n, d_sa_out, el_size, force ? (uint64_t)atoll(force) : 0, s);
+        const unsigned long long force = bk::env::sa_wide_chunk();
+        if (n >= 0xFFFFFFFFULL || force > 0) return build_sa_device_wide(d_seq, n, d_sa_out, el_size, (uint64_t)force, s);
     }
     uint64_t *key[2] = {nullptr, nullptr};
     uint32_t *val[2] = {nullptr, nullptr};

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bk_ctx_int.h"
+#include "bk_env.h"
 
 namespace {
 
@@ -444,7 +445,7 @@ extern "C" int bk_sam_format(bk_ctx *c, const bk_sam_job *job, bk_sam_sink sink,
     hipStream_t s = c->stream;
     const uint64_t nr = job->n_reads;
     const uint32_t n_ent = (uint32_t)c->entries.size();
-    const bool timing = getenv("BK_TIMING") != nullptr;
+    const bool timing = bk::env::timing();
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     double t_mark = now(), t_dev = 0, t_settle = 0, t_pin = 0;
     auto lap = [&](const char *what) { const double t = now(); if (timing) fprintf(stderr, "bk timing: bk_sam_format %-28s %7.1f ms\n", what, 1e3 * (t - t_mark)); t_mark = t; };

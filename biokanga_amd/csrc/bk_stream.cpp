@@ -25,6 +25,7 @@
 
 #include "bk_ctx_int.h"
 #include "bk_wait.h"
+#include "bk_env.h"
 
 namespace {
 
@@ -190,7 +191,7 @@ struct bk_stream {
     void run_align()
     {
         (void)hipSetDevice(ctx->device);
-        const bool timing = getenv("BK_TIMING") != nullptr;       // per batch on stderr: how long the aligner thread waited for it, prepared it, aligned it
+        const bool timing = bk::env::timing();       // per batch on stderr: how long the aligner thread waited for it, prepared it, aligned it
         double t_free = now_s();
         for (;;) {
             Job *j = pop(q_al);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bk_cpus.h"
+#include "bk_env.h"
 
 namespace bk {
 
@@ -22,7 +23,7 @@ inline std::atomic<int> &live_contexts() { static std::atomic<int> n{0}; return 
 inline bool sleepy_waits()
 {
     static const int cpus = effective_cpus();
-    static const int ranks = [] { const char *e = getenv("LOCAL_WORLD_SIZE"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
+    static const int ranks = env::local_world_size();
     const int ctxs = live_contexts().load(std::memory_order_relaxed);
     return 4 * (ctxs > 1 ? ctxs : 1) * ranks > cpus;
 }

@@ -39,6 +39,7 @@
 
 #include "../../../include/biokanga_amd.h"
 #include "../sfx_file.h"
+#include "../bk_env.h"
 #include "bam_writer.h"
 #include "fasta.h"
 #include "genome_loader.h"
@@ -123,7 +124,7 @@ int cmd_index(int argc, char **argv, int first)
     int nthreads = a.num("T", 0);
     if (nthreads <= 0) nthreads = effective_cpus();
     // (BK_TIMING=1: the stages' wall-clock on stderr)
-    const bool timing = getenv("BK_TIMING") != nullptr;
+    const bool timing = bk::env::timing();
     timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     auto lap = [&](const char *what) {
@@ -174,7 +175,7 @@ int cmd_index(int argc, char **argv, int first)
 
 // BK_TIMING=1: wall-clock of the front end's own stages on stderr (the library prints its own)
 struct HostClock {
-    bool on = getenv("BK_TIMING") != nullptr;
+    bool on = bk::env::timing();
     double t0 = now();
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     static double wall() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)(ts.tv_sec % 60) + 1e-9 * (double)ts.tv_nsec; }      // (the log's seconds)
@@ -784,7 +785,7 @@ time_t g_t0 = 0;
 [[noreturn]] void end_process(int rc)
 {
     diag("Exit code: %d Total processing time: %ld seconds", rc, (long)(time(nullptr) - g_t0));
-    if (getenv("BK_TIMING")) {                     // what the exit has to give back
+    if (bk::env::timing()) {                     // what the exit has to give back
         if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {
             char line[256];
             while (fgets(line, sizeof line, f))
@@ -860,8 +861,7 @@ int cmd_align(int argc, char **argv, int first)
     const bool out_special = stat(opath0.c_str(), &ost) == 0 && !S_ISREG(ost.st_mode);      // a FIFO, /dev/fd/N of a process substitution, /dev/null
     const bool sam_plain = o.fmt >= 5 && !out_special && !(opath0.size() > 5 && !strcasecmp(opath0.c_str() + opath0.size() - 4, ".bam")) &&
                            !(opath0.size() > 3 && !strcasecmp(opath0.c_str() + opath0.size() - 3, ".gz"));
-    const char *early_env = getenv("BK_SAM_EARLY_MIN");                   // (tests lower the input size from which the file is started early)
-    const bool pre_early = sam_plain && all_plain && plain_bytes >= (early_env ? strtoull(early_env, nullptr, 10) : (256ULL << 20));
+    const bool pre_early = sam_plain && all_plain && plain_bytes >= bk::env::sam_early_min(256ULL << 20);      // (tests lower the input size from which the file is started early)
     const uint64_t pre_early_est = (1u << 20) + plain_bytes + plain_bytes / (o.pe_mode ? 2 : 3);
     if (pre_early) pre.start(opath0.c_str(), pre_early_est, 2);
     const bool long_run = est_reads / ndev >= kLongRunMinReads;
@@ -916,8 +916,7 @@ int cmd_align(int argc, char **argv, int first)
          (unsigned long long)(est_reads / ndev), (unsigned long long)BK_POLICY_MIN_READS);
     // (the SAM file of any other large run is started now: name + bases (+ qualities) + about 31 bytes per record, 55 for a paired end)
     if (sam_plain && pre.fd < 0) {
-        const char *min_env = getenv("BK_SAM_DEVICE_MIN");               // (tests lower the size from which the large-run machinery is used)
-        if (nr >= (size_t)(min_env ? strtoull(min_env, nullptr, 10) : 200000ULL)) {
+        if (nr >= (size_t)bk::env::sam_device_min(200000ULL)) {               // (tests lower the size from which the large-run machinery is used)
             uint64_t est = (1u << 20) + rs.name_bytes() + 40ULL * nr + (o.pe_mode ? 24ULL * nr : 0) + (uint64_t)n_ent * 128;
             est += (uint64_t)(a.num("g", 3) != 3 ? 2 : 1) * rs.base_bytes();
             pre.start(opath0.c_str(), est);

@@ -1,5 +1,6 @@
 // fast_inflate.cpp - see fast_inflate.h.  The format is RFC 1951's; the tables and loops are this file's own.
 #include "fast_inflate.h"
+#include "../bk_env.h"
 
 #include <sys/mman.h>
 
@@ -510,7 +511,7 @@ int64_t find_block_start(const uint8_t *in, size_t in_len, uint64_t from, uint64
     return -1;
 }
 
-const bool g_debug = getenv("BK_INFLATE_DEBUG") != nullptr;      // pieces, sizes and stage times on stderr (tools/inflate_bench.sh)
+const bool g_debug = bk::env::inflate_debug();      // pieces, sizes and stage times on stderr (tools/inflate_bench.sh)
 
 inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
@@ -605,8 +606,7 @@ long inflate_raw_parallel(const uint8_t *in, size_t in_len, uint8_t *out, size_t
 {
     if (pieces_used) *pieces_used = 1;
     // compressed bytes from which another thread pays: 8 MB (BK_INFLATE_PIECE_MIN: the tests' small streams)
-    const char *pm = getenv("BK_INFLATE_PIECE_MIN");
-    const size_t piece_min = pm ? std::max<size_t>(4096, strtoull(pm, nullptr, 10)) : (size_t)8 << 20;
+    const size_t piece_min = std::max<size_t>(4096, (size_t)bk::env::inflate_piece_min(8ULL << 20));
     size_t want = std::min<size_t>((size_t)std::max(1, nthreads), in_len / piece_min);
     if (want < 2) return inflate_raw(in, in_len, out, out_cap, out, in_used);
     // where the pieces start

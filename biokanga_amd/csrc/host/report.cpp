@@ -12,6 +12,7 @@
 #include <thread>
 
 #include "../sfx_file.h"
+#include "../bk_env.h"
 #include "bam_writer.h"
 
 namespace bkcli {
@@ -545,9 +546,9 @@ int report_text(Report &R)
         // hands over reads, names, records and the output order, and copies the text it gets back, slice by slice, into the file.
         // Whatever the device path cannot take, or fails on, is formatted below by the host threads.
         bool device_done = false;
-        const char *dev_min = getenv("BK_SAM_DEVICE_MIN");                        // (records from which the device formats: tests set it to 1, a huge value keeps the host path)
-        if (R.ctx != nullptr && !out.gz && !out.pipe && R.src.empty() && R.seg2.empty() && R.trims.empty() && nr >= (size_t)(dev_min ? strtoull(dev_min, nullptr, 10) : 100000ULL)) {
-            const bool timing0 = getenv("BK_TIMING") != nullptr;
+        const size_t dev_min = (size_t)bk::env::sam_device_min(100000ULL);       // (records from which the device formats: tests set it to 1, a huge value keeps the host path)
+        if (R.ctx != nullptr && !out.gz && !out.pipe && R.src.empty() && R.seg2.empty() && R.trims.empty() && nr >= dev_min) {
+            const bool timing0 = bk::env::timing();
             timespec t0s; clock_gettime(CLOCK_MONOTONIC, &t0s);
             out.flush();
             struct SinkState { int fd; off_t base; int nthreads; SamPrealloc *pre; std::atomic<long> us_wait{0}, us_copy{0}, us_zap{0}; };
@@ -615,7 +616,7 @@ int report_text(Report &R)
             R.sam_prep = nullptr;                                                    // (consumed by the call whatever its outcome)
             uint64_t n_rep = 0, n_bytes = 0;
             int drc = BK_ERR_PARAMS;
-            if (getenv("BK_SAM_DEVICE_FAIL")) { if (job.prep) bk_sam_prep_free(job.prep); }       // (tests: the device declines after its head start)
+            if (bk::env::sam_device_fail()) { if (job.prep) bk_sam_prep_free(job.prep); }       // (tests: the device declines after its head start)
             else if (rs.lens.size() == nr) drc = bk_sam_format(R.ctx, &job, sink, &st, &n_rep, &n_bytes);
             if (drc == BK_OK) {
                 out.pos += (off_t)n_bytes;
@@ -639,7 +640,7 @@ int report_text(Report &R)
         std::vector<Stripe> bufs((size_t)nt);
         std::vector<uint64_t> cnts((size_t)nt);
         std::vector<std::vector<uint8_t>> zbufs((size_t)nt);
-        const bool timing = getenv("BK_TIMING") != nullptr;
+        const bool timing = bk::env::timing();
         auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
         double t_fmt = 0, t_grow = 0, t_put = 0;
         unsigned rounds_mapped = 0, rounds_pwrite = 0;
