@@ -321,14 +321,22 @@ __global__ void __launch_bounds__(256) k_pack_reads(DevBatch b, const uint32_t *
 // row is a copy - applies the N policy, initialises the result record and appends the read to the first active list.  Lean batches
 // (b.rd2 set) get 2 bit/base rows, and 4 bit/base rows only for the reads that hold an N: 60 bytes written per 100-base read
 // instead of the 248 of full rows in both forms.
+#ifndef BK_PREP_TRANSPOSE
+#define BK_PREP_TRANSPOSE 1
+#endif
 template <int NW, bool PACKED>
 __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b, StripeSet out)
 {
     __shared__ uint32_t s_cnt, s_base, s_cmax;
+    // TR: rows and result records leave through the wave's words of LDS (see the kernel's end): reads of up to 128 bases
+    constexpr bool TR = NW == 8 && BK_PREP_TRANSPOSE;
+    __shared__ uint4 s_tr[TR ? 4 : 1][TR ? 64 * (NW / 2) : 1];
     if (threadIdx.x == 0) { s_cnt = 0; s_cmax = 0; }
     __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool lean = b.rd2 != nullptr;
+    const int wv = threadIdx.x >> 6;
+    const bool wave_full = (r | 63u) < b.n_reads;                    // every lane of this wave has a read
     bool go = false, has_n = false;
     uint32_t my_cmax = 0;
     int len = 0;
@@ -469,7 +477,7 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
             }
             for (uint32_t q = NW / 2; 2 * q < wpr; q++) { row0[q] = make_uint4(0, 0, 0, 0); row1[q] = make_uint4(0, 0, 0, 0); }
         }
-        if (lean) {
+        if (lean && !(TR && wave_full)) {
             uint4 *t0 = reinterpret_cast<uint4 *>(b.rd2 + (uint64_t)r * 2 * (NW / 2));
             uint4 *t1 = reinterpret_cast<uint4 *>(b.rd2 + ((uint64_t)r * 2 + 1) * (NW / 2));
 #pragma unroll
@@ -478,7 +486,34 @@ __global__ void __launch_bounds__(256) k_prep_fused(DevAlignCfg cfg, DevBatch b,
                 t1[q] = make_uint4((uint32_t)r2[2 * q], (uint32_t)(r2[2 * q] >> 32), (uint32_t)r2[2 * q + 1], (uint32_t)(r2[2 * q + 1] >> 32));
             }
         }
-        b.out[r] = h;
+        if (!(TR && wave_full)) b.out[r] = h;
+    }
+    if (TR && wave_full) {
+        // A wave's 64 reads are neighbours: their rows (64 bytes each) and result records (20 bytes each) are contiguous in memory.  Stored
+        // lane by lane, every store instruction touched 64 lines for 16 (4) bytes of each; through the wave's words of LDS every
+        // instruction writes 1 KB (256 bytes) of consecutive memory.
+        constexpr int RW = NW / 2;                                   // 16-byte words of a read's two rows (NW = 8: four)
+        uint4 *sr = s_tr[wv];
+        if (lean) {
+#pragma unroll
+            for (int q = 0; q < NW / 4; q++) {
+                sr[lane * RW + q] = make_uint4((uint32_t)f2[2 * q], (uint32_t)(f2[2 * q] >> 32), (uint32_t)f2[2 * q + 1], (uint32_t)(f2[2 * q + 1] >> 32));
+                sr[lane * RW + NW / 4 + q] = make_uint4((uint32_t)r2[2 * q], (uint32_t)(r2[2 * q] >> 32), (uint32_t)r2[2 * q + 1], (uint32_t)(r2[2 * q + 1] >> 32));
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint4 *dst = reinterpret_cast<uint4 *>(b.rd2 + (uint64_t)(r - (uint32_t)lane) * 2 * (NW / 2));
+#pragma unroll
+            for (int k = 0; k < RW; k++) dst[k * 64 + lane] = sr[k * 64 + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t *sh = reinterpret_cast<uint32_t *>(sr);
+        const uint32_t *hw = reinterpret_cast<const uint32_t *>(&h);
+#pragma unroll
+        for (int k = 0; k < 5; k++) sh[lane * 5 + k] = hw[k];
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *od = reinterpret_cast<uint32_t *>(b.out + (r - (uint32_t)lane));
+#pragma unroll
+        for (int k = 0; k < 5; k++) od[k * 64 + lane] = sh[k * 64 + lane];
     }
 }
 

@@ -14,7 +14,7 @@ try:
     d = json.load(open(sys.argv[1]))
     r = d["roofline"]
     k = {n: round(q["ms"] / d["steps"], 2) for n, q in r["per_kernel"].items()}
-    print(f"{sys.argv[2]:>12}: kernel-only {d['value_kernel_only'] / 1e6:7.1f} M reads/s; ms per step {k}; search stage {round(r['k_search_stage']['ms'] / d['steps'], 2)}; dominant {r['kernel']} frac {r['frac']:.3f}; image {d['index_image']['headline']}")
+    print(f"{sys.argv[2]:>12}: kernel-only {d['value_kernel_only'] / 1e6:7.1f} M reads/s; ms per step {k}; search stage {round(r['k_search_stage']['ms'] / d['steps'], 2)}; read preparation {round(r['device_ms']['ms_prep'] / d['steps'], 2)}; dominant {r['kernel']} frac {r['frac']:.3f}; image {d['index_image']['headline']}")
 except Exception as e:
     print(sys.argv[2], "failed:", e)
 PY
