@@ -397,8 +397,12 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     const bool act = (GROUP && grouped) ? (uint32_t)lane < gtot : jj < n;
                     // (a round takes its windows from the array when every candidate of it has its entry there)
                     sw_r = SW && sw_core && ((GROUP && grouped) || (jj0 + 64 < n ? jj0 + 64 : n) <= sw_n_c);
-                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip;
-                    // a lane without a candidate leaves the words undefined - nothing of them is looked at below)
+                    // (the candidate's entry of the window array is requested together with its suffix array element: one round trip - the
+                    // element FIRST: the compiler waits for the entry's last word right where it is issued, and an element asked for
+                    // behind that left a trip later, 3 % of the kernel's time (profiles/r06_g_kwave_ab.txt).  Target positions of an index
+                    // of 4-byte elements: 32-bit arithmetic; a lane without a candidate leaves the words undefined - nothing of them is
+                    // looked at below)
+                    lo = act ? (lelem ? (P)lfirst : (P)sa_get<WIDE>(ix, lfirst + jj)) : (P)0;
                     if (SW && sw_r && act) {
                         // (only the words the core's window reaches into: which, is the same for every candidate of the core)
                         const uint32_t eidx = lsw_base + jj;
@@ -407,8 +411,6 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         for (int q = 0; q < E; q++)
                             if (q >= sw_q0 && q <= sw_q1) e[q] = ep[q * 32];
                     }
-                    // (target positions of an index of 4-byte elements: 32-bit arithmetic)
-                    lo = act ? (lelem ? (P)lfirst : (P)sa_get<WIDE>(ix, lfirst + jj)) : (P)0;
                 };
                 for (uint32_t j0 = 0; j0 < ((GROUP && grouped) ? 1u : n) && !done; j0 += 64) {
                     WPROF_N(6);
