@@ -948,6 +948,8 @@ def main():
         arr = (ctypes.c_ulonglong * 16)()
         if bk.load_library().bk_debug_prof(arr) == 0:
             print("diag prof:", list(arr), file=sys.stderr)
+        if hasattr(bk.load_library(), "bk_debug_prof_wave") and bk.load_library().bk_debug_prof_wave(arr) == 0:
+            print("diag prof wave:", list(arr)[:8], file=sys.stderr)
     ctr, tim, hits = main_leg["ctr"], main_leg["tim"], main_leg["hits"]
     accepted = int((hits["nar"] == 1).sum())
     total_reads = args.reads * world * args.steps

@@ -95,10 +95,40 @@ __device__ __forceinline__ bool same_key_earlier_in_round(bool cand, uint32_t ke
 }
 
 // the wave kernel's LDS set of seen keys (HASH form)
-constexpr uint32_t kLdsSet = 2048, kLdsSetFill = 1536, kLdsEmpty = 0xFFFFFFFFu;
+#ifndef BK_LDS_SET
+#define BK_LDS_SET 2048
+#endif
+constexpr uint32_t kLdsSet = BK_LDS_SET, kLdsSetFill = kLdsSet * 3 / 4, kLdsEmpty = 0xFFFFFFFFu;
+
+// Open addressing by buckets of four keys (one 16-byte LDS read per probe): nearly every look-up is for a key that is NOT there (2 % of a
+// pass's candidates are repeats of earlier ones), and such a look-up walks to the first free slot - 8.5 slots on average at three
+// quarters full with a slot per probe, the slowest of a round's 64 lanes some dozens, a quarter of the 5-byte forms' time
+// (profiles/r06_zb_kwave_C5_round_sections.txt).  With four slots per probe it is one or two.  A key lives in the first bucket of its
+// probe sequence that had a free slot when it came; keys never leave (the set is cleared per strand pass), so a look-up ends at the first
+// bucket with a free slot.  The bucket comes from the product's HIGH bits.
+#ifndef BK_LDS_SET_BUCKETS
+#define BK_LDS_SET_BUCKETS 1
+#endif
+constexpr uint32_t kLdsBuckets = kLdsSet / 4;
+typedef uint32_t lset_u32x4 __attribute__((ext_vector_type(4)));
+static_assert((kLdsSet & (kLdsSet - 1)) == 0 && kLdsSet >= 64, "the set's size is a power of two");
+
+__device__ __forceinline__ uint32_t lset_bucket(uint32_t key)
+{
+    return (uint32_t)(((uint64_t)(key * 2654435761u) * kLdsBuckets) >> 32);
+}
 
 __device__ __forceinline__ bool lset_contains(const uint32_t *set, uint32_t key)
 {
+#if BK_LDS_SET_BUCKETS
+    uint32_t b = lset_bucket(key);
+    for (;;) {
+        const lset_u32x4 v = *reinterpret_cast<const volatile lset_u32x4 *>(set + 4 * b);
+        if (v.x == key || v.y == key || v.z == key || v.w == key) return true;
+        if (v.x == kLdsEmpty || v.y == kLdsEmpty || v.z == kLdsEmpty || v.w == kLdsEmpty) return false;
+        b = (b + 1) & (kLdsBuckets - 1);
+    }
+#else
     uint32_t h = hash_key(key, kLdsSet - 1);
     for (;;) {
         const uint32_t v = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -106,16 +136,30 @@ __device__ __forceinline__ bool lset_contains(const uint32_t *set, uint32_t key)
         if (v == key) return true;
         h = (h + 1) & (kLdsSet - 1);
     }
+#endif
 }
 
 __device__ __forceinline__ void lset_insert(uint32_t *set, uint32_t key)
 {
+#if BK_LDS_SET_BUCKETS
+    uint32_t b = lset_bucket(key);
+    for (;;) {
+        const lset_u32x4 v = *reinterpret_cast<const volatile lset_u32x4 *>(set + 4 * b);
+        if (v.x == key || v.y == key || v.z == key || v.w == key) return;
+        // (the first free slot of the bucket; another lane of the round may take it first: the bucket is looked at again)
+        const int i = v.x == kLdsEmpty ? 0 : (v.y == kLdsEmpty ? 1 : (v.z == kLdsEmpty ? 2 : (v.w == kLdsEmpty ? 3 : 4)));
+        if (i == 4) { b = (b + 1) & (kLdsBuckets - 1); continue; }
+        const uint32_t old = atomicCAS(&set[4 * b + i], kLdsEmpty, key);
+        if (old == kLdsEmpty || old == key) return;
+    }
+#else
     uint32_t h = hash_key(key, kLdsSet - 1);
     for (;;) {
         const uint32_t old = atomicCAS(&set[h], kLdsEmpty, key);
         if (old == kLdsEmpty || old == key) return;
         h = (h + 1) & (kLdsSet - 1);
     }
+#endif
 }
 
 }  // namespace bk

@@ -67,7 +67,22 @@ static __device__ unsigned long long g_wprof[64 * 8];
 #define WPROF(k) do { const long long now_ = clock64(); wp[k] += (unsigned long long)(now_ - wp_last); wp_last = now_; } while (0)
 #define WPROF_N(k) wp[k]++
 #define WPROF_END do { if (lane == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_wprof[(blockIdx.x & 63) * 8 + k_], wp[k_]); } while (0)
+#define RPROF(k) do { } while (0)
+#define RPROF_N(k) do { } while (0)
+#elif defined(BK_PROF) && BK_PROF == 4
+// where a ROUND's cycles go (lane 0 of every wave, every mark behind a wait for what is in flight): 0 the suffix array elements in hand,
+// 1 windows fetched and compared, 2 the look-up in the set of seen keys, 3 the keys' insertion, 4 the round's bookkeeping; 5 = rounds,
+// 6 = rounds of a strand pass that lives in the HBM table, 7 = cycles outside the rounds
+static __device__ unsigned long long g_wprof[64 * 8];
+#define WPROF_DECL long long wp_last = clock64(); unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WPROF(k) do { const long long now_ = clock64(); wp[7] += (unsigned long long)(now_ - wp_last); wp_last = now_; } while (0)
+#define WPROF_N(k) do { if ((k) == 6) wp[5]++; } while (0)
+#define RPROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = clock64(); wp[k] += (unsigned long long)(now_ - wp_last); wp_last = now_; } while (0)
+#define RPROF_N(k) wp[k]++
+#define WPROF_END do { if (lane == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_wprof[(blockIdx.x & 63) * 8 + k_], wp[k_]); } while (0)
 #else
+#define RPROF(k) do { } while (0)
+#define RPROF_N(k) do { } while (0)
 #define WPROF_DECL do { } while (0)
 #define WPROF(k) do { } while (0)
 #define WPROF_N(k) do { } while (0)
@@ -116,7 +131,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
     // HASH: the set of seen target keys of a strand pass lives in LDS (kLdsSet keys per wave, open addressing) and spills into the
     // wave's HBM table only when a pass inserts more than kLdsSetFill keys - a look-up and an insert in HBM are two or three more
     // random cache lines (and a compare-and-swap) on the dependent chain of every candidate
-    __shared__ uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_set[HASH ? 4 : 1][HASH ? kLdsSet : 4];
     // the sequences' first and last base (up to 64 of them): a finished read finds its sequence without a trip to HBM at its very end
     __shared__ uint64_t s_es[64], s_ee[64];
     if (ix.n_ent <= 64) {
@@ -420,6 +435,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                     P loci;
                     bool sw_now;
                     request(j0, sw_now, ev, loci);
+                    RPROF(0);
                     const P t = loci - (P)lofs;
                     bool valid = active && loci >= (P)lofs;
 #ifdef BK_CAND_HIST
@@ -477,6 +493,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         }
                         valid = !w.eos && (!llazy || im_clean<NW>(w.im, cmask[lc]));
                     }
+                    RPROF(1);
                     bool dup = false;
                     const uint32_t key = (uint32_t)(1 + loci - (uint32_t)lofs);       // 32-bit truncation as :5932
                     const bool fused = HASH && spilled;          // the pass lives in the HBM table since an earlier round: look-up and insert are one walk
@@ -499,6 +516,8 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         }
                     }
                     const bool isnew = valid && !dup;
+                    RPROF(2);
+                    if (HASH && spilled) RPROF_N(6);
                     if (kDiag) { n_fetch += __popcll(__ballot(active && loci >= (uint64_t)ofs)); n_dup += __popcll(__ballot(dup)); }
                     const uint64_t newmask = __ballot(isnew);
                     const uint32_t pre = (uint32_t)__popcll(newmask & lt_mask);
@@ -547,6 +566,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                             __builtin_amdgcn_wave_barrier();
                         }
                     }
+                    RPROF(3);
                     int cm = (proc && w.mm <= mm && w.mm < nxt) ? w.mm : 127;
                     bool acc = cm != 127;
                     uint64_t keep = ~0ULL;
@@ -597,6 +617,7 @@ __global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_B
                         } else if (bmin < nxt)
                             nxt = bmin;
                     }
+                    RPROF(4);
                     if (exit_now) done = true;
                     if (!(GROUP && grouped) && cutoff < j0 + 64) { walked = cutoff; break; }
 #pragma clang diagnostic pop
@@ -760,7 +781,7 @@ extern "C" int bk_debug_cand_hist(int op, void *out, unsigned long long n)
 }
 #endif
 
-#if defined(BK_PROF) && BK_PROF == 3
+#if defined(BK_PROF) && (BK_PROF == 3 || BK_PROF == 4)
 extern "C" int bk_debug_prof_wave(unsigned long long *out8)
 {
     unsigned long long h[64 * 8];
