@@ -350,7 +350,7 @@ def reference_baseline(seq, sa, entries, reads_np, read_len, max_subs, gpu_hits,
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-SWIN_TUNE = {"off": 0, "partial": 1, "full": 3}       # bk_ctx_tune("use_swin", ..) per index layout
+SWIN_TUNE = {"off": 0, "partial": 1, "forced": 2, "full": 3}       # bk_ctx_tune("use_swin", ..) per index layout
 
 
 def fetch_correction(kernel, window_array):
@@ -611,7 +611,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help="(internal) one step only, nothing reported: what the live counter passes profile")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--no-full-cli", action="store_true", help="skip the T_e2e run of our command line on a whole step's reads")
-    ap.add_argument("--window-array", default="policy", choices=["policy", "partial", "on", "off", "full"],
+    ap.add_argument("--window-array", default="policy", choices=["policy", "partial", "on", "off", "full", "forced"],
                     help="index layout of the headline: 'policy' = what `biokanga align` picks for this many reads per device; 'partial' (= 'on') = the "
                          "suffix-ordered window array for the part of the suffix array the wave kernel's long walks visit; 'full' = for every suffix "
                          "(149 GB at 3.1 Gbp); the other layouts are measured beside it")
@@ -887,8 +887,9 @@ def main():
     if headline != "off" and not main_leg["window_array_resident"]:
         headline = "off"                 # (asked for, but this index / these reads cannot have it: 5-byte elements, long reads, no room)
     other_legs = {}
-    if not args.no_other_layout and E == 4:
-        for lay in [x for x in args.other_layouts.split(",") if x in SWIN_TUNE and x != headline]:
+    if not args.no_other_layout:
+        # (an index of 5-byte elements: the partial array made when asked for, "use_swin" 2 - the policy leaves such an index without)
+        for lay in ([x for x in args.other_layouts.split(",") if x in SWIN_TUNE and x != headline] if E == 4 else [x for x in ("forced",) if x != headline]):
             leg = measure(lay)
             if lay == "off" or leg["window_array_resident"]:      # (else the library did not build it: there is no such layout to report)
                 other_legs[lay] = leg
@@ -1052,7 +1053,7 @@ def main():
     if other_legs:
         layouts["results_bit_identical_between_layouts"] = bool(all(np.array_equal(main_leg["hits"].view(np.uint8), leg["hits"].view(np.uint8))
                                                                     for leg in other_legs.values()))
-    part_rec, full_rec, off_rec = layouts.get("window_array_partial"), layouts.get("window_array_full"), layouts.get("window_array_off")
+    part_rec, full_rec, off_rec = layouts.get("window_array_partial") or layouts.get("window_array_forced"), layouts.get("window_array_full"), layouts.get("window_array_off")
     built = ((layouts.get("window_array_" + headline) or {}).get("window_array_built") or (part_rec or {}).get("window_array_built") or {})
     setup_s = built.get("setup_s")
 

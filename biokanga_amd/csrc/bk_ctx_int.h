@@ -76,6 +76,7 @@ struct bk_ctx {
     uint32_t *d_swmap = nullptr;          // .. and which blocks of the suffix array it holds (DevIndex::swmap; null: all of them)
     int use_swin = 1;         // 0: none; 1: the part of the suffix array the wave kernel's long walks visit; 2: the same, whatever the batch's read lengths; 3: every suffix
     uint64_t swin_budget = 0; // most bytes the partial array may take (0: by the free memory)
+    int swin_skip_short = 0;  // the coverage rule leaves out this many of the reads' shortest core lengths
     int swin_w = 0;           // the core length the partial array's coverage was made for
     uint64_t swin_bytes = 0;  // what array and map occupy
     double swin_setup_s = 0;  // .. and what making them took (allocation included)

@@ -61,7 +61,8 @@ void launch_build_isa(const uint32_t *sa, uint64_t n, uint32_t *isa, hipStream_t
 void launch_build_swin(const DevIndex &ix, void *swin, int words, hipStream_t s);
 void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t a, uint64_t e, uint64_t n_words,
                         const unsigned long long *starts, hipStream_t s);
-void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
+void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t min_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
+void launch_count_nonzero(const uint32_t *flags, uint64_t n, unsigned long long *count, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);
 void launch_build_k2(const DevIndex &ix, uint32_t *k2, uint32_t *k3, uint32_t *k4, unsigned long long *bad, hipStream_t s, uint64_t i0 = 0, uint64_t i1 = 0, bool write_k2 = true);

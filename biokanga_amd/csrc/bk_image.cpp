@@ -570,6 +570,8 @@ struct SwinBuild {
     int w[kSwLevels] = {}, n_levels = 0;
     int words = 3;                            // 16-byte words per entry (SwGeo)
     uint32_t max_run = 0, cap_blocks = 0;
+    uint32_t min_run = kSwMinRun;             // shortest run covered whole (raised where the rule's coverage would not fit the budget: swin_fit)
+    int mode = 0;                             // 0: one range, entries sized by its coverage; 1: ranges behind the upload's slices; 2: ranges of an index in place
     uint64_t done = 0;                        // suffix array indexes below this are dealt with (a multiple of 64, or n)
     uint64_t range_cap = 0;                   // most indexes one range may hold (what the scratch is sized for)
     unsigned long long *d_brk[kSwLevels] = {};
@@ -615,12 +617,19 @@ int swin_core_lens_k(const bk_ctx *c, uint32_t maxlen, int k, int *w)
     }
     return n;
 }
-int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w) { return swin_core_lens_k(c, maxlen, c->ix.k, w); }
+int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w)
+{
+    int n = swin_core_lens_k(c, maxlen, c->ix.k, w);
+    // ("swin_skip_short": without the shortest of them)
+    const int skip = c->swin_skip_short > 0 ? std::min(c->swin_skip_short, n - 1) : 0;
+    if (skip) { for (int i = skip; i < n; i++) w[i - skip] = w[i]; n -= skip; }
+    return n;
+}
 
 
 // sliced: the suffix array arrives in ranges (swin_range per range, entries allocated by the budget up front, bucket starts noted by the
 // k-mer table's builder); else ONE swin_range call over the whole array, which allocates what its coverage turned out to need
-int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, int words, uint64_t budget, uint64_t range_cap, bool sliced, hipStream_t s)
+int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, int words, uint64_t budget, uint64_t range_cap, int mode, hipStream_t s)
 {
     const uint64_t n = c->ix.n;
     const uint64_t n_blocks = (n + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
@@ -644,7 +653,8 @@ int swin_begin(bk_ctx *c, SwinBuild &sb, const int *w, int n_levels, int words, 
     SW_TRY(hipMemsetAsync(sb.d_used, 0, 4, s));
     SW_TRY(bk::prim::inclusive_sum(nullptr, sb.tmp_bytes, sb.d_flags, sb.d_incl, (size_t)blocks, s));
     SW_TRY(dev_malloc(&sb.d_tmp, sb.tmp_bytes + 256));
-    if (sliced) {
+    sb.mode = mode;
+    if (mode == 1) {
         if (sb.ent_state == 0) SW_TRY(dev_malloc(&sb.d_ent, (uint64_t)sb.cap_blocks * block_bytes));      // (else: alloc_ahead's thread brings it)
         SW_TRY(dev_malloc(&sb.d_starts, ((n >> 6) + 4) * 8));
         SW_TRY(clear_dev(sb.d_starts, ((n >> 6) + 4) * 8, s));
@@ -663,7 +673,7 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
         const uint64_t a = sb.done, len = e - a;
         const uint64_t n_words = (len >> 6) + 2, n_blocks = (len + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
         launch_swin_breaks(ix, sb.w, sb.n_levels, sb.d_brk, a, e, n_words, sb.d_starts, s);
-        for (int l = 0; l < sb.n_levels; l++) launch_swin_cover(sb.d_brk[l], len, sb.max_run, sb.d_flags, n_blocks, l == 0, s);
+        for (int l = 0; l < sb.n_levels; l++) launch_swin_cover(sb.d_brk[l], len, sb.max_run, sb.min_run, sb.d_flags, n_blocks, l == 0, s);
         SW_TRY(hipGetLastError());
         size_t tb = sb.tmp_bytes;
         SW_TRY(bk::prim::inclusive_sum(sb.d_tmp, tb, sb.d_flags, sb.d_incl, (size_t)n_blocks, s));
@@ -686,6 +696,48 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
         sb.filled = e;
         sb.done = e;
     }
+    return BK_OK;
+}
+
+// An index whose rule covers more than the budget holds (a 17 Gbp genome that is 85 % repeats: a tenth of its suffixes lie in runs of 65
+// and more) gets the part of it that is walked most: a run's suffixes are each fetched once per read that meets the run, and a run of R
+// copies is met by R times as many reads as a unique place - so the longest runs first.  One pass over the ranges counts the blocks the
+// rule would cover for a ladder of shortest-run lengths (the heads of the runs beyond MaxIter are in every one of them); the shortest
+// that fits is taken, and the entries are sized by its count.  Mode 2 only (the index is in place and is gone over twice).
+int swin_fit(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, hipStream_t s)
+{
+    static const uint32_t ladder[] = {kSwMinRun, 96, 128, 160, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560, 3072, 4096, 6144, 8192};
+    constexpr int NL = (int)(sizeof(ladder) / sizeof(ladder[0]));
+    const uint64_t n = ix.n;
+    unsigned long long *d_cnt = nullptr;
+    SW_TRY(dev_malloc(&d_cnt, NL * 8));
+    SW_TRY(hipMemsetAsync(d_cnt, 0, NL * 8, s));
+    for (uint64_t a = 0; a < n;) {
+        uint64_t e = std::min<uint64_t>(n, (a + sb.range_cap - 64) & ~63ULL);
+        const uint64_t len = e - a, n_words = (len >> 6) + 2, n_blocks = (len + (1u << kSwBlkShift) - 1) >> kSwBlkShift;
+        launch_swin_breaks(ix, sb.w, sb.n_levels, sb.d_brk, a, e, n_words, nullptr, s);
+        for (int q = 0; q < NL; q++) {
+            if (ladder[q] > sb.max_run) break;
+            for (int l = 0; l < sb.n_levels; l++) launch_swin_cover(sb.d_brk[l], len, sb.max_run, ladder[q], sb.d_flags, n_blocks, l == 0, s);
+            launch_count_nonzero(sb.d_flags, n_blocks, d_cnt + q, s);
+        }
+        SW_TRY(hipGetLastError());
+        a = e;
+    }
+    unsigned long long cnt[NL] = {};
+    SW_TRY(hipMemcpyAsync(cnt, d_cnt, NL * 8, hipMemcpyDeviceToHost, s));
+    SW_TRY(hipStreamSynchronize(s));
+    free_dev(d_cnt);
+    int pick = 0;
+    while (pick + 1 < NL && ladder[pick + 1] <= sb.max_run && cnt[pick] > sb.cap_blocks) pick++;
+    sb.min_run = ladder[pick];
+    const uint64_t blocks = std::min<uint64_t>(cnt[pick], sb.cap_blocks);
+    if (blocks == 0) return 1;
+    sb.cap_blocks = (uint32_t)blocks;
+    SW_TRY(dev_malloc(&sb.d_ent, blocks * ((uint64_t)(16 * sb.words) << kSwBlkShift)));
+    StageClock clk;
+    if (clk.on) fprintf(stderr, "biokanga_amd: window array: runs of %u and more suffixes covered whole (the rule at 65: %.1f %% of the suffix array, this: %.1f %%, room for %.1f %%)\n", sb.min_run,
+                        100.0 * (double)cnt[0] * 32.0 / (double)n, 100.0 * (double)cnt[pick] * 32.0 / (double)n, 100.0 * (double)blocks * 32.0 / (double)n);
     return BK_OK;
 }
 
@@ -726,16 +778,26 @@ int swin_end(bk_ctx *c, SwinBuild &sb, hipStream_t s)
 // most bytes the partial array may take: a third of what every suffix would, half of what is free beyond `reserve`, the caller's cap
 uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve, int words)
 {
-    const uint64_t work = ((c->ix.n >> kSwBlkShift) + 1) * 12 + (c->ix.n >> 3) * (kSwLevels + 1) + (64ULL << 20);      // (flags, scan, map, break bitmaps while it is made)
+    // (flags, scan, map, break bitmaps while it is made: of the whole index, or - beyond 2^32 suffixes - of a range of 2^31 and the map)
+    const bool ranged = c->ix.n >= (1ULL << 32);
+    const uint64_t span = ranged ? (1ULL << 31) : c->ix.n;
+    const uint64_t work = ((span >> kSwBlkShift) + 1) * 8 + ((c->ix.n >> kSwBlkShift) + 1) * 4 + (span >> 3) * (kSwLevels + 1) + (64ULL << 20);
     if (free_b < reserve + work + (1ULL << 30)) return 0;
-    uint64_t budget = std::min<uint64_t>(c->ix.n * 16 * (uint64_t)words / 3, (free_b - reserve - work) / 2);
+    // (such an index's array is only made when asked for, and its walks are where its time goes: five sixths of what is free, not half)
+    uint64_t budget = std::min<uint64_t>(c->ix.n * 16 * (uint64_t)words / 3, ranged ? (free_b - reserve - work) / 6 * 5 : (free_b - reserve - work) / 2);
     if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
     return budget;
 }
 
 int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
 {
-    if (!c->use_swin || c->swin_denied || c->d_sa_hi || c->ix.n >= (1ULL << 32) || !c->ix.tgt2 || !c->ix.isa || !c->ix.k2 || !c->use_wave) return BK_OK;
+    // (an index of 5-byte elements has no inverse suffix array: its wave kernel forms keep the reference's set of seen keys, and take
+    // windows from the array all the same)
+    const bool wide = c->d_sa_hi != nullptr || c->ix.n >= (1ULL << 32);
+    if (!c->use_swin || c->swin_denied || !c->ix.tgt2 || (!wide && !c->ix.isa) || !c->ix.k2 || !c->use_wave) return BK_OK;
+    // (.. when asked to - "use_swin" 2, `--window-array on`: making it goes over such an index twice, seconds at 17 Gbp, which a job of
+    // BASELINE config 5's size per device does not earn back; the policy's 1 leaves such an index without)
+    if (wide && c->use_swin != 2) return BK_OK;
     const bool full = c->use_swin == 3;
     int w[kSwLevels];
     const int n_levels = swin_core_lens(c, maxlen, w);
@@ -778,7 +840,11 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
         const uint64_t budget = swin_budget_for(c, (uint64_t)free_b, reserve, words);
         if (!budget) { c->swin_denied = true; return BK_OK; }
         SwinBuild sb;
-        int rb = swin_begin(c, sb, w, n_levels, words, budget, c->ix.n, false, s);
+        // (an index beyond 2^32 suffixes is gone over in ranges of 2^31 - its break bitmaps would be 2 GB a level otherwise - and twice:
+        // what the rule covers there does not fit, swin_fit)
+        const bool ranged = c->ix.n >= (1ULL << 32);
+        int rb = swin_begin(c, sb, w, n_levels, words, budget, ranged ? (1ULL << 31) : c->ix.n, ranged ? 2 : 0, s);
+        if (!rb && ranged) rb = swin_fit(c, sb, c->ix, s);
         if (!rb) rb = swin_range(c, sb, c->ix, c->ix.n, s);
         if (!rb) rb = swin_end(c, sb, s);
         if (rb == BK_ERR_INTERNAL) return rb;
@@ -897,7 +963,7 @@ int bk_ctx_create_ex(bk_ctx **out, const char *sfx_path, int device_id, const bk
                 int w[kSwLevels];
                 const int n_levels = swin_core_lens_k(c, 100, tp.k, w);
                 sb.ent_state = 1;                                   // (its entries come from alloc_ahead's thread, started below)
-                swin_sliced = swin_begin(c, sb, w, n_levels, 3, swin_ahead, n / n_slices + 128, true, c->stream) == BK_OK;
+                swin_sliced = swin_begin(c, sb, w, n_levels, 3, swin_ahead, n / n_slices + 128, 1, c->stream) == BK_OK;
                 if (!swin_sliced) { (void)hipGetLastError(); sb.ent_state = 0; }
                 else sb.alloc_ahead(device_id, swin_ahead);
             }

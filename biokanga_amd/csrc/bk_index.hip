@@ -168,7 +168,7 @@ __global__ void k_check_k2(DevIndex ix, const uint32_t *__restrict__ k2, unsigne
 template <int E>
 __device__ __forceinline__ void swin_entry(const DevIndex &ix, uint64_t i, uint4 *__restrict__ swin, uint64_t idx)
 {
-    const int64_t base0 = (int64_t)ix.sa_lo[i] - SwGeo<E>::pre;
+    const int64_t base0 = (int64_t)(ix.sa_hi != nullptr ? sa_get<true>(ix, i) : (uint64_t)ix.sa_lo[i]) - SwGeo<E>::pre;      // (5-byte elements: their fifth byte too)
     uint64_t wd[2 * E];
 #pragma unroll
     for (int k = 0; k < 2 * E; k++) {
@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256) k_swin_breaks(DevIndex ix, SwinLevels lv,
                 if (x) shared = k + (__clz((int)x) >> 1);
                 else if ((a | c) & 3u) shared = deep_from - 1;   // an N or a sequence end among the 15 bases: no deeper than the keys
                 else if (w_max > deep_from) {
-                    const uint64_t pa = (uint64_t)ix.sa_lo[i - 1] + (uint64_t)deep_from, pb = (uint64_t)ix.sa_lo[i] + (uint64_t)deep_from;
+                    const bool wide_el = ix.sa_hi != nullptr;
+                    const uint64_t pa = (wide_el ? sa_get<true>(ix, i - 1) : (uint64_t)ix.sa_lo[i - 1]) + (uint64_t)deep_from, pb = (wide_el ? sa_get<true>(ix, i) : (uint64_t)ix.sa_lo[i]) + (uint64_t)deep_from;
                     const int span = w_max - deep_from;
                     shared = deep_from;
                     if (pa + (uint64_t)span < n && pb + (uint64_t)span < n && !window_flagged(ix, pa, span) && !window_flagged(ix, pb, span)) {
@@ -283,16 +284,16 @@ __global__ void __launch_bounds__(256) k_swin_bucket_starts(DevIndex ix, uint64_
     const int lane = threadIdx.x & 63;
     const uint64_t span = (n_codes + 63) & ~63ULL;
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+        uint64_t lo = ~0ULL, hi = ~0ULL;
         if (c < n_codes) {
             if (ix.ktab2) { lo = ix.ktab2[c].x; hi = ix.ktab2[c + 1].x; }
-            else { lo = ix.ktab32[c]; hi = ix.ktab32[c + 1]; }
+            else { lo = ktab_get(ix, c); hi = ktab_get(ix, c + 1); }           // (32- or 64-bit entries)
         }
         // neighbouring codes' buckets start in the same word of the bitmap: their bits are OR-ed along the lanes first (the starts
         // are non-decreasing), so that a word takes one atomic from the wave instead of twenty
         const bool in = c < n_codes && hi != lo && lo >= a && lo < e;
-        const uint32_t w = in ? (uint32_t)((lo - a) >> 5) : 0xFFFFFFFFu;
-        uint32_t bits = in ? 1u << (lo & 31) : 0u;
+        const uint32_t w = in ? (uint32_t)((lo - a) >> 5) : 0xFFFFFFFFu;            // (a range holds fewer than 2^37 indexes)
+        uint32_t bits = in ? 1u << (uint32_t)(lo & 31) : 0u;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t ob = __shfl_up(bits, off), ow = __shfl_up(w, off);
             if (lane >= off && ow == w) bits |= ob;
@@ -329,7 +330,7 @@ __device__ __forceinline__ uint64_t swin_prev_break(const unsigned long long *__
     }
 }
 
-__global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__restrict__ brk, uint64_t n, uint32_t max_run, uint32_t *__restrict__ flags, uint64_t n_blocks, int first_level)
+__global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__restrict__ brk, uint64_t n, uint32_t max_run, uint32_t min_run, uint32_t *__restrict__ flags, uint64_t n_blocks, int first_level)
 {
     constexpr uint64_t B = 1ULL << kSwBlkShift;
     for (uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; blk < n_blocks; blk += (uint64_t)gridDim.x * blockDim.x) {
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__
         const uint64_t s0 = swin_prev_break(brk, b0, max_run);
         if (s0 != ~0ULL) {
             const uint64_t e0 = swin_next_break(brk, b0, s0 + max_run - b0);        // (0: the run is longer than max_run)
-            if (e0) cov = e0 - s0 >= kSwMinRun;
+            if (e0) cov = e0 - s0 >= min_run;
             else cov = b0 - s0 < kSwHead;
         }
         // the runs that start inside the block: only the last of them can be long enough (the others end inside the block)
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(256) k_swin_cover(const unsigned long long *__
             const unsigned long long w = (brk[b0 >> 6] >> (b0 & 63)) & ((1ULL << B) - 1) & ~1ULL;
             if (w) {
                 const uint64_t s = b0 + (uint64_t)(63 - __clzll((long long)w));
-                if (s < n) cov = swin_next_break(brk, s, kSwMinRun - 1) == 0;
+                if (s < n) cov = swin_next_break(brk, s, min_run - 1) == 0;
             }
         }
         flags[blk] = cov ? 1u : 0u;
@@ -399,10 +400,10 @@ void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned
     }
 }
 
-void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s)
+void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t min_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::min<uint64_t>((n_blocks + 255) / 256, 262144);
-    hipLaunchKernelGGL(k_swin_cover, dim3(blocks), dim3(256), 0, s, brk, n, max_run, flags, n_blocks, first_level);
+    hipLaunchKernelGGL(k_swin_cover, dim3(blocks), dim3(256), 0, s, brk, n, max_run, min_run, flags, n_blocks, first_level);
 }
 
 // map: the n_blocks entries of the range's blocks; `used` moves on by the range's covered blocks
@@ -412,6 +413,22 @@ void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blo
     const unsigned blocks = (unsigned)std::min<uint64_t>((n_blocks + 255) / 256, 262144);
     hipLaunchKernelGGL(k_swin_map, dim3(blocks), dim3(256), 0, s, flags, incl, n_blocks, cap_blocks, used, map);
     hipLaunchKernelGGL(k_swin_advance, dim3(1), dim3(1), 0, s, incl + (n_blocks - 1), cap_blocks, used);
+}
+
+// adds the number of non-zero flags to *count
+__global__ void __launch_bounds__(256) k_count_nonzero(const uint32_t *__restrict__ flags, uint64_t n, unsigned long long *__restrict__ count)
+{
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((n + 63) & ~63ULL); i += (uint64_t)gridDim.x * blockDim.x)
+        mine += (unsigned long long)__popcll(__ballot(i < n && flags[i] != 0));
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+void launch_count_nonzero(const uint32_t *flags, uint64_t n, unsigned long long *count, hipStream_t s)
+{
+    if (!n) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_count_nonzero, dim3(blocks), dim3(256), 0, s, flags, n, count);
 }
 
 // map: the whole map (indexed by suffix array index >> kSwBlkShift); entries of the indexes [a, e)

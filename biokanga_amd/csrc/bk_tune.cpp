@@ -152,6 +152,11 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         }
         return old;
     }
+    if (n == "swin_skip_short") {           // the partial window array's rule without the reads' this many shortest core lengths; applies to the next build
+        int64_t old = c->swin_skip_short;
+        c->swin_skip_short = value < 0 ? 0 : (int)std::min<int64_t>(value, kSwLevels - 1);
+        return old;
+    }
     if (n == "swin_budget_kb") {            // most the partial window array may take (0: what the free memory allows); applies to the next build
         int64_t old = (int64_t)(c->swin_budget >> 10);
         c->swin_budget = value > 0 ? (uint64_t)value << 10 : 0;

@@ -99,7 +99,7 @@ struct WaveArgs {
     uint32_t *cursor, *next_act, *next_cnt, *cmax_next;
 };
 template <int NW, bool WIDE, bool HASH, bool SW, bool GROUP>
-__global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : 2)) k_wave(WaveArgs wa)
+__global__ void __launch_bounds__(256, NW <= 8 ? ((HASH || !SW) ? 4 : BK_WAVE8_BLOCKS) : ((NW == 16 && !HASH) ? BK_WAVE16_BLOCKS : ((NW == 16 && SW) ? 4 : 2))) k_wave(WaveArgs wa)
 {
     const DevIndex &ix = wa.ix;
     const DevAlignCfg &cfg = wa.cfg;
@@ -726,7 +726,8 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
     // forms and the hash-set forms do, cost the 8-word inverse-suffix-array forms more registers than it saved rounds - round 3)
     nw &= 0xff;
     if (nw <= 8) {
-        if (wide) BK_WAVE(8, true, true, false, true);
+        if (wide && sw) BK_WAVE(8, true, true, true, true);                 // (5-byte elements: the set of seen keys, windows from the array where it holds them)
+        else if (wide) BK_WAVE(8, true, true, false, true);
         else if (hash) BK_WAVE(8, false, true, false, true);
 #ifdef BK_WAVE8_GROUP
         else if (sw) BK_WAVE(8, false, false, true, true);
@@ -735,7 +736,8 @@ void launch_wave(const DevIndex &ix, const DevAlignCfg &cfg, const DevBatch &b, 
 #endif
         else BK_WAVE(8, false, false, false, false);
     } else if (nw <= 16) {
-        if (wide) BK_WAVE(16, true, true, false, true);
+        if (wide && sw) BK_WAVE(16, true, true, true, true);
+        else if (wide) BK_WAVE(16, true, true, false, true);
         else if (hash) BK_WAVE(16, false, true, false, true);
         else if (sw) BK_WAVE(16, false, false, true, true);
         else BK_WAVE(16, false, false, false, true);

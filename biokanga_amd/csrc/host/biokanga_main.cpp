@@ -910,9 +910,12 @@ int cmd_align(int argc, char **argv, int first)
 
     size_t nr = rs.size();
     // (the other devices' contexts, copies of the first's image, make their window arrays when their first batch arrives)
-    for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want_array ? 1 : 0);
+    // (--window-array on asks for it whatever the index: one of 5-byte elements gets it only so - "use_swin" 2 -, the policy's own
+    // choice leaves it without: making it goes over a 17 Gbp index twice)
+    for (bk_ctx *c : ctxs) (void)bk_ctx_tune(c, "use_swin", want_array ? ((!wa.empty() && !wa_off) ? 2 : 1) : 0);
     diag("Index image: %s, suffix-ordered window array %s (%zu reads per device, %llu estimated from the input files' sizes; every table comes with the index from %llu reads per device on; --index-image lean | full and --window-array on | off override)",
-         (ctx_flags & BK_CTX_LEAN_IMAGE) ? "lean" : ((ctx_flags & BK_CTX_GROW_IMAGE) ? "lean, grows on a long run" : "every table"), want_array ? "on" : "off", nr / ctxs.size(),
+         (ctx_flags & BK_CTX_LEAN_IMAGE) ? "lean" : ((ctx_flags & BK_CTX_GROW_IMAGE) ? "lean, grows on a long run" : "every table"),
+         !want_array ? "off" : ((bk_sfx_el_size(ctx) == 5 && (wa.empty() || wa_off)) ? "off (an index of 5-byte elements gets it with --window-array on only)" : "on"), nr / ctxs.size(),
          (unsigned long long)(est_reads / ndev), (unsigned long long)BK_POLICY_MIN_READS);
     // (the SAM file of any other large run is started now: name + bases (+ qualities) + about 31 bytes per record, 55 for a paired end)
     if (sam_plain && pre.fd < 0) {

@@ -212,8 +212,11 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_wave" (wave kernel, 0: general hash-set kernel)   "use_isa" (inverse suffix
  *   array dedupe, 0: hash set)   "use_tgt2" (2 bit/base window compare)   "heavy_thresh" (longest interval the lane/flat kernels take, 0..100)
  *   "use_swin" (suffix-ordered window array: 0 none - every window from the 2-bit target; 1 for the part of the suffix array the wave kernel's long
- *   walks visit, reads of <= 100 bases and the middle cores of reads of <= 160; 2 the same whatever the batch's longest read; 3 for every suffix)
- *   "swin_budget_kb" (most the partial array may take; 0: a third of what every suffix would, within half of the free HBM)
+ *   walks visit, reads of <= 100 bases and the middle cores of reads of <= 160; 2 the same whatever the batch's longest read; 3 for every suffix.
+ *   An index of 5-byte elements gets the partial array only at 2: making it goes over such an index twice - once to find the shortest run
+ *   length whose coverage fits the memory that is free -, 1.7 s at 17 Gbp for 5 % of its wave kernel's time)
+ *   "swin_budget_kb" (most the partial array may take; 0: a third of what every suffix would, within half of the free HBM - five sixths for an
+ *   index beyond 2^32 suffixes)   "swin_skip_short" (the coverage rule without the reads' this many shortest core lengths; 0)
  *   "swin_resident", "swin_mbytes", "swin_setup_us", "swin_covered_ppm", "swin_core_lens" (read only, value ignored: whether the window array
  *   is in HBM right now, what it occupies, what making it took, the share of the suffix array it holds, the core lengths its coverage is for)
  *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's

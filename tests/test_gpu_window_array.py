@@ -117,6 +117,52 @@ def test_partial_window_array_changes_no_result(tmp_path, read_len, max_subs):
     assert np.count_nonzero(exp["nar"] == 1) > nreads // 4
 
 
+@pytest.mark.parametrize("read_len,max_subs", [(100, 3), (150, 5)])
+def test_partial_window_array_with_5_byte_elements(tmp_path, read_len, max_subs):
+    """an index of 5-byte suffix array elements has no inverse suffix array: its wave kernel keeps the reference's set of seen keys
+    (`SfxArrayV2.cpp:5932`) and, when the array is asked for ("use_swin" 2: the policy's 1 leaves such an index without), takes the windows
+    of covered intervals from it - the same records as without, and as the oracle's"""
+    bk = _bk()
+    seq, ents, reads = _family_genome(900 + read_len, 600000, read_len, 16000, max_subs + 1)
+    n = len(seq)
+    import torch
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_sa = torch.empty(n * 5, dtype=torch.uint8, device=dev)
+    bk.build_sa_device(d_seq.data_ptr(), n, d_sa.data_ptr(), 5, 0)
+    path = str(tmp_path / "fam5.sfx")
+    sa5 = d_sa.cpu().numpy().reshape(n, 5)
+    sa = sa5[:, 0].astype(np.uint64) | (sa5[:, 1].astype(np.uint64) << 8) | (sa5[:, 2].astype(np.uint64) << 16) | (sa5[:, 3].astype(np.uint64) << 24) | (sa5[:, 4].astype(np.uint64) << 32)
+    helpers.write_sfx(path, "fam5", [("s1", int(ents[0]["seq_len"])), ("s2", int(ents[1]["seq_len"]))], seq, sa, el_size=5)
+    nreads = len(reads)
+    bases = reads.reshape(-1)
+    offs = np.arange(nreads, dtype=np.uint64) * read_len
+    lens = np.full(nreads, read_len, dtype=np.uint32)
+    o = helpers.OracleSfx(path)
+    exp, octr = o.align(bases, offs, lens, helpers.make_params(max_subs=max_subs), nthreads=8)
+    o.close()
+    covered = {}
+    with bk.Aligner(path, bk.AlignParams(max_subs=max_subs)) as al:
+        assert al.lib.bk_sfx_el_size(al.h) == 5
+        for name, knobs in (("policy", [("use_swin", 1)]),
+                            ("none", [("use_swin", 0)]),
+                            ("asked for", [("use_swin", 2)]),
+                            ("asked for, every read through the wave kernel", [("heavy_thresh", 0)]),
+                            ("asked for, 40 KB", [("use_swin", 0), ("swin_budget_kb", 40), ("use_swin", 2), ("heavy_thresh", 3)]),
+                            ("asked for, unverified small buckets off", [("use_swin", 0), ("swin_budget_kb", 0), ("use_swin", 2), ("lazy_search", 0), ("heavy_thresh", 64)])):
+            for kv in knobs:
+                al.tune(*kv)
+            al.counters(reset=True)
+            got = al.align(bases, offs, lens)
+            ctr = al.counters()
+            _same(got, exp, name)
+            assert (ctr["n_search"], ctr["n_cand"], ctr["n_lcm_calls"]) == (octr.n_search, octr.n_cand, octr.n_lcm_calls), name
+            covered[name] = al.tune("swin_covered_ppm", 0) if al.tune("swin_resident", 0) else 0
+    assert covered["policy"] == 0 and covered["none"] == 0
+    assert 0 < covered["asked for, 40 KB"] < covered["asked for"] < 600_000
+    assert np.count_nonzero(exp["nar"] == 1) > nreads // 4
+
+
 def test_partial_window_array_follows_the_batch(tmp_path):
     """a batch whose reads are searched with other core lengths than the array was made for gets an array of its own - once: after that
     the array is kept whatever the next batch's read length (coverage never changes a result; batches of variable-length reads would
