@@ -827,9 +827,12 @@ def main():
         """both clocks in one index layout: `warmup` untimed + exactly `steps` timed steps each, a barrier + device synchronisation on
         both sides of the timed steps, the maximum over ranks"""
         res = {"layout": layout}
+        torch.cuda.empty_cache()                           # (what the library may give the window array is what hipMemGetInfo calls free)
         t_set = time.time()
         al.tune("use_swin", SWIN_TUNE[layout])
         step()                                             # (builds the window array when it is asked for, fits and serves these reads)
+        if E != 4 and layout == "forced":
+            step()                                         # (an index of 5-byte elements: made when a second batch arrives, from what the first one's phases say)
         torch.cuda.synchronize()
         t_first = time.time() - t_set
         res["window_array_resident"] = al.tune("swin_resident", 0) == 1

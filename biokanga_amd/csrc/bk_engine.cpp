@@ -14,7 +14,7 @@ int size_heavy_scratch(bk_ctx *c)
     if (worst > kNodeCap) worst = kNodeCap;
     uint32_t ts = 1024;
     while (ts < 2 * worst) ts <<= 1;
-    uint32_t slots = 8192;                  // one per resident wave of the wave kernels when they fit in 16 GB
+    uint32_t slots = 4096;                  // one per resident wave of the hash-set forms (four blocks of four waves a CU: 40 KB of LDS each) when they fit in 16 GB
     while ((uint64_t)slots * ts * 8 > (16ULL << 30) && slots > 64) slots >>= 1;
     if (c->hs.htab && c->hs.tab_size == ts && c->hs.n_slots == slots) return BK_OK;
     free_dev(c->hs.htab);

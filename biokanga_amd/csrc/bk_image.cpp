@@ -605,23 +605,39 @@ struct SwinBuild {
 
 // the core lengths reads of maxlen bases are searched with, shortest first (LocateCoreMultiples' CoreLen per phase of AlignReads' schedule):
 // the last phase's, then the ones before it; at most kSwLevels of them.  Returns their number
-int swin_core_lens_k(const bk_ctx *c, uint32_t maxlen, int k, int *w)
+// wave_share (optional): per level, the reads the wave kernel took in the phases that search with that core length, per read of the last
+// chunk whose counts have come back (bk_ctx::hist_wave) - what the level's intervals are walked by
+int swin_core_lens_k(const bk_ctx *c, uint32_t maxlen, int k, int *w, double *wave_share = nullptr)
 {
     const ReadPlan p = make_plan((int)std::max<uint32_t>(maxlen, 1), c->cfg);
     int n = 0;
-    for (int ph = p.n_phases - 1; ph >= 0 && n < kSwLevels; ph--) {
+    for (int ph = p.n_phases - 1; ph >= 0; ph--) {
         int mm, cl, cd;
         phase_params(p, c->cfg, ph, mm, cl, cd);
         cl = std::min(std::max(cl, k), 120);
-        if (n == 0 || cl > w[n - 1]) w[n++] = cl;
+        if (n == 0 || cl > w[n - 1]) {
+            if (n == kSwLevels) break;
+            w[n] = cl;
+            if (wave_share) wave_share[n] = 0.0;
+            n++;
+        }
+        if (wave_share && ph < kMaxPhases) wave_share[n - 1] += c->hist_wave[ph];
     }
     return n;
 }
-int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w)
+// skip_auto: (an index of 5-byte elements, whose array is cut to the memory that is free) leave out the shortest core lengths while the
+// phases that use them send the wave kernel less than a twentieth of its reads: the last phases' cores select the longest runs of all,
+// which the coverage would be spent on first, for the few reads that get that far
+int swin_core_lens(const bk_ctx *c, uint32_t maxlen, int *w, bool skip_auto = false)
 {
-    int n = swin_core_lens_k(c, maxlen, c->ix.k, w);
-    // ("swin_skip_short": without the shortest of them)
-    const int skip = c->swin_skip_short > 0 ? std::min(c->swin_skip_short, n - 1) : 0;
+    double share[kSwLevels];
+    int n = swin_core_lens_k(c, maxlen, c->ix.k, w, share);
+    int skip = c->swin_skip_short > 0 ? std::min(c->swin_skip_short, n - 1) : 0;         // ("swin_skip_short": this many, whatever the phases say)
+    if (!skip && skip_auto && c->hist_valid) {
+        double total = 0.0, acc = 0.0;
+        for (int i = 0; i < n; i++) total += share[i];
+        while (skip < n - 1 && acc + share[skip] < 0.05 * total) acc += share[skip++];
+    }
     if (skip) { for (int i = skip; i < n; i++) w[i - skip] = w[i]; n -= skip; }
     return n;
 }
@@ -706,7 +722,8 @@ int swin_range(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, uint64_t upto, hipS
 // that fits is taken, and the entries are sized by its count.  Mode 2 only (the index is in place and is gone over twice).
 int swin_fit(bk_ctx *c, SwinBuild &sb, const DevIndex &ix, hipStream_t s)
 {
-    static const uint32_t ladder[] = {kSwMinRun, 96, 128, 160, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560, 3072, 4096, 6144, 8192};
+    static const uint32_t ladder[] = {kSwMinRun, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1088, 1152, 1216, 1280,
+                                      1344, 1408, 1472, 1536, 1664, 1792, 1920, 2048, 2304, 2560, 3072, 4096, 6144, 8192};
     constexpr int NL = (int)(sizeof(ladder) / sizeof(ladder[0]));
     const uint64_t n = ix.n;
     unsigned long long *d_cnt = nullptr;
@@ -783,8 +800,9 @@ uint64_t swin_budget_for(const bk_ctx *c, uint64_t free_b, uint64_t reserve, int
     const uint64_t span = ranged ? (1ULL << 31) : c->ix.n;
     const uint64_t work = ((span >> kSwBlkShift) + 1) * 8 + ((c->ix.n >> kSwBlkShift) + 1) * 4 + (span >> 3) * (kSwLevels + 1) + (64ULL << 20);
     if (free_b < reserve + work + (1ULL << 30)) return 0;
-    // (such an index's array is only made when asked for, and its walks are where its time goes: five sixths of what is free, not half)
-    uint64_t budget = std::min<uint64_t>(c->ix.n * 16 * (uint64_t)words / 3, ranged ? (free_b - reserve - work) / 6 * 5 : (free_b - reserve - work) / 2);
+    // (such an index's array is only made when asked for, and its walks are where its time goes: what is free beyond the reserve, not half of it - a batch that then
+    // finds no room for its scratch has the array released first, align_chunk)
+    uint64_t budget = std::min<uint64_t>(c->ix.n * 16 * (uint64_t)words / 3, ranged ? (free_b - reserve - work) / 16 * 15 : (free_b - reserve - work) / 2);
     if (c->swin_budget) budget = std::min<uint64_t>(budget, c->swin_budget);
     return budget;
 }
@@ -799,11 +817,14 @@ int maybe_build_swin(bk_ctx *c, uint32_t maxlen, uint32_t nreads, hipStream_t s)
     // BASELINE config 5's size per device does not earn back; the policy's 1 leaves such an index without)
     if (wide && c->use_swin != 2) return BK_OK;
     const bool full = c->use_swin == 3;
+    // (.. and from the second batch on: which core lengths are worth covering is read off the batch before, swin_core_lens)
+    if (wide && !c->hist_valid && c->swin_skip_short == 0) return BK_OK;
     int w[kSwLevels];
-    const int n_levels = swin_core_lens(c, maxlen, w);
+    const int n_levels = swin_core_lens(c, maxlen, w, wide);
     // entries of three 16-byte words for the kernel family of reads of up to 128 bases, of five for the one of up to 256 (SwGeo)
     const int words = maxlen <= 128 ? 3 : 5;
     const int w_key = w[0] | (w[n_levels - 1] << 8) | (n_levels << 16) | (words << 24);
+    if (wide && c->d_swin && c->ix.sw_words == words) return BK_OK;      // (such an index's array is kept as it was made: its levels follow a batch's phases, which differ a little every time)
     if (c->d_swin) {
         // (a partial array made for other core lengths is made again ONCE - the eager build's guess of a hundred bases against what the
         // first batch really holds; after that an array of the right entry size is kept whatever the next batch's longest read: coverage
