@@ -86,6 +86,8 @@ struct bk_ctx {
     int use_wave = 1;        // 1: k_light / k_wave for reads <= 256 bp, 0: k_extend / k_heavy only
     int lazy_search = 1;     // 1: small k-mer buckets are handed to the extend kernels unverified
     bool ktab64 = false;
+    int ktab_wide = 0;                    // "ktab_wide": 0 bucket starts of 64 bits only where the index needs them; 1 always, packed as ktab_hi + offsets; 2 always, unpacked (tests)
+    uint64_t *d_ktab_hi = nullptr;        // .. stored as 32-bit offsets from a 64-bit start per 2^16 codes (DevIndex::ktab_hi) when every such group spans less than 2^32 suffixes
     int k_req = -1;          // requested k (-1 auto)
     int use_ktab = 1;
     uint32_t el_size = 4;

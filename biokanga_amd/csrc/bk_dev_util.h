@@ -248,7 +248,22 @@ __device__ __forceinline__ uint32_t flags_to_bits16(uint64_t f)   // f: flags at
 __device__ __forceinline__ uint64_t ktab_get(const DevIndex &ix, uint64_t c)
 {
     if (ix.ktab2) return (uint64_t)ix.ktab2[c].x;
+    if (ix.ktab_hi) return ix.ktab_hi[c >> 16] + (uint64_t)ix.ktab32[c];       // (a 512 KB array: it stays in the caches)
     return ix.ktab32 ? (uint64_t)ix.ktab32[c] : ix.ktab64[c];
+}
+
+// a bucket's start and end (the next bucket's start) in one go: the packed table's 64-bit start is looked up once for both
+__device__ __forceinline__ void ktab_get_pair(const DevIndex &ix, uint64_t c, uint64_t &lo, uint64_t &hi)
+{
+    if (ix.ktab_hi && !ix.ktab2) {
+        const uint64_t base = ix.ktab_hi[c >> 16];
+        const uint32_t o0 = ix.ktab32[c], o1 = ix.ktab32[c + 1];
+        lo = base + o0;
+        hi = ((c + 1) & 0xFFFFULL) ? base + o1 : ix.ktab_hi[(c + 1) >> 16];       // (a group's first offset is 0)
+        return;
+    }
+    lo = ktab_get(ix, c);
+    hi = ktab_get(ix, c + 1);
 }
 
 // SA index range [lo, hi) that can contain suffixes starting with the core

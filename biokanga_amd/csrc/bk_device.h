@@ -100,6 +100,7 @@ struct DevIndex {
     uint32_t max_id;
     const uint32_t *ktab32;     // one of ktab32/ktab64 when k > 0
     const uint64_t *ktab64;
+    const uint64_t *ktab_hi;    // with ktab32, an index beyond 2^32 suffixes: bucket start = ktab_hi[c >> 16] + ktab32[c] - half of ktab64's bytes (k_pack_ktab64)
     const uint2 *ktab2;         // instead of ktab32 when the second-level keys exist: {ktab32[c], y} - y = the key of a bucket of one suffix (no second line), the map of the first five bits of a larger bucket's keys (k_make_ktab2)
     int ktab2_elem;             // ktab2's second word of a bucket of one suffix is that suffix's array ELEMENT (its target position), not its second-level key: the search hands it on (kElemFlag)
     const uint32_t *k2;         // second-level keys: the 15 bases following the first k of suffix sa[i], 2 bits each + kind; may be null

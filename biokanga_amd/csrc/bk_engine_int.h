@@ -62,6 +62,7 @@ void launch_build_swin(const DevIndex &ix, void *swin, int words, hipStream_t s)
 void launch_swin_breaks(const DevIndex &ix, const int *w, int n_levels, unsigned long long *const *brk, uint64_t a, uint64_t e, uint64_t n_words,
                         const unsigned long long *starts, hipStream_t s);
 void launch_swin_cover(const unsigned long long *brk, uint64_t n, uint32_t max_run, uint32_t min_run, uint32_t *flags, uint64_t n_blocks, int first_level, hipStream_t s);
+void launch_pack_ktab64(const uint64_t *tab, uint64_t n_entries, uint32_t *off, uint64_t *hi, uint32_t *overflow, hipStream_t s);
 void launch_count_nonzero(const uint32_t *flags, uint64_t n, unsigned long long *count, hipStream_t s);
 void launch_swin_map(const uint32_t *flags, const uint32_t *incl, uint64_t n_blocks, uint32_t cap_blocks, uint32_t *used, uint32_t *map, hipStream_t s);
 void launch_swin_fill(const DevIndex &ix, const uint32_t *map, void *swin, int words, uint64_t a, uint64_t e, hipStream_t s);

@@ -248,10 +248,10 @@ void grow_tick(bk_ctx *c, uint64_t nreads, bool now)
 int tables_begin(bk_ctx *c, TablePlan &tp)
 {
     grow_drop(c);
-    free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_isa);
-    c->d_ktab = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
+    free_dev(c->d_ktab); free_dev(c->d_ktab_hi); free_dev(c->d_k2); free_dev(c->d_isa);
+    c->d_ktab = nullptr; c->d_ktab_hi = nullptr; c->d_k2 = nullptr; c->d_isa = nullptr;
     for (int i = 0; i < kMoreKeys; i++) { free_dev(c->d_kx[i]); c->d_kx[i] = nullptr; c->ix.kx[i] = nullptr; }
-    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
+    c->ix.ktab32 = nullptr; c->ix.ktab64 = nullptr; c->ix.ktab_hi = nullptr; c->ix.ktab2 = nullptr; c->ix.k2 = nullptr; c->ix.isa = nullptr;
     c->ktab_is2 = false;
     c->ix.ktab2_elem = 0;
     c->ix.k = 0;
@@ -264,7 +264,7 @@ int tables_begin(bk_ctx *c, TablePlan &tp)
         if (k > 16) k = 16;
         if (k < 2) k = 2;
         const uint64_t ncodes = 1ULL << (2 * k);
-        c->ktab64 = c->ix.n >= (1ULL << 32);
+        c->ktab64 = c->ix.n >= (1ULL << 32) || c->ktab_wide != 0;
         const uint64_t ktab_bytes = (ncodes + 1) * (c->ktab64 ? 8 : 4);
         const uint64_t need = k2s_start(c->ix.n, kK2Levels + 1) * 4;          // (the keys and their sampled levels, bk_dev_k2.h)
         const bool want_isa = c->use_wave && c->use_isa && c->d_sa_hi == nullptr && c->ix.n < (1ULL << 32);
@@ -323,8 +323,29 @@ int tables_end(bk_ctx *c, TablePlan &tp)
     unsigned long long bad2[2] = {0, 0};
     if (tp.k2) HIP_TRY(hipMemcpyAsync(bad2, tp.d_bad, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (tp.ktab && c->ktab64 && c->ktab_wide != 2) {
+        // the table of an index beyond 2^32 suffixes at half its size (17 of 34 GB at k = 16: room for the window array such an index may
+        // ask for): 32-bit offsets from a 64-bit start per 2^16 codes - unless a group of codes spans 2^32 suffixes
+        const uint64_t n_entries = (1ULL << (2 * tp.k)) + 1, n_hi = (n_entries >> 16) + 2;
+        uint32_t *d_off = nullptr, *d_flag = nullptr, flag = 1;
+        uint64_t *d_hi = nullptr;
+        if (dev_malloc(&d_off, n_entries * 4) == hipSuccess && dev_malloc(&d_hi, n_hi * 8) == hipSuccess && dev_malloc(&d_flag, 4) == hipSuccess &&
+            hipMemsetAsync(d_flag, 0, 4, c->stream) == hipSuccess) {
+            launch_pack_ktab64((const uint64_t *)c->d_ktab, n_entries, d_off, d_hi, d_flag, c->stream);
+            if (hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) flag = 1;
+        }
+        (void)hipGetLastError();
+        free_dev(d_flag);
+        if (flag == 0) {
+            free_dev(c->d_ktab);
+            c->d_ktab = d_off;
+            c->ktab_bytes = (size_t)n_entries * 4;
+            c->d_ktab_hi = d_hi;
+        } else { free_dev(d_off); free_dev(d_hi); }
+    }
     if (tp.ktab) {
-        if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+        if (c->ktab64 && c->d_ktab_hi) { c->ix.ktab32 = (const uint32_t *)c->d_ktab; c->ix.ktab_hi = c->d_ktab_hi; }
+        else if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
         else if (tp.ktab2) { c->ix.ktab2 = reinterpret_cast<const uint2 *>(c->d_ktab); c->ktab_is2 = true; c->ix.ktab2_elem = (c->use_ktab2 >= 2 && c->d_sa_hi == nullptr) ? 1 : 0; }
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
         c->ix.k = tp.k;
@@ -1063,6 +1084,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     c->n_tgt4_words = src->n_tgt4_words;
     c->sort_shift = src->sort_shift;
     c->ktab64 = src->ktab64;
+    c->ktab_wide = src->ktab_wide;
     c->ktab_is2 = src->ktab_is2;
     c->use_ktab2 = src->use_ktab2;
     c->grow_elem = src->grow_elem;
@@ -1093,6 +1115,7 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     dup(c->d_sa_lo, src->d_sa_lo, (size_t)n * 4);
     dup(c->d_sa_hi, src->d_sa_hi, (size_t)n);
     dup(c->d_ktab, (const uint8_t *)src->d_ktab, src->ktab_bytes);
+    dup(c->d_ktab_hi, src->d_ktab_hi, (size_t)(((((1ULL << (2 * src->ix.k)) + 1) >> 16) + 2) * 8));
     dup(c->d_k2, src->d_k2, (size_t)k2s_start(n, kK2Levels + 1) * 4);
     for (int i = 0; i < kMoreKeys; i++) dup(c->d_kx[i], src->d_kx[i], (size_t)k2s_start(n, kK2Levels + 1) * 4);
     dup(c->d_isa, src->d_isa, (size_t)n * 4);
@@ -1104,7 +1127,8 @@ int bk_ctx_clone(bk_ctx **out, const bk_ctx *src, int device_id)
     if (!ok) { bk_ctx_destroy(c); return rc; }
     c->ix.tgt4 = c->d_tgt4; c->ix.sa_lo = c->d_sa_lo; c->ix.sa_hi = c->d_sa_hi;
     if (c->d_ktab) {
-        if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
+        if (c->ktab64 && c->d_ktab_hi) { c->ix.ktab32 = (const uint32_t *)c->d_ktab; c->ix.ktab_hi = c->d_ktab_hi; }
+        else if (c->ktab64) c->ix.ktab64 = (const uint64_t *)c->d_ktab;
         else if (c->ktab_is2) c->ix.ktab2 = (const uint2 *)c->d_ktab;
         else c->ix.ktab32 = (const uint32_t *)c->d_ktab;
     }
@@ -1124,7 +1148,7 @@ void bk_ctx_destroy(bk_ctx *c)
     grow_drop(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_tgt4); free_dev(c->d_sa_lo); free_dev(c->d_sa_hi);
-    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_k2); free_dev(c->d_kx[0]); free_dev(c->d_kx[1]); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
+    free_dev(c->d_snp_planes); free_dev(c->d_snp_tot); free_dev(c->d_snp_sites); free_dev(c->d_ent_start); free_dev(c->d_ent_end); free_dev(c->d_ent_id); free_dev(c->d_id2idx); free_dev(c->d_ktab); free_dev(c->d_ktab_hi); free_dev(c->d_k2); free_dev(c->d_kx[0]); free_dev(c->d_kx[1]); free_dev(c->d_slist); free_dev(c->d_slist_stage); free_dev(c->d_sort[0]); free_dev(c->d_sort[1]); free_dev(c->d_sort[2]); free_dev(c->d_sort_tmp); free_dev(c->d_tgt2); free_dev(c->d_tgt2s); free_dev(c->d_nflag); free_dev(c->d_rd2); free_dev(c->d_rmeta);
     free_dev(c->d_rd4); free_dev(c->d_iv_first); free_dev(c->d_iv_n); free_dev(c->d_iv2);
     free_dev(c->d_act[0]); free_dev(c->d_act[1]); free_dev(c->d_heavy); free_dev(c->d_wave); free_dev(c->d_iv32); free_dev(c->d_wave_work); free_dev(c->d_small);
     for (int i = 0; i < 3; i++) free_dev(c->d_stage[i]);

@@ -499,6 +499,25 @@ void launch_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v, hi
     hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
 }
 
+// A k-mer table of 64-bit bucket starts (an index beyond 2^32 suffixes: 34 GB at k = 16) as 32-bit offsets from the start of every
+// 2^16-th code's bucket: half the bytes.  *overflow is set when a group of 2^16 codes spans 2^32 suffixes or more (the table then stays
+// as it is)
+__global__ void __launch_bounds__(256) k_pack_ktab64(const uint64_t *__restrict__ tab, uint64_t n_entries, uint32_t *__restrict__ off, uint64_t *__restrict__ hi,
+                                                     uint32_t *__restrict__ overflow)
+{
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_entries; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t base = tab[c & ~0xFFFFULL], v = tab[c] - base;
+        if (v >> 32) atomicOr(overflow, 1u);
+        off[c] = (uint32_t)v;
+        if ((c & 0xFFFFULL) == 0) hi[c >> 16] = base;
+    }
+}
+
+void launch_pack_ktab64(const uint64_t *tab, uint64_t n_entries, uint32_t *off, uint64_t *hi, uint32_t *overflow, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_ktab64, dim3(65536), dim3(256), 0, s, tab, n_entries, off, hi, overflow);
+}
+
 void launch_pack_target2(const uint64_t *tgt4, uint64_t nwords4, uint64_t *tgt2, unsigned int *nflag32, int flag_shift, hipStream_t s)
 {
     uint64_t blocks = (nwords4 / 4 + 255) / 256;

@@ -157,8 +157,7 @@ __global__ void __launch_bounds__(256) k_search_a_ilp(DevIndex ix, DevAlignCfg c
                 const uint2 e0 = ix.ktab2[code], e1 = ix.ktab2[code + 1];
                 lo[u] = e0.x; hi[u] = e1.x; key0[u] = e0.y;             // (a bucket of one: its key; a larger one: the map of its keys' first five bits)
             } else {
-                lo[u] = ktab_get(ix, code);
-                hi[u] = ktab_get(ix, code + 1);
+                ktab_get_pair(ix, code, lo[u], hi[u]);
             }
         }
     }

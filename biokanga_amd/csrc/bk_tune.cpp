@@ -87,6 +87,13 @@ int64_t bk_ctx_tune(bk_ctx *c, const char *name, int64_t value)
         int rc = build_tables(c);
         return rc ? rc : old;
     }
+    if (n == "ktab_wide") {                // the k-mer table of an index beyond 2^32 suffixes on any index (tests): 1 packed (ktab_hi + 32-bit offsets), 2 plain 64-bit starts
+        int64_t old = c->ktab_wide;
+        c->ktab_wide = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        int rc = build_tables(c);
+        return rc ? rc : old;
+    }
+    if (n == "ktab_packed") return c->ix.ktab_hi != nullptr;       // (read only)
     if (n == "use_k3") {                   // how many key arrays behind the second-level keys (rebuilt with the tables)
         int64_t old = c->use_k3;
         c->use_k3 = value < 0 ? 0 : (value > kMoreKeys ? kMoreKeys : (int)value);

@@ -214,9 +214,11 @@ int  bk_ctx_set_params(bk_ctx *ctx, const bk_align_params *p);
  *   "use_swin" (suffix-ordered window array: 0 none - every window from the 2-bit target; 1 for the part of the suffix array the wave kernel's long
  *   walks visit, reads of <= 100 bases and the middle cores of reads of <= 160; 2 the same whatever the batch's longest read; 3 for every suffix.
  *   An index of 5-byte elements gets the partial array only at 2: making it goes over such an index twice - once to find the shortest run
- *   length whose coverage fits the memory that is free -, 1.7 s at 17 Gbp for 5 % of its wave kernel's time)
+ *   length whose coverage fits the memory that is free -, 2 s at 17 Gbp for a seventh of its wave kernel's time)
  *   "swin_budget_kb" (most the partial array may take; 0: a third of what every suffix would, within half of the free HBM - nearly all of it for an
  *   index beyond 2^32 suffixes)   "swin_skip_short" (the coverage rule without the reads' this many shortest core lengths; 0)
+ *   "ktab_wide" (tests: 1 = the k-mer table with 64-bit bucket starts whatever the index's size, packed as an index beyond 2^32 suffixes has
+ *   it - a 64-bit start per 2^16 codes + 32-bit offsets, half the bytes -, 2 = unpacked; rebuilt)   "ktab_packed" (read only)
  *   "swin_resident", "swin_mbytes", "swin_setup_us", "swin_covered_ppm", "swin_core_lens" (read only, value ignored: whether the window array
  *   is in HBM right now, what it occupies, what making it took, the share of the suffix array it holds, the core lengths its coverage is for)
  *   "async_phases" (1: the main path's phase loop never reads a count back - launches sized by bounds, sorts by the previous chunk's

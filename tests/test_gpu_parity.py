@@ -64,7 +64,8 @@ def test_hip_matches_reference_and_oracle(golden_tmp, fixture, tag):
                                   ("use_swin", 3), (("use_swin", 3), ("heavy_thresh", 0)), ("use_swin", 0),
                                   (("kmer_bits", 6), ("lazy_search", 0)), (("kmer_bits", 9), ("use_wave", 0)),
                                   (("use_k2", 0), ("lazy_search", 0)), ("use_k3", 0), ("use_k3", 1), (("use_k3", 0), ("lazy_search", 0)), (("use_k3", 1), ("lazy_search", 0)), (("use_k3", 0), ("kmer_bits", 6)), (("kmer_bits", 6), ("heavy_thresh", 0)), ("use_ktab2", 0), ("use_ktab2", 2), (("use_ktab2", 2), ("lazy_search", 0)), (("use_ktab2", 2), ("heavy_thresh", 0)), (("use_ktab2", 2), ("use_iv32", 0)), (("use_ktab2", 0), ("kmer_bits", 9)), ("use_iv32", 0), (("use_iv32", 0), ("lazy_search", 0)),
-                                  ("async_phases", 0), (("async_phases", 0), ("chunk_reads", 333)), (("async_phases", 0), ("sort_lists", 0))])
+                                  ("async_phases", 0), (("async_phases", 0), ("chunk_reads", 333)), (("async_phases", 0), ("sort_lists", 0)),
+                                  ("ktab_wide", 1), ("ktab_wide", 2), (("ktab_wide", 1), ("lazy_search", 0)), (("ktab_wide", 1), ("kmer_bits", 9)), (("ktab_wide", 1), ("use_swin", 2))])
 def test_paths_agree(golden_tmp, fixture, knob):
     """wave-per-read kernel == lane-per-read kernel; table-accelerated search == plain bisection;
     chunking does not matter."""
@@ -83,6 +84,20 @@ def test_paths_agree(golden_tmp, fixture, knob):
     if knob == ("heavy_thresh", 0):
         # every call with at least one non-empty core interval went through the wave-per-read kernel
         assert c1["n_heavy"] > c0["n_heavy"] and c1["n_heavy"] >= np.count_nonzero(ref["rslt"] != 0)
+
+
+def test_wide_kmer_table_is_packed(golden_tmp):
+    """the k-mer table of an index beyond 2^32 suffixes (64-bit bucket starts) is kept as 32-bit offsets from a 64-bit start per 2^16
+    codes; "ktab_wide" makes a small index build it: 1 packed, 2 plain 64-bit, 0 back to what the index needs"""
+    bk = _bk()
+    d, names, bases, offs, lens, keep = load_fixture(golden_tmp, "repeat", "s3")
+    with bk.Aligner(os.path.join(d, "genome.sfx"), bk.AlignParams(max_subs=3)) as al:
+        ref = al.align(bases, offs[keep], lens[keep])
+        assert al.tune("ktab_packed", 0) == 0
+        for mode, packed in ((1, 1), (2, 0), (0, 0)):
+            al.tune("ktab_wide", mode)
+            assert al.tune("ktab_packed", 0) == packed
+            assert_hits_equal(al.align(bases, offs[keep], lens[keep]), ref, [names[i] for i in keep])
 
 
 @pytest.mark.parametrize("fixture", ["basic", "repeat", "lengths"])
