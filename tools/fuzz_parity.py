@@ -212,6 +212,8 @@ def main():
             al.tune(knob, val)
         if int(rng.integers(0, 6)) == 0:                 # (the key arrays behind the second-level keys: none, one, both - the tables are rebuilt)
             al.tune("use_k3", int(rng.integers(0, 3)))
+        if int(rng.integers(0, 8)) == 0:                 # (the k-mer table as an index beyond 2^32 suffixes has it: packed, plain 64-bit, back - rebuilt)
+            al.tune("ktab_wide", int(rng.integers(0, 3)))
         packed = bool(rng.integers(0, 2))                # the same reads across the boundary at 2 bit/base
         got = al.align_packed(*bk.pack_reads(bases, offs, lens)) if packed else al.align(bases, offs, lens)
         kw = dict(kw, packed=packed)
